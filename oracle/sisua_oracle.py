@@ -1,0 +1,689 @@
+"""Float64 NumPy restatement of the SISUA VAE training step (the oracle).
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.
+
+PARITY UNPINNED for the network numerics: the arithmetic of the reference's
+hot path lives in third-party packages that are absent from /root/reference and
+not installable here (``odin-ai==1.2.5`` -- setup.py:27 -- on top of unpinned
+TensorFlow / TensorFlow-Probability), the reference's own tests hold no golden
+vectors for it and v0's ``fit`` raises
+``NameError`` (sisua/models/single_cell_model.py:236).  What IS pinned, against
+the reference's own code executed in the build container
+(tests/golden/make_reference_fixtures.py): ``split``
+(sisua/data/single_cell_dataset.py:72-77), ``apply_artificial_corruption``
+(sisua/data/utils.py:168-228) and ``get_library_size``
+(sisua/data/utils.py:231-263).  Everything else below restates the published
+definitions of the third-party operators at the reference's call sites; every
+frozen assumption is listed in DESIGN.md ("Frozen third-party semantics") and
+is cross-checked in tests/ against scipy / torch.distributions closed forms and
+finite differences.
+
+Reference call sites each function follows:
+
+* ``forward_backward``     sisua/models/single_cell_model.py:119-151 (encode =
+                           log1p + encoder MLP + latent; decode = decoder MLP +
+                           output head), ctor defaults :74-97, configs/base.yaml
+* ``_scvi_*``              sisua/models/scvi.py:33-171
+* DCA latent               sisua/models/dca.py:13-28
+* SISUA label heads        sisua/models/vae.py:19-44, configs/base.yaml:6,38-43
+* ``adam_update``          configs/base.yaml:45-50 (adam, lr 1e-3, clipnorm 100)
+* ``split_indices`` etc.   sisua/data/*, sisua/train.py:118-147
+"""
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+from scipy.special import digamma, expit, gammaln
+
+# --------------------------------------------------------------------------
+# Frozen third-party constants (DESIGN.md "Frozen third-party semantics")
+# --------------------------------------------------------------------------
+SOFTPLUS_INV_1 = float(np.log(np.expm1(1.0)))  # softplus1(0) == 1
+NBD_EPS = 1e-8                                  # scVI log-likelihood epsilon
+SCVI_RHO_MIN = 1e-7                             # scvi.py:131
+STREAM_INPUT_DROPOUT = 0
+STREAM_ENC_DROPOUT = 16    # + layer index
+STREAM_ENCL_DROPOUT = 32   # + layer index
+STREAM_DEC_DROPOUT = 48    # + layer index
+STREAM_EPS_Z = 64
+STREAM_EPS_L = 65
+
+LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
+LABEL_LIKELIHOODS = ("nb", "onehot")
+
+
+def n_params_per_gene(likelihood: str) -> int:
+  return {"nb": 2, "zinb": 3, "nbd": 2, "zinbd": 3}[likelihood]
+
+
+# --------------------------------------------------------------------------
+# Model specification
+# --------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Spec:
+  """Configuration of one model; mirrors the ctor surface of
+  SingleCellModel / SCVI / SISUA / DeepCountAutoencoder
+  (single_cell_model.py:74-97, scvi.py:33-48, vae.py:40-44, dca.py:16-28)."""
+  model: str = "vae"                  # 'vae' | 'dca' | 'scvi' | 'sisua'
+  n_genes: int = 0
+  likelihood: str = "zinb"
+  enc_units: Tuple[int, ...] = (64, 64)
+  dec_units: Tuple[int, ...] = (64, 64)
+  latent_dim: int = 10
+  encl_units: Tuple[int, ...] = (64,)     # scvi library encoder (scvi.py:41-44)
+  labels: Tuple[Tuple[int, str], ...] = ()  # ((dim, 'nb'|'onehot'), ...)
+  batchnorm: bool = True
+  dropout_enc: float = 0.1
+  dropout_dec: float = 0.1
+  input_dropout: float = 0.0
+  log_norm: bool = True
+  beta: float = 1.0
+  alpha: float = 10.0
+  latent_activation: str = "relu"     # dca only: 'relu' | 'linear'
+  clip_library: float = 1e3           # scvi.py:47
+  bn_momentum: float = 0.99
+  bn_eps: float = 1e-3
+  lr: float = 1e-3
+  adam_beta1: float = 0.9
+  adam_beta2: float = 0.999
+  adam_eps: float = 1e-7
+  clipnorm: float = 100.0             # <= 0 disables
+  seed: int = 8
+
+  def __post_init__(self):
+    assert self.model in ("vae", "dca", "scvi", "sisua"), self.model
+    assert self.likelihood in LIKELIHOODS, self.likelihood
+    if self.model == "scvi":
+      assert self.likelihood in ("nbd", "zinbd")  # scvi.py:50-52
+    for _, llk in self.labels:
+      assert llk in LABEL_LIKELIHOODS, llk
+    if self.model != "sisua":
+      assert len(self.labels) == 0
+
+  @property
+  def k(self) -> int:
+    return n_params_per_gene(self.likelihood)
+
+  @property
+  def zero_inflated(self) -> bool:
+    return self.likelihood in ("zinb", "zinbd")
+
+  @property
+  def stochastic(self) -> bool:
+    return self.model != "dca"
+
+
+def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
+  """Ordered list of trainable tensors (name, logical shape).  The HIP
+  library exposes the same manifest (names, order, logical shapes)."""
+  out: List[Tuple[str, Tuple[int, ...]]] = []
+
+  def mlp(prefix, n_in, units):
+    for i, u in enumerate(units):
+      out.append((f"{prefix}{i}/W", (n_in, u)))
+      if spec.batchnorm:
+        out.append((f"{prefix}{i}/gamma", (u,)))
+        out.append((f"{prefix}{i}/beta", (u,)))
+      else:
+        out.append((f"{prefix}{i}/b", (u,)))
+      n_in = u
+    return n_in
+
+  G, D = spec.n_genes, spec.latent_dim
+  h = mlp("enc", G, spec.enc_units)
+  out.append(("lat/W", (h, 2 * D if spec.stochastic else D)))
+  out.append(("lat/b", (2 * D if spec.stochastic else D,)))
+  if spec.model == "scvi":
+    hl = mlp("encl", G, spec.encl_units)
+    out.append(("latl/W", (hl, 2)))
+    out.append(("latl/b", (2,)))
+  hd = mlp("dec", D, spec.dec_units)
+  if spec.model == "scvi":
+    # three separate Dense heads (scvi.py:67-86): MeanScale, Dispersion,
+    # DropoutLogits -- separate tensors for per-tensor clipnorm.
+    for c in range(spec.k):
+      out.append((f"out{c}/W", (hd, G)))
+      out.append((f"out{c}/b", (G,)))
+  else:
+    out.append(("out/W", (hd, spec.k * G)))
+    out.append(("out/b", (spec.k * G,)))
+  for j, (P, llk) in enumerate(spec.labels):
+    ky = 2 if llk == "nb" else 1
+    out.append((f"lab{j}/W", (hd, ky * P)))
+    out.append((f"lab{j}/b", (ky * P,)))
+  return out
+
+
+def bn_manifest(spec: Spec) -> List[Tuple[str, int]]:
+  """Ordered list of batch-norm layers (prefix, width) holding moving stats."""
+  if not spec.batchnorm:
+    return []
+  out = [(f"enc{i}", u) for i, u in enumerate(spec.enc_units)]
+  if spec.model == "scvi":
+    out += [(f"encl{i}", u) for i, u in enumerate(spec.encl_units)]
+  out += [(f"dec{i}", u) for i, u in enumerate(spec.dec_units)]
+  return out
+
+
+def init_params(spec: Spec, seed: Optional[int] = None) -> Dict[str, np.ndarray]:
+  """Glorot-uniform weights, zero biases, gamma=1, beta=0 (Keras defaults;
+  frozen assumption).  RNG: numpy default_rng(seed), tensors in manifest order."""
+  rng = np.random.default_rng(spec.seed if seed is None else seed)
+  params = {}
+  for name, shape in manifest(spec):
+    kind = name.split("/")[1]
+    if kind == "W":
+      limit = np.sqrt(6.0 / (shape[0] + shape[1]))
+      params[name] = rng.uniform(-limit, limit, size=shape).astype(np.float32).astype(np.float64)
+    elif kind == "gamma":
+      params[name] = np.ones(shape)
+    else:
+      params[name] = np.zeros(shape)
+  return params
+
+
+def init_bn_state(spec: Spec) -> Dict[str, np.ndarray]:
+  st = {}
+  for prefix, u in bn_manifest(spec):
+    st[f"{prefix}/moving_mean"] = np.zeros(u)
+    st[f"{prefix}/moving_var"] = np.ones(u)
+  return st
+
+
+# --------------------------------------------------------------------------
+# Philox4x32-10 counter-based RNG (Salmon et al., SC'11; Random123 KATs in
+# tests/test_oracle_rng.py).  The HIP kernels implement the same function, so
+# dropout masks are bit-identical and Gaussian noise agrees to fp32 rounding.
+# counter = (column_block, cell_id, step, stream | sample<<8); key = seed.
+# --------------------------------------------------------------------------
+_PH_M0 = np.uint64(0xD2511F53)
+_PH_M1 = np.uint64(0xCD9E8D57)
+_PH_W0 = np.uint64(0x9E3779B9)
+_PH_W1 = np.uint64(0xBB67AE85)
+_MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+  """Vectorised Philox4x32-10.  All inputs broadcastable uint32-valued arrays;
+  returns four uint32 arrays."""
+  c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & _MASK32 for c in (c0, c1, c2, c3))
+  c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+  k0 = np.uint64(k0) & _MASK32
+  k1 = np.uint64(k1) & _MASK32
+  for r in range(10):
+    p0 = _PH_M0 * c0
+    p1 = _PH_M1 * c2
+    hi0, lo0 = p0 >> np.uint64(32), p0 & _MASK32
+    hi1, lo1 = p1 >> np.uint64(32), p1 & _MASK32
+    c0, c1, c2, c3 = (hi1 ^ c1 ^ k0), lo1, (hi0 ^ c3 ^ k1), lo0
+    k0 = (k0 + _PH_W0) & _MASK32
+    k1 = (k1 + _PH_W1) & _MASK32
+  return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def _philox_words(seed: int, stream: int, step: int, cell_ids, n_cols: int, sample: int = 0):
+  """uint32 words [len(cell_ids), 4*ceil(n_cols/4)]: word j of row i is output
+  (j % 4) of philox(counter=(j//4, cell_id, step, stream | sample<<8))."""
+  cell_ids = np.asarray(cell_ids, dtype=np.uint64).reshape(-1, 1)
+  nblk = (n_cols + 3) // 4
+  blk = np.arange(nblk, dtype=np.uint64).reshape(1, -1)
+  c3 = np.uint64((stream & 0xFF) | ((sample & 0xFFFFFF) << 8))
+  w = philox4x32_10(blk, cell_ids, np.uint64(step & 0xFFFFFFFF), c3,
+                    seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+  return np.stack(w, axis=-1).reshape(cell_ids.shape[0], nblk * 4)
+
+
+def philox_dropout_mask(seed, stream, step, cell_ids, n_cols, p, sample=0):
+  """Inverted-dropout multiplier (Keras Dropout): keep iff u >= p with
+  u = (word >> 8) * 2^-24 compared in fp32; kept entries scale by 1/(1-p)."""
+  if p <= 0.0:
+    return np.ones((len(cell_ids), n_cols))
+  w = _philox_words(seed, stream, step, cell_ids, n_cols, sample)[:, :n_cols]
+  u = (w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+  keep = u >= np.float32(p)
+  return keep.astype(np.float64) * float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+
+
+def philox_normal(seed, stream, step, cell_ids, n_cols, sample=0):
+  """Box-Muller on word pairs: columns (4q, 4q+1) from words (0,1) of block q,
+  columns (4q+2, 4q+3) from words (2,3)."""
+  w = _philox_words(seed, stream, step, cell_ids, n_cols, sample)
+  n = w.shape[0]
+  w = w.reshape(n, -1, 2, 2)  # [row, block, pair, (a,b)]
+  u1 = ((w[..., 0] >> np.uint32(8)).astype(np.float64) + 1.0) * 2.0 ** -24
+  u2 = (w[..., 1] >> np.uint32(8)).astype(np.float64) * 2.0 ** -24
+  r = np.sqrt(-2.0 * np.log(u1))
+  out = np.stack([r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)], axis=-1)
+  return out.reshape(n, -1)[:, :n_cols]
+
+
+class PhiloxNoise:
+  """Noise source used by both oracle and GPU in un-injected runs."""
+
+  def __init__(self, seed: int, step: int, cell_ids, sample: int = 0):
+    self.seed, self.step, self.sample = int(seed), int(step), int(sample)
+    self.cell_ids = np.asarray(cell_ids, dtype=np.int64)
+
+  def dropout(self, stream: int, n_cols: int, p: float):
+    return philox_dropout_mask(self.seed, stream, self.step, self.cell_ids, n_cols, p, self.sample)
+
+  def normal(self, stream: int, n_cols: int):
+    return philox_normal(self.seed, stream, self.step, self.cell_ids, n_cols, self.sample)
+
+
+class InjectedNoise:
+  """Noise given explicitly (parity runs, smx_set_noise)."""
+
+  def __init__(self, dropout: Dict[int, np.ndarray] = None, normal: Dict[int, np.ndarray] = None):
+    self._d = dropout or {}
+    self._n = normal or {}
+
+  def dropout(self, stream, n_cols, p):
+    if p <= 0.0:
+      return 1.0
+    return np.asarray(self._d[stream], dtype=np.float64)
+
+  def normal(self, stream, n_cols):
+    return np.asarray(self._n[stream], dtype=np.float64)
+
+
+# --------------------------------------------------------------------------
+# Elementary functions
+# --------------------------------------------------------------------------
+def softplus(x):
+  return np.logaddexp(0.0, x)
+
+
+def softplus1(x):
+  """softplus shifted so that softplus1(0) == 1 (odin `softplus1`; frozen)."""
+  return softplus(x + SOFTPLUS_INV_1)
+
+
+def log_sigmoid(x):
+  return -softplus(-x)
+
+
+# --------------------------------------------------------------------------
+# Count likelihoods: elementwise log-prob and gradients wrt raw parameters
+# (SURVEY.md section 8 rows a-10 / a-11).  `p` is a list of k arrays [B, G].
+# --------------------------------------------------------------------------
+def _nb_core(x, p, likelihood, direct):
+  """Returns (ell, d ell / d p0, d ell / d p1) for the count part."""
+  if likelihood in ("nb", "zinb"):
+    a, l = p[0], p[1]
+    r = np.exp(a)
+    ell = (gammaln(x + r) - gammaln(r) - gammaln(x + 1.0)
+           + x * log_sigmoid(l) + r * log_sigmoid(-l))
+    d_r = digamma(x + r) - digamma(r) + log_sigmoid(-l)
+    d_a = r * d_r
+    d_l = x - (x + r) * expit(l)
+    return ell, d_a, d_l
+  # mean / dispersion form (scVI)
+  a, b = p[0], p[1]
+  if direct:
+    mu, th = a, b
+  else:
+    mu, th = softplus(a), softplus1(b)
+  e = NBD_EPS
+  lt = np.log(th + mu + e)
+  ell = (th * (np.log(th + e) - lt) + x * (np.log(mu + e) - lt)
+         + gammaln(x + th) - gammaln(th) - gammaln(x + 1.0))
+  d_mu = -th / (th + mu + e) + x / (mu + e) - x / (th + mu + e)
+  d_th = (np.log(th + e) - lt + th / (th + e) - th / (th + mu + e)
+          - x / (th + mu + e) + digamma(x + th) - digamma(th))
+  if direct:
+    return ell, d_mu, d_th
+  return ell, d_mu * expit(a), d_th * expit(b + SOFTPLUS_INV_1)
+
+
+def count_llk(x, p: Sequence[np.ndarray], likelihood: str, direct: bool = False):
+  """Elementwise log p(x | params) and its gradients wrt each raw parameter
+  plane.  `direct=True` (SCVI): planes are (mean, dispersion[, gate]) already
+  activated."""
+  ell, d0, d1 = _nb_core(x, p, likelihood, direct)
+  if likelihood in ("nb", "nbd"):
+    return ell, [d0, d1]
+  g = p[2]
+  zero = (x == 0)
+  # x == 0: log(pi + (1-pi) NB(0)) = logaddexp(g, ell) - softplus(g)
+  # x  > 0: ell - softplus(g)
+  lse = np.logaddexp(g, ell)
+  llk = np.where(zero, lse, ell) - softplus(g)
+  w = np.where(zero, np.exp(ell - lse), 1.0)          # d llk / d ell
+  d_g = np.where(zero, 1.0 - w, 0.0) - expit(g)
+  return llk, [w * d0, w * d1, d_g]
+
+
+def label_llk(y, raw, llk_kind):
+  """Per-cell label log-likelihood and gradient wrt the head's raw output.
+  'nb': raw = [a | l], ADT levels y real-valued (configs/base.yaml:38-40);
+  'onehot': raw = logits, y one-hot (configs/base.yaml:41-43)."""
+  if llk_kind == "nb":
+    P = y.shape[1]
+    ell, (da, dl) = count_llk(y, [raw[:, :P], raw[:, P:]], "nb")
+    return ell.sum(1), np.concatenate([da, dl], axis=1)
+  m = raw.max(1, keepdims=True)
+  lse = m + np.log(np.exp(raw - m).sum(1, keepdims=True))
+  logp = raw - lse
+  return (y * logp).sum(1), y - np.exp(logp) * y.sum(1, keepdims=True)
+
+
+# --------------------------------------------------------------------------
+# MLP block: Dense -> BatchNorm -> ReLU -> Dropout   (NetConf; frozen order)
+# --------------------------------------------------------------------------
+def _mlp_fwd(spec, params, bn_state, prefix, units, h, training, noise, stream0, p_drop, new_bn):
+  caches = []
+  for i, _ in enumerate(units):
+    W = params[f"{prefix}{i}/W"]
+    pre = h @ W
+    c = {"h_in": h}
+    if spec.batchnorm:
+      mm, mv = bn_state[f"{prefix}{i}/moving_mean"], bn_state[f"{prefix}{i}/moving_var"]
+      if training:
+        mu, var = pre.mean(0), pre.var(0)
+        new_bn[f"{prefix}{i}/moving_mean"] = mm * spec.bn_momentum + mu * (1 - spec.bn_momentum)
+        new_bn[f"{prefix}{i}/moving_var"] = mv * spec.bn_momentum + var * (1 - spec.bn_momentum)
+        new_bn[f"{prefix}{i}/batch_mean"] = mu
+        new_bn[f"{prefix}{i}/batch_var"] = var
+      else:
+        mu, var = mm, mv
+      inv = 1.0 / np.sqrt(var + spec.bn_eps)
+      xhat = (pre - mu) * inv
+      y = params[f"{prefix}{i}/gamma"] * xhat + params[f"{prefix}{i}/beta"]
+      c.update(xhat=xhat, inv=inv)
+    else:
+      y = pre + params[f"{prefix}{i}/b"]
+    act = np.maximum(y, 0.0)
+    mask = noise.dropout(stream0 + i, y.shape[1], p_drop) if training else 1.0
+    h = act * mask
+    c.update(pos=(y > 0), mask=mask)
+    caches.append(c)
+  return h, caches
+
+
+def _mlp_bwd(spec, params, prefix, units, caches, dh, grads, training):
+  for i in reversed(range(len(units))):
+    c = caches[i]
+    dy = dh * c["mask"] * c["pos"]
+    if spec.batchnorm:
+      gamma = params[f"{prefix}{i}/gamma"]
+      grads[f"{prefix}{i}/gamma"] = (dy * c["xhat"]).sum(0)
+      grads[f"{prefix}{i}/beta"] = dy.sum(0)
+      dxh = dy * gamma
+      if training:
+        B = dy.shape[0]
+        dpre = c["inv"] / B * (B * dxh - dxh.sum(0) - c["xhat"] * (dxh * c["xhat"]).sum(0))
+      else:
+        dpre = dxh * c["inv"]
+    else:
+      grads[f"{prefix}{i}/b"] = dy.sum(0)
+      dpre = dy
+    grads[f"{prefix}{i}/W"] = c["h_in"].T @ dpre
+    dh = dpre @ params[f"{prefix}{i}/W"].T
+  return dh
+
+
+# --------------------------------------------------------------------------
+# Full forward (+ backward) of one minibatch
+# --------------------------------------------------------------------------
+def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndarray] = (),
+                     library: Optional[np.ndarray] = None, mask: Optional[np.ndarray] = None,
+                     training: bool = True, backward: bool = True):
+  """One minibatch.  Returns dict with loss, per-cell terms, distribution
+  parameters, gradients (if `backward`) and the updated BN moving stats.
+
+  x [B,G] counts; y list of label arrays [B,P_j]; library [B,2] =
+  (local_mean, local_var) (data/_single_cell_base.py:568-570); mask [B] bool
+  (labelled cells, :580-591)."""
+  x = np.asarray(x, dtype=np.float64)
+  B, G = x.shape
+  D = spec.latent_dim
+  new_bn: Dict[str, np.ndarray] = {}
+  out: Dict[str, object] = {}
+
+  # ---- encode (single_cell_model.py:119-139) --------------------------------
+  h0 = np.log1p(x) if spec.log_norm else x
+  in_mask = noise.dropout(STREAM_INPUT_DROPOUT, G, spec.input_dropout) if training else 1.0
+  h0 = h0 * in_mask
+  h, enc_c = _mlp_fwd(spec, params, bn_state, "enc", spec.enc_units, h0, training, noise,
+                      STREAM_ENC_DROPOUT, spec.dropout_enc, new_bn)
+  lat = h @ params["lat/W"] + params["lat/b"]
+  if spec.stochastic:
+    mu, s_raw = lat[:, :D], lat[:, D:]
+    sig = softplus1(s_raw)
+    eps = noise.normal(STREAM_EPS_Z, D)
+    z = mu + sig * eps
+    kl = 0.5 * (sig ** 2 + mu ** 2 - 1.0 - 2.0 * np.log(sig)).sum(1)
+  else:  # dca.py:13-28: deterministic latent, no KL
+    mu, sig, eps = lat, None, None
+    z = np.maximum(lat, 0.0) if spec.latent_activation == "relu" else lat
+    kl = np.zeros(B)
+  out.update(z_mean=mu, z_scale=sig, z=z)
+
+  # ---- scvi library latent (scvi.py:37-45, 88-106) --------------------------
+  kl_l = np.zeros(B)
+  if spec.model == "scvi":
+    hl, encl_c = _mlp_fwd(spec, params, bn_state, "encl", spec.encl_units, h0, training, noise,
+                          STREAM_ENCL_DROPOUT, spec.dropout_enc, new_bn)
+    latl = hl @ params["latl/W"] + params["latl/b"]
+    mu_l, sig_l = latl[:, 0], softplus1(latl[:, 1])
+    eps_l = noise.normal(STREAM_EPS_L, 1)[:, 0]
+    l = mu_l + sig_l * eps_l
+    assert library is not None, "scvi needs the library prior (scvi.py:100-105)"
+    mp, sp = library[:, 0], np.sqrt(library[:, 1])
+    kl_l = np.log(sp / sig_l) + (sig_l ** 2 + (mu_l - mp) ** 2) / (2 * sp ** 2) - 0.5
+    out.update(l_mean=mu_l, l_scale=sig_l, l=l)
+
+  # ---- decode (single_cell_model.py:141-151; scvi.py:108-171) ---------------
+  d, dec_c = _mlp_fwd(spec, params, bn_state, "dec", spec.dec_units, z, training, noise,
+                      STREAM_DEC_DROPOUT, spec.dropout_dec, new_bn)
+  k = spec.k
+  if spec.model == "scvi":
+    raw = [d @ params[f"out{c}/W"] + params[f"out{c}/b"] for c in range(k)]
+    m = raw[0].max(1, keepdims=True)
+    e = np.exp(raw[0] - m)
+    rho_raw = e / e.sum(1, keepdims=True)
+    rho = np.clip(rho_raw, SCVI_RHO_MIN, 1.0 - SCVI_RHO_MIN)
+    lhat = np.clip(l, 0.0, spec.clip_library)
+    rate = np.exp(lhat)[:, None] * rho
+    theta = np.exp(raw[1])
+    planes = [rate, theta] + ([raw[2]] if k == 3 else [])
+    llk_e, dplanes = count_llk(x, planes, spec.likelihood, direct=True)
+  else:
+    raw_all = d @ params["out/W"] + params["out/b"]
+    planes = [raw_all[:, c * G:(c + 1) * G] for c in range(k)]
+    llk_e, dplanes = count_llk(x, planes, spec.likelihood)
+  llk_x = llk_e.sum(1)
+  out["x_params"] = planes
+
+  # ---- label heads (vae.py:19-44) -------------------------------------------
+  llk_y = np.zeros(B)
+  lab_raw, lab_d = [], []
+  mvec = np.zeros(B) if mask is None else np.asarray(mask, dtype=np.float64).reshape(B)
+  for j, (P, kind) in enumerate(spec.labels):
+    rawy = d @ params[f"lab{j}/W"] + params[f"lab{j}/b"]
+    ly, dly = label_llk(np.asarray(y[j], dtype=np.float64), rawy, kind)
+    llk_y = llk_y + ly
+    lab_raw.append(rawy)
+    lab_d.append(dly)
+  out["y_params"] = lab_raw
+
+  # ---- ELBO (SURVEY a-15) ----------------------------------------------------
+  elbo = llk_x + spec.alpha * mvec * llk_y - spec.beta * (kl + kl_l)
+  out.update(loss=float(-elbo.mean()), elbo=elbo, llk_x=llk_x, llk_y=llk_y, kl=kl, kl_l=kl_l,
+             metrics=dict(loss=float(-elbo.mean()), nllk_x=float(-llk_x.mean()),
+                          nllk_y=float(-(mvec * llk_y).mean()), kl=float(kl.mean()),
+                          kl_l=float(kl_l.mean())),
+             new_bn=new_bn)
+  if not backward:
+    return out
+
+  # ---- backward --------------------------------------------------------------
+  grads: Dict[str, np.ndarray] = {}
+  c_x = -1.0 / B                       # d loss / d llk_x[b]
+  c_kl = spec.beta / B                 # d loss / d kl[b]
+  dd = np.zeros_like(d)
+  for j, (P, kind) in enumerate(spec.labels):
+    draw = lab_d[j] * (c_x * spec.alpha * mvec)[:, None]
+    grads[f"lab{j}/W"] = d.T @ draw
+    grads[f"lab{j}/b"] = draw.sum(0)
+    dd += draw @ params[f"lab{j}/W"].T
+  dl = None
+  if spec.model == "scvi":
+    drate, dtheta = dplanes[0] * c_x, dplanes[1] * c_x
+    inside = (rho_raw > SCVI_RHO_MIN) & (rho_raw < 1.0 - SCVI_RHO_MIN)
+    drho = drate * np.exp(lhat)[:, None] * inside
+    draw0 = rho_raw * (drho - (drho * rho_raw).sum(1, keepdims=True))
+    dlhat = (drate * rate).sum(1)
+    dl = dlhat * ((l > 0.0) & (l < spec.clip_library))
+    draws = [draw0, dtheta * theta] + ([dplanes[2] * c_x] if k == 3 else [])
+    for c in range(k):
+      grads[f"out{c}/W"] = d.T @ draws[c]
+      grads[f"out{c}/b"] = draws[c].sum(0)
+      dd += draws[c] @ params[f"out{c}/W"].T
+    out["d_x_params"] = draws
+  else:
+    draw_all = np.concatenate(dplanes, axis=1) * c_x
+    grads["out/W"] = d.T @ draw_all
+    grads["out/b"] = draw_all.sum(0)
+    dd += draw_all @ params["out/W"].T
+    out["d_x_params"] = [draw_all[:, c * G:(c + 1) * G] for c in range(k)]
+  dz = _mlp_bwd(spec, params, "dec", spec.dec_units, dec_c, dd, grads, training)
+
+  if spec.stochastic:
+    dmu = dz + c_kl * mu
+    dsig = dz * eps + c_kl * (sig - 1.0 / sig)
+    dlat = np.concatenate([dmu, dsig * expit(s_raw + SOFTPLUS_INV_1)], axis=1)
+  else:
+    dlat = dz * (lat > 0) if spec.latent_activation == "relu" else dz
+  grads["lat/W"] = h.T @ dlat
+  grads["lat/b"] = dlat.sum(0)
+  dh = dlat @ params["lat/W"].T
+  dh0 = _mlp_bwd(spec, params, "enc", spec.enc_units, enc_c, dh, grads, training)
+
+  if spec.model == "scvi":
+    dmu_l = dl + c_kl * (mu_l - mp) / sp ** 2
+    dsig_l = dl * eps_l + c_kl * (sig_l / sp ** 2 - 1.0 / sig_l)
+    dlatl = np.stack([dmu_l, dsig_l * expit(latl[:, 1] + SOFTPLUS_INV_1)], axis=1)
+    grads["latl/W"] = hl.T @ dlatl
+    grads["latl/b"] = dlatl.sum(0)
+    dhl = dlatl @ params["latl/W"].T
+    dh0 = dh0 + _mlp_bwd(spec, params, "encl", spec.encl_units, encl_c, dhl, grads, training)
+  out["grads"] = grads
+  out["d_h0"] = dh0 * in_mask
+  return out
+
+
+# --------------------------------------------------------------------------
+# Optimiser: per-tensor clipnorm then Adam (Keras form; frozen)
+# --------------------------------------------------------------------------
+def init_opt_state(params):
+  return {"t": 0, "m": {k: np.zeros_like(v) for k, v in params.items()},
+          "v": {k: np.zeros_like(v) for k, v in params.items()}}
+
+
+def adam_update(spec: Spec, params, grads, opt):
+  """In place.  g <- g * min(1, clipnorm/||g||) per tensor; then
+  lr_t = lr*sqrt(1-b2^t)/(1-b1^t); w -= lr_t * m / (sqrt(v) + eps)."""
+  opt["t"] += 1
+  t = opt["t"]
+  lr_t = spec.lr * np.sqrt(1.0 - spec.adam_beta2 ** t) / (1.0 - spec.adam_beta1 ** t)
+  norms = {}
+  for name in params:
+    g = grads[name]
+    nrm = float(np.sqrt((g * g).sum()))
+    norms[name] = nrm
+    if spec.clipnorm > 0 and nrm > spec.clipnorm:
+      g = g * (spec.clipnorm / nrm)
+    m = opt["m"][name] = spec.adam_beta1 * opt["m"][name] + (1 - spec.adam_beta1) * g
+    v = opt["v"][name] = spec.adam_beta2 * opt["v"][name] + (1 - spec.adam_beta2) * g * g
+    params[name] = params[name] - lr_t * m / (np.sqrt(v) + spec.adam_eps)
+  return norms
+
+
+def apply_bn_update(bn_state, new_bn):
+  for k_, v in new_bn.items():
+    if k_.endswith("moving_mean") or k_.endswith("moving_var"):
+      bn_state[k_] = v
+
+
+def train_step(spec, params, bn_state, opt, x, noise, y=(), library=None, mask=None):
+  """forward + backward + optimiser; mutates params/bn_state/opt; returns metrics."""
+  res = forward_backward(spec, params, bn_state, x, noise, y=y, library=library, mask=mask)
+  adam_update(spec, params, res["grads"], opt)
+  apply_bn_update(bn_state, res["new_bn"])
+  return res
+
+
+# --------------------------------------------------------------------------
+# Data-side semantics (host logic of the hot path's callers)
+# --------------------------------------------------------------------------
+def split_indices(n_obs: int, train_percent: float = 0.8, seed: int = 1):
+  """sisua/data/single_cell_dataset.py:72-77."""
+  train_percent = np.clip(train_percent, 0.0, 1.0)
+  ids = np.random.RandomState(seed=seed).permutation(n_obs).astype("int32")
+  n_train = int(train_percent * n_obs)
+  return ids[:n_train], ids[n_train:]
+
+
+def corrupt_binomial(x: np.ndarray, dropout: float = 0.2, retain_rate: float = 0.2, seed: int = 8):
+  """'binomial' branch of apply_artificial_corruption, sisua/data/utils.py:168-228
+  (returns a corrupted copy)."""
+  x = np.array(x, copy=True)
+  if not (0.0 < dropout < 1.0 or 0.0 < retain_rate < 1.0):
+    return x
+  rand = np.random.RandomState(seed=seed)
+  i, j = np.nonzero(x)
+  ix = rand.choice(range(len(i)), size=int(np.floor(dropout * len(i))), replace=False)
+  i, j = i[ix], j[ix]
+  x[i, j] = rand.binomial(n=(x[i, j]).astype(np.int32), p=retain_rate)
+  return x
+
+
+def library_size(x: np.ndarray):
+  """get_library_size, sisua/data/utils.py:231-263 -> (log_counts[N], mean, var)."""
+  total = x.sum(axis=1)
+  log_counts = np.log(total + 1e-8)
+  return log_counts, np.float32(np.mean(log_counts)), np.float32(np.var(log_counts))
+
+
+def label_mask(n_obs: int, labels_percent: float, n_omics: int, seed: int = 1):
+  """Per-cell 'labelled' flag, drawn once and frozen
+  (data/_single_cell_base.py:575-591: forced False with one omic; the TF
+  generator stream itself is not reproducible, numpy RandomState stands in)."""
+  if n_omics <= 1 or labels_percent <= 0.0:
+    return np.zeros(n_obs, dtype=bool)
+  return np.random.RandomState(seed).uniform(size=n_obs) < np.clip(labels_percent, 0.0, 1.0)
+
+
+def epoch_order(n_obs: int, epoch: int, shuffle: int = 1000, seed: int = 1):
+  """Order in which cells are visited in one epoch: a streaming shuffle buffer of
+  size `shuffle` over the sequential stream (tf.data .shuffle(1000),
+  data/_single_cell_base.py:597-600); buffer slot picks from
+  RandomState(seed + epoch)."""
+  if not shuffle or shuffle <= 0:
+    return np.arange(n_obs, dtype=np.int32)
+  rng = np.random.RandomState(seed + epoch)
+  buf = list(range(min(shuffle, n_obs)))
+  nxt = len(buf)
+  out = np.empty(n_obs, dtype=np.int32)
+  picks = rng.randint(0, 2 ** 31 - 1, size=n_obs)
+  for t in range(n_obs):
+    k_ = picks[t] % len(buf)
+    out[t] = buf[k_]
+    if nxt < n_obs:
+      buf[k_] = nxt
+      nxt += 1
+    else:
+      buf[k_] = buf[-1]
+      buf.pop()
+  return out
+
+
+def batches(order: np.ndarray, batch_size: int, drop_remainder: bool = True):
+  n = len(order)
+  end = (n // batch_size) * batch_size if drop_remainder else n
+  return [order[s:s + batch_size] for s in range(0, end, batch_size)]

@@ -1,0 +1,181 @@
+"""The oracle against independent closed forms (scipy, torch.distributions) and
+finite differences.  These are the cross-checks that stand in for the golden
+vectors the reference does not have."""
+import numpy as np
+import pytest
+import scipy.stats as st
+import torch
+import torch.distributions as td
+
+from oracle import sisua_oracle as so
+
+
+def _grid():
+  rng = np.random.default_rng(0)
+  x = np.concatenate([np.zeros(40), rng.integers(1, 12, 60), [181, 1000, 10738]])
+  a = rng.uniform(-4, 6, x.size)
+  l = rng.uniform(-8, 8, x.size)
+  g = rng.uniform(-6, 6, x.size)
+  return x[None, :], a[None, :], l[None, :], g[None, :]
+
+
+def test_nb_matches_scipy_and_torch():
+  x, a, l, g = _grid()
+  llk, _ = so.count_llk(x, [a, l], "nb")
+  r, p = np.exp(a), so.expit(l)
+  ref = st.nbinom.logpmf(x, r, 1 - p)
+  assert np.allclose(llk, ref, rtol=1e-10, atol=1e-9)
+  tref = td.NegativeBinomial(total_count=torch.tensor(r), logits=torch.tensor(l)).log_prob(torch.tensor(x))
+  assert np.allclose(llk, tref.numpy(), rtol=1e-9, atol=1e-8)
+
+
+def test_zinb_matches_naive_mixture():
+  x, a, l, g = _grid()
+  llk, _ = so.count_llk(x, [a, l, g], "zinb")
+  nb = np.exp(st.nbinom.logpmf(x, np.exp(a), 1 - so.expit(l)))
+  pi = so.expit(g)
+  naive = np.log(np.where(x == 0, pi + (1 - pi) * nb, (1 - pi) * nb))
+  ok = np.isfinite(naive)
+  assert ok.sum() > 90
+  assert np.allclose(llk[ok], naive[ok], rtol=1e-9, atol=1e-9)
+
+
+def test_nbd_is_nb_with_mean_dispersion():
+  x, a, b, g = _grid()
+  llk, _ = so.count_llk(x, [a, b], "nbd")
+  mu, th = so.softplus(a), so.softplus1(b)
+  ref = st.nbinom.logpmf(x, th, th / (th + mu))
+  assert np.allclose(llk, ref, rtol=1e-5, atol=1e-5)  # scVI's 1e-8 epsilons
+  llk_d, _ = so.count_llk(x, [mu, th], "nbd", direct=True)
+  assert np.allclose(llk_d, llk, rtol=1e-12)
+
+
+@pytest.mark.parametrize("lk", so.LIKELIHOODS)
+@pytest.mark.parametrize("direct", [False, True])
+def test_count_llk_gradients_fd(lk, direct):
+  if direct and lk in ("nb", "zinb"):
+    pytest.skip("direct mode is the scvi mean/dispersion form only")
+  x, a, l, g = _grid()
+  x = np.minimum(x, 300.0)
+  if direct:
+    a, l = so.softplus(a) + 0.05, so.softplus1(l)
+  planes = [a, l, g][: so.n_params_per_gene(lk)]
+  _, grads = so.count_llk(x, planes, lk, direct=direct)
+  for i in range(len(planes)):
+    h = 1e-6
+    pp = [p.copy() for p in planes]; pm = [p.copy() for p in planes]
+    pp[i] += h; pm[i] -= h
+    fd = (so.count_llk(x, pp, lk, direct=direct)[0] - so.count_llk(x, pm, lk, direct=direct)[0]) / (2 * h)
+    assert np.allclose(grads[i], fd, rtol=2e-5, atol=2e-6), (lk, i)
+
+
+def test_kl_terms_match_torch():
+  rng = np.random.default_rng(1)
+  mu, s = rng.normal(size=(5, 7)), rng.uniform(0.2, 2.0, size=(5, 7))
+  kl = 0.5 * (s ** 2 + mu ** 2 - 1 - 2 * np.log(s)).sum(1)
+  ref = td.kl_divergence(td.Independent(td.Normal(torch.tensor(mu), torch.tensor(s)), 1),
+                         td.Independent(td.Normal(torch.zeros(5, 7, dtype=torch.float64),
+                                                  torch.ones(5, 7, dtype=torch.float64)), 1))
+  assert np.allclose(kl, ref.numpy(), rtol=1e-12)
+
+
+def test_label_llk_onehot_and_nb():
+  rng = np.random.default_rng(2)
+  y = np.eye(7)[rng.integers(0, 7, 9)]
+  raw = rng.normal(size=(9, 7))
+  ll, d = so.label_llk(y, raw, "onehot")
+  ref = td.OneHotCategorical(logits=torch.tensor(raw)).log_prob(torch.tensor(y))
+  assert np.allclose(ll, ref.numpy(), rtol=1e-12)
+  yy = rng.uniform(0.5, 9.1, size=(9, 4))
+  raw = rng.normal(size=(9, 8))
+  ll, d = so.label_llk(yy, raw, "nb")
+  h = 1e-6
+  for idx in [(0, 0), (3, 5), (8, 7)]:
+    rp, rm = raw.copy(), raw.copy()
+    rp[idx] += h; rm[idx] -= h
+    fd = (so.label_llk(yy, rp, "nb")[0].sum() - so.label_llk(yy, rm, "nb")[0].sum()) / (2 * h)
+    assert np.isclose(d[idx], fd, rtol=1e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------
+# whole-step gradient check by central differences, every model family
+# ---------------------------------------------------------------------------
+def _toy(model, lk, labels=(), bn=True, **kw):
+  G = 13
+  spec = so.Spec(model=model, n_genes=G, likelihood=lk, enc_units=(6, 5), dec_units=(7,), latent_dim=3,
+                 encl_units=(4,), labels=labels, batchnorm=bn, dropout_enc=0.25, dropout_dec=0.25,
+                 input_dropout=0.2, seed=3, **kw)
+  rng = np.random.default_rng(5)
+  B = 6
+  x = rng.poisson(1.5, size=(B, G)).astype(np.float64) * (rng.uniform(size=(B, G)) < 0.6)
+  y = []
+  for P, kind in labels:
+    y.append(np.eye(P)[rng.integers(0, P, B)] if kind == "onehot" else rng.uniform(0.5, 9.0, size=(B, P)))
+  lc, lm, lv = so.library_size(x + 1.0)
+  lib = np.tile(np.array([[float(lm), float(lv) + 0.05]]), (B, 1))
+  mask = np.array([1, 0, 1, 1, 0, 1], dtype=bool)
+  params = so.init_params(spec)
+  for name in params:  # move off the symmetric init (gamma=1, beta=0, b=0)
+    params[name] = params[name] + 0.1 * rng.normal(size=params[name].shape)
+  return spec, params, so.init_bn_state(spec), x, y, lib, mask
+
+
+CASES = [("vae", "zinb", (), True), ("vae", "nb", (), False), ("vae", "zinbd", (), True),
+         ("vae", "nbd", (), True), ("dca", "zinb", (), True), ("scvi", "zinbd", (), True),
+         ("scvi", "nbd", (), False), ("sisua", "zinb", ((4, "nb"), (3, "onehot")), True)]
+
+
+@pytest.mark.parametrize("model,lk,labels,bn", CASES)
+def test_full_step_gradients_fd(model, lk, labels, bn):
+  spec, params, bn_state, x, y, lib, mask = _toy(model, lk, labels, bn)
+  noise = so.PhiloxNoise(spec.seed, 7, np.arange(x.shape[0]) + 100)
+
+  def loss_of(p):
+    return so.forward_backward(spec, p, bn_state, x, noise, y=y, library=lib, mask=mask, backward=False)["loss"]
+
+  res = so.forward_backward(spec, params, bn_state, x, noise, y=y, library=lib, mask=mask)
+  assert np.isfinite(res["loss"])
+  rng = np.random.default_rng(11)
+  assert set(res["grads"]) == {n for n, _ in so.manifest(spec)}
+  for name, g in res["grads"].items():
+    assert g.shape == params[name].shape
+    flat = params[name].reshape(-1)
+    for idx in rng.choice(flat.size, size=min(4, flat.size), replace=False):
+      h = 1e-5
+      pp = {k: v.copy() for k, v in params.items()}
+      pm = {k: v.copy() for k, v in params.items()}
+      pp[name].reshape(-1)[idx] += h
+      pm[name].reshape(-1)[idx] -= h
+      fd = (loss_of(pp) - loss_of(pm)) / (2 * h)
+      assert np.isclose(g.reshape(-1)[idx], fd, rtol=2e-4, atol=1e-7), (name, idx, g.reshape(-1)[idx], fd)
+
+
+def test_adam_clipnorm_step():
+  spec = so.Spec(model="vae", n_genes=4, enc_units=(3,), dec_units=(3,), latent_dim=2, clipnorm=1.0)
+  params = so.init_params(spec)
+  p0 = {k: v.copy() for k, v in params.items()}
+  grads = {k: np.full_like(v, 3.0) for k, v in params.items()}
+  opt = so.init_opt_state(params)
+  norms = so.adam_update(spec, params, grads, opt)
+  for k, v in params.items():
+    assert np.isclose(norms[k], 3.0 * np.sqrt(v.size))
+    # first Adam step moves every weight by ~lr regardless of gradient scale
+    assert np.allclose(p0[k] - v, spec.lr, rtol=1e-4)
+  # second step with tiny gradient: clip inactive
+  grads = {k: np.full_like(v, 1e-3) for k, v in params.items()}
+  so.adam_update(spec, params, grads, opt)
+  assert opt["t"] == 2
+
+
+def test_data_side_semantics():
+  tr, te = so.split_indices(100, 0.8, seed=1)
+  assert len(tr) == 80 and len(te) == 20 and len(set(tr) | set(te)) == 100
+  order = so.epoch_order(2500, 0, shuffle=1000, seed=1)
+  assert sorted(order.tolist()) == list(range(2500))
+  assert order[:10].max() < 1010  # streaming buffer: early picks come from the head
+  assert not np.array_equal(order, so.epoch_order(2500, 1, shuffle=1000, seed=1))
+  bs = so.batches(order, 128)
+  assert len(bs) == 19 and all(len(b) == 128 for b in bs)
+  assert not so.label_mask(50, 0.1, n_omics=1).any()
+  m = so.label_mask(5000, 0.1, n_omics=2)
+  assert abs(m.mean() - 0.1) < 0.02
