@@ -1,0 +1,200 @@
+/* sisua_hip.h -- C-ABI of the MI355X-native SISUA training hot path.
+ *
+ * The reference (trungnt13/sisua) has no FFI: its hot path is reached through the
+ * Python class surface SingleCellModel.fit/predict/encode/decode
+ * (sisua/models/single_cell_model.py:67-306), which hands every minibatch to
+ * odin-ai / TensorFlow.  This library replaces everything below that class
+ * surface.  Each entry point cites the reference interface it replaces; the
+ * ctypes binding a maintainer would add is sisua_amd/_hip.py (see
+ * INTEGRATION.md).
+ *
+ * Conventions: plain pointers and sizes, no torch / HIP types.  Every function
+ * returns 0 on success and a negative smx_status otherwise; smx_last_error()
+ * returns a thread-local message.  The caller owns every host buffer, the
+ * library owns every device buffer.  One host thread (process) per GPU; all
+ * kernels of a model run on one HIP stream owned by the model.  Host arrays
+ * are dense row-major with LOGICAL shapes (the padded HBM layout is private).
+ */
+#ifndef SISUA_HIP_H_
+#define SISUA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMX_ABI_VERSION 1
+#define SMX_MAX_LAYERS 8
+#define SMX_MAX_LABELS 4
+
+typedef enum {
+  SMX_OK = 0,
+  SMX_ERR_INVALID = -1,   /* bad argument / shape / state            */
+  SMX_ERR_HIP = -2,       /* a HIP runtime call failed               */
+  SMX_ERR_NOMEM = -3,
+  SMX_ERR_COMM = -4,      /* RCCL not loadable or a collective failed */
+  SMX_ERR_NAN = -5        /* terminate_on_nan (configs/base.yaml:59)  */
+} smx_status;
+
+/* Model families: sisua/models/vae.py:15-16 (VAE), dca.py:13-28, scvi.py:20-171,
+ * vae.py:19-44 (SISUA = VAE + label heads). */
+typedef enum { SMX_MODEL_VAE = 0, SMX_MODEL_DCA = 1, SMX_MODEL_SCVI = 2, SMX_MODEL_SISUA = 3 } smx_model_kind;
+/* Count likelihoods selected by RVmeta.posterior (configs/base.yaml:32-40,
+ * data/_single_cell_base.py:518-533). */
+typedef enum { SMX_LLK_NB = 0, SMX_LLK_ZINB = 1, SMX_LLK_NBD = 2, SMX_LLK_ZINBD = 3 } smx_likelihood;
+typedef enum { SMX_LABEL_NB = 0, SMX_LABEL_ONEHOT = 1 } smx_label_likelihood;
+typedef enum { SMX_ACT_RELU = 0, SMX_ACT_LINEAR = 1 } smx_activation;
+
+/* Constructor arguments of SingleCellModel / SCVI / SISUA / DeepCountAutoencoder
+ * (single_cell_model.py:74-97, scvi.py:33-48, vae.py:40-44, dca.py:16-28) plus
+ * the optimiser block of configs/base.yaml:45-50. */
+typedef struct {
+  int32_t abi_version;                 /* must be SMX_ABI_VERSION */
+  int32_t model;                       /* smx_model_kind */
+  int32_t likelihood;                  /* smx_likelihood */
+  int32_t n_genes;                     /* G */
+  int32_t latent_dim;                  /* D */
+  int32_t n_enc, enc_units[SMX_MAX_LAYERS];
+  int32_t n_dec, dec_units[SMX_MAX_LAYERS];
+  int32_t n_encl, encl_units[SMX_MAX_LAYERS];   /* scvi library encoder */
+  int32_t n_labels, label_dim[SMX_MAX_LABELS], label_llk[SMX_MAX_LABELS];
+  int32_t batchnorm;                   /* NetConf.batchnorm */
+  int32_t log_norm;                    /* single_cell_model.py:82 */
+  int32_t latent_activation;           /* dca only */
+  float dropout_enc, dropout_dec, input_dropout;
+  float beta, alpha;                   /* base.yaml:6-7 */
+  float clip_library;                  /* scvi.py:47 */
+  float bn_momentum, bn_eps;
+  float lr, adam_beta1, adam_beta2, adam_eps, clipnorm;
+  int32_t max_batch;                   /* largest minibatch a step will see */
+  uint64_t seed;                       /* Philox key (dropout masks, eps) */
+} smx_config;
+
+/* Scalars of one step, mean over the (global) minibatch; names follow the
+ * reference's logged scalars (tutorials/notebook/...ipynb:238: loss, nllk_x, KLqp). */
+typedef struct {
+  float loss, nllk_x, nllk_y, kl, kl_l;
+  float grad_norm_max;   /* largest per-tensor gradient norm before clipping */
+  int32_t nan_flag;      /* non-zero if any of the above is not finite */
+  int32_t step;          /* optimiser step count after this call */
+} smx_metrics;
+
+typedef struct smx_model smx_model;
+
+/* ---- process / device ---------------------------------------------------- */
+const char* smx_last_error(void);
+int smx_abi_version(void);
+/* Number of visible HIP devices (0 when there is no GPU). */
+int smx_device_count(void);
+/* Bind this process to a device.  Replaces `CUDA_VISIBLE_DEVICES='0'` (train.py:20). */
+int smx_init(int device);
+int smx_synchronize(void);
+
+/* ---- model lifetime ------------------------------------------------------ */
+/* SingleCellModel.__init__ (single_cell_model.py:74-101). Glorot-uniform weights
+ * are NOT drawn here: the host sets them with smx_set_tensor (keeps init RNG on
+ * the Python side, shared with the oracle). */
+int smx_model_create(const smx_config* cfg, smx_model** out);
+int smx_model_destroy(smx_model* m);
+
+/* Manifest of trainable tensors, in oracle order (oracle/sisua_oracle.py:manifest). */
+int smx_num_tensors(const smx_model* m);
+int smx_tensor_info(const smx_model* m, int index, char* name, int name_cap, int32_t* rows, int32_t* cols);
+/* which: 0 = parameters, 1 = gradients of the last step (after all-reduce, before
+ * clipping), 2 = Adam m, 3 = Adam v.  Replaces save_weights/load_weights
+ * (single_cell_model.py:283-306) and serves the parity tests. */
+int smx_get_tensor(smx_model* m, int which, int index, float* host);
+int smx_set_tensor(smx_model* m, int which, int index, const float* host);
+/* Batch-norm moving statistics, layer order = oracle bn_manifest; which: 0 mean, 1 var. */
+int smx_num_bn_layers(const smx_model* m);
+int smx_get_bn(smx_model* m, int layer, int which, float* host, int32_t* width);
+int smx_set_bn(smx_model* m, int layer, int which, const float* host);
+int smx_get_step(const smx_model* m, int32_t* step);
+int smx_set_step(smx_model* m, int32_t step);
+
+/* ---- data ---------------------------------------------------------------- */
+/* Upload the (already split / corrupted) cells x genes matrix once; it stays
+ * resident in HBM (replaces the per-step tf.data H2D copy of
+ * data/_single_cell_base.py:539-602).  X [n_cells, G] dense float32 (the
+ * reference's on-disk format, data/utils.py:427-431).  labels[j] is
+ * [n_cells, label_dim[j]] or NULL; library [n_cells,2] = (local_mean, local_var)
+ * (:568-570) or NULL; label_mask [n_cells] 0/1 or NULL (:580-591).
+ * cell_id_base offsets the Philox cell ids (rank shard offset). */
+int smx_dataset_upload(smx_model* m, const float* X, int64_t n_cells, const float* const* labels,
+                       const float* library, const uint8_t* label_mask, int64_t cell_id_base);
+int64_t smx_dataset_size(const smx_model* m);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* One optimiser step on the cells `row_ids` of the resident matrix: forward,
+ * ELBO, backward, (all-reduce), per-tensor clipnorm, Adam.  Replaces one
+ * iteration of the odin Trainer loop under SingleCellModel.fit
+ * (single_cell_model.py:213-236).  `out` may be NULL (no host
+ * sync).  batch <= cfg.max_batch. */
+int smx_train_step(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out);
+/* Same arithmetic, launched as one captured hipGraph (fixed batch size). */
+int smx_train_step_graph(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out);
+/* Queue `n_steps` steps whose row ids are order[s*batch .. (s+1)*batch); no host
+ * sync between steps.  `out` (may be NULL) receives the last step's metrics. */
+int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t batch, int use_graph,
+                    smx_metrics* out);
+/* Validation loss: eval-mode forward (moving BN stats, no dropout) + ELBO, no
+ * update (valid_freq loop of BetaVAE.fit). */
+int smx_eval_step(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out);
+
+/* Eval-mode forward for predict/encode/decode (single_cell_model.py:119-211):
+ * writes distribution parameters into caller-owned buffers (any may be NULL).
+ * Input cells: row_ids into the resident matrix, or host_x [batch,G] when
+ * row_ids == NULL (host_library [batch,2] for scvi).  sample_index selects the
+ * Monte-Carlo draw of eps.  Outputs: z_mean/z_scale/z_sample [batch,D];
+ * l_mean/l_scale/l_sample [batch] (scvi); x_params [k,batch,G] planes in
+ * likelihood order (nb/zinb: log total_count, logits, gate logits;
+ * nbd/zinbd: mean, dispersion, gate logits -- already activated);
+ * y_params[j] [batch, ky*P_j] raw head outputs. */
+int smx_forward(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library,
+                int32_t batch, int32_t sample_index, int32_t training, float* z_mean, float* z_scale,
+                float* z_sample, float* l_mean, float* l_scale, float* l_sample, float* x_params,
+                float* const* y_params);
+
+/* Test hook: inject noise for the NEXT step instead of Philox.  stream ids as in
+ * oracle/sisua_oracle.py (STREAM_*); data [batch, width] holds eps values or
+ * dropout multipliers.  smx_clear_noise() returns to Philox. */
+int smx_set_noise(smx_model* m, int32_t stream, const float* data, int32_t batch, int32_t width);
+int smx_clear_noise(smx_model* m);
+
+/* ---- data parallel (one process per GPU) ---------------------------------- */
+/* 128-byte RCCL unique id, created on rank 0 and handed to every rank by the
+ * host (torch.distributed / a file store). */
+int smx_comm_unique_id(uint8_t id[128]);
+/* Join the communicator; afterwards every train step all-reduces the flat
+ * gradient buffer (+ BN batch stats + metrics) once over xGMI. */
+int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]);
+int smx_comm_world(const smx_model* m);
+
+/* ---- measurement ---------------------------------------------------------- */
+/* HIP-event timing of one named kernel class inside eager steps, on the model's
+ * stream.  kernel: "loss", "gemm_out_fwd", "gemm_out_dw", "gemm_out_dx",
+ * "gemm_enc_fwd", "gemm_enc_dw", "adam", "allreduce", "step".  Enable, run steps, read. */
+int smx_timing_enable(smx_model* m, const char* kernel);
+int smx_timing_read(smx_model* m, double* total_ms, int64_t* launches);
+/* Algorithmic bytes (fwd+bwd loss kernel = (4+8k)G + 16D + 4 per cell). */
+int64_t smx_loss_bytes_per_cell(const smx_model* m);
+
+/* ---- kernel-level entry points (parity tests of single kernels) ------------ */
+/* Fused count log-likelihood forward+backward over host planes [k][B][G]:
+ * llk[B] and grads [k][B][G] (d llk / d plane, unscaled).  direct != 0: planes
+ * are (mean, dispersion, gate) (scvi.py:151-164). */
+int smx_k_count_llk(int likelihood, int direct, const float* x, const float* planes, int32_t B, int32_t G,
+                    float* llk, float* grads);
+/* C[M,N] = op(A) * op(B) in fp32 on the MFMA path; transA: A given as [K,M];
+ * transB: B given as [N,K]; split_k >= 1 (slabs summed on return). */
+int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M, int32_t N, int32_t K,
+               int32_t split_k, int32_t tile_cfg, float* C);
+/* Philox words / dropout multipliers / normals exactly as the kernels draw them. */
+int smx_k_noise(uint64_t seed, int32_t stream, int32_t step, int32_t sample, const int64_t* cell_ids, int32_t B,
+                int32_t width, float dropout_p, float* dropout_mult, float* normal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SISUA_HIP_H_ */

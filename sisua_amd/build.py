@@ -1,0 +1,58 @@
+"""Build libsisua_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsisua_hip.so")
+SOURCES = ["smx_gemm.hip", "smx_kernels.hip", "smx_model.hip"]
+HEADERS = ["smx_device.h", "smx_internal.h", os.path.join("..", "..", "include", "sisua_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _hipcc():
+  for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+    if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+      return c
+  raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+  if not os.path.exists(target):
+    return True
+  t = os.path.getmtime(target)
+  return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+  hipcc = _hipcc()
+  hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+  objs, jobs = [], []
+  for s in SOURCES:
+    src = os.path.join(CSRC, s)
+    obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+    objs.append(obj)
+    if force or _stale(obj, [src] + hdrs):
+      jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+  def run(cmd):
+    if verbose:
+      print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError("build failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return r.stderr
+
+  with ThreadPoolExecutor(max_workers=3) as ex:
+    for err in ex.map(run, jobs):
+      if verbose and err.strip():
+        print(err)
+  if force or jobs or _stale(LIB, objs):
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
+  return LIB
+
+
+if __name__ == "__main__":
+  print(build(force="--force" in sys.argv))

@@ -1,0 +1,158 @@
+"""Plain configuration records of the model API.
+
+`RVmeta` and `NetConf` mirror the two odin config records the reference passes
+around (sisua/train.py:75-89; sisua/models/single_cell_model.py:74-81): they are
+data only.  `ModelConfig` is the flattened form handed to the C-ABI
+(include/sisua_hip.h: smx_config).
+"""
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
+
+
+@dataclass
+class RVmeta:
+  """Random-variable description: RVmeta(event_shape, posterior, projection, name)
+  (sisua/train.py:79-89; data/_single_cell_base.py:518-533)."""
+  event_shape: int = 10
+  posterior: str = "diag"
+  projection: bool = True
+  name: Optional[str] = None
+  kwargs: dict = field(default_factory=dict)
+
+  def __post_init__(self):
+    if isinstance(self.event_shape, (tuple, list)):
+      self.event_shape = int(np.prod(self.event_shape))
+    self.event_shape = int(self.event_shape)
+    self.posterior = str(self.posterior).lower()
+
+  @property
+  def is_zero_inflated(self):
+    return self.posterior in ("zinb", "zinbd")
+
+  @property
+  def is_deterministic(self):
+    return self.posterior in ("relu", "linear", "identity")
+
+  def copy(self):
+    return dataclasses.replace(self, kwargs=dict(self.kwargs))
+
+
+@dataclass
+class NetConf:
+  """MLP description: NetConf(units, batchnorm, dropout, input_dropout)
+  (configs/base.yaml:10-17; single_cell_model.py:78-81).  Block order is
+  Dense -> BatchNorm -> ReLU -> Dropout (frozen third-party semantics)."""
+  units: Sequence[int] = (64, 64)
+  batchnorm: bool = True
+  dropout: float = 0.0
+  input_dropout: float = 0.0
+  activation: str = "relu"
+  name: Optional[str] = None
+
+  def __post_init__(self):
+    self.units = tuple(int(u) for u in (self.units if isinstance(self.units, (tuple, list)) else [self.units]))
+    assert self.activation == "relu", "only relu hidden activations are built"
+
+  def copy(self):
+    return dataclasses.replace(self)
+
+
+@dataclass(frozen=True)
+class ModelConfig:
+  """Flat model description; field names and defaults equal
+  oracle/sisua_oracle.py:Spec so parity tests can build both from one dict."""
+  model: str = "vae"
+  n_genes: int = 0
+  likelihood: str = "zinb"
+  enc_units: Tuple[int, ...] = (64, 64)
+  dec_units: Tuple[int, ...] = (64, 64)
+  latent_dim: int = 10
+  encl_units: Tuple[int, ...] = (64,)
+  labels: Tuple[Tuple[int, str], ...] = ()
+  batchnorm: bool = True
+  dropout_enc: float = 0.1
+  dropout_dec: float = 0.1
+  input_dropout: float = 0.0
+  log_norm: bool = True
+  beta: float = 1.0
+  alpha: float = 10.0
+  latent_activation: str = "relu"
+  clip_library: float = 1e3
+  bn_momentum: float = 0.99
+  bn_eps: float = 1e-3
+  lr: float = 1e-3
+  adam_beta1: float = 0.9
+  adam_beta2: float = 0.999
+  adam_eps: float = 1e-7
+  clipnorm: float = 100.0
+  seed: int = 8
+
+  @property
+  def k(self) -> int:
+    return 3 if self.likelihood in ("zinb", "zinbd") else 2
+
+  @property
+  def stochastic(self) -> bool:
+    return self.model != "dca"
+
+  def to_dict(self):
+    return dataclasses.asdict(self)
+
+
+def manifest(cfg: ModelConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+  """Trainable tensors in library order (names, logical shapes); checked
+  against smx_tensor_info at model creation."""
+  out = []
+
+  def mlp(prefix, n_in, units):
+    for i, u in enumerate(units):
+      out.append((f"{prefix}{i}/W", (n_in, u)))
+      if cfg.batchnorm:
+        out.append((f"{prefix}{i}/gamma", (u,)))
+        out.append((f"{prefix}{i}/beta", (u,)))
+      else:
+        out.append((f"{prefix}{i}/b", (u,)))
+      n_in = u
+    return n_in
+
+  G, D = cfg.n_genes, cfg.latent_dim
+  h = mlp("enc", G, cfg.enc_units)
+  nl = 2 * D if cfg.stochastic else D
+  out += [("lat/W", (h, nl)), ("lat/b", (nl,))]
+  if cfg.model == "scvi":
+    hl = mlp("encl", G, cfg.encl_units)
+    out += [("latl/W", (hl, 2)), ("latl/b", (2,))]
+  hd = mlp("dec", D, cfg.dec_units)
+  if cfg.model == "scvi":
+    for c in range(cfg.k):
+      out += [(f"out{c}/W", (hd, G)), (f"out{c}/b", (G,))]
+  else:
+    out += [("out/W", (hd, cfg.k * G)), ("out/b", (cfg.k * G,))]
+  for j, (P, llk) in enumerate(cfg.labels):
+    ky = 2 if llk == "nb" else 1
+    out += [(f"lab{j}/W", (hd, ky * P)), (f"lab{j}/b", (ky * P,))]
+  return out
+
+
+def init_params(cfg: ModelConfig, seed: Optional[int] = None) -> Dict[str, np.ndarray]:
+  """Glorot-uniform kernels, zero biases, gamma = 1, beta = 0 (Keras defaults),
+  drawn with numpy default_rng(seed) in manifest order."""
+  rng = np.random.default_rng(cfg.seed if seed is None else seed)
+  params = {}
+  for name, shape in manifest(cfg):
+    kind = name.split("/")[1]
+    if kind == "W":
+      limit = np.sqrt(6.0 / (shape[0] + shape[1]))
+      params[name] = rng.uniform(-limit, limit, size=shape).astype(np.float32)
+    elif kind == "gamma":
+      params[name] = np.ones(shape, dtype=np.float32)
+    else:
+      params[name] = np.zeros(shape, dtype=np.float32)
+  return params

@@ -1,0 +1,162 @@
+// smx_device.h -- device-side helpers shared by the kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smx {
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. SC'11).  Same function as
+// oracle/sisua_oracle.py:philox4x32_10; counter = (column_block, cell_id, step,
+// stream | sample<<8), key = seed.  Integer-exact, so dropout masks are
+// bit-identical to the oracle's.
+// ---------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
+// Parameters of one noise stream for one launch.
+struct NoiseKey {
+  uint32_t k0, k1;   // seed lo/hi
+  uint32_t step;     // optimiser step (counter word 2) when step_ptr == nullptr
+  uint32_t stream;   // stream | sample << 8 (counter word 3)
+  const uint32_t* step_ptr;  // device-resident step counter (graph replay); overrides `step`
+};
+
+__device__ inline U4 philox_block(const NoiseKey& nk, uint32_t cell_id, uint32_t col_block) {
+  const uint32_t step = nk.step_ptr ? *nk.step_ptr : nk.step;
+  return philox4x32_10(col_block, cell_id, step, nk.stream, nk.k0, nk.k1);
+}
+
+__device__ inline float u24(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }  // 2^-24
+
+// Inverted-dropout multipliers for the 4 columns of one Philox block.
+__device__ inline float4 dropout_mult4(const U4& w, float p, float scale) {
+  float4 m;
+  m.x = (u24(w.x) >= p) ? scale : 0.f;
+  m.y = (u24(w.y) >= p) ? scale : 0.f;
+  m.z = (u24(w.z) >= p) ? scale : 0.f;
+  m.w = (u24(w.w) >= p) ? scale : 0.f;
+  return m;
+}
+
+__device__ inline float dropout_mult1(const U4& w, int lane4, float p, float scale) {
+  const uint32_t v = lane4 == 0 ? w.x : lane4 == 1 ? w.y : lane4 == 2 ? w.z : w.w;
+  return (u24(v) >= p) ? scale : 0.f;
+}
+
+// Four standard normals from one block (Box-Muller on word pairs).
+__device__ inline float4 normal4(const U4& w) {
+  const float u1a = ((float)(w.x >> 8) + 1.0f) * 5.9604644775390625e-08f;
+  const float u2a = u24(w.y);
+  const float u1b = ((float)(w.z >> 8) + 1.0f) * 5.9604644775390625e-08f;
+  const float u2b = u24(w.w);
+  const float ra = sqrtf(-2.0f * logf(u1a));
+  const float rb = sqrtf(-2.0f * logf(u1b));
+  float sa, ca, sb, cb;
+  sincospif(2.0f * u2a, &sa, &ca);
+  sincospif(2.0f * u2b, &sb, &cb);
+  return float4{ra * ca, ra * sa, rb * cb, rb * sb};
+}
+
+// ---------------------------------------------------------------------------
+// Elementary functions (fp32)
+// ---------------------------------------------------------------------------
+#define SMX_SOFTPLUS_INV_1 0.54132485461291810f  // log(e - 1)
+
+__device__ inline float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+__device__ inline float sigmoidf(float x) {
+  const float e = expf(-fabsf(x));
+  const float s = 1.0f / (1.0f + e);
+  return x >= 0.f ? s : e * s;
+}
+__device__ inline float logaddexpf(float a, float b) {
+  const float m = fmaxf(a, b);
+  return m + log1pf(expf(-fabsf(a - b)));
+}
+
+// lgamma(x + r) - lgamma(r) and digamma(x + r) - digamma(r) for x >= 0, r > 0, in
+// fp32 without the cancellation of two separate lgamma calls:
+//  * x a small integer: log of the rising factorial r (r+1) ... (r+x-1) and its
+//    logarithmic derivative P'/P (exact recurrences);
+//  * otherwise both arguments are shifted above 8 by the same n and the
+//    Stirling series is differenced analytically:
+//      D = x ln(x+r') + (r'-1/2) log1p(x/r') - x + c(x+r') - c(r') + ln prod (r+i)/(x+r+i).
+struct LgDg { float lg, dg; };
+
+__device__ inline float stirling_corr(float z) {  // 1/(12z) - 1/(360z^3) + 1/(1260z^5)
+  const float iz = 1.0f / z, iz2 = iz * iz;
+  return iz * (0.083333333333f + iz2 * (-0.0027777777778f + iz2 * 0.00079365079365f));
+}
+__device__ inline float digamma_corr(float z) {  // -1/(2z) - 1/(12z^2) + 1/(120z^4) - 1/(252z^6)
+  const float iz = 1.0f / z, iz2 = iz * iz;
+  return -0.5f * iz - iz2 * (0.083333333333f - iz2 * (0.0083333333333f - iz2 * 0.003968253968f));
+}
+
+__device__ inline LgDg lgamma_digamma_diff(float x, float r) {
+  LgDg o{0.f, 0.f};
+  if (x <= 0.f) return o;
+  r = fminf(fmaxf(r, 1e-30f), 1e30f);
+  if (x <= 8.0f && x == floorf(x) && r < 1e4f) {
+    float P = 1.f, dP = 0.f;
+    const int n = (int)x;
+    for (int i = 0; i < n; ++i) {
+      const float t = r + (float)i;
+      dP = fmaf(dP, t, P);
+      P *= t;
+    }
+    o.lg = logf(P);
+    o.dg = dP / P;
+    return o;
+  }
+  float lg_shift = 0.f, dg_shift = 0.f, rs = r;
+  if (r < 8.0f) {
+    const int n = (int)ceilf(8.0f - r);
+    float ratio = 1.f;
+    for (int i = 0; i < n; ++i) {
+      const float a = r + (float)i, b = x + a;
+      ratio *= a / b;
+      dg_shift += x / (a * b);
+      if ((i & 3) == 3) { lg_shift += logf(ratio); ratio = 1.f; }
+    }
+    lg_shift += logf(ratio);
+    rs = r + (float)n;
+  }
+  const float zr = x + rs;
+  const float l1p = log1pf(x / rs);
+  o.lg = x * logf(zr) + (rs - 0.5f) * l1p - x + (stirling_corr(zr) - stirling_corr(rs)) + lg_shift;
+  o.dg = l1p + (digamma_corr(zr) - digamma_corr(rs)) + dg_shift;
+  return o;
+}
+
+// ---------------------------------------------------------------------------
+// wave / block reductions (wave = 64)
+// ---------------------------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+}  // namespace smx

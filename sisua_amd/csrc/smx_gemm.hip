@@ -1,0 +1,264 @@
+// smx_gemm.hip -- fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32:
+// exact fp32 products, k-ordered fmaf accumulation) for every dense product of
+// the SISUA step: forward h*W, weight gradient h^T*dy, input gradient dy*W^T.
+//
+// Shapes are skinny (M or K is the minibatch), so the kernel is organised around
+// HBM/L2 traffic and occupancy rather than MFMA peak:
+//   * a workgroup is 4 waves, each wave owns one 32x32 accumulator tile; the
+//     waves are laid out WM x WN over the output tile and WK over the K tile
+//     (WK > 1: in-workgroup split-K, reduced through LDS), plus gridDim.z-way
+//     split-K into slabs that the consumer kernel sums in a fixed order
+//     (deterministic, no float atomics);
+//   * both operands are staged K-major in LDS ([k][m] / [k][n]) so every MFMA
+//     operand read is a conflict-free ds_read_b32 row;
+//   * the A operand can be produced on the fly from the resident cells x genes
+//     matrix: row gather, log1p and input dropout are applied while staging
+//     (SingleCellModel.encode, sisua/models/single_cell_model.py:126-134).
+#include "smx_internal.h"
+#include "../../include/sisua_hip.h"
+
+namespace smx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int XF>
+__device__ inline float4 xform4(float4 v, const AXform& xf, int batch_idx, int src_row, int gene) {
+  if (XF) {
+    if (xf.log1p) {
+      v.x = log1pf(v.x); v.y = log1pf(v.y); v.z = log1pf(v.z); v.w = log1pf(v.w);
+    }
+    if (xf.inj_mask) {
+      const float4 m = *reinterpret_cast<const float4*>(xf.inj_mask + (long)batch_idx * xf.inj_ld + gene);
+      v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    } else if (xf.drop_p > 0.f) {
+      const U4 w = philox_block(xf.nk, xf.cell_base + (uint32_t)src_row, (uint32_t)(gene >> 2));
+      const float4 m = dropout_mult4(w, xf.drop_p, xf.drop_scale);
+      v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    }
+  }
+  return v;
+}
+
+// A_KM: A stored [K][M] (direct staging); else [M][K] (transposed staging).
+// B_NM: B stored [N][K] (transposed staging); else [K][N] (direct staging).
+template <int WM, int WN, int WK, int A_KM, int B_NM, int XF>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, BK = 32 * WK;
+  constexpr int LDAS = A_KM ? BM + 4 : BM + 1;
+  constexpr int LDBS = B_NM ? BN + 1 : BN + 4;
+  constexpr int NA = BM * BK / 1024;  // float4 per thread for the A tile
+  constexpr int NB = BN * BK / 1024;
+  static_assert(WM * WN * WK == 4, "4 waves per workgroup");
+  static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+  constexpr int SMEM_TILES = BK * LDAS + BK * LDBS;
+  constexpr int SMEM_RED = (WK > 1) ? (WK - 1) * WM * WN * 1024 : 0;
+  constexpr int SMEM = SMEM_TILES > SMEM_RED ? SMEM_TILES : SMEM_RED;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  float* As = smem;
+  float* Bs = smem + BK * LDAS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / (WM * WN), wm = (wave / WN) % WM, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int k_begin = blockIdx.z * g.k_chunk;
+  const int k_end = min(g.K, k_begin + g.k_chunk);
+
+  float4 ra[NA], rb[NB];
+
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int f = tid + 256 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (A_KM) {
+        const int kr = f / (BM / 4), mq = f % (BM / 4);
+        const int k = k0 + kr, m = m0 + mq * 4;
+        if (k < k_end && m < g.M) {
+          const int src = (XF && g.xf.rows) ? g.xf.rows[k] : k;
+          v = *reinterpret_cast<const float4*>(g.A + (long)src * g.lda + m);
+          v = xform4<XF>(v, g.xf, k, src, m);
+        }
+      } else {
+        const int mr = f / (BK / 4), kq = f % (BK / 4);
+        const int m = m0 + mr, k = k0 + kq * 4;
+        if (m < g.M && k < k_end) {
+          const int src = (XF && g.xf.rows) ? g.xf.rows[m] : m;
+          v = *reinterpret_cast<const float4*>(g.A + (long)src * g.lda + k);
+          v = xform4<XF>(v, g.xf, m, src, k);
+          // K is ragged only when it is the batch axis (A_KM); here K is a padded feature axis.
+        }
+      }
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int f = tid + 256 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (B_NM) {
+        const int nr = f / (BK / 4), kq = f % (BK / 4);
+        const int n = n0 + nr, k = k0 + kq * 4;
+        if (k < k_end) v = *reinterpret_cast<const float4*>(g.B + (long)n * g.ldb + k);
+      } else {
+        const int kr = f / (BN / 4), nq = f % (BN / 4);
+        const int k = k0 + kr, n = n0 + nq * 4;
+        if (k < k_end) v = *reinterpret_cast<const float4*>(g.B + (long)k * g.ldb + n);
+      }
+      rb[j] = v;
+    }
+  };
+
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int f = tid + 256 * j;
+      if (A_KM) {
+        const int kr = f / (BM / 4), mq = f % (BM / 4);
+        *reinterpret_cast<float4*>(&As[kr * LDAS + mq * 4]) = ra[j];
+      } else {
+        const int mr = f / (BK / 4), kq = f % (BK / 4);
+        As[(kq * 4 + 0) * LDAS + mr] = ra[j].x;
+        As[(kq * 4 + 1) * LDAS + mr] = ra[j].y;
+        As[(kq * 4 + 2) * LDAS + mr] = ra[j].z;
+        As[(kq * 4 + 3) * LDAS + mr] = ra[j].w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int f = tid + 256 * j;
+      if (B_NM) {
+        const int nr = f / (BK / 4), kq = f % (BK / 4);
+        Bs[(kq * 4 + 0) * LDBS + nr] = rb[j].x;
+        Bs[(kq * 4 + 1) * LDBS + nr] = rb[j].y;
+        Bs[(kq * 4 + 2) * LDBS + nr] = rb[j].z;
+        Bs[(kq * 4 + 3) * LDBS + nr] = rb[j].w;
+      } else {
+        const int kr = f / (BN / 4), nq = f % (BN / 4);
+        *reinterpret_cast<float4*>(&Bs[kr * LDBS + nq * 4]) = rb[j];
+      }
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float csum = 0.f;  // column sum of op(B) (bias gradient), threads < BN of M-tile 0
+  const bool do_colsum = (g.colsum != nullptr) && (blockIdx.x == 0) && (tid < BN);
+
+  if (k_begin < k_end) load_tiles(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    store_tiles();
+    __syncthreads();
+    if (k0 + BK < k_end) load_tiles(k0 + BK);
+    const float* as = As + (wk * 32 + lh) * LDAS + wm * 32 + li;
+    const float* bs = Bs + (wk * 32 + lh) * LDBS + wn * 32 + li;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float a = as[2 * s * LDAS];
+      const float b = bs[2 * s * LDBS];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (do_colsum) {
+#pragma unroll 8
+      for (int k = 0; k < BK; ++k) csum += Bs[k * LDBS + tid];
+    }
+    __syncthreads();
+  }
+
+  if (WK > 1) {  // in-workgroup split-K: waves wk > 0 hand their tile to wave wk == 0
+    float* red = smem;  // tiles are dead after the last barrier of the loop
+    if (wk > 0) {
+      float* dst = red + (((wk - 1) * WM * WN + wm * WN + wn) * 1024);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int q = 0; q < WK - 1; ++q) {
+        const float* src = red + ((q * WM * WN + wm * WN + wn) * 1024);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += src[r * 64 + lane];
+      }
+    }
+  }
+
+  if (wk == 0) {
+    float* C = g.C + (long)blockIdx.z * g.slab_stride;
+    const int col = n0 + wn * 32 + li;
+    const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < g.M) C[(long)row * g.ldc + col] = acc[r] + bias;
+    }
+  }
+  if (do_colsum) g.colsum[n0 + tid] = csum;
+}
+
+template <int WM, int WN, int WK>
+static int launch_cfg(hipStream_t st, GemmArgs g, int* eff_split) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, BK = 32 * WK;
+  g.k_chunk = round_up((g.K + g.split_k - 1) / g.split_k, BK);
+  g.split_k = (g.K + g.k_chunk - 1) / g.k_chunk;  // drop empty slices
+  if (eff_split) *eff_split = g.split_k;
+  if (g.N % BN != 0) { set_error("gemm: N not a multiple of the tile width"); return SMX_ERR_INVALID; }
+  dim3 grid((g.M + BM - 1) / BM, g.N / BN, g.split_k), block(256);
+  const int mode = (g.a_kmajor ? 2 : 0) | (g.b_nmajor ? 1 : 0);
+  if (g.use_xform) {
+    if (mode == 0) hipLaunchKernelGGL((gemm_kernel<WM, WN, WK, 0, 0, 1>), grid, block, 0, st, g);
+    else if (mode == 2) hipLaunchKernelGGL((gemm_kernel<WM, WN, WK, 1, 0, 1>), grid, block, 0, st, g);
+    else { set_error("gemm: gather transform only with k-major B"); return SMX_ERR_INVALID; }
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((gemm_kernel<WM, WN, WK, 0, 0, 0>), grid, block, 0, st, g);
+    else if (mode == 1) hipLaunchKernelGGL((gemm_kernel<WM, WN, WK, 0, 1, 0>), grid, block, 0, st, g);
+    else if (mode == 2) hipLaunchKernelGGL((gemm_kernel<WM, WN, WK, 1, 0, 0>), grid, block, 0, st, g);
+    else { set_error("gemm: A k-major with B n-major is not used by the model"); return SMX_ERR_INVALID; }
+  }
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+int suggest_split_k(int M, int N, int K) {
+  if (K < 512) return 1;
+  const int tiles = ((M + 31) / 32) * (N / 32);
+  int s = 256 / (tiles > 0 ? tiles : 1);
+  if (s > 16) s = 16;         // the consumer re-reads every slab
+  if (s < 1) s = 1;
+  const int chunk = round_up((K + s - 1) / s, 128);  // whole 128-deep tiles per slice
+  return (K + chunk - 1) / chunk;
+}
+
+int launch_gemm(hipStream_t st, const GemmArgs& g_in, int* eff_split) {
+  GemmArgs g = g_in;
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) { set_error("gemm: empty problem"); return SMX_ERR_INVALID; }
+  if ((g.N % 32) || (g.lda % 4) || (g.ldb % 4) || (g.ldc % 4)) {
+    set_error("gemm: N must be a multiple of 32 and leading dimensions multiples of 4");
+    return SMX_ERR_INVALID;
+  }
+  if (g.a_kmajor && (g.M % 4)) { set_error("gemm: k-major A needs M % 4 == 0"); return SMX_ERR_INVALID; }
+  if (!g.a_kmajor && (g.K % 4)) { set_error("gemm: row-major A needs K % 4 == 0"); return SMX_ERR_INVALID; }
+  if (g.b_nmajor && (g.K % 4)) { set_error("gemm: n-major B needs K % 4 == 0"); return SMX_ERR_INVALID; }
+  if (g.split_k < 1) g.split_k = 1;
+  if (g.split_k > 1 && (g.bias || g.colsum)) { set_error("gemm: bias/colsum need split_k == 1"); return SMX_ERR_INVALID; }
+  if (g.colsum && g.b_nmajor) { set_error("gemm: colsum needs k-major B"); return SMX_ERR_INVALID; }
+  int tile = g.tile;
+  if (tile == TILE_AUTO) {
+    const int kper = g.K / g.split_k;
+    if (kper >= 128 && (long)((g.M + 127) / 128) * (g.N / 32) < 128) tile = TILE_32x32_K4;
+    else if (g.M > 64 || g.N % 64) tile = TILE_128x32;
+    else if (g.M > 32) tile = TILE_64x64;
+    else tile = (g.N % 128 == 0) ? TILE_32x128 : TILE_64x64;
+  }
+  switch (tile) {
+    case TILE_128x32: return launch_cfg<4, 1, 1>(st, g, eff_split);
+    case TILE_64x64: return launch_cfg<2, 2, 1>(st, g, eff_split);
+    case TILE_32x128: return launch_cfg<1, 4, 1>(st, g, eff_split);
+    case TILE_32x32_K4: return launch_cfg<1, 1, 4>(st, g, eff_split);
+    case TILE_64x32_K2: return launch_cfg<2, 1, 2>(st, g, eff_split);
+    default: set_error("gemm: unknown tile configuration"); return SMX_ERR_INVALID;
+  }
+}
+
+}  // namespace smx

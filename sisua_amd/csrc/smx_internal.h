@@ -1,0 +1,208 @@
+// smx_internal.h -- host-side declarations shared by the translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "smx_device.h"
+
+namespace smx {
+
+void set_error(const std::string& msg);
+#define SMX_HIP(call)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      smx::set_error(std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                     std::to_string(__LINE__) + ")");                                          \
+      return SMX_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// --------------------------------------------------------------------------
+// GEMM (smx_gemm.hip): C[M,N] (+ slabs) = op(A)[M,K] * op(B)[K,N], fp32 MFMA.
+// --------------------------------------------------------------------------
+enum GemmTile { TILE_AUTO = 0, TILE_128x32 = 1, TILE_64x64 = 2, TILE_32x128 = 3, TILE_32x32_K4 = 4, TILE_64x32_K2 = 5 };
+
+// Optional transform applied to A while it is staged: row gather from the
+// resident cells x genes matrix, log1p, input dropout (Philox or injected).
+struct AXform {
+  const int32_t* rows = nullptr;  // batch index -> row of A (nullptr: identity)
+  int log1p = 0;
+  float drop_p = 0.f, drop_scale = 1.f;  // input dropout (0 disables)
+  NoiseKey nk{0, 0, 0, 0, nullptr};
+  uint32_t cell_base = 0;
+  const float* inj_mask = nullptr;  // injected multipliers [batch][ld]
+  int inj_ld = 0;
+};
+
+struct GemmArgs {
+  const float* A = nullptr; int lda = 0; int a_kmajor = 0;  // a_kmajor: A stored [K][M]
+  const float* B = nullptr; int ldb = 0; int b_nmajor = 0;  // b_nmajor: B stored [N][K]
+  float* C = nullptr; int ldc = 0; long slab_stride = 0;
+  int M = 0, N = 0, K = 0;
+  int split_k = 1;                 // gridDim.z; slab z written at C + z*slab_stride
+  int k_chunk = 0;                 // K range per slice (set by the launcher)
+  const float* bias = nullptr;     // [N], only with split_k == 1
+  float* colsum = nullptr;         // [N] column sums of op(B) over K (bias gradient); split_k == 1, B k-major
+  int use_xform = 0;
+  AXform xf;
+  int tile = TILE_AUTO;
+};
+// Returns 0 or a negative smx_status.  N, lda, ldb, ldc multiples of 4; N multiple of 32.
+// eff_split (optional) receives the number of slabs actually written.
+int launch_gemm(hipStream_t st, const GemmArgs& g, int* eff_split = nullptr);
+// Heuristic split-K factor used by the model for K-heavy products.
+int suggest_split_k(int M, int N, int K);
+
+// --------------------------------------------------------------------------
+// Fused kernels (smx_kernels.hip)
+// --------------------------------------------------------------------------
+struct LossArgs {
+  int likelihood = 0;   // smx_likelihood
+  int direct = 0;       // planes already activated (scvi)
+  int backward = 1;
+  const float* X = nullptr; int ldx = 0;  // counts [rows][ldx]
+  const int32_t* rows = nullptr;          // gather (nullptr: identity)
+  const float* P = nullptr;               // planes: plane c of cell b at P + b*ldp + c*plane_stride
+  long ldp = 0; long plane_stride = 0;
+  float* dP = nullptr;                    // same layout as P
+  float* llk_part = nullptr;              // [B][n_chunks] partial sums (without the -lgamma(x+1) constant)
+  int B = 0, G = 0, Gp = 0;
+  float grad_scale = 1.f;                 // d loss / d llk (= -1/B_global); 1 for the test entry
+};
+int loss_chunks(int Gp);
+int launch_count_loss(hipStream_t st, const LossArgs& a);
+
+struct BnFwdArgs {
+  const float* pre = nullptr; int n_slabs = 1; long slab_stride = 0; int ld = 0;  // pre-activation slabs [S][B][ld]
+  int B = 0, H = 0, Hp = 0;
+  int batchnorm = 1, training = 1;
+  const float* gamma = nullptr; const float* beta = nullptr; const float* bias = nullptr;
+  float* moving_mean = nullptr; float* moving_var = nullptr;   // updated in place when update_moving
+  float* batch_mean = nullptr; float* batch_var = nullptr;     // [Hp] outputs (training)
+  int update_moving = 1;
+  float momentum = 0.99f, eps = 1e-3f;
+  float* xhat = nullptr;     // [B][Hp] normalised pre-activation (saved for backward)
+  float* inv_std = nullptr;  // [Hp]
+  float* out = nullptr;      // [B][Hp] relu + dropout
+  float drop_p = 0.f;
+  NoiseKey nk{0, 0, 0, 0, nullptr};
+  const int32_t* rows = nullptr; uint32_t cell_base = 0;  // cell id = cell_base + rows[b]
+  const float* inj_mask = nullptr; int inj_ld = 0;
+};
+int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a);
+
+struct BnBwdArgs {
+  const float* dout = nullptr; int n_slabs = 1; long slab_stride = 0; int ld = 0;  // d loss / d out slabs
+  const float* out = nullptr;    // forward output (relu/dropout mask: out > 0)
+  const float* xhat = nullptr; const float* inv_std = nullptr; const float* gamma = nullptr;
+  int B = 0, H = 0, Hp = 0;
+  int batchnorm = 1, training = 1;
+  float drop_scale = 1.f;        // 1/(1-p) (1 in eval)
+  float* dpre = nullptr;         // [B][Hp]
+  float* dgamma = nullptr; float* dbeta = nullptr; float* dbias = nullptr;
+};
+int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a);
+
+struct LatentArgs {
+  int stochastic = 1, relu = 0, training = 1;
+  const float* lat = nullptr; int ld = 0;   // [B][2*Dp] (mu | s_raw) or [B][Dp]
+  int B = 0, D = 0, Dp = 0;
+  NoiseKey nk{0, 0, 0, 0, nullptr};
+  const int32_t* rows = nullptr; uint32_t cell_base = 0;
+  const float* inj_eps = nullptr; int inj_ld = 0;
+  float* z = nullptr; float* sig = nullptr; float* eps = nullptr;  // [B][Dp]
+  float* kl = nullptr;                                             // [B]
+  // backward
+  const float* dz = nullptr; int dz_slabs = 1; long dz_slab_stride = 0;
+  float kl_scale = 0.f;       // beta / B_global
+  float* dlat = nullptr;      // [B][2*Dp] or [B][Dp]
+};
+int launch_latent_fwd(hipStream_t st, const LatentArgs& a);
+int launch_latent_bwd(hipStream_t st, const LatentArgs& a);
+
+// scvi library latent: latl [B][ldl] (mu_l, s_raw_l) -> l sample, KL vs N(lib_mean, sqrt(lib_var))
+struct LibLatentArgs {
+  const float* latl = nullptr; int ld = 0; int B = 0;
+  const float* library = nullptr;  // [n_cells][2] resident, gathered by rows; or [B][2] when rows == nullptr
+  const int32_t* rows = nullptr; uint32_t cell_base = 0;
+  NoiseKey nk{0, 0, 0, 0, nullptr};
+  const float* inj_eps = nullptr;
+  float clip_library = 1e3f;
+  float* l = nullptr; float* sig = nullptr; float* eps = nullptr; float* kl = nullptr;  // [B]
+  const float* dl = nullptr;  // [B] d loss / d l (already masked by the clip)
+  float kl_scale = 0.f;
+  float* dlatl = nullptr;     // [B][ld]
+};
+int launch_lib_latent_fwd(hipStream_t st, const LibLatentArgs& a);
+int launch_lib_latent_bwd(hipStream_t st, const LibLatentArgs& a);
+
+// scvi head: raw [B][3][Gp] -> planes (rate, theta, gate) and back.
+struct ScviHeadArgs {
+  const float* raw = nullptr; float* planes = nullptr; long ld = 0; long plane_stride = 0;
+  int B = 0, G = 0, Gp = 0, k = 2;
+  const float* l = nullptr; float clip_library = 1e3f;
+  float* rho_raw = nullptr;          // [B][Gp] saved softmax
+  const float* dplanes = nullptr; float* draw = nullptr; float* dl = nullptr;
+};
+int launch_scvi_head_fwd(hipStream_t st, const ScviHeadArgs& a);
+int launch_scvi_head_bwd(hipStream_t st, const ScviHeadArgs& a);
+
+struct LabelArgs {
+  int kind = 0;                  // smx_label_likelihood
+  const float* raw = nullptr; int ld = 0;          // [B][ky*Pp]
+  const float* Y = nullptr; int ldy = 0;           // labels [rows][ldy]
+  const int32_t* rows = nullptr;
+  const uint8_t* mask = nullptr;                   // resident [n_cells] or nullptr (all unlabeled)
+  int B = 0, P = 0, Pp = 0;
+  float grad_scale = 0.f;        // -alpha / B_global
+  float* draw = nullptr;         // [B][ky*Pp]
+  float* llk = nullptr;          // [B]  mask * llk_y  (accumulated across label heads: add != 0)
+  int add = 0;
+  int backward = 1;
+};
+int launch_label_loss(hipStream_t st, const LabelArgs& a);
+
+// Per-step device-resident scalars.
+struct StepState {
+  uint32_t step;      // index of the step in flight (Philox counter word 2); = next - 1 during a step
+  uint32_t next;      // optimiser steps started so far
+  float lr_t;         // bias-corrected Adam step size of the step in flight
+  uint32_t cursor;    // position (in steps) inside the uploaded row-id order
+};
+// Copies this step's `batch` row ids from order + cursor*batch to rows, advances cursor/step, sets lr_t.
+int launch_step_begin(hipStream_t st, StepState* s, const int32_t* order, int32_t* rows, int batch, float lr,
+                      float b1, float b2);
+
+struct MetricsArgs {
+  const float* llk_part = nullptr; int n_chunks = 0;   // [B][n_chunks]
+  const float* lgx1 = nullptr; const int32_t* rows = nullptr;  // per-cell sum lgamma(x+1), gathered
+  const float* llk_y = nullptr;   // [B] masked label llk or nullptr
+  const float* kl = nullptr; const float* kl_l = nullptr;
+  int B = 0; float alpha = 0.f, beta = 1.f; float inv_global_batch = 0.f;
+  float* out = nullptr;           // [8]: loss, nllk_x, nllk_y, kl, kl_l, (5..7 reserved)
+};
+int launch_metrics(hipStream_t st, const MetricsArgs& a);
+
+// Optimiser over the flat parameter buffer.
+struct OptChunk { int32_t tensor; int32_t offset; int32_t count; int32_t first_chunk; int32_t n_chunks; int32_t pad[3]; };
+struct AdamArgs {
+  float* params = nullptr; float* grads = nullptr; float* m = nullptr; float* v = nullptr;
+  const OptChunk* chunks = nullptr; int n_chunks = 0;
+  float* partial = nullptr;     // [n_chunks] sum of squares per chunk
+  float* tensor_norm = nullptr; // [n_tensors] written by the update kernel (pre-clip norms)
+  const StepState* state = nullptr;
+  float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, clipnorm = 100.f;
+  float grad_scale = 1.f;       // 1/world after a sum all-reduce
+};
+int launch_adam(hipStream_t st, const AdamArgs& a);
+
+// Test helper: Philox multipliers / normals exactly as kernels draw them.
+int launch_noise_probe(hipStream_t st, NoiseKey nk, const int64_t* cell_ids, int B, int width, float p, float* mult,
+                       float* normal);
+
+}  // namespace smx

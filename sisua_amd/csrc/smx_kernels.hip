@@ -1,0 +1,654 @@
+// smx_kernels.hip -- the fused non-GEMM kernels of the SISUA step (gfx950).
+//
+//  count_loss     NB / ZINB / NBD / ZINBD log-likelihood, forward + gradient wrt the
+//                 parameter planes, one pass over B x G (the bandwidth-bound kernel the
+//                 roofline is quoted on: SURVEY.md 8d, rows a-10/a-11)
+//  bn_act_fwd/bwd (split-K slab sum) -> BatchNorm -> ReLU -> Dropout and its backward
+//  latent_fwd/bwd diagonal-Gaussian head: softplus1, reparameterised sample (Philox),
+//                 analytic KL (a-7); deterministic DCA latent (a-14)
+//  label_loss     masked NB / one-hot label heads of SISUA (a-13)
+//  scvi_head      softmax-rate / exp-dispersion head of SCVI and its backward (a-12)
+//  metrics        ELBO scalars (a-15);  adam: per-tensor clipnorm + Adam (a-16)
+#include "smx_internal.h"
+#include "../../include/sisua_hip.h"
+
+namespace smx {
+
+// ===========================================================================
+// count likelihood, elementwise
+// ===========================================================================
+template <int LK, int DIRECT>
+__device__ inline void count_elem(float x, float p0, float p1, float p2, float& llk, float& d0, float& d1,
+                                  float& d2) {
+  float ell;
+  if (LK == SMX_LLK_NB || LK == SMX_LLK_ZINB) {
+    const float r = expf(p0);
+    const float sp = softplusf(p1);          // softplus(l); log_sigmoid(l) = l - sp, log_sigmoid(-l) = -sp
+    const LgDg t = lgamma_digamma_diff(x, r);
+    ell = t.lg + x * (p1 - sp) - r * sp;
+    d0 = r * (t.dg - sp);
+    d1 = x - (x + r) * sigmoidf(p1);
+  } else {
+    float mu, th, g0 = 1.f, g1 = 1.f;
+    if (DIRECT) { mu = p0; th = p1; }
+    else {
+      mu = softplusf(p0); th = softplusf(p1 + SMX_SOFTPLUS_INV_1);
+      g0 = sigmoidf(p0); g1 = sigmoidf(p1 + SMX_SOFTPLUS_INV_1);
+    }
+    const float e = 1e-8f;
+    const float lt = logf(th + mu + e), lth = logf(th + e);
+    const float inv = 1.0f / (th + mu + e);
+    const LgDg t = lgamma_digamma_diff(x, th);
+    ell = th * (lth - lt) + x * (logf(mu + e) - lt) + t.lg;
+    d0 = (-th * inv + x / (mu + e) - x * inv) * g0;
+    d1 = (lth - lt + th / (th + e) - th * inv - x * inv + t.dg) * g1;
+  }
+  if (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) {
+    const float spg = softplusf(p2);
+    const float sg = sigmoidf(p2);
+    if (x == 0.f) {
+      const float lse = logaddexpf(p2, ell);
+      const float w = expf(ell - lse);
+      llk = lse - spg;
+      d0 *= w; d1 *= w;
+      d2 = (1.f - w) - sg;
+    } else {
+      llk = ell - spg;
+      d2 = -sg;
+    }
+  } else {
+    llk = ell;
+    d2 = 0.f;
+  }
+}
+
+// grid (n_chunks, B); thread = 4 consecutive genes of one cell.
+template <int LK, int DIRECT, int BWD>
+__global__ __launch_bounds__(256) void count_loss_kernel(LossArgs a) {
+  constexpr int K = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
+  const int b = blockIdx.y;
+  const int g0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  float acc = 0.f;
+  if (g0 < a.Gp) {
+    const long src = a.rows ? a.rows[b] : b;
+    const float4 x4 = *reinterpret_cast<const float4*>(a.X + src * a.ldx + g0);
+    const float* pb = a.P + (long)b * a.ldp + g0;
+    const float4 q0 = *reinterpret_cast<const float4*>(pb);
+    const float4 q1 = *reinterpret_cast<const float4*>(pb + a.plane_stride);
+    float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (K == 3) q2 = *reinterpret_cast<const float4*>(pb + 2 * a.plane_stride);
+    const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+    const float a0[4] = {q0.x, q0.y, q0.z, q0.w};
+    const float a1[4] = {q1.x, q1.y, q1.z, q1.w};
+    const float a2[4] = {q2.x, q2.y, q2.z, q2.w};
+    float r0[4], r1[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float llk = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+      if (g0 + e < a.G) {
+        count_elem<LK, DIRECT>(xs[e], a0[e], a1[e], a2[e], llk, d0, d1, d2);
+        acc += llk;
+      }
+      r0[e] = d0 * a.grad_scale; r1[e] = d1 * a.grad_scale; r2[e] = d2 * a.grad_scale;
+    }
+    if (BWD) {
+      float* db = a.dP + (long)b * a.ldp + g0;
+      *reinterpret_cast<float4*>(db) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+      *reinterpret_cast<float4*>(db + a.plane_stride) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+      if (K == 3) *reinterpret_cast<float4*>(db + 2 * a.plane_stride) = make_float4(r2[0], r2[1], r2[2], r2[3]);
+    }
+  }
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.llk_part[(long)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+int loss_chunks(int Gp) { return (Gp + 1023) / 1024; }
+
+template <int LK, int DIRECT>
+static void launch_loss_t(hipStream_t st, const LossArgs& a, dim3 grid) {
+  if (a.backward) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, 1>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, 0>), grid, dim3(256), 0, st, a);
+}
+
+int launch_count_loss(hipStream_t st, const LossArgs& a) {
+  if (a.B <= 0 || a.Gp % 4 || a.ldx % 4 || a.ldp % 4 || a.plane_stride % 4) {
+    set_error("count_loss: bad shapes");
+    return SMX_ERR_INVALID;
+  }
+  dim3 grid(loss_chunks(a.Gp), a.B);
+  switch (a.likelihood) {
+    case SMX_LLK_NB: launch_loss_t<SMX_LLK_NB, 0>(st, a, grid); break;
+    case SMX_LLK_ZINB: launch_loss_t<SMX_LLK_ZINB, 0>(st, a, grid); break;
+    case SMX_LLK_NBD:
+      if (a.direct) launch_loss_t<SMX_LLK_NBD, 1>(st, a, grid); else launch_loss_t<SMX_LLK_NBD, 0>(st, a, grid);
+      break;
+    case SMX_LLK_ZINBD:
+      if (a.direct) launch_loss_t<SMX_LLK_ZINBD, 1>(st, a, grid); else launch_loss_t<SMX_LLK_ZINBD, 0>(st, a, grid);
+      break;
+    default: set_error("count_loss: unknown likelihood"); return SMX_ERR_INVALID;
+  }
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// ===========================================================================
+// BatchNorm + ReLU + Dropout.  A workgroup owns 8 columns (all rows):
+// thread = (column c = tid & 7, row lane rl = tid >> 3), rows rl, rl+32, ...
+// ===========================================================================
+constexpr int BN_COLS = 8;
+constexpr int BN_RL = 32;
+
+__device__ inline float bn_col_reduce(float v, float* sh /*[32][8]*/) {
+  const int c = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  __syncthreads();
+  sh[rl * BN_COLS + c] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < BN_RL; ++i) s += sh[i * BN_COLS + c];  // fixed order: deterministic
+  return s;
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
+  __shared__ float sh[BN_RL * BN_COLS];
+  const int c = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int col = blockIdx.x * BN_COLS + c;
+  const bool live = col < a.H;  // padded columns produce zeros
+  const float bias = (!a.batchnorm && a.bias && live) ? a.bias[col] : 0.f;
+
+  // pass 1: slab sum (+ bias) -> xhat buffer (scratch), column sum
+  float s1 = 0.f;
+  for (int r = rl; r < a.B; r += BN_RL) {
+    float v = 0.f;
+    const float* p = a.pre + (long)r * a.ld + col;
+    for (int s = 0; s < a.n_slabs; ++s) v += p[(long)s * a.slab_stride];
+    v += bias;
+    a.xhat[(long)r * a.Hp + col] = v;
+    s1 += v;
+  }
+  float mean = 0.f, inv = 1.f, gamma = 1.f, beta = 0.f;
+  if (a.batchnorm) {
+    gamma = live ? a.gamma[col] : 0.f;
+    beta = live ? a.beta[col] : 0.f;
+    float var;
+    if (a.training) {
+      s1 = bn_col_reduce(s1, sh);
+      mean = s1 / (float)a.B;
+      float s2 = 0.f;
+      for (int r = rl; r < a.B; r += BN_RL) {
+        const float d = a.xhat[(long)r * a.Hp + col] - mean;
+        s2 += d * d;
+      }
+      s2 = bn_col_reduce(s2, sh);
+      var = s2 / (float)a.B;
+      if (rl == 0) {
+        if (a.batch_mean) { a.batch_mean[col] = mean; a.batch_var[col] = var; }
+        if (a.update_moving && live) {
+          a.moving_mean[col] = a.moving_mean[col] * a.momentum + mean * (1.f - a.momentum);
+          a.moving_var[col] = a.moving_var[col] * a.momentum + var * (1.f - a.momentum);
+        }
+      }
+    } else {
+      mean = live ? a.moving_mean[col] : 0.f;
+      var = live ? a.moving_var[col] : 1.f;
+    }
+    inv = rsqrtf(var + a.eps);
+    if (rl == 0 && a.inv_std) a.inv_std[col] = inv;
+  }
+  const float scale = (a.training && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
+  for (int r = rl; r < a.B; r += BN_RL) {
+    const long o = (long)r * a.Hp + col;
+    float v = a.xhat[o];
+    float y = v;
+    if (a.batchnorm) {
+      v = (v - mean) * inv;
+      y = gamma * v + beta;
+      a.xhat[o] = v;
+    }
+    float h = fmaxf(y, 0.f);
+    if (a.training && a.drop_p > 0.f) {
+      float mult;
+      if (a.inj_mask) mult = a.inj_mask[(long)r * a.inj_ld + col];
+      else {
+        const uint32_t cell = a.cell_base + (uint32_t)(a.rows ? a.rows[r] : r);
+        const U4 w = philox_block(a.nk, cell, (uint32_t)(col >> 2));
+        mult = dropout_mult1(w, col & 3, a.drop_p, scale);
+      }
+      h *= mult;
+    }
+    a.out[o] = live ? h : 0.f;
+  }
+}
+
+int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a) {
+  if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_fwd: bad shapes"); return SMX_ERR_INVALID; }
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(a.Hp / BN_COLS), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdArgs a) {
+  __shared__ float sh[BN_RL * BN_COLS];
+  const int c = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int col = blockIdx.x * BN_COLS + c;
+  const bool live = col < a.H;
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = rl; r < a.B; r += BN_RL) {
+    const long o = (long)r * a.Hp + col;
+    float g = 0.f;
+    const float* p = a.dout + (long)r * a.ld + col;
+    for (int s = 0; s < a.n_slabs; ++s) g += p[(long)s * a.slab_stride];
+    const float dy = (live && a.out[o] > 0.f) ? g * a.drop_scale : 0.f;
+    a.dpre[o] = dy;
+    s1 += dy;
+    if (a.batchnorm) s2 += dy * a.xhat[o];
+  }
+  s1 = bn_col_reduce(s1, sh);
+  if (!a.batchnorm) {
+    if (rl == 0 && a.dbias && live) a.dbias[col] = s1;
+    return;
+  }
+  s2 = bn_col_reduce(s2, sh);
+  const float gamma = live ? a.gamma[col] : 0.f;
+  const float inv = a.inv_std[col];
+  if (rl == 0) { a.dgamma[col] = live ? s2 : 0.f; a.dbeta[col] = live ? s1 : 0.f; }
+  const float invB = 1.f / (float)a.B;
+  for (int r = rl; r < a.B; r += BN_RL) {
+    const long o = (long)r * a.Hp + col;
+    const float dy = a.dpre[o];
+    float d;
+    if (a.training) d = gamma * inv * (dy - invB * (s1 + a.xhat[o] * s2));
+    else d = dy * gamma * inv;
+    a.dpre[o] = d;
+  }
+}
+
+int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a) {
+  if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_bwd: bad shapes"); return SMX_ERR_INVALID; }
+  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(a.Hp / BN_COLS), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// ===========================================================================
+// Latent head.  One wave per cell, lanes over latent dims.
+// ===========================================================================
+__global__ __launch_bounds__(256) void latent_fwd_kernel(LatentArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  float kl = 0.f;
+  const uint32_t cell = a.cell_base + (uint32_t)(a.rows ? a.rows[b] : b);
+  for (int d = lane; d < a.Dp; d += 64) {
+    const long o = (long)b * a.Dp + d;
+    float z = 0.f, sig = 1.f, eps = 0.f;
+    if (d < a.D) {
+      const float mu = a.lat[(long)b * a.ld + d];
+      if (a.stochastic) {
+        sig = softplusf(a.lat[(long)b * a.ld + a.Dp + d] + SMX_SOFTPLUS_INV_1);
+        if (a.inj_eps) eps = a.inj_eps[(long)b * a.inj_ld + d];
+        else {
+          const float4 n = normal4(philox_block(a.nk, cell, (uint32_t)(d >> 2)));
+          eps = (d & 3) == 0 ? n.x : (d & 3) == 1 ? n.y : (d & 3) == 2 ? n.z : n.w;
+        }
+        z = mu + sig * eps;
+        kl += 0.5f * (sig * sig + mu * mu - 1.f - 2.f * logf(sig));
+      } else {
+        z = a.relu ? fmaxf(mu, 0.f) : mu;
+      }
+    }
+    a.z[o] = z;
+    if (a.sig) { a.sig[o] = sig; a.eps[o] = eps; }
+  }
+  kl = wave_sum(kl);
+  if (lane == 0 && a.kl) a.kl[b] = kl;
+}
+
+int launch_latent_fwd(hipStream_t st, const LatentArgs& a) {
+  hipLaunchKernelGGL(latent_fwd_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+__global__ __launch_bounds__(256) void latent_bwd_kernel(LatentArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.B * a.Dp) return;
+  const int b = idx / a.Dp, d = idx % a.Dp;
+  float dz = 0.f;
+  for (int s = 0; s < a.dz_slabs; ++s) dz += a.dz[(long)s * a.dz_slab_stride + idx];
+  if (a.stochastic) {
+    float dmu = 0.f, ds = 0.f;
+    if (d < a.D) {
+      const float mu = a.lat[(long)b * a.ld + d];
+      const float sraw = a.lat[(long)b * a.ld + a.Dp + d];
+      const float sig = a.sig[idx], eps = a.eps[idx];
+      dmu = dz + a.kl_scale * mu;
+      ds = (dz * eps + a.kl_scale * (sig - 1.f / sig)) * sigmoidf(sraw + SMX_SOFTPLUS_INV_1);
+    }
+    a.dlat[(long)b * a.ld + d] = dmu;
+    a.dlat[(long)b * a.ld + a.Dp + d] = ds;
+  } else {
+    float g = 0.f;
+    if (d < a.D) g = (a.relu && !(a.lat[(long)b * a.ld + d] > 0.f)) ? 0.f : dz;
+    a.dlat[(long)b * a.ld + d] = g;
+  }
+}
+
+int launch_latent_bwd(hipStream_t st, const LatentArgs& a) {
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3((a.B * a.Dp + 255) / 256), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// ---- scvi library latent (scvi.py:37-45, 88-106, 117) -------------------------
+__global__ void lib_latent_fwd_kernel(LibLatentArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const long src = a.rows ? a.rows[b] : b;
+  const float mu = a.latl[(long)b * a.ld], sig = softplusf(a.latl[(long)b * a.ld + 1] + SMX_SOFTPLUS_INV_1);
+  float eps;
+  if (a.inj_eps) eps = a.inj_eps[b];
+  else eps = normal4(philox_block(a.nk, a.cell_base + (uint32_t)src, 0u)).x;
+  const float mp = a.library[src * 2], vp = a.library[src * 2 + 1];
+  const float sp = sqrtf(vp);
+  a.l[b] = mu + sig * eps;
+  a.sig[b] = sig;
+  a.eps[b] = eps;
+  a.kl[b] = logf(sp / sig) + (sig * sig + (mu - mp) * (mu - mp)) / (2.f * vp) - 0.5f;
+}
+int launch_lib_latent_fwd(hipStream_t st, const LibLatentArgs& a) {
+  hipLaunchKernelGGL(lib_latent_fwd_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+__global__ void lib_latent_bwd_kernel(LibLatentArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const long src = a.rows ? a.rows[b] : b;
+  const float mu = a.latl[(long)b * a.ld], sraw = a.latl[(long)b * a.ld + 1];
+  const float sig = a.sig[b], eps = a.eps[b];
+  const float mp = a.library[src * 2], vp = a.library[src * 2 + 1];
+  const float dl = a.dl[b];
+  for (int j = 2; j < a.ld; ++j) a.dlatl[(long)b * a.ld + j] = 0.f;
+  a.dlatl[(long)b * a.ld] = dl + a.kl_scale * (mu - mp) / vp;
+  a.dlatl[(long)b * a.ld + 1] = (dl * eps + a.kl_scale * (sig / vp - 1.f / sig)) * sigmoidf(sraw + SMX_SOFTPLUS_INV_1);
+}
+int launch_lib_latent_bwd(hipStream_t st, const LibLatentArgs& a) {
+  hipLaunchKernelGGL(lib_latent_bwd_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// ===========================================================================
+// scvi head: one workgroup per cell, three sweeps over G (max, sum, write)
+// ===========================================================================
+__device__ inline float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__device__ inline float block_max(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+__global__ __launch_bounds__(256) void scvi_head_fwd_kernel(ScviHeadArgs a) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  const float* raw = a.raw + (long)b * a.ld;
+  float* pl = a.planes + (long)b * a.ld;
+  float mx = -3.0e38f;
+  for (int g = threadIdx.x; g < a.G; g += 256) mx = fmaxf(mx, raw[g]);
+  mx = block_max(mx, sh);
+  float sum = 0.f;
+  for (int g = threadIdx.x; g < a.G; g += 256) sum += expf(raw[g] - mx);
+  sum = block_sum(sum, sh);
+  const float inv = 1.f / sum;
+  const float el = expf(fminf(fmaxf(a.l[b], 0.f), a.clip_library));
+  for (int g = threadIdx.x; g < a.Gp; g += 256) {
+    float rho = 0.f, rate = 0.f, th = 0.f, gate = 0.f;
+    if (g < a.G) {
+      rho = expf(raw[g] - mx) * inv;
+      rate = el * fminf(fmaxf(rho, 1e-7f), 1.f - 1e-7f);
+      th = expf(raw[a.plane_stride + g]);
+      if (a.k == 3) gate = raw[2 * a.plane_stride + g];
+    }
+    a.rho_raw[(long)b * a.Gp + g] = rho;
+    pl[g] = rate;
+    pl[a.plane_stride + g] = th;
+    if (a.k == 3) pl[2 * a.plane_stride + g] = gate;
+  }
+}
+int launch_scvi_head_fwd(hipStream_t st, const ScviHeadArgs& a) {
+  hipLaunchKernelGGL(scvi_head_fwd_kernel, dim3(a.B), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+__global__ __launch_bounds__(256) void scvi_head_bwd_kernel(ScviHeadArgs a) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  const float* pl = a.planes + (long)b * a.ld;
+  const float* dp = a.dplanes + (long)b * a.ld;
+  float* dr = a.draw + (long)b * a.ld;
+  const float* rho = a.rho_raw + (long)b * a.Gp;
+  const float lraw = a.l[b];
+  const float el = expf(fminf(fmaxf(lraw, 0.f), a.clip_library));
+  float s = 0.f, dlh = 0.f;
+  for (int g = threadIdx.x; g < a.G; g += 256) {
+    const float r = rho[g];
+    const float drate = dp[g];
+    const float inside = (r > 1e-7f && r < 1.f - 1e-7f) ? 1.f : 0.f;
+    s += drate * el * inside * r;
+    dlh += drate * pl[g];
+  }
+  s = block_sum(s, sh);
+  dlh = block_sum(dlh, sh);
+  if (threadIdx.x == 0) a.dl[b] = (lraw > 0.f && lraw < a.clip_library) ? dlh : 0.f;
+  for (int g = threadIdx.x; g < a.Gp; g += 256) {
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (g < a.G) {
+      const float r = rho[g];
+      const float inside = (r > 1e-7f && r < 1.f - 1e-7f) ? 1.f : 0.f;
+      d0 = r * (dp[g] * el * inside - s);
+      d1 = dp[a.plane_stride + g] * pl[a.plane_stride + g];
+      if (a.k == 3) d2 = dp[2 * a.plane_stride + g];
+    }
+    dr[g] = d0;
+    dr[a.plane_stride + g] = d1;
+    if (a.k == 3) dr[2 * a.plane_stride + g] = d2;
+  }
+}
+int launch_scvi_head_bwd(hipStream_t st, const ScviHeadArgs& a) {
+  hipLaunchKernelGGL(scvi_head_bwd_kernel, dim3(a.B), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// ===========================================================================
+// SISUA label heads: one thread per cell (P is tens of columns)
+// ===========================================================================
+__global__ void label_loss_kernel(LabelArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const long src = a.rows ? a.rows[b] : b;
+  const float* y = a.Y + src * a.ldy;
+  const float* raw = a.raw + (long)b * a.ld;
+  const float m = a.mask ? (a.mask[src] ? 1.f : 0.f) : 0.f;
+  const float gs = a.grad_scale * m;
+  float llk = 0.f;
+  if (a.kind == SMX_LABEL_NB) {
+    for (int p = 0; p < a.Pp; ++p) {
+      float d0 = 0.f, d1 = 0.f;
+      if (p < a.P) {
+        float e, d2;
+        count_elem<SMX_LLK_NB, 0>(y[p], raw[p], raw[a.Pp + p], 0.f, e, d0, d1, d2);
+        llk += e - lgammaf(y[p] + 1.f);
+      }
+      if (a.backward) { a.draw[(long)b * a.ld + p] = d0 * gs; a.draw[(long)b * a.ld + a.Pp + p] = d1 * gs; }
+    }
+  } else {
+    float mx = -3.0e38f, ysum = 0.f;
+    for (int p = 0; p < a.P; ++p) { mx = fmaxf(mx, raw[p]); ysum += y[p]; }
+    float se = 0.f;
+    for (int p = 0; p < a.P; ++p) se += expf(raw[p] - mx);
+    const float lse = mx + logf(se);
+    for (int p = 0; p < a.Pp; ++p) {
+      float d = 0.f;
+      if (p < a.P) {
+        const float lp = raw[p] - lse;
+        llk += y[p] * lp;
+        d = y[p] - expf(lp) * ysum;
+      }
+      if (a.backward) a.draw[(long)b * a.ld + p] = d * gs;
+    }
+  }
+  a.llk[b] = (a.add ? a.llk[b] : 0.f) + m * llk;
+}
+int launch_label_loss(hipStream_t st, const LabelArgs& a) {
+  hipLaunchKernelGGL(label_loss_kernel, dim3((a.B + 63) / 64), dim3(64), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// ===========================================================================
+// per-step scalars, metrics
+// ===========================================================================
+__global__ void step_begin_kernel(StepState* s, const int32_t* order, int32_t* rows, int batch, float lr, float b1,
+                                  float b2) {
+  const uint32_t cur = s->cursor;
+  if (order) {
+    for (int i = threadIdx.x; i < batch; i += blockDim.x) rows[i] = order[(long)cur * batch + i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = s->next + 1;  // 1-based Adam step
+    s->step = s->next;
+    s->next = t;
+    s->cursor = cur + 1;
+    s->lr_t = lr * sqrtf(1.f - powf(b2, (float)t)) / (1.f - powf(b1, (float)t));
+  }
+}
+int launch_step_begin(hipStream_t st, StepState* s, const int32_t* order, int32_t* rows, int batch, float lr,
+                      float b1, float b2) {
+  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(256), 0, st, s, order, rows, batch, lr, b1, b2);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+__global__ __launch_bounds__(256) void metrics_kernel(MetricsArgs a) {
+  __shared__ float sh[4];
+  float sx = 0.f, sy = 0.f, sk = 0.f, sl = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    float llk = 0.f;
+    for (int c = 0; c < a.n_chunks; ++c) llk += a.llk_part[(long)b * a.n_chunks + c];
+    if (a.lgx1) llk -= a.lgx1[a.rows ? a.rows[b] : b];
+    sx += llk;
+    if (a.llk_y) sy += a.llk_y[b];
+    if (a.kl) sk += a.kl[b];
+    if (a.kl_l) sl += a.kl_l[b];
+  }
+  sx = block_sum(sx, sh); sy = block_sum(sy, sh); sk = block_sum(sk, sh); sl = block_sum(sl, sh);
+  if (threadIdx.x == 0) {
+    const float s = a.inv_global_batch;
+    a.out[0] = -(sx + a.alpha * sy - a.beta * (sk + sl)) * s;
+    a.out[1] = -sx * s;
+    a.out[2] = -sy * s;
+    a.out[3] = sk * s;
+    a.out[4] = sl * s;
+    a.out[5] = 0.f; a.out[6] = 0.f; a.out[7] = 0.f;
+  }
+}
+int launch_metrics(hipStream_t st, const MetricsArgs& a) {
+  hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// ===========================================================================
+// optimiser: per-tensor clipnorm + Adam over the flat buffer
+// ===========================================================================
+__global__ __launch_bounds__(256) void grad_sqsum_kernel(AdamArgs a) {
+  __shared__ float sh[4];
+  const OptChunk ch = a.chunks[blockIdx.x];
+  float s = 0.f;
+  const float4* g4 = reinterpret_cast<const float4*>(a.grads + ch.offset);
+  for (int i = threadIdx.x; i < ch.count / 4; i += 256) {
+    const float4 g = g4[i];
+    s += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
+  __shared__ float sh[4];
+  const OptChunk ch = a.chunks[blockIdx.x];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < ch.n_chunks; i += 256) s += a.partial[ch.first_chunk + i];
+  s = block_sum(s, sh);
+  const float norm = sqrtf(s) * a.grad_scale;
+  float clip = a.grad_scale;
+  if (a.clipnorm > 0.f && norm > a.clipnorm) clip *= a.clipnorm / norm;
+  if (threadIdx.x == 0 && blockIdx.x == ch.first_chunk) a.tensor_norm[ch.tensor] = norm;
+  const float lr_t = a.state->lr_t;
+  const float4* g4 = reinterpret_cast<const float4*>(a.grads + ch.offset);
+  float4* m4 = reinterpret_cast<float4*>(a.m + ch.offset);
+  float4* v4 = reinterpret_cast<float4*>(a.v + ch.offset);
+  float4* p4 = reinterpret_cast<float4*>(a.params + ch.offset);
+  for (int i = threadIdx.x; i < ch.count / 4; i += 256) {
+    const float4 g = g4[i];
+    float4 m = m4[i], v = v4[i], p = p4[i];
+    const float gg[4] = {g.x * clip, g.y * clip, g.z * clip, g.w * clip};
+    float mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w}, pp[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mm[e] = a.b1 * mm[e] + (1.f - a.b1) * gg[e];
+      vv[e] = a.b2 * vv[e] + (1.f - a.b2) * gg[e] * gg[e];
+      pp[e] -= lr_t * mm[e] / (sqrtf(vv[e]) + a.eps);
+    }
+    m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    v4[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+  }
+}
+
+int launch_adam(hipStream_t st, const AdamArgs& a) {
+  hipLaunchKernelGGL(grad_sqsum_kernel, dim3(a.n_chunks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_chunks), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// ===========================================================================
+// noise probe (tests): what the kernels draw for (cell, column)
+// ===========================================================================
+__global__ void noise_probe_kernel(NoiseKey nk, const int64_t* cell_ids, int B, int width, float p, float* mult,
+                                   float* normal) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * width) return;
+  const int b = idx / width, c = idx % width;
+  const U4 w = philox_block(nk, (uint32_t)cell_ids[b], (uint32_t)(c >> 2));
+  if (mult) mult[idx] = (p > 0.f) ? dropout_mult1(w, c & 3, p, 1.f / (1.f - p)) : 1.f;
+  if (normal) {
+    const float4 n = normal4(w);
+    normal[idx] = (c & 3) == 0 ? n.x : (c & 3) == 1 ? n.y : (c & 3) == 2 ? n.z : n.w;
+  }
+}
+int launch_noise_probe(hipStream_t st, NoiseKey nk, const int64_t* cell_ids, int B, int width, float p, float* mult,
+                       float* normal) {
+  hipLaunchKernelGGL(noise_probe_kernel, dim3((B * width + 255) / 256), dim3(256), 0, st, nk, cell_ids, B, width, p,
+                     mult, normal);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+}  // namespace smx

@@ -1,0 +1,1272 @@
+// smx_model.hip -- model state, step orchestration and the C-ABI of include/sisua_hip.h.
+//
+// HBM layout (all fp32, row-major, every feature axis padded to a multiple of 32
+// so rows are 128-byte aligned and float4 accesses never straddle a row):
+//   X        [n_cells][Gp]            resident counts (zero padded), gathered by row id
+//   params   flat buffer, tensors in manifest order; W as [in_p][chunks*chunk_wp]
+//            (output head: k planes of Gp; latent head: mu | s planes of Dp)
+//   grads    same layout + tail [BN batch stats | 8 metric scalars]: ONE buffer,
+//            ONE all-reduce per step under data parallelism
+//   adam m/v same layout
+//   P, dP    [B][k*Gp] distribution parameter planes and their gradients
+// Padded rows/columns of every weight stay exactly zero (their gradients are zero
+// by construction), so padded lanes never leak into logical results.
+#include <dlfcn.h>
+#include <math.h>
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sisua_hip.h"
+#include "smx_internal.h"
+
+namespace smx {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace smx
+using namespace smx;
+
+#define SMX_CHECK(expr)            \
+  do {                             \
+    int rc_ = (expr);              \
+    if (rc_ != SMX_OK) return rc_; \
+  } while (0)
+#define SMX_REQUIRE(cond, msg)                 \
+  do {                                         \
+    if (!(cond)) { set_error(msg); return SMX_ERR_INVALID; } \
+  } while (0)
+
+enum { ST_INPUT_DROPOUT = 0, ST_ENC_DROPOUT = 16, ST_ENCL_DROPOUT = 32, ST_DEC_DROPOUT = 48, ST_EPS_Z = 64, ST_EPS_L = 65 };
+
+namespace {
+
+struct TensorInfo {
+  std::string name;
+  int rows = 1, cols = 0;               // logical
+  int chunks = 1, chunk_w = 0, chunk_wp = 0;
+  int rows_p = 1, ld = 0;
+  size_t offset = 0, count = 0;
+};
+
+struct MlpLayer {
+  int in = 0, in_p = 0, out = 0, out_p = 0;
+  int tW = -1, tGamma = -1, tBeta = -1, tBias = -1;
+  int bn = -1;
+  int stream = 0;
+  float drop_p = 0.f;
+  float *xhat = nullptr, *out_buf = nullptr, *inv_std = nullptr, *dpre = nullptr;
+};
+
+struct Injected { float* d = nullptr; int ld = 0; };
+
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int load_rccl() {
+  if (g_rccl.lib) return SMX_OK;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { set_error(std::string("cannot load librccl: ") + dlerror()); return SMX_ERR_COMM; }
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+  g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+    set_error("librccl lacks a required symbol");
+    return SMX_ERR_COMM;
+  }
+  g_rccl.lib = h;
+  return SMX_OK;
+}
+
+__global__ void bn_moving_update_kernel(float* moving, const float* batch_sum, int n, float inv_world, float momentum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) moving[i] = moving[i] * momentum + batch_sum[i] * inv_world * (1.f - momentum);
+}
+
+}  // namespace
+
+struct smx_model {
+  smx_config cfg;
+  int device = 0;
+  hipStream_t st = nullptr;
+  int G = 0, Gp = 0, D = 0, Dp = 0, k = 0, Bmax = 0;
+  bool stochastic = true, scvi = false;
+  std::vector<TensorInfo> tensors;
+  size_t flat_count = 0, tail_off_bn = 0, tail_off_metrics = 0, grads_count = 0;
+  float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  std::vector<MlpLayer> enc, encl, dec;
+  int t_latW = -1, t_latb = -1, t_latlW = -1, t_latlb = -1;
+  int t_outW[3] = {-1, -1, -1}, t_outb[3] = {-1, -1, -1};
+  int t_labW[SMX_MAX_LABELS], t_labb[SMX_MAX_LABELS];
+  int lab_ky[SMX_MAX_LABELS], lab_Pp[SMX_MAX_LABELS];
+  // batch-norm moving stats: layer i at bn_moving + bn_off[i]: mean[w_p] then var[w_p]
+  std::vector<int> bn_w, bn_wp;
+  std::vector<size_t> bn_off;
+  float* bn_moving = nullptr;
+  size_t bn_total = 0;
+  // dataset
+  float* X = nullptr; int64_t N = 0; int64_t cell_base = 0;
+  float* Y[SMX_MAX_LABELS] = {nullptr, nullptr, nullptr, nullptr};
+  float* library = nullptr; uint8_t* mask = nullptr; float* lgx1 = nullptr;
+  // host-batch staging for smx_forward(host_x)
+  float* hostX = nullptr; float* hostLib = nullptr; float* hostLgx1 = nullptr;
+  // step state
+  int32_t* rows = nullptr; int32_t* order = nullptr; size_t order_cap = 0;
+  StepState* state = nullptr; uint32_t h_next = 0;
+  float *latbuf = nullptr, *dlat = nullptr, *z = nullptr, *sig = nullptr, *eps = nullptr, *kl = nullptr;
+  float *latlbuf = nullptr, *dlatl = nullptr, *lsmp = nullptr, *lsig = nullptr, *leps = nullptr, *kl_l = nullptr, *dl = nullptr;
+  float *P = nullptr, *dP = nullptr, *raw = nullptr, *draw = nullptr, *rho = nullptr, *llk_part = nullptr;
+  float* laby_raw[SMX_MAX_LABELS] = {nullptr, nullptr, nullptr, nullptr};
+  float* laby_draw[SMX_MAX_LABELS] = {nullptr, nullptr, nullptr, nullptr};
+  float* llk_y = nullptr;
+  float* slab = nullptr; size_t slab_cap = 0; int max_feat_p = 0;
+  // optimiser
+  OptChunk* chunks = nullptr; int n_chunks = 0; float* partial = nullptr; float* tensor_norm = nullptr;
+  // noise injection
+  std::map<int, Injected> injected; bool use_injected = false;
+  // comm
+  ncclComm_t comm = nullptr; int rank = 0, world = 1;
+  // graphs
+  std::map<int, hipGraphExec_t> graphs;
+  bool capturing = false;
+  // timing
+  std::string timing_label; std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events; size_t timing_used = 0;
+};
+
+namespace {
+
+struct Timed {
+  smx_model* m; hipEvent_t stop = nullptr;
+  Timed(smx_model* m_, const char* label) : m(m_) {
+    if (m->capturing || m->timing_label.empty() || m->timing_label != label) return;
+    if (m->timing_used == m->timing_events.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      m->timing_events.push_back({a, b});
+    }
+    auto& ev = m->timing_events[m->timing_used++];
+    hipEventRecord(ev.first, m->st);
+    stop = ev.second;
+  }
+  ~Timed() { if (stop) hipEventRecord(stop, m->st); }
+};
+
+int add_tensor(smx_model* m, const std::string& name, int rows, int cols, int chunks, bool vec) {
+  TensorInfo t;
+  t.name = name; t.rows = vec ? 1 : rows; t.cols = cols; t.chunks = chunks;
+  t.chunk_w = cols / chunks; t.chunk_wp = round_up(t.chunk_w, 32);
+  t.rows_p = vec ? 1 : round_up(rows, 32);
+  t.ld = chunks * t.chunk_wp;
+  t.offset = m->flat_count;
+  t.count = (size_t)t.rows_p * t.ld;
+  m->flat_count += (t.count + 63) / 64 * 64;
+  m->tensors.push_back(t);
+  return (int)m->tensors.size() - 1;
+}
+
+int build_mlp(smx_model* m, std::vector<MlpLayer>& mlp, const char* prefix, int n_in, int n, const int32_t* units,
+              int stream0, float drop_p) {
+  for (int i = 0; i < n; ++i) {
+    MlpLayer L;
+    L.in = n_in; L.in_p = round_up(n_in, 32); L.out = units[i]; L.out_p = round_up(units[i], 32);
+    std::string p = std::string(prefix) + std::to_string(i);
+    L.tW = add_tensor(m, p + "/W", n_in, units[i], 1, false);
+    if (m->cfg.batchnorm) {
+      L.tGamma = add_tensor(m, p + "/gamma", 1, units[i], 1, true);
+      L.tBeta = add_tensor(m, p + "/beta", 1, units[i], 1, true);
+      L.bn = (int)m->bn_w.size();
+      m->bn_w.push_back(units[i]); m->bn_wp.push_back(L.out_p);
+    } else {
+      L.tBias = add_tensor(m, p + "/b", 1, units[i], 1, true);
+    }
+    L.stream = stream0 + i; L.drop_p = drop_p;
+    mlp.push_back(L);
+    n_in = units[i];
+  }
+  return n_in;
+}
+
+template <typename T>
+int dmalloc(T** p, size_t n) {
+  if (n == 0) n = 1;
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) { set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e)); return SMX_ERR_NOMEM; }
+  e = hipMemset(*p, 0, n * sizeof(T));
+  if (e != hipSuccess) { set_error(std::string("hipMemset failed: ") + hipGetErrorString(e)); return SMX_ERR_HIP; }
+  return SMX_OK;
+}
+
+float* P_(smx_model* m, int t) { return m->params + m->tensors[t].offset; }
+float* G_(smx_model* m, int t) { return m->grads + m->tensors[t].offset; }
+
+NoiseKey make_key(smx_model* m, int stream, int sample, bool training) {
+  NoiseKey nk;
+  nk.k0 = (uint32_t)(m->cfg.seed & 0xFFFFFFFFu);
+  nk.k1 = (uint32_t)(m->cfg.seed >> 32);
+  nk.step = 0;
+  nk.stream = (uint32_t)((stream & 0xFF) | ((sample & 0xFFFFFF) << 8));
+  nk.step_ptr = training ? &m->state->step : nullptr;
+  return nk;
+}
+
+const Injected* inj(smx_model* m, int stream) {
+  if (!m->use_injected) return nullptr;
+  auto it = m->injected.find(stream);
+  return it == m->injected.end() ? nullptr : &it->second;
+}
+
+// ---- one pass description ----------------------------------------------------
+struct Pass {
+  int B = 0;
+  const int32_t* rows = nullptr;   // device row ids into X (nullptr: identity on Xsrc)
+  const float* Xsrc = nullptr;     // m->X or m->hostX
+  const float* lib = nullptr;      // library [..][2] matching Xsrc indexing
+  const float* lgx1 = nullptr;
+  uint32_t cell_base = 0;
+  int training = 1;
+  int sample = 0;
+  int global_batch = 0;
+};
+
+int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
+                const char* label0) {
+  const float* in = in0;
+  int ld = ld0;
+  for (size_t i = 0; i < mlp.size(); ++i) {
+    MlpLayer& L = mlp[i];
+    const TensorInfo& tw = m->tensors[L.tW];
+    GemmArgs g;
+    g.A = in; g.lda = ld; g.B = P_(m, L.tW); g.ldb = tw.ld;
+    g.M = ps.B; g.N = L.out_p; g.K = L.in_p;
+    g.C = m->slab; g.ldc = L.out_p; g.slab_stride = (long)ps.B * L.out_p;
+    g.split_k = suggest_split_k(ps.B, L.out_p, L.in_p);
+    if (i == 0 && in_is_x) {
+      g.use_xform = 1;
+      g.xf.rows = ps.rows; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
+      if (ps.training && m->cfg.input_dropout > 0.f) {
+        g.xf.drop_p = m->cfg.input_dropout; g.xf.drop_scale = 1.f / (1.f - m->cfg.input_dropout);
+        g.xf.nk = make_key(m, ST_INPUT_DROPOUT, ps.sample, true);
+        if (const Injected* ij = inj(m, ST_INPUT_DROPOUT)) { g.xf.inj_mask = ij->d; g.xf.inj_ld = ij->ld; }
+      }
+    }
+    int eff = 1;
+    {
+      Timed t(m, (i == 0 && in_is_x) ? label0 : "gemm_mlp_fwd");
+      SMX_CHECK(launch_gemm(m->st, g, &eff));
+    }
+    BnFwdArgs b;
+    b.pre = m->slab; b.n_slabs = eff; b.slab_stride = g.slab_stride; b.ld = L.out_p;
+    b.B = ps.B; b.H = L.out; b.Hp = L.out_p; b.batchnorm = m->cfg.batchnorm; b.training = ps.training;
+    if (m->cfg.batchnorm) {
+      b.gamma = P_(m, L.tGamma); b.beta = P_(m, L.tBeta);
+      b.moving_mean = m->bn_moving + m->bn_off[L.bn]; b.moving_var = b.moving_mean + L.out_p;
+      b.batch_mean = m->grads + m->tail_off_bn + m->bn_off[L.bn]; b.batch_var = b.batch_mean + L.out_p;
+      b.update_moving = (m->world == 1);
+      b.momentum = m->cfg.bn_momentum; b.eps = m->cfg.bn_eps;
+    } else {
+      b.bias = P_(m, L.tBias);
+    }
+    b.xhat = L.xhat; b.inv_std = L.inv_std; b.out = L.out_buf;
+    b.drop_p = ps.training ? L.drop_p : 0.f;
+    b.nk = make_key(m, L.stream, ps.sample, true);
+    b.rows = ps.rows; b.cell_base = ps.cell_base;
+    if (const Injected* ij = inj(m, L.stream)) { b.inj_mask = ij->d; b.inj_ld = ij->ld; }
+    {
+      Timed t(m, "bn_fwd");
+      SMX_CHECK(launch_bn_act_fwd(m->st, b));
+    }
+    in = L.out_buf; ld = L.out_p;
+  }
+  return SMX_OK;
+}
+
+// backward through an MLP.  d(out of last layer) arrives as `n_slabs` slabs in m->slab.
+// Leaves d(input of first layer) as slabs in m->slab unless skip_input_grad.
+int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
+                 int n_slabs, bool skip_input_grad, int* out_slabs, const char* label_dw0) {
+  for (int i = (int)mlp.size() - 1; i >= 0; --i) {
+    MlpLayer& L = mlp[i];
+    const TensorInfo& tw = m->tensors[L.tW];
+    BnBwdArgs b;
+    b.dout = m->slab; b.n_slabs = n_slabs; b.slab_stride = (long)ps.B * L.out_p; b.ld = L.out_p;
+    b.out = L.out_buf; b.xhat = L.xhat; b.inv_std = L.inv_std;
+    b.B = ps.B; b.H = L.out; b.Hp = L.out_p; b.batchnorm = m->cfg.batchnorm; b.training = ps.training;
+    b.drop_scale = (ps.training && L.drop_p > 0.f) ? 1.f / (1.f - L.drop_p) : 1.f;
+    b.dpre = L.dpre;
+    if (m->cfg.batchnorm) { b.gamma = P_(m, L.tGamma); b.dgamma = G_(m, L.tGamma); b.dbeta = G_(m, L.tBeta); }
+    else b.dbias = G_(m, L.tBias);
+    {
+      Timed t(m, "bn_bwd");
+      SMX_CHECK(launch_bn_act_bwd(m->st, b));
+    }
+    // dW = in^T * dpre
+    const bool first_x = (i == 0 && in_is_x);
+    GemmArgs g;
+    g.A = (i == 0) ? in0 : mlp[i - 1].out_buf; g.lda = (i == 0) ? ld0 : mlp[i - 1].out_p; g.a_kmajor = 1;
+    g.B = L.dpre; g.ldb = L.out_p;
+    g.C = G_(m, L.tW); g.ldc = tw.ld;
+    g.M = L.in_p; g.N = L.out_p; g.K = ps.B;
+    if (first_x) {
+      g.use_xform = 1;
+      g.xf.rows = ps.rows; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
+      if (ps.training && m->cfg.input_dropout > 0.f) {
+        g.xf.drop_p = m->cfg.input_dropout; g.xf.drop_scale = 1.f / (1.f - m->cfg.input_dropout);
+        g.xf.nk = make_key(m, ST_INPUT_DROPOUT, ps.sample, true);
+        if (const Injected* ij = inj(m, ST_INPUT_DROPOUT)) { g.xf.inj_mask = ij->d; g.xf.inj_ld = ij->ld; }
+      }
+    }
+    {
+      Timed t(m, first_x ? label_dw0 : "gemm_mlp_dw");
+      SMX_CHECK(launch_gemm(m->st, g));
+    }
+    if (i == 0 && skip_input_grad) { n_slabs = 0; break; }
+    // d in = dpre * W^T  -> slabs
+    GemmArgs h;
+    h.A = L.dpre; h.lda = L.out_p; h.B = P_(m, L.tW); h.ldb = tw.ld; h.b_nmajor = 1;
+    h.M = ps.B; h.N = L.in_p; h.K = L.out_p;
+    h.C = m->slab; h.ldc = L.in_p; h.slab_stride = (long)ps.B * L.in_p;
+    h.split_k = suggest_split_k(ps.B, L.in_p, L.out_p);
+    int eff = 1;
+    {
+      Timed t(m, "gemm_mlp_dx");
+      SMX_CHECK(launch_gemm(m->st, h, &eff));
+    }
+    n_slabs = eff;
+  }
+  if (out_slabs) *out_slabs = n_slabs;
+  return SMX_OK;
+}
+
+int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward) {
+  const smx_config& c = m->cfg;
+  const float inv_gb = 1.f / (float)ps.global_batch;
+  // ---- encoder ----
+  SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd"));
+  const MlpLayer& eL = m->enc.back();
+  const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
+  {
+    const TensorInfo& tw = m->tensors[m->t_latW];
+    GemmArgs g;
+    g.A = eL.out_buf; g.lda = eL.out_p; g.B = P_(m, m->t_latW); g.ldb = tw.ld;
+    g.C = m->latbuf; g.ldc = lat_ld; g.M = ps.B; g.N = lat_ld; g.K = eL.out_p; g.bias = P_(m, m->t_latb);
+    Timed t(m, "gemm_lat_fwd");
+    SMX_CHECK(launch_gemm(m->st, g));
+  }
+  LatentArgs la;
+  la.stochastic = m->stochastic; la.relu = (c.latent_activation == SMX_ACT_RELU); la.training = ps.training;
+  la.lat = m->latbuf; la.ld = lat_ld; la.B = ps.B; la.D = m->D; la.Dp = m->Dp;
+  la.nk = make_key(m, ST_EPS_Z, ps.sample, ps.training != 0);
+  la.rows = ps.rows; la.cell_base = ps.cell_base;
+  if (const Injected* ij = inj(m, ST_EPS_Z)) { la.inj_eps = ij->d; la.inj_ld = ij->ld; }
+  la.z = m->z; la.sig = m->sig; la.eps = m->eps; la.kl = m->kl;
+  {
+    Timed t(m, "latent_fwd");
+    SMX_CHECK(launch_latent_fwd(m->st, la));
+  }
+  // ---- scvi library latent ----
+  if (m->scvi) {
+    SMX_CHECK(mlp_forward(m, m->encl, ps, ps.Xsrc, m->Gp, true, "gemm_encl_fwd"));
+    const MlpLayer& lL = m->encl.back();
+    const TensorInfo& tw = m->tensors[m->t_latlW];
+    GemmArgs g;
+    g.A = lL.out_buf; g.lda = lL.out_p; g.B = P_(m, m->t_latlW); g.ldb = tw.ld;
+    g.C = m->latlbuf; g.ldc = 32; g.M = ps.B; g.N = 32; g.K = lL.out_p; g.bias = P_(m, m->t_latlb);
+    SMX_CHECK(launch_gemm(m->st, g));
+    LibLatentArgs ll;
+    ll.latl = m->latlbuf; ll.ld = 32; ll.B = ps.B; ll.library = ps.lib; ll.rows = ps.rows; ll.cell_base = ps.cell_base;
+    ll.nk = make_key(m, ST_EPS_L, ps.sample, ps.training != 0);
+    if (const Injected* ij = inj(m, ST_EPS_L)) ll.inj_eps = ij->d;
+    ll.clip_library = c.clip_library;
+    ll.l = m->lsmp; ll.sig = m->lsig; ll.eps = m->leps; ll.kl = m->kl_l;
+    SMX_CHECK(launch_lib_latent_fwd(m->st, ll));
+  }
+  // ---- decoder ----
+  SMX_CHECK(mlp_forward(m, m->dec, ps, m->z, m->Dp, false, ""));
+  const MlpLayer& dL = m->dec.back();
+  const long ldp = (long)m->k * m->Gp;
+  if (m->scvi) {
+    for (int ch = 0; ch < m->k; ++ch) {
+      const TensorInfo& tw = m->tensors[m->t_outW[ch]];
+      GemmArgs g;
+      g.A = dL.out_buf; g.lda = dL.out_p; g.B = P_(m, m->t_outW[ch]); g.ldb = tw.ld;
+      g.C = m->raw + (long)ch * m->Gp; g.ldc = (int)ldp; g.M = ps.B; g.N = m->Gp; g.K = dL.out_p;
+      g.bias = P_(m, m->t_outb[ch]);
+      Timed t(m, "gemm_out_fwd");
+      SMX_CHECK(launch_gemm(m->st, g));
+    }
+    ScviHeadArgs sh;
+    sh.raw = m->raw; sh.planes = m->P; sh.ld = ldp; sh.plane_stride = m->Gp; sh.B = ps.B; sh.G = m->G; sh.Gp = m->Gp;
+    sh.k = m->k; sh.l = m->lsmp; sh.clip_library = c.clip_library; sh.rho_raw = m->rho;
+    SMX_CHECK(launch_scvi_head_fwd(m->st, sh));
+  } else {
+    const TensorInfo& tw = m->tensors[m->t_outW[0]];
+    GemmArgs g;
+    g.A = dL.out_buf; g.lda = dL.out_p; g.B = P_(m, m->t_outW[0]); g.ldb = tw.ld;
+    g.C = m->P; g.ldc = (int)ldp; g.M = ps.B; g.N = (int)ldp; g.K = dL.out_p; g.bias = P_(m, m->t_outb[0]);
+    Timed t(m, "gemm_out_fwd");
+    SMX_CHECK(launch_gemm(m->st, g));
+  }
+  // ---- label heads (raw outputs) ----
+  for (int j = 0; j < c.n_labels; ++j) {
+    const TensorInfo& tw = m->tensors[m->t_labW[j]];
+    GemmArgs g;
+    g.A = dL.out_buf; g.lda = dL.out_p; g.B = P_(m, m->t_labW[j]); g.ldb = tw.ld;
+    g.C = m->laby_raw[j]; g.ldc = tw.ld; g.M = ps.B; g.N = tw.ld; g.K = dL.out_p; g.bias = P_(m, m->t_labb[j]);
+    SMX_CHECK(launch_gemm(m->st, g));
+  }
+  if (!with_loss) return SMX_OK;
+  // ---- losses ----
+  LossArgs lo;
+  lo.likelihood = c.likelihood; lo.direct = m->scvi; lo.backward = backward;
+  lo.X = ps.Xsrc; lo.ldx = m->Gp; lo.rows = ps.rows;
+  lo.P = m->P; lo.ldp = ldp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
+  lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = -inv_gb;
+  {
+    Timed t(m, "loss");
+    SMX_CHECK(launch_count_loss(m->st, lo));
+  }
+  for (int j = 0; j < c.n_labels; ++j) {
+    const TensorInfo& tw = m->tensors[m->t_labW[j]];
+    LabelArgs lb;
+    lb.kind = c.label_llk[j]; lb.raw = m->laby_raw[j]; lb.ld = tw.ld; lb.Y = m->Y[j]; lb.ldy = m->lab_Pp[j];
+    lb.rows = ps.rows; lb.mask = m->mask; lb.B = ps.B; lb.P = c.label_dim[j]; lb.Pp = m->lab_Pp[j];
+    lb.grad_scale = -c.alpha * inv_gb; lb.draw = m->laby_draw[j]; lb.llk = m->llk_y; lb.add = (j > 0);
+    lb.backward = backward;
+    SMX_CHECK(launch_label_loss(m->st, lb));
+  }
+  MetricsArgs me;
+  me.llk_part = m->llk_part; me.n_chunks = loss_chunks(m->Gp); me.lgx1 = ps.lgx1; me.rows = ps.rows;
+  me.llk_y = c.n_labels ? m->llk_y : nullptr;
+  me.kl = m->stochastic ? m->kl : nullptr; me.kl_l = m->scvi ? m->kl_l : nullptr;
+  me.B = ps.B; me.alpha = c.alpha; me.beta = c.beta; me.inv_global_batch = inv_gb;
+  me.out = m->grads + m->tail_off_metrics;
+  {
+    Timed t(m, "metrics");
+    SMX_CHECK(launch_metrics(m->st, me));
+  }
+  return SMX_OK;
+}
+
+int backward_pass(smx_model* m, const Pass& ps) {
+  const smx_config& c = m->cfg;
+  const float inv_gb = 1.f / (float)ps.global_batch;
+  const MlpLayer& dL = m->dec.back();
+  const long ldp = (long)m->k * m->Gp;
+  int n_slabs = 0;
+  const long dd_stride = (long)ps.B * dL.out_p;
+  const float* dparams = m->dP;
+  if (m->scvi) {
+    ScviHeadArgs sh;
+    sh.raw = m->raw; sh.planes = m->P; sh.ld = ldp; sh.plane_stride = m->Gp; sh.B = ps.B; sh.G = m->G; sh.Gp = m->Gp;
+    sh.k = m->k; sh.l = m->lsmp; sh.clip_library = c.clip_library; sh.rho_raw = m->rho;
+    sh.dplanes = m->dP; sh.draw = m->draw; sh.dl = m->dl;
+    SMX_CHECK(launch_scvi_head_bwd(m->st, sh));
+    dparams = m->draw;
+  }
+  const int n_heads = m->scvi ? m->k : 1;
+  for (int ch = 0; ch < n_heads; ++ch) {
+    const TensorInfo& tw = m->tensors[m->t_outW[ch]];
+    const float* dp = dparams + (m->scvi ? (long)ch * m->Gp : 0);
+    const int ncols = m->scvi ? m->Gp : (int)ldp;
+    {  // dW = d^T dP, db = colsum(dP)
+      GemmArgs g;
+      g.A = dL.out_buf; g.lda = dL.out_p; g.a_kmajor = 1; g.B = dp; g.ldb = (int)ldp;
+      g.C = G_(m, m->t_outW[ch]); g.ldc = tw.ld; g.M = dL.out_p; g.N = ncols; g.K = ps.B;
+      g.colsum = G_(m, m->t_outb[ch]);
+      Timed t(m, "gemm_out_dw");
+      SMX_CHECK(launch_gemm(m->st, g));
+    }
+    {  // dd += dP W^T
+      GemmArgs g;
+      g.A = dp; g.lda = (int)ldp; g.B = P_(m, m->t_outW[ch]); g.ldb = tw.ld; g.b_nmajor = 1;
+      g.C = m->slab + (long)n_slabs * dd_stride; g.ldc = dL.out_p; g.slab_stride = dd_stride;
+      g.M = ps.B; g.N = dL.out_p; g.K = ncols;
+      g.split_k = suggest_split_k(ps.B, dL.out_p, ncols);
+      int eff = 1;
+      Timed t(m, "gemm_out_dx");
+      SMX_CHECK(launch_gemm(m->st, g, &eff));
+      n_slabs += eff;
+    }
+  }
+  for (int j = 0; j < c.n_labels; ++j) {
+    const TensorInfo& tw = m->tensors[m->t_labW[j]];
+    {
+      GemmArgs g;
+      g.A = dL.out_buf; g.lda = dL.out_p; g.a_kmajor = 1; g.B = m->laby_draw[j]; g.ldb = tw.ld;
+      g.C = G_(m, m->t_labW[j]); g.ldc = tw.ld; g.M = dL.out_p; g.N = tw.ld; g.K = ps.B;
+      g.colsum = G_(m, m->t_labb[j]);
+      SMX_CHECK(launch_gemm(m->st, g));
+    }
+    {
+      GemmArgs g;
+      g.A = m->laby_draw[j]; g.lda = tw.ld; g.B = P_(m, m->t_labW[j]); g.ldb = tw.ld; g.b_nmajor = 1;
+      g.C = m->slab + (long)n_slabs * dd_stride; g.ldc = dL.out_p; g.slab_stride = dd_stride;
+      g.M = ps.B; g.N = dL.out_p; g.K = tw.ld;
+      SMX_CHECK(launch_gemm(m->st, g));
+      n_slabs += 1;
+    }
+  }
+  // ---- decoder MLP, leaves dz slabs ----
+  int dz_slabs = 0;
+  SMX_CHECK(mlp_backward(m, m->dec, ps, m->z, m->Dp, false, n_slabs, false, &dz_slabs, ""));
+  // ---- latent ----
+  const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
+  LatentArgs la;
+  la.stochastic = m->stochastic; la.relu = (c.latent_activation == SMX_ACT_RELU);
+  la.lat = m->latbuf; la.ld = lat_ld; la.B = ps.B; la.D = m->D; la.Dp = m->Dp;
+  la.sig = m->sig; la.eps = m->eps; la.dz = m->slab; la.dz_slabs = dz_slabs; la.dz_slab_stride = (long)ps.B * m->Dp;
+  la.kl_scale = c.beta * inv_gb; la.dlat = m->dlat;
+  {
+    Timed t(m, "latent_bwd");
+    SMX_CHECK(launch_latent_bwd(m->st, la));
+  }
+  const MlpLayer& eL = m->enc.back();
+  {
+    const TensorInfo& tw = m->tensors[m->t_latW];
+    GemmArgs g;
+    g.A = eL.out_buf; g.lda = eL.out_p; g.a_kmajor = 1; g.B = m->dlat; g.ldb = lat_ld;
+    g.C = G_(m, m->t_latW); g.ldc = tw.ld; g.M = eL.out_p; g.N = lat_ld; g.K = ps.B; g.colsum = G_(m, m->t_latb);
+    Timed t(m, "gemm_lat_dw");
+    SMX_CHECK(launch_gemm(m->st, g));
+    GemmArgs h;
+    h.A = m->dlat; h.lda = lat_ld; h.B = P_(m, m->t_latW); h.ldb = tw.ld; h.b_nmajor = 1;
+    h.C = m->slab; h.ldc = eL.out_p; h.slab_stride = (long)ps.B * eL.out_p;
+    h.M = ps.B; h.N = eL.out_p; h.K = lat_ld;
+    SMX_CHECK(launch_gemm(m->st, h));
+  }
+  SMX_CHECK(mlp_backward(m, m->enc, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_enc_dw"));
+  // ---- scvi library branch ----
+  if (m->scvi) {
+    LibLatentArgs ll;
+    ll.latl = m->latlbuf; ll.ld = 32; ll.B = ps.B; ll.library = ps.lib; ll.rows = ps.rows;
+    ll.sig = m->lsig; ll.eps = m->leps; ll.dl = m->dl; ll.kl_scale = c.beta * inv_gb; ll.dlatl = m->dlatl;
+    SMX_CHECK(launch_lib_latent_bwd(m->st, ll));
+    const MlpLayer& lL = m->encl.back();
+    const TensorInfo& tw = m->tensors[m->t_latlW];
+    GemmArgs g;
+    g.A = lL.out_buf; g.lda = lL.out_p; g.a_kmajor = 1; g.B = m->dlatl; g.ldb = 32;
+    g.C = G_(m, m->t_latlW); g.ldc = tw.ld; g.M = lL.out_p; g.N = 32; g.K = ps.B; g.colsum = G_(m, m->t_latlb);
+    SMX_CHECK(launch_gemm(m->st, g));
+    GemmArgs h;
+    h.A = m->dlatl; h.lda = 32; h.B = P_(m, m->t_latlW); h.ldb = tw.ld; h.b_nmajor = 1;
+    h.C = m->slab; h.ldc = lL.out_p; h.slab_stride = (long)ps.B * lL.out_p;
+    h.M = ps.B; h.N = lL.out_p; h.K = 32;
+    SMX_CHECK(launch_gemm(m->st, h));
+    SMX_CHECK(mlp_backward(m, m->encl, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_encl_dw"));
+  }
+  return SMX_OK;
+}
+
+int optimizer_pass(smx_model* m) {
+  const smx_config& c = m->cfg;
+  if (m->world > 1) {
+    Timed t(m, "allreduce");
+    ncclResult_t r = g_rccl.AllReduce(m->grads, m->grads, m->grads_count, ncclFloat32, ncclSum, m->comm, m->st);
+    if (r != ncclSuccess) {
+      set_error(std::string("ncclAllReduce failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+      return SMX_ERR_COMM;
+    }
+    if (m->bn_total) {
+      hipLaunchKernelGGL(bn_moving_update_kernel, dim3((unsigned)((m->bn_total + 255) / 256)), dim3(256), 0, m->st,
+                         m->bn_moving, m->grads + m->tail_off_bn, (int)m->bn_total, 1.f / (float)m->world,
+                         c.bn_momentum);
+    }
+  }
+  AdamArgs a;
+  a.params = m->params; a.grads = m->grads; a.m = m->adam_m; a.v = m->adam_v;
+  a.chunks = m->chunks; a.n_chunks = m->n_chunks; a.partial = m->partial; a.tensor_norm = m->tensor_norm;
+  a.state = m->state; a.b1 = c.adam_beta1; a.b2 = c.adam_beta2; a.eps = c.adam_eps; a.clipnorm = c.clipnorm;
+  a.grad_scale = 1.f / (float)m->world;
+  Timed t(m, "adam");
+  SMX_CHECK(launch_adam(m->st, a));
+  return SMX_OK;
+}
+
+// the whole training step as a launch sequence on m->st (capturable)
+int train_sequence(smx_model* m, int B) {
+  Pass ps;
+  ps.B = B; ps.rows = m->rows; ps.Xsrc = m->X; ps.lib = m->library; ps.lgx1 = m->lgx1;
+  ps.cell_base = (uint32_t)m->cell_base; ps.training = 1; ps.sample = 0; ps.global_batch = B * m->world;
+  Timed t(m, "step");
+  SMX_CHECK(launch_step_begin(m->st, m->state, m->order, m->rows, B, m->cfg.lr, m->cfg.adam_beta1, m->cfg.adam_beta2));
+  SMX_CHECK(forward_pass(m, ps, true, true));
+  SMX_CHECK(backward_pass(m, ps));
+  SMX_CHECK(optimizer_pass(m));
+  return SMX_OK;
+}
+
+int read_metrics(smx_model* m, smx_metrics* out) {
+  if (!out) return SMX_OK;
+  float h[8];
+  std::vector<float> norms(m->tensors.size());
+  SMX_HIP(hipMemcpyAsync(h, m->grads + m->tail_off_metrics, sizeof(h), hipMemcpyDeviceToHost, m->st));
+  SMX_HIP(hipMemcpyAsync(norms.data(), m->tensor_norm, norms.size() * sizeof(float), hipMemcpyDeviceToHost, m->st));
+  SMX_HIP(hipStreamSynchronize(m->st));
+  out->loss = h[0]; out->nllk_x = h[1]; out->nllk_y = h[2]; out->kl = h[3]; out->kl_l = h[4];
+  float mx = 0.f;
+  for (float v : norms) mx = (v > mx || v != v) ? v : mx;
+  out->grad_norm_max = mx;
+  out->nan_flag = !(isfinite(h[0]) && isfinite(h[1]) && isfinite(h[3]) && isfinite(mx));
+  out->step = (int32_t)m->h_next;
+  return SMX_OK;
+}
+
+int upload_order(smx_model* m, const int32_t* order, size_t n) {
+  if (n > m->order_cap) {
+    if (m->order) hipFree(m->order);
+    m->order = nullptr;
+    m->order_cap = n * 2;
+    SMX_CHECK(dmalloc(&m->order, m->order_cap));
+  }
+  SMX_HIP(hipMemcpyAsync(m->order, order, n * sizeof(int32_t), hipMemcpyHostToDevice, m->st));
+  SMX_HIP(hipMemsetAsync(&m->state->cursor, 0, sizeof(uint32_t), m->st));
+  return SMX_OK;
+}
+
+int check_rows(smx_model* m, const int32_t* ids, size_t n) {
+  SMX_REQUIRE(m->X != nullptr, "no dataset uploaded (smx_dataset_upload)");
+  for (size_t i = 0; i < n; ++i)
+    if (ids[i] < 0 || (int64_t)ids[i] >= m->N) { set_error("row id out of range"); return SMX_ERR_INVALID; }
+  return SMX_OK;
+}
+
+int launch_train(smx_model* m, int B, bool use_graph) {
+  if (use_graph && m->world == 1 && !m->use_injected && m->timing_label.empty()) {
+    auto it = m->graphs.find(B);
+    if (it == m->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      SMX_HIP(hipStreamBeginCapture(m->st, hipStreamCaptureModeThreadLocal));
+      m->capturing = true;
+      int rc = train_sequence(m, B);
+      m->capturing = false;
+      hipError_t e = hipStreamEndCapture(m->st, &graph);
+      if (rc != SMX_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+      if (e != hipSuccess) { set_error(std::string("graph capture failed: ") + hipGetErrorString(e)); return SMX_ERR_HIP; }
+      hipGraphExec_t exec = nullptr;
+      SMX_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      hipGraphDestroy(graph);
+      it = m->graphs.emplace(B, exec).first;
+    }
+    SMX_HIP(hipGraphLaunch(it->second, m->st));
+  } else {
+    SMX_CHECK(train_sequence(m, B));
+  }
+  m->h_next += 1;
+  return SMX_OK;
+}
+
+// pack logical host tensor <-> padded internal layout
+void pack(const TensorInfo& t, const float* host, std::vector<float>& dev) {
+  dev.assign(t.count, 0.f);
+  for (int r = 0; r < t.rows; ++r)
+    for (int ch = 0; ch < t.chunks; ++ch)
+      memcpy(&dev[(size_t)r * t.ld + (size_t)ch * t.chunk_wp], host + (size_t)r * t.cols + (size_t)ch * t.chunk_w,
+             sizeof(float) * t.chunk_w);
+}
+void unpack(const TensorInfo& t, const std::vector<float>& dev, float* host, float scale) {
+  for (int r = 0; r < t.rows; ++r)
+    for (int ch = 0; ch < t.chunks; ++ch)
+      for (int j = 0; j < t.chunk_w; ++j)
+        host[(size_t)r * t.cols + (size_t)ch * t.chunk_w + j] = dev[(size_t)r * t.ld + (size_t)ch * t.chunk_wp + j] * scale;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C-ABI
+// ===========================================================================
+extern "C" {
+
+const char* smx_last_error(void) { return g_err.c_str(); }
+int smx_abi_version(void) { return SMX_ABI_VERSION; }
+
+int smx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int smx_init(int device) {
+  int n = smx_device_count();
+  if (device < 0 || device >= n) {
+    set_error("smx_init: no such HIP device (" + std::to_string(device) + " of " + std::to_string(n) + ")");
+    return SMX_ERR_INVALID;
+  }
+  SMX_HIP(hipSetDevice(device));
+  return SMX_OK;
+}
+
+int smx_synchronize(void) {
+  SMX_HIP(hipDeviceSynchronize());
+  return SMX_OK;
+}
+
+int smx_model_create(const smx_config* cfg, smx_model** out) {
+  SMX_REQUIRE(cfg && out, "null argument");
+  SMX_REQUIRE(cfg->abi_version == SMX_ABI_VERSION, "smx_config.abi_version mismatch");
+  SMX_REQUIRE(cfg->n_genes > 0 && cfg->latent_dim > 0 && cfg->max_batch > 0, "n_genes, latent_dim, max_batch must be > 0");
+  SMX_REQUIRE(cfg->n_enc >= 1 && cfg->n_enc <= SMX_MAX_LAYERS && cfg->n_dec >= 1 && cfg->n_dec <= SMX_MAX_LAYERS,
+              "encoder/decoder need 1..8 layers");
+  SMX_REQUIRE(cfg->model >= SMX_MODEL_VAE && cfg->model <= SMX_MODEL_SISUA, "unknown model kind");
+  SMX_REQUIRE(cfg->likelihood >= SMX_LLK_NB && cfg->likelihood <= SMX_LLK_ZINBD, "unknown likelihood");
+  SMX_REQUIRE(cfg->n_labels >= 0 && cfg->n_labels <= SMX_MAX_LABELS, "too many label heads");
+  SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->n_labels == 0, "label heads need model = SISUA");
+  if (cfg->model == SMX_MODEL_SCVI) {
+    SMX_REQUIRE(cfg->likelihood == SMX_LLK_NBD || cfg->likelihood == SMX_LLK_ZINBD, "scvi supports nbd / zinbd only");
+    SMX_REQUIRE(cfg->n_encl >= 1 && cfg->n_encl <= SMX_MAX_LAYERS, "scvi needs a library encoder");
+  }
+  SMX_REQUIRE(cfg->dropout_enc >= 0 && cfg->dropout_enc < 1 && cfg->dropout_dec >= 0 && cfg->dropout_dec < 1 &&
+                  cfg->input_dropout >= 0 && cfg->input_dropout < 1, "dropout rates must be in [0,1)");
+  int dev = 0;
+  SMX_HIP(hipGetDevice(&dev));
+  smx_model* m = new smx_model();
+  m->cfg = *cfg; m->device = dev;
+  m->G = cfg->n_genes; m->Gp = round_up(m->G, 32); m->D = cfg->latent_dim; m->Dp = round_up(m->D, 32);
+  m->k = (cfg->likelihood == SMX_LLK_ZINB || cfg->likelihood == SMX_LLK_ZINBD) ? 3 : 2;
+  m->stochastic = cfg->model != SMX_MODEL_DCA; m->scvi = cfg->model == SMX_MODEL_SCVI;
+  m->Bmax = cfg->max_batch;
+  int rc = SMX_OK;
+  auto fail = [&](int code) { smx_model_destroy(m); return code; };
+  if (hipStreamCreate(&m->st) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(SMX_ERR_HIP); }
+  // ---- manifest (same order as oracle/sisua_oracle.py:manifest) ----
+  int h = build_mlp(m, m->enc, "enc", m->G, cfg->n_enc, cfg->enc_units, ST_ENC_DROPOUT, cfg->dropout_enc);
+  m->t_latW = add_tensor(m, "lat/W", h, (m->stochastic ? 2 : 1) * m->D, m->stochastic ? 2 : 1, false);
+  m->t_latb = add_tensor(m, "lat/b", 1, (m->stochastic ? 2 : 1) * m->D, m->stochastic ? 2 : 1, true);
+  if (m->scvi) {
+    int hl = build_mlp(m, m->encl, "encl", m->G, cfg->n_encl, cfg->encl_units, ST_ENCL_DROPOUT, cfg->dropout_enc);
+    m->t_latlW = add_tensor(m, "latl/W", hl, 2, 1, false);
+    m->t_latlb = add_tensor(m, "latl/b", 1, 2, 1, true);
+  }
+  int hd = build_mlp(m, m->dec, "dec", m->D, cfg->n_dec, cfg->dec_units, ST_DEC_DROPOUT, cfg->dropout_dec);
+  if (m->scvi) {
+    for (int ch = 0; ch < m->k; ++ch) {
+      m->t_outW[ch] = add_tensor(m, "out" + std::to_string(ch) + "/W", hd, m->G, 1, false);
+      m->t_outb[ch] = add_tensor(m, "out" + std::to_string(ch) + "/b", 1, m->G, 1, true);
+    }
+  } else {
+    m->t_outW[0] = add_tensor(m, "out/W", hd, m->k * m->G, m->k, false);
+    m->t_outb[0] = add_tensor(m, "out/b", 1, m->k * m->G, m->k, true);
+  }
+  for (int j = 0; j < cfg->n_labels; ++j) {
+    SMX_REQUIRE(cfg->label_dim[j] > 0, "label_dim must be > 0");
+    m->lab_ky[j] = cfg->label_llk[j] == SMX_LABEL_NB ? 2 : 1;
+    m->lab_Pp[j] = round_up(cfg->label_dim[j], 32);
+    m->t_labW[j] = add_tensor(m, "lab" + std::to_string(j) + "/W", hd, m->lab_ky[j] * cfg->label_dim[j], m->lab_ky[j], false);
+    m->t_labb[j] = add_tensor(m, "lab" + std::to_string(j) + "/b", 1, m->lab_ky[j] * cfg->label_dim[j], m->lab_ky[j], true);
+  }
+  // ---- flat buffers ----
+  size_t off = 0;
+  for (size_t i = 0; i < m->bn_w.size(); ++i) { m->bn_off.push_back(off); off += 2 * (size_t)m->bn_wp[i]; }
+  m->bn_total = off;
+  m->tail_off_bn = m->flat_count;
+  m->tail_off_metrics = m->tail_off_bn + (m->bn_total + 63) / 64 * 64;
+  m->grads_count = m->tail_off_metrics + 64;
+  if ((rc = dmalloc(&m->params, m->flat_count))) return fail(rc);
+  if ((rc = dmalloc(&m->grads, m->grads_count))) return fail(rc);
+  if ((rc = dmalloc(&m->adam_m, m->flat_count))) return fail(rc);
+  if ((rc = dmalloc(&m->adam_v, m->flat_count))) return fail(rc);
+  if ((rc = dmalloc(&m->bn_moving, m->bn_total))) return fail(rc);
+  {  // moving variance starts at 1 (Keras)
+    std::vector<float> init(m->bn_total, 0.f);
+    for (size_t i = 0; i < m->bn_w.size(); ++i)
+      for (int j = 0; j < m->bn_wp[i]; ++j) init[m->bn_off[i] + m->bn_wp[i] + j] = 1.f;
+    if (m->bn_total && hipMemcpy(m->bn_moving, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("bn init copy failed"); return fail(SMX_ERR_HIP);
+    }
+  }
+  // ---- activations ----
+  const size_t B = m->Bmax;
+  m->max_feat_p = m->Dp;
+  auto alloc_mlp = [&](std::vector<MlpLayer>& mlp) {
+    for (auto& L : mlp) {
+      if (L.out_p > m->max_feat_p) m->max_feat_p = L.out_p;
+      if ((rc = dmalloc(&L.xhat, B * L.out_p))) return rc;
+      if ((rc = dmalloc(&L.out_buf, B * L.out_p))) return rc;
+      if ((rc = dmalloc(&L.dpre, B * L.out_p))) return rc;
+      if ((rc = dmalloc(&L.inv_std, (size_t)L.out_p))) return rc;
+    }
+    return (int)SMX_OK;
+  };
+  if ((rc = alloc_mlp(m->enc)) || (rc = alloc_mlp(m->encl)) || (rc = alloc_mlp(m->dec))) return fail(rc);
+  m->slab_cap = (size_t)(16 * 3 + SMX_MAX_LABELS + 1) * B * m->max_feat_p;
+  const size_t lat_ld = (m->stochastic ? 2 : 1) * (size_t)m->Dp;
+  const size_t ldp = (size_t)m->k * m->Gp;
+  if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
+      (rc = dmalloc(&m->z, B * m->Dp)) || (rc = dmalloc(&m->sig, B * m->Dp)) || (rc = dmalloc(&m->eps, B * m->Dp)) ||
+      (rc = dmalloc(&m->kl, B)) || (rc = dmalloc(&m->P, B * ldp)) || (rc = dmalloc(&m->dP, B * ldp)) ||
+      (rc = dmalloc(&m->llk_part, B * loss_chunks(m->Gp))) || (rc = dmalloc(&m->llk_y, B)) ||
+      (rc = dmalloc(&m->rows, B)) || (rc = dmalloc(&m->state, (size_t)1)) ||
+      (rc = dmalloc(&m->hostX, B * m->Gp)) || (rc = dmalloc(&m->hostLib, B * 2)) || (rc = dmalloc(&m->hostLgx1, B)))
+    return fail(rc);
+  if (m->scvi) {
+    if ((rc = dmalloc(&m->raw, B * ldp)) || (rc = dmalloc(&m->draw, B * ldp)) || (rc = dmalloc(&m->rho, B * m->Gp)) ||
+        (rc = dmalloc(&m->latlbuf, B * 32)) || (rc = dmalloc(&m->dlatl, B * 32)) || (rc = dmalloc(&m->lsmp, B)) ||
+        (rc = dmalloc(&m->lsig, B)) || (rc = dmalloc(&m->leps, B)) || (rc = dmalloc(&m->kl_l, B)) || (rc = dmalloc(&m->dl, B)))
+      return fail(rc);
+  }
+  for (int j = 0; j < cfg->n_labels; ++j) {
+    const size_t ld = m->tensors[m->t_labW[j]].ld;
+    if ((rc = dmalloc(&m->laby_raw[j], B * ld)) || (rc = dmalloc(&m->laby_draw[j], B * ld))) return fail(rc);
+  }
+  // ---- optimiser chunk table ----
+  std::vector<OptChunk> chunks;
+  const int CH = 4096;
+  for (size_t t = 0; t < m->tensors.size(); ++t) {
+    const TensorInfo& ti = m->tensors[t];
+    const int first = (int)chunks.size();
+    const int n = (int)((ti.count + CH - 1) / CH);
+    for (int i = 0; i < n; ++i) {
+      OptChunk c;
+      memset(&c, 0, sizeof(c));
+      c.tensor = (int)t; c.offset = (int)(ti.offset + (size_t)i * CH);
+      c.count = (int)((size_t)(i + 1) * CH <= ti.count ? CH : ti.count - (size_t)i * CH);
+      c.first_chunk = first; c.n_chunks = n;
+      chunks.push_back(c);
+    }
+  }
+  m->n_chunks = (int)chunks.size();
+  if ((rc = dmalloc(&m->chunks, chunks.size())) || (rc = dmalloc(&m->partial, chunks.size())) ||
+      (rc = dmalloc(&m->tensor_norm, m->tensors.size())))
+    return fail(rc);
+  if (hipMemcpy(m->chunks, chunks.data(), chunks.size() * sizeof(OptChunk), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("chunk table copy failed"); return fail(SMX_ERR_HIP);
+  }
+  *out = m;
+  return SMX_OK;
+}
+
+int smx_model_destroy(smx_model* m) {
+  if (!m) return SMX_OK;
+  if (m->st) hipStreamSynchronize(m->st);
+  for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
+  for (auto& ev : m->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+  if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
+  auto fr = [](void* p) { if (p) hipFree(p); };
+  fr(m->params); fr(m->grads); fr(m->adam_m); fr(m->adam_v); fr(m->bn_moving);
+  for (auto* mlp : {&m->enc, &m->encl, &m->dec})
+    for (auto& L : *mlp) { fr(L.xhat); fr(L.out_buf); fr(L.dpre); fr(L.inv_std); }
+  fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1); fr(m->hostX); fr(m->hostLib); fr(m->hostLgx1);
+  for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); fr(m->laby_raw[j]); fr(m->laby_draw[j]); }
+  fr(m->rows); fr(m->order); fr(m->state);
+  fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);
+  fr(m->latlbuf); fr(m->dlatl); fr(m->lsmp); fr(m->lsig); fr(m->leps); fr(m->kl_l); fr(m->dl);
+  fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);
+  fr(m->chunks); fr(m->partial); fr(m->tensor_norm);
+  for (auto& kv : m->injected) fr(kv.second.d);
+  if (m->st) hipStreamDestroy(m->st);
+  delete m;
+  return SMX_OK;
+}
+
+int smx_num_tensors(const smx_model* m) { return m ? (int)m->tensors.size() : 0; }
+
+int smx_tensor_info(const smx_model* m, int index, char* name, int name_cap, int32_t* rows, int32_t* cols) {
+  SMX_REQUIRE(m && index >= 0 && index < (int)m->tensors.size(), "tensor index out of range");
+  const TensorInfo& t = m->tensors[index];
+  if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (rows) *rows = t.rows;
+  if (cols) *cols = t.cols;
+  return SMX_OK;
+}
+
+static float* which_buf(smx_model* m, int which) {
+  switch (which) { case 0: return m->params; case 1: return m->grads; case 2: return m->adam_m; case 3: return m->adam_v; }
+  return nullptr;
+}
+
+int smx_get_tensor(smx_model* m, int which, int index, float* host) {
+  SMX_REQUIRE(m && host && index >= 0 && index < (int)m->tensors.size(), "bad tensor index");
+  float* base = which_buf(m, which);
+  SMX_REQUIRE(base, "which must be 0..3");
+  const TensorInfo& t = m->tensors[index];
+  std::vector<float> dev(t.count);
+  SMX_HIP(hipStreamSynchronize(m->st));
+  SMX_HIP(hipMemcpy(dev.data(), base + t.offset, t.count * sizeof(float), hipMemcpyDeviceToHost));
+  unpack(t, dev, host, which == 1 ? 1.f / (float)m->world : 1.f);
+  return SMX_OK;
+}
+
+int smx_set_tensor(smx_model* m, int which, int index, const float* host) {
+  SMX_REQUIRE(m && host && index >= 0 && index < (int)m->tensors.size(), "bad tensor index");
+  float* base = which_buf(m, which);
+  SMX_REQUIRE(base, "which must be 0..3");
+  const TensorInfo& t = m->tensors[index];
+  std::vector<float> dev;
+  pack(t, host, dev);
+  SMX_HIP(hipStreamSynchronize(m->st));
+  SMX_HIP(hipMemcpy(base + t.offset, dev.data(), t.count * sizeof(float), hipMemcpyHostToDevice));
+  return SMX_OK;
+}
+
+int smx_num_bn_layers(const smx_model* m) { return m ? (int)m->bn_w.size() : 0; }
+
+int smx_get_bn(smx_model* m, int layer, int which, float* host, int32_t* width) {
+  SMX_REQUIRE(m && layer >= 0 && layer < (int)m->bn_w.size() && (which == 0 || which == 1), "bad bn layer");
+  if (width) *width = m->bn_w[layer];
+  if (host) {
+    SMX_HIP(hipStreamSynchronize(m->st));
+    SMX_HIP(hipMemcpy(host, m->bn_moving + m->bn_off[layer] + (size_t)which * m->bn_wp[layer],
+                      m->bn_w[layer] * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  return SMX_OK;
+}
+
+int smx_set_bn(smx_model* m, int layer, int which, const float* host) {
+  SMX_REQUIRE(m && host && layer >= 0 && layer < (int)m->bn_w.size() && (which == 0 || which == 1), "bad bn layer");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  SMX_HIP(hipMemcpy(m->bn_moving + m->bn_off[layer] + (size_t)which * m->bn_wp[layer], host,
+                    m->bn_w[layer] * sizeof(float), hipMemcpyHostToDevice));
+  return SMX_OK;
+}
+
+int smx_get_step(const smx_model* m, int32_t* step) {
+  SMX_REQUIRE(m && step, "null argument");
+  *step = (int32_t)m->h_next;
+  return SMX_OK;
+}
+
+int smx_set_step(smx_model* m, int32_t step) {
+  SMX_REQUIRE(m && step >= 0, "bad step");
+  StepState s;
+  memset(&s, 0, sizeof(s));
+  s.next = (uint32_t)step; s.step = step > 0 ? (uint32_t)step - 1 : 0;
+  SMX_HIP(hipStreamSynchronize(m->st));
+  SMX_HIP(hipMemcpy(m->state, &s, sizeof(s), hipMemcpyHostToDevice));
+  m->h_next = (uint32_t)step;
+  return SMX_OK;
+}
+
+int smx_dataset_upload(smx_model* m, const float* X, int64_t n_cells, const float* const* labels, const float* library,
+                       const uint8_t* label_mask, int64_t cell_id_base) {
+  SMX_REQUIRE(m && X && n_cells > 0, "bad dataset");
+  SMX_REQUIRE(n_cells < (int64_t)1 << 31, "row ids are int32");
+  SMX_REQUIRE(!m->scvi || library, "scvi needs the library prior (scvi.py:100-105)");
+  for (int j = 0; j < m->cfg.n_labels; ++j) SMX_REQUIRE(labels && labels[j], "missing label matrix");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  auto fr = [](void* p) { if (p) hipFree(p); };
+  fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1);
+  m->X = nullptr; m->library = nullptr; m->mask = nullptr; m->lgx1 = nullptr;
+  for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); m->Y[j] = nullptr; }
+  m->N = n_cells; m->cell_base = cell_id_base;
+  int rc;
+  if ((rc = dmalloc(&m->X, (size_t)n_cells * m->Gp)) || (rc = dmalloc(&m->lgx1, (size_t)n_cells))) return rc;
+  SMX_HIP(hipMemcpy2D(m->X, (size_t)m->Gp * sizeof(float), X, (size_t)m->G * sizeof(float), (size_t)m->G * sizeof(float),
+                      (size_t)n_cells, hipMemcpyHostToDevice));
+  std::vector<float> lg((size_t)n_cells);
+  for (int64_t i = 0; i < n_cells; ++i) {
+    double s = 0.0;
+    const float* row = X + (size_t)i * m->G;
+    for (int g = 0; g < m->G; ++g) if (row[g] > 0.f) s += lgamma((double)row[g] + 1.0);
+    lg[(size_t)i] = (float)s;
+  }
+  SMX_HIP(hipMemcpy(m->lgx1, lg.data(), lg.size() * sizeof(float), hipMemcpyHostToDevice));
+  for (int j = 0; j < m->cfg.n_labels; ++j) {
+    const int P = m->cfg.label_dim[j], Pp = m->lab_Pp[j];
+    if ((rc = dmalloc(&m->Y[j], (size_t)n_cells * Pp))) return rc;
+    SMX_HIP(hipMemcpy2D(m->Y[j], (size_t)Pp * sizeof(float), labels[j], (size_t)P * sizeof(float), (size_t)P * sizeof(float),
+                        (size_t)n_cells, hipMemcpyHostToDevice));
+  }
+  if (library) {
+    if ((rc = dmalloc(&m->library, (size_t)n_cells * 2))) return rc;
+    SMX_HIP(hipMemcpy(m->library, library, (size_t)n_cells * 2 * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (label_mask) {
+    if ((rc = dmalloc(&m->mask, (size_t)n_cells))) return rc;
+    SMX_HIP(hipMemcpy(m->mask, label_mask, (size_t)n_cells, hipMemcpyHostToDevice));
+  }
+  return SMX_OK;
+}
+
+int64_t smx_dataset_size(const smx_model* m) { return m ? m->N : 0; }
+
+int smx_train_step(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out) {
+  return smx_train_steps(m, row_ids, 1, batch, 0, out);
+}
+int smx_train_step_graph(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out) {
+  return smx_train_steps(m, row_ids, 1, batch, 1, out);
+}
+
+int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t batch, int use_graph, smx_metrics* out) {
+  SMX_REQUIRE(m && order && n_steps > 0, "bad arguments");
+  SMX_REQUIRE(batch > 0 && batch <= m->Bmax, "batch must be in 1..max_batch");
+  SMX_CHECK(check_rows(m, order, (size_t)n_steps * batch));
+  SMX_CHECK(upload_order(m, order, (size_t)n_steps * batch));
+  for (int s = 0; s < n_steps; ++s) SMX_CHECK(launch_train(m, batch, use_graph != 0));
+  if (m->use_injected) { m->use_injected = false; }
+  SMX_CHECK(read_metrics(m, out));
+  if (out && out->nan_flag) { set_error("non-finite loss or gradient norm"); return SMX_ERR_NAN; }
+  return SMX_OK;
+}
+
+static int setup_pass(smx_model* m, Pass& ps, const int32_t* row_ids, const float* host_x, const float* host_library,
+                      int32_t batch, int training, int sample) {
+  SMX_REQUIRE(batch > 0 && batch <= m->Bmax, "batch must be in 1..max_batch");
+  ps.B = batch; ps.training = training; ps.sample = sample; ps.global_batch = batch;
+  if (row_ids) {
+    SMX_CHECK(check_rows(m, row_ids, (size_t)batch));
+    SMX_HIP(hipMemcpyAsync(m->rows, row_ids, (size_t)batch * sizeof(int32_t), hipMemcpyHostToDevice, m->st));
+    ps.rows = m->rows; ps.Xsrc = m->X; ps.lib = m->library; ps.lgx1 = m->lgx1; ps.cell_base = (uint32_t)m->cell_base;
+  } else {
+    SMX_REQUIRE(host_x, "need row_ids or host_x");
+    SMX_REQUIRE(!m->scvi || host_library, "scvi needs host_library with host_x");
+    SMX_HIP(hipMemsetAsync(m->hostX, 0, (size_t)batch * m->Gp * sizeof(float), m->st));
+    SMX_HIP(hipMemcpy2DAsync(m->hostX, (size_t)m->Gp * sizeof(float), host_x, (size_t)m->G * sizeof(float),
+                             (size_t)m->G * sizeof(float), (size_t)batch, hipMemcpyHostToDevice, m->st));
+    std::vector<float> lg((size_t)batch);
+    for (int i = 0; i < batch; ++i) {
+      double s = 0.0;
+      for (int g = 0; g < m->G; ++g) { const float v = host_x[(size_t)i * m->G + g]; if (v > 0.f) s += lgamma((double)v + 1.0); }
+      lg[(size_t)i] = (float)s;
+    }
+    SMX_HIP(hipMemcpy(m->hostLgx1, lg.data(), lg.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (host_library) SMX_HIP(hipMemcpy(m->hostLib, host_library, (size_t)batch * 2 * sizeof(float), hipMemcpyHostToDevice));
+    ps.rows = nullptr; ps.Xsrc = m->hostX; ps.lib = m->hostLib; ps.lgx1 = m->hostLgx1; ps.cell_base = 0;
+  }
+  return SMX_OK;
+}
+
+int smx_eval_step(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out) {
+  SMX_REQUIRE(m && row_ids, "bad arguments");
+  Pass ps;
+  SMX_CHECK(setup_pass(m, ps, row_ids, nullptr, nullptr, batch, 0, 0));
+  SMX_CHECK(forward_pass(m, ps, true, false));
+  SMX_CHECK(read_metrics(m, out));
+  return SMX_OK;
+}
+
+int smx_forward(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,
+                int32_t sample_index, int32_t training, float* z_mean, float* z_scale, float* z_sample, float* l_mean,
+                float* l_scale, float* l_sample, float* x_params, float* const* y_params) {
+  SMX_REQUIRE(m, "null model");
+  Pass ps;
+  SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, training, sample_index));
+  SMX_REQUIRE(!(training && !row_ids), "training-mode forward needs resident rows");
+  SMX_CHECK(forward_pass(m, ps, false, false));
+  SMX_HIP(hipStreamSynchronize(m->st));
+  const int B = batch, D = m->D, Dp = m->Dp, G = m->G, Gp = m->Gp;
+  const int lat_ld = m->stochastic ? 2 * Dp : Dp;
+  std::vector<float> tmp;
+  auto fetch2d = [&](float* dst, const float* src, int ld, int w) -> int {
+    if (!dst) return SMX_OK;
+    SMX_HIP(hipMemcpy2D(dst, (size_t)w * sizeof(float), src, (size_t)ld * sizeof(float), (size_t)w * sizeof(float), (size_t)B,
+                        hipMemcpyDeviceToHost));
+    return SMX_OK;
+  };
+  SMX_CHECK(fetch2d(z_mean, m->latbuf, lat_ld, D));
+  if (m->stochastic) SMX_CHECK(fetch2d(z_scale, m->sig, Dp, D));
+  SMX_CHECK(fetch2d(z_sample, m->z, Dp, D));
+  if (m->scvi) {
+    SMX_CHECK(fetch2d(l_mean, m->latlbuf, 32, 1));
+    SMX_CHECK(fetch2d(l_scale, m->lsig, 1, 1));
+    SMX_CHECK(fetch2d(l_sample, m->lsmp, 1, 1));
+  }
+  if (x_params) {
+    for (int ch = 0; ch < m->k; ++ch)
+      SMX_CHECK(fetch2d(x_params + (size_t)ch * B * G, m->P + (size_t)ch * Gp, m->k * Gp, G));
+  }
+  if (y_params) {
+    for (int j = 0; j < m->cfg.n_labels; ++j) {
+      if (!y_params[j]) continue;
+      const int P = m->cfg.label_dim[j], Pp = m->lab_Pp[j], ld = m->tensors[m->t_labW[j]].ld;
+      tmp.resize((size_t)B * ld);
+      SMX_HIP(hipMemcpy(tmp.data(), m->laby_raw[j], tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+      for (int b = 0; b < B; ++b)
+        for (int c = 0; c < m->lab_ky[j]; ++c)
+          memcpy(y_params[j] + ((size_t)b * m->lab_ky[j] + c) * P, &tmp[(size_t)b * ld + (size_t)c * Pp], sizeof(float) * P);
+    }
+  }
+  return SMX_OK;
+}
+
+int smx_set_noise(smx_model* m, int32_t stream, const float* data, int32_t batch, int32_t width) {
+  SMX_REQUIRE(m && data && batch > 0 && batch <= m->Bmax && width > 0, "bad noise block");
+  const int ld = round_up(width, 32);
+  Injected& ij = m->injected[stream];
+  if (ij.d && ij.ld != ld) { hipFree(ij.d); ij.d = nullptr; }
+  if (!ij.d) { SMX_CHECK(dmalloc(&ij.d, (size_t)m->Bmax * ld)); ij.ld = ld; }
+  SMX_HIP(hipStreamSynchronize(m->st));
+  SMX_HIP(hipMemset(ij.d, 0, (size_t)m->Bmax * ld * sizeof(float)));
+  SMX_HIP(hipMemcpy2D(ij.d, (size_t)ld * sizeof(float), data, (size_t)width * sizeof(float), (size_t)width * sizeof(float),
+                      (size_t)batch, hipMemcpyHostToDevice));
+  m->use_injected = true;
+  return SMX_OK;
+}
+
+int smx_clear_noise(smx_model* m) {
+  SMX_REQUIRE(m, "null model");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  for (auto& kv : m->injected) if (kv.second.d) hipFree(kv.second.d);
+  m->injected.clear();
+  m->use_injected = false;
+  return SMX_OK;
+}
+
+int smx_comm_unique_id(uint8_t id[128]) {
+  SMX_CHECK(load_rccl());
+  ncclUniqueId uid;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclResult_t r = g_rccl.GetUniqueId(&uid);
+  if (r != ncclSuccess) { set_error("ncclGetUniqueId failed"); return SMX_ERR_COMM; }
+  memcpy(id, &uid, 128);
+  return SMX_OK;
+}
+
+int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]) {
+  SMX_REQUIRE(m && world >= 1 && rank >= 0 && rank < world, "bad rank/world");
+  SMX_CHECK(load_rccl());
+  ncclUniqueId uid;
+  memcpy(&uid, id, 128);
+  ncclResult_t r = g_rccl.CommInitRank(&m->comm, world, uid, rank);
+  if (r != ncclSuccess) {
+    set_error(std::string("ncclCommInitRank failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    return SMX_ERR_COMM;
+  }
+  m->rank = rank; m->world = world;
+  for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
+  m->graphs.clear();
+  return SMX_OK;
+}
+
+int smx_comm_world(const smx_model* m) { return m ? m->world : 0; }
+
+int smx_timing_enable(smx_model* m, const char* kernel) {
+  SMX_REQUIRE(m, "null model");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  m->timing_label = kernel ? kernel : "";
+  m->timing_used = 0;
+  return SMX_OK;
+}
+
+int smx_timing_read(smx_model* m, double* total_ms, int64_t* launches) {
+  SMX_REQUIRE(m && total_ms && launches, "null argument");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  double tot = 0.0;
+  for (size_t i = 0; i < m->timing_used; ++i) {
+    float ms = 0.f;
+    SMX_HIP(hipEventElapsedTime(&ms, m->timing_events[i].first, m->timing_events[i].second));
+    tot += ms;
+  }
+  *total_ms = tot; *launches = (int64_t)m->timing_used;
+  m->timing_used = 0;
+  return SMX_OK;
+}
+
+int64_t smx_loss_bytes_per_cell(const smx_model* m) {
+  if (!m) return 0;
+  return (int64_t)(4 + 8 * m->k) * m->G + 16 * (int64_t)m->D + 4;
+}
+
+// ---- kernel-level entry points ------------------------------------------------
+int smx_k_count_llk(int likelihood, int direct, const float* x, const float* planes, int32_t B, int32_t G, float* llk,
+                    float* grads) {
+  SMX_REQUIRE(x && planes && llk && B > 0 && G > 0, "bad arguments");
+  const int k = (likelihood == SMX_LLK_ZINB || likelihood == SMX_LLK_ZINBD) ? 3 : 2;
+  const int Gp = round_up(G, 32);
+  const int nch = loss_chunks(Gp);
+  float *dX = nullptr, *dPl = nullptr, *dG = nullptr, *dPart = nullptr;
+  int rc;
+  if ((rc = dmalloc(&dX, (size_t)B * Gp)) || (rc = dmalloc(&dPl, (size_t)B * k * Gp)) || (rc = dmalloc(&dG, (size_t)B * k * Gp)) ||
+      (rc = dmalloc(&dPart, (size_t)B * nch)))
+    return rc;
+  SMX_HIP(hipMemcpy2D(dX, (size_t)Gp * 4, x, (size_t)G * 4, (size_t)G * 4, (size_t)B, hipMemcpyHostToDevice));
+  for (int c = 0; c < k; ++c)
+    SMX_HIP(hipMemcpy2D(dPl + (size_t)c * Gp, (size_t)k * Gp * 4, planes + (size_t)c * B * G, (size_t)G * 4, (size_t)G * 4,
+                        (size_t)B, hipMemcpyHostToDevice));
+  LossArgs lo;
+  lo.likelihood = likelihood; lo.direct = direct; lo.backward = grads != nullptr;
+  lo.X = dX; lo.ldx = Gp; lo.P = dPl; lo.ldp = (long)k * Gp; lo.plane_stride = Gp; lo.dP = dG; lo.llk_part = dPart;
+  lo.B = B; lo.G = G; lo.Gp = Gp; lo.grad_scale = 1.f;
+  rc = launch_count_loss(nullptr, lo);
+  if (rc == SMX_OK) {
+    std::vector<float> part((size_t)B * nch);
+    SMX_HIP(hipDeviceSynchronize());
+    SMX_HIP(hipMemcpy(part.data(), dPart, part.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) {
+      double s = 0.0;
+      for (int c = 0; c < nch; ++c) s += part[(size_t)b * nch + c];
+      for (int g = 0; g < G; ++g) { const float v = x[(size_t)b * G + g]; if (v > 0.f) s -= lgamma((double)v + 1.0); }
+      llk[b] = (float)s;
+    }
+    if (grads)
+      for (int c = 0; c < k; ++c)
+        SMX_HIP(hipMemcpy2D(grads + (size_t)c * B * G, (size_t)G * 4, dG + (size_t)c * Gp, (size_t)k * Gp * 4, (size_t)G * 4,
+                            (size_t)B, hipMemcpyDeviceToHost));
+  }
+  hipFree(dX); hipFree(dPl); hipFree(dG); hipFree(dPart);
+  return rc;
+}
+
+int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M, int32_t N, int32_t K, int32_t split_k,
+               int32_t tile_cfg, float* C) {
+  SMX_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "bad arguments");
+  // pad to the library's internal conventions: feature axes to 32, batch axes free
+  const int Np = round_up(N, 32);
+  const int Kp = round_up(K, 4), Mp = round_up(M, 4);
+  const int lda = transA ? Mp : Kp, a_rows = transA ? K : M, a_cols = transA ? M : K;
+  const int ldb = transB ? Kp : Np, b_rows = transB ? N : K, b_cols = transB ? K : N;
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  int rc;
+  const int S = split_k < 1 ? 1 : split_k;
+  if ((rc = dmalloc(&dA, (size_t)a_rows * lda)) || (rc = dmalloc(&dB, (size_t)round_up(b_rows, 32) * ldb)) ||
+      (rc = dmalloc(&dC, (size_t)S * M * Np)))
+    return rc;
+  SMX_HIP(hipMemcpy2D(dA, (size_t)lda * 4, A, (size_t)a_cols * 4, (size_t)a_cols * 4, (size_t)a_rows, hipMemcpyHostToDevice));
+  SMX_HIP(hipMemcpy2D(dB, (size_t)ldb * 4, B, (size_t)b_cols * 4, (size_t)b_cols * 4, (size_t)b_rows, hipMemcpyHostToDevice));
+  GemmArgs g;
+  g.A = dA; g.lda = lda; g.a_kmajor = transA; g.B = dB; g.ldb = ldb; g.b_nmajor = transB;
+  g.C = dC; g.ldc = Np; g.slab_stride = (long)M * Np; g.M = transA ? Mp : M; g.N = Np; g.K = (transA) ? K : Kp;
+  if (transA) g.M = Mp;
+  g.split_k = S; g.tile = tile_cfg;
+  int eff = 1;
+  // rows of C beyond M (when M was padded for k-major A) are never stored: allocate for Mp
+  if (transA && Mp != M) { hipFree(dC); dC = nullptr; if ((rc = dmalloc(&dC, (size_t)S * Mp * Np))) return rc; g.C = dC; g.slab_stride = (long)Mp * Np; }
+  rc = launch_gemm(nullptr, g, &eff);
+  if (rc == SMX_OK) {
+    SMX_HIP(hipDeviceSynchronize());
+    const int rowsC = transA ? Mp : M;
+    std::vector<float> h((size_t)eff * rowsC * Np);
+    SMX_HIP(hipMemcpy(h.data(), dC, h.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < M; ++i)
+      for (int j = 0; j < N; ++j) {
+        float s = 0.f;
+        for (int z = 0; z < eff; ++z) s += h[((size_t)z * rowsC + i) * Np + j];
+        C[(size_t)i * N + j] = s;
+      }
+  }
+  hipFree(dA); hipFree(dB); hipFree(dC);
+  return rc;
+}
+
+int smx_k_noise(uint64_t seed, int32_t stream, int32_t step, int32_t sample, const int64_t* cell_ids, int32_t B, int32_t width,
+                float dropout_p, float* dropout_mult, float* normal) {
+  SMX_REQUIRE(cell_ids && B > 0 && width > 0, "bad arguments");
+  int64_t* dIds = nullptr; float *dM = nullptr, *dN = nullptr;
+  int rc;
+  if ((rc = dmalloc(&dIds, (size_t)B)) || (rc = dmalloc(&dM, (size_t)B * width)) || (rc = dmalloc(&dN, (size_t)B * width))) return rc;
+  SMX_HIP(hipMemcpy(dIds, cell_ids, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice));
+  NoiseKey nk;
+  nk.k0 = (uint32_t)(seed & 0xFFFFFFFFu); nk.k1 = (uint32_t)(seed >> 32); nk.step = (uint32_t)step;
+  nk.stream = (uint32_t)((stream & 0xFF) | ((sample & 0xFFFFFF) << 8)); nk.step_ptr = nullptr;
+  rc = launch_noise_probe(nullptr, nk, dIds, B, width, dropout_p, dM, dN);
+  if (rc == SMX_OK) {
+    SMX_HIP(hipDeviceSynchronize());
+    if (dropout_mult) SMX_HIP(hipMemcpy(dropout_mult, dM, (size_t)B * width * 4, hipMemcpyDeviceToHost));
+    if (normal) SMX_HIP(hipMemcpy(normal, dN, (size_t)B * width * 4, hipMemcpyDeviceToHost));
+  }
+  hipFree(dIds); hipFree(dM); hipFree(dN);
+  return rc;
+}
+
+}  // extern "C"

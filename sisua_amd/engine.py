@@ -1,0 +1,289 @@
+"""Engine: the Python owner of one `smx_model` (one GPU, one stream).
+
+Thin, mechanical wrapper over the C-ABI (include/sisua_hip.h): it converts numpy
+arrays to pointers, keeps the tensor manifest, and raises `SmxError` on any
+non-zero status.  All arithmetic happens in libsisua_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from sisua_amd import _hip
+from sisua_amd._hip import SmxError, check, smx_config, smx_metrics
+from sisua_amd.config import ModelConfig, init_params, manifest
+
+STREAM_INPUT_DROPOUT = 0
+STREAM_ENC_DROPOUT = 16
+STREAM_ENCL_DROPOUT = 32
+STREAM_DEC_DROPOUT = 48
+STREAM_EPS_Z = 64
+STREAM_EPS_L = 65
+
+
+def _fp(a: Optional[np.ndarray]):
+  return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a, shape=None):
+  a = np.ascontiguousarray(a, dtype=np.float32)
+  if shape is not None and tuple(a.shape) != tuple(shape):
+    raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+  return a
+
+
+def make_smx_config(cfg: ModelConfig, max_batch: int) -> smx_config:
+  c = smx_config()
+  c.abi_version = _hip.SMX_ABI_VERSION
+  c.model = _hip.MODEL_KINDS[cfg.model]
+  c.likelihood = _hip.LIKELIHOODS[cfg.likelihood]
+  c.n_genes, c.latent_dim = int(cfg.n_genes), int(cfg.latent_dim)
+  for name, units in (("enc", cfg.enc_units), ("dec", cfg.dec_units), ("encl", cfg.encl_units if cfg.model == "scvi" else ())):
+    if len(units) > _hip.SMX_MAX_LAYERS:
+      raise ValueError(f"at most {_hip.SMX_MAX_LAYERS} layers per network")
+    setattr(c, f"n_{name}", len(units))
+    arr = getattr(c, f"{name}_units")
+    for i, u in enumerate(units):
+      arr[i] = int(u)
+  if len(cfg.labels) > _hip.SMX_MAX_LABELS:
+    raise ValueError(f"at most {_hip.SMX_MAX_LABELS} label heads")
+  c.n_labels = len(cfg.labels)
+  for j, (P, llk) in enumerate(cfg.labels):
+    c.label_dim[j] = int(P)
+    c.label_llk[j] = _hip.LABEL_LIKELIHOODS[llk]
+  c.batchnorm, c.log_norm = int(cfg.batchnorm), int(cfg.log_norm)
+  c.latent_activation = _hip.ACTIVATIONS[cfg.latent_activation]
+  c.dropout_enc, c.dropout_dec, c.input_dropout = cfg.dropout_enc, cfg.dropout_dec, cfg.input_dropout
+  c.beta, c.alpha, c.clip_library = cfg.beta, cfg.alpha, cfg.clip_library
+  c.bn_momentum, c.bn_eps = cfg.bn_momentum, cfg.bn_eps
+  c.lr, c.adam_beta1, c.adam_beta2, c.adam_eps, c.clipnorm = cfg.lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps, cfg.clipnorm
+  c.max_batch = int(max_batch)
+  c.seed = int(cfg.seed) & 0xFFFFFFFFFFFFFFFF
+  return c
+
+
+class Engine:
+
+  def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, init: bool = True):
+    self.lib = _hip.require_gpu(device)
+    self.cfg = cfg
+    self.max_batch = int(max_batch)
+    self._h = C.c_void_p()
+    c = make_smx_config(cfg, max_batch)
+    check(self.lib.smx_model_create(C.byref(c), C.byref(self._h)))
+    # manifest handshake: the library's tensor list must equal the host's
+    self.names, self.shapes = [], {}
+    buf = C.create_string_buffer(64)
+    rows, cols = C.c_int32(), C.c_int32()
+    for i in range(self.lib.smx_num_tensors(self._h)):
+      check(self.lib.smx_tensor_info(self._h, i, buf, 64, C.byref(rows), C.byref(cols)))
+      name = buf.value.decode()
+      self.names.append(name)
+      self.shapes[name] = (rows.value, cols.value) if name.endswith("/W") else (cols.value,)
+    expect = manifest(cfg)
+    if [(n, tuple(self.shapes[n])) for n in self.names] != [(n, tuple(s)) for n, s in expect]:
+      raise SmxError("tensor manifest of libsisua_hip.so differs from sisua_amd.config.manifest")
+    self.index = {n: i for i, n in enumerate(self.names)}
+    self.n_cells = 0
+    if init:
+      self.set_params(init_params(cfg))
+
+  # ---- lifetime ---------------------------------------------------------------
+  def close(self):
+    if getattr(self, "_h", None) is not None and self._h:
+      self.lib.smx_model_destroy(self._h)
+      self._h = C.c_void_p()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  # ---- parameters / state -------------------------------------------------------
+  def get_params(self, which: int = 0) -> Dict[str, np.ndarray]:
+    """which: 0 params, 1 gradients of the last step, 2 Adam m, 3 Adam v."""
+    out = {}
+    for i, n in enumerate(self.names):
+      a = np.empty(self.shapes[n], dtype=np.float32)
+      check(self.lib.smx_get_tensor(self._h, which, i, _fp(a)))
+      out[n] = a
+    return out
+
+  def set_params(self, params: Dict[str, np.ndarray], which: int = 0):
+    for n, v in params.items():
+      a = _f32(v, self.shapes[n])
+      check(self.lib.smx_set_tensor(self._h, which, self.index[n], _fp(a)))
+
+  def get_bn(self) -> Dict[int, Dict[str, np.ndarray]]:
+    out = {}
+    w = C.c_int32()
+    for i in range(self.lib.smx_num_bn_layers(self._h)):
+      check(self.lib.smx_get_bn(self._h, i, 0, None, C.byref(w)))
+      mean, var = np.empty(w.value, np.float32), np.empty(w.value, np.float32)
+      check(self.lib.smx_get_bn(self._h, i, 0, _fp(mean), None))
+      check(self.lib.smx_get_bn(self._h, i, 1, _fp(var), None))
+      out[i] = dict(moving_mean=mean, moving_var=var)
+    return out
+
+  def set_bn(self, state: Dict[int, Dict[str, np.ndarray]]):
+    for i, st in state.items():
+      check(self.lib.smx_set_bn(self._h, int(i), 0, _fp(_f32(st["moving_mean"]))))
+      check(self.lib.smx_set_bn(self._h, int(i), 1, _fp(_f32(st["moving_var"]))))
+
+  @property
+  def step(self) -> int:
+    s = C.c_int32()
+    check(self.lib.smx_get_step(self._h, C.byref(s)))
+    return s.value
+
+  @step.setter
+  def step(self, value: int):
+    check(self.lib.smx_set_step(self._h, int(value)))
+
+  # ---- data ----------------------------------------------------------------------
+  def upload(self, X, labels: Sequence[np.ndarray] = (), library=None, label_mask=None, cell_id_base: int = 0):
+    X = _f32(X)
+    if X.ndim != 2 or X.shape[1] != self.cfg.n_genes:
+      raise ValueError(f"X must be [n_cells, {self.cfg.n_genes}]")
+    n = X.shape[0]
+    labs = [_f32(y, (n, P)) for y, (P, _) in zip(labels, self.cfg.labels)]
+    if len(labs) != len(self.cfg.labels):
+      raise ValueError("one label matrix per label head is required")
+    lab_ptrs = (C.POINTER(C.c_float) * max(1, len(labs)))(*[_fp(y) for y in labs]) if labs else None
+    lib_arr = None if library is None else _f32(library, (n, 2))
+    mask_arr = None if label_mask is None else np.ascontiguousarray(label_mask, dtype=np.uint8).reshape(n)
+    check(self.lib.smx_dataset_upload(self._h, _fp(X), n, lab_ptrs, _fp(lib_arr),
+                                      None if mask_arr is None else mask_arr.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                      int(cell_id_base)))
+    self.n_cells = n
+
+  # ---- steps -----------------------------------------------------------------------
+  @staticmethod
+  def _ids(row_ids):
+    return np.ascontiguousarray(row_ids, dtype=np.int32).reshape(-1)
+
+  def train_step(self, row_ids, graph: bool = False, metrics: bool = True):
+    ids = self._ids(row_ids)
+    m = smx_metrics()
+    fn = self.lib.smx_train_step_graph if graph else self.lib.smx_train_step
+    check(fn(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size, C.byref(m) if metrics else None))
+    return m.as_dict() if metrics else None
+
+  def train_steps(self, order, n_steps: int, batch: int, graph: bool = True, metrics: bool = False):
+    ids = self._ids(order)
+    if ids.size != n_steps * batch:
+      raise ValueError("order must hold n_steps * batch row ids")
+    m = smx_metrics()
+    check(self.lib.smx_train_steps(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), int(n_steps), int(batch),
+                                   int(graph), C.byref(m) if metrics else None))
+    return m.as_dict() if metrics else None
+
+  def eval_step(self, row_ids):
+    ids = self._ids(row_ids)
+    m = smx_metrics()
+    check(self.lib.smx_eval_step(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size, C.byref(m)))
+    return m.as_dict()
+
+  def forward(self, row_ids=None, x=None, library=None, sample_index: int = 0, training: bool = False,
+              want_x_params: bool = True):
+    """Eval-mode forward; returns dict of logical-shape arrays."""
+    cfg = self.cfg
+    if row_ids is not None:
+      ids = self._ids(row_ids)
+      B, idp, xp, lp = ids.size, ids.ctypes.data_as(C.POINTER(C.c_int32)), None, None
+    else:
+      xa = _f32(x)
+      B, idp, xp = xa.shape[0], None, _fp(xa)
+      la = None if library is None else _f32(library, (B, 2))
+      lp = _fp(la)
+    D, G, k = cfg.latent_dim, cfg.n_genes, cfg.k
+    out = dict(z_mean=np.empty((B, D), np.float32), z_sample=np.empty((B, D), np.float32))
+    out["z_scale"] = np.empty((B, D), np.float32) if cfg.stochastic else None
+    if cfg.model == "scvi":
+      out.update(l_mean=np.empty((B,), np.float32), l_scale=np.empty((B,), np.float32), l_sample=np.empty((B,), np.float32))
+    if want_x_params:
+      out["x_params"] = np.empty((k, B, G), np.float32)
+    ys = [np.empty((B, (2 if llk == "nb" else 1) * P), np.float32) for P, llk in cfg.labels]
+    yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
+    check(self.lib.smx_forward(self._h, idp, xp, lp, B, int(sample_index), int(training), _fp(out["z_mean"]),
+                               _fp(out.get("z_scale")), _fp(out["z_sample"]), _fp(out.get("l_mean")),
+                               _fp(out.get("l_scale")), _fp(out.get("l_sample")), _fp(out.get("x_params")), yptrs))
+    out["y_params"] = ys
+    return out
+
+  # ---- noise injection (parity tests) ----------------------------------------------
+  def set_noise(self, stream: int, data):
+    a = _f32(data)
+    if a.ndim == 1:
+      a = a.reshape(-1, 1)
+    check(self.lib.smx_set_noise(self._h, int(stream), _fp(a), a.shape[0], a.shape[1]))
+
+  def clear_noise(self):
+    check(self.lib.smx_clear_noise(self._h))
+
+  # ---- data parallel ------------------------------------------------------------------
+  @staticmethod
+  def comm_unique_id() -> bytes:
+    lib = _hip.load()
+    buf = (C.c_uint8 * 128)()
+    check(lib.smx_comm_unique_id(buf))
+    return bytes(buf)
+
+  def comm_init(self, rank: int, world: int, uid: bytes):
+    buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+    check(self.lib.smx_comm_init(self._h, int(rank), int(world), buf))
+
+  @property
+  def world(self) -> int:
+    return self.lib.smx_comm_world(self._h)
+
+  # ---- measurement ----------------------------------------------------------------------
+  def timing_enable(self, kernel: Optional[str]):
+    check(self.lib.smx_timing_enable(self._h, kernel.encode() if kernel else None))
+
+  def timing_read(self):
+    ms, n = C.c_double(), C.c_int64()
+    check(self.lib.smx_timing_read(self._h, C.byref(ms), C.byref(n)))
+    return ms.value, n.value
+
+  def loss_bytes_per_cell(self) -> int:
+    return int(self.lib.smx_loss_bytes_per_cell(self._h))
+
+  def synchronize(self):
+    check(self.lib.smx_synchronize())
+
+
+# ---- kernel-level helpers (tests) -----------------------------------------------------
+def k_count_llk(likelihood: str, x, planes, direct: bool = False, want_grads: bool = True):
+  lib = _hip.require_gpu()
+  x = _f32(x)
+  B, G = x.shape
+  pl = _f32(planes)
+  k = pl.shape[0]
+  llk = np.empty(B, np.float32)
+  grads = np.empty((k, B, G), np.float32) if want_grads else None
+  check(lib.smx_k_count_llk(_hip.LIKELIHOODS[likelihood], int(direct), _fp(x), _fp(pl), B, G, _fp(llk), _fp(grads)))
+  return llk, grads
+
+
+def k_gemm(A, B, trans_a=False, trans_b=False, split_k=1, tile=0):
+  lib = _hip.require_gpu()
+  A, B = _f32(A), _f32(B)
+  M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
+  N = B.shape[0] if trans_b else B.shape[1]
+  Cm = np.empty((M, N), np.float32)
+  check(lib.smx_k_gemm(int(trans_a), int(trans_b), _fp(A), _fp(B), M, N, K, int(split_k), int(tile), _fp(Cm)))
+  return Cm
+
+
+def k_noise(seed, stream, step, cell_ids, width, p=0.0, sample=0):
+  lib = _hip.require_gpu()
+  ids = np.ascontiguousarray(cell_ids, dtype=np.int64)
+  mult = np.empty((ids.size, width), np.float32)
+  nrm = np.empty((ids.size, width), np.float32)
+  check(lib.smx_k_noise(int(seed), int(stream), int(step), int(sample), ids.ctypes.data_as(C.POINTER(C.c_int64)),
+                        ids.size, int(width), float(p), _fp(mult), _fp(nrm)))
+  return mult, nrm

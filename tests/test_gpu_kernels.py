@@ -1,0 +1,112 @@
+"""Parity of single HIP kernels against the oracle, through the C-ABI
+(smx_k_* entry points).  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+from oracle import sisua_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+  from sisua_amd import build
+  build.build(verbose=False)
+  from sisua_amd import engine
+  return engine
+
+
+def test_philox_dropout_bit_exact_and_normals(eng):
+  ids = np.array([0, 1, 5, 4096, 2 ** 31 - 1, 123456789], dtype=np.int64)
+  for stream, step, sample, p, width in ((16, 0, 0, 0.1, 130), (48, 77, 3, 0.3, 64), (0, 2 ** 31, 0, 0.25, 37)):
+    mult, nrm = eng.k_noise(8, stream, step, ids, width, p=p, sample=sample)
+    ref_m = so.philox_dropout_mask(8, stream, step, ids, width, p, sample)
+    assert np.array_equal(mult, ref_m.astype(np.float32))          # integer-exact decisions
+    ref_n = so.philox_normal(8, stream, step, ids, width, sample)
+    assert np.allclose(nrm, ref_n, rtol=2e-5, atol=2e-6)
+  # 64-bit seed reaches both key words
+  m1, _ = eng.k_noise((7 << 32) | 8, 16, 0, ids, 16, p=0.5)
+  assert np.array_equal(m1, so.philox_dropout_mask((7 << 32) | 8, 16, 0, ids, 16, 0.5).astype(np.float32))
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+def test_gemm_all_layouts_and_tiles(eng, ta, tb, tile):
+  rng = np.random.default_rng(tile * 7 + ta * 2 + tb)
+  for (M, N, K, S) in ((128, 96, 64, 1), (37, 32, 200, 1), (130, 256, 515, 4), (5, 64, 33, 2)):
+    if tile == 3 and N % 128:
+      continue
+    if tile in (2,) and N % 64:
+      continue
+    A = rng.normal(size=(K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.normal(size=(N, K) if tb else (K, N)).astype(np.float32)
+    ref = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)
+    out = eng.k_gemm(A, B, ta, tb, split_k=S, tile=tile)
+    assert np.allclose(out, ref, rtol=2e-5, atol=2e-4 * np.sqrt(K)), (M, N, K, S, np.abs(out - ref).max())
+
+
+def test_gemm_layout_is_not_transposed(eng):
+  # A = I with an asymmetric B catches a swapped C/D register map
+  B = np.arange(64 * 96, dtype=np.float32).reshape(64, 96)
+  assert np.array_equal(eng.k_gemm(np.eye(64, dtype=np.float32), B), B)
+
+
+def _edge_grid():
+  rng = np.random.default_rng(0)
+  x = np.concatenate([np.zeros(24), np.arange(1, 13), rng.integers(1, 200, 20), [181, 1000, 10738, 8, 9]]).astype(np.float32)
+  r_log = np.log(np.array([1e-4, 1e-2, 1.0, 7.9, 8.1, 50.0, 1e4]))
+  l = np.array([-30.0, -5.0, -0.5, 0.0, 0.7, 6.0, 30.0])
+  X, A, L = np.meshgrid(x, r_log, l, indexing="ij")
+  n = X.size
+  G = 64
+  pad = (-n) % G
+  def f(v, fill):
+    return np.concatenate([v.ravel(), np.full(pad, fill)]).reshape(-1, G).astype(np.float32)
+  g = rng.uniform(-6, 6, size=n + pad).reshape(-1, G).astype(np.float32)
+  return f(X, 0), f(A, 0), f(L, 0), g
+
+
+@pytest.mark.parametrize("lk", so.LIKELIHOODS)
+def test_count_llk_edge_grid(eng, lk):
+  """SURVEY 8c KAT grid: x in {0..12, 181, 1000, 10738}, r in {1e-4..1e4}, |logits| <= 30."""
+  x, a, l, g = _edge_grid()
+  if lk in ("nbd", "zinbd"):
+    l = np.clip(l, -10, 10)       # second plane is the dispersion pre-activation here
+    a = np.clip(a, -8, 9.2)
+  planes = [a, l, g][: so.n_params_per_gene(lk)]
+  llk, grads = eng.k_count_llk(lk, x, np.stack(planes))
+  ref_e, ref_g = so.count_llk(x.astype(np.float64), [p.astype(np.float64) for p in planes], lk)
+  ref = ref_e.sum(1)
+  assert np.allclose(llk, ref, rtol=1e-4, atol=1e-2)
+  for i in range(len(planes)):
+    err = np.abs(grads[i] - ref_g[i])
+    tol = 1e-4 * np.abs(ref_g[i]) + 1e-4 * (1 + np.abs(x))
+    assert (err <= tol).all(), (lk, i, err.max(), np.unravel_index(np.argmax(err - tol), err.shape))
+
+
+@pytest.mark.parametrize("lk", ["nbd", "zinbd"])
+def test_count_llk_direct_mode(eng, lk):
+  rng = np.random.default_rng(4)
+  B, G = 9, 203   # ragged G: exercises the padded tail
+  x = rng.poisson(1.0, size=(B, G)).astype(np.float32) * (rng.uniform(size=(B, G)) < 0.3)
+  mu = rng.lognormal(0, 1.5, size=(B, G)).astype(np.float32)
+  th = rng.lognormal(0, 1.0, size=(B, G)).astype(np.float32)
+  gate = rng.normal(size=(B, G)).astype(np.float32)
+  planes = [mu, th, gate][: so.n_params_per_gene(lk)]
+  llk, grads = eng.k_count_llk(lk, x, np.stack(planes), direct=True)
+  ref_e, ref_g = so.count_llk(x.astype(np.float64), [p.astype(np.float64) for p in planes], lk, direct=True)
+  assert np.allclose(llk, ref_e.sum(1), rtol=1e-5, atol=1e-3)
+  for i in range(len(planes)):
+    assert np.allclose(grads[i], ref_g[i], rtol=2e-4, atol=2e-5)
+
+
+def test_count_llk_sizes_and_empty_rows(eng):
+  rng = np.random.default_rng(5)
+  for B, G in ((1, 1), (3, 31), (2, 1024), (2, 1025), (4, 1998), (1, 4100)):
+    x = (rng.poisson(2.0, size=(B, G)) * (rng.uniform(size=(B, G)) < 0.07)).astype(np.float32)
+    x[0, :] = 0                     # an all-zero cell
+    planes = np.stack([rng.normal(size=(B, G)), rng.normal(size=(B, G)), rng.normal(size=(B, G))]).astype(np.float32)
+    llk, grads = eng.k_count_llk("zinb", x, planes)
+    ref_e, ref_g = so.count_llk(x.astype(np.float64), list(planes.astype(np.float64)), "zinb")
+    assert np.allclose(llk, ref_e.sum(1), rtol=1e-5, atol=1e-4)
+    assert np.allclose(grads, np.stack(ref_g), rtol=1e-4, atol=1e-5)

@@ -1,0 +1,215 @@
+"""Whole-step parity: forward, ELBO, every gradient, Adam update and BN moving
+statistics of the HIP path against the float64 oracle on the same seeded inputs;
+tolerance 1e-4 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from oracle import sisua_oracle as so
+from tests.util import make_pair, perturbed_params, rel_l2, synth_counts, synth_labels
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def Engine():
+  from sisua_amd import build
+  build.build(verbose=False)
+  from sisua_amd.engine import Engine
+  return Engine
+
+
+CASES = {
+    "vae_zinb": dict(model="vae", n_genes=203, likelihood="zinb", enc_units=(48, 40), dec_units=(40,), latent_dim=10),
+    "vae_nb_nobn": dict(model="vae", n_genes=64, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=5,
+                        batchnorm=False, input_dropout=0.3),
+    "vae_zinbd": dict(model="vae", n_genes=130, likelihood="zinbd", enc_units=(64, 64), dec_units=(64, 64), latent_dim=12,
+                      input_dropout=0.2),
+    "vae_nbd": dict(model="vae", n_genes=97, likelihood="nbd", enc_units=(33,), dec_units=(17,), latent_dim=7),
+    "dca_zinb": dict(model="dca", n_genes=150, likelihood="zinb", enc_units=(32,), dec_units=(32,), latent_dim=8),
+    "dca_linear": dict(model="dca", n_genes=70, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=8,
+                       latent_activation="linear"),
+    "sisua": dict(model="sisua", n_genes=180, likelihood="zinb", enc_units=(64,), dec_units=(64,), latent_dim=9,
+                  labels=((12, "nb"), (7, "onehot"))),
+    "scvi_zinbd": dict(model="scvi", n_genes=160, likelihood="zinbd", enc_units=(48,), dec_units=(48,), latent_dim=6,
+                       encl_units=(16,)),
+    "scvi_nbd": dict(model="scvi", n_genes=96, likelihood="nbd", enc_units=(32,), dec_units=(32,), latent_dim=4,
+                     encl_units=(8,), batchnorm=False),
+    "paper_shape": dict(model="vae", n_genes=1998, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=32),
+}
+
+
+def _problem(kw, n=300, seed=0):
+  spec, cfg = make_pair(**kw)
+  x = synth_counts(n, spec.n_genes, sparsity=0.85, seed=seed, max_count=2000 if spec.n_genes < 500 else None)
+  ys = synth_labels(n, spec.labels)
+  _, lm, lv = so.library_size(x)
+  lib = np.tile(np.array([[lm, lv]], dtype=np.float32), (n, 1))
+  mask = so.label_mask(n, 0.4, n_omics=1 + len(spec.labels), seed=1)
+  return spec, cfg, x, ys, lib, mask
+
+
+def _oracle_step(spec, params, bn, opt, x, ys, lib, mask, rows, step, cell_base=0):
+  noise = so.PhiloxNoise(spec.seed, step, rows + cell_base)
+  return so.train_step(spec, params, bn, opt, x[rows], noise, y=[y[rows] for y in ys], library=lib[rows], mask=mask[rows])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("batch", [32, 100])
+def test_one_step_matches_oracle(Engine, name, batch):
+  kw = CASES[name]
+  spec, cfg, x, ys, lib, mask = _problem(kw)
+  params = perturbed_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = Engine(cfg, max_batch=128, init=False)
+  e.set_params(params)
+  e.upload(x, ys, lib, mask, cell_id_base=1000)
+  rows = np.random.default_rng(1).choice(x.shape[0], size=batch, replace=False).astype(np.int32)
+  p0 = {k: v.copy() for k, v in params.items()}
+  res = _oracle_step(spec, params, bn, opt, x, ys, lib, mask, rows, 0, cell_base=1000)
+  m = e.train_step(rows)
+  assert m["nan_flag"] == 0 and m["step"] == 1
+  for key in ("loss", "nllk_x", "kl"):
+    assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
+  if spec.labels:
+    assert np.isclose(m["nllk_y"], res["metrics"]["nllk_y"], rtol=RTOL, atol=1e-5)
+  if spec.model == "scvi":
+    assert np.isclose(m["kl_l"], res["metrics"]["kl_l"], rtol=RTOL, atol=1e-5)
+  grads = e.get_params(which=1)
+  worst = {k: rel_l2(grads[k], res["grads"][k]) for k in grads}
+  assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  newp = e.get_params()
+  for k in newp:  # the first Adam step moves every weight by ~lr: compare the update itself
+    assert rel_l2(newp[k] - p0[k], params[k] - p0[k]) < 2e-3, k
+    assert np.allclose(newp[k], params[k], rtol=1e-5, atol=1e-6), k
+  names = [p for p, _ in so.bn_manifest(spec)]
+  for i, st in e.get_bn().items():
+    assert np.allclose(st["moving_mean"], bn[f"{names[i]}/moving_mean"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(st["moving_var"], bn[f"{names[i]}/moving_var"], rtol=1e-4, atol=1e-6)
+  e.close()
+
+
+@pytest.mark.parametrize("name", ["vae_zinb", "sisua", "scvi_zinbd"])
+def test_injected_noise_matches_oracle(Engine, name):
+  """smx_set_noise hook: same parameters + same minibatch + same injected eps / dropout
+  masks => same loss and gradients (SURVEY.md section 7 'hard parts')."""
+  kw = dict(CASES[name], input_dropout=0.25)
+  spec, cfg, x, ys, lib, mask = _problem(kw)
+  params = perturbed_params(spec)
+  B = 64
+  rows = np.arange(10, 10 + B, dtype=np.int32)
+  rng = np.random.default_rng(9)
+  def dmask(w, p):
+    return (rng.uniform(size=(B, w)) >= p).astype(np.float32) / np.float32(1 - p)
+  drop = {so.STREAM_INPUT_DROPOUT: dmask(spec.n_genes, 0.25)}
+  for i, u in enumerate(spec.enc_units):
+    drop[so.STREAM_ENC_DROPOUT + i] = dmask(u, spec.dropout_enc)
+  for i, u in enumerate(spec.dec_units):
+    drop[so.STREAM_DEC_DROPOUT + i] = dmask(u, spec.dropout_dec)
+  normal = {so.STREAM_EPS_Z: rng.normal(size=(B, spec.latent_dim)).astype(np.float32)}
+  if spec.model == "scvi":
+    for i, u in enumerate(spec.encl_units):
+      drop[so.STREAM_ENCL_DROPOUT + i] = dmask(u, spec.dropout_enc)
+    normal[so.STREAM_EPS_L] = rng.normal(size=(B, 1)).astype(np.float32)
+  e = Engine(cfg, max_batch=B, init=False)
+  e.set_params(params)
+  e.upload(x, ys, lib, mask)
+  for s, v in {**drop, **normal}.items():
+    e.set_noise(s, v)
+  res = so.forward_backward(spec, params, so.init_bn_state(spec), x[rows], so.InjectedNoise(drop, normal),
+                            y=[y[rows] for y in ys], library=lib[rows], mask=mask[rows])
+  m = e.train_step(rows)
+  assert np.isclose(m["loss"], res["loss"], rtol=RTOL)
+  grads = e.get_params(which=1)
+  worst = {k: rel_l2(grads[k], res["grads"][k]) for k in grads}
+  assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  e.close()
+
+
+@pytest.mark.parametrize("name,graph", [("vae_zinb", False), ("vae_zinb", True), ("sisua", True), ("scvi_zinbd", False)])
+def test_trajectory_matches_oracle(Engine, name, graph):
+  """50-step seeded trajectory: ELBO per step within 1e-4 relative."""
+  kw = CASES[name]
+  spec, cfg, x, ys, lib, mask = _problem(kw, n=512)
+  params = {k: v.copy() for k, v in so.init_params(spec).items()}
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  B, steps = 64, 50
+  e = Engine(cfg, max_batch=B, init=False)
+  e.set_params(params)
+  e.upload(x, ys, lib, mask)
+  order = np.concatenate([so.epoch_order(x.shape[0], ep, shuffle=100, seed=1) for ep in range(8)])[: steps * B].astype(np.int32)
+  ref, got = [], []
+  for s in range(steps):
+    rows = order[s * B:(s + 1) * B]
+    ref.append(_oracle_step(spec, params, bn, opt, x, ys, lib, mask, rows, s)["loss"])
+    got.append(e.train_step(rows, graph=graph)["loss"])
+  ref, got = np.array(ref), np.array(got)
+  assert np.allclose(got, ref, rtol=RTOL), np.abs(got / ref - 1).max()
+  assert ref[-5:].mean() < ref[:5].mean()      # and it trains
+  e.close()
+
+
+def test_graph_and_eager_are_bitwise_identical(Engine):
+  kw = CASES["vae_zinb"]
+  spec, cfg, x, ys, lib, mask = _problem(kw)
+  outs = []
+  for graph in (False, True):
+    e = Engine(cfg, max_batch=64)
+    e.upload(x, ys, lib, mask)
+    order = np.arange(64 * 6, dtype=np.int32) % x.shape[0]
+    e.train_steps(order, 6, 64, graph=graph)
+    outs.append(e.get_params())
+    e.close()
+  for k in outs[0]:
+    assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_eval_and_forward_match_oracle(Engine):
+  kw = CASES["sisua"]
+  spec, cfg, x, ys, lib, mask = _problem(kw)
+  params = perturbed_params(spec)
+  bn = so.init_bn_state(spec)
+  rng = np.random.default_rng(2)
+  for k in bn:  # non-trivial moving statistics
+    bn[k] = (bn[k] + 0.2 * rng.uniform(size=bn[k].shape)).astype(np.float32).astype(np.float64)
+  e = Engine(cfg, max_batch=128, init=False)
+  e.set_params(params)
+  names = [p for p, _ in so.bn_manifest(spec)]
+  e.set_bn({i: dict(moving_mean=bn[f"{n}/moving_mean"], moving_var=bn[f"{n}/moving_var"]) for i, n in enumerate(names)})
+  e.upload(x, ys, lib, mask)
+  rows = np.arange(40, 140, dtype=np.int32)
+  noise = so.PhiloxNoise(spec.seed, 0, rows, sample=0)
+  res = so.forward_backward(spec, params, bn, x[rows], noise, y=[y[rows] for y in ys], library=lib[rows],
+                            mask=mask[rows], training=False, backward=False)
+  m = e.eval_step(rows)
+  assert np.isclose(m["loss"], res["loss"], rtol=RTOL)
+  out = e.forward(row_ids=rows, sample_index=0)
+  assert np.allclose(out["z_mean"], res["z_mean"], rtol=1e-4, atol=1e-5)
+  assert np.allclose(out["z_scale"], res["z_scale"], rtol=1e-4, atol=1e-5)
+  assert np.allclose(out["z_sample"], res["z"], rtol=1e-3, atol=1e-4)
+  for c in range(spec.k):
+    assert np.allclose(out["x_params"][c], res["x_params"][c], rtol=1e-3, atol=1e-4)
+  for j in range(len(spec.labels)):
+    assert np.allclose(out["y_params"][j], res["y_params"][j], rtol=1e-3, atol=1e-4)
+  # host-batch path (predict on raw arrays) agrees with the resident-row path on the means
+  out2 = e.forward(x=x[rows], library=lib[rows])
+  assert np.allclose(out2["z_mean"], out["z_mean"], rtol=1e-6, atol=1e-6)
+  # a different MC sample index changes the draw, not the mean
+  out3 = e.forward(row_ids=rows, sample_index=1)
+  assert np.array_equal(out3["z_mean"], out["z_mean"]) and not np.allclose(out3["z_sample"], out["z_sample"])
+  e.close()
+
+
+def test_error_paths(Engine):
+  from sisua_amd import SmxError
+  spec, cfg, x, ys, lib, mask = _problem(CASES["vae_zinb"], n=50)
+  e = Engine(cfg, max_batch=16)
+  with pytest.raises(SmxError):
+    e.train_step(np.arange(8, dtype=np.int32))            # no dataset yet
+  e.upload(x, ys, lib, mask)
+  with pytest.raises(SmxError):
+    e.train_step(np.arange(32, dtype=np.int32))           # batch > max_batch
+  with pytest.raises(SmxError):
+    e.train_step(np.array([0, 1, 50], dtype=np.int32))    # row id out of range
+  assert e.train_step(np.arange(16, dtype=np.int32))["step"] == 1
+  e.close()

@@ -1,0 +1,50 @@
+"""Shared builders for the parity tests: one dict -> oracle Spec + ModelConfig,
+plus small synthetic datasets with the reference datasets' sparsity."""
+import numpy as np
+
+from oracle import sisua_oracle as so
+
+
+def make_pair(**kw):
+  from sisua_amd.config import ModelConfig
+  return so.Spec(**kw), ModelConfig(**kw)
+
+
+def synth_counts(n, g, sparsity=0.9, seed=0, max_count=None):
+  rng = np.random.default_rng(seed)
+  mg = rng.normal(-0.5, 1.2, size=g)
+  sc = rng.lognormal(0.0, 0.3, size=n)
+  lam = sc[:, None] * np.exp(mg)[None, :] * rng.gamma(2.0, 0.5, size=(n, g))
+  x = rng.poisson(lam).astype(np.float32)
+  thr = np.quantile(rng.uniform(size=(n, g)), 1 - sparsity)
+  keep = rng.uniform(size=(n, g)) > sparsity
+  x = x * keep
+  if max_count:
+    x[rng.integers(0, n), rng.integers(0, g)] = max_count
+  x[:, 0] = np.maximum(x[:, 0], 1.0)  # no all-zero cell (library size is log of the total)
+  return x.astype(np.float32)
+
+
+def synth_labels(n, labels, seed=1):
+  rng = np.random.default_rng(seed)
+  ys = []
+  for P, kind in labels:
+    if kind == "onehot":
+      ys.append(np.eye(P, dtype=np.float32)[rng.integers(0, P, n)])
+    else:
+      ys.append(np.clip(rng.lognormal(0.6, 0.6, size=(n, P)), 0.5, 9.1).astype(np.float32))
+  return ys
+
+
+def perturbed_params(spec, scale=0.05, seed=3):
+  """Oracle init moved off the symmetric point (gamma=1, beta=0, b=0), fp32-representable."""
+  rng = np.random.default_rng(seed)
+  p = so.init_params(spec)
+  return {k: (v + scale * rng.normal(size=v.shape)).astype(np.float32).astype(np.float64) for k, v in p.items()}
+
+
+def rel_l2(a, b):
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  d = np.linalg.norm(a - b)
+  n = np.linalg.norm(b)
+  return d / n if n > 0 else d
