@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- cells/sec of VAE training on the pbmc8k_ly-shaped workload
+(BASELINE.json configs[1]: VAE, hidden 128, latent 32, ZINB, batch 128).
+
+One "step" = one optimiser step of the hot path on one minibatch: gather +
+log1p + encoder, reparameterised latent, decoder, ZINB+KL ELBO, backward,
+(all-reduce), clipnorm + Adam; inputs already resident in HBM.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, cells sharded over ranks (weak scaling: 128 cells per
+GPU per step), one RCCL all-reduce of the flat gradient buffer per step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.3 TB/s achievable)
+
+
+def build_workload(rank: int, world: int, workload: str):
+  """Reproduces on_train (sisua/train.py:118-147) on synthetic 8kly-shaped data:
+  split(0.8) -> split(0.9) -> corrupt(train) -> library stats."""
+  from sisua_amd import data
+  from sisua_amd.config import ModelConfig
+  if workload == "8kly":
+    x, _ = data.synthetic_8kly(seed=8 + rank)
+    units, latent, batch = (128,), 32, 128
+  elif workload == "8kly-2layer":
+    x, _ = data.synthetic_8kly(seed=8 + rank)
+    units, latent, batch = (128, 128), 32, 128
+  else:
+    raise ValueError(workload)
+  tr, _ = data.split_indices(x.shape[0], 0.8, seed=1)
+  tr2, _ = data.split_indices(len(tr), 0.9, seed=1)
+  xt = data.corrupt(x[tr][tr2], 0.2, 0.2, seed=8)
+  xt[xt.sum(1) == 0, 0] = 1.0
+  cfg = ModelConfig(model="vae", n_genes=x.shape[1], likelihood="zinb", enc_units=units, dec_units=units,
+                    latent_dim=latent, batchnorm=True, dropout_enc=0.1, dropout_dec=0.1, input_dropout=0.0,
+                    log_norm=True, beta=1.0, lr=1e-3, clipnorm=100.0, seed=8)
+  return cfg, xt, batch
+
+
+def make_order(n_cells: int, batch: int, n_steps: int):
+  from sisua_amd import data
+  chunks, ep = [], 0
+  have = 0
+  while have < n_steps:
+    bs = data.iter_batches(data.epoch_order(n_cells, ep, shuffle=1000, seed=1), batch, drop_remainder=True)
+    chunks += bs
+    have += len(bs)
+    ep += 1
+  return np.concatenate(chunks[:n_steps]).astype(np.int32)
+
+
+def cpu_baseline(cfg, xt, batch, budget_s=12.0):
+  """The oracle (NumPy float64 restatement; BLAS threads = host cores) timed on a
+  bounded sample of the same workload: as many steps as fit in ~budget_s."""
+  from oracle import sisua_oracle as so
+  spec = so.Spec(**cfg.to_dict())
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  order = make_order(xt.shape[0], batch, 400)
+  x64 = xt.astype(np.float64)
+  t_start, done, t_steps = time.perf_counter(), 0, 0.0
+  while True:
+    rows = order[done * batch:(done + 1) * batch]
+    t0 = time.perf_counter()
+    so.train_step(spec, params, bn, opt, x64[rows], so.PhiloxNoise(spec.seed, done, rows))
+    dt = time.perf_counter() - t0
+    if done >= 2:  # first two steps warm caches / BLAS threads
+      t_steps += dt
+    done += 1
+    if time.perf_counter() - t_start > budget_s or done >= 400:
+      break
+  timed = max(done - 2, 1)
+  return dict(value=round(batch * timed / t_steps, 1), unit="cells/s", cores=os.cpu_count(), kind="port",
+              sample=f"{timed} steps of batch {batch} of the same workload, NumPy float64 oracle "
+                     f"(oracle/sisua_oracle.py), BLAS threads = host cores")
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=300)
+  ap.add_argument("--warmup", type=int, default=30)
+  ap.add_argument("--workload", default="8kly")
+  ap.add_argument("--no-graph", action="store_true")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--cpu-budget", type=float, default=12.0)
+  args = ap.parse_args()
+
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      sys.exit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    args.gpus = world
+
+  # the HIP library first (binds /opt/rocm's runtime), torch only as rendezvous plumbing
+  from sisua_amd import _hip
+  from sisua_amd.engine import Engine
+  _hip.require_gpu(local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+  cfg, xt, batch = build_workload(rank, world, args.workload)
+  eng = Engine(cfg, max_batch=batch, device=local_rank)
+  eng.upload(xt, cell_id_base=rank * (1 << 24))
+  if world > 1:
+    uid = [Engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    eng.comm_init(rank, world, uid[0])
+
+  use_graph = not args.no_graph
+  order = make_order(xt.shape[0], batch, args.warmup + args.steps)
+  if args.warmup:
+    eng.train_steps(order[: args.warmup * batch], args.warmup, batch, graph=use_graph)
+  eng.synchronize()
+  if dist is not None:
+    dist.barrier()
+  t0 = time.perf_counter()
+  m = eng.train_steps(order[args.warmup * batch:], args.steps, batch, graph=use_graph, metrics=True)
+  eng.synchronize()
+  dt = time.perf_counter() - t0
+  if dist is not None:
+    import torch
+    t = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    dist.barrier()
+
+  # ---- roofline of the ZINB+KL loss kernel: HIP events on the model's stream ----
+  n_ev = min(args.steps, 200)
+  eng.timing_enable("loss")
+  eng.train_steps(order[: n_ev * batch], n_ev, batch, graph=False)
+  loss_ms, loss_n = eng.timing_read()
+  eng.timing_enable(None)
+  per_kernel = {}
+  for name in ("gemm_enc_fwd", "gemm_out_fwd", "gemm_out_dw", "gemm_out_dx", "gemm_enc_dw", "adam", "step"):
+    eng.timing_enable(name)
+    eng.train_steps(order[: 50 * batch], 50, batch, graph=False)
+    ms, n = eng.timing_read()
+    per_kernel[name] = round(1e3 * ms / max(n, 1), 2)
+  eng.timing_enable(None)
+
+  if rank == 0:
+    bytes_per_launch = eng.loss_bytes_per_cell() * batch
+    avg_s = (loss_ms / max(loss_n, 1)) * 1e-3
+    achieved = bytes_per_launch / avg_s / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "loss_traffic_bytes.json")
+    if os.path.exists(tfile):
+      try:
+        traffic = json.load(open(tfile)).get(args.workload)
+      except Exception:
+        traffic = None
+    out = {
+        "metric": "cells/sec VAE training (pbmc8k_ly, batch=128)",
+        "value": round(args.steps * batch * world / dt, 1),
+        "unit": "cells/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}-shaped synthetic counts {xt.shape[0]}x{xt.shape[1]} "
+                               f"(train split, corrupted), VAE zinb hidden={list(cfg.enc_units)} latent={cfg.latent_dim}, "
+                               f"batch {batch}/GPU, hipGraph={'on' if use_graph else 'off'}",
+                   "global_batch": batch * world, "parallelism": f"dp{world}"},
+        "final_loss": round(m["loss"], 4),
+        "roofline": {"bound": "hbm", "kernel": "count_loss_kernel<ZINB> fwd+bwd", "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": traffic, "bytes_per_launch": bytes_per_launch,
+                     "avg_launch_us": round(avg_s * 1e6, 3), "launches_timed": loss_n},
+        "kernel_us": per_kernel,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      out["cpu_baseline"] = cpu_baseline(cfg, xt, batch, args.cpu_budget)
+    print(json.dumps(out), flush=True)
+  eng.close()
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -131,7 +131,7 @@ struct LibLatentArgs {
   const float* library = nullptr;  // [n_cells][2] resident, gathered by rows; or [B][2] when rows == nullptr
   const int32_t* rows = nullptr; uint32_t cell_base = 0;
   NoiseKey nk{0, 0, 0, 0, nullptr};
-  const float* inj_eps = nullptr;
+  const float* inj_eps = nullptr; int inj_ld = 1;
   float clip_library = 1e3f;
   float* l = nullptr; float* sig = nullptr; float* eps = nullptr; float* kl = nullptr;  // [B]
   const float* dl = nullptr;  // [B] d loss / d l (already masked by the clip)

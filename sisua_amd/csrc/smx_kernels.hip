@@ -350,7 +350,7 @@ __global__ void lib_latent_fwd_kernel(LibLatentArgs a) {
   const long src = a.rows ? a.rows[b] : b;
   const float mu = a.latl[(long)b * a.ld], sig = softplusf(a.latl[(long)b * a.ld + 1] + SMX_SOFTPLUS_INV_1);
   float eps;
-  if (a.inj_eps) eps = a.inj_eps[b];
+  if (a.inj_eps) eps = a.inj_eps[(long)b * a.inj_ld];
   else eps = normal4(philox_block(a.nk, a.cell_base + (uint32_t)src, 0u)).x;
   const float mp = a.library[src * 2], vp = a.library[src * 2 + 1];
   const float sp = sqrtf(vp);

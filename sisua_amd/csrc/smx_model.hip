@@ -387,7 +387,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward) {
     LibLatentArgs ll;
     ll.latl = m->latlbuf; ll.ld = 32; ll.B = ps.B; ll.library = ps.lib; ll.rows = ps.rows; ll.cell_base = ps.cell_base;
     ll.nk = make_key(m, ST_EPS_L, ps.sample, ps.training != 0);
-    if (const Injected* ij = inj(m, ST_EPS_L)) ll.inj_eps = ij->d;
+    if (const Injected* ij = inj(m, ST_EPS_L)) { ll.inj_eps = ij->d; ll.inj_ld = ij->ld; }
     ll.clip_library = c.clip_library;
     ll.l = m->lsmp; ll.sig = m->lsig; ll.eps = m->leps; ll.kl = m->kl_l;
     SMX_CHECK(launch_lib_latent_fwd(m->st, ll));

