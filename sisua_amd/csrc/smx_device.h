@@ -80,16 +80,36 @@ __device__ inline float4 normal4(const U4& w) {
 // ---------------------------------------------------------------------------
 #define SMX_SOFTPLUS_INV_1 0.54132485461291810f  // log(e - 1)
 
-__device__ inline float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+// Fast transcendental forms (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp of the
+// base-2 function): the kernels are parity-bound at 1e-4, not at 1 ulp.
+__device__ inline float fexp(float x) { return __expf(x); }
+__device__ inline float flog(float x) { return __logf(x); }
+__device__ inline float frcp(float x) { return __frcp_rn(x); }
+
+// log(1 + e) for 0 <= e <= 1 without losing e below 2^-24: series under 1/32, v_log above.
+__device__ inline float log1p_small(float e) {
+  const float ser = e * (1.0f - e * (0.5f - e * (0.33333334f - e * (0.25f - e * 0.2f))));
+  return e < 0.03125f ? ser : flog(1.0f + e);
+}
+
+// softplus(x) and sigmoid(x) from ONE exponential.
+struct SpSg { float sp, sg; };
+__device__ inline SpSg softplus_sigmoid(float x) {
+  const float e = fexp(-fabsf(x));
+  const float inv = frcp(1.0f + e);
+  SpSg o;
+  o.sp = fmaxf(x, 0.f) + log1p_small(e);
+  o.sg = x >= 0.f ? inv : e * inv;
+  return o;
+}
+__device__ inline float softplusf(float x) { return fmaxf(x, 0.f) + log1p_small(fexp(-fabsf(x))); }
 __device__ inline float sigmoidf(float x) {
-  const float e = expf(-fabsf(x));
-  const float s = 1.0f / (1.0f + e);
+  const float e = fexp(-fabsf(x));
+  const float s = frcp(1.0f + e);
   return x >= 0.f ? s : e * s;
 }
-__device__ inline float logaddexpf(float a, float b) {
-  const float m = fmaxf(a, b);
-  return m + log1pf(expf(-fabsf(a - b)));
-}
+// log1p for count inputs (x >= 0; 1 + x is exact for integer counts < 2^24)
+__device__ inline float log1p_count(float x) { return flog(1.0f + x); }
 
 // lgamma(x + r) - lgamma(r) and digamma(x + r) - digamma(r) for x >= 0, r > 0, in
 // fp32 without the cancellation of two separate lgamma calls:
@@ -121,8 +141,8 @@ __device__ inline LgDg lgamma_digamma_diff(float x, float r) {
       dP = fmaf(dP, t, P);
       P *= t;
     }
-    o.lg = logf(P);
-    o.dg = dP / P;
+    o.lg = flog(P);
+    o.dg = dP * frcp(P);
     return o;
   }
   float lg_shift = 0.f, dg_shift = 0.f, rs = r;
@@ -133,9 +153,9 @@ __device__ inline LgDg lgamma_digamma_diff(float x, float r) {
       const float a = r + (float)i, b = x + a;
       ratio *= a / b;
       dg_shift += x / (a * b);
-      if ((i & 3) == 3) { lg_shift += logf(ratio); ratio = 1.f; }
+      if ((i & 3) == 3) { lg_shift += flog(ratio); ratio = 1.f; }
     }
-    lg_shift += logf(ratio);
+    lg_shift += flog(ratio);
     rs = r + (float)n;
   }
   const float zr = x + rs;

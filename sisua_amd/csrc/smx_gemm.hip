@@ -25,7 +25,7 @@ template <int XF>
 __device__ inline float4 xform4(float4 v, const AXform& xf, int batch_idx, int src_row, int gene) {
   if (XF) {
     if (xf.log1p) {
-      v.x = log1pf(v.x); v.y = log1pf(v.y); v.z = log1pf(v.z); v.w = log1pf(v.w);
+      v.x = log1p_count(v.x); v.y = log1p_count(v.y); v.z = log1p_count(v.z); v.w = log1p_count(v.w);
     }
     if (xf.inj_mask) {
       const float4 m = *reinterpret_cast<const float4*>(xf.inj_mask + (long)batch_idx * xf.inj_ld + gene);
@@ -246,7 +246,9 @@ int launch_gemm(hipStream_t st, const GemmArgs& g_in, int* eff_split) {
   int tile = g.tile;
   if (tile == TILE_AUTO) {
     const int kper = g.K / g.split_k;
-    if (kper >= 128 && (long)((g.M + 127) / 128) * (g.N / 32) < 128) tile = TILE_32x32_K4;
+    if (g.use_xform && !g.a_kmajor && g.N == 128) tile = TILE_32x128;  // transform each A element once
+    else if (g.use_xform && !g.a_kmajor && g.N == 64) tile = TILE_64x64;
+    else if (kper >= 128 && (long)((g.M + 127) / 128) * (g.N / 32) < 128) tile = TILE_32x32_K4;
     else if (g.M > 64 || g.N % 64) tile = TILE_128x32;
     else if (g.M > 32) tile = TILE_64x64;
     else tile = (g.N % 128 == 0) ? TILE_32x128 : TILE_64x64;

@@ -9,6 +9,8 @@
 //  label_loss     masked NB / one-hot label heads of SISUA (a-13)
 //  scvi_head      softmax-rate / exp-dispersion head of SCVI and its backward (a-12)
 //  metrics        ELBO scalars (a-15);  adam: per-tensor clipnorm + Adam (a-16)
+#include <stdlib.h>
+
 #include "smx_internal.h"
 #include "../../include/sisua_hip.h"
 
@@ -22,39 +24,42 @@ __device__ inline void count_elem(float x, float p0, float p1, float p2, float& 
                                   float& d2) {
   float ell;
   if (LK == SMX_LLK_NB || LK == SMX_LLK_ZINB) {
-    const float r = expf(p0);
-    const float sp = softplusf(p1);          // softplus(l); log_sigmoid(l) = l - sp, log_sigmoid(-l) = -sp
+    const float r = fexp(p0);
+    const SpSg s = softplus_sigmoid(p1);     // log_sigmoid(l) = l - sp, log_sigmoid(-l) = -sp
     const LgDg t = lgamma_digamma_diff(x, r);
-    ell = t.lg + x * (p1 - sp) - r * sp;
-    d0 = r * (t.dg - sp);
-    d1 = x - (x + r) * sigmoidf(p1);
+    ell = t.lg + x * (p1 - s.sp) - r * s.sp;
+    d0 = r * (t.dg - s.sp);
+    d1 = x - (x + r) * s.sg;
   } else {
     float mu, th, g0 = 1.f, g1 = 1.f;
     if (DIRECT) { mu = p0; th = p1; }
     else {
-      mu = softplusf(p0); th = softplusf(p1 + SMX_SOFTPLUS_INV_1);
-      g0 = sigmoidf(p0); g1 = sigmoidf(p1 + SMX_SOFTPLUS_INV_1);
+      const SpSg s0 = softplus_sigmoid(p0), s1 = softplus_sigmoid(p1 + SMX_SOFTPLUS_INV_1);
+      mu = s0.sp; th = s1.sp; g0 = s0.sg; g1 = s1.sg;
     }
     const float e = 1e-8f;
-    const float lt = logf(th + mu + e), lth = logf(th + e);
-    const float inv = 1.0f / (th + mu + e);
+    const float lt = flog(th + mu + e), lth = flog(th + e);
+    const float inv = frcp(th + mu + e);
     const LgDg t = lgamma_digamma_diff(x, th);
-    ell = th * (lth - lt) + x * (logf(mu + e) - lt) + t.lg;
-    d0 = (-th * inv + x / (mu + e) - x * inv) * g0;
-    d1 = (lth - lt + th / (th + e) - th * inv - x * inv + t.dg) * g1;
+    ell = th * (lth - lt) + x * (flog(mu + e) - lt) + t.lg;
+    d0 = (-th * inv + x * frcp(mu + e) - x * inv) * g0;
+    d1 = (lth - lt + th * frcp(th + e) - th * inv - x * inv + t.dg) * g1;
   }
   if (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) {
-    const float spg = softplusf(p2);
-    const float sg = sigmoidf(p2);
+    const SpSg sg = softplus_sigmoid(p2);
     if (x == 0.f) {
-      const float lse = logaddexpf(p2, ell);
-      const float w = expf(ell - lse);
-      llk = lse - spg;
+      // lse = logaddexp(g, ell); w = d lse / d ell = sigmoid(ell - g): one exponential for both
+      const float dlt = ell - p2;
+      const float e3 = fexp(-fabsf(dlt));
+      const float inv3 = frcp(1.0f + e3);
+      const float lse = fmaxf(p2, ell) + log1p_small(e3);
+      const float w = dlt >= 0.f ? inv3 : e3 * inv3;
+      llk = lse - sg.sp;
       d0 *= w; d1 *= w;
-      d2 = (1.f - w) - sg;
+      d2 = (1.f - w) - sg.sg;
     } else {
-      llk = ell - spg;
-      d2 = -sg;
+      llk = ell - sg.sp;
+      d2 = -sg.sg;
     }
   } else {
     llk = ell;
@@ -62,40 +67,57 @@ __device__ inline void count_elem(float x, float p0, float p1, float p2, float& 
   }
 }
 
-// grid (n_chunks, B); thread = 4 consecutive genes of one cell.
-template <int LK, int DIRECT, int BWD>
+// grid (n_chunks, B); thread = VEC consecutive genes of one cell (VEC*4-byte accesses).
+template <int VEC> struct VecT;
+template <> struct VecT<4> { typedef float4 T; };
+template <> struct VecT<2> { typedef float2 T; };
+template <> struct VecT<1> { typedef float T; };
+
+template <int VEC>
+__device__ inline void vload(const float* p, float (&v)[VEC]) {
+  const typename VecT<VEC>::T t = *reinterpret_cast<const typename VecT<VEC>::T*>(p);
+  const float* f = reinterpret_cast<const float*>(&t);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) v[i] = f[i];
+}
+template <int VEC>
+__device__ inline void vstore(float* p, const float (&v)[VEC]) {
+  typename VecT<VEC>::T t;
+  float* f = reinterpret_cast<float*>(&t);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) f[i] = v[i];
+  *reinterpret_cast<typename VecT<VEC>::T*>(p) = t;
+}
+
+template <int LK, int DIRECT, int BWD, int VEC>
 __global__ __launch_bounds__(256) void count_loss_kernel(LossArgs a) {
   constexpr int K = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
   const int b = blockIdx.y;
-  const int g0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int g0 = (blockIdx.x * 256 + threadIdx.x) * VEC;
   float acc = 0.f;
   if (g0 < a.Gp) {
     const long src = a.rows ? a.rows[b] : b;
-    const float4 x4 = *reinterpret_cast<const float4*>(a.X + src * a.ldx + g0);
+    float xs[VEC], a0[VEC], a1[VEC], a2[VEC];
     const float* pb = a.P + (long)b * a.ldp + g0;
-    const float4 q0 = *reinterpret_cast<const float4*>(pb);
-    const float4 q1 = *reinterpret_cast<const float4*>(pb + a.plane_stride);
-    float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (K == 3) q2 = *reinterpret_cast<const float4*>(pb + 2 * a.plane_stride);
-    const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
-    const float a0[4] = {q0.x, q0.y, q0.z, q0.w};
-    const float a1[4] = {q1.x, q1.y, q1.z, q1.w};
-    const float a2[4] = {q2.x, q2.y, q2.z, q2.w};
-    float r0[4], r1[4], r2[4];
+    vload<VEC>(a.X + src * a.ldx + g0, xs);
+    vload<VEC>(pb, a0);
+    vload<VEC>(pb + a.plane_stride, a1);
+    if (K == 3) vload<VEC>(pb + 2 * a.plane_stride, a2);
+    float r0[VEC], r1[VEC], r2[VEC];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < VEC; ++e) {
       float llk = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
       if (g0 + e < a.G) {
-        count_elem<LK, DIRECT>(xs[e], a0[e], a1[e], a2[e], llk, d0, d1, d2);
+        count_elem<LK, DIRECT>(xs[e], a0[e], a1[e], K == 3 ? a2[e] : 0.f, llk, d0, d1, d2);
         acc += llk;
       }
       r0[e] = d0 * a.grad_scale; r1[e] = d1 * a.grad_scale; r2[e] = d2 * a.grad_scale;
     }
     if (BWD) {
       float* db = a.dP + (long)b * a.ldp + g0;
-      *reinterpret_cast<float4*>(db) = make_float4(r0[0], r0[1], r0[2], r0[3]);
-      *reinterpret_cast<float4*>(db + a.plane_stride) = make_float4(r1[0], r1[1], r1[2], r1[3]);
-      if (K == 3) *reinterpret_cast<float4*>(db + 2 * a.plane_stride) = make_float4(r2[0], r2[1], r2[2], r2[3]);
+      vstore<VEC>(db, r0);
+      vstore<VEC>(db + a.plane_stride, r1);
+      if (K == 3) vstore<VEC>(db + 2 * a.plane_stride, r2);
     }
   }
   __shared__ float red[4];
@@ -105,12 +127,24 @@ __global__ __launch_bounds__(256) void count_loss_kernel(LossArgs a) {
   if (threadIdx.x == 0) a.llk_part[(long)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-int loss_chunks(int Gp) { return (Gp + 1023) / 1024; }
+static int g_loss_vec = 0;
+static int loss_vec() {
+  if (!g_loss_vec) {
+    const char* e = getenv("SMX_LOSS_VEC");
+    g_loss_vec = e ? atoi(e) : 2;
+    if (g_loss_vec != 1 && g_loss_vec != 2 && g_loss_vec != 4) g_loss_vec = 2;
+  }
+  return g_loss_vec;
+}
+int loss_chunks(int Gp) { return (Gp + 256 * loss_vec() - 1) / (256 * loss_vec()); }
 
 template <int LK, int DIRECT>
 static void launch_loss_t(hipStream_t st, const LossArgs& a, dim3 grid) {
-  if (a.backward) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, 1>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, 0>), grid, dim3(256), 0, st, a);
+  const int v = loss_vec();
+#define SMX_LOSS_LAUNCH(B_, V_) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_>), grid, dim3(256), 0, st, a)
+  if (a.backward) { if (v == 4) SMX_LOSS_LAUNCH(1, 4); else if (v == 2) SMX_LOSS_LAUNCH(1, 2); else SMX_LOSS_LAUNCH(1, 1); }
+  else { if (v == 4) SMX_LOSS_LAUNCH(0, 4); else if (v == 2) SMX_LOSS_LAUNCH(0, 2); else SMX_LOSS_LAUNCH(0, 1); }
+#undef SMX_LOSS_LAUNCH
 }
 
 int launch_count_loss(hipStream_t st, const LossArgs& a) {
@@ -135,39 +169,76 @@ int launch_count_loss(hipStream_t st, const LossArgs& a) {
 }
 
 // ===========================================================================
-// BatchNorm + ReLU + Dropout.  A workgroup owns 8 columns (all rows):
-// thread = (column c = tid & 7, row lane rl = tid >> 3), rows rl, rl+32, ...
+// BatchNorm + ReLU + Dropout.  A workgroup owns BN_COLS columns and all rows:
+// thread = (column c = tid % BN_COLS, row lane rl = tid / BN_COLS); rows are walked
+// in chunks of BN_RL * BN_RPT with every slab load of a chunk in flight at once
+// (the kernel is a latency chain, not a bandwidth problem).
 // ===========================================================================
-constexpr int BN_COLS = 8;
-constexpr int BN_RL = 32;
+constexpr int BN_COLS = 4;
+constexpr int BN_RL = 64;
+constexpr int BN_RPT = 2;
 
-__device__ inline float bn_col_reduce(float v, float* sh /*[32][8]*/) {
-  const int c = threadIdx.x & 7, rl = threadIdx.x >> 3;
+__device__ inline float bn_col_reduce(float v, float* sh /*[BN_RL][BN_COLS]*/) {
+  const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   __syncthreads();
   sh[rl * BN_COLS + c] = v;
   __syncthreads();
   float s = 0.f;
-#pragma unroll
+#pragma unroll 16
   for (int i = 0; i < BN_RL; ++i) s += sh[i * BN_COLS + c];  // fixed order: deterministic
   return s;
 }
 
+// sum of the split-K slabs for BN_RPT rows of one column, loads issued together
+__device__ inline void slab_sum(const float* base, int n_slabs, long slab_stride, int ld, int col, int r0, int rl,
+                                int B, float (&acc)[BN_RPT]) {
+#pragma unroll
+  for (int i = 0; i < BN_RPT; ++i) acc[i] = 0.f;
+  int s = 0;
+  for (; s + 4 <= n_slabs; s += 4) {
+    float t[4][BN_RPT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < BN_RPT; ++i) {
+        const int r = r0 + rl + BN_RL * i;
+        t[q][i] = r < B ? base[(long)(s + q) * slab_stride + (long)r * ld + col] : 0.f;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < BN_RPT; ++i) acc[i] += t[q][i];
+  }
+  for (; s < n_slabs; ++s)
+#pragma unroll
+    for (int i = 0; i < BN_RPT; ++i) {
+      const int r = r0 + rl + BN_RL * i;
+      if (r < B) acc[i] += base[(long)s * slab_stride + (long)r * ld + col];
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
   __shared__ float sh[BN_RL * BN_COLS];
-  const int c = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = blockIdx.x * BN_COLS + c;
   const bool live = col < a.H;  // padded columns produce zeros
   const float bias = (!a.batchnorm && a.bias && live) ? a.bias[col] : 0.f;
+  constexpr int CH = BN_RL * BN_RPT;
 
   // pass 1: slab sum (+ bias) -> xhat buffer (scratch), column sum
   float s1 = 0.f;
-  for (int r = rl; r < a.B; r += BN_RL) {
-    float v = 0.f;
-    const float* p = a.pre + (long)r * a.ld + col;
-    for (int s = 0; s < a.n_slabs; ++s) v += p[(long)s * a.slab_stride];
-    v += bias;
-    a.xhat[(long)r * a.Hp + col] = v;
-    s1 += v;
+  for (int r0 = 0; r0 < a.B; r0 += CH) {
+    float acc[BN_RPT];
+    slab_sum(a.pre, a.n_slabs, a.slab_stride, a.ld, col, r0, rl, a.B, acc);
+#pragma unroll
+    for (int i = 0; i < BN_RPT; ++i) {
+      const int r = r0 + rl + BN_RL * i;
+      if (r < a.B) {
+        const float v = acc[i] + bias;
+        a.xhat[(long)r * a.Hp + col] = v;
+        s1 += v;
+      }
+    }
   }
   float mean = 0.f, inv = 1.f, gamma = 1.f, beta = 0.f;
   if (a.batchnorm) {
@@ -198,7 +269,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
     inv = rsqrtf(var + a.eps);
     if (rl == 0 && a.inv_std) a.inv_std[col] = inv;
   }
-  const float scale = (a.training && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
+  const bool drop = a.training && a.drop_p > 0.f;
+  const float scale = drop ? 1.f / (1.f - a.drop_p) : 1.f;
   for (int r = rl; r < a.B; r += BN_RL) {
     const long o = (long)r * a.Hp + col;
     float v = a.xhat[o];
@@ -209,7 +281,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
       a.xhat[o] = v;
     }
     float h = fmaxf(y, 0.f);
-    if (a.training && a.drop_p > 0.f) {
+    if (drop) {
       float mult;
       if (a.inj_mask) mult = a.inj_mask[(long)r * a.inj_ld + col];
       else {
@@ -232,19 +304,25 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a) {
 
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdArgs a) {
   __shared__ float sh[BN_RL * BN_COLS];
-  const int c = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = blockIdx.x * BN_COLS + c;
   const bool live = col < a.H;
+  constexpr int CH = BN_RL * BN_RPT;
   float s1 = 0.f, s2 = 0.f;
-  for (int r = rl; r < a.B; r += BN_RL) {
-    const long o = (long)r * a.Hp + col;
-    float g = 0.f;
-    const float* p = a.dout + (long)r * a.ld + col;
-    for (int s = 0; s < a.n_slabs; ++s) g += p[(long)s * a.slab_stride];
-    const float dy = (live && a.out[o] > 0.f) ? g * a.drop_scale : 0.f;
-    a.dpre[o] = dy;
-    s1 += dy;
-    if (a.batchnorm) s2 += dy * a.xhat[o];
+  for (int r0 = 0; r0 < a.B; r0 += CH) {
+    float acc[BN_RPT];
+    slab_sum(a.dout, a.n_slabs, a.slab_stride, a.ld, col, r0, rl, a.B, acc);
+#pragma unroll
+    for (int i = 0; i < BN_RPT; ++i) {
+      const int r = r0 + rl + BN_RL * i;
+      if (r < a.B) {
+        const long o = (long)r * a.Hp + col;
+        const float dy = (live && a.out[o] > 0.f) ? acc[i] * a.drop_scale : 0.f;
+        a.dpre[o] = dy;
+        s1 += dy;
+        if (a.batchnorm) s2 += dy * a.xhat[o];
+      }
+    }
   }
   s1 = bn_col_reduce(s1, sh);
   if (!a.batchnorm) {

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import sisua_oracle as so
-from tests.util import make_pair, perturbed_params, rel_l2, synth_counts, synth_labels
+from tests.util import grad_errors, make_pair, perturbed_params, rel_l2, synth_counts, synth_labels
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -76,13 +76,17 @@ def test_one_step_matches_oracle(Engine, name, batch):
   if spec.model == "scvi":
     assert np.isclose(m["kl_l"], res["metrics"]["kl_l"], rtol=RTOL, atol=1e-5)
   grads = e.get_params(which=1)
-  worst = {k: rel_l2(grads[k], res["grads"][k]) for k in grads}
+  worst = grad_errors(grads, res["grads"])
   assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
   newp = e.get_params()
-  for k in newp:  # the first Adam step moves every weight by ~lr: compare the update itself
-    assert rel_l2(newp[k] - p0[k], params[k] - p0[k]) < 2e-3, k
-    # |dw| <= lr * |dg| / (|g| + 3e-6): fp32 noise on near-zero gradients moves a weight by << lr
-    assert np.allclose(newp[k], params[k], rtol=1e-5, atol=1e-4), k
+  top = max(np.linalg.norm(v) for v in res["grads"].values())
+  for k in newp:
+    # first Adam step: dw = lr * g / (|g| + 3.2e-6), so fp32 noise dg on a near-zero gradient moves a
+    # weight by up to lr * |dg| / 3.2e-6 (< lr/2); everywhere else the update is ~lr * sign(g)
+    assert np.allclose(newp[k], params[k], rtol=1e-5, atol=5e-4), k
+    big = np.abs(res["grads"][k]) > 1e-3 * np.abs(res["grads"][k]).max()
+    if big.any() and np.linalg.norm(res["grads"][k]) > 1e-3 * top:  # skip analytically-zero gradients
+      assert rel_l2((newp[k] - p0[k])[big], (params[k] - p0[k])[big]) < 1e-2, k
   names = [p for p, _ in so.bn_manifest(spec)]
   for i, st in e.get_bn().items():
     assert np.allclose(st["moving_mean"], bn[f"{names[i]}/moving_mean"], rtol=1e-4, atol=1e-6)
@@ -122,7 +126,7 @@ def test_injected_noise_matches_oracle(Engine, name):
   m = e.train_step(rows)
   assert np.isclose(m["loss"], res["loss"], rtol=RTOL)
   grads = e.get_params(which=1)
-  worst = {k: rel_l2(grads[k], res["grads"][k]) for k in grads}
+  worst = grad_errors(grads, res["grads"])
   assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
   e.close()
 
