@@ -156,6 +156,11 @@ int smx_forward(smx_model* m, const int32_t* row_ids, const float* host_x, const
                 float* z_sample, float* l_mean, float* l_scale, float* l_sample, float* x_params,
                 float* const* y_params);
 
+/* Decoder only (SingleCellModel.decode, single_cell_model.py:141-151; scvi.py:108-171):
+ * z [batch,D] (and l [batch] for scvi) -> the same x_params / y_params as smx_forward,
+ * eval mode. */
+int smx_decode(smx_model* m, const float* z, const float* l, int32_t batch, float* x_params, float* const* y_params);
+
 /* Test hook: inject noise for the NEXT step instead of Philox.  stream ids as in
  * oracle/sisua_oracle.py (STREAM_*); data [batch, width] holds eps values or
  * dropout multipliers.  smx_clear_noise() returns to Philox. */

@@ -349,9 +349,10 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
   return SMX_OK;
 }
 
-int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward) {
+int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, bool decode_only = false) {
   const smx_config& c = m->cfg;
   const float inv_gb = 1.f / (float)ps.global_batch;
+  if (!decode_only) {
   // ---- encoder ----
   SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd"));
   const MlpLayer& eL = m->enc.back();
@@ -392,6 +393,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward) {
     ll.l = m->lsmp; ll.sig = m->lsig; ll.eps = m->leps; ll.kl = m->kl_l;
     SMX_CHECK(launch_lib_latent_fwd(m->st, ll));
   }
+  }  // !decode_only
   // ---- decoder ----
   SMX_CHECK(mlp_forward(m, m->dec, ps, m->z, m->Dp, false, ""));
   const MlpLayer& dL = m->dec.back();
@@ -1077,6 +1079,39 @@ int smx_forward(smx_model* m, const int32_t* row_ids, const float* host_x, const
       SMX_CHECK(fetch2d(x_params + (size_t)ch * B * G, m->P + (size_t)ch * Gp, m->k * Gp, G));
   }
   if (y_params) {
+    for (int j = 0; j < m->cfg.n_labels; ++j) {
+      if (!y_params[j]) continue;
+      const int P = m->cfg.label_dim[j], Pp = m->lab_Pp[j], ld = m->tensors[m->t_labW[j]].ld;
+      tmp.resize((size_t)B * ld);
+      SMX_HIP(hipMemcpy(tmp.data(), m->laby_raw[j], tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+      for (int b = 0; b < B; ++b)
+        for (int c = 0; c < m->lab_ky[j]; ++c)
+          memcpy(y_params[j] + ((size_t)b * m->lab_ky[j] + c) * P, &tmp[(size_t)b * ld + (size_t)c * Pp], sizeof(float) * P);
+    }
+  }
+  return SMX_OK;
+}
+
+int smx_decode(smx_model* m, const float* z, const float* l, int32_t batch, float* x_params, float* const* y_params) {
+  SMX_REQUIRE(m && z, "null argument");
+  SMX_REQUIRE(batch > 0 && batch <= m->Bmax, "batch must be in 1..max_batch");
+  SMX_REQUIRE(!m->scvi || l, "scvi decode needs the library latent");
+  Pass ps;
+  ps.B = batch; ps.training = 0; ps.sample = 0; ps.global_batch = batch; ps.rows = nullptr; ps.Xsrc = m->hostX;
+  ps.lib = m->hostLib; ps.lgx1 = m->hostLgx1; ps.cell_base = 0;
+  SMX_HIP(hipMemsetAsync(m->z, 0, (size_t)batch * m->Dp * sizeof(float), m->st));
+  SMX_HIP(hipMemcpy2DAsync(m->z, (size_t)m->Dp * sizeof(float), z, (size_t)m->D * sizeof(float), (size_t)m->D * sizeof(float),
+                           (size_t)batch, hipMemcpyHostToDevice, m->st));
+  if (m->scvi) SMX_HIP(hipMemcpyAsync(m->lsmp, l, (size_t)batch * sizeof(float), hipMemcpyHostToDevice, m->st));
+  SMX_CHECK(forward_pass(m, ps, false, false, true));
+  SMX_HIP(hipStreamSynchronize(m->st));
+  const int B = batch, G = m->G, Gp = m->Gp;
+  if (x_params)
+    for (int ch = 0; ch < m->k; ++ch)
+      SMX_HIP(hipMemcpy2D(x_params + (size_t)ch * B * G, (size_t)G * sizeof(float), m->P + (size_t)ch * Gp,
+                          (size_t)m->k * Gp * sizeof(float), (size_t)G * sizeof(float), (size_t)B, hipMemcpyDeviceToHost));
+  if (y_params) {
+    std::vector<float> tmp;
     for (int j = 0; j < m->cfg.n_labels; ++j) {
       if (!y_params[j]) continue;
       const int P = m->cfg.label_dim[j], Pp = m->lab_Pp[j], ld = m->tensors[m->t_labW[j]].ld;

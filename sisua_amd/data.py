@@ -162,3 +162,136 @@ def synthetic_scalability(n: int, seed: int = 8):
   randint(0,10,(n,10)) proteins (tests/test_scalability.py:22-27)."""
   rng = np.random.default_rng(seed)
   return rng.integers(0, 100, size=(n, 500)).astype(np.float32), rng.integers(0, 10, size=(n, 10)).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# Minimal multi-omic container + minibatch description: what SingleCellModel.fit /
+# predict need from SingleCellOMIC (data/_single_cell_base.py) without AnnData.
+# ---------------------------------------------------------------------------
+class BatchDataset:
+  """What `SingleCellOMIC.create_dataset` returns in the reference (a tf.data pipeline of
+  dict(inputs, library, mask) batches, _single_cell_base.py:539-602), as plain arrays plus
+  the batching recipe; the arrays are uploaded to HBM once and minibatches are row ids."""
+
+  def __init__(self, arrays: Sequence[np.ndarray], omics: Sequence[str], library: np.ndarray, mask: np.ndarray,
+               batch_size: int = 64, drop_remainder: bool = False, shuffle: int = 1000, seed: int = 1):
+    self.arrays = [np.ascontiguousarray(a, dtype=np.float32) for a in arrays]
+    self.omics = list(omics)
+    self.library = np.ascontiguousarray(library, dtype=np.float32)
+    self.mask = np.ascontiguousarray(mask, dtype=bool)
+    self.batch_size, self.drop_remainder, self.shuffle, self.seed = int(batch_size), bool(drop_remainder), int(shuffle or 0), int(seed)
+
+  @property
+  def n_obs(self):
+    return self.arrays[0].shape[0]
+
+  def epoch_batches(self, epoch: int) -> List[np.ndarray]:
+    return iter_batches(epoch_order(self.n_obs, epoch, self.shuffle, self.seed), self.batch_size, self.drop_remainder)
+
+  def steps_per_epoch(self) -> int:
+    n = self.n_obs
+    return n // self.batch_size if self.drop_remainder else -(-n // self.batch_size)
+
+  def __iter__(self):
+    for ids in self.epoch_batches(0):
+      inputs = [a[ids] for a in self.arrays]
+      yield dict(inputs=inputs[0] if len(inputs) == 1 else inputs, library=self.library[ids], mask=self.mask[ids])
+
+
+class SingleCellOMIC:
+  """Multi-omic cells x features container with the methods the training path calls on the
+  reference's SingleCellOMIC: split, corrupt, library statistics, create_dataset, get_rv."""
+
+  def __init__(self, X, var_names=None, name: str = "scOMICS", omic: str = "transcriptomic"):
+    self.name = name
+    self._data, self._vars = {}, {}
+    self.add_omic(omic, X, var_names)
+
+  def add_omic(self, omic: str, X, var_names=None):
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    if self._data and X.shape[0] != self.n_obs:
+      raise ValueError(f"Number of cell mismatch {self.n_obs} and {X.shape[0]}")
+    self._data[str(omic)] = X
+    self._vars[str(omic)] = np.array([f"{omic}{i}" for i in range(X.shape[1])]) if var_names is None else np.asarray(var_names)
+    return self
+
+  @property
+  def omics(self):
+    return list(self._data)
+
+  @property
+  def n_omics(self):
+    return len(self._data)
+
+  @property
+  def n_obs(self):
+    return next(iter(self._data.values())).shape[0]
+
+  def get_omic(self, omic):
+    return self._data[str(omic)]
+
+  def numpy(self, omic=None):
+    return self._data[str(omic) if omic is not None else self.omics[0]]
+
+  def get_dim(self, omic):
+    return self._data[str(omic)].shape[1]
+
+  def get_var_names(self, omic):
+    return self._vars[str(omic)]
+
+  def __getitem__(self, ids):
+    out = None
+    for om in self.omics:
+      if out is None:
+        out = SingleCellOMIC(self._data[om][ids], self._vars[om], name=self.name, omic=om)
+      else:
+        out.add_omic(om, self._data[om][ids], self._vars[om])
+    return out
+
+  def copy(self):
+    return self[np.arange(self.n_obs)]
+
+  def split(self, train_percent=0.8, copy=True, seed=1):
+    tr, te = split_indices(self.n_obs, train_percent, seed)
+    return (None if len(tr) == 0 else self[tr]), (None if len(te) == 0 else self[te])
+
+  def corrupt(self, dropout_rate=0.2, retain_rate=0.2, distribution="binomial", omic=None, inplace=True, seed=8):
+    om = self if inplace else self.copy()
+    key = str(omic) if omic is not None else om.omics[0]
+    corrupt(om._data[key], dropout_rate, retain_rate, distribution, seed, inplace=True)
+    return om
+
+  def sparsity(self, omic=None):
+    return float((self.numpy(omic) == 0).mean())
+
+  def library_size(self, omic=None):
+    return library_matrix(self.numpy(omic))
+
+  def get_rv(self, omic, distribution=None):
+    from sisua_amd.config import RVmeta
+    omic = str(omic)
+    if distribution is None:
+      if omic in ("transcriptomic", "atac", "chromatin"):
+        distribution = "zinb"
+      elif omic == "proteomic":
+        distribution = "nb"
+      elif omic in ("celltype", "disease", "progenitor"):
+        distribution = "onehot"
+      else:
+        raise ValueError(f"No default distribution for OMIC {omic}")
+    return RVmeta(event_shape=self.get_dim(omic), posterior=distribution, projection=True, name=omic)
+
+  create_rv = get_rv
+
+  def create_dataset(self, omics=None, labels_percent=0, batch_size=64, drop_remainder=False, shuffle=1000, seed=1):
+    if omics is None:
+      omics = [self.omics[0]]
+    if isinstance(omics, str):
+      omics = [omics]
+    omics = [str(o) for o in omics]
+    arrays = [self.get_omic(o) for o in omics]
+    return BatchDataset(arrays, omics, self.library_size(omics[0]), label_mask(self.n_obs, labels_percent, len(omics), seed),
+                        batch_size, drop_remainder, shuffle, seed)
+
+  def __repr__(self):
+    return f"<SingleCellOMIC '{self.name}' n_obs={self.n_obs} " + " ".join(f"{o}:{self.get_dim(o)}" for o in self.omics) + ">"

@@ -1,0 +1,326 @@
+"""Result objects of predict / encode / decode.
+
+The reference returns TensorFlow-Probability distributions and its consumers
+(sisua/analysis/posterior.py:187-220, 233-249, 927-937; tests/test_save_load_model.py:32-46)
+touch only `.mean() .variance() .stddev() .sample(n) .log_prob(x) .batch_shape
+.event_shape .name`, `Independent.distribution / .reinterpreted_batch_ndims` and
+`ZeroInflated.count_distribution`.  These classes carry the parameter arrays the
+GPU forward produced (NumPy, host side) and implement exactly that surface; they
+are result containers, not part of the training hot path.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+from scipy.special import gammaln
+
+SOFTPLUS_INV_1 = float(np.log(np.expm1(1.0)))
+
+
+def _softplus(x):
+  return np.logaddexp(0.0, x)
+
+
+def _log_sigmoid(x):
+  return -_softplus(-x)
+
+
+class Distribution:
+  name: str = "Distribution"
+  _event_ndims = 0
+
+  def _params(self) -> List[np.ndarray]:
+    raise NotImplementedError
+
+  @property
+  def batch_shape(self):
+    s = np.broadcast_shapes(*[np.shape(p) for p in self._params()])
+    return tuple(s[:len(s) - self._event_ndims])
+
+  @property
+  def event_shape(self):
+    s = np.broadcast_shapes(*[np.shape(p) for p in self._params()])
+    return tuple(s[len(s) - self._event_ndims:])
+
+  def mean(self):
+    raise NotImplementedError
+
+  def variance(self):
+    raise NotImplementedError
+
+  def stddev(self):
+    return np.sqrt(self.variance())
+
+  def log_prob(self, x):
+    raise NotImplementedError
+
+  def sample(self, sample_shape=(), seed=None):
+    raise NotImplementedError
+
+  def _sshape(self, sample_shape):
+    if isinstance(sample_shape, (int, np.integer)):
+      return (int(sample_shape),)
+    return tuple(int(s) for s in sample_shape)
+
+  def __repr__(self):
+    return f"<{type(self).__name__} '{self.name}' batch_shape={self.batch_shape} event_shape={self.event_shape}>"
+
+
+class Normal(Distribution):
+
+  def __init__(self, loc, scale, name="Normal"):
+    self.loc, self.scale, self.name = np.asarray(loc), np.asarray(scale), name
+
+  def _params(self):
+    return [self.loc, self.scale]
+
+  def mean(self):
+    return np.broadcast_to(self.loc, np.broadcast_shapes(self.loc.shape, self.scale.shape)).copy()
+
+  def variance(self):
+    return np.broadcast_to(self.scale ** 2, np.broadcast_shapes(self.loc.shape, self.scale.shape)).copy()
+
+  def log_prob(self, x):
+    z = (np.asarray(x) - self.loc) / self.scale
+    return -0.5 * z * z - np.log(self.scale) - 0.5 * np.log(2 * np.pi)
+
+  def sample(self, sample_shape=(), seed=None):
+    rng = np.random.default_rng(seed)
+    shp = self._sshape(sample_shape) + np.broadcast_shapes(self.loc.shape, self.scale.shape)
+    return self.loc + self.scale * rng.standard_normal(shp)
+
+
+class MultivariateNormalDiag(Normal):
+  """Diagonal Gaussian over the last axis (the 'diag' latent posterior)."""
+  _event_ndims = 1
+
+  def __init__(self, loc, scale_diag, name="MultivariateNormalDiag"):
+    super().__init__(loc, scale_diag, name)
+
+  def log_prob(self, x):
+    return super().log_prob(x).sum(-1)
+
+
+class Deterministic(Distribution):
+  """Point mass (DCA's deterministic latent, dca.py:13-28)."""
+  _event_ndims = 1
+
+  def __init__(self, loc, name="Deterministic"):
+    self.loc, self.name = np.asarray(loc), name
+
+  def _params(self):
+    return [self.loc]
+
+  def mean(self):
+    return self.loc.copy()
+
+  def variance(self):
+    return np.zeros_like(self.loc)
+
+  def sample(self, sample_shape=(), seed=None):
+    return np.broadcast_to(self.loc, self._sshape(sample_shape) + self.loc.shape).copy()
+
+  def log_prob(self, x):
+    return np.where(np.all(np.asarray(x) == self.loc, axis=-1), 0.0, -np.inf)
+
+
+class NegativeBinomial(Distribution):
+  """TFP convention: total_count r, logits l; mean = r exp(l)."""
+
+  def __init__(self, total_count, logits, name="NegativeBinomial"):
+    self.total_count, self.logits, self.name = np.asarray(total_count), np.asarray(logits), name
+
+  def _params(self):
+    return [self.total_count, self.logits]
+
+  def mean(self):
+    return self.total_count * np.exp(self.logits)
+
+  def variance(self):
+    return self.mean() * (1.0 + np.exp(self.logits))
+
+  def log_prob(self, x):
+    x, r, l = np.asarray(x, dtype=np.float64), self.total_count.astype(np.float64), self.logits.astype(np.float64)
+    return gammaln(x + r) - gammaln(r) - gammaln(x + 1.0) + x * _log_sigmoid(l) + r * _log_sigmoid(-l)
+
+  def sample(self, sample_shape=(), seed=None):
+    rng = np.random.default_rng(seed)
+    shp = self._sshape(sample_shape) + np.broadcast_shapes(self.total_count.shape, self.logits.shape)
+    lam = rng.gamma(np.broadcast_to(self.total_count, shp), np.broadcast_to(np.exp(self.logits), shp))
+    return rng.poisson(lam).astype(np.float32)
+
+
+class NegativeBinomialDisp(Distribution):
+  """Mean / dispersion form (scVI): var = mean + mean^2 / disp."""
+
+  def __init__(self, loc, disp, name="NegativeBinomialDisp", eps=1e-8):
+    self.loc, self.disp, self.name, self.eps = np.asarray(loc), np.asarray(disp), name, eps
+
+  def _params(self):
+    return [self.loc, self.disp]
+
+  def mean(self):
+    return np.broadcast_to(self.loc, np.broadcast_shapes(self.loc.shape, self.disp.shape)).copy()
+
+  def variance(self):
+    return self.loc + self.loc ** 2 / self.disp
+
+  def log_prob(self, x):
+    x, mu, th, e = np.asarray(x, np.float64), self.loc.astype(np.float64), self.disp.astype(np.float64), self.eps
+    lt = np.log(th + mu + e)
+    return (th * (np.log(th + e) - lt) + x * (np.log(mu + e) - lt) + gammaln(x + th) - gammaln(th) - gammaln(x + 1.0))
+
+  def sample(self, sample_shape=(), seed=None):
+    rng = np.random.default_rng(seed)
+    shp = self._sshape(sample_shape) + np.broadcast_shapes(self.loc.shape, self.disp.shape)
+    lam = rng.gamma(np.broadcast_to(self.disp, shp), np.broadcast_to(self.loc / self.disp, shp))
+    return rng.poisson(lam).astype(np.float32)
+
+
+class ZeroInflated(Distribution):
+  """pi = sigmoid(logits) mass at zero mixed with `count_distribution`."""
+
+  def __init__(self, count_distribution: Distribution, logits, name="ZeroInflated"):
+    self.count_distribution, self.logits, self.name = count_distribution, np.asarray(logits), name
+
+  def _params(self):
+    return self.count_distribution._params() + [self.logits]
+
+  @property
+  def probs(self):
+    return 1.0 / (1.0 + np.exp(-self.logits))
+
+  def mean(self):
+    return (1.0 - self.probs) * self.count_distribution.mean()
+
+  def variance(self):
+    pi, m, v = self.probs, self.count_distribution.mean(), self.count_distribution.variance()
+    return (1.0 - pi) * (v + pi * m * m)
+
+  def log_prob(self, x):
+    x = np.asarray(x, np.float64)
+    g = self.logits.astype(np.float64)
+    ell = self.count_distribution.log_prob(x)
+    return np.where(x == 0, np.logaddexp(g, ell), ell) - _softplus(g)
+
+  def sample(self, sample_shape=(), seed=None):
+    rng = np.random.default_rng(seed)
+    s = self.count_distribution.sample(sample_shape, seed=rng.integers(1 << 31))
+    keep = rng.uniform(size=s.shape) >= np.broadcast_to(self.probs, s.shape)
+    return s * keep
+
+
+class OneHotCategorical(Distribution):
+  _event_ndims = 1
+
+  def __init__(self, logits, name="OneHotCategorical"):
+    self.logits, self.name = np.asarray(logits), name
+
+  def _params(self):
+    return [self.logits]
+
+  def _logp(self):
+    m = self.logits.max(-1, keepdims=True)
+    return self.logits - (m + np.log(np.exp(self.logits - m).sum(-1, keepdims=True)))
+
+  def mean(self):
+    return np.exp(self._logp())
+
+  def variance(self):
+    p = self.mean()
+    return p * (1 - p)
+
+  def log_prob(self, x):
+    return (np.asarray(x) * self._logp()).sum(-1)
+
+  def sample(self, sample_shape=(), seed=None):
+    rng = np.random.default_rng(seed)
+    p = self.mean()
+    shp = self._sshape(sample_shape) + p.shape[:-1]
+    u = rng.uniform(size=shp + (1,))
+    idx = (u > np.cumsum(np.broadcast_to(p, shp + p.shape[-1:]), -1)).sum(-1).clip(0, p.shape[-1] - 1)
+    return np.eye(p.shape[-1], dtype=np.float32)[idx]
+
+
+class Independent(Distribution):
+  """Reinterprets the last `reinterpreted_batch_ndims` batch axes as event axes."""
+
+  def __init__(self, distribution: Distribution, reinterpreted_batch_ndims: int = 1, name=None):
+    self.distribution = distribution
+    self.reinterpreted_batch_ndims = int(reinterpreted_batch_ndims)
+    self.name = name or distribution.name
+
+  def _params(self):
+    return self.distribution._params()
+
+  @property
+  def batch_shape(self):
+    b = self.distribution.batch_shape
+    return tuple(b[:len(b) - self.reinterpreted_batch_ndims])
+
+  @property
+  def event_shape(self):
+    b = self.distribution.batch_shape
+    return tuple(b[len(b) - self.reinterpreted_batch_ndims:]) + tuple(self.distribution.event_shape)
+
+  def mean(self):
+    return self.distribution.mean()
+
+  def variance(self):
+    return self.distribution.variance()
+
+  def sample(self, sample_shape=(), seed=None):
+    return self.distribution.sample(sample_shape, seed)
+
+  def log_prob(self, x):
+    lp = self.distribution.log_prob(x)
+    return lp.sum(axis=tuple(range(-self.reinterpreted_batch_ndims, 0)))
+
+
+# ---------------------------------------------------------------------------
+def _cat(arrs, axis):
+  return np.concatenate([np.asarray(a) for a in arrs], axis=axis)
+
+
+def concat_distributions(dists: Sequence[Distribution], axis: int = 0, name: Optional[str] = None) -> Distribution:
+  """Merge per-minibatch distributions along a batch axis (odin `concat_distributions`,
+  used by SingleCellModel.predict, single_cell_model.py:184-210)."""
+  d0 = dists[0]
+  nm = name or d0.name
+  if isinstance(d0, Independent):
+    return Independent(concat_distributions([d.distribution for d in dists], axis, d0.distribution.name),
+                       d0.reinterpreted_batch_ndims, name=nm)
+  if isinstance(d0, ZeroInflated):
+    return ZeroInflated(concat_distributions([d.count_distribution for d in dists], axis, d0.count_distribution.name),
+                        _cat([d.logits for d in dists], axis), name=nm)
+  if isinstance(d0, MultivariateNormalDiag):
+    return MultivariateNormalDiag(_cat([d.loc for d in dists], axis), _cat([d.scale for d in dists], axis), name=nm)
+  if isinstance(d0, Normal):
+    return Normal(_cat([d.loc for d in dists], axis), _cat([d.scale for d in dists], axis), name=nm)
+  if isinstance(d0, Deterministic):
+    return Deterministic(_cat([d.loc for d in dists], axis), name=nm)
+  if isinstance(d0, NegativeBinomial):
+    return NegativeBinomial(_cat([d.total_count for d in dists], axis), _cat([d.logits for d in dists], axis), name=nm)
+  if isinstance(d0, NegativeBinomialDisp):
+    return NegativeBinomialDisp(_cat([d.loc for d in dists], axis), _cat([d.disp for d in dists], axis), name=nm)
+  if isinstance(d0, OneHotCategorical):
+    return OneHotCategorical(_cat([d.logits for d in dists], axis), name=nm)
+  raise TypeError(f"cannot concatenate {type(d0)}")
+
+
+def count_distribution(likelihood: str, planes, name: str, activated: bool) -> Distribution:
+  """Build the output distribution from the parameter planes of smx_forward.
+  nb/zinb planes: (log total_count, logits[, gate]); nbd/zinbd: pre-activation
+  (softplus mean, softplus1 dispersion) unless `activated` (scvi feeds mean/disp)."""
+  if likelihood in ("nb", "zinb"):
+    base = NegativeBinomial(np.exp(planes[0]), planes[1], name="NegativeBinomial")
+  else:
+    if activated:
+      mu, th = planes[0], planes[1]
+    else:
+      mu, th = _softplus(planes[0]), _softplus(planes[1] + SOFTPLUS_INV_1)
+    base = NegativeBinomialDisp(mu, th, name="NegativeBinomialDisp")
+  if likelihood in ("zinb", "zinbd"):
+    base = ZeroInflated(base, planes[2], name="ZeroInflated")
+  return Independent(base, 1, name=name)

@@ -214,6 +214,20 @@ class Engine:
     out["y_params"] = ys
     return out
 
+  def decode(self, z, l=None):
+    """Decoder + output heads from given latents (eval mode)."""
+    cfg = self.cfg
+    za = _f32(z)
+    B = za.shape[0]
+    if za.shape[1] != cfg.latent_dim:
+      raise ValueError(f"z must be [batch, {cfg.latent_dim}]")
+    la = None if l is None else _f32(np.reshape(l, (B,)))
+    xp = np.empty((cfg.k, B, cfg.n_genes), np.float32)
+    ys = [np.empty((B, (2 if llk == "nb" else 1) * P), np.float32) for P, llk in cfg.labels]
+    yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
+    check(self.lib.smx_decode(self._h, _fp(za), _fp(la), B, _fp(xp), yptrs))
+    return dict(x_params=xp, y_params=ys)
+
   # ---- noise injection (parity tests) ----------------------------------------------
   def set_noise(self, stream: int, data):
     a = _f32(data)

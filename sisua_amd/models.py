@@ -1,0 +1,630 @@
+"""Model classes with the reference's operator surface.
+
+`SingleCellModel`, `VAE`, `SISUA`, `SCVI`, `DeepCountAutoencoder`, `get_model`,
+`get_all_models`, `load_model` keep the names, constructor arguments, method
+signatures and error behaviour of sisua/models/{single_cell_model,vae,scvi,dca,__init__}.py
+so that `sisua.train` / `sisua.analysis` style callers can switch packages.  Everything
+numeric is delegated to libsisua_hip.so through `Engine`; this module holds no arithmetic
+of the training step.
+"""
+from __future__ import annotations
+
+import inspect
+import os
+import pickle
+import time
+import warnings
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from sisua_amd import distributions as D
+from sisua_amd.config import ModelConfig, NetConf, RVmeta, init_params
+from sisua_amd.data import BatchDataset, SingleCellOMIC, library_matrix
+from sisua_amd.engine import Engine
+
+__all__ = ["SingleCellModel", "VAE", "SISUA", "SCVI", "DeepCountAutoencoder", "NetConf", "RVmeta", "get_model",
+           "get_all_models", "load_model"]
+
+_OMIC_ORDER = ["transcriptomic", "proteomic", "celltype", "disease", "progenitor", "chromatin"]
+
+
+class classproperty:
+
+  def __init__(self, fn):
+    self.fn = fn
+
+  def __get__(self, obj, owner):
+    return self.fn(owner)
+
+
+def _flatten(x):
+  if x is None:
+    return []
+  if isinstance(x, (list, tuple)):
+    out = []
+    for i in x:
+      out += _flatten(i)
+    return out
+  return [x]
+
+
+def _to_data(x, batch_size=64) -> BatchDataset:
+  """single_cell_model.py:44-61: SingleCellOMIC -> its dataset; prepared dataset -> itself;
+  raw ndarray(s) -> wrapped, further arrays assigned the next OMIC names in order."""
+  if isinstance(x, SingleCellOMIC):
+    return x.create_dataset(batch_size=batch_size)
+  if isinstance(x, BatchDataset):
+    return x
+  arrs = _flatten(x)
+  sco = SingleCellOMIC(np.asarray(arrs[0]))
+  for arr, om in zip(arrs[1:], _OMIC_ORDER[1:]):
+    sco.add_omic(om, np.asarray(arr))
+  return sco.create_dataset(sco.omics, batch_size=batch_size, drop_remainder=True)
+
+
+class _Layer:
+  """Named handle for `output_layers[i].name` / `posteriors[i]` (train.py:110; posterior.py:176)."""
+
+  def __init__(self, rv: RVmeta):
+    self.rv = rv
+    self.name = rv.name
+    self.event_shape = (rv.event_shape,)
+    self.is_zero_inflated = rv.is_zero_inflated
+    self.posterior = rv.posterior
+
+
+class SingleCellModel:
+  r"""Note: seed the model (`seed=`) for reproducible results; it keys the Philox
+  streams of dropout and the reparameterisation noise."""
+
+  _kind = "vae"
+
+  def __init__(self,
+               outputs: RVmeta,
+               latents: RVmeta = RVmeta(10, "diag", True, "Latents"),
+               encoder: NetConf = NetConf([64, 64], batchnorm=True, input_dropout=0.3),
+               decoder: NetConf = NetConf([64, 64], batchnorm=True),
+               log_norm=True,
+               beta=1.0,
+               name=None,
+               **kwargs):
+    frame_args = dict(outputs=outputs, latents=latents, encoder=encoder, decoder=decoder, log_norm=log_norm, beta=beta,
+                      name=name, **kwargs)
+    self.init_args = frame_args
+    outs = [o.copy() for o in _flatten(outputs)]
+    if not outs or outs[0].posterior not in ("nb", "zinb", "nbd", "zinbd"):
+      raise ValueError("the first output must be a count distribution: 'nb', 'zinb', 'nbd' or 'zinbd', "
+                       f"given: {outs[0].posterior if outs else None}")
+    self._outputs = outs
+    self._labels = [l.copy() for l in _flatten(kwargs.pop("labels", None))]
+    self._latents = [l.copy() for l in _flatten(latents)]
+    self._encoder = _flatten(encoder)
+    self._decoder = _flatten(decoder)[0]
+    self._log_norm = bool(log_norm)
+    self.beta = float(beta)
+    self.alpha = float(kwargs.pop("alpha", 10.0))
+    self.seed = int(kwargs.pop("seed", 8))
+    self.clip_library = float(kwargs.pop("clip_library", 1e3))
+    self.device = int(kwargs.pop("device", 0))
+    for k in ("reduce_latent", "input_shape", "step", "path", "analytic", "gamma", "lamda"):
+      kwargs.pop(k, None)
+    self.name = name or type(self).__name__
+    self.dataset = None
+    self.metadata = dict()
+    self._n_inputs = 1
+    self.train_history: Dict[str, list] = {}
+    self.valid_history: Dict[str, list] = {}
+    self._engine: Optional[Engine] = None
+    self._opt = dict(lr=1e-3, clipnorm=100.0)
+    self._cfg = self._make_config()
+
+  # ---- configuration --------------------------------------------------------------
+  def _latent_activation(self):
+    return "relu"
+
+  def _make_config(self) -> ModelConfig:
+    enc = self._encoder[0]
+    labels = []
+    for rv in self._labels:
+      if rv.posterior in ("nb", "nbd"):
+        labels.append((rv.event_shape, "nb"))
+      elif rv.posterior in ("onehot", "categorical"):
+        labels.append((rv.event_shape, "onehot"))
+      else:
+        raise ValueError(f"label posterior '{rv.posterior}' is not built (supported: 'nb', 'onehot')")
+    encl = self._encoder[1].units if len(self._encoder) > 1 else (64,)
+    return ModelConfig(model=self._kind, n_genes=self._outputs[0].event_shape, likelihood=self._outputs[0].posterior,
+                       enc_units=tuple(enc.units), dec_units=tuple(self._decoder.units),
+                       latent_dim=self._latents[0].event_shape, encl_units=tuple(encl), labels=tuple(labels),
+                       batchnorm=bool(enc.batchnorm), dropout_enc=float(enc.dropout), dropout_dec=float(self._decoder.dropout),
+                       input_dropout=float(enc.input_dropout), log_norm=self._log_norm, beta=self.beta, alpha=self.alpha,
+                       latent_activation=self._latent_activation(), clip_library=self.clip_library,
+                       lr=float(self._opt["lr"]), clipnorm=float(self._opt["clipnorm"]), seed=self.seed)
+
+  def _ensure_engine(self, max_batch: int) -> Engine:
+    cfg = self._make_config()
+    e = self._engine
+    if e is not None and e.max_batch >= max_batch and e.cfg == cfg:
+      return e
+    state = None
+    if e is not None:  # carry weights / optimiser state into the re-created engine
+      state = self._get_state()
+      e.close()
+    self._cfg = cfg
+    self._engine = Engine(cfg, max_batch=max(int(max_batch), 64), device=self.device, init=state is None)
+    if state is not None:
+      self._set_state(state)
+    return self._engine
+
+  def _get_state(self):
+    e = self._engine
+    return dict(params=e.get_params(0), m=e.get_params(2), v=e.get_params(3), bn=e.get_bn(), step=e.step)
+
+  def _set_state(self, st):
+    e = self._engine
+    e.set_params(st["params"], 0)
+    e.set_params(st["m"], 2)
+    e.set_params(st["v"], 3)
+    e.set_bn(st["bn"])
+    e.step = int(st["step"])
+
+  # ---- reference attribute surface ---------------------------------------------------
+  def set_metadata(self, sco: SingleCellOMIC):
+    assert isinstance(sco, SingleCellOMIC), f"sco must be instance of SingleCellOMIC but given: {type(sco)}"
+    self.dataset = sco.name
+    for om in sco.omics:
+      self.metadata[om] = sco.get_var_names(om)
+    return self
+
+  @property
+  def log_norm(self):
+    return self._log_norm
+
+  @property
+  def posteriors(self):
+    return [_Layer(rv) for rv in self._outputs + self._labels]
+
+  @property
+  def output_layers(self):
+    return [_Layer(rv) for rv in self._outputs]
+
+  @property
+  def labels(self):
+    return list(self._labels)
+
+  @property
+  def latents(self):
+    return [_Layer(rv) for rv in self._latents]
+
+  @property
+  def encoder(self):
+    return self._encoder[0] if len(self._encoder) == 1 else list(self._encoder)
+
+  @property
+  def decoder(self):
+    return self._decoder
+
+  @property
+  def is_zero_inflated(self):
+    return self._outputs[0].is_zero_inflated
+
+  @property
+  def is_semi_supervised(self):
+    return len(self._labels) > 0
+
+  @property
+  def is_fitted(self):
+    return self.step > 0
+
+  @property
+  def step(self):
+    return 0 if self._engine is None else self._engine.step
+
+  @classproperty
+  def id(cls):
+    return "".join(c for c in cls.__name__ if c.isupper()).lower()
+
+  # ---- fit -------------------------------------------------------------------------------
+  def fit(self,
+          train: Union[SingleCellOMIC, BatchDataset],
+          valid: Union[SingleCellOMIC, BatchDataset] = None,
+          metadata: SingleCellOMIC = None,
+          **kwargs):
+    r"""Train on the GPU.  Keyword arguments are the `train:` block of configs/base.yaml:45-62
+    (optimizer, learning_rate, clipnorm, valid_freq, epochs, max_iter, earlystop_*,
+    terminate_on_nan, checkpoint, log_tag, ...) plus `batch_size`."""
+    if isinstance(train, SingleCellOMIC):
+      self.set_metadata(train)
+    elif isinstance(valid, SingleCellOMIC):
+      self.set_metadata(valid)
+    elif isinstance(metadata, SingleCellOMIC):
+      self.set_metadata(metadata)
+    if self.dataset is None or len(self.metadata) == 0:
+      raise RuntimeError("First time call `fit`, set the 'metadata' argument to a "
+                         "SingleCellOMIC dataset to keep the dataset name and OMICs' "
+                         "variables description.")
+    batch_size = kwargs.pop("batch_size", 64)
+    train = _to_data(train, batch_size=batch_size)
+    if valid is not None:
+      valid = _to_data(valid, batch_size=batch_size)
+    return self._fit(train, valid, **kwargs)
+
+  def _fit(self, train: BatchDataset, valid: Optional[BatchDataset], optimizer="adam", learning_rate=1e-3, clipnorm=100.0,
+           valid_freq=500, valid_interval=0, epochs=500, max_iter=-1, sample_shape=(), logging_interval=2,
+           earlystop_threshold=0.001, earlystop_progress_length=0, earlystop_patience=20, earlystop_min_epoch=-1,
+           terminate_on_nan=True, checkpoint=None, allow_rollback=False, allow_none_gradients=False,
+           track_gradient_norms=False, log_tag=None, verbose=False, use_graph=True, **ignored):
+    if str(optimizer).lower() != "adam":
+      raise ValueError("only the 'adam' optimizer of configs/base.yaml is built")
+    self._opt = dict(lr=float(learning_rate), clipnorm=float(clipnorm or 0.0))
+    n_lab = len(self._labels)
+    if len(train.arrays) < 1 + n_lab:
+      raise ValueError(f"{type(self).__name__} needs {1 + n_lab} omics per batch, the dataset has {len(train.arrays)}")
+    e = self._ensure_engine(max(train.batch_size, valid.batch_size if valid is not None else 1))
+    B = train.batch_size
+    n_tr = train.n_obs
+    # train and validation cells live in ONE resident matrix; validation rows are offset
+    X = train.arrays[0]
+    labs = [train.arrays[1 + j] for j in range(n_lab)]
+    lib, mask = train.library, train.mask
+    if valid is not None:
+      X = np.concatenate([X, valid.arrays[0]], 0)
+      labs = [np.concatenate([a, valid.arrays[1 + j]], 0) for j, a in enumerate(labs)]
+      lib = np.concatenate([lib, valid.library], 0)
+      mask = np.concatenate([mask, valid.mask], 0)
+    e.upload(X, labs, lib, mask)
+    hist_t = self.train_history
+    hist_v = self.valid_history
+    best, bad, it, t_log = np.inf, 0, 0, time.time()
+    stop = False
+    for epoch in range(int(epochs)):
+      batches = [b for b in train.epoch_batches(epoch) if len(b) == B]  # fixed batch size on the device
+      pos = 0
+      while pos < len(batches) and not stop:
+        room = len(batches) - pos
+        until_valid = valid_freq - (it % valid_freq) if valid_freq and valid_freq > 0 else room
+        n = min(room, until_valid, (max_iter - it) if max_iter and max_iter > 0 else room)
+        if n <= 0:
+          stop = True
+          break
+        order = np.concatenate(batches[pos:pos + n]).astype(np.int32)
+        m = e.train_steps(order, n, B, graph=bool(use_graph), metrics=True)
+        pos += n
+        it += n
+        for k in ("loss", "nllk_x", "nllk_y", "kl", "kl_l"):
+          hist_t.setdefault(k, []).append(float(m[k]))
+        if terminate_on_nan and m["nan_flag"]:
+          raise FloatingPointError(f"non-finite loss at iteration {it}")
+        if verbose and time.time() - t_log > logging_interval:
+          print(f"[{log_tag or self.name}] it {it} epoch {epoch} loss {m['loss']:.4f} nllk_x {m['nllk_x']:.4f} kl {m['kl']:.4f}")
+          t_log = time.time()
+        if valid is not None and valid_freq and it % valid_freq == 0:
+          vl = self._validate(e, valid, n_tr)
+          hist_v.setdefault("val_loss", []).append(vl)
+          improved = vl < best * (1.0 - float(earlystop_threshold)) if np.isfinite(best) else True
+          if vl < best:
+            best = vl
+            if checkpoint is not None:
+              checkpoint()
+          bad = 0 if improved else bad + 1
+          if earlystop_patience and bad >= int(earlystop_patience) and epoch >= int(earlystop_min_epoch):
+            stop = True
+        if max_iter and max_iter > 0 and it >= max_iter:
+          stop = True
+      if stop:
+        break
+    if valid is not None and not hist_v.get("val_loss"):
+      hist_v.setdefault("val_loss", []).append(self._validate(e, valid, n_tr))
+    if checkpoint is not None and valid is None:
+      checkpoint()
+    return self
+
+  @staticmethod
+  def _validate(e: Engine, valid: BatchDataset, offset: int) -> float:
+    tot, n = 0.0, 0
+    for ids in valid.epoch_batches(0):
+      if len(ids) == 0:
+        continue
+      m = e.eval_step((ids + offset).astype(np.int32))
+      tot += m["loss"] * len(ids)
+      n += len(ids)
+    return tot / max(n, 1)
+
+  # ---- inference ------------------------------------------------------------------------------
+  def _latent_dists(self, out, sl=slice(None)):
+    cfg = self._cfg
+    if cfg.stochastic:
+      qz = D.MultivariateNormalDiag(out["z_mean"][sl], out["z_scale"][sl], name=self._latents[0].name or "Latents")
+    else:
+      qz = D.Deterministic(out["z_sample"][sl], name=self._latents[0].name or "Latents")
+    if cfg.model == "scvi":
+      ql = D.Independent(D.Normal(out["l_mean"][sl][:, None], out["l_scale"][sl][:, None], name="Library"), 1)
+      return [qz, ql]
+    return qz
+
+  def _output_dists(self, xp_list, yp_list):
+    """xp_list: per-MC-sample x_params [k,B,G]; yp_list: per-sample list of label raw outputs."""
+    cfg = self._cfg
+    stack = (lambda a: a[0]) if len(xp_list) == 1 else (lambda a: np.stack(a, 0))
+    planes = [stack([xp[c] for xp in xp_list]) for c in range(cfg.k)]
+    outs = [D.count_distribution(cfg.likelihood, planes, self._outputs[0].name or "transcriptomic", activated=cfg.model == "scvi")]
+    for j, (P, kind) in enumerate(cfg.labels):
+      raw = stack([yp[j] for yp in yp_list])
+      nm = self._labels[j].name or f"label{j}"
+      if kind == "nb":
+        outs.append(D.Independent(D.NegativeBinomial(np.exp(raw[..., :P]), raw[..., P:]), 1, name=nm))
+      else:
+        outs.append(D.OneHotCategorical(raw, name=nm))
+    return outs[0] if len(outs) == 1 else tuple(outs)
+
+  def __call__(self, inputs=None, library=None, mask=None, training=None, sample_shape=(), **kwargs):
+    arrs = _flatten(inputs)
+    x = np.ascontiguousarray(arrs[0], dtype=np.float32)
+    if self._cfg.model == "scvi" and library is None:
+      library = library_matrix(x)
+    n = int(np.prod(sample_shape)) if np.size(sample_shape) else 0
+    e = self._ensure_engine(x.shape[0])
+    outs = [e.forward(x=x, library=library, sample_index=s) for s in range(max(n, 1))]
+    pX = self._output_dists([o["x_params"] for o in outs], [o["y_params"] for o in outs])
+    return pX, self._latent_dists(outs[0])
+
+  def encode(self, inputs, library=None, training=None, mask=None, sample_shape=(), **kwargs):
+    r"""log1p + encoder network + latent posterior (single_cell_model.py:119-139); SCVI
+    returns [q(z|x), q(l|x)] (scvi.py:88-106)."""
+    arrs = _flatten(inputs)[:self._n_inputs]
+    x = np.ascontiguousarray(arrs[0], dtype=np.float32)
+    if self._cfg.model == "scvi" and library is None:
+      library = library_matrix(x)
+    e = self._ensure_engine(x.shape[0])
+    out = e.forward(x=x, library=library, want_x_params=False)
+    return self._latent_dists(out)
+
+  def decode(self, latents, training=None, mask=None, sample_shape=(), **kwargs):
+    r"""Decoder network + output distributions (single_cell_model.py:141-151; scvi.py:108-171).
+    `latents`: array [B,D] or latent distribution(s) (a distribution is sampled, as TFP's
+    tensor coercion does)."""
+    lat = _flatten(latents)
+
+    def val(v):
+      return v.sample(seed=self.seed) if isinstance(v, D.Distribution) else np.asarray(v)
+
+    z = val(lat[0]).astype(np.float32)
+    l = val(lat[1]).astype(np.float32).reshape(-1) if len(lat) > 1 else None
+    e = self._ensure_engine(z.shape[0])
+    out = e.decode(z, l)
+    return self._output_dists([out["x_params"]], [out["y_params"]])
+
+  def predict(self, inputs, sample_shape=(), batch_size=32, verbose=True, device="GPU"):
+    r"""Predict on minibatches then return a single distribution by concatenation.
+
+    Return:
+      X : `Distribution` or tuple of `Distribution` (multiple outputs)
+      Z : `Distribution` or tuple of `Distribution` (multiple latents)
+    """
+    assert device in ("CPU", "GPU"), f"Only support device CPU or GPU, but given: {device}"
+    if device == "CPU":
+      raise RuntimeError("sisua_amd has no CPU path; predict runs on the MI355X")
+    ds = _to_data(inputs, batch_size=batch_size) if not isinstance(inputs, BatchDataset) else inputs
+    if not isinstance(inputs, (BatchDataset, SingleCellOMIC)):
+      ds.drop_remainder = False
+    ds.shuffle = 0 if isinstance(inputs, (np.ndarray, list, tuple)) else ds.shuffle
+    X, Z = [], []
+    for data in ds:
+      pX, qZ = self(**data, training=False, sample_shape=sample_shape)
+      X.append(pX)
+      Z.append(qZ)
+    multi_x = isinstance(X[0], (tuple, list))
+    first = X[0][0] if multi_x else X[0]
+    axis = 0 if len(first.batch_shape) == 1 else 1
+    if multi_x:
+      Xc = tuple(D.concat_distributions([x[i] for x in X], axis=axis, name=self.posteriors[i].name) for i in range(len(X[0])))
+    else:
+      Xc = D.concat_distributions(X, axis=axis, name=self.posteriors[0].name)
+    if isinstance(Z[0], (tuple, list)):
+      Zc = tuple(D.concat_distributions([z[i] for z in Z], axis=0) for i in range(len(Z[0])))
+    else:
+      Zc = D.concat_distributions(Z, axis=0)
+    return Xc, Zc
+
+  def marginal_log_prob(self, inputs=None, library=None, mask=None, sample_shape=100, **kwargs):
+    r"""Importance-weighted estimate of log p(x) with `sample_shape` posterior draws
+    (Posterior.cal_marginal_llk, analysis/posterior.py:941-976).  Returns
+    (mllk[B], {output name: mean log-likelihood [B]})."""
+    arrs = _flatten(inputs)
+    x = np.ascontiguousarray(arrs[0], dtype=np.float32)
+    S = int(np.prod(sample_shape)) if np.size(sample_shape) else 1
+    if self._cfg.model == "scvi" and library is None:
+      library = library_matrix(x)
+    e = self._ensure_engine(x.shape[0])
+    logw, llks = [], {}
+    for s in range(S):
+      out = e.forward(x=x, library=library, sample_index=s)
+      pX = self._output_dists([out["x_params"]], [out["y_params"]])
+      pXs = pX if isinstance(pX, tuple) else (pX,)
+      lw = pXs[0].log_prob(x)
+      llks.setdefault(pXs[0].name, []).append(lw)
+      for j, p in enumerate(pXs[1:]):
+        if len(arrs) > 1 + j:
+          ly = p.log_prob(arrs[1 + j])
+          llks.setdefault(p.name, []).append(ly)
+      if self._cfg.stochastic:
+        z = out["z_sample"].astype(np.float64)
+        qz = D.MultivariateNormalDiag(out["z_mean"], out["z_scale"])
+        lw = lw + D.MultivariateNormalDiag(np.zeros_like(z), np.ones_like(z)).log_prob(z) - qz.log_prob(z)
+      if self._cfg.model == "scvi":
+        lsmp = out["l_sample"].astype(np.float64)
+        pl = D.Normal(library[:, 0], np.sqrt(library[:, 1]))
+        lw = lw + pl.log_prob(lsmp) - D.Normal(out["l_mean"], out["l_scale"]).log_prob(lsmp)
+      logw.append(lw)
+    logw = np.stack(logw, 0)
+    mx = logw.max(0)
+    mllk = mx + np.log(np.exp(logw - mx).mean(0))
+    return mllk, {k: np.mean(v, 0) for k, v in llks.items()}
+
+  # ---- evaluation hand-off -----------------------------------------------------------------------
+  def create_posterior(self, test_sco: SingleCellOMIC = None, **kwargs):
+    r"""The reference builds `sisua.analysis.Posterior(scm=self, sco=test, ...)`
+    (single_cell_model.py:247-281).  The analysis package is outside this build
+    (SURVEY.md section 2 row 13); when the reference's `sisua` is importable its
+    Posterior is used with this model, otherwise a clear error is raised."""
+    if not self.is_fitted:
+      raise RuntimeError("fit() must be called before creating Posterior.")
+    try:
+      from sisua.analysis.posterior import Posterior  # type: ignore
+    except Exception as err:
+      raise NotImplementedError("sisua.analysis.Posterior is not part of sisua_amd; install the reference "
+                                "package to score this model (predict / marginal_log_prob are provided)") from err
+    return Posterior(scm=self, sco=test_sco, **kwargs)
+
+  # ---- checkpoints --------------------------------------------------------------------------------
+  def save_weights(self, filepath, overwrite=True):
+    r"""Weights + optimiser state + BN statistics in `<filepath>.npz` and the
+    `<filepath>.metamodel` pickle [class_name, dataset, metadata, init_args] of the
+    reference (single_cell_model.py:295-306)."""
+    if self._engine is None:
+      self._ensure_engine(64)
+    if not overwrite and os.path.exists(f"{filepath}.npz"):
+      raise FileExistsError(f"{filepath}.npz")
+    st = self._get_state()
+    flat = {f"p/{k}": v for k, v in st["params"].items()}
+    flat.update({f"m/{k}": v for k, v in st["m"].items()})
+    flat.update({f"v/{k}": v for k, v in st["v"].items()})
+    for i, b in st["bn"].items():
+      flat[f"bn/{i}/moving_mean"], flat[f"bn/{i}/moving_var"] = b["moving_mean"], b["moving_var"]
+    flat["step"] = np.array(st["step"], dtype=np.int64)
+    d = os.path.dirname(os.path.abspath(filepath))
+    os.makedirs(d, exist_ok=True)
+    np.savez(f"{filepath}.npz", **flat)
+    with open(f"{filepath}.metamodel", "wb") as f:
+      pickle.dump([self.__class__.__name__, self.dataset, self.metadata, dict(self.init_args)], f)
+    return self
+
+  def load_weights(self, filepath, raise_notfound=False, verbose=False):
+    r"""Load all the saved weights at given path (single_cell_model.py:283-293)."""
+    if not os.path.exists(f"{filepath}.npz"):
+      if raise_notfound:
+        raise FileNotFoundError(f"Cannot find saved weights at path: {filepath}")
+      return self
+    z = np.load(f"{filepath}.npz")
+    if self._engine is None:
+      self._ensure_engine(64)
+    bn = {}
+    for k in z.files:
+      if k.startswith("bn/"):
+        _, i, nm = k.split("/")
+        bn.setdefault(int(i), {})[nm] = z[k]
+    self._set_state(dict(params={k[2:]: z[k] for k in z.files if k.startswith("p/")},
+                         m={k[2:]: z[k] for k in z.files if k.startswith("m/")},
+                         v={k[2:]: z[k] for k in z.files if k.startswith("v/")}, bn=bn, step=int(z["step"])))
+    metamodel_path = f"{filepath}.metamodel"
+    if os.path.exists(metamodel_path):
+      with open(metamodel_path, "rb") as f:
+        class_name, dataset, metadata, kwargs = pickle.load(f)
+      assert class_name == self.__class__.__name__
+      self.dataset = dataset
+      self.metadata = metadata
+    if verbose:
+      print(f"Loaded weights from {filepath} (step {self.step})")
+    return self
+
+  def plot_learning_curves(self, path=None, **kwargs):
+    return dict(train=self.train_history, valid=self.valid_history)
+
+  def __repr__(self):
+    c = self._cfg
+    return (f"<{type(self).__name__} id={self.id} G={c.n_genes} {c.likelihood} enc={list(c.enc_units)} D={c.latent_dim} "
+            f"dec={list(c.dec_units)} labels={list(c.labels)} step={self.step}>")
+
+
+class VAE(SingleCellModel):
+  r"""Variational Auto Encoder (sisua/models/vae.py:15-16)."""
+  _kind = "vae"
+
+
+class SISUA(SingleCellModel):
+  r"""Multi-task SemI-SUpervised Autoencoder (sisua/models/vae.py:19-44):
+  transcriptomic zero-inflated negative binomial, proteomic negative binomial or
+  one-hot categorical label heads weighted by `alpha`, diagonal Gaussian latent.
+
+      RVmeta(rna_dim, 'zinbd'/'zinb', projection=True, name='RNA')
+      RVmeta(adt_dim, 'onehot'/'nbd'/'nb', True, 'ADT')
+  """
+  _kind = "sisua"
+
+  def __init__(self, outputs, labels, **kwargs):
+    super().__init__(outputs=outputs, labels=labels, **kwargs)
+    self._n_inputs = 1
+
+
+class SCVI(SingleCellModel):
+  r"""Single cell variational inference (sisua/models/scvi.py:20-171).
+
+  Arguments:
+    clip_library : `float` (default=`1e3`) clipping of the library latent before exp
+  """
+  _kind = "scvi"
+
+  def __init__(self,
+               outputs,
+               latents=RVmeta(10, "diag", True, "Latents"),
+               library=RVmeta(1, "normal", True, "Library"),
+               encoder=NetConf([64, 64], batchnorm=True, dropout=0.1, name="Encoder"),
+               encoder_l=NetConf([64], batchnorm=True, dropout=0.1, name="EncoderL"),
+               clip_library=1e3,
+               **kwargs):
+    outs = _flatten(outputs)
+    assert outs[0].posterior in ("zinbd", "nbd"), \
+      "scVI only support transcriptomic distribution: 'zinbd' or 'nbd', " + "but given: %s" % str(outs)
+    if outs[0].kwargs.get("dispersion", "full") != "full" or outs[0].kwargs.get("inflation", "full") != "full":
+      raise ValueError("only dispersion='full' and inflation='full' are built")
+    super().__init__(outs, latents=[latents, library], encoder=[encoder, encoder_l], clip_library=clip_library, **kwargs)
+    self.init_args = dict(outputs=outputs, latents=latents, library=library, encoder=encoder, encoder_l=encoder_l,
+                          clip_library=clip_library, **kwargs)
+
+
+class DeepCountAutoencoder(SingleCellModel):
+  r"""Deep Count Autoencoder (sisua/models/dca.py:13-28): deterministic latent."""
+  _kind = "dca"
+
+  def __init__(self, outputs, latents=RVmeta(10, "relu", True, name="Latents"), **kwargs):
+    lat = [z.copy() for z in _flatten(latents)]
+    for z in lat:
+      if not z.is_deterministic:
+        warnings.warn("DeepCountAutoencoder only support deterministic latents, "
+                      f"but given {z}, use default linear Dense layer for latents.")
+        z.posterior = "linear"
+    self._dca_activation = "relu" if lat[0].posterior == "relu" else "linear"
+    super().__init__(outputs=outputs, latents=lat, **kwargs)
+    self.init_args = dict(outputs=outputs, latents=latents, **kwargs)
+
+  def _latent_activation(self):
+    return self._dca_activation
+
+
+# ---- registry (sisua/models/__init__.py:11-38) -------------------------------------------------------
+def get_all_models() -> list:
+  all_models = []
+  for key, val in globals().items():
+    if isinstance(val, type) and issubclass(val, SingleCellModel):
+      all_models.append(val)
+  return sorted(all_models, key=lambda cls: cls.id)
+
+
+def get_model(model):
+  if isinstance(model, type):
+    model = model.__name__
+  model = str(model).lower()
+  for key, val in globals().items():
+    if isinstance(val, type) and issubclass(val, SingleCellModel):
+      if model == key.lower() or model == val.id:
+        return val
+  raise RuntimeError(f"Cannot find SingleCellModel with type '{model}'")
+
+
+def load_model(filepath: str) -> SingleCellModel:
+  with open(f"{filepath}.metamodel", "rb") as f:
+    class_name, dataset, metadata, kwargs = pickle.load(f)
+  model = get_model(class_name)(**kwargs)
+  model.load_weights(filepath, raise_notfound=True)
+  return model

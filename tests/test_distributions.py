@@ -1,0 +1,76 @@
+"""Result objects (sisua_amd/distributions.py) against scipy / torch closed forms and the
+structural assertions the reference's tests make on model outputs
+(tests/test_singlecell_models.py:41-91, 105-114)."""
+import numpy as np
+import scipy.stats as st
+import torch
+import torch.distributions as td
+
+from sisua_amd import distributions as D
+
+
+def test_nb_and_zinb_surface():
+  rng = np.random.default_rng(0)
+  a, l, g = rng.normal(size=(5, 7)), rng.normal(size=(5, 7)), rng.normal(size=(5, 7))
+  x = rng.poisson(2.0, size=(5, 7)).astype(float)
+  nb = D.NegativeBinomial(np.exp(a), l)
+  assert np.allclose(nb.log_prob(x), st.nbinom.logpmf(x, np.exp(a), 1 - 1 / (1 + np.exp(-l))))
+  tnb = td.NegativeBinomial(torch.tensor(np.exp(a)), logits=torch.tensor(l))
+  assert np.allclose(nb.mean(), tnb.mean.numpy()) and np.allclose(nb.variance(), tnb.variance.numpy())
+  zi = D.ZeroInflated(nb, g)
+  pi = 1 / (1 + np.exp(-g))
+  naive = np.log(np.where(x == 0, pi + (1 - pi) * np.exp(nb.log_prob(x)), (1 - pi) * np.exp(nb.log_prob(x))))
+  assert np.allclose(zi.log_prob(x), naive)
+  ind = D.Independent(zi, 1, name="transcriptomic")
+  assert ind.batch_shape == (5,) and ind.event_shape == (7,) and ind.name == "transcriptomic"
+  assert ind.distribution is zi and zi.count_distribution is nb and ind.reinterpreted_batch_ndims == 1
+  assert np.allclose(ind.log_prob(x), zi.log_prob(x).sum(-1))
+  s = ind.sample(11, seed=1)
+  assert s.shape == (11, 5, 7) and (s >= 0).all()
+  big = D.ZeroInflated(D.NegativeBinomial(np.full(20000, 3.0), np.full(20000, 0.5)), np.full(20000, -1.0))
+  smp = big.sample(seed=3)
+  assert abs(smp.mean() - big.mean()[0]) < 0.15 and abs(smp.var() - big.variance()[0]) < 1.0
+
+
+def test_nbd_matches_mean_dispersion_nb():
+  rng = np.random.default_rng(1)
+  mu, th = rng.lognormal(size=(4, 6)), rng.lognormal(size=(4, 6))
+  x = rng.poisson(2.0, size=(4, 6)).astype(float)
+  d = D.NegativeBinomialDisp(mu, th)
+  assert np.allclose(d.log_prob(x), st.nbinom.logpmf(x, th, th / (th + mu)), atol=1e-5)
+  assert np.allclose(d.variance(), mu + mu ** 2 / th)
+
+
+def test_gaussians_onehot_and_concat():
+  rng = np.random.default_rng(2)
+  mu, s = rng.normal(size=(6, 3)), rng.uniform(0.5, 2, size=(6, 3))
+  q = D.MultivariateNormalDiag(mu, s, name="Latents")
+  z = rng.normal(size=(6, 3))
+  ref = td.Independent(td.Normal(torch.tensor(mu), torch.tensor(s)), 1).log_prob(torch.tensor(z)).numpy()
+  assert np.allclose(q.log_prob(z), ref) and q.batch_shape == (6,) and q.event_shape == (3,)
+  assert np.allclose(q.mean(), mu) and np.allclose(q.variance(), s ** 2) and q.sample(4).shape == (4, 6, 3)
+  oh = D.OneHotCategorical(rng.normal(size=(6, 5)))
+  y = np.eye(5)[rng.integers(0, 5, 6)]
+  assert np.allclose(oh.log_prob(y), td.OneHotCategorical(logits=torch.tensor(oh.logits)).log_prob(torch.tensor(y)).numpy())
+  assert oh.sample(seed=0).sum(-1).tolist() == [1.0] * 6
+  parts = [D.Independent(D.ZeroInflated(D.NegativeBinomial(np.ones((2, 4)) * i, np.zeros((2, 4))), np.zeros((2, 4))), 1,
+                         name="transcriptomic") for i in (1, 2, 3)]
+  cat = D.concat_distributions(parts, axis=0, name="transcriptomic")
+  assert cat.batch_shape == (6,) and cat.event_shape == (4,) and isinstance(cat.distribution, D.ZeroInflated)
+  assert np.allclose(cat.distribution.count_distribution.total_count[:, 0], [1, 1, 2, 2, 3, 3])
+  # leading Monte-Carlo axis: merge along axis 1 (single_cell_model.py:184-187)
+  mc = [D.Independent(D.NegativeBinomial(np.ones((3, 2, 4)), np.zeros((3, 2, 4))), 1) for _ in range(2)]
+  assert D.concat_distributions(mc, axis=1).batch_shape == (3, 4)
+  det = D.concat_distributions([D.Deterministic(np.ones((2, 3))), D.Deterministic(np.zeros((1, 3)))])
+  assert det.mean().shape == (3, 3)
+
+
+def test_count_distribution_factory():
+  p = [np.zeros((2, 3)), np.ones((2, 3)), np.zeros((2, 3))]
+  d = D.count_distribution("zinb", p, "transcriptomic", activated=False)
+  assert isinstance(d.distribution, D.ZeroInflated) and np.allclose(d.distribution.count_distribution.total_count, 1.0)
+  d2 = D.count_distribution("nbd", p[:2], "transcriptomic", activated=False)
+  assert isinstance(d2.distribution, D.NegativeBinomialDisp)
+  assert np.allclose(d2.distribution.loc, np.log(2.0)) and np.allclose(d2.mean(), np.log(2.0))
+  d3 = D.count_distribution("zinbd", [np.full((2, 3), 5.0), np.full((2, 3), 2.0), p[2]], "x", activated=True)
+  assert np.allclose(d3.distribution.count_distribution.loc, 5.0)

@@ -1,0 +1,131 @@
+"""The reference's model-level test strategy (tests/test_singlecell_models.py:28-32, 93-188;
+tests/test_save_load_model.py:198-201) on the HIP path: registry, fit/predict for DCA, VAE,
+SISUA, SCVI with 'loss decreases', output distribution classes / shapes, save -> load."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import synth_counts, synth_labels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+  from sisua_amd import build
+  build.build(verbose=False)
+  import sisua_amd.models as M
+  return M
+
+
+def _sco(n=600, g=120, with_labels=True):
+  from sisua_amd.data import SingleCellOMIC
+  sco = SingleCellOMIC(synth_counts(n, g, sparsity=0.8, seed=3), name="toy")
+  if with_labels:
+    sco.add_omic("proteomic", synth_labels(n, ((9, "nb"),))[0])
+  return sco
+
+
+def _decreases(hist, frac=0.7):
+  h = np.asarray(hist)
+  k = max(len(h) // 6, 1)
+  blocks = [h[i:i + k].mean() for i in range(0, len(h) - k + 1, k)]
+  return np.mean(np.diff(blocks) < 0) >= frac and blocks[-1] < blocks[0]
+
+
+def test_registry(api):
+  ids = [m.id for m in api.get_all_models()]
+  assert {"dca", "vae", "sisua", "scvi"} <= set(ids)
+  assert api.get_model("vae") is api.VAE and api.get_model("DeepCountAutoencoder") is api.DeepCountAutoencoder
+  assert api.get_model(api.SCVI) is api.SCVI
+  with pytest.raises(RuntimeError):
+    api.get_model("nope")
+
+
+@pytest.mark.parametrize("name", ["dca", "vae", "sisua", "scvi"])
+def test_fit_predict(api, name):
+  from sisua_amd import distributions as D
+  sco = _sco()
+  train, test = sco.split(0.8)
+  cls = api.get_model(name)
+  rna = sco.get_rv("transcriptomic", "zinbd" if name == "scvi" else "zinb")
+  kw = dict(outputs=rna, latents=api.RVmeta(8, "diag" if name != "dca" else "relu", True, "Latents"),
+            encoder=api.NetConf([32], batchnorm=True, dropout=0.1), decoder=api.NetConf([32], batchnorm=True, dropout=0.1))
+  if name == "sisua":
+    kw["labels"] = [sco.get_rv("proteomic")]
+  if name == "dca":
+    kw.pop("latents")
+  model = cls(**kw)
+  assert not model.is_fitted and model.is_zero_inflated and model.is_semi_supervised == (name == "sisua")
+  with pytest.raises(RuntimeError):   # fit without metadata (single_cell_model.py:227-231)
+    cls(**kw).fit(train.create_dataset(batch_size=32))
+  omics = ["transcriptomic"] + (["proteomic"] if name == "sisua" else [])
+  ds = train.create_dataset(omics, labels_percent=0.5, batch_size=64, drop_remainder=True)
+  vs = test.create_dataset(omics, labels_percent=1.0, batch_size=64, drop_remainder=True)
+  model.fit(ds, valid=vs, metadata=sco, epochs=12, valid_freq=20, learning_rate=2e-3)
+  assert model.is_fitted and model.dataset == "toy" and "transcriptomic" in model.metadata
+  assert _decreases(model.train_history["loss"]) and len(model.valid_history["val_loss"]) >= 1
+  X, Z = model.predict(test.create_dataset(omics, batch_size=50, shuffle=0), verbose=False)
+  n = test.n_obs
+  Xs = X if isinstance(X, tuple) else (X,)
+  assert isinstance(Xs[0], D.Independent) and isinstance(Xs[0].distribution, D.ZeroInflated)
+  assert Xs[0].batch_shape == (n,) and Xs[0].event_shape == (120,) and Xs[0].name == "transcriptomic"
+  assert np.isfinite(Xs[0].mean()).all() and (Xs[0].mean() >= 0).all()
+  if name == "sisua":
+    assert len(Xs) == 2 and Xs[1].event_shape == (9,) and Xs[1].name == "proteomic"
+  Zs = Z if isinstance(Z, tuple) else (Z,)
+  assert Zs[0].mean().shape == (n, 8)
+  if name == "scvi":
+    assert len(Zs) == 2 and Zs[1].mean().shape == (n, 1)
+  if name == "dca":
+    assert isinstance(Zs[0], D.Deterministic) and (Zs[0].mean() >= 0).all()
+  # Monte-Carlo axis (posterior.py:175-182 uses sample_shape=10)
+  X3, _ = model.predict(test.numpy()[:20], sample_shape=3, batch_size=8, verbose=False)
+  X3 = X3[0] if isinstance(X3, tuple) else X3
+  assert X3.batch_shape == (3, 20) and X3.mean().shape == (3, 20, 120)
+  # encode / decode round trip agrees with __call__
+  q = model.encode(test.numpy()[:16])
+  q0 = q[0] if isinstance(q, list) else q
+  assert np.allclose(q0.mean(), Zs[0].mean()[:16], atol=1e-5)
+  lat = [d.mean() for d in q] if isinstance(q, list) else q0.mean()
+  pX = model.decode(lat)
+  pX = pX[0] if isinstance(pX, tuple) else pX
+  assert pX.mean().shape == (16, 120)
+  mllk, llk = model.marginal_log_prob(inputs=test.numpy()[:16], sample_shape=8)
+  assert mllk.shape == (16,) and np.isfinite(mllk).all() and "transcriptomic" in llk
+  assert (mllk >= llk["transcriptomic"] - 50).all()
+
+
+def test_save_load_roundtrip(api, tmp_path):
+  sco = _sco(with_labels=False)
+  train, test = sco.split(0.8)
+  kw = dict(outputs=sco.get_rv("transcriptomic"), latents=api.RVmeta(6, "diag", True, "Latents"),
+            encoder=api.NetConf([32, 16], batchnorm=True, dropout=0.1), decoder=api.NetConf([16], batchnorm=True))
+  m1 = api.VAE(**kw)
+  path = os.path.join(tmp_path, "model")
+  m1.fit(train, epochs=4, batch_size=64, checkpoint=lambda: m1.save_weights(path))
+  _, z1 = m1.predict(test.numpy(), batch_size=64, verbose=False)
+  m1.save_weights(path)
+  m2 = api.load_model(path)
+  assert type(m2) is api.VAE and m2.dataset == "toy" and m2.step == m1.step
+  _, z2 = m2.predict(test.numpy(), batch_size=64, verbose=False)
+  assert np.allclose(z1.mean(), z2.mean()) and np.allclose(z1.variance(), z2.variance())   # test_save_load_model.py:198-201
+  # resume: both continue identically (optimizer state + BN stats + step restored)
+  ds = train.create_dataset(batch_size=64, drop_remainder=True)
+  m1.fit(ds, epochs=1)
+  m2.fit(ds, epochs=1, metadata=sco)
+  assert np.allclose(m1.train_history["loss"][-1], m2.train_history["loss"][-1], rtol=1e-6)
+  m3 = api.VAE(**kw).load_weights(os.path.join(tmp_path, "missing"))
+  assert not m3.is_fitted
+  with pytest.raises(FileNotFoundError):
+    api.VAE(**kw).load_weights(os.path.join(tmp_path, "missing"), raise_notfound=True)
+
+
+def test_experiment_driver_cortex_plumbing(api):
+  """BASELINE.json configs[0]: cortex, VAE, batch 32, 5 epochs (335 steps): loss finite and falling."""
+  from sisua_amd.train import Experiment
+  exp = Experiment(dict(model=dict(name="vae"), dataset=dict(name="cortex", batch_size=32), train=dict(epochs=5)))
+  model = exp.run()
+  assert model.step == 335 and np.isfinite(model.train_history["loss"]).all()
+  assert model.train_history["loss"][-1] < model.train_history["loss"][0]
