@@ -625,8 +625,15 @@ int read_metrics(smx_model* m, smx_metrics* out) {
   return SMX_OK;
 }
 
+void drop_graphs(smx_model* m) {  // captured graphs bake device pointers in: drop them when a buffer moves
+  for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
+  m->graphs.clear();
+}
+
 int upload_order(smx_model* m, const int32_t* order, size_t n) {
   if (n > m->order_cap) {
+    SMX_HIP(hipStreamSynchronize(m->st));
+    drop_graphs(m);
     if (m->order) hipFree(m->order);
     m->order = nullptr;
     m->order_cap = n * 2;
@@ -957,6 +964,7 @@ int smx_dataset_upload(smx_model* m, const float* X, int64_t n_cells, const floa
   SMX_REQUIRE(!m->scvi || library, "scvi needs the library prior (scvi.py:100-105)");
   for (int j = 0; j < m->cfg.n_labels; ++j) SMX_REQUIRE(labels && labels[j], "missing label matrix");
   SMX_HIP(hipStreamSynchronize(m->st));
+  drop_graphs(m);
   auto fr = [](void* p) { if (p) hipFree(p); };
   fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1);
   m->X = nullptr; m->library = nullptr; m->mask = nullptr; m->lgx1 = nullptr;
@@ -1169,8 +1177,7 @@ int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]) {
     return SMX_ERR_COMM;
   }
   m->rank = rank; m->world = world;
-  for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
-  m->graphs.clear();
+  drop_graphs(m);
   return SMX_OK;
 }
 
