@@ -111,37 +111,26 @@ def main():
   # the HIP library first (binds /opt/rocm's runtime), torch only as rendezvous plumbing
   from sisua_amd import _hip
   from sisua_amd.engine import Engine
+  from sisua_amd.parallel import ControlPlane, attach_engine
   _hip.require_gpu(local_rank)
-  dist = None
-  if world > 1:
-    import torch.distributed as dist
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+  cp = ControlPlane(rank, world)
 
   cfg, xt, batch = build_workload(rank, world, args.workload)
   eng = Engine(cfg, max_batch=batch, device=local_rank)
   eng.upload(xt, cell_id_base=rank * (1 << 24))
-  if world > 1:
-    uid = [Engine.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    eng.comm_init(rank, world, uid[0])
+  attach_engine(eng, cp)
 
   use_graph = not args.no_graph
   order = make_order(xt.shape[0], batch, args.warmup + args.steps)
   if args.warmup:
     eng.train_steps(order[: args.warmup * batch], args.warmup, batch, graph=use_graph)
   eng.synchronize()
-  if dist is not None:
-    dist.barrier()
+  cp.barrier()
   t0 = time.perf_counter()
   m = eng.train_steps(order[args.warmup * batch:], args.steps, batch, graph=use_graph, metrics=True)
   eng.synchronize()
-  dt = time.perf_counter() - t0
-  if dist is not None:
-    import torch
-    t = torch.tensor([dt], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    dist.barrier()
+  cp.barrier()
+  dt = cp.max(time.perf_counter() - t0)
 
   # ---- roofline of the ZINB+KL loss kernel: HIP events on the model's stream ----
   n_ev = min(args.steps, 200)
@@ -191,9 +180,7 @@ def main():
       out["cpu_baseline"] = cpu_baseline(cfg, xt, batch, args.cpu_budget)
     print(json.dumps(out), flush=True)
   eng.close()
-  if dist is not None:
-    dist.barrier()
-    dist.destroy_process_group()
+  cp.close()
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <math.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -141,6 +142,7 @@ struct smx_model {
   // graphs
   std::map<int, hipGraphExec_t> graphs;
   bool capturing = false;
+  bool graph_comm_failed = false;
   // timing
   std::string timing_label; std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events; size_t timing_used = 0;
 };
@@ -573,14 +575,15 @@ int backward_pass(smx_model* m, const Pass& ps) {
 
 int optimizer_pass(smx_model* m) {
   const smx_config& c = m->cfg;
-  if (m->world > 1) {
+  static const bool force_ar = getenv("SMX_FORCE_ALLREDUCE") != nullptr;  // exercise RCCL on a 1-rank communicator
+  if (m->comm && (m->world > 1 || force_ar)) {
     Timed t(m, "allreduce");
     ncclResult_t r = g_rccl.AllReduce(m->grads, m->grads, m->grads_count, ncclFloat32, ncclSum, m->comm, m->st);
     if (r != ncclSuccess) {
       set_error(std::string("ncclAllReduce failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
       return SMX_ERR_COMM;
     }
-    if (m->bn_total) {
+    if (m->bn_total && m->world > 1) {
       hipLaunchKernelGGL(bn_moving_update_kernel, dim3((unsigned)((m->bn_total + 255) / 256)), dim3(256), 0, m->st,
                          m->bn_moving, m->grads + m->tail_off_bn, (int)m->bn_total, 1.f / (float)m->world,
                          c.bn_momentum);
@@ -652,7 +655,10 @@ int check_rows(smx_model* m, const int32_t* ids, size_t n) {
 }
 
 int launch_train(smx_model* m, int B, bool use_graph) {
-  if (use_graph && m->world == 1 && !m->use_injected && m->timing_label.empty()) {
+  // With a communicator the RCCL all-reduce is captured too (RCCL supports stream capture);
+  // SMX_NO_GRAPH_COMM=1 or a failed capture falls back to eager launches for good.
+  static const bool no_graph_comm = getenv("SMX_NO_GRAPH_COMM") != nullptr;
+  if (use_graph && !(m->comm && (no_graph_comm || m->graph_comm_failed)) && !m->use_injected && m->timing_label.empty()) {
     auto it = m->graphs.find(B);
     if (it == m->graphs.end()) {
       hipGraph_t graph = nullptr;
@@ -661,11 +667,21 @@ int launch_train(smx_model* m, int B, bool use_graph) {
       int rc = train_sequence(m, B);
       m->capturing = false;
       hipError_t e = hipStreamEndCapture(m->st, &graph);
-      if (rc != SMX_OK) { if (graph) hipGraphDestroy(graph); return rc; }
-      if (e != hipSuccess) { set_error(std::string("graph capture failed: ") + hipGetErrorString(e)); return SMX_ERR_HIP; }
       hipGraphExec_t exec = nullptr;
-      SMX_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      hipGraphDestroy(graph);
+      if (rc == SMX_OK && e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (graph) hipGraphDestroy(graph);
+      if (rc != SMX_OK || e != hipSuccess) {
+        (void)hipGetLastError();
+        if (m->comm) {  // capture with the collective failed: run this and all later steps eagerly
+          m->graph_comm_failed = true;
+          SMX_CHECK(train_sequence(m, B));
+          m->h_next += 1;
+          return SMX_OK;
+        }
+        if (rc != SMX_OK) return rc;
+        set_error(std::string("graph capture failed: ") + hipGetErrorString(e));
+        return SMX_ERR_HIP;
+      }
       it = m->graphs.emplace(B, exec).first;
     }
     SMX_HIP(hipGraphLaunch(it->second, m->st));

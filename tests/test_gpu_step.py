@@ -218,3 +218,24 @@ def test_error_paths(Engine):
     e.train_step(np.array([0, 1, 50], dtype=np.int32))    # row id out of range
   assert e.train_step(np.arange(16, dtype=np.int32))["step"] == 1
   e.close()
+
+
+def test_rccl_single_rank_allreduce_is_identity(Engine, monkeypatch):
+  """The data-parallel code path (RCCL communicator, one all-reduce of the flat buffer per step)
+  exercised on the one GPU of the test box: a 1-rank all-reduce must not change the result."""
+  monkeypatch.setenv("SMX_FORCE_ALLREDUCE", "1")
+  spec, cfg, x, ys, lib, mask = _problem(CASES["vae_zinb"])
+  outs = []
+  for use_comm in (False, True):
+    e = Engine(cfg, max_batch=64)
+    e.upload(x, ys, lib, mask)
+    if use_comm:
+      e.comm_init(0, 1, Engine.comm_unique_id())
+      assert e.world == 1
+    order = np.arange(64 * 4, dtype=np.int32) % x.shape[0]
+    m = e.train_steps(order, 4, 64, graph=True, metrics=True)
+    outs.append((m["loss"], e.get_params()))
+    e.close()
+  assert outs[0][0] == outs[1][0]
+  for k in outs[0][1]:
+    assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
