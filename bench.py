@@ -95,7 +95,7 @@ def main():
   ap.add_argument("--steps", type=int, default=300)
   ap.add_argument("--warmup", type=int, default=30)
   ap.add_argument("--workload", default="8kly")
-  ap.add_argument("--no-graph", action="store_true")
+  ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (eager launches measured faster)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-budget", type=float, default=12.0)
   args = ap.parse_args()
@@ -120,7 +120,7 @@ def main():
   eng.upload(xt, cell_id_base=rank * (1 << 24))
   attach_engine(eng, cp)
 
-  use_graph = not args.no_graph
+  use_graph = args.graph
   order = make_order(xt.shape[0], batch, args.warmup + args.steps)
   if args.warmup:
     eng.train_steps(order[: args.warmup * batch], args.warmup, batch, graph=use_graph)

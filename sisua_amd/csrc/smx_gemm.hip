@@ -14,6 +14,8 @@
 //   * the A operand can be produced on the fly from the resident cells x genes
 //     matrix: row gather, log1p and input dropout are applied while staging
 //     (SingleCellModel.encode, sisua/models/single_cell_model.py:126-134).
+#include <string.h>
+
 #include "smx_internal.h"
 #include "../../include/sisua_hip.h"
 
@@ -41,8 +43,18 @@ __device__ inline float4 xform4(float4 v, const AXform& xf, int batch_idx, int s
 
 // A_KM: A stored [K][M] (direct staging); else [M][K] (transposed staging).
 // B_NM: B stored [N][K] (transposed staging); else [K][N] (direct staging).
+template <int WM, int WN, int WK, int A_KM, int B_NM>
+struct GemmSmem {
+  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 32 * WK;
+  static constexpr int LDAS = A_KM ? BM + 4 : BM + 1;
+  static constexpr int LDBS = B_NM ? BN + 1 : BN + 4;
+  static constexpr int TILES = BK * LDAS + BK * LDBS;
+  static constexpr int RED = (WK > 1) ? (WK - 1) * WM * WN * 1024 : 0;
+  static constexpr int FLOATS = TILES > RED ? TILES : RED;
+};
+
 template <int WM, int WN, int WK, int A_KM, int B_NM, int XF>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz, float* smem) {
   constexpr int BM = 32 * WM, BN = 32 * WN, BK = 32 * WK;
   constexpr int LDAS = A_KM ? BM + 4 : BM + 1;
   constexpr int LDBS = B_NM ? BN + 1 : BN + 4;
@@ -50,10 +62,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int NB = BN * BK / 1024;
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
   static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
-  constexpr int SMEM_TILES = BK * LDAS + BK * LDBS;
-  constexpr int SMEM_RED = (WK > 1) ? (WK - 1) * WM * WN * 1024 : 0;
-  constexpr int SMEM = SMEM_TILES > SMEM_RED ? SMEM_TILES : SMEM_RED;
-  __shared__ __attribute__((aligned(16))) float smem[SMEM];
   float* As = smem;
   float* Bs = smem + BK * LDAS;
 
@@ -61,8 +69,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wk = wave / (WM * WN), wm = (wave / WN) % WM, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int k_begin = blockIdx.z * g.k_chunk;
+  const int m0 = bx * BM, n0 = by * BN;
+  const int k_begin = bz * g.k_chunk;
   const int k_end = min(g.K, k_begin + g.k_chunk);
 
   float4 ra[NA], rb[NB];
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float csum = 0.f;  // column sum of op(B) (bias gradient), threads < BN of M-tile 0
-  const bool do_colsum = (g.colsum != nullptr) && (blockIdx.x == 0) && (tid < BN);
+  const bool do_colsum = (g.colsum != nullptr) && (bx == 0) && (tid < BN);
 
   if (k_begin < k_end) load_tiles(k_begin);
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 
   if (wk == 0) {
-    float* C = g.C + (long)blockIdx.z * g.slab_stride;
+    float* C = g.C + (long)bz * g.slab_stride;
     const int col = n0 + wn * 32 + li;
     const float bias = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
@@ -195,6 +203,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   }
   if (do_colsum) g.colsum[n0 + tid] = csum;
+}
+
+template <int WM, int WN, int WK, int A_KM, int B_NM, int XF>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[GemmSmem<WM, WN, WK, A_KM, B_NM>::FLOATS];
+  gemm_body<WM, WN, WK, A_KM, B_NM, XF>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// ---------------------------------------------------------------------------
+// Grouped launch: several independent products share one grid, so the narrow ones fill the CUs
+// the wide one leaves idle and a whole kernel boundary disappears.  Tiles 128x32 and 32x32(K4).
+// ---------------------------------------------------------------------------
+struct GemmGroup {
+  int n;
+  int start[SMX_GROUP_MAX + 1];   // first flat block of each problem
+  int gx[SMX_GROUP_MAX], gy[SMX_GROUP_MAX];
+  int variant[SMX_GROUP_MAX];     // tile (0: 128x32, 1: 32x32 K4) * 8 + a_kmajor * 4 + b_nmajor * 2 + xform
+  GemmArgs p[SMX_GROUP_MAX];
+};
+
+__global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup G) {
+  __shared__ __attribute__((aligned(16))) float smem[GemmSmem<1, 1, 4, 1, 0>::FLOATS];
+  static_assert(GemmSmem<1, 1, 4, 1, 0>::FLOATS >= GemmSmem<4, 1, 1, 0, 0>::FLOATS &&
+                GemmSmem<1, 1, 4, 1, 0>::FLOATS >= GemmSmem<1, 1, 4, 0, 1>::FLOATS &&
+                GemmSmem<1, 1, 4, 1, 0>::FLOATS >= GemmSmem<4, 1, 1, 1, 0>::FLOATS, "LDS of the widest variant");
+  // Read the descriptor through the kernarg segment pointer: indexing the by-value struct with a
+  // run-time problem id would make the compiler copy all of it to scratch in every thread.
+  const GemmGroup& Gr = *(const GemmGroup*)__builtin_amdgcn_kernarg_segment_ptr();
+  int pi = 0;
+  while (pi + 1 < Gr.n && (int)blockIdx.x >= Gr.start[pi + 1]) ++pi;
+  const int local = blockIdx.x - Gr.start[pi];
+  const int gx = Gr.gx[pi], gy = Gr.gy[pi];
+  const int bx = local % gx, by = (local / gx) % gy, bz = local / (gx * gy);
+  const GemmArgs& g = Gr.p[pi];
+  switch (Gr.variant[pi]) {
+    case 0: gemm_body<4, 1, 1, 0, 0, 0>(g, bx, by, bz, smem); break;
+    case 1: gemm_body<4, 1, 1, 0, 0, 1>(g, bx, by, bz, smem); break;
+    case 2: gemm_body<4, 1, 1, 0, 1, 0>(g, bx, by, bz, smem); break;
+    case 4: gemm_body<4, 1, 1, 1, 0, 0>(g, bx, by, bz, smem); break;
+    case 5: gemm_body<4, 1, 1, 1, 0, 1>(g, bx, by, bz, smem); break;
+    case 8: gemm_body<1, 1, 4, 0, 0, 0>(g, bx, by, bz, smem); break;
+    case 9: gemm_body<1, 1, 4, 0, 0, 1>(g, bx, by, bz, smem); break;
+    case 10: gemm_body<1, 1, 4, 0, 1, 0>(g, bx, by, bz, smem); break;
+    case 12: gemm_body<1, 1, 4, 1, 0, 0>(g, bx, by, bz, smem); break;
+    case 13: gemm_body<1, 1, 4, 1, 0, 1>(g, bx, by, bz, smem); break;
+    default: break;
+  }
 }
 
 template <int WM, int WN, int WK>
@@ -230,8 +285,42 @@ int suggest_split_k(int M, int N, int K) {
   return (K + chunk - 1) / chunk;
 }
 
-int launch_gemm(hipStream_t st, const GemmArgs& g_in, int* eff_split) {
-  GemmArgs g = g_in;
+static int validate_gemm(GemmArgs& g);
+
+int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_splits) {
+  if (n <= 0 || n > SMX_GROUP_MAX) { set_error("gemm group: 1..SMX_GROUP_MAX problems"); return SMX_ERR_INVALID; }
+  GemmGroup G;
+  memset(&G, 0, sizeof(G));
+  G.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    GemmArgs g = list[i];
+    int rc = validate_gemm(g);
+    if (rc != SMX_OK) return rc;
+    if (g.a_kmajor && g.b_nmajor) { set_error("gemm group: unsupported layout"); return SMX_ERR_INVALID; }
+    if (g.use_xform && g.b_nmajor) { set_error("gemm group: gather transform only with k-major B"); return SMX_ERR_INVALID; }
+    // tile: K4 (32x32, in-workgroup split-K) for K-deep or narrow problems, 128x32 otherwise
+    const int kper = g.K / g.split_k;
+    int tile = g.tile;
+    if (tile != TILE_128x32 && tile != TILE_32x32_K4)
+      tile = (kper >= 128 && (long)((g.M + 127) / 128) * (g.N / 32) < 128) ? TILE_32x32_K4 : TILE_128x32;
+    const int BM = tile == TILE_128x32 ? 128 : 32, BK = tile == TILE_128x32 ? 32 : 128;
+    g.k_chunk = round_up((g.K + g.split_k - 1) / g.split_k, BK);
+    g.split_k = (g.K + g.k_chunk - 1) / g.k_chunk;
+    if (eff_splits) eff_splits[i] = g.split_k;
+    G.gx[i] = (g.M + BM - 1) / BM; G.gy[i] = g.N / 32;
+    G.variant[i] = (tile == TILE_128x32 ? 0 : 8) + (g.a_kmajor ? 4 : 0) + (g.b_nmajor ? 2 : 0) + (g.use_xform ? 1 : 0);
+    G.start[i] = total;
+    total += G.gx[i] * G.gy[i] * g.split_k;
+    G.p[i] = g;
+  }
+  G.start[n] = total;
+  hipLaunchKernelGGL(gemm_group_kernel, dim3(total), dim3(256), 0, st, G);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+static int validate_gemm(GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) { set_error("gemm: empty problem"); return SMX_ERR_INVALID; }
   if ((g.N % 32) || (g.lda % 4) || (g.ldb % 4) || (g.ldc % 4)) {
     set_error("gemm: N must be a multiple of 32 and leading dimensions multiples of 4");
@@ -243,6 +332,13 @@ int launch_gemm(hipStream_t st, const GemmArgs& g_in, int* eff_split) {
   if (g.split_k < 1) g.split_k = 1;
   if (g.split_k > 1 && (g.bias || g.colsum)) { set_error("gemm: bias/colsum need split_k == 1"); return SMX_ERR_INVALID; }
   if (g.colsum && g.b_nmajor) { set_error("gemm: colsum needs k-major B"); return SMX_ERR_INVALID; }
+  return SMX_OK;
+}
+
+int launch_gemm(hipStream_t st, const GemmArgs& g_in, int* eff_split) {
+  GemmArgs g = g_in;
+  int rc = validate_gemm(g);
+  if (rc != SMX_OK) return rc;
   int tile = g.tile;
   if (tile == TILE_AUTO) {
     const int kper = g.K / g.split_k;

@@ -55,6 +55,10 @@ struct GemmArgs {
 // Returns 0 or a negative smx_status.  N, lda, ldb, ldc multiples of 4; N multiple of 32.
 // eff_split (optional) receives the number of slabs actually written.
 int launch_gemm(hipStream_t st, const GemmArgs& g, int* eff_split = nullptr);
+// Several independent products in ONE launch (tiles 128x32 / 32x32-K4 only); eff_splits[i] receives
+// the slab count of problem i.
+#define SMX_GROUP_MAX 8
+int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_splits = nullptr);
 // Heuristic split-K factor used by the model for K-heavy products.
 int suggest_split_k(int M, int N, int K);
 
@@ -200,6 +204,42 @@ struct AdamArgs {
   float grad_scale = 1.f;       // 1/world after a sum all-reduce
 };
 int launch_adam(hipStream_t st, const AdamArgs& a);
+
+// Single-workgroup fused middle of the network (smx_mid.hip).
+#ifndef SMX_MAX_LAYERS
+#define SMX_MAX_LAYERS 8
+#endif
+struct MidLayer {
+  const float* W; int ldw;                 // [in_p][ldw]
+  const float* gamma; const float* beta; const float* bias;
+  float* moving_mean; float* moving_var; float* batch_mean; float* batch_var;
+  float* xhat; float* outb; float* inv_std; float* dpre;   // [B][out_p] saved activations
+  float* dgamma; float* dbeta; float* dbias;
+  int in_p, out, out_p;
+  float drop_p; uint32_t stream;
+  const float* inj_mask; int inj_ld;
+};
+
+struct MidArgs {
+  int B, batchnorm, training, update_moving;
+  float momentum, eps;
+  const float* h0; int h0_w;               // activated output of encoder layer 0 [B][h0_w]
+  int n_enc; MidLayer enc[SMX_MAX_LAYERS]; // encoder layers 1.. (layer 0 is the wide product)
+  const float* Wlat; int ld_wlat; const float* blat; int lat_in_p, lat_ld, D, Dp, stochastic, relu;
+  float* latbuf; float* z; float* sig; float* eps_out; float* kl;
+  int n_dec; MidLayer dec[SMX_MAX_LAYERS];
+  uint32_t k0, k1; const uint32_t* step_ptr; uint32_t step, sample;
+  const int32_t* rows; uint32_t cell_base;
+  const float* inj_eps; int inj_eps_ld;
+  unsigned long long* dbg;   // optional stage stamps (diagnostic builds of the host only)
+  // backward only
+  float kl_scale; float* dlat; float* dpre_enc0;   // d loss / d pre-activation of encoder layer 0 goes to enc0's dpre
+  const float* enc0_out; const float* enc0_xhat; const float* enc0_inv_std; const float* enc0_gamma;
+  float* enc0_dgamma; float* enc0_dbeta; float* enc0_dbias; int enc0_out_w, enc0_out_p; float enc0_drop_p;
+};
+
+int launch_mid_fwd(hipStream_t st, const MidArgs& a);
+int launch_mid_bwd(hipStream_t st, const MidArgs& a);
 
 // Test helper: Philox multipliers / normals exactly as kernels draw them.
 int launch_noise_probe(hipStream_t st, NoiseKey nk, const int64_t* cell_ids, int B, int width, float p, float* mult,

@@ -131,8 +131,8 @@ static int g_loss_vec = 0;
 static int loss_vec() {
   if (!g_loss_vec) {
     const char* e = getenv("SMX_LOSS_VEC");
-    g_loss_vec = e ? atoi(e) : 2;
-    if (g_loss_vec != 1 && g_loss_vec != 2 && g_loss_vec != 4) g_loss_vec = 2;
+    g_loss_vec = e ? atoi(e) : 1;
+    if (g_loss_vec != 1 && g_loss_vec != 2 && g_loss_vec != 4) g_loss_vec = 1;
   }
   return g_loss_vec;
 }

@@ -14,9 +14,11 @@
 #include <dlfcn.h>
 #include <math.h>
 #include <rccl/rccl.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -101,7 +103,9 @@ __global__ void bn_moving_update_kernel(float* moving, const float* batch_sum, i
 struct smx_model {
   smx_config cfg;
   int device = 0;
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr, st2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
+  bool forked = false;
   int G = 0, Gp = 0, D = 0, Dp = 0, k = 0, Bmax = 0;
   bool stochastic = true, scvi = false;
   std::vector<TensorInfo> tensors;
@@ -243,10 +247,11 @@ struct Pass {
 };
 
 int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
-                const char* label0) {
+                const char* label0, int n_layers = -1) {
   const float* in = in0;
   int ld = ld0;
-  for (size_t i = 0; i < mlp.size(); ++i) {
+  const size_t nl = n_layers < 0 ? mlp.size() : (size_t)n_layers;
+  for (size_t i = 0; i < nl; ++i) {
     MlpLayer& L = mlp[i];
     const TensorInfo& tw = m->tensors[L.tW];
     GemmArgs g;
@@ -329,32 +334,132 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
         if (const Injected* ij = inj(m, ST_INPUT_DROPOUT)) { g.xf.inj_mask = ij->d; g.xf.inj_ld = ij->ld; }
       }
     }
-    {
+    if (i == 0 && skip_input_grad) {
       Timed t(m, first_x ? label_dw0 : "gemm_mlp_dw");
       SMX_CHECK(launch_gemm(m->st, g));
+      n_slabs = 0;
+      break;
     }
-    if (i == 0 && skip_input_grad) { n_slabs = 0; break; }
-    // d in = dpre * W^T  -> slabs
+    // d in = dpre * W^T  -> slabs; independent of dW: one grouped launch for both
     GemmArgs h;
     h.A = L.dpre; h.lda = L.out_p; h.B = P_(m, L.tW); h.ldb = tw.ld; h.b_nmajor = 1;
     h.M = ps.B; h.N = L.in_p; h.K = L.out_p;
     h.C = m->slab; h.ldc = L.in_p; h.slab_stride = (long)ps.B * L.in_p;
     h.split_k = suggest_split_k(ps.B, L.in_p, L.out_p);
-    int eff = 1;
+    GemmArgs pair[2] = {g, h};
+    int effs[2] = {1, 1};
     {
-      Timed t(m, "gemm_mlp_dx");
-      SMX_CHECK(launch_gemm(m->st, h, &eff));
+      Timed t(m, "gemm_mlp_bwd");
+      SMX_CHECK(launch_gemm_group(m->st, pair, 2, effs));
     }
+    const int eff = effs[1];
     n_slabs = eff;
   }
   if (out_slabs) *out_slabs = n_slabs;
   return SMX_OK;
 }
 
+// ---- side stream: work that only the optimiser waits for (metrics, weight gradients of the
+// output head and of the middle layers) leaves the critical path ------------------------------
+bool side_ok(smx_model* m) { return m->st2 != nullptr && m->timing_label.empty(); }
+hipStream_t side_stream(smx_model* m) { return (m->forked && side_ok(m)) ? m->st2 : m->st; }
+int side_fork(smx_model* m, hipEvent_t ev) {
+  if (!side_ok(m)) return SMX_OK;
+  SMX_HIP(hipEventRecord(ev, m->st));
+  SMX_HIP(hipStreamWaitEvent(m->st2, ev, 0));
+  m->forked = true;
+  return SMX_OK;
+}
+int side_join(smx_model* m) {
+  if (!m->forked) return SMX_OK;
+  SMX_HIP(hipEventRecord(m->ev_join, m->st2));
+  SMX_HIP(hipStreamWaitEvent(m->st, m->ev_join, 0));
+  m->forked = false;
+  return SMX_OK;
+}
+
+bool use_mid(const smx_model* m, int B) {
+  // single-workgroup fusion of the middle is opt-in until it beats the per-operator path
+  static const bool off = getenv("SMX_FUSED") == nullptr;
+  if (off || m->scvi || B > 128) return false;
+  for (auto* mlp : {&m->enc, &m->dec})
+    for (auto& L : *mlp) if (L.out_p > 128) return false;
+  if ((m->stochastic ? 2 : 1) * m->Dp > 128) return false;
+  return true;
+}
+
+void fill_mid_layer(smx_model* m, const MlpLayer& L, MidLayer& o, bool training) {
+  memset(&o, 0, sizeof(o));
+  const TensorInfo& tw = m->tensors[L.tW];
+  o.W = P_(m, L.tW); o.ldw = tw.ld;
+  if (m->cfg.batchnorm) {
+    o.gamma = P_(m, L.tGamma); o.beta = P_(m, L.tBeta);
+    o.moving_mean = m->bn_moving + m->bn_off[L.bn]; o.moving_var = o.moving_mean + L.out_p;
+    o.batch_mean = m->grads + m->tail_off_bn + m->bn_off[L.bn]; o.batch_var = o.batch_mean + L.out_p;
+    o.dgamma = G_(m, L.tGamma); o.dbeta = G_(m, L.tBeta);
+  } else {
+    o.bias = P_(m, L.tBias); o.dbias = G_(m, L.tBias);
+  }
+  o.xhat = L.xhat; o.outb = L.out_buf; o.inv_std = L.inv_std; o.dpre = L.dpre;
+  o.in_p = L.in_p; o.out = L.out; o.out_p = L.out_p;
+  o.drop_p = training ? L.drop_p : 0.f; o.stream = (uint32_t)L.stream;
+  if (const Injected* ij = inj(m, L.stream)) { o.inj_mask = ij->d; o.inj_ld = ij->ld; }
+}
+
+void fill_mid_args(smx_model* m, const Pass& ps, MidArgs& a) {
+  memset(&a, 0, sizeof(a));
+  const smx_config& c = m->cfg;
+  a.B = ps.B; a.batchnorm = c.batchnorm; a.training = ps.training; a.update_moving = (m->world == 1);
+  a.momentum = c.bn_momentum; a.eps = c.bn_eps;
+  const MlpLayer& e0 = m->enc[0];
+  a.h0 = e0.out_buf; a.h0_w = e0.out_p;
+  a.n_enc = (int)m->enc.size() - 1;
+  for (int i = 0; i < a.n_enc; ++i) fill_mid_layer(m, m->enc[i + 1], a.enc[i], ps.training != 0);
+  const TensorInfo& tl = m->tensors[m->t_latW];
+  a.Wlat = P_(m, m->t_latW); a.ld_wlat = tl.ld; a.blat = P_(m, m->t_latb);
+  a.lat_in_p = m->enc.back().out_p; a.lat_ld = (m->stochastic ? 2 : 1) * m->Dp; a.D = m->D; a.Dp = m->Dp;
+  a.stochastic = m->stochastic; a.relu = (c.latent_activation == SMX_ACT_RELU);
+  a.latbuf = m->latbuf; a.z = m->z; a.sig = m->sig; a.eps_out = m->eps; a.kl = m->kl;
+  a.n_dec = (int)m->dec.size();
+  for (int i = 0; i < a.n_dec; ++i) fill_mid_layer(m, m->dec[i], a.dec[i], ps.training != 0);
+  a.k0 = (uint32_t)(c.seed & 0xFFFFFFFFu); a.k1 = (uint32_t)(c.seed >> 32);
+  a.step_ptr = ps.training ? &m->state->step : nullptr; a.step = 0; a.sample = (uint32_t)ps.sample;
+  a.rows = ps.rows; a.cell_base = ps.cell_base;
+  if (const Injected* ij = inj(m, ST_EPS_Z)) { a.inj_eps = ij->d; a.inj_eps_ld = ij->ld; }
+  a.kl_scale = c.beta / (float)ps.global_batch; a.dlat = m->dlat;
+  a.dpre_enc0 = e0.dpre; a.enc0_out = e0.out_buf; a.enc0_xhat = e0.xhat; a.enc0_inv_std = e0.inv_std;
+  a.enc0_out_w = e0.out; a.enc0_out_p = e0.out_p; a.enc0_drop_p = ps.training ? e0.drop_p : 0.f;
+  if (c.batchnorm) { a.enc0_gamma = P_(m, e0.tGamma); a.enc0_dgamma = G_(m, e0.tGamma); a.enc0_dbeta = G_(m, e0.tBeta); }
+  else a.enc0_dbias = G_(m, e0.tBias);
+}
+
 int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, bool decode_only = false) {
   const smx_config& c = m->cfg;
   const float inv_gb = 1.f / (float)ps.global_batch;
-  if (!decode_only) {
+  const bool mid = !decode_only && use_mid(m, ps.B);
+  if (mid) {
+    SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd", 1));
+    MidArgs ma;
+    fill_mid_args(m, ps, ma);
+    static unsigned long long* dbg = nullptr;
+    static const bool want_dbg = getenv("SMX_MID_STAMPS") != nullptr;
+    if (want_dbg && !dbg) dmalloc(&dbg, (size_t)32);
+    ma.dbg = want_dbg ? dbg : nullptr;
+    Timed t(m, "mid_fwd");
+    SMX_CHECK(launch_mid_fwd(m->st, ma));
+    if (want_dbg && !m->capturing) {
+      unsigned long long h[32];
+      hipStreamSynchronize(m->st);
+      hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+      static int printed = 0;
+      if (printed++ % 50 == 10) {
+        fprintf(stderr, "mid_fwd stamps (cycles @100MHz*?):");
+        for (int i = 1; i < 8; ++i) fprintf(stderr, " %lld", (long long)(h[i] - h[i - 1]));
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+  if (!decode_only && !mid) {
   // ---- encoder ----
   SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd"));
   const MlpLayer& eL = m->enc.back();
@@ -397,7 +502,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, bo
   }
   }  // !decode_only
   // ---- decoder ----
-  SMX_CHECK(mlp_forward(m, m->dec, ps, m->z, m->Dp, false, ""));
+  if (!mid) SMX_CHECK(mlp_forward(m, m->dec, ps, m->z, m->Dp, false, ""));
   const MlpLayer& dL = m->dec.back();
   const long ldp = (long)m->k * m->Gp;
   if (m->scvi) {
@@ -456,9 +561,72 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, bo
   me.kl = m->stochastic ? m->kl : nullptr; me.kl_l = m->scvi ? m->kl_l : nullptr;
   me.B = ps.B; me.alpha = c.alpha; me.beta = c.beta; me.inv_global_batch = inv_gb;
   me.out = m->grads + m->tail_off_metrics;
+  if (backward) SMX_CHECK(side_fork(m, m->ev_fork));   // dP / llk / kl are final: side work may start
   {
     Timed t(m, "metrics");
-    SMX_CHECK(launch_metrics(m->st, me));
+    SMX_CHECK(launch_metrics(side_stream(m), me));
+  }
+  return SMX_OK;
+}
+
+// fused-middle backward: slab-consuming BN backward of the last decoder layer, the single-workgroup
+// chain down to d pre-activation of encoder layer 0, then the wide encoder weight gradient on the main
+// stream while the small weight gradients run on the side stream.
+int backward_mid(smx_model* m, const Pass& ps, int n_slabs) {
+  const smx_config& c = m->cfg;
+  MlpLayer& dL = m->dec.back();
+  {
+    BnBwdArgs b;
+    b.dout = m->slab; b.n_slabs = n_slabs; b.slab_stride = (long)ps.B * dL.out_p; b.ld = dL.out_p;
+    b.out = dL.out_buf; b.xhat = dL.xhat; b.inv_std = dL.inv_std;
+    b.B = ps.B; b.H = dL.out; b.Hp = dL.out_p; b.batchnorm = c.batchnorm; b.training = ps.training;
+    b.drop_scale = (ps.training && dL.drop_p > 0.f) ? 1.f / (1.f - dL.drop_p) : 1.f;
+    b.dpre = dL.dpre;
+    if (c.batchnorm) { b.gamma = P_(m, dL.tGamma); b.dgamma = G_(m, dL.tGamma); b.dbeta = G_(m, dL.tBeta); }
+    else b.dbias = G_(m, dL.tBias);
+    Timed t(m, "bn_bwd");
+    SMX_CHECK(launch_bn_act_bwd(m->st, b));
+  }
+  MidArgs ma;
+  fill_mid_args(m, ps, ma);
+  {
+    Timed t(m, "mid_bwd");
+    SMX_CHECK(launch_mid_bwd(m->st, ma));
+  }
+  auto dwa = [&](const float* A, int lda, int M, const float* Bm, int ldb, int N, int tW, float* colsum, bool xform) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.a_kmajor = 1; g.B = Bm; g.ldb = ldb;
+    g.C = G_(m, tW); g.ldc = m->tensors[tW].ld; g.M = M; g.N = N; g.K = ps.B; g.colsum = colsum;
+    if (xform) {
+      g.use_xform = 1;
+      g.xf.rows = ps.rows; g.xf.log1p = c.log_norm; g.xf.cell_base = ps.cell_base;
+      if (ps.training && c.input_dropout > 0.f) {
+        g.xf.drop_p = c.input_dropout; g.xf.drop_scale = 1.f / (1.f - c.input_dropout);
+        g.xf.nk = make_key(m, ST_INPUT_DROPOUT, ps.sample, true);
+        if (const Injected* ij = inj(m, ST_INPUT_DROPOUT)) { g.xf.inj_mask = ij->d; g.xf.inj_ld = ij->ld; }
+      }
+    }
+    return g;
+  };
+  // all weight gradients below the output head are independent now: ONE grouped launch
+  std::vector<GemmArgs> grp;
+  grp.push_back(dwa(ps.Xsrc, m->Gp, m->enc[0].in_p, m->enc[0].dpre, m->enc[0].out_p, m->enc[0].out_p, m->enc[0].tW, nullptr, true));
+  for (size_t i = 0; i < m->dec.size(); ++i) {
+    MlpLayer& L = m->dec[i];
+    const float* in = (i == 0) ? m->z : m->dec[i - 1].out_buf;
+    grp.push_back(dwa(in, L.in_p, L.in_p, L.dpre, L.out_p, L.out_p, L.tW, nullptr, false));
+  }
+  const int lat_ld = (m->stochastic ? 2 : 1) * m->Dp;
+  grp.push_back(dwa(m->enc.back().out_buf, m->enc.back().out_p, m->enc.back().out_p, m->dlat, lat_ld, lat_ld, m->t_latW,
+                    G_(m, m->t_latb), false));
+  for (size_t i = 1; i < m->enc.size(); ++i) {
+    MlpLayer& L = m->enc[i];
+    grp.push_back(dwa(m->enc[i - 1].out_buf, L.in_p, L.in_p, L.dpre, L.out_p, L.out_p, L.tW, nullptr, false));
+  }
+  Timed t(m, "gemm_enc_dw");
+  for (size_t i = 0; i < grp.size(); i += SMX_GROUP_MAX) {
+    const int n = (int)std::min<size_t>(SMX_GROUP_MAX, grp.size() - i);
+    SMX_CHECK(launch_gemm_group(m->st, grp.data() + i, n));
   }
   return SMX_OK;
 }
@@ -480,48 +648,62 @@ int backward_pass(smx_model* m, const Pass& ps) {
     dparams = m->draw;
   }
   const int n_heads = m->scvi ? m->k : 1;
-  for (int ch = 0; ch < n_heads; ++ch) {
-    const TensorInfo& tw = m->tensors[m->t_outW[ch]];
-    const float* dp = dparams + (m->scvi ? (long)ch * m->Gp : 0);
-    const int ncols = m->scvi ? m->Gp : (int)ldp;
-    {  // dW = d^T dP, db = colsum(dP)
-      GemmArgs g;
+  {
+    // weight gradient and input gradient of every head read the same dP and are independent:
+    // one grouped launch (dW tiles + split-K dX slabs side by side)
+    std::vector<GemmArgs> grp;
+    std::vector<int> is_dx;
+    for (int ch = 0; ch < n_heads; ++ch) {
+      const TensorInfo& tw = m->tensors[m->t_outW[ch]];
+      const float* dp = dparams + (m->scvi ? (long)ch * m->Gp : 0);
+      const int ncols = m->scvi ? m->Gp : (int)ldp;
+      GemmArgs g;  // dW = d^T dP, db = colsum(dP)
       g.A = dL.out_buf; g.lda = dL.out_p; g.a_kmajor = 1; g.B = dp; g.ldb = (int)ldp;
       g.C = G_(m, m->t_outW[ch]); g.ldc = tw.ld; g.M = dL.out_p; g.N = ncols; g.K = ps.B;
       g.colsum = G_(m, m->t_outb[ch]);
-      Timed t(m, "gemm_out_dw");
-      SMX_CHECK(launch_gemm(m->st, g));
+      g.tile = TILE_128x32;
+      grp.push_back(g); is_dx.push_back(0);
+      GemmArgs h;  // dd += dP W^T
+      h.A = dp; h.lda = (int)ldp; h.B = P_(m, m->t_outW[ch]); h.ldb = tw.ld; h.b_nmajor = 1;
+      h.C = nullptr; h.ldc = dL.out_p; h.slab_stride = dd_stride;
+      h.M = ps.B; h.N = dL.out_p; h.K = ncols;
+      h.split_k = suggest_split_k(ps.B, dL.out_p, ncols);
+      h.tile = TILE_32x32_K4;
+      grp.push_back(h); is_dx.push_back(1);
     }
-    {  // dd += dP W^T
-      GemmArgs g;
-      g.A = dp; g.lda = (int)ldp; g.B = P_(m, m->t_outW[ch]); g.ldb = tw.ld; g.b_nmajor = 1;
-      g.C = m->slab + (long)n_slabs * dd_stride; g.ldc = dL.out_p; g.slab_stride = dd_stride;
-      g.M = ps.B; g.N = dL.out_p; g.K = ncols;
-      g.split_k = suggest_split_k(ps.B, dL.out_p, ncols);
-      int eff = 1;
-      Timed t(m, "gemm_out_dx");
-      SMX_CHECK(launch_gemm(m->st, g, &eff));
-      n_slabs += eff;
-    }
-  }
-  for (int j = 0; j < c.n_labels; ++j) {
-    const TensorInfo& tw = m->tensors[m->t_labW[j]];
-    {
+    for (int j = 0; j < c.n_labels; ++j) {
+      const TensorInfo& tw = m->tensors[m->t_labW[j]];
       GemmArgs g;
       g.A = dL.out_buf; g.lda = dL.out_p; g.a_kmajor = 1; g.B = m->laby_draw[j]; g.ldb = tw.ld;
       g.C = G_(m, m->t_labW[j]); g.ldc = tw.ld; g.M = dL.out_p; g.N = tw.ld; g.K = ps.B;
       g.colsum = G_(m, m->t_labb[j]);
-      SMX_CHECK(launch_gemm(m->st, g));
+      grp.push_back(g); is_dx.push_back(0);
+      GemmArgs h;
+      h.A = m->laby_draw[j]; h.lda = tw.ld; h.B = P_(m, m->t_labW[j]); h.ldb = tw.ld; h.b_nmajor = 1;
+      h.C = nullptr; h.ldc = dL.out_p; h.slab_stride = dd_stride;
+      h.M = ps.B; h.N = dL.out_p; h.K = tw.ld;
+      grp.push_back(h); is_dx.push_back(1);
     }
-    {
-      GemmArgs g;
-      g.A = m->laby_draw[j]; g.lda = tw.ld; g.B = P_(m, m->t_labW[j]); g.ldb = tw.ld; g.b_nmajor = 1;
-      g.C = m->slab + (long)n_slabs * dd_stride; g.ldc = dL.out_p; g.slab_stride = dd_stride;
-      g.M = ps.B; g.N = dL.out_p; g.K = tw.ld;
-      SMX_CHECK(launch_gemm(m->st, g));
-      n_slabs += 1;
+    // slab slots: split factors are known up front (launch_gemm_group recomputes the same values)
+    for (size_t i = 0; i < grp.size(); ++i) {
+      if (!is_dx[i]) continue;
+      GemmArgs& h = grp[i];
+      const int BK = 128;  // K4 tile for split products; single-slab products may take either tile
+      int eff = 1;
+      if (h.split_k > 1) {
+        const int chunk = round_up((h.K + h.split_k - 1) / h.split_k, BK);
+        eff = (h.K + chunk - 1) / chunk;
+      }
+      h.C = m->slab + (long)n_slabs * dd_stride;
+      n_slabs += eff;
+    }
+    Timed t(m, "gemm_out_bwd");
+    for (size_t i = 0; i < grp.size(); i += SMX_GROUP_MAX) {
+      const int n = (int)std::min<size_t>(SMX_GROUP_MAX, grp.size() - i);
+      SMX_CHECK(launch_gemm_group(m->st, grp.data() + i, n));
     }
   }
+  if (use_mid(m, ps.B)) return backward_mid(m, ps, n_slabs);
   // ---- decoder MLP, leaves dz slabs ----
   int dz_slabs = 0;
   SMX_CHECK(mlp_backward(m, m->dec, ps, m->z, m->Dp, false, n_slabs, false, &dz_slabs, ""));
@@ -575,6 +757,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
 
 int optimizer_pass(smx_model* m) {
   const smx_config& c = m->cfg;
+  SMX_CHECK(side_join(m));
   static const bool force_ar = getenv("SMX_FORCE_ALLREDUCE") != nullptr;  // exercise RCCL on a 1-rank communicator
   if (m->comm && (m->world > 1 || force_ar)) {
     Timed t(m, "allreduce");
@@ -765,6 +948,15 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   int rc = SMX_OK;
   auto fail = [&](int code) { smx_model_destroy(m); return code; };
   if (hipStreamCreate(&m->st) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(SMX_ERR_HIP); }
+  // Forked streams inside the captured graph measured SLOWER on ROCm 7.2 (+38 us per step: the
+  // cross-stream dependencies cost more than the overlap buys); opt-in only.
+  if (getenv("SMX_SIDE_STREAM")) {
+    if (hipStreamCreate(&m->st2) != hipSuccess || hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
+      set_error("side stream creation failed"); return fail(SMX_ERR_HIP);
+    }
+  }
   // ---- manifest (same order as oracle/sisua_oracle.py:manifest) ----
   int h = build_mlp(m, m->enc, "enc", m->G, cfg->n_enc, cfg->enc_units, ST_ENC_DROPOUT, cfg->dropout_enc);
   m->t_latW = add_tensor(m, "lat/W", h, (m->stochastic ? 2 : 1) * m->D, m->stochastic ? 2 : 1, false);
@@ -875,6 +1067,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
 int smx_model_destroy(smx_model* m) {
   if (!m) return SMX_OK;
   if (m->st) hipStreamSynchronize(m->st);
+  if (m->st2) hipStreamSynchronize(m->st2);
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
   for (auto& ev : m->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
   if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
@@ -890,6 +1083,10 @@ int smx_model_destroy(smx_model* m) {
   fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);
   fr(m->chunks); fr(m->partial); fr(m->tensor_norm);
   for (auto& kv : m->injected) fr(kv.second.d);
+  if (m->ev_fork) hipEventDestroy(m->ev_fork);
+  if (m->ev_fork2) hipEventDestroy(m->ev_fork2);
+  if (m->ev_join) hipEventDestroy(m->ev_join);
+  if (m->st2) hipStreamDestroy(m->st2);
   if (m->st) hipStreamDestroy(m->st);
   delete m;
   return SMX_OK;

@@ -23,7 +23,7 @@ def test_philox_dropout_bit_exact_and_normals(eng):
     ref_m = so.philox_dropout_mask(8, stream, step, ids, width, p, sample)
     assert np.array_equal(mult, ref_m.astype(np.float32))          # integer-exact decisions
     ref_n = so.philox_normal(8, stream, step, ids, width, sample)
-    assert np.allclose(nrm, ref_n, rtol=2e-5, atol=2e-6)
+    assert np.allclose(nrm, ref_n, rtol=2e-5, atol=1e-5)   # fast v_log / v_sin / v_cos forms
   # 64-bit seed reaches both key words
   m1, _ = eng.k_noise((7 << 32) | 8, 16, 0, ids, 16, p=0.5)
   assert np.array_equal(m1, so.philox_dropout_mask((7 << 32) | 8, 16, 0, ids, 16, 0.5).astype(np.float32))

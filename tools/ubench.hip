@@ -2,6 +2,7 @@
 // per-kernel cost of dependent launches (eager / graph), dependent-load chains, stream copy rate.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <chrono>
 #include <vector>
 #define CK(x) do { hipError_t e=(x); if(e!=hipSuccess){printf("ERR %s line %d: %s\n",#x,__LINE__,hipGetErrorString(e)); return 1;} } while(0)
@@ -12,6 +13,9 @@ __global__ void k_chain(const int* idx, int* out, int n) {  // n dependent loads
   if (threadIdx.x == 0 && blockIdx.x == 0) { int j = 0; for (int i = 0; i < n; ++i) j = idx[j]; out[0] = j; }
 }
 __global__ void k_copy(const float4* a, float4* b, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+__global__ void k_copy1(const float* a, float* b, size_t n) {  // 4 B per lane, the loss kernel's access width
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
 }
 __global__ void k_fma(float* out, int iters) {
@@ -47,6 +51,15 @@ template <typename F> double time_eager(hipStream_t st, int nk, int reps, F laun
 
 int main() {
   hipStream_t st; CK(hipStreamCreate(&st));
+  if (getenv("UBENCH_CALIB")) {  // one launch each, for PMC byte-counter calibration: 64 MiB read + 64 MiB written
+    size_t sz = (size_t)64 << 20;
+    float4 *a, *b; CK(hipMalloc(&a, sz)); CK(hipMalloc(&b, sz)); CK(hipMemset(a, 1, sz)); CK(hipMemset(b, 0, sz));
+    CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, st, a, b, sz / 16);
+    hipLaunchKernelGGL(k_copy1, dim3(2048), dim3(256), 0, st, (const float*)a, (float*)b, sz / 4);
+    CK(hipStreamSynchronize(st));
+    return 0;
+  }
   int *d; CK(hipMalloc(&d, 1 << 20)); CK(hipMemset(d, 0, 1 << 20));
   printf("per-kernel cost, dependent launches on one stream (us):\n");
   for (int wg : {1, 16, 256, 2048}) {
