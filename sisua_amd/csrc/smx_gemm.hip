@@ -14,6 +14,7 @@
 //   * the A operand can be produced on the fly from the resident cells x genes
 //     matrix: row gather, log1p and input dropout are applied while staging
 //     (SingleCellModel.encode, sisua/models/single_cell_model.py:126-134).
+#include <stdlib.h>
 #include <string.h>
 
 #include "smx_internal.h"
@@ -342,8 +343,9 @@ int launch_gemm(hipStream_t st, const GemmArgs& g_in, int* eff_split) {
   int tile = g.tile;
   if (tile == TILE_AUTO) {
     const int kper = g.K / g.split_k;
-    if (g.use_xform && !g.a_kmajor && g.N == 128) tile = TILE_32x128;  // transform each A element once
-    else if (g.use_xform && !g.a_kmajor && g.N == 64) tile = TILE_64x64;
+    static const int xf_tile = getenv("SMX_XF_TILE") ? atoi(getenv("SMX_XF_TILE")) : 0;
+    if (g.use_xform && !g.a_kmajor && xf_tile) tile = xf_tile;
+    else if (g.use_xform && !g.a_kmajor) tile = TILE_32x32_K4;  // measured best for the gathered log1p operand (log is one v_log)
     else if (kper >= 128 && (long)((g.M + 127) / 128) * (g.N / 32) < 128) tile = TILE_32x32_K4;
     else if (g.M > 64 || g.N % 64) tile = TILE_128x32;
     else if (g.M > 32) tile = TILE_64x64;

@@ -173,14 +173,16 @@ int launch_label_loss(hipStream_t st, const LabelArgs& a);
 
 // Per-step device-resident scalars.
 struct StepState {
-  uint32_t step;      // index of the step in flight (Philox counter word 2); = next - 1 during a step
-  uint32_t next;      // optimiser steps started so far
+  uint32_t step;      // index of the step in flight (Philox counter word 2)
+  uint32_t next;      // master copy only: optimiser steps completed so far
   float lr_t;         // bias-corrected Adam step size of the step in flight
-  uint32_t cursor;    // position (in steps) inside the uploaded row-id order
+  uint32_t cursor;    // position (in steps) of the step in flight inside the uploaded row-id order
 };
-// Copies this step's `batch` row ids from order + cursor*batch to rows, advances cursor/step, sets lr_t.
-int launch_step_begin(hipStream_t st, StepState* s, const int32_t* order, int32_t* rows, int batch, float lr,
-                      float b1, float b2);
+// Prepares the per-step state `dst` (+ row ids) of the step at order position `cursor` from the master
+// counter.  Eager mode runs it once per train_steps call (later steps are prepared by the optimiser
+// kernel of the step before); graph mode runs it as the first node of every step.
+int launch_step_begin(hipStream_t st, StepState* master, StepState* dst, const int32_t* order, int32_t* rows,
+                      int batch, int cursor_from_master, uint32_t cursor, float lr, float b1, float b2);
 
 struct MetricsArgs {
   const float* llk_part = nullptr; int n_chunks = 0;   // [B][n_chunks]
@@ -195,6 +197,11 @@ int launch_metrics(hipStream_t st, const MetricsArgs& a);
 // Optimiser over the flat parameter buffer.
 struct OptChunk { int32_t tensor; int32_t offset; int32_t count; int32_t first_chunk; int32_t n_chunks; int32_t pad[3]; };
 struct AdamArgs {
+  // ELBO scalars ride along as one extra workgroup of the gradient-norm kernel
+  MetricsArgs metrics; int with_metrics = 0;
+  // the optimiser's workgroup 0 finishes the step: master counter, and the state + row ids of the next step
+  StepState* master = nullptr; StepState* next_state = nullptr; const int32_t* order = nullptr; int32_t* next_rows = nullptr;
+  int batch = 0, prepare_next = 0; float lr = 1e-3f;
   float* params = nullptr; float* grads = nullptr; float* m = nullptr; float* v = nullptr;
   const OptChunk* chunks = nullptr; int n_chunks = 0;
   float* partial = nullptr;     // [n_chunks] sum of squares per chunk

@@ -178,15 +178,16 @@ constexpr int BN_COLS = 4;
 constexpr int BN_RL = 64;
 constexpr int BN_RPT = 2;
 
-__device__ inline float bn_col_reduce(float v, float* sh /*[BN_RL][BN_COLS]*/) {
-  const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
+// column sum over the workgroup: lanes of a wave that share a column are 4 apart (xor 4..32),
+// then the 4 waves meet in LDS; fixed order -> deterministic
+__device__ inline float bn_col_reduce(float v, float* sh /*[4][BN_COLS]*/) {
+  const int c = threadIdx.x % BN_COLS, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = BN_COLS; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
   __syncthreads();
-  sh[rl * BN_COLS + c] = v;
+  if ((threadIdx.x & 63) < BN_COLS) sh[w * BN_COLS + c] = v;
   __syncthreads();
-  float s = 0.f;
-#pragma unroll 16
-  for (int i = 0; i < BN_RL; ++i) s += sh[i * BN_COLS + c];  // fixed order: deterministic
-  return s;
+  return (sh[c] + sh[BN_COLS + c]) + (sh[2 * BN_COLS + c] + sh[3 * BN_COLS + c]);
 }
 
 // sum of the split-K slabs for BN_RPT rows of one column, loads issued together
@@ -195,17 +196,17 @@ __device__ inline void slab_sum(const float* base, int n_slabs, long slab_stride
 #pragma unroll
   for (int i = 0; i < BN_RPT; ++i) acc[i] = 0.f;
   int s = 0;
-  for (; s + 4 <= n_slabs; s += 4) {
-    float t[4][BN_RPT];
+  for (; s + 8 <= n_slabs; s += 8) {
+    float t[8][BN_RPT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 8; ++q)
 #pragma unroll
       for (int i = 0; i < BN_RPT; ++i) {
         const int r = r0 + rl + BN_RL * i;
         t[q][i] = r < B ? base[(long)(s + q) * slab_stride + (long)r * ld + col] : 0.f;
       }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 8; ++q)
 #pragma unroll
       for (int i = 0; i < BN_RPT; ++i) acc[i] += t[q][i];
   }
@@ -217,15 +218,17 @@ __device__ inline void slab_sum(const float* base, int n_slabs, long slab_stride
     }
 }
 
+template <bool SMALL>  // SMALL: B <= BN_RL * BN_RPT, every value of the column stays in registers
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
-  __shared__ float sh[BN_RL * BN_COLS];
+  __shared__ float sh[4 * BN_COLS];
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = blockIdx.x * BN_COLS + c;
   const bool live = col < a.H;  // padded columns produce zeros
   const float bias = (!a.batchnorm && a.bias && live) ? a.bias[col] : 0.f;
   constexpr int CH = BN_RL * BN_RPT;
+  float vreg[BN_RPT];
 
-  // pass 1: slab sum (+ bias) -> xhat buffer (scratch), column sum
+  // pass 1: slab sum (+ bias), column sum
   float s1 = 0.f;
   for (int r0 = 0; r0 < a.B; r0 += CH) {
     float acc[BN_RPT];
@@ -233,9 +236,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
 #pragma unroll
     for (int i = 0; i < BN_RPT; ++i) {
       const int r = r0 + rl + BN_RL * i;
+      const float v = acc[i] + bias;
+      if (SMALL) vreg[i] = v;
       if (r < a.B) {
-        const float v = acc[i] + bias;
-        a.xhat[(long)r * a.Hp + col] = v;
+        if (!SMALL) a.xhat[(long)r * a.Hp + col] = v;
         s1 += v;
       }
     }
@@ -249,9 +253,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
       s1 = bn_col_reduce(s1, sh);
       mean = s1 / (float)a.B;
       float s2 = 0.f;
-      for (int r = rl; r < a.B; r += BN_RL) {
-        const float d = a.xhat[(long)r * a.Hp + col] - mean;
-        s2 += d * d;
+      if (SMALL) {
+#pragma unroll
+        for (int i = 0; i < BN_RPT; ++i)
+          if (rl + BN_RL * i < a.B) { const float d = vreg[i] - mean; s2 += d * d; }
+      } else {
+        for (int r = rl; r < a.B; r += BN_RL) {
+          const float d = a.xhat[(long)r * a.Hp + col] - mean;
+          s2 += d * d;
+        }
       }
       s2 = bn_col_reduce(s2, sh);
       var = s2 / (float)a.B;
@@ -271,15 +281,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
   }
   const bool drop = a.training && a.drop_p > 0.f;
   const float scale = drop ? 1.f / (1.f - a.drop_p) : 1.f;
-  for (int r = rl; r < a.B; r += BN_RL) {
+  auto finish = [&](int r, float v) {
     const long o = (long)r * a.Hp + col;
-    float v = a.xhat[o];
     float y = v;
     if (a.batchnorm) {
       v = (v - mean) * inv;
       y = gamma * v + beta;
-      a.xhat[o] = v;
     }
+    if (a.batchnorm || SMALL) a.xhat[o] = v;
     float h = fmaxf(y, 0.f);
     if (drop) {
       float mult;
@@ -292,22 +301,32 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
       h *= mult;
     }
     a.out[o] = live ? h : 0.f;
+  };
+  if (SMALL) {
+#pragma unroll
+    for (int i = 0; i < BN_RPT; ++i)
+      if (rl + BN_RL * i < a.B) finish(rl + BN_RL * i, vreg[i]);
+  } else {
+    for (int r = rl; r < a.B; r += BN_RL) finish(r, a.xhat[(long)r * a.Hp + col]);
   }
 }
 
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a) {
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_fwd: bad shapes"); return SMX_ERR_INVALID; }
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(a.Hp / BN_COLS), dim3(256), 0, st, a);
+  if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(a.Hp / BN_COLS), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(a.Hp / BN_COLS), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
 
+template <bool SMALL>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdArgs a) {
-  __shared__ float sh[BN_RL * BN_COLS];
+  __shared__ float sh[4 * BN_COLS];
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = blockIdx.x * BN_COLS + c;
   const bool live = col < a.H;
   constexpr int CH = BN_RL * BN_RPT;
+  float dyreg[BN_RPT], xhreg[BN_RPT];
   float s1 = 0.f, s2 = 0.f;
   for (int r0 = 0; r0 < a.B; r0 += CH) {
     float acc[BN_RPT];
@@ -315,18 +334,26 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < BN_RPT; ++i) {
       const int r = r0 + rl + BN_RL * i;
+      float dy = 0.f, xh = 0.f;
       if (r < a.B) {
         const long o = (long)r * a.Hp + col;
-        const float dy = (live && a.out[o] > 0.f) ? acc[i] * a.drop_scale : 0.f;
-        a.dpre[o] = dy;
+        dy = (live && a.out[o] > 0.f) ? acc[i] * a.drop_scale : 0.f;
+        if (a.batchnorm) xh = a.xhat[o];
+        if (!SMALL) a.dpre[o] = dy;
         s1 += dy;
-        if (a.batchnorm) s2 += dy * a.xhat[o];
+        s2 += dy * xh;
       }
+      if (SMALL) { dyreg[i] = dy; xhreg[i] = xh; }
     }
   }
   s1 = bn_col_reduce(s1, sh);
   if (!a.batchnorm) {
     if (rl == 0 && a.dbias && live) a.dbias[col] = s1;
+    if (SMALL) {
+#pragma unroll
+      for (int i = 0; i < BN_RPT; ++i)
+        if (rl + BN_RL * i < a.B) a.dpre[(long)(rl + BN_RL * i) * a.Hp + col] = dyreg[i];
+    }
     return;
   }
   s2 = bn_col_reduce(s2, sh);
@@ -334,19 +361,25 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdArgs a) {
   const float inv = a.inv_std[col];
   if (rl == 0) { a.dgamma[col] = live ? s2 : 0.f; a.dbeta[col] = live ? s1 : 0.f; }
   const float invB = 1.f / (float)a.B;
-  for (int r = rl; r < a.B; r += BN_RL) {
-    const long o = (long)r * a.Hp + col;
-    const float dy = a.dpre[o];
+  auto finish = [&](int r, float dy, float xh) {
     float d;
-    if (a.training) d = gamma * inv * (dy - invB * (s1 + a.xhat[o] * s2));
+    if (a.training) d = gamma * inv * (dy - invB * (s1 + xh * s2));
     else d = dy * gamma * inv;
-    a.dpre[o] = d;
+    a.dpre[(long)r * a.Hp + col] = d;
+  };
+  if (SMALL) {
+#pragma unroll
+    for (int i = 0; i < BN_RPT; ++i)
+      if (rl + BN_RL * i < a.B) finish(rl + BN_RL * i, dyreg[i], xhreg[i]);
+  } else {
+    for (int r = rl; r < a.B; r += BN_RL) finish(r, a.dpre[(long)r * a.Hp + col], a.xhat[(long)r * a.Hp + col]);
   }
 }
 
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a) {
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_bwd: bad shapes"); return SMX_ERR_INVALID; }
-  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(a.Hp / BN_COLS), dim3(256), 0, st, a);
+  if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(a.Hp / BN_COLS), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(a.Hp / BN_COLS), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
@@ -600,29 +633,33 @@ int launch_label_loss(hipStream_t st, const LabelArgs& a) {
 // ===========================================================================
 // per-step scalars, metrics
 // ===========================================================================
-__global__ void step_begin_kernel(StepState* s, const int32_t* order, int32_t* rows, int batch, float lr, float b1,
-                                  float b2) {
-  const uint32_t cur = s->cursor;
-  if (order) {
+__device__ inline float adam_lr_t(float lr, float b1, float b2, uint32_t t /* 1-based */) {
+  return lr * sqrtf(1.f - powf(b2, (float)t)) / (1.f - powf(b1, (float)t));
+}
+
+__global__ void step_begin_kernel(StepState* master, StepState* dst, const int32_t* order, int32_t* rows, int batch,
+                                  int cursor_from_master, uint32_t cursor, float lr, float b1, float b2) {
+  const uint32_t cur = cursor_from_master ? master->cursor : cursor;
+  if (order)
     for (int i = threadIdx.x; i < batch; i += blockDim.x) rows[i] = order[(long)cur * batch + i];
-  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t t = s->next + 1;  // 1-based Adam step
-    s->step = s->next;
-    s->next = t;
-    s->cursor = cur + 1;
-    s->lr_t = lr * sqrtf(1.f - powf(b2, (float)t)) / (1.f - powf(b1, (float)t));
+    const uint32_t step = master->next;
+    dst->step = step;
+    dst->cursor = cur;
+    dst->lr_t = adam_lr_t(lr, b1, b2, step + 1);
+    if (cursor_from_master) master->cursor = cur + 1;
   }
 }
-int launch_step_begin(hipStream_t st, StepState* s, const int32_t* order, int32_t* rows, int batch, float lr,
-                      float b1, float b2) {
-  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(256), 0, st, s, order, rows, batch, lr, b1, b2);
+int launch_step_begin(hipStream_t st, StepState* master, StepState* dst, const int32_t* order, int32_t* rows,
+                      int batch, int cursor_from_master, uint32_t cursor, float lr, float b1, float b2) {
+  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(256), 0, st, master, dst, order, rows, batch, cursor_from_master,
+                     cursor, lr, b1, b2);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
 
-__global__ __launch_bounds__(256) void metrics_kernel(MetricsArgs a) {
+__device__ inline void metrics_body(const MetricsArgs& a) {
   __shared__ float sh[4];
   float sx = 0.f, sy = 0.f, sk = 0.f, sl = 0.f;
   for (int b = threadIdx.x; b < a.B; b += 256) {
@@ -645,6 +682,8 @@ __global__ __launch_bounds__(256) void metrics_kernel(MetricsArgs a) {
     a.out[5] = 0.f; a.out[6] = 0.f; a.out[7] = 0.f;
   }
 }
+
+__global__ __launch_bounds__(256) void metrics_kernel(MetricsArgs a) { metrics_body(a); }
 int launch_metrics(hipStream_t st, const MetricsArgs& a) {
   hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
@@ -655,6 +694,10 @@ int launch_metrics(hipStream_t st, const MetricsArgs& a) {
 // optimiser: per-tensor clipnorm + Adam over the flat buffer
 // ===========================================================================
 __global__ __launch_bounds__(256) void grad_sqsum_kernel(AdamArgs a) {
+  if ((int)blockIdx.x == a.n_chunks) {  // the extra workgroup: ELBO scalars of this step
+    metrics_body(a.metrics);
+    return;
+  }
   __shared__ float sh[4];
   const OptChunk ch = a.chunks[blockIdx.x];
   float s = 0.f;
@@ -697,10 +740,23 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
     v4[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
     p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
   }
+  if (blockIdx.x == 0 && a.master) {  // close the step; nobody reads next_state / next_rows during this step
+    const uint32_t step = a.state->step, cur = a.state->cursor;
+    if (a.prepare_next)
+      for (int i = threadIdx.x; i < a.batch; i += 256) a.next_rows[i] = a.order[(long)(cur + 1) * a.batch + i];
+    if (threadIdx.x == 0) {
+      a.master->next = step + 1;
+      if (a.prepare_next) {
+        a.next_state->step = step + 1;
+        a.next_state->cursor = cur + 1;
+        a.next_state->lr_t = adam_lr_t(a.lr, a.b1, a.b2, step + 2);
+      }
+    }
+  }
 }
 
 int launch_adam(hipStream_t st, const AdamArgs& a) {
-  hipLaunchKernelGGL(grad_sqsum_kernel, dim3(a.n_chunks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(grad_sqsum_kernel, dim3(a.n_chunks + (a.with_metrics ? 1 : 0)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_chunks), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;

@@ -128,8 +128,11 @@ struct smx_model {
   // host-batch staging for smx_forward(host_x)
   float* hostX = nullptr; float* hostLib = nullptr; float* hostLgx1 = nullptr;
   // step state
-  int32_t* rows = nullptr; int32_t* order = nullptr; size_t order_cap = 0;
-  StepState* state = nullptr; uint32_t h_next = 0;
+  int32_t* rows2[2] = {nullptr, nullptr}; int32_t* order = nullptr; size_t order_cap = 0;
+  StepState* state3 = nullptr;  // [0],[1]: per-step state by parity, [2]: master counter
+  int par = 0; uint32_t h_next = 0;
+  MetricsArgs pending_metrics; bool have_pending_metrics = false;
+  int seq_batch = 0, seq_prepare_next = 0;
   float *latbuf = nullptr, *dlat = nullptr, *z = nullptr, *sig = nullptr, *eps = nullptr, *kl = nullptr;
   float *latlbuf = nullptr, *dlatl = nullptr, *lsmp = nullptr, *lsig = nullptr, *leps = nullptr, *kl_l = nullptr, *dl = nullptr;
   float *P = nullptr, *dP = nullptr, *raw = nullptr, *draw = nullptr, *rho = nullptr, *llk_part = nullptr;
@@ -214,6 +217,9 @@ int dmalloc(T** p, size_t n) {
   return SMX_OK;
 }
 
+int32_t* cur_rows(smx_model* m) { return m->rows2[m->par]; }
+StepState* cur_state(smx_model* m) { return m->state3 + m->par; }
+StepState* master_state(smx_model* m) { return m->state3 + 2; }
 float* P_(smx_model* m, int t) { return m->params + m->tensors[t].offset; }
 float* G_(smx_model* m, int t) { return m->grads + m->tensors[t].offset; }
 
@@ -223,7 +229,7 @@ NoiseKey make_key(smx_model* m, int stream, int sample, bool training) {
   nk.k1 = (uint32_t)(m->cfg.seed >> 32);
   nk.step = 0;
   nk.stream = (uint32_t)((stream & 0xFF) | ((sample & 0xFFFFFF) << 8));
-  nk.step_ptr = training ? &m->state->step : nullptr;
+  nk.step_ptr = training ? &cur_state(m)->step : nullptr;
   return nk;
 }
 
@@ -423,7 +429,7 @@ void fill_mid_args(smx_model* m, const Pass& ps, MidArgs& a) {
   a.n_dec = (int)m->dec.size();
   for (int i = 0; i < a.n_dec; ++i) fill_mid_layer(m, m->dec[i], a.dec[i], ps.training != 0);
   a.k0 = (uint32_t)(c.seed & 0xFFFFFFFFu); a.k1 = (uint32_t)(c.seed >> 32);
-  a.step_ptr = ps.training ? &m->state->step : nullptr; a.step = 0; a.sample = (uint32_t)ps.sample;
+  a.step_ptr = ps.training ? &cur_state(m)->step : nullptr; a.step = 0; a.sample = (uint32_t)ps.sample;
   a.rows = ps.rows; a.cell_base = ps.cell_base;
   if (const Injected* ij = inj(m, ST_EPS_Z)) { a.inj_eps = ij->d; a.inj_eps_ld = ij->ld; }
   a.kl_scale = c.beta / (float)ps.global_batch; a.dlat = m->dlat;
@@ -561,10 +567,15 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, bo
   me.kl = m->stochastic ? m->kl : nullptr; me.kl_l = m->scvi ? m->kl_l : nullptr;
   me.B = ps.B; me.alpha = c.alpha; me.beta = c.beta; me.inv_global_batch = inv_gb;
   me.out = m->grads + m->tail_off_metrics;
-  if (backward) SMX_CHECK(side_fork(m, m->ev_fork));   // dP / llk / kl are final: side work may start
+  if (backward && !(m->comm && m->world > 1)) {  // training step: an extra workgroup of the gradient-norm kernel computes
+    // the scalars (under data parallelism they must be in the flat buffer BEFORE the all-reduce: separate launch below)
+    m->pending_metrics = me;
+    m->have_pending_metrics = true;
+    return SMX_OK;
+  }
   {
     Timed t(m, "metrics");
-    SMX_CHECK(launch_metrics(side_stream(m), me));
+    SMX_CHECK(launch_metrics(m->st, me));
   }
   return SMX_OK;
 }
@@ -775,20 +786,30 @@ int optimizer_pass(smx_model* m) {
   AdamArgs a;
   a.params = m->params; a.grads = m->grads; a.m = m->adam_m; a.v = m->adam_v;
   a.chunks = m->chunks; a.n_chunks = m->n_chunks; a.partial = m->partial; a.tensor_norm = m->tensor_norm;
-  a.state = m->state; a.b1 = c.adam_beta1; a.b2 = c.adam_beta2; a.eps = c.adam_eps; a.clipnorm = c.clipnorm;
+  a.state = cur_state(m); a.b1 = c.adam_beta1; a.b2 = c.adam_beta2; a.eps = c.adam_eps; a.clipnorm = c.clipnorm;
   a.grad_scale = 1.f / (float)m->world;
+  if (m->have_pending_metrics) { a.metrics = m->pending_metrics; a.with_metrics = 1; m->have_pending_metrics = false; }
+  a.master = master_state(m); a.lr = c.lr; a.batch = m->seq_batch;
+  a.prepare_next = m->seq_prepare_next;
+  if (a.prepare_next) { a.next_state = m->state3 + (m->par ^ 1); a.next_rows = m->rows2[m->par ^ 1]; a.order = m->order; }
   Timed t(m, "adam");
   SMX_CHECK(launch_adam(m->st, a));
   return SMX_OK;
 }
 
-// the whole training step as a launch sequence on m->st (capturable)
-int train_sequence(smx_model* m, int B) {
+// the whole training step as a launch sequence on m->st (capturable).
+//   with_begin:   launch the state/row-id preparation kernel first (graph replay: every step, cursor kept in
+//                 the master state; eager: only the first step of a train_steps call)
+//   prepare_next: the optimiser kernel prepares the other parity's state + row ids for the step after
+int train_sequence(smx_model* m, int B, bool with_begin, bool begin_from_master, uint32_t cursor, bool prepare_next) {
   Pass ps;
-  ps.B = B; ps.rows = m->rows; ps.Xsrc = m->X; ps.lib = m->library; ps.lgx1 = m->lgx1;
+  ps.B = B; ps.rows = cur_rows(m); ps.Xsrc = m->X; ps.lib = m->library; ps.lgx1 = m->lgx1;
   ps.cell_base = (uint32_t)m->cell_base; ps.training = 1; ps.sample = 0; ps.global_batch = B * m->world;
+  m->seq_batch = B; m->seq_prepare_next = prepare_next ? 1 : 0;
   Timed t(m, "step");
-  SMX_CHECK(launch_step_begin(m->st, m->state, m->order, m->rows, B, m->cfg.lr, m->cfg.adam_beta1, m->cfg.adam_beta2));
+  if (with_begin)
+    SMX_CHECK(launch_step_begin(m->st, master_state(m), cur_state(m), m->order, cur_rows(m), B, begin_from_master ? 1 : 0,
+                                cursor, m->cfg.lr, m->cfg.adam_beta1, m->cfg.adam_beta2));
   SMX_CHECK(forward_pass(m, ps, true, true));
   SMX_CHECK(backward_pass(m, ps));
   SMX_CHECK(optimizer_pass(m));
@@ -822,11 +843,11 @@ int upload_order(smx_model* m, const int32_t* order, size_t n) {
     drop_graphs(m);
     if (m->order) hipFree(m->order);
     m->order = nullptr;
-    m->order_cap = n * 2;
+    m->order_cap = n * 2 + (size_t)m->Bmax;
     SMX_CHECK(dmalloc(&m->order, m->order_cap));
   }
   SMX_HIP(hipMemcpyAsync(m->order, order, n * sizeof(int32_t), hipMemcpyHostToDevice, m->st));
-  SMX_HIP(hipMemsetAsync(&m->state->cursor, 0, sizeof(uint32_t), m->st));
+  SMX_HIP(hipMemsetAsync(&master_state(m)->cursor, 0, sizeof(uint32_t), m->st));
   return SMX_OK;
 }
 
@@ -837,7 +858,7 @@ int check_rows(smx_model* m, const int32_t* ids, size_t n) {
   return SMX_OK;
 }
 
-int launch_train(smx_model* m, int B, bool use_graph) {
+int launch_train(smx_model* m, int B, bool use_graph, int s_idx, int n_steps) {
   // With a communicator the RCCL all-reduce is captured too (RCCL supports stream capture);
   // SMX_NO_GRAPH_COMM=1 or a failed capture falls back to eager launches for good.
   static const bool no_graph_comm = getenv("SMX_NO_GRAPH_COMM") != nullptr;
@@ -847,7 +868,8 @@ int launch_train(smx_model* m, int B, bool use_graph) {
       hipGraph_t graph = nullptr;
       SMX_HIP(hipStreamBeginCapture(m->st, hipStreamCaptureModeThreadLocal));
       m->capturing = true;
-      int rc = train_sequence(m, B);
+      m->par = 0;
+      int rc = train_sequence(m, B, true, true, 0, false);
       m->capturing = false;
       hipError_t e = hipStreamEndCapture(m->st, &graph);
       hipGraphExec_t exec = nullptr;
@@ -857,7 +879,7 @@ int launch_train(smx_model* m, int B, bool use_graph) {
         (void)hipGetLastError();
         if (m->comm) {  // capture with the collective failed: run this and all later steps eagerly
           m->graph_comm_failed = true;
-          SMX_CHECK(train_sequence(m, B));
+          SMX_CHECK(train_sequence(m, B, true, true, 0, false));
           m->h_next += 1;
           return SMX_OK;
         }
@@ -867,9 +889,14 @@ int launch_train(smx_model* m, int B, bool use_graph) {
       }
       it = m->graphs.emplace(B, exec).first;
     }
+    m->par = 0;
     SMX_HIP(hipGraphLaunch(it->second, m->st));
   } else {
-    SMX_CHECK(train_sequence(m, B));
+    // eager: the preparation kernel runs once per call; afterwards each optimiser kernel prepares the
+    // other parity's state + row ids, so a step is not fronted by a 1-workgroup latency kernel
+    const bool first = (s_idx == 0), last = (s_idx == n_steps - 1);
+    if (first) m->par = 0; else m->par ^= 1;
+    SMX_CHECK(train_sequence(m, B, first, false, (uint32_t)s_idx, !last));
   }
   m->h_next += 1;
   return SMX_OK;
@@ -1024,7 +1051,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
       (rc = dmalloc(&m->z, B * m->Dp)) || (rc = dmalloc(&m->sig, B * m->Dp)) || (rc = dmalloc(&m->eps, B * m->Dp)) ||
       (rc = dmalloc(&m->kl, B)) || (rc = dmalloc(&m->P, B * ldp)) || (rc = dmalloc(&m->dP, B * ldp)) ||
       (rc = dmalloc(&m->llk_part, B * loss_chunks(m->Gp))) || (rc = dmalloc(&m->llk_y, B)) ||
-      (rc = dmalloc(&m->rows, B)) || (rc = dmalloc(&m->state, (size_t)1)) ||
+      (rc = dmalloc(&m->rows2[0], B)) || (rc = dmalloc(&m->rows2[1], B)) || (rc = dmalloc(&m->state3, (size_t)3)) ||
       (rc = dmalloc(&m->hostX, B * m->Gp)) || (rc = dmalloc(&m->hostLib, B * 2)) || (rc = dmalloc(&m->hostLgx1, B)))
     return fail(rc);
   if (m->scvi) {
@@ -1077,7 +1104,7 @@ int smx_model_destroy(smx_model* m) {
     for (auto& L : *mlp) { fr(L.xhat); fr(L.out_buf); fr(L.dpre); fr(L.inv_std); }
   fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1); fr(m->hostX); fr(m->hostLib); fr(m->hostLgx1);
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); fr(m->laby_raw[j]); fr(m->laby_draw[j]); }
-  fr(m->rows); fr(m->order); fr(m->state);
+  fr(m->rows2[0]); fr(m->rows2[1]); fr(m->order); fr(m->state3);
   fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);
   fr(m->latlbuf); fr(m->dlatl); fr(m->lsmp); fr(m->lsig); fr(m->leps); fr(m->kl_l); fr(m->dl);
   fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);
@@ -1161,11 +1188,11 @@ int smx_get_step(const smx_model* m, int32_t* step) {
 
 int smx_set_step(smx_model* m, int32_t step) {
   SMX_REQUIRE(m && step >= 0, "bad step");
-  StepState s;
-  memset(&s, 0, sizeof(s));
-  s.next = (uint32_t)step; s.step = step > 0 ? (uint32_t)step - 1 : 0;
+  StepState s[3];
+  memset(s, 0, sizeof(s));
+  s[2].next = (uint32_t)step;
   SMX_HIP(hipStreamSynchronize(m->st));
-  SMX_HIP(hipMemcpy(m->state, &s, sizeof(s), hipMemcpyHostToDevice));
+  SMX_HIP(hipMemcpy(m->state3, s, sizeof(s), hipMemcpyHostToDevice));
   m->h_next = (uint32_t)step;
   return SMX_OK;
 }
@@ -1226,7 +1253,7 @@ int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t
   SMX_REQUIRE(batch > 0 && batch <= m->Bmax, "batch must be in 1..max_batch");
   SMX_CHECK(check_rows(m, order, (size_t)n_steps * batch));
   SMX_CHECK(upload_order(m, order, (size_t)n_steps * batch));
-  for (int s = 0; s < n_steps; ++s) SMX_CHECK(launch_train(m, batch, use_graph != 0));
+  for (int s = 0; s < n_steps; ++s) SMX_CHECK(launch_train(m, batch, use_graph != 0, s, n_steps));
   if (m->use_injected) { m->use_injected = false; }
   SMX_CHECK(read_metrics(m, out));
   if (out && out->nan_flag) { set_error("non-finite loss or gradient norm"); return SMX_ERR_NAN; }
@@ -1239,8 +1266,8 @@ static int setup_pass(smx_model* m, Pass& ps, const int32_t* row_ids, const floa
   ps.B = batch; ps.training = training; ps.sample = sample; ps.global_batch = batch;
   if (row_ids) {
     SMX_CHECK(check_rows(m, row_ids, (size_t)batch));
-    SMX_HIP(hipMemcpyAsync(m->rows, row_ids, (size_t)batch * sizeof(int32_t), hipMemcpyHostToDevice, m->st));
-    ps.rows = m->rows; ps.Xsrc = m->X; ps.lib = m->library; ps.lgx1 = m->lgx1; ps.cell_base = (uint32_t)m->cell_base;
+    SMX_HIP(hipMemcpyAsync(cur_rows(m), row_ids, (size_t)batch * sizeof(int32_t), hipMemcpyHostToDevice, m->st));
+    ps.rows = cur_rows(m); ps.Xsrc = m->X; ps.lib = m->library; ps.lgx1 = m->lgx1; ps.cell_base = (uint32_t)m->cell_base;
   } else {
     SMX_REQUIRE(host_x, "need row_ids or host_x");
     SMX_REQUIRE(!m->scvi || host_library, "scvi needs host_library with host_x");

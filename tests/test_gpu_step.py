@@ -55,13 +55,13 @@ def _oracle_step(spec, params, bn, opt, x, ys, lib, mask, rows, step, cell_base=
 
 
 @pytest.mark.parametrize("name", list(CASES))
-@pytest.mark.parametrize("batch", [32, 100])
+@pytest.mark.parametrize("batch", [32, 100, 160])
 def test_one_step_matches_oracle(Engine, name, batch):
   kw = CASES[name]
   spec, cfg, x, ys, lib, mask = _problem(kw)
   params = perturbed_params(spec)
   bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
-  e = Engine(cfg, max_batch=128, init=False)
+  e = Engine(cfg, max_batch=max(128, batch), init=False)
   e.set_params(params)
   e.upload(x, ys, lib, mask, cell_id_base=1000)
   rows = np.random.default_rng(1).choice(x.shape[0], size=batch, replace=False).astype(np.int32)
