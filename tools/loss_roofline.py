@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Loss-kernel roofline away from the launch-latency regime: the same count_loss_kernel<ZINB> fwd+bwd
+at the per-GPU size of BASELINE.json configs[4] (G = 20000, 128 cells per GPU) and at larger batches.
+HIP events on the model's stream (smx_timing_*), synthetic log-normal counts thinned to ~93 % zeros."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from sisua_amd.config import ModelConfig
+from sisua_amd.engine import Engine
+
+HBM_PEAK = 8000.0
+out = []
+for G, B in ((1998, 128), (20000, 128), (20000, 512), (20000, 1024)):
+  rng = np.random.default_rng(8)
+  n = max(2 * B, 512)
+  x = np.floor(rng.lognormal(0.0, 1.0, size=(n, G))).astype(np.float32) * (rng.uniform(size=(n, G)) < 0.12)
+  x[:, 0] += 1
+  cfg = ModelConfig(model="vae", n_genes=G, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=32)
+  e = Engine(cfg, max_batch=B)
+  e.upload(x)
+  order = (np.arange(40 * B) % n).astype(np.int32)
+  e.train_steps(order[: 5 * B], 5, B, graph=False)
+  e.timing_enable("loss")
+  e.train_steps(order, 40, B, graph=False)
+  ms, cnt = e.timing_read()
+  e.timing_enable(None)
+  bytes_per_launch = e.loss_bytes_per_cell() * B
+  us = 1e3 * ms / cnt
+  gbs = bytes_per_launch / (us * 1e-6) / 1e9
+  out.append(dict(G=G, B=B, bytes_per_launch=bytes_per_launch, avg_launch_us=round(us, 2), achieved_GBs=round(gbs, 1),
+                  frac_of_8TBs=round(gbs / HBM_PEAK, 4)))
+  print(out[-1], flush=True)
+  e.close()
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "loss_roofline.json"), "w"), indent=1)

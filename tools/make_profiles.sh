@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round profiles: rocprofv3 kernel-trace/stats of the default bench command, PMC traffic passes for the
+# loss kernel, loss-kernel roofline at larger sizes.  Writes under gpurun_out/ (copy the summaries to profiles/).
+set -u
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+TAG=${1:-r01}
+O=$R/gpurun_out/$TAG
+rm -rf $O; mkdir -p $O
+cd $R
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err
+python3 tools/prof_summary.py $O/trace > $O/kernel_stats_summary.txt 2>&1
+python3 bench.py --steps 300 --warmup 30 > $O/bench.json 2> $O/bench.err
+./tools/pmc_pass.sh > $O/pmc_summary.txt 2>&1
+cp gpurun_out/pmc/pmc_summary.json $O/ 2>/dev/null
+python3 tools/loss_roofline.py > $O/loss_roofline.txt 2>&1
+rm -rf $O/trace/*/*kernel_trace.csv   # keep the stats, drop the bulky trace
+ls -la $O

@@ -13,9 +13,9 @@ for r in csv.DictReader(open(stats)):
   print(f"{r['Name'][:86]:86s} calls={int(r['Calls']):6d} avg={float(r['AverageNs']) / 1e3:8.2f}us  {float(r['Percentage']):6.2f}%")
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-starts = [i for i, n in enumerate(names) if "step_begin" in n]
+starts = [i for i, n in enumerate(names) if "adam_update" in n]   # last kernel of a step
 if len(starts) > 12:
-  a, b = starts[len(starts) // 2], starts[len(starts) // 2 + 1]
+  a, b = starts[len(starts) // 2] + 1, starts[len(starts) // 2 + 1] + 1
   print(f"# one step: {b - a} kernels")
   prev = None
   t0 = int(rows[a]["Start_Timestamp"])
