@@ -54,7 +54,7 @@ struct GemmSmem {
   static constexpr int FLOATS = TILES > RED ? TILES : RED;
 };
 
-template <int WM, int WN, int WK, int A_KM, int B_NM, int XF>
+template <int WM, int WN, int WK, int A_KM, int B_NM, int XF, int EPI = 0>
 __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz, float* smem) {
   constexpr int BM = 32 * WM, BN = 32 * WN, BK = 32 * WK;
   constexpr int LDAS = A_KM ? BM + 4 : BM + 1;
@@ -193,7 +193,43 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
     }
   }
 
-  if (wk == 0) {
+  if (EPI == 2 && wk == 0) {
+    // latent-head backward on the d z tile: rows = cells, cols = latent dims
+    const EpiLatentBwd& e = g.lb;
+    const int d = n0 + wn * 32 + li;
+    const bool live = d < e.D;
+    // all loads first (independent, in flight together), then the arithmetic, then the stores
+    float mu[16], sr[16], sg[16], ep[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int b = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const bool ok = live && b < g.M;
+      mu[r] = ok ? e.lat[(long)b * e.ld + d] : 0.f;
+      sr[r] = (ok && e.stochastic) ? e.lat[(long)b * e.ld + e.Dp + d] : 0.f;
+      sg[r] = (ok && e.stochastic) ? e.sig[(long)b * e.Dp + d] : 1.f;
+      ep[r] = (ok && e.stochastic) ? e.eps[(long)b * e.Dp + d] : 0.f;
+    }
+    float o0[16], o1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float dz = acc[r];
+      if (e.stochastic) {
+        o0[r] = live ? dz + e.kl_scale * mu[r] : 0.f;
+        o1[r] = live ? (dz * ep[r] + e.kl_scale * (sg[r] - frcp(sg[r]))) * sigmoidf(sr[r] + SMX_SOFTPLUS_INV_1) : 0.f;
+      } else {
+        o0[r] = (live && !(e.relu && !(mu[r] > 0.f))) ? dz : 0.f;
+        o1[r] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int b = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (b < g.M) {
+        e.dlat[(long)b * e.ld + d] = o0[r];
+        if (e.stochastic) e.dlat[(long)b * e.ld + e.Dp + d] = o1[r];
+      }
+    }
+  } else if (wk == 0) {
     float* C = g.C + (long)bz * g.slab_stride;
     const int col = n0 + wn * 32 + li;
     const float bias = g.bias ? g.bias[col] : 0.f;
@@ -247,6 +283,7 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup G) {
     case 8: gemm_body<1, 1, 4, 0, 0, 0>(g, bx, by, bz, smem); break;
     case 9: gemm_body<1, 1, 4, 0, 0, 1>(g, bx, by, bz, smem); break;
     case 10: gemm_body<1, 1, 4, 0, 1, 0>(g, bx, by, bz, smem); break;
+    case 11: gemm_body<1, 1, 4, 0, 1, 0, 2>(g, bx, by, bz, smem); break;   // + latent-head backward epilogue
     case 12: gemm_body<1, 1, 4, 1, 0, 0>(g, bx, by, bz, smem); break;
     case 13: gemm_body<1, 1, 4, 1, 0, 1>(g, bx, by, bz, smem); break;
     default: break;
@@ -311,6 +348,10 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
     if (eff_splits) eff_splits[i] = g.split_k;
     G.gx[i] = (g.M + BM - 1) / BM; G.gy[i] = g.N / 32;
     G.variant[i] = (tile == TILE_128x32 ? 0 : 8) + (g.a_kmajor ? 4 : 0) + (g.b_nmajor ? 2 : 0) + (g.use_xform ? 1 : 0);
+    if (g.epi == 2) {
+      if (G.variant[i] != 10) { set_error("gemm group: latent epilogue needs the K4 W^T variant"); return SMX_ERR_INVALID; }
+      G.variant[i] = 11;
+    }
     G.start[i] = total;
     total += G.gx[i] * G.gy[i] * g.split_k;
     G.p[i] = g;
@@ -333,6 +374,10 @@ static int validate_gemm(GemmArgs& g) {
   if (g.split_k < 1) g.split_k = 1;
   if (g.split_k > 1 && (g.bias || g.colsum)) { set_error("gemm: bias/colsum need split_k == 1"); return SMX_ERR_INVALID; }
   if (g.colsum && g.b_nmajor) { set_error("gemm: colsum needs k-major B"); return SMX_ERR_INVALID; }
+  if (g.epi == 2 && (g.split_k != 1 || !g.lb.dlat || g.N != g.lb.Dp)) {
+    set_error("gemm: latent-backward epilogue needs split_k == 1 and N == Dp");
+    return SMX_ERR_INVALID;
+  }
   return SMX_OK;
 }
 
@@ -340,6 +385,7 @@ int launch_gemm(hipStream_t st, const GemmArgs& g_in, int* eff_split) {
   GemmArgs g = g_in;
   int rc = validate_gemm(g);
   if (rc != SMX_OK) return rc;
+  if (g.epi != 0) { set_error("gemm: epilogues run through launch_gemm_group"); return SMX_ERR_INVALID; }
   int tile = g.tile;
   if (tile == TILE_AUTO) {
     const int kper = g.K / g.split_k;

@@ -39,6 +39,15 @@ struct AXform {
   int inj_ld = 0;
 };
 
+// Epilogue of the d z = dpre * W_dec^T product: the latent head's backward is elementwise in (cell, dim),
+// so it runs on the accumulator tile and writes d lat directly (d z itself is never stored).
+struct EpiLatentBwd {
+  const float* lat = nullptr; int ld = 0;            // [B][ld]: mu | s_raw
+  const float* sig = nullptr; const float* eps = nullptr;  // [B][Dp]
+  float kl_scale = 0.f; int D = 0, Dp = 0, stochastic = 1, relu = 0;
+  float* dlat = nullptr;                             // [B][ld]
+};
+
 struct GemmArgs {
   const float* A = nullptr; int lda = 0; int a_kmajor = 0;  // a_kmajor: A stored [K][M]
   const float* B = nullptr; int ldb = 0; int b_nmajor = 0;  // b_nmajor: B stored [N][K]
@@ -51,6 +60,8 @@ struct GemmArgs {
   int use_xform = 0;
   AXform xf;
   int tile = TILE_AUTO;
+  int epi = 0;                     // 0: store C; 2: latent-head backward (EpiLatentBwd), split_k == 1
+  EpiLatentBwd lb;
 };
 // Returns 0 or a negative smx_status.  N, lda, ldb, ldc multiples of 4; N multiple of 32.
 // eff_split (optional) receives the number of slabs actually written.

@@ -309,7 +309,8 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
 // backward through an MLP.  d(out of last layer) arrives as `n_slabs` slabs in m->slab.
 // Leaves d(input of first layer) as slabs in m->slab unless skip_input_grad.
 int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
-                 int n_slabs, bool skip_input_grad, int* out_slabs, const char* label_dw0) {
+                 int n_slabs, bool skip_input_grad, int* out_slabs, const char* label_dw0,
+                 const EpiLatentBwd* lat_epi = nullptr) {
   for (int i = (int)mlp.size() - 1; i >= 0; --i) {
     MlpLayer& L = mlp[i];
     const TensorInfo& tw = m->tensors[L.tW];
@@ -353,6 +354,9 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     h.M = ps.B; h.N = L.in_p; h.K = L.out_p;
     h.C = m->slab; h.ldc = L.in_p; h.slab_stride = (long)ps.B * L.in_p;
     h.split_k = suggest_split_k(ps.B, L.in_p, L.out_p);
+    if (i == 0 && lat_epi) {  // d z feeds the latent head only: run its backward in the epilogue
+      h.epi = 2; h.lb = *lat_epi; h.split_k = 1; h.tile = TILE_32x32_K4;
+    }
     GemmArgs pair[2] = {g, h};
     int effs[2] = {1, 1};
     {
@@ -719,33 +723,26 @@ int backward_pass(smx_model* m, const Pass& ps) {
     }
   }
   if (use_mid(m, ps.B)) return backward_mid(m, ps, n_slabs);
-  // ---- decoder MLP, leaves dz slabs ----
-  int dz_slabs = 0;
-  SMX_CHECK(mlp_backward(m, m->dec, ps, m->z, m->Dp, false, n_slabs, false, &dz_slabs, ""));
-  // ---- latent ----
+  // ---- decoder MLP; the latent head's backward runs in the epilogue of the d z product ----
   const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
-  LatentArgs la;
-  la.stochastic = m->stochastic; la.relu = (c.latent_activation == SMX_ACT_RELU);
-  la.lat = m->latbuf; la.ld = lat_ld; la.B = ps.B; la.D = m->D; la.Dp = m->Dp;
-  la.sig = m->sig; la.eps = m->eps; la.dz = m->slab; la.dz_slabs = dz_slabs; la.dz_slab_stride = (long)ps.B * m->Dp;
-  la.kl_scale = c.beta * inv_gb; la.dlat = m->dlat;
-  {
-    Timed t(m, "latent_bwd");
-    SMX_CHECK(launch_latent_bwd(m->st, la));
-  }
+  EpiLatentBwd le;
+  le.lat = m->latbuf; le.ld = lat_ld; le.sig = m->sig; le.eps = m->eps; le.kl_scale = c.beta * inv_gb;
+  le.D = m->D; le.Dp = m->Dp; le.stochastic = m->stochastic; le.relu = (c.latent_activation == SMX_ACT_RELU);
+  le.dlat = m->dlat;
+  SMX_CHECK(mlp_backward(m, m->dec, ps, m->z, m->Dp, false, n_slabs, false, nullptr, "", &le));
   const MlpLayer& eL = m->enc.back();
-  {
+  {  // weight gradient of the latent head and d h = d lat * W_lat^T are independent: one grouped launch
     const TensorInfo& tw = m->tensors[m->t_latW];
-    GemmArgs g;
+    GemmArgs pair[2];
+    GemmArgs& g = pair[0];
     g.A = eL.out_buf; g.lda = eL.out_p; g.a_kmajor = 1; g.B = m->dlat; g.ldb = lat_ld;
     g.C = G_(m, m->t_latW); g.ldc = tw.ld; g.M = eL.out_p; g.N = lat_ld; g.K = ps.B; g.colsum = G_(m, m->t_latb);
-    Timed t(m, "gemm_lat_dw");
-    SMX_CHECK(launch_gemm(m->st, g));
-    GemmArgs h;
+    GemmArgs& h = pair[1];
     h.A = m->dlat; h.lda = lat_ld; h.B = P_(m, m->t_latW); h.ldb = tw.ld; h.b_nmajor = 1;
     h.C = m->slab; h.ldc = eL.out_p; h.slab_stride = (long)ps.B * eL.out_p;
     h.M = ps.B; h.N = eL.out_p; h.K = lat_ld;
-    SMX_CHECK(launch_gemm(m->st, h));
+    Timed t(m, "gemm_lat_bwd");
+    SMX_CHECK(launch_gemm_group(m->st, pair, 2));
   }
   SMX_CHECK(mlp_backward(m, m->enc, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_enc_dw"));
   // ---- scvi library branch ----
