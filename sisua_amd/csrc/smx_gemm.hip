@@ -316,8 +316,10 @@ static int launch_cfg(hipStream_t st, GemmArgs g, int* eff_split) {
 int suggest_split_k(int M, int N, int K) {
   if (K < 512) return 1;
   const int tiles = ((M + 31) / 32) * (N / 32);
-  int s = 256 / (tiles > 0 ? tiles : 1);
-  if (s > 16) s = 16;         // the consumer re-reads every slab
+  static const int cap = getenv("SMX_SPLIT_CAP") ? atoi(getenv("SMX_SPLIT_CAP")) : 16;
+  static const int target = getenv("SMX_SPLIT_TARGET") ? atoi(getenv("SMX_SPLIT_TARGET")) : 256;
+  int s = target / (tiles > 0 ? tiles : 1);
+  if (s > cap) s = cap;       // the consumer re-reads every slab
   if (s < 1) s = 1;
   const int chunk = round_up((K + s - 1) / s, 128);  // whole 128-deep tiles per slice
   return (K + chunk - 1) / chunk;

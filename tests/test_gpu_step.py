@@ -239,3 +239,43 @@ def test_rccl_single_rank_allreduce_is_identity(Engine, monkeypatch):
   assert outs[0][0] == outs[1][0]
   for k in outs[0][1]:
     assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def _golden(name):
+  import os
+  return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+
+
+def test_hip_matches_committed_step_fixture(Engine):
+  """one full VAE step with fixed params / eps / masks against COMMITTED numbers."""
+  from tests.golden import make_oracle_fixtures as mk
+  fx = _golden("oracle_step_fixture.npz")
+  spec, cfg = make_pair(**mk.STEP_KW)
+  names = [n for n, _ in so.manifest(spec)]
+  e = Engine(cfg, max_batch=8, init=False)
+  e.set_params({n: fx[f"p0/{n}"] for n in names})
+  e.upload(fx["x"])
+  for k in fx.files:
+    if k.startswith("drop/") or k.startswith("eps/"):
+      e.set_noise(int(k.split("/")[1]), fx[k])
+  m = e.train_step(np.arange(8, dtype=np.int32))
+  assert np.isclose(m["loss"], float(fx["loss"]), rtol=RTOL) and np.isclose(m["kl"], float(fx["kl"]), rtol=RTOL)
+  worst = grad_errors(e.get_params(which=1), {n: fx[f"g/{n}"] for n in names})
+  assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  newp = e.get_params()
+  for n in names:
+    assert np.allclose(newp[n], fx[f"p1/{n}"], rtol=1e-5, atol=5e-4), n
+  e.close()
+
+
+def test_hip_matches_committed_trajectory_fixture(Engine):
+  """50-step seeded trajectory, ELBO per step within 1e-4 of the COMMITTED values."""
+  from tests.golden import make_oracle_fixtures as mk
+  fx = _golden("oracle_trajectory_fixture.npz")
+  spec, cfg = make_pair(**mk.TRAJ_KW)
+  e = Engine(cfg, max_batch=64)
+  e.upload(fx["x"])
+  got = [e.train_step(fx["order"][s * 64:(s + 1) * 64])["loss"] for s in range(50)]
+  assert np.allclose(got, fx["loss"], rtol=RTOL), np.abs(np.array(got) / fx["loss"] - 1).max()
+  assert np.allclose(e.get_params()["lat/W"], fx["final_lat_W"], rtol=1e-3, atol=2e-3)
+  e.close()

@@ -32,3 +32,41 @@ def test_split_bit_exact():
     assert np.array_equal(te, FX[f"split_{n}_{int(pct * 100)}_{seed}_test"])
   # the C1/C2 cell counts of SURVEY.md section 8 (train.py:66,120)
   assert len(FX["split_2404_90_1_train"]) == 2163 and len(FX["split_3757_90_1_train"]) == 3381
+
+
+# ---- committed known-answer vectors of the network numerics (tests/golden/make_oracle_fixtures.py) ----
+def _step_fixture():
+  import importlib.util
+  spec_mod = importlib.util.spec_from_file_location("mkfx", os.path.join(os.path.dirname(__file__), "golden", "make_oracle_fixtures.py"))
+  mk = importlib.util.module_from_spec(spec_mod)
+  spec_mod.loader.exec_module(mk)
+  return mk, np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_step_fixture.npz"))
+
+
+def test_oracle_reproduces_committed_step():
+  mk, fx = _step_fixture()
+  spec = so.Spec(**mk.STEP_KW)
+  names = [n for n, _ in so.manifest(spec)]
+  params = {n: fx[f"p0/{n}"].copy() for n in names}
+  drop = {int(k.split("/")[1]): fx[k] for k in fx.files if k.startswith("drop/")}
+  eps = {so.STREAM_EPS_Z: fx[f"eps/{so.STREAM_EPS_Z}"]}
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  res = so.train_step(spec, params, bn, opt, fx["x"], so.InjectedNoise(drop, eps))
+  assert np.isclose(res["loss"], float(fx["loss"]), rtol=1e-12)
+  for n in names:
+    assert np.allclose(res["grads"][n], fx[f"g/{n}"], rtol=1e-10, atol=1e-14)
+    assert np.allclose(params[n], fx[f"p1/{n}"], rtol=1e-12, atol=1e-15)
+
+
+def test_oracle_reproduces_committed_trajectory():
+  mk, _ = _step_fixture()
+  fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_trajectory_fixture.npz"))
+  spec = so.Spec(**mk.TRAJ_KW)
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  x, order = fx["x"], fx["order"]
+  for s in range(10):
+    rows = order[s * 64:(s + 1) * 64]
+    r = so.train_step(spec, params, bn, opt, x[rows], so.PhiloxNoise(spec.seed, s, rows))
+    assert np.isclose(r["loss"], fx["loss"][s], rtol=1e-10)
+  assert fx["loss"][-5:].mean() < fx["loss"][:5].mean()
