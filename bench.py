@@ -40,12 +40,22 @@ def build_workload(rank: int, world: int, workload: str):
   elif workload == "8kly-2layer":
     x, _ = data.synthetic_8kly(seed=8 + rank)
     units, latent, batch = (128, 128), 32, 128
+  elif workload == "c5-shard":
+    # per-GPU slice of BASELINE.json configs[4] (1e6 x 20000 log-normal counts, 128 cells per GPU per step):
+    # 4096 resident cells are enough to exercise the step at its real width
+    rng = np.random.default_rng(8 + rank)
+    x = (np.floor(rng.lognormal(0.0, 1.0, size=(4096, 20000))) * (rng.uniform(size=(4096, 20000)) < 0.12)).astype(np.float32)
+    x[:, 0] += 1
+    units, latent, batch = (128,), 32, 128
   else:
     raise ValueError(workload)
-  tr, _ = data.split_indices(x.shape[0], 0.8, seed=1)
-  tr2, _ = data.split_indices(len(tr), 0.9, seed=1)
-  xt = data.corrupt(x[tr][tr2], 0.2, 0.2, seed=8)
-  xt[xt.sum(1) == 0, 0] = 1.0
+  if workload == "c5-shard":
+    xt = x
+  else:
+    tr, _ = data.split_indices(x.shape[0], 0.8, seed=1)
+    tr2, _ = data.split_indices(len(tr), 0.9, seed=1)
+    xt = data.corrupt(x[tr][tr2], 0.2, 0.2, seed=8)
+    xt[xt.sum(1) == 0, 0] = 1.0
   cfg = ModelConfig(model="vae", n_genes=x.shape[1], likelihood="zinb", enc_units=units, dec_units=units,
                     latent_dim=latent, batchnorm=True, dropout_enc=0.1, dropout_dec=0.1, input_dropout=0.0,
                     log_norm=True, beta=1.0, lr=1e-3, clipnorm=100.0, seed=8)
@@ -176,7 +186,7 @@ def main():
       except Exception:
         traffic = None
     out = {
-        "metric": "cells/sec VAE training (pbmc8k_ly, batch=128)",
+        "metric": "cells/sec VAE training (pbmc8k_ly, batch=128)" if args.workload.startswith("8kly") else f"cells/sec VAE training ({args.workload}, batch={batch})",
         "value": round(args.steps * batch * world / dt, 1),
         "unit": "cells/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

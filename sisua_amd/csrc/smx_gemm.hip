@@ -321,6 +321,10 @@ int suggest_split_k(int M, int N, int K) {
   int s = target / (tiles > 0 ? tiles : 1);
   if (s > cap) s = cap;       // the consumer re-reads every slab
   if (s < 1) s = 1;
+  // very deep K (wide gene panels): a slice longer than 8 tiles is a latency-bound loop on a
+  // half-empty chip; trade slab traffic for occupancy, up to 64 slices
+  while (s < 64 && K / s > 1024) s *= 2;
+  if (s > 64) s = 64;
   const int chunk = round_up((K + s - 1) / s, 128);  // whole 128-deep tiles per slice
   return (K + chunk - 1) / chunk;
 }

@@ -1046,7 +1046,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     return (int)SMX_OK;
   };
   if ((rc = alloc_mlp(m->enc)) || (rc = alloc_mlp(m->encl)) || (rc = alloc_mlp(m->dec))) return fail(rc);
-  m->slab_cap = (size_t)(32 * 3 + SMX_MAX_LABELS + 1) * B * m->max_feat_p;
+  m->slab_cap = (size_t)(64 * 3 + SMX_MAX_LABELS + 1) * B * m->max_feat_p;
   const size_t lat_ld = (m->stochastic ? 2 : 1) * (size_t)m->Dp;
   const size_t ldp = (size_t)m->k * m->Gp;
   if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
