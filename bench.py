@@ -133,6 +133,8 @@ def main():
   from sisua_amd import _hip
   from sisua_amd.engine import Engine
   from sisua_amd.parallel import ControlPlane, attach_engine
+  if os.environ.get("SMX_SHARE_GPU"):   # debugging aid: several ranks on one device (RCCL permitting)
+    local_rank = local_rank % max(_hip.load().smx_device_count(), 1)
   _hip.require_gpu(local_rank)
   cp = ControlPlane(rank, world)
 
