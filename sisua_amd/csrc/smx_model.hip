@@ -147,6 +147,9 @@ struct smx_model {
   std::map<int, Injected> injected; bool use_injected = false;
   // comm
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
+  hipStream_t st_comm = nullptr; hipEvent_t ev_c1 = nullptr, ev_c2 = nullptr, ev_c3 = nullptr;
+  size_t bucket1_off = 0, bucket1_count = 0;   // gradients of the output / label heads: ready first, reduced early
+  bool bucket1_in_flight = false;
   // graphs
   std::map<int, hipGraphExec_t> graphs;
   bool capturing = false;
@@ -389,6 +392,27 @@ int side_join(smx_model* m) {
   return SMX_OK;
 }
 
+// data-parallel overlap: two buckets on a communication stream (eager launches only)
+bool dp_active(const smx_model* m) {
+  static const bool force_ar = getenv("SMX_FORCE_ALLREDUCE") != nullptr;  // exercise RCCL on a 1-rank communicator
+  return m->comm && (m->world > 1 || force_ar);
+}
+// Measured on a 1-rank communicator: the cross-stream events of the two-bucket form cost +42 us per step,
+// one all-reduce on the model's own stream +2.6 us.  The overlap only pays when the collective itself is
+// much longer than that, so the default is the single all-reduce; SMX_DP_BUCKETS=2 selects the overlap.
+bool dp_overlap(const smx_model* m) {
+  static const bool two = getenv("SMX_DP_BUCKETS") != nullptr && atoi(getenv("SMX_DP_BUCKETS")) == 2;
+  return dp_active(m) && two && !m->capturing && m->st_comm != nullptr;
+}
+int dp_allreduce(smx_model* m, size_t off, size_t count, hipStream_t st) {
+  ncclResult_t r = g_rccl.AllReduce(m->grads + off, m->grads + off, count, ncclFloat32, ncclSum, m->comm, st);
+  if (r != ncclSuccess) {
+    set_error(std::string("ncclAllReduce failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    return SMX_ERR_COMM;
+  }
+  return SMX_OK;
+}
+
 bool use_mid(const smx_model* m, int B) {
   // single-workgroup fusion of the middle is opt-in until it beats the per-operator path
   static const bool off = getenv("SMX_FUSED") == nullptr;
@@ -575,7 +599,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, bo
   me.kl = m->stochastic ? m->kl : nullptr; me.kl_l = m->scvi ? m->kl_l : nullptr;
   me.B = ps.B; me.alpha = c.alpha; me.beta = c.beta; me.inv_global_batch = inv_gb;
   me.out = m->grads + m->tail_off_metrics;
-  if (backward && !(m->comm && m->world > 1)) {  // training step: an extra workgroup of the gradient-norm kernel computes
+  if (backward && !dp_active(m)) {  // training step: an extra workgroup of the gradient-norm kernel computes
     // the scalars (under data parallelism they must be in the flat buffer BEFORE the all-reduce: separate launch below)
     m->pending_metrics = me;
     m->have_pending_metrics = true;
@@ -716,10 +740,18 @@ int backward_pass(smx_model* m, const Pass& ps) {
       h.C = m->slab + (long)n_slabs * dd_stride;
       n_slabs += eff;
     }
-    Timed t(m, "gemm_out_bwd");
-    for (size_t i = 0; i < grp.size(); i += SMX_GROUP_MAX) {
-      const int n = (int)std::min<size_t>(SMX_GROUP_MAX, grp.size() - i);
-      SMX_CHECK(launch_gemm_group(m->st, grp.data() + i, n));
+    {
+      Timed t(m, "gemm_out_bwd");
+      for (size_t i = 0; i < grp.size(); i += SMX_GROUP_MAX) {
+        const int n = (int)std::min<size_t>(SMX_GROUP_MAX, grp.size() - i);
+        SMX_CHECK(launch_gemm_group(m->st, grp.data() + i, n));
+      }
+    }
+    if (dp_overlap(m)) {  // head gradients are final: reduce them while the rest of backward runs
+      SMX_HIP(hipEventRecord(m->ev_c1, m->st));
+      SMX_HIP(hipStreamWaitEvent(m->st_comm, m->ev_c1, 0));
+      SMX_CHECK(dp_allreduce(m, m->bucket1_off, m->bucket1_count, m->st_comm));
+      m->bucket1_in_flight = true;
     }
   }
   if (use_mid(m, ps.B)) return backward_mid(m, ps, n_slabs);
@@ -770,13 +802,19 @@ int backward_pass(smx_model* m, const Pass& ps) {
 int optimizer_pass(smx_model* m) {
   const smx_config& c = m->cfg;
   SMX_CHECK(side_join(m));
-  static const bool force_ar = getenv("SMX_FORCE_ALLREDUCE") != nullptr;  // exercise RCCL on a 1-rank communicator
-  if (m->comm && (m->world > 1 || force_ar)) {
+  if (dp_active(m)) {
     Timed t(m, "allreduce");
-    ncclResult_t r = g_rccl.AllReduce(m->grads, m->grads, m->grads_count, ncclFloat32, ncclSum, m->comm, m->st);
-    if (r != ncclSuccess) {
-      set_error(std::string("ncclAllReduce failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
-      return SMX_ERR_COMM;
+    if (m->bucket1_in_flight) {
+      // front bucket [encoder/latent/decoder grads | BN stats | metrics] behind the head bucket on the
+      // communication stream; the optimiser waits for both
+      SMX_HIP(hipEventRecord(m->ev_c2, m->st));
+      SMX_HIP(hipStreamWaitEvent(m->st_comm, m->ev_c2, 0));
+      SMX_CHECK(dp_allreduce(m, 0, m->bucket1_off, m->st_comm));
+      SMX_HIP(hipEventRecord(m->ev_c3, m->st_comm));
+      SMX_HIP(hipStreamWaitEvent(m->st, m->ev_c3, 0));
+      m->bucket1_in_flight = false;
+    } else {
+      SMX_CHECK(dp_allreduce(m, 0, m->grads_count, m->st));   // one all-reduce of the whole flat buffer
     }
     if (m->bn_total && m->world > 1) {
       hipLaunchKernelGGL(bn_moving_update_kernel, dim3((unsigned)((m->bn_total + 255) / 256)), dim3(256), 0, m->st,
@@ -1013,12 +1051,26 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     m->t_labb[j] = add_tensor(m, "lab" + std::to_string(j) + "/b", 1, m->lab_ky[j] * cfg->label_dim[j], m->lab_ky[j], true);
   }
   // ---- flat buffers ----
+  // layout: [encoder / latent / decoder tensors | tail: BN batch stats, metrics | output + label heads].
+  // The head gradients (3/4 of the bytes) are produced by the FIRST backward launch, so under data
+  // parallelism that contiguous bucket is all-reduced on a communication stream while the rest of
+  // the backward pass runs; the front bucket (with the tail) follows when backward is done.
   size_t off = 0;
   for (size_t i = 0; i < m->bn_w.size(); ++i) { m->bn_off.push_back(off); off += 2 * (size_t)m->bn_wp[i]; }
   m->bn_total = off;
-  m->tail_off_bn = m->flat_count;
-  m->tail_off_metrics = m->tail_off_bn + (m->bn_total + 63) / 64 * 64;
-  m->grads_count = m->tail_off_metrics + 64;
+  {
+    auto is_head = [](const std::string& n) { return n.compare(0, 3, "out") == 0 || n.compare(0, 3, "lab") == 0; };
+    size_t cur = 0;
+    for (auto& t : m->tensors) if (!is_head(t.name)) { t.offset = cur; cur += (t.count + 63) / 64 * 64; }
+    m->tail_off_bn = cur;
+    m->tail_off_metrics = m->tail_off_bn + (m->bn_total + 63) / 64 * 64;
+    cur = m->tail_off_metrics + 64;
+    m->bucket1_off = cur;
+    for (auto& t : m->tensors) if (is_head(t.name)) { t.offset = cur; cur += (t.count + 63) / 64 * 64; }
+    m->bucket1_count = cur - m->bucket1_off;
+    m->flat_count = cur;
+    m->grads_count = cur;
+  }
   if ((rc = dmalloc(&m->params, m->flat_count))) return fail(rc);
   if ((rc = dmalloc(&m->grads, m->grads_count))) return fail(rc);
   if ((rc = dmalloc(&m->adam_m, m->flat_count))) return fail(rc);
@@ -1112,6 +1164,10 @@ int smx_model_destroy(smx_model* m) {
   fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);
   fr(m->chunks); fr(m->partial); fr(m->tensor_norm);
   for (auto& kv : m->injected) fr(kv.second.d);
+  if (m->st_comm) { hipStreamSynchronize(m->st_comm); hipStreamDestroy(m->st_comm); }
+  if (m->ev_c1) hipEventDestroy(m->ev_c1);
+  if (m->ev_c2) hipEventDestroy(m->ev_c2);
+  if (m->ev_c3) hipEventDestroy(m->ev_c3);
   if (m->ev_fork) hipEventDestroy(m->ev_fork);
   if (m->ev_fork2) hipEventDestroy(m->ev_fork2);
   if (m->ev_join) hipEventDestroy(m->ev_join);
@@ -1419,6 +1475,15 @@ int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]) {
     return SMX_ERR_COMM;
   }
   m->rank = rank; m->world = world;
+  if (!m->st_comm) {
+    if (hipStreamCreateWithFlags(&m->st_comm, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_c1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_c2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_c3, hipEventDisableTiming) != hipSuccess) {
+      set_error("communication stream creation failed");
+      return SMX_ERR_HIP;
+    }
+  }
   drop_graphs(m);
   return SMX_OK;
 }

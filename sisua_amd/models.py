@@ -254,7 +254,7 @@ class SingleCellModel:
            valid_freq=500, valid_interval=0, epochs=500, max_iter=-1, sample_shape=(), logging_interval=2,
            earlystop_threshold=0.001, earlystop_progress_length=0, earlystop_patience=20, earlystop_min_epoch=-1,
            terminate_on_nan=True, checkpoint=None, allow_rollback=False, allow_none_gradients=False,
-           track_gradient_norms=False, log_tag=None, verbose=False, use_graph=True, **ignored):
+           track_gradient_norms=False, log_tag=None, verbose=False, use_graph=False, **ignored):
     if str(optimizer).lower() != "adam":
       raise ValueError("only the 'adam' optimizer of configs/base.yaml is built")
     self._opt = dict(lr=float(learning_rate), clipnorm=float(clipnorm or 0.0))

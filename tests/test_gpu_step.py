@@ -220,11 +220,14 @@ def test_error_paths(Engine):
   e.close()
 
 
-def test_rccl_single_rank_allreduce_is_identity(Engine, monkeypatch):
-  """The data-parallel code path (RCCL communicator, one all-reduce of the flat buffer per step)
-  exercised on the one GPU of the test box: a 1-rank all-reduce must not change the result."""
+@pytest.mark.parametrize("graph,buckets", [(False, "1"), (False, "2"), (True, "1")])
+def test_rccl_single_rank_allreduce_is_identity(Engine, monkeypatch, graph, buckets):
+  """The data-parallel code path exercised on the one GPU of the test box (1-rank RCCL communicator,
+  SMX_FORCE_ALLREDUCE): eager = two buckets on the communication stream overlapped with backward,
+  graph = one captured all-reduce.  A 1-rank all-reduce must not change any result."""
   monkeypatch.setenv("SMX_FORCE_ALLREDUCE", "1")
-  spec, cfg, x, ys, lib, mask = _problem(CASES["vae_zinb"])
+  monkeypatch.setenv("SMX_DP_BUCKETS", buckets)
+  spec, cfg, x, ys, lib, mask = _problem(CASES["sisua"])
   outs = []
   for use_comm in (False, True):
     e = Engine(cfg, max_batch=64)
@@ -232,13 +235,16 @@ def test_rccl_single_rank_allreduce_is_identity(Engine, monkeypatch):
     if use_comm:
       e.comm_init(0, 1, Engine.comm_unique_id())
       assert e.world == 1
-    order = np.arange(64 * 4, dtype=np.int32) % x.shape[0]
-    m = e.train_steps(order, 4, 64, graph=True, metrics=True)
-    outs.append((m["loss"], e.get_params()))
+    order = np.arange(64 * 6, dtype=np.int32) % x.shape[0]
+    m = e.train_steps(order, 6, 64, graph=graph, metrics=True)
+    outs.append((m, e.get_params(), e.get_bn()))
     e.close()
-  assert outs[0][0] == outs[1][0]
+  for key in ("loss", "nllk_x", "nllk_y", "kl"):
+    assert outs[0][0][key] == outs[1][0][key], key
   for k in outs[0][1]:
     assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+  for i in outs[0][2]:
+    assert np.array_equal(outs[0][2][i]["moving_mean"], outs[1][2][i]["moving_mean"])
 
 
 def _golden(name):
