@@ -40,6 +40,10 @@ def build_workload(rank: int, world: int, workload: str):
   elif workload == "8kly-2layer":
     x, _ = data.synthetic_8kly(seed=8 + rank)
     units, latent, batch = (128, 128), 32, 128
+  elif workload in ("8kly-scvi", "eccly-sisua"):
+    # BASELINE.json configs[2] / configs[3]: SCVI nbd batch 256; SISUA zinb + ADT nb labels (10 %), alpha 10, batch 256
+    x, y = data.synthetic_8kly(seed=8 + rank) if workload == "8kly-scvi" else data.synthetic_eccly(seed=8 + rank)
+    units, latent, batch = (128,), 32, 256
   elif workload == "c5-shard":
     # per-GPU slice of BASELINE.json configs[4] (1e6 x 20000 log-normal counts, 128 cells per GPU per step):
     # 4096 resident cells are enough to exercise the step at its real width
@@ -56,10 +60,20 @@ def build_workload(rank: int, world: int, workload: str):
     tr2, _ = data.split_indices(len(tr), 0.9, seed=1)
     xt = data.corrupt(x[tr][tr2], 0.2, 0.2, seed=8)
     xt[xt.sum(1) == 0, 0] = 1.0
-  cfg = ModelConfig(model="vae", n_genes=x.shape[1], likelihood="zinb", enc_units=units, dec_units=units,
-                    latent_dim=latent, batchnorm=True, dropout_enc=0.1, dropout_dec=0.1, input_dropout=0.0,
-                    log_norm=True, beta=1.0, lr=1e-3, clipnorm=100.0, seed=8)
-  return cfg, xt, batch
+  kw = dict(n_genes=x.shape[1], enc_units=units, dec_units=units, latent_dim=latent, batchnorm=True, dropout_enc=0.1,
+            dropout_dec=0.1, input_dropout=0.0, log_norm=True, beta=1.0, lr=1e-3, clipnorm=100.0, seed=8)
+  extra = {}
+  if workload == "8kly-scvi":
+    cfg = ModelConfig(model="scvi", likelihood="nbd", encl_units=(64,), **kw)
+    extra["library"] = data.library_matrix(xt)
+  elif workload == "eccly-sisua":
+    yt = y[tr][tr2]
+    cfg = ModelConfig(model="sisua", likelihood="zinb", labels=((yt.shape[1], "nb"),), alpha=10.0, **kw)
+    extra["labels"] = [yt]
+    extra["label_mask"] = data.label_mask(xt.shape[0], 0.1, 2, seed=1)
+  else:
+    cfg = ModelConfig(model="vae", likelihood="zinb", **kw)
+  return cfg, xt, batch, extra
 
 
 def make_order(n_cells: int, batch: int, n_steps: int):
@@ -74,7 +88,7 @@ def make_order(n_cells: int, batch: int, n_steps: int):
   return np.concatenate(chunks[:n_steps]).astype(np.int32)
 
 
-def cpu_baseline(cfg, xt, batch, budget_s=12.0, threads=None):
+def cpu_baseline(cfg, xt, batch, budget_s=12.0, threads=None, extra=None):
   """The oracle (NumPy float64 restatement) timed on a bounded sample of the same workload:
   as many steps as fit in ~budget_s.  BLAS threads are capped at 16: on the 256-core GPU host
   more threads are SLOWER for these skinny products (measured 1/8/16/32/64/256 threads ->
@@ -83,10 +97,10 @@ def cpu_baseline(cfg, xt, batch, budget_s=12.0, threads=None):
   from threadpoolctl import threadpool_limits
   threads = threads or min(16, os.cpu_count() or 1)
   with threadpool_limits(limits=threads):
-    return _cpu_baseline(cfg, xt, batch, budget_s, threads)
+    return _cpu_baseline(cfg, xt, batch, budget_s, threads, extra or {})
 
 
-def _cpu_baseline(cfg, xt, batch, budget_s, threads):
+def _cpu_baseline(cfg, xt, batch, budget_s, threads, extra):
   from oracle import sisua_oracle as so
   spec = so.Spec(**cfg.to_dict())
   params = so.init_params(spec)
@@ -97,7 +111,10 @@ def _cpu_baseline(cfg, xt, batch, budget_s, threads):
   while True:
     rows = order[done * batch:(done + 1) * batch]
     t0 = time.perf_counter()
-    so.train_step(spec, params, bn, opt, x64[rows], so.PhiloxNoise(spec.seed, done, rows))
+    so.train_step(spec, params, bn, opt, x64[rows], so.PhiloxNoise(spec.seed, done, rows),
+                  y=[y[rows] for y in extra.get("labels", [])],
+                  library=extra["library"][rows] if "library" in extra else None,
+                  mask=extra["label_mask"][rows] if "label_mask" in extra else None)
     dt = time.perf_counter() - t0
     if done >= 2:  # first two steps warm caches / BLAS threads
       t_steps += dt
@@ -138,9 +155,9 @@ def main():
   _hip.require_gpu(local_rank)
   cp = ControlPlane(rank, world)
 
-  cfg, xt, batch = build_workload(rank, world, args.workload)
+  cfg, xt, batch, extra = build_workload(rank, world, args.workload)
   eng = Engine(cfg, max_batch=batch, device=local_rank)
-  eng.upload(xt, cell_id_base=rank * (1 << 24))
+  eng.upload(xt, cell_id_base=rank * (1 << 24), **extra)
   attach_engine(eng, cp)
 
   use_graph = args.graph
@@ -196,7 +213,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}-shaped synthetic counts {xt.shape[0]}x{xt.shape[1]} "
-                               f"(train split, corrupted), VAE zinb hidden={list(cfg.enc_units)} latent={cfg.latent_dim}, "
+                               f"(train split, corrupted), {cfg.model} {cfg.likelihood} hidden={list(cfg.enc_units)} latent={cfg.latent_dim}, "
                                f"batch {batch}/GPU, hipGraph={'on' if use_graph else 'off'}",
                    "global_batch": batch * world, "parallelism": f"dp{world}"},
         "final_loss": round(m["loss"], 4),
@@ -209,7 +226,7 @@ def main():
         "kernel_us": per_kernel,
     }
     if world == 1 and not args.no_cpu_baseline:
-      out["cpu_baseline"] = cpu_baseline(cfg, xt, batch, args.cpu_budget)
+      out["cpu_baseline"] = cpu_baseline(cfg, xt, batch, args.cpu_budget, extra=extra)
     print(json.dumps(out), flush=True)
   eng.close()
   cp.close()

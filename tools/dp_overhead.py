@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sisua_amd.engine import Engine
 import bench
-cfg, xt, batch = bench.build_workload(0, 1, "8kly")
+cfg, xt, batch, _ = bench.build_workload(0, 1, "8kly")
 for comm in (False, True):
   for graph in (False, True):
     e = Engine(cfg, max_batch=batch); e.upload(xt)
