@@ -89,11 +89,11 @@ __device__ inline void vstore(float* p, const float (&v)[VEC]) {
   *reinterpret_cast<typename VecT<VEC>::T*>(p) = t;
 }
 
-template <int LK, int DIRECT, int BWD, int VEC>
-__global__ __launch_bounds__(256) void count_loss_kernel(LossArgs a) {
+template <int LK, int DIRECT, int BWD, int VEC, int BLOCK = 256>
+__global__ __launch_bounds__(BLOCK) void count_loss_kernel(LossArgs a) {
   constexpr int K = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
   const int b = blockIdx.y;
-  const int g0 = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  const int g0 = (blockIdx.x * BLOCK + threadIdx.x) * VEC;
   float acc = 0.f;
   if (g0 < a.Gp) {
     const long src = a.rows ? a.rows[b] : b;
@@ -107,7 +107,12 @@ __global__ __launch_bounds__(256) void count_loss_kernel(LossArgs a) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       float llk = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
-      if (g0 + e < a.G) {
+      if (a.likelihood == -1) {  // diagnostic: same traffic, no arithmetic
+        d0 = a0[e] + xs[e]; d1 = a1[e]; d2 = a2[e]; acc += d0;
+      } else if (a.likelihood == -2) {  // diagnostic: every count treated as 0 (no lgamma work)
+        count_elem<LK, DIRECT>(0.f, a0[e], a1[e], K == 3 ? a2[e] : 0.f, llk, d0, d1, d2);
+        acc += llk + xs[e];
+      } else if (g0 + e < a.G) {
         count_elem<LK, DIRECT>(xs[e], a0[e], a1[e], K == 3 ? a2[e] : 0.f, llk, d0, d1, d2);
         acc += llk;
       }
@@ -120,13 +125,21 @@ __global__ __launch_bounds__(256) void count_loss_kernel(LossArgs a) {
       if (K == 3) vstore<VEC>(db + 2 * a.plane_stride, r2);
     }
   }
-  __shared__ float red[4];
+  // one partial per wave, no workgroup barrier: the consumer sums [n_chunks * waves] values per cell
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) a.llk_part[(long)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if ((threadIdx.x & 63) == 0)
+    a.llk_part[((long)b * gridDim.x + blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6)] = acc;
 }
 
+static int g_loss_block = 0;
+static int loss_block() {
+  if (!g_loss_block) {
+    const char* e = getenv("SMX_LOSS_BLOCK");
+    g_loss_block = e ? atoi(e) : 256;
+    if (g_loss_block != 256 && g_loss_block != 512 && g_loss_block != 1024) g_loss_block = 256;
+  }
+  return g_loss_block;
+}
 static int g_loss_vec = 0;
 static int loss_vec() {
   if (!g_loss_vec) {
@@ -136,12 +149,17 @@ static int loss_vec() {
   }
   return g_loss_vec;
 }
-int loss_chunks(int Gp) { return (Gp + 256 * loss_vec() - 1) / (256 * loss_vec()); }
+static int loss_grid_x(int Gp) { return (Gp + loss_block() * loss_vec() - 1) / (loss_block() * loss_vec()); }
+// number of partial sums per cell the loss kernel writes (one per wave)
+int loss_chunks(int Gp) { return loss_grid_x(Gp) * (loss_block() / 64); }
 
 template <int LK, int DIRECT>
 static void launch_loss_t(hipStream_t st, const LossArgs& a, dim3 grid) {
-  const int v = loss_vec();
-#define SMX_LOSS_LAUNCH(B_, V_) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_>), grid, dim3(256), 0, st, a)
+  const int v = loss_vec(), blk = loss_block();
+#define SMX_LOSS_LAUNCH(B_, V_) do { \
+    if (blk == 1024) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 1024>), grid, dim3(1024), 0, st, a); \
+    else if (blk == 512) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 512>), grid, dim3(512), 0, st, a); \
+    else hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 256>), grid, dim3(256), 0, st, a); } while (0)
   if (a.backward) { if (v == 4) SMX_LOSS_LAUNCH(1, 4); else if (v == 2) SMX_LOSS_LAUNCH(1, 2); else SMX_LOSS_LAUNCH(1, 1); }
   else { if (v == 4) SMX_LOSS_LAUNCH(0, 4); else if (v == 2) SMX_LOSS_LAUNCH(0, 2); else SMX_LOSS_LAUNCH(0, 1); }
 #undef SMX_LOSS_LAUNCH
@@ -152,7 +170,8 @@ int launch_count_loss(hipStream_t st, const LossArgs& a) {
     set_error("count_loss: bad shapes");
     return SMX_ERR_INVALID;
   }
-  dim3 grid(loss_chunks(a.Gp), a.B);
+  dim3 grid(loss_grid_x(a.Gp), a.B);
+  if (getenv("SMX_LOSS_NOP")) { LossArgs b = a; b.likelihood = -atoi(getenv("SMX_LOSS_NOP")); launch_loss_t<SMX_LLK_ZINB, 0>(st, b, grid); return SMX_OK; }
   switch (a.likelihood) {
     case SMX_LLK_NB: launch_loss_t<SMX_LLK_NB, 0>(st, a, grid); break;
     case SMX_LLK_ZINB: launch_loss_t<SMX_LLK_ZINB, 0>(st, a, grid); break;
