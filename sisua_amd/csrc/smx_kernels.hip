@@ -237,8 +237,29 @@ __device__ inline void slab_sum(const float* base, int n_slabs, long slab_stride
     }
 }
 
+// extra workgroups of the BN launch: Philox multipliers / normals for later layers, 4 columns per thread
+__device__ inline void noise_fill(const BnFwdArgs& a, int job_block) {
+  const NoiseJob& j = a.jobs[job_block / SMX_NOISE_BLOCKS_PER_JOB];
+  const int sub = job_block % SMX_NOISE_BLOCKS_PER_JOB;
+  const int wq = (j.width + 3) >> 2;
+  NoiseKey nk = a.nk;
+  nk.stream = j.stream;
+  const float scale = j.p > 0.f ? 1.f / (1.f - j.p) : 1.f;
+  for (int idx = sub * 256 + threadIdx.x; idx < a.B * wq; idx += SMX_NOISE_BLOCKS_PER_JOB * 256) {
+    const int r = idx / wq, c0 = (idx % wq) * 4;
+    const uint32_t cell = a.cell_base + (uint32_t)(a.rows ? a.rows[r] : r);
+    const U4 w = philox_block(nk, cell, (uint32_t)(c0 >> 2));
+    const float4 v = j.normal ? normal4(w) : dropout_mult4(w, j.p, scale);
+    *reinterpret_cast<float4*>(j.dst + (long)r * j.ld + c0) = v;
+  }
+}
+
 template <bool SMALL>  // SMALL: B <= BN_RL * BN_RPT, every value of the column stays in registers
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
+  if ((int)blockIdx.x >= a.Hp / BN_COLS) {
+    noise_fill(a, (int)blockIdx.x - a.Hp / BN_COLS);
+    return;
+  }
   __shared__ float sh[4 * BN_COLS];
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = blockIdx.x * BN_COLS + c;
@@ -332,8 +353,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
 
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a) {
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_fwd: bad shapes"); return SMX_ERR_INVALID; }
-  if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(a.Hp / BN_COLS), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(a.Hp / BN_COLS), dim3(256), 0, st, a);
+  const int grid = a.Hp / BN_COLS + a.n_jobs * SMX_NOISE_BLOCKS_PER_JOB;
+  if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(grid), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }

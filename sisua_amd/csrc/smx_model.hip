@@ -62,6 +62,7 @@ struct MlpLayer {
   int stream = 0;
   float drop_p = 0.f;
   float *xhat = nullptr, *out_buf = nullptr, *inv_std = nullptr, *dpre = nullptr;
+  float* noise = nullptr;   // [Bmax][out_p] dropout multipliers produced ahead of the layer (fused small-layer path)
 };
 
 struct Injected { float* d = nullptr; int ld = 0; };
@@ -134,6 +135,8 @@ struct smx_model {
   int par = 0; uint32_t h_next = 0;
   MetricsArgs pending_metrics; bool have_pending_metrics = false;
   int seq_batch = 0, seq_prepare_next = 0;
+  bool eps_ahead_ok = false;   // latent head fusable: eps may be drawn ahead by the first BN launch
+  float* noise_eps = nullptr;  // [Bmax][Dp] eps drawn ahead of the latent head
   float *latbuf = nullptr, *dlat = nullptr, *z = nullptr, *sig = nullptr, *eps = nullptr, *kl = nullptr;
   float *latlbuf = nullptr, *dlatl = nullptr, *lsmp = nullptr, *lsig = nullptr, *leps = nullptr, *kl_l = nullptr, *dl = nullptr;
   float *P = nullptr, *dP = nullptr, *raw = nullptr, *draw = nullptr, *rho = nullptr, *llk_part = nullptr;
@@ -278,8 +281,14 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
         if (const Injected* ij = inj(m, ST_INPUT_DROPOUT)) { g.xf.inj_mask = ij->d; g.xf.inj_ld = ij->ld; }
       }
     }
+    // measured: the 4-workgroup fused small-layer kernels are 3 us/step SLOWER than two wider launches;
+    // opt-in (SMX_SMALL_FUSION=1) and covered by tests/test_gpu_variants.py
+    static const bool no_fz = getenv("SMX_SMALL_FUSION") == nullptr;
+    static const bool no_ahead = getenv("SMX_NO_NOISE_AHEAD") != nullptr;
+    const bool ahead = !no_fz && !no_ahead && !m->scvi;
+    const bool fuse = !no_fz && !(i == 0 && in_is_x) && dense_bn_fusable(ps.B, L.in_p);
     int eff = 1;
-    {
+    if (!fuse) {
       Timed t(m, (i == 0 && in_is_x) ? label0 : "gemm_mlp_fwd");
       SMX_CHECK(launch_gemm(m->st, g, &eff));
     }
@@ -300,7 +309,31 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     b.nk = make_key(m, L.stream, ps.sample, true);
     b.rows = ps.rows; b.cell_base = ps.cell_base;
     if (const Injected* ij = inj(m, L.stream)) { b.inj_mask = ij->d; b.inj_ld = ij->ld; }
-    {
+    if (fuse && ahead && !b.inj_mask && b.drop_p > 0.f) { b.inj_mask = L.noise; b.inj_ld = L.out_p; }
+    if (!fuse && ahead && i == 0 && in_is_x && &mlp == &m->enc) {
+      // this launch precedes every fused small layer of the step: draw their noise on otherwise idle CUs
+      auto add = [&](float* dst, int ld, int width, int normal, float p, int stream) {
+        if (b.n_jobs < SMX_NOISE_JOBS) {
+          NoiseJob& j = b.jobs[b.n_jobs++];
+          j.dst = dst; j.ld = ld; j.width = width; j.normal = normal; j.p = p;
+          j.stream = (uint32_t)((stream & 0xFF) | ((ps.sample & 0xFFFFFF) << 8));
+        }
+      };
+      if (ps.training) {
+        for (size_t q = 1; q < m->enc.size(); ++q)
+          if (m->enc[q].drop_p > 0.f && dense_bn_fusable(ps.B, m->enc[q].in_p) && !inj(m, m->enc[q].stream))
+            add(m->enc[q].noise, m->enc[q].out_p, m->enc[q].out, 0, m->enc[q].drop_p, m->enc[q].stream);
+        for (size_t q = 0; q < m->dec.size(); ++q)
+          if (m->dec[q].drop_p > 0.f && dense_bn_fusable(ps.B, m->dec[q].in_p) && !inj(m, m->dec[q].stream))
+            add(m->dec[q].noise, m->dec[q].out_p, m->dec[q].out, 0, m->dec[q].drop_p, m->dec[q].stream);
+      }
+      if (m->stochastic && !inj(m, ST_EPS_Z) && m->eps_ahead_ok) add(m->noise_eps, m->Dp, m->D, 1, 0.f, ST_EPS_Z);
+      if (b.n_jobs) { b.nk.step_ptr = ps.training ? &cur_state(m)->step : nullptr; }
+    }
+    if (fuse) {
+      Timed t(m, "dense_bn_fwd");
+      SMX_CHECK(launch_dense_bn_act_fwd(m->st, in, ld, L.in_p, P_(m, L.tW), tw.ld, b));
+    } else {
       Timed t(m, "bn_fwd");
       SMX_CHECK(launch_bn_act_fwd(m->st, b));
     }
@@ -499,7 +532,9 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, bo
   SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd"));
   const MlpLayer& eL = m->enc.back();
   const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
-  {
+  static const bool no_fz = getenv("SMX_SMALL_FUSION") == nullptr;
+  const bool fuse_lat = !no_fz && latent_head_fusable(eL.out_p, lat_ld, m->Dp);
+  if (!fuse_lat) {
     const TensorInfo& tw = m->tensors[m->t_latW];
     GemmArgs g;
     g.A = eL.out_buf; g.lda = eL.out_p; g.B = P_(m, m->t_latW); g.ldb = tw.ld;
@@ -513,8 +548,14 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, bo
   la.nk = make_key(m, ST_EPS_Z, ps.sample, ps.training != 0);
   la.rows = ps.rows; la.cell_base = ps.cell_base;
   if (const Injected* ij = inj(m, ST_EPS_Z)) { la.inj_eps = ij->d; la.inj_ld = ij->ld; }
+  static const bool no_ahead = getenv("SMX_NO_NOISE_AHEAD") != nullptr;
+  if (fuse_lat && m->stochastic && !la.inj_eps && !no_ahead && !m->scvi && m->eps_ahead_ok) { la.inj_eps = m->noise_eps; la.inj_ld = m->Dp; }
   la.z = m->z; la.sig = m->sig; la.eps = m->eps; la.kl = m->kl;
-  {
+  if (fuse_lat) {
+    Timed t(m, "latent_head_fwd");
+    SMX_CHECK(launch_latent_head_fwd(m->st, la, eL.out_buf, eL.out_p, eL.out_p, P_(m, m->t_latW), m->tensors[m->t_latW].ld,
+                                     P_(m, m->t_latb), m->latbuf));
+  } else {
     Timed t(m, "latent_fwd");
     SMX_CHECK(launch_latent_fwd(m->st, la));
   }
@@ -1094,6 +1135,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
       if ((rc = dmalloc(&L.out_buf, B * L.out_p))) return rc;
       if ((rc = dmalloc(&L.dpre, B * L.out_p))) return rc;
       if ((rc = dmalloc(&L.inv_std, (size_t)L.out_p))) return rc;
+      if ((rc = dmalloc(&L.noise, B * L.out_p))) return rc;
     }
     return (int)SMX_OK;
   };
@@ -1102,7 +1144,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   const size_t lat_ld = (m->stochastic ? 2 : 1) * (size_t)m->Dp;
   const size_t ldp = (size_t)m->k * m->Gp;
   if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
-      (rc = dmalloc(&m->z, B * m->Dp)) || (rc = dmalloc(&m->sig, B * m->Dp)) || (rc = dmalloc(&m->eps, B * m->Dp)) ||
+      (rc = dmalloc(&m->z, B * m->Dp)) || (rc = dmalloc(&m->noise_eps, B * m->Dp)) || (rc = dmalloc(&m->sig, B * m->Dp)) || (rc = dmalloc(&m->eps, B * m->Dp)) ||
       (rc = dmalloc(&m->kl, B)) || (rc = dmalloc(&m->P, B * ldp)) || (rc = dmalloc(&m->dP, B * ldp)) ||
       (rc = dmalloc(&m->llk_part, B * loss_chunks(m->Gp))) || (rc = dmalloc(&m->llk_y, B)) ||
       (rc = dmalloc(&m->rows2[0], B)) || (rc = dmalloc(&m->rows2[1], B)) || (rc = dmalloc(&m->state3, (size_t)3)) ||
@@ -1118,6 +1160,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     const size_t ld = m->tensors[m->t_labW[j]].ld;
     if ((rc = dmalloc(&m->laby_raw[j], B * ld)) || (rc = dmalloc(&m->laby_draw[j], B * ld))) return fail(rc);
   }
+  m->eps_ahead_ok = latent_head_fusable(m->enc.back().out_p, (m->stochastic ? 2 : 1) * m->Dp, m->Dp);
   // ---- optimiser chunk table ----
   std::vector<OptChunk> chunks;
   const int CH = 4096;
@@ -1155,11 +1198,11 @@ int smx_model_destroy(smx_model* m) {
   auto fr = [](void* p) { if (p) hipFree(p); };
   fr(m->params); fr(m->grads); fr(m->adam_m); fr(m->adam_v); fr(m->bn_moving);
   for (auto* mlp : {&m->enc, &m->encl, &m->dec})
-    for (auto& L : *mlp) { fr(L.xhat); fr(L.out_buf); fr(L.dpre); fr(L.inv_std); }
+    for (auto& L : *mlp) { fr(L.xhat); fr(L.out_buf); fr(L.dpre); fr(L.inv_std); fr(L.noise); }
   fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1); fr(m->hostX); fr(m->hostLib); fr(m->hostLgx1);
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); fr(m->laby_raw[j]); fr(m->laby_draw[j]); }
   fr(m->rows2[0]); fr(m->rows2[1]); fr(m->order); fr(m->state3);
-  fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);
+  fr(m->noise_eps); fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);
   fr(m->latlbuf); fr(m->dlatl); fr(m->lsmp); fr(m->lsig); fr(m->leps); fr(m->kl_l); fr(m->dl);
   fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);
   fr(m->chunks); fr(m->partial); fr(m->tensor_norm);
