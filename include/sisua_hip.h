@@ -161,6 +161,14 @@ int smx_forward(smx_model* m, const int32_t* row_ids, const float* host_x, const
  * eval mode. */
 int smx_decode(smx_model* m, const float* z, const float* l, int32_t batch, float* x_params, float* const* y_params);
 
+/* Importance-weighted marginal log-likelihood, the scoring path of Posterior.cal_marginal_llk ->
+ * scm.marginal_log_prob(**Xs, sample_shape=100) (sisua/analysis/posterior.py:941-976): the encoder runs once,
+ * then n_samples times {sample z (Philox draw s), decoder, output head, forward-only likelihood kernel} with
+ * a running log-sum-exp per cell on the device.  mllk[batch] = log mean_s p(x|z_s) p(z_s) / q(z_s|x);
+ * llk_mean[batch] = mean_s log p(x|z_s) (may be NULL).  Cells: row_ids or host_x (+ host_library for scvi). */
+int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,
+                     int32_t n_samples, float* mllk, float* llk_mean);
+
 /* Test hook: inject noise for the NEXT step instead of Philox.  stream ids as in
  * oracle/sisua_oracle.py (STREAM_*); data [batch, width] holds eps values or
  * dropout multipliers.  smx_clear_noise() returns to Philox. */

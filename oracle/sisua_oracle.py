@@ -578,6 +578,35 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
 
 
 # --------------------------------------------------------------------------
+# Importance-weighted marginal log-likelihood (Posterior.cal_marginal_llk ->
+# scm.marginal_log_prob(**Xs, sample_shape=100), sisua/analysis/posterior.py:941-976)
+# --------------------------------------------------------------------------
+def marginal_log_prob(spec: Spec, params, bn_state, x, cell_ids, n_samples: int, library=None):
+  """log p(x) ~= logsumexp_s[ log p(x|z_s) + log p(z_s) - log q(z_s|x) ] - log S with z_s ~ q(z|x) in eval
+  mode (moving BN statistics, no dropout); draw s uses Philox (step 0, sample s).  SCVI adds the library
+  latent's prior/posterior terms.  Returns (mllk[B], mean_s log p(x|z_s)[B])."""
+  logw, llks = [], []
+  for s_ in range(n_samples):
+    noise = PhiloxNoise(spec.seed, 0, cell_ids, sample=s_)
+    r = forward_backward(spec, params, bn_state, x, noise, library=library, training=False, backward=False)
+    lw = r["llk_x"].copy()
+    if spec.stochastic:
+      z, mu, sig = r["z"], r["z_mean"], r["z_scale"]
+      eps = (z - mu) / sig
+      lw += (-0.5 * z ** 2 + 0.5 * eps ** 2 + np.log(sig)).sum(1)
+    if spec.model == "scvi":
+      l, mu_l, sig_l = r["l"], r["l_mean"], r["l_scale"]
+      mp, sp = library[:, 0], np.sqrt(library[:, 1])
+      eps_l = (l - mu_l) / sig_l
+      lw += -0.5 * ((l - mp) / sp) ** 2 - np.log(sp) + 0.5 * eps_l ** 2 + np.log(sig_l)
+    logw.append(lw)
+    llks.append(r["llk_x"])
+  logw = np.stack(logw, 0)
+  mx = logw.max(0)
+  return mx + np.log(np.exp(logw - mx).sum(0)) - np.log(n_samples), np.mean(llks, 0)
+
+
+# --------------------------------------------------------------------------
 # Optimiser: per-tensor clipnorm then Adam (Keras form; frozen)
 # --------------------------------------------------------------------------
 def init_opt_state(params):

@@ -95,6 +95,41 @@ int load_rccl() {
   return SMX_OK;
 }
 
+// importance weights of one posterior draw, folded into a running log-sum-exp per cell:
+//   log w = log p(x|z) + log N(z;0,I) - log N(z;mu,sigma) [+ the library latent's terms, scvi]
+struct IwArgs {
+  const float* llk_part; int n_chunks; const float* lgx1; const int32_t* rows;
+  const float* z; const float* sig; const float* eps; int D, Dp, stochastic;
+  const float* l; const float* lsig; const float* leps; const float* library;  // scvi (library indexed like lgx1)
+  float* run_max; float* run_sum; float* llk_sum; int B, first;
+};
+__global__ void iw_accum_kernel(IwArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  float llk = 0.f;
+  for (int c = 0; c < a.n_chunks; ++c) llk += a.llk_part[(long)b * a.n_chunks + c];
+  const long src = a.rows ? a.rows[b] : b;
+  llk -= a.lgx1[src];
+  float lw = llk;
+  if (a.stochastic)
+    for (int d = 0; d < a.D; ++d) {
+      const float z = a.z[(long)b * a.Dp + d], e = a.eps[(long)b * a.Dp + d], s = a.sig[(long)b * a.Dp + d];
+      lw += -0.5f * z * z + 0.5f * e * e + logf(s);
+    }
+  if (a.l) {
+    const float mp = a.library[src * 2], vp = a.library[src * 2 + 1];
+    const float l = a.l[b], e = a.leps[b], s = a.lsig[b];
+    lw += -0.5f * (l - mp) * (l - mp) / vp - 0.5f * logf(vp) + 0.5f * e * e + logf(s);
+  }
+  if (a.first) { a.run_max[b] = lw; a.run_sum[b] = 1.f; a.llk_sum[b] = llk; }
+  else {
+    const float mx = a.run_max[b], nm = fmaxf(mx, lw);
+    a.run_sum[b] = a.run_sum[b] * expf(mx - nm) + expf(lw - nm);
+    a.run_max[b] = nm;
+    a.llk_sum[b] += llk;
+  }
+}
+
 __global__ void bn_moving_update_kernel(float* moving, const float* batch_sum, int n, float inv_world, float momentum) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) moving[i] = moving[i] * momentum + batch_sum[i] * inv_world * (1.f - momentum);
@@ -501,10 +536,13 @@ void fill_mid_args(smx_model* m, const Pass& ps, MidArgs& a) {
   else a.enc0_dbias = G_(m, e0.tBias);
 }
 
-int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, bool decode_only = false) {
+// mode: 0 full forward; 1 decoder only (z given in m->z); 2 resample (encoder outputs m->latbuf / m->latlbuf kept,
+// only the latent draw and everything after it run again)
+int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, int mode = 0) {
+  const bool decode_only = (mode == 1), resample = (mode == 2);
   const smx_config& c = m->cfg;
   const float inv_gb = 1.f / (float)ps.global_batch;
-  const bool mid = !decode_only && use_mid(m, ps.B);
+  const bool mid = (mode == 0) && use_mid(m, ps.B);
   if (mid) {
     SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd", 1));
     MidArgs ma;
@@ -529,12 +567,12 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, bo
   }
   if (!decode_only && !mid) {
   // ---- encoder ----
-  SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd"));
+  if (!resample) SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd"));
   const MlpLayer& eL = m->enc.back();
   const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
   static const bool no_fz = getenv("SMX_SMALL_FUSION") == nullptr;
-  const bool fuse_lat = !no_fz && latent_head_fusable(eL.out_p, lat_ld, m->Dp);
-  if (!fuse_lat) {
+  const bool fuse_lat = !no_fz && !resample && latent_head_fusable(eL.out_p, lat_ld, m->Dp);
+  if (!fuse_lat && !resample) {
     const TensorInfo& tw = m->tensors[m->t_latW];
     GemmArgs g;
     g.A = eL.out_buf; g.lda = eL.out_p; g.B = P_(m, m->t_latW); g.ldb = tw.ld;
@@ -561,13 +599,15 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, bo
   }
   // ---- scvi library latent ----
   if (m->scvi) {
-    SMX_CHECK(mlp_forward(m, m->encl, ps, ps.Xsrc, m->Gp, true, "gemm_encl_fwd"));
-    const MlpLayer& lL = m->encl.back();
-    const TensorInfo& tw = m->tensors[m->t_latlW];
-    GemmArgs g;
-    g.A = lL.out_buf; g.lda = lL.out_p; g.B = P_(m, m->t_latlW); g.ldb = tw.ld;
-    g.C = m->latlbuf; g.ldc = 32; g.M = ps.B; g.N = 32; g.K = lL.out_p; g.bias = P_(m, m->t_latlb);
-    SMX_CHECK(launch_gemm(m->st, g));
+    if (!resample) {
+      SMX_CHECK(mlp_forward(m, m->encl, ps, ps.Xsrc, m->Gp, true, "gemm_encl_fwd"));
+      const MlpLayer& lL = m->encl.back();
+      const TensorInfo& tw = m->tensors[m->t_latlW];
+      GemmArgs g;
+      g.A = lL.out_buf; g.lda = lL.out_p; g.B = P_(m, m->t_latlW); g.ldb = tw.ld;
+      g.C = m->latlbuf; g.ldc = 32; g.M = ps.B; g.N = 32; g.K = lL.out_p; g.bias = P_(m, m->t_latlb);
+      SMX_CHECK(launch_gemm(m->st, g));
+    }
     LibLatentArgs ll;
     ll.latl = m->latlbuf; ll.ld = 32; ll.B = ps.B; ll.library = ps.lib; ll.rows = ps.rows; ll.cell_base = ps.cell_base;
     ll.nk = make_key(m, ST_EPS_L, ps.sample, ps.training != 0);
@@ -1452,7 +1492,7 @@ int smx_decode(smx_model* m, const float* z, const float* l, int32_t batch, floa
   SMX_HIP(hipMemcpy2DAsync(m->z, (size_t)m->Dp * sizeof(float), z, (size_t)m->D * sizeof(float), (size_t)m->D * sizeof(float),
                            (size_t)batch, hipMemcpyHostToDevice, m->st));
   if (m->scvi) SMX_HIP(hipMemcpyAsync(m->lsmp, l, (size_t)batch * sizeof(float), hipMemcpyHostToDevice, m->st));
-  SMX_CHECK(forward_pass(m, ps, false, false, true));
+  SMX_CHECK(forward_pass(m, ps, false, false, 1));
   SMX_HIP(hipStreamSynchronize(m->st));
   const int B = batch, G = m->G, Gp = m->Gp;
   if (x_params)
@@ -1472,6 +1512,49 @@ int smx_decode(smx_model* m, const float* z, const float* l, int32_t batch, floa
     }
   }
   return SMX_OK;
+}
+
+int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,
+                     int32_t n_samples, float* mllk, float* llk_mean) {
+  SMX_REQUIRE(m && mllk && n_samples > 0, "bad arguments");
+  Pass ps;
+  SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, 0, 0));
+  float* run = nullptr;   // [3][B]: running max, running sum, sum of log p(x|z)
+  SMX_CHECK(dmalloc(&run, (size_t)3 * batch));
+  int rc = SMX_OK;
+  for (int s = 0; s < n_samples && rc == SMX_OK; ++s) {
+    ps.sample = s;
+    rc = forward_pass(m, ps, false, false, s == 0 ? 0 : 2);
+    if (rc != SMX_OK) break;
+    LossArgs lo;
+    lo.likelihood = m->cfg.likelihood; lo.direct = m->scvi; lo.backward = 0;
+    lo.X = ps.Xsrc; lo.ldx = m->Gp; lo.rows = ps.rows;
+    lo.P = m->P; lo.ldp = (long)m->k * m->Gp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
+    lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = 0.f;
+    rc = launch_count_loss(m->st, lo);
+    if (rc != SMX_OK) break;
+    IwArgs a;
+    a.llk_part = m->llk_part; a.n_chunks = loss_chunks(m->Gp); a.lgx1 = ps.lgx1; a.rows = ps.rows;
+    a.z = m->z; a.sig = m->sig; a.eps = m->eps; a.D = m->D; a.Dp = m->Dp; a.stochastic = m->stochastic;
+    a.l = m->scvi ? m->lsmp : nullptr; a.lsig = m->lsig; a.leps = m->leps; a.library = ps.lib;
+    a.run_max = run; a.run_sum = run + batch; a.llk_sum = run + 2 * batch; a.B = batch; a.first = (s == 0);
+    hipLaunchKernelGGL(iw_accum_kernel, dim3((batch + 127) / 128), dim3(128), 0, m->st, a);
+  }
+  if (rc == SMX_OK) {
+    std::vector<float> h((size_t)3 * batch);
+    hipError_t e = hipMemcpyAsync(h.data(), run, h.size() * sizeof(float), hipMemcpyDeviceToHost, m->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->st);
+    if (e != hipSuccess) { set_error(std::string("marginal_llk readback failed: ") + hipGetErrorString(e)); rc = SMX_ERR_HIP; }
+    else
+      for (int b = 0; b < batch; ++b) {
+        mllk[b] = h[b] + logf(h[batch + b]) - logf((float)n_samples);
+        if (llk_mean) llk_mean[b] = h[2 * batch + b] / (float)n_samples;
+      }
+  } else {
+    hipStreamSynchronize(m->st);
+  }
+  hipFree(run);
+  return rc;
 }
 
 int smx_set_noise(smx_model* m, int32_t stream, const float* data, int32_t batch, int32_t width) {

@@ -228,6 +228,20 @@ class Engine:
     check(self.lib.smx_decode(self._h, _fp(za), _fp(la), B, _fp(xp), yptrs))
     return dict(x_params=xp, y_params=ys)
 
+  def marginal_llk(self, row_ids=None, x=None, library=None, n_samples: int = 100):
+    """Importance-weighted log p(x) per cell and the mean reconstruction log-likelihood (GPU)."""
+    if row_ids is not None:
+      ids = self._ids(row_ids)
+      B, idp, xp, lp = ids.size, ids.ctypes.data_as(C.POINTER(C.c_int32)), None, None
+    else:
+      xa = _f32(x)
+      B, idp, xp = xa.shape[0], None, _fp(xa)
+      la = None if library is None else _f32(library, (B, 2))
+      lp = _fp(la)
+    mllk, llk = np.empty(B, np.float32), np.empty(B, np.float32)
+    check(self.lib.smx_marginal_llk(self._h, idp, xp, lp, B, int(n_samples), _fp(mllk), _fp(llk)))
+    return mllk, llk
+
   # ---- noise injection (parity tests) ----------------------------------------------
   def set_noise(self, stream: int, data):
     a = _f32(data)

@@ -427,40 +427,25 @@ class SingleCellModel:
       Zc = D.concat_distributions(Z, axis=0)
     return Xc, Zc
 
-  def marginal_log_prob(self, inputs=None, library=None, mask=None, sample_shape=100, **kwargs):
+  def marginal_log_prob(self, inputs=None, library=None, mask=None, sample_shape=100, batch_size=128, **kwargs):
     r"""Importance-weighted estimate of log p(x) with `sample_shape` posterior draws
-    (Posterior.cal_marginal_llk, analysis/posterior.py:941-976).  Returns
-    (mllk[B], {output name: mean log-likelihood [B]})."""
+    (Posterior.cal_marginal_llk, analysis/posterior.py:941-976), computed on the GPU
+    (`smx_marginal_llk`: encoder once, then per draw decoder + forward-only likelihood kernel with a
+    running log-sum-exp).  Returns (mllk[B], {output name: mean_s log p(x|z_s) [B]})."""
     arrs = _flatten(inputs)
     x = np.ascontiguousarray(arrs[0], dtype=np.float32)
     S = int(np.prod(sample_shape)) if np.size(sample_shape) else 1
     if self._cfg.model == "scvi" and library is None:
       library = library_matrix(x)
-    e = self._ensure_engine(x.shape[0])
-    logw, llks = [], {}
-    for s in range(S):
-      out = e.forward(x=x, library=library, sample_index=s)
-      pX = self._output_dists([out["x_params"]], [out["y_params"]])
-      pXs = pX if isinstance(pX, tuple) else (pX,)
-      lw = pXs[0].log_prob(x)
-      llks.setdefault(pXs[0].name, []).append(lw)
-      for j, p in enumerate(pXs[1:]):
-        if len(arrs) > 1 + j:
-          ly = p.log_prob(arrs[1 + j])
-          llks.setdefault(p.name, []).append(ly)
-      if self._cfg.stochastic:
-        z = out["z_sample"].astype(np.float64)
-        qz = D.MultivariateNormalDiag(out["z_mean"], out["z_scale"])
-        lw = lw + D.MultivariateNormalDiag(np.zeros_like(z), np.ones_like(z)).log_prob(z) - qz.log_prob(z)
-      if self._cfg.model == "scvi":
-        lsmp = out["l_sample"].astype(np.float64)
-        pl = D.Normal(library[:, 0], np.sqrt(library[:, 1]))
-        lw = lw + pl.log_prob(lsmp) - D.Normal(out["l_mean"], out["l_scale"]).log_prob(lsmp)
-      logw.append(lw)
-    logw = np.stack(logw, 0)
-    mx = logw.max(0)
-    mllk = mx + np.log(np.exp(logw - mx).mean(0))
-    return mllk, {k: np.mean(v, 0) for k, v in llks.items()}
+    e = self._ensure_engine(min(int(batch_size), x.shape[0]))
+    B = min(e.max_batch, x.shape[0])
+    mllk, llk = [], []
+    for s0 in range(0, x.shape[0], B):
+      sl = slice(s0, s0 + B)
+      a, b = e.marginal_llk(x=x[sl], library=None if library is None else library[sl], n_samples=S)
+      mllk.append(a)
+      llk.append(b)
+    return np.concatenate(mllk), {self._outputs[0].name or "transcriptomic": np.concatenate(llk)}
 
   # ---- evaluation hand-off -----------------------------------------------------------------------
   def create_posterior(self, test_sco: SingleCellOMIC = None, **kwargs):

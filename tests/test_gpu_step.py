@@ -285,3 +285,27 @@ def test_hip_matches_committed_trajectory_fixture(Engine):
   assert np.allclose(got, fx["loss"], rtol=RTOL), np.abs(np.array(got) / fx["loss"] - 1).max()
   assert np.allclose(e.get_params()["lat/W"], fx["final_lat_W"], rtol=1e-3, atol=2e-3)
   e.close()
+
+
+@pytest.mark.parametrize("name", ["vae_zinb", "scvi_zinbd", "dca_zinb"])
+def test_marginal_llk_matches_oracle(Engine, name):
+  """importance-weighted log p(x) (posterior.py:941-976) on the GPU vs the oracle."""
+  spec, cfg, x, ys, lib, mask = _problem(dict(CASES[name], labels=()) if name != "sisua" else CASES[name])
+  params = perturbed_params(spec)
+  bn = so.init_bn_state(spec)
+  e = Engine(cfg, max_batch=64, init=False)
+  e.set_params(params)
+  e.upload(x, ys, lib, mask, cell_id_base=500)
+  rows = np.arange(20, 70, dtype=np.int32)
+  S = 12
+  ref_m, ref_l = so.marginal_log_prob(spec, params, bn, x[rows], rows + 500, S, library=lib[rows])
+  got_m, got_l = e.marginal_llk(row_ids=rows, n_samples=S)
+  assert np.allclose(got_m, ref_m, rtol=RTOL, atol=1e-3), np.abs(got_m - ref_m).max()
+  assert np.allclose(got_l, ref_l, rtol=RTOL, atol=1e-3)
+  # host-batch entry (cell ids = position in the batch) and the jensen bound mllk >= mean llk - KL-ish slack
+  ref_m2, _ = so.marginal_log_prob(spec, params, bn, x[rows], np.arange(len(rows)), S, library=lib[rows])
+  got_m2, _ = e.marginal_llk(x=x[rows], library=lib[rows], n_samples=S)
+  assert np.allclose(got_m2, ref_m2, rtol=RTOL, atol=1e-3)
+  one, _ = e.marginal_llk(row_ids=rows, n_samples=1)
+  assert np.isfinite(one).all()
+  e.close()
