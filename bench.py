@@ -89,42 +89,52 @@ def make_order(n_cells: int, batch: int, n_steps: int):
 
 
 def cpu_baseline(cfg, xt, batch, budget_s=12.0, threads=None, extra=None):
-  """The oracle (NumPy float64 restatement) timed on a bounded sample of the same workload:
-  as many steps as fit in ~budget_s.  BLAS threads are capped at 16: on the 256-core GPU host
-  more threads are SLOWER for these skinny products (measured 1/8/16/32/64/256 threads ->
-  3.2k/3.4k/3.5k/1.7k/0.8k/0.9k cells/s); the special functions (scipy gammaln/digamma over
-  B x G) are single-threaded and dominate."""
-  from threadpoolctl import threadpool_limits
-  threads = threads or min(16, os.cpu_count() or 1)
-  with threadpool_limits(limits=threads):
-    return _cpu_baseline(cfg, xt, batch, budget_s, threads, extra or {})
-
-
-def _cpu_baseline(cfg, xt, batch, budget_s, threads, extra):
-  from oracle import sisua_oracle as so
-  spec = so.Spec(**cfg.to_dict())
-  params = so.init_params(spec)
-  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  """CPU baseline on a bounded sample of the same workload (as many steps as fit in ~budget_s), kind "port":
+  * VAE workloads: the C / OpenMP fp32 port of the step (oracle/sisua_step.c, validated against the NumPy oracle in
+    tests/test_oracle_cport.py) on 16 threads (measured on the 256-core GPU host: 1/8/16/32/64/128 threads ->
+    2.0k/6.2k/7.8k/5.2k/3.3k/1.8k cells/s);
+  * other models: the NumPy float64 oracle with 16 BLAS threads (its SciPy special functions are single-threaded)."""
+  extra = extra or {}
   order = make_order(xt.shape[0], batch, 400)
-  x64 = xt.astype(np.float64)
+  if cfg.model == "vae":
+    from oracle import sisua_oracle as so
+    from oracle.cport import CStep
+    spec = so.Spec(**cfg.to_dict())
+    cs = CStep(spec, so.init_params(spec))
+    threads = threads or min(16, os.cpu_count() or 1)
+    cs.set_threads(threads)
+    step_fn = lambda i, rows: cs.train_step(xt[rows], rows, i)
+    what = f"C/OpenMP fp32 port of the step (oracle/sisua_step.c), {threads} threads"
+  else:
+    from threadpoolctl import threadpool_limits
+    from oracle import sisua_oracle as so
+    threads = threads or min(16, os.cpu_count() or 1)
+    spec = so.Spec(**cfg.to_dict())
+    params = so.init_params(spec)
+    bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+    x64 = xt.astype(np.float64)
+
+    def step_fn(i, rows):
+      with threadpool_limits(limits=threads):
+        so.train_step(spec, params, bn, opt, x64[rows], so.PhiloxNoise(spec.seed, i, rows),
+                      y=[y[rows] for y in extra.get("labels", [])],
+                      library=extra["library"][rows] if "library" in extra else None,
+                      mask=extra["label_mask"][rows] if "label_mask" in extra else None)
+    what = f"NumPy float64 oracle (oracle/sisua_oracle.py), {threads} BLAS threads"
   t_start, done, t_steps = time.perf_counter(), 0, 0.0
   while True:
     rows = order[done * batch:(done + 1) * batch]
     t0 = time.perf_counter()
-    so.train_step(spec, params, bn, opt, x64[rows], so.PhiloxNoise(spec.seed, done, rows),
-                  y=[y[rows] for y in extra.get("labels", [])],
-                  library=extra["library"][rows] if "library" in extra else None,
-                  mask=extra["label_mask"][rows] if "label_mask" in extra else None)
+    step_fn(done, rows)
     dt = time.perf_counter() - t0
-    if done >= 2:  # first two steps warm caches / BLAS threads
+    if done >= 2:  # first two steps warm caches / thread pools
       t_steps += dt
     done += 1
-    if time.perf_counter() - t_start > budget_s or done >= 400:
+    if (time.perf_counter() - t_start > budget_s and done >= 4) or done >= 400:
       break
   timed = max(done - 2, 1)
   return dict(value=round(batch * timed / t_steps, 1), unit="cells/s", cores=threads, kind="port",
-              sample=f"{timed} steps of batch {batch} of the same workload, NumPy float64 oracle "
-                     f"(oracle/sisua_oracle.py), {threads} BLAS threads (host has {os.cpu_count()} cores)")
+              sample=f"{timed} steps of batch {batch} of the same workload; {what} (host has {os.cpu_count()} cores)")
 
 
 def main():

@@ -1,0 +1,338 @@
+/* sisua_step.c -- C / OpenMP fp32 port of the VAE training step: the timed CPU baseline.
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  This is the "C++/OpenMP fp32 restatement of the
+ * identical step" that BASELINE.md section 3 names as the CPU baseline: the same formulas as
+ * oracle/sisua_oracle.py (SURVEY.md section 8 rows a-6 ... a-16; reference call sites
+ * sisua/models/single_cell_model.py:119-151, configs/base.yaml:45-50), fp32 storage, Philox4x32-10 noise
+ * identical to the oracle / the HIP kernels, OpenMP over cells (elementwise work) and over output rows
+ * (products).  Scope: the VAE family of the benchmark (model 'vae', nb / zinb / nbd / zinbd, any MLP depth,
+ * BatchNorm on or off).  It is validated against the NumPy oracle in tests/test_oracle_cport.py and is
+ * never the checker itself.   Build: oracle/build_c.py (gcc -O3 -march=x86-64-v3 -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define OST_MAX_LAYERS 8
+#define SP_INV1 0.5413248546129181f
+
+typedef struct {
+  int32_t G, D, n_enc, enc[OST_MAX_LAYERS], n_dec, dec[OST_MAX_LAYERS];
+  int32_t likelihood; /* 0 nb, 1 zinb, 2 nbd, 3 zinbd */
+  int32_t batchnorm, log_norm;
+  float dropout_enc, dropout_dec, input_dropout, beta, bn_momentum, bn_eps, lr, b1, b2, adam_eps, clipnorm;
+  uint64_t seed;
+} ost_config;
+
+typedef struct { int in, out; float *W, *gamma, *beta, *bias; float *mm, *mv;          /* parameters, moving stats */
+                 float *gW, *ggamma, *gbeta, *gbias;                                   /* gradients */
+                 float *pre, *xhat, *act, *mask, *inv; int stream; float drop; } layer_t;
+
+typedef struct {
+  ost_config c; int k, Bcap;
+  layer_t enc[OST_MAX_LAYERS], dec[OST_MAX_LAYERS];
+  float *Wlat, *blat, *gWlat, *gblat, *Wout, *bout, *gWout, *gbout;
+  /* flat views for the optimiser */
+  int n_tensors; float* tp[64]; float* tg[64]; float* tm[64]; float* tv[64]; size_t tn[64];
+  int t;
+  /* activations */
+  float *h0, *in_mask, *lat, *z, *sig, *eps, *P, *dP, *dd, *dz, *dlat, *dh, *tmp;
+} ost_t;
+
+/* ---- Philox4x32-10, same counter layout as oracle/sisua_oracle.py ------------------------------ */
+static inline void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t o[4]) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+static void dropout_row(const ost_t* m, int stream, int step, int64_t cell, int n, float p, float* out) {
+  const float scale = 1.0f / (1.0f - p);
+  for (int q = 0; q < (n + 3) / 4; ++q) {
+    uint32_t w[4];
+    philox((uint32_t)q, (uint32_t)cell, (uint32_t)step, (uint32_t)stream, (uint32_t)m->c.seed, (uint32_t)(m->c.seed >> 32), w);
+    for (int e = 0; e < 4 && 4 * q + e < n; ++e) out[4 * q + e] = ((float)(w[e] >> 8) * 5.9604644775390625e-08f >= p) ? scale : 0.f;
+  }
+}
+static void normal_row(const ost_t* m, int stream, int step, int64_t cell, int n, float* out) {
+  for (int q = 0; q < (n + 3) / 4; ++q) {
+    uint32_t w[4];
+    float v[4];
+    philox((uint32_t)q, (uint32_t)cell, (uint32_t)step, (uint32_t)stream, (uint32_t)m->c.seed, (uint32_t)(m->c.seed >> 32), w);
+    for (int pr = 0; pr < 2; ++pr) {
+      const double u1 = ((double)(w[2 * pr] >> 8) + 1.0) * 5.9604644775390625e-08, u2 = (double)(w[2 * pr + 1] >> 8) * 5.9604644775390625e-08;
+      const double r = sqrt(-2.0 * log(u1));
+      v[2 * pr] = (float)(r * cos(6.283185307179586 * u2)); v[2 * pr + 1] = (float)(r * sin(6.283185307179586 * u2));
+    }
+    for (int e = 0; e < 4 && 4 * q + e < n; ++e) out[4 * q + e] = v[e];
+  }
+}
+
+/* ---- products (row-parallel, i-k-j so the inner loop vectorises) --------------------------------- */
+static void gemm_nn(const float* A, const float* B, float* C, int M, int K, int N) { /* C[M,N] = A[M,K] B[K,N] */
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < M; ++i) {
+    float* c = C + (size_t)i * N;
+    memset(c, 0, sizeof(float) * N);
+    for (int k = 0; k < K; ++k) { const float a = A[(size_t)i * K + k]; if (a == 0.f) continue; const float* b = B + (size_t)k * N; for (int j = 0; j < N; ++j) c[j] += a * b[j]; }
+  }
+}
+static void gemm_tn(const float* A, const float* B, float* C, int K, int M, int N) { /* C[M,N] = A[K,M]^T B[K,N] */
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < M; ++i) {
+    float* c = C + (size_t)i * N;
+    memset(c, 0, sizeof(float) * N);
+    for (int k = 0; k < K; ++k) { const float a = A[(size_t)k * M + i]; if (a == 0.f) continue; const float* b = B + (size_t)k * N; for (int j = 0; j < N; ++j) c[j] += a * b[j]; }
+  }
+}
+static void gemm_nt(const float* A, const float* B, float* C, int M, int K, int N) { /* C[M,N] = A[M,K] B[N,K]^T */
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int i = 0; i < M; ++i)
+    for (int j = 0; j < N; ++j) {
+      const float *a = A + (size_t)i * K, *b = B + (size_t)j * K;
+      float s = 0.f;
+      for (int k = 0; k < K; ++k) s += a[k] * b[k];
+      C[(size_t)i * N + j] = s;
+    }
+}
+
+static inline float softplusf_(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+static double digamma_(double x) {
+  double r = 0.0;
+  while (x < 6.0) { r -= 1.0 / x; x += 1.0; }
+  const double f = 1.0 / (x * x);
+  return r + log(x) - 0.5 / x - f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f / 132))));
+}
+
+/* elementwise count log-likelihood and gradients wrt the raw planes (oracle count_llk) */
+static inline float count_elem(int lik, float x, float p0, float p1, float p2, float* d0, float* d1, float* d2) {
+  double ell;
+  if (lik <= 1) {
+    const double r = exp((double)p0), sp = softplusf_(p1);
+    ell = lgamma(x + r) - lgamma(r) - lgamma(x + 1.0) + x * (p1 - sp) - r * sp;
+    *d0 = (float)(r * ((x > 0 ? digamma_(x + r) - digamma_(r) : 0.0) - sp));
+    *d1 = (float)(x - (x + r) * sigmoidf_(p1));
+  } else {
+    const double mu = softplusf_(p0), th = softplusf_(p1 + SP_INV1), e = 1e-8, lt = log(th + mu + e);
+    ell = th * (log(th + e) - lt) + x * (log(mu + e) - lt) + lgamma(x + th) - lgamma(th) - lgamma(x + 1.0);
+    const double dmu = -th / (th + mu + e) + x / (mu + e) - x / (th + mu + e);
+    const double dth = log(th + e) - lt + th / (th + e) - th / (th + mu + e) - x / (th + mu + e) + (x > 0 ? digamma_(x + th) - digamma_(th) : 0.0);
+    *d0 = (float)(dmu * sigmoidf_(p0)); *d1 = (float)(dth * sigmoidf_(p1 + SP_INV1));
+  }
+  if (lik == 0 || lik == 2) { *d2 = 0.f; return (float)ell; }
+  const double spg = softplusf_(p2), sg = sigmoidf_(p2);
+  if (x == 0.f) {
+    const double mx = fmax((double)p2, ell), lse = mx + log(exp(p2 - mx) + exp(ell - mx)), w = exp(ell - lse);
+    *d0 *= (float)w; *d1 *= (float)w; *d2 = (float)((1.0 - w) - sg);
+    return (float)(lse - spg);
+  }
+  *d2 = (float)(-sg);
+  return (float)(ell - spg);
+}
+
+static float* falloc(size_t n) { float* p = (float*)calloc(n ? n : 1, sizeof(float)); return p; }
+static void reg(ost_t* m, float* p, float* g, size_t n) { int i = m->n_tensors++; m->tp[i] = p; m->tg[i] = g; m->tn[i] = n; m->tm[i] = falloc(n); m->tv[i] = falloc(n); }
+
+static void init_mlp(ost_t* m, layer_t* L, int n, const int32_t* units, int n_in, int stream0, float drop, const float* const** pp) {
+  for (int i = 0; i < n; ++i) {
+    layer_t* l = &L[i];
+    l->in = n_in; l->out = units[i]; l->stream = stream0 + i; l->drop = drop;
+    const size_t nw = (size_t)n_in * units[i];
+    l->W = falloc(nw); memcpy(l->W, *(*pp)++, nw * sizeof(float)); l->gW = falloc(nw); reg(m, l->W, l->gW, nw);
+    if (m->c.batchnorm) {
+      l->gamma = falloc(units[i]); memcpy(l->gamma, *(*pp)++, units[i] * sizeof(float)); l->ggamma = falloc(units[i]); reg(m, l->gamma, l->ggamma, units[i]);
+      l->beta = falloc(units[i]); memcpy(l->beta, *(*pp)++, units[i] * sizeof(float)); l->gbeta = falloc(units[i]); reg(m, l->beta, l->gbeta, units[i]);
+      l->mm = falloc(units[i]); l->mv = falloc(units[i]); for (int j = 0; j < units[i]; ++j) l->mv[j] = 1.f;
+    } else {
+      l->bias = falloc(units[i]); memcpy(l->bias, *(*pp)++, units[i] * sizeof(float)); l->gbias = falloc(units[i]); reg(m, l->bias, l->gbias, units[i]);
+    }
+    l->inv = falloc(units[i]);
+    n_in = units[i];
+  }
+}
+
+void* ost_create(const ost_config* c, const float* const* params) {
+  ost_t* m = (ost_t*)calloc(1, sizeof(ost_t));
+  m->c = *c; m->k = (c->likelihood == 1 || c->likelihood == 3) ? 3 : 2;
+  const float* const* pp = params;
+  init_mlp(m, m->enc, c->n_enc, c->enc, c->G, 16, c->dropout_enc, &pp);
+  const int H = c->enc[c->n_enc - 1], D = c->D;
+  m->Wlat = falloc((size_t)H * 2 * D); memcpy(m->Wlat, *pp++, (size_t)H * 2 * D * sizeof(float)); m->gWlat = falloc((size_t)H * 2 * D); reg(m, m->Wlat, m->gWlat, (size_t)H * 2 * D);
+  m->blat = falloc(2 * D); memcpy(m->blat, *pp++, 2 * D * sizeof(float)); m->gblat = falloc(2 * D); reg(m, m->blat, m->gblat, 2 * D);
+  init_mlp(m, m->dec, c->n_dec, c->dec, D, 48, c->dropout_dec, &pp);
+  const int Hd = c->dec[c->n_dec - 1]; const size_t kg = (size_t)m->k * c->G;
+  m->Wout = falloc(Hd * kg); memcpy(m->Wout, *pp++, Hd * kg * sizeof(float)); m->gWout = falloc(Hd * kg); reg(m, m->Wout, m->gWout, Hd * kg);
+  m->bout = falloc(kg); memcpy(m->bout, *pp++, kg * sizeof(float)); m->gbout = falloc(kg); reg(m, m->bout, m->gbout, kg);
+  return m;
+}
+
+static void ensure(ost_t* m, int B) {
+  if (B <= m->Bcap) return;
+  m->Bcap = B;
+  const int G = m->c.G, D = m->c.D; int maxw = 2 * D;
+  for (int i = 0; i < m->c.n_enc; ++i) if (m->c.enc[i] > maxw) maxw = m->c.enc[i];
+  for (int i = 0; i < m->c.n_dec; ++i) if (m->c.dec[i] > maxw) maxw = m->c.dec[i];
+  layer_t* Ls[2] = {m->enc, m->dec}; const int ns[2] = {m->c.n_enc, m->c.n_dec};
+  for (int q = 0; q < 2; ++q) for (int i = 0; i < ns[q]; ++i) { layer_t* l = &Ls[q][i]; const size_t n = (size_t)B * l->out; l->pre = falloc(n); l->xhat = falloc(n); l->act = falloc(n); l->mask = falloc(n); }
+  m->h0 = falloc((size_t)B * G); m->in_mask = falloc((size_t)B * G); m->lat = falloc((size_t)B * 2 * D); m->z = falloc((size_t)B * D); m->sig = falloc((size_t)B * D); m->eps = falloc((size_t)B * D);
+  m->P = falloc((size_t)B * m->k * G); m->dP = falloc((size_t)B * m->k * G); m->dd = falloc((size_t)B * maxw); m->dz = falloc((size_t)B * maxw); m->dlat = falloc((size_t)B * 2 * D); m->dh = falloc((size_t)B * maxw); m->tmp = falloc((size_t)B * maxw);
+}
+
+static void mlp_fwd(ost_t* m, layer_t* L, int n, const float* in, int B, int step, const int64_t* cells) {
+  for (int i = 0; i < n; ++i) {
+    layer_t* l = &L[i]; const int N = l->out;
+    gemm_nn(in, l->W, l->pre, B, l->in, N);
+    if (m->c.batchnorm) {
+#pragma omp parallel for schedule(static)
+      for (int j = 0; j < N; ++j) {
+        double s = 0, s2 = 0;
+        for (int b = 0; b < B; ++b) s += l->pre[(size_t)b * N + j];
+        const double mean = s / B;
+        for (int b = 0; b < B; ++b) { const double d = l->pre[(size_t)b * N + j] - mean; s2 += d * d; }
+        const double var = s2 / B; const float inv = (float)(1.0 / sqrt(var + m->c.bn_eps));
+        l->inv[j] = inv;
+        l->mm[j] = l->mm[j] * m->c.bn_momentum + (float)mean * (1.f - m->c.bn_momentum);
+        l->mv[j] = l->mv[j] * m->c.bn_momentum + (float)var * (1.f - m->c.bn_momentum);
+        for (int b = 0; b < B; ++b) l->xhat[(size_t)b * N + j] = (l->pre[(size_t)b * N + j] - (float)mean) * inv;
+      }
+    }
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+      float* mk = l->mask + (size_t)b * N;
+      if (l->drop > 0.f) dropout_row(m, l->stream, step, cells[b], N, l->drop, mk); else for (int j = 0; j < N; ++j) mk[j] = 1.f;
+      for (int j = 0; j < N; ++j) {
+        const float y = m->c.batchnorm ? l->gamma[j] * l->xhat[(size_t)b * N + j] + l->beta[j] : l->pre[(size_t)b * N + j] + l->bias[j];
+        l->act[(size_t)b * N + j] = fmaxf(y, 0.f) * mk[j];
+      }
+    }
+    in = l->act;
+  }
+}
+
+/* dh: d loss / d output of the last layer [B][out]; returns d input in m->tmp-sized buffer `din` */
+static void mlp_bwd(ost_t* m, layer_t* L, int n, const float* in0, float* dh, float* din, int B) {
+  for (int i = n - 1; i >= 0; --i) {
+    layer_t* l = &L[i]; const int N = l->out; const float* in = i == 0 ? in0 : L[i - 1].act;
+    float* dpre = l->pre; /* reuse */
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < N; ++j) {
+      double s1 = 0, s2 = 0;
+      for (int b = 0; b < B; ++b) {
+        const size_t o = (size_t)b * N + j;
+        const float dy = (l->act[o] > 0.f) ? dh[o] * l->mask[o] : 0.f;
+        dh[o] = dy; s1 += dy; if (m->c.batchnorm) s2 += dy * l->xhat[o];
+      }
+      if (m->c.batchnorm) {
+        l->ggamma[j] = (float)s2; l->gbeta[j] = (float)s1;
+        for (int b = 0; b < B; ++b) { const size_t o = (size_t)b * N + j; dpre[o] = l->gamma[j] * l->inv[j] * (dh[o] - (float)((s1 + l->xhat[o] * s2) / B)); }
+      } else {
+        l->gbias[j] = (float)s1;
+        for (int b = 0; b < B; ++b) dpre[(size_t)b * N + j] = dh[(size_t)b * N + j];
+      }
+    }
+    gemm_tn(in, dpre, l->gW, B, l->in, N);
+    if (i > 0 || din) { float* dst = i > 0 ? dh : din; gemm_nt(dpre, l->W, dst, B, N, l->in); }
+  }
+}
+
+float ost_train_step(void* h, const float* x, const int64_t* cells, int B, int step) {
+  ost_t* m = (ost_t*)h; ensure(m, B);
+  const ost_config* c = &m->c; const int G = c->G, D = c->D, k = m->k; const size_t kg = (size_t)k * G;
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < B; ++b) {
+    float* mk = m->in_mask + (size_t)b * G;
+    if (c->input_dropout > 0.f) dropout_row(m, 0, step, cells[b], G, c->input_dropout, mk); else for (int g = 0; g < G; ++g) mk[g] = 1.f;
+    for (int g = 0; g < G; ++g) { const float v = x[(size_t)b * G + g]; m->h0[(size_t)b * G + g] = (c->log_norm ? log1pf(v) : v) * mk[g]; }
+  }
+  mlp_fwd(m, m->enc, c->n_enc, m->h0, B, step, cells);
+  const layer_t* eL = &m->enc[c->n_enc - 1]; const int H = eL->out;
+  gemm_nn(eL->act, m->Wlat, m->lat, B, H, 2 * D);
+  double kl_sum = 0;
+#pragma omp parallel for schedule(static) reduction(+ : kl_sum)
+  for (int b = 0; b < B; ++b) {
+    normal_row(m, 64, step, cells[b], D, m->eps + (size_t)b * D);
+    for (int d = 0; d < D; ++d) {
+      const float mu = m->lat[(size_t)b * 2 * D + d] + m->blat[d], sg = softplusf_(m->lat[(size_t)b * 2 * D + D + d] + m->blat[D + d] + SP_INV1);
+      m->lat[(size_t)b * 2 * D + d] = mu; m->sig[(size_t)b * D + d] = sg;
+      m->z[(size_t)b * D + d] = mu + sg * m->eps[(size_t)b * D + d];
+      kl_sum += 0.5 * ((double)sg * sg + (double)mu * mu - 1.0 - 2.0 * log(sg));
+    }
+  }
+  mlp_fwd(m, m->dec, c->n_dec, m->z, B, step, cells);
+  const layer_t* dL = &m->dec[c->n_dec - 1]; const int Hd = dL->out;
+  gemm_nn(dL->act, m->Wout, m->P, B, Hd, (int)kg);
+  double llk_sum = 0; const float cx = -1.0f / B;
+#pragma omp parallel for schedule(static) reduction(+ : llk_sum)
+  for (int b = 0; b < B; ++b) {
+    float* p = m->P + (size_t)b * kg; float* dp = m->dP + (size_t)b * kg;
+    for (int g = 0; g < G; ++g) {
+      float d0, d1, d2;
+      const float p2 = k == 3 ? p[2 * G + g] + m->bout[2 * G + g] : 0.f;
+      llk_sum += count_elem(c->likelihood, x[(size_t)b * G + g], p[g] + m->bout[g], p[G + g] + m->bout[G + g], p2, &d0, &d1, &d2);
+      dp[g] = d0 * cx; dp[G + g] = d1 * cx; if (k == 3) dp[2 * G + g] = d2 * cx;
+    }
+  }
+  const float loss = (float)(-(llk_sum - c->beta * kl_sum) / B);
+  /* ---- backward ---- */
+  gemm_tn(dL->act, m->dP, m->gWout, B, Hd, (int)kg);
+#pragma omp parallel for schedule(static)
+  for (size_t j = 0; j < kg; ++j) { double s = 0; for (int b = 0; b < B; ++b) s += m->dP[(size_t)b * kg + j]; m->gbout[j] = (float)s; }
+  gemm_nt(m->dP, m->Wout, m->dd, B, (int)kg, Hd);
+  mlp_bwd(m, m->dec, c->n_dec, m->z, m->dd, m->dz, B);
+  const float ckl = c->beta / B;
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int d = 0; d < D; ++d) {
+      const float mu = m->lat[(size_t)b * 2 * D + d], sraw = m->lat[(size_t)b * 2 * D + D + d] + m->blat[D + d], sg = m->sig[(size_t)b * D + d], dz = m->dz[(size_t)b * D + d];
+      m->dlat[(size_t)b * 2 * D + d] = dz + ckl * mu;
+      m->dlat[(size_t)b * 2 * D + D + d] = (dz * m->eps[(size_t)b * D + d] + ckl * (sg - 1.f / sg)) * sigmoidf_(sraw + SP_INV1);
+    }
+  gemm_tn(eL->act, m->dlat, m->gWlat, B, H, 2 * D);
+  for (int j = 0; j < 2 * D; ++j) { double s = 0; for (int b = 0; b < B; ++b) s += m->dlat[(size_t)b * 2 * D + j]; m->gblat[j] = (float)s; }
+  gemm_nt(m->dlat, m->Wlat, m->dh, B, 2 * D, H);
+  mlp_bwd(m, m->enc, c->n_enc, m->h0, m->dh, NULL, B);
+  /* ---- per-tensor clipnorm + Adam ---- */
+  m->t += 1;
+  const double lr_t = c->lr * sqrt(1.0 - pow(c->b2, m->t)) / (1.0 - pow(c->b1, m->t));
+  for (int i = 0; i < m->n_tensors; ++i) {
+    double n2 = 0; const size_t n = m->tn[i]; float *g = m->tg[i], *p = m->tp[i], *mm = m->tm[i], *vv = m->tv[i];
+#pragma omp parallel for schedule(static) reduction(+ : n2)
+    for (size_t j = 0; j < n; ++j) n2 += (double)g[j] * g[j];
+    const double nrm = sqrt(n2); const float clip = (c->clipnorm > 0 && nrm > c->clipnorm) ? (float)(c->clipnorm / nrm) : 1.f;
+#pragma omp parallel for schedule(static)
+    for (size_t j = 0; j < n; ++j) {
+      const float gj = g[j] * clip;
+      mm[j] = c->b1 * mm[j] + (1.f - c->b1) * gj; vv[j] = c->b2 * vv[j] + (1.f - c->b2) * gj * gj;
+      p[j] -= (float)lr_t * mm[j] / (sqrtf(vv[j]) + c->adam_eps);
+    }
+  }
+  return loss;
+}
+
+int ost_num_tensors(void* h) { return ((ost_t*)h)->n_tensors; }
+long ost_tensor_size(void* h, int i) { return (long)((ost_t*)h)->tn[i]; }
+void ost_get_param(void* h, int i, float* out) { ost_t* m = (ost_t*)h; memcpy(out, m->tp[i], m->tn[i] * sizeof(float)); }
+void ost_get_grad(void* h, int i, float* out) { ost_t* m = (ost_t*)h; memcpy(out, m->tg[i], m->tn[i] * sizeof(float)); }
+int ost_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void ost_set_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+void ost_destroy(void* h) { free(h); /* process-lifetime buffers: the baseline runs once */ }
