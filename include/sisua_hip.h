@@ -186,8 +186,8 @@ int smx_comm_world(const smx_model* m);
 
 /* ---- measurement ---------------------------------------------------------- */
 /* HIP-event timing of one named kernel class inside eager steps, on the model's
- * stream.  kernel: "loss", "gemm_out_fwd", "gemm_out_dw", "gemm_out_dx",
- * "gemm_enc_fwd", "gemm_enc_dw", "adam", "allreduce", "step", or "null" (an event pair around
+ * stream.  kernel: "loss", "gemm_enc_fwd", "gemm_out_fwd", "gemm_out_bwd" (grouped dW + dX),
+ * "gemm_enc_dw", "bn_fwd", "bn_bwd", "adam", "allreduce", "step", or "null" (an event pair around
  * nothing: the overhead to subtract from single-kernel timings).  Enable, run steps, read. */
 int smx_timing_enable(smx_model* m, const char* kernel);
 int smx_timing_read(smx_model* m, double* total_ms, int64_t* launches);
