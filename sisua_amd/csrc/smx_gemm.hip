@@ -363,6 +363,20 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
     G.p[i] = g;
   }
   G.start[n] = total;
+  // The grouped kernel carries the register budget of its widest variant (2 workgroups per CU).  That is free
+  // while the whole group fits the chip in about one wave of workgroups; wide problems (gene panels of 20 000)
+  // run faster as separate launches with their own occupancy.
+  bool has_epi = false;
+  for (int i = 0; i < n; ++i) has_epi |= (G.p[i].epi != 0);
+  if (total > 768 && !has_epi) {
+    for (int i = 0; i < n; ++i) {
+      GemmArgs g = list[i];
+      g.tile = (G.variant[i] & 8) ? TILE_32x32_K4 : TILE_128x32;
+      int rc = launch_gemm(st, g, nullptr);
+      if (rc != SMX_OK) return rc;
+    }
+    return SMX_OK;
+  }
   hipLaunchKernelGGL(gemm_group_kernel, dim3(total), dim3(256), 0, st, G);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
