@@ -331,6 +331,14 @@ int suggest_split_k(int M, int N, int K) {
 
 static int validate_gemm(GemmArgs& g);
 
+// Products whose 128x32 tiling leaves CUs idle (fewer tiles than this) take the 32x32 K4 tile instead:
+// four times the workgroups, each with a quarter of the dependent K loop.  In isolation K4 wins up to ~256 tiles
+// (tools/gemm_sweep.py); inside the step, with cold operands, 128 and 256 measure the same.
+static int k4_tiles() {
+  static const int v = getenv("SMX_K4_TILES") ? atoi(getenv("SMX_K4_TILES")) : 128;
+  return v;
+}
+
 int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_splits) {
   if (n <= 0 || n > SMX_GROUP_MAX) { set_error("gemm group: 1..SMX_GROUP_MAX problems"); return SMX_ERR_INVALID; }
   GemmGroup G;
@@ -347,7 +355,7 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
     const int kper = g.K / g.split_k;
     int tile = g.tile;
     if (tile != TILE_128x32 && tile != TILE_32x32_K4)
-      tile = (kper >= 128 && (long)((g.M + 127) / 128) * (g.N / 32) < 128) ? TILE_32x32_K4 : TILE_128x32;
+      tile = (kper >= 128 && (long)((g.M + 127) / 128) * (g.N / 32) < k4_tiles()) ? TILE_32x32_K4 : TILE_128x32;
     const int BM = tile == TILE_128x32 ? 128 : 32, BK = tile == TILE_128x32 ? 32 : 128;
     g.k_chunk = round_up((g.K + g.split_k - 1) / g.split_k, BK);
     g.split_k = (g.K + g.k_chunk - 1) / g.k_chunk;
@@ -412,7 +420,7 @@ int launch_gemm(hipStream_t st, const GemmArgs& g_in, int* eff_split) {
     static const int xf_tile = getenv("SMX_XF_TILE") ? atoi(getenv("SMX_XF_TILE")) : 0;
     if (g.use_xform && !g.a_kmajor && xf_tile) tile = xf_tile;
     else if (g.use_xform && !g.a_kmajor) tile = TILE_32x32_K4;  // measured best for the gathered log1p operand (log is one v_log)
-    else if (kper >= 128 && (long)((g.M + 127) / 128) * (g.N / 32) < 128) tile = TILE_32x32_K4;
+    else if (kper >= 128 && (long)((g.M + 127) / 128) * (g.N / 32) < k4_tiles()) tile = TILE_32x32_K4;
     else if (g.M > 64 || g.N % 64) tile = TILE_128x32;
     else if (g.M > 32) tile = TILE_64x64;
     else tile = (g.N % 128 == 0) ? TILE_32x128 : TILE_64x64;

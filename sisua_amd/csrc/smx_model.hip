@@ -1708,6 +1708,20 @@ int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M
   // rows of C beyond M (when M was padded for k-major A) are never stored: allocate for Mp
   if (transA && Mp != M) { hipFree(dC); dC = nullptr; if ((rc = dmalloc(&dC, (size_t)S * Mp * Np))) return rc; g.C = dC; g.slab_stride = (long)Mp * Np; }
   rc = launch_gemm(nullptr, g, &eff);
+  if (rc == SMX_OK && getenv("SMX_KGEMM_REPS")) {  // diagnostic: average launch time of this shape / tile
+    const int reps = atoi(getenv("SMX_KGEMM_REPS"));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i) launch_gemm(nullptr, g, nullptr);
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < reps; ++i) launch_gemm(nullptr, g, nullptr);
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    fprintf(stderr, "k_gemm tA=%d tB=%d M=%d N=%d K=%d split=%d tile=%d: %.2f us\n", transA, transB, M, N, K, eff, tile_cfg,
+            1e3f * ms / reps);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
   if (rc == SMX_OK) {
     SMX_HIP(hipDeviceSynchronize());
     const int rowsC = transA ? Mp : M;
