@@ -169,6 +169,15 @@ int smx_decode(smx_model* m, const float* z, const float* l, int32_t batch, floa
 int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,
                      int32_t n_samples, float* mllk, float* llk_mean);
 
+/* Posterior-predictive scoring, Posterior.cal_llk (sisua/analysis/posterior.py:919-938): the cells given by
+ * row_ids / host_x are encoded once, then n_samples posterior draws are decoded and the output distribution is
+ * scored against each target matrix (host [batch, n_genes]; a NULL entry = the input cells themselves) with a
+ * running log-sum-exp over the draws on the device.  out[(t*2 + j)*batch + b] = logsumexp_s log p_j(target_t[b] |
+ * z_s) - log n_samples, j = 0 the model's output distribution ("reconstructed"), j = 1 its count distribution
+ * without the zero-inflation gate ("imputed", posterior.py:218-225; equals j = 0 for nb / nbd). n_targets <= 4. */
+int smx_score_llk(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library,
+                  const float* const* targets, int32_t n_targets, int32_t batch, int32_t n_samples, float* out);
+
 /* Test hook: inject noise for the NEXT step instead of Philox.  stream ids as in
  * oracle/sisua_oracle.py (STREAM_*); data [batch, width] holds eps values or
  * dropout multipliers.  smx_clear_noise() returns to Philox. */

@@ -606,6 +606,32 @@ def marginal_log_prob(spec: Spec, params, bn_state, x, cell_ids, n_samples: int,
   return mx + np.log(np.exp(logw - mx).sum(0)) - np.log(n_samples), np.mean(llks, 0)
 
 
+def posterior_llk(spec: Spec, params, bn_state, x, cell_ids, targets, n_samples: int, library=None):
+  """Posterior.cal_llk (sisua/analysis/posterior.py:919-938): per cell, logsumexp_s log p(target | z_s) - log S
+  with z_s ~ q(z|x) in eval mode (Philox step 0, sample s).  For every target [B,G] returns two rows: under
+  the output distribution ('reconstructed') and under its count distribution with the zero-inflation wrapper
+  removed ('imputed', posterior.py:218-225).  Result [len(targets), 2, B]."""
+  zi = spec.likelihood in ("zinb", "zinbd")
+  base = {"zinb": "nb", "zinbd": "nbd"}.get(spec.likelihood, spec.likelihood)
+  direct = spec.model == "scvi"
+  acc = [[[], []] for _ in targets]
+  for s_ in range(n_samples):
+    noise = PhiloxNoise(spec.seed, 0, cell_ids, sample=s_)
+    r = forward_backward(spec, params, bn_state, x, noise, library=library, training=False, backward=False)
+    planes = r["x_params"]
+    for t, tgt in enumerate(targets):
+      tgt = np.asarray(x if tgt is None else tgt, dtype=np.float64)
+      acc[t][0].append(count_llk(tgt, planes, spec.likelihood, direct=direct)[0].sum(1))
+      acc[t][1].append(count_llk(tgt, planes[:2], base, direct=direct)[0].sum(1) if zi else acc[t][0][-1])
+  out = np.empty((len(targets), 2, np.asarray(x).shape[0]))
+  for t in range(len(targets)):
+    for j in range(2):
+      a = np.stack(acc[t][j], 0)
+      mx = a.max(0)
+      out[t, j] = mx + np.log(np.exp(a - mx).sum(0)) - np.log(n_samples)
+  return out
+
+
 # --------------------------------------------------------------------------
 # Optimiser: per-tensor clipnorm then Adam (Keras form; frozen)
 # --------------------------------------------------------------------------

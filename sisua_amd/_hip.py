@@ -85,6 +85,7 @@ SIGNATURES = {
                               C.POINTER(_FP)]),
     "smx_decode": (C.c_int, [_VP, _FP, _FP, C.c_int32, _FP, C.POINTER(_FP)]),
     "smx_marginal_llk": (C.c_int, [_VP, _IP, _FP, _FP, C.c_int32, C.c_int32, _FP, _FP]),
+    "smx_score_llk": (C.c_int, [_VP, _IP, _FP, _FP, C.POINTER(_FP), C.c_int32, C.c_int32, C.c_int32, _FP]),
     "smx_set_noise": (C.c_int, [_VP, C.c_int32, _FP, C.c_int32, C.c_int32]),
     "smx_clear_noise": (C.c_int, [_VP]),
     "smx_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),

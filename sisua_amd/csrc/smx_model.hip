@@ -121,12 +121,12 @@ __global__ void iw_accum_kernel(IwArgs a) {
     const float l = a.l[b], e = a.leps[b], s = a.lsig[b];
     lw += -0.5f * (l - mp) * (l - mp) / vp - 0.5f * logf(vp) + 0.5f * e * e + logf(s);
   }
-  if (a.first) { a.run_max[b] = lw; a.run_sum[b] = 1.f; a.llk_sum[b] = llk; }
+  if (a.first) { a.run_max[b] = lw; a.run_sum[b] = 1.f; if (a.llk_sum) a.llk_sum[b] = llk; }
   else {
     const float mx = a.run_max[b], nm = fmaxf(mx, lw);
     a.run_sum[b] = a.run_sum[b] * expf(mx - nm) + expf(lw - nm);
     a.run_max[b] = nm;
-    a.llk_sum[b] += llk;
+    if (a.llk_sum) a.llk_sum[b] += llk;
   }
 }
 
@@ -1554,6 +1554,82 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
     hipStreamSynchronize(m->st);
   }
   hipFree(run);
+  return rc;
+}
+
+int smx_score_llk(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library,
+                  const float* const* targets, int32_t n_targets, int32_t batch, int32_t n_samples, float* out) {
+  SMX_REQUIRE(m && out && n_samples > 0 && n_targets >= 1 && n_targets <= 4, "bad arguments");
+  Pass ps;
+  SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, 0, 0));
+  const int lk = m->cfg.likelihood;
+  const bool zi = (lk == SMX_LLK_ZINB || lk == SMX_LLK_ZINBD);
+  const int n_dist = zi ? 2 : 1;
+  const size_t plane = (size_t)batch * m->Gp;
+  float *tX = nullptr, *tLg = nullptr, *run = nullptr;   // run: [n_targets][2]{max, sum}[batch]
+  int rc = SMX_OK;
+  if ((rc = dmalloc(&tX, plane * n_targets)) || (rc = dmalloc(&tLg, (size_t)batch * n_targets)) ||
+      (rc = dmalloc(&run, (size_t)n_targets * 2 * 2 * batch))) {
+    hipFree(tX); hipFree(tLg); hipFree(run);
+    return rc;
+  }
+  hipError_t e = hipMemsetAsync(tX, 0, plane * n_targets * sizeof(float), m->st);
+  std::vector<float> lg((size_t)batch);
+  for (int t = 0; t < n_targets && e == hipSuccess; ++t) {
+    const float* src = targets ? targets[t] : nullptr;
+    if (!src) continue;   // NULL target: score against the input cells themselves
+    e = hipMemcpy2DAsync(tX + plane * t, (size_t)m->Gp * sizeof(float), src, (size_t)m->G * sizeof(float),
+                         (size_t)m->G * sizeof(float), (size_t)batch, hipMemcpyHostToDevice, m->st);
+    for (int i = 0; i < batch; ++i) {
+      double acc = 0.0;
+      for (int g = 0; g < m->G; ++g) { const float v = src[(size_t)i * m->G + g]; if (v > 0.f) acc += lgamma((double)v + 1.0); }
+      lg[(size_t)i] = (float)acc;
+    }
+    if (e == hipSuccess) e = hipMemcpy(tLg + (size_t)batch * t, lg.data(), lg.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) { set_error(std::string("score_llk upload failed: ") + hipGetErrorString(e)); rc = SMX_ERR_HIP; }
+  for (int s = 0; s < n_samples && rc == SMX_OK; ++s) {
+    ps.sample = s;
+    rc = forward_pass(m, ps, false, false, s == 0 ? 0 : 2);
+    for (int t = 0; t < n_targets && rc == SMX_OK; ++t) {
+      const bool own = !(targets && targets[t]);
+      for (int j = 0; j < n_dist && rc == SMX_OK; ++j) {
+        LossArgs lo;
+        // j == 1: the count distribution under the zero-inflation wrapper (first two planes, no gate)
+        lo.likelihood = (j == 0) ? lk : (lk == SMX_LLK_ZINB ? SMX_LLK_NB : SMX_LLK_NBD);
+        lo.direct = m->scvi; lo.backward = 0;
+        lo.X = own ? ps.Xsrc : tX + plane * t; lo.ldx = m->Gp; lo.rows = own ? ps.rows : nullptr;
+        lo.P = m->P; lo.ldp = (long)m->k * m->Gp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
+        lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = 0.f;
+        rc = launch_count_loss(m->st, lo);
+        if (rc != SMX_OK) break;
+        IwArgs a;
+        memset(&a, 0, sizeof(a));
+        a.llk_part = m->llk_part; a.n_chunks = loss_chunks(m->Gp);
+        a.lgx1 = own ? ps.lgx1 : tLg + (size_t)batch * t; a.rows = own ? ps.rows : nullptr;
+        a.D = m->D; a.Dp = m->Dp; a.stochastic = 0; a.l = nullptr;
+        float* r = run + ((size_t)t * 2 + j) * 2 * batch;
+        a.run_max = r; a.run_sum = r + batch; a.llk_sum = nullptr; a.B = batch; a.first = (s == 0);
+        hipLaunchKernelGGL(iw_accum_kernel, dim3((batch + 127) / 128), dim3(128), 0, m->st, a);
+      }
+    }
+  }
+  if (rc == SMX_OK) {
+    std::vector<float> h((size_t)n_targets * 2 * 2 * batch);
+    e = hipMemcpyAsync(h.data(), run, h.size() * sizeof(float), hipMemcpyDeviceToHost, m->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->st);
+    if (e != hipSuccess) { set_error(std::string("score_llk readback failed: ") + hipGetErrorString(e)); rc = SMX_ERR_HIP; }
+    else
+      for (int t = 0; t < n_targets; ++t)
+        for (int j = 0; j < 2; ++j) {
+          const float* r = h.data() + ((size_t)t * 2 + (j < n_dist ? j : 0)) * 2 * batch;
+          for (int b = 0; b < batch; ++b)
+            out[((size_t)t * 2 + j) * batch + b] = r[b] + logf(r[batch + b]) - logf((float)n_samples);
+        }
+  } else {
+    hipStreamSynchronize(m->st);
+  }
+  hipFree(tX); hipFree(tLg); hipFree(run);
   return rc;
 }
 

@@ -242,6 +242,24 @@ class Engine:
     check(self.lib.smx_marginal_llk(self._h, idp, xp, lp, B, int(n_samples), _fp(mllk), _fp(llk)))
     return mllk, llk
 
+  def score_llk(self, targets, row_ids=None, x=None, library=None, n_samples: int = 10):
+    """Posterior-predictive log-likelihood per cell (Posterior.cal_llk, posterior.py:919-938), on the GPU.
+    `targets`: list of [B, G] matrices (None = the input cells).  Returns [len(targets), 2, B]:
+    [:, 0] under the output distribution, [:, 1] under its count distribution without zero inflation."""
+    if row_ids is not None:
+      ids = self._ids(row_ids)
+      B, idp, xp, lp = ids.size, ids.ctypes.data_as(C.POINTER(C.c_int32)), None, None
+    else:
+      xa = _f32(x)
+      B, idp, xp = xa.shape[0], None, _fp(xa)
+      la = None if library is None else _f32(library, (B, 2))
+      lp = _fp(la)
+    keep = [None if t is None else _f32(t, (B, self.cfg.n_genes)) for t in targets]
+    arr = (C.POINTER(C.c_float) * len(keep))(*[_fp(t) if t is not None else C.POINTER(C.c_float)() for t in keep])
+    out = np.empty((len(keep), 2, B), np.float32)
+    check(self.lib.smx_score_llk(self._h, idp, xp, lp, arr, len(keep), B, int(n_samples), _fp(out)))
+    return out
+
   # ---- noise injection (parity tests) ----------------------------------------------
   def set_noise(self, stream: int, data):
     a = _f32(data)

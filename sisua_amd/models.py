@@ -447,6 +447,29 @@ class SingleCellModel:
       llk.append(b)
     return np.concatenate(mllk), {self._outputs[0].name or "transcriptomic": np.concatenate(llk)}
 
+  def posterior_llk(self, corrupted, original=None, library=None, sample_shape=10, batch_size=128):
+    r"""The four scores of `Posterior.cal_llk` (analysis/posterior.py:919-938) on the GPU
+    (`smx_score_llk`): cells are encoded from `corrupted`, `sample_shape` posterior draws are decoded, and
+    the 'reconstructed' (output distribution) and 'imputed' (count distribution without zero inflation)
+    likelihoods of the original and of the corrupted counts are reduced as
+    mean_cells(logsumexp_draws - log n_draws).  Returns the dict with the reference's keys."""
+    x_cor = np.ascontiguousarray(_flatten(corrupted)[0], dtype=np.float32)
+    x_org = x_cor if original is None else np.ascontiguousarray(_flatten(original)[0], dtype=np.float32)
+    S = int(np.prod(sample_shape)) if np.size(sample_shape) else 1
+    if self._cfg.model == "scvi" and library is None:
+      library = library_matrix(x_cor)
+    e = self._ensure_engine(min(int(batch_size), x_cor.shape[0]))
+    B = min(e.max_batch, x_cor.shape[0])
+    parts = []
+    for s0 in range(0, x_cor.shape[0], B):
+      sl = slice(s0, s0 + B)
+      parts.append(e.score_llk([x_org[sl], None], x=x_cor[sl], library=None if library is None else library[sl],
+                               n_samples=S))
+    sc = np.concatenate(parts, axis=2).mean(axis=2)   # [target, dist]
+    name = self._outputs[0].name or "transcriptomic"
+    return {f"llk_{name}_imp_org": float(sc[0, 1]), f"llk_{name}_imp_cor": float(sc[1, 1]),
+            f"llk_{name}_rec_cor": float(sc[1, 0]), f"llk_{name}_rec_org": float(sc[0, 0])}
+
   # ---- evaluation hand-off -----------------------------------------------------------------------
   def create_posterior(self, test_sco: SingleCellOMIC = None, **kwargs):
     r"""The reference builds `sisua.analysis.Posterior(scm=self, sco=test, ...)`

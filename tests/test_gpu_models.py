@@ -97,6 +97,9 @@ def test_fit_predict(api, name):
   mllk, llk = model.marginal_log_prob(inputs=test.numpy()[:16], sample_shape=8)
   assert mllk.shape == (16,) and np.isfinite(mllk).all() and "transcriptomic" in llk
   assert (mllk >= llk["transcriptomic"] - 50).all()
+  sc = model.posterior_llk(test.numpy()[:16], original=test.numpy()[:16] + 1.0, sample_shape=4)
+  assert set(sc) == {f"llk_transcriptomic_{a}_{b}" for a in ("imp", "rec") for b in ("org", "cor")}
+  assert all(np.isfinite(v) for v in sc.values())
 
 
 def test_save_load_roundtrip(api, tmp_path):

@@ -309,3 +309,31 @@ def test_marginal_llk_matches_oracle(Engine, name):
   one, _ = e.marginal_llk(row_ids=rows, n_samples=1)
   assert np.isfinite(one).all()
   e.close()
+
+
+@pytest.mark.parametrize("name", ["vae_zinb", "vae_nbd", "vae_zinbd", "scvi_zinbd", "scvi_nbd", "dca_zinb"])
+def test_score_llk_matches_oracle(Engine, name):
+  """Posterior.cal_llk (posterior.py:919-938) -- reconstructed / imputed likelihood of the
+  original and the corrupted counts, log-mean-exp over posterior draws, GPU vs oracle."""
+  spec, cfg, x, ys, lib, mask = _problem(dict(CASES[name], labels=()))
+  params = perturbed_params(spec)
+  bn = so.init_bn_state(spec)
+  e = Engine(cfg, max_batch=64, init=False)
+  e.set_params(params)
+  x_cor = so.corrupt_binomial(x, 0.3, 0.2, seed=3).astype(np.float32)
+  e.upload(x_cor, ys, lib, mask, cell_id_base=500)
+  rows = np.arange(10, 60, dtype=np.int32)
+  S = 6
+  ref = so.posterior_llk(spec, params, bn, x_cor[rows], rows + 500, [x[rows], None], S, library=lib[rows])
+  got = e.score_llk([x[rows], None], row_ids=rows, n_samples=S)
+  assert got.shape == ref.shape == (2, 2, len(rows))
+  assert np.allclose(got, ref, rtol=RTOL, atol=1e-3), np.abs(got - ref).max()
+  if spec.likelihood in ("nb", "nbd"):
+    assert np.array_equal(got[:, 0], got[:, 1])
+  else:   # dropping the zero-inflation gate changes the score
+    assert np.abs(got[:, 0] - got[:, 1]).max() > 1e-3
+  # host-batch entry: cell ids = position in the batch
+  ref2 = so.posterior_llk(spec, params, bn, x_cor[rows], np.arange(len(rows)), [x[rows]], S, library=lib[rows])
+  got2 = e.score_llk([x[rows]], x=x_cor[rows], library=lib[rows], n_samples=S)
+  assert np.allclose(got2, ref2, rtol=RTOL, atol=1e-3)
+  e.close()

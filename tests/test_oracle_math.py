@@ -179,3 +179,28 @@ def test_data_side_semantics():
   assert not so.label_mask(50, 0.1, n_omics=1).any()
   m = so.label_mask(5000, 0.1, n_omics=2)
   assert abs(m.mean() - 0.1) < 0.02
+
+
+def test_posterior_llk_against_scipy_nbinom():
+  """posterior_llk (Posterior.cal_llk, posterior.py:919-938): the 'imputed' score must equal the plain NB
+  log-pmf of the target under the decoded parameters (scipy, independent code), log-mean-exp over draws."""
+  from scipy import stats
+  from scipy.special import logsumexp
+  spec = so.Spec(model="vae", n_genes=40, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=4, seed=5)
+  params = so.init_params(spec)
+  bn = so.init_bn_state(spec)
+  rng = np.random.default_rng(0)
+  x = rng.poisson(1.0, (9, 40)).astype(np.float64)
+  tgt = rng.poisson(1.5, (9, 40)).astype(np.float64)
+  ids = np.arange(9) + 100
+  S = 5
+  got = so.posterior_llk(spec, params, bn, x, ids, [tgt, None], S)
+  per_draw = []
+  for s_ in range(S):
+    r = so.forward_backward(spec, params, bn, x, so.PhiloxNoise(spec.seed, 0, ids, sample=s_), training=False,
+                            backward=False)
+    a, l = r["x_params"][0], r["x_params"][1]   # total_count = exp(a), logits l: p_success = sigmoid(l)
+    per_draw.append(stats.nbinom.logpmf(tgt, np.exp(a), 1.0 - 1.0 / (1.0 + np.exp(-l))).sum(1))
+  ref = logsumexp(np.stack(per_draw), axis=0) - np.log(S)
+  assert np.allclose(got[0, 1], ref, rtol=1e-9, atol=1e-9)
+  assert got.shape == (2, 2, 9) and (got[:, 0] != got[:, 1]).any()
