@@ -125,6 +125,26 @@ int smx_dataset_upload(smx_model* m, const float* X, int64_t n_cells, const floa
                        const float* library, const uint8_t* label_mask, int64_t cell_id_base);
 int64_t smx_dataset_size(const smx_model* m);
 
+/* Library-size statistics of the RESIDENT matrix, get_library_size (sisua/data/utils.py:231-263) as the
+ * reference recomputes them after corrupt() (sisua/data/_single_cell_analysis.py:110): log_counts = log(sum_g x
+ * + 1e-8) per cell, local_mean / local_var over cells.  Fills the resident [n_cells, 2] library prior with
+ * (local_mean, local_var) and returns them in stats[0..1] (stats may be NULL). */
+int smx_dataset_library(smx_model* m, float stats[2]);
+
+/* apply_artificial_corruption(distribution='binomial') (sisua/data/utils.py:168-228; SingleCellOMIC.corrupt,
+ * _single_cell_analysis.py:78-111) IN PLACE on the resident matrix: exactly floor(dropout * nnz) of the non-zero
+ * entries, chosen without replacement, become Binomial(n = x, p = retain_rate).  The draws come from the Philox
+ * counter RNG keyed by (seed, cell id, gene), not from NumPy's MT19937 stream: same law, order independent,
+ * bit-identical to oracle/sisua_oracle.py:corrupt_philox (the host path sisua_amd.data.corrupt keeps the
+ * reference's RandomState stream bit-exactly).  Refreshes the per-row likelihood constants; call
+ * smx_dataset_library afterwards as the reference does.  Same argument checks as the reference: dropout in
+ * [0, 1); no-op unless 0 < dropout < 1 or 0 < retain_rate < 1. */
+int smx_dataset_corrupt(smx_model* m, double dropout, double retain_rate, uint64_t seed, int64_t* n_corrupted);
+
+/* Read back rows of the resident matrix (tests / checkpoints): X [n_rows, n_genes], the per-row constant
+ * sum_g lgamma(x+1) [n_rows], the library prior [n_rows, 2]; any output may be NULL. */
+int smx_dataset_read(smx_model* m, int64_t row0, int64_t n_rows, float* X, float* row_const, float* library);
+
 /* ---- the hot path -------------------------------------------------------- */
 /* One optimiser step on the cells `row_ids` of the resident matrix: forward,
  * ELBO, backward, (all-reduce), per-tensor clipnorm, Adam.  Replaces one

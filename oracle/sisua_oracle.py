@@ -698,6 +698,49 @@ def corrupt_binomial(x: np.ndarray, dropout: float = 0.2, retain_rate: float = 0
   return x
 
 
+STREAM_CORRUPT_SELECT = 80
+STREAM_CORRUPT_BINOMIAL = 81
+
+
+def corrupt_philox(x: np.ndarray, dropout: float, retain_rate: float, seed: int, cell_ids):
+  """Counter-RNG form of the 'binomial' branch of apply_artificial_corruption (sisua/data/utils.py:168-228)
+  for a matrix that lives on the device.  Same semantics -- exactly floor(dropout * nnz) of the
+  non-zero entries, chosen without replacement, are replaced by Binomial(n = x_ij, p = retain_rate) -- but the
+  draws come from Philox, so the result does not depend on traversal order (the reference's MT19937
+  `choice`/`binomial` stream is inherently sequential; `corrupt_binomial` above restates that one bit-exactly):
+    * entry (i, j) has the 64-bit key (w0 << 32 | w1) of philox(counter = (j, cell_id_i, 0, SELECT));
+      the floor(dropout * nnz) smallest keys are selected (ties: every entry with key <= threshold);
+    * trial t of a selected entry succeeds iff word (t % 4) of
+      philox(counter = (j, cell_id_i, 0, BINOMIAL | (t // 4) << 8)) < floor(retain_rate * 2^32).
+  Returns a corrupted copy and the number of corrupted entries."""
+  x = np.array(x, copy=True)
+  if not (0.0 < dropout < 1.0 or 0.0 < retain_rate < 1.0):
+    return x, 0
+  cell_ids = np.asarray(cell_ids, dtype=np.uint64)
+  i, j = np.nonzero(x)
+  n_sel = int(np.floor(dropout * len(i)))
+  if n_sel == 0:
+    return x, 0
+  k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+  w = philox4x32_10(j.astype(np.uint64), cell_ids[i], np.uint64(0), np.uint64(STREAM_CORRUPT_SELECT), k0, k1)
+  key = (w[0].astype(np.uint64) << np.uint64(32)) | w[1].astype(np.uint64)
+  thr_key = np.partition(key, n_sel - 1)[n_sel - 1]
+  sel = key <= thr_key
+  i, j = i[sel], j[sel]
+  n = x[i, j].astype(np.int64)
+  thr = np.uint64(int(np.floor(float(retain_rate) * 2.0 ** 32)))
+  got = np.zeros(len(n), dtype=np.int64)
+  for blk in range(int((n.max() + 3) // 4)):
+    live = n > 4 * blk
+    c3 = np.uint64(STREAM_CORRUPT_BINOMIAL | (blk << 8))
+    ww = philox4x32_10(j[live].astype(np.uint64), cell_ids[i[live]], np.uint64(0), c3, k0, k1)
+    for q in range(4):
+      ok = (ww[q].astype(np.uint64) < thr) & (n[live] > 4 * blk + q)
+      got[live] += ok
+  x[i, j] = got.astype(x.dtype)
+  return x, int(sel.sum())
+
+
 def library_size(x: np.ndarray):
   """get_library_size, sisua/data/utils.py:231-263 -> (log_counts[N], mean, var)."""
   total = x.sum(axis=1)

@@ -84,6 +84,9 @@ SIGNATURES = {
     "smx_forward": (C.c_int, [_VP, _IP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP,
                               C.POINTER(_FP)]),
     "smx_decode": (C.c_int, [_VP, _FP, _FP, C.c_int32, _FP, C.POINTER(_FP)]),
+    "smx_dataset_library": (C.c_int, [_VP, _FP]),
+    "smx_dataset_corrupt": (C.c_int, [_VP, C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_int64)]),
+    "smx_dataset_read": (C.c_int, [_VP, C.c_int64, C.c_int64, _FP, _FP, _FP]),
     "smx_marginal_llk": (C.c_int, [_VP, _IP, _FP, _FP, C.c_int32, C.c_int32, _FP, _FP]),
     "smx_score_llk": (C.c_int, [_VP, _IP, _FP, _FP, C.POINTER(_FP), C.c_int32, C.c_int32, C.c_int32, _FP]),
     "smx_set_noise": (C.c_int, [_VP, C.c_int32, _FP, C.c_int32, C.c_int32]),

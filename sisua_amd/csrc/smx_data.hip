@@ -1,0 +1,166 @@
+// smx_data.hip -- kernels over the HBM-resident cells x genes matrix: per-row constants
+// and library-size statistics (get_library_size, sisua/data/utils.py:231-263), and the 'binomial'
+// artificial corruption (apply_artificial_corruption, sisua/data/utils.py:168-228) with the counter RNG.
+//
+// All of it is once-per-dataset streaming work: one pass over X per launch, a wave per row (stats) or a
+// workgroup-strided sweep (corruption); nothing here is on the per-step path.
+#include "smx_internal.h"
+#include "../../include/sisua_hip.h"
+
+namespace smx {
+
+__device__ inline double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// One wave per row.  lgx1[row] = sum_g lgamma(x+1) (the likelihood's data-only constant);
+// logcount[row] = log(float(sum_g x) + 1e-8) in fp32 as NumPy evaluates it on the float32 matrix.
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ X, long ld, long N, int G,
+                                                        float* __restrict__ lgx1, double* __restrict__ logcount) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int lane = threadIdx.x & 63;
+  const float* r = X + row * ld;
+  double tot = 0.0, lg = 0.0;
+  for (int g = lane * 4; g < G; g += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(r + g);   // ld is padded to 32 columns of zeros
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (g + q < G) {
+        tot += (double)e[q];
+        if (e[q] > 0.f) lg += lgamma((double)e[q] + 1.0);
+      }
+  }
+  tot = wave_sum_f64(tot);
+  lg = wave_sum_f64(lg);
+  if (lane == 0) {
+    lgx1[row] = (float)lg;
+    if (logcount) logcount[row] = (double)logf((float)tot + 1e-8f);
+  }
+}
+
+// mean and (population) variance of logcount[0..N): one workgroup, two passes, fp64
+__global__ __launch_bounds__(1024) void library_moments_kernel(const double* __restrict__ logcount, long N,
+                                                               double* __restrict__ stats) {
+  __shared__ double sh[16];
+  __shared__ double mean_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  double s = 0.0;
+  for (long i = tid; i < N; i += 1024) s += logcount[i];
+  s = wave_sum_f64(s);
+  if (lane == 0) sh[w] = s;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    mean_s = t / (double)N;
+  }
+  __syncthreads();
+  const double mean = mean_s;
+  double v = 0.0;
+  for (long i = tid; i < N; i += 1024) { const double d = logcount[i] - mean; v += d * d; }
+  v = wave_sum_f64(v);
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    stats[0] = mean;
+    stats[1] = t / (double)N;
+  }
+}
+
+__global__ void library_fill_kernel(float* __restrict__ library, long N, const double* __restrict__ stats) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { library[2 * i] = (float)stats[0]; library[2 * i + 1] = (float)stats[1]; }
+}
+
+int launch_row_stats(hipStream_t st, const float* X, long ld, long N, int G, float* lgx1, double* logcount) {
+  hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, X, ld, N, G, lgx1, logcount);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+int launch_library_stats(hipStream_t st, const double* logcount, long N, double* stats, float* library) {
+  hipLaunchKernelGGL(library_moments_kernel, dim3(1), dim3(1024), 0, st, logcount, N, stats);
+  if (library)
+    hipLaunchKernelGGL(library_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, library, N, stats);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Corruption.  Entry (row, gene) with x > 0 carries the 64-bit key (w0 << 32 | w1) of
+// philox(counter = (gene, cell_id, 0, SELECT)); the floor(dropout * nnz) smallest keys are corrupted.
+// The threshold key is found by an 8-pass radix select (one 256-bin histogram of the next byte per pass).
+// ---------------------------------------------------------------------------
+__device__ inline uint64_t corrupt_key(uint32_t k0, uint32_t k1, uint32_t cell, uint32_t gene) {
+  const U4 w = philox4x32_10(gene, cell, 0u, (uint32_t)ST_CORRUPT_SELECT, k0, k1);
+  return ((uint64_t)w.x << 32) | (uint64_t)w.y;
+}
+
+__global__ __launch_bounds__(256) void corrupt_hist_kernel(CorruptArgs a, int pass) {
+  __shared__ unsigned int h[256];
+  h[threadIdx.x] = 0u;
+  __syncthreads();
+  const int shift = 56 - 8 * pass;
+  for (long row = blockIdx.x; row < a.N; row += gridDim.x) {
+    const float* r = a.X + row * a.ld;
+    const uint32_t cell = a.cell_base + (uint32_t)row;
+    for (int g = threadIdx.x; g < a.G; g += 256) {
+      if (!(r[g] > 0.f)) continue;
+      const uint64_t key = corrupt_key(a.k0, a.k1, cell, (uint32_t)g);
+      if (pass > 0 && (key >> (shift + 8)) != (a.prefix >> (shift + 8))) continue;
+      atomicAdd(&h[(unsigned)((key >> shift) & 0xFFu)], 1u);
+    }
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&a.hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+// x <- Binomial(n = x, p): trial t succeeds iff word (t % 4) of
+// philox(counter = (gene, cell_id, 0, BINOMIAL | (t / 4) << 8)) < thr_binom (= floor(p * 2^32)).
+__global__ __launch_bounds__(256) void corrupt_apply_kernel(CorruptArgs a) {
+  unsigned long long mine = 0ull;
+  for (long row = blockIdx.x; row < a.N; row += gridDim.x) {
+    float* r = a.X + row * a.ld;
+    const uint32_t cell = a.cell_base + (uint32_t)row;
+    for (int g = threadIdx.x; g < a.G; g += 256) {
+      const float x = r[g];
+      if (!(x > 0.f)) continue;
+      if (corrupt_key(a.k0, a.k1, cell, (uint32_t)g) > a.prefix) continue;
+      const long n = (long)x;
+      long got = 0;
+      for (long blk = 0; 4 * blk < n; ++blk) {
+        const U4 w = philox4x32_10((uint32_t)g, cell, 0u, (uint32_t)ST_CORRUPT_BINOMIAL | ((uint32_t)blk << 8), a.k0, a.k1);
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * blk + q < n && (uint64_t)ww[q] < a.thr_binom) ++got;
+      }
+      r[g] = (float)got;
+      ++mine;
+    }
+  }
+  if (mine) atomicAdd(a.hist, mine);
+}
+
+int launch_corrupt_hist(hipStream_t st, const CorruptArgs& a, int pass) {
+  const unsigned blocks = (unsigned)(a.N < 4096 ? a.N : 4096);
+  hipLaunchKernelGGL(corrupt_hist_kernel, dim3(blocks), dim3(256), 0, st, a, pass);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+int launch_corrupt_apply(hipStream_t st, const CorruptArgs& a) {
+  const unsigned blocks = (unsigned)(a.N < 4096 ? a.N : 4096);
+  hipLaunchKernelGGL(corrupt_apply_kernel, dim3(blocks), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+}  // namespace smx

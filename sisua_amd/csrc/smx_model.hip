@@ -1355,14 +1355,8 @@ int smx_dataset_upload(smx_model* m, const float* X, int64_t n_cells, const floa
   if ((rc = dmalloc(&m->X, (size_t)n_cells * m->Gp)) || (rc = dmalloc(&m->lgx1, (size_t)n_cells))) return rc;
   SMX_HIP(hipMemcpy2D(m->X, (size_t)m->Gp * sizeof(float), X, (size_t)m->G * sizeof(float), (size_t)m->G * sizeof(float),
                       (size_t)n_cells, hipMemcpyHostToDevice));
-  std::vector<float> lg((size_t)n_cells);
-  for (int64_t i = 0; i < n_cells; ++i) {
-    double s = 0.0;
-    const float* row = X + (size_t)i * m->G;
-    for (int g = 0; g < m->G; ++g) if (row[g] > 0.f) s += lgamma((double)row[g] + 1.0);
-    lg[(size_t)i] = (float)s;
-  }
-  SMX_HIP(hipMemcpy(m->lgx1, lg.data(), lg.size() * sizeof(float), hipMemcpyHostToDevice));
+  // per-row constant sum_g lgamma(x+1) of the likelihood, on the device (one wave per row)
+  SMX_CHECK(launch_row_stats(m->st, m->X, m->Gp, m->N, m->G, m->lgx1, nullptr));
   for (int j = 0; j < m->cfg.n_labels; ++j) {
     const int P = m->cfg.label_dim[j], Pp = m->lab_Pp[j];
     if ((rc = dmalloc(&m->Y[j], (size_t)n_cells * Pp))) return rc;
@@ -1381,6 +1375,96 @@ int smx_dataset_upload(smx_model* m, const float* X, int64_t n_cells, const floa
 }
 
 int64_t smx_dataset_size(const smx_model* m) { return m ? m->N : 0; }
+
+int smx_dataset_library(smx_model* m, float stats[2]) {
+  SMX_REQUIRE(m && m->X && m->N > 0, "no resident dataset");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  double* work = nullptr;   // [N] log counts + [2] moments
+  int rc;
+  if ((rc = dmalloc(&work, (size_t)m->N + 2))) return rc;
+  if (!m->library && (rc = dmalloc(&m->library, (size_t)m->N * 2))) { hipFree(work); return rc; }
+  drop_graphs(m);   // a captured step may hold the old (null) library pointer
+  rc = launch_row_stats(m->st, m->X, m->Gp, m->N, m->G, m->lgx1, work);
+  if (rc == SMX_OK) rc = launch_library_stats(m->st, work, m->N, work + m->N, m->library);
+  double h[2] = {0.0, 0.0};
+  if (rc == SMX_OK) {
+    hipError_t e = hipMemcpyAsync(h, work + m->N, sizeof(h), hipMemcpyDeviceToHost, m->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->st);
+    if (e != hipSuccess) { set_error(std::string("dataset_library failed: ") + hipGetErrorString(e)); rc = SMX_ERR_HIP; }
+  }
+  hipFree(work);
+  if (rc == SMX_OK && stats) { stats[0] = (float)h[0]; stats[1] = (float)h[1]; }
+  return rc;
+}
+
+int smx_dataset_corrupt(smx_model* m, double dropout, double retain_rate, uint64_t seed, int64_t* n_corrupted) {
+  SMX_REQUIRE(m && m->X && m->N > 0, "no resident dataset");
+  SMX_REQUIRE(dropout >= 0.0 && dropout < 1.0, "dropout value must be >= 0 and < 1");   // utils.py:184-185
+  SMX_REQUIRE(retain_rate >= 0.0 && retain_rate <= 1.0, "retain_rate must be in [0, 1]");
+  if (n_corrupted) *n_corrupted = 0;
+  if (!((dropout > 0.0 && dropout < 1.0) || (retain_rate > 0.0 && retain_rate < 1.0))) return SMX_OK;   // utils.py:188-189
+  SMX_HIP(hipStreamSynchronize(m->st));
+  unsigned long long* hist = nullptr;
+  int rc;
+  if ((rc = dmalloc(&hist, 256))) return rc;
+  CorruptArgs a;
+  a.X = m->X; a.ld = m->Gp; a.N = m->N; a.G = m->G;
+  a.k0 = (uint32_t)(seed & 0xFFFFFFFFu); a.k1 = (uint32_t)(seed >> 32); a.cell_base = (uint32_t)m->cell_base;
+  a.hist = hist;
+  a.thr_binom = (uint64_t)floor(retain_rate * 4294967296.0);
+  unsigned long long h[256];
+  unsigned long long rank = 0;   // 1-based rank of the threshold key among the keys that share the prefix
+  bool nothing = false;
+  for (int pass = 0; pass < 8 && rc == SMX_OK && !nothing; ++pass) {
+    hipError_t e = hipMemsetAsync(hist, 0, sizeof(h), m->st);
+    if (e == hipSuccess) rc = launch_corrupt_hist(m->st, a, pass);
+    if (rc == SMX_OK && e == hipSuccess) e = hipMemcpyAsync(h, hist, sizeof(h), hipMemcpyDeviceToHost, m->st);
+    if (rc == SMX_OK && e == hipSuccess) e = hipStreamSynchronize(m->st);
+    if (e != hipSuccess) { set_error(std::string("dataset_corrupt failed: ") + hipGetErrorString(e)); rc = SMX_ERR_HIP; }
+    if (rc != SMX_OK) break;
+    if (pass == 0) {
+      unsigned long long nnz = 0;
+      for (int d = 0; d < 256; ++d) nnz += h[d];
+      rank = (unsigned long long)floor(dropout * (double)nnz);   // int(np.floor(dropout * len(i))), utils.py:213-215
+      if (rank == 0) { nothing = true; break; }
+    }
+    unsigned long long cum = 0;
+    int digit = 255;
+    for (int d = 0; d < 256; ++d) {
+      if (cum + h[d] >= rank) { digit = d; break; }
+      cum += h[d];
+    }
+    rank -= cum;
+    a.prefix |= (uint64_t)digit << (56 - 8 * pass);
+  }
+  if (rc == SMX_OK && !nothing) {
+    hipError_t e = hipMemsetAsync(hist, 0, sizeof(unsigned long long), m->st);
+    if (e == hipSuccess) rc = launch_corrupt_apply(m->st, a);
+    // the per-row constant sum lgamma(x+1) follows the matrix
+    if (rc == SMX_OK) rc = launch_row_stats(m->st, m->X, m->Gp, m->N, m->G, m->lgx1, nullptr);
+    if (rc == SMX_OK && e == hipSuccess) e = hipMemcpyAsync(h, hist, sizeof(unsigned long long), hipMemcpyDeviceToHost, m->st);
+    if (rc == SMX_OK && e == hipSuccess) e = hipStreamSynchronize(m->st);
+    if (e != hipSuccess) { set_error(std::string("dataset_corrupt failed: ") + hipGetErrorString(e)); rc = SMX_ERR_HIP; }
+    if (rc == SMX_OK && n_corrupted) *n_corrupted = (int64_t)h[0];
+  }
+  hipFree(hist);
+  return rc;
+}
+
+int smx_dataset_read(smx_model* m, int64_t row0, int64_t n_rows, float* X, float* row_const, float* library) {
+  SMX_REQUIRE(m && m->X, "no resident dataset");
+  SMX_REQUIRE(row0 >= 0 && n_rows > 0 && row0 + n_rows <= m->N, "rows out of range");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  if (X)
+    SMX_HIP(hipMemcpy2D(X, (size_t)m->G * sizeof(float), m->X + (size_t)row0 * m->Gp, (size_t)m->Gp * sizeof(float),
+                        (size_t)m->G * sizeof(float), (size_t)n_rows, hipMemcpyDeviceToHost));
+  if (row_const) SMX_HIP(hipMemcpy(row_const, m->lgx1 + row0, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToHost));
+  if (library) {
+    SMX_REQUIRE(m->library, "no library prior resident");
+    SMX_HIP(hipMemcpy(library, m->library + 2 * row0, (size_t)n_rows * 2 * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  return SMX_OK;
+}
 
 int smx_train_step(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out) {
   return smx_train_steps(m, row_ids, 1, batch, 0, out);
@@ -1415,13 +1499,7 @@ static int setup_pass(smx_model* m, Pass& ps, const int32_t* row_ids, const floa
     SMX_HIP(hipMemsetAsync(m->hostX, 0, (size_t)batch * m->Gp * sizeof(float), m->st));
     SMX_HIP(hipMemcpy2DAsync(m->hostX, (size_t)m->Gp * sizeof(float), host_x, (size_t)m->G * sizeof(float),
                              (size_t)m->G * sizeof(float), (size_t)batch, hipMemcpyHostToDevice, m->st));
-    std::vector<float> lg((size_t)batch);
-    for (int i = 0; i < batch; ++i) {
-      double s = 0.0;
-      for (int g = 0; g < m->G; ++g) { const float v = host_x[(size_t)i * m->G + g]; if (v > 0.f) s += lgamma((double)v + 1.0); }
-      lg[(size_t)i] = (float)s;
-    }
-    SMX_HIP(hipMemcpy(m->hostLgx1, lg.data(), lg.size() * sizeof(float), hipMemcpyHostToDevice));
+    SMX_CHECK(launch_row_stats(m->st, m->hostX, m->Gp, batch, m->G, m->hostLgx1, nullptr));
     if (host_library) SMX_HIP(hipMemcpy(m->hostLib, host_library, (size_t)batch * 2 * sizeof(float), hipMemcpyHostToDevice));
     ps.rows = nullptr; ps.Xsrc = m->hostX; ps.lib = m->hostLib; ps.lgx1 = m->hostLgx1; ps.cell_base = 0;
   }

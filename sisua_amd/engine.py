@@ -242,6 +242,30 @@ class Engine:
     check(self.lib.smx_marginal_llk(self._h, idp, xp, lp, B, int(n_samples), _fp(mllk), _fp(llk)))
     return mllk, llk
 
+  # ---- resident-matrix preprocessing ---------------------------------------
+  def dataset_library(self):
+    """get_library_size (data/utils.py:231-263) over the resident matrix on the GPU; fills the resident
+    library prior and returns (local_mean, local_var)."""
+    st = np.zeros(2, np.float32)
+    check(self.lib.smx_dataset_library(self._h, _fp(st)))
+    return float(st[0]), float(st[1])
+
+  def dataset_corrupt(self, dropout_rate: float = 0.2, retain_rate: float = 0.2, seed: int = 8) -> int:
+    """'binomial' artificial corruption (data/utils.py:168-228) in place on the resident matrix with the
+    counter RNG (oracle: corrupt_philox).  Returns the number of corrupted entries."""
+    n = C.c_int64(0)
+    check(self.lib.smx_dataset_corrupt(self._h, float(dropout_rate), float(retain_rate), int(seed), C.byref(n)))
+    return int(n.value)
+
+  def dataset_read(self, row0: int = 0, n_rows: int = None, library: bool = False):
+    """Rows of the resident matrix, their constants sum_g lgamma(x+1), and optionally the library prior."""
+    n = int(self.lib.smx_dataset_size(self._h)) - int(row0) if n_rows is None else int(n_rows)
+    X = np.empty((n, self.cfg.n_genes), np.float32)
+    rc = np.empty(n, np.float32)
+    lb = np.empty((n, 2), np.float32) if library else None
+    check(self.lib.smx_dataset_read(self._h, int(row0), n, _fp(X), _fp(rc), _fp(lb) if library else None))
+    return (X, rc, lb) if library else (X, rc)
+
   def score_llk(self, targets, row_ids=None, x=None, library=None, n_samples: int = 10):
     """Posterior-predictive log-likelihood per cell (Posterior.cal_llk, posterior.py:919-938), on the GPU.
     `targets`: list of [B, G] matrices (None = the input cells).  Returns [len(targets), 2, B]:

@@ -1,0 +1,103 @@
+"""preprocessing of the HBM-resident matrix on the GPU (library statistics, artificial
+corruption) against the oracle; all calls go through the C-ABI."""
+import numpy as np
+import pytest
+
+from oracle import sisua_oracle as so
+from tests.util import make_pair, synth_counts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine():
+  from sisua_amd.engine import Engine as E
+  return E
+
+
+def _engine(Engine, x, base=0, model="vae", likelihood="zinb"):
+  kw = dict(model=model, n_genes=x.shape[1], likelihood=likelihood, enc_units=(16,), dec_units=(16,), latent_dim=4)
+  if model == "scvi":
+    kw["encl_units"] = (8,)
+  spec, cfg = make_pair(**kw)
+  e = Engine(cfg, max_batch=32)
+  lib = np.zeros((len(x), 2), np.float32) + 1.0 if model == "scvi" else None
+  e.upload(x, library=lib, cell_id_base=base)
+  return spec, e
+
+
+@pytest.mark.parametrize("shape,sparsity", [((300, 203), 0.85), ((64, 31), 0.3), ((1000, 1998), 0.93)])
+def test_library_statistics_match_reference_formula(Engine, shape, sparsity):
+  x = synth_counts(shape[0], shape[1], sparsity=sparsity, seed=2)
+  x[3] = 0.0     # an empty cell: log(0 + 1e-8)
+  _, e = _engine(Engine, x)
+  mean, var = e.dataset_library()
+  _, rm, rv = so.library_size(x)     # pinned against the reference by tests/golden/reference_data_fixtures.npz
+  assert np.isclose(mean, rm, rtol=1e-5) and np.isclose(var, rv, rtol=1e-5), (mean, rm, var, rv)
+  X, rc, lib = e.dataset_read(library=True)
+  assert np.array_equal(X, x)
+  assert np.allclose(lib, np.array([[rm, rv]], np.float32), rtol=1e-5)
+  from scipy.special import gammaln
+  assert np.allclose(rc, gammaln(x.astype(np.float64) + 1.0).sum(1), rtol=1e-6, atol=1e-4)
+  e.close()
+
+
+@pytest.mark.parametrize("dropout,retain,seed,base", [(0.2, 0.2, 8, 0), (0.5, 0.7, 12345678901, 700), (0.0, 0.5, 3, 0),
+                                                    (0.999, 0.0, 1, 5)])
+def test_corruption_bit_exact_vs_oracle(Engine, dropout, retain, seed, base):
+  x = synth_counts(257, 203, sparsity=0.8, seed=4, max_count=3000)
+  x[5, 7] = 4097.0   # a long binomial trial loop
+  _, e = _engine(Engine, x, base=base)
+  n = e.dataset_corrupt(dropout, retain, seed)
+  ref, n_ref = so.corrupt_philox(x, dropout, retain, seed, np.arange(len(x)) + base)
+  X, rc = e.dataset_read()
+  assert n == n_ref == int(np.floor(dropout * np.count_nonzero(x)))
+  assert np.array_equal(X, ref)
+  from scipy.special import gammaln
+  assert np.allclose(rc, gammaln(ref.astype(np.float64) + 1.0).sum(1), rtol=1e-6, atol=1e-4)
+  e.close()
+
+
+def test_corruption_properties_at_8kly_size(Engine):
+  """Size-independent properties (the reference's own checks, tests/test_datasets.py:80-98): counts only
+  decrease, zeros stay zero, exactly floor(rate * nnz) entries are touched, thinning keeps ~retain_rate of the
+  selected mass, idempotent arguments are no-ops, and training still runs on the corrupted matrix."""
+  x = synth_counts(3381, 1998, sparsity=0.93, seed=8)
+  spec, e = _engine(Engine, x)
+  nnz = np.count_nonzero(x)
+  assert e.dataset_corrupt(0.0, 1.0, 8) == 0 and e.dataset_corrupt(0.0, 0.0, 8) == 0
+  assert np.array_equal(e.dataset_read()[0], x)
+  n = e.dataset_corrupt(0.2, 0.2, 8)
+  X, _ = e.dataset_read()
+  assert n == int(np.floor(0.2 * nnz))
+  assert (X <= x).all() and (X[x == 0] == 0).all() and (X == np.floor(X)).all()
+  changed = X != x
+  assert changed.sum() <= n and changed.sum() > 0.7 * n          # Binomial(n, .2) == n only for small n
+  # E[ sum of selected after ] = 0.2 * sum of selected before; selected mass ~ 0.2 of total (uniform choice)
+  lost = x.sum() - X.sum()
+  assert abs(lost / (0.2 * 0.8 * x.sum()) - 1.0) < 0.05
+  with pytest.raises(RuntimeError):
+    e.dataset_corrupt(1.0, 0.2, 8)                                # utils.py:184-185
+  mean, var = e.dataset_library()
+  _, rm, rv = so.library_size(X)
+  assert np.isclose(mean, rm, rtol=1e-5) and np.isclose(var, rv, rtol=1e-4)
+  loss = e.train_step(np.arange(32, dtype=np.int32))["loss"]
+  assert np.isfinite(loss)
+  e.close()
+
+
+def test_library_feeds_scvi_prior(Engine):
+  """SCVI reads the resident library prior (scvi.py:100-105): after smx_dataset_library the KL of the
+  library latent must match the oracle evaluated with the recomputed statistics."""
+  x = synth_counts(200, 96, sparsity=0.7, seed=6)
+  spec, e = _engine(Engine, x, model="scvi", likelihood="zinbd")
+  mean, var = e.dataset_library()
+  params = e.get_params()
+  lib = np.tile(np.array([[mean, var]], np.float32), (len(x), 1))
+  rows = np.arange(32, dtype=np.int32)
+  got = e.eval_step(rows)
+  ref = so.forward_backward(spec, {k: v.astype(np.float64) for k, v in params.items()}, so.init_bn_state(spec), x[rows],
+                            so.PhiloxNoise(spec.seed, 0, rows), library=lib[rows].astype(np.float64), training=False,
+                            backward=False)
+  assert np.isclose(got["kl_l"], ref["kl_l"].mean(), rtol=1e-4, atol=1e-5), (got["kl_l"], ref["kl_l"].mean())
+  e.close()
