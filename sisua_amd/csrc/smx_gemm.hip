@@ -376,7 +376,7 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
   // run faster as separate launches with their own occupancy.
   bool has_epi = false;
   for (int i = 0; i < n; ++i) has_epi |= (G.p[i].epi != 0);
-  if (total > 768 && !has_epi) {
+  if ((total > 768 || n == 1) && !has_epi) {   // a lone product also runs leaner as its own kernel
     for (int i = 0; i < n; ++i) {
       GemmArgs g = list[i];
       g.tile = (G.variant[i] & 8) ? TILE_32x32_K4 : TILE_128x32;

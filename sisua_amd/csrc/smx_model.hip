@@ -143,6 +143,7 @@ struct smx_model {
   hipStream_t st = nullptr, st2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
   bool forked = false;
+  bool head_fused = false;   // this step's output head ran as the fused kernel (smx_head.hip)
   int G = 0, Gp = 0, D = 0, Dp = 0, k = 0, Bmax = 0;
   bool stochastic = true, scvi = false;
   std::vector<TensorInfo> tensors;
@@ -481,6 +482,17 @@ int dp_allreduce(smx_model* m, size_t off, size_t count, hipStream_t st) {
   return SMX_OK;
 }
 
+// fused output head (product + likelihood + dW/db in one kernel): count heads with raw parameter planes.
+// Opt-in (SMX_OUT_FUSED=1): parity-green but not faster -- 16 genes x whole batch per workgroup gives only
+// Gp/16 = 126 workgroups at 8kly width, so the two MFMA phases (3.5 + 3.2 us) and the likelihood (6.1 us, four
+// elements per lane at two waves per SIMD) run on half the chip: 20.2 us against 8.0 + 5.5 + ~8 us for the
+// separate product / loss / weight-gradient launches (step 125 vs 123 us).
+bool use_fused_head(const smx_model* m, int B) {
+  static const bool on = getenv("SMX_OUT_FUSED") != nullptr && atoi(getenv("SMX_OUT_FUSED")) != 0;
+  if (!on || m->scvi || m->dec.empty()) return false;
+  return out_head_supported(B, m->dec.back().out_p, m->Gp);
+}
+
 bool use_mid(const smx_model* m, int B) {
   // single-workgroup fusion of the middle is opt-in until it beats the per-operator path
   static const bool off = getenv("SMX_FUSED") == nullptr;
@@ -635,7 +647,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     sh.raw = m->raw; sh.planes = m->P; sh.ld = ldp; sh.plane_stride = m->Gp; sh.B = ps.B; sh.G = m->G; sh.Gp = m->Gp;
     sh.k = m->k; sh.l = m->lsmp; sh.clip_library = c.clip_library; sh.rho_raw = m->rho;
     SMX_CHECK(launch_scvi_head_fwd(m->st, sh));
-  } else {
+  } else if (!(m->head_fused = (with_loss && backward && use_fused_head(m, ps.B)))) {
     const TensorInfo& tw = m->tensors[m->t_outW[0]];
     GemmArgs g;
     g.A = dL.out_buf; g.lda = dL.out_p; g.B = P_(m, m->t_outW[0]); g.ldb = tw.ld;
@@ -658,7 +670,23 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   lo.X = ps.Xsrc; lo.ldx = m->Gp; lo.rows = ps.rows;
   lo.P = m->P; lo.ldp = ldp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
   lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = -inv_gb;
-  {
+  int n_llk_chunks = loss_chunks(m->Gp);
+  if (m->head_fused) {
+    // training step of a count head: output product, likelihood, dP, dW_out and db_out in one kernel
+    const TensorInfo& tw = m->tensors[m->t_outW[0]];
+    OutHeadArgs oh;
+    oh.H = dL.out_buf; oh.ldh = dL.out_p; oh.W = P_(m, m->t_outW[0]); oh.ldw = tw.ld; oh.bias = P_(m, m->t_outb[0]);
+    oh.X = ps.Xsrc; oh.ldx = m->Gp; oh.rows = ps.rows;
+    oh.dP = m->dP; oh.ldp = ldp; oh.plane_stride = m->Gp;
+    oh.dW = G_(m, m->t_outW[0]); oh.db = G_(m, m->t_outb[0]);
+    oh.llk_part = m->llk_part; oh.n_chunks = n_llk_chunks = out_head_chunks(m->Gp);
+    oh.B = ps.B; oh.G = m->G; oh.Gp = m->Gp; oh.Hp = dL.out_p; oh.likelihood = c.likelihood; oh.grad_scale = -inv_gb;
+    static const int head_diag = getenv("SMX_HEAD_DIAG") ? atoi(getenv("SMX_HEAD_DIAG")) : 0;
+    oh.diag = head_diag;
+    const int reps = (!m->capturing && m->timing_label == "out_head") ? SMX_LOSS_TIMING_REPEAT : 1;
+    Timed t(m, "out_head");
+    for (int r = 0; r < reps; ++r) SMX_CHECK(launch_out_head_train(m->st, oh));
+  } else {
     // timing mode: the (idempotent) kernel is launched SMX_LOSS_TIMING_REPEAT times inside one event pair so
     // the pair's own ~5 us overhead can be separated from the per-launch time (bench.py)
     const int reps = (!m->capturing && m->timing_label == "loss") ? SMX_LOSS_TIMING_REPEAT : 1;
@@ -675,7 +703,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     SMX_CHECK(launch_label_loss(m->st, lb));
   }
   MetricsArgs me;
-  me.llk_part = m->llk_part; me.n_chunks = loss_chunks(m->Gp); me.lgx1 = ps.lgx1; me.rows = ps.rows;
+  me.llk_part = m->llk_part; me.n_chunks = n_llk_chunks; me.lgx1 = ps.lgx1; me.rows = ps.rows;
   me.llk_y = c.n_labels ? m->llk_y : nullptr;
   me.kl = m->stochastic ? m->kl : nullptr; me.kl_l = m->scvi ? m->kl_l : nullptr;
   me.B = ps.B; me.alpha = c.alpha; me.beta = c.beta; me.inv_global_batch = inv_gb;
@@ -786,7 +814,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
       g.C = G_(m, m->t_outW[ch]); g.ldc = tw.ld; g.M = dL.out_p; g.N = ncols; g.K = ps.B;
       g.colsum = G_(m, m->t_outb[ch]);
       g.tile = TILE_128x32;
-      grp.push_back(g); is_dx.push_back(0);
+      if (!m->head_fused) { grp.push_back(g); is_dx.push_back(0); }   // the fused head already wrote dW / db
       GemmArgs h;  // dd += dP W^T
       h.A = dp; h.lda = (int)ldp; h.B = P_(m, m->t_outW[ch]); h.ldb = tw.ld; h.b_nmajor = 1;
       h.C = nullptr; h.ldc = dL.out_p; h.slab_stride = dd_stride;
@@ -1186,7 +1214,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
       (rc = dmalloc(&m->z, B * m->Dp)) || (rc = dmalloc(&m->noise_eps, B * m->Dp)) || (rc = dmalloc(&m->sig, B * m->Dp)) || (rc = dmalloc(&m->eps, B * m->Dp)) ||
       (rc = dmalloc(&m->kl, B)) || (rc = dmalloc(&m->P, B * ldp)) || (rc = dmalloc(&m->dP, B * ldp)) ||
-      (rc = dmalloc(&m->llk_part, B * loss_chunks(m->Gp))) || (rc = dmalloc(&m->llk_y, B)) ||
+      (rc = dmalloc(&m->llk_part, B * (size_t)std::max(loss_chunks(m->Gp), out_head_chunks(m->Gp)))) || (rc = dmalloc(&m->llk_y, B)) ||
       (rc = dmalloc(&m->rows2[0], B)) || (rc = dmalloc(&m->rows2[1], B)) || (rc = dmalloc(&m->state3, (size_t)3)) ||
       (rc = dmalloc(&m->hostX, B * m->Gp)) || (rc = dmalloc(&m->hostLib, B * 2)) || (rc = dmalloc(&m->hostLgx1, B)))
     return fail(rc);

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("flag", ["SMX_FUSED", "SMX_SMALL_FUSION", "SMX_SIDE_STREAM"])
+@pytest.mark.parametrize("flag", ["SMX_FUSED", "SMX_SMALL_FUSION", "SMX_SIDE_STREAM", "SMX_OUT_FUSED"])
 def test_step_parity_under_flag(flag):
   env = dict(os.environ, **{flag: "1"})
   r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_step.py", "-m", "gpu", "-q", "-x", "-k",
