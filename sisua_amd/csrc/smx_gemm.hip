@@ -50,7 +50,7 @@ struct GemmSmem {
   static constexpr int LDAS = A_KM ? BM + 4 : BM + 1;
   static constexpr int LDBS = B_NM ? BN + 1 : BN + 4;
   static constexpr int TILES = BK * LDAS + BK * LDBS;
-  static constexpr int RED = (WK > 1) ? (WK - 1) * WM * WN * 1024 : 0;
+  static constexpr int RED = (WK > 1) ? WK * WM * WN * 1024 : 0;
   static constexpr int FLOATS = TILES > RED ? TILES : RED;
 };
 
@@ -175,68 +175,78 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
     __syncthreads();
   }
 
-  if (WK > 1) {  // in-workgroup split-K: waves wk > 0 hand their tile to wave wk == 0
+  // In-workgroup split-K: every wave parks its partial tile in LDS, then wave wk finishes registers
+  // [wk * RPW, (wk + 1) * RPW) of the tile (sum over the WK partials in wave order) -- the reduction, the
+  // epilogue arithmetic and the stores are spread over all four waves instead of serialised on one.
+  constexpr int RPW = 16 / WK;
+  float out[RPW];
+  if (WK > 1) {
     float* red = smem;  // tiles are dead after the last barrier of the loop
-    if (wk > 0) {
-      float* dst = red + (((wk - 1) * WM * WN + wm * WN + wn) * 1024);
+    float* dst = red + ((wk * WM * WN + wm * WN + wn) * 1024);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[r];
-    }
+    for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[r];
     __syncthreads();
-    if (wk == 0) {
 #pragma unroll
-      for (int q = 0; q < WK - 1; ++q) {
-        const float* src = red + ((q * WM * WN + wm * WN + wn) * 1024);
+    for (int j = 0; j < RPW; ++j) {
+      const int r = wk * RPW + j;
+      float v = red[((wm * WN + wn) * 1024) + r * 64 + lane];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += src[r * 64 + lane];
-      }
+      for (int q = 1; q < WK; ++q) v += red[((q * WM * WN + wm * WN + wn) * 1024) + r * 64 + lane];
+      out[j] = v;
     }
+  } else {
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) out[j] = acc[j];
   }
+  const int r_base = wk * RPW;   // out[j] is register r_base + j of the wave-level 32x32 tile
 
-  if (EPI == 2 && wk == 0) {
+  if (EPI == 2) {
     // latent-head backward on the d z tile: rows = cells, cols = latent dims
     const EpiLatentBwd& e = g.lb;
     const int d = n0 + wn * 32 + li;
     const bool live = d < e.D;
     // all loads first (independent, in flight together), then the arithmetic, then the stores
-    float mu[16], sr[16], sg[16], ep[16];
+    float mu[RPW], sr[RPW], sg[RPW], ep[RPW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int j = 0; j < RPW; ++j) {
+      const int r = r_base + j;
       const int b = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const bool ok = live && b < g.M;
-      mu[r] = ok ? e.lat[(long)b * e.ld + d] : 0.f;
-      sr[r] = (ok && e.stochastic) ? e.lat[(long)b * e.ld + e.Dp + d] : 0.f;
-      sg[r] = (ok && e.stochastic) ? e.sig[(long)b * e.Dp + d] : 1.f;
-      ep[r] = (ok && e.stochastic) ? e.eps[(long)b * e.Dp + d] : 0.f;
+      mu[j] = ok ? e.lat[(long)b * e.ld + d] : 0.f;
+      sr[j] = (ok && e.stochastic) ? e.lat[(long)b * e.ld + e.Dp + d] : 0.f;
+      sg[j] = (ok && e.stochastic) ? e.sig[(long)b * e.Dp + d] : 1.f;
+      ep[j] = (ok && e.stochastic) ? e.eps[(long)b * e.Dp + d] : 0.f;
     }
-    float o0[16], o1[16];
+    float o0[RPW], o1[RPW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float dz = acc[r];
+    for (int j = 0; j < RPW; ++j) {
+      const float dz = out[j];
       if (e.stochastic) {
-        o0[r] = live ? dz + e.kl_scale * mu[r] : 0.f;
-        o1[r] = live ? (dz * ep[r] + e.kl_scale * (sg[r] - frcp(sg[r]))) * sigmoidf(sr[r] + SMX_SOFTPLUS_INV_1) : 0.f;
+        o0[j] = live ? dz + e.kl_scale * mu[j] : 0.f;
+        o1[j] = live ? (dz * ep[j] + e.kl_scale * (sg[j] - frcp(sg[j]))) * sigmoidf(sr[j] + SMX_SOFTPLUS_INV_1) : 0.f;
       } else {
-        o0[r] = (live && !(e.relu && !(mu[r] > 0.f))) ? dz : 0.f;
-        o1[r] = 0.f;
+        o0[j] = (live && !(e.relu && !(mu[j] > 0.f))) ? dz : 0.f;
+        o1[j] = 0.f;
       }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int j = 0; j < RPW; ++j) {
+      const int r = r_base + j;
       const int b = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (b < g.M) {
-        e.dlat[(long)b * e.ld + d] = o0[r];
-        if (e.stochastic) e.dlat[(long)b * e.ld + e.Dp + d] = o1[r];
+        e.dlat[(long)b * e.ld + d] = o0[j];
+        if (e.stochastic) e.dlat[(long)b * e.ld + e.Dp + d] = o1[j];
       }
     }
-  } else if (wk == 0) {
+  } else {
     float* C = g.C + (long)bz * g.slab_stride;
     const int col = n0 + wn * 32 + li;
     const float bias = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int j = 0; j < RPW; ++j) {
+      const int r = r_base + j;
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row < g.M) C[(long)row * g.ldc + col] = acc[r] + bias;
+      if (row < g.M) C[(long)row * g.ldc + col] = out[j] + bias;
     }
   }
   if (do_colsum) g.colsum[n0 + tid] = csum;
@@ -246,6 +256,12 @@ template <int WM, int WN, int WK, int A_KM, int B_NM, int XF>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[GemmSmem<WM, WN, WK, A_KM, B_NM>::FLOATS];
   gemm_body<WM, WN, WK, A_KM, B_NM, XF>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// the K4 W^T product with the latent-head backward epilogue as its own kernel
+__global__ __launch_bounds__(256) void gemm_latent_bwd_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[GemmSmem<1, 1, 4, 0, 1>::FLOATS];
+  gemm_body<1, 1, 4, 0, 1, 0, 2>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -376,13 +392,20 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
   // run faster as separate launches with their own occupancy.
   bool has_epi = false;
   for (int i = 0; i < n; ++i) has_epi |= (G.p[i].epi != 0);
-  if ((total > 768 || n == 1) && !has_epi) {   // a lone product also runs leaner as its own kernel
+  static const bool split_all = getenv("SMX_SPLIT_GROUPS") != nullptr;
+  if (((total > 768 || n == 1) && !has_epi) || split_all) {   // a lone product also runs leaner as its own kernel
     for (int i = 0; i < n; ++i) {
+      if (G.variant[i] == 11) {
+        const GemmArgs& g = G.p[i];
+        hipLaunchKernelGGL(gemm_latent_bwd_kernel, dim3(G.gx[i], G.gy[i], 1), dim3(256), 0, st, g);
+        continue;
+      }
       GemmArgs g = list[i];
       g.tile = (G.variant[i] & 8) ? TILE_32x32_K4 : TILE_128x32;
       int rc = launch_gemm(st, g, nullptr);
       if (rc != SMX_OK) return rc;
     }
+    SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
   hipLaunchKernelGGL(gemm_group_kernel, dim3(total), dim3(256), 0, st, G);
