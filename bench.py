@@ -215,7 +215,7 @@ def main():
       except Exception:
         traffic = None
     out = {
-        "metric": "cells/sec VAE training (pbmc8k_ly, batch=128)" if args.workload.startswith("8kly") else f"cells/sec VAE training ({args.workload}, batch={batch})",
+        "metric": "cells/sec VAE training (pbmc8k_ly, batch=128)" if args.workload == "8kly" else f"cells/sec {cfg.model} training ({args.workload}, batch={batch})",
         "value": round(args.steps * batch * world / dt, 1),
         "unit": "cells/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

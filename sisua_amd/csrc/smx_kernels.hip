@@ -143,20 +143,29 @@ int launch_count_loss(hipStream_t st, const LossArgs& a) {
 // in chunks of BN_RL * BN_RPT with every slab load of a chunk in flight at once
 // (the kernel is a latency chain, not a bandwidth problem).
 // ===========================================================================
-constexpr int BN_COLS = 4;
+#ifndef SMX_BN_COLS
+#define SMX_BN_COLS 8
+#endif
+constexpr int BN_COLS = SMX_BN_COLS;
 constexpr int BN_RL = 64;
 constexpr int BN_RPT = 2;
+constexpr int BN_THREADS = BN_COLS * BN_RL;   // one wave per BN_COLS... waves = BN_THREADS / 64
+constexpr int BN_WAVES = BN_THREADS / 64;
 
 // column sum over the workgroup: lanes of a wave that share a column are 4 apart (xor 4..32),
 // then the 4 waves meet in LDS; fixed order -> deterministic
-__device__ inline float bn_col_reduce(float v, float* sh /*[4][BN_COLS]*/) {
+__device__ inline float bn_col_reduce(float v, float* sh /*[BN_WAVES][BN_COLS]*/) {
   const int c = threadIdx.x % BN_COLS, w = threadIdx.x >> 6;
 #pragma unroll
   for (int off = BN_COLS; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
   __syncthreads();
   if ((threadIdx.x & 63) < BN_COLS) sh[w * BN_COLS + c] = v;
   __syncthreads();
-  return (sh[c] + sh[BN_COLS + c]) + (sh[2 * BN_COLS + c] + sh[3 * BN_COLS + c]);
+  float t = 0.f;
+#pragma unroll
+  for (int q = 0; q < BN_WAVES; q += 4)
+    t += (sh[q * BN_COLS + c] + sh[(q + 1) * BN_COLS + c]) + (sh[(q + 2) * BN_COLS + c] + sh[(q + 3) * BN_COLS + c]);
+  return t;
 }
 
 // sum of the split-K slabs for BN_RPT rows of one column, loads issued together
@@ -195,7 +204,7 @@ __device__ inline void noise_fill(const BnFwdArgs& a, int job_block) {
   NoiseKey nk = a.nk;
   nk.stream = j.stream;
   const float scale = j.p > 0.f ? 1.f / (1.f - j.p) : 1.f;
-  for (int idx = sub * 256 + threadIdx.x; idx < a.B * wq; idx += SMX_NOISE_BLOCKS_PER_JOB * 256) {
+  for (int idx = sub * BN_THREADS + threadIdx.x; idx < a.B * wq; idx += SMX_NOISE_BLOCKS_PER_JOB * BN_THREADS) {
     const int r = idx / wq, c0 = (idx % wq) * 4;
     const uint32_t cell = a.cell_base + (uint32_t)(a.rows ? a.rows[r] : r);
     const U4 w = philox_block(nk, cell, (uint32_t)(c0 >> 2));
@@ -205,12 +214,12 @@ __device__ inline void noise_fill(const BnFwdArgs& a, int job_block) {
 }
 
 template <bool SMALL>  // SMALL: B <= BN_RL * BN_RPT, every value of the column stays in registers
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
+__global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
   if ((int)blockIdx.x >= a.Hp / BN_COLS) {
     noise_fill(a, (int)blockIdx.x - a.Hp / BN_COLS);
     return;
   }
-  __shared__ float sh[4 * BN_COLS];
+  __shared__ float sh[BN_WAVES * BN_COLS];
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = blockIdx.x * BN_COLS + c;
   const bool live = col < a.H;  // padded columns produce zeros
@@ -304,15 +313,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdArgs a) {
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a) {
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_fwd: bad shapes"); return SMX_ERR_INVALID; }
   const int grid = a.Hp / BN_COLS + a.n_jobs * SMX_NOISE_BLOCKS_PER_JOB;
-  if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+  if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(grid), dim3(BN_THREADS), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
 
 template <bool SMALL>
-__global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdArgs a) {
-  __shared__ float sh[4 * BN_COLS];
+__global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
+  __shared__ float sh[BN_WAVES * BN_COLS];
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = blockIdx.x * BN_COLS + c;
   const bool live = col < a.H;
@@ -369,8 +378,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdArgs a) {
 
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a) {
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_bwd: bad shapes"); return SMX_ERR_INVALID; }
-  if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(a.Hp / BN_COLS), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(a.Hp / BN_COLS), dim3(256), 0, st, a);
+  if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(a.Hp / BN_COLS), dim3(BN_THREADS), 0, st, a);
+  else hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(a.Hp / BN_COLS), dim3(BN_THREADS), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
