@@ -310,7 +310,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
   }
 }
 
-int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a) {
+static int bn_diag() { static const int v = getenv("SMX_BN_DIAG") ? atoi(getenv("SMX_BN_DIAG")) : 0; return v; }
+
+int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
+  BnFwdArgs a = a_in;
+  if (bn_diag() & 1) a.drop_p = 0.f;                      // diagnostic: no dropout draw
+  if (bn_diag() & 2) a.n_slabs = 1;                       // diagnostic: one slab only
+  if (bn_diag() & 8) a.n_jobs = 0;                        // diagnostic: no look-ahead noise workgroups
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_fwd: bad shapes"); return SMX_ERR_INVALID; }
   const int grid = a.Hp / BN_COLS + a.n_jobs * SMX_NOISE_BLOCKS_PER_JOB;
   if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(grid), dim3(BN_THREADS), 0, st, a);
@@ -376,7 +382,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
   }
 }
 
-int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a) {
+int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
+  BnBwdArgs a = a_in;
+  if (bn_diag() & 4) a.n_slabs = 1;                       // diagnostic: one slab only
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_bwd: bad shapes"); return SMX_ERR_INVALID; }
   if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(a.Hp / BN_COLS), dim3(BN_THREADS), 0, st, a);
   else hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(a.Hp / BN_COLS), dim3(BN_THREADS), 0, st, a);

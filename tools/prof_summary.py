@@ -15,7 +15,14 @@ rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"
 names = [r["Kernel_Name"] for r in rows]
 starts = [i for i, n in enumerate(names) if "adam_update" in n]   # last kernel of a step
 if len(starts) > 12:
-  a, b = starts[len(starts) // 2] + 1, starts[len(starts) // 2 + 1] + 1
+  # a step of the TIMED region: the most common kernel count per step (the later timing passes of bench.py
+  # repeat the loss kernel inside an event pair and would show up as longer steps)
+  from collections import Counter
+  counts = Counter(starts[i + 1] - starts[i] for i in range(len(starts) - 1))
+  modal = counts.most_common(1)[0][0]
+  cand = [i for i in range(len(starts) - 1) if starts[i + 1] - starts[i] == modal]
+  pick = cand[len(cand) // 2]
+  a, b = starts[pick] + 1, starts[pick + 1] + 1
   print(f"# one step: {b - a} kernels")
   prev = None
   t0 = int(rows[a]["Start_Timestamp"])
