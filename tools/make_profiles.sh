@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-r01}
 O=$R/gpurun_out/$TAG
-rm -rf $O; mkdir -p $O
+rm -rf $O; mkdir -p $O   # (gpurun merges into an existing gpurun_out/: remove stale trace dirs locally before copying)
 cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err
 python3 tools/prof_summary.py $O/trace > $O/kernel_stats_summary.txt 2>&1
