@@ -337,3 +337,38 @@ def test_score_llk_matches_oracle(Engine, name):
   got2 = e.score_llk([x[rows]], x=x_cor[rows], library=lib[rows], n_samples=S)
   assert np.allclose(got2, ref2, rtol=RTOL, atol=1e-3)
   e.close()
+
+
+@pytest.mark.parametrize("name", ["vae_zinb", "scvi_zinbd"])
+def test_clipnorm_bites_and_matches_oracle(Engine, name):
+  """Per-tensor clipnorm (configs/base.yaml:46-50) with a threshold far below the gradient norms: from the
+  second step on the clipped and unclipped Adam trajectories differ, so the norm path is what is tested."""
+  kw = dict(CASES[name], clipnorm=0.05, lr=5e-3)
+  spec, cfg, x, ys, lib, mask = _problem(kw)
+  params = perturbed_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = Engine(cfg, max_batch=64, init=False)
+  e.set_params(params)
+  e.upload(x, ys, lib, mask, cell_id_base=0)
+  got, ref, norms = [], [], None
+  for step in range(6):
+    rows = np.arange(step * 40, step * 40 + 64, dtype=np.int32) % x.shape[0]
+    res = _oracle_step(spec, params, bn, opt, x, ys, lib, mask, rows, step)
+    m = e.train_step(rows)
+    got.append(m["loss"]); ref.append(res["metrics"]["loss"])
+    norms = max(np.linalg.norm(g) for g in res["grads"].values())
+    assert np.isclose(m["grad_norm_max"], norms, rtol=1e-3), (step, m["grad_norm_max"], norms)
+  assert norms > 10 * spec.clipnorm          # the threshold really was exceeded
+  assert np.allclose(got, ref, rtol=RTOL), np.abs(np.array(got) / np.array(ref) - 1).max()
+  newp = e.get_params()
+  for k in newp:
+    assert np.allclose(newp[k], params[k], rtol=1e-4, atol=2e-3), k
+  # the same run without clipping ends somewhere else
+  spec2, cfg2 = make_pair(**dict(kw, clipnorm=0.0))
+  e2 = Engine(cfg2, max_batch=64, init=False)
+  e2.set_params(perturbed_params(spec2))
+  e2.upload(x, ys, lib, mask, cell_id_base=0)
+  for step in range(6):
+    e2.train_step(np.arange(step * 40, step * 40 + 64, dtype=np.int32) % x.shape[0])
+  assert not np.allclose(e2.get_params()["lat/W"], newp["lat/W"], atol=1e-4)
+  e.close(); e2.close()
