@@ -200,6 +200,18 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
   }
   const int r_base = wk * RPW;   // out[j] is register r_base + j of the wave-level 32x32 tile
 
+  if (g.sq_part) {   // sum of squares of this wave's part of the (weight-gradient) tile
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const int r = r_base + j;
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < g.M) sq += out[j] * out[j];
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) g.sq_part[((long)by * g.sq_gx + bx) * 4 + wave] = sq;
+  }
+
   if (EPI == 2) {
     // latent-head backward on the d z tile: rows = cells, cols = latent dims
     const EpiLatentBwd& e = g.lb;
@@ -314,6 +326,11 @@ static int launch_cfg(hipStream_t st, GemmArgs g, int* eff_split) {
   if (eff_split) *eff_split = g.split_k;
   if (g.N % BN != 0) { set_error("gemm: N not a multiple of the tile width"); return SMX_ERR_INVALID; }
   dim3 grid((g.M + BM - 1) / BM, g.N / BN, g.split_k), block(256);
+  if (g.sq_part) {
+    if (g.split_k != 1) { set_error("gemm: sum-of-squares partials need split_k == 1"); return SMX_ERR_INVALID; }
+    g.sq_gx = (int)grid.x;
+    if (g.sq_count) *g.sq_count = (int)(grid.x * grid.y) * 4;
+  }
   const int mode = (g.a_kmajor ? 2 : 0) | (g.b_nmajor ? 1 : 0);
   if (g.use_xform) {
     if (mode == 0) hipLaunchKernelGGL((gemm_kernel<WM, WN, WK, 0, 0, 1>), grid, block, 0, st, g);
@@ -381,6 +398,11 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
     if (g.epi == 2) {
       if (G.variant[i] != 10) { set_error("gemm group: latent epilogue needs the K4 W^T variant"); return SMX_ERR_INVALID; }
       G.variant[i] = 11;
+    }
+    if (g.sq_part) {
+      if (g.split_k != 1) { set_error("gemm group: sum-of-squares partials need split_k == 1"); return SMX_ERR_INVALID; }
+      g.sq_gx = G.gx[i];
+      if (g.sq_count) *g.sq_count = G.gx[i] * G.gy[i] * 4;
     }
     G.start[i] = total;
     total += G.gx[i] * G.gy[i] * g.split_k;

@@ -60,6 +60,10 @@ struct GemmArgs {
   int use_xform = 0;
   AXform xf;
   int tile = TILE_AUTO;
+  // weight-gradient products: every wave adds the sum of squares of its part of the tile to
+  // sq_part[(by * sq_gx + bx) * 4 + wave] (per-tensor clipnorm without a separate pass over the gradient);
+  // the launcher fills sq_gx and *sq_count (= slots written)
+  float* sq_part = nullptr; int sq_gx = 0; int* sq_count = nullptr;
   int epi = 0;                     // 0: store C; 2: latent-head backward (EpiLatentBwd), split_k == 1
   EpiLatentBwd lb;
 };
@@ -218,7 +222,9 @@ struct MetricsArgs {
 int launch_metrics(hipStream_t st, const MetricsArgs& a);
 
 // Optimiser over the flat parameter buffer.
-struct OptChunk { int32_t tensor; int32_t offset; int32_t count; int32_t first_chunk; int32_t n_chunks; int32_t pad[3]; };
+#define SMX_MAX_TENSORS 48
+#define SMX_SQ_SMALL_TENSOR 65536   // floats: below this a workgroup re-derives the tensor's norm by itself
+struct OptChunk { int32_t tensor; int32_t offset; int32_t count; int32_t first_chunk; int32_t n_chunks; int32_t tensor_count; int32_t pad[2]; };
 struct AdamArgs {
   // ELBO scalars ride along as one extra workgroup of the gradient-norm kernel
   MetricsArgs metrics; int with_metrics = 0;
@@ -228,6 +234,9 @@ struct AdamArgs {
   float* params = nullptr; float* grads = nullptr; float* m = nullptr; float* v = nullptr;
   const OptChunk* chunks = nullptr; int n_chunks = 0;
   float* partial = nullptr;     // [n_chunks] sum of squares per chunk
+  // norms without the separate pass (use_sq): per tensor either the slots the weight-gradient products wrote
+  // (sq_count > 0) or, for small tensors, a sweep of the tensor's gradient by every workgroup that needs it
+  int use_sq = 0; const float* sq_slots = nullptr; int sq_first[SMX_MAX_TENSORS]; int sq_count[SMX_MAX_TENSORS];
   float* tensor_norm = nullptr; // [n_tensors] written by the update kernel (pre-clip norms)
   const StepState* state = nullptr;
   float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, clipnorm = 100.f;

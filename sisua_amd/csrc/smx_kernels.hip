@@ -728,10 +728,28 @@ __global__ __launch_bounds__(256) void grad_sqsum_kernel(AdamArgs a) {
 }
 
 __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
+  if ((int)blockIdx.x == a.n_chunks) {  // use_sq form: the ELBO scalars ride along here
+    metrics_body(a.metrics);
+    return;
+  }
   __shared__ float sh[4];
   const OptChunk ch = a.chunks[blockIdx.x];
   float s = 0.f;
-  for (int i = threadIdx.x; i < ch.n_chunks; i += 256) s += a.partial[ch.first_chunk + i];
+  if (a.use_sq) {
+    const int cnt = a.sq_count[ch.tensor];
+    if (cnt > 0) {   // partial sums written by the weight-gradient product's workgroups
+      const float* sl = a.sq_slots + a.sq_first[ch.tensor];
+      for (int i = threadIdx.x; i < cnt; i += 256) s += sl[i];
+    } else {         // small tensor (bias, BatchNorm scale / shift): sweep its whole gradient
+      const float4* t4 = reinterpret_cast<const float4*>(a.grads + a.chunks[ch.first_chunk].offset);
+      for (int i = threadIdx.x; i < ch.tensor_count / 4; i += 256) {
+        const float4 g = t4[i];
+        s += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < ch.n_chunks; i += 256) s += a.partial[ch.first_chunk + i];
+  }
   s = block_sum(s, sh);
   const float norm = sqrtf(s) * a.grad_scale;
   float clip = a.grad_scale;
@@ -776,6 +794,11 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
 // while the workgroup waits for its tensor's other chunks) was measured at 39 us against 16 us for this pair:
 // an agent-scope acquire/release round across the 8 XCDs costs far more than a kernel boundary (1.5 us).
 int launch_adam(hipStream_t st, const AdamArgs& a) {
+  if (a.use_sq) {   // norms come from the weight-gradient products: no pass over the gradient buffer
+    hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_chunks + (a.with_metrics ? 1 : 0)), dim3(256), 0, st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   hipLaunchKernelGGL(grad_sqsum_kernel, dim3(a.n_chunks + (a.with_metrics ? 1 : 0)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_chunks), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());

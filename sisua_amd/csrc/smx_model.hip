@@ -143,7 +143,9 @@ struct smx_model {
   hipStream_t st = nullptr, st2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
   bool forked = false;
-  bool head_fused = false;   // this step's output head ran as the fused kernel (smx_head.hip)
+  bool head_fused = false;
+  // sum-of-squares slots written by the weight-gradient products (per-tensor clipnorm without a separate pass)
+  float* sq_slots = nullptr; std::vector<int> sq_first, sq_count;   // this step's output head ran as the fused kernel (smx_head.hip)
   int G = 0, Gp = 0, D = 0, Dp = 0, k = 0, Bmax = 0;
   bool stochastic = true, scvi = false;
   std::vector<TensorInfo> tensors;
@@ -378,6 +380,14 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
   return SMX_OK;
 }
 
+// ask the product that writes the gradient of tensor t for sum-of-squares partials
+void want_sq(smx_model* m, GemmArgs& g, int t) {
+  static const bool off = getenv("SMX_NO_SQ_PARTIALS") != nullptr;
+  if (off || !m->sq_slots) return;
+  g.sq_part = m->sq_slots + m->sq_first[(size_t)t];
+  g.sq_count = &m->sq_count[(size_t)t];
+}
+
 // backward through an MLP.  d(out of last layer) arrives as `n_slabs` slabs in m->slab.
 // Leaves d(input of first layer) as slabs in m->slab unless skip_input_grad.
 int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
@@ -405,6 +415,7 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     g.B = L.dpre; g.ldb = L.out_p;
     g.C = G_(m, L.tW); g.ldc = tw.ld;
     g.M = L.in_p; g.N = L.out_p; g.K = ps.B;
+    want_sq(m, g, L.tW);
     if (first_x) {
       g.use_xform = 1;
       g.xf.rows = ps.rows; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
@@ -749,6 +760,7 @@ int backward_mid(smx_model* m, const Pass& ps, int n_slabs) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.a_kmajor = 1; g.B = Bm; g.ldb = ldb;
     g.C = G_(m, tW); g.ldc = m->tensors[tW].ld; g.M = M; g.N = N; g.K = ps.B; g.colsum = colsum;
+    want_sq(m, g, tW);
     if (xform) {
       g.use_xform = 1;
       g.xf.rows = ps.rows; g.xf.log1p = c.log_norm; g.xf.cell_base = ps.cell_base;
@@ -785,6 +797,7 @@ int backward_mid(smx_model* m, const Pass& ps, int n_slabs) {
 
 int backward_pass(smx_model* m, const Pass& ps) {
   const smx_config& c = m->cfg;
+  std::fill(m->sq_count.begin(), m->sq_count.end(), 0);   // the products of this step report what they wrote
   const float inv_gb = 1.f / (float)ps.global_batch;
   const MlpLayer& dL = m->dec.back();
   const long ldp = (long)m->k * m->Gp;
@@ -813,6 +826,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
       g.A = dL.out_buf; g.lda = dL.out_p; g.a_kmajor = 1; g.B = dp; g.ldb = (int)ldp;
       g.C = G_(m, m->t_outW[ch]); g.ldc = tw.ld; g.M = dL.out_p; g.N = ncols; g.K = ps.B;
       g.colsum = G_(m, m->t_outb[ch]);
+      want_sq(m, g, m->t_outW[ch]);
       g.tile = TILE_128x32;
       if (!m->head_fused) { grp.push_back(g); is_dx.push_back(0); }   // the fused head already wrote dW / db
       GemmArgs h;  // dd += dP W^T
@@ -829,6 +843,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
       g.A = dL.out_buf; g.lda = dL.out_p; g.a_kmajor = 1; g.B = m->laby_draw[j]; g.ldb = tw.ld;
       g.C = G_(m, m->t_labW[j]); g.ldc = tw.ld; g.M = dL.out_p; g.N = tw.ld; g.K = ps.B;
       g.colsum = G_(m, m->t_labb[j]);
+      want_sq(m, g, m->t_labW[j]);
       grp.push_back(g); is_dx.push_back(0);
       GemmArgs h;
       h.A = m->laby_draw[j]; h.lda = tw.ld; h.B = P_(m, m->t_labW[j]); h.ldb = tw.ld; h.b_nmajor = 1;
@@ -878,6 +893,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
     GemmArgs& g = pair[0];
     g.A = eL.out_buf; g.lda = eL.out_p; g.a_kmajor = 1; g.B = m->dlat; g.ldb = lat_ld;
     g.C = G_(m, m->t_latW); g.ldc = tw.ld; g.M = eL.out_p; g.N = lat_ld; g.K = ps.B; g.colsum = G_(m, m->t_latb);
+    want_sq(m, g, m->t_latW);
     GemmArgs& h = pair[1];
     h.A = m->dlat; h.lda = lat_ld; h.B = P_(m, m->t_latW); h.ldb = tw.ld; h.b_nmajor = 1;
     h.C = m->slab; h.ldc = eL.out_p; h.slab_stride = (long)ps.B * eL.out_p;
@@ -897,6 +913,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
     GemmArgs g;
     g.A = lL.out_buf; g.lda = lL.out_p; g.a_kmajor = 1; g.B = m->dlatl; g.ldb = 32;
     g.C = G_(m, m->t_latlW); g.ldc = tw.ld; g.M = lL.out_p; g.N = 32; g.K = ps.B; g.colsum = G_(m, m->t_latlb);
+    want_sq(m, g, m->t_latlW);
     SMX_CHECK(launch_gemm(m->st, g));
     GemmArgs h;
     h.A = m->dlatl; h.lda = 32; h.B = P_(m, m->t_latlW); h.ldb = tw.ld; h.b_nmajor = 1;
@@ -934,6 +951,14 @@ int optimizer_pass(smx_model* m) {
   AdamArgs a;
   a.params = m->params; a.grads = m->grads; a.m = m->adam_m; a.v = m->adam_v;
   a.chunks = m->chunks; a.n_chunks = m->n_chunks; a.partial = m->partial; a.tensor_norm = m->tensor_norm;
+  // norms from the products' partials when every large tensor has them (single GPU: under data parallelism the
+  // norm is that of the all-reduced gradient, which only a pass after the collective can give)
+  a.use_sq = (m->sq_slots != nullptr && !dp_active(m)) ? 1 : 0;
+  for (size_t t = 0; t < m->tensors.size() && a.use_sq; ++t) {
+    a.sq_first[t] = m->sq_first[t]; a.sq_count[t] = m->sq_count[t];
+    if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) a.use_sq = 0;
+  }
+  a.sq_slots = m->sq_slots;
   a.state = cur_state(m); a.b1 = c.adam_beta1; a.b2 = c.adam_beta2; a.eps = c.adam_eps; a.clipnorm = c.clipnorm;
   a.grad_scale = 1.f / (float)m->world;
   if (m->have_pending_metrics) { a.metrics = m->pending_metrics; a.with_metrics = 1; m->have_pending_metrics = false; }
@@ -1241,11 +1266,22 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
       memset(&c, 0, sizeof(c));
       c.tensor = (int)t; c.offset = (int)(ti.offset + (size_t)i * CH);
       c.count = (int)((size_t)(i + 1) * CH <= ti.count ? CH : ti.count - (size_t)i * CH);
-      c.first_chunk = first; c.n_chunks = n;
+      c.first_chunk = first; c.n_chunks = n; c.tensor_count = (int32_t)ti.count;
       chunks.push_back(c);
     }
   }
   m->n_chunks = (int)chunks.size();
+  if (m->tensors.size() <= SMX_MAX_TENSORS) {   // slots for the products' sum-of-squares partials (32 x 32 tiles at most)
+    size_t total = 0;
+    m->sq_first.assign(m->tensors.size(), 0);
+    m->sq_count.assign(m->tensors.size(), 0);
+    for (size_t t = 0; t < m->tensors.size(); ++t) {
+      const TensorInfo& ti = m->tensors[t];
+      m->sq_first[t] = (int)total;
+      total += (size_t)((ti.rows_p + 31) / 32) * (size_t)((ti.ld + 31) / 32) * 4;
+    }
+    if ((rc = dmalloc(&m->sq_slots, total))) return fail(rc);
+  }
   if ((rc = dmalloc(&m->chunks, chunks.size())) || (rc = dmalloc(&m->partial, chunks.size())) ||
       (rc = dmalloc(&m->tensor_norm, m->tensors.size())))
     return fail(rc);
@@ -1273,7 +1309,7 @@ int smx_model_destroy(smx_model* m) {
   fr(m->noise_eps); fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);
   fr(m->latlbuf); fr(m->dlatl); fr(m->lsmp); fr(m->lsig); fr(m->leps); fr(m->kl_l); fr(m->dl);
   fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);
-  fr(m->chunks); fr(m->partial); fr(m->tensor_norm);
+  fr(m->chunks); fr(m->partial); fr(m->tensor_norm); fr(m->sq_slots);
   for (auto& kv : m->injected) fr(kv.second.d);
   if (m->st_comm) { hipStreamSynchronize(m->st_comm); hipStreamDestroy(m->st_comm); }
   if (m->ev_c1) hipEventDestroy(m->ev_c1);
