@@ -395,6 +395,49 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
 // ===========================================================================
 // Latent head.  One wave per cell, lanes over latent dims.
 // ===========================================================================
+// one lane = 4 consecutive latent dims of one cell (one Philox block, 16-byte accesses); the Dp/4 lanes of a
+// cell are adjacent, so the KL sum is a short shuffle reduction.  Dp/4 is a power of two <= 64 (Dp in {32, 64,
+// 128, 256}); other widths take the scalar kernel below.
+__global__ __launch_bounds__(64) void latent_fwd_quad_kernel(LatentArgs a) {
+  const int dq = a.Dp >> 2;
+  const int idx = blockIdx.x * 64 + threadIdx.x;
+  const int b = idx / dq, d0 = (idx % dq) * 4;
+  float kl = 0.f;
+  if (b < a.B) {
+    float zz[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {1.f, 1.f, 1.f, 1.f}, ee[4] = {0.f, 0.f, 0.f, 0.f};
+    const float4 m4 = *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + d0);
+    const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
+    if (a.stochastic) {
+      const float4 s4 = *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + a.Dp + d0);
+      const float sr[4] = {s4.x, s4.y, s4.z, s4.w};
+      float4 n4;
+      if (a.inj_eps) n4 = *reinterpret_cast<const float4*>(a.inj_eps + (long)b * a.inj_ld + d0);
+      else n4 = normal4(philox_block(a.nk, a.cell_base + (uint32_t)(a.rows ? a.rows[b] : b), (uint32_t)(d0 >> 2)));
+      const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (d0 + e < a.D) {
+          const float sg = softplusf(sr[e] + SMX_SOFTPLUS_INV_1);
+          ss[e] = sg; ee[e] = nn[e];
+          zz[e] = mu[e] + sg * nn[e];
+          kl += 0.5f * (sg * sg + mu[e] * mu[e] - 1.f - 2.f * logf(sg));
+        }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (d0 + e < a.D) zz[e] = a.relu ? fmaxf(mu[e], 0.f) : mu[e];
+    }
+    const long o = (long)b * a.Dp + d0;
+    *reinterpret_cast<float4*>(a.z + o) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+    if (a.sig) {
+      *reinterpret_cast<float4*>(a.sig + o) = make_float4(ss[0], ss[1], ss[2], ss[3]);
+      *reinterpret_cast<float4*>(a.eps + o) = make_float4(ee[0], ee[1], ee[2], ee[3]);
+    }
+  }
+  for (int off = 1; off < dq; off <<= 1) kl += __shfl_xor(kl, off, 64);
+  if (b < a.B && (idx % dq) == 0 && a.kl) a.kl[b] = kl;
+}
+
 __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentArgs a) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -427,6 +470,13 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentArgs a) {
 }
 
 int launch_latent_fwd(hipStream_t st, const LatentArgs& a) {
+  const int dq = a.Dp >> 2;
+  static const bool scalar_only = getenv("SMX_LATENT_SCALAR") != nullptr;
+  if (!scalar_only && dq >= 1 && dq <= 64 && (dq & (dq - 1)) == 0 && (a.ld % 4) == 0 && (!a.inj_eps || (a.inj_ld % 4) == 0)) {
+    hipLaunchKernelGGL(latent_fwd_quad_kernel, dim3((a.B * dq + 63) / 64), dim3(64), 0, st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   hipLaunchKernelGGL(latent_fwd_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
