@@ -93,7 +93,8 @@ struct LossArgs {
   int B = 0, G = 0, Gp = 0;
   float grad_scale = 1.f;                 // d loss / d llk (= -1/B_global); 1 for the test entry
 };
-int loss_chunks(int Gp);
+int loss_chunks(int Gp, int B);   // partial sums per cell written by a launch over B cells
+int loss_chunks_max(int Gp);      // upper bound over every batch size (allocation)
 int launch_count_loss(hipStream_t st, const LossArgs& a);
 
 // Noise for LATER small layers, generated by extra workgroups of the first BatchNorm launch (they run on

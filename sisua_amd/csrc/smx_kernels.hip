@@ -90,22 +90,23 @@ static int loss_block() {
   }
   return g_loss_block;
 }
-static int g_loss_vec = 0;
-static int loss_vec() {
-  if (!g_loss_vec) {
-    const char* e = getenv("SMX_LOSS_VEC");
-    g_loss_vec = e ? atoi(e) : 1;
-    if (g_loss_vec != 1 && g_loss_vec != 2 && g_loss_vec != 4) g_loss_vec = 1;
-  }
-  return g_loss_vec;
+// Elements per lane: 4-byte accesses win while the launch is latency-bound (one wave of workgroups), 8-byte
+// from ~0.4 M elements (47 % of the HBM peak at 128 x 20 000 against 38 %), 16-byte from ~8 M (64 % at 1024 x
+// 20 000) -- tools/loss_roofline.py.  SMX_LOSS_VEC forces a width.
+static int loss_vec(int B, int Gp) {
+  static const int forced = getenv("SMX_LOSS_VEC") ? atoi(getenv("SMX_LOSS_VEC")) : 0;
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  const long n = (long)B * Gp;
+  return n < 400000 ? 1 : (n < 8000000 ? 2 : 4);
 }
-static int loss_grid_x(int Gp) { return (Gp + loss_block() * loss_vec() - 1) / (loss_block() * loss_vec()); }
+static int loss_grid_x(int Gp, int vec) { return (Gp + loss_block() * vec - 1) / (loss_block() * vec); }
 // number of partial sums per cell the loss kernel writes (one per wave)
-int loss_chunks(int Gp) { return loss_grid_x(Gp) * (loss_block() / 64); }
+int loss_chunks(int Gp, int B) { return loss_grid_x(Gp, loss_vec(B, Gp)) * (loss_block() / 64); }
+int loss_chunks_max(int Gp) { return loss_grid_x(Gp, 1) * (loss_block() / 64); }
 
 template <int LK, int DIRECT>
 static void launch_loss_t(hipStream_t st, const LossArgs& a, dim3 grid) {
-  const int v = loss_vec(), blk = loss_block();
+  const int v = loss_vec(a.B, a.Gp), blk = loss_block();
 #define SMX_LOSS_LAUNCH(B_, V_) do { \
     if (blk == 1024) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 1024>), grid, dim3(1024), 0, st, a); \
     else if (blk == 512) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 512>), grid, dim3(512), 0, st, a); \
@@ -120,7 +121,7 @@ int launch_count_loss(hipStream_t st, const LossArgs& a) {
     set_error("count_loss: bad shapes");
     return SMX_ERR_INVALID;
   }
-  dim3 grid(loss_grid_x(a.Gp), a.B);
+  dim3 grid(loss_grid_x(a.Gp, loss_vec(a.B, a.Gp)), a.B);
   if (getenv("SMX_LOSS_NOP")) { LossArgs b = a; b.likelihood = -atoi(getenv("SMX_LOSS_NOP")); launch_loss_t<SMX_LLK_ZINB, 0>(st, b, grid); return SMX_OK; }
   switch (a.likelihood) {
     case SMX_LLK_NB: launch_loss_t<SMX_LLK_NB, 0>(st, a, grid); break;

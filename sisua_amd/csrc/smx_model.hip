@@ -681,7 +681,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   lo.X = ps.Xsrc; lo.ldx = m->Gp; lo.rows = ps.rows;
   lo.P = m->P; lo.ldp = ldp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
   lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = -inv_gb;
-  int n_llk_chunks = loss_chunks(m->Gp);
+  int n_llk_chunks = loss_chunks(m->Gp, ps.B);
   if (m->head_fused) {
     // training step of a count head: output product, likelihood, dP, dW_out and db_out in one kernel
     const TensorInfo& tw = m->tensors[m->t_outW[0]];
@@ -1239,7 +1239,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
       (rc = dmalloc(&m->z, B * m->Dp)) || (rc = dmalloc(&m->noise_eps, B * m->Dp)) || (rc = dmalloc(&m->sig, B * m->Dp)) || (rc = dmalloc(&m->eps, B * m->Dp)) ||
       (rc = dmalloc(&m->kl, B)) || (rc = dmalloc(&m->P, B * ldp)) || (rc = dmalloc(&m->dP, B * ldp)) ||
-      (rc = dmalloc(&m->llk_part, B * (size_t)std::max(loss_chunks(m->Gp), out_head_chunks(m->Gp)))) || (rc = dmalloc(&m->llk_y, B)) ||
+      (rc = dmalloc(&m->llk_part, B * (size_t)std::max(loss_chunks_max(m->Gp), out_head_chunks(m->Gp)))) || (rc = dmalloc(&m->llk_y, B)) ||
       (rc = dmalloc(&m->rows2[0], B)) || (rc = dmalloc(&m->rows2[1], B)) || (rc = dmalloc(&m->state3, (size_t)3)) ||
       (rc = dmalloc(&m->hostX, B * m->Gp)) || (rc = dmalloc(&m->hostLib, B * 2)) || (rc = dmalloc(&m->hostLgx1, B)))
     return fail(rc);
@@ -1676,7 +1676,7 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
     rc = launch_count_loss(m->st, lo);
     if (rc != SMX_OK) break;
     IwArgs a;
-    a.llk_part = m->llk_part; a.n_chunks = loss_chunks(m->Gp); a.lgx1 = ps.lgx1; a.rows = ps.rows;
+    a.llk_part = m->llk_part; a.n_chunks = loss_chunks(m->Gp, ps.B); a.lgx1 = ps.lgx1; a.rows = ps.rows;
     a.z = m->z; a.sig = m->sig; a.eps = m->eps; a.D = m->D; a.Dp = m->Dp; a.stochastic = m->stochastic;
     a.l = m->scvi ? m->lsmp : nullptr; a.lsig = m->lsig; a.leps = m->leps; a.library = ps.lib;
     a.run_max = run; a.run_sum = run + batch; a.llk_sum = run + 2 * batch; a.B = batch; a.first = (s == 0);
@@ -1747,7 +1747,7 @@ int smx_score_llk(smx_model* m, const int32_t* row_ids, const float* host_x, con
         if (rc != SMX_OK) break;
         IwArgs a;
         memset(&a, 0, sizeof(a));
-        a.llk_part = m->llk_part; a.n_chunks = loss_chunks(m->Gp);
+        a.llk_part = m->llk_part; a.n_chunks = loss_chunks(m->Gp, ps.B);
         a.lgx1 = own ? ps.lgx1 : tLg + (size_t)batch * t; a.rows = own ? ps.rows : nullptr;
         a.D = m->D; a.Dp = m->Dp; a.stochastic = 0; a.l = nullptr;
         float* r = run + ((size_t)t * 2 + j) * 2 * batch;
@@ -1867,7 +1867,7 @@ int smx_k_count_llk(int likelihood, int direct, const float* x, const float* pla
   SMX_REQUIRE(x && planes && llk && B > 0 && G > 0, "bad arguments");
   const int k = (likelihood == SMX_LLK_ZINB || likelihood == SMX_LLK_ZINBD) ? 3 : 2;
   const int Gp = round_up(G, 32);
-  const int nch = loss_chunks(Gp);
+  const int nch = loss_chunks(Gp, B);
   float *dX = nullptr, *dPl = nullptr, *dG = nullptr, *dPart = nullptr;
   int rc;
   if ((rc = dmalloc(&dX, (size_t)B * Gp)) || (rc = dmalloc(&dPl, (size_t)B * k * Gp)) || (rc = dmalloc(&dG, (size_t)B * k * Gp)) ||

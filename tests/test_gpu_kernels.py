@@ -110,3 +110,18 @@ def test_count_llk_sizes_and_empty_rows(eng):
     ref_e, ref_g = so.count_llk(x.astype(np.float64), list(planes.astype(np.float64)), "zinb")
     assert np.allclose(llk, ref_e.sum(1), rtol=1e-5, atol=1e-4)
     assert np.allclose(grads, np.stack(ref_g), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,G,lk", [(260, 1998, "zinb"), (300, 1501, "nbd"), (70, 130000, "zinb"), (66, 126001, "nb")])
+def test_count_llk_wide_access_forms(eng, B, G, lk):
+  """The loss kernel switches to 8-byte accesses from ~0.4 M elements and 16-byte from ~8 M: same results,
+  ragged gene counts included (the full-size property: the sum of the per-cell values equals the sum of the
+  elementwise oracle)."""
+  rng = np.random.default_rng(B + G)
+  x = (rng.poisson(3.0, size=(B, G)) * (rng.uniform(size=(B, G)) < 0.1)).astype(np.float32)
+  k = 3 if lk.startswith("zi") else 2
+  planes = rng.normal(size=(k, B, G)).astype(np.float32)
+  llk, grads = eng.k_count_llk(lk, x, planes)
+  ref_e, ref_g = so.count_llk(x.astype(np.float64), list(planes.astype(np.float64)), lk)
+  assert np.allclose(llk, ref_e.sum(1), rtol=1e-5, atol=1e-3)
+  assert np.allclose(grads, np.stack(ref_g), rtol=1e-4, atol=1e-5)

@@ -14,7 +14,10 @@ from sisua_amd.engine import Engine
 
 HBM_PEAK = 8000.0
 out = []
-for G, B in ((1998, 128), (20000, 128), (20000, 512), (20000, 1024)):
+SIZES = ((1998, 128), (20000, 128), (20000, 512), (20000, 1024))
+if os.environ.get("LOSS_SIZES"):   # e.g. LOSS_SIZES=1998x256,5000x128
+  SIZES = tuple(tuple(int(v) for v in t.split("x")) for t in os.environ["LOSS_SIZES"].split(","))
+for G, B in SIZES:
   rng = np.random.default_rng(8)
   n = max(2 * B, 512)
   x = np.floor(rng.lognormal(0.0, 1.0, size=(n, G))).astype(np.float32) * (rng.uniform(size=(n, G)) < 0.12)
