@@ -51,7 +51,9 @@ struct GemmSmem {
   static constexpr int LDBS = B_NM ? BN + 1 : BN + 4;
   static constexpr int TILES = BK * LDAS + BK * LDBS;
   static constexpr int RED = (WK > 1) ? WK * WM * WN * 1024 : 0;
-  static constexpr int FLOATS = TILES > RED ? TILES : RED;
+  static constexpr int STORE = (WK == 1) ? 4 * 32 * 36 : 0;   // per-wave transposed output tiles (wide_store)
+  static constexpr int FLOATS0 = TILES > RED ? TILES : RED;
+  static constexpr int FLOATS = FLOATS0 > STORE ? FLOATS0 : STORE;
 };
 
 template <int WM, int WN, int WK, int A_KM, int B_NM, int XF, int EPI = 0>
@@ -250,6 +252,25 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
         if (e.stochastic) e.dlat[(long)b * e.ld + e.Dp + d] = o1[j];
       }
     }
+  } else if (WK == 1 && g.wide_store) {
+    // Whole 32 x 32 tile per wave: transpose it through LDS so that every lane stores 16 bytes (4 store
+    // instructions of 1 KB per wave instead of 16 of 256 B -- wide outputs are store-issue bound otherwise).
+    float* C = g.C + (long)bz * g.slab_stride;
+    float* tile = smem + wave * (32 * 36);   // operand tiles are dead after the loop's last barrier
+    const float bias = g.bias ? g.bias[n0 + wn * 32 + li] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = out[r] + bias;
+    // same wave wrote and reads: no workgroup barrier needed, only the LDS counter
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    const int rq = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = rq + 8 * i;
+      const int row = m0 + wm * 32 + rr;
+      const float4 v = *reinterpret_cast<const float4*>(&tile[rr * 36 + c4]);
+      if (row < g.M) *reinterpret_cast<float4*>(&C[(long)row * g.ldc + n0 + wn * 32 + c4]) = v;
+    }
   } else {
     float* C = g.C + (long)bz * g.slab_stride;
     const int col = n0 + wn * 32 + li;
@@ -326,6 +347,10 @@ static int launch_cfg(hipStream_t st, GemmArgs g, int* eff_split) {
   if (eff_split) *eff_split = g.split_k;
   if (g.N % BN != 0) { set_error("gemm: N not a multiple of the tile width"); return SMX_ERR_INVALID; }
   dim3 grid((g.M + BM - 1) / BM, g.N / BN, g.split_k), block(256);
+  {
+    static const int ws = getenv("SMX_WIDE_STORE") ? atoi(getenv("SMX_WIDE_STORE")) : -1;
+    g.wide_store = (WK == 1) && (ws >= 0 ? ws != 0 : (long)g.M * g.N >= 65536);
+  }
   if (g.sq_part) {
     if (g.split_k != 1) { set_error("gemm: sum-of-squares partials need split_k == 1"); return SMX_ERR_INVALID; }
     g.sq_gx = (int)grid.x;
@@ -398,6 +423,10 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
     if (g.epi == 2) {
       if (G.variant[i] != 10) { set_error("gemm group: latent epilogue needs the K4 W^T variant"); return SMX_ERR_INVALID; }
       G.variant[i] = 11;
+    }
+    {
+      static const int ws = getenv("SMX_WIDE_STORE") ? atoi(getenv("SMX_WIDE_STORE")) : -1;
+      g.wide_store = (tile == TILE_128x32) && (ws >= 0 ? ws != 0 : (long)g.M * g.N >= 65536);
     }
     if (g.sq_part) {
       if (g.split_k != 1) { set_error("gemm group: sum-of-squares partials need split_k == 1"); return SMX_ERR_INVALID; }

@@ -64,6 +64,7 @@ struct GemmArgs {
   // sq_part[(by * sq_gx + bx) * 4 + wave] (per-tensor clipnorm without a separate pass over the gradient);
   // the launcher fills sq_gx and *sq_count (= slots written)
   float* sq_part = nullptr; int sq_gx = 0; int* sq_count = nullptr;
+  int wide_store = 0;   // set by the launcher: 16-byte stores through an LDS transpose (large outputs)
   int epi = 0;                     // 0: store C; 2: latent-head backward (EpiLatentBwd), split_k == 1
   EpiLatentBwd lb;
 };
