@@ -426,7 +426,9 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
     }
     {
       static const int ws = getenv("SMX_WIDE_STORE") ? atoi(getenv("SMX_WIDE_STORE")) : -1;
-      g.wide_store = (tile == TILE_128x32) && (ws >= 0 ? ws != 0 : (long)g.M * g.N >= 65536);
+      // measured: inside the grouped kernel the transpose costs more than the wider stores save (+0.9 us per step)
+      static const bool grp_on = getenv("SMX_WIDE_STORE_GROUP") != nullptr && atoi(getenv("SMX_WIDE_STORE_GROUP")) != 0;
+      g.wide_store = grp_on && (tile == TILE_128x32) && (ws >= 0 ? ws != 0 : (long)g.M * g.N >= 65536);
     }
     if (g.sq_part) {
       if (g.split_k != 1) { set_error("gemm group: sum-of-squares partials need split_k == 1"); return SMX_ERR_INVALID; }
