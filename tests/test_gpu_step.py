@@ -372,3 +372,28 @@ def test_clipnorm_bites_and_matches_oracle(Engine, name):
     e2.train_step(np.arange(step * 40, step * 40 + 64, dtype=np.int32) % x.shape[0])
   assert not np.allclose(e2.get_params()["lat/W"], newp["lat/W"], atol=1e-4)
   e.close(); e2.close()
+
+
+def test_one_step_wide_gene_panel(Engine):
+  """BASELINE configs[4] width (G = 20 000, the per-GPU slice of C5): exercises the 64-slice split-K products,
+  wide groups as separate launches, 16-byte product stores and the 8-byte loss-kernel form against the oracle."""
+  kw = dict(model="vae", n_genes=20000, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=32)
+  spec, cfg = make_pair(**kw)
+  rng = np.random.default_rng(4)
+  n, B = 96, 64
+  x = (np.floor(rng.lognormal(0.0, 1.0, size=(n, 20000))) * (rng.uniform(size=(n, 20000)) < 0.1)).astype(np.float32)
+  x[:, 0] += 1
+  params = perturbed_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = Engine(cfg, max_batch=B, init=False)
+  e.set_params(params)
+  e.upload(x, cell_id_base=7)
+  rows = np.arange(5, 5 + B, dtype=np.int32)
+  res = so.train_step(spec, params, bn, opt, x[rows], so.PhiloxNoise(spec.seed, 0, rows + 7))
+  m = e.train_step(rows)
+  for key in ("loss", "nllk_x", "kl"):
+    assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
+  worst = grad_errors(e.get_params(which=1), res["grads"])
+  assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  assert np.isclose(m["grad_norm_max"], max(np.linalg.norm(g) for g in res["grads"].values()), rtol=1e-3)
+  e.close()
