@@ -188,6 +188,7 @@ struct smx_model {
   std::map<int, Injected> injected; bool use_injected = false;
   // comm
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
+  bool dp_force = false, dp_two_buckets = false;   // SMX_FORCE_ALLREDUCE / SMX_DP_BUCKETS=2, read when the communicator is attached
   hipStream_t st_comm = nullptr; hipEvent_t ev_c1 = nullptr, ev_c2 = nullptr, ev_c3 = nullptr;
   size_t bucket1_off = 0, bucket1_count = 0;   // gradients of the output / label heads: ready first, reduced early
   bool bucket1_in_flight = false;
@@ -382,8 +383,7 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
 
 // ask the product that writes the gradient of tensor t for sum-of-squares partials
 void want_sq(smx_model* m, GemmArgs& g, int t) {
-  static const bool off = getenv("SMX_NO_SQ_PARTIALS") != nullptr;
-  if (off || !m->sq_slots) return;
+  if (!m->sq_slots || getenv("SMX_NO_SQ_PARTIALS") != nullptr) return;   // read per call: tests toggle it
   g.sq_part = m->sq_slots + m->sq_first[(size_t)t];
   g.sq_count = &m->sq_count[(size_t)t];
 }
@@ -474,15 +474,13 @@ int side_join(smx_model* m) {
 
 // data-parallel overlap: two buckets on a communication stream (eager launches only)
 bool dp_active(const smx_model* m) {
-  static const bool force_ar = getenv("SMX_FORCE_ALLREDUCE") != nullptr;  // exercise RCCL on a 1-rank communicator
-  return m->comm && (m->world > 1 || force_ar);
+  return m->comm && (m->world > 1 || m->dp_force);   // dp_force: exercise RCCL on a 1-rank communicator (tests)
 }
 // Measured on a 1-rank communicator: the cross-stream events of the two-bucket form cost +42 us per step,
 // one all-reduce on the model's own stream +2.6 us.  The overlap only pays when the collective itself is
 // much longer than that, so the default is the single all-reduce; SMX_DP_BUCKETS=2 selects the overlap.
 bool dp_overlap(const smx_model* m) {
-  static const bool two = getenv("SMX_DP_BUCKETS") != nullptr && atoi(getenv("SMX_DP_BUCKETS")) == 2;
-  return dp_active(m) && two && !m->capturing && m->st_comm != nullptr;
+  return dp_active(m) && m->dp_two_buckets && !m->capturing && m->st_comm != nullptr;
 }
 int dp_allreduce(smx_model* m, size_t off, size_t count, hipStream_t st) {
   ncclResult_t r = g_rccl.AllReduce(m->grads + off, m->grads + off, count, ncclFloat32, ncclSum, m->comm, st);
@@ -953,7 +951,7 @@ int optimizer_pass(smx_model* m) {
   a.chunks = m->chunks; a.n_chunks = m->n_chunks; a.partial = m->partial; a.tensor_norm = m->tensor_norm;
   // norms from the products' partials when every large tensor has them (single GPU: under data parallelism the
   // norm is that of the all-reduced gradient, which only a pass after the collective can give)
-  a.use_sq = (m->sq_slots != nullptr && !dp_active(m)) ? 1 : 0;
+  a.use_sq = (m->sq_slots != nullptr && !dp_active(m) && getenv("SMX_NO_SQ_PARTIALS") == nullptr) ? 1 : 0;
   for (size_t t = 0; t < m->tensors.size() && a.use_sq; ++t) {
     a.sq_first[t] = m->sq_first[t]; a.sq_count[t] = m->sq_count[t];
     if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) a.use_sq = 0;
@@ -1819,6 +1817,8 @@ int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]) {
     return SMX_ERR_COMM;
   }
   m->rank = rank; m->world = world;
+  m->dp_force = getenv("SMX_FORCE_ALLREDUCE") != nullptr;
+  m->dp_two_buckets = getenv("SMX_DP_BUCKETS") != nullptr && atoi(getenv("SMX_DP_BUCKETS")) == 2;
   if (!m->st_comm) {
     if (hipStreamCreateWithFlags(&m->st_comm, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_c1, hipEventDisableTiming) != hipSuccess ||
