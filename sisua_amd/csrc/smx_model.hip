@@ -568,23 +568,9 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd", 1));
     MidArgs ma;
     fill_mid_args(m, ps, ma);
-    static unsigned long long* dbg = nullptr;
-    static const bool want_dbg = getenv("SMX_MID_STAMPS") != nullptr;
-    if (want_dbg && !dbg) dmalloc(&dbg, (size_t)32);
-    ma.dbg = want_dbg ? dbg : nullptr;
+    ma.dbg = nullptr;
     Timed t(m, "mid_fwd");
     SMX_CHECK(launch_mid_fwd(m->st, ma));
-    if (want_dbg && !m->capturing) {
-      unsigned long long h[32];
-      hipStreamSynchronize(m->st);
-      hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-      static int printed = 0;
-      if (printed++ % 50 == 10) {
-        fprintf(stderr, "mid_fwd stamps (cycles @100MHz*?):");
-        for (int i = 1; i < 8; ++i) fprintf(stderr, " %lld", (long long)(h[i] - h[i - 1]));
-        fprintf(stderr, "\n");
-      }
-    }
   }
   if (!decode_only && !mid) {
   // ---- encoder ----
