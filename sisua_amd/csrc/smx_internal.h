@@ -129,6 +129,17 @@ struct BnFwdArgs {
 };
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a);
 
+// ELBO scalars of a step; computed by one workgroup that rides along with another launch
+struct MetricsArgs {
+  const float* llk_part = nullptr; int n_chunks = 0;   // [B][n_chunks]
+  const float* lgx1 = nullptr; const int32_t* rows = nullptr;  // per-cell sum lgamma(x+1), gathered
+  const float* llk_y = nullptr;   // [B] masked label llk or nullptr
+  const float* kl = nullptr; const float* kl_l = nullptr;
+  int B = 0; float alpha = 0.f, beta = 1.f; float inv_global_batch = 0.f;
+  float* out = nullptr;           // [8]: loss, nllk_x, nllk_y, kl, kl_l, (5..7 reserved)
+};
+int launch_metrics(hipStream_t st, const MetricsArgs& a);
+
 struct BnBwdArgs {
   const float* dout = nullptr; int n_slabs = 1; long slab_stride = 0; int ld = 0;  // d loss / d out slabs
   const float* out = nullptr;    // forward output (relu/dropout mask: out > 0)
@@ -138,6 +149,8 @@ struct BnBwdArgs {
   float drop_scale = 1.f;        // 1/(1-p) (1 in eval)
   float* dpre = nullptr;         // [B][Hp]
   float* dgamma = nullptr; float* dbeta = nullptr; float* dbias = nullptr;
+  // data parallel: the ELBO scalars must be in the flat buffer before the all-reduce -- one extra workgroup here
+  MetricsArgs metrics; int with_metrics = 0;
 };
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a);
 
@@ -213,15 +226,6 @@ struct StepState {
 int launch_step_begin(hipStream_t st, StepState* master, StepState* dst, const int32_t* order, int32_t* rows,
                       int batch, int cursor_from_master, uint32_t cursor, float lr, float b1, float b2);
 
-struct MetricsArgs {
-  const float* llk_part = nullptr; int n_chunks = 0;   // [B][n_chunks]
-  const float* lgx1 = nullptr; const int32_t* rows = nullptr;  // per-cell sum lgamma(x+1), gathered
-  const float* llk_y = nullptr;   // [B] masked label llk or nullptr
-  const float* kl = nullptr; const float* kl_l = nullptr;
-  int B = 0; float alpha = 0.f, beta = 1.f; float inv_global_batch = 0.f;
-  float* out = nullptr;           // [8]: loss, nllk_x, nllk_y, kl, kl_l, (5..7 reserved)
-};
-int launch_metrics(hipStream_t st, const MetricsArgs& a);
 
 // Optimiser over the flat parameter buffer.
 #define SMX_MAX_TENSORS 48

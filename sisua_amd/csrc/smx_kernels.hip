@@ -326,8 +326,14 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
   return SMX_OK;
 }
 
+__device__ inline void metrics_body(const MetricsArgs& a);
+
 template <bool SMALL>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
+  if ((int)blockIdx.x == a.Hp / BN_COLS) {   // the extra workgroup (with_metrics): ELBO scalars, 256 threads
+    if (threadIdx.x < 256) metrics_body(a.metrics);
+    return;
+  }
   __shared__ float sh[BN_WAVES * BN_COLS];
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = blockIdx.x * BN_COLS + c;
@@ -387,8 +393,9 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
   BnBwdArgs a = a_in;
   if (bn_diag() & 4) a.n_slabs = 1;                       // diagnostic: one slab only
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_bwd: bad shapes"); return SMX_ERR_INVALID; }
-  if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(a.Hp / BN_COLS), dim3(BN_THREADS), 0, st, a);
-  else hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(a.Hp / BN_COLS), dim3(BN_THREADS), 0, st, a);
+  const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0);
+  if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  else hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(grid), dim3(BN_THREADS), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }

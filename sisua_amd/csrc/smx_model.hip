@@ -171,7 +171,7 @@ struct smx_model {
   int32_t* rows2[2] = {nullptr, nullptr}; int32_t* order = nullptr; size_t order_cap = 0;
   StepState* state3 = nullptr;  // [0],[1]: per-step state by parity, [2]: master counter
   int par = 0; uint32_t h_next = 0;
-  MetricsArgs pending_metrics; bool have_pending_metrics = false;
+  MetricsArgs pending_metrics; bool have_pending_metrics = false, metrics_before_allreduce = false;
   int seq_batch = 0, seq_prepare_next = 0;
   bool eps_ahead_ok = false;   // latent head fusable: eps may be drawn ahead by the first BN launch
   float* noise_eps = nullptr;  // [Bmax][Dp] eps drawn ahead of the latent head
@@ -405,6 +405,9 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     if (m->cfg.batchnorm) { b.gamma = P_(m, L.tGamma); b.dgamma = G_(m, L.tGamma); b.dbeta = G_(m, L.tBeta); }
     else b.dbias = G_(m, L.tBias);
     {
+      if (m->metrics_before_allreduce && m->have_pending_metrics) {
+        b.metrics = m->pending_metrics; b.with_metrics = 1; m->have_pending_metrics = false;
+      }
       Timed t(m, "bn_bwd");
       SMX_CHECK(launch_bn_act_bwd(m->st, b));
     }
@@ -703,10 +706,13 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   me.kl = m->stochastic ? m->kl : nullptr; me.kl_l = m->scvi ? m->kl_l : nullptr;
   me.B = ps.B; me.alpha = c.alpha; me.beta = c.beta; me.inv_global_batch = inv_gb;
   me.out = m->grads + m->tail_off_metrics;
-  if (backward && !dp_active(m)) {  // training step: an extra workgroup of the gradient-norm kernel computes
-    // the scalars (under data parallelism they must be in the flat buffer BEFORE the all-reduce: separate launch below)
+  if (backward) {
+    // training step: the scalars come from one extra workgroup of a later launch -- of the optimiser kernel, or,
+    // under data parallelism (they must be in the flat buffer BEFORE the all-reduce), of the first
+    // BatchNorm-backward launch
     m->pending_metrics = me;
     m->have_pending_metrics = true;
+    m->metrics_before_allreduce = dp_active(m);
     return SMX_OK;
   }
   {
@@ -731,6 +737,9 @@ int backward_mid(smx_model* m, const Pass& ps, int n_slabs) {
     b.dpre = dL.dpre;
     if (c.batchnorm) { b.gamma = P_(m, dL.tGamma); b.dgamma = G_(m, dL.tGamma); b.dbeta = G_(m, dL.tBeta); }
     else b.dbias = G_(m, dL.tBias);
+    if (m->metrics_before_allreduce && m->have_pending_metrics) {
+      b.metrics = m->pending_metrics; b.with_metrics = 1; m->have_pending_metrics = false;
+    }
     Timed t(m, "bn_bwd");
     SMX_CHECK(launch_bn_act_bwd(m->st, b));
   }
@@ -912,6 +921,10 @@ int backward_pass(smx_model* m, const Pass& ps) {
 int optimizer_pass(smx_model* m) {
   const smx_config& c = m->cfg;
   SMX_CHECK(side_join(m));
+  if (dp_active(m) && m->have_pending_metrics) {   // no BatchNorm-backward launch took them along
+    SMX_CHECK(launch_metrics(m->st, m->pending_metrics));
+    m->have_pending_metrics = false;
+  }
   if (dp_active(m)) {
     Timed t(m, "allreduce");
     if (m->bucket1_in_flight) {
