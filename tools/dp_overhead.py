@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sisua_amd.engine import Engine
 import bench
+os.environ.setdefault("SMX_FORCE_ALLREDUCE", "1")   # the 1-rank communicator really runs the data-parallel path
 cfg, xt, batch, _ = bench.build_workload(0, 1, "8kly")
 for comm in (False, True):
   for graph in (False, True):
@@ -12,5 +13,5 @@ for comm in (False, True):
     order = bench.make_order(xt.shape[0], batch, 330)
     e.train_steps(order[:30 * batch], 30, batch, graph=graph); e.synchronize()
     t = time.perf_counter(); e.train_steps(order[30 * batch:], 300, batch, graph=graph); e.synchronize(); dt = time.perf_counter() - t
-    print(f"comm={comm} graph={graph} single={os.environ.get('SMX_DP_SINGLE')}: {dt / 300 * 1e6:.1f} us/step", flush=True)
+    print(f"comm={comm} graph={graph} buckets={os.environ.get('SMX_DP_BUCKETS', '1')}: {dt / 300 * 1e6:.1f} us/step", flush=True)
     e.close()
