@@ -149,7 +149,7 @@ int launch_count_loss(hipStream_t st, const LossArgs& a) {
 #endif
 constexpr int BN_COLS = SMX_BN_COLS;
 constexpr int BN_RL = 64;
-constexpr int BN_RPT = 2;
+constexpr int BN_RPT_DEFAULT = 2;   // rows per thread; the register-resident kernels exist for 2, 4, 8, 16 (B <= 1024)
 constexpr int BN_THREADS = BN_COLS * BN_RL;   // one wave per BN_COLS... waves = BN_THREADS / 64
 constexpr int BN_WAVES = BN_THREADS / 64;
 
@@ -170,22 +170,24 @@ __device__ inline float bn_col_reduce(float v, float* sh /*[BN_WAVES][BN_COLS]*/
 }
 
 // sum of the split-K slabs for BN_RPT rows of one column, loads issued together
+template <int BN_RPT>
 __device__ inline void slab_sum(const float* base, int n_slabs, long slab_stride, int ld, int col, int r0, int rl,
                                 int B, float (&acc)[BN_RPT]) {
 #pragma unroll
   for (int i = 0; i < BN_RPT; ++i) acc[i] = 0.f;
+  constexpr int SU = BN_RPT <= 2 ? 8 : (BN_RPT <= 4 ? 4 : 2);   // slabs per batch of loads: 16 values in flight per lane
   int s = 0;
-  for (; s + 8 <= n_slabs; s += 8) {
-    float t[8][BN_RPT];
+  for (; s + SU <= n_slabs; s += SU) {
+    float t[SU][BN_RPT];
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < SU; ++q)
 #pragma unroll
       for (int i = 0; i < BN_RPT; ++i) {
         const int r = r0 + rl + BN_RL * i;
         t[q][i] = r < B ? base[(long)(s + q) * slab_stride + (long)r * ld + col] : 0.f;
       }
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < SU; ++q)
 #pragma unroll
       for (int i = 0; i < BN_RPT; ++i) acc[i] += t[q][i];
   }
@@ -214,8 +216,12 @@ __device__ inline void noise_fill(const BnFwdArgs& a, int job_block) {
   }
 }
 
-template <bool SMALL>  // SMALL: B <= BN_RL * BN_RPT, every value of the column stays in registers
+// RPT > 0: B <= BN_RL * RPT, every value of the column stays in registers (RPT rows per thread);
+// RPT == 0: any B, the normalised values make a round trip through xhat
+template <int RPT>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
+  constexpr bool SMALL = RPT > 0;
+  constexpr int BN_RPT = SMALL ? RPT : BN_RPT_DEFAULT;
   if ((int)blockIdx.x >= a.Hp / BN_COLS) {
     noise_fill(a, (int)blockIdx.x - a.Hp / BN_COLS);
     return;
@@ -320,16 +326,21 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
   if (bn_diag() & 8) a.n_jobs = 0;                        // diagnostic: no look-ahead noise workgroups
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_fwd: bad shapes"); return SMX_ERR_INVALID; }
   const int grid = a.Hp / BN_COLS + a.n_jobs * SMX_NOISE_BLOCKS_PER_JOB;
-  if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(grid), dim3(BN_THREADS), 0, st, a);
-  else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  if (a.B <= BN_RL * 2) hipLaunchKernelGGL(bn_act_fwd_kernel<2>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  else if (a.B <= BN_RL * 4) hipLaunchKernelGGL(bn_act_fwd_kernel<4>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  else if (a.B <= BN_RL * 8) hipLaunchKernelGGL(bn_act_fwd_kernel<8>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  else if (a.B <= BN_RL * 16) hipLaunchKernelGGL(bn_act_fwd_kernel<16>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  else hipLaunchKernelGGL(bn_act_fwd_kernel<0>, dim3(grid), dim3(BN_THREADS), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
 
 __device__ inline void metrics_body(const MetricsArgs& a);
 
-template <bool SMALL>
+template <int RPT>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
+  constexpr bool SMALL = RPT > 0;
+  constexpr int BN_RPT = SMALL ? RPT : BN_RPT_DEFAULT;
   if ((int)blockIdx.x == a.Hp / BN_COLS) {   // the extra workgroup (with_metrics): ELBO scalars, 256 threads
     if (threadIdx.x < 256) metrics_body(a.metrics);
     return;
@@ -394,8 +405,11 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
   if (bn_diag() & 4) a.n_slabs = 1;                       // diagnostic: one slab only
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_bwd: bad shapes"); return SMX_ERR_INVALID; }
   const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0);
-  if (a.B <= BN_RL * BN_RPT) hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(grid), dim3(BN_THREADS), 0, st, a);
-  else hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  if (a.B <= BN_RL * 2) hipLaunchKernelGGL(bn_act_bwd_kernel<2>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  else if (a.B <= BN_RL * 4) hipLaunchKernelGGL(bn_act_bwd_kernel<4>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  else if (a.B <= BN_RL * 8) hipLaunchKernelGGL(bn_act_bwd_kernel<8>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  else if (a.B <= BN_RL * 16) hipLaunchKernelGGL(bn_act_bwd_kernel<16>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  else hipLaunchKernelGGL(bn_act_bwd_kernel<0>, dim3(grid), dim3(BN_THREADS), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
