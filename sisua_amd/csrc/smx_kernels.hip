@@ -618,7 +618,148 @@ __global__ __launch_bounds__(256) void scvi_head_fwd_kernel(ScviHeadArgs a) {
     if (a.k == 3) pl[2 * a.plane_stride + g] = gate;
   }
 }
+// Register-resident forms for gene panels up to 1024 * NV genes: one read of the raw planes (16-byte accesses),
+// the softmax terms stay in registers between the max, the sum and the write (the generic kernels above sweep
+// the row three times).
+template <int NV>
+__global__ __launch_bounds__(256) void scvi_head_fwd_reg_kernel(ScviHeadArgs a) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  const float* raw = a.raw + (long)b * a.ld;
+  float* pl = a.planes + (long)b * a.ld;
+  float4 r0[NV], r1[NV], r2[NV];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const bool ok = g < a.Gp;
+    r0[j] = ok ? *reinterpret_cast<const float4*>(raw + g) : z4;
+    r1[j] = ok ? *reinterpret_cast<const float4*>(raw + a.plane_stride + g) : z4;
+    r2[j] = (ok && a.k == 3) ? *reinterpret_cast<const float4*>(raw + 2 * a.plane_stride + g) : z4;
+  }
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const float v[4] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (g + e < a.G) mx = fmaxf(mx, v[e]);
+  }
+  mx = block_max(mx, sh);
+  float ex[NV][4];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const float v[4] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ex[j][e] = (g + e < a.G) ? expf(v[e] - mx) : 0.f;
+      sum += ex[j][e];
+    }
+  }
+  sum = block_sum(sum, sh);
+  const float inv = 1.f / sum;
+  const float el = expf(fminf(fmaxf(a.l[b], 0.f), a.clip_library));
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    if (g >= a.Gp) continue;
+    const float t[4] = {r1[j].x, r1[j].y, r1[j].z, r1[j].w};
+    const float gt[4] = {r2[j].x, r2[j].y, r2[j].z, r2[j].w};
+    float rho[4], rate[4], th[4], gate[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool live = g + e < a.G;
+      rho[e] = live ? ex[j][e] * inv : 0.f;
+      rate[e] = live ? el * fminf(fmaxf(rho[e], 1e-7f), 1.f - 1e-7f) : 0.f;
+      th[e] = live ? expf(t[e]) : 0.f;
+      gate[e] = live ? gt[e] : 0.f;
+    }
+    *reinterpret_cast<float4*>(a.rho_raw + (long)b * a.Gp + g) = make_float4(rho[0], rho[1], rho[2], rho[3]);
+    *reinterpret_cast<float4*>(pl + g) = make_float4(rate[0], rate[1], rate[2], rate[3]);
+    *reinterpret_cast<float4*>(pl + a.plane_stride + g) = make_float4(th[0], th[1], th[2], th[3]);
+    if (a.k == 3) *reinterpret_cast<float4*>(pl + 2 * a.plane_stride + g) = make_float4(gate[0], gate[1], gate[2], gate[3]);
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void scvi_head_bwd_reg_kernel(ScviHeadArgs a) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  const float* pl = a.planes + (long)b * a.ld;
+  const float* dp = a.dplanes + (long)b * a.ld;
+  float* dr = a.draw + (long)b * a.ld;
+  const float* rho = a.rho_raw + (long)b * a.Gp;
+  const float lraw = a.l[b];
+  const float el = expf(fminf(fmaxf(lraw, 0.f), a.clip_library));
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 rh[NV], d0v[NV], p0v[NV], d1v[NV], p1v[NV], d2v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const bool ok = g < a.Gp;
+    rh[j] = ok ? *reinterpret_cast<const float4*>(rho + g) : z4;
+    d0v[j] = ok ? *reinterpret_cast<const float4*>(dp + g) : z4;
+    p0v[j] = ok ? *reinterpret_cast<const float4*>(pl + g) : z4;
+    d1v[j] = ok ? *reinterpret_cast<const float4*>(dp + a.plane_stride + g) : z4;
+    p1v[j] = ok ? *reinterpret_cast<const float4*>(pl + a.plane_stride + g) : z4;
+    d2v[j] = (ok && a.k == 3) ? *reinterpret_cast<const float4*>(dp + 2 * a.plane_stride + g) : z4;
+  }
+  float s = 0.f, dlh = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const float r[4] = {rh[j].x, rh[j].y, rh[j].z, rh[j].w};
+    const float dd[4] = {d0v[j].x, d0v[j].y, d0v[j].z, d0v[j].w};
+    const float pp[4] = {p0v[j].x, p0v[j].y, p0v[j].z, p0v[j].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (g + e < a.G) {
+        const float inside = (r[e] > 1e-7f && r[e] < 1.f - 1e-7f) ? 1.f : 0.f;
+        s += dd[e] * el * inside * r[e];
+        dlh += dd[e] * pp[e];
+      }
+  }
+  s = block_sum(s, sh);
+  dlh = block_sum(dlh, sh);
+  if (threadIdx.x == 0) a.dl[b] = (lraw > 0.f && lraw < a.clip_library) ? dlh : 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    if (g >= a.Gp) continue;
+    const float r[4] = {rh[j].x, rh[j].y, rh[j].z, rh[j].w};
+    const float dd[4] = {d0v[j].x, d0v[j].y, d0v[j].z, d0v[j].w};
+    const float d1[4] = {d1v[j].x, d1v[j].y, d1v[j].z, d1v[j].w};
+    const float p1[4] = {p1v[j].x, p1v[j].y, p1v[j].z, p1v[j].w};
+    const float d2[4] = {d2v[j].x, d2v[j].y, d2v[j].z, d2v[j].w};
+    float o0[4], o1[4], o2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool live = g + e < a.G;
+      const float inside = (r[e] > 1e-7f && r[e] < 1.f - 1e-7f) ? 1.f : 0.f;
+      o0[e] = live ? r[e] * (dd[e] * el * inside - s) : 0.f;
+      o1[e] = live ? d1[e] * p1[e] : 0.f;
+      o2[e] = live ? d2[e] : 0.f;
+    }
+    *reinterpret_cast<float4*>(dr + g) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+    *reinterpret_cast<float4*>(dr + a.plane_stride + g) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    if (a.k == 3) *reinterpret_cast<float4*>(dr + 2 * a.plane_stride + g) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+  }
+}
+
+static bool scvi_head_reg_ok(const ScviHeadArgs& a) {
+  static const bool off = getenv("SMX_SCVI_HEAD_SWEEP") != nullptr;
+  return !off && (a.ld % 4) == 0 && (a.plane_stride % 4) == 0 && (a.Gp % 4) == 0 && a.Gp <= 4096;
+}
+
 int launch_scvi_head_fwd(hipStream_t st, const ScviHeadArgs& a) {
+  if (scvi_head_reg_ok(a)) {
+    if (a.Gp <= 2048) hipLaunchKernelGGL(scvi_head_fwd_reg_kernel<2>, dim3(a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(scvi_head_fwd_reg_kernel<4>, dim3(a.B), dim3(256), 0, st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   hipLaunchKernelGGL(scvi_head_fwd_kernel, dim3(a.B), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
@@ -659,6 +800,12 @@ __global__ __launch_bounds__(256) void scvi_head_bwd_kernel(ScviHeadArgs a) {
   }
 }
 int launch_scvi_head_bwd(hipStream_t st, const ScviHeadArgs& a) {
+  if (scvi_head_reg_ok(a)) {
+    if (a.Gp <= 2048) hipLaunchKernelGGL(scvi_head_bwd_reg_kernel<2>, dim3(a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(scvi_head_bwd_reg_kernel<4>, dim3(a.B), dim3(256), 0, st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   hipLaunchKernelGGL(scvi_head_bwd_kernel, dim3(a.B), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
