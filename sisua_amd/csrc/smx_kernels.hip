@@ -812,10 +812,12 @@ int launch_scvi_head_bwd(hipStream_t st, const ScviHeadArgs& a) {
 }
 
 // ===========================================================================
-// SISUA label heads: one thread per cell (P is tens of columns)
+// SISUA label heads: one wave per cell, lanes over the label columns (P is tens of columns); unlabelled cells
+// (mask == 0, 90 % of them at labels_percent = 0.1) contribute nothing and only zero their gradient rows.
 // ===========================================================================
-__global__ void label_loss_kernel(LabelArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void label_loss_kernel(LabelArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.B) return;
   const long src = a.rows ? a.rows[b] : b;
   const float* y = a.Y + src * a.ldy;
@@ -823,8 +825,13 @@ __global__ void label_loss_kernel(LabelArgs a) {
   const float m = a.mask ? (a.mask[src] ? 1.f : 0.f) : 0.f;
   const float gs = a.grad_scale * m;
   float llk = 0.f;
-  if (a.kind == SMX_LABEL_NB) {
-    for (int p = 0; p < a.Pp; ++p) {
+  if (m == 0.f) {   // wave-uniform
+    if (a.backward) {
+      const int width = (a.kind == SMX_LABEL_NB ? 2 : 1) * a.Pp;
+      for (int p = lane; p < width; p += 64) a.draw[(long)b * a.ld + p] = 0.f;
+    }
+  } else if (a.kind == SMX_LABEL_NB) {
+    for (int p = lane; p < a.Pp; p += 64) {
       float d0 = 0.f, d1 = 0.f;
       if (p < a.P) {
         float e, d2;
@@ -833,13 +840,17 @@ __global__ void label_loss_kernel(LabelArgs a) {
       }
       if (a.backward) { a.draw[(long)b * a.ld + p] = d0 * gs; a.draw[(long)b * a.ld + a.Pp + p] = d1 * gs; }
     }
+    llk = wave_sum(llk);
   } else {
     float mx = -3.0e38f, ysum = 0.f;
-    for (int p = 0; p < a.P; ++p) { mx = fmaxf(mx, raw[p]); ysum += y[p]; }
+    for (int p = lane; p < a.P; p += 64) { mx = fmaxf(mx, raw[p]); ysum += y[p]; }
+    mx = wave_max(mx);
+    ysum = wave_sum(ysum);
     float se = 0.f;
-    for (int p = 0; p < a.P; ++p) se += expf(raw[p] - mx);
+    for (int p = lane; p < a.P; p += 64) se += expf(raw[p] - mx);
+    se = wave_sum(se);
     const float lse = mx + logf(se);
-    for (int p = 0; p < a.Pp; ++p) {
+    for (int p = lane; p < a.Pp; p += 64) {
       float d = 0.f;
       if (p < a.P) {
         const float lp = raw[p] - lse;
@@ -848,11 +859,12 @@ __global__ void label_loss_kernel(LabelArgs a) {
       }
       if (a.backward) a.draw[(long)b * a.ld + p] = d * gs;
     }
+    llk = wave_sum(llk);
   }
-  a.llk[b] = (a.add ? a.llk[b] : 0.f) + m * llk;
+  if (lane == 0) a.llk[b] = (a.add ? a.llk[b] : 0.f) + m * llk;
 }
 int launch_label_loss(hipStream_t st, const LabelArgs& a) {
-  hipLaunchKernelGGL(label_loss_kernel, dim3((a.B + 63) / 64), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(label_loss_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
