@@ -103,19 +103,24 @@ struct IwArgs {
   const float* l; const float* lsig; const float* leps; const float* library;  // scvi (library indexed like lgx1)
   float* run_max; float* run_sum; float* llk_sum; int B, first;
 };
-__global__ void iw_accum_kernel(IwArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per cell: lanes over the loss kernel's partial sums and over the latent dims
+__global__ __launch_bounds__(256) void iw_accum_kernel(IwArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.B) return;
   float llk = 0.f;
-  for (int c = 0; c < a.n_chunks; ++c) llk += a.llk_part[(long)b * a.n_chunks + c];
+  for (int c = lane; c < a.n_chunks; c += 64) llk += a.llk_part[(long)b * a.n_chunks + c];
+  llk = wave_sum(llk);
   const long src = a.rows ? a.rows[b] : b;
   llk -= a.lgx1[src];
-  float lw = llk;
+  float lw = 0.f;
   if (a.stochastic)
-    for (int d = 0; d < a.D; ++d) {
+    for (int d = lane; d < a.D; d += 64) {
       const float z = a.z[(long)b * a.Dp + d], e = a.eps[(long)b * a.Dp + d], s = a.sig[(long)b * a.Dp + d];
       lw += -0.5f * z * z + 0.5f * e * e + logf(s);
     }
+  lw = wave_sum(lw) + llk;
+  if (lane != 0) return;
   if (a.l) {
     const float mp = a.library[src * 2], vp = a.library[src * 2 + 1];
     const float l = a.l[b], e = a.leps[b], s = a.lsig[b];
@@ -1677,7 +1682,7 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
     a.z = m->z; a.sig = m->sig; a.eps = m->eps; a.D = m->D; a.Dp = m->Dp; a.stochastic = m->stochastic;
     a.l = m->scvi ? m->lsmp : nullptr; a.lsig = m->lsig; a.leps = m->leps; a.library = ps.lib;
     a.run_max = run; a.run_sum = run + batch; a.llk_sum = run + 2 * batch; a.B = batch; a.first = (s == 0);
-    hipLaunchKernelGGL(iw_accum_kernel, dim3((batch + 127) / 128), dim3(128), 0, m->st, a);
+    hipLaunchKernelGGL(iw_accum_kernel, dim3((batch + 3) / 4), dim3(256), 0, m->st, a);
   }
   if (rc == SMX_OK) {
     std::vector<float> h((size_t)3 * batch);
@@ -1749,7 +1754,7 @@ int smx_score_llk(smx_model* m, const int32_t* row_ids, const float* host_x, con
         a.D = m->D; a.Dp = m->Dp; a.stochastic = 0; a.l = nullptr;
         float* r = run + ((size_t)t * 2 + j) * 2 * batch;
         a.run_max = r; a.run_sum = r + batch; a.llk_sum = nullptr; a.B = batch; a.first = (s == 0);
-        hipLaunchKernelGGL(iw_accum_kernel, dim3((batch + 127) / 128), dim3(128), 0, m->st, a);
+        hipLaunchKernelGGL(iw_accum_kernel, dim3((batch + 3) / 4), dim3(256), 0, m->st, a);
       }
     }
   }
