@@ -16,6 +16,8 @@ import time
 import warnings
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 from sisua_amd import distributions as D
@@ -278,8 +280,15 @@ class SingleCellModel:
     hist_v = self.valid_history
     best, bad, it, t_log = np.inf, 0, 0, time.time()
     stop = False
+    # the next epoch's minibatch order is prepared on a host thread while the device runs the current one
+    # (the ctypes call releases the GIL); epoch_batches is a pure function of (seed, epoch)
+    def _prepare(ep):
+      return [b for b in train.epoch_batches(ep) if len(b) == B]  # fixed batch size on the device
+    pool = ThreadPoolExecutor(max_workers=1)
+    ahead = pool.submit(_prepare, 0) if int(epochs) > 0 else None
     for epoch in range(int(epochs)):
-      batches = [b for b in train.epoch_batches(epoch) if len(b) == B]  # fixed batch size on the device
+      batches = ahead.result()
+      ahead = pool.submit(_prepare, epoch + 1) if epoch + 1 < int(epochs) else None
       pos = 0
       while pos < len(batches) and not stop:
         room = len(batches) - pos
@@ -314,6 +323,7 @@ class SingleCellModel:
           stop = True
       if stop:
         break
+    pool.shutdown(wait=True)
     if valid is not None and not hist_v.get("val_loss"):
       hist_v.setdefault("val_loss", []).append(self._validate(e, valid, n_tr))
     if checkpoint is not None and valid is None:
