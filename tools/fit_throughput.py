@@ -21,3 +21,10 @@ for epochs in (50, 200):
   dt = time.perf_counter() - t
   steps = epochs * (tr.n_obs // 128)
   print(f"fit: {epochs} epochs = {steps} steps in {dt:.3f} s -> {steps * 128 / dt:.0f} cells/s ({dt / steps * 1e6:.1f} us/step)")
+
+xs = test.numpy() if hasattr(test, "numpy") else x[:900]
+for bs, S in ((32, ()), (128, ()), (8, 10), (128, 10)):
+  t = time.perf_counter()
+  X, Z = model.predict(xs, sample_shape=S, batch_size=bs, verbose=False)
+  dt = time.perf_counter() - t
+  print(f"predict: {xs.shape[0]} cells, batch {bs}, sample_shape {S}: {dt * 1e3:.1f} ms -> {xs.shape[0] / dt:.0f} cells/s")
