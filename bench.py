@@ -172,6 +172,7 @@ def main():
 
   use_graph = args.graph
   order = make_order(xt.shape[0], batch, args.warmup + args.steps)
+  eng.eval_step(order[:batch])   # loads the code object (not a training step: parameters and optimiser state untouched)
   if args.warmup:
     eng.train_steps(order[: args.warmup * batch], args.warmup, batch, graph=use_graph)
   eng.synchronize()
@@ -195,7 +196,8 @@ def main():
   per_kernel = {}
   for name in ("gemm_enc_fwd", "gemm_out_fwd", "out_head", "gemm_out_bwd", "gemm_enc_dw", "adam", "step"):
     eng.timing_enable(name)
-    eng.train_steps(order[: 50 * batch], 50, batch, graph=False)
+    n_k = min(50, args.warmup + args.steps)
+    eng.train_steps(order[: n_k * batch], n_k, batch, graph=False)
     ms, n = eng.timing_read()
     per_kernel[name] = round(1e3 * ms / max(n, 1), 2)
   eng.timing_enable(None)
