@@ -145,6 +145,7 @@ def main():
   ap.add_argument("--workload", default="8kly")
   ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (eager launches measured faster)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--storage", default="f32", choices=("f32", "u16"), help="resident count matrix: float32 (reference layout) or uint16")
   ap.add_argument("--cpu-budget", type=float, default=12.0)
   args = ap.parse_args()
 
@@ -167,7 +168,7 @@ def main():
 
   cfg, xt, batch, extra = build_workload(rank, world, args.workload)
   eng = Engine(cfg, max_batch=batch, device=local_rank)
-  eng.upload(xt, cell_id_base=rank * (1 << 24), **extra)
+  eng.upload(xt, cell_id_base=rank * (1 << 24), storage=args.storage, **extra)
   attach_engine(eng, cp)
 
   use_graph = args.graph
@@ -226,7 +227,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}-shaped synthetic counts {xt.shape[0]}x{xt.shape[1]} "
                                f"(train split, corrupted), {cfg.model} {cfg.likelihood} hidden={list(cfg.enc_units)} latent={cfg.latent_dim}, "
-                               f"batch {batch}/GPU, hipGraph={'on' if use_graph else 'off'}",
+                               f"batch {batch}/GPU, hipGraph={'on' if use_graph else 'off'}, X resident as {args.storage}",
                    "global_batch": batch * world, "parallelism": f"dp{world}"},
         "final_loss": round(m["loss"], 4),
         "roofline": {"bound": "hbm", "kernel": "count_loss_kernel<ZINB> fwd+bwd", "achieved": round(achieved, 1),

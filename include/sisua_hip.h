@@ -123,6 +123,12 @@ int smx_set_step(smx_model* m, int32_t step);
  * cell_id_base offsets the Philox cell ids (rank shard offset). */
 int smx_dataset_upload(smx_model* m, const float* X, int64_t n_cells, const float* const* labels,
                        const float* library, const uint8_t* label_mask, int64_t cell_id_base);
+/* The same with the counts stored compactly as uint16 (every count must be <= 65535): half the
+ * HBM footprint and half the gather traffic of the dense float32 memmap of the reference
+ * (sisua/data/utils.py:401-452), identical results -- the kernels widen on load.  Labels stay float32. */
+int smx_dataset_upload_u16(smx_model* m, const uint16_t* X, int64_t n_cells, const float* const* labels,
+                           const float* library, const uint8_t* label_mask, int64_t cell_id_base);
+
 int64_t smx_dataset_size(const smx_model* m);
 
 /* Library-size statistics of the RESIDENT matrix, get_library_size (sisua/data/utils.py:231-263) as the

@@ -17,16 +17,18 @@ __device__ inline double wave_sum_f64(double v) {
 
 // One wave per row.  lgx1[row] = sum_g lgamma(x+1) (the likelihood's data-only constant);
 // logcount[row] = log(float(sum_g x) + 1e-8) in fp32 as NumPy evaluates it on the float32 matrix.
-__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ X, long ld, long N, int G,
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ X, int u16, long ld, long N, int G,
                                                         float* __restrict__ lgx1, double* __restrict__ logcount) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= N) return;
   const int lane = threadIdx.x & 63;
   const float* r = X + row * ld;
+  const uint16_t* rh = reinterpret_cast<const uint16_t*>(X) + row * ld;
   double tot = 0.0, lg = 0.0;
   for (int g = lane * 4; g < G; g += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(r + g);   // ld is padded to 32 columns of zeros
-    const float e[4] = {v.x, v.y, v.z, v.w};
+    float e[4];
+    if (u16) { const ushort4 h = *reinterpret_cast<const ushort4*>(rh + g); e[0] = h.x; e[1] = h.y; e[2] = h.z; e[3] = h.w; }
+    else { const float4 v = *reinterpret_cast<const float4*>(r + g); e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w; }   // ld is padded with zeros
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (g + q < G) {
@@ -79,8 +81,8 @@ __global__ void library_fill_kernel(float* __restrict__ library, long N, const d
   if (i < N) { library[2 * i] = (float)stats[0]; library[2 * i + 1] = (float)stats[1]; }
 }
 
-int launch_row_stats(hipStream_t st, const float* X, long ld, long N, int G, float* lgx1, double* logcount) {
-  hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, X, ld, N, G, lgx1, logcount);
+int launch_row_stats(hipStream_t st, const float* X, int u16, long ld, long N, int G, float* lgx1, double* logcount) {
+  hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, X, u16, ld, N, G, lgx1, logcount);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
@@ -98,6 +100,14 @@ int launch_library_stats(hipStream_t st, const double* logcount, long N, double*
 // philox(counter = (gene, cell_id, 0, SELECT)); the floor(dropout * nnz) smallest keys are corrupted.
 // The threshold key is found by an 8-pass radix select (one 256-bin histogram of the next byte per pass).
 // ---------------------------------------------------------------------------
+__device__ inline float corrupt_get(const CorruptArgs& a, long row, int g) {
+  return a.u16 ? (float)reinterpret_cast<const uint16_t*>(a.X)[row * a.ld + g] : a.X[row * a.ld + g];
+}
+__device__ inline void corrupt_put(const CorruptArgs& a, long row, int g, float v) {
+  if (a.u16) reinterpret_cast<uint16_t*>(a.X)[row * a.ld + g] = (uint16_t)v;
+  else a.X[row * a.ld + g] = v;
+}
+
 __device__ inline uint64_t corrupt_key(uint32_t k0, uint32_t k1, uint32_t cell, uint32_t gene) {
   const U4 w = philox4x32_10(gene, cell, 0u, (uint32_t)ST_CORRUPT_SELECT, k0, k1);
   return ((uint64_t)w.x << 32) | (uint64_t)w.y;
@@ -109,10 +119,9 @@ __global__ __launch_bounds__(256) void corrupt_hist_kernel(CorruptArgs a, int pa
   __syncthreads();
   const int shift = 56 - 8 * pass;
   for (long row = blockIdx.x; row < a.N; row += gridDim.x) {
-    const float* r = a.X + row * a.ld;
     const uint32_t cell = a.cell_base + (uint32_t)row;
     for (int g = threadIdx.x; g < a.G; g += 256) {
-      if (!(r[g] > 0.f)) continue;
+      if (!(corrupt_get(a, row, g) > 0.f)) continue;
       const uint64_t key = corrupt_key(a.k0, a.k1, cell, (uint32_t)g);
       if (pass > 0 && (key >> (shift + 8)) != (a.prefix >> (shift + 8))) continue;
       atomicAdd(&h[(unsigned)((key >> shift) & 0xFFu)], 1u);
@@ -127,10 +136,9 @@ __global__ __launch_bounds__(256) void corrupt_hist_kernel(CorruptArgs a, int pa
 __global__ __launch_bounds__(256) void corrupt_apply_kernel(CorruptArgs a) {
   unsigned long long mine = 0ull;
   for (long row = blockIdx.x; row < a.N; row += gridDim.x) {
-    float* r = a.X + row * a.ld;
     const uint32_t cell = a.cell_base + (uint32_t)row;
     for (int g = threadIdx.x; g < a.G; g += 256) {
-      const float x = r[g];
+      const float x = corrupt_get(a, row, g);
       if (!(x > 0.f)) continue;
       if (corrupt_key(a.k0, a.k1, cell, (uint32_t)g) > a.prefix) continue;
       const long n = (long)x;
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void corrupt_apply_kernel(CorruptArgs a) {
         for (int q = 0; q < 4; ++q)
           if (4 * blk + q < n && (uint64_t)ww[q] < a.thr_binom) ++got;
       }
-      r[g] = (float)got;
+      corrupt_put(a, row, g, (float)got);
       ++mine;
     }
   }

@@ -42,6 +42,17 @@ __device__ inline float4 xform4(float4 v, const AXform& xf, int batch_idx, int s
   return v;
 }
 
+// four consecutive elements of the A operand; with the gather transform A may be the compact uint16 store
+// XF: 0 plain operand, 1 gather transform on a float32 store, 2 gather transform on the compact uint16 store
+template <int XF>
+__device__ inline float4 load_a4(const GemmArgs& g, long off) {
+  if (XF == 2) {
+    const ushort4 h = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(g.A) + off);
+    return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+  }
+  return *reinterpret_cast<const float4*>(g.A + off);
+}
+
 // A_KM: A stored [K][M] (direct staging); else [M][K] (transposed staging).
 // B_NM: B stored [N][K] (transposed staging); else [K][N] (direct staging).
 template <int WM, int WN, int WK, int A_KM, int B_NM>
@@ -88,7 +99,7 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
         const int k = k0 + kr, m = m0 + mq * 4;
         if (k < k_end && m < g.M) {
           const int src = (XF && g.xf.rows) ? g.xf.rows[k] : k;
-          v = *reinterpret_cast<const float4*>(g.A + (long)src * g.lda + m);
+          v = load_a4<XF>(g, (long)src * g.lda + m);
           v = xform4<XF>(v, g.xf, k, src, m);
         }
       } else {
@@ -96,7 +107,7 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
         const int m = m0 + mr, k = k0 + kq * 4;
         if (m < g.M && k < k_end) {
           const int src = (XF && g.xf.rows) ? g.xf.rows[m] : m;
-          v = *reinterpret_cast<const float4*>(g.A + (long)src * g.lda + k);
+          v = load_a4<XF>(g, (long)src * g.lda + k);
           v = xform4<XF>(v, g.xf, m, src, k);
           // K is ragged only when it is the batch axis (A_KM); here K is a padded feature axis.
         }
@@ -357,7 +368,11 @@ static int launch_cfg(hipStream_t st, GemmArgs g, int* eff_split) {
     if (g.sq_count) *g.sq_count = (int)(grid.x * grid.y) * 4;
   }
   const int mode = (g.a_kmajor ? 2 : 0) | (g.b_nmajor ? 1 : 0);
-  if (g.use_xform) {
+  if (g.use_xform && g.xf.u16) {
+    if (mode == 0) hipLaunchKernelGGL((gemm_kernel<WM, WN, WK, 0, 0, 2>), grid, block, 0, st, g);
+    else if (mode == 2) hipLaunchKernelGGL((gemm_kernel<WM, WN, WK, 1, 0, 2>), grid, block, 0, st, g);
+    else { set_error("gemm: gather transform only with k-major B"); return SMX_ERR_INVALID; }
+  } else if (g.use_xform) {
     if (mode == 0) hipLaunchKernelGGL((gemm_kernel<WM, WN, WK, 0, 0, 1>), grid, block, 0, st, g);
     else if (mode == 2) hipLaunchKernelGGL((gemm_kernel<WM, WN, WK, 1, 0, 1>), grid, block, 0, st, g);
     else { set_error("gemm: gather transform only with k-major B"); return SMX_ERR_INVALID; }
@@ -443,10 +458,11 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
   // The grouped kernel carries the register budget of its widest variant (2 workgroups per CU).  That is free
   // while the whole group fits the chip in about one wave of workgroups; wide problems (gene panels of 20 000)
   // run faster as separate launches with their own occupancy.
-  bool has_epi = false;
-  for (int i = 0; i < n; ++i) has_epi |= (G.p[i].epi != 0);
+  bool has_epi = false, has_u16 = false;
+  for (int i = 0; i < n; ++i) { has_epi |= (G.p[i].epi != 0); has_u16 |= (G.p[i].use_xform && G.p[i].xf.u16); }
   static const bool split_all = getenv("SMX_SPLIT_GROUPS") != nullptr;
-  if (((total > 768 || n == 1) && !has_epi) || split_all) {   // a lone product also runs leaner as its own kernel
+  // (the grouped kernel carries no uint16-store variant: those products keep their own launches)
+  if (((total > 768 || n == 1) && !has_epi) || split_all || has_u16) {   // a lone product also runs leaner as its own kernel
     for (int i = 0; i < n; ++i) {
       if (G.variant[i] == 11) {
         const GemmArgs& g = G.p[i];

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(HD_THREADS) void out_head_train_kernel(OutHeadArgs 
     xs[i] = 0.f;
     if (b < a.B) {
       const long src = a.rows ? a.rows[b] : b;
-      xs[i] = a.X[src * a.ldx + gene];
+      xs[i] = a.x_u16 ? (float)reinterpret_cast<const uint16_t*>(a.X)[src * a.ldx + gene] : a.X[src * a.ldx + gene];
     }
   }
 #pragma unroll

@@ -37,6 +37,7 @@ struct AXform {
   uint32_t cell_base = 0;
   const float* inj_mask = nullptr;  // injected multipliers [batch][ld]
   int inj_ld = 0;
+  int u16 = 0;                      // A is the compact resident store: uint16 counts, same row pitch in elements
 };
 
 // Epilogue of the d z = dpre * W_dec^T product: the latent head's backward is elementwise in (cell, dim),
@@ -86,6 +87,7 @@ struct LossArgs {
   int direct = 0;       // planes already activated (scvi)
   int backward = 1;
   const float* X = nullptr; int ldx = 0;  // counts [rows][ldx]
+  int x_u16 = 0;                          // X is uint16 (compact resident store)
   const int32_t* rows = nullptr;          // gather (nullptr: identity)
   const float* P = nullptr;               // planes: plane c of cell b at P + b*ldp + c*plane_stride
   long ldp = 0; long plane_stride = 0;
@@ -302,7 +304,7 @@ struct OutHeadArgs {
   const float* H = nullptr; int ldh = 0;          // decoder output [B][ldh] (after BN / ReLU / dropout)
   const float* W = nullptr; int ldw = 0;          // [Hp][k * Gp]
   const float* bias = nullptr;                    // [k * Gp]
-  const float* X = nullptr; int ldx = 0; const int32_t* rows = nullptr;
+  const float* X = nullptr; int ldx = 0; const int32_t* rows = nullptr; int x_u16 = 0;
   float* dP = nullptr; long ldp = 0; long plane_stride = 0;
   float* dW = nullptr; float* db = nullptr;       // gradient tensors, laid out as W / bias
   float* llk_part = nullptr; int n_chunks = 0;    // [B][n_chunks], n_chunks = out_head_chunks(Gp)
@@ -317,13 +319,13 @@ int launch_out_head_train(hipStream_t st, const OutHeadArgs& a);
 // ---- dataset kernels (smx_data.hip) ------------------------------------------------------------
 enum { ST_CORRUPT_SELECT = 80, ST_CORRUPT_BINOMIAL = 81 };   // Philox streams of the on-device corruption
 struct CorruptArgs {
-  float* X = nullptr; long ld = 0; long N = 0; int G = 0;
+  float* X = nullptr; long ld = 0; long N = 0; int G = 0; int u16 = 0;   // u16: X is uint16_t*
   uint32_t k0 = 0, k1 = 0, cell_base = 0;
   uint64_t prefix = 0;                  // radix-select prefix (hist passes) / threshold key (apply)
   uint64_t thr_binom = 0;               // floor(retain_rate * 2^32)
   unsigned long long* hist = nullptr;   // [256] byte histogram (hist passes) / [1] corrupted-entry counter (apply)
 };
-int launch_row_stats(hipStream_t st, const float* X, long ld, long N, int G, float* lgx1, double* logcount);
+int launch_row_stats(hipStream_t st, const float* X, int u16, long ld, long N, int G, float* lgx1, double* logcount);
 int launch_library_stats(hipStream_t st, const double* logcount, long N, double* stats, float* library);
 int launch_corrupt_hist(hipStream_t st, const CorruptArgs& a, int pass);
 int launch_corrupt_apply(hipStream_t st, const CorruptArgs& a);

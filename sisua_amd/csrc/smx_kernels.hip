@@ -39,7 +39,7 @@ __device__ inline void vstore(float* p, const float (&v)[VEC]) {
   *reinterpret_cast<typename VecT<VEC>::T*>(p) = t;
 }
 
-template <int LK, int DIRECT, int BWD, int VEC, int BLOCK = 256>
+template <int LK, int DIRECT, int BWD, int VEC, int BLOCK = 256, int U16 = 0>   // U16: counts from the compact uint16 store
 __global__ __launch_bounds__(BLOCK) void count_loss_kernel(LossArgs a) {
   constexpr int K = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
   const int b = blockIdx.y;
@@ -49,7 +49,14 @@ __global__ __launch_bounds__(BLOCK) void count_loss_kernel(LossArgs a) {
     const long src = a.rows ? a.rows[b] : b;
     float xs[VEC], a0[VEC], a1[VEC], a2[VEC];
     const float* pb = a.P + (long)b * a.ldp + g0;
-    vload<VEC>(a.X + src * a.ldx + g0, xs);
+    if (U16) {
+      const uint16_t* xh = reinterpret_cast<const uint16_t*>(a.X) + src * a.ldx + g0;
+      if (VEC == 4) { const ushort4 h = *reinterpret_cast<const ushort4*>(xh); xs[0] = h.x; xs[1 % VEC] = h.y; xs[2 % VEC] = h.z; xs[3 % VEC] = h.w; }
+      else if (VEC == 2) { const ushort2 h = *reinterpret_cast<const ushort2*>(xh); xs[0] = h.x; xs[1 % VEC] = h.y; }
+      else xs[0] = (float)xh[0];
+    } else {
+      vload<VEC>(a.X + src * a.ldx + g0, xs);
+    }
     vload<VEC>(pb, a0);
     vload<VEC>(pb + a.plane_stride, a1);
     if (K == 3) vload<VEC>(pb + 2 * a.plane_stride, a2);
@@ -82,6 +89,7 @@ __global__ __launch_bounds__(BLOCK) void count_loss_kernel(LossArgs a) {
 }
 
 static int g_loss_block = 0;
+// (the uint16-store variants exist for 256-thread workgroups only: SMX_LOSS_BLOCK is a float32-store diagnostic)
 static int loss_block() {
   if (!g_loss_block) {
     const char* e = getenv("SMX_LOSS_BLOCK");
@@ -108,7 +116,8 @@ template <int LK, int DIRECT>
 static void launch_loss_t(hipStream_t st, const LossArgs& a, dim3 grid) {
   const int v = loss_vec(a.B, a.Gp), blk = loss_block();
 #define SMX_LOSS_LAUNCH(B_, V_) do { \
-    if (blk == 1024) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 1024>), grid, dim3(1024), 0, st, a); \
+    if (a.x_u16) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 256, 1>), grid, dim3(256), 0, st, a); \
+    else if (blk == 1024) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 1024>), grid, dim3(1024), 0, st, a); \
     else if (blk == 512) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 512>), grid, dim3(512), 0, st, a); \
     else hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 256>), grid, dim3(256), 0, st, a); } while (0)
   if (a.backward) { if (v == 4) SMX_LOSS_LAUNCH(1, 4); else if (v == 2) SMX_LOSS_LAUNCH(1, 2); else SMX_LOSS_LAUNCH(1, 1); }
@@ -121,6 +130,7 @@ int launch_count_loss(hipStream_t st, const LossArgs& a) {
     set_error("count_loss: bad shapes");
     return SMX_ERR_INVALID;
   }
+  if (a.x_u16 && loss_block() != 256) { set_error("count_loss: SMX_LOSS_BLOCK is a float32-store diagnostic"); return SMX_ERR_INVALID; }
   dim3 grid(loss_grid_x(a.Gp, loss_vec(a.B, a.Gp)), a.B);
   if (getenv("SMX_LOSS_NOP")) { LossArgs b = a; b.likelihood = -atoi(getenv("SMX_LOSS_NOP")); launch_loss_t<SMX_LLK_ZINB, 0>(st, b, grid); return SMX_OK; }
   switch (a.likelihood) {

@@ -149,6 +149,7 @@ struct smx_model {
   hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
   bool forked = false;
   bool head_fused = false;
+  bool x_u16 = false;   // the resident matrix is stored as uint16 counts (smx_dataset_upload_u16)
   float* pinned = nullptr; size_t pinned_floats = 0;   // host staging for the parameter planes handed back by smx_forward / smx_decode
   // sum-of-squares slots written by the weight-gradient products (per-tensor clipnorm without a separate pass)
   float* sq_slots = nullptr; std::vector<int> sq_first, sq_count;   // this step's output head ran as the fused kernel (smx_head.hip)
@@ -296,6 +297,7 @@ struct Pass {
   int B = 0;
   const int32_t* rows = nullptr;   // device row ids into X (nullptr: identity on Xsrc)
   const float* Xsrc = nullptr;     // m->X or m->hostX
+  int x_u16 = 0;                   // Xsrc is the compact uint16 store (resident rows only)
   const float* lib = nullptr;      // library [..][2] matching Xsrc indexing
   const float* lgx1 = nullptr;
   uint32_t cell_base = 0;
@@ -319,7 +321,7 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     g.split_k = suggest_split_k(ps.B, L.out_p, L.in_p);
     if (i == 0 && in_is_x) {
       g.use_xform = 1;
-      g.xf.rows = ps.rows; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
+      g.xf.rows = ps.rows; g.xf.u16 = ps.x_u16; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
       if (ps.training && m->cfg.input_dropout > 0.f) {
         g.xf.drop_p = m->cfg.input_dropout; g.xf.drop_scale = 1.f / (1.f - m->cfg.input_dropout);
         g.xf.nk = make_key(m, ST_INPUT_DROPOUT, ps.sample, true);
@@ -427,7 +429,7 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     want_sq(m, g, L.tW);
     if (first_x) {
       g.use_xform = 1;
-      g.xf.rows = ps.rows; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
+      g.xf.rows = ps.rows; g.xf.u16 = ps.x_u16; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
       if (ps.training && m->cfg.input_dropout > 0.f) {
         g.xf.drop_p = m->cfg.input_dropout; g.xf.drop_scale = 1.f / (1.f - m->cfg.input_dropout);
         g.xf.nk = make_key(m, ST_INPUT_DROPOUT, ps.sample, true);
@@ -671,7 +673,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   // ---- losses ----
   LossArgs lo;
   lo.likelihood = c.likelihood; lo.direct = m->scvi; lo.backward = backward;
-  lo.X = ps.Xsrc; lo.ldx = m->Gp; lo.rows = ps.rows;
+  lo.X = ps.Xsrc; lo.x_u16 = ps.x_u16; lo.ldx = m->Gp; lo.rows = ps.rows;
   lo.P = m->P; lo.ldp = ldp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
   lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = -inv_gb;
   int n_llk_chunks = loss_chunks(m->Gp, ps.B);
@@ -680,7 +682,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     const TensorInfo& tw = m->tensors[m->t_outW[0]];
     OutHeadArgs oh;
     oh.H = dL.out_buf; oh.ldh = dL.out_p; oh.W = P_(m, m->t_outW[0]); oh.ldw = tw.ld; oh.bias = P_(m, m->t_outb[0]);
-    oh.X = ps.Xsrc; oh.ldx = m->Gp; oh.rows = ps.rows;
+    oh.X = ps.Xsrc; oh.x_u16 = ps.x_u16; oh.ldx = m->Gp; oh.rows = ps.rows;
     oh.dP = m->dP; oh.ldp = ldp; oh.plane_stride = m->Gp;
     oh.dW = G_(m, m->t_outW[0]); oh.db = G_(m, m->t_outb[0]);
     oh.llk_part = m->llk_part; oh.n_chunks = n_llk_chunks = out_head_chunks(m->Gp);
@@ -762,7 +764,7 @@ int backward_mid(smx_model* m, const Pass& ps, int n_slabs) {
     want_sq(m, g, tW);
     if (xform) {
       g.use_xform = 1;
-      g.xf.rows = ps.rows; g.xf.log1p = c.log_norm; g.xf.cell_base = ps.cell_base;
+      g.xf.rows = ps.rows; g.xf.u16 = ps.x_u16; g.xf.log1p = c.log_norm; g.xf.cell_base = ps.cell_base;
       if (ps.training && c.input_dropout > 0.f) {
         g.xf.drop_p = c.input_dropout; g.xf.drop_scale = 1.f / (1.f - c.input_dropout);
         g.xf.nk = make_key(m, ST_INPUT_DROPOUT, ps.sample, true);
@@ -979,7 +981,7 @@ int optimizer_pass(smx_model* m) {
 //   prepare_next: the optimiser kernel prepares the other parity's state + row ids for the step after
 int train_sequence(smx_model* m, int B, bool with_begin, bool begin_from_master, uint32_t cursor, bool prepare_next) {
   Pass ps;
-  ps.B = B; ps.rows = cur_rows(m); ps.Xsrc = m->X; ps.lib = m->library; ps.lgx1 = m->lgx1;
+  ps.B = B; ps.rows = cur_rows(m); ps.Xsrc = m->X; ps.x_u16 = m->x_u16; ps.lib = m->library; ps.lgx1 = m->lgx1;
   ps.cell_base = (uint32_t)m->cell_base; ps.training = 1; ps.sample = 0; ps.global_batch = B * m->world;
   m->seq_batch = B; m->seq_prepare_next = prepare_next ? 1 : 0;
   Timed t(m, "step");
@@ -1406,8 +1408,21 @@ int smx_set_step(smx_model* m, int32_t step) {
   return SMX_OK;
 }
 
+static int dataset_upload_impl(smx_model* m, const void* X, bool u16, int64_t n_cells, const float* const* labels,
+                               const float* library, const uint8_t* label_mask, int64_t cell_id_base);
+
 int smx_dataset_upload(smx_model* m, const float* X, int64_t n_cells, const float* const* labels, const float* library,
                        const uint8_t* label_mask, int64_t cell_id_base) {
+  return dataset_upload_impl(m, X, false, n_cells, labels, library, label_mask, cell_id_base);
+}
+
+int smx_dataset_upload_u16(smx_model* m, const uint16_t* X, int64_t n_cells, const float* const* labels, const float* library,
+                           const uint8_t* label_mask, int64_t cell_id_base) {
+  return dataset_upload_impl(m, X, true, n_cells, labels, library, label_mask, cell_id_base);
+}
+
+static int dataset_upload_impl(smx_model* m, const void* X, bool u16, int64_t n_cells, const float* const* labels,
+                               const float* library, const uint8_t* label_mask, int64_t cell_id_base) {
   SMX_REQUIRE(m && X && n_cells > 0, "bad dataset");
   SMX_REQUIRE(n_cells < (int64_t)1 << 31, "row ids are int32");
   SMX_REQUIRE(!m->scvi || library, "scvi needs the library prior (scvi.py:100-105)");
@@ -1420,11 +1435,20 @@ int smx_dataset_upload(smx_model* m, const float* X, int64_t n_cells, const floa
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); m->Y[j] = nullptr; }
   m->N = n_cells; m->cell_base = cell_id_base;
   int rc;
-  if ((rc = dmalloc(&m->X, (size_t)n_cells * m->Gp)) || (rc = dmalloc(&m->lgx1, (size_t)n_cells))) return rc;
-  SMX_HIP(hipMemcpy2D(m->X, (size_t)m->Gp * sizeof(float), X, (size_t)m->G * sizeof(float), (size_t)m->G * sizeof(float),
-                      (size_t)n_cells, hipMemcpyHostToDevice));
+  m->x_u16 = u16;
+  if (u16) {   // compact store: uint16 counts, same row pitch in ELEMENTS (Gp), half the bytes
+    uint16_t* xh = nullptr;
+    if ((rc = dmalloc(&xh, (size_t)n_cells * m->Gp)) || (rc = dmalloc(&m->lgx1, (size_t)n_cells))) return rc;
+    m->X = reinterpret_cast<float*>(xh);
+    SMX_HIP(hipMemcpy2D(xh, (size_t)m->Gp * sizeof(uint16_t), X, (size_t)m->G * sizeof(uint16_t), (size_t)m->G * sizeof(uint16_t),
+                        (size_t)n_cells, hipMemcpyHostToDevice));
+  } else {
+    if ((rc = dmalloc(&m->X, (size_t)n_cells * m->Gp)) || (rc = dmalloc(&m->lgx1, (size_t)n_cells))) return rc;
+    SMX_HIP(hipMemcpy2D(m->X, (size_t)m->Gp * sizeof(float), X, (size_t)m->G * sizeof(float), (size_t)m->G * sizeof(float),
+                        (size_t)n_cells, hipMemcpyHostToDevice));
+  }
   // per-row constant sum_g lgamma(x+1) of the likelihood, on the device (one wave per row)
-  SMX_CHECK(launch_row_stats(m->st, m->X, m->Gp, m->N, m->G, m->lgx1, nullptr));
+  SMX_CHECK(launch_row_stats(m->st, m->X, m->x_u16 ? 1 : 0, m->Gp, m->N, m->G, m->lgx1, nullptr));
   for (int j = 0; j < m->cfg.n_labels; ++j) {
     const int P = m->cfg.label_dim[j], Pp = m->lab_Pp[j];
     if ((rc = dmalloc(&m->Y[j], (size_t)n_cells * Pp))) return rc;
@@ -1452,7 +1476,7 @@ int smx_dataset_library(smx_model* m, float stats[2]) {
   if ((rc = dmalloc(&work, (size_t)m->N + 2))) return rc;
   if (!m->library && (rc = dmalloc(&m->library, (size_t)m->N * 2))) { hipFree(work); return rc; }
   drop_graphs(m);   // a captured step may hold the old (null) library pointer
-  rc = launch_row_stats(m->st, m->X, m->Gp, m->N, m->G, m->lgx1, work);
+  rc = launch_row_stats(m->st, m->X, m->x_u16 ? 1 : 0, m->Gp, m->N, m->G, m->lgx1, work);
   if (rc == SMX_OK) rc = launch_library_stats(m->st, work, m->N, work + m->N, m->library);
   double h[2] = {0.0, 0.0};
   if (rc == SMX_OK) {
@@ -1476,7 +1500,7 @@ int smx_dataset_corrupt(smx_model* m, double dropout, double retain_rate, uint64
   int rc;
   if ((rc = dmalloc(&hist, 256))) return rc;
   CorruptArgs a;
-  a.X = m->X; a.ld = m->Gp; a.N = m->N; a.G = m->G;
+  a.X = m->X; a.ld = m->Gp; a.N = m->N; a.G = m->G; a.u16 = m->x_u16 ? 1 : 0;
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFu); a.k1 = (uint32_t)(seed >> 32); a.cell_base = (uint32_t)m->cell_base;
   a.hist = hist;
   a.thr_binom = (uint64_t)floor(retain_rate * 4294967296.0);
@@ -1509,7 +1533,7 @@ int smx_dataset_corrupt(smx_model* m, double dropout, double retain_rate, uint64
     hipError_t e = hipMemsetAsync(hist, 0, sizeof(unsigned long long), m->st);
     if (e == hipSuccess) rc = launch_corrupt_apply(m->st, a);
     // the per-row constant sum lgamma(x+1) follows the matrix
-    if (rc == SMX_OK) rc = launch_row_stats(m->st, m->X, m->Gp, m->N, m->G, m->lgx1, nullptr);
+    if (rc == SMX_OK) rc = launch_row_stats(m->st, m->X, m->x_u16 ? 1 : 0, m->Gp, m->N, m->G, m->lgx1, nullptr);
     if (rc == SMX_OK && e == hipSuccess) e = hipMemcpyAsync(h, hist, sizeof(unsigned long long), hipMemcpyDeviceToHost, m->st);
     if (rc == SMX_OK && e == hipSuccess) e = hipStreamSynchronize(m->st);
     if (e != hipSuccess) { set_error(std::string("dataset_corrupt failed: ") + hipGetErrorString(e)); rc = SMX_ERR_HIP; }
@@ -1523,7 +1547,12 @@ int smx_dataset_read(smx_model* m, int64_t row0, int64_t n_rows, float* X, float
   SMX_REQUIRE(m && m->X, "no resident dataset");
   SMX_REQUIRE(row0 >= 0 && n_rows > 0 && row0 + n_rows <= m->N, "rows out of range");
   SMX_HIP(hipStreamSynchronize(m->st));
-  if (X)
+  if (X && m->x_u16) {
+    std::vector<uint16_t> tmp((size_t)n_rows * m->G);
+    SMX_HIP(hipMemcpy2D(tmp.data(), (size_t)m->G * sizeof(uint16_t), reinterpret_cast<const uint16_t*>(m->X) + (size_t)row0 * m->Gp,
+                        (size_t)m->Gp * sizeof(uint16_t), (size_t)m->G * sizeof(uint16_t), (size_t)n_rows, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); ++i) X[i] = (float)tmp[i];
+  } else if (X)
     SMX_HIP(hipMemcpy2D(X, (size_t)m->G * sizeof(float), m->X + (size_t)row0 * m->Gp, (size_t)m->Gp * sizeof(float),
                         (size_t)m->G * sizeof(float), (size_t)n_rows, hipMemcpyDeviceToHost));
   if (row_const) SMX_HIP(hipMemcpy(row_const, m->lgx1 + row0, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToHost));
@@ -1560,14 +1589,14 @@ static int setup_pass(smx_model* m, Pass& ps, const int32_t* row_ids, const floa
   if (row_ids) {
     SMX_CHECK(check_rows(m, row_ids, (size_t)batch));
     SMX_HIP(hipMemcpyAsync(cur_rows(m), row_ids, (size_t)batch * sizeof(int32_t), hipMemcpyHostToDevice, m->st));
-    ps.rows = cur_rows(m); ps.Xsrc = m->X; ps.lib = m->library; ps.lgx1 = m->lgx1; ps.cell_base = (uint32_t)m->cell_base;
+    ps.rows = cur_rows(m); ps.Xsrc = m->X; ps.x_u16 = m->x_u16; ps.lib = m->library; ps.lgx1 = m->lgx1; ps.cell_base = (uint32_t)m->cell_base;
   } else {
     SMX_REQUIRE(host_x, "need row_ids or host_x");
     SMX_REQUIRE(!m->scvi || host_library, "scvi needs host_library with host_x");
     SMX_HIP(hipMemsetAsync(m->hostX, 0, (size_t)batch * m->Gp * sizeof(float), m->st));
     SMX_HIP(hipMemcpy2DAsync(m->hostX, (size_t)m->Gp * sizeof(float), host_x, (size_t)m->G * sizeof(float),
                              (size_t)m->G * sizeof(float), (size_t)batch, hipMemcpyHostToDevice, m->st));
-    SMX_CHECK(launch_row_stats(m->st, m->hostX, m->Gp, batch, m->G, m->hostLgx1, nullptr));
+    SMX_CHECK(launch_row_stats(m->st, m->hostX, 0, m->Gp, batch, m->G, m->hostLgx1, nullptr));
     if (host_library) SMX_HIP(hipMemcpy(m->hostLib, host_library, (size_t)batch * 2 * sizeof(float), hipMemcpyHostToDevice));
     ps.rows = nullptr; ps.Xsrc = m->hostX; ps.lib = m->hostLib; ps.lgx1 = m->hostLgx1; ps.cell_base = 0;
   }
@@ -1689,7 +1718,7 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
     if (rc != SMX_OK) break;
     LossArgs lo;
     lo.likelihood = m->cfg.likelihood; lo.direct = m->scvi; lo.backward = 0;
-    lo.X = ps.Xsrc; lo.ldx = m->Gp; lo.rows = ps.rows;
+    lo.X = ps.Xsrc; lo.x_u16 = ps.x_u16; lo.ldx = m->Gp; lo.rows = ps.rows;
     lo.P = m->P; lo.ldp = (long)m->k * m->Gp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
     lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = 0.f;
     rc = launch_count_loss(m->st, lo);
@@ -1759,7 +1788,7 @@ int smx_score_llk(smx_model* m, const int32_t* row_ids, const float* host_x, con
         // j == 1: the count distribution under the zero-inflation wrapper (first two planes, no gate)
         lo.likelihood = (j == 0) ? lk : (lk == SMX_LLK_ZINB ? SMX_LLK_NB : SMX_LLK_NBD);
         lo.direct = m->scvi; lo.backward = 0;
-        lo.X = own ? ps.Xsrc : tX + plane * t; lo.ldx = m->Gp; lo.rows = own ? ps.rows : nullptr;
+        lo.X = own ? ps.Xsrc : tX + plane * t; lo.x_u16 = own ? ps.x_u16 : 0; lo.ldx = m->Gp; lo.rows = own ? ps.rows : nullptr;
         lo.P = m->P; lo.ldp = (long)m->k * m->Gp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
         lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = 0.f;
         rc = launch_count_loss(m->st, lo);

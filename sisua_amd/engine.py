@@ -144,8 +144,19 @@ class Engine:
     check(self.lib.smx_set_step(self._h, int(value)))
 
   # ---- data ----------------------------------------------------------------------
-  def upload(self, X, labels: Sequence[np.ndarray] = (), library=None, label_mask=None, cell_id_base: int = 0):
-    X = _f32(X)
+  def upload(self, X, labels: Sequence[np.ndarray] = (), library=None, label_mask=None, cell_id_base: int = 0,
+             storage: str = "f32"):
+    """Make the cells x genes matrix resident in HBM.  storage='u16' keeps the counts as uint16 (half the bytes;
+    integer counts <= 65535 only), storage='f32' is the reference's dense float32 layout."""
+    if storage not in ("f32", "u16"):
+      raise ValueError("storage must be 'f32' or 'u16'")
+    if storage == "u16":
+      Xf = np.asarray(X)
+      if Xf.size and (Xf.min() < 0 or Xf.max() > 65535 or not np.array_equal(Xf, np.floor(Xf))):
+        raise ValueError("storage='u16' needs integer counts in [0, 65535]")
+      X = np.ascontiguousarray(Xf, dtype=np.uint16)
+    else:
+      X = _f32(X)
     if X.ndim != 2 or X.shape[1] != self.cfg.n_genes:
       raise ValueError(f"X must be [n_cells, {self.cfg.n_genes}]")
     n = X.shape[0]
@@ -155,9 +166,12 @@ class Engine:
     lab_ptrs = (C.POINTER(C.c_float) * max(1, len(labs)))(*[_fp(y) for y in labs]) if labs else None
     lib_arr = None if library is None else _f32(library, (n, 2))
     mask_arr = None if label_mask is None else np.ascontiguousarray(label_mask, dtype=np.uint8).reshape(n)
-    check(self.lib.smx_dataset_upload(self._h, _fp(X), n, lab_ptrs, _fp(lib_arr),
-                                      None if mask_arr is None else mask_arr.ctypes.data_as(C.POINTER(C.c_uint8)),
-                                      int(cell_id_base)))
+    mask_ptr = None if mask_arr is None else mask_arr.ctypes.data_as(C.POINTER(C.c_uint8))
+    if storage == "u16":
+      check(self.lib.smx_dataset_upload_u16(self._h, X.ctypes.data_as(C.POINTER(C.c_uint16)), n, lab_ptrs, _fp(lib_arr),
+                                            mask_ptr, int(cell_id_base)))
+    else:
+      check(self.lib.smx_dataset_upload(self._h, _fp(X), n, lab_ptrs, _fp(lib_arr), mask_ptr, int(cell_id_base)))
     self.n_cells = n
 
   # ---- steps -----------------------------------------------------------------------

@@ -101,3 +101,47 @@ def test_library_feeds_scvi_prior(Engine):
                             backward=False)
   assert np.isclose(got["kl_l"], ref["kl_l"].mean(), rtol=1e-4, atol=1e-5), (got["kl_l"], ref["kl_l"].mean())
   e.close()
+
+
+@pytest.mark.parametrize("model,likelihood", [("vae", "zinb"), ("scvi", "zinbd"), ("vae", "nb")])
+def test_u16_store_is_bit_identical_to_f32(Engine, model, likelihood):
+  """SURVEY 8f-2 compact count format: the uint16 resident store must give exactly the float32 results --
+  training trajectory, parameters, scoring, corruption, library statistics."""
+  x = synth_counts(400, 203, sparsity=0.8, seed=9, max_count=60000)
+  kw = dict(model=model, n_genes=203, likelihood=likelihood, enc_units=(32,), dec_units=(32,), latent_dim=6, input_dropout=0.2)
+  if model == "scvi":
+    kw["encl_units"] = (16,)
+  spec, cfg = make_pair(**kw)
+  _, lm, lv = so.library_size(x)
+  lib = np.tile(np.array([[lm, lv]], np.float32), (len(x), 1)) if model == "scvi" else None
+  outs = []
+  for storage in ("f32", "u16"):
+    e = Engine(cfg, max_batch=64)
+    e.upload(x, library=lib, cell_id_base=11, storage=storage)
+    order = (np.arange(64 * 5) * 7 % len(x)).astype(np.int32)
+    losses = [e.train_step(order[s * 64:(s + 1) * 64])["loss"] for s in range(5)]
+    rows = np.arange(40, dtype=np.int32)
+    mllk, _ = e.marginal_llk(row_ids=rows, n_samples=3)
+    n_cor = e.dataset_corrupt(0.3, 0.4, 5)
+    stats = e.dataset_library()
+    X, rc, lb = e.dataset_read(library=True)
+    after = e.train_step(order[:64])["loss"]
+    outs.append((losses, e.get_params(), mllk, n_cor, stats, X, rc, after))
+    e.close()
+  a, b = outs
+  assert a[0] == b[0] and a[7] == b[7]
+  for k in a[1]:
+    assert np.array_equal(a[1][k], b[1][k]), k
+  assert np.array_equal(a[2], b[2]) and a[3] == b[3] and a[4] == b[4]
+  assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
+
+
+def test_u16_store_rejects_what_it_cannot_hold(Engine):
+  x = synth_counts(50, 64, sparsity=0.5, seed=1)
+  _, e = _engine(Engine, x)
+  for bad in (x + 0.5, np.where(x > 0, 70000.0, 0.0).astype(np.float32), -x - 1):
+    with pytest.raises(ValueError):
+      e.upload(bad, storage="u16")
+  with pytest.raises(ValueError):
+    e.upload(x, storage="bf16")
+  e.close()
