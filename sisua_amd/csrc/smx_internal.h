@@ -131,6 +131,14 @@ struct BnFwdArgs {
 };
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a);
 
+// Per-step device-resident scalars.
+struct StepState {
+  uint32_t step;      // index of the step in flight (Philox counter word 2)
+  uint32_t next;      // master copy only: optimiser steps completed so far
+  float lr_t;         // bias-corrected Adam step size of the step in flight
+  uint32_t cursor;    // position (in steps) of the step in flight inside the uploaded row-id order
+};
+
 // ELBO scalars of a step; computed by one workgroup that rides along with another launch
 struct MetricsArgs {
   const float* llk_part = nullptr; int n_chunks = 0;   // [B][n_chunks]
@@ -141,6 +149,30 @@ struct MetricsArgs {
   float* out = nullptr;           // [8]: loss, nllk_x, nllk_y, kl, kl_l, (5..7 reserved)
 };
 int launch_metrics(hipStream_t st, const MetricsArgs& a);
+
+// Optimiser over the flat parameter buffer.
+#define SMX_MAX_TENSORS 48
+#define SMX_SQ_SMALL_TENSOR 65536   // floats: below this a workgroup re-derives the tensor's norm by itself
+struct OptChunk { int32_t tensor; int32_t offset; int32_t count; int32_t first_chunk; int32_t n_chunks; int32_t tensor_count; int32_t pad[2]; };
+struct AdamArgs {
+  // ELBO scalars ride along as one extra workgroup of the gradient-norm kernel
+  MetricsArgs metrics; int with_metrics = 0;
+  // the optimiser's workgroup 0 finishes the step: master counter, and the state + row ids of the next step
+  StepState* master = nullptr; StepState* next_state = nullptr; const int32_t* order = nullptr; int32_t* next_rows = nullptr;
+  int batch = 0, prepare_next = 0; float lr = 1e-3f;
+  float* params = nullptr; float* grads = nullptr; float* m = nullptr; float* v = nullptr;
+  const OptChunk* chunks = nullptr; int n_chunks = 0;
+  int n_launch = 0;             // chunks [0, n_launch) are applied by the optimiser launch (the rest rode along earlier)
+  float* partial = nullptr;     // [n_chunks] sum of squares per chunk
+  // norms without the separate pass (use_sq): per tensor either the slots the weight-gradient products wrote
+  // (sq_count > 0) or, for small tensors, a sweep of the tensor's gradient by every workgroup that needs it
+  int use_sq = 0; const float* sq_slots = nullptr; int sq_first[SMX_MAX_TENSORS]; int sq_count[SMX_MAX_TENSORS];
+  float* tensor_norm = nullptr; // [n_tensors] written by the update kernel (pre-clip norms)
+  const StepState* state = nullptr;
+  float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, clipnorm = 100.f;
+  float grad_scale = 1.f;       // 1/world after a sum all-reduce
+};
+int launch_adam(hipStream_t st, const AdamArgs& a);
 
 struct BnBwdArgs {
   const float* dout = nullptr; int n_slabs = 1; long slab_stride = 0; int ld = 0;  // d loss / d out slabs
@@ -153,6 +185,9 @@ struct BnBwdArgs {
   float* dgamma = nullptr; float* dbeta = nullptr; float* dbias = nullptr;
   // data parallel: the ELBO scalars must be in the flat buffer before the all-reduce -- one extra workgroup here
   MetricsArgs metrics; int with_metrics = 0;
+  // single GPU: the output / label heads' gradients are final before this launch, and this launch leaves most CUs
+  // idle -- adam_count extra workgroups apply the optimiser to chunks [adam_first, adam_first + adam_count)
+  AdamArgs adam; int adam_first = 0, adam_count = 0;
 };
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a);
 
@@ -215,13 +250,6 @@ struct LabelArgs {
 };
 int launch_label_loss(hipStream_t st, const LabelArgs& a);
 
-// Per-step device-resident scalars.
-struct StepState {
-  uint32_t step;      // index of the step in flight (Philox counter word 2)
-  uint32_t next;      // master copy only: optimiser steps completed so far
-  float lr_t;         // bias-corrected Adam step size of the step in flight
-  uint32_t cursor;    // position (in steps) of the step in flight inside the uploaded row-id order
-};
 // Prepares the per-step state `dst` (+ row ids) of the step at order position `cursor` from the master
 // counter.  Eager mode runs it once per train_steps call (later steps are prepared by the optimiser
 // kernel of the step before); graph mode runs it as the first node of every step.
@@ -229,28 +257,6 @@ int launch_step_begin(hipStream_t st, StepState* master, StepState* dst, const i
                       int batch, int cursor_from_master, uint32_t cursor, float lr, float b1, float b2);
 
 
-// Optimiser over the flat parameter buffer.
-#define SMX_MAX_TENSORS 48
-#define SMX_SQ_SMALL_TENSOR 65536   // floats: below this a workgroup re-derives the tensor's norm by itself
-struct OptChunk { int32_t tensor; int32_t offset; int32_t count; int32_t first_chunk; int32_t n_chunks; int32_t tensor_count; int32_t pad[2]; };
-struct AdamArgs {
-  // ELBO scalars ride along as one extra workgroup of the gradient-norm kernel
-  MetricsArgs metrics; int with_metrics = 0;
-  // the optimiser's workgroup 0 finishes the step: master counter, and the state + row ids of the next step
-  StepState* master = nullptr; StepState* next_state = nullptr; const int32_t* order = nullptr; int32_t* next_rows = nullptr;
-  int batch = 0, prepare_next = 0; float lr = 1e-3f;
-  float* params = nullptr; float* grads = nullptr; float* m = nullptr; float* v = nullptr;
-  const OptChunk* chunks = nullptr; int n_chunks = 0;
-  float* partial = nullptr;     // [n_chunks] sum of squares per chunk
-  // norms without the separate pass (use_sq): per tensor either the slots the weight-gradient products wrote
-  // (sq_count > 0) or, for small tensors, a sweep of the tensor's gradient by every workgroup that needs it
-  int use_sq = 0; const float* sq_slots = nullptr; int sq_first[SMX_MAX_TENSORS]; int sq_count[SMX_MAX_TENSORS];
-  float* tensor_norm = nullptr; // [n_tensors] written by the update kernel (pre-clip norms)
-  const StepState* state = nullptr;
-  float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, clipnorm = 100.f;
-  float grad_scale = 1.f;       // 1/world after a sum all-reduce
-};
-int launch_adam(hipStream_t st, const AdamArgs& a);
 
 // Small-layer fusions (smx_fused.hip): latent head GEMM + sample + KL; Dense + BN + ReLU + Dropout.
 bool latent_head_fusable(int K, int lat_ld, int Dp);

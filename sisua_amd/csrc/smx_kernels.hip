@@ -346,14 +346,20 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
 }
 
 __device__ inline void metrics_body(const MetricsArgs& a);
+__device__ inline void adam_chunk_body(const AdamArgs& a, int chunk);
 
 template <int RPT>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
   constexpr bool SMALL = RPT > 0;
   constexpr int BN_RPT = SMALL ? RPT : BN_RPT_DEFAULT;
-  if ((int)blockIdx.x == a.Hp / BN_COLS) {   // the extra workgroup (with_metrics): ELBO scalars, 256 threads
-    if (threadIdx.x < 256) metrics_body(a.metrics);
-    return;
+  {
+    const int nb = a.Hp / BN_COLS, extra = (int)blockIdx.x - nb;
+    if (extra >= 0) {
+      if (threadIdx.x >= 256) return;                   // the riders are 256-thread bodies
+      if (a.with_metrics && extra == 0) metrics_body(a.metrics);                          // ELBO scalars
+      else adam_chunk_body(a.adam, a.adam_first + extra - (a.with_metrics ? 1 : 0));      // optimiser chunks of the heads
+      return;
+    }
   }
   __shared__ float sh[BN_WAVES * BN_COLS];
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
@@ -414,7 +420,7 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
   BnBwdArgs a = a_in;
   if (bn_diag() & 4) a.n_slabs = 1;                       // diagnostic: one slab only
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_bwd: bad shapes"); return SMX_ERR_INVALID; }
-  const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0);
+  const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count;
   if (a.B <= BN_RL * 2) hipLaunchKernelGGL(bn_act_bwd_kernel<2>, dim3(grid), dim3(BN_THREADS), 0, st, a);
   else if (a.B <= BN_RL * 4) hipLaunchKernelGGL(bn_act_bwd_kernel<4>, dim3(grid), dim3(BN_THREADS), 0, st, a);
   else if (a.B <= BN_RL * 8) hipLaunchKernelGGL(bn_act_bwd_kernel<8>, dim3(grid), dim3(BN_THREADS), 0, st, a);
@@ -968,13 +974,10 @@ __global__ __launch_bounds__(256) void grad_sqsum_kernel(AdamArgs a) {
   if (threadIdx.x == 0) a.partial[blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
-  if ((int)blockIdx.x == a.n_chunks) {  // use_sq form: the ELBO scalars ride along here
-    metrics_body(a.metrics);
-    return;
-  }
+// clip + Adam for one chunk of the flat buffer; 256 threads
+__device__ inline void adam_chunk_body(const AdamArgs& a, int chunk) {
   __shared__ float sh[4];
-  const OptChunk ch = a.chunks[blockIdx.x];
+  const OptChunk ch = a.chunks[chunk];
   float s = 0.f;
   if (a.use_sq) {
     const int cnt = a.sq_count[ch.tensor];
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
   const float norm = sqrtf(s) * a.grad_scale;
   float clip = a.grad_scale;
   if (a.clipnorm > 0.f && norm > a.clipnorm) clip *= a.clipnorm / norm;
-  if (threadIdx.x == 0 && blockIdx.x == ch.first_chunk) a.tensor_norm[ch.tensor] = norm;
+  if (threadIdx.x == 0 && chunk == ch.first_chunk) a.tensor_norm[ch.tensor] = norm;
   const float lr_t = a.state->lr_t;
   const float4* g4 = reinterpret_cast<const float4*>(a.grads + ch.offset);
   float4* m4 = reinterpret_cast<float4*>(a.m + ch.offset);
@@ -1016,6 +1019,14 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
     v4[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
     p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
   }
+}
+
+__global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
+  if ((int)blockIdx.x == a.n_launch) {  // use_sq form: the ELBO scalars ride along here
+    metrics_body(a.metrics);
+    return;
+  }
+  adam_chunk_body(a, (int)blockIdx.x);
   if (blockIdx.x == 0 && a.master) {  // close the step; nobody reads next_state / next_rows during this step
     const uint32_t step = a.state->step, cur = a.state->cursor;
     if (a.prepare_next)
@@ -1036,12 +1047,12 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
 // an agent-scope acquire/release round across the 8 XCDs costs far more than a kernel boundary (1.5 us).
 int launch_adam(hipStream_t st, const AdamArgs& a) {
   if (a.use_sq) {   // norms come from the weight-gradient products: no pass over the gradient buffer
-    hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_chunks + (a.with_metrics ? 1 : 0)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_launch + (a.with_metrics ? 1 : 0)), dim3(256), 0, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
   hipLaunchKernelGGL(grad_sqsum_kernel, dim3(a.n_chunks + (a.with_metrics ? 1 : 0)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_chunks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_launch), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }

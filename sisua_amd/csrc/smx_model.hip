@@ -149,6 +149,9 @@ struct smx_model {
   hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
   bool forked = false;
   bool head_fused = false;
+  int chunk_first_head = 0;           // first optimiser chunk of the output / label heads (they are last in the table)
+  bool adam_early_pending = false;    // the heads' gradients are final: the next BatchNorm-backward launch may carry their update
+  int adam_early_from = -1;           // >= 0: chunks [adam_early_from, n_chunks) of this step were applied early
   bool x_u16 = false;   // the resident matrix is stored as uint16 counts (smx_dataset_upload_u16)
   float* pinned = nullptr; size_t pinned_floats = 0;   // host staging for the parameter planes handed back by smx_forward / smx_decode
   // sum-of-squares slots written by the weight-gradient products (per-tensor clipnorm without a separate pass)
@@ -389,6 +392,28 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
   return SMX_OK;
 }
 
+void fill_adam_args(smx_model* m, AdamArgs& a);
+bool dp_active(const smx_model* m);
+
+// Single GPU: once the head products have written dW / db of the output and label heads (3/4 of the parameters),
+// their clip + Adam update rides along with the next BatchNorm-backward launch, which leaves most CUs idle; the
+// optimiser launch at the end of the step then covers only the encoder / latent / decoder chunks.
+void attach_early_adam(smx_model* m, BnBwdArgs& b) {
+  if (!m->adam_early_pending) return;
+  m->adam_early_pending = false;
+  static const bool off = getenv("SMX_NO_ADAM_EARLY") != nullptr;
+  if (off || dp_active(m) || !m->sq_slots || m->chunk_first_head >= m->n_chunks || getenv("SMX_NO_SQ_PARTIALS") != nullptr) return;
+  for (size_t t = (size_t)m->t_outW[0]; t < m->tensors.size(); ++t)   // head tensors are the last ones of the manifest
+    if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) return;
+  fill_adam_args(m, b.adam);
+  b.adam.use_sq = 1;
+  for (size_t t = 0; t < m->tensors.size(); ++t) { b.adam.sq_first[t] = m->sq_first[t]; b.adam.sq_count[t] = m->sq_count[t]; }
+  b.adam.master = nullptr; b.adam.with_metrics = 0;
+  b.adam_first = m->chunk_first_head;
+  b.adam_count = m->n_chunks - m->chunk_first_head;
+  m->adam_early_from = m->chunk_first_head;
+}
+
 // ask the product that writes the gradient of tensor t for sum-of-squares partials
 void want_sq(smx_model* m, GemmArgs& g, int t) {
   if (!m->sq_slots || getenv("SMX_NO_SQ_PARTIALS") != nullptr) return;   // read per call: tests toggle it
@@ -416,6 +441,7 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
       if (m->metrics_before_allreduce && m->have_pending_metrics) {
         b.metrics = m->pending_metrics; b.with_metrics = 1; m->have_pending_metrics = false;
       }
+      attach_early_adam(m, b);
       Timed t(m, "bn_bwd");
       SMX_CHECK(launch_bn_act_bwd(m->st, b));
     }
@@ -748,6 +774,7 @@ int backward_mid(smx_model* m, const Pass& ps, int n_slabs) {
     if (m->metrics_before_allreduce && m->have_pending_metrics) {
       b.metrics = m->pending_metrics; b.with_metrics = 1; m->have_pending_metrics = false;
     }
+    attach_early_adam(m, b);
     Timed t(m, "bn_bwd");
     SMX_CHECK(launch_bn_act_bwd(m->st, b));
   }
@@ -799,6 +826,7 @@ int backward_mid(smx_model* m, const Pass& ps, int n_slabs) {
 int backward_pass(smx_model* m, const Pass& ps) {
   const smx_config& c = m->cfg;
   std::fill(m->sq_count.begin(), m->sq_count.end(), 0);   // the products of this step report what they wrote
+  m->adam_early_pending = false; m->adam_early_from = -1;
   const float inv_gb = 1.f / (float)ps.global_batch;
   const MlpLayer& dL = m->dec.back();
   const long ldp = (long)m->k * m->Gp;
@@ -872,6 +900,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
         SMX_CHECK(launch_gemm_group(m->st, grp.data() + i, n));
       }
     }
+    m->adam_early_pending = true;   // dW / db of every head are final now
     if (dp_overlap(m)) {  // head gradients are final: reduce them while the rest of backward runs
       SMX_HIP(hipEventRecord(m->ev_c1, m->st));
       SMX_HIP(hipStreamWaitEvent(m->st_comm, m->ev_c1, 0));
@@ -926,6 +955,23 @@ int backward_pass(smx_model* m, const Pass& ps) {
   return SMX_OK;
 }
 
+// everything of AdamArgs that does not depend on which launch carries the chunks
+void fill_adam_args(smx_model* m, AdamArgs& a) {
+  const smx_config& c = m->cfg;
+  a.params = m->params; a.grads = m->grads; a.m = m->adam_m; a.v = m->adam_v;
+  a.chunks = m->chunks; a.n_chunks = m->n_chunks; a.n_launch = m->n_chunks; a.partial = m->partial; a.tensor_norm = m->tensor_norm;
+  // norms from the products' partials when every large tensor has them (single GPU: under data parallelism the
+  // norm is that of the all-reduced gradient, which only a pass after the collective can give)
+  a.use_sq = (m->sq_slots != nullptr && !dp_active(m) && getenv("SMX_NO_SQ_PARTIALS") == nullptr) ? 1 : 0;
+  for (size_t t = 0; t < m->tensors.size() && a.use_sq; ++t) {
+    a.sq_first[t] = m->sq_first[t]; a.sq_count[t] = m->sq_count[t];
+    if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) a.use_sq = 0;
+  }
+  a.sq_slots = m->sq_slots;
+  a.state = cur_state(m); a.b1 = c.adam_beta1; a.b2 = c.adam_beta2; a.eps = c.adam_eps; a.clipnorm = c.clipnorm;
+  a.grad_scale = 1.f / (float)m->world;
+}
+
 int optimizer_pass(smx_model* m) {
   const smx_config& c = m->cfg;
   SMX_CHECK(side_join(m));
@@ -954,18 +1000,9 @@ int optimizer_pass(smx_model* m) {
     }
   }
   AdamArgs a;
-  a.params = m->params; a.grads = m->grads; a.m = m->adam_m; a.v = m->adam_v;
-  a.chunks = m->chunks; a.n_chunks = m->n_chunks; a.partial = m->partial; a.tensor_norm = m->tensor_norm;
-  // norms from the products' partials when every large tensor has them (single GPU: under data parallelism the
-  // norm is that of the all-reduced gradient, which only a pass after the collective can give)
-  a.use_sq = (m->sq_slots != nullptr && !dp_active(m) && getenv("SMX_NO_SQ_PARTIALS") == nullptr) ? 1 : 0;
-  for (size_t t = 0; t < m->tensors.size() && a.use_sq; ++t) {
-    a.sq_first[t] = m->sq_first[t]; a.sq_count[t] = m->sq_count[t];
-    if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) a.use_sq = 0;
-  }
-  a.sq_slots = m->sq_slots;
-  a.state = cur_state(m); a.b1 = c.adam_beta1; a.b2 = c.adam_beta2; a.eps = c.adam_eps; a.clipnorm = c.clipnorm;
-  a.grad_scale = 1.f / (float)m->world;
+  fill_adam_args(m, a);
+  a.n_launch = m->adam_early_from >= 0 ? m->adam_early_from : m->n_chunks;   // the head chunks may have ridden along already
+  m->adam_early_from = -1;
   if (m->have_pending_metrics) { a.metrics = m->pending_metrics; a.with_metrics = 1; m->have_pending_metrics = false; }
   a.master = master_state(m); a.lr = c.lr; a.batch = m->seq_batch;
   a.prepare_next = m->seq_prepare_next;
@@ -1276,6 +1313,9 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     }
   }
   m->n_chunks = (int)chunks.size();
+  m->chunk_first_head = m->n_chunks;
+  for (size_t i = 0; i < chunks.size(); ++i)
+    if (chunks[i].tensor == m->t_outW[0]) { m->chunk_first_head = (int)i; break; }
   if (m->tensors.size() <= SMX_MAX_TENSORS) {   // slots for the products' sum-of-squares partials (32 x 32 tiles at most)
     size_t total = 0;
     m->sq_first.assign(m->tensors.size(), 0);
