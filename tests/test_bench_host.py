@@ -1,0 +1,49 @@
+"""Host-side pieces of bench.py (no GPU): workload construction, the minibatch order, the contract of the
+JSON line's static fields."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+@pytest.mark.parametrize("workload,batch,model,lk", [("8kly", 128, "vae", "zinb"), ("8kly-2layer", 128, "vae", "zinb"),
+                                                      ("8kly-scvi", 256, "scvi", "nbd"), ("eccly-sisua", 256, "sisua", "zinb")])
+def test_workloads_follow_baseline_configs(workload, batch, model, lk):
+  cfg, xt, b, extra = bench.build_workload(0, 1, workload)
+  assert b == batch and cfg.model == model and cfg.likelihood == lk and cfg.n_genes == xt.shape[1]
+  assert xt.dtype == np.float32 and (xt >= 0).all() and np.array_equal(xt, np.floor(xt))
+  assert (xt.sum(1) > 0).all()                               # library size is the log of the total
+  if workload.startswith("8kly"):
+    assert xt.shape == (3381, 1998)                          # split(0.8) -> split(0.9) of 4697 cells
+    assert 0.90 < (xt == 0).mean() < 0.96
+  if model == "scvi":
+    assert extra["library"].shape == (xt.shape[0], 2)
+  if model == "sisua":
+    assert extra["labels"][0].shape[0] == xt.shape[0] and extra["label_mask"].shape == (xt.shape[0],)
+    assert 0.05 < extra["label_mask"].mean() < 0.15          # labels_percent = 0.1
+
+
+def test_ranks_get_different_shards_and_same_model():
+  c0, x0, _, _ = bench.build_workload(0, 2, "8kly")
+  c1, x1, _, _ = bench.build_workload(1, 2, "8kly")
+  assert c0 == c1 and x0.shape == x1.shape and not np.array_equal(x0, x1)
+
+
+def test_order_is_whole_batches_of_valid_rows():
+  order = bench.make_order(3381, 128, 57)
+  assert order.dtype == np.int32 and order.size == 57 * 128 and order.min() >= 0 and order.max() < 3381
+  first_epoch = order[: 26 * 128]
+  assert len(np.unique(first_epoch)) == first_epoch.size    # an epoch never repeats a cell
+
+
+def test_world_size_mismatch_is_refused():
+  env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+  r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+  assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
