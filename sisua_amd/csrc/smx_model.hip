@@ -425,7 +425,7 @@ void want_sq(smx_model* m, GemmArgs& g, int t) {
 // Leaves d(input of first layer) as slabs in m->slab unless skip_input_grad.
 int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
                  int n_slabs, bool skip_input_grad, int* out_slabs, const char* label_dw0,
-                 const EpiLatentBwd* lat_epi = nullptr) {
+                 const EpiLatentBwd* lat_epi = nullptr, GemmArgs* defer_dw0 = nullptr) {
   for (int i = (int)mlp.size() - 1; i >= 0; --i) {
     MlpLayer& L = mlp[i];
     const TensorInfo& tw = m->tensors[L.tW];
@@ -463,8 +463,11 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
       }
     }
     if (i == 0 && skip_input_grad) {
-      Timed t(m, first_x ? label_dw0 : "gemm_mlp_dw");
-      SMX_CHECK(launch_gemm(m->st, g));
+      if (defer_dw0) *defer_dw0 = g;   // the caller launches it (possibly grouped with another first-layer gradient)
+      else {
+        Timed t(m, first_x ? label_dw0 : "gemm_mlp_dw");
+        SMX_CHECK(launch_gemm(m->st, g));
+      }
       n_slabs = 0;
       break;
     }
@@ -931,7 +934,10 @@ int backward_pass(smx_model* m, const Pass& ps) {
     Timed t(m, "gemm_lat_bwd");
     SMX_CHECK(launch_gemm_group(m->st, pair, 2));
   }
-  SMX_CHECK(mlp_backward(m, m->enc, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_enc_dw"));
+  GemmArgs dw0[2];
+  int n_dw0 = 0;
+  SMX_CHECK(mlp_backward(m, m->enc, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_enc_dw", nullptr, &dw0[n_dw0]));
+  ++n_dw0;
   // ---- scvi library branch ----
   if (m->scvi) {
     LibLatentArgs ll;
@@ -944,13 +950,23 @@ int backward_pass(smx_model* m, const Pass& ps) {
     g.A = lL.out_buf; g.lda = lL.out_p; g.a_kmajor = 1; g.B = m->dlatl; g.ldb = 32;
     g.C = G_(m, m->t_latlW); g.ldc = tw.ld; g.M = lL.out_p; g.N = 32; g.K = ps.B; g.colsum = G_(m, m->t_latlb);
     want_sq(m, g, m->t_latlW);
-    SMX_CHECK(launch_gemm(m->st, g));
     GemmArgs h;
     h.A = m->dlatl; h.lda = 32; h.B = P_(m, m->t_latlW); h.ldb = tw.ld; h.b_nmajor = 1;
     h.C = m->slab; h.ldc = lL.out_p; h.slab_stride = (long)ps.B * lL.out_p;
     h.M = ps.B; h.N = lL.out_p; h.K = 32;
-    SMX_CHECK(launch_gemm(m->st, h));
-    SMX_CHECK(mlp_backward(m, m->encl, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_encl_dw"));
+    GemmArgs pair[2] = {g, h};   // weight and input gradient of the library head: independent, one grouped launch
+    SMX_CHECK(launch_gemm_group(m->st, pair, 2));
+    SMX_CHECK(mlp_backward(m, m->encl, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_encl_dw", nullptr, &dw0[n_dw0]));
+    ++n_dw0;
+  }
+  // the first-layer weight gradients (gather + log1p of the same resident rows) of the encoder and, for scvi,
+  // the library encoder are independent: one grouped launch
+  if (n_dw0 == 1) {
+    Timed t(m, "gemm_enc_dw");
+    SMX_CHECK(launch_gemm(m->st, dw0[0]));
+  } else if (n_dw0 == 2) {
+    Timed t(m, "gemm_enc_dw");
+    SMX_CHECK(launch_gemm_group(m->st, dw0, 2));
   }
   return SMX_OK;
 }
