@@ -692,7 +692,10 @@ def corrupt_binomial(x: np.ndarray, dropout: float = 0.2, retain_rate: float = 0
     return x
   rand = np.random.RandomState(seed=seed)
   i, j = np.nonzero(x)
-  ix = rand.choice(range(len(i)), size=int(np.floor(dropout * len(i))), replace=False)
+  n_sel = int(np.floor(dropout * len(i)))
+  if n_sel == 0:   # the reference's choice / fancy indexing fails on the empty selection; nothing to corrupt
+    return x
+  ix = rand.choice(range(len(i)), size=n_sel, replace=False)
   i, j = i[ix], j[ix]
   x[i, j] = rand.binomial(n=(x[i, j]).astype(np.int32), p=retain_rate)
   return x

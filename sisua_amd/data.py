@@ -38,7 +38,13 @@ def corrupt(x: np.ndarray, dropout_rate: float = 0.2, retain_rate: float = 0.2, 
     return out
   rand = np.random.RandomState(seed=seed)
   i, j = np.nonzero(x)
-  ix = rand.choice(range(len(i)), size=int(np.floor(dropout_rate * len(i))), replace=False)
+  n_sel = int(np.floor(dropout_rate * len(i)))
+  if n_sel == 0:   # nothing to corrupt (the reference's rand.choice / fancy indexing fails on this empty case)
+    if distribution not in ("binomial", "uniform"):
+      raise ValueError("Only support 2 corruption distribution: 'uniform' and 'binomial', "
+                       f"but given: '{distribution}'")
+    return out
+  ix = rand.choice(range(len(i)), size=n_sel, replace=False)
   i, j = i[ix], j[ix]
   if distribution == "binomial":
     vals = rand.binomial(n=(x[i, j]).astype(np.int32), p=retain_rate)
