@@ -30,12 +30,16 @@ __device__ inline void count_elem(float x, float p0, float p1, float p2, float& 
       mu = s0.sp; th = s1.sp; g0 = s0.sg; g1 = s1.sg;
     }
     const float e = 1e-8f;
-    const float lt = flog(th + mu + e), lth = flog(th + e);
-    const float inv = frcp(th + mu + e);
+    // log(th+e) - log(th+mu+e) = -log1p(mu / (th+e)) and th/(th+e) - th/(th+mu+e) = th mu / ((th+e)(th+mu+e)):
+    // written as differences of O(1) terms they lose everything for a large dispersion (th ~ 1e3 next to a
+    // small mean: the Poisson limit), and the error is then multiplied by th again through exp() in the scvi head
+    const float inv_te = frcp(th + e), inv = frcp(th + mu + e);
+    const float l1p = log1p_small(mu * inv_te);
+    const float lt = flog(th + mu + e);
     const LgDg t = lgamma_digamma_diff(x, th);
-    ell = th * (lth - lt) + x * (flog(mu + e) - lt) + t.lg;
+    ell = -th * l1p + x * (flog(mu + e) - lt) + t.lg;
     d0 = (-th * inv + x * frcp(mu + e) - x * inv) * g0;
-    d1 = (lth - lt + th * frcp(th + e) - th * inv - x * inv + t.dg) * g1;
+    d1 = (-l1p + th * mu * inv_te * inv - x * inv + t.dg) * g1;
   }
   if (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) {
     const SpSg sg = softplus_sigmoid(p2);

@@ -1,0 +1,93 @@
+"""Property tests (hypothesis) through the C-ABI on arbitrary small shapes: ragged products, ragged gene panels,
+odd layer widths and batch sizes.  Every example is checked against the oracle / NumPy."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import sisua_oracle as so
+from tests.util import grad_errors, make_pair, perturbed_params
+
+pytestmark = pytest.mark.gpu
+SET = settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+@pytest.fixture(scope="module")
+def eng():
+  from sisua_amd import engine
+  return engine
+
+
+@SET
+@given(M=st.integers(1, 200), N=st.integers(1, 300), K=st.integers(1, 600), layout=st.sampled_from([(False, False), (True, False), (False, True)]),
+       split=st.integers(1, 8), seed=st.integers(0, 10**6))
+def test_products_on_arbitrary_shapes(eng, M, N, K, layout, split, seed):
+  ta, tb = layout
+  rng = np.random.default_rng(seed)
+  A = rng.normal(size=(K, M) if ta else (M, K)).astype(np.float32)
+  B = rng.normal(size=(N, K) if tb else (K, N)).astype(np.float32)
+  ref = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)
+  out = eng.k_gemm(A, B, ta, tb, split_k=split, tile=0)
+  assert np.allclose(out, ref, rtol=2e-5, atol=2e-4 * np.sqrt(K)), (M, N, K, ta, tb, split, np.abs(out - ref).max())
+
+
+@SET
+@given(B=st.integers(1, 40), G=st.integers(1, 700), lk=st.sampled_from(so.LIKELIHOODS), seed=st.integers(0, 10**6), zero_frac=st.floats(0.0, 1.0))
+def test_count_likelihood_on_arbitrary_shapes(eng, B, G, lk, seed, zero_frac):
+  rng = np.random.default_rng(seed)
+  x = (rng.poisson(4.0, size=(B, G)) * (rng.uniform(size=(B, G)) >= zero_frac)).astype(np.float32)
+  k = 3 if lk.startswith("zi") else 2
+  planes = rng.uniform(-4, 4, size=(k, B, G)).astype(np.float32)
+  llk, grads = eng.k_count_llk(lk, x, planes)
+  ref_e, ref_g = so.count_llk(x.astype(np.float64), list(planes.astype(np.float64)), lk)
+  assert np.allclose(llk, ref_e.sum(1), rtol=2e-5, atol=2e-3), np.abs(llk - ref_e.sum(1)).max()
+  assert np.allclose(grads, np.stack(ref_g), rtol=2e-4, atol=2e-5)
+
+
+@SET
+@given(n=st.integers(1, 80), G=st.integers(1, 130), rate=st.floats(0.0, 0.95), retain=st.floats(0.0, 1.0), seed=st.integers(0, 2**40),
+       u16=st.booleans())
+def test_resident_matrix_kernels_on_arbitrary_shapes(eng, n, G, rate, retain, seed, u16):
+  rng = np.random.default_rng(seed % 2**32)
+  x = rng.poisson(1.2, size=(n, G)).astype(np.float32)
+  spec, cfg = make_pair(model="vae", n_genes=G, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=2)
+  e = eng.Engine(cfg, max_batch=8)
+  e.upload(x, cell_id_base=3, storage="u16" if u16 else "f32")
+  mean, var = e.dataset_library()
+  _, rm, rv = so.library_size(x)
+  assert np.isclose(mean, rm, rtol=1e-5, atol=1e-6) and np.isclose(var, rv, rtol=1e-4, atol=1e-6)
+  k = e.dataset_corrupt(rate, retain, seed)
+  ref, k_ref = so.corrupt_philox(x, rate, retain, seed, np.arange(n) + 3)
+  X, _ = e.dataset_read()
+  assert k == k_ref and np.array_equal(X, ref)
+  e.close()
+
+
+@settings(max_examples=12, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(G=st.integers(5, 150), H=st.integers(1, 70), H2=st.integers(1, 40), D=st.integers(1, 20), B=st.integers(2, 64),
+       model=st.sampled_from(["vae", "dca", "scvi"]), bn=st.booleans(), seed=st.integers(0, 10**6))
+def test_one_step_on_arbitrary_widths(eng, G, H, H2, D, B, model, bn, seed):
+  lk = "zinbd" if model == "scvi" else "zinb"
+  kw = dict(model=model, n_genes=G, likelihood=lk, enc_units=(H,), dec_units=(H2,), latent_dim=D, batchnorm=bn, seed=seed)
+  if model == "scvi":
+    kw["encl_units"] = (max(1, H // 2),)
+  spec, cfg = make_pair(**kw)
+  rng = np.random.default_rng(seed)
+  n = B + 5
+  x = (rng.poisson(3.0, size=(n, G)) * (rng.uniform(size=(n, G)) < 0.4)).astype(np.float32)
+  x[:, 0] += 1
+  _, lm, lv = so.library_size(x)
+  lib = np.tile(np.array([[lm, lv]], np.float32), (n, 1))
+  params = perturbed_params(spec)
+  bnst, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = eng.Engine(cfg, max_batch=B, init=False)
+  e.set_params(params)
+  e.upload(x, library=lib if model == "scvi" else None)
+  rows = rng.permutation(n)[:B].astype(np.int32)
+  res = so.train_step(spec, params, bnst, opt, x[rows], so.PhiloxNoise(spec.seed, 0, rows), library=lib[rows].astype(np.float64))
+  m = e.train_step(rows)
+  assert np.isclose(m["loss"], res["metrics"]["loss"], rtol=1e-4, atol=1e-5), (m["loss"], res["metrics"]["loss"])
+  # tiny layers make analytically-zero gradients common (a bias in front of BatchNorm): judge those on 1 % of the
+  # largest gradient norm
+  worst = grad_errors(e.get_params(which=1), res["grads"], floor_frac=1e-2)
+  assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  e.close()

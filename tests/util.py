@@ -50,8 +50,8 @@ def rel_l2(a, b, floor=1e-5):
   return d / max(np.linalg.norm(b), floor)
 
 
-def grad_errors(got, ref):
-  """Per-tensor relative L2 error; tensors whose true gradient is below 1e-3 of the largest
+def grad_errors(got, ref, floor_frac=1e-3):
+  """Per-tensor relative L2 error; tensors whose true gradient is below `floor_frac` of the largest
   gradient norm are judged on that absolute scale (fp32 rounding of an exact zero)."""
   top = max(np.linalg.norm(np.asarray(v, np.float64)) for v in ref.values())
-  return {k: rel_l2(got[k], ref[k], floor=max(1e-3 * top, 1e-5)) for k in got}
+  return {k: rel_l2(got[k], ref[k], floor=max(floor_frac * top, 1e-5)) for k in got}
