@@ -91,3 +91,38 @@ def test_one_step_on_arbitrary_widths(eng, G, H, H2, D, B, model, bn, seed):
   worst = grad_errors(e.get_params(which=1), res["grads"], floor_frac=1e-2)
   assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
   e.close()
+
+
+@SET
+@given(B=st.integers(1, 24), G=st.integers(1, 300), lk=st.sampled_from(["nbd", "zinbd"]), seed=st.integers(0, 10**6))
+def test_direct_mean_dispersion_over_wide_ranges(eng, B, G, lk, seed):
+  """The scvi head hands (rate, dispersion) already activated: rates down to 1e-6 next to dispersions up to 1e4
+  (the Poisson limit) and the reverse; gradients are judged on the scale of the largest entry of each plane."""
+  rng = np.random.default_rng(seed)
+  x = (rng.poisson(3.0, size=(B, G)) * (rng.uniform(size=(B, G)) < 0.5)).astype(np.float32)
+  mu = np.exp(rng.uniform(np.log(1e-6), np.log(1e3), size=(B, G)))
+  th = np.exp(rng.uniform(np.log(1e-3), np.log(1e4), size=(B, G)))
+  planes = [mu, th] + ([rng.uniform(-5, 5, size=(B, G))] if lk == "zinbd" else [])
+  planes32 = np.stack(planes).astype(np.float32)
+  llk, grads = eng.k_count_llk(lk, x, planes32, direct=True)
+  ref_e, ref_g = so.count_llk(x.astype(np.float64), list(planes32.astype(np.float64)), lk, direct=True)
+  assert np.allclose(llk, ref_e.sum(1), rtol=1e-4, atol=1e-2), np.abs(llk - ref_e.sum(1)).max()
+  for c in range(len(planes)):
+    # d/d(theta) is multiplied by theta again in the head (theta = exp(raw)): compare theta * d/d(theta)
+    scale = planes32[c].astype(np.float64) if c < 2 else 1.0
+    got, ref = grads[c] * scale, ref_g[c] * scale
+    assert np.allclose(got, ref, rtol=2e-3, atol=2e-4 * max(1.0, np.abs(ref).max())), (c, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+@SET
+@given(B=st.integers(1, 24), G=st.integers(1, 300), lk=st.sampled_from(["nb", "zinb"]), seed=st.integers(0, 10**6))
+def test_total_count_logits_over_wide_ranges(eng, B, G, lk, seed):
+  rng = np.random.default_rng(seed)
+  x = (rng.poisson(5.0, size=(B, G)) * (rng.uniform(size=(B, G)) < 0.5)).astype(np.float32)
+  planes = [rng.uniform(-9, 9, size=(B, G)), rng.uniform(-12, 12, size=(B, G))] + ([rng.uniform(-8, 8, size=(B, G))] if lk == "zinb" else [])
+  planes32 = np.stack(planes).astype(np.float32)
+  llk, grads = eng.k_count_llk(lk, x, planes32)
+  ref_e, ref_g = so.count_llk(x.astype(np.float64), list(planes32.astype(np.float64)), lk)
+  assert np.allclose(llk, ref_e.sum(1), rtol=1e-4, atol=1e-2), np.abs(llk - ref_e.sum(1)).max()
+  for c in range(len(planes)):
+    assert np.allclose(grads[c], ref_g[c], rtol=2e-3, atol=2e-4 * max(1.0, np.abs(ref_g[c]).max())), (c, np.abs(grads[c] - ref_g[c]).max())
