@@ -126,3 +126,75 @@ def test_total_count_logits_over_wide_ranges(eng, B, G, lk, seed):
   assert np.allclose(llk, ref_e.sum(1), rtol=1e-4, atol=1e-2), np.abs(llk - ref_e.sum(1)).max()
   for c in range(len(planes)):
     assert np.allclose(grads[c], ref_g[c], rtol=2e-3, atol=2e-4 * max(1.0, np.abs(ref_g[c]).max())), (c, np.abs(grads[c] - ref_g[c]).max())
+
+
+@settings(max_examples=15, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(G=st.integers(5, 120), H=st.integers(2, 48), D=st.integers(1, 12), B=st.integers(2, 70), P1=st.integers(1, 150), P2=st.integers(2, 90),
+       kinds=st.sampled_from([("nb",), ("onehot",), ("nb", "onehot"), ("onehot", "nb")]), pct=st.floats(0.0, 1.0), seed=st.integers(0, 10**6))
+def test_semi_supervised_step_on_arbitrary_label_widths(eng, G, H, D, B, P1, P2, kinds, pct, seed):
+  """SISUA label heads: label widths beyond one wave (P > 64), any mix of NB / one-hot heads, any labelled
+  fraction (all cells unlabelled and all labelled included)."""
+  dims = (P1, P2)[: len(kinds)]
+  labels = tuple((int(p), k) for p, k in zip(dims, kinds))
+  spec, cfg = make_pair(model="sisua", n_genes=G, likelihood="zinb", enc_units=(H,), dec_units=(H,), latent_dim=D, labels=labels, seed=seed)
+  rng = np.random.default_rng(seed)
+  n = B + 3
+  x = (rng.poisson(3.0, size=(n, G)) * (rng.uniform(size=(n, G)) < 0.4)).astype(np.float32)
+  x[:, 0] += 1
+  ys = []
+  for p, k in labels:
+    ys.append(np.eye(p, dtype=np.float32)[rng.integers(0, p, n)] if k == "onehot" else rng.uniform(0.5, 9.0, size=(n, p)).astype(np.float32))
+  mask = rng.uniform(size=n) < pct
+  params = perturbed_params(spec)
+  bnst, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = eng.Engine(cfg, max_batch=B, init=False)
+  e.set_params(params)
+  e.upload(x, ys, None, mask)
+  rows = rng.permutation(n)[:B].astype(np.int32)
+  res = so.train_step(spec, params, bnst, opt, x[rows], so.PhiloxNoise(spec.seed, 0, rows), y=[y[rows] for y in ys], mask=mask[rows])
+  m = e.train_step(rows)
+  for key in ("loss", "nllk_x", "nllk_y", "kl"):
+    assert np.isclose(m[key], res["metrics"][key], rtol=1e-4, atol=1e-4), (key, m[key], res["metrics"][key])
+  worst = grad_errors(e.get_params(which=1), res["grads"], floor_frac=1e-2)
+  assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  e.close()
+
+
+@settings(max_examples=12, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(G=st.integers(5, 120), H=st.integers(2, 40), D=st.integers(1, 10), B=st.integers(1, 48), S=st.integers(1, 5),
+       model=st.sampled_from(["vae", "scvi"]), seed=st.integers(0, 10**6), resident=st.booleans())
+def test_scoring_paths_on_arbitrary_shapes(eng, G, H, D, B, S, model, seed, resident):
+  """marginal_log_prob and the Posterior.cal_llk scores (SURVEY 8f-1) vs the oracle: any batch, draw count, width;
+  cells addressed as resident rows or handed over as a host batch."""
+  lk = "zinbd" if model == "scvi" else "zinb"
+  kw = dict(model=model, n_genes=G, likelihood=lk, enc_units=(H,), dec_units=(H,), latent_dim=D, seed=seed)
+  if model == "scvi":
+    kw["encl_units"] = (max(1, H // 2),)
+  spec, cfg = make_pair(**kw)
+  rng = np.random.default_rng(seed)
+  n = B + 4
+  x = (rng.poisson(3.0, size=(n, G)) * (rng.uniform(size=(n, G)) < 0.4)).astype(np.float32)
+  x[:, 0] += 1
+  x_org = x + rng.poisson(0.5, size=x.shape).astype(np.float32)
+  _, lm, lv = so.library_size(x)
+  lib = np.tile(np.array([[lm, lv]], np.float32), (n, 1))
+  params = perturbed_params(spec)
+  bnst = so.init_bn_state(spec)
+  e = eng.Engine(cfg, max_batch=B, init=False)
+  e.set_params(params)
+  e.upload(x, library=lib if model == "scvi" else None, cell_id_base=9)
+  rows = rng.permutation(n)[:B].astype(np.int32)
+  ids = rows + 9 if resident else np.arange(B)
+  libd = lib[rows].astype(np.float64)
+  ref_m, ref_l = so.marginal_log_prob(spec, params, bnst, x[rows], ids, S, library=libd)
+  ref_s = so.posterior_llk(spec, params, bnst, x[rows], ids, [x_org[rows], None], S, library=libd)
+  if resident:
+    got_m, got_l = e.marginal_llk(row_ids=rows, n_samples=S)
+    got_s = e.score_llk([x_org[rows], None], row_ids=rows, n_samples=S)
+  else:
+    got_m, got_l = e.marginal_llk(x=x[rows], library=lib[rows], n_samples=S)
+    got_s = e.score_llk([x_org[rows], None], x=x[rows], library=lib[rows], n_samples=S)
+  assert np.allclose(got_m, ref_m, rtol=1e-4, atol=2e-3), np.abs(got_m - ref_m).max()
+  assert np.allclose(got_l, ref_l, rtol=1e-4, atol=2e-3)
+  assert np.allclose(got_s, ref_s, rtol=1e-4, atol=2e-3), np.abs(got_s - ref_s).max()
+  e.close()
