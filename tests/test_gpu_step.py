@@ -400,3 +400,30 @@ def test_one_step_wide_gene_panel(Engine):
   assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
   assert np.isclose(m["grad_norm_max"], max(np.linalg.norm(g) for g in res["grads"].values()), rtol=1e-3)
   e.close()
+
+
+@pytest.mark.parametrize("batch", [300, 600, 1100])
+def test_one_step_large_batches(Engine, batch):
+  """BatchNorm keeps 2 / 4 / 8 / 16 rows per lane in registers (batch <= 1024) and falls back to the round trip
+  through memory beyond: batch 300 (8 rows), 600 (16 rows), 1100 (fallback) against the oracle."""
+  kw = dict(model="vae", n_genes=150, likelihood="zinb", enc_units=(40, 24), dec_units=(24,), latent_dim=6, input_dropout=0.1)
+  spec, cfg = make_pair(**kw)
+  n = batch + 50
+  x = synth_counts(n, 150, sparsity=0.8, seed=3)
+  params = perturbed_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = Engine(cfg, max_batch=batch, init=False)
+  e.set_params(params)
+  e.upload(x, cell_id_base=5)
+  rows = np.random.default_rng(2).permutation(n)[:batch].astype(np.int32)
+  res = so.train_step(spec, params, bn, opt, x[rows], so.PhiloxNoise(spec.seed, 0, rows + 5))
+  m = e.train_step(rows)
+  for key in ("loss", "nllk_x", "kl"):
+    assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
+  worst = grad_errors(e.get_params(which=1), res["grads"])
+  assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  names = [p for p, _ in so.bn_manifest(spec)]
+  for i, st in e.get_bn().items():
+    assert np.allclose(st["moving_mean"], bn[f"{names[i]}/moving_mean"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(st["moving_var"], bn[f"{names[i]}/moving_var"], rtol=1e-4, atol=1e-6)
+  e.close()
