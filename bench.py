@@ -239,7 +239,10 @@ def main():
         "kernel_us": per_kernel,
     }
     if world == 1 and not args.no_cpu_baseline:
-      out["cpu_baseline"] = cpu_baseline(cfg, xt, batch, args.cpu_budget, extra=extra)
+      try:
+        out["cpu_baseline"] = cpu_baseline(cfg, xt, batch, args.cpu_budget, extra=extra)
+      except Exception as err:   # the GPU line must not be lost to the host-side baseline (e.g. no compiler on the box)
+        out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port", "sample": f"failed: {err}"[:200]}
     print(json.dumps(out), flush=True)
   eng.close()
   cp.close()
