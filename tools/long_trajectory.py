@@ -25,4 +25,11 @@ for s in range(n_steps):
   rel.append(abs(got / ref - 1.0))
   if s in (0, 9, 49, 99, 199, 299, 499, 999) or s == n_steps - 1:
     print(f"step {s + 1:5d}: gpu {got:.5f} oracle {ref:.5f} rel {rel[-1]:.2e}  (max so far {max(rel):.2e})", flush=True)
+# latent means of 256 cells after training: eval-mode encoders of both (moving BatchNorm statistics, no dropout)
+rows = np.arange(256, dtype=np.int32)
+zm = np.concatenate([e.forward(row_ids=rows[i:i + batch], want_x_params=False)["z_mean"] for i in range(0, len(rows), batch)])
+ref = so.forward_backward(spec, params, bn, x64[rows], so.PhiloxNoise(spec.seed, 0, rows), training=False, backward=False)
+num = np.linalg.norm(zm - ref["z_mean"]); den = np.linalg.norm(ref["z_mean"])
+print(f"step {n_steps:5d}: latent means of 256 cells: rel-L2 {num / den:.2e}, max abs {np.abs(zm - ref['z_mean']).max():.2e} "
+      f"(|z_mean| up to {np.abs(ref['z_mean']).max():.2f})", flush=True)
 e.close()
