@@ -8,7 +8,7 @@ from scipy.special import expit
 
 from sisua_amd import distributions as D
 
-SET = settings(max_examples=60, deadline=None)
+SET = settings(max_examples=60, deadline=None, derandomize=True)
 
 
 @SET
