@@ -182,6 +182,16 @@ int smx_forward(smx_model* m, const int32_t* row_ids, const float* host_x, const
                 float* z_sample, float* l_mean, float* l_scale, float* l_sample, float* x_params,
                 float* const* y_params);
 
+/* n_samples Monte-Carlo draws of one batch in ONE call: SingleCellModel.predict(sample_shape=n) as
+ * Posterior._initialize uses it (sisua/analysis/posterior.py:172-182, sample_shape = 10).  The encoders run once (eval
+ * mode); draw s re-samples the latents with Philox sample index s and decodes -- the same numbers as n_samples calls of
+ * smx_forward(sample_index = s).  z_mean / z_scale [batch, D] and l_mean / l_scale [batch] once; z_samples
+ * [n_samples, batch, D]; l_samples [n_samples, batch]; x_params [n_samples, k, batch, n_genes]; y_params[j]
+ * [n_samples, batch, ky * P_j].  Any output may be NULL. */
+int smx_forward_samples(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,
+                        int32_t n_samples, float* z_mean, float* z_scale, float* z_samples, float* l_mean, float* l_scale,
+                        float* l_samples, float* x_params, float* const* y_params);
+
 /* Decoder only (SingleCellModel.decode, single_cell_model.py:141-151; scvi.py:108-171):
  * z [batch,D] (and l [batch] for scvi) -> the same x_params / y_params as smx_forward,
  * eval mode. */

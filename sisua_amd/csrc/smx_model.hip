@@ -1689,16 +1689,12 @@ static int fetch_planes(smx_model* m, int B, float* x_params) {
   return SMX_OK;
 }
 
-int smx_forward(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,
-                int32_t sample_index, int32_t training, float* z_mean, float* z_scale, float* z_sample, float* l_mean,
-                float* l_scale, float* l_sample, float* x_params, float* const* y_params) {
-  SMX_REQUIRE(m, "null model");
-  Pass ps;
-  SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, training, sample_index));
-  SMX_REQUIRE(!(training && !row_ids), "training-mode forward needs resident rows");
-  SMX_CHECK(forward_pass(m, ps, false, false));
+// copy the results of the forward pass in flight back to the caller's arrays (any pointer may be NULL);
+// y_off: element offset into every y_params[j] (draw index * batch * width)
+static int fetch_forward(smx_model* m, int B, float* z_mean, float* z_scale, float* z_sample, float* l_mean, float* l_scale,
+                         float* l_sample, float* x_params, float* const* y_params, size_t y_draw) {
   SMX_HIP(hipStreamSynchronize(m->st));
-  const int B = batch, D = m->D, Dp = m->Dp;
+  const int D = m->D, Dp = m->Dp;
   const int lat_ld = m->stochastic ? 2 * Dp : Dp;
   std::vector<float> tmp;
   auto fetch2d = [&](float* dst, const float* src, int ld, int w) -> int {
@@ -1720,12 +1716,43 @@ int smx_forward(smx_model* m, const int32_t* row_ids, const float* host_x, const
     for (int j = 0; j < m->cfg.n_labels; ++j) {
       if (!y_params[j]) continue;
       const int P = m->cfg.label_dim[j], Pp = m->lab_Pp[j], ld = m->tensors[m->t_labW[j]].ld;
+      float* dst = y_params[j] + y_draw * (size_t)B * m->lab_ky[j] * P;
       tmp.resize((size_t)B * ld);
       SMX_HIP(hipMemcpy(tmp.data(), m->laby_raw[j], tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
       for (int b = 0; b < B; ++b)
         for (int c = 0; c < m->lab_ky[j]; ++c)
-          memcpy(y_params[j] + ((size_t)b * m->lab_ky[j] + c) * P, &tmp[(size_t)b * ld + (size_t)c * Pp], sizeof(float) * P);
+          memcpy(dst + ((size_t)b * m->lab_ky[j] + c) * P, &tmp[(size_t)b * ld + (size_t)c * Pp], sizeof(float) * P);
     }
+  }
+  return SMX_OK;
+}
+
+int smx_forward(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,
+                int32_t sample_index, int32_t training, float* z_mean, float* z_scale, float* z_sample, float* l_mean,
+                float* l_scale, float* l_sample, float* x_params, float* const* y_params) {
+  SMX_REQUIRE(m, "null model");
+  Pass ps;
+  SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, training, sample_index));
+  SMX_REQUIRE(!(training && !row_ids), "training-mode forward needs resident rows");
+  SMX_CHECK(forward_pass(m, ps, false, false));
+  return fetch_forward(m, batch, z_mean, z_scale, z_sample, l_mean, l_scale, l_sample, x_params, y_params, 0);
+}
+
+int smx_forward_samples(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,
+                        int32_t n_samples, float* z_mean, float* z_scale, float* z_samples, float* l_mean, float* l_scale,
+                        float* l_samples, float* x_params, float* const* y_params) {
+  SMX_REQUIRE(m && n_samples > 0, "bad arguments");
+  Pass ps;
+  SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, 0, 0));
+  const size_t B = (size_t)batch;
+  for (int s = 0; s < n_samples; ++s) {
+    ps.sample = s;
+    // the encoders run once (eval mode: no noise in them); later draws re-sample the latents and decode
+    SMX_CHECK(forward_pass(m, ps, false, false, s == 0 ? 0 : 2));
+    SMX_CHECK(fetch_forward(m, batch, s == 0 ? z_mean : nullptr, s == 0 ? z_scale : nullptr,
+                            z_samples ? z_samples + (size_t)s * B * m->D : nullptr, s == 0 ? l_mean : nullptr,
+                            s == 0 ? l_scale : nullptr, l_samples ? l_samples + (size_t)s * B : nullptr,
+                            x_params ? x_params + (size_t)s * m->k * B * m->G : nullptr, y_params, (size_t)s));
   }
   return SMX_OK;
 }

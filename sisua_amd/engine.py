@@ -228,6 +228,33 @@ class Engine:
     out["y_params"] = ys
     return out
 
+  def forward_samples(self, n_samples: int, row_ids=None, x=None, library=None):
+    """n_samples Monte-Carlo draws of one batch in one call (the encoders run once): arrays with a leading draw axis
+    for z_sample / l_sample / x_params / y_params, one copy of the posterior means and scales."""
+    cfg = self.cfg
+    S = int(n_samples)
+    if row_ids is not None:
+      ids = self._ids(row_ids)
+      B, idp, xp, lp = ids.size, ids.ctypes.data_as(C.POINTER(C.c_int32)), None, None
+    else:
+      xa = _f32(x)
+      B, idp, xp = xa.shape[0], None, _fp(xa)
+      la = None if library is None else _f32(library, (B, 2))
+      lp = _fp(la)
+    D, G, k = cfg.latent_dim, cfg.n_genes, cfg.k
+    out = dict(z_mean=np.empty((B, D), np.float32), z_sample=np.empty((S, B, D), np.float32))
+    out["z_scale"] = np.empty((B, D), np.float32) if cfg.stochastic else None
+    if cfg.model == "scvi":
+      out.update(l_mean=np.empty((B,), np.float32), l_scale=np.empty((B,), np.float32), l_sample=np.empty((S, B), np.float32))
+    out["x_params"] = np.empty((S, k, B, G), np.float32)
+    ys = [np.empty((S, B, (2 if llk == "nb" else 1) * P), np.float32) for P, llk in cfg.labels]
+    yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
+    check(self.lib.smx_forward_samples(self._h, idp, xp, lp, B, S, _fp(out["z_mean"]), _fp(out.get("z_scale")),
+                                       _fp(out["z_sample"]), _fp(out.get("l_mean")), _fp(out.get("l_scale")),
+                                       _fp(out.get("l_sample")), _fp(out["x_params"]), yptrs))
+    out["y_params"] = ys
+    return out
+
   def decode(self, z, l=None):
     """Decoder + output heads from given latents (eval mode)."""
     cfg = self.cfg

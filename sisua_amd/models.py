@@ -375,6 +375,13 @@ class SingleCellModel:
       library = library_matrix(x)
     n = int(np.prod(sample_shape)) if np.size(sample_shape) else 0
     e = self._ensure_engine(x.shape[0])
+    if n > 1:   # every draw in one call: the encoders run once, the draws re-sample the latents and decode
+      o = e.forward_samples(n, x=x, library=library)
+      pX = self._output_dists([o["x_params"][s] for s in range(n)], [[y[s] for y in o["y_params"]] for s in range(n)])
+      first = dict(o, z_sample=o["z_sample"][0])
+      if "l_sample" in o:
+        first["l_sample"] = o["l_sample"][0]
+      return pX, self._latent_dists(first)
     outs = [e.forward(x=x, library=library, sample_index=s) for s in range(max(n, 1))]
     pX = self._output_dists([o["x_params"] for o in outs], [o["y_params"] for o in outs])
     return pX, self._latent_dists(outs[0])

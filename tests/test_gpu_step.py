@@ -427,3 +427,26 @@ def test_one_step_large_batches(Engine, batch):
     assert np.allclose(st["moving_mean"], bn[f"{names[i]}/moving_mean"], rtol=1e-4, atol=1e-6)
     assert np.allclose(st["moving_var"], bn[f"{names[i]}/moving_var"], rtol=1e-4, atol=1e-6)
   e.close()
+
+
+@pytest.mark.parametrize("name", ["vae_zinb", "scvi_zinbd", "sisua"])
+def test_forward_samples_equals_repeated_forward(Engine, name):
+  """smx_forward_samples (predict(sample_shape=n): encoders once, n re-sampled decodes) must return exactly what n
+  calls of smx_forward(sample_index=s) return, for resident rows and for a host batch."""
+  spec, cfg, x, ys, lib, mask = _problem(CASES[name])
+  e = Engine(cfg, max_batch=48)
+  e.upload(x, ys, lib, mask, cell_id_base=77)
+  rows = np.arange(5, 45, dtype=np.int32)
+  S = 4
+  for kw in (dict(row_ids=rows), dict(x=x[rows], library=lib[rows])):
+    many = e.forward_samples(S, **kw)
+    for s in range(S):
+      one = e.forward(sample_index=s, **kw)
+      assert np.array_equal(many["x_params"][s], one["x_params"]) and np.array_equal(many["z_sample"][s], one["z_sample"])
+      for a, b in zip(many["y_params"], one["y_params"]):
+        assert np.array_equal(a[s], b)
+      if spec.model == "scvi":
+        assert np.array_equal(many["l_sample"][s], one["l_sample"])
+    assert np.array_equal(many["z_mean"], one["z_mean"])
+    assert not np.array_equal(many["z_sample"][0], many["z_sample"][1])
+  e.close()
