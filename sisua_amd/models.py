@@ -353,14 +353,19 @@ class SingleCellModel:
       return [qz, ql]
     return qz
 
-  def _output_dists(self, xp_list, yp_list):
-    """xp_list: per-MC-sample x_params [k,B,G]; yp_list: per-sample list of label raw outputs."""
+  def _output_dists(self, xp_list, yp_list, stacked=False):
+    """xp_list: per-MC-sample x_params [k,B,G]; yp_list: per-sample list of label raw outputs.
+    stacked=True: xp_list is one array [S,k,B,G] and yp_list one array [S,B,w] per label head (views, no copies)."""
     cfg = self._cfg
-    stack = (lambda a: a[0]) if len(xp_list) == 1 else (lambda a: np.stack(a, 0))
-    planes = [stack([xp[c] for xp in xp_list]) for c in range(cfg.k)]
+    if stacked:
+      planes = [xp_list[:, c] for c in range(cfg.k)]
+      stack = None
+    else:
+      stack = (lambda a: a[0]) if len(xp_list) == 1 else (lambda a: np.stack(a, 0))
+      planes = [stack([xp[c] for xp in xp_list]) for c in range(cfg.k)]
     outs = [D.count_distribution(cfg.likelihood, planes, self._outputs[0].name or "transcriptomic", activated=cfg.model == "scvi")]
     for j, (P, kind) in enumerate(cfg.labels):
-      raw = stack([yp[j] for yp in yp_list])
+      raw = yp_list[j] if stacked else stack([yp[j] for yp in yp_list])
       nm = self._labels[j].name or f"label{j}"
       if kind == "nb":
         outs.append(D.Independent(D.NegativeBinomial(np.exp(raw[..., :P]), raw[..., P:]), 1, name=nm))
@@ -377,7 +382,7 @@ class SingleCellModel:
     e = self._ensure_engine(x.shape[0])
     if n > 1:   # every draw in one call: the encoders run once, the draws re-sample the latents and decode
       o = e.forward_samples(n, x=x, library=library)
-      pX = self._output_dists([o["x_params"][s] for s in range(n)], [[y[s] for y in o["y_params"]] for s in range(n)])
+      pX = self._output_dists(o["x_params"], o["y_params"], stacked=True)
       first = dict(o, z_sample=o["z_sample"][0])
       if "l_sample" in o:
         first["l_sample"] = o["l_sample"][0]
