@@ -161,7 +161,8 @@ int smx_train_step(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metr
 /* Same arithmetic, launched as one captured hipGraph (fixed batch size). */
 int smx_train_step_graph(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out);
 /* Queue `n_steps` steps whose row ids are order[s*batch .. (s+1)*batch); no host
- * sync between steps.  `out` (may be NULL) receives the last step's metrics. */
+ * sync between steps.  `out` (may be NULL) receives the last step's metrics; a non-finite loss or gradient
+ * norm is reported through out->nan_flag with status SMX_OK (terminate_on_nan is the caller's decision). */
 int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t batch, int use_graph,
                     smx_metrics* out);
 /* Validation loss: eval-mode forward (moving BN stats, no dropout) + ELBO, no
@@ -225,9 +226,25 @@ int smx_clear_noise(smx_model* m);
  * host (torch.distributed / a file store). */
 int smx_comm_unique_id(uint8_t id[128]);
 /* Join the communicator; afterwards every train step all-reduces the flat
- * gradient buffer (+ BN batch stats + metrics) once over xGMI. */
+ * gradient buffer (+ BN batch stats + metrics) once over xGMI.  The loss is scaled by 1 / (batch * world), so
+ * the summed buffer holds the gradient of the GLOBAL minibatch mean; smx_get_tensor(which = 1) returns it.
+ * On failure the model is left without a communicator (world 1) and SMX_ERR_COMM is returned. */
 int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]);
 int smx_comm_world(const smx_model* m);
+int smx_comm_rank(const smx_model* m);
+/* Which communication library the process is bound to, and the HIP runtime both it and this library run on
+ * (RCCL is resolved as the sibling of the loaded libamdhip64: ROCm's, or torch's bundled copy when torch was
+ * imported first; SMX_RCCL_PATH overrides).  rccl_version: ncclGetVersion code.  Any output may be NULL. */
+int smx_comm_library(char* rccl_path, int rccl_cap, char* hip_path, int hip_cap, int32_t* rccl_version);
+/* SyncBatchNorm (SURVEY.md 8e caveat i; opt-in): BatchNorm statistics over the GLOBAL minibatch, as the
+ * single-process reference computes them -- one extra all-reduce of [world][2][H] column statistics per
+ * BatchNorm layer forward and one backward.  Off (default): per-replica statistics, ONE all-reduce per step.
+ * Every rank must run the same batch size. */
+int smx_comm_set_sync_bn(smx_model* m, int on);
+/* Test hook: join n models of THIS process (one device; each driven by its own host thread) into a loopback
+ * communicator -- rank i = models[i].  Their steps all-reduce through events + a summing kernel instead of RCCL,
+ * so the world > 1 arithmetic of the step can be checked on a one-GPU box.  Eager launches only. */
+int smx_comm_init_local(smx_model* const* models, int n);
 
 /* ---- measurement ---------------------------------------------------------- */
 /* HIP-event timing of one named kernel class inside eager steps, on the model's
@@ -245,6 +262,12 @@ int64_t smx_loss_bytes_per_cell(const smx_model* m);
  * are (mean, dispersion, gate) (scvi.py:151-164). */
 int smx_k_count_llk(int likelihood, int direct, const float* x, const float* planes, int32_t B, int32_t G,
                     float* llk, float* grads);
+/* The optimiser launch by itself over caller-given tensors (per-tensor clipnorm + Adam, row a-16): n_tensors
+ * tensors of sizes[i] floats, concatenated in params / grads / m / v (host arrays; params, m, v updated in
+ * place).  step = the 1-based count t of this update (lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) is evaluated on the
+ * device as in a training step).  norms[n_tensors] (may be NULL): gradient norms before clipping. */
+int smx_k_adam(int32_t n_tensors, const int32_t* sizes, float* params, const float* grads, float* m, float* v,
+               int32_t step, float lr, float beta1, float beta2, float eps, float clipnorm, float* norms);
 /* C[M,N] = op(A) * op(B) in fp32 on the MFMA path; transA: A given as [K,M];
  * transB: B given as [N,K]; split_k >= 1 (slabs summed on return). */
 int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M, int32_t N, int32_t K,

@@ -673,6 +673,40 @@ def train_step(spec, params, bn_state, opt, x, noise, y=(), library=None, mask=N
   return res
 
 
+def dp_train_step(spec, params, bn_state, opt, x, rank_rows, step, cell_base=0, y=(), library=None, mask=None,
+                  sync_bn=False):
+  """Data-parallel contract of the HIP library (one optimiser step of `len(rank_rows)` replicas).
+
+  rank_rows[r] = row ids (into x / y / library / mask) of rank r's minibatch, equal sizes.  The noise of a cell is
+  keyed by its global id (`cell_base + row`), so it does not depend on the sharding.
+  * sync_bn=False (the library's default): every replica normalises with the statistics of ITS minibatch; the
+    loss is the mean over the global minibatch, so the reduced gradient is the mean of the replicas' gradients;
+    the moving statistics follow the mean of the replicas' batch statistics; metrics are global means.
+  * sync_bn=True: BatchNorm statistics over the global minibatch == the single-process step on the
+    concatenated minibatch (what the reference's single process computes, sisua/train.py:126-135).
+  Then per-tensor clipnorm (norm of the REDUCED gradient) + Adam, once.  Mutates params / bn_state / opt."""
+  rank_rows = [np.asarray(r) for r in rank_rows]
+  world = len(rank_rows)
+  assert len({len(r) for r in rank_rows}) == 1, "equal batch sizes on every rank"
+
+  def run(rows):
+    return forward_backward(spec, params, bn_state, x[rows], PhiloxNoise(spec.seed, step, rows + cell_base),
+                            y=[a[rows] for a in y], library=None if library is None else library[rows],
+                            mask=None if mask is None else mask[rows])
+
+  if sync_bn or not spec.batchnorm:
+    res = run(np.concatenate(rank_rows))
+    grads, new_bn, metrics = res["grads"], res["new_bn"], res["metrics"]
+  else:
+    parts = [run(rows) for rows in rank_rows]
+    grads = {k: sum(p_["grads"][k] for p_ in parts) / world for k in parts[0]["grads"]}
+    new_bn = {k: sum(p_["new_bn"][k] for p_ in parts) / world for k in parts[0]["new_bn"]}
+    metrics = {k: float(np.mean([p_["metrics"][k] for p_ in parts])) for k in parts[0]["metrics"]}
+  norms = adam_update(spec, params, grads, opt)
+  apply_bn_update(bn_state, new_bn)
+  return dict(grads=grads, metrics=metrics, loss=metrics["loss"], norms=norms, new_bn=new_bn)
+
+
 # --------------------------------------------------------------------------
 # Data-side semantics (host logic of the hot path's callers)
 # --------------------------------------------------------------------------

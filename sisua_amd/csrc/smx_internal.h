@@ -191,6 +191,12 @@ struct BnBwdArgs {
 };
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a);
 
+// SyncBatchNorm (smx_kernels.hip): phase 0 leaves this rank's column statistics in `gather` [world][2][Hp],
+// the caller all-reduces it, phase 1 finishes the pass with the global statistics.
+struct BnSyncArgs { float* gather = nullptr; int rank = 0, world = 1; };
+int launch_bn_sync_fwd(hipStream_t st, const BnFwdArgs& a, const BnSyncArgs& y, int phase);
+int launch_bn_sync_bwd(hipStream_t st, const BnBwdArgs& a, const BnSyncArgs& y, int phase);
+
 struct LatentArgs {
   int stochastic = 1, relu = 0, training = 1;
   const float* lat = nullptr; int ld = 0;   // [B][2*Dp] (mu | s_raw) or [B][Dp]

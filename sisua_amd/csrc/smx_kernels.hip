@@ -431,6 +431,146 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
 }
 
 // ===========================================================================
+// SyncBatchNorm (opt-in under data parallelism, SURVEY.md 8e caveat i): statistics over the GLOBAL minibatch.
+// Each BatchNorm pass is cut in two around one small all-reduce: the first launch leaves this rank's column
+// statistics in its own slot of a [world][2][Hp] buffer (zeros in the other slots, so that the sum all-reduce
+// is an all-gather), the second combines the slots in rank order -- Chan's pairwise form, no E[x^2] - E[x]^2
+// cancellation -- and finishes the pass.  Equal batch sizes on every rank.  Plain row loops: the values make the
+// round trip through xhat / dpre (the register-resident forms are for the single collective-free launch).
+// ===========================================================================
+__global__ __launch_bounds__(BN_THREADS) void bn_sync_stats_fwd_kernel(BnFwdArgs a, BnSyncArgs y) {
+  __shared__ float sh[BN_WAVES * BN_COLS];
+  const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
+  const int col = blockIdx.x * BN_COLS + c;
+  float s1 = 0.f;
+  for (int r0 = 0; r0 < a.B; r0 += BN_RL * 2) {
+    float acc[2];
+    slab_sum<2>(a.pre, a.n_slabs, a.slab_stride, a.ld, col, r0, rl, a.B, acc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = r0 + rl + BN_RL * i;
+      if (r < a.B) { a.xhat[(long)r * a.Hp + col] = acc[i]; s1 += acc[i]; }
+    }
+  }
+  s1 = bn_col_reduce(s1, sh);
+  const float mean = s1 / (float)a.B;
+  float s2 = 0.f;
+  for (int r = rl; r < a.B; r += BN_RL) { const float d = a.xhat[(long)r * a.Hp + col] - mean; s2 += d * d; }
+  s2 = bn_col_reduce(s2, sh);
+  if (rl == 0)
+    for (int r = 0; r < y.world; ++r) {
+      y.gather[((long)r * 2 + 0) * a.Hp + col] = r == y.rank ? mean : 0.f;
+      y.gather[((long)r * 2 + 1) * a.Hp + col] = r == y.rank ? s2 : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_sync_apply_fwd_kernel(BnFwdArgs a, BnSyncArgs y) {
+  const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
+  const int col = blockIdx.x * BN_COLS + c;
+  const bool live = col < a.H;
+  float mean = 0.f;
+  for (int r = 0; r < y.world; ++r) mean += y.gather[((long)r * 2) * a.Hp + col];
+  mean /= (float)y.world;
+  float m2 = 0.f;
+  for (int r = 0; r < y.world; ++r) {
+    const float d = y.gather[((long)r * 2) * a.Hp + col] - mean;
+    m2 += y.gather[((long)r * 2 + 1) * a.Hp + col] + (float)a.B * d * d;
+  }
+  const float var = m2 / ((float)a.B * (float)y.world);
+  const float inv = rsqrtf(var + a.eps);
+  const float gamma = live ? a.gamma[col] : 0.f, beta = live ? a.beta[col] : 0.f;
+  if (rl == 0) {
+    if (a.batch_mean) { a.batch_mean[col] = mean; a.batch_var[col] = var; }
+    if (a.inv_std) a.inv_std[col] = inv;
+  }
+  const bool drop = a.training && a.drop_p > 0.f;
+  const float scale = drop ? 1.f / (1.f - a.drop_p) : 1.f;
+  for (int r = rl; r < a.B; r += BN_RL) {
+    const long o = (long)r * a.Hp + col;
+    const float v = (a.xhat[o] - mean) * inv;
+    a.xhat[o] = v;
+    float h = fmaxf(gamma * v + beta, 0.f);
+    if (drop) {
+      float mult;
+      if (a.inj_mask) mult = a.inj_mask[(long)r * a.inj_ld + col];
+      else {
+        const uint32_t cell = a.cell_base + (uint32_t)(a.rows ? a.rows[r] : r);
+        mult = dropout_mult1(philox_block(a.nk, cell, (uint32_t)(col >> 2)), col & 3, a.drop_p, scale);
+      }
+      h *= mult;
+    }
+    a.out[o] = live ? h : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_sync_stats_bwd_kernel(BnBwdArgs a, BnSyncArgs y) {
+  __shared__ float sh[BN_WAVES * BN_COLS];
+  const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
+  const int col = blockIdx.x * BN_COLS + c;
+  const bool live = col < a.H;
+  float s1 = 0.f, s2 = 0.f;
+  for (int r0 = 0; r0 < a.B; r0 += BN_RL * 2) {
+    float acc[2];
+    slab_sum<2>(a.dout, a.n_slabs, a.slab_stride, a.ld, col, r0, rl, a.B, acc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = r0 + rl + BN_RL * i;
+      if (r < a.B) {
+        const long o = (long)r * a.Hp + col;
+        const float dy = (live && a.out[o] > 0.f) ? acc[i] * a.drop_scale : 0.f;
+        a.dpre[o] = dy;
+        s1 += dy;
+        s2 += dy * a.xhat[o];
+      }
+    }
+  }
+  s1 = bn_col_reduce(s1, sh);
+  s2 = bn_col_reduce(s2, sh);
+  if (rl == 0) {
+    // this rank's share of the parameter gradients: the gradient all-reduce sums the shares
+    a.dgamma[col] = live ? s2 : 0.f;
+    a.dbeta[col] = live ? s1 : 0.f;
+    for (int r = 0; r < y.world; ++r) {
+      y.gather[((long)r * 2 + 0) * a.Hp + col] = r == y.rank ? s1 : 0.f;
+      y.gather[((long)r * 2 + 1) * a.Hp + col] = r == y.rank ? s2 : 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_sync_apply_bwd_kernel(BnBwdArgs a, BnSyncArgs y) {
+  const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
+  const int col = blockIdx.x * BN_COLS + c;
+  const bool live = col < a.H;
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = 0; r < y.world; ++r) {
+    s1 += y.gather[((long)r * 2 + 0) * a.Hp + col];
+    s2 += y.gather[((long)r * 2 + 1) * a.Hp + col];
+  }
+  const float gamma = live ? a.gamma[col] : 0.f;
+  const float inv = a.inv_std[col];
+  const float invN = 1.f / ((float)a.B * (float)y.world);
+  for (int r = rl; r < a.B; r += BN_RL) {
+    const long o = (long)r * a.Hp + col;
+    a.dpre[o] = gamma * inv * (a.dpre[o] - invN * (s1 + a.xhat[o] * s2));
+  }
+}
+
+int launch_bn_sync_fwd(hipStream_t st, const BnFwdArgs& a, const BnSyncArgs& y, int phase) {
+  if (a.Hp % BN_COLS || a.B <= 0 || !a.batchnorm || !a.training || y.world < 1 || !y.gather) { set_error("bn_sync_fwd: bad arguments"); return SMX_ERR_INVALID; }
+  if (phase == 0) hipLaunchKernelGGL(bn_sync_stats_fwd_kernel, dim3(a.Hp / BN_COLS), dim3(BN_THREADS), 0, st, a, y);
+  else hipLaunchKernelGGL(bn_sync_apply_fwd_kernel, dim3(a.Hp / BN_COLS), dim3(BN_THREADS), 0, st, a, y);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+int launch_bn_sync_bwd(hipStream_t st, const BnBwdArgs& a, const BnSyncArgs& y, int phase) {
+  if (a.Hp % BN_COLS || a.B <= 0 || !a.batchnorm || !a.training || y.world < 1 || !y.gather) { set_error("bn_sync_bwd: bad arguments"); return SMX_ERR_INVALID; }
+  if (phase == 0) hipLaunchKernelGGL(bn_sync_stats_bwd_kernel, dim3(a.Hp / BN_COLS), dim3(BN_THREADS), 0, st, a, y);
+  else hipLaunchKernelGGL(bn_sync_apply_bwd_kernel, dim3(a.Hp / BN_COLS), dim3(BN_THREADS), 0, st, a, y);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// ===========================================================================
 // Latent head.  One wave per cell, lanes over latent dims.
 // ===========================================================================
 // one lane = 4 consecutive latent dims of one cell (one Philox block, 16-byte accesses); the Dp/4 lanes of a

@@ -12,13 +12,19 @@
 // Padded rows/columns of every weight stay exactly zero (their gradients are zero
 // by construction), so padded lanes never leak into logical results.
 #include <dlfcn.h>
+#include <limits.h>
 #include <math.h>
 #include <rccl/rccl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <chrono>
 #include <map>
 #include <string>
 #include <vector>
@@ -69,27 +75,73 @@ struct Injected { float* d = nullptr; int ld = 0; };
 
 struct RcclApi {
   void* lib = nullptr;
+  std::string path, hip_path;
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_rccl;
 
+std::string path_of_symbol(const void* sym) {
+  Dl_info info;
+  if (sym && dladdr(sym, &info) && info.dli_fname) {
+    char real[PATH_MAX];
+    return realpath(info.dli_fname, real) ? std::string(real) : std::string(info.dli_fname);
+  }
+  return "";
+}
+
+// RCCL is resolved DETERMINISTICALLY as the sibling of the HIP runtime this process actually runs on: a process
+// holds exactly one libamdhip64.so.7 (ROCm's, or the copy bundled with torch when torch was imported first -- same
+// soname), and the communication library must have been built against that one.  A bare dlopen("librccl.so.1")
+// would return whichever copy happens to be mapped already.  SMX_RCCL_PATH overrides; smx_comm_library() reports.
 int load_rccl() {
   if (g_rccl.lib) return SMX_OK;
-  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) { set_error(std::string("cannot load librccl: ") + dlerror()); return SMX_ERR_COMM; }
+  g_rccl.hip_path = path_of_symbol((const void*)&hipGetDeviceCount);
+  std::vector<std::string> cands;
+  if (const char* e = getenv("SMX_RCCL_PATH")) cands.push_back(e);
+  const size_t slash = g_rccl.hip_path.rfind('/');
+  if (slash != std::string::npos) {
+    const std::string dir = g_rccl.hip_path.substr(0, slash + 1);
+    cands.push_back(dir + "librccl.so.1");
+    cands.push_back(dir + "librccl.so");
+  }
+  cands.push_back("librccl.so.1");
+  cands.push_back("librccl.so");
+  void* h = nullptr;
+  std::string why;
+  for (const std::string& c : cands) {
+    if (c.find('/') != std::string::npos && access(c.c_str(), R_OK) != 0) continue;
+    h = dlopen(c.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+    why = dlerror();
+  }
+  if (!h) { set_error("cannot load librccl (looked beside " + g_rccl.hip_path + "): " + why); return SMX_ERR_COMM; }
   g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
   g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_rccl.GetVersion = (decltype(g_rccl.GetVersion))dlsym(h, "ncclGetVersion");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
     set_error("librccl lacks a required symbol");
+    dlclose(h);
     return SMX_ERR_COMM;
+  }
+  g_rccl.path = path_of_symbol((const void*)g_rccl.AllReduce);
+  // the bound RCCL must sit on the SAME HIP runtime as this library: two runtimes in one process do not share
+  // streams.  RCCL's own libamdhip64 dependency resolves by soname to the mapped copy, so it suffices that
+  // only one copy is mapped -- checked by asking the dynamic loader where RCCL's hipMalloc would come from.
+  if (void* sym = dlsym(h, "hipGetDeviceCount")) {   // found through RCCL's dependency chain
+    const std::string theirs = path_of_symbol(sym);
+    if (!theirs.empty() && !g_rccl.hip_path.empty() && theirs != g_rccl.hip_path) {
+      set_error("librccl (" + g_rccl.path + ") runs on " + theirs + " but libsisua_hip on " + g_rccl.hip_path);
+      dlclose(h);
+      return SMX_ERR_COMM;
+    }
   }
   g_rccl.lib = h;
   return SMX_OK;
@@ -138,6 +190,42 @@ __global__ __launch_bounds__(256) void iw_accum_kernel(IwArgs a) {
 __global__ void bn_moving_update_kernel(float* moving, const float* batch_sum, int n, float inv_world, float momentum) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) moving[i] = moving[i] * momentum + batch_sum[i] * inv_world * (1.f - momentum);
+}
+
+// ---- loopback communicator (test hook, smx_comm_init_local) -----------------------------------------------
+// N models of ONE process on ONE device, each driven by its own host thread, all-reduce their flat buffers through
+// events and a summing kernel instead of RCCL: the whole world > 1 arithmetic of the step (loss scaling by the
+// global batch, the norm of the reduced gradient, averaged moving statistics, SyncBatchNorm's mid-pass
+// collectives) runs on the single GPU of a test box.  Summation order is rank 0..N-1 on every rank.
+#define SMX_LOCAL_MAX 8
+struct LocalGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  int world = 0, arrived = 0;
+  uint64_t gen = 0;
+  bool broken = false;
+  const float* src[SMX_LOCAL_MAX] = {};          // this collective's source pointer of every rank
+  hipEvent_t ready[SMX_LOCAL_MAX] = {}, done[SMX_LOCAL_MAX] = {};
+  ~LocalGroup() {
+    for (int r = 0; r < SMX_LOCAL_MAX; ++r) { if (ready[r]) hipEventDestroy(ready[r]); if (done[r]) hipEventDestroy(done[r]); }
+  }
+  // host rendezvous of the member threads; false after a timeout (a member died) -- the group is then unusable
+  bool barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (broken) return false;
+    const uint64_t g0 = gen;
+    if (++arrived == world) { arrived = 0; ++gen; cv.notify_all(); return true; }
+    if (!cv.wait_for(lk, std::chrono::seconds(20), [&] { return gen != g0 || broken; }) || broken) { broken = true; cv.notify_all(); return false; }
+    return true;
+  }
+};
+struct LocalSrc { const float* p[SMX_LOCAL_MAX]; int n; };
+__global__ void local_sum_kernel(LocalSrc s, float* dst, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = s.p[0][i];
+    for (int r = 1; r < s.n; ++r) acc += s.p[r][i];
+    dst[i] = acc;
+  }
 }
 
 }  // namespace
@@ -198,6 +286,9 @@ struct smx_model {
   std::map<int, Injected> injected; bool use_injected = false;
   // comm
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
+  std::shared_ptr<LocalGroup> local; float* local_scratch = nullptr; size_t local_scratch_cap = 0;   // loopback communicator (tests)
+  // SyncBatchNorm (opt-in, smx_comm_set_sync_bn): per BN launch one small all-reduce of per-rank column statistics
+  bool sync_bn = false; float* sync_buf = nullptr; size_t sync_cap = 0;
   bool dp_force = false, dp_two_buckets = false;   // SMX_FORCE_ALLREDUCE / SMX_DP_BUCKETS=2, read when the communicator is attached
   hipStream_t st_comm = nullptr; hipEvent_t ev_c1 = nullptr, ev_c2 = nullptr, ev_c3 = nullptr;
   size_t bucket1_off = 0, bucket1_count = 0;   // gradients of the output / label heads: ready first, reduced early
@@ -309,6 +400,13 @@ struct Pass {
   int global_batch = 0;
 };
 
+void fill_adam_args(smx_model* m, AdamArgs& a);
+bool dp_active(const smx_model* m);
+int dp_allreduce_buf(smx_model* m, float* buf, size_t count, hipStream_t st);
+// SyncBatchNorm applies to training passes of a data-parallel job only (eval mode uses the moving statistics)
+bool sync_bn_on(const smx_model* m, int training) { return m->sync_bn && training && m->cfg.batchnorm && dp_active(m); }
+BnSyncArgs sync_args(smx_model* m) { BnSyncArgs y; y.gather = m->sync_buf; y.rank = m->rank; y.world = m->world; return y; }
+
 int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
                 const char* label0, int n_layers = -1) {
   const float* in = in0;
@@ -336,8 +434,10 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     static const bool no_fz = getenv("SMX_SMALL_FUSION") == nullptr;
     static const bool no_ahead = getenv("SMX_NO_NOISE_AHEAD") != nullptr;
     const bool ahead = !no_fz && !no_ahead && !m->scvi;
-    const bool fuse = !no_fz && !(i == 0 && in_is_x) && dense_bn_fusable(ps.B, L.in_p);
+    const bool sync = sync_bn_on(m, ps.training);
+    const bool fuse = !no_fz && !sync && !(i == 0 && in_is_x) && dense_bn_fusable(ps.B, L.in_p);
     int eff = 1;
+    SMX_REQUIRE((size_t)std::max(g.split_k, 1) * (size_t)g.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
     if (!fuse) {
       Timed t(m, (i == 0 && in_is_x) ? label0 : "gemm_mlp_fwd");
       SMX_CHECK(launch_gemm(m->st, g, &eff));
@@ -380,7 +480,15 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
       if (m->stochastic && !inj(m, ST_EPS_Z) && m->eps_ahead_ok) add(m->noise_eps, m->Dp, m->D, 1, 0.f, ST_EPS_Z);
       if (b.n_jobs) { b.nk.step_ptr = ps.training ? &cur_state(m)->step : nullptr; }
     }
-    if (fuse) {
+    if (sync) {
+      Timed t(m, "bn_fwd");
+      b.n_jobs = 0;
+      const BnSyncArgs y = sync_args(m);
+      SMX_REQUIRE((size_t)y.world * 2 * L.out_p <= m->sync_cap, "SyncBatchNorm buffer too small");
+      SMX_CHECK(launch_bn_sync_fwd(m->st, b, y, 0));
+      SMX_CHECK(dp_allreduce_buf(m, m->sync_buf, (size_t)y.world * 2 * L.out_p, m->st));
+      SMX_CHECK(launch_bn_sync_fwd(m->st, b, y, 1));
+    } else if (fuse) {
       Timed t(m, "dense_bn_fwd");
       SMX_CHECK(launch_dense_bn_act_fwd(m->st, in, ld, L.in_p, P_(m, L.tW), tw.ld, b));
     } else {
@@ -392,8 +500,6 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
   return SMX_OK;
 }
 
-void fill_adam_args(smx_model* m, AdamArgs& a);
-bool dp_active(const smx_model* m);
 
 // Single GPU: once the head products have written dW / db of the output and label heads (3/4 of the parameters),
 // their clip + Adam update rides along with the next BatchNorm-backward launch, which leaves most CUs idle; the
@@ -437,7 +543,14 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     b.dpre = L.dpre;
     if (m->cfg.batchnorm) { b.gamma = P_(m, L.tGamma); b.dgamma = G_(m, L.tGamma); b.dbeta = G_(m, L.tBeta); }
     else b.dbias = G_(m, L.tBias);
-    {
+    if (sync_bn_on(m, ps.training)) {   // the ELBO scalars then go with a launch of their own (optimizer_pass)
+      Timed t(m, "bn_bwd");
+      m->adam_early_pending = false;
+      const BnSyncArgs y = sync_args(m);
+      SMX_CHECK(launch_bn_sync_bwd(m->st, b, y, 0));
+      SMX_CHECK(dp_allreduce_buf(m, m->sync_buf, (size_t)y.world * 2 * L.out_p, m->st));
+      SMX_CHECK(launch_bn_sync_bwd(m->st, b, y, 1));
+    } else {
       if (m->metrics_before_allreduce && m->have_pending_metrics) {
         b.metrics = m->pending_metrics; b.with_metrics = 1; m->have_pending_metrics = false;
       }
@@ -477,6 +590,7 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     h.M = ps.B; h.N = L.in_p; h.K = L.out_p;
     h.C = m->slab; h.ldc = L.in_p; h.slab_stride = (long)ps.B * L.in_p;
     h.split_k = suggest_split_k(ps.B, L.in_p, L.out_p);
+    SMX_REQUIRE((size_t)h.split_k * (size_t)h.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
     if (i == 0 && lat_epi) {  // d z feeds the latent head only: run its backward in the epilogue
       h.epi = 2; h.lb = *lat_epi; h.split_k = 1; h.tile = TILE_32x32_K4;
     }
@@ -514,22 +628,47 @@ int side_join(smx_model* m) {
 
 // data-parallel overlap: two buckets on a communication stream (eager launches only)
 bool dp_active(const smx_model* m) {
-  return m->comm && (m->world > 1 || m->dp_force);   // dp_force: exercise RCCL on a 1-rank communicator (tests)
+  // dp_force: exercise RCCL on a 1-rank communicator (tests); local: the loopback communicator of the tests
+  return (m->comm && (m->world > 1 || m->dp_force)) || (m->local && m->world > 1);
 }
 // Measured on a 1-rank communicator: the cross-stream events of the two-bucket form cost +42 us per step,
 // one all-reduce on the model's own stream +2.6 us.  The overlap only pays when the collective itself is
 // much longer than that, so the default is the single all-reduce; SMX_DP_BUCKETS=2 selects the overlap.
 bool dp_overlap(const smx_model* m) {
-  return dp_active(m) && m->dp_two_buckets && !m->capturing && m->st_comm != nullptr;
+  return dp_active(m) && m->dp_two_buckets && !m->capturing && m->st_comm != nullptr && !m->local;
 }
-int dp_allreduce(smx_model* m, size_t off, size_t count, hipStream_t st) {
-  ncclResult_t r = g_rccl.AllReduce(m->grads + off, m->grads + off, count, ncclFloat32, ncclSum, m->comm, st);
+int local_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
+  LocalGroup& g = *m->local;
+  const int me = m->rank;
+  SMX_REQUIRE(count <= m->local_scratch_cap, "loopback all-reduce: scratch too small");
+  { std::lock_guard<std::mutex> lk(g.mu); g.src[me] = buf; }
+  SMX_HIP(hipEventRecord(g.ready[me], st));
+  if (!g.barrier()) { set_error("loopback communicator: a member did not arrive (timeout)"); return SMX_ERR_COMM; }
+  LocalSrc src;
+  src.n = g.world;
+  for (int r = 0; r < g.world; ++r) {
+    src.p[r] = g.src[r];
+    if (r != me) SMX_HIP(hipStreamWaitEvent(st, g.ready[r], 0));
+  }
+  const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, 2048);
+  hipLaunchKernelGGL(local_sum_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, m->local_scratch, count);
+  SMX_HIP(hipEventRecord(g.done[me], st));
+  if (!g.barrier()) { set_error("loopback communicator: a member did not arrive (timeout)"); return SMX_ERR_COMM; }
+  for (int r = 0; r < g.world; ++r)
+    if (r != me) SMX_HIP(hipStreamWaitEvent(st, g.done[r], 0));   // nobody still reads this rank's buffer
+  SMX_HIP(hipMemcpyAsync(buf, m->local_scratch, count * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return SMX_OK;
+}
+int dp_allreduce_buf(smx_model* m, float* buf, size_t count, hipStream_t st) {
+  if (m->local) return local_allreduce(m, buf, count, st);
+  ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclFloat32, ncclSum, m->comm, st);
   if (r != ncclSuccess) {
     set_error(std::string("ncclAllReduce failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
     return SMX_ERR_COMM;
   }
   return SMX_OK;
 }
+int dp_allreduce(smx_model* m, size_t off, size_t count, hipStream_t st) { return dp_allreduce_buf(m, m->grads + off, count, st); }
 
 // fused output head (product + likelihood + dW/db in one kernel): count heads with raw parameter planes.
 // Opt-in (SMX_OUT_FUSED=1): parity-green but not faster -- 16 genes x whole batch per workgroup gives only
@@ -545,7 +684,7 @@ bool use_fused_head(const smx_model* m, int B) {
 bool use_mid(const smx_model* m, int B) {
   // single-workgroup fusion of the middle is opt-in until it beats the per-operator path
   static const bool off = getenv("SMX_FUSED") == nullptr;
-  if (off || m->scvi || B > 128) return false;
+  if (off || m->scvi || B > 128 || m->sync_bn) return false;
   for (auto* mlp : {&m->enc, &m->dec})
     for (auto& L : *mlp) if (L.out_p > 128) return false;
   if ((m->stochastic ? 2 : 1) * m->Dp > 128) return false;
@@ -895,6 +1034,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
       }
       h.C = m->slab + (long)n_slabs * dd_stride;
       n_slabs += eff;
+      SMX_REQUIRE((size_t)n_slabs * (size_t)dd_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
     }
     {
       Timed t(m, "gemm_out_bwd");
@@ -985,7 +1125,9 @@ void fill_adam_args(smx_model* m, AdamArgs& a) {
   }
   a.sq_slots = m->sq_slots;
   a.state = cur_state(m); a.b1 = c.adam_beta1; a.b2 = c.adam_beta2; a.eps = c.adam_eps; a.clipnorm = c.clipnorm;
-  a.grad_scale = 1.f / (float)m->world;
+  // the likelihood / KL / label kernels already scale by 1 / (batch * world), so the SUM all-reduce leaves the
+  // global-mean gradient: nothing more to divide by (it used to be divided by world once more here)
+  a.grad_scale = 1.f;
 }
 
 int optimizer_pass(smx_model* m) {
@@ -1094,7 +1236,7 @@ int launch_train(smx_model* m, int B, bool use_graph, int s_idx, int n_steps) {
   // With a communicator the RCCL all-reduce is captured too (RCCL supports stream capture);
   // SMX_NO_GRAPH_COMM=1 or a failed capture falls back to eager launches for good.
   static const bool no_graph_comm = getenv("SMX_NO_GRAPH_COMM") != nullptr;
-  if (use_graph && !(m->comm && (no_graph_comm || m->graph_comm_failed)) && !m->use_injected && m->timing_label.empty()) {
+  if (use_graph && !m->local && !(m->comm && (no_graph_comm || m->graph_comm_failed)) && !m->use_injected && m->timing_label.empty()) {
     auto it = m->graphs.find(B);
     if (it == m->graphs.end()) {
       hipGraph_t graph = nullptr;
@@ -1360,7 +1502,10 @@ int smx_model_destroy(smx_model* m) {
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
   for (auto& ev : m->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
   if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
+  m->comm = nullptr;
+  m->local.reset();
   auto fr = [](void* p) { if (p) hipFree(p); };
+  fr(m->local_scratch); fr(m->sync_buf);
   fr(m->params); fr(m->grads); fr(m->adam_m); fr(m->adam_v); fr(m->bn_moving);
   for (auto* mlp : {&m->enc, &m->encl, &m->dec})
     for (auto& L : *mlp) { fr(L.xhat); fr(L.out_buf); fr(L.dpre); fr(L.inv_std); fr(L.noise); }
@@ -1410,7 +1555,7 @@ int smx_get_tensor(smx_model* m, int which, int index, float* host) {
   std::vector<float> dev(t.count);
   SMX_HIP(hipStreamSynchronize(m->st));
   SMX_HIP(hipMemcpy(dev.data(), base + t.offset, t.count * sizeof(float), hipMemcpyDeviceToHost));
-  unpack(t, dev, host, which == 1 ? 1.f / (float)m->world : 1.f);
+  unpack(t, dev, host, 1.f);
   return SMX_OK;
 }
 
@@ -1633,8 +1778,9 @@ int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t
   SMX_CHECK(upload_order(m, order, (size_t)n_steps * batch));
   for (int s = 0; s < n_steps; ++s) SMX_CHECK(launch_train(m, batch, use_graph != 0, s, n_steps));
   if (m->use_injected) { m->use_injected = false; }
+  // a non-finite loss / gradient norm is REPORTED (out->nan_flag), not an error of the call: terminate_on_nan
+  // (configs/base.yaml:59) is the caller's decision
   SMX_CHECK(read_metrics(m, out));
-  if (out && out->nan_flag) { set_error("non-finite loss or gradient norm"); return SMX_ERR_NAN; }
   return SMX_OK;
 }
 
@@ -1939,16 +2085,43 @@ int smx_comm_unique_id(uint8_t id[128]) {
   return SMX_OK;
 }
 
+static int comm_detach(smx_model* m) {   // leave whatever communicator the model is in
+  if (m->st) SMX_HIP(hipStreamSynchronize(m->st));
+  if (m->st_comm) SMX_HIP(hipStreamSynchronize(m->st_comm));
+  if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
+  m->comm = nullptr;
+  m->local.reset();
+  m->rank = 0; m->world = 1;
+  drop_graphs(m);
+  return SMX_OK;
+}
+
+static int ensure_sync_buf(smx_model* m) {
+  int wmax = 0;
+  for (int w : m->bn_wp) wmax = std::max(wmax, w);
+  const size_t need = (size_t)m->world * 2 * (size_t)wmax;
+  if (!m->sync_bn || need <= m->sync_cap) return SMX_OK;
+  if (m->sync_buf) hipFree(m->sync_buf);
+  m->sync_buf = nullptr; m->sync_cap = 0;
+  SMX_CHECK(dmalloc(&m->sync_buf, need));
+  m->sync_cap = need;
+  return SMX_OK;
+}
+
 int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]) {
-  SMX_REQUIRE(m && world >= 1 && rank >= 0 && rank < world, "bad rank/world");
+  SMX_REQUIRE(m && id && world >= 1 && rank >= 0 && rank < world, "bad rank/world");
   SMX_CHECK(load_rccl());
+  SMX_CHECK(comm_detach(m));
   ncclUniqueId uid;
   memcpy(&uid, id, 128);
-  ncclResult_t r = g_rccl.CommInitRank(&m->comm, world, uid, rank);
+  ncclComm_t comm = nullptr;
+  ncclResult_t r = g_rccl.CommInitRank(&comm, world, uid, rank);
   if (r != ncclSuccess) {
+    // RCCL may leave a half-built handle behind: it is NOT kept (smx_model_destroy must not hand it to CommDestroy)
     set_error(std::string("ncclCommInitRank failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
     return SMX_ERR_COMM;
   }
+  m->comm = comm;
   m->rank = rank; m->world = world;
   m->dp_force = getenv("SMX_FORCE_ALLREDUCE") != nullptr;
   m->dp_two_buckets = getenv("SMX_DP_BUCKETS") != nullptr && atoi(getenv("SMX_DP_BUCKETS")) == 2;
@@ -1961,10 +2134,61 @@ int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]) {
       return SMX_ERR_HIP;
     }
   }
+  SMX_CHECK(ensure_sync_buf(m));
   drop_graphs(m);
   return SMX_OK;
 }
 
+int smx_comm_init_local(smx_model* const* models, int n) {
+  SMX_REQUIRE(models && n >= 1 && n <= SMX_LOCAL_MAX, "loopback communicator: 1..8 models");
+  for (int r = 0; r < n; ++r) {
+    SMX_REQUIRE(models[r], "null model");
+    SMX_REQUIRE(models[r]->device == models[0]->device, "loopback communicator: all models on one device");
+    SMX_REQUIRE(models[r]->grads_count == models[0]->grads_count, "loopback communicator: models differ");
+    for (int q = 0; q < r; ++q) SMX_REQUIRE(models[q] != models[r], "loopback communicator: a model is listed twice");
+  }
+  auto g = std::make_shared<LocalGroup>();
+  g->world = n;
+  for (int r = 0; r < n; ++r) {
+    SMX_HIP(hipEventCreateWithFlags(&g->ready[r], hipEventDisableTiming));
+    SMX_HIP(hipEventCreateWithFlags(&g->done[r], hipEventDisableTiming));
+  }
+  for (int r = 0; r < n; ++r) {
+    smx_model* m = models[r];
+    SMX_CHECK(comm_detach(m));
+    m->rank = r; m->world = n; m->local = g;
+    int wmax = 0;
+    for (int w : m->bn_wp) wmax = std::max(wmax, w);
+    const size_t need = std::max(m->grads_count, (size_t)n * 2 * (size_t)wmax);
+    if (need > m->local_scratch_cap) {
+      if (m->local_scratch) hipFree(m->local_scratch);
+      m->local_scratch = nullptr; m->local_scratch_cap = 0;
+      SMX_CHECK(dmalloc(&m->local_scratch, need));
+      m->local_scratch_cap = need;
+    }
+    SMX_CHECK(ensure_sync_buf(m));
+  }
+  return SMX_OK;
+}
+
+int smx_comm_set_sync_bn(smx_model* m, int on) {
+  SMX_REQUIRE(m, "null model");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  m->sync_bn = on != 0;
+  SMX_CHECK(ensure_sync_buf(m));
+  drop_graphs(m);
+  return SMX_OK;
+}
+
+int smx_comm_library(char* rccl_path, int rccl_cap, char* hip_path, int hip_cap, int32_t* rccl_version) {
+  SMX_CHECK(load_rccl());
+  if (rccl_path && rccl_cap > 0) { strncpy(rccl_path, g_rccl.path.c_str(), rccl_cap - 1); rccl_path[rccl_cap - 1] = 0; }
+  if (hip_path && hip_cap > 0) { strncpy(hip_path, g_rccl.hip_path.c_str(), hip_cap - 1); hip_path[hip_cap - 1] = 0; }
+  if (rccl_version) { int v = 0; if (g_rccl.GetVersion) g_rccl.GetVersion(&v); *rccl_version = v; }
+  return SMX_OK;
+}
+
+int smx_comm_rank(const smx_model* m) { return m ? m->rank : 0; }
 int smx_comm_world(const smx_model* m) { return m ? m->world : 0; }
 
 int smx_timing_enable(smx_model* m, const char* kernel) {
@@ -2031,6 +2255,75 @@ int smx_k_count_llk(int likelihood, int direct, const float* x, const float* pla
                             (size_t)B, hipMemcpyDeviceToHost));
   }
   hipFree(dX); hipFree(dPl); hipFree(dG); hipFree(dPart);
+  return rc;
+}
+
+int smx_k_adam(int32_t n_tensors, const int32_t* sizes, float* params, const float* grads, float* mom, float* vel,
+               int32_t step, float lr, float beta1, float beta2, float eps, float clipnorm, float* norms) {
+  SMX_REQUIRE(n_tensors > 0 && n_tensors <= SMX_MAX_TENSORS && sizes && params && grads && mom && vel && step >= 1, "bad arguments");
+  // the model's own layout: every tensor padded to a multiple of 64 floats, 4096-float optimiser chunks
+  std::vector<size_t> off((size_t)n_tensors), pad((size_t)n_tensors);
+  std::vector<OptChunk> chunks;
+  size_t total = 0, logical = 0;
+  const int CH = 4096;
+  for (int t = 0; t < n_tensors; ++t) {
+    SMX_REQUIRE(sizes[t] > 0, "empty tensor");
+    off[t] = total; pad[t] = ((size_t)sizes[t] + 63) / 64 * 64;
+    const int first = (int)chunks.size(), n = (int)((pad[t] + CH - 1) / CH);
+    for (int i = 0; i < n; ++i) {
+      OptChunk c;
+      memset(&c, 0, sizeof(c));
+      c.tensor = t; c.offset = (int)(off[t] + (size_t)i * CH);
+      c.count = (int)((size_t)(i + 1) * CH <= pad[t] ? CH : pad[t] - (size_t)i * CH);
+      c.first_chunk = first; c.n_chunks = n; c.tensor_count = (int32_t)pad[t];
+      chunks.push_back(c);
+    }
+    total += pad[t]; logical += (size_t)sizes[t];
+  }
+  float *dP = nullptr, *dG = nullptr, *dM = nullptr, *dV = nullptr, *dPart = nullptr, *dNorm = nullptr;
+  OptChunk* dCh = nullptr; StepState* dSt = nullptr;
+  int rc;
+  if ((rc = dmalloc(&dP, total)) || (rc = dmalloc(&dG, total)) || (rc = dmalloc(&dM, total)) || (rc = dmalloc(&dV, total)) ||
+      (rc = dmalloc(&dPart, chunks.size())) || (rc = dmalloc(&dNorm, (size_t)n_tensors)) || (rc = dmalloc(&dCh, chunks.size())) ||
+      (rc = dmalloc(&dSt, (size_t)3)))
+    return rc;
+  auto put = [&](float* dst, const float* src) -> int {
+    size_t lo = 0;
+    for (int t = 0; t < n_tensors; ++t) {
+      SMX_HIP(hipMemcpy(dst + off[t], src + lo, (size_t)sizes[t] * sizeof(float), hipMemcpyHostToDevice));
+      lo += (size_t)sizes[t];
+    }
+    return SMX_OK;
+  };
+  auto get = [&](float* dst, const float* src) -> int {
+    size_t lo = 0;
+    for (int t = 0; t < n_tensors; ++t) {
+      SMX_HIP(hipMemcpy(dst + lo, src + off[t], (size_t)sizes[t] * sizeof(float), hipMemcpyDeviceToHost));
+      lo += (size_t)sizes[t];
+    }
+    return SMX_OK;
+  };
+  rc = put(dP, params); if (rc == SMX_OK) rc = put(dG, grads); if (rc == SMX_OK) rc = put(dM, mom); if (rc == SMX_OK) rc = put(dV, vel);
+  if (rc == SMX_OK && hipMemcpy(dCh, chunks.data(), chunks.size() * sizeof(OptChunk), hipMemcpyHostToDevice) != hipSuccess) rc = SMX_ERR_HIP;
+  StepState st3[3];
+  memset(st3, 0, sizeof(st3));
+  st3[2].next = (uint32_t)(step - 1);   // optimiser steps completed so far
+  if (rc == SMX_OK && hipMemcpy(dSt, st3, sizeof(st3), hipMemcpyHostToDevice) != hipSuccess) rc = SMX_ERR_HIP;
+  // the step's scalars exactly as a training step prepares them (bias-corrected step size on the device)
+  if (rc == SMX_OK) rc = launch_step_begin(nullptr, dSt + 2, dSt, nullptr, nullptr, 0, 0, 0u, lr, beta1, beta2);
+  if (rc == SMX_OK) {
+    AdamArgs a;
+    a.params = dP; a.grads = dG; a.m = dM; a.v = dV; a.chunks = dCh; a.n_chunks = (int)chunks.size(); a.n_launch = a.n_chunks;
+    a.partial = dPart; a.tensor_norm = dNorm; a.use_sq = 0; a.state = dSt;
+    a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.clipnorm = clipnorm; a.grad_scale = 1.f; a.lr = lr;
+    rc = launch_adam(nullptr, a);
+  }
+  if (rc == SMX_OK && hipDeviceSynchronize() != hipSuccess) { set_error("k_adam: device synchronize failed"); rc = SMX_ERR_HIP; }
+  if (rc == SMX_OK) rc = get(params, dP);
+  if (rc == SMX_OK) rc = get(mom, dM);
+  if (rc == SMX_OK) rc = get(vel, dV);
+  if (rc == SMX_OK && norms && hipMemcpy(norms, dNorm, (size_t)n_tensors * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = SMX_ERR_HIP;
+  hipFree(dP); hipFree(dG); hipFree(dM); hipFree(dV); hipFree(dPart); hipFree(dNorm); hipFree(dCh); hipFree(dSt);
   return rc;
 }
 

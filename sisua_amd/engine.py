@@ -351,6 +351,30 @@ class Engine:
   def world(self) -> int:
     return self.lib.smx_comm_world(self._h)
 
+  @property
+  def rank(self) -> int:
+    return self.lib.smx_comm_rank(self._h)
+
+  def set_sync_bn(self, on: bool = True):
+    """SyncBatchNorm under data parallelism (global-batch statistics; one small extra all-reduce per BatchNorm pass)."""
+    check(self.lib.smx_comm_set_sync_bn(self._h, int(bool(on))))
+
+  @staticmethod
+  def comm_library() -> dict:
+    """Paths of the bound RCCL and of the HIP runtime both libraries run on, and the RCCL version code."""
+    lib = _hip.load()
+    a, b, v = C.create_string_buffer(4096), C.create_string_buffer(4096), C.c_int32()
+    check(lib.smx_comm_library(a, 4096, b, 4096, C.byref(v)))
+    return dict(rccl=a.value.decode(), hip=b.value.decode(), rccl_version=int(v.value))
+
+  @staticmethod
+  def comm_init_local(engines: Sequence["Engine"]):
+    """Test hook: loopback communicator over engines of this process (rank i = engines[i]); afterwards each engine
+    must be driven by its own host thread, all of them running the same number of equal-size steps."""
+    lib = _hip.load()
+    arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    check(lib.smx_comm_init_local(arr, len(engines)))
+
   # ---- measurement ----------------------------------------------------------------------
   def timing_enable(self, kernel: Optional[str]):
     check(self.lib.smx_timing_enable(self._h, kernel.encode() if kernel else None))
@@ -378,6 +402,21 @@ def k_count_llk(likelihood: str, x, planes, direct: bool = False, want_grads: bo
   grads = np.empty((k, B, G), np.float32) if want_grads else None
   check(lib.smx_k_count_llk(_hip.LIKELIHOODS[likelihood], int(direct), _fp(x), _fp(pl), B, G, _fp(llk), _fp(grads)))
   return llk, grads
+
+
+def k_adam(params, grads, m, v, step: int, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, clipnorm=100.0):
+  """The optimiser launch by itself over lists of arrays (updated copies are returned): (params, m, v, norms)."""
+  lib = _hip.require_gpu()
+  sizes = np.array([int(np.size(p)) for p in params], dtype=np.int32)
+  cat = lambda xs: np.ascontiguousarray(np.concatenate([np.asarray(x, np.float32).ravel() for x in xs]))
+  P, G, M, V = cat(params), cat(grads), cat(m), cat(v)
+  norms = np.empty(len(sizes), np.float32)
+  check(lib.smx_k_adam(len(sizes), sizes.ctypes.data_as(C.POINTER(C.c_int32)), _fp(P), _fp(G), _fp(M), _fp(V), int(step),
+                       float(lr), float(beta1), float(beta2), float(eps), float(clipnorm), _fp(norms)))
+  cut = np.cumsum(sizes)[:-1]
+  shp = [np.shape(p) for p in params]
+  un = lambda flat: [a.reshape(sh) for a, sh in zip(np.split(flat, cut), shp)]
+  return un(P), un(M), un(V), norms
 
 
 def k_gemm(A, B, trans_a=False, trans_b=False, split_k=1, tile=0):

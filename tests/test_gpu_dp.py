@@ -1,0 +1,260 @@
+"""Data-parallel arithmetic of the HIP library with world > 1 on ONE GPU.
+
+`smx_comm_init_local` joins several models of this process into a loopback communicator (events + a summing
+kernel in place of RCCL; every model is driven by its own host thread).  Everything else of the step is the
+production path: loss scaled by 1 / (batch * world), ONE all-reduce of [grads | BN batch stats | metrics], the
+norm of the REDUCED gradient for per-tensor clipnorm, averaged moving statistics, Adam -- and, opt-in,
+SyncBatchNorm with its per-layer statistics all-reduce.  Checked against oracle.dp_train_step."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import sisua_oracle as so
+from tests.util import grad_errors, make_pair, perturbed_params, rel_l2, synth_counts, synth_labels
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def Engine():
+  from sisua_amd import build
+  build.build(verbose=False)
+  from sisua_amd.engine import Engine
+  return Engine
+
+
+def run_ranks(fns, timeout=120):
+  """One host thread per rank (the ctypes calls release the GIL); re-raises the first failure."""
+  errs, outs = [None] * len(fns), [None] * len(fns)
+
+  def wrap(i):
+    try:
+      outs[i] = fns[i]()
+    except BaseException as e:  # noqa: BLE001
+      errs[i] = e
+
+  ts = [threading.Thread(target=wrap, args=(i,), daemon=True) for i in range(len(fns))]
+  for t in ts:
+    t.start()
+  for t in ts:
+    t.join(timeout)
+  assert not any(t.is_alive() for t in ts), "a rank thread hangs"
+  for e in errs:
+    if e is not None:
+      raise e
+  return outs
+
+
+CASES = {
+    "vae_zinb": dict(model="vae", n_genes=203, likelihood="zinb", enc_units=(48, 40), dec_units=(40,), latent_dim=10),
+    "vae_clip": dict(model="vae", n_genes=120, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=6, clipnorm=0.05,
+                     lr=5e-3),
+    "sisua": dict(model="sisua", n_genes=180, likelihood="zinb", enc_units=(64,), dec_units=(64,), latent_dim=9,
+                  labels=((12, "nb"), (7, "onehot"))),
+    "scvi_zinbd": dict(model="scvi", n_genes=160, likelihood="zinbd", enc_units=(48,), dec_units=(48,), latent_dim=6,
+                       encl_units=(16,)),
+    "vae_nobn": dict(model="vae", n_genes=64, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=5, batchnorm=False),
+}
+
+
+def _problem(kw, n=400):
+  spec, cfg = make_pair(**kw)
+  x = synth_counts(n, spec.n_genes, sparsity=0.85, seed=0)
+  ys = synth_labels(n, spec.labels)
+  _, lm, lv = so.library_size(x)
+  lib = np.tile(np.array([[lm, lv]], dtype=np.float32), (n, 1))
+  mask = so.label_mask(n, 0.4, n_omics=1 + len(spec.labels), seed=1)
+  return spec, cfg, x, ys, lib, mask
+
+
+@pytest.mark.parametrize("name,world,sync_bn", [("vae_zinb", 2, False), ("vae_zinb", 2, True), ("vae_clip", 2, False),
+                                                ("vae_clip", 3, True), ("sisua", 2, False), ("sisua", 2, True),
+                                                ("scvi_zinbd", 2, False), ("scvi_zinbd", 2, True), ("vae_nobn", 4, False)])
+def test_world_n_steps_match_oracle(Engine, name, world, sync_bn):
+  """3 optimiser steps of `world` replicas, every rank holding the WHOLE matrix but drawing its own rows: loss /
+  metrics / reduced gradients / gradient norms / parameters / moving statistics of EVERY rank equal the oracle's
+  data-parallel contract."""
+  spec, cfg, x, ys, lib, mask = _problem(CASES[name])
+  params = perturbed_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  B, steps, base = 48, 3, 1000
+  engines = []
+  for r in range(world):
+    e = Engine(cfg, max_batch=64, init=False)
+    e.set_params(params)
+    e.upload(x, ys, lib, mask, cell_id_base=base)
+    engines.append(e)
+  Engine.comm_init_local(engines)
+  for e in engines:
+    assert e.world == world
+    e.set_sync_bn(sync_bn)
+  assert [e.rank for e in engines] == list(range(world))
+  rng = np.random.default_rng(5)
+  for step in range(steps):
+    rows = rng.permutation(x.shape[0])[: B * world].astype(np.int32).reshape(world, B)
+    p_before = {k: v.copy() for k, v in params.items()}
+    ref = so.dp_train_step(spec, params, bn, opt, x, list(rows), step, cell_base=base, y=ys, library=lib, mask=mask,
+                           sync_bn=sync_bn)
+    ms = run_ranks([lambda r=r: engines[r].train_step(rows[r]) for r in range(world)])
+    for r, (e, m) in enumerate(zip(engines, ms)):
+      assert m["nan_flag"] == 0 and m["step"] == step + 1
+      for key in ("loss", "nllk_x", "kl") + (("nllk_y",) if spec.labels else ()) + (("kl_l",) if spec.model == "scvi" else ()):
+        assert np.isclose(m[key], ref["metrics"][key], rtol=RTOL, atol=1e-5), (r, step, key, m[key], ref["metrics"][key])
+      assert np.isclose(m["grad_norm_max"], max(ref["norms"].values()), rtol=1e-3), (r, step)
+      if step == 0:   # the reduced gradient itself (later steps start from fp32-rounded parameters)
+        worst = grad_errors(e.get_params(which=1), ref["grads"])
+        assert max(worst.values()) < RTOL, (r, sorted(worst.items(), key=lambda kv: -kv[1])[:3])
+  # after 3 steps: every rank holds the same parameters, and they are the oracle's
+  finals = [e.get_params() for e in engines]
+  for k in finals[0]:
+    for r in range(1, world):
+      assert np.array_equal(finals[0][k], finals[r][k]), (k, r)
+    g = ref["grads"][k]   # of the last step; judge the move where the gradient is not fp32 noise around zero
+    big = np.abs(g) > 1e-3 * np.abs(g).max()
+    if big.any() and np.linalg.norm(g) > 1e-3 * max(np.linalg.norm(v) for v in ref["grads"].values()):
+      assert rel_l2((finals[0][k] - p_before[k])[big], (params[k] - p_before[k])[big]) < 2e-2, k
+    assert np.allclose(finals[0][k], params[k], rtol=1e-4, atol=max(5e-4, 0.75 * spec.lr)), k
+  names = [p for p, _ in so.bn_manifest(spec)]
+  for e in engines:
+    for i, st in e.get_bn().items():
+      assert np.allclose(st["moving_mean"], bn[f"{names[i]}/moving_mean"], rtol=1e-4, atol=1e-6)
+      assert np.allclose(st["moving_var"], bn[f"{names[i]}/moving_var"], rtol=1e-4, atol=1e-6)
+  if name == "vae_clip":
+    assert max(ref["norms"].values()) > 10 * spec.clipnorm   # the threshold was exceeded: the norm path is what ran
+  for e in engines:
+    e.close()
+
+
+def test_sync_bn_equals_single_process_on_the_global_batch(Engine):
+  """SURVEY 8e caveat (i): with SyncBatchNorm two replicas of 32 cells ARE one process on the 64 cells."""
+  spec, cfg, x, ys, lib, mask = _problem(CASES["vae_zinb"])
+  one = Engine(cfg, max_batch=64)
+  one.upload(x, ys, lib, mask)
+  two = [Engine(cfg, max_batch=64) for _ in range(2)]
+  for e in two:
+    e.upload(x, ys, lib, mask)
+  Engine.comm_init_local(two)
+  for e in two:
+    e.set_sync_bn(True)
+  rng = np.random.default_rng(0)
+  for step in range(4):
+    rows = rng.permutation(x.shape[0])[:64].astype(np.int32)
+    m1 = one.train_step(rows)
+    m2 = run_ranks([lambda r=r: two[r].train_step(rows[r * 32:(r + 1) * 32]) for r in range(2)])
+    assert np.isclose(m1["loss"], m2[0]["loss"], rtol=2e-6) and m2[0]["loss"] == m2[1]["loss"]
+  a, b = one.get_params(), two[0].get_params()
+  for k in a:   # different summation order (2 x 32 vs 64 rows) only
+    assert np.allclose(a[k], b[k], rtol=1e-4, atol=2e-5), k
+  for e in [one] + two:
+    e.close()
+
+
+def test_k_adam_matches_oracle(Engine):
+  """The optimiser kernel by itself (smx_k_adam): per-tensor clipnorm + Keras Adam to 1e-6, several steps, with
+  tensors above and below the clip threshold and sizes that are not multiples of the 4096-float chunk."""
+  from sisua_amd.engine import k_adam
+  rng = np.random.default_rng(0)
+  shapes = [(33, 17), (5,), (128, 96), (4097,), (1, 3)]
+  spec = so.Spec(model="vae", n_genes=8, enc_units=(4,), dec_units=(4,), latent_dim=2, clipnorm=2.0, lr=3e-3)
+  names = [f"t{i}" for i in range(len(shapes))]
+  params = {n: rng.normal(size=s) for n, s in zip(names, shapes)}
+  params = {k: v.astype(np.float32).astype(np.float64) for k, v in params.items()}
+  opt = so.init_opt_state(params)
+  gp = [params[n].astype(np.float32) for n in names]
+  gm = [np.zeros(s, np.float32) for s in shapes]
+  gv = [np.zeros(s, np.float32) for s in shapes]
+  for t in range(1, 6):
+    scale = [0.01, 3.0, 0.05, 0.2, 10.0]
+    grads = {n: (sc * rng.normal(size=s)).astype(np.float32).astype(np.float64) for n, s, sc in zip(names, shapes, scale)}
+    before = {n: params[n].copy() for n in names}
+    norms = so.adam_update(spec, params, grads, opt)
+    gp, gm, gv, gn = k_adam(gp, [grads[n] for n in names], gm, gv, t, lr=spec.lr, beta1=spec.adam_beta1,
+                            beta2=spec.adam_beta2, eps=spec.adam_eps, clipnorm=spec.clipnorm)
+    assert any(v > spec.clipnorm for v in norms.values()) and any(v < spec.clipnorm for v in norms.values())
+    for i, n in enumerate(names):
+      assert np.isclose(gn[i], norms[n], rtol=1e-6), (t, n)
+      step_ref, step_got = params[n] - before[n], gp[i].astype(np.float64) - before[n]
+      # the update itself, not the parameter: rel-L2 of the MOVE (fp32 storage of the parameter: 6e-8 * |p| absolute)
+      assert np.linalg.norm(step_got - step_ref) <= 1e-5 * np.linalg.norm(step_ref) + 2e-7 * np.linalg.norm(before[n]), (t, n)
+      assert np.allclose(gm[i], opt["m"][n], rtol=1e-6, atol=1e-12), (t, n)
+      # 1 - beta2 in fp32 (0.999f = 0.99900001...) is 1.3e-5 off the float64 value; it cancels against the same factor
+      # in lr_t, which is why the MOVE above agrees to 1e-5
+      assert np.allclose(gv[i], opt["v"][n], rtol=3e-5, atol=1e-14), (t, n)
+    # the oracle continues from the GPU's fp32 state so that the comparison stays per-step
+    for i, n in enumerate(names):
+      params[n] = gp[i].astype(np.float64); opt["m"][n] = gm[i].astype(np.float64); opt["v"][n] = gv[i].astype(np.float64)
+
+
+def test_comm_library_is_resolved_beside_the_hip_runtime(Engine):
+  info = Engine.comm_library()
+  assert os.path.isabs(info["rccl"]) and os.path.exists(info["rccl"]) and "rccl" in os.path.basename(info["rccl"])
+  assert os.path.exists(info["hip"]) and "amdhip64" in os.path.basename(info["hip"])
+  # deterministic rule: RCCL is the sibling of the HIP runtime the process runs on (unless SMX_RCCL_PATH overrides)
+  if not os.environ.get("SMX_RCCL_PATH"):
+    assert os.path.dirname(info["rccl"]) == os.path.dirname(info["hip"]), info
+  assert info["rccl_version"] > 20000
+
+
+_BAD_COMM = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+from sisua_amd import SmxError
+from sisua_amd.config import ModelConfig
+from sisua_amd.engine import Engine
+rank = int(sys.argv[1]); uid_file = sys.argv[2]
+e = Engine(ModelConfig(n_genes=40, enc_units=(16,), dec_units=(16,), latent_dim=4), max_batch=16)
+if rank == 0:
+  uid = Engine.comm_unique_id()
+  open(uid_file + ".tmp", "wb").write(uid); os.replace(uid_file + ".tmp", uid_file)
+else:
+  t0 = time.time()
+  while not os.path.exists(uid_file):
+    assert time.time() - t0 < 60
+    time.sleep(0.05)
+  uid = open(uid_file, "rb").read()
+try:
+  e.comm_init(rank, 2, uid)     # two ranks on ONE device: RCCL refuses (duplicate GPU)
+  print("JOINED", flush=True)
+except SmxError as err:
+  assert "-4" in str(err) or "ncclCommInitRank" in str(err), err
+  assert e.world == 1           # left without a communicator
+  x = np.ones((32, 40), np.float32)
+  e.upload(x)
+  m = e.train_step(np.arange(16, dtype=np.int32))   # and still usable as a single-GPU model
+  assert m["step"] == 1 and m["nan_flag"] == 0
+  print("REFUSED", flush=True)
+e.close()
+print("CLEAN", flush=True)
+"""
+
+
+def test_comm_init_failure_leaves_a_clean_model(Engine, tmp_path):
+  """a failed ncclCommInitRank used to leave a half-built handle that smx_model_destroy then
+  freed again (double free).  Two processes on the one GPU of the box: RCCL refuses the duplicate device; both
+  processes must report SMX_ERR_COMM, keep working with world 1 and exit cleanly."""
+  script = tmp_path / "bad_comm.py"
+  script.write_text(_BAD_COMM.format(root=ROOT))
+  uid_file = str(tmp_path / "uid.bin")
+  env = dict(os.environ, NCCL_DEBUG="WARN")
+  ps = [subprocess.Popen([sys.executable, str(script), str(r), uid_file], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         env=env, text=True) for r in range(2)]
+  outs = []
+  for p in ps:
+    try:
+      out, _ = p.communicate(timeout=120)
+    except subprocess.TimeoutExpired:
+      for q in ps:
+        q.kill()
+      pytest.fail("comm_init on a duplicate device hangs")
+    outs.append((p.returncode, out))
+  for rc, out in outs:
+    assert rc == 0 and "CLEAN" in out, out[-2000:]
+  if not all("REFUSED" in out for _, out in outs):   # an RCCL build that accepts two ranks on one device
+    assert all("JOINED" in out for _, out in outs), outs
