@@ -1,0 +1,164 @@
+"""Parity at the BASELINE.json configurations' own shapes: the HIP path against the float64
+oracle on the workloads bench.py builds -- C2 (8kly VAE zinb, batch 128), C3 (8kly SCVI nbd, batch 256), C4
+(eccly SISUA zinb + 38 ADT nb labels at 10 %, alpha 10, batch 256), and the per-GPU slice of C5 (20 000 genes,
+batch 128, counts resident as uint16, 4096 cells) -- plus the north star's latent-means criterion: eval-mode
+latent means after training on the GPU and on the oracle with the same Philox noise within 1e-4."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import sisua_oracle as so
+from tests.util import grad_errors, rel_l2
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def Engine():
+  from sisua_amd import build
+  build.build(verbose=False)
+  from sisua_amd.engine import Engine
+  return Engine
+
+
+_WL = {}
+
+
+def _workload(name):
+  """bench.py's workload (split(0.8) -> split(0.9) -> corrupt of the synthetic stand-in), cached per module."""
+  if name not in _WL:
+    import bench
+    cfg, xt, batch, extra = bench.build_workload(0, 1, name)
+    _WL[name] = (so.Spec(**cfg.to_dict()), cfg, xt, batch, extra)
+  return _WL[name]
+
+
+def _oracle_kwargs(extra, rows):
+  return dict(y=[y[rows] for y in extra.get("labels", [])],
+              library=extra["library"][rows] if "library" in extra else None,
+              mask=extra["label_mask"][rows] if "label_mask" in extra else None)
+
+
+def _upload(e, xt, extra, **kw):
+  e.upload(xt, extra.get("labels", ()), extra.get("library"), extra.get("label_mask"), **kw)
+
+
+def _metric_keys(spec):
+  return ("loss", "nllk_x", "kl") + (("nllk_y",) if spec.labels else ()) + (("kl_l",) if spec.model == "scvi" else ())
+
+
+@pytest.mark.parametrize("workload,shape", [("8kly", (3381, 1998)), ("8kly-scvi", (3381, 1998)), ("eccly-sisua", (2116, 2000))])
+def test_one_step_all_gradients_at_baseline_shape(Engine, workload, shape):
+  """One optimiser step at the configuration's own batch size: ELBO scalars, EVERY gradient (rel-L2 <= 1e-4), the
+  BatchNorm moving statistics and the gradient norms against the oracle."""
+  spec, cfg, xt, B, extra = _workload(workload)
+  assert xt.shape == shape
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = Engine(cfg, max_batch=B, init=False)
+  e.set_params(params)
+  _upload(e, xt, extra, cell_id_base=17)
+  rows = np.random.default_rng(3).permutation(xt.shape[0])[:B].astype(np.int32)
+  res = so.train_step(spec, params, bn, opt, xt[rows], so.PhiloxNoise(spec.seed, 0, rows + 17), **_oracle_kwargs(extra, rows))
+  m = e.train_step(rows)
+  assert m["nan_flag"] == 0
+  for key in _metric_keys(spec):
+    assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
+  worst = grad_errors(e.get_params(which=1), res["grads"])
+  assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  assert np.isclose(m["grad_norm_max"], max(np.linalg.norm(g) for g in res["grads"].values()), rtol=1e-4)
+  names = [p for p, _ in so.bn_manifest(spec)]
+  for i, st in e.get_bn().items():
+    assert np.allclose(st["moving_mean"], bn[f"{names[i]}/moving_mean"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(st["moving_var"], bn[f"{names[i]}/moving_var"], rtol=1e-4, atol=1e-6)
+  if spec.labels:   # labels_percent = 0.1: the batch must hold labelled and unlabelled cells for the mask to matter
+    mk = extra["label_mask"][rows]
+    assert 0 < mk.sum() < B
+  e.close()
+
+
+@pytest.mark.parametrize("workload,steps", [("8kly-scvi", 20), ("eccly-sisua", 20)])
+def test_trajectory_at_baseline_shape(Engine, workload, steps):
+  """20 seeded optimiser steps in the epoch order fit() uses (shuffle buffer 1000, drop_remainder): every ELBO
+  scalar of every step within 1e-4 of the oracle's trajectory."""
+  import bench
+  spec, cfg, xt, B, extra = _workload(workload)
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = Engine(cfg, max_batch=B, init=False)
+  e.set_params(params)
+  _upload(e, xt, extra)
+  order = bench.make_order(xt.shape[0], B, steps)
+  for s in range(steps):
+    rows = order[s * B:(s + 1) * B]
+    res = so.train_step(spec, params, bn, opt, xt[rows], so.PhiloxNoise(spec.seed, s, rows), **_oracle_kwargs(extra, rows))
+    m = e.train_step(rows)
+    for key in _metric_keys(spec):
+      assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (s, key, m[key], res["metrics"][key])
+  e.close()
+
+
+def test_c5_slice_u16_store(Engine):
+  """Per-GPU slice of BASELINE configs[4]: 20 000 genes, batch 128, 4096 resident cells stored as uint16: one step
+  with every gradient, then 4 more steps of the ELBO trajectory; the float32 store gives bit-identical losses."""
+  spec, cfg, xt, B, extra = _workload("c5-shard")
+  assert xt.shape == (4096, 20000) and B == 128
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = Engine(cfg, max_batch=B, init=False)
+  e.set_params(params)
+  e.upload(xt, cell_id_base=5, storage="u16")
+  rng = np.random.default_rng(11)
+  got = []
+  for s in range(5):
+    rows = rng.permutation(xt.shape[0])[:B].astype(np.int32)
+    res = so.train_step(spec, params, bn, opt, xt[rows], so.PhiloxNoise(spec.seed, s, rows + 5))
+    m = e.train_step(rows)
+    got.append((rows, m["loss"]))
+    for key in ("loss", "nllk_x", "kl"):
+      assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (s, key, m[key], res["metrics"][key])
+    if s == 0:
+      worst = grad_errors(e.get_params(which=1), res["grads"])
+      assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+      assert np.isclose(m["grad_norm_max"], max(np.linalg.norm(g) for g in res["grads"].values()), rtol=1e-4)
+  e.close()
+  e2 = Engine(cfg, max_batch=B)
+  e2.upload(xt, cell_id_base=5, storage="f32")
+  for rows, loss in got:
+    assert e2.train_step(rows)["loss"] == loss
+  e2.close()
+
+
+def test_latent_means_after_training_match_oracle(Engine):
+  """north_star: 'ELBO / latent means within 1e-4 relative on fixed seeds'.  C2 (batch 128): the GPU and the
+  oracle train with the same Philox noise; after 100 and after 300 optimiser steps the eval-mode latent means of
+  256 fixed cells agree to 1e-4 (relative L2), the latent scales too, and every step's ELBO to 1e-4."""
+  import bench
+  spec, cfg, xt, B, extra = _workload("8kly")
+  assert B == 128
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = Engine(cfg, max_batch=256, init=False)
+  e.set_params(params)
+  e.upload(xt)
+  order = bench.make_order(xt.shape[0], B, 300)
+  probe = np.random.default_rng(0).permutation(xt.shape[0])[:256].astype(np.int32)
+  worst_loss = 0.0
+  for s in range(300):
+    rows = order[s * B:(s + 1) * B]
+    ref = so.train_step(spec, params, bn, opt, xt[rows], so.PhiloxNoise(spec.seed, s, rows))["loss"]
+    got = e.train_step(rows)["loss"]
+    worst_loss = max(worst_loss, abs(got / ref - 1.0))
+    if s + 1 in (100, 300):
+      r = so.forward_backward(spec, params, bn, xt[probe], so.PhiloxNoise(spec.seed, 0, probe), training=False, backward=False)
+      out = e.forward(row_ids=probe, want_x_params=False)
+      assert rel_l2(out["z_mean"], r["z_mean"]) < RTOL, (s + 1, rel_l2(out["z_mean"], r["z_mean"]))
+      assert rel_l2(out["z_scale"], r["z_scale"]) < RTOL, (s + 1, rel_l2(out["z_scale"], r["z_scale"]))
+  assert worst_loss < RTOL, worst_loss
+  e.close()

@@ -182,10 +182,11 @@ def test_k_adam_matches_oracle(Engine):
       step_ref, step_got = params[n] - before[n], gp[i].astype(np.float64) - before[n]
       # the update itself, not the parameter: rel-L2 of the MOVE (fp32 storage of the parameter: 6e-8 * |p| absolute)
       assert np.linalg.norm(step_got - step_ref) <= 1e-5 * np.linalg.norm(step_ref) + 2e-7 * np.linalg.norm(before[n]), (t, n)
-      assert np.allclose(gm[i], opt["m"][n], rtol=1e-6, atol=1e-12), (t, n)
+      # fp32 storage: b1 * m + (1 - b1) * g rounds twice, and the two terms may cancel
+      assert np.allclose(gm[i], opt["m"][n], rtol=1e-6, atol=3e-7 * np.abs(opt["m"][n]).max()), (t, n)
       # 1 - beta2 in fp32 (0.999f = 0.99900001...) is 1.3e-5 off the float64 value; it cancels against the same factor
       # in lr_t, which is why the MOVE above agrees to 1e-5
-      assert np.allclose(gv[i], opt["v"][n], rtol=3e-5, atol=1e-14), (t, n)
+      assert np.allclose(gv[i], opt["v"][n], rtol=3e-5, atol=3e-7 * np.abs(opt["v"][n]).max()), (t, n)
     # the oracle continues from the GPU's fp32 state so that the comparison stays per-step
     for i, n in enumerate(names):
       params[n] = gp[i].astype(np.float64); opt["m"][n] = gm[i].astype(np.float64); opt["v"][n] = gv[i].astype(np.float64)

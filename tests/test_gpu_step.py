@@ -286,7 +286,7 @@ def test_hip_matches_committed_trajectory_fixture(Engine):
   e.upload(fx["x"])
   got = [e.train_step(fx["order"][s * 64:(s + 1) * 64])["loss"] for s in range(50)]
   assert np.allclose(got, fx["loss"], rtol=RTOL), np.abs(np.array(got) / fx["loss"] - 1).max()
-  assert np.allclose(e.get_params()["lat/W"], fx["final_lat_W"], rtol=1e-3, atol=2e-3)
+  assert rel_l2(e.get_params()["lat/W"], fx["final_lat_W"]) < RTOL   # the latent head's weights after the 50 steps
   e.close()
 
 
