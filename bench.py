@@ -10,8 +10,12 @@ log1p + encoder, reparameterised latent, decoder, ZINB+KL ELBO, backward,
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, cells sharded over ranks (weak scaling: 128 cells per
-GPU per step), one RCCL all-reduce of the flat gradient buffer per step.
+N > 1: one process per GPU; ONE dataset, rank r keeps the r-th contiguous 1/N of its cells
+resident; one RCCL all-reduce of the flat gradient buffer per step.
+--scaling weak (default): 128 cells per GPU per step (global batch 128 N) -- the mode the
+north star's ">= 6.5x at 8 GPUs" can be claimed under, a latency-bound 128-cell step cannot
+be cut in eight.  --scaling strong: the reference's global batch is preserved (128 / N cells
+per GPU); with --sync-bn that is the single-process arithmetic (SyncBatchNorm).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -35,19 +39,19 @@ def build_workload(rank: int, world: int, workload: str):
   from sisua_amd import data
   from sisua_amd.config import ModelConfig
   if workload == "8kly":
-    x, _ = data.synthetic_8kly(seed=8 + rank)
+    x, _ = data.synthetic_8kly(seed=8)
     units, latent, batch = (128,), 32, 128
   elif workload == "8kly-2layer":
-    x, _ = data.synthetic_8kly(seed=8 + rank)
+    x, _ = data.synthetic_8kly(seed=8)
     units, latent, batch = (128, 128), 32, 128
   elif workload in ("8kly-scvi", "eccly-sisua"):
     # BASELINE.json configs[2] / configs[3]: SCVI nbd batch 256; SISUA zinb + ADT nb labels (10 %), alpha 10, batch 256
-    x, y = data.synthetic_8kly(seed=8 + rank) if workload == "8kly-scvi" else data.synthetic_eccly(seed=8 + rank)
+    x, y = data.synthetic_8kly(seed=8) if workload == "8kly-scvi" else data.synthetic_eccly(seed=8)
     units, latent, batch = (128,), 32, 256
   elif workload == "c5-shard":
     # per-GPU slice of BASELINE.json configs[4] (1e6 x 20000 log-normal counts, 128 cells per GPU per step):
-    # 4096 resident cells are enough to exercise the step at its real width
-    rng = np.random.default_rng(8 + rank)
+    # 4096 resident cells per GPU are enough to exercise the step at its real width
+    rng = np.random.default_rng(8 + rank)   # generated per shard from (seed, rank), as SURVEY.md 8d describes for C5
     x = (np.floor(rng.lognormal(0.0, 1.0, size=(4096, 20000))) * (rng.uniform(size=(4096, 20000)) < 0.12)).astype(np.float32)
     x[:, 0] += 1
     units, latent, batch = (128,), 32, 128
@@ -73,6 +77,13 @@ def build_workload(rank: int, world: int, workload: str):
     extra["label_mask"] = data.label_mask(xt.shape[0], 0.1, 2, seed=1)
   else:
     cfg = ModelConfig(model="vae", likelihood="zinb", **kw)
+  if world > 1 and workload != "c5-shard":   # ONE dataset: this rank's contiguous shard of the training cells
+    lo, hi = data.shard_range(xt.shape[0], rank, world)
+    extra = {k: ([a[lo:hi] for a in v] if k == "labels" else v[lo:hi]) for k, v in extra.items()}
+    xt = xt[lo:hi]
+    extra["cell_id_base"] = lo
+  elif world > 1:
+    extra["cell_id_base"] = rank * xt.shape[0]
   return cfg, xt, batch, extra
 
 
@@ -147,6 +158,9 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--storage", default="f32", choices=("f32", "u16"), help="resident count matrix: float32 (reference layout) or uint16")
   ap.add_argument("--cpu-budget", type=float, default=12.0)
+  ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                  help="N > 1: weak = the configuration's batch per GPU; strong = the global batch is preserved (batch / N per GPU)")
+  ap.add_argument("--sync-bn", action="store_true", help="N > 1: SyncBatchNorm (global-batch statistics)")
   args = ap.parse_args()
 
   rank = int(os.environ.get("RANK", "0"))
@@ -167,9 +181,16 @@ def main():
   cp = ControlPlane(rank, world)
 
   cfg, xt, batch, extra = build_workload(rank, world, args.workload)
+  cell_base = extra.pop("cell_id_base", 0)
+  if args.scaling == "strong" and world > 1:
+    if batch % world:
+      sys.exit(f"--scaling strong: batch {batch} is not divisible by {world} ranks")
+    batch //= world
   eng = Engine(cfg, max_batch=batch, device=local_rank)
-  eng.upload(xt, cell_id_base=rank * (1 << 24), storage=args.storage, **extra)
+  eng.upload(xt, cell_id_base=cell_base, storage=args.storage, **extra)
   attach_engine(eng, cp)
+  if world > 1 and args.sync_bn:
+    eng.set_sync_bn(True)
 
   use_graph = args.graph
   order = make_order(xt.shape[0], batch, args.warmup + args.steps)
@@ -223,12 +244,12 @@ def main():
         "unit": "cells/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}-shaped synthetic counts {xt.shape[0]}x{xt.shape[1]} "
                                f"(train split, corrupted), {cfg.model} {cfg.likelihood} hidden={list(cfg.enc_units)} latent={cfg.latent_dim}, "
                                f"batch {batch}/GPU, hipGraph={'on' if use_graph else 'off'}, X resident as {args.storage}",
-                   "global_batch": batch * world, "parallelism": f"dp{world}"},
+                   "global_batch": batch * world, "parallelism": f"dp{world}" + ("+syncbn" if (world > 1 and args.sync_bn) else "")},
         "final_loss": round(m["loss"], 4),
         "roofline": {"bound": "hbm", "kernel": "count_loss_kernel<ZINB> fwd+bwd", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -165,6 +165,11 @@ int smx_train_step_graph(smx_model* m, const int32_t* row_ids, int32_t batch, sm
  * norm is reported through out->nan_flag with status SMX_OK (terminate_on_nan is the caller's decision). */
 int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t batch, int use_graph,
                     smx_metrics* out);
+/* ELBO scalars of EVERY step of the last smx_train_steps call, kept on the device while the steps ran (no host
+ * sync between them): host [n_steps][8] = (loss, nllk_x, nllk_y, kl, kl_l, 0, 0, 0) per step, global-minibatch
+ * means.  Feeds the per-epoch train_history of SingleCellModel.fit (tests/test_singlecell_models.py:28-32 of the
+ * reference reads train_history['loss'] per epoch). */
+int smx_metrics_history(smx_model* m, int32_t n_steps, float* host);
 /* Validation loss: eval-mode forward (moving BN stats, no dropout) + ELBO, no
  * update (valid_freq loop of BetaVAE.fit). */
 int smx_eval_step(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out);

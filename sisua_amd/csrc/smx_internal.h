@@ -147,6 +147,9 @@ struct MetricsArgs {
   const float* kl = nullptr; const float* kl_l = nullptr;
   int B = 0; float alpha = 0.f, beta = 1.f; float inv_global_batch = 0.f;
   float* out = nullptr;           // [8]: loss, nllk_x, nllk_y, kl, kl_l, (5..7 reserved)
+  // per-step history of a train_steps call (single GPU: written here; data parallel: by the optimiser launch,
+  // after the all-reduce): hist[cursor * 8 + i] = out[i]
+  float* hist = nullptr; const StepState* state = nullptr;
 };
 int launch_metrics(hipStream_t st, const MetricsArgs& a);
 
@@ -170,7 +173,8 @@ struct AdamArgs {
   float* tensor_norm = nullptr; // [n_tensors] written by the update kernel (pre-clip norms)
   const StepState* state = nullptr;
   float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, clipnorm = 100.f;
-  float grad_scale = 1.f;       // 1/world after a sum all-reduce
+  float grad_scale = 1.f;       // extra factor on the gradient (1: the loss is already scaled by 1 / global batch)
+  float* hist_dp = nullptr; const float* tail_metrics = nullptr;   // data parallel: the reduced scalars go to the history here
 };
 int launch_adam(hipStream_t st, const AdamArgs& a);
 

@@ -1084,6 +1084,11 @@ __device__ inline void metrics_body(const MetricsArgs& a) {
     a.out[3] = sk * s;
     a.out[4] = sl * s;
     a.out[5] = 0.f; a.out[6] = 0.f; a.out[7] = 0.f;
+    if (a.hist) {
+      float* h = a.hist + (long)a.state->cursor * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) h[i] = a.out[i];
+    }
   }
 }
 
@@ -1169,6 +1174,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
   adam_chunk_body(a, (int)blockIdx.x);
   if (blockIdx.x == 0 && a.master) {  // close the step; nobody reads next_state / next_rows during this step
     const uint32_t step = a.state->step, cur = a.state->cursor;
+    if (a.hist_dp && threadIdx.x < 8) a.hist_dp[(long)cur * 8 + threadIdx.x] = a.tail_metrics[threadIdx.x];
     if (a.prepare_next)
       for (int i = threadIdx.x; i < a.batch; i += 256) a.next_rows[i] = a.order[(long)(cur + 1) * a.batch + i];
     if (threadIdx.x == 0) {

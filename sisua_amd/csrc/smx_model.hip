@@ -267,6 +267,7 @@ struct smx_model {
   float* hostX = nullptr; float* hostLib = nullptr; float* hostLgx1 = nullptr;
   // step state
   int32_t* rows2[2] = {nullptr, nullptr}; int32_t* order = nullptr; size_t order_cap = 0;
+  float* mhist = nullptr; size_t mhist_cap = 0; int32_t mhist_steps = 0;   // ELBO scalars of every step of the last train_steps call
   StepState* state3 = nullptr;  // [0],[1]: per-step state by parity, [2]: master counter
   int par = 0; uint32_t h_next = 0;
   MetricsArgs pending_metrics; bool have_pending_metrics = false, metrics_before_allreduce = false;
@@ -882,6 +883,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   me.kl = m->stochastic ? m->kl : nullptr; me.kl_l = m->scvi ? m->kl_l : nullptr;
   me.B = ps.B; me.alpha = c.alpha; me.beta = c.beta; me.inv_global_batch = inv_gb;
   me.out = m->grads + m->tail_off_metrics;
+  if (backward && !dp_active(m)) { me.hist = m->mhist; me.state = cur_state(m); }
   if (backward) {
     // training step: the scalars come from one extra workgroup of a later launch -- of the optimiser kernel, or,
     // under data parallelism (they must be in the flat buffer BEFORE the all-reduce), of the first
@@ -1163,6 +1165,7 @@ int optimizer_pass(smx_model* m) {
   m->adam_early_from = -1;
   if (m->have_pending_metrics) { a.metrics = m->pending_metrics; a.with_metrics = 1; m->have_pending_metrics = false; }
   a.master = master_state(m); a.lr = c.lr; a.batch = m->seq_batch;
+  if (dp_active(m)) { a.hist_dp = m->mhist; a.tail_metrics = m->grads + m->tail_off_metrics; }
   a.prepare_next = m->seq_prepare_next;
   if (a.prepare_next) { a.next_state = m->state3 + (m->par ^ 1); a.next_rows = m->rows2[m->par ^ 1]; a.order = m->order; }
   Timed t(m, "adam");
@@ -1211,7 +1214,16 @@ void drop_graphs(smx_model* m) {  // captured graphs bake device pointers in: dr
   m->graphs.clear();
 }
 
-int upload_order(smx_model* m, const int32_t* order, size_t n) {
+int upload_order(smx_model* m, const int32_t* order, size_t n, size_t n_steps) {
+  if (n_steps > m->mhist_cap) {
+    SMX_HIP(hipStreamSynchronize(m->st));
+    drop_graphs(m);
+    if (m->mhist) hipFree(m->mhist);
+    m->mhist = nullptr; m->mhist_cap = 0;
+    SMX_CHECK(dmalloc(&m->mhist, (n_steps * 2 + 64) * 8));
+    m->mhist_cap = n_steps * 2 + 64;
+  }
+  m->mhist_steps = (int32_t)n_steps;
   if (n > m->order_cap) {
     SMX_HIP(hipStreamSynchronize(m->st));
     drop_graphs(m);
@@ -1511,7 +1523,7 @@ int smx_model_destroy(smx_model* m) {
     for (auto& L : *mlp) { fr(L.xhat); fr(L.out_buf); fr(L.dpre); fr(L.inv_std); fr(L.noise); }
   fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1); fr(m->hostX); fr(m->hostLib); fr(m->hostLgx1);
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); fr(m->laby_raw[j]); fr(m->laby_draw[j]); }
-  fr(m->rows2[0]); fr(m->rows2[1]); fr(m->order); fr(m->state3);
+  fr(m->rows2[0]); fr(m->rows2[1]); fr(m->order); fr(m->state3); fr(m->mhist);
   fr(m->noise_eps); fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);
   fr(m->latlbuf); fr(m->dlatl); fr(m->lsmp); fr(m->lsig); fr(m->leps); fr(m->kl_l); fr(m->dl);
   fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);
@@ -1775,12 +1787,19 @@ int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t
   SMX_REQUIRE(m && order && n_steps > 0, "bad arguments");
   SMX_REQUIRE(batch > 0 && batch <= m->Bmax, "batch must be in 1..max_batch");
   SMX_CHECK(check_rows(m, order, (size_t)n_steps * batch));
-  SMX_CHECK(upload_order(m, order, (size_t)n_steps * batch));
+  SMX_CHECK(upload_order(m, order, (size_t)n_steps * batch, (size_t)n_steps));
   for (int s = 0; s < n_steps; ++s) SMX_CHECK(launch_train(m, batch, use_graph != 0, s, n_steps));
   if (m->use_injected) { m->use_injected = false; }
   // a non-finite loss / gradient norm is REPORTED (out->nan_flag), not an error of the call: terminate_on_nan
   // (configs/base.yaml:59) is the caller's decision
   SMX_CHECK(read_metrics(m, out));
+  return SMX_OK;
+}
+
+int smx_metrics_history(smx_model* m, int32_t n_steps, float* host) {
+  SMX_REQUIRE(m && host && n_steps > 0 && n_steps <= m->mhist_steps, "no such history (steps of the last smx_train_steps call)");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  SMX_HIP(hipMemcpy(host, m->mhist, (size_t)n_steps * 8 * sizeof(float), hipMemcpyDeviceToHost));
   return SMX_OK;
 }
 

@@ -116,6 +116,14 @@ def shard_for_rank(ids: np.ndarray, rank: int, world: int) -> np.ndarray:
   return ids[:n][rank::world]
 
 
+def shard_range(n_obs: int, rank: int, world: int) -> Tuple[int, int]:
+  """Contiguous data-parallel partition [lo, hi) of the cells (rank r owns N / world cells resident in
+  its HBM), every rank the same count.  Contiguous so that a cell's GLOBAL id (the Philox key of its dropout masks
+  and eps) is `lo + local row`: the noise of a cell does not depend on how the cells are sharded."""
+  n = n_obs // world
+  return rank * n, (rank + 1) * n
+
+
 # ---------------------------------------------------------------------------
 # synthetic stand-ins (SURVEY.md 8d); generator seed 8 = the repo's habitual seed
 # ---------------------------------------------------------------------------

@@ -195,6 +195,12 @@ class Engine:
                                    int(graph), C.byref(m) if metrics else None))
     return m.as_dict() if metrics else None
 
+  def metrics_history(self, n_steps: int) -> Dict[str, np.ndarray]:
+    """Per-step ELBO scalars of the last train_steps call: dict of arrays [n_steps]."""
+    h = np.empty((int(n_steps), 8), np.float32)
+    check(self.lib.smx_metrics_history(self._h, int(n_steps), _fp(h)))
+    return {k: h[:, i].copy() for i, k in enumerate(("loss", "nllk_x", "nllk_y", "kl", "kl_l"))}
+
   def eval_step(self, row_ids):
     ids = self._ids(row_ids)
     m = smx_metrics()

@@ -256,82 +256,146 @@ class SingleCellModel:
            valid_freq=500, valid_interval=0, epochs=500, max_iter=-1, sample_shape=(), logging_interval=2,
            earlystop_threshold=0.001, earlystop_progress_length=0, earlystop_patience=20, earlystop_min_epoch=-1,
            terminate_on_nan=True, checkpoint=None, allow_rollback=False, allow_none_gradients=False,
-           track_gradient_norms=False, log_tag=None, verbose=False, use_graph=False, **ignored):
+           track_gradient_norms=False, log_tag=None, verbose=False, use_graph=False, distributed="auto",
+           dp_batch="global", sync_bn=False, storage="f32", epochs_are_total=False, **ignored):
+    r"""The training loop (odin Trainer under single_cell_model.py:213-236).
+
+    The minibatch schedule is a pure function of the optimiser step count: iteration `it` visits batch
+    `it % steps_per_epoch` of the shuffle order of epoch `it // steps_per_epoch`, and the Philox streams are keyed by
+    `it` -- so a model restored with `load_weights` continues exactly where the interrupted run was (train.py:107-108).
+    `epochs` counts the epochs of THIS call (`epochs_are_total=True`: of the whole schedule, used when an experiment resumes).  `train_history[k]` holds one value per epoch (the mean over the epoch's
+    steps, kept on the device: `smx_metrics_history`), `valid_history['val_loss']` one per validation pass.
+
+    Data parallel (one process per GPU; `distributed='auto'` reads RANK / LOCAL_RANK / WORLD_SIZE as set by
+    `python -m torch.distributed.run`): rank r keeps the r-th contiguous 1/world of the training cells resident and
+    draws `batch_size / world` of them per step (`dp_batch='global'`: the reference's global batch is preserved,
+    SURVEY.md 8e) or `batch_size` (`dp_batch='per_rank'`); ONE RCCL all-reduce of the gradients per step;
+    `sync_bn=True` adds SyncBatchNorm (statistics over the global batch, as the single process computes them);
+    every rank evaluates the validation cells; only rank 0 runs `checkpoint`."""
     if str(optimizer).lower() != "adam":
       raise ValueError("only the 'adam' optimizer of configs/base.yaml is built")
+    from sisua_amd import data as _data
+    from sisua_amd.parallel import ControlPlane, attach_engine, env_rank_world
     self._opt = dict(lr=float(learning_rate), clipnorm=float(clipnorm or 0.0))
     n_lab = len(self._labels)
     if len(train.arrays) < 1 + n_lab:
       raise ValueError(f"{type(self).__name__} needs {1 + n_lab} omics per batch, the dataset has {len(train.arrays)}")
-    e = self._ensure_engine(max(train.batch_size, valid.batch_size if valid is not None else 1))
-    B = train.batch_size
-    n_tr = train.n_obs
-    # train and validation cells live in ONE resident matrix; validation rows are offset
-    X = train.arrays[0]
-    labs = [train.arrays[1 + j] for j in range(n_lab)]
-    lib, mask = train.library, train.mask
+    cp = None
+    if distributed in ("auto", True):
+      rank, local_rank, world = env_rank_world()
+    elif hasattr(distributed, "rank") and hasattr(distributed, "world"):   # a ready control plane (tests: LocalControlPlane)
+      cp, rank, local_rank, world = distributed, distributed.rank, self.device, distributed.world
+    else:
+      rank, local_rank, world = 0, 0, 1
+    B, drop_rem, lo, hi = train.batch_size, train.drop_remainder, 0, train.n_obs
+    if world > 1:
+      if dp_batch == "global":
+        if B % world:
+          raise ValueError(f"batch_size {B} is not divisible by the {world} ranks (dp_batch='global')")
+        B = B // world
+      elif dp_batch != "per_rank":
+        raise ValueError("dp_batch must be 'global' or 'per_rank'")
+      lo, hi = _data.shard_range(train.n_obs, rank, world)
+      drop_rem = True   # every rank runs the same number of equal-size steps
+      self.device = local_rank
+      cp = cp or ControlPlane(rank, world)
+    e = self._ensure_engine(max(B, valid.batch_size if valid is not None else 1))
+    if world > 1 and e.world != world:
+      attach_engine(e, cp)
+    if world > 1:
+      e.set_sync_bn(bool(sync_bn))
+    n_tr = hi - lo
+    if n_tr < 1 or (drop_rem and n_tr < B):
+      raise ValueError(f"{n_tr} training cells cannot fill one batch of {B} (drop_remainder)")
+    # train (this rank's shard) and validation cells live in ONE resident matrix; validation rows are offset
+    X = train.arrays[0][lo:hi]
+    labs = [train.arrays[1 + j][lo:hi] for j in range(n_lab)]
+    lib, mask = train.library[lo:hi], train.mask[lo:hi]
     if valid is not None:
       X = np.concatenate([X, valid.arrays[0]], 0)
       labs = [np.concatenate([a, valid.arrays[1 + j]], 0) for j, a in enumerate(labs)]
       lib = np.concatenate([lib, valid.library], 0)
       mask = np.concatenate([mask, valid.mask], 0)
-    e.upload(X, labs, lib, mask)
-    hist_t = self.train_history
-    hist_v = self.valid_history
-    best, bad, it, t_log = np.inf, 0, 0, time.time()
-    stop = False
-    # the next epoch's minibatch order is prepared on a host thread while the device runs the current one
-    # (the ctypes call releases the GIL); epoch_batches is a pure function of (seed, epoch)
-    def _prepare(ep):
-      return [b for b in train.epoch_batches(ep) if len(b) == B]  # fixed batch size on the device
+    e.upload(X, labs, lib, mask, cell_id_base=lo, storage=storage)   # Philox cell ids are GLOBAL: sharding-independent noise
+    seed_r = train.seed + 7919 * rank
+
+    def _prepare(ep):   # pure function of (seed, epoch): prepared on a host thread while the device runs the epoch before
+      return _data.iter_batches(_data.epoch_order(n_tr, ep, train.shuffle, seed_r), B, drop_rem)
+
+    spe = n_tr // B if drop_rem else -(-n_tr // B)
+    hist_t, hist_v = self.train_history, self.valid_history
+    it = int(e.step)
+    ep0 = it // spe
+    it_end = (int(epochs) if epochs_are_total else ep0 + int(epochs)) * spe
+    if max_iter and max_iter > 0:
+      it_end = min(it_end, it + int(max_iter))
+    best, bad, t_log, stop = np.inf, 0, time.time(), False
     pool = ThreadPoolExecutor(max_workers=1)
-    ahead = pool.submit(_prepare, 0) if int(epochs) > 0 else None
-    for epoch in range(int(epochs)):
-      batches = ahead.result()
-      ahead = pool.submit(_prepare, epoch + 1) if epoch + 1 < int(epochs) else None
-      pos = 0
-      while pos < len(batches) and not stop:
-        room = len(batches) - pos
-        until_valid = valid_freq - (it % valid_freq) if valid_freq and valid_freq > 0 else room
-        n = min(room, until_valid, (max_iter - it) if max_iter and max_iter > 0 else room)
-        if n <= 0:
-          stop = True
-          break
-        order = np.concatenate(batches[pos:pos + n]).astype(np.int32)
-        m = e.train_steps(order, n, B, graph=bool(use_graph), metrics=True)
-        pos += n
-        it += n
-        for k in ("loss", "nllk_x", "nllk_y", "kl", "kl_l"):
-          hist_t.setdefault(k, []).append(float(m[k]))
-        if terminate_on_nan and m["nan_flag"]:
-          raise FloatingPointError(f"non-finite loss at iteration {it}")
-        if verbose and time.time() - t_log > logging_interval:
-          print(f"[{log_tag or self.name}] it {it} epoch {epoch} loss {m['loss']:.4f} nllk_x {m['nllk_x']:.4f} kl {m['kl']:.4f}")
-          t_log = time.time()
-        if valid is not None and valid_freq and it % valid_freq == 0:
-          vl = self._validate(e, valid, n_tr)
-          hist_v.setdefault("val_loss", []).append(vl)
-          improved = vl < best * (1.0 - float(earlystop_threshold)) if np.isfinite(best) else True
-          if vl < best:
-            best = vl
-            if checkpoint is not None:
-              checkpoint()
-          bad = 0 if improved else bad + 1
-          if earlystop_patience and bad >= int(earlystop_patience) and epoch >= int(earlystop_min_epoch):
-            stop = True
-        if max_iter and max_iter > 0 and it >= max_iter:
-          stop = True
-      if stop:
-        break
-    pool.shutdown(wait=True)
+    ahead = pool.submit(_prepare, ep0) if it < it_end else None
+    epoch = ep0
+    try:
+      while it < it_end and not stop:
+        batches = ahead.result()
+        ahead = pool.submit(_prepare, epoch + 1) if (epoch + 1) * spe < it_end else None
+        pos = it - epoch * spe
+        acc = {}
+        while pos < spe and it < it_end and not stop:
+          room = min(spe - pos, it_end - it)
+          until_valid = valid_freq - (it % valid_freq) if valid_freq and valid_freq > 0 else room
+          n = max(1, min(room, until_valid))
+          # a ragged last batch (drop_remainder=False, the reference's default for fit(SingleCellOMIC)) is a step of its own
+          bs = len(batches[pos])
+          while n > 1 and len(batches[pos + n - 1]) != bs:
+            n -= 1
+          order = np.concatenate(batches[pos:pos + n]).astype(np.int32)
+          m = e.train_steps(order, n, bs, graph=bool(use_graph) and bs == B, metrics=True)
+          h = e.metrics_history(n)
+          pos += n
+          it += n
+          for k, v in h.items():
+            acc.setdefault(k, []).append(v)
+          if m["nan_flag"] or not np.isfinite(h["loss"]).all():
+            if terminate_on_nan:
+              raise FloatingPointError(f"non-finite loss or gradient norm at iteration {it}")
+            warnings.warn(f"non-finite loss or gradient norm at iteration {it}")
+          if verbose and rank == 0 and time.time() - t_log > logging_interval:
+            print(f"[{log_tag or self.name}] it {it} epoch {epoch} loss {m['loss']:.4f} nllk_x {m['nllk_x']:.4f} kl {m['kl']:.4f}")
+            t_log = time.time()
+          if valid is not None and valid_freq and it % valid_freq == 0:
+            vl = self._validate(e, valid, n_tr, cp)
+            hist_v.setdefault("val_loss", []).append(vl)
+            improved = vl < best * (1.0 - float(earlystop_threshold)) if np.isfinite(best) else True
+            if vl < best:
+              best = vl
+              self._checkpoint(checkpoint, rank, cp)
+            bad = 0 if improved else bad + 1
+            if earlystop_patience and bad >= int(earlystop_patience) and epoch >= int(earlystop_min_epoch):
+              stop = True
+        for k, parts in acc.items():   # one value per epoch: the mean over its steps
+          hist_t.setdefault(k, []).append(float(np.mean(np.concatenate(parts))))
+        epoch += 1
+    finally:
+      pool.shutdown(wait=True)
     if valid is not None and not hist_v.get("val_loss"):
-      hist_v.setdefault("val_loss", []).append(self._validate(e, valid, n_tr))
-    if checkpoint is not None and valid is None:
-      checkpoint()
+      hist_v.setdefault("val_loss", []).append(self._validate(e, valid, n_tr, cp))
+    if valid is None:
+      self._checkpoint(checkpoint, rank, cp)
+    if cp is not None:
+      cp.barrier()
     return self
 
   @staticmethod
-  def _validate(e: Engine, valid: BatchDataset, offset: int) -> float:
+  def _checkpoint(checkpoint, rank, cp):
+    if checkpoint is not None and rank == 0:   # replicas are identical: one writer
+      checkpoint()
+    if cp is not None:
+      cp.barrier()
+
+  @staticmethod
+  def _validate(e: Engine, valid: BatchDataset, offset: int, cp=None) -> float:
+    """Eval-mode ELBO of the validation cells.  Data parallel: every rank scores all of them (its own draw of the
+    latent noise) and the ranks' values are averaged over the control plane, so that every rank takes the same
+    early-stopping / checkpoint decisions."""
     tot, n = 0.0, 0
     for ids in valid.epoch_batches(0):
       if len(ids) == 0:
@@ -339,7 +403,10 @@ class SingleCellModel:
       m = e.eval_step((ids + offset).astype(np.int32))
       tot += m["loss"] * len(ids)
       n += len(ids)
-    return tot / max(n, 1)
+    vl = tot / max(n, 1)
+    if cp is not None and cp.world > 1:
+      vl = float(cp.sum_array(np.array([vl]))[0]) / cp.world
+    return vl
 
   # ---- inference ------------------------------------------------------------------------------
   def _latent_dists(self, out, sl=slice(None)):
@@ -509,9 +576,12 @@ class SingleCellModel:
 
   # ---- checkpoints --------------------------------------------------------------------------------
   def save_weights(self, filepath, overwrite=True):
-    r"""Weights + optimiser state + BN statistics in `<filepath>.npz` and the
-    `<filepath>.metamodel` pickle [class_name, dataset, metadata, init_args] of the
-    reference (single_cell_model.py:295-306)."""
+    r"""Weights + optimiser state + BN statistics + step in `<filepath>.npz`, and the reference's sidecar
+    `<filepath>.metamodel` = pickle([class_name, dataset, metadata, init_kwargs]) (single_cell_model.py:295-306).
+    The sidecar holds PLAIN records only (dicts / lists / numpy arrays: `RVmeta` / `NetConf` arguments are stored as
+    `{"__record__": "RVmeta", ...}` and rebuilt on load), so reading it needs neither this package's classes nor
+    odin's.  Both files are written to a temporary name and renamed (the weights last): an interrupted save leaves
+    the previous checkpoint intact (the TF checkpoint writer of the reference is atomic in the same way)."""
     if self._engine is None:
       self._ensure_engine(64)
     if not overwrite and os.path.exists(f"{filepath}.npz"):
@@ -525,9 +595,13 @@ class SingleCellModel:
     flat["step"] = np.array(st["step"], dtype=np.int64)
     d = os.path.dirname(os.path.abspath(filepath))
     os.makedirs(d, exist_ok=True)
-    np.savez(f"{filepath}.npz", **flat)
-    with open(f"{filepath}.metamodel", "wb") as f:
-      pickle.dump([self.__class__.__name__, self.dataset, self.metadata, dict(self.init_args)], f)
+    tmp = f"{filepath}.tmp{os.getpid()}"
+    with open(f"{tmp}.metamodel", "wb") as f:
+      pickle.dump([self.__class__.__name__, self.dataset, _to_plain(self.metadata), _to_plain(dict(self.init_args))], f)
+    os.replace(f"{tmp}.metamodel", f"{filepath}.metamodel")
+    with open(f"{tmp}.npz", "wb") as f:
+      np.savez(f, **flat)
+    os.replace(f"{tmp}.npz", f"{filepath}.npz")
     return self
 
   def load_weights(self, filepath, raise_notfound=False, verbose=False):
@@ -549,8 +623,7 @@ class SingleCellModel:
                          v={k[2:]: z[k] for k in z.files if k.startswith("v/")}, bn=bn, step=int(z["step"])))
     metamodel_path = f"{filepath}.metamodel"
     if os.path.exists(metamodel_path):
-      with open(metamodel_path, "rb") as f:
-        class_name, dataset, metadata, kwargs = pickle.load(f)
+      class_name, dataset, metadata, kwargs = read_metamodel(metamodel_path)
       assert class_name == self.__class__.__name__
       self.dataset = dataset
       self.metadata = metadata
@@ -653,8 +726,83 @@ def get_model(model):
 
 
 def load_model(filepath: str) -> SingleCellModel:
-  with open(f"{filepath}.metamodel", "rb") as f:
-    class_name, dataset, metadata, kwargs = pickle.load(f)
+  r"""sisua/models/__init__.py:30-38.  The sidecar is a pickle (as in the reference): load trusted files only."""
+  class_name, dataset, metadata, kwargs = read_metamodel(f"{filepath}.metamodel")
   model = get_model(class_name)(**kwargs)
   model.load_weights(filepath, raise_notfound=True)
   return model
+
+
+# ---- the `.metamodel` sidecar as plain records ---------------------------------------------------------
+_RECORDS = {"RVmeta": RVmeta, "NetConf": NetConf}
+
+
+def _to_plain(v):
+  """Config records -> tagged dicts, containers recursively; arrays and scalars stay."""
+  if isinstance(v, (RVmeta, NetConf)):
+    d = {k: _to_plain(getattr(v, k)) for k in v.__dataclass_fields__}
+    d["__record__"] = type(v).__name__
+    return d
+  if isinstance(v, dict):
+    return {k: _to_plain(x) for k, x in v.items()}
+  if isinstance(v, (list, tuple)):
+    return [_to_plain(x) for x in v]
+  return v
+
+
+def _from_plain(v):
+  if isinstance(v, dict) and "__record__" in v:
+    cls = _RECORDS[v["__record__"]]
+    return cls(**{k: _from_plain(x) for k, x in v.items() if k != "__record__" and k in cls.__dataclass_fields__})
+  if isinstance(v, dict):
+    return {k: _from_plain(x) for k, x in v.items()}
+  if isinstance(v, list):
+    return [_from_plain(x) for x in v]
+  return v
+
+
+class _Shim:
+  """Stand-in for a class this process cannot import (odin's RVmeta / NetConf inside a sidecar the REFERENCE
+  wrote): pickle restores its attribute dict, `_shim_to_record` turns it into this package's record."""
+
+  def __init__(self, *a, **kw):
+    self.__dict__.update(kw)
+
+  def __setstate__(self, state):
+    self.__dict__.update(state if isinstance(state, dict) else {})
+
+
+class _TolerantUnpickler(pickle.Unpickler):
+
+  def find_class(self, module, name):
+    try:
+      return super().find_class(module, name)
+    except Exception:
+      return type(name, (_Shim,), {"_shim_name": name})
+
+
+def _shim_to_record(v):
+  if isinstance(v, _Shim):
+    nm, st = getattr(v, "_shim_name", ""), dict(v.__dict__)
+    if nm in ("RVmeta", "RVconf", "RandomVariable"):
+      ev = st.get("event_shape", st.get("dim", 10))
+      return RVmeta(event_shape=ev, posterior=st.get("posterior", "diag"), projection=bool(st.get("projection", True)),
+                    name=st.get("name"), kwargs=dict(st.get("kwargs", {}) or {}))
+    if nm in ("NetConf", "NetworkConfig"):
+      return NetConf(units=st.get("units", (64, 64)), batchnorm=bool(st.get("batchnorm", True)),
+                     dropout=float(st.get("dropout", 0.0) or 0.0), input_dropout=float(st.get("input_dropout", 0.0) or 0.0),
+                     name=st.get("name"))
+    return st
+  if isinstance(v, dict):
+    return {k: _shim_to_record(x) for k, x in v.items()}
+  if isinstance(v, (list, tuple)):
+    return [_shim_to_record(x) for x in v]
+  return v
+
+
+def read_metamodel(path: str):
+  """[class_name, dataset, metadata, init_kwargs] of a `.metamodel` sidecar: this package's plain-record form, or
+  one written by the reference itself (its odin RVmeta / NetConf instances are mapped onto the records here)."""
+  with open(path, "rb") as f:
+    class_name, dataset, metadata, kwargs = _TolerantUnpickler(f).load()
+  return class_name, dataset, _shim_to_record(_from_plain(metadata)), _shim_to_record(_from_plain(kwargs))

@@ -65,9 +65,66 @@ class ControlPlane:
       self.dist.destroy_process_group()
 
 
-def attach_engine(engine, cp: ControlPlane):
-  """Join the engine to the RCCL communicator of the job (unique id from rank 0)."""
+class LocalControlPlane:
+  """Same interface for `world` replicas living in ONE process as threads on ONE GPU (tests: the data-parallel path
+  of SingleCellModel.fit on a one-GPU box).  `LocalControlPlane.group(world)` returns one plane per rank; the engines
+  join the library's loopback communicator (smx_comm_init_local) instead of RCCL."""
+
+  class _Shared:
+
+    def __init__(self, world):
+      import threading
+      self.world = world
+      self.barrier = threading.Barrier(world, timeout=120)
+      self.box = [None] * world
+      self.engines = [None] * world
+
+  def __init__(self, rank: int, shared: "LocalControlPlane._Shared"):
+    self.rank, self.world, self._s = rank, shared.world, shared
+
+  @classmethod
+  def group(cls, world: int):
+    sh = cls._Shared(world)
+    return [cls(r, sh) for r in range(world)]
+
+  def barrier(self):
+    self._s.barrier.wait()
+
+  def _gather(self, value):
+    self._s.box[self.rank] = value
+    self._s.barrier.wait()
+    vals = list(self._s.box)
+    self._s.barrier.wait()
+    return vals
+
+  def broadcast_bytes(self, make: Callable[[], bytes], src: int = 0) -> bytes:
+    return self._gather(make() if self.rank == src else None)[src]
+
+  def max(self, value: float) -> float:
+    return float(max(self._gather(float(value))))
+
+  def sum_array(self, a: np.ndarray) -> np.ndarray:
+    return np.sum(self._gather(np.asarray(a, dtype=np.float64)), axis=0)
+
+  def attach(self, engine):
+    self._s.engines[self.rank] = engine
+    self._s.barrier.wait()
+    if self.rank == 0:
+      from sisua_amd.engine import Engine
+      Engine.comm_init_local(self._s.engines)
+    self._s.barrier.wait()
+
+  def close(self):
+    pass
+
+
+def attach_engine(engine, cp):
+  """Join the engine to the communicator of the job: RCCL (unique id from rank 0 over the control plane), or the
+  library's loopback communicator for an in-process LocalControlPlane."""
   if cp.world <= 1:
+    return
+  if isinstance(cp, LocalControlPlane):
+    cp.attach(engine)
     return
   from sisua_amd.engine import Engine
   uid = cp.broadcast_bytes(Engine.comm_unique_id)

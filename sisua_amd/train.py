@@ -67,16 +67,34 @@ def _from_config(cfg: Dict, fn, overrides=None):
   return fn(**kw)
 
 
-class Experiment:
+def config_hash(cfg: Dict, exclude_keys=("train", "verbose"), hash_length: int = 5) -> str:
+  """Identity of an experiment: md5 of the configuration without the keys that do not change WHAT is trained
+  (`Experimenter(exclude_keys=["train", "verbose"], hash_length=5)`, sisua/train.py:51-55)."""
+  import hashlib
+  import json
+  core = {k: v for k, v in cfg.items() if k not in exclude_keys}
+  return hashlib.md5(json.dumps(core, sort_keys=True, default=str).encode()).hexdigest()[:hash_length]
 
-  def __init__(self, cfg: Dict = None, model_dir: str = None):
+
+class Experiment:
+  """on_load_data -> on_create_model -> on_train of sisua/train.py:61-147.  With `save_path` every configuration gets
+  its own directory `<save_path>/exp_<5-char hash>/` (train.py:49-59): the model ALWAYS tries `load_weights` from
+  there when it is created (train.py:107-108), so re-running an interrupted experiment resumes it -- the training
+  schedule is a pure function of the restored step count (SingleCellModel._fit), the remaining epochs are
+  `train.epochs` minus the epochs already done."""
+
+  def __init__(self, cfg: Dict = None, model_dir: str = None, save_path: str = None):
     self.cfg = copy.deepcopy(DEFAULT_CONFIG)
     for k, v in (cfg or {}).items():
       if isinstance(v, dict) and isinstance(self.cfg.get(k), dict):
         _deep_update(self.cfg[k], v)
       else:
         self.cfg[k] = v
+    self.hash = config_hash(self.cfg)
+    if model_dir is None and save_path is not None:
+      model_dir = os.path.join(save_path, f"exp_{self.hash}")
     self.model_dir = model_dir
+    self.resumed_from = 0
 
   def on_load_data(self):
     ds = self.cfg["dataset"]
@@ -98,6 +116,7 @@ class Experiment:
     self.model = _from_config({k: v for k, v in model.items() if k not in ("name", "encoder", "decoder")}, cls, overrides)
     if self.model_dir:
       self.model.load_weights(os.path.join(self.model_dir, "model"), verbose=self.cfg["verbose"])
+      self.resumed_from = int(self.model.step)
     self.omics = [l.name for l in self.model.output_layers] + [l.name for l in self.model.labels]
 
   def on_train(self):
@@ -109,6 +128,8 @@ class Experiment:
                                     drop_remainder=True, shuffle=1000)
     fn_save = partial(self.model.save_weights, filepath=os.path.join(self.model_dir, "model")) if self.model_dir else None
     tr["sample_shape"] = tuple(tr.get("sample_shape", ()))
+    # re-running an interrupted experiment finishes ITS schedule: `train.epochs` is then the total, not an increment
+    tr["epochs_are_total"] = bool(self.resumed_from)
     self.model.fit(mk(train), valid=mk(valid), checkpoint=fn_save, log_tag=f"{self.cfg['model']['name']}-{ds['name']}",
                    verbose=self.cfg["verbose"], **tr)
     return self.model
@@ -143,6 +164,6 @@ def _parse_overrides(argv):
 
 
 if __name__ == "__main__":
-  exp = Experiment(_parse_overrides(sys.argv[1:]), model_dir=os.environ.get("SISUA_EXP"))
+  exp = Experiment(_parse_overrides(sys.argv[1:]), save_path=os.environ.get("SISUA_EXP"))
   m = exp.run()
-  print(m, "final loss", m.train_history["loss"][-1], "val", m.valid_history.get("val_loss", [None])[-1])
+  print(m, "final loss", (m.train_history.get("loss") or [None])[-1], "val", m.valid_history.get("val_loss", [None])[-1])

@@ -30,10 +30,16 @@ def test_workloads_follow_baseline_configs(workload, batch, model, lk):
     assert 0.05 < extra["label_mask"].mean() < 0.15          # labels_percent = 0.1
 
 
-def test_ranks_get_different_shards_and_same_model():
-  c0, x0, _, _ = bench.build_workload(0, 2, "8kly")
-  c1, x1, _, _ = bench.build_workload(1, 2, "8kly")
-  assert c0 == c1 and x0.shape == x1.shape and not np.array_equal(x0, x1)
+def test_ranks_shard_one_dataset():
+  """ONE matrix, rank r keeps the r-th contiguous 1/world of its cells; cell ids stay global."""
+  c, x, _, e = bench.build_workload(0, 1, "eccly-sisua")
+  c0, x0, _, e0 = bench.build_workload(0, 2, "eccly-sisua")
+  c1, x1, _, e1 = bench.build_workload(1, 2, "eccly-sisua")
+  n = x.shape[0] // 2
+  assert c0 == c1 == c and x0.shape == x1.shape == (n, x.shape[1])
+  assert np.array_equal(x0, x[:n]) and np.array_equal(x1, x[n:2 * n])
+  assert (e0["cell_id_base"], e1["cell_id_base"]) == (0, n)
+  assert np.array_equal(e1["labels"][0], e["labels"][0][n:2 * n]) and np.array_equal(e1["label_mask"], e["label_mask"][n:2 * n])
 
 
 def test_order_is_whole_batches_of_valid_rows():
