@@ -216,7 +216,7 @@ def main():
   eng.timing_enable(None)
   ev_overhead_us = 1e3 * null_ms / max(null_n, 1)
   per_kernel = {}
-  for name in ("gemm_enc_fwd", "gemm_out_fwd", "out_head", "gemm_out_bwd", "gemm_enc_dw", "adam", "step"):
+  for name in ("gemm_enc_fwd", "gemm_out_fwd", "out_head", "out_head_product", "gemm_out_bwd", "gemm_enc_dw", "adam", "step"):
     eng.timing_enable(name)
     n_k = min(50, args.warmup + args.steps)
     eng.train_steps(order[: n_k * batch], n_k, batch, graph=False)

@@ -69,8 +69,9 @@ __device__ inline float4 normal4(const U4& w) {
   const float u2b = u24(w.w);
   // fast forms: v_log_f32 and the revolution-based v_sin_f32 / v_cos_f32 (sin(2 pi u) directly);
   // absolute error of a draw ~1e-6, far inside the 1e-4 parity budget
-  const float ra = __fsqrt_rn(-2.0f * __logf(u1a));
-  const float rb = __fsqrt_rn(-2.0f * __logf(u1b));
+  // -2 ln u = -2 ln2 log2 u: one v_log_f32 and one v_sqrt_f32 per pair (u >= 2^-24: never denormal)
+  const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1a));
+  const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1b));
   const float sa = __builtin_amdgcn_sinf(u2a), ca = __builtin_amdgcn_cosf(u2a);
   const float sb = __builtin_amdgcn_sinf(u2b), cb = __builtin_amdgcn_cosf(u2b);
   return float4{ra * ca, ra * sa, rb * cb, rb * sb};
@@ -81,11 +82,16 @@ __device__ inline float4 normal4(const U4& w) {
 // ---------------------------------------------------------------------------
 #define SMX_SOFTPLUS_INV_1 0.54132485461291810f  // log(e - 1)
 
-// Fast transcendental forms (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp of the
-// base-2 function): the kernels are parity-bound at 1e-4, not at 1 ulp.
-__device__ inline float fexp(float x) { return __expf(x); }
-__device__ inline float flog(float x) { return __logf(x); }
-__device__ inline float frcp(float x) { return __frcp_rn(x); }
+// Fast transcendental forms: ONE hardware instruction each (v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sqrt_f32, ~1 ulp of
+// the base-2 function) -- the kernels are parity-bound at 1e-4, not at 1 ulp.  The HIP spellings do NOT give
+// these: __logf expands to the denormal-safe log (v_ldexp + v_log + a 4-term correction, 14 instructions),
+// __frcp_rn to the correctly rounded division (v_div_scale / v_div_fmas / v_div_fixup, 10 instructions); together
+// they were half of the likelihood kernel's ~500 vector instructions per element.  Every argument here is a
+// normal float (1 + e, rising factorials >= 1e-30, mu + 1e-8, ...), so the denormal paths bought nothing.
+__device__ inline float fexp(float x) { return __expf(x); }                                        // v_mul + v_exp
+__device__ inline float flog(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }   // v_log (log2) + v_mul
+__device__ inline float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // log(1 + e) for e >= 0 without losing e below 2^-24: series under 1/32, v_log above.
 __device__ inline float log1p_small(float e) {

@@ -1,0 +1,206 @@
+// smx_headloss.hip -- output-head product FUSED with the count likelihood, wide (training step of VAE / DCA /
+// SISUA count outputs; SURVEY.md 8 rows a-9 + a-10 / a-11):
+//
+//   P = d W_out + b  ->  NB / ZINB / NBD / ZINBD log-likelihood of x and d llk / d P, scaled  ->  dP, llk partials
+//
+// The parameter planes P never exist in memory: they live in MFMA accumulators, the likelihood runs on them and
+// only dP (which the two backward products read) and one partial sum per (cell, gene tile) are written.  Against
+// the product + loss kernel pair that removes the P write (4kG B/cell), the P read and one kernel boundary.
+//
+// Shape of the work: a workgroup owns a 32-cell x 32-gene tile with ALL k planes of it and
+// splits K = H over its 4 waves, so that the grid is (B / 32) x (Gp / 32) = 252 workgroups at the benchmark size
+// (one per CU) -- the earlier fused head (smx_head.hip: 16 genes x whole batch, with dW / db folded in) had 126.
+//  * no LDS in the main loop: with K split over the waves no operand element is used by two waves, so both go
+//    straight from global memory to the MFMA operand registers.  The k index of v_mfma_f32_32x32x2_f32 is free
+//    to permute: lane (i, h) supplies k = 16 h + s in step s, i.e. 16 CONSECUTIVE floats of row i of d (four
+//    16-byte loads) and, for W, rows 16 h + s of a 128-byte column segment (coalesced);
+//  * the 4 partial tiles meet in LDS (k x 16 KB), wave q finishes accumulator registers 4q .. 4q+3 of every plane
+//    = cells 8q .. 8q+7 of the tile: sum in wave order, bias, likelihood, gradient stores;
+//  * the counts x are gathered BEFORE the product (they do not depend on it);
+//  * XCD-aware mapping: the (B / 32) workgroups that share a W tile are 8 blocks apart (same XCD under round-robin
+//    dispatch), so each W tile is fetched into one L2 only.
+#include <stdlib.h>
+
+#include "smx_internal.h"
+#include "smx_loss.h"
+#include "../../include/sisua_hip.h"
+
+namespace smx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// EPI: 1 likelihood epilogue (the training kernel); 0 product only -- stores P instead of dP, reads no counts
+// (what the standalone product kernel does; used to attribute the fused kernel's time to the likelihood).
+// NW waves per workgroup split every 128-deep slab of K: lane (i, h) of wave q supplies k = q KS + (KS/2) h + s in
+// MFMA step s (KS = 128 / NW) and finishes accumulator registers q RPW .. q RPW + RPW - 1 (RPW = 16 / NW).
+template <int LK, int U16, int EPI, int NW>
+__global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) {
+  constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
+  constexpr int KS = 128 / NW, KH = KS / 2, RPW = 16 / NW;
+  __shared__ float red[NW * NP * 1024];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  // blocks b, b + 8, b + 16, ... share an XCD: give them the cell tiles of ONE gene tile
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int ct = idx % a.n_ct, gt = (idx / a.n_ct) * 8 + xcd;
+  if (gt >= a.n_gt) return;
+  const int m0 = ct * 32, n0 = gt * 32;
+  const int col = n0 + i;
+  // accumulator register r of a 32 x 32 tile is row (r & 3) + 8 (r >> 2) + 4 h, column i
+  int rowof[RPW];
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) { const int r = q * RPW + j; rowof[j] = m0 + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+  // ---- loads, oldest first: row ids of this wave's finishing cells -> operands of the first K slab -> the counts
+  // (they do not depend on the product; their latency hides under the MFMAs) -----------------------------------------
+  long src[RPW];
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int cell = min(rowof[j], a.B - 1);
+    src[j] = (EPI && a.rows) ? a.rows[cell] : cell;
+  }
+  float bias[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) bias[p] = a.bias[(long)p * a.Gp + col];
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x16 acc[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  const int arow = min(m0 + i, a.B - 1);   // rows beyond the batch compute garbage that is never stored
+  float av[KH], bv[NP][KH];
+  // ALL operand loads of a slab are issued before its first MFMA (left alone the compiler waits for each W load
+  // right before the MFMA that uses it: ~30 serial L2 / HBM round trips, 9.8 us for the product alone)
+  auto load_slab = [&](int kc) {
+    const int k0 = kc + KS * q + KH * h;          // first k of this lane half in this slab
+    const float* ap = a.H + (long)arow * a.ldh + k0;
+#pragma unroll
+    for (int v = 0; v < KH / 4; ++v) {
+      const float4 t = *reinterpret_cast<const float4*>(ap + 4 * v);
+      av[4 * v] = t.x; av[4 * v + 1] = t.y; av[4 * v + 2] = t.z; av[4 * v + 3] = t.w;
+    }
+    const float* wp = a.W + (long)k0 * a.ldw + col;
+#pragma unroll
+    for (int s = 0; s < KH; ++s)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) bv[p][s] = wp[(long)s * a.ldw + (long)p * a.Gp];
+  };
+  auto mfma_slab = [&]() {
+#pragma unroll
+    for (int s = 0; s < KH; ++s)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[p][s], acc[p], 0, 0, 0);
+  };
+  const bool active = KS * q < a.Hp;              // wave-uniform: this wave has a K slice in the first slab
+  if (active) load_slab(0);
+  __builtin_amdgcn_sched_barrier(0);
+  float xs[RPW];
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    xs[j] = 0.f;
+    if (EPI) xs[j] = U16 ? (float)reinterpret_cast<const uint16_t*>(a.X)[src[j] * a.ldx + col] : a.X[src[j] * a.ldx + col];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (active) mfma_slab();
+  for (int kc = 128; kc + KS * q < a.Hp; kc += 128) {
+    load_slab(kc);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_slab();
+  }
+
+  // ---- the NW partial tiles meet in LDS; wave q finishes registers q RPW .. q RPW + RPW - 1 ---------------------
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((q * NP + p) * 16 + r) * 64 + lane] = acc[p][r];
+  __syncthreads();
+  float v[NP][RPW];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const int r = q * RPW + j;
+      float t = red[((0 * NP + p) * 16 + r) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) t += red[((w * NP + p) * 16 + r) * 64 + lane];
+      v[p][j] = t + bias[p];
+    }
+
+  // ---- likelihood + gradient on the tile: the RPW elements of a lane as interleaved straight-line chains ------------
+  const bool live = col < a.G;
+  float llk[RPW], d0[RPW], d1[RPW], d2[RPW];
+  if (EPI) {
+    float p2[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) p2[j] = NP == 3 ? v[NP - 1][j] : 0.f;
+    count_elem_vec<LK, 0, RPW>(xs, v[0], v[1], p2, llk, d0, d1, d2);
+  }
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int cell = rowof[j];
+    const bool ok = live && cell < a.B;
+    float d[3];
+    if (EPI) { d[0] = ok ? d0[j] * a.grad_scale : 0.f; d[1] = ok ? d1[j] * a.grad_scale : 0.f; d[2] = ok ? d2[j] * a.grad_scale : 0.f; }
+    else { d[0] = v[0][j]; d[1] = v[1][j]; d[2] = NP == 3 ? v[NP - 1][j] : 0.f; }
+    if (cell < a.B) {
+      float* dp = a.dP + (long)cell * a.ldp + col;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) dp[(long)p * a.plane_stride] = d[p];
+    }
+    if (EPI) {
+      // per-cell partial over the tile's 32 genes: the 32 lanes of this half hold them
+      float t = ok ? llk[j] : 0.f;
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) t += __shfl_xor(t, off, 64);
+      if (i == 0 && cell < a.B) a.llk_part[(long)cell * a.n_gt + gt] = t;
+    }
+  }
+}
+
+bool head_loss_supported(int B, int Hp, int Gp) { return B > 0 && Hp % 32 == 0 && Gp % 32 == 0; }
+int head_loss_chunks(int Gp) { return Gp / 32; }
+
+static int head_waves() {   // waves per workgroup (SMX_HEAD_WAVES = 4 | 8)
+  static const int v = getenv("SMX_HEAD_WAVES") ? atoi(getenv("SMX_HEAD_WAVES")) : 8;
+  return v == 4 ? 4 : 8;
+}
+
+template <int LK, int NW>
+static void launch_hl_w(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
+  if (a.product_only) {
+    hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 0, NW>), grid, dim3(64 * NW), 0, st, a);
+  } else if (a.x_u16) {
+    hipLaunchKernelGGL((out_head_loss_kernel<LK, 1, 1, NW>), grid, dim3(64 * NW), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 1, NW>), grid, dim3(64 * NW), 0, st, a);
+  }
+}
+template <int LK>
+static void launch_hl(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
+  if (head_waves() == 4) launch_hl_w<LK, 4>(st, a, grid); else launch_hl_w<LK, 8>(st, a, grid);
+}
+
+int launch_out_head_loss(hipStream_t st, const HeadLossArgs& a_in) {
+  HeadLossArgs a = a_in;
+  if (!head_loss_supported(a.B, a.Hp, a.Gp) || (a.ldh % 4) || !a.H || !a.W || !a.bias || !a.dP || (!a.product_only && (!a.X || !a.llk_part))) {
+    set_error("out_head_loss: bad shapes");
+    return SMX_ERR_INVALID;
+  }
+  a.n_ct = (a.B + 31) / 32;
+  a.n_gt = a.Gp / 32;
+  const int gt8 = (a.n_gt + 7) / 8 * 8;
+  dim3 grid((unsigned)(a.n_ct * gt8));
+  switch (a.likelihood) {
+    case SMX_LLK_NB: launch_hl<SMX_LLK_NB>(st, a, grid); break;
+    case SMX_LLK_ZINB: launch_hl<SMX_LLK_ZINB>(st, a, grid); break;
+    case SMX_LLK_NBD: launch_hl<SMX_LLK_NBD>(st, a, grid); break;
+    case SMX_LLK_ZINBD: launch_hl<SMX_LLK_ZINBD>(st, a, grid); break;
+    default: set_error("out_head_loss: unknown likelihood"); return SMX_ERR_INVALID;
+  }
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+}  // namespace smx

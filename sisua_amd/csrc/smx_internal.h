@@ -332,6 +332,23 @@ bool out_head_supported(int B, int Hp, int Gp);
 int out_head_chunks(int Gp);
 int launch_out_head_train(hipStream_t st, const OutHeadArgs& a);
 
+// ---- output product fused with the count likelihood, wide (smx_headloss.hip) -------------------
+struct HeadLossArgs {
+  const float* H = nullptr; int ldh = 0;          // decoder output [B][ldh] (after BN / ReLU / dropout)
+  const float* W = nullptr; int ldw = 0;          // [Hp][k * Gp]
+  const float* bias = nullptr;                    // [k * Gp]
+  const float* X = nullptr; int ldx = 0; const int32_t* rows = nullptr; int x_u16 = 0;
+  float* dP = nullptr; long ldp = 0; long plane_stride = 0;   // d loss / d P (product_only: P itself)
+  float* llk_part = nullptr;                      // [B][Gp / 32]
+  int B = 0, G = 0, Gp = 0, Hp = 0, likelihood = 0;
+  float grad_scale = 1.f;
+  int product_only = 0;                           // timing variant: the product alone, P stored
+  int n_ct = 0, n_gt = 0;                         // set by the launcher
+};
+bool head_loss_supported(int B, int Hp, int Gp);
+int head_loss_chunks(int Gp);
+int launch_out_head_loss(hipStream_t st, const HeadLossArgs& a);
+
 // ---- dataset kernels (smx_data.hip) ------------------------------------------------------------
 enum { ST_CORRUPT_SELECT = 80, ST_CORRUPT_BINOMIAL = 81 };   // Philox streams of the on-device corruption
 struct CorruptArgs {

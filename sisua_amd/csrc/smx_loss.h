@@ -63,5 +63,115 @@ __device__ inline void count_elem(float x, float p0, float p1, float p2, float& 
   }
 }
 
+// ===========================================================================
+// The same arithmetic for N independent elements of one lane, written stage by stage as straight-line code
+// (selects instead of branches; the rare Stirling path of lgamma / digamma behind ONE wave-uniform test) so that
+// the scheduler can interleave the N dependent chains: with one or two waves per SIMD a lone chain issues one
+// dependent instruction per ~13 cycles, and an element-after-element epilogue ran at a third of the rate.
+// Results are bit-identical to count_elem (same operations in the same order per element).
+// ===========================================================================
+template <int N>
+__device__ inline void lgamma_digamma_diff_vec(const float (&x)[N], const float (&r_in)[N], float (&lg)[N], float (&dg)[N]) {
+  float r[N];
+  bool rare = false;
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    r[e] = fminf(fmaxf(r_in[e], 1e-30f), 1e30f);
+    float P = 1.f, dP = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float t = r[e] + (float)i;
+      const bool on = (float)i < x[e];
+      dP = on ? fmaf(dP, t, P) : dP;
+      P = on ? P * t : P;
+    }
+    lg[e] = flog(P);
+    dg[e] = dP * frcp(P);
+    rare |= !((x[e] <= 8.0f) && (x[e] == floorf(x[e])) && (r[e] < 1e4f));
+  }
+  if (!__any(rare)) return;   // wave-uniform: 99 % of single-cell counts are integers in 0..8
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const bool small = (x[e] <= 8.0f) && (x[e] == floorf(x[e])) && (r[e] < 1e4f);
+    const float nf = fmaxf(ceilf(4.0f - r[e]), 0.f);
+    float ratio = 1.f, dg_shift = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = r[e] + (float)i, b = x[e] + a;
+      const bool on = (float)i < nf;
+      const float ib = frcp(b);
+      ratio = on ? ratio * a * ib : ratio;
+      dg_shift = on ? dg_shift + x[e] * ib * frcp(a) : dg_shift;
+    }
+    const float lg_shift = flog(ratio);
+    const float rs = r[e] + nf;
+    const float zr = x[e] + rs;
+    const float l1p = log1p_small(x[e] * frcp(rs));
+    const float lgr = x[e] * flog(zr) + (rs - 0.5f) * l1p - x[e] + (stirling_corr(zr) - stirling_corr(rs)) + lg_shift;
+    const float dgr = l1p + (digamma_corr(zr) - digamma_corr(rs)) + dg_shift;
+    lg[e] = small ? lg[e] : lgr;
+    dg[e] = small ? dg[e] : dgr;
+  }
+}
+
+template <int LK, int DIRECT, int N>
+__device__ inline void count_elem_vec(const float (&x)[N], const float (&p0)[N], const float (&p1)[N], const float (&p2)[N],
+                                      float (&llk)[N], float (&d0)[N], float (&d1)[N], float (&d2)[N]) {
+  float ell[N];
+  if (LK == SMX_LLK_NB || LK == SMX_LLK_ZINB) {
+    float r[N], lg[N], dg[N];
+    SpSg s[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) { r[e] = fexp(p0[e]); s[e] = softplus_sigmoid(p1[e]); }
+    lgamma_digamma_diff_vec<N>(x, r, lg, dg);
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      ell[e] = lg[e] + x[e] * (p1[e] - s[e].sp) - r[e] * s[e].sp;
+      d0[e] = r[e] * (dg[e] - s[e].sp);
+      d1[e] = x[e] - (x[e] + r[e]) * s[e].sg;
+    }
+  } else {
+    float mu[N], th[N], g0[N], g1[N], lg[N], dg[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      if (DIRECT) { mu[e] = p0[e]; th[e] = p1[e]; g0[e] = 1.f; g1[e] = 1.f; }
+      else {
+        const SpSg s0 = softplus_sigmoid(p0[e]), s1 = softplus_sigmoid(p1[e] + SMX_SOFTPLUS_INV_1);
+        mu[e] = s0.sp; th[e] = s1.sp; g0[e] = s0.sg; g1[e] = s1.sg;
+      }
+    }
+    lgamma_digamma_diff_vec<N>(x, th, lg, dg);
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const float eps = 1e-8f;
+      const float inv_te = frcp(th[e] + eps), inv = frcp(th[e] + mu[e] + eps);
+      const float l1p = log1p_small(mu[e] * inv_te);
+      const float lt = flog(th[e] + mu[e] + eps);
+      ell[e] = -th[e] * l1p + x[e] * (flog(mu[e] + eps) - lt) + lg[e];
+      d0[e] = (-th[e] * inv + x[e] * frcp(mu[e] + eps) - x[e] * inv) * g0[e];
+      d1[e] = (-l1p + th[e] * mu[e] * inv_te * inv - x[e] * inv + dg[e]) * g1[e];
+    }
+  }
+  if (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const SpSg sg = softplus_sigmoid(p2[e]);
+      const float dlt = ell[e] - p2[e];
+      const float e3 = fexp(-fabsf(dlt));
+      const float inv3 = frcp(1.0f + e3);
+      const float lse = fmaxf(p2[e], ell[e]) + log1p_small(e3);
+      const float w = dlt >= 0.f ? inv3 : e3 * inv3;
+      const bool zero = x[e] == 0.f;
+      llk[e] = (zero ? lse : ell[e]) - sg.sp;
+      d0[e] = zero ? d0[e] * w : d0[e];
+      d1[e] = zero ? d1[e] * w : d1[e];
+      d2[e] = (zero ? (1.f - w) : 0.f) - sg.sg;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < N; ++e) { llk[e] = ell[e]; d2[e] = 0.f; }
+  }
+}
+
 }  // namespace smx
 #endif  // SMX_LOSS_H_

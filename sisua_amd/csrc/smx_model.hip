@@ -237,6 +237,7 @@ struct smx_model {
   hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
   bool forked = false;
   bool head_fused = false;
+  bool head_loss = false;             // this step's output product ran fused with the likelihood (smx_headloss.hip)
   int chunk_first_head = 0;           // first optimiser chunk of the output / label heads (they are last in the table)
   bool adam_early_pending = false;    // the heads' gradients are final: the next BatchNorm-backward launch may carry their update
   int adam_early_from = -1;           // >= 0: chunks [adam_early_from, n_chunks) of this step were applied early
@@ -682,6 +683,15 @@ bool use_fused_head(const smx_model* m, int B) {
   return out_head_supported(B, m->dec.back().out_p, m->Gp);
 }
 
+// Training steps of the count heads with raw parameter planes (VAE / DCA / SISUA): output product + likelihood +
+// dP in ONE wide kernel, P never materialised (smx_headloss.hip).  SMX_NO_HEAD_LOSS=1 keeps the product / loss
+// kernel pair (what eval, predict and the scoring paths always use).
+bool use_head_loss(const smx_model* m, int B) {
+  static const bool off = getenv("SMX_NO_HEAD_LOSS") != nullptr;
+  if (off || m->scvi || m->dec.empty()) return false;
+  return head_loss_supported(B, m->dec.back().out_p, m->Gp);
+}
+
 bool use_mid(const smx_model* m, int B) {
   // single-workgroup fusion of the middle is opt-in until it beats the per-operator path
   static const bool off = getenv("SMX_FUSED") == nullptr;
@@ -744,6 +754,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   const smx_config& c = m->cfg;
   const float inv_gb = 1.f / (float)ps.global_batch;
   const bool mid = (mode == 0) && use_mid(m, ps.B);
+  m->head_loss = false;
   if (mid) {
     SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd", 1));
     MidArgs ma;
@@ -822,6 +833,8 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     sh.raw = m->raw; sh.planes = m->P; sh.ld = ldp; sh.plane_stride = m->Gp; sh.B = ps.B; sh.G = m->G; sh.Gp = m->Gp;
     sh.k = m->k; sh.l = m->lsmp; sh.clip_library = c.clip_library; sh.rho_raw = m->rho;
     SMX_CHECK(launch_scvi_head_fwd(m->st, sh));
+  } else if ((m->head_loss = (with_loss && backward && !use_fused_head(m, ps.B) && use_head_loss(m, ps.B)))) {
+    m->head_fused = false;   // the product runs below, fused with the likelihood
   } else if (!(m->head_fused = (with_loss && backward && use_fused_head(m, ps.B)))) {
     const TensorInfo& tw = m->tensors[m->t_outW[0]];
     GemmArgs g;
@@ -846,7 +859,26 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   lo.P = m->P; lo.ldp = ldp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
   lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = -inv_gb;
   int n_llk_chunks = loss_chunks(m->Gp, ps.B);
-  if (m->head_fused) {
+  if (m->head_loss) {
+    const TensorInfo& tw = m->tensors[m->t_outW[0]];
+    HeadLossArgs hl;
+    hl.H = dL.out_buf; hl.ldh = dL.out_p; hl.W = P_(m, m->t_outW[0]); hl.ldw = tw.ld; hl.bias = P_(m, m->t_outb[0]);
+    hl.X = ps.Xsrc; hl.x_u16 = ps.x_u16; hl.ldx = m->Gp; hl.rows = ps.rows;
+    hl.dP = m->dP; hl.ldp = ldp; hl.plane_stride = m->Gp; hl.llk_part = m->llk_part;
+    hl.B = ps.B; hl.G = m->G; hl.Gp = m->Gp; hl.Hp = dL.out_p; hl.likelihood = c.likelihood; hl.grad_scale = -inv_gb;
+    n_llk_chunks = head_loss_chunks(m->Gp);
+    if (!m->capturing && m->timing_label == "out_head_product") {
+      // timing mode: the product alone (P stored, no counts, no likelihood) -- what the fused kernel's time is
+      // compared with to attribute the rest to the likelihood (bench.py, roofline)
+      HeadLossArgs po = hl;
+      po.product_only = 1; po.dP = m->P;
+      Timed t(m, "out_head_product");
+      for (int r = 0; r < SMX_LOSS_TIMING_REPEAT; ++r) SMX_CHECK(launch_out_head_loss(m->st, po));
+    }
+    const int reps = (!m->capturing && m->timing_label == "out_head") ? SMX_LOSS_TIMING_REPEAT : 1;   // idempotent
+    Timed t(m, "out_head");
+    for (int r = 0; r < reps; ++r) SMX_CHECK(launch_out_head_loss(m->st, hl));
+  } else if (m->head_fused) {
     // training step of a count head: output product, likelihood, dP, dW_out and db_out in one kernel
     const TensorInfo& tw = m->tensors[m->t_outW[0]];
     OutHeadArgs oh;
@@ -1451,7 +1483,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
       (rc = dmalloc(&m->z, B * m->Dp)) || (rc = dmalloc(&m->noise_eps, B * m->Dp)) || (rc = dmalloc(&m->sig, B * m->Dp)) || (rc = dmalloc(&m->eps, B * m->Dp)) ||
       (rc = dmalloc(&m->kl, B)) || (rc = dmalloc(&m->P, B * ldp)) || (rc = dmalloc(&m->dP, B * ldp)) ||
-      (rc = dmalloc(&m->llk_part, B * (size_t)std::max(loss_chunks_max(m->Gp), out_head_chunks(m->Gp)))) || (rc = dmalloc(&m->llk_y, B)) ||
+      (rc = dmalloc(&m->llk_part, B * (size_t)std::max(std::max(loss_chunks_max(m->Gp), out_head_chunks(m->Gp)), head_loss_chunks(m->Gp)))) || (rc = dmalloc(&m->llk_y, B)) ||
       (rc = dmalloc(&m->rows2[0], B)) || (rc = dmalloc(&m->rows2[1], B)) || (rc = dmalloc(&m->state3, (size_t)3)) ||
       (rc = dmalloc(&m->hostX, B * m->Gp)) || (rc = dmalloc(&m->hostLib, B * 2)) || (rc = dmalloc(&m->hostLgx1, B)))
     return fail(rc);
@@ -2283,7 +2315,7 @@ int smx_k_adam(int32_t n_tensors, const int32_t* sizes, float* params, const flo
   // the model's own layout: every tensor padded to a multiple of 64 floats, 4096-float optimiser chunks
   std::vector<size_t> off((size_t)n_tensors), pad((size_t)n_tensors);
   std::vector<OptChunk> chunks;
-  size_t total = 0, logical = 0;
+  size_t total = 0;
   const int CH = 4096;
   for (int t = 0; t < n_tensors; ++t) {
     SMX_REQUIRE(sizes[t] > 0, "empty tensor");
@@ -2297,7 +2329,7 @@ int smx_k_adam(int32_t n_tensors, const int32_t* sizes, float* params, const flo
       c.first_chunk = first; c.n_chunks = n; c.tensor_count = (int32_t)pad[t];
       chunks.push_back(c);
     }
-    total += pad[t]; logical += (size_t)sizes[t];
+    total += pad[t];
   }
   float *dP = nullptr, *dG = nullptr, *dM = nullptr, *dV = nullptr, *dPart = nullptr, *dNorm = nullptr;
   OptChunk* dCh = nullptr; StepState* dSt = nullptr;
