@@ -111,6 +111,21 @@ struct NoiseJob {
 #define SMX_NOISE_JOBS 6
 #define SMX_NOISE_BLOCKS_PER_JOB 8
 
+struct LatentArgs {
+  int stochastic = 1, relu = 0, training = 1;
+  const float* lat = nullptr; int ld = 0;   // [B][2*Dp] (mu | s_raw) or [B][Dp]
+  int B = 0, D = 0, Dp = 0;
+  NoiseKey nk{0, 0, 0, 0, nullptr};
+  const int32_t* rows = nullptr; uint32_t cell_base = 0;
+  const float* inj_eps = nullptr; int inj_ld = 0;
+  float* z = nullptr; float* sig = nullptr; float* eps = nullptr;  // [B][Dp]
+  float* kl = nullptr;                                             // [B]
+  // backward
+  const float* dz = nullptr; int dz_slabs = 1; long dz_slab_stride = 0;
+  float kl_scale = 0.f;       // beta / B_global
+  float* dlat = nullptr;      // [B][2*Dp] or [B][Dp]
+};
+
 struct BnFwdArgs {
   const float* pre = nullptr; int n_slabs = 1; long slab_stride = 0; int ld = 0;  // pre-activation slabs [S][B][ld]
   int B = 0, H = 0, Hp = 0;
@@ -128,8 +143,14 @@ struct BnFwdArgs {
   const int32_t* rows = nullptr; uint32_t cell_base = 0;  // cell id = cell_base + rows[b]
   const float* inj_mask = nullptr; int inj_ld = 0;
   int n_jobs = 0; NoiseJob jobs[SMX_NOISE_JOBS];
+  // front != 0 (first decoder layer): the layer's INPUT is produced by this launch too -- the latent sample
+  // z = mu + sigma eps with its KL (`lat`; every workgroup computes the whole [B][Dp] tile into LDS, workgroup 0
+  // also stores z / sigma / eps / KL for the backward pass) and the layer's product pre = z W as dot products
+  // (K = Dp <= 64: 64 fmas per output row and thread), so the latent kernel and the product kernel disappear
+  int front = 0; LatentArgs lat; const float* W = nullptr; int ldw = 0;
 };
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a);
+bool bn_front_supported(int B, int Dp);
 
 // Per-step device-resident scalars.
 struct StepState {
@@ -201,20 +222,6 @@ struct BnSyncArgs { float* gather = nullptr; int rank = 0, world = 1; };
 int launch_bn_sync_fwd(hipStream_t st, const BnFwdArgs& a, const BnSyncArgs& y, int phase);
 int launch_bn_sync_bwd(hipStream_t st, const BnBwdArgs& a, const BnSyncArgs& y, int phase);
 
-struct LatentArgs {
-  int stochastic = 1, relu = 0, training = 1;
-  const float* lat = nullptr; int ld = 0;   // [B][2*Dp] (mu | s_raw) or [B][Dp]
-  int B = 0, D = 0, Dp = 0;
-  NoiseKey nk{0, 0, 0, 0, nullptr};
-  const int32_t* rows = nullptr; uint32_t cell_base = 0;
-  const float* inj_eps = nullptr; int inj_ld = 0;
-  float* z = nullptr; float* sig = nullptr; float* eps = nullptr;  // [B][Dp]
-  float* kl = nullptr;                                             // [B]
-  // backward
-  const float* dz = nullptr; int dz_slabs = 1; long dz_slab_stride = 0;
-  float kl_scale = 0.f;       // beta / B_global
-  float* dlat = nullptr;      // [B][2*Dp] or [B][Dp]
-};
 int launch_latent_fwd(hipStream_t st, const LatentArgs& a);
 int launch_latent_bwd(hipStream_t st, const LatentArgs& a);
 

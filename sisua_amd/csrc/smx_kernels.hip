@@ -228,7 +228,57 @@ __device__ inline void noise_fill(const BnFwdArgs& a, int job_block) {
 
 // RPT > 0: B <= BN_RL * RPT, every value of the column stays in registers (RPT rows per thread);
 // RPT == 0: any B, the normalised values make a round trip through xhat
-template <int RPT>
+// the latent tile of the whole minibatch into LDS (row stride Dp + 1), one thread per 4 latent dims of a cell; the
+// first workgroup also leaves z / sigma / eps / KL in memory for the backward pass (same arithmetic, same Philox
+// blocks as latent_fwd_quad_kernel)
+__device__ inline void latent_tile_to_lds(const LatentArgs& a, float* zs, bool store) {
+  const int dq = a.Dp >> 2, ldz = a.Dp + 1;
+  for (int idx = threadIdx.x; idx < ((a.B * dq + 63) & ~63); idx += BN_THREADS) {
+    const int b = idx / dq, d0 = (idx % dq) * 4;
+    float kl = 0.f;
+    if (b < a.B) {
+      float zz[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {1.f, 1.f, 1.f, 1.f}, ee[4] = {0.f, 0.f, 0.f, 0.f};
+      const float4 m4 = *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + d0);
+      const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
+      if (a.stochastic) {
+        const float4 s4 = *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + a.Dp + d0);
+        const float sr[4] = {s4.x, s4.y, s4.z, s4.w};
+        float4 n4;
+        if (a.inj_eps) n4 = *reinterpret_cast<const float4*>(a.inj_eps + (long)b * a.inj_ld + d0);
+        else n4 = normal4(philox_block(a.nk, a.cell_base + (uint32_t)(a.rows ? a.rows[b] : b), (uint32_t)(d0 >> 2)));
+        const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (d0 + e < a.D) {
+            const float sg = softplusf(sr[e] + SMX_SOFTPLUS_INV_1);
+            ss[e] = sg; ee[e] = nn[e];
+            zz[e] = mu[e] + sg * nn[e];
+            kl += 0.5f * (sg * sg + mu[e] * mu[e] - 1.f - 2.f * flog(sg));
+          }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (d0 + e < a.D) zz[e] = a.relu ? fmaxf(mu[e], 0.f) : mu[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) zs[b * ldz + d0 + e] = zz[e];
+      if (store) {
+        const long o = (long)b * a.Dp + d0;
+        *reinterpret_cast<float4*>(a.z + o) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        if (a.sig) {
+          *reinterpret_cast<float4*>(a.sig + o) = make_float4(ss[0], ss[1], ss[2], ss[3]);
+          *reinterpret_cast<float4*>(a.eps + o) = make_float4(ee[0], ee[1], ee[2], ee[3]);
+        }
+      }
+    }
+    if (store && a.kl) {   // the dq lanes of a cell are adjacent (dq a power of two <= 16, 64 % dq == 0)
+      for (int off = 1; off < dq; off <<= 1) kl += __shfl_xor(kl, off, 64);
+      if (b < a.B && (idx % dq) == 0) a.kl[b] = kl;
+    }
+  }
+}
+
+template <int RPT, int FRONT = 0>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
   constexpr bool SMALL = RPT > 0;
   constexpr int BN_RPT = SMALL ? RPT : BN_RPT_DEFAULT;
@@ -237,17 +287,42 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
     return;
   }
   __shared__ float sh[BN_WAVES * BN_COLS];
+  extern __shared__ float zs[];   // FRONT: [B][Dp + 1]
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = blockIdx.x * BN_COLS + c;
   const bool live = col < a.H;  // padded columns produce zeros
   const float bias = (!a.batchnorm && a.bias && live) ? a.bias[col] : 0.f;
   constexpr int CH = BN_RL * BN_RPT;
   float vreg[BN_RPT];
+  float wcol[FRONT ? 64 : 1];
+  if (FRONT) {
+    // this thread's column of W first (its latency hides under the latent tile), then the tile, then the barrier
+#pragma unroll
+    for (int k = 0; k < 64; ++k) wcol[k] = (k < a.lat.Dp) ? a.W[(long)k * a.ldw + col] : 0.f;
+    latent_tile_to_lds(a.lat, zs, blockIdx.x == 0);
+    __syncthreads();
+  }
 
   // pass 1: slab sum (+ bias), column sum
   float s1 = 0.f;
   for (int r0 = 0; r0 < a.B; r0 += CH) {
     float acc[BN_RPT];
+    if (FRONT) {
+      const int ldz = a.lat.Dp + 1;
+#pragma unroll
+      for (int i = 0; i < BN_RPT; ++i) {
+        const int r = min(r0 + rl + BN_RL * i, a.B - 1);
+        float t = 0.f;
+        if (a.lat.Dp <= 32) {
+#pragma unroll
+          for (int k = 0; k < 32; ++k) t = fmaf(zs[r * ldz + k], wcol[k], t);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 64; ++k) t = fmaf(zs[r * ldz + k], wcol[k], t);
+        }
+        acc[i] = t;
+      }
+    } else
     slab_sum(a.pre, a.n_slabs, a.slab_stride, a.ld, col, r0, rl, a.B, acc);
 #pragma unroll
     for (int i = 0; i < BN_RPT; ++i) {
@@ -329,8 +404,26 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
 
 static int bn_diag() { static const int v = getenv("SMX_BN_DIAG") ? atoi(getenv("SMX_BN_DIAG")) : 0; return v; }
 
+bool bn_front_supported(int B, int Dp) {
+  const int dq = Dp >> 2;
+  return B > 0 && B <= BN_RL * 4 && Dp >= 4 && Dp <= 64 && (Dp % 4) == 0 && (dq & (dq - 1)) == 0 && (size_t)B * (Dp + 1) * sizeof(float) <= 60 * 1024;
+}
+
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
   BnFwdArgs a = a_in;
+  if (a.front) {
+    if (!bn_front_supported(a.B, a.lat.Dp) || a.n_jobs || !a.W || (a.lat.ld % 4) || (a.lat.inj_eps && (a.lat.inj_ld % 4)) ||
+        (a.lat.Dp > 32 && a.lat.Dp != 64)) {
+      set_error("bn_act_fwd: latent front not applicable");
+      return SMX_ERR_INVALID;
+    }
+    if (a.Hp % BN_COLS) { set_error("bn_act_fwd: bad shapes"); return SMX_ERR_INVALID; }
+    const size_t lds = (size_t)a.B * (a.lat.Dp + 1) * sizeof(float);
+    if (a.B <= BN_RL * 2) hipLaunchKernelGGL((bn_act_fwd_kernel<2, 1>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<4, 1>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   if (bn_diag() & 1) a.drop_p = 0.f;                      // diagnostic: no dropout draw
   if (bn_diag() & 2) a.n_slabs = 1;                       // diagnostic: one slab only
   if (bn_diag() & 8) a.n_jobs = 0;                        // diagnostic: no look-ahead noise workgroups

@@ -410,7 +410,7 @@ bool sync_bn_on(const smx_model* m, int training) { return m->sync_bn && trainin
 BnSyncArgs sync_args(smx_model* m) { BnSyncArgs y; y.gather = m->sync_buf; y.rank = m->rank; y.world = m->world; return y; }
 
 int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
-                const char* label0, int n_layers = -1) {
+                const char* label0, int n_layers = -1, const LatentArgs* front = nullptr) {
   const float* in = in0;
   int ld = ld0;
   const size_t nl = n_layers < 0 ? mlp.size() : (size_t)n_layers;
@@ -437,10 +437,11 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     static const bool no_ahead = getenv("SMX_NO_NOISE_AHEAD") != nullptr;
     const bool ahead = !no_fz && !no_ahead && !m->scvi;
     const bool sync = sync_bn_on(m, ps.training);
-    const bool fuse = !no_fz && !sync && !(i == 0 && in_is_x) && dense_bn_fusable(ps.B, L.in_p);
+    const bool with_front = (front != nullptr && i == 0);   // the BatchNorm launch produces its own input (latent sample + product)
+    const bool fuse = !no_fz && !sync && !with_front && !(i == 0 && in_is_x) && dense_bn_fusable(ps.B, L.in_p);
     int eff = 1;
     SMX_REQUIRE((size_t)std::max(g.split_k, 1) * (size_t)g.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
-    if (!fuse) {
+    if (!fuse && !with_front) {
       Timed t(m, (i == 0 && in_is_x) ? label0 : "gemm_mlp_fwd");
       SMX_CHECK(launch_gemm(m->st, g, &eff));
     }
@@ -482,7 +483,11 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
       if (m->stochastic && !inj(m, ST_EPS_Z) && m->eps_ahead_ok) add(m->noise_eps, m->Dp, m->D, 1, 0.f, ST_EPS_Z);
       if (b.n_jobs) { b.nk.step_ptr = ps.training ? &cur_state(m)->step : nullptr; }
     }
-    if (sync) {
+    if (with_front) {
+      b.front = 1; b.lat = *front; b.W = P_(m, L.tW); b.ldw = tw.ld; b.n_jobs = 0;
+      Timed t(m, "bn_fwd");
+      SMX_CHECK(launch_bn_act_fwd(m->st, b));
+    } else if (sync) {
       Timed t(m, "bn_fwd");
       b.n_jobs = 0;
       const BnSyncArgs y = sync_args(m);
@@ -755,6 +760,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   const float inv_gb = 1.f / (float)ps.global_batch;
   const bool mid = (mode == 0) && use_mid(m, ps.B);
   m->head_loss = false;
+  bool front_ok = false; LatentArgs front_la;
   if (mid) {
     SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd", 1));
     MidArgs ma;
@@ -787,7 +793,15 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   static const bool no_ahead = getenv("SMX_NO_NOISE_AHEAD") != nullptr;
   if (fuse_lat && m->stochastic && !la.inj_eps && !no_ahead && !m->scvi && m->eps_ahead_ok) { la.inj_eps = m->noise_eps; la.inj_ld = m->Dp; }
   la.z = m->z; la.sig = m->sig; la.eps = m->eps; la.kl = m->kl;
-  if (fuse_lat) {
+  // The latent sample + KL and the first decoder product run INSIDE the decoder's first BatchNorm launch (two
+  // launches fewer) when the shapes allow; SMX_NO_FRONT=1 keeps the three-launch form.
+  static const bool no_front = getenv("SMX_NO_FRONT") != nullptr;
+  front_ok = !no_front && !fuse_lat && !sync_bn_on(m, ps.training) && bn_front_supported(ps.B, m->Dp) && (m->Dp == 32 || m->Dp == 64) &&
+             m->dec[0].in_p == m->Dp && m->dec[0].out_p % 8 == 0 && (lat_ld % 4) == 0 && (!la.inj_eps || (la.inj_ld % 4) == 0);
+  front_la = la;
+  if (front_ok) {
+    // (launched below with the decoder)
+  } else if (fuse_lat) {
     Timed t(m, "latent_head_fwd");
     SMX_CHECK(launch_latent_head_fwd(m->st, la, eL.out_buf, eL.out_p, eL.out_p, P_(m, m->t_latW), m->tensors[m->t_latW].ld,
                                      P_(m, m->t_latb), m->latbuf));
@@ -816,7 +830,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   }
   }  // !decode_only
   // ---- decoder ----
-  if (!mid) SMX_CHECK(mlp_forward(m, m->dec, ps, m->z, m->Dp, false, ""));
+  if (!mid) SMX_CHECK(mlp_forward(m, m->dec, ps, m->z, m->Dp, false, "", -1, front_ok ? &front_la : nullptr));
   const MlpLayer& dL = m->dec.back();
   const long ldp = (long)m->k * m->Gp;
   if (m->scvi) {
