@@ -462,7 +462,7 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
   for (int i = 0; i < n; ++i) { has_epi |= (G.p[i].epi != 0); has_u16 |= (G.p[i].use_xform && G.p[i].xf.u16); }
   static const bool split_all = getenv("SMX_SPLIT_GROUPS") != nullptr;
   // (the grouped kernel carries no uint16-store variant: those products keep their own launches)
-  if (((total > 768 || n == 1) && !has_epi) || split_all || has_u16) {   // a lone product also runs leaner as its own kernel
+  if ((total > 768 && !has_epi) || n == 1 || split_all || has_u16) {   // a lone product also runs leaner as its own kernel
     for (int i = 0; i < n; ++i) {
       if (G.variant[i] == 11) {
         const GemmArgs& g = G.p[i];

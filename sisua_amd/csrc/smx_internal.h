@@ -213,7 +213,13 @@ struct BnBwdArgs {
   // single GPU: the output / label heads' gradients are final before this launch, and this launch leaves most CUs
   // idle -- adam_count extra workgroups apply the optimiser to chunks [adam_first, adam_first + adam_count)
   AdamArgs adam; int adam_first = 0, adam_count = 0;
+  // front != 0 (last encoder layer): the incoming gradient d h = d lat W_lat^T is produced here as dot products
+  // (K = width of the latent head <= 64; d lat [B][fK] staged in LDS, this thread's row of W_lat in registers)
+  // instead of being read from a slab another launch wrote
+  int front = 0; const float* fD = nullptr; int fld = 0; const float* fW = nullptr; int fldw = 0; int fK = 0;
+  int diag = 0;   // SMX_BN_DIAG bits 16 / 32 / 64: skip the front's dot products / tile load / W row load (timing only)
 };
+bool bn_bwd_front_supported(int B, int K);
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a);
 
 // SyncBatchNorm (smx_kernels.hip): phase 0 leaves this rank's column statistics in `gather` [world][2][Hp],

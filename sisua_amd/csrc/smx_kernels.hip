@@ -231,22 +231,39 @@ __device__ inline void noise_fill(const BnFwdArgs& a, int job_block) {
 // the latent tile of the whole minibatch into LDS (row stride Dp + 1), one thread per 4 latent dims of a cell; the
 // first workgroup also leaves z / sigma / eps / KL in memory for the backward pass (same arithmetic, same Philox
 // blocks as latent_fwd_quad_kernel)
+template <int MAXIT>
 __device__ inline void latent_tile_to_lds(const LatentArgs& a, float* zs, bool store) {
   const int dq = a.Dp >> 2, ldz = a.Dp + 1;
-  for (int idx = threadIdx.x; idx < ((a.B * dq + 63) & ~63); idx += BN_THREADS) {
+  const int total = a.B * dq;
+  // every load of every iteration first (left as a loop the compiler waits for each iteration's loads in turn:
+  // MAXIT serial round trips to data the previous launch has just written)
+  float4 m4[MAXIT], s4[MAXIT], n4[MAXIT];
+  uint32_t cell[MAXIT];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int idx = threadIdx.x + it * BN_THREADS;
+    const bool ok = idx < total;
+    const int b = ok ? idx / dq : 0, d0 = (idx % dq) * 4;
+    m4[it] = ok ? *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + d0) : z4;
+    s4[it] = (ok && a.stochastic) ? *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + a.Dp + d0) : z4;
+    n4[it] = (ok && a.stochastic && a.inj_eps) ? *reinterpret_cast<const float4*>(a.inj_eps + (long)b * a.inj_ld + d0) : z4;
+    cell[it] = a.cell_base + (uint32_t)((ok && a.rows) ? a.rows[b] : b);
+  }
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int idx = threadIdx.x + it * BN_THREADS;
+    if (it * BN_THREADS >= ((total + 63) & ~63)) break;   // block-uniform
     const int b = idx / dq, d0 = (idx % dq) * 4;
     float kl = 0.f;
-    if (b < a.B) {
+    if (idx < total) {
       float zz[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {1.f, 1.f, 1.f, 1.f}, ee[4] = {0.f, 0.f, 0.f, 0.f};
-      const float4 m4 = *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + d0);
-      const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
+      const float mu[4] = {m4[it].x, m4[it].y, m4[it].z, m4[it].w};
       if (a.stochastic) {
-        const float4 s4 = *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + a.Dp + d0);
-        const float sr[4] = {s4.x, s4.y, s4.z, s4.w};
-        float4 n4;
-        if (a.inj_eps) n4 = *reinterpret_cast<const float4*>(a.inj_eps + (long)b * a.inj_ld + d0);
-        else n4 = normal4(philox_block(a.nk, a.cell_base + (uint32_t)(a.rows ? a.rows[b] : b), (uint32_t)(d0 >> 2)));
-        const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+        const float sr[4] = {s4[it].x, s4[it].y, s4[it].z, s4[it].w};
+        float4 nq = n4[it];
+        if (!a.inj_eps) nq = normal4(philox_block(a.nk, cell[it], (uint32_t)(d0 >> 2)));
+        const float nn[4] = {nq.x, nq.y, nq.z, nq.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (d0 + e < a.D) {
@@ -271,9 +288,9 @@ __device__ inline void latent_tile_to_lds(const LatentArgs& a, float* zs, bool s
         }
       }
     }
-    if (store && a.kl) {   // the dq lanes of a cell are adjacent (dq a power of two <= 16, 64 % dq == 0)
+    if (store && a.kl && idx < ((total + 63) & ~63)) {   // the dq lanes of a cell are adjacent (dq a power of two <= 16)
       for (int off = 1; off < dq; off <<= 1) kl += __shfl_xor(kl, off, 64);
-      if (b < a.B && (idx % dq) == 0) a.kl[b] = kl;
+      if (idx < total && (idx % dq) == 0) a.kl[b] = kl;
     }
   }
 }
@@ -296,11 +313,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
   float vreg[BN_RPT];
   float wcol[FRONT ? 64 : 1];
   if (FRONT) {
-    // this thread's column of W first (its latency hides under the latent tile), then the tile, then the barrier
-#pragma unroll
-    for (int k = 0; k < 64; ++k) wcol[k] = (k < a.lat.Dp) ? a.W[(long)k * a.ldw + col] : 0.f;
-    latent_tile_to_lds(a.lat, zs, blockIdx.x == 0);
+    // this workgroup's [Dp][8] tile of W: one coalesced pass into LDS (its latency hides under the latent tile)
+    float* ws = zs + a.B * (a.lat.Dp + 1);       // [Dp][BN_COLS]
+    float wl = 0.f;
+    const bool wl_on = (int)threadIdx.x < a.lat.Dp * BN_COLS;
+    if (wl_on) wl = a.W[(long)(threadIdx.x / BN_COLS) * a.ldw + blockIdx.x * BN_COLS + (threadIdx.x % BN_COLS)];
+    latent_tile_to_lds<BN_RPT * 2>(a.lat, zs, blockIdx.x == 0);   // B Dp / 4 quads over 512 threads: <= 2 RPT iterations
+    if (wl_on) ws[threadIdx.x] = wl;
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 64; ++k) wcol[k] = (k < a.lat.Dp) ? ws[k * BN_COLS + c] : 0.f;
   }
 
   // pass 1: slab sum (+ bias), column sum
@@ -406,7 +428,7 @@ static int bn_diag() { static const int v = getenv("SMX_BN_DIAG") ? atoi(getenv(
 
 bool bn_front_supported(int B, int Dp) {
   const int dq = Dp >> 2;
-  return B > 0 && B <= BN_RL * 4 && Dp >= 4 && Dp <= 64 && (Dp % 4) == 0 && (dq & (dq - 1)) == 0 && (size_t)B * (Dp + 1) * sizeof(float) <= 60 * 1024;
+  return B > 0 && B <= BN_RL * 4 && Dp >= 4 && Dp <= 64 && (Dp % 4) == 0 && (dq & (dq - 1)) == 0 && ((size_t)B * (Dp + 1) + (size_t)Dp * 8) * sizeof(float) <= 60 * 1024;
 }
 
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
@@ -418,7 +440,7 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
       return SMX_ERR_INVALID;
     }
     if (a.Hp % BN_COLS) { set_error("bn_act_fwd: bad shapes"); return SMX_ERR_INVALID; }
-    const size_t lds = (size_t)a.B * (a.lat.Dp + 1) * sizeof(float);
+    const size_t lds = ((size_t)a.B * (a.lat.Dp + 1) + (size_t)a.lat.Dp * BN_COLS) * sizeof(float);
     if (a.B <= BN_RL * 2) hipLaunchKernelGGL((bn_act_fwd_kernel<2, 1>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
     else hipLaunchKernelGGL((bn_act_fwd_kernel<4, 1>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
     SMX_HIP(hipGetLastError());
@@ -441,10 +463,11 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
 __device__ inline void metrics_body(const MetricsArgs& a);
 __device__ inline void adam_chunk_body(const AdamArgs& a, int chunk);
 
-template <int RPT>
+template <int RPT, int FRONT = 0>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
   constexpr bool SMALL = RPT > 0;
   constexpr int BN_RPT = SMALL ? RPT : BN_RPT_DEFAULT;
+  extern __shared__ float ds[];   // FRONT: d lat tile [B][fK + 1]
   {
     const int nb = a.Hp / BN_COLS, extra = (int)blockIdx.x - nb;
     if (extra >= 0) {
@@ -461,8 +484,62 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
   constexpr int CH = BN_RL * BN_RPT;
   float dyreg[BN_RPT], xhreg[BN_RPT];
   float s1 = 0.f, s2 = 0.f;
+  float wrow[FRONT ? 64 : 1];
+  if (FRONT) {
+    const int ldd = a.fK + 1, kq = a.fK >> 2;
+    // this workgroup's 8 rows of W_lat: ONE coalesced pass into LDS (every thread loading its own row from global
+    // memory is 8 different cache lines per quarter-wave: 5 us), then each thread copies its row to registers
+    float* ws = ds + ((a.B * ldd + 3) & ~3);     // [BN_COLS][fK + 4], 16-byte aligned
+    const int ldw_s = a.fK + 4;
+    float4 wl = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool wl_on = (int)threadIdx.x < BN_COLS * kq && !(a.diag & 64);
+    if (wl_on) wl = *reinterpret_cast<const float4*>(a.fW + (long)(blockIdx.x * BN_COLS + threadIdx.x / kq) * a.fldw + (threadIdx.x % kq) * 4);
+    {   // all loads of the tile in flight at once (B fK / 4 float4 over 512 threads: <= 2 RPT per thread), then LDS
+      constexpr int MAXIT = BN_RPT * 2;
+      float4 tl[MAXIT];
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int idx = threadIdx.x + it * BN_THREADS;
+        tl[it] = (idx < a.B * kq && !(a.diag & 32)) ? *reinterpret_cast<const float4*>(a.fD + (long)(idx / kq) * a.fld + (idx % kq) * 4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int idx = threadIdx.x + it * BN_THREADS;
+        if (idx < a.B * kq) {
+          const int o = (idx / kq) * ldd + (idx % kq) * 4;
+          ds[o] = tl[it].x; ds[o + 1] = tl[it].y; ds[o + 2] = tl[it].z; ds[o + 3] = tl[it].w;
+        }
+      }
+      if ((int)threadIdx.x < BN_COLS * kq) *reinterpret_cast<float4*>(&ws[(threadIdx.x / kq) * ldw_s + (threadIdx.x % kq) * 4]) = wl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const float4 t = (4 * v < a.fK) ? *reinterpret_cast<const float4*>(&ws[c * ldw_s + 4 * v]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      wrow[4 * v] = t.x; wrow[4 * v + 1] = t.y; wrow[4 * v + 2] = t.z; wrow[4 * v + 3] = t.w;
+    }
+  }
   for (int r0 = 0; r0 < a.B; r0 += CH) {
     float acc[BN_RPT];
+    if (FRONT) {
+      const int ldd = a.fK + 1;
+#pragma unroll
+      for (int i = 0; i < BN_RPT; ++i) {
+        const int r = min(r0 + rl + BN_RL * i, a.B - 1);
+        float t = 0.f;
+        if (a.diag & 16) {
+          t = ds[r * ldd] + wrow[0] + wrow[63];
+        } else if (a.fK <= 32) {
+#pragma unroll
+          for (int k = 0; k < 32; ++k) t = fmaf(ds[r * ldd + k], wrow[k], t);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 64; ++k) t = fmaf(ds[r * ldd + k], wrow[k], t);
+        }
+        acc[i] = t;
+      }
+    } else
     slab_sum(a.dout, a.n_slabs, a.slab_stride, a.ld, col, r0, rl, a.B, acc);
 #pragma unroll
     for (int i = 0; i < BN_RPT; ++i) {
@@ -509,8 +586,25 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
   }
 }
 
+bool bn_bwd_front_supported(int B, int K) {
+  return B > 0 && B <= BN_RL * 4 && (K == 32 || K == 64) && ((size_t)B * (K + 1) + 8 * (K + 4)) * sizeof(float) <= 60 * 1024;
+}
+
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
   BnBwdArgs a = a_in;
+  a.diag = bn_diag();
+  if (a.front) {
+    if (!bn_bwd_front_supported(a.B, a.fK) || !a.fD || !a.fW || (a.fld % 4) || (a.fldw % 4) || a.Hp % BN_COLS) {
+      set_error("bn_act_bwd: gradient front not applicable");
+      return SMX_ERR_INVALID;
+    }
+    const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count;
+    const size_t lds = ((size_t)a.B * (a.fK + 1) + 4 + (size_t)BN_COLS * (a.fK + 4)) * sizeof(float);
+    if (a.B <= BN_RL * 2) hipLaunchKernelGGL((bn_act_bwd_kernel<2, 1>), dim3(grid), dim3(BN_THREADS), lds, st, a);
+    else hipLaunchKernelGGL((bn_act_bwd_kernel<4, 1>), dim3(grid), dim3(BN_THREADS), lds, st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   if (bn_diag() & 4) a.n_slabs = 1;                       // diagnostic: one slab only
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_bwd: bad shapes"); return SMX_ERR_INVALID; }
   const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count;

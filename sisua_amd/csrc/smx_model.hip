@@ -538,7 +538,11 @@ void want_sq(smx_model* m, GemmArgs& g, int t) {
 // Leaves d(input of first layer) as slabs in m->slab unless skip_input_grad.
 int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
                  int n_slabs, bool skip_input_grad, int* out_slabs, const char* label_dw0,
-                 const EpiLatentBwd* lat_epi = nullptr, GemmArgs* defer_dw0 = nullptr) {
+                 const EpiLatentBwd* lat_epi = nullptr, GemmArgs* defer_dw0 = nullptr,
+                 const BnBwdArgs* grad_front = nullptr, std::vector<GemmArgs>* defer = nullptr) {
+  // grad_front: the LAST layer's BatchNorm-backward launch computes its incoming gradient itself (fD fW^T as dot
+  // products) instead of reading slabs.  defer: weight-gradient products that nothing later in the backward pass
+  // reads are appended there instead of being launched (the caller runs them as ONE grouped launch at the end).
   for (int i = (int)mlp.size() - 1; i >= 0; --i) {
     MlpLayer& L = mlp[i];
     const TensorInfo& tw = m->tensors[L.tW];
@@ -550,6 +554,9 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     b.dpre = L.dpre;
     if (m->cfg.batchnorm) { b.gamma = P_(m, L.tGamma); b.dgamma = G_(m, L.tGamma); b.dbeta = G_(m, L.tBeta); }
     else b.dbias = G_(m, L.tBias);
+    if (grad_front && i == (int)mlp.size() - 1) {
+      b.front = 1; b.fD = grad_front->fD; b.fld = grad_front->fld; b.fW = grad_front->fW; b.fldw = grad_front->fldw; b.fK = grad_front->fK;
+    }
     if (sync_bn_on(m, ps.training)) {   // the ELBO scalars then go with a launch of their own (optimizer_pass)
       Timed t(m, "bn_bwd");
       m->adam_early_pending = false;
@@ -601,9 +608,13 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     if (i == 0 && lat_epi) {  // d z feeds the latent head only: run its backward in the epilogue
       h.epi = 2; h.lb = *lat_epi; h.split_k = 1; h.tile = TILE_32x32_K4;
     }
-    GemmArgs pair[2] = {g, h};
     int effs[2] = {1, 1};
-    {
+    if (defer && i == 0 && lat_epi) {   // d z (+ latent-head backward) alone; d W joins the final grouped launch
+      defer->push_back(g);
+      Timed t(m, "gemm_mlp_bwd");
+      SMX_CHECK(launch_gemm_group(m->st, &h, 1, effs + 1));
+    } else {
+      GemmArgs pair[2] = {g, h};
       Timed t(m, "gemm_mlp_bwd");
       SMX_CHECK(launch_gemm_group(m->st, pair, 2, effs));
     }
@@ -1106,25 +1117,37 @@ int backward_pass(smx_model* m, const Pass& ps) {
   le.lat = m->latbuf; le.ld = lat_ld; le.sig = m->sig; le.eps = m->eps; le.kl_scale = c.beta * inv_gb;
   le.D = m->D; le.Dp = m->Dp; le.stochastic = m->stochastic; le.relu = (c.latent_activation == SMX_ACT_RELU);
   le.dlat = m->dlat;
-  SMX_CHECK(mlp_backward(m, m->dec, ps, m->z, m->Dp, false, n_slabs, false, nullptr, "", &le));
+  // Products that only the optimiser reads (the weight gradients of the first decoder layer, of the latent head and of
+  // the first encoder layers) run as ONE grouped launch at the end; the last encoder layer's BatchNorm-backward
+  // launch computes d h = d lat W_lat^T itself.  SMX_NO_BWD_FRONT=1: the separate launches of before.
+  static const bool no_bfront = getenv("SMX_NO_BWD_FRONT") != nullptr;
   const MlpLayer& eL = m->enc.back();
-  {  // weight gradient of the latent head and d h = d lat * W_lat^T are independent: one grouped launch
+  const bool bfront = !no_bfront && !sync_bn_on(m, ps.training) && bn_bwd_front_supported(ps.B, lat_ld) && eL.out_p % 8 == 0;
+  std::vector<GemmArgs> tail;
+  SMX_CHECK(mlp_backward(m, m->dec, ps, m->z, m->Dp, false, n_slabs, false, nullptr, "", &le, nullptr, nullptr, bfront ? &tail : nullptr));
+  BnBwdArgs gf;
+  {  // weight gradient of the latent head and d h = d lat * W_lat^T
     const TensorInfo& tw = m->tensors[m->t_latW];
     GemmArgs pair[2];
     GemmArgs& g = pair[0];
     g.A = eL.out_buf; g.lda = eL.out_p; g.a_kmajor = 1; g.B = m->dlat; g.ldb = lat_ld;
     g.C = G_(m, m->t_latW); g.ldc = tw.ld; g.M = eL.out_p; g.N = lat_ld; g.K = ps.B; g.colsum = G_(m, m->t_latb);
     want_sq(m, g, m->t_latW);
-    GemmArgs& h = pair[1];
-    h.A = m->dlat; h.lda = lat_ld; h.B = P_(m, m->t_latW); h.ldb = tw.ld; h.b_nmajor = 1;
-    h.C = m->slab; h.ldc = eL.out_p; h.slab_stride = (long)ps.B * eL.out_p;
-    h.M = ps.B; h.N = eL.out_p; h.K = lat_ld;
-    Timed t(m, "gemm_lat_bwd");
-    SMX_CHECK(launch_gemm_group(m->st, pair, 2));
+    if (bfront) {
+      tail.push_back(g);
+      gf.fD = m->dlat; gf.fld = lat_ld; gf.fW = P_(m, m->t_latW); gf.fldw = tw.ld; gf.fK = lat_ld;
+    } else {   // independent: one grouped launch
+      GemmArgs& h = pair[1];
+      h.A = m->dlat; h.lda = lat_ld; h.B = P_(m, m->t_latW); h.ldb = tw.ld; h.b_nmajor = 1;
+      h.C = m->slab; h.ldc = eL.out_p; h.slab_stride = (long)ps.B * eL.out_p;
+      h.M = ps.B; h.N = eL.out_p; h.K = lat_ld;
+      Timed t(m, "gemm_lat_bwd");
+      SMX_CHECK(launch_gemm_group(m->st, pair, 2));
+    }
   }
   GemmArgs dw0[2];
   int n_dw0 = 0;
-  SMX_CHECK(mlp_backward(m, m->enc, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_enc_dw", nullptr, &dw0[n_dw0]));
+  SMX_CHECK(mlp_backward(m, m->enc, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_enc_dw", nullptr, &dw0[n_dw0], bfront ? &gf : nullptr));
   ++n_dw0;
   // ---- scvi library branch ----
   if (m->scvi) {
@@ -1149,12 +1172,13 @@ int backward_pass(smx_model* m, const Pass& ps) {
   }
   // the first-layer weight gradients (gather + log1p of the same resident rows) of the encoder and, for scvi,
   // the library encoder are independent: one grouped launch
-  if (n_dw0 == 1) {
+  for (int q = 0; q < n_dw0; ++q) tail.push_back(dw0[q]);
+  {
     Timed t(m, "gemm_enc_dw");
-    SMX_CHECK(launch_gemm(m->st, dw0[0]));
-  } else if (n_dw0 == 2) {
-    Timed t(m, "gemm_enc_dw");
-    SMX_CHECK(launch_gemm_group(m->st, dw0, 2));
+    if (tail.size() == 1) SMX_CHECK(launch_gemm(m->st, tail[0]));
+    else
+      for (size_t q = 0; q < tail.size(); q += SMX_GROUP_MAX)
+        SMX_CHECK(launch_gemm_group(m->st, tail.data() + q, (int)std::min<size_t>(SMX_GROUP_MAX, tail.size() - q)));
   }
   return SMX_OK;
 }
