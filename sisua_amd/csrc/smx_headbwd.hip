@@ -1,0 +1,194 @@
+// smx_headbwd.hip -- the two backward products of the output head in ONE launch (count heads with raw parameter
+// planes; SURVEY.md 8 row a-16, the largest weight gradient):
+//
+//   role 0   dW_out = d^T dP   [H][k Gp]   (+ db = column sums of dP, + per-tensor sum of squares for clipnorm)
+//   role 1   dd     = dP W_out^T  [B][H]   as split-K slabs over the k Gp axis (summed by the BatchNorm-backward launch)
+//
+// Same shape of work as the fused forward (smx_headloss.hip): 8 waves per workgroup split K, every operand goes
+// straight from global memory into MFMA operand registers with ALL loads of a K slab in flight (the k index of
+// v_mfma_f32_32x32x2_f32 is free to permute), the 8 partial tiles meet in LDS and every wave finishes two
+// accumulator registers.  The grouped LDS-tiled form this replaces took 14.1 us for 0.39 GFLOP and 12 MB: its
+// workgroups walked K in serial load -> LDS -> barrier -> MFMA rounds at two workgroups per CU.
+//   role 0: tile = 32 rows of H x 32 genes x k planes; K = the minibatch (16 cells per wave and 128-cell slab: lane
+//           (i, hh) supplies cells 8 hh + s); both operands are coalesced 128-byte row segments (d[cell][h0 + i],
+//           dP[cell][g0 + i]); the (H / 32) workgroups of a gene tile are 8 blocks apart (same XCD).
+//   role 1: tile = 32 cells x 32 columns of H; K = this slice of the k Gp axis (64 per wave and 512-wide slab: lane
+//           (i, hh) supplies 32 consecutive k: one whole 128-byte line of row i of dP and of row h0 + i of W_out).
+#include <stdlib.h>
+
+#include "smx_internal.h"
+#include "../../include/sisua_hip.h"
+
+namespace smx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NP>
+__global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
+  __shared__ float red[8 * 1024];   // ONE plane's eight partial tiles at a time (32 KB: two workgroups per CU, not one)
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = lane & 31, hh = lane >> 5;
+  // accumulator register r of a 32 x 32 tile is row (r & 3) + 8 (r >> 2) + 4 hh, column i; wave q finishes r = 2q, 2q + 1
+  int rowof[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int r = 2 * q + j; rowof[j] = (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+  if ((int)blockIdx.x < a.n_w) {
+    // ======================= role 0: dW tile (+ db, + sum of squares) ==========================================
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int ht = idx % a.n_ht, gt = (idx / a.n_ht) * 8 + xcd;
+    if (gt >= a.n_gt || (a.diag & 1)) return;
+    const int h0 = ht * 32, g0 = gt * 32;
+    f32x16 acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    float csum[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) csum[p] = 0.f;
+    for (int kc = 0; kc < a.B; kc += 128) {
+      const int k0 = kc + 16 * q + 8 * hh;
+      if (kc + 16 * q >= a.B) break;   // wave-uniform
+      float av[8], bv[NP][8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int cell = min(k0 + s, a.B - 1);
+        av[s] = a.D[(long)cell * a.ldd + h0 + i];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bv[p][s] = a.dP[(long)cell * a.ldp + (long)p * a.Gp + g0 + i];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bool on = k0 + s < a.B;       // K is the (ragged) minibatch axis: cells beyond it contribute nothing
+        const float av_s = on ? av[s] : 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const float b = on ? bv[p][s] : 0.f;
+          csum[p] += b;
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_s, b, acc[p], 0, 0, 0);
+        }
+      }
+    }
+    float sq = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (p) __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(q * 16 + r) * 64 + lane] = acc[p][r];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = 2 * q + j;
+        float t = red[(0 * 16 + r) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) t += red[(w * 16 + r) * 64 + lane];
+        const int h = h0 + rowof[j];
+        a.dW[(long)h * a.ldw + (long)p * a.Gp + g0 + i] = t;   // rows >= H and columns >= G are zero by construction
+        sq += t * t;
+      }
+    }
+    if (a.sq_part) {
+      sq = wave_sum(sq);
+      if (lane == 0) a.sq_part[((long)ht * a.n_gt + gt) * 8 + q] = sq;   // 8 slots per (H tile, gene tile): <= 4 per 32 x 32 tile
+    }
+    if (ht == 0) {   // bias gradient: column sums of dP over the whole minibatch (each lane holds its K slice's part)
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < NP; ++p) red[(q * NP + p) * 64 + lane] = csum[p];
+      __syncthreads();
+      if (q < NP && lane < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[(w * NP + q) * 64 + lane] + red[(w * NP + q) * 64 + 32 + lane];
+        a.db[(long)q * a.Gp + g0 + lane] = t;
+      }
+    }
+    return;
+  }
+
+  // ========================= role 1: one split-K slab tile of dd = dP W^T ===========================================
+  if (a.diag & 2) return;
+  const int b1 = blockIdx.x - a.n_w;
+  const int tiles = a.n_ct * a.n_ht;
+  const int z = b1 / tiles, t1 = b1 % tiles;
+  const int ct = t1 / a.n_ht, ht = t1 % a.n_ht;
+  const int m0 = ct * 32, h0 = ht * 32;
+  const long kbeg = (long)z * a.k_chunk, kend = min((long)a.ldp, kbeg + a.k_chunk);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int cell = min(m0 + i, a.B - 1);       // rows beyond the minibatch compute garbage that nobody reads
+  const float* ap = a.dP + (long)cell * a.ldp;
+  const float* bp = a.W + (long)(h0 + i) * a.ldw;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // one 512-wide slab per iteration: lane (i, hh) of wave q supplies the 32 consecutive k at 64 q + 32 hh -- one whole
+  // 128-byte line of row i of dP and of row h0 + i of W per lane (eight 16-byte loads each, unconditional: a
+  // predicated 16-byte load is split into four 4-byte loads by the compiler, 4x the instructions at 32 lines each)
+  for (long kb = kbeg; kb < kend; kb += 512) {
+    const long k0 = kb + 64 * q + 32 * hh;
+    const bool on = k0 < kend;                       // kend is a multiple of 32: a lane's 32 k are all in or all out
+    const long kl = on ? k0 : kbeg;                  // (loads of an 'out' lane read valid memory and are zeroed below)
+    float4 a4[8], b4[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      a4[v] = *reinterpret_cast<const float4*>(ap + kl + 4 * v);
+      b4[v] = *reinterpret_cast<const float4*>(bp + kl + 4 * v);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float m = on ? 1.f : 0.f;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].x * m, b4[v].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].y * m, b4[v].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].z * m, b4[v].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].w * m, b4[v].w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(q * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  float* slab = a.slab + (long)z * a.slab_stride;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = 2 * q + j;
+    float t = red[(0 * 16 + r) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) t += red[(w * 16 + r) * 64 + lane];
+    const int row = m0 + rowof[j];
+    if (row < a.B) slab[(long)row * a.ldd + h0 + i] = t;
+  }
+}
+
+bool head_bwd_supported(int B, int Hp, int Gp) { return B > 0 && Hp % 32 == 0 && Gp % 32 == 0; }
+
+// slices of the k Gp axis for dd: whole 512-wide slabs per slice, at most `max_slabs` slices
+int head_bwd_slices(long ldp, int max_slabs, int* k_chunk) {
+  int chunk = (int)((ldp + max_slabs - 1) / max_slabs);
+  chunk = (chunk + 511) / 512 * 512;
+  if (k_chunk) *k_chunk = chunk;
+  return (int)((ldp + chunk - 1) / chunk);
+}
+
+int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a_in) {
+  HeadBwdArgs a = a_in;
+  if (!head_bwd_supported(a.B, a.Hp, a.Gp) || !a.D || !a.dP || !a.W || !a.dW || !a.db || !a.slab || (a.ldp % 4) || (a.ldw % 4) ||
+      a.n_slices < 1 || a.k_chunk % 512) {
+    set_error("out_head_bwd: bad shapes");
+    return SMX_ERR_INVALID;
+  }
+  { static const int dg = getenv("SMX_HEADBWD_DIAG") ? atoi(getenv("SMX_HEADBWD_DIAG")) : 0; a.diag = dg; }
+  a.n_ht = a.Hp / 32; a.n_gt = a.Gp / 32; a.n_ct = (a.B + 31) / 32;
+  a.n_w = a.n_ht * ((a.n_gt + 7) / 8 * 8);
+  const int n_d = a.n_ct * a.n_ht * a.n_slices;
+  if (a.sq_count) *a.sq_count = a.n_ht * a.n_gt * 8;
+  dim3 grid((unsigned)(a.n_w + n_d));
+  if (a.n_planes == 3) hipLaunchKernelGGL((out_head_bwd_kernel<3>), grid, dim3(512), 0, st, a);
+  else if (a.n_planes == 2) hipLaunchKernelGGL((out_head_bwd_kernel<2>), grid, dim3(512), 0, st, a);
+  else { set_error("out_head_bwd: 2 or 3 planes"); return SMX_ERR_INVALID; }
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+}  // namespace smx

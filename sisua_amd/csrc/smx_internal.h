@@ -362,6 +362,23 @@ bool head_loss_supported(int B, int Hp, int Gp);
 int head_loss_chunks(int Gp);
 int launch_out_head_loss(hipStream_t st, const HeadLossArgs& a);
 
+// ---- both backward products of the output head in one launch (smx_headbwd.hip) ------------------
+struct HeadBwdArgs {
+  const float* D = nullptr; int ldd = 0;           // decoder output [B][ldd = Hp]
+  const float* dP = nullptr; long ldp = 0;         // [B][k * Gp]
+  const float* W = nullptr; int ldw = 0;           // [Hp][k * Gp]
+  float* dW = nullptr; float* db = nullptr;        // gradients, laid out as W / bias
+  float* slab = nullptr; long slab_stride = 0;     // dd slabs [n_slices][B][Hp]
+  int B = 0, Hp = 0, Gp = 0, n_planes = 0;
+  int n_slices = 0, k_chunk = 0;                   // from head_bwd_slices
+  float* sq_part = nullptr; int* sq_count = nullptr;
+  int n_ht = 0, n_gt = 0, n_ct = 0, n_w = 0;       // set by the launcher
+  int diag = 0;                                    // SMX_HEADBWD_DIAG bit 1 / 2: role-0 / role-1 workgroups return at once (timing only)
+};
+bool head_bwd_supported(int B, int Hp, int Gp);
+int head_bwd_slices(long ldp, int max_slabs, int* k_chunk);
+int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a);
+
 // ---- dataset kernels (smx_data.hip) ------------------------------------------------------------
 enum { ST_CORRUPT_SELECT = 80, ST_CORRUPT_BINOMIAL = 81 };   // Philox streams of the on-device corruption
 struct CorruptArgs {

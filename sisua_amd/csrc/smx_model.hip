@@ -1043,12 +1043,32 @@ int backward_pass(smx_model* m, const Pass& ps) {
     dparams = m->draw;
   }
   const int n_heads = m->scvi ? m->k : 1;
+  // count heads with raw planes: both products of the output head in one launch of the wide direct-operand kernel
+  // (smx_headbwd.hip); SMX_NO_HEAD_BWD=1 or scvi: the grouped LDS-tiled products below
+  static const bool no_hbwd = getenv("SMX_NO_HEAD_BWD") != nullptr;
+  const bool hbwd = !no_hbwd && !m->scvi && !m->head_fused && head_bwd_supported(ps.B, dL.out_p, m->Gp);
+  if (hbwd) {
+    const TensorInfo& tw = m->tensors[m->t_outW[0]];
+    HeadBwdArgs hb;
+    hb.D = dL.out_buf; hb.ldd = dL.out_p; hb.dP = m->dP; hb.ldp = ldp; hb.W = P_(m, m->t_outW[0]); hb.ldw = tw.ld;
+    hb.dW = G_(m, m->t_outW[0]); hb.db = G_(m, m->t_outb[0]);
+    hb.B = ps.B; hb.Hp = dL.out_p; hb.Gp = m->Gp; hb.n_planes = m->k;
+    hb.n_slices = head_bwd_slices(ldp, ldp <= 8192 ? 16 : 32, &hb.k_chunk);
+    hb.slab = m->slab; hb.slab_stride = dd_stride;
+    SMX_REQUIRE((size_t)hb.n_slices * (size_t)dd_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
+    if (m->sq_slots && getenv("SMX_NO_SQ_PARTIALS") == nullptr) {
+      hb.sq_part = m->sq_slots + m->sq_first[(size_t)m->t_outW[0]]; hb.sq_count = &m->sq_count[(size_t)m->t_outW[0]];
+    }
+    n_slabs = hb.n_slices;
+    Timed t(m, "gemm_out_bwd");
+    SMX_CHECK(launch_out_head_bwd(m->st, hb));
+  }
   {
     // weight gradient and input gradient of every head read the same dP and are independent:
     // one grouped launch (dW tiles + split-K dX slabs side by side)
     std::vector<GemmArgs> grp;
     std::vector<int> is_dx;
-    for (int ch = 0; ch < n_heads; ++ch) {
+    for (int ch = 0; ch < n_heads && !hbwd; ++ch) {
       const TensorInfo& tw = m->tensors[m->t_outW[ch]];
       const float* dp = dparams + (m->scvi ? (long)ch * m->Gp : 0);
       const int ncols = m->scvi ? m->Gp : (int)ldp;
@@ -1095,8 +1115,8 @@ int backward_pass(smx_model* m, const Pass& ps) {
       n_slabs += eff;
       SMX_REQUIRE((size_t)n_slabs * (size_t)dd_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
     }
-    {
-      Timed t(m, "gemm_out_bwd");
+    if (!grp.empty()) {
+      Timed t(m, hbwd ? "gemm_lab_bwd" : "gemm_out_bwd");
       for (size_t i = 0; i < grp.size(); i += SMX_GROUP_MAX) {
         const int n = (int)std::min<size_t>(SMX_GROUP_MAX, grp.size() - i);
         SMX_CHECK(launch_gemm_group(m->st, grp.data() + i, n));
