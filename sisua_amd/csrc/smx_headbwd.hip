@@ -15,6 +15,7 @@
 //   role 1: tile = 32 cells x 32 columns of H; K = this slice of the k Gp axis (64 per wave and 512-wide slab: lane
 //           (i, hh) supplies 32 consecutive k: one whole 128-byte line of row i of dP and of row h0 + i of W_out).
 #include <stdlib.h>
+#include <string.h>
 
 #include "smx_internal.h"
 #include "../../include/sisua_hip.h"
@@ -187,6 +188,130 @@ int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a_in) {
   if (a.n_planes == 3) hipLaunchKernelGGL((out_head_bwd_kernel<3>), grid, dim3(512), 0, st, a);
   else if (a.n_planes == 2) hipLaunchKernelGGL((out_head_bwd_kernel<2>), grid, dim3(512), 0, st, a);
   else { set_error("out_head_bwd: 2 or 3 planes"); return SMX_ERR_INVALID; }
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+}  // namespace smx
+
+// =====================================================================================================================
+// Weight gradients whose contraction axis is the minibatch (C = A^T Bm, K = B cells), grouped in one launch: the first
+// encoder layer (A = log1p of the gathered count rows), the latent head (+ bias gradient), the first decoder layer.
+// Same scheme as role 0 above: 32 x 32 tile per workgroup, 8 waves split the cells, both operands are coalesced
+// 128-byte row segments loaded straight into MFMA operand registers.
+// =====================================================================================================================
+namespace smx {
+
+__global__ __launch_bounds__(512) void wgrad_group_kernel(WgradGroup G) {
+  __shared__ float red[8 * 1024];
+  __shared__ float sqs[8];
+  // the descriptor through the kernarg segment pointer: indexing the by-value struct with a run-time problem id would
+  // make the compiler copy all of it to scratch (see gemm_group_kernel)
+  const WgradGroup& Gr = *(const WgradGroup*)__builtin_amdgcn_kernarg_segment_ptr();
+  int pi = 0;
+  while (pi + 1 < Gr.n && (int)blockIdx.x >= Gr.p[pi + 1].start) ++pi;
+  const WgradProblem& P = Gr.p[pi];
+  const int local = blockIdx.x - P.start;
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = lane & 31, hh = lane >> 5;
+  // blocks 8 apart share an XCD: they take the column tiles of ONE row tile (the gathered A rows are fetched once)
+  const int xcd = local & 7, idx = local >> 3;
+  const int nt = idx % P.n_nt, mt = (idx / P.n_nt) * 8 + xcd;
+  if (mt >= P.n_mt) return;
+  const int m0 = mt * 32, n0 = nt * 32;
+  const int B = Gr.B;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float csum = 0.f;
+  for (int kc = 0; kc < B; kc += 128) {
+    if (kc + 16 * q >= B) break;   // wave-uniform
+    const int k0 = kc + 16 * q + 8 * hh;
+    long arow[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int cell = min(k0 + s, B - 1);
+      arow[s] = (P.a_mode && P.rows) ? (long)P.rows[cell] : (long)cell;
+    }
+    float av[8], bv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int cell = min(k0 + s, B - 1);
+      bv[s] = P.Bm[(long)cell * P.ldb + n0 + i];
+      if (P.a_mode == 2) av[s] = (float)reinterpret_cast<const uint16_t*>(P.A)[arow[s] * P.lda + m0 + i];
+      else av[s] = P.A[arow[s] * P.lda + m0 + i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bool on = k0 + s < B;
+      float a_s = av[s];
+      if (P.a_mode && P.log1p) a_s = log1p_count(a_s);
+      a_s = on ? a_s : 0.f;
+      const float b_s = on ? bv[s] : 0.f;
+      csum += b_s;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s, b_s, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(q * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = 2 * q + j;
+    float t = red[(0 * 16 + r) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) t += red[(w * 16 + r) * 64 + lane];
+    const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    if (row < P.M) { P.C[(long)row * P.ldc + n0 + i] = t; sq += t * t; }
+  }
+  if (P.sq_part) {   // 4 slots per 32 x 32 tile (the layout of the per-tensor slot table): waves pair up
+    sq = wave_sum(sq);
+    if (lane == 0) sqs[q] = sq;
+  }
+  if (P.colsum && mt == 0) {
+    __syncthreads();
+    red[q * 64 + lane] = csum;
+  }
+  __syncthreads();
+  if (P.sq_part && threadIdx.x < 4) P.sq_part[((long)mt * P.n_nt + nt) * 4 + threadIdx.x] = sqs[2 * threadIdx.x] + sqs[2 * threadIdx.x + 1];
+  if (P.colsum && mt == 0 && q == 0 && lane < 32) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += red[w * 64 + lane] + red[w * 64 + 32 + lane];
+    P.colsum[n0 + lane] = t;
+  }
+}
+
+bool wgrad_supported(const GemmArgs& g, int B) {
+  // C = A^T Bm with A stored [K][M] (k-major), Bm [K][N], K = the minibatch; optional gather + log1p of A; no input dropout
+  if (!g.a_kmajor || g.b_nmajor || g.K != B || g.split_k > 1 || g.epi != 0 || g.bias) return false;
+  if (g.N % 32 || g.M % 32 || g.M <= 0) return false;   // (every weight has its rows padded to 32)
+  if (g.use_xform && (g.xf.drop_p > 0.f || g.xf.inj_mask)) return false;
+  return true;
+}
+
+int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B) {
+  if (n < 1 || n > SMX_GROUP_MAX) { set_error("wgrad group: 1..SMX_GROUP_MAX problems"); return SMX_ERR_INVALID; }
+  WgradGroup G;
+  memset(&G, 0, sizeof(G));
+  G.n = n; G.B = B;
+  int total = 0;
+  for (int k = 0; k < n; ++k) {
+    const GemmArgs& g = list[k];
+    if (!wgrad_supported(g, B)) { set_error("wgrad group: unsupported problem"); return SMX_ERR_INVALID; }
+    WgradProblem& P = G.p[k];
+    P.A = g.A; P.lda = g.lda; P.a_mode = g.use_xform ? (g.xf.u16 ? 2 : 1) : 0; P.log1p = g.use_xform ? g.xf.log1p : 0;
+    P.rows = g.use_xform ? g.xf.rows : nullptr;
+    P.Bm = g.B; P.ldb = g.ldb; P.C = g.C; P.ldc = g.ldc; P.M = g.M; P.N = g.N;
+    P.colsum = g.colsum; P.sq_part = g.sq_part;
+    P.n_mt = (g.M + 31) / 32; P.n_nt = g.N / 32;
+    P.start = total;
+    total += P.n_nt * ((P.n_mt + 7) / 8 * 8);
+    if (g.sq_part && g.sq_count) *g.sq_count = P.n_mt * P.n_nt * 4;
+  }
+  hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)total), dim3(512), 0, st, G);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }

@@ -379,6 +379,19 @@ bool head_bwd_supported(int B, int Hp, int Gp);
 int head_bwd_slices(long ldp, int max_slabs, int* k_chunk);
 int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a);
 
+// ---- grouped weight gradients with K = the minibatch (smx_headbwd.hip) ---------------------------
+struct WgradProblem {
+  const float* A; int lda; int a_mode; int log1p;   // a_mode 0: A [K][M]; 1: rows of the float32 count store gathered by `rows`; 2: uint16 store
+  const int32_t* rows;
+  const float* Bm; int ldb;
+  float* C; int ldc; int M, N;
+  float* colsum; float* sq_part;
+  int start, n_mt, n_nt;
+};
+struct WgradGroup { int n; int B; WgradProblem p[SMX_GROUP_MAX]; };
+bool wgrad_supported(const GemmArgs& g, int B);
+int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B);
+
 // ---- dataset kernels (smx_data.hip) ------------------------------------------------------------
 enum { ST_CORRUPT_SELECT = 80, ST_CORRUPT_BINOMIAL = 81 };   // Philox streams of the on-device corruption
 struct CorruptArgs {

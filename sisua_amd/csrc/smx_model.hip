@@ -1195,7 +1195,13 @@ int backward_pass(smx_model* m, const Pass& ps) {
   for (int q = 0; q < n_dw0; ++q) tail.push_back(dw0[q]);
   {
     Timed t(m, "gemm_enc_dw");
-    if (tail.size() == 1) SMX_CHECK(launch_gemm(m->st, tail[0]));
+    // every product here contracts over the minibatch: the wide direct-operand kernel takes them all in one launch
+    // (SMX_NO_WGRAD=1, input dropout or an unsupported shape: the LDS-tiled products)
+    static const bool no_wgrad = getenv("SMX_NO_WGRAD") != nullptr;
+    bool wg_ok = !no_wgrad && tail.size() <= SMX_GROUP_MAX;
+    for (const GemmArgs& g : tail) wg_ok = wg_ok && wgrad_supported(g, ps.B);
+    if (wg_ok) SMX_CHECK(launch_wgrad_group(m->st, tail.data(), (int)tail.size(), ps.B));
+    else if (tail.size() == 1) SMX_CHECK(launch_gemm(m->st, tail[0]));
     else
       for (size_t q = 0; q < tail.size(); q += SMX_GROUP_MAX)
         SMX_CHECK(launch_gemm_group(m->st, tail.data() + q, (int)std::min<size_t>(SMX_GROUP_MAX, tail.size() - q)));
