@@ -205,18 +205,30 @@ def main():
   cp.barrier()
   dt = cp.max(time.perf_counter() - t0)
 
-  # ---- roofline of the ZINB+KL loss kernel: HIP events on the model's stream ----
+  # ---- roofline of the ZINB likelihood: HIP events on the model's stream --------------------------------------
+  # In a training step the likelihood runs as the epilogue of the output product (out_head_loss_kernel, P never
+  # leaves the registers).  Its time is attributed as SURVEY.md section 7 ("roofline honesty") asks: the fused
+  # kernel minus the SAME kernel without the likelihood (product only, P stored) -- both launched 8 times back to
+  # back inside one event pair, so the pair's own overhead and the launch gaps cancel in the difference.  The
+  # standalone kernel (count_loss_kernel, what eval / predict / scoring use; flag head_loss = 0) is timed too.
   n_ev = min(args.steps, 200)
-  eng.timing_enable("null")       # event pair around nothing: overhead of the timing method itself
-  eng.train_steps(order[: n_ev * batch], n_ev, batch, graph=False)
-  null_ms, null_n = eng.timing_read()
-  eng.timing_enable("loss")
-  eng.train_steps(order[: n_ev * batch], n_ev, batch, graph=False)
-  loss_ms, loss_n = eng.timing_read()
+
+  def timed(label):
+    eng.timing_enable(label)
+    eng.train_steps(order[: n_ev * batch], n_ev, batch, graph=False)
+    ms, n = eng.timing_read()
+    return 1e3 * ms / max(n, 1), n
+
+  null_us, _ = timed("null")      # event pair around nothing: overhead of the timing method itself
+  fused_us, fused_n = timed("out_head")
+  prod_us, _ = timed("out_head_product")
+  eng.set_flag("head_loss", False)
+  alone_us, alone_n = timed("loss")
+  eng.set_flag("head_loss", True)
   eng.timing_enable(None)
-  ev_overhead_us = 1e3 * null_ms / max(null_n, 1)
+  ev_overhead_us = null_us
   per_kernel = {}
-  for name in ("gemm_enc_fwd", "gemm_out_fwd", "out_head", "out_head_product", "gemm_out_bwd", "gemm_enc_dw", "adam", "step"):
+  for name in ("gemm_enc_fwd", "bn_fwd", "out_head", "gemm_out_bwd", "bn_bwd", "gemm_enc_dw", "adam", "step"):
     eng.timing_enable(name)
     n_k = min(50, args.warmup + args.steps)
     eng.train_steps(order[: n_k * batch], n_k, batch, graph=False)
@@ -226,16 +238,17 @@ def main():
 
   if rank == 0:
     bytes_per_launch = eng.loss_bytes_per_cell() * batch
-    # in timing mode the library launches the (idempotent) loss kernel LOSS_REPEAT times inside each event
-    # pair; subtracting the pair's own overhead (the "null" pair) leaves LOSS_REPEAT back-to-back launches
-    raw_us = 1e3 * loss_ms / max(loss_n, 1)
-    avg_s = max(raw_us - ev_overhead_us, 0.1) / LOSS_REPEAT * 1e-6
-    achieved = bytes_per_launch / avg_s / 1e9
+    fused = fused_n > 0
+    t_fused = max(fused_us - ev_overhead_us, 0.1) / LOSS_REPEAT
+    t_prod = max(prod_us - ev_overhead_us, 0.1) / LOSS_REPEAT
+    t_alone = max(alone_us - ev_overhead_us, 0.1) / LOSS_REPEAT
+    t_attr = max(t_fused - t_prod, 0.05) if fused else t_alone     # us of a launch attributable to the likelihood
+    achieved = bytes_per_launch / (t_attr * 1e-6) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "loss_traffic_bytes.json")
     if os.path.exists(tfile):
       try:
-        traffic = json.load(open(tfile)).get(args.workload)
+        traffic = json.load(open(tfile)).get(args.workload + ("" if not fused else ":fused"))
       except Exception:
         traffic = None
     out = {
@@ -251,12 +264,17 @@ def main():
                                f"batch {batch}/GPU, hipGraph={'on' if use_graph else 'off'}, X resident as {args.storage}",
                    "global_batch": batch * world, "parallelism": f"dp{world}" + ("+syncbn" if (world > 1 and args.sync_bn) else "")},
         "final_loss": round(m["loss"], 4),
-        "roofline": {"bound": "hbm", "kernel": "count_loss_kernel<ZINB> fwd+bwd", "achieved": round(achieved, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "roofline": {"bound": "hbm",
+                     "kernel": ("out_head_loss_kernel (output product + likelihood fwd+bwd fused); time attributed to the likelihood = "
+                                "fused kernel - the same kernel without the likelihood") if fused else "count_loss_kernel fwd+bwd",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "bytes_per_launch": bytes_per_launch,
-                     "avg_launch_us": round(avg_s * 1e6, 3), "event_pair_overhead_us": round(ev_overhead_us, 3),
-                     "raw_event_us": round(raw_us, 3), "launches_per_event_pair": LOSS_REPEAT,
-                     "launches_timed": loss_n * LOSS_REPEAT},
+                     "avg_launch_us": round(t_attr, 3), "fused_kernel_us": round(t_fused, 3), "product_only_us": round(t_prod, 3),
+                     "standalone": {"kernel": "count_loss_kernel fwd+bwd (eval / predict / scoring; training with head_loss = 0)",
+                                    "avg_launch_us": round(t_alone, 3), "achieved": round(bytes_per_launch / (t_alone * 1e-6) / 1e9, 1),
+                                    "frac": round(bytes_per_launch / (t_alone * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                     "event_pair_overhead_us": round(ev_overhead_us, 3), "launches_per_event_pair": LOSS_REPEAT,
+                     "launches_timed": fused_n * LOSS_REPEAT},
         "kernel_us": per_kernel,
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -251,9 +251,22 @@ int smx_comm_set_sync_bn(smx_model* m, int on);
  * so the world > 1 arithmetic of the step can be checked on a one-GPU box.  Eager launches only. */
 int smx_comm_init_local(smx_model* const* models, int n);
 
+/* ---- code-path switches ---------------------------------------------------- */
+/* The training step has two forms of several stages: the default wide / fused kernels and the separate-launch forms
+ * they replaced (which eval, predict and the scoring paths always use).  name: "head_loss" (output product fused with
+ * the likelihood), "front" (latent sample + first decoder product inside BatchNorm-forward), "bwd_front" (d h inside
+ * BatchNorm-backward + the weight gradients grouped at the end), "head_bwd" (both backward products of the output
+ * head in one launch), "wgrad" (minibatch-contracted weight gradients as the wide kernel).  value 1 = default form,
+ * 0 = separate launches.  Results agree to rounding; used for A/B measurements and by the parity tests of both
+ * forms.  Defaults may also be set with SMX_NO_HEAD_LOSS / SMX_NO_FRONT / SMX_NO_BWD_FRONT / SMX_NO_HEAD_BWD /
+ * SMX_NO_WGRAD in the environment. */
+int smx_set_flag(smx_model* m, const char* name, int value);
+
 /* ---- measurement ---------------------------------------------------------- */
 /* HIP-event timing of one named kernel class inside eager steps, on the model's
- * stream.  kernel: "loss", "gemm_enc_fwd", "gemm_out_fwd", "gemm_out_bwd" (grouped dW + dX),
+ * stream.  kernel: "out_head" (the fused output product + likelihood; 8 idempotent launches per event pair),
+ * "out_head_product" (the same kernel without the likelihood: what the fused kernel's time is compared with), "loss"
+ * (the standalone likelihood kernel, flag head_loss = 0), "gemm_enc_fwd", "gemm_out_fwd", "gemm_out_bwd" (dW + dX of the head),
  * "gemm_enc_dw", "bn_fwd", "bn_bwd", "adam", "allreduce", "step", or "null" (an event pair around
  * nothing: the overhead to subtract from single-kernel timings).  Enable, run steps, read. */
 int smx_timing_enable(smx_model* m, const char* kernel);

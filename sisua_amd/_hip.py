@@ -104,6 +104,7 @@ SIGNATURES = {
     "smx_comm_init_local": (C.c_int, [C.POINTER(_VP), C.c_int]),
     "smx_k_adam": (C.c_int, [C.c_int32, _IP, _FP, _FP, _FP, _FP, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                              C.c_float, _FP]),
+    "smx_set_flag": (C.c_int, [_VP, C.c_char_p, C.c_int]),
     "smx_timing_enable": (C.c_int, [_VP, C.c_char_p]),
     "smx_timing_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "smx_loss_bytes_per_cell": (C.c_int64, [_VP]),

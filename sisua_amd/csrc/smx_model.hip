@@ -238,6 +238,16 @@ struct smx_model {
   bool forked = false;
   bool head_fused = false;
   bool head_loss = false;             // this step's output product ran fused with the likelihood (smx_headloss.hip)
+  // code-path switches (smx_set_flag; defaults from the SMX_NO_* environment variables): 1 = the default wide / fused
+  // kernels, 0 = the separate-launch forms they replaced (kept for eval, for shapes the fused kernels do not take, and
+  // as A/B references)
+  struct Flags {
+    int head_loss = getenv("SMX_NO_HEAD_LOSS") ? 0 : 1;    // output product + likelihood in one kernel
+    int front = getenv("SMX_NO_FRONT") ? 0 : 1;            // latent sample + first decoder product inside BatchNorm-forward
+    int bwd_front = getenv("SMX_NO_BWD_FRONT") ? 0 : 1;    // d h inside BatchNorm-backward, weight gradients grouped at the end
+    int head_bwd = getenv("SMX_NO_HEAD_BWD") ? 0 : 1;      // both backward products of the output head in one wide launch
+    int wgrad = getenv("SMX_NO_WGRAD") ? 0 : 1;            // K = minibatch weight gradients as the wide direct-operand kernel
+  } flags;
   int chunk_first_head = 0;           // first optimiser chunk of the output / label heads (they are last in the table)
   bool adam_early_pending = false;    // the heads' gradients are final: the next BatchNorm-backward launch may carry their update
   int adam_early_from = -1;           // >= 0: chunks [adam_early_from, n_chunks) of this step were applied early
@@ -703,8 +713,7 @@ bool use_fused_head(const smx_model* m, int B) {
 // dP in ONE wide kernel, P never materialised (smx_headloss.hip).  SMX_NO_HEAD_LOSS=1 keeps the product / loss
 // kernel pair (what eval, predict and the scoring paths always use).
 bool use_head_loss(const smx_model* m, int B) {
-  static const bool off = getenv("SMX_NO_HEAD_LOSS") != nullptr;
-  if (off || m->scvi || m->dec.empty()) return false;
+  if (!m->flags.head_loss || m->scvi || m->dec.empty()) return false;
   return head_loss_supported(B, m->dec.back().out_p, m->Gp);
 }
 
@@ -806,8 +815,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   la.z = m->z; la.sig = m->sig; la.eps = m->eps; la.kl = m->kl;
   // The latent sample + KL and the first decoder product run INSIDE the decoder's first BatchNorm launch (two
   // launches fewer) when the shapes allow; SMX_NO_FRONT=1 keeps the three-launch form.
-  static const bool no_front = getenv("SMX_NO_FRONT") != nullptr;
-  front_ok = !no_front && !fuse_lat && !sync_bn_on(m, ps.training) && bn_front_supported(ps.B, m->Dp) && (m->Dp == 32 || m->Dp == 64) &&
+  front_ok = m->flags.front && !fuse_lat && !sync_bn_on(m, ps.training) && bn_front_supported(ps.B, m->Dp) && (m->Dp == 32 || m->Dp == 64) &&
              m->dec[0].in_p == m->Dp && m->dec[0].out_p % 8 == 0 && (lat_ld % 4) == 0 && (!la.inj_eps || (la.inj_ld % 4) == 0);
   front_la = la;
   if (front_ok) {
@@ -1045,8 +1053,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
   const int n_heads = m->scvi ? m->k : 1;
   // count heads with raw planes: both products of the output head in one launch of the wide direct-operand kernel
   // (smx_headbwd.hip); SMX_NO_HEAD_BWD=1 or scvi: the grouped LDS-tiled products below
-  static const bool no_hbwd = getenv("SMX_NO_HEAD_BWD") != nullptr;
-  const bool hbwd = !no_hbwd && !m->scvi && !m->head_fused && head_bwd_supported(ps.B, dL.out_p, m->Gp);
+  const bool hbwd = m->flags.head_bwd && !m->scvi && !m->head_fused && head_bwd_supported(ps.B, dL.out_p, m->Gp);
   if (hbwd) {
     const TensorInfo& tw = m->tensors[m->t_outW[0]];
     HeadBwdArgs hb;
@@ -1140,9 +1147,8 @@ int backward_pass(smx_model* m, const Pass& ps) {
   // Products that only the optimiser reads (the weight gradients of the first decoder layer, of the latent head and of
   // the first encoder layers) run as ONE grouped launch at the end; the last encoder layer's BatchNorm-backward
   // launch computes d h = d lat W_lat^T itself.  SMX_NO_BWD_FRONT=1: the separate launches of before.
-  static const bool no_bfront = getenv("SMX_NO_BWD_FRONT") != nullptr;
   const MlpLayer& eL = m->enc.back();
-  const bool bfront = !no_bfront && !sync_bn_on(m, ps.training) && bn_bwd_front_supported(ps.B, lat_ld) && eL.out_p % 8 == 0;
+  const bool bfront = m->flags.bwd_front && !sync_bn_on(m, ps.training) && bn_bwd_front_supported(ps.B, lat_ld) && eL.out_p % 8 == 0;
   std::vector<GemmArgs> tail;
   SMX_CHECK(mlp_backward(m, m->dec, ps, m->z, m->Dp, false, n_slabs, false, nullptr, "", &le, nullptr, nullptr, bfront ? &tail : nullptr));
   BnBwdArgs gf;
@@ -1197,8 +1203,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
     Timed t(m, "gemm_enc_dw");
     // every product here contracts over the minibatch: the wide direct-operand kernel takes them all in one launch
     // (SMX_NO_WGRAD=1, input dropout or an unsupported shape: the LDS-tiled products)
-    static const bool no_wgrad = getenv("SMX_NO_WGRAD") != nullptr;
-    bool wg_ok = !no_wgrad && tail.size() <= SMX_GROUP_MAX;
+    bool wg_ok = m->flags.wgrad && tail.size() <= SMX_GROUP_MAX;
     for (const GemmArgs& g : tail) wg_ok = wg_ok && wgrad_supported(g, ps.B);
     if (wg_ok) SMX_CHECK(launch_wgrad_group(m->st, tail.data(), (int)tail.size(), ps.B));
     else if (tail.size() == 1) SMX_CHECK(launch_gemm(m->st, tail[0]));
@@ -2305,6 +2310,18 @@ int smx_comm_library(char* rccl_path, int rccl_cap, char* hip_path, int hip_cap,
 
 int smx_comm_rank(const smx_model* m) { return m ? m->rank : 0; }
 int smx_comm_world(const smx_model* m) { return m ? m->world : 0; }
+
+int smx_set_flag(smx_model* m, const char* name, int value) {
+  SMX_REQUIRE(m && name, "null argument");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  const std::string n(name);
+  int* f = n == "head_loss" ? &m->flags.head_loss : n == "front" ? &m->flags.front : n == "bwd_front" ? &m->flags.bwd_front
+         : n == "head_bwd" ? &m->flags.head_bwd : n == "wgrad" ? &m->flags.wgrad : nullptr;
+  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad)");
+  *f = value ? 1 : 0;
+  drop_graphs(m);   // a captured step bakes the launch sequence in
+  return SMX_OK;
+}
 
 int smx_timing_enable(smx_model* m, const char* kernel) {
   SMX_REQUIRE(m, "null model");

@@ -381,6 +381,10 @@ class Engine:
     arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
     check(lib.smx_comm_init_local(arr, len(engines)))
 
+  def set_flag(self, name: str, value: bool):
+    """Code-path switch of the training step (smx_set_flag): head_loss, front, bwd_front, head_bwd, wgrad."""
+    check(self.lib.smx_set_flag(self._h, name.encode(), int(bool(value))))
+
   # ---- measurement ----------------------------------------------------------------------
   def timing_enable(self, kernel: Optional[str]):
     check(self.lib.smx_timing_enable(self._h, kernel.encode() if kernel else None))

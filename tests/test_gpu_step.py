@@ -94,6 +94,42 @@ def test_one_step_matches_oracle(Engine, name, batch):
   e.close()
 
 
+@pytest.mark.parametrize("flags", [("head_loss",), ("front",), ("bwd_front",), ("head_bwd",), ("wgrad",),
+                                   ("head_loss", "front", "bwd_front", "head_bwd", "wgrad")])
+@pytest.mark.parametrize("name", ["vae_zinb", "sisua", "paper_shape", "dca_zinb"])
+def test_separate_launch_forms_match_oracle(Engine, name, flags):
+  """Every stage that has a fused / wide default form also keeps its separate-launch form (smx_set_flag): eval and
+  the scoring paths use those, and shapes the fused kernels do not take fall back to them.  Same parity bar, and
+  three steps of both forms end within rounding of each other."""
+  kw = CASES[name]
+  spec, cfg, x, ys, lib, mask = _problem(kw)
+  params = perturbed_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  B = 96
+  e, e0 = Engine(cfg, max_batch=128, init=False), Engine(cfg, max_batch=128, init=False)
+  for eng in (e, e0):
+    eng.set_params(params)
+    eng.upload(x, ys, lib, mask, cell_id_base=1000)
+  for f in flags:
+    e.set_flag(f, False)
+  rows = np.random.default_rng(1).choice(x.shape[0], size=B, replace=False).astype(np.int32)
+  res = _oracle_step(spec, params, bn, opt, x, ys, lib, mask, rows, 0, cell_base=1000)
+  m = e.train_step(rows)
+  for key in ("loss", "nllk_x", "kl"):
+    assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
+  worst = grad_errors(e.get_params(which=1), res["grads"])
+  assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  assert np.isclose(m["grad_norm_max"], max(np.linalg.norm(g) for g in res["grads"].values()), rtol=1e-4)
+  m0 = e0.train_step(rows)
+  for s in (1, 2):
+    r2 = ((rows + 7 * s) % x.shape[0]).astype(np.int32)
+    m, m0 = e.train_step(r2), e0.train_step(r2)
+  assert np.isclose(m["loss"], m0["loss"], rtol=1e-5)
+  with pytest.raises(Exception):
+    e.set_flag("no_such_flag", True)
+  e.close(); e0.close()
+
+
 @pytest.mark.parametrize("name", ["vae_zinb", "sisua", "scvi_zinbd"])
 def test_injected_noise_matches_oracle(Engine, name):
   """smx_set_noise hook: same parameters + same minibatch + same injected eps / dropout
