@@ -473,7 +473,8 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
     eps_l = noise.normal(STREAM_EPS_L, 1)[:, 0]
     l = mu_l + sig_l * eps_l
     assert library is not None, "scvi needs the library prior (scvi.py:100-105)"
-    mp, sp = library[:, 0], np.sqrt(library[:, 1])
+    library = np.asarray(library, dtype=np.float64)   # (a float32 array here made sqrt round to float32: 3e-8 on KL_l;
+    mp, sp = library[:, 0], np.sqrt(library[:, 1])    #  found by the independent torch step, tests/test_oracle_torch.py)
     kl_l = np.log(sp / sig_l) + (sig_l ** 2 + (mu_l - mp) ** 2) / (2 * sp ** 2) - 0.5
     out.update(l_mean=mu_l, l_scale=sig_l, l=l)
 
@@ -596,6 +597,7 @@ def marginal_log_prob(spec: Spec, params, bn_state, x, cell_ids, n_samples: int,
       lw += (-0.5 * z ** 2 + 0.5 * eps ** 2 + np.log(sig)).sum(1)
     if spec.model == "scvi":
       l, mu_l, sig_l = r["l"], r["l_mean"], r["l_scale"]
+      library = np.asarray(library, dtype=np.float64)
       mp, sp = library[:, 0], np.sqrt(library[:, 1])
       eps_l = (l - mu_l) / sig_l
       lw += -0.5 * ((l - mp) / sp) ** 2 - np.log(sp) + 0.5 * eps_l ** 2 + np.log(sig_l)

@@ -1,0 +1,180 @@
+"""An INDEPENDENT second implementation of the whole training step, checked against the oracle.
+
+`oracle/sisua_oracle.py` derives every gradient by hand.  Here the same step is written once more in torch float64
+with nothing shared but the frozen third-party semantics: likelihoods and KL terms come from
+`torch.distributions` wherever a distribution exists there (NegativeBinomial, Normal, kl_divergence,
+OneHotCategorical), gradients from `torch.autograd`, the optimiser from `torch.optim.Adam` (with the epsilon
+re-expressed per step so that it is Keras's `m / (sqrt(v) + eps)`), clipping by hand (torch's helper adds 1e-6 to the
+norm).  The noise (dropout masks, eps) is the only thing taken from the oracle: it is an input of the step.
+Agreement: loss and updated parameters to 1e-9, every gradient to 1e-8 (relative L2), BatchNorm moving statistics to 1e-12, two steps,
+all four model families + the ablations the GPU tests run.  CPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.distributions as td
+
+from oracle import sisua_oracle as so
+from tests.util import perturbed_params, synth_counts, synth_labels
+
+torch.set_default_dtype(torch.float64)
+SP1 = float(np.log(np.expm1(1.0)))
+
+
+def softplus1(x):
+  return torch.nn.functional.softplus(x + SP1)
+
+
+def mlp(spec, P, bn, prefix, units, h, noise, stream0, p_drop, new_bn):
+  """Dense (no bias under BN) -> BatchNorm(batch statistics, biased variance) -> ReLU -> inverted Dropout."""
+  for i, _ in enumerate(units):
+    pre = h @ P[f"{prefix}{i}/W"]
+    if spec.batchnorm:
+      mu = pre.mean(0)
+      var = ((pre - mu) ** 2).mean(0)
+      new_bn[f"{prefix}{i}/moving_mean"] = spec.bn_momentum * bn[f"{prefix}{i}/moving_mean"] + (1 - spec.bn_momentum) * mu.detach().numpy()
+      new_bn[f"{prefix}{i}/moving_var"] = spec.bn_momentum * bn[f"{prefix}{i}/moving_var"] + (1 - spec.bn_momentum) * var.detach().numpy()
+      y = P[f"{prefix}{i}/gamma"] * (pre - mu) / torch.sqrt(var + spec.bn_eps) + P[f"{prefix}{i}/beta"]
+    else:
+      y = pre + P[f"{prefix}{i}/b"]
+    h = torch.relu(y) * torch.as_tensor(noise.dropout(stream0 + i, y.shape[1], p_drop))
+  return h
+
+
+def count_log_prob(x, planes, likelihood, direct):
+  """log p(x) per (cell, gene).  'nb'/'zinb': TFP NegativeBinomial(total_count = exp(a), logits) -- the torch
+  distribution of the same name has the same convention; 'nbd'/'zinbd': the scVI formula (there is no distribution
+  object with its epsilon terms); zero inflation: log(pi 1[x = 0] + (1 - pi) NB(x)) through logsumexp."""
+  if likelihood in ("nb", "zinb"):
+    lp = td.NegativeBinomial(total_count=torch.exp(planes[0]), logits=planes[1]).log_prob(x)
+  else:
+    mu, th = (planes[0], planes[1]) if direct else (torch.nn.functional.softplus(planes[0]), softplus1(planes[1]))
+    e = so.NBD_EPS
+    lp = (th * (torch.log(th + e) - torch.log(th + mu + e)) + x * (torch.log(mu + e) - torch.log(th + mu + e))
+          + torch.lgamma(x + th) - torch.lgamma(th) - torch.lgamma(x + 1))
+  if likelihood in ("zinb", "zinbd"):
+    g = planes[2]
+    log_pi, log_1mpi = torch.nn.functional.logsigmoid(g), torch.nn.functional.logsigmoid(-g)
+    zero = torch.logsumexp(torch.stack([log_pi, log_1mpi + lp]), 0)
+    lp = torch.where(x == 0, zero, log_1mpi + lp)
+  return lp
+
+
+def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
+  P = {k: torch.tensor(v, requires_grad=True) for k, v in params.items()}
+  x = torch.as_tensor(np.asarray(x, np.float64))
+  B, G, D = x.shape[0], spec.n_genes, spec.latent_dim
+  new_bn = {}
+  h0 = torch.log1p(x) if spec.log_norm else x
+  h0 = h0 * torch.as_tensor(noise.dropout(so.STREAM_INPUT_DROPOUT, G, spec.input_dropout))
+  h = mlp(spec, P, bn, "enc", spec.enc_units, h0, noise, so.STREAM_ENC_DROPOUT, spec.dropout_enc, new_bn)
+  lat = h @ P["lat/W"] + P["lat/b"]
+  if spec.stochastic:
+    q = td.Normal(lat[:, :D], softplus1(lat[:, D:]))
+    z = q.loc + q.scale * torch.as_tensor(noise.normal(so.STREAM_EPS_Z, D))
+    kl = td.kl_divergence(q, td.Normal(torch.zeros_like(q.loc), torch.ones_like(q.scale))).sum(1)
+  else:
+    z = torch.relu(lat) if spec.latent_activation == "relu" else lat
+    kl = torch.zeros(B)
+  kl_l = torch.zeros(B)
+  if spec.model == "scvi":
+    hl = mlp(spec, P, bn, "encl", spec.encl_units, h0, noise, so.STREAM_ENCL_DROPOUT, spec.dropout_enc, new_bn)
+    latl = hl @ P["latl/W"] + P["latl/b"]
+    ql = td.Normal(latl[:, 0], softplus1(latl[:, 1]))
+    l = ql.loc + ql.scale * torch.as_tensor(noise.normal(so.STREAM_EPS_L, 1)[:, 0])
+    lib = torch.as_tensor(np.asarray(library, np.float64))
+    kl_l = td.kl_divergence(ql, td.Normal(lib[:, 0], torch.sqrt(lib[:, 1])))
+  d = mlp(spec, P, bn, "dec", spec.dec_units, z, noise, so.STREAM_DEC_DROPOUT, spec.dropout_dec, new_bn)
+  if spec.model == "scvi":
+    raw = [d @ P[f"out{c}/W"] + P[f"out{c}/b"] for c in range(spec.k)]
+    rho = torch.clamp(torch.softmax(raw[0], dim=1), so.SCVI_RHO_MIN, 1 - so.SCVI_RHO_MIN)
+    rate = torch.exp(torch.clamp(l, 0.0, spec.clip_library))[:, None] * rho
+    planes = [rate, torch.exp(raw[1])] + ([raw[2]] if spec.k == 3 else [])
+    llk_x = count_log_prob(x, planes, spec.likelihood, True).sum(1)
+  else:
+    raw = d @ P["out/W"] + P["out/b"]
+    llk_x = count_log_prob(x, [raw[:, c * G:(c + 1) * G] for c in range(spec.k)], spec.likelihood, False).sum(1)
+  llk_y = torch.zeros(B)
+  for j, (Pj, kind) in enumerate(spec.labels):
+    ry = d @ P[f"lab{j}/W"] + P[f"lab{j}/b"]
+    yj = torch.as_tensor(np.asarray(y[j], np.float64))
+    if kind == "nb":
+      # protein levels are real-valued (dataset.html:187): the same density formula, support check off
+      llk_y = llk_y + td.NegativeBinomial(total_count=torch.exp(ry[:, :Pj]), logits=ry[:, Pj:], validate_args=False).log_prob(yj).sum(1)
+    else:
+      llk_y = llk_y + td.OneHotCategorical(logits=ry).log_prob(yj)
+  m = torch.zeros(B) if mask is None else torch.as_tensor(np.asarray(mask, np.float64))
+  loss = -(llk_x + spec.alpha * m * llk_y - spec.beta * (kl + kl_l)).mean()
+  loss.backward()
+  return P, float(loss.detach()), {k: v.grad.numpy() for k, v in P.items()}, new_bn
+
+
+def keras_adam(spec, P, state, t):
+  """torch.optim.Adam with Keras's epsilon: torch divides by sqrt(v / (1 - b2^t)) + eps, Keras by sqrt(v) + eps under
+  lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); they coincide for eps_torch = eps / sqrt(1 - b2^t)."""
+  if "opt" not in state:
+    state["opt"] = torch.optim.Adam(list(P.values()), lr=spec.lr, betas=(spec.adam_beta1, spec.adam_beta2), eps=spec.adam_eps)
+    state["names"] = list(P)
+  opt = state["opt"]
+  for grp in opt.param_groups:
+    grp["eps"] = spec.adam_eps / np.sqrt(1.0 - spec.adam_beta2 ** t)
+  for p in P.values():   # per-tensor clipnorm (configs/base.yaml:50)
+    n = float(p.grad.norm())
+    if spec.clipnorm > 0 and n > spec.clipnorm:
+      p.grad.mul_(spec.clipnorm / n)
+  opt.step()
+
+
+CASES = {
+    "vae_zinb": dict(model="vae", n_genes=60, likelihood="zinb", enc_units=(24, 20), dec_units=(20,), latent_dim=6, input_dropout=0.2),
+    "vae_nb_nobn": dict(model="vae", n_genes=40, likelihood="nb", enc_units=(16,), dec_units=(16,), latent_dim=5, batchnorm=False),
+    "vae_zinbd": dict(model="vae", n_genes=50, likelihood="zinbd", enc_units=(16,), dec_units=(16, 12), latent_dim=4),
+    "vae_nbd_clip": dict(model="vae", n_genes=33, likelihood="nbd", enc_units=(12,), dec_units=(12,), latent_dim=3, clipnorm=0.05),
+    "dca_zinb": dict(model="dca", n_genes=45, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=4),
+    "dca_linear": dict(model="dca", n_genes=30, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=4, latent_activation="linear"),
+    "sisua": dict(model="sisua", n_genes=48, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5,
+                  labels=((7, "nb"), (4, "onehot")), alpha=10.0),
+    "scvi_zinbd": dict(model="scvi", n_genes=52, likelihood="zinbd", enc_units=(16,), dec_units=(16,), latent_dim=4, encl_units=(8,)),
+    "scvi_nbd": dict(model="scvi", n_genes=36, likelihood="nbd", enc_units=(12,), dec_units=(12,), latent_dim=3, encl_units=(6,),
+                     batchnorm=False),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_torch_autograd_step_equals_the_oracle(name):
+  spec = so.Spec(**CASES[name])
+  n, B = 90, 40
+  x = synth_counts(n, spec.n_genes, sparsity=0.7, seed=2, max_count=300)
+  ys = synth_labels(n, spec.labels)
+  _, lm, lv = so.library_size(x)
+  lib = np.tile(np.array([[lm, lv]]), (n, 1))
+  mask = so.label_mask(n, 0.5, n_omics=1 + len(spec.labels), seed=1)
+  params = perturbed_params(spec)
+  t_params = {k: v.copy() for k, v in params.items()}
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  t_bn, state = {k: v.copy() for k, v in bn.items()}, {}
+  P = None
+  for step in range(2):
+    rows = np.random.default_rng(step).permutation(n)[:B]
+    kw = dict(y=[a[rows] for a in ys], library=lib[rows], mask=mask[rows])
+    res = so.train_step(spec, params, bn, opt, x[rows], so.PhiloxNoise(spec.seed, step, rows), **kw)
+    if P is None:
+      P, loss, grads, new_bn = torch_step(spec, t_params, t_bn, x[rows], so.PhiloxNoise(spec.seed, step, rows), **kw)
+    else:   # the same leaf tensors keep their optimiser state across steps
+      for p in P.values():
+        p.grad = None
+      cur = {k: v.detach().numpy().copy() for k, v in P.items()}
+      P2, loss, grads, new_bn = torch_step(spec, cur, t_bn, x[rows], so.PhiloxNoise(spec.seed, step, rows), **kw)
+      for k in P:
+        P[k].grad = P2[k].grad
+    assert np.isclose(loss, res["loss"], rtol=1e-9, atol=0), (step, loss, res["loss"])   # (scvi: 1e-10 from exp / softmax in a different order)
+    top = max(np.linalg.norm(g) for g in res["grads"].values())
+    for k, g in res["grads"].items():
+      assert np.linalg.norm(grads[k] - g) <= 1e-8 * max(np.linalg.norm(g), 1e-6 * top), (step, k)
+    keras_adam(spec, P, state, step + 1)
+    t_bn.update(new_bn)
+    for k in params:
+      assert np.allclose(P[k].detach().numpy(), params[k], rtol=1e-9, atol=1e-11), (step, k)
+    for k in bn:
+      assert np.allclose(t_bn[k], bn[k], rtol=1e-12, atol=1e-14), (step, k)
+  if "clip" in name:   # the clipped branch really ran
+    assert max(np.linalg.norm(g) for g in res["grads"].values()) > spec.clipnorm
