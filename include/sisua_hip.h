@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SMX_ABI_VERSION 1
+#define SMX_ABI_VERSION 2
 #define SMX_MAX_LAYERS 8
 #define SMX_MAX_LABELS 4
 
@@ -43,7 +43,9 @@ typedef enum { SMX_MODEL_VAE = 0, SMX_MODEL_DCA = 1, SMX_MODEL_SCVI = 2, SMX_MOD
 /* Count likelihoods selected by RVmeta.posterior (configs/base.yaml:32-40,
  * data/_single_cell_base.py:518-533). */
 typedef enum { SMX_LLK_NB = 0, SMX_LLK_ZINB = 1, SMX_LLK_NBD = 2, SMX_LLK_ZINBD = 3 } smx_likelihood;
-typedef enum { SMX_LABEL_NB = 0, SMX_LABEL_ONEHOT = 1 } smx_label_likelihood;
+/* Label heads of SISUA (vae.py:19-44): NB (ADT counts), one-hot categorical (cell types); of MISA (vae.py:47-98): every
+ * label dimension a mixture of label_components (2..4) negative binomials. */
+typedef enum { SMX_LABEL_NB = 0, SMX_LABEL_ONEHOT = 1, SMX_LABEL_MIXNB = 2 } smx_label_likelihood;
 typedef enum { SMX_ACT_RELU = 0, SMX_ACT_LINEAR = 1 } smx_activation;
 
 /* Constructor arguments of SingleCellModel / SCVI / SISUA / DeepCountAutoencoder
@@ -59,6 +61,7 @@ typedef struct {
   int32_t n_dec, dec_units[SMX_MAX_LAYERS];
   int32_t n_encl, encl_units[SMX_MAX_LAYERS];   /* scvi library encoder */
   int32_t n_labels, label_dim[SMX_MAX_LABELS], label_llk[SMX_MAX_LABELS];
+  int32_t label_components[SMX_MAX_LABELS];   /* SMX_LABEL_MIXNB: mixture components (MISA n_components, vae.py:77) */
   int32_t batchnorm;                   /* NetConf.batchnorm */
   int32_t log_norm;                    /* single_cell_model.py:82 */
   int32_t latent_activation;           /* dca only */
@@ -182,7 +185,8 @@ int smx_eval_step(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metri
  * l_mean/l_scale/l_sample [batch] (scvi); x_params [k,batch,G] planes in
  * likelihood order (nb/zinb: log total_count, logits, gate logits;
  * nbd/zinbd: mean, dispersion, gate logits -- already activated);
- * y_params[j] [batch, ky*P_j] raw head outputs. */
+ * y_params[j] [batch, ky*P_j] raw head outputs (ky = 2 NB: log total_count | logits; 1 one-hot: logits; 3 C mixture of
+ * C NB: C mixture logits | C log total_counts | C logits, each P_j wide). */
 int smx_forward(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library,
                 int32_t batch, int32_t sample_index, int32_t training, float* z_mean, float* z_scale,
                 float* z_sample, float* l_mean, float* l_scale, float* l_sample, float* x_params,

@@ -52,7 +52,13 @@ STREAM_EPS_Z = 64
 STREAM_EPS_L = 65
 
 LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
-LABEL_LIKELIHOODS = ("nb", "onehot")
+LABEL_LIKELIHOODS = ("nb", "onehot", "mixnb2", "mixnb3", "mixnb4")   # mixnbC: MISA's C-component mixture of NB per label
+
+
+def label_planes(llk: str) -> int:
+  """Raw head outputs per label dimension: 'nb' (log total_count, logits) 2; 'onehot' 1; 'mixnbC' 3 C -- C mixture
+  logits, then C log total_counts, then C logits (component-major planes of width P)."""
+  return 2 if llk == "nb" else 1 if llk == "onehot" else 3 * int(llk[5:])
 
 
 def n_params_per_gene(likelihood: str) -> int:
@@ -67,14 +73,14 @@ class Spec:
   """Configuration of one model; mirrors the ctor surface of
   SingleCellModel / SCVI / SISUA / DeepCountAutoencoder
   (single_cell_model.py:74-97, scvi.py:33-48, vae.py:40-44, dca.py:16-28)."""
-  model: str = "vae"                  # 'vae' | 'dca' | 'scvi' | 'sisua'
+  model: str = "vae"                  # 'vae' | 'dca' | 'scvi' | 'sisua' (MISA = sisua with 'mixnbC' label heads)
   n_genes: int = 0
   likelihood: str = "zinb"
   enc_units: Tuple[int, ...] = (64, 64)
   dec_units: Tuple[int, ...] = (64, 64)
   latent_dim: int = 10
   encl_units: Tuple[int, ...] = (64,)     # scvi library encoder (scvi.py:41-44)
-  labels: Tuple[Tuple[int, str], ...] = ()  # ((dim, 'nb'|'onehot'), ...)
+  labels: Tuple[Tuple[int, str], ...] = ()  # ((dim, 'nb'|'onehot'|'mixnbC'), ...)
   batchnorm: bool = True
   dropout_enc: float = 0.1
   dropout_dec: float = 0.1
@@ -151,7 +157,7 @@ def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
     out.append(("out/W", (hd, spec.k * G)))
     out.append(("out/b", (spec.k * G,)))
   for j, (P, llk) in enumerate(spec.labels):
-    ky = 2 if llk == "nb" else 1
+    ky = label_planes(llk)
     out.append((f"lab{j}/W", (hd, ky * P)))
     out.append((f"lab{j}/b", (ky * P,)))
   return out
@@ -358,13 +364,30 @@ def count_llk(x, p: Sequence[np.ndarray], likelihood: str, direct: bool = False)
 
 
 def label_llk(y, raw, llk_kind):
-  """Per-cell label log-likelihood and gradient wrt the head's raw output.
-  'nb': raw = [a | l], ADT levels y real-valued (configs/base.yaml:38-40);
-  'onehot': raw = logits, y one-hot (configs/base.yaml:41-43)."""
+  """Per-cell log-likelihood of one label head and its gradient wrt the raw head outputs.
+  'nb' (ADT counts, configs/base.yaml:38-40), 'onehot' (cell types, :41-43), 'mixnbC' (MISA, sisua/models/vae.py:47-98:
+  every label dimension is a C-component mixture of negative binomials, independent across dimensions --
+  [3P-recall] odin's mixture-NB layer: log p(y_p) = logsumexp_c(log softmax(a)_pc + log NB(y_p; exp(r_pc), l_pc)))."""
   if llk_kind == "nb":
-    P = y.shape[1]
+    P = raw.shape[1] // 2
     ell, (da, dl) = count_llk(y, [raw[:, :P], raw[:, P:]], "nb")
     return ell.sum(1), np.concatenate([da, dl], axis=1)
+  if llk_kind.startswith("mixnb"):
+    C = int(llk_kind[5:])
+    P = raw.shape[1] // (3 * C)
+    a = np.stack([raw[:, c * P:(c + 1) * P] for c in range(C)], 0)                      # [C, B, P] mixture logits
+    parts = [count_llk(y, [raw[:, (C + c) * P:(C + c + 1) * P], raw[:, (2 * C + c) * P:(2 * C + c + 1) * P]], "nb") for c in range(C)]
+    ell = np.stack([pt[0] for pt in parts], 0)
+    am = a.max(0)
+    log_pi = a - (am + np.log(np.exp(a - am).sum(0)))
+    joint = log_pi + ell
+    jm = joint.max(0)
+    llk_p = jm + np.log(np.exp(joint - jm).sum(0))
+    resp = np.exp(joint - llk_p)
+    d_a = [resp[c] - np.exp(log_pi[c]) for c in range(C)]
+    d_r = [resp[c] * parts[c][1][0] for c in range(C)]
+    d_l = [resp[c] * parts[c][1][1] for c in range(C)]
+    return llk_p.sum(1), np.concatenate(d_a + d_r + d_l, axis=1)
   m = raw.max(1, keepdims=True)
   lse = m + np.log(np.exp(raw - m).sum(1, keepdims=True))
   logp = raw - lse

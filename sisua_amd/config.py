@@ -16,6 +16,12 @@ import numpy as np
 LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
 
 
+def label_planes(llk: str) -> int:
+  """Raw head outputs per label dimension: 'nb' 2 (log total_count, logits), 'onehot' 1, 'mixnbC' 3 C (C mixture
+  logits, C log total_counts, C logits: MISA's mixture-of-NB labels, sisua/models/vae.py:47-98)."""
+  return 2 if llk == "nb" else 1 if llk == "onehot" else 3 * int(llk[5:])
+
+
 @dataclass
 class RVmeta:
   """Random-variable description: RVmeta(event_shape, posterior, projection, name)
@@ -136,7 +142,7 @@ def manifest(cfg: ModelConfig) -> List[Tuple[str, Tuple[int, ...]]]:
   else:
     out += [("out/W", (hd, cfg.k * G)), ("out/b", (cfg.k * G,))]
   for j, (P, llk) in enumerate(cfg.labels):
-    ky = 2 if llk == "nb" else 1
+    ky = label_planes(llk)
     out += [(f"lab{j}/W", (hd, ky * P)), (f"lab{j}/b", (ky * P,))]
   return out
 

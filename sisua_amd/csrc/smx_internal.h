@@ -260,6 +260,7 @@ int launch_scvi_head_bwd(hipStream_t st, const ScviHeadArgs& a);
 
 struct LabelArgs {
   int kind = 0;                  // smx_label_likelihood
+  int C = 1;                     // mixture components (SMX_LABEL_MIXNB)
   const float* raw = nullptr; int ld = 0;          // [B][ky*Pp]
   const float* Y = nullptr; int ldy = 0;           // labels [rows][ldy]
   const int32_t* rows = nullptr;

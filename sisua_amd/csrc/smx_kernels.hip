@@ -1170,9 +1170,46 @@ __global__ __launch_bounds__(256) void label_loss_kernel(LabelArgs a) {
   float llk = 0.f;
   if (m == 0.f) {   // wave-uniform
     if (a.backward) {
-      const int width = (a.kind == SMX_LABEL_NB ? 2 : 1) * a.Pp;
+      const int width = (a.kind == SMX_LABEL_NB ? 2 : a.kind == SMX_LABEL_MIXNB ? 3 * a.C : 1) * a.Pp;
       for (int p = lane; p < width; p += 64) a.draw[(long)b * a.ld + p] = 0.f;
     }
+  } else if (a.kind == SMX_LABEL_MIXNB) {
+    // MISA: log p(y_p) = logsumexp_c(log softmax(mix)_c + log NB(y_p; exp(r_c), l_c)); planes: C mixture logits, C log
+    // total_counts, C logits.  Gradients: d mix_c = resp_c - pi_c, d (r_c, l_c) = resp_c * d NB_c.
+    const int C = a.C;
+    for (int p = lane; p < a.Pp; p += 64) {
+      float e[4], d0[4], d1[4], mx[4];
+      float am = -3.0e38f, jm = -3.0e38f;
+      const bool live = p < a.P;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        e[c] = 0.f; d0[c] = 0.f; d1[c] = 0.f; mx[c] = 0.f;
+        if (c < C && live) {
+          float d2;
+          mx[c] = raw[c * a.Pp + p];
+          count_elem<SMX_LLK_NB, 0>(y[p], raw[(C + c) * a.Pp + p], raw[(2 * C + c) * a.Pp + p], 0.f, e[c], d0[c], d1[c], d2);
+          am = fmaxf(am, mx[c]);
+          jm = fmaxf(jm, mx[c] + e[c]);
+        }
+      }
+      float sa = 0.f, sj = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < C && live) { sa += expf(mx[c] - am); sj += expf(mx[c] + e[c] - jm); }
+      const float lse_a = am + logf(sa), lse_j = jm + logf(sj);
+      if (live) llk += lse_j - lse_a - lgammaf(y[p] + 1.f);
+      if (a.backward) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < C) {
+            const float resp = live ? expf(mx[c] + e[c] - lse_j) : 0.f, pi = live ? expf(mx[c] - lse_a) : 0.f;
+            a.draw[(long)b * a.ld + c * a.Pp + p] = (resp - pi) * gs;
+            a.draw[(long)b * a.ld + (C + c) * a.Pp + p] = resp * d0[c] * gs;
+            a.draw[(long)b * a.ld + (2 * C + c) * a.Pp + p] = resp * d1[c] * gs;
+          }
+      }
+    }
+    llk = wave_sum(llk);
   } else if (a.kind == SMX_LABEL_NB) {
     for (int p = lane; p < a.Pp; p += 64) {
       float d0 = 0.f, d1 = 0.f;

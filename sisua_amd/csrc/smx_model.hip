@@ -936,7 +936,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   for (int j = 0; j < c.n_labels; ++j) {
     const TensorInfo& tw = m->tensors[m->t_labW[j]];
     LabelArgs lb;
-    lb.kind = c.label_llk[j]; lb.raw = m->laby_raw[j]; lb.ld = tw.ld; lb.Y = m->Y[j]; lb.ldy = m->lab_Pp[j];
+    lb.kind = c.label_llk[j]; lb.C = c.label_components[j]; lb.raw = m->laby_raw[j]; lb.ld = tw.ld; lb.Y = m->Y[j]; lb.ldy = m->lab_Pp[j];
     lb.rows = ps.rows; lb.mask = m->mask; lb.B = ps.B; lb.P = c.label_dim[j]; lb.Pp = m->lab_Pp[j];
     lb.grad_scale = -c.alpha * inv_gb; lb.draw = m->laby_draw[j]; lb.llk = m->llk_y; lb.add = (j > 0);
     lb.backward = backward;
@@ -1492,7 +1492,9 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   }
   for (int j = 0; j < cfg->n_labels; ++j) {
     SMX_REQUIRE(cfg->label_dim[j] > 0, "label_dim must be > 0");
-    m->lab_ky[j] = cfg->label_llk[j] == SMX_LABEL_NB ? 2 : 1;
+    SMX_REQUIRE(cfg->label_llk[j] >= SMX_LABEL_NB && cfg->label_llk[j] <= SMX_LABEL_MIXNB, "unknown label likelihood");
+    if (cfg->label_llk[j] == SMX_LABEL_MIXNB) SMX_REQUIRE(cfg->label_components[j] >= 2 && cfg->label_components[j] <= 4, "mixture label heads have 2..4 components");
+    m->lab_ky[j] = cfg->label_llk[j] == SMX_LABEL_NB ? 2 : cfg->label_llk[j] == SMX_LABEL_ONEHOT ? 1 : 3 * cfg->label_components[j];
     m->lab_Pp[j] = round_up(cfg->label_dim[j], 32);
     m->t_labW[j] = add_tensor(m, "lab" + std::to_string(j) + "/W", hd, m->lab_ky[j] * cfg->label_dim[j], m->lab_ky[j], false);
     m->t_labb[j] = add_tensor(m, "lab" + std::to_string(j) + "/b", 1, m->lab_ky[j] * cfg->label_dim[j], m->lab_ky[j], true);

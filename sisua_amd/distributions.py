@@ -243,6 +243,45 @@ class OneHotCategorical(Distribution):
     return np.eye(p.shape[-1], dtype=np.float32)[idx]
 
 
+class MixtureNegativeBinomial(Distribution):
+  """Per-dimension mixture of C negative binomials (MISA's label heads, sisua/models/vae.py:47-98; TFP
+  MixtureSameFamily(Categorical(logits), NegativeBinomial) semantics).  Parameters [..., C, P]: mixture logits, total
+  counts, logits; batch shape [..., P]."""
+
+  def __init__(self, mix_logits, total_count, logits, name="MixtureNegativeBinomial"):
+    self.mix_logits = np.asarray(mix_logits, np.float64)
+    self.components = NegativeBinomial(total_count, logits)
+    self.name = name
+
+  def _params(self):
+    return [self.mix_logits[..., 0, :]]
+
+  def _log_pi(self):
+    m = self.mix_logits.max(-2, keepdims=True)
+    return self.mix_logits - (m + np.log(np.exp(self.mix_logits - m).sum(-2, keepdims=True)))
+
+  def mean(self):
+    return (np.exp(self._log_pi()) * self.components.mean()).sum(-2)
+
+  def variance(self):   # law of total variance over the component index
+    pi, mc = np.exp(self._log_pi()), self.components.mean()
+    mean = (pi * mc).sum(-2, keepdims=True)
+    return (pi * (self.components.variance() + (mc - mean) ** 2)).sum(-2)
+
+  def log_prob(self, x):
+    j = self._log_pi() + self.components.log_prob(np.asarray(x, np.float64)[..., None, :])
+    m = j.max(-2, keepdims=True)
+    return (m + np.log(np.exp(j - m).sum(-2, keepdims=True)))[..., 0, :]
+
+  def sample(self, sample_shape=(), seed=None):
+    rng = np.random.default_rng(seed)
+    comp = self.components.sample(sample_shape, seed=rng.integers(1 << 31))          # [S.., ..., C, P]
+    pi = np.broadcast_to(np.exp(self._log_pi()), comp.shape)
+    u = rng.uniform(size=comp.shape[:-2] + comp.shape[-1:])[..., None, :]
+    pick = (np.cumsum(pi, axis=-2) < u).sum(-2, keepdims=True).clip(0, comp.shape[-2] - 1)
+    return np.take_along_axis(comp, pick, axis=-2)[..., 0, :]
+
+
 class Independent(Distribution):
   """Reinterprets the last `reinterpreted_batch_ndims` batch axes as event axes."""
 
@@ -306,6 +345,9 @@ def concat_distributions(dists: Sequence[Distribution], axis: int = 0, name: Opt
     return NegativeBinomialDisp(_cat([d.loc for d in dists], axis), _cat([d.disp for d in dists], axis), name=nm)
   if isinstance(d0, OneHotCategorical):
     return OneHotCategorical(_cat([d.logits for d in dists], axis), name=nm)
+  if isinstance(d0, MixtureNegativeBinomial):   # parameters [..., C, P]: the batch axes are the leading ones
+    return MixtureNegativeBinomial(_cat([d.mix_logits for d in dists], axis), _cat([d.components.total_count for d in dists], axis),
+                                   _cat([d.components.logits for d in dists], axis), name=nm)
   raise TypeError(f"cannot concatenate {type(d0)}")
 
 

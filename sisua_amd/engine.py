@@ -13,7 +13,7 @@ import numpy as np
 
 from sisua_amd import _hip
 from sisua_amd._hip import SmxError, check, smx_config, smx_metrics
-from sisua_amd.config import ModelConfig, init_params, manifest
+from sisua_amd.config import ModelConfig, init_params, label_planes, manifest
 
 STREAM_INPUT_DROPOUT = 0
 STREAM_ENC_DROPOUT = 16
@@ -52,7 +52,8 @@ def make_smx_config(cfg: ModelConfig, max_batch: int) -> smx_config:
   c.n_labels = len(cfg.labels)
   for j, (P, llk) in enumerate(cfg.labels):
     c.label_dim[j] = int(P)
-    c.label_llk[j] = _hip.LABEL_LIKELIHOODS[llk]
+    c.label_llk[j] = _hip.LABEL_LIKELIHOODS["mixnb" if llk.startswith("mixnb") else llk]
+    c.label_components[j] = int(llk[5:]) if llk.startswith("mixnb") else 1
   c.batchnorm, c.log_norm = int(cfg.batchnorm), int(cfg.log_norm)
   c.latent_activation = _hip.ACTIVATIONS[cfg.latent_activation]
   c.dropout_enc, c.dropout_dec, c.input_dropout = cfg.dropout_enc, cfg.dropout_dec, cfg.input_dropout
@@ -226,7 +227,7 @@ class Engine:
       out.update(l_mean=np.empty((B,), np.float32), l_scale=np.empty((B,), np.float32), l_sample=np.empty((B,), np.float32))
     if want_x_params:
       out["x_params"] = np.empty((k, B, G), np.float32)
-    ys = [np.empty((B, (2 if llk == "nb" else 1) * P), np.float32) for P, llk in cfg.labels]
+    ys = [np.empty((B, label_planes(llk) * P), np.float32) for P, llk in cfg.labels]
     yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
     check(self.lib.smx_forward(self._h, idp, xp, lp, B, int(sample_index), int(training), _fp(out["z_mean"]),
                                _fp(out.get("z_scale")), _fp(out["z_sample"]), _fp(out.get("l_mean")),
@@ -253,7 +254,7 @@ class Engine:
     if cfg.model == "scvi":
       out.update(l_mean=np.empty((B,), np.float32), l_scale=np.empty((B,), np.float32), l_sample=np.empty((S, B), np.float32))
     out["x_params"] = np.empty((S, k, B, G), np.float32)
-    ys = [np.empty((S, B, (2 if llk == "nb" else 1) * P), np.float32) for P, llk in cfg.labels]
+    ys = [np.empty((S, B, label_planes(llk) * P), np.float32) for P, llk in cfg.labels]
     yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
     check(self.lib.smx_forward_samples(self._h, idp, xp, lp, B, S, _fp(out["z_mean"]), _fp(out.get("z_scale")),
                                        _fp(out["z_sample"]), _fp(out.get("l_mean")), _fp(out.get("l_scale")),
@@ -270,7 +271,7 @@ class Engine:
       raise ValueError(f"z must be [batch, {cfg.latent_dim}]")
     la = None if l is None else _f32(np.reshape(l, (B,)))
     xp = np.empty((cfg.k, B, cfg.n_genes), np.float32)
-    ys = [np.empty((B, (2 if llk == "nb" else 1) * P), np.float32) for P, llk in cfg.labels]
+    ys = [np.empty((B, label_planes(llk) * P), np.float32) for P, llk in cfg.labels]
     yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
     check(self.lib.smx_decode(self._h, _fp(za), _fp(la), B, _fp(xp), yptrs))
     return dict(x_params=xp, y_params=ys)

@@ -25,7 +25,7 @@ from sisua_amd.config import ModelConfig, NetConf, RVmeta, init_params
 from sisua_amd.data import BatchDataset, SingleCellOMIC, library_matrix
 from sisua_amd.engine import Engine
 
-__all__ = ["SingleCellModel", "VAE", "SISUA", "SCVI", "DeepCountAutoencoder", "NetConf", "RVmeta", "get_model",
+__all__ = ["SingleCellModel", "VAE", "SISUA", "MISA", "SCVI", "DeepCountAutoencoder", "NetConf", "RVmeta", "get_model",
            "get_all_models", "load_model"]
 
 _OMIC_ORDER = ["transcriptomic", "proteomic", "celltype", "disease", "progenitor", "chromatin"]
@@ -133,8 +133,15 @@ class SingleCellModel:
         labels.append((rv.event_shape, "nb"))
       elif rv.posterior in ("onehot", "categorical"):
         labels.append((rv.event_shape, "onehot"))
+      elif rv.posterior in ("mixnb", "mixnbd"):     # MISA (vae.py:47-98): mixture of negative binomials per label dimension
+        C = int(rv.kwargs.get("n_components", 2))
+        if not 2 <= C <= 4:
+          raise ValueError(f"mixture label heads are built for 2..4 components, given: {C}")
+        if rv.kwargs.get("zero_inflated", False):
+          raise ValueError("zero-inflated mixture label heads are not built")
+        labels.append((rv.event_shape, f"mixnb{C}"))
       else:
-        raise ValueError(f"label posterior '{rv.posterior}' is not built (supported: 'nb', 'onehot')")
+        raise ValueError(f"label posterior '{rv.posterior}' is not built (supported: 'nb', 'onehot', 'mixnb')")
     encl = self._encoder[1].units if len(self._encoder) > 1 else (64,)
     return ModelConfig(model=self._kind, n_genes=self._outputs[0].event_shape, likelihood=self._outputs[0].posterior,
                        enc_units=tuple(enc.units), dec_units=tuple(self._decoder.units),
@@ -436,6 +443,10 @@ class SingleCellModel:
       nm = self._labels[j].name or f"label{j}"
       if kind == "nb":
         outs.append(D.Independent(D.NegativeBinomial(np.exp(raw[..., :P]), raw[..., P:]), 1, name=nm))
+      elif kind.startswith("mixnb"):
+        C = int(kind[5:])
+        pl = np.reshape(raw, raw.shape[:-1] + (3 * C, P))     # planes: C mixture logits | C log total_counts | C logits
+        outs.append(D.Independent(D.MixtureNegativeBinomial(pl[..., :C, :], np.exp(pl[..., C:2 * C, :]), pl[..., 2 * C:, :]), 1, name=nm))
       else:
         outs.append(D.OneHotCategorical(raw, name=nm))
     return outs[0] if len(outs) == 1 else tuple(outs)
@@ -658,6 +669,30 @@ class SISUA(SingleCellModel):
   def __init__(self, outputs, labels, **kwargs):
     super().__init__(outputs=outputs, labels=labels, **kwargs)
     self._n_inputs = 1
+
+
+class MISA(SISUA):
+  r"""MIxture of labels for Semi-supervised Autoencoder (sisua/models/vae.py:47-98): SISUA whose label heads are
+  mixture distributions.  Discrete labels (ADT counts) become `n_components`-component mixtures of negative
+  binomials per label dimension ('mixnb'); other label posteriors are converted with the reference's warning.
+  Built: 'mixnb' with 2..4 components, not zero-inflated; continuous mixtures ('mixgaussian', 'mixtril') are not."""
+  _kind = "sisua"
+
+  def __init__(self, outputs, labels, n_components=2, zero_inflated=False, **kwargs):
+    labs = [l.copy() for l in _flatten(labels)]
+    n_components, zero_inflated = int(n_components), bool(zero_inflated)
+    for rv in labs:
+      if rv.posterior in ("nb", "nbd", "zinb", "zinbd", "onehot", "categorical", "bernoulli", "poisson") or rv.posterior[:5] == "mixnb":
+        if rv.posterior[:3] != "mix":
+          warnings.warn(f"MISA only support labels is a mixture distribution , given: {rv.posterior}")
+          rv.posterior = "mixnb"
+        rv.kwargs.setdefault("zero_inflated", zero_inflated)
+      elif rv.posterior[:3] not in ("mix", "mdn"):
+        warnings.warn(f"MISA only support labels is a mixture distribution , given: {rv.posterior}")
+        rv.posterior = "mixgaussian"
+      rv.kwargs.setdefault("n_components", n_components)
+    super().__init__(outputs=outputs, labels=labs, **kwargs)
+    self.init_args = dict(outputs=outputs, labels=labels, n_components=n_components, zero_inflated=zero_inflated, **kwargs)
 
 
 class SCVI(SingleCellModel):

@@ -31,8 +31,8 @@ def test_header_and_binding_agree(lib):
 def test_config_struct_layout_matches_header():
   import ctypes as C
   from sisua_amd import _hip
-  # 5 + 3*(1+8) + (1+4+4) + 3 ints, 13 floats, 1 int, (pad), 1 u64
-  n_int = 5 + 3 * 9 + 9 + 3
+  # 5 + 3*(1+8) + (1+4+4+4) + 3 ints, 13 floats, 1 int, (pad), 1 u64
+  n_int = 5 + 3 * 9 + 13 + 3
   assert C.sizeof(_hip.smx_config) == (n_int + 13 + 1) * 4 + (4 if (n_int + 14) % 2 else 0) + 8
   assert C.sizeof(_hip.smx_metrics) == 32
 

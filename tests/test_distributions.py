@@ -74,3 +74,25 @@ def test_count_distribution_factory():
   assert np.allclose(d2.distribution.loc, np.log(2.0)) and np.allclose(d2.mean(), np.log(2.0))
   d3 = D.count_distribution("zinbd", [np.full((2, 3), 5.0), np.full((2, 3), 2.0), p[2]], "x", activated=True)
   assert np.allclose(d3.distribution.count_distribution.loc, 5.0)
+
+
+def test_mixture_negative_binomial_surface():
+  """MISA label heads: log_prob against torch MixtureSameFamily, moments against a large sample."""
+  import torch
+  import torch.distributions as td
+  from sisua_amd import distributions as D
+  rng = np.random.default_rng(0)
+  B, C, P = 4, 3, 5
+  mix, r, l = rng.normal(size=(B, C, P)), np.exp(rng.normal(size=(B, C, P))), rng.normal(size=(B, C, P))
+  d = D.MixtureNegativeBinomial(mix, r, l)
+  assert d.batch_shape == (B, P)
+  y = np.floor(rng.uniform(0, 9, size=(B, P)))
+  ref = td.MixtureSameFamily(td.Categorical(logits=torch.tensor(mix).permute(0, 2, 1)),
+                             td.NegativeBinomial(total_count=torch.tensor(r).permute(0, 2, 1), logits=torch.tensor(l).permute(0, 2, 1)))
+  assert np.allclose(d.log_prob(y), ref.log_prob(torch.tensor(y)).numpy(), rtol=1e-10)
+  assert np.allclose(d.mean(), ref.mean.numpy(), rtol=1e-10) and np.allclose(d.variance(), ref.variance.numpy(), rtol=1e-10)
+  s = d.sample(20000, seed=1)
+  assert s.shape == (20000, B, P)
+  assert np.allclose(s.mean(0), d.mean(), rtol=0.15, atol=0.05)
+  ind = D.Independent(d, 1, name="proteomic")
+  assert ind.event_shape == (P,) and ind.batch_shape == (B,) and np.allclose(ind.log_prob(y), d.log_prob(y).sum(-1))

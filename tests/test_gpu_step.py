@@ -31,6 +31,8 @@ CASES = {
                        latent_activation="linear"),
     "sisua": dict(model="sisua", n_genes=180, likelihood="zinb", enc_units=(64,), dec_units=(64,), latent_dim=9,
                   labels=((12, "nb"), (7, "onehot"))),
+    "misa": dict(model="sisua", n_genes=140, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=8,
+                 labels=((12, "mixnb2"), (5, "mixnb3"))),
     "scvi_zinbd": dict(model="scvi", n_genes=160, likelihood="zinbd", enc_units=(48,), dec_units=(48,), latent_dim=6,
                        encl_units=(16,)),
     "scvi_nbd": dict(model="scvi", n_genes=96, likelihood="nbd", enc_units=(32,), dec_units=(32,), latent_dim=4,
@@ -167,7 +169,7 @@ def test_injected_noise_matches_oracle(Engine, name):
   e.close()
 
 
-@pytest.mark.parametrize("name,graph", [("vae_zinb", False), ("vae_zinb", True), ("sisua", True), ("scvi_zinbd", False)])
+@pytest.mark.parametrize("name,graph", [("vae_zinb", False), ("vae_zinb", True), ("sisua", True), ("scvi_zinbd", False), ("misa", False)])
 def test_trajectory_matches_oracle(Engine, name, graph):
   """50-step seeded trajectory: ELBO per step within 1e-4 relative."""
   kw = CASES[name]

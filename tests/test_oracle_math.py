@@ -97,6 +97,29 @@ def test_label_llk_onehot_and_nb():
     assert np.isclose(d[idx], fd, rtol=1e-5, atol=1e-7)
 
 
+def test_label_llk_mixture_nb_matches_torch_mixture_same_family():
+  """MISA's label head (vae.py:47-98): per-dimension mixture of C negative binomials == torch
+  MixtureSameFamily(Categorical(logits), NegativeBinomial(total_count, logits)); gradients by central differences."""
+  rng = np.random.default_rng(4)
+  B, P = 7, 5
+  for C in (2, 3):
+    y = np.floor(rng.uniform(0, 12, size=(B, P)))
+    raw = rng.normal(size=(B, 3 * C * P))
+    ll, d = so.label_llk(y, raw, f"mixnb{C}")
+    pl = torch.tensor(raw).reshape(B, 3 * C, P)
+    mix = td.Categorical(logits=pl[:, :C].permute(0, 2, 1))                                   # [B, P] batch, C categories
+    comp = td.NegativeBinomial(total_count=torch.exp(pl[:, C:2 * C].permute(0, 2, 1)), logits=pl[:, 2 * C:].permute(0, 2, 1))
+    ref = td.MixtureSameFamily(mix, comp).log_prob(torch.tensor(y)).sum(1)
+    assert np.allclose(ll, ref.numpy(), rtol=1e-12)
+    h = 1e-6
+    for idx in [(0, 0), (3, C * P + 2), (6, 3 * C * P - 1), (2, 2 * C * P + 1)]:
+      rp, rm = raw.copy(), raw.copy()
+      rp[idx] += h; rm[idx] -= h
+      fd = (so.label_llk(y, rp, f"mixnb{C}")[0].sum() - so.label_llk(y, rm, f"mixnb{C}")[0].sum()) / (2 * h)
+      assert np.isclose(d[idx], fd, rtol=1e-5, atol=1e-7), (C, idx)
+    assert so.label_planes(f"mixnb{C}") == 3 * C
+
+
 # ---------------------------------------------------------------------------
 # whole-step gradient check by central differences, every model family
 # ---------------------------------------------------------------------------
@@ -122,7 +145,8 @@ def _toy(model, lk, labels=(), bn=True, **kw):
 
 CASES = [("vae", "zinb", (), True), ("vae", "nb", (), False), ("vae", "zinbd", (), True),
          ("vae", "nbd", (), True), ("dca", "zinb", (), True), ("scvi", "zinbd", (), True),
-         ("scvi", "nbd", (), False), ("sisua", "zinb", ((4, "nb"), (3, "onehot")), True)]
+         ("scvi", "nbd", (), False), ("sisua", "zinb", ((4, "nb"), (3, "onehot")), True),
+         ("sisua", "zinb", ((4, "mixnb2"), (3, "mixnb3")), True)]   # MISA
 
 
 @pytest.mark.parametrize("model,lk,labels,bn", CASES)

@@ -100,6 +100,12 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
     if kind == "nb":
       # protein levels are real-valued (dataset.html:187): the same density formula, support check off
       llk_y = llk_y + td.NegativeBinomial(total_count=torch.exp(ry[:, :Pj]), logits=ry[:, Pj:], validate_args=False).log_prob(yj).sum(1)
+    elif kind.startswith("mixnb"):   # MISA: MixtureSameFamily over C negative binomials per label dimension
+      C = int(kind[5:])
+      pl = ry.reshape(B, 3 * C, Pj)
+      comp = td.NegativeBinomial(total_count=torch.exp(pl[:, C:2 * C].permute(0, 2, 1)), logits=pl[:, 2 * C:].permute(0, 2, 1),
+                                 validate_args=False)
+      llk_y = llk_y + td.MixtureSameFamily(td.Categorical(logits=pl[:, :C].permute(0, 2, 1)), comp, validate_args=False).log_prob(yj).sum(1)
     else:
       llk_y = llk_y + td.OneHotCategorical(logits=ry).log_prob(yj)
   m = torch.zeros(B) if mask is None else torch.as_tensor(np.asarray(mask, np.float64))
@@ -133,6 +139,8 @@ CASES = {
     "dca_linear": dict(model="dca", n_genes=30, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=4, latent_activation="linear"),
     "sisua": dict(model="sisua", n_genes=48, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5,
                   labels=((7, "nb"), (4, "onehot")), alpha=10.0),
+    "misa": dict(model="sisua", n_genes=40, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5,
+                 labels=((6, "mixnb2"), (3, "mixnb3")), alpha=10.0),
     "scvi_zinbd": dict(model="scvi", n_genes=52, likelihood="zinbd", enc_units=(16,), dec_units=(16,), latent_dim=4, encl_units=(8,)),
     "scvi_nbd": dict(model="scvi", n_genes=36, likelihood="nbd", enc_units=(12,), dec_units=(12,), latent_dim=3, encl_units=(6,),
                      batchnorm=False),
