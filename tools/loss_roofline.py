@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Loss-kernel roofline away from the launch-latency regime: the same count_loss_kernel<ZINB> fwd+bwd
+"""Likelihood roofline away from the launch-latency regime: the standalone count_loss_kernel<ZINB> fwd+bwd and the
+likelihood-attributable time of the fused output head (fused kernel - product only), both
 at the per-GPU size of BASELINE.json configs[4] (G = 20000, 128 cells per GPU) and at larger batches.
 HIP events on the model's stream (smx_timing_*), synthetic log-normal counts thinned to ~93 % zeros."""
 import json
@@ -27,18 +28,28 @@ for G, B in SIZES:
   e.upload(x)
   order = (np.arange(40 * B) % n).astype(np.int32)
   e.train_steps(order[: 5 * B], 5, B, graph=False)
-  e.timing_enable("null")     # event pair around nothing
-  e.train_steps(order, 40, B, graph=False)
-  ms0, cnt0 = e.timing_read()
-  e.timing_enable("loss")     # LOSS_REPEAT back-to-back launches per event pair (bench.py)
-  e.train_steps(order, 40, B, graph=False)
-  ms, cnt = e.timing_read()
+
+  def timed(label):
+    e.timing_enable(label)
+    e.train_steps(order, 40, B, graph=False)
+    ms, cnt = e.timing_read()
+    return 1e3 * ms / max(cnt, 1)
+
+  null = timed("null")                       # event pair around nothing
+  fused, prod = timed("out_head"), timed("out_head_product")   # 8 back-to-back launches per event pair (bench.py)
+  e.set_flag("head_loss", False)
+  alone = timed("loss")
+  e.set_flag("head_loss", True)
   e.timing_enable(None)
   bytes_per_launch = e.loss_bytes_per_cell() * B
-  us = (1e3 * ms / cnt - 1e3 * ms0 / cnt0) / 8
-  gbs = bytes_per_launch / (us * 1e-6) / 1e9
-  out.append(dict(G=G, B=B, bytes_per_launch=bytes_per_launch, avg_launch_us=round(us, 2), achieved_GBs=round(gbs, 1),
-                  frac_of_8TBs=round(gbs / HBM_PEAK, 4)))
-  print(out[-1], flush=True)
+  us_alone, us_attr = (alone - null) / 8, (fused - prod) / 8
+  row = dict(G=G, B=B, bytes_per_launch=bytes_per_launch,
+             standalone_us=round(us_alone, 2), standalone_GBs=round(bytes_per_launch / (us_alone * 1e-6) / 1e9, 1),
+             standalone_frac=round(bytes_per_launch / (us_alone * 1e-6) / 1e9 / HBM_PEAK, 4),
+             fused_kernel_us=round((fused - null) / 8, 2), product_only_us=round((prod - null) / 8, 2),
+             attributable_us=round(us_attr, 2), attributable_GBs=round(bytes_per_launch / (us_attr * 1e-6) / 1e9, 1),
+             attributable_frac=round(bytes_per_launch / (us_attr * 1e-6) / 1e9 / HBM_PEAK, 4))
+  out.append(row)
+  print(row, flush=True)
   e.close()
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "loss_roofline.json"), "w"), indent=1)

@@ -4,7 +4,7 @@
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r01}
+TAG=${1:-r02}
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O   # (gpurun merges into an existing gpurun_out/: remove stale trace dirs locally before copying)
 cd $R
@@ -14,5 +14,11 @@ python3 bench.py --steps 300 --warmup 30 > $O/bench.json 2> $O/bench.err
 ./tools/pmc_pass.sh > $O/pmc_summary.txt 2>&1
 cp gpurun_out/pmc/pmc_summary.json $O/ 2>/dev/null
 python3 tools/loss_roofline.py > $O/loss_roofline.txt 2>&1
+# MFMA utilisation of the product kernels (separate PMC pass + the stats above)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/mfma -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/mfma.err
+python3 tools/mfma_util.py $O/mfma $O/trace > $O/mfma_utilisation.txt 2>&1
+rm -rf $O/mfma
+python3 tools/divergence_event.py > $O/divergence_event.txt 2>&1
+TRAJ_STEPS=400 python3 tools/divergence_trace.py > $O/divergence_trace.txt 2>&1
 rm -rf $O/trace/*/*kernel_trace.csv   # keep the stats, drop the bulky trace
 ls -la $O

@@ -8,6 +8,6 @@ OUT=$R/gpurun_out/pmc
 rm -rf $OUT; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
   UBENCH_CALIB=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/calib_$c -- $R/tools/ubench > /dev/null 2>&1
-  SMX_LOSS_VEC=${SMX_LOSS_VEC:-1} rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/bench_$c -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_$c.json 2> $OUT/bench_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/bench_$c -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_$c.json 2> $OUT/bench_$c.err
 done
 python3 $R/tools/pmc_summary.py $OUT

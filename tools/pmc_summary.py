@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reduce the PMC passes of tools/pmc_pass.sh to per-launch HBM bytes of the loss kernel.
+"""Reduce the PMC passes of tools/pmc_pass.sh to per-launch HBM bytes of the likelihood kernels (fused, product-only, standalone).
 Counter unit and the gfx950 FETCH_SIZE correction are CALIBRATED on copy kernels of known size
 (64 MiB read + 64 MiB written, 16 B/lane and 4 B/lane) run in the same passes."""
 import csv
@@ -8,6 +8,10 @@ import json
 import sys
 
 out = sys.argv[1]
+# kernel families of the default bench command: the fused training kernel, its product-only timing variant, the
+# standalone likelihood kernel (eval / flag head_loss = 0), the head's backward products
+FAMILIES = {"fused": "out_head_loss_kernel<1, 0, 1", "product_only": "out_head_loss_kernel<1, 0, 0",
+            "standalone": "count_loss_kernel<1, 0, 1", "head_bwd": "out_head_bwd_kernel"}
 
 
 def counter_rows(d):
@@ -30,20 +34,30 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
   last16 = k16[0][-1] if k16 else None
   last4 = k4[0][-1] if k4 else None
   rows = counter_rows(f"{out}/bench_{c}")
-  vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == c and "count_loss_kernel" in r["Kernel_Name"]]
-  res[c] = dict(calib_16B_per_lane=last16, calib_4B_per_lane=last4, loss_kernel_mean=sum(vals) / max(len(vals), 1), n=len(vals))
+  fam = {}
+  for name, pat in FAMILIES.items():
+    vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == c and pat in r["Kernel_Name"]]
+    fam[name] = dict(mean=sum(vals) / max(len(vals), 1), n=len(vals))
+  res[c] = dict(calib_16B_per_lane=last16, calib_4B_per_lane=last4, kernels=fam)
 known = 64 * 1024 * 1024
-summary = {"raw": res}
+summary = {"raw": res, "hbm_bytes_per_launch": {}}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-  cal4 = res[c]["calib_4B_per_lane"]
+  cal4, cal16 = res[c]["calib_4B_per_lane"], res[c]["calib_16B_per_lane"]
   if cal4:
-    bytes_per_unit = known / cal4   # calibrated on the loss kernel's own access width (4 B/lane)
-    summary[c + "_bytes_per_unit_4B"] = bytes_per_unit
-    summary[c + "_loss_bytes"] = res[c]["loss_kernel_mean"] * bytes_per_unit
-  cal16 = res[c]["calib_16B_per_lane"]
+    summary[c + "_bytes_per_unit_4B"] = known / cal4    # calibrated on 4 B / lane accesses (what these kernels issue)
   if cal16:
     summary[c + "_bytes_per_unit_16B"] = known / cal16
-if "FETCH_SIZE_loss_bytes" in summary and "WRITE_SIZE_loss_bytes" in summary:
-  summary["loss_kernel_hbm_bytes_per_launch"] = summary["FETCH_SIZE_loss_bytes"] + summary["WRITE_SIZE_loss_bytes"]
+for name in FAMILIES:
+  tot, ok = 0.0, True
+  for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    u = summary.get(c + "_bytes_per_unit_4B")
+    k = res[c]["kernels"][name]
+    if not u or not k["n"]:
+      ok = False
+      break
+    summary["hbm_bytes_per_launch"][f"{name}:{c}"] = k["mean"] * u
+    tot += k["mean"] * u
+  if ok:
+    summary["hbm_bytes_per_launch"][name] = tot
 print(json.dumps(summary, indent=1))
 json.dump(summary, open(out + "/pmc_summary.json", "w"), indent=1)
