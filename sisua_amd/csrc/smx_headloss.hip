@@ -37,7 +37,7 @@ template <int LK, int U16, int EPI, int NW>
 __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) {
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
   constexpr int KS = 128 / NW, KH = KS / 2, RPW = 16 / NW;
-  __shared__ float red[NW * NP * 1024];
+  __shared__ float red[NW * 1024];   // ONE plane's NW partial tiles at a time (32 KB at 8 waves: two workgroups per CU)
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   // blocks b, b + 8, b + 16, ... share an XCD: give them the cell tiles of ONE gene tile
@@ -110,23 +110,23 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
     mfma_slab();
   }
 
-  // ---- the NW partial tiles meet in LDS; wave q finishes registers q RPW .. q RPW + RPW - 1 ---------------------
-#pragma unroll
-  for (int p = 0; p < NP; ++p)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[((q * NP + p) * 16 + r) * 64 + lane] = acc[p][r];
-  __syncthreads();
+  // ---- the NW partial tiles meet in LDS, plane by plane; wave q finishes registers q RPW .. q RPW + RPW - 1 ---------
   float v[NP][RPW];
 #pragma unroll
-  for (int p = 0; p < NP; ++p)
+  for (int p = 0; p < NP; ++p) {
+    if (p) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(q * 16 + r) * 64 + lane] = acc[p][r];
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
       const int r = q * RPW + j;
-      float t = red[((0 * NP + p) * 16 + r) * 64 + lane];
+      float t = red[(0 * 16 + r) * 64 + lane];
 #pragma unroll
-      for (int w = 1; w < NW; ++w) t += red[((w * NP + p) * 16 + r) * 64 + lane];
+      for (int w = 1; w < NW; ++w) t += red[(w * 16 + r) * 64 + lane];
       v[p][j] = t + bias[p];
     }
+  }
 
   // ---- likelihood + gradient on the tile: the RPW elements of a lane as interleaved straight-line chains ------------
   const bool live = col < a.G;

@@ -526,6 +526,9 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
   m->adam_early_pending = false;
   static const bool off = getenv("SMX_NO_ADAM_EARLY") != nullptr;
   if (off || dp_active(m) || !m->sq_slots || m->chunk_first_head >= m->n_chunks || getenv("SMX_NO_SQ_PARTIALS") != nullptr) return;
+  // riders use half of a 512-thread BatchNorm workgroup: fine while the heads' update is a few MB (C2: 22 MB, hidden
+  // under the launch), but at the 20 000-gene width it ran at 2.8 TB/s against 6.2 TB/s for the optimiser's own launch
+  if (m->n_chunks - m->chunk_first_head > 512) return;
   for (size_t t = (size_t)m->t_outW[0]; t < m->tensors.size(); ++t)   // head tensors are the last ones of the manifest
     if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) return;
   fill_adam_args(m, b.adam);
