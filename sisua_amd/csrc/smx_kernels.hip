@@ -428,7 +428,7 @@ static int bn_diag() { static const int v = getenv("SMX_BN_DIAG") ? atoi(getenv(
 
 bool bn_front_supported(int B, int Dp) {
   const int dq = Dp >> 2;
-  return B > 0 && B <= BN_RL * 4 && Dp >= 4 && Dp <= 64 && (Dp % 4) == 0 && (dq & (dq - 1)) == 0 && ((size_t)B * (Dp + 1) + (size_t)Dp * 8) * sizeof(float) <= 60 * 1024;
+  return B > 0 && B <= BN_RL * 4 && Dp >= 4 && Dp <= 64 && (Dp % 4) == 0 && (dq & (dq - 1)) == 0 && ((size_t)B * (Dp + 1) + (size_t)Dp * 8) * sizeof(float) <= 96 * 1024;
 }
 
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
@@ -441,6 +441,9 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
     }
     if (a.Hp % BN_COLS) { set_error("bn_act_fwd: bad shapes"); return SMX_ERR_INVALID; }
     const size_t lds = ((size_t)a.B * (a.lat.Dp + 1) + (size_t)a.lat.Dp * BN_COLS) * sizeof(float);
+    static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_fwd_kernel<4, 1>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+    if (lds > 64 * 1024 && !big_ok) { set_error("bn_act_fwd: cannot reserve the dynamic LDS of the latent front"); return SMX_ERR_HIP; }
     if (a.B <= BN_RL * 2) hipLaunchKernelGGL((bn_act_fwd_kernel<2, 1>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
     else hipLaunchKernelGGL((bn_act_fwd_kernel<4, 1>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
     SMX_HIP(hipGetLastError());
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
 }
 
 bool bn_bwd_front_supported(int B, int K) {
-  return B > 0 && B <= BN_RL * 4 && (K == 32 || K == 64) && ((size_t)B * (K + 1) + 8 * (K + 4)) * sizeof(float) <= 60 * 1024;
+  return B > 0 && B <= BN_RL * 4 && (K == 32 || K == 64) && ((size_t)B * (K + 1) + 8 * (K + 4)) * sizeof(float) <= 96 * 1024;
 }
 
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
@@ -600,6 +603,9 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
     }
     const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count;
     const size_t lds = ((size_t)a.B * (a.fK + 1) + 4 + (size_t)BN_COLS * (a.fK + 4)) * sizeof(float);
+    static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_bwd_kernel<4, 1>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+    if (lds > 64 * 1024 && !big_ok) { set_error("bn_act_bwd: cannot reserve the dynamic LDS of the gradient front"); return SMX_ERR_HIP; }
     if (a.B <= BN_RL * 2) hipLaunchKernelGGL((bn_act_bwd_kernel<2, 1>), dim3(grid), dim3(BN_THREADS), lds, st, a);
     else hipLaunchKernelGGL((bn_act_bwd_kernel<4, 1>), dim3(grid), dim3(BN_THREADS), lds, st, a);
     SMX_HIP(hipGetLastError());

@@ -293,7 +293,7 @@ struct smx_model {
   float* llk_y = nullptr;
   float* slab = nullptr; size_t slab_cap = 0; int max_feat_p = 0;
   // optimiser
-  OptChunk* chunks = nullptr; int n_chunks = 0; float* partial = nullptr; float* tensor_norm = nullptr;
+  OptChunk* chunks = nullptr; int n_chunks = 0; int chunks_floats = 4096; float* partial = nullptr; float* tensor_norm = nullptr;
   // noise injection
   std::map<int, Injected> injected; bool use_injected = false;
   // comm
@@ -528,7 +528,7 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
   if (off || dp_active(m) || !m->sq_slots || m->chunk_first_head >= m->n_chunks || getenv("SMX_NO_SQ_PARTIALS") != nullptr) return;
   // riders use half of a 512-thread BatchNorm workgroup: fine while the heads' update is a few MB (C2: 22 MB, hidden
   // under the launch), but at the 20 000-gene width it ran at 2.8 TB/s against 6.2 TB/s for the optimiser's own launch
-  if (m->n_chunks - m->chunk_first_head > 512) return;
+  if ((long)(m->n_chunks - m->chunk_first_head) * m->chunks_floats > 512L * 4096) return;
   for (size_t t = (size_t)m->t_outW[0]; t < m->tensors.size(); ++t)   // head tensors are the last ones of the manifest
     if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) return;
   fill_adam_args(m, b.adam);
@@ -1574,7 +1574,9 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   m->eps_ahead_ok = latent_head_fusable(m->enc.back().out_p, (m->stochastic ? 2 : 1) * m->Dp, m->Dp);
   // ---- optimiser chunk table ----
   std::vector<OptChunk> chunks;
-  const int CH = 4096;
+  // floats per optimiser workgroup (SMX_OPT_CHUNK = 1024 | 2048 | 4096 | 8192)
+  static const int ch_env = getenv("SMX_OPT_CHUNK") ? atoi(getenv("SMX_OPT_CHUNK")) : 0;
+  const int CH = (ch_env == 1024 || ch_env == 2048 || ch_env == 4096 || ch_env == 8192) ? ch_env : 4096;
   for (size_t t = 0; t < m->tensors.size(); ++t) {
     const TensorInfo& ti = m->tensors[t];
     const int first = (int)chunks.size();
@@ -1589,6 +1591,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     }
   }
   m->n_chunks = (int)chunks.size();
+  m->chunks_floats = CH;
   m->chunk_first_head = m->n_chunks;
   for (size_t i = 0; i < chunks.size(); ++i)
     if (chunks[i].tensor == m->t_outW[0]) { m->chunk_first_head = (int)i; break; }
