@@ -38,8 +38,10 @@ typedef enum {
 } smx_status;
 
 /* Model families: sisua/models/vae.py:15-16 (VAE), dca.py:13-28, scvi.py:20-171,
- * vae.py:19-44 (SISUA = VAE + label heads). */
-typedef enum { SMX_MODEL_VAE = 0, SMX_MODEL_DCA = 1, SMX_MODEL_SCVI = 2, SMX_MODEL_SISUA = 3 } smx_model_kind;
+ * vae.py:19-44 (SISUA = VAE + label heads; MISA = SISUA with mixture label heads, vae.py:47-98). */
+/* SMX_MODEL_SCALE: scale.py:13-49 (SCALE, Xiong et al. 2019): VAE whose prior over z is a trainable mixture of
+ * n_components diagonal Gaussians, KL term by one-sample Monte Carlo (`analytic=False`). */
+typedef enum { SMX_MODEL_VAE = 0, SMX_MODEL_DCA = 1, SMX_MODEL_SCVI = 2, SMX_MODEL_SISUA = 3, SMX_MODEL_SCALE = 4 } smx_model_kind;
 /* Count likelihoods selected by RVmeta.posterior (configs/base.yaml:32-40,
  * data/_single_cell_base.py:518-533). */
 typedef enum { SMX_LLK_NB = 0, SMX_LLK_ZINB = 1, SMX_LLK_NBD = 2, SMX_LLK_ZINBD = 3 } smx_likelihood;
@@ -62,6 +64,7 @@ typedef struct {
   int32_t n_encl, encl_units[SMX_MAX_LAYERS];   /* scvi library encoder */
   int32_t n_labels, label_dim[SMX_MAX_LABELS], label_llk[SMX_MAX_LABELS];
   int32_t label_components[SMX_MAX_LABELS];   /* SMX_LABEL_MIXNB: mixture components (MISA n_components, vae.py:77) */
+  int32_t n_components;                /* SMX_MODEL_SCALE: components of the mixture prior (scale.py:27), 1..32 */
   int32_t batchnorm;                   /* NetConf.batchnorm */
   int32_t log_norm;                    /* single_cell_model.py:82 */
   int32_t latent_activation;           /* dca only */

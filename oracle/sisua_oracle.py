@@ -73,7 +73,8 @@ class Spec:
   """Configuration of one model; mirrors the ctor surface of
   SingleCellModel / SCVI / SISUA / DeepCountAutoencoder
   (single_cell_model.py:74-97, scvi.py:33-48, vae.py:40-44, dca.py:16-28)."""
-  model: str = "vae"                  # 'vae' | 'dca' | 'scvi' | 'sisua' (MISA = sisua with 'mixnbC' label heads)
+  model: str = "vae"                  # 'vae' | 'dca' | 'scvi' | 'sisua' (MISA = sisua with 'mixnbC' label heads) | 'scale'
+  n_components: int = 10              # scale: components of the Gaussian-mixture prior (scale.py:27)
   n_genes: int = 0
   likelihood: str = "zinb"
   enc_units: Tuple[int, ...] = (64, 64)
@@ -100,7 +101,8 @@ class Spec:
   seed: int = 8
 
   def __post_init__(self):
-    assert self.model in ("vae", "dca", "scvi", "sisua"), self.model
+    assert self.model in ("vae", "dca", "scvi", "sisua", "scale"), self.model
+    assert 1 <= self.n_components <= 32
     assert self.likelihood in LIKELIHOODS, self.likelihood
     if self.model == "scvi":
       assert self.likelihood in ("nbd", "zinbd")  # scvi.py:50-52
@@ -142,6 +144,9 @@ def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
   h = mlp("enc", G, spec.enc_units)
   out.append(("lat/W", (h, 2 * D if spec.stochastic else D)))
   out.append(("lat/b", (2 * D if spec.stochastic else D,)))
+  if spec.model == "scale":   # trainable Gaussian-mixture prior over z (Xiong et al. 2019; scale.py:13-49)
+    C = spec.n_components
+    out += [("prior/logits", (C,)), ("prior/loc", (C, D)), ("prior/scale", (C, D))]
   if spec.model == "scvi":
     hl = mlp("encl", G, spec.encl_units)
     out.append(("latl/W", (hl, 2)))
@@ -186,8 +191,10 @@ def init_params(spec: Spec, seed: Optional[int] = None) -> Dict[str, np.ndarray]
       params[name] = rng.uniform(-limit, limit, size=shape).astype(np.float32).astype(np.float64)
     elif kind == "gamma":
       params[name] = np.ones(shape)
+    elif name == "prior/loc":   # the mixture must not start symmetric: component means spread over the unit box
+      params[name] = rng.uniform(-1.0, 1.0, size=shape).astype(np.float32).astype(np.float64)
     else:
-      params[name] = np.zeros(shape)
+      params[name] = np.zeros(shape)   # biases, mixture logits (uniform weights), raw prior scales (softplus1(0) = 1)
   return params
 
 
@@ -485,6 +492,20 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
     z = np.maximum(lat, 0.0) if spec.latent_activation == "relu" else lat
     kl = np.zeros(B)
   out.update(z_mean=mu, z_scale=sig, z=z)
+  scale_c = None
+  if spec.model == "scale":
+    # SCALE (sisua/models/scale.py:13-49: mixture latent, `analytic=False`): the KL term is a ONE-SAMPLE Monte-Carlo
+    # estimate log q(z|x) - log p(z) at the z that is decoded, with p(z) = sum_c softmax(a)_c N(z; m_c, diag s_c^2),
+    # s = softplus1(raw) -- the published model (Xiong et al. 2019); odin's mixture layer itself is not citable.
+    a, m_c, s_c = params["prior/logits"], params["prior/loc"], softplus1(params["prior/scale"])
+    log_pi = a - (a.max() + np.log(np.exp(a - a.max()).sum()))
+    dzm = (z[:, None, :] - m_c[None]) / s_c[None]                                   # [B, C, D]
+    comp = log_pi[None] + (-0.5 * dzm ** 2 - np.log(s_c)[None] - 0.5 * np.log(2 * np.pi)).sum(2)
+    cm = comp.max(1, keepdims=True)
+    log_p = (cm + np.log(np.exp(comp - cm).sum(1, keepdims=True)))[:, 0]
+    log_q = (-0.5 * eps ** 2 - np.log(sig) - 0.5 * np.log(2 * np.pi)).sum(1)
+    kl = log_q - log_p
+    scale_c = dict(resp=np.exp(comp - log_p[:, None]), log_pi=log_pi, dzm=dzm, s=s_c)
 
   # ---- scvi library latent (scvi.py:37-45, 88-106) --------------------------
   kl_l = np.zeros(B)
@@ -577,7 +598,17 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
     out["d_x_params"] = [draw_all[:, c * G:(c + 1) * G] for c in range(k)]
   dz = _mlp_bwd(spec, params, "dec", spec.dec_units, dec_c, dd, grads, training)
 
-  if spec.stochastic:
+  if spec.model == "scale":
+    r_, dzm, s_c = scale_c["resp"], scale_c["dzm"], scale_c["s"]
+    # d(-log p)/dz = sum_c resp_c (z - m_c) / s_c^2; log q depends on (sigma, eps) only: d log q / d sigma = -1 / sigma
+    dz = dz + c_kl * (r_[:, :, None] * dzm / s_c[None]).sum(1)
+    dmu = dz
+    dsig = dz * eps - c_kl / sig
+    dlat = np.concatenate([dmu, dsig * expit(s_raw + SOFTPLUS_INV_1)], axis=1)
+    grads["prior/logits"] = c_kl * (np.exp(scale_c["log_pi"])[None] - r_).sum(0)
+    grads["prior/loc"] = -c_kl * (r_[:, :, None] * dzm / s_c[None]).sum(0)
+    grads["prior/scale"] = -c_kl * (r_[:, :, None] * (dzm ** 2 - 1.0) / s_c[None]).sum(0) * expit(params["prior/scale"] + SOFTPLUS_INV_1)
+  elif spec.stochastic:
     dmu = dz + c_kl * mu
     dsig = dz * eps + c_kl * (sig - 1.0 / sig)
     dlat = np.concatenate([dmu, dsig * expit(s_raw + SOFTPLUS_INV_1)], axis=1)
@@ -614,7 +645,9 @@ def marginal_log_prob(spec: Spec, params, bn_state, x, cell_ids, n_samples: int,
     noise = PhiloxNoise(spec.seed, 0, cell_ids, sample=s_)
     r = forward_backward(spec, params, bn_state, x, noise, library=library, training=False, backward=False)
     lw = r["llk_x"].copy()
-    if spec.stochastic:
+    if spec.model == "scale":   # log p_GMM(z) - log q(z|x) is minus the Monte-Carlo KL term of this draw
+      lw -= r["kl"]
+    elif spec.stochastic:
       z, mu, sig = r["z"], r["z_mean"], r["z_scale"]
       eps = (z - mu) / sig
       lw += (-0.5 * z ** 2 + 0.5 * eps ** 2 + np.log(sig)).sum(1)

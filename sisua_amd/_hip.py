@@ -17,7 +17,7 @@ SMX_ABI_VERSION = 2
 SMX_MAX_LAYERS = 8
 SMX_MAX_LABELS = 4
 
-MODEL_KINDS = {"vae": 0, "dca": 1, "scvi": 2, "sisua": 3}
+MODEL_KINDS = {"vae": 0, "dca": 1, "scvi": 2, "sisua": 3, "scale": 4}
 LIKELIHOODS = {"nb": 0, "zinb": 1, "nbd": 2, "zinbd": 3}
 LABEL_LIKELIHOODS = {"nb": 0, "onehot": 1, "mixnb": 2}
 ACTIVATIONS = {"relu": 0, "linear": 1}
@@ -35,7 +35,7 @@ class smx_config(C.Structure):
       ("n_dec", C.c_int32), ("dec_units", C.c_int32 * SMX_MAX_LAYERS),
       ("n_encl", C.c_int32), ("encl_units", C.c_int32 * SMX_MAX_LAYERS),
       ("n_labels", C.c_int32), ("label_dim", C.c_int32 * SMX_MAX_LABELS), ("label_llk", C.c_int32 * SMX_MAX_LABELS),
-      ("label_components", C.c_int32 * SMX_MAX_LABELS),
+      ("label_components", C.c_int32 * SMX_MAX_LABELS), ("n_components", C.c_int32),
       ("batchnorm", C.c_int32), ("log_norm", C.c_int32), ("latent_activation", C.c_int32),
       ("dropout_enc", C.c_float), ("dropout_dec", C.c_float), ("input_dropout", C.c_float),
       ("beta", C.c_float), ("alpha", C.c_float), ("clip_library", C.c_float),

@@ -99,6 +99,7 @@ class ModelConfig:
   adam_eps: float = 1e-7
   clipnorm: float = 100.0
   seed: int = 8
+  n_components: int = 10   # model 'scale': components of the Gaussian-mixture prior
 
   @property
   def k(self) -> int:
@@ -132,6 +133,9 @@ def manifest(cfg: ModelConfig) -> List[Tuple[str, Tuple[int, ...]]]:
   h = mlp("enc", G, cfg.enc_units)
   nl = 2 * D if cfg.stochastic else D
   out += [("lat/W", (h, nl)), ("lat/b", (nl,))]
+  if cfg.model == "scale":
+    C = cfg.n_components
+    out += [("prior/logits", (C,)), ("prior/loc", (C, D)), ("prior/scale", (C, D))]
   if cfg.model == "scvi":
     hl = mlp("encl", G, cfg.encl_units)
     out += [("latl/W", (hl, 2)), ("latl/b", (2,))]
@@ -159,6 +163,8 @@ def init_params(cfg: ModelConfig, seed: Optional[int] = None) -> Dict[str, np.nd
       params[name] = rng.uniform(-limit, limit, size=shape).astype(np.float32)
     elif kind == "gamma":
       params[name] = np.ones(shape, dtype=np.float32)
+    elif name == "prior/loc":   # scale: the mixture components must not start identical
+      params[name] = rng.uniform(-1.0, 1.0, size=shape).astype(np.float32)
     else:
       params[name] = np.zeros(shape, dtype=np.float32)
   return params

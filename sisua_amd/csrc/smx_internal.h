@@ -47,6 +47,8 @@ struct EpiLatentBwd {
   const float* sig = nullptr; const float* eps = nullptr;  // [B][Dp]
   float kl_scale = 0.f; int D = 0, Dp = 0, stochastic = 1, relu = 0;
   float* dlat = nullptr;                             // [B][ld]
+  // SCALE (Monte-Carlo KL against the mixture prior): d(-log p)/dz [B][Dp] from scale_prior_fwd; nullptr: analytic KL
+  const float* dklz = nullptr;
 };
 
 struct GemmArgs {
@@ -230,6 +232,19 @@ int launch_bn_sync_bwd(hipStream_t st, const BnBwdArgs& a, const BnSyncArgs& y, 
 
 int launch_latent_fwd(hipStream_t st, const LatentArgs& a);
 int launch_latent_bwd(hipStream_t st, const LatentArgs& a);
+
+// SCALE (sisua/models/scale.py:13-49): trainable Gaussian-mixture prior over z, one-sample Monte-Carlo KL
+struct ScalePriorArgs {
+  const float* z = nullptr; const float* sig = nullptr; const float* eps = nullptr; int B = 0, D = 0, Dp = 0, C = 0;
+  const float* logits = nullptr; const float* loc = nullptr; const float* scale_raw = nullptr;   // [C], [Cp][Dp], [Cp][Dp]
+  float* kl = nullptr;        // [B]  log q(z|x) - log p(z)
+  float* resp = nullptr;      // [B][32] responsibilities
+  float* dklz = nullptr;      // [B][Dp] d(-log p)/dz
+  float kl_scale = 0.f;       // beta / B_global
+  float* g_logits = nullptr; float* g_loc = nullptr; float* g_scale = nullptr;   // gradients (backward)
+};
+int launch_scale_prior_fwd(hipStream_t st, const ScalePriorArgs& a);
+int launch_scale_prior_bwd(hipStream_t st, const ScalePriorArgs& a);
 
 // scvi library latent: latl [B][ldl] (mu_l, s_raw_l) -> l sample, KL vs N(lib_mean, sqrt(lib_var))
 struct LibLatentArgs {

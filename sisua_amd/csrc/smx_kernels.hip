@@ -883,6 +883,105 @@ int launch_latent_bwd(hipStream_t st, const LatentArgs& a) {
   return SMX_OK;
 }
 
+// ---- SCALE: Gaussian-mixture prior, one-sample Monte-Carlo KL (scale.py:13-49; Xiong et al. 2019) -------------------
+// one wave per cell; lanes over the latent dims; the C (<= 32) components are walked serially (C D ~ 100 terms)
+__global__ __launch_bounds__(256) void scale_prior_fwd_kernel(ScalePriorArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const float HALF_LOG_2PI = 0.9189385332046727f;
+  // log softmax of the mixture logits (lane c holds logit c)
+  const float lg = lane < a.C ? a.logits[lane] : -3.0e38f;
+  const float lmx = wave_max(lg);
+  const float lse = lmx + flog(wave_sum(lane < a.C ? fexp(lg - lmx) : 0.f));
+  float comp_mine = -3.0e38f;          // lane c keeps component c's joint log density
+  for (int c = 0; c < a.C; ++c) {
+    float t = 0.f;
+    for (int d = lane; d < a.D; d += 64) {
+      const float s = softplusf(a.scale_raw[(long)c * a.Dp + d] + SMX_SOFTPLUS_INV_1);
+      const float u = (a.z[(long)b * a.Dp + d] - a.loc[(long)c * a.Dp + d]) * frcp(s);
+      t += -0.5f * u * u - flog(s) - HALF_LOG_2PI;
+    }
+    t = wave_sum(t) + (a.logits[c] - lse);
+    if (lane == c) comp_mine = t;
+  }
+  const float cmx = wave_max(comp_mine);
+  const float log_p = cmx + flog(wave_sum(lane < a.C ? fexp(comp_mine - cmx) : 0.f));
+  const float resp = lane < a.C ? fexp(comp_mine - log_p) : 0.f;
+  if (lane < 32) a.resp[(long)b * 32 + lane] = resp;
+  float lq = 0.f;
+  for (int d = lane; d < a.D; d += 64) {
+    const float e = a.eps[(long)b * a.Dp + d];
+    lq += -0.5f * e * e - flog(a.sig[(long)b * a.Dp + d]) - HALF_LOG_2PI;
+  }
+  lq = wave_sum(lq);
+  if (lane == 0) a.kl[b] = lq - log_p;
+  // d(-log p)/dz_d = sum_c resp_c (z_d - m_cd) / s_cd^2
+  for (int d = lane; d < a.Dp; d += 64) {
+    float g = 0.f;
+    const float zd = a.z[(long)b * a.Dp + d];
+    for (int c = 0; c < a.C; ++c) {   // (every lane takes part in the shuffle; padded dims contribute nothing)
+      const float rc = __shfl(resp, c, 64);
+      const float s = softplusf(a.scale_raw[(long)c * a.Dp + d] + SMX_SOFTPLUS_INV_1);
+      g += (d < a.D) ? rc * (zd - a.loc[(long)c * a.Dp + d]) * frcp(s * s) : 0.f;
+    }
+    a.dklz[(long)b * a.Dp + d] = g;
+  }
+}
+int launch_scale_prior_fwd(hipStream_t st, const ScalePriorArgs& a) {
+  if (a.C < 2 || a.C > 32 || a.B <= 0) { set_error("scale prior: 2..32 components"); return SMX_ERR_INVALID; }
+  hipLaunchKernelGGL(scale_prior_fwd_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+// gradients of the prior's parameters: one workgroup per component, lanes over the latent dims, waves over the cells
+__global__ __launch_bounds__(256) void scale_prior_bwd_kernel(ScalePriorArgs a) {
+  __shared__ float sh[4][3][64];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int d0 = 0; d0 < a.Dp; d0 += 64) {
+    const int d = d0 + lane;
+    float g_loc = 0.f, g_sc = 0.f, g_lg = 0.f;
+    const bool live = d < a.D;
+    const float raw = live ? a.scale_raw[(long)c * a.Dp + d] : 0.f;
+    const float s = softplusf(raw + SMX_SOFTPLUS_INV_1), m = live ? a.loc[(long)c * a.Dp + d] : 0.f;
+    const float is = frcp(s);
+    for (int b = w; b < a.B; b += 4) {
+      const float rc = a.resp[(long)b * 32 + c];
+      if (live) {
+        const float u = (a.z[(long)b * a.Dp + d] - m) * is;
+        g_loc += rc * u * is;
+        g_sc += rc * (u * u - 1.f) * is;
+      }
+      if (d0 == 0 && lane == 0) g_lg += rc;
+    }
+    sh[w][0][lane] = g_loc; sh[w][1][lane] = g_sc; sh[w][2][lane] = g_lg;
+    __syncthreads();
+    if (w == 0) {
+      const float t0 = (sh[0][0][lane] + sh[1][0][lane]) + (sh[2][0][lane] + sh[3][0][lane]);
+      const float t1 = (sh[0][1][lane] + sh[1][1][lane]) + (sh[2][1][lane] + sh[3][1][lane]);
+      if (d < a.Dp) {
+        a.g_loc[(long)c * a.Dp + d] = live ? -a.kl_scale * t0 : 0.f;
+        a.g_scale[(long)c * a.Dp + d] = live ? -a.kl_scale * t1 * sigmoidf(raw + SMX_SOFTPLUS_INV_1) : 0.f;
+      }
+      if (d0 == 0 && lane == 0) {
+        const float rsum = (sh[0][2][0] + sh[1][2][0]) + (sh[2][2][0] + sh[3][2][0]);
+        // softmax(logits)_c * B - sum_b resp_bc
+        float mx = -3.0e38f;
+        for (int q = 0; q < a.C; ++q) mx = fmaxf(mx, a.logits[q]);
+        float se = 0.f;
+        for (int q = 0; q < a.C; ++q) se += fexp(a.logits[q] - mx);
+        a.g_logits[c] = a.kl_scale * ((float)a.B * fexp(a.logits[c] - mx) * frcp(se) - rsum);
+      }
+    }
+    __syncthreads();
+  }
+}
+int launch_scale_prior_bwd(hipStream_t st, const ScalePriorArgs& a) {
+  hipLaunchKernelGGL(scale_prior_bwd_kernel, dim3(a.C), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
 // ---- scvi library latent (scvi.py:37-45, 88-106, 117) -------------------------
 __global__ void lib_latent_fwd_kernel(LibLatentArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;

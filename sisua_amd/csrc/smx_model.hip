@@ -154,6 +154,7 @@ struct IwArgs {
   const float* z; const float* sig; const float* eps; int D, Dp, stochastic;
   const float* l; const float* lsig; const float* leps; const float* library;  // scvi (library indexed like lgx1)
   float* run_max; float* run_sum; float* llk_sum; int B, first;
+  const float* klmc;   // scale: log q(z|x) - log p_mixture(z) of this draw (replaces the N(0, I) prior terms)
 };
 // one wave per cell: lanes over the loss kernel's partial sums and over the latent dims
 __global__ __launch_bounds__(256) void iw_accum_kernel(IwArgs a) {
@@ -166,7 +167,8 @@ __global__ __launch_bounds__(256) void iw_accum_kernel(IwArgs a) {
   const long src = a.rows ? a.rows[b] : b;
   llk -= a.lgx1[src];
   float lw = 0.f;
-  if (a.stochastic)
+  if (a.klmc) lw = (lane == 0) ? -a.klmc[b] : 0.f;
+  else if (a.stochastic)
     for (int d = lane; d < a.D; d += 64) {
       const float z = a.z[(long)b * a.Dp + d], e = a.eps[(long)b * a.Dp + d], s = a.sig[(long)b * a.Dp + d];
       lw += -0.5f * z * z + 0.5f * e * e + logf(s);
@@ -256,7 +258,9 @@ struct smx_model {
   // sum-of-squares slots written by the weight-gradient products (per-tensor clipnorm without a separate pass)
   float* sq_slots = nullptr; std::vector<int> sq_first, sq_count;   // this step's output head ran as the fused kernel (smx_head.hip)
   int G = 0, Gp = 0, D = 0, Dp = 0, k = 0, Bmax = 0;
-  bool stochastic = true, scvi = false;
+  bool stochastic = true, scvi = false, scale = false;
+  int t_prLogits = -1, t_prLoc = -1, t_prScale = -1;    // scale: Gaussian-mixture prior
+  float *resp = nullptr, *dklz = nullptr;
   std::vector<TensorInfo> tensors;
   size_t flat_count = 0, tail_off_bn = 0, tail_off_metrics = 0, grads_count = 0;
   float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
@@ -723,7 +727,7 @@ bool use_head_loss(const smx_model* m, int B) {
 bool use_mid(const smx_model* m, int B) {
   // single-workgroup fusion of the middle is opt-in until it beats the per-operator path
   static const bool off = getenv("SMX_FUSED") == nullptr;
-  if (off || m->scvi || B > 128 || m->sync_bn) return false;
+  if (off || m->scvi || m->scale || B > 128 || m->sync_bn) return false;
   for (auto* mlp : {&m->enc, &m->dec})
     for (auto& L : *mlp) if (L.out_p > 128) return false;
   if ((m->stochastic ? 2 : 1) * m->Dp > 128) return false;
@@ -798,7 +802,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   const MlpLayer& eL = m->enc.back();
   const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
   static const bool no_fz = getenv("SMX_SMALL_FUSION") == nullptr;
-  const bool fuse_lat = !no_fz && !resample && latent_head_fusable(eL.out_p, lat_ld, m->Dp);
+  const bool fuse_lat = !no_fz && !m->scale && !resample && latent_head_fusable(eL.out_p, lat_ld, m->Dp);
   if (!fuse_lat && !resample) {
     const TensorInfo& tw = m->tensors[m->t_latW];
     GemmArgs g;
@@ -818,7 +822,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   la.z = m->z; la.sig = m->sig; la.eps = m->eps; la.kl = m->kl;
   // The latent sample + KL and the first decoder product run INSIDE the decoder's first BatchNorm launch (two
   // launches fewer) when the shapes allow; SMX_NO_FRONT=1 keeps the three-launch form.
-  front_ok = m->flags.front && !fuse_lat && !sync_bn_on(m, ps.training) && bn_front_supported(ps.B, m->Dp) && (m->Dp == 32 || m->Dp == 64) &&
+  front_ok = m->flags.front && !m->scale && !fuse_lat && !sync_bn_on(m, ps.training) && bn_front_supported(ps.B, m->Dp) && (m->Dp == 32 || m->Dp == 64) &&
              m->dec[0].in_p == m->Dp && m->dec[0].out_p % 8 == 0 && (lat_ld % 4) == 0 && (!la.inj_eps || (la.inj_ld % 4) == 0);
   front_la = la;
   if (front_ok) {
@@ -830,6 +834,13 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   } else {
     Timed t(m, "latent_fwd");
     SMX_CHECK(launch_latent_fwd(m->st, la));
+  }
+  if (m->scale) {   // Monte-Carlo KL against the mixture prior at the z just drawn (overwrites the analytic KL)
+    ScalePriorArgs sp;
+    sp.z = m->z; sp.sig = m->sig; sp.eps = m->eps; sp.B = ps.B; sp.D = m->D; sp.Dp = m->Dp; sp.C = c.n_components;
+    sp.logits = P_(m, m->t_prLogits); sp.loc = P_(m, m->t_prLoc); sp.scale_raw = P_(m, m->t_prScale);
+    sp.kl = m->kl; sp.resp = m->resp; sp.dklz = m->dklz;
+    SMX_CHECK(launch_scale_prior_fwd(m->st, sp));
   }
   // ---- scvi library latent ----
   if (m->scvi) {
@@ -1147,6 +1158,15 @@ int backward_pass(smx_model* m, const Pass& ps) {
   le.lat = m->latbuf; le.ld = lat_ld; le.sig = m->sig; le.eps = m->eps; le.kl_scale = c.beta * inv_gb;
   le.D = m->D; le.Dp = m->Dp; le.stochastic = m->stochastic; le.relu = (c.latent_activation == SMX_ACT_RELU);
   le.dlat = m->dlat;
+  if (m->scale) {
+    le.dklz = m->dklz;
+    ScalePriorArgs sp;
+    sp.z = m->z; sp.B = ps.B; sp.D = m->D; sp.Dp = m->Dp; sp.C = c.n_components;
+    sp.logits = P_(m, m->t_prLogits); sp.loc = P_(m, m->t_prLoc); sp.scale_raw = P_(m, m->t_prScale);
+    sp.resp = m->resp; sp.kl_scale = c.beta * inv_gb;
+    sp.g_logits = G_(m, m->t_prLogits); sp.g_loc = G_(m, m->t_prLoc); sp.g_scale = G_(m, m->t_prScale);
+    SMX_CHECK(launch_scale_prior_bwd(m->st, sp));
+  }
   // Products that only the optimiser reads (the weight gradients of the first decoder layer, of the latent head and of
   // the first encoder layers) run as ONE grouped launch at the end; the last encoder layer's BatchNorm-backward
   // launch computes d h = d lat W_lat^T itself.  SMX_NO_BWD_FRONT=1: the separate launches of before.
@@ -1444,7 +1464,8 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   SMX_REQUIRE(cfg->n_genes > 0 && cfg->latent_dim > 0 && cfg->max_batch > 0, "n_genes, latent_dim, max_batch must be > 0");
   SMX_REQUIRE(cfg->n_enc >= 1 && cfg->n_enc <= SMX_MAX_LAYERS && cfg->n_dec >= 1 && cfg->n_dec <= SMX_MAX_LAYERS,
               "encoder/decoder need 1..8 layers");
-  SMX_REQUIRE(cfg->model >= SMX_MODEL_VAE && cfg->model <= SMX_MODEL_SISUA, "unknown model kind");
+  SMX_REQUIRE(cfg->model >= SMX_MODEL_VAE && cfg->model <= SMX_MODEL_SCALE, "unknown model kind");
+  if (cfg->model == SMX_MODEL_SCALE) SMX_REQUIRE(cfg->n_components >= 2 && cfg->n_components <= 32, "scale: 2..32 mixture components");
   SMX_REQUIRE(cfg->likelihood >= SMX_LLK_NB && cfg->likelihood <= SMX_LLK_ZINBD, "unknown likelihood");
   SMX_REQUIRE(cfg->n_labels >= 0 && cfg->n_labels <= SMX_MAX_LABELS, "too many label heads");
   SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->n_labels == 0, "label heads need model = SISUA");
@@ -1460,7 +1481,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   m->cfg = *cfg; m->device = dev;
   m->G = cfg->n_genes; m->Gp = round_up(m->G, 32); m->D = cfg->latent_dim; m->Dp = round_up(m->D, 32);
   m->k = (cfg->likelihood == SMX_LLK_ZINB || cfg->likelihood == SMX_LLK_ZINBD) ? 3 : 2;
-  m->stochastic = cfg->model != SMX_MODEL_DCA; m->scvi = cfg->model == SMX_MODEL_SCVI;
+  m->stochastic = cfg->model != SMX_MODEL_DCA; m->scvi = cfg->model == SMX_MODEL_SCVI; m->scale = cfg->model == SMX_MODEL_SCALE;
   m->Bmax = cfg->max_batch;
   int rc = SMX_OK;
   auto fail = [&](int code) { smx_model_destroy(m); return code; };
@@ -1478,6 +1499,11 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   int h = build_mlp(m, m->enc, "enc", m->G, cfg->n_enc, cfg->enc_units, ST_ENC_DROPOUT, cfg->dropout_enc);
   m->t_latW = add_tensor(m, "lat/W", h, (m->stochastic ? 2 : 1) * m->D, m->stochastic ? 2 : 1, false);
   m->t_latb = add_tensor(m, "lat/b", 1, (m->stochastic ? 2 : 1) * m->D, m->stochastic ? 2 : 1, true);
+  if (m->scale) {   // trainable mixture prior: logits [C], means and raw scales [C][D]
+    m->t_prLogits = add_tensor(m, "prior/logits", 1, cfg->n_components, 1, true);
+    m->t_prLoc = add_tensor(m, "prior/loc", cfg->n_components, m->D, 1, false);
+    m->t_prScale = add_tensor(m, "prior/scale", cfg->n_components, m->D, 1, false);
+  }
   if (m->scvi) {
     int hl = build_mlp(m, m->encl, "encl", m->G, cfg->n_encl, cfg->encl_units, ST_ENCL_DROPOUT, cfg->dropout_enc);
     m->t_latlW = add_tensor(m, "latl/W", hl, 2, 1, false);
@@ -1561,6 +1587,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
       (rc = dmalloc(&m->rows2[0], B)) || (rc = dmalloc(&m->rows2[1], B)) || (rc = dmalloc(&m->state3, (size_t)3)) ||
       (rc = dmalloc(&m->hostX, B * m->Gp)) || (rc = dmalloc(&m->hostLib, B * 2)) || (rc = dmalloc(&m->hostLgx1, B)))
     return fail(rc);
+  if (m->scale && ((rc = dmalloc(&m->resp, B * 32)) || (rc = dmalloc(&m->dklz, B * m->Dp)))) return fail(rc);
   if (m->scvi) {
     if ((rc = dmalloc(&m->raw, B * ldp)) || (rc = dmalloc(&m->draw, B * ldp)) || (rc = dmalloc(&m->rho, B * m->Gp)) ||
         (rc = dmalloc(&m->latlbuf, B * 32)) || (rc = dmalloc(&m->dlatl, B * 32)) || (rc = dmalloc(&m->lsmp, B)) ||
@@ -1633,6 +1660,7 @@ int smx_model_destroy(smx_model* m) {
   fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1); fr(m->hostX); fr(m->hostLib); fr(m->hostLgx1);
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); fr(m->laby_raw[j]); fr(m->laby_draw[j]); }
   fr(m->rows2[0]); fr(m->rows2[1]); fr(m->order); fr(m->state3); fr(m->mhist);
+  fr(m->resp); fr(m->dklz);
   fr(m->noise_eps); fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);
   fr(m->latlbuf); fr(m->dlatl); fr(m->lsmp); fr(m->lsig); fr(m->leps); fr(m->kl_l); fr(m->dl);
   fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);
@@ -2085,6 +2113,7 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
     a.z = m->z; a.sig = m->sig; a.eps = m->eps; a.D = m->D; a.Dp = m->Dp; a.stochastic = m->stochastic;
     a.l = m->scvi ? m->lsmp : nullptr; a.lsig = m->lsig; a.leps = m->leps; a.library = ps.lib;
     a.run_max = run; a.run_sum = run + batch; a.llk_sum = run + 2 * batch; a.B = batch; a.first = (s == 0);
+    a.klmc = m->scale ? m->kl : nullptr;
     hipLaunchKernelGGL(iw_accum_kernel, dim3((batch + 3) / 4), dim3(256), 0, m->st, a);
   }
   if (rc == SMX_OK) {

@@ -60,6 +60,7 @@ def make_smx_config(cfg: ModelConfig, max_batch: int) -> smx_config:
   c.beta, c.alpha, c.clip_library = cfg.beta, cfg.alpha, cfg.clip_library
   c.bn_momentum, c.bn_eps = cfg.bn_momentum, cfg.bn_eps
   c.lr, c.adam_beta1, c.adam_beta2, c.adam_eps, c.clipnorm = cfg.lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps, cfg.clipnorm
+  c.n_components = int(cfg.n_components)
   c.max_batch = int(max_batch)
   c.seed = int(cfg.seed) & 0xFFFFFFFFFFFFFFFF
   return c
@@ -82,7 +83,7 @@ class Engine:
       check(self.lib.smx_tensor_info(self._h, i, buf, 64, C.byref(rows), C.byref(cols)))
       name = buf.value.decode()
       self.names.append(name)
-      self.shapes[name] = (rows.value, cols.value) if name.endswith("/W") else (cols.value,)
+      self.shapes[name] = (rows.value, cols.value) if (name.endswith("/W") or rows.value > 1) else (cols.value,)
     expect = manifest(cfg)
     if [(n, tuple(self.shapes[n])) for n in self.names] != [(n, tuple(s)) for n, s in expect]:
       raise SmxError("tensor manifest of libsisua_hip.so differs from sisua_amd.config.manifest")

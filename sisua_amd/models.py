@@ -25,7 +25,7 @@ from sisua_amd.config import ModelConfig, NetConf, RVmeta, init_params
 from sisua_amd.data import BatchDataset, SingleCellOMIC, library_matrix
 from sisua_amd.engine import Engine
 
-__all__ = ["SingleCellModel", "VAE", "SISUA", "MISA", "SCVI", "DeepCountAutoencoder", "NetConf", "RVmeta", "get_model",
+__all__ = ["SingleCellModel", "VAE", "SISUA", "MISA", "SCALE", "SCVI", "DeepCountAutoencoder", "NetConf", "RVmeta", "get_model",
            "get_all_models", "load_model"]
 
 _OMIC_ORDER = ["transcriptomic", "proteomic", "celltype", "disease", "progenitor", "chromatin"]
@@ -149,7 +149,8 @@ class SingleCellModel:
                        batchnorm=bool(enc.batchnorm), dropout_enc=float(enc.dropout), dropout_dec=float(self._decoder.dropout),
                        input_dropout=float(enc.input_dropout), log_norm=self._log_norm, beta=self.beta, alpha=self.alpha,
                        latent_activation=self._latent_activation(), clip_library=self.clip_library,
-                       lr=float(self._opt["lr"]), clipnorm=float(self._opt["clipnorm"]), seed=self.seed)
+                       lr=float(self._opt["lr"]), clipnorm=float(self._opt["clipnorm"]), seed=self.seed,
+                       n_components=int(getattr(self, "_n_components", 10)))
 
   def _ensure_engine(self, max_batch: int) -> Engine:
     cfg = self._make_config()
@@ -693,6 +694,31 @@ class MISA(SISUA):
       rv.kwargs.setdefault("n_components", n_components)
     super().__init__(outputs=outputs, labels=labs, **kwargs)
     self.init_args = dict(outputs=outputs, labels=labels, n_components=n_components, zero_inflated=zero_inflated, **kwargs)
+
+
+class SCALE(SingleCellModel):
+  r"""SCALE - "Single-Cell ATAC-seq analysis via Latent feature Extraction" (sisua/models/scale.py:13-49; Xiong et al.
+  2019, Nature Communications): a VAE whose prior over z is a TRAINABLE mixture of `n_components` diagonal Gaussians; the
+  KL term is the one-sample Monte-Carlo estimate log q(z|x) - log p(z) (`analytic=False`, scale.py:49).  Built:
+  covariance='none' (diagonal), untied mixtures / locations / scales (the reference's defaults).  [3P-recall: the
+  published model; odin's mixture latent layer behind the reference's class is not citable.]"""
+  _kind = "scale"
+
+  def __init__(self, outputs, latents=RVmeta(10, "mixgaus", True, name="Latents"), n_components=10, covariance="none",
+               tie_mixtures=False, tie_loc=False, tie_scale=False, **kwargs):
+    lat = [z.copy() for z in _flatten(latents)]
+    for z in lat:
+      if z.posterior[:3] != "mix":
+        warnings.warn(f"SCALE only allow mixture distribution for latents  posterior, but given: {z.posterior}")
+        z.posterior = "mixgaus"
+    if str(covariance) != "none" or tie_mixtures or tie_loc or tie_scale:
+      raise ValueError("SCALE is built for covariance='none' and untied mixture parameters (the reference's defaults)")
+    self._n_components = int(lat[0].kwargs.get("n_components", n_components))
+    if not 2 <= self._n_components <= 32:
+      raise ValueError(f"SCALE is built for 2..32 mixture components, given: {self._n_components}")
+    super().__init__(outputs=outputs, latents=lat, **kwargs)
+    self.init_args = dict(outputs=outputs, latents=latents, n_components=n_components, covariance=covariance,
+                          tie_mixtures=tie_mixtures, tie_loc=tie_loc, tie_scale=tie_scale, **kwargs)
 
 
 class SCVI(SingleCellModel):

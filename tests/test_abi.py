@@ -31,8 +31,8 @@ def test_header_and_binding_agree(lib):
 def test_config_struct_layout_matches_header():
   import ctypes as C
   from sisua_amd import _hip
-  # 5 + 3*(1+8) + (1+4+4+4) + 3 ints, 13 floats, 1 int, (pad), 1 u64
-  n_int = 5 + 3 * 9 + 13 + 3
+  # 5 + 3*(1+8) + (1+4+4+4+1) + 3 ints, 13 floats, 1 int, (pad), 1 u64
+  n_int = 5 + 3 * 9 + 14 + 3
   assert C.sizeof(_hip.smx_config) == (n_int + 13 + 1) * 4 + (4 if (n_int + 14) % 2 else 0) + 8
   assert C.sizeof(_hip.smx_metrics) == 32
 
@@ -57,7 +57,9 @@ def test_manifest_and_init_match_oracle():
              dict(model="scvi", n_genes=33, likelihood="zinbd", enc_units=(8,), dec_units=(8,), latent_dim=3, encl_units=(4,)),
              dict(model="sisua", n_genes=20, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=3,
                   labels=((5, "nb"), (3, "onehot")), batchnorm=False),
-             dict(model="dca", n_genes=20, likelihood="nbd", enc_units=(8,), dec_units=(8,), latent_dim=3)):
+             dict(model="dca", n_genes=20, likelihood="nbd", enc_units=(8,), dec_units=(8,), latent_dim=3),
+             dict(model="scale", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, n_components=5),
+             dict(model="sisua", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((5, "mixnb3"),))):
     spec, cfg = make_pair(**kw)
     assert config.manifest(cfg) == so.manifest(spec)
     a, b = config.init_params(cfg), so.init_params(spec)

@@ -296,3 +296,28 @@ def test_misa_fit_predict(api):
   assert np.isfinite(X[1].mean()).all() and np.isfinite(X[1].log_prob(test.numpy("proteomic"))).all()
   with pytest.raises(ValueError):
     api.MISA(outputs=sco.get_rv("transcriptomic"), labels=[sco.get_rv("proteomic")], n_components=7)._make_config()
+
+
+def test_scale_fit_predict(api, tmp_path):
+  """SCALE (sisua/models/scale.py:13-49): mixture prior over the latents, Monte-Carlo KL; trains, predicts, and its
+  prior parameters move and survive a checkpoint."""
+  sco = _sco(with_labels=False)
+  train, test = sco.split(0.8)
+  assert api.get_model("scale") is api.SCALE
+  m = api.SCALE(outputs=sco.get_rv("transcriptomic"), latents=api.RVmeta(8, "mixgaus", True, "Latents"), n_components=5,
+                encoder=api.NetConf([32], batchnorm=True, dropout=0.1), decoder=api.NetConf([32], batchnorm=True, dropout=0.1))
+  m.fit(train, epochs=12, batch_size=64, learning_rate=2e-3)
+  h = np.asarray(m.train_history["loss"])   # (the one-sample Monte-Carlo KL makes late epochs noisy: judge the trend)
+  assert _decreases(h[:7]) and h[-3:].mean() < h[3:6].mean() and np.isfinite(m.train_history["kl"]).all(), h
+  p = m._engine.get_params()
+  assert p["prior/loc"].shape == (5, 8) and p["prior/logits"].shape == (5,) and np.abs(p["prior/scale"]).max() > 1e-3
+  X, Z = m.predict(test.numpy(), batch_size=64, verbose=False)
+  assert Z.mean().shape == (test.n_obs, 8) and X.mean().shape == (test.n_obs, 120)
+  mllk, _ = m.marginal_log_prob(inputs=test.numpy()[:16], sample_shape=8)
+  assert np.isfinite(mllk).all()
+  path = os.path.join(tmp_path, "scale")
+  m.save_weights(path)
+  m2 = api.load_model(path)
+  assert type(m2) is api.SCALE and np.array_equal(m2._engine.get_params()["prior/loc"], p["prior/loc"])
+  with pytest.raises(ValueError):
+    api.SCALE(outputs=sco.get_rv("transcriptomic"), covariance="full")

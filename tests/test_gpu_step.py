@@ -33,6 +33,7 @@ CASES = {
                   labels=((12, "nb"), (7, "onehot"))),
     "misa": dict(model="sisua", n_genes=140, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=8,
                  labels=((12, "mixnb2"), (5, "mixnb3"))),
+    "scale": dict(model="scale", n_genes=150, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=10, n_components=7),
     "scvi_zinbd": dict(model="scvi", n_genes=160, likelihood="zinbd", enc_units=(48,), dec_units=(48,), latent_dim=6,
                        encl_units=(16,)),
     "scvi_nbd": dict(model="scvi", n_genes=96, likelihood="nbd", enc_units=(32,), dec_units=(32,), latent_dim=4,
@@ -169,7 +170,7 @@ def test_injected_noise_matches_oracle(Engine, name):
   e.close()
 
 
-@pytest.mark.parametrize("name,graph", [("vae_zinb", False), ("vae_zinb", True), ("sisua", True), ("scvi_zinbd", False), ("misa", False)])
+@pytest.mark.parametrize("name,graph", [("vae_zinb", False), ("vae_zinb", True), ("sisua", True), ("scvi_zinbd", False), ("misa", False), ("scale", True)])
 def test_trajectory_matches_oracle(Engine, name, graph):
   """50-step seeded trajectory: ELBO per step within 1e-4 relative."""
   kw = CASES[name]
@@ -328,7 +329,7 @@ def test_hip_matches_committed_trajectory_fixture(Engine):
   e.close()
 
 
-@pytest.mark.parametrize("name", ["vae_zinb", "scvi_zinbd", "dca_zinb"])
+@pytest.mark.parametrize("name", ["vae_zinb", "scvi_zinbd", "dca_zinb", "scale"])
 def test_marginal_llk_matches_oracle(Engine, name):
   """importance-weighted log p(x) (posterior.py:941-976) on the GPU vs the oracle."""
   spec, cfg, x, ys, lib, mask = _problem(dict(CASES[name], labels=()) if name != "sisua" else CASES[name])

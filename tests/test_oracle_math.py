@@ -127,7 +127,7 @@ def _toy(model, lk, labels=(), bn=True, **kw):
   G = 13
   spec = so.Spec(model=model, n_genes=G, likelihood=lk, enc_units=(6, 5), dec_units=(7,), latent_dim=3,
                  encl_units=(4,), labels=labels, batchnorm=bn, dropout_enc=0.25, dropout_dec=0.25,
-                 input_dropout=0.2, seed=3, **kw)
+                 input_dropout=0.2, seed=3, n_components=4, **kw)
   rng = np.random.default_rng(5)
   B = 6
   x = rng.poisson(1.5, size=(B, G)).astype(np.float64) * (rng.uniform(size=(B, G)) < 0.6)
@@ -146,7 +146,8 @@ def _toy(model, lk, labels=(), bn=True, **kw):
 CASES = [("vae", "zinb", (), True), ("vae", "nb", (), False), ("vae", "zinbd", (), True),
          ("vae", "nbd", (), True), ("dca", "zinb", (), True), ("scvi", "zinbd", (), True),
          ("scvi", "nbd", (), False), ("sisua", "zinb", ((4, "nb"), (3, "onehot")), True),
-         ("sisua", "zinb", ((4, "mixnb2"), (3, "mixnb3")), True)]   # MISA
+         ("sisua", "zinb", ((4, "mixnb2"), (3, "mixnb3")), True),   # MISA
+         ("scale", "zinb", (), True), ("scale", "nb", (), False)]    # SCALE: mixture prior, Monte-Carlo KL
 
 
 @pytest.mark.parametrize("model,lk,labels,bn", CASES)

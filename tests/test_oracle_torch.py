@@ -71,7 +71,12 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
   if spec.stochastic:
     q = td.Normal(lat[:, :D], softplus1(lat[:, D:]))
     z = q.loc + q.scale * torch.as_tensor(noise.normal(so.STREAM_EPS_Z, D))
-    kl = td.kl_divergence(q, td.Normal(torch.zeros_like(q.loc), torch.ones_like(q.scale))).sum(1)
+    if spec.model == "scale":   # Monte-Carlo KL against the trainable mixture prior: log q(z|x) - log p(z)
+      prior = td.MixtureSameFamily(td.Categorical(logits=P["prior/logits"]),
+                                   td.Independent(td.Normal(P["prior/loc"], softplus1(P["prior/scale"])), 1))
+      kl = td.Independent(q, 1).log_prob(z) - prior.log_prob(z)
+    else:
+      kl = td.kl_divergence(q, td.Normal(torch.zeros_like(q.loc), torch.ones_like(q.scale))).sum(1)
   else:
     z = torch.relu(lat) if spec.latent_activation == "relu" else lat
     kl = torch.zeros(B)
@@ -141,6 +146,7 @@ CASES = {
                   labels=((7, "nb"), (4, "onehot")), alpha=10.0),
     "misa": dict(model="sisua", n_genes=40, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5,
                  labels=((6, "mixnb2"), (3, "mixnb3")), alpha=10.0),
+    "scale": dict(model="scale", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=6),
     "scvi_zinbd": dict(model="scvi", n_genes=52, likelihood="zinbd", enc_units=(16,), dec_units=(16,), latent_dim=4, encl_units=(8,)),
     "scvi_nbd": dict(model="scvi", n_genes=36, likelihood="nbd", enc_units=(12,), dec_units=(12,), latent_dim=3, encl_units=(6,),
                      batchnorm=False),
