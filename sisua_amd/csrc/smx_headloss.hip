@@ -162,9 +162,9 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
 bool head_loss_supported(int B, int Hp, int Gp) { return B > 0 && Hp % 32 == 0 && Gp % 32 == 0; }
 int head_loss_chunks(int Gp) { return Gp / 32; }
 
-static int head_waves() {   // waves per workgroup (SMX_HEAD_WAVES = 4 | 8)
+static int head_waves() {   // waves per workgroup (SMX_HEAD_WAVES = 4 | 8 | 16)
   static const int v = getenv("SMX_HEAD_WAVES") ? atoi(getenv("SMX_HEAD_WAVES")) : 8;
-  return v == 4 ? 4 : 8;
+  return (v == 4 || v == 16) ? v : 8;
 }
 
 template <int LK, int NW>
@@ -179,7 +179,9 @@ static void launch_hl_w(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
 }
 template <int LK>
 static void launch_hl(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
-  if (head_waves() == 4) launch_hl_w<LK, 4>(st, a, grid); else launch_hl_w<LK, 8>(st, a, grid);
+  if (head_waves() == 4) launch_hl_w<LK, 4>(st, a, grid);
+  else if (head_waves() == 16) launch_hl_w<LK, 16>(st, a, grid);
+  else launch_hl_w<LK, 8>(st, a, grid);
 }
 
 int launch_out_head_loss(hipStream_t st, const HeadLossArgs& a_in) {

@@ -8,7 +8,11 @@ from oracle import sisua_oracle as so
 from tests.util import grad_errors, make_pair, perturbed_params
 
 pytestmark = pytest.mark.gpu
-SET = settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+import os
+_N = int(os.environ.get("SMX_HYP_EXAMPLES", "0"))   # stress runs while developing: SMX_HYP_EXAMPLES=400
+def _n(default):
+  return _N or default
+SET = settings(max_examples=_n(25), deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 
 
 @pytest.fixture(scope="module")
@@ -62,14 +66,20 @@ def test_resident_matrix_kernels_on_arbitrary_shapes(eng, n, G, rate, retain, se
   e.close()
 
 
-@settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
-@given(G=st.integers(5, 150), H=st.integers(1, 70), H2=st.integers(1, 40), D=st.integers(1, 20), B=st.integers(4, 64),
-       model=st.sampled_from(["vae", "dca", "scvi"]), bn=st.booleans(), seed=st.integers(0, 10**6))
-def test_one_step_on_arbitrary_widths(eng, G, H, H2, D, B, model, bn, seed):
-  lk = "zinbd" if model == "scvi" else "zinb"
+@settings(max_examples=_n(12), deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(G=st.integers(5, 150), H=st.integers(1, 70), H2=st.integers(1, 40), D=st.integers(1, 40), B=st.integers(4, 300),
+       model=st.sampled_from(["vae", "dca", "scvi", "scale"]), lk0=st.sampled_from(["zinb", "nb", "zinbd", "nbd"]), bn=st.booleans(),
+       seed=st.integers(0, 10**6))
+def test_one_step_on_arbitrary_widths(eng, G, H, H2, D, B, model, lk0, bn, seed):
+  """Any gene panel / layer / latent width and batch size (batches beyond 128 and 256 take the 4- and 8-rows-per-lane
+  BatchNorm forms and the fronts' larger LDS tiles; latent widths beyond 32 the 64-wide front), every likelihood,
+  with and without BatchNorm: the fused / wide default kernels against the oracle."""
+  lk = ("zinbd" if lk0.startswith("zi") else "nbd") if model == "scvi" else lk0
   kw = dict(model=model, n_genes=G, likelihood=lk, enc_units=(H,), dec_units=(H2,), latent_dim=D, batchnorm=bn, seed=seed)
   if model == "scvi":
     kw["encl_units"] = (max(1, H // 2),)
+  if model == "scale":
+    kw["n_components"] = 2 + seed % 7
   spec, cfg = make_pair(**kw)
   rng = np.random.default_rng(seed)
   n = B + 5
@@ -128,9 +138,10 @@ def test_total_count_logits_over_wide_ranges(eng, B, G, lk, seed):
     assert np.allclose(grads[c], ref_g[c], rtol=2e-3, atol=2e-4 * max(1.0, np.abs(ref_g[c]).max())), (c, np.abs(grads[c] - ref_g[c]).max())
 
 
-@settings(max_examples=15, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@settings(max_examples=_n(15), deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(G=st.integers(5, 120), H=st.integers(2, 48), D=st.integers(1, 12), B=st.integers(4, 70), P1=st.integers(1, 150), P2=st.integers(2, 90),
-       kinds=st.sampled_from([("nb",), ("onehot",), ("nb", "onehot"), ("onehot", "nb")]), pct=st.floats(0.0, 1.0), seed=st.integers(0, 10**6))
+       kinds=st.sampled_from([("nb",), ("onehot",), ("nb", "onehot"), ("onehot", "nb"), ("mixnb2",), ("mixnb3", "nb"), ("onehot", "mixnb4")]),
+       pct=st.floats(0.0, 1.0), seed=st.integers(0, 10**6))
 def test_semi_supervised_step_on_arbitrary_label_widths(eng, G, H, D, B, P1, P2, kinds, pct, seed):
   """SISUA label heads: label widths beyond one wave (P > 64), any mix of NB / one-hot heads, any labelled
   fraction (all cells unlabelled and all labelled included).  Batches of 2-3 cells are left out: BatchNorm over two
@@ -144,7 +155,8 @@ def test_semi_supervised_step_on_arbitrary_label_widths(eng, G, H, D, B, P1, P2,
   x[:, 0] += 1
   ys = []
   for p, k in labels:
-    ys.append(np.eye(p, dtype=np.float32)[rng.integers(0, p, n)] if k == "onehot" else rng.uniform(0.5, 9.0, size=(n, p)).astype(np.float32))
+    ys.append(np.eye(p, dtype=np.float32)[rng.integers(0, p, n)] if k == "onehot" else
+              np.floor(rng.uniform(0, 40, size=(n, p))).astype(np.float32) if k.startswith("mixnb") else rng.uniform(0.5, 9.0, size=(n, p)).astype(np.float32))
   mask = rng.uniform(size=n) < pct
   params = perturbed_params(spec)
   bnst, opt = so.init_bn_state(spec), so.init_opt_state(params)
@@ -161,7 +173,7 @@ def test_semi_supervised_step_on_arbitrary_label_widths(eng, G, H, D, B, P1, P2,
   e.close()
 
 
-@settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@settings(max_examples=_n(12), deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(G=st.integers(5, 120), H=st.integers(2, 40), D=st.integers(1, 10), B=st.integers(1, 48), S=st.integers(1, 5),
        model=st.sampled_from(["vae", "scvi"]), seed=st.integers(0, 10**6), resident=st.booleans())
 def test_scoring_paths_on_arbitrary_shapes(eng, G, H, D, B, S, model, seed, resident):
