@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SMX_ABI_VERSION 2
+#define SMX_ABI_VERSION 3
 #define SMX_MAX_LAYERS 8
 #define SMX_MAX_LABELS 4
 
@@ -41,7 +41,12 @@ typedef enum {
  * vae.py:19-44 (SISUA = VAE + label heads; MISA = SISUA with mixture label heads, vae.py:47-98). */
 /* SMX_MODEL_SCALE: scale.py:13-49 (SCALE, Xiong et al. 2019): VAE whose prior over z is a trainable mixture of
  * n_components diagonal Gaussians, KL term by one-sample Monte Carlo (`analytic=False`). */
-typedef enum { SMX_MODEL_VAE = 0, SMX_MODEL_DCA = 1, SMX_MODEL_SCVI = 2, SMX_MODEL_SISUA = 3, SMX_MODEL_SCALE = 4 } smx_model_kind;
+/* SMX_MODEL_FVAE: fvae.py:9-18 (FVAE / SemiFVAE; Kim & Mnih 2018): VAE + a discriminator on z whose logit estimates the
+ * total correlation; the VAE's tensors follow -ELBO + gamma TC, the discriminator's tensors its own classification loss
+ * (z against z with every dimension permuted over the minibatch), both in the same step.  n_labels = 1 with
+ * SMX_LABEL_ONEHOT makes it the semi-supervised form (one logit per class, TC logit = their logsumexp). */
+typedef enum { SMX_MODEL_VAE = 0, SMX_MODEL_DCA = 1, SMX_MODEL_SCVI = 2, SMX_MODEL_SISUA = 3, SMX_MODEL_SCALE = 4,
+               SMX_MODEL_FVAE = 5 } smx_model_kind;
 /* Count likelihoods selected by RVmeta.posterior (configs/base.yaml:32-40,
  * data/_single_cell_base.py:518-533). */
 typedef enum { SMX_LLK_NB = 0, SMX_LLK_ZINB = 1, SMX_LLK_NBD = 2, SMX_LLK_ZINBD = 3 } smx_likelihood;
@@ -65,6 +70,8 @@ typedef struct {
   int32_t n_labels, label_dim[SMX_MAX_LABELS], label_llk[SMX_MAX_LABELS];
   int32_t label_components[SMX_MAX_LABELS];   /* SMX_LABEL_MIXNB: mixture components (MISA n_components, vae.py:77) */
   int32_t n_components;                /* SMX_MODEL_SCALE: components of the mixture prior (scale.py:27), 1..32 */
+  int32_t disc_units, disc_layers;     /* SMX_MODEL_FVAE: hidden width / hidden layers of the discriminator (odin: 1000, 5) */
+  float gamma, disc_leak;              /* SMX_MODEL_FVAE: weight of the TC term (6.0); leaky-ReLU slope (0.2) */
   int32_t batchnorm;                   /* NetConf.batchnorm */
   int32_t log_norm;                    /* single_cell_model.py:82 */
   int32_t latent_activation;           /* dca only */
@@ -84,6 +91,7 @@ typedef struct {
   float grad_norm_max;   /* largest per-tensor gradient norm before clipping */
   int32_t nan_flag;      /* non-zero if any of the above is not finite */
   int32_t step;          /* optimiser step count after this call */
+  float tc, dtc_loss;    /* SMX_MODEL_FVAE: total-correlation estimate mean d(z); the discriminator's loss (0 otherwise) */
 } smx_metrics;
 
 typedef struct smx_model smx_model;

@@ -26,6 +26,8 @@ Reference call sites each function follows:
 * ``_scvi_*``              sisua/models/scvi.py:33-171
 * DCA latent               sisua/models/dca.py:13-28
 * SISUA label heads        sisua/models/vae.py:19-44, configs/base.yaml:6,38-43
+* FactorVAE / SemiFVAE     sisua/models/fvae.py:9-18 (thin subclasses of odin's factorVAE / SemifactorVAE, absent):
+                           Kim & Mnih 2018, Algorithm 2, see ``_factor_forward``
 * ``adam_update``          configs/base.yaml:45-50 (adam, lr 1e-3, clipnorm 100)
 * ``split_indices`` etc.   sisua/data/*, sisua/train.py:118-147
 """
@@ -50,6 +52,7 @@ STREAM_ENCL_DROPOUT = 32   # + layer index
 STREAM_DEC_DROPOUT = 48    # + layer index
 STREAM_EPS_Z = 64
 STREAM_EPS_L = 65
+STREAM_PERMUTE = 66        # fvae: uniforms whose per-dimension ranks are the permute_dims permutations
 
 LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
 LABEL_LIKELIHOODS = ("nb", "onehot", "mixnb2", "mixnb3", "mixnb4")   # mixnbC: MISA's C-component mixture of NB per label
@@ -73,7 +76,14 @@ class Spec:
   """Configuration of one model; mirrors the ctor surface of
   SingleCellModel / SCVI / SISUA / DeepCountAutoencoder
   (single_cell_model.py:74-97, scvi.py:33-48, vae.py:40-44, dca.py:16-28)."""
-  model: str = "vae"                  # 'vae' | 'dca' | 'scvi' | 'sisua' (MISA = sisua with 'mixnbC' label heads) | 'scale'
+  model: str = "vae"                  # 'vae' | 'dca' | 'scvi' | 'sisua' (MISA = sisua with 'mixnbC' label heads) | 'scale' | 'fvae'
+  # fvae (fvae.py:9-18; Kim & Mnih 2018): total-correlation discriminator on z -- disc_layers hidden layers of disc_units
+  # leaky-ReLU(disc_leak) units, no BatchNorm / dropout; gamma weighs the TC term.  One 'onehot' label variable makes it
+  # the semi-supervised form (SemiFVAE): the discriminator has one logit per class, its TC logit is their logsumexp.
+  disc_units: int = 1000
+  disc_layers: int = 5
+  gamma: float = 6.0
+  disc_leak: float = 0.2
   n_components: int = 10              # scale: components of the Gaussian-mixture prior (scale.py:27)
   n_genes: int = 0
   likelihood: str = "zinb"
@@ -101,14 +111,17 @@ class Spec:
   seed: int = 8
 
   def __post_init__(self):
-    assert self.model in ("vae", "dca", "scvi", "sisua", "scale"), self.model
+    assert self.model in ("vae", "dca", "scvi", "sisua", "scale", "fvae"), self.model
     assert 1 <= self.n_components <= 32
     assert self.likelihood in LIKELIHOODS, self.likelihood
     if self.model == "scvi":
       assert self.likelihood in ("nbd", "zinbd")  # scvi.py:50-52
     for _, llk in self.labels:
       assert llk in LABEL_LIKELIHOODS, llk
-    if self.model != "sisua":
+    if self.model == "fvae":
+      assert len(self.labels) <= 1 and all(llk == "onehot" for _, llk in self.labels), "SemiFVAE: one 'onehot' label variable"
+      assert self.disc_layers >= 1 and self.disc_units >= 1 and 0.0 <= self.disc_leak < 1.0
+    elif self.model != "sisua":
       assert len(self.labels) == 0
 
   @property
@@ -122,6 +135,11 @@ class Spec:
   @property
   def stochastic(self) -> bool:
     return self.model != "dca"
+
+  @property
+  def disc_outputs(self) -> int:
+    """Logits of the fvae discriminator: 1 (FVAE) or the number of classes (SemiFVAE)."""
+    return self.labels[0][0] if self.labels else 1
 
 
 def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
@@ -152,6 +170,12 @@ def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
     out.append(("latl/W", (hl, 2)))
     out.append(("latl/b", (2,)))
   hd = mlp("dec", D, spec.dec_units)
+  if spec.model == "fvae":   # the discriminator: Dense + bias, never BatchNorm
+    n_in = D
+    for i in range(spec.disc_layers):
+      out += [(f"disc{i}/W", (n_in, spec.disc_units)), (f"disc{i}/b", (spec.disc_units,))]
+      n_in = spec.disc_units
+    out += [("discout/W", (n_in, spec.disc_outputs)), ("discout/b", (spec.disc_outputs,))]
   if spec.model == "scvi":
     # three separate Dense heads (scvi.py:67-86): MeanScale, Dispersion,
     # DropoutLogits -- separate tensors for per-tensor clipnorm.
@@ -161,7 +185,7 @@ def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
   else:
     out.append(("out/W", (hd, spec.k * G)))
     out.append(("out/b", (spec.k * G,)))
-  for j, (P, llk) in enumerate(spec.labels):
+  for j, (P, llk) in enumerate(() if spec.model == "fvae" else spec.labels):   # (SemiFVAE's labels go to the discriminator)
     ky = label_planes(llk)
     out.append((f"lab{j}/W", (hd, ky * P)))
     out.append((f"lab{j}/b", (ky * P,)))
@@ -286,13 +310,23 @@ class PhiloxNoise:
   def normal(self, stream: int, n_cols: int):
     return philox_normal(self.seed, stream, self.step, self.cell_ids, n_cols, self.sample)
 
+  def uniform(self, stream: int, n_cols: int):
+    """u = (word >> 8) 2^-24 (float32, exact), the same uniform the dropout decision uses."""
+    w = _philox_words(self.seed, stream, self.step, self.cell_ids, n_cols, self.sample)[:, :n_cols]
+    return (w >> np.uint32(8)).astype(np.float64) * 2.0 ** -24
+
 
 class InjectedNoise:
   """Noise given explicitly (parity runs, smx_set_noise)."""
 
-  def __init__(self, dropout: Dict[int, np.ndarray] = None, normal: Dict[int, np.ndarray] = None):
+  def __init__(self, dropout: Dict[int, np.ndarray] = None, normal: Dict[int, np.ndarray] = None,
+               uniform: Dict[int, np.ndarray] = None):
     self._d = dropout or {}
     self._n = normal or {}
+    self._u = uniform or {}
+
+  def uniform(self, stream, n_cols):
+    return np.asarray(self._u[stream], dtype=np.float64)
 
   def dropout(self, stream, n_cols, p):
     if p <= 0.0:
@@ -457,6 +491,71 @@ def _mlp_bwd(spec, params, prefix, units, caches, dh, grads, training):
 
 
 # --------------------------------------------------------------------------
+# FactorVAE (sisua/models/fvae.py:9-18 -> odin factorVAE / SemifactorVAE, absent; Kim & Mnih 2018 "Disentangling by
+# Factorising", Algorithm 2).  Frozen reading [3P-recall]:
+# * discriminator D: z -> disc_layers x Dense(disc_units) + leaky_relu(0.2) -> Dense(n_out); n_out = 1 logit d(z) (the
+#   two-logit softmax form of the paper with d = l0 - l1), or one logit per class with d = logsumexp (SemiFVAE,
+#   ss_strategy 'logsumexp');
+# * VAE objective   J_vae = -ELBO + gamma mean_b d(z_b) [+ alpha mean_b mask_b CE(y_b, logits_b)], gradient with
+#   respect to the VAE's tensors only (the discriminator is a fixed function in it);
+# * discriminator objective  J_d = 1/2 [mean softplus(-d(z)) + mean softplus(d(z_perm))] [+ the same supervised term],
+#   z detached, gradient with respect to the discriminator's tensors only; z_perm = permute_dims(z): every latent
+#   dimension permuted over the minibatch independently;
+# * both objectives are evaluated at the same parameters and the same z (Algorithm 2 reuses the z of the VAE step for
+#   the discriminator step), and each tensor takes one Adam step per minibatch -- the reference's two optimisers
+#   (identical Adam settings) are then one optimiser over the union of the tensors, since clipnorm and Adam are per tensor.
+# --------------------------------------------------------------------------
+def permute_dims(z, u):
+  """z_perm[rank_d(b), d] = z[b, d], rank_d(b) = position of (u[b, d], b) in the sorted column d of u."""
+  zp = np.empty_like(z)
+  for d in range(z.shape[1]):
+    order = np.argsort(u[:, d], kind="stable")     # ties (probability ~ B^2 2^-24) broken by row index
+    zp[:, d] = z[order, d]
+  return zp
+
+
+def _factor_forward(spec: Spec, params, z, u, y=None, mvec=None):
+  B = z.shape[0]
+  h = np.concatenate([z, permute_dims(z, u)], axis=0)            # rows [0, B): z; rows [B, 2B): z_perm
+  caches = []
+  for i in range(spec.disc_layers):
+    pre = h @ params[f"disc{i}/W"] + params[f"disc{i}/b"]
+    caches.append(dict(h_in=h, slope=np.where(pre > 0, 1.0, spec.disc_leak)))
+    h = np.where(pre > 0, pre, spec.disc_leak * pre)
+  logits = h @ params["discout/W"] + params["discout/b"]         # [2B, n_out]
+  mx = logits.max(1, keepdims=True)
+  d = (mx + np.log(np.exp(logits - mx).sum(1, keepdims=True)))[:, 0]
+  sm = np.exp(logits - d[:, None])                                # softmax = d logsumexp / d logits (1 when n_out = 1)
+  tc = d[:B]
+  dloss = 0.5 * (softplus(-d[:B]) + softplus(d[B:]))
+  sup = np.zeros(B)
+  dsup = np.zeros_like(logits)
+  if spec.labels:
+    yy = np.asarray(y, dtype=np.float64)
+    sup = -mvec * (yy * (logits[:B] - d[:B, None])).sum(1)        # masked cross-entropy against the one-hot label
+    dsup[:B] = mvec[:, None] * (sm[:B] * yy.sum(1, keepdims=True) - yy)
+  return dict(h_last=h, caches=caches, logits=logits, d=d, sm=sm, tc=tc, dloss=dloss, sup=sup, dsup=dsup)
+
+
+def _factor_backward(spec: Spec, params, f, up, grads=None):
+  """Upstream `up` [rows, n_out] on the logits of the first `rows` rows; fills `grads` with the discriminator's
+  gradients when given; returns d objective / d (input rows)."""
+  rows = up.shape[0]
+  if grads is not None:
+    grads["discout/W"] = f["h_last"][:rows].T @ up
+    grads["discout/b"] = up.sum(0)
+  dh = up @ params["discout/W"].T
+  for i in reversed(range(spec.disc_layers)):
+    c = f["caches"][i]
+    dpre = dh * c["slope"][:rows]
+    if grads is not None:
+      grads[f"disc{i}/W"] = c["h_in"][:rows].T @ dpre
+      grads[f"disc{i}/b"] = dpre.sum(0)
+    dh = dpre @ params[f"disc{i}/W"].T
+  return dh
+
+
+# --------------------------------------------------------------------------
 # Full forward (+ backward) of one minibatch
 # --------------------------------------------------------------------------
 def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndarray] = (),
@@ -548,7 +647,12 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
   llk_y = np.zeros(B)
   lab_raw, lab_d = [], []
   mvec = np.zeros(B) if mask is None else np.asarray(mask, dtype=np.float64).reshape(B)
-  for j, (P, kind) in enumerate(spec.labels):
+  fac = None
+  if spec.model == "fvae":
+    fac = _factor_forward(spec, params, z, noise.uniform(STREAM_PERMUTE, D), y[0] if spec.labels else None, mvec)
+    llk_y = -fac["sup"]      # (already masked; the mask is idempotent below)
+    out.update(disc_logits=fac["logits"])
+  for j, (P, kind) in enumerate(() if spec.model == "fvae" else spec.labels):
     rawy = d @ params[f"lab{j}/W"] + params[f"lab{j}/b"]
     ly, dly = label_llk(np.asarray(y[j], dtype=np.float64), rawy, kind)
     llk_y = llk_y + ly
@@ -558,11 +662,15 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
 
   # ---- ELBO (SURVEY a-15) ----------------------------------------------------
   elbo = llk_x + spec.alpha * mvec * llk_y - spec.beta * (kl + kl_l)
-  out.update(loss=float(-elbo.mean()), elbo=elbo, llk_x=llk_x, llk_y=llk_y, kl=kl, kl_l=kl_l,
-             metrics=dict(loss=float(-elbo.mean()), nllk_x=float(-llk_x.mean()),
-                          nllk_y=float(-(mvec * llk_y).mean()), kl=float(kl.mean()),
-                          kl_l=float(kl_l.mean())),
-             new_bn=new_bn)
+  loss = float(-elbo.mean())
+  metrics = dict(loss=loss, nllk_x=float(-llk_x.mean()), nllk_y=float(-(mvec * llk_y).mean()), kl=float(kl.mean()),
+                 kl_l=float(kl_l.mean()))
+  if fac is not None:
+    loss = loss + spec.gamma * float(fac["tc"].mean())           # J_vae
+    dtc = float(fac["dloss"].mean() + spec.alpha * fac["sup"].mean())   # J_d
+    metrics.update(loss=loss, tc=float(fac["tc"].mean()), dtc_loss=dtc)
+    out.update(dtc_loss=dtc)
+  out.update(loss=loss, elbo=elbo, llk_x=llk_x, llk_y=llk_y, kl=kl, kl_l=kl_l, metrics=metrics, new_bn=new_bn)
   if not backward:
     return out
 
@@ -571,7 +679,7 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
   c_x = -1.0 / B                       # d loss / d llk_x[b]
   c_kl = spec.beta / B                 # d loss / d kl[b]
   dd = np.zeros_like(d)
-  for j, (P, kind) in enumerate(spec.labels):
+  for j, (P, kind) in enumerate(() if spec.model == "fvae" else spec.labels):
     draw = lab_d[j] * (c_x * spec.alpha * mvec)[:, None]
     grads[f"lab{j}/W"] = d.T @ draw
     grads[f"lab{j}/b"] = draw.sum(0)
@@ -597,6 +705,13 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
     dd += draw_all @ params["out/W"].T
     out["d_x_params"] = [draw_all[:, c * G:(c + 1) * G] for c in range(k)]
   dz = _mlp_bwd(spec, params, "dec", spec.dec_units, dec_c, dd, grads, training)
+  if fac is not None:
+    sm, dsup, dlog = fac["sm"], fac["dsup"], fac["d"]
+    # J_vae through the (fixed) discriminator into z: rows [0, B) only
+    dz = dz + _factor_backward(spec, params, fac, (spec.gamma / B) * sm[:B] + (spec.alpha / B) * dsup[:B])
+    # J_d into the discriminator's tensors: z and z_perm are constants of it
+    up = np.concatenate([(-0.5 / B) * expit(-dlog[:B])[:, None] * sm[:B], (0.5 / B) * expit(dlog[B:])[:, None] * sm[B:]], axis=0)
+    _factor_backward(spec, params, fac, up + (spec.alpha / B) * dsup, grads)
 
   if spec.model == "scale":
     r_, dzm, s_c = scale_c["resp"], scale_c["dzm"], scale_c["s"]
@@ -752,7 +867,8 @@ def dp_train_step(spec, params, bn_state, opt, x, rank_rows, step, cell_base=0, 
                             y=[a[rows] for a in y], library=None if library is None else library[rows],
                             mask=None if mask is None else mask[rows])
 
-  if sync_bn or not spec.batchnorm:
+  assert not (sync_bn and spec.model == "fvae"), "fvae permutes z within a rank's minibatch: no single-process equivalent"
+  if (sync_bn or not spec.batchnorm) and spec.model != "fvae":
     res = run(np.concatenate(rank_rows))
     grads, new_bn, metrics = res["grads"], res["new_bn"], res["metrics"]
   else:

@@ -100,6 +100,11 @@ class ModelConfig:
   clipnorm: float = 100.0
   seed: int = 8
   n_components: int = 10   # model 'scale': components of the Gaussian-mixture prior
+  # model 'fvae' (sisua/models/fvae.py:9-18; odin factorVAE defaults): the total-correlation discriminator
+  disc_units: int = 1000
+  disc_layers: int = 5
+  gamma: float = 6.0
+  disc_leak: float = 0.2
 
   @property
   def k(self) -> int:
@@ -108,6 +113,15 @@ class ModelConfig:
   @property
   def stochastic(self) -> bool:
     return self.model != "dca"
+
+  @property
+  def disc_outputs(self) -> int:
+    return self.labels[0][0] if self.labels else 1
+
+  @property
+  def head_labels(self):
+    """Label variables that have a head on the decoder (SemiFVAE's one-hot labels are classified by the discriminator)."""
+    return () if self.model == "fvae" else self.labels
 
   def to_dict(self):
     return dataclasses.asdict(self)
@@ -140,12 +154,18 @@ def manifest(cfg: ModelConfig) -> List[Tuple[str, Tuple[int, ...]]]:
     hl = mlp("encl", G, cfg.encl_units)
     out += [("latl/W", (hl, 2)), ("latl/b", (2,))]
   hd = mlp("dec", D, cfg.dec_units)
+  if cfg.model == "fvae":   # discriminator on z: Dense + bias, never BatchNorm
+    n_in = D
+    for i in range(cfg.disc_layers):
+      out += [(f"disc{i}/W", (n_in, cfg.disc_units)), (f"disc{i}/b", (cfg.disc_units,))]
+      n_in = cfg.disc_units
+    out += [("discout/W", (n_in, cfg.disc_outputs)), ("discout/b", (cfg.disc_outputs,))]
   if cfg.model == "scvi":
     for c in range(cfg.k):
       out += [(f"out{c}/W", (hd, G)), (f"out{c}/b", (G,))]
   else:
     out += [("out/W", (hd, cfg.k * G)), ("out/b", (cfg.k * G,))]
-  for j, (P, llk) in enumerate(cfg.labels):
+  for j, (P, llk) in enumerate(cfg.head_labels):
     ky = label_planes(llk)
     out += [(f"lab{j}/W", (hd, ky * P)), (f"lab{j}/b", (ky * P,))]
   return out

@@ -1,0 +1,111 @@
+// smx_factor.hip -- the two small kernels of the FactorVAE discriminator (sisua/models/fvae.py:9-18: FVAE / SemiFVAE
+// are thin subclasses of odin's factorVAE / SemifactorVAE; the algorithm is Kim & Mnih 2018, Algorithm 2).  The
+// discriminator's Dense layers run on the generic products (smx_gemm.hip) and the bias + leaky-ReLU launches
+// (smx_kernels.hip); what is specific is
+//   permute_dims_kernel   z_perm: every latent dimension permuted over the minibatch independently.  The permutation of
+//                         dimension d is the rank of the cell's Philox uniform u[cell][d] within column d (ties by row),
+//                         so it depends on (seed, step, cell ids) only and the oracle draws the same one;
+//   disc_head_kernel      logits -> d = logsumexp (one logit: d itself), the total-correlation estimate d(z), the
+//                         discriminator's loss 1/2 [softplus(-d(z)) + softplus(d(z_perm))], SemiFVAE's masked
+//                         cross-entropy, and the two upstream gradients (VAE objective on the rows of z, discriminator
+//                         objective on all 2B rows).
+// Both are HBM-trivial ([B][D] and [2B][<= 32] floats); they exist to keep the step on the device.
+#include "smx_internal.h"
+#include "smx_device.h"
+#include "../../include/sisua_hip.h"
+
+namespace smx {
+
+__global__ __launch_bounds__(256) void permute_dims_kernel(PermuteArgs a) {
+  extern __shared__ float us[];   // [B] uniforms of this latent dimension
+  const int d = blockIdx.x;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    float u;
+    if (a.inj_u) u = a.inj_u[(long)b * a.inj_ld + d];
+    else {
+      const uint32_t cell = a.cell_base + (uint32_t)(a.rows ? a.rows[b] : b);
+      const U4 w = philox_block(a.nk, cell, (uint32_t)(d >> 2));
+      const int q = d & 3;
+      u = u24(q == 0 ? w.x : q == 1 ? w.y : q == 2 ? w.z : w.w);
+    }
+    us[b] = u;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    const float u = us[b];
+    int rank = 0;
+    for (int o = 0; o < a.B; ++o) {
+      const float v = us[o];
+      rank += (v < u || (v == u && o < b)) ? 1 : 0;
+    }
+    const float zv = a.z[(long)b * a.ldz + d];
+    a.zz[(long)b * a.ld + d] = zv;
+    a.zz[(long)(a.B + rank) * a.ld + d] = zv;
+  }
+}
+
+int launch_permute_dims(hipStream_t st, const PermuteArgs& a) {
+  if (a.B <= 0 || a.D <= 0 || a.D > a.ld || (size_t)a.B * sizeof(float) > 64 * 1024) { set_error("permute_dims: bad shapes"); return SMX_ERR_INVALID; }
+  hipLaunchKernelGGL(permute_dims_kernel, dim3(a.D), dim3(256), (size_t)a.B * sizeof(float), st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// one thread per row of the stacked batch [z ; z_perm]
+__global__ __launch_bounds__(256) void disc_head_kernel(DiscHeadArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= 2 * a.B) return;
+  float l[32];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    float v = 0.f;
+    if (j < a.n_out) {
+      v = a.bias[j];
+      for (int s = 0; s < a.n_slabs; ++s) v += a.logits[(long)s * a.slab_stride + (long)r * a.ld + j];
+      mx = fmaxf(mx, v);
+    }
+    l[j] = v;
+  }
+  float se = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) if (j < a.n_out) se += expf(l[j] - mx);
+  const float d = mx + logf(se);
+  const bool real = r < a.B;
+  if (real) a.tc_cell[r] = d;
+  a.dl_cell[r] = 0.5f * softplusf(real ? -d : d);
+  float mk = 0.f, ysum = 0.f, ce = 0.f;
+  const float* y = nullptr;
+  if (real && a.Y) {
+    const long row = a.rows ? a.rows[r] : r;
+    mk = (a.mask && a.mask[row]) ? 1.f : 0.f;
+    y = a.Y + row * a.ldy;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) if (j < a.n_out) { ysum += y[j]; ce -= y[j] * (l[j] - d); }
+    a.llk_y[r] = -mk * ce;
+  } else if (real && a.llk_y) a.llk_y[r] = 0.f;
+  if (!a.backward) return;
+  // d J_d / d d(row): -1/2 sigmoid(-d) on the rows of z, +1/2 sigmoid(d) on the permuted rows (means over the global batch)
+  const float gd = (real ? -0.5f / (1.f + expf(d)) : 0.5f / (1.f + expf(-d))) * a.inv_gb;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    float ut = 0.f, ud = 0.f;
+    if (j < a.n_out) {
+      const float sm = expf(l[j] - d);                                        // softmax = d logsumexp / d logit (1 for one logit)
+      const float sup = (y != nullptr) ? a.alpha * a.inv_gb * mk * (sm * ysum - y[j]) : 0.f;
+      ut = a.gamma * a.inv_gb * sm + sup;
+      ud = gd * sm + sup;
+    }
+    if (real) a.u_tc[(long)r * 32 + j] = ut;
+    a.u_d[(long)r * 32 + j] = ud;
+  }
+}
+
+int launch_disc_head(hipStream_t st, const DiscHeadArgs& a) {
+  if (a.B <= 0 || a.n_out < 1 || a.n_out > 32 || a.ld < a.n_out) { set_error("disc_head: bad shapes"); return SMX_ERR_INVALID; }
+  hipLaunchKernelGGL(disc_head_kernel, dim3((2 * a.B + 255) / 256), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+}  // namespace smx

@@ -231,13 +231,14 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
     const int d = n0 + wn * 32 + li;
     const bool live = d < e.D;
     // all loads first (independent, in flight together), then the arithmetic, then the stores
-    float mu[RPW], sr[RPW], sg[RPW], ep[RPW], dk[RPW];
+    float mu[RPW], sr[RPW], sg[RPW], ep[RPW], dk[RPW], za[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
       const int r = r_base + j;
       const int b = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const bool ok = live && b < g.M;
       dk[j] = (ok && e.dklz) ? e.dklz[(long)b * e.Dp + d] : 0.f;
+      za[j] = (ok && e.dz_add) ? e.dz_add[(long)b * e.Dp + d] : 0.f;
       mu[j] = ok ? e.lat[(long)b * e.ld + d] : 0.f;
       sr[j] = (ok && e.stochastic) ? e.lat[(long)b * e.ld + e.Dp + d] : 0.f;
       sg[j] = (ok && e.stochastic) ? e.sig[(long)b * e.Dp + d] : 1.f;
@@ -246,7 +247,7 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
     float o0[RPW], o1[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
-      const float dz = out[j];
+      const float dz = out[j] + za[j];
       if (e.stochastic && e.dklz) {   // SCALE: Monte-Carlo KL, log q depends on (sigma, eps) only
         const float dzt = dz + e.kl_scale * dk[j];
         o0[j] = live ? dzt : 0.f;

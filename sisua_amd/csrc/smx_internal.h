@@ -49,6 +49,8 @@ struct EpiLatentBwd {
   float* dlat = nullptr;                             // [B][ld]
   // SCALE (Monte-Carlo KL against the mixture prior): d(-log p)/dz [B][Dp] from scale_prior_fwd; nullptr: analytic KL
   const float* dklz = nullptr;
+  // FactorVAE: gradient of the total-correlation term with respect to z [B][Dp], added to the product's d z
+  const float* dz_add = nullptr;
 };
 
 struct GemmArgs {
@@ -150,6 +152,7 @@ struct BnFwdArgs {
   // also stores z / sigma / eps / KL for the backward pass) and the layer's product pre = z W as dot products
   // (K = Dp <= 64: 64 fmas per output row and thread), so the latent kernel and the product kernel disappear
   int front = 0; LatentArgs lat; const float* W = nullptr; int ldw = 0;
+  float leak = 0.f;   // activation max(y, 0) + leak min(y, 0): 0 = ReLU; the FactorVAE discriminator's leaky ReLU uses 0.2
 };
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a);
 bool bn_front_supported(int B, int Dp);
@@ -173,6 +176,9 @@ struct MetricsArgs {
   // per-step history of a train_steps call (single GPU: written here; data parallel: by the optimiser launch,
   // after the all-reduce): hist[cursor * 8 + i] = out[i]
   float* hist = nullptr; const StepState* state = nullptr;
+  // FactorVAE: tc [B] = d(z_b); dl [2B] = the discriminator's per-row loss; out[5] = mean tc, out[6] = discriminator
+  // objective (mean dl pairs - alpha mean llk_y), out[0] += gamma mean tc
+  const float* tc = nullptr; const float* dl = nullptr; float gamma = 0.f;
 };
 int launch_metrics(hipStream_t st, const MetricsArgs& a);
 
@@ -220,6 +226,7 @@ struct BnBwdArgs {
   // instead of being read from a slab another launch wrote
   int front = 0; const float* fD = nullptr; int fld = 0; const float* fW = nullptr; int fldw = 0; int fK = 0;
   int diag = 0;   // SMX_BN_DIAG bits 16 / 32 / 64: skip the front's dot products / tile load / W row load (timing only)
+  float leak = 0.f;   // slope of the activation for out <= 0 (layers without dropout only)
 };
 bool bn_bwd_front_supported(int B, int K);
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a);
@@ -407,6 +414,32 @@ struct WgradProblem {
 struct WgradGroup { int n; int B; WgradProblem p[SMX_GROUP_MAX]; };
 bool wgrad_supported(const GemmArgs& g, int B);
 int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B);
+
+// ---- FactorVAE discriminator (smx_factor.hip; sisua/models/fvae.py:9-18, Kim & Mnih 2018 Algorithm 2) -------------
+enum { ST_PERMUTE = 66 };   // Philox stream of the permute_dims uniforms
+struct PermuteArgs {
+  const float* z = nullptr; int ldz = 0;     // latent sample [B][ldz]
+  float* zz = nullptr; int ld = 0;           // [2B][ld]: rows [0, B) = z, rows [B, 2B) = z with every column permuted over the batch
+  int B = 0, D = 0;
+  NoiseKey nk{0, 0, 0, 0, nullptr};
+  const int32_t* rows = nullptr; uint32_t cell_base = 0;
+  const float* inj_u = nullptr; int inj_ld = 0;   // injected uniforms [B][inj_ld] (smx_set_noise stream 66)
+};
+int launch_permute_dims(hipStream_t st, const PermuteArgs& a);
+
+struct DiscHeadArgs {
+  const float* logits = nullptr; int n_slabs = 1; long slab_stride = 0; int ld = 0;   // [S][2B][ld] split-K slabs of h W_out
+  const float* bias = nullptr; int n_out = 1; int B = 0;
+  float gamma = 0.f, alpha = 0.f, inv_gb = 0.f;
+  int backward = 1;
+  const float* Y = nullptr; int ldy = 0; const int32_t* rows = nullptr; const uint8_t* mask = nullptr;   // SemiFVAE: resident one-hot labels
+  float* u_tc = nullptr;     // [B][32]  d J_vae / d logits (rows of z)
+  float* u_d = nullptr;      // [2B][32] d J_d / d logits
+  float* tc_cell = nullptr;  // [B]  d(z_b)
+  float* dl_cell = nullptr;  // [2B] 1/2 softplus(-d(z_b)) | 1/2 softplus(d(z_perm_b))
+  float* llk_y = nullptr;    // [B] -mask CE (SemiFVAE) or nullptr
+};
+int launch_disc_head(hipStream_t st, const DiscHeadArgs& a);
 
 // ---- dataset kernels (smx_data.hip) ------------------------------------------------------------
 enum { ST_CORRUPT_SELECT = 80, ST_CORRUPT_BINOMIAL = 81 };   // Philox streams of the on-device corruption

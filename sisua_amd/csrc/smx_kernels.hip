@@ -403,6 +403,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
     }
     if (a.batchnorm || SMALL) a.xhat[o] = v;
     float h = fmaxf(y, 0.f);
+    if (a.leak != 0.f) h += a.leak * fminf(y, 0.f);
     if (drop) {
       float mult;
       if (a.inj_mask) mult = a.inj_mask[(long)r * a.inj_ld + col];
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
       if (r < a.B) {
         const long o = (long)r * a.Hp + col;
         dy = (live && a.out[o] > 0.f) ? acc[i] * a.drop_scale : 0.f;
+        if (a.leak != 0.f && live && !(a.out[o] > 0.f)) dy = acc[i] * a.leak;
         if (a.batchnorm) xh = a.xhat[o];
         if (!SMALL) a.dpre[o] = dy;
         s1 += dy;
@@ -1385,7 +1387,7 @@ int launch_step_begin(hipStream_t st, StepState* master, StepState* dst, const i
 
 __device__ inline void metrics_body(const MetricsArgs& a) {
   __shared__ float sh[4];
-  float sx = 0.f, sy = 0.f, sk = 0.f, sl = 0.f;
+  float sx = 0.f, sy = 0.f, sk = 0.f, sl = 0.f, st = 0.f, sd = 0.f;
   // only the batch total of the count log-likelihood is needed: a flat, coalesced sweep of [B][n_chunks]
   const int total = a.B * a.n_chunks;
   {
@@ -1403,16 +1405,18 @@ __device__ inline void metrics_body(const MetricsArgs& a) {
     if (a.llk_y) sy += a.llk_y[b];
     if (a.kl) sk += a.kl[b];
     if (a.kl_l) sl += a.kl_l[b];
+    if (a.tc) { st += a.tc[b]; sd += a.dl[b] + a.dl[a.B + b]; }
   }
   sx = block_sum(sx, sh); sy = block_sum(sy, sh); sk = block_sum(sk, sh); sl = block_sum(sl, sh);
+  if (a.tc) { st = block_sum(st, sh); sd = block_sum(sd, sh); }
   if (threadIdx.x == 0) {
     const float s = a.inv_global_batch;
-    a.out[0] = -(sx + a.alpha * sy - a.beta * (sk + sl)) * s;
+    a.out[0] = (a.gamma * st - (sx + a.alpha * sy - a.beta * (sk + sl))) * s;
     a.out[1] = -sx * s;
     a.out[2] = -sy * s;
     a.out[3] = sk * s;
     a.out[4] = sl * s;
-    a.out[5] = 0.f; a.out[6] = 0.f; a.out[7] = 0.f;
+    a.out[5] = st * s; a.out[6] = a.tc ? (sd - a.alpha * sy) * s : 0.f; a.out[7] = 0.f;
     if (a.hist) {
       float* h = a.hist + (long)a.state->cursor * 8;
 #pragma unroll

@@ -67,6 +67,7 @@ struct MlpLayer {
   int bn = -1;
   int stream = 0;
   float drop_p = 0.f;
+  float leak = 0.f;         // activation slope for y <= 0 (0: ReLU; the FactorVAE discriminator: 0.2)
   float *xhat = nullptr, *out_buf = nullptr, *inv_std = nullptr, *dpre = nullptr;
   float* noise = nullptr;   // [Bmax][out_p] dropout multipliers produced ahead of the layer (fused small-layer path)
 };
@@ -258,7 +259,12 @@ struct smx_model {
   // sum-of-squares slots written by the weight-gradient products (per-tensor clipnorm without a separate pass)
   float* sq_slots = nullptr; std::vector<int> sq_first, sq_count;   // this step's output head ran as the fused kernel (smx_head.hip)
   int G = 0, Gp = 0, D = 0, Dp = 0, k = 0, Bmax = 0;
-  bool stochastic = true, scvi = false, scale = false;
+  bool stochastic = true, scvi = false, scale = false, fvae = false;
+  int n_heads = 0;                    // label heads on the decoder (0 for fvae: SemiFVAE's labels go to the discriminator)
+  // fvae: discriminator on z (smx_factor.hip)
+  std::vector<MlpLayer> disc; int t_discoutW = -1, t_discoutb = -1;
+  float *zz = nullptr, *u_tc = nullptr, *u_d = nullptr, *tc_cell = nullptr, *dl_cell = nullptr, *dz_tc = nullptr;
+  float *disc_dpre = nullptr, *disc_db = nullptr;
   int t_prLogits = -1, t_prLoc = -1, t_prScale = -1;    // scale: Gaussian-mixture prior
   float *resp = nullptr, *dklz = nullptr;
   std::vector<TensorInfo> tensors;
@@ -349,13 +355,13 @@ int add_tensor(smx_model* m, const std::string& name, int rows, int cols, int ch
 }
 
 int build_mlp(smx_model* m, std::vector<MlpLayer>& mlp, const char* prefix, int n_in, int n, const int32_t* units,
-              int stream0, float drop_p) {
+              int stream0, float drop_p, bool batchnorm, float leak = 0.f) {
   for (int i = 0; i < n; ++i) {
     MlpLayer L;
     L.in = n_in; L.in_p = round_up(n_in, 32); L.out = units[i]; L.out_p = round_up(units[i], 32);
     std::string p = std::string(prefix) + std::to_string(i);
     L.tW = add_tensor(m, p + "/W", n_in, units[i], 1, false);
-    if (m->cfg.batchnorm) {
+    if (batchnorm) {
       L.tGamma = add_tensor(m, p + "/gamma", 1, units[i], 1, true);
       L.tBeta = add_tensor(m, p + "/beta", 1, units[i], 1, true);
       L.bn = (int)m->bn_w.size();
@@ -363,7 +369,7 @@ int build_mlp(smx_model* m, std::vector<MlpLayer>& mlp, const char* prefix, int 
     } else {
       L.tBias = add_tensor(m, p + "/b", 1, units[i], 1, true);
     }
-    L.stream = stream0 + i; L.drop_p = drop_p;
+    L.stream = stream0 + i; L.drop_p = drop_p; L.leak = leak;
     mlp.push_back(L);
     n_in = units[i];
   }
@@ -450,9 +456,9 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     static const bool no_fz = getenv("SMX_SMALL_FUSION") == nullptr;
     static const bool no_ahead = getenv("SMX_NO_NOISE_AHEAD") != nullptr;
     const bool ahead = !no_fz && !no_ahead && !m->scvi;
-    const bool sync = sync_bn_on(m, ps.training);
+    const bool sync = sync_bn_on(m, ps.training) && L.bn >= 0;
     const bool with_front = (front != nullptr && i == 0);   // the BatchNorm launch produces its own input (latent sample + product)
-    const bool fuse = !no_fz && !sync && !with_front && !(i == 0 && in_is_x) && dense_bn_fusable(ps.B, L.in_p);
+    const bool fuse = !no_fz && !sync && !with_front && !(i == 0 && in_is_x) && L.leak == 0.f && dense_bn_fusable(ps.B, L.in_p);
     int eff = 1;
     SMX_REQUIRE((size_t)std::max(g.split_k, 1) * (size_t)g.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
     if (!fuse && !with_front) {
@@ -461,8 +467,8 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     }
     BnFwdArgs b;
     b.pre = m->slab; b.n_slabs = eff; b.slab_stride = g.slab_stride; b.ld = L.out_p;
-    b.B = ps.B; b.H = L.out; b.Hp = L.out_p; b.batchnorm = m->cfg.batchnorm; b.training = ps.training;
-    if (m->cfg.batchnorm) {
+    b.B = ps.B; b.H = L.out; b.Hp = L.out_p; b.batchnorm = L.bn >= 0; b.training = ps.training; b.leak = L.leak;
+    if (L.bn >= 0) {
       b.gamma = P_(m, L.tGamma); b.beta = P_(m, L.tBeta);
       b.moving_mean = m->bn_moving + m->bn_off[L.bn]; b.moving_var = b.moving_mean + L.out_p;
       b.batch_mean = m->grads + m->tail_off_bn + m->bn_off[L.bn]; b.batch_var = b.batch_mean + L.out_p;
@@ -566,15 +572,15 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     BnBwdArgs b;
     b.dout = m->slab; b.n_slabs = n_slabs; b.slab_stride = (long)ps.B * L.out_p; b.ld = L.out_p;
     b.out = L.out_buf; b.xhat = L.xhat; b.inv_std = L.inv_std;
-    b.B = ps.B; b.H = L.out; b.Hp = L.out_p; b.batchnorm = m->cfg.batchnorm; b.training = ps.training;
+    b.B = ps.B; b.H = L.out; b.Hp = L.out_p; b.batchnorm = L.bn >= 0; b.training = ps.training; b.leak = L.leak;
     b.drop_scale = (ps.training && L.drop_p > 0.f) ? 1.f / (1.f - L.drop_p) : 1.f;
     b.dpre = L.dpre;
-    if (m->cfg.batchnorm) { b.gamma = P_(m, L.tGamma); b.dgamma = G_(m, L.tGamma); b.dbeta = G_(m, L.tBeta); }
+    if (L.bn >= 0) { b.gamma = P_(m, L.tGamma); b.dgamma = G_(m, L.tGamma); b.dbeta = G_(m, L.tBeta); }
     else b.dbias = G_(m, L.tBias);
     if (grad_front && i == (int)mlp.size() - 1) {
       b.front = 1; b.fD = grad_front->fD; b.fld = grad_front->fld; b.fW = grad_front->fW; b.fldw = grad_front->fldw; b.fK = grad_front->fK;
     }
-    if (sync_bn_on(m, ps.training)) {   // the ELBO scalars then go with a launch of their own (optimizer_pass)
+    if (sync_bn_on(m, ps.training) && L.bn >= 0) {   // the ELBO scalars then go with a launch of their own (optimizer_pass)
       Timed t(m, "bn_bwd");
       m->adam_early_pending = false;
       const BnSyncArgs y = sync_args(m);
@@ -727,7 +733,7 @@ bool use_head_loss(const smx_model* m, int B) {
 bool use_mid(const smx_model* m, int B) {
   // single-workgroup fusion of the middle is opt-in until it beats the per-operator path
   static const bool off = getenv("SMX_FUSED") == nullptr;
-  if (off || m->scvi || m->scale || B > 128 || m->sync_bn) return false;
+  if (off || m->scvi || m->scale || m->fvae || B > 128 || m->sync_bn) return false;
   for (auto* mlp : {&m->enc, &m->dec})
     for (auto& L : *mlp) if (L.out_p > 128) return false;
   if ((m->stochastic ? 2 : 1) * m->Dp > 128) return false;
@@ -781,6 +787,7 @@ void fill_mid_args(smx_model* m, const Pass& ps, MidArgs& a) {
 
 // mode: 0 full forward; 1 decoder only (z given in m->z); 2 resample (encoder outputs m->latbuf / m->latlbuf kept,
 // only the latent draw and everything after it run again)
+int factor_forward(smx_model* m, const Pass& ps, bool backward);
 int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, int mode = 0) {
   const bool decode_only = (mode == 1), resample = (mode == 2);
   const smx_config& c = m->cfg;
@@ -891,7 +898,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     SMX_CHECK(launch_gemm(m->st, g));
   }
   // ---- label heads (raw outputs) ----
-  for (int j = 0; j < c.n_labels; ++j) {
+  for (int j = 0; j < m->n_heads; ++j) {
     const TensorInfo& tw = m->tensors[m->t_labW[j]];
     GemmArgs g;
     g.A = dL.out_buf; g.lda = dL.out_p; g.B = P_(m, m->t_labW[j]); g.ldb = tw.ld;
@@ -947,7 +954,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     Timed t(m, "loss");
     for (int r = 0; r < reps; ++r) SMX_CHECK(launch_count_loss(m->st, lo));
   }
-  for (int j = 0; j < c.n_labels; ++j) {
+  for (int j = 0; j < m->n_heads; ++j) {
     const TensorInfo& tw = m->tensors[m->t_labW[j]];
     LabelArgs lb;
     lb.kind = c.label_llk[j]; lb.C = c.label_components[j]; lb.raw = m->laby_raw[j]; lb.ld = tw.ld; lb.Y = m->Y[j]; lb.ldy = m->lab_Pp[j];
@@ -956,9 +963,11 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     lb.backward = backward;
     SMX_CHECK(launch_label_loss(m->st, lb));
   }
+  if (m->fvae) SMX_CHECK(factor_forward(m, ps, backward));
   MetricsArgs me;
   me.llk_part = m->llk_part; me.n_chunks = n_llk_chunks; me.lgx1 = ps.lgx1; me.rows = ps.rows;
   me.llk_y = c.n_labels ? m->llk_y : nullptr;
+  if (m->fvae) { me.tc = m->tc_cell; me.dl = m->dl_cell; me.gamma = c.gamma; }
   me.kl = m->stochastic ? m->kl : nullptr; me.kl_l = m->scvi ? m->kl_l : nullptr;
   me.B = ps.B; me.alpha = c.alpha; me.beta = c.beta; me.inv_global_batch = inv_gb;
   me.out = m->grads + m->tail_off_metrics;
@@ -976,6 +985,117 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     Timed t(m, "metrics");
     SMX_CHECK(launch_metrics(m->st, me));
   }
+  return SMX_OK;
+}
+
+// ---- FactorVAE discriminator (fvae.py:9-18; Kim & Mnih 2018, Algorithm 2) -------------------------------------------
+// forward: stacked batch [z ; permute_dims(z)] through the discriminator, then the head (TC estimate, discriminator
+// loss, SemiFVAE's cross-entropy, both upstream gradients).  Runs after the latent sample exists; m->slab is free then.
+int factor_forward(smx_model* m, const Pass& ps, bool backward) {
+  const smx_config& c = m->cfg;
+  const int B = ps.B, B2 = 2 * ps.B;
+  SMX_REQUIRE(B2 <= 2 * m->Bmax, "batch exceeds max_batch");
+  PermuteArgs pa;
+  pa.z = m->z; pa.ldz = m->Dp; pa.zz = m->zz; pa.ld = m->Dp; pa.B = B; pa.D = m->D;
+  pa.nk = make_key(m, ST_PERMUTE, ps.sample, ps.training != 0);
+  pa.rows = ps.rows; pa.cell_base = ps.cell_base;
+  if (const Injected* ij = inj(m, ST_PERMUTE)) { pa.inj_u = ij->d; pa.inj_ld = ij->ld; }
+  {
+    Timed t(m, "disc_permute");
+    SMX_CHECK(launch_permute_dims(m->st, pa));
+  }
+  Pass p2 = ps;
+  p2.B = B2; p2.rows = nullptr; p2.training = 1;   // (no BatchNorm / dropout in the discriminator: the mode is immaterial)
+  SMX_CHECK(mlp_forward(m, m->disc, p2, m->zz, m->Dp, false, "disc_fwd"));
+  const MlpLayer& last = m->disc.back();
+  const TensorInfo& tw = m->tensors[m->t_discoutW];
+  GemmArgs g;
+  g.A = last.out_buf; g.lda = last.out_p; g.B = P_(m, m->t_discoutW); g.ldb = tw.ld;
+  g.M = B2; g.N = tw.ld; g.K = last.out_p;
+  g.C = m->slab; g.ldc = tw.ld; g.slab_stride = (long)B2 * tw.ld;
+  g.split_k = suggest_split_k(B2, tw.ld, last.out_p);
+  SMX_REQUIRE((size_t)std::max(g.split_k, 1) * (size_t)g.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
+  int eff = 1;
+  {
+    Timed t(m, "disc_fwd");
+    SMX_CHECK(launch_gemm(m->st, g, &eff));
+  }
+  DiscHeadArgs h;
+  h.logits = m->slab; h.n_slabs = eff; h.slab_stride = g.slab_stride; h.ld = tw.ld;
+  h.bias = P_(m, m->t_discoutb); h.n_out = tw.cols; h.B = B;
+  h.gamma = c.gamma; h.alpha = c.alpha; h.inv_gb = 1.f / (float)ps.global_batch; h.backward = backward ? 1 : 0;
+  if (c.n_labels && m->Y[0] && ps.Xsrc == m->X) { h.Y = m->Y[0]; h.ldy = m->lab_Pp[0]; h.rows = ps.rows; h.mask = m->mask; }
+  h.u_tc = m->u_tc; h.u_d = m->u_d; h.tc_cell = m->tc_cell; h.dl_cell = m->dl_cell; h.llk_y = c.n_labels ? m->llk_y : nullptr;
+  Timed t(m, "disc_head");
+  SMX_CHECK(launch_disc_head(m->st, h));
+  return SMX_OK;
+}
+
+// One backward sweep of the discriminator over the first `rows` rows of the stacked batch with upstream `up`
+// [rows][32] on the logits.  with_grads: the discriminator's own gradients (its objective; nothing flows into z);
+// otherwise only d objective / d z, left in m->dz_tc (the VAE objective's TC term; the weights are constants of it).
+int factor_sweep(smx_model* m, int rows, const float* up, bool with_grads) {
+  const MlpLayer& last = m->disc.back();
+  const TensorInfo& two = m->tensors[m->t_discoutW];
+  if (with_grads) {
+    GemmArgs gw;
+    gw.A = last.out_buf; gw.lda = last.out_p; gw.a_kmajor = 1; gw.B = up; gw.ldb = 32;
+    gw.C = G_(m, m->t_discoutW); gw.ldc = two.ld; gw.M = last.out_p; gw.N = two.ld; gw.K = rows;
+    gw.colsum = G_(m, m->t_discoutb);
+    want_sq(m, gw, m->t_discoutW);
+    Timed t(m, "disc_bwd");
+    SMX_CHECK(launch_gemm(m->st, gw));
+  }
+  int n_slabs = 1;
+  {
+    GemmArgs gh;
+    gh.A = up; gh.lda = 32; gh.B = P_(m, m->t_discoutW); gh.ldb = two.ld; gh.b_nmajor = 1;
+    gh.M = rows; gh.N = last.out_p; gh.K = two.ld;
+    gh.C = m->slab; gh.ldc = last.out_p; gh.slab_stride = (long)rows * last.out_p; gh.split_k = 1;
+    Timed t(m, "disc_bwd");
+    SMX_CHECK(launch_gemm(m->st, gh, &n_slabs));
+  }
+  for (int i = (int)m->disc.size() - 1; i >= 0; --i) {
+    MlpLayer& L = m->disc[i];
+    const TensorInfo& tw = m->tensors[L.tW];
+    BnBwdArgs b;
+    b.dout = m->slab; b.n_slabs = n_slabs; b.slab_stride = (long)rows * L.out_p; b.ld = L.out_p;
+    b.out = L.out_buf; b.B = rows; b.H = L.out; b.Hp = L.out_p; b.batchnorm = 0; b.training = 1; b.drop_scale = 1.f; b.leak = L.leak;
+    b.dpre = with_grads ? L.dpre : m->disc_dpre;
+    b.dbias = with_grads ? G_(m, L.tBias) : m->disc_db;
+    {
+      Timed t(m, "disc_bwd");
+      SMX_CHECK(launch_bn_act_bwd(m->st, b));
+    }
+    const float* in = (i == 0) ? m->zz : m->disc[i - 1].out_buf;
+    const int ld_in = (i == 0) ? m->Dp : m->disc[i - 1].out_p;
+    if (with_grads) {
+      GemmArgs g;
+      g.A = in; g.lda = ld_in; g.a_kmajor = 1; g.B = b.dpre; g.ldb = L.out_p;
+      g.C = G_(m, L.tW); g.ldc = tw.ld; g.M = L.in_p; g.N = L.out_p; g.K = rows;
+      want_sq(m, g, L.tW);
+      Timed t(m, "disc_bwd");
+      SMX_CHECK(launch_gemm(m->st, g));
+      if (i == 0) break;   // z is a constant of the discriminator's objective
+    }
+    GemmArgs h;
+    h.A = b.dpre; h.lda = L.out_p; h.B = P_(m, L.tW); h.ldb = tw.ld; h.b_nmajor = 1;
+    h.M = rows; h.N = L.in_p; h.K = L.out_p;
+    if (i == 0) { h.C = m->dz_tc; h.ldc = m->Dp; h.split_k = 1; h.tile = TILE_32x32_K4; }
+    else {
+      h.C = m->slab; h.ldc = L.in_p; h.slab_stride = (long)rows * L.in_p;
+      h.split_k = suggest_split_k(rows, L.in_p, L.out_p);
+      SMX_REQUIRE((size_t)h.split_k * (size_t)h.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
+    }
+    Timed t(m, "disc_bwd");
+    SMX_CHECK(launch_gemm(m->st, h, &n_slabs));
+  }
+  return SMX_OK;
+}
+
+int factor_backward(smx_model* m, const Pass& ps) {
+  SMX_CHECK(factor_sweep(m, 2 * ps.B, m->u_d, true));    // discriminator objective -> the discriminator's tensors
+  SMX_CHECK(factor_sweep(m, ps.B, m->u_tc, false));      // gamma TC (+ alpha CE) -> d z
   return SMX_OK;
 }
 
@@ -1051,6 +1171,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
   std::fill(m->sq_count.begin(), m->sq_count.end(), 0);   // the products of this step report what they wrote
   m->adam_early_pending = false; m->adam_early_from = -1;
   const float inv_gb = 1.f / (float)ps.global_batch;
+  if (m->fvae) SMX_CHECK(factor_backward(m, ps));   // first: it uses the slab buffer the head's backward fills next
   const MlpLayer& dL = m->dec.back();
   const long ldp = (long)m->k * m->Gp;
   int n_slabs = 0;
@@ -1108,7 +1229,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
       h.tile = TILE_32x32_K4;
       grp.push_back(h); is_dx.push_back(1);
     }
-    for (int j = 0; j < c.n_labels; ++j) {
+    for (int j = 0; j < m->n_heads; ++j) {
       const TensorInfo& tw = m->tensors[m->t_labW[j]];
       GemmArgs g;
       g.A = dL.out_buf; g.lda = dL.out_p; g.a_kmajor = 1; g.B = m->laby_draw[j]; g.ldb = tw.ld;
@@ -1158,6 +1279,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
   le.lat = m->latbuf; le.ld = lat_ld; le.sig = m->sig; le.eps = m->eps; le.kl_scale = c.beta * inv_gb;
   le.D = m->D; le.Dp = m->Dp; le.stochastic = m->stochastic; le.relu = (c.latent_activation == SMX_ACT_RELU);
   le.dlat = m->dlat;
+  if (m->fvae) le.dz_add = m->dz_tc;
   if (m->scale) {
     le.dklz = m->dklz;
     ScalePriorArgs sp;
@@ -1330,6 +1452,8 @@ int read_metrics(smx_model* m, smx_metrics* out) {
   out->grad_norm_max = mx;
   out->nan_flag = !(isfinite(h[0]) && isfinite(h[1]) && isfinite(h[3]) && isfinite(mx));
   out->step = (int32_t)m->h_next;
+  out->tc = h[5]; out->dtc_loss = h[6];
+  if (m->fvae && !(isfinite(h[5]) && isfinite(h[6]))) out->nan_flag = 1;
   return SMX_OK;
 }
 
@@ -1464,11 +1588,18 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   SMX_REQUIRE(cfg->n_genes > 0 && cfg->latent_dim > 0 && cfg->max_batch > 0, "n_genes, latent_dim, max_batch must be > 0");
   SMX_REQUIRE(cfg->n_enc >= 1 && cfg->n_enc <= SMX_MAX_LAYERS && cfg->n_dec >= 1 && cfg->n_dec <= SMX_MAX_LAYERS,
               "encoder/decoder need 1..8 layers");
-  SMX_REQUIRE(cfg->model >= SMX_MODEL_VAE && cfg->model <= SMX_MODEL_SCALE, "unknown model kind");
+  SMX_REQUIRE(cfg->model >= SMX_MODEL_VAE && cfg->model <= SMX_MODEL_FVAE, "unknown model kind");
+  if (cfg->model == SMX_MODEL_FVAE) {
+    SMX_REQUIRE(cfg->disc_layers >= 1 && cfg->disc_layers <= SMX_MAX_LAYERS && cfg->disc_units >= 1, "fvae: discriminator needs 1..8 hidden layers");
+    SMX_REQUIRE(cfg->disc_leak >= 0.f && cfg->disc_leak < 1.f, "fvae: leaky-ReLU slope in [0, 1)");
+    SMX_REQUIRE(cfg->n_labels <= 1, "fvae: at most one (one-hot) label variable");
+    if (cfg->n_labels == 1)
+      SMX_REQUIRE(cfg->label_llk[0] == SMX_LABEL_ONEHOT && cfg->label_dim[0] >= 2 && cfg->label_dim[0] <= 32, "fvae: the label variable is one-hot with 2..32 classes");
+  }
   if (cfg->model == SMX_MODEL_SCALE) SMX_REQUIRE(cfg->n_components >= 2 && cfg->n_components <= 32, "scale: 2..32 mixture components");
   SMX_REQUIRE(cfg->likelihood >= SMX_LLK_NB && cfg->likelihood <= SMX_LLK_ZINBD, "unknown likelihood");
   SMX_REQUIRE(cfg->n_labels >= 0 && cfg->n_labels <= SMX_MAX_LABELS, "too many label heads");
-  SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->n_labels == 0, "label heads need model = SISUA");
+  SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->model == SMX_MODEL_FVAE || cfg->n_labels == 0, "label heads need model = SISUA");
   if (cfg->model == SMX_MODEL_SCVI) {
     SMX_REQUIRE(cfg->likelihood == SMX_LLK_NBD || cfg->likelihood == SMX_LLK_ZINBD, "scvi supports nbd / zinbd only");
     SMX_REQUIRE(cfg->n_encl >= 1 && cfg->n_encl <= SMX_MAX_LAYERS, "scvi needs a library encoder");
@@ -1482,6 +1613,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   m->G = cfg->n_genes; m->Gp = round_up(m->G, 32); m->D = cfg->latent_dim; m->Dp = round_up(m->D, 32);
   m->k = (cfg->likelihood == SMX_LLK_ZINB || cfg->likelihood == SMX_LLK_ZINBD) ? 3 : 2;
   m->stochastic = cfg->model != SMX_MODEL_DCA; m->scvi = cfg->model == SMX_MODEL_SCVI; m->scale = cfg->model == SMX_MODEL_SCALE;
+  m->fvae = cfg->model == SMX_MODEL_FVAE; m->n_heads = m->fvae ? 0 : cfg->n_labels;
   m->Bmax = cfg->max_batch;
   int rc = SMX_OK;
   auto fail = [&](int code) { smx_model_destroy(m); return code; };
@@ -1496,7 +1628,8 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     }
   }
   // ---- manifest (same order as oracle/sisua_oracle.py:manifest) ----
-  int h = build_mlp(m, m->enc, "enc", m->G, cfg->n_enc, cfg->enc_units, ST_ENC_DROPOUT, cfg->dropout_enc);
+  const bool bnorm = cfg->batchnorm != 0;
+  int h = build_mlp(m, m->enc, "enc", m->G, cfg->n_enc, cfg->enc_units, ST_ENC_DROPOUT, cfg->dropout_enc, bnorm);
   m->t_latW = add_tensor(m, "lat/W", h, (m->stochastic ? 2 : 1) * m->D, m->stochastic ? 2 : 1, false);
   m->t_latb = add_tensor(m, "lat/b", 1, (m->stochastic ? 2 : 1) * m->D, m->stochastic ? 2 : 1, true);
   if (m->scale) {   // trainable mixture prior: logits [C], means and raw scales [C][D]
@@ -1505,11 +1638,20 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     m->t_prScale = add_tensor(m, "prior/scale", cfg->n_components, m->D, 1, false);
   }
   if (m->scvi) {
-    int hl = build_mlp(m, m->encl, "encl", m->G, cfg->n_encl, cfg->encl_units, ST_ENCL_DROPOUT, cfg->dropout_enc);
+    int hl = build_mlp(m, m->encl, "encl", m->G, cfg->n_encl, cfg->encl_units, ST_ENCL_DROPOUT, cfg->dropout_enc, bnorm);
     m->t_latlW = add_tensor(m, "latl/W", hl, 2, 1, false);
     m->t_latlb = add_tensor(m, "latl/b", 1, 2, 1, true);
   }
-  int hd = build_mlp(m, m->dec, "dec", m->D, cfg->n_dec, cfg->dec_units, ST_DEC_DROPOUT, cfg->dropout_dec);
+  int hd = build_mlp(m, m->dec, "dec", m->D, cfg->n_dec, cfg->dec_units, ST_DEC_DROPOUT, cfg->dropout_dec, bnorm);
+  if (m->fvae) {   // discriminator: Dense + bias + leaky ReLU, never BatchNorm / dropout; then the logit layer
+    int32_t du[SMX_MAX_LAYERS];
+    for (int i = 0; i < cfg->disc_layers; ++i) du[i] = cfg->disc_units;
+    const int hu = build_mlp(m, m->disc, "disc", m->D, cfg->disc_layers, du, 0, 0.f, false, cfg->disc_leak);
+    const int n_out = cfg->n_labels ? cfg->label_dim[0] : 1;
+    m->t_discoutW = add_tensor(m, "discout/W", hu, n_out, 1, false);
+    m->t_discoutb = add_tensor(m, "discout/b", 1, n_out, 1, true);
+    if (cfg->n_labels) m->lab_Pp[0] = round_up(cfg->label_dim[0], 32);
+  }
   if (m->scvi) {
     for (int ch = 0; ch < m->k; ++ch) {
       m->t_outW[ch] = add_tensor(m, "out" + std::to_string(ch) + "/W", hd, m->G, 1, false);
@@ -1519,7 +1661,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     m->t_outW[0] = add_tensor(m, "out/W", hd, m->k * m->G, m->k, false);
     m->t_outb[0] = add_tensor(m, "out/b", 1, m->k * m->G, m->k, true);
   }
-  for (int j = 0; j < cfg->n_labels; ++j) {
+  for (int j = 0; j < m->n_heads; ++j) {
     SMX_REQUIRE(cfg->label_dim[j] > 0, "label_dim must be > 0");
     SMX_REQUIRE(cfg->label_llk[j] >= SMX_LABEL_NB && cfg->label_llk[j] <= SMX_LABEL_MIXNB, "unknown label likelihood");
     if (cfg->label_llk[j] == SMX_LABEL_MIXNB) SMX_REQUIRE(cfg->label_components[j] >= 2 && cfg->label_components[j] <= 4, "mixture label heads have 2..4 components");
@@ -1577,6 +1719,19 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     return (int)SMX_OK;
   };
   if ((rc = alloc_mlp(m->enc)) || (rc = alloc_mlp(m->encl)) || (rc = alloc_mlp(m->dec))) return fail(rc);
+  if (m->fvae) {   // the discriminator sees the stacked batch [z ; z_perm]: 2 B rows
+    int up = 32;
+    for (auto& L : m->disc) {
+      up = std::max(up, L.out_p);
+      if (L.out_p > m->max_feat_p) m->max_feat_p = L.out_p;
+      if ((rc = dmalloc(&L.xhat, 2 * B * L.out_p)) || (rc = dmalloc(&L.out_buf, 2 * B * L.out_p)) || (rc = dmalloc(&L.dpre, 2 * B * L.out_p)))
+        return fail(rc);
+    }
+    if ((rc = dmalloc(&m->zz, 2 * B * m->Dp)) || (rc = dmalloc(&m->u_tc, B * 32)) || (rc = dmalloc(&m->u_d, 2 * B * 32)) ||
+        (rc = dmalloc(&m->tc_cell, B)) || (rc = dmalloc(&m->dl_cell, 2 * B)) || (rc = dmalloc(&m->dz_tc, B * m->Dp)) ||
+        (rc = dmalloc(&m->disc_dpre, B * up)) || (rc = dmalloc(&m->disc_db, (size_t)up)))
+      return fail(rc);
+  }
   m->slab_cap = (size_t)(64 * 3 + SMX_MAX_LABELS + 1) * B * m->max_feat_p;
   const size_t lat_ld = (m->stochastic ? 2 : 1) * (size_t)m->Dp;
   const size_t ldp = (size_t)m->k * m->Gp;
@@ -1594,7 +1749,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
         (rc = dmalloc(&m->lsig, B)) || (rc = dmalloc(&m->leps, B)) || (rc = dmalloc(&m->kl_l, B)) || (rc = dmalloc(&m->dl, B)))
       return fail(rc);
   }
-  for (int j = 0; j < cfg->n_labels; ++j) {
+  for (int j = 0; j < m->n_heads; ++j) {
     const size_t ld = m->tensors[m->t_labW[j]].ld;
     if ((rc = dmalloc(&m->laby_raw[j], B * ld)) || (rc = dmalloc(&m->laby_draw[j], B * ld))) return fail(rc);
   }
@@ -1661,6 +1816,8 @@ int smx_model_destroy(smx_model* m) {
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); fr(m->laby_raw[j]); fr(m->laby_draw[j]); }
   fr(m->rows2[0]); fr(m->rows2[1]); fr(m->order); fr(m->state3); fr(m->mhist);
   fr(m->resp); fr(m->dklz);
+  for (auto& L : m->disc) { fr(L.xhat); fr(L.out_buf); fr(L.dpre); }
+  fr(m->zz); fr(m->u_tc); fr(m->u_d); fr(m->tc_cell); fr(m->dl_cell); fr(m->dz_tc); fr(m->disc_dpre); fr(m->disc_db);
   fr(m->noise_eps); fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);
   fr(m->latlbuf); fr(m->dlatl); fr(m->lsmp); fr(m->lsig); fr(m->leps); fr(m->kl_l); fr(m->dl);
   fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);
@@ -2015,7 +2172,7 @@ static int fetch_forward(smx_model* m, int B, float* z_mean, float* z_scale, flo
   }
   SMX_CHECK(fetch_planes(m, B, x_params));
   if (y_params) {
-    for (int j = 0; j < m->cfg.n_labels; ++j) {
+    for (int j = 0; j < m->n_heads; ++j) {
       if (!y_params[j]) continue;
       const int P = m->cfg.label_dim[j], Pp = m->lab_Pp[j], ld = m->tensors[m->t_labW[j]].ld;
       float* dst = y_params[j] + y_draw * (size_t)B * m->lab_ky[j] * P;
@@ -2076,7 +2233,7 @@ int smx_decode(smx_model* m, const float* z, const float* l, int32_t batch, floa
   SMX_CHECK(fetch_planes(m, B, x_params));
   if (y_params) {
     std::vector<float> tmp;
-    for (int j = 0; j < m->cfg.n_labels; ++j) {
+    for (int j = 0; j < m->n_heads; ++j) {
       if (!y_params[j]) continue;
       const int P = m->cfg.label_dim[j], Pp = m->lab_Pp[j], ld = m->tensors[m->t_labW[j]].ld;
       tmp.resize((size_t)B * ld);

@@ -61,6 +61,8 @@ def make_smx_config(cfg: ModelConfig, max_batch: int) -> smx_config:
   c.bn_momentum, c.bn_eps = cfg.bn_momentum, cfg.bn_eps
   c.lr, c.adam_beta1, c.adam_beta2, c.adam_eps, c.clipnorm = cfg.lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps, cfg.clipnorm
   c.n_components = int(cfg.n_components)
+  c.disc_units, c.disc_layers = int(cfg.disc_units), int(cfg.disc_layers)
+  c.gamma, c.disc_leak = float(cfg.gamma), float(cfg.disc_leak)
   c.max_batch = int(max_batch)
   c.seed = int(cfg.seed) & 0xFFFFFFFFFFFFFFFF
   return c
@@ -201,7 +203,7 @@ class Engine:
     """Per-step ELBO scalars of the last train_steps call: dict of arrays [n_steps]."""
     h = np.empty((int(n_steps), 8), np.float32)
     check(self.lib.smx_metrics_history(self._h, int(n_steps), _fp(h)))
-    return {k: h[:, i].copy() for i, k in enumerate(("loss", "nllk_x", "nllk_y", "kl", "kl_l"))}
+    return {k: h[:, i].copy() for i, k in enumerate(("loss", "nllk_x", "nllk_y", "kl", "kl_l", "tc", "dtc_loss"))}
 
   def eval_step(self, row_ids):
     ids = self._ids(row_ids)
@@ -228,7 +230,7 @@ class Engine:
       out.update(l_mean=np.empty((B,), np.float32), l_scale=np.empty((B,), np.float32), l_sample=np.empty((B,), np.float32))
     if want_x_params:
       out["x_params"] = np.empty((k, B, G), np.float32)
-    ys = [np.empty((B, label_planes(llk) * P), np.float32) for P, llk in cfg.labels]
+    ys = [np.empty((B, label_planes(llk) * P), np.float32) for P, llk in cfg.head_labels]
     yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
     check(self.lib.smx_forward(self._h, idp, xp, lp, B, int(sample_index), int(training), _fp(out["z_mean"]),
                                _fp(out.get("z_scale")), _fp(out["z_sample"]), _fp(out.get("l_mean")),
@@ -255,7 +257,7 @@ class Engine:
     if cfg.model == "scvi":
       out.update(l_mean=np.empty((B,), np.float32), l_scale=np.empty((B,), np.float32), l_sample=np.empty((S, B), np.float32))
     out["x_params"] = np.empty((S, k, B, G), np.float32)
-    ys = [np.empty((S, B, label_planes(llk) * P), np.float32) for P, llk in cfg.labels]
+    ys = [np.empty((S, B, label_planes(llk) * P), np.float32) for P, llk in cfg.head_labels]
     yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
     check(self.lib.smx_forward_samples(self._h, idp, xp, lp, B, S, _fp(out["z_mean"]), _fp(out.get("z_scale")),
                                        _fp(out["z_sample"]), _fp(out.get("l_mean")), _fp(out.get("l_scale")),
@@ -272,7 +274,7 @@ class Engine:
       raise ValueError(f"z must be [batch, {cfg.latent_dim}]")
     la = None if l is None else _f32(np.reshape(l, (B,)))
     xp = np.empty((cfg.k, B, cfg.n_genes), np.float32)
-    ys = [np.empty((B, label_planes(llk) * P), np.float32) for P, llk in cfg.labels]
+    ys = [np.empty((B, label_planes(llk) * P), np.float32) for P, llk in cfg.head_labels]
     yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
     check(self.lib.smx_decode(self._h, _fp(za), _fp(la), B, _fp(xp), yptrs))
     return dict(x_params=xp, y_params=ys)

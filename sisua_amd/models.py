@@ -150,7 +150,7 @@ class SingleCellModel:
                        input_dropout=float(enc.input_dropout), log_norm=self._log_norm, beta=self.beta, alpha=self.alpha,
                        latent_activation=self._latent_activation(), clip_library=self.clip_library,
                        lr=float(self._opt["lr"]), clipnorm=float(self._opt["clipnorm"]), seed=self.seed,
-                       n_components=int(getattr(self, "_n_components", 10)))
+                       n_components=int(getattr(self, "_n_components", 10)), **getattr(self, "_disc_cfg", {}))
 
   def _ensure_engine(self, max_batch: int) -> Engine:
     cfg = self._make_config()
@@ -439,7 +439,7 @@ class SingleCellModel:
       stack = (lambda a: a[0]) if len(xp_list) == 1 else (lambda a: np.stack(a, 0))
       planes = [stack([xp[c] for xp in xp_list]) for c in range(cfg.k)]
     outs = [D.count_distribution(cfg.likelihood, planes, self._outputs[0].name or "transcriptomic", activated=cfg.model == "scvi")]
-    for j, (P, kind) in enumerate(cfg.labels):
+    for j, (P, kind) in enumerate(cfg.head_labels):
       raw = yp_list[j] if stacked else stack([yp[j] for yp in yp_list])
       nm = self._labels[j].name or f"label{j}"
       if kind == "nb":
@@ -719,6 +719,45 @@ class SCALE(SingleCellModel):
     super().__init__(outputs=outputs, latents=lat, **kwargs)
     self.init_args = dict(outputs=outputs, latents=latents, n_components=n_components, covariance=covariance,
                           tie_mixtures=tie_mixtures, tie_loc=tie_loc, tie_scale=tie_scale, **kwargs)
+
+
+class FVAE(SingleCellModel):
+  r"""FactorVAE (sisua/models/fvae.py:9-12 -> odin `factorVAE`; Kim & Mnih 2018 "Disentangling by Factorising"): a VAE
+  whose objective carries `gamma` x the total correlation of q(z), estimated by a discriminator on z that is trained in
+  the same step to tell z from z with every dimension permuted over the minibatch (Algorithm 2).
+
+    discriminator : dict(units=1000, n_hidden_layers=5) -- hidden width / depth (leaky ReLU 0.2, no BatchNorm)
+    gamma         : weight of the total-correlation term (6.0)
+
+  [3P-recall: odin's class is not in the reference tree; this follows the paper with odin's defaults.]  Both optimisers
+  of the reference (VAE, discriminator; identical Adam settings) are one Adam over all tensors here -- clipnorm and
+  Adam are per tensor, and each tensor takes one step per minibatch."""
+  _kind = "fvae"
+
+  def __init__(self, outputs, discriminator=None, gamma=6.0, **kwargs):
+    disc = dict(units=1000, n_hidden_layers=5)
+    disc.update(discriminator or {})
+    unknown = set(disc) - {"units", "n_hidden_layers", "alpha"}
+    if unknown:
+      raise ValueError(f"discriminator options not built: {sorted(unknown)}")
+    self._disc_cfg = dict(disc_units=int(disc["units"]), disc_layers=int(disc["n_hidden_layers"]), gamma=float(gamma),
+                          disc_leak=float(disc.get("alpha", 0.2)))
+    super().__init__(outputs=outputs, **kwargs)
+    self.gamma = float(gamma)
+    self.init_args = dict(outputs=outputs, discriminator=dict(disc), gamma=gamma, **kwargs)
+
+
+class SemiFVAE(FVAE):
+  r"""Semi-supervised FactorVAE (sisua/models/fvae.py:15-18 -> odin `SemifactorVAE`): the discriminator has one logit
+  per class of ONE one-hot label variable, its total-correlation logit is their logsumexp, and the masked
+  cross-entropy of the labelled cells (x `alpha`) joins both objectives."""
+
+  def __init__(self, outputs, labels, **kwargs):
+    labs = _flatten(labels)
+    if len(labs) != 1 or labs[0].posterior not in ("onehot", "categorical") or not 2 <= labs[0].event_shape <= 32:
+      raise ValueError("SemiFVAE is built for one 'onehot' label variable with 2..32 classes")
+    super().__init__(outputs=outputs, labels=labels, **kwargs)
+    self.init_args = dict(self.init_args, labels=labels)
 
 
 class SCVI(SingleCellModel):

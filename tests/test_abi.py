@@ -28,13 +28,27 @@ def test_header_and_binding_agree(lib):
   assert lib.smx_abi_version() == _hip.SMX_ABI_VERSION
 
 
-def test_config_struct_layout_matches_header():
+def test_config_struct_layout_matches_header(tmp_path):
+  """sizeof / offsetof of every field of smx_config and smx_metrics as gcc lays include/sisua_hip.h out == the ctypes
+  mirror in sisua_amd/_hip.py."""
   import ctypes as C
+  import subprocess
   from sisua_amd import _hip
-  # 5 + 3*(1+8) + (1+4+4+4+1) + 3 ints, 13 floats, 1 int, (pad), 1 u64
-  n_int = 5 + 3 * 9 + 14 + 3
-  assert C.sizeof(_hip.smx_config) == (n_int + 13 + 1) * 4 + (4 if (n_int + 14) % 2 else 0) + 8
-  assert C.sizeof(_hip.smx_metrics) == 32
+  lines = []
+  for st in ("smx_config", "smx_metrics"):
+    lines.append(f'printf("{st} %zu\\n", sizeof({st}));')
+    for name, _ in getattr(_hip, st)._fields_:
+      lines.append(f'printf("{st}.{name} %zu\\n", offsetof({st}, {name}));')
+  src = tmp_path / "layout.c"
+  src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sisua_hip.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n")
+  exe = tmp_path / "layout"
+  subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+  got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+  for st in ("smx_config", "smx_metrics"):
+    cls = getattr(_hip, st)
+    assert int(got[st]) == C.sizeof(cls), st
+    for name, _ in cls._fields_:
+      assert int(got[f"{st}.{name}"]) == getattr(cls, name).offset, (st, name)
 
 
 def test_no_cpu_fallback(lib):
@@ -59,7 +73,10 @@ def test_manifest_and_init_match_oracle():
                   labels=((5, "nb"), (3, "onehot")), batchnorm=False),
              dict(model="dca", n_genes=20, likelihood="nbd", enc_units=(8,), dec_units=(8,), latent_dim=3),
              dict(model="scale", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, n_components=5),
-             dict(model="sisua", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((5, "mixnb3"),))):
+             dict(model="sisua", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((5, "mixnb3"),)),
+             dict(model="fvae", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, disc_units=12, disc_layers=2),
+             dict(model="fvae", n_genes=20, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=3, disc_units=12, disc_layers=1,
+                  labels=((4, "onehot"),))):
     spec, cfg = make_pair(**kw)
     assert config.manifest(cfg) == so.manifest(spec)
     a, b = config.init_params(cfg), so.init_params(spec)

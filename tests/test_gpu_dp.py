@@ -59,6 +59,7 @@ CASES = {
                   labels=((12, "nb"), (7, "onehot"))),
     "scvi_zinbd": dict(model="scvi", n_genes=160, likelihood="zinbd", enc_units=(48,), dec_units=(48,), latent_dim=6,
                        encl_units=(16,)),
+    "fvae": dict(model="fvae", n_genes=110, likelihood="zinb", enc_units=(32,), dec_units=(32,), latent_dim=8, disc_units=60, disc_layers=2),
     "vae_nobn": dict(model="vae", n_genes=64, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=5, batchnorm=False),
 }
 
@@ -75,7 +76,7 @@ def _problem(kw, n=400):
 
 @pytest.mark.parametrize("name,world,sync_bn", [("vae_zinb", 2, False), ("vae_zinb", 2, True), ("vae_clip", 2, False),
                                                 ("vae_clip", 3, True), ("sisua", 2, False), ("sisua", 2, True),
-                                                ("scvi_zinbd", 2, False), ("scvi_zinbd", 2, True), ("vae_nobn", 4, False)])
+                                                ("scvi_zinbd", 2, False), ("scvi_zinbd", 2, True), ("vae_nobn", 4, False), ("fvae", 2, False)])
 def test_world_n_steps_match_oracle(Engine, name, world, sync_bn):
   """3 optimiser steps of `world` replicas, every rank holding the WHOLE matrix but drawing its own rows: loss /
   metrics / reduced gradients / gradient norms / parameters / moving statistics of EVERY rank equal the oracle's
@@ -104,7 +105,8 @@ def test_world_n_steps_match_oracle(Engine, name, world, sync_bn):
     ms = run_ranks([lambda r=r: engines[r].train_step(rows[r]) for r in range(world)])
     for r, (e, m) in enumerate(zip(engines, ms)):
       assert m["nan_flag"] == 0 and m["step"] == step + 1
-      for key in ("loss", "nllk_x", "kl") + (("nllk_y",) if spec.labels else ()) + (("kl_l",) if spec.model == "scvi" else ()):
+      for key in ("loss", "nllk_x", "kl") + (("nllk_y",) if spec.labels else ()) + (("kl_l",) if spec.model == "scvi" else ()) + \
+          (("tc", "dtc_loss") if spec.model == "fvae" else ()):   # (fvae: z is permuted within each rank's minibatch)
         assert np.isclose(m[key], ref["metrics"][key], rtol=RTOL, atol=1e-5), (r, step, key, m[key], ref["metrics"][key])
       assert np.isclose(m["grad_norm_max"], max(ref["norms"].values()), rtol=1e-3), (r, step)
       if step == 0:   # the reduced gradient itself (later steps start from fp32-rounded parameters)

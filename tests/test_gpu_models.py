@@ -321,3 +321,46 @@ def test_scale_fit_predict(api, tmp_path):
   assert type(m2) is api.SCALE and np.array_equal(m2._engine.get_params()["prior/loc"], p["prior/loc"])
   with pytest.raises(ValueError):
     api.SCALE(outputs=sco.get_rv("transcriptomic"), covariance="full")
+
+
+def test_fvae_fit_predict(api, tmp_path):
+  """FVAE / SemiFVAE (sisua/models/fvae.py:9-18): the VAE trains against -ELBO + gamma TC while the discriminator learns
+  to tell z from permute_dims(z) in the same step; both objectives are logged; predict / checkpoint as any model."""
+  sco = _sco(with_labels=False)
+  train, test = sco.split(0.8)
+  assert api.get_model("fvae") is api.FVAE and api.get_model("semifvae") is api.SemiFVAE
+  kw = dict(latents=api.RVmeta(8, "diag", True, "Latents"), encoder=api.NetConf([32], batchnorm=True, dropout=0.1),
+            decoder=api.NetConf([32], batchnorm=True, dropout=0.1), discriminator=dict(units=64, n_hidden_layers=3))
+  m = api.FVAE(outputs=sco.get_rv("transcriptomic"), gamma=4.0, **kw)
+  assert m._make_config().gamma == 4.0 and m._make_config().disc_units == 64
+  m.fit(train, valid=test, epochs=10, batch_size=64, learning_rate=2e-3, valid_freq=15)
+  h = m.train_history
+  assert len(m.valid_history["val_loss"]) >= 1 and np.isfinite(m.valid_history["val_loss"]).all()
+  assert _decreases(h["nllk_x"]) and np.isfinite(h["tc"]).all() and np.isfinite(h["dtc_loss"]).all()
+  # an untrained discriminator scores chance: 1/2 [softplus(0) + softplus(0)] = log 2; training it must not end above that
+  assert h["dtc_loss"][-1] <= np.log(2.0) + 1e-3, h["dtc_loss"]
+  p = m._engine.get_params()
+  assert p["disc0/W"].shape == (8, 64) and p["discout/W"].shape == (64, 1) and np.abs(p["disc2/b"]).max() > 0
+  X, Z = m.predict(test.numpy(), batch_size=64, verbose=False)
+  assert Z.mean().shape == (test.n_obs, 8) and X.mean().shape == (test.n_obs, 120)
+  path = os.path.join(tmp_path, "fvae")
+  m.save_weights(path)
+  m2 = api.load_model(path)
+  assert type(m2) is api.FVAE and np.array_equal(m2._engine.get_params()["disc1/W"], p["disc1/W"])
+  with pytest.raises(ValueError):
+    api.FVAE(outputs=sco.get_rv("transcriptomic"), discriminator=dict(batchnorm=True))
+  # semi-supervised form: one one-hot label variable, classified by the discriminator
+  from sisua_amd.data import SingleCellOMIC
+  x = synth_counts(600, 120, sparsity=0.8, seed=3)
+  cls = (np.log1p(x[:, :40]).sum(1) > np.median(np.log1p(x[:, :40]).sum(1))).astype(int) + 2 * (x[:, 40:80].sum(1) > np.median(x[:, 40:80].sum(1)))
+  sco2 = SingleCellOMIC(x, name="toy")
+  sco2.add_omic("celltype", np.eye(4, dtype=np.float32)[cls])
+  tr2, _ = sco2.split(0.8)
+  s = api.SemiFVAE(outputs=sco2.get_rv("transcriptomic"), labels=[sco2.get_rv("celltype", "onehot")], alpha=5.0, **kw)
+  assert s.is_semi_supervised and s._make_config().disc_outputs == 4
+  s.fit(tr2.create_dataset(["transcriptomic", "celltype"], labels_percent=0.5, batch_size=64, drop_remainder=True), metadata=sco2,
+        epochs=10, learning_rate=2e-3)
+  hs = s.train_history
+  assert hs["nllk_y"][-1] < hs["nllk_y"][0] and np.isfinite(hs["loss"]).all(), hs["nllk_y"]   # the classifier learns the labelled cells
+  with pytest.raises(ValueError):
+    api.SemiFVAE(outputs=sco2.get_rv("transcriptomic"), labels=[sco.get_rv("transcriptomic")])

@@ -68,7 +68,7 @@ def test_resident_matrix_kernels_on_arbitrary_shapes(eng, n, G, rate, retain, se
 
 @settings(max_examples=_n(12), deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(G=st.integers(5, 150), H=st.integers(1, 70), H2=st.integers(1, 40), D=st.integers(1, 40), B=st.integers(4, 300),
-       model=st.sampled_from(["vae", "dca", "scvi", "scale"]), lk0=st.sampled_from(["zinb", "nb", "zinbd", "nbd"]), bn=st.booleans(),
+       model=st.sampled_from(["vae", "dca", "scvi", "scale", "fvae"]), lk0=st.sampled_from(["zinb", "nb", "zinbd", "nbd"]), bn=st.booleans(),
        seed=st.integers(0, 10**6))
 def test_one_step_on_arbitrary_widths(eng, G, H, H2, D, B, model, lk0, bn, seed):
   """Any gene panel / layer / latent width and batch size (batches beyond 128 and 256 take the 4- and 8-rows-per-lane
@@ -80,6 +80,8 @@ def test_one_step_on_arbitrary_widths(eng, G, H, H2, D, B, model, lk0, bn, seed)
     kw["encl_units"] = (max(1, H // 2),)
   if model == "scale":
     kw["n_components"] = 2 + seed % 7
+  if model == "fvae":
+    kw.update(disc_units=1 + (seed * 7) % 90, disc_layers=1 + seed % 3)
   spec, cfg = make_pair(**kw)
   rng = np.random.default_rng(seed)
   n = B + 5

@@ -34,6 +34,10 @@ CASES = {
     "misa": dict(model="sisua", n_genes=140, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=8,
                  labels=((12, "mixnb2"), (5, "mixnb3"))),
     "scale": dict(model="scale", n_genes=150, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=10, n_components=7),
+    "fvae": dict(model="fvae", n_genes=150, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=10, disc_units=100,
+                 disc_layers=3),
+    "semifvae": dict(model="fvae", n_genes=120, likelihood="nb", enc_units=(40,), dec_units=(40,), latent_dim=7, disc_units=70,
+                     disc_layers=2, labels=((6, "onehot"),), gamma=3.0),
     "scvi_zinbd": dict(model="scvi", n_genes=160, likelihood="zinbd", enc_units=(48,), dec_units=(48,), latent_dim=6,
                        encl_units=(16,)),
     "scvi_nbd": dict(model="scvi", n_genes=96, likelihood="nbd", enc_units=(32,), dec_units=(32,), latent_dim=4,
@@ -78,6 +82,9 @@ def test_one_step_matches_oracle(Engine, name, batch):
     assert np.isclose(m["nllk_y"], res["metrics"]["nllk_y"], rtol=RTOL, atol=1e-5)
   if spec.model == "scvi":
     assert np.isclose(m["kl_l"], res["metrics"]["kl_l"], rtol=RTOL, atol=1e-5)
+  if spec.model == "fvae":
+    for key in ("tc", "dtc_loss"):
+      assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
   grads = e.get_params(which=1)
   worst = grad_errors(grads, res["grads"])
   assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
@@ -133,7 +140,7 @@ def test_separate_launch_forms_match_oracle(Engine, name, flags):
   e.close(); e0.close()
 
 
-@pytest.mark.parametrize("name", ["vae_zinb", "sisua", "scvi_zinbd"])
+@pytest.mark.parametrize("name", ["vae_zinb", "sisua", "scvi_zinbd", "fvae", "semifvae"])
 def test_injected_noise_matches_oracle(Engine, name):
   """smx_set_noise hook: same parameters + same minibatch + same injected eps / dropout
   masks => same loss and gradients (SURVEY.md section 7 'hard parts')."""
@@ -155,12 +162,17 @@ def test_injected_noise_matches_oracle(Engine, name):
     for i, u in enumerate(spec.encl_units):
       drop[so.STREAM_ENCL_DROPOUT + i] = dmask(u, spec.dropout_enc)
     normal[so.STREAM_EPS_L] = rng.normal(size=(B, 1)).astype(np.float32)
+  uniform = {}
+  if spec.model == "fvae":   # the permute_dims permutations are the ranks of these (one tie on purpose: broken by row)
+    u = rng.uniform(size=(B, spec.latent_dim)).astype(np.float32)
+    u[7, 0] = u[3, 0]
+    uniform[so.STREAM_PERMUTE] = u
   e = Engine(cfg, max_batch=B, init=False)
   e.set_params(params)
   e.upload(x, ys, lib, mask)
-  for s, v in {**drop, **normal}.items():
+  for s, v in {**drop, **normal, **uniform}.items():
     e.set_noise(s, v)
-  res = so.forward_backward(spec, params, so.init_bn_state(spec), x[rows], so.InjectedNoise(drop, normal),
+  res = so.forward_backward(spec, params, so.init_bn_state(spec), x[rows], so.InjectedNoise(drop, normal, uniform),
                             y=[y[rows] for y in ys], library=lib[rows], mask=mask[rows])
   m = e.train_step(rows)
   assert np.isclose(m["loss"], res["loss"], rtol=RTOL)
@@ -170,7 +182,8 @@ def test_injected_noise_matches_oracle(Engine, name):
   e.close()
 
 
-@pytest.mark.parametrize("name,graph", [("vae_zinb", False), ("vae_zinb", True), ("sisua", True), ("scvi_zinbd", False), ("misa", False), ("scale", True)])
+@pytest.mark.parametrize("name,graph", [("vae_zinb", False), ("vae_zinb", True), ("sisua", True), ("scvi_zinbd", False), ("misa", False), ("scale", True),
+                                        ("fvae", True), ("semifvae", False)])
 def test_trajectory_matches_oracle(Engine, name, graph):
   """50-step seeded trajectory: ELBO per step within 1e-4 relative."""
   kw = CASES[name]

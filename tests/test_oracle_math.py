@@ -127,7 +127,7 @@ def _toy(model, lk, labels=(), bn=True, **kw):
   G = 13
   spec = so.Spec(model=model, n_genes=G, likelihood=lk, enc_units=(6, 5), dec_units=(7,), latent_dim=3,
                  encl_units=(4,), labels=labels, batchnorm=bn, dropout_enc=0.25, dropout_dec=0.25,
-                 input_dropout=0.2, seed=3, n_components=4, **kw)
+                 input_dropout=0.2, seed=3, n_components=4, disc_units=5, disc_layers=2, **kw)
   rng = np.random.default_rng(5)
   B = 6
   x = rng.poisson(1.5, size=(B, G)).astype(np.float64) * (rng.uniform(size=(B, G)) < 0.6)
@@ -147,7 +147,8 @@ CASES = [("vae", "zinb", (), True), ("vae", "nb", (), False), ("vae", "zinbd", (
          ("vae", "nbd", (), True), ("dca", "zinb", (), True), ("scvi", "zinbd", (), True),
          ("scvi", "nbd", (), False), ("sisua", "zinb", ((4, "nb"), (3, "onehot")), True),
          ("sisua", "zinb", ((4, "mixnb2"), (3, "mixnb3")), True),   # MISA
-         ("scale", "zinb", (), True), ("scale", "nb", (), False)]    # SCALE: mixture prior, Monte-Carlo KL
+         ("scale", "zinb", (), True), ("scale", "nb", (), False),    # SCALE: mixture prior, Monte-Carlo KL
+         ("fvae", "zinb", (), True), ("fvae", "nb", ((3, "onehot"),), False)]   # FVAE / SemiFVAE: two objectives
 
 
 @pytest.mark.parametrize("model,lk,labels,bn", CASES)
@@ -155,8 +156,8 @@ def test_full_step_gradients_fd(model, lk, labels, bn):
   spec, params, bn_state, x, y, lib, mask = _toy(model, lk, labels, bn)
   noise = so.PhiloxNoise(spec.seed, 7, np.arange(x.shape[0]) + 100)
 
-  def loss_of(p):
-    return so.forward_backward(spec, p, bn_state, x, noise, y=y, library=lib, mask=mask, backward=False)["loss"]
+  def loss_of(p, key="loss"):
+    return so.forward_backward(spec, p, bn_state, x, noise, y=y, library=lib, mask=mask, backward=False)[key]
 
   res = so.forward_backward(spec, params, bn_state, x, noise, y=y, library=lib, mask=mask)
   assert np.isfinite(res["loss"])
@@ -171,7 +172,10 @@ def test_full_step_gradients_fd(model, lk, labels, bn):
       pm = {k: v.copy() for k, v in params.items()}
       pp[name].reshape(-1)[idx] += h
       pm[name].reshape(-1)[idx] -= h
-      fd = (loss_of(pp) - loss_of(pm)) / (2 * h)
+      # fvae: the discriminator's tensors follow ITS objective (z a constant of it, which holds under this
+      # perturbation: z does not depend on them); every other tensor the VAE objective with the discriminator fixed
+      key = "dtc_loss" if name.startswith("disc") else "loss"
+      fd = (loss_of(pp, key) - loss_of(pm, key)) / (2 * h)
       assert np.isclose(g.reshape(-1)[idx], fd, rtol=2e-4, atol=1e-7), (name, idx, g.reshape(-1)[idx], fd)
 
 

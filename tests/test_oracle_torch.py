@@ -99,7 +99,28 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
     raw = d @ P["out/W"] + P["out/b"]
     llk_x = count_log_prob(x, [raw[:, c * G:(c + 1) * G] for c in range(spec.k)], spec.likelihood, False).sum(1)
   llk_y = torch.zeros(B)
-  for j, (Pj, kind) in enumerate(spec.labels):
+  m = torch.zeros(B) if mask is None else torch.as_tensor(np.asarray(mask, np.float64))
+  extra_vae, j_disc = 0.0, None
+  if spec.model == "fvae":
+    # FactorVAE (Kim & Mnih 2018, Algorithm 2).  Two objectives, kept apart with detach(): the VAE objective sees the
+    # discriminator as a fixed function (frozen copies of its tensors), the discriminator objective sees z as a constant.
+    def disc(inp, W):
+      hh = inp
+      for i in range(spec.disc_layers):
+        hh = torch.nn.functional.leaky_relu(hh @ W[f"disc{i}/W"] + W[f"disc{i}/b"], spec.disc_leak)
+      return hh @ W["discout/W"] + W["discout/b"]
+    frozen = {k: v.detach() for k, v in P.items() if k.startswith("disc")}
+    order = torch.argsort(torch.as_tensor(noise.uniform(so.STREAM_PERMUTE, D)), dim=0, stable=True)   # rank of (u, row) per column
+    zd = z.detach()
+    logits_v, logits_z, logits_p = disc(z, frozen), disc(zd, P), disc(torch.gather(zd, 0, order), P)
+    extra_vae = spec.gamma * torch.logsumexp(logits_v, 1).mean()
+    j_disc = 0.5 * (torch.nn.functional.softplus(-torch.logsumexp(logits_z, 1)).mean()
+                    + torch.nn.functional.softplus(torch.logsumexp(logits_p, 1)).mean())
+    if spec.labels:
+      yj = torch.as_tensor(np.asarray(y[0], np.float64))
+      llk_y = td.OneHotCategorical(logits=logits_v).log_prob(yj)
+      j_disc = j_disc - spec.alpha * (m * td.OneHotCategorical(logits=logits_z).log_prob(yj)).mean()
+  for j, (Pj, kind) in enumerate(() if spec.model == "fvae" else spec.labels):
     ry = d @ P[f"lab{j}/W"] + P[f"lab{j}/b"]
     yj = torch.as_tensor(np.asarray(y[j], np.float64))
     if kind == "nb":
@@ -113,9 +134,8 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
       llk_y = llk_y + td.MixtureSameFamily(td.Categorical(logits=pl[:, :C].permute(0, 2, 1)), comp, validate_args=False).log_prob(yj).sum(1)
     else:
       llk_y = llk_y + td.OneHotCategorical(logits=ry).log_prob(yj)
-  m = torch.zeros(B) if mask is None else torch.as_tensor(np.asarray(mask, np.float64))
-  loss = -(llk_x + spec.alpha * m * llk_y - spec.beta * (kl + kl_l)).mean()
-  loss.backward()
+  loss = -(llk_x + spec.alpha * m * llk_y - spec.beta * (kl + kl_l)).mean() + extra_vae
+  (loss if j_disc is None else loss + j_disc).backward()
   return P, float(loss.detach()), {k: v.grad.numpy() for k, v in P.items()}, new_bn
 
 
@@ -147,6 +167,9 @@ CASES = {
     "misa": dict(model="sisua", n_genes=40, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5,
                  labels=((6, "mixnb2"), (3, "mixnb3")), alpha=10.0),
     "scale": dict(model="scale", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=6),
+    "fvae": dict(model="fvae", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, disc_units=24, disc_layers=3),
+    "semifvae": dict(model="fvae", n_genes=40, likelihood="nb", enc_units=(16,), dec_units=(16,), latent_dim=4, disc_units=20, disc_layers=2,
+                     labels=((5, "onehot"),), gamma=3.0, alpha=4.0),
     "scvi_zinbd": dict(model="scvi", n_genes=52, likelihood="zinbd", enc_units=(16,), dec_units=(16,), latent_dim=4, encl_units=(8,)),
     "scvi_nbd": dict(model="scvi", n_genes=36, likelihood="nbd", enc_units=(12,), dec_units=(12,), latent_dim=3, encl_units=(6,),
                      batchnorm=False),
