@@ -145,12 +145,14 @@ def test_latent_means_after_training_match_oracle(Engine):
     'on' in one arithmetic and 'off' in the other (ReLU's derivative is discontinuous); for a gene that only that
     cell of the batch expresses the encoder weight's gradient then differs by O(1), and Adam turns it into ~10
     full-size steps (m decays by 0.9 per step while sqrt(v) stays): one weight moves by ~1e-2, the loss by < 1e-5.
-    Verified, not assumed: tools/divergence_event.py finds the first O(1) gradient difference of this build
-    (profiles/r02_divergence_event.txt: step 115, only column 99 of enc0/W differs; the ReLU input of unit 99 for one
-    cell is -1.3e-6 in float64, inside the float32 resolution 2e-7 x a few sums) and tools/divergence_trace.py shows
-    the consequence (profiles/r02_divergence_trace.txt: one enc0/W entry 3e-5 -> 4e-3 -> 1e-2 while everything else
-    still agrees to 1e-6).  The same holds between any two implementations (fp32 vs fp64, or two fp32 orders of
-    summation), the reference's included."""
+    Verified, not assumed: tools/divergence_event.py finds the first step at which any gradient differs beyond rounding
+    and the ReLU input behind it (profiles/r02_divergence_event.txt, this build: every tensor agrees to 1.2e-6 through
+    step 213; at step 214 decoder unit 94 of one cell has ReLU input +1.3e-7 in float64, inside the float32 resolution
+    of its sum, and exactly the 32 entries of that unit's column of dec0/W differ; an earlier build of this round had
+    the same event in the encoder at step 115 -- where it falls moves with every change of summation order) and
+    tools/divergence_trace.py shows the consequence (profiles/r02_divergence_trace.txt: eval-mode latent means agree
+    to 9e-7 at step 200, 1e-4 at 220, 1e-2 at 320 while the loss still agrees to 1e-5).  The same holds between any
+    two implementations (fp32 vs fp64, or two fp32 orders of summation), the reference's included."""
   import bench
   spec, cfg, xt, B, extra = _workload("8kly")
   assert B == 128

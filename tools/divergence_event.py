@@ -1,13 +1,15 @@
-"""Why GPU and oracle trajectories separate: find the first optimiser step at which one encoder-weight gradient differs
-by O(1) between the two, and show the state of the hidden unit / cell behind it (tools/divergence_trace.py shows the
-consequence over the following steps).  TRAJ_STEPS (default 160)."""
+"""Why GPU and oracle trajectories separate: find the first optimiser step at which ANY gradient tensor differs between
+the two by more than 1e-3 (relative L2; rounding leaves ~1e-6), and show the hidden unit / cell behind it: a ReLU whose
+input is within float32 rounding of 0 is 'on' in one arithmetic and 'off' in the other (tools/divergence_trace.py shows
+the consequence over the following steps).  The step at which this happens depends on the build (any change of
+summation order moves it).  TRAJ_STEPS (default 320)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 from oracle import sisua_oracle as so
 from sisua_amd.engine import Engine
-n_steps = int(os.environ.get("TRAJ_STEPS", "160"))
+n_steps = int(os.environ.get("TRAJ_STEPS", "320"))
 cfg, xt, batch, _ = bench.build_workload(0, 1, "8kly")
 spec = so.Spec(**cfg.to_dict())
 params = so.init_params(spec)
@@ -16,33 +18,44 @@ e = Engine(cfg, max_batch=batch, init=False)
 e.set_params(params); e.upload(xt)
 order = bench.make_order(xt.shape[0], batch, n_steps)
 x64 = xt.astype(np.float64)
+
+captured = {}
+_orig = so._mlp_fwd
+def _capture(spec_, params_, bn_state, prefix, units, h, training, noise, stream0, p_drop, new_bn):
+  out, caches = _orig(spec_, params_, bn_state, prefix, units, h, training, noise, stream0, p_drop, new_bn)
+  captured[prefix] = caches
+  return out, caches
+so._mlp_fwd = _capture
+
 for s in range(n_steps):
   rows = order[s * batch:(s + 1) * batch]
   p_before = {k: v.copy() for k, v in params.items()}
-  bn_before = {k: v.copy() for k, v in bn.items()}
   ref = so.train_step(spec, params, bn, opt, x64[rows], so.PhiloxNoise(spec.seed, s, rows))
   e.train_step(rows)
-  g = e.get_params(which=1)["enc0/W"].astype(np.float64)
-  r = ref["grads"]["enc0/W"]
-  d = np.abs(g - r)
-  scale = np.abs(r).max()
-  i, j = np.unravel_index(d.argmax(), d.shape)
-  if d.max() > 1e-3 * scale:
-    print(f"step {s + 1}: enc0/W gradient [{i},{j}] gpu {g[i, j]:+.6e} oracle {r[i, j]:+.6e} (largest |g| {scale:.2e}); "
-          f"all other entries agree to {np.sort(d.ravel())[-20] / scale:.1e} of the largest")
-    # the oracle's ReLU input of unit j for every cell of the batch (training-mode BatchNorm of this batch)
-    h0 = np.log1p(x64[rows])
-    pre = h0 @ p_before["enc0/W"]
-    mu, var = pre.mean(0), pre.var(0)
-    y = p_before["enc0/gamma"] * (pre - mu) / np.sqrt(var + spec.bn_eps) + p_before["enc0/beta"]
-    col = np.abs(g[:, j] - r[:, j])
-    print(f"  column {j} (hidden unit {j}): {int((col > 1e-4 * scale).sum())} of {col.size} gene rows differ by more than 1e-4 of the largest gradient;"
-          f" other columns: {int((np.delete(d, j, axis=1) > 1e-4 * scale).sum())} entries")
-    order_y = np.argsort(np.abs(y[:, j]))
-    print(f"  ReLU input of unit {j}, the three cells closest to 0 (typical |y| {np.abs(y[:, j]).mean():.2f}): "
-          + ", ".join(f"cell {c}: {y[c, j]:+.3e}" for c in order_y[:3]))
-    print(f"  float32 resolution of the pre-activation there: |pre| {np.abs(pre[order_y[0], j]):.2f} * 6e-8 * gamma/std {abs(p_before['enc0/gamma'][j]) / np.sqrt(var[j] + spec.bn_eps):.2f}"
-          f" = {np.abs(pre[order_y[0], j]) * 6e-8 * abs(p_before['enc0/gamma'][j]) / np.sqrt(var[j] + spec.bn_eps):.1e}")
+  got = e.get_params(which=1)
+  err = {k: np.linalg.norm(got[k] - ref["grads"][k]) / max(np.linalg.norm(ref["grads"][k]), 1e-30) for k in ref["grads"]}
+  worst = max(err, key=err.get)
+  if err[worst] > 1e-3:
+    print(f"step {s + 1}: first gradient difference beyond rounding: " + ", ".join(f"{k} {v:.1e}" for k, v in sorted(err.items(), key=lambda kv: -kv[1])[:4])
+          + f"; every tensor agreed to {prev_worst:.1e} at step {s}")
+    # ReLU inputs of this step's forward pass (float64, the parameters before the update), nearest to 0
+    for prefix, units in (("enc", spec.enc_units), ("dec", spec.dec_units)):
+      for i, _ in enumerate(units):
+        c = captured[prefix][i]
+        y = p_before[f"{prefix}{i}/gamma"] * c["xhat"] + p_before[f"{prefix}{i}/beta"]
+        pre = c["h_in"] @ p_before[f"{prefix}{i}/W"]
+        b, u = np.unravel_index(np.abs(y).argmin(), y.shape)
+        res = np.abs(pre[b, u]) * 6e-8 * abs(p_before[f"{prefix}{i}/gamma"][u]) * c["inv"][u]
+        n_sum = c["h_in"].shape[1]
+        print(f"  {prefix}{i}: ReLU input nearest to 0: cell {b}, unit {u}: y = {y[b, u]:+.3e} (typical |y| {np.abs(y).mean():.2f}); float32 resolution there: "
+              f"|pre| {abs(pre[b, u]):.2f} x 6e-8 x gamma/std {abs(p_before[f'{prefix}{i}/gamma'][u]) * c['inv'][u]:.2f} = {res:.1e} per rounding, {n_sum} terms in the sum")
+        # where the difference sits: the column of this unit in the layer's weight gradient
+        g, r = got[f"{prefix}{i}/W"].astype(np.float64), ref["grads"][f"{prefix}{i}/W"]
+        d = np.abs(g - r)
+        scale = np.abs(r).max()
+        col = (d > 1e-4 * scale)
+        print(f"       weight-gradient entries off by more than 1e-4 of the largest: {int(col[:, u].sum())} in column {u}, {int(col.sum() - col[:, u].sum())} elsewhere")
     break
+  prev_worst = err[worst]
 else:
-  print(f"no O(1) gradient difference in {n_steps} steps")
+  print(f"no gradient difference beyond rounding in {n_steps} steps (worst {prev_worst:.1e})")
