@@ -184,6 +184,9 @@ int launch_metrics(hipStream_t st, const MetricsArgs& a);
 
 // Optimiser over the flat parameter buffer.
 #define SMX_MAX_TENSORS 48
+#define SMX_SQR_MAX 16             // reduce riders per BatchNorm-backward launch
+#define SMX_SQR_PER_TENSOR 8       // ... and per tensor
+#define SMX_SQR_MIN_SLOTS 4096     // tensors with fewer sum-of-squares slots are summed by the optimiser's workgroups themselves
 #define SMX_SQ_SMALL_TENSOR 65536   // floats: below this a workgroup re-derives the tensor's norm by itself
 struct OptChunk { int32_t tensor; int32_t offset; int32_t count; int32_t first_chunk; int32_t n_chunks; int32_t tensor_count; int32_t pad[2]; };
 struct AdamArgs {
@@ -221,6 +224,10 @@ struct BnBwdArgs {
   // single GPU: the output / label heads' gradients are final before this launch, and this launch leaves most CUs
   // idle -- adam_count extra workgroups apply the optimiser to chunks [adam_first, adam_first + adam_count)
   AdamArgs adam; int adam_first = 0, adam_count = 0;
+  // ... or, when that update is too large to ride along, sqr_count workgroups that only sum sum-of-squares slots:
+  // rider i leaves the sum of sq_slots[sqr_first[i] .. + sqr_n[i]) in sq_total[sqr_dst[i]] (up to SMX_SQR_PER_TENSOR
+  // riders per tensor; the optimiser's workgroups then read that many numbers instead of every slot)
+  int sqr_count = 0; int sqr_first[SMX_SQR_MAX], sqr_n[SMX_SQR_MAX], sqr_dst[SMX_SQR_MAX]; float* sq_total = nullptr;
   // front != 0 (last encoder layer): the incoming gradient d h = d lat W_lat^T is produced here as dot products
   // (K = width of the latent head <= 64; d lat [B][fK] staged in LDS, this thread's row of W_lat in registers)
   // instead of being read from a slab another launch wrote

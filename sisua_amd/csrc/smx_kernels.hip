@@ -325,6 +325,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
     for (int k = 0; k < 64; ++k) wcol[k] = (k < a.lat.Dp) ? ws[k * BN_COLS + c] : 0.f;
   }
 
+  // dropout multipliers drawn ahead by an earlier launch (or injected): loaded now, used after the reductions
+  const bool drop = a.training && a.drop_p > 0.f;
+  float mpre[BN_RPT];
+  if (SMALL && drop && a.inj_mask) {
+#pragma unroll
+    for (int i = 0; i < BN_RPT; ++i) {
+      const int r = rl + BN_RL * i;
+      mpre[i] = r < a.B ? a.inj_mask[(long)r * a.inj_ld + col] : 0.f;
+    }
+  }
   // pass 1: slab sum (+ bias), column sum
   float s1 = 0.f;
   for (int r0 = 0; r0 < a.B; r0 += CH) {
@@ -392,9 +402,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
     inv = rsqrtf(var + a.eps);
     if (rl == 0 && a.inv_std) a.inv_std[col] = inv;
   }
-  const bool drop = a.training && a.drop_p > 0.f;
   const float scale = drop ? 1.f / (1.f - a.drop_p) : 1.f;
-  auto finish = [&](int r, float v) {
+  auto finish = [&](int r, float v, float mahead) {
     const long o = (long)r * a.Hp + col;
     float y = v;
     if (a.batchnorm) {
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
     if (a.leak != 0.f) h += a.leak * fminf(y, 0.f);
     if (drop) {
       float mult;
-      if (a.inj_mask) mult = a.inj_mask[(long)r * a.inj_ld + col];
+      if (a.inj_mask) mult = SMALL ? mahead : a.inj_mask[(long)r * a.inj_ld + col];
       else {
         const uint32_t cell = a.cell_base + (uint32_t)(a.rows ? a.rows[r] : r);
         const U4 w = philox_block(a.nk, cell, (uint32_t)(col >> 2));
@@ -419,9 +428,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
   if (SMALL) {
 #pragma unroll
     for (int i = 0; i < BN_RPT; ++i)
-      if (rl + BN_RL * i < a.B) finish(rl + BN_RL * i, vreg[i]);
+      if (rl + BN_RL * i < a.B) finish(rl + BN_RL * i, vreg[i], mpre[i]);
   } else {
-    for (int r = rl; r < a.B; r += BN_RL) finish(r, a.xhat[(long)r * a.Hp + col]);
+    for (int r = rl; r < a.B; r += BN_RL) finish(r, a.xhat[(long)r * a.Hp + col], 0.f);
   }
 }
 
@@ -466,6 +475,7 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
 
 __device__ inline void metrics_body(const MetricsArgs& a);
 __device__ inline void adam_chunk_body(const AdamArgs& a, int chunk);
+__device__ inline void sq_reduce_body(const float* sl, int cnt, float* dst);
 
 template <int RPT, int FRONT = 0>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
@@ -476,8 +486,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
     const int nb = a.Hp / BN_COLS, extra = (int)blockIdx.x - nb;
     if (extra >= 0) {
       if (threadIdx.x >= 256) return;                   // the riders are 256-thread bodies
-      if (a.with_metrics && extra == 0) metrics_body(a.metrics);                          // ELBO scalars
-      else adam_chunk_body(a.adam, a.adam_first + extra - (a.with_metrics ? 1 : 0));      // optimiser chunks of the heads
+      const int e = extra - (a.with_metrics ? 1 : 0);
+      if (e < 0) metrics_body(a.metrics);                                                 // ELBO scalars
+      else if (e < a.adam_count) adam_chunk_body(a.adam, a.adam_first + e);               // optimiser chunks of the heads
+      else {                                                                              // or only their gradient norms
+        const int i = e - a.adam_count;
+        sq_reduce_body(a.adam.sq_slots + a.sqr_first[i], a.sqr_n[i], a.sq_total + a.sqr_dst[i]);
+      }
       return;
     }
   }
@@ -603,7 +618,7 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
       set_error("bn_act_bwd: gradient front not applicable");
       return SMX_ERR_INVALID;
     }
-    const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count;
+    const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count + a.sqr_count;
     const size_t lds = ((size_t)a.B * (a.fK + 1) + 4 + (size_t)BN_COLS * (a.fK + 4)) * sizeof(float);
     static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_bwd_kernel<4, 1>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
@@ -615,7 +630,7 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
   }
   if (bn_diag() & 4) a.n_slabs = 1;                       // diagnostic: one slab only
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_bwd: bad shapes"); return SMX_ERR_INVALID; }
-  const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count;
+  const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count + a.sqr_count;
   if (a.B <= BN_RL * 2) hipLaunchKernelGGL(bn_act_bwd_kernel<2>, dim3(grid), dim3(BN_THREADS), 0, st, a);
   else if (a.B <= BN_RL * 4) hipLaunchKernelGGL(bn_act_bwd_kernel<4>, dim3(grid), dim3(BN_THREADS), 0, st, a);
   else if (a.B <= BN_RL * 8) hipLaunchKernelGGL(bn_act_bwd_kernel<8>, dim3(grid), dim3(BN_THREADS), 0, st, a);
@@ -1450,6 +1465,20 @@ __global__ __launch_bounds__(256) void grad_sqsum_kernel(AdamArgs a) {
   }
   s = block_sum(s, sh);
   if (threadIdx.x == 0) a.partial[blockIdx.x] = s;
+}
+
+// sum of a range of sum-of-squares slots (fixed order: deterministic); 256 threads
+__device__ inline void sq_reduce_body(const float* sl, int cnt, float* dst) {
+  __shared__ float sh[4];
+  float p[4] = {0.f, 0.f, 0.f, 0.f};
+  int i = threadIdx.x;
+  for (; i + 3 * 256 < cnt; i += 4 * 256) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] += sl[i + u * 256];
+  }
+  for (; i < cnt; i += 256) p[0] += sl[i];
+  const float s = block_sum((p[0] + p[1]) + (p[2] + p[3]), sh);
+  if (threadIdx.x == 0) *dst = s;
 }
 
 // clip + Adam for one chunk of the flat buffer; 256 threads

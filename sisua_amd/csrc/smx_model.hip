@@ -257,7 +257,7 @@ struct smx_model {
   bool x_u16 = false;   // the resident matrix is stored as uint16 counts (smx_dataset_upload_u16)
   float* pinned = nullptr; size_t pinned_floats = 0;   // host staging for the parameter planes handed back by smx_forward / smx_decode
   // sum-of-squares slots written by the weight-gradient products (per-tensor clipnorm without a separate pass)
-  float* sq_slots = nullptr; std::vector<int> sq_first, sq_count;   // this step's output head ran as the fused kernel (smx_head.hip)
+  float* sq_slots = nullptr; std::vector<int> sq_first, sq_count; std::vector<char> sq_reduced; int sq_total_first = 0;   // this step's output head ran as the fused kernel (smx_head.hip)
   int G = 0, Gp = 0, D = 0, Dp = 0, k = 0, Bmax = 0;
   bool stochastic = true, scvi = false, scale = false, fvae = false;
   int n_heads = 0;                    // label heads on the decoder (0 for fvae: SemiFVAE's labels go to the discriminator)
@@ -294,6 +294,10 @@ struct smx_model {
   MetricsArgs pending_metrics; bool have_pending_metrics = false, metrics_before_allreduce = false;
   int seq_batch = 0, seq_prepare_next = 0;
   bool eps_ahead_ok = false;   // latent head fusable: eps may be drawn ahead by the first BN launch
+  // this pass's first encoder BatchNorm launch has drawn, on otherwise idle CUs, what the decoder's front launch would
+  // draw redundantly in each of its workgroups: eps of the latent sample (-> noise_eps) / the dropout multipliers of
+  // the first decoder layer (-> dec[0].noise)
+  bool ahead_front_eps = false, ahead_front_drop = false;
   float* noise_eps = nullptr;  // [Bmax][Dp] eps drawn ahead of the latent head
   float *latbuf = nullptr, *dlat = nullptr, *z = nullptr, *sig = nullptr, *eps = nullptr, *kl = nullptr;
   float *latlbuf = nullptr, *dlatl = nullptr, *lsmp = nullptr, *lsig = nullptr, *leps = nullptr, *kl_l = nullptr, *dl = nullptr;
@@ -429,6 +433,18 @@ int dp_allreduce_buf(smx_model* m, float* buf, size_t count, hipStream_t st);
 bool sync_bn_on(const smx_model* m, int training) { return m->sync_bn && training && m->cfg.batchnorm && dp_active(m); }
 BnSyncArgs sync_args(smx_model* m) { BnSyncArgs y; y.gather = m->sync_buf; y.rank = m->rank; y.world = m->world; return y; }
 
+// shapes / modes under which the decoder's first BatchNorm launch takes the latent sample and its product along
+// (forward_pass adds what depends on injected noise)
+bool use_mid(const smx_model* m, int B);
+static bool front_shapes_ok(smx_model* m, const Pass& ps) {
+  if (use_mid(m, ps.B)) return false;
+  const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
+  static const bool no_fz = getenv("SMX_SMALL_FUSION") == nullptr;
+  const bool fuse_lat = !no_fz && !m->scale && latent_head_fusable(m->enc.back().out_p, lat_ld, m->Dp);
+  return m->flags.front && !m->scale && !fuse_lat && !sync_bn_on(m, ps.training) && bn_front_supported(ps.B, m->Dp) &&
+         (m->Dp == 32 || m->Dp == 64) && m->dec[0].in_p == m->Dp && m->dec[0].out_p % 8 == 0 && (lat_ld % 4) == 0;
+}
+
 int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
                 const char* label0, int n_layers = -1, const LatentArgs* front = nullptr) {
   const float* in = in0;
@@ -503,7 +519,23 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
       if (m->stochastic && !inj(m, ST_EPS_Z) && m->eps_ahead_ok) add(m->noise_eps, m->Dp, m->D, 1, 0.f, ST_EPS_Z);
       if (b.n_jobs) { b.nk.step_ptr = ps.training ? &cur_state(m)->step : nullptr; }
     }
+    if (!fuse && !ahead && !no_ahead && !sync && i == 0 && in_is_x && &mlp == &m->enc && ps.training && front_shapes_ok(m, ps) &&
+        !with_front && b.n_jobs == 0) {
+      // the decoder's front launch (latent sample + first decoder layer) computes the whole latent tile in EVERY one of
+      // its workgroups: its Philox draws (eps: ~1.2 us at batch 128, twice that at 256; dropout ~1 us) are made here
+      // instead, once, by extra workgroups on CUs this launch leaves idle
+      auto add = [&](float* dst, int ld, int width, int normal, float p, int stream) {
+        NoiseJob& j = b.jobs[b.n_jobs++];
+        j.dst = dst; j.ld = ld; j.width = width; j.normal = normal; j.p = p;
+        j.stream = (uint32_t)((stream & 0xFF) | ((ps.sample & 0xFFFFFF) << 8));
+      };
+      const MlpLayer& d0 = m->dec[0];
+      if (d0.drop_p > 0.f && !inj(m, d0.stream)) { add(d0.noise, d0.out_p, d0.out, 0, d0.drop_p, d0.stream); m->ahead_front_drop = true; }
+      if (m->stochastic && !inj(m, ST_EPS_Z)) { add(m->noise_eps, m->Dp, m->D, 1, 0.f, ST_EPS_Z); m->ahead_front_eps = true; }
+      if (b.n_jobs) b.nk.step_ptr = &cur_state(m)->step;
+    }
     if (with_front) {
+      if (m->ahead_front_drop && !b.inj_mask && b.drop_p > 0.f) { b.inj_mask = L.noise; b.inj_ld = L.out_p; }
       b.front = 1; b.lat = *front; b.W = P_(m, L.tW); b.ldw = tw.ld; b.n_jobs = 0;
       Timed t(m, "bn_fwd");
       SMX_CHECK(launch_bn_act_fwd(m->st, b));
@@ -536,11 +568,31 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
   m->adam_early_pending = false;
   static const bool off = getenv("SMX_NO_ADAM_EARLY") != nullptr;
   if (off || dp_active(m) || !m->sq_slots || m->chunk_first_head >= m->n_chunks || getenv("SMX_NO_SQ_PARTIALS") != nullptr) return;
-  // riders use half of a 512-thread BatchNorm workgroup: fine while the heads' update is a few MB (C2: 22 MB, hidden
-  // under the launch), but at the 20 000-gene width it ran at 2.8 TB/s against 6.2 TB/s for the optimiser's own launch
-  if ((long)(m->n_chunks - m->chunk_first_head) * m->chunks_floats > 512L * 4096) return;
   for (size_t t = (size_t)m->t_outW[0]; t < m->tensors.size(); ++t)   // head tensors are the last ones of the manifest
     if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) return;
+  // riders use half of a 512-thread BatchNorm workgroup: fine while the heads' update is a few MB (C2: 22 MB, hidden
+  // under the launch), but at the 20 000-gene width it ran at 2.8 TB/s against 6.2 TB/s for the optimiser's own launch.
+  // There only the heads' sum-of-squares slots are reduced here (one rider workgroup per tensor with many slots:
+  // 30 000 for the output head at 20 000 genes), so that each of the optimiser's ~1900 workgroups for that tensor
+  // reads ONE number instead of sweeping all of them (225 MB of L2 reads, 66 -> 5x us of the optimiser launch).
+  if ((long)(m->n_chunks - m->chunk_first_head) * m->chunks_floats > 512L * 4096) {
+    fill_adam_args(m, b.adam);
+    for (size_t t = 0; t < m->tensors.size(); ++t) { b.adam.sq_first[t] = m->sq_first[t]; b.adam.sq_count[t] = m->sq_count[t]; }
+    for (size_t t = (size_t)m->t_outW[0]; t < m->tensors.size(); ++t) {
+      const int cnt = m->sq_count[t];
+      const int R = std::min(SMX_SQR_PER_TENSOR, (cnt + SMX_SQR_MIN_SLOTS - 1) / SMX_SQR_MIN_SLOTS);
+      if (cnt <= SMX_SQR_MIN_SLOTS || b.sqr_count + R > SMX_SQR_MAX) continue;
+      const int seg = ((cnt + R - 1) / R + 255) / 256 * 256;
+      int r = 0;
+      for (int lo = 0; lo < cnt; lo += seg, ++r) {
+        const int i = b.sqr_count++;
+        b.sqr_first[i] = m->sq_first[t] + lo; b.sqr_n[i] = std::min(seg, cnt - lo); b.sqr_dst[i] = (int)t * SMX_SQR_PER_TENSOR + r;
+      }
+      m->sq_reduced[t] = (char)r;   // the optimiser reads r partial sums for this tensor
+    }
+    b.sq_total = m->sq_slots + m->sq_total_first;
+    return;
+  }
   fill_adam_args(m, b.adam);
   b.adam.use_sq = 1;
   for (size_t t = 0; t < m->tensors.size(); ++t) { b.adam.sq_first[t] = m->sq_first[t]; b.adam.sq_count[t] = m->sq_count[t]; }
@@ -794,6 +846,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   const float inv_gb = 1.f / (float)ps.global_batch;
   const bool mid = (mode == 0) && use_mid(m, ps.B);
   m->head_loss = false;
+  m->ahead_front_eps = m->ahead_front_drop = false;
   bool front_ok = false; LatentArgs front_la;
   if (mid) {
     SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd", 1));
@@ -826,11 +879,11 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   if (const Injected* ij = inj(m, ST_EPS_Z)) { la.inj_eps = ij->d; la.inj_ld = ij->ld; }
   static const bool no_ahead = getenv("SMX_NO_NOISE_AHEAD") != nullptr;
   if (fuse_lat && m->stochastic && !la.inj_eps && !no_ahead && !m->scvi && m->eps_ahead_ok) { la.inj_eps = m->noise_eps; la.inj_ld = m->Dp; }
+  if (m->ahead_front_eps && !la.inj_eps) { la.inj_eps = m->noise_eps; la.inj_ld = m->Dp; }
   la.z = m->z; la.sig = m->sig; la.eps = m->eps; la.kl = m->kl;
   // The latent sample + KL and the first decoder product run INSIDE the decoder's first BatchNorm launch (two
   // launches fewer) when the shapes allow; SMX_NO_FRONT=1 keeps the three-launch form.
-  front_ok = m->flags.front && !m->scale && !fuse_lat && !sync_bn_on(m, ps.training) && bn_front_supported(ps.B, m->Dp) && (m->Dp == 32 || m->Dp == 64) &&
-             m->dec[0].in_p == m->Dp && m->dec[0].out_p % 8 == 0 && (lat_ld % 4) == 0 && (!la.inj_eps || (la.inj_ld % 4) == 0);
+  front_ok = front_shapes_ok(m, ps) && (!la.inj_eps || (la.inj_ld % 4) == 0);
   front_la = la;
   if (front_ok) {
     // (launched below with the decoder)
@@ -1169,6 +1222,7 @@ int backward_mid(smx_model* m, const Pass& ps, int n_slabs) {
 int backward_pass(smx_model* m, const Pass& ps) {
   const smx_config& c = m->cfg;
   std::fill(m->sq_count.begin(), m->sq_count.end(), 0);   // the products of this step report what they wrote
+  std::fill(m->sq_reduced.begin(), m->sq_reduced.end(), 0);
   m->adam_early_pending = false; m->adam_early_from = -1;
   const float inv_gb = 1.f / (float)ps.global_batch;
   if (m->fvae) SMX_CHECK(factor_backward(m, ps));   // first: it uses the slab buffer the head's backward fills next
@@ -1370,6 +1424,7 @@ void fill_adam_args(smx_model* m, AdamArgs& a) {
   for (size_t t = 0; t < m->tensors.size() && a.use_sq; ++t) {
     a.sq_first[t] = m->sq_first[t]; a.sq_count[t] = m->sq_count[t];
     if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) a.use_sq = 0;
+    if (m->sq_reduced[t]) { a.sq_first[t] = m->sq_total_first + (int)t * SMX_SQR_PER_TENSOR; a.sq_count[t] = m->sq_reduced[t]; }   // riders have summed the slots
   }
   a.sq_slots = m->sq_slots;
   a.state = cur_state(m); a.b1 = c.adam_beta1; a.b2 = c.adam_beta2; a.eps = c.adam_eps; a.clipnorm = c.clipnorm;
@@ -1786,7 +1841,9 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
       m->sq_first[t] = (int)total;
       total += (size_t)((ti.rows_p + 31) / 32) * (size_t)((ti.ld + 31) / 32) * 4;
     }
-    if ((rc = dmalloc(&m->sq_slots, total))) return fail(rc);
+    m->sq_total_first = (int)total;   // SMX_SQR_PER_TENSOR more slots per tensor: the sums the reduce riders leave (attach_early_adam)
+    m->sq_reduced.assign(m->tensors.size(), 0);
+    if ((rc = dmalloc(&m->sq_slots, total + m->tensors.size() * SMX_SQR_PER_TENSOR))) return fail(rc);
   }
   if ((rc = dmalloc(&m->chunks, chunks.size())) || (rc = dmalloc(&m->partial, chunks.size())) ||
       (rc = dmalloc(&m->tensor_norm, m->tensors.size())))
