@@ -271,10 +271,13 @@ int smx_comm_init_local(smx_model* const* models, int n);
  * they replaced (which eval, predict and the scoring paths always use).  name: "head_loss" (output product fused with
  * the likelihood), "front" (latent sample + first decoder product inside BatchNorm-forward), "bwd_front" (d h inside
  * BatchNorm-backward + the weight gradients grouped at the end), "head_bwd" (both backward products of the output
- * head in one launch), "wgrad" (minibatch-contracted weight gradients as the wide kernel).  value 1 = default form,
- * 0 = separate launches.  Results agree to rounding; used for A/B measurements and by the parity tests of both
- * forms.  Defaults may also be set with SMX_NO_HEAD_LOSS / SMX_NO_FRONT / SMX_NO_BWD_FRONT / SMX_NO_HEAD_BWD /
- * SMX_NO_WGRAD in the environment. */
+ * head in one launch), "wgrad" (minibatch-contracted weight gradients as the wide kernel), "scvi_fused" (scvi
+ * training step: library latent + softmax-rate head + likelihood + their backward as one row-local launch,
+ * scvi.py:88-171), "twin" (scvi: the first layers of the encoder and of the library encoder, and pairs of output
+ * heads, side by side in one launch).  value 1 = default form, 0 = separate launches.  Results agree to rounding;
+ * used for A/B measurements and by the parity tests of both forms.  Defaults may also be set with SMX_NO_HEAD_LOSS /
+ * SMX_NO_FRONT / SMX_NO_BWD_FRONT / SMX_NO_HEAD_BWD / SMX_NO_WGRAD / SMX_NO_SCVI_FUSED / SMX_NO_TWIN in the
+ * environment. */
 int smx_set_flag(smx_model* m, const char* name, int value);
 
 /* ---- measurement ---------------------------------------------------------- */

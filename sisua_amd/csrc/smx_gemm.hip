@@ -308,6 +308,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   gemm_body<WM, WN, WK, A_KM, B_NM, XF>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
+// two products side by side along N in one grid: N tiles [0, ny1) belong to g, the rest to g2
+template <int XF>
+__global__ __launch_bounds__(256) void gemm_dual_kernel(GemmArgs g, GemmArgs g2, int ny1) {
+  __shared__ __attribute__((aligned(16))) float smem[GemmSmem<1, 1, 4, 0, 0>::FLOATS];
+  if ((int)blockIdx.y < ny1) gemm_body<1, 1, 4, 0, 0, XF>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+  else gemm_body<1, 1, 4, 0, 0, XF>(g2, blockIdx.x, (int)blockIdx.y - ny1, blockIdx.z, smem);
+}
+
 // the K4 W^T product with the latent-head backward epilogue as its own kernel
 __global__ __launch_bounds__(256) void gemm_latent_bwd_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[GemmSmem<1, 1, 4, 0, 1>::FLOATS];
@@ -504,6 +512,34 @@ static int validate_gemm(GemmArgs& g) {
     set_error("gemm: latent-backward epilogue needs split_k == 1 and N == Dp");
     return SMX_ERR_INVALID;
   }
+  return SMX_OK;
+}
+
+int launch_gemm_dual(hipStream_t st, const GemmArgs& g1_in, const GemmArgs& g2_in, int* eff_split) {
+  GemmArgs g1 = g1_in, g2 = g2_in;
+  int rc = validate_gemm(g1);
+  if (rc == SMX_OK) rc = validate_gemm(g2);
+  if (rc != SMX_OK) return rc;
+  if (g1.a_kmajor || g1.b_nmajor || g2.a_kmajor || g2.b_nmajor || g1.epi || g2.epi || g1.sq_part || g2.sq_part || g1.colsum || g2.colsum ||
+      g1.A != g2.A || g1.lda != g2.lda || g1.M != g2.M || g1.K != g2.K || g1.use_xform != g2.use_xform ||
+      (g1.use_xform && (g1.xf.rows != g2.xf.rows || g1.xf.u16 != g2.xf.u16 || g1.xf.log1p != g2.xf.log1p || g1.xf.drop_p != 0.f || g2.xf.drop_p != 0.f ||
+                        g1.xf.inj_mask || g2.xf.inj_mask))) {
+    set_error("gemm dual: the two products must share the A operand and its transform");
+    return SMX_ERR_INVALID;
+  }
+  g2.split_k = g1.split_k;
+  if (g1.split_k > 1 && (g2.bias || g1.bias)) { set_error("gemm dual: bias needs split_k == 1"); return SMX_ERR_INVALID; }
+  g1.k_chunk = round_up((g1.K + g1.split_k - 1) / g1.split_k, 128);
+  g1.split_k = (g1.K + g1.k_chunk - 1) / g1.k_chunk;
+  g2.k_chunk = g1.k_chunk; g2.split_k = g1.split_k;
+  if (eff_split) *eff_split = g1.split_k;
+  g1.wide_store = g2.wide_store = 0;
+  const int ny1 = g1.N / 32;
+  dim3 grid((g1.M + 31) / 32, ny1 + g2.N / 32, g1.split_k), block(256);
+  if (g1.use_xform && g1.xf.u16) hipLaunchKernelGGL(gemm_dual_kernel<2>, grid, block, 0, st, g1, g2, ny1);
+  else if (g1.use_xform) hipLaunchKernelGGL(gemm_dual_kernel<1>, grid, block, 0, st, g1, g2, ny1);
+  else hipLaunchKernelGGL(gemm_dual_kernel<0>, grid, block, 0, st, g1, g2, ny1);
+  SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
 

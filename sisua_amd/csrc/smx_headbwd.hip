@@ -24,7 +24,8 @@ namespace smx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int NP>
+// SEP: the planes are separate tensors (scvi's heads: W_p [Hp][Gp] each, their own bias / clipnorm)
+template <int NP, int SEP = 0>
 __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
   __shared__ float red[8 * 1024];   // ONE plane's eight partial tiles at a time (32 KB: two workgroups per CU, not one)
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
     float sq = 0.f;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
+      if (SEP) sq = 0.f;
       if (p) __syncthreads();
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[(q * 16 + r) * 64 + lane] = acc[p][r];
@@ -86,11 +88,16 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
 #pragma unroll
         for (int w = 1; w < 8; ++w) t += red[(w * 16 + r) * 64 + lane];
         const int h = h0 + rowof[j];
-        a.dW[(long)h * a.ldw + (long)p * a.Gp + g0 + i] = t;   // rows >= H and columns >= G are zero by construction
+        if (SEP) a.dWp[p][(long)h * a.ldw + g0 + i] = t;
+        else a.dW[(long)h * a.ldw + (long)p * a.Gp + g0 + i] = t;   // rows >= H and columns >= G are zero by construction
         sq += t * t;
       }
+      if (SEP && a.sqp[p]) {
+        const float sw = wave_sum(sq);
+        if (lane == 0) a.sqp[p][((long)ht * a.n_gt + gt) * 8 + q] = sw;
+      }
     }
-    if (a.sq_part) {
+    if (!SEP && a.sq_part) {
       sq = wave_sum(sq);
       if (lane == 0) a.sq_part[((long)ht * a.n_gt + gt) * 8 + q] = sq;   // 8 slots per (H tile, gene tile): <= 4 per 32 x 32 tile
     }
@@ -103,7 +110,10 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) t += red[(w * NP + q) * 64 + lane] + red[(w * NP + q) * 64 + 32 + lane];
-        a.db[(long)q * a.Gp + g0 + lane] = t;
+        if (SEP) {   // (q is wave-uniform; the pointer array is indexed with constants only)
+          float* dbq = q == 0 ? a.dbp[0] : (q == 1 ? a.dbp[1] : a.dbp[2]);
+          dbq[g0 + lane] = t;
+        } else a.db[(long)q * a.Gp + g0 + lane] = t;
       }
     }
     return;
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int cell = min(m0 + i, a.B - 1);       // rows beyond the minibatch compute garbage that nobody reads
   const float* ap = a.dP + (long)cell * a.ldp;
-  const float* bp = a.W + (long)(h0 + i) * a.ldw;
+  const float* bp = SEP ? a.Wp[0] : a.W + (long)(h0 + i) * a.ldw;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // one 512-wide slab per iteration: lane (i, hh) of wave q supplies the 32 consecutive k at 64 q + 32 hh -- one whole
   // 128-byte line of row i of dP and of row h0 + i of W per lane (eight 16-byte loads each, unconditional: a
@@ -136,10 +146,16 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
     const bool on = k0 < kend;                       // kend is a multiple of 32: a lane's 32 k are all in or all out
     const long kl = on ? k0 : kbeg;                  // (loads of an 'out' lane read valid memory and are zeroed below)
     float4 a4[8], b4[8];
+    const float* bq = bp + kl;
+    if (SEP) {   // plane of this lane's 32 k (Gp is a multiple of 32: never straddled)
+      const int pl = (int)(kl / a.Gp);
+      const float* wb = pl == 0 ? a.Wp[0] : (pl == 1 ? a.Wp[1] : a.Wp[2]);
+      bq = wb + (long)(h0 + i) * a.ldw + (kl - (long)pl * a.Gp);
+    }
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
       a4[v] = *reinterpret_cast<const float4*>(ap + kl + 4 * v);
-      b4[v] = *reinterpret_cast<const float4*>(bp + kl + 4 * v);
+      b4[v] = *reinterpret_cast<const float4*>(bq + 4 * v);
     }
     __builtin_amdgcn_sched_barrier(0);
     const float m = on ? 1.f : 0.f;
@@ -178,7 +194,12 @@ int head_bwd_slices(long ldp, int max_slabs, int* k_chunk) {
 
 int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a_in) {
   HeadBwdArgs a = a_in;
-  if (!head_bwd_supported(a.B, a.Hp, a.Gp) || !a.D || !a.dP || !a.W || !a.dW || !a.db || !a.slab || (a.ldp % 4) || (a.ldw % 4) ||
+  bool ptrs = a.W && a.dW && a.db;
+  if (a.sep) {
+    ptrs = a.n_planes >= 2 && a.n_planes <= 3;
+    for (int p = 0; p < a.n_planes && ptrs; ++p) ptrs = a.Wp[p] && a.dWp[p] && a.dbp[p];
+  }
+  if (!head_bwd_supported(a.B, a.Hp, a.Gp) || !a.D || !a.dP || !ptrs || !a.slab || (a.ldp % 4) || (a.ldw % 4) ||
       a.n_slices < 1 || a.k_chunk % 512) {
     set_error("out_head_bwd: bad shapes");
     return SMX_ERR_INVALID;
@@ -189,6 +210,14 @@ int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a_in) {
   const int n_d = a.n_ct * a.n_ht * ((a.n_slices + 7) / 8 * 8);
   if (a.sq_count) *a.sq_count = a.n_ht * a.n_gt * 8;
   dim3 grid((unsigned)(a.n_w + n_d));
+  if (a.sep) {
+    for (int p = 0; p < a.n_planes; ++p)
+      if (a.sqp[p] && a.sq_countp[p]) *a.sq_countp[p] = a.n_ht * a.n_gt * 8;
+    if (a.n_planes == 3) hipLaunchKernelGGL((out_head_bwd_kernel<3, 1>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((out_head_bwd_kernel<2, 1>), grid, dim3(512), 0, st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   if (a.n_planes == 3) hipLaunchKernelGGL((out_head_bwd_kernel<3>), grid, dim3(512), 0, st, a);
   else if (a.n_planes == 2) hipLaunchKernelGGL((out_head_bwd_kernel<2>), grid, dim3(512), 0, st, a);
   else { set_error("out_head_bwd: 2 or 3 planes"); return SMX_ERR_INVALID; }

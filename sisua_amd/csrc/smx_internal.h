@@ -80,6 +80,9 @@ int launch_gemm(hipStream_t st, const GemmArgs& g, int* eff_split = nullptr);
 // the slab count of problem i.
 #define SMX_GROUP_MAX 8
 int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_splits = nullptr);
+// Two products that share the A operand (same M, K, layout, gather transform) and the split factor, side by side along N
+// in ONE launch of the 32x32-K4 kernel (scvi: first layers of both encoders; the two / three output heads).
+int launch_gemm_dual(hipStream_t st, const GemmArgs& g1, const GemmArgs& g2, int* eff_split = nullptr);
 // Heuristic split-K factor used by the model for K-heavy products.
 int suggest_split_k(int M, int N, int K);
 
@@ -237,6 +240,10 @@ struct BnBwdArgs {
 };
 bool bn_bwd_front_supported(int B, int K);
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a);
+// two layers over the same minibatch in ONE launch (scvi: encoder + library encoder)
+bool bn_dual_supported(int B);
+int launch_bn_act_fwd_dual(hipStream_t st, const BnFwdArgs& a, const BnFwdArgs& b);
+int launch_bn_act_bwd_dual(hipStream_t st, const BnBwdArgs& a, const BnBwdArgs& b);   // both with the gradient front
 
 // SyncBatchNorm (smx_kernels.hip): phase 0 leaves this rank's column statistics in `gather` [world][2][Hp],
 // the caller all-reduces it, phase 1 finishes the pass with the global statistics.
@@ -286,6 +293,29 @@ struct ScviHeadArgs {
 };
 int launch_scvi_head_fwd(hipStream_t st, const ScviHeadArgs& a);
 int launch_scvi_head_bwd(hipStream_t st, const ScviHeadArgs& a);
+
+// scvi head of a training step as ONE row-local launch (smx_scvi.hip): library latent (its head as dot products,
+// sample, KL), softmax-rate head, NBD / ZINBD likelihood + gradient, backward through the head and the library latent
+struct ScviTrainArgs {
+  const float* raw = nullptr; long ld = 0; long plane_stride = 0;   // raw head outputs [B][k][Gp] (bias added)
+  int B = 0, G = 0, Gp = 0; int likelihood = 0;
+  const float* X = nullptr; int ldx = 0; int x_u16 = 0; const int32_t* rows = nullptr;
+  float clip_library = 1e3f; float grad_scale = 1.f;
+  float* draw = nullptr;       // [B][ld] d loss / d raw
+  float* llk_part = nullptr;   // [B] one partial per cell (without the -lgamma(x+1) constant)
+  const float* hl = nullptr; int ldh = 0; int Kl = 0;                    // library encoder output [B][ldh], Kl columns
+  const float* Wl = nullptr; int ldwl = 0; const float* bl = nullptr;    // library latent head [Kl][ldwl] (columns mu, s), bias
+  const float* library = nullptr; uint32_t cell_base = 0;
+  NoiseKey nk{0, 0, 0, 0, nullptr};
+  const float* inj_eps = nullptr; int inj_ld = 1;
+  float kl_scale = 0.f;
+  float* latl = nullptr; int ldl = 0;                                    // [B][ldl]: (mu_l, s_l) kept for inspection
+  float* l = nullptr; float* sig = nullptr; float* eps = nullptr; float* kl = nullptr;   // [B]
+  float* dlatl = nullptr;      // [B][ldl] gradient wrt (mu_l, s_l), zeros beyond
+  float* dl = nullptr;         // [B]
+};
+bool scvi_head_train_supported(const ScviTrainArgs& a);
+int launch_scvi_head_train(hipStream_t st, const ScviTrainArgs& a);
 
 struct LabelArgs {
   int kind = 0;                  // smx_label_likelihood
@@ -402,6 +432,9 @@ struct HeadBwdArgs {
   int B = 0, Hp = 0, Gp = 0, n_planes = 0;
   int n_slices = 0, k_chunk = 0;                   // from head_bwd_slices
   float* sq_part = nullptr; int* sq_count = nullptr;
+  // sep != 0 (scvi): every plane is a tensor of its own -- W / dW [Hp][ldw = Gp], bias gradient [Gp], sum-of-squares slots
+  int sep = 0; const float* Wp[3] = {nullptr, nullptr, nullptr}; float* dWp[3] = {nullptr, nullptr, nullptr};
+  float* dbp[3] = {nullptr, nullptr, nullptr}; float* sqp[3] = {nullptr, nullptr, nullptr}; int* sq_countp[3] = {nullptr, nullptr, nullptr};
   int n_ht = 0, n_gt = 0, n_ct = 0, n_w = 0;       // set by the launcher
   int diag = 0;                                    // SMX_HEADBWD_DIAG bit 1 / 2: role-0 / role-1 workgroups return at once (timing only)
 };

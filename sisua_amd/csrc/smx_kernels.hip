@@ -295,18 +295,18 @@ __device__ inline void latent_tile_to_lds(const LatentArgs& a, float* zs, bool s
   }
 }
 
-template <int RPT, int FRONT = 0>
-__global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
+template <int RPT, int FRONT>
+__device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
   constexpr bool SMALL = RPT > 0;
   constexpr int BN_RPT = SMALL ? RPT : BN_RPT_DEFAULT;
-  if ((int)blockIdx.x >= a.Hp / BN_COLS) {
-    noise_fill(a, (int)blockIdx.x - a.Hp / BN_COLS);
+  if (bid >= a.Hp / BN_COLS) {
+    noise_fill(a, bid - a.Hp / BN_COLS);
     return;
   }
   __shared__ float sh[BN_WAVES * BN_COLS];
   extern __shared__ float zs[];   // FRONT: [B][Dp + 1]
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
-  const int col = blockIdx.x * BN_COLS + c;
+  const int col = bid * BN_COLS + c;
   const bool live = col < a.H;  // padded columns produce zeros
   const float bias = (!a.batchnorm && a.bias && live) ? a.bias[col] : 0.f;
   constexpr int CH = BN_RL * BN_RPT;
@@ -317,8 +317,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
     float* ws = zs + a.B * (a.lat.Dp + 1);       // [Dp][BN_COLS]
     float wl = 0.f;
     const bool wl_on = (int)threadIdx.x < a.lat.Dp * BN_COLS;
-    if (wl_on) wl = a.W[(long)(threadIdx.x / BN_COLS) * a.ldw + blockIdx.x * BN_COLS + (threadIdx.x % BN_COLS)];
-    latent_tile_to_lds<BN_RPT * 2>(a.lat, zs, blockIdx.x == 0);   // B Dp / 4 quads over 512 threads: <= 2 RPT iterations
+    if (wl_on) wl = a.W[(long)(threadIdx.x / BN_COLS) * a.ldw + bid * BN_COLS + (threadIdx.x % BN_COLS)];
+    latent_tile_to_lds<BN_RPT * 2>(a.lat, zs, bid == 0);   // B Dp / 4 quads over 512 threads: <= 2 RPT iterations
     if (wl_on) ws[threadIdx.x] = wl;
     __syncthreads();
 #pragma unroll
@@ -434,6 +434,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) {
   }
 }
 
+template <int RPT, int FRONT = 0>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) { bn_act_fwd_body<RPT, FRONT>(a, (int)blockIdx.x); }
+// two independent layers over the same minibatch in ONE launch (scvi: first layers of the encoder and of the library
+// encoder): blocks [0, na) belong to a (its column blocks, then its noise jobs), the rest to b
+template <int RPT>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_dual_kernel(BnFwdArgs a, BnFwdArgs b, int na) {
+  if ((int)blockIdx.x < na) bn_act_fwd_body<RPT, 0>(a, (int)blockIdx.x);
+  else bn_act_fwd_body<RPT, 0>(b, (int)blockIdx.x - na);
+}
+
 static int bn_diag() { static const int v = getenv("SMX_BN_DIAG") ? atoi(getenv("SMX_BN_DIAG")) : 0; return v; }
 
 bool bn_front_supported(int B, int Dp) {
@@ -473,17 +483,32 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
   return SMX_OK;
 }
 
+// two layers over the same minibatch, one launch (no latent front, no SyncBatchNorm; register-resident forms only)
+bool bn_dual_supported(int B) { return B > 0 && B <= BN_RL * 4; }
+int launch_bn_act_fwd_dual(hipStream_t st, const BnFwdArgs& a, const BnFwdArgs& b) {
+  if (a.front || b.front || b.n_jobs || a.B != b.B || !bn_dual_supported(a.B) || a.Hp % BN_COLS || b.Hp % BN_COLS) {
+    set_error("bn_act_fwd_dual: bad shapes");
+    return SMX_ERR_INVALID;
+  }
+  const int na = a.Hp / BN_COLS + a.n_jobs * SMX_NOISE_BLOCKS_PER_JOB;
+  const int grid = na + b.Hp / BN_COLS;
+  if (a.B <= BN_RL * 2) hipLaunchKernelGGL(bn_act_fwd_dual_kernel<2>, dim3(grid), dim3(BN_THREADS), 0, st, a, b, na);
+  else hipLaunchKernelGGL(bn_act_fwd_dual_kernel<4>, dim3(grid), dim3(BN_THREADS), 0, st, a, b, na);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
 __device__ inline void metrics_body(const MetricsArgs& a);
 __device__ inline void adam_chunk_body(const AdamArgs& a, int chunk);
 __device__ inline void sq_reduce_body(const float* sl, int cnt, float* dst);
 
-template <int RPT, int FRONT = 0>
-__global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
+template <int RPT, int FRONT>
+__device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
   constexpr bool SMALL = RPT > 0;
   constexpr int BN_RPT = SMALL ? RPT : BN_RPT_DEFAULT;
   extern __shared__ float ds[];   // FRONT: d lat tile [B][fK + 1]
   {
-    const int nb = a.Hp / BN_COLS, extra = (int)blockIdx.x - nb;
+    const int nb = a.Hp / BN_COLS, extra = bid - nb;
     if (extra >= 0) {
       if (threadIdx.x >= 256) return;                   // the riders are 256-thread bodies
       const int e = extra - (a.with_metrics ? 1 : 0);
@@ -498,7 +523,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
   }
   __shared__ float sh[BN_WAVES * BN_COLS];
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
-  const int col = blockIdx.x * BN_COLS + c;
+  const int col = bid * BN_COLS + c;
   const bool live = col < a.H;
   constexpr int CH = BN_RL * BN_RPT;
   float dyreg[BN_RPT], xhreg[BN_RPT];
@@ -512,7 +537,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
     const int ldw_s = a.fK + 4;
     float4 wl = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool wl_on = (int)threadIdx.x < BN_COLS * kq && !(a.diag & 64);
-    if (wl_on) wl = *reinterpret_cast<const float4*>(a.fW + (long)(blockIdx.x * BN_COLS + threadIdx.x / kq) * a.fldw + (threadIdx.x % kq) * 4);
+    if (wl_on) wl = *reinterpret_cast<const float4*>(a.fW + (long)(bid * BN_COLS + threadIdx.x / kq) * a.fldw + (threadIdx.x % kq) * 4);
     {   // all loads of the tile in flight at once (B fK / 4 float4 over 512 threads: <= 2 RPT per thread), then LDS
       constexpr int MAXIT = BN_RPT * 2;
       float4 tl[MAXIT];
@@ -606,6 +631,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) {
   }
 }
 
+template <int RPT, int FRONT = 0>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) { bn_act_bwd_body<RPT, FRONT>(a, (int)blockIdx.x); }
+// two independent layers in ONE launch, both with the gradient front (scvi: last layers of the encoder and of the
+// library encoder): blocks [0, na) belong to a (column blocks, then its riders), the rest to b (no riders)
+template <int RPT>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_dual_kernel(BnBwdArgs a, BnBwdArgs b, int na) {
+  if ((int)blockIdx.x < na) bn_act_bwd_body<RPT, 1>(a, (int)blockIdx.x);
+  else bn_act_bwd_body<RPT, 1>(b, (int)blockIdx.x - na);
+}
+
 bool bn_bwd_front_supported(int B, int K) {
   return B > 0 && B <= BN_RL * 4 && (K == 32 || K == 64) && ((size_t)B * (K + 1) + 8 * (K + 4)) * sizeof(float) <= 96 * 1024;
 }
@@ -636,6 +671,30 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
   else if (a.B <= BN_RL * 8) hipLaunchKernelGGL(bn_act_bwd_kernel<8>, dim3(grid), dim3(BN_THREADS), 0, st, a);
   else if (a.B <= BN_RL * 16) hipLaunchKernelGGL(bn_act_bwd_kernel<16>, dim3(grid), dim3(BN_THREADS), 0, st, a);
   else hipLaunchKernelGGL(bn_act_bwd_kernel<0>, dim3(grid), dim3(BN_THREADS), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// both layers with the gradient front (their incoming gradients as dot products of an LDS tile)
+int launch_bn_act_bwd_dual(hipStream_t st, const BnBwdArgs& a_in, const BnBwdArgs& b_in) {
+  BnBwdArgs a = a_in, b = b_in;
+  a.diag = b.diag = 0;
+  auto ok = [](const BnBwdArgs& x) {
+    return x.front && bn_bwd_front_supported(x.B, x.fK) && x.fD && x.fW && !(x.fld % 4) && !(x.fldw % 4) && !(x.Hp % BN_COLS);
+  };
+  if (!ok(a) || !ok(b) || a.B != b.B || !bn_dual_supported(a.B) || b.with_metrics || b.adam_count || b.sqr_count) {
+    set_error("bn_act_bwd_dual: gradient fronts not applicable");
+    return SMX_ERR_INVALID;
+  }
+  const int na = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count + a.sqr_count;
+  const int grid = na + b.Hp / BN_COLS;
+  auto need = [](const BnBwdArgs& x) { return ((size_t)x.B * (x.fK + 1) + 4 + (size_t)BN_COLS * (x.fK + 4)) * sizeof(float); };
+  const size_t lds = need(a) > need(b) ? need(a) : need(b);
+  static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_bwd_dual_kernel<4>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+  if (lds > 64 * 1024 && !big_ok) { set_error("bn_act_bwd_dual: cannot reserve the dynamic LDS of the gradient fronts"); return SMX_ERR_HIP; }
+  if (a.B <= BN_RL * 2) hipLaunchKernelGGL(bn_act_bwd_dual_kernel<2>, dim3(grid), dim3(BN_THREADS), lds, st, a, b, na);
+  else hipLaunchKernelGGL(bn_act_bwd_dual_kernel<4>, dim3(grid), dim3(BN_THREADS), lds, st, a, b, na);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }

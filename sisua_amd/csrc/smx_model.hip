@@ -250,6 +250,8 @@ struct smx_model {
     int bwd_front = getenv("SMX_NO_BWD_FRONT") ? 0 : 1;    // d h inside BatchNorm-backward, weight gradients grouped at the end
     int head_bwd = getenv("SMX_NO_HEAD_BWD") ? 0 : 1;      // both backward products of the output head in one wide launch
     int wgrad = getenv("SMX_NO_WGRAD") ? 0 : 1;            // K = minibatch weight gradients as the wide direct-operand kernel
+    int scvi_fused = getenv("SMX_NO_SCVI_FUSED") ? 0 : 1;  // scvi: library latent + softmax head + likelihood + their backward as one row-local launch
+    int twin = getenv("SMX_NO_TWIN") ? 0 : 1;              // scvi: first layers of both encoders (and pairs of heads) side by side in one launch
   } flags;
   int chunk_first_head = 0;           // first optimiser chunk of the output / label heads (they are last in the table)
   bool adam_early_pending = false;    // the heads' gradients are final: the next BatchNorm-backward launch may carry their update
@@ -298,6 +300,8 @@ struct smx_model {
   // draw redundantly in each of its workgroups: eps of the latent sample (-> noise_eps) / the dropout multipliers of
   // the first decoder layer (-> dec[0].noise)
   bool ahead_front_eps = false, ahead_front_drop = false;
+  bool scvi_fused = false;     // this training pass ran the scvi head as ONE row-local launch (smx_scvi.hip)
+  bool encl_twinned = false;   // ... and the library encoder's first layer beside the encoder's (one product + one BatchNorm launch)
   float* noise_eps = nullptr;  // [Bmax][Dp] eps drawn ahead of the latent head
   float *latbuf = nullptr, *dlat = nullptr, *z = nullptr, *sig = nullptr, *eps = nullptr, *kl = nullptr;
   float *latlbuf = nullptr, *dlatl = nullptr, *lsmp = nullptr, *lsig = nullptr, *leps = nullptr, *kl_l = nullptr, *dl = nullptr;
@@ -445,20 +449,23 @@ static bool front_shapes_ok(smx_model* m, const Pass& ps) {
          (m->Dp == 32 || m->Dp == 64) && m->dec[0].in_p == m->Dp && m->dec[0].out_p % 8 == 0 && (lat_ld % 4) == 0;
 }
 
+// twin: another MLP whose FIRST layer consumes the same input (scvi: the library encoder beside the encoder).  When the
+// shapes allow, both first layers run as ONE product launch and ONE BatchNorm launch (side by side along the output
+// columns); *twin_done tells the caller, who then continues the twin from its second layer (first_layer = 1).
 int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
-                const char* label0, int n_layers = -1, const LatentArgs* front = nullptr) {
+                const char* label0, int n_layers = -1, const LatentArgs* front = nullptr, int first_layer = 0,
+                std::vector<MlpLayer>* twin = nullptr, bool* twin_done = nullptr) {
   const float* in = in0;
   int ld = ld0;
   const size_t nl = n_layers < 0 ? mlp.size() : (size_t)n_layers;
-  for (size_t i = 0; i < nl; ++i) {
-    MlpLayer& L = mlp[i];
+  auto make_gemm = [&](MlpLayer& L, const float* a_in, int a_ld, bool first_x, float* slab) {
     const TensorInfo& tw = m->tensors[L.tW];
     GemmArgs g;
-    g.A = in; g.lda = ld; g.B = P_(m, L.tW); g.ldb = tw.ld;
+    g.A = a_in; g.lda = a_ld; g.B = P_(m, L.tW); g.ldb = tw.ld;
     g.M = ps.B; g.N = L.out_p; g.K = L.in_p;
-    g.C = m->slab; g.ldc = L.out_p; g.slab_stride = (long)ps.B * L.out_p;
+    g.C = slab; g.ldc = L.out_p; g.slab_stride = (long)ps.B * L.out_p;
     g.split_k = suggest_split_k(ps.B, L.out_p, L.in_p);
-    if (i == 0 && in_is_x) {
+    if (first_x) {
       g.use_xform = 1;
       g.xf.rows = ps.rows; g.xf.u16 = ps.x_u16; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
       if (ps.training && m->cfg.input_dropout > 0.f) {
@@ -467,22 +474,11 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
         if (const Injected* ij = inj(m, ST_INPUT_DROPOUT)) { g.xf.inj_mask = ij->d; g.xf.inj_ld = ij->ld; }
       }
     }
-    // measured: the 4-workgroup fused small-layer kernels are 3 us/step SLOWER than two wider launches;
-    // opt-in (SMX_SMALL_FUSION=1) and covered by tests/test_gpu_variants.py
-    static const bool no_fz = getenv("SMX_SMALL_FUSION") == nullptr;
-    static const bool no_ahead = getenv("SMX_NO_NOISE_AHEAD") != nullptr;
-    const bool ahead = !no_fz && !no_ahead && !m->scvi;
-    const bool sync = sync_bn_on(m, ps.training) && L.bn >= 0;
-    const bool with_front = (front != nullptr && i == 0);   // the BatchNorm launch produces its own input (latent sample + product)
-    const bool fuse = !no_fz && !sync && !with_front && !(i == 0 && in_is_x) && L.leak == 0.f && dense_bn_fusable(ps.B, L.in_p);
-    int eff = 1;
-    SMX_REQUIRE((size_t)std::max(g.split_k, 1) * (size_t)g.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
-    if (!fuse && !with_front) {
-      Timed t(m, (i == 0 && in_is_x) ? label0 : "gemm_mlp_fwd");
-      SMX_CHECK(launch_gemm(m->st, g, &eff));
-    }
+    return g;
+  };
+  auto make_bn = [&](MlpLayer& L, const float* slab, int eff, long slab_stride) {
     BnFwdArgs b;
-    b.pre = m->slab; b.n_slabs = eff; b.slab_stride = g.slab_stride; b.ld = L.out_p;
+    b.pre = slab; b.n_slabs = eff; b.slab_stride = slab_stride; b.ld = L.out_p;
     b.B = ps.B; b.H = L.out; b.Hp = L.out_p; b.batchnorm = L.bn >= 0; b.training = ps.training; b.leak = L.leak;
     if (L.bn >= 0) {
       b.gamma = P_(m, L.tGamma); b.beta = P_(m, L.tBeta);
@@ -498,6 +494,43 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     b.nk = make_key(m, L.stream, ps.sample, true);
     b.rows = ps.rows; b.cell_base = ps.cell_base;
     if (const Injected* ij = inj(m, L.stream)) { b.inj_mask = ij->d; b.inj_ld = ij->ld; }
+    return b;
+  };
+  if (twin_done) *twin_done = false;
+  for (size_t i = (size_t)first_layer; i < nl; ++i) {
+    if (i > 0 && i == (size_t)first_layer) { in = mlp[i - 1].out_buf; ld = mlp[i - 1].out_p; }
+    MlpLayer& L = mlp[i];
+    const TensorInfo& tw = m->tensors[L.tW];
+    GemmArgs g = make_gemm(L, in, ld, i == 0 && in_is_x, m->slab);
+    // measured: the 4-workgroup fused small-layer kernels are 3 us/step SLOWER than two wider launches;
+    // opt-in (SMX_SMALL_FUSION=1) and covered by tests/test_gpu_variants.py
+    static const bool no_fz = getenv("SMX_SMALL_FUSION") == nullptr;
+    static const bool no_ahead = getenv("SMX_NO_NOISE_AHEAD") != nullptr;
+    const bool no_twin = !m->flags.twin;
+    const bool ahead = !no_fz && !no_ahead && !m->scvi;
+    const bool sync = sync_bn_on(m, ps.training) && L.bn >= 0;
+    const bool with_front = (front != nullptr && i == 0);   // the BatchNorm launch produces its own input (latent sample + product)
+    const bool fuse = !no_fz && !sync && !with_front && !(i == 0 && in_is_x) && L.leak == 0.f && dense_bn_fusable(ps.B, L.in_p);
+    int eff = 1;
+    SMX_REQUIRE((size_t)std::max(g.split_k, 1) * (size_t)g.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
+    // ---- the twin's first layer beside this one: one product launch, one BatchNorm launch ----
+    bool dual = false;
+    GemmArgs g2;
+    if (twin && i == 0 && !fuse && !with_front && !sync && !no_twin && no_fz && in_is_x && !twin->empty() && bn_dual_supported(ps.B) &&
+        !(ps.training && m->cfg.input_dropout > 0.f) && (*twin)[0].in_p == L.in_p && L.leak == 0.f && (*twin)[0].leak == 0.f) {
+      MlpLayer& T = (*twin)[0];
+      float* slab2 = m->slab + (size_t)std::max(g.split_k, 1) * (size_t)g.slab_stride;
+      g2 = make_gemm(T, in, ld, true, slab2);
+      dual = ((size_t)std::max(g.split_k, 1) * ((size_t)g.slab_stride + (size_t)g2.slab_stride) <= m->slab_cap);
+    }
+    if (dual) {
+      Timed t(m, label0);
+      SMX_CHECK(launch_gemm_dual(m->st, g, g2, &eff));
+    } else if (!fuse && !with_front) {
+      Timed t(m, (i == 0 && in_is_x) ? label0 : "gemm_mlp_fwd");
+      SMX_CHECK(launch_gemm(m->st, g, &eff));
+    }
+    BnFwdArgs b = make_bn(L, m->slab, eff, g.slab_stride);
     if (fuse && ahead && !b.inj_mask && b.drop_p > 0.f) { b.inj_mask = L.noise; b.inj_ld = L.out_p; }
     if (!fuse && ahead && i == 0 && in_is_x && &mlp == &m->enc) {
       // this launch precedes every fused small layer of the step: draw their noise on otherwise idle CUs
@@ -534,7 +567,13 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
       if (m->stochastic && !inj(m, ST_EPS_Z)) { add(m->noise_eps, m->Dp, m->D, 1, 0.f, ST_EPS_Z); m->ahead_front_eps = true; }
       if (b.n_jobs) b.nk.step_ptr = &cur_state(m)->step;
     }
-    if (with_front) {
+    if (dual) {
+      MlpLayer& T = (*twin)[0];
+      const BnFwdArgs b2 = make_bn(T, g2.C, eff, g2.slab_stride);
+      Timed t(m, "bn_fwd");
+      SMX_CHECK(launch_bn_act_fwd_dual(m->st, b, b2));
+      if (twin_done) *twin_done = true;
+    } else if (with_front) {
       if (m->ahead_front_drop && !b.inj_mask && b.drop_p > 0.f) { b.inj_mask = L.noise; b.inj_ld = L.out_p; }
       b.front = 1; b.lat = *front; b.W = P_(m, L.tW); b.ldw = tw.ld; b.n_jobs = 0;
       Timed t(m, "bn_fwd");
@@ -614,25 +653,35 @@ void want_sq(smx_model* m, GemmArgs& g, int t) {
 int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
                  int n_slabs, bool skip_input_grad, int* out_slabs, const char* label_dw0,
                  const EpiLatentBwd* lat_epi = nullptr, GemmArgs* defer_dw0 = nullptr,
-                 const BnBwdArgs* grad_front = nullptr, std::vector<GemmArgs>* defer = nullptr) {
+                 const BnBwdArgs* grad_front = nullptr, std::vector<GemmArgs>* defer = nullptr,
+                 std::vector<MlpLayer>* twin = nullptr, const BnBwdArgs* twin_front = nullptr, bool* twin_done = nullptr,
+                 bool last_bn_done = false) {
   // grad_front: the LAST layer's BatchNorm-backward launch computes its incoming gradient itself (fD fW^T as dot
   // products) instead of reading slabs.  defer: weight-gradient products that nothing later in the backward pass
   // reads are appended there instead of being launched (the caller runs them as ONE grouped launch at the end).
-  for (int i = (int)mlp.size() - 1; i >= 0; --i) {
-    MlpLayer& L = mlp[i];
-    const TensorInfo& tw = m->tensors[L.tW];
+  // twin / twin_front: another MLP whose last layer's BatchNorm-backward (also with a gradient front) is independent of
+  // this one's: both in ONE launch (*twin_done); the caller then walks the twin with last_bn_done = true.
+  auto make_b = [&](MlpLayer& L, int slabs, const BnBwdArgs* front) {
     BnBwdArgs b;
-    b.dout = m->slab; b.n_slabs = n_slabs; b.slab_stride = (long)ps.B * L.out_p; b.ld = L.out_p;
+    b.dout = m->slab; b.n_slabs = slabs; b.slab_stride = (long)ps.B * L.out_p; b.ld = L.out_p;
     b.out = L.out_buf; b.xhat = L.xhat; b.inv_std = L.inv_std;
     b.B = ps.B; b.H = L.out; b.Hp = L.out_p; b.batchnorm = L.bn >= 0; b.training = ps.training; b.leak = L.leak;
     b.drop_scale = (ps.training && L.drop_p > 0.f) ? 1.f / (1.f - L.drop_p) : 1.f;
     b.dpre = L.dpre;
     if (L.bn >= 0) { b.gamma = P_(m, L.tGamma); b.dgamma = G_(m, L.tGamma); b.dbeta = G_(m, L.tBeta); }
     else b.dbias = G_(m, L.tBias);
-    if (grad_front && i == (int)mlp.size() - 1) {
-      b.front = 1; b.fD = grad_front->fD; b.fld = grad_front->fld; b.fW = grad_front->fW; b.fldw = grad_front->fldw; b.fK = grad_front->fK;
-    }
-    if (sync_bn_on(m, ps.training) && L.bn >= 0) {   // the ELBO scalars then go with a launch of their own (optimizer_pass)
+    if (front) { b.front = 1; b.fD = front->fD; b.fld = front->fld; b.fW = front->fW; b.fldw = front->fldw; b.fK = front->fK; }
+    return b;
+  };
+  if (twin_done) *twin_done = false;
+  for (int i = (int)mlp.size() - 1; i >= 0; --i) {
+    MlpLayer& L = mlp[i];
+    const TensorInfo& tw = m->tensors[L.tW];
+    const bool last = (i == (int)mlp.size() - 1);
+    BnBwdArgs b = make_b(L, n_slabs, (grad_front && last) ? grad_front : nullptr);
+    if (last && last_bn_done) {
+      // (this layer's BatchNorm-backward ran beside the other MLP's)
+    } else if (sync_bn_on(m, ps.training) && L.bn >= 0) {   // the ELBO scalars then go with a launch of their own (optimizer_pass)
       Timed t(m, "bn_bwd");
       m->adam_early_pending = false;
       const BnSyncArgs y = sync_args(m);
@@ -645,7 +694,16 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
       }
       attach_early_adam(m, b);
       Timed t(m, "bn_bwd");
-      SMX_CHECK(launch_bn_act_bwd(m->st, b));
+      const bool dual = last && b.front && twin && twin_front && !twin->empty() && m->flags.twin && bn_dual_supported(ps.B) &&
+                        bn_bwd_front_supported(ps.B, twin_front->fK) && twin->back().out_p % 8 == 0 &&
+                        !(sync_bn_on(m, ps.training) && twin->back().bn >= 0);
+      if (dual) {
+        const BnBwdArgs b2 = make_b(twin->back(), 0, twin_front);
+        SMX_CHECK(launch_bn_act_bwd_dual(m->st, b, b2));
+        if (twin_done) *twin_done = true;
+      } else {
+        SMX_CHECK(launch_bn_act_bwd(m->st, b));
+      }
     }
     // dW = in^T * dpre
     const bool first_x = (i == 0 && in_is_x);
@@ -837,6 +895,32 @@ void fill_mid_args(smx_model* m, const Pass& ps, MidArgs& a) {
   else a.enc0_dbias = G_(m, e0.tBias);
 }
 
+// arguments of the row-local scvi head launch of a training step; returns whether that launch applies
+// (out == nullptr: only the test)
+static bool scvi_train_args(smx_model* m, const Pass& ps, ScviTrainArgs* out) {
+  const smx_config& c = m->cfg;
+  if (!m->scvi || !m->flags.scvi_fused || m->encl.empty()) return false;
+  const MlpLayer& lL = m->encl.back();
+  const TensorInfo& twl = m->tensors[m->t_latlW];
+  ScviTrainArgs a;
+  const long ldp = (long)m->k * m->Gp;
+  a.raw = m->raw; a.ld = ldp; a.plane_stride = m->Gp; a.B = ps.B; a.G = m->G; a.Gp = m->Gp; a.likelihood = c.likelihood;
+  a.X = ps.Xsrc; a.ldx = m->Gp; a.x_u16 = ps.x_u16; a.rows = ps.rows;
+  a.clip_library = c.clip_library; a.grad_scale = -1.f / (float)ps.global_batch;
+  a.draw = m->draw; a.llk_part = m->llk_part;
+  a.hl = lL.out_buf; a.ldh = lL.out_p; a.Kl = lL.out_p;
+  a.Wl = P_(m, m->t_latlW); a.ldwl = twl.ld; a.bl = P_(m, m->t_latlb);
+  a.library = ps.lib; a.cell_base = ps.cell_base;
+  a.nk = make_key(m, ST_EPS_L, ps.sample, ps.training != 0);
+  if (const Injected* ij = inj(m, ST_EPS_L)) { a.inj_eps = ij->d; a.inj_ld = ij->ld; }
+  a.kl_scale = c.beta / (float)ps.global_batch;
+  a.latl = m->latlbuf; a.ldl = 32; a.l = m->lsmp; a.sig = m->lsig; a.eps = m->leps; a.kl = m->kl_l;
+  a.dlatl = m->dlatl; a.dl = m->dl;
+  if (!scvi_head_train_supported(a)) return false;
+  if (out) *out = a;
+  return true;
+}
+
 // mode: 0 full forward; 1 decoder only (z given in m->z); 2 resample (encoder outputs m->latbuf / m->latlbuf kept,
 // only the latent draw and everything after it run again)
 int factor_forward(smx_model* m, const Pass& ps, bool backward);
@@ -847,6 +931,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   const bool mid = (mode == 0) && use_mid(m, ps.B);
   m->head_loss = false;
   m->ahead_front_eps = m->ahead_front_drop = false;
+  m->scvi_fused = false; m->encl_twinned = false;
   bool front_ok = false; LatentArgs front_la;
   if (mid) {
     SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd", 1));
@@ -858,7 +943,9 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   }
   if (!decode_only && !mid) {
   // ---- encoder ----
-  if (!resample) SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd"));
+  bool twin_done = false;
+  if (!resample) SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd", -1, nullptr, 0, m->scvi ? &m->encl : nullptr, &twin_done));
+  m->encl_twinned = twin_done;
   const MlpLayer& eL = m->enc.back();
   const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
   static const bool no_fz = getenv("SMX_SMALL_FUSION") == nullptr;
@@ -904,8 +991,11 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   }
   // ---- scvi library latent ----
   if (m->scvi) {
-    if (!resample) {
-      SMX_CHECK(mlp_forward(m, m->encl, ps, ps.Xsrc, m->Gp, true, "gemm_encl_fwd"));
+    if (!resample) SMX_CHECK(mlp_forward(m, m->encl, ps, ps.Xsrc, m->Gp, true, "gemm_encl_fwd", -1, nullptr, twin_done ? 1 : 0));
+    // training step: the library latent (its head as dot products, the sample, KL_l) is part of the row-local head
+    // launch below (smx_scvi.hip); otherwise the product + lib_latent_fwd pair
+    m->scvi_fused = with_loss && backward && mode == 0 && scvi_train_args(m, ps, nullptr);
+    if (!resample && !m->scvi_fused) {
       const MlpLayer& lL = m->encl.back();
       const TensorInfo& tw = m->tensors[m->t_latlW];
       GemmArgs g;
@@ -913,13 +1003,15 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
       g.C = m->latlbuf; g.ldc = 32; g.M = ps.B; g.N = 32; g.K = lL.out_p; g.bias = P_(m, m->t_latlb);
       SMX_CHECK(launch_gemm(m->st, g));
     }
-    LibLatentArgs ll;
-    ll.latl = m->latlbuf; ll.ld = 32; ll.B = ps.B; ll.library = ps.lib; ll.rows = ps.rows; ll.cell_base = ps.cell_base;
-    ll.nk = make_key(m, ST_EPS_L, ps.sample, ps.training != 0);
-    if (const Injected* ij = inj(m, ST_EPS_L)) { ll.inj_eps = ij->d; ll.inj_ld = ij->ld; }
-    ll.clip_library = c.clip_library;
-    ll.l = m->lsmp; ll.sig = m->lsig; ll.eps = m->leps; ll.kl = m->kl_l;
-    SMX_CHECK(launch_lib_latent_fwd(m->st, ll));
+    if (!m->scvi_fused) {
+      LibLatentArgs ll;
+      ll.latl = m->latlbuf; ll.ld = 32; ll.B = ps.B; ll.library = ps.lib; ll.rows = ps.rows; ll.cell_base = ps.cell_base;
+      ll.nk = make_key(m, ST_EPS_L, ps.sample, ps.training != 0);
+      if (const Injected* ij = inj(m, ST_EPS_L)) { ll.inj_eps = ij->d; ll.inj_ld = ij->ld; }
+      ll.clip_library = c.clip_library;
+      ll.l = m->lsmp; ll.sig = m->lsig; ll.eps = m->leps; ll.kl = m->kl_l;
+      SMX_CHECK(launch_lib_latent_fwd(m->st, ll));
+    }
   }
   }  // !decode_only
   // ---- decoder ----
@@ -927,15 +1019,31 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   const MlpLayer& dL = m->dec.back();
   const long ldp = (long)m->k * m->Gp;
   if (m->scvi) {
+    GemmArgs hg[3];
     for (int ch = 0; ch < m->k; ++ch) {
       const TensorInfo& tw = m->tensors[m->t_outW[ch]];
-      GemmArgs g;
+      GemmArgs& g = hg[ch];
       g.A = dL.out_buf; g.lda = dL.out_p; g.B = P_(m, m->t_outW[ch]); g.ldb = tw.ld;
       g.C = m->raw + (long)ch * m->Gp; g.ldc = (int)ldp; g.M = ps.B; g.N = m->Gp; g.K = dL.out_p;
       g.bias = P_(m, m->t_outb[ch]);
-      Timed t(m, "gemm_out_fwd");
-      SMX_CHECK(launch_gemm(m->st, g));
     }
+    {
+      // the heads read the same decoder output: pairs of them side by side in one launch
+      const bool no_twin = !m->flags.twin;
+      Timed t(m, "gemm_out_fwd");
+      int ch = 0;
+      for (; !no_twin && ch + 1 < m->k; ch += 2) SMX_CHECK(launch_gemm_dual(m->st, hg[ch], hg[ch + 1]));
+      for (; ch < m->k; ++ch) SMX_CHECK(launch_gemm(m->st, hg[ch]));
+    }
+  }
+  if (m->scvi && m->scvi_fused) {
+    ScviTrainArgs st;
+    scvi_train_args(m, ps, &st);
+    // (timing mode: the idempotent launch repeated inside one event pair, as for the other likelihood kernels)
+    const int reps = (!m->capturing && m->timing_label == "loss") ? SMX_LOSS_TIMING_REPEAT : 1;
+    Timed t(m, "loss");
+    for (int r = 0; r < reps; ++r) SMX_CHECK(launch_scvi_head_train(m->st, st));
+  } else if (m->scvi) {
     ScviHeadArgs sh;
     sh.raw = m->raw; sh.planes = m->P; sh.ld = ldp; sh.plane_stride = m->Gp; sh.B = ps.B; sh.G = m->G; sh.Gp = m->Gp;
     sh.k = m->k; sh.l = m->lsmp; sh.clip_library = c.clip_library; sh.rho_raw = m->rho;
@@ -966,7 +1074,9 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   lo.P = m->P; lo.ldp = ldp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
   lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = -inv_gb;
   int n_llk_chunks = loss_chunks(m->Gp, ps.B);
-  if (m->head_loss) {
+  if (m->scvi && m->scvi_fused) {
+    n_llk_chunks = 1;   // the row-local head launch above left one partial per cell
+  } else if (m->head_loss) {
     const TensorInfo& tw = m->tensors[m->t_outW[0]];
     HeadLossArgs hl;
     hl.H = dL.out_buf; hl.ldh = dL.out_p; hl.W = P_(m, m->t_outW[0]); hl.ldw = tw.ld; hl.bias = P_(m, m->t_outb[0]);
@@ -1236,23 +1346,33 @@ int backward_pass(smx_model* m, const Pass& ps) {
     sh.raw = m->raw; sh.planes = m->P; sh.ld = ldp; sh.plane_stride = m->Gp; sh.B = ps.B; sh.G = m->G; sh.Gp = m->Gp;
     sh.k = m->k; sh.l = m->lsmp; sh.clip_library = c.clip_library; sh.rho_raw = m->rho;
     sh.dplanes = m->dP; sh.draw = m->draw; sh.dl = m->dl;
-    SMX_CHECK(launch_scvi_head_bwd(m->st, sh));
+    if (!m->scvi_fused) SMX_CHECK(launch_scvi_head_bwd(m->st, sh));   // (the row-local head launch of the forward pass left d raw and d l)
     dparams = m->draw;
   }
   const int n_heads = m->scvi ? m->k : 1;
   // count heads with raw planes: both products of the output head in one launch of the wide direct-operand kernel
   // (smx_headbwd.hip); SMX_NO_HEAD_BWD=1 or scvi: the grouped LDS-tiled products below
-  const bool hbwd = m->flags.head_bwd && !m->scvi && !m->head_fused && head_bwd_supported(ps.B, dL.out_p, m->Gp);
+  // (scvi: the planes are separate head tensors -- the kernel's SEP form)
+  const bool hbwd = m->flags.head_bwd && !m->head_fused && head_bwd_supported(ps.B, dL.out_p, m->Gp) && (!m->scvi || (m->k >= 2 && m->k <= 3));
   if (hbwd) {
     const TensorInfo& tw = m->tensors[m->t_outW[0]];
     HeadBwdArgs hb;
-    hb.D = dL.out_buf; hb.ldd = dL.out_p; hb.dP = m->dP; hb.ldp = ldp; hb.W = P_(m, m->t_outW[0]); hb.ldw = tw.ld;
+    hb.D = dL.out_buf; hb.ldd = dL.out_p; hb.dP = dparams; hb.ldp = ldp; hb.W = P_(m, m->t_outW[0]); hb.ldw = tw.ld;
     hb.dW = G_(m, m->t_outW[0]); hb.db = G_(m, m->t_outb[0]);
+    if (m->scvi) {
+      hb.sep = 1;
+      for (int ch = 0; ch < m->k; ++ch) {
+        hb.Wp[ch] = P_(m, m->t_outW[ch]); hb.dWp[ch] = G_(m, m->t_outW[ch]); hb.dbp[ch] = G_(m, m->t_outb[ch]);
+        if (m->sq_slots && getenv("SMX_NO_SQ_PARTIALS") == nullptr) {
+          hb.sqp[ch] = m->sq_slots + m->sq_first[(size_t)m->t_outW[ch]]; hb.sq_countp[ch] = &m->sq_count[(size_t)m->t_outW[ch]];
+        }
+      }
+    }
     hb.B = ps.B; hb.Hp = dL.out_p; hb.Gp = m->Gp; hb.n_planes = m->k;
     hb.n_slices = head_bwd_slices(ldp, ldp <= 8192 ? 16 : 32, &hb.k_chunk);
     hb.slab = m->slab; hb.slab_stride = dd_stride;
     SMX_REQUIRE((size_t)hb.n_slices * (size_t)dd_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
-    if (m->sq_slots && getenv("SMX_NO_SQ_PARTIALS") == nullptr) {
+    if (!m->scvi && m->sq_slots && getenv("SMX_NO_SQ_PARTIALS") == nullptr) {
       hb.sq_part = m->sq_slots + m->sq_first[(size_t)m->t_outW[0]]; hb.sq_count = &m->sq_count[(size_t)m->t_outW[0]];
     }
     n_slabs = hb.n_slices;
@@ -1372,27 +1492,47 @@ int backward_pass(smx_model* m, const Pass& ps) {
   }
   GemmArgs dw0[2];
   int n_dw0 = 0;
-  SMX_CHECK(mlp_backward(m, m->enc, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_enc_dw", nullptr, &dw0[n_dw0], bfront ? &gf : nullptr));
+  // scvi: the library encoder's last BatchNorm-backward takes its incoming gradient d h_l = d latl W_latl^T as a front
+  // too (K = 32) -- and then runs beside the encoder's in ONE launch when d latl is there already (the row-local head
+  // launch of the forward pass leaves it); the library head's weight gradient joins the grouped launch at the end
+  BnBwdArgs gfl;
+  bool lfront = false, twin_done = false;
+  if (m->scvi) {
+    const MlpLayer& lL = m->encl.back();
+    const TensorInfo& tw = m->tensors[m->t_latlW];
+    lfront = bfront && bn_bwd_front_supported(ps.B, 32) && lL.out_p % 8 == 0 && (tw.ld % 4) == 0;
+    gfl.fD = m->dlatl; gfl.fld = 32; gfl.fW = P_(m, m->t_latlW); gfl.fldw = tw.ld; gfl.fK = 32;
+  }
+  const bool twin_bwd = m->scvi && lfront && m->scvi_fused;
+  SMX_CHECK(mlp_backward(m, m->enc, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_enc_dw", nullptr, &dw0[n_dw0], bfront ? &gf : nullptr,
+                         nullptr, twin_bwd ? &m->encl : nullptr, twin_bwd ? &gfl : nullptr, &twin_done));
   ++n_dw0;
   // ---- scvi library branch ----
   if (m->scvi) {
-    LibLatentArgs ll;
-    ll.latl = m->latlbuf; ll.ld = 32; ll.B = ps.B; ll.library = ps.lib; ll.rows = ps.rows;
-    ll.sig = m->lsig; ll.eps = m->leps; ll.dl = m->dl; ll.kl_scale = c.beta * inv_gb; ll.dlatl = m->dlatl;
-    SMX_CHECK(launch_lib_latent_bwd(m->st, ll));
+    if (!m->scvi_fused) {
+      LibLatentArgs ll;
+      ll.latl = m->latlbuf; ll.ld = 32; ll.B = ps.B; ll.library = ps.lib; ll.rows = ps.rows;
+      ll.sig = m->lsig; ll.eps = m->leps; ll.dl = m->dl; ll.kl_scale = c.beta * inv_gb; ll.dlatl = m->dlatl;
+      SMX_CHECK(launch_lib_latent_bwd(m->st, ll));
+    }
     const MlpLayer& lL = m->encl.back();
     const TensorInfo& tw = m->tensors[m->t_latlW];
     GemmArgs g;
     g.A = lL.out_buf; g.lda = lL.out_p; g.a_kmajor = 1; g.B = m->dlatl; g.ldb = 32;
     g.C = G_(m, m->t_latlW); g.ldc = tw.ld; g.M = lL.out_p; g.N = 32; g.K = ps.B; g.colsum = G_(m, m->t_latlb);
     want_sq(m, g, m->t_latlW);
-    GemmArgs h;
-    h.A = m->dlatl; h.lda = 32; h.B = P_(m, m->t_latlW); h.ldb = tw.ld; h.b_nmajor = 1;
-    h.C = m->slab; h.ldc = lL.out_p; h.slab_stride = (long)ps.B * lL.out_p;
-    h.M = ps.B; h.N = lL.out_p; h.K = 32;
-    GemmArgs pair[2] = {g, h};   // weight and input gradient of the library head: independent, one grouped launch
-    SMX_CHECK(launch_gemm_group(m->st, pair, 2));
-    SMX_CHECK(mlp_backward(m, m->encl, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_encl_dw", nullptr, &dw0[n_dw0]));
+    if (lfront) {
+      tail.push_back(g);
+    } else {
+      GemmArgs h;
+      h.A = m->dlatl; h.lda = 32; h.B = P_(m, m->t_latlW); h.ldb = tw.ld; h.b_nmajor = 1;
+      h.C = m->slab; h.ldc = lL.out_p; h.slab_stride = (long)ps.B * lL.out_p;
+      h.M = ps.B; h.N = lL.out_p; h.K = 32;
+      GemmArgs pair[2] = {g, h};   // weight and input gradient of the library head: independent, one grouped launch
+      SMX_CHECK(launch_gemm_group(m->st, pair, 2));
+    }
+    SMX_CHECK(mlp_backward(m, m->encl, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_encl_dw", nullptr, &dw0[n_dw0],
+                           lfront ? &gfl : nullptr, nullptr, nullptr, nullptr, nullptr, twin_done));
     ++n_dw0;
   }
   // the first-layer weight gradients (gather + log1p of the same resident rows) of the encoder and, for scvi,
@@ -1839,7 +1979,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     for (size_t t = 0; t < m->tensors.size(); ++t) {
       const TensorInfo& ti = m->tensors[t];
       m->sq_first[t] = (int)total;
-      total += (size_t)((ti.rows_p + 31) / 32) * (size_t)((ti.ld + 31) / 32) * 4;
+      total += (size_t)((ti.rows_p + 31) / 32) * (size_t)((ti.ld + 31) / 32) * 8;   // (the wide head-backward kernel leaves 8 per tile when the planes are separate tensors)
     }
     m->sq_total_first = (int)total;   // SMX_SQR_PER_TENSOR more slots per tensor: the sums the reduce riders leave (attach_early_adam)
     m->sq_reduced.assign(m->tensors.size(), 0);
@@ -2567,8 +2707,9 @@ int smx_set_flag(smx_model* m, const char* name, int value) {
   SMX_HIP(hipStreamSynchronize(m->st));
   const std::string n(name);
   int* f = n == "head_loss" ? &m->flags.head_loss : n == "front" ? &m->flags.front : n == "bwd_front" ? &m->flags.bwd_front
-         : n == "head_bwd" ? &m->flags.head_bwd : n == "wgrad" ? &m->flags.wgrad : nullptr;
-  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad)");
+         : n == "head_bwd" ? &m->flags.head_bwd : n == "wgrad" ? &m->flags.wgrad : n == "scvi_fused" ? &m->flags.scvi_fused
+         : n == "twin" ? &m->flags.twin : nullptr;
+  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin)");
   *f = value ? 1 : 0;
   drop_graphs(m);   // a captured step bakes the launch sequence in
   return SMX_OK;

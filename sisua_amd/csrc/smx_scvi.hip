@@ -1,0 +1,203 @@
+// smx_scvi.hip -- the scVI output head of a TRAINING step as one row-local launch (SURVEY.md 8 row a-12;
+// sisua/models/scvi.py:88-171):
+//
+//   library latent  (mu_l, s_l) = h_l W_l + b_l  ->  l = mu_l + sigma_l eps,  KL_l vs N(local_mean, sqrt(local_var))
+//   head            rho = clip(softmax_G(raw_0)),  rate = exp(clip(l, 0, 1e3)) rho,  theta = exp(raw_1),  gate = raw_2
+//   likelihood      NBD / ZINBD log-likelihood of the cell's counts and its gradient wrt (rate, theta, gate)
+//   backward        through exp / the softmax (row sums) -> d raw planes;  d l -> d (mu_l, s_l)
+//
+// Every step of that chain is local to one cell's row of G genes, so one 256-thread workgroup per cell keeps the row
+// in registers from the raw head outputs to their gradients: the activated planes, their gradients and the saved
+// softmax never exist in memory.  It replaces five launches of the separate form (library-latent product,
+// lib_latent_fwd, scvi_head_fwd, count_loss, scvi_head_bwd) and lib_latent_bwd: 6 launches, ~33 us of a 180 us step
+// at batch 256.  Evaluation / prediction / scoring keep the separate kernels (they hand the planes back).
+#include <stdlib.h>
+
+#include "smx_internal.h"
+#include "smx_loss.h"
+#include "../../include/sisua_hip.h"
+
+namespace smx {
+
+__device__ inline float scvi_block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__device__ inline float scvi_block_max(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+template <int NV, int LK, int U16>
+__global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
+  constexpr int K3 = (LK == SMX_LLK_ZINBD) ? 1 : 0;
+  __shared__ float sh[4];
+  __shared__ float shl[2];
+  const int b = blockIdx.x;
+  const long src = a.rows ? a.rows[b] : b;
+  const float* raw = a.raw + (long)b * a.ld;
+  // ---- every load of the row first: raw planes and the cell's counts ------------------------------------------------
+  float4 r0[NV], r1[NV], r2[NV], xv[NV];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const bool ok = g < a.Gp;
+    r0[j] = ok ? *reinterpret_cast<const float4*>(raw + g) : z4;
+    r1[j] = ok ? *reinterpret_cast<const float4*>(raw + a.plane_stride + g) : z4;
+    r2[j] = (ok && K3) ? *reinterpret_cast<const float4*>(raw + 2 * a.plane_stride + g) : z4;
+    if (U16) {
+      const ushort4 h = ok ? *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(a.X) + src * a.ldx + g) : make_ushort4(0, 0, 0, 0);
+      xv[j] = make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+    } else {
+      xv[j] = ok ? *reinterpret_cast<const float4*>(a.X + src * a.ldx + g) : z4;
+    }
+  }
+  // ---- library latent of this cell (wave 0; its loads overlap the row's) ----------------------------------------------
+  float mu_l = 0.f, sraw_l = 0.f, sig_l = 1.f, eps_l = 0.f, mp = 0.f, vp = 1.f;
+  if (threadIdx.x < 64) {
+    float p0 = 0.f, p1 = 0.f;
+    for (int k = threadIdx.x; k < a.Kl; k += 64) {
+      const float h = a.hl[(long)b * a.ldh + k];
+      const float2 w = *reinterpret_cast<const float2*>(a.Wl + (long)k * a.ldwl);
+      p0 = fmaf(h, w.x, p0); p1 = fmaf(h, w.y, p1);
+    }
+    p0 = wave_sum(p0); p1 = wave_sum(p1);
+    if (threadIdx.x == 0) {
+      mu_l = p0 + a.bl[0]; sraw_l = p1 + a.bl[1];
+      sig_l = softplusf(sraw_l + SMX_SOFTPLUS_INV_1);
+      if (a.inj_eps) eps_l = a.inj_eps[(long)b * a.inj_ld];
+      else eps_l = normal4(philox_block(a.nk, a.cell_base + (uint32_t)src, 0u)).x;
+      mp = a.library[src * 2]; vp = a.library[src * 2 + 1];
+      const float sp = sqrtf(vp);
+      const float l = mu_l + sig_l * eps_l;
+      a.l[b] = l; a.sig[b] = sig_l; a.eps[b] = eps_l;
+      a.kl[b] = logf(sp / sig_l) + (sig_l * sig_l + (mu_l - mp) * (mu_l - mp)) / (2.f * vp) - 0.5f;
+      a.latl[(long)b * a.ldl] = mu_l; a.latl[(long)b * a.ldl + 1] = sraw_l;
+      shl[0] = l;
+    }
+  }
+  // ---- softmax over the genes (row max, row sum) ----------------------------------------------------------------------
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const float v[4] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (g + e < a.G) mx = fmaxf(mx, v[e]);
+  }
+  mx = scvi_block_max(mx, sh);   // (its barriers also publish shl[0])
+  float ex[NV][4];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const float v[4] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ex[j][e] = (g + e < a.G) ? fexp(v[e] - mx) : 0.f;
+      sum += ex[j][e];
+    }
+  }
+  sum = scvi_block_sum(sum, sh);
+  const float inv = 1.f / sum;
+  const float lraw = shl[0];
+  const float el = expf(fminf(fmaxf(lraw, 0.f), a.clip_library));
+  // ---- parameters, likelihood and its gradient; the two row sums of the backward pass ---------------------------------
+  float d0s[NV][4], d1s[NV][4], d2s[NV][4], rho[NV][4];
+  float llk_sum = 0.f, s = 0.f, dlh = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const float t[4] = {r1[j].x, r1[j].y, r1[j].z, r1[j].w};
+    const float gt[4] = {r2[j].x, r2[j].y, r2[j].z, r2[j].w};
+    const float xs[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+    float rate[4], th[4], gate[4], llk[4], d0[4], d1[4], d2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool live = g + e < a.G;
+      rho[j][e] = live ? ex[j][e] * inv : 0.f;
+      rate[e] = live ? el * fminf(fmaxf(rho[j][e], 1e-7f), 1.f - 1e-7f) : 1.f;   // (dead lanes: any finite parameters)
+      th[e] = live ? fexp(t[e]) : 1.f;
+      gate[e] = live ? gt[e] : 0.f;
+    }
+    count_elem_vec<LK, 1, 4>(xs, rate, th, gate, llk, d0, d1, d2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool live = g + e < a.G;
+      const float dd = live ? d0[e] * a.grad_scale : 0.f;   // d loss / d rate
+      d0s[j][e] = dd;
+      d1s[j][e] = live ? d1[e] * a.grad_scale * th[e] : 0.f;   // d loss / d raw_1 (theta = exp(raw_1))
+      d2s[j][e] = live ? d2[e] * a.grad_scale : 0.f;
+      if (live) {
+        llk_sum += llk[e];
+        const float inside = (rho[j][e] > 1e-7f && rho[j][e] < 1.f - 1e-7f) ? 1.f : 0.f;
+        s += dd * el * inside * rho[j][e];
+        dlh += dd * rate[e];
+      }
+    }
+  }
+  llk_sum = scvi_block_sum(llk_sum, sh);
+  s = scvi_block_sum(s, sh);
+  dlh = scvi_block_sum(dlh, sh);
+  // ---- gradient wrt the raw head outputs ------------------------------------------------------------------------------
+  float* dr = a.draw + (long)b * a.ld;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    if (g >= a.Gp) continue;
+    float o0[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool live = g + e < a.G;
+      const float inside = (rho[j][e] > 1e-7f && rho[j][e] < 1.f - 1e-7f) ? 1.f : 0.f;
+      o0[e] = live ? rho[j][e] * (d0s[j][e] * el * inside - s) : 0.f;
+    }
+    *reinterpret_cast<float4*>(dr + g) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+    *reinterpret_cast<float4*>(dr + a.plane_stride + g) = make_float4(d1s[j][0], d1s[j][1], d1s[j][2], d1s[j][3]);
+    if (K3) *reinterpret_cast<float4*>(dr + 2 * a.plane_stride + g) = make_float4(d2s[j][0], d2s[j][1], d2s[j][2], d2s[j][3]);
+  }
+  // ---- the cell's scalars: likelihood partial, d l and the library latent's backward ----------------------------------
+  if (threadIdx.x == 0) {
+    a.llk_part[b] = llk_sum;
+    const float dl = (lraw > 0.f && lraw < a.clip_library) ? dlh : 0.f;
+    a.dl[b] = dl;
+    float* o = a.dlatl + (long)b * a.ldl;
+    o[0] = dl + a.kl_scale * (mu_l - mp) / vp;
+    o[1] = (dl * eps_l + a.kl_scale * (sig_l / vp - 1.f / sig_l)) * sigmoidf(sraw_l + SMX_SOFTPLUS_INV_1);
+  }
+  if (threadIdx.x >= 2 && (int)threadIdx.x < a.ldl) a.dlatl[(long)b * a.ldl + threadIdx.x] = 0.f;
+}
+
+bool scvi_head_train_supported(const ScviTrainArgs& a) {
+  static const bool off = getenv("SMX_NO_SCVI_FUSED") != nullptr;
+  return !off && (a.likelihood == SMX_LLK_NBD || a.likelihood == SMX_LLK_ZINBD) && (a.ld % 4) == 0 && (a.plane_stride % 4) == 0 &&
+         (a.Gp % 4) == 0 && a.Gp <= 4096 && (a.ldx % 4) == 0 && (a.ldwl % 2) == 0 && a.ldl >= 2 && a.ldl <= 256 && a.Kl > 0;
+}
+
+template <int NV, int LK>
+static void launch_sht(hipStream_t st, const ScviTrainArgs& a) {
+  if (a.x_u16) hipLaunchKernelGGL((scvi_head_train_kernel<NV, LK, 1>), dim3(a.B), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((scvi_head_train_kernel<NV, LK, 0>), dim3(a.B), dim3(256), 0, st, a);
+}
+
+int launch_scvi_head_train(hipStream_t st, const ScviTrainArgs& a) {
+  if (!scvi_head_train_supported(a) || !a.raw || !a.X || !a.draw || !a.llk_part || !a.hl || !a.Wl || !a.bl || !a.library ||
+      !a.latl || !a.l || !a.sig || !a.eps || !a.kl || !a.dlatl || !a.dl) {
+    set_error("scvi_head_train: bad arguments");
+    return SMX_ERR_INVALID;
+  }
+  const bool zi = a.likelihood == SMX_LLK_ZINBD;
+  if (a.Gp <= 2048) { if (zi) launch_sht<2, SMX_LLK_ZINBD>(st, a); else launch_sht<2, SMX_LLK_NBD>(st, a); }
+  else { if (zi) launch_sht<4, SMX_LLK_ZINBD>(st, a); else launch_sht<4, SMX_LLK_NBD>(st, a); }
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+}  // namespace smx

@@ -140,6 +140,38 @@ def test_separate_launch_forms_match_oracle(Engine, name, flags):
   e.close(); e0.close()
 
 
+@pytest.mark.parametrize("flags", [("scvi_fused",), ("twin",), ("scvi_fused", "twin"), ("scvi_fused", "twin", "bwd_front", "front", "wgrad")])
+@pytest.mark.parametrize("name", ["scvi_zinbd", "scvi_nbd"])
+def test_scvi_separate_launch_forms_match_oracle(Engine, name, flags):
+  """scvi: the row-local head launch of a training step (library latent + softmax head + likelihood + their backward,
+  smx_scvi.hip) and the side-by-side launches of the two encoders / pairs of heads keep their separate-launch forms
+  (what evaluation, prediction and scoring use): same parity bar, and three steps of both forms end within rounding."""
+  kw = CASES[name]
+  spec, cfg, x, ys, lib, mask = _problem(kw)
+  params = perturbed_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  B = 96
+  e, e0 = Engine(cfg, max_batch=128, init=False), Engine(cfg, max_batch=128, init=False)
+  for eng in (e, e0):
+    eng.set_params(params)
+    eng.upload(x, ys, lib, mask, cell_id_base=1000)
+  for f in flags:
+    e.set_flag(f, False)
+  rows = np.random.default_rng(1).choice(x.shape[0], size=B, replace=False).astype(np.int32)
+  res = _oracle_step(spec, params, bn, opt, x, ys, lib, mask, rows, 0, cell_base=1000)
+  for eng in (e, e0):
+    m = eng.train_step(rows)
+    for key in ("loss", "nllk_x", "kl", "kl_l"):
+      assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
+    worst = grad_errors(eng.get_params(which=1), res["grads"])
+    assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  for s in (1, 2):
+    r2 = ((rows + 7 * s) % x.shape[0]).astype(np.int32)
+    m, m0 = e.train_step(r2), e0.train_step(r2)
+  assert np.isclose(m["loss"], m0["loss"], rtol=1e-5)
+  e.close(); e0.close()
+
+
 @pytest.mark.parametrize("name", ["vae_zinb", "sisua", "scvi_zinbd", "fvae", "semifvae"])
 def test_injected_noise_matches_oracle(Engine, name):
   """smx_set_noise hook: same parameters + same minibatch + same injected eps / dropout
