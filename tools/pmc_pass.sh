@@ -6,6 +6,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/pmc
 rm -rf $OUT; mkdir -p $OUT
+[ -x $R/tools/ubench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $R/tools/ubench.hip -o $R/tools/ubench
 for c in FETCH_SIZE WRITE_SIZE; do
   UBENCH_CALIB=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/calib_$c -- $R/tools/ubench > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/bench_$c -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_$c.json 2> $OUT/bench_$c.err
