@@ -410,7 +410,8 @@ int suggest_split_k(int M, int N, int K) {
   if (s < 1) s = 1;
   // very deep K (wide gene panels): a slice longer than 8 tiles is a latency-bound loop on a
   // half-empty chip; trade slab traffic for occupancy, up to 64 slices
-  while (s < 64 && K / s > 1024) s *= 2;
+  static const int deep = getenv("SMX_SPLIT_DEEP") ? atoi(getenv("SMX_SPLIT_DEEP")) : 1024;
+  while (s < 64 && K / s > deep) s *= 2;
   if (s > 64) s = 64;
   const int chunk = round_up((K + s - 1) / s, 128);  // whole 128-deep tiles per slice
   return (K + chunk - 1) / chunk;
