@@ -127,16 +127,26 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
   const int tiles = a.n_ct * a.n_ht;
   const int xcd1 = b1 & 7, idx1 = b1 >> 3;
   const int z = (idx1 / tiles) * 8 + xcd1, t1 = idx1 % tiles;
-  if (z >= a.n_slices) return;
+  if (z >= a.n_slices + a.n_extra) return;
   const int ct = t1 / a.n_ht, ht = t1 % a.n_ht;
   const int m0 = ct * 32, h0 = ht * 32;
-  const long kbeg = (long)z * a.k_chunk, kend = min((long)a.ldp, kbeg + a.k_chunk);
+  long kbeg = (long)z * a.k_chunk, kend = min((long)a.ldp, kbeg + a.k_chunk);
+  const float* Ab = a.dP; long lda_b = a.ldp; const float* Wb = a.W; int ldw_b = a.ldw;
+  const bool extra = z >= a.n_slices;   // block-uniform: a label head's d Y W_lab^T (the array entries picked with constants)
+  if (extra) {
+    const int e = z - a.n_slices;
+    Ab = e == 0 ? a.xA[0] : e == 1 ? a.xA[1] : e == 2 ? a.xA[2] : a.xA[3];
+    lda_b = e == 0 ? a.xlda[0] : e == 1 ? a.xlda[1] : e == 2 ? a.xlda[2] : a.xlda[3];
+    Wb = e == 0 ? a.xW[0] : e == 1 ? a.xW[1] : e == 2 ? a.xW[2] : a.xW[3];
+    ldw_b = e == 0 ? a.xldw[0] : e == 1 ? a.xldw[1] : e == 2 ? a.xldw[2] : a.xldw[3];
+    kbeg = 0; kend = e == 0 ? a.xK[0] : e == 1 ? a.xK[1] : e == 2 ? a.xK[2] : a.xK[3];
+  }
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int cell = min(m0 + i, a.B - 1);       // rows beyond the minibatch compute garbage that nobody reads
-  const float* ap = a.dP + (long)cell * a.ldp;
-  const float* bp = SEP ? a.Wp[0] : a.W + (long)(h0 + i) * a.ldw;
+  const float* ap = Ab + (long)cell * lda_b;
+  const float* bp = (SEP && !extra) ? a.Wp[0] : Wb + (long)(h0 + i) * ldw_b;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // one 512-wide slab per iteration: lane (i, hh) of wave q supplies the 32 consecutive k at 64 q + 32 hh -- one whole
   // 128-byte line of row i of dP and of row h0 + i of W per lane (eight 16-byte loads each, unconditional: a
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
     const long kl = on ? k0 : kbeg;                  // (loads of an 'out' lane read valid memory and are zeroed below)
     float4 a4[8], b4[8];
     const float* bq = bp + kl;
-    if (SEP) {   // plane of this lane's 32 k (Gp is a multiple of 32: never straddled)
+    if (SEP && !extra) {   // plane of this lane's 32 k (Gp is a multiple of 32: never straddled)
       const int pl = (int)(kl / a.Gp);
       const float* wb = pl == 0 ? a.Wp[0] : (pl == 1 ? a.Wp[1] : a.Wp[2]);
       bq = wb + (long)(h0 + i) * a.ldw + (kl - (long)pl * a.Gp);
@@ -207,7 +217,10 @@ int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a_in) {
   { static const int dg = getenv("SMX_HEADBWD_DIAG") ? atoi(getenv("SMX_HEADBWD_DIAG")) : 0; a.diag = dg; }
   a.n_ht = a.Hp / 32; a.n_gt = a.Gp / 32; a.n_ct = (a.B + 31) / 32;
   a.n_w = a.n_ht * ((a.n_gt + 7) / 8 * 8);
-  const int n_d = a.n_ct * a.n_ht * ((a.n_slices + 7) / 8 * 8);
+  if (a.n_extra < 0 || a.n_extra > SMX_MAX_LABELS) { set_error("out_head_bwd: bad label riders"); return SMX_ERR_INVALID; }
+  for (int e = 0; e < a.n_extra; ++e)
+    if (!a.xA[e] || !a.xW[e] || a.xK[e] <= 0 || (a.xK[e] % 32) || (a.xlda[e] % 4) || (a.xldw[e] % 4)) { set_error("out_head_bwd: bad label riders"); return SMX_ERR_INVALID; }
+  const int n_d = a.n_ct * a.n_ht * ((a.n_slices + a.n_extra + 7) / 8 * 8);
   if (a.sq_count) *a.sq_count = a.n_ht * a.n_gt * 8;
   dim3 grid((unsigned)(a.n_w + n_d));
   if (a.sep) {

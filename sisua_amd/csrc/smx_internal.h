@@ -6,6 +6,7 @@
 #include <string>
 
 #include "smx_device.h"
+#include "../../include/sisua_hip.h"
 
 namespace smx {
 
@@ -200,7 +201,8 @@ struct AdamArgs {
   int batch = 0, prepare_next = 0; float lr = 1e-3f;
   float* params = nullptr; float* grads = nullptr; float* m = nullptr; float* v = nullptr;
   const OptChunk* chunks = nullptr; int n_chunks = 0;
-  int n_launch = 0;             // chunks [0, n_launch) are applied by the optimiser launch (the rest rode along earlier)
+  int n_launch = 0;             // workgroups of the optimiser launch: every chunk but [gap_from, gap_from + gap_len) (those rode along earlier)
+  int gap_from = 0, gap_len = 0;
   float* partial = nullptr;     // [n_chunks] sum of squares per chunk
   // norms without the separate pass (use_sq): per tensor either the slots the weight-gradient products wrote
   // (sq_count > 0) or, for small tensors, a sweep of the tensor's gradient by every workgroup that needs it
@@ -435,6 +437,10 @@ struct HeadBwdArgs {
   // sep != 0 (scvi): every plane is a tensor of its own -- W / dW [Hp][ldw = Gp], bias gradient [Gp], sum-of-squares slots
   int sep = 0; const float* Wp[3] = {nullptr, nullptr, nullptr}; float* dWp[3] = {nullptr, nullptr, nullptr};
   float* dbp[3] = {nullptr, nullptr, nullptr}; float* sqp[3] = {nullptr, nullptr, nullptr}; int* sq_countp[3] = {nullptr, nullptr, nullptr};
+  // label heads riding along (SISUA / MISA): n_extra more d d slabs, slab n_slices + e = xA[e] xW[e]^T with xA [B][xlda]
+  // (the head's d Y), xW [Hp][xldw] (its weights), K = xK[e] (a multiple of 32) -- what a grouped launch of its own did
+  int n_extra = 0; const float* xA[SMX_MAX_LABELS] = {nullptr, nullptr, nullptr, nullptr}; int xlda[SMX_MAX_LABELS] = {0, 0, 0, 0};
+  const float* xW[SMX_MAX_LABELS] = {nullptr, nullptr, nullptr, nullptr}; int xldw[SMX_MAX_LABELS] = {0, 0, 0, 0}; int xK[SMX_MAX_LABELS] = {0, 0, 0, 0};
   int n_ht = 0, n_gt = 0, n_ct = 0, n_w = 0;       // set by the launcher
   int diag = 0;                                    // SMX_HEADBWD_DIAG bit 1 / 2: role-0 / role-1 workgroups return at once (timing only)
 };

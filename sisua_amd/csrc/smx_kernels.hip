@@ -1592,7 +1592,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
     metrics_body(a.metrics);
     return;
   }
-  adam_chunk_body(a, (int)blockIdx.x);
+  adam_chunk_body(a, (int)blockIdx.x >= a.gap_from ? (int)blockIdx.x + a.gap_len : (int)blockIdx.x);
   if (blockIdx.x == 0 && a.master) {  // close the step; nobody reads next_state / next_rows during this step
     const uint32_t step = a.state->step, cur = a.state->cursor;
     if (a.hist_dp && threadIdx.x < 8) a.hist_dp[(long)cur * 8 + threadIdx.x] = a.tail_metrics[threadIdx.x];

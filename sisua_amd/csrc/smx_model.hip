@@ -252,8 +252,12 @@ struct smx_model {
     int wgrad = getenv("SMX_NO_WGRAD") ? 0 : 1;            // K = minibatch weight gradients as the wide direct-operand kernel
     int scvi_fused = getenv("SMX_NO_SCVI_FUSED") ? 0 : 1;  // scvi: library latent + softmax head + likelihood + their backward as one row-local launch
     int twin = getenv("SMX_NO_TWIN") ? 0 : 1;              // scvi: first layers of both encoders (and pairs of heads) side by side in one launch
+    int label_ride = getenv("SMX_NO_LABEL_RIDE") ? 0 : 1;  // label heads' backward inside the output head's backward launch + the final grouped launch
   } flags;
   int chunk_first_head = 0;           // first optimiser chunk of the output / label heads (they are last in the table)
+  int chunk_first_label = 0;          // first optimiser chunk of the label heads (n_chunks without label heads)
+  bool lab_deferred = false;          // this step's label-head weight gradients come with the grouped launch at the END of backward
+  int adam_early_to = -1;             // chunks [adam_early_from, adam_early_to) of this step were applied early
   bool adam_early_pending = false;    // the heads' gradients are final: the next BatchNorm-backward launch may carry their update
   int adam_early_from = -1;           // >= 0: chunks [adam_early_from, n_chunks) of this step were applied early
   bool x_u16 = false;   // the resident matrix is stored as uint16 counts (smx_dataset_upload_u16)
@@ -636,9 +640,12 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
   b.adam.use_sq = 1;
   for (size_t t = 0; t < m->tensors.size(); ++t) { b.adam.sq_first[t] = m->sq_first[t]; b.adam.sq_count[t] = m->sq_count[t]; }
   b.adam.master = nullptr; b.adam.with_metrics = 0;
+  // (label heads whose weight gradients come with the grouped launch at the END of the backward pass stay with the
+  // optimiser launch)
+  const int early_to = m->lab_deferred ? m->chunk_first_label : m->n_chunks;
   b.adam_first = m->chunk_first_head;
-  b.adam_count = m->n_chunks - m->chunk_first_head;
-  m->adam_early_from = m->chunk_first_head;
+  b.adam_count = early_to - m->chunk_first_head;
+  m->adam_early_from = m->chunk_first_head; m->adam_early_to = early_to;
 }
 
 // ask the product that writes the gradient of tensor t for sum-of-squares partials
@@ -1341,6 +1348,8 @@ int backward_pass(smx_model* m, const Pass& ps) {
   int n_slabs = 0;
   const long dd_stride = (long)ps.B * dL.out_p;
   const float* dparams = m->dP;
+  std::vector<GemmArgs> lab_dw;
+  m->lab_deferred = false;
   if (m->scvi) {
     ScviHeadArgs sh;
     sh.raw = m->raw; sh.planes = m->P; sh.ld = ldp; sh.plane_stride = m->Gp; sh.B = ps.B; sh.G = m->G; sh.Gp = m->Gp;
@@ -1376,6 +1385,22 @@ int backward_pass(smx_model* m, const Pass& ps) {
       hb.sq_part = m->sq_slots + m->sq_first[(size_t)m->t_outW[0]]; hb.sq_count = &m->sq_count[(size_t)m->t_outW[0]];
     }
     n_slabs = hb.n_slices;
+    // label heads (SISUA / MISA): d d += d Y W_lab^T as extra slabs of this launch, the head's weight gradient with the
+    // grouped launch at the end of the backward pass -- instead of a grouped launch of their own here (8.6 us at C4)
+    if (m->n_heads > 0 && m->flags.label_ride && !m->fvae && !use_mid(m, ps.B)) {
+      bool ok = true;
+      for (int j = 0; j < m->n_heads; ++j) ok = ok && (m->tensors[m->t_labW[j]].ld % 32) == 0;
+      ok = ok && (size_t)(hb.n_slices + m->n_heads) * (size_t)dd_stride <= m->slab_cap;
+      if (ok) {
+        for (int j = 0; j < m->n_heads; ++j) {
+          const TensorInfo& tl = m->tensors[m->t_labW[j]];
+          hb.xA[j] = m->laby_draw[j]; hb.xlda[j] = tl.ld; hb.xW[j] = P_(m, m->t_labW[j]); hb.xldw[j] = tl.ld; hb.xK[j] = tl.ld;
+        }
+        hb.n_extra = m->n_heads;
+        n_slabs += m->n_heads;
+        m->lab_deferred = true;
+      }
+    }
     Timed t(m, "gemm_out_bwd");
     SMX_CHECK(launch_out_head_bwd(m->st, hb));
   }
@@ -1410,6 +1435,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
       g.C = G_(m, m->t_labW[j]); g.ldc = tw.ld; g.M = dL.out_p; g.N = tw.ld; g.K = ps.B;
       g.colsum = G_(m, m->t_labb[j]);
       want_sq(m, g, m->t_labW[j]);
+      if (m->lab_deferred) { lab_dw.push_back(g); continue; }   // (d d rode with the output head's backward launch)
       grp.push_back(g); is_dx.push_back(0);
       GemmArgs h;
       h.A = m->laby_draw[j]; h.lda = tw.ld; h.B = P_(m, m->t_labW[j]); h.ldb = tw.ld; h.b_nmajor = 1;
@@ -1470,6 +1496,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
   const bool bfront = m->flags.bwd_front && !sync_bn_on(m, ps.training) && bn_bwd_front_supported(ps.B, lat_ld) && eL.out_p % 8 == 0;
   std::vector<GemmArgs> tail;
   SMX_CHECK(mlp_backward(m, m->dec, ps, m->z, m->Dp, false, n_slabs, false, nullptr, "", &le, nullptr, nullptr, bfront ? &tail : nullptr));
+  for (const GemmArgs& g : lab_dw) tail.push_back(g);
   BnBwdArgs gf;
   {  // weight gradient of the latent head and d h = d lat * W_lat^T
     const TensorInfo& tw = m->tensors[m->t_latW];
@@ -1557,7 +1584,8 @@ int backward_pass(smx_model* m, const Pass& ps) {
 void fill_adam_args(smx_model* m, AdamArgs& a) {
   const smx_config& c = m->cfg;
   a.params = m->params; a.grads = m->grads; a.m = m->adam_m; a.v = m->adam_v;
-  a.chunks = m->chunks; a.n_chunks = m->n_chunks; a.n_launch = m->n_chunks; a.partial = m->partial; a.tensor_norm = m->tensor_norm;
+  a.chunks = m->chunks; a.n_chunks = m->n_chunks; a.n_launch = m->n_chunks; a.gap_from = m->n_chunks; a.gap_len = 0;
+  a.partial = m->partial; a.tensor_norm = m->tensor_norm;
   // norms from the products' partials when every large tensor has them (single GPU: under data parallelism the
   // norm is that of the all-reduced gradient, which only a pass after the collective can give)
   a.use_sq = (m->sq_slots != nullptr && !dp_active(m) && getenv("SMX_NO_SQ_PARTIALS") == nullptr) ? 1 : 0;
@@ -1602,7 +1630,12 @@ int optimizer_pass(smx_model* m) {
   }
   AdamArgs a;
   fill_adam_args(m, a);
-  a.n_launch = m->adam_early_from >= 0 ? m->adam_early_from : m->n_chunks;   // the head chunks may have ridden along already
+  if (m->adam_early_from >= 0) {   // the head chunks have ridden along already
+    a.gap_from = m->adam_early_from; a.gap_len = m->adam_early_to - m->adam_early_from;
+    a.n_launch = m->n_chunks - a.gap_len;
+  } else {
+    a.gap_from = m->n_chunks; a.gap_len = 0; a.n_launch = m->n_chunks;
+  }
   m->adam_early_from = -1;
   if (m->have_pending_metrics) { a.metrics = m->pending_metrics; a.with_metrics = 1; m->have_pending_metrics = false; }
   a.master = master_state(m); a.lr = c.lr; a.batch = m->seq_batch;
@@ -1972,6 +2005,10 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   m->chunk_first_head = m->n_chunks;
   for (size_t i = 0; i < chunks.size(); ++i)
     if (chunks[i].tensor == m->t_outW[0]) { m->chunk_first_head = (int)i; break; }
+  m->chunk_first_label = m->n_chunks;
+  if (m->n_heads > 0)
+    for (size_t i = 0; i < chunks.size(); ++i)
+      if (chunks[i].tensor == m->t_labW[0]) { m->chunk_first_label = (int)i; break; }
   if (m->tensors.size() <= SMX_MAX_TENSORS) {   // slots for the products' sum-of-squares partials (32 x 32 tiles at most)
     size_t total = 0;
     m->sq_first.assign(m->tensors.size(), 0);
@@ -2708,8 +2745,8 @@ int smx_set_flag(smx_model* m, const char* name, int value) {
   const std::string n(name);
   int* f = n == "head_loss" ? &m->flags.head_loss : n == "front" ? &m->flags.front : n == "bwd_front" ? &m->flags.bwd_front
          : n == "head_bwd" ? &m->flags.head_bwd : n == "wgrad" ? &m->flags.wgrad : n == "scvi_fused" ? &m->flags.scvi_fused
-         : n == "twin" ? &m->flags.twin : nullptr;
-  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin)");
+         : n == "twin" ? &m->flags.twin : n == "label_ride" ? &m->flags.label_ride : nullptr;
+  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride)");
   *f = value ? 1 : 0;
   drop_graphs(m);   // a captured step bakes the launch sequence in
   return SMX_OK;
@@ -2837,7 +2874,7 @@ int smx_k_adam(int32_t n_tensors, const int32_t* sizes, float* params, const flo
   if (rc == SMX_OK) rc = launch_step_begin(nullptr, dSt + 2, dSt, nullptr, nullptr, 0, 0, 0u, lr, beta1, beta2);
   if (rc == SMX_OK) {
     AdamArgs a;
-    a.params = dP; a.grads = dG; a.m = dM; a.v = dV; a.chunks = dCh; a.n_chunks = (int)chunks.size(); a.n_launch = a.n_chunks;
+    a.params = dP; a.grads = dG; a.m = dM; a.v = dV; a.chunks = dCh; a.n_chunks = (int)chunks.size(); a.n_launch = a.n_chunks; a.gap_from = a.n_chunks; a.gap_len = 0;
     a.partial = dPart; a.tensor_norm = dNorm; a.use_sq = 0; a.state = dSt;
     a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.clipnorm = clipnorm; a.grad_scale = 1.f; a.lr = lr;
     rc = launch_adam(nullptr, a);

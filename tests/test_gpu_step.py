@@ -140,6 +140,45 @@ def test_separate_launch_forms_match_oracle(Engine, name, flags):
   e.close(); e0.close()
 
 
+@pytest.mark.parametrize("flags", [("label_ride",), ("label_ride", "wgrad"), ("wgrad",), ("head_bwd",), ("bwd_front", "wgrad")])
+@pytest.mark.parametrize("name", ["sisua", "misa"])
+def test_label_backward_forms_match_oracle(Engine, name, flags):
+  """Label heads' backward: d d as extra slabs of the output head's backward launch and the head's weight gradient in
+  the grouped launch at the end of the backward pass (its optimiser chunks then wait for the last launch), or the
+  grouped launch of their own: same parity bar, and the optimiser saw every tensor's final gradient in both forms."""
+  kw = CASES[name]
+  spec, cfg, x, ys, lib, mask = _problem(kw)
+  params = perturbed_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  B = 96
+  e, e0 = Engine(cfg, max_batch=128, init=False), Engine(cfg, max_batch=128, init=False)
+  for eng in (e, e0):
+    eng.set_params(params)
+    eng.upload(x, ys, lib, mask, cell_id_base=1000)
+  for f in flags:
+    e.set_flag(f, False)
+  rows = np.random.default_rng(1).choice(x.shape[0], size=B, replace=False).astype(np.int32)
+  p0 = {k: v.copy() for k, v in params.items()}
+  res = _oracle_step(spec, params, bn, opt, x, ys, lib, mask, rows, 0, cell_base=1000)   # (updates params in place)
+  for eng in (e, e0):
+    m = eng.train_step(rows)
+    for key in ("loss", "nllk_x", "nllk_y", "kl"):
+      assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
+    worst = grad_errors(eng.get_params(which=1), res["grads"])
+    assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    got = eng.get_params()
+    for k in got:
+      assert np.allclose(got[k], params[k], rtol=1e-5, atol=5e-4), k
+      big = np.abs(res["grads"][k]) > 1e-3 * np.abs(res["grads"][k]).max()
+      if k.startswith("lab") and big.any():
+        assert rel_l2((got[k] - p0[k])[big], (params[k] - p0[k])[big]) < 1e-2, k
+  for s in (1, 2):
+    r2 = ((rows + 7 * s) % x.shape[0]).astype(np.int32)
+    m, m0 = e.train_step(r2), e0.train_step(r2)
+  assert np.isclose(m["loss"], m0["loss"], rtol=1e-5)
+  e.close(); e0.close()
+
+
 @pytest.mark.parametrize("flags", [("scvi_fused",), ("twin",), ("scvi_fused", "twin"), ("scvi_fused", "twin", "bwd_front", "front", "wgrad")])
 @pytest.mark.parametrize("name", ["scvi_zinbd", "scvi_nbd"])
 def test_scvi_separate_launch_forms_match_oracle(Engine, name, flags):
