@@ -213,6 +213,18 @@ int smx_forward_samples(smx_model* m, const int32_t* row_ids, const float* host_
                         int32_t n_samples, float* z_mean, float* z_scale, float* z_samples, float* l_mean, float* l_scale,
                         float* l_samples, float* x_params, float* const* y_params);
 
+/* SingleCellModel.predict(inputs, sample_shape, batch_size) over a whole host matrix in ONE call
+ * (sisua/models/single_cell_model.py:153-211: "predict on minibatches then return a single distribution by
+ * concatenation").  host_x [n_cells, n_genes] (host_library [n_cells, 2] for scvi) is walked in minibatches of `batch`
+ * (<= max_batch; the last one may be smaller) and every result is written straight to its final place:
+ * z_mean / z_scale [n_cells, D]; l_mean / l_scale [n_cells]; z_samples [n_samples, n_cells, D]; l_samples
+ * [n_samples, n_cells]; x_params [n_samples, k, n_cells, n_genes]; y_params[j] [n_samples, n_cells, ky * P_j].  Same numbers
+ * as smx_forward_samples batch by batch (draw s uses Philox sample index s; the noise of a cell is keyed by its index
+ * within its minibatch, as there).  Any output may be NULL. */
+int smx_predict(smx_model* m, const float* host_x, const float* host_library, int64_t n_cells, int32_t batch,
+                int32_t n_samples, float* z_mean, float* z_scale, float* z_samples, float* l_mean, float* l_scale,
+                float* l_samples, float* x_params, float* const* y_params);
+
 /* Decoder only (SingleCellModel.decode, single_cell_model.py:141-151; scvi.py:108-171):
  * z [batch,D] (and l [batch] for scvi) -> the same x_params / y_params as smx_forward,
  * eval mode. */

@@ -261,6 +261,7 @@ struct smx_model {
   bool adam_early_pending = false;    // the heads' gradients are final: the next BatchNorm-backward launch may carry their update
   int adam_early_from = -1;           // >= 0: chunks [adam_early_from, n_chunks) of this step were applied early
   bool x_u16 = false;   // the resident matrix is stored as uint16 counts (smx_dataset_upload_u16)
+  float* pred_stage = nullptr; size_t pred_floats = 0;   // device staging of smx_predict (one chunk of cells, laid out like the caller's arrays)
   float* pinned = nullptr; size_t pinned_floats = 0;   // host staging for the parameter planes handed back by smx_forward / smx_decode
   // sum-of-squares slots written by the weight-gradient products (per-tensor clipnorm without a separate pass)
   float* sq_slots = nullptr; std::vector<int> sq_first, sq_count; std::vector<char> sq_reduced; int sq_total_first = 0;   // this step's output head ran as the fused kernel (smx_head.hip)
@@ -2057,6 +2058,7 @@ int smx_model_destroy(smx_model* m) {
   fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);
   fr(m->chunks); fr(m->partial); fr(m->tensor_norm); fr(m->sq_slots);
   if (m->pinned) hipHostFree(m->pinned);
+  if (m->pred_stage) hipFree(m->pred_stage);
   for (auto& kv : m->injected) fr(kv.second.d);
   if (m->st_comm) { hipStreamSynchronize(m->st_comm); hipStreamDestroy(m->st_comm); }
   if (m->ev_c1) hipEventDestroy(m->ev_c1);
@@ -2446,6 +2448,128 @@ int smx_forward_samples(smx_model* m, const int32_t* row_ids, const float* host_
                             z_samples ? z_samples + (size_t)s * B * m->D : nullptr, s == 0 ? l_mean : nullptr,
                             s == 0 ? l_scale : nullptr, l_samples ? l_samples + (size_t)s * B : nullptr,
                             x_params ? x_params + (size_t)s * m->k * B * m->G : nullptr, y_params, (size_t)s));
+  }
+  return SMX_OK;
+}
+
+// SingleCellModel.predict over a whole host matrix in ONE call.  The batch loop runs here; after every forward pass one
+// small launch packs what the caller asked for (parameter planes, latent moments, draws, label outputs) into device
+// staging laid out like the caller's arrays for a CHUNK of cells (up to 128 MB), and each chunk leaves the device as a
+// few large contiguous copies straight into its final place (48 GB/s into pageable memory as into pinned,
+// tools/pcie_probe.hip).  No per-batch result arrays, no host re-packing, no concatenation afterwards -- and no swarm
+// of small pitched copies (each a synchronous call: at batch 8 x 10 draws they cost 4x the whole old path).
+struct PackJob { float* dst; long dpitch; const float* src; long spitch; int width; int height; };
+#define SMX_PACK_MAX 16
+struct PackJobs { int n; PackJob j[SMX_PACK_MAX]; };
+__global__ __launch_bounds__(256) void pack_kernel(PackJobs jobs_by_value) {
+  const PackJobs& J = *(const PackJobs*)__builtin_amdgcn_kernarg_segment_ptr();   // (run-time job index: no scratch copy)
+  const PackJob& j = J.j[blockIdx.y];
+  const long total = (long)j.width * j.height;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / j.width, c = i % j.width;
+    j.dst[r * j.dpitch + c] = j.src[r * j.spitch + c];
+  }
+}
+
+int smx_predict(smx_model* m, const float* host_x, const float* host_library, int64_t n_cells, int32_t batch, int32_t n_samples,
+                float* z_mean, float* z_scale, float* z_samples, float* l_mean, float* l_scale, float* l_samples,
+                float* x_params, float* const* y_params) {
+  SMX_REQUIRE(m && host_x && n_cells > 0 && n_samples > 0, "bad arguments");
+  SMX_REQUIRE(batch > 0 && batch <= m->Bmax, "batch must be in 1..max_batch");
+  const size_t N = (size_t)n_cells, G = (size_t)m->G, D = (size_t)m->D, k = (size_t)m->k, S = (size_t)n_samples;
+  const int Dp = m->Dp, lat_ld = m->stochastic ? 2 * Dp : Dp;
+  if (!m->stochastic) z_scale = nullptr;
+  if (!m->scvi) l_mean = l_scale = l_samples = nullptr;
+  // ---- staging layout for a chunk of C cells (segments in floats; per-cell widths) ----
+  size_t wy[SMX_MAX_LABELS] = {0, 0, 0, 0};
+  size_t per_cell = 0;
+  if (z_mean) per_cell += D;
+  if (z_scale) per_cell += D;
+  if (l_mean) per_cell += 1;
+  if (l_scale) per_cell += 1;
+  if (z_samples) per_cell += S * D;
+  if (l_samples) per_cell += S;
+  if (x_params) per_cell += S * k * G;
+  for (int j = 0; j < m->n_heads; ++j)
+    if (y_params && y_params[j]) { wy[j] = (size_t)m->lab_ky[j] * (size_t)m->cfg.label_dim[j]; per_cell += S * wy[j]; }
+  SMX_REQUIRE(per_cell > 0, "no output requested");
+  const size_t cap_floats = (size_t)32 << 20;   // 128 MB
+  size_t C = std::max<size_t>((size_t)batch, cap_floats / per_cell / (size_t)batch * (size_t)batch);   // whole batches per chunk
+  C = std::min(C, (N + (size_t)batch - 1) / (size_t)batch * (size_t)batch);
+  if (C * per_cell > m->pred_floats) {
+    if (m->pred_stage) hipFree(m->pred_stage);
+    m->pred_stage = nullptr; m->pred_floats = 0;
+    SMX_CHECK(dmalloc(&m->pred_stage, C * per_cell));
+    m->pred_floats = C * per_cell;
+  }
+  float* st = m->pred_stage;
+  float *s_zm = nullptr, *s_zs = nullptr, *s_lm = nullptr, *s_ls = nullptr, *s_zd = nullptr, *s_ld = nullptr, *s_xp = nullptr, *s_y[SMX_MAX_LABELS] = {nullptr, nullptr, nullptr, nullptr};
+  if (z_mean) { s_zm = st; st += C * D; }
+  if (z_scale) { s_zs = st; st += C * D; }
+  if (l_mean) { s_lm = st; st += C; }
+  if (l_scale) { s_ls = st; st += C; }
+  if (z_samples) { s_zd = st; st += S * C * D; }
+  if (l_samples) { s_ld = st; st += S * C; }
+  if (x_params) { s_xp = st; st += S * k * C * G; }
+  for (int j = 0; j < m->n_heads; ++j)
+    if (wy[j]) { s_y[j] = st; st += S * C * wy[j]; }
+  auto out = [&](float* dst, const float* src, size_t count) -> int {   // one contiguous device -> host copy
+    SMX_HIP(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, m->st));
+    return SMX_OK;
+  };
+  for (size_t c0 = 0; c0 < N; c0 += C) {
+    const size_t Cn = std::min(C, N - c0);   // cells of this chunk
+    for (size_t b0 = 0; b0 < Cn; b0 += (size_t)batch) {
+      const int B = (int)std::min<size_t>((size_t)batch, Cn - b0);
+      const size_t g0 = c0 + b0;
+      Pass ps;
+      SMX_CHECK(setup_pass(m, ps, nullptr, host_x + g0 * G, host_library ? host_library + g0 * 2 : nullptr, B, 0, 0));
+      for (size_t s = 0; s < S; ++s) {
+        ps.sample = (int)s;
+        // the encoders run once per batch (eval mode: no noise in them); later draws re-sample the latents and decode
+        SMX_CHECK(forward_pass(m, ps, false, false, s == 0 ? 0 : 2));
+        PackJobs J; J.n = 0;
+        auto add = [&](float* dst, size_t dpitch, const float* src, size_t spitch, size_t width) {
+          if (!dst || J.n >= SMX_PACK_MAX) return;
+          PackJob& q = J.j[J.n++];
+          q.dst = dst; q.dpitch = (long)dpitch; q.src = src; q.spitch = (long)spitch; q.width = (int)width; q.height = B;
+        };
+        if (s == 0) {
+          add(s_zm ? s_zm + b0 * D : nullptr, D, m->latbuf, (size_t)lat_ld, D);
+          add(s_zs ? s_zs + b0 * D : nullptr, D, m->sig, (size_t)Dp, D);
+          add(s_lm ? s_lm + b0 : nullptr, 1, m->latlbuf, 32, 1);
+          add(s_ls ? s_ls + b0 : nullptr, 1, m->lsig, 1, 1);
+        }
+        add(s_zd ? s_zd + (s * Cn + b0) * D : nullptr, D, m->z, (size_t)Dp, D);
+        add(s_ld ? s_ld + s * Cn + b0 : nullptr, 1, m->lsmp, 1, 1);
+        if (s_xp)
+          for (size_t c = 0; c < k; ++c) add(s_xp + ((s * k + c) * Cn + b0) * G, G, m->P + c * (size_t)m->Gp, k * (size_t)m->Gp, G);
+        for (int j = 0; j < m->n_heads; ++j) {
+          if (!s_y[j]) continue;
+          const size_t P = (size_t)m->cfg.label_dim[j], Pp = (size_t)m->lab_Pp[j], ld = (size_t)m->tensors[m->t_labW[j]].ld;
+          for (size_t c = 0; c < (size_t)m->lab_ky[j]; ++c) add(s_y[j] + (s * Cn + b0) * wy[j] + c * P, wy[j], m->laby_raw[j] + c * Pp, ld, P);
+        }
+        if (J.n) {
+          const unsigned gx = (unsigned)std::min<size_t>(256, ((size_t)B * std::max(G, D) + 255) / 256);
+          hipLaunchKernelGGL(pack_kernel, dim3(gx, (unsigned)J.n), dim3(256), 0, m->st, J);
+          SMX_HIP(hipGetLastError());
+        }
+      }
+    }
+    // ---- the chunk leaves the device: every segment's rows are contiguous here and in the caller's arrays ----
+    if (s_zm) SMX_CHECK(out(z_mean + c0 * D, s_zm, Cn * D));
+    if (s_zs) SMX_CHECK(out(z_scale + c0 * D, s_zs, Cn * D));
+    if (s_lm) SMX_CHECK(out(l_mean + c0, s_lm, Cn));
+    if (s_ls) SMX_CHECK(out(l_scale + c0, s_ls, Cn));
+    for (size_t s = 0; s < S; ++s) {
+      if (s_zd) SMX_CHECK(out(z_samples + (s * N + c0) * D, s_zd + s * Cn * D, Cn * D));
+      if (s_ld) SMX_CHECK(out(l_samples + s * N + c0, s_ld + s * Cn, Cn));
+      if (s_xp)
+        for (size_t c = 0; c < k; ++c) SMX_CHECK(out(x_params + ((s * k + c) * N + c0) * G, s_xp + (s * k + c) * Cn * G, Cn * G));
+      for (int j = 0; j < m->n_heads; ++j)
+        if (s_y[j]) SMX_CHECK(out(y_params[j] + (s * N + c0) * wy[j], s_y[j] + s * Cn * wy[j], Cn * wy[j]));
+    }
+    SMX_HIP(hipStreamSynchronize(m->st));
   }
   return SMX_OK;
 }

@@ -265,6 +265,28 @@ class Engine:
     out["y_params"] = ys
     return out
 
+  def predict(self, x, library=None, n_samples: int = 1, batch: Optional[int] = None):
+    """Eval-mode forward of a whole host matrix in one call (smx_predict): arrays over ALL cells, with a leading draw
+    axis for z_sample / l_sample / x_params / y_params -- the layout of forward_samples with n = every cell."""
+    cfg = self.cfg
+    xa = _f32(x)
+    N, S = xa.shape[0], int(n_samples)
+    B = min(int(batch or self.max_batch), self.max_batch)
+    la = None if library is None else _f32(library, (N, 2))
+    D, G, k = cfg.latent_dim, cfg.n_genes, cfg.k
+    out = dict(z_mean=np.empty((N, D), np.float32), z_sample=np.empty((S, N, D), np.float32))
+    out["z_scale"] = np.empty((N, D), np.float32) if cfg.stochastic else None
+    if cfg.model == "scvi":
+      out.update(l_mean=np.empty((N,), np.float32), l_scale=np.empty((N,), np.float32), l_sample=np.empty((S, N), np.float32))
+    out["x_params"] = np.empty((S, k, N, G), np.float32)
+    ys = [np.empty((S, N, label_planes(llk) * P), np.float32) for P, llk in cfg.head_labels]
+    yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
+    check(self.lib.smx_predict(self._h, _fp(xa), _fp(la), N, B, S, _fp(out["z_mean"]), _fp(out.get("z_scale")),
+                               _fp(out["z_sample"]), _fp(out.get("l_mean")), _fp(out.get("l_scale")), _fp(out.get("l_sample")),
+                               _fp(out["x_params"]), yptrs))
+    out["y_params"] = ys
+    return out
+
   def decode(self, z, l=None):
     """Decoder + output heads from given latents (eval mode)."""
     cfg = self.cfg

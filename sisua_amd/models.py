@@ -510,6 +510,12 @@ class SingleCellModel:
     if not isinstance(inputs, (BatchDataset, SingleCellOMIC)):
       ds.drop_remainder = False
     ds.shuffle = 0 if isinstance(inputs, (np.ndarray, list, tuple)) else ds.shuffle
+    if ds.shuffle == 0 and ds.n_obs > 0:
+      # cells in their own order: the minibatch loop runs inside the library (smx_predict) and every result is written
+      # once, straight into the arrays the returned distributions hold -- no per-batch arrays, no concatenation
+      n_use = ds.n_obs if not ds.drop_remainder else (ds.n_obs // ds.batch_size) * ds.batch_size
+      if n_use > 0:
+        return self._predict_all(ds.arrays[0][:n_use], ds.library[:n_use], sample_shape, ds.batch_size)
     X, Z = [], []
     for data in ds:
       pX, qZ = self(**data, training=False, sample_shape=sample_shape)
@@ -527,6 +533,23 @@ class SingleCellModel:
     else:
       Zc = D.concat_distributions(Z, axis=0)
     return Xc, Zc
+
+  def _predict_all(self, x, library, sample_shape, batch_size):
+    n = int(np.prod(sample_shape)) if np.size(sample_shape) else 0
+    e = self._ensure_engine(min(int(batch_size), x.shape[0]))
+    lib = library if self._cfg.model == "scvi" else None
+    if lib is not None and lib.shape[1] != 2:
+      lib = library_matrix(x)
+    o = e.predict(x, library=lib, n_samples=max(n, 1), batch=min(int(batch_size), e.max_batch))
+    if n > 1:
+      pX = self._output_dists(o["x_params"], o["y_params"], stacked=True)
+    else:
+      pX = self._output_dists([o["x_params"][0]], [[y[0] for y in o["y_params"]]])
+    first = dict(o, z_sample=o["z_sample"][0])
+    if "l_sample" in o:
+      first["l_sample"] = o["l_sample"][0]
+    qZ = self._latent_dists(first)
+    return pX, (tuple(qZ) if isinstance(qZ, list) else qZ)
 
   def marginal_log_prob(self, inputs=None, library=None, mask=None, sample_shape=100, batch_size=128, **kwargs):
     r"""Importance-weighted estimate of log p(x) with `sample_shape` posterior draws

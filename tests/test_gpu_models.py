@@ -95,6 +95,21 @@ def test_fit_predict(api, name):
   X3, _ = model.predict(test.numpy()[:20], sample_shape=3, batch_size=8, verbose=False)
   X3 = X3[0] if isinstance(X3, tuple) else X3
   assert X3.batch_shape == (3, 20) and X3.mean().shape == (3, 20, 120)
+  # the one-call path (smx_predict: batch loop in the library, results written once into their final arrays) holds the
+  # same numbers as minibatch-by-minibatch calls, ragged last batch included
+  from sisua_amd.data import library_matrix
+  xs = test.numpy()[:50]
+  lib = library_matrix(xs)
+  for S in ((), 2):
+    Xa, Za = model.predict(xs, sample_shape=S, batch_size=16, verbose=False)
+    Xa0 = Xa[0] if isinstance(Xa, tuple) else Xa
+    Za0 = Za[0] if isinstance(Za, (tuple, list)) else Za
+    for i in range(0, 50, 16):
+      pX, qZ = model(inputs=xs[i:i + 16], library=lib[i:i + 16], sample_shape=S)
+      pX0 = pX[0] if isinstance(pX, tuple) else pX
+      qZ0 = qZ[0] if isinstance(qZ, (tuple, list)) else qZ
+      assert np.array_equal(pX0.mean(), Xa0.mean()[..., i:i + 16, :])
+      assert np.array_equal(qZ0.mean(), Za0.mean()[i:i + 16])
   # encode / decode round trip agrees with __call__
   q = model.encode(test.numpy()[:16])
   q0 = q[0] if isinstance(q, list) else q

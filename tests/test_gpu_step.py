@@ -253,7 +253,7 @@ def test_injected_noise_matches_oracle(Engine, name):
   e.close()
 
 
-@pytest.mark.parametrize("name,graph", [("vae_zinb", False), ("vae_zinb", True), ("sisua", True), ("scvi_zinbd", False), ("misa", False), ("scale", True),
+@pytest.mark.parametrize("name,graph", [("vae_zinb", False), ("vae_zinb", True), ("sisua", True), ("scvi_zinbd", False), ("scvi_nbd", True), ("misa", False), ("scale", True),
                                         ("fvae", True), ("semifvae", False)])
 def test_trajectory_matches_oracle(Engine, name, graph):
   """50-step seeded trajectory: ELBO per step within 1e-4 relative."""
