@@ -48,6 +48,11 @@ def build_workload(rank: int, world: int, workload: str):
     # BASELINE.json configs[2] / configs[3]: SCVI nbd batch 256; SISUA zinb + ADT nb labels (10 %), alpha 10, batch 256
     x, y = data.synthetic_8kly(seed=8) if workload == "8kly-scvi" else data.synthetic_eccly(seed=8)
     units, latent, batch = (128,), 32, 256
+  elif workload == "cortex-base":
+    # the reference's own default run (configs/base.yaml: cortex, encoder / decoder units [64, 64], latent 12, zinbd,
+    # batch 64; BASELINE.json configs[0] is the same data at batch 32)
+    x, _ = data.synthetic_cortex(seed=8)
+    units, latent, batch = (64, 64), 12, 64
   elif workload == "c5-shard":
     # per-GPU slice of BASELINE.json configs[4] (1e6 x 20000 log-normal counts, 128 cells per GPU per step):
     # 4096 resident cells per GPU are enough to exercise the step at its real width
@@ -75,6 +80,8 @@ def build_workload(rank: int, world: int, workload: str):
     cfg = ModelConfig(model="sisua", likelihood="zinb", labels=((yt.shape[1], "nb"),), alpha=10.0, **kw)
     extra["labels"] = [yt]
     extra["label_mask"] = data.label_mask(xt.shape[0], 0.1, 2, seed=1)
+  elif workload == "cortex-base":
+    cfg = ModelConfig(model="vae", likelihood="zinbd", **kw)
   else:
     cfg = ModelConfig(model="vae", likelihood="zinb", **kw)
   if world > 1 and workload != "c5-shard":   # ONE dataset: this rank's contiguous shard of the training cells

@@ -318,7 +318,7 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
     float wl = 0.f;
     const bool wl_on = (int)threadIdx.x < a.lat.Dp * BN_COLS;
     if (wl_on) wl = a.W[(long)(threadIdx.x / BN_COLS) * a.ldw + bid * BN_COLS + (threadIdx.x % BN_COLS)];
-    latent_tile_to_lds<BN_RPT * 2>(a.lat, zs, bid == 0);   // B Dp / 4 quads over 512 threads: <= 2 RPT iterations
+    latent_tile_to_lds<BN_RPT * 2>(a.lat, zs, bid == 0 && a.lat.z != nullptr);   // B Dp / 4 quads over 512 threads: <= 2 RPT iterations
     if (wl_on) ws[threadIdx.x] = wl;
     __syncthreads();
 #pragma unroll

@@ -514,7 +514,18 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     const bool no_twin = !m->flags.twin;
     const bool ahead = !no_fz && !no_ahead && !m->scvi;
     const bool sync = sync_bn_on(m, ps.training) && L.bn >= 0;
-    const bool with_front = (front != nullptr && i == 0);   // the BatchNorm launch produces its own input (latent sample + product)
+    // hidden -> hidden layers up to 64 wide: the BatchNorm launch stages the layer's INPUT tile [B][K] in LDS and forms its
+    // own columns as dot products -- the same front the first decoder layer uses for the latent sample, here as a plain
+    // copy (no product launch; the reference's default networks are [64, 64], configs/base.yaml:10-17)
+    LatentArgs dense_la;
+    const bool dense_front = m->flags.front && no_fz && !sync && !(front != nullptr && i == 0) && !(i == 0 && in_is_x) && L.leak == 0.f &&
+                             (L.in_p == 32 || L.in_p == 64) && bn_front_supported(ps.B, L.in_p) && L.out_p % 8 == 0 && (ld % 4) == 0 && !use_mid(m, ps.B);
+    if (dense_front) {
+      dense_la.stochastic = 0; dense_la.relu = 0; dense_la.training = ps.training;
+      dense_la.lat = in; dense_la.ld = ld; dense_la.B = ps.B; dense_la.D = L.in; dense_la.Dp = L.in_p;
+    }
+    const LatentArgs* front_i = (front != nullptr && i == 0) ? front : (dense_front ? &dense_la : nullptr);
+    const bool with_front = front_i != nullptr;   // the BatchNorm launch produces its own input (latent sample / input tile + product)
     const bool fuse = !no_fz && !sync && !with_front && !(i == 0 && in_is_x) && L.leak == 0.f && dense_bn_fusable(ps.B, L.in_p);
     int eff = 1;
     SMX_REQUIRE((size_t)std::max(g.split_k, 1) * (size_t)g.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
@@ -579,8 +590,8 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
       SMX_CHECK(launch_bn_act_fwd_dual(m->st, b, b2));
       if (twin_done) *twin_done = true;
     } else if (with_front) {
-      if (m->ahead_front_drop && !b.inj_mask && b.drop_p > 0.f) { b.inj_mask = L.noise; b.inj_ld = L.out_p; }
-      b.front = 1; b.lat = *front; b.W = P_(m, L.tW); b.ldw = tw.ld; b.n_jobs = 0;
+      if (m->ahead_front_drop && front != nullptr && i == 0 && !b.inj_mask && b.drop_p > 0.f) { b.inj_mask = L.noise; b.inj_ld = L.out_p; }
+      b.front = 1; b.lat = *front_i; b.W = P_(m, L.tW); b.ldw = tw.ld; b.n_jobs = 0;
       Timed t(m, "bn_fwd");
       SMX_CHECK(launch_bn_act_fwd(m->st, b));
     } else if (sync) {
@@ -682,11 +693,14 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     return b;
   };
   if (twin_done) *twin_done = false;
+  BnBwdArgs carried;            // gradient front handed from layer i + 1 to layer i (hidden layers up to 64 wide)
+  bool have_carried = false;
   for (int i = (int)mlp.size() - 1; i >= 0; --i) {
     MlpLayer& L = mlp[i];
     const TensorInfo& tw = m->tensors[L.tW];
     const bool last = (i == (int)mlp.size() - 1);
-    BnBwdArgs b = make_b(L, n_slabs, (grad_front && last) ? grad_front : nullptr);
+    BnBwdArgs b = make_b(L, n_slabs, (grad_front && last) ? grad_front : (have_carried ? &carried : nullptr));
+    have_carried = false;
     if (last && last_bn_done) {
       // (this layer's BatchNorm-backward ran beside the other MLP's)
     } else if (sync_bn_on(m, ps.training) && L.bn >= 0) {   // the ELBO scalars then go with a launch of their own (optimizer_pass)
@@ -738,6 +752,18 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
       }
       n_slabs = 0;
       break;
+    }
+    // hidden layers up to 64 wide: the layer below takes d in = dpre W^T as the gradient front of its BatchNorm-backward
+    // launch (dot products over K = this layer's width) and d W joins the grouped launch at the end -- no product launch
+    if (defer && i > 0 && !(i == 0 && lat_epi) && m->flags.bwd_front && (L.out_p == 32 || L.out_p == 64) &&
+        bn_bwd_front_supported(ps.B, L.out_p) && mlp[i - 1].out_p % 8 == 0 && (tw.ld % 4) == 0 && (L.out_p % 4) == 0 &&
+        !(sync_bn_on(m, ps.training) && mlp[i - 1].bn >= 0)) {
+      defer->push_back(g);
+      carried = BnBwdArgs();
+      carried.fD = L.dpre; carried.fld = L.out_p; carried.fW = P_(m, L.tW); carried.fldw = tw.ld; carried.fK = L.out_p;
+      have_carried = true;
+      n_slabs = 0;
+      continue;
     }
     // d in = dpre * W^T  -> slabs; independent of dW: one grouped launch for both
     GemmArgs h;
@@ -1533,7 +1559,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
   }
   const bool twin_bwd = m->scvi && lfront && m->scvi_fused;
   SMX_CHECK(mlp_backward(m, m->enc, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_enc_dw", nullptr, &dw0[n_dw0], bfront ? &gf : nullptr,
-                         nullptr, twin_bwd ? &m->encl : nullptr, twin_bwd ? &gfl : nullptr, &twin_done));
+                         bfront ? &tail : nullptr, twin_bwd ? &m->encl : nullptr, twin_bwd ? &gfl : nullptr, &twin_done));
   ++n_dw0;
   // ---- scvi library branch ----
   if (m->scvi) {
@@ -1560,7 +1586,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
       SMX_CHECK(launch_gemm_group(m->st, pair, 2));
     }
     SMX_CHECK(mlp_backward(m, m->encl, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_encl_dw", nullptr, &dw0[n_dw0],
-                           lfront ? &gfl : nullptr, nullptr, nullptr, nullptr, nullptr, twin_done));
+                           lfront ? &gfl : nullptr, bfront ? &tail : nullptr, nullptr, nullptr, nullptr, twin_done));
     ++n_dw0;
   }
   // the first-layer weight gradients (gather + log1p of the same resident rows) of the encoder and, for scvi,

@@ -106,7 +106,7 @@ def test_one_step_matches_oracle(Engine, name, batch):
 
 @pytest.mark.parametrize("flags", [("head_loss",), ("front",), ("bwd_front",), ("head_bwd",), ("wgrad",),
                                    ("head_loss", "front", "bwd_front", "head_bwd", "wgrad")])
-@pytest.mark.parametrize("name", ["vae_zinb", "sisua", "paper_shape", "dca_zinb"])
+@pytest.mark.parametrize("name", ["vae_zinb", "vae_zinbd", "sisua", "paper_shape", "dca_zinb"])
 def test_separate_launch_forms_match_oracle(Engine, name, flags):
   """Every stage that has a fused / wide default form also keeps its separate-launch form (smx_set_flag): eval and
   the scoring paths use those, and shapes the fused kernels do not take fall back to them.  Same parity bar, and
