@@ -311,18 +311,52 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
   const float bias = (!a.batchnorm && a.bias && live) ? a.bias[col] : 0.f;
   constexpr int CH = BN_RL * BN_RPT;
   float vreg[BN_RPT];
-  float wcol[FRONT ? 64 : 1];
+  // FRONT = 1: input tile up to 64 wide; FRONT = 2: exactly 128 wide (hidden -> hidden layers of 128-unit networks: the
+  // column of W costs 128 registers, fine at one workgroup per CU)
+  constexpr int FK = FRONT == 2 ? 128 : 64;
+  float wcol[FRONT == 1 ? 64 : 1];   // FRONT = 2 reads its column of W from LDS inside the dot products (128 registers spilled)
+  const float* wcol_lds = nullptr;
   if (FRONT) {
     // this workgroup's [Dp][8] tile of W: one coalesced pass into LDS (its latency hides under the latent tile)
     float* ws = zs + a.B * (a.lat.Dp + 1);       // [Dp][BN_COLS]
-    float wl = 0.f;
-    const bool wl_on = (int)threadIdx.x < a.lat.Dp * BN_COLS;
-    if (wl_on) wl = a.W[(long)(threadIdx.x / BN_COLS) * a.ldw + bid * BN_COLS + (threadIdx.x % BN_COLS)];
-    latent_tile_to_lds<BN_RPT * 2>(a.lat, zs, bid == 0 && a.lat.z != nullptr);   // B Dp / 4 quads over 512 threads: <= 2 RPT iterations
-    if (wl_on) ws[threadIdx.x] = wl;
-    __syncthreads();
+    float wl[FRONT == 2 ? 2 : 1];
 #pragma unroll
-    for (int k = 0; k < 64; ++k) wcol[k] = (k < a.lat.Dp) ? ws[k * BN_COLS + c] : 0.f;
+    for (int u = 0; u < (FRONT == 2 ? 2 : 1); ++u) {
+      const int t = (int)threadIdx.x + u * BN_THREADS;
+      wl[u] = (t < a.lat.Dp * BN_COLS) ? a.W[(long)(t / BN_COLS) * a.ldw + bid * BN_COLS + (t % BN_COLS)] : 0.f;
+    }
+    if constexpr (FRONT == 2) {   // a plain input tile (hidden layers): every load first, then LDS
+      constexpr int MAXIT = BN_RPT * 4;
+      const int kq = a.lat.Dp >> 2, ldz = a.lat.Dp + 1, total = a.B * kq;
+      float4 t4[MAXIT];
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int idx = threadIdx.x + it * BN_THREADS;
+        t4[it] = idx < total ? *reinterpret_cast<const float4*>(a.lat.lat + (long)(idx / kq) * a.lat.ld + (idx % kq) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int idx = threadIdx.x + it * BN_THREADS;
+        if (idx < total) {
+          const int o = (idx / kq) * ldz + (idx % kq) * 4;
+          zs[o] = t4[it].x; zs[o + 1] = t4[it].y; zs[o + 2] = t4[it].z; zs[o + 3] = t4[it].w;
+        }
+      }
+    } else {
+      latent_tile_to_lds<BN_RPT * 2>(a.lat, zs, bid == 0 && a.lat.z != nullptr);   // B Dp / 4 quads over 512 threads: <= 2 RPT iterations
+    }
+#pragma unroll
+    for (int u = 0; u < (FRONT == 2 ? 2 : 1); ++u) {
+      const int t = (int)threadIdx.x + u * BN_THREADS;
+      if (t < a.lat.Dp * BN_COLS) ws[t] = wl[u];
+    }
+    __syncthreads();
+    if constexpr (FRONT == 1) {
+#pragma unroll
+      for (int k = 0; k < 64; ++k) wcol[k] = (k < a.lat.Dp) ? ws[k * BN_COLS + c] : 0.f;
+    } else {
+      wcol_lds = ws + c;
+    }
   }
 
   // dropout multipliers drawn ahead by an earlier launch (or injected): loaded now, used after the reductions
@@ -345,7 +379,10 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
       for (int i = 0; i < BN_RPT; ++i) {
         const int r = min(r0 + rl + BN_RL * i, a.B - 1);
         float t = 0.f;
-        if (a.lat.Dp <= 32) {
+        if (FRONT == 2) {
+#pragma unroll 16
+          for (int k = 0; k < FK; ++k) t = fmaf(zs[r * ldz + k], wcol_lds[k * BN_COLS], t);
+        } else if (a.lat.Dp <= 32) {
 #pragma unroll
           for (int k = 0; k < 32; ++k) t = fmaf(zs[r * ldz + k], wcol[k], t);
         } else {
@@ -448,14 +485,14 @@ static int bn_diag() { static const int v = getenv("SMX_BN_DIAG") ? atoi(getenv(
 
 bool bn_front_supported(int B, int Dp) {
   const int dq = Dp >> 2;
-  return B > 0 && B <= BN_RL * 4 && Dp >= 4 && Dp <= 64 && (Dp % 4) == 0 && (dq & (dq - 1)) == 0 && ((size_t)B * (Dp + 1) + (size_t)Dp * 8) * sizeof(float) <= 96 * 1024;
+  return B > 0 && B <= BN_RL * 4 && Dp >= 4 && (Dp <= 64 || Dp == 128) && (Dp % 4) == 0 && (dq & (dq - 1)) == 0 && ((size_t)B * (Dp + 1) + (size_t)Dp * 8) * sizeof(float) <= 96 * 1024;
 }
 
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
   BnFwdArgs a = a_in;
   if (a.front) {
     if (!bn_front_supported(a.B, a.lat.Dp) || a.n_jobs || !a.W || (a.lat.ld % 4) || (a.lat.inj_eps && (a.lat.inj_ld % 4)) ||
-        (a.lat.Dp > 32 && a.lat.Dp != 64)) {
+        (a.lat.Dp > 32 && a.lat.Dp != 64 && a.lat.Dp != 128)) {
       set_error("bn_act_fwd: latent front not applicable");
       return SMX_ERR_INVALID;
     }
@@ -464,7 +501,15 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
     static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_fwd_kernel<4, 1>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     if (lds > 64 * 1024 && !big_ok) { set_error("bn_act_fwd: cannot reserve the dynamic LDS of the latent front"); return SMX_ERR_HIP; }
-    if (a.B <= BN_RL * 2) hipLaunchKernelGGL((bn_act_fwd_kernel<2, 1>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
+    if (a.lat.Dp == 128) {   // (B <= 128 by the LDS bound of bn_front_supported)
+      static const bool big2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_fwd_kernel<2, 2>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+      if (a.B > BN_RL * 2 || a.lat.stochastic || a.lat.relu || a.lat.z || (lds > 64 * 1024 && !big2)) {   // (plain input tiles only)
+        set_error("bn_act_fwd: 128-wide front not applicable");
+        return SMX_ERR_INVALID;
+      }
+      hipLaunchKernelGGL((bn_act_fwd_kernel<2, 2>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
+    } else if (a.B <= BN_RL * 2) hipLaunchKernelGGL((bn_act_fwd_kernel<2, 1>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
     else hipLaunchKernelGGL((bn_act_fwd_kernel<4, 1>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
@@ -528,7 +573,8 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
   constexpr int CH = BN_RL * BN_RPT;
   float dyreg[BN_RPT], xhreg[BN_RPT];
   float s1 = 0.f, s2 = 0.f;
-  float wrow[FRONT ? 64 : 1];
+  constexpr int FK = FRONT == 2 ? 128 : 64;   // FRONT = 2: K = 128 exactly (see bn_act_fwd_body)
+  float wrow[FRONT ? FK : 1];
   if (FRONT) {
     const int ldd = a.fK + 1, kq = a.fK >> 2;
     // this workgroup's 8 rows of W_lat: ONE coalesced pass into LDS (every thread loading its own row from global
@@ -536,10 +582,10 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
     float* ws = ds + ((a.B * ldd + 3) & ~3);     // [BN_COLS][fK + 4], 16-byte aligned
     const int ldw_s = a.fK + 4;
     float4 wl = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool wl_on = (int)threadIdx.x < BN_COLS * kq && !(a.diag & 64);
+    const bool wl_on = (int)threadIdx.x < BN_COLS * kq && !(a.diag & 64);   // (8 rows x fK / 4 <= 256 float4: one per thread)
     if (wl_on) wl = *reinterpret_cast<const float4*>(a.fW + (long)(bid * BN_COLS + threadIdx.x / kq) * a.fldw + (threadIdx.x % kq) * 4);
-    {   // all loads of the tile in flight at once (B fK / 4 float4 over 512 threads: <= 2 RPT per thread), then LDS
-      constexpr int MAXIT = BN_RPT * 2;
+    {   // all loads of the tile in flight at once (B fK / 4 float4 over 512 threads), then LDS
+      constexpr int MAXIT = BN_RPT * (FK / 32);
       float4 tl[MAXIT];
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it) {
@@ -559,7 +605,7 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
     }
     __syncthreads();
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
+    for (int v = 0; v < FK / 4; ++v) {
       const float4 t = (4 * v < a.fK) ? *reinterpret_cast<const float4*>(&ws[c * ldw_s + 4 * v]) : make_float4(0.f, 0.f, 0.f, 0.f);
       wrow[4 * v] = t.x; wrow[4 * v + 1] = t.y; wrow[4 * v + 2] = t.z; wrow[4 * v + 3] = t.w;
     }
@@ -574,6 +620,9 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
         float t = 0.f;
         if (a.diag & 16) {
           t = ds[r * ldd] + wrow[0] + wrow[63];
+        } else if (FRONT == 2) {
+#pragma unroll
+          for (int k = 0; k < FK; ++k) t = fmaf(ds[r * ldd + k], wrow[k], t);
         } else if (a.fK <= 32) {
 #pragma unroll
           for (int k = 0; k < 32; ++k) t = fmaf(ds[r * ldd + k], wrow[k], t);
@@ -642,7 +691,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_dual_kernel(BnBwdArgs a
 }
 
 bool bn_bwd_front_supported(int B, int K) {
-  return B > 0 && B <= BN_RL * 4 && (K == 32 || K == 64) && ((size_t)B * (K + 1) + 8 * (K + 4)) * sizeof(float) <= 96 * 1024;
+  return B > 0 && B <= BN_RL * 4 && (K == 32 || K == 64 || (K == 128 && B <= BN_RL * 2)) && ((size_t)B * (K + 1) + 8 * (K + 4)) * sizeof(float) <= 96 * 1024;
 }
 
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
@@ -658,7 +707,12 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
     static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_bwd_kernel<4, 1>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     if (lds > 64 * 1024 && !big_ok) { set_error("bn_act_bwd: cannot reserve the dynamic LDS of the gradient front"); return SMX_ERR_HIP; }
-    if (a.B <= BN_RL * 2) hipLaunchKernelGGL((bn_act_bwd_kernel<2, 1>), dim3(grid), dim3(BN_THREADS), lds, st, a);
+    if (a.fK == 128) {
+      static const bool big2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_bwd_kernel<2, 2>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+      if (lds > 64 * 1024 && !big2) { set_error("bn_act_bwd: cannot reserve the dynamic LDS of the gradient front"); return SMX_ERR_HIP; }
+      hipLaunchKernelGGL((bn_act_bwd_kernel<2, 2>), dim3(grid), dim3(BN_THREADS), lds, st, a);
+    } else if (a.B <= BN_RL * 2) hipLaunchKernelGGL((bn_act_bwd_kernel<2, 1>), dim3(grid), dim3(BN_THREADS), lds, st, a);
     else hipLaunchKernelGGL((bn_act_bwd_kernel<4, 1>), dim3(grid), dim3(BN_THREADS), lds, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
@@ -680,7 +734,7 @@ int launch_bn_act_bwd_dual(hipStream_t st, const BnBwdArgs& a_in, const BnBwdArg
   BnBwdArgs a = a_in, b = b_in;
   a.diag = b.diag = 0;
   auto ok = [](const BnBwdArgs& x) {
-    return x.front && bn_bwd_front_supported(x.B, x.fK) && x.fD && x.fW && !(x.fld % 4) && !(x.fldw % 4) && !(x.Hp % BN_COLS);
+    return x.front && x.fK <= 64 && bn_bwd_front_supported(x.B, x.fK) && x.fD && x.fW && !(x.fld % 4) && !(x.fldw % 4) && !(x.Hp % BN_COLS);
   };
   if (!ok(a) || !ok(b) || a.B != b.B || !bn_dual_supported(a.B) || b.with_metrics || b.adam_count || b.sqr_count) {
     set_error("bn_act_bwd_dual: gradient fronts not applicable");

@@ -514,12 +514,13 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     const bool no_twin = !m->flags.twin;
     const bool ahead = !no_fz && !no_ahead && !m->scvi;
     const bool sync = sync_bn_on(m, ps.training) && L.bn >= 0;
-    // hidden -> hidden layers up to 64 wide: the BatchNorm launch stages the layer's INPUT tile [B][K] in LDS and forms its
+    // hidden -> hidden layers 32 / 64 / 128 wide: the BatchNorm launch stages the layer's INPUT tile [B][K] in LDS and forms its
     // own columns as dot products -- the same front the first decoder layer uses for the latent sample, here as a plain
     // copy (no product launch; the reference's default networks are [64, 64], configs/base.yaml:10-17)
     LatentArgs dense_la;
     const bool dense_front = m->flags.front && no_fz && !sync && !(front != nullptr && i == 0) && !(i == 0 && in_is_x) && L.leak == 0.f &&
-                             (L.in_p == 32 || L.in_p == 64) && bn_front_supported(ps.B, L.in_p) && L.out_p % 8 == 0 && (ld % 4) == 0 && !use_mid(m, ps.B);
+                             (L.in_p == 32 || L.in_p == 64 || (L.in_p == 128 && ps.B <= 128)) && bn_front_supported(ps.B, L.in_p) && L.out_p % 8 == 0 &&
+                             (ld % 4) == 0 && !use_mid(m, ps.B);
     if (dense_front) {
       dense_la.stochastic = 0; dense_la.relu = 0; dense_la.training = ps.training;
       dense_la.lat = in; dense_la.ld = ld; dense_la.B = ps.B; dense_la.D = L.in; dense_la.Dp = L.in_p;
@@ -716,7 +717,7 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
       }
       attach_early_adam(m, b);
       Timed t(m, "bn_bwd");
-      const bool dual = last && b.front && twin && twin_front && !twin->empty() && m->flags.twin && bn_dual_supported(ps.B) &&
+      const bool dual = last && b.front && b.fK <= 64 && twin && twin_front && twin_front->fK <= 64 && !twin->empty() && m->flags.twin && bn_dual_supported(ps.B) &&
                         bn_bwd_front_supported(ps.B, twin_front->fK) && twin->back().out_p % 8 == 0 &&
                         !(sync_bn_on(m, ps.training) && twin->back().bn >= 0);
       if (dual) {
@@ -753,9 +754,9 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
       n_slabs = 0;
       break;
     }
-    // hidden layers up to 64 wide: the layer below takes d in = dpre W^T as the gradient front of its BatchNorm-backward
+    // hidden layers 32 / 64 / 128 wide: the layer below takes d in = dpre W^T as the gradient front of its BatchNorm-backward
     // launch (dot products over K = this layer's width) and d W joins the grouped launch at the end -- no product launch
-    if (defer && i > 0 && !(i == 0 && lat_epi) && m->flags.bwd_front && (L.out_p == 32 || L.out_p == 64) &&
+    if (defer && i > 0 && !(i == 0 && lat_epi) && m->flags.bwd_front && (L.out_p == 32 || L.out_p == 64 || L.out_p == 128) &&
         bn_bwd_front_supported(ps.B, L.out_p) && mlp[i - 1].out_p % 8 == 0 && (tw.ld % 4) == 0 && (L.out_p % 4) == 0 &&
         !(sync_bn_on(m, ps.training) && mlp[i - 1].bn >= 0)) {
       defer->push_back(g);
