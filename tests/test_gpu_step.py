@@ -42,6 +42,12 @@ CASES = {
                        encl_units=(16,)),
     "scvi_nbd": dict(model="scvi", n_genes=96, likelihood="nbd", enc_units=(32,), dec_units=(32,), latent_dim=4,
                      encl_units=(8,), batchnorm=False),
+    # scvi's own defaults (scvi.py:33-48: encoder [64, 64], library encoder [64], latent 10) and a two-layer library encoder:
+    # the side-by-side first layers continue into deeper ones, gradient fronts are handed down layer by layer
+    "scvi_default": dict(model="scvi", n_genes=200, likelihood="zinbd", enc_units=(64, 64), dec_units=(64, 64), latent_dim=10,
+                         encl_units=(64,)),
+    "scvi_deep": dict(model="scvi", n_genes=120, likelihood="nbd", enc_units=(64, 40), dec_units=(48,), latent_dim=8,
+                      encl_units=(32, 24)),
     "paper_shape": dict(model="vae", n_genes=1998, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=32),
 }
 
@@ -180,7 +186,7 @@ def test_label_backward_forms_match_oracle(Engine, name, flags):
 
 
 @pytest.mark.parametrize("flags", [("scvi_fused",), ("twin",), ("scvi_fused", "twin"), ("scvi_fused", "twin", "bwd_front", "front", "wgrad")])
-@pytest.mark.parametrize("name", ["scvi_zinbd", "scvi_nbd"])
+@pytest.mark.parametrize("name", ["scvi_zinbd", "scvi_nbd", "scvi_default", "scvi_deep"])
 def test_scvi_separate_launch_forms_match_oracle(Engine, name, flags):
   """scvi: the row-local head launch of a training step (library latent + softmax head + likelihood + their backward,
   smx_scvi.hip) and the side-by-side launches of the two encoders / pairs of heads keep their separate-launch forms
