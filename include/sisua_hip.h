@@ -278,6 +278,13 @@ int smx_comm_set_sync_bn(smx_model* m, int on);
  * so the world > 1 arithmetic of the step can be checked on a one-GPU box.  Eager launches only. */
 int smx_comm_init_local(smx_model* const* models, int n);
 
+/* ---- host-side helper ------------------------------------------------------ */
+/* Visit order of one epoch under a streaming shuffle buffer of `buffer` cells (tf.data .shuffle(1000) after .cache,
+ * before .batch: sisua/data/_single_cell_base.py:597-600): at step t the element picks[t] % len(buffer) leaves the
+ * buffer and the next unseen cell takes its place.  picks[n_obs]: non-negative random integers from the caller's
+ * generator (the stream that defines the order); out[n_obs] receives the cell indices.  No device work. */
+int smx_shuffle_order(int32_t n_obs, int32_t buffer, const int64_t* picks, int32_t* out);
+
 /* ---- code-path switches ---------------------------------------------------- */
 /* The training step has two forms of several stages: the default wide / fused kernels and the separate-launch forms
  * they replaced (which eval, predict and the scoring paths always use).  name: "head_loss" (output product fused with

@@ -90,6 +90,7 @@ SIGNATURES = {
                               C.POINTER(_FP)]),
     "smx_forward_samples": (C.c_int, [_VP, _IP, _FP, _FP, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP,
                                       C.POINTER(_FP)]),
+    "smx_shuffle_order": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "smx_predict": (C.c_int, [_VP, _FP, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP,
                               C.POINTER(_FP)]),
     "smx_decode": (C.c_int, [_VP, _FP, _FP, C.c_int32, _FP, C.POINTER(_FP)]),

@@ -1817,6 +1817,26 @@ extern "C" {
 const char* smx_last_error(void) { return g_err.c_str(); }
 int smx_abi_version(void) { return SMX_ABI_VERSION; }
 
+// Host-side helper (no device work): the visit order of one epoch under a streaming shuffle buffer, the sequential part
+// of sisua_amd/data.py::epoch_order (tf.data's .shuffle(buffer) semantics, _single_cell_base.py:597-600).  picks[t] are
+// the caller's random integers (NumPy RandomState stream: the order is defined there); 2.3 ms per 3381-cell epoch in
+// Python -- as long as the device needs for the epoch itself -- against ~10 us here.
+int smx_shuffle_order(int32_t n_obs, int32_t buffer, const int64_t* picks, int32_t* out) {
+  SMX_REQUIRE(n_obs >= 0 && buffer > 0 && (n_obs == 0 || (picks && out)), "bad arguments");
+  std::vector<int32_t> buf((size_t)std::min(buffer, n_obs));
+  for (size_t i = 0; i < buf.size(); ++i) buf[i] = (int32_t)i;
+  int32_t nxt = (int32_t)buf.size();
+  size_t len = buf.size();
+  for (int32_t t = 0; t < n_obs; ++t) {
+    SMX_REQUIRE(picks[t] >= 0 && len > 0, "negative pick");
+    const size_t k = (size_t)(picks[t] % (int64_t)len);
+    out[t] = buf[k];
+    if (nxt < n_obs) buf[k] = nxt++;
+    else { buf[k] = buf[len - 1]; --len; }
+  }
+  return SMX_OK;
+}
+
 int smx_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -17,6 +17,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import ctypes as _C
+
 import numpy as np
 
 
@@ -81,16 +83,37 @@ def label_mask(n_obs: int, labels_percent: float, n_omics: int, seed: int = 1) -
   return np.random.RandomState(seed).uniform(size=n_obs) < labels_percent
 
 
+_SHUFFLE_LIB = [False]
+
+
+def _shuffle_lib():
+  """libsisua_hip.so when it is built (its smx_shuffle_order is host-only code); None otherwise: the Python walk below
+  is the definition, the library only runs it faster (tests/test_data.py checks they agree)."""
+  if _SHUFFLE_LIB[0] is False:
+    try:
+      from sisua_amd import _hip
+      _SHUFFLE_LIB[0] = _hip.load()
+    except Exception:
+      _SHUFFLE_LIB[0] = None
+  return _SHUFFLE_LIB[0]
+
+
 def epoch_order(n_obs: int, epoch: int, shuffle: int = 1000, seed: int = 1) -> np.ndarray:
   """Visit order of one epoch under a streaming shuffle buffer of size `shuffle`
   (tf.data .shuffle(1000) after .cache, before .batch)."""
   if not shuffle or shuffle <= 0:
     return np.arange(n_obs, dtype=np.int32)
   rng = np.random.RandomState(seed + epoch)
-  buf = list(range(min(shuffle, n_obs)))
-  nxt = len(buf)
   out = np.empty(n_obs, dtype=np.int32)
   picks = rng.randint(0, 2 ** 31 - 1, size=n_obs)
+  lib = _shuffle_lib()
+  if lib is not None:   # the sequential walk in C (smx_shuffle_order): ~10 us instead of 2.3 ms per 3381-cell epoch
+    p64 = np.ascontiguousarray(picks, dtype=np.int64)
+    rc = lib.smx_shuffle_order(int(n_obs), int(shuffle), p64.ctypes.data_as(_C.POINTER(_C.c_int64)), out.ctypes.data_as(_C.POINTER(_C.c_int32)))
+    if rc == 0:
+      return out
+  buf = list(range(min(shuffle, n_obs)))
+  nxt = len(buf)
   for t in range(n_obs):
     k = picks[t] % len(buf)
     out[t] = buf[k]

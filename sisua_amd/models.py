@@ -339,50 +339,91 @@ class SingleCellModel:
       it_end = min(it_end, it + int(max_iter))
     best, bad, t_log, stop = np.inf, 0, time.time(), False
     pool = ThreadPoolExecutor(max_workers=1)
-    ahead = pool.submit(_prepare, ep0) if it < it_end else None
-    epoch = ep0
+    # One library call covers every step up to the next event on the host's side -- a validation pass, the end of the
+    # schedule, a ragged batch, a progress line -- across epoch boundaries (at 26 steps per epoch a call per epoch left
+    # the device idle for ~8 % of the time between calls).  The per-epoch history comes from the per-step scalars the
+    # device keeps (smx_metrics_history), cut at the epoch boundaries afterwards.
+    max_chunk = 4096 if not verbose else max(spe, 512)
+    cache, pending = {}, {}
+
+    def batches_of(ep):
+      if ep not in cache:
+        cache[ep] = pending.pop(ep).result() if ep in pending else _prepare(ep)
+      return cache[ep]
+
+    def prefetch(ep_from, ep_to):   # on the host thread, while the device runs the chunk just launched
+      for ep in range(ep_from, ep_to):
+        if ep not in cache and ep not in pending and ep * spe < it_end:
+          pending[ep] = pool.submit(_prepare, ep)
+
+    acc = {}
     try:
+      prefetch(ep0, ep0 + 2)
       while it < it_end and not stop:
-        batches = ahead.result()
-        ahead = pool.submit(_prepare, epoch + 1) if (epoch + 1) * spe < it_end else None
-        pos = it - epoch * spe
-        acc = {}
-        while pos < spe and it < it_end and not stop:
-          room = min(spe - pos, it_end - it)
-          until_valid = valid_freq - (it % valid_freq) if valid_freq and valid_freq > 0 else room
-          n = max(1, min(room, until_valid))
-          # a ragged last batch (drop_remainder=False, the reference's default for fit(SingleCellOMIC)) is a step of its own
-          bs = len(batches[pos])
-          while n > 1 and len(batches[pos + n - 1]) != bs:
-            n -= 1
-          order = np.concatenate(batches[pos:pos + n]).astype(np.int32)
-          m = e.train_steps(order, n, bs, graph=bool(use_graph) and bs == B, metrics=True)
-          h = e.metrics_history(n)
-          pos += n
-          it += n
+        until_valid = valid_freq - (it % valid_freq) if valid_freq and valid_freq > 0 else it_end - it
+        want = max(1, min(it_end - it, until_valid, max_chunk))
+        # gather `want` steps of equal batch size, walking over epoch boundaries
+        parts, n, bs, j = [], 0, None, it
+        while n < want:
+          ep, pos = divmod(j, spe)
+          b = batches_of(ep)
+          take = 0
+          while pos + take < spe and n + take < want and (bs is None or len(b[pos + take]) == bs):
+            if bs is None:
+              bs = len(b[pos])   # a ragged last batch (drop_remainder=False, the reference's default for fit(SingleCellOMIC)) is a step of its own
+            take += 1
+          if take == 0:
+            break
+          parts += b[pos:pos + take]
+          n += take
+          j += take
+          if pos + take < spe:   # stopped inside the epoch (ragged batch ahead or enough steps)
+            break
+        order = np.concatenate(parts).astype(np.int32)
+        first_ep, last_ep = it // spe, (it + n - 1) // spe
+        for ep in [k for k in cache if k < first_ep]:
+          del cache[ep]
+        m = e.train_steps(order, n, bs, graph=bool(use_graph) and bs == B, metrics=True)
+        nxt = min(it_end - (it + n), valid_freq if valid_freq and valid_freq > 0 else max_chunk, max_chunk)
+        prefetch(last_ep, last_ep + 2 + max(nxt, 0) // max(spe, 1))   # what the next call will walk
+        h = e.metrics_history(n)
+        # per-epoch means: cut the per-step scalars at the epoch boundaries
+        s0 = 0
+        while s0 < n:
+          ep_here = (it + s0) // spe
+          s1 = min(n, (ep_here + 1) * spe - it)
           for k, v in h.items():
-            acc.setdefault(k, []).append(v)
-          if m["nan_flag"] or not np.isfinite(h["loss"]).all():
-            if terminate_on_nan:
-              raise FloatingPointError(f"non-finite loss or gradient norm at iteration {it}")
-            warnings.warn(f"non-finite loss or gradient norm at iteration {it}")
-          if verbose and rank == 0 and time.time() - t_log > logging_interval:
-            print(f"[{log_tag or self.name}] it {it} epoch {epoch} loss {m['loss']:.4f} nllk_x {m['nllk_x']:.4f} kl {m['kl']:.4f}")
-            t_log = time.time()
-          if valid is not None and valid_freq and it % valid_freq == 0:
-            vl = self._validate(e, valid, n_tr, cp)
-            hist_v.setdefault("val_loss", []).append(vl)
-            improved = vl < best * (1.0 - float(earlystop_threshold)) if np.isfinite(best) else True
-            if vl < best:
-              best = vl
-              self._checkpoint(checkpoint, rank, cp)
-            bad = 0 if improved else bad + 1
-            if earlystop_patience and bad >= int(earlystop_patience) and epoch >= int(earlystop_min_epoch):
-              stop = True
-        for k, parts in acc.items():   # one value per epoch: the mean over its steps
-          hist_t.setdefault(k, []).append(float(np.mean(np.concatenate(parts))))
-        epoch += 1
+            acc.setdefault(k, []).append(v[s0:s1])
+          if it + s1 == (ep_here + 1) * spe:   # the epoch is complete: one value per epoch, the mean over its steps
+            for k, seg in acc.items():
+              hist_t.setdefault(k, []).append(float(np.mean(np.concatenate(seg))))
+            acc = {}
+          s0 = s1
+        it += n
+        epoch = (it - 1) // spe
+        if m["nan_flag"] or not np.isfinite(h["loss"]).all():
+          if terminate_on_nan:
+            raise FloatingPointError(f"non-finite loss or gradient norm at iteration {it}")
+          warnings.warn(f"non-finite loss or gradient norm at iteration {it}")
+        if verbose and rank == 0 and time.time() - t_log > logging_interval:
+          print(f"[{log_tag or self.name}] it {it} epoch {epoch} loss {m['loss']:.4f} nllk_x {m['nllk_x']:.4f} kl {m['kl']:.4f}")
+          t_log = time.time()
+        if valid is not None and valid_freq and it % valid_freq == 0:
+          vl = self._validate(e, valid, n_tr, cp)
+          hist_v.setdefault("val_loss", []).append(vl)
+          improved = vl < best * (1.0 - float(earlystop_threshold)) if np.isfinite(best) else True
+          if vl < best:
+            best = vl
+            self._checkpoint(checkpoint, rank, cp)
+          bad = 0 if improved else bad + 1
+          if earlystop_patience and bad >= int(earlystop_patience) and epoch >= int(earlystop_min_epoch):
+            stop = True
+      if acc:   # the schedule ended (max_iter, early stop) inside an epoch: its mean over the steps that ran
+        for k, seg in acc.items():
+          hist_t.setdefault(k, []).append(float(np.mean(np.concatenate(seg))))
     finally:
+      for f in pending.values():
+        f.cancel()
       pool.shutdown(wait=True)
     if valid is not None and not hist_v.get("val_loss"):
       hist_v.setdefault("val_loss", []).append(self._validate(e, valid, n_tr, cp))
