@@ -276,7 +276,16 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
     float* tile = smem + wave * (32 * 36);   // operand tiles are dead after the loop's last barrier
     const float bias = g.bias ? g.bias[n0 + wn * 32 + li] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = out[r] + bias;
+    for (int r = 0; r < 16; ++r) {
+      float v = out[r] + bias;
+      if (g.act == 1) v = fmaxf(v, 0.f) + g.leak * fminf(v, 0.f);
+      else if (g.act == 2) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float y = row < g.M ? g.act_out[(long)row * g.act_ld + n0 + wn * 32 + li] : 0.f;
+        v = y > 0.f ? v : v * g.leak;
+      }
+      tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = v;
+    }
     // same wave wrote and reads: no workgroup barrier needed, only the LDS counter
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
@@ -296,7 +305,12 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
     for (int j = 0; j < RPW; ++j) {
       const int r = r_base + j;
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row < g.M) C[(long)row * g.ldc + col] = out[j] + bias;
+      if (row < g.M) {
+        float v = out[j] + bias;
+        if (g.act == 1) v = fmaxf(v, 0.f) + g.leak * fminf(v, 0.f);
+        else if (g.act == 2) v = g.act_out[(long)row * g.act_ld + col] > 0.f ? v : v * g.leak;
+        C[(long)row * g.ldc + col] = v;
+      }
     }
   }
   if (do_colsum) g.colsum[n0 + tid] = csum;
@@ -507,7 +521,8 @@ static int validate_gemm(GemmArgs& g) {
   if (!g.a_kmajor && (g.K % 4)) { set_error("gemm: row-major A needs K % 4 == 0"); return SMX_ERR_INVALID; }
   if (g.b_nmajor && (g.K % 4)) { set_error("gemm: n-major B needs K % 4 == 0"); return SMX_ERR_INVALID; }
   if (g.split_k < 1) g.split_k = 1;
-  if (g.split_k > 1 && (g.bias || g.colsum)) { set_error("gemm: bias/colsum need split_k == 1"); return SMX_ERR_INVALID; }
+  if (g.split_k > 1 && (g.bias || g.colsum || g.act)) { set_error("gemm: bias/colsum/activation need split_k == 1"); return SMX_ERR_INVALID; }
+  if (g.act == 2 && (!g.act_out || g.act_ld < g.N)) { set_error("gemm: activation backward needs the forward output"); return SMX_ERR_INVALID; }
   if (g.colsum && g.b_nmajor) { set_error("gemm: colsum needs k-major B"); return SMX_ERR_INVALID; }
   if (g.epi == 2 && (g.split_k != 1 || !g.lb.dlat || g.N != g.lb.Dp)) {
     set_error("gemm: latent-backward epilogue needs split_k == 1 and N == Dp");

@@ -73,6 +73,10 @@ struct GemmArgs {
   int wide_store = 0;   // set by the launcher: 16-byte stores through an LDS transpose (large outputs)
   int epi = 0;                     // 0: store C; 2: latent-head backward (EpiLatentBwd), split_k == 1
   EpiLatentBwd lb;
+  // activation in the store path (layers without BatchNorm and dropout; split_k == 1): act = 1: C = act(acc + bias) with
+  // act(v) = max(v, 0) + leak min(v, 0); act = 2 (backward): C = acc * act'(y) with y = act_out[row][col] the layer's
+  // forward output (1 where y > 0, leak elsewhere) -- the bias / activation launches of such layers disappear
+  int act = 0; float leak = 0.f; const float* act_out = nullptr; int act_ld = 0;
 };
 // Returns 0 or a negative smx_status.  N, lda, ldb, ldc multiples of 4; N multiple of 32.
 // eff_split (optional) receives the number of slabs actually written.

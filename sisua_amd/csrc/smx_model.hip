@@ -252,6 +252,7 @@ struct smx_model {
     int wgrad = getenv("SMX_NO_WGRAD") ? 0 : 1;            // K = minibatch weight gradients as the wide direct-operand kernel
     int scvi_fused = getenv("SMX_NO_SCVI_FUSED") ? 0 : 1;  // scvi: library latent + softmax head + likelihood + their backward as one row-local launch
     int twin = getenv("SMX_NO_TWIN") ? 0 : 1;              // scvi: first layers of both encoders (and pairs of heads) side by side in one launch
+    int act_epilogue = getenv("SMX_NO_ACT_EPILOGUE") ? 0 : 1;  // layers without BatchNorm / dropout: bias + activation (and its derivative) in the products' store paths
     int label_ride = getenv("SMX_NO_LABEL_RIDE") ? 0 : 1;  // label heads' backward inside the output head's backward launch + the final grouped launch
   } flags;
   int chunk_first_head = 0;           // first optimiser chunk of the output / label heads (they are last in the table)
@@ -540,6 +541,17 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
       g2 = make_gemm(T, in, ld, true, slab2);
       dual = ((size_t)std::max(g.split_k, 1) * ((size_t)g.slab_stride + (size_t)g2.slab_stride) <= m->slab_cap);
     }
+    // layers without BatchNorm and without dropout (the FactorVAE discriminator; plain autoencoders at evaluation): bias
+    // and activation in the product's own store path -- no bias / activation launch
+    const bool epi_act = m->flags.act_epilogue && !dual && !fuse && !with_front && !sync && L.bn < 0 && !(ps.training && L.drop_p > 0.f) &&
+                         g.split_k <= 1 && !m->use_injected;
+    if (epi_act) {
+      g.bias = P_(m, L.tBias); g.act = 1; g.leak = L.leak; g.C = L.out_buf; g.ldc = L.out_p; g.split_k = 1;
+      Timed t(m, (i == 0 && in_is_x) ? label0 : "gemm_mlp_fwd");
+      SMX_CHECK(launch_gemm(m->st, g));
+      in = L.out_buf; ld = L.out_p;
+      continue;
+    }
     if (dual) {
       Timed t(m, label0);
       SMX_CHECK(launch_gemm_dual(m->st, g, g2, &eff));
@@ -696,14 +708,17 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
   if (twin_done) *twin_done = false;
   BnBwdArgs carried;            // gradient front handed from layer i + 1 to layer i (hidden layers up to 64 wide)
   bool have_carried = false;
+  bool dpre_done = false;       // layer i's d pre-activation was written by the d in product of layer i + 1 (activation epilogue)
   for (int i = (int)mlp.size() - 1; i >= 0; --i) {
     MlpLayer& L = mlp[i];
     const TensorInfo& tw = m->tensors[L.tW];
     const bool last = (i == (int)mlp.size() - 1);
     BnBwdArgs b = make_b(L, n_slabs, (grad_front && last) ? grad_front : (have_carried ? &carried : nullptr));
     have_carried = false;
-    if (last && last_bn_done) {
-      // (this layer's BatchNorm-backward ran beside the other MLP's)
+    const bool dpre_ready = dpre_done;
+    dpre_done = false;
+    if ((last && last_bn_done) || dpre_ready) {
+      // (this layer's BatchNorm-backward ran beside the other MLP's / its d pre-activation came with the product above)
     } else if (sync_bn_on(m, ps.training) && L.bn >= 0) {   // the ELBO scalars then go with a launch of their own (optimizer_pass)
       Timed t(m, "bn_bwd");
       m->adam_early_pending = false;
@@ -736,6 +751,7 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     g.C = G_(m, L.tW); g.ldc = tw.ld;
     g.M = L.in_p; g.N = L.out_p; g.K = ps.B;
     want_sq(m, g, L.tW);
+    if (dpre_ready) g.colsum = G_(m, L.tBias);   // (no bias / activation backward launch ran: the bias gradient is the column sum of d pre)
     if (first_x) {
       g.use_xform = 1;
       g.xf.rows = ps.rows; g.xf.u16 = ps.x_u16; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
@@ -775,6 +791,14 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     SMX_REQUIRE((size_t)h.split_k * (size_t)h.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
     if (i == 0 && lat_epi) {  // d z feeds the latent head only: run its backward in the epilogue
       h.epi = 2; h.lb = *lat_epi; h.split_k = 1; h.tile = TILE_32x32_K4;
+    }
+    // the layer below has neither BatchNorm nor dropout: its activation's derivative goes into this product's store path
+    // and the result IS its d pre-activation (its bias gradient: the column sums its weight-gradient product takes along)
+    if (i > 0 && m->flags.act_epilogue && mlp[i - 1].bn < 0 && !(ps.training && mlp[i - 1].drop_p > 0.f) && h.split_k <= 1) {
+      MlpLayer& Lo = mlp[i - 1];
+      h.split_k = 1; h.act = 2; h.leak = Lo.leak; h.act_out = Lo.out_buf; h.act_ld = Lo.out_p;
+      h.C = Lo.dpre; h.ldc = Lo.out_p; h.slab_stride = 0;
+      dpre_done = true;
     }
     int effs[2] = {1, 1};
     if (defer && i == 0 && lat_epi) {   // d z (+ latent-head backward) alone; d W joins the final grouped launch
@@ -2916,8 +2940,8 @@ int smx_set_flag(smx_model* m, const char* name, int value) {
   const std::string n(name);
   int* f = n == "head_loss" ? &m->flags.head_loss : n == "front" ? &m->flags.front : n == "bwd_front" ? &m->flags.bwd_front
          : n == "head_bwd" ? &m->flags.head_bwd : n == "wgrad" ? &m->flags.wgrad : n == "scvi_fused" ? &m->flags.scvi_fused
-         : n == "twin" ? &m->flags.twin : n == "label_ride" ? &m->flags.label_ride : nullptr;
-  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride)");
+         : n == "twin" ? &m->flags.twin : n == "label_ride" ? &m->flags.label_ride : n == "act_epilogue" ? &m->flags.act_epilogue : nullptr;
+  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue)");
   *f = value ? 1 : 0;
   drop_graphs(m);   // a captured step bakes the launch sequence in
   return SMX_OK;

@@ -146,6 +146,36 @@ def test_separate_launch_forms_match_oracle(Engine, name, flags):
   e.close(); e0.close()
 
 
+@pytest.mark.parametrize("name", ["fvae", "semifvae"])
+def test_activation_epilogue_forms_match_oracle(Engine, name):
+  """Layers without BatchNorm and dropout (the FactorVAE discriminator): bias + activation in the products' store paths
+  and the activation's derivative in the d-input products, or the separate bias / activation launches (flag
+  act_epilogue): both match the oracle, three steps of both end within rounding of each other."""
+  kw = CASES[name]
+  spec, cfg, x, ys, lib, mask = _problem(kw)
+  params = perturbed_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  B = 96
+  e, e0 = Engine(cfg, max_batch=128, init=False), Engine(cfg, max_batch=128, init=False)
+  for eng in (e, e0):
+    eng.set_params(params)
+    eng.upload(x, ys, lib, mask, cell_id_base=1000)
+  e.set_flag("act_epilogue", False)
+  rows = np.random.default_rng(1).choice(x.shape[0], size=B, replace=False).astype(np.int32)
+  res = _oracle_step(spec, params, bn, opt, x, ys, lib, mask, rows, 0, cell_base=1000)
+  for eng in (e, e0):
+    m = eng.train_step(rows)
+    for key in ("loss", "nllk_x", "kl", "tc", "dtc_loss"):
+      assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
+    worst = grad_errors(eng.get_params(which=1), res["grads"])
+    assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  for s in (1, 2):
+    r2 = ((rows + 7 * s) % x.shape[0]).astype(np.int32)
+    m, m0 = e.train_step(r2), e0.train_step(r2)
+  assert np.isclose(m["loss"], m0["loss"], rtol=1e-5) and np.isclose(m["dtc_loss"], m0["dtc_loss"], rtol=1e-4)
+  e.close(); e0.close()
+
+
 @pytest.mark.parametrize("flags", [("label_ride",), ("label_ride", "wgrad"), ("wgrad",), ("head_bwd",), ("bwd_front", "wgrad")])
 @pytest.mark.parametrize("name", ["sisua", "misa"])
 def test_label_backward_forms_match_oracle(Engine, name, flags):

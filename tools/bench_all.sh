@@ -3,7 +3,7 @@
 TAG=${1:-all}
 O=gpurun_out/$TAG
 mkdir -p $O
-for w in 8kly c5-shard 8kly-scvi eccly-sisua 8kly-2layer; do
+for w in 8kly c5-shard 8kly-scvi eccly-sisua 8kly-2layer cortex-base; do
   python3 bench.py --workload $w --no-cpu-baseline --steps 300 --warmup 30 > $O/bench_$w.json 2> $O/bench_$w.err
   python3 - "$O/bench_$w.json" "$w" <<'PY'
 import json, sys

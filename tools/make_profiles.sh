@@ -22,7 +22,7 @@ python3 tools/divergence_event.py > $O/divergence_event.txt 2>&1
 TRAJ_STEPS=400 python3 tools/divergence_trace.py > $O/divergence_trace.txt 2>&1
 # the other single-GPU workloads (BASELINE configs C3 / C4 on one GPU, the C5 shard, the two-layer variant): bench line + one step's timeline
 : > $O/workloads.txt
-for w in 8kly-scvi eccly-sisua c5-shard 8kly-2layer; do
+for w in 8kly-scvi eccly-sisua c5-shard 8kly-2layer cortex-base; do
   python3 bench.py --workload $w --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$w -- python3 bench.py --workload $w --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2> $O/rocprof_$w.err
   echo "## $w" >> $O/workloads.txt

@@ -17,6 +17,9 @@ variants = {
   "dca zinb": dict(model="dca", likelihood="zinb"),
   "vae zinb units [256,128]": dict(model="vae", likelihood="zinb", enc_units=(256, 128), dec_units=(128, 256)),
   "vae zinb latent 10": dict(model="vae", likelihood="zinb", latent_dim=10),
+  "vae zinb units [64,64]": dict(model="vae", likelihood="zinb", enc_units=(64, 64), dec_units=(64, 64)),
+  "scale zinb (10 components)": dict(model="scale", likelihood="zinb", n_components=10),
+  "fvae zinb (5 x 1000 discriminator)": dict(model="fvae", likelihood="zinb", disc_units=1000, disc_layers=5),
 }
 order = bench.make_order(xt.shape[0], batch, 330)
 for name, kw in variants.items():
