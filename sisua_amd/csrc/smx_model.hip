@@ -1277,15 +1277,25 @@ int factor_sweep(smx_model* m, int rows, const float* up, bool with_grads) {
     Timed t(m, "disc_bwd");
     SMX_CHECK(launch_gemm(m->st, gh, &n_slabs));
   }
+  // The discriminator's layers have neither BatchNorm nor dropout: below the top layer the activation's derivative runs
+  // in the store path of the d-input product above (which then writes the layer's d pre-activation directly) and the bias
+  // gradient is the column sum its weight-gradient product takes along -- no bias / activation backward launch per
+  // layer (flag act_epilogue).  Without gradients (the TC sweep) the d pre-activations ping-pong between two scratch
+  // buffers, as a product must not write the operand it reads.
+  float* pong[2] = {m->disc_dpre, m->slab};
+  int pp = 0;
+  bool ready = false;
+  float* dpre_i = nullptr;
   for (int i = (int)m->disc.size() - 1; i >= 0; --i) {
     MlpLayer& L = m->disc[i];
     const TensorInfo& tw = m->tensors[L.tW];
-    BnBwdArgs b;
-    b.dout = m->slab; b.n_slabs = n_slabs; b.slab_stride = (long)rows * L.out_p; b.ld = L.out_p;
-    b.out = L.out_buf; b.B = rows; b.H = L.out; b.Hp = L.out_p; b.batchnorm = 0; b.training = 1; b.drop_scale = 1.f; b.leak = L.leak;
-    b.dpre = with_grads ? L.dpre : m->disc_dpre;
-    b.dbias = with_grads ? G_(m, L.tBias) : m->disc_db;
-    {
+    if (!ready) {
+      dpre_i = with_grads ? L.dpre : pong[pp];
+      BnBwdArgs b;
+      b.dout = m->slab; b.n_slabs = n_slabs; b.slab_stride = (long)rows * L.out_p; b.ld = L.out_p;
+      b.out = L.out_buf; b.B = rows; b.H = L.out; b.Hp = L.out_p; b.batchnorm = 0; b.training = 1; b.drop_scale = 1.f; b.leak = L.leak;
+      b.dpre = dpre_i;
+      b.dbias = with_grads ? G_(m, L.tBias) : m->disc_db;
       Timed t(m, "disc_bwd");
       SMX_CHECK(launch_bn_act_bwd(m->st, b));
     }
@@ -1293,24 +1303,36 @@ int factor_sweep(smx_model* m, int rows, const float* up, bool with_grads) {
     const int ld_in = (i == 0) ? m->Dp : m->disc[i - 1].out_p;
     if (with_grads) {
       GemmArgs g;
-      g.A = in; g.lda = ld_in; g.a_kmajor = 1; g.B = b.dpre; g.ldb = L.out_p;
+      g.A = in; g.lda = ld_in; g.a_kmajor = 1; g.B = dpre_i; g.ldb = L.out_p;
       g.C = G_(m, L.tW); g.ldc = tw.ld; g.M = L.in_p; g.N = L.out_p; g.K = rows;
+      if (ready) g.colsum = G_(m, L.tBias);
       want_sq(m, g, L.tW);
       Timed t(m, "disc_bwd");
       SMX_CHECK(launch_gemm(m->st, g));
       if (i == 0) break;   // z is a constant of the discriminator's objective
     }
     GemmArgs h;
-    h.A = b.dpre; h.lda = L.out_p; h.B = P_(m, L.tW); h.ldb = tw.ld; h.b_nmajor = 1;
+    h.A = dpre_i; h.lda = L.out_p; h.B = P_(m, L.tW); h.ldb = tw.ld; h.b_nmajor = 1;
     h.M = rows; h.N = L.in_p; h.K = L.out_p;
+    ready = false;
     if (i == 0) { h.C = m->dz_tc; h.ldc = m->Dp; h.split_k = 1; h.tile = TILE_32x32_K4; }
     else {
       h.C = m->slab; h.ldc = L.in_p; h.slab_stride = (long)rows * L.in_p;
       h.split_k = suggest_split_k(rows, L.in_p, L.out_p);
       SMX_REQUIRE((size_t)h.split_k * (size_t)h.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
+      if (m->flags.act_epilogue && h.split_k <= 1 && (with_grads || pong[pp ^ 1] != dpre_i)) {
+        MlpLayer& Lo = m->disc[i - 1];
+        float* next = with_grads ? Lo.dpre : pong[pp ^= 1];
+        h.split_k = 1; h.act = 2; h.leak = Lo.leak; h.act_out = Lo.out_buf; h.act_ld = Lo.out_p;
+        h.C = next; h.ldc = Lo.out_p; h.slab_stride = 0;
+        ready = true;
+      }
     }
-    Timed t(m, "disc_bwd");
-    SMX_CHECK(launch_gemm(m->st, h, &n_slabs));
+    {
+      Timed t(m, "disc_bwd");
+      SMX_CHECK(launch_gemm(m->st, h, &n_slabs));
+    }
+    if (ready) dpre_i = h.C;
   }
   return SMX_OK;
 }
