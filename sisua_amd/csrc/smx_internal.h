@@ -216,6 +216,9 @@ struct AdamArgs {
   float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, clipnorm = 100.f;
   float grad_scale = 1.f;       // extra factor on the gradient (1: the loss is already scaled by 1 / global batch)
   float* hist_dp = nullptr; const float* tail_metrics = nullptr;   // data parallel: the reduced scalars go to the history here
+  // data parallel, world > 1: the moving BatchNorm statistics take the all-reduced batch statistics (mean over the ranks)
+  // in extra workgroups of the gradient-norm launch (it was a launch of its own)
+  float* bn_moving = nullptr; const float* bn_batch = nullptr; int bn_total = 0; float bn_inv_world = 1.f, bn_momentum = 0.99f;
 };
 int launch_adam(hipStream_t st, const AdamArgs& a);
 

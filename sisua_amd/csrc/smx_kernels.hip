@@ -1564,8 +1564,11 @@ int launch_metrics(hipStream_t st, const MetricsArgs& a) {
 // optimiser: per-tensor clipnorm + Adam over the flat buffer
 // ===========================================================================
 __global__ __launch_bounds__(256) void grad_sqsum_kernel(AdamArgs a) {
-  if ((int)blockIdx.x == a.n_chunks) {  // the extra workgroup: ELBO scalars of this step
-    metrics_body(a.metrics);
+  const int extra = (int)blockIdx.x - a.n_chunks;
+  if (extra >= 0) {   // extra workgroups: the ELBO scalars of this step, then the moving BatchNorm statistics (data parallel)
+    if (a.with_metrics && extra == 0) { metrics_body(a.metrics); return; }
+    const int i = (extra - (a.with_metrics ? 1 : 0)) * 256 + (int)threadIdx.x;
+    if (i < a.bn_total) a.bn_moving[i] = a.bn_moving[i] * a.bn_momentum + a.bn_batch[i] * a.bn_inv_world * (1.f - a.bn_momentum);
     return;
   }
   __shared__ float sh[4];
@@ -1672,7 +1675,7 @@ int launch_adam(hipStream_t st, const AdamArgs& a) {
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
-  hipLaunchKernelGGL(grad_sqsum_kernel, dim3(a.n_chunks + (a.with_metrics ? 1 : 0)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(grad_sqsum_kernel, dim3(a.n_chunks + (a.with_metrics ? 1 : 0) + (a.bn_total + 255) / 256), dim3(256), 0, st, a);
   hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_launch), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;

@@ -1696,14 +1696,19 @@ int optimizer_pass(smx_model* m) {
     } else {
       SMX_CHECK(dp_allreduce(m, 0, m->grads_count, m->st));   // one all-reduce of the whole flat buffer
     }
-    if (m->bn_total && m->world > 1) {
+  }
+  AdamArgs a;
+  fill_adam_args(m, a);
+  if (dp_active(m) && m->bn_total && m->world > 1) {
+    if (!a.use_sq) {   // (the usual case under data parallelism: the gradient-norm launch takes the update along)
+      a.bn_moving = m->bn_moving; a.bn_batch = m->grads + m->tail_off_bn; a.bn_total = (int)m->bn_total;
+      a.bn_inv_world = 1.f / (float)m->world; a.bn_momentum = c.bn_momentum;
+    } else {
       hipLaunchKernelGGL(bn_moving_update_kernel, dim3((unsigned)((m->bn_total + 255) / 256)), dim3(256), 0, m->st,
                          m->bn_moving, m->grads + m->tail_off_bn, (int)m->bn_total, 1.f / (float)m->world,
                          c.bn_momentum);
     }
   }
-  AdamArgs a;
-  fill_adam_args(m, a);
   if (m->adam_early_from >= 0) {   // the head chunks have ridden along already
     a.gap_from = m->adam_early_from; a.gap_len = m->adam_early_to - m->adam_early_from;
     a.n_launch = m->n_chunks - a.gap_len;
