@@ -163,7 +163,7 @@ def main():
   ap.add_argument("--workload", default="8kly")
   ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (eager launches measured faster)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--storage", default="f32", choices=("f32", "u16"), help="resident count matrix: float32 (reference layout) or uint16")
+  ap.add_argument("--storage", default="f32", choices=("f32", "u16", "csr"), help="resident count matrix: float32 (reference layout), uint16, or the non-zeros only (CSR)")
   ap.add_argument("--cpu-budget", type=float, default=12.0)
   ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
                   help="N > 1: weak = the configuration's batch per GPU; strong = the global batch is preserved (batch / N per GPU)")

@@ -143,6 +143,14 @@ int smx_dataset_upload(smx_model* m, const float* X, int64_t n_cells, const floa
 int smx_dataset_upload_u16(smx_model* m, const uint16_t* X, int64_t n_cells, const float* const* labels,
                            const float* library, const uint8_t* label_mask, int64_t cell_id_base);
 
+/* Compact sparse store (the dense float32 memmap semantics of sisua/data/utils.py:401-452 over the
+ * non-zeros only): the counts as CSR -- indptr [n_cells + 1] (indptr[0] = 0), then column indices (< n_genes) and
+ * float32 values of the non-zeros row by row; 8 bytes per non-zero on the device.  Every pass expands its minibatch's
+ * rows into a dense float32 tile first, so every result is bit-identical to the float32 store.  smx_dataset_library /
+ * smx_dataset_corrupt need a dense store; input dropout too (its noise is keyed by the dense store's rows). */
+int smx_dataset_upload_csr(smx_model* m, const int64_t* indptr, const int32_t* cols, const float* vals, int64_t n_cells,
+                           const float* const* labels, const float* library, const uint8_t* label_mask, int64_t cell_id_base);
+
 int64_t smx_dataset_size(const smx_model* m);
 
 /* Library-size statistics of the RESIDENT matrix, get_library_size (sisua/data/utils.py:231-263) as the

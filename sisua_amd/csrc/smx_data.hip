@@ -44,6 +44,48 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
   }
 }
 
+// ---- compact sparse store (CSR: SURVEY.md 8f-2, the dense float32 memmap semantics of sisua/data/utils.py:401-452
+// over 7-12 % of its bytes) ------------------------------------------------------------------------------------------
+// lgx1 of every resident row, one wave per row (the data-only constant of the likelihood, as row_stats_kernel)
+__global__ __launch_bounds__(256) void csr_row_stats_kernel(const int64_t* __restrict__ indptr, const float* __restrict__ vals,
+                                                            long N, float* __restrict__ lgx1) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int lane = threadIdx.x & 63;
+  double lg = 0.0;
+  for (int64_t i = indptr[row] + lane; i < indptr[row + 1]; i += 64) {
+    const float v = vals[i];
+    if (v > 0.f) lg += lgamma((double)v + 1.0);
+  }
+  lg = wave_sum_f64(lg);
+  if (lane == 0) lgx1[row] = (float)lg;
+}
+int launch_csr_row_stats(hipStream_t st, const int64_t* indptr, const float* vals, long N, float* lgx1) {
+  hipLaunchKernelGGL(csr_row_stats_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, indptr, vals, N, lgx1);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// The rows of a minibatch as a dense [B][ld] float32 tile (zeroed by the caller): the per-step reader of the sparse
+// store.  One wave per row; every consumer of X then reads the tile exactly as it reads a host batch.
+__global__ __launch_bounds__(256) void csr_expand_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+                                                         const float* __restrict__ vals, const int32_t* __restrict__ rows, long row0,
+                                                         int B, long ld, float* __restrict__ out) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63;
+  const long src = rows ? rows[b] : row0 + b;
+  float* o = out + (long)b * ld;
+  for (int64_t i = indptr[src] + lane; i < indptr[src + 1]; i += 64) o[cols[i]] = vals[i];
+}
+int launch_csr_expand(hipStream_t st, const int64_t* indptr, const int32_t* cols, const float* vals, const int32_t* rows, long row0,
+                      int B, long ld, float* out) {
+  SMX_HIP(hipMemsetAsync(out, 0, (size_t)B * (size_t)ld * sizeof(float), st));
+  hipLaunchKernelGGL(csr_expand_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, indptr, cols, vals, rows, row0, B, ld, out);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
 // mean and (population) variance of logcount[0..N): one workgroup, two passes, fp64
 __global__ __launch_bounds__(1024) void library_moments_kernel(const double* __restrict__ logcount, long N,
                                                                double* __restrict__ stats) {

@@ -309,6 +309,7 @@ struct ScviTrainArgs {
   const float* raw = nullptr; long ld = 0; long plane_stride = 0;   // raw head outputs [B][k][Gp] (bias added)
   int B = 0, G = 0, Gp = 0; int likelihood = 0;
   const float* X = nullptr; int ldx = 0; int x_u16 = 0; const int32_t* rows = nullptr;
+  int x_identity = 0;          // X holds the minibatch's rows already (row b = cell b): `rows` then serves the library / noise keys only
   float clip_library = 1e3f; float grad_scale = 1.f;
   float* draw = nullptr;       // [B][ld] d loss / d raw
   float* llk_part = nullptr;   // [B] one partial per cell (without the -lgamma(x+1) constant)
@@ -504,6 +505,10 @@ struct CorruptArgs {
   unsigned long long* hist = nullptr;   // [256] byte histogram (hist passes) / [1] corrupted-entry counter (apply)
 };
 int launch_row_stats(hipStream_t st, const float* X, int u16, long ld, long N, int G, float* lgx1, double* logcount);
+// compact sparse store: per-row constants, and the per-step reader (minibatch rows -> dense float32 tile)
+int launch_csr_row_stats(hipStream_t st, const int64_t* indptr, const float* vals, long N, float* lgx1);
+int launch_csr_expand(hipStream_t st, const int64_t* indptr, const int32_t* cols, const float* vals, const int32_t* rows, long row0,
+                      int B, long ld, float* out);
 int launch_library_stats(hipStream_t st, const double* logcount, long N, double* stats, float* library);
 int launch_corrupt_hist(hipStream_t st, const CorruptArgs& a, int pass);
 int launch_corrupt_apply(hipStream_t st, const CorruptArgs& a);

@@ -262,6 +262,9 @@ struct smx_model {
   bool adam_early_pending = false;    // the heads' gradients are final: the next BatchNorm-backward launch may carry their update
   int adam_early_from = -1;           // >= 0: chunks [adam_early_from, n_chunks) of this step were applied early
   bool x_u16 = false;   // the resident matrix is stored as uint16 counts (smx_dataset_upload_u16)
+  // compact sparse store (smx_dataset_upload_csr): CSR arrays resident, the minibatch's rows expanded per pass into xbatch
+  int64_t* csr_indptr = nullptr; int32_t* csr_cols = nullptr; float* csr_vals = nullptr; bool x_csr = false;
+  float* xbatch = nullptr;   // [Bmax][Gp]
   float* pred_stage = nullptr; size_t pred_floats = 0;   // device staging of smx_predict (one chunk of cells, laid out like the caller's arrays)
   float* pinned = nullptr; size_t pinned_floats = 0;   // host staging for the parameter planes handed back by smx_forward / smx_decode
   // sum-of-squares slots written by the weight-gradient products (per-tensor clipnorm without a separate pass)
@@ -406,6 +409,17 @@ StepState* master_state(smx_model* m) { return m->state3 + 2; }
 float* P_(smx_model* m, int t) { return m->params + m->tensors[t].offset; }
 float* G_(smx_model* m, int t) { return m->grads + m->tensors[t].offset; }
 
+// the sparse store's arrays (m->X aliases the expansion tile while it is in use)
+static void release_csr(smx_model* m) {
+  if (!m->x_csr) return;
+  if (m->csr_indptr) hipFree(m->csr_indptr);
+  if (m->csr_cols) hipFree(m->csr_cols);
+  if (m->csr_vals) hipFree(m->csr_vals);
+  if (m->xbatch) hipFree(m->xbatch);
+  m->csr_indptr = nullptr; m->csr_cols = nullptr; m->csr_vals = nullptr; m->xbatch = nullptr;
+  m->X = nullptr; m->x_csr = false;
+}
+
 NoiseKey make_key(smx_model* m, int stream, int sample, bool training) {
   NoiseKey nk;
   nk.k0 = (uint32_t)(m->cfg.seed & 0xFFFFFFFFu);
@@ -426,7 +440,8 @@ const Injected* inj(smx_model* m, int stream) {
 struct Pass {
   int B = 0;
   const int32_t* rows = nullptr;   // device row ids into X (nullptr: identity on Xsrc)
-  const float* Xsrc = nullptr;     // m->X or m->hostX
+  const int32_t* xrows = nullptr;  // ... as the readers of X see them: == rows, or nullptr when Xsrc already holds the minibatch's rows (sparse store)
+  const float* Xsrc = nullptr;     // m->X, m->hostX, or the expanded minibatch of the sparse store
   int x_u16 = 0;                   // Xsrc is the compact uint16 store (resident rows only)
   const float* lib = nullptr;      // library [..][2] matching Xsrc indexing
   const float* lgx1 = nullptr;
@@ -473,7 +488,7 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     g.split_k = suggest_split_k(ps.B, L.out_p, L.in_p);
     if (first_x) {
       g.use_xform = 1;
-      g.xf.rows = ps.rows; g.xf.u16 = ps.x_u16; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
+      g.xf.rows = ps.xrows; g.xf.u16 = ps.x_u16; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
       if (ps.training && m->cfg.input_dropout > 0.f) {
         g.xf.drop_p = m->cfg.input_dropout; g.xf.drop_scale = 1.f / (1.f - m->cfg.input_dropout);
         g.xf.nk = make_key(m, ST_INPUT_DROPOUT, ps.sample, true);
@@ -754,7 +769,7 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     if (dpre_ready) g.colsum = G_(m, L.tBias);   // (no bias / activation backward launch ran: the bias gradient is the column sum of d pre)
     if (first_x) {
       g.use_xform = 1;
-      g.xf.rows = ps.rows; g.xf.u16 = ps.x_u16; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
+      g.xf.rows = ps.xrows; g.xf.u16 = ps.x_u16; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
       if (ps.training && m->cfg.input_dropout > 0.f) {
         g.xf.drop_p = m->cfg.input_dropout; g.xf.drop_scale = 1.f / (1.f - m->cfg.input_dropout);
         g.xf.nk = make_key(m, ST_INPUT_DROPOUT, ps.sample, true);
@@ -900,6 +915,7 @@ bool use_head_loss(const smx_model* m, int B) {
 }
 
 bool use_mid(const smx_model* m, int B) {
+  if (m->x_csr) return false;   // (the single-workgroup middle reads X through the resident row ids)
   // single-workgroup fusion of the middle is opt-in until it beats the per-operator path
   static const bool off = getenv("SMX_FUSED") == nullptr;
   if (off || m->scvi || m->scale || m->fvae || B > 128 || m->sync_bn) return false;
@@ -964,7 +980,7 @@ static bool scvi_train_args(smx_model* m, const Pass& ps, ScviTrainArgs* out) {
   ScviTrainArgs a;
   const long ldp = (long)m->k * m->Gp;
   a.raw = m->raw; a.ld = ldp; a.plane_stride = m->Gp; a.B = ps.B; a.G = m->G; a.Gp = m->Gp; a.likelihood = c.likelihood;
-  a.X = ps.Xsrc; a.ldx = m->Gp; a.x_u16 = ps.x_u16; a.rows = ps.rows;
+  a.X = ps.Xsrc; a.ldx = m->Gp; a.x_u16 = ps.x_u16; a.rows = ps.rows; a.x_identity = (ps.rows != nullptr && ps.xrows == nullptr) ? 1 : 0;
   a.clip_library = c.clip_library; a.grad_scale = -1.f / (float)ps.global_batch;
   a.draw = m->draw; a.llk_part = m->llk_part;
   a.hl = lL.out_buf; a.ldh = lL.out_p; a.Kl = lL.out_p;
@@ -1129,7 +1145,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   // ---- losses ----
   LossArgs lo;
   lo.likelihood = c.likelihood; lo.direct = m->scvi; lo.backward = backward;
-  lo.X = ps.Xsrc; lo.x_u16 = ps.x_u16; lo.ldx = m->Gp; lo.rows = ps.rows;
+  lo.X = ps.Xsrc; lo.x_u16 = ps.x_u16; lo.ldx = m->Gp; lo.rows = ps.xrows;
   lo.P = m->P; lo.ldp = ldp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
   lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = -inv_gb;
   int n_llk_chunks = loss_chunks(m->Gp, ps.B);
@@ -1139,7 +1155,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     const TensorInfo& tw = m->tensors[m->t_outW[0]];
     HeadLossArgs hl;
     hl.H = dL.out_buf; hl.ldh = dL.out_p; hl.W = P_(m, m->t_outW[0]); hl.ldw = tw.ld; hl.bias = P_(m, m->t_outb[0]);
-    hl.X = ps.Xsrc; hl.x_u16 = ps.x_u16; hl.ldx = m->Gp; hl.rows = ps.rows;
+    hl.X = ps.Xsrc; hl.x_u16 = ps.x_u16; hl.ldx = m->Gp; hl.rows = ps.xrows;
     hl.dP = m->dP; hl.ldp = ldp; hl.plane_stride = m->Gp; hl.llk_part = m->llk_part;
     hl.B = ps.B; hl.G = m->G; hl.Gp = m->Gp; hl.Hp = dL.out_p; hl.likelihood = c.likelihood; hl.grad_scale = -inv_gb;
     n_llk_chunks = head_loss_chunks(m->Gp);
@@ -1159,7 +1175,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     const TensorInfo& tw = m->tensors[m->t_outW[0]];
     OutHeadArgs oh;
     oh.H = dL.out_buf; oh.ldh = dL.out_p; oh.W = P_(m, m->t_outW[0]); oh.ldw = tw.ld; oh.bias = P_(m, m->t_outb[0]);
-    oh.X = ps.Xsrc; oh.x_u16 = ps.x_u16; oh.ldx = m->Gp; oh.rows = ps.rows;
+    oh.X = ps.Xsrc; oh.x_u16 = ps.x_u16; oh.ldx = m->Gp; oh.rows = ps.xrows;
     oh.dP = m->dP; oh.ldp = ldp; oh.plane_stride = m->Gp;
     oh.dW = G_(m, m->t_outW[0]); oh.db = G_(m, m->t_outb[0]);
     oh.llk_part = m->llk_part; oh.n_chunks = n_llk_chunks = out_head_chunks(m->Gp);
@@ -1378,7 +1394,7 @@ int backward_mid(smx_model* m, const Pass& ps, int n_slabs) {
     want_sq(m, g, tW);
     if (xform) {
       g.use_xform = 1;
-      g.xf.rows = ps.rows; g.xf.u16 = ps.x_u16; g.xf.log1p = c.log_norm; g.xf.cell_base = ps.cell_base;
+      g.xf.rows = ps.xrows; g.xf.u16 = ps.x_u16; g.xf.log1p = c.log_norm; g.xf.cell_base = ps.cell_base;
       if (ps.training && c.input_dropout > 0.f) {
         g.xf.drop_p = c.input_dropout; g.xf.drop_scale = 1.f / (1.f - c.input_dropout);
         g.xf.nk = make_key(m, ST_INPUT_DROPOUT, ps.sample, true);
@@ -1726,13 +1742,24 @@ int optimizer_pass(smx_model* m) {
   return SMX_OK;
 }
 
+// sparse store: expand the rows of this pass into the dense tile the readers of X take (they then index it with
+// identity rows; everything else -- labels, library prior, label mask, lgx1, noise keys -- keeps the resident row ids)
+int csr_stage(smx_model* m, Pass& ps) {
+  if (!m->x_csr || ps.Xsrc != m->X) return SMX_OK;
+  SMX_REQUIRE(ps.rows != nullptr && ps.B <= m->Bmax, "sparse store: resident rows only");
+  SMX_REQUIRE(!(ps.training && m->cfg.input_dropout > 0.f), "sparse store: input dropout is keyed by the dense store's rows (use the float32 / uint16 store)");
+  SMX_CHECK(launch_csr_expand(m->st, m->csr_indptr, m->csr_cols, m->csr_vals, ps.rows, 0, ps.B, m->Gp, m->xbatch));
+  ps.Xsrc = m->xbatch; ps.xrows = nullptr; ps.x_u16 = 0;
+  return SMX_OK;
+}
+
 // the whole training step as a launch sequence on m->st (capturable).
 //   with_begin:   launch the state/row-id preparation kernel first (graph replay: every step, cursor kept in
 //                 the master state; eager: only the first step of a train_steps call)
 //   prepare_next: the optimiser kernel prepares the other parity's state + row ids for the step after
 int train_sequence(smx_model* m, int B, bool with_begin, bool begin_from_master, uint32_t cursor, bool prepare_next) {
   Pass ps;
-  ps.B = B; ps.rows = cur_rows(m); ps.Xsrc = m->X; ps.x_u16 = m->x_u16; ps.lib = m->library; ps.lgx1 = m->lgx1;
+  ps.B = B; ps.rows = cur_rows(m); ps.xrows = ps.rows; ps.Xsrc = m->X; ps.x_u16 = m->x_u16; ps.lib = m->library; ps.lgx1 = m->lgx1;
   ps.cell_base = (uint32_t)m->cell_base; ps.training = 1; ps.sample = 0; ps.global_batch = B * m->world;
   m->seq_batch = B; m->seq_prepare_next = prepare_next ? 1 : 0;
   Timed t(m, "step");
@@ -1740,6 +1767,7 @@ int train_sequence(smx_model* m, int B, bool with_begin, bool begin_from_master,
     SMX_CHECK(launch_step_begin(m->st, master_state(m), cur_state(m), m->order, cur_rows(m), B, begin_from_master ? 1 : 0,
                                 cursor, m->cfg.lr, m->cfg.adam_beta1, m->cfg.adam_beta2));
   { Timed null_pair(m, "null"); }  // an event pair around nothing: the timing method's own overhead
+  SMX_CHECK(csr_stage(m, ps));     // sparse store: this minibatch's rows as a dense tile (no-op otherwise)
   SMX_CHECK(forward_pass(m, ps, true, true));
   SMX_CHECK(backward_pass(m, ps));
   SMX_CHECK(optimizer_pass(m));
@@ -2145,6 +2173,7 @@ int smx_model_destroy(smx_model* m) {
   fr(m->params); fr(m->grads); fr(m->adam_m); fr(m->adam_v); fr(m->bn_moving);
   for (auto* mlp : {&m->enc, &m->encl, &m->dec})
     for (auto& L : *mlp) { fr(L.xhat); fr(L.out_buf); fr(L.dpre); fr(L.inv_std); fr(L.noise); }
+  release_csr(m);   // (the sparse store: m->X aliased its expansion tile)
   fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1); fr(m->hostX); fr(m->hostLib); fr(m->hostLgx1);
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); fr(m->laby_raw[j]); fr(m->laby_draw[j]); }
   fr(m->rows2[0]); fr(m->rows2[1]); fr(m->order); fr(m->state3); fr(m->mhist);
@@ -2262,6 +2291,63 @@ int smx_dataset_upload_u16(smx_model* m, const uint16_t* X, int64_t n_cells, con
   return dataset_upload_impl(m, X, true, n_cells, labels, library, label_mask, cell_id_base);
 }
 
+static int upload_side_arrays(smx_model* m, int64_t n_cells, const float* const* labels, const float* library, const uint8_t* label_mask) {
+  int rc;
+  for (int j = 0; j < m->cfg.n_labels; ++j) {
+    const int P = m->cfg.label_dim[j], Pp = m->lab_Pp[j];
+    if ((rc = dmalloc(&m->Y[j], (size_t)n_cells * Pp))) return rc;
+    SMX_HIP(hipMemcpy2D(m->Y[j], (size_t)Pp * sizeof(float), labels[j], (size_t)P * sizeof(float), (size_t)P * sizeof(float),
+                        (size_t)n_cells, hipMemcpyHostToDevice));
+  }
+  if (library) {
+    if ((rc = dmalloc(&m->library, (size_t)n_cells * 2))) return rc;
+    SMX_HIP(hipMemcpy(m->library, library, (size_t)n_cells * 2 * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (label_mask) {
+    if ((rc = dmalloc(&m->mask, (size_t)n_cells))) return rc;
+    SMX_HIP(hipMemcpy(m->mask, label_mask, (size_t)n_cells, hipMemcpyHostToDevice));
+  }
+  return SMX_OK;
+}
+
+// Compact sparse store: the counts as CSR (indptr [n_cells + 1], column indices and values of the non-zeros, rows in
+// order, columns < n_genes) -- 8 bytes per non-zero instead of 4 per entry (7-12 % non-zeros in the named datasets).
+// Every pass expands its minibatch's rows into a dense float32 tile first (csr_stage), so results are bit-identical to
+// the float32 store; the resident-matrix kernels (library statistics, corruption) stay with the dense stores.
+int smx_dataset_upload_csr(smx_model* m, const int64_t* indptr, const int32_t* cols, const float* vals, int64_t n_cells,
+                           const float* const* labels, const float* library, const uint8_t* label_mask, int64_t cell_id_base) {
+  SMX_REQUIRE(m && indptr && n_cells > 0, "bad dataset");
+  SMX_REQUIRE(n_cells < (int64_t)1 << 31, "row ids are int32");
+  SMX_REQUIRE(!m->scvi || library, "scvi needs the library prior (scvi.py:100-105)");
+  for (int j = 0; j < m->cfg.n_labels; ++j) SMX_REQUIRE(labels && labels[j], "missing label matrix");
+  const int64_t nnz = indptr[n_cells];
+  SMX_REQUIRE(indptr[0] == 0 && nnz >= 0 && (nnz == 0 || (cols && vals)), "bad CSR arrays");
+  for (int64_t r = 0; r < n_cells; ++r) SMX_REQUIRE(indptr[r + 1] >= indptr[r], "CSR indptr must not decrease");
+  for (int64_t i = 0; i < nnz; ++i) SMX_REQUIRE(cols[i] >= 0 && cols[i] < m->G, "CSR column index out of range");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  drop_graphs(m);
+  auto fr = [](void* p) { if (p) hipFree(p); };
+  release_csr(m);
+  fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1);
+  m->X = nullptr; m->library = nullptr; m->mask = nullptr; m->lgx1 = nullptr;
+  for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); m->Y[j] = nullptr; }
+  m->N = n_cells; m->cell_base = cell_id_base; m->x_u16 = false;
+  int rc;
+  m->x_csr = true;
+  if ((rc = dmalloc(&m->csr_indptr, (size_t)n_cells + 1)) || (rc = dmalloc(&m->csr_cols, (size_t)std::max<int64_t>(nnz, 1))) ||
+      (rc = dmalloc(&m->csr_vals, (size_t)std::max<int64_t>(nnz, 1))) || (rc = dmalloc(&m->xbatch, (size_t)m->Bmax * m->Gp)) ||
+      (rc = dmalloc(&m->lgx1, (size_t)n_cells)))
+    return rc;
+  m->X = m->xbatch;   // (non-null: "a dataset is resident"; csr_stage fills it per pass)
+  SMX_HIP(hipMemcpy(m->csr_indptr, indptr, ((size_t)n_cells + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  if (nnz) {
+    SMX_HIP(hipMemcpy(m->csr_cols, cols, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    SMX_HIP(hipMemcpy(m->csr_vals, vals, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+  }
+  SMX_CHECK(launch_csr_row_stats(m->st, m->csr_indptr, m->csr_vals, m->N, m->lgx1));
+  return upload_side_arrays(m, n_cells, labels, library, label_mask);
+}
+
 static int dataset_upload_impl(smx_model* m, const void* X, bool u16, int64_t n_cells, const float* const* labels,
                                const float* library, const uint8_t* label_mask, int64_t cell_id_base) {
   SMX_REQUIRE(m && X && n_cells > 0, "bad dataset");
@@ -2271,6 +2357,7 @@ static int dataset_upload_impl(smx_model* m, const void* X, bool u16, int64_t n_
   SMX_HIP(hipStreamSynchronize(m->st));
   drop_graphs(m);
   auto fr = [](void* p) { if (p) hipFree(p); };
+  release_csr(m);
   fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1);
   m->X = nullptr; m->library = nullptr; m->mask = nullptr; m->lgx1 = nullptr;
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); m->Y[j] = nullptr; }
@@ -2290,27 +2377,14 @@ static int dataset_upload_impl(smx_model* m, const void* X, bool u16, int64_t n_
   }
   // per-row constant sum_g lgamma(x+1) of the likelihood, on the device (one wave per row)
   SMX_CHECK(launch_row_stats(m->st, m->X, m->x_u16 ? 1 : 0, m->Gp, m->N, m->G, m->lgx1, nullptr));
-  for (int j = 0; j < m->cfg.n_labels; ++j) {
-    const int P = m->cfg.label_dim[j], Pp = m->lab_Pp[j];
-    if ((rc = dmalloc(&m->Y[j], (size_t)n_cells * Pp))) return rc;
-    SMX_HIP(hipMemcpy2D(m->Y[j], (size_t)Pp * sizeof(float), labels[j], (size_t)P * sizeof(float), (size_t)P * sizeof(float),
-                        (size_t)n_cells, hipMemcpyHostToDevice));
-  }
-  if (library) {
-    if ((rc = dmalloc(&m->library, (size_t)n_cells * 2))) return rc;
-    SMX_HIP(hipMemcpy(m->library, library, (size_t)n_cells * 2 * sizeof(float), hipMemcpyHostToDevice));
-  }
-  if (label_mask) {
-    if ((rc = dmalloc(&m->mask, (size_t)n_cells))) return rc;
-    SMX_HIP(hipMemcpy(m->mask, label_mask, (size_t)n_cells, hipMemcpyHostToDevice));
-  }
-  return SMX_OK;
+  return upload_side_arrays(m, n_cells, labels, library, label_mask);
 }
 
 int64_t smx_dataset_size(const smx_model* m) { return m ? m->N : 0; }
 
 int smx_dataset_library(smx_model* m, float stats[2]) {
   SMX_REQUIRE(m && m->X && m->N > 0, "no resident dataset");
+  SMX_REQUIRE(!m->x_csr, "the resident-matrix kernels take a dense store (float32 / uint16), not the sparse one");
   SMX_HIP(hipStreamSynchronize(m->st));
   double* work = nullptr;   // [N] log counts + [2] moments
   int rc;
@@ -2332,6 +2406,7 @@ int smx_dataset_library(smx_model* m, float stats[2]) {
 
 int smx_dataset_corrupt(smx_model* m, double dropout, double retain_rate, uint64_t seed, int64_t* n_corrupted) {
   SMX_REQUIRE(m && m->X && m->N > 0, "no resident dataset");
+  SMX_REQUIRE(!m->x_csr, "the resident-matrix kernels take a dense store (float32 / uint16), not the sparse one");
   SMX_REQUIRE(dropout >= 0.0 && dropout < 1.0, "dropout value must be >= 0 and < 1");   // utils.py:184-185
   SMX_REQUIRE(retain_rate >= 0.0 && retain_rate <= 1.0, "retain_rate must be in [0, 1]");
   if (n_corrupted) *n_corrupted = 0;
@@ -2388,7 +2463,15 @@ int smx_dataset_read(smx_model* m, int64_t row0, int64_t n_rows, float* X, float
   SMX_REQUIRE(m && m->X, "no resident dataset");
   SMX_REQUIRE(row0 >= 0 && n_rows > 0 && row0 + n_rows <= m->N, "rows out of range");
   SMX_HIP(hipStreamSynchronize(m->st));
-  if (X && m->x_u16) {
+  if (X && m->x_csr) {   // the sparse store's rows, expanded a tile at a time
+    for (int64_t r = 0; r < n_rows; r += m->Bmax) {
+      const int B = (int)std::min<int64_t>(m->Bmax, n_rows - r);
+      SMX_CHECK(launch_csr_expand(m->st, m->csr_indptr, m->csr_cols, m->csr_vals, nullptr, (long)(row0 + r), B, m->Gp, m->xbatch));
+      SMX_HIP(hipMemcpy2DAsync(X + (size_t)r * m->G, (size_t)m->G * sizeof(float), m->xbatch, (size_t)m->Gp * sizeof(float),
+                               (size_t)m->G * sizeof(float), (size_t)B, hipMemcpyDeviceToHost, m->st));
+      SMX_HIP(hipStreamSynchronize(m->st));
+    }
+  } else if (X && m->x_u16) {
     std::vector<uint16_t> tmp((size_t)n_rows * m->G);
     SMX_HIP(hipMemcpy2D(tmp.data(), (size_t)m->G * sizeof(uint16_t), reinterpret_cast<const uint16_t*>(m->X) + (size_t)row0 * m->Gp,
                         (size_t)m->Gp * sizeof(uint16_t), (size_t)m->G * sizeof(uint16_t), (size_t)n_rows, hipMemcpyDeviceToHost));
@@ -2438,7 +2521,8 @@ static int setup_pass(smx_model* m, Pass& ps, const int32_t* row_ids, const floa
   if (row_ids) {
     SMX_CHECK(check_rows(m, row_ids, (size_t)batch));
     SMX_HIP(hipMemcpyAsync(cur_rows(m), row_ids, (size_t)batch * sizeof(int32_t), hipMemcpyHostToDevice, m->st));
-    ps.rows = cur_rows(m); ps.Xsrc = m->X; ps.x_u16 = m->x_u16; ps.lib = m->library; ps.lgx1 = m->lgx1; ps.cell_base = (uint32_t)m->cell_base;
+    ps.rows = cur_rows(m); ps.xrows = ps.rows; ps.Xsrc = m->X; ps.x_u16 = m->x_u16; ps.lib = m->library; ps.lgx1 = m->lgx1; ps.cell_base = (uint32_t)m->cell_base;
+    SMX_CHECK(csr_stage(m, ps));
   } else {
     SMX_REQUIRE(host_x, "need row_ids or host_x");
     SMX_REQUIRE(!m->scvi || host_library, "scvi needs host_library with host_x");
@@ -2716,7 +2800,7 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
     if (rc != SMX_OK) break;
     LossArgs lo;
     lo.likelihood = m->cfg.likelihood; lo.direct = m->scvi; lo.backward = 0;
-    lo.X = ps.Xsrc; lo.x_u16 = ps.x_u16; lo.ldx = m->Gp; lo.rows = ps.rows;
+    lo.X = ps.Xsrc; lo.x_u16 = ps.x_u16; lo.ldx = m->Gp; lo.rows = ps.xrows;
     lo.P = m->P; lo.ldp = (long)m->k * m->Gp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
     lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = 0.f;
     rc = launch_count_loss(m->st, lo);
@@ -2787,7 +2871,7 @@ int smx_score_llk(smx_model* m, const int32_t* row_ids, const float* host_x, con
         // j == 1: the count distribution under the zero-inflation wrapper (first two planes, no gate)
         lo.likelihood = (j == 0) ? lk : (lk == SMX_LLK_ZINB ? SMX_LLK_NB : SMX_LLK_NBD);
         lo.direct = m->scvi; lo.backward = 0;
-        lo.X = own ? ps.Xsrc : tX + plane * t; lo.x_u16 = own ? ps.x_u16 : 0; lo.ldx = m->Gp; lo.rows = own ? ps.rows : nullptr;
+        lo.X = own ? ps.Xsrc : tX + plane * t; lo.x_u16 = own ? ps.x_u16 : 0; lo.ldx = m->Gp; lo.rows = own ? ps.xrows : nullptr;
         lo.P = m->P; lo.ldp = (long)m->k * m->Gp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
         lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = 0.f;
         rc = launch_count_loss(m->st, lo);

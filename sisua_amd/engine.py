@@ -151,9 +151,12 @@ class Engine:
   def upload(self, X, labels: Sequence[np.ndarray] = (), library=None, label_mask=None, cell_id_base: int = 0,
              storage: str = "f32"):
     """Make the cells x genes matrix resident in HBM.  storage='u16' keeps the counts as uint16 (half the bytes;
-    integer counts <= 65535 only), storage='f32' is the reference's dense float32 layout."""
-    if storage not in ("f32", "u16"):
-      raise ValueError("storage must be 'f32' or 'u16'")
+    integer counts <= 65535 only), storage='f32' is the reference's dense float32 layout, storage='csr' keeps the
+    non-zeros only (8 bytes each; X may also be a (indptr, indices, data) triple or a scipy.sparse CSR matrix)."""
+    if storage not in ("f32", "u16", "csr"):
+      raise ValueError("storage must be 'f32', 'u16' or 'csr'")
+    if storage == "csr":
+      return self._upload_csr(X, labels, library, label_mask, cell_id_base)
     if storage == "u16":
       Xf = np.asarray(X)
       if Xf.size and (Xf.min() < 0 or Xf.max() > 65535 or not np.array_equal(Xf, np.floor(Xf))):
@@ -176,6 +179,41 @@ class Engine:
                                             mask_ptr, int(cell_id_base)))
     else:
       check(self.lib.smx_dataset_upload(self._h, _fp(X), n, lab_ptrs, _fp(lib_arr), mask_ptr, int(cell_id_base)))
+    self.n_cells = n
+
+  def _upload_csr(self, X, labels, library, label_mask, cell_id_base):
+    G = self.cfg.n_genes
+    if isinstance(X, tuple) and len(X) == 3:
+      indptr, indices, data = X
+    elif hasattr(X, "tocsr"):   # scipy.sparse
+      if X.shape[1] != G:
+        raise ValueError(f"X must be [n_cells, {G}]")
+      X = X.tocsr()
+      X.sort_indices()
+      indptr, indices, data = X.indptr, X.indices, X.data
+    else:
+      Xd = _f32(X)
+      if Xd.ndim != 2 or Xd.shape[1] != G:
+        raise ValueError(f"X must be [n_cells, {G}]")
+      nz = Xd != 0
+      indptr = np.concatenate([[0], np.cumsum(nz.sum(1))])
+      indices = np.nonzero(nz)[1]
+      data = Xd[nz]
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    n = indptr.size - 1
+    if n < 1 or indptr[0] != 0 or indptr[-1] != indices.size or indices.size != data.size:
+      raise ValueError("inconsistent CSR arrays")
+    labs = [_f32(y, (n, P)) for y, (P, _) in zip(labels, self.cfg.labels)]
+    if len(labs) != len(self.cfg.labels):
+      raise ValueError("one label matrix per label head is required")
+    lab_ptrs = (C.POINTER(C.c_float) * max(1, len(labs)))(*[_fp(y) for y in labs]) if labs else None
+    lib_arr = None if library is None else _f32(library, (n, 2))
+    mask_arr = None if label_mask is None else np.ascontiguousarray(label_mask, dtype=np.uint8).reshape(n)
+    mask_ptr = None if mask_arr is None else mask_arr.ctypes.data_as(C.POINTER(C.c_uint8))
+    check(self.lib.smx_dataset_upload_csr(self._h, indptr.ctypes.data_as(C.POINTER(C.c_int64)), indices.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          _fp(data), n, lab_ptrs, _fp(lib_arr), mask_ptr, int(cell_id_base)))
     self.n_cells = n
 
   # ---- steps -----------------------------------------------------------------------

@@ -145,3 +145,72 @@ def test_u16_store_rejects_what_it_cannot_hold(Engine):
   with pytest.raises(ValueError):
     e.upload(x, storage="bf16")
   e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,likelihood,graph", [("vae", "zinb", False), ("vae", "nb", True), ("scvi", "zinbd", False), ("sisua", "zinb", False)])
+def test_csr_store_is_bit_identical_to_f32(Engine, model, likelihood, graph):
+  """SURVEY 8f-2 compact count format, sparse: the CSR resident store (non-zeros only; every pass expands its
+  minibatch's rows into a dense tile first) must give exactly the float32 results -- training trajectory, parameters,
+  evaluation, forward pass, scoring, and the rows read back; the resident-matrix kernels refuse it."""
+  x = synth_counts(400, 203, sparsity=0.9, seed=9, max_count=60000)
+  x[7] = 0.0                                   # an empty row
+  kw = dict(model=model, n_genes=203, likelihood=likelihood, enc_units=(32,), dec_units=(32,), latent_dim=6)
+  ys, mask = [], None
+  if model == "scvi":
+    kw["encl_units"] = (16,)
+  if model == "sisua":
+    kw["labels"] = ((9, "nb"),)
+    ys = [np.random.default_rng(3).poisson(3.0, size=(len(x), 9)).astype(np.float32)]
+    mask = (np.arange(len(x)) % 3 == 0)
+  spec, cfg = make_pair(**kw)
+  _, lm, lv = so.library_size(x)
+  lib = np.tile(np.array([[lm, lv]], np.float32), (len(x), 1)) if model == "scvi" else None
+  outs = []
+  for storage in ("f32", "csr"):
+    e = Engine(cfg, max_batch=64)
+    e.upload(x, ys, library=lib, label_mask=mask, cell_id_base=11, storage=storage)
+    order = (np.arange(64 * 5) * 7 % len(x)).astype(np.int32)
+    losses = [e.train_step(order[s * 64:(s + 1) * 64], graph=graph)["loss"] for s in range(5)]
+    losses += [e.train_steps(order[:128], 2, 64, graph=graph, metrics=True)["loss"], e.train_step(order[:50])["loss"]]
+    rows = np.arange(40, dtype=np.int32)
+    ev = e.eval_step(rows)["loss"]
+    fw = e.forward(row_ids=rows)
+    mllk, _ = e.marginal_llk(row_ids=rows, n_samples=3)
+    X, rc = e.dataset_read(library=False)
+    outs.append((losses, e.get_params(), ev, fw["x_params"], fw["z_mean"], mllk, X, rc))
+    if storage == "csr":
+      for fn in (lambda: e.dataset_corrupt(0.3, 0.4, 5), e.dataset_library):
+        with pytest.raises(Exception):
+          fn()
+    e.close()
+  a, b = outs
+  assert a[0] == b[0] and a[2] == b[2]
+  for k in a[1]:
+    assert np.array_equal(a[1][k], b[1][k]), k
+  for i in (3, 4, 5, 6):
+    assert np.array_equal(a[i], b[i]), i
+  assert np.allclose(a[7], b[7], rtol=1e-6) and np.array_equal(b[6], x)
+
+
+@pytest.mark.gpu
+def test_csr_store_takes_sparse_inputs_and_rejects_bad_ones(Engine):
+  import scipy.sparse as sp
+  x = synth_counts(60, 64, sparsity=0.85, seed=1)
+  _, e = _engine(Engine, x)
+  m = sp.csr_matrix(x)
+  for X in (m, (m.indptr, m.indices, m.data), sp.coo_matrix(x)):
+    e.upload(X, storage="csr")
+    got, _ = e.dataset_read(library=False)
+    assert np.array_equal(got, x)
+  bad_cols = m.indices.copy(); bad_cols[0] = 64
+  for X in ((m.indptr, bad_cols, m.data), (m.indptr[:-1], m.indices, m.data), (m.indptr[::-1].copy(), m.indices, m.data)):
+    with pytest.raises(Exception):
+      e.upload(X, storage="csr")
+  # input dropout is keyed by the dense store's rows: refused, not silently different
+  spec, cfg = make_pair(model="vae", n_genes=64, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=4, input_dropout=0.3)
+  e2 = Engine(cfg, max_batch=32)
+  e2.upload(x, storage="csr")
+  with pytest.raises(Exception):
+    e2.train_step(np.arange(32, dtype=np.int32))
+  e2.close(); e.close()
