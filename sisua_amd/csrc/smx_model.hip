@@ -2675,7 +2675,8 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
   for (int j = 0; j < m->n_heads; ++j)
     if (y_params && y_params[j]) { wy[j] = (size_t)m->lab_ky[j] * (size_t)m->cfg.label_dim[j]; per_cell += S * wy[j]; }
   SMX_REQUIRE(per_cell > 0, "no output requested");
-  const size_t cap_floats = (size_t)32 << 20;   // 128 MB
+  // 128 MB of staging (SMX_PREDICT_STAGE_FLOATS: tests force several chunks on small problems)
+  const size_t cap_floats = getenv("SMX_PREDICT_STAGE_FLOATS") ? (size_t)std::max(1L, atol(getenv("SMX_PREDICT_STAGE_FLOATS"))) : (size_t)32 << 20;
   size_t C = std::max<size_t>((size_t)batch, cap_floats / per_cell / (size_t)batch * (size_t)batch);   // whole batches per chunk
   C = std::min(C, (N + (size_t)batch - 1) / (size_t)batch * (size_t)batch);
   if (C * per_cell > m->pred_floats) {

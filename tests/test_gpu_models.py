@@ -110,6 +110,17 @@ def test_fit_predict(api, name):
       qZ0 = qZ[0] if isinstance(qZ, (tuple, list)) else qZ
       assert np.array_equal(pX0.mean(), Xa0.mean()[..., i:i + 16, :])
       assert np.array_equal(qZ0.mean(), Za0.mean()[i:i + 16])
+  # ... and when the result leaves the device in several chunks (staging forced small: 16 cells per chunk)
+  os.environ["SMX_PREDICT_STAGE_FLOATS"] = "20000"
+  try:
+    Xb, Zb = model.predict(xs, sample_shape=2, batch_size=16, verbose=False)
+  finally:
+    del os.environ["SMX_PREDICT_STAGE_FLOATS"]
+  Xb0 = Xb[0] if isinstance(Xb, tuple) else Xb
+  Zb0 = Zb[0] if isinstance(Zb, (tuple, list)) else Zb
+  assert np.array_equal(Xb0.mean(), Xa0.mean()) and np.array_equal(Zb0.mean(), Za0.mean())
+  if isinstance(Xb, tuple):
+    assert np.array_equal(Xb[1].mean(), Xa[1].mean())
   # encode / decode round trip agrees with __call__
   q = model.encode(test.numpy()[:16])
   q0 = q[0] if isinstance(q, list) else q
