@@ -30,14 +30,17 @@ namespace smx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // EPI: 1 likelihood epilogue (the training kernel); 0 product only -- stores P instead of dP, reads no counts
-// (what the standalone product kernel does; used to attribute the fused kernel's time to the likelihood).
+// (what the standalone product kernel does; used to attribute the fused kernel's time to the likelihood);
+// 2 likelihood values only (scoring over stacked posterior draws: no gradient, no stores but the partial sums).
 // NW waves per workgroup split every 128-deep slab of K: lane (i, h) of wave q supplies k = q KS + (KS/2) h + s in
 // MFMA step s (KS = 128 / NW) and finishes accumulator registers q RPW .. q RPW + RPW - 1 (RPW = 16 / NW).
-template <int LK, int U16, int EPI, int NW>
+// SLAB: depth of K a workgroup takes per round of loads (128 in training; the scoring form with 1 / 2 waves per
+// workgroup uses 32 / 64 so that a lane still holds 16 k-steps of operands).
+template <int LK, int U16, int EPI, int NW, int SLAB = 128>
 __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) {
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
-  constexpr int KS = 128 / NW, KH = KS / 2, RPW = 16 / NW;
-  __shared__ float red[NW * 1024];   // ONE plane's NW partial tiles at a time (32 KB at 8 waves: two workgroups per CU)
+  constexpr int KS = SLAB / NW, KH = KS / 2, RPW = 16 / NW;
+  __shared__ float red[NW > 1 ? NW * 1024 : 1];   // ONE plane's NW partial tiles at a time (32 KB at 8 waves: two workgroups per CU)
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   // blocks b, b + 8, b + 16, ... share an XCD: give them the cell tiles of ONE gene tile
@@ -56,7 +59,8 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
   long src[RPW];
 #pragma unroll
   for (int j = 0; j < RPW; ++j) {
-    const int cell = min(rowof[j], a.B - 1);
+    int cell = min(rowof[j], a.B - 1);
+    if (EPI == 2) cell %= a.row_mod;
     src[j] = (EPI && a.rows) ? a.rows[cell] : cell;
   }
   float bias[NP];
@@ -75,11 +79,17 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
   // right before the MFMA that uses it: ~30 serial L2 / HBM round trips, 9.8 us for the product alone)
   auto load_slab = [&](int kc) {
     const int k0 = kc + KS * q + KH * h;          // first k of this lane half in this slab
-    const float* ap = a.H + (long)arow * a.ldh + k0;
+    if (EPI == 2) {   // k-major H (smx_score.hip): lanes i = 32 consecutive rows of one k, as for W
+      const float* ap = a.H + (long)k0 * a.ldh + arow;
 #pragma unroll
-    for (int v = 0; v < KH / 4; ++v) {
-      const float4 t = *reinterpret_cast<const float4*>(ap + 4 * v);
-      av[4 * v] = t.x; av[4 * v + 1] = t.y; av[4 * v + 2] = t.z; av[4 * v + 3] = t.w;
+      for (int s = 0; s < KH; ++s) av[s] = ap[(long)s * a.ldh];
+    } else {
+      const float* ap = a.H + (long)arow * a.ldh + k0;
+#pragma unroll
+      for (int v = 0; v < KH / 4; ++v) {
+        const float4 t = *reinterpret_cast<const float4*>(ap + 4 * v);
+        av[4 * v] = t.x; av[4 * v + 1] = t.y; av[4 * v + 2] = t.z; av[4 * v + 3] = t.w;
+      }
     }
     const float* wp = a.W + (long)k0 * a.ldw + col;
 #pragma unroll
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
   }
   __builtin_amdgcn_sched_barrier(0);
   if (active) mfma_slab();
-  for (int kc = 128; kc + KS * q < a.Hp; kc += 128) {
+  for (int kc = SLAB; kc + KS * q < a.Hp; kc += SLAB) {
     load_slab(kc);
     __builtin_amdgcn_sched_barrier(0);
     mfma_slab();
@@ -112,8 +122,14 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
 
   // ---- the NW partial tiles meet in LDS, plane by plane; wave q finishes registers q RPW .. q RPW + RPW - 1 ---------
   float v[NP][RPW];
+  if (NW == 1) {
 #pragma unroll
-  for (int p = 0; p < NP; ++p) {
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) v[p][j] = acc[p][j] + bias[p];
+  }
+#pragma unroll
+  for (int p = 0; p < NP && NW > 1; ++p) {
     if (p) __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(q * 16 + r) * 64 + lane] = acc[p][r];
@@ -135,7 +151,13 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
     float p2[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) p2[j] = NP == 3 ? v[NP - 1][j] : 0.f;
-    count_elem_vec<LK, 0, RPW>(xs, v[0], v[1], p2, llk, d0, d1, d2);
+    constexpr int CH = RPW > 4 ? 4 : RPW;   // interleaved chains at a time (all 16 of a one-wave workgroup would spill)
+#pragma unroll
+    for (int c = 0; c < RPW; c += CH) {
+      typedef float Vec[CH];
+      count_elem_vec<LK, 0, CH>(*(const Vec*)(xs + c), *(const Vec*)(v[0] + c), *(const Vec*)(v[1] + c), *(const Vec*)(p2 + c),
+                                *(Vec*)(llk + c), *(Vec*)(d0 + c), *(Vec*)(d1 + c), *(Vec*)(d2 + c));
+    }
   }
 #pragma unroll
   for (int j = 0; j < RPW; ++j) {
@@ -144,7 +166,7 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
     float d[3];
     if (EPI) { d[0] = ok ? d0[j] * a.grad_scale : 0.f; d[1] = ok ? d1[j] * a.grad_scale : 0.f; d[2] = ok ? d2[j] * a.grad_scale : 0.f; }
     else { d[0] = v[0][j]; d[1] = v[1][j]; d[2] = NP == 3 ? v[NP - 1][j] : 0.f; }
-    if (cell < a.B) {
+    if (EPI != 2 && cell < a.B) {
       float* dp = a.dP + (long)cell * a.ldp + col;
 #pragma unroll
       for (int p = 0; p < NP; ++p) dp[(long)p * a.plane_stride] = d[p];
@@ -179,6 +201,26 @@ static void launch_hl_w(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
 }
 template <int LK>
 static void launch_hl(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
+  if (a.llk_only) {
+    // waves per workgroup = ways K is split (measured at 128 cells x 1000 draws, 8 000 genes: 1 / 2 / 4 / 8 waves
+    // 3.45 / 3.28 / 3.42 / 3.84 ms: with hundreds of cell tiles the chip is full without the split, and every wave
+    // less means fewer partial tiles through LDS)
+    static const int lw = getenv("SMX_SCORE_HEAD_WAVES") ? atoi(getenv("SMX_SCORE_HEAD_WAVES")) : 2;
+    if (lw == 4) {
+      if (a.x_u16) hipLaunchKernelGGL((out_head_loss_kernel<LK, 1, 2, 4>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 2, 4>), grid, dim3(256), 0, st, a);
+    } else if (lw == 2) {
+      if (a.x_u16) hipLaunchKernelGGL((out_head_loss_kernel<LK, 1, 2, 2, 64>), grid, dim3(128), 0, st, a);
+      else hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 2, 2, 64>), grid, dim3(128), 0, st, a);
+    } else if (lw == 1) {
+      if (a.x_u16) hipLaunchKernelGGL((out_head_loss_kernel<LK, 1, 2, 1, 32>), grid, dim3(64), 0, st, a);
+      else hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 2, 1, 32>), grid, dim3(64), 0, st, a);
+    } else {
+      if (a.x_u16) hipLaunchKernelGGL((out_head_loss_kernel<LK, 1, 2, 8>), grid, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 2, 8>), grid, dim3(512), 0, st, a);
+    }
+    return;
+  }
   if (head_waves() == 4) launch_hl_w<LK, 4>(st, a, grid);
   else if (head_waves() == 16) launch_hl_w<LK, 16>(st, a, grid);
   else launch_hl_w<LK, 8>(st, a, grid);
@@ -186,7 +228,8 @@ static void launch_hl(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
 
 int launch_out_head_loss(hipStream_t st, const HeadLossArgs& a_in) {
   HeadLossArgs a = a_in;
-  if (!head_loss_supported(a.B, a.Hp, a.Gp) || (a.ldh % 4) || !a.H || !a.W || !a.bias || !a.dP || (!a.product_only && (!a.X || !a.llk_part))) {
+  if (!head_loss_supported(a.B, a.Hp, a.Gp) || (!a.llk_only && (a.ldh % 4)) || (a.llk_only && a.ldh < a.B) || !a.H || !a.W || !a.bias || (!a.dP && !a.llk_only) || (!a.product_only && (!a.X || !a.llk_part)) ||
+      (a.llk_only && (a.product_only || a.row_mod <= 0))) {
     set_error("out_head_loss: bad shapes");
     return SMX_ERR_INVALID;
   }

@@ -426,11 +426,42 @@ struct HeadLossArgs {
   int B = 0, G = 0, Gp = 0, Hp = 0, likelihood = 0;
   float grad_scale = 1.f;
   int product_only = 0;                           // timing variant: the product alone, P stored
+  // scoring (smx_marginal_llk, stacked draws): likelihood partials only, nothing else stored; row r of H is draw
+  // r / row_mod of cell r % row_mod, whose counts are row (r % row_mod) of X / rows; H is then K-MAJOR ([Hp][ldh], row r
+  // of the stacked batch in column r)
+  int llk_only = 0, row_mod = 0;
   int n_ct = 0, n_gt = 0;                         // set by the launcher
 };
 bool head_loss_supported(int B, int Hp, int Gp);
 int head_loss_chunks(int Gp);
 int launch_out_head_loss(hipStream_t st, const HeadLossArgs& a);
+
+// ---- importance-weighted log p(x) over stacked posterior draws (smx_score.hip) ------------------
+#define SMX_SCORE_MAX_DRAWS 1024   // draws per stacked pass (chunks of them fold into the running log-sum-exp)
+struct ScoreDrawArgs {
+  const float* lat = nullptr; int ld = 0;   // [B][2 * Dp] (mu | s_raw)
+  int B = 0, D = 0, Dp = 0, S = 0, s0 = 0;  // S draws starting at sample index s0
+  NoiseKey nk{0, 0, 0, 0, nullptr};         // stream word without the sample index
+  const int32_t* rows = nullptr; uint32_t cell_base = 0;
+  float* z = nullptr;                       // [S * B][Dp]
+  float* lw = nullptr;                      // [S * B]: log N(z; 0, I) - log q(z | x)
+};
+int launch_score_draws(hipStream_t st, const ScoreDrawArgs& a);
+struct ScoreBnArgs {
+  float* h = nullptr; long R = 0; int H = 0, Hp = 0;
+  const float* gamma = nullptr; const float* beta = nullptr; const float* moving_mean = nullptr; const float* moving_var = nullptr;
+  float eps = 1e-3f, leak = 0.f;
+  float* out_t = nullptr; long ldt = 0;   // non-null: write the result transposed, out_t [Hp][ldt] (gamma may then be null: plain transpose)
+};
+int launch_score_bn_act(hipStream_t st, const ScoreBnArgs& a);
+struct IwStackArgs {
+  const float* llk_part = nullptr; int n_chunks = 0;   // [S * B][n_chunks]
+  const float* lw = nullptr;                            // [S * B]
+  const float* lgx1 = nullptr; const int32_t* rows = nullptr;
+  float* run_max = nullptr; float* run_sum = nullptr; float* llk_sum = nullptr;   // [B]
+  int B = 0, S = 0, first = 1;
+};
+int launch_iw_stack(hipStream_t st, const IwStackArgs& a);
 
 // ---- both backward products of the output head in one launch (smx_headbwd.hip) ------------------
 struct HeadBwdArgs {

@@ -254,6 +254,7 @@ struct smx_model {
     int twin = getenv("SMX_NO_TWIN") ? 0 : 1;              // scvi: first layers of both encoders (and pairs of heads) side by side in one launch
     int act_epilogue = getenv("SMX_NO_ACT_EPILOGUE") ? 0 : 1;  // layers without BatchNorm / dropout: bias + activation (and its derivative) in the products' store paths
     int label_ride = getenv("SMX_NO_LABEL_RIDE") ? 0 : 1;  // label heads' backward inside the output head's backward launch + the final grouped launch
+    int stacked_scoring = getenv("SMX_NO_STACKED_SCORING") ? 0 : 1;  // marginal_llk: all posterior draws as rows of ONE decoder pass
   } flags;
   int chunk_first_head = 0;           // first optimiser chunk of the output / label heads (they are last in the table)
   int chunk_first_label = 0;          // first optimiser chunk of the label heads (n_chunks without label heads)
@@ -266,6 +267,7 @@ struct smx_model {
   int64_t* csr_indptr = nullptr; int32_t* csr_cols = nullptr; float* csr_vals = nullptr; bool x_csr = false;
   float* xbatch = nullptr;   // [Bmax][Gp]
   float* pred_stage = nullptr; size_t pred_floats = 0;   // device staging of smx_predict (one chunk of cells, laid out like the caller's arrays)
+  float* score_buf = nullptr; size_t score_floats = 0;   // smx_marginal_llk, stacked draws: z | lw | two activation buffers | likelihood partials
   float* pinned = nullptr; size_t pinned_floats = 0;   // host staging for the parameter planes handed back by smx_forward / smx_decode
   // sum-of-squares slots written by the weight-gradient products (per-tensor clipnorm without a separate pass)
   float* sq_slots = nullptr; std::vector<int> sq_first, sq_count; std::vector<char> sq_reduced; int sq_total_first = 0;   // this step's output head ran as the fused kernel (smx_head.hip)
@@ -2186,6 +2188,7 @@ int smx_model_destroy(smx_model* m) {
   fr(m->chunks); fr(m->partial); fr(m->tensor_norm); fr(m->sq_slots);
   if (m->pinned) hipHostFree(m->pinned);
   if (m->pred_stage) hipFree(m->pred_stage);
+  if (m->score_buf) hipFree(m->score_buf);
   for (auto& kv : m->injected) fr(kv.second.d);
   if (m->st_comm) { hipStreamSynchronize(m->st_comm); hipStreamDestroy(m->st_comm); }
   if (m->ev_c1) hipEventDestroy(m->ev_c1);
@@ -2787,15 +2790,93 @@ int smx_decode(smx_model* m, const float* z, const float* l, int32_t batch, floa
   return SMX_OK;
 }
 
+// Stacked form (smx_score.hip): the encoder runs once, then the S draws of the B cells go through the decoder and the
+// fused output head as S * B rows at a time.  Models whose draws are more than z = mu + sigma eps (scvi's library
+// latent and softmax head, SCALE's mixture prior) and deterministic latents keep the draw-by-draw loop.
+static bool stacked_scoring_ok(const smx_model* m) {
+  if (!m->flags.stacked_scoring || m->scvi || m->scale || !m->stochastic || m->use_injected || m->dec.empty()) return false;
+  if (!head_loss_supported(1, m->dec.back().out_p, m->Gp) || (m->dec.back().out_p % 4)) return false;
+  for (const MlpLayer& L : m->dec)
+    if ((L.in_p % 4) || (L.out_p % 32)) return false;
+  return m->dec[0].in_p == m->Dp;
+}
+
+static int marginal_llk_stacked(smx_model* m, const Pass& ps, int n_samples, float* run) {
+  const int B = ps.B, n_gt = head_loss_chunks(m->Gp);
+  int Hmax = 0;
+  for (const MlpLayer& L : m->dec) Hmax = std::max(Hmax, L.out_p);
+  // rows per stacked pass: whole draws, up to 16 384 rows (SMX_SCORE_ROWS: the tests force several chunks)
+  const long cap_rows = getenv("SMX_SCORE_ROWS") ? std::max(1L, atol(getenv("SMX_SCORE_ROWS"))) : 16384L;
+  const int Sc = (int)std::min<long>(std::min<long>(n_samples, SMX_SCORE_MAX_DRAWS), std::max<long>(1, cap_rows / B));
+  const size_t R = (size_t)Sc * B;
+  const size_t need = R * ((size_t)m->Dp + 1 + 3 * (size_t)Hmax + (size_t)n_gt);
+  if (need > m->score_floats) {
+    if (m->score_buf) hipFree(m->score_buf);
+    m->score_buf = nullptr; m->score_floats = 0;
+    SMX_CHECK(dmalloc(&m->score_buf, need));
+    m->score_floats = need;
+  }
+  float* z = m->score_buf;
+  float* lw = z + R * m->Dp;
+  float* hb[2] = {lw + R, lw + R + R * Hmax};
+  float* ht = hb[1] + R * Hmax;          // the last layer's output, k-major [Hp][R]
+  float* part = ht + R * Hmax;
+  // the encoder and the latent head (this pass also decodes draw 0 at batch size; its results are not used)
+  SMX_CHECK(forward_pass(m, ps, false, false, 0));
+  for (int s0 = 0; s0 < n_samples; s0 += Sc) {
+    const int S = std::min(Sc, n_samples - s0);
+    const long rows = (long)S * B;
+    ScoreDrawArgs d;
+    d.lat = m->latbuf; d.ld = 2 * m->Dp; d.B = B; d.D = m->D; d.Dp = m->Dp; d.S = S; d.s0 = s0;
+    d.nk = make_key(m, ST_EPS_Z, 0, false); d.rows = ps.rows; d.cell_base = ps.cell_base; d.z = z; d.lw = lw;
+    SMX_CHECK(launch_score_draws(m->st, d));
+    const float* in = z;
+    int ld = m->Dp;
+    for (size_t i = 0; i < m->dec.size(); ++i) {
+      MlpLayer& L = m->dec[i];
+      GemmArgs g;
+      g.A = in; g.lda = ld; g.B = P_(m, L.tW); g.ldb = m->tensors[L.tW].ld;
+      g.M = (int)rows; g.N = L.out_p; g.K = L.in_p; g.C = hb[i & 1]; g.ldc = L.out_p; g.split_k = 1;
+      if (L.bn < 0) { g.bias = P_(m, L.tBias); g.act = 1; g.leak = L.leak; }
+      SMX_CHECK(launch_gemm(m->st, g));
+      const bool last = (i + 1 == m->dec.size());
+      if (L.bn >= 0 || last) {
+        ScoreBnArgs b;
+        b.h = hb[i & 1]; b.R = rows; b.H = L.out; b.Hp = L.out_p; b.eps = m->cfg.bn_eps; b.leak = L.leak;
+        if (L.bn >= 0) {
+          b.gamma = P_(m, L.tGamma); b.beta = P_(m, L.tBeta);
+          b.moving_mean = m->bn_moving + m->bn_off[L.bn]; b.moving_var = b.moving_mean + L.out_p;
+        }
+        if (last) { b.out_t = ht; b.ldt = rows; }
+        SMX_CHECK(launch_score_bn_act(m->st, b));
+      }
+      in = hb[i & 1]; ld = L.out_p;
+    }
+    HeadLossArgs hl;
+    hl.H = ht; hl.ldh = (int)rows; hl.W = P_(m, m->t_outW[0]); hl.ldw = m->tensors[m->t_outW[0]].ld; hl.bias = P_(m, m->t_outb[0]);
+    hl.X = ps.Xsrc; hl.x_u16 = ps.x_u16; hl.ldx = m->Gp; hl.rows = ps.xrows; hl.llk_part = part;
+    hl.B = (int)rows; hl.G = m->G; hl.Gp = m->Gp; hl.Hp = m->dec.back().out_p; hl.likelihood = m->cfg.likelihood; hl.grad_scale = 0.f;
+    hl.llk_only = 1; hl.row_mod = B;
+    SMX_CHECK(launch_out_head_loss(m->st, hl));
+    IwStackArgs w;
+    w.llk_part = part; w.n_chunks = n_gt; w.lw = lw; w.lgx1 = ps.lgx1; w.rows = ps.rows;
+    w.run_max = run; w.run_sum = run + B; w.llk_sum = run + 2 * B; w.B = B; w.S = S; w.first = (s0 == 0);
+    SMX_CHECK(launch_iw_stack(m->st, w));
+  }
+  return SMX_OK;
+}
+
 int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,
                      int32_t n_samples, float* mllk, float* llk_mean) {
   SMX_REQUIRE(m && mllk && n_samples > 0, "bad arguments");
   Pass ps;
   SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, 0, 0));
+  const bool stacked = stacked_scoring_ok(m);
   float* run = nullptr;   // [3][B]: running max, running sum, sum of log p(x|z)
   SMX_CHECK(dmalloc(&run, (size_t)3 * batch));
   int rc = SMX_OK;
-  for (int s = 0; s < n_samples && rc == SMX_OK; ++s) {
+  if (stacked) rc = marginal_llk_stacked(m, ps, n_samples, run);
+  for (int s = 0; !stacked && s < n_samples && rc == SMX_OK; ++s) {
     ps.sample = s;
     rc = forward_pass(m, ps, false, false, s == 0 ? 0 : 2);
     if (rc != SMX_OK) break;
@@ -3052,8 +3133,9 @@ int smx_set_flag(smx_model* m, const char* name, int value) {
   const std::string n(name);
   int* f = n == "head_loss" ? &m->flags.head_loss : n == "front" ? &m->flags.front : n == "bwd_front" ? &m->flags.bwd_front
          : n == "head_bwd" ? &m->flags.head_bwd : n == "wgrad" ? &m->flags.wgrad : n == "scvi_fused" ? &m->flags.scvi_fused
-         : n == "twin" ? &m->flags.twin : n == "label_ride" ? &m->flags.label_ride : n == "act_epilogue" ? &m->flags.act_epilogue : nullptr;
-  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue)");
+         : n == "twin" ? &m->flags.twin : n == "label_ride" ? &m->flags.label_ride : n == "act_epilogue" ? &m->flags.act_epilogue
+         : n == "stacked_scoring" ? &m->flags.stacked_scoring : nullptr;
+  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue, stacked_scoring)");
   *f = value ? 1 : 0;
   drop_graphs(m);   // a captured step bakes the launch sequence in
   return SMX_OK;

@@ -446,7 +446,8 @@ class Engine:
     check(lib.smx_comm_init_local(arr, len(engines)))
 
   def set_flag(self, name: str, value: bool):
-    """Code-path switch of the training step (smx_set_flag): head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue."""
+    """Code-path switch (smx_set_flag).  Training step: head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride,
+    act_epilogue; scoring: stacked_scoring."""
     check(self.lib.smx_set_flag(self._h, name.encode(), int(bool(value))))
 
   # ---- measurement ----------------------------------------------------------------------

@@ -595,8 +595,10 @@ class SingleCellModel:
   def marginal_log_prob(self, inputs=None, library=None, mask=None, sample_shape=100, batch_size=128, **kwargs):
     r"""Importance-weighted estimate of log p(x) with `sample_shape` posterior draws
     (Posterior.cal_marginal_llk, analysis/posterior.py:941-976), computed on the GPU
-    (`smx_marginal_llk`: encoder once, then per draw decoder + forward-only likelihood kernel with a
-    running log-sum-exp).  Returns (mllk[B], {output name: mean_s log p(x|z_s) [B]})."""
+    (`smx_marginal_llk`: encoder once; the draws of a batch then go through the decoder and the output head --
+    fused with the forward-only likelihood -- stacked as rows of one pass, up to 16 384 rows at a time, with a running
+    log-sum-exp across passes; scvi / SCALE / deterministic latents decode draw by draw).
+    Returns (mllk[B], {output name: mean_s log p(x|z_s) [B]})."""
     arrs = _flatten(inputs)
     x = np.ascontiguousarray(arrs[0], dtype=np.float32)
     S = int(np.prod(sample_shape)) if np.size(sample_shape) else 1

@@ -1,6 +1,8 @@
 """Whole-step parity: forward, ELBO, every gradient, Adam update and BN moving
 statistics of the HIP path against the float64 oracle on the same seeded inputs;
 tolerance 1e-4 relative (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -470,7 +472,38 @@ def test_marginal_llk_matches_oracle(Engine, name):
   assert np.allclose(got_m2, ref_m2, rtol=RTOL, atol=1e-3)
   one, _ = e.marginal_llk(row_ids=rows, n_samples=1)
   assert np.isfinite(one).all()
+  # the stacked form (all draws as rows of one decoder pass; VAE-family models) and the draw-by-draw form see the same
+  # draws: both match the oracle and each other; several stacked passes fold into the same running log-sum-exp
+  e.set_flag("stacked_scoring", False)
+  loop_m, loop_l = e.marginal_llk(row_ids=rows, n_samples=S)
+  e.set_flag("stacked_scoring", True)
+  assert np.allclose(loop_m, ref_m, rtol=RTOL, atol=1e-3) and np.allclose(loop_l, ref_l, rtol=RTOL, atol=1e-3)
+  assert np.allclose(loop_m, got_m, rtol=1e-5, atol=1e-3)
+  os.environ["SMX_SCORE_ROWS"] = "250"   # 5 draws of the 50 cells per pass: 5 + 5 + 2
+  try:
+    ch_m, ch_l = e.marginal_llk(row_ids=rows, n_samples=S)
+  finally:
+    del os.environ["SMX_SCORE_ROWS"]
+  assert np.allclose(ch_m, got_m, rtol=1e-5, atol=1e-3) and np.allclose(ch_l, got_l, rtol=1e-5, atol=1e-3)
   e.close()
+
+
+def test_marginal_llk_stacked_two_layer_decoder_and_compact_store(Engine):
+  """Stacked scoring through a two-layer decoder, the uint16 and the sparse store, 100 draws (posterior.py:964)."""
+  spec, cfg, x, ys, lib, mask = _problem(dict(CASES["vae_zinb"], labels=(), dec_units=(40, 56)))
+  params = perturbed_params(spec)
+  bn = so.init_bn_state(spec)
+  rows = np.arange(3, 40, dtype=np.int32)
+  S = 100
+  ref_m, ref_l = so.marginal_log_prob(spec, params, bn, x[rows], rows, S, library=lib[rows])
+  for storage in ("f32", "u16", "csr"):
+    e = Engine(cfg, max_batch=64, init=False)
+    e.set_params(params)
+    e.upload(x, ys, lib, mask, storage=storage)
+    got_m, got_l = e.marginal_llk(row_ids=rows, n_samples=S)
+    assert np.allclose(got_m, ref_m, rtol=RTOL, atol=1e-3), (storage, np.abs(got_m - ref_m).max())
+    assert np.allclose(got_l, ref_l, rtol=RTOL, atol=1e-3), storage
+    e.close()
 
 
 @pytest.mark.parametrize("name", ["vae_zinb", "vae_nbd", "vae_zinbd", "scvi_zinbd", "scvi_nbd", "dca_zinb"])

@@ -19,8 +19,12 @@ def timed(f, reps):
   e.synchronize()
   return (time.perf_counter() - t) / reps
 
-t = timed(lambda: e.marginal_llk(row_ids=rows, n_samples=100), 5)
-print(f"marginal_llk: {batch} cells x 100 draws: {t * 1e3:.2f} ms -> {batch / t:.0f} cells/s")
+for stacked in (False, True):
+  e.set_flag("stacked_scoring", stacked)
+  for draws in (100, 1000):
+    t = timed(lambda: e.marginal_llk(row_ids=rows, n_samples=draws), 5)
+    print(f"marginal_llk ({'stacked draws' if stacked else 'one decoder pass per draw'}): {batch} cells x {draws} draws: {t * 1e3:.2f} ms "
+          f"-> {batch / t:.0f} cells/s, {batch * draws / t / 1e6:.2f} M draws/s")
 t = timed(lambda: e.score_llk([x_org, None], row_ids=rows, n_samples=10), 10)
 print(f"score_llk (2 targets x 2 distributions): {batch} cells x 10 draws: {t * 1e3:.2f} ms -> {batch / t:.0f} cells/s")
 t = timed(lambda: e.dataset_library(), 20)
