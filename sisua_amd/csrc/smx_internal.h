@@ -452,8 +452,26 @@ struct ScoreBnArgs {
   const float* gamma = nullptr; const float* beta = nullptr; const float* moving_mean = nullptr; const float* moving_var = nullptr;
   float eps = 1e-3f, leak = 0.f;
   float* out_t = nullptr; long ldt = 0;   // non-null: write the result transposed, out_t [Hp][ldt] (gamma may then be null: plain transpose)
+  __bf16* out3 = nullptr;                 // non-null: write the result as its three-way bf16 split [3][R][Hp] (gamma may be null)
 };
+struct ScoreSplitWArgs {
+  const float* W = nullptr; int ldw = 0, Gp = 0;   // [Hp][k * Gp]
+  int n_gt = 0, nslab = 0, NP = 0;                 // gene tiles of 32, slabs of 32 k, parameter planes
+  __bf16* img = nullptr;                           // [n_gt][nslab][3][NP][2][2][32][8]
+};
+int launch_score_split_w(hipStream_t st, const ScoreSplitWArgs& a);
 int launch_score_bn_act(hipStream_t st, const ScoreBnArgs& a);
+struct ScoreHeadArgs {
+  const __bf16* A3 = nullptr;                     // last decoder output as its three-way bf16 split [3][R][Hp]
+  const __bf16* Wimg = nullptr;                   // W as slab images (score_split_w_kernel)
+  const float* bias = nullptr;                    // [k * Gp]
+  const float* X = nullptr; int ldx = 0; const int32_t* rows = nullptr; int x_u16 = 0;   // counts of cell (row % row_mod)
+  float* llk_part = nullptr;                      // [R][Gp / 32]
+  int R = 0, row_mod = 0, G = 0, Gp = 0, Hp = 0, likelihood = 0;
+  int n_rb = 0, n_gt = 0, rb_group = 0, gt_per_xcd = 0;   // set by the launcher
+};
+bool score_head_supported(int Hp, int Gp);
+int launch_score_head(hipStream_t st, const ScoreHeadArgs& a);
 struct IwStackArgs {
   const float* llk_part = nullptr; int n_chunks = 0;   // [S * B][n_chunks]
   const float* lw = nullptr;                            // [S * B]

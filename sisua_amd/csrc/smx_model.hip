@@ -267,7 +267,8 @@ struct smx_model {
   int64_t* csr_indptr = nullptr; int32_t* csr_cols = nullptr; float* csr_vals = nullptr; bool x_csr = false;
   float* xbatch = nullptr;   // [Bmax][Gp]
   float* pred_stage = nullptr; size_t pred_floats = 0;   // device staging of smx_predict (one chunk of cells, laid out like the caller's arrays)
-  float* score_buf = nullptr; size_t score_floats = 0;   // smx_marginal_llk, stacked draws: z | lw | two activation buffers | likelihood partials
+  float* score_buf = nullptr; size_t score_floats = 0;   // smx_marginal_llk, stacked draws: z | lw | two activation buffers | last layer (k-major f32 or bf16 split) | likelihood partials
+  float* score_wimg = nullptr; size_t score_wimg_floats = 0;   // the output head's W as bf16 slab images (smx_score.hip)
   float* pinned = nullptr; size_t pinned_floats = 0;   // host staging for the parameter planes handed back by smx_forward / smx_decode
   // sum-of-squares slots written by the weight-gradient products (per-tensor clipnorm without a separate pass)
   float* sq_slots = nullptr; std::vector<int> sq_first, sq_count; std::vector<char> sq_reduced; int sq_total_first = 0;   // this step's output head ran as the fused kernel (smx_head.hip)
@@ -2189,6 +2190,7 @@ int smx_model_destroy(smx_model* m) {
   if (m->pinned) hipHostFree(m->pinned);
   if (m->pred_stage) hipFree(m->pred_stage);
   if (m->score_buf) hipFree(m->score_buf);
+  if (m->score_wimg) hipFree(m->score_wimg);
   for (auto& kv : m->injected) fr(kv.second.d);
   if (m->st_comm) { hipStreamSynchronize(m->st_comm); hipStreamDestroy(m->st_comm); }
   if (m->ev_c1) hipEventDestroy(m->ev_c1);
@@ -2809,7 +2811,7 @@ static int marginal_llk_stacked(smx_model* m, const Pass& ps, int n_samples, flo
   const long cap_rows = getenv("SMX_SCORE_ROWS") ? std::max(1L, atol(getenv("SMX_SCORE_ROWS"))) : 16384L;
   const int Sc = (int)std::min<long>(std::min<long>(n_samples, SMX_SCORE_MAX_DRAWS), std::max<long>(1, cap_rows / B));
   const size_t R = (size_t)Sc * B;
-  const size_t need = R * ((size_t)m->Dp + 1 + 3 * (size_t)Hmax + (size_t)n_gt);
+  const size_t need = R * ((size_t)m->Dp + 1 + 4 * (size_t)Hmax + (size_t)n_gt);
   if (need > m->score_floats) {
     if (m->score_buf) hipFree(m->score_buf);
     m->score_buf = nullptr; m->score_floats = 0;
@@ -2819,8 +2821,23 @@ static int marginal_llk_stacked(smx_model* m, const Pass& ps, int n_samples, flo
   float* z = m->score_buf;
   float* lw = z + R * m->Dp;
   float* hb[2] = {lw + R, lw + R + R * Hmax};
-  float* ht = hb[1] + R * Hmax;          // the last layer's output, k-major [Hp][R]
-  float* part = ht + R * Hmax;
+  float* ht = hb[1] + R * Hmax;          // the last layer's output: bf16 three-way split [3][R][Hp], or k-major f32 [Hp][R]
+  float* part = ht + 2 * R * Hmax;
+  const bool wide_head = getenv("SMX_SCORE_HEAD_WIDE") != nullptr || !score_head_supported(m->dec.back().out_p, m->Gp);   // the training kernel's direct-operand form (A/B)
+  const int NP = m->k, nslab = m->dec.back().out_p / 32;
+  if (!wide_head) {
+    const size_t wneed = ((size_t)n_gt * nslab * 3 * NP * 1024 + 1) / 2;   // bf16 elements as floats
+    if (wneed > m->score_wimg_floats) {
+      if (m->score_wimg) hipFree(m->score_wimg);
+      m->score_wimg = nullptr; m->score_wimg_floats = 0;
+      SMX_CHECK(dmalloc(&m->score_wimg, wneed));
+      m->score_wimg_floats = wneed;
+    }
+    ScoreSplitWArgs sw;
+    sw.W = P_(m, m->t_outW[0]); sw.ldw = m->tensors[m->t_outW[0]].ld; sw.Gp = m->Gp; sw.n_gt = n_gt; sw.nslab = nslab; sw.NP = NP;
+    sw.img = reinterpret_cast<__bf16*>(m->score_wimg);
+    SMX_CHECK(launch_score_split_w(m->st, sw));
+  }
   // the encoder and the latent head (this pass also decodes draw 0 at batch size; its results are not used)
   SMX_CHECK(forward_pass(m, ps, false, false, 0));
   for (int s0 = 0; s0 < n_samples; s0 += Sc) {
@@ -2847,17 +2864,26 @@ static int marginal_llk_stacked(smx_model* m, const Pass& ps, int n_samples, flo
           b.gamma = P_(m, L.tGamma); b.beta = P_(m, L.tBeta);
           b.moving_mean = m->bn_moving + m->bn_off[L.bn]; b.moving_var = b.moving_mean + L.out_p;
         }
-        if (last) { b.out_t = ht; b.ldt = rows; }
+        if (last && wide_head) { b.out_t = ht; b.ldt = rows; }
+        else if (last) b.out3 = reinterpret_cast<__bf16*>(ht);
         SMX_CHECK(launch_score_bn_act(m->st, b));
       }
       in = hb[i & 1]; ld = L.out_p;
     }
+    if (!wide_head) {
+      ScoreHeadArgs sh;
+      sh.A3 = reinterpret_cast<const __bf16*>(ht); sh.Wimg = reinterpret_cast<const __bf16*>(m->score_wimg); sh.bias = P_(m, m->t_outb[0]);
+      sh.X = ps.Xsrc; sh.x_u16 = ps.x_u16; sh.ldx = m->Gp; sh.rows = ps.xrows; sh.llk_part = part;
+      sh.R = (int)rows; sh.row_mod = B; sh.G = m->G; sh.Gp = m->Gp; sh.Hp = m->dec.back().out_p; sh.likelihood = m->cfg.likelihood;
+      SMX_CHECK(launch_score_head(m->st, sh));
+    } else {
     HeadLossArgs hl;
     hl.H = ht; hl.ldh = (int)rows; hl.W = P_(m, m->t_outW[0]); hl.ldw = m->tensors[m->t_outW[0]].ld; hl.bias = P_(m, m->t_outb[0]);
     hl.X = ps.Xsrc; hl.x_u16 = ps.x_u16; hl.ldx = m->Gp; hl.rows = ps.xrows; hl.llk_part = part;
     hl.B = (int)rows; hl.G = m->G; hl.Gp = m->Gp; hl.Hp = m->dec.back().out_p; hl.likelihood = m->cfg.likelihood; hl.grad_scale = 0.f;
     hl.llk_only = 1; hl.row_mod = B;
     SMX_CHECK(launch_out_head_loss(m->st, hl));
+    }
     IwStackArgs w;
     w.llk_part = part; w.n_chunks = n_gt; w.lw = lw; w.lgx1 = ps.lgx1; w.rows = ps.rows;
     w.run_max = run; w.run_sum = run + B; w.llk_sum = run + 2 * B; w.B = B; w.S = S; w.first = (s0 == 0);

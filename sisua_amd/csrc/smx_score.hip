@@ -10,8 +10,11 @@
 //                          only one partial sum per (row, 32 genes) is stored
 //   iw_stack_kernel        per cell: log w of its draws, log-sum-exp folded into the running (max, sum) pair
 // Same Philox counters as the draw-by-draw form (sample index in the stream word), so both see the same draws.
+#include <stdlib.h>
+
 #include "smx_internal.h"
 #include "smx_device.h"
+#include "smx_loss.h"
 
 namespace smx {
 
@@ -104,7 +107,18 @@ __global__ __launch_bounds__(256) void score_bn_act_t_kernel(ScoreBnArgs a) {
   }
 }
 
+__global__ void score_bn_act_split_kernel(ScoreBnArgs a);   // (below, beside the kernel that reads its output)
 int launch_score_bn_act(hipStream_t st, const ScoreBnArgs& a) {
+  if (a.out3) {
+    if (a.R <= 0 || a.Hp <= 0 || (a.Hp % 4) || !a.h || (a.gamma && (!a.beta || !a.moving_mean || !a.moving_var))) {
+      set_error("score_bn_act: bad arguments (split form)");
+      return SMX_ERR_INVALID;
+    }
+    const long total = a.R * (a.Hp >> 2);
+    hipLaunchKernelGGL(score_bn_act_split_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   if (a.out_t) {
     if (a.R <= 0 || a.Hp <= 0 || (a.Hp % 32) || !a.h || a.ldt < a.R || (a.gamma && (!a.beta || !a.moving_mean || !a.moving_var))) {
       set_error("score_bn_act: bad arguments (transposed form)");
@@ -122,6 +136,285 @@ int launch_score_bn_act(hipStream_t st, const ScoreBnArgs& a) {
   hipLaunchKernelGGL(score_bn_act_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Output head of a stacked pass: product + count log-likelihood, likelihood partials only.
+//
+// Two measured facts shape it (profiles/r02_scoring_path.txt, tools/coexec.hip):
+//  * the training kernel's direct-operand form (smx_headloss.hip, EPI = 2) and an LDS-shared f32 form both stop at ~0.43
+//    of the f32 MFMA peak here.  v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate and does not overlap with the
+//    partner wave's vector instructions (an MFMA wave and a v_fma_f32 wave on one SIMD take the SUM of their times);
+//    the likelihood is ~230 vector instructions per element, about as many cycles as the f32 MFMAs of the tile, and
+//    the two add up.  bf16 MFMAs do run beside vector work.
+//  * so the product is formed from bf16 MFMAs on operands split three ways, x = x0 + x1 + x2 (each the bf16 rounding
+//    of what is left), keeping the six products x0y0, x0y1, x1y0, x0y2, x2y0, x1y1: what is dropped (x1y2, x2y1, x2y2)
+//    is below 2^-23 of |x y| -- the rounding of one f32 multiply -- and the sum is accumulated in f32 as before.
+//    6 MFMAs of 32 cycles per 16 k instead of 8 of 64: 0.375 of the cycles, on the matrix pipe, beside the likelihood.
+// The operands arrive split: the last decoder layer's launch writes its output as three bf16 arrays [3][R][Hp]
+// (score_bn_act_kernel), and W is split once per call into per-(gene tile, 32-deep slab) images in the exact order the
+// MFMA B operand is read (score_split_w_kernel), so the hot loop converts nothing.  A workgroup of 4 waves takes 128
+// rows x 32 genes x all planes: the gene tile's whole W image (K <= 128: up to 72 KB with 3 planes, two workgroups per
+// CU) goes global -> LDS by LDS-DMA and each wave loads the 32 rows of its A operand into registers, ALL up front (a
+// slab-by-slab double buffer was tried first: a memory round trip takes ~3 us under this load, more than the 0.5 us of
+// MFMAs of a slab, and it waited once per slab: 4.0 ms per 128 x 1000 draws against 2.6 ms this way, 3.3 ms for the
+// f32 forms).  What remains is the likelihood's vector work: ~230 instructions per element, 60 % of the vector peak.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline void split3(float x, __bf16& x0, __bf16& x1, __bf16& x2) {
+  x0 = (__bf16)x;
+  const float r1 = x - (float)x0;   // exact
+  x1 = (__bf16)r1;
+  x2 = (__bf16)(r1 - (float)x1);
+}
+
+// evaluation-mode BatchNorm + activation of the LAST decoder layer, written as the three-way bf16 split [3][R][Hp]
+// (gamma == nullptr: the split alone; bias and activation were applied in the product's store path)
+__global__ __launch_bounds__(256) void score_bn_act_split_kernel(ScoreBnArgs a) {
+  const int q = a.Hp >> 2;
+  const long total = a.R * q;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % q) * 4;
+    const long o = (i / q) * a.Hp + c;
+    float4 v = *reinterpret_cast<const float4*>(a.h + o);
+    float* e = reinterpret_cast<float*>(&v);
+    __bf16 t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float hval = e[j];
+      if (a.gamma) {
+        const float inv = rsqrtf(a.moving_var[c + j] + a.eps);
+        const float y = a.gamma[c + j] * ((e[j] - a.moving_mean[c + j]) * inv) + a.beta[c + j];
+        hval = fmaxf(y, 0.f);
+        if (a.leak != 0.f) hval += a.leak * fminf(y, 0.f);
+        if (c + j >= a.H) hval = 0.f;
+      }
+      split3(hval, t[0][j], t[1][j], t[2][j]);
+    }
+#pragma unroll
+    for (int T = 0; T < 3; ++T) *reinterpret_cast<uint2*>(a.out3 + (long)T * a.R * a.Hp + o) = *reinterpret_cast<const uint2*>(t[T]);
+  }
+}
+
+// W [Hp][k * Gp] -> images [gene tile][slab][term][plane][k block n][lane half h][column][8 k] of bf16: the 16 bytes at
+// (term, plane, n, h, column i) are what lane (i, h) feeds to v_mfma_f32_32x32x16_bf16 for k = 32 slab + 16 n + 8 h ..+7
+__global__ __launch_bounds__(256) void score_split_w_kernel(ScoreSplitWArgs a) {
+  const long total = (long)a.n_gt * a.nslab * a.NP * 128;   // items of 8 k
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+    const int c = (int)(it & 31), h = (int)(it >> 5) & 1, n = (int)(it >> 6) & 1;
+    long rest = it >> 7;
+    const int p = (int)(rest % a.NP); rest /= a.NP;
+    const int slab = (int)(rest % a.nslab), gt = (int)(rest / a.nslab);
+    const float* src = a.W + (long)(32 * slab + 16 * n + 8 * h) * a.ldw + (long)p * a.Gp + 32 * gt + c;
+    __bf16 t[3][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) split3(src[(long)k * a.ldw], t[0][k], t[1][k], t[2][k]);
+#pragma unroll
+    for (int T = 0; T < 3; ++T) {
+      const long dst = (((((long)(gt * a.nslab + slab) * 3 + T) * a.NP + p) * 2 + n) * 2 + h) * 32 + c;
+      *reinterpret_cast<uint4*>(a.img + dst * 8) = *reinterpret_cast<const uint4*>(t[T]);
+    }
+  }
+}
+
+int launch_score_split_w(hipStream_t st, const ScoreSplitWArgs& a) {
+  if (a.n_gt <= 0 || a.nslab <= 0 || (a.NP != 2 && a.NP != 3) || !a.W || !a.img) { set_error("score_split_w: bad arguments"); return SMX_ERR_INVALID; }
+  const long total = (long)a.n_gt * a.nslab * a.NP * 128;
+  hipLaunchKernelGGL(score_split_w_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+template <int LK, int NSLAB>
+__global__ __launch_bounds__(256) void score_head_kernel(ScoreHeadArgs a) {
+  constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
+  constexpr int UNITS = 3 * NP * 128;             // 16-byte units of one slab image
+  constexpr int ALL = NSLAB * UNITS;              // ... of the gene tile's whole K (72 KB at Hp = 128 with 3 planes)
+  extern __shared__ uint4 bl[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  // blocks 8 apart share an XCD: they take the row blocks of ONE gene tile (its W images stay in that L2), in groups
+  // of row blocks over which ALL of the XCD's gene tiles pass before the next group (A stays in the L2 meanwhile)
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int per_grp = a.rb_group * a.gt_per_xcd;
+  const int grp = idx / per_grp, rem = idx % per_grp;
+  const int rb = grp * a.rb_group + rem % a.rb_group, gt = (rem / a.rb_group) * 8 + xcd;
+  if (gt >= a.n_gt || rb >= a.n_rb) return;
+  const int m0 = rb * 128 + 32 * w, n0 = gt * 32, col = n0 + i;
+  const int arow = min(m0 + i, a.R - 1);   // rows beyond the pass compute garbage that is never stored
+  const uint4* wimg = reinterpret_cast<const uint4*>(a.Wimg) + (long)gt * ALL;
+  const long aterm = (long)a.R * a.Hp;   // bf16 elements between the terms of A
+
+  // ---- every load of the tile is requested up front (K <= 128: the whole W image of the gene tile fits in LDS and the
+  // wave's A operand in registers).  A memory round trip under this load takes ~3 us, longer than the MFMAs of a slab:
+  // a slab-by-slab pipeline waited for it once per slab; this way a workgroup waits once and the CU's other workgroup
+  // computes meanwhile ----
+  // W image: global -> LDS directly (no staging registers; one wave-instruction moves 1 KB to wave-uniform base + 16 lane)
+  constexpr int UPT = (ALL + 255) / 256;
+#pragma unroll
+  for (int u = 0; u < UPT; ++u) {
+    const int q0 = u * 256 + w * 64;   // first unit of this wave's piece (ALL is a multiple of 64)
+    if (q0 < ALL)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wimg + q0 + lane),
+                                       (__attribute__((address_space(3))) void*)(bl + q0), 16, 0, 0);
+  }
+  uint4 av[NSLAB][3][2];
+  {
+    const __bf16* ap = a.A3 + (long)arow * a.Hp + 8 * h;
+#pragma unroll
+    for (int t = 0; t < NSLAB; ++t)
+#pragma unroll
+      for (int T = 0; T < 3; ++T)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) av[t][T][n] = *reinterpret_cast<const uint4*>(ap + T * aterm + 32 * t + 16 * n);
+  }
+  // the counts of the wave's 16 rows x this column
+  float xs[16];
+  {
+    const int base = m0 % a.row_mod;
+    int src[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int cell = base + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (cell >= a.row_mod) cell -= a.row_mod;
+      if (cell >= a.row_mod) cell %= a.row_mod;   // (fewer than 32 cells per draw)
+      src[r] = a.rows ? a.rows[cell] : cell;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      xs[r] = a.x_u16 ? (float)reinterpret_cast<const uint16_t*>(a.X)[(long)src[r] * a.ldx + col] : a.X[(long)src[r] * a.ldx + col];
+  }
+  __syncthreads();   // (waits for this wave's loads -- the image pieces included -- then for the other waves')
+
+  f32x16 acc[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NSLAB; ++t) {
+    const uint4* bb = &bl[t * UNITS];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        uint4 braw[3];
+#pragma unroll
+        for (int T = 0; T < 3; ++T) braw[T] = bb[(((T * NP + p) * 2 + n) * 2 + h) * 32 + i];
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&braw[0]), b1 = *reinterpret_cast<const bf16x8*>(&braw[1]),
+                     b2 = *reinterpret_cast<const bf16x8*>(&braw[2]);
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&av[t][0][n]), a1 = *reinterpret_cast<const bf16x8*>(&av[t][1][n]),
+                     a2 = *reinterpret_cast<const bf16x8*>(&av[t][2][n]);
+        // smallest terms first
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[p], 0, 0, 0);
+      }
+  }
+
+  // ---- likelihood of the wave's 32 x 32 tile: register r of plane p is row (r & 3) + 8 (r >> 2) + 4 h, column i ----
+  float bias[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) bias[p] = a.bias[(long)p * a.Gp + col];
+  const bool live = col < a.G;
+  float L[16];
+#pragma unroll
+  for (int c = 0; c < 16; c += 8) {
+    float p0[8], p1[8], p2[8], d0[8], d1[8], d2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      p0[j] = acc[0][c + j] + bias[0];
+      p1[j] = acc[1][c + j] + bias[1];
+      p2[j] = NP == 3 ? acc[NP - 1][c + j] + bias[NP - 1] : 0.f;
+    }
+    typedef float Vec[8];
+    count_elem_vec<LK, 0, 8>(*(const Vec*)(xs + c), p0, p1, p2, *(Vec*)(L + c), d0, d1, d2);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) L[r] = live ? L[r] : 0.f;
+  // per-row sums over the 32 columns (the 32 lanes of this half): a halving exchange -- 8 + 4 + 2 + 1 + 1 shuffles
+  // instead of 16 x 5; afterwards lane i holds row r = bits 4..1 of i
+  float v8[8], v4[4], v2[2];
+  {
+    const bool up = (i & 16) != 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const float keep = up ? L[8 + q] : L[q], send = up ? L[q] : L[8 + q]; v8[q] = keep + __shfl_xor(send, 16, 64); }
+  }
+  {
+    const bool up = (i & 8) != 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float keep = up ? v8[4 + q] : v8[q], send = up ? v8[q] : v8[4 + q]; v4[q] = keep + __shfl_xor(send, 8, 64); }
+  }
+  {
+    const bool up = (i & 4) != 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { const float keep = up ? v4[2 + q] : v4[q], send = up ? v4[q] : v4[2 + q]; v2[q] = keep + __shfl_xor(send, 4, 64); }
+  }
+  float tot;
+  {
+    const bool up = (i & 2) != 0;
+    const float keep = up ? v2[1] : v2[0], send = up ? v2[0] : v2[1];
+    tot = keep + __shfl_xor(send, 2, 64);
+  }
+  tot += __shfl_xor(tot, 1, 64);
+  {
+    const int r = (i >> 1) & 15;   // bit 4 chose r >= 8, bit 3 the upper half of those, ...
+    const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if ((i & 1) == 0 && row < a.R) a.llk_part[(long)row * a.n_gt + gt] = tot;
+  }
+}
+
+bool score_head_supported(int Hp, int Gp) { return Hp > 0 && Hp % 32 == 0 && Hp <= 128 && Gp % 32 == 0; }
+
+template <int LK, int NSLAB>
+static int launch_score_head_t(hipStream_t st, const ScoreHeadArgs& a, dim3 grid) {
+  constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
+  constexpr size_t lds = (size_t)NSLAB * 3 * NP * 128 * 16;
+  static bool raised = false;   // (above 64 KB of dynamic LDS a kernel needs the attribute once)
+  if (!raised && lds > 64 * 1024) {
+    SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_head_kernel<LK, NSLAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    raised = true;
+  }
+  hipLaunchKernelGGL((score_head_kernel<LK, NSLAB>), grid, dim3(256), lds, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+template <int LK>
+static int launch_score_head_lk(hipStream_t st, const ScoreHeadArgs& a, dim3 grid) {
+  switch (a.Hp / 32) {
+    case 1: return launch_score_head_t<LK, 1>(st, a, grid);
+    case 2: return launch_score_head_t<LK, 2>(st, a, grid);
+    case 3: return launch_score_head_t<LK, 3>(st, a, grid);
+    default: return launch_score_head_t<LK, 4>(st, a, grid);
+  }
+}
+
+int launch_score_head(hipStream_t st, const ScoreHeadArgs& a_in) {
+  ScoreHeadArgs a = a_in;
+  if (!score_head_supported(a.Hp, a.Gp) || a.R <= 0 || a.row_mod <= 0 || !a.A3 || !a.Wimg || !a.bias || !a.X || !a.llk_part) {
+    set_error("score_head: bad shapes");
+    return SMX_ERR_INVALID;
+  }
+  a.n_rb = (a.R + 127) / 128;
+  a.n_gt = a.Gp / 32;
+  // (row blocks per L2 group: measured 4 / 8 / 16 / 32 / all within 3 % of each other once the loads are issued up
+  // front -- the A operand's re-reads are served by the Infinity Cache at no visible cost; default: one group)
+  static const int rbg = getenv("SMX_SCORE_RB_GROUP") ? std::max(1, atoi(getenv("SMX_SCORE_RB_GROUP"))) : (1 << 30);
+  a.rb_group = std::min(rbg, a.n_rb);
+  a.gt_per_xcd = (a.n_gt + 7) / 8;
+  const int n_grp = (a.n_rb + a.rb_group - 1) / a.rb_group;
+  const dim3 grid((unsigned)(8 * n_grp * a.rb_group * a.gt_per_xcd));
+  switch (a.likelihood) {
+    case SMX_LLK_NB: return launch_score_head_lk<SMX_LLK_NB>(st, a, grid);
+    case SMX_LLK_ZINB: return launch_score_head_lk<SMX_LLK_ZINB>(st, a, grid);
+    case SMX_LLK_NBD: return launch_score_head_lk<SMX_LLK_NBD>(st, a, grid);
+    case SMX_LLK_ZINBD: return launch_score_head_lk<SMX_LLK_ZINBD>(st, a, grid);
+    default: set_error("score_head: unknown likelihood"); return SMX_ERR_INVALID;
+  }
 }
 
 // one workgroup per cell, one wave per draw in turn: lanes over the head kernel's partial sums

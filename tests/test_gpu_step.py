@@ -479,6 +479,13 @@ def test_marginal_llk_matches_oracle(Engine, name):
   e.set_flag("stacked_scoring", True)
   assert np.allclose(loop_m, ref_m, rtol=RTOL, atol=1e-3) and np.allclose(loop_l, ref_l, rtol=RTOL, atol=1e-3)
   assert np.allclose(loop_m, got_m, rtol=1e-5, atol=1e-3)
+  os.environ["SMX_SCORE_HEAD_WIDE"] = "1"   # the f32 direct-operand head kernel in its likelihood-only mode
+  try:
+    wide_m, wide_l = e.marginal_llk(row_ids=rows, n_samples=S)
+  finally:
+    del os.environ["SMX_SCORE_HEAD_WIDE"]
+  assert np.allclose(wide_m, ref_m, rtol=RTOL, atol=1e-3) and np.allclose(wide_m, got_m, rtol=1e-5, atol=1e-3)
+  assert np.allclose(wide_l, got_l, rtol=1e-5, atol=1e-3)
   os.environ["SMX_SCORE_ROWS"] = "250"   # 5 draws of the 50 cells per pass: 5 + 5 + 2
   try:
     ch_m, ch_l = e.marginal_llk(row_ids=rows, n_samples=S)
