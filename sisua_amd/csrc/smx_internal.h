@@ -474,9 +474,9 @@ bool score_head_supported(int Hp, int Gp);
 int launch_score_head(hipStream_t st, const ScoreHeadArgs& a);
 struct IwStackArgs {
   const float* llk_part = nullptr; int n_chunks = 0;   // [S * B][n_chunks]
-  const float* lw = nullptr;                            // [S * B]
+  const float* lw = nullptr;                            // [S * B] latent part of log w (nullptr: plain log-mean-exp of the likelihoods)
   const float* lgx1 = nullptr; const int32_t* rows = nullptr;
-  float* run_max = nullptr; float* run_sum = nullptr; float* llk_sum = nullptr;   // [B]
+  float* run_max = nullptr; float* run_sum = nullptr; float* llk_sum = nullptr;   // [B] (llk_sum may be null)
   int B = 0, S = 0, first = 1;
 };
 int launch_iw_stack(hipStream_t st, const IwStackArgs& a);

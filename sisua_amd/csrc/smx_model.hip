@@ -269,6 +269,7 @@ struct smx_model {
   float* pred_stage = nullptr; size_t pred_floats = 0;   // device staging of smx_predict (one chunk of cells, laid out like the caller's arrays)
   float* score_buf = nullptr; size_t score_floats = 0;   // smx_marginal_llk, stacked draws: z | lw | two activation buffers | last layer (k-major f32 or bf16 split) | likelihood partials
   float* score_wimg = nullptr; size_t score_wimg_floats = 0;   // the output head's W as bf16 slab images (smx_score.hip)
+  float* score_aux = nullptr; size_t score_aux_floats = 0;     // scoring calls: running log-sum-exp state, staged target counts and their row constants
   float* pinned = nullptr; size_t pinned_floats = 0;   // host staging for the parameter planes handed back by smx_forward / smx_decode
   // sum-of-squares slots written by the weight-gradient products (per-tensor clipnorm without a separate pass)
   float* sq_slots = nullptr; std::vector<int> sq_first, sq_count; std::vector<char> sq_reduced; int sq_total_first = 0;   // this step's output head ran as the fused kernel (smx_head.hip)
@@ -2191,6 +2192,7 @@ int smx_model_destroy(smx_model* m) {
   if (m->pred_stage) hipFree(m->pred_stage);
   if (m->score_buf) hipFree(m->score_buf);
   if (m->score_wimg) hipFree(m->score_wimg);
+  if (m->score_aux) hipFree(m->score_aux);
   for (auto& kv : m->injected) fr(kv.second.d);
   if (m->st_comm) { hipStreamSynchronize(m->st_comm); hipStreamDestroy(m->st_comm); }
   if (m->ev_c1) hipEventDestroy(m->ev_c1);
@@ -2803,7 +2805,17 @@ static bool stacked_scoring_ok(const smx_model* m) {
   return m->dec[0].in_p == m->Dp;
 }
 
-static int marginal_llk_stacked(smx_model* m, const Pass& ps, int n_samples, float* run) {
+// one score over the stacked draws: the likelihood of `X` under the decoded parameters, folded per cell into a running
+// log-sum-exp (with the latent terms of the importance weight: marginal_log_prob; without: Posterior.cal_llk's scores)
+struct ScoreJob {
+  const float* X = nullptr; int x_u16 = 0; const int32_t* xrows = nullptr;   // counts to score, [.. or B][Gp]
+  const float* lgx1 = nullptr; const int32_t* lgrows = nullptr;              // their sum lgamma(x + 1) per cell
+  int likelihood = 0;                                                        // the model's, or its count part without the zero-inflation gate
+  int with_lw = 0;
+  float* run_max = nullptr; float* run_sum = nullptr; float* llk_sum = nullptr;   // [B] each (llk_sum may be null)
+};
+
+static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const ScoreJob* jobs, int n_jobs) {
   const int B = ps.B, n_gt = head_loss_chunks(m->Gp);
   int Hmax = 0;
   for (const MlpLayer& L : m->dec) Hmax = std::max(Hmax, L.out_p);
@@ -2824,19 +2836,31 @@ static int marginal_llk_stacked(smx_model* m, const Pass& ps, int n_samples, flo
   float* ht = hb[1] + R * Hmax;          // the last layer's output: bf16 three-way split [3][R][Hp], or k-major f32 [Hp][R]
   float* part = ht + 2 * R * Hmax;
   const bool wide_head = getenv("SMX_SCORE_HEAD_WIDE") != nullptr || !score_head_supported(m->dec.back().out_p, m->Gp);   // the training kernel's direct-operand form (A/B)
-  const int NP = m->k, nslab = m->dec.back().out_p / 32;
+  const int nslab = m->dec.back().out_p / 32;
+  // W as bf16 slab images, one set per plane count in use (3: zero-inflated likelihoods; 2: the others and the
+  // count part of a zero-inflated one) -- once per call, W does not change meanwhile
+  const __bf16* wimg[4] = {nullptr, nullptr, nullptr, nullptr};
   if (!wide_head) {
-    const size_t wneed = ((size_t)n_gt * nslab * 3 * NP * 1024 + 1) / 2;   // bf16 elements as floats
+    bool use_np[4] = {false, false, false, false};
+    for (int j = 0; j < n_jobs; ++j) use_np[(jobs[j].likelihood == SMX_LLK_ZINB || jobs[j].likelihood == SMX_LLK_ZINBD) ? 3 : 2] = true;
+    const size_t per_plane = (size_t)n_gt * nslab * 3 * 1024;   // bf16 elements per plane of an image set
+    const size_t wneed = (per_plane * ((use_np[2] ? 2 : 0) + (use_np[3] ? 3 : 0)) + 1) / 2;   // ... as floats
     if (wneed > m->score_wimg_floats) {
       if (m->score_wimg) hipFree(m->score_wimg);
       m->score_wimg = nullptr; m->score_wimg_floats = 0;
       SMX_CHECK(dmalloc(&m->score_wimg, wneed));
       m->score_wimg_floats = wneed;
     }
-    ScoreSplitWArgs sw;
-    sw.W = P_(m, m->t_outW[0]); sw.ldw = m->tensors[m->t_outW[0]].ld; sw.Gp = m->Gp; sw.n_gt = n_gt; sw.nslab = nslab; sw.NP = NP;
-    sw.img = reinterpret_cast<__bf16*>(m->score_wimg);
-    SMX_CHECK(launch_score_split_w(m->st, sw));
+    __bf16* at = reinterpret_cast<__bf16*>(m->score_wimg);
+    for (int np = 2; np <= 3; ++np) {
+      if (!use_np[np]) continue;
+      ScoreSplitWArgs sw;
+      sw.W = P_(m, m->t_outW[0]); sw.ldw = m->tensors[m->t_outW[0]].ld; sw.Gp = m->Gp; sw.n_gt = n_gt; sw.nslab = nslab; sw.NP = np;
+      sw.img = at;
+      SMX_CHECK(launch_score_split_w(m->st, sw));
+      wimg[np] = at;
+      at += per_plane * np;
+    }
   }
   // the encoder and the latent head (this pass also decodes draw 0 at batch size; its results are not used)
   SMX_CHECK(forward_pass(m, ps, false, false, 0));
@@ -2870,25 +2894,48 @@ static int marginal_llk_stacked(smx_model* m, const Pass& ps, int n_samples, flo
       }
       in = hb[i & 1]; ld = L.out_p;
     }
-    if (!wide_head) {
-      ScoreHeadArgs sh;
-      sh.A3 = reinterpret_cast<const __bf16*>(ht); sh.Wimg = reinterpret_cast<const __bf16*>(m->score_wimg); sh.bias = P_(m, m->t_outb[0]);
-      sh.X = ps.Xsrc; sh.x_u16 = ps.x_u16; sh.ldx = m->Gp; sh.rows = ps.xrows; sh.llk_part = part;
-      sh.R = (int)rows; sh.row_mod = B; sh.G = m->G; sh.Gp = m->Gp; sh.Hp = m->dec.back().out_p; sh.likelihood = m->cfg.likelihood;
-      SMX_CHECK(launch_score_head(m->st, sh));
-    } else {
-    HeadLossArgs hl;
-    hl.H = ht; hl.ldh = (int)rows; hl.W = P_(m, m->t_outW[0]); hl.ldw = m->tensors[m->t_outW[0]].ld; hl.bias = P_(m, m->t_outb[0]);
-    hl.X = ps.Xsrc; hl.x_u16 = ps.x_u16; hl.ldx = m->Gp; hl.rows = ps.xrows; hl.llk_part = part;
-    hl.B = (int)rows; hl.G = m->G; hl.Gp = m->Gp; hl.Hp = m->dec.back().out_p; hl.likelihood = m->cfg.likelihood; hl.grad_scale = 0.f;
-    hl.llk_only = 1; hl.row_mod = B;
-    SMX_CHECK(launch_out_head_loss(m->st, hl));
+    for (int j = 0; j < n_jobs; ++j) {
+      const ScoreJob& q = jobs[j];
+      if (!wide_head) {
+        ScoreHeadArgs sh;
+        sh.A3 = reinterpret_cast<const __bf16*>(ht);
+        sh.Wimg = wimg[(q.likelihood == SMX_LLK_ZINB || q.likelihood == SMX_LLK_ZINBD) ? 3 : 2]; sh.bias = P_(m, m->t_outb[0]);
+        sh.X = q.X; sh.x_u16 = q.x_u16; sh.ldx = m->Gp; sh.rows = q.xrows; sh.llk_part = part;
+        sh.R = (int)rows; sh.row_mod = B; sh.G = m->G; sh.Gp = m->Gp; sh.Hp = m->dec.back().out_p; sh.likelihood = q.likelihood;
+        SMX_CHECK(launch_score_head(m->st, sh));
+      } else {
+        HeadLossArgs hl;
+        hl.H = ht; hl.ldh = (int)rows; hl.W = P_(m, m->t_outW[0]); hl.ldw = m->tensors[m->t_outW[0]].ld; hl.bias = P_(m, m->t_outb[0]);
+        hl.X = q.X; hl.x_u16 = q.x_u16; hl.ldx = m->Gp; hl.rows = q.xrows; hl.llk_part = part;
+        hl.B = (int)rows; hl.G = m->G; hl.Gp = m->Gp; hl.Hp = m->dec.back().out_p; hl.likelihood = q.likelihood; hl.grad_scale = 0.f;
+        hl.llk_only = 1; hl.row_mod = B;
+        SMX_CHECK(launch_out_head_loss(m->st, hl));
+      }
+      IwStackArgs w;
+      w.llk_part = part; w.n_chunks = n_gt; w.lw = q.with_lw ? lw : nullptr; w.lgx1 = q.lgx1; w.rows = q.lgrows;
+      w.run_max = q.run_max; w.run_sum = q.run_sum; w.llk_sum = q.llk_sum; w.B = B; w.S = S; w.first = (s0 == 0);
+      SMX_CHECK(launch_iw_stack(m->st, w));
     }
-    IwStackArgs w;
-    w.llk_part = part; w.n_chunks = n_gt; w.lw = lw; w.lgx1 = ps.lgx1; w.rows = ps.rows;
-    w.run_max = run; w.run_sum = run + B; w.llk_sum = run + 2 * B; w.B = B; w.S = S; w.first = (s0 == 0);
-    SMX_CHECK(launch_iw_stack(m->st, w));
   }
+  return SMX_OK;
+}
+
+static int marginal_llk_stacked(smx_model* m, const Pass& ps, int n_samples, float* run) {
+  ScoreJob q;
+  q.X = ps.Xsrc; q.x_u16 = ps.x_u16; q.xrows = ps.xrows; q.lgx1 = ps.lgx1; q.lgrows = ps.rows; q.likelihood = m->cfg.likelihood;
+  q.with_lw = 1; q.run_max = run; q.run_sum = run + ps.B; q.llk_sum = run + 2 * ps.B;
+  return stacked_scores(m, ps, n_samples, &q, 1);
+}
+
+// scratch of the scoring entry points, kept across calls (hipMalloc + hipFree per call cost more than the stacked pass)
+static int score_aux(smx_model* m, size_t floats, float** out) {
+  if (floats > m->score_aux_floats) {
+    if (m->score_aux) { SMX_HIP(hipStreamSynchronize(m->st)); hipFree(m->score_aux); }
+    m->score_aux = nullptr; m->score_aux_floats = 0;
+    SMX_CHECK(dmalloc(&m->score_aux, floats));
+    m->score_aux_floats = floats;
+  }
+  *out = m->score_aux;
   return SMX_OK;
 }
 
@@ -2899,7 +2946,7 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
   SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, 0, 0));
   const bool stacked = stacked_scoring_ok(m);
   float* run = nullptr;   // [3][B]: running max, running sum, sum of log p(x|z)
-  SMX_CHECK(dmalloc(&run, (size_t)3 * batch));
+  SMX_CHECK(score_aux(m, (size_t)3 * batch, &run));
   int rc = SMX_OK;
   if (stacked) rc = marginal_llk_stacked(m, ps, n_samples, run);
   for (int s = 0; !stacked && s < n_samples && rc == SMX_OK; ++s) {
@@ -2934,7 +2981,6 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
   } else {
     hipStreamSynchronize(m->st);
   }
-  hipFree(run);
   return rc;
 }
 
@@ -2949,27 +2995,41 @@ int smx_score_llk(smx_model* m, const int32_t* row_ids, const float* host_x, con
   const size_t plane = (size_t)batch * m->Gp;
   float *tX = nullptr, *tLg = nullptr, *run = nullptr;   // run: [n_targets][2]{max, sum}[batch]
   int rc = SMX_OK;
-  if ((rc = dmalloc(&tX, plane * n_targets)) || (rc = dmalloc(&tLg, (size_t)batch * n_targets)) ||
-      (rc = dmalloc(&run, (size_t)n_targets * 2 * 2 * batch))) {
-    hipFree(tX); hipFree(tLg); hipFree(run);
-    return rc;
+  {
+    float* aux = nullptr;
+    SMX_CHECK(score_aux(m, plane * n_targets + (size_t)batch * n_targets + (size_t)n_targets * 2 * 2 * batch, &aux));
+    tX = aux; tLg = tX + plane * n_targets; run = tLg + (size_t)batch * n_targets;
   }
   hipError_t e = hipMemsetAsync(tX, 0, plane * n_targets * sizeof(float), m->st);
-  std::vector<float> lg((size_t)batch);
-  for (int t = 0; t < n_targets && e == hipSuccess; ++t) {
+  for (int t = 0; t < n_targets && e == hipSuccess && rc == SMX_OK; ++t) {
     const float* src = targets ? targets[t] : nullptr;
     if (!src) continue;   // NULL target: score against the input cells themselves
     e = hipMemcpy2DAsync(tX + plane * t, (size_t)m->Gp * sizeof(float), src, (size_t)m->G * sizeof(float),
                          (size_t)m->G * sizeof(float), (size_t)batch, hipMemcpyHostToDevice, m->st);
-    for (int i = 0; i < batch; ++i) {
-      double acc = 0.0;
-      for (int g = 0; g < m->G; ++g) { const float v = src[(size_t)i * m->G + g]; if (v > 0.f) acc += lgamma((double)v + 1.0); }
-      lg[(size_t)i] = (float)acc;
-    }
-    if (e == hipSuccess) e = hipMemcpy(tLg + (size_t)batch * t, lg.data(), lg.size() * sizeof(float), hipMemcpyHostToDevice);
+    // sum lgamma(x + 1) per cell of the target, on the device (the kernel the resident matrix's constants come from;
+    // on the host it was ~0.5 ms of lgamma() calls per call)
+    if (e == hipSuccess) rc = launch_row_stats(m->st, tX + plane * t, 0, m->Gp, batch, m->G, tLg + (size_t)batch * t, nullptr);
   }
   if (e != hipSuccess) { set_error(std::string("score_llk upload failed: ") + hipGetErrorString(e)); rc = SMX_ERR_HIP; }
-  for (int s = 0; s < n_samples && rc == SMX_OK; ++s) {
+  const bool stacked = stacked_scoring_ok(m);
+  if (stacked && rc == SMX_OK) {
+    // all draws as rows of one decoder pass; one likelihood-only head launch per (target, distribution)
+    ScoreJob jobs[8];
+    int nj = 0;
+    for (int t = 0; t < n_targets; ++t) {
+      const bool own = !(targets && targets[t]);
+      for (int j = 0; j < n_dist; ++j) {
+        ScoreJob& q = jobs[nj++];
+        q.likelihood = (j == 0) ? lk : (lk == SMX_LLK_ZINB ? SMX_LLK_NB : SMX_LLK_NBD);
+        q.X = own ? ps.Xsrc : tX + plane * t; q.x_u16 = own ? ps.x_u16 : 0; q.xrows = own ? ps.xrows : nullptr;
+        q.lgx1 = own ? ps.lgx1 : tLg + (size_t)batch * t; q.lgrows = own ? ps.rows : nullptr;
+        float* r = run + ((size_t)t * 2 + j) * 2 * batch;
+        q.with_lw = 0; q.run_max = r; q.run_sum = r + batch; q.llk_sum = nullptr;
+      }
+    }
+    rc = stacked_scores(m, ps, n_samples, jobs, nj);
+  }
+  for (int s = 0; !stacked && s < n_samples && rc == SMX_OK; ++s) {
     ps.sample = s;
     rc = forward_pass(m, ps, false, false, s == 0 ? 0 : 2);
     for (int t = 0; t < n_targets && rc == SMX_OK; ++t) {
@@ -3010,7 +3070,6 @@ int smx_score_llk(smx_model* m, const int32_t* row_ids, const float* host_x, con
   } else {
     hipStreamSynchronize(m->st);
   }
-  hipFree(tX); hipFree(tLg); hipFree(run);
   return rc;
 }
 

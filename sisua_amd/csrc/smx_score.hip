@@ -429,7 +429,7 @@ __global__ __launch_bounds__(512) void iw_stack_kernel(IwStackArgs a) {
     float llk = 0.f;
     for (int c = lane; c < a.n_chunks; c += 64) llk += a.llk_part[r * a.n_chunks + c];
     llk = wave_sum(llk) - lg;
-    if (lane == 0) { llks[s] = llk; lws[s] = llk + a.lw[r]; }
+    if (lane == 0) { llks[s] = llk; lws[s] = llk + (a.lw ? a.lw[r] : 0.f); }
   }
   __syncthreads();
   // log-sum-exp of the chunk's weights and the sum of its likelihoods, in a fixed order
@@ -447,17 +447,17 @@ __global__ __launch_bounds__(512) void iw_stack_kernel(IwStackArgs a) {
   for (int s = lane; s < a.S; s += 64) { se += expf(lws[s] - mx); sl += llks[s]; }
   se = wave_sum(se); sl = wave_sum(sl);
   if (lane != 0) return;
-  if (a.first) { a.run_max[b] = mx; a.run_sum[b] = se; a.llk_sum[b] = sl; }
+  if (a.first) { a.run_max[b] = mx; a.run_sum[b] = se; if (a.llk_sum) a.llk_sum[b] = sl; }
   else {
     const float om = a.run_max[b], nm = fmaxf(om, mx);
     a.run_sum[b] = a.run_sum[b] * expf(om - nm) + se * expf(mx - nm);
     a.run_max[b] = nm;
-    a.llk_sum[b] += sl;
+    if (a.llk_sum) a.llk_sum[b] += sl;
   }
 }
 
 int launch_iw_stack(hipStream_t st, const IwStackArgs& a) {
-  if (a.B <= 0 || a.S <= 0 || a.S > SMX_SCORE_MAX_DRAWS || a.n_chunks <= 0 || !a.llk_part || !a.lw || !a.lgx1 || !a.run_max || !a.run_sum || !a.llk_sum) {
+  if (a.B <= 0 || a.S <= 0 || a.S > SMX_SCORE_MAX_DRAWS || a.n_chunks <= 0 || !a.llk_part || !a.lgx1 || !a.run_max || !a.run_sum) {
     set_error("iw_stack: bad arguments");
     return SMX_ERR_INVALID;
   }

@@ -538,6 +538,19 @@ def test_score_llk_matches_oracle(Engine, name):
   ref2 = so.posterior_llk(spec, params, bn, x_cor[rows], np.arange(len(rows)), [x[rows]], S, library=lib[rows])
   got2 = e.score_llk([x[rows]], x=x_cor[rows], library=lib[rows], n_samples=S)
   assert np.allclose(got2, ref2, rtol=RTOL, atol=1e-3)
+  # VAE-family models score all draws as rows of one decoder pass; the draw-by-draw form (and the f32 head kernel of the
+  # stacked form) give the same scores; several stacked passes fold into the same running log-mean-exp
+  e.set_flag("stacked_scoring", False)
+  loop = e.score_llk([x[rows], None], row_ids=rows, n_samples=S)
+  e.set_flag("stacked_scoring", True)
+  assert np.allclose(loop, ref, rtol=RTOL, atol=1e-3) and np.allclose(loop, got, rtol=1e-5, atol=1e-3)
+  for var, val in (("SMX_SCORE_HEAD_WIDE", "1"), ("SMX_SCORE_ROWS", "100")):
+    os.environ[var] = val
+    try:
+      alt = e.score_llk([x[rows], None], row_ids=rows, n_samples=S)
+    finally:
+      del os.environ[var]
+    assert np.allclose(alt, got, rtol=1e-5, atol=1e-3), var
   e.close()
 
 
