@@ -461,6 +461,7 @@ def _mlp_fwd(spec, params, bn_state, prefix, units, h, training, noise, stream0,
     else:
       y = pre + params[f"{prefix}{i}/b"]
     act = np.maximum(y, 0.0)
+    _log_kink(y)
     mask = noise.dropout(stream0 + i, y.shape[1], p_drop) if training else 1.0
     h = act * mask
     c.update(pos=(y > 0), mask=mask)
@@ -514,12 +515,26 @@ def permute_dims(z, u):
   return zp
 
 
+# Kink margin.  ReLU / leaky-ReLU derivatives jump at 0: a pre-activation that this float64 pass computes as +-1e-8 can
+# come out on the other side of 0 in float32, and the gradients behind it then differ by a whole element's contribution
+# (profiles/r02_divergence_event.txt; seen once in ~3000 random property-test examples: 9.6e-9 in a discriminator layer,
+# 0.5 % on that layer's gradient, forward values equal to 1e-8).  Tests that compare single steps on random shapes set
+# KINK_LOG = [] before a pass and skip the comparison when min(KINK_LOG) is within float32 rounding of 0.
+KINK_LOG = None
+
+
+def _log_kink(pre):
+  if KINK_LOG is not None and pre.size:
+    KINK_LOG.append(float(np.abs(pre).min()))
+
+
 def _factor_forward(spec: Spec, params, z, u, y=None, mvec=None):
   B = z.shape[0]
   h = np.concatenate([z, permute_dims(z, u)], axis=0)            # rows [0, B): z; rows [B, 2B): z_perm
   caches = []
   for i in range(spec.disc_layers):
     pre = h @ params[f"disc{i}/W"] + params[f"disc{i}/b"]
+    _log_kink(pre)
     caches.append(dict(h_in=h, slope=np.where(pre > 0, 1.0, spec.disc_leak)))
     h = np.where(pre > 0, pre, spec.disc_leak * pre)
   logits = h @ params["discout/W"] + params["discout/b"]         # [2B, n_out]

@@ -2,7 +2,7 @@
 odd layer widths and batch sizes.  Every example is checked against the oracle / NumPy."""
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings, strategies as st
+from hypothesis import HealthCheck, assume, given, settings, strategies as st
 
 from oracle import sisua_oracle as so
 from tests.util import grad_errors, make_pair, perturbed_params
@@ -12,6 +12,22 @@ import os
 _N = int(os.environ.get("SMX_HYP_EXAMPLES", "0"))   # stress runs while developing: SMX_HYP_EXAMPLES=400
 def _n(default):
   return _N or default
+def _oracle_step_off_kinks(e, *args, **kw):
+  """The oracle's training step; the example is discarded (hypothesis.assume) when one of its ReLU / leaky-ReLU inputs
+  lies within float32 rounding of 0: the activation's derivative jumps there, so the float32 and float64 gradients of that
+  layer legitimately differ by one element's contribution (oracle/sisua_oracle.py KINK_LOG; 1 example in ~3000)."""
+  so.KINK_LOG = []
+  try:
+    res = so.train_step(*args, **kw)
+    margin = min(so.KINK_LOG) if so.KINK_LOG else 1.0
+  finally:
+    so.KINK_LOG = None
+  if margin <= 2e-6:
+    e.close()
+    assume(False)
+  return res
+
+
 SET = settings(max_examples=_n(25), deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 
 
@@ -95,7 +111,7 @@ def test_one_step_on_arbitrary_widths(eng, G, H, H2, D, B, model, lk0, bn, seed)
   e.set_params(params)
   e.upload(x, library=lib if model == "scvi" else None)
   rows = rng.permutation(n)[:B].astype(np.int32)
-  res = so.train_step(spec, params, bnst, opt, x[rows], so.PhiloxNoise(spec.seed, 0, rows), library=lib[rows].astype(np.float64))
+  res = _oracle_step_off_kinks(e, spec, params, bnst, opt, x[rows], so.PhiloxNoise(spec.seed, 0, rows), library=lib[rows].astype(np.float64))
   m = e.train_step(rows)
   assert np.isclose(m["loss"], res["metrics"]["loss"], rtol=1e-4, atol=1e-5), (m["loss"], res["metrics"]["loss"])
   # tiny layers make analytically-zero gradients common (a bias in front of BatchNorm): judge those on 1 % of the
@@ -166,7 +182,7 @@ def test_semi_supervised_step_on_arbitrary_label_widths(eng, G, H, D, B, P1, P2,
   e.set_params(params)
   e.upload(x, ys, None, mask)
   rows = rng.permutation(n)[:B].astype(np.int32)
-  res = so.train_step(spec, params, bnst, opt, x[rows], so.PhiloxNoise(spec.seed, 0, rows), y=[y[rows] for y in ys], mask=mask[rows])
+  res = _oracle_step_off_kinks(e, spec, params, bnst, opt, x[rows], so.PhiloxNoise(spec.seed, 0, rows), y=[y[rows] for y in ys], mask=mask[rows])
   m = e.train_step(rows)
   for key in ("loss", "nllk_x", "nllk_y", "kl"):
     assert np.isclose(m[key], res["metrics"][key], rtol=1e-4, atol=1e-4), (key, m[key], res["metrics"][key])
