@@ -444,7 +444,12 @@ struct ScoreDrawArgs {
   NoiseKey nk{0, 0, 0, 0, nullptr};         // stream word without the sample index
   const int32_t* rows = nullptr; uint32_t cell_base = 0;
   float* z = nullptr;                       // [S * B][Dp]
-  float* lw = nullptr;                      // [S * B]: log N(z; 0, I) - log q(z | x)
+  float* lw = nullptr;                      // [S * B]: log N(z; 0, I) - log q(z | x)  (+ the library latent's terms, scvi)
+  // scvi: the library latent l = mu_l + sigma_l eps_l of every row as well (scvi.py:37-45, 88-106)
+  const float* latl = nullptr; int ld_l = 0;            // [B][ld_l]: (mu_l, s_raw_l) in columns 0, 1
+  const float* library = nullptr; const int32_t* lib_rows = nullptr;   // prior (mean, variance) per cell, indexed like lgx1
+  NoiseKey nk_l{0, 0, 0, 0, nullptr};
+  float* l = nullptr;                       // [S * B]
 };
 int launch_score_draws(hipStream_t st, const ScoreDrawArgs& a);
 struct ScoreBnArgs {
@@ -472,6 +477,16 @@ struct ScoreHeadArgs {
 };
 bool score_head_supported(int Hp, int Gp);
 int launch_score_head(hipStream_t st, const ScoreHeadArgs& a);
+// scvi head of stacked rows: softmax-rate head + NBD / ZINBD log-likelihood of one row per workgroup, from the raw planes
+struct ScviScoreArgs {
+  const float* raw = nullptr; long ld = 0; long plane_stride = 0;   // [R][k * Gp]
+  int R = 0, G = 0, Gp = 0, k = 2, likelihood = 0, row_mod = 0;
+  const float* l = nullptr; float clip_library = 1e3f;             // [R]
+  const float* X = nullptr; int ldx = 0; const int32_t* rows = nullptr; int x_u16 = 0;
+  float* llk = nullptr;                                             // [R]
+};
+bool scvi_score_supported(int Gp);
+int launch_scvi_score_rows(hipStream_t st, const ScviScoreArgs& a);
 struct IwStackArgs {
   const float* llk_part = nullptr; int n_chunks = 0;   // [S * B][n_chunks]
   const float* lw = nullptr;                            // [S * B] latent part of log w (nullptr: plain log-mean-exp of the likelihoods)

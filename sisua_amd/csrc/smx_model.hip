@@ -2795,10 +2795,12 @@ int smx_decode(smx_model* m, const float* z, const float* l, int32_t batch, floa
 }
 
 // Stacked form (smx_score.hip): the encoder runs once, then the S draws of the B cells go through the decoder and the
-// fused output head as S * B rows at a time.  Models whose draws are more than z = mu + sigma eps (scvi's library
-// latent and softmax head, SCALE's mixture prior) and deterministic latents keep the draw-by-draw loop.
+// output head as S * B rows at a time (scvi: its library latent drawn per row as well, the raw planes materialised and a
+// row-local softmax + likelihood launch, since its rate is normalised over all genes of a row).  SCALE's mixture prior
+// and deterministic latents keep the draw-by-draw loop.
 static bool stacked_scoring_ok(const smx_model* m) {
-  if (!m->flags.stacked_scoring || m->scvi || m->scale || !m->stochastic || m->use_injected || m->dec.empty()) return false;
+  if (!m->flags.stacked_scoring || m->scale || !m->stochastic || m->use_injected || m->dec.empty()) return false;
+  if (m->scvi && !scvi_score_supported(m->Gp)) return false;
   if (!head_loss_supported(1, m->dec.back().out_p, m->Gp) || (m->dec.back().out_p % 4)) return false;
   for (const MlpLayer& L : m->dec)
     if ((L.in_p % 4) || (L.out_p % 32)) return false;
@@ -2820,10 +2822,12 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
   int Hmax = 0;
   for (const MlpLayer& L : m->dec) Hmax = std::max(Hmax, L.out_p);
   // rows per stacked pass: whole draws, up to 16 384 rows (SMX_SCORE_ROWS: the tests force several chunks)
-  const long cap_rows = getenv("SMX_SCORE_ROWS") ? std::max(1L, atol(getenv("SMX_SCORE_ROWS"))) : 16384L;
+  // (scvi: 4 096 rows -- their raw planes are 100 MB at 2 000 genes)
+  const long cap_rows = getenv("SMX_SCORE_ROWS") ? std::max(1L, atol(getenv("SMX_SCORE_ROWS"))) : (m->scvi ? 4096L : 16384L);
   const int Sc = (int)std::min<long>(std::min<long>(n_samples, SMX_SCORE_MAX_DRAWS), std::max<long>(1, cap_rows / B));
   const size_t R = (size_t)Sc * B;
-  const size_t need = R * ((size_t)m->Dp + 1 + 4 * (size_t)Hmax + (size_t)n_gt);
+  const size_t raw_ld = (size_t)m->k * m->Gp;
+  const size_t need = R * ((size_t)m->Dp + 2 + 4 * (size_t)Hmax + (size_t)n_gt + (m->scvi ? raw_ld : 0));
   if (need > m->score_floats) {
     if (m->score_buf) hipFree(m->score_buf);
     m->score_buf = nullptr; m->score_floats = 0;
@@ -2835,12 +2839,14 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
   float* hb[2] = {lw + R, lw + R + R * Hmax};
   float* ht = hb[1] + R * Hmax;          // the last layer's output: bf16 three-way split [3][R][Hp], or k-major f32 [Hp][R]
   float* part = ht + 2 * R * Hmax;
-  const bool wide_head = getenv("SMX_SCORE_HEAD_WIDE") != nullptr || !score_head_supported(m->dec.back().out_p, m->Gp);   // the training kernel's direct-operand form (A/B)
+  float* lsmp = part + R * n_gt;         // scvi: the library latent of every row ...
+  float* raw = lsmp + R;                 // ... and the k raw planes [R][k * Gp]
+  const bool wide_head = m->scvi || getenv("SMX_SCORE_HEAD_WIDE") != nullptr || !score_head_supported(m->dec.back().out_p, m->Gp);   // the training kernel's direct-operand form (A/B)
   const int nslab = m->dec.back().out_p / 32;
   // W as bf16 slab images, one set per plane count in use (3: zero-inflated likelihoods; 2: the others and the
   // count part of a zero-inflated one) -- once per call, W does not change meanwhile
   const __bf16* wimg[4] = {nullptr, nullptr, nullptr, nullptr};
-  if (!wide_head) {
+  if (!wide_head && !m->scvi) {
     bool use_np[4] = {false, false, false, false};
     for (int j = 0; j < n_jobs; ++j) use_np[(jobs[j].likelihood == SMX_LLK_ZINB || jobs[j].likelihood == SMX_LLK_ZINBD) ? 3 : 2] = true;
     const size_t per_plane = (size_t)n_gt * nslab * 3 * 1024;   // bf16 elements per plane of an image set
@@ -2870,6 +2876,9 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
     ScoreDrawArgs d;
     d.lat = m->latbuf; d.ld = 2 * m->Dp; d.B = B; d.D = m->D; d.Dp = m->Dp; d.S = S; d.s0 = s0;
     d.nk = make_key(m, ST_EPS_Z, 0, false); d.rows = ps.rows; d.cell_base = ps.cell_base; d.z = z; d.lw = lw;
+    if (m->scvi) {
+      d.latl = m->latlbuf; d.ld_l = 32; d.library = ps.lib; d.lib_rows = ps.rows; d.nk_l = make_key(m, ST_EPS_L, 0, false); d.l = lsmp;
+    }
     SMX_CHECK(launch_score_draws(m->st, d));
     const float* in = z;
     int ld = m->Dp;
@@ -2888,15 +2897,30 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
           b.gamma = P_(m, L.tGamma); b.beta = P_(m, L.tBeta);
           b.moving_mean = m->bn_moving + m->bn_off[L.bn]; b.moving_var = b.moving_mean + L.out_p;
         }
-        if (last && wide_head) { b.out_t = ht; b.ldt = rows; }
+        if (last && m->scvi) { /* row-major f32, in place: the A operand of the plane products below */ }
+        else if (last && wide_head) { b.out_t = ht; b.ldt = rows; }
         else if (last) b.out3 = reinterpret_cast<__bf16*>(ht);
-        SMX_CHECK(launch_score_bn_act(m->st, b));
+        if (b.gamma || b.out_t || b.out3) SMX_CHECK(launch_score_bn_act(m->st, b));
       }
       in = hb[i & 1]; ld = L.out_p;
     }
+    if (m->scvi) {
+      for (int ch = 0; ch < m->k; ++ch) {
+        GemmArgs g;
+        g.A = in; g.lda = ld; g.B = P_(m, m->t_outW[ch]); g.ldb = m->tensors[m->t_outW[ch]].ld;
+        g.C = raw + (size_t)ch * m->Gp; g.ldc = (int)raw_ld; g.M = (int)rows; g.N = m->Gp; g.K = ld; g.bias = P_(m, m->t_outb[ch]); g.split_k = 1;
+        SMX_CHECK(launch_gemm(m->st, g));
+      }
+    }
     for (int j = 0; j < n_jobs; ++j) {
       const ScoreJob& q = jobs[j];
-      if (!wide_head) {
+      if (m->scvi) {
+        ScviScoreArgs sa;
+        sa.raw = raw; sa.ld = (long)raw_ld; sa.plane_stride = m->Gp; sa.R = (int)rows; sa.G = m->G; sa.Gp = m->Gp; sa.k = m->k;
+        sa.likelihood = q.likelihood; sa.row_mod = B; sa.l = lsmp; sa.clip_library = m->cfg.clip_library;
+        sa.X = q.X; sa.ldx = m->Gp; sa.rows = q.xrows; sa.x_u16 = q.x_u16; sa.llk = part;
+        SMX_CHECK(launch_scvi_score_rows(m->st, sa));
+      } else if (!wide_head) {
         ScoreHeadArgs sh;
         sh.A3 = reinterpret_cast<const __bf16*>(ht);
         sh.Wimg = wimg[(q.likelihood == SMX_LLK_ZINB || q.likelihood == SMX_LLK_ZINBD) ? 3 : 2]; sh.bias = P_(m, m->t_outb[0]);
@@ -2912,7 +2936,7 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
         SMX_CHECK(launch_out_head_loss(m->st, hl));
       }
       IwStackArgs w;
-      w.llk_part = part; w.n_chunks = n_gt; w.lw = q.with_lw ? lw : nullptr; w.lgx1 = q.lgx1; w.rows = q.lgrows;
+      w.llk_part = part; w.n_chunks = m->scvi ? 1 : n_gt; w.lw = q.with_lw ? lw : nullptr; w.lgx1 = q.lgx1; w.rows = q.lgrows;
       w.run_max = q.run_max; w.run_sum = q.run_sum; w.llk_sum = q.llk_sum; w.B = B; w.S = S; w.first = (s0 == 0);
       SMX_CHECK(launch_iw_stack(m->st, w));
     }

@@ -41,7 +41,19 @@ __global__ __launch_bounds__(256) void score_draws_kernel(ScoreDrawArgs a) {
     a.z[r * a.Dp + d] = z;
   }
   lw = wave_sum(lw);
-  if (lane == 0) a.lw[r] = lw;
+  if (lane != 0) return;
+  if (a.latl) {
+    const long src = a.lib_rows ? a.lib_rows[b] : b;
+    const float mu = a.latl[(long)b * a.ld_l], sig = softplusf(a.latl[(long)b * a.ld_l + 1] + SMX_SOFTPLUS_INV_1);
+    NoiseKey nl = a.nk_l;
+    nl.stream = (a.nk_l.stream & 0xFFu) | (((uint32_t)(a.s0 + s) & 0xFFFFFFu) << 8);
+    const float eps = normal4(philox_block(nl, cell, 0u)).x;
+    const float l = mu + sig * eps;
+    const float mp = a.library[src * 2], vp = a.library[src * 2 + 1];
+    lw += -0.5f * (l - mp) * (l - mp) / vp - 0.5f * logf(vp) + 0.5f * eps * eps + logf(sig);
+    a.l[r] = l;
+  }
+  a.lw[r] = lw;
 }
 
 int launch_score_draws(hipStream_t st, const ScoreDrawArgs& a) {
@@ -415,6 +427,113 @@ int launch_score_head(hipStream_t st, const ScoreHeadArgs& a_in) {
     case SMX_LLK_ZINBD: return launch_score_head_lk<SMX_LLK_ZINBD>(st, a, grid);
     default: set_error("score_head: unknown likelihood"); return SMX_ERR_INVALID;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// scvi (scvi.py:108-171): the rate is softmax over ALL genes of a row times exp(l), so the likelihood cannot ride on a
+// 32-gene tile of the product.  The k raw planes of the stacked rows are materialised (k products over S B rows), then
+// one workgroup per row keeps its planes in registers: max, sum, rate / dispersion / gate, the NBD / ZINBD log-likelihood
+// of the row's counts and its sum -- the activated planes and the softmax are never stored.
+__device__ inline float blk_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ inline float blk_max(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+template <int NV, int LK>
+__global__ __launch_bounds__(256) void scvi_score_rows_kernel(ScviScoreArgs a) {
+  constexpr bool ZI = (LK == SMX_LLK_ZINBD);
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  const float* raw = a.raw + (long)b * a.ld;
+  const int cell = b % a.row_mod;
+  const long src = a.rows ? a.rows[cell] : cell;
+  float4 r0[NV], r1[NV], r2[NV], xv[NV];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const bool ok = g < a.Gp;
+    r0[j] = ok ? *reinterpret_cast<const float4*>(raw + g) : z4;
+    r1[j] = ok ? *reinterpret_cast<const float4*>(raw + a.plane_stride + g) : z4;
+    r2[j] = (ok && ZI) ? *reinterpret_cast<const float4*>(raw + 2 * a.plane_stride + g) : z4;
+    if (!ok) xv[j] = z4;
+    else if (a.x_u16) { const ushort4 u = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(a.X) + src * a.ldx + g); xv[j] = make_float4(u.x, u.y, u.z, u.w); }
+    else xv[j] = *reinterpret_cast<const float4*>(a.X + src * a.ldx + g);
+  }
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const float v[4] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (g + e < a.G) mx = fmaxf(mx, v[e]);
+  }
+  mx = blk_max(mx, sh);
+  float ex[NV][4];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const float v[4] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ex[j][e] = (g + e < a.G) ? fexp(v[e] - mx) : 0.f;
+      sum += ex[j][e];
+    }
+  }
+  sum = blk_sum(sum, sh);
+  const float inv = 1.f / sum;
+  const float el = expf(fminf(fmaxf(a.l[b], 0.f), a.clip_library));
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int g = (threadIdx.x + 256 * j) * 4;
+    const float t[4] = {r1[j].x, r1[j].y, r1[j].z, r1[j].w};
+    const float gt[4] = {r2[j].x, r2[j].y, r2[j].z, r2[j].w};
+    const float xs[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+    float rate[4], th[4], gate[4], llk[4], d0[4], d1[4], d2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      rate[e] = el * fminf(fmaxf(ex[j][e] * inv, 1e-7f), 1.f - 1e-7f);
+      th[e] = fexp(t[e]);
+      gate[e] = gt[e];
+    }
+    count_elem_vec<LK, 1, 4>(xs, rate, th, gate, llk, d0, d1, d2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc += (g + e < a.G) ? llk[e] : 0.f;
+  }
+  acc = blk_sum(acc, sh);
+  if (threadIdx.x == 0) a.llk[b] = acc;
+}
+
+bool scvi_score_supported(int Gp) { return Gp % 4 == 0 && Gp <= 4096; }
+
+int launch_scvi_score_rows(hipStream_t st, const ScviScoreArgs& a) {
+  if (!scvi_score_supported(a.Gp) || a.R <= 0 || a.row_mod <= 0 || !a.raw || !a.l || !a.X || !a.llk || (a.likelihood != SMX_LLK_NBD && a.likelihood != SMX_LLK_ZINBD) ||
+      (a.likelihood == SMX_LLK_ZINBD && a.k != 3)) {
+    set_error("scvi_score_rows: bad arguments");
+    return SMX_ERR_INVALID;
+  }
+  const dim3 grid((unsigned)a.R), block(256);
+  if (a.Gp <= 2048) {
+    if (a.likelihood == SMX_LLK_ZINBD) hipLaunchKernelGGL((scvi_score_rows_kernel<2, SMX_LLK_ZINBD>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((scvi_score_rows_kernel<2, SMX_LLK_NBD>), grid, block, 0, st, a);
+  } else {
+    if (a.likelihood == SMX_LLK_ZINBD) hipLaunchKernelGGL((scvi_score_rows_kernel<4, SMX_LLK_ZINBD>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((scvi_score_rows_kernel<4, SMX_LLK_NBD>), grid, block, 0, st, a);
+  }
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
 }
 
 // one workgroup per cell, one wave per draw in turn: lanes over the head kernel's partial sums
