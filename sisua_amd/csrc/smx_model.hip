@@ -2969,6 +2969,8 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
   Pass ps;
   SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, 0, 0));
   const bool stacked = stacked_scoring_ok(m);
+  // a deterministic latent (DCA) decodes to the same parameters in every draw: one pass is the whole estimate
+  if (!m->stochastic) n_samples = 1;
   float* run = nullptr;   // [3][B]: running max, running sum, sum of log p(x|z)
   SMX_CHECK(score_aux(m, (size_t)3 * batch, &run));
   int rc = SMX_OK;
@@ -3011,6 +3013,7 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
 int smx_score_llk(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library,
                   const float* const* targets, int32_t n_targets, int32_t batch, int32_t n_samples, float* out) {
   SMX_REQUIRE(m && out && n_samples > 0 && n_targets >= 1 && n_targets <= 4, "bad arguments");
+  if (!m->stochastic) n_samples = 1;   // (deterministic latent: every draw decodes to the same parameters)
   Pass ps;
   SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, 0, 0));
   const int lk = m->cfg.likelihood;
