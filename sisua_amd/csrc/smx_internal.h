@@ -450,6 +450,8 @@ struct ScoreDrawArgs {
   const float* library = nullptr; const int32_t* lib_rows = nullptr;   // prior (mean, variance) per cell, indexed like lgx1
   NoiseKey nk_l{0, 0, 0, 0, nullptr};
   float* l = nullptr;                       // [S * B]
+  // SCALE: the trainable Gaussian-mixture prior replaces N(0, I) in log w (scale.py:13-49); Dp <= 64
+  const float* pr_logits = nullptr; const float* pr_loc = nullptr; const float* pr_scale_raw = nullptr; int C = 0;   // [C], [C][Dp], [C][Dp]
 };
 int launch_score_draws(hipStream_t st, const ScoreDrawArgs& a);
 struct ScoreBnArgs {

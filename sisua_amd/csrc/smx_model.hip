@@ -2796,10 +2796,11 @@ int smx_decode(smx_model* m, const float* z, const float* l, int32_t batch, floa
 
 // Stacked form (smx_score.hip): the encoder runs once, then the S draws of the B cells go through the decoder and the
 // output head as S * B rows at a time (scvi: its library latent drawn per row as well, the raw planes materialised and a
-// row-local softmax + likelihood launch, since its rate is normalised over all genes of a row).  SCALE's mixture prior
-// and deterministic latents keep the draw-by-draw loop.
+// row-local softmax + likelihood launch, since its rate is normalised over all genes of a row; SCALE: its mixture prior
+// in the latent part of log w).
 static bool stacked_scoring_ok(const smx_model* m) {
-  if (!m->flags.stacked_scoring || m->scale || !m->stochastic || m->use_injected || m->dec.empty()) return false;
+  if (!m->flags.stacked_scoring || !m->stochastic || m->use_injected || m->dec.empty()) return false;
+  if (m->scale && (m->Dp > 64 || m->cfg.n_components > 32)) return false;
   if (m->scvi && !scvi_score_supported(m->Gp)) return false;
   if (!head_loss_supported(1, m->dec.back().out_p, m->Gp) || (m->dec.back().out_p % 4)) return false;
   for (const MlpLayer& L : m->dec)
@@ -2876,6 +2877,9 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
     ScoreDrawArgs d;
     d.lat = m->latbuf; d.ld = 2 * m->Dp; d.B = B; d.D = m->D; d.Dp = m->Dp; d.S = S; d.s0 = s0;
     d.nk = make_key(m, ST_EPS_Z, 0, false); d.rows = ps.rows; d.cell_base = ps.cell_base; d.z = z; d.lw = lw;
+    if (m->scale) {
+      d.pr_logits = P_(m, m->t_prLogits); d.pr_loc = P_(m, m->t_prLoc); d.pr_scale_raw = P_(m, m->t_prScale); d.C = m->cfg.n_components;
+    }
     if (m->scvi) {
       d.latl = m->latlbuf; d.ld_l = 32; d.library = ps.lib; d.lib_rows = ps.rows; d.nk_l = make_key(m, ST_EPS_L, 0, false); d.l = lsmp;
     }

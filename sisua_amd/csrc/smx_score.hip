@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void score_draws_kernel(ScoreDrawArgs a) {
   NoiseKey nk = a.nk;
   nk.stream = (a.nk.stream & 0xFFu) | (((uint32_t)(a.s0 + s) & 0xFFFFFFu) << 8);
   float lw = 0.f;
+  float z_mine = 0.f;   // (mixture prior: Dp <= 64, lane d keeps z_d)
   for (int d = lane; d < a.Dp; d += 64) {
     float z = 0.f;
     if (d < a.D) {
@@ -36,11 +37,32 @@ __global__ __launch_bounds__(256) void score_draws_kernel(ScoreDrawArgs a) {
       const float4 n = normal4(philox_block(nk, cell, (uint32_t)(d >> 2)));
       const float eps = (d & 3) == 0 ? n.x : (d & 3) == 1 ? n.y : (d & 3) == 2 ? n.z : n.w;
       z = mu + sig * eps;
-      lw += -0.5f * z * z + 0.5f * eps * eps + logf(sig);   // log N(z; 0, I) - log N(z; mu, sigma), constants cancel
+      // log N(z; 0, I) - log N(z; mu, sigma), constants cancel (mixture prior: the q term only, the prior follows)
+      lw += (a.pr_logits ? 0.f : -0.5f * z * z) + 0.5f * eps * eps + (a.pr_logits ? flog(sig) : logf(sig));
     }
     a.z[r * a.Dp + d] = z;
+    z_mine = z;
   }
   lw = wave_sum(lw);
+  if (a.pr_logits) {
+    // log p(z) under the mixture, as scale_prior_fwd_kernel forms it: lane c keeps component c's joint log density
+    const float lg = lane < a.C ? a.pr_logits[lane] : -3.0e38f;
+    const float lmx = wave_max(lg);
+    const float lse = lmx + flog(wave_sum(lane < a.C ? fexp(lg - lmx) : 0.f));
+    float comp_mine = -3.0e38f;
+    for (int c = 0; c < a.C; ++c) {
+      float t = 0.f;
+      if (lane < a.D) {
+        const float sc = softplusf(a.pr_scale_raw[(long)c * a.Dp + lane] + SMX_SOFTPLUS_INV_1);
+        const float u = (z_mine - a.pr_loc[(long)c * a.Dp + lane]) * frcp(sc);
+        t = -0.5f * u * u - flog(sc);
+      }
+      t = wave_sum(t) + (a.pr_logits[c] - lse);
+      if (lane == c) comp_mine = t;
+    }
+    const float cmx = wave_max(comp_mine);
+    lw += cmx + flog(wave_sum(lane < a.C ? fexp(comp_mine - cmx) : 0.f));
+  }
   if (lane != 0) return;
   if (a.latl) {
     const long src = a.lib_rows ? a.lib_rows[b] : b;
@@ -57,7 +79,10 @@ __global__ __launch_bounds__(256) void score_draws_kernel(ScoreDrawArgs a) {
 }
 
 int launch_score_draws(hipStream_t st, const ScoreDrawArgs& a) {
-  if (a.S <= 0 || a.B <= 0 || a.Dp <= 0 || !a.lat || !a.z || !a.lw) { set_error("score_draws: bad arguments"); return SMX_ERR_INVALID; }
+  if (a.S <= 0 || a.B <= 0 || a.Dp <= 0 || !a.lat || !a.z || !a.lw || (a.pr_logits && (a.Dp > 64 || a.C < 2 || a.C > 32 || !a.pr_loc || !a.pr_scale_raw))) {
+    set_error("score_draws: bad arguments");
+    return SMX_ERR_INVALID;
+  }
   const long R = (long)a.S * a.B;
   hipLaunchKernelGGL(score_draws_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());

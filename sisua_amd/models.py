@@ -597,7 +597,7 @@ class SingleCellModel:
     (Posterior.cal_marginal_llk, analysis/posterior.py:941-976), computed on the GPU
     (`smx_marginal_llk`: encoder once; the draws of a batch then go through the decoder and the output head --
     fused with the forward-only likelihood -- stacked as rows of one pass, up to 16 384 rows at a time, with a running
-    log-sum-exp across passes; scvi / SCALE / deterministic latents decode draw by draw).
+    log-sum-exp across passes; scvi materialises its raw planes per pass and normalises row-locally).
     Returns (mllk[B], {output name: mean_s log p(x|z_s) [B]})."""
     arrs = _flatten(inputs)
     x = np.ascontiguousarray(arrs[0], dtype=np.float32)
