@@ -2647,17 +2647,52 @@ int smx_forward_samples(smx_model* m, const int32_t* row_ids, const float* host_
 // few large contiguous copies straight into its final place (48 GB/s into pageable memory as into pinned,
 // tools/pcie_probe.hip).  No per-batch result arrays, no host re-packing, no concatenation afterwards -- and no swarm
 // of small pitched copies (each a synchronous call: at batch 8 x 10 draws they cost 4x the whole old path).
-struct PackJob { float* dst; long dpitch; const float* src; long spitch; int width; int height; };
+// (n_rep repetitions of a job, e.g. the draws of a stacked pass: repetition q reads src + q src_rep, writes dst + q dst_rep)
+struct PackJob { float* dst; long dpitch; const float* src; long spitch; int width; int height; int n_rep; long dst_rep; long src_rep; };
 #define SMX_PACK_MAX 16
 struct PackJobs { int n; PackJob j[SMX_PACK_MAX]; };
 __global__ __launch_bounds__(256) void pack_kernel(PackJobs jobs_by_value) {
   const PackJobs& J = *(const PackJobs*)__builtin_amdgcn_kernarg_segment_ptr();   // (run-time job index: no scratch copy)
   const PackJob& j = J.j[blockIdx.y];
+  if ((int)blockIdx.z >= j.n_rep) return;
   const long total = (long)j.width * j.height;
+  float* dst = j.dst + (long)blockIdx.z * j.dst_rep;
+  const float* src = j.src + (long)blockIdx.z * j.src_rep;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long r = i / j.width, c = i % j.width;
-    j.dst[r * j.dpitch + c] = j.src[r * j.spitch + c];
+    dst[r * j.dpitch + c] = src[r * j.spitch + c];
   }
+}
+
+// Decoder layers over `rows` stacked rows (evaluation mode: moving statistics, no dropout; smx_score.hip).  The last
+// layer's output: last_form 0 row-major f32 in place, 1 k-major f32 in ht [Hp][rows], 2 its three-way bf16 split in ht.
+static bool stacked_scoring_ok(const smx_model* m);
+static int stacked_decoder(smx_model* m, const float* z, long rows, float* const* hb, int last_form, float* ht, const float** out, int* out_ld) {
+  const float* in = z;
+  int ld = m->Dp;
+  for (size_t i = 0; i < m->dec.size(); ++i) {
+    MlpLayer& L = m->dec[i];
+    GemmArgs g;
+    g.A = in; g.lda = ld; g.B = P_(m, L.tW); g.ldb = m->tensors[L.tW].ld;
+    g.M = (int)rows; g.N = L.out_p; g.K = L.in_p; g.C = hb[i & 1]; g.ldc = L.out_p; g.split_k = 1;
+    if (L.bn < 0) { g.bias = P_(m, L.tBias); g.act = 1; g.leak = L.leak; }
+    SMX_CHECK(launch_gemm(m->st, g));
+    const bool last = (i + 1 == m->dec.size());
+    if (L.bn >= 0 || (last && last_form != 0)) {
+      ScoreBnArgs b;
+      b.h = hb[i & 1]; b.R = rows; b.H = L.out; b.Hp = L.out_p; b.eps = m->cfg.bn_eps; b.leak = L.leak;
+      if (L.bn >= 0) {
+        b.gamma = P_(m, L.tGamma); b.beta = P_(m, L.tBeta);
+        b.moving_mean = m->bn_moving + m->bn_off[L.bn]; b.moving_var = b.moving_mean + L.out_p;
+      }
+      if (last && last_form == 1) { b.out_t = ht; b.ldt = rows; }
+      else if (last && last_form == 2) b.out3 = reinterpret_cast<__bf16*>(ht);
+      SMX_CHECK(launch_score_bn_act(m->st, b));
+    }
+    in = hb[i & 1]; ld = L.out_p;
+  }
+  *out = in; *out_ld = ld;
+  return SMX_OK;
 }
 
 int smx_predict(smx_model* m, const float* host_x, const float* host_library, int64_t n_cells, int32_t batch, int32_t n_samples,
@@ -2707,6 +2742,9 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
     SMX_HIP(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, m->st));
     return SMX_OK;
   };
+  int n_pack_y = 0;
+  for (int j = 0; j < m->n_heads; ++j) n_pack_y += wy[j] ? m->lab_ky[j] : 0;
+  const bool stack = S > 1 && stacked_scoring_ok(m) && !m->scvi && 1 + (int)k + n_pack_y <= SMX_PACK_MAX;
   for (size_t c0 = 0; c0 < N; c0 += C) {
     const size_t Cn = std::min(C, N - c0);   // cells of this chunk
     for (size_t b0 = 0; b0 < Cn; b0 += (size_t)batch) {
@@ -2714,6 +2752,87 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
       const size_t g0 = c0 + b0;
       Pass ps;
       SMX_CHECK(setup_pass(m, ps, nullptr, host_x + g0 * G, host_library ? host_library + g0 * 2 : nullptr, B, 0, 0));
+      if (stack) {
+        // ---- several draws: the encoder once, then the draws of this batch as rows of one decoder pass (as the scoring
+        // paths, smx_score.hip) -- at batch 8 x 10 draws (Posterior's defaults, posterior.py:114-115) the draw-by-draw form
+        // is 50 launches per 8 cells ----
+        ps.sample = 0;
+        SMX_CHECK(forward_pass(m, ps, false, false, 0));   // (also decodes draw 0 at batch size; not used)
+        int Hmax = 0, lab_floats = 0;
+        for (const MlpLayer& L : m->dec) Hmax = std::max(Hmax, L.out_p);
+        for (int j = 0; j < m->n_heads; ++j) lab_floats += s_y[j] ? m->tensors[m->t_labW[j]].ld : 0;
+        const size_t ldp = k * (size_t)m->Gp;
+        const int Sc = (int)std::min<size_t>(S, std::max<size_t>(1, (size_t)4096 / (size_t)B));   // draws per pass
+        const size_t R = (size_t)Sc * B;
+        const size_t need = R * ((size_t)Dp + 1 + 2 * (size_t)Hmax + ldp + (size_t)lab_floats);
+        if (need > m->score_floats) {
+          if (m->score_buf) { SMX_HIP(hipStreamSynchronize(m->st)); hipFree(m->score_buf); }
+          m->score_buf = nullptr; m->score_floats = 0;
+          SMX_CHECK(dmalloc(&m->score_buf, need));
+          m->score_floats = need;
+        }
+        float* zst = m->score_buf;
+        float* lwst = zst + R * Dp;
+        float* hb[2] = {lwst + R, lwst + R + R * Hmax};
+        float* Pst = hb[1] + R * Hmax;
+        float* yst = Pst + R * ldp;
+        {
+          PackJobs J; J.n = 0;
+          auto add1 = [&](float* dst, size_t dpitch, const float* src, size_t spitch, size_t width) {
+            if (!dst) return;
+            PackJob& q = J.j[J.n++];
+            q.dst = dst; q.dpitch = (long)dpitch; q.src = src; q.spitch = (long)spitch; q.width = (int)width; q.height = B; q.n_rep = 1; q.dst_rep = 0; q.src_rep = 0;
+          };
+          add1(s_zm ? s_zm + b0 * D : nullptr, D, m->latbuf, (size_t)lat_ld, D);
+          add1(s_zs ? s_zs + b0 * D : nullptr, D, m->sig, (size_t)Dp, D);
+          if (J.n) { hipLaunchKernelGGL(pack_kernel, dim3(8, (unsigned)J.n, 1), dim3(256), 0, m->st, J); SMX_HIP(hipGetLastError()); }
+        }
+        for (size_t s0 = 0; s0 < S; s0 += (size_t)Sc) {
+          const int Sn = (int)std::min<size_t>((size_t)Sc, S - s0);
+          const long rows = (long)Sn * B;
+          ScoreDrawArgs d;
+          d.lat = m->latbuf; d.ld = 2 * Dp; d.B = B; d.D = m->D; d.Dp = Dp; d.S = Sn; d.s0 = (int)s0;
+          d.nk = make_key(m, ST_EPS_Z, 0, false); d.rows = ps.rows; d.cell_base = ps.cell_base; d.z = zst; d.lw = lwst;
+          SMX_CHECK(launch_score_draws(m->st, d));
+          const float* hl = nullptr; int hld = 0;
+          SMX_CHECK(stacked_decoder(m, zst, rows, hb, 0, nullptr, &hl, &hld));
+          PackJobs J; J.n = 0;
+          auto addr = [&](float* dst, size_t dpitch, size_t dst_rep, const float* src, size_t spitch, size_t src_rep, size_t width) {
+            if (!dst || J.n >= SMX_PACK_MAX) return;
+            PackJob& q = J.j[J.n++];
+            q.dst = dst; q.dpitch = (long)dpitch; q.src = src; q.spitch = (long)spitch; q.width = (int)width; q.height = B;
+            q.n_rep = Sn; q.dst_rep = (long)dst_rep; q.src_rep = (long)src_rep;
+          };
+          addr(s_zd ? s_zd + (s0 * Cn + b0) * D : nullptr, D, Cn * D, zst, (size_t)Dp, (size_t)B * Dp, D);
+          if (s_xp) {
+            GemmArgs g;
+            g.A = hl; g.lda = hld; g.B = P_(m, m->t_outW[0]); g.ldb = m->tensors[m->t_outW[0]].ld;
+            g.C = Pst; g.ldc = (int)ldp; g.M = (int)rows; g.N = (int)ldp; g.K = hld; g.bias = P_(m, m->t_outb[0]); g.split_k = 1;
+            SMX_CHECK(launch_gemm(m->st, g));
+            for (size_t c = 0; c < k; ++c)
+              addr(s_xp + ((s0 * k + c) * Cn + b0) * G, G, k * Cn * G, Pst + c * (size_t)m->Gp, ldp, (size_t)B * ldp, G);
+          }
+          float* ycur = yst;
+          for (int j = 0; j < m->n_heads; ++j) {
+            if (!s_y[j]) continue;
+            const TensorInfo& tw = m->tensors[m->t_labW[j]];
+            GemmArgs g;
+            g.A = hl; g.lda = hld; g.B = P_(m, m->t_labW[j]); g.ldb = tw.ld;
+            g.C = ycur; g.ldc = tw.ld; g.M = (int)rows; g.N = tw.ld; g.K = hld; g.bias = P_(m, m->t_labb[j]); g.split_k = 1;
+            SMX_CHECK(launch_gemm(m->st, g));
+            const size_t P = (size_t)m->cfg.label_dim[j], Pp = (size_t)m->lab_Pp[j], ld = (size_t)tw.ld;
+            for (size_t c = 0; c < (size_t)m->lab_ky[j]; ++c)
+              addr(s_y[j] + (s0 * Cn + b0) * wy[j] + c * P, wy[j], Cn * wy[j], ycur + c * Pp, ld, (size_t)B * ld, P);
+            ycur += R * ld;
+          }
+          if (J.n) {
+            const unsigned gx = (unsigned)std::min<size_t>(64, ((size_t)B * std::max(G, D) + 255) / 256);
+            hipLaunchKernelGGL(pack_kernel, dim3(gx, (unsigned)J.n, (unsigned)Sn), dim3(256), 0, m->st, J);
+            SMX_HIP(hipGetLastError());
+          }
+        }
+        continue;
+      }
       for (size_t s = 0; s < S; ++s) {
         ps.sample = (int)s;
         // the encoders run once per batch (eval mode: no noise in them); later draws re-sample the latents and decode
@@ -2723,6 +2842,7 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
           if (!dst || J.n >= SMX_PACK_MAX) return;
           PackJob& q = J.j[J.n++];
           q.dst = dst; q.dpitch = (long)dpitch; q.src = src; q.spitch = (long)spitch; q.width = (int)width; q.height = B;
+          q.n_rep = 1; q.dst_rep = 0; q.src_rep = 0;
         };
         if (s == 0) {
           add(s_zm ? s_zm + b0 * D : nullptr, D, m->latbuf, (size_t)lat_ld, D);
@@ -2884,30 +3004,9 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
       d.latl = m->latlbuf; d.ld_l = 32; d.library = ps.lib; d.lib_rows = ps.rows; d.nk_l = make_key(m, ST_EPS_L, 0, false); d.l = lsmp;
     }
     SMX_CHECK(launch_score_draws(m->st, d));
-    const float* in = z;
-    int ld = m->Dp;
-    for (size_t i = 0; i < m->dec.size(); ++i) {
-      MlpLayer& L = m->dec[i];
-      GemmArgs g;
-      g.A = in; g.lda = ld; g.B = P_(m, L.tW); g.ldb = m->tensors[L.tW].ld;
-      g.M = (int)rows; g.N = L.out_p; g.K = L.in_p; g.C = hb[i & 1]; g.ldc = L.out_p; g.split_k = 1;
-      if (L.bn < 0) { g.bias = P_(m, L.tBias); g.act = 1; g.leak = L.leak; }
-      SMX_CHECK(launch_gemm(m->st, g));
-      const bool last = (i + 1 == m->dec.size());
-      if (L.bn >= 0 || last) {
-        ScoreBnArgs b;
-        b.h = hb[i & 1]; b.R = rows; b.H = L.out; b.Hp = L.out_p; b.eps = m->cfg.bn_eps; b.leak = L.leak;
-        if (L.bn >= 0) {
-          b.gamma = P_(m, L.tGamma); b.beta = P_(m, L.tBeta);
-          b.moving_mean = m->bn_moving + m->bn_off[L.bn]; b.moving_var = b.moving_mean + L.out_p;
-        }
-        if (last && m->scvi) { /* row-major f32, in place: the A operand of the plane products below */ }
-        else if (last && wide_head) { b.out_t = ht; b.ldt = rows; }
-        else if (last) b.out3 = reinterpret_cast<__bf16*>(ht);
-        if (b.gamma || b.out_t || b.out3) SMX_CHECK(launch_score_bn_act(m->st, b));
-      }
-      in = hb[i & 1]; ld = L.out_p;
-    }
+    const float* in = nullptr;
+    int ld = 0;
+    SMX_CHECK(stacked_decoder(m, z, rows, hb, m->scvi ? 0 : (wide_head ? 1 : 2), ht, &in, &ld));
     if (m->scvi) {
       for (int ch = 0; ch < m->k; ++ch) {
         GemmArgs g;

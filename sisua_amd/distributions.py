@@ -128,11 +128,23 @@ class Deterministic(Distribution):
 class NegativeBinomial(Distribution):
   """TFP convention: total_count r, logits l; mean = r exp(l)."""
 
-  def __init__(self, total_count, logits, name="NegativeBinomial"):
-    self.total_count, self.logits, self.name = np.asarray(total_count), np.asarray(logits), name
+  def __init__(self, total_count=None, logits=None, name="NegativeBinomial", log_total_count=None):
+    # the network emits log total_count: exp() of a whole prediction (75 MB for 940 cells x 10 draws) is only taken when
+    # somebody asks for total_count / mean / log_prob, not at construction (8 ms of a 26 ms predict call)
+    if (total_count is None) == (log_total_count is None):
+      raise ValueError("give total_count or log_total_count")
+    self._total_count = None if total_count is None else np.asarray(total_count)
+    self._log_total_count = None if log_total_count is None else np.asarray(log_total_count)
+    self.logits, self.name = np.asarray(logits), name
+
+  @property
+  def total_count(self):
+    if self._total_count is None:
+      self._total_count = np.exp(self._log_total_count)
+    return self._total_count
 
   def _params(self):
-    return [self.total_count, self.logits]
+    return [self._total_count if self._total_count is not None else self._log_total_count, self.logits]   # (shapes only)
 
   def mean(self):
     return self.total_count * np.exp(self.logits)
@@ -356,7 +368,7 @@ def count_distribution(likelihood: str, planes, name: str, activated: bool) -> D
   nb/zinb planes: (log total_count, logits[, gate]); nbd/zinbd: pre-activation
   (softplus mean, softplus1 dispersion) unless `activated` (scvi feeds mean/disp)."""
   if likelihood in ("nb", "zinb"):
-    base = NegativeBinomial(np.exp(planes[0]), planes[1], name="NegativeBinomial")
+    base = NegativeBinomial(logits=planes[1], name="NegativeBinomial", log_total_count=planes[0])
   else:
     if activated:
       mu, th = planes[0], planes[1]

@@ -21,9 +21,10 @@ for bs, S in ((128, ()), (32, ()), (128, 10), (8, 10)):
   dt = (time.perf_counter() - t) / 3
   print(f"predict {xs.shape[0]} cells batch {bs} sample_shape {S}: {dt * 1e3:.2f} ms -> {xs.shape[0] / dt:.0f} cells/s")
 if "--profile" in sys.argv:
+  S_prof = 10 if "--draws" in sys.argv else ()
   pr = cProfile.Profile(); pr.enable()
   for _ in range(5):
-    model.predict(xs, batch_size=128, verbose=False)
+    model.predict(xs, sample_shape=S_prof, batch_size=128, verbose=False)
   pr.disable()
   s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(18); print(s.getvalue()[:3500])
 t = time.perf_counter(); Z = model.encode(xs[:128]); print(f"encode 128 cells: {(time.perf_counter() - t) * 1e3:.2f} ms")
