@@ -1005,6 +1005,7 @@ static bool scvi_train_args(smx_model* m, const Pass& ps, ScviTrainArgs* out) {
 int factor_forward(smx_model* m, const Pass& ps, bool backward);
 int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, int mode = 0) {
   const bool decode_only = (mode == 1), resample = (mode == 2);
+  const bool encode_only = (mode == 3);   // encoders + latent heads + latent moments / draw 0, no decoder (the stacked-draw paths)
   const smx_config& c = m->cfg;
   const float inv_gb = 1.f / (float)ps.global_batch;
   const bool mid = (mode == 0) && use_mid(m, ps.B);
@@ -1049,7 +1050,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   la.z = m->z; la.sig = m->sig; la.eps = m->eps; la.kl = m->kl;
   // The latent sample + KL and the first decoder product run INSIDE the decoder's first BatchNorm launch (two
   // launches fewer) when the shapes allow; SMX_NO_FRONT=1 keeps the three-launch form.
-  front_ok = front_shapes_ok(m, ps) && (!la.inj_eps || (la.inj_ld % 4) == 0);
+  front_ok = !encode_only && front_shapes_ok(m, ps) && (!la.inj_eps || (la.inj_ld % 4) == 0);
   front_la = la;
   if (front_ok) {
     // (launched below with the decoder)
@@ -1093,6 +1094,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     }
   }
   }  // !decode_only
+  if (encode_only) return SMX_OK;
   // ---- decoder ----
   if (!mid) SMX_CHECK(mlp_forward(m, m->dec, ps, m->z, m->Dp, false, "", -1, front_ok ? &front_la : nullptr));
   const MlpLayer& dL = m->dec.back();
@@ -2757,7 +2759,7 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
         // paths, smx_score.hip) -- at batch 8 x 10 draws (Posterior's defaults, posterior.py:114-115) the draw-by-draw form
         // is 50 launches per 8 cells ----
         ps.sample = 0;
-        SMX_CHECK(forward_pass(m, ps, false, false, 0));   // (also decodes draw 0 at batch size; not used)
+        SMX_CHECK(forward_pass(m, ps, false, false, 3));   // encoder + latent moments only
         int Hmax = 0, lab_floats = 0;
         for (const MlpLayer& L : m->dec) Hmax = std::max(Hmax, L.out_p);
         for (int j = 0; j < m->n_heads; ++j) lab_floats += s_y[j] ? m->tensors[m->t_labW[j]].ld : 0;
@@ -2989,8 +2991,8 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
       at += per_plane * np;
     }
   }
-  // the encoder and the latent head (this pass also decodes draw 0 at batch size; its results are not used)
-  SMX_CHECK(forward_pass(m, ps, false, false, 0));
+  // the encoders and the latent heads
+  SMX_CHECK(forward_pass(m, ps, false, false, 3));
   for (int s0 = 0; s0 < n_samples; s0 += Sc) {
     const int S = std::min(Sc, n_samples - s0);
     const long rows = (long)S * B;
