@@ -202,23 +202,11 @@ static void launch_hl_w(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
 template <int LK>
 static void launch_hl(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
   if (a.llk_only) {
-    // waves per workgroup = ways K is split (measured at 128 cells x 1000 draws, 8 000 genes: 1 / 2 / 4 / 8 waves
-    // 3.45 / 3.28 / 3.42 / 3.84 ms: with hundreds of cell tiles the chip is full without the split, and every wave
-    // less means fewer partial tiles through LDS)
-    static const int lw = getenv("SMX_SCORE_HEAD_WAVES") ? atoi(getenv("SMX_SCORE_HEAD_WAVES")) : 2;
-    if (lw == 4) {
-      if (a.x_u16) hipLaunchKernelGGL((out_head_loss_kernel<LK, 1, 2, 4>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 2, 4>), grid, dim3(256), 0, st, a);
-    } else if (lw == 2) {
-      if (a.x_u16) hipLaunchKernelGGL((out_head_loss_kernel<LK, 1, 2, 2, 64>), grid, dim3(128), 0, st, a);
-      else hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 2, 2, 64>), grid, dim3(128), 0, st, a);
-    } else if (lw == 1) {
-      if (a.x_u16) hipLaunchKernelGGL((out_head_loss_kernel<LK, 1, 2, 1, 32>), grid, dim3(64), 0, st, a);
-      else hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 2, 1, 32>), grid, dim3(64), 0, st, a);
-    } else {
-      if (a.x_u16) hipLaunchKernelGGL((out_head_loss_kernel<LK, 1, 2, 8>), grid, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 2, 8>), grid, dim3(512), 0, st, a);
-    }
+    // 2 waves per workgroup (K slab 64): measured at 128 cells x 1000 draws, 8 000 genes with 1 / 2 / 4 / 8 / 16 waves:
+    // 3.45 / 3.28 / 3.42 / 3.84 / 5.77 ms -- with hundreds of cell tiles the chip is full without a deep split, and every
+    // wave less means fewer partial tiles through LDS (profiles/r02_scoring_path.txt)
+    if (a.x_u16) hipLaunchKernelGGL((out_head_loss_kernel<LK, 1, 2, 2, 64>), grid, dim3(128), 0, st, a);
+    else hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 2, 2, 64>), grid, dim3(128), 0, st, a);
     return;
   }
   if (head_waves() == 4) launch_hl_w<LK, 4>(st, a, grid);
