@@ -304,8 +304,9 @@ int smx_shuffle_order(int32_t n_obs, int32_t buffer, const int64_t* picks, int32
  * heads, side by side in one launch), "label_ride" (SISUA / MISA: the label heads' d d as extra slabs of the output
  * head's backward launch, their weight gradients in the grouped launch at the end), "act_epilogue" (layers without
  * BatchNorm and dropout, e.g. the FactorVAE discriminator: bias + activation and the activation's derivative in the
- * products' store paths), "stacked_scoring" (smx_marginal_llk: all posterior draws of a batch as rows of ONE decoder
- * pass, the output head fused with the likelihood; 0 = one decoder pass per draw; SMX_NO_STACKED_SCORING).
+ * products' store paths), "stacked_scoring" (smx_marginal_llk, smx_score_llk and smx_predict with several draws: all
+ * posterior draws of a batch as rows of ONE decoder pass, in the scoring calls the output head fused with the
+ * likelihood; 0 = one decoder pass per draw; SMX_NO_STACKED_SCORING).
  * value 1 = default form, 0 = separate launches.  Results agree to rounding;
  * used for A/B measurements and by the parity tests of both forms.  Defaults may also be set with SMX_NO_HEAD_LOSS /
  * SMX_NO_FRONT / SMX_NO_BWD_FRONT / SMX_NO_HEAD_BWD / SMX_NO_WGRAD / SMX_NO_SCVI_FUSED / SMX_NO_TWIN /
