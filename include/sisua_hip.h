@@ -226,9 +226,10 @@ int smx_forward_samples(smx_model* m, const int32_t* row_ids, const float* host_
  * concatenation").  host_x [n_cells, n_genes] (host_library [n_cells, 2] for scvi) is walked in minibatches of `batch`
  * (<= max_batch; the last one may be smaller) and every result is written straight to its final place:
  * z_mean / z_scale [n_cells, D]; l_mean / l_scale [n_cells]; z_samples [n_samples, n_cells, D]; l_samples
- * [n_samples, n_cells]; x_params [n_samples, k, n_cells, n_genes]; y_params[j] [n_samples, n_cells, ky * P_j].  Same numbers
+ * [n_samples, n_cells]; x_params [n_samples, k, n_cells, n_genes]; y_params[j] [n_samples, n_cells, ky * P_j].  Same draws
  * as smx_forward_samples batch by batch (draw s uses Philox sample index s; the noise of a cell is keyed by its index
- * within its minibatch, as there).  Any output may be NULL. */
+ * within its minibatch, as there); the same numbers bit for bit at one draw, to rounding with several (their decodes
+ * then run as rows of one pass, flag "stacked_scoring").  Any output may be NULL. */
 int smx_predict(smx_model* m, const float* host_x, const float* host_library, int64_t n_cells, int32_t batch,
                 int32_t n_samples, float* z_mean, float* z_scale, float* z_samples, float* l_mean, float* l_scale,
                 float* l_samples, float* x_params, float* const* y_params);
@@ -240,7 +241,8 @@ int smx_decode(smx_model* m, const float* z, const float* l, int32_t batch, floa
 
 /* Importance-weighted marginal log-likelihood, the scoring path of Posterior.cal_marginal_llk ->
  * scm.marginal_log_prob(**Xs, sample_shape=100) (sisua/analysis/posterior.py:941-976): the encoder runs once,
- * then n_samples times {sample z (Philox draw s), decoder, output head, forward-only likelihood kernel} with
+ * then the n_samples draws (z of draw s from Philox sample index s) go through decoder, output head and forward-only
+ * likelihood as rows of one pass (up to 16 384 rows at a time; flag "stacked_scoring" = 0: draw by draw) with
  * a running log-sum-exp per cell on the device.  mllk[batch] = log mean_s p(x|z_s) p(z_s) / q(z_s|x);
  * llk_mean[batch] = mean_s log p(x|z_s) (may be NULL).  Cells: row_ids or host_x (+ host_library for scvi). */
 int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,
