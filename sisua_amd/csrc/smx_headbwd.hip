@@ -147,7 +147,6 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
   const int cell = min(m0 + i, a.B - 1);       // rows beyond the minibatch compute garbage that nobody reads
   const float* ap = Ab + (long)cell * lda_b;
   const float* bp = (SEP && !extra) ? a.Wp[0] : Wb + (long)(h0 + i) * ldw_b;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // one 512-wide slab per iteration: lane (i, hh) of wave q supplies the 32 consecutive k at 64 q + 32 hh -- one whole
   // 128-byte line of row i of dP and of row h0 + i of W per lane (eight 16-byte loads each, unconditional: a
   // predicated 16-byte load is split into four 4-byte loads by the compiler, 4x the instructions at 32 lines each)

@@ -100,7 +100,6 @@ __device__ inline float col_sum(int B, int w, float* red, F f) {
 // BatchNorm + ReLU + Dropout on act (LDS, in place), saving xhat / out for the backward pass.
 __device__ inline void mid_bn_act(const MidArgs& a, const MidLayer& L, float* act, float* red) {
   const int w = L.out_p, B = a.B;
-  const int rg_n = MID_THREADS / w;
   const int c = threadIdx.x % w, rg = threadIdx.x / w;
   const bool live = c < L.out;
   float mean = 0.f, inv = 1.f, gamma = 1.f, beta = 0.f;
