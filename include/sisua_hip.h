@@ -213,8 +213,9 @@ int smx_forward(smx_model* m, const int32_t* row_ids, const float* host_x, const
 
 /* n_samples Monte-Carlo draws of one batch in ONE call: SingleCellModel.predict(sample_shape=n) as
  * Posterior._initialize uses it (sisua/analysis/posterior.py:172-182, sample_shape = 10).  The encoders run once (eval
- * mode); draw s re-samples the latents with Philox sample index s and decodes -- the same numbers as n_samples calls of
- * smx_forward(sample_index = s).  z_mean / z_scale [batch, D] and l_mean / l_scale [batch] once; z_samples
+ * mode); draw s re-samples the latents with Philox sample index s and decodes -- the same draws as n_samples calls of
+ * smx_forward(sample_index = s), and the same numbers to rounding (a host batch's draws are decoded as rows of one pass,
+ * as in smx_predict; bit for bit with flag "stacked_scoring" = 0 and for resident rows).  z_mean / z_scale [batch, D] and l_mean / l_scale [batch] once; z_samples
  * [n_samples, batch, D]; l_samples [n_samples, batch]; x_params [n_samples, k, batch, n_genes]; y_params[j]
  * [n_samples, batch, ky * P_j].  Any output may be NULL. */
 int smx_forward_samples(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,

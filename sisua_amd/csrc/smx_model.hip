@@ -2624,10 +2624,15 @@ int smx_forward(smx_model* m, const int32_t* row_ids, const float* host_x, const
   return fetch_forward(m, batch, z_mean, z_scale, z_sample, l_mean, l_scale, l_sample, x_params, y_params, 0);
 }
 
+static bool stacked_scoring_ok(const smx_model* m);
 int smx_forward_samples(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,
                         int32_t n_samples, float* z_mean, float* z_scale, float* z_samples, float* l_mean, float* l_scale,
                         float* l_samples, float* x_params, float* const* y_params) {
   SMX_REQUIRE(m && n_samples > 0, "bad arguments");
+  // several draws of a host batch: smx_predict over this one batch (same cell ids, same draws, same output layouts) decodes
+  // them as rows of one pass instead of one decoder pass per draw
+  if (!row_ids && host_x && n_samples > 1 && batch > 0 && batch <= m->Bmax && stacked_scoring_ok(m) && !m->scvi)
+    return smx_predict(m, host_x, host_library, batch, batch, n_samples, z_mean, z_scale, z_samples, l_mean, l_scale, l_samples, x_params, y_params);
   Pass ps;
   SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, 0, 0));
   const size_t B = (size_t)batch;
