@@ -178,15 +178,38 @@ __device__ inline LgDg lgamma_digamma_diff(float x, float r) {
 // ---------------------------------------------------------------------------
 // wave / block reductions (wave = 64)
 // ---------------------------------------------------------------------------
+// (four DPP steps inside the rows of 16, then two ds_bpermute across the four rows -- instead of six ds_bpermute)
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+#define SMX_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false))
+  SMX_DPP_ADD(0xB1);    // quad_perm [1, 0, 3, 2]
+  SMX_DPP_ADD(0x4E);    // quad_perm [2, 3, 0, 1]
+  SMX_DPP_ADD(0x141);   // row_half_mirror
+  SMX_DPP_ADD(0x140);   // row_mirror
+#undef SMX_DPP_ADD
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+// Sum over the 32 lanes of each half of a wave (lanes 0..31 and 32..63 separately), every lane gets its half's sum.
+// Four DPP steps inside the rows of 16 (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: ~8 cycles each) and ONE
+// ds_bpermute across the two rows of a half, instead of five ds_bpermute round trips through the LDS pipe.
+__device__ inline float half_wave_sum(float v) {
+#define SMX_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false))
+  SMX_DPP_ADD(0xB1);    // quad_perm [1, 0, 3, 2]
+  SMX_DPP_ADD(0x4E);    // quad_perm [2, 3, 0, 1]
+  SMX_DPP_ADD(0x141);   // row_half_mirror
+  SMX_DPP_ADD(0x140);   // row_mirror
+#undef SMX_DPP_ADD
+  return v + __shfl_xor(v, 16, 64);
 }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+#define SMX_DPP_MAX(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xF, 0xF, false)))
+  SMX_DPP_MAX(0xB1);
+  SMX_DPP_MAX(0x4E);
+  SMX_DPP_MAX(0x141);
+  SMX_DPP_MAX(0x140);
+#undef SMX_DPP_MAX
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
 }
 
 }  // namespace smx

@@ -173,9 +173,7 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
     }
     if (EPI) {
       // per-cell partial over the tile's 32 genes: the 32 lanes of this half hold them
-      float t = ok ? llk[j] : 0.f;
-#pragma unroll
-      for (int off = 1; off < 32; off <<= 1) t += __shfl_xor(t, off, 64);
+      const float t = half_wave_sum(ok ? llk[j] : 0.f);
       if (i == 0 && cell < a.B) a.llk_part[(long)cell * a.n_gt + gt] = t;
     }
   }
