@@ -87,7 +87,8 @@ __device__ inline float4 normal4(const U4& w) {
 // these: __logf expands to the denormal-safe log (v_ldexp + v_log + a 4-term correction, 14 instructions),
 // __frcp_rn to the correctly rounded division (v_div_scale / v_div_fmas / v_div_fixup, 10 instructions); together
 // they were half of the likelihood kernel's ~500 vector instructions per element.  Every argument here is a
-// normal float (1 + e, rising factorials >= 1e-30, mu + 1e-8, ...), so the denormal paths bought nothing.
+// normal float (1 + e, rising factorials >= 1e-30, mu + 1e-8, ...; the Stirling shift keeps its numerator and
+// denominator apart for that reason), so the denormal paths bought nothing.
 __device__ inline float fexp(float x) { return __expf(x); }                                        // v_mul + v_exp
 __device__ inline float flog(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }   // v_log (log2) + v_mul
 __device__ inline float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -157,16 +158,19 @@ __device__ inline LgDg lgamma_digamma_diff(float x, float r) {
   // series is differenced analytically (no cancellation of two large lgamma values); at z >= 4 the three
   // correction terms leave < 4e-8 (lgamma) / 6e-8 (digamma).
   const float nf = fmaxf(ceilf(4.0f - r), 0.f);
-  float ratio = 1.f, dg_shift = 0.f;
+  // (numerator and denominator of prod (r+i)/(x+r+i) kept apart: their ratio falls below the smallest normal float for
+  // tiny r and large x -- r = 1e-30, x = 1e3 gives 6e-42 -- where v_log_f32 returns -inf; each product alone stays normal:
+  // num >= 1e-30, den <= (x + 4)^4)
+  float num = 1.f, den = 1.f, dg_shift = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float a = r + (float)i, b = x + a;
     const bool on = (float)i < nf;
-    const float ib = frcp(b);
-    ratio = on ? ratio * a * ib : ratio;
-    dg_shift = on ? dg_shift + x * ib * frcp(a) : dg_shift;
+    num = on ? num * a : num;
+    den = on ? den * b : den;
+    dg_shift = on ? dg_shift + x * frcp(b) * frcp(a) : dg_shift;
   }
-  const float lg_shift = flog(ratio);
+  const float lg_shift = flog(num) - flog(den);
   const float rs = r + nf;
   const float zr = x + rs;
   const float l1p = log1p_small(x * frcp(rs));

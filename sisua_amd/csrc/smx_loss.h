@@ -94,16 +94,16 @@ __device__ inline void lgamma_digamma_diff_vec(const float (&x)[N], const float 
   for (int e = 0; e < N; ++e) {
     const bool small = (x[e] <= 8.0f) && (x[e] == floorf(x[e])) && (r[e] < 1e4f);
     const float nf = fmaxf(ceilf(4.0f - r[e]), 0.f);
-    float ratio = 1.f, dg_shift = 0.f;
+    float num = 1.f, den = 1.f, dg_shift = 0.f;   // kept apart: see lgamma_digamma_diff
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float a = r[e] + (float)i, b = x[e] + a;
       const bool on = (float)i < nf;
-      const float ib = frcp(b);
-      ratio = on ? ratio * a * ib : ratio;
-      dg_shift = on ? dg_shift + x[e] * ib * frcp(a) : dg_shift;
+      num = on ? num * a : num;
+      den = on ? den * b : den;
+      dg_shift = on ? dg_shift + x[e] * frcp(b) * frcp(a) : dg_shift;
     }
-    const float lg_shift = flog(ratio);
+    const float lg_shift = flog(num) - flog(den);
     const float rs = r[e] + nf;
     const float zr = x[e] + rs;
     const float l1p = log1p_small(x[e] * frcp(rs));

@@ -2656,7 +2656,9 @@ int smx_forward_samples(smx_model* m, const int32_t* row_ids, const float* host_
 // of small pitched copies (each a synchronous call: at batch 8 x 10 draws they cost 4x the whole old path).
 // (n_rep repetitions of a job, e.g. the draws of a stacked pass: repetition q reads src + q src_rep, writes dst + q dst_rep)
 struct PackJob { float* dst; long dpitch; const float* src; long spitch; int width; int height; int n_rep; long dst_rep; long src_rep; };
-#define SMX_PACK_MAX 16
+// A job list travels as a kernel argument (2 KB); a pass that needs more jobs than fit (MISA with four components: 3 latent +
+// 3 planes + 12 label planes) launches the full list and starts the next one -- jobs are independent of each other.
+#define SMX_PACK_MAX 32
 struct PackJobs { int n; PackJob j[SMX_PACK_MAX]; };
 __global__ __launch_bounds__(256) void pack_kernel(PackJobs jobs_by_value) {
   const PackJobs& J = *(const PackJobs*)__builtin_amdgcn_kernarg_segment_ptr();   // (run-time job index: no scratch copy)
@@ -2749,9 +2751,7 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
     SMX_HIP(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, m->st));
     return SMX_OK;
   };
-  int n_pack_y = 0;
-  for (int j = 0; j < m->n_heads; ++j) n_pack_y += wy[j] ? m->lab_ky[j] : 0;
-  const bool stack = S > 1 && stacked_scoring_ok(m) && !m->scvi && 1 + (int)k + n_pack_y <= SMX_PACK_MAX;
+  const bool stack = S > 1 && stacked_scoring_ok(m) && !m->scvi;
   for (size_t c0 = 0; c0 < N; c0 += C) {
     const size_t Cn = std::min(C, N - c0);   // cells of this chunk
     for (size_t b0 = 0; b0 < Cn; b0 += (size_t)batch) {
@@ -2804,8 +2804,17 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
           const float* hl = nullptr; int hld = 0;
           SMX_CHECK(stacked_decoder(m, zst, rows, hb, 0, nullptr, &hl, &hld));
           PackJobs J; J.n = 0;
+          int pack_err = SMX_OK;
+          auto flush = [&]() {
+            if (!J.n || pack_err != SMX_OK) return;
+            const unsigned gx = (unsigned)std::min<size_t>(64, ((size_t)B * std::max(G, D) + 255) / 256);
+            hipLaunchKernelGGL(pack_kernel, dim3(gx, (unsigned)J.n, (unsigned)Sn), dim3(256), 0, m->st, J);
+            if (hipGetLastError() != hipSuccess) { set_error("pack_kernel launch failed"); pack_err = SMX_ERR_HIP; }
+            J.n = 0;
+          };
           auto addr = [&](float* dst, size_t dpitch, size_t dst_rep, const float* src, size_t spitch, size_t src_rep, size_t width) {
-            if (!dst || J.n >= SMX_PACK_MAX) return;
+            if (!dst) return;
+            if (J.n == SMX_PACK_MAX) flush();
             PackJob& q = J.j[J.n++];
             q.dst = dst; q.dpitch = (long)dpitch; q.src = src; q.spitch = (long)spitch; q.width = (int)width; q.height = B;
             q.n_rep = Sn; q.dst_rep = (long)dst_rep; q.src_rep = (long)src_rep;
@@ -2832,11 +2841,8 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
               addr(s_y[j] + (s0 * Cn + b0) * wy[j] + c * P, wy[j], Cn * wy[j], ycur + c * Pp, ld, (size_t)B * ld, P);
             ycur += R * ld;
           }
-          if (J.n) {
-            const unsigned gx = (unsigned)std::min<size_t>(64, ((size_t)B * std::max(G, D) + 255) / 256);
-            hipLaunchKernelGGL(pack_kernel, dim3(gx, (unsigned)J.n, (unsigned)Sn), dim3(256), 0, m->st, J);
-            SMX_HIP(hipGetLastError());
-          }
+          flush();
+          SMX_CHECK(pack_err);
         }
         continue;
       }
@@ -2845,8 +2851,17 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
         // the encoders run once per batch (eval mode: no noise in them); later draws re-sample the latents and decode
         SMX_CHECK(forward_pass(m, ps, false, false, s == 0 ? 0 : 2));
         PackJobs J; J.n = 0;
+        int pack_err = SMX_OK;
+        auto flush = [&]() {
+          if (!J.n || pack_err != SMX_OK) return;
+          const unsigned gx = (unsigned)std::min<size_t>(256, ((size_t)B * std::max(G, D) + 255) / 256);
+          hipLaunchKernelGGL(pack_kernel, dim3(gx, (unsigned)J.n), dim3(256), 0, m->st, J);
+          if (hipGetLastError() != hipSuccess) { set_error("pack_kernel launch failed"); pack_err = SMX_ERR_HIP; }
+          J.n = 0;
+        };
         auto add = [&](float* dst, size_t dpitch, const float* src, size_t spitch, size_t width) {
-          if (!dst || J.n >= SMX_PACK_MAX) return;
+          if (!dst) return;
+          if (J.n == SMX_PACK_MAX) flush();
           PackJob& q = J.j[J.n++];
           q.dst = dst; q.dpitch = (long)dpitch; q.src = src; q.spitch = (long)spitch; q.width = (int)width; q.height = B;
           q.n_rep = 1; q.dst_rep = 0; q.src_rep = 0;
@@ -2866,11 +2881,8 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
           const size_t P = (size_t)m->cfg.label_dim[j], Pp = (size_t)m->lab_Pp[j], ld = (size_t)m->tensors[m->t_labW[j]].ld;
           for (size_t c = 0; c < (size_t)m->lab_ky[j]; ++c) add(s_y[j] + (s * Cn + b0) * wy[j] + c * P, wy[j], m->laby_raw[j] + c * Pp, ld, P);
         }
-        if (J.n) {
-          const unsigned gx = (unsigned)std::min<size_t>(256, ((size_t)B * std::max(G, D) + 255) / 256);
-          hipLaunchKernelGGL(pack_kernel, dim3(gx, (unsigned)J.n), dim3(256), 0, m->st, J);
-          SMX_HIP(hipGetLastError());
-        }
+        flush();
+        SMX_CHECK(pack_err);
       }
     }
     // ---- the chunk leaves the device: every segment's rows are contiguous here and in the caller's arrays ----

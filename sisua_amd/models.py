@@ -336,7 +336,9 @@ class SingleCellModel:
     ep0 = it // spe
     it_end = (int(epochs) if epochs_are_total else ep0 + int(epochs)) * spe
     if max_iter and max_iter > 0:
-      it_end = min(it_end, it + int(max_iter))
+      # a resumed run (`epochs_are_total`: the schedule counts from step 0 of the experiment, train.py) keeps the ORIGINAL
+      # cap: max_iter is then an absolute step count as well, not `max_iter` more steps from the restored one
+      it_end = min(it_end, int(max_iter) if epochs_are_total else it + int(max_iter))
     best, bad, t_log, stop = np.inf, 0, time.time(), False
     pool = ThreadPoolExecutor(max_workers=1)
     # One library call covers every step up to the next event on the host's side -- a validation pass, the end of the

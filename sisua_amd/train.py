@@ -92,7 +92,11 @@ class Experiment:
         self.cfg[k] = v
     self.hash = config_hash(self.cfg)
     if model_dir is None and save_path is not None:
-      model_dir = os.path.join(save_path, f"exp_{self.hash}")
+      # SISUA_EXP names the experiments' ROOT as in the reference (train.py:49-59: one `exp_<hash>` directory per
+      # configuration).  A directory that already holds a checkpoint itself (SISUA_EXP meant the model directory before
+      # round 2) keeps being found: it is used as it is.
+      legacy = any(os.path.exists(os.path.join(save_path, f)) for f in ("model.npz", "model.metamodel"))
+      model_dir = save_path if legacy else os.path.join(save_path, f"exp_{self.hash}")
     self.model_dir = model_dir
     self.resumed_from = 0
 

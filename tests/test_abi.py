@@ -51,6 +51,51 @@ def test_config_struct_layout_matches_header(tmp_path):
       assert int(got[f"{st}.{name}"]) == getattr(cls, name).offset, (st, name)
 
 
+def _gcc_layout(tmp_path, structs):
+  """sizeof / offsetof of the named structures' fields as gcc lays include/sisua_hip.h out: {'smx_config': size, 'smx_config.field': offset}"""
+  import subprocess
+  lines = []
+  for st, fields in structs.items():
+    lines.append(f'printf("{st} %zu\\n", sizeof({st}));')
+    lines += [f'printf("{st}.{name} %zu\\n", offsetof({st}, {name}));' for name in fields]
+  src = tmp_path / "layout2.c"
+  src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sisua_hip.h"\nint main(void) {\n' + "\n".join(lines) +
+                 '\nprintf("abi %d\\n", SMX_ABI_VERSION);\nreturn 0; }\n')
+  exe = tmp_path / "layout2"
+  subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+  return {k: int(v) for k, v in (l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())}
+
+
+def test_integration_snippet_matches_header(tmp_path):
+  """The ctypes stub a maintainer copies from INTEGRATION.md section B is the header's layout: the fenced structure block is
+  executed, and sizeof / EVERY field offset / the ABI version are compared with what gcc makes of include/sisua_hip.h (a stale
+  stub mis-offsets every later field silently, VERDICT r02 row b).  The block is generated (tools/gen_integration_stub.py);
+  the generator's --check mode must agree, and the field NAMES must be exactly the header's, in order."""
+  import ctypes as C
+  import subprocess
+  import sys
+  doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+  m = re.search(r"<!-- stub:structs:begin.*?-->\s*```python\n(.*?)```\s*<!-- stub:structs:end -->", doc, flags=re.S)
+  assert m, "INTEGRATION.md lost its generated structure block"
+  ns = {}
+  exec(m.group(1), ns)
+  structs = {st: [n for n, _ in ns[st]._fields_] for st in ("smx_config", "smx_metrics")}
+  got = _gcc_layout(tmp_path, structs)
+  assert ns["SMX_ABI_VERSION"] == got["abi"]
+  for st, fields in structs.items():
+    assert C.sizeof(ns[st]) == got[st], st
+    for name in fields:
+      assert getattr(ns[st], name).offset == got[f"{st}.{name}"], (st, name)
+  # same fields as the binding the product uses, and no literal version left in the usage example
+  from sisua_amd import _hip
+  for st in structs:
+    assert structs[st] == [n for n, _ in getattr(_hip, st)._fields_], st
+  usage = doc[m.end():]
+  assert "abi_version=SMX_ABI_VERSION" in usage and not re.search(r"abi_version\s*=\s*\d", usage)
+  r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_integration_stub.py"), "--check"], capture_output=True, text=True)
+  assert r.returncode == 0, r.stderr + r.stdout
+
+
 def test_no_cpu_fallback(lib):
   from sisua_amd import _hip
   from sisua_amd.config import ModelConfig

@@ -84,6 +84,29 @@ def test_count_llk_edge_grid(eng, lk):
     assert (err <= tol).all(), (lk, i, err.max(), np.unravel_index(np.argmax(err - tol), err.shape))
 
 
+@pytest.mark.parametrize("lk", ["nb", "zinb"])
+def test_count_llk_tiny_total_count_stays_finite(eng, lk):
+  """log total_count down to -69 (r = 1e-30, the kernel's clamp) with counts from 9 to 1e5: the Stirling branch's shift
+  prod (r+i)/(x+r+i) is ~1e-42 there, below the smallest normal float, where v_log_f32 returns -inf -- its
+  numerator and denominator are kept apart, and the result must agree with the float64 oracle."""
+  xs = np.array([9, 50, 181, 1000, 10738, 65535, 100000], np.float32)
+  a = np.array([-69.0, -60.0, -46.0, -30.0, -12.0], np.float32)
+  l = np.array([-3.0, 0.0, 2.0], np.float32)
+  X, A, L = [v.ravel() for v in np.meshgrid(xs, a, l, indexing="ij")]
+  n = X.size
+  G = 32
+  pad = (-n) % G
+  f = lambda v: np.concatenate([v, np.zeros(pad, np.float32)]).reshape(-1, G).astype(np.float32)
+  x, pa, pl = f(X), f(A), f(L)
+  planes = [pa, pl, np.zeros_like(pa)][: so.n_params_per_gene(lk)]
+  llk, grads = eng.k_count_llk(lk, x, np.stack(planes))
+  ref_e, ref_g = so.count_llk(x.astype(np.float64), [p.astype(np.float64) for p in planes], lk)
+  assert np.isfinite(llk).all() and np.isfinite(grads).all()
+  assert np.allclose(llk, ref_e.sum(1), rtol=1e-4, atol=1e-2)
+  for i in range(len(planes)):
+    assert (np.abs(grads[i] - ref_g[i]) <= 1e-4 * np.abs(ref_g[i]) + 1e-4 * (1 + np.abs(x))).all(), (lk, i)
+
+
 @pytest.mark.parametrize("lk", ["nbd", "zinbd"])
 def test_count_llk_direct_mode(eng, lk):
   rng = np.random.default_rng(4)

@@ -662,3 +662,29 @@ def test_forward_samples_equals_repeated_forward(Engine, name):
     assert np.array_equal(many["z_mean"], one["z_mean"])
     assert not np.array_equal(many["z_sample"][0], many["z_sample"][1])
   e.close()
+
+
+@pytest.mark.parametrize("labels", [((9, "mixnb4"),), ((6, "mixnb2"), (5, "mixnb2")),
+                                    ((5, "mixnb4"), (4, "mixnb4"), (3, "mixnb4"), (6, "mixnb4"))])
+@pytest.mark.parametrize("S", [1, 3])
+def test_predict_packs_every_label_plane(Engine, labels, S):
+  """smx_predict hands its outputs to one pack launch per pass; a MISA model with four mixture components (3 latent + 3
+  count planes + 12 label planes) or several mixture label heads needs more pack jobs than one launch's argument list
+  held in round 2, and the planes beyond it were silently left out.  Every plane of every head must equal
+  what smx_forward returns minibatch by minibatch -- bit for bit at one draw, to rounding with several (stacked decode)."""
+  kw = dict(model="sisua", n_genes=90, likelihood="zinb", enc_units=(32,), dec_units=(32,), latent_dim=6, labels=labels)
+  spec, cfg, x, ys, lib, mask = _problem(kw, n=100)
+  e = Engine(cfg, max_batch=40)
+  e.upload(x, ys, lib, mask)
+  got = e.predict(x, n_samples=S, batch=40)
+  for b0 in range(0, 100, 40):
+    xb = x[b0:b0 + 40]
+    for s in range(S):
+      one = e.forward(x=xb, sample_index=s)
+      cmp = np.array_equal if S == 1 else (lambda a, b: np.allclose(a, b, rtol=2e-5, atol=2e-5))
+      assert cmp(got["x_params"][s][:, b0:b0 + 40], one["x_params"])
+      assert cmp(got["z_sample"][s][b0:b0 + 40], one["z_sample"])
+      for j, (a, b) in enumerate(zip(got["y_params"], one["y_params"])):
+        assert np.isfinite(a).all() and cmp(a[s][b0:b0 + 40], b), (j, s, b0)
+    assert np.array_equal(got["z_mean"][b0:b0 + 40], one["z_mean"])
+  e.close()
