@@ -322,7 +322,9 @@ int smx_set_flag(smx_model* m, const char* name, int value);
  * "out_head_product" (the same kernel without the likelihood: what the fused kernel's time is compared with), "loss"
  * (the standalone likelihood kernel, flag head_loss = 0), "gemm_enc_fwd", "gemm_out_fwd", "gemm_out_bwd" (dW + dX of the head),
  * "gemm_enc_dw", "bn_fwd", "bn_bwd", "adam", "allreduce", "step", or "null" (an event pair around
- * nothing: the overhead to subtract from single-kernel timings).  Enable, run steps, read. */
+ * nothing: the overhead to subtract from single-kernel timings).  "out_head@N" / "out_head_product@N" / "loss@N": N
+ * launches per event pair instead of 8 (N = 1: the single launch rocprofv3's per-kernel duration is compared with).
+ * Enable, run steps, read. */
 int smx_timing_enable(smx_model* m, const char* kernel);
 int smx_timing_read(smx_model* m, double* total_ms, int64_t* launches);
 /* Algorithmic bytes (fwd+bwd loss kernel = (4+8k)G + 16D + 4 per cell). */

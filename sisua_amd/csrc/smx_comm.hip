@@ -1,0 +1,243 @@
+// smx_comm.hip -- data parallel: RCCL resolution, the loopback communicator of the tests, the all-reduce of the flat buffer.
+#include "smx_model.h"
+
+namespace smx {
+
+RcclApi g_rccl;
+
+std::string path_of_symbol(const void* sym) {
+  Dl_info info;
+  if (sym && dladdr(sym, &info) && info.dli_fname) {
+    char real[PATH_MAX];
+    return realpath(info.dli_fname, real) ? std::string(real) : std::string(info.dli_fname);
+  }
+  return "";
+}
+
+// RCCL is resolved DETERMINISTICALLY as the sibling of the HIP runtime this process actually runs on: a process
+// holds exactly one libamdhip64.so.7 (ROCm's, or the copy bundled with torch when torch was imported first -- same
+// soname), and the communication library must have been built against that one.  A bare dlopen("librccl.so.1")
+// would return whichever copy happens to be mapped already.  SMX_RCCL_PATH overrides; smx_comm_library() reports.
+int load_rccl() {
+  if (g_rccl.lib) return SMX_OK;
+  g_rccl.hip_path = path_of_symbol((const void*)&hipGetDeviceCount);
+  std::vector<std::string> cands;
+  if (const char* e = getenv("SMX_RCCL_PATH")) cands.push_back(e);
+  const size_t slash = g_rccl.hip_path.rfind('/');
+  if (slash != std::string::npos) {
+    const std::string dir = g_rccl.hip_path.substr(0, slash + 1);
+    cands.push_back(dir + "librccl.so.1");
+    cands.push_back(dir + "librccl.so");
+  }
+  cands.push_back("librccl.so.1");
+  cands.push_back("librccl.so");
+  void* h = nullptr;
+  std::string why;
+  for (const std::string& c : cands) {
+    if (c.find('/') != std::string::npos && access(c.c_str(), R_OK) != 0) continue;
+    h = dlopen(c.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+    why = dlerror();
+  }
+  if (!h) { set_error("cannot load librccl (looked beside " + g_rccl.hip_path + "): " + why); return SMX_ERR_COMM; }
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+  g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_rccl.GetVersion = (decltype(g_rccl.GetVersion))dlsym(h, "ncclGetVersion");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+    set_error("librccl lacks a required symbol");
+    dlclose(h);
+    return SMX_ERR_COMM;
+  }
+  g_rccl.path = path_of_symbol((const void*)g_rccl.AllReduce);
+  // the bound RCCL must sit on the SAME HIP runtime as this library: two runtimes in one process do not share
+  // streams.  RCCL's own libamdhip64 dependency resolves by soname to the mapped copy, so it suffices that
+  // only one copy is mapped -- checked by asking the dynamic loader where RCCL's hipMalloc would come from.
+  if (void* sym = dlsym(h, "hipGetDeviceCount")) {   // found through RCCL's dependency chain
+    const std::string theirs = path_of_symbol(sym);
+    if (!theirs.empty() && !g_rccl.hip_path.empty() && theirs != g_rccl.hip_path) {
+      set_error("librccl (" + g_rccl.path + ") runs on " + theirs + " but libsisua_hip on " + g_rccl.hip_path);
+      dlclose(h);
+      return SMX_ERR_COMM;
+    }
+  }
+  g_rccl.lib = h;
+  return SMX_OK;
+}
+
+struct LocalSrc { const float* p[SMX_LOCAL_MAX]; int n; };
+__global__ void local_sum_kernel(LocalSrc s, float* dst, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = s.p[0][i];
+    for (int r = 1; r < s.n; ++r) acc += s.p[r][i];
+    dst[i] = acc;
+  }
+}
+
+// data-parallel overlap: two buckets on a communication stream (eager launches only)
+bool dp_active(const smx_model* m) {
+  // dp_force: exercise RCCL on a 1-rank communicator (tests); local: the loopback communicator of the tests
+  return (m->comm && (m->world > 1 || m->dp_force)) || (m->local && m->world > 1);
+}
+// Measured on a 1-rank communicator: the cross-stream events of the two-bucket form cost +42 us per step,
+// one all-reduce on the model's own stream +2.6 us.  The overlap only pays when the collective itself is
+// much longer than that, so the default is the single all-reduce; SMX_DP_BUCKETS=2 selects the overlap.
+bool dp_overlap(const smx_model* m) {
+  return dp_active(m) && m->dp_two_buckets && !m->capturing && m->st_comm != nullptr && !m->local;
+}
+int local_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
+  LocalGroup& g = *m->local;
+  const int me = m->rank;
+  SMX_REQUIRE(count <= m->local_scratch_cap, "loopback all-reduce: scratch too small");
+  { std::lock_guard<std::mutex> lk(g.mu); g.src[me] = buf; }
+  SMX_HIP(hipEventRecord(g.ready[me], st));
+  if (!g.barrier()) { set_error("loopback communicator: a member did not arrive (timeout)"); return SMX_ERR_COMM; }
+  LocalSrc src;
+  src.n = g.world;
+  for (int r = 0; r < g.world; ++r) {
+    src.p[r] = g.src[r];
+    if (r != me) SMX_HIP(hipStreamWaitEvent(st, g.ready[r], 0));
+  }
+  const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, 2048);
+  hipLaunchKernelGGL(local_sum_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, m->local_scratch, count);
+  SMX_HIP(hipEventRecord(g.done[me], st));
+  if (!g.barrier()) { set_error("loopback communicator: a member did not arrive (timeout)"); return SMX_ERR_COMM; }
+  for (int r = 0; r < g.world; ++r)
+    if (r != me) SMX_HIP(hipStreamWaitEvent(st, g.done[r], 0));   // nobody still reads this rank's buffer
+  SMX_HIP(hipMemcpyAsync(buf, m->local_scratch, count * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return SMX_OK;
+}
+int dp_allreduce_buf(smx_model* m, float* buf, size_t count, hipStream_t st) {
+  if (m->local) return local_allreduce(m, buf, count, st);
+  ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclFloat32, ncclSum, m->comm, st);
+  if (r != ncclSuccess) {
+    set_error(std::string("ncclAllReduce failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    return SMX_ERR_COMM;
+  }
+  return SMX_OK;
+}
+int dp_allreduce(smx_model* m, size_t off, size_t count, hipStream_t st) { return dp_allreduce_buf(m, m->grads + off, count, st); }
+
+}  // namespace smx
+
+extern "C" {
+
+int smx_comm_unique_id(uint8_t id[128]) {
+  SMX_CHECK(load_rccl());
+  ncclUniqueId uid;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclResult_t r = g_rccl.GetUniqueId(&uid);
+  if (r != ncclSuccess) { set_error("ncclGetUniqueId failed"); return SMX_ERR_COMM; }
+  memcpy(id, &uid, 128);
+  return SMX_OK;
+}
+
+static int comm_detach(smx_model* m) {   // leave whatever communicator the model is in
+  if (m->st) SMX_HIP(hipStreamSynchronize(m->st));
+  if (m->st_comm) SMX_HIP(hipStreamSynchronize(m->st_comm));
+  if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
+  m->comm = nullptr;
+  m->local.reset();
+  m->rank = 0; m->world = 1;
+  drop_graphs(m);
+  return SMX_OK;
+}
+
+static int ensure_sync_buf(smx_model* m) {
+  int wmax = 0;
+  for (int w : m->bn_wp) wmax = std::max(wmax, w);
+  const size_t need = (size_t)m->world * 2 * (size_t)wmax;
+  if (!m->sync_bn || need <= m->sync_cap) return SMX_OK;
+  if (m->sync_buf) hipFree(m->sync_buf);
+  m->sync_buf = nullptr; m->sync_cap = 0;
+  SMX_CHECK(dmalloc(&m->sync_buf, need));
+  m->sync_cap = need;
+  return SMX_OK;
+}
+
+int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]) {
+  SMX_REQUIRE(m && id && world >= 1 && rank >= 0 && rank < world, "bad rank/world");
+  SMX_CHECK(load_rccl());
+  SMX_CHECK(comm_detach(m));
+  ncclUniqueId uid;
+  memcpy(&uid, id, 128);
+  ncclComm_t comm = nullptr;
+  ncclResult_t r = g_rccl.CommInitRank(&comm, world, uid, rank);
+  if (r != ncclSuccess) {
+    // RCCL may leave a half-built handle behind: it is NOT kept (smx_model_destroy must not hand it to CommDestroy)
+    set_error(std::string("ncclCommInitRank failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    return SMX_ERR_COMM;
+  }
+  m->comm = comm;
+  m->rank = rank; m->world = world;
+  m->dp_force = getenv("SMX_FORCE_ALLREDUCE") != nullptr;
+  m->dp_two_buckets = getenv("SMX_DP_BUCKETS") != nullptr && atoi(getenv("SMX_DP_BUCKETS")) == 2;
+  if (!m->st_comm) {
+    if (hipStreamCreateWithFlags(&m->st_comm, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_c1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_c2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_c3, hipEventDisableTiming) != hipSuccess) {
+      set_error("communication stream creation failed");
+      return SMX_ERR_HIP;
+    }
+  }
+  SMX_CHECK(ensure_sync_buf(m));
+  drop_graphs(m);
+  return SMX_OK;
+}
+
+int smx_comm_init_local(smx_model* const* models, int n) {
+  SMX_REQUIRE(models && n >= 1 && n <= SMX_LOCAL_MAX, "loopback communicator: 1..8 models");
+  for (int r = 0; r < n; ++r) {
+    SMX_REQUIRE(models[r], "null model");
+    SMX_REQUIRE(models[r]->device == models[0]->device, "loopback communicator: all models on one device");
+    SMX_REQUIRE(models[r]->grads_count == models[0]->grads_count, "loopback communicator: models differ");
+    for (int q = 0; q < r; ++q) SMX_REQUIRE(models[q] != models[r], "loopback communicator: a model is listed twice");
+  }
+  auto g = std::make_shared<LocalGroup>();
+  g->world = n;
+  for (int r = 0; r < n; ++r) {
+    SMX_HIP(hipEventCreateWithFlags(&g->ready[r], hipEventDisableTiming));
+    SMX_HIP(hipEventCreateWithFlags(&g->done[r], hipEventDisableTiming));
+  }
+  for (int r = 0; r < n; ++r) {
+    smx_model* m = models[r];
+    SMX_CHECK(comm_detach(m));
+    m->rank = r; m->world = n; m->local = g;
+    int wmax = 0;
+    for (int w : m->bn_wp) wmax = std::max(wmax, w);
+    const size_t need = std::max(m->grads_count, (size_t)n * 2 * (size_t)wmax);
+    if (need > m->local_scratch_cap) {
+      if (m->local_scratch) hipFree(m->local_scratch);
+      m->local_scratch = nullptr; m->local_scratch_cap = 0;
+      SMX_CHECK(dmalloc(&m->local_scratch, need));
+      m->local_scratch_cap = need;
+    }
+    SMX_CHECK(ensure_sync_buf(m));
+  }
+  return SMX_OK;
+}
+
+int smx_comm_set_sync_bn(smx_model* m, int on) {
+  SMX_REQUIRE(m, "null model");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  m->sync_bn = on != 0;
+  SMX_CHECK(ensure_sync_buf(m));
+  drop_graphs(m);
+  return SMX_OK;
+}
+
+int smx_comm_library(char* rccl_path, int rccl_cap, char* hip_path, int hip_cap, int32_t* rccl_version) {
+  SMX_CHECK(load_rccl());
+  if (rccl_path && rccl_cap > 0) { strncpy(rccl_path, g_rccl.path.c_str(), rccl_cap - 1); rccl_path[rccl_cap - 1] = 0; }
+  if (hip_path && hip_cap > 0) { strncpy(hip_path, g_rccl.hip_path.c_str(), hip_cap - 1); hip_path[hip_cap - 1] = 0; }
+  if (rccl_version) { int v = 0; if (g_rccl.GetVersion) g_rccl.GetVersion(&v); *rccl_version = v; }
+  return SMX_OK;
+}
+
+int smx_comm_rank(const smx_model* m) { return m ? m->rank : 0; }
+int smx_comm_world(const smx_model* m) { return m ? m->world : 0; }
+
+}  // extern "C"

@@ -112,9 +112,9 @@ int loss_chunks(int Gp, int B);   // partial sums per cell written by a launch o
 int loss_chunks_max(int Gp);      // upper bound over every batch size (allocation)
 int launch_count_loss(hipStream_t st, const LossArgs& a);
 
-// Noise for LATER small layers, generated by extra workgroups of the first BatchNorm launch (they run on
-// idle CUs beside the 32 BN workgroups), so the 4-workgroup fused kernels downstream read multipliers / eps
-// instead of evaluating Philox in their serial tails.
+// Noise for a LATER launch, generated by extra workgroups of the first BatchNorm launch (they run on idle CUs beside
+// the 32 BN workgroups): the decoder's front launch computes the whole latent tile in every workgroup and reads its
+// eps / dropout multipliers instead of evaluating Philox redundantly.
 struct NoiseJob {
   float* dst = nullptr; int ld = 0; int width = 0;   // [B][ld], columns >= width left untouched
   int normal = 0;                                    // 0: dropout multipliers, 1: standard normals
@@ -351,69 +351,9 @@ int launch_step_begin(hipStream_t st, StepState* master, StepState* dst, const i
 
 
 
-// Small-layer fusions (smx_fused.hip): latent head GEMM + sample + KL; Dense + BN + ReLU + Dropout.
-bool latent_head_fusable(int K, int lat_ld, int Dp);
-int launch_latent_head_fwd(hipStream_t st, const LatentArgs& la, const float* h, int ldh, int K, const float* W, int ldw,
-                           const float* bias, float* latbuf);
-bool dense_bn_fusable(int B, int K);
-int launch_dense_bn_act_fwd(hipStream_t st, const float* in, int ldi, int K, const float* W, int ldw, const BnFwdArgs& bn);
-
-// Single-workgroup fused middle of the network (smx_mid.hip).
-#ifndef SMX_MAX_LAYERS
-#define SMX_MAX_LAYERS 8
-#endif
-struct MidLayer {
-  const float* W; int ldw;                 // [in_p][ldw]
-  const float* gamma; const float* beta; const float* bias;
-  float* moving_mean; float* moving_var; float* batch_mean; float* batch_var;
-  float* xhat; float* outb; float* inv_std; float* dpre;   // [B][out_p] saved activations
-  float* dgamma; float* dbeta; float* dbias;
-  int in_p, out, out_p;
-  float drop_p; uint32_t stream;
-  const float* inj_mask; int inj_ld;
-};
-
-struct MidArgs {
-  int B, batchnorm, training, update_moving;
-  float momentum, eps;
-  const float* h0; int h0_w;               // activated output of encoder layer 0 [B][h0_w]
-  int n_enc; MidLayer enc[SMX_MAX_LAYERS]; // encoder layers 1.. (layer 0 is the wide product)
-  const float* Wlat; int ld_wlat; const float* blat; int lat_in_p, lat_ld, D, Dp, stochastic, relu;
-  float* latbuf; float* z; float* sig; float* eps_out; float* kl;
-  int n_dec; MidLayer dec[SMX_MAX_LAYERS];
-  uint32_t k0, k1; const uint32_t* step_ptr; uint32_t step, sample;
-  const int32_t* rows; uint32_t cell_base;
-  const float* inj_eps; int inj_eps_ld;
-  unsigned long long* dbg;   // optional stage stamps (diagnostic builds of the host only)
-  // backward only
-  float kl_scale; float* dlat; float* dpre_enc0;   // d loss / d pre-activation of encoder layer 0 goes to enc0's dpre
-  const float* enc0_out; const float* enc0_xhat; const float* enc0_inv_std; const float* enc0_gamma;
-  float* enc0_dgamma; float* enc0_dbeta; float* enc0_dbias; int enc0_out_w, enc0_out_p; float enc0_drop_p;
-};
-
-int launch_mid_fwd(hipStream_t st, const MidArgs& a);
-int launch_mid_bwd(hipStream_t st, const MidArgs& a);
-
 // Test helper: Philox multipliers / normals exactly as kernels draw them.
 int launch_noise_probe(hipStream_t st, NoiseKey nk, const int64_t* cell_ids, int B, int width, float p, float* mult,
                        float* normal);
-
-// ---- fused output head of a training step (smx_head.hip) -------------------------------------
-struct OutHeadArgs {
-  const float* H = nullptr; int ldh = 0;          // decoder output [B][ldh] (after BN / ReLU / dropout)
-  const float* W = nullptr; int ldw = 0;          // [Hp][k * Gp]
-  const float* bias = nullptr;                    // [k * Gp]
-  const float* X = nullptr; int ldx = 0; const int32_t* rows = nullptr; int x_u16 = 0;
-  float* dP = nullptr; long ldp = 0; long plane_stride = 0;
-  float* dW = nullptr; float* db = nullptr;       // gradient tensors, laid out as W / bias
-  float* llk_part = nullptr; int n_chunks = 0;    // [B][n_chunks], n_chunks = out_head_chunks(Gp)
-  int B = 0, G = 0, Gp = 0, Hp = 0, likelihood = 0;
-  float grad_scale = 1.f;
-  int diag = 0;   // SMX_HEAD_DIAG bit mask: skip 1 forward product, 2 likelihood arithmetic, 4 weight-gradient product
-};
-bool out_head_supported(int B, int Hp, int Gp);
-int out_head_chunks(int Gp);
-int launch_out_head_train(hipStream_t st, const OutHeadArgs& a);
 
 // ---- output product fused with the count likelihood, wide (smx_headloss.hip) -------------------
 struct HeadLossArgs {

@@ -1,0 +1,190 @@
+// smx_kapi.hip -- kernel-level entry points (parity tests of single kernels): smx_k_count_llk, smx_k_adam, smx_k_gemm, smx_k_noise.
+#include "smx_model.h"
+
+extern "C" {
+
+// ---- kernel-level entry points ------------------------------------------------
+int smx_k_count_llk(int likelihood, int direct, const float* x, const float* planes, int32_t B, int32_t G, float* llk,
+                    float* grads) {
+  SMX_REQUIRE(x && planes && llk && B > 0 && G > 0, "bad arguments");
+  const int k = (likelihood == SMX_LLK_ZINB || likelihood == SMX_LLK_ZINBD) ? 3 : 2;
+  const int Gp = round_up(G, 32);
+  const int nch = loss_chunks(Gp, B);
+  float *dX = nullptr, *dPl = nullptr, *dG = nullptr, *dPart = nullptr;
+  int rc;
+  if ((rc = dmalloc(&dX, (size_t)B * Gp)) || (rc = dmalloc(&dPl, (size_t)B * k * Gp)) || (rc = dmalloc(&dG, (size_t)B * k * Gp)) ||
+      (rc = dmalloc(&dPart, (size_t)B * nch)))
+    return rc;
+  SMX_HIP(hipMemcpy2D(dX, (size_t)Gp * 4, x, (size_t)G * 4, (size_t)G * 4, (size_t)B, hipMemcpyHostToDevice));
+  for (int c = 0; c < k; ++c)
+    SMX_HIP(hipMemcpy2D(dPl + (size_t)c * Gp, (size_t)k * Gp * 4, planes + (size_t)c * B * G, (size_t)G * 4, (size_t)G * 4,
+                        (size_t)B, hipMemcpyHostToDevice));
+  LossArgs lo;
+  lo.likelihood = likelihood; lo.direct = direct; lo.backward = grads != nullptr;
+  lo.X = dX; lo.ldx = Gp; lo.P = dPl; lo.ldp = (long)k * Gp; lo.plane_stride = Gp; lo.dP = dG; lo.llk_part = dPart;
+  lo.B = B; lo.G = G; lo.Gp = Gp; lo.grad_scale = 1.f;
+  rc = launch_count_loss(nullptr, lo);
+  if (rc == SMX_OK) {
+    std::vector<float> part((size_t)B * nch);
+    SMX_HIP(hipDeviceSynchronize());
+    SMX_HIP(hipMemcpy(part.data(), dPart, part.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) {
+      double s = 0.0;
+      for (int c = 0; c < nch; ++c) s += part[(size_t)b * nch + c];
+      for (int g = 0; g < G; ++g) { const float v = x[(size_t)b * G + g]; if (v > 0.f) s -= lgamma((double)v + 1.0); }
+      llk[b] = (float)s;
+    }
+    if (grads)
+      for (int c = 0; c < k; ++c)
+        SMX_HIP(hipMemcpy2D(grads + (size_t)c * B * G, (size_t)G * 4, dG + (size_t)c * Gp, (size_t)k * Gp * 4, (size_t)G * 4,
+                            (size_t)B, hipMemcpyDeviceToHost));
+  }
+  hipFree(dX); hipFree(dPl); hipFree(dG); hipFree(dPart);
+  return rc;
+}
+
+int smx_k_adam(int32_t n_tensors, const int32_t* sizes, float* params, const float* grads, float* mom, float* vel,
+               int32_t step, float lr, float beta1, float beta2, float eps, float clipnorm, float* norms) {
+  SMX_REQUIRE(n_tensors > 0 && n_tensors <= SMX_MAX_TENSORS && sizes && params && grads && mom && vel && step >= 1, "bad arguments");
+  // the model's own layout: every tensor padded to a multiple of 64 floats, 4096-float optimiser chunks
+  std::vector<size_t> off((size_t)n_tensors), pad((size_t)n_tensors);
+  std::vector<OptChunk> chunks;
+  size_t total = 0;
+  const int CH = 4096;
+  for (int t = 0; t < n_tensors; ++t) {
+    SMX_REQUIRE(sizes[t] > 0, "empty tensor");
+    off[t] = total; pad[t] = ((size_t)sizes[t] + 63) / 64 * 64;
+    const int first = (int)chunks.size(), n = (int)((pad[t] + CH - 1) / CH);
+    for (int i = 0; i < n; ++i) {
+      OptChunk c;
+      memset(&c, 0, sizeof(c));
+      c.tensor = t; c.offset = (int)(off[t] + (size_t)i * CH);
+      c.count = (int)((size_t)(i + 1) * CH <= pad[t] ? CH : pad[t] - (size_t)i * CH);
+      c.first_chunk = first; c.n_chunks = n; c.tensor_count = (int32_t)pad[t];
+      chunks.push_back(c);
+    }
+    total += pad[t];
+  }
+  float *dP = nullptr, *dG = nullptr, *dM = nullptr, *dV = nullptr, *dPart = nullptr, *dNorm = nullptr;
+  OptChunk* dCh = nullptr; StepState* dSt = nullptr;
+  int rc;
+  if ((rc = dmalloc(&dP, total)) || (rc = dmalloc(&dG, total)) || (rc = dmalloc(&dM, total)) || (rc = dmalloc(&dV, total)) ||
+      (rc = dmalloc(&dPart, chunks.size())) || (rc = dmalloc(&dNorm, (size_t)n_tensors)) || (rc = dmalloc(&dCh, chunks.size())) ||
+      (rc = dmalloc(&dSt, (size_t)3)))
+    return rc;
+  auto put = [&](float* dst, const float* src) -> int {
+    size_t lo = 0;
+    for (int t = 0; t < n_tensors; ++t) {
+      SMX_HIP(hipMemcpy(dst + off[t], src + lo, (size_t)sizes[t] * sizeof(float), hipMemcpyHostToDevice));
+      lo += (size_t)sizes[t];
+    }
+    return SMX_OK;
+  };
+  auto get = [&](float* dst, const float* src) -> int {
+    size_t lo = 0;
+    for (int t = 0; t < n_tensors; ++t) {
+      SMX_HIP(hipMemcpy(dst + lo, src + off[t], (size_t)sizes[t] * sizeof(float), hipMemcpyDeviceToHost));
+      lo += (size_t)sizes[t];
+    }
+    return SMX_OK;
+  };
+  rc = put(dP, params); if (rc == SMX_OK) rc = put(dG, grads); if (rc == SMX_OK) rc = put(dM, mom); if (rc == SMX_OK) rc = put(dV, vel);
+  if (rc == SMX_OK && hipMemcpy(dCh, chunks.data(), chunks.size() * sizeof(OptChunk), hipMemcpyHostToDevice) != hipSuccess) rc = SMX_ERR_HIP;
+  StepState st3[3];
+  memset(st3, 0, sizeof(st3));
+  st3[2].next = (uint32_t)(step - 1);   // optimiser steps completed so far
+  if (rc == SMX_OK && hipMemcpy(dSt, st3, sizeof(st3), hipMemcpyHostToDevice) != hipSuccess) rc = SMX_ERR_HIP;
+  // the step's scalars exactly as a training step prepares them (bias-corrected step size on the device)
+  if (rc == SMX_OK) rc = launch_step_begin(nullptr, dSt + 2, dSt, nullptr, nullptr, 0, 0, 0u, lr, beta1, beta2);
+  if (rc == SMX_OK) {
+    AdamArgs a;
+    a.params = dP; a.grads = dG; a.m = dM; a.v = dV; a.chunks = dCh; a.n_chunks = (int)chunks.size(); a.n_launch = a.n_chunks; a.gap_from = a.n_chunks; a.gap_len = 0;
+    a.partial = dPart; a.tensor_norm = dNorm; a.use_sq = 0; a.state = dSt;
+    a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.clipnorm = clipnorm; a.grad_scale = 1.f; a.lr = lr;
+    rc = launch_adam(nullptr, a);
+  }
+  if (rc == SMX_OK && hipDeviceSynchronize() != hipSuccess) { set_error("k_adam: device synchronize failed"); rc = SMX_ERR_HIP; }
+  if (rc == SMX_OK) rc = get(params, dP);
+  if (rc == SMX_OK) rc = get(mom, dM);
+  if (rc == SMX_OK) rc = get(vel, dV);
+  if (rc == SMX_OK && norms && hipMemcpy(norms, dNorm, (size_t)n_tensors * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = SMX_ERR_HIP;
+  hipFree(dP); hipFree(dG); hipFree(dM); hipFree(dV); hipFree(dPart); hipFree(dNorm); hipFree(dCh); hipFree(dSt);
+  return rc;
+}
+
+int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M, int32_t N, int32_t K, int32_t split_k,
+               int32_t tile_cfg, float* C) {
+  SMX_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "bad arguments");
+  // pad to the library's internal conventions: feature axes to 32, batch axes free
+  const int Np = round_up(N, 32);
+  const int Kp = round_up(K, 4), Mp = round_up(M, 4);
+  const int lda = transA ? Mp : Kp, a_rows = transA ? K : M, a_cols = transA ? M : K;
+  const int ldb = transB ? Kp : Np, b_rows = transB ? N : K, b_cols = transB ? K : N;
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  int rc;
+  const int S = split_k < 1 ? 1 : split_k;
+  if ((rc = dmalloc(&dA, (size_t)a_rows * lda)) || (rc = dmalloc(&dB, (size_t)round_up(b_rows, 32) * ldb)) ||
+      (rc = dmalloc(&dC, (size_t)S * M * Np)))
+    return rc;
+  SMX_HIP(hipMemcpy2D(dA, (size_t)lda * 4, A, (size_t)a_cols * 4, (size_t)a_cols * 4, (size_t)a_rows, hipMemcpyHostToDevice));
+  SMX_HIP(hipMemcpy2D(dB, (size_t)ldb * 4, B, (size_t)b_cols * 4, (size_t)b_cols * 4, (size_t)b_rows, hipMemcpyHostToDevice));
+  GemmArgs g;
+  g.A = dA; g.lda = lda; g.a_kmajor = transA; g.B = dB; g.ldb = ldb; g.b_nmajor = transB;
+  g.C = dC; g.ldc = Np; g.slab_stride = (long)M * Np; g.M = transA ? Mp : M; g.N = Np; g.K = (transA) ? K : Kp;
+  if (transA) g.M = Mp;
+  g.split_k = S; g.tile = tile_cfg;
+  int eff = 1;
+  // rows of C beyond M (when M was padded for k-major A) are never stored: allocate for Mp
+  if (transA && Mp != M) { hipFree(dC); dC = nullptr; if ((rc = dmalloc(&dC, (size_t)S * Mp * Np))) return rc; g.C = dC; g.slab_stride = (long)Mp * Np; }
+  rc = launch_gemm(nullptr, g, &eff);
+  if (rc == SMX_OK && getenv("SMX_KGEMM_REPS")) {  // diagnostic: average launch time of this shape / tile
+    const int reps = atoi(getenv("SMX_KGEMM_REPS"));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i) launch_gemm(nullptr, g, nullptr);
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < reps; ++i) launch_gemm(nullptr, g, nullptr);
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    fprintf(stderr, "k_gemm tA=%d tB=%d M=%d N=%d K=%d split=%d tile=%d: %.2f us\n", transA, transB, M, N, K, eff, tile_cfg,
+            1e3f * ms / reps);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+  if (rc == SMX_OK) {
+    SMX_HIP(hipDeviceSynchronize());
+    const int rowsC = transA ? Mp : M;
+    std::vector<float> h((size_t)eff * rowsC * Np);
+    SMX_HIP(hipMemcpy(h.data(), dC, h.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < M; ++i)
+      for (int j = 0; j < N; ++j) {
+        float s = 0.f;
+        for (int z = 0; z < eff; ++z) s += h[((size_t)z * rowsC + i) * Np + j];
+        C[(size_t)i * N + j] = s;
+      }
+  }
+  hipFree(dA); hipFree(dB); hipFree(dC);
+  return rc;
+}
+
+int smx_k_noise(uint64_t seed, int32_t stream, int32_t step, int32_t sample, const int64_t* cell_ids, int32_t B, int32_t width,
+                float dropout_p, float* dropout_mult, float* normal) {
+  SMX_REQUIRE(cell_ids && B > 0 && width > 0, "bad arguments");
+  int64_t* dIds = nullptr; float *dM = nullptr, *dN = nullptr;
+  int rc;
+  if ((rc = dmalloc(&dIds, (size_t)B)) || (rc = dmalloc(&dM, (size_t)B * width)) || (rc = dmalloc(&dN, (size_t)B * width))) return rc;
+  SMX_HIP(hipMemcpy(dIds, cell_ids, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice));
+  NoiseKey nk;
+  nk.k0 = (uint32_t)(seed & 0xFFFFFFFFu); nk.k1 = (uint32_t)(seed >> 32); nk.step = (uint32_t)step;
+  nk.stream = (uint32_t)((stream & 0xFF) | ((sample & 0xFFFFFF) << 8)); nk.step_ptr = nullptr;
+  rc = launch_noise_probe(nullptr, nk, dIds, B, width, dropout_p, dM, dN);
+  if (rc == SMX_OK) {
+    SMX_HIP(hipDeviceSynchronize());
+    if (dropout_mult) SMX_HIP(hipMemcpy(dropout_mult, dM, (size_t)B * width * 4, hipMemcpyDeviceToHost));
+    if (normal) SMX_HIP(hipMemcpy(normal, dN, (size_t)B * width * 4, hipMemcpyDeviceToHost));
+  }
+  hipFree(dIds); hipFree(dM); hipFree(dN);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,1226 @@
+// smx_step.hip -- one training / evaluation step as a launch sequence: forward, ELBO, backward, (all-reduce), optimiser;
+// eager and captured-graph execution.
+#include "smx_model.h"
+
+namespace smx {
+
+__global__ void bn_moving_update_kernel(float* moving, const float* batch_sum, int n, float inv_world, float momentum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) moving[i] = moving[i] * momentum + batch_sum[i] * inv_world * (1.f - momentum);
+}
+
+void fill_adam_args(smx_model* m, AdamArgs& a);
+// SyncBatchNorm applies to training passes of a data-parallel job only (eval mode uses the moving statistics)
+bool sync_bn_on(const smx_model* m, int training) { return m->sync_bn && training && m->cfg.batchnorm && dp_active(m); }
+BnSyncArgs sync_args(smx_model* m) { BnSyncArgs y; y.gather = m->sync_buf; y.rank = m->rank; y.world = m->world; return y; }
+
+// shapes / modes under which the decoder's first BatchNorm launch takes the latent sample and its product along
+// (forward_pass adds what depends on injected noise)
+static bool front_shapes_ok(smx_model* m, const Pass& ps) {
+  const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
+  return m->flags.front && !m->scale && !sync_bn_on(m, ps.training) && bn_front_supported(ps.B, m->Dp) &&
+         (m->Dp == 32 || m->Dp == 64) && m->dec[0].in_p == m->Dp && m->dec[0].out_p % 8 == 0 && (lat_ld % 4) == 0;
+}
+
+
+// twin: another MLP whose FIRST layer consumes the same input (scvi: the library encoder beside the encoder).  When the
+// shapes allow, both first layers run as ONE product launch and ONE BatchNorm launch (side by side along the output
+// columns); *twin_done tells the caller, who then continues the twin from its second layer (first_layer = 1).
+int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
+                const char* label0, int n_layers = -1, const LatentArgs* front = nullptr, int first_layer = 0,
+                std::vector<MlpLayer>* twin = nullptr, bool* twin_done = nullptr) {
+  const float* in = in0;
+  int ld = ld0;
+  const size_t nl = n_layers < 0 ? mlp.size() : (size_t)n_layers;
+  auto make_gemm = [&](MlpLayer& L, const float* a_in, int a_ld, bool first_x, float* slab) {
+    const TensorInfo& tw = m->tensors[L.tW];
+    GemmArgs g;
+    g.A = a_in; g.lda = a_ld; g.B = P_(m, L.tW); g.ldb = tw.ld;
+    g.M = ps.B; g.N = L.out_p; g.K = L.in_p;
+    g.C = slab; g.ldc = L.out_p; g.slab_stride = (long)ps.B * L.out_p;
+    g.split_k = suggest_split_k(ps.B, L.out_p, L.in_p);
+    if (first_x) {
+      g.use_xform = 1;
+      g.xf.rows = ps.xrows; g.xf.u16 = ps.x_u16; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
+      if (ps.training && m->cfg.input_dropout > 0.f) {
+        g.xf.drop_p = m->cfg.input_dropout; g.xf.drop_scale = 1.f / (1.f - m->cfg.input_dropout);
+        g.xf.nk = make_key(m, ST_INPUT_DROPOUT, ps.sample, true);
+        if (const Injected* ij = inj(m, ST_INPUT_DROPOUT)) { g.xf.inj_mask = ij->d; g.xf.inj_ld = ij->ld; }
+      }
+    }
+    return g;
+  };
+  auto make_bn = [&](MlpLayer& L, const float* slab, int eff, long slab_stride) {
+    BnFwdArgs b;
+    b.pre = slab; b.n_slabs = eff; b.slab_stride = slab_stride; b.ld = L.out_p;
+    b.B = ps.B; b.H = L.out; b.Hp = L.out_p; b.batchnorm = L.bn >= 0; b.training = ps.training; b.leak = L.leak;
+    if (L.bn >= 0) {
+      b.gamma = P_(m, L.tGamma); b.beta = P_(m, L.tBeta);
+      b.moving_mean = m->bn_moving + m->bn_off[L.bn]; b.moving_var = b.moving_mean + L.out_p;
+      b.batch_mean = m->grads + m->tail_off_bn + m->bn_off[L.bn]; b.batch_var = b.batch_mean + L.out_p;
+      b.update_moving = (m->world == 1);
+      b.momentum = m->cfg.bn_momentum; b.eps = m->cfg.bn_eps;
+    } else {
+      b.bias = P_(m, L.tBias);
+    }
+    b.xhat = L.xhat; b.inv_std = L.inv_std; b.out = L.out_buf;
+    b.drop_p = ps.training ? L.drop_p : 0.f;
+    b.nk = make_key(m, L.stream, ps.sample, true);
+    b.rows = ps.rows; b.cell_base = ps.cell_base;
+    if (const Injected* ij = inj(m, L.stream)) { b.inj_mask = ij->d; b.inj_ld = ij->ld; }
+    return b;
+  };
+  if (twin_done) *twin_done = false;
+  for (size_t i = (size_t)first_layer; i < nl; ++i) {
+    if (i > 0 && i == (size_t)first_layer) { in = mlp[i - 1].out_buf; ld = mlp[i - 1].out_p; }
+    MlpLayer& L = mlp[i];
+    const TensorInfo& tw = m->tensors[L.tW];
+    GemmArgs g = make_gemm(L, in, ld, i == 0 && in_is_x, m->slab);
+    static const bool no_ahead = getenv("SMX_NO_NOISE_AHEAD") != nullptr;
+    const bool no_twin = !m->flags.twin;
+    const bool sync = sync_bn_on(m, ps.training) && L.bn >= 0;
+    // hidden -> hidden layers 32 / 64 / 128 wide: the BatchNorm launch stages the layer's INPUT tile [B][K] in LDS and forms its
+    // own columns as dot products -- the same front the first decoder layer uses for the latent sample, here as a plain
+    // copy (no product launch; the reference's default networks are [64, 64], configs/base.yaml:10-17)
+    LatentArgs dense_la;
+    const bool dense_front = m->flags.front && !sync && !(front != nullptr && i == 0) && !(i == 0 && in_is_x) && L.leak == 0.f &&
+                             (L.in_p == 32 || L.in_p == 64 || (L.in_p == 128 && ps.B <= 128)) && bn_front_supported(ps.B, L.in_p) && L.out_p % 8 == 0 &&
+                             (ld % 4) == 0;
+    if (dense_front) {
+      dense_la.stochastic = 0; dense_la.relu = 0; dense_la.training = ps.training;
+      dense_la.lat = in; dense_la.ld = ld; dense_la.B = ps.B; dense_la.D = L.in; dense_la.Dp = L.in_p;
+    }
+    const LatentArgs* front_i = (front != nullptr && i == 0) ? front : (dense_front ? &dense_la : nullptr);
+    const bool with_front = front_i != nullptr;   // the BatchNorm launch produces its own input (latent sample / input tile + product)
+    int eff = 1;
+    SMX_REQUIRE((size_t)std::max(g.split_k, 1) * (size_t)g.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
+    // ---- the twin's first layer beside this one: one product launch, one BatchNorm launch ----
+    bool dual = false;
+    GemmArgs g2;
+    if (twin && i == 0 && !with_front && !sync && !no_twin && in_is_x && !twin->empty() && bn_dual_supported(ps.B) &&
+        !(ps.training && m->cfg.input_dropout > 0.f) && (*twin)[0].in_p == L.in_p && L.leak == 0.f && (*twin)[0].leak == 0.f) {
+      MlpLayer& T = (*twin)[0];
+      float* slab2 = m->slab + (size_t)std::max(g.split_k, 1) * (size_t)g.slab_stride;
+      g2 = make_gemm(T, in, ld, true, slab2);
+      dual = ((size_t)std::max(g.split_k, 1) * ((size_t)g.slab_stride + (size_t)g2.slab_stride) <= m->slab_cap);
+    }
+    // layers without BatchNorm and without dropout (the FactorVAE discriminator; plain autoencoders at evaluation): bias
+    // and activation in the product's own store path -- no bias / activation launch
+    const bool epi_act = m->flags.act_epilogue && !dual && !with_front && !sync && L.bn < 0 && !(ps.training && L.drop_p > 0.f) &&
+                         g.split_k <= 1 && !m->use_injected;
+    if (epi_act) {
+      g.bias = P_(m, L.tBias); g.act = 1; g.leak = L.leak; g.C = L.out_buf; g.ldc = L.out_p; g.split_k = 1;
+      Timed t(m, (i == 0 && in_is_x) ? label0 : "gemm_mlp_fwd");
+      SMX_CHECK(launch_gemm(m->st, g));
+      in = L.out_buf; ld = L.out_p;
+      continue;
+    }
+    if (dual) {
+      Timed t(m, label0);
+      SMX_CHECK(launch_gemm_dual(m->st, g, g2, &eff));
+    } else if (!with_front) {
+      Timed t(m, (i == 0 && in_is_x) ? label0 : "gemm_mlp_fwd");
+      SMX_CHECK(launch_gemm(m->st, g, &eff));
+    }
+    BnFwdArgs b = make_bn(L, m->slab, eff, g.slab_stride);
+    if (!no_ahead && !sync && i == 0 && in_is_x && &mlp == &m->enc && ps.training && front_shapes_ok(m, ps) &&
+        !with_front && b.n_jobs == 0) {
+      // the decoder's front launch (latent sample + first decoder layer) computes the whole latent tile in EVERY one of
+      // its workgroups: its Philox draws (eps: ~1.2 us at batch 128, twice that at 256; dropout ~1 us) are made here
+      // instead, once, by extra workgroups on CUs this launch leaves idle
+      auto add = [&](float* dst, int ld, int width, int normal, float p, int stream) {
+        NoiseJob& j = b.jobs[b.n_jobs++];
+        j.dst = dst; j.ld = ld; j.width = width; j.normal = normal; j.p = p;
+        j.stream = (uint32_t)((stream & 0xFF) | ((ps.sample & 0xFFFFFF) << 8));
+      };
+      const MlpLayer& d0 = m->dec[0];
+      if (d0.drop_p > 0.f && !inj(m, d0.stream)) { add(d0.noise, d0.out_p, d0.out, 0, d0.drop_p, d0.stream); m->ahead_front_drop = true; }
+      if (m->stochastic && !inj(m, ST_EPS_Z)) { add(m->noise_eps, m->Dp, m->D, 1, 0.f, ST_EPS_Z); m->ahead_front_eps = true; }
+      if (b.n_jobs) b.nk.step_ptr = &cur_state(m)->step;
+    }
+    if (dual) {
+      MlpLayer& T = (*twin)[0];
+      const BnFwdArgs b2 = make_bn(T, g2.C, eff, g2.slab_stride);
+      Timed t(m, "bn_fwd");
+      SMX_CHECK(launch_bn_act_fwd_dual(m->st, b, b2));
+      if (twin_done) *twin_done = true;
+    } else if (with_front) {
+      if (m->ahead_front_drop && front != nullptr && i == 0 && !b.inj_mask && b.drop_p > 0.f) { b.inj_mask = L.noise; b.inj_ld = L.out_p; }
+      b.front = 1; b.lat = *front_i; b.W = P_(m, L.tW); b.ldw = tw.ld; b.n_jobs = 0;
+      Timed t(m, "bn_fwd");
+      SMX_CHECK(launch_bn_act_fwd(m->st, b));
+    } else if (sync) {
+      Timed t(m, "bn_fwd");
+      b.n_jobs = 0;
+      const BnSyncArgs y = sync_args(m);
+      SMX_REQUIRE((size_t)y.world * 2 * L.out_p <= m->sync_cap, "SyncBatchNorm buffer too small");
+      SMX_CHECK(launch_bn_sync_fwd(m->st, b, y, 0));
+      SMX_CHECK(dp_allreduce_buf(m, m->sync_buf, (size_t)y.world * 2 * L.out_p, m->st));
+      SMX_CHECK(launch_bn_sync_fwd(m->st, b, y, 1));
+    } else {
+      Timed t(m, "bn_fwd");
+      SMX_CHECK(launch_bn_act_fwd(m->st, b));
+    }
+    in = L.out_buf; ld = L.out_p;
+  }
+  return SMX_OK;
+}
+
+
+// Single GPU: once the head products have written dW / db of the output and label heads (3/4 of the parameters),
+// their clip + Adam update rides along with the next BatchNorm-backward launch, which leaves most CUs idle; the
+// optimiser launch at the end of the step then covers only the encoder / latent / decoder chunks.
+void attach_early_adam(smx_model* m, BnBwdArgs& b) {
+  if (!m->adam_early_pending) return;
+  m->adam_early_pending = false;
+  static const bool off = getenv("SMX_NO_ADAM_EARLY") != nullptr;
+  if (off || dp_active(m) || !m->sq_slots || m->chunk_first_head >= m->n_chunks || getenv("SMX_NO_SQ_PARTIALS") != nullptr) return;
+  for (size_t t = (size_t)m->t_outW[0]; t < m->tensors.size(); ++t)   // head tensors are the last ones of the manifest
+    if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) return;
+  // riders use half of a 512-thread BatchNorm workgroup: fine while the heads' update is a few MB (C2: 22 MB, hidden
+  // under the launch), but at the 20 000-gene width it ran at 2.8 TB/s against 6.2 TB/s for the optimiser's own launch.
+  // There only the heads' sum-of-squares slots are reduced here (one rider workgroup per tensor with many slots:
+  // 30 000 for the output head at 20 000 genes), so that each of the optimiser's ~1900 workgroups for that tensor
+  // reads ONE number instead of sweeping all of them (225 MB of L2 reads, 66 -> 5x us of the optimiser launch).
+  if ((long)(m->n_chunks - m->chunk_first_head) * m->chunks_floats > 512L * 4096) {
+    fill_adam_args(m, b.adam);
+    for (size_t t = 0; t < m->tensors.size(); ++t) { b.adam.sq_first[t] = m->sq_first[t]; b.adam.sq_count[t] = m->sq_count[t]; }
+    for (size_t t = (size_t)m->t_outW[0]; t < m->tensors.size(); ++t) {
+      const int cnt = m->sq_count[t];
+      const int R = std::min(SMX_SQR_PER_TENSOR, (cnt + SMX_SQR_MIN_SLOTS - 1) / SMX_SQR_MIN_SLOTS);
+      if (cnt <= SMX_SQR_MIN_SLOTS || b.sqr_count + R > SMX_SQR_MAX) continue;
+      const int seg = ((cnt + R - 1) / R + 255) / 256 * 256;
+      int r = 0;
+      for (int lo = 0; lo < cnt; lo += seg, ++r) {
+        const int i = b.sqr_count++;
+        b.sqr_first[i] = m->sq_first[t] + lo; b.sqr_n[i] = std::min(seg, cnt - lo); b.sqr_dst[i] = (int)t * SMX_SQR_PER_TENSOR + r;
+      }
+      m->sq_reduced[t] = (char)r;   // the optimiser reads r partial sums for this tensor
+    }
+    b.sq_total = m->sq_slots + m->sq_total_first;
+    return;
+  }
+  fill_adam_args(m, b.adam);
+  b.adam.use_sq = 1;
+  for (size_t t = 0; t < m->tensors.size(); ++t) { b.adam.sq_first[t] = m->sq_first[t]; b.adam.sq_count[t] = m->sq_count[t]; }
+  b.adam.master = nullptr; b.adam.with_metrics = 0;
+  // (label heads whose weight gradients come with the grouped launch at the END of the backward pass stay with the
+  // optimiser launch)
+  const int early_to = m->lab_deferred ? m->chunk_first_label : m->n_chunks;
+  b.adam_first = m->chunk_first_head;
+  b.adam_count = early_to - m->chunk_first_head;
+  m->adam_early_from = m->chunk_first_head; m->adam_early_to = early_to;
+}
+
+// ask the product that writes the gradient of tensor t for sum-of-squares partials
+void want_sq(smx_model* m, GemmArgs& g, int t) {
+  if (!m->sq_slots || getenv("SMX_NO_SQ_PARTIALS") != nullptr) return;   // read per call: tests toggle it
+  g.sq_part = m->sq_slots + m->sq_first[(size_t)t];
+  g.sq_count = &m->sq_count[(size_t)t];
+}
+
+// backward through an MLP.  d(out of last layer) arrives as `n_slabs` slabs in m->slab.
+// Leaves d(input of first layer) as slabs in m->slab unless skip_input_grad.
+int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const float* in0, int ld0, bool in_is_x,
+                 int n_slabs, bool skip_input_grad, int* out_slabs, const char* label_dw0,
+                 const EpiLatentBwd* lat_epi = nullptr, GemmArgs* defer_dw0 = nullptr,
+                 const BnBwdArgs* grad_front = nullptr, std::vector<GemmArgs>* defer = nullptr,
+                 std::vector<MlpLayer>* twin = nullptr, const BnBwdArgs* twin_front = nullptr, bool* twin_done = nullptr,
+                 bool last_bn_done = false) {
+  // grad_front: the LAST layer's BatchNorm-backward launch computes its incoming gradient itself (fD fW^T as dot
+  // products) instead of reading slabs.  defer: weight-gradient products that nothing later in the backward pass
+  // reads are appended there instead of being launched (the caller runs them as ONE grouped launch at the end).
+  // twin / twin_front: another MLP whose last layer's BatchNorm-backward (also with a gradient front) is independent of
+  // this one's: both in ONE launch (*twin_done); the caller then walks the twin with last_bn_done = true.
+  auto make_b = [&](MlpLayer& L, int slabs, const BnBwdArgs* front) {
+    BnBwdArgs b;
+    b.dout = m->slab; b.n_slabs = slabs; b.slab_stride = (long)ps.B * L.out_p; b.ld = L.out_p;
+    b.out = L.out_buf; b.xhat = L.xhat; b.inv_std = L.inv_std;
+    b.B = ps.B; b.H = L.out; b.Hp = L.out_p; b.batchnorm = L.bn >= 0; b.training = ps.training; b.leak = L.leak;
+    b.drop_scale = (ps.training && L.drop_p > 0.f) ? 1.f / (1.f - L.drop_p) : 1.f;
+    b.dpre = L.dpre;
+    if (L.bn >= 0) { b.gamma = P_(m, L.tGamma); b.dgamma = G_(m, L.tGamma); b.dbeta = G_(m, L.tBeta); }
+    else b.dbias = G_(m, L.tBias);
+    if (front) { b.front = 1; b.fD = front->fD; b.fld = front->fld; b.fW = front->fW; b.fldw = front->fldw; b.fK = front->fK; }
+    return b;
+  };
+  if (twin_done) *twin_done = false;
+  BnBwdArgs carried;            // gradient front handed from layer i + 1 to layer i (hidden layers up to 64 wide)
+  bool have_carried = false;
+  bool dpre_done = false;       // layer i's d pre-activation was written by the d in product of layer i + 1 (activation epilogue)
+  for (int i = (int)mlp.size() - 1; i >= 0; --i) {
+    MlpLayer& L = mlp[i];
+    const TensorInfo& tw = m->tensors[L.tW];
+    const bool last = (i == (int)mlp.size() - 1);
+    BnBwdArgs b = make_b(L, n_slabs, (grad_front && last) ? grad_front : (have_carried ? &carried : nullptr));
+    have_carried = false;
+    const bool dpre_ready = dpre_done;
+    dpre_done = false;
+    if ((last && last_bn_done) || dpre_ready) {
+      // (this layer's BatchNorm-backward ran beside the other MLP's / its d pre-activation came with the product above)
+    } else if (sync_bn_on(m, ps.training) && L.bn >= 0) {   // the ELBO scalars then go with a launch of their own (optimizer_pass)
+      Timed t(m, "bn_bwd");
+      m->adam_early_pending = false;
+      const BnSyncArgs y = sync_args(m);
+      SMX_CHECK(launch_bn_sync_bwd(m->st, b, y, 0));
+      SMX_CHECK(dp_allreduce_buf(m, m->sync_buf, (size_t)y.world * 2 * L.out_p, m->st));
+      SMX_CHECK(launch_bn_sync_bwd(m->st, b, y, 1));
+    } else {
+      if (m->metrics_before_allreduce && m->have_pending_metrics) {
+        b.metrics = m->pending_metrics; b.with_metrics = 1; m->have_pending_metrics = false;
+      }
+      attach_early_adam(m, b);
+      Timed t(m, "bn_bwd");
+      const bool dual = last && b.front && b.fK <= 64 && twin && twin_front && twin_front->fK <= 64 && !twin->empty() && m->flags.twin && bn_dual_supported(ps.B) &&
+                        bn_bwd_front_supported(ps.B, twin_front->fK) && twin->back().out_p % 8 == 0 &&
+                        !(sync_bn_on(m, ps.training) && twin->back().bn >= 0);
+      if (dual) {
+        const BnBwdArgs b2 = make_b(twin->back(), 0, twin_front);
+        SMX_CHECK(launch_bn_act_bwd_dual(m->st, b, b2));
+        if (twin_done) *twin_done = true;
+      } else {
+        SMX_CHECK(launch_bn_act_bwd(m->st, b));
+      }
+    }
+    // dW = in^T * dpre
+    const bool first_x = (i == 0 && in_is_x);
+    GemmArgs g;
+    g.A = (i == 0) ? in0 : mlp[i - 1].out_buf; g.lda = (i == 0) ? ld0 : mlp[i - 1].out_p; g.a_kmajor = 1;
+    g.B = L.dpre; g.ldb = L.out_p;
+    g.C = G_(m, L.tW); g.ldc = tw.ld;
+    g.M = L.in_p; g.N = L.out_p; g.K = ps.B;
+    want_sq(m, g, L.tW);
+    if (dpre_ready) g.colsum = G_(m, L.tBias);   // (no bias / activation backward launch ran: the bias gradient is the column sum of d pre)
+    if (first_x) {
+      g.use_xform = 1;
+      g.xf.rows = ps.xrows; g.xf.u16 = ps.x_u16; g.xf.log1p = m->cfg.log_norm; g.xf.cell_base = ps.cell_base;
+      if (ps.training && m->cfg.input_dropout > 0.f) {
+        g.xf.drop_p = m->cfg.input_dropout; g.xf.drop_scale = 1.f / (1.f - m->cfg.input_dropout);
+        g.xf.nk = make_key(m, ST_INPUT_DROPOUT, ps.sample, true);
+        if (const Injected* ij = inj(m, ST_INPUT_DROPOUT)) { g.xf.inj_mask = ij->d; g.xf.inj_ld = ij->ld; }
+      }
+    }
+    if (i == 0 && skip_input_grad) {
+      if (defer_dw0) *defer_dw0 = g;   // the caller launches it (possibly grouped with another first-layer gradient)
+      else {
+        Timed t(m, first_x ? label_dw0 : "gemm_mlp_dw");
+        SMX_CHECK(launch_gemm(m->st, g));
+      }
+      n_slabs = 0;
+      break;
+    }
+    // hidden layers 32 / 64 / 128 wide: the layer below takes d in = dpre W^T as the gradient front of its BatchNorm-backward
+    // launch (dot products over K = this layer's width) and d W joins the grouped launch at the end -- no product launch
+    if (defer && i > 0 && !(i == 0 && lat_epi) && m->flags.bwd_front && (L.out_p == 32 || L.out_p == 64 || L.out_p == 128) &&
+        bn_bwd_front_supported(ps.B, L.out_p) && mlp[i - 1].out_p % 8 == 0 && (tw.ld % 4) == 0 && (L.out_p % 4) == 0 &&
+        !(sync_bn_on(m, ps.training) && mlp[i - 1].bn >= 0)) {
+      defer->push_back(g);
+      carried = BnBwdArgs();
+      carried.fD = L.dpre; carried.fld = L.out_p; carried.fW = P_(m, L.tW); carried.fldw = tw.ld; carried.fK = L.out_p;
+      have_carried = true;
+      n_slabs = 0;
+      continue;
+    }
+    // d in = dpre * W^T  -> slabs; independent of dW: one grouped launch for both
+    GemmArgs h;
+    h.A = L.dpre; h.lda = L.out_p; h.B = P_(m, L.tW); h.ldb = tw.ld; h.b_nmajor = 1;
+    h.M = ps.B; h.N = L.in_p; h.K = L.out_p;
+    h.C = m->slab; h.ldc = L.in_p; h.slab_stride = (long)ps.B * L.in_p;
+    h.split_k = suggest_split_k(ps.B, L.in_p, L.out_p);
+    SMX_REQUIRE((size_t)h.split_k * (size_t)h.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
+    if (i == 0 && lat_epi) {  // d z feeds the latent head only: run its backward in the epilogue
+      h.epi = 2; h.lb = *lat_epi; h.split_k = 1; h.tile = TILE_32x32_K4;
+    }
+    // the layer below has neither BatchNorm nor dropout: its activation's derivative goes into this product's store path
+    // and the result IS its d pre-activation (its bias gradient: the column sums its weight-gradient product takes along)
+    if (i > 0 && m->flags.act_epilogue && mlp[i - 1].bn < 0 && !(ps.training && mlp[i - 1].drop_p > 0.f) && h.split_k <= 1) {
+      MlpLayer& Lo = mlp[i - 1];
+      h.split_k = 1; h.act = 2; h.leak = Lo.leak; h.act_out = Lo.out_buf; h.act_ld = Lo.out_p;
+      h.C = Lo.dpre; h.ldc = Lo.out_p; h.slab_stride = 0;
+      dpre_done = true;
+    }
+    int effs[2] = {1, 1};
+    if (defer && i == 0 && lat_epi) {   // d z (+ latent-head backward) alone; d W joins the final grouped launch
+      defer->push_back(g);
+      Timed t(m, "gemm_mlp_bwd");
+      SMX_CHECK(launch_gemm_group(m->st, &h, 1, effs + 1));
+    } else {
+      GemmArgs pair[2] = {g, h};
+      Timed t(m, "gemm_mlp_bwd");
+      SMX_CHECK(launch_gemm_group(m->st, pair, 2, effs));
+    }
+    const int eff = effs[1];
+    n_slabs = eff;
+  }
+  if (out_slabs) *out_slabs = n_slabs;
+  return SMX_OK;
+}
+
+// Training steps of the count heads with raw parameter planes (VAE / DCA / SISUA): output product + likelihood +
+// dP in ONE wide kernel, P never materialised (smx_headloss.hip).  SMX_NO_HEAD_LOSS=1 keeps the product / loss
+// kernel pair (what eval, predict and the scoring paths always use).
+bool use_head_loss(const smx_model* m, int B) {
+  if (!m->flags.head_loss || m->scvi || m->dec.empty()) return false;
+  return head_loss_supported(B, m->dec.back().out_p, m->Gp);
+}
+
+// arguments of the row-local scvi head launch of a training step; returns whether that launch applies
+// (out == nullptr: only the test)
+static bool scvi_train_args(smx_model* m, const Pass& ps, ScviTrainArgs* out) {
+  const smx_config& c = m->cfg;
+  if (!m->scvi || !m->flags.scvi_fused || m->encl.empty()) return false;
+  const MlpLayer& lL = m->encl.back();
+  const TensorInfo& twl = m->tensors[m->t_latlW];
+  ScviTrainArgs a;
+  const long ldp = (long)m->k * m->Gp;
+  a.raw = m->raw; a.ld = ldp; a.plane_stride = m->Gp; a.B = ps.B; a.G = m->G; a.Gp = m->Gp; a.likelihood = c.likelihood;
+  a.X = ps.Xsrc; a.ldx = m->Gp; a.x_u16 = ps.x_u16; a.rows = ps.rows; a.x_identity = (ps.rows != nullptr && ps.xrows == nullptr) ? 1 : 0;
+  a.clip_library = c.clip_library; a.grad_scale = -1.f / (float)ps.global_batch;
+  a.draw = m->draw; a.llk_part = m->llk_part;
+  a.hl = lL.out_buf; a.ldh = lL.out_p; a.Kl = lL.out_p;
+  a.Wl = P_(m, m->t_latlW); a.ldwl = twl.ld; a.bl = P_(m, m->t_latlb);
+  a.library = ps.lib; a.cell_base = ps.cell_base;
+  a.nk = make_key(m, ST_EPS_L, ps.sample, ps.training != 0);
+  if (const Injected* ij = inj(m, ST_EPS_L)) { a.inj_eps = ij->d; a.inj_ld = ij->ld; }
+  a.kl_scale = c.beta / (float)ps.global_batch;
+  a.latl = m->latlbuf; a.ldl = 32; a.l = m->lsmp; a.sig = m->lsig; a.eps = m->leps; a.kl = m->kl_l;
+  a.dlatl = m->dlatl; a.dl = m->dl;
+  if (!scvi_head_train_supported(a)) return false;
+  if (out) *out = a;
+  return true;
+}
+
+// mode: 0 full forward; 1 decoder only (z given in m->z); 2 resample (encoder outputs m->latbuf / m->latlbuf kept,
+// only the latent draw and everything after it run again)
+int factor_forward(smx_model* m, const Pass& ps, bool backward);
+int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, int mode) {
+  const bool decode_only = (mode == 1), resample = (mode == 2);
+  const bool encode_only = (mode == 3);   // encoders + latent heads + latent moments / draw 0, no decoder (the stacked-draw paths)
+  const smx_config& c = m->cfg;
+  const float inv_gb = 1.f / (float)ps.global_batch;
+  m->head_loss = false;
+  m->ahead_front_eps = m->ahead_front_drop = false;
+  m->scvi_fused = false; m->encl_twinned = false;
+  bool front_ok = false; LatentArgs front_la;
+  if (!decode_only) {
+  // ---- encoder ----
+  bool twin_done = false;
+  if (!resample) SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd", -1, nullptr, 0, m->scvi ? &m->encl : nullptr, &twin_done));
+  m->encl_twinned = twin_done;
+  const MlpLayer& eL = m->enc.back();
+  const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
+  if (!resample) {
+    const TensorInfo& tw = m->tensors[m->t_latW];
+    GemmArgs g;
+    g.A = eL.out_buf; g.lda = eL.out_p; g.B = P_(m, m->t_latW); g.ldb = tw.ld;
+    g.C = m->latbuf; g.ldc = lat_ld; g.M = ps.B; g.N = lat_ld; g.K = eL.out_p; g.bias = P_(m, m->t_latb);
+    Timed t(m, "gemm_lat_fwd");
+    SMX_CHECK(launch_gemm(m->st, g));
+  }
+  LatentArgs la;
+  la.stochastic = m->stochastic; la.relu = (c.latent_activation == SMX_ACT_RELU); la.training = ps.training;
+  la.lat = m->latbuf; la.ld = lat_ld; la.B = ps.B; la.D = m->D; la.Dp = m->Dp;
+  la.nk = make_key(m, ST_EPS_Z, ps.sample, ps.training != 0);
+  la.rows = ps.rows; la.cell_base = ps.cell_base;
+  if (const Injected* ij = inj(m, ST_EPS_Z)) { la.inj_eps = ij->d; la.inj_ld = ij->ld; }
+  if (m->ahead_front_eps && !la.inj_eps) { la.inj_eps = m->noise_eps; la.inj_ld = m->Dp; }
+  la.z = m->z; la.sig = m->sig; la.eps = m->eps; la.kl = m->kl;
+  // The latent sample + KL and the first decoder product run INSIDE the decoder's first BatchNorm launch (two
+  // launches fewer) when the shapes allow; SMX_NO_FRONT=1 keeps the three-launch form.
+  front_ok = !encode_only && front_shapes_ok(m, ps) && (!la.inj_eps || (la.inj_ld % 4) == 0);
+  front_la = la;
+  if (front_ok) {
+    // (launched below with the decoder)
+  } else {
+    Timed t(m, "latent_fwd");
+    SMX_CHECK(launch_latent_fwd(m->st, la));
+  }
+  if (m->scale) {   // Monte-Carlo KL against the mixture prior at the z just drawn (overwrites the analytic KL)
+    ScalePriorArgs sp;
+    sp.z = m->z; sp.sig = m->sig; sp.eps = m->eps; sp.B = ps.B; sp.D = m->D; sp.Dp = m->Dp; sp.C = c.n_components;
+    sp.logits = P_(m, m->t_prLogits); sp.loc = P_(m, m->t_prLoc); sp.scale_raw = P_(m, m->t_prScale);
+    sp.kl = m->kl; sp.resp = m->resp; sp.dklz = m->dklz;
+    SMX_CHECK(launch_scale_prior_fwd(m->st, sp));
+  }
+  // ---- scvi library latent ----
+  if (m->scvi) {
+    if (!resample) SMX_CHECK(mlp_forward(m, m->encl, ps, ps.Xsrc, m->Gp, true, "gemm_encl_fwd", -1, nullptr, twin_done ? 1 : 0));
+    // training step: the library latent (its head as dot products, the sample, KL_l) is part of the row-local head
+    // launch below (smx_scvi.hip); otherwise the product + lib_latent_fwd pair
+    m->scvi_fused = with_loss && backward && mode == 0 && scvi_train_args(m, ps, nullptr);
+    if (!resample && !m->scvi_fused) {
+      const MlpLayer& lL = m->encl.back();
+      const TensorInfo& tw = m->tensors[m->t_latlW];
+      GemmArgs g;
+      g.A = lL.out_buf; g.lda = lL.out_p; g.B = P_(m, m->t_latlW); g.ldb = tw.ld;
+      g.C = m->latlbuf; g.ldc = 32; g.M = ps.B; g.N = 32; g.K = lL.out_p; g.bias = P_(m, m->t_latlb);
+      SMX_CHECK(launch_gemm(m->st, g));
+    }
+    if (!m->scvi_fused) {
+      LibLatentArgs ll;
+      ll.latl = m->latlbuf; ll.ld = 32; ll.B = ps.B; ll.library = ps.lib; ll.rows = ps.rows; ll.cell_base = ps.cell_base;
+      ll.nk = make_key(m, ST_EPS_L, ps.sample, ps.training != 0);
+      if (const Injected* ij = inj(m, ST_EPS_L)) { ll.inj_eps = ij->d; ll.inj_ld = ij->ld; }
+      ll.clip_library = c.clip_library;
+      ll.l = m->lsmp; ll.sig = m->lsig; ll.eps = m->leps; ll.kl = m->kl_l;
+      SMX_CHECK(launch_lib_latent_fwd(m->st, ll));
+    }
+  }
+  }  // !decode_only
+  if (encode_only) return SMX_OK;
+  // ---- decoder ----
+  SMX_CHECK(mlp_forward(m, m->dec, ps, m->z, m->Dp, false, "", -1, front_ok ? &front_la : nullptr));
+  const MlpLayer& dL = m->dec.back();
+  const long ldp = (long)m->k * m->Gp;
+  if (m->scvi) {
+    GemmArgs hg[3];
+    for (int ch = 0; ch < m->k; ++ch) {
+      const TensorInfo& tw = m->tensors[m->t_outW[ch]];
+      GemmArgs& g = hg[ch];
+      g.A = dL.out_buf; g.lda = dL.out_p; g.B = P_(m, m->t_outW[ch]); g.ldb = tw.ld;
+      g.C = m->raw + (long)ch * m->Gp; g.ldc = (int)ldp; g.M = ps.B; g.N = m->Gp; g.K = dL.out_p;
+      g.bias = P_(m, m->t_outb[ch]);
+    }
+    {
+      // the heads read the same decoder output: pairs of them side by side in one launch
+      const bool no_twin = !m->flags.twin;
+      Timed t(m, "gemm_out_fwd");
+      int ch = 0;
+      for (; !no_twin && ch + 1 < m->k; ch += 2) SMX_CHECK(launch_gemm_dual(m->st, hg[ch], hg[ch + 1]));
+      for (; ch < m->k; ++ch) SMX_CHECK(launch_gemm(m->st, hg[ch]));
+    }
+  }
+  if (m->scvi && m->scvi_fused) {
+    ScviTrainArgs st;
+    scvi_train_args(m, ps, &st);
+    // (timing mode: the idempotent launch repeated inside one event pair, as for the other likelihood kernels)
+    const int reps = (!m->capturing && m->timing_label == "loss") ? m->timing_reps : 1;
+    Timed t(m, "loss");
+    for (int r = 0; r < reps; ++r) SMX_CHECK(launch_scvi_head_train(m->st, st));
+  } else if (m->scvi) {
+    ScviHeadArgs sh;
+    sh.raw = m->raw; sh.planes = m->P; sh.ld = ldp; sh.plane_stride = m->Gp; sh.B = ps.B; sh.G = m->G; sh.Gp = m->Gp;
+    sh.k = m->k; sh.l = m->lsmp; sh.clip_library = c.clip_library; sh.rho_raw = m->rho;
+    SMX_CHECK(launch_scvi_head_fwd(m->st, sh));
+  } else if ((m->head_loss = (with_loss && backward && use_head_loss(m, ps.B)))) {
+    // the product runs below, fused with the likelihood
+  } else {
+    const TensorInfo& tw = m->tensors[m->t_outW[0]];
+    GemmArgs g;
+    g.A = dL.out_buf; g.lda = dL.out_p; g.B = P_(m, m->t_outW[0]); g.ldb = tw.ld;
+    g.C = m->P; g.ldc = (int)ldp; g.M = ps.B; g.N = (int)ldp; g.K = dL.out_p; g.bias = P_(m, m->t_outb[0]);
+    Timed t(m, "gemm_out_fwd");
+    SMX_CHECK(launch_gemm(m->st, g));
+  }
+  // ---- label heads (raw outputs) ----
+  for (int j = 0; j < m->n_heads; ++j) {
+    const TensorInfo& tw = m->tensors[m->t_labW[j]];
+    GemmArgs g;
+    g.A = dL.out_buf; g.lda = dL.out_p; g.B = P_(m, m->t_labW[j]); g.ldb = tw.ld;
+    g.C = m->laby_raw[j]; g.ldc = tw.ld; g.M = ps.B; g.N = tw.ld; g.K = dL.out_p; g.bias = P_(m, m->t_labb[j]);
+    SMX_CHECK(launch_gemm(m->st, g));
+  }
+  if (!with_loss) return SMX_OK;
+  // ---- losses ----
+  LossArgs lo;
+  lo.likelihood = c.likelihood; lo.direct = m->scvi; lo.backward = backward;
+  lo.X = ps.Xsrc; lo.x_u16 = ps.x_u16; lo.ldx = m->Gp; lo.rows = ps.xrows;
+  lo.P = m->P; lo.ldp = ldp; lo.plane_stride = m->Gp; lo.dP = m->dP; lo.llk_part = m->llk_part;
+  lo.B = ps.B; lo.G = m->G; lo.Gp = m->Gp; lo.grad_scale = -inv_gb;
+  int n_llk_chunks = loss_chunks(m->Gp, ps.B);
+  if (m->scvi && m->scvi_fused) {
+    n_llk_chunks = 1;   // the row-local head launch above left one partial per cell
+  } else if (m->head_loss) {
+    const TensorInfo& tw = m->tensors[m->t_outW[0]];
+    HeadLossArgs hl;
+    hl.H = dL.out_buf; hl.ldh = dL.out_p; hl.W = P_(m, m->t_outW[0]); hl.ldw = tw.ld; hl.bias = P_(m, m->t_outb[0]);
+    hl.X = ps.Xsrc; hl.x_u16 = ps.x_u16; hl.ldx = m->Gp; hl.rows = ps.xrows;
+    hl.dP = m->dP; hl.ldp = ldp; hl.plane_stride = m->Gp; hl.llk_part = m->llk_part;
+    hl.B = ps.B; hl.G = m->G; hl.Gp = m->Gp; hl.Hp = dL.out_p; hl.likelihood = c.likelihood; hl.grad_scale = -inv_gb;
+    n_llk_chunks = head_loss_chunks(m->Gp);
+    if (!m->capturing && m->timing_label == "out_head_product") {
+      // timing mode: the product alone (P stored, no counts, no likelihood) -- what the fused kernel's time is
+      // compared with to attribute the rest to the likelihood (bench.py, roofline)
+      HeadLossArgs po = hl;
+      po.product_only = 1; po.dP = m->P;
+      Timed t(m, "out_head_product");
+      for (int r = 0; r < m->timing_reps; ++r) SMX_CHECK(launch_out_head_loss(m->st, po));
+    }
+    const int reps = (!m->capturing && m->timing_label == "out_head") ? m->timing_reps : 1;   // idempotent
+    Timed t(m, "out_head");
+    for (int r = 0; r < reps; ++r) SMX_CHECK(launch_out_head_loss(m->st, hl));
+  } else {
+    // timing mode: the (idempotent) kernel is launched SMX_LOSS_TIMING_REPEAT times inside one event pair so
+    // the pair's own ~5 us overhead can be separated from the per-launch time (bench.py)
+    const int reps = (!m->capturing && m->timing_label == "loss") ? m->timing_reps : 1;
+    Timed t(m, "loss");
+    for (int r = 0; r < reps; ++r) SMX_CHECK(launch_count_loss(m->st, lo));
+  }
+  for (int j = 0; j < m->n_heads; ++j) {
+    const TensorInfo& tw = m->tensors[m->t_labW[j]];
+    LabelArgs lb;
+    lb.kind = c.label_llk[j]; lb.C = c.label_components[j]; lb.raw = m->laby_raw[j]; lb.ld = tw.ld; lb.Y = m->Y[j]; lb.ldy = m->lab_Pp[j];
+    lb.rows = ps.rows; lb.mask = m->mask; lb.B = ps.B; lb.P = c.label_dim[j]; lb.Pp = m->lab_Pp[j];
+    lb.grad_scale = -c.alpha * inv_gb; lb.draw = m->laby_draw[j]; lb.llk = m->llk_y; lb.add = (j > 0);
+    lb.backward = backward;
+    SMX_CHECK(launch_label_loss(m->st, lb));
+  }
+  if (m->fvae) SMX_CHECK(factor_forward(m, ps, backward));
+  MetricsArgs me;
+  me.llk_part = m->llk_part; me.n_chunks = n_llk_chunks; me.lgx1 = ps.lgx1; me.rows = ps.rows;
+  me.llk_y = c.n_labels ? m->llk_y : nullptr;
+  if (m->fvae) { me.tc = m->tc_cell; me.dl = m->dl_cell; me.gamma = c.gamma; }
+  me.kl = m->stochastic ? m->kl : nullptr; me.kl_l = m->scvi ? m->kl_l : nullptr;
+  me.B = ps.B; me.alpha = c.alpha; me.beta = c.beta; me.inv_global_batch = inv_gb;
+  me.out = m->grads + m->tail_off_metrics;
+  if (backward && !dp_active(m)) { me.hist = m->mhist; me.state = cur_state(m); }
+  if (backward) {
+    // training step: the scalars come from one extra workgroup of a later launch -- of the optimiser kernel, or,
+    // under data parallelism (they must be in the flat buffer BEFORE the all-reduce), of the first
+    // BatchNorm-backward launch
+    m->pending_metrics = me;
+    m->have_pending_metrics = true;
+    m->metrics_before_allreduce = dp_active(m);
+    return SMX_OK;
+  }
+  {
+    Timed t(m, "metrics");
+    SMX_CHECK(launch_metrics(m->st, me));
+  }
+  return SMX_OK;
+}
+
+// ---- FactorVAE discriminator (fvae.py:9-18; Kim & Mnih 2018, Algorithm 2) -------------------------------------------
+// forward: stacked batch [z ; permute_dims(z)] through the discriminator, then the head (TC estimate, discriminator
+// loss, SemiFVAE's cross-entropy, both upstream gradients).  Runs after the latent sample exists; m->slab is free then.
+int factor_forward(smx_model* m, const Pass& ps, bool backward) {
+  const smx_config& c = m->cfg;
+  const int B = ps.B, B2 = 2 * ps.B;
+  SMX_REQUIRE(B2 <= 2 * m->Bmax, "batch exceeds max_batch");
+  PermuteArgs pa;
+  pa.z = m->z; pa.ldz = m->Dp; pa.zz = m->zz; pa.ld = m->Dp; pa.B = B; pa.D = m->D;
+  pa.nk = make_key(m, ST_PERMUTE, ps.sample, ps.training != 0);
+  pa.rows = ps.rows; pa.cell_base = ps.cell_base;
+  if (const Injected* ij = inj(m, ST_PERMUTE)) { pa.inj_u = ij->d; pa.inj_ld = ij->ld; }
+  {
+    Timed t(m, "disc_permute");
+    SMX_CHECK(launch_permute_dims(m->st, pa));
+  }
+  Pass p2 = ps;
+  p2.B = B2; p2.rows = nullptr; p2.training = 1;   // (no BatchNorm / dropout in the discriminator: the mode is immaterial)
+  SMX_CHECK(mlp_forward(m, m->disc, p2, m->zz, m->Dp, false, "disc_fwd"));
+  const MlpLayer& last = m->disc.back();
+  const TensorInfo& tw = m->tensors[m->t_discoutW];
+  GemmArgs g;
+  g.A = last.out_buf; g.lda = last.out_p; g.B = P_(m, m->t_discoutW); g.ldb = tw.ld;
+  g.M = B2; g.N = tw.ld; g.K = last.out_p;
+  g.C = m->slab; g.ldc = tw.ld; g.slab_stride = (long)B2 * tw.ld;
+  g.split_k = suggest_split_k(B2, tw.ld, last.out_p);
+  SMX_REQUIRE((size_t)std::max(g.split_k, 1) * (size_t)g.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
+  int eff = 1;
+  {
+    Timed t(m, "disc_fwd");
+    SMX_CHECK(launch_gemm(m->st, g, &eff));
+  }
+  DiscHeadArgs h;
+  h.logits = m->slab; h.n_slabs = eff; h.slab_stride = g.slab_stride; h.ld = tw.ld;
+  h.bias = P_(m, m->t_discoutb); h.n_out = tw.cols; h.B = B;
+  h.gamma = c.gamma; h.alpha = c.alpha; h.inv_gb = 1.f / (float)ps.global_batch; h.backward = backward ? 1 : 0;
+  if (c.n_labels && m->Y[0] && ps.Xsrc == m->X) { h.Y = m->Y[0]; h.ldy = m->lab_Pp[0]; h.rows = ps.rows; h.mask = m->mask; }
+  h.u_tc = m->u_tc; h.u_d = m->u_d; h.tc_cell = m->tc_cell; h.dl_cell = m->dl_cell; h.llk_y = c.n_labels ? m->llk_y : nullptr;
+  Timed t(m, "disc_head");
+  SMX_CHECK(launch_disc_head(m->st, h));
+  return SMX_OK;
+}
+
+// One backward sweep of the discriminator over the first `rows` rows of the stacked batch with upstream `up`
+// [rows][32] on the logits.  with_grads: the discriminator's own gradients (its objective; nothing flows into z);
+// otherwise only d objective / d z, left in m->dz_tc (the VAE objective's TC term; the weights are constants of it).
+int factor_sweep(smx_model* m, int rows, const float* up, bool with_grads) {
+  const MlpLayer& last = m->disc.back();
+  const TensorInfo& two = m->tensors[m->t_discoutW];
+  if (with_grads) {
+    GemmArgs gw;
+    gw.A = last.out_buf; gw.lda = last.out_p; gw.a_kmajor = 1; gw.B = up; gw.ldb = 32;
+    gw.C = G_(m, m->t_discoutW); gw.ldc = two.ld; gw.M = last.out_p; gw.N = two.ld; gw.K = rows;
+    gw.colsum = G_(m, m->t_discoutb);
+    want_sq(m, gw, m->t_discoutW);
+    Timed t(m, "disc_bwd");
+    SMX_CHECK(launch_gemm(m->st, gw));
+  }
+  int n_slabs = 1;
+  {
+    GemmArgs gh;
+    gh.A = up; gh.lda = 32; gh.B = P_(m, m->t_discoutW); gh.ldb = two.ld; gh.b_nmajor = 1;
+    gh.M = rows; gh.N = last.out_p; gh.K = two.ld;
+    gh.C = m->slab; gh.ldc = last.out_p; gh.slab_stride = (long)rows * last.out_p; gh.split_k = 1;
+    Timed t(m, "disc_bwd");
+    SMX_CHECK(launch_gemm(m->st, gh, &n_slabs));
+  }
+  // The discriminator's layers have neither BatchNorm nor dropout: below the top layer the activation's derivative runs
+  // in the store path of the d-input product above (which then writes the layer's d pre-activation directly) and the bias
+  // gradient is the column sum its weight-gradient product takes along -- no bias / activation backward launch per
+  // layer (flag act_epilogue).  Without gradients (the TC sweep) the d pre-activations ping-pong between two scratch
+  // buffers, as a product must not write the operand it reads.
+  float* pong[2] = {m->disc_dpre, m->slab};
+  int pp = 0;
+  bool ready = false;
+  float* dpre_i = nullptr;
+  for (int i = (int)m->disc.size() - 1; i >= 0; --i) {
+    MlpLayer& L = m->disc[i];
+    const TensorInfo& tw = m->tensors[L.tW];
+    if (!ready) {
+      dpre_i = with_grads ? L.dpre : pong[pp];
+      BnBwdArgs b;
+      b.dout = m->slab; b.n_slabs = n_slabs; b.slab_stride = (long)rows * L.out_p; b.ld = L.out_p;
+      b.out = L.out_buf; b.B = rows; b.H = L.out; b.Hp = L.out_p; b.batchnorm = 0; b.training = 1; b.drop_scale = 1.f; b.leak = L.leak;
+      b.dpre = dpre_i;
+      b.dbias = with_grads ? G_(m, L.tBias) : m->disc_db;
+      Timed t(m, "disc_bwd");
+      SMX_CHECK(launch_bn_act_bwd(m->st, b));
+    }
+    const float* in = (i == 0) ? m->zz : m->disc[i - 1].out_buf;
+    const int ld_in = (i == 0) ? m->Dp : m->disc[i - 1].out_p;
+    if (with_grads) {
+      GemmArgs g;
+      g.A = in; g.lda = ld_in; g.a_kmajor = 1; g.B = dpre_i; g.ldb = L.out_p;
+      g.C = G_(m, L.tW); g.ldc = tw.ld; g.M = L.in_p; g.N = L.out_p; g.K = rows;
+      if (ready) g.colsum = G_(m, L.tBias);
+      want_sq(m, g, L.tW);
+      Timed t(m, "disc_bwd");
+      SMX_CHECK(launch_gemm(m->st, g));
+      if (i == 0) break;   // z is a constant of the discriminator's objective
+    }
+    GemmArgs h;
+    h.A = dpre_i; h.lda = L.out_p; h.B = P_(m, L.tW); h.ldb = tw.ld; h.b_nmajor = 1;
+    h.M = rows; h.N = L.in_p; h.K = L.out_p;
+    ready = false;
+    if (i == 0) { h.C = m->dz_tc; h.ldc = m->Dp; h.split_k = 1; h.tile = TILE_32x32_K4; }
+    else {
+      h.C = m->slab; h.ldc = L.in_p; h.slab_stride = (long)rows * L.in_p;
+      h.split_k = suggest_split_k(rows, L.in_p, L.out_p);
+      SMX_REQUIRE((size_t)h.split_k * (size_t)h.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
+      if (m->flags.act_epilogue && h.split_k <= 1 && (with_grads || pong[pp ^ 1] != dpre_i)) {
+        MlpLayer& Lo = m->disc[i - 1];
+        float* next = with_grads ? Lo.dpre : pong[pp ^= 1];
+        h.split_k = 1; h.act = 2; h.leak = Lo.leak; h.act_out = Lo.out_buf; h.act_ld = Lo.out_p;
+        h.C = next; h.ldc = Lo.out_p; h.slab_stride = 0;
+        ready = true;
+      }
+    }
+    {
+      Timed t(m, "disc_bwd");
+      SMX_CHECK(launch_gemm(m->st, h, &n_slabs));
+    }
+    if (ready) dpre_i = h.C;
+  }
+  return SMX_OK;
+}
+
+int factor_backward(smx_model* m, const Pass& ps) {
+  SMX_CHECK(factor_sweep(m, 2 * ps.B, m->u_d, true));    // discriminator objective -> the discriminator's tensors
+  SMX_CHECK(factor_sweep(m, ps.B, m->u_tc, false));      // gamma TC (+ alpha CE) -> d z
+  return SMX_OK;
+}
+
+int backward_pass(smx_model* m, const Pass& ps) {
+  const smx_config& c = m->cfg;
+  std::fill(m->sq_count.begin(), m->sq_count.end(), 0);   // the products of this step report what they wrote
+  std::fill(m->sq_reduced.begin(), m->sq_reduced.end(), 0);
+  m->adam_early_pending = false; m->adam_early_from = -1;
+  const float inv_gb = 1.f / (float)ps.global_batch;
+  if (m->fvae) SMX_CHECK(factor_backward(m, ps));   // first: it uses the slab buffer the head's backward fills next
+  const MlpLayer& dL = m->dec.back();
+  const long ldp = (long)m->k * m->Gp;
+  int n_slabs = 0;
+  const long dd_stride = (long)ps.B * dL.out_p;
+  const float* dparams = m->dP;
+  std::vector<GemmArgs> lab_dw;
+  m->lab_deferred = false;
+  if (m->scvi) {
+    ScviHeadArgs sh;
+    sh.raw = m->raw; sh.planes = m->P; sh.ld = ldp; sh.plane_stride = m->Gp; sh.B = ps.B; sh.G = m->G; sh.Gp = m->Gp;
+    sh.k = m->k; sh.l = m->lsmp; sh.clip_library = c.clip_library; sh.rho_raw = m->rho;
+    sh.dplanes = m->dP; sh.draw = m->draw; sh.dl = m->dl;
+    if (!m->scvi_fused) SMX_CHECK(launch_scvi_head_bwd(m->st, sh));   // (the row-local head launch of the forward pass left d raw and d l)
+    dparams = m->draw;
+  }
+  const int n_heads = m->scvi ? m->k : 1;
+  // count heads with raw planes: both products of the output head in one launch of the wide direct-operand kernel
+  // (smx_headbwd.hip); SMX_NO_HEAD_BWD=1 or scvi: the grouped LDS-tiled products below
+  // (scvi: the planes are separate head tensors -- the kernel's SEP form)
+  const bool hbwd = m->flags.head_bwd && head_bwd_supported(ps.B, dL.out_p, m->Gp) && (!m->scvi || (m->k >= 2 && m->k <= 3));
+  if (hbwd) {
+    const TensorInfo& tw = m->tensors[m->t_outW[0]];
+    HeadBwdArgs hb;
+    hb.D = dL.out_buf; hb.ldd = dL.out_p; hb.dP = dparams; hb.ldp = ldp; hb.W = P_(m, m->t_outW[0]); hb.ldw = tw.ld;
+    hb.dW = G_(m, m->t_outW[0]); hb.db = G_(m, m->t_outb[0]);
+    if (m->scvi) {
+      hb.sep = 1;
+      for (int ch = 0; ch < m->k; ++ch) {
+        hb.Wp[ch] = P_(m, m->t_outW[ch]); hb.dWp[ch] = G_(m, m->t_outW[ch]); hb.dbp[ch] = G_(m, m->t_outb[ch]);
+        if (m->sq_slots && getenv("SMX_NO_SQ_PARTIALS") == nullptr) {
+          hb.sqp[ch] = m->sq_slots + m->sq_first[(size_t)m->t_outW[ch]]; hb.sq_countp[ch] = &m->sq_count[(size_t)m->t_outW[ch]];
+        }
+      }
+    }
+    hb.B = ps.B; hb.Hp = dL.out_p; hb.Gp = m->Gp; hb.n_planes = m->k;
+    hb.n_slices = head_bwd_slices(ldp, ldp <= 8192 ? 16 : 32, &hb.k_chunk);
+    hb.slab = m->slab; hb.slab_stride = dd_stride;
+    SMX_REQUIRE((size_t)hb.n_slices * (size_t)dd_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
+    if (!m->scvi && m->sq_slots && getenv("SMX_NO_SQ_PARTIALS") == nullptr) {
+      hb.sq_part = m->sq_slots + m->sq_first[(size_t)m->t_outW[0]]; hb.sq_count = &m->sq_count[(size_t)m->t_outW[0]];
+    }
+    n_slabs = hb.n_slices;
+    // label heads (SISUA / MISA): d d += d Y W_lab^T as extra slabs of this launch, the head's weight gradient with the
+    // grouped launch at the end of the backward pass -- instead of a grouped launch of their own here (8.6 us at C4)
+    if (m->n_heads > 0 && m->flags.label_ride && !m->fvae) {
+      bool ok = true;
+      for (int j = 0; j < m->n_heads; ++j) ok = ok && (m->tensors[m->t_labW[j]].ld % 32) == 0;
+      ok = ok && (size_t)(hb.n_slices + m->n_heads) * (size_t)dd_stride <= m->slab_cap;
+      if (ok) {
+        for (int j = 0; j < m->n_heads; ++j) {
+          const TensorInfo& tl = m->tensors[m->t_labW[j]];
+          hb.xA[j] = m->laby_draw[j]; hb.xlda[j] = tl.ld; hb.xW[j] = P_(m, m->t_labW[j]); hb.xldw[j] = tl.ld; hb.xK[j] = tl.ld;
+        }
+        hb.n_extra = m->n_heads;
+        n_slabs += m->n_heads;
+        m->lab_deferred = true;
+      }
+    }
+    Timed t(m, "gemm_out_bwd");
+    SMX_CHECK(launch_out_head_bwd(m->st, hb));
+  }
+  {
+    // weight gradient and input gradient of every head read the same dP and are independent:
+    // one grouped launch (dW tiles + split-K dX slabs side by side)
+    std::vector<GemmArgs> grp;
+    std::vector<int> is_dx;
+    for (int ch = 0; ch < n_heads && !hbwd; ++ch) {
+      const TensorInfo& tw = m->tensors[m->t_outW[ch]];
+      const float* dp = dparams + (m->scvi ? (long)ch * m->Gp : 0);
+      const int ncols = m->scvi ? m->Gp : (int)ldp;
+      GemmArgs g;  // dW = d^T dP, db = colsum(dP)
+      g.A = dL.out_buf; g.lda = dL.out_p; g.a_kmajor = 1; g.B = dp; g.ldb = (int)ldp;
+      g.C = G_(m, m->t_outW[ch]); g.ldc = tw.ld; g.M = dL.out_p; g.N = ncols; g.K = ps.B;
+      g.colsum = G_(m, m->t_outb[ch]);
+      want_sq(m, g, m->t_outW[ch]);
+      g.tile = TILE_128x32;
+      grp.push_back(g); is_dx.push_back(0);
+      GemmArgs h;  // dd += dP W^T
+      h.A = dp; h.lda = (int)ldp; h.B = P_(m, m->t_outW[ch]); h.ldb = tw.ld; h.b_nmajor = 1;
+      h.C = nullptr; h.ldc = dL.out_p; h.slab_stride = dd_stride;
+      h.M = ps.B; h.N = dL.out_p; h.K = ncols;
+      h.split_k = suggest_split_k(ps.B, dL.out_p, ncols);
+      h.tile = TILE_32x32_K4;
+      grp.push_back(h); is_dx.push_back(1);
+    }
+    for (int j = 0; j < m->n_heads; ++j) {
+      const TensorInfo& tw = m->tensors[m->t_labW[j]];
+      GemmArgs g;
+      g.A = dL.out_buf; g.lda = dL.out_p; g.a_kmajor = 1; g.B = m->laby_draw[j]; g.ldb = tw.ld;
+      g.C = G_(m, m->t_labW[j]); g.ldc = tw.ld; g.M = dL.out_p; g.N = tw.ld; g.K = ps.B;
+      g.colsum = G_(m, m->t_labb[j]);
+      want_sq(m, g, m->t_labW[j]);
+      if (m->lab_deferred) { lab_dw.push_back(g); continue; }   // (d d rode with the output head's backward launch)
+      grp.push_back(g); is_dx.push_back(0);
+      GemmArgs h;
+      h.A = m->laby_draw[j]; h.lda = tw.ld; h.B = P_(m, m->t_labW[j]); h.ldb = tw.ld; h.b_nmajor = 1;
+      h.C = nullptr; h.ldc = dL.out_p; h.slab_stride = dd_stride;
+      h.M = ps.B; h.N = dL.out_p; h.K = tw.ld;
+      grp.push_back(h); is_dx.push_back(1);
+    }
+    // slab slots: split factors are known up front (launch_gemm_group recomputes the same values)
+    for (size_t i = 0; i < grp.size(); ++i) {
+      if (!is_dx[i]) continue;
+      GemmArgs& h = grp[i];
+      const int BK = 128;  // K4 tile for split products; single-slab products may take either tile
+      int eff = 1;
+      if (h.split_k > 1) {
+        const int chunk = round_up((h.K + h.split_k - 1) / h.split_k, BK);
+        eff = (h.K + chunk - 1) / chunk;
+      }
+      h.C = m->slab + (long)n_slabs * dd_stride;
+      n_slabs += eff;
+      SMX_REQUIRE((size_t)n_slabs * (size_t)dd_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
+    }
+    if (!grp.empty()) {
+      Timed t(m, hbwd ? "gemm_lab_bwd" : "gemm_out_bwd");
+      for (size_t i = 0; i < grp.size(); i += SMX_GROUP_MAX) {
+        const int n = (int)std::min<size_t>(SMX_GROUP_MAX, grp.size() - i);
+        SMX_CHECK(launch_gemm_group(m->st, grp.data() + i, n));
+      }
+    }
+    m->adam_early_pending = true;   // dW / db of every head are final now
+    if (dp_overlap(m)) {  // head gradients are final: reduce them while the rest of backward runs
+      SMX_HIP(hipEventRecord(m->ev_c1, m->st));
+      SMX_HIP(hipStreamWaitEvent(m->st_comm, m->ev_c1, 0));
+      SMX_CHECK(dp_allreduce(m, m->bucket1_off, m->bucket1_count, m->st_comm));
+      m->bucket1_in_flight = true;
+    }
+  }
+  // ---- decoder MLP; the latent head's backward runs in the epilogue of the d z product ----
+  const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
+  EpiLatentBwd le;
+  le.lat = m->latbuf; le.ld = lat_ld; le.sig = m->sig; le.eps = m->eps; le.kl_scale = c.beta * inv_gb;
+  le.D = m->D; le.Dp = m->Dp; le.stochastic = m->stochastic; le.relu = (c.latent_activation == SMX_ACT_RELU);
+  le.dlat = m->dlat;
+  if (m->fvae) le.dz_add = m->dz_tc;
+  if (m->scale) {
+    le.dklz = m->dklz;
+    ScalePriorArgs sp;
+    sp.z = m->z; sp.B = ps.B; sp.D = m->D; sp.Dp = m->Dp; sp.C = c.n_components;
+    sp.logits = P_(m, m->t_prLogits); sp.loc = P_(m, m->t_prLoc); sp.scale_raw = P_(m, m->t_prScale);
+    sp.resp = m->resp; sp.kl_scale = c.beta * inv_gb;
+    sp.g_logits = G_(m, m->t_prLogits); sp.g_loc = G_(m, m->t_prLoc); sp.g_scale = G_(m, m->t_prScale);
+    SMX_CHECK(launch_scale_prior_bwd(m->st, sp));
+  }
+  // Products that only the optimiser reads (the weight gradients of the first decoder layer, of the latent head and of
+  // the first encoder layers) run as ONE grouped launch at the end; the last encoder layer's BatchNorm-backward
+  // launch computes d h = d lat W_lat^T itself.  SMX_NO_BWD_FRONT=1: the separate launches of before.
+  const MlpLayer& eL = m->enc.back();
+  const bool bfront = m->flags.bwd_front && !sync_bn_on(m, ps.training) && bn_bwd_front_supported(ps.B, lat_ld) && eL.out_p % 8 == 0;
+  std::vector<GemmArgs> tail;
+  SMX_CHECK(mlp_backward(m, m->dec, ps, m->z, m->Dp, false, n_slabs, false, nullptr, "", &le, nullptr, nullptr, bfront ? &tail : nullptr));
+  for (const GemmArgs& g : lab_dw) tail.push_back(g);
+  BnBwdArgs gf;
+  {  // weight gradient of the latent head and d h = d lat * W_lat^T
+    const TensorInfo& tw = m->tensors[m->t_latW];
+    GemmArgs pair[2];
+    GemmArgs& g = pair[0];
+    g.A = eL.out_buf; g.lda = eL.out_p; g.a_kmajor = 1; g.B = m->dlat; g.ldb = lat_ld;
+    g.C = G_(m, m->t_latW); g.ldc = tw.ld; g.M = eL.out_p; g.N = lat_ld; g.K = ps.B; g.colsum = G_(m, m->t_latb);
+    want_sq(m, g, m->t_latW);
+    if (bfront) {
+      tail.push_back(g);
+      gf.fD = m->dlat; gf.fld = lat_ld; gf.fW = P_(m, m->t_latW); gf.fldw = tw.ld; gf.fK = lat_ld;
+    } else {   // independent: one grouped launch
+      GemmArgs& h = pair[1];
+      h.A = m->dlat; h.lda = lat_ld; h.B = P_(m, m->t_latW); h.ldb = tw.ld; h.b_nmajor = 1;
+      h.C = m->slab; h.ldc = eL.out_p; h.slab_stride = (long)ps.B * eL.out_p;
+      h.M = ps.B; h.N = eL.out_p; h.K = lat_ld;
+      Timed t(m, "gemm_lat_bwd");
+      SMX_CHECK(launch_gemm_group(m->st, pair, 2));
+    }
+  }
+  GemmArgs dw0[2];
+  int n_dw0 = 0;
+  // scvi: the library encoder's last BatchNorm-backward takes its incoming gradient d h_l = d latl W_latl^T as a front
+  // too (K = 32) -- and then runs beside the encoder's in ONE launch when d latl is there already (the row-local head
+  // launch of the forward pass leaves it); the library head's weight gradient joins the grouped launch at the end
+  BnBwdArgs gfl;
+  bool lfront = false, twin_done = false;
+  if (m->scvi) {
+    const MlpLayer& lL = m->encl.back();
+    const TensorInfo& tw = m->tensors[m->t_latlW];
+    lfront = bfront && bn_bwd_front_supported(ps.B, 32) && lL.out_p % 8 == 0 && (tw.ld % 4) == 0;
+    gfl.fD = m->dlatl; gfl.fld = 32; gfl.fW = P_(m, m->t_latlW); gfl.fldw = tw.ld; gfl.fK = 32;
+  }
+  const bool twin_bwd = m->scvi && lfront && m->scvi_fused;
+  SMX_CHECK(mlp_backward(m, m->enc, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_enc_dw", nullptr, &dw0[n_dw0], bfront ? &gf : nullptr,
+                         bfront ? &tail : nullptr, twin_bwd ? &m->encl : nullptr, twin_bwd ? &gfl : nullptr, &twin_done));
+  ++n_dw0;
+  // ---- scvi library branch ----
+  if (m->scvi) {
+    if (!m->scvi_fused) {
+      LibLatentArgs ll;
+      ll.latl = m->latlbuf; ll.ld = 32; ll.B = ps.B; ll.library = ps.lib; ll.rows = ps.rows;
+      ll.sig = m->lsig; ll.eps = m->leps; ll.dl = m->dl; ll.kl_scale = c.beta * inv_gb; ll.dlatl = m->dlatl;
+      SMX_CHECK(launch_lib_latent_bwd(m->st, ll));
+    }
+    const MlpLayer& lL = m->encl.back();
+    const TensorInfo& tw = m->tensors[m->t_latlW];
+    GemmArgs g;
+    g.A = lL.out_buf; g.lda = lL.out_p; g.a_kmajor = 1; g.B = m->dlatl; g.ldb = 32;
+    g.C = G_(m, m->t_latlW); g.ldc = tw.ld; g.M = lL.out_p; g.N = 32; g.K = ps.B; g.colsum = G_(m, m->t_latlb);
+    want_sq(m, g, m->t_latlW);
+    if (lfront) {
+      tail.push_back(g);
+    } else {
+      GemmArgs h;
+      h.A = m->dlatl; h.lda = 32; h.B = P_(m, m->t_latlW); h.ldb = tw.ld; h.b_nmajor = 1;
+      h.C = m->slab; h.ldc = lL.out_p; h.slab_stride = (long)ps.B * lL.out_p;
+      h.M = ps.B; h.N = lL.out_p; h.K = 32;
+      GemmArgs pair[2] = {g, h};   // weight and input gradient of the library head: independent, one grouped launch
+      SMX_CHECK(launch_gemm_group(m->st, pair, 2));
+    }
+    SMX_CHECK(mlp_backward(m, m->encl, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_encl_dw", nullptr, &dw0[n_dw0],
+                           lfront ? &gfl : nullptr, bfront ? &tail : nullptr, nullptr, nullptr, nullptr, twin_done));
+    ++n_dw0;
+  }
+  // the first-layer weight gradients (gather + log1p of the same resident rows) of the encoder and, for scvi,
+  // the library encoder are independent: one grouped launch
+  for (int q = 0; q < n_dw0; ++q) tail.push_back(dw0[q]);
+  {
+    Timed t(m, "gemm_enc_dw");
+    // every product here contracts over the minibatch: the wide direct-operand kernel takes them all in one launch
+    // (SMX_NO_WGRAD=1, input dropout or an unsupported shape: the LDS-tiled products)
+    bool wg_ok = m->flags.wgrad && tail.size() <= SMX_GROUP_MAX;
+    for (const GemmArgs& g : tail) wg_ok = wg_ok && wgrad_supported(g, ps.B);
+    if (wg_ok) SMX_CHECK(launch_wgrad_group(m->st, tail.data(), (int)tail.size(), ps.B));
+    else if (tail.size() == 1) SMX_CHECK(launch_gemm(m->st, tail[0]));
+    else
+      for (size_t q = 0; q < tail.size(); q += SMX_GROUP_MAX)
+        SMX_CHECK(launch_gemm_group(m->st, tail.data() + q, (int)std::min<size_t>(SMX_GROUP_MAX, tail.size() - q)));
+  }
+  return SMX_OK;
+}
+
+// everything of AdamArgs that does not depend on which launch carries the chunks
+void fill_adam_args(smx_model* m, AdamArgs& a) {
+  const smx_config& c = m->cfg;
+  a.params = m->params; a.grads = m->grads; a.m = m->adam_m; a.v = m->adam_v;
+  a.chunks = m->chunks; a.n_chunks = m->n_chunks; a.n_launch = m->n_chunks; a.gap_from = m->n_chunks; a.gap_len = 0;
+  a.partial = m->partial; a.tensor_norm = m->tensor_norm;
+  // norms from the products' partials when every large tensor has them (single GPU: under data parallelism the
+  // norm is that of the all-reduced gradient, which only a pass after the collective can give)
+  a.use_sq = (m->sq_slots != nullptr && !dp_active(m) && getenv("SMX_NO_SQ_PARTIALS") == nullptr) ? 1 : 0;
+  for (size_t t = 0; t < m->tensors.size() && a.use_sq; ++t) {
+    a.sq_first[t] = m->sq_first[t]; a.sq_count[t] = m->sq_count[t];
+    if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) a.use_sq = 0;
+    if (m->sq_reduced[t]) { a.sq_first[t] = m->sq_total_first + (int)t * SMX_SQR_PER_TENSOR; a.sq_count[t] = m->sq_reduced[t]; }   // riders have summed the slots
+  }
+  a.sq_slots = m->sq_slots;
+  a.state = cur_state(m); a.b1 = c.adam_beta1; a.b2 = c.adam_beta2; a.eps = c.adam_eps; a.clipnorm = c.clipnorm;
+  // the likelihood / KL / label kernels already scale by 1 / (batch * world), so the SUM all-reduce leaves the
+  // global-mean gradient: nothing more to divide by (it used to be divided by world once more here)
+  a.grad_scale = 1.f;
+}
+
+int optimizer_pass(smx_model* m) {
+  const smx_config& c = m->cfg;
+  if (dp_active(m) && m->have_pending_metrics) {   // no BatchNorm-backward launch took them along
+    SMX_CHECK(launch_metrics(m->st, m->pending_metrics));
+    m->have_pending_metrics = false;
+  }
+  if (dp_active(m)) {
+    Timed t(m, "allreduce");
+    if (m->bucket1_in_flight) {
+      // front bucket [encoder/latent/decoder grads | BN stats | metrics] behind the head bucket on the
+      // communication stream; the optimiser waits for both
+      SMX_HIP(hipEventRecord(m->ev_c2, m->st));
+      SMX_HIP(hipStreamWaitEvent(m->st_comm, m->ev_c2, 0));
+      SMX_CHECK(dp_allreduce(m, 0, m->bucket1_off, m->st_comm));
+      SMX_HIP(hipEventRecord(m->ev_c3, m->st_comm));
+      SMX_HIP(hipStreamWaitEvent(m->st, m->ev_c3, 0));
+      m->bucket1_in_flight = false;
+    } else {
+      SMX_CHECK(dp_allreduce(m, 0, m->grads_count, m->st));   // one all-reduce of the whole flat buffer
+    }
+  }
+  AdamArgs a;
+  fill_adam_args(m, a);
+  if (dp_active(m) && m->bn_total && m->world > 1) {
+    if (!a.use_sq) {   // (the usual case under data parallelism: the gradient-norm launch takes the update along)
+      a.bn_moving = m->bn_moving; a.bn_batch = m->grads + m->tail_off_bn; a.bn_total = (int)m->bn_total;
+      a.bn_inv_world = 1.f / (float)m->world; a.bn_momentum = c.bn_momentum;
+    } else {
+      hipLaunchKernelGGL(bn_moving_update_kernel, dim3((unsigned)((m->bn_total + 255) / 256)), dim3(256), 0, m->st,
+                         m->bn_moving, m->grads + m->tail_off_bn, (int)m->bn_total, 1.f / (float)m->world,
+                         c.bn_momentum);
+    }
+  }
+  if (m->adam_early_from >= 0) {   // the head chunks have ridden along already
+    a.gap_from = m->adam_early_from; a.gap_len = m->adam_early_to - m->adam_early_from;
+    a.n_launch = m->n_chunks - a.gap_len;
+  } else {
+    a.gap_from = m->n_chunks; a.gap_len = 0; a.n_launch = m->n_chunks;
+  }
+  m->adam_early_from = -1;
+  if (m->have_pending_metrics) { a.metrics = m->pending_metrics; a.with_metrics = 1; m->have_pending_metrics = false; }
+  a.master = master_state(m); a.lr = c.lr; a.batch = m->seq_batch;
+  if (dp_active(m)) { a.hist_dp = m->mhist; a.tail_metrics = m->grads + m->tail_off_metrics; }
+  a.prepare_next = m->seq_prepare_next;
+  if (a.prepare_next) { a.next_state = m->state3 + (m->par ^ 1); a.next_rows = m->rows2[m->par ^ 1]; a.order = m->order; }
+  Timed t(m, "adam");
+  SMX_CHECK(launch_adam(m->st, a));
+  return SMX_OK;
+}
+
+// sparse store: expand the rows of this pass into the dense tile the readers of X take (they then index it with
+// identity rows; everything else -- labels, library prior, label mask, lgx1, noise keys -- keeps the resident row ids)
+int csr_stage(smx_model* m, Pass& ps) {
+  if (!m->x_csr || ps.Xsrc != m->X) return SMX_OK;
+  SMX_REQUIRE(ps.rows != nullptr && ps.B <= m->Bmax, "sparse store: resident rows only");
+  SMX_REQUIRE(!(ps.training && m->cfg.input_dropout > 0.f), "sparse store: input dropout is keyed by the dense store's rows (use the float32 / uint16 store)");
+  SMX_CHECK(launch_csr_expand(m->st, m->csr_indptr, m->csr_cols, m->csr_vals, ps.rows, 0, ps.B, m->Gp, m->xbatch));
+  ps.Xsrc = m->xbatch; ps.xrows = nullptr; ps.x_u16 = 0;
+  return SMX_OK;
+}
+
+// the whole training step as a launch sequence on m->st (capturable).
+//   with_begin:   launch the state/row-id preparation kernel first (graph replay: every step, cursor kept in
+//                 the master state; eager: only the first step of a train_steps call)
+//   prepare_next: the optimiser kernel prepares the other parity's state + row ids for the step after
+int train_sequence(smx_model* m, int B, bool with_begin, bool begin_from_master, uint32_t cursor, bool prepare_next) {
+  Pass ps;
+  ps.B = B; ps.rows = cur_rows(m); ps.xrows = ps.rows; ps.Xsrc = m->X; ps.x_u16 = m->x_u16; ps.lib = m->library; ps.lgx1 = m->lgx1;
+  ps.cell_base = (uint32_t)m->cell_base; ps.training = 1; ps.sample = 0; ps.global_batch = B * m->world;
+  m->seq_batch = B; m->seq_prepare_next = prepare_next ? 1 : 0;
+  Timed t(m, "step");
+  if (with_begin)
+    SMX_CHECK(launch_step_begin(m->st, master_state(m), cur_state(m), m->order, cur_rows(m), B, begin_from_master ? 1 : 0,
+                                cursor, m->cfg.lr, m->cfg.adam_beta1, m->cfg.adam_beta2));
+  { Timed null_pair(m, "null"); }  // an event pair around nothing: the timing method's own overhead
+  SMX_CHECK(csr_stage(m, ps));     // sparse store: this minibatch's rows as a dense tile (no-op otherwise)
+  SMX_CHECK(forward_pass(m, ps, true, true));
+  SMX_CHECK(backward_pass(m, ps));
+  SMX_CHECK(optimizer_pass(m));
+  return SMX_OK;
+}
+
+int read_metrics(smx_model* m, smx_metrics* out) {
+  if (!out) return SMX_OK;
+  float h[8];
+  std::vector<float> norms(m->tensors.size());
+  SMX_HIP(hipMemcpyAsync(h, m->grads + m->tail_off_metrics, sizeof(h), hipMemcpyDeviceToHost, m->st));
+  SMX_HIP(hipMemcpyAsync(norms.data(), m->tensor_norm, norms.size() * sizeof(float), hipMemcpyDeviceToHost, m->st));
+  SMX_HIP(hipStreamSynchronize(m->st));
+  out->loss = h[0]; out->nllk_x = h[1]; out->nllk_y = h[2]; out->kl = h[3]; out->kl_l = h[4];
+  float mx = 0.f;
+  for (float v : norms) mx = (v > mx || v != v) ? v : mx;
+  out->grad_norm_max = mx;
+  out->nan_flag = !(isfinite(h[0]) && isfinite(h[1]) && isfinite(h[3]) && isfinite(mx));
+  out->step = (int32_t)m->h_next;
+  out->tc = h[5]; out->dtc_loss = h[6];
+  if (m->fvae && !(isfinite(h[5]) && isfinite(h[6]))) out->nan_flag = 1;
+  return SMX_OK;
+}
+
+int upload_order(smx_model* m, const int32_t* order, size_t n, size_t n_steps) {
+  if (n_steps > m->mhist_cap) {
+    SMX_HIP(hipStreamSynchronize(m->st));
+    drop_graphs(m);
+    if (m->mhist) hipFree(m->mhist);
+    m->mhist = nullptr; m->mhist_cap = 0;
+    SMX_CHECK(dmalloc(&m->mhist, (n_steps * 2 + 64) * 8));
+    m->mhist_cap = n_steps * 2 + 64;
+  }
+  m->mhist_steps = (int32_t)n_steps;
+  if (n > m->order_cap) {
+    SMX_HIP(hipStreamSynchronize(m->st));
+    drop_graphs(m);
+    if (m->order) hipFree(m->order);
+    m->order = nullptr;
+    m->order_cap = n * 2 + (size_t)m->Bmax;
+    SMX_CHECK(dmalloc(&m->order, m->order_cap));
+  }
+  SMX_HIP(hipMemcpyAsync(m->order, order, n * sizeof(int32_t), hipMemcpyHostToDevice, m->st));
+  SMX_HIP(hipMemsetAsync(&master_state(m)->cursor, 0, sizeof(uint32_t), m->st));
+  return SMX_OK;
+}
+
+int check_rows(smx_model* m, const int32_t* ids, size_t n) {
+  SMX_REQUIRE(m->X != nullptr, "no dataset uploaded (smx_dataset_upload)");
+  for (size_t i = 0; i < n; ++i)
+    if (ids[i] < 0 || (int64_t)ids[i] >= m->N) { set_error("row id out of range"); return SMX_ERR_INVALID; }
+  return SMX_OK;
+}
+
+int launch_train(smx_model* m, int B, bool use_graph, int s_idx, int n_steps) {
+  // With a communicator the RCCL all-reduce is captured too (RCCL supports stream capture);
+  // SMX_NO_GRAPH_COMM=1 or a failed capture falls back to eager launches for good.
+  static const bool no_graph_comm = getenv("SMX_NO_GRAPH_COMM") != nullptr;
+  if (use_graph && !m->local && !(m->comm && (no_graph_comm || m->graph_comm_failed)) && !m->use_injected && m->timing_label.empty()) {
+    auto it = m->graphs.find(B);
+    if (it == m->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      SMX_HIP(hipStreamBeginCapture(m->st, hipStreamCaptureModeThreadLocal));
+      m->capturing = true;
+      m->par = 0;
+      int rc = train_sequence(m, B, true, true, 0, false);
+      m->capturing = false;
+      hipError_t e = hipStreamEndCapture(m->st, &graph);
+      hipGraphExec_t exec = nullptr;
+      if (rc == SMX_OK && e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (graph) hipGraphDestroy(graph);
+      if (rc != SMX_OK || e != hipSuccess) {
+        (void)hipGetLastError();
+        if (m->comm) {  // capture with the collective failed: run this and all later steps eagerly
+          m->graph_comm_failed = true;
+          SMX_CHECK(train_sequence(m, B, true, true, 0, false));
+          m->h_next += 1;
+          return SMX_OK;
+        }
+        if (rc != SMX_OK) return rc;
+        set_error(std::string("graph capture failed: ") + hipGetErrorString(e));
+        return SMX_ERR_HIP;
+      }
+      it = m->graphs.emplace(B, exec).first;
+    }
+    m->par = 0;
+    SMX_HIP(hipGraphLaunch(it->second, m->st));
+  } else {
+    // eager: the preparation kernel runs once per call; afterwards each optimiser kernel prepares the
+    // other parity's state + row ids, so a step is not fronted by a 1-workgroup latency kernel
+    const bool first = (s_idx == 0), last = (s_idx == n_steps - 1);
+    if (first) m->par = 0; else m->par ^= 1;
+    SMX_CHECK(train_sequence(m, B, first, false, (uint32_t)s_idx, !last));
+  }
+  m->h_next += 1;
+  return SMX_OK;
+}
+
+int setup_pass(smx_model* m, Pass& ps, const int32_t* row_ids, const float* host_x, const float* host_library,
+                      int32_t batch, int training, int sample) {
+  SMX_REQUIRE(batch > 0 && batch <= m->Bmax, "batch must be in 1..max_batch");
+  ps.B = batch; ps.training = training; ps.sample = sample; ps.global_batch = batch;
+  if (row_ids) {
+    SMX_CHECK(check_rows(m, row_ids, (size_t)batch));
+    SMX_HIP(hipMemcpyAsync(cur_rows(m), row_ids, (size_t)batch * sizeof(int32_t), hipMemcpyHostToDevice, m->st));
+    ps.rows = cur_rows(m); ps.xrows = ps.rows; ps.Xsrc = m->X; ps.x_u16 = m->x_u16; ps.lib = m->library; ps.lgx1 = m->lgx1; ps.cell_base = (uint32_t)m->cell_base;
+    SMX_CHECK(csr_stage(m, ps));
+  } else {
+    SMX_REQUIRE(host_x, "need row_ids or host_x");
+    SMX_REQUIRE(!m->scvi || host_library, "scvi needs host_library with host_x");
+    SMX_HIP(hipMemsetAsync(m->hostX, 0, (size_t)batch * m->Gp * sizeof(float), m->st));
+    SMX_HIP(hipMemcpy2DAsync(m->hostX, (size_t)m->Gp * sizeof(float), host_x, (size_t)m->G * sizeof(float),
+                             (size_t)m->G * sizeof(float), (size_t)batch, hipMemcpyHostToDevice, m->st));
+    SMX_CHECK(launch_row_stats(m->st, m->hostX, 0, m->Gp, batch, m->G, m->hostLgx1, nullptr));
+    if (host_library) SMX_HIP(hipMemcpy(m->hostLib, host_library, (size_t)batch * 2 * sizeof(float), hipMemcpyHostToDevice));
+    ps.rows = nullptr; ps.Xsrc = m->hostX; ps.lib = m->hostLib; ps.lgx1 = m->hostLgx1; ps.cell_base = 0;
+  }
+  return SMX_OK;
+}
+
+}  // namespace smx
+
+extern "C" {
+
+int smx_train_step(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out) {
+  return smx_train_steps(m, row_ids, 1, batch, 0, out);
+}
+int smx_train_step_graph(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out) {
+  return smx_train_steps(m, row_ids, 1, batch, 1, out);
+}
+
+int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t batch, int use_graph, smx_metrics* out) {
+  SMX_REQUIRE(m && order && n_steps > 0, "bad arguments");
+  SMX_REQUIRE(batch > 0 && batch <= m->Bmax, "batch must be in 1..max_batch");
+  SMX_CHECK(check_rows(m, order, (size_t)n_steps * batch));
+  SMX_CHECK(upload_order(m, order, (size_t)n_steps * batch, (size_t)n_steps));
+  for (int s = 0; s < n_steps; ++s) SMX_CHECK(launch_train(m, batch, use_graph != 0, s, n_steps));
+  if (m->use_injected) { m->use_injected = false; }
+  // a non-finite loss / gradient norm is REPORTED (out->nan_flag), not an error of the call: terminate_on_nan
+  // (configs/base.yaml:59) is the caller's decision
+  SMX_CHECK(read_metrics(m, out));
+  return SMX_OK;
+}
+
+int smx_metrics_history(smx_model* m, int32_t n_steps, float* host) {
+  SMX_REQUIRE(m && host && n_steps > 0 && n_steps <= m->mhist_steps, "no such history (steps of the last smx_train_steps call)");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  SMX_HIP(hipMemcpy(host, m->mhist, (size_t)n_steps * 8 * sizeof(float), hipMemcpyDeviceToHost));
+  return SMX_OK;
+}
+
+int smx_eval_step(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out) {
+  SMX_REQUIRE(m && row_ids, "bad arguments");
+  Pass ps;
+  SMX_CHECK(setup_pass(m, ps, row_ids, nullptr, nullptr, batch, 0, 0));
+  SMX_CHECK(forward_pass(m, ps, true, false));
+  SMX_CHECK(read_metrics(m, out));
+  return SMX_OK;
+}
+
+}  // extern "C"
