@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from oracle import sisua_oracle as so
-from tests.util import grad_errors, make_pair, perturbed_params, rel_l2, synth_counts, synth_labels
+from tests.util import adam_state_errors, grad_errors, make_pair, masked_move_error, perturbed_params, rel_l2, synth_counts, synth_labels
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -112,16 +112,19 @@ def test_world_n_steps_match_oracle(Engine, name, world, sync_bn):
       if step == 0:   # the reduced gradient itself (later steps start from fp32-rounded parameters)
         worst = grad_errors(e.get_params(which=1), ref["grads"])
         assert max(worst.values()) < RTOL, (r, sorted(worst.items(), key=lambda kv: -kv[1])[:3])
-  # after 3 steps: every rank holds the same parameters, and they are the oracle's
+  # after 3 steps: every rank holds the same parameters and optimiser state, and they are the oracle's.  The moments are
+  # what is held to a tight tolerance (m linear, v quadratic in the gradients); the weights are judged where the gradient is
+  # far above float32 rounding -- elsewhere Adam turns rounding noise into steps of up to lr
   finals = [e.get_params() for e in engines]
   for k in finals[0]:
     for r in range(1, world):
       assert np.array_equal(finals[0][k], finals[r][k]), (k, r)
-    g = ref["grads"][k]   # of the last step; judge the move where the gradient is not fp32 noise around zero
-    big = np.abs(g) > 1e-3 * np.abs(g).max()
-    if big.any() and np.linalg.norm(g) > 1e-3 * max(np.linalg.norm(v) for v in ref["grads"].values()):
-      assert rel_l2((finals[0][k] - p_before[k])[big], (params[k] - p_before[k])[big]) < 2e-2, k
-    assert np.allclose(finals[0][k], params[k], rtol=1e-4, atol=max(5e-4, 0.75 * spec.lr)), k
+  em, ev, where = adam_state_errors(engines[0], opt)
+  assert em < 1e-3 and ev < 2e-3, (em, ev, where)
+  for k in finals[0]:
+    err = masked_move_error(finals[0][k], p_before[k], params[k], ref["grads"][k], spec.lr)
+    assert err is None or err < 1e-2, (k, err)
+    assert np.abs(finals[0][k] - params[k]).max() <= 3.01 * 1.6 * spec.lr, k   # (3 steps of at most lr_t <= 1.6 lr each: a sanity bound, not the parity check)
   names = [p for p, _ in so.bn_manifest(spec)]
   for e in engines:
     for i, st in e.get_bn().items():
@@ -261,3 +264,108 @@ def test_comm_init_failure_leaves_a_clean_model(Engine, tmp_path):
     assert rc == 0 and "CLEAN" in out, out[-2000:]
   if not all("REFUSED" in out for _, out in outs):   # an RCCL build that accepts two ranks on one device
     assert all("JOINED" in out for _, out in outs), outs
+
+
+# ---- world 8 at the BASELINE.json splits -------------------------------------------------------
+def _baseline_split(workload, world):
+  """bench.py's workload cut into `world` contiguous shards exactly as `bench.py --gpus world` / fit(distributed) cut it."""
+  import bench
+  full = bench.build_workload(0, 1, workload)
+  return full, [bench.build_workload(r, world, workload) for r in range(world)]
+
+
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_world8_c4_split_matches_oracle(Engine, sync_bn):
+  """BASELINE configs[3] as the 8-GPU job runs it: eccly-shaped 2116 x 2000 training cells in 8 contiguous shards of 264,
+  SISUA zinb + 38 ADT nb labels at 10 %, alpha = 10, global batch 256 = 8 ranks x 32 cells; two optimiser steps on the
+  loopback communicator against oracle.dp_train_step on the UNSHARDED matrix (the noise of a cell is keyed by its global id)."""
+  world, B, base = 8, 32, 0
+  (cfg, xt, batch, extra), shards = _baseline_split("eccly-sisua", world)
+  assert batch == 256 and cfg.labels == ((38, "nb"),) and cfg.alpha == 10.0 and xt.shape[1] == 2000
+  spec = so.Spec(**cfg.to_dict())
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  engines, los = [], []
+  for r, (c, xs, _, ex) in enumerate(shards):
+    lo = ex["cell_id_base"]
+    assert xs.shape[0] == xt.shape[0] // world and lo == r * xs.shape[0] and np.array_equal(xs, xt[lo:lo + xs.shape[0]])
+    e = Engine(c, max_batch=B, init=False)
+    e.set_params(params)
+    e.upload(xs, ex["labels"], None, ex["label_mask"], cell_id_base=lo)
+    engines.append(e); los.append(lo)
+  Engine.comm_init_local(engines)
+  for e in engines:
+    e.set_sync_bn(sync_bn)
+  rng = np.random.default_rng(8)
+  n_lab = 0
+  for step in range(2):
+    local = [rng.permutation(shards[r][1].shape[0])[:B].astype(np.int32) for r in range(world)]
+    glob = [local[r] + los[r] for r in range(world)]
+    n_lab += int(sum(extra["label_mask"][g].sum() for g in glob))
+    ref = so.dp_train_step(spec, params, bn, opt, xt, glob, step, cell_base=base, y=extra["labels"], mask=extra["label_mask"], sync_bn=sync_bn)
+    ms = run_ranks([lambda r=r: engines[r].train_step(local[r]) for r in range(world)])
+    for r, m in enumerate(ms):
+      assert m["nan_flag"] == 0 and m["step"] == step + 1
+      for key in ("loss", "nllk_x", "nllk_y", "kl"):
+        assert np.isclose(m[key], ref["metrics"][key], rtol=RTOL, atol=1e-5), (r, step, key, m[key], ref["metrics"][key])
+      assert m["loss"] == ms[0]["loss"]
+    if step == 0:
+      for r in (0, 7):
+        worst = grad_errors(engines[r].get_params(which=1), ref["grads"])
+        assert max(worst.values()) < RTOL, (r, sorted(worst.items(), key=lambda kv: -kv[1])[:3])
+    em, ev, where = adam_state_errors(engines[0], opt)
+    assert em < (2e-4 if step == 0 else 1e-3) and ev < (4e-4 if step == 0 else 2e-3), (step, em, ev, where)
+  assert n_lab > 0   # labelled cells took part: the alpha = 10 term is in the gradients
+  a, b = engines[0].get_params(), engines[7].get_params()
+  for k in a:
+    assert np.array_equal(a[k], b[k]), k
+  names = [p for p, _ in so.bn_manifest(spec)]
+  for i, st in engines[3].get_bn().items():
+    assert np.allclose(st["moving_mean"], bn[f"{names[i]}/moving_mean"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(st["moving_var"], bn[f"{names[i]}/moving_var"], rtol=1e-4, atol=1e-6)
+  for e in engines:
+    e.close()
+
+
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_world8_c5_split_matches_oracle(Engine, sync_bn):
+  """BASELINE configs[4]'s per-step shape: global batch 1024 = 8 ranks x 128 cells x 20 000 genes (a 256-cell slice resident
+  per rank, uint16 store, each rank's cells generated from (seed, rank) as bench.py's c5-shard does); one optimiser step against
+  oracle.dp_train_step: ELBO scalars, every reduced gradient, gradient norms, Adam moments."""
+  import bench
+  world, B, per = 8, 128, 256
+  shards = [bench.build_workload(r, world, "c5-shard") for r in range(world)]
+  cfg = shards[0][0]
+  assert cfg.n_genes == 20000 and shards[0][2] == B
+  spec = so.Spec(**cfg.to_dict())
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  xs = [s[1][:per] for s in shards]
+  assert not np.array_equal(xs[0], xs[1])
+  xt = np.concatenate(xs, 0)
+  engines = []
+  for r in range(world):
+    e = Engine(cfg, max_batch=B, init=False)
+    e.set_params(params)
+    e.upload(xs[r], cell_id_base=r * per, storage="u16")
+    engines.append(e)
+  Engine.comm_init_local(engines)
+  for e in engines:
+    e.set_sync_bn(sync_bn)
+  rng = np.random.default_rng(5)
+  local = [rng.permutation(per)[:B].astype(np.int32) for r in range(world)]
+  glob = [local[r] + r * per for r in range(world)]
+  ref = so.dp_train_step(spec, params, bn, opt, xt, glob, 0, cell_base=0, sync_bn=sync_bn)
+  ms = run_ranks([lambda r=r: engines[r].train_step(local[r]) for r in range(world)], timeout=300)
+  for r, m in enumerate(ms):
+    assert m["nan_flag"] == 0
+    for key in ("loss", "nllk_x", "kl"):
+      assert np.isclose(m[key], ref["metrics"][key], rtol=RTOL, atol=1e-5), (r, key, m[key], ref["metrics"][key])
+    assert np.isclose(m["grad_norm_max"], max(ref["norms"].values()), rtol=1e-3), r
+  for r in (0, 5):
+    worst = grad_errors(engines[r].get_params(which=1), ref["grads"])
+    assert max(worst.values()) < RTOL, (r, sorted(worst.items(), key=lambda kv: -kv[1])[:3])
+  em, ev, where = adam_state_errors(engines[2], opt)
+  assert em < 2e-4 and ev < 4e-4, (em, ev, where)
+  for e in engines:
+    e.close()

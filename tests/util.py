@@ -58,3 +58,25 @@ def grad_errors(got, ref, floor_frac=1e-3):
   gradient norm are judged on that absolute scale (fp32 rounding of an exact zero)."""
   top = max(np.linalg.norm(np.asarray(v, np.float64)) for v in ref.values())
   return {k: rel_l2(got[k], ref[k], floor=max(floor_frac * top, 1e-5)) for k in got}
+
+
+def adam_state_errors(engine, opt, floor_frac=1e-3):
+  """Per-tensor relative L2 error of the optimiser's first and second moments on the device (smx_get_tensor which = 2 / 3)
+  against the oracle's.  m is LINEAR in the gradients and v quadratic, so -- unlike the post-update weights, where Adam turns
+  a rounding-level gradient into a full-size step -- they can be held to the gradients' own tolerance.
+  Returns (worst m error, worst v error, their tensors)."""
+  em = grad_errors(engine.get_params(which=2), opt["m"], floor_frac)
+  ev = grad_errors(engine.get_params(which=3), opt["v"], floor_frac)
+  km, kv = max(em, key=em.get), max(ev, key=ev.get)
+  return em[km], ev[kv], (km, kv)
+
+
+def masked_move_error(after, before, ref_after, grad, lr, frac=1e-2):
+  """Relative L2 error of one tensor's update (after - before vs the oracle's) over the elements whose gradient is above
+  `frac` of the tensor's largest: where |g| is far above float32 rounding the Adam step is a smooth function of g.  None when
+  no element qualifies (a tensor whose gradient is rounding noise throughout)."""
+  g = np.abs(np.asarray(grad, np.float64))
+  big = g > frac * g.max() if g.size and g.max() > 0 else np.zeros(g.shape, bool)
+  if not big.any():
+    return None
+  return rel_l2((np.asarray(after, np.float64) - before)[big], (ref_after - before)[big], floor=1e-3 * lr * np.sqrt(big.sum()))
