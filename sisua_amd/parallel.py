@@ -1,14 +1,20 @@
-"""Data-parallel plumbing: one process per GPU, cells sharded over ranks, ONE RCCL
-all-reduce of the flat gradient buffer per step (inside libsisua_hip.so).
+"""Data-parallel plumbing: one process per GPU, cells sharded over ranks, ONE all-reduce of the flat gradient
+buffer per step (inside libsisua_hip.so: RCCL over xGMI).
 
-torch.distributed (gloo, CPU) is used only as the rendezvous / control plane:
-exchanging the 128-byte RCCL unique id, barriers and max-over-ranks timing.  The
-data plane never touches torch.
+The control plane -- exchanging the 128-byte communicator id, barriers, max-over-ranks timing, the validation loss
+averaged over the ranks -- is a ~100-line TCP star in this file (rank 0 serves, every collective is gather -> reduce ->
+reply): no torch, no MPI.  The launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, as
+`python -m torch.distributed.run` or any other launcher sets them) is all it reads.  The data plane never touches it.
 """
 from __future__ import annotations
 
+import hashlib
 import os
-from typing import Callable, Optional, Tuple
+import socket
+import struct
+import tempfile
+import time
+from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 
@@ -17,52 +23,168 @@ def env_rank_world() -> Tuple[int, int, int]:
   return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-class ControlPlane:
-  """gloo process group wrapper; a no-op for world == 1."""
+_MAGIC = b"SMXCP1"
+_OP_BARRIER, _OP_BCAST, _OP_MAX, _OP_SUM, _OP_CLOSE = range(5)
 
-  def __init__(self, rank: int, world: int, init_method: Optional[str] = None):
-    self.rank, self.world, self.dist = rank, world, None
-    if world > 1:
-      import torch.distributed as dist
-      if not dist.is_initialized():
-        kw = dict(backend="gloo", rank=rank, world_size=world)
-        if init_method:
-          kw["init_method"] = init_method
-        dist.init_process_group(**kw)
-      self.dist = dist
+
+def _send(sock: socket.socket, op: int, payload: bytes = b""):
+  sock.sendall(struct.pack("<BQ", op, len(payload)) + payload)
+
+
+def _recv_exact(sock: socket.socket, n: int) -> bytes:
+  buf = bytearray()
+  while len(buf) < n:
+    chunk = sock.recv(n - len(buf))
+    if not chunk:
+      raise ConnectionError("control plane: peer closed the connection")
+    buf += chunk
+  return bytes(buf)
+
+
+def _recv(sock: socket.socket) -> Tuple[int, bytes]:
+  op, n = struct.unpack("<BQ", _recv_exact(sock, 9))
+  return op, _recv_exact(sock, n) if n else b""
+
+
+class ControlPlane:
+  """TCP star over the ranks of one job; a no-op for world == 1.
+
+  Rendezvous: rank 0 listens on SMX_CP_PORT at MASTER_ADDR when that variable is set (any topology); otherwise on an
+  ephemeral loopback port which it publishes in a file keyed by (MASTER_ADDR, MASTER_PORT, run id, uid) under the
+  temporary directory -- one node, which is what `bench.py --gpus N` and fit(distributed='auto') run on.  (MASTER_PORT
+  itself belongs to the launcher: torch.distributed.run keeps its own store there.)  Every rank proves the job's token
+  in its hello, so a stale file or a foreign listener is retried, not trusted."""
+
+  def __init__(self, rank: int, world: int, addr: Optional[str] = None, port: Optional[int] = None, timeout: float = 120.0):
+    self.rank, self.world = int(rank), int(world)
+    self._peers: List[socket.socket] = []   # rank 0: socket of rank r at index r - 1
+    self._root: Optional[socket.socket] = None
+    self._file = None
+    if self.world <= 1:
+      return
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    mport = os.environ.get("MASTER_PORT", "0")
+    run = os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("SMX_RUN_ID", "none"))
+    token = hashlib.sha256(f"{addr}:{mport}:{run}:{self.world}".encode()).digest()[:16]
+    fixed = port if port is not None else (int(os.environ["SMX_CP_PORT"]) if os.environ.get("SMX_CP_PORT") else None)
+    rfile = os.path.join(tempfile.gettempdir(), f"smx_cp_{os.getuid()}_{hashlib.sha256(token).hexdigest()[:16]}.port")
+    deadline = time.time() + timeout
+    if self.rank == 0:
+      srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+      srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+      srv.bind((addr if fixed else "127.0.0.1", fixed or 0))
+      srv.listen(self.world)
+      if not fixed:
+        tmp = f"{rfile}.{os.getpid()}"
+        with open(tmp, "w") as f:
+          f.write(str(srv.getsockname()[1]))
+        os.replace(tmp, rfile)   # atomic: a reader sees the old file or the new one
+        self._file = rfile
+      got = {}
+      srv.settimeout(1.0)
+      while len(got) < self.world - 1:
+        if time.time() > deadline:
+          raise TimeoutError(f"control plane: {self.world - 1 - len(got)} rank(s) did not join within {timeout:.0f} s")
+        try:
+          c, _ = srv.accept()
+        except socket.timeout:
+          continue
+        try:
+          c.settimeout(10.0)
+          hello = _recv_exact(c, len(_MAGIC) + 16 + 4)
+          r = struct.unpack("<I", hello[-4:])[0]
+          if hello[:len(_MAGIC)] != _MAGIC or hello[len(_MAGIC):-4] != token or not 0 < r < self.world or r in got:
+            c.close()
+            continue
+          c.sendall(_MAGIC)
+          c.settimeout(None)
+          c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+          got[r] = c
+        except (OSError, ConnectionError, struct.error):
+          c.close()
+      srv.close()
+      self._peers = [got[r] for r in range(1, self.world)]
+    else:
+      while True:
+        if time.time() > deadline:
+          raise TimeoutError(f"control plane: rank {self.rank} could not reach rank 0 within {timeout:.0f} s")
+        try:
+          p = fixed or int(open(rfile).read().strip())
+          c = socket.create_connection((addr if fixed else "127.0.0.1", p), timeout=5.0)
+          c.sendall(_MAGIC + token + struct.pack("<I", self.rank))
+          if _recv_exact(c, len(_MAGIC)) != _MAGIC:
+            raise ConnectionError("bad reply")
+          c.settimeout(None)
+          c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+          self._root = c
+          break
+        except (OSError, ValueError, ConnectionError):
+          time.sleep(0.05)   # no file yet, a stale file of an earlier job, or rank 0 not listening yet
+
+  # every collective: the ranks send (op, payload) to rank 0, which reduces and replies to each
+  def _collective(self, op: int, payload: bytes, reduce: Callable[[List[bytes]], bytes]) -> bytes:
+    if self.world <= 1:
+      return reduce([payload])
+    if self.rank == 0:
+      parts = [payload]
+      for c in self._peers:
+        o, data = _recv(c)
+        if o != op:
+          raise RuntimeError(f"control plane: ranks disagree on the collective ({o} vs {op})")
+        parts.append(data)
+      out = reduce(parts)
+      for c in self._peers:
+        _send(c, op, out)
+      return out
+    _send(self._root, op, payload)
+    o, data = _recv(self._root)
+    if o != op:
+      raise RuntimeError(f"control plane: ranks disagree on the collective ({o} vs {op})")
+    return data
 
   def barrier(self):
-    if self.dist is not None:
-      self.dist.barrier()
+    self._collective(_OP_BARRIER, b"", lambda parts: b"")
 
   def broadcast_bytes(self, make: Callable[[], bytes], src: int = 0) -> bytes:
     """Rank `src` calls make(); every rank returns the same bytes."""
-    if self.dist is None:
-      return make()
-    box = [make() if self.rank == src else None]
-    self.dist.broadcast_object_list(box, src=src)
-    return box[0]
+    mine = bytes(make()) if self.rank == src else b""
+    return self._collective(_OP_BCAST, mine, lambda parts: parts[src])
 
   def max(self, value: float) -> float:
-    if self.dist is None:
-      return float(value)
-    import torch
-    t = torch.tensor([float(value)], dtype=torch.float64)
-    self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-    return float(t.item())
+    out = self._collective(_OP_MAX, struct.pack("<d", float(value)), lambda parts: struct.pack("<d", max(struct.unpack("<d", p)[0] for p in parts)))
+    return struct.unpack("<d", out)[0]
 
   def sum_array(self, a: np.ndarray) -> np.ndarray:
-    if self.dist is None:
+    """Element-wise float64 sum over the ranks, in rank order on rank 0 (every rank receives the same bits)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if self.world <= 1:
       return a
-    import torch
-    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
-    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-    return t.numpy()
+
+    def reduce(parts):
+      acc = np.frombuffer(parts[0], np.float64).copy()
+      for p in parts[1:]:
+        acc += np.frombuffer(p, np.float64)
+      return acc.tobytes()
+    return np.frombuffer(self._collective(_OP_SUM, a.tobytes(), reduce), np.float64).reshape(a.shape).copy()
 
   def close(self):
-    if self.dist is not None and self.dist.is_initialized():
-      self.dist.barrier()
-      self.dist.destroy_process_group()
+    if self.world > 1 and (self._peers or self._root):
+      try:
+        self._collective(_OP_CLOSE, b"", lambda parts: b"")
+      except (OSError, ConnectionError, RuntimeError):
+        pass
+    for c in self._peers + ([self._root] if self._root else []):
+      try:
+        c.close()
+      except OSError:
+        pass
+    self._peers, self._root = [], None
+    if self._file:
+      try:
+        os.unlink(self._file)
+      except OSError:
+        pass
+      self._file = None
 
 
 class LocalControlPlane:

@@ -1,13 +1,13 @@
-"""Data-parallel path on CPU: world_size 2 over gloo.  Covers the control plane
-(sisua_amd/parallel.py) and the DP contract the HIP library implements with one
-all-reduce: sum of the per-rank flat buffers [grads | BN batch stats | metrics] / world
-== the single-process result on the concatenated minibatch with per-replica BN."""
+"""Data-parallel path on CPU, world_size 2 (and 3): the package's own TCP control plane (sisua_amd/parallel.py: no torch)
+and, beside it, a torch.distributed gloo group in the same processes as an independent check of every collective.
+Covers the DP contract the HIP library implements with one all-reduce: sum of the per-rank flat buffers
+[grads | BN batch stats | metrics] / world == the single-process result on the concatenated minibatch with
+per-replica BN."""
 import os
 import socket
 
 import numpy as np
 import pytest
-import torch.multiprocessing as mp
 
 from oracle import sisua_oracle as so
 from tests.util import perturbed_params, synth_counts
@@ -44,12 +44,25 @@ def _worker(rank, world, port, out_dir):
   flat = np.concatenate([res["grads"][n].ravel() / world for n, _ in so.manifest(spec)] +
                         [res["new_bn"]["enc0/batch_mean"] / world, np.array([res["loss"] / world])])
   tot = cp.sum_array(flat)
+  # the same reduction over gloo (torch.distributed is test infrastructure here, not a dependency of the package)
+  import torch
+  import torch.distributed as dist
+  dist.init_process_group(backend="gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
+  t = torch.from_numpy(flat.copy())
+  dist.all_reduce(t, op=dist.ReduceOp.SUM)
+  assert np.allclose(tot, t.numpy(), rtol=1e-15, atol=1e-300)
+  tm = torch.tensor([1.0 + rank], dtype=torch.float64)
+  dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+  assert cp.max(1.0 + rank) == float(tm.item())
+  dist.barrier()
+  dist.destroy_process_group()
   np.save(os.path.join(out_dir, f"rank{rank}.npy"), tot)
   np.save(os.path.join(out_dir, f"rows{rank}.npy"), rows)
   cp.close()
 
 
 def test_world2_gloo(tmp_path):
+  import torch.multiprocessing as mp   # (lazily: the TCP workers below re-import this module and must stay torch-free)
   world, port = 2, _free_port()
   mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
   a, b = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
@@ -80,3 +93,62 @@ def test_control_plane_single_process_is_noop():
   assert cp.broadcast_bytes(lambda: b"x") == b"x" and cp.max(3.0) == 3.0
   cp.barrier()
   cp.close()
+
+
+def _tcp_worker(rank, world, port, out_dir):
+  import sys
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                    SMX_RUN_ID=f"t{port}")
+  from sisua_amd.parallel import ControlPlane
+  if rank == world - 1:
+    import time
+    time.sleep(0.5)    # a late joiner: the others wait in the rendezvous
+  cp = ControlPlane(rank, world)
+  assert "torch" not in sys.modules, "the control plane must not import torch"
+  for i in range(3):
+    cp.barrier()
+    assert cp.broadcast_bytes(lambda: bytes([rank, i]) * 64, src=i % world) == bytes([i % world, i]) * 64
+    assert cp.max(float(rank * (i + 1))) == float((world - 1) * (i + 1))
+    a = np.arange(7, dtype=np.float64).reshape(7, 1) * (rank + 1) + i
+    assert np.array_equal(cp.sum_array(a), np.arange(7, dtype=np.float64).reshape(7, 1) * (world * (world + 1) / 2) + i * world)
+  big = np.full(300000, 1.0 / (rank + 1))                    # 2.4 MB frames
+  tot = cp.sum_array(big)
+  assert tot.shape == big.shape and np.allclose(tot, sum(1.0 / (r + 1) for r in range(world)))
+  cp.close()
+  open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tcp_control_plane(tmp_path, world):
+  """The ~100-line TCP star that replaced torch.distributed as the control plane: rendezvous through
+  the published port file (MASTER_PORT itself stays free for the launcher), barrier / broadcast / max / sum, a late
+  joiner, frames of a few MB, and no torch import in the workers."""
+  import multiprocessing as pymp
+  ctx = pymp.get_context("spawn")
+  port = _free_port()
+  ps = [ctx.Process(target=_tcp_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+  for p in ps:
+    p.start()
+  for p in ps:
+    p.join(120)
+  assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
+  assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_tcp_control_plane_fixed_port_and_stale_file(tmp_path, monkeypatch):
+  """SMX_CP_PORT pins the port (any topology); a stale rendezvous file of an earlier job is retried past, not trusted."""
+  import threading
+  from sisua_amd.parallel import ControlPlane
+  port = _free_port()
+  monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+  monkeypatch.setenv("MASTER_PORT", "1")
+  monkeypatch.setenv("SMX_CP_PORT", str(port))
+  out = [None, None]
+
+  def run(r):
+    cp = ControlPlane(r, 2)
+    out[r] = cp.sum_array(np.array([r + 1.0]))[0]
+    cp.close()
+  ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+  [t.start() for t in ts]; [t.join(60) for t in ts]
+  assert out == [3.0, 3.0]
