@@ -33,7 +33,7 @@ LOSS_REPEAT = 8   # SMX_LOSS_TIMING_REPEAT in sisua_amd/csrc/smx_model.h
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.3 TB/s achievable)
 
 
-def build_workload(rank: int, world: int, workload: str):
+def build_workload(rank: int, world: int, workload: str, n_cells: int = 4096):
   """Reproduces on_train (sisua/train.py:118-147) on synthetic 8kly-shaped data:
   split(0.8) -> split(0.9) -> corrupt(train) -> library stats."""
   from sisua_amd import data
@@ -55,9 +55,10 @@ def build_workload(rank: int, world: int, workload: str):
     units, latent, batch = (64, 64), 12, 64
   elif workload == "c5-shard":
     # per-GPU slice of BASELINE.json configs[4] (1e6 x 20000 log-normal counts, 128 cells per GPU per step):
-    # 4096 resident cells per GPU are enough to exercise the step at its real width
+    # 4096 resident cells per GPU are enough to exercise the step at its real width (host-generated: the parity tests and the
+    # CPU baseline need the rows on the host; `--workload c5` generates the full 1e6 / world cells per GPU on the device)
     rng = np.random.default_rng(8 + rank)   # generated per shard from (seed, rank), as SURVEY.md 8d describes for C5
-    x = (np.floor(rng.lognormal(0.0, 1.0, size=(4096, 20000))) * (rng.uniform(size=(4096, 20000)) < 0.12)).astype(np.float32)
+    x = (np.floor(rng.lognormal(0.0, 1.0, size=(n_cells, 20000))) * (rng.uniform(size=(n_cells, 20000)) < 0.12)).astype(np.float32)
     x[:, 0] += 1
     units, latent, batch = (128,), 32, 128
   else:
@@ -163,6 +164,7 @@ def main():
   ap.add_argument("--workload", default="8kly")
   ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (eager launches measured faster)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--c5-cells", type=int, default=0, help="--workload c5: total cells over all ranks (default 1 000 000)")
   ap.add_argument("--no-c5-entry", action="store_true", help="skip the roofline entries at the C5-shard width (128 cells x 20 000 genes)")
   ap.add_argument("--storage", default="f32", choices=("f32", "u16", "csr"), help="resident count matrix: float32 (reference layout), uint16, or the non-zeros only (CSR)")
   ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -188,14 +190,30 @@ def main():
   _hip.require_gpu(local_rank)
   cp = ControlPlane(rank, world)
 
-  cfg, xt, batch, extra = build_workload(rank, world, args.workload)
+  c5_full = args.workload == "c5"
+  if c5_full:
+    # BASELINE.json configs[4] at its real residency: 1e6 cells x 20 000 genes in total, this rank's 1e6 / world cells
+    # generated ON the device as uint16 from (seed, rank) (40 GB on one GPU, 5 GB per GPU on eight); 128 cells
+    # per GPU per step (global batch 1024 on eight GPUs)
+    cfg, _, batch, extra = build_workload(rank, world, "c5-shard", n_cells=8)
+    extra = {}
+    n_c5 = (args.c5_cells or 1_000_000) // world
+
+    class _Shape:   # (only its shape is used below: the matrix lives on the device)
+      shape = (n_c5, cfg.n_genes)
+    xt = _Shape()
+  else:
+    cfg, xt, batch, extra = build_workload(rank, world, args.workload)
   cell_base = extra.pop("cell_id_base", 0)
   if args.scaling == "strong" and world > 1:
     if batch % world:
       sys.exit(f"--scaling strong: batch {batch} is not divisible by {world} ranks")
     batch //= world
   eng = Engine(cfg, max_batch=batch, device=local_rank)
-  eng.upload(xt, cell_id_base=cell_base, storage=args.storage, **extra)
+  if c5_full:
+    eng.generate_lognormal(n_c5, seed=8, rank=rank, storage="u16" if args.storage != "f32" else "f32")
+  else:
+    eng.upload(xt, cell_id_base=cell_base, storage=args.storage, **extra)
   attach_engine(eng, cp)
   if world > 1 and args.sync_bn:
     eng.set_sync_bn(True)
@@ -324,6 +342,12 @@ def main():
                    "unfused_likelihood_bytes": unfused_bytes, "fused_kernel_us": round(kt["x8"]["fused"], 3),
                    "product_only_us": round(kt["x8"]["product"], 3), "attributed_us": round(t_attr, 3),
                    "bytes_over_attributed_time_gbs": round(unfused_bytes / (t_attr * 1e-6) / 1e9, 1)}
+    if c5_full:
+      resident_as = f"this rank's 1/{world} of {n_c5 * world} cells generated on the device from (seed, rank), resident as uint16"
+    elif args.workload == "c5-shard":
+      resident_as = f"log-normal counts, resident as {args.storage}"
+    else:
+      resident_as = f"train split, corrupted; resident as {args.storage}"
     out = {
         "metric": "cells/sec VAE training (pbmc8k_ly, batch=128)" if args.workload == "8kly" else f"cells/sec {cfg.model} training ({args.workload}, batch={batch})",
         "value": round(args.steps * batch * world / dt, 1),
@@ -333,8 +357,8 @@ def main():
         "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}-shaped synthetic counts {xt.shape[0]}x{xt.shape[1]} "
-                               f"(train split, corrupted), {cfg.model} {cfg.likelihood} hidden={list(cfg.enc_units)} latent={cfg.latent_dim}, "
-                               f"batch {batch}/GPU, hipGraph={'on' if use_graph else 'off'}, X resident as {args.storage}",
+                               f"({resident_as}), {cfg.model} {cfg.likelihood} hidden={list(cfg.enc_units)} latent={cfg.latent_dim}, "
+                               f"batch {batch}/GPU, hipGraph={'on' if use_graph else 'off'}",
                    "global_batch": batch * world, "parallelism": f"dp{world}" + ("+syncbn" if (world > 1 and args.sync_bn) else "")},
         "final_loss": round(m["loss"], 4),
         "roofline": {"bound": "hbm", "kernel": head["name"], "rows": head["rows"],
@@ -346,7 +370,7 @@ def main():
                      "event_pair_overhead_us": round(null_us, 3), "launches_per_event_pair": LOSS_REPEAT},
         "kernel_us": per_kernel,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not c5_full:
       try:
         out["cpu_baseline"] = cpu_baseline(cfg, xt, batch, args.cpu_budget, extra=extra)
       except Exception as err:   # the GPU line must not be lost to the host-side baseline (e.g. no compiler on the box)

@@ -151,6 +151,15 @@ int smx_dataset_upload_u16(smx_model* m, const uint16_t* X, int64_t n_cells, con
 int smx_dataset_upload_csr(smx_model* m, const int64_t* indptr, const int32_t* cols, const float* vals, int64_t n_cells,
                            const float* const* labels, const float* library, const uint8_t* label_mask, int64_t cell_id_base);
 
+/* The rank's shard of BASELINE.json configs[4] ("synthetic 1e6 cells x 20k genes log-normal counts"), generated ON the
+ * device ("generated on-device per shard from (seed, rank)"; the reference's scaling test draws its matrix
+ * with NumPy on the host, tests/test_scalability.py:22-27): n_cells rows of ONE virtual matrix whose entry (cell, gene) is
+ * a function of (seed, global cell id = rank * n_cells + row, gene) only -- x = floor(LogNormal(mu_gene, 1)) kept with
+ * probability `density` (0.14 leaves ~93 % zeros), capped at 65535, gene 0 >= 1.  storage_u16 != 0: the compact store
+ * (40 GB for 1e6 x 20 000).  Replaces the resident matrix; no labels / library prior (VAE / DCA models).  Bit-for-bit the
+ * oracle's generate_lognormal_rows up to exp() rounding at integer boundaries. */
+int smx_dataset_generate_lognormal(smx_model* m, uint64_t seed, int32_t rank, int64_t n_cells, int32_t storage_u16, double density);
+
 int64_t smx_dataset_size(const smx_model* m);
 
 /* Library-size statistics of the RESIDENT matrix, get_library_size (sisua/data/utils.py:231-263) as the

@@ -967,6 +967,47 @@ def corrupt_philox(x: np.ndarray, dropout: float, retain_rate: float, seed: int,
   return x, int(sel.sum())
 
 
+STREAM_GENERATE = 90
+STREAM_GENERATE_MU = 91
+
+
+def generate_lognormal_rows(seed: int, cell_ids, n_genes: int, density: float = 0.14, return_real: bool = False):
+  """Rows of the synthetic scaling matrix of BASELINE.json configs[4] ("x = floor(LogNormal(mu_g, 1))
+  thinned to ~93 % zeros, generated on-device per shard from (seed, rank)"; the reference's scaling test draws
+  randint counts on the host, tests/test_scalability.py:22-27) -- what smx_dataset_generate_lognormal writes for the cells
+  with these GLOBAL ids:
+    * block q = g // 2 of cell c: w = philox(counter = (q, c, 0, GENERATE), key = seed); (n0, n1) = Box-Muller(w0, w1) as
+      philox_normal; gene 2q + e is kept iff (w[2 + e] >> 8) 2^-24 < density (compared in float32);
+    * mu_g = 0.5 * standard normal e = g % 4 of philox(counter = (g // 4, 0xFFFFFFFF, 0, GENERATE_MU));
+    * x = min(floor(exp(mu_g + n)), 65535) where kept, 0 elsewhere; gene 0 is at least 1.
+  return_real: also the un-floored exp(mu_g + n) (float64) -- the device evaluates it with ~1e-6 relative error, so an
+  entry within that of an integer may differ by one there (the tests allow exactly those)."""
+  cell_ids = np.asarray(cell_ids, dtype=np.uint64).reshape(-1, 1)
+  G = int(n_genes)
+  k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+  nq = (G + 1) // 2
+  q = np.arange(nq, dtype=np.uint64).reshape(1, -1)
+  w = philox4x32_10(q, cell_ids, np.uint64(0), np.uint64(STREAM_GENERATE), k0, k1)
+  u1 = ((w[0] >> np.uint64(8)).astype(np.float64) + 1.0) * 2.0 ** -24
+  u2 = (w[1] >> np.uint64(8)).astype(np.float64) * 2.0 ** -24
+  r = np.sqrt(-2.0 * np.log(u1))
+  nrm = np.stack([r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)], axis=-1).reshape(len(cell_ids), -1)[:, :G]
+  uk = np.stack([(w[2] >> np.uint64(8)), (w[3] >> np.uint64(8))], axis=-1).reshape(len(cell_ids), -1)[:, :G]
+  keep = (uk.astype(np.float32) * np.float32(2.0 ** -24)) < np.float32(density)
+  nb = (G + 3) // 4
+  wm = philox4x32_10(np.arange(nb, dtype=np.uint64), np.uint64(0xFFFFFFFF), np.uint64(0), np.uint64(STREAM_GENERATE_MU), k0, k1)
+  wm = np.stack(wm, axis=-1).reshape(nb, 2, 2)
+  m1 = ((wm[..., 0] >> np.uint64(8)).astype(np.float64) + 1.0) * 2.0 ** -24
+  m2 = (wm[..., 1] >> np.uint64(8)).astype(np.float64) * 2.0 ** -24
+  mr = np.sqrt(-2.0 * np.log(m1))
+  mu = 0.5 * np.stack([mr * np.cos(2 * np.pi * m2), mr * np.sin(2 * np.pi * m2)], axis=-1).reshape(-1)[:G]
+  real = np.exp(mu[None, :] + nrm)
+  x = np.where(keep, np.minimum(np.floor(real), 65535.0), 0.0)
+  x[:, 0] = np.maximum(x[:, 0], 1.0)
+  x = x.astype(np.float32)
+  return (x, np.where(keep, real, 0.0)) if return_real else x
+
+
 def library_size(x: np.ndarray):
   """get_library_size, sisua/data/utils.py:231-263 -> (log_counts[N], mean, var)."""
   total = x.sum(axis=1)

@@ -83,6 +83,7 @@ SIGNATURES = {
     "smx_dataset_upload_csr": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _FP, C.c_int64, C.POINTER(_FP), _FP,
                                          C.POINTER(C.c_uint8), C.c_int64]),
     "smx_dataset_size": (C.c_int64, [_VP]),
+    "smx_dataset_generate_lognormal": (C.c_int, [_VP, C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_double]),
     "smx_train_step": (C.c_int, [_VP, _IP, C.c_int32, C.POINTER(smx_metrics)]),
     "smx_train_step_graph": (C.c_int, [_VP, _IP, C.c_int32, C.POINTER(smx_metrics)]),
     "smx_train_steps": (C.c_int, [_VP, _IP, C.c_int32, C.c_int32, C.c_int, C.POINTER(smx_metrics)]),

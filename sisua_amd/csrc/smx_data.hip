@@ -4,6 +4,8 @@
 //
 // All of it is once-per-dataset streaming work: one pass over X per launch, a wave per row (stats) or a
 // workgroup-strided sweep (corruption); nothing here is on the per-step path.
+#include <algorithm>
+
 #include "smx_internal.h"
 #include "../../include/sisua_hip.h"
 
@@ -82,6 +84,63 @@ int launch_csr_expand(hipStream_t st, const int64_t* indptr, const int32_t* cols
                       int B, long ld, float* out) {
   SMX_HIP(hipMemsetAsync(out, 0, (size_t)B * (size_t)ld * sizeof(float), st));
   hipLaunchKernelGGL(csr_expand_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, indptr, cols, vals, rows, row0, B, ld, out);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// ---- on-device generator of the synthetic scaling configuration (BASELINE.json configs[4]; SURVEY.md 8d: "x =
+// floor(LogNormal(mu_g, 1)) thinned to ~93 % zeros, generated on-device per shard from (seed, rank)") --------------------
+// Entry (cell c, gene g) is a pure function of (seed, GLOBAL cell id, g) -- a shard is the rows [rank n, (rank + 1) n) of
+// ONE virtual matrix, whatever the number of ranks:
+//   block q = g / 2 of cell c: w = philox(counter = (q, cell id, 0, ST_GENERATE), key = seed)
+//   (n0, n1) = Box-Muller(w.x, w.y);  keep_e = u24(w.z / w.w) < density;  x = keep ? min(floor(exp(mu_g + n_e)), 65535) : 0
+//   mu_g = 0.5 * standard normal of gene g (gene_mu_kernel: philox(counter = (g / 4, 0xFFFFFFFF, 0, ST_GENERATE_MU)))
+//   gene 0 of every cell is at least 1 (no all-zero cell).
+// oracle/sisua_oracle.py:generate_lognormal_rows restates it; the fast v_log / v_sin / v_cos / v_exp forms leave ~1e-6
+// relative on exp(.), so a value within that of an integer may floor differently there (tests/test_gpu_dataset.py allows
+// exactly those).
+__global__ void gene_mu_kernel(uint32_t k0, uint32_t k1, int G, float* __restrict__ mu) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q * 4 >= G) return;
+  const float4 n = normal4(philox4x32_10((uint32_t)q, 0xFFFFFFFFu, 0u, (uint32_t)ST_GENERATE_MU, k0, k1));
+  const float v[4] = {n.x, n.y, n.z, n.w};
+  for (int e = 0; e < 4; ++e)
+    if (q * 4 + e < G) mu[q * 4 + e] = 0.5f * v[e];
+}
+// one thread per pair of genes; a workgroup walks one row (rows are gridDim.y-strided: N up to 2^31 - 1)
+template <int U16>
+__global__ __launch_bounds__(256) void generate_lognormal_kernel(void* __restrict__ Xv, long ld, long N, int G, uint32_t k0, uint32_t k1,
+                                                                 uint32_t cell_base, float density, const float* __restrict__ mu) {
+  for (long row = blockIdx.y; row < N; row += gridDim.y) {
+    const uint32_t cell = cell_base + (uint32_t)row;
+    for (int q = blockIdx.x * 256 + threadIdx.x; 2 * q < (int)ld; q += gridDim.x * 256) {   // the padded columns too: zeros beyond G
+      const U4 w = philox4x32_10((uint32_t)q, cell, 0u, (uint32_t)ST_GENERATE, k0, k1);
+      const float u1 = ((float)(w.x >> 8) + 1.0f) * 5.9604644775390625e-08f;
+      const float u2 = u24(w.y);
+      const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+      const float nrm[2] = {r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2)};
+      const float uk[2] = {u24(w.z), u24(w.w)};
+      float x[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int g = 2 * q + e;
+        const float v = g < G ? fminf(floorf(fexp(mu[min(g, G - 1)] + nrm[e])), 65535.f) : 0.f;
+        x[e] = (g < G && uk[e] < density) ? v : 0.f;
+        if (g == 0) x[e] = fmaxf(x[e], 1.f);
+      }
+      if (U16) reinterpret_cast<ushort2*>(reinterpret_cast<uint16_t*>(Xv) + row * ld)[q] = make_ushort2((unsigned short)x[0], (unsigned short)x[1]);
+      else reinterpret_cast<float2*>(reinterpret_cast<float*>(Xv) + row * ld)[q] = make_float2(x[0], x[1]);
+    }
+  }
+}
+int launch_generate_lognormal(hipStream_t st, void* X, int u16, long ld, long N, int G, uint64_t seed, uint32_t cell_base, float density,
+                              float* mu) {
+  const uint32_t k0 = (uint32_t)(seed & 0xFFFFFFFFu), k1 = (uint32_t)(seed >> 32);
+  hipLaunchKernelGGL(gene_mu_kernel, dim3((unsigned)((G + 1023) / 1024)), dim3(256), 0, st, k0, k1, G, mu);
+  const unsigned gx = (unsigned)std::max(1, std::min(64, ((int)ld / 2 + 255) / 256));
+  const unsigned gy = (unsigned)std::min<long>(N, 65535);
+  if (u16) hipLaunchKernelGGL(generate_lognormal_kernel<1>, dim3(gx, gy), dim3(256), 0, st, X, ld, N, G, k0, k1, cell_base, density, mu);
+  else hipLaunchKernelGGL(generate_lognormal_kernel<0>, dim3(gx, gy), dim3(256), 0, st, X, ld, N, G, k0, k1, cell_base, density, mu);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }

@@ -106,6 +106,37 @@ static int dataset_upload_impl(smx_model* m, const void* X, bool u16, int64_t n_
   return upload_side_arrays(m, n_cells, labels, library, label_mask);
 }
 
+// BASELINE.json configs[4] (synthetic 1e6 cells x 20k genes log-normal counts): the rank's shard generated ON the device
+//  -- 40 GB as uint16 at the full size, nothing crosses PCIe.  Rows are those of one virtual matrix keyed by
+// the global cell id rank * n_cells + row (smx_data.hip: generate_lognormal_kernel).
+int smx_dataset_generate_lognormal(smx_model* m, uint64_t seed, int32_t rank, int64_t n_cells, int32_t storage_u16, double density) {
+  SMX_REQUIRE(m && n_cells > 0 && rank >= 0, "bad arguments");
+  SMX_REQUIRE(n_cells < (int64_t)1 << 31 && (int64_t)rank * n_cells + n_cells <= (int64_t)0xFFFFFFFF, "cell ids are 32-bit");
+  SMX_REQUIRE(density > 0.0 && density <= 1.0, "density must be in (0, 1]");
+  SMX_REQUIRE(!m->scvi && m->cfg.n_labels == 0, "the generator makes counts only (no library prior, no labels)");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  drop_graphs(m);
+  auto fr = [](void* p) { if (p) hipFree(p); };
+  release_csr(m);
+  fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1);
+  m->X = nullptr; m->library = nullptr; m->mask = nullptr; m->lgx1 = nullptr;
+  for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); m->Y[j] = nullptr; }
+  m->N = n_cells; m->cell_base = (int64_t)rank * n_cells; m->x_u16 = storage_u16 != 0;
+  const size_t bytes = (size_t)n_cells * (size_t)m->Gp * (m->x_u16 ? sizeof(uint16_t) : sizeof(float));
+  hipError_t e = hipMalloc((void**)&m->X, bytes);   // (no memset of tens of GB: the generator writes every element of every padded row)
+  if (e != hipSuccess) { m->X = nullptr; m->N = 0; set_error(std::string("hipMalloc of the resident matrix failed: ") + hipGetErrorString(e)); return SMX_ERR_NOMEM; }
+  int rc;
+  float* mu = nullptr;
+  if ((rc = dmalloc(&m->lgx1, (size_t)n_cells)) || (rc = dmalloc(&mu, (size_t)m->Gp))) return rc;
+  // (Gp is a multiple of 32: the kernel covers the padded columns too, writing zeros beyond G)
+  rc = launch_generate_lognormal(m->st, m->X, m->x_u16 ? 1 : 0, m->Gp, m->N, m->G, seed, (uint32_t)m->cell_base, (float)density, mu);
+  if (rc == SMX_OK) rc = launch_row_stats(m->st, m->X, m->x_u16 ? 1 : 0, m->Gp, m->N, m->G, m->lgx1, nullptr);
+  hipError_t es = hipStreamSynchronize(m->st);
+  hipFree(mu);
+  if (rc == SMX_OK && es != hipSuccess) { set_error(std::string("generator failed: ") + hipGetErrorString(es)); rc = SMX_ERR_HIP; }
+  return rc;
+}
+
 int64_t smx_dataset_size(const smx_model* m) { return m ? m->N : 0; }
 
 int smx_dataset_library(smx_model* m, float stats[2]) {

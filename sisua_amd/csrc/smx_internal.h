@@ -503,6 +503,9 @@ int launch_disc_head(hipStream_t st, const DiscHeadArgs& a);
 
 // ---- dataset kernels (smx_data.hip) ------------------------------------------------------------
 enum { ST_CORRUPT_SELECT = 80, ST_CORRUPT_BINOMIAL = 81 };   // Philox streams of the on-device corruption
+enum { ST_GENERATE = 90, ST_GENERATE_MU = 91 };               // ... of the on-device generator (smx_dataset_generate_lognormal)
+int launch_generate_lognormal(hipStream_t st, void* X, int u16, long ld, long N, int G, uint64_t seed, uint32_t cell_base, float density,
+                              float* mu);
 struct CorruptArgs {
   float* X = nullptr; long ld = 0; long N = 0; int G = 0; int u16 = 0;   // u16: X is uint16_t*
   uint32_t k0 = 0, k1 = 0, cell_base = 0;

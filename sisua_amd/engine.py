@@ -354,6 +354,14 @@ class Engine:
     return mllk, llk
 
   # ---- resident-matrix preprocessing ---------------------------------------
+  def generate_lognormal(self, n_cells: int, seed: int = 8, rank: int = 0, storage: str = "u16", density: float = 0.14):
+    """The rank's shard of BASELINE configs[4] generated on the device (smx_dataset_generate_lognormal): nothing crosses
+    PCIe; rows are those of one virtual matrix keyed by the global cell id rank * n_cells + row."""
+    if storage not in ("u16", "f32"):
+      raise ValueError("storage must be 'u16' or 'f32'")
+    check(self.lib.smx_dataset_generate_lognormal(self._h, int(seed), int(rank), int(n_cells), 1 if storage == "u16" else 0, float(density)))
+    self.n_cells = int(n_cells)
+
   def dataset_library(self):
     """get_library_size (data/utils.py:231-263) over the resident matrix on the GPU; fills the resident
     library prior and returns (local_mean, local_var)."""

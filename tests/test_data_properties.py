@@ -69,3 +69,22 @@ def test_library_size_matches_its_definition(seed, shape):
   ref = np.log(x.sum(1) + 1e-8)
   assert np.allclose(np.ravel(lc), ref, rtol=1e-6) and np.isclose(mean, ref.mean(), rtol=1e-5, atol=1e-6)
   assert np.isclose(var, ref.var(), rtol=1e-4, atol=1e-6)
+
+
+def test_generated_scaling_matrix_is_sharding_independent_and_shaped_like_c5():
+  """oracle.generate_lognormal_rows (the restatement of smx_dataset_generate_lognormal, BASELINE configs[4]): a row is a
+  function of (seed, global cell id) only -- shards of any size concatenate to the same matrix --, counts are non-negative
+  integers <= 65535 with ~93 % zeros at the default density, no cell is empty, genes differ in their means."""
+  from oracle import sisua_oracle as so
+  G = 2000
+  a = so.generate_lognormal_rows(8, np.arange(0, 96), G)
+  b = np.concatenate([so.generate_lognormal_rows(8, np.arange(r * 32, (r + 1) * 32), G) for r in range(3)])
+  assert np.array_equal(a, b) and a.dtype == np.float32 and a.shape == (96, G)
+  assert not np.array_equal(a, so.generate_lognormal_rows(9, np.arange(0, 96), G))
+  assert np.array_equal(a, np.floor(a)) and a.min() >= 0 and a.max() <= 65535 and (a.sum(1) > 0).all()
+  assert 0.91 < (a == 0).mean() < 0.95
+  big = so.generate_lognormal_rows(8, np.arange(4000000000, 4000000004, dtype=np.uint64), 64)   # 32-bit cell ids beyond 2^31
+  assert big.shape == (4, 64) and np.isfinite(big).all()
+  dense = so.generate_lognormal_rows(8, np.arange(512), 40, density=1.0)
+  m = np.log1p(dense).mean(0)
+  assert m.std() > 0.1                                         # per-gene log-means differ (mu_g = 0.5 n_g)

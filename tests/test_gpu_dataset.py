@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import sisua_oracle as so
-from tests.util import make_pair, synth_counts
+from tests.util import grad_errors, make_pair, synth_counts
 
 pytestmark = pytest.mark.gpu
 
@@ -214,3 +214,97 @@ def test_csr_store_takes_sparse_inputs_and_rejects_bad_ones(Engine):
   with pytest.raises(Exception):
     e2.train_step(np.arange(32, dtype=np.int32))
   e2.close(); e.close()
+
+
+def _rows_match_generator(got, cell_ids, seed, density, G):
+  """Device rows vs oracle.generate_lognormal_rows: identical except where the un-floored value sits within float32
+  evaluation error of an integer (the device's v_log / v_sin / v_cos / v_exp forms: ~1e-6 relative on exp(.)), and there by
+  exactly one count.  Returns the number of such entries."""
+  ref, real = so.generate_lognormal_rows(seed, cell_ids, G, density, return_real=True)
+  diff = got != ref
+  if diff.any():
+    near = np.abs(real - np.round(real)) <= 2e-5 * np.maximum(real, 1.0)
+    assert (near | ~diff).all(), "entries differ away from an integer boundary"
+    assert np.abs(got - ref)[diff].max() == 1.0
+    assert diff.mean() < 1e-4, diff.mean()
+  return int(diff.sum())
+
+
+@pytest.mark.parametrize("storage,G,rank", [("u16", 203, 2), ("f32", 64, 0), ("u16", 1998, 7)])
+def test_generator_matches_oracle(Engine, storage, G, rank):
+  """smx_dataset_generate_lognormal (BASELINE configs[4]'s matrix, generated on the device from (seed, rank)) against the
+  oracle's restatement: rows, the per-row likelihood constants, padded columns, shard independence."""
+  from scipy.special import gammaln
+  spec, cfg = make_pair(model="vae", n_genes=G, likelihood="zinb", enc_units=(32,), dec_units=(32,), latent_dim=8)
+  e = Engine(cfg, max_batch=64)
+  n = 300
+  e.generate_lognormal(n, seed=8, rank=rank, storage=storage, density=0.14)
+  assert e.n_cells == n
+  x, lg = e.dataset_read(0, n)
+  ids = np.arange(rank * n, (rank + 1) * n)
+  _rows_match_generator(x, ids, 8, 0.14, G)
+  assert np.allclose(lg, gammaln(x.astype(np.float64) + 1.0).sum(1), rtol=1e-6, atol=1e-4)
+  assert 0.90 < (x == 0).mean() < 0.96 and (x[:, 0] >= 1).all()
+  # the same cells as part of a larger shard of another job: rank 0 of a shard three times the size holds them too
+  if rank == 2:
+    e2 = Engine(cfg, max_batch=64)
+    e2.generate_lognormal(3 * n, seed=8, rank=0, storage=storage, density=0.14)
+    x2, _ = e2.dataset_read(2 * n, n)
+    assert np.array_equal(x, x2)
+    e2.close()
+  # a training step runs on it and matches the oracle on the device's own rows (noise keyed by the global cell ids)
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e.set_params(params)
+  rows = np.arange(100, 164, dtype=np.int32)
+  res = so.train_step(spec, params, bn, opt, x[rows], so.PhiloxNoise(spec.seed, 0, rows + rank * n))
+  m = e.train_step(rows)
+  assert np.isclose(m["loss"], res["metrics"]["loss"], rtol=1e-4)
+  e.close()
+
+
+def test_c5_at_full_residency(Engine):
+  """BASELINE configs[4] at its real residency on ONE GPU: 1e6 cells x 20 000 genes generated on the device as uint16
+  (40 GB resident, 2e10 elements: every row offset beyond 2^31 elements must be 64-bit arithmetic).  Rows are drawn from
+  the LAST 1 % of the matrix (element offsets > 1.98e10): read-back against the oracle's generator, the per-row likelihood
+  constants, three optimiser steps (ELBO scalars; every gradient at the first) against the oracle on those rows, and the
+  library statistics over all 1e6 rows."""
+  from scipy.special import gammaln
+  N, G, B = 1_000_000, 20000, 128
+  spec, cfg = make_pair(model="vae", n_genes=G, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=32)
+  e = Engine(cfg, max_batch=B, init=False)
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e.set_params(params)
+  e.generate_lognormal(N, seed=8, rank=0, storage="u16", density=0.14)
+  assert e.n_cells == N
+  rng = np.random.default_rng(3)
+  tail0 = N - 10_000
+  assert tail0 * 20000 > 2 ** 31 * 9                            # far beyond 32-bit element offsets
+  # read-back of a block at the very end and of scattered tail rows
+  xe, lge = e.dataset_read(N - 64, 64)
+  _rows_match_generator(xe, np.arange(N - 64, N), 8, 0.14, G)
+  assert np.allclose(lge, gammaln(xe.astype(np.float64) + 1.0).sum(1), rtol=1e-6, atol=1e-3)
+  for s in range(3):
+    rows = np.sort(rng.choice(np.arange(tail0, N), size=B, replace=False)).astype(np.int32)
+    xr = np.concatenate([e.dataset_read(int(r), 1)[0] for r in rows])   # the device's own rows (boundary ties aside, the oracle's)
+    if s == 0:
+      _rows_match_generator(xr, rows, 8, 0.14, G)
+    res = so.train_step(spec, params, bn, opt, xr, so.PhiloxNoise(spec.seed, s, rows))
+    m = e.train_step(rows)
+    assert m["nan_flag"] == 0
+    for key in ("loss", "nllk_x", "kl"):
+      assert np.isclose(m[key], res["metrics"][key], rtol=1e-4, atol=1e-5), (s, key, m[key], res["metrics"][key])
+    if s == 0:
+      worst = grad_errors(e.get_params(which=1), res["grads"])
+      assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+      assert np.isclose(m["grad_norm_max"], max(np.linalg.norm(g) for g in res["grads"].values()), rtol=1e-4)
+  # library statistics over the whole resident matrix (get_library_size, sisua/data/utils.py:231-263): against the oracle's
+  # generator on a random sample of cells (standard error of the sample mean ~ sd / sqrt(4000))
+  lm, lv = e.dataset_library()
+  sample = rng.choice(N, size=4000, replace=False)
+  lc = np.log(so.generate_lognormal_rows(8, sample, G).sum(1) + 1e-8)
+  assert abs(lm - lc.mean()) < 5 * lc.std() / np.sqrt(4000) + 1e-3 and abs(lv - lc.var()) < 0.25 * lc.var()
+  lib_tail = e.dataset_read(N - 4, 4, library=True)[-1]
+  assert np.allclose(lib_tail, [[lm, lv]] * 4)
+  e.close()
