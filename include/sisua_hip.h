@@ -319,6 +319,10 @@ int smx_shuffle_order(int32_t n_obs, int32_t buffer, const int64_t* picks, int32
  * products' store paths), "stacked_scoring" (smx_marginal_llk, smx_score_llk and smx_predict with several draws: all
  * posterior draws of a batch as rows of ONE decoder pass, in the scoring calls the output head fused with the
  * likelihood; 0 = one decoder pass per draw; SMX_NO_STACKED_SCORING).
+ * "bf16x3": the training products of the output head (the fused head, both products of its backward, the first layer's
+ * weight gradient) from bf16 MFMAs on operands split three ways in registers (f32 accuracy to one rounding of a product;
+ * 0.375 of the f32 MFMAs' cycles, on the matrix pipe): 1 always, 0 never (exact f32 MFMAs), -1 (default) from the head's
+ * width -- SMX_BF16X3 in the environment sets the same default.
  * value 1 = default form, 0 = separate launches.  Results agree to rounding;
  * used for A/B measurements and by the parity tests of both forms.  Defaults may also be set with SMX_NO_HEAD_LOSS /
  * SMX_NO_FRONT / SMX_NO_BWD_FRONT / SMX_NO_HEAD_BWD / SMX_NO_WGRAD / SMX_NO_SCVI_FUSED / SMX_NO_TWIN /

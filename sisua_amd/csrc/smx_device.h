@@ -180,6 +180,59 @@ __device__ inline LgDg lgamma_digamma_diff(float x, float r) {
 }
 
 // ---------------------------------------------------------------------------
+// f32 products from bf16 MFMAs on three-way split operands (gfx950: v_mfma_f32_32x32x16_bf16)
+// ---------------------------------------------------------------------------
+// x = x0 + x1 + x2, each term the bf16 rounding of what the earlier ones left (the first two remainders are exact in f32).
+// Of the nine cross products of two split operands the six with index sum <= 2 are kept: x0 y0, x0 y1, x1 y0, x0 y2, x2 y0,
+// x1 y1 -- what is dropped is below 2^-23 |x y|, the rounding of ONE f32 multiply, and the sum is accumulated in f32 by
+// the MFMA.  Why: v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate and holds the SIMD's vector issue while it runs
+// (tools/coexec.hip), so an f32-MFMA product and the vector work beside it ADD; six bf16 MFMAs of 32 cycles per 16 k take
+// 0.375 of the cycles of eight f32 ones and run on the matrix pipe beside the vector work.
+typedef __bf16 smx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float smx_f32x16 __attribute__((ext_vector_type(16)));
+struct Split8 { smx_bf16x8 t0, t1, t2; };
+__device__ inline Split8 split3x8(const float (&x)[8]) {
+  Split8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const __bf16 a = (__bf16)x[k];
+    const float r1 = x[k] - (float)a;   // exact
+    const __bf16 b = (__bf16)r1;
+    const __bf16 c = (__bf16)(r1 - (float)b);
+    o.t0[k] = a; o.t1[k] = b; o.t2[k] = c;
+  }
+  return o;
+}
+// acc += A B over 16 k: lane (i, h) gives rows / columns i, k = 8 h .. 8 h + 7 of the step (smallest terms first)
+__device__ inline smx_f32x16 mfma_bf16x3(const Split8& a, const Split8& b, smx_f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t2, b.t0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t0, b.t2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t1, b.t1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t1, b.t0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t0, b.t1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t0, b.t0, acc, 0, 0, 0);
+  return acc;
+}
+
+// ---------------------------------------------------------------------------
+// LDS-DMA (global -> LDS, 16 bytes per lane, no VGPR destination) as inline assembly
+// ---------------------------------------------------------------------------
+// One wave-instruction lands 64 x 16 B = 1 KiB linearly at the wave-uniform LDS byte address `lds_dst`; each lane names its own
+// source.  Written as inline asm, not __builtin_amdgcn_global_load_lds, for pipelines that keep several stages in flight across a
+// barrier: the compiler tracks the builtin as a pending LDS write and puts `s_waitcnt vmcnt(0)` before every ds_read it cannot
+// prove disjoint (a ring of stage buffers indexed by st % N is such a case -- the pipeline then runs one stage deep); an asm load
+// is invisible to that logic, so the kernel's own counted `s_waitcnt vmcnt(N)` + `s_barrier` are what orders the reads
+// (cdna_hip_programming.md: "Pipelining across barriers").  M0 carries the LDS base and is compiler-reserved: saved and restored.
+__device__ inline void glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ inline uint32_t lds_addr(const void* p) {   // byte address within the workgroup's LDS of a pointer into a __shared__ array
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+// ---------------------------------------------------------------------------
 // wave / block reductions (wave = 64)
 // ---------------------------------------------------------------------------
 // (four DPP steps inside the rows of 16, then two ds_bpermute across the four rows -- instead of six ds_bpermute)

@@ -25,7 +25,9 @@ namespace smx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // SEP: the planes are separate tensors (scvi's heads: W_p [Hp][Gp] each, their own bias / clipnorm)
-template <int NP, int SEP = 0>
+// B3: both products from bf16 MFMAs on three-way split operands (smx_device.h), split in registers after the loads: in
+// either role a lane's loads are runs of 8 consecutive k, i.e. whole operands of v_mfma_f32_32x32x16_bf16
+template <int NP, int SEP = 0, int B3 = 0>
 __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
   __shared__ float red[8 * 1024];   // ONE plane's eight partial tiles at a time (32 KB: two workgroups per CU, not one)
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -61,15 +63,28 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
         for (int p = 0; p < NP; ++p) bv[p][s] = a.dP[(long)cell * a.ldp + (long)p * a.Gp + g0 + i];
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (B3) {
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const bool on = k0 + s < a.B;       // K is the (ragged) minibatch axis: cells beyond it contribute nothing
-        const float av_s = on ? av[s] : 0.f;
+        for (int s = 0; s < 8; ++s) {
+          const bool on = k0 + s < a.B;     // K is the (ragged) minibatch axis: cells beyond it contribute nothing
+          av[s] = on ? av[s] : 0.f;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const float b = on ? bv[p][s] : 0.f;
-          csum[p] += b;
-          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_s, b, acc[p], 0, 0, 0);
+          for (int p = 0; p < NP; ++p) { bv[p][s] = on ? bv[p][s] : 0.f; csum[p] += bv[p][s]; }
+        }
+        const Split8 sa = split3x8(av);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) acc[p] = mfma_bf16x3(sa, split3x8(bv[p]), acc[p]);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const bool on = k0 + s < a.B;       // K is the (ragged) minibatch axis: cells beyond it contribute nothing
+          const float av_s = on ? av[s] : 0.f;
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const float b = on ? bv[p][s] : 0.f;
+            csum[p] += b;
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_s, b, acc[p], 0, 0, 0);
+          }
         }
       }
     }
@@ -168,12 +183,23 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     const float m = on ? 1.f : 0.f;
+    if constexpr (B3) {
+      // step t: the lane's k 8 t .. 8 t + 7 of its 32 (both lane halves' runs form the step's 16 k; A and B agree)
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].x * m, b4[v].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].y * m, b4[v].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].z * m, b4[v].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].w * m, b4[v].w, acc, 0, 0, 0);
+      for (int t = 0; t < 4; ++t) {
+        const float ax[8] = {a4[2 * t].x * m, a4[2 * t].y * m, a4[2 * t].z * m, a4[2 * t].w * m,
+                             a4[2 * t + 1].x * m, a4[2 * t + 1].y * m, a4[2 * t + 1].z * m, a4[2 * t + 1].w * m};
+        const float bx[8] = {b4[2 * t].x, b4[2 * t].y, b4[2 * t].z, b4[2 * t].w, b4[2 * t + 1].x, b4[2 * t + 1].y, b4[2 * t + 1].z, b4[2 * t + 1].w};
+        acc = mfma_bf16x3(split3x8(ax), split3x8(bx), acc);
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].x * m, b4[v].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].y * m, b4[v].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].z * m, b4[v].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].w * m, b4[v].w, acc, 0, 0, 0);
+      }
     }
   }
 #pragma unroll
@@ -203,35 +229,35 @@ int head_bwd_slices(long ldp, int max_slabs, int* k_chunk) {
 
 int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a_in) {
   HeadBwdArgs a = a_in;
-  bool ptrs = a.W && a.dW && a.db;
+  bool ptrs = a.W && (a.skip_dw || (a.dW && a.db));
   if (a.sep) {
     ptrs = a.n_planes >= 2 && a.n_planes <= 3;
     for (int p = 0; p < a.n_planes && ptrs; ++p) ptrs = a.Wp[p] && a.dWp[p] && a.dbp[p];
   }
-  if (!head_bwd_supported(a.B, a.Hp, a.Gp) || !a.D || !a.dP || !ptrs || !a.slab || (a.ldp % 4) || (a.ldw % 4) ||
+  if (!head_bwd_supported(a.B, a.Hp, a.Gp) || !a.D || !a.dP || !ptrs || (!a.slab && !a.skip_dd) || (a.ldp % 4) || (a.ldw % 4) ||
       a.n_slices < 1 || a.k_chunk % 512) {
     set_error("out_head_bwd: bad shapes");
     return SMX_ERR_INVALID;
   }
   { static const int dg = getenv("SMX_HEADBWD_DIAG") ? atoi(getenv("SMX_HEADBWD_DIAG")) : 0; a.diag = dg; }
   a.n_ht = a.Hp / 32; a.n_gt = a.Gp / 32; a.n_ct = (a.B + 31) / 32;
-  a.n_w = a.n_ht * ((a.n_gt + 7) / 8 * 8);
+  a.n_w = a.skip_dw ? 0 : a.n_ht * ((a.n_gt + 7) / 8 * 8);
   if (a.n_extra < 0 || a.n_extra > SMX_MAX_LABELS) { set_error("out_head_bwd: bad label riders"); return SMX_ERR_INVALID; }
   for (int e = 0; e < a.n_extra; ++e)
     if (!a.xA[e] || !a.xW[e] || a.xK[e] <= 0 || (a.xK[e] % 32) || (a.xlda[e] % 4) || (a.xldw[e] % 4)) { set_error("out_head_bwd: bad label riders"); return SMX_ERR_INVALID; }
-  const int n_d = a.n_ct * a.n_ht * ((a.n_slices + a.n_extra + 7) / 8 * 8);
-  if (a.sq_count) *a.sq_count = a.n_ht * a.n_gt * 8;
+  const int n_d = a.skip_dd ? 0 : a.n_ct * a.n_ht * ((a.n_slices + a.n_extra + 7) / 8 * 8);
+  if (a.sq_count && !a.skip_dw) *a.sq_count = a.n_ht * a.n_gt * 8;
   dim3 grid((unsigned)(a.n_w + n_d));
   if (a.sep) {
     for (int p = 0; p < a.n_planes; ++p)
       if (a.sqp[p] && a.sq_countp[p]) *a.sq_countp[p] = a.n_ht * a.n_gt * 8;
-    if (a.n_planes == 3) hipLaunchKernelGGL((out_head_bwd_kernel<3, 1>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((out_head_bwd_kernel<2, 1>), grid, dim3(512), 0, st, a);
+    if (a.n_planes == 3) { if (a.bf16x3) hipLaunchKernelGGL((out_head_bwd_kernel<3, 1, 1>), grid, dim3(512), 0, st, a); else hipLaunchKernelGGL((out_head_bwd_kernel<3, 1>), grid, dim3(512), 0, st, a); }
+    else { if (a.bf16x3) hipLaunchKernelGGL((out_head_bwd_kernel<2, 1, 1>), grid, dim3(512), 0, st, a); else hipLaunchKernelGGL((out_head_bwd_kernel<2, 1>), grid, dim3(512), 0, st, a); }
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
-  if (a.n_planes == 3) hipLaunchKernelGGL((out_head_bwd_kernel<3>), grid, dim3(512), 0, st, a);
-  else if (a.n_planes == 2) hipLaunchKernelGGL((out_head_bwd_kernel<2>), grid, dim3(512), 0, st, a);
+  if (a.n_planes == 3) { if (a.bf16x3) hipLaunchKernelGGL((out_head_bwd_kernel<3, 0, 1>), grid, dim3(512), 0, st, a); else hipLaunchKernelGGL((out_head_bwd_kernel<3>), grid, dim3(512), 0, st, a); }
+  else if (a.n_planes == 2) { if (a.bf16x3) hipLaunchKernelGGL((out_head_bwd_kernel<2, 0, 1>), grid, dim3(512), 0, st, a); else hipLaunchKernelGGL((out_head_bwd_kernel<2>), grid, dim3(512), 0, st, a); }
   else { set_error("out_head_bwd: 2 or 3 planes"); return SMX_ERR_INVALID; }
   SMX_HIP(hipGetLastError());
   return SMX_OK;
@@ -287,15 +313,28 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(WgradGroup G) {
       else av[s] = P.A[arow[s] * P.lda + m0 + i];
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (Gr.b3) {   // (launch-uniform) the product from bf16 MFMAs on three-way split operands: the lane's 8 cells are one operand
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const bool on = k0 + s < B;
-      float a_s = av[s];
-      if (P.a_mode && P.log1p) a_s = log1p_count(a_s);
-      a_s = on ? a_s : 0.f;
-      const float b_s = on ? bv[s] : 0.f;
-      csum += b_s;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s, b_s, acc, 0, 0, 0);
+      for (int s = 0; s < 8; ++s) {
+        const bool on = k0 + s < B;
+        float a_s = av[s];
+        if (P.a_mode && P.log1p) a_s = log1p_count(a_s);
+        av[s] = on ? a_s : 0.f;
+        bv[s] = on ? bv[s] : 0.f;
+        csum += bv[s];
+      }
+      acc = mfma_bf16x3(split3x8(av), split3x8(bv), acc);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bool on = k0 + s < B;
+        float a_s = av[s];
+        if (P.a_mode && P.log1p) a_s = log1p_count(a_s);
+        a_s = on ? a_s : 0.f;
+        const float b_s = on ? bv[s] : 0.f;
+        csum += b_s;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s, b_s, acc, 0, 0, 0);
+      }
     }
   }
 #pragma unroll
@@ -337,11 +376,11 @@ bool wgrad_supported(const GemmArgs& g, int B) {
   return true;
 }
 
-int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B) {
+int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int bf16x3) {
   if (n < 1 || n > SMX_GROUP_MAX) { set_error("wgrad group: 1..SMX_GROUP_MAX problems"); return SMX_ERR_INVALID; }
   WgradGroup G;
   memset(&G, 0, sizeof(G));
-  G.n = n; G.B = B;
+  G.n = n; G.B = B; G.b3 = bf16x3;
   int total = 0;
   for (int k = 0; k < n; ++k) {
     const GemmArgs& g = list[k];

@@ -36,8 +36,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // MFMA step s (KS = 128 / NW) and finishes accumulator registers q RPW .. q RPW + RPW - 1 (RPW = 16 / NW).
 // SLAB: depth of K a workgroup takes per round of loads (128 in training; the scoring form with 1 / 2 waves per
 // workgroup uses 32 / 64 so that a lane still holds 16 k-steps of operands).
-template <int LK, int U16, int EPI, int NW, int SLAB = 128>
+// B3: the product from bf16 MFMAs on three-way split operands (smx_device.h: split3x8 / mfma_bf16x3), split in registers
+// right after the loads -- a lane's 8 consecutive k of a slab ARE its operand of one v_mfma_f32_32x32x16_bf16 (8 waves, K
+// slab 128: KH = 8).  Same operand ownership, same exchange, same epilogue as the f32 form; the wide output heads take it
+// (launch_hl), where the f32 MFMAs' vector-pipe time dominates the launch.
+template <int LK, int U16, int EPI, int NW, int SLAB = 128, int B3 = 0>
 __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) {
+  static_assert(!B3 || SLAB / NW == 16, "the bf16 form needs 8 consecutive k per lane half");
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
   constexpr int KS = SLAB / NW, KH = KS / 2, RPW = 16 / NW;
   __shared__ float red[NW > 1 ? NW * 1024 : 1];   // ONE plane's NW partial tiles at a time (32 KB at 8 waves: two workgroups per CU)
@@ -98,10 +103,16 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
       for (int p = 0; p < NP; ++p) bv[p][s] = wp[(long)s * a.ldw + (long)p * a.Gp];
   };
   auto mfma_slab = [&]() {
+    if constexpr (B3) {
+      const Split8 sa = split3x8(*reinterpret_cast<const float (*)[8]>(&av[0]));
 #pragma unroll
-    for (int s = 0; s < KH; ++s)
+      for (int p = 0; p < NP; ++p) acc[p] = mfma_bf16x3(sa, split3x8(*reinterpret_cast<const float (*)[8]>(&bv[p][0])), acc[p]);
+    } else {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[p][s], acc[p], 0, 0, 0);
+      for (int s = 0; s < KH; ++s)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[p][s], acc[p], 0, 0, 0);
+    }
   };
   const bool active = KS * q < a.Hp;              // wave-uniform: this wave has a K slice in the first slab
   if (active) load_slab(0);
@@ -187,15 +198,21 @@ static int head_waves() {   // waves per workgroup (SMX_HEAD_WAVES = 4 | 8 | 16)
   return (v == 4 || v == 16) ? v : 8;
 }
 
-template <int LK, int NW>
+template <int LK, int NW, int B3 = 0>
 static void launch_hl_w(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
   if (a.product_only) {
-    hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 0, NW>), grid, dim3(64 * NW), 0, st, a);
+    hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 0, NW, 128, B3>), grid, dim3(64 * NW), 0, st, a);
   } else if (a.x_u16) {
-    hipLaunchKernelGGL((out_head_loss_kernel<LK, 1, 1, NW>), grid, dim3(64 * NW), 0, st, a);
+    hipLaunchKernelGGL((out_head_loss_kernel<LK, 1, 1, NW, 128, B3>), grid, dim3(64 * NW), 0, st, a);
   } else {
-    hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 1, NW>), grid, dim3(64 * NW), 0, st, a);
+    hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 1, NW, 128, B3>), grid, dim3(64 * NW), 0, st, a);
   }
+}
+// bf16 x 3 products: SMX_BF16X3 = 1 always, 0 never; default from the width (a launch-bound head of ~2000 genes gains
+// nothing: its f32 MFMAs are not what it waits for)
+bool use_bf16x3(long work) {
+  static const int forced = getenv("SMX_BF16X3") ? atoi(getenv("SMX_BF16X3")) : -1;
+  return forced >= 0 ? forced != 0 : work >= SMX_BF16X3_MIN_WORK;
 }
 template <int LK>
 static void launch_hl(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
@@ -209,6 +226,7 @@ static void launch_hl(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
   }
   if (head_waves() == 4) launch_hl_w<LK, 4>(st, a, grid);
   else if (head_waves() == 16) launch_hl_w<LK, 16>(st, a, grid);
+  else if (a.bf16x3) launch_hl_w<LK, 8, 1>(st, a, grid);
   else launch_hl_w<LK, 8>(st, a, grid);
 }
 

@@ -371,7 +371,11 @@ struct HeadLossArgs {
   // of the stacked batch in column r)
   int llk_only = 0, row_mod = 0;
   int n_ct = 0, n_gt = 0;                         // set by the launcher
+  int bf16x3 = 0;                                 // the product from bf16 MFMAs on three-way split operands (smx_device.h)
 };
+// cells x padded genes x planes from which the output head's products run as bf16 x 3 by default (flag "bf16x3" / SMX_BF16X3)
+#define SMX_BF16X3_MIN_WORK (128L * 8192 * 3)
+bool use_bf16x3(long work);
 bool head_loss_supported(int B, int Hp, int Gp);
 int head_loss_chunks(int Gp);
 int launch_out_head_loss(hipStream_t st, const HeadLossArgs& a);
@@ -457,10 +461,27 @@ struct HeadBwdArgs {
   const float* xW[SMX_MAX_LABELS] = {nullptr, nullptr, nullptr, nullptr}; int xldw[SMX_MAX_LABELS] = {0, 0, 0, 0}; int xK[SMX_MAX_LABELS] = {0, 0, 0, 0};
   int n_ht = 0, n_gt = 0, n_ct = 0, n_w = 0;       // set by the launcher
   int diag = 0;                                    // SMX_HEADBWD_DIAG bit 1 / 2: role-0 / role-1 workgroups return at once (timing only)
+  int bf16x3 = 0;                                  // both products from bf16 MFMAs on three-way split operands (smx_device.h)
+  int skip_dw = 0;                                 // role 1 (d d) only
+  int skip_dd = 0;                                 // role 0 only: d d came from launch_bigk
 };
 bool head_bwd_supported(int B, int Hp, int Gp);
 int head_bwd_slices(long ldp, int max_slabs, int* k_chunk);
 int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a);
+
+// ---- products contracting over the gene axis of a wide panel: one workgroup per K slice + a reduce launch (smx_bigk.hip) ----
+struct BigKArgs {
+  const float* A = nullptr; long lda = 0;          // [M][K] rows, k contiguous (float32, or the uint16 store: a_u16)
+  int a_u16 = 0, log1p = 0; const int32_t* rows = nullptr;   // gather by row id (nullptr: identity), log1p on the way
+  const float* Bm = nullptr; long ldb = 0; int b_kmajor = 0; // b_kmajor: B stored [K][N] (n contiguous); else [N][K] (k contiguous)
+  float* part = nullptr; long slab_stride = 0;     // [n_slices][M][ldc] partial slabs (scratch)
+  float* out = nullptr; int ldc = 0;               // [M][ldc]: their sum in slice order
+  int M = 0, N = 0, K = 0;
+  int n_slices = 0, k_chunk = 0;                   // from bigk_slices
+};
+int bigk_slices(long K, int max_slices, int* k_chunk);
+bool bigk_supported(const BigKArgs& a);
+int launch_bigk(hipStream_t st, const BigKArgs& a);
 
 // ---- grouped weight gradients with K = the minibatch (smx_headbwd.hip) ---------------------------
 struct WgradProblem {
@@ -471,9 +492,9 @@ struct WgradProblem {
   float* colsum; float* sq_part;
   int start, n_mt, n_nt;
 };
-struct WgradGroup { int n; int B; WgradProblem p[SMX_GROUP_MAX]; };
+struct WgradGroup { int n; int B; int b3; WgradProblem p[SMX_GROUP_MAX]; };   // b3: bf16 x 3 MFMAs (smx_device.h)
 bool wgrad_supported(const GemmArgs& g, int B);
-int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B);
+int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int bf16x3 = 0);
 
 // ---- FactorVAE discriminator (smx_factor.hip; sisua/models/fvae.py:9-18, Kim & Mnih 2018 Algorithm 2) -------------
 enum { ST_PERMUTE = 66 };   // Philox stream of the permute_dims uniforms

@@ -46,6 +46,7 @@ using namespace smx;
   } while (0)
 
 #define SMX_LOSS_TIMING_REPEAT 8
+#define SMX_BIGK_MAX_SLICES 256   // about one K slice per CU (smx_bigk.hip)
 enum { ST_INPUT_DROPOUT = 0, ST_ENC_DROPOUT = 16, ST_ENCL_DROPOUT = 32, ST_DEC_DROPOUT = 48, ST_EPS_Z = 64, ST_EPS_L = 65 };
 
 namespace smx {
@@ -133,6 +134,9 @@ struct smx_model {
     int act_epilogue = getenv("SMX_NO_ACT_EPILOGUE") ? 0 : 1;  // layers without BatchNorm / dropout: bias + activation (and its derivative) in the products' store paths
     int label_ride = getenv("SMX_NO_LABEL_RIDE") ? 0 : 1;  // label heads' backward inside the output head's backward launch + the final grouped launch
     int stacked_scoring = getenv("SMX_NO_STACKED_SCORING") ? 0 : 1;  // marginal_llk: all posterior draws as rows of ONE decoder pass
+    // training products of the output head (fused head, its backward, the encoder's weight gradient) from bf16 MFMAs on
+    // three-way split operands: 1 always, 0 never (the exact-f32 MFMA forms), -1 from the width (SMX_BF16X3_MIN_WORK)
+    int bf16x3 = -1;
   } flags;
   int chunk_first_head = 0;           // first optimiser chunk of the output / label heads (they are last in the table)
   int chunk_first_label = 0;          // first optimiser chunk of the label heads (n_chunks without label heads)
@@ -200,6 +204,7 @@ struct smx_model {
   float* laby_draw[SMX_MAX_LABELS] = {nullptr, nullptr, nullptr, nullptr};
   float* llk_y = nullptr;
   float* slab = nullptr; size_t slab_cap = 0; int max_feat_p = 0;
+  float* bigk_part = nullptr; size_t bigk_floats = 0;   // [SMX_BIGK_MAX_SLICES][Bmax][max_feat_p]: per-slice slabs of smx_bigk.hip (wide panels only)
   // optimiser
   OptChunk* chunks = nullptr; int n_chunks = 0; int chunks_floats = 4096; float* partial = nullptr; float* tensor_norm = nullptr;
   // noise injection

@@ -281,6 +281,11 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   m->slab_cap = (size_t)(64 * 3 + SMX_MAX_LABELS + 1) * B * m->max_feat_p;
   const size_t lat_ld = (m->stochastic ? 2 : 1) * (size_t)m->Dp;
   const size_t ldp = (size_t)m->k * m->Gp;
+  // wide panels: scratch for the per-slice slabs of the products that contract over the gene axis (smx_bigk.hip)
+  if (m->Gp >= 4096) {
+    m->bigk_floats = (size_t)SMX_BIGK_MAX_SLICES * B * m->max_feat_p;
+    if ((rc = dmalloc(&m->bigk_part, m->bigk_floats))) return fail(rc);
+  }
   if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
       (rc = dmalloc(&m->z, B * m->Dp)) || (rc = dmalloc(&m->noise_eps, B * m->Dp)) || (rc = dmalloc(&m->sig, B * m->Dp)) || (rc = dmalloc(&m->eps, B * m->Dp)) ||
       (rc = dmalloc(&m->kl, B)) || (rc = dmalloc(&m->P, B * ldp)) || (rc = dmalloc(&m->dP, B * ldp)) ||
@@ -354,6 +359,7 @@ int smx_model_destroy(smx_model* m) {
   if (m->st) hipStreamSynchronize(m->st);
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
   for (auto& ev : m->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+  if (m->bigk_part) hipFree(m->bigk_part);
   if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
   m->comm = nullptr;
   m->local.reset();
@@ -496,9 +502,9 @@ int smx_set_flag(smx_model* m, const char* name, int value) {
   int* f = n == "head_loss" ? &m->flags.head_loss : n == "front" ? &m->flags.front : n == "bwd_front" ? &m->flags.bwd_front
          : n == "head_bwd" ? &m->flags.head_bwd : n == "wgrad" ? &m->flags.wgrad : n == "scvi_fused" ? &m->flags.scvi_fused
          : n == "twin" ? &m->flags.twin : n == "label_ride" ? &m->flags.label_ride : n == "act_epilogue" ? &m->flags.act_epilogue
-         : n == "stacked_scoring" ? &m->flags.stacked_scoring : nullptr;
-  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue, stacked_scoring)");
-  *f = value ? 1 : 0;
+         : n == "stacked_scoring" ? &m->flags.stacked_scoring : n == "bf16x3" ? &m->flags.bf16x3 : nullptr;
+  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue, stacked_scoring, bf16x3)");
+  *f = (f == &m->flags.bf16x3 && value < 0) ? -1 : (value ? 1 : 0);   // bf16x3: -1 = by the width of the head (the default)
   drop_graphs(m);   // a captured step bakes the launch sequence in
   return SMX_OK;
 }

@@ -115,7 +115,23 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
       in = L.out_buf; ld = L.out_p;
       continue;
     }
-    if (dual) {
+    // wide panel (the bf16 x 3 regime): the first layer's product as one workgroup per K slice + a reduce launch (smx_bigk.hip)
+    bool bigk = false;
+    BigKArgs bk;
+    if (i == 0 && in_is_x && !dual && !with_front && m->bigk_part && !g.xf.drop_p && !g.xf.inj_mask && L.out_p <= 128 &&
+        (m->flags.bf16x3 < 0 ? use_bf16x3((long)ps.B * m->Gp * m->k) : m->flags.bf16x3 != 0) && getenv("SMX_NO_BIGK") == nullptr) {
+      bk.A = in; bk.lda = ld; bk.a_u16 = ps.x_u16; bk.log1p = m->cfg.log_norm; bk.rows = ps.xrows;
+      bk.Bm = P_(m, L.tW); bk.ldb = tw.ld; bk.b_kmajor = 1;
+      bk.M = ps.B; bk.N = L.out_p; bk.K = L.in_p; bk.ldc = L.out_p; bk.slab_stride = (long)ps.B * L.out_p;
+      bk.part = m->bigk_part; bk.out = m->slab;
+      bk.n_slices = bigk_slices(bk.K, SMX_BIGK_MAX_SLICES, &bk.k_chunk);
+      bigk = bk.log1p && bigk_supported(bk) && (size_t)bk.n_slices * (size_t)bk.slab_stride <= m->bigk_floats;
+    }
+    if (bigk) {
+      Timed t(m, label0);
+      SMX_CHECK(launch_bigk(m->st, bk));
+      eff = 1;
+    } else if (dual) {
       Timed t(m, label0);
       SMX_CHECK(launch_gemm_dual(m->st, g, g2, &eff));
     } else if (!with_front) {
@@ -537,6 +553,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     hl.X = ps.Xsrc; hl.x_u16 = ps.x_u16; hl.ldx = m->Gp; hl.rows = ps.xrows;
     hl.dP = m->dP; hl.ldp = ldp; hl.plane_stride = m->Gp; hl.llk_part = m->llk_part;
     hl.B = ps.B; hl.G = m->G; hl.Gp = m->Gp; hl.Hp = dL.out_p; hl.likelihood = c.likelihood; hl.grad_scale = -inv_gb;
+    hl.bf16x3 = m->flags.bf16x3 < 0 ? (use_bf16x3((long)ps.B * m->Gp * m->k) ? 1 : 0) : m->flags.bf16x3;
     n_llk_chunks = head_loss_chunks(m->Gp);
     if (!m->capturing && m->timing_label == "out_head_product") {
       // timing mode: the product alone (P stored, no counts, no likelihood) -- what the fused kernel's time is
@@ -765,6 +782,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
       }
     }
     hb.B = ps.B; hb.Hp = dL.out_p; hb.Gp = m->Gp; hb.n_planes = m->k;
+    hb.bf16x3 = m->flags.bf16x3 < 0 ? (use_bf16x3((long)ps.B * m->Gp * m->k) ? 1 : 0) : m->flags.bf16x3;
     hb.n_slices = head_bwd_slices(ldp, ldp <= 8192 ? 16 : 32, &hb.k_chunk);
     hb.slab = m->slab; hb.slab_stride = dd_stride;
     SMX_REQUIRE((size_t)hb.n_slices * (size_t)dd_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
@@ -789,7 +807,23 @@ int backward_pass(smx_model* m, const Pass& ps) {
       }
     }
     Timed t(m, "gemm_out_bwd");
-    SMX_CHECK(launch_out_head_bwd(m->st, hb));
+    // a wide head (the bf16 x 3 regime): d d = dP W^T (K = every gene of every plane) as one workgroup per K slice + a reduce
+    // launch (smx_bigk.hip) -- ONE slab for the BatchNorm-backward launch; d W / d b stay with the 32 x 32-tile kernel
+    bool dd_bigk = false;
+    if (hb.bf16x3 && !hb.sep && hb.n_extra == 0 && m->bigk_part && dL.out_p <= 128 && getenv("SMX_NO_BIGK") == nullptr) {
+      BigKArgs bk;
+      bk.A = dparams; bk.lda = ldp; bk.Bm = P_(m, m->t_outW[0]); bk.ldb = tw.ld; bk.b_kmajor = 0;
+      bk.M = ps.B; bk.N = dL.out_p; bk.K = (int)ldp; bk.ldc = dL.out_p; bk.slab_stride = dd_stride;
+      bk.part = m->bigk_part; bk.out = m->slab;
+      bk.n_slices = bigk_slices(bk.K, SMX_BIGK_MAX_SLICES, &bk.k_chunk);
+      if (bigk_supported(bk) && (size_t)bk.n_slices * (size_t)bk.slab_stride <= m->bigk_floats) {
+        SMX_CHECK(launch_bigk(m->st, bk));
+        dd_bigk = true;
+        n_slabs = 1;
+      }
+    }
+    hb.skip_dd = dd_bigk ? 1 : 0;
+    if (!(hb.skip_dw && hb.skip_dd)) SMX_CHECK(launch_out_head_bwd(m->st, hb));
   }
   {
     // weight gradient and input gradient of every head read the same dP and are independent:
@@ -957,7 +991,8 @@ int backward_pass(smx_model* m, const Pass& ps) {
     // (SMX_NO_WGRAD=1, input dropout or an unsupported shape: the LDS-tiled products)
     bool wg_ok = m->flags.wgrad && tail.size() <= SMX_GROUP_MAX;
     for (const GemmArgs& g : tail) wg_ok = wg_ok && wgrad_supported(g, ps.B);
-    if (wg_ok) SMX_CHECK(launch_wgrad_group(m->st, tail.data(), (int)tail.size(), ps.B));
+    const int b3 = m->flags.bf16x3 < 0 ? (use_bf16x3((long)ps.B * m->Gp * m->k) ? 1 : 0) : m->flags.bf16x3;
+    if (wg_ok) SMX_CHECK(launch_wgrad_group(m->st, tail.data(), (int)tail.size(), ps.B, b3));
     else if (tail.size() == 1) SMX_CHECK(launch_gemm(m->st, tail[0]));
     else
       for (size_t q = 0; q < tail.size(); q += SMX_GROUP_MAX)

@@ -51,6 +51,10 @@ CASES = {
     "scvi_deep": dict(model="scvi", n_genes=120, likelihood="nbd", enc_units=(64, 40), dec_units=(48,), latent_dim=8,
                       encl_units=(32, 24)),
     "paper_shape": dict(model="vae", n_genes=1998, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=32),
+    # wide panels (>= 4096 padded genes): with flag bf16x3 the products that contract over the gene axis run as one workgroup
+    # per K slice + a reduce launch (smx_bigk.hip), d W of a 128-wide head as the gene-tile-owner kernel (smx_wide.hip)
+    "wide_panel_64": dict(model="vae", n_genes=4200, likelihood="zinb", enc_units=(64,), dec_units=(64,), latent_dim=10),
+    "wide_panel_128": dict(model="vae", n_genes=4500, likelihood="nb", enc_units=(128,), dec_units=(128,), latent_dim=16),
 }
 
 
@@ -701,3 +705,36 @@ def test_predict_packs_every_label_plane(Engine, labels, S):
         assert np.isfinite(a).all() and cmp(a[s][b0:b0 + 40], b), (j, s, b0)
     assert np.array_equal(got["z_mean"][b0:b0 + 40], one["z_mean"])
   e.close()
+
+
+@pytest.mark.parametrize("batch", [128, 100])
+@pytest.mark.parametrize("name", ["vae_zinb", "vae_nb_nobn", "vae_zinbd", "sisua", "scvi_zinbd", "scvi_nbd", "paper_shape", "wide_panel_64",
+                                  "wide_panel_128"])
+def test_bf16x3_products_match_oracle(Engine, name, batch):
+  """The output head's training products (fused head, both products of its backward -- the scvi form with separate plane
+  tensors included --, the first layer's weight gradient) formed from bf16 MFMAs on operands split three ways in registers
+  (smx_device.h: six of the nine cross products; what is dropped is below one f32 rounding of a product): same 1e-4 bar on
+  the ELBO scalars and on EVERY gradient as the exact-f32 MFMA forms, full and ragged minibatches; and the two forms agree
+  with each other far inside that bar."""
+  spec, cfg, x, ys, lib, mask = _problem(CASES[name])
+  params = perturbed_params(spec)
+  rows = np.random.default_rng(2).choice(x.shape[0], size=batch, replace=False).astype(np.int32)
+  got = {}
+  for b3 in (1, 0):
+    e = Engine(cfg, max_batch=128, init=False)
+    e.set_params(params)
+    e.upload(x, ys, lib, mask, cell_id_base=1000)
+    e.set_flag("bf16x3", bool(b3))
+    m = e.train_step(rows)
+    got[b3] = (m, e.get_params(which=1))
+    e.close()
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  res = _oracle_step(spec, params, bn, opt, x, ys, lib, mask, rows, 0, cell_base=1000)
+  m, grads = got[1]
+  for key in ("loss", "nllk_x", "kl"):
+    assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
+  worst = grad_errors(grads, res["grads"])
+  assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  between = grad_errors(grads, got[0][1])
+  assert max(between.values()) < 2e-5, sorted(between.items(), key=lambda kv: -kv[1])[:3]
+  assert abs(m["loss"] - got[0][0]["loss"]) <= 2e-6 * abs(m["loss"])
