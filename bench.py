@@ -230,10 +230,15 @@ def main():
   eng.synchronize()
   cp.barrier()
   t0 = time.perf_counter()
-  m = eng.train_steps(order[args.warmup * batch:], args.steps, batch, graph=use_graph, metrics=True)
+  eng.train_steps(order[args.warmup * batch:], args.steps, batch, graph=use_graph)   # K steps queued by ONE library call, no host sync between them
   eng.synchronize()
   cp.barrier()
   dt = cp.max(time.perf_counter() - t0)
+  # the ELBO scalars of every timed step stayed on the device (smx_metrics_history): read after the clock has stopped
+  hist = eng.metrics_history(args.steps)
+  m = {k: float(v[-1]) for k, v in hist.items()}
+  if not np.isfinite(hist["loss"]).all():
+    sys.exit("bench: non-finite loss in the timed steps")
 
   # ---- roofline: every figure is ONE kernel's algorithmic bytes over that kernel's OWN duration -----------------
   # HIP events on the model's stream; the kernel is launched LOSS_REPEAT times back to back inside one event pair and the

@@ -40,7 +40,8 @@ typedef enum {
 /* Model families: sisua/models/vae.py:15-16 (VAE), dca.py:13-28, scvi.py:20-171,
  * vae.py:19-44 (SISUA = VAE + label heads; MISA = SISUA with mixture label heads, vae.py:47-98). */
 /* SMX_MODEL_SCALE: scale.py:13-49 (SCALE, Xiong et al. 2019): VAE whose prior over z is a trainable mixture of
- * n_components diagonal Gaussians, KL term by one-sample Monte Carlo (`analytic=False`). */
+ * n_components diagonal Gaussians, KL term by one-sample Monte Carlo (`analytic=False`).  With label heads (n_labels > 0) it
+ * is SCALAR (scale.py:52-59: SCALE + SISUA's semi-supervised heads). */
 /* SMX_MODEL_FVAE: fvae.py:9-18 (FVAE / SemiFVAE; Kim & Mnih 2018): VAE + a discriminator on z whose logit estimates the
  * total correlation; the VAE's tensors follow -ELBO + gamma TC, the discriminator's tensors its own classification loss
  * (z against z with every dimension permuted over the minibatch), both in the same step.  n_labels = 1 with
@@ -49,7 +50,9 @@ typedef enum { SMX_MODEL_VAE = 0, SMX_MODEL_DCA = 1, SMX_MODEL_SCVI = 2, SMX_MOD
                SMX_MODEL_FVAE = 5 } smx_model_kind;
 /* Count likelihoods selected by RVmeta.posterior (configs/base.yaml:32-40,
  * data/_single_cell_base.py:518-533). */
-typedef enum { SMX_LLK_NB = 0, SMX_LLK_ZINB = 1, SMX_LLK_NBD = 2, SMX_LLK_ZINBD = 3 } smx_likelihood;
+/* SMX_LLK_MSE: RVmeta(dim, 'mse') (the reference's tests/test_singlecell_models.py:82-91, 97-100): a deterministic output, ONE
+ * parameter plane (the mean), log p(x) := -mean_g (x - mean)^2 -- exactly minus tf.losses.mse.  No marginal-likelihood scoring. */
+typedef enum { SMX_LLK_NB = 0, SMX_LLK_ZINB = 1, SMX_LLK_NBD = 2, SMX_LLK_ZINBD = 3, SMX_LLK_MSE = 4 } smx_likelihood;
 /* Label heads of SISUA (vae.py:19-44): NB (ADT counts), one-hot categorical (cell types); of MISA (vae.py:47-98): every
  * label dimension a mixture of label_components (2..4) negative binomials. */
 typedef enum { SMX_LABEL_NB = 0, SMX_LABEL_ONEHOT = 1, SMX_LABEL_MIXNB = 2 } smx_label_likelihood;

@@ -55,6 +55,7 @@ STREAM_EPS_L = 65
 STREAM_PERMUTE = 66        # fvae: uniforms whose per-dimension ranks are the permute_dims permutations
 
 LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
+OUTPUT_POSTERIORS = LIKELIHOODS + ("mse",)   # + the deterministic output RVmeta(dim, 'mse') of the reference's tests (one plane: the mean)
 LABEL_LIKELIHOODS = ("nb", "onehot", "mixnb2", "mixnb3", "mixnb4")   # mixnbC: MISA's C-component mixture of NB per label
 
 
@@ -65,7 +66,7 @@ def label_planes(llk: str) -> int:
 
 
 def n_params_per_gene(likelihood: str) -> int:
-  return {"nb": 2, "zinb": 3, "nbd": 2, "zinbd": 3}[likelihood]
+  return {"nb": 2, "zinb": 3, "nbd": 2, "zinbd": 3, "mse": 1}[likelihood]
 
 
 # --------------------------------------------------------------------------
@@ -113,7 +114,7 @@ class Spec:
   def __post_init__(self):
     assert self.model in ("vae", "dca", "scvi", "sisua", "scale", "fvae"), self.model
     assert 1 <= self.n_components <= 32
-    assert self.likelihood in LIKELIHOODS, self.likelihood
+    assert self.likelihood in OUTPUT_POSTERIORS, self.likelihood
     if self.model == "scvi":
       assert self.likelihood in ("nbd", "zinbd")  # scvi.py:50-52
     for _, llk in self.labels:
@@ -121,7 +122,7 @@ class Spec:
     if self.model == "fvae":
       assert len(self.labels) <= 1 and all(llk == "onehot" for _, llk in self.labels), "SemiFVAE: one 'onehot' label variable"
       assert self.disc_layers >= 1 and self.disc_units >= 1 and 0.0 <= self.disc_leak < 1.0
-    elif self.model != "sisua":
+    elif self.model not in ("sisua", "scale"):   # ('scale' with label heads = SCALAR, sisua/models/scale.py:52-59)
       assert len(self.labels) == 0
 
   @property
@@ -390,6 +391,11 @@ def count_llk(x, p: Sequence[np.ndarray], likelihood: str, direct: bool = False)
   """Elementwise log p(x | params) and its gradients wrt each raw parameter
   plane.  `direct=True` (SCVI): planes are (mean, dispersion[, gate]) already
   activated."""
+  if likelihood == "mse":
+    # RVmeta(dim, 'mse') (tests/test_singlecell_models.py:82-91 of the reference: a VectorDeterministic whose
+    # -log_prob(x) IS tf.losses.mse(x, mean) = mean over the last axis of (x - mean)^2): one plane, the mean
+    G = np.shape(x)[-1]
+    return -((x - p[0]) ** 2) / G, [2.0 * (x - p[0]) / G]
   ell, d0, d1 = _nb_core(x, p, likelihood, direct)
   if likelihood in ("nb", "nbd"):
     return ell, [d0, d1]

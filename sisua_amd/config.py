@@ -14,6 +14,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
+OUTPUT_POSTERIORS = LIKELIHOODS + ("mse",)   # 'mse': deterministic output, -log_prob(x) = mean squared error (tests/test_singlecell_models.py:82-91)
 
 
 def label_planes(llk: str) -> int:
@@ -44,7 +45,7 @@ class RVmeta:
 
   @property
   def is_deterministic(self):
-    return self.posterior in ("relu", "linear", "identity")
+    return self.posterior in ("relu", "linear", "identity", "mse")
 
   def copy(self):
     return dataclasses.replace(self, kwargs=dict(self.kwargs))
@@ -108,7 +109,7 @@ class ModelConfig:
 
   @property
   def k(self) -> int:
-    return 3 if self.likelihood in ("zinb", "zinbd") else 2
+    return 1 if self.likelihood == "mse" else 3 if self.likelihood in ("zinb", "zinbd") else 2
 
   @property
   def stochastic(self) -> bool:

@@ -108,6 +108,7 @@ struct LossArgs {
   int B = 0, G = 0, Gp = 0;
   float grad_scale = 1.f;                 // d loss / d llk (= -1/B_global); 1 for the test entry
 };
+inline int llk_planes(int likelihood) { return likelihood == SMX_LLK_MSE ? 1 : (likelihood == SMX_LLK_ZINB || likelihood == SMX_LLK_ZINBD) ? 3 : 2; }
 int loss_chunks(int Gp, int B);   // partial sums per cell written by a launch over B cells
 int loss_chunks_max(int Gp);      // upper bound over every batch size (allocation)
 int launch_count_loss(hipStream_t st, const LossArgs& a);

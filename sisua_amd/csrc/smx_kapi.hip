@@ -7,7 +7,7 @@ extern "C" {
 int smx_k_count_llk(int likelihood, int direct, const float* x, const float* planes, int32_t B, int32_t G, float* llk,
                     float* grads) {
   SMX_REQUIRE(x && planes && llk && B > 0 && G > 0, "bad arguments");
-  const int k = (likelihood == SMX_LLK_ZINB || likelihood == SMX_LLK_ZINBD) ? 3 : 2;
+  const int k = llk_planes(likelihood);
   const int Gp = round_up(G, 32);
   const int nch = loss_chunks(Gp, B);
   float *dX = nullptr, *dPl = nullptr, *dG = nullptr, *dPart = nullptr;

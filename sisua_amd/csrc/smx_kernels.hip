@@ -41,7 +41,8 @@ __device__ inline void vstore(float* p, const float (&v)[VEC]) {
 
 template <int LK, int DIRECT, int BWD, int VEC, int BLOCK = 256, int U16 = 0>   // U16: counts from the compact uint16 store
 __global__ __launch_bounds__(BLOCK) void count_loss_kernel(LossArgs a) {
-  constexpr int K = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
+  constexpr int K = LK == SMX_LLK_MSE ? 1 : (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
+  const float inv_g = 1.f / (float)a.G;   // SMX_LLK_MSE: -log p = mean over the genes of (x - mean)^2
   const int b = blockIdx.y;
   const int g0 = (blockIdx.x * BLOCK + threadIdx.x) * VEC;
   float acc = 0.f;
@@ -58,19 +59,23 @@ __global__ __launch_bounds__(BLOCK) void count_loss_kernel(LossArgs a) {
       vload<VEC>(a.X + src * a.ldx + g0, xs);
     }
     vload<VEC>(pb, a0);
-    vload<VEC>(pb + a.plane_stride, a1);
+    if (K >= 2) vload<VEC>(pb + a.plane_stride, a1);
     if (K == 3) vload<VEC>(pb + 2 * a.plane_stride, a2);
     float r0[VEC], r1[VEC], r2[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       float llk = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
       if (a.likelihood == -1) {  // diagnostic: same traffic, no arithmetic
-        d0 = a0[e] + xs[e]; d1 = a1[e]; d2 = a2[e]; acc += d0;
+        d0 = a0[e] + xs[e]; d1 = K >= 2 ? a1[e] : 0.f; d2 = K == 3 ? a2[e] : 0.f; acc += d0;
       } else if (a.likelihood == -2) {  // diagnostic: every count treated as 0 (no lgamma work)
-        count_elem<LK, DIRECT>(0.f, a0[e], a1[e], K == 3 ? a2[e] : 0.f, llk, d0, d1, d2);
+        count_elem<LK == SMX_LLK_MSE ? SMX_LLK_NB : LK, DIRECT>(0.f, a0[e], K >= 2 ? a1[e] : 0.f, K == 3 ? a2[e] : 0.f, llk, d0, d1, d2);
         acc += llk + xs[e];
       } else if (g0 + e < a.G) {
-        count_elem<LK, DIRECT>(xs[e], a0[e], a1[e], K == 3 ? a2[e] : 0.f, llk, d0, d1, d2);
+        if (LK == SMX_LLK_MSE) {
+          const float df = xs[e] - a0[e];
+          llk = -(df * df) * inv_g; d0 = 2.f * df * inv_g;
+        } else
+        count_elem<LK == SMX_LLK_MSE ? SMX_LLK_NB : LK, DIRECT>(xs[e], a0[e], K >= 2 ? a1[e] : 0.f, K == 3 ? a2[e] : 0.f, llk, d0, d1, d2);
         acc += llk;
       }
       r0[e] = d0 * a.grad_scale; r1[e] = d1 * a.grad_scale; r2[e] = d2 * a.grad_scale;
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(BLOCK) void count_loss_kernel(LossArgs a) {
     if (BWD) {
       float* db = a.dP + (long)b * a.ldp + g0;
       vstore<VEC>(db, r0);
-      vstore<VEC>(db + a.plane_stride, r1);
+      if (K >= 2) vstore<VEC>(db + a.plane_stride, r1);
       if (K == 3) vstore<VEC>(db + 2 * a.plane_stride, r2);
     }
   }
@@ -142,6 +147,7 @@ int launch_count_loss(hipStream_t st, const LossArgs& a) {
     case SMX_LLK_ZINBD:
       if (a.direct) launch_loss_t<SMX_LLK_ZINBD, 1>(st, a, grid); else launch_loss_t<SMX_LLK_ZINBD, 0>(st, a, grid);
       break;
+    case SMX_LLK_MSE: launch_loss_t<SMX_LLK_MSE, 0>(st, a, grid); break;
     default: set_error("count_loss: unknown likelihood"); return SMX_ERR_INVALID;
   }
   SMX_HIP(hipGetLastError());

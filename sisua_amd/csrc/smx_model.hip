@@ -152,9 +152,11 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
       SMX_REQUIRE(cfg->label_llk[0] == SMX_LABEL_ONEHOT && cfg->label_dim[0] >= 2 && cfg->label_dim[0] <= 32, "fvae: the label variable is one-hot with 2..32 classes");
   }
   if (cfg->model == SMX_MODEL_SCALE) SMX_REQUIRE(cfg->n_components >= 2 && cfg->n_components <= 32, "scale: 2..32 mixture components");
-  SMX_REQUIRE(cfg->likelihood >= SMX_LLK_NB && cfg->likelihood <= SMX_LLK_ZINBD, "unknown likelihood");
+  SMX_REQUIRE(cfg->likelihood >= SMX_LLK_NB && cfg->likelihood <= SMX_LLK_MSE, "unknown likelihood");
   SMX_REQUIRE(cfg->n_labels >= 0 && cfg->n_labels <= SMX_MAX_LABELS, "too many label heads");
-  SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->model == SMX_MODEL_FVAE || cfg->n_labels == 0, "label heads need model = SISUA");
+  // (SCALE with label heads = SCALAR, sisua/models/scale.py:52-59: the mixture prior of SCALE under SISUA's semi-supervised heads)
+  SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->model == SMX_MODEL_FVAE || cfg->model == SMX_MODEL_SCALE || cfg->n_labels == 0,
+              "label heads need model = SISUA, SCALE (SCALAR) or FVAE (SemiFVAE)");
   if (cfg->model == SMX_MODEL_SCVI) {
     SMX_REQUIRE(cfg->likelihood == SMX_LLK_NBD || cfg->likelihood == SMX_LLK_ZINBD, "scvi supports nbd / zinbd only");
     SMX_REQUIRE(cfg->n_encl >= 1 && cfg->n_encl <= SMX_MAX_LAYERS, "scvi needs a library encoder");
@@ -166,7 +168,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   smx_model* m = new smx_model();
   m->cfg = *cfg; m->device = dev;
   m->G = cfg->n_genes; m->Gp = round_up(m->G, 32); m->D = cfg->latent_dim; m->Dp = round_up(m->D, 32);
-  m->k = (cfg->likelihood == SMX_LLK_ZINB || cfg->likelihood == SMX_LLK_ZINBD) ? 3 : 2;
+  m->k = llk_planes(cfg->likelihood);
   m->stochastic = cfg->model != SMX_MODEL_DCA; m->scvi = cfg->model == SMX_MODEL_SCVI; m->scale = cfg->model == SMX_MODEL_SCALE;
   m->fvae = cfg->model == SMX_MODEL_FVAE; m->n_heads = m->fvae ? 0 : cfg->n_labels;
   m->Bmax = cfg->max_batch;

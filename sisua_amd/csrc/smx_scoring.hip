@@ -190,6 +190,7 @@ extern "C" {
 int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library, int32_t batch,
                      int32_t n_samples, float* mllk, float* llk_mean) {
   SMX_REQUIRE(m && mllk && n_samples > 0, "bad arguments");
+  SMX_REQUIRE(m->cfg.likelihood != SMX_LLK_MSE, "the 'mse' output is not a normalised density: no marginal likelihood");
   Pass ps;
   SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, 0, 0));
   const bool stacked = stacked_scoring_ok(m);
@@ -237,6 +238,7 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
 int smx_score_llk(smx_model* m, const int32_t* row_ids, const float* host_x, const float* host_library,
                   const float* const* targets, int32_t n_targets, int32_t batch, int32_t n_samples, float* out) {
   SMX_REQUIRE(m && out && n_samples > 0 && n_targets >= 1 && n_targets <= 4, "bad arguments");
+  SMX_REQUIRE(m->cfg.likelihood != SMX_LLK_MSE, "the 'mse' output is not a normalised density: no posterior-predictive scores");
   if (!m->stochastic) n_samples = 1;   // (deterministic latent: every draw decodes to the same parameters)
   Pass ps;
   SMX_CHECK(setup_pass(m, ps, row_ids, host_x, host_library, batch, 0, 0));

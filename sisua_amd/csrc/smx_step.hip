@@ -376,7 +376,7 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
 // dP in ONE wide kernel, P never materialised (smx_headloss.hip).  SMX_NO_HEAD_LOSS=1 keeps the product / loss
 // kernel pair (what eval, predict and the scoring paths always use).
 bool use_head_loss(const smx_model* m, int B) {
-  if (!m->flags.head_loss || m->scvi || m->dec.empty()) return false;
+  if (!m->flags.head_loss || m->scvi || m->dec.empty() || m->k < 2) return false;   // (k = 1: the 'mse' output, product + loss kernel pair)
   return head_loss_supported(B, m->dec.back().out_p, m->Gp);
 }
 
@@ -584,7 +584,8 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   }
   if (m->fvae) SMX_CHECK(factor_forward(m, ps, backward));
   MetricsArgs me;
-  me.llk_part = m->llk_part; me.n_chunks = n_llk_chunks; me.lgx1 = ps.lgx1; me.rows = ps.rows;
+  me.llk_part = m->llk_part; me.n_chunks = n_llk_chunks; me.rows = ps.rows;
+  me.lgx1 = c.likelihood == SMX_LLK_MSE ? nullptr : ps.lgx1;   // (the count likelihoods' data-only constant sum_g lgamma(x + 1))
   me.llk_y = c.n_labels ? m->llk_y : nullptr;
   if (m->fvae) { me.tc = m->tc_cell; me.dl = m->dl_cell; me.gamma = c.gamma; }
   me.kl = m->stochastic ? m->kl : nullptr; me.kl_l = m->scvi ? m->kl_l : nullptr;
@@ -766,7 +767,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
   // count heads with raw planes: both products of the output head in one launch of the wide direct-operand kernel
   // (smx_headbwd.hip); SMX_NO_HEAD_BWD=1 or scvi: the grouped LDS-tiled products below
   // (scvi: the planes are separate head tensors -- the kernel's SEP form)
-  const bool hbwd = m->flags.head_bwd && head_bwd_supported(ps.B, dL.out_p, m->Gp) && (!m->scvi || (m->k >= 2 && m->k <= 3));
+  const bool hbwd = m->flags.head_bwd && head_bwd_supported(ps.B, dL.out_p, m->Gp) && m->k >= 2 && m->k <= 3;
   if (hbwd) {
     const TensorInfo& tw = m->tensors[m->t_outW[0]];
     HeadBwdArgs hb;

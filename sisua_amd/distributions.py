@@ -125,6 +125,21 @@ class Deterministic(Distribution):
     return np.where(np.all(np.asarray(x) == self.loc, axis=-1), 0.0, -np.inf)
 
 
+class VectorDeterministic(Deterministic):
+  """The output of RVmeta(dim, 'mse') (the reference's tests/test_singlecell_models.py:82-91): a point mass at `loc` over the
+  last axis whose log_prob is MINUS THE MEAN SQUARED ERROR -- the identity the reference's test pins exactly,
+  `-dist.log_prob(z) == tf.losses.mse(z, y.mean())` = mean over the last axis of the squared difference, evaluated in the
+  arguments' own precision (float32 for float32 inputs, as TensorFlow does)."""
+
+  def __init__(self, loc, name="VectorDeterministic"):
+    super().__init__(loc, name)
+
+  def log_prob(self, x):
+    x = np.asarray(x)
+    d = x - self.loc.astype(np.result_type(x, self.loc), copy=False)
+    return -np.mean(d * d, axis=-1)
+
+
 class NegativeBinomial(Distribution):
   """TFP convention: total_count r, logits l; mean = r exp(l)."""
 
@@ -367,6 +382,8 @@ def count_distribution(likelihood: str, planes, name: str, activated: bool) -> D
   """Build the output distribution from the parameter planes of smx_forward.
   nb/zinb planes: (log total_count, logits[, gate]); nbd/zinbd: pre-activation
   (softplus mean, softplus1 dispersion) unless `activated` (scvi feeds mean/disp)."""
+  if likelihood == "mse":   # one plane: the mean (RVmeta(dim, 'mse'): deterministic output)
+    return VectorDeterministic(planes[0], name=name)
   if likelihood in ("nb", "zinb"):
     base = NegativeBinomial(logits=planes[1], name="NegativeBinomial", log_total_count=planes[0])
   else:

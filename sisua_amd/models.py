@@ -26,7 +26,7 @@ from sisua_amd.data import BatchDataset, SingleCellOMIC, library_matrix
 from sisua_amd.engine import Engine
 
 __all__ = ["SingleCellModel", "VAE", "SISUA", "MISA", "SCALE", "SCVI", "DeepCountAutoencoder", "NetConf", "RVmeta", "get_model",
-           "get_all_models", "load_model"]
+           "get_all_models", "load_model", "SCALAR"]
 
 _OMIC_ORDER = ["transcriptomic", "proteomic", "celltype", "disease", "progenitor", "chromatin"]
 
@@ -95,8 +95,8 @@ class SingleCellModel:
                       name=name, **kwargs)
     self.init_args = frame_args
     outs = [o.copy() for o in _flatten(outputs)]
-    if not outs or outs[0].posterior not in ("nb", "zinb", "nbd", "zinbd"):
-      raise ValueError("the first output must be a count distribution: 'nb', 'zinb', 'nbd' or 'zinbd', "
+    if not outs or outs[0].posterior not in ("nb", "zinb", "nbd", "zinbd", "mse"):
+      raise ValueError("the first output must be a count distribution ('nb', 'zinb', 'nbd', 'zinbd') or the deterministic 'mse', "
                        f"given: {outs[0].posterior if outs else None}")
     self._outputs = outs
     self._labels = [l.copy() for l in _flatten(kwargs.pop("labels", None))]
@@ -787,6 +787,18 @@ class SCALE(SingleCellModel):
     super().__init__(outputs=outputs, latents=lat, **kwargs)
     self.init_args = dict(outputs=outputs, latents=latents, n_components=n_components, covariance=covariance,
                           tie_mixtures=tie_mixtures, tie_loc=tie_loc, tie_scale=tie_scale, **kwargs)
+
+
+class SCALAR(SCALE):
+  r"""SCALE with semi-supervised extension - "Single-Cell ATAC-seq analysis via Latent and ADT Recombination"
+  (sisua/models/scale.py:52-59: `class SCALAR(SCALE, SISUA)`): SCALE's trainable mixture prior over z with SISUA's label
+  heads on the decoder output (`labels`: NB / one-hot posteriors weighted by `alpha` and the per-cell label mask)."""
+  _kind = "scale"
+
+  def __init__(self, outputs, labels, **kwargs):
+    super().__init__(outputs=outputs, labels=labels, **kwargs)
+    self.init_args = dict(self.init_args, labels=labels)
+    self._n_inputs = 1
 
 
 class FVAE(SingleCellModel):

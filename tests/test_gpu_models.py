@@ -360,6 +360,57 @@ def test_scale_fit_predict(api, tmp_path):
     api.SCALE(outputs=sco.get_rv("transcriptomic"), covariance="full")
 
 
+def test_unsupervised_mse_fit_predict(api):
+  """The reference's test_unsupervised_fit_predict (tests/test_singlecell_models.py:93-114): a DeepCountAutoencoder with
+  outputs=RVmeta(dim, posterior='mse'), latent_dim 10: the loss falls, predict(sample_shape=2) returns VectorDeterministic
+  outputs AND latents with the draw axis in front, from a dataset and from a raw matrix; and -log_prob is the mean squared
+  error of the prediction exactly."""
+  from sisua_amd import distributions as D
+  sco = _sco(with_labels=False)
+  train, test = sco.split(0.8)
+  dca = api.DeepCountAutoencoder(outputs=api.RVmeta(sco.n_vars if hasattr(sco, "n_vars") else sco.numpy().shape[1], posterior="mse"),
+                                 latents=api.RVmeta(10, "relu", True, name="Latents"))
+  assert not dca.is_zero_inflated
+  dca.fit(train.create_dataset(batch_size=64, drop_remainder=True), valid=test.create_dataset(batch_size=60, drop_remainder=True),
+          metadata=sco, epochs=10, valid_freq=9, learning_rate=2e-3)
+  # (the squared error of a few large counts dominates a minibatch's loss: the epoch means fall overall, not in every move)
+  h = np.asarray(dca.train_history["loss"])
+  assert h[-3:].mean() < 0.8 * h[:3].mean() and np.mean(np.diff(h) < 0) >= 0.6, h
+  assert len(dca.valid_history["val_loss"]) >= 2 and dca.valid_history["val_loss"][-1] < dca.valid_history["val_loss"][0]
+  pX, qZ = dca.predict(test.create_dataset(batch_size=50, shuffle=0), sample_shape=2, verbose=False)
+  assert isinstance(pX, D.VectorDeterministic) and pX.batch_shape[0] == 2 and pX.batch_shape[1] == test.n_obs
+  assert isinstance(qZ, D.Deterministic)
+  X = sco.numpy()[:128]
+  pX, qZ = dca.predict(X, sample_shape=2, verbose=False)
+  assert isinstance(pX, D.VectorDeterministic) and pX.batch_shape[0] == 2 and pX.batch_shape[1] == X.shape[0]
+  d1 = -pX.log_prob(X)[0]
+  assert np.all(d1 == np.mean(np.square(X - pX.mean()[0]), axis=-1))
+  with pytest.raises(Exception):
+    dca.marginal_log_prob(X[:8], sample_shape=3)          # not a normalised density
+
+
+def test_scalar_fit_predict(api):
+  """SCALAR (sisua/models/scale.py:52-59: `class SCALAR(SCALE, SISUA)`): SCALE's mixture prior with SISUA's semi-supervised
+  label heads -- registry, the reference's warning for a non-mixture latent, fit (both terms are learnt), predict."""
+  from sisua_amd import distributions as D
+  sco = _sco()
+  train, test = sco.split(0.8)
+  assert api.get_model("scalar") is api.SCALAR and issubclass(api.SCALAR, api.SCALE)
+  with pytest.warns(UserWarning, match="mixture distribution"):
+    m = api.SCALAR(outputs=sco.get_rv("transcriptomic"), labels=[sco.get_rv("proteomic")], latents=api.RVmeta(8, "diag", True, "Latents"),
+                   n_components=4, encoder=api.NetConf([32], batchnorm=True, dropout=0.1), decoder=api.NetConf([32], batchnorm=True, dropout=0.1))
+  assert m.is_semi_supervised and m._make_config().model == "scale" and m._make_config().labels == ((9, "nb"),)
+  omics = ["transcriptomic", "proteomic"]
+  m.fit(train.create_dataset(omics, labels_percent=0.5, batch_size=64, drop_remainder=True),
+        valid=test.create_dataset(omics, labels_percent=1.0, batch_size=60, drop_remainder=True), metadata=sco, epochs=12,
+        valid_freq=20, learning_rate=2e-3)
+  hx, hy = np.asarray(m.train_history["nllk_x"]), np.asarray(m.train_history["nllk_y"])
+  assert len(hx) == 12 and hx[-3:].mean() < hx[:3].mean() and hy[-3:].mean() < hy[:3].mean()
+  X, Z = m.predict(test.create_dataset(omics, batch_size=40, shuffle=0), verbose=False)
+  assert isinstance(X, tuple) and X[1].batch_shape == (test.n_obs,) and X[1].event_shape == (9,)
+  assert np.isfinite(X[1].mean()).all() and Z.event_shape == (8,)
+
+
 def test_fvae_fit_predict(api, tmp_path):
   """FVAE / SemiFVAE (sisua/models/fvae.py:9-18): the VAE trains against -ELBO + gamma TC while the discriminator learns
   to tell z from permute_dims(z) in the same step; both objectives are logged; predict / checkpoint as any model."""

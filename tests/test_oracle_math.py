@@ -233,3 +233,25 @@ def test_posterior_llk_against_scipy_nbinom():
   ref = logsumexp(np.stack(per_draw), axis=0) - np.log(S)
   assert np.allclose(got[0, 1], ref, rtol=1e-9, atol=1e-9)
   assert got.shape == (2, 2, 9) and (got[:, 0] != got[:, 1]).any()
+
+
+def test_mse_output_is_minus_the_mean_squared_error_with_its_gradient():
+  """'mse' output of the oracle (RVmeta(dim, 'mse'), tests/test_singlecell_models.py:82-91 of the reference): the per-cell
+  log-likelihood is minus the mean over the genes of the squared error; gradient by central differences; a VAE / DCA step with
+  it runs and its loss is nllk_x (+ KL)."""
+  rng = np.random.default_rng(1)
+  x = rng.poisson(3.0, size=(5, 17)).astype(np.float64)
+  mu = rng.normal(2.0, 1.0, size=(5, 17))
+  ell, (d0,) = so.count_llk(x, [mu], "mse")
+  assert np.allclose(ell.sum(1), -np.mean((x - mu) ** 2, axis=1), rtol=1e-14)
+  e = 1e-6
+  up, _ = so.count_llk(x, [mu + e], "mse")
+  dn, _ = so.count_llk(x, [mu - e], "mse")
+  assert np.allclose((up - dn) / (2 * e), d0, rtol=1e-7, atol=1e-9)
+  for model in ("dca", "vae"):
+    spec = so.Spec(model=model, n_genes=17, likelihood="mse", enc_units=(8,), dec_units=(8,), latent_dim=3)
+    assert spec.k == 1 and dict(so.manifest(spec))["out/W"] == (8, 17)
+    p = so.init_params(spec)
+    r = so.forward_backward(spec, p, so.init_bn_state(spec), x[:4], so.PhiloxNoise(spec.seed, 0, np.arange(4)))
+    assert np.isclose(r["loss"], r["metrics"]["nllk_x"] + r["metrics"]["kl"]) and r["metrics"]["nllk_x"] > 0
+    assert set(r["grads"]) == set(p)

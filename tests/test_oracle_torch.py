@@ -167,6 +167,8 @@ CASES = {
     "misa": dict(model="sisua", n_genes=40, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5,
                  labels=((6, "mixnb2"), (3, "mixnb3")), alpha=10.0),
     "scale": dict(model="scale", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=6),
+    "scalar": dict(model="scale", n_genes=42, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=4,
+                   labels=((6, "nb"), (3, "onehot")), alpha=10.0),   # SCALE + label heads (scale.py:52-59)
     "fvae": dict(model="fvae", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, disc_units=24, disc_layers=3),
     "semifvae": dict(model="fvae", n_genes=40, likelihood="nb", enc_units=(16,), dec_units=(16,), latent_dim=4, disc_units=20, disc_layers=2,
                      labels=((5, "onehot"),), gamma=3.0, alpha=4.0),
