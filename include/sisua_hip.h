@@ -287,6 +287,16 @@ int smx_comm_unique_id(uint8_t id[128]);
 int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]);
 int smx_comm_world(const smx_model* m);
 int smx_comm_rank(const smx_model* m);
+/* The same all-reduce as a hand-written two-shot exchange over peer-mapped buffers instead of RCCL (reduce-scatter
+ * + all-gather of the flat buffer through HIP-IPC-mapped peer memory over xGMI; sums in rank order -- bitwise the same on every
+ * rank): smx_comm_p2p_export allocates this rank's communication region and returns its two 64-byte IPC handles (the flat
+ * gradient buffer | the region); the host gathers the `world` x 128 bytes in rank order (control plane) and hands them to
+ * smx_comm_p2p_init, after which every training step's collective (and SyncBatchNorm's small ones) takes this path -- with or
+ * without an RCCL communicator (call smx_comm_init first when both are wanted).  world <= 8 (one node).  Waits on peers are
+ * bounded (~2 s): smx_comm_p2p_error reports (and clears) a timed-out exchange instead of hanging the device. */
+int smx_comm_p2p_export(smx_model* m, int world, uint8_t handles[128]);
+int smx_comm_p2p_init(smx_model* m, int rank, int world, const uint8_t* all_handles);
+int smx_comm_p2p_error(smx_model* m, int32_t* error);
 /* Which communication library the process is bound to, and the HIP runtime both it and this library run on
  * (RCCL is resolved as the sibling of the loaded libamdhip64: ROCm's, or torch's bundled copy when torch was
  * imported first; SMX_RCCL_PATH overrides).  rccl_version: ncclGetVersion code.  Any output may be NULL. */

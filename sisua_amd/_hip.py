@@ -106,6 +106,9 @@ SIGNATURES = {
     "smx_clear_noise": (C.c_int, [_VP]),
     "smx_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "smx_comm_init": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
+    "smx_comm_p2p_export": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint8)]),
+    "smx_comm_p2p_init": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
+    "smx_comm_p2p_error": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
     "smx_comm_world": (C.c_int, [_VP]),
     "smx_comm_rank": (C.c_int, [_VP]),
     "smx_comm_library": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, _IP]),

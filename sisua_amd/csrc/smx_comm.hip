@@ -79,7 +79,7 @@ __global__ void local_sum_kernel(LocalSrc s, float* dst, size_t count) {
 // data-parallel overlap: two buckets on a communication stream (eager launches only)
 bool dp_active(const smx_model* m) {
   // dp_force: exercise RCCL on a 1-rank communicator (tests); local: the loopback communicator of the tests
-  return (m->comm && (m->world > 1 || m->dp_force)) || (m->local && m->world > 1);
+  return (m->comm && (m->world > 1 || m->dp_force)) || (m->local && m->world > 1) || (m->p2p && m->p2p->error && (m->world > 1 || m->dp_force));
 }
 // Measured on a 1-rank communicator: the cross-stream events of the two-bucket form cost +42 us per step,
 // one all-reduce on the model's own stream +2.6 us.  The overlap only pays when the collective itself is
@@ -111,6 +111,7 @@ int local_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
 }
 int dp_allreduce_buf(smx_model* m, float* buf, size_t count, hipStream_t st) {
   if (m->local) return local_allreduce(m, buf, count, st);
+  if (m->p2p && m->p2p->error) return p2p_allreduce(m, buf, count, st);
   ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclFloat32, ncclSum, m->comm, st);
   if (r != ncclSuccess) {
     set_error(std::string("ncclAllReduce failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
@@ -137,6 +138,7 @@ int smx_comm_unique_id(uint8_t id[128]) {
 static int comm_detach(smx_model* m) {   // leave whatever communicator the model is in
   if (m->st) SMX_HIP(hipStreamSynchronize(m->st));
   if (m->st_comm) SMX_HIP(hipStreamSynchronize(m->st_comm));
+  p2p_release(m);
   if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
   m->comm = nullptr;
   m->local.reset();
@@ -145,7 +147,25 @@ static int comm_detach(smx_model* m) {   // leave whatever communicator the mode
   return SMX_OK;
 }
 
-static int ensure_sync_buf(smx_model* m) {
+}  // extern "C"
+namespace smx {
+// the communication stream of the two-bucket form (SMX_DP_BUCKETS=2: the heads' gradients, 3/4 of the bytes and final after the
+// head's backward launch, are reduced while the rest of the backward pass runs) and the switches read when a communicator is attached
+int ensure_comm_stream(smx_model* m) {
+  m->dp_force = getenv("SMX_FORCE_ALLREDUCE") != nullptr;
+  m->dp_two_buckets = getenv("SMX_DP_BUCKETS") != nullptr && atoi(getenv("SMX_DP_BUCKETS")) == 2;
+  if (!m->st_comm) {
+    if (hipStreamCreateWithFlags(&m->st_comm, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_c1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_c2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_c3, hipEventDisableTiming) != hipSuccess) {
+      set_error("communication stream creation failed");
+      return SMX_ERR_HIP;
+    }
+  }
+  return SMX_OK;
+}
+int ensure_sync_buf(smx_model* m) {
   int wmax = 0;
   for (int w : m->bn_wp) wmax = std::max(wmax, w);
   const size_t need = (size_t)m->world * 2 * (size_t)wmax;
@@ -156,6 +176,8 @@ static int ensure_sync_buf(smx_model* m) {
   m->sync_cap = need;
   return SMX_OK;
 }
+}  // namespace smx
+extern "C" {
 
 int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]) {
   SMX_REQUIRE(m && id && world >= 1 && rank >= 0 && rank < world, "bad rank/world");
@@ -172,17 +194,7 @@ int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]) {
   }
   m->comm = comm;
   m->rank = rank; m->world = world;
-  m->dp_force = getenv("SMX_FORCE_ALLREDUCE") != nullptr;
-  m->dp_two_buckets = getenv("SMX_DP_BUCKETS") != nullptr && atoi(getenv("SMX_DP_BUCKETS")) == 2;
-  if (!m->st_comm) {
-    if (hipStreamCreateWithFlags(&m->st_comm, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_c1, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_c2, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_c3, hipEventDisableTiming) != hipSuccess) {
-      set_error("communication stream creation failed");
-      return SMX_ERR_HIP;
-    }
-  }
+  SMX_CHECK(ensure_comm_stream(m));
   SMX_CHECK(ensure_sync_buf(m));
   drop_graphs(m);
   return SMX_OK;

@@ -113,6 +113,23 @@ struct LocalGroup {
   }
 };
 
+// ---- peer-to-peer all-reduce over IPC-mapped buffers (smx_p2p.hip) ----------------------------------------------------
+#define SMX_P2P_MAX 8
+struct P2PState {
+  int rank = 0, world = 1, pending_world = 0; unsigned epoch = 0; bool owns_region = false;
+  float* grads[SMX_P2P_MAX] = {};          // every rank's flat gradient buffer (own: m->grads; peers: IPC-mapped)
+  void* region_base[SMX_P2P_MAX] = {};     // every rank's communication region
+  unsigned* flags[SMX_P2P_MAX] = {};       // ... its flag block [2][SMX_P2P_MAX]
+  float* staging[SMX_P2P_MAX] = {};        // ... its reduce-scatter output (1 / world of the buffer)
+  float* scratch[SMX_P2P_MAX] = {};        // ... its small-buffer scratch
+  size_t staging_floats = 0, scratch_floats = 0;
+  unsigned* done = nullptr; unsigned* error = nullptr;   // local words behind the flags
+};
+int p2p_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st);
+void p2p_release(smx_model* m);
+int ensure_sync_buf(smx_model* m);
+int ensure_comm_stream(smx_model* m);
+
 }  // namespace smx
 
 struct smx_model {
@@ -212,6 +229,7 @@ struct smx_model {
   // comm
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
   std::shared_ptr<LocalGroup> local; float* local_scratch = nullptr; size_t local_scratch_cap = 0;   // loopback communicator (tests)
+  std::shared_ptr<P2PState> p2p;   // hand-written two-shot all-reduce over IPC-mapped peer buffers (smx_p2p.hip); takes precedence over RCCL
   // SyncBatchNorm (opt-in, smx_comm_set_sync_bn): per BN launch one small all-reduce of per-rank column statistics
   bool sync_bn = false; float* sync_buf = nullptr; size_t sync_cap = 0;
   bool dp_force = false, dp_two_buckets = false;   // SMX_FORCE_ALLREDUCE / SMX_DP_BUCKETS=2, read when the communicator is attached

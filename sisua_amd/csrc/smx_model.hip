@@ -362,6 +362,7 @@ int smx_model_destroy(smx_model* m) {
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
   for (auto& ev : m->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
   if (m->bigk_part) hipFree(m->bigk_part);
+  p2p_release(m);
   if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
   m->comm = nullptr;
   m->local.reset();

@@ -1,0 +1,234 @@
+// smx_p2p.hip -- the data-parallel all-reduce as a hand-written two-shot exchange over peer-mapped buffers (SURVEY.md 5,
+// "Distributed comm backend": the flat-buffer plan; BASELINE.json north_star: "a single all-reduce of gradients over xGMI per
+// step").  The reference has no counterpart (sisua/train.py:20 pins one device).
+//
+// One process per GPU.  Every rank exports two allocations through HIP IPC -- its flat gradient buffer G_r and a small
+// communication region R_r = [flags | staging S_r | scratch X_r] -- and maps its peers' (xGMI: a peer pointer is a load /
+// store target like local memory).  An all-reduce of G over `world` ranks, chunk c = the c-th 1 / world of the buffer:
+//
+//   launch A  signal READY(e) to every peer; wait for every peer's READY(e)        -- all backward passes have written G
+//             S_r = sum over q (rank order) of G_q[chunk r]                        -- reduce-scatter: reads 1/world of every peer
+//             the last workgroup to finish signals REDUCED(e) to every peer
+//   launch B  for every q: wait for REDUCED(e) of q; G_r[chunk q] = S_q            -- all-gather: reads every peer's staging
+//
+// Two launches, two flag rounds, each byte crosses a link twice (in, as 1/world pieces from 7 peers at once: the bandwidth of
+// all links together).  No exit round: S_r is rewritten only in launch A(e + 1), behind READY(e + 1) of every peer -- which a
+// peer raises after its own launch B(e) has completed on its stream; G_r is read by peers only between READY(e) and
+// REDUCED(e).  Summation in rank order on every rank: bitwise the same result everywhere, run to run.
+// Flags are monotonic epochs written with system-scope release stores and polled with system-scope acquire loads; every wait
+// is BOUNDED (a peer that died must not hang the device: after ~2 s the wait gives up and raises an error word the host
+// reads at the next synchronising call).  Buffers other than G (SyncBatchNorm's statistics) take the same path through X_r.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "smx_model.h"
+
+namespace smx {
+
+struct P2PArgs {
+  const float* g[SMX_P2P_MAX];       // every rank's buffer to reduce (own: local pointer), same length
+  float* s[SMX_P2P_MAX];             // every rank's staging (own: local)
+  unsigned* flags[SMX_P2P_MAX];      // every rank's flag block [2][SMX_P2P_MAX] (READY | REDUCED by source rank), own: local
+  float* out;                        // where the sum goes (== g[rank] for the in-place form)
+  unsigned* done;                    // local: workgroups of launch A that have finished
+  unsigned* error;                   // local: non-zero after a timed-out wait
+  long count, chunk;                 // floats in all / per rank (chunk a multiple of 4)
+  int rank, world; unsigned epoch;
+};
+
+__device__ inline bool wait_flag(const unsigned* f, unsigned epoch, unsigned* error) {
+  const long long t0 = wall_clock64();   // 100 MHz on gfx9: 2 s = 2e8 ticks
+  while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > 200000000LL) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void p2p_reduce_scatter_kernel(P2PArgs a) {
+  __shared__ int ok_s;
+  if (threadIdx.x < (unsigned)a.world) {
+    const int q = threadIdx.x;
+    if (blockIdx.x == 0 && q != a.rank)   // READY(e): "my G is final" into peer q's block, slot [0][rank]
+      __hip_atomic_store(a.flags[q] + a.rank, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (threadIdx.x == 0) ok_s = 1;
+  __syncthreads();
+  if (threadIdx.x < (unsigned)a.world && (int)threadIdx.x != a.rank)
+    if (!wait_flag(a.flags[a.rank] + threadIdx.x, a.epoch, a.error)) ok_s = 0;
+  __syncthreads();
+  if (ok_s) {
+    const long base = (long)a.rank * a.chunk;
+    const long n4 = std::max<long>(0, std::min(a.chunk, a.count - base)) >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+      float4 acc = reinterpret_cast<const float4*>(a.g[0] + base)[i];
+      for (int q = 1; q < a.world; ++q) {
+        const float4 v = reinterpret_cast<const float4*>(a.g[q] + base)[i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      reinterpret_cast<float4*>(a.s[a.rank])[i] = acc;
+    }
+  }
+  // REDUCED(e) once every workgroup's part of S is visible system-wide
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) ok_s = (atomicAdd(a.done, 1u) == gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (ok_s) {
+    if (threadIdx.x == 0) *a.done = 0;
+    if (threadIdx.x < (unsigned)a.world && (int)threadIdx.x != a.rank)
+      __hip_atomic_store(a.flags[threadIdx.x] + SMX_P2P_MAX + a.rank, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// grid = world x blocks_per_rank: blockIdx.y = the source rank whose reduced chunk this workgroup fetches
+__global__ __launch_bounds__(256) void p2p_all_gather_kernel(P2PArgs a) {
+  __shared__ int ok_s;
+  const int q = blockIdx.y;
+  if (threadIdx.x == 0) ok_s = (q == a.rank) ? 1 : (wait_flag(a.flags[a.rank] + SMX_P2P_MAX + q, a.epoch, a.error) ? 1 : 0);
+  __syncthreads();
+  if (!ok_s) return;
+  const long base = (long)q * a.chunk;
+  const long n4 = std::max<long>(0, std::min(a.chunk, a.count - base)) >> 2;
+  const float4* src = reinterpret_cast<const float4*>(a.s[q]);
+  float4* dst = reinterpret_cast<float4*>(a.out + base);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+
+// the all-reduce of `count` floats at `buf` (the registered gradient buffer or anything that fits the scratch) on stream st
+int p2p_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
+  P2PState& p = *m->p2p;
+  SMX_REQUIRE((count % 4) == 0, "p2p all-reduce: the length must be a multiple of 4 floats");
+  P2PArgs a;
+  memset(&a, 0, sizeof(a));
+  const bool is_g = buf >= m->grads && buf + count <= m->grads + m->grads_count;
+  if (!is_g) {   // a small buffer (SyncBatchNorm statistics): through the exported scratch
+    SMX_REQUIRE(count <= p.scratch_floats, "p2p all-reduce: buffer exceeds the exported scratch");
+    SMX_HIP(hipMemcpyAsync(p.scratch[p.rank], buf, count * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  const size_t off = is_g ? (size_t)(buf - m->grads) : 0;
+  for (int q = 0; q < p.world; ++q) {
+    a.g[q] = is_g ? p.grads[q] + off : p.scratch[q];
+    a.s[q] = p.staging[q];
+    a.flags[q] = p.flags[q];
+  }
+  a.out = is_g ? buf : p.scratch[p.rank];
+  a.done = p.done; a.error = p.error;
+  a.count = (long)count;
+  a.chunk = (long)(((count + p.world - 1) / p.world + 3) / 4 * 4);
+  SMX_REQUIRE((size_t)a.chunk <= p.staging_floats, "p2p all-reduce: staging too small");
+  a.rank = p.rank; a.world = p.world; a.epoch = ++p.epoch;
+  // few, fat workgroups: the exchange is link-bound and the flag rounds must be co-resident with whatever else runs
+  const unsigned nb = (unsigned)std::max<long>(1, std::min<long>(64, (a.chunk / 4 + 255) / 256));
+  hipLaunchKernelGGL(p2p_reduce_scatter_kernel, dim3(nb), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(p2p_all_gather_kernel, dim3(std::max(1u, nb / 2), (unsigned)p.world), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  if (!is_g) SMX_HIP(hipMemcpyAsync(buf, p.scratch[p.rank], count * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return SMX_OK;
+}
+
+void p2p_release(smx_model* m) {
+  if (!m->p2p) return;
+  P2PState& p = *m->p2p;
+  for (int q = 0; q < p.world; ++q) {
+    if (q == p.rank) continue;
+    if (p.grads[q]) hipIpcCloseMemHandle(p.grads[q]);
+    if (p.region_base[q]) hipIpcCloseMemHandle(p.region_base[q]);
+  }
+  if (p.region_base[p.rank] && p.owns_region) hipFree(p.region_base[p.rank]);
+  m->p2p.reset();
+}
+
+static void region_layout(smx_model* m, int world, size_t* staging_floats, size_t* scratch_floats, size_t* bytes) {
+  const size_t chunk = ((m->grads_count + world - 1) / world + 3) / 4 * 4 + 64;
+  size_t scratch = 4096;
+  for (size_t i = 0; i < m->bn_wp.size(); ++i) scratch = std::max(scratch, (size_t)SMX_P2P_MAX * 2 * m->bn_wp[i]);
+  *staging_floats = chunk; *scratch_floats = scratch;
+  *bytes = 1024 + (chunk + scratch) * sizeof(float);   // [flags 2 x SMX_P2P_MAX words | done | error | pad to 1 KB][staging][scratch]
+}
+
+}  // namespace smx
+
+extern "C" {
+
+// this rank's two IPC handles: [0, 64) the flat gradient buffer, [64, 128) the communication region (allocated here)
+int smx_comm_p2p_export(smx_model* m, int world, uint8_t handles[128]) {
+  SMX_REQUIRE(m && handles && world >= 1 && world <= SMX_P2P_MAX, "bad arguments (world <= 8)");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  p2p_release(m);
+  m->p2p = std::make_shared<P2PState>();
+  P2PState& p = *m->p2p;
+  size_t bytes;
+  region_layout(m, world, &p.staging_floats, &p.scratch_floats, &bytes);
+  void* region = nullptr;
+  SMX_HIP(hipMalloc(&region, bytes));
+  SMX_HIP(hipMemset(region, 0, bytes));
+  p.owns_region = true; p.pending_world = world;
+  p.region_base[0] = region;   // (parked until the rank is known: smx_comm_p2p_init moves it to slot `rank`)
+  hipIpcMemHandle_t hg, hr;
+  SMX_HIP(hipIpcGetMemHandle(&hg, m->grads));
+  SMX_HIP(hipIpcGetMemHandle(&hr, region));
+  memcpy(handles, &hg, 64);
+  memcpy(handles + 64, &hr, 64);
+  return SMX_OK;
+}
+
+// all_handles [world][128]: what every rank's smx_comm_p2p_export returned, in rank order (gathered by the control plane)
+int smx_comm_p2p_init(smx_model* m, int rank, int world, const uint8_t* all_handles) {
+  SMX_REQUIRE(m && all_handles && world >= 1 && world <= SMX_P2P_MAX && rank >= 0 && rank < world, "bad arguments");
+  SMX_REQUIRE(m->p2p && m->p2p->pending_world == world, "call smx_comm_p2p_export(world) first");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  P2PState& p = *m->p2p;
+  void* mine = p.region_base[0];
+  p.region_base[0] = nullptr;
+  p.rank = rank; p.world = world;
+  auto carve = [&](int q, void* base) {
+    p.region_base[q] = base;
+    p.flags[q] = reinterpret_cast<unsigned*>(base);
+    p.staging[q] = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(base) + 1024);
+    p.scratch[q] = p.staging[q] + p.staging_floats;
+  };
+  for (int q = 0; q < world; ++q) {
+    if (q == rank) { carve(q, mine); p.grads[q] = m->grads; continue; }
+    hipIpcMemHandle_t hg, hr;
+    memcpy(&hg, all_handles + (size_t)q * 128, 64);
+    memcpy(&hr, all_handles + (size_t)q * 128 + 64, 64);
+    void *pg = nullptr, *pr = nullptr;
+    hipError_t e1 = hipIpcOpenMemHandle(&pg, hg, hipIpcMemLazyEnablePeerAccess);
+    hipError_t e2 = e1 == hipSuccess ? hipIpcOpenMemHandle(&pr, hr, hipIpcMemLazyEnablePeerAccess) : e1;
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      set_error(std::string("hipIpcOpenMemHandle of rank ") + std::to_string(q) + " failed: " + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+      if (pg) hipIpcCloseMemHandle(pg);
+      carve(rank, mine);
+      p2p_release(m);
+      return SMX_ERR_COMM;
+    }
+    p.grads[q] = reinterpret_cast<float*>(pg);
+    carve(q, pr);
+  }
+  p.done = p.flags[rank] + 2 * SMX_P2P_MAX;
+  p.error = p.done + 1;
+  m->rank = rank; m->world = world;
+  SMX_CHECK(smx::ensure_comm_stream(m));
+  if (!m->comm) SMX_CHECK(smx::ensure_sync_buf(m));
+  drop_graphs(m);
+  return SMX_OK;
+}
+
+// non-zero after a wait on a peer timed out (the results of that step are then garbage); clears the word
+int smx_comm_p2p_error(smx_model* m, int32_t* error) {
+  SMX_REQUIRE(m && error, "null argument");
+  *error = 0;
+  if (!m->p2p || !m->p2p->error) return SMX_OK;
+  SMX_HIP(hipStreamSynchronize(m->st));
+  unsigned e = 0;
+  SMX_HIP(hipMemcpy(&e, m->p2p->error, sizeof(e), hipMemcpyDeviceToHost));
+  if (e) SMX_HIP(hipMemset(m->p2p->error, 0, sizeof(e)));
+  *error = (int32_t)e;
+  return SMX_OK;
+}
+
+}  // extern "C"

@@ -1157,7 +1157,8 @@ int launch_train(smx_model* m, int B, bool use_graph, int s_idx, int n_steps) {
   // With a communicator the RCCL all-reduce is captured too (RCCL supports stream capture);
   // SMX_NO_GRAPH_COMM=1 or a failed capture falls back to eager launches for good.
   static const bool no_graph_comm = getenv("SMX_NO_GRAPH_COMM") != nullptr;
-  if (use_graph && !m->local && !(m->comm && (no_graph_comm || m->graph_comm_failed)) && !m->use_injected && m->timing_label.empty()) {
+  // (the peer-to-peer exchange carries its epoch as a kernel argument: never captured)
+  if (use_graph && !m->local && !m->p2p && !(m->comm && (no_graph_comm || m->graph_comm_failed)) && !m->use_injected && m->timing_label.empty()) {
     auto it = m->graphs.find(B);
     if (it == m->graphs.end()) {
       hipGraph_t graph = nullptr;

@@ -425,6 +425,25 @@ class Engine:
     buf = (C.c_uint8 * 128).from_buffer_copy(uid)
     check(self.lib.smx_comm_init(self._h, int(rank), int(world), buf))
 
+  def comm_p2p_export(self, world: int) -> bytes:
+    """This rank's two IPC handles (flat gradient buffer | communication region) for the hand-written two-shot all-reduce
+    over peer-mapped buffers (smx_comm_p2p_export); gather every rank's 128 bytes in rank order, then comm_p2p_init."""
+    buf = (C.c_uint8 * 128)()
+    check(self.lib.smx_comm_p2p_export(self._h, int(world), buf))
+    return bytes(buf)
+
+  def comm_p2p_init(self, rank: int, world: int, all_handles: bytes):
+    if len(all_handles) != 128 * world:
+      raise ValueError("all_handles must hold world x 128 bytes in rank order")
+    buf = (C.c_uint8 * len(all_handles)).from_buffer_copy(all_handles)
+    check(self.lib.smx_comm_p2p_init(self._h, int(rank), int(world), buf))
+
+  def comm_p2p_error(self) -> int:
+    """Non-zero after a wait on a peer timed out in the peer-to-peer exchange (cleared by the call)."""
+    e = C.c_int32(0)
+    check(self.lib.smx_comm_p2p_error(self._h, C.byref(e)))
+    return int(e.value)
+
   @property
   def world(self) -> int:
     return self.lib.smx_comm_world(self._h)

@@ -24,7 +24,7 @@ def env_rank_world() -> Tuple[int, int, int]:
 
 
 _MAGIC = b"SMXCP1"
-_OP_BARRIER, _OP_BCAST, _OP_MAX, _OP_SUM, _OP_CLOSE = range(5)
+_OP_BARRIER, _OP_BCAST, _OP_MAX, _OP_SUM, _OP_CLOSE, _OP_GATHER = range(6)
 
 
 def _send(sock: socket.socket, op: int, payload: bytes = b""):
@@ -150,6 +150,13 @@ class ControlPlane:
     mine = bytes(make()) if self.rank == src else b""
     return self._collective(_OP_BCAST, mine, lambda parts: parts[src])
 
+  def allgather_bytes(self, mine: bytes) -> List[bytes]:
+    """Every rank's equal-length byte string, in rank order, on every rank."""
+    mine = bytes(mine)
+    out = self._collective(_OP_GATHER, mine, lambda parts: b"".join(parts))
+    n = len(mine)
+    return [out[i * n:(i + 1) * n] for i in range(max(self.world, 1))]
+
   def max(self, value: float) -> float:
     out = self._collective(_OP_MAX, struct.pack("<d", float(value)), lambda parts: struct.pack("<d", max(struct.unpack("<d", p)[0] for p in parts)))
     return struct.unpack("<d", out)[0]
@@ -222,6 +229,9 @@ class LocalControlPlane:
   def broadcast_bytes(self, make: Callable[[], bytes], src: int = 0) -> bytes:
     return self._gather(make() if self.rank == src else None)[src]
 
+  def allgather_bytes(self, mine: bytes) -> List[bytes]:
+    return [bytes(b) for b in self._gather(bytes(mine))]
+
   def max(self, value: float) -> float:
     return float(max(self._gather(float(value))))
 
@@ -249,5 +259,12 @@ def attach_engine(engine, cp):
     cp.attach(engine)
     return
   from sisua_amd.engine import Engine
-  uid = cp.broadcast_bytes(Engine.comm_unique_id)
-  engine.comm_init(cp.rank, cp.world, uid)
+  mode = os.environ.get("SMX_ALLREDUCE", "rccl").lower()   # 'rccl' (default) | 'p2p' (hand-written two-shot exchange over IPC-mapped
+  if mode not in ("rccl", "p2p", "p2p-only"):               # peer buffers, beside RCCL) | 'p2p-only' (no RCCL communicator at all)
+    raise ValueError("SMX_ALLREDUCE must be 'rccl', 'p2p' or 'p2p-only'")
+  if mode != "p2p-only":
+    uid = cp.broadcast_bytes(Engine.comm_unique_id)
+    engine.comm_init(cp.rank, cp.world, uid)
+  if mode != "rccl":
+    handles = cp.allgather_bytes(engine.comm_p2p_export(cp.world))
+    engine.comm_p2p_init(cp.rank, cp.world, b"".join(handles))

@@ -1,0 +1,145 @@
+"""The hand-written two-shot all-reduce over IPC-mapped peer buffers (sisua_amd/csrc/smx_p2p.hip) with REAL
+processes: 2 and 3 fresh child processes share the box's one GPU (each opens the others' gradient buffers and communication
+regions through HIP IPC -- on an 8-GPU node the same handles map peer memory over xGMI), join over the package's TCP control
+plane, and run optimiser steps whose collective is the peer-to-peer exchange (no RCCL communicator: RCCL refuses two ranks on
+one device).  Checked against oracle.dp_train_step, and the ranks against each other bit for bit.  A second test lets a peer
+die: the survivor's bounded waits must give up and report, not hang the device."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import sisua_oracle as so
+from tests.util import adam_state_errors, grad_errors, make_pair, perturbed_params, synth_counts
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+KW = dict(model="vae", n_genes=203, likelihood="zinb", enc_units=(48, 40), dec_units=(40,), latent_dim=10)
+KW_SYNC = dict(model="vae", n_genes=120, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=6)
+
+_CHILD = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+rank, world, out, sync_bn, die = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+from tests.util import make_pair, perturbed_params, synth_counts
+from sisua_amd.engine import Engine
+from sisua_amd.parallel import ControlPlane
+kw = {kw!r}
+spec, cfg = make_pair(**kw)
+x = synth_counts(400, spec.n_genes, sparsity=0.85, seed=0)
+e = Engine(cfg, max_batch=64, init=False)
+e.set_params(perturbed_params(spec))
+e.upload(x, cell_id_base=1000)
+cp = ControlPlane(rank, world)
+handles = cp.allgather_bytes(e.comm_p2p_export(world))
+e.comm_p2p_init(rank, world, b"".join(handles))
+assert e.world == world and e.rank == rank
+e.set_sync_bn(bool(sync_bn))
+cp.barrier()
+if die and rank == 1:
+  cp.close()
+  os._exit(0)                       # a peer that never takes part in the exchange
+rng = np.random.default_rng(5)
+res = dict()
+for step in range(3):
+  rows = rng.permutation(400)[: 48 * world].astype(np.int32).reshape(world, 48)
+  m = e.train_step(rows[rank])
+  res[f"loss{{step}}"] = m["loss"]; res[f"kl{{step}}"] = m["kl"]; res[f"gn{{step}}"] = m["grad_norm_max"]
+  if step == 0:
+    for k, v in e.get_params(which=1).items():
+      res["g/" + k] = v
+  if die:
+    break
+res["err"] = e.comm_p2p_error()
+for k, v in e.get_params().items():
+  res["p/" + k] = v
+for k, v in e.get_params(which=2).items():
+  res["m/" + k] = v
+np.savez(out, **res)
+if not die:
+  cp.barrier()
+  cp.close()
+e.close()
+print("DONE", flush=True)
+"""
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _run(tmp_path, world, kw, sync_bn=0, die=0, timeout=180, extra_env=None):
+  script = tmp_path / "p2p_child.py"
+  script.write_text(_CHILD.format(root=ROOT, kw=kw))
+  port = _free_port()
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="1", SMX_CP_PORT=str(port), WORLD_SIZE=str(world), SMX_RUN_ID=f"p2p{port}",
+             **(extra_env or {}))
+  ps = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(tmp_path / f"r{r}.npz"), str(sync_bn), str(die)],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(env, RANK=str(r)), text=True) for r in range(world)]
+  outs = []
+  for p in ps:
+    try:
+      out, _ = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+      for q in ps:
+        q.kill()
+      pytest.fail("a rank of the peer-to-peer exchange hangs")
+    outs.append((p.returncode, out))
+  return outs
+
+
+@pytest.mark.parametrize("world,sync_bn,buckets", [(2, 0, 1), (3, 0, 1), (2, 1, 1), (2, 0, 2)])
+def test_p2p_allreduce_between_processes_matches_oracle(tmp_path, world, sync_bn, buckets):
+  """buckets = 2 (SMX_DP_BUCKETS=2): the heads' gradients are exchanged on the communication stream while the rest of the
+  backward pass runs, the remainder afterwards -- two exchanges per step, the same numbers."""
+  from sisua_amd import build
+  build.build(verbose=False)
+  kw = KW_SYNC if sync_bn else KW
+  outs = _run(tmp_path, world, kw, sync_bn=sync_bn, extra_env={"SMX_DP_BUCKETS": str(buckets)})
+  for rc, out in outs:
+    assert rc == 0 and "DONE" in out, out[-3000:]
+  got = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+  spec, _ = make_pair(**kw)
+  x = synth_counts(400, spec.n_genes, sparsity=0.85, seed=0)
+  params = perturbed_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  rng = np.random.default_rng(5)
+  for step in range(3):
+    rows = rng.permutation(400)[: 48 * world].astype(np.int32).reshape(world, 48)
+    ref = so.dp_train_step(spec, params, bn, opt, x, list(rows), step, cell_base=1000, sync_bn=bool(sync_bn))
+    for r in range(world):
+      assert int(got[r]["err"]) == 0
+      assert np.isclose(float(got[r][f"loss{step}"]), ref["metrics"]["loss"], rtol=1e-4), (r, step)
+      assert np.isclose(float(got[r][f"kl{step}"]), ref["metrics"]["kl"], rtol=1e-4, atol=1e-5), (r, step)
+      assert np.isclose(float(got[r][f"gn{step}"]), max(ref["norms"].values()), rtol=1e-3), (r, step)
+      assert float(got[r][f"loss{step}"]) == float(got[0][f"loss{step}"])          # the ranks agree bit for bit
+    if step == 0:
+      for r in range(world):
+        g = {k[2:]: got[r][k] for k in got[r].files if k.startswith("g/")}
+        worst = grad_errors(g, ref["grads"])
+        assert max(worst.values()) < 1e-4, (r, sorted(worst.items(), key=lambda kv: -kv[1])[:3])
+  for k in [k for k in got[0].files if k[:2] in ("p/", "m/")]:
+    for r in range(1, world):
+      assert np.array_equal(got[0][k], got[r][k]), (k, r)
+  em = grad_errors({k[2:]: got[0][k] for k in got[0].files if k.startswith("m/")}, opt["m"])
+  assert max(em.values()) < 1e-3, sorted(em.items(), key=lambda kv: -kv[1])[:3]
+
+
+def test_p2p_exchange_gives_up_on_a_dead_peer(tmp_path):
+  """Rank 1 leaves after the handles were exchanged; rank 0's step waits ~2 s for its READY flag, gives up, and the host
+  reads the error word -- the device is not left with a spinning kernel."""
+  from sisua_amd import build
+  build.build(verbose=False)
+  outs = _run(tmp_path, 2, KW, die=1, timeout=120)
+  assert outs[0][0] == 0 and "DONE" in outs[0][1], outs[0][1][-3000:]
+  r0 = np.load(tmp_path / "r0.npz")
+  assert int(r0["err"]) != 0
