@@ -47,6 +47,7 @@ __device__ inline bool wait_flag(const unsigned* f, unsigned epoch, unsigned* er
   return true;
 }
 
+template <int W>   // W = world (compile-time: the per-rank load arrays stay in registers)
 __global__ __launch_bounds__(256) void p2p_reduce_scatter_kernel(P2PArgs a) {
   __shared__ int ok_s;
   if (threadIdx.x < (unsigned)a.world) {
@@ -62,13 +63,27 @@ __global__ __launch_bounds__(256) void p2p_reduce_scatter_kernel(P2PArgs a) {
   if (ok_s) {
     const long base = (long)a.rank * a.chunk;
     const long n4 = std::max<long>(0, std::min(a.chunk, a.count - base)) >> 2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-      float4 acc = reinterpret_cast<const float4*>(a.g[0] + base)[i];
-      for (int q = 1; q < a.world; ++q) {
-        const float4 v = reinterpret_cast<const float4*>(a.g[q] + base)[i];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    // four positions x every rank in flight per thread (a link's latency x bandwidth is ~150 KB: one 16-byte load per thread of
+    // a small grid would leave the links idle most of the time); the sum itself in rank order
+    const long stride = (long)gridDim.x * 256;
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+      float4 v[W][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+          const long i = i0 + u * stride;
+          v[q][u] = i < n4 ? reinterpret_cast<const float4*>(a.g[q] + base)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = i0 + u * stride;
+        if (i >= n4) break;
+        float4 acc = v[0][u];
+#pragma unroll
+        for (int q = 1; q < W; ++q) { acc.x += v[q][u].x; acc.y += v[q][u].y; acc.z += v[q][u].z; acc.w += v[q][u].w; }
+        reinterpret_cast<float4*>(a.s[a.rank])[i] = acc;
       }
-      reinterpret_cast<float4*>(a.s[a.rank])[i] = acc;
     }
   }
   // REDUCED(e) once every workgroup's part of S is visible system-wide
@@ -94,7 +109,14 @@ __global__ __launch_bounds__(256) void p2p_all_gather_kernel(P2PArgs a) {
   const long n4 = std::max<long>(0, std::min(a.chunk, a.count - base)) >> 2;
   const float4* src = reinterpret_cast<const float4*>(a.s[q]);
   float4* dst = reinterpret_cast<float4*>(a.out + base);
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) dst[i] = src[i];
+  const long stride = (long)gridDim.x * 256;
+  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {   // four loads in flight per thread
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const long i = i0 + u * stride; v[u] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const long i = i0 + u * stride; if (i < n4) dst[i] = v[u]; }
+  }
 }
 
 // the all-reduce of `count` floats at `buf` (the registered gradient buffer or anything that fits the scratch) on stream st
@@ -121,9 +143,19 @@ int p2p_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
   SMX_REQUIRE((size_t)a.chunk <= p.staging_floats, "p2p all-reduce: staging too small");
   a.rank = p.rank; a.world = p.world; a.epoch = ++p.epoch;
   // few, fat workgroups: the exchange is link-bound and the flag rounds must be co-resident with whatever else runs
-  const unsigned nb = (unsigned)std::max<long>(1, std::min<long>(64, (a.chunk / 4 + 255) / 256));
-  hipLaunchKernelGGL(p2p_reduce_scatter_kernel, dim3(nb), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(p2p_all_gather_kernel, dim3(std::max(1u, nb / 2), (unsigned)p.world), dim3(256), 0, st, a);
+  // a fraction of the chip: the exchange is link-bound, and every rank's launches must be resident together (the flag rounds)
+  const unsigned nb = (unsigned)std::max<long>(1, std::min<long>(128, (a.chunk / 4 + 1023) / 1024));
+  switch (p.world) {
+    case 1: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<1>, dim3(nb), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<2>, dim3(nb), dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<3>, dim3(nb), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<4>, dim3(nb), dim3(256), 0, st, a); break;
+    case 5: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<5>, dim3(nb), dim3(256), 0, st, a); break;
+    case 6: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<6>, dim3(nb), dim3(256), 0, st, a); break;
+    case 7: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<7>, dim3(nb), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<8>, dim3(nb), dim3(256), 0, st, a); break;
+  }
+  hipLaunchKernelGGL(p2p_all_gather_kernel, dim3(std::max(1u, std::min(nb, 128u / (unsigned)p.world)), (unsigned)p.world), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   if (!is_g) SMX_HIP(hipMemcpyAsync(buf, p.scratch[p.rank], count * sizeof(float), hipMemcpyDeviceToDevice, st));
   return SMX_OK;
