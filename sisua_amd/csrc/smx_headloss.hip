@@ -208,8 +208,7 @@ static void launch_hl_w(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
     hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 1, NW, 128, B3>), grid, dim3(64 * NW), 0, st, a);
   }
 }
-// bf16 x 3 products: SMX_BF16X3 = 1 always, 0 never; default from the width (a launch-bound head of ~2000 genes gains
-// nothing: its f32 MFMAs are not what it waits for)
+// bf16 x 3 products: SMX_BF16X3 = 1 always, 0 never (the exact-f32 MFMA forms); default: SMX_BF16X3_MIN_WORK (smx_internal.h)
 bool use_bf16x3(long work) {
   static const int forced = getenv("SMX_BF16X3") ? atoi(getenv("SMX_BF16X3")) : -1;
   return forced >= 0 ? forced != 0 : work >= SMX_BF16X3_MIN_WORK;

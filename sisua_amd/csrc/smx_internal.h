@@ -374,8 +374,10 @@ struct HeadLossArgs {
   int n_ct = 0, n_gt = 0;                         // set by the launcher
   int bf16x3 = 0;                                 // the product from bf16 MFMAs on three-way split operands (smx_device.h)
 };
-// cells x padded genes x planes from which the output head's products run as bf16 x 3 by default (flag "bf16x3" / SMX_BF16X3)
-#define SMX_BF16X3_MIN_WORK (128L * 8192 * 3)
+// cells x padded genes x planes from which the output head's products run as bf16 x 3 by default (flag "bf16x3" / SMX_BF16X3):
+// every size -- measured A/B on one box, us per step f32 -> bf16 x 3: 8kly 84.7 -> 83.2, 8kly-scvi 115.3 -> 114.3, eccly-sisua
+// 125.9 -> 122.3, 8kly-2layer 125.9 -> 124.1, c5-shard 263 -> 222 (with the gene-axis products of smx_bigk.hip)
+#define SMX_BF16X3_MIN_WORK 1L
 bool use_bf16x3(long work);
 bool head_loss_supported(int B, int Hp, int Gp);
 int head_loss_chunks(int Gp);
