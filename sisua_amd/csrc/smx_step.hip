@@ -187,7 +187,19 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
 // their clip + Adam update rides along with the next BatchNorm-backward launch, which leaves most CUs idle; the
 // optimiser launch at the end of the step then covers only the encoder / latent / decoder chunks.
 void attach_early_adam(smx_model* m, BnBwdArgs& b) {
-  if (!m->adam_early_pending) return;
+  if (!m->adam_early_pending) {
+    // the second part of the heads' update: riders of the NEXT BatchNorm-backward launch of the step (see below)
+    if (m->adam_rest_to > m->adam_rest_from) {
+      fill_adam_args(m, b.adam);
+      b.adam.use_sq = 1;
+      for (size_t t = 0; t < m->tensors.size(); ++t) { b.adam.sq_first[t] = m->sq_first[t]; b.adam.sq_count[t] = m->sq_count[t]; }
+      b.adam.master = nullptr; b.adam.with_metrics = 0;
+      b.adam_first = m->adam_rest_from; b.adam_count = m->adam_rest_to - m->adam_rest_from;
+      m->adam_early_to = m->adam_rest_to;
+      m->adam_rest_from = m->adam_rest_to = 0;
+    }
+    return;
+  }
   m->adam_early_pending = false;
   static const bool off = getenv("SMX_NO_ADAM_EARLY") != nullptr;
   if (off || dp_active(m) || !m->sq_slots || m->chunk_first_head >= m->n_chunks || getenv("SMX_NO_SQ_PARTIALS") != nullptr) return;
@@ -223,9 +235,17 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
   // (label heads whose weight gradients come with the grouped launch at the END of the backward pass stay with the
   // optimiser launch)
   const int early_to = m->lab_deferred ? m->chunk_first_label : m->n_chunks;
+  // the riders (22 MB of optimiser traffic at the benchmark size) set the duration of the launch that carries them (10 us against
+  // 6 for its own work) while the NEXT BatchNorm-backward launch of the step leaves the chip as idle: split them over the two
+  // (SMX_ADAM_SPLIT = share of the first, default 0.5; a step with one such launch keeps them all, the final launch takes what
+  // nobody carried)
+  static const float split = getenv("SMX_ADAM_SPLIT") ? (float)atof(getenv("SMX_ADAM_SPLIT")) : 0.5f;
+  const int total = early_to - m->chunk_first_head;
+  const int first = std::max(1, std::min(total, (int)(total * std::min(std::max(split, 0.f), 1.f) + 0.5f)));
   b.adam_first = m->chunk_first_head;
-  b.adam_count = early_to - m->chunk_first_head;
-  m->adam_early_from = m->chunk_first_head; m->adam_early_to = early_to;
+  b.adam_count = first;
+  m->adam_early_from = m->chunk_first_head; m->adam_early_to = m->chunk_first_head + first;
+  m->adam_rest_from = m->chunk_first_head + first; m->adam_rest_to = early_to;
 }
 
 // ask the product that writes the gradient of tensor t for sum-of-squares partials
@@ -745,7 +765,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
   const smx_config& c = m->cfg;
   std::fill(m->sq_count.begin(), m->sq_count.end(), 0);   // the products of this step report what they wrote
   std::fill(m->sq_reduced.begin(), m->sq_reduced.end(), 0);
-  m->adam_early_pending = false; m->adam_early_from = -1;
+  m->adam_early_pending = false; m->adam_early_from = -1; m->adam_rest_from = m->adam_rest_to = 0;
   const float inv_gb = 1.f / (float)ps.global_batch;
   if (m->fvae) SMX_CHECK(factor_backward(m, ps));   // first: it uses the slab buffer the head's backward fills next
   const MlpLayer& dL = m->dec.back();
