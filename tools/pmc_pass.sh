@@ -9,6 +9,6 @@ rm -rf $OUT; mkdir -p $OUT
 [ -x $R/tools/ubench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $R/tools/ubench.hip -o $R/tools/ubench
 for c in FETCH_SIZE WRITE_SIZE; do
   UBENCH_CALIB=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/calib_$c -- $R/tools/ubench > /dev/null 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/bench_$c -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_$c.json 2> $OUT/bench_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/bench_$c -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-c5-entry > $OUT/bench_$c.json 2> $OUT/bench_$c.err
 done
 python3 $R/tools/pmc_summary.py $OUT
