@@ -181,7 +181,7 @@ def main():
       sys.exit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     args.gpus = world
 
-  # the HIP library first (binds /opt/rocm's runtime), torch only as rendezvous plumbing
+  # the HIP library (binds /opt/rocm's runtime); ranks meet over the package's own TCP control plane (MASTER_ADDR / MASTER_PORT)
   from sisua_amd import _hip
   from sisua_amd.engine import Engine
   from sisua_amd.parallel import ControlPlane, attach_engine

@@ -152,8 +152,8 @@ def load():
     fn.argtypes = args
   if lib.smx_abi_version() != SMX_ABI_VERSION:
     raise SmxError("libsisua_hip.so ABI version mismatch; rebuild")
-  # Data-parallel jobs: bind ROCm's own RCCL now.  The library dlopen()s "librccl.so.1" lazily; if torch
-  # (imported later for the gloo control plane) loaded its bundled copy first, that older build would be
+  # Data-parallel jobs: bind ROCm's own RCCL now.  The library dlopen()s "librccl.so.1" lazily; if a caller's torch
+  # (which bundles its own RCCL) were imported first, that older build would be
   # picked up by soname instead of the one matching /opt/rocm's HIP runtime.
   if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     for cand in ("/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"):
