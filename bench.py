@@ -33,25 +33,48 @@ LOSS_REPEAT = 8   # SMX_LOSS_TIMING_REPEAT in sisua_amd/csrc/smx_model.h
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.3 TB/s achievable)
 
 
+import functools  # noqa: E402
+
+
+@functools.lru_cache(maxsize=4)
+def _prepared(workload: str):
+  """The workload's training matrix before sharding (read-only, cached: the world-8 tests cut the same matrix nine times):
+  synthetic stand-in -> split(0.8) -> split(0.9) -> corrupt(train)."""
+  from sisua_amd import data
+  if workload in ("8kly", "8kly-2layer", "8kly-scvi"):
+    x, y = data.synthetic_8kly(seed=8)
+  elif workload == "eccly-sisua":
+    x, y = data.synthetic_eccly(seed=8)
+  elif workload == "cortex-base":
+    x, y = data.synthetic_cortex(seed=8)
+  else:
+    raise ValueError(workload)
+  tr, _ = data.split_indices(x.shape[0], 0.8, seed=1)
+  tr2, _ = data.split_indices(len(tr), 0.9, seed=1)
+  xt = data.corrupt(x[tr][tr2], 0.2, 0.2, seed=8)
+  xt[xt.sum(1) == 0, 0] = 1.0
+  yt = y[tr][tr2] if y is not None else None
+  for a in (xt, yt):
+    if a is not None:
+      a.flags.writeable = False
+  return xt, yt
+
+
 def build_workload(rank: int, world: int, workload: str, n_cells: int = 4096):
   """Reproduces on_train (sisua/train.py:118-147) on synthetic 8kly-shaped data:
   split(0.8) -> split(0.9) -> corrupt(train) -> library stats."""
   from sisua_amd import data
   from sisua_amd.config import ModelConfig
   if workload == "8kly":
-    x, _ = data.synthetic_8kly(seed=8)
     units, latent, batch = (128,), 32, 128
   elif workload == "8kly-2layer":
-    x, _ = data.synthetic_8kly(seed=8)
     units, latent, batch = (128, 128), 32, 128
   elif workload in ("8kly-scvi", "eccly-sisua"):
     # BASELINE.json configs[2] / configs[3]: SCVI nbd batch 256; SISUA zinb + ADT nb labels (10 %), alpha 10, batch 256
-    x, y = data.synthetic_8kly(seed=8) if workload == "8kly-scvi" else data.synthetic_eccly(seed=8)
     units, latent, batch = (128,), 32, 256
   elif workload == "cortex-base":
     # the reference's own default run (configs/base.yaml: cortex, encoder / decoder units [64, 64], latent 12, zinbd,
     # batch 64; BASELINE.json configs[0] is the same data at batch 32)
-    x, _ = data.synthetic_cortex(seed=8)
     units, latent, batch = (64, 64), 12, 64
   elif workload == "c5-shard":
     # per-GPU slice of BASELINE.json configs[4] (1e6 x 20000 log-normal counts, 128 cells per GPU per step):
@@ -64,12 +87,10 @@ def build_workload(rank: int, world: int, workload: str, n_cells: int = 4096):
   else:
     raise ValueError(workload)
   if workload == "c5-shard":
-    xt = x
+    xt, yt = x, None
   else:
-    tr, _ = data.split_indices(x.shape[0], 0.8, seed=1)
-    tr2, _ = data.split_indices(len(tr), 0.9, seed=1)
-    xt = data.corrupt(x[tr][tr2], 0.2, 0.2, seed=8)
-    xt[xt.sum(1) == 0, 0] = 1.0
+    xt, yt = _prepared(workload)
+    x = xt
   kw = dict(n_genes=x.shape[1], enc_units=units, dec_units=units, latent_dim=latent, batchnorm=True, dropout_enc=0.1,
             dropout_dec=0.1, input_dropout=0.0, log_norm=True, beta=1.0, lr=1e-3, clipnorm=100.0, seed=8)
   extra = {}
@@ -77,7 +98,6 @@ def build_workload(rank: int, world: int, workload: str, n_cells: int = 4096):
     cfg = ModelConfig(model="scvi", likelihood="nbd", encl_units=(64,), **kw)
     extra["library"] = data.library_matrix(xt)
   elif workload == "eccly-sisua":
-    yt = y[tr][tr2]
     cfg = ModelConfig(model="sisua", likelihood="zinb", labels=((yt.shape[1], "nb"),), alpha=10.0, **kw)
     extra["labels"] = [yt]
     extra["label_mask"] = data.label_mask(xt.shape[0], 0.1, 2, seed=1)

@@ -46,6 +46,10 @@ __device__ inline U4 philox_block(const NoiseKey& nk, uint32_t cell_id, uint32_t
 
 __device__ inline float u24(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }  // 2^-24
 
+// a zero quad as a VALUE: `ok ? *p : z4` with a named z4 is an lvalue conditional, which gives z4 an address -- a scratch
+// slot per lane, and every launch of a kernel with a private segment pays for its set-up
+__device__ inline float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
 // Inverted-dropout multipliers for the 4 columns of one Philox block.
 __device__ inline float4 dropout_mult4(const U4& w, float p, float scale) {
   float4 m;

@@ -251,9 +251,11 @@ __device__ inline void latent_tile_to_lds(const LatentArgs& a, float* zs, bool s
     const int idx = threadIdx.x + it * BN_THREADS;
     const bool ok = idx < total;
     const int b = ok ? idx / dq : 0, d0 = (idx % dq) * 4;
-    m4[it] = ok ? *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + d0) : z4;
-    s4[it] = (ok && a.stochastic) ? *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + a.Dp + d0) : z4;
-    n4[it] = (ok && a.stochastic && a.inj_eps) ? *reinterpret_cast<const float4*>(a.inj_eps + (long)b * a.inj_ld + d0) : z4;
+    // (assign-then-overwrite, not `ok ? *p : z4`: that conditional is an lvalue, so z4 gets an address -- in scratch)
+    m4[it] = z4; s4[it] = z4; n4[it] = z4;
+    if (ok) m4[it] = *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + d0);
+    if (ok && a.stochastic) s4[it] = *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + a.Dp + d0);
+    if (ok && a.stochastic && a.inj_eps) n4[it] = *reinterpret_cast<const float4*>(a.inj_eps + (long)b * a.inj_ld + d0);
     cell[it] = a.cell_base + (uint32_t)((ok && a.rows) ? a.rows[b] : b);
   }
 #pragma unroll
@@ -263,34 +265,36 @@ __device__ inline void latent_tile_to_lds(const LatentArgs& a, float* zs, bool s
     const int b = idx / dq, d0 = (idx % dq) * 4;
     float kl = 0.f;
     if (idx < total) {
-      float zz[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {1.f, 1.f, 1.f, 1.f}, ee[4] = {0.f, 0.f, 0.f, 0.f};
-      const float mu[4] = {m4[it].x, m4[it].y, m4[it].z, m4[it].w};
+      float4 zq = z4, sq = make_float4(1.f, 1.f, 1.f, 1.f), eq = z4;
+      const float4 mq = m4[it];
       if (a.stochastic) {
-        const float sr[4] = {s4[it].x, s4[it].y, s4[it].z, s4[it].w};
         float4 nq = n4[it];
         if (!a.inj_eps) nq = normal4(philox_block(a.nk, cell[it], (uint32_t)(d0 >> 2)));
-        const float nn[4] = {nq.x, nq.y, nq.z, nq.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
+        const float4 sr = s4[it];
+        auto one = [&](int e, float mu, float s_raw, float nn, float& z, float& s, float& en) {
           if (d0 + e < a.D) {
-            const float sg = softplusf(sr[e] + SMX_SOFTPLUS_INV_1);
-            ss[e] = sg; ee[e] = nn[e];
-            zz[e] = mu[e] + sg * nn[e];
-            kl += 0.5f * (sg * sg + mu[e] * mu[e] - 1.f - 2.f * flog(sg));
+            const float sg = softplusf(s_raw + SMX_SOFTPLUS_INV_1);
+            s = sg; en = nn;
+            z = mu + sg * nn;
+            kl += 0.5f * (sg * sg + mu * mu - 1.f - 2.f * flog(sg));
           }
+        };
+        one(0, mq.x, sr.x, nq.x, zq.x, sq.x, eq.x);
+        one(1, mq.y, sr.y, nq.y, zq.y, sq.y, eq.y);
+        one(2, mq.z, sr.z, nq.z, zq.z, sq.z, eq.z);
+        one(3, mq.w, sr.w, nq.w, zq.w, sq.w, eq.w);
       } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (d0 + e < a.D) zz[e] = a.relu ? fmaxf(mu[e], 0.f) : mu[e];
+        auto one = [&](int e, float mu, float& z) { if (d0 + e < a.D) z = a.relu ? fmaxf(mu, 0.f) : mu; };
+        one(0, mq.x, zq.x); one(1, mq.y, zq.y); one(2, mq.z, zq.z); one(3, mq.w, zq.w);
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) zs[b * ldz + d0 + e] = zz[e];
+      float* zrow = zs + b * ldz + d0;
+      zrow[0] = zq.x; zrow[1] = zq.y; zrow[2] = zq.z; zrow[3] = zq.w;
       if (store) {
         const long o = (long)b * a.Dp + d0;
-        *reinterpret_cast<float4*>(a.z + o) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        *reinterpret_cast<float4*>(a.z + o) = zq;
         if (a.sig) {
-          *reinterpret_cast<float4*>(a.sig + o) = make_float4(ss[0], ss[1], ss[2], ss[3]);
-          *reinterpret_cast<float4*>(a.eps + o) = make_float4(ee[0], ee[1], ee[2], ee[3]);
+          *reinterpret_cast<float4*>(a.sig + o) = sq;
+          *reinterpret_cast<float4*>(a.eps + o) = eq;
         }
       }
     }
@@ -1212,14 +1216,13 @@ __global__ __launch_bounds__(256) void scvi_head_fwd_reg_kernel(ScviHeadArgs a) 
   const float* raw = a.raw + (long)b * a.ld;
   float* pl = a.planes + (long)b * a.ld;
   float4 r0[NV], r1[NV], r2[NV];
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int g = (threadIdx.x + 256 * j) * 4;
     const bool ok = g < a.Gp;
-    r0[j] = ok ? *reinterpret_cast<const float4*>(raw + g) : z4;
-    r1[j] = ok ? *reinterpret_cast<const float4*>(raw + a.plane_stride + g) : z4;
-    r2[j] = (ok && a.k == 3) ? *reinterpret_cast<const float4*>(raw + 2 * a.plane_stride + g) : z4;
+    r0[j] = ok ? *reinterpret_cast<const float4*>(raw + g) : zero4();
+    r1[j] = ok ? *reinterpret_cast<const float4*>(raw + a.plane_stride + g) : zero4();
+    r2[j] = (ok && a.k == 3) ? *reinterpret_cast<const float4*>(raw + 2 * a.plane_stride + g) : zero4();
   }
   float mx = -3.0e38f;
 #pragma unroll
@@ -1277,18 +1280,17 @@ __global__ __launch_bounds__(256) void scvi_head_bwd_reg_kernel(ScviHeadArgs a) 
   const float* rho = a.rho_raw + (long)b * a.Gp;
   const float lraw = a.l[b];
   const float el = expf(fminf(fmaxf(lraw, 0.f), a.clip_library));
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 rh[NV], d0v[NV], p0v[NV], d1v[NV], p1v[NV], d2v[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int g = (threadIdx.x + 256 * j) * 4;
     const bool ok = g < a.Gp;
-    rh[j] = ok ? *reinterpret_cast<const float4*>(rho + g) : z4;
-    d0v[j] = ok ? *reinterpret_cast<const float4*>(dp + g) : z4;
-    p0v[j] = ok ? *reinterpret_cast<const float4*>(pl + g) : z4;
-    d1v[j] = ok ? *reinterpret_cast<const float4*>(dp + a.plane_stride + g) : z4;
-    p1v[j] = ok ? *reinterpret_cast<const float4*>(pl + a.plane_stride + g) : z4;
-    d2v[j] = (ok && a.k == 3) ? *reinterpret_cast<const float4*>(dp + 2 * a.plane_stride + g) : z4;
+    rh[j] = ok ? *reinterpret_cast<const float4*>(rho + g) : zero4();
+    d0v[j] = ok ? *reinterpret_cast<const float4*>(dp + g) : zero4();
+    p0v[j] = ok ? *reinterpret_cast<const float4*>(pl + g) : zero4();
+    d1v[j] = ok ? *reinterpret_cast<const float4*>(dp + a.plane_stride + g) : zero4();
+    p1v[j] = ok ? *reinterpret_cast<const float4*>(pl + a.plane_stride + g) : zero4();
+    d2v[j] = (ok && a.k == 3) ? *reinterpret_cast<const float4*>(dp + 2 * a.plane_stride + g) : zero4();
   }
   float s = 0.f, dlh = 0.f;
 #pragma unroll

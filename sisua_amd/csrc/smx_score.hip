@@ -488,9 +488,9 @@ __global__ __launch_bounds__(256) void scvi_score_rows_kernel(ScviScoreArgs a) {
   for (int j = 0; j < NV; ++j) {
     const int g = (threadIdx.x + 256 * j) * 4;
     const bool ok = g < a.Gp;
-    r0[j] = ok ? *reinterpret_cast<const float4*>(raw + g) : z4;
-    r1[j] = ok ? *reinterpret_cast<const float4*>(raw + a.plane_stride + g) : z4;
-    r2[j] = (ok && ZI) ? *reinterpret_cast<const float4*>(raw + 2 * a.plane_stride + g) : z4;
+    r0[j] = ok ? *reinterpret_cast<const float4*>(raw + g) : zero4();
+    r1[j] = ok ? *reinterpret_cast<const float4*>(raw + a.plane_stride + g) : zero4();
+    r2[j] = (ok && ZI) ? *reinterpret_cast<const float4*>(raw + 2 * a.plane_stride + g) : zero4();
     if (!ok) xv[j] = z4;
     else if (a.x_u16) { const ushort4 u = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(a.X) + src * a.ldx + g); xv[j] = make_float4(u.x, u.y, u.z, u.w); }
     else xv[j] = *reinterpret_cast<const float4*>(a.X + src * a.ldx + g);

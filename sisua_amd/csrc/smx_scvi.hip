@@ -45,19 +45,18 @@ __global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
   const float* raw = a.raw + (long)b * a.ld;
   // ---- every load of the row first: raw planes and the cell's counts ------------------------------------------------
   float4 r0[NV], r1[NV], r2[NV], xv[NV];
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int g = (threadIdx.x + 256 * j) * 4;
     const bool ok = g < a.Gp;
-    r0[j] = ok ? *reinterpret_cast<const float4*>(raw + g) : z4;
-    r1[j] = ok ? *reinterpret_cast<const float4*>(raw + a.plane_stride + g) : z4;
-    r2[j] = (ok && K3) ? *reinterpret_cast<const float4*>(raw + 2 * a.plane_stride + g) : z4;
+    r0[j] = ok ? *reinterpret_cast<const float4*>(raw + g) : zero4();
+    r1[j] = ok ? *reinterpret_cast<const float4*>(raw + a.plane_stride + g) : zero4();
+    r2[j] = (ok && K3) ? *reinterpret_cast<const float4*>(raw + 2 * a.plane_stride + g) : zero4();
     if (U16) {
       const ushort4 h = ok ? *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(a.X) + xsrc * a.ldx + g) : make_ushort4(0, 0, 0, 0);
       xv[j] = make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
     } else {
-      xv[j] = ok ? *reinterpret_cast<const float4*>(a.X + xsrc * a.ldx + g) : z4;
+      xv[j] = ok ? *reinterpret_cast<const float4*>(a.X + xsrc * a.ldx + g) : zero4();
     }
   }
   // ---- library latent of this cell (wave 0; its loads overlap the row's) ----------------------------------------------

@@ -334,7 +334,7 @@ def test_world8_c5_split_matches_oracle(Engine, sync_bn):
   oracle.dp_train_step: ELBO scalars, every reduced gradient, gradient norms, Adam moments."""
   import bench
   world, B, per = 8, 128, 256
-  shards = [bench.build_workload(r, world, "c5-shard") for r in range(world)]
+  shards = [bench.build_workload(r, world, "c5-shard", n_cells=per) for r in range(world)]   # (only the resident slice is drawn)
   cfg = shards[0][0]
   assert cfg.n_genes == 20000 and shards[0][2] == B
   spec = so.Spec(**cfg.to_dict())

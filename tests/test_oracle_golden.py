@@ -70,3 +70,19 @@ def test_oracle_reproduces_committed_trajectory():
     r = so.train_step(spec, params, bn, opt, x[rows], so.PhiloxNoise(spec.seed, s, rows))
     assert np.isclose(r["loss"], fx["loss"][s], rtol=1e-10)
   assert fx["loss"][-5:].mean() < fx["loss"][:5].mean()
+
+
+def test_oracle_reproduces_committed_c2_trajectory():
+  """tests/golden/oracle_c2_trajectory.npz (what the GPU test at BASELINE configs[1] is held against) is the oracle's output:
+  same matrix, same row order, and the first steps re-derived here agree to float64 rounding."""
+  from tests.golden import make_c2_trajectory as mk
+  fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_c2_trajectory.npz"))
+  cfg, xt, B, order, probe = mk.inputs()
+  assert tuple(fx["x_shape"]) == xt.shape and int(fx["x_crc32"]) == mk.checksum(xt)
+  assert np.array_equal(order, fx["order"]) and np.array_equal(probe, fx["probe"])
+  out = mk.run(n_steps=4)
+  for key in ("loss", "nllk_x", "kl"):
+    assert np.allclose(out[key], fx[key][:4], rtol=1e-10), key
+  assert len(fx["loss"]) == 300 and fx["loss"][-10:].mean() < 0.45 * fx["loss"][:3].mean()
+  for at in (100, 300):
+    assert fx[f"z_mean_{at}"].shape == (256, cfg.latent_dim) and np.all(fx[f"z_scale_{at}"] > 0)
