@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "smx_internal.h"
+#include "smx_panel.h"
 #include "../../include/sisua_hip.h"
 
 namespace smx {
@@ -273,15 +274,8 @@ int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a_in) {
 // =====================================================================================================================
 namespace smx {
 
-__global__ __launch_bounds__(512) void wgrad_group_kernel(WgradGroup G) {
-  __shared__ float red[8 * 1024];
-  __shared__ float sqs[8];
-  // the descriptor through the kernarg segment pointer: indexing the by-value struct with a run-time problem id would
-  // make the compiler copy all of it to scratch (see gemm_group_kernel)
-  const WgradGroup& Gr = *(const WgradGroup*)__builtin_amdgcn_kernarg_segment_ptr();
-  int pi = 0;
-  while (pi + 1 < Gr.n && (int)blockIdx.x >= Gr.p[pi + 1].start) ++pi;
-  const WgradProblem& P = Gr.p[pi];
+// one 32 x 32 tile of problem P: `red` 8 partial tiles (32 KB), `sqs` 8 floats
+__device__ inline void wgrad_tile_body(const WgradGroup& Gr, const WgradProblem& P, float* red, float* sqs) {
   const int local = blockIdx.x - P.start;
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = lane & 31, hh = lane >> 5;
@@ -368,6 +362,38 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(WgradGroup G) {
   }
 }
 
+
+__global__ __launch_bounds__(512) void wgrad_group_kernel(WgradGroup G) {
+  __shared__ float red[8 * 1024];
+  __shared__ float sqs[8];
+  // the descriptor through the kernarg segment pointer: indexing the by-value struct with a run-time problem id would
+  // make the compiler copy all of it to scratch (see gemm_group_kernel)
+  const WgradGroup& Gr = *(const WgradGroup*)__builtin_amdgcn_kernarg_segment_ptr();
+  int pi = 0;
+  while (pi + 1 < Gr.n && (int)blockIdx.x >= Gr.p[pi + 1].start) ++pi;
+  wgrad_tile_body(Gr, Gr.p[pi], red, sqs);
+}
+
+// The same group with wide problems in it (a gene panel as M, N <= 128): those take the panel form (smx_panel.h, role 0), one
+// workgroup per 32 rows with every column tile; the group's small problems keep the 32 x 32 tiles.  A kernel of its own: the
+// panel form's 128 registers would otherwise cap the occupancy of every launch of the tile kernel (48 registers).
+__global__ __launch_bounds__(512, 4) void wgrad_panel_group_kernel(WgradGroup G) {
+  __shared__ __attribute__((aligned(16))) float red[SMX_PANEL_SMEM_FLOATS];
+  __shared__ float sqs[8];
+  const WgradGroup& Gr = *(const WgradGroup*)__builtin_amdgcn_kernarg_segment_ptr();
+  int pi = 0;
+  while (pi + 1 < Gr.n && (int)blockIdx.x >= Gr.p[pi + 1].start) ++pi;
+  const WgradProblem& P = Gr.p[pi];
+  if (!P.panel) { wgrad_tile_body(Gr, P, red, sqs); return; }   // (block-uniform)
+  PanelProblem pp;
+  pp.big = P.A; pp.ld_big = P.lda; pp.big_mode = P.a_mode; pp.log1p = P.a_mode ? P.log1p : 0; pp.rows = P.a_mode ? P.rows : nullptr;
+  pp.S = P.Bm; pp.ldS = P.ldb; pp.n_st = P.n_nt; pp.out = P.C; pp.ld_out = P.ldc;
+  pp.s_colsum = P.colsum; pp.sq_part = P.sq_part; pp.n_wt = P.n_mt; pp.B = Gr.B;
+  if (P.a_mode == 2) panel_body<0, 2>(pp, (int)blockIdx.x - P.start, red);
+  else if (P.a_mode == 1) panel_body<0, 1>(pp, (int)blockIdx.x - P.start, red);
+  else panel_body<0, 0>(pp, (int)blockIdx.x - P.start, red);
+}
+
 bool wgrad_supported(const GemmArgs& g, int B) {
   // C = A^T Bm with A stored [K][M] (k-major), Bm [K][N], K = the minibatch; optional gather + log1p of A; no input dropout
   if (!g.a_kmajor || g.b_nmajor || g.K != B || g.split_k > 1 || g.epi != 0 || g.bias) return false;
@@ -382,6 +408,7 @@ int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int b
   memset(&G, 0, sizeof(G));
   G.n = n; G.B = B; G.b3 = bf16x3;
   int total = 0;
+  bool any_panel = false;
   for (int k = 0; k < n; ++k) {
     const GemmArgs& g = list[k];
     if (!wgrad_supported(g, B)) { set_error("wgrad group: unsupported problem"); return SMX_ERR_INVALID; }
@@ -392,10 +419,44 @@ int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int b
     P.colsum = g.colsum; P.sq_part = g.sq_part;
     P.n_mt = (g.M + 31) / 32; P.n_nt = g.N / 32;
     P.start = total;
+    P.panel = (bf16x3 && g.M >= SMX_PANEL_MIN_WIDE && g.N <= 128 && getenv("SMX_NO_PANEL") == nullptr) ? 1 : 0;
+    if (P.panel) {
+      any_panel = true;
+      total += P.n_mt;
+      if (g.sq_part && g.sq_count) *g.sq_count = P.n_mt * 8;
+      continue;
+    }
     total += P.n_nt * ((P.n_mt + 7) / 8 * 8);
     if (g.sq_part && g.sq_count) *g.sq_count = P.n_mt * P.n_nt * 4;
   }
-  hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)total), dim3(512), 0, st, G);
+  if (any_panel) hipLaunchKernelGGL(wgrad_panel_group_kernel, dim3((unsigned)total), dim3(512), 0, st, G);
+  else hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)total), dim3(512), 0, st, G);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+
+// ---- the output head's dW / db at a wide panel (smx_panel.h, role 1): one workgroup per (gene tile, plane) ----------------
+__global__ __launch_bounds__(512, 4) void panel_dw_kernel(PanelProblem P) {   // (4 waves per SIMD: 128 registers, two workgroups per CU)
+  __shared__ __attribute__((aligned(16))) float smem[SMX_PANEL_SMEM_FLOATS];
+  panel_body<1, 0>(P, (int)blockIdx.x, smem);
+}
+
+bool panel_dw_supported(const HeadBwdArgs& a) {
+  return !a.sep && a.B > 0 && a.Hp % 32 == 0 && a.Hp <= 128 && a.Gp % 32 == 0 && a.Gp >= SMX_PANEL_MIN_WIDE &&
+         a.n_planes >= 1 && a.n_planes <= 3 && getenv("SMX_NO_PANEL") == nullptr;
+}
+
+int launch_panel_dw(hipStream_t st, const HeadBwdArgs& a) {
+  if (!panel_dw_supported(a) || !a.D || !a.dP || !a.dW || !a.db) { set_error("panel_dw: bad shapes"); return SMX_ERR_INVALID; }
+  PanelProblem P;
+  P.big = a.dP; P.ld_big = a.ldp; P.sub_stride = a.Gp; P.n_sub = a.n_planes;
+  P.S = a.D; P.ldS = a.ldd; P.n_st = a.Hp / 32;
+  P.out = a.dW; P.ld_out = a.ldw; P.big_colsum = a.db; P.sq_part = a.sq_part;
+  P.n_wt = a.Gp / 32; P.B = a.B;
+  const int total = P.n_wt * P.n_sub;
+  if (a.sq_part && a.sq_count) *a.sq_count = total * 8;
+  hipLaunchKernelGGL(panel_dw_kernel, dim3((unsigned)total), dim3(512), 0, st, P);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }

@@ -494,9 +494,26 @@ struct WgradProblem {
   float* C; int ldc; int M, N;
   float* colsum; float* sq_part;
   int start, n_mt, n_nt;
+  int panel;   // a wide M (a gene panel) with N <= 128: one workgroup per 32 rows with every column tile (smx_panel.h, role 0)
 };
 struct WgradGroup { int n; int B; int b3; WgradProblem p[SMX_GROUP_MAX]; };   // b3: bf16 x 3 MFMAs (smx_device.h)
 bool wgrad_supported(const GemmArgs& g, int B);
+
+// ---- minibatch-contracted weight gradients of a wide panel: one workgroup per 32 entries of the wide axis (smx_panel.h) ----
+#define SMX_PANEL_MIN_WIDE 4096   // entries of the wide axis from which the panel form replaces the 32 x 32-tile kernels
+struct PanelProblem {
+  const void* big = nullptr; long ld_big = 0;      // the panel [cells][wide entries] (float32, or the uint16 count store: big_mode 2)
+  int big_mode = 0, log1p = 0; const int32_t* rows = nullptr;   // gather by row id (nullptr: identity), log1p on the way
+  long sub_stride = 0; int n_sub = 1;              // role 1: planes of the head (offset of plane p in the panel's AND the output's columns)
+  const float* S = nullptr; int ldS = 0; int n_st = 0;          // narrow operand [cells][ldS]: n_st <= 4 tiles of 32 columns
+  float* out = nullptr; long ld_out = 0;           // role 0: [wide][ld_out]; role 1: [32 n_st][ld_out]
+  float* big_colsum = nullptr;                     // column sums of the panel over the cells (role 1: the bias gradient) or nullptr
+  float* s_colsum = nullptr;                       // column sums of S (role 0: the layer's bias gradient) or nullptr
+  float* sq_part = nullptr;                        // 8 sum-of-squares slots per workgroup or nullptr
+  int n_wt = 0; int B = 0;                         // tiles of the wide axis; cells
+};
+bool panel_dw_supported(const HeadBwdArgs& a);
+int launch_panel_dw(hipStream_t st, const HeadBwdArgs& a);   // the output head's dW / db (role 1) in place of launch_out_head_bwd's role 0
 int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int bf16x3 = 0);
 
 // ---- FactorVAE discriminator (smx_factor.hip; sisua/models/fvae.py:9-18, Kim & Mnih 2018 Algorithm 2) -------------

@@ -844,7 +844,10 @@ int backward_pass(smx_model* m, const Pass& ps) {
       }
     }
     hb.skip_dd = dd_bigk ? 1 : 0;
-    if (!(hb.skip_dw && hb.skip_dd)) SMX_CHECK(launch_out_head_bwd(m->st, hb));
+    // ... and then d W / d b with one workgroup per (gene tile, plane) that holds every row of H (smx_panel.h): the panel is
+    // transformed and split once, not once per 32 rows of H
+    if (dd_bigk && panel_dw_supported(hb)) SMX_CHECK(launch_panel_dw(m->st, hb));
+    else if (!(hb.skip_dw && hb.skip_dd)) SMX_CHECK(launch_out_head_bwd(m->st, hb));
   }
   {
     // weight gradient and input gradient of every head read the same dP and are independent:

@@ -57,7 +57,10 @@ CASES = {
                       encl_units=(32, 24)),
     "paper_shape": dict(model="vae", n_genes=1998, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=32),
     # wide panels (>= 4096 padded genes): with flag bf16x3 the products that contract over the gene axis run as one workgroup
-    # per K slice + a reduce launch (smx_bigk.hip), d W of a 128-wide head as the gene-tile-owner kernel (smx_wide.hip)
+    # per K slice + a reduce launch (smx_bigk.hip), the products that contract over the minibatch (d W of the head, the first
+    # encoder layer's weight gradient) as one workgroup per 32 genes with every tile of H (smx_panel.h); without BatchNorm the
+    # layer has a bias, whose gradient is the panel form's column sum of the narrow operand; 96 units: three tiles of H
+    "wide_panel_nobn_96": dict(model="vae", n_genes=4128, likelihood="nb", enc_units=(96,), dec_units=(96,), latent_dim=8, batchnorm=False),
     "wide_panel_64": dict(model="vae", n_genes=4200, likelihood="zinb", enc_units=(64,), dec_units=(64,), latent_dim=10),
     "wide_panel_128": dict(model="vae", n_genes=4500, likelihood="nb", enc_units=(128,), dec_units=(128,), latent_dim=16),
 }
@@ -714,7 +717,7 @@ def test_predict_packs_every_label_plane(Engine, labels, S):
 
 @pytest.mark.parametrize("batch", [128, 100])
 @pytest.mark.parametrize("name", ["vae_zinb", "vae_nb_nobn", "vae_zinbd", "sisua", "scvi_zinbd", "scvi_nbd", "paper_shape", "wide_panel_64",
-                                  "wide_panel_128"])
+                                  "wide_panel_128", "wide_panel_nobn_96"])
 def test_bf16x3_products_match_oracle(Engine, name, batch):
   """The output head's training products (fused head, both products of its backward -- the scvi form with separate plane
   tensors included --, the first layer's weight gradient) formed from bf16 MFMAs on operands split three ways in registers
