@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "smx_internal.h"
 #include "smx_panel.h"
 #include "../../include/sisua_hip.h"
@@ -377,7 +379,8 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(WgradGroup G) {
 // The same group with wide problems in it (a gene panel as M, N <= 128): those take the panel form (smx_panel.h, role 0), one
 // workgroup per 32 rows with every column tile; the group's small problems keep the 32 x 32 tiles.  A kernel of its own: the
 // panel form's 128 registers would otherwise cap the occupancy of every launch of the tile kernel (48 registers).
-__global__ __launch_bounds__(512, 4) void wgrad_panel_group_kernel(WgradGroup G) {
+template <int ONE>
+__global__ __launch_bounds__(512, ONE ? 4 : 2) void wgrad_panel_group_kernel(WgradGroup G) {   // (one chunk: 128 registers, two workgroups per CU)
   __shared__ __attribute__((aligned(16))) float red[SMX_PANEL_SMEM_FLOATS];
   __shared__ float sqs[8];
   const WgradGroup& Gr = *(const WgradGroup*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -389,9 +392,9 @@ __global__ __launch_bounds__(512, 4) void wgrad_panel_group_kernel(WgradGroup G)
   pp.big = P.A; pp.ld_big = P.lda; pp.big_mode = P.a_mode; pp.log1p = P.a_mode ? P.log1p : 0; pp.rows = P.a_mode ? P.rows : nullptr;
   pp.S = P.Bm; pp.ldS = P.ldb; pp.n_st = P.n_nt; pp.out = P.C; pp.ld_out = P.ldc;
   pp.s_colsum = P.colsum; pp.sq_part = P.sq_part; pp.n_wt = P.n_mt; pp.B = Gr.B;
-  if (P.a_mode == 2) panel_body<0, 2>(pp, (int)blockIdx.x - P.start, red);
-  else if (P.a_mode == 1) panel_body<0, 1>(pp, (int)blockIdx.x - P.start, red);
-  else panel_body<0, 0>(pp, (int)blockIdx.x - P.start, red);
+  if (P.a_mode == 2) panel_body<0, 2, ONE>(pp, (int)blockIdx.x - P.start, P.panel, red);
+  else if (P.a_mode == 1) panel_body<0, 1, ONE>(pp, (int)blockIdx.x - P.start, P.panel, red);
+  else panel_body<0, 0, ONE>(pp, (int)blockIdx.x - P.start, P.panel, red);
 }
 
 bool wgrad_supported(const GemmArgs& g, int B) {
@@ -419,17 +422,18 @@ int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int b
     P.colsum = g.colsum; P.sq_part = g.sq_part;
     P.n_mt = (g.M + 31) / 32; P.n_nt = g.N / 32;
     P.start = total;
-    P.panel = (bf16x3 && g.M >= SMX_PANEL_MIN_WIDE && g.N <= 128 && getenv("SMX_NO_PANEL") == nullptr) ? 1 : 0;
+    P.panel = (bf16x3 && g.M >= SMX_PANEL_MIN_WIDE && g.N <= 128 && getenv("SMX_NO_PANEL") == nullptr) ? panel_grid(P.n_mt) : 0;
     if (P.panel) {
       any_panel = true;
-      total += P.n_mt;
+      total += P.panel;
       if (g.sq_part && g.sq_count) *g.sq_count = P.n_mt * 8;
       continue;
     }
     total += P.n_nt * ((P.n_mt + 7) / 8 * 8);
     if (g.sq_part && g.sq_count) *g.sq_count = P.n_mt * P.n_nt * 4;
   }
-  if (any_panel) hipLaunchKernelGGL(wgrad_panel_group_kernel, dim3((unsigned)total), dim3(512), 0, st, G);
+  if (any_panel && B <= 128) hipLaunchKernelGGL(wgrad_panel_group_kernel<1>, dim3((unsigned)total), dim3(512), 0, st, G);
+  else if (any_panel) hipLaunchKernelGGL(wgrad_panel_group_kernel<0>, dim3((unsigned)total), dim3(512), 0, st, G);
   else hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)total), dim3(512), 0, st, G);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
@@ -437,9 +441,18 @@ int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int b
 
 
 // ---- the output head's dW / db at a wide panel (smx_panel.h, role 1): one workgroup per (gene tile, plane) ----------------
-__global__ __launch_bounds__(512, 4) void panel_dw_kernel(PanelProblem P) {   // (4 waves per SIMD: 128 registers, two workgroups per CU)
+template <int ONE>
+__global__ __launch_bounds__(512, ONE ? 4 : 2) void panel_dw_kernel(PanelProblem P) {   // (one chunk: 4 waves per SIMD = 128 registers, two workgroups per CU)
   __shared__ __attribute__((aligned(16))) float smem[SMX_PANEL_SMEM_FLOATS];
-  panel_body<1, 0>(P, (int)blockIdx.x, smem);
+  panel_body<1, 0, ONE>(P, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+
+int panel_grid(int units) {
+  // the workgroups are resident two per CU (128 registers, 45 KB of LDS) and each walks units first, first + grid, ...: as
+  // many rounds as 512 workgroups need, then the grid that fills those rounds evenly (1875 units: 4 rounds of 469)
+  static const int cap = getenv("SMX_PANEL_GRID") ? std::max(atoi(getenv("SMX_PANEL_GRID")), 1) : 512;
+  const int rounds = (units + cap - 1) / cap;
+  return (units + rounds - 1) / std::max(rounds, 1);
 }
 
 bool panel_dw_supported(const HeadBwdArgs& a) {
@@ -456,7 +469,8 @@ int launch_panel_dw(hipStream_t st, const HeadBwdArgs& a) {
   P.n_wt = a.Gp / 32; P.B = a.B;
   const int total = P.n_wt * P.n_sub;
   if (a.sq_part && a.sq_count) *a.sq_count = total * 8;
-  hipLaunchKernelGGL(panel_dw_kernel, dim3((unsigned)total), dim3(512), 0, st, P);
+  if (a.B <= 128) hipLaunchKernelGGL(panel_dw_kernel<1>, dim3((unsigned)panel_grid(total)), dim3(512), 0, st, P);
+  else hipLaunchKernelGGL(panel_dw_kernel<0>, dim3((unsigned)panel_grid(total)), dim3(512), 0, st, P);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }

@@ -494,7 +494,7 @@ struct WgradProblem {
   float* C; int ldc; int M, N;
   float* colsum; float* sq_part;
   int start, n_mt, n_nt;
-  int panel;   // a wide M (a gene panel) with N <= 128: one workgroup per 32 rows with every column tile (smx_panel.h, role 0)
+  int panel;   // > 0: a wide M (a gene panel) with N <= 128 in the panel form (smx_panel.h, role 0): this many workgroups walk its 32-row tiles
 };
 struct WgradGroup { int n; int B; int b3; WgradProblem p[SMX_GROUP_MAX]; };   // b3: bf16 x 3 MFMAs (smx_device.h)
 bool wgrad_supported(const GemmArgs& g, int B);
@@ -512,6 +512,7 @@ struct PanelProblem {
   float* sq_part = nullptr;                        // 8 sum-of-squares slots per workgroup or nullptr
   int n_wt = 0; int B = 0;                         // tiles of the wide axis; cells
 };
+int panel_grid(int units);   // workgroups for `units` tiles: whole rounds of at most two per CU, evenly filled
 bool panel_dw_supported(const HeadBwdArgs& a);
 int launch_panel_dw(hipStream_t st, const HeadBwdArgs& a);   // the output head's dW / db (role 1) in place of launch_out_head_bwd's role 0
 int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int bf16x3 = 0);
