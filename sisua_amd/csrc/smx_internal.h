@@ -88,6 +88,10 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
 // Two products that share the A operand (same M, K, layout, gather transform) and the split factor, side by side along N
 // in ONE launch of the 32x32-K4 kernel (scvi: first layers of both encoders; the two / three output heads).
 int launch_gemm_dual(hipStream_t st, const GemmArgs& g1, const GemmArgs& g2, int* eff_split = nullptr);
+// Direct-operand bf16 x 3 form for mid-size products with a deep contraction axis (smx_dgemm.hip): A [M][K], B either layout,
+// bias / activation store paths as launch_gemm; split_k must be 1
+bool dgemm_supported(const GemmArgs& g);
+int launch_dgemm(hipStream_t st, const GemmArgs& g);
 // Heuristic split-K factor used by the model for K-heavy products.
 int suggest_split_k(int M, int N, int K);
 

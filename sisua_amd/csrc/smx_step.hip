@@ -23,6 +23,11 @@ static bool front_shapes_ok(smx_model* m, const Pass& ps) {
 }
 
 
+// the model's products run from bf16 MFMAs on three-way split operands (flag "bf16x3": -1 = by size, SMX_BF16X3_MIN_WORK)
+static bool b3_on(const smx_model* m, const Pass& ps) {
+  return m->flags.bf16x3 < 0 ? use_bf16x3((long)ps.B * m->Gp * m->k) : m->flags.bf16x3 != 0;
+}
+
 // twin: another MLP whose FIRST layer consumes the same input (scvi: the library encoder beside the encoder).  When the
 // shapes allow, both first layers run as ONE product launch and ONE BatchNorm launch (side by side along the output
 // columns); *twin_done tells the caller, who then continues the twin from its second layer (first_layer = 1).
@@ -111,7 +116,9 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     if (epi_act) {
       g.bias = P_(m, L.tBias); g.act = 1; g.leak = L.leak; g.C = L.out_buf; g.ldc = L.out_p; g.split_k = 1;
       Timed t(m, (i == 0 && in_is_x) ? label0 : "gemm_mlp_fwd");
-      SMX_CHECK(launch_gemm(m->st, g));
+      // a deep contraction (the discriminator's 1000-wide layers): the direct-operand bf16 x 3 form (smx_dgemm.hip)
+      if (b3_on(m, ps) && dgemm_supported(g) && getenv("SMX_NO_DGEMM") == nullptr) SMX_CHECK(launch_dgemm(m->st, g));
+      else SMX_CHECK(launch_gemm(m->st, g));
       in = L.out_buf; ld = L.out_p;
       continue;
     }
@@ -674,8 +681,15 @@ int factor_forward(smx_model* m, const Pass& ps, bool backward) {
 // One backward sweep of the discriminator over the first `rows` rows of the stacked batch with upstream `up`
 // [rows][32] on the logits.  with_grads: the discriminator's own gradients (its objective; nothing flows into z);
 // otherwise only d objective / d z, left in m->dz_tc (the VAE objective's TC term; the weights are constants of it).
-int factor_sweep(smx_model* m, int rows, const float* up, bool with_grads) {
+int factor_sweep(smx_model* m, const Pass& ps, int rows, const float* up, bool with_grads) {
   const MlpLayer& last = m->disc.back();
+  // flag bf16x3: the weight gradients (K = the stacked minibatch) through the direct-operand 32 x 32-tile kernel of
+  // smx_headbwd.hip, the 1000-deep input gradients through smx_dgemm.hip -- both from bf16 MFMAs on split operands
+  const bool b3 = b3_on(m, ps) && getenv("SMX_NO_DGEMM") == nullptr;
+  auto wgrad = [&](const GemmArgs& g) -> int {
+    if (b3 && m->flags.wgrad && wgrad_supported(g, rows)) return launch_wgrad_group(m->st, &g, 1, rows, 1);
+    return launch_gemm(m->st, g);
+  };
   const TensorInfo& two = m->tensors[m->t_discoutW];
   if (with_grads) {
     GemmArgs gw;
@@ -684,7 +698,7 @@ int factor_sweep(smx_model* m, int rows, const float* up, bool with_grads) {
     gw.colsum = G_(m, m->t_discoutb);
     want_sq(m, gw, m->t_discoutW);
     Timed t(m, "disc_bwd");
-    SMX_CHECK(launch_gemm(m->st, gw));
+    SMX_CHECK(wgrad(gw));
   }
   int n_slabs = 1;
   {
@@ -726,7 +740,7 @@ int factor_sweep(smx_model* m, int rows, const float* up, bool with_grads) {
       if (ready) g.colsum = G_(m, L.tBias);
       want_sq(m, g, L.tW);
       Timed t(m, "disc_bwd");
-      SMX_CHECK(launch_gemm(m->st, g));
+      SMX_CHECK(wgrad(g));
       if (i == 0) break;   // z is a constant of the discriminator's objective
     }
     GemmArgs h;
@@ -737,6 +751,7 @@ int factor_sweep(smx_model* m, int rows, const float* up, bool with_grads) {
     else {
       h.C = m->slab; h.ldc = L.in_p; h.slab_stride = (long)rows * L.in_p;
       h.split_k = suggest_split_k(rows, L.in_p, L.out_p);
+      if (b3) { GemmArgs probe = h; probe.split_k = 1; if (dgemm_supported(probe)) h.split_k = 1; }   // (the direct form splits K over its waves)
       SMX_REQUIRE((size_t)h.split_k * (size_t)h.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
       if (m->flags.act_epilogue && h.split_k <= 1 && (with_grads || pong[pp ^ 1] != dpre_i)) {
         MlpLayer& Lo = m->disc[i - 1];
@@ -748,7 +763,8 @@ int factor_sweep(smx_model* m, int rows, const float* up, bool with_grads) {
     }
     {
       Timed t(m, "disc_bwd");
-      SMX_CHECK(launch_gemm(m->st, h, &n_slabs));
+      if (b3 && dgemm_supported(h)) { SMX_CHECK(launch_dgemm(m->st, h)); n_slabs = 1; }
+      else SMX_CHECK(launch_gemm(m->st, h, &n_slabs));
     }
     if (ready) dpre_i = h.C;
   }
@@ -756,8 +772,8 @@ int factor_sweep(smx_model* m, int rows, const float* up, bool with_grads) {
 }
 
 int factor_backward(smx_model* m, const Pass& ps) {
-  SMX_CHECK(factor_sweep(m, 2 * ps.B, m->u_d, true));    // discriminator objective -> the discriminator's tensors
-  SMX_CHECK(factor_sweep(m, ps.B, m->u_tc, false));      // gamma TC (+ alpha CE) -> d z
+  SMX_CHECK(factor_sweep(m, ps, 2 * ps.B, m->u_d, true));    // discriminator objective -> the discriminator's tensors
+  SMX_CHECK(factor_sweep(m, ps, ps.B, m->u_tc, false));      // gamma TC (+ alpha CE) -> d z
   return SMX_OK;
 }
 
