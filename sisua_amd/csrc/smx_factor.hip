@@ -51,59 +51,64 @@ int launch_permute_dims(hipStream_t st, const PermuteArgs& a) {
   return SMX_OK;
 }
 
-// one thread per row of the stacked batch [z ; z_perm]
+__device__ inline float half_wave_max(float v) {
+#define SMX_DPP_MAX(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xF, 0xF, false)))
+  SMX_DPP_MAX(0xB1);
+  SMX_DPP_MAX(0x4E);
+  SMX_DPP_MAX(0x141);
+  SMX_DPP_MAX(0x140);
+#undef SMX_DPP_MAX
+  return fmaxf(v, __shfl_xor(v, 16, 64));
+}
+
+// one LANE per (row of the stacked batch [z ; z_perm], logit): the 32 lanes of a wave half are one row -- its slabs, the label
+// row and both upstream gradients move as coalesced 128-byte rows, and the row's log-sum-exp is a half-wave reduction.  (One
+// thread per row walked its 32 columns and the split-K slabs of each with strided 4-byte accesses: 12.7 us for a single
+// workgroup of latency.)
 __global__ __launch_bounds__(256) void disc_head_kernel(DiscHeadArgs a) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= 2 * a.B) return;
-  float l[32];
-  float mx = -3.0e38f;
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    float v = 0.f;
-    if (j < a.n_out) {
-      v = a.bias[j];
-      for (int s = 0; s < a.n_slabs; ++s) v += a.logits[(long)s * a.slab_stride + (long)r * a.ld + j];
-      mx = fmaxf(mx, v);
-    }
-    l[j] = v;
+  const int r = blockIdx.x * 8 + (threadIdx.x >> 5), j = threadIdx.x & 31;
+  if (r >= 2 * a.B) return;   // (whole half-waves leave together)
+  const bool live = j < a.n_out;
+  float l = 0.f;
+  if (live) {
+    l = a.bias[j];
+    for (int s = 0; s < a.n_slabs; ++s) l += a.logits[(long)s * a.slab_stride + (long)r * a.ld + j];
   }
-  float se = 0.f;
-#pragma unroll
-  for (int j = 0; j < 32; ++j) if (j < a.n_out) se += expf(l[j] - mx);
+  const float mx = half_wave_max(live ? l : -3.0e38f);
+  const float se = half_wave_sum(live ? expf(l - mx) : 0.f);
   const float d = mx + logf(se);
   const bool real = r < a.B;
-  if (real) a.tc_cell[r] = d;
-  a.dl_cell[r] = 0.5f * softplusf(real ? -d : d);
-  float mk = 0.f, ysum = 0.f, ce = 0.f;
-  const float* y = nullptr;
-  if (real && a.Y) {
+  if (j == 0) {
+    if (real) a.tc_cell[r] = d;
+    a.dl_cell[r] = 0.5f * softplusf(real ? -d : d);
+  }
+  float mk = 0.f, ysum = 0.f, yj = 0.f;
+  const bool sup = real && a.Y;
+  if (sup) {
     const long row = a.rows ? a.rows[r] : r;
     mk = (a.mask && a.mask[row]) ? 1.f : 0.f;
-    y = a.Y + row * a.ldy;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) if (j < a.n_out) { ysum += y[j]; ce -= y[j] * (l[j] - d); }
-    a.llk_y[r] = -mk * ce;
-  } else if (real && a.llk_y) a.llk_y[r] = 0.f;
+    yj = live ? a.Y[row * a.ldy + j] : 0.f;
+    ysum = half_wave_sum(yj);
+    const float ce = -half_wave_sum(live ? yj * (l - d) : 0.f);
+    if (j == 0) a.llk_y[r] = -mk * ce;
+  } else if (real && a.llk_y && j == 0) a.llk_y[r] = 0.f;
   if (!a.backward) return;
   // d J_d / d d(row): -1/2 sigmoid(-d) on the rows of z, +1/2 sigmoid(d) on the permuted rows (means over the global batch)
   const float gd = (real ? -0.5f / (1.f + expf(d)) : 0.5f / (1.f + expf(-d))) * a.inv_gb;
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    float ut = 0.f, ud = 0.f;
-    if (j < a.n_out) {
-      const float sm = expf(l[j] - d);                                        // softmax = d logsumexp / d logit (1 for one logit)
-      const float sup = (y != nullptr) ? a.alpha * a.inv_gb * mk * (sm * ysum - y[j]) : 0.f;
-      ut = a.gamma * a.inv_gb * sm + sup;
-      ud = gd * sm + sup;
-    }
-    if (real) a.u_tc[(long)r * 32 + j] = ut;
-    a.u_d[(long)r * 32 + j] = ud;
+  float ut = 0.f, ud = 0.f;
+  if (live) {
+    const float sm = expf(l - d);                                        // softmax = d logsumexp / d logit (1 for one logit)
+    const float su = sup ? a.alpha * a.inv_gb * mk * (sm * ysum - yj) : 0.f;
+    ut = a.gamma * a.inv_gb * sm + su;
+    ud = gd * sm + su;
   }
+  if (real) a.u_tc[(long)r * 32 + j] = ut;
+  a.u_d[(long)r * 32 + j] = ud;
 }
 
 int launch_disc_head(hipStream_t st, const DiscHeadArgs& a) {
   if (a.B <= 0 || a.n_out < 1 || a.n_out > 32 || a.ld < a.n_out) { set_error("disc_head: bad shapes"); return SMX_ERR_INVALID; }
-  hipLaunchKernelGGL(disc_head_kernel, dim3((2 * a.B + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(disc_head_kernel, dim3((2 * a.B + 7) / 8), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
