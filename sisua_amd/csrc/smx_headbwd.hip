@@ -32,7 +32,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // either role a lane's loads are runs of 8 consecutive k, i.e. whole operands of v_mfma_f32_32x32x16_bf16
 template <int NP, int SEP = 0, int B3 = 0>
 __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
-  __shared__ float red[8 * 1024];   // ONE plane's eight partial tiles at a time (32 KB: two workgroups per CU, not one)
+  // ONE plane's eight partial tiles at a time (32 KB); the bf16 form's role 1 turns its operands through wave-private tiles
+  // first (2 x 8 x 32 x 36 floats = 72 KB, the partial tiles then go over them): two workgroups per CU either way
+  __shared__ __attribute__((aligned(16))) float red[B3 ? 2 * 8 * 32 * 36 : 8 * 1024];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = lane & 31, hh = lane >> 5;
   // accumulator register r of a 32 x 32 tile is row (r & 3) + 8 (r >> 2) + 4 hh, column i; wave q finishes r = 2q, 2q + 1
@@ -162,6 +164,65 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if constexpr (B3) {
+    // Both operands are k-contiguous rows (dP's cells, W's rows of H).  They are read COALESCED -- 8 lanes per 128-byte line, 4
+    // loads of 16 bytes per lane and round of 32 k -- and turned into MFMA operand vectors (row i, 8 consecutive k per lane)
+    // through a tile in LDS that is private to the wave; the waves walk their k = kbeg + 32 q, + 256, ... independently, the
+    // next round's loads in flight under the current one's products (smx_dgemm.hip has the measurement behind this: a lane
+    // reading its own row's line in 16-byte pieces, the f32 form below, sends every piece to L2 again)
+    constexpr int LD = 36;
+    const int qs = __builtin_amdgcn_readfirstlane(q);
+    float* ta = red + qs * (32 * LD);
+    float* tb = red + (8 + qs) * (32 * LD);
+    const int lr = lane >> 3, lc = lane & 7;
+    const float* arow[4];
+    long wrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      arow[j] = Ab + (long)min(m0 + 8 * j + lr, a.B - 1) * lda_b + 4 * lc;   // rows beyond the minibatch compute garbage that nobody reads
+      wrow[j] = (long)(h0 + 8 * j + lr) * ((SEP && !extra) ? a.ldw : ldw_b) + 4 * lc;
+    }
+    float4 a0, a1, a2, a3, b0, b1, b2, b3;
+    auto load_round = [&](long kb) {
+      const float* wb = Wb;
+      long kw = kb;
+      if (SEP && !extra) {   // the plane of this round's 32 k (Gp is a multiple of 32: never straddled; wave-uniform)
+        const int pl = (int)(kb / a.Gp);
+        wb = pl == 0 ? a.Wp[0] : (pl == 1 ? a.Wp[1] : a.Wp[2]);
+        kw = kb - (long)pl * a.Gp;
+      }
+      a0 = *reinterpret_cast<const float4*>(arow[0] + kb); a1 = *reinterpret_cast<const float4*>(arow[1] + kb);
+      a2 = *reinterpret_cast<const float4*>(arow[2] + kb); a3 = *reinterpret_cast<const float4*>(arow[3] + kb);
+      b0 = *reinterpret_cast<const float4*>(wb + wrow[0] + kw); b1 = *reinterpret_cast<const float4*>(wb + wrow[1] + kw);
+      b2 = *reinterpret_cast<const float4*>(wb + wrow[2] + kw); b3 = *reinterpret_cast<const float4*>(wb + wrow[3] + kw);
+    };
+    float* wa = ta + lr * LD + 4 * lc;
+    float* wbt = tb + lr * LD + 4 * lc;
+    if (kbeg + 32 * qs < kend) load_round(kbeg + 32 * qs);
+    for (long kb = kbeg + 32 * qs; kb < kend; kb += 256) {   // kend - kbeg is a multiple of 32: a wave's 32 k are all in
+      *reinterpret_cast<float4*>(wa) = a0; *reinterpret_cast<float4*>(wa + 8 * LD) = a1;
+      *reinterpret_cast<float4*>(wa + 16 * LD) = a2; *reinterpret_cast<float4*>(wa + 24 * LD) = a3;
+      *reinterpret_cast<float4*>(wbt) = b0; *reinterpret_cast<float4*>(wbt + 8 * LD) = b1;
+      *reinterpret_cast<float4*>(wbt + 16 * LD) = b2; *reinterpret_cast<float4*>(wbt + 24 * LD) = b3;
+      if (kb + 256 < kend) load_round(kb + 256);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {   // step t: lane (i, hh) supplies k = 16 t + 8 hh + s of the wave's 32, for both operands
+        const float* pa = ta + i * LD + 16 * t + 8 * hh;
+        const float* pb = tb + i * LD + 16 * t + 8 * hh;
+        const float4 x0 = *reinterpret_cast<const float4*>(pa), x1 = *reinterpret_cast<const float4*>(pa + 4);
+        const float4 y0 = *reinterpret_cast<const float4*>(pb), y1 = *reinterpret_cast<const float4*>(pb + 4);
+        const float ax[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const float bx[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+        acc = mfma_bf16x3(split3x8(ax), split3x8(bx), acc);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // the reads are done before the next round overwrites the tile
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();   // every wave is done with its operand tiles: the partial tiles go over them
+  } else {
   const int cell = min(m0 + i, a.B - 1);       // rows beyond the minibatch compute garbage that nobody reads
   const float* ap = Ab + (long)cell * lda_b;
   const float* bp = (SEP && !extra) ? a.Wp[0] : Wb + (long)(h0 + i) * ldw_b;
@@ -204,6 +265,7 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v].w * m, b4[v].w, acc, 0, 0, 0);
       }
     }
+  }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[(q * 16 + r) * 64 + lane] = acc[r];
