@@ -484,7 +484,7 @@ int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int b
     P.colsum = g.colsum; P.sq_part = g.sq_part;
     P.n_mt = (g.M + 31) / 32; P.n_nt = g.N / 32;
     P.start = total;
-    P.panel = (bf16x3 && g.M >= SMX_PANEL_MIN_WIDE && g.N <= 128 && getenv("SMX_NO_PANEL") == nullptr) ? panel_grid(P.n_mt) : 0;
+    P.panel = (bf16x3 && (g.M >= SMX_PANEL_MIN_WIDE || g.panel_hint) && g.N <= 128 && getenv("SMX_NO_PANEL") == nullptr) ? panel_grid(P.n_mt) : 0;
     if (P.panel) {
       any_panel = true;
       total += P.panel;

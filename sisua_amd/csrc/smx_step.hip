@@ -687,8 +687,24 @@ int factor_sweep(smx_model* m, const Pass& ps, int rows, const float* up, bool w
   // smx_headbwd.hip, the 1000-deep input gradients through smx_dgemm.hip -- both from bf16 MFMAs on split operands
   const bool b3 = b3_on(m, ps) && getenv("SMX_NO_DGEMM") == nullptr;
   auto wgrad = [&](const GemmArgs& g) -> int {
-    if (b3 && m->flags.wgrad && wgrad_supported(g, rows)) return launch_wgrad_group(m->st, &g, 1, rows, 1);
-    return launch_gemm(m->st, g);
+    if (!(b3 && m->flags.wgrad && wgrad_supported(g, rows))) return launch_gemm(m->st, g);
+    // a square 1000 x 1000 gradient: as up to 8 column groups of 128 in the panel form (smx_panel.h role 0: a workgroup takes 32
+    // rows with the group's four column tiles -- the A tile is split once per group instead of once per 32 columns)
+    if (g.M >= 512 && g.N % 128 == 0 && g.N / 128 <= SMX_GROUP_MAX && g.N > 128 && getenv("SMX_NO_PANEL") == nullptr) {
+      GemmArgs part[SMX_GROUP_MAX];
+      int counts[SMX_GROUP_MAX];
+      const int ng = g.N / 128, per = ((g.M + 31) / 32) * 8;
+      for (int k = 0; k < ng; ++k) {
+        part[k] = g;
+        part[k].B = g.B + 128 * k; part[k].C = g.C + 128 * k; part[k].N = 128; part[k].panel_hint = 1;
+        if (g.colsum) part[k].colsum = g.colsum + 128 * k;
+        if (g.sq_part) { part[k].sq_part = g.sq_part + (long)per * k; part[k].sq_count = &counts[k]; }
+      }
+      const int rc = launch_wgrad_group(m->st, part, ng, rows, 1);
+      if (rc == SMX_OK && g.sq_part && g.sq_count) *g.sq_count = per * ng;
+      return rc;
+    }
+    return launch_wgrad_group(m->st, &g, 1, rows, 1);
   };
   const TensorInfo& two = m->tensors[m->t_discoutW];
   if (with_grads) {

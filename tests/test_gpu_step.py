@@ -45,10 +45,13 @@ CASES = {
                  disc_layers=3),
     "semifvae": dict(model="fvae", n_genes=120, likelihood="nb", enc_units=(40,), dec_units=(40,), latent_dim=7, disc_units=70,
                      disc_layers=2, labels=((6, "onehot"),), gamma=3.0),
-    # a discriminator as deep as odin's default (1000 units: here 600, padded to 608): its layers' forward products and input
-    # gradients take the direct-operand bf16 x 3 form of smx_dgemm.hip (K >= 512), the weight gradients the 32 x 32-tile kernel
-    "fvae_deep_disc": dict(model="fvae", n_genes=96, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=6, disc_units=600,
+    # a discriminator as deep as odin's default (1000 units: here 640 and 600, the latter padded to 608): its layers' forward
+    # products and input gradients take the bf16 x 3 form of smx_dgemm.hip (K >= 512); the square weight gradients the panel form
+    # of smx_panel.h in column groups of 128 (640 = 5 groups) or, when the width is no multiple of 128, the 32 x 32-tile kernel
+    "fvae_deep_disc": dict(model="fvae", n_genes=96, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=6, disc_units=640,
                            disc_layers=3),
+    "fvae_deep_disc_608": dict(model="fvae", n_genes=96, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=6, disc_units=600,
+                               disc_layers=2),
     "scvi_zinbd": dict(model="scvi", n_genes=160, likelihood="zinbd", enc_units=(48,), dec_units=(48,), latent_dim=6,
                        encl_units=(16,)),
     "scvi_nbd": dict(model="scvi", n_genes=96, likelihood="nbd", enc_units=(32,), dec_units=(32,), latent_dim=4,
