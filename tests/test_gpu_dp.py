@@ -327,7 +327,7 @@ def test_world8_c4_split_matches_oracle(Engine, sync_bn):
     e.close()
 
 
-@pytest.mark.parametrize("sync_bn", [True])   # (the C4 split above runs both forms; at this width the oracle's eight ranks cost 5 s each way)
+@pytest.mark.parametrize("sync_bn", [False])   # (bench.py's mode; the C4 split above runs both forms -- at this width the oracle's eight ranks cost 5 s each way)
 def test_world8_c5_split_matches_oracle(Engine, sync_bn):
   """BASELINE configs[4]'s per-step shape: global batch 1024 = 8 ranks x 128 cells x 20 000 genes (a 256-cell slice resident
   per rank, uint16 store, each rank's cells generated from (seed, rank) as bench.py's c5-shard does); one optimiser step against
