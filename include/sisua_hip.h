@@ -369,7 +369,9 @@ int smx_k_count_llk(int likelihood, int direct, const float* x, const float* pla
 int smx_k_adam(int32_t n_tensors, const int32_t* sizes, float* params, const float* grads, float* m, float* v,
                int32_t step, float lr, float beta1, float beta2, float eps, float clipnorm, float* norms);
 /* C[M,N] = op(A) * op(B) in fp32 on the MFMA path; transA: A given as [K,M];
- * transB: B given as [N,K]; split_k >= 1 (slabs summed on return). */
+ * transB: B given as [N,K]; split_k >= 1 (slabs summed on return).  tile_cfg 0: the library's choice of LDS tile; 100: the
+ * direct bf16 x 3 form for deep contractions (transA = 0, K >= 512); 101 / 102: the minibatch-contracted weight-gradient forms
+ * (transA = 1, transB = 0; 32 x 32 tiles / the gene-tile-owner panel form, N <= 128) -- test entries for those kernels. */
 int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M, int32_t N, int32_t K,
                int32_t split_k, int32_t tile_cfg, float* C);
 /* Philox words / dropout multipliers / normals exactly as the kernels draw them. */

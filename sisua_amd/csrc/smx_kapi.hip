@@ -115,9 +115,15 @@ int smx_k_adam(int32_t n_tensors, const int32_t* sizes, float* params, const flo
 int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M, int32_t N, int32_t K, int32_t split_k,
                int32_t tile_cfg, float* C) {
   SMX_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "bad arguments");
+  // tile_cfg 100 / 101 / 102: the bf16 x 3 forms outside the LDS-tiled kernel -- smx_dgemm.hip (A [M][K]; K padded to 32 with
+  // zeros), the 32 x 32-tile weight-gradient kernel and the panel form of smx_panel.h (both: A [K][M], Bm [K][N], M padded to 32)
+  const bool direct = tile_cfg == 100, wg = tile_cfg == 101 || tile_cfg == 102;
+  SMX_REQUIRE(!direct || !transA, "tile 100 (dgemm) takes A as [M][K]");
+  SMX_REQUIRE(!wg || (transA && !transB), "tiles 101 / 102 (weight-gradient forms) take A as [K][M] and B as [K][N]");
+  SMX_REQUIRE(tile_cfg != 102 || N <= 128, "tile 102 (panel form): N <= 128");
   // pad to the library's internal conventions: feature axes to 32, batch axes free
   const int Np = round_up(N, 32);
-  const int Kp = round_up(K, 4), Mp = round_up(M, 4);
+  const int Kp = direct ? round_up(K, 32) : round_up(K, 4), Mp = wg ? round_up(M, 32) : round_up(M, 4);
   const int lda = transA ? Mp : Kp, a_rows = transA ? K : M, a_cols = transA ? M : K;
   const int ldb = transB ? Kp : Np, b_rows = transB ? N : K, b_cols = transB ? K : N;
   float *dA = nullptr, *dB = nullptr, *dC = nullptr;
@@ -136,8 +142,17 @@ int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M
   int eff = 1;
   // rows of C beyond M (when M was padded for k-major A) are never stored: allocate for Mp
   if (transA && Mp != M) { hipFree(dC); dC = nullptr; if ((rc = dmalloc(&dC, (size_t)S * Mp * Np))) return rc; g.C = dC; g.slab_stride = (long)Mp * Np; }
+  if (direct) {
+    g.K = Kp;   // (the padding of A and B is zero: dmalloc clears)
+    SMX_REQUIRE(dgemm_supported(g), "tile 100 (dgemm): K >= 512 after padding to 32, split_k = 1");
+    rc = launch_dgemm(nullptr, g);
+  } else if (wg) {
+    g.split_k = 1; g.panel_hint = tile_cfg == 102;
+    SMX_REQUIRE(S == 1 && wgrad_supported(g, K), "tiles 101 / 102: split_k = 1");
+    rc = launch_wgrad_group(nullptr, &g, 1, K, 1);
+  } else
   rc = launch_gemm(nullptr, g, &eff);
-  if (rc == SMX_OK && getenv("SMX_KGEMM_REPS")) {  // diagnostic: average launch time of this shape / tile
+  if (rc == SMX_OK && getenv("SMX_KGEMM_REPS") && !direct && !wg) {  // diagnostic: average launch time of this shape / tile
     const int reps = atoi(getenv("SMX_KGEMM_REPS"));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);

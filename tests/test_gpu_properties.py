@@ -51,6 +51,34 @@ def test_products_on_arbitrary_shapes(eng, M, N, K, layout, split, seed):
 
 
 @SET
+@given(M=st.integers(1, 300), N=st.integers(1, 200), K=st.integers(481, 1400), trans_b=st.booleans(), seed=st.integers(0, 10**6))
+def test_deep_products_bf16x3_on_arbitrary_shapes(eng, M, N, K, trans_b, seed):
+  """smx_dgemm.hip (tile code 100): K split over a workgroup's waves in rounds of 32 (any multiple of 32 after padding: waves
+  without a round, partial last rounds), ragged M, both layouts of B; bf16 MFMAs on three-way split operands -- one f32 rounding
+  per product, so the same tolerance as the exact-f32 kernels."""
+  rng = np.random.default_rng(seed)
+  A = rng.normal(size=(M, K)).astype(np.float32)
+  B = rng.normal(size=(N, K) if trans_b else (K, N)).astype(np.float32)
+  ref = A.astype(np.float64) @ (B.T if trans_b else B).astype(np.float64)
+  out = eng.k_gemm(A, B, False, trans_b, split_k=1, tile=100)
+  assert np.allclose(out, ref, rtol=2e-5, atol=2e-4 * np.sqrt(K)), (M, N, K, trans_b, np.abs(out - ref).max())
+
+
+@SET
+@given(M=st.integers(1, 260), N=st.integers(1, 128), K=st.integers(1, 300), panel=st.booleans(), seed=st.integers(0, 10**6))
+def test_weight_gradient_forms_on_arbitrary_shapes(eng, M, N, K, panel, seed):
+  """C = A^T B over a ragged minibatch axis K (1 .. 300 cells: one, two and three chunks of 128, the raw buffer loads' range
+  check standing in for masks) in the 32 x 32-tile kernel (tile code 101) and the gene-tile-owner panel form (102: every
+  column tile in one workgroup, workgroups walking several row tiles)."""
+  rng = np.random.default_rng(seed)
+  A = rng.normal(size=(K, M)).astype(np.float32)
+  B = rng.normal(size=(K, N)).astype(np.float32)
+  ref = A.T.astype(np.float64) @ B.astype(np.float64)
+  out = eng.k_gemm(A, B, True, False, split_k=1, tile=102 if panel else 101)
+  assert np.allclose(out, ref, rtol=2e-5, atol=2e-4 * np.sqrt(K)), (M, N, K, panel, np.abs(out - ref).max())
+
+
+@SET
 @given(B=st.integers(1, 40), G=st.integers(1, 700), lk=st.sampled_from(so.LIKELIHOODS), seed=st.integers(0, 10**6), zero_frac=st.floats(0.0, 1.0))
 def test_count_likelihood_on_arbitrary_shapes(eng, B, G, lk, seed, zero_frac):
   rng = np.random.default_rng(seed)
