@@ -195,10 +195,15 @@ int smx_train_step(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metr
 /* Same arithmetic, launched as one captured hipGraph (fixed batch size). */
 int smx_train_step_graph(smx_model* m, const int32_t* row_ids, int32_t batch, smx_metrics* out);
 /* Queue `n_steps` steps whose row ids are order[s*batch .. (s+1)*batch); no host
- * sync between steps.  `out` (may be NULL) receives the last step's metrics; a non-finite loss or gradient
+ * sync between steps (order = NULL: the ids staged by smx_train_stage).  `out` (may be NULL) receives the last step's metrics; a non-finite loss or gradient
  * norm is reported through out->nan_flag with status SMX_OK (terminate_on_nan is the caller's decision). */
 int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t batch, int use_graph,
                     smx_metrics* out);
+/* The row ids of the NEXT smx_train_steps call made resident ahead of it: that call is then given order = NULL (same
+ * n_steps and batch) and queues its steps without the host-to-device copy of the ids -- the minibatch schedule of an epoch is
+ * input data like the matrix itself (an input pipeline's prefetch; single_cell_model.py:213-236 iterates a prepared
+ * tf.data stream).  The staged ids serve ONE call. */
+int smx_train_stage(smx_model* m, const int32_t* order, int32_t n_steps, int32_t batch);
 /* ELBO scalars of EVERY step of the last smx_train_steps call, kept on the device while the steps ran (no host
  * sync between them): host [n_steps][8] = (loss, nllk_x, nllk_y, kl, kl_l, 0, 0, 0) per step, global-minibatch
  * means.  Feeds the per-epoch train_history of SingleCellModel.fit (tests/test_singlecell_models.py:28-32 of the

@@ -87,6 +87,7 @@ SIGNATURES = {
     "smx_train_step": (C.c_int, [_VP, _IP, C.c_int32, C.POINTER(smx_metrics)]),
     "smx_train_step_graph": (C.c_int, [_VP, _IP, C.c_int32, C.POINTER(smx_metrics)]),
     "smx_train_steps": (C.c_int, [_VP, _IP, C.c_int32, C.c_int32, C.c_int, C.POINTER(smx_metrics)]),
+    "smx_train_stage": (C.c_int, [_VP, _IP, C.c_int32, C.c_int32]),
     "smx_metrics_history": (C.c_int, [_VP, C.c_int32, _FP]),
     "smx_eval_step": (C.c_int, [_VP, _IP, C.c_int32, C.POINTER(smx_metrics)]),
     "smx_forward": (C.c_int, [_VP, _IP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP,

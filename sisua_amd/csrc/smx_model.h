@@ -204,6 +204,7 @@ struct smx_model {
   // step state
   int32_t* rows2[2] = {nullptr, nullptr}; int32_t* order = nullptr; size_t order_cap = 0;
   float* mhist = nullptr; size_t mhist_cap = 0; int32_t mhist_steps = 0;   // ELBO scalars of every step of the last train_steps call
+  int32_t staged_steps = 0, staged_batch = 0;   // row ids made resident by smx_train_stage for the next smx_train_steps(order = NULL)
   StepState* state3 = nullptr;  // [0],[1]: per-step state by parity, [2]: master counter
   int par = 0; uint32_t h_next = 0;
   MetricsArgs pending_metrics; bool have_pending_metrics = false, metrics_before_allreduce = false;

@@ -1287,15 +1287,29 @@ int smx_train_step_graph(smx_model* m, const int32_t* row_ids, int32_t batch, sm
 }
 
 int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t batch, int use_graph, smx_metrics* out) {
-  SMX_REQUIRE(m && order && n_steps > 0, "bad arguments");
+  SMX_REQUIRE(m && n_steps > 0, "bad arguments");
   SMX_REQUIRE(batch > 0 && batch <= m->Bmax, "batch must be in 1..max_batch");
-  SMX_CHECK(check_rows(m, order, (size_t)n_steps * batch));
-  SMX_CHECK(upload_order(m, order, (size_t)n_steps * batch, (size_t)n_steps));
+  if (order) {
+    SMX_CHECK(check_rows(m, order, (size_t)n_steps * batch));
+    SMX_CHECK(upload_order(m, order, (size_t)n_steps * batch, (size_t)n_steps));
+  } else {
+    SMX_REQUIRE(m->staged_steps == n_steps && m->staged_batch == batch, "order = NULL: no ids staged for this n_steps x batch (smx_train_stage)");
+  }
+  m->staged_steps = 0;   // (staged ids serve one call)
   for (int s = 0; s < n_steps; ++s) SMX_CHECK(launch_train(m, batch, use_graph != 0, s, n_steps));
   if (m->use_injected) { m->use_injected = false; }
   // a non-finite loss / gradient norm is REPORTED (out->nan_flag), not an error of the call: terminate_on_nan
   // (configs/base.yaml:59) is the caller's decision
   SMX_CHECK(read_metrics(m, out));
+  return SMX_OK;
+}
+
+int smx_train_stage(smx_model* m, const int32_t* order, int32_t n_steps, int32_t batch) {
+  SMX_REQUIRE(m && order && n_steps > 0, "bad arguments");
+  SMX_REQUIRE(batch > 0 && batch <= m->Bmax, "batch must be in 1..max_batch");
+  SMX_CHECK(check_rows(m, order, (size_t)n_steps * batch));
+  SMX_CHECK(upload_order(m, order, (size_t)n_steps * batch, (size_t)n_steps));
+  m->staged_steps = n_steps; m->staged_batch = batch;
   return SMX_OK;
 }
 

@@ -229,13 +229,24 @@ class Engine:
     return m.as_dict() if metrics else None
 
   def train_steps(self, order, n_steps: int, batch: int, graph: bool = True, metrics: bool = False):
+    """order = None: the row ids made resident by stage_steps(order, n_steps, batch) (no host-to-device copy in this call)."""
+    if order is None:
+      ptr = None
+    else:
+      ids = self._ids(order)
+      if ids.size != n_steps * batch:
+        raise ValueError("order must hold n_steps * batch row ids")
+      ptr = ids.ctypes.data_as(C.POINTER(C.c_int32))
+    m = smx_metrics()
+    check(self.lib.smx_train_steps(self._h, ptr, int(n_steps), int(batch), int(graph), C.byref(m) if metrics else None))
+    return m.as_dict() if metrics else None
+
+  def stage_steps(self, order, n_steps: int, batch: int):
+    """The next train_steps call's row ids, uploaded ahead of it (an input pipeline's prefetch)."""
     ids = self._ids(order)
     if ids.size != n_steps * batch:
       raise ValueError("order must hold n_steps * batch row ids")
-    m = smx_metrics()
-    check(self.lib.smx_train_steps(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), int(n_steps), int(batch),
-                                   int(graph), C.byref(m) if metrics else None))
-    return m.as_dict() if metrics else None
+    check(self.lib.smx_train_stage(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), int(n_steps), int(batch)))
 
   def metrics_history(self, n_steps: int) -> Dict[str, np.ndarray]:
     """Per-step ELBO scalars of the last train_steps call: dict of arrays [n_steps]."""

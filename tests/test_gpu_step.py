@@ -354,6 +354,39 @@ def test_graph_and_eager_are_bitwise_identical(Engine):
     assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
+def test_staged_row_ids_equal_passed_row_ids(Engine):
+  """smx_train_stage: the row ids of the next train_steps call uploaded ahead of it (bench.py stages the timed steps' ids before
+  the clock starts).  Bit-identical to passing them in the call; staged ids serve exactly one call of the same shape."""
+  from sisua_amd._hip import SmxError
+  spec, cfg, x, ys, lib, mask = _problem(CASES["vae_zinb"], n=256)
+  params = perturbed_params(spec)
+  order = (np.random.default_rng(3).permutation(256)[: 3 * 64].tolist() + list(range(2 * 64)))
+  order = np.asarray(order, np.int32)
+  got = []
+  for staged in (False, True):
+    e = Engine(cfg, max_batch=64, init=False)
+    e.set_params(params)
+    e.upload(x, ys, lib, mask)
+    if staged:
+      with pytest.raises(SmxError):
+        e.train_steps(None, 5, 64, graph=False)        # nothing staged
+      e.stage_steps(order, 5, 64)
+      with pytest.raises(SmxError):
+        e.train_steps(None, 4, 64, graph=False)        # another shape (and the staged ids are spent by the attempt)
+      e.stage_steps(order, 5, 64)
+      e.train_steps(None, 5, 64, graph=False)
+      with pytest.raises(SmxError):
+        e.train_steps(None, 5, 64, graph=False)        # one call only
+    else:
+      e.train_steps(order, 5, 64, graph=False)
+    h = e.metrics_history(5)
+    got.append((h["loss"].copy(), e.get_params()))
+    e.close()
+  assert np.array_equal(got[0][0], got[1][0])
+  for k in got[0][1]:
+    assert np.array_equal(got[0][1][k], got[1][1][k]), k
+
+
 def test_eval_and_forward_match_oracle(Engine):
   kw = CASES["sisua"]
   spec, cfg, x, ys, lib, mask = _problem(kw)
