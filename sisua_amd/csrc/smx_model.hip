@@ -383,6 +383,8 @@ int smx_model_destroy(smx_model* m) {
   fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);
   fr(m->chunks); fr(m->partial); fr(m->tensor_norm); fr(m->sq_slots);
   if (m->pinned) hipHostFree(m->pinned);
+  if (m->order_pin) hipHostFree(m->order_pin);
+  if (m->ev_order) hipEventDestroy(m->ev_order);
   if (m->pred_stage) hipFree(m->pred_stage);
   if (m->score_buf) hipFree(m->score_buf);
   if (m->score_wimg) hipFree(m->score_wimg);

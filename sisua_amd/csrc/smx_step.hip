@@ -1196,7 +1196,22 @@ int upload_order(smx_model* m, const int32_t* order, size_t n, size_t n_steps) {
     m->order_cap = n * 2 + (size_t)m->Bmax;
     SMX_CHECK(dmalloc(&m->order, m->order_cap));
   }
-  SMX_HIP(hipMemcpyAsync(m->order, order, n * sizeof(int32_t), hipMemcpyHostToDevice, m->st));
+  // through a pinned buffer of the model's own: the copy is then a real asynchronous DMA (from pageable memory the runtime
+  // stages it synchronously: ~80 us for 10 KB, 4 us per step of a 20-step call).  The buffer is reused only after the
+  // previous call's copy has run (an event; by then normally long done)
+  if (n > m->order_pin_cap) {
+    if (m->order_pin_busy) { SMX_HIP(hipEventSynchronize(m->ev_order)); m->order_pin_busy = false; }
+    if (m->order_pin) hipHostFree(m->order_pin);
+    m->order_pin = nullptr; m->order_pin_cap = 0;
+    SMX_HIP(hipHostMalloc((void**)&m->order_pin, (n * 2 + (size_t)m->Bmax) * sizeof(int32_t), hipHostMallocDefault));
+    m->order_pin_cap = n * 2 + (size_t)m->Bmax;
+  }
+  if (!m->ev_order) SMX_HIP(hipEventCreateWithFlags(&m->ev_order, hipEventDisableTiming));
+  if (m->order_pin_busy) { SMX_HIP(hipEventSynchronize(m->ev_order)); m->order_pin_busy = false; }
+  memcpy(m->order_pin, order, n * sizeof(int32_t));
+  SMX_HIP(hipMemcpyAsync(m->order, m->order_pin, n * sizeof(int32_t), hipMemcpyHostToDevice, m->st));
+  SMX_HIP(hipEventRecord(m->ev_order, m->st));
+  m->order_pin_busy = true;
   SMX_HIP(hipMemsetAsync(&master_state(m)->cursor, 0, sizeof(uint32_t), m->st));
   return SMX_OK;
 }
