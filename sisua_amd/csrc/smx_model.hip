@@ -384,6 +384,7 @@ int smx_model_destroy(smx_model* m) {
   fr(m->chunks); fr(m->partial); fr(m->tensor_norm); fr(m->sq_slots);
   if (m->pinned) hipHostFree(m->pinned);
   if (m->order_pin) hipHostFree(m->order_pin);
+  if (m->metrics_pin) hipHostFree(m->metrics_pin);
   if (m->ev_order) hipEventDestroy(m->ev_order);
   if (m->pred_stage) hipFree(m->pred_stage);
   if (m->score_buf) hipFree(m->score_buf);

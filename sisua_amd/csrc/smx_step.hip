@@ -1162,11 +1162,15 @@ int train_sequence(smx_model* m, int B, bool with_begin, bool begin_from_master,
 
 int read_metrics(smx_model* m, smx_metrics* out) {
   if (!out) return SMX_OK;
-  float h[8];
-  std::vector<float> norms(m->tensors.size());
-  SMX_HIP(hipMemcpyAsync(h, m->grads + m->tail_off_metrics, sizeof(h), hipMemcpyDeviceToHost, m->st));
-  SMX_HIP(hipMemcpyAsync(norms.data(), m->tensor_norm, norms.size() * sizeof(float), hipMemcpyDeviceToHost, m->st));
+  // into pinned memory (two real DMA copies; into pageable arrays the runtime stages each one synchronously)
+  const size_t nt = m->tensors.size();
+  if (!m->metrics_pin) SMX_HIP(hipHostMalloc((void**)&m->metrics_pin, (8 + nt) * sizeof(float), hipHostMallocDefault));
+  float* h = m->metrics_pin;
+  float* norms_p = m->metrics_pin + 8;
+  SMX_HIP(hipMemcpyAsync(h, m->grads + m->tail_off_metrics, 8 * sizeof(float), hipMemcpyDeviceToHost, m->st));
+  SMX_HIP(hipMemcpyAsync(norms_p, m->tensor_norm, nt * sizeof(float), hipMemcpyDeviceToHost, m->st));
   SMX_HIP(hipStreamSynchronize(m->st));
+  std::vector<float> norms(norms_p, norms_p + nt);
   out->loss = h[0]; out->nllk_x = h[1]; out->nllk_y = h[2]; out->kl = h[3]; out->kl_l = h[4];
   float mx = 0.f;
   for (float v : norms) mx = (v > mx || v != v) ? v : mx;
