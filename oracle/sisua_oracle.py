@@ -56,13 +56,20 @@ STREAM_PERMUTE = 66        # fvae: uniforms whose per-dimension ranks are the pe
 
 LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
 OUTPUT_POSTERIORS = LIKELIHOODS + ("mse",)   # + the deterministic output RVmeta(dim, 'mse') of the reference's tests (one plane: the mean)
-LABEL_LIKELIHOODS = ("nb", "onehot", "mixnb2", "mixnb3", "mixnb4")   # mixnbC: MISA's C-component mixture of NB per label
+LABEL_LIKELIHOODS = ("nb", "onehot", "mixnb2", "mixnb3", "mixnb4",   # mixnbC: MISA's C-component mixture of NB per label
+                     "mixgauss2", "mixgauss3", "mixgauss4")           # mixgaussC: its C-component mixture of Gaussians (continuous labels)
+
+
+def mixture_components(llk: str) -> int:
+  """C of 'mixnbC' / 'mixgaussC' (0: not a mixture head)."""
+  return int(llk[-1]) if llk.startswith("mix") else 0
 
 
 def label_planes(llk: str) -> int:
   """Raw head outputs per label dimension: 'nb' (log total_count, logits) 2; 'onehot' 1; 'mixnbC' 3 C -- C mixture
-  logits, then C log total_counts, then C logits (component-major planes of width P)."""
-  return 2 if llk == "nb" else 1 if llk == "onehot" else 3 * int(llk[5:])
+  logits, then C log total_counts, then C logits (component-major planes of width P); 'mixgaussC' 3 C -- C mixture logits,
+  C locations, C raw scales."""
+  return 2 if llk == "nb" else 1 if llk == "onehot" else 3 * mixture_components(llk)
 
 
 def n_params_per_gene(likelihood: str) -> int:
@@ -419,11 +426,22 @@ def label_llk(y, raw, llk_kind):
     P = raw.shape[1] // 2
     ell, (da, dl) = count_llk(y, [raw[:, :P], raw[:, P:]], "nb")
     return ell.sum(1), np.concatenate([da, dl], axis=1)
-  if llk_kind.startswith("mixnb"):
-    C = int(llk_kind[5:])
+  if llk_kind.startswith("mix"):
+    C = mixture_components(llk_kind)
     P = raw.shape[1] // (3 * C)
     a = np.stack([raw[:, c * P:(c + 1) * P] for c in range(C)], 0)                      # [C, B, P] mixture logits
-    parts = [count_llk(y, [raw[:, (C + c) * P:(C + c + 1) * P], raw[:, (2 * C + c) * P:(2 * C + c + 1) * P]], "nb") for c in range(C)]
+    if llk_kind.startswith("mixgauss"):
+      # MISA's continuous labels (vae.py:86-92 -> 'mixgaussian'): every label dimension a C-component mixture of normals,
+      # independent across dimensions as for 'mixnb'; component c: loc = raw, scale = softplus(raw + softplus_inverse(1))
+      # ([3P-recall] odin's scale activation 'softplus1', the one its latent layers use)
+      parts = []
+      for c in range(C):
+        mu, sr = raw[:, (C + c) * P:(C + c + 1) * P], raw[:, (2 * C + c) * P:(2 * C + c + 1) * P]
+        sg = softplus(sr + SOFTPLUS_INV_1)
+        zz = (y - mu) / sg
+        parts.append((-0.5 * zz * zz - np.log(sg) - 0.5 * np.log(2.0 * np.pi), [zz / sg, (zz * zz - 1.0) / sg * expit(sr + SOFTPLUS_INV_1)]))
+    else:
+      parts = [count_llk(y, [raw[:, (C + c) * P:(C + c + 1) * P], raw[:, (2 * C + c) * P:(2 * C + c + 1) * P]], "nb") for c in range(C)]
     ell = np.stack([pt[0] for pt in parts], 0)
     am = a.max(0)
     log_pi = a - (am + np.log(np.exp(a - am).sum(0)))

@@ -19,8 +19,14 @@ OUTPUT_POSTERIORS = LIKELIHOODS + ("mse",)   # 'mse': deterministic output, -log
 
 def label_planes(llk: str) -> int:
   """Raw head outputs per label dimension: 'nb' 2 (log total_count, logits), 'onehot' 1, 'mixnbC' 3 C (C mixture
-  logits, C log total_counts, C logits: MISA's mixture-of-NB labels, sisua/models/vae.py:47-98)."""
-  return 2 if llk == "nb" else 1 if llk == "onehot" else 3 * int(llk[5:])
+  logits, C log total_counts, C logits: MISA's mixture-of-NB labels, sisua/models/vae.py:47-98), 'mixgaussC' 3 C (C mixture
+  logits, C locations, C raw scales: its mixture-of-Gaussians labels for continuous variables, vae.py:86-92)."""
+  return 2 if llk == "nb" else 1 if llk == "onehot" else 3 * mixture_components(llk)
+
+
+def mixture_components(llk: str) -> int:
+  """C of 'mixnbC' / 'mixgaussC' (0: not a mixture head)."""
+  return int(llk[-1]) if llk.startswith("mix") else 0
 
 
 @dataclass

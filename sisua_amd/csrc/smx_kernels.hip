@@ -1413,13 +1413,16 @@ __global__ __launch_bounds__(256) void label_loss_kernel(LabelArgs a) {
   float llk = 0.f;
   if (m == 0.f) {   // wave-uniform
     if (a.backward) {
-      const int width = (a.kind == SMX_LABEL_NB ? 2 : a.kind == SMX_LABEL_MIXNB ? 3 * a.C : 1) * a.Pp;
+      const int width = (a.kind == SMX_LABEL_NB ? 2 : (a.kind == SMX_LABEL_MIXNB || a.kind == SMX_LABEL_MIXGAUSS) ? 3 * a.C : 1) * a.Pp;
       for (int p = lane; p < width; p += 64) a.draw[(long)b * a.ld + p] = 0.f;
     }
-  } else if (a.kind == SMX_LABEL_MIXNB) {
-    // MISA: log p(y_p) = logsumexp_c(log softmax(mix)_c + log NB(y_p; exp(r_c), l_c)); planes: C mixture logits, C log
-    // total_counts, C logits.  Gradients: d mix_c = resp_c - pi_c, d (r_c, l_c) = resp_c * d NB_c.
+  } else if (a.kind == SMX_LABEL_MIXNB || a.kind == SMX_LABEL_MIXGAUSS) {
+    // MISA: log p(y_p) = logsumexp_c(log softmax(mix)_c + log f_c(y_p)); f_c = NB(exp(r_c), l_c) with planes C mixture logits,
+    // C log total_counts, C logits -- or, for continuous labels ('mixgaussian', vae.py:86-92), f_c = Normal(loc_c,
+    // softplus(s_c + softplus_inverse(1))) with planes C mixture logits, C locations, C raw scales.
+    // Gradients: d mix_c = resp_c - pi_c, d (component parameters) = resp_c * d log f_c.
     const int C = a.C;
+    const bool gauss = a.kind == SMX_LABEL_MIXGAUSS;   // (launch-uniform)
     for (int p = lane; p < a.Pp; p += 64) {
       float e[4], d0[4], d1[4], mx[4];
       float am = -3.0e38f, jm = -3.0e38f;
@@ -1430,6 +1433,14 @@ __global__ __launch_bounds__(256) void label_loss_kernel(LabelArgs a) {
         if (c < C && live) {
           float d2;
           mx[c] = raw[c * a.Pp + p];
+          if (gauss) {
+            const float mu = raw[(C + c) * a.Pp + p];
+            const SpSg s = softplus_sigmoid(raw[(2 * C + c) * a.Pp + p] + SMX_SOFTPLUS_INV_1);   // sp = sigma, sg = d sigma / d raw
+            const float inv = frcp(s.sp), zz = (y[p] - mu) * inv;
+            e[c] = -0.5f * zz * zz - flog(s.sp) - 0.9189385332046727f;   // 0.5 log(2 pi)
+            d0[c] = zz * inv;
+            d1[c] = (zz * zz - 1.f) * inv * s.sg;
+          } else
           count_elem<SMX_LLK_NB, 0>(y[p], raw[(C + c) * a.Pp + p], raw[(2 * C + c) * a.Pp + p], 0.f, e[c], d0[c], d1[c], d2);
           am = fmaxf(am, mx[c]);
           jm = fmaxf(jm, mx[c] + e[c]);
@@ -1440,7 +1451,7 @@ __global__ __launch_bounds__(256) void label_loss_kernel(LabelArgs a) {
       for (int c = 0; c < 4; ++c)
         if (c < C && live) { sa += expf(mx[c] - am); sj += expf(mx[c] + e[c] - jm); }
       const float lse_a = am + logf(sa), lse_j = jm + logf(sj);
-      if (live) llk += lse_j - lse_a - lgammaf(y[p] + 1.f);
+      if (live) llk += lse_j - lse_a - (gauss ? 0.f : lgammaf(y[p] + 1.f));
       if (a.backward) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)

@@ -211,8 +211,8 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   }
   for (int j = 0; j < m->n_heads; ++j) {
     SMX_REQUIRE(cfg->label_dim[j] > 0, "label_dim must be > 0");
-    SMX_REQUIRE(cfg->label_llk[j] >= SMX_LABEL_NB && cfg->label_llk[j] <= SMX_LABEL_MIXNB, "unknown label likelihood");
-    if (cfg->label_llk[j] == SMX_LABEL_MIXNB) SMX_REQUIRE(cfg->label_components[j] >= 2 && cfg->label_components[j] <= 4, "mixture label heads have 2..4 components");
+    SMX_REQUIRE(cfg->label_llk[j] >= SMX_LABEL_NB && cfg->label_llk[j] <= SMX_LABEL_MIXGAUSS, "unknown label likelihood");
+    if (cfg->label_llk[j] == SMX_LABEL_MIXNB || cfg->label_llk[j] == SMX_LABEL_MIXGAUSS) SMX_REQUIRE(cfg->label_components[j] >= 2 && cfg->label_components[j] <= 4, "mixture label heads have 2..4 components");
     m->lab_ky[j] = cfg->label_llk[j] == SMX_LABEL_NB ? 2 : cfg->label_llk[j] == SMX_LABEL_ONEHOT ? 1 : 3 * cfg->label_components[j];
     m->lab_Pp[j] = round_up(cfg->label_dim[j], 32);
     m->t_labW[j] = add_tensor(m, "lab" + std::to_string(j) + "/W", hd, m->lab_ky[j] * cfg->label_dim[j], m->lab_ky[j], false);

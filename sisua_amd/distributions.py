@@ -309,6 +309,16 @@ class MixtureNegativeBinomial(Distribution):
     return np.take_along_axis(comp, pick, axis=-2)[..., 0, :]
 
 
+class MixtureNormal(MixtureNegativeBinomial):
+  """Per-dimension mixture of C normals (MISA's heads for continuous labels, 'mixgaussian', sisua/models/vae.py:86-92; TFP
+  MixtureSameFamily(Categorical(logits), Normal) semantics).  Parameters [..., C, P]: mixture logits, locations, scales."""
+
+  def __init__(self, mix_logits, loc, scale, name="MixtureNormal"):
+    self.mix_logits = np.asarray(mix_logits, np.float64)
+    self.components = Normal(loc, scale)
+    self.name = name
+
+
 class Independent(Distribution):
   """Reinterprets the last `reinterpreted_batch_ndims` batch axes as event axes."""
 

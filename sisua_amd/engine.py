@@ -52,8 +52,8 @@ def make_smx_config(cfg: ModelConfig, max_batch: int) -> smx_config:
   c.n_labels = len(cfg.labels)
   for j, (P, llk) in enumerate(cfg.labels):
     c.label_dim[j] = int(P)
-    c.label_llk[j] = _hip.LABEL_LIKELIHOODS["mixnb" if llk.startswith("mixnb") else llk]
-    c.label_components[j] = int(llk[5:]) if llk.startswith("mixnb") else 1
+    c.label_llk[j] = _hip.LABEL_LIKELIHOODS[llk[:-1] if llk.startswith("mix") else llk]
+    c.label_components[j] = int(llk[-1]) if llk.startswith("mix") else 1
   c.batchnorm, c.log_norm = int(cfg.batchnorm), int(cfg.log_norm)
   c.latent_activation = _hip.ACTIVATIONS[cfg.latent_activation]
   c.dropout_enc, c.dropout_dec, c.input_dropout = cfg.dropout_enc, cfg.dropout_dec, cfg.input_dropout

@@ -140,8 +140,15 @@ class SingleCellModel:
         if rv.kwargs.get("zero_inflated", False):
           raise ValueError("zero-inflated mixture label heads are not built")
         labels.append((rv.event_shape, f"mixnb{C}"))
+      elif rv.posterior in ("mixgaussian", "mixgaus", "mixgauss", "mixnormal", "mdn"):   # MISA's continuous labels (vae.py:86-92)
+        C = int(rv.kwargs.get("n_components", 2))
+        if not 2 <= C <= 4:
+          raise ValueError(f"mixture label heads are built for 2..4 components, given: {C}")
+        if rv.kwargs.get("covariance", "none") not in ("none", "diag"):
+          raise ValueError("mixture-of-Gaussians label heads are built with independent dimensions (covariance='none')")
+        labels.append((rv.event_shape, f"mixgauss{C}"))
       else:
-        raise ValueError(f"label posterior '{rv.posterior}' is not built (supported: 'nb', 'onehot', 'mixnb')")
+        raise ValueError(f"label posterior '{rv.posterior}' is not built (supported: 'nb', 'onehot', 'mixnb', 'mixgaussian')")
     encl = self._encoder[1].units if len(self._encoder) > 1 else (64,)
     return ModelConfig(model=self._kind, n_genes=self._outputs[0].event_shape, likelihood=self._outputs[0].posterior,
                        enc_units=tuple(enc.units), dec_units=tuple(self._decoder.units),
@@ -488,9 +495,14 @@ class SingleCellModel:
       if kind == "nb":
         outs.append(D.Independent(D.NegativeBinomial(np.exp(raw[..., :P]), raw[..., P:]), 1, name=nm))
       elif kind.startswith("mixnb"):
-        C = int(kind[5:])
+        C = int(kind[-1])
         pl = np.reshape(raw, raw.shape[:-1] + (3 * C, P))     # planes: C mixture logits | C log total_counts | C logits
         outs.append(D.Independent(D.MixtureNegativeBinomial(pl[..., :C, :], np.exp(pl[..., C:2 * C, :]), pl[..., 2 * C:, :]), 1, name=nm))
+      elif kind.startswith("mixgauss"):
+        C = int(kind[-1])
+        pl = np.reshape(raw, raw.shape[:-1] + (3 * C, P))     # planes: C mixture logits | C locations | C raw scales
+        scale = np.logaddexp(0.0, pl[..., 2 * C:, :].astype(np.float64) + np.log(np.expm1(1.0)))   # softplus1
+        outs.append(D.Independent(D.MixtureNormal(pl[..., :C, :], pl[..., C:2 * C, :], scale), 1, name=nm))
       else:
         outs.append(D.OneHotCategorical(raw, name=nm))
     return outs[0] if len(outs) == 1 else tuple(outs)
@@ -744,7 +756,8 @@ class MISA(SISUA):
   r"""MIxture of labels for Semi-supervised Autoencoder (sisua/models/vae.py:47-98): SISUA whose label heads are
   mixture distributions.  Discrete labels (ADT counts) become `n_components`-component mixtures of negative
   binomials per label dimension ('mixnb'); other label posteriors are converted with the reference's warning.
-  Built: 'mixnb' with 2..4 components, not zero-inflated; continuous mixtures ('mixgaussian', 'mixtril') are not."""
+  Built: 'mixnb' with 2..4 components, not zero-inflated; 'mixgaussian' with 2..4 components and independent label
+  dimensions; the full-covariance 'mixtril' is not."""
   _kind = "sisua"
 
   def __init__(self, outputs, labels, n_components=2, zero_inflated=False, **kwargs):

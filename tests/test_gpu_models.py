@@ -335,6 +335,37 @@ def test_misa_fit_predict(api):
     api.MISA(outputs=sco.get_rv("transcriptomic"), labels=[sco.get_rv("proteomic")], n_components=7)._make_config()
 
 
+def test_misa_continuous_labels_fit_predict(api):
+  """MISA with a CONTINUOUS label variable (vae.py:86-92): a non-mixture continuous posterior becomes 'mixgaussian' (with the
+  reference's warning) -- a mixture of normals per label dimension --, the model trains on it, and predict returns that mixture."""
+  from sisua_amd import distributions as D
+  from sisua_amd.data import SingleCellOMIC
+  sco = SingleCellOMIC(synth_counts(600, 100, sparsity=0.8, seed=4), name="toy")
+  sco.add_omic("proteomic", synth_labels(600, ((7, "mixgauss2"),))[0])      # log-normalised levels: real-valued, bimodal
+  train, test = sco.split(0.8)
+  with pytest.warns(UserWarning, match="mixture distribution"):
+    m = api.MISA(outputs=sco.get_rv("transcriptomic"), labels=[sco.get_rv("proteomic", "gaussian")], n_components=2,
+                 latents=api.RVmeta(8, "diag", True, "Latents"),
+                 encoder=api.NetConf([32], batchnorm=True, dropout=0.1), decoder=api.NetConf([32], batchnorm=True, dropout=0.1))
+  assert m.labels[0].posterior == "mixgaussian" and m.labels[0].kwargs["n_components"] == 2
+  assert m._make_config().labels == ((7, "mixgauss2"),)
+  omics = ["transcriptomic", "proteomic"]
+  m.fit(train.create_dataset(omics, labels_percent=0.5, batch_size=64, drop_remainder=True),
+        valid=test.create_dataset(omics, labels_percent=1.0, batch_size=60, drop_remainder=True), metadata=sco, epochs=15,
+        valid_freq=20, learning_rate=2e-3)
+  h = np.asarray(m.train_history["nllk_y"])
+  assert len(h) == 15 and np.isfinite(h).all() and h[-3:].mean() < h[:3].mean()
+  X, Z = m.predict(test.create_dataset(omics, batch_size=40, shuffle=0), verbose=False)
+  assert isinstance(X, tuple) and isinstance(X[1].distribution, D.MixtureNormal)
+  assert X[1].batch_shape == (test.n_obs,) and X[1].event_shape == (7,)
+  y = test.numpy("proteomic")
+  lp = X[1].log_prob(y)
+  assert np.isfinite(X[1].mean()).all() and np.isfinite(lp).all()
+  # the head's own density integrates to one where it matters: its log-probability of the labels beats a far-off constant guess
+  assert lp.mean() > D.Independent(D.Normal(np.zeros_like(y) + 10.0, np.ones_like(y)), 1).log_prob(y).mean()
+  assert np.allclose(X[1].distribution.mean(), (np.exp(X[1].distribution._log_pi()) * X[1].distribution.components.mean()).sum(-2))
+
+
 def test_scale_fit_predict(api, tmp_path):
   """SCALE (sisua/models/scale.py:13-49): mixture prior over the latents, Monte-Carlo KL; trains, predicts, and its
   prior parameters move and survive a checkpoint."""

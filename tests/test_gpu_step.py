@@ -35,6 +35,9 @@ CASES = {
                   labels=((12, "nb"), (7, "onehot"))),
     "misa": dict(model="sisua", n_genes=140, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=8,
                  labels=((12, "mixnb2"), (5, "mixnb3"))),
+    # MISA with a continuous label variable (vae.py:86-92 'mixgaussian': mixture of normals per label dimension) beside a count one
+    "misa_gauss": dict(model="sisua", n_genes=120, likelihood="nb", enc_units=(40,), dec_units=(40,), latent_dim=6,
+                       labels=((9, "mixgauss3"), (6, "mixnb2")), alpha=10.0),
     "scale": dict(model="scale", n_genes=150, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=10, n_components=7),
     # the deterministic 'mse' output (RVmeta(dim, 'mse'), tests/test_singlecell_models.py:82-100 of the reference): one plane
     "dca_mse": dict(model="dca", n_genes=110, likelihood="mse", enc_units=(32,), dec_units=(32,), latent_dim=8),
@@ -201,7 +204,7 @@ def test_activation_epilogue_forms_match_oracle(Engine, name):
 
 
 @pytest.mark.parametrize("flags", [("label_ride",), ("label_ride", "wgrad"), ("wgrad",), ("head_bwd",), ("bwd_front", "wgrad")])
-@pytest.mark.parametrize("name", ["sisua", "misa"])
+@pytest.mark.parametrize("name", ["sisua", "misa", "misa_gauss"])
 def test_label_backward_forms_match_oracle(Engine, name, flags):
   """Label heads' backward: d d as extra slabs of the output head's backward launch and the head's weight gradient in
   the grouped launch at the end of the backward pass (its optimiser chunks then wait for the last launch), or the

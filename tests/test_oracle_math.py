@@ -120,6 +120,29 @@ def test_label_llk_mixture_nb_matches_torch_mixture_same_family():
     assert so.label_planes(f"mixnb{C}") == 3 * C
 
 
+def test_label_llk_mixture_normal_matches_torch_mixture_same_family():
+  """MISA's head for continuous labels ('mixgaussian', vae.py:86-92): per-dimension mixture of C normals with scale =
+  softplus(raw + softplus_inverse(1)) == torch MixtureSameFamily(Categorical(logits), Normal); gradients by central differences."""
+  rng = np.random.default_rng(5)
+  B, P = 6, 4
+  for C in (2, 4):
+    y = rng.normal(1.0, 2.0, size=(B, P))
+    raw = rng.normal(size=(B, 3 * C * P))
+    ll, d = so.label_llk(y, raw, f"mixgauss{C}")
+    pl = torch.tensor(raw).reshape(B, 3 * C, P)
+    mix = td.Categorical(logits=pl[:, :C].permute(0, 2, 1))
+    scale = torch.nn.functional.softplus(pl[:, 2 * C:].permute(0, 2, 1) + so.SOFTPLUS_INV_1)
+    ref = td.MixtureSameFamily(mix, td.Normal(pl[:, C:2 * C].permute(0, 2, 1), scale)).log_prob(torch.tensor(y)).sum(1)
+    assert np.allclose(ll, ref.numpy(), rtol=1e-12)
+    h = 1e-6
+    for idx in [(0, 0), (3, C * P + 2), (5, 3 * C * P - 1), (2, 2 * C * P + 1)]:
+      rp, rm = raw.copy(), raw.copy()
+      rp[idx] += h; rm[idx] -= h
+      fd = (so.label_llk(y, rp, f"mixgauss{C}")[0].sum() - so.label_llk(y, rm, f"mixgauss{C}")[0].sum()) / (2 * h)
+      assert np.isclose(d[idx], fd, rtol=1e-5, atol=1e-7), (C, idx)
+    assert so.label_planes(f"mixgauss{C}") == 3 * C and so.mixture_components(f"mixgauss{C}") == C
+
+
 # ---------------------------------------------------------------------------
 # whole-step gradient check by central differences, every model family
 # ---------------------------------------------------------------------------
@@ -147,6 +170,7 @@ CASES = [("vae", "zinb", (), True), ("vae", "nb", (), False), ("vae", "zinbd", (
          ("vae", "nbd", (), True), ("dca", "zinb", (), True), ("scvi", "zinbd", (), True),
          ("scvi", "nbd", (), False), ("sisua", "zinb", ((4, "nb"), (3, "onehot")), True),
          ("sisua", "zinb", ((4, "mixnb2"), (3, "mixnb3")), True),   # MISA
+         ("sisua", "nb", ((3, "mixgauss2"), (4, "nb")), True),      # MISA with a continuous label variable
          ("scale", "zinb", (), True), ("scale", "nb", (), False),    # SCALE: mixture prior, Monte-Carlo KL
          ("fvae", "zinb", (), True), ("fvae", "nb", ((3, "onehot"),), False)]   # FVAE / SemiFVAE: two objectives
 

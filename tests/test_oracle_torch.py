@@ -126,8 +126,13 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
     if kind == "nb":
       # protein levels are real-valued (dataset.html:187): the same density formula, support check off
       llk_y = llk_y + td.NegativeBinomial(total_count=torch.exp(ry[:, :Pj]), logits=ry[:, Pj:], validate_args=False).log_prob(yj).sum(1)
+    elif kind.startswith("mixgauss"):   # MISA, continuous labels: MixtureSameFamily over C normals per label dimension
+      C = int(kind[-1])
+      pl = ry.reshape(B, 3 * C, Pj)
+      comp = td.Normal(pl[:, C:2 * C].permute(0, 2, 1), torch.nn.functional.softplus(pl[:, 2 * C:].permute(0, 2, 1) + so.SOFTPLUS_INV_1))
+      llk_y = llk_y + td.MixtureSameFamily(td.Categorical(logits=pl[:, :C].permute(0, 2, 1)), comp).log_prob(yj).sum(1)
     elif kind.startswith("mixnb"):   # MISA: MixtureSameFamily over C negative binomials per label dimension
-      C = int(kind[5:])
+      C = int(kind[-1])
       pl = ry.reshape(B, 3 * C, Pj)
       comp = td.NegativeBinomial(total_count=torch.exp(pl[:, C:2 * C].permute(0, 2, 1)), logits=pl[:, 2 * C:].permute(0, 2, 1),
                                  validate_args=False)
@@ -166,6 +171,8 @@ CASES = {
                   labels=((7, "nb"), (4, "onehot")), alpha=10.0),
     "misa": dict(model="sisua", n_genes=40, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5,
                  labels=((6, "mixnb2"), (3, "mixnb3")), alpha=10.0),
+    "misa_gauss": dict(model="sisua", n_genes=36, likelihood="nb", enc_units=(16,), dec_units=(16,), latent_dim=4,
+                       labels=((5, "mixgauss3"), (4, "mixnb2")), alpha=10.0),
     "scale": dict(model="scale", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=6),
     "scalar": dict(model="scale", n_genes=42, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=4,
                    labels=((6, "nb"), (3, "onehot")), alpha=10.0),   # SCALE + label heads (scale.py:52-59)

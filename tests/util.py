@@ -31,6 +31,9 @@ def synth_labels(n, labels, seed=1):
   for P, kind in labels:
     if kind == "onehot":
       ys.append(np.eye(P, dtype=np.float32)[rng.integers(0, P, n)])
+    elif kind.startswith("mixgauss"):   # continuous, bimodal (log-normalised protein levels: a background and a signal mode)
+      on = rng.uniform(size=(n, P)) < 0.4
+      ys.append(np.where(on, rng.normal(2.5, 0.5, size=(n, P)), rng.normal(-0.5, 0.8, size=(n, P))).astype(np.float32))
     elif kind.startswith("mixnb"):   # bimodal ADT-like counts: a background and a signal population per protein
       on = rng.uniform(size=(n, P)) < 0.4
       ys.append(np.where(on, rng.poisson(30.0, size=(n, P)), rng.poisson(2.0, size=(n, P))).astype(np.float32))
