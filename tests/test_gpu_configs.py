@@ -135,6 +135,35 @@ def test_c5_slice_u16_store(Engine):
   e2.close()
 
 
+@pytest.mark.parametrize("storage", ["u16", "f32"])
+def test_c5_width_trajectory_and_latent_means_match_oracle(Engine, storage):
+  """The north star's criterion at the width of BASELINE configs[4] (20 000 genes, batch 128), where every product of the output
+  head and the first encoder layer runs in its wide-panel form (bf16 x 3 MFMAs; smx_bigk.hip, smx_panel.h): 40 optimiser steps
+  against the oracle's committed trajectory (tests/golden/make_c5_trajectory.py) -- ELBO and its two terms within 1e-4 at EVERY
+  step, eval-mode latent means and scales of 128 probe cells after the 40 steps within 1e-4 (relative L2) --, from the uint16
+  and from the float32 resident matrix."""
+  from tests.golden import make_c5_trajectory as fxgen
+  cfg, xt, B, order, probe = fxgen.inputs()
+  spec = so.Spec(**cfg.to_dict())
+  fx = np.load(os.path.join(ROOT, "tests", "golden", "oracle_c5_trajectory.npz"))
+  assert tuple(fx["x_shape"]) == xt.shape and int(fx["x_crc32"]) == fxgen.checksum(xt), "the fixture was made from another matrix"
+  assert np.array_equal(order, fx["order"]) and np.array_equal(probe, fx["probe"])
+  e = Engine(cfg, max_batch=B, init=False)
+  e.set_params(so.init_params(spec))
+  e.upload(xt, storage=storage)
+  worst = 0.0
+  for s in range(len(fx["loss"])):
+    got = e.train_step(order[s * B:(s + 1) * B])
+    assert got["nan_flag"] == 0
+    for key in ("loss", "nllk_x", "kl"):
+      worst = max(worst, abs(got[key] / fx[key][s] - 1.0))
+  assert worst < RTOL, worst
+  out = e.forward(row_ids=probe, want_x_params=False)
+  for key in ("z_mean", "z_scale"):
+    assert rel_l2(out[key], fx[key]) < RTOL, (key, rel_l2(out[key], fx[key]))
+  e.close()
+
+
 def test_latent_means_after_training_match_oracle(Engine):
   """north_star: 'ELBO / latent means within 1e-4 relative on fixed seeds'.  C2 (batch 128): the GPU and the
   oracle train with the same Philox noise.

@@ -86,3 +86,16 @@ def test_oracle_reproduces_committed_c2_trajectory():
   assert len(fx["loss"]) == 300 and fx["loss"][-10:].mean() < 0.45 * fx["loss"][:3].mean()
   for at in (100, 300):
     assert fx[f"z_mean_{at}"].shape == (256, cfg.latent_dim) and np.all(fx[f"z_scale_{at}"] > 0)
+
+
+def test_oracle_reproduces_committed_c5_trajectory():
+  """tests/golden/oracle_c5_trajectory.npz (the 20 000-gene trajectory the GPU test is held against) is the oracle's output."""
+  from tests.golden import make_c5_trajectory as mk
+  fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_c5_trajectory.npz"))
+  cfg, xt, B, order, probe = mk.inputs()
+  assert tuple(fx["x_shape"]) == xt.shape and int(fx["x_crc32"]) == mk.checksum(xt)
+  out = mk.run(n_steps=2)
+  for key in ("loss", "nllk_x", "kl"):
+    assert np.allclose(out[key], fx[key][:2], rtol=1e-10), key
+  assert len(fx["loss"]) == mk.STEPS and fx["loss"][-3:].mean() < 0.8 * fx["loss"][:3].mean()
+  assert fx["z_mean"].shape == (128, cfg.latent_dim) and np.all(fx["z_scale"] > 0)

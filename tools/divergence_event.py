@@ -10,13 +10,19 @@ import bench
 from oracle import sisua_oracle as so
 from sisua_amd.engine import Engine
 n_steps = int(os.environ.get("TRAJ_STEPS", "320"))
-cfg, xt, batch, _ = bench.build_workload(0, 1, "8kly")
+THRESH = float(os.environ.get("TRAJ_THRESH", "1e-3"))
+if os.environ.get("TRAJ_WORKLOAD", "8kly") == "c5":   # the 20 000-gene trajectory of tests/golden/make_c5_trajectory.py
+  from tests.golden import make_c5_trajectory as fxgen
+  cfg, xt, batch, order, _ = fxgen.inputs()
+  n_steps = min(n_steps, len(order) // batch)
+else:
+  cfg, xt, batch, _ = bench.build_workload(0, 1, "8kly")
+  order = bench.make_order(xt.shape[0], batch, n_steps)
 spec = so.Spec(**cfg.to_dict())
 params = so.init_params(spec)
 bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
 e = Engine(cfg, max_batch=batch, init=False)
 e.set_params(params); e.upload(xt)
-order = bench.make_order(xt.shape[0], batch, n_steps)
 x64 = xt.astype(np.float64)
 
 captured = {}
@@ -35,7 +41,8 @@ for s in range(n_steps):
   got = e.get_params(which=1)
   err = {k: np.linalg.norm(got[k] - ref["grads"][k]) / max(np.linalg.norm(ref["grads"][k]), 1e-30) for k in ref["grads"]}
   worst = max(err, key=err.get)
-  if err[worst] > 1e-3:
+  print(f"step {s + 1}: worst gradient difference {err[worst]:.1e} ({worst})", flush=True)
+  if err[worst] > THRESH:
     print(f"step {s + 1}: first gradient difference beyond rounding: " + ", ".join(f"{k} {v:.1e}" for k, v in sorted(err.items(), key=lambda kv: -kv[1])[:4])
           + f"; every tensor agreed to {prev_worst:.1e} at step {s}")
     # ReLU inputs of this step's forward pass (float64, the parameters before the update), nearest to 0
