@@ -11,8 +11,9 @@
 // slices as the chip has CUs, and the slabs are summed by a second, bandwidth-bound launch (bigk_reduce_kernel) in slice
 // order -- deterministic, and the consumer reads ONE slab:
 //   * both operands go global -> LDS by LDS-DMA (16 B per lane, landed linearly; the lane -> address map is chosen so that
-//     the linear image IS the swizzled tile; inline asm: smx_device.h glds16), three 32-deep stages in flight across the
-//     barriers, one counted `s_waitcnt vmcnt(N)` + raw `s_barrier` per stage;
+//     the linear image IS the swizzled tile; inline asm: smx_device.h glds16), up to three 32-deep stages in flight across the
+//     barriers (SMX_BIGK_STAGES; default ONE: measured fastest, smx_internal.h), one counted `s_waitcnt vmcnt(N)` + raw
+//     `s_barrier` per stage;
 //   * 8 waves = 4 row tiles x 2 column halves, two 32 x 32 accumulators each; operands read from LDS as the lanes' runs of
 //     8 consecutive k, split three ways in registers: bf16 MFMAs, f32 accuracy (smx_device.h);
 //   * the gather by row id, the uint16 store and log1p of the encoder front are applied on the way (address of the DMA / at
@@ -27,7 +28,7 @@
 
 namespace smx {
 
-#define BIGK_STAGES 4
+#define BIGK_STAGES 4   // most stages in flight (LDS of the deepest form); a.stages of them are used
 
 // A_U16: A is the compact uint16 store; B_KM: B stored [K][N] (else [N][K]); LOG1P on A
 template <int A_U16, int B_KM, int LOG1P>
@@ -36,7 +37,8 @@ __global__ __launch_bounds__(512) void bigk_kernel(BigKArgs a) {
   constexpr int B_STAGE = 128 * 32 * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* As = lds;                               // BIGK_STAGES x A_STAGE
-  unsigned char* Bs = lds + BIGK_STAGES * A_STAGE;       // BIGK_STAGES x B_STAGE
+  const int NS = a.stages;                               // stage buffers in use (2..BIGK_STAGES)
+  unsigned char* Bs = lds + NS * A_STAGE;                // NS x B_STAGE
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 31, hh = lane >> 5;
   const int rt = w & 3, ch = w >> 2;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(512) void bigk_kernel(BigKArgs a) {
   const long b_step = B_KM ? 32 * a.ldb : 32;
   const uint32_t as_l = lds_addr(As), bs_l = lds_addr(Bs);
   auto issue = [&](int st) {
-    const uint32_t ad = as_l + (st % BIGK_STAGES) * A_STAGE, bd = bs_l + (st % BIGK_STAGES) * B_STAGE;
+    const uint32_t ad = as_l + (st % NS) * A_STAGE, bd = bs_l + (st % NS) * B_STAGE;
     if (A_U16) {
       glds16(ag[0], __builtin_amdgcn_readfirstlane(ad + 1024 * w));
       ag[0] += 64;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(512) void bigk_kernel(BigKArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-  for (int st = 0; st < BIGK_STAGES - 1 && st < n_st; ++st) issue(st);
+  for (int st = 0; st < NS - 1 && st < n_st; ++st) issue(st);
   for (int st = 0; st < n_st; ++st) {
     // this wave's DMA instructions complete in issue order: stage st has landed once at most the instructions of the
     // stages st + 1, st + 2 are outstanding (IPS per stage; fewer stages follow near the end), then the barrier collects the
@@ -117,13 +119,13 @@ __global__ __launch_bounds__(512) void bigk_kernel(BigKArgs a) {
     // a prefetch distance of ONE stage -- 24 us for d d at 128 x 60 000 against 9.)
     constexpr int IPS = A_U16 ? 3 : 4;
     const int after = n_st - 1 - st;
-    if (after >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * IPS));
-    else if (after == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | IPS);
+    if (NS >= 4 && after >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * IPS));
+    else if (NS >= 3 && after >= 1) __builtin_amdgcn_s_waitcnt(0x0F70 | IPS);
     else __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_s_barrier();
-    if (st + BIGK_STAGES - 1 < n_st) issue(st + BIGK_STAGES - 1);
-    const unsigned char* ab = As + (st % BIGK_STAGES) * A_STAGE;
-    const unsigned char* bb = Bs + (st % BIGK_STAGES) * B_STAGE;
+    if (st + NS - 1 < n_st) issue(st + NS - 1);
+    const unsigned char* ab = As + (st % NS) * A_STAGE;
+    const unsigned char* bb = Bs + (st % NS) * B_STAGE;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       // ---- A: row m = 32 rt + i, k = 16 t + 8 hh .. + 7 ----
@@ -235,12 +237,14 @@ int launch_bigk(hipStream_t st, const BigKArgs& a_in) {
   if (!bigk_supported(a)) { set_error("bigk: unsupported shapes"); return SMX_ERR_INVALID; }
   if (a.n_slices <= 0 || a.k_chunk % 32 || (long)a.n_slices * a.k_chunk < a.K) { set_error("bigk: bad slicing"); return SMX_ERR_INVALID; }
   const dim3 grid((unsigned)a.n_slices, (unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
-  const size_t lds = (size_t)BIGK_STAGES * ((a.a_u16 ? 128 * 32 * 2 : 128 * 32 * 4) + 128 * 32 * 4);
+  static const int stages_env = getenv("SMX_BIGK_STAGES") ? atoi(getenv("SMX_BIGK_STAGES")) : 0;
+  a.stages = (stages_env >= 2 && stages_env <= BIGK_STAGES) ? stages_env : SMX_BIGK_STAGES_DEFAULT;
+  const size_t lds = (size_t)a.stages * ((a.a_u16 ? 128 * 32 * 2 : 128 * 32 * 4) + 128 * 32 * 4);
 #define SMX_BIGK_LAUNCH(U, KM, L)                                                                                         \
   do {                                                                                                                  \
     static bool raised = false;                                                                                         \
-    if (!raised && lds > 64 * 1024) {                                                                                   \
-      SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bigk_kernel<U, KM, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    if (!raised) {                                                                                   \
+      SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bigk_kernel<U, KM, L>), hipFuncAttributeMaxDynamicSharedMemorySize, BIGK_STAGES * 2 * 128 * 32 * 4)); \
       raised = true;                                                                                                    \
     }                                                                                                                   \
     hipLaunchKernelGGL((bigk_kernel<U, KM, L>), grid, dim3(512), lds, st, a);                                              \

@@ -486,7 +486,12 @@ struct BigKArgs {
   float* out = nullptr; int ldc = 0;               // [M][ldc]: their sum in slice order
   int M = 0, N = 0, K = 0;
   int n_slices = 0, k_chunk = 0;                   // from bigk_slices
+  int stages = 0;                                  // set by the launcher: 32-deep stages in flight + 1 (SMX_BIGK_STAGES)
 };
+// measured at 128 x 20 000 (tools/bigk_stages_ab.sh, same box): 4 / 3 / 2 stage buffers -> c5-shard 205.4 / 203.8 / 202.9 us per step, bit-identical
+// results: the operands of these launches come from the last-level cache, one stage ahead covers their latency, and 64 KB of LDS
+// instead of 128 KB lets the next workgroup in while one drains
+#define SMX_BIGK_STAGES_DEFAULT 2
 int bigk_slices(long K, int max_slices, int* k_chunk);
 bool bigk_supported(const BigKArgs& a);
 int launch_bigk(hipStream_t st, const BigKArgs& a);
