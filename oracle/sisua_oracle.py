@@ -93,6 +93,11 @@ class Spec:
   gamma: float = 6.0
   disc_leak: float = 0.2
   n_components: int = 10              # scale: components of the Gaussian-mixture prior (scale.py:27)
+  # scale.py:29-33: the mixture's weights fixed uniform / one location / one scale vector shared by every component.  A tied
+  # tensor keeps its [C] / [C, D] shape with identical rows: every row starts equal and receives the SUM of the rows' gradients
+  tie_mixtures: bool = False
+  tie_loc: bool = False
+  tie_scale: bool = False
   n_genes: int = 0
   likelihood: str = "zinb"
   enc_units: Tuple[int, ...] = (64, 64)
@@ -225,6 +230,8 @@ def init_params(spec: Spec, seed: Optional[int] = None) -> Dict[str, np.ndarray]
       params[name] = np.ones(shape)
     elif name == "prior/loc":   # the mixture must not start symmetric: component means spread over the unit box
       params[name] = rng.uniform(-1.0, 1.0, size=shape).astype(np.float32).astype(np.float64)
+      if spec.tie_loc:          # one shared location (the draw above keeps every other tensor's stream where it was)
+        params[name][:] = 0.0
     else:
       params[name] = np.zeros(shape)   # biases, mixture logits (uniform weights), raw prior scales (softplus1(0) = 1)
   return params
@@ -762,6 +769,12 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
     grads["prior/logits"] = c_kl * (np.exp(scale_c["log_pi"])[None] - r_).sum(0)
     grads["prior/loc"] = -c_kl * (r_[:, :, None] * dzm / s_c[None]).sum(0)
     grads["prior/scale"] = -c_kl * (r_[:, :, None] * (dzm ** 2 - 1.0) / s_c[None]).sum(0) * expit(params["prior/scale"] + SOFTPLUS_INV_1)
+    if spec.tie_mixtures:
+      grads["prior/logits"] = np.zeros_like(grads["prior/logits"])
+    if spec.tie_loc:
+      grads["prior/loc"] = np.broadcast_to(grads["prior/loc"].sum(0, keepdims=True), grads["prior/loc"].shape).copy()
+    if spec.tie_scale:
+      grads["prior/scale"] = np.broadcast_to(grads["prior/scale"].sum(0, keepdims=True), grads["prior/scale"].shape).copy()
   elif spec.stochastic:
     dmu = dz + c_kl * mu
     dsig = dz * eps + c_kl * (sig - 1.0 / sig)

@@ -107,6 +107,9 @@ class ModelConfig:
   clipnorm: float = 100.0
   seed: int = 8
   n_components: int = 10   # model 'scale': components of the Gaussian-mixture prior
+  tie_mixtures: bool = False   # scale.py:29-33: uniform fixed mixture weights / one location / one scale vector for every component
+  tie_loc: bool = False
+  tie_scale: bool = False
   # model 'fvae' (sisua/models/fvae.py:9-18; odin factorVAE defaults): the total-correlation discriminator
   disc_units: int = 1000
   disc_layers: int = 5
@@ -192,6 +195,8 @@ def init_params(cfg: ModelConfig, seed: Optional[int] = None) -> Dict[str, np.nd
       params[name] = np.ones(shape, dtype=np.float32)
     elif name == "prior/loc":   # scale: the mixture components must not start identical
       params[name] = rng.uniform(-1.0, 1.0, size=shape).astype(np.float32)
+      if cfg.tie_loc:
+        params[name][:] = 0.0
     else:
       params[name] = np.zeros(shape, dtype=np.float32)
   return params

@@ -278,6 +278,7 @@ struct ScalePriorArgs {
   float* dklz = nullptr;      // [B][Dp] d(-log p)/dz
   float kl_scale = 0.f;       // beta / B_global
   float* g_logits = nullptr; float* g_loc = nullptr; float* g_scale = nullptr;   // gradients (backward)
+  int tie_mixtures = 0, tie_loc = 0, tie_scale = 0;   // scale.py:29-33: a tied tensor's rows all receive the sum of the rows' gradients (logits: none)
 };
 int launch_scale_prior_fwd(hipStream_t st, const ScalePriorArgs& a);
 int launch_scale_prior_bwd(hipStream_t st, const ScalePriorArgs& a);

@@ -1116,8 +1116,27 @@ __global__ __launch_bounds__(256) void scale_prior_bwd_kernel(ScalePriorArgs a) 
     __syncthreads();
   }
 }
+// tied mixture parameters (scale.py:29-33): one location / one scale vector shared by every component = a [C][D] tensor whose rows
+// are equal and all receive the SUM of the rows' gradients (in component order); fixed uniform weights = no logits gradient
+__global__ __launch_bounds__(256) void scale_prior_tie_kernel(ScalePriorArgs a) {
+  for (int d = threadIdx.x; d < a.Dp; d += 256) {
+    if (a.tie_loc) {
+      float t = 0.f;
+      for (int c = 0; c < a.C; ++c) t += a.g_loc[(long)c * a.Dp + d];
+      for (int c = 0; c < a.C; ++c) a.g_loc[(long)c * a.Dp + d] = t;
+    }
+    if (a.tie_scale) {
+      float t = 0.f;
+      for (int c = 0; c < a.C; ++c) t += a.g_scale[(long)c * a.Dp + d];
+      for (int c = 0; c < a.C; ++c) a.g_scale[(long)c * a.Dp + d] = t;
+    }
+  }
+  if (a.tie_mixtures && (int)threadIdx.x < a.C) a.g_logits[threadIdx.x] = 0.f;
+}
+
 int launch_scale_prior_bwd(hipStream_t st, const ScalePriorArgs& a) {
   hipLaunchKernelGGL(scale_prior_bwd_kernel, dim3(a.C), dim3(256), 0, st, a);
+  if (a.tie_mixtures || a.tie_loc || a.tie_scale) hipLaunchKernelGGL(scale_prior_tie_kernel, dim3(1), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }

@@ -154,6 +154,7 @@ struct smx_model {
     // training products of the output head (fused head, its backward, the encoder's weight gradient) from bf16 MFMAs on
     // three-way split operands: 1 always, 0 never (the exact-f32 MFMA forms), -1 from the width (SMX_BF16X3_MIN_WORK)
     int bf16x3 = -1;
+  int tie_mixtures = 0, tie_loc = 0, tie_scale = 0;   // SCALE (scale.py:29-33): the prior's mixture weights fixed / one location / one scale for every component
   } flags;
   int chunk_first_head = 0;           // first optimiser chunk of the output / label heads (they are last in the table)
   int chunk_first_label = 0;          // first optimiser chunk of the label heads (n_chunks without label heads)

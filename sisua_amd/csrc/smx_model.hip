@@ -508,8 +508,9 @@ int smx_set_flag(smx_model* m, const char* name, int value) {
   int* f = n == "head_loss" ? &m->flags.head_loss : n == "front" ? &m->flags.front : n == "bwd_front" ? &m->flags.bwd_front
          : n == "head_bwd" ? &m->flags.head_bwd : n == "wgrad" ? &m->flags.wgrad : n == "scvi_fused" ? &m->flags.scvi_fused
          : n == "twin" ? &m->flags.twin : n == "label_ride" ? &m->flags.label_ride : n == "act_epilogue" ? &m->flags.act_epilogue
-         : n == "stacked_scoring" ? &m->flags.stacked_scoring : n == "bf16x3" ? &m->flags.bf16x3 : nullptr;
-  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue, stacked_scoring, bf16x3)");
+         : n == "stacked_scoring" ? &m->flags.stacked_scoring : n == "bf16x3" ? &m->flags.bf16x3
+         : n == "tie_mixtures" ? &m->flags.tie_mixtures : n == "tie_loc" ? &m->flags.tie_loc : n == "tie_scale" ? &m->flags.tie_scale : nullptr;
+  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue, stacked_scoring, bf16x3; SCALE: tie_mixtures, tie_loc, tie_scale)");
   *f = (f == &m->flags.bf16x3 && value < 0) ? -1 : (value ? 1 : 0);   // bf16x3: -1 = by the width of the head (the default)
   drop_graphs(m);   // a captured step bakes the launch sequence in
   return SMX_OK;

@@ -91,6 +91,10 @@ class Engine:
       raise SmxError("tensor manifest of libsisua_hip.so differs from sisua_amd.config.manifest")
     self.index = {n: i for i, n in enumerate(self.names)}
     self.n_cells = 0
+    if cfg.model == "scale":   # scale.py:29-33: tied mixture parameters (model semantics carried as flags: no layout change of smx_config)
+      for name in ("tie_mixtures", "tie_loc", "tie_scale"):
+        if getattr(cfg, name, False):
+          check(self.lib.smx_set_flag(self._h, name.encode(), 1))
     if init:
       self.set_params(init_params(cfg))
 

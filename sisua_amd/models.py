@@ -157,7 +157,7 @@ class SingleCellModel:
                        input_dropout=float(enc.input_dropout), log_norm=self._log_norm, beta=self.beta, alpha=self.alpha,
                        latent_activation=self._latent_activation(), clip_library=self.clip_library,
                        lr=float(self._opt["lr"]), clipnorm=float(self._opt["clipnorm"]), seed=self.seed,
-                       n_components=int(getattr(self, "_n_components", 10)), **getattr(self, "_disc_cfg", {}))
+                       n_components=int(getattr(self, "_n_components", 10)), **getattr(self, "_ties", {}), **getattr(self, "_disc_cfg", {}))
 
   def _ensure_engine(self, max_batch: int) -> Engine:
     cfg = self._make_config()
@@ -781,7 +781,7 @@ class SCALE(SingleCellModel):
   r"""SCALE - "Single-Cell ATAC-seq analysis via Latent feature Extraction" (sisua/models/scale.py:13-49; Xiong et al.
   2019, Nature Communications): a VAE whose prior over z is a TRAINABLE mixture of `n_components` diagonal Gaussians; the
   KL term is the one-sample Monte-Carlo estimate log q(z|x) - log p(z) (`analytic=False`, scale.py:49).  Built:
-  covariance='none' (diagonal), untied mixtures / locations / scales (the reference's defaults).  [3P-recall: the
+  covariance='none' (diagonal components) with or without tied mixture weights / locations / scales (scale.py:29-33).  [3P-recall: the
   published model; odin's mixture latent layer behind the reference's class is not citable.]"""
   _kind = "scale"
 
@@ -792,9 +792,13 @@ class SCALE(SingleCellModel):
       if z.posterior[:3] != "mix":
         warnings.warn(f"SCALE only allow mixture distribution for latents  posterior, but given: {z.posterior}")
         z.posterior = "mixgaus"
-    if str(covariance) != "none" or tie_mixtures or tie_loc or tie_scale:
-      raise ValueError("SCALE is built for covariance='none' and untied mixture parameters (the reference's defaults)")
-    self._n_components = int(lat[0].kwargs.get("n_components", n_components))
+    kw0 = lat[0].kwargs
+    covariance = str(kw0.get("covariance", covariance))
+    if covariance not in ("none", "diag"):
+      raise ValueError("SCALE is built for covariance='none' (diagonal components)")
+    self._ties = dict(tie_mixtures=bool(kw0.get("tie_mixtures", tie_mixtures)), tie_loc=bool(kw0.get("tie_loc", tie_loc)),
+                      tie_scale=bool(kw0.get("tie_scale", tie_scale)))
+    self._n_components = int(kw0.get("n_components", n_components))
     if not 2 <= self._n_components <= 32:
       raise ValueError(f"SCALE is built for 2..32 mixture components, given: {self._n_components}")
     super().__init__(outputs=outputs, latents=lat, **kwargs)

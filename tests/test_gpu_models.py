@@ -391,6 +391,29 @@ def test_scale_fit_predict(api, tmp_path):
     api.SCALE(outputs=sco.get_rv("transcriptomic"), covariance="full")
 
 
+def test_scale_tied_mixture_parameters(api, tmp_path):
+  """SCALE's tie options (scale.py:29-33): one scale vector shared by every component and fixed uniform weights stay tied through
+  training (identical rows, zero logits) while the untied locations move apart; the options survive save / load."""
+  sco = _sco(with_labels=False)
+  train, _ = sco.split(0.8)
+  m = api.SCALE(outputs=sco.get_rv("transcriptomic"), latents=api.RVmeta(6, "mixgaus", True, "Latents"), n_components=4,
+                tie_scale=True, tie_mixtures=True,
+                encoder=api.NetConf([32], batchnorm=True, dropout=0.1), decoder=api.NetConf([32], batchnorm=True, dropout=0.1))
+  cfg = m._make_config()
+  assert cfg.tie_scale and cfg.tie_mixtures and not cfg.tie_loc
+  m.fit(train, epochs=6, batch_size=64, learning_rate=2e-3)
+  p = m._engine.get_params()
+  assert np.isfinite(m.train_history["loss"]).all()
+  assert np.abs(p["prior/scale"]).max() > 1e-4 and np.array_equal(p["prior/scale"], np.broadcast_to(p["prior/scale"][:1], p["prior/scale"].shape))
+  assert not p["prior/logits"].any()
+  assert not np.array_equal(p["prior/loc"][0], p["prior/loc"][1])
+  path = os.path.join(tmp_path, "scale_tied")
+  m.save_weights(path)
+  m2 = api.load_model(path)
+  c2 = m2._make_config()
+  assert c2.tie_scale and c2.tie_mixtures and not c2.tie_loc and np.array_equal(m2._engine.get_params()["prior/scale"], p["prior/scale"])
+
+
 def test_unsupervised_mse_fit_predict(api):
   """The reference's test_unsupervised_fit_predict (tests/test_singlecell_models.py:93-114): a DeepCountAutoencoder with
   outputs=RVmeta(dim, posterior='mse'), latent_dim 10: the loss falls, predict(sample_shape=2) returns VectorDeterministic

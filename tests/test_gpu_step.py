@@ -42,6 +42,11 @@ CASES = {
     # the deterministic 'mse' output (RVmeta(dim, 'mse'), tests/test_singlecell_models.py:82-100 of the reference): one plane
     "dca_mse": dict(model="dca", n_genes=110, likelihood="mse", enc_units=(32,), dec_units=(32,), latent_dim=8),
     "vae_mse": dict(model="vae", n_genes=203, likelihood="mse", enc_units=(48,), dec_units=(40,), latent_dim=6),
+    # SCALE with tied mixture parameters (scale.py:29-33): one scale vector for every component, weights fixed uniform; one location
+    "scale_tied": dict(model="scale", n_genes=120, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=7, n_components=5,
+                       tie_scale=True, tie_mixtures=True),
+    "scale_tied_loc": dict(model="scale", n_genes=90, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=6, n_components=4,
+                           tie_loc=True),
     "scalar": dict(model="scale", n_genes=130, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=8, n_components=5,
                    labels=((10, "nb"), (4, "onehot"))),   # SCALAR = SCALE + SISUA's label heads (scale.py:52-59)
     "fvae": dict(model="fvae", n_genes=150, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=10, disc_units=100,

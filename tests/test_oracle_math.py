@@ -203,6 +203,45 @@ def test_full_step_gradients_fd(model, lk, labels, bn):
       assert np.isclose(g.reshape(-1)[idx], fd, rtol=2e-4, atol=1e-7), (name, idx, g.reshape(-1)[idx], fd)
 
 
+def test_scale_tied_mixture_gradients_fd():
+  """SCALE's tied mixture parameters (scale.py:29-33): one location and / or one scale vector shared by every component, the
+  weights fixed uniform.  A tied tensor keeps identical rows and every row receives the derivative with respect to the SHARED
+  value: central differences that move all rows of a column together; the logits of fixed weights get no gradient."""
+  for ties in (dict(tie_loc=True), dict(tie_scale=True, tie_mixtures=True), dict(tie_loc=True, tie_scale=True, tie_mixtures=True)):
+    spec, params, bn_state, x, y, lib, mask = _toy("scale", "zinb", (), True, **ties)
+    rng = np.random.default_rng(2)
+    for name, on in (("prior/loc", spec.tie_loc), ("prior/scale", spec.tie_scale)):
+      if on:   # a tied tensor has identical rows (here: off the init by one shared perturbation)
+        params[name] = np.broadcast_to(params[name][:1], params[name].shape).copy()
+    if spec.tie_mixtures:
+      params["prior/logits"] = np.zeros_like(params["prior/logits"])
+    noise = so.PhiloxNoise(spec.seed, 7, np.arange(x.shape[0]) + 100)
+    loss_of = lambda p: so.forward_backward(spec, p, bn_state, x, noise, y=y, library=lib, mask=mask, backward=False)["loss"]
+    res = so.forward_backward(spec, params, bn_state, x, noise, y=y, library=lib, mask=mask)
+    g = res["grads"]
+    if spec.tie_mixtures:
+      assert not g["prior/logits"].any()
+    for name, on in (("prior/loc", spec.tie_loc), ("prior/scale", spec.tie_scale)):
+      if on:
+        assert np.array_equal(g[name], np.broadcast_to(g[name][:1], g[name].shape))       # every row the same
+      for d in rng.choice(params[name].shape[1], size=2, replace=False):
+        h = 1e-5
+        pp = {k: v.copy() for k, v in params.items()}
+        pm = {k: v.copy() for k, v in params.items()}
+        rows = slice(None) if on else slice(1, 2)
+        pp[name][rows, d] += h
+        pm[name][rows, d] -= h
+        fd = (loss_of(pp) - loss_of(pm)) / (2 * h)
+        assert np.isclose(g[name][1, d], fd, rtol=2e-4, atol=1e-7), (ties, name, d, g[name][1, d], fd)
+    # init: a tied location starts at zero in every row, the other tensors keep their streams
+    p0, p1 = so.init_params(spec), so.init_params(so.Spec(**{**spec.__dict__, "tie_loc": False, "tie_scale": False, "tie_mixtures": False}))
+    for k in p0:
+      if k == "prior/loc" and spec.tie_loc:
+        assert not p0[k].any()
+      else:
+        assert np.array_equal(p0[k], p1[k]), k
+
+
 def test_adam_clipnorm_step():
   spec = so.Spec(model="vae", n_genes=4, enc_units=(3,), dec_units=(3,), latent_dim=2, clipnorm=1.0)
   params = so.init_params(spec)

@@ -46,7 +46,13 @@ def perturbed_params(spec, scale=0.05, seed=3):
   """Oracle init moved off the symmetric point (gamma=1, beta=0, b=0), fp32-representable."""
   rng = np.random.default_rng(seed)
   p = so.init_params(spec)
-  return {k: (v + scale * rng.normal(size=v.shape)).astype(np.float32).astype(np.float64) for k, v in p.items()}
+  out = {k: (v + scale * rng.normal(size=v.shape)).astype(np.float32).astype(np.float64) for k, v in p.items()}
+  for name, on in (("prior/loc", getattr(spec, "tie_loc", False)), ("prior/scale", getattr(spec, "tie_scale", False))):
+    if on and name in out:   # SCALE's tied tensors keep identical rows
+      out[name] = np.broadcast_to(out[name][:1], out[name].shape).copy()
+  if getattr(spec, "tie_mixtures", False) and "prior/logits" in out:
+    out["prior/logits"] = np.zeros_like(out["prior/logits"])
+  return out
 
 
 def rel_l2(a, b, floor=1e-5):
