@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512) void dgemm_kernel(GemmArgs g) {
     if (row < g.M) {
       float v = t + bias;
       if (g.act == 1) v = fmaxf(v, 0.f) + g.leak * fminf(v, 0.f);
-      else if (g.act == 2) v = g.act_out[(long)row * g.act_ld + col] > 0.f ? v : v * g.leak;
+      else if (g.act == 2) v = g.act_out[(long)((g.act_wrap > 0 && row >= g.act_wrap) ? row - g.act_wrap : row) * g.act_ld + col] > 0.f ? v : v * g.leak;
       g.C[(long)row * g.ldc + col] = v;
     }
   }

@@ -281,7 +281,8 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
       if (g.act == 1) v = fmaxf(v, 0.f) + g.leak * fminf(v, 0.f);
       else if (g.act == 2) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float y = row < g.M ? g.act_out[(long)row * g.act_ld + n0 + wn * 32 + li] : 0.f;
+        const int arow = (g.act_wrap > 0 && row >= g.act_wrap) ? row - g.act_wrap : row;
+        const float y = row < g.M ? g.act_out[(long)arow * g.act_ld + n0 + wn * 32 + li] : 0.f;
         v = y > 0.f ? v : v * g.leak;
       }
       tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = v;
@@ -308,7 +309,7 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
       if (row < g.M) {
         float v = out[j] + bias;
         if (g.act == 1) v = fmaxf(v, 0.f) + g.leak * fminf(v, 0.f);
-        else if (g.act == 2) v = g.act_out[(long)row * g.act_ld + col] > 0.f ? v : v * g.leak;
+        else if (g.act == 2) v = g.act_out[(long)((g.act_wrap > 0 && row >= g.act_wrap) ? row - g.act_wrap : row) * g.act_ld + col] > 0.f ? v : v * g.leak;
         C[(long)row * g.ldc + col] = v;
       }
     }

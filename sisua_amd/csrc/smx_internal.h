@@ -77,6 +77,7 @@ struct GemmArgs {
   // act(v) = max(v, 0) + leak min(v, 0); act = 2 (backward): C = acc * act'(y) with y = act_out[row][col] the layer's
   // forward output (1 where y > 0, leak elsewhere) -- the bias / activation launches of such layers disappear
   int act = 0; float leak = 0.f; const float* act_out = nullptr; int act_ld = 0;
+  int act_wrap = 0;     // act = 2, > 0: output rows >= act_wrap take the forward output of row - act_wrap (two backward sweeps stacked as rows of one product)
   int panel_hint = 0;   // launch_wgrad_group: take the panel form (smx_panel.h) for this problem whatever its M (N <= 128)
 };
 // Returns 0 or a negative smx_status.  N, lda, ldb, ldc multiples of 4; N multiple of 32.

@@ -179,7 +179,7 @@ struct smx_model {
   int n_heads = 0;                    // label heads on the decoder (0 for fvae: SemiFVAE's labels go to the discriminator)
   // fvae: discriminator on z (smx_factor.hip)
   std::vector<MlpLayer> disc; int t_discoutW = -1, t_discoutb = -1;
-  float *zz = nullptr, *u_tc = nullptr, *u_d = nullptr, *tc_cell = nullptr, *dl_cell = nullptr, *dz_tc = nullptr;
+  float *zz = nullptr, *u_d = nullptr, *tc_cell = nullptr, *dl_cell = nullptr, *dz_tc = nullptr;
   float *disc_dpre = nullptr, *disc_db = nullptr;
   int t_prLogits = -1, t_prLoc = -1, t_prScale = -1;    // scale: Gaussian-mixture prior
   float *resp = nullptr, *dklz = nullptr;

@@ -272,10 +272,11 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     for (auto& L : m->disc) {
       up = std::max(up, L.out_p);
       if (L.out_p > m->max_feat_p) m->max_feat_p = L.out_p;
-      if ((rc = dmalloc(&L.xhat, 2 * B * L.out_p)) || (rc = dmalloc(&L.out_buf, 2 * B * L.out_p)) || (rc = dmalloc(&L.dpre, 2 * B * L.out_p)))
+      if ((rc = dmalloc(&L.xhat, 2 * B * L.out_p)) || (rc = dmalloc(&L.out_buf, 2 * B * L.out_p)) || (rc = dmalloc(&L.dpre, 3 * B * L.out_p)))   // (d pre: both backward sweeps as rows of one buffer)
         return fail(rc);
     }
-    if ((rc = dmalloc(&m->zz, 2 * B * m->Dp)) || (rc = dmalloc(&m->u_tc, B * 32)) || (rc = dmalloc(&m->u_d, 2 * B * 32)) ||
+    // the two upstream gradients on the logits in ONE buffer: rows [0, 2B) the discriminator's objective, rows [2B, 3B) the TC term
+    if ((rc = dmalloc(&m->zz, 2 * B * m->Dp)) || (rc = dmalloc(&m->u_d, 3 * B * 32)) ||
         (rc = dmalloc(&m->tc_cell, B)) || (rc = dmalloc(&m->dl_cell, 2 * B)) || (rc = dmalloc(&m->dz_tc, B * m->Dp)) ||
         (rc = dmalloc(&m->disc_dpre, B * up)) || (rc = dmalloc(&m->disc_db, (size_t)up)))
       return fail(rc);
@@ -377,7 +378,7 @@ int smx_model_destroy(smx_model* m) {
   fr(m->rows2[0]); fr(m->rows2[1]); fr(m->order); fr(m->state3); fr(m->mhist);
   fr(m->resp); fr(m->dklz);
   for (auto& L : m->disc) { fr(L.xhat); fr(L.out_buf); fr(L.dpre); }
-  fr(m->zz); fr(m->u_tc); fr(m->u_d); fr(m->tc_cell); fr(m->dl_cell); fr(m->dz_tc); fr(m->disc_dpre); fr(m->disc_db);
+  fr(m->zz); fr(m->u_d); fr(m->tc_cell); fr(m->dl_cell); fr(m->dz_tc); fr(m->disc_dpre); fr(m->disc_db);
   fr(m->noise_eps); fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);
   fr(m->latlbuf); fr(m->dlatl); fr(m->lsmp); fr(m->lsig); fr(m->leps); fr(m->kl_l); fr(m->dl);
   fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);

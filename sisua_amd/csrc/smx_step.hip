@@ -672,7 +672,8 @@ int factor_forward(smx_model* m, const Pass& ps, bool backward) {
   h.bias = P_(m, m->t_discoutb); h.n_out = tw.cols; h.B = B;
   h.gamma = c.gamma; h.alpha = c.alpha; h.inv_gb = 1.f / (float)ps.global_batch; h.backward = backward ? 1 : 0;
   if (c.n_labels && m->Y[0] && ps.Xsrc == m->X) { h.Y = m->Y[0]; h.ldy = m->lab_Pp[0]; h.rows = ps.rows; h.mask = m->mask; }
-  h.u_tc = m->u_tc; h.u_d = m->u_d; h.tc_cell = m->tc_cell; h.dl_cell = m->dl_cell; h.llk_y = c.n_labels ? m->llk_y : nullptr;
+  h.u_tc = m->u_d + (size_t)2 * B * 32; h.u_d = m->u_d;   // (one buffer: rows [0, 2B) the discriminator's objective, [2B, 3B) the TC term)
+  h.tc_cell = m->tc_cell; h.dl_cell = m->dl_cell; h.llk_y = c.n_labels ? m->llk_y : nullptr;
   Timed t(m, "disc_head");
   SMX_CHECK(launch_disc_head(m->st, h));
   return SMX_OK;
@@ -787,9 +788,84 @@ int factor_sweep(smx_model* m, const Pass& ps, int rows, const float* up, bool w
   return SMX_OK;
 }
 
+// Both backward sweeps of the discriminator as rows of ONE chain of products: rows [0, 2B) carry the discriminator's own objective
+// (its weight gradients contract over exactly these rows), rows [2B, 3B) the VAE objective's TC term on the rows of z (they only
+// pass through the weights: d objective / d z in the end).  The input gradients of a layer are then one launch of 3B rows
+// instead of one of 2B and one of B (each a latency chain of ~8 us whatever its row count), the activation's derivative for
+// the extra rows reads the forward output of row - 2B (GemmArgs::act_wrap), every bias gradient is the column sum of its
+// weight-gradient product.  Needs the store-path activation (flag act_epilogue); without it: the two sweeps of factor_sweep.
+static int factor_backward_stacked(smx_model* m, const Pass& ps) {
+  const int B = ps.B, R2 = 2 * B, R3 = 3 * B;
+  const MlpLayer& last = m->disc.back();
+  const TensorInfo& two = m->tensors[m->t_discoutW];
+  const bool b3 = b3_on(m, ps) && getenv("SMX_NO_DGEMM") == nullptr;
+  const float* up = m->u_d;   // [3B][32]
+  auto wgrad = [&](const GemmArgs& g) -> int {
+    if (!(b3 && m->flags.wgrad && wgrad_supported(g, R2))) return launch_gemm(m->st, g);
+    if (g.M >= 512 && g.N % 128 == 0 && g.N / 128 <= SMX_GROUP_MAX && g.N > 128 && getenv("SMX_NO_PANEL") == nullptr) {
+      GemmArgs part[SMX_GROUP_MAX];
+      int counts[SMX_GROUP_MAX];
+      const int ng = g.N / 128, per = ((g.M + 31) / 32) * 8;
+      for (int k = 0; k < ng; ++k) {
+        part[k] = g;
+        part[k].B = g.B + 128 * k; part[k].C = g.C + 128 * k; part[k].N = 128; part[k].panel_hint = 1;
+        if (g.colsum) part[k].colsum = g.colsum + 128 * k;
+        if (g.sq_part) { part[k].sq_part = g.sq_part + (long)per * k; part[k].sq_count = &counts[k]; }
+      }
+      const int rc = launch_wgrad_group(m->st, part, ng, R2, 1);
+      if (rc == SMX_OK && g.sq_part && g.sq_count) *g.sq_count = per * ng;
+      return rc;
+    }
+    return launch_wgrad_group(m->st, &g, 1, R2, 1);
+  };
+  Timed t(m, "disc_bwd");
+  {   // the logit layer: weight gradient over the discriminator's rows, then the input gradient of all 3B rows -> d pre of the last hidden layer
+    GemmArgs gw;
+    gw.A = last.out_buf; gw.lda = last.out_p; gw.a_kmajor = 1; gw.B = up; gw.ldb = 32;
+    gw.C = G_(m, m->t_discoutW); gw.ldc = two.ld; gw.M = last.out_p; gw.N = two.ld; gw.K = R2;
+    gw.colsum = G_(m, m->t_discoutb);
+    want_sq(m, gw, m->t_discoutW);
+    SMX_CHECK(wgrad(gw));
+    MlpLayer& Ll = m->disc.back();
+    GemmArgs gh;
+    gh.A = up; gh.lda = 32; gh.B = P_(m, m->t_discoutW); gh.ldb = two.ld; gh.b_nmajor = 1;
+    gh.M = R3; gh.N = last.out_p; gh.K = two.ld; gh.split_k = 1;
+    gh.act = 2; gh.leak = Ll.leak; gh.act_out = Ll.out_buf; gh.act_ld = Ll.out_p; gh.act_wrap = R2;
+    gh.C = Ll.dpre; gh.ldc = Ll.out_p;
+    SMX_CHECK(launch_gemm(m->st, gh));
+  }
+  for (int i = (int)m->disc.size() - 1; i >= 0; --i) {
+    MlpLayer& L = m->disc[i];
+    const TensorInfo& tw = m->tensors[L.tW];
+    const float* in = (i == 0) ? m->zz : m->disc[i - 1].out_buf;
+    const int ld_in = (i == 0) ? m->Dp : m->disc[i - 1].out_p;
+    GemmArgs g;   // weight gradient (+ bias gradient as its column sum) over the discriminator's 2B rows
+    g.A = in; g.lda = ld_in; g.a_kmajor = 1; g.B = L.dpre; g.ldb = L.out_p;
+    g.C = G_(m, L.tW); g.ldc = tw.ld; g.M = L.in_p; g.N = L.out_p; g.K = R2;
+    g.colsum = G_(m, L.tBias);
+    want_sq(m, g, L.tW);
+    SMX_CHECK(wgrad(g));
+    GemmArgs h;   // input gradient
+    h.B = P_(m, L.tW); h.ldb = tw.ld; h.b_nmajor = 1; h.K = L.out_p; h.split_k = 1;
+    if (i == 0) {   // into z: only the TC rows (z is a constant of the discriminator's objective)
+      h.A = L.dpre + (size_t)R2 * L.out_p; h.lda = L.out_p; h.M = B; h.N = L.in_p;
+      h.C = m->dz_tc; h.ldc = m->Dp; h.tile = TILE_32x32_K4;
+    } else {
+      MlpLayer& Lo = m->disc[i - 1];
+      h.A = L.dpre; h.lda = L.out_p; h.M = R3; h.N = L.in_p;
+      h.act = 2; h.leak = Lo.leak; h.act_out = Lo.out_buf; h.act_ld = Lo.out_p; h.act_wrap = R2;
+      h.C = Lo.dpre; h.ldc = Lo.out_p;
+    }
+    if (b3 && dgemm_supported(h)) SMX_CHECK(launch_dgemm(m->st, h));
+    else SMX_CHECK(launch_gemm(m->st, h));
+  }
+  return SMX_OK;
+}
+
 int factor_backward(smx_model* m, const Pass& ps) {
-  SMX_CHECK(factor_sweep(m, ps, 2 * ps.B, m->u_d, true));    // discriminator objective -> the discriminator's tensors
-  SMX_CHECK(factor_sweep(m, ps, ps.B, m->u_tc, false));      // gamma TC (+ alpha CE) -> d z
+  if (m->flags.act_epilogue && getenv("SMX_FVAE_TWO_SWEEPS") == nullptr) return factor_backward_stacked(m, ps);
+  SMX_CHECK(factor_sweep(m, ps, 2 * ps.B, m->u_d, true));                          // discriminator objective -> the discriminator's tensors
+  SMX_CHECK(factor_sweep(m, ps, ps.B, m->u_d + (size_t)2 * ps.B * 32, false));     // gamma TC (+ alpha CE) -> d z
   return SMX_OK;
 }
 
