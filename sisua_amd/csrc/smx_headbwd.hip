@@ -21,6 +21,7 @@
 
 #include "smx_internal.h"
 #include "smx_panel.h"
+#include "smx_dgemm.h"
 #include "../../include/sisua_hip.h"
 
 namespace smx {
@@ -459,6 +460,29 @@ __global__ __launch_bounds__(512, ONE ? 4 : 2) void wgrad_panel_group_kernel(Wgr
   else panel_body<0, 0, ONE>(pp, (int)blockIdx.x - P.start, P.panel, red);
 }
 
+// The group beside ONE product of the direct-operand form (smx_dgemm.h): a layer's weight gradient and its input gradient both
+// read the layer's d pre-activation and nothing of each other -- FactorVAE's 1000-wide discriminator layers, where each of the
+// two is a latency chain of ~9 us that leaves the chip half idle.  Workgroups [0, n_w) are the group's, the rest the product's.
+template <int ONE>
+__global__ __launch_bounds__(512, ONE ? 4 : 2) void wgrad_dgemm_kernel(WgradGroup G, GemmArgs g, int n_w) {
+  constexpr int SM = SMX_DG_SMEM_FLOATS(1) > SMX_PANEL_SMEM_FLOATS ? SMX_DG_SMEM_FLOATS(1) : SMX_PANEL_SMEM_FLOATS;
+  __shared__ __attribute__((aligned(16))) float red[SM];
+  __shared__ float sqs[8];
+  if ((int)blockIdx.x >= n_w) { dgemm_body<1>(g, (int)blockIdx.x - n_w, red); return; }   // (block-uniform)
+  const WgradGroup& Gr = *(const WgradGroup*)__builtin_amdgcn_kernarg_segment_ptr();
+  int pi = 0;
+  while (pi + 1 < Gr.n && (int)blockIdx.x >= Gr.p[pi + 1].start) ++pi;
+  const WgradProblem& P = Gr.p[pi];
+  if (!P.panel) { wgrad_tile_body(Gr, P, red, sqs); return; }
+  PanelProblem pp;
+  pp.big = P.A; pp.ld_big = P.lda; pp.big_mode = P.a_mode; pp.log1p = P.a_mode ? P.log1p : 0; pp.rows = P.a_mode ? P.rows : nullptr;
+  pp.S = P.Bm; pp.ldS = P.ldb; pp.n_st = P.n_nt; pp.out = P.C; pp.ld_out = P.ldc;
+  pp.s_colsum = P.colsum; pp.sq_part = P.sq_part; pp.n_wt = P.n_mt; pp.B = Gr.B;
+  if (P.a_mode == 2) panel_body<0, 2, ONE>(pp, (int)blockIdx.x - P.start, P.panel, red);
+  else if (P.a_mode == 1) panel_body<0, 1, ONE>(pp, (int)blockIdx.x - P.start, P.panel, red);
+  else panel_body<0, 0, ONE>(pp, (int)blockIdx.x - P.start, P.panel, red);
+}
+
 bool wgrad_supported(const GemmArgs& g, int B) {
   // C = A^T Bm with A stored [K][M] (k-major), Bm [K][N], K = the minibatch; optional gather + log1p of A; no input dropout
   if (!g.a_kmajor || g.b_nmajor || g.K != B || g.split_k > 1 || g.epi != 0 || g.bias) return false;
@@ -467,7 +491,7 @@ bool wgrad_supported(const GemmArgs& g, int B) {
   return true;
 }
 
-int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int bf16x3) {
+int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int bf16x3, const GemmArgs* beside) {
   if (n < 1 || n > SMX_GROUP_MAX) { set_error("wgrad group: 1..SMX_GROUP_MAX problems"); return SMX_ERR_INVALID; }
   WgradGroup G;
   memset(&G, 0, sizeof(G));
@@ -494,10 +518,20 @@ int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int b
     total += P.n_nt * ((P.n_mt + 7) / 8 * 8);
     if (g.sq_part && g.sq_count) *g.sq_count = P.n_mt * P.n_nt * 4;
   }
+  if (beside && !(dgemm_supported(*beside) && beside->b_nmajor)) { set_error("wgrad group: the product beside it is not of the direct-operand form"); return SMX_ERR_INVALID; }
+  if (beside && any_panel) {   // (without a panel problem the two stay two launches: the tile kernel's 48 registers are worth more)
+    const GemmArgs& d = *beside;
+    const int d_grid = ((d.M + 31) / 32) * ((d.N / 32 + 7) / 8 * 8);
+    if (B <= 128) hipLaunchKernelGGL(wgrad_dgemm_kernel<1>, dim3((unsigned)(total + d_grid)), dim3(512), 0, st, G, d, total);
+    else hipLaunchKernelGGL(wgrad_dgemm_kernel<0>, dim3((unsigned)(total + d_grid)), dim3(512), 0, st, G, d, total);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   if (any_panel && B <= 128) hipLaunchKernelGGL(wgrad_panel_group_kernel<1>, dim3((unsigned)total), dim3(512), 0, st, G);
   else if (any_panel) hipLaunchKernelGGL(wgrad_panel_group_kernel<0>, dim3((unsigned)total), dim3(512), 0, st, G);
   else hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)total), dim3(512), 0, st, G);
   SMX_HIP(hipGetLastError());
+  if (beside) return launch_dgemm(st, *beside);
   return SMX_OK;
 }
 

@@ -527,7 +527,9 @@ struct PanelProblem {
 int panel_grid(int units);   // workgroups for `units` tiles: whole rounds of at most two per CU, evenly filled
 bool panel_dw_supported(const HeadBwdArgs& a);
 int launch_panel_dw(hipStream_t st, const HeadBwdArgs& a);   // the output head's dW / db (role 1) in place of launch_out_head_bwd's role 0
-int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int bf16x3 = 0);
+// beside: one product of smx_dgemm.hip's form (b_nmajor) that depends on nothing the group writes -- the same launch carries it when
+// the group holds a panel problem, a launch of its own follows otherwise
+int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int bf16x3 = 0, const GemmArgs* beside = nullptr);
 
 // ---- FactorVAE discriminator (smx_factor.hip; sisua/models/fvae.py:9-18, Kim & Mnih 2018 Algorithm 2) -------------
 enum { ST_PERMUTE = 66 };   // Philox stream of the permute_dims uniforms

@@ -554,7 +554,7 @@ int launch_bn_act_fwd_dual(hipStream_t st, const BnFwdArgs& a, const BnFwdArgs& 
 }
 
 __device__ inline void metrics_body(const MetricsArgs& a);
-__device__ inline void adam_chunk_body(const AdamArgs& a, int chunk);
+template <int NT = 256> __device__ inline void adam_chunk_body(const AdamArgs& a, int chunk);
 __device__ inline void sq_reduce_body(const float* sl, int cnt, float* dst);
 
 template <int RPT, int FRONT>
@@ -565,10 +565,10 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
   {
     const int nb = a.Hp / BN_COLS, extra = bid - nb;
     if (extra >= 0) {
-      if (threadIdx.x >= 256) return;                   // the riders are 256-thread bodies
       const int e = extra - (a.with_metrics ? 1 : 0);
+      if (e >= 0 && e < a.adam_count) { adam_chunk_body<BN_THREADS>(a.adam, a.adam_first + e); return; }   // optimiser chunks of the heads: every thread of the workgroup
+      if (threadIdx.x >= 256) return;                   // the other riders are 256-thread bodies
       if (e < 0) metrics_body(a.metrics);                                                 // ELBO scalars
-      else if (e < a.adam_count) adam_chunk_body(a.adam, a.adam_first + e);               // optimiser chunks of the heads
       else {                                                                              // or only their gradient norms
         const int i = e - a.adam_count;
         sq_reduce_body(a.adam.sq_slots + a.sqr_first[i], a.sqr_n[i], a.sq_total + a.sqr_dst[i]);
@@ -1635,12 +1635,15 @@ __device__ inline void sq_reduce_body(const float* sl, int cnt, float* dst) {
   if (threadIdx.x == 0) *dst = s;
 }
 
-// clip + Adam for one chunk of the flat buffer; 256 threads
+// clip + Adam for one chunk of the flat buffer; NT = 256 threads, or 512 as a rider of a 512-thread launch (the tensor's norm is
+// summed by the first 256 threads in the same order either way: both forms give the same bits)
+template <int NT>
 __device__ inline void adam_chunk_body(const AdamArgs& a, int chunk) {
   __shared__ float sh[4];
   const OptChunk ch = a.chunks[chunk];
   float s = 0.f;
-  if (a.use_sq) {
+  if (NT > 256 && threadIdx.x >= 256) {
+  } else if (a.use_sq) {
     const int cnt = a.sq_count[ch.tensor];
     if (cnt > 0) {   // partial sums written by the weight-gradient product's workgroups
       const float* sl = a.sq_slots + a.sq_first[ch.tensor];
@@ -1655,7 +1658,15 @@ __device__ inline void adam_chunk_body(const AdamArgs& a, int chunk) {
   } else {
     for (int i = threadIdx.x; i < ch.n_chunks; i += 256) s += a.partial[ch.first_chunk + i];
   }
-  s = block_sum(s, sh);
+  if (NT > 256) {   // (block_sum with the waves past the fourth standing by)
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  } else {
+    s = block_sum(s, sh);
+  }
   const float norm = sqrtf(s) * a.grad_scale;
   float clip = a.grad_scale;
   if (a.clipnorm > 0.f && norm > a.clipnorm) clip *= a.clipnorm / norm;
@@ -1665,7 +1676,7 @@ __device__ inline void adam_chunk_body(const AdamArgs& a, int chunk) {
   float4* m4 = reinterpret_cast<float4*>(a.m + ch.offset);
   float4* v4 = reinterpret_cast<float4*>(a.v + ch.offset);
   float4* p4 = reinterpret_cast<float4*>(a.params + ch.offset);
-  for (int i = threadIdx.x; i < ch.count / 4; i += 256) {
+  for (int i = threadIdx.x; i < ch.count / 4; i += NT) {
     const float4 g = g4[i];
     float4 m = m4[i], v = v4[i], p = p4[i];
     const float gg[4] = {g.x * clip, g.y * clip, g.z * clip, g.w * clip};

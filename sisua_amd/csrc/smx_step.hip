@@ -199,9 +199,13 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
     if (m->adam_rest_to > m->adam_rest_from) {
       fill_adam_args(m, b.adam);
       b.adam.use_sq = 1;
-      for (size_t t = 0; t < m->tensors.size(); ++t) { b.adam.sq_first[t] = m->sq_first[t]; b.adam.sq_count[t] = m->sq_count[t]; }
+      for (size_t t = 0; t < m->tensors.size(); ++t) {
+        b.adam.sq_first[t] = m->sq_first[t]; b.adam.sq_count[t] = m->sq_count[t];
+        if (m->sq_reduced[t]) { b.adam.sq_first[t] = m->sq_total_first + (int)t * SMX_SQR_PER_TENSOR; b.adam.sq_count[t] = m->sq_reduced[t]; }   // (summed by the launch before)
+      }
       b.adam.master = nullptr; b.adam.with_metrics = 0;
       b.adam_first = m->adam_rest_from; b.adam_count = m->adam_rest_to - m->adam_rest_from;
+      if (m->adam_early_from < 0) m->adam_early_from = m->adam_rest_from;
       m->adam_early_to = m->adam_rest_to;
       m->adam_rest_from = m->adam_rest_to = 0;
     }
@@ -233,6 +237,12 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
       m->sq_reduced[t] = (char)r;   // the optimiser reads r partial sums for this tensor
     }
     b.sq_total = m->sq_slots + m->sq_total_first;
+    // ... and a share of the heads' chunks rides with the NEXT BatchNorm-backward launch as full 512-thread workgroups (the norms are
+    // single numbers by then): SMX_ADAM_WIDE_SHARE of them, the optimiser launch keeps the rest
+    static const float share = getenv("SMX_ADAM_WIDE_SHARE") ? (float)atof(getenv("SMX_ADAM_WIDE_SHARE")) : 0.3f;
+    const int early_to = m->lab_deferred ? m->chunk_first_label : m->n_chunks;
+    const int n = (int)((early_to - m->chunk_first_head) * std::min(std::max(share, 0.f), 1.f));
+    if (n > 0) { m->adam_rest_from = m->chunk_first_head; m->adam_rest_to = m->chunk_first_head + n; }
     return;
   }
   fill_adam_args(m, b.adam);
@@ -800,7 +810,13 @@ static int factor_backward_stacked(smx_model* m, const Pass& ps) {
   const TensorInfo& two = m->tensors[m->t_discoutW];
   const bool b3 = b3_on(m, ps) && getenv("SMX_NO_DGEMM") == nullptr;
   const float* up = m->u_d;   // [3B][32]
-  auto wgrad = [&](const GemmArgs& g) -> int {
+  static const bool beside_on = getenv("SMX_FVAE_NO_BESIDE") == nullptr;
+  // beside: the layer's input gradient in the same launch (wgrad_dgemm_kernel) where both forms apply, right after it otherwise
+  auto input_grad = [&](const GemmArgs& h) -> int {
+    if (b3 && dgemm_supported(h)) return launch_dgemm(m->st, h);
+    return launch_gemm(m->st, h);
+  };
+  auto wgrad = [&](const GemmArgs& g, const GemmArgs* beside = nullptr) -> int {
     if (!(b3 && m->flags.wgrad && wgrad_supported(g, R2))) return launch_gemm(m->st, g);
     if (g.M >= 512 && g.N % 128 == 0 && g.N / 128 <= SMX_GROUP_MAX && g.N > 128 && getenv("SMX_NO_PANEL") == nullptr) {
       GemmArgs part[SMX_GROUP_MAX];
@@ -812,11 +828,11 @@ static int factor_backward_stacked(smx_model* m, const Pass& ps) {
         if (g.colsum) part[k].colsum = g.colsum + 128 * k;
         if (g.sq_part) { part[k].sq_part = g.sq_part + (long)per * k; part[k].sq_count = &counts[k]; }
       }
-      const int rc = launch_wgrad_group(m->st, part, ng, R2, 1);
+      const int rc = launch_wgrad_group(m->st, part, ng, R2, 1, beside);
       if (rc == SMX_OK && g.sq_part && g.sq_count) *g.sq_count = per * ng;
       return rc;
     }
-    return launch_wgrad_group(m->st, &g, 1, R2, 1);
+    return launch_wgrad_group(m->st, &g, 1, R2, 1, beside);
   };
   Timed t(m, "disc_bwd");
   {   // the logit layer: weight gradient over the discriminator's rows, then the input gradient of all 3B rows -> d pre of the last hidden layer
@@ -844,7 +860,6 @@ static int factor_backward_stacked(smx_model* m, const Pass& ps) {
     g.C = G_(m, L.tW); g.ldc = tw.ld; g.M = L.in_p; g.N = L.out_p; g.K = R2;
     g.colsum = G_(m, L.tBias);
     want_sq(m, g, L.tW);
-    SMX_CHECK(wgrad(g));
     GemmArgs h;   // input gradient
     h.B = P_(m, L.tW); h.ldb = tw.ld; h.b_nmajor = 1; h.K = L.out_p; h.split_k = 1;
     if (i == 0) {   // into z: only the TC rows (z is a constant of the discriminator's objective)
@@ -856,8 +871,8 @@ static int factor_backward_stacked(smx_model* m, const Pass& ps) {
       h.act = 2; h.leak = Lo.leak; h.act_out = Lo.out_buf; h.act_ld = Lo.out_p; h.act_wrap = R2;
       h.C = Lo.dpre; h.ldc = Lo.out_p;
     }
-    if (b3 && dgemm_supported(h)) SMX_CHECK(launch_dgemm(m->st, h));
-    else SMX_CHECK(launch_gemm(m->st, h));
+    if (beside_on && b3 && m->flags.wgrad && wgrad_supported(g, R2) && dgemm_supported(h) && h.b_nmajor) SMX_CHECK(wgrad(g, &h));
+    else { SMX_CHECK(wgrad(g)); SMX_CHECK(input_grad(h)); }
   }
   return SMX_OK;
 }
