@@ -263,8 +263,29 @@ def attach_engine(engine, cp):
   if mode not in ("rccl", "p2p", "p2p-only"):               # peer buffers, beside RCCL) | 'p2p-only' (no RCCL communicator at all)
     raise ValueError("SMX_ALLREDUCE must be 'rccl', 'p2p' or 'p2p-only'")
   if mode != "p2p-only":
-    uid = cp.broadcast_bytes(Engine.comm_unique_id)
-    engine.comm_init(cp.rank, cp.world, uid)
+    def unique_id():
+      try:
+        return Engine.comm_unique_id()
+      except Exception as e:   # (librccl did not load: the peers must still get an answer)
+        return b"!" + str(e).encode()
+    uid = cp.broadcast_bytes(unique_id)
+    err = None
+    try:
+      if uid[:1] == b"!" and len(uid) != 128:
+        raise RuntimeError(uid[1:].decode(errors="replace"))
+      engine.comm_init(cp.rank, cp.world, uid)
+    except Exception as e:   # (a failed ncclCommInitRank leaves the model without a communicator: smx_comm.hip)
+      err = e
+    failed = [b == b"1" for b in cp.allgather_bytes(b"1" if err is not None else b"0")]
+    if any(failed):
+      # every rank failed the same way (library mismatch, a refused device set): the job goes on over the hand-written exchange,
+      # which needs nothing but HIP IPC; a communicator that came up on SOME ranks only cannot be repaired from here
+      if not all(failed) or os.environ.get("SMX_NO_COMM_FALLBACK"):
+        raise err if err is not None else RuntimeError("RCCL communicator: ranks " + str([i for i, f in enumerate(failed) if f]) + " failed to join")
+      if cp.rank == 0:
+        import warnings
+        warnings.warn(f"RCCL communicator unavailable ({err}); falling back to SMX_ALLREDUCE=p2p-only")
+      mode = "p2p-only"
   if mode != "rccl":
     handles = cp.allgather_bytes(engine.comm_p2p_export(cp.world))
     engine.comm_p2p_init(cp.rank, cp.world, b"".join(handles))

@@ -36,8 +36,12 @@ e = Engine(cfg, max_batch=64, init=False)
 e.set_params(perturbed_params(spec))
 e.upload(x, cell_id_base=1000)
 cp = ControlPlane(rank, world)
-handles = cp.allgather_bytes(e.comm_p2p_export(world))
-e.comm_p2p_init(rank, world, b"".join(handles))
+if os.environ.get("SMX_TEST_ATTACH"):   # the package's own way in: RCCL first, the exchange if no communicator comes up
+  from sisua_amd.parallel import attach_engine
+  attach_engine(e, cp)
+else:
+  handles = cp.allgather_bytes(e.comm_p2p_export(world))
+  e.comm_p2p_init(rank, world, b"".join(handles))
 assert e.world == world and e.rank == rank
 e.set_sync_bn(bool(sync_bn))
 cp.barrier()
@@ -143,3 +147,26 @@ def test_p2p_exchange_gives_up_on_a_dead_peer(tmp_path):
   assert outs[0][0] == 0 and "DONE" in outs[0][1], outs[0][1][-3000:]
   r0 = np.load(tmp_path / "r0.npz")
   assert int(r0["err"]) != 0
+
+
+def test_attach_engine_falls_back_to_the_exchange_when_rccl_refuses(tmp_path):
+  """parallel.attach_engine with the default SMX_ALLREDUCE: RCCL refuses two ranks on the box's one device on EVERY rank, the
+  ranks agree on that over the control plane and carry on over the peer-to-peer exchange -- same results as joining it directly."""
+  from sisua_amd import build
+  build.build(verbose=False)
+  direct = tmp_path / "direct"; direct.mkdir()
+  fb = tmp_path / "fallback"; fb.mkdir()
+  outs = _run(direct, 2, KW)
+  assert all(rc == 0 and "DONE" in out for rc, out in outs), outs[0][1][-2000:]
+  outs = _run(fb, 2, KW, extra_env=dict(SMX_TEST_ATTACH="1"))
+  assert all(rc == 0 and "DONE" in out for rc, out in outs), outs[0][1][-3000:]
+  assert "falling back to SMX_ALLREDUCE=p2p-only" in outs[0][1]
+  a, b = np.load(direct / "r0.npz"), np.load(fb / "r0.npz")
+  b1 = np.load(fb / "r1.npz")
+  for k in a.files:
+    np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    if k.startswith(("p/", "m/", "g/")):
+      np.testing.assert_array_equal(b[k], b1[k], err_msg=k)
+  # and the switch that forbids the fallback keeps the old behaviour: the job stops with RCCL's error
+  outs = _run(fb, 2, KW, extra_env=dict(SMX_TEST_ATTACH="1", SMX_NO_COMM_FALLBACK="1"))
+  assert all(rc != 0 for rc, _ in outs)
