@@ -195,8 +195,16 @@ int smx_comm_p2p_export(smx_model* m, int world, uint8_t handles[128]) {
   P2PState& p = *m->p2p;
   size_t bytes;
   region_layout(m, world, &p.staging_floats, &p.scratch_floats, &bytes);
+  // Fine-grained device memory: peers STORE their flags into this region while this rank's waves poll it.  A coarse-grained
+  // allocation is only promised to be coherent across agents at kernel boundaries (the owner's L2 may keep serving a polled line);
+  // on one device -- where the tests run -- every process shares the L2 and either kind works, so the kind that is right on a
+  // multi-GPU node is the one used everywhere (SMX_P2P_COARSE=1: plain hipMalloc, as rounds 1-3a did).
   void* region = nullptr;
-  SMX_HIP(hipMalloc(&region, bytes));
+  if (getenv("SMX_P2P_COARSE") != nullptr || hipExtMallocWithFlags(&region, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    region = nullptr;
+    SMX_HIP(hipMalloc(&region, bytes));
+  }
   SMX_HIP(hipMemset(region, 0, bytes));
   p.owns_region = true; p.pending_world = world;
   p.region_base[0] = region;   // (parked until the rank is known: smx_comm_p2p_init moves it to slot `rank`)
