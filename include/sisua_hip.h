@@ -54,8 +54,11 @@ typedef enum { SMX_MODEL_VAE = 0, SMX_MODEL_DCA = 1, SMX_MODEL_SCVI = 2, SMX_MOD
  * parameter plane (the mean), log p(x) := -mean_g (x - mean)^2 -- exactly minus tf.losses.mse.  No marginal-likelihood scoring. */
 typedef enum { SMX_LLK_NB = 0, SMX_LLK_ZINB = 1, SMX_LLK_NBD = 2, SMX_LLK_ZINBD = 3, SMX_LLK_MSE = 4 } smx_likelihood;
 /* Label heads of SISUA (vae.py:19-44): NB (ADT counts), one-hot categorical (cell types); of MISA (vae.py:47-98): every
- * label dimension a mixture of label_components (2..4) negative binomials. */
-typedef enum { SMX_LABEL_NB = 0, SMX_LABEL_ONEHOT = 1, SMX_LABEL_MIXNB = 2, SMX_LABEL_MIXGAUSS = 3 } smx_label_likelihood;
+ * label dimension a mixture of label_components (2..4) negative binomials (SMX_LABEL_MIXNB) or, for continuous labels, normals
+ * (SMX_LABEL_MIXGAUSS, 'mixgaussian', vae.py:86-92); SMX_LABEL_MIXTRIL ('mixtril', the class's docstring example vae.py:58): ONE
+ * mixture of label_components full-covariance Gaussians over the whole label vector (lower-triangular scale factors; label_dim <= 64;
+ * the head then has label_components * (2 + label_dim) planes). */
+typedef enum { SMX_LABEL_NB = 0, SMX_LABEL_ONEHOT = 1, SMX_LABEL_MIXNB = 2, SMX_LABEL_MIXGAUSS = 3, SMX_LABEL_MIXTRIL = 4 } smx_label_likelihood;
 typedef enum { SMX_ACT_RELU = 0, SMX_ACT_LINEAR = 1 } smx_activation;
 
 /* Constructor arguments of SingleCellModel / SCVI / SISUA / DeepCountAutoencoder
@@ -71,7 +74,7 @@ typedef struct {
   int32_t n_dec, dec_units[SMX_MAX_LAYERS];
   int32_t n_encl, encl_units[SMX_MAX_LAYERS];   /* scvi library encoder */
   int32_t n_labels, label_dim[SMX_MAX_LABELS], label_llk[SMX_MAX_LABELS];
-  int32_t label_components[SMX_MAX_LABELS];   /* SMX_LABEL_MIXNB / SMX_LABEL_MIXGAUSS: mixture components (MISA n_components, vae.py:77) */
+  int32_t label_components[SMX_MAX_LABELS];   /* SMX_LABEL_MIXNB / MIXGAUSS / MIXTRIL: mixture components (MISA n_components, vae.py:77) */
   int32_t n_components;                /* SMX_MODEL_SCALE: components of the mixture prior (scale.py:27), 1..32 */
   int32_t disc_units, disc_layers;     /* SMX_MODEL_FVAE: hidden width / hidden layers of the discriminator (odin: 1000, 5) */
   float gamma, disc_leak;              /* SMX_MODEL_FVAE: weight of the TC term (6.0); leaky-ReLU slope (0.2) */

@@ -57,7 +57,8 @@ STREAM_PERMUTE = 66        # fvae: uniforms whose per-dimension ranks are the pe
 LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
 OUTPUT_POSTERIORS = LIKELIHOODS + ("mse",)   # + the deterministic output RVmeta(dim, 'mse') of the reference's tests (one plane: the mean)
 LABEL_LIKELIHOODS = ("nb", "onehot", "mixnb2", "mixnb3", "mixnb4",   # mixnbC: MISA's C-component mixture of NB per label
-                     "mixgauss2", "mixgauss3", "mixgauss4")           # mixgaussC: its C-component mixture of Gaussians (continuous labels)
+                     "mixgauss2", "mixgauss3", "mixgauss4",           # mixgaussC: its C-component mixture of Gaussians (continuous labels)
+                     "mixtril2", "mixtril3", "mixtril4")              # mixtrilC: C full-covariance Gaussians over the whole label vector
 
 
 def mixture_components(llk: str) -> int:
@@ -65,10 +66,16 @@ def mixture_components(llk: str) -> int:
   return int(llk[-1]) if llk.startswith("mix") else 0
 
 
-def label_planes(llk: str) -> int:
+def label_planes(llk: str, P: int = 0) -> int:
   """Raw head outputs per label dimension: 'nb' (log total_count, logits) 2; 'onehot' 1; 'mixnbC' 3 C -- C mixture
   logits, then C log total_counts, then C logits (component-major planes of width P); 'mixgaussC' 3 C -- C mixture logits,
-  C locations, C raw scales."""
+  C locations, C raw scales; 'mixtrilC' C (2 + P) -- C planes whose FIRST column is a component's mixture logit (one per cell:
+  the mixture is over the whole label vector), C planes of locations, then per component P planes holding the columns of its
+  lower-triangular scale factor (plane j, row p >= j: L[p][j]; the entries above the diagonal and the logit planes' other
+  columns are inert: no gradient ever reaches them)."""
+  if llk.startswith("mixtril"):
+    assert P > 0, "label_planes('mixtrilC') needs the label dimension"
+    return mixture_components(llk) * (2 + P)
   return 2 if llk == "nb" else 1 if llk == "onehot" else 3 * mixture_components(llk)
 
 
@@ -199,7 +206,7 @@ def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
     out.append(("out/W", (hd, spec.k * G)))
     out.append(("out/b", (spec.k * G,)))
   for j, (P, llk) in enumerate(() if spec.model == "fvae" else spec.labels):   # (SemiFVAE's labels go to the discriminator)
-    ky = label_planes(llk)
+    ky = label_planes(llk, P)
     out.append((f"lab{j}/W", (hd, ky * P)))
     out.append((f"lab{j}/b", (ky * P,)))
   return out
@@ -424,6 +431,57 @@ def count_llk(x, p: Sequence[np.ndarray], likelihood: str, direct: bool = False)
   return llk, [w * d0, w * d1, d_g]
 
 
+TRIL_DIAG_SHIFT = 1e-5   # [3P-recall] tfp.bijectors.FillScaleTriL(diag_shift=1e-5), diagonal through softplus
+
+
+def _mixtril_llk(y, raw, C):
+  """MISA's 'mixtril' head (the reference's own docstring example, sisua/models/vae.py:58): ONE C-component mixture over the whole
+  label vector, component c = MultivariateNormalTriL(loc_c, L_c) ([3P-recall] odin's MixtureDensityNetwork with covariance =
+  'tril'; TFP: diag(L) = softplus(raw) + 1e-5, strict lower triangle = raw).  Plane layout: label_planes.
+    log N(y; mu, L L^T) = -1/2 |u|^2 - sum_p log L_pp - P/2 log 2 pi,  u = L^-1 (y - mu)
+    d / d mu = w,  d / d L_pj = w_p u_j - [p == j] / L_pp,  w = L^-T u."""
+  B = raw.shape[0]
+  # ky * P = C (2 + P) P  ->  P from the width
+  W = raw.shape[1]
+  P = int(round((-2 + np.sqrt(4 + 4 * W / C)) / 2))
+  assert C * (2 + P) * P == W, "mixtril: head width is not C (2 + P) P"
+  plane = lambda k: raw[:, k * P:(k + 1) * P]
+  a = np.stack([plane(c)[:, 0] for c in range(C)], 0)                                  # [C, B] mixture logits
+  ell = np.zeros((C, B))
+  keep = []
+  for c in range(C):
+    mu = plane(C + c)
+    Lraw = np.stack([plane(2 * C + c * P + j) for j in range(P)], 2)                   # [B, p, j]
+    diag_raw = np.einsum("bpp->bp", Lraw)
+    L = np.tril(Lraw, -1)
+    dg = softplus(diag_raw) + TRIL_DIAG_SHIFT
+    L[:, np.arange(P), np.arange(P)] = dg
+    u = np.zeros((B, P))
+    for p_ in range(P):                                                                # forward substitution
+      u[:, p_] = ((y - mu)[:, p_] - (L[:, p_, :p_] * u[:, :p_]).sum(1)) / dg[:, p_]
+    w = np.zeros((B, P))
+    for p_ in range(P - 1, -1, -1):                                                    # back substitution with L^T
+      w[:, p_] = (u[:, p_] - (L[:, p_ + 1:, p_] * w[:, p_ + 1:]).sum(1)) / dg[:, p_]
+    ell[c] = -0.5 * (u * u).sum(1) - np.log(dg).sum(1) - 0.5 * P * np.log(2.0 * np.pi)
+    dL = np.tril(w[:, :, None] * u[:, None, :])                                        # [B, p, j] = w_p u_j, j <= p
+    dL[:, np.arange(P), np.arange(P)] = (w * u - 1.0 / dg) * expit(diag_raw)
+    keep.append((w, dL))
+  am = a.max(0)
+  log_pi = a - (am + np.log(np.exp(a - am).sum(0)))
+  joint = log_pi + ell
+  jm = joint.max(0)
+  llk = jm + np.log(np.exp(joint - jm).sum(0))
+  resp = np.exp(joint - llk)                                                           # [C, B]
+  d = np.zeros_like(raw)
+  for c in range(C):
+    d[:, c * P] = resp[c] - np.exp(log_pi[c])
+    d[:, (C + c) * P:(C + c + 1) * P] = resp[c][:, None] * keep[c][0]
+    for j in range(P):
+      k = 2 * C + c * P + j
+      d[:, k * P:(k + 1) * P] = resp[c][:, None] * keep[c][1][:, :, j]
+  return llk, d
+
+
 def label_llk(y, raw, llk_kind):
   """Per-cell log-likelihood of one label head and its gradient wrt the raw head outputs.
   'nb' (ADT counts, configs/base.yaml:38-40), 'onehot' (cell types, :41-43), 'mixnbC' (MISA, sisua/models/vae.py:47-98:
@@ -433,6 +491,8 @@ def label_llk(y, raw, llk_kind):
     P = raw.shape[1] // 2
     ell, (da, dl) = count_llk(y, [raw[:, :P], raw[:, P:]], "nb")
     return ell.sum(1), np.concatenate([da, dl], axis=1)
+  if llk_kind.startswith("mixtril"):
+    return _mixtril_llk(y, raw, mixture_components(llk_kind))
   if llk_kind.startswith("mix"):
     C = mixture_components(llk_kind)
     P = raw.shape[1] // (3 * C)

@@ -17,10 +17,17 @@ LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
 OUTPUT_POSTERIORS = LIKELIHOODS + ("mse",)   # 'mse': deterministic output, -log_prob(x) = mean squared error (tests/test_singlecell_models.py:82-91)
 
 
-def label_planes(llk: str) -> int:
+def label_planes(llk: str, P: int = 0) -> int:
   """Raw head outputs per label dimension: 'nb' 2 (log total_count, logits), 'onehot' 1, 'mixnbC' 3 C (C mixture
   logits, C log total_counts, C logits: MISA's mixture-of-NB labels, sisua/models/vae.py:47-98), 'mixgaussC' 3 C (C mixture
-  logits, C locations, C raw scales: its mixture-of-Gaussians labels for continuous variables, vae.py:86-92)."""
+  logits, C locations, C raw scales: its mixture-of-Gaussians labels for continuous variables, vae.py:86-92), 'mixtrilC'
+  C (2 + P) (the docstring example of vae.py:58: C full-covariance Gaussians over the whole label vector -- C planes whose
+  first column is a component's mixture logit, C planes of locations, per component P planes = the columns of its
+  lower-triangular scale factor; the other entries are inert)."""
+  if llk.startswith("mixtril"):
+    if P <= 0:
+      raise ValueError("label_planes('mixtrilC') needs the label dimension")
+    return mixture_components(llk) * (2 + P)
   return 2 if llk == "nb" else 1 if llk == "onehot" else 3 * mixture_components(llk)
 
 
@@ -176,7 +183,7 @@ def manifest(cfg: ModelConfig) -> List[Tuple[str, Tuple[int, ...]]]:
   else:
     out += [("out/W", (hd, cfg.k * G)), ("out/b", (cfg.k * G,))]
   for j, (P, llk) in enumerate(cfg.head_labels):
-    ky = label_planes(llk)
+    ky = label_planes(llk, P)
     out += [(f"lab{j}/W", (hd, ky * P)), (f"lab{j}/b", (ky * P,))]
   return out
 

@@ -1516,7 +1516,98 @@ __global__ __launch_bounds__(256) void label_loss_kernel(LabelArgs a) {
   }
   if (lane == 0) a.llk[b] = (a.add ? a.llk[b] : 0.f) + m * llk;
 }
+// MISA's 'mixtril' head (sisua/models/vae.py:58, the class's own example): ONE C-component mixture over the whole label vector,
+// component c = MultivariateNormalTriL(loc_c, L_c), diag(L) = softplus(raw) + 1e-5 (TFP's FillScaleTriL), strict lower triangle = raw.
+// Planes of width Pp (config.label_planes): C logit planes (column 0), C location planes, per component P planes = the columns of L
+// (plane j, row p >= j).  One wave per cell, lane p = label dimension p (P <= 64); a component's L sits in LDS as [P][P + 1]:
+//   u = L^-1 (y - mu)   forward substitution: lane j publishes u_j, the lanes below subtract L[p][j] u_j
+//   w = L^-T u          back substitution through the column view
+//   log N = -1/2 |u|^2 - sum log L_pp - P/2 log 2 pi;   d mu = w,   d L[p][j] = w_p u_j - [p == j] / L_pp
+// and the mixture over components as in label_loss_kernel: d logit_c = resp_c - pi_c, component gradients times resp_c.
+__global__ __launch_bounds__(64) void label_tril_kernel(LabelArgs a) {
+  extern __shared__ float Ls[];   // [P][P + 1]
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const long src = a.rows ? a.rows[b] : b;
+  const float* raw = a.raw + (long)b * a.ld;
+  float* draw = a.draw + (long)b * a.ld;
+  const float m = a.mask ? (a.mask[src] ? 1.f : 0.f) : 0.f;
+  const float gs = a.grad_scale * m;
+  const int C = a.C, P = a.P, Pp = a.Pp, ldl = P + 1;
+  if (m == 0.f) {   // (block-uniform)
+    if (a.backward) for (int i = lane; i < C * (2 + P) * Pp; i += 64) draw[i] = 0.f;
+    if (lane == 0) a.llk[b] = a.add ? a.llk[b] : 0.f;
+    return;
+  }
+  const bool live = lane < P;
+  const float yv = live ? a.Y[src * a.ldy + lane] : 0.f;
+  float e[4], mx[4], u_c[4], w_c[4], dinv[4], dsg[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    e[c] = 0.f; mx[c] = 0.f; u_c[c] = 0.f; w_c[c] = 0.f; dinv[c] = 0.f; dsg[c] = 0.f;
+    if (c >= C) continue;   // (uniform)
+    mx[c] = raw[c * Pp];
+    const float mu = live ? raw[(C + c) * Pp + lane] : 0.f;
+    float lpp = 1.f, sg = 0.f;
+    for (int j = 0; j < P; ++j) {   // plane j = column j of L, coalesced over the rows
+      float v = live ? raw[(2 * C + c * P + j) * Pp + lane] : 0.f;
+      if (j == lane) { const SpSg t = softplus_sigmoid(v); v = t.sp + 1e-5f; lpp = v; sg = t.sg; }
+      if (live) Ls[lane * ldl + j] = j <= lane ? v : 0.f;
+    }
+    __syncthreads();
+    const float inv = frcp(lpp);
+    float r = yv - mu, u = 0.f;
+    for (int j = 0; j < P; ++j) {
+      const float uj = __shfl(r * inv, j, 64);
+      if (lane == j) u = uj;
+      else if (lane > j && live) r -= Ls[lane * ldl + j] * uj;
+    }
+    float s = u, w = 0.f;
+    for (int i = P - 1; i >= 0; --i) {
+      const float wi = __shfl(s * inv, i, 64);
+      if (lane == i) w = wi;
+      else if (lane < i) s -= Ls[i * ldl + lane] * wi;
+    }
+    __syncthreads();   // (the next component overwrites L)
+    const float quad = wave_sum(live ? u * u : 0.f), logdet = wave_sum(live ? flog(lpp) : 0.f);
+    e[c] = -0.5f * quad - logdet - 0.9189385332046727f * (float)P;
+    u_c[c] = u; w_c[c] = w; dinv[c] = inv; dsg[c] = sg;
+  }
+  float am = -3.0e38f, jm = -3.0e38f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (c < C) { am = fmaxf(am, mx[c]); jm = fmaxf(jm, mx[c] + e[c]); }
+  float sa = 0.f, sj = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (c < C) { sa += expf(mx[c] - am); sj += expf(mx[c] + e[c] - jm); }
+  const float lse_a = am + logf(sa), lse_j = jm + logf(sj);
+  if (lane == 0) a.llk[b] = (a.add ? a.llk[b] : 0.f) + (lse_j - lse_a);
+  if (!a.backward) return;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c >= C) continue;
+    const float resp = expf(mx[c] + e[c] - lse_j), pi = expf(mx[c] - lse_a);
+    for (int p = lane; p < Pp; p += 64) {
+      draw[c * Pp + p] = p == 0 ? (resp - pi) * gs : 0.f;
+      draw[(C + c) * Pp + p] = p < P ? resp * w_c[c] * gs : 0.f;   // (p == lane here: P <= 64)
+    }
+    for (int j = 0; j < P; ++j) {
+      const float uj = __shfl(u_c[c], j, 64);
+      float d = 0.f;
+      if (live && j < lane) d = w_c[c] * uj;
+      else if (live && j == lane) d = (w_c[c] * uj - dinv[c]) * dsg[c];
+      for (int p = lane; p < Pp; p += 64) draw[(2 * C + c * P + j) * Pp + p] = p < P ? resp * d * gs : 0.f;
+    }
+  }
+}
+
 int launch_label_loss(hipStream_t st, const LabelArgs& a) {
+  if (a.kind == SMX_LABEL_MIXTRIL) {
+    if (a.P < 1 || a.P > 64 || a.C < 2 || a.C > 4) { set_error("label_loss: 'mixtril' heads take 1..64 label dimensions and 2..4 components"); return SMX_ERR_INVALID; }
+    hipLaunchKernelGGL(label_tril_kernel, dim3(a.B), dim3(64), (size_t)a.P * (a.P + 1) * sizeof(float), st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   hipLaunchKernelGGL(label_loss_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;

@@ -319,6 +319,68 @@ class MixtureNormal(MixtureNegativeBinomial):
     self.name = name
 
 
+class MixtureMultivariateNormalTriL(Distribution):
+  """ONE mixture of C full-covariance Gaussians over the last axis (MISA's 'mixtril' heads, the example of
+  sisua/models/vae.py:58; TFP MixtureSameFamily(Categorical(logits), MultivariateNormalTriL(loc, scale_tril)) semantics).
+  Parameters: mixture logits [..., C], locations [..., C, P], lower-triangular scale factors [..., C, P, P]."""
+  _event_ndims = 1
+
+  def __init__(self, mix_logits, loc, scale_tril, name="MixtureMultivariateNormalTriL"):
+    self.mix_logits = np.asarray(mix_logits, np.float64)
+    self.loc = np.asarray(loc, np.float64)
+    self.scale_tril = np.tril(np.asarray(scale_tril, np.float64))
+    self.name = name
+
+  def _params(self):
+    return [self.loc[..., 0, :]]
+
+  def _log_pi(self):
+    a = self.mix_logits
+    m = a.max(-1, keepdims=True)
+    return a - (m + np.log(np.exp(a - m).sum(-1, keepdims=True)))
+
+  def mean(self):
+    return (np.exp(self._log_pi())[..., None] * self.loc).sum(-2)
+
+  def covariance(self):
+    """Law of total covariance: sum_c pi_c (L_c L_c^T + mu_c mu_c^T) - mean mean^T."""
+    pi = np.exp(self._log_pi())[..., None, None]
+    second = self.scale_tril @ np.swapaxes(self.scale_tril, -1, -2) + self.loc[..., :, None] * self.loc[..., None, :]
+    mu = self.mean()
+    return (pi * second).sum(-3) - mu[..., :, None] * mu[..., None, :]
+
+  def variance(self):
+    return np.einsum("...pp->...p", self.covariance())
+
+  def component_log_prob(self, x):
+    """log N(x; loc_c, L_c L_c^T) per component: [..., C]."""
+    d = np.asarray(x, np.float64)[..., None, :] - self.loc
+    L = np.broadcast_to(self.scale_tril, d.shape[:-1] + self.scale_tril.shape[-2:])
+    u = np.zeros(d.shape)
+    P = d.shape[-1]
+    for p in range(P):   # forward substitution (P is tens at most)
+      u[..., p] = (d[..., p] - (L[..., p, :p] * u[..., :p]).sum(-1)) / L[..., p, p]
+    logdet = np.log(np.einsum("...pp->...p", L)).sum(-1)
+    return -0.5 * (u * u).sum(-1) - logdet - 0.5 * P * np.log(2.0 * np.pi)
+
+  def log_prob(self, x):
+    j = self._log_pi() + self.component_log_prob(x)
+    m = j.max(-1, keepdims=True)
+    return (m + np.log(np.exp(j - m).sum(-1, keepdims=True)))[..., 0]
+
+  def sample(self, sample_shape=(), seed=None):
+    rng = np.random.default_rng(seed)
+    shp = self._sshape(sample_shape)
+    pi = np.exp(self._log_pi())
+    bshape = pi.shape[:-1]
+    u = rng.uniform(size=shp + bshape)[..., None]
+    pick = (np.cumsum(np.broadcast_to(pi, shp + pi.shape), axis=-1) < u).sum(-1).clip(0, pi.shape[-1] - 1)        # [S.., ...]
+    eps = rng.standard_normal(size=shp + bshape + self.loc.shape[-1:])
+    loc = np.take_along_axis(np.broadcast_to(self.loc, shp + self.loc.shape), pick[..., None, None], axis=-2)[..., 0, :]
+    L = np.take_along_axis(np.broadcast_to(self.scale_tril, shp + self.scale_tril.shape), pick[..., None, None, None], axis=-3)[..., 0, :, :]
+    return loc + np.einsum("...pq,...q->...p", L, eps)
+
+
 class Independent(Distribution):
   """Reinterprets the last `reinterpreted_batch_ndims` batch axes as event axes."""
 
@@ -385,6 +447,9 @@ def concat_distributions(dists: Sequence[Distribution], axis: int = 0, name: Opt
   if isinstance(d0, MixtureNegativeBinomial):   # parameters [..., C, P]: the batch axes are the leading ones
     return MixtureNegativeBinomial(_cat([d.mix_logits for d in dists], axis), _cat([d.components.total_count for d in dists], axis),
                                    _cat([d.components.logits for d in dists], axis), name=nm)
+  if isinstance(d0, MixtureMultivariateNormalTriL):
+    return MixtureMultivariateNormalTriL(_cat([d.mix_logits for d in dists], axis), _cat([d.loc for d in dists], axis),
+                                         _cat([d.scale_tril for d in dists], axis), name=nm)
   raise TypeError(f"cannot concatenate {type(d0)}")
 
 

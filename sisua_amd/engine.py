@@ -283,7 +283,7 @@ class Engine:
       out.update(l_mean=np.empty((B,), np.float32), l_scale=np.empty((B,), np.float32), l_sample=np.empty((B,), np.float32))
     if want_x_params:
       out["x_params"] = np.empty((k, B, G), np.float32)
-    ys = [np.empty((B, label_planes(llk) * P), np.float32) for P, llk in cfg.head_labels]
+    ys = [np.empty((B, label_planes(llk, P) * P), np.float32) for P, llk in cfg.head_labels]
     yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
     check(self.lib.smx_forward(self._h, idp, xp, lp, B, int(sample_index), int(training), _fp(out["z_mean"]),
                                _fp(out.get("z_scale")), _fp(out["z_sample"]), _fp(out.get("l_mean")),
@@ -310,7 +310,7 @@ class Engine:
     if cfg.model == "scvi":
       out.update(l_mean=np.empty((B,), np.float32), l_scale=np.empty((B,), np.float32), l_sample=np.empty((S, B), np.float32))
     out["x_params"] = np.empty((S, k, B, G), np.float32)
-    ys = [np.empty((S, B, label_planes(llk) * P), np.float32) for P, llk in cfg.head_labels]
+    ys = [np.empty((S, B, label_planes(llk, P) * P), np.float32) for P, llk in cfg.head_labels]
     yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
     check(self.lib.smx_forward_samples(self._h, idp, xp, lp, B, S, _fp(out["z_mean"]), _fp(out.get("z_scale")),
                                        _fp(out["z_sample"]), _fp(out.get("l_mean")), _fp(out.get("l_scale")),
@@ -332,7 +332,7 @@ class Engine:
     if cfg.model == "scvi":
       out.update(l_mean=np.empty((N,), np.float32), l_scale=np.empty((N,), np.float32), l_sample=np.empty((S, N), np.float32))
     out["x_params"] = np.empty((S, k, N, G), np.float32)
-    ys = [np.empty((S, N, label_planes(llk) * P), np.float32) for P, llk in cfg.head_labels]
+    ys = [np.empty((S, N, label_planes(llk, P) * P), np.float32) for P, llk in cfg.head_labels]
     yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
     check(self.lib.smx_predict(self._h, _fp(xa), _fp(la), N, B, S, _fp(out["z_mean"]), _fp(out.get("z_scale")),
                                _fp(out["z_sample"]), _fp(out.get("l_mean")), _fp(out.get("l_scale")), _fp(out.get("l_sample")),
@@ -349,7 +349,7 @@ class Engine:
       raise ValueError(f"z must be [batch, {cfg.latent_dim}]")
     la = None if l is None else _f32(np.reshape(l, (B,)))
     xp = np.empty((cfg.k, B, cfg.n_genes), np.float32)
-    ys = [np.empty((B, label_planes(llk) * P), np.float32) for P, llk in cfg.head_labels]
+    ys = [np.empty((B, label_planes(llk, P) * P), np.float32) for P, llk in cfg.head_labels]
     yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
     check(self.lib.smx_decode(self._h, _fp(za), _fp(la), B, _fp(xp), yptrs))
     return dict(x_params=xp, y_params=ys)

@@ -140,15 +140,22 @@ class SingleCellModel:
         if rv.kwargs.get("zero_inflated", False):
           raise ValueError("zero-inflated mixture label heads are not built")
         labels.append((rv.event_shape, f"mixnb{C}"))
-      elif rv.posterior in ("mixgaussian", "mixgaus", "mixgauss", "mixnormal", "mdn"):   # MISA's continuous labels (vae.py:86-92)
+      elif rv.posterior in ("mixgaussian", "mixgaus", "mixgauss", "mixnormal", "mdn", "mixtril", "mixfull", "mdntril"):
+        # MISA's continuous labels (vae.py:86-92); 'mixtril' (the class's docstring example, vae.py:58) = covariance 'tril'
         C = int(rv.kwargs.get("n_components", 2))
         if not 2 <= C <= 4:
           raise ValueError(f"mixture label heads are built for 2..4 components, given: {C}")
-        if rv.kwargs.get("covariance", "none") not in ("none", "diag"):
-          raise ValueError("mixture-of-Gaussians label heads are built with independent dimensions (covariance='none')")
-        labels.append((rv.event_shape, f"mixgauss{C}"))
+        cov = rv.kwargs.get("covariance", "tril" if rv.posterior in ("mixtril", "mixfull", "mdntril") else "none")
+        if cov in ("tril", "full"):
+          if rv.event_shape > 64:
+            raise ValueError("'mixtril' label heads are built for at most 64 label dimensions")
+          labels.append((rv.event_shape, f"mixtril{C}"))
+        elif cov in ("none", "diag"):
+          labels.append((rv.event_shape, f"mixgauss{C}"))
+        else:
+          raise ValueError(f"mixture-of-Gaussians label heads are built with covariance 'none' / 'diag' (independent dimensions) or 'tril' / 'full', given: {cov}")
       else:
-        raise ValueError(f"label posterior '{rv.posterior}' is not built (supported: 'nb', 'onehot', 'mixnb', 'mixgaussian')")
+        raise ValueError(f"label posterior '{rv.posterior}' is not built (supported: 'nb', 'onehot', 'mixnb', 'mixgaussian', 'mixtril')")
     encl = self._encoder[1].units if len(self._encoder) > 1 else (64,)
     return ModelConfig(model=self._kind, n_genes=self._outputs[0].event_shape, likelihood=self._outputs[0].posterior,
                        enc_units=tuple(enc.units), dec_units=tuple(self._decoder.units),
@@ -503,6 +510,14 @@ class SingleCellModel:
         pl = np.reshape(raw, raw.shape[:-1] + (3 * C, P))     # planes: C mixture logits | C locations | C raw scales
         scale = np.logaddexp(0.0, pl[..., 2 * C:, :].astype(np.float64) + np.log(np.expm1(1.0)))   # softplus1
         outs.append(D.Independent(D.MixtureNormal(pl[..., :C, :], pl[..., C:2 * C, :], scale), 1, name=nm))
+      elif kind.startswith("mixtril"):
+        C = int(kind[-1])
+        pl = np.reshape(raw, raw.shape[:-1] + (C * (2 + P), P)).astype(np.float64)   # planes: C logits (column 0) | C locations | C x P columns of L
+        cols = np.reshape(pl[..., 2 * C:, :], raw.shape[:-1] + (C, P, P))              # [..., c, j, p] = L_c[p][j]
+        L = np.tril(np.swapaxes(cols, -1, -2), -1)
+        dg = np.logaddexp(0.0, np.einsum("...pp->...p", np.swapaxes(cols, -1, -2))) + 1e-5   # softplus + TFP's diag_shift
+        L = L + dg[..., :, None] * np.eye(P)
+        outs.append(D.MixtureMultivariateNormalTriL(pl[..., :C, 0], pl[..., C:2 * C, :], L, name=nm))
       else:
         outs.append(D.OneHotCategorical(raw, name=nm))
     return outs[0] if len(outs) == 1 else tuple(outs)
@@ -757,7 +772,8 @@ class MISA(SISUA):
   mixture distributions.  Discrete labels (ADT counts) become `n_components`-component mixtures of negative
   binomials per label dimension ('mixnb'); other label posteriors are converted with the reference's warning.
   Built: 'mixnb' with 2..4 components, not zero-inflated; 'mixgaussian' with 2..4 components and independent label
-  dimensions; the full-covariance 'mixtril' is not."""
+  dimensions; 'mixtril' (the docstring example of vae.py:58): ONE mixture of 2..4 full-covariance Gaussians over the whole label
+  vector (at most 64 label dimensions)."""
   _kind = "sisua"
 
   def __init__(self, outputs, labels, n_components=2, zero_inflated=False, **kwargs):

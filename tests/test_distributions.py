@@ -121,3 +121,25 @@ def test_mse_posterior_identity():
   # leading sample axes broadcast as the other result distributions do
   ys = D.VectorDeterministic(np.stack([mean, mean + 1]), name="x")
   assert ys.batch_shape == (2, 8) and ys.log_prob(z).shape == (2, 8)
+
+
+def test_mixture_multivariate_normal_tril_surface():
+  """MISA's 'mixtril' head as a distribution: log_prob / mean / covariance against torch's MixtureSameFamily over
+  MultivariateNormal(scale_tril), samples against its moments, concatenation along the batch axis."""
+  rng = np.random.default_rng(2)
+  N, C, P = 7, 3, 4
+  logits, loc = rng.normal(size=(N, C)), rng.normal(size=(N, C, P))
+  L = np.tril(rng.normal(size=(N, C, P, P)) * 0.4, -1) + np.eye(P) * rng.uniform(0.5, 1.5, size=(N, C, P, 1))
+  d = D.MixtureMultivariateNormalTriL(logits, loc, L, name="proteomic")
+  ref = td.MixtureSameFamily(td.Categorical(logits=torch.tensor(logits)), td.MultivariateNormal(torch.tensor(loc), scale_tril=torch.tensor(np.tril(L))))
+  x = rng.normal(size=(N, P))
+  assert d.batch_shape == (N,) and d.event_shape == (P,)
+  assert np.allclose(d.log_prob(x), ref.log_prob(torch.tensor(x)).numpy(), rtol=1e-11, atol=1e-11)
+  assert np.allclose(d.mean(), ref.mean.numpy()) and np.allclose(d.variance(), ref.variance.numpy())
+  s = d.sample(20000, seed=1)
+  assert s.shape == (20000, N, P)
+  assert np.abs(s.mean(0) - d.mean()).max() < 0.06 and np.abs(s.var(0) - d.variance()).max() < 0.15
+  cov = np.einsum("snp,snq->npq", s - s.mean(0), s - s.mean(0)) / s.shape[0]
+  assert np.abs(cov - d.covariance()).max() < 0.15
+  both = D.concat_distributions([D.MixtureMultivariateNormalTriL(logits[:3], loc[:3], L[:3]), D.MixtureMultivariateNormalTriL(logits[3:], loc[3:], L[3:])])
+  assert np.array_equal(both.log_prob(x), d.log_prob(x))

@@ -366,6 +366,41 @@ def test_misa_continuous_labels_fit_predict(api):
   assert np.allclose(X[1].distribution.mean(), (np.exp(X[1].distribution._log_pi()) * X[1].distribution.components.mean()).sum(-2))
 
 
+def test_misa_mixtril_labels_fit_predict(api):
+  """MISA as the reference's own docstring builds it (sisua/models/vae.py:54-60): `adt = RVmeta(dim, 'mixtril', True, 'proteomic')`,
+  `MISA(rna, adt, n_components=2)` -- ONE mixture of full-covariance Gaussians over the label vector.  Trains, and predict returns
+  that mixture; on correlated labels its density beats the independent-dimensions head's trained the same way."""
+  from sisua_amd import distributions as D
+  from sisua_amd.data import SingleCellOMIC
+  sco = SingleCellOMIC(synth_counts(600, 100, sparsity=0.8, seed=4), name="toy")
+  sco.add_omic("proteomic", synth_labels(600, ((6, "mixtril2"),))[0])      # real-valued, two populations, correlated dimensions
+  train, test = sco.split(0.8)
+  omics = ["transcriptomic", "proteomic"]
+  lps = {}
+  for post in ("mixtril", "mixgaussian"):
+    adt = api.RVmeta(6, post, True, "proteomic")
+    m = api.MISA(outputs=sco.get_rv("transcriptomic"), labels=adt, n_components=2, latents=api.RVmeta(8, "diag", True, "Latents"),
+                 encoder=api.NetConf([32], batchnorm=True, dropout=0.1), decoder=api.NetConf([32], batchnorm=True, dropout=0.1))
+    assert m._make_config().labels == ((6, "mixtril2" if post == "mixtril" else "mixgauss2"),)
+    m.fit(train.create_dataset(omics, labels_percent=0.8, batch_size=64, drop_remainder=True),
+          valid=test.create_dataset(omics, labels_percent=1.0, batch_size=60, drop_remainder=True), metadata=sco, epochs=40,
+          valid_freq=20, learning_rate=3e-3)
+    h = np.asarray(m.train_history["nllk_y"])
+    assert len(h) == 40 and np.isfinite(h).all() and h[-3:].mean() < h[:3].mean()
+    X, Z = m.predict(test.create_dataset(omics, batch_size=40, shuffle=0), verbose=False)
+    y = test.numpy("proteomic")
+    lps[post] = X[1].log_prob(y)
+    assert np.isfinite(lps[post]).all() and X[1].batch_shape == (test.n_obs,) and X[1].event_shape == (6,)
+    if post == "mixtril":
+      assert isinstance(X[1], D.MixtureMultivariateNormalTriL) and X[1].name == "proteomic"
+      assert np.isfinite(X[1].mean()).all() and (X[1].variance() > 0).all()
+      smp = X[1].sample(3, seed=0)
+      assert smp.shape == (3, test.n_obs, 6) and np.isfinite(smp).all()
+  assert lps["mixtril"].mean() > lps["mixgaussian"].mean()
+  with pytest.raises(ValueError):
+    api.MISA(outputs=sco.get_rv("transcriptomic"), labels=api.RVmeta(70, "mixtril", True, "proteomic"))._make_config()
+
+
 def test_scale_fit_predict(api, tmp_path):
   """SCALE (sisua/models/scale.py:13-49): mixture prior over the latents, Monte-Carlo KL; trains, predicts, and its
   prior parameters move and survive a checkpoint."""

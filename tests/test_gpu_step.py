@@ -38,6 +38,12 @@ CASES = {
     # MISA with a continuous label variable (vae.py:86-92 'mixgaussian': mixture of normals per label dimension) beside a count one
     "misa_gauss": dict(model="sisua", n_genes=120, likelihood="nb", enc_units=(40,), dec_units=(40,), latent_dim=6,
                        labels=((9, "mixgauss3"), (6, "mixnb2")), alpha=10.0),
+    # MISA's docstring example (vae.py:58 'mixtril'): ONE mixture of full-covariance Gaussians over the label vector (label_tril_kernel);
+    # 14 = the protein panel of pbmc8k_ly, 38 > 32 = two padded plane widths
+    "misa_tril": dict(model="sisua", n_genes=120, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=6,
+                      labels=((14, "mixtril2"), (5, "onehot")), alpha=10.0),
+    "misa_tril_wide": dict(model="sisua", n_genes=90, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=5,
+                           labels=((38, "mixtril3"),), alpha=4.0),
     "scale": dict(model="scale", n_genes=150, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=10, n_components=7),
     # the deterministic 'mse' output (RVmeta(dim, 'mse'), tests/test_singlecell_models.py:82-100 of the reference): one plane
     "dca_mse": dict(model="dca", n_genes=110, likelihood="mse", enc_units=(32,), dec_units=(32,), latent_dim=8),
@@ -738,7 +744,8 @@ def test_forward_samples_equals_repeated_forward(Engine, name):
 
 
 @pytest.mark.parametrize("labels", [((9, "mixnb4"),), ((6, "mixnb2"), (5, "mixnb2")),
-                                    ((5, "mixnb4"), (4, "mixnb4"), (3, "mixnb4"), (6, "mixnb4"))])
+                                    ((5, "mixnb4"), (4, "mixnb4"), (3, "mixnb4"), (6, "mixnb4")),
+                                    ((14, "mixtril2"), (4, "nb"))])   # 'mixtril': 2 x (2 + 14) = 32 planes of one head
 @pytest.mark.parametrize("S", [1, 3])
 def test_predict_packs_every_label_plane(Engine, labels, S):
   """smx_predict hands its outputs to one pack launch per pass; a MISA model with four mixture components (3 latent + 3

@@ -143,6 +143,41 @@ def test_label_llk_mixture_normal_matches_torch_mixture_same_family():
     assert so.label_planes(f"mixgauss{C}") == 3 * C and so.mixture_components(f"mixgauss{C}") == C
 
 
+def test_label_llk_mixture_tril_matches_torch_mixture_same_family():
+  """MISA's 'mixtril' head (the docstring example of sisua/models/vae.py:58): ONE mixture of C full-covariance Gaussians over the
+  whole label vector == torch MixtureSameFamily(Categorical(logits), MultivariateNormal(loc, scale_tril)), diag(L) = softplus(raw)
+  + 1e-5; gradients by central differences; the inert entries (logit planes beyond column 0, L above its diagonal) get none."""
+  rng = np.random.default_rng(6)
+  B = 5
+  for C, P in ((2, 5), (3, 4), (4, 3)):
+    kind = f"mixtril{C}"
+    ky = so.label_planes(kind, P)
+    assert ky == C * (2 + P) and so.mixture_components(kind) == C
+    y = rng.normal(0.5, 1.5, size=(B, P))
+    raw = rng.normal(size=(B, ky * P)) * 0.7
+    ll, d = so.label_llk(y, raw, kind)
+    pl = torch.tensor(raw).reshape(B, ky, P)
+    cols = pl[:, 2 * C:].reshape(B, C, P, P)                     # [b, c, j, p] = L_c[p][j]
+    Lr = cols.permute(0, 1, 3, 2)
+    L = torch.tril(Lr, -1) + torch.diag_embed(torch.nn.functional.softplus(torch.diagonal(Lr, dim1=-2, dim2=-1)) + so.TRIL_DIAG_SHIFT)
+    ref = td.MixtureSameFamily(td.Categorical(logits=pl[:, :C, 0]), td.MultivariateNormal(pl[:, C:2 * C], scale_tril=L)).log_prob(torch.tensor(y))
+    assert np.allclose(ll, ref.numpy(), rtol=1e-11, atol=1e-11)
+    h = 1e-6
+    inert = np.ones(ky * P, bool)
+    for c in range(C):
+      inert[c * P] = False
+      inert[(C + c) * P:(C + c + 1) * P] = False
+      for j in range(P):
+        k = 2 * C + c * P + j
+        inert[k * P + j:(k + 1) * P] = False
+    assert np.all(d[:, inert] == 0.0) and np.all(np.abs(d[:, ~inert]).max(0) > 0)
+    for col in rng.choice(np.flatnonzero(~inert), 12, replace=False):
+      rp, rm = raw.copy(), raw.copy()
+      rp[:, col] += h; rm[:, col] -= h
+      fd = (so.label_llk(y, rp, kind)[0] - so.label_llk(y, rm, kind)[0]) / (2 * h)
+      assert np.allclose(d[:, col], fd, rtol=2e-5, atol=1e-7), (C, P, col)
+
+
 # ---------------------------------------------------------------------------
 # whole-step gradient check by central differences, every model family
 # ---------------------------------------------------------------------------
@@ -171,6 +206,7 @@ CASES = [("vae", "zinb", (), True), ("vae", "nb", (), False), ("vae", "zinbd", (
          ("scvi", "nbd", (), False), ("sisua", "zinb", ((4, "nb"), (3, "onehot")), True),
          ("sisua", "zinb", ((4, "mixnb2"), (3, "mixnb3")), True),   # MISA
          ("sisua", "nb", ((3, "mixgauss2"), (4, "nb")), True),      # MISA with a continuous label variable
+         ("sisua", "zinb", ((4, "mixtril2"),), True),               # MISA, full-covariance mixture over the label vector (vae.py:58)
          ("scale", "zinb", (), True), ("scale", "nb", (), False),    # SCALE: mixture prior, Monte-Carlo KL
          ("fvae", "zinb", (), True), ("fvae", "nb", ((3, "onehot"),), False)]   # FVAE / SemiFVAE: two objectives
 

@@ -126,6 +126,12 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
     if kind == "nb":
       # protein levels are real-valued (dataset.html:187): the same density formula, support check off
       llk_y = llk_y + td.NegativeBinomial(total_count=torch.exp(ry[:, :Pj]), logits=ry[:, Pj:], validate_args=False).log_prob(yj).sum(1)
+    elif kind.startswith("mixtril"):   # MISA's docstring example (vae.py:58): ONE mixture of C full-covariance Gaussians over the label vector
+      C = int(kind[-1])
+      pl = ry.reshape(B, C * (2 + Pj), Pj)
+      Lr = pl[:, 2 * C:].reshape(B, C, Pj, Pj).permute(0, 1, 3, 2)          # planes are the COLUMNS of L
+      L = torch.tril(Lr, -1) + torch.diag_embed(torch.nn.functional.softplus(torch.diagonal(Lr, dim1=-2, dim2=-1)) + so.TRIL_DIAG_SHIFT)
+      llk_y = llk_y + td.MixtureSameFamily(td.Categorical(logits=pl[:, :C, 0]), td.MultivariateNormal(pl[:, C:2 * C], scale_tril=L)).log_prob(yj)
     elif kind.startswith("mixgauss"):   # MISA, continuous labels: MixtureSameFamily over C normals per label dimension
       C = int(kind[-1])
       pl = ry.reshape(B, 3 * C, Pj)
@@ -173,6 +179,8 @@ CASES = {
                  labels=((6, "mixnb2"), (3, "mixnb3")), alpha=10.0),
     "misa_gauss": dict(model="sisua", n_genes=36, likelihood="nb", enc_units=(16,), dec_units=(16,), latent_dim=4,
                        labels=((5, "mixgauss3"), (4, "mixnb2")), alpha=10.0),
+    "misa_tril": dict(model="sisua", n_genes=36, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=4,
+                      labels=((5, "mixtril3"), (3, "onehot")), alpha=10.0),
     "scale": dict(model="scale", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=6),
     "scalar": dict(model="scale", n_genes=42, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=4,
                    labels=((6, "nb"), (3, "onehot")), alpha=10.0),   # SCALE + label heads (scale.py:52-59)

@@ -31,6 +31,11 @@ def synth_labels(n, labels, seed=1):
   for P, kind in labels:
     if kind == "onehot":
       ys.append(np.eye(P, dtype=np.float32)[rng.integers(0, P, n)])
+    elif kind.startswith("mixtril"):   # continuous and CORRELATED across the label dimensions: two populations with their own covariance
+      on = rng.uniform(size=(n, 1)) < 0.4
+      A0, A1 = rng.normal(size=(P, P)) * 0.4 + np.eye(P) * 0.6, rng.normal(size=(P, P)) * 0.3 + np.eye(P) * 0.5
+      e = rng.normal(size=(n, P))
+      ys.append(np.where(on, 2.0 + e @ A1.T, -0.5 + e @ A0.T).astype(np.float32))
     elif kind.startswith("mixgauss"):   # continuous, bimodal (log-normalised protein levels: a background and a signal mode)
       on = rng.uniform(size=(n, P)) < 0.4
       ys.append(np.where(on, rng.normal(2.5, 0.5, size=(n, P)), rng.normal(-0.5, 0.8, size=(n, P))).astype(np.float32))
