@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "smx_internal.h"
+#include "smx_adam.h"
 #include "../../include/sisua_hip.h"
 
 namespace smx {
@@ -336,6 +337,16 @@ __global__ __launch_bounds__(256) void gemm_latent_bwd_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[GemmSmem<1, 1, 4, 0, 1>::FLOATS];
   gemm_body<1, 1, 4, 0, 1, 0, 2>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
+// ... and with optimiser chunks riding along (the heads' update at a wide gene panel, smx_step.hip: attach_early_adam): workgroups
+// [gx, gx + ride_count) of row 0 each apply one chunk; the product's own 4 workgroups leave the chip idle for ~6 us otherwise
+__global__ __launch_bounds__(256) void gemm_latent_bwd_ride_kernel(GemmArgs g, AdamArgs a, int gx, int ride_first) {
+  __shared__ __attribute__((aligned(16))) float smem[GemmSmem<1, 1, 4, 0, 1>::FLOATS];
+  if ((int)blockIdx.x >= gx) {   // (block-uniform)
+    if (blockIdx.y == 0) adam_chunk_body<256>(a, ride_first + (int)blockIdx.x - gx);
+    return;
+  }
+  gemm_body<1, 1, 4, 0, 1, 0, 2>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
 
 // ---------------------------------------------------------------------------
 // Grouped launch: several independent products share one grid, so the narrow ones fill the CUs
@@ -496,7 +507,10 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
     for (int i = 0; i < n; ++i) {
       if (G.variant[i] == 11) {
         const GemmArgs& g = G.p[i];
-        hipLaunchKernelGGL(gemm_latent_bwd_kernel, dim3(G.gx[i], G.gy[i], 1), dim3(256), 0, st, g);
+        if (g.ride_adam && g.ride_count > 0)
+          hipLaunchKernelGGL(gemm_latent_bwd_ride_kernel, dim3(G.gx[i] + g.ride_count, G.gy[i], 1), dim3(256), 0, st, g, *g.ride_adam, G.gx[i], g.ride_first);
+        else
+          hipLaunchKernelGGL(gemm_latent_bwd_kernel, dim3(G.gx[i], G.gy[i], 1), dim3(256), 0, st, g);
         continue;
       }
       GemmArgs g = list[i];

@@ -54,6 +54,7 @@ struct EpiLatentBwd {
   const float* dz_add = nullptr;
 };
 
+struct AdamArgs;
 struct GemmArgs {
   const float* A = nullptr; int lda = 0; int a_kmajor = 0;  // a_kmajor: A stored [K][M]
   const float* B = nullptr; int ldb = 0; int b_nmajor = 0;  // b_nmajor: B stored [N][K]
@@ -79,6 +80,9 @@ struct GemmArgs {
   int act = 0; float leak = 0.f; const float* act_out = nullptr; int act_ld = 0;
   int act_wrap = 0;     // act = 2, > 0: output rows >= act_wrap take the forward output of row - act_wrap (two backward sweeps stacked as rows of one product)
   int panel_hint = 0;   // launch_wgrad_group: take the panel form (smx_panel.h) for this problem whatever its M (N <= 128)
+  // the latent head's backward product (epi = 2, its own kernel) can carry optimiser chunks [ride_first, ride_first + ride_count) of
+  // *ride_adam (a HOST pointer, copied into the launch) as extra workgroups: the launch has four workgroups of its own
+  const AdamArgs* ride_adam = nullptr; int ride_first = 0, ride_count = 0;
 };
 // Returns 0 or a negative smx_status.  N, lda, ldb, ldc multiples of 4; N multiple of 32.
 // eff_split (optional) receives the number of slabs actually written.

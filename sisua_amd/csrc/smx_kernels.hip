@@ -13,6 +13,7 @@
 
 #include "smx_internal.h"
 #include "smx_loss.h"
+#include "smx_adam.h"
 #include "../../include/sisua_hip.h"
 
 namespace smx {
@@ -554,7 +555,6 @@ int launch_bn_act_fwd_dual(hipStream_t st, const BnFwdArgs& a, const BnFwdArgs& 
 }
 
 __device__ inline void metrics_body(const MetricsArgs& a);
-template <int NT = 256> __device__ inline void adam_chunk_body(const AdamArgs& a, int chunk);
 __device__ inline void sq_reduce_body(const float* sl, int cnt, float* dst);
 
 template <int RPT, int FRONT>
@@ -1726,73 +1726,6 @@ __device__ inline void sq_reduce_body(const float* sl, int cnt, float* dst) {
   if (threadIdx.x == 0) *dst = s;
 }
 
-// clip + Adam for one chunk of the flat buffer; NT = 256 threads, or 512 as a rider of a 512-thread launch (the tensor's norm is
-// summed by the first 256 threads in the same order either way: both forms give the same bits).  A thread's first operands are
-// requested BEFORE the norm is reduced and each later round's before the current round's arithmetic: a workgroup lives for 2-4
-// rounds, so the reduction's barrier and the first loads' latency were a third of its life.  (Nontemporal loads / stores of the
-// moments, to keep the weights in the last-level cache, measured slower: c5-shard 198.0 -> 200.0 us, C2 80.4 -> 81.7.)
-typedef float smx_f32x4 __attribute__((ext_vector_type(4)));
-template <int NT>
-__device__ inline void adam_chunk_body(const AdamArgs& a, int chunk) {
-  __shared__ float sh[4];
-  const OptChunk ch = a.chunks[chunk];
-  const smx_f32x4* g4 = reinterpret_cast<const smx_f32x4*>(a.grads + ch.offset);
-  smx_f32x4* m4 = reinterpret_cast<smx_f32x4*>(a.m + ch.offset);
-  smx_f32x4* v4 = reinterpret_cast<smx_f32x4*>(a.v + ch.offset);
-  smx_f32x4* p4 = reinterpret_cast<smx_f32x4*>(a.params + ch.offset);
-  const int n4 = ch.count / 4;
-  int i = threadIdx.x;
-  smx_f32x4 g = {0.f, 0.f, 0.f, 0.f}, m = g, v = g, p = g;
-  auto fetch = [&](int j, smx_f32x4& go, smx_f32x4& mo, smx_f32x4& vo, smx_f32x4& po) {
-    go = g4[j]; mo = m4[j]; vo = v4[j]; po = p4[j];
-  };
-  if (i < n4) fetch(i, g, m, v, p);
-  float s = 0.f;
-  if (NT > 256 && threadIdx.x >= 256) {
-  } else if (a.use_sq) {
-    const int cnt = a.sq_count[ch.tensor];
-    if (cnt > 0) {   // partial sums written by the weight-gradient product's workgroups
-      const float* sl = a.sq_slots + a.sq_first[ch.tensor];
-      for (int k = threadIdx.x; k < cnt; k += 256) s += sl[k];
-    } else {         // small tensor (bias, BatchNorm scale / shift): sweep its whole gradient
-      const float4* t4 = reinterpret_cast<const float4*>(a.grads + a.chunks[ch.first_chunk].offset);
-      for (int k = threadIdx.x; k < ch.tensor_count / 4; k += 256) {
-        const float4 q = t4[k];
-        s += (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
-      }
-    }
-  } else {
-    for (int k = threadIdx.x; k < ch.n_chunks; k += 256) s += a.partial[ch.first_chunk + k];
-  }
-  if (NT > 256) {   // (block_sum with the waves past the fourth standing by)
-    s = wave_sum(s);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    s = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-  } else {
-    s = block_sum(s, sh);
-  }
-  const float norm = sqrtf(s) * a.grad_scale;
-  float clip = a.grad_scale;
-  if (a.clipnorm > 0.f && norm > a.clipnorm) clip *= a.clipnorm / norm;
-  if (threadIdx.x == 0 && chunk == ch.first_chunk) a.tensor_norm[ch.tensor] = norm;
-  const float lr_t = a.state->lr_t;
-  while (i < n4) {
-    const int j = i + NT;
-    smx_f32x4 gn = g, mn = m, vn = v, pn = p;
-    if (j < n4) fetch(j, gn, mn, vn, pn);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float ge = g[e] * clip;
-      m[e] = a.b1 * m[e] + (1.f - a.b1) * ge;
-      v[e] = a.b2 * v[e] + (1.f - a.b2) * ge * ge;
-      p[e] -= lr_t * m[e] * frcp(fsqrt(v[e]) + a.eps);   // v_sqrt + v_rcp (1 ulp each) instead of 22 instructions
-    }
-    m4[i] = m; v4[i] = v; p4[i] = p;
-    g = gn; m = mn; v = vn; p = pn; i = j;
-  }
-}
 __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
   if ((int)blockIdx.x == a.n_launch) {  // use_sq form: the ELBO scalars ride along here
     metrics_body(a.metrics);

@@ -162,6 +162,7 @@ struct smx_model {
   int adam_early_to = -1;             // chunks [adam_early_from, adam_early_to) of this step were applied early
   bool adam_early_pending = false;    // the heads' gradients are final: the next BatchNorm-backward launch may carry their update
   int adam_early_from = -1;           // >= 0: chunks [adam_early_from, n_chunks) of this step were applied early
+  int adam_ride_b = 0;                // wide panels: this many of the waiting chunks go with the latent head's backward product
   int adam_rest_from = 0, adam_rest_to = 0;   // ... and [adam_rest_from, adam_rest_to) wait for the next BatchNorm-backward launch to carry them
   bool x_u16 = false;   // the resident matrix is stored as uint16 counts (smx_dataset_upload_u16)
   // compact sparse store (smx_dataset_upload_csr): CSR arrays resident, the minibatch's rows expanded per pass into xbatch

@@ -193,17 +193,37 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
 // Single GPU: once the head products have written dW / db of the output and label heads (3/4 of the parameters),
 // their clip + Adam update rides along with the next BatchNorm-backward launch, which leaves most CUs idle; the
 // optimiser launch at the end of the step then covers only the encoder / latent / decoder chunks.
+// optimiser arguments of a launch that carries chunks of the heads' update as riders (norms from the products' partials, or from the
+// sums the reduce riders of an earlier launch left)
+static void fill_rider_adam(smx_model* m, AdamArgs& a) {
+  fill_adam_args(m, a);
+  a.use_sq = 1;
+  for (size_t t = 0; t < m->tensors.size(); ++t) {
+    a.sq_first[t] = m->sq_first[t]; a.sq_count[t] = m->sq_count[t];
+    if (m->sq_reduced[t]) { a.sq_first[t] = m->sq_total_first + (int)t * SMX_SQR_PER_TENSOR; a.sq_count[t] = m->sq_reduced[t]; }   // (summed by the launch before)
+  }
+  a.master = nullptr; a.with_metrics = 0;
+}
+
+// wide panels: the latent head's backward product (four workgroups of its own) takes the first adam_ride_b of the waiting chunks;
+// `store` must stay alive until the product is launched
+void take_adam_riders(smx_model* m, GemmArgs& h, AdamArgs& store) {
+  const int n = std::min(m->adam_ride_b, m->adam_rest_to - m->adam_rest_from);
+  m->adam_ride_b = 0;
+  if (n <= 0) return;
+  fill_rider_adam(m, store);
+  h.ride_adam = &store; h.ride_first = m->adam_rest_from; h.ride_count = n;
+  if (m->adam_early_from < 0) m->adam_early_from = m->adam_rest_from;
+  m->adam_rest_from += n;
+  m->adam_early_to = m->adam_rest_from;
+}
+
 void attach_early_adam(smx_model* m, BnBwdArgs& b) {
   if (!m->adam_early_pending) {
     // the second part of the heads' update: riders of the NEXT BatchNorm-backward launch of the step (see below)
+    if (m->adam_ride_b > 0) { m->adam_rest_to = std::max(m->adam_rest_from, m->adam_rest_to - m->adam_ride_b); m->adam_ride_b = 0; }   // (no product took its share)
     if (m->adam_rest_to > m->adam_rest_from) {
-      fill_adam_args(m, b.adam);
-      b.adam.use_sq = 1;
-      for (size_t t = 0; t < m->tensors.size(); ++t) {
-        b.adam.sq_first[t] = m->sq_first[t]; b.adam.sq_count[t] = m->sq_count[t];
-        if (m->sq_reduced[t]) { b.adam.sq_first[t] = m->sq_total_first + (int)t * SMX_SQR_PER_TENSOR; b.adam.sq_count[t] = m->sq_reduced[t]; }   // (summed by the launch before)
-      }
-      b.adam.master = nullptr; b.adam.with_metrics = 0;
+      fill_rider_adam(m, b.adam);
       b.adam_first = m->adam_rest_from; b.adam_count = m->adam_rest_to - m->adam_rest_from;
       if (m->adam_early_from < 0) m->adam_early_from = m->adam_rest_from;
       m->adam_early_to = m->adam_rest_to;
@@ -240,9 +260,12 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
     // ... and a share of the heads' chunks rides with the NEXT BatchNorm-backward launch as full 512-thread workgroups (the norms are
     // single numbers by then): SMX_ADAM_WIDE_SHARE of them, the optimiser launch keeps the rest
     static const float share = getenv("SMX_ADAM_WIDE_SHARE") ? (float)atof(getenv("SMX_ADAM_WIDE_SHARE")) : 0.3f;
+    // ... and SMX_ADAM_WIDE_SHARE_B of them before that with the latent head's backward product (take_adam_riders)
+    static const float share_b = getenv("SMX_ADAM_WIDE_SHARE_B") ? (float)atof(getenv("SMX_ADAM_WIDE_SHARE_B")) : 0.f;
     const int early_to = m->lab_deferred ? m->chunk_first_label : m->n_chunks;
     const int n = (int)((early_to - m->chunk_first_head) * std::min(std::max(share, 0.f), 1.f));
-    if (n > 0) { m->adam_rest_from = m->chunk_first_head; m->adam_rest_to = m->chunk_first_head + n; }
+    const int nb = std::min((int)((early_to - m->chunk_first_head) * std::min(std::max(share_b, 0.f), 1.f)), early_to - m->chunk_first_head - n);
+    if (n + nb > 0) { m->adam_rest_from = m->chunk_first_head; m->adam_rest_to = m->chunk_first_head + n + nb; m->adam_ride_b = nb; }
     return;
   }
   fill_adam_args(m, b.adam);
@@ -395,6 +418,8 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     int effs[2] = {1, 1};
     if (defer && i == 0 && lat_epi) {   // d z (+ latent-head backward) alone; d W joins the final grouped launch
       defer->push_back(g);
+      AdamArgs riders;
+      if (m->adam_ride_b > 0) take_adam_riders(m, h, riders);
       Timed t(m, "gemm_mlp_bwd");
       SMX_CHECK(launch_gemm_group(m->st, &h, 1, effs + 1));
     } else {
@@ -888,7 +913,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
   const smx_config& c = m->cfg;
   std::fill(m->sq_count.begin(), m->sq_count.end(), 0);   // the products of this step report what they wrote
   std::fill(m->sq_reduced.begin(), m->sq_reduced.end(), 0);
-  m->adam_early_pending = false; m->adam_early_from = -1; m->adam_rest_from = m->adam_rest_to = 0;
+  m->adam_early_pending = false; m->adam_early_from = -1; m->adam_rest_from = m->adam_rest_to = 0; m->adam_ride_b = 0;
   const float inv_gb = 1.f / (float)ps.global_batch;
   if (m->fvae) SMX_CHECK(factor_backward(m, ps));   // first: it uses the slab buffer the head's backward fills next
   const MlpLayer& dL = m->dec.back();
