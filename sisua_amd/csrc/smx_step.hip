@@ -261,7 +261,7 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
     // single numbers by then): SMX_ADAM_WIDE_SHARE of them, the optimiser launch keeps the rest
     static const float share = getenv("SMX_ADAM_WIDE_SHARE") ? (float)atof(getenv("SMX_ADAM_WIDE_SHARE")) : 0.3f;
     // ... and SMX_ADAM_WIDE_SHARE_B of them before that with the latent head's backward product (take_adam_riders)
-    static const float share_b = getenv("SMX_ADAM_WIDE_SHARE_B") ? (float)atof(getenv("SMX_ADAM_WIDE_SHARE_B")) : 0.f;
+    static const float share_b = getenv("SMX_ADAM_WIDE_SHARE_B") ? (float)atof(getenv("SMX_ADAM_WIDE_SHARE_B")) : 0.1f;
     const int early_to = m->lab_deferred ? m->chunk_first_label : m->n_chunks;
     const int n = (int)((early_to - m->chunk_first_head) * std::min(std::max(share, 0.f), 1.f));
     const int nb = std::min((int)((early_to - m->chunk_first_head) * std::min(std::max(share_b, 0.f), 1.f)), early_to - m->chunk_first_head - n);
