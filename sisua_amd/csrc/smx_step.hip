@@ -286,6 +286,9 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
   b.adam_count = first;
   m->adam_early_from = m->chunk_first_head; m->adam_early_to = m->chunk_first_head + first;
   m->adam_rest_from = m->chunk_first_head + first; m->adam_rest_to = early_to;
+  // ... of which SMX_ADAM_SPLIT_B of the total go with the latent head's backward product between the two (take_adam_riders)
+  static const float split_b = getenv("SMX_ADAM_SPLIT_B") ? (float)atof(getenv("SMX_ADAM_SPLIT_B")) : 0.f;
+  m->adam_ride_b = std::min((int)(total * std::min(std::max(split_b, 0.f), 1.f)), m->adam_rest_to - m->adam_rest_from);
 }
 
 // ask the product that writes the gradient of tensor t for sum-of-squares partials
