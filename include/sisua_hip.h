@@ -57,8 +57,9 @@ typedef enum { SMX_LLK_NB = 0, SMX_LLK_ZINB = 1, SMX_LLK_NBD = 2, SMX_LLK_ZINBD 
  * label dimension a mixture of label_components (2..4) negative binomials (SMX_LABEL_MIXNB) or, for continuous labels, normals
  * (SMX_LABEL_MIXGAUSS, 'mixgaussian', vae.py:86-92); SMX_LABEL_MIXTRIL ('mixtril', the class's docstring example vae.py:58): ONE
  * mixture of label_components full-covariance Gaussians over the whole label vector (lower-triangular scale factors; label_dim <= 64;
- * the head then has label_components * (2 + label_dim) planes). */
-typedef enum { SMX_LABEL_NB = 0, SMX_LABEL_ONEHOT = 1, SMX_LABEL_MIXNB = 2, SMX_LABEL_MIXGAUSS = 3, SMX_LABEL_MIXTRIL = 4 } smx_label_likelihood;
+ * the head then has label_components * (2 + label_dim) planes); SMX_LABEL_MIXZINB: MISA(zero_inflated=True), vae.py:76-84 -- the
+ * components of SMX_LABEL_MIXNB zero-inflated, a fourth group of label_components gate-logit planes. */
+typedef enum { SMX_LABEL_NB = 0, SMX_LABEL_ONEHOT = 1, SMX_LABEL_MIXNB = 2, SMX_LABEL_MIXGAUSS = 3, SMX_LABEL_MIXTRIL = 4, SMX_LABEL_MIXZINB = 5 } smx_label_likelihood;
 typedef enum { SMX_ACT_RELU = 0, SMX_ACT_LINEAR = 1 } smx_activation;
 
 /* Constructor arguments of SingleCellModel / SCVI / SISUA / DeepCountAutoencoder

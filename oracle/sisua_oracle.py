@@ -58,7 +58,8 @@ LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
 OUTPUT_POSTERIORS = LIKELIHOODS + ("mse",)   # + the deterministic output RVmeta(dim, 'mse') of the reference's tests (one plane: the mean)
 LABEL_LIKELIHOODS = ("nb", "onehot", "mixnb2", "mixnb3", "mixnb4",   # mixnbC: MISA's C-component mixture of NB per label
                      "mixgauss2", "mixgauss3", "mixgauss4",           # mixgaussC: its C-component mixture of Gaussians (continuous labels)
-                     "mixtril2", "mixtril3", "mixtril4")              # mixtrilC: C full-covariance Gaussians over the whole label vector
+                     "mixtril2", "mixtril3", "mixtril4",              # mixtrilC: C full-covariance Gaussians over the whole label vector
+                     "mixzinb2", "mixzinb3", "mixzinb4")              # mixzinbC: MISA(zero_inflated=True), mixture of zero-inflated NB per label
 
 
 def mixture_components(llk: str) -> int:
@@ -76,6 +77,8 @@ def label_planes(llk: str, P: int = 0) -> int:
   if llk.startswith("mixtril"):
     assert P > 0, "label_planes('mixtrilC') needs the label dimension"
     return mixture_components(llk) * (2 + P)
+  if llk.startswith("mixzinb"):   # MISA(zero_inflated=True, vae.py:76-84): the mixnb planes + C zero-inflation gate logits
+    return 4 * mixture_components(llk)
   return 2 if llk == "nb" else 1 if llk == "onehot" else 3 * mixture_components(llk)
 
 
@@ -495,7 +498,8 @@ def label_llk(y, raw, llk_kind):
     return _mixtril_llk(y, raw, mixture_components(llk_kind))
   if llk_kind.startswith("mix"):
     C = mixture_components(llk_kind)
-    P = raw.shape[1] // (3 * C)
+    zi = llk_kind.startswith("mixzinb")   # MISA(zero_inflated=True): every component a zero-inflated NB, a 4th group of C gate planes
+    P = raw.shape[1] // ((4 if zi else 3) * C)
     a = np.stack([raw[:, c * P:(c + 1) * P] for c in range(C)], 0)                      # [C, B, P] mixture logits
     if llk_kind.startswith("mixgauss"):
       # MISA's continuous labels (vae.py:86-92 -> 'mixgaussian'): every label dimension a C-component mixture of normals,
@@ -507,6 +511,9 @@ def label_llk(y, raw, llk_kind):
         sg = softplus(sr + SOFTPLUS_INV_1)
         zz = (y - mu) / sg
         parts.append((-0.5 * zz * zz - np.log(sg) - 0.5 * np.log(2.0 * np.pi), [zz / sg, (zz * zz - 1.0) / sg * expit(sr + SOFTPLUS_INV_1)]))
+    elif zi:
+      parts = [count_llk(y, [raw[:, (C + c) * P:(C + c + 1) * P], raw[:, (2 * C + c) * P:(2 * C + c + 1) * P],
+                             raw[:, (3 * C + c) * P:(3 * C + c + 1) * P]], "zinb") for c in range(C)]
     else:
       parts = [count_llk(y, [raw[:, (C + c) * P:(C + c + 1) * P], raw[:, (2 * C + c) * P:(2 * C + c + 1) * P]], "nb") for c in range(C)]
     ell = np.stack([pt[0] for pt in parts], 0)
@@ -519,7 +526,8 @@ def label_llk(y, raw, llk_kind):
     d_a = [resp[c] - np.exp(log_pi[c]) for c in range(C)]
     d_r = [resp[c] * parts[c][1][0] for c in range(C)]
     d_l = [resp[c] * parts[c][1][1] for c in range(C)]
-    return llk_p.sum(1), np.concatenate(d_a + d_r + d_l, axis=1)
+    d_g = [resp[c] * parts[c][1][2] for c in range(C)] if zi else []
+    return llk_p.sum(1), np.concatenate(d_a + d_r + d_l + d_g, axis=1)
   m = raw.max(1, keepdims=True)
   lse = m + np.log(np.exp(raw - m).sum(1, keepdims=True))
   logp = raw - lse

@@ -28,6 +28,8 @@ def label_planes(llk: str, P: int = 0) -> int:
     if P <= 0:
       raise ValueError("label_planes('mixtrilC') needs the label dimension")
     return mixture_components(llk) * (2 + P)
+  if llk.startswith("mixzinb"):   # MISA(zero_inflated=True, vae.py:76-84): the 'mixnb' planes + C zero-inflation gate logits
+    return 4 * mixture_components(llk)
   return 2 if llk == "nb" else 1 if llk == "onehot" else 3 * mixture_components(llk)
 
 

@@ -1432,23 +1432,24 @@ __global__ __launch_bounds__(256) void label_loss_kernel(LabelArgs a) {
   float llk = 0.f;
   if (m == 0.f) {   // wave-uniform
     if (a.backward) {
-      const int width = (a.kind == SMX_LABEL_NB ? 2 : (a.kind == SMX_LABEL_MIXNB || a.kind == SMX_LABEL_MIXGAUSS) ? 3 * a.C : 1) * a.Pp;
+      const int width = (a.kind == SMX_LABEL_NB ? 2 : (a.kind == SMX_LABEL_MIXNB || a.kind == SMX_LABEL_MIXGAUSS) ? 3 * a.C : a.kind == SMX_LABEL_MIXZINB ? 4 * a.C : 1) * a.Pp;
       for (int p = lane; p < width; p += 64) a.draw[(long)b * a.ld + p] = 0.f;
     }
-  } else if (a.kind == SMX_LABEL_MIXNB || a.kind == SMX_LABEL_MIXGAUSS) {
+  } else if (a.kind == SMX_LABEL_MIXNB || a.kind == SMX_LABEL_MIXGAUSS || a.kind == SMX_LABEL_MIXZINB) {
     // MISA: log p(y_p) = logsumexp_c(log softmax(mix)_c + log f_c(y_p)); f_c = NB(exp(r_c), l_c) with planes C mixture logits,
     // C log total_counts, C logits -- or, for continuous labels ('mixgaussian', vae.py:86-92), f_c = Normal(loc_c,
     // softplus(s_c + softplus_inverse(1))) with planes C mixture logits, C locations, C raw scales.
     // Gradients: d mix_c = resp_c - pi_c, d (component parameters) = resp_c * d log f_c.
     const int C = a.C;
-    const bool gauss = a.kind == SMX_LABEL_MIXGAUSS;   // (launch-uniform)
+    // MISA(zero_inflated=True) (vae.py:76-84): f_c = ZINB with a fourth group of C gate-logit planes.
+    const bool gauss = a.kind == SMX_LABEL_MIXGAUSS, zi = a.kind == SMX_LABEL_MIXZINB;   // (launch-uniform)
     for (int p = lane; p < a.Pp; p += 64) {
-      float e[4], d0[4], d1[4], mx[4];
+      float e[4], d0[4], d1[4], dg[4], mx[4];
       float am = -3.0e38f, jm = -3.0e38f;
       const bool live = p < a.P;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        e[c] = 0.f; d0[c] = 0.f; d1[c] = 0.f; mx[c] = 0.f;
+        e[c] = 0.f; d0[c] = 0.f; d1[c] = 0.f; dg[c] = 0.f; mx[c] = 0.f;
         if (c < C && live) {
           float d2;
           mx[c] = raw[c * a.Pp + p];
@@ -1459,7 +1460,9 @@ __global__ __launch_bounds__(256) void label_loss_kernel(LabelArgs a) {
             e[c] = -0.5f * zz * zz - flog(s.sp) - 0.9189385332046727f;   // 0.5 log(2 pi)
             d0[c] = zz * inv;
             d1[c] = (zz * zz - 1.f) * inv * s.sg;
-          } else
+          } else if (zi)
+          count_elem<SMX_LLK_ZINB, 0>(y[p], raw[(C + c) * a.Pp + p], raw[(2 * C + c) * a.Pp + p], raw[(3 * C + c) * a.Pp + p], e[c], d0[c], d1[c], dg[c]);
+          else
           count_elem<SMX_LLK_NB, 0>(y[p], raw[(C + c) * a.Pp + p], raw[(2 * C + c) * a.Pp + p], 0.f, e[c], d0[c], d1[c], d2);
           am = fmaxf(am, mx[c]);
           jm = fmaxf(jm, mx[c] + e[c]);
@@ -1479,6 +1482,7 @@ __global__ __launch_bounds__(256) void label_loss_kernel(LabelArgs a) {
             a.draw[(long)b * a.ld + c * a.Pp + p] = (resp - pi) * gs;
             a.draw[(long)b * a.ld + (C + c) * a.Pp + p] = resp * d0[c] * gs;
             a.draw[(long)b * a.ld + (2 * C + c) * a.Pp + p] = resp * d1[c] * gs;
+            if (zi) a.draw[(long)b * a.ld + (3 * C + c) * a.Pp + p] = resp * dg[c] * gs;
           }
       }
     }

@@ -211,13 +211,14 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   }
   for (int j = 0; j < m->n_heads; ++j) {
     SMX_REQUIRE(cfg->label_dim[j] > 0, "label_dim must be > 0");
-    SMX_REQUIRE(cfg->label_llk[j] >= SMX_LABEL_NB && cfg->label_llk[j] <= SMX_LABEL_MIXTRIL, "unknown label likelihood");
+    SMX_REQUIRE(cfg->label_llk[j] >= SMX_LABEL_NB && cfg->label_llk[j] <= SMX_LABEL_MIXZINB, "unknown label likelihood");
     if (cfg->label_llk[j] >= SMX_LABEL_MIXNB) SMX_REQUIRE(cfg->label_components[j] >= 2 && cfg->label_components[j] <= 4, "mixture label heads have 2..4 components");
     if (cfg->label_llk[j] == SMX_LABEL_MIXTRIL) SMX_REQUIRE(cfg->label_dim[j] <= 64, "'mixtril' label heads take at most 64 label dimensions");
     // planes of the head: (log total_count, logits) | logits | C x (mixture logit, two component parameters) | 'mixtril': C mixture-logit
     // planes, C location planes, C x P planes = the columns of the components' scale factors (label_tril_kernel)
     m->lab_ky[j] = cfg->label_llk[j] == SMX_LABEL_NB ? 2 : cfg->label_llk[j] == SMX_LABEL_ONEHOT ? 1 :
-                   cfg->label_llk[j] == SMX_LABEL_MIXTRIL ? cfg->label_components[j] * (2 + cfg->label_dim[j]) : 3 * cfg->label_components[j];
+                   cfg->label_llk[j] == SMX_LABEL_MIXTRIL ? cfg->label_components[j] * (2 + cfg->label_dim[j]) :
+                   cfg->label_llk[j] == SMX_LABEL_MIXZINB ? 4 * cfg->label_components[j] : 3 * cfg->label_components[j];
     m->lab_Pp[j] = round_up(cfg->label_dim[j], 32);
     m->t_labW[j] = add_tensor(m, "lab" + std::to_string(j) + "/W", hd, m->lab_ky[j] * cfg->label_dim[j], m->lab_ky[j], false);
     m->t_labb[j] = add_tensor(m, "lab" + std::to_string(j) + "/b", 1, m->lab_ky[j] * cfg->label_dim[j], m->lab_ky[j], true);

@@ -275,9 +275,11 @@ class MixtureNegativeBinomial(Distribution):
   MixtureSameFamily(Categorical(logits), NegativeBinomial) semantics).  Parameters [..., C, P]: mixture logits, total
   counts, logits; batch shape [..., P]."""
 
-  def __init__(self, mix_logits, total_count, logits, name="MixtureNegativeBinomial"):
+  def __init__(self, mix_logits, total_count, logits, name="MixtureNegativeBinomial", gate_logits=None):
     self.mix_logits = np.asarray(mix_logits, np.float64)
     self.components = NegativeBinomial(total_count, logits)
+    if gate_logits is not None:   # MISA(zero_inflated=True): every component zero-inflated by its own gate
+      self.components = ZeroInflated(self.components, np.asarray(gate_logits, np.float64))
     self.name = name
 
   def _params(self):
@@ -444,6 +446,13 @@ def concat_distributions(dists: Sequence[Distribution], axis: int = 0, name: Opt
     return NegativeBinomialDisp(_cat([d.loc for d in dists], axis), _cat([d.disp for d in dists], axis), name=nm)
   if isinstance(d0, OneHotCategorical):
     return OneHotCategorical(_cat([d.logits for d in dists], axis), name=nm)
+  if isinstance(d0, MixtureNormal):
+    return MixtureNormal(_cat([d.mix_logits for d in dists], axis), _cat([d.components.loc for d in dists], axis),
+                         _cat([d.components.scale for d in dists], axis), name=nm)
+  if isinstance(d0, MixtureNegativeBinomial) and isinstance(d0.components, ZeroInflated):
+    return MixtureNegativeBinomial(_cat([d.mix_logits for d in dists], axis), _cat([d.components.count_distribution.total_count for d in dists], axis),
+                                   _cat([d.components.count_distribution.logits for d in dists], axis), name=nm,
+                                   gate_logits=_cat([d.components.logits for d in dists], axis))
   if isinstance(d0, MixtureNegativeBinomial):   # parameters [..., C, P]: the batch axes are the leading ones
     return MixtureNegativeBinomial(_cat([d.mix_logits for d in dists], axis), _cat([d.components.total_count for d in dists], axis),
                                    _cat([d.components.logits for d in dists], axis), name=nm)

@@ -133,13 +133,11 @@ class SingleCellModel:
         labels.append((rv.event_shape, "nb"))
       elif rv.posterior in ("onehot", "categorical"):
         labels.append((rv.event_shape, "onehot"))
-      elif rv.posterior in ("mixnb", "mixnbd"):     # MISA (vae.py:47-98): mixture of negative binomials per label dimension
+      elif rv.posterior in ("mixnb", "mixnbd", "mixzinb", "mixzinbd"):     # MISA (vae.py:47-98): mixture of negative binomials per label dimension
         C = int(rv.kwargs.get("n_components", 2))
         if not 2 <= C <= 4:
           raise ValueError(f"mixture label heads are built for 2..4 components, given: {C}")
-        if rv.kwargs.get("zero_inflated", False):
-          raise ValueError("zero-inflated mixture label heads are not built")
-        labels.append((rv.event_shape, f"mixnb{C}"))
+        labels.append((rv.event_shape, f"mixzinb{C}" if (rv.kwargs.get("zero_inflated", False) or rv.posterior[:7] == "mixzinb") else f"mixnb{C}"))   # (vae.py:76-84)
       elif rv.posterior in ("mixgaussian", "mixgaus", "mixgauss", "mixnormal", "mdn", "mixtril", "mixfull", "mdntril"):
         # MISA's continuous labels (vae.py:86-92); 'mixtril' (the class's docstring example, vae.py:58) = covariance 'tril'
         C = int(rv.kwargs.get("n_components", 2))
@@ -505,6 +503,11 @@ class SingleCellModel:
         C = int(kind[-1])
         pl = np.reshape(raw, raw.shape[:-1] + (3 * C, P))     # planes: C mixture logits | C log total_counts | C logits
         outs.append(D.Independent(D.MixtureNegativeBinomial(pl[..., :C, :], np.exp(pl[..., C:2 * C, :]), pl[..., 2 * C:, :]), 1, name=nm))
+      elif kind.startswith("mixzinb"):
+        C = int(kind[-1])
+        pl = np.reshape(raw, raw.shape[:-1] + (4 * C, P))     # planes: C mixture logits | C log total_counts | C logits | C gate logits
+        outs.append(D.Independent(D.MixtureNegativeBinomial(pl[..., :C, :], np.exp(pl[..., C:2 * C, :]), pl[..., 2 * C:3 * C, :],
+                                                            gate_logits=pl[..., 3 * C:, :]), 1, name=nm))
       elif kind.startswith("mixgauss"):
         C = int(kind[-1])
         pl = np.reshape(raw, raw.shape[:-1] + (3 * C, P))     # planes: C mixture logits | C locations | C raw scales
@@ -771,7 +774,7 @@ class MISA(SISUA):
   r"""MIxture of labels for Semi-supervised Autoencoder (sisua/models/vae.py:47-98): SISUA whose label heads are
   mixture distributions.  Discrete labels (ADT counts) become `n_components`-component mixtures of negative
   binomials per label dimension ('mixnb'); other label posteriors are converted with the reference's warning.
-  Built: 'mixnb' with 2..4 components, not zero-inflated; 'mixgaussian' with 2..4 components and independent label
+  Built: 'mixnb' with 2..4 components, zero-inflated or not (`zero_inflated`, vae.py:76-84); 'mixgaussian' with 2..4 components and independent label
   dimensions; 'mixtril' (the docstring example of vae.py:58): ONE mixture of 2..4 full-covariance Gaussians over the whole label
   vector (at most 64 label dimensions)."""
   _kind = "sisua"
@@ -780,7 +783,7 @@ class MISA(SISUA):
     labs = [l.copy() for l in _flatten(labels)]
     n_components, zero_inflated = int(n_components), bool(zero_inflated)
     for rv in labs:
-      if rv.posterior in ("nb", "nbd", "zinb", "zinbd", "onehot", "categorical", "bernoulli", "poisson") or rv.posterior[:5] == "mixnb":
+      if rv.posterior in ("nb", "nbd", "zinb", "zinbd", "onehot", "categorical", "bernoulli", "poisson") or rv.posterior[:5] == "mixnb" or rv.posterior[:7] == "mixzinb":
         if rv.posterior[:3] != "mix":
           warnings.warn(f"MISA only support labels is a mixture distribution , given: {rv.posterior}")
           rv.posterior = "mixnb"

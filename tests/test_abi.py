@@ -122,6 +122,7 @@ def test_manifest_and_init_match_oracle():
              dict(model="sisua", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((5, "mixnb3"),)),
              dict(model="sisua", n_genes=20, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((4, "mixgauss2"), (3, "nb"))),
              dict(model="sisua", n_genes=20, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((4, "mixtril2"), (3, "nb"))),
+             dict(model="sisua", n_genes=20, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((4, "mixzinb3"),)),
              dict(model="fvae", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, disc_units=12, disc_layers=2),
              dict(model="fvae", n_genes=20, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=3, disc_units=12, disc_layers=1,
                   labels=((4, "onehot"),))):

@@ -44,6 +44,9 @@ CASES = {
                       labels=((14, "mixtril2"), (5, "onehot")), alpha=10.0),
     "misa_tril_wide": dict(model="sisua", n_genes=90, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=5,
                            labels=((38, "mixtril3"),), alpha=4.0),
+    # MISA(zero_inflated=True) (vae.py:76-84): mixtures of ZERO-INFLATED negative binomials per label dimension
+    "misa_zi": dict(model="sisua", n_genes=110, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=6,
+                    labels=((11, "mixzinb3"), (5, "mixnb2")), alpha=10.0),
     "scale": dict(model="scale", n_genes=150, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=10, n_components=7),
     # the deterministic 'mse' output (RVmeta(dim, 'mse'), tests/test_singlecell_models.py:82-100 of the reference): one plane
     "dca_mse": dict(model="dca", n_genes=110, likelihood="mse", enc_units=(32,), dec_units=(32,), latent_dim=8),
@@ -745,7 +748,8 @@ def test_forward_samples_equals_repeated_forward(Engine, name):
 
 @pytest.mark.parametrize("labels", [((9, "mixnb4"),), ((6, "mixnb2"), (5, "mixnb2")),
                                     ((5, "mixnb4"), (4, "mixnb4"), (3, "mixnb4"), (6, "mixnb4")),
-                                    ((14, "mixtril2"), (4, "nb"))])   # 'mixtril': 2 x (2 + 14) = 32 planes of one head
+                                    ((14, "mixtril2"), (4, "nb")),   # 'mixtril': 2 x (2 + 14) = 32 planes of one head
+                                    ((7, "mixzinb4"),)])
 @pytest.mark.parametrize("S", [1, 3])
 def test_predict_packs_every_label_plane(Engine, labels, S):
   """smx_predict hands its outputs to one pack launch per pass; a MISA model with four mixture components (3 latent + 3

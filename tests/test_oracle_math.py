@@ -143,6 +143,33 @@ def test_label_llk_mixture_normal_matches_torch_mixture_same_family():
     assert so.label_planes(f"mixgauss{C}") == 3 * C and so.mixture_components(f"mixgauss{C}") == C
 
 
+def test_label_llk_mixture_zinb_matches_scipy():
+  """MISA(zero_inflated=True) (sisua/models/vae.py:76-84): every label dimension a C-component mixture of ZERO-INFLATED negative
+  binomials -- values against scipy's nbinom with the gate mixed in by hand, gradients by central differences."""
+  import scipy.stats as st
+  from scipy.special import expit, logsumexp, log_softmax
+  rng = np.random.default_rng(7)
+  B, P = 6, 4
+  for C in (2, 3):
+    kind = f"mixzinb{C}"
+    assert so.label_planes(kind) == 4 * C and so.mixture_components(kind) == C
+    y = rng.poisson(3.0, size=(B, P)).astype(np.float64) * (rng.uniform(size=(B, P)) > 0.4)
+    raw = rng.normal(size=(B, 4 * C * P)) * 0.8
+    ll, d = so.label_llk(y, raw, kind)
+    pl = raw.reshape(B, 4 * C, P)
+    nb = st.nbinom(np.exp(pl[:, C:2 * C]), expit(-pl[:, 2 * C:3 * C])).pmf(y[:, None, :])
+    gate = expit(pl[:, 3 * C:])
+    f = np.where(y[:, None, :] == 0, gate + (1 - gate) * nb, (1 - gate) * nb)
+    ref = logsumexp(log_softmax(pl[:, :C], axis=1) + np.log(f), axis=1).sum(1)
+    assert np.allclose(ll, ref, rtol=1e-10)
+    h = 1e-6
+    for col in rng.choice(4 * C * P, 14, replace=False):
+      rp, rm = raw.copy(), raw.copy()
+      rp[:, col] += h; rm[:, col] -= h
+      fd = (so.label_llk(y, rp, kind)[0] - so.label_llk(y, rm, kind)[0]) / (2 * h)
+      assert np.allclose(d[:, col], fd, rtol=2e-5, atol=1e-7), (C, col)
+
+
 def test_label_llk_mixture_tril_matches_torch_mixture_same_family():
   """MISA's 'mixtril' head (the docstring example of sisua/models/vae.py:58): ONE mixture of C full-covariance Gaussians over the
   whole label vector == torch MixtureSameFamily(Categorical(logits), MultivariateNormal(loc, scale_tril)), diag(L) = softplus(raw)
@@ -207,6 +234,7 @@ CASES = [("vae", "zinb", (), True), ("vae", "nb", (), False), ("vae", "zinbd", (
          ("sisua", "zinb", ((4, "mixnb2"), (3, "mixnb3")), True),   # MISA
          ("sisua", "nb", ((3, "mixgauss2"), (4, "nb")), True),      # MISA with a continuous label variable
          ("sisua", "zinb", ((4, "mixtril2"),), True),               # MISA, full-covariance mixture over the label vector (vae.py:58)
+         ("sisua", "nb", ((4, "mixzinb2"),), True),                 # MISA(zero_inflated=True)
          ("scale", "zinb", (), True), ("scale", "nb", (), False),    # SCALE: mixture prior, Monte-Carlo KL
          ("fvae", "zinb", (), True), ("fvae", "nb", ((3, "onehot"),), False)]   # FVAE / SemiFVAE: two objectives
 

@@ -137,6 +137,13 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
       pl = ry.reshape(B, 3 * C, Pj)
       comp = td.Normal(pl[:, C:2 * C].permute(0, 2, 1), torch.nn.functional.softplus(pl[:, 2 * C:].permute(0, 2, 1) + so.SOFTPLUS_INV_1))
       llk_y = llk_y + td.MixtureSameFamily(td.Categorical(logits=pl[:, :C].permute(0, 2, 1)), comp).log_prob(yj).sum(1)
+    elif kind.startswith("mixzinb"):   # MISA(zero_inflated=True): the components zero-inflated (no torch class: the gate mixed in by hand)
+      C = int(kind[-1])
+      pl = ry.reshape(B, 4 * C, Pj)
+      nb = td.NegativeBinomial(total_count=torch.exp(pl[:, C:2 * C]), logits=pl[:, 2 * C:3 * C], validate_args=False).log_prob(yj[:, None, :])
+      g = pl[:, 3 * C:]
+      comp = torch.where(yj[:, None, :] == 0, torch.logaddexp(g, nb), nb) - torch.nn.functional.softplus(g)
+      llk_y = llk_y + torch.logsumexp(torch.log_softmax(pl[:, :C], 1) + comp, 1).sum(1)
     elif kind.startswith("mixnb"):   # MISA: MixtureSameFamily over C negative binomials per label dimension
       C = int(kind[-1])
       pl = ry.reshape(B, 3 * C, Pj)
@@ -179,6 +186,8 @@ CASES = {
                  labels=((6, "mixnb2"), (3, "mixnb3")), alpha=10.0),
     "misa_gauss": dict(model="sisua", n_genes=36, likelihood="nb", enc_units=(16,), dec_units=(16,), latent_dim=4,
                        labels=((5, "mixgauss3"), (4, "mixnb2")), alpha=10.0),
+    "misa_zi": dict(model="sisua", n_genes=36, likelihood="nb", enc_units=(16,), dec_units=(16,), latent_dim=4,
+                    labels=((6, "mixzinb2"),), alpha=10.0),
     "misa_tril": dict(model="sisua", n_genes=36, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=4,
                       labels=((5, "mixtril3"), (3, "onehot")), alpha=10.0),
     "scale": dict(model="scale", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=6),

@@ -39,6 +39,10 @@ def synth_labels(n, labels, seed=1):
     elif kind.startswith("mixgauss"):   # continuous, bimodal (log-normalised protein levels: a background and a signal mode)
       on = rng.uniform(size=(n, P)) < 0.4
       ys.append(np.where(on, rng.normal(2.5, 0.5, size=(n, P)), rng.normal(-0.5, 0.8, size=(n, P))).astype(np.float32))
+    elif kind.startswith("mixzinb"):   # the bimodal counts below with dropouts: a third of the entries zeroed
+      on = rng.uniform(size=(n, P)) < 0.4
+      yy = np.where(on, rng.poisson(30.0, size=(n, P)), rng.poisson(8.0, size=(n, P)))   # (neither mode puts mass on zero: the zeros need the gate)
+      ys.append((yy * (rng.uniform(size=(n, P)) > 0.33)).astype(np.float32))
     elif kind.startswith("mixnb"):   # bimodal ADT-like counts: a background and a signal population per protein
       on = rng.uniform(size=(n, P)) < 0.4
       ys.append(np.where(on, rng.poisson(30.0, size=(n, P)), rng.poisson(2.0, size=(n, P))).astype(np.float32))
