@@ -8,10 +8,12 @@ reply): no torch, no MPI.  The launcher's environment (RANK / LOCAL_RANK / WORLD
 """
 from __future__ import annotations
 
+import contextlib
 import hashlib
 import os
 import socket
 import struct
+import sys
 import tempfile
 import time
 from typing import Callable, List, Optional, Tuple
@@ -250,6 +252,29 @@ class LocalControlPlane:
     pass
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+  """File descriptor 1 points at stderr inside the block (C stdio flushed on both sides): RCCL prints a five-line banner
+  ("RCCL version : ...") with printf to STDOUT when a communicator is created, and a job's stdout may be a contract of its own
+  (bench.py: rank 0 prints ONE JSON line).  SMX_KEEP_RCCL_BANNER=1 leaves stdout alone."""
+  if os.environ.get("SMX_KEEP_RCCL_BANNER"):
+    yield
+    return
+  import ctypes
+  libc = ctypes.CDLL(None)
+  sys.stdout.flush()
+  libc.fflush(None)
+  saved = os.dup(1)
+  os.dup2(2, 1)
+  try:
+    yield
+  finally:
+    sys.stdout.flush()
+    libc.fflush(None)
+    os.dup2(saved, 1)
+    os.close(saved)
+
+
 def attach_engine(engine, cp):
   """Join the engine to the communicator of the job: RCCL (unique id from rank 0 over the control plane), or the
   library's loopback communicator for an in-process LocalControlPlane."""
@@ -265,7 +290,8 @@ def attach_engine(engine, cp):
   if mode != "p2p-only":
     def unique_id():
       try:
-        return Engine.comm_unique_id()
+        with stdout_to_stderr():
+          return Engine.comm_unique_id()
       except Exception as e:   # (librccl did not load: the peers must still get an answer)
         return b"!" + str(e).encode()
     uid = cp.broadcast_bytes(unique_id)
@@ -273,7 +299,8 @@ def attach_engine(engine, cp):
     try:
       if uid[:1] == b"!" and len(uid) != 128:
         raise RuntimeError(uid[1:].decode(errors="replace"))
-      engine.comm_init(cp.rank, cp.world, uid)
+      with stdout_to_stderr():
+        engine.comm_init(cp.rank, cp.world, uid)
     except Exception as e:   # (a failed ncclCommInitRank leaves the model without a communicator: smx_comm.hip)
       err = e
     failed = [b == b"1" for b in cp.allgather_bytes(b"1" if err is not None else b"0")]

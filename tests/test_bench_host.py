@@ -53,3 +53,16 @@ def test_world_size_mismatch_is_refused():
   env = dict(os.environ, WORLD_SIZE="1", RANK="0")
   r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
   assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+
+
+def test_rccl_banner_is_kept_off_stdout():
+  """RCCL prints a five-line banner with printf to STDOUT when a communicator is created; bench.py's stdout is ONE JSON line.
+  parallel.stdout_to_stderr points file descriptor 1 at stderr around the call, C stdio flushed on both sides."""
+  code = ("import ctypes\nfrom sisua_amd.parallel import stdout_to_stderr\nlibc = ctypes.CDLL(None)\nprint('{\"before\": 1}', flush=True)\n"
+          "with stdout_to_stderr():\n  libc.printf(b'RCCL version : x\\n')\n  print('inside')\nlibc.printf(b'after-c\\n')\nprint('after')\n")
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+  assert r.returncode == 0, r.stderr
+  assert "RCCL version" not in r.stdout and "inside" not in r.stdout and "RCCL version : x" in r.stderr and "inside" in r.stderr
+  assert r.stdout.splitlines()[0] == '{"before": 1}' and sorted(r.stdout.splitlines()[1:]) == ["after", "after-c"]
+  kept = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, SMX_KEEP_RCCL_BANNER="1"))
+  assert "RCCL version : x" in kept.stdout

@@ -369,3 +369,16 @@ def test_world8_c5_split_matches_oracle(Engine, sync_bn):
   assert em < 2e-4 and ev < 4e-4, (em, ev, where)
   for e in engines:
     e.close()
+
+
+def test_rccl_banner_does_not_reach_stdout(tmp_path):
+  """Creating an RCCL communicator prints RCCL's banner with printf to STDOUT ("RCCL version : ..."); the job's stdout is a contract
+  (bench.py: rank 0 prints ONE JSON line).  parallel.stdout_to_stderr around the calls keeps stdout clean -- checked with a real
+  1-rank communicator in a fresh process (the banner appears once per process)."""
+  import subprocess, sys
+  code = ("import sys\nsys.path.insert(0, %r)\nfrom sisua_amd.engine import Engine\nfrom sisua_amd.parallel import stdout_to_stderr\n"
+          "from tests.util import make_pair\nspec, cfg = make_pair(model='vae', n_genes=40, likelihood='nb', enc_units=(16,), dec_units=(16,), latent_dim=4)\n"
+          "e = Engine(cfg, max_batch=32)\nwith stdout_to_stderr():\n  e.comm_init(0, 1, Engine.comm_unique_id())\nprint('{\"ok\": 1}')\ne.close()\n" % ROOT)
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=180)
+  assert r.returncode == 0, r.stderr[-2000:]
+  assert r.stdout.strip() == '{"ok": 1}', r.stdout
