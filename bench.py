@@ -234,7 +234,7 @@ def main():
     eng.generate_lognormal(n_c5, seed=8, rank=rank, storage="u16" if args.storage != "f32" else "f32")
   else:
     eng.upload(xt, cell_id_base=cell_base, storage=args.storage, **extra)
-  attach_engine(eng, cp)
+  collective = attach_engine(eng, cp)
   if world > 1 and args.sync_bn:
     eng.set_sync_bn(True)
 
@@ -257,6 +257,18 @@ def main():
   eng.synchronize()
   cp.barrier()
   dt = cp.max(time.perf_counter() - t0)
+  # N > 1: the step's collective ALONE (50 all-reduces of the zeroed flat gradient buffer through the path the steps take, events on
+  # the model's stream; max over ranks) -- what share of ms_per_step is link time is the first thing to know about a scaling curve
+  dp_info = None
+  if world > 1:
+    nbytes = None
+    try:
+      us, nbytes = eng.comm_time_allreduce(50)
+    except Exception as err:   # (every rank still takes part in the max below)
+      us = -1.0
+      print(f"bench: timing the collective failed: {err}", file=sys.stderr)
+    us = cp.max(us)
+    dp_info = {"collective": collective, "allreduce_us": round(us, 1) if us >= 0 else None, "allreduce_bytes": nbytes}
   # the ELBO scalars of every timed step stayed on the device (smx_metrics_history): read after the clock has stopped
   hist = eng.metrics_history(args.steps)
   m = {k: float(v[-1]) for k, v in hist.items()}
@@ -398,6 +410,8 @@ def main():
                      "event_pair_overhead_us": round(null_us, 3), "launches_per_event_pair": LOSS_REPEAT},
         "kernel_us": per_kernel,
     }
+    if dp_info is not None:
+      out["dp"] = dp_info
     if world == 1 and not args.no_cpu_baseline and not c5_full:
       try:
         out["cpu_baseline"] = cpu_baseline(cfg, xt, batch, args.cpu_budget, extra=extra)

@@ -306,6 +306,12 @@ int smx_comm_rank(const smx_model* m);
 int smx_comm_p2p_export(smx_model* m, int world, uint8_t handles[128]);
 int smx_comm_p2p_init(smx_model* m, int rank, int world, const uint8_t* all_handles);
 int smx_comm_p2p_error(smx_model* m, int32_t* error);
+/* Measurement hook (bench.py, N > 1): the step's collective ALONE -- `iters` all-reduces of the (zeroed) flat gradient buffer
+ * through whichever path the steps take (RCCL, the peer-to-peer exchange, the loopback communicator), timed with events on the
+ * model's stream after three untimed calls; every rank must call it with the same `iters`.  us_per_call: this rank's average;
+ * floats (may be NULL): the buffer's length.
+ * The gradient buffer is scratch between steps: nothing of the model's state changes. */
+int smx_comm_time_allreduce(smx_model* m, int iters, float* us_per_call, int64_t* floats);
 /* Which communication library the process is bound to, and the HIP runtime both it and this library run on
  * (RCCL is resolved as the sibling of the loaded libamdhip64: ROCm's, or torch's bundled copy when torch was
  * imported first; SMX_RCCL_PATH overrides).  rccl_version: ncclGetVersion code.  Any output may be NULL. */

@@ -110,6 +110,7 @@ SIGNATURES = {
     "smx_comm_p2p_export": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint8)]),
     "smx_comm_p2p_init": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
     "smx_comm_p2p_error": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
+    "smx_comm_time_allreduce": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "smx_comm_world": (C.c_int, [_VP]),
     "smx_comm_rank": (C.c_int, [_VP]),
     "smx_comm_library": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, _IP]),

@@ -249,6 +249,28 @@ int smx_comm_library(char* rccl_path, int rccl_cap, char* hip_path, int hip_cap,
   return SMX_OK;
 }
 
+int smx_comm_time_allreduce(smx_model* m, int iters, float* us_per_call, int64_t* floats) {
+  SMX_REQUIRE(m && us_per_call && iters >= 1 && iters <= 100000, "bad arguments");
+  SMX_REQUIRE(smx::dp_active(m), "no communicator attached (or a world of one without SMX_FORCE_ALLREDUCE)");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  SMX_HIP(hipMemsetAsync(m->grads, 0, m->grads_count * sizeof(float), m->st));   // (sums of zeros: no overflow however often it runs)
+  for (int i = 0; i < 3; ++i) SMX_CHECK(smx::dp_allreduce(m, 0, m->grads_count, m->st));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  SMX_HIP(hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); smx::set_error("hipEventCreate failed"); return SMX_ERR_HIP; }
+  int rc = SMX_OK;
+  float ms = 0.f;
+  if (hipEventRecord(e0, m->st) != hipSuccess) rc = SMX_ERR_HIP;
+  for (int i = 0; i < iters && rc == SMX_OK; ++i) rc = smx::dp_allreduce(m, 0, m->grads_count, m->st);
+  if (rc == SMX_OK && (hipEventRecord(e1, m->st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)) {
+    smx::set_error("event timing of the all-reduce failed");
+    rc = SMX_ERR_HIP;
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  if (rc == SMX_OK) { *us_per_call = 1e3f * ms / (float)iters; if (floats) *floats = (int64_t)m->grads_count; }
+  return rc;
+}
+
 int smx_comm_rank(const smx_model* m) { return m ? m->rank : 0; }
 int smx_comm_world(const smx_model* m) { return m ? m->world : 0; }
 

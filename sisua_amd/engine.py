@@ -459,6 +459,12 @@ class Engine:
     check(self.lib.smx_comm_p2p_error(self._h, C.byref(e)))
     return int(e.value)
 
+  def comm_time_allreduce(self, iters: int = 50):
+    """(microseconds per all-reduce of the flat gradient buffer ALONE, its bytes), through the path the steps take (every rank calls it)."""
+    us, n = C.c_float(0.0), C.c_int64(0)
+    check(self.lib.smx_comm_time_allreduce(self._h, int(iters), C.byref(us), C.byref(n)))
+    return float(us.value), 4 * int(n.value)
+
   @property
   def world(self) -> int:
     return self.lib.smx_comm_world(self._h)

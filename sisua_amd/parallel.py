@@ -279,10 +279,10 @@ def attach_engine(engine, cp):
   """Join the engine to the communicator of the job: RCCL (unique id from rank 0 over the control plane), or the
   library's loopback communicator for an in-process LocalControlPlane."""
   if cp.world <= 1:
-    return
+    return "none"
   if isinstance(cp, LocalControlPlane):
     cp.attach(engine)
-    return
+    return "loopback"
   from sisua_amd.engine import Engine
   mode = os.environ.get("SMX_ALLREDUCE", "rccl").lower()   # 'rccl' (default) | 'p2p' (hand-written two-shot exchange over IPC-mapped
   if mode not in ("rccl", "p2p", "p2p-only"):               # peer buffers, beside RCCL) | 'p2p-only' (no RCCL communicator at all)
@@ -316,3 +316,4 @@ def attach_engine(engine, cp):
   if mode != "rccl":
     handles = cp.allgather_bytes(engine.comm_p2p_export(cp.world))
     engine.comm_p2p_init(cp.rank, cp.world, b"".join(handles))
+  return mode   # the collective the steps take: 'rccl', or the exchange ('p2p' beside an RCCL communicator, 'p2p-only' without one)

@@ -476,6 +476,15 @@ def test_rccl_single_rank_allreduce_is_identity(Engine, monkeypatch, graph, buck
     order = np.arange(64 * 6, dtype=np.int32) % x.shape[0]
     m = e.train_steps(order, 6, 64, graph=graph, metrics=True)
     outs.append((m, e.get_params(), e.get_bn()))
+    if use_comm:   # the measurement hook of bench.py (N > 1): the collective alone; it must leave the model's state as it is
+      us, nbytes = e.comm_time_allreduce(20)
+      assert 0.0 < us < 1e4 and nbytes >= 4 * sum(v.size for v in outs[-1][1].values())
+      assert all(np.array_equal(v, outs[-1][1][k]) for k, v in e.get_params().items())
+      m2 = e.train_steps(order, 6, 64, graph=graph, metrics=True)
+      assert np.isfinite(m2["loss"])
+    else:
+      with pytest.raises(Exception, match="communicator"):
+        e.comm_time_allreduce(5)
     e.close()
   for key in ("loss", "nllk_x", "nllk_y", "kl"):
     assert outs[0][0][key] == outs[1][0][key], key
