@@ -252,11 +252,16 @@ def main():
   eng.stage_steps(order[args.warmup * batch:], args.steps, batch)
   eng.synchronize()
   cp.barrier()
+  if world > 1:
+    # the control plane's barrier is a TCP round (its replies leave rank 0 one after the other: ~100 us of skew, several per cent of a
+    # 20-step run); a collective on the devices + synchronize lines the ranks up to microseconds before the clock starts
+    eng.comm_time_allreduce(1)
   t0 = time.perf_counter()
   eng.train_steps(None, args.steps, batch, graph=use_graph)   # K steps queued by ONE library call, no host sync between them
   eng.synchronize()
+  t1 = time.perf_counter()   # this rank's K steps are done (every step ends in a collective: so are everybody's)
   cp.barrier()
-  dt = cp.max(time.perf_counter() - t0)
+  dt = cp.max(t1 - t0)       # MAX over ranks of the K steps between the two barrier + synchronize brackets
   # N > 1: the step's collective ALONE (50 all-reduces of the zeroed flat gradient buffer through the path the steps take, events on
   # the model's stream; max over ranks) -- what share of ms_per_step is link time is the first thing to know about a scaling curve
   dp_info = None
