@@ -47,7 +47,9 @@ typedef enum {
  * (z against z with every dimension permuted over the minibatch), both in the same step.  n_labels = 1 with
  * SMX_LABEL_ONEHOT makes it the semi-supervised form (one logit per class, TC logit = their logsumexp). */
 typedef enum { SMX_MODEL_VAE = 0, SMX_MODEL_DCA = 1, SMX_MODEL_SCVI = 2, SMX_MODEL_SISUA = 3, SMX_MODEL_SCALE = 4,
-               SMX_MODEL_FVAE = 5 } smx_model_kind;
+               SMX_MODEL_FVAE = 5,
+               SMX_MODEL_SCALE_TRIL = 6 /* SCALE with covariance = 'tril' / 'full' (scale.py:28,35): a lower-triangular scale factor per
+                                          component -- prior/scale is [n_components * latent_dim][latent_dim] (diag = softplus + 1e-5) */ } smx_model_kind;
 /* Count likelihoods selected by RVmeta.posterior (configs/base.yaml:32-40,
  * data/_single_cell_base.py:518-533). */
 /* SMX_LLK_MSE: RVmeta(dim, 'mse') (the reference's tests/test_singlecell_models.py:82-91, 97-100): a deterministic output, ONE

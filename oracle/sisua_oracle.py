@@ -108,6 +108,10 @@ class Spec:
   tie_mixtures: bool = False
   tie_loc: bool = False
   tie_scale: bool = False
+  # scale.py:28,35: `covariance` of the mixture's components -- 'none' / 'diag': diagonal (prior/scale [C, D], softplus1); 'tril' /
+  # 'full': a lower-triangular factor per component (prior/scale [C D, D]: row c D + p = row p of L_c; diag = softplus(raw) + 1e-5,
+  # [3P-recall] TFP's FillScaleTriL; entries above the diagonal are inert), not combinable with the tie_* options here
+  covariance: str = "none"
   n_genes: int = 0
   likelihood: str = "zinb"
   enc_units: Tuple[int, ...] = (64, 64)
@@ -136,6 +140,9 @@ class Spec:
   def __post_init__(self):
     assert self.model in ("vae", "dca", "scvi", "sisua", "scale", "fvae"), self.model
     assert 1 <= self.n_components <= 32
+    assert self.covariance in ("none", "diag", "tril", "full"), self.covariance
+    if self.scale_tril:
+      assert not (self.tie_mixtures or self.tie_loc or self.tie_scale), "tied mixture parameters are built for diagonal components only"
     assert self.likelihood in OUTPUT_POSTERIORS, self.likelihood
     if self.model == "scvi":
       assert self.likelihood in ("nbd", "zinbd")  # scvi.py:50-52
@@ -146,6 +153,10 @@ class Spec:
       assert self.disc_layers >= 1 and self.disc_units >= 1 and 0.0 <= self.disc_leak < 1.0
     elif self.model not in ("sisua", "scale"):   # ('scale' with label heads = SCALAR, sisua/models/scale.py:52-59)
       assert len(self.labels) == 0
+
+  @property
+  def scale_tril(self):
+    return self.model == "scale" and self.covariance in ("tril", "full")
 
   @property
   def k(self) -> int:
@@ -187,7 +198,7 @@ def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
   out.append(("lat/b", (2 * D if spec.stochastic else D,)))
   if spec.model == "scale":   # trainable Gaussian-mixture prior over z (Xiong et al. 2019; scale.py:13-49)
     C = spec.n_components
-    out += [("prior/logits", (C,)), ("prior/loc", (C, D)), ("prior/scale", (C, D))]
+    out += [("prior/logits", (C,)), ("prior/loc", (C, D)), ("prior/scale", (C * D, D) if spec.scale_tril else (C, D))]
   if spec.model == "scvi":
     hl = mlp("encl", G, spec.encl_units)
     out.append(("latl/W", (hl, 2)))
@@ -242,6 +253,10 @@ def init_params(spec: Spec, seed: Optional[int] = None) -> Dict[str, np.ndarray]
       params[name] = rng.uniform(-1.0, 1.0, size=shape).astype(np.float32).astype(np.float64)
       if spec.tie_loc:          # one shared location (the draw above keeps every other tensor's stream where it was)
         params[name][:] = 0.0
+    elif name == "prior/scale" and spec.scale_tril:   # L_c = I: softplus(log(e - 1)) = 1 on the diagonals, zeros below
+      params[name] = np.zeros(shape)
+      Dd = shape[1]
+      params[name][np.arange(shape[0]), np.arange(shape[0]) % Dd] = float(np.float32(SOFTPLUS_INV_1))   # (fp32-representable like every initial value)
     else:
       params[name] = np.zeros(shape)   # biases, mixture logits (uniform weights), raw prior scales (softplus1(0) = 1)
   return params
@@ -710,15 +725,34 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
     # SCALE (sisua/models/scale.py:13-49: mixture latent, `analytic=False`): the KL term is a ONE-SAMPLE Monte-Carlo
     # estimate log q(z|x) - log p(z) at the z that is decoded, with p(z) = sum_c softmax(a)_c N(z; m_c, diag s_c^2),
     # s = softplus1(raw) -- the published model (Xiong et al. 2019); odin's mixture layer itself is not citable.
-    a, m_c, s_c = params["prior/logits"], params["prior/loc"], softplus1(params["prior/scale"])
+    a, m_c = params["prior/logits"], params["prior/loc"]
     log_pi = a - (a.max() + np.log(np.exp(a - a.max()).sum()))
-    dzm = (z[:, None, :] - m_c[None]) / s_c[None]                                   # [B, C, D]
-    comp = log_pi[None] + (-0.5 * dzm ** 2 - np.log(s_c)[None] - 0.5 * np.log(2 * np.pi)).sum(2)
+    tril_c = None
+    if spec.scale_tril:
+      # covariance = 'tril': component c = N(m_c, L_c L_c^T); u = L^-1 (z - m) by forward substitution, w = L^-T u by back substitution
+      # (d log N / d m = w = -d log N / d z, d log N / d L_pj = w_p u_j - [p == j] / L_pp)
+      C_ = a.shape[0]
+      Lraw = params["prior/scale"].reshape(C_, D, D)
+      dg = softplus(np.einsum("cpp->cp", Lraw)) + TRIL_DIAG_SHIFT
+      Lc = np.tril(Lraw, -1)
+      Lc[:, np.arange(D), np.arange(D)] = dg
+      u = np.zeros((B, C_, D)); w = np.zeros((B, C_, D))
+      for p_ in range(D):
+        u[:, :, p_] = ((z[:, None, p_] - m_c[None, :, p_]) - (Lc[None, :, p_, :p_] * u[:, :, :p_]).sum(2)) / dg[None, :, p_]
+      for p_ in range(D - 1, -1, -1):
+        w[:, :, p_] = (u[:, :, p_] - (Lc[None, :, p_ + 1:, p_] * w[:, :, p_ + 1:]).sum(2)) / dg[None, :, p_]
+      comp = log_pi[None] - 0.5 * (u * u).sum(2) - np.log(dg).sum(1)[None] - 0.5 * D * np.log(2 * np.pi)
+      dzm, s_c = None, None
+      tril_c = dict(u=u, w=w, dg=dg, Lraw=Lraw)
+    else:
+      s_c = softplus1(params["prior/scale"])
+      dzm = (z[:, None, :] - m_c[None]) / s_c[None]                                   # [B, C, D]
+      comp = log_pi[None] + (-0.5 * dzm ** 2 - np.log(s_c)[None] - 0.5 * np.log(2 * np.pi)).sum(2)
     cm = comp.max(1, keepdims=True)
     log_p = (cm + np.log(np.exp(comp - cm).sum(1, keepdims=True)))[:, 0]
     log_q = (-0.5 * eps ** 2 - np.log(sig) - 0.5 * np.log(2 * np.pi)).sum(1)
     kl = log_q - log_p
-    scale_c = dict(resp=np.exp(comp - log_p[:, None]), log_pi=log_pi, dzm=dzm, s=s_c)
+    scale_c = dict(resp=np.exp(comp - log_p[:, None]), log_pi=log_pi, dzm=dzm, s=s_c, tril=tril_c)
 
   # ---- scvi library latent (scvi.py:37-45, 88-106) --------------------------
   kl_l = np.zeros(B)
@@ -828,15 +862,23 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
     _factor_backward(spec, params, fac, up + (spec.alpha / B) * dsup, grads)
 
   if spec.model == "scale":
-    r_, dzm, s_c = scale_c["resp"], scale_c["dzm"], scale_c["s"]
-    # d(-log p)/dz = sum_c resp_c (z - m_c) / s_c^2; log q depends on (sigma, eps) only: d log q / d sigma = -1 / sigma
-    dz = dz + c_kl * (r_[:, :, None] * dzm / s_c[None]).sum(1)
+    r_, dzm, s_c, tr = scale_c["resp"], scale_c["dzm"], scale_c["s"], scale_c["tril"]
+    # d(-log p)/dz = sum_c resp_c (z - m_c) / s_c^2 (tril: sum_c resp_c w_c); log q depends on (sigma, eps) only: d log q / d sigma = -1 / sigma
+    dz = dz + c_kl * ((r_[:, :, None] * tr["w"]).sum(1) if tr is not None else (r_[:, :, None] * dzm / s_c[None]).sum(1))
     dmu = dz
     dsig = dz * eps - c_kl / sig
     dlat = np.concatenate([dmu, dsig * expit(s_raw + SOFTPLUS_INV_1)], axis=1)
     grads["prior/logits"] = c_kl * (np.exp(scale_c["log_pi"])[None] - r_).sum(0)
-    grads["prior/loc"] = -c_kl * (r_[:, :, None] * dzm / s_c[None]).sum(0)
-    grads["prior/scale"] = -c_kl * (r_[:, :, None] * (dzm ** 2 - 1.0) / s_c[None]).sum(0) * expit(params["prior/scale"] + SOFTPLUS_INV_1)
+    if tr is not None:
+      u, w, dg, Lraw = tr["u"], tr["w"], tr["dg"], tr["Lraw"]
+      grads["prior/loc"] = -c_kl * (r_[:, :, None] * w).sum(0)
+      dL = np.tril(np.einsum("bc,bcp,bcj->cpj", r_, w, u))                       # sum_b r (w u^T), lower triangle
+      dd = (np.einsum("bc,bcp->cp", r_, w * u) - r_.sum(0)[:, None] / dg) * expit(np.einsum("cpp->cp", Lraw))
+      dL[:, np.arange(D), np.arange(D)] = dd
+      grads["prior/scale"] = (-c_kl * dL).reshape(-1, D)
+    else:
+      grads["prior/loc"] = -c_kl * (r_[:, :, None] * dzm / s_c[None]).sum(0)
+      grads["prior/scale"] = -c_kl * (r_[:, :, None] * (dzm ** 2 - 1.0) / s_c[None]).sum(0) * expit(params["prior/scale"] + SOFTPLUS_INV_1)
     if spec.tie_mixtures:
       grads["prior/logits"] = np.zeros_like(grads["prior/logits"])
     if spec.tie_loc:

@@ -13,6 +13,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+SOFTPLUS_INV_1 = float(np.log(np.expm1(1.0)))   # softplus(SOFTPLUS_INV_1) == 1
 LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
 OUTPUT_POSTERIORS = LIKELIHOODS + ("mse",)   # 'mse': deterministic output, -log_prob(x) = mean squared error (tests/test_singlecell_models.py:82-91)
 
@@ -119,6 +120,9 @@ class ModelConfig:
   tie_mixtures: bool = False   # scale.py:29-33: uniform fixed mixture weights / one location / one scale vector for every component
   tie_loc: bool = False
   tie_scale: bool = False
+  # scale.py:28,35 `covariance` of the mixture's components: 'none' / 'diag' (diagonal, prior/scale [C, D]) or 'tril' / 'full' (a
+  # lower-triangular factor per component, prior/scale [C D, D]; diag = softplus(raw) + 1e-5; not with the tie_* options)
+  covariance: str = "none"
   # model 'fvae' (sisua/models/fvae.py:9-18; odin factorVAE defaults): the total-correlation discriminator
   disc_units: int = 1000
   disc_layers: int = 5
@@ -132,6 +136,15 @@ class ModelConfig:
   @property
   def stochastic(self) -> bool:
     return self.model != "dca"
+
+  @property
+  def scale_tril(self) -> bool:
+    if self.covariance not in ("none", "diag", "tril", "full"):
+      raise ValueError(f"covariance must be 'none' / 'diag' or 'tril' / 'full', given: {self.covariance}")
+    tril = self.model == "scale" and self.covariance in ("tril", "full")
+    if tril and (self.tie_mixtures or self.tie_loc or self.tie_scale):
+      raise ValueError("tied mixture parameters are built for diagonal components only (covariance='none')")
+    return tril
 
   @property
   def disc_outputs(self) -> int:
@@ -168,7 +181,7 @@ def manifest(cfg: ModelConfig) -> List[Tuple[str, Tuple[int, ...]]]:
   out += [("lat/W", (h, nl)), ("lat/b", (nl,))]
   if cfg.model == "scale":
     C = cfg.n_components
-    out += [("prior/logits", (C,)), ("prior/loc", (C, D)), ("prior/scale", (C, D))]
+    out += [("prior/logits", (C,)), ("prior/loc", (C, D)), ("prior/scale", (C * D, D) if cfg.scale_tril else (C, D))]
   if cfg.model == "scvi":
     hl = mlp("encl", G, cfg.encl_units)
     out += [("latl/W", (hl, 2)), ("latl/b", (2,))]
@@ -206,6 +219,9 @@ def init_params(cfg: ModelConfig, seed: Optional[int] = None) -> Dict[str, np.nd
       params[name] = rng.uniform(-1.0, 1.0, size=shape).astype(np.float32)
       if cfg.tie_loc:
         params[name][:] = 0.0
+    elif name == "prior/scale" and cfg.scale_tril:   # L_c = I: softplus(log(e - 1)) = 1 on the diagonals
+      params[name] = np.zeros(shape, dtype=np.float32)
+      params[name][np.arange(shape[0]), np.arange(shape[0]) % shape[1]] = SOFTPLUS_INV_1
     else:
       params[name] = np.zeros(shape, dtype=np.float32)
   return params

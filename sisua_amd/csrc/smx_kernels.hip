@@ -1068,8 +1068,148 @@ __global__ __launch_bounds__(256) void scale_prior_fwd_kernel(ScalePriorArgs a) 
     a.dklz[(long)b * a.Dp + d] = g;
   }
 }
+// ---- covariance = 'tril' (scale.py:28,35): component c = N(m_c, L_c L_c^T), diag L = softplus(raw) + 1e-5, strict lower triangle raw ----
+// One wave per cell, lane p = latent dimension p (D <= 32); the component's factor sits in the wave's LDS tile [D][D + 1].
+//   u = L^-1 (z - m) forward substitution, w = L^-T u back substitution;  log N = -1/2 |u|^2 - sum log L_pp - D/2 log 2 pi
+//   d(-log p)/dz = sum_c resp_c w_c.  Two sweeps over the components (densities -> responsibilities, then the gradient): C D^2 is small.
+__device__ inline void tril_load(const ScalePriorArgs& a, int c, int lane, float* L, float& lpp, float& sg) {
+  const int D = a.D, ldl = D + 1;
+  lpp = 1.f; sg = 0.f;
+  for (int j = 0; j < D; ++j) {   // lane p reads row p of L_c
+    float v = lane < D ? a.scale_raw[((long)c * D + lane) * a.Dp + j] : 0.f;
+    if (j == lane) { const SpSg t = softplus_sigmoid(v); v = t.sp + 1e-5f; lpp = v; sg = t.sg; }
+    if (lane < D) L[lane * ldl + j] = j <= lane ? v : 0.f;
+  }
+}
+__device__ inline void tril_solve(int D, int lane, const float* L, float lpp, float r, float& u, float& w) {
+  const int ldl = D + 1;
+  const float inv = frcp(lpp);
+  u = 0.f; w = 0.f;
+  for (int j = 0; j < D; ++j) {
+    const float uj = __shfl(r * inv, j, 64);
+    if (lane == j) u = uj;
+    else if (lane > j && lane < D) r -= L[lane * ldl + j] * uj;
+  }
+  float s = u;
+  for (int i = D - 1; i >= 0; --i) {
+    const float wi = __shfl(s * inv, i, 64);
+    if (lane == i) w = wi;
+    else if (lane < i) s -= L[i * ldl + lane] * wi;
+  }
+}
+__global__ __launch_bounds__(256) void scale_prior_tril_fwd_kernel(ScalePriorArgs a) {
+  extern __shared__ float Lall[];   // 4 waves x [D][D + 1]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wv;
+  if (b >= a.B) return;   // (a wave-uniform exit; no workgroup barrier below)
+  float* L = Lall + wv * a.D * (a.D + 1);
+  const float HALF_LOG_2PI = 0.9189385332046727f;
+  const float lg = lane < a.C ? a.logits[lane] : -3.0e38f;
+  const float lmx = wave_max(lg);
+  const float lse = lmx + flog(wave_sum(lane < a.C ? fexp(lg - lmx) : 0.f));
+  const float zd = lane < a.D ? a.z[(long)b * a.Dp + lane] : 0.f;
+  float comp_mine = -3.0e38f;
+  for (int c = 0; c < a.C; ++c) {
+    float lpp, sg, u, w;
+    tril_load(a, c, lane, L, lpp, sg);
+    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+    tril_solve(a.D, lane, L, lpp, zd - (lane < a.D ? a.loc[(long)c * a.Dp + lane] : 0.f), u, w);
+    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+    const float t = wave_sum(lane < a.D ? -0.5f * u * u - flog(lpp) - HALF_LOG_2PI : 0.f) + (a.logits[c] - lse);
+    if (lane == c) comp_mine = t;
+  }
+  const float cmx = wave_max(comp_mine);
+  const float log_p = cmx + flog(wave_sum(lane < a.C ? fexp(comp_mine - cmx) : 0.f));
+  const float resp = lane < a.C ? fexp(comp_mine - log_p) : 0.f;
+  if (lane < 32) a.resp[(long)b * 32 + lane] = resp;
+  float lq = 0.f;
+  if (lane < a.D) {
+    const float e = a.eps[(long)b * a.Dp + lane];
+    lq = -0.5f * e * e - flog(a.sig[(long)b * a.Dp + lane]) - HALF_LOG_2PI;
+  }
+  lq = wave_sum(lq);
+  if (lane == 0) a.kl[b] = lq - log_p;
+  float g = 0.f;
+  for (int c = 0; c < a.C; ++c) {
+    float lpp, sg, u, w;
+    tril_load(a, c, lane, L, lpp, sg);
+    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+    tril_solve(a.D, lane, L, lpp, zd - (lane < a.D ? a.loc[(long)c * a.Dp + lane] : 0.f), u, w);
+    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+    g += __shfl(resp, c, 64) * w;
+  }
+  for (int d = lane; d < a.Dp; d += 64) a.dklz[(long)b * a.Dp + d] = d < a.D ? g : 0.f;   // (d == lane for d < D <= 32)
+}
+// gradients of the prior's parameters: one workgroup per component, the factor once in LDS, waves over the cells, lane p = row p
+__global__ __launch_bounds__(256) void scale_prior_tril_bwd_kernel(ScalePriorArgs a) {
+  extern __shared__ float sm[];   // L [D][D + 1] | partial sums [4][D][D + 2]
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int D = a.D, ldl = D + 1, lda = D + 2;
+  float* L = sm;
+  float* part = sm + D * ldl;
+  float lpp = 1.f, sg = 0.f;
+  if (wv == 0) tril_load(a, c, lane, L, lpp, sg);
+  __syncthreads();
+  if (wv != 0 && lane < D) { lpp = L[lane * ldl + lane]; }
+  float acc[32];   // row p of sum_b r (w u^T); [j = p] also carries the -r / L_pp term
+#pragma unroll
+  for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+  float g_loc = 0.f, g_lg = 0.f;
+  const float mloc = lane < D ? a.loc[(long)c * a.Dp + lane] : 0.f;
+  const float invl = frcp(lpp);
+  for (int b = wv; b < a.B; b += 4) {
+    const float rc = a.resp[(long)b * 32 + c];
+    float u, w;
+    tril_solve(D, lane, L, lpp, (lane < D ? a.z[(long)b * a.Dp + lane] : 0.f) - mloc, u, w);
+    g_loc += rc * w;
+    g_lg += rc;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      if (j < D) {   // (uniform)
+        const float uj = __shfl(u, j, 64);
+        acc[j] += rc * (w * uj - (j == lane ? invl : 0.f));
+      }
+    }
+  }
+  if (lane < D) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j < D) part[(wv * D + lane) * lda + j] = acc[j];
+    part[(wv * D + lane) * lda + D] = g_loc;
+  }
+  if (lane == 0) part[(wv * D) * lda + D + 1] = g_lg;
+  __syncthreads();
+  if (wv == 0 && lane < D) {
+    for (int j = 0; j < D; ++j) {
+      const float t = (part[(0 * D + lane) * lda + j] + part[(1 * D + lane) * lda + j]) + (part[(2 * D + lane) * lda + j] + part[(3 * D + lane) * lda + j]);
+      float g = 0.f;
+      if (j < lane) g = -a.kl_scale * t;
+      else if (j == lane) g = -a.kl_scale * t * sg;
+      a.g_scale[((long)c * D + lane) * a.Dp + j] = g;
+    }
+    for (int j = D; j < a.Dp; ++j) a.g_scale[((long)c * D + lane) * a.Dp + j] = 0.f;
+    const float tl = (part[(0 * D + lane) * lda + D] + part[(1 * D + lane) * lda + D]) + (part[(2 * D + lane) * lda + D] + part[(3 * D + lane) * lda + D]);
+    a.g_loc[(long)c * a.Dp + lane] = -a.kl_scale * tl;
+  }
+  if (wv == 0 && lane >= D && lane < a.Dp) a.g_loc[(long)c * a.Dp + lane] = 0.f;
+  if (wv == 0 && lane == 0) {
+    const float rsum = (part[(0 * D) * lda + D + 1] + part[(1 * D) * lda + D + 1]) + (part[(2 * D) * lda + D + 1] + part[(3 * D) * lda + D + 1]);
+    float mx = -3.0e38f;
+    for (int q = 0; q < a.C; ++q) mx = fmaxf(mx, a.logits[q]);
+    float se = 0.f;
+    for (int q = 0; q < a.C; ++q) se += fexp(a.logits[q] - mx);
+    a.g_logits[c] = a.kl_scale * ((float)a.B * fexp(a.logits[c] - mx) * frcp(se) - rsum);
+  }
+}
+
 int launch_scale_prior_fwd(hipStream_t st, const ScalePriorArgs& a) {
   if (a.C < 2 || a.C > 32 || a.B <= 0) { set_error("scale prior: 2..32 components"); return SMX_ERR_INVALID; }
+  if (a.tril) {
+    if (a.D < 1 || a.D > 32) { set_error("scale prior: full-covariance components take at most 32 latent dimensions"); return SMX_ERR_INVALID; }
+    hipLaunchKernelGGL(scale_prior_tril_fwd_kernel, dim3((a.B + 3) / 4), dim3(256), (size_t)4 * a.D * (a.D + 1) * sizeof(float), st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   hipLaunchKernelGGL(scale_prior_fwd_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
@@ -1135,6 +1275,12 @@ __global__ __launch_bounds__(256) void scale_prior_tie_kernel(ScalePriorArgs a) 
 }
 
 int launch_scale_prior_bwd(hipStream_t st, const ScalePriorArgs& a) {
+  if (a.tril) {
+    if (a.D < 1 || a.D > 32 || a.tie_mixtures || a.tie_loc || a.tie_scale) { set_error("scale prior: full-covariance components take at most 32 latent dimensions and no tied parameters"); return SMX_ERR_INVALID; }
+    hipLaunchKernelGGL(scale_prior_tril_bwd_kernel, dim3(a.C), dim3(256), (size_t)(a.D * (a.D + 1) + 4 * a.D * (a.D + 2)) * sizeof(float), st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   hipLaunchKernelGGL(scale_prior_bwd_kernel, dim3(a.C), dim3(256), 0, st, a);
   if (a.tie_mixtures || a.tie_loc || a.tie_scale) hipLaunchKernelGGL(scale_prior_tie_kernel, dim3(1), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());

@@ -177,6 +177,7 @@ struct smx_model {
   float* sq_slots = nullptr; std::vector<int> sq_first, sq_count; std::vector<char> sq_reduced; int sq_total_first = 0;
   int G = 0, Gp = 0, D = 0, Dp = 0, k = 0, Bmax = 0;
   bool stochastic = true, scvi = false, scale = false, fvae = false;
+  bool scale_tril = false;   // SCALE with full-covariance components (SMX_MODEL_SCALE_TRIL): prior/scale holds C lower-triangular D x D factors
   int n_heads = 0;                    // label heads on the decoder (0 for fvae: SemiFVAE's labels go to the discriminator)
   // fvae: discriminator on z (smx_factor.hip)
   std::vector<MlpLayer> disc; int t_discoutW = -1, t_discoutb = -1;

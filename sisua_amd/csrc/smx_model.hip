@@ -143,7 +143,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   SMX_REQUIRE(cfg->n_genes > 0 && cfg->latent_dim > 0 && cfg->max_batch > 0, "n_genes, latent_dim, max_batch must be > 0");
   SMX_REQUIRE(cfg->n_enc >= 1 && cfg->n_enc <= SMX_MAX_LAYERS && cfg->n_dec >= 1 && cfg->n_dec <= SMX_MAX_LAYERS,
               "encoder/decoder need 1..8 layers");
-  SMX_REQUIRE(cfg->model >= SMX_MODEL_VAE && cfg->model <= SMX_MODEL_FVAE, "unknown model kind");
+  SMX_REQUIRE(cfg->model >= SMX_MODEL_VAE && cfg->model <= SMX_MODEL_SCALE_TRIL, "unknown model kind");
   if (cfg->model == SMX_MODEL_FVAE) {
     SMX_REQUIRE(cfg->disc_layers >= 1 && cfg->disc_layers <= SMX_MAX_LAYERS && cfg->disc_units >= 1, "fvae: discriminator needs 1..8 hidden layers");
     SMX_REQUIRE(cfg->disc_leak >= 0.f && cfg->disc_leak < 1.f, "fvae: leaky-ReLU slope in [0, 1)");
@@ -151,11 +151,12 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     if (cfg->n_labels == 1)
       SMX_REQUIRE(cfg->label_llk[0] == SMX_LABEL_ONEHOT && cfg->label_dim[0] >= 2 && cfg->label_dim[0] <= 32, "fvae: the label variable is one-hot with 2..32 classes");
   }
-  if (cfg->model == SMX_MODEL_SCALE) SMX_REQUIRE(cfg->n_components >= 2 && cfg->n_components <= 32, "scale: 2..32 mixture components");
+  if (cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL) SMX_REQUIRE(cfg->n_components >= 2 && cfg->n_components <= 32, "scale: 2..32 mixture components");
+  if (cfg->model == SMX_MODEL_SCALE_TRIL) SMX_REQUIRE(cfg->latent_dim <= 32, "scale with full-covariance components: at most 32 latent dimensions");
   SMX_REQUIRE(cfg->likelihood >= SMX_LLK_NB && cfg->likelihood <= SMX_LLK_MSE, "unknown likelihood");
   SMX_REQUIRE(cfg->n_labels >= 0 && cfg->n_labels <= SMX_MAX_LABELS, "too many label heads");
   // (SCALE with label heads = SCALAR, sisua/models/scale.py:52-59: the mixture prior of SCALE under SISUA's semi-supervised heads)
-  SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->model == SMX_MODEL_FVAE || cfg->model == SMX_MODEL_SCALE || cfg->n_labels == 0,
+  SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->model == SMX_MODEL_FVAE || cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL || cfg->n_labels == 0,
               "label heads need model = SISUA, SCALE (SCALAR) or FVAE (SemiFVAE)");
   if (cfg->model == SMX_MODEL_SCVI) {
     SMX_REQUIRE(cfg->likelihood == SMX_LLK_NBD || cfg->likelihood == SMX_LLK_ZINBD, "scvi supports nbd / zinbd only");
@@ -169,7 +170,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   m->cfg = *cfg; m->device = dev;
   m->G = cfg->n_genes; m->Gp = round_up(m->G, 32); m->D = cfg->latent_dim; m->Dp = round_up(m->D, 32);
   m->k = llk_planes(cfg->likelihood);
-  m->stochastic = cfg->model != SMX_MODEL_DCA; m->scvi = cfg->model == SMX_MODEL_SCVI; m->scale = cfg->model == SMX_MODEL_SCALE;
+  m->stochastic = cfg->model != SMX_MODEL_DCA; m->scvi = cfg->model == SMX_MODEL_SCVI; m->scale = cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL; m->scale_tril = cfg->model == SMX_MODEL_SCALE_TRIL;
   m->fvae = cfg->model == SMX_MODEL_FVAE; m->n_heads = m->fvae ? 0 : cfg->n_labels;
   m->Bmax = cfg->max_batch;
   int rc = SMX_OK;
@@ -183,7 +184,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   if (m->scale) {   // trainable mixture prior: logits [C], means and raw scales [C][D]
     m->t_prLogits = add_tensor(m, "prior/logits", 1, cfg->n_components, 1, true);
     m->t_prLoc = add_tensor(m, "prior/loc", cfg->n_components, m->D, 1, false);
-    m->t_prScale = add_tensor(m, "prior/scale", cfg->n_components, m->D, 1, false);
+    m->t_prScale = add_tensor(m, "prior/scale", m->scale_tril ? cfg->n_components * m->D : cfg->n_components, m->D, 1, false);   // (tril: row c D + p = row p of L_c)
   }
   if (m->scvi) {
     int hl = build_mlp(m, m->encl, "encl", m->G, cfg->n_encl, cfg->encl_units, ST_ENCL_DROPOUT, cfg->dropout_enc, bnorm);

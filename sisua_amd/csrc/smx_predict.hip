@@ -123,7 +123,7 @@ int stacked_decoder(smx_model* m, const float* z, long rows, float* const* hb, i
 // in the latent part of log w).
 bool stacked_scoring_ok(const smx_model* m) {
   if (!m->flags.stacked_scoring || !m->stochastic || m->use_injected || m->dec.empty()) return false;
-  if (m->scale && (m->Dp > 64 || m->cfg.n_components > 32)) return false;
+  if (m->scale && (m->Dp > 64 || m->cfg.n_components > 32 || m->scale_tril)) return false;   // (full-covariance components: the draw-by-draw form, whose prior term is scale_prior_fwd's)
   if (m->scvi && !scvi_score_supported(m->Gp)) return false;
   if (!head_loss_supported(1, m->dec.back().out_p, m->Gp) || (m->dec.back().out_p % 4)) return false;
   for (const MlpLayer& L : m->dec)

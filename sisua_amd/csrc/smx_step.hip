@@ -520,7 +520,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     ScalePriorArgs sp;
     sp.z = m->z; sp.sig = m->sig; sp.eps = m->eps; sp.B = ps.B; sp.D = m->D; sp.Dp = m->Dp; sp.C = c.n_components;
     sp.logits = P_(m, m->t_prLogits); sp.loc = P_(m, m->t_prLoc); sp.scale_raw = P_(m, m->t_prScale);
-    sp.kl = m->kl; sp.resp = m->resp; sp.dklz = m->dklz;
+    sp.kl = m->kl; sp.resp = m->resp; sp.dklz = m->dklz; sp.tril = m->scale_tril;
     SMX_CHECK(launch_scale_prior_fwd(m->st, sp));
   }
   // ---- scvi library latent ----
@@ -1082,7 +1082,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
     sp.logits = P_(m, m->t_prLogits); sp.loc = P_(m, m->t_prLoc); sp.scale_raw = P_(m, m->t_prScale);
     sp.resp = m->resp; sp.kl_scale = c.beta * inv_gb;
     sp.g_logits = G_(m, m->t_prLogits); sp.g_loc = G_(m, m->t_prLoc); sp.g_scale = G_(m, m->t_prScale);
-    sp.tie_mixtures = m->flags.tie_mixtures; sp.tie_loc = m->flags.tie_loc; sp.tie_scale = m->flags.tie_scale;
+    sp.tie_mixtures = m->flags.tie_mixtures; sp.tie_loc = m->flags.tie_loc; sp.tie_scale = m->flags.tie_scale; sp.tril = m->scale_tril;
     SMX_CHECK(launch_scale_prior_bwd(m->st, sp));
   }
   // Products that only the optimiser reads (the weight gradients of the first decoder layer, of the latent head and of

@@ -162,7 +162,8 @@ class SingleCellModel:
                        input_dropout=float(enc.input_dropout), log_norm=self._log_norm, beta=self.beta, alpha=self.alpha,
                        latent_activation=self._latent_activation(), clip_library=self.clip_library,
                        lr=float(self._opt["lr"]), clipnorm=float(self._opt["clipnorm"]), seed=self.seed,
-                       n_components=int(getattr(self, "_n_components", 10)), **getattr(self, "_ties", {}), **getattr(self, "_disc_cfg", {}))
+                       n_components=int(getattr(self, "_n_components", 10)), covariance=str(getattr(self, "_covariance", "none")),
+                       **getattr(self, "_ties", {}), **getattr(self, "_disc_cfg", {}))
 
   def _ensure_engine(self, max_batch: int) -> Engine:
     cfg = self._make_config()
@@ -800,7 +801,8 @@ class SCALE(SingleCellModel):
   r"""SCALE - "Single-Cell ATAC-seq analysis via Latent feature Extraction" (sisua/models/scale.py:13-49; Xiong et al.
   2019, Nature Communications): a VAE whose prior over z is a TRAINABLE mixture of `n_components` diagonal Gaussians; the
   KL term is the one-sample Monte-Carlo estimate log q(z|x) - log p(z) (`analytic=False`, scale.py:49).  Built:
-  covariance='none' (diagonal components) with or without tied mixture weights / locations / scales (scale.py:29-33).  [3P-recall: the
+  covariance='none' / 'diag' (diagonal components) with or without tied mixture weights / locations / scales (scale.py:29-33), and
+  covariance='tril' / 'full' (a lower-triangular scale factor per component, at most 32 latent dimensions, untied).  [3P-recall: the
   published model; odin's mixture latent layer behind the reference's class is not citable.]"""
   _kind = "scale"
 
@@ -813,13 +815,19 @@ class SCALE(SingleCellModel):
         z.posterior = "mixgaus"
     kw0 = lat[0].kwargs
     covariance = str(kw0.get("covariance", covariance))
-    if covariance not in ("none", "diag"):
-      raise ValueError("SCALE is built for covariance='none' (diagonal components)")
+    if covariance not in ("none", "diag", "tril", "full"):
+      raise ValueError("SCALE is built for covariance='none' / 'diag' (diagonal components) and 'tril' / 'full' (a lower-triangular factor per component)")
+    self._covariance = covariance
     self._ties = dict(tie_mixtures=bool(kw0.get("tie_mixtures", tie_mixtures)), tie_loc=bool(kw0.get("tie_loc", tie_loc)),
                       tie_scale=bool(kw0.get("tie_scale", tie_scale)))
     self._n_components = int(kw0.get("n_components", n_components))
     if not 2 <= self._n_components <= 32:
       raise ValueError(f"SCALE is built for 2..32 mixture components, given: {self._n_components}")
+    if covariance in ("tril", "full"):
+      if any(self._ties.values()):
+        raise ValueError("tied mixture parameters are built for diagonal components only (covariance='none')")
+      if lat[0].event_shape > 32:
+        raise ValueError("full-covariance mixture components are built for at most 32 latent dimensions")
     super().__init__(outputs=outputs, latents=lat, **kwargs)
     self.init_args = dict(outputs=outputs, latents=latents, n_components=n_components, covariance=covariance,
                           tie_mixtures=tie_mixtures, tie_loc=tie_loc, tie_scale=tie_scale, **kwargs)

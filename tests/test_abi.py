@@ -119,6 +119,7 @@ def test_manifest_and_init_match_oracle():
              dict(model="dca", n_genes=20, likelihood="nbd", enc_units=(8,), dec_units=(8,), latent_dim=3),
              dict(model="scale", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, n_components=5),
              dict(model="scale", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, n_components=4, tie_loc=True, tie_mixtures=True),
+             dict(model="scale", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, n_components=4, covariance="tril"),
              dict(model="sisua", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((5, "mixnb3"),)),
              dict(model="sisua", n_genes=20, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((4, "mixgauss2"), (3, "nb"))),
              dict(model="sisua", n_genes=20, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((4, "mixtril2"), (3, "nb"))),

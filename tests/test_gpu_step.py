@@ -48,6 +48,8 @@ CASES = {
     "misa_zi": dict(model="sisua", n_genes=110, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=6,
                     labels=((11, "mixzinb3"), (5, "mixnb2")), alpha=10.0),
     "scale": dict(model="scale", n_genes=150, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=10, n_components=7),
+    # SCALE with full-covariance components (scale.py:28,35 covariance='tril'): a lower-triangular factor per component
+    "scale_tril": dict(model="scale", n_genes=130, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=9, n_components=5, covariance="tril"),
     # the deterministic 'mse' output (RVmeta(dim, 'mse'), tests/test_singlecell_models.py:82-100 of the reference): one plane
     "dca_mse": dict(model="dca", n_genes=110, likelihood="mse", enc_units=(32,), dec_units=(32,), latent_dim=8),
     "vae_mse": dict(model="vae", n_genes=203, likelihood="mse", enc_units=(48,), dec_units=(40,), latent_dim=6),
@@ -333,7 +335,7 @@ def test_injected_noise_matches_oracle(Engine, name):
 
 
 @pytest.mark.parametrize("name,graph", [("vae_zinb", False), ("vae_zinb", True), ("sisua", True), ("scvi_zinbd", False), ("scvi_nbd", True), ("misa", False), ("scale", True),
-                                        ("fvae", True), ("semifvae", False)])
+                                        ("scale_tril", False), ("fvae", True), ("semifvae", False)])
 def test_trajectory_matches_oracle(Engine, name, graph):
   """50-step seeded trajectory: ELBO per step within 1e-4 relative."""
   kw = CASES[name]
@@ -542,7 +544,7 @@ def test_hip_matches_committed_trajectory_fixture(Engine):
   e.close()
 
 
-@pytest.mark.parametrize("name", ["vae_zinb", "scvi_zinbd", "dca_zinb", "scale"])
+@pytest.mark.parametrize("name", ["vae_zinb", "scvi_zinbd", "dca_zinb", "scale", "scale_tril"])
 def test_marginal_llk_matches_oracle(Engine, name):
   """importance-weighted log p(x) (posterior.py:941-976) on the GPU vs the oracle."""
   spec, cfg, x, ys, lib, mask = _problem(dict(CASES[name], labels=()) if name != "sisua" else CASES[name])

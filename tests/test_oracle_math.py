@@ -228,6 +228,33 @@ def _toy(model, lk, labels=(), bn=True, **kw):
   return spec, params, so.init_bn_state(spec), x, y, lib, mask
 
 
+def test_scale_tril_prior_gradients_fd():
+  """SCALE with covariance='tril' (scale.py:28,35): every entry of the prior's tensors by central differences -- the lower triangles
+  and diagonals of the scale factors move the loss, the entries above the diagonals do not (and get a zero gradient)."""
+  spec, params, bn_state, x, y, lib, mask = _toy("scale", "zinb", (), True, covariance="tril")
+  D, C = spec.latent_dim, spec.n_components
+  assert dict(so.manifest(spec))["prior/scale"] == (C * D, D)
+  noise = so.PhiloxNoise(spec.seed, 7, np.arange(x.shape[0]) + 100)
+  res = so.forward_backward(spec, params, bn_state, x, noise)
+  g = res["grads"]["prior/scale"].reshape(C, D, D)
+  assert np.all(np.triu(g, 1) == 0.0) and np.all(np.abs(np.tril(g)).reshape(C, -1).max(1) > 0)
+  h = 1e-5
+  for name in ("prior/scale", "prior/loc", "prior/logits"):
+    flat = params[name].reshape(-1)
+    for idx in range(flat.size):
+      pp = {k: v.copy() for k, v in params.items()}
+      pm = {k: v.copy() for k, v in params.items()}
+      pp[name].reshape(-1)[idx] += h
+      pm[name].reshape(-1)[idx] -= h
+      fd = (so.forward_backward(spec, pp, bn_state, x, noise, backward=False)["loss"] - so.forward_backward(spec, pm, bn_state, x, noise, backward=False)["loss"]) / (2 * h)
+      assert np.isclose(res["grads"][name].reshape(-1)[idx], fd, rtol=2e-4, atol=2e-8), (name, idx)
+  # the initial prior is the unit Gaussian mixture: L = I
+  p0 = so.init_params(spec)["prior/scale"].reshape(C, D, D)
+  assert np.allclose(np.tril(p0, -1), 0) and np.allclose(so.softplus(np.einsum("cpp->cp", p0)), 1.0)
+  with pytest.raises(AssertionError):
+    so.Spec(model="scale", n_genes=5, covariance="tril", tie_loc=True)
+
+
 CASES = [("vae", "zinb", (), True), ("vae", "nb", (), False), ("vae", "zinbd", (), True),
          ("vae", "nbd", (), True), ("dca", "zinb", (), True), ("scvi", "zinbd", (), True),
          ("scvi", "nbd", (), False), ("sisua", "zinb", ((4, "nb"), (3, "onehot")), True),

@@ -72,8 +72,13 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
     q = td.Normal(lat[:, :D], softplus1(lat[:, D:]))
     z = q.loc + q.scale * torch.as_tensor(noise.normal(so.STREAM_EPS_Z, D))
     if spec.model == "scale":   # Monte-Carlo KL against the trainable mixture prior: log q(z|x) - log p(z)
-      prior = td.MixtureSameFamily(td.Categorical(logits=P["prior/logits"]),
-                                   td.Independent(td.Normal(P["prior/loc"], softplus1(P["prior/scale"])), 1))
+      if spec.scale_tril:   # covariance = 'tril' (scale.py:28): full-covariance components, diag(L) = softplus(raw) + 1e-5
+        Lr = P["prior/scale"].reshape(spec.n_components, D, D)
+        L = torch.tril(Lr, -1) + torch.diag_embed(torch.nn.functional.softplus(torch.diagonal(Lr, dim1=-2, dim2=-1)) + so.TRIL_DIAG_SHIFT)
+        comp = td.MultivariateNormal(P["prior/loc"], scale_tril=L)
+      else:
+        comp = td.Independent(td.Normal(P["prior/loc"], softplus1(P["prior/scale"])), 1)
+      prior = td.MixtureSameFamily(td.Categorical(logits=P["prior/logits"]), comp)
       kl = td.Independent(q, 1).log_prob(z) - prior.log_prob(z)
     else:
       kl = td.kl_divergence(q, td.Normal(torch.zeros_like(q.loc), torch.ones_like(q.scale))).sum(1)
@@ -191,6 +196,7 @@ CASES = {
     "misa_tril": dict(model="sisua", n_genes=36, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=4,
                       labels=((5, "mixtril3"), (3, "onehot")), alpha=10.0),
     "scale": dict(model="scale", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=6),
+    "scale_tril": dict(model="scale", n_genes=40, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=4, covariance="tril"),
     "scalar": dict(model="scale", n_genes=42, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=4,
                    labels=((6, "nb"), (3, "onehot")), alpha=10.0),   # SCALE + label heads (scale.py:52-59)
     "fvae": dict(model="fvae", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, disc_units=24, disc_layers=3),

@@ -59,6 +59,8 @@ def perturbed_params(spec, scale=0.05, seed=3):
   for name, on in (("prior/loc", getattr(spec, "tie_loc", False)), ("prior/scale", getattr(spec, "tie_scale", False))):
     if on and name in out:   # SCALE's tied tensors keep identical rows
       out[name] = np.broadcast_to(out[name][:1], out[name].shape).copy()
+  if getattr(spec, "scale_tril", False):   # full-covariance components: off-diagonals that matter (the 0.05 above leaves L ~ I)
+    out["prior/scale"] = (out["prior/scale"] + 0.3 * rng.normal(size=out["prior/scale"].shape)).astype(np.float32).astype(np.float64)
   if getattr(spec, "tie_mixtures", False) and "prior/logits" in out:
     out["prior/logits"] = np.zeros_like(out["prior/logits"])
   return out
