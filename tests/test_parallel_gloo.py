@@ -152,3 +152,66 @@ def test_tcp_control_plane_fixed_port_and_stale_file(tmp_path, monkeypatch):
   ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
   [t.start() for t in ts]; [t.join(60) for t in ts]
   assert out == [3.0, 3.0]
+
+
+class _FakeEngine:
+  """Stands in for sisua_amd.engine.Engine in attach_engine: records the calls, fails ncclCommInitRank on the ranks it is told to."""
+
+  def __init__(self, fail):
+    self.fail, self.calls = fail, []
+
+  def comm_init(self, rank, world, uid):
+    self.calls.append("comm_init")
+    if self.fail:
+      raise RuntimeError("ncclCommInitRank failed: invalid usage")
+
+  def comm_p2p_export(self, world):
+    self.calls.append("p2p_export")
+    return bytes(128)
+
+  def comm_p2p_init(self, rank, world, handles):
+    self.calls.append(f"p2p_init:{len(handles)}")
+
+
+def _attach_worker(rank, world, port, out_dir, failing):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), SMX_RUN_ID=f"a{port}")
+  os.environ.pop("SMX_ALLREDUCE", None)
+  import warnings
+  from sisua_amd import engine as eng_mod
+  from sisua_amd.parallel import ControlPlane, attach_engine
+  eng_mod.Engine.comm_unique_id = staticmethod(lambda: bytes(128))   # (no GPU, no librccl on this box's path: the id is opaque here)
+  cp = ControlPlane(rank, world)
+  e = _FakeEngine(rank in failing)
+  try:
+    with warnings.catch_warnings(record=True) as w:
+      warnings.simplefilter("always")
+      mode = attach_engine(e, cp)
+    res = f"{mode}|{','.join(e.calls)}|{int(any('falling back' in str(x.message) for x in w))}"
+  except RuntimeError as err:
+    res = f"raised:{err}|{','.join(e.calls)}"
+  cp.barrier()
+  cp.close()
+  open(os.path.join(out_dir, f"res{rank}"), "w").write(res)
+
+
+@pytest.mark.parametrize("failing,expect", [((), "rccl"), ((0, 1), "p2p-only"), ((1,), "raised")])
+def test_attach_engine_agrees_on_the_collective(tmp_path, failing, expect):
+  """parallel.attach_engine over the TCP control plane with two ranks and a stand-in engine (no GPU): RCCL comes up on every rank ->
+  'rccl'; on NO rank -> every rank takes the peer-to-peer exchange (handles of both ranks gathered), rank 0 warns; on SOME ranks only ->
+  every rank stops (a half-built communicator cannot be repaired), nobody hangs."""
+  import multiprocessing as pymp
+  ctx = pymp.get_context("spawn")
+  port = _free_port()
+  ps = [ctx.Process(target=_attach_worker, args=(r, 2, port, str(tmp_path), tuple(failing))) for r in range(2)]
+  for p in ps:
+    p.start()
+  for p in ps:
+    p.join(120)
+  assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
+  res = [(tmp_path / f"res{r}").read_text() for r in range(2)]
+  if expect == "rccl":
+    assert res == ["rccl|comm_init|0", "rccl|comm_init|0"]
+  elif expect == "p2p-only":
+    assert res == ["p2p-only|comm_init,p2p_export,p2p_init:256|1", "p2p-only|comm_init,p2p_export,p2p_init:256|0"]
+  else:
+    assert all(r.startswith("raised:") for r in res), res
