@@ -816,3 +816,24 @@ def test_bf16x3_products_match_oracle(Engine, name, batch):
   between = grad_errors(grads, got[0][1])
   assert max(between.values()) < 2e-5, sorted(between.items(), key=lambda kv: -kv[1])[:3]
   assert abs(m["loss"] - got[0][0]["loss"]) <= 2e-6 * abs(m["loss"])
+
+
+@pytest.mark.parametrize("name", ["misa_tril", "scale_tril"])
+def test_hip_matches_committed_variant_steps(Engine, name):
+  """One training step of the round-3 variants -- MISA's 'mixtril' + zero-inflated mixture heads, SCALE with full-covariance
+  components -- against COMMITTED numbers (tests/golden/oracle_variants_fixture.npz): loss terms and every gradient."""
+  from tests.golden import make_head_fixtures as mk
+  fx = _golden("oracle_variants_fixture.npz")
+  spec, cfg = make_pair(**mk.CASES[name])
+  names = [n for n, _ in so.manifest(spec)]
+  e = Engine(cfg, max_batch=32, init=False)
+  e.set_params({n: fx[f"{name}/p0/{n}"] for n in names})
+  ys = [fx[f"{name}/y{j}"] for j in range(len(spec.labels))]
+  e.upload(fx[f"{name}/x"], ys, None, fx[f"{name}/mask"] if ys else None, cell_id_base=mk.CELL_BASE)
+  rows = np.arange(7, 7 + mk.B, dtype=np.int32)
+  m = e.train_step(rows)
+  for key in ("loss", "nllk_x", "kl") + (("nllk_y",) if ys else ()):
+    assert np.isclose(m[key], float(fx[f"{name}/{key}"]), rtol=RTOL, atol=1e-5), (key, m[key], float(fx[f"{name}/{key}"]))
+  worst = grad_errors(e.get_params(which=1), {n: fx[f"{name}/g/{n}"] for n in names})
+  assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  e.close()

@@ -3,6 +3,7 @@ reference's own code (tests/golden/make_reference_fixtures.py).  Bit-exact."""
 import os
 
 import numpy as np
+import pytest
 
 from oracle import sisua_oracle as so
 
@@ -99,3 +100,28 @@ def test_oracle_reproduces_committed_c5_trajectory():
     assert np.allclose(out[key], fx[key][:2], rtol=1e-10), key
   assert len(fx["loss"]) == mk.STEPS and fx["loss"][-3:].mean() < 0.8 * fx["loss"][:3].mean()
   assert fx["z_mean"].shape == (128, cfg.latent_dim) and np.all(fx["z_scale"] > 0)
+
+
+def _variants_fixture():
+  import importlib.util
+  spec_mod = importlib.util.spec_from_file_location("mkvar", os.path.join(os.path.dirname(__file__), "golden", "make_head_fixtures.py"))
+  mk = importlib.util.module_from_spec(spec_mod)
+  spec_mod.loader.exec_module(mk)
+  return mk, np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_variants_fixture.npz"))
+
+
+@pytest.mark.parametrize("name", ["misa_tril", "scale_tril"])
+def test_oracle_reproduces_committed_variant_steps(name):
+  """tests/golden/oracle_variants_fixture.npz (MISA's 'mixtril' + zero-inflated heads, SCALE with full-covariance components): the
+  committed inputs are what the generator builds, and the oracle gives the committed loss terms and gradients again."""
+  mk, fx = _variants_fixture()
+  spec, x, ys, mask, rows = mk.inputs(name)
+  assert np.array_equal(x, fx[f"{name}/x"]) and np.array_equal(mask, fx[f"{name}/mask"])
+  names = [n for n, _ in so.manifest(spec)]
+  params = {n: fx[f"{name}/p0/{n}"].copy() for n in names}
+  res = so.forward_backward(spec, params, so.init_bn_state(spec), x[rows], so.PhiloxNoise(spec.seed, mk.STEP, rows + mk.CELL_BASE),
+                            y=[fx[f"{name}/y{j}"][rows] for j in range(len(spec.labels))], mask=mask[rows])
+  for k in ("loss", "nllk_x", "nllk_y", "kl"):
+    assert np.isclose(res["metrics"][k], float(fx[f"{name}/{k}"]), rtol=1e-12, atol=1e-14), k
+  for n in names:
+    assert np.allclose(res["grads"][n], fx[f"{name}/g/{n}"], rtol=1e-10, atol=1e-14), n
