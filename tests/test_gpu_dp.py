@@ -61,6 +61,11 @@ CASES = {
                        encl_units=(16,)),
     "fvae": dict(model="fvae", n_genes=110, likelihood="zinb", enc_units=(32,), dec_units=(32,), latent_dim=8, disc_units=60, disc_layers=2),
     "vae_nobn": dict(model="vae", n_genes=64, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=5, batchnorm=False),
+    # round-3 variants through the same flat-buffer collective: MISA's full-covariance / zero-inflated mixture heads, SCALE's priors
+    "misa_mix": dict(model="sisua", n_genes=90, likelihood="zinb", enc_units=(32,), dec_units=(32,), latent_dim=6,
+                     labels=((7, "mixtril2"), (5, "mixzinb3")), alpha=10.0),
+    "scale": dict(model="scale", n_genes=100, likelihood="zinb", enc_units=(32,), dec_units=(32,), latent_dim=7, n_components=4),
+    "scale_tril": dict(model="scale", n_genes=100, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=6, n_components=3, covariance="tril"),
 }
 
 
@@ -76,7 +81,8 @@ def _problem(kw, n=400):
 
 @pytest.mark.parametrize("name,world,sync_bn", [("vae_zinb", 2, False), ("vae_zinb", 2, True), ("vae_clip", 2, False),
                                                 ("vae_clip", 3, True), ("sisua", 2, False), ("sisua", 2, True),
-                                                ("scvi_zinbd", 2, False), ("scvi_zinbd", 2, True), ("vae_nobn", 4, False), ("fvae", 2, False)])
+                                                ("scvi_zinbd", 2, False), ("scvi_zinbd", 2, True), ("vae_nobn", 4, False), ("fvae", 2, False),
+                                                ("misa_mix", 2, False), ("scale", 2, True), ("scale_tril", 3, False)])
 def test_world_n_steps_match_oracle(Engine, name, world, sync_bn):
   """3 optimiser steps of `world` replicas, every rank holding the WHOLE matrix but drawing its own rows: loss /
   metrics / reduced gradients / gradient norms / parameters / moving statistics of EVERY rank equal the oracle's
