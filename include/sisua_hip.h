@@ -49,7 +49,10 @@ typedef enum {
 typedef enum { SMX_MODEL_VAE = 0, SMX_MODEL_DCA = 1, SMX_MODEL_SCVI = 2, SMX_MODEL_SISUA = 3, SMX_MODEL_SCALE = 4,
                SMX_MODEL_FVAE = 5,
                SMX_MODEL_SCALE_TRIL = 6 /* SCALE with covariance = 'tril' / 'full' (scale.py:28,35): a lower-triangular scale factor per
-                                          component -- prior/scale is [n_components * latent_dim][latent_dim] (diag = softplus + 1e-5) */ } smx_model_kind;
+                                          component -- prior/scale is [n_components * latent_dim][latent_dim] (diag = softplus + 1e-5) */,
+               SMX_MODEL_SCALE_POST = 7 /* scale.py:26,38-47 read literally: the latent POSTERIOR is a mixture of n_components (2 .. min(latent_dim,
+                                          8)) diagonal Gaussians from a (1 + 2 n_components) * latent_dim wide latent head (logits in the first columns
+                                          of plane 0 | locations | raw scales), standard-normal prior, Monte-Carlo KL; no prior tensors */ } smx_model_kind;
 /* Count likelihoods selected by RVmeta.posterior (configs/base.yaml:32-40,
  * data/_single_cell_base.py:518-533). */
 /* SMX_LLK_MSE: RVmeta(dim, 'mse') (the reference's tests/test_singlecell_models.py:82-91, 97-100): a deterministic output, ONE

@@ -53,6 +53,7 @@ STREAM_DEC_DROPOUT = 48    # + layer index
 STREAM_EPS_Z = 64
 STREAM_EPS_L = 65
 STREAM_PERMUTE = 66        # fvae: uniforms whose per-dimension ranks are the permute_dims permutations
+STREAM_MIX_PICK = 67       # scale, mixture-density posterior: the uniform that picks a cell's component
 
 LIKELIHOODS = ("nb", "zinb", "nbd", "zinbd")
 OUTPUT_POSTERIORS = LIKELIHOODS + ("mse",)   # + the deterministic output RVmeta(dim, 'mse') of the reference's tests (one plane: the mean)
@@ -112,6 +113,13 @@ class Spec:
   # 'full': a lower-triangular factor per component (prior/scale [C D, D]: row c D + p = row p of L_c; diag = softplus(raw) + 1e-5,
   # [3P-recall] TFP's FillScaleTriL; entries above the diagonal are inert), not combinable with the tie_* options here
   covariance: str = "none"
+  # scale.py:26,38-47 READ LITERALLY: the class sets the latent POSTERIOR to 'mixgaus' -- q(z|x) = sum_c pi_c(x) N(mu_c(x), diag sigma_c(x)^2)
+  # from a (C + 2 C D)-wide latent head, a standard-normal prior, KL = log q(z|x) - log p(z) at one draw (`analytic=False`); the draw
+  # picks a component by the cell's uniform and is reparameterised through that component only ([3P-recall] TFP MixtureSameFamily,
+  # reparameterize=False).  latent_mixture=True selects this reading (no prior/* tensors; n_components <= latent_dim; covariance 'none',
+  # no tie_*); False (default) is the published model's trainable mixture PRIOR.  Head planes of width D: [logits in the first C
+  # columns | mu_1 .. mu_C | raw sigma_1 .. raw sigma_C].
+  latent_mixture: bool = False
   n_genes: int = 0
   likelihood: str = "zinb"
   enc_units: Tuple[int, ...] = (64, 64)
@@ -143,6 +151,9 @@ class Spec:
     assert self.covariance in ("none", "diag", "tril", "full"), self.covariance
     if self.scale_tril:
       assert not (self.tie_mixtures or self.tie_loc or self.tie_scale), "tied mixture parameters are built for diagonal components only"
+    if self.latent_mixture:
+      assert self.model == "scale" and not self.scale_tril and not (self.tie_mixtures or self.tie_loc or self.tie_scale)
+      assert 2 <= self.n_components <= min(self.latent_dim, 8), "mixture-density posterior: 2 .. min(latent_dim, 8) components"
     assert self.likelihood in OUTPUT_POSTERIORS, self.likelihood
     if self.model == "scvi":
       assert self.likelihood in ("nbd", "zinbd")  # scvi.py:50-52
@@ -194,9 +205,10 @@ def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
 
   G, D = spec.n_genes, spec.latent_dim
   h = mlp("enc", G, spec.enc_units)
-  out.append(("lat/W", (h, 2 * D if spec.stochastic else D)))
-  out.append(("lat/b", (2 * D if spec.stochastic else D,)))
-  if spec.model == "scale":   # trainable Gaussian-mixture prior over z (Xiong et al. 2019; scale.py:13-49)
+  nl = (1 + 2 * spec.n_components) * D if spec.latent_mixture else (2 * D if spec.stochastic else D)
+  out.append(("lat/W", (h, nl)))
+  out.append(("lat/b", (nl,)))
+  if spec.model == "scale" and not spec.latent_mixture:   # trainable Gaussian-mixture prior over z (Xiong et al. 2019; scale.py:13-49)
     C = spec.n_components
     out += [("prior/logits", (C,)), ("prior/loc", (C, D)), ("prior/scale", (C * D, D) if spec.scale_tril else (C, D))]
   if spec.model == "scvi":
@@ -709,7 +721,31 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
   h, enc_c = _mlp_fwd(spec, params, bn_state, "enc", spec.enc_units, h0, training, noise,
                       STREAM_ENC_DROPOUT, spec.dropout_enc, new_bn)
   lat = h @ params["lat/W"] + params["lat/b"]
-  if spec.stochastic:
+  mixq = None
+  if spec.latent_mixture:
+    C_ = spec.n_components
+    a_q = lat[:, :C_]                                                            # plane 0, first C columns
+    mu_c = lat[:, D:(1 + C_) * D].reshape(B, C_, D)
+    sraw_c = lat[:, (1 + C_) * D:].reshape(B, C_, D)
+    sig_c = softplus1(sraw_c)
+    am = a_q.max(1, keepdims=True)
+    log_pi_q = a_q - (am + np.log(np.exp(a_q - am).sum(1, keepdims=True)))
+    pi_q = np.exp(log_pi_q)
+    u = noise.uniform(STREAM_MIX_PICK, 1)[:, 0]
+    pick = np.minimum((np.cumsum(pi_q.astype(np.float32), axis=1) < u[:, None].astype(np.float32)).sum(1), C_ - 1)   # (float32 running sums: the device's comparison)
+    eps = noise.normal(STREAM_EPS_Z, D)
+    idx = np.arange(B)
+    z = mu_c[idx, pick] + sig_c[idx, pick] * eps
+    dzm_q = (z[:, None, :] - mu_c) / sig_c                                       # [B, C, D]
+    comp_q = log_pi_q + (-0.5 * dzm_q ** 2 - np.log(sig_c) - 0.5 * np.log(2 * np.pi)).sum(2)
+    cmq = comp_q.max(1, keepdims=True)
+    log_q = (cmq + np.log(np.exp(comp_q - cmq).sum(1, keepdims=True)))[:, 0]
+    log_p0 = (-0.5 * z ** 2 - 0.5 * np.log(2 * np.pi)).sum(1)
+    kl = log_q - log_p0
+    mu = (pi_q[:, :, None] * mu_c).sum(1)                                         # what predict / encode report: the mixture's moments
+    sig = np.sqrt(np.maximum((pi_q[:, :, None] * (sig_c ** 2 + mu_c ** 2)).sum(1) - mu ** 2, 0.0))
+    mixq = dict(pi=pi_q, resp=np.exp(comp_q - log_q[:, None]), dzm=dzm_q, sig=sig_c, sraw=sraw_c, pick=pick, eps=eps)
+  elif spec.stochastic:
     mu, s_raw = lat[:, :D], lat[:, D:]
     sig = softplus1(s_raw)
     eps = noise.normal(STREAM_EPS_Z, D)
@@ -721,7 +757,7 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
     kl = np.zeros(B)
   out.update(z_mean=mu, z_scale=sig, z=z)
   scale_c = None
-  if spec.model == "scale":
+  if spec.model == "scale" and not spec.latent_mixture:
     # SCALE (sisua/models/scale.py:13-49: mixture latent, `analytic=False`): the KL term is a ONE-SAMPLE Monte-Carlo
     # estimate log q(z|x) - log p(z) at the z that is decoded, with p(z) = sum_c softmax(a)_c N(z; m_c, diag s_c^2),
     # s = softplus1(raw) -- the published model (Xiong et al. 2019); odin's mixture layer itself is not citable.
@@ -861,7 +897,21 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
     up = np.concatenate([(-0.5 / B) * expit(-dlog[:B])[:, None] * sm[:B], (0.5 / B) * expit(dlog[B:])[:, None] * sm[B:]], axis=0)
     _factor_backward(spec, params, fac, up + (spec.alpha / B) * dsup, grads)
 
-  if spec.model == "scale":
+  if mixq is not None:
+    # log q(z|x) depends on z and on every component's parameters; z on the picked component's (mu_k, sigma_k) only
+    r_, dzm, sg_c, pk = mixq["resp"], mixq["dzm"], mixq["sig"], mixq["pick"]
+    g = dz + c_kl * (z - (r_[:, :, None] * dzm / sg_c).sum(1))                    # d loss / d z: decoder + d KL / d z
+    d_a = c_kl * (r_ - mixq["pi"])
+    d_mu = c_kl * r_[:, :, None] * dzm / sg_c
+    d_sg = c_kl * r_[:, :, None] * (dzm ** 2 - 1.0) / sg_c
+    idx = np.arange(B)
+    d_mu[idx, pk] += g
+    d_sg[idx, pk] += g * mixq["eps"]
+    dlat = np.zeros_like(lat)
+    dlat[:, :spec.n_components] = d_a
+    dlat[:, D:(1 + spec.n_components) * D] = d_mu.reshape(B, -1)
+    dlat[:, (1 + spec.n_components) * D:] = (d_sg * expit(mixq["sraw"] + SOFTPLUS_INV_1)).reshape(B, -1)
+  elif spec.model == "scale":
     r_, dzm, s_c, tr = scale_c["resp"], scale_c["dzm"], scale_c["s"], scale_c["tril"]
     # d(-log p)/dz = sum_c resp_c (z - m_c) / s_c^2 (tril: sum_c resp_c w_c); log q depends on (sigma, eps) only: d log q / d sigma = -1 / sigma
     dz = dz + c_kl * ((r_[:, :, None] * tr["w"]).sum(1) if tr is not None else (r_[:, :, None] * dzm / s_c[None]).sum(1))

@@ -123,6 +123,9 @@ class ModelConfig:
   # scale.py:28,35 `covariance` of the mixture's components: 'none' / 'diag' (diagonal, prior/scale [C, D]) or 'tril' / 'full' (a
   # lower-triangular factor per component, prior/scale [C D, D]; diag = softplus(raw) + 1e-5; not with the tie_* options)
   covariance: str = "none"
+  # scale.py:26,38-47 read literally: q(z|x) itself a mixture of n_components diagonal Gaussians (a (1 + 2 C) D-wide latent head: logits in
+  # the first C columns of plane 0, C location planes, C raw-scale planes), standard-normal prior, Monte-Carlo KL; no prior/* tensors
+  latent_mixture: bool = False
   # model 'fvae' (sisua/models/fvae.py:9-18; odin factorVAE defaults): the total-correlation discriminator
   disc_units: int = 1000
   disc_layers: int = 5
@@ -142,6 +145,11 @@ class ModelConfig:
     if self.covariance not in ("none", "diag", "tril", "full"):
       raise ValueError(f"covariance must be 'none' / 'diag' or 'tril' / 'full', given: {self.covariance}")
     tril = self.model == "scale" and self.covariance in ("tril", "full")
+    if self.latent_mixture:
+      if self.model != "scale" or tril or self.tie_mixtures or self.tie_loc or self.tie_scale:
+        raise ValueError("the mixture-density posterior (latent_mixture) is built for model 'scale' with covariance='none' and no tied parameters")
+      if not 2 <= self.n_components <= min(self.latent_dim, 8):
+        raise ValueError("the mixture-density posterior takes 2 .. min(latent_dim, 8) components")
     if tril and (self.tie_mixtures or self.tie_loc or self.tie_scale):
       raise ValueError("tied mixture parameters are built for diagonal components only (covariance='none')")
     return tril
@@ -177,9 +185,10 @@ def manifest(cfg: ModelConfig) -> List[Tuple[str, Tuple[int, ...]]]:
 
   G, D = cfg.n_genes, cfg.latent_dim
   h = mlp("enc", G, cfg.enc_units)
-  nl = 2 * D if cfg.stochastic else D
+  _ = cfg.scale_tril   # (validates the SCALE options)
+  nl = (1 + 2 * cfg.n_components) * D if cfg.latent_mixture else (2 * D if cfg.stochastic else D)
   out += [("lat/W", (h, nl)), ("lat/b", (nl,))]
-  if cfg.model == "scale":
+  if cfg.model == "scale" and not cfg.latent_mixture:
     C = cfg.n_components
     out += [("prior/logits", (C,)), ("prior/loc", (C, D)), ("prior/scale", (C * D, D) if cfg.scale_tril else (C, D))]
   if cfg.model == "scvi":

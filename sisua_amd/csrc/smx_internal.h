@@ -149,6 +149,27 @@ struct LatentArgs {
   float* dlat = nullptr;      // [B][2*Dp] or [B][Dp]
 };
 
+// SCALE read literally (scale.py:26,38-47; SMX_MODEL_SCALE_POST): q(z|x) = sum_c pi_c N(mu_c, diag sigma_c^2) from a latent head of
+// 1 + 2 C planes of width Dp (logits in the first C columns of plane 0 | mu_1 .. mu_C | raw sigma_1 .. sigma_C), C <= 8, D <= 64.
+enum { ST_MIX_PICK = 67 };   // Philox stream of the uniform that picks a cell's component
+struct MixLatArgs {
+  const float* lat = nullptr; int ld = 0; int B = 0, D = 0, Dp = 0, C = 0;
+  NoiseKey nk{0, 0, 0, 0, nullptr}; NoiseKey nk_pick{0, 0, 0, 0, nullptr};
+  const int32_t* rows = nullptr; uint32_t cell_base = 0;
+  const float* inj_eps = nullptr; int inj_ld = 0;
+  float* z = nullptr; float* eps = nullptr;     // [B][Dp] the draw and its noise
+  float* zmean = nullptr; float* zstd = nullptr;   // [B][Dp] the mixture's mean / standard deviation (what predict and encode report)
+  float* kl = nullptr;        // [B] log q(z|x) - log N(z; 0, I)
+  float* resp = nullptr;      // [B][32] responsibilities of the components under q at z
+  int32_t* pick = nullptr;    // [B] the picked component
+  // backward
+  const float* dz = nullptr; int dz_slabs = 1; long dz_slab_stride = 0; int ldz = 0;
+  float kl_scale = 0.f;       // beta / B_global
+  float* dlat = nullptr;      // [B][ld]
+};
+int launch_mixlat_fwd(hipStream_t st, const MixLatArgs& a);
+int launch_mixlat_bwd(hipStream_t st, const MixLatArgs& a);
+
 struct BnFwdArgs {
   const float* pre = nullptr; int n_slabs = 1; long slab_stride = 0; int ld = 0;  // pre-activation slabs [S][B][ld]
   int B = 0, H = 0, Hp = 0;

@@ -993,6 +993,135 @@ int launch_latent_fwd(hipStream_t st, const LatentArgs& a) {
   return SMX_OK;
 }
 
+// ---- SCALE with a mixture-density POSTERIOR (MixLatArgs): one wave per cell, lane d = latent dimension d ----------------------
+__device__ inline void mixlat_softmax(const MixLatArgs& a, const float* lat, int lane, float& logpi, float& pi) {
+  const float lg = lane < a.C ? lat[lane] : -3.0e38f;
+  const float mx = wave_max(lg);
+  const float ex = lane < a.C ? fexp(lg - mx) : 0.f;
+  const float se = wave_sum(ex);
+  logpi = lg - mx - flog(se);
+  pi = ex * frcp(se);
+}
+__global__ __launch_bounds__(256) void mixlat_fwd_kernel(MixLatArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const float HALF_LOG_2PI = 0.9189385332046727f;
+  const float* lat = a.lat + (long)b * a.ld;
+  const uint32_t cell = a.cell_base + (uint32_t)(a.rows ? a.rows[b] : b);
+  float logpi, pi;
+  mixlat_softmax(a, lat, lane, logpi, pi);
+  // the component: the first c whose running sum of pi reaches the cell's uniform (sums in component order)
+  const float u = u24(philox_block(a.nk_pick, cell, 0u).x);
+  int k = 0;
+  float run = 0.f;
+  for (int c = 0; c < a.C; ++c) {
+    run += __shfl(pi, c, 64);
+    k += (run < u) ? 1 : 0;
+  }
+  k = min(k, a.C - 1);
+  const bool live = lane < a.D;
+  float eps = 0.f;
+  if (live) {
+    if (a.inj_eps) eps = a.inj_eps[(long)b * a.inj_ld + lane];
+    else {
+      const float4 n = normal4(philox_block(a.nk, cell, (uint32_t)(lane >> 2)));
+      eps = (lane & 3) == 0 ? n.x : (lane & 3) == 1 ? n.y : (lane & 3) == 2 ? n.z : n.w;
+    }
+  }
+  float mu[8], sg[8];
+  float z = 0.f, mean = 0.f, second = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    mu[c] = 0.f; sg[c] = 1.f;
+    if (c < a.C) {   // (uniform)
+      if (live) { mu[c] = lat[(1 + c) * a.Dp + lane]; sg[c] = softplusf(lat[(1 + a.C + c) * a.Dp + lane] + SMX_SOFTPLUS_INV_1); }
+      const float pc = __shfl(pi, c, 64);
+      mean += pc * mu[c];
+      second += pc * (sg[c] * sg[c] + mu[c] * mu[c]);
+      if (c == k) z = mu[c] + sg[c] * eps;
+    }
+  }
+  float comp_mine = -3.0e38f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c < a.C) {
+      const float dzm = (z - mu[c]) * frcp(sg[c]);
+      const float t = wave_sum(live ? -0.5f * dzm * dzm - flog(sg[c]) - HALF_LOG_2PI : 0.f) + __shfl(logpi, c, 64);
+      if (lane == c) comp_mine = t;
+    }
+  }
+  const float cmx = wave_max(comp_mine);
+  const float log_q = cmx + flog(wave_sum(lane < a.C ? fexp(comp_mine - cmx) : 0.f));
+  const float log_p = wave_sum(live ? -0.5f * z * z - HALF_LOG_2PI : 0.f);
+  if (lane < 32) a.resp[(long)b * 32 + lane] = lane < a.C ? fexp(comp_mine - log_q) : 0.f;
+  if (lane == 0) { a.kl[b] = log_q - log_p; a.pick[b] = k; }
+  for (int d = lane; d < a.Dp; d += 64) {   // (d == lane for d < D <= 64)
+    const long o = (long)b * a.Dp + d;
+    a.z[o] = d < a.D ? z : 0.f;
+    a.eps[o] = d < a.D ? eps : 0.f;
+    a.zmean[o] = d < a.D ? mean : 0.f;
+    a.zstd[o] = d < a.D ? fsqrt(fmaxf(second - mean * mean, 0.f)) : 1.f;
+  }
+}
+// d lat from d z: log q depends on z and on every component's parameters, z on the picked component's (mu_k, sigma_k) only
+__global__ __launch_bounds__(256) void mixlat_bwd_kernel(MixLatArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const float* lat = a.lat + (long)b * a.ld;
+  float* dl = a.dlat + (long)b * a.ld;
+  float logpi, pi;
+  mixlat_softmax(a, lat, lane, logpi, pi);
+  const float rme = lane < a.C ? a.resp[(long)b * 32 + lane] : 0.f;
+  const int k = a.pick[b];
+  const bool live = lane < a.D;
+  float dz = 0.f;
+  if (live) for (int s = 0; s < a.dz_slabs; ++s) dz += a.dz[(long)s * a.dz_slab_stride + (long)b * a.ldz + lane];
+  const float z = live ? a.z[(long)b * a.Dp + lane] : 0.f, eps = live ? a.eps[(long)b * a.Dp + lane] : 0.f;
+  float mu[8], sg[8], sraw[8];
+  float dqz = 0.f;   // d log q / d z_d = -sum_c r_c (z - mu_c) / sigma_c^2
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    mu[c] = 0.f; sg[c] = 1.f; sraw[c] = 0.f;
+    if (c < a.C) {
+      if (live) { mu[c] = lat[(1 + c) * a.Dp + lane]; sraw[c] = lat[(1 + a.C + c) * a.Dp + lane]; sg[c] = softplusf(sraw[c] + SMX_SOFTPLUS_INV_1); }
+      const float is = frcp(sg[c]);
+      dqz -= __shfl(rme, c, 64) * (z - mu[c]) * is * is;
+    }
+  }
+  const float g = dz + a.kl_scale * (z + dqz);
+  for (int d = lane; d < a.Dp; d += 64) dl[d] = d < a.C ? a.kl_scale * (rme - pi) : 0.f;   // plane 0: logits (d == lane)
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c < a.C) {
+      const float rc = __shfl(rme, c, 64), is = frcp(sg[c]);
+      const float dzm = (z - mu[c]) * is;
+      float dmu = a.kl_scale * rc * dzm * is, dsg = a.kl_scale * rc * (dzm * dzm - 1.f) * is;
+      if (c == k) { dmu += g; dsg += g * eps; }
+      for (int d = lane; d < a.Dp; d += 64) {
+        dl[(1 + c) * a.Dp + d] = d < a.D ? dmu : 0.f;
+        dl[(1 + a.C + c) * a.Dp + d] = d < a.D ? dsg * sigmoidf(sraw[c] + SMX_SOFTPLUS_INV_1) : 0.f;
+      }
+    }
+  }
+}
+static bool mixlat_ok(const MixLatArgs& a) {
+  return a.B > 0 && a.C >= 2 && a.C <= 8 && a.D >= a.C && a.D <= 64 && a.Dp <= 64 && a.ld == (1 + 2 * a.C) * a.Dp && a.lat && a.z && a.eps && a.resp && a.pick;
+}
+int launch_mixlat_fwd(hipStream_t st, const MixLatArgs& a) {
+  if (!mixlat_ok(a) || !a.kl || !a.zmean || !a.zstd) { set_error("mixlat_fwd: bad arguments (2..8 components <= latent_dim <= 64)"); return SMX_ERR_INVALID; }
+  hipLaunchKernelGGL(mixlat_fwd_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+int launch_mixlat_bwd(hipStream_t st, const MixLatArgs& a) {
+  if (!mixlat_ok(a) || !a.dz || !a.dlat || a.dz_slabs < 1) { set_error("mixlat_bwd: bad arguments"); return SMX_ERR_INVALID; }
+  hipLaunchKernelGGL(mixlat_bwd_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
 __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentArgs a) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= a.B * a.Dp) return;

@@ -177,6 +177,9 @@ struct smx_model {
   float* sq_slots = nullptr; std::vector<int> sq_first, sq_count; std::vector<char> sq_reduced; int sq_total_first = 0;
   int G = 0, Gp = 0, D = 0, Dp = 0, k = 0, Bmax = 0;
   bool stochastic = true, scvi = false, scale = false, fvae = false;
+  bool mixpost = false;      // SMX_MODEL_SCALE_POST: q(z|x) a mixture of cfg.n_components diagonal Gaussians (lat head: 1 + 2 C planes)
+  int lat_planes = 2;        // planes of width Dp of the latent head's output: 2 (mu, raw sigma), 1 (deterministic), 1 + 2 C (mixture posterior)
+  float* zmean = nullptr; int32_t* zpick = nullptr;   // mixture posterior: the mixture's mean [B][Dp] (what predict / encode report), the picked component [B]
   bool scale_tril = false;   // SCALE with full-covariance components (SMX_MODEL_SCALE_TRIL): prior/scale holds C lower-triangular D x D factors
   int n_heads = 0;                    // label heads on the decoder (0 for fvae: SemiFVAE's labels go to the discriminator)
   // fvae: discriminator on z (smx_factor.hip)

@@ -143,7 +143,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   SMX_REQUIRE(cfg->n_genes > 0 && cfg->latent_dim > 0 && cfg->max_batch > 0, "n_genes, latent_dim, max_batch must be > 0");
   SMX_REQUIRE(cfg->n_enc >= 1 && cfg->n_enc <= SMX_MAX_LAYERS && cfg->n_dec >= 1 && cfg->n_dec <= SMX_MAX_LAYERS,
               "encoder/decoder need 1..8 layers");
-  SMX_REQUIRE(cfg->model >= SMX_MODEL_VAE && cfg->model <= SMX_MODEL_SCALE_TRIL, "unknown model kind");
+  SMX_REQUIRE(cfg->model >= SMX_MODEL_VAE && cfg->model <= SMX_MODEL_SCALE_POST, "unknown model kind");
   if (cfg->model == SMX_MODEL_FVAE) {
     SMX_REQUIRE(cfg->disc_layers >= 1 && cfg->disc_layers <= SMX_MAX_LAYERS && cfg->disc_units >= 1, "fvae: discriminator needs 1..8 hidden layers");
     SMX_REQUIRE(cfg->disc_leak >= 0.f && cfg->disc_leak < 1.f, "fvae: leaky-ReLU slope in [0, 1)");
@@ -153,6 +153,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   }
   if (cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL) SMX_REQUIRE(cfg->n_components >= 2 && cfg->n_components <= 32, "scale: 2..32 mixture components");
   if (cfg->model == SMX_MODEL_SCALE_TRIL) SMX_REQUIRE(cfg->latent_dim <= 32, "scale with full-covariance components: at most 32 latent dimensions");
+  if (cfg->model == SMX_MODEL_SCALE_POST) SMX_REQUIRE(cfg->n_components >= 2 && cfg->n_components <= 8 && cfg->n_components <= cfg->latent_dim && cfg->latent_dim <= 64 && cfg->n_labels == 0, "scale with a mixture-density posterior: 2 .. min(latent_dim, 8) components, at most 64 latent dimensions, no label heads");
   SMX_REQUIRE(cfg->likelihood >= SMX_LLK_NB && cfg->likelihood <= SMX_LLK_MSE, "unknown likelihood");
   SMX_REQUIRE(cfg->n_labels >= 0 && cfg->n_labels <= SMX_MAX_LABELS, "too many label heads");
   // (SCALE with label heads = SCALAR, sisua/models/scale.py:52-59: the mixture prior of SCALE under SISUA's semi-supervised heads)
@@ -171,6 +172,8 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   m->G = cfg->n_genes; m->Gp = round_up(m->G, 32); m->D = cfg->latent_dim; m->Dp = round_up(m->D, 32);
   m->k = llk_planes(cfg->likelihood);
   m->stochastic = cfg->model != SMX_MODEL_DCA; m->scvi = cfg->model == SMX_MODEL_SCVI; m->scale = cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL; m->scale_tril = cfg->model == SMX_MODEL_SCALE_TRIL;
+  m->mixpost = cfg->model == SMX_MODEL_SCALE_POST;
+  m->lat_planes = m->mixpost ? 1 + 2 * cfg->n_components : (m->stochastic ? 2 : 1);
   m->fvae = cfg->model == SMX_MODEL_FVAE; m->n_heads = m->fvae ? 0 : cfg->n_labels;
   m->Bmax = cfg->max_batch;
   int rc = SMX_OK;
@@ -179,8 +182,8 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   // ---- manifest (same order as oracle/sisua_oracle.py:manifest) ----
   const bool bnorm = cfg->batchnorm != 0;
   int h = build_mlp(m, m->enc, "enc", m->G, cfg->n_enc, cfg->enc_units, ST_ENC_DROPOUT, cfg->dropout_enc, bnorm);
-  m->t_latW = add_tensor(m, "lat/W", h, (m->stochastic ? 2 : 1) * m->D, m->stochastic ? 2 : 1, false);
-  m->t_latb = add_tensor(m, "lat/b", 1, (m->stochastic ? 2 : 1) * m->D, m->stochastic ? 2 : 1, true);
+  m->t_latW = add_tensor(m, "lat/W", h, m->lat_planes * m->D, m->lat_planes, false);
+  m->t_latb = add_tensor(m, "lat/b", 1, m->lat_planes * m->D, m->lat_planes, true);
   if (m->scale) {   // trainable mixture prior: logits [C], means and raw scales [C][D]
     m->t_prLogits = add_tensor(m, "prior/logits", 1, cfg->n_components, 1, true);
     m->t_prLoc = add_tensor(m, "prior/loc", cfg->n_components, m->D, 1, false);
@@ -288,7 +291,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
       return fail(rc);
   }
   m->slab_cap = (size_t)(64 * 3 + SMX_MAX_LABELS + 1) * B * m->max_feat_p;
-  const size_t lat_ld = (m->stochastic ? 2 : 1) * (size_t)m->Dp;
+  const size_t lat_ld = (size_t)m->lat_planes * (size_t)m->Dp;
   const size_t ldp = (size_t)m->k * m->Gp;
   // wide panels: scratch for the per-slice slabs of the products that contract over the gene axis (smx_bigk.hip)
   if (m->Gp >= 4096) {
@@ -303,6 +306,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
       (rc = dmalloc(&m->hostX, B * m->Gp)) || (rc = dmalloc(&m->hostLib, B * 2)) || (rc = dmalloc(&m->hostLgx1, B)))
     return fail(rc);
   if (m->scale && ((rc = dmalloc(&m->resp, B * 32)) || (rc = dmalloc(&m->dklz, B * m->Dp)))) return fail(rc);
+  if (m->mixpost && ((rc = dmalloc(&m->resp, B * 32)) || (rc = dmalloc(&m->zmean, B * m->Dp)) || (rc = dmalloc(&m->zpick, B)))) return fail(rc);
   if (m->scvi) {
     if ((rc = dmalloc(&m->raw, B * ldp)) || (rc = dmalloc(&m->draw, B * ldp)) || (rc = dmalloc(&m->rho, B * m->Gp)) ||
         (rc = dmalloc(&m->latlbuf, B * 32)) || (rc = dmalloc(&m->dlatl, B * 32)) || (rc = dmalloc(&m->lsmp, B)) ||
@@ -382,7 +386,7 @@ int smx_model_destroy(smx_model* m) {
   fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1); fr(m->hostX); fr(m->hostLib); fr(m->hostLgx1);
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); fr(m->laby_raw[j]); fr(m->laby_draw[j]); }
   fr(m->rows2[0]); fr(m->rows2[1]); fr(m->order); fr(m->state3); fr(m->mhist);
-  fr(m->resp); fr(m->dklz);
+  fr(m->resp); fr(m->dklz); fr(m->zmean); fr(m->zpick);
   for (auto& L : m->disc) { fr(L.xhat); fr(L.out_buf); fr(L.dpre); }
   fr(m->zz); fr(m->u_d); fr(m->tc_cell); fr(m->dl_cell); fr(m->dz_tc); fr(m->disc_dpre); fr(m->disc_db);
   fr(m->noise_eps); fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);

@@ -30,7 +30,7 @@ static int fetch_forward(smx_model* m, int B, float* z_mean, float* z_scale, flo
                          float* l_sample, float* x_params, float* const* y_params, size_t y_draw) {
   SMX_HIP(hipStreamSynchronize(m->st));
   const int D = m->D, Dp = m->Dp;
-  const int lat_ld = m->stochastic ? 2 * Dp : Dp;
+  const int lat_ld = m->lat_planes * Dp;
   std::vector<float> tmp;
   auto fetch2d = [&](float* dst, const float* src, int ld, int w) -> int {
     if (!dst) return SMX_OK;
@@ -38,7 +38,7 @@ static int fetch_forward(smx_model* m, int B, float* z_mean, float* z_scale, flo
                         hipMemcpyDeviceToHost));
     return SMX_OK;
   };
-  SMX_CHECK(fetch2d(z_mean, m->latbuf, lat_ld, D));
+  SMX_CHECK(fetch2d(z_mean, m->mixpost ? m->zmean : m->latbuf, m->mixpost ? Dp : lat_ld, D));   // (mixture-density posterior: the mixture's mean)
   if (m->stochastic) SMX_CHECK(fetch2d(z_scale, m->sig, Dp, D));
   SMX_CHECK(fetch2d(z_sample, m->z, Dp, D));
   if (m->scvi) {
@@ -123,6 +123,7 @@ int stacked_decoder(smx_model* m, const float* z, long rows, float* const* hb, i
 // in the latent part of log w).
 bool stacked_scoring_ok(const smx_model* m) {
   if (!m->flags.stacked_scoring || !m->stochastic || m->use_injected || m->dec.empty()) return false;
+  if (m->mixpost) return false;   // (mixture-density posterior: every draw picks its component -- the draw-by-draw form)
   if (m->scale && (m->Dp > 64 || m->cfg.n_components > 32 || m->scale_tril)) return false;   // (full-covariance components: the draw-by-draw form, whose prior term is scale_prior_fwd's)
   if (m->scvi && !scvi_score_supported(m->Gp)) return false;
   if (!head_loss_supported(1, m->dec.back().out_p, m->Gp) || (m->dec.back().out_p % 4)) return false;
@@ -175,7 +176,7 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
   SMX_REQUIRE(m && host_x && n_cells > 0 && n_samples > 0, "bad arguments");
   SMX_REQUIRE(batch > 0 && batch <= m->Bmax, "batch must be in 1..max_batch");
   const size_t N = (size_t)n_cells, G = (size_t)m->G, D = (size_t)m->D, k = (size_t)m->k, S = (size_t)n_samples;
-  const int Dp = m->Dp, lat_ld = m->stochastic ? 2 * Dp : Dp;
+  const int Dp = m->Dp, lat_ld = m->lat_planes * Dp;
   if (!m->stochastic) z_scale = nullptr;
   if (!m->scvi) l_mean = l_scale = l_samples = nullptr;
   // ---- staging layout for a chunk of C cells (segments in floats; per-cell widths) ----
@@ -255,7 +256,7 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
             PackJob& q = J.j[J.n++];
             q.dst = dst; q.dpitch = (long)dpitch; q.src = src; q.spitch = (long)spitch; q.width = (int)width; q.height = B; q.n_rep = 1; q.dst_rep = 0; q.src_rep = 0;
           };
-          add1(s_zm ? s_zm + b0 * D : nullptr, D, m->latbuf, (size_t)lat_ld, D);
+          add1(s_zm ? s_zm + b0 * D : nullptr, D, m->mixpost ? m->zmean : m->latbuf, (size_t)(m->mixpost ? Dp : lat_ld), D);
           add1(s_zs ? s_zs + b0 * D : nullptr, D, m->sig, (size_t)Dp, D);
           if (J.n) { hipLaunchKernelGGL(pack_kernel, dim3(8, (unsigned)J.n, 1), dim3(256), 0, m->st, J); SMX_HIP(hipGetLastError()); }
         }
@@ -332,7 +333,7 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
           q.n_rep = 1; q.dst_rep = 0; q.src_rep = 0;
         };
         if (s == 0) {
-          add(s_zm ? s_zm + b0 * D : nullptr, D, m->latbuf, (size_t)lat_ld, D);
+          add(s_zm ? s_zm + b0 * D : nullptr, D, m->mixpost ? m->zmean : m->latbuf, (size_t)(m->mixpost ? Dp : lat_ld), D);
           add(s_zs ? s_zs + b0 * D : nullptr, D, m->sig, (size_t)Dp, D);
           add(s_lm ? s_lm + b0 : nullptr, 1, m->latlbuf, 32, 1);
           add(s_ls ? s_ls + b0 : nullptr, 1, m->lsig, 1, 1);

@@ -216,7 +216,7 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
     a.z = m->z; a.sig = m->sig; a.eps = m->eps; a.D = m->D; a.Dp = m->Dp; a.stochastic = m->stochastic;
     a.l = m->scvi ? m->lsmp : nullptr; a.lsig = m->lsig; a.leps = m->leps; a.library = ps.lib;
     a.run_max = run; a.run_sum = run + batch; a.llk_sum = run + 2 * batch; a.B = batch; a.first = (s == 0);
-    a.klmc = m->scale ? m->kl : nullptr;
+    a.klmc = (m->scale || m->mixpost) ? m->kl : nullptr;   // (Monte-Carlo KL models: log p(z) - log q(z|x) of the draw is minus that term)
     hipLaunchKernelGGL(iw_accum_kernel, dim3((batch + 3) / 4), dim3(256), 0, m->st, a);
   }
   if (rc == SMX_OK) {

@@ -17,8 +17,8 @@ BnSyncArgs sync_args(smx_model* m) { BnSyncArgs y; y.gather = m->sync_buf; y.ran
 // shapes / modes under which the decoder's first BatchNorm launch takes the latent sample and its product along
 // (forward_pass adds what depends on injected noise)
 static bool front_shapes_ok(smx_model* m, const Pass& ps) {
-  const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
-  return m->flags.front && !m->scale && !sync_bn_on(m, ps.training) && bn_front_supported(ps.B, m->Dp) &&
+  const int lat_ld = m->lat_planes * m->Dp;
+  return m->flags.front && !m->scale && !m->mixpost && !sync_bn_on(m, ps.training) && bn_front_supported(ps.B, m->Dp) &&
          (m->Dp == 32 || m->Dp == 64) && m->dec[0].in_p == m->Dp && m->dec[0].out_p % 8 == 0 && (lat_ld % 4) == 0;
 }
 
@@ -489,7 +489,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   if (!resample) SMX_CHECK(mlp_forward(m, m->enc, ps, ps.Xsrc, m->Gp, true, "gemm_enc_fwd", -1, nullptr, 0, m->scvi ? &m->encl : nullptr, &twin_done));
   m->encl_twinned = twin_done;
   const MlpLayer& eL = m->enc.back();
-  const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
+  const int lat_ld = m->lat_planes * m->Dp;
   if (!resample) {
     const TensorInfo& tw = m->tensors[m->t_latW];
     GemmArgs g;
@@ -497,6 +497,16 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     g.C = m->latbuf; g.ldc = lat_ld; g.M = ps.B; g.N = lat_ld; g.K = eL.out_p; g.bias = P_(m, m->t_latb);
     Timed t(m, "gemm_lat_fwd");
     SMX_CHECK(launch_gemm(m->st, g));
+  }
+  if (m->mixpost) {   // SCALE read literally: the draw from the mixture-density posterior and its Monte-Carlo KL (never the fused front)
+    MixLatArgs ma;
+    ma.lat = m->latbuf; ma.ld = lat_ld; ma.B = ps.B; ma.D = m->D; ma.Dp = m->Dp; ma.C = c.n_components;
+    ma.nk = make_key(m, ST_EPS_Z, ps.sample, ps.training != 0); ma.nk_pick = make_key(m, ST_MIX_PICK, ps.sample, ps.training != 0);
+    ma.rows = ps.rows; ma.cell_base = ps.cell_base;
+    if (const Injected* ij = inj(m, ST_EPS_Z)) { ma.inj_eps = ij->d; ma.inj_ld = ij->ld; }
+    ma.z = m->z; ma.eps = m->eps; ma.zmean = m->zmean; ma.zstd = m->sig; ma.kl = m->kl; ma.resp = m->resp; ma.pick = m->zpick;
+    Timed t(m, "latent_fwd");
+    SMX_CHECK(launch_mixlat_fwd(m->st, ma));
   }
   LatentArgs la;
   la.stochastic = m->stochastic; la.relu = (c.latent_activation == SMX_ACT_RELU); la.training = ps.training;
@@ -510,8 +520,8 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   // launches fewer) when the shapes allow; SMX_NO_FRONT=1 keeps the three-launch form.
   front_ok = !encode_only && front_shapes_ok(m, ps) && (!la.inj_eps || (la.inj_ld % 4) == 0);
   front_la = la;
-  if (front_ok) {
-    // (launched below with the decoder)
+  if (front_ok || m->mixpost) {
+    // (launched below with the decoder / drawn above)
   } else {
     Timed t(m, "latent_fwd");
     SMX_CHECK(launch_latent_fwd(m->st, la));
@@ -1069,7 +1079,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
     }
   }
   // ---- decoder MLP; the latent head's backward runs in the epilogue of the d z product ----
-  const int lat_ld = m->stochastic ? 2 * m->Dp : m->Dp;
+  const int lat_ld = m->lat_planes * m->Dp;
   EpiLatentBwd le;
   le.lat = m->latbuf; le.ld = lat_ld; le.sig = m->sig; le.eps = m->eps; le.kl_scale = c.beta * inv_gb;
   le.D = m->D; le.Dp = m->Dp; le.stochastic = m->stochastic; le.relu = (c.latent_activation == SMX_ACT_RELU);
@@ -1091,7 +1101,21 @@ int backward_pass(smx_model* m, const Pass& ps) {
   const MlpLayer& eL = m->enc.back();
   const bool bfront = m->flags.bwd_front && !sync_bn_on(m, ps.training) && bn_bwd_front_supported(ps.B, lat_ld) && eL.out_p % 8 == 0;
   std::vector<GemmArgs> tail;
-  SMX_CHECK(mlp_backward(m, m->dec, ps, m->z, m->Dp, false, n_slabs, false, nullptr, "", &le, nullptr, nullptr, bfront ? &tail : nullptr));
+  if (m->mixpost) {
+    // mixture-density posterior: d z leaves the decoder as slabs, a launch of its own turns it into d lat (every component's
+    // parameters through log q, the picked component's through z as well)
+    int dz_slabs = 1;
+    SMX_CHECK(mlp_backward(m, m->dec, ps, m->z, m->Dp, false, n_slabs, false, &dz_slabs, "", nullptr, nullptr, nullptr, bfront ? &tail : nullptr));
+    MixLatArgs ma;
+    ma.lat = m->latbuf; ma.ld = lat_ld; ma.B = ps.B; ma.D = m->D; ma.Dp = m->Dp; ma.C = c.n_components;
+    ma.z = m->z; ma.eps = m->eps; ma.resp = m->resp; ma.pick = m->zpick;
+    ma.dz = m->slab; ma.dz_slabs = dz_slabs; ma.dz_slab_stride = (long)ps.B * m->dec[0].in_p; ma.ldz = m->dec[0].in_p;
+    ma.kl_scale = c.beta * inv_gb; ma.dlat = m->dlat;
+    Timed t(m, "latent_bwd");
+    SMX_CHECK(launch_mixlat_bwd(m->st, ma));
+  } else {
+    SMX_CHECK(mlp_backward(m, m->dec, ps, m->z, m->Dp, false, n_slabs, false, nullptr, "", &le, nullptr, nullptr, bfront ? &tail : nullptr));
+  }
   for (const GemmArgs& g : lab_dw) tail.push_back(g);
   BnBwdArgs gf;
   {  // weight gradient of the latent head and d h = d lat * W_lat^T

@@ -37,7 +37,7 @@ def _f32(a, shape=None):
 def make_smx_config(cfg: ModelConfig, max_batch: int) -> smx_config:
   c = smx_config()
   c.abi_version = _hip.SMX_ABI_VERSION
-  c.model = _hip.MODEL_KINDS["scale_tril" if cfg.scale_tril else cfg.model]   # (SCALE's covariance='tril' changes a tensor's shape: a model kind of its own, no new field)
+  c.model = _hip.MODEL_KINDS["scale_post" if cfg.latent_mixture else "scale_tril" if cfg.scale_tril else cfg.model]   # (SCALE's covariance='tril' changes a tensor's shape: a model kind of its own, no new field)
   c.likelihood = _hip.LIKELIHOODS[cfg.likelihood]
   c.n_genes, c.latent_dim = int(cfg.n_genes), int(cfg.latent_dim)
   for name, units in (("enc", cfg.enc_units), ("dec", cfg.dec_units), ("encl", cfg.encl_units if cfg.model == "scvi" else ())):

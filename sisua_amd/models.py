@@ -162,7 +162,7 @@ class SingleCellModel:
                        input_dropout=float(enc.input_dropout), log_norm=self._log_norm, beta=self.beta, alpha=self.alpha,
                        latent_activation=self._latent_activation(), clip_library=self.clip_library,
                        lr=float(self._opt["lr"]), clipnorm=float(self._opt["clipnorm"]), seed=self.seed,
-                       n_components=int(getattr(self, "_n_components", 10)), covariance=str(getattr(self, "_covariance", "none")),
+                       n_components=int(getattr(self, "_n_components", 10)), covariance=str(getattr(self, "_covariance", "none")), latent_mixture=bool(getattr(self, "_latent_mixture", False)),
                        **getattr(self, "_ties", {}), **getattr(self, "_disc_cfg", {}))
 
   def _ensure_engine(self, max_batch: int) -> Engine:
@@ -802,12 +802,15 @@ class SCALE(SingleCellModel):
   2019, Nature Communications): a VAE whose prior over z is a TRAINABLE mixture of `n_components` diagonal Gaussians; the
   KL term is the one-sample Monte-Carlo estimate log q(z|x) - log p(z) (`analytic=False`, scale.py:49).  Built:
   covariance='none' / 'diag' (diagonal components) with or without tied mixture weights / locations / scales (scale.py:29-33), and
-  covariance='tril' / 'full' (a lower-triangular scale factor per component, at most 32 latent dimensions, untied).  [3P-recall: the
+  covariance='tril' / 'full' (a lower-triangular scale factor per component, at most 32 latent dimensions, untied).
+  `mixture='posterior'` selects the LITERAL reading of scale.py:26,38-47 instead: q(z|x) a mixture-density layer of `n_components`
+  (2 .. min(latent_dim, 8)) diagonal Gaussians, standard-normal prior, the same Monte-Carlo KL; `predict` / `encode` then report the
+  mixture's mean and standard deviation per latent dimension.  [3P-recall: the
   published model; odin's mixture latent layer behind the reference's class is not citable.]"""
   _kind = "scale"
 
   def __init__(self, outputs, latents=RVmeta(10, "mixgaus", True, name="Latents"), n_components=10, covariance="none",
-               tie_mixtures=False, tie_loc=False, tie_scale=False, **kwargs):
+               tie_mixtures=False, tie_loc=False, tie_scale=False, mixture="prior", **kwargs):
     lat = [z.copy() for z in _flatten(latents)]
     for z in lat:
       if z.posterior[:3] != "mix":
@@ -823,6 +826,17 @@ class SCALE(SingleCellModel):
     self._n_components = int(kw0.get("n_components", n_components))
     if not 2 <= self._n_components <= 32:
       raise ValueError(f"SCALE is built for 2..32 mixture components, given: {self._n_components}")
+    # mixture='prior' (default): the published model's trainable mixture prior; 'posterior': scale.py:26,38-47 read literally -- q(z|x)
+    # itself a mixture-density layer against a standard-normal prior
+    mixture = str(kw0.get("mixture", mixture))
+    if mixture not in ("prior", "posterior"):
+      raise ValueError("mixture must be 'prior' (the published model) or 'posterior' (the literal reading of scale.py)")
+    self._latent_mixture = mixture == "posterior"
+    if self._latent_mixture:
+      if covariance not in ("none", "diag") or any(self._ties.values()):
+        raise ValueError("the mixture-density posterior is built with covariance='none' and no tied parameters")
+      if not 2 <= self._n_components <= min(lat[0].event_shape, 8):
+        raise ValueError("the mixture-density posterior takes 2 .. min(latent_dim, 8) components")
     if covariance in ("tril", "full"):
       if any(self._ties.values()):
         raise ValueError("tied mixture parameters are built for diagonal components only (covariance='none')")
@@ -830,7 +844,7 @@ class SCALE(SingleCellModel):
         raise ValueError("full-covariance mixture components are built for at most 32 latent dimensions")
     super().__init__(outputs=outputs, latents=lat, **kwargs)
     self.init_args = dict(outputs=outputs, latents=latents, n_components=n_components, covariance=covariance,
-                          tie_mixtures=tie_mixtures, tie_loc=tie_loc, tie_scale=tie_scale, **kwargs)
+                          tie_mixtures=tie_mixtures, tie_loc=tie_loc, tie_scale=tie_scale, mixture=mixture, **kwargs)
 
 
 class SCALAR(SCALE):

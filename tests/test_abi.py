@@ -120,6 +120,7 @@ def test_manifest_and_init_match_oracle():
              dict(model="scale", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, n_components=5),
              dict(model="scale", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, n_components=4, tie_loc=True, tie_mixtures=True),
              dict(model="scale", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, n_components=4, covariance="tril"),
+             dict(model="scale", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=4, n_components=3, latent_mixture=True),
              dict(model="sisua", n_genes=20, likelihood="zinb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((5, "mixnb3"),)),
              dict(model="sisua", n_genes=20, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((4, "mixgauss2"), (3, "nb"))),
              dict(model="sisua", n_genes=20, likelihood="nb", enc_units=(8,), dec_units=(8,), latent_dim=3, labels=((4, "mixtril2"), (3, "nb"))),

@@ -66,6 +66,7 @@ CASES = {
                      labels=((7, "mixtril2"), (5, "mixzinb3")), alpha=10.0),
     "scale": dict(model="scale", n_genes=100, likelihood="zinb", enc_units=(32,), dec_units=(32,), latent_dim=7, n_components=4),
     "scale_tril": dict(model="scale", n_genes=100, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=6, n_components=3, covariance="tril"),
+    "scale_post": dict(model="scale", n_genes=100, likelihood="zinb", enc_units=(32,), dec_units=(32,), latent_dim=6, n_components=3, latent_mixture=True),
 }
 
 
@@ -82,7 +83,7 @@ def _problem(kw, n=400):
 @pytest.mark.parametrize("name,world,sync_bn", [("vae_zinb", 2, False), ("vae_zinb", 2, True), ("vae_clip", 2, False),
                                                 ("vae_clip", 3, True), ("sisua", 2, False), ("sisua", 2, True),
                                                 ("scvi_zinbd", 2, False), ("scvi_zinbd", 2, True), ("vae_nobn", 4, False), ("fvae", 2, False),
-                                                ("misa_mix", 2, False), ("scale", 2, True), ("scale_tril", 3, False)])
+                                                ("misa_mix", 2, False), ("scale", 2, True), ("scale_tril", 3, False), ("scale_post", 2, True)])
 def test_world_n_steps_match_oracle(Engine, name, world, sync_bn):
   """3 optimiser steps of `world` replicas, every rank holding the WHOLE matrix but drawing its own rows: loss /
   metrics / reduced gradients / gradient norms / parameters / moving statistics of EVERY rank equal the oracle's

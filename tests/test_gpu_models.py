@@ -458,6 +458,35 @@ def test_scale_fit_predict(api, tmp_path):
     api.SCALE(outputs=sco.get_rv("transcriptomic"), covariance="tril", tie_loc=True)
 
 
+def test_scale_mixture_posterior_fit_predict(api, tmp_path):
+  """SCALE(mixture='posterior'): sisua/models/scale.py:26,38-47 read literally -- the latent POSTERIOR is the mixture-density layer
+  ((1 + 2 C) D-wide latent head, no prior tensors), standard-normal prior, Monte-Carlo KL.  Trains; predict / encode report the
+  mixture's moments; scoring and a checkpoint round trip work."""
+  sco = _sco(with_labels=False)
+  train, test = sco.split(0.8)
+  m = api.SCALE(outputs=sco.get_rv("transcriptomic"), latents=api.RVmeta(6, "mixgaus", True, "Latents"), n_components=3, mixture="posterior",
+                encoder=api.NetConf([32], batchnorm=True, dropout=0.1), decoder=api.NetConf([32], batchnorm=True, dropout=0.1))
+  cfg = m._make_config()
+  assert cfg.latent_mixture and not cfg.scale_tril
+  m.fit(train, epochs=12, batch_size=64, learning_rate=2e-3)
+  h = np.asarray(m.train_history["loss"])
+  assert _decreases(h[:7]) and h[-3:].mean() < h[3:6].mean() and np.isfinite(m.train_history["kl"]).all(), h
+  p = m._engine.get_params()
+  assert p["lat/W"].shape == (32, (1 + 2 * 3) * 6) and not any(k.startswith("prior/") for k in p)
+  X, Z = m.predict(test.numpy(), batch_size=64, verbose=False)
+  assert Z.mean().shape == (test.n_obs, 6) and np.isfinite(Z.mean()).all() and (Z.stddev() > 0).all() and np.isfinite(X.mean()).all()
+  mllk, _ = m.marginal_log_prob(inputs=test.numpy()[:16], sample_shape=8)
+  assert np.isfinite(mllk).all()
+  path = os.path.join(tmp_path, "scale_post")
+  m.save_weights(path)
+  m2 = api.load_model(path)
+  assert type(m2) is api.SCALE and m2._make_config().latent_mixture
+  assert np.array_equal(m2._engine.get_params()["lat/W"], p["lat/W"])
+  for bad in (dict(n_components=9), dict(covariance="tril"), dict(tie_loc=True), dict(mixture="both")):
+    with pytest.raises(ValueError):
+      api.SCALE(outputs=sco.get_rv("transcriptomic"), latents=api.RVmeta(6, "mixgaus", True, "Latents"), **dict(dict(n_components=3, mixture="posterior"), **bad))
+
+
 def test_scale_full_covariance_fit_predict(api, tmp_path):
   """SCALE(covariance='tril') (sisua/models/scale.py:28,35): every mixture component carries a lower-triangular scale factor; trains,
   the factors leave the identity (below the diagonal too, never above it), scoring and a checkpoint round trip work."""

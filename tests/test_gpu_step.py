@@ -50,6 +50,10 @@ CASES = {
     "scale": dict(model="scale", n_genes=150, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=10, n_components=7),
     # SCALE with full-covariance components (scale.py:28,35 covariance='tril'): a lower-triangular factor per component
     "scale_tril": dict(model="scale", n_genes=130, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=9, n_components=5, covariance="tril"),
+    # SCALE read literally (scale.py:26,38-47): the latent POSTERIOR is the mixture-density layer, standard-normal prior, Monte-Carlo KL
+    "scale_post": dict(model="scale", n_genes=120, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=8, n_components=4, latent_mixture=True),
+    "scale_post_nobn": dict(model="scale", n_genes=90, likelihood="nb", enc_units=(32, 24), dec_units=(24,), latent_dim=5, n_components=3, latent_mixture=True,
+                            batchnorm=False),
     # the deterministic 'mse' output (RVmeta(dim, 'mse'), tests/test_singlecell_models.py:82-100 of the reference): one plane
     "dca_mse": dict(model="dca", n_genes=110, likelihood="mse", enc_units=(32,), dec_units=(32,), latent_dim=8),
     "vae_mse": dict(model="vae", n_genes=203, likelihood="mse", enc_units=(48,), dec_units=(40,), latent_dim=6),
@@ -335,7 +339,7 @@ def test_injected_noise_matches_oracle(Engine, name):
 
 
 @pytest.mark.parametrize("name,graph", [("vae_zinb", False), ("vae_zinb", True), ("sisua", True), ("scvi_zinbd", False), ("scvi_nbd", True), ("misa", False), ("scale", True),
-                                        ("scale_tril", False), ("fvae", True), ("semifvae", False)])
+                                        ("scale_tril", False), ("scale_post", True), ("fvae", True), ("semifvae", False)])
 def test_trajectory_matches_oracle(Engine, name, graph):
   """50-step seeded trajectory: ELBO per step within 1e-4 relative."""
   kw = CASES[name]
@@ -406,8 +410,9 @@ def test_staged_row_ids_equal_passed_row_ids(Engine):
     assert np.array_equal(got[0][1][k], got[1][1][k]), k
 
 
-def test_eval_and_forward_match_oracle(Engine):
-  kw = CASES["sisua"]
+@pytest.mark.parametrize("case", ["sisua", "scale_post"])
+def test_eval_and_forward_match_oracle(Engine, case):
+  kw = CASES[case]   # ('scale_post': z_mean / z_scale are the mixture posterior's moments; a different draw may pick another component)
   spec, cfg, x, ys, lib, mask = _problem(kw)
   params = perturbed_params(spec)
   bn = so.init_bn_state(spec)
@@ -544,7 +549,7 @@ def test_hip_matches_committed_trajectory_fixture(Engine):
   e.close()
 
 
-@pytest.mark.parametrize("name", ["vae_zinb", "scvi_zinbd", "dca_zinb", "scale", "scale_tril"])
+@pytest.mark.parametrize("name", ["vae_zinb", "scvi_zinbd", "dca_zinb", "scale", "scale_tril", "scale_post"])
 def test_marginal_llk_matches_oracle(Engine, name):
   """importance-weighted log p(x) (posterior.py:941-976) on the GPU vs the oracle."""
   spec, cfg, x, ys, lib, mask = _problem(dict(CASES[name], labels=()) if name != "sisua" else CASES[name])
@@ -734,7 +739,7 @@ def test_one_step_large_batches(Engine, batch):
   e.close()
 
 
-@pytest.mark.parametrize("name", ["vae_zinb", "scvi_zinbd", "sisua"])
+@pytest.mark.parametrize("name", ["vae_zinb", "scvi_zinbd", "sisua", "scale_post"])
 def test_forward_samples_equals_repeated_forward(Engine, name):
   """smx_forward_samples (predict(sample_shape=n): encoders once, n re-sampled decodes) must return exactly what n
   calls of smx_forward(sample_index=s) return, for resident rows and for a host batch."""

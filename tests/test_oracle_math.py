@@ -210,9 +210,12 @@ def test_label_llk_mixture_tril_matches_torch_mixture_same_family():
 # ---------------------------------------------------------------------------
 def _toy(model, lk, labels=(), bn=True, **kw):
   G = 13
+  if model == "scale_post":
+    model, kw = "scale", dict(kw, latent_mixture=True, n_components=3)
+  kw.setdefault("n_components", 4)
   spec = so.Spec(model=model, n_genes=G, likelihood=lk, enc_units=(6, 5), dec_units=(7,), latent_dim=3,
                  encl_units=(4,), labels=labels, batchnorm=bn, dropout_enc=0.25, dropout_dec=0.25,
-                 input_dropout=0.2, seed=3, n_components=4, disc_units=5, disc_layers=2, **kw)
+                 input_dropout=0.2, seed=3, disc_units=5, disc_layers=2, **kw)
   rng = np.random.default_rng(5)
   B = 6
   x = rng.poisson(1.5, size=(B, G)).astype(np.float64) * (rng.uniform(size=(B, G)) < 0.6)
@@ -263,6 +266,7 @@ CASES = [("vae", "zinb", (), True), ("vae", "nb", (), False), ("vae", "zinbd", (
          ("sisua", "zinb", ((4, "mixtril2"),), True),               # MISA, full-covariance mixture over the label vector (vae.py:58)
          ("sisua", "nb", ((4, "mixzinb2"),), True),                 # MISA(zero_inflated=True)
          ("scale", "zinb", (), True), ("scale", "nb", (), False),    # SCALE: mixture prior, Monte-Carlo KL
+         ("scale_post", "zinb", (), True), ("scale_post", "nb", (), False),   # SCALE read literally: mixture-density posterior
          ("fvae", "zinb", (), True), ("fvae", "nb", ((3, "onehot"),), False)]   # FVAE / SemiFVAE: two objectives
 
 

@@ -68,7 +68,17 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
   h0 = h0 * torch.as_tensor(noise.dropout(so.STREAM_INPUT_DROPOUT, G, spec.input_dropout))
   h = mlp(spec, P, bn, "enc", spec.enc_units, h0, noise, so.STREAM_ENC_DROPOUT, spec.dropout_enc, new_bn)
   lat = h @ P["lat/W"] + P["lat/b"]
-  if spec.stochastic:
+  if spec.latent_mixture:   # SCALE read literally (scale.py:26,38-47): a mixture-density POSTERIOR, standard-normal prior, Monte-Carlo KL
+    C = spec.n_components
+    mu_c, sig_c = lat[:, D:(1 + C) * D].reshape(B, C, D), softplus1(lat[:, (1 + C) * D:].reshape(B, C, D))
+    qm = td.MixtureSameFamily(td.Categorical(logits=lat[:, :C]), td.Independent(td.Normal(mu_c, sig_c), 1))
+    pi32 = torch.softmax(lat[:, :C], 1).detach().numpy().astype(np.float32)
+    u = noise.uniform(so.STREAM_MIX_PICK, 1)[:, 0].astype(np.float32)
+    pick = torch.as_tensor(np.minimum((np.cumsum(pi32, axis=1) < u[:, None]).sum(1), C - 1))
+    rows = torch.arange(B)
+    z = mu_c[rows, pick] + sig_c[rows, pick] * torch.as_tensor(noise.normal(so.STREAM_EPS_Z, D))   # reparameterised through the picked component only
+    kl = qm.log_prob(z) - td.Independent(td.Normal(torch.zeros_like(z), torch.ones_like(z)), 1).log_prob(z)
+  elif spec.stochastic:
     q = td.Normal(lat[:, :D], softplus1(lat[:, D:]))
     z = q.loc + q.scale * torch.as_tensor(noise.normal(so.STREAM_EPS_Z, D))
     if spec.model == "scale":   # Monte-Carlo KL against the trainable mixture prior: log q(z|x) - log p(z)
@@ -197,6 +207,7 @@ CASES = {
                       labels=((5, "mixtril3"), (3, "onehot")), alpha=10.0),
     "scale": dict(model="scale", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=6),
     "scale_tril": dict(model="scale", n_genes=40, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=4, covariance="tril"),
+    "scale_post": dict(model="scale", n_genes=40, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=3, latent_mixture=True),
     "scalar": dict(model="scale", n_genes=42, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=4,
                    labels=((6, "nb"), (3, "onehot")), alpha=10.0),   # SCALE + label heads (scale.py:52-59)
     "fvae": dict(model="fvae", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, disc_units=24, disc_layers=3),
