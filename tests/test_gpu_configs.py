@@ -206,3 +206,33 @@ def test_latent_means_after_training_match_oracle(Engine):
         assert rel_l2(out[key], fx[f"{key}_{s + 1}"]) < tol, (s + 1, key, rel_l2(out[key], fx[f"{key}_{s + 1}"]))
   assert worst_loss < RTOL, worst_loss
   e.close()
+
+
+@pytest.mark.parametrize("kind", ["mixnb2", "mixzinb2", "mixtril2"])
+def test_misa_heads_at_the_c4_shape(Engine, kind):
+  """BASELINE configs[3]'s shape (eccly: 2116 x 2000 training cells, 38 ADT label dimensions at 10 %, alpha = 10, batch 256) with MISA's
+  label heads in place of SISUA's NB one: mixtures of (zero-inflated) negative binomials on the counts, and the reference's docstring
+  example 'mixtril' -- ONE full-covariance Gaussian mixture over all 38 dimensions (two padded plane widths, 80 head planes) -- on their
+  log1p: one optimiser step, every ELBO scalar and every gradient against the oracle."""
+  import dataclasses
+  spec0, cfg0, xt, B, extra = _workload("eccly-sisua")
+  P = cfg0.labels[0][0]
+  assert P == 38 and B == 256
+  cfg = dataclasses.replace(cfg0, labels=((P, kind),))
+  spec = so.Spec(**cfg.to_dict())
+  labels = [np.log1p(extra["labels"][0]).astype(np.float32)] if kind.startswith("mixtril") else extra["labels"]
+  ex = dict(extra, labels=labels)
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = Engine(cfg, max_batch=B, init=False)
+  e.set_params(params)
+  _upload(e, xt, ex, cell_id_base=5)
+  rows = np.random.default_rng(4).permutation(xt.shape[0])[:B].astype(np.int32)
+  res = so.train_step(spec, params, bn, opt, xt[rows], so.PhiloxNoise(spec.seed, 0, rows + 5), **_oracle_kwargs(ex, rows))
+  m = e.train_step(rows)
+  assert m["nan_flag"] == 0 and 0 < ex["label_mask"][rows].sum() < B
+  for key in _metric_keys(spec):
+    assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
+  worst = grad_errors(e.get_params(which=1), res["grads"])
+  assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  e.close()
