@@ -305,6 +305,7 @@ struct ScalePriorArgs {
   float kl_scale = 0.f;       // beta / B_global
   float* g_logits = nullptr; float* g_loc = nullptr; float* g_scale = nullptr;   // gradients (backward)
   int tie_mixtures = 0, tie_loc = 0, tie_scale = 0;   // scale.py:29-33: a tied tensor's rows all receive the sum of the rows' gradients (logits: none)
+  float* tril_part = nullptr; size_t tril_part_floats = 0;   // covariance = 'tril', backward: partial sums [C][ceil(B / 16)][D][D + 2]
   int tril = 0;   // covariance = 'tril': scale_raw / g_scale are [C D][Dp], row c D + p = row p of component c's lower-triangular factor (D <= 32)
 };
 int launch_scale_prior_fwd(hipStream_t st, const ScalePriorArgs& a);

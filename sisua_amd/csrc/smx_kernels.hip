@@ -1201,78 +1201,122 @@ __global__ __launch_bounds__(256) void scale_prior_fwd_kernel(ScalePriorArgs a) 
 // One wave per cell, lane p = latent dimension p (D <= 32); the component's factor sits in the wave's LDS tile [D][D + 1].
 //   u = L^-1 (z - m) forward substitution, w = L^-T u back substitution;  log N = -1/2 |u|^2 - sum log L_pp - D/2 log 2 pi
 //   d(-log p)/dz = sum_c resp_c w_c.  Two sweeps over the components (densities -> responsibilities, then the gradient): C D^2 is small.
-__device__ inline void tril_load(const ScalePriorArgs& a, int c, int lane, float* L, float& lpp, float& sg) {
+// lane p fetches row p of L_c: eight 16-byte loads, all in flight at once (a load per entry, each followed by its LDS store, was a
+// chain of D dependent memory round trips per component: 566 us per step at D = 32, C = 10)
+struct TrilRow { float4 q[8]; };
+__device__ inline TrilRow tril_fetch(const ScalePriorArgs& a, int c, int lane) {
+  TrilRow r;
+  const float4* row = reinterpret_cast<const float4*>(a.scale_raw + ((long)c * a.D + (lane < a.D ? lane : 0)) * a.Dp);   // (Dp = 32)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.q[k] = row[k];
+  return r;
+}
+__device__ inline void tril_store(const ScalePriorArgs& a, const TrilRow& r, int lane, float* L, float& lpp, float& sg) {
   const int D = a.D, ldl = D + 1;
   lpp = 1.f; sg = 0.f;
-  for (int j = 0; j < D; ++j) {   // lane p reads row p of L_c
-    float v = lane < D ? a.scale_raw[((long)c * D + lane) * a.Dp + j] : 0.f;
-    if (j == lane) { const SpSg t = softplus_sigmoid(v); v = t.sp + 1e-5f; lpp = v; sg = t.sg; }
-    if (lane < D) L[lane * ldl + j] = j <= lane ? v : 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float e[4] = {r.q[k].x, r.q[k].y, r.q[k].z, r.q[k].w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = 4 * k + t;
+      float v = e[t];
+      if (j == lane) { const SpSg s = softplus_sigmoid(v); v = s.sp + 1e-5f; lpp = v; sg = s.sg; }
+      if (lane < D && j < D) L[lane * ldl + j] = j <= lane ? v : 0.f;
+    }
   }
 }
-__device__ inline void tril_solve(int D, int lane, const float* L, float lpp, float r, float& u, float& w) {
+__device__ inline void tril_load(const ScalePriorArgs& a, int c, int lane, float* L, float& lpp, float& sg) {
+  const TrilRow r = tril_fetch(a, c, lane);
+  tril_store(a, r, lane, L, lpp, sg);
+}
+// The two substitutions with the factor in REGISTERS (lane p: row p and column p, read once from the LDS tile) and the pivot
+// broadcast by v_readlane: a step is multiply -> readlane -> fused multiply-add.  (Its first form read L from LDS inside the loop and
+// broadcast with __shfl = ds_bpermute, two LDS round trips per step: ~330 cycles per step, 9 us per 32-dimensional solve.)
+struct TrilRegs { float row[32]; float col[32]; };
+__device__ inline float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ inline void tril_regs(int D, int lane, const float* L, TrilRegs& t) {
   const int ldl = D + 1;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    t.row[j] = (lane < D && j < D) ? L[lane * ldl + j] : 0.f;    // (zero above the diagonal)
+    t.col[j] = (lane < D && j < D) ? L[j * ldl + lane] : 0.f;    // L[j][lane]: zero for j < lane
+  }
+}
+__device__ inline void tril_solve(int D, int lane, const TrilRegs& t, float lpp, float r, float& u, float& w) {
   const float inv = frcp(lpp);
   u = 0.f; w = 0.f;
-  for (int j = 0; j < D; ++j) {
-    const float uj = __shfl(r * inv, j, 64);
-    if (lane == j) u = uj;
-    else if (lane > j && lane < D) r -= L[lane * ldl + j] * uj;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    if (j < D) {   // (uniform)
+      const float uj = lane_bcast(r * inv, j);
+      if (lane == j) u = uj;
+      else if (lane > j) r -= t.row[j] * uj;
+    }
   }
   float s = u;
-  for (int i = D - 1; i >= 0; --i) {
-    const float wi = __shfl(s * inv, i, 64);
-    if (lane == i) w = wi;
-    else if (lane < i) s -= L[i * ldl + lane] * wi;
+#pragma unroll
+  for (int i = 31; i >= 0; --i) {
+    if (i < D) {
+      const float wi = lane_bcast(s * inv, i);
+      if (lane == i) w = wi;
+      else if (lane < i) s -= t.col[i] * wi;
+    }
   }
 }
-__global__ __launch_bounds__(256) void scale_prior_tril_fwd_kernel(ScalePriorArgs a) {
-  extern __shared__ float Lall[];   // 4 waves x [D][D + 1]
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int b = blockIdx.x * 4 + wv;
-  if (b >= a.B) return;   // (a wave-uniform exit; no workgroup barrier below)
-  float* L = Lall + wv * a.D * (a.D + 1);
+// forward: one WORKGROUP per cell, one wave per component (SMX_TRILF_WAVES at a time): a component's substitutions are ~4 000
+// dependent instructions of one wave -- ten of them in a row per cell took 97 us, side by side they take one's time
+#define SMX_TRILF_WAVES 12
+__global__ __launch_bounds__(64 * SMX_TRILF_WAVES) void scale_prior_tril_fwd_kernel(ScalePriorArgs a) {
+  extern __shared__ float sm[];   // waves x [D][D + 1] | w of every component [C][D] | joint log density of every component [32]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.x;
+  const int D = a.D;
+  float* L = sm + wv * D * (D + 1);
+  float* Wc = sm + SMX_TRILF_WAVES * D * (D + 1);
+  float* comp = Wc + a.C * D;
   const float HALF_LOG_2PI = 0.9189385332046727f;
   const float lg = lane < a.C ? a.logits[lane] : -3.0e38f;
   const float lmx = wave_max(lg);
   const float lse = lmx + flog(wave_sum(lane < a.C ? fexp(lg - lmx) : 0.f));
-  const float zd = lane < a.D ? a.z[(long)b * a.Dp + lane] : 0.f;
-  float comp_mine = -3.0e38f;
-  for (int c = 0; c < a.C; ++c) {
+  const float zd = lane < D ? a.z[(long)b * a.Dp + lane] : 0.f;
+  for (int c = wv; c < a.C; c += SMX_TRILF_WAVES) {
     float lpp, sg, u, w;
     tril_load(a, c, lane, L, lpp, sg);
     __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
-    tril_solve(a.D, lane, L, lpp, zd - (lane < a.D ? a.loc[(long)c * a.Dp + lane] : 0.f), u, w);
-    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
-    const float t = wave_sum(lane < a.D ? -0.5f * u * u - flog(lpp) - HALF_LOG_2PI : 0.f) + (a.logits[c] - lse);
-    if (lane == c) comp_mine = t;
+    TrilRegs tr;
+    tril_regs(D, lane, L, tr);
+    tril_solve(D, lane, tr, lpp, zd - (lane < D ? a.loc[(long)c * a.Dp + lane] : 0.f), u, w);
+    if (lane < D) Wc[c * D + lane] = w;
+    const float t = wave_sum(lane < D ? -0.5f * u * u - flog(lpp) - HALF_LOG_2PI : 0.f) + (a.logits[c] - lse);
+    if (lane == 0) comp[c] = t;
+    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();   // (the tile is rewritten by this wave's next component)
   }
+  __syncthreads();
+  if (wv != 0) return;
+  const float comp_mine = lane < a.C ? comp[lane] : -3.0e38f;
   const float cmx = wave_max(comp_mine);
   const float log_p = cmx + flog(wave_sum(lane < a.C ? fexp(comp_mine - cmx) : 0.f));
   const float resp = lane < a.C ? fexp(comp_mine - log_p) : 0.f;
   if (lane < 32) a.resp[(long)b * 32 + lane] = resp;
   float lq = 0.f;
-  if (lane < a.D) {
+  if (lane < D) {
     const float e = a.eps[(long)b * a.Dp + lane];
     lq = -0.5f * e * e - flog(a.sig[(long)b * a.Dp + lane]) - HALF_LOG_2PI;
   }
   lq = wave_sum(lq);
   if (lane == 0) a.kl[b] = lq - log_p;
-  float g = 0.f;
-  for (int c = 0; c < a.C; ++c) {
-    float lpp, sg, u, w;
-    tril_load(a, c, lane, L, lpp, sg);
-    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
-    tril_solve(a.D, lane, L, lpp, zd - (lane < a.D ? a.loc[(long)c * a.Dp + lane] : 0.f), u, w);
-    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
-    g += __shfl(resp, c, 64) * w;
-  }
-  for (int d = lane; d < a.Dp; d += 64) a.dklz[(long)b * a.Dp + d] = d < a.D ? g : 0.f;   // (d == lane for d < D <= 32)
+  float g = 0.f;   // d(-log p)/dz = sum_c resp_c w_c
+  for (int c = 0; c < a.C; ++c) g += lane_bcast(resp, c) * (lane < D ? Wc[c * D + lane] : 0.f);
+  for (int d = lane; d < a.Dp; d += 64) a.dklz[(long)b * a.Dp + d] = d < D ? g : 0.f;   // (d == lane for d < D <= 32)
 }
-// gradients of the prior's parameters: one workgroup per component, the factor once in LDS, waves over the cells, lane p = row p
-__global__ __launch_bounds__(256) void scale_prior_tril_bwd_kernel(ScalePriorArgs a) {
-  extern __shared__ float sm[];   // L [D][D + 1] | partial sums [4][D][D + 2]
-  const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// gradients of the prior's parameters: a workgroup per (component, group of SMX_TRILB_CELLS cells) -- the factor once in registers,
+// waves over the group's cells, lane p = row p -- leaves its partial sums in `part`; scale_prior_tril_reduce_kernel adds the groups
+// in order (deterministic) and applies the diagonal's derivative.  (One workgroup per component walking all cells: 99 - 142 us.)
+#define SMX_TRILB_WAVES 8
+#define SMX_TRILB_CELLS 8
+__global__ __launch_bounds__(64 * SMX_TRILB_WAVES) void scale_prior_tril_bwd_kernel(ScalePriorArgs a, float* gpart) {
+  extern __shared__ float sm[];   // L [D][D + 1] | partial sums [waves][D][D + 2]
+  const int c = blockIdx.x, grp = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int D = a.D, ldl = D + 1, lda = D + 2;
   float* L = sm;
   float* part = sm + D * ldl;
@@ -1280,22 +1324,25 @@ __global__ __launch_bounds__(256) void scale_prior_tril_bwd_kernel(ScalePriorArg
   if (wv == 0) tril_load(a, c, lane, L, lpp, sg);
   __syncthreads();
   if (wv != 0 && lane < D) { lpp = L[lane * ldl + lane]; }
+  TrilRegs tr;
+  tril_regs(D, lane, L, tr);
   float acc[32];   // row p of sum_b r (w u^T); [j = p] also carries the -r / L_pp term
 #pragma unroll
   for (int j = 0; j < 32; ++j) acc[j] = 0.f;
   float g_loc = 0.f, g_lg = 0.f;
   const float mloc = lane < D ? a.loc[(long)c * a.Dp + lane] : 0.f;
   const float invl = frcp(lpp);
-  for (int b = wv; b < a.B; b += 4) {
+  const int b_end = min(a.B, (grp + 1) * SMX_TRILB_CELLS);
+  for (int b = grp * SMX_TRILB_CELLS + wv; b < b_end; b += SMX_TRILB_WAVES) {
     const float rc = a.resp[(long)b * 32 + c];
     float u, w;
-    tril_solve(D, lane, L, lpp, (lane < D ? a.z[(long)b * a.Dp + lane] : 0.f) - mloc, u, w);
+    tril_solve(D, lane, tr, lpp, (lane < D ? a.z[(long)b * a.Dp + lane] : 0.f) - mloc, u, w);
     g_loc += rc * w;
     g_lg += rc;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       if (j < D) {   // (uniform)
-        const float uj = __shfl(u, j, 64);
+        const float uj = lane_bcast(u, j);
         acc[j] += rc * (w * uj - (j == lane ? invl : 0.f));
       }
     }
@@ -1308,34 +1355,57 @@ __global__ __launch_bounds__(256) void scale_prior_tril_bwd_kernel(ScalePriorArg
   }
   if (lane == 0) part[(wv * D) * lda + D + 1] = g_lg;
   __syncthreads();
-  if (wv == 0 && lane < D) {
-    for (int j = 0; j < D; ++j) {
-      const float t = (part[(0 * D + lane) * lda + j] + part[(1 * D + lane) * lda + j]) + (part[(2 * D + lane) * lda + j] + part[(3 * D + lane) * lda + j]);
-      float g = 0.f;
-      if (j < lane) g = -a.kl_scale * t;
-      else if (j == lane) g = -a.kl_scale * t * sg;
-      a.g_scale[((long)c * D + lane) * a.Dp + j] = g;
+  // this group's sums over its waves (wave order) -> gpart[c][grp][D][D + 2]
+  float* out = gpart + ((long)c * gridDim.y + grp) * D * lda;
+  for (int i = threadIdx.x; i < D * lda; i += 64 * SMX_TRILB_WAVES) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < SMX_TRILB_WAVES; ++q) t += part[q * D * lda + i];
+    out[i] = t;
+  }
+}
+__global__ __launch_bounds__(256) void scale_prior_tril_reduce_kernel(ScalePriorArgs a, const float* gpart, int n_grp) {
+  const int c = blockIdx.x;
+  const int D = a.D, lda = D + 2;
+  const float* base = gpart + (long)c * n_grp * D * lda;
+  for (int i = threadIdx.x; i < D * lda; i += 256) {   // one thread per entry of the component's [D][D + 2] sums, the groups in order
+    float t = 0.f;
+    for (int q0 = 0; q0 < n_grp; q0 += 8) {   // eight groups' loads in flight, added in group order
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = q0 + k < n_grp ? base[(long)(q0 + k) * D * lda + i] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += v[k];
     }
-    for (int j = D; j < a.Dp; ++j) a.g_scale[((long)c * D + lane) * a.Dp + j] = 0.f;
-    const float tl = (part[(0 * D + lane) * lda + D] + part[(1 * D + lane) * lda + D]) + (part[(2 * D + lane) * lda + D] + part[(3 * D + lane) * lda + D]);
-    a.g_loc[(long)c * a.Dp + lane] = -a.kl_scale * tl;
+    const int p = i / lda, j = i - p * lda;
+    if (j < D) {
+      float g = 0.f;
+      if (j < p) g = -a.kl_scale * t;
+      else if (j == p) g = -a.kl_scale * t * sigmoidf(a.scale_raw[((long)c * D + p) * a.Dp + p]);
+      a.g_scale[((long)c * D + p) * a.Dp + j] = g;
+    } else if (j == D) {
+      a.g_loc[(long)c * a.Dp + p] = -a.kl_scale * t;
+    } else if (p == 0) {   // j == D + 1: the sum of the responsibilities
+      float mx = -3.0e38f;
+      for (int q = 0; q < a.C; ++q) mx = fmaxf(mx, a.logits[q]);
+      float se = 0.f;
+      for (int q = 0; q < a.C; ++q) se += fexp(a.logits[q] - mx);
+      a.g_logits[c] = a.kl_scale * ((float)a.B * fexp(a.logits[c] - mx) * frcp(se) - t);
+    }
   }
-  if (wv == 0 && lane >= D && lane < a.Dp) a.g_loc[(long)c * a.Dp + lane] = 0.f;
-  if (wv == 0 && lane == 0) {
-    const float rsum = (part[(0 * D) * lda + D + 1] + part[(1 * D) * lda + D + 1]) + (part[(2 * D) * lda + D + 1] + part[(3 * D) * lda + D + 1]);
-    float mx = -3.0e38f;
-    for (int q = 0; q < a.C; ++q) mx = fmaxf(mx, a.logits[q]);
-    float se = 0.f;
-    for (int q = 0; q < a.C; ++q) se += fexp(a.logits[q] - mx);
-    a.g_logits[c] = a.kl_scale * ((float)a.B * fexp(a.logits[c] - mx) * frcp(se) - rsum);
+  for (int i = threadIdx.x; i < D * (a.Dp - D); i += 256) {   // the padded columns
+    const int p = i / (a.Dp - D), j = D + i % (a.Dp - D);
+    a.g_scale[((long)c * D + p) * a.Dp + j] = 0.f;
   }
+  for (int d = D + (int)threadIdx.x; d < a.Dp; d += 256) a.g_loc[(long)c * a.Dp + d] = 0.f;
 }
 
 int launch_scale_prior_fwd(hipStream_t st, const ScalePriorArgs& a) {
   if (a.C < 2 || a.C > 32 || a.B <= 0) { set_error("scale prior: 2..32 components"); return SMX_ERR_INVALID; }
   if (a.tril) {
     if (a.D < 1 || a.D > 32) { set_error("scale prior: full-covariance components take at most 32 latent dimensions"); return SMX_ERR_INVALID; }
-    hipLaunchKernelGGL(scale_prior_tril_fwd_kernel, dim3((a.B + 3) / 4), dim3(256), (size_t)4 * a.D * (a.D + 1) * sizeof(float), st, a);
+    if (a.Dp != 32) { set_error("scale prior: full-covariance components expect a 32-wide padded latent"); return SMX_ERR_INVALID; }
+    hipLaunchKernelGGL(scale_prior_tril_fwd_kernel, dim3(a.B), dim3(64 * SMX_TRILF_WAVES), (size_t)(SMX_TRILF_WAVES * a.D * (a.D + 1) + a.C * a.D + 32) * sizeof(float), st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
@@ -1406,7 +1476,10 @@ __global__ __launch_bounds__(256) void scale_prior_tie_kernel(ScalePriorArgs a) 
 int launch_scale_prior_bwd(hipStream_t st, const ScalePriorArgs& a) {
   if (a.tril) {
     if (a.D < 1 || a.D > 32 || a.tie_mixtures || a.tie_loc || a.tie_scale) { set_error("scale prior: full-covariance components take at most 32 latent dimensions and no tied parameters"); return SMX_ERR_INVALID; }
-    hipLaunchKernelGGL(scale_prior_tril_bwd_kernel, dim3(a.C), dim3(256), (size_t)(a.D * (a.D + 1) + 4 * a.D * (a.D + 2)) * sizeof(float), st, a);
+    const int n_grp = (a.B + SMX_TRILB_CELLS - 1) / SMX_TRILB_CELLS;
+    if (!a.tril_part || (size_t)a.C * n_grp * a.D * (a.D + 2) > a.tril_part_floats) { set_error("scale prior: no scratch for the full-covariance gradients"); return SMX_ERR_INVALID; }
+    hipLaunchKernelGGL(scale_prior_tril_bwd_kernel, dim3(a.C, n_grp), dim3(64 * SMX_TRILB_WAVES), (size_t)(a.D * (a.D + 1) + SMX_TRILB_WAVES * a.D * (a.D + 2)) * sizeof(float), st, a, a.tril_part);
+    hipLaunchKernelGGL(scale_prior_tril_reduce_kernel, dim3(a.C), dim3(256), 0, st, a, a.tril_part, n_grp);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
@@ -1827,10 +1900,17 @@ __global__ __launch_bounds__(64) void label_tril_kernel(LabelArgs a) {
     mx[c] = raw[c * Pp];
     const float mu = live ? raw[(C + c) * Pp + lane] : 0.f;
     float lpp = 1.f, sg = 0.f;
-    for (int j = 0; j < P; ++j) {   // plane j = column j of L, coalesced over the rows
-      float v = live ? raw[(2 * C + c * P + j) * Pp + lane] : 0.f;
-      if (j == lane) { const SpSg t = softplus_sigmoid(v); v = t.sp + 1e-5f; lpp = v; sg = t.sg; }
-      if (live) Ls[lane * ldl + j] = j <= lane ? v : 0.f;
+    for (int j0 = 0; j0 < P; j0 += 8) {   // plane j = column j of L, coalesced over the rows; eight planes' loads in flight at once
+      float v8[8];                        // (one load per plane, each followed by its LDS store, was a chain of P memory round trips)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v8[t] = (live && j0 + t < P) ? raw[(2 * C + c * P + j0 + t) * Pp + lane] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int j = j0 + t;
+        float v = v8[t];
+        if (j == lane) { const SpSg sp = softplus_sigmoid(v); v = sp.sp + 1e-5f; lpp = v; sg = sp.sg; }
+        if (live && j < P) Ls[lane * ldl + j] = j <= lane ? v : 0.f;
+      }
     }
     __syncthreads();
     const float inv = frcp(lpp);

@@ -180,6 +180,7 @@ struct smx_model {
   bool mixpost = false;      // SMX_MODEL_SCALE_POST: q(z|x) a mixture of cfg.n_components diagonal Gaussians (lat head: 1 + 2 C planes)
   int lat_planes = 2;        // planes of width Dp of the latent head's output: 2 (mu, raw sigma), 1 (deterministic), 1 + 2 C (mixture posterior)
   float* zmean = nullptr; int32_t* zpick = nullptr;   // mixture posterior: the mixture's mean [B][Dp] (what predict / encode report), the picked component [B]
+  float* tril_part = nullptr; size_t tril_part_floats = 0;   // scale_tril: scratch of the prior's backward (partial sums per component and cell group)
   bool scale_tril = false;   // SCALE with full-covariance components (SMX_MODEL_SCALE_TRIL): prior/scale holds C lower-triangular D x D factors
   int n_heads = 0;                    // label heads on the decoder (0 for fvae: SemiFVAE's labels go to the discriminator)
   // fvae: discriminator on z (smx_factor.hip)

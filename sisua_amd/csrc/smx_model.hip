@@ -306,6 +306,10 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
       (rc = dmalloc(&m->hostX, B * m->Gp)) || (rc = dmalloc(&m->hostLib, B * 2)) || (rc = dmalloc(&m->hostLgx1, B)))
     return fail(rc);
   if (m->scale && ((rc = dmalloc(&m->resp, B * 32)) || (rc = dmalloc(&m->dklz, B * m->Dp)))) return fail(rc);
+  if (m->scale_tril) {
+    m->tril_part_floats = (size_t)cfg->n_components * ((B + 7) / 8) * m->D * (m->D + 2);
+    if ((rc = dmalloc(&m->tril_part, m->tril_part_floats))) return fail(rc);
+  }
   if (m->mixpost && ((rc = dmalloc(&m->resp, B * 32)) || (rc = dmalloc(&m->zmean, B * m->Dp)) || (rc = dmalloc(&m->zpick, B)))) return fail(rc);
   if (m->scvi) {
     if ((rc = dmalloc(&m->raw, B * ldp)) || (rc = dmalloc(&m->draw, B * ldp)) || (rc = dmalloc(&m->rho, B * m->Gp)) ||
@@ -386,7 +390,7 @@ int smx_model_destroy(smx_model* m) {
   fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1); fr(m->hostX); fr(m->hostLib); fr(m->hostLgx1);
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); fr(m->laby_raw[j]); fr(m->laby_draw[j]); }
   fr(m->rows2[0]); fr(m->rows2[1]); fr(m->order); fr(m->state3); fr(m->mhist);
-  fr(m->resp); fr(m->dklz); fr(m->zmean); fr(m->zpick);
+  fr(m->resp); fr(m->dklz); fr(m->zmean); fr(m->zpick); fr(m->tril_part);
   for (auto& L : m->disc) { fr(L.xhat); fr(L.out_buf); fr(L.dpre); }
   fr(m->zz); fr(m->u_d); fr(m->tc_cell); fr(m->dl_cell); fr(m->dz_tc); fr(m->disc_dpre); fr(m->disc_db);
   fr(m->noise_eps); fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);

@@ -1093,6 +1093,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
     sp.resp = m->resp; sp.kl_scale = c.beta * inv_gb;
     sp.g_logits = G_(m, m->t_prLogits); sp.g_loc = G_(m, m->t_prLoc); sp.g_scale = G_(m, m->t_prScale);
     sp.tie_mixtures = m->flags.tie_mixtures; sp.tie_loc = m->flags.tie_loc; sp.tie_scale = m->flags.tie_scale; sp.tril = m->scale_tril;
+    sp.tril_part = m->tril_part; sp.tril_part_floats = m->tril_part_floats;
     SMX_CHECK(launch_scale_prior_bwd(m->st, sp));
   }
   // Products that only the optimiser reads (the weight gradients of the first decoder layer, of the latent head and of

@@ -19,6 +19,9 @@ variants = {
   "vae zinb latent 10": dict(model="vae", likelihood="zinb", latent_dim=10),
   "vae zinb units [64,64]": dict(model="vae", likelihood="zinb", enc_units=(64, 64), dec_units=(64, 64)),
   "scale zinb (10 components)": dict(model="scale", likelihood="zinb", n_components=10),
+  "scale zinb tied loc / scale": dict(model="scale", likelihood="zinb", n_components=10, tie_loc=True, tie_scale=True),
+  "scale zinb covariance tril": dict(model="scale", likelihood="zinb", n_components=10, covariance="tril"),
+  "scale zinb mixture posterior (8)": dict(model="scale", likelihood="zinb", n_components=8, latent_mixture=True),
   "fvae zinb (5 x 1000 discriminator)": dict(model="fvae", likelihood="zinb", disc_units=1000, disc_layers=5),
 }
 order = bench.make_order(xt.shape[0], batch, 330)
