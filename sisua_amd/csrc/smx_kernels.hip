@@ -1914,17 +1914,25 @@ __global__ __launch_bounds__(64) void label_tril_kernel(LabelArgs a) {
     }
     __syncthreads();
     const float inv = frcp(lpp);
+    // (pivots broadcast by v_readlane, the factor's entries of eight steps read ahead of the chain: with __shfl = ds_bpermute and
+    // an LDS read inside every step a substitution step took ~330 cycles.  Fully unrolled forms with the factor in registers
+    // measured SLOWER here -- 68 us per launch against 30: one wave executes the whole cell, and the unrolled code's predicated
+    // steps beyond P and per-component copies are ~20 000 serial instructions)
     float r = yv - mu, u = 0.f;
+#pragma unroll 8
     for (int j = 0; j < P; ++j) {
-      const float uj = __shfl(r * inv, j, 64);
+      const float lj = live ? Ls[lane * ldl + j] : 0.f;
+      const float uj = lane_bcast(r * inv, j);
       if (lane == j) u = uj;
-      else if (lane > j && live) r -= Ls[lane * ldl + j] * uj;
+      else if (lane > j) r -= lj * uj;
     }
     float s = u, w = 0.f;
+#pragma unroll 8
     for (int i = P - 1; i >= 0; --i) {
-      const float wi = __shfl(s * inv, i, 64);
+      const float li = live ? Ls[i * ldl + lane] : 0.f;   // (zero above the diagonal: lanes beyond i add nothing)
+      const float wi = lane_bcast(s * inv, i);
       if (lane == i) w = wi;
-      else if (lane < i) s -= Ls[i * ldl + lane] * wi;
+      else if (lane < i) s -= li * wi;
     }
     __syncthreads();   // (the next component overwrites L)
     const float quad = wave_sum(live ? u * u : 0.f), logdet = wave_sum(live ? flog(lpp) : 0.f);
@@ -1951,7 +1959,7 @@ __global__ __launch_bounds__(64) void label_tril_kernel(LabelArgs a) {
       draw[(C + c) * Pp + p] = p < P ? resp * w_c[c] * gs : 0.f;   // (p == lane here: P <= 64)
     }
     for (int j = 0; j < P; ++j) {
-      const float uj = __shfl(u_c[c], j, 64);
+      const float uj = lane_bcast(u_c[c], j);
       float d = 0.f;
       if (live && j < lane) d = w_c[c] * uj;
       else if (live && j == lane) d = (w_c[c] * uj - dinv[c]) * dsg[c];
