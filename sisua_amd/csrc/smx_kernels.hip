@@ -1152,6 +1152,8 @@ int launch_latent_bwd(hipStream_t st, const LatentArgs& a) {
   return SMX_OK;
 }
 
+// a lane's value to every lane (v_readlane: the lane index is uniform); __shfl would go through the LDS crossbar (ds_bpermute)
+__device__ inline float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 // ---- SCALE: Gaussian-mixture prior, one-sample Monte-Carlo KL (scale.py:13-49; Xiong et al. 2019) -------------------
 // one wave per cell; lanes over the latent dims; the C (<= 32) components are walked serially (C D ~ 100 terms)
 __global__ __launch_bounds__(256) void scale_prior_fwd_kernel(ScalePriorArgs a) {
@@ -1164,6 +1166,30 @@ __global__ __launch_bounds__(256) void scale_prior_fwd_kernel(ScalePriorArgs a) 
   const float lmx = wave_max(lg);
   const float lse = lmx + flog(wave_sum(lane < a.C ? fexp(lg - lmx) : 0.f));
   float comp_mine = -3.0e38f;          // lane c keeps component c's joint log density
+  if (a.D <= 64) {
+    // (eight components' parameters requested together: a load pair per component inside the loop was a chain of C dependent
+    // memory round trips -- 13 us per launch at 10 components)
+    const bool live = lane < a.D;
+    const float zd = live ? a.z[(long)b * a.Dp + lane] : 0.f;
+    for (int c0 = 0; c0 < a.C; c0 += 8) {
+      float sr[8], lc[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool on = live && c0 + k < a.C;
+        sr[k] = on ? a.scale_raw[(long)(c0 + k) * a.Dp + lane] : 0.f;
+        lc[k] = on ? a.loc[(long)(c0 + k) * a.Dp + lane] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (c0 + k < a.C) {   // (uniform)
+          const float s = softplusf(sr[k] + SMX_SOFTPLUS_INV_1);
+          const float u = (zd - lc[k]) * frcp(s);
+          const float t = wave_sum(live ? -0.5f * u * u - flog(s) - HALF_LOG_2PI : 0.f) + (a.logits[c0 + k] - lse);
+          if (lane == c0 + k) comp_mine = t;
+        }
+      }
+    }
+  } else
   for (int c = 0; c < a.C; ++c) {
     float t = 0.f;
     for (int d = lane; d < a.D; d += 64) {
@@ -1189,10 +1215,22 @@ __global__ __launch_bounds__(256) void scale_prior_fwd_kernel(ScalePriorArgs a) 
   for (int d = lane; d < a.Dp; d += 64) {
     float g = 0.f;
     const float zd = a.z[(long)b * a.Dp + d];
-    for (int c = 0; c < a.C; ++c) {   // (every lane takes part in the shuffle; padded dims contribute nothing)
-      const float rc = __shfl(resp, c, 64);
-      const float s = softplusf(a.scale_raw[(long)c * a.Dp + d] + SMX_SOFTPLUS_INV_1);
-      g += (d < a.D) ? rc * (zd - a.loc[(long)c * a.Dp + d]) * frcp(s * s) : 0.f;
+    for (int c0 = 0; c0 < a.C; c0 += 8) {   // (every lane takes part in the broadcasts; padded dims contribute nothing)
+      float sr[8], lc[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool on = d < a.D && c0 + k < a.C;
+        sr[k] = on ? a.scale_raw[(long)(c0 + k) * a.Dp + d] : 0.f;
+        lc[k] = on ? a.loc[(long)(c0 + k) * a.Dp + d] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (c0 + k < a.C) {
+          const float rc = lane_bcast(resp, c0 + k);
+          const float s = softplusf(sr[k] + SMX_SOFTPLUS_INV_1);
+          g += (d < a.D) ? rc * (zd - lc[k]) * frcp(s * s) : 0.f;
+        }
+      }
     }
     a.dklz[(long)b * a.Dp + d] = g;
   }
@@ -1234,7 +1272,6 @@ __device__ inline void tril_load(const ScalePriorArgs& a, int c, int lane, float
 // broadcast by v_readlane: a step is multiply -> readlane -> fused multiply-add.  (Its first form read L from LDS inside the loop and
 // broadcast with __shfl = ds_bpermute, two LDS round trips per step: ~330 cycles per step, 9 us per 32-dimensional solve.)
 struct TrilRegs { float row[32]; float col[32]; };
-__device__ inline float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 __device__ inline void tril_regs(int D, int lane, const float* L, TrilRegs& t) {
   const int ldl = D + 1;
 #pragma unroll
@@ -1424,14 +1461,26 @@ __global__ __launch_bounds__(256) void scale_prior_bwd_kernel(ScalePriorArgs a) 
     const float raw = live ? a.scale_raw[(long)c * a.Dp + d] : 0.f;
     const float s = softplusf(raw + SMX_SOFTPLUS_INV_1), m = live ? a.loc[(long)c * a.Dp + d] : 0.f;
     const float is = frcp(s);
-    for (int b = w; b < a.B; b += 4) {
-      const float rc = a.resp[(long)b * 32 + c];
-      if (live) {
-        const float u = (a.z[(long)b * a.Dp + d] - m) * is;
-        g_loc += rc * u * is;
-        g_sc += rc * (u * u - 1.f) * is;
+    for (int b0 = w; b0 < a.B; b0 += 32) {   // eight of this wave's cells at a time: their loads in flight together
+      float rcv[8], zv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int b = b0 + 4 * k;
+        rcv[k] = b < a.B ? a.resp[(long)b * 32 + c] : 0.f;
+        zv[k] = (b < a.B && live) ? a.z[(long)b * a.Dp + d] : m;
       }
-      if (d0 == 0 && lane == 0) g_lg += rc;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {   // (cell order as before: the sums keep their bits)
+        if (b0 + 4 * k < a.B) {
+          const float rc = rcv[k];
+          if (live) {
+            const float u = (zv[k] - m) * is;
+            g_loc += rc * u * is;
+            g_sc += rc * (u * u - 1.f) * is;
+          }
+          if (d0 == 0 && lane == 0) g_lg += rc;
+        }
+      }
     }
     sh[w][0][lane] = g_loc; sh[w][1][lane] = g_sc; sh[w][2][lane] = g_lg;
     __syncthreads();
