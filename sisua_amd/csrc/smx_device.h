@@ -240,6 +240,8 @@ __device__ inline uint32_t lds_addr(const void* p) {   // byte address within th
 // wave / block reductions (wave = 64)
 // ---------------------------------------------------------------------------
 // (four DPP steps inside the rows of 16, then two ds_bpermute across the four rows -- instead of six ds_bpermute)
+// a lane's value to every lane (v_readlane: the lane index is uniform); __shfl would go through the LDS crossbar (ds_bpermute)
+__device__ inline float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 __device__ inline float wave_sum(float v) {
 #define SMX_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false))
   SMX_DPP_ADD(0xB1);    // quad_perm [1, 0, 3, 2]

@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(256) void mixlat_fwd_kernel(MixLatArgs a) {
   int k = 0;
   float run = 0.f;
   for (int c = 0; c < a.C; ++c) {
-    run += __shfl(pi, c, 64);
+    run += lane_bcast(pi, c);
     k += (run < u) ? 1 : 0;
   }
   k = min(k, a.C - 1);
@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(256) void mixlat_fwd_kernel(MixLatArgs a) {
     mu[c] = 0.f; sg[c] = 1.f;
     if (c < a.C) {   // (uniform)
       if (live) { mu[c] = lat[(1 + c) * a.Dp + lane]; sg[c] = softplusf(lat[(1 + a.C + c) * a.Dp + lane] + SMX_SOFTPLUS_INV_1); }
-      const float pc = __shfl(pi, c, 64);
+      const float pc = lane_bcast(pi, c);
       mean += pc * mu[c];
       second += pc * (sg[c] * sg[c] + mu[c] * mu[c]);
       if (c == k) z = mu[c] + sg[c] * eps;
@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(256) void mixlat_fwd_kernel(MixLatArgs a) {
   for (int c = 0; c < 8; ++c) {
     if (c < a.C) {
       const float dzm = (z - mu[c]) * frcp(sg[c]);
-      const float t = wave_sum(live ? -0.5f * dzm * dzm - flog(sg[c]) - HALF_LOG_2PI : 0.f) + __shfl(logpi, c, 64);
+      const float t = wave_sum(live ? -0.5f * dzm * dzm - flog(sg[c]) - HALF_LOG_2PI : 0.f) + lane_bcast(logpi, c);
       if (lane == c) comp_mine = t;
     }
   }
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(256) void mixlat_bwd_kernel(MixLatArgs a) {
     if (c < a.C) {
       if (live) { mu[c] = lat[(1 + c) * a.Dp + lane]; sraw[c] = lat[(1 + a.C + c) * a.Dp + lane]; sg[c] = softplusf(sraw[c] + SMX_SOFTPLUS_INV_1); }
       const float is = frcp(sg[c]);
-      dqz -= __shfl(rme, c, 64) * (z - mu[c]) * is * is;
+      dqz -= lane_bcast(rme, c) * (z - mu[c]) * is * is;
     }
   }
   const float g = dz + a.kl_scale * (z + dqz);
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(256) void mixlat_bwd_kernel(MixLatArgs a) {
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     if (c < a.C) {
-      const float rc = __shfl(rme, c, 64), is = frcp(sg[c]);
+      const float rc = lane_bcast(rme, c), is = frcp(sg[c]);
       const float dzm = (z - mu[c]) * is;
       float dmu = a.kl_scale * rc * dzm * is, dsg = a.kl_scale * rc * (dzm * dzm - 1.f) * is;
       if (c == k) { dmu += g; dsg += g * eps; }
@@ -1152,8 +1152,6 @@ int launch_latent_bwd(hipStream_t st, const LatentArgs& a) {
   return SMX_OK;
 }
 
-// a lane's value to every lane (v_readlane: the lane index is uniform); __shfl would go through the LDS crossbar (ds_bpermute)
-__device__ inline float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 // ---- SCALE: Gaussian-mixture prior, one-sample Monte-Carlo KL (scale.py:13-49; Xiong et al. 2019) -------------------
 // one wave per cell; lanes over the latent dims; the C (<= 32) components are walked serially (C D ~ 100 terms)
 __global__ __launch_bounds__(256) void scale_prior_fwd_kernel(ScalePriorArgs a) {
