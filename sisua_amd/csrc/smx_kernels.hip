@@ -1961,12 +1961,10 @@ __global__ __launch_bounds__(64) void label_tril_kernel(LabelArgs a) {
     }
     __syncthreads();
     const float inv = frcp(lpp);
-    // (pivots broadcast by v_readlane, the factor's entries of eight steps read ahead of the chain: with __shfl = ds_bpermute and
-    // an LDS read inside every step a substitution step took ~330 cycles.  Fully unrolled forms with the factor in registers
+    // (pivots broadcast by v_readlane: with __shfl = ds_bpermute a substitution step took two LDS round trips.  Fully unrolled forms with the factor in registers
     // measured SLOWER here -- 68 us per launch against 30: one wave executes the whole cell, and the unrolled code's predicated
     // steps beyond P and per-component copies are ~20 000 serial instructions)
     float r = yv - mu, u = 0.f;
-#pragma unroll 8
     for (int j = 0; j < P; ++j) {
       const float lj = live ? Ls[lane * ldl + j] : 0.f;
       const float uj = lane_bcast(r * inv, j);
@@ -1974,7 +1972,6 @@ __global__ __launch_bounds__(64) void label_tril_kernel(LabelArgs a) {
       else if (lane > j) r -= lj * uj;
     }
     float s = u, w = 0.f;
-#pragma unroll 8
     for (int i = P - 1; i >= 0; --i) {
       const float li = live ? Ls[i * ldl + lane] : 0.f;   // (zero above the diagonal: lanes beyond i add nothing)
       const float wi = lane_bcast(s * inv, i);
