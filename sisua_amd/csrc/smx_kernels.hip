@@ -1923,9 +1923,12 @@ __global__ __launch_bounds__(256) void label_loss_kernel(LabelArgs a) {
 //   w = L^-T u          back substitution through the column view
 //   log N = -1/2 |u|^2 - sum log L_pp - P/2 log 2 pi;   d mu = w,   d L[p][j] = w_p u_j - [p == j] / L_pp
 // and the mixture over components as in label_loss_kernel: d logit_c = resp_c - pi_c, component gradients times resp_c.
-__global__ __launch_bounds__(64) void label_tril_kernel(LabelArgs a) {
-  extern __shared__ float Ls[];   // [P][P + 1]
-  const int lane = threadIdx.x, b = blockIdx.x;
+// One workgroup per cell, one WAVE per component (the components' substitution chains side by side instead of one after the other
+// in a single wave: 30 -> 16 us per launch at 38 label dimensions and two components); wave c keeps its factor in its own LDS tile,
+// the components' log densities meet in LDS, every wave then writes its own component's gradient planes.
+__global__ __launch_bounds__(256) void label_tril_kernel(LabelArgs a) {
+  extern __shared__ float Lsm[];   // C x [P][P + 1] | e [4]
+  const int lane = threadIdx.x & 63, c = threadIdx.x >> 6, b = blockIdx.x;   // (blockDim = 64 C)
   const long src = a.rows ? a.rows[b] : b;
   const float* raw = a.raw + (long)b * a.ld;
   float* draw = a.draw + (long)b * a.ld;
@@ -1933,89 +1936,79 @@ __global__ __launch_bounds__(64) void label_tril_kernel(LabelArgs a) {
   const float gs = a.grad_scale * m;
   const int C = a.C, P = a.P, Pp = a.Pp, ldl = P + 1;
   if (m == 0.f) {   // (block-uniform)
-    if (a.backward) for (int i = lane; i < C * (2 + P) * Pp; i += 64) draw[i] = 0.f;
-    if (lane == 0) a.llk[b] = a.add ? a.llk[b] : 0.f;
+    if (a.backward) for (int i = threadIdx.x; i < C * (2 + P) * Pp; i += 64 * C) draw[i] = 0.f;
+    if (threadIdx.x == 0) a.llk[b] = a.add ? a.llk[b] : 0.f;
     return;
   }
+  float* Ls = Lsm + c * P * ldl;
+  float* esh = Lsm + C * P * ldl;
   const bool live = lane < P;
   const float yv = live ? a.Y[src * a.ldy + lane] : 0.f;
-  float e[4], mx[4], u_c[4], w_c[4], dinv[4], dsg[4];
+  const float mxc = raw[c * Pp];
+  const float mu = live ? raw[(C + c) * Pp + lane] : 0.f;
+  float lpp = 1.f, sg = 0.f;
+  for (int j0 = 0; j0 < P; j0 += 8) {   // plane j = column j of L, coalesced over the rows; eight planes' loads in flight at once
+    float v8[8];                        // (one load per plane, each followed by its LDS store, was a chain of P memory round trips)
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    e[c] = 0.f; mx[c] = 0.f; u_c[c] = 0.f; w_c[c] = 0.f; dinv[c] = 0.f; dsg[c] = 0.f;
-    if (c >= C) continue;   // (uniform)
-    mx[c] = raw[c * Pp];
-    const float mu = live ? raw[(C + c) * Pp + lane] : 0.f;
-    float lpp = 1.f, sg = 0.f;
-    for (int j0 = 0; j0 < P; j0 += 8) {   // plane j = column j of L, coalesced over the rows; eight planes' loads in flight at once
-      float v8[8];                        // (one load per plane, each followed by its LDS store, was a chain of P memory round trips)
+    for (int t = 0; t < 8; ++t) v8[t] = (live && j0 + t < P) ? raw[(2 * C + c * P + j0 + t) * Pp + lane] : 0.f;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) v8[t] = (live && j0 + t < P) ? raw[(2 * C + c * P + j0 + t) * Pp + lane] : 0.f;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int j = j0 + t;
-        float v = v8[t];
-        if (j == lane) { const SpSg sp = softplus_sigmoid(v); v = sp.sp + 1e-5f; lpp = v; sg = sp.sg; }
-        if (live && j < P) Ls[lane * ldl + j] = j <= lane ? v : 0.f;
-      }
+    for (int t = 0; t < 8; ++t) {
+      const int j = j0 + t;
+      float v = v8[t];
+      if (j == lane) { const SpSg sp = softplus_sigmoid(v); v = sp.sp + 1e-5f; lpp = v; sg = sp.sg; }
+      if (live && j < P) Ls[lane * ldl + j] = j <= lane ? v : 0.f;
     }
-    __syncthreads();
-    const float inv = frcp(lpp);
-    // (pivots broadcast by v_readlane: with __shfl = ds_bpermute a substitution step took two LDS round trips.  Fully unrolled forms with the factor in registers
-    // measured SLOWER here -- 68 us per launch against 30: one wave executes the whole cell, and the unrolled code's predicated
-    // steps beyond P and per-component copies are ~20 000 serial instructions)
-    float r = yv - mu, u = 0.f;
-    for (int j = 0; j < P; ++j) {
-      const float lj = live ? Ls[lane * ldl + j] : 0.f;
-      const float uj = lane_bcast(r * inv, j);
-      if (lane == j) u = uj;
-      else if (lane > j) r -= lj * uj;
-    }
-    float s = u, w = 0.f;
-    for (int i = P - 1; i >= 0; --i) {
-      const float li = live ? Ls[i * ldl + lane] : 0.f;   // (zero above the diagonal: lanes beyond i add nothing)
-      const float wi = lane_bcast(s * inv, i);
-      if (lane == i) w = wi;
-      else if (lane < i) s -= li * wi;
-    }
-    __syncthreads();   // (the next component overwrites L)
-    const float quad = wave_sum(live ? u * u : 0.f), logdet = wave_sum(live ? flog(lpp) : 0.f);
-    e[c] = -0.5f * quad - logdet - 0.9189385332046727f * (float)P;
-    u_c[c] = u; w_c[c] = w; dinv[c] = inv; dsg[c] = sg;
   }
+  __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();   // (the tile is this wave's own)
+  const float inv = frcp(lpp);
+  // (pivots broadcast by v_readlane: with __shfl = ds_bpermute a substitution step took two LDS round trips.  Fully unrolled forms with
+  // the factor in registers measured SLOWER: the unrolled code's predicated steps beyond P are thousands of serial instructions)
+  float r = yv - mu, u = 0.f;
+  for (int j = 0; j < P; ++j) {
+    const float lj = live ? Ls[lane * ldl + j] : 0.f;
+    const float uj = lane_bcast(r * inv, j);
+    if (lane == j) u = uj;
+    else if (lane > j) r -= lj * uj;
+  }
+  float sw = u, w = 0.f;
+  for (int i = P - 1; i >= 0; --i) {
+    const float li = live ? Ls[i * ldl + lane] : 0.f;   // (zero above the diagonal: lanes beyond i add nothing)
+    const float wi = lane_bcast(sw * inv, i);
+    if (lane == i) w = wi;
+    else if (lane < i) sw -= li * wi;
+  }
+  const float quad = wave_sum(live ? u * u : 0.f), logdet = wave_sum(live ? flog(lpp) : 0.f);
+  const float ec = -0.5f * quad - logdet - 0.9189385332046727f * (float)P;
+  if (lane == 0) { esh[c] = ec; esh[4 + c] = mxc; }
+  __syncthreads();
   float am = -3.0e38f, jm = -3.0e38f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-    if (c < C) { am = fmaxf(am, mx[c]); jm = fmaxf(jm, mx[c] + e[c]); }
+  for (int q = 0; q < C; ++q) { am = fmaxf(am, esh[4 + q]); jm = fmaxf(jm, esh[4 + q] + esh[q]); }
   float sa = 0.f, sj = 0.f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-    if (c < C) { sa += expf(mx[c] - am); sj += expf(mx[c] + e[c] - jm); }
+  for (int q = 0; q < C; ++q) { sa += expf(esh[4 + q] - am); sj += expf(esh[4 + q] + esh[q] - jm); }   // (component order: every wave the same bits)
   const float lse_a = am + logf(sa), lse_j = jm + logf(sj);
-  if (lane == 0) a.llk[b] = (a.add ? a.llk[b] : 0.f) + (lse_j - lse_a);
+  if (threadIdx.x == 0) a.llk[b] = (a.add ? a.llk[b] : 0.f) + (lse_j - lse_a);
   if (!a.backward) return;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (c >= C) continue;
-    const float resp = expf(mx[c] + e[c] - lse_j), pi = expf(mx[c] - lse_a);
-    for (int p = lane; p < Pp; p += 64) {
-      draw[c * Pp + p] = p == 0 ? (resp - pi) * gs : 0.f;
-      draw[(C + c) * Pp + p] = p < P ? resp * w_c[c] * gs : 0.f;   // (p == lane here: P <= 64)
-    }
-    for (int j = 0; j < P; ++j) {
-      const float uj = lane_bcast(u_c[c], j);
-      float d = 0.f;
-      if (live && j < lane) d = w_c[c] * uj;
-      else if (live && j == lane) d = (w_c[c] * uj - dinv[c]) * dsg[c];
-      for (int p = lane; p < Pp; p += 64) draw[(2 * C + c * P + j) * Pp + p] = p < P ? resp * d * gs : 0.f;
-    }
+  const float resp = expf(mxc + ec - lse_j), pi = expf(mxc - lse_a);
+  for (int p = lane; p < Pp; p += 64) {
+    draw[c * Pp + p] = p == 0 ? (resp - pi) * gs : 0.f;
+    draw[(C + c) * Pp + p] = p < P ? resp * w * gs : 0.f;   // (p == lane here: P <= 64)
+  }
+  for (int j = 0; j < P; ++j) {
+    const float uj = lane_bcast(u, j);
+    float d = 0.f;
+    if (live && j < lane) d = w * uj;
+    else if (live && j == lane) d = (w * uj - inv) * sg;
+    for (int p = lane; p < Pp; p += 64) draw[(2 * C + c * P + j) * Pp + p] = p < P ? resp * d * gs : 0.f;
   }
 }
 
 int launch_label_loss(hipStream_t st, const LabelArgs& a) {
   if (a.kind == SMX_LABEL_MIXTRIL) {
     if (a.P < 1 || a.P > 64 || a.C < 2 || a.C > 4) { set_error("label_loss: 'mixtril' heads take 1..64 label dimensions and 2..4 components"); return SMX_ERR_INVALID; }
-    hipLaunchKernelGGL(label_tril_kernel, dim3(a.B), dim3(64), (size_t)a.P * (a.P + 1) * sizeof(float), st, a);
+    const size_t lds = ((size_t)a.C * a.P * (a.P + 1) + 8) * sizeof(float);   // (66.6 KB at C = 4, P = 64)
+    static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&label_tril_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) == hipSuccess;
+    if (lds > 64 * 1024 && !big_ok) { set_error("label_loss: cannot reserve the LDS of the 'mixtril' head"); return SMX_ERR_HIP; }
+    hipLaunchKernelGGL(label_tril_kernel, dim3(a.B), dim3(64 * a.C), lds, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }

@@ -44,6 +44,8 @@ CASES = {
                       labels=((14, "mixtril2"), (5, "onehot")), alpha=10.0),
     "misa_tril_wide": dict(model="sisua", n_genes=90, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=5,
                            labels=((38, "mixtril3"),), alpha=4.0),
+    "misa_tril_max": dict(model="sisua", n_genes=60, likelihood="nb", enc_units=(24,), dec_units=(24,), latent_dim=4,
+                          labels=((64, "mixtril4"),), alpha=2.0),   # the largest head the kernel takes: four waves, 66.6 KB of LDS
     # MISA(zero_inflated=True) (vae.py:76-84): mixtures of ZERO-INFLATED negative binomials per label dimension
     "misa_zi": dict(model="sisua", n_genes=110, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=6,
                     labels=((11, "mixzinb3"), (5, "mixnb2")), alpha=10.0),
@@ -339,7 +341,7 @@ def test_injected_noise_matches_oracle(Engine, name):
 
 
 @pytest.mark.parametrize("name,graph", [("vae_zinb", False), ("vae_zinb", True), ("sisua", True), ("scvi_zinbd", False), ("scvi_nbd", True), ("misa", False), ("scale", True),
-                                        ("scale_tril", False), ("scale_post", True), ("fvae", True), ("semifvae", False)])
+                                        ("scale_tril", False), ("scale_post", True), ("misa_tril", False), ("misa_zi", True), ("fvae", True), ("semifvae", False)])
 def test_trajectory_matches_oracle(Engine, name, graph):
   """50-step seeded trajectory: ELBO per step within 1e-4 relative."""
   kw = CASES[name]
