@@ -1119,6 +1119,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
   }
   for (const GemmArgs& g : lab_dw) tail.push_back(g);
   BnBwdArgs gf;
+  int dh_slabs = 1;   // slabs of d h the encoder's backward sums
   {  // weight gradient of the latent head and d h = d lat * W_lat^T
     const TensorInfo& tw = m->tensors[m->t_latW];
     GemmArgs pair[2];
@@ -1134,8 +1135,14 @@ int backward_pass(smx_model* m, const Pass& ps) {
       h.A = m->dlat; h.lda = lat_ld; h.B = P_(m, m->t_latW); h.ldb = tw.ld; h.b_nmajor = 1;
       h.C = m->slab; h.ldc = eL.out_p; h.slab_stride = (long)ps.B * eL.out_p;
       h.M = ps.B; h.N = eL.out_p; h.K = lat_ld;
+      int effs[2] = {1, 1};
+      if (lat_ld > 128) {   // (a wide latent head -- the mixture-density posterior's (1 + 2 C) planes: d h contracts over all of them)
+        h.split_k = suggest_split_k(ps.B, eL.out_p, lat_ld);
+        SMX_REQUIRE((size_t)std::max(h.split_k, 1) * (size_t)h.slab_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
+      }
       Timed t(m, "gemm_lat_bwd");
-      SMX_CHECK(launch_gemm_group(m->st, pair, 2));
+      SMX_CHECK(launch_gemm_group(m->st, pair, 2, effs));
+      dh_slabs = effs[1];
     }
   }
   GemmArgs dw0[2];
@@ -1152,7 +1159,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
     gfl.fD = m->dlatl; gfl.fld = 32; gfl.fW = P_(m, m->t_latlW); gfl.fldw = tw.ld; gfl.fK = 32;
   }
   const bool twin_bwd = m->scvi && lfront && m->scvi_fused;
-  SMX_CHECK(mlp_backward(m, m->enc, ps, ps.Xsrc, m->Gp, true, 1, true, nullptr, "gemm_enc_dw", nullptr, &dw0[n_dw0], bfront ? &gf : nullptr,
+  SMX_CHECK(mlp_backward(m, m->enc, ps, ps.Xsrc, m->Gp, true, dh_slabs, true, nullptr, "gemm_enc_dw", nullptr, &dw0[n_dw0], bfront ? &gf : nullptr,
                          bfront ? &tail : nullptr, twin_bwd ? &m->encl : nullptr, twin_bwd ? &gfl : nullptr, &twin_done));
   ++n_dw0;
   // ---- scvi library branch ----
