@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SMX_ABI_VERSION 3
+#define SMX_ABI_VERSION 4
 #define SMX_MAX_LAYERS 8
 #define SMX_MAX_LABELS 4
 
@@ -64,7 +64,11 @@ typedef enum { SMX_LLK_NB = 0, SMX_LLK_ZINB = 1, SMX_LLK_NBD = 2, SMX_LLK_ZINBD 
  * mixture of label_components full-covariance Gaussians over the whole label vector (lower-triangular scale factors; label_dim <= 64;
  * the head then has label_components * (2 + label_dim) planes); SMX_LABEL_MIXZINB: MISA(zero_inflated=True), vae.py:76-84 -- the
  * components of SMX_LABEL_MIXNB zero-inflated, a fourth group of label_components gate-logit planes. */
-typedef enum { SMX_LABEL_NB = 0, SMX_LABEL_ONEHOT = 1, SMX_LABEL_MIXNB = 2, SMX_LABEL_MIXGAUSS = 3, SMX_LABEL_MIXTRIL = 4, SMX_LABEL_MIXZINB = 5 } smx_label_likelihood;
+/* SMX_LABEL_NBD / ZINB / ZINBD: the remaining count posteriors of RVmeta as heads (vae.py:30 "'onehot'/'nbd'/'nb'"; the second OUTPUT of
+ * tests/test_singlecell_models.py:133-134 is 'nbd'): planes as for the gene output -- (mean, dispersion) through softplus / softplus1,
+ * (log total_count, logits, gate logits), (mean, dispersion, gate logits). */
+typedef enum { SMX_LABEL_NB = 0, SMX_LABEL_ONEHOT = 1, SMX_LABEL_MIXNB = 2, SMX_LABEL_MIXGAUSS = 3, SMX_LABEL_MIXTRIL = 4, SMX_LABEL_MIXZINB = 5,
+               SMX_LABEL_NBD = 6, SMX_LABEL_ZINB = 7, SMX_LABEL_ZINBD = 8 } smx_label_likelihood;
 typedef enum { SMX_ACT_RELU = 0, SMX_ACT_LINEAR = 1 } smx_activation;
 
 /* Constructor arguments of SingleCellModel / SCVI / SISUA / DeepCountAutoencoder
@@ -81,6 +85,16 @@ typedef struct {
   int32_t n_encl, encl_units[SMX_MAX_LAYERS];   /* scvi library encoder */
   int32_t n_labels, label_dim[SMX_MAX_LABELS], label_llk[SMX_MAX_LABELS];
   int32_t label_components[SMX_MAX_LABELS];   /* SMX_LABEL_MIXNB / MIXGAUSS / MIXTRIL: mixture components (MISA n_components, vae.py:77) */
+  /* outputs[1:] of the reference's constructors (single_cell_model.py:74-97; tests/test_singlecell_models.py:129-141
+   * `VAE(outputs=[RVmeta(G, 'zinb'), RVmeta(P, 'nbd')])`; scvi.py:168-169 `pY = [p(d) for p in self.posteriors[1:]]`): a head with
+   * label_observed[j] != 0 is a further OUTPUT variable -- fully observed (the label mask is not consulted), weight 1 instead of alpha,
+   * its negative log-likelihood reported as smx_metrics.nllk_o.  Observed heads come first; any model kind but SMX_MODEL_FVAE /
+   * SMX_MODEL_SCALE_POST takes them (label heads proper keep their model-kind rule). */
+  int32_t label_observed[SMX_MAX_LABELS];
+  /* scvi.py:55-56,66-86,136-160 `dispersion` / `inflation` of the gene output: 0 = 'full' (a Dense head per cell and gene), 1 = 'share'
+   * (no head: ONE trainable vector [n_genes] shared by every cell -- tensor out1/b resp. out2/b without out1/W resp. out2/W; theta = exp of
+   * it, gate logits = it).  SMX_MODEL_SCVI only. */
+  int32_t scvi_dispersion, scvi_inflation;
   int32_t n_components;                /* SMX_MODEL_SCALE: components of the mixture prior (scale.py:27), 1..32 */
   int32_t disc_units, disc_layers;     /* SMX_MODEL_FVAE: hidden width / hidden layers of the discriminator (odin: 1000, 5) */
   float gamma, disc_leak;              /* SMX_MODEL_FVAE: weight of the TC term (6.0); leaky-ReLU slope (0.2) */
@@ -104,6 +118,7 @@ typedef struct {
   int32_t nan_flag;      /* non-zero if any of the above is not finite */
   int32_t step;          /* optimiser step count after this call */
   float tc, dtc_loss;    /* SMX_MODEL_FVAE: total-correlation estimate mean d(z); the discriminator's loss (0 otherwise) */
+  float nllk_o;          /* the observed extra outputs (label_observed): -mean sum of their log-likelihoods (0 without them) */
 } smx_metrics;
 
 typedef struct smx_model smx_model;

@@ -60,7 +60,9 @@ OUTPUT_POSTERIORS = LIKELIHOODS + ("mse",)   # + the deterministic output RVmeta
 LABEL_LIKELIHOODS = ("nb", "onehot", "mixnb2", "mixnb3", "mixnb4",   # mixnbC: MISA's C-component mixture of NB per label
                      "mixgauss2", "mixgauss3", "mixgauss4",           # mixgaussC: its C-component mixture of Gaussians (continuous labels)
                      "mixtril2", "mixtril3", "mixtril4",              # mixtrilC: C full-covariance Gaussians over the whole label vector
-                     "mixzinb2", "mixzinb3", "mixzinb4")              # mixzinbC: MISA(zero_inflated=True), mixture of zero-inflated NB per label
+                     "mixzinb2", "mixzinb3", "mixzinb4",              # mixzinbC: MISA(zero_inflated=True), mixture of zero-inflated NB per label
+                     "nbd", "zinb", "zinbd")                          # the other count posteriors of RVmeta as heads on the decoder output (vae.py:30:
+                                                                      # 'onehot'/'nbd'/'nb'; tests/test_singlecell_models.py:133-134: a second OUTPUT 'nbd')
 
 
 def mixture_components(llk: str) -> int:
@@ -80,6 +82,8 @@ def label_planes(llk: str, P: int = 0) -> int:
     return mixture_components(llk) * (2 + P)
   if llk.startswith("mixzinb"):   # MISA(zero_inflated=True, vae.py:76-84): the mixnb planes + C zero-inflation gate logits
     return 4 * mixture_components(llk)
+  if llk in ("nbd", "zinb", "zinbd"):   # planes as for the gene output: (mean, dispersion[, gate]) raw / (log total_count, logits, gate)
+    return 2 if llk == "nbd" else 3
   return 2 if llk == "nb" else 1 if llk == "onehot" else 3 * mixture_components(llk)
 
 
@@ -127,6 +131,17 @@ class Spec:
   latent_dim: int = 10
   encl_units: Tuple[int, ...] = (64,)     # scvi library encoder (scvi.py:41-44)
   labels: Tuple[Tuple[int, str], ...] = ()  # ((dim, 'nb'|'onehot'|'mixnbC'), ...)
+  # outputs[1:] of the reference's constructors (single_cell_model.py:74-97; tests/test_singlecell_models.py:129-141:
+  # `VAE(outputs=[RVmeta(G, 'zinb'), RVmeta(P, 'nbd')])`, `(pX, pY), qZ = vae.predict(...)`; scvi.py:168-169: `pY = [p(d) for p in
+  # self.posteriors[1:]]`): further FULLY OBSERVED output variables, each a head on the decoder output like a label head but with
+  # weight 1 and no label mask (an ordinary ELBO term).  Heads (tensors lab{j}/*, targets y[j]) are ordered extra outputs, then labels.
+  extra_outputs: Tuple[Tuple[int, str], ...] = ()
+  # scvi.py:55-56,66-86,136-160: `dispersion` / `inflation` of the gene output.  'full': a Dense head on the decoder output (per cell and
+  # gene); otherwise the reference builds NO head and the distribution layer keeps its own variable -- frozen here as [3P-recall]
+  # 'share' (alias 'gene'): ONE trainable vector [G] shared by every cell (tensor out1/b resp. out2/b WITHOUT a kernel out{c}/W), zero
+  # initial value, fed like the head's output: theta = exp(r_g) (scvi.py:139-140), gate logits g_g.
+  dispersion: str = "full"
+  inflation: str = "full"
   batchnorm: bool = True
   dropout_enc: float = 0.1
   dropout_dec: float = 0.1
@@ -157,8 +172,13 @@ class Spec:
     assert self.likelihood in OUTPUT_POSTERIORS, self.likelihood
     if self.model == "scvi":
       assert self.likelihood in ("nbd", "zinbd")  # scvi.py:50-52
-    for _, llk in self.labels:
+    for _, llk in self.labels + self.extra_outputs:
       assert llk in LABEL_LIKELIHOODS, llk
+    assert self.dispersion in ("full", "share") and self.inflation in ("full", "share"), (self.dispersion, self.inflation)
+    if self.model != "scvi":
+      assert self.dispersion == "full" and self.inflation == "full", "dispersion / inflation are options of scvi (scvi.py:55-56)"
+    if self.extra_outputs:
+      assert self.model != "fvae" and not self.latent_mixture, "extra outputs are not built for fvae / the mixture-density posterior"
     if self.model == "fvae":
       assert len(self.labels) <= 1 and all(llk == "onehot" for _, llk in self.labels), "SemiFVAE: one 'onehot' label variable"
       assert self.disc_layers >= 1 and self.disc_units >= 1 and 0.0 <= self.disc_leak < 1.0
@@ -185,6 +205,16 @@ class Spec:
   def disc_outputs(self) -> int:
     """Logits of the fvae discriminator: 1 (FVAE) or the number of classes (SemiFVAE)."""
     return self.labels[0][0] if self.labels else 1
+
+  @property
+  def heads(self):
+    """Heads on the decoder output as (dim, kind, observed): the extra outputs (fully observed, weight 1), then the label variables
+    (weight alpha, per-cell label mask).  SemiFVAE's labels go to the discriminator: no head."""
+    return tuple((P, k, True) for P, k in self.extra_outputs) + (() if self.model == "fvae" else tuple((P, k, False) for P, k in self.labels))
+
+  def head_plane(self, c: int) -> bool:
+    """scvi: whether plane c of the gene output (0 MeanScale, 1 Dispersion, 2 DropoutLogits) is a Dense head (scvi.py:66-86)."""
+    return c == 0 or (c == 1 and self.dispersion == "full") or (c == 2 and self.inflation == "full")
 
 
 def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
@@ -226,12 +256,13 @@ def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
     # three separate Dense heads (scvi.py:67-86): MeanScale, Dispersion,
     # DropoutLogits -- separate tensors for per-tensor clipnorm.
     for c in range(spec.k):
-      out.append((f"out{c}/W", (hd, G)))
-      out.append((f"out{c}/b", (G,)))
+      if spec.head_plane(c):
+        out.append((f"out{c}/W", (hd, G)))
+      out.append((f"out{c}/b", (G,)))   # (no head: the shared per-gene vector itself)
   else:
     out.append(("out/W", (hd, spec.k * G)))
     out.append(("out/b", (spec.k * G,)))
-  for j, (P, llk) in enumerate(() if spec.model == "fvae" else spec.labels):   # (SemiFVAE's labels go to the discriminator)
+  for j, (P, llk, _) in enumerate(spec.heads):
     ky = label_planes(llk, P)
     out.append((f"lab{j}/W", (hd, ky * P)))
     out.append((f"lab{j}/b", (ky * P,)))
@@ -517,10 +548,11 @@ def label_llk(y, raw, llk_kind):
   'nb' (ADT counts, configs/base.yaml:38-40), 'onehot' (cell types, :41-43), 'mixnbC' (MISA, sisua/models/vae.py:47-98:
   every label dimension is a C-component mixture of negative binomials, independent across dimensions --
   [3P-recall] odin's mixture-NB layer: log p(y_p) = logsumexp_c(log softmax(a)_pc + log NB(y_p; exp(r_pc), l_pc)))."""
-  if llk_kind == "nb":
-    P = raw.shape[1] // 2
-    ell, (da, dl) = count_llk(y, [raw[:, :P], raw[:, P:]], "nb")
-    return ell.sum(1), np.concatenate([da, dl], axis=1)
+  if llk_kind in ("nb", "nbd", "zinb", "zinbd"):   # a count posterior over the head's P dimensions, planes as for the gene output
+    kk = n_params_per_gene(llk_kind)
+    P = raw.shape[1] // kk
+    ell, ds = count_llk(y, [raw[:, c * P:(c + 1) * P] for c in range(kk)], llk_kind)
+    return ell.sum(1), np.concatenate(ds, axis=1)
   if llk_kind.startswith("mixtril"):
     return _mixtril_llk(y, raw, mixture_components(llk_kind))
   if llk_kind.startswith("mix"):
@@ -810,7 +842,7 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
                       STREAM_DEC_DROPOUT, spec.dropout_dec, new_bn)
   k = spec.k
   if spec.model == "scvi":
-    raw = [d @ params[f"out{c}/W"] + params[f"out{c}/b"] for c in range(k)]
+    raw = [(d @ params[f"out{c}/W"] if spec.head_plane(c) else 0.0) + np.broadcast_to(params[f"out{c}/b"], (B, G)) for c in range(k)]
     m = raw[0].max(1, keepdims=True)
     e = np.exp(raw[0] - m)
     rho_raw = e / e.sum(1, keepdims=True)
@@ -828,7 +860,7 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
   out["x_params"] = planes
 
   # ---- label heads (vae.py:19-44) -------------------------------------------
-  llk_y = np.zeros(B)
+  llk_y, llk_o = np.zeros(B), np.zeros(B)
   lab_raw, lab_d = [], []
   mvec = np.zeros(B) if mask is None else np.asarray(mask, dtype=np.float64).reshape(B)
   fac = None
@@ -836,25 +868,28 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
     fac = _factor_forward(spec, params, z, noise.uniform(STREAM_PERMUTE, D), y[0] if spec.labels else None, mvec)
     llk_y = -fac["sup"]      # (already masked; the mask is idempotent below)
     out.update(disc_logits=fac["logits"])
-  for j, (P, kind) in enumerate(() if spec.model == "fvae" else spec.labels):
+  for j, (P, kind, observed) in enumerate(spec.heads):
     rawy = d @ params[f"lab{j}/W"] + params[f"lab{j}/b"]
     ly, dly = label_llk(np.asarray(y[j], dtype=np.float64), rawy, kind)
-    llk_y = llk_y + ly
+    if observed:
+      llk_o = llk_o + ly
+    else:
+      llk_y = llk_y + ly
     lab_raw.append(rawy)
     lab_d.append(dly)
   out["y_params"] = lab_raw
 
   # ---- ELBO (SURVEY a-15) ----------------------------------------------------
-  elbo = llk_x + spec.alpha * mvec * llk_y - spec.beta * (kl + kl_l)
+  elbo = llk_x + llk_o + spec.alpha * mvec * llk_y - spec.beta * (kl + kl_l)
   loss = float(-elbo.mean())
   metrics = dict(loss=loss, nllk_x=float(-llk_x.mean()), nllk_y=float(-(mvec * llk_y).mean()), kl=float(kl.mean()),
-                 kl_l=float(kl_l.mean()))
+                 kl_l=float(kl_l.mean()), nllk_o=float(-llk_o.mean()))
   if fac is not None:
     loss = loss + spec.gamma * float(fac["tc"].mean())           # J_vae
     dtc = float(fac["dloss"].mean() + spec.alpha * fac["sup"].mean())   # J_d
     metrics.update(loss=loss, tc=float(fac["tc"].mean()), dtc_loss=dtc)
     out.update(dtc_loss=dtc)
-  out.update(loss=loss, elbo=elbo, llk_x=llk_x, llk_y=llk_y, kl=kl, kl_l=kl_l, metrics=metrics, new_bn=new_bn)
+  out.update(loss=loss, elbo=elbo, llk_x=llk_x, llk_y=llk_y, llk_o=llk_o, kl=kl, kl_l=kl_l, metrics=metrics, new_bn=new_bn)
   if not backward:
     return out
 
@@ -863,8 +898,8 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
   c_x = -1.0 / B                       # d loss / d llk_x[b]
   c_kl = spec.beta / B                 # d loss / d kl[b]
   dd = np.zeros_like(d)
-  for j, (P, kind) in enumerate(() if spec.model == "fvae" else spec.labels):
-    draw = lab_d[j] * (c_x * spec.alpha * mvec)[:, None]
+  for j, (P, kind, observed) in enumerate(spec.heads):
+    draw = lab_d[j] * (c_x if observed else (c_x * spec.alpha * mvec)[:, None])
     grads[f"lab{j}/W"] = d.T @ draw
     grads[f"lab{j}/b"] = draw.sum(0)
     dd += draw @ params[f"lab{j}/W"].T
@@ -878,9 +913,10 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
     dl = dlhat * ((l > 0.0) & (l < spec.clip_library))
     draws = [draw0, dtheta * theta] + ([dplanes[2] * c_x] if k == 3 else [])
     for c in range(k):
-      grads[f"out{c}/W"] = d.T @ draws[c]
       grads[f"out{c}/b"] = draws[c].sum(0)
-      dd += draws[c] @ params[f"out{c}/W"].T
+      if spec.head_plane(c):
+        grads[f"out{c}/W"] = d.T @ draws[c]
+        dd += draws[c] @ params[f"out{c}/W"].T
     out["d_x_params"] = draws
   else:
     draw_all = np.concatenate(dplanes, axis=1) * c_x

@@ -13,13 +13,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsisua_hip.so")
 
-SMX_ABI_VERSION = 3
+SMX_ABI_VERSION = 4
 SMX_MAX_LAYERS = 8
 SMX_MAX_LABELS = 4
 
 MODEL_KINDS = {"vae": 0, "dca": 1, "scvi": 2, "sisua": 3, "scale": 4, "fvae": 5, "scale_tril": 6, "scale_post": 7}
 LIKELIHOODS = {"nb": 0, "zinb": 1, "nbd": 2, "zinbd": 3, "mse": 4}
-LABEL_LIKELIHOODS = {"nb": 0, "onehot": 1, "mixnb": 2, "mixgauss": 3, "mixtril": 4, "mixzinb": 5}
+LABEL_LIKELIHOODS = {"nb": 0, "onehot": 1, "mixnb": 2, "mixgauss": 3, "mixtril": 4, "mixzinb": 5, "nbd": 6, "zinb": 7, "zinbd": 8}
+SCVI_PLANE_OPTIONS = {"full": 0, "share": 1}
 ACTIVATIONS = {"relu": 0, "linear": 1}
 
 
@@ -35,7 +36,8 @@ class smx_config(C.Structure):
       ("n_dec", C.c_int32), ("dec_units", C.c_int32 * SMX_MAX_LAYERS),
       ("n_encl", C.c_int32), ("encl_units", C.c_int32 * SMX_MAX_LAYERS),
       ("n_labels", C.c_int32), ("label_dim", C.c_int32 * SMX_MAX_LABELS), ("label_llk", C.c_int32 * SMX_MAX_LABELS),
-      ("label_components", C.c_int32 * SMX_MAX_LABELS), ("n_components", C.c_int32),
+      ("label_components", C.c_int32 * SMX_MAX_LABELS), ("label_observed", C.c_int32 * SMX_MAX_LABELS),
+      ("scvi_dispersion", C.c_int32), ("scvi_inflation", C.c_int32), ("n_components", C.c_int32),
       ("disc_units", C.c_int32), ("disc_layers", C.c_int32), ("gamma", C.c_float), ("disc_leak", C.c_float),
       ("batchnorm", C.c_int32), ("log_norm", C.c_int32), ("latent_activation", C.c_int32),
       ("dropout_enc", C.c_float), ("dropout_dec", C.c_float), ("input_dropout", C.c_float),
@@ -50,7 +52,7 @@ class smx_config(C.Structure):
 class smx_metrics(C.Structure):
   _fields_ = [("loss", C.c_float), ("nllk_x", C.c_float), ("nllk_y", C.c_float), ("kl", C.c_float),
               ("kl_l", C.c_float), ("grad_norm_max", C.c_float), ("nan_flag", C.c_int32), ("step", C.c_int32),
-              ("tc", C.c_float), ("dtc_loss", C.c_float)]
+              ("tc", C.c_float), ("dtc_loss", C.c_float), ("nllk_o", C.c_float)]
 
   def as_dict(self):
     return {k: getattr(self, k) for k, _ in self._fields_}

@@ -31,6 +31,8 @@ def label_planes(llk: str, P: int = 0) -> int:
     return mixture_components(llk) * (2 + P)
   if llk.startswith("mixzinb"):   # MISA(zero_inflated=True, vae.py:76-84): the 'mixnb' planes + C zero-inflation gate logits
     return 4 * mixture_components(llk)
+  if llk in ("nbd", "zinb", "zinbd"):   # the other count posteriors as heads (vae.py:30): planes as for the gene output
+    return 2 if llk == "nbd" else 3
   return 2 if llk == "nb" else 1 if llk == "onehot" else 3 * mixture_components(llk)
 
 
@@ -99,6 +101,12 @@ class ModelConfig:
   latent_dim: int = 10
   encl_units: Tuple[int, ...] = (64,)
   labels: Tuple[Tuple[int, str], ...] = ()
+  # outputs[1:] of the reference's constructors (tests/test_singlecell_models.py:129-141; scvi.py:168-169): further fully observed
+  # output variables -- heads on the decoder output with weight 1 and no label mask.  Heads are ordered extra outputs, then labels.
+  extra_outputs: Tuple[Tuple[int, str], ...] = ()
+  # scvi.py:55-56,66-86: 'full' = a Dense head; 'share' = one trainable per-gene vector (out1/b resp. out2/b without a kernel)
+  dispersion: str = "full"
+  inflation: str = "full"
   batchnorm: bool = True
   dropout_enc: float = 0.1
   dropout_dec: float = 0.1
@@ -160,8 +168,22 @@ class ModelConfig:
 
   @property
   def head_labels(self):
-    """Label variables that have a head on the decoder (SemiFVAE's one-hot labels are classified by the discriminator)."""
-    return () if self.model == "fvae" else self.labels
+    """(dim, kind) of every head on the decoder output: the extra outputs, then the label variables (SemiFVAE's one-hot labels are
+    classified by the discriminator: no head)."""
+    return self.extra_outputs + (() if self.model == "fvae" else self.labels)
+
+  @property
+  def targets(self):
+    """(dim, kind) of the target arrays a dataset carries beside the counts, in upload order: extra outputs, then labels."""
+    return self.extra_outputs + self.labels
+
+  def head_plane(self, c: int) -> bool:
+    """scvi: whether plane c of the gene output (0 MeanScale, 1 Dispersion, 2 DropoutLogits) is a Dense head (scvi.py:66-86)."""
+    if self.dispersion not in ("full", "share") or self.inflation not in ("full", "share"):
+      raise ValueError(f"dispersion / inflation must be 'full' or 'share', given: {self.dispersion} / {self.inflation}")
+    if self.model != "scvi" and (self.dispersion != "full" or self.inflation != "full"):
+      raise ValueError("dispersion / inflation are options of scvi (scvi.py:55-56)")
+    return c == 0 or (c == 1 and self.dispersion == "full") or (c == 2 and self.inflation == "full")
 
   def to_dict(self):
     return dataclasses.asdict(self)
@@ -185,7 +207,9 @@ def manifest(cfg: ModelConfig) -> List[Tuple[str, Tuple[int, ...]]]:
 
   G, D = cfg.n_genes, cfg.latent_dim
   h = mlp("enc", G, cfg.enc_units)
-  _ = cfg.scale_tril   # (validates the SCALE options)
+  _ = cfg.scale_tril, cfg.head_plane(0)   # (validates the SCALE / scvi options)
+  if cfg.extra_outputs and (cfg.model == "fvae" or cfg.latent_mixture):
+    raise ValueError("extra outputs are not built for FVAE / the mixture-density posterior")
   nl = (1 + 2 * cfg.n_components) * D if cfg.latent_mixture else (2 * D if cfg.stochastic else D)
   out += [("lat/W", (h, nl)), ("lat/b", (nl,))]
   if cfg.model == "scale" and not cfg.latent_mixture:
@@ -203,7 +227,7 @@ def manifest(cfg: ModelConfig) -> List[Tuple[str, Tuple[int, ...]]]:
     out += [("discout/W", (n_in, cfg.disc_outputs)), ("discout/b", (cfg.disc_outputs,))]
   if cfg.model == "scvi":
     for c in range(cfg.k):
-      out += [(f"out{c}/W", (hd, G)), (f"out{c}/b", (G,))]
+      out += ([(f"out{c}/W", (hd, G))] if cfg.head_plane(c) else []) + [(f"out{c}/b", (G,))]
   else:
     out += [("out/W", (hd, cfg.k * G)), ("out/b", (cfg.k * G,))]
   for j, (P, llk) in enumerate(cfg.head_labels):

@@ -210,9 +210,10 @@ struct MetricsArgs {
   const float* llk_part = nullptr; int n_chunks = 0;   // [B][n_chunks]
   const float* lgx1 = nullptr; const int32_t* rows = nullptr;  // per-cell sum lgamma(x+1), gathered
   const float* llk_y = nullptr;   // [B] masked label llk or nullptr
+  const float* llk_o = nullptr;   // [B] log-likelihood of the observed extra outputs (weight 1) or nullptr -> out[7]
   const float* kl = nullptr; const float* kl_l = nullptr;
   int B = 0; float alpha = 0.f, beta = 1.f; float inv_global_batch = 0.f;
-  float* out = nullptr;           // [8]: loss, nllk_x, nllk_y, kl, kl_l, (5..7 reserved)
+  float* out = nullptr;           // [8]: loss, nllk_x, nllk_y, kl, kl_l, tc, dtc_loss, nllk_o
   // per-step history of a train_steps call (single GPU: written here; data parallel: by the optimiser launch,
   // after the all-reduce): hist[cursor * 8 + i] = out[i]
   float* hist = nullptr; const StepState* state = nullptr;
@@ -361,6 +362,10 @@ struct ScviTrainArgs {
 };
 bool scvi_head_train_supported(const ScviTrainArgs& a);
 int launch_scvi_head_train(hipStream_t st, const ScviTrainArgs& a);
+// a plane of scvi's gene output without a Dense head (dispersion / inflation = 'share', scvi.py:66-86): its per-gene vector copied into
+// every row of the raw plane / the column sum of the plane's d raw (row order)
+int launch_plane_fill(hipStream_t st, float* dst, long ld, const float* v, int B, int Np);
+int launch_plane_colsum(hipStream_t st, const float* src, long ld, float* dst, int B, int Np);
 
 struct LabelArgs {
   int kind = 0;                  // smx_label_likelihood
@@ -369,6 +374,7 @@ struct LabelArgs {
   const float* Y = nullptr; int ldy = 0;           // labels [rows][ldy]
   const int32_t* rows = nullptr;
   const uint8_t* mask = nullptr;                   // resident [n_cells] or nullptr (all unlabeled)
+  int observed = 0;                                // an observed OUTPUT variable (outputs[1:]): every cell counts, the mask is not consulted
   int B = 0, P = 0, Pp = 0;
   float grad_scale = 0.f;        // -alpha / B_global
   float* draw = nullptr;         // [B][ky*Pp]

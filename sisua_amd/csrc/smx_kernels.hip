@@ -1822,12 +1822,13 @@ __global__ __launch_bounds__(256) void label_loss_kernel(LabelArgs a) {
   const long src = a.rows ? a.rows[b] : b;
   const float* y = a.Y + src * a.ldy;
   const float* raw = a.raw + (long)b * a.ld;
-  const float m = a.mask ? (a.mask[src] ? 1.f : 0.f) : 0.f;
+  const float m = a.observed ? 1.f : a.mask ? (a.mask[src] ? 1.f : 0.f) : 0.f;
   const float gs = a.grad_scale * m;
   float llk = 0.f;
   if (m == 0.f) {   // wave-uniform
     if (a.backward) {
-      const int width = (a.kind == SMX_LABEL_NB ? 2 : (a.kind == SMX_LABEL_MIXNB || a.kind == SMX_LABEL_MIXGAUSS) ? 3 * a.C : a.kind == SMX_LABEL_MIXZINB ? 4 * a.C : 1) * a.Pp;
+      const int width = ((a.kind == SMX_LABEL_NB || a.kind == SMX_LABEL_NBD) ? 2 : (a.kind == SMX_LABEL_ZINB || a.kind == SMX_LABEL_ZINBD) ? 3 :
+                         (a.kind == SMX_LABEL_MIXNB || a.kind == SMX_LABEL_MIXGAUSS) ? 3 * a.C : a.kind == SMX_LABEL_MIXZINB ? 4 * a.C : 1) * a.Pp;
       for (int p = lane; p < width; p += 64) a.draw[(long)b * a.ld + p] = 0.f;
     }
   } else if (a.kind == SMX_LABEL_MIXNB || a.kind == SMX_LABEL_MIXGAUSS || a.kind == SMX_LABEL_MIXZINB) {
@@ -1882,15 +1883,24 @@ __global__ __launch_bounds__(256) void label_loss_kernel(LabelArgs a) {
       }
     }
     llk = wave_sum(llk);
-  } else if (a.kind == SMX_LABEL_NB) {
+  } else if (a.kind == SMX_LABEL_NB || a.kind == SMX_LABEL_NBD || a.kind == SMX_LABEL_ZINB || a.kind == SMX_LABEL_ZINBD) {
+    // a count posterior over the head's columns, planes as for the gene output (the elementwise likelihood of smx_loss.h)
+    const bool zi = a.kind == SMX_LABEL_ZINB || a.kind == SMX_LABEL_ZINBD;   // (launch-uniform)
     for (int p = lane; p < a.Pp; p += 64) {
-      float d0 = 0.f, d1 = 0.f;
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f;
       if (p < a.P) {
-        float e, d2;
-        count_elem<SMX_LLK_NB, 0>(y[p], raw[p], raw[a.Pp + p], 0.f, e, d0, d1, d2);
+        float e;
+        const float p2 = zi ? raw[2 * a.Pp + p] : 0.f;
+        if (a.kind == SMX_LABEL_NB) count_elem<SMX_LLK_NB, 0>(y[p], raw[p], raw[a.Pp + p], 0.f, e, d0, d1, d2);
+        else if (a.kind == SMX_LABEL_NBD) count_elem<SMX_LLK_NBD, 0>(y[p], raw[p], raw[a.Pp + p], 0.f, e, d0, d1, d2);
+        else if (a.kind == SMX_LABEL_ZINB) count_elem<SMX_LLK_ZINB, 0>(y[p], raw[p], raw[a.Pp + p], p2, e, d0, d1, d2);
+        else count_elem<SMX_LLK_ZINBD, 0>(y[p], raw[p], raw[a.Pp + p], p2, e, d0, d1, d2);
         llk += e - lgammaf(y[p] + 1.f);
       }
-      if (a.backward) { a.draw[(long)b * a.ld + p] = d0 * gs; a.draw[(long)b * a.ld + a.Pp + p] = d1 * gs; }
+      if (a.backward) {
+        a.draw[(long)b * a.ld + p] = d0 * gs; a.draw[(long)b * a.ld + a.Pp + p] = d1 * gs;
+        if (zi) a.draw[(long)b * a.ld + 2 * a.Pp + p] = d2 * gs;
+      }
     }
     llk = wave_sum(llk);
   } else {
@@ -1932,7 +1942,7 @@ __global__ __launch_bounds__(256) void label_tril_kernel(LabelArgs a) {
   const long src = a.rows ? a.rows[b] : b;
   const float* raw = a.raw + (long)b * a.ld;
   float* draw = a.draw + (long)b * a.ld;
-  const float m = a.mask ? (a.mask[src] ? 1.f : 0.f) : 0.f;
+  const float m = a.observed ? 1.f : a.mask ? (a.mask[src] ? 1.f : 0.f) : 0.f;
   const float gs = a.grad_scale * m;
   const int C = a.C, P = a.P, Pp = a.Pp, ldl = P + 1;
   if (m == 0.f) {   // (block-uniform)
@@ -2048,7 +2058,7 @@ int launch_step_begin(hipStream_t st, StepState* master, StepState* dst, const i
 
 __device__ inline void metrics_body(const MetricsArgs& a) {
   __shared__ float sh[4];
-  float sx = 0.f, sy = 0.f, sk = 0.f, sl = 0.f, st = 0.f, sd = 0.f;
+  float sx = 0.f, sy = 0.f, sk = 0.f, sl = 0.f, st = 0.f, sd = 0.f, so = 0.f;
   // only the batch total of the count log-likelihood is needed: a flat, coalesced sweep of [B][n_chunks]
   const int total = a.B * a.n_chunks;
   {
@@ -2064,20 +2074,22 @@ __device__ inline void metrics_body(const MetricsArgs& a) {
   for (int b = threadIdx.x; b < a.B; b += 256) {
     if (a.lgx1) sx -= a.lgx1[a.rows ? a.rows[b] : b];
     if (a.llk_y) sy += a.llk_y[b];
+    if (a.llk_o) so += a.llk_o[b];
     if (a.kl) sk += a.kl[b];
     if (a.kl_l) sl += a.kl_l[b];
     if (a.tc) { st += a.tc[b]; sd += a.dl[b] + a.dl[a.B + b]; }
   }
   sx = block_sum(sx, sh); sy = block_sum(sy, sh); sk = block_sum(sk, sh); sl = block_sum(sl, sh);
   if (a.tc) { st = block_sum(st, sh); sd = block_sum(sd, sh); }
+  if (a.llk_o) so = block_sum(so, sh);
   if (threadIdx.x == 0) {
     const float s = a.inv_global_batch;
-    a.out[0] = (a.gamma * st - (sx + a.alpha * sy - a.beta * (sk + sl))) * s;
+    a.out[0] = (a.gamma * st - (sx + so + a.alpha * sy - a.beta * (sk + sl))) * s;
     a.out[1] = -sx * s;
     a.out[2] = -sy * s;
     a.out[3] = sk * s;
     a.out[4] = sl * s;
-    a.out[5] = st * s; a.out[6] = a.tc ? (sd - a.alpha * sy) * s : 0.f; a.out[7] = 0.f;
+    a.out[5] = st * s; a.out[6] = a.tc ? (sd - a.alpha * sy) * s : 0.f; a.out[7] = -so * s;
     if (a.hist) {
       float* h = a.hist + (long)a.state->cursor * 8;
 #pragma unroll

@@ -157,8 +157,16 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   SMX_REQUIRE(cfg->likelihood >= SMX_LLK_NB && cfg->likelihood <= SMX_LLK_MSE, "unknown likelihood");
   SMX_REQUIRE(cfg->n_labels >= 0 && cfg->n_labels <= SMX_MAX_LABELS, "too many label heads");
   // (SCALE with label heads = SCALAR, sisua/models/scale.py:52-59: the mixture prior of SCALE under SISUA's semi-supervised heads)
-  SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->model == SMX_MODEL_FVAE || cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL || cfg->n_labels == 0,
+  int n_observed = 0;
+  for (int j = 0; j < cfg->n_labels; ++j) {
+    if (cfg->label_observed[j]) { SMX_REQUIRE(j == n_observed, "observed output heads come before the label heads"); ++n_observed; }
+  }
+  // (outputs[1:], tests/test_singlecell_models.py:129-141 / scvi.py:168-169: observed heads on any model's decoder output)
+  SMX_REQUIRE(n_observed == 0 || (cfg->model != SMX_MODEL_FVAE && cfg->model != SMX_MODEL_SCALE_POST), "extra outputs are not built for FVAE / the mixture-density posterior");
+  SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->model == SMX_MODEL_FVAE || cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL || cfg->n_labels == n_observed,
               "label heads need model = SISUA, SCALE (SCALAR) or FVAE (SemiFVAE)");
+  SMX_REQUIRE(cfg->scvi_dispersion >= 0 && cfg->scvi_dispersion <= 1 && cfg->scvi_inflation >= 0 && cfg->scvi_inflation <= 1, "scvi_dispersion / scvi_inflation: 0 ('full') or 1 ('share')");
+  SMX_REQUIRE(cfg->model == SMX_MODEL_SCVI || (cfg->scvi_dispersion == 0 && cfg->scvi_inflation == 0), "dispersion / inflation are options of scvi");
   if (cfg->model == SMX_MODEL_SCVI) {
     SMX_REQUIRE(cfg->likelihood == SMX_LLK_NBD || cfg->likelihood == SMX_LLK_ZINBD, "scvi supports nbd / zinbd only");
     SMX_REQUIRE(cfg->n_encl >= 1 && cfg->n_encl <= SMX_MAX_LAYERS, "scvi needs a library encoder");
@@ -174,7 +182,8 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   m->stochastic = cfg->model != SMX_MODEL_DCA; m->scvi = cfg->model == SMX_MODEL_SCVI; m->scale = cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL; m->scale_tril = cfg->model == SMX_MODEL_SCALE_TRIL;
   m->mixpost = cfg->model == SMX_MODEL_SCALE_POST;
   m->lat_planes = m->mixpost ? 1 + 2 * cfg->n_components : (m->stochastic ? 2 : 1);
-  m->fvae = cfg->model == SMX_MODEL_FVAE; m->n_heads = m->fvae ? 0 : cfg->n_labels;
+  m->fvae = cfg->model == SMX_MODEL_FVAE; m->n_heads = m->fvae ? 0 : cfg->n_labels; m->n_observed = n_observed;
+  m->out_has_W[1] = cfg->scvi_dispersion == 0; m->out_has_W[2] = cfg->scvi_inflation == 0;
   m->Bmax = cfg->max_batch;
   int rc = SMX_OK;
   auto fail = [&](int code) { smx_model_destroy(m); return code; };
@@ -205,8 +214,8 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     if (cfg->n_labels) m->lab_Pp[0] = round_up(cfg->label_dim[0], 32);
   }
   if (m->scvi) {
-    for (int ch = 0; ch < m->k; ++ch) {
-      m->t_outW[ch] = add_tensor(m, "out" + std::to_string(ch) + "/W", hd, m->G, 1, false);
+    for (int ch = 0; ch < m->k; ++ch) {   // (scvi.py:66-86: no Dense head for a 'share'd plane -- its per-gene vector is out{ch}/b alone)
+      if (m->out_has_W[ch]) m->t_outW[ch] = add_tensor(m, "out" + std::to_string(ch) + "/W", hd, m->G, 1, false);
       m->t_outb[ch] = add_tensor(m, "out" + std::to_string(ch) + "/b", 1, m->G, 1, true);
     }
   } else {
@@ -215,12 +224,13 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   }
   for (int j = 0; j < m->n_heads; ++j) {
     SMX_REQUIRE(cfg->label_dim[j] > 0, "label_dim must be > 0");
-    SMX_REQUIRE(cfg->label_llk[j] >= SMX_LABEL_NB && cfg->label_llk[j] <= SMX_LABEL_MIXZINB, "unknown label likelihood");
-    if (cfg->label_llk[j] >= SMX_LABEL_MIXNB) SMX_REQUIRE(cfg->label_components[j] >= 2 && cfg->label_components[j] <= 4, "mixture label heads have 2..4 components");
+    SMX_REQUIRE(cfg->label_llk[j] >= SMX_LABEL_NB && cfg->label_llk[j] <= SMX_LABEL_ZINBD, "unknown label likelihood");
+    if (cfg->label_llk[j] >= SMX_LABEL_MIXNB && cfg->label_llk[j] <= SMX_LABEL_MIXZINB) SMX_REQUIRE(cfg->label_components[j] >= 2 && cfg->label_components[j] <= 4, "mixture label heads have 2..4 components");
     if (cfg->label_llk[j] == SMX_LABEL_MIXTRIL) SMX_REQUIRE(cfg->label_dim[j] <= 64, "'mixtril' label heads take at most 64 label dimensions");
     // planes of the head: (log total_count, logits) | logits | C x (mixture logit, two component parameters) | 'mixtril': C mixture-logit
     // planes, C location planes, C x P planes = the columns of the components' scale factors (label_tril_kernel)
-    m->lab_ky[j] = cfg->label_llk[j] == SMX_LABEL_NB ? 2 : cfg->label_llk[j] == SMX_LABEL_ONEHOT ? 1 :
+    m->lab_ky[j] = (cfg->label_llk[j] == SMX_LABEL_NB || cfg->label_llk[j] == SMX_LABEL_NBD) ? 2 : (cfg->label_llk[j] == SMX_LABEL_ZINB || cfg->label_llk[j] == SMX_LABEL_ZINBD) ? 3 :
+                   cfg->label_llk[j] == SMX_LABEL_ONEHOT ? 1 :
                    cfg->label_llk[j] == SMX_LABEL_MIXTRIL ? cfg->label_components[j] * (2 + cfg->label_dim[j]) :
                    cfg->label_llk[j] == SMX_LABEL_MIXZINB ? 4 * cfg->label_components[j] : 3 * cfg->label_components[j];
     m->lab_Pp[j] = round_up(cfg->label_dim[j], 32);
@@ -301,7 +311,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
       (rc = dmalloc(&m->z, B * m->Dp)) || (rc = dmalloc(&m->noise_eps, B * m->Dp)) || (rc = dmalloc(&m->sig, B * m->Dp)) || (rc = dmalloc(&m->eps, B * m->Dp)) ||
       (rc = dmalloc(&m->kl, B)) || (rc = dmalloc(&m->P, B * ldp)) || (rc = dmalloc(&m->dP, B * ldp)) ||
-      (rc = dmalloc(&m->llk_part, B * (size_t)std::max(loss_chunks_max(m->Gp), head_loss_chunks(m->Gp)))) || (rc = dmalloc(&m->llk_y, B)) ||
+      (rc = dmalloc(&m->llk_part, B * (size_t)std::max(loss_chunks_max(m->Gp), head_loss_chunks(m->Gp)))) || (rc = dmalloc(&m->llk_y, B)) || (rc = dmalloc(&m->llk_o, B)) ||
       (rc = dmalloc(&m->rows2[0], B)) || (rc = dmalloc(&m->rows2[1], B)) || (rc = dmalloc(&m->state3, (size_t)3)) ||
       (rc = dmalloc(&m->hostX, B * m->Gp)) || (rc = dmalloc(&m->hostLib, B * 2)) || (rc = dmalloc(&m->hostLgx1, B)))
     return fail(rc);
@@ -395,7 +405,7 @@ int smx_model_destroy(smx_model* m) {
   fr(m->zz); fr(m->u_d); fr(m->tc_cell); fr(m->dl_cell); fr(m->dz_tc); fr(m->disc_dpre); fr(m->disc_db);
   fr(m->noise_eps); fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);
   fr(m->latlbuf); fr(m->dlatl); fr(m->lsmp); fr(m->lsig); fr(m->leps); fr(m->kl_l); fr(m->dl);
-  fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->slab);
+  fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->llk_o); fr(m->slab);
   fr(m->chunks); fr(m->partial); fr(m->tensor_norm); fr(m->sq_slots);
   if (m->pinned) hipHostFree(m->pinned);
   if (m->order_pin) hipHostFree(m->order_pin);

@@ -126,6 +126,10 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
     SMX_CHECK(stacked_decoder(m, z, rows, hb, m->scvi ? 0 : (wide_head ? 1 : 2), ht, &in, &ld));
     if (m->scvi) {
       for (int ch = 0; ch < m->k; ++ch) {
+        if (!m->out_has_W[ch]) {   // (dispersion / inflation = 'share': the per-gene vector in every row)
+          SMX_CHECK(launch_plane_fill(m->st, raw + (size_t)ch * m->Gp, (long)raw_ld, P_(m, m->t_outb[ch]), (int)rows, m->Gp));
+          continue;
+        }
         GemmArgs g;
         g.A = in; g.lda = ld; g.B = P_(m, m->t_outW[ch]); g.ldb = m->tensors[m->t_outW[ch]].ld;
         g.C = raw + (size_t)ch * m->Gp; g.ldc = (int)raw_ld; g.M = (int)rows; g.N = m->Gp; g.K = ld; g.bias = P_(m, m->t_outb[ch]); g.split_k = 1;

@@ -200,4 +200,32 @@ int launch_scvi_head_train(hipStream_t st, const ScviTrainArgs& a) {
   return SMX_OK;
 }
 
+// ---- scvi.py:55-56,66-86: a plane of the gene output WITHOUT a Dense head (dispersion / inflation = 'share') ----------------
+// The plane's raw value is one trainable per-gene vector v[g] shared by every cell: forward = the vector copied into every row of the
+// raw plane (what the head's product + bias leaves for a 'full' plane, so every consumer downstream is unchanged), backward = the
+// column sum of the plane's d raw in row order (deterministic); no kernel, no d d contribution.
+__global__ __launch_bounds__(256) void plane_fill_kernel(float* dst, long ld, const float* v, int B, int Np) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= Np) return;
+  const float x = v[g];
+  for (int b = blockIdx.y; b < B; b += gridDim.y) dst[(long)b * ld + g] = x;
+}
+__global__ __launch_bounds__(256) void plane_colsum_kernel(const float* src, long ld, float* dst, int B, int Np) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= Np) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += src[(long)b * ld + g];
+  dst[g] = s;
+}
+int launch_plane_fill(hipStream_t st, float* dst, long ld, const float* v, int B, int Np) {
+  hipLaunchKernelGGL(plane_fill_kernel, dim3((Np + 255) / 256, std::min(B, 16)), dim3(256), 0, st, dst, ld, v, B, Np);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+int launch_plane_colsum(hipStream_t st, const float* src, long ld, float* dst, int B, int Np) {
+  hipLaunchKernelGGL(plane_colsum_kernel, dim3((Np + 255) / 256), dim3(256), 0, st, src, ld, dst, B, Np);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
 }  // namespace smx

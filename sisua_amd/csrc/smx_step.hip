@@ -565,9 +565,14 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   const long ldp = (long)m->k * m->Gp;
   if (m->scvi) {
     GemmArgs hg[3];
+    int n_hg = 0;
     for (int ch = 0; ch < m->k; ++ch) {
+      if (!m->out_has_W[ch]) {   // dispersion / inflation = 'share' (scvi.py:66-86): the per-gene vector in every row of the raw plane
+        SMX_CHECK(launch_plane_fill(m->st, m->raw + (long)ch * m->Gp, ldp, P_(m, m->t_outb[ch]), ps.B, m->Gp));
+        continue;
+      }
       const TensorInfo& tw = m->tensors[m->t_outW[ch]];
-      GemmArgs& g = hg[ch];
+      GemmArgs& g = hg[n_hg++];
       g.A = dL.out_buf; g.lda = dL.out_p; g.B = P_(m, m->t_outW[ch]); g.ldb = tw.ld;
       g.C = m->raw + (long)ch * m->Gp; g.ldc = (int)ldp; g.M = ps.B; g.N = m->Gp; g.K = dL.out_p;
       g.bias = P_(m, m->t_outb[ch]);
@@ -577,8 +582,8 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
       const bool no_twin = !m->flags.twin;
       Timed t(m, "gemm_out_fwd");
       int ch = 0;
-      for (; !no_twin && ch + 1 < m->k; ch += 2) SMX_CHECK(launch_gemm_dual(m->st, hg[ch], hg[ch + 1]));
-      for (; ch < m->k; ++ch) SMX_CHECK(launch_gemm(m->st, hg[ch]));
+      for (; !no_twin && ch + 1 < n_hg; ch += 2) SMX_CHECK(launch_gemm_dual(m->st, hg[ch], hg[ch + 1]));
+      for (; ch < n_hg; ++ch) SMX_CHECK(launch_gemm(m->st, hg[ch]));
     }
   }
   if (m->scvi && m->scvi_fused) {
@@ -653,7 +658,11 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     LabelArgs lb;
     lb.kind = c.label_llk[j]; lb.C = c.label_components[j]; lb.raw = m->laby_raw[j]; lb.ld = tw.ld; lb.Y = m->Y[j]; lb.ldy = m->lab_Pp[j];
     lb.rows = ps.rows; lb.mask = m->mask; lb.B = ps.B; lb.P = c.label_dim[j]; lb.Pp = m->lab_Pp[j];
-    lb.grad_scale = -c.alpha * inv_gb; lb.draw = m->laby_draw[j]; lb.llk = m->llk_y; lb.add = (j > 0);
+    // an observed output variable (outputs[1:]): weight 1, every cell, its own accumulator; a label variable: alpha, the label mask
+    const bool obs = j < m->n_observed;
+    lb.observed = obs ? 1 : 0;
+    lb.grad_scale = obs ? -inv_gb : -c.alpha * inv_gb; lb.draw = m->laby_draw[j];
+    lb.llk = obs ? m->llk_o : m->llk_y; lb.add = obs ? (j > 0) : (j > m->n_observed);
     lb.backward = backward;
     SMX_CHECK(launch_label_loss(m->st, lb));
   }
@@ -661,7 +670,8 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   MetricsArgs me;
   me.llk_part = m->llk_part; me.n_chunks = n_llk_chunks; me.rows = ps.rows;
   me.lgx1 = c.likelihood == SMX_LLK_MSE ? nullptr : ps.lgx1;   // (the count likelihoods' data-only constant sum_g lgamma(x + 1))
-  me.llk_y = c.n_labels ? m->llk_y : nullptr;
+  me.llk_y = c.n_labels > m->n_observed ? m->llk_y : nullptr;
+  me.llk_o = m->n_observed ? m->llk_o : nullptr;
   if (m->fvae) { me.tc = m->tc_cell; me.dl = m->dl_cell; me.gamma = c.gamma; }
   me.kl = m->stochastic ? m->kl : nullptr; me.kl_l = m->scvi ? m->kl_l : nullptr;
   me.B = ps.B; me.alpha = c.alpha; me.beta = c.beta; me.inv_global_batch = inv_gb;
@@ -948,7 +958,8 @@ int backward_pass(smx_model* m, const Pass& ps) {
   // count heads with raw planes: both products of the output head in one launch of the wide direct-operand kernel
   // (smx_headbwd.hip); SMX_NO_HEAD_BWD=1 or scvi: the grouped LDS-tiled products below
   // (scvi: the planes are separate head tensors -- the kernel's SEP form)
-  const bool hbwd = m->flags.head_bwd && head_bwd_supported(ps.B, dL.out_p, m->Gp) && m->k >= 2 && m->k <= 3;
+  const bool all_heads = m->out_has_W[1] && (m->k < 3 || m->out_has_W[2]);   // (scvi with a 'share'd plane: the grouped products below)
+  const bool hbwd = m->flags.head_bwd && head_bwd_supported(ps.B, dL.out_p, m->Gp) && m->k >= 2 && m->k <= 3 && all_heads;
   if (hbwd) {
     const TensorInfo& tw = m->tensors[m->t_outW[0]];
     HeadBwdArgs hb;
@@ -974,7 +985,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
     n_slabs = hb.n_slices;
     // label heads (SISUA / MISA): d d += d Y W_lab^T as extra slabs of this launch, the head's weight gradient with the
     // grouped launch at the end of the backward pass -- instead of a grouped launch of their own here (8.6 us at C4)
-    if (m->n_heads > 0 && m->flags.label_ride && !m->fvae) {
+    if (m->n_heads > 0 && m->flags.label_ride && !m->fvae && !m->scvi) {
       bool ok = true;
       for (int j = 0; j < m->n_heads; ++j) ok = ok && (m->tensors[m->t_labW[j]].ld % 32) == 0;
       ok = ok && (size_t)(hb.n_slices + m->n_heads) * (size_t)dd_stride <= m->slab_cap;
@@ -1016,6 +1027,10 @@ int backward_pass(smx_model* m, const Pass& ps) {
     std::vector<GemmArgs> grp;
     std::vector<int> is_dx;
     for (int ch = 0; ch < n_heads && !hbwd; ++ch) {
+      if (m->scvi && !m->out_has_W[ch]) {   // no Dense head: the per-gene vector's gradient is the column sum of the plane's d raw
+        SMX_CHECK(launch_plane_colsum(m->st, dparams + (long)ch * m->Gp, ldp, G_(m, m->t_outb[ch]), ps.B, m->Gp));
+        continue;
+      }
       const TensorInfo& tw = m->tensors[m->t_outW[ch]];
       const float* dp = dparams + (m->scvi ? (long)ch * m->Gp : 0);
       const int ncols = m->scvi ? m->Gp : (int)ldp;
@@ -1329,7 +1344,8 @@ int read_metrics(smx_model* m, smx_metrics* out) {
   out->grad_norm_max = mx;
   out->nan_flag = !(isfinite(h[0]) && isfinite(h[1]) && isfinite(h[3]) && isfinite(mx));
   out->step = (int32_t)m->h_next;
-  out->tc = h[5]; out->dtc_loss = h[6];
+  out->tc = h[5]; out->dtc_loss = h[6]; out->nllk_o = h[7];
+  if (m->n_observed && !isfinite(h[7])) out->nan_flag = 1;
   if (m->fvae && !(isfinite(h[5]) && isfinite(h[6]))) out->nan_flag = 1;
   return SMX_OK;
 }

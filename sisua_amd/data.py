@@ -264,6 +264,11 @@ class SingleCellOMIC:
   def n_obs(self):
     return next(iter(self._data.values())).shape[0]
 
+  @property
+  def n_vars(self):
+    """Number of variables of the first OMIC (AnnData's n_vars; tests/test_singlecell_models.py:127)."""
+    return next(iter(self._data.values())).shape[1]
+
   def get_omic(self, omic):
     return self._data[str(omic)]
 

@@ -47,13 +47,16 @@ def make_smx_config(cfg: ModelConfig, max_batch: int) -> smx_config:
     arr = getattr(c, f"{name}_units")
     for i, u in enumerate(units):
       arr[i] = int(u)
-  if len(cfg.labels) > _hip.SMX_MAX_LABELS:
-    raise ValueError(f"at most {_hip.SMX_MAX_LABELS} label heads")
-  c.n_labels = len(cfg.labels)
-  for j, (P, llk) in enumerate(cfg.labels):
+  if len(cfg.targets) > _hip.SMX_MAX_LABELS:
+    raise ValueError(f"at most {_hip.SMX_MAX_LABELS} heads (extra outputs + label variables)")
+  c.n_labels = len(cfg.targets)
+  for j, (P, llk) in enumerate(cfg.targets):
     c.label_dim[j] = int(P)
     c.label_llk[j] = _hip.LABEL_LIKELIHOODS[llk[:-1] if llk.startswith("mix") else llk]
     c.label_components[j] = int(llk[-1]) if llk.startswith("mix") else 1
+    c.label_observed[j] = 1 if j < len(cfg.extra_outputs) else 0
+  c.scvi_dispersion = _hip.SCVI_PLANE_OPTIONS[cfg.dispersion]
+  c.scvi_inflation = _hip.SCVI_PLANE_OPTIONS[cfg.inflation]
   c.batchnorm, c.log_norm = int(cfg.batchnorm), int(cfg.log_norm)
   c.latent_activation = _hip.ACTIVATIONS[cfg.latent_activation]
   c.dropout_enc, c.dropout_dec, c.input_dropout = cfg.dropout_enc, cfg.dropout_dec, cfg.input_dropout
@@ -171,8 +174,8 @@ class Engine:
     if X.ndim != 2 or X.shape[1] != self.cfg.n_genes:
       raise ValueError(f"X must be [n_cells, {self.cfg.n_genes}]")
     n = X.shape[0]
-    labs = [_f32(y, (n, P)) for y, (P, _) in zip(labels, self.cfg.labels)]
-    if len(labs) != len(self.cfg.labels):
+    labs = [_f32(y, (n, P)) for y, (P, _) in zip(labels, self.cfg.targets)]
+    if len(labs) != len(self.cfg.targets):
       raise ValueError("one label matrix per label head is required")
     lab_ptrs = (C.POINTER(C.c_float) * max(1, len(labs)))(*[_fp(y) for y in labs]) if labs else None
     lib_arr = None if library is None else _f32(library, (n, 2))
@@ -209,8 +212,8 @@ class Engine:
     n = indptr.size - 1
     if n < 1 or indptr[0] != 0 or indptr[-1] != indices.size or indices.size != data.size:
       raise ValueError("inconsistent CSR arrays")
-    labs = [_f32(y, (n, P)) for y, (P, _) in zip(labels, self.cfg.labels)]
-    if len(labs) != len(self.cfg.labels):
+    labs = [_f32(y, (n, P)) for y, (P, _) in zip(labels, self.cfg.targets)]
+    if len(labs) != len(self.cfg.targets):
       raise ValueError("one label matrix per label head is required")
     lab_ptrs = (C.POINTER(C.c_float) * max(1, len(labs)))(*[_fp(y) for y in labs]) if labs else None
     lib_arr = None if library is None else _f32(library, (n, 2))
@@ -256,7 +259,7 @@ class Engine:
     """Per-step ELBO scalars of the last train_steps call: dict of arrays [n_steps]."""
     h = np.empty((int(n_steps), 8), np.float32)
     check(self.lib.smx_metrics_history(self._h, int(n_steps), _fp(h)))
-    return {k: h[:, i].copy() for i, k in enumerate(("loss", "nllk_x", "nllk_y", "kl", "kl_l", "tc", "dtc_loss"))}
+    return {k: h[:, i].copy() for i, k in enumerate(("loss", "nllk_x", "nllk_y", "kl", "kl_l", "tc", "dtc_loss", "nllk_o"))}
 
   def eval_step(self, row_ids):
     ids = self._ids(row_ids)

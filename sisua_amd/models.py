@@ -65,6 +65,34 @@ def _to_data(x, batch_size=64) -> BatchDataset:
   return sco.create_dataset(sco.omics, batch_size=batch_size, drop_remainder=True)
 
 
+def _head_kind(rv: RVmeta, what: str):
+  """(dim, kind) of a head on the decoder output for a label variable (`labels=`) or a further output variable (`outputs[1:]`):
+  the count posteriors of RVmeta ('nb' / 'nbd' / 'zinb' / 'zinbd', vae.py:30), 'onehot', and MISA's mixtures."""
+  if rv.posterior in ("nb", "nbd", "zinb", "zinbd"):
+    return (rv.event_shape, rv.posterior)
+  if rv.posterior in ("onehot", "categorical"):
+    return (rv.event_shape, "onehot")
+  if rv.posterior in ("mixnb", "mixnbd", "mixzinb", "mixzinbd"):     # MISA (vae.py:47-98): mixture of negative binomials per label dimension
+    C = int(rv.kwargs.get("n_components", 2))
+    if not 2 <= C <= 4:
+      raise ValueError(f"mixture label heads are built for 2..4 components, given: {C}")
+    return (rv.event_shape, f"mixzinb{C}" if (rv.kwargs.get("zero_inflated", False) or rv.posterior[:7] == "mixzinb") else f"mixnb{C}")   # (vae.py:76-84)
+  if rv.posterior in ("mixgaussian", "mixgaus", "mixgauss", "mixnormal", "mdn", "mixtril", "mixfull", "mdntril"):
+    # MISA's continuous labels (vae.py:86-92); 'mixtril' (the class's docstring example, vae.py:58) = covariance 'tril'
+    C = int(rv.kwargs.get("n_components", 2))
+    if not 2 <= C <= 4:
+      raise ValueError(f"mixture label heads are built for 2..4 components, given: {C}")
+    cov = rv.kwargs.get("covariance", "tril" if rv.posterior in ("mixtril", "mixfull", "mdntril") else "none")
+    if cov in ("tril", "full"):
+      if rv.event_shape > 64:
+        raise ValueError("'mixtril' label heads are built for at most 64 label dimensions")
+      return (rv.event_shape, f"mixtril{C}")
+    if cov in ("none", "diag"):
+      return (rv.event_shape, f"mixgauss{C}")
+    raise ValueError(f"mixture-of-Gaussians label heads are built with covariance 'none' / 'diag' (independent dimensions) or 'tril' / 'full', given: {cov}")
+  raise ValueError(f"{what} posterior '{rv.posterior}' is not built (supported: 'nb', 'nbd', 'zinb', 'zinbd', 'onehot', 'mixnb', 'mixgaussian', 'mixtril')")
+
+
 class _Layer:
   """Named handle for `output_layers[i].name` / `posteriors[i]` (train.py:110; posterior.py:176)."""
 
@@ -127,33 +155,12 @@ class SingleCellModel:
 
   def _make_config(self) -> ModelConfig:
     enc = self._encoder[0]
-    labels = []
-    for rv in self._labels:
-      if rv.posterior in ("nb", "nbd"):
-        labels.append((rv.event_shape, "nb"))
-      elif rv.posterior in ("onehot", "categorical"):
-        labels.append((rv.event_shape, "onehot"))
-      elif rv.posterior in ("mixnb", "mixnbd", "mixzinb", "mixzinbd"):     # MISA (vae.py:47-98): mixture of negative binomials per label dimension
-        C = int(rv.kwargs.get("n_components", 2))
-        if not 2 <= C <= 4:
-          raise ValueError(f"mixture label heads are built for 2..4 components, given: {C}")
-        labels.append((rv.event_shape, f"mixzinb{C}" if (rv.kwargs.get("zero_inflated", False) or rv.posterior[:7] == "mixzinb") else f"mixnb{C}"))   # (vae.py:76-84)
-      elif rv.posterior in ("mixgaussian", "mixgaus", "mixgauss", "mixnormal", "mdn", "mixtril", "mixfull", "mdntril"):
-        # MISA's continuous labels (vae.py:86-92); 'mixtril' (the class's docstring example, vae.py:58) = covariance 'tril'
-        C = int(rv.kwargs.get("n_components", 2))
-        if not 2 <= C <= 4:
-          raise ValueError(f"mixture label heads are built for 2..4 components, given: {C}")
-        cov = rv.kwargs.get("covariance", "tril" if rv.posterior in ("mixtril", "mixfull", "mdntril") else "none")
-        if cov in ("tril", "full"):
-          if rv.event_shape > 64:
-            raise ValueError("'mixtril' label heads are built for at most 64 label dimensions")
-          labels.append((rv.event_shape, f"mixtril{C}"))
-        elif cov in ("none", "diag"):
-          labels.append((rv.event_shape, f"mixgauss{C}"))
-        else:
-          raise ValueError(f"mixture-of-Gaussians label heads are built with covariance 'none' / 'diag' (independent dimensions) or 'tril' / 'full', given: {cov}")
-      else:
-        raise ValueError(f"label posterior '{rv.posterior}' is not built (supported: 'nb', 'onehot', 'mixnb', 'mixgaussian', 'mixtril')")
+    labels = [_head_kind(rv, "label") for rv in self._labels]
+    extras = [_head_kind(rv, "output") for rv in self._outputs[1:]]   # outputs[1:]: fully observed heads (weight 1, no label mask)
+    if extras and (self._kind == "fvae" or getattr(self, "_latent_mixture", False)):
+      raise ValueError(f"{type(self).__name__} is built for ONE output variable (outputs[1:] are not built for FVAE / the mixture-density posterior)")
+    if len(extras) + len(labels) > 4:
+      raise ValueError("at most 4 heads (outputs[1:] + label variables) are built")
     encl = self._encoder[1].units if len(self._encoder) > 1 else (64,)
     return ModelConfig(model=self._kind, n_genes=self._outputs[0].event_shape, likelihood=self._outputs[0].posterior,
                        enc_units=tuple(enc.units), dec_units=tuple(self._decoder.units),
@@ -162,6 +169,7 @@ class SingleCellModel:
                        input_dropout=float(enc.input_dropout), log_norm=self._log_norm, beta=self.beta, alpha=self.alpha,
                        latent_activation=self._latent_activation(), clip_library=self.clip_library,
                        lr=float(self._opt["lr"]), clipnorm=float(self._opt["clipnorm"]), seed=self.seed,
+                       extra_outputs=tuple(extras), dispersion=str(getattr(self, "_dispersion", "full")), inflation=str(getattr(self, "_inflation", "full")),
                        n_components=int(getattr(self, "_n_components", 10)), covariance=str(getattr(self, "_covariance", "none")), latent_mixture=bool(getattr(self, "_latent_mixture", False)),
                        **getattr(self, "_ties", {}), **getattr(self, "_disc_cfg", {}))
 
@@ -268,9 +276,19 @@ class SingleCellModel:
                          "SingleCellOMIC dataset to keep the dataset name and OMICs' "
                          "variables description.")
     batch_size = kwargs.pop("batch_size", 64)
-    train = _to_data(train, batch_size=batch_size)
+    need = len(self._outputs) - 1 + len(self._labels)   # target omics beside the counts: outputs[1:], then the label variables
+
+    def to_data(x):
+      # a SingleCellOMIC handed to a model with several variables: its first 1 + need OMICs (the reference's create_dataset default is
+      # the current OMIC alone, _single_cell_base.py:557-558, which such a model cannot train on); label variables stay unlabelled
+      # (labels_percent = 0, the reference's default) unless the caller prepares the dataset with its own labels_percent
+      if isinstance(x, SingleCellOMIC) and need > 0 and len(x.omics) > need:
+        return x.create_dataset(x.omics[:1 + need], batch_size=batch_size)
+      return _to_data(x, batch_size=batch_size)
+
+    train = to_data(train)
     if valid is not None:
-      valid = _to_data(valid, batch_size=batch_size)
+      valid = to_data(valid)
     return self._fit(train, valid, **kwargs)
 
   def _fit(self, train: BatchDataset, valid: Optional[BatchDataset], optimizer="adam", learning_rate=1e-3, clipnorm=100.0,
@@ -298,7 +316,7 @@ class SingleCellModel:
     from sisua_amd import data as _data
     from sisua_amd.parallel import ControlPlane, attach_engine, env_rank_world
     self._opt = dict(lr=float(learning_rate), clipnorm=float(clipnorm or 0.0))
-    n_lab = len(self._labels)
+    n_lab = len(self._outputs) - 1 + len(self._labels)   # target arrays beside the counts: outputs[1:], then the label variables
     if len(train.arrays) < 1 + n_lab:
       raise ValueError(f"{type(self).__name__} needs {1 + n_lab} omics per batch, the dataset has {len(train.arrays)}")
     cp = None
@@ -495,11 +513,12 @@ class SingleCellModel:
       stack = (lambda a: a[0]) if len(xp_list) == 1 else (lambda a: np.stack(a, 0))
       planes = [stack([xp[c] for xp in xp_list]) for c in range(cfg.k)]
     outs = [D.count_distribution(cfg.likelihood, planes, self._outputs[0].name or "transcriptomic", activated=cfg.model == "scvi")]
+    n_extra = len(cfg.extra_outputs)
     for j, (P, kind) in enumerate(cfg.head_labels):
       raw = yp_list[j] if stacked else stack([yp[j] for yp in yp_list])
-      nm = self._labels[j].name or f"label{j}"
-      if kind == "nb":
-        outs.append(D.Independent(D.NegativeBinomial(np.exp(raw[..., :P]), raw[..., P:]), 1, name=nm))
+      nm = (self._outputs[1 + j].name or f"output{1 + j}") if j < n_extra else (self._labels[j - n_extra].name or f"label{j - n_extra}")
+      if kind in ("nb", "nbd", "zinb", "zinbd"):   # planes of width P, as for the gene output
+        outs.append(D.count_distribution(kind, [raw[..., c * P:(c + 1) * P] for c in range(3 if kind[0] == "z" else 2)], nm, activated=False))
       elif kind.startswith("mixnb"):
         C = int(kind[-1])
         pl = np.reshape(raw, raw.shape[:-1] + (3 * C, P))     # planes: C mixture logits | C log total_counts | C logits
@@ -633,6 +652,9 @@ class SingleCellModel:
     log-sum-exp across passes; scvi materialises its raw planes per pass and normalises row-locally).
     Returns (mllk[B], {output name: mean_s log p(x|z_s) [B]})."""
     arrs = _flatten(inputs)
+    if len(self._outputs) > 1:
+      raise NotImplementedError("marginal_log_prob of a model with several output variables (the joint log p(x, y)) is not built; "
+                                "predict() returns every output's distribution")
     x = np.ascontiguousarray(arrs[0], dtype=np.float32)
     S = int(np.prod(sample_shape)) if np.size(sample_shape) else 1
     if self._cfg.model == "scvi" and library is None:
@@ -917,8 +939,18 @@ class SCVI(SingleCellModel):
     outs = _flatten(outputs)
     assert outs[0].posterior in ("zinbd", "nbd"), \
       "scVI only support transcriptomic distribution: 'zinbd' or 'nbd', " + "but given: %s" % str(outs)
-    if outs[0].kwargs.get("dispersion", "full") != "full" or outs[0].kwargs.get("inflation", "full") != "full":
-      raise ValueError("only dispersion='full' and inflation='full' are built")
+    # scvi.py:55-56,66-86: 'full' = a Dense head per plane; otherwise NO head and the distribution layer keeps its own variable --
+    # built as 'share' (alias 'gene', scVI's name): one trainable per-gene vector shared by every cell ([3P-recall] odin's
+    # NegativeBinomialDispLayer(dispersion='share')); 'single' (one scalar for every gene) is not built
+    opts = {}
+    for key in ("dispersion", "inflation"):
+      v = str(outs[0].kwargs.get(key, "full")).lower()
+      v = "share" if v in ("share", "gene") else v
+      if v not in ("full", "share"):
+        raise ValueError(f"scVI {key}='{v}' is not built (supported: 'full', 'share' / 'gene')")
+      opts[key] = v
+    self._dispersion, self._inflation = opts["dispersion"], opts["inflation"] if outs[0].posterior == "zinbd" else "full"
+    self.dispersion, self.inflation = self._dispersion, self._inflation
     super().__init__(outs, latents=[latents, library], encoder=[encoder, encoder_l], clip_library=clip_library, **kwargs)
     self.init_args = dict(outputs=outputs, latents=latents, library=library, encoder=encoder, encoder_l=encoder_l,
                           clip_library=clip_library, **kwargs)

@@ -95,13 +95,32 @@ CASES = {
     "wide_panel_nobn_96": dict(model="vae", n_genes=4128, likelihood="nb", enc_units=(96,), dec_units=(96,), latent_dim=8, batchnorm=False),
     "wide_panel_64": dict(model="vae", n_genes=4200, likelihood="zinb", enc_units=(64,), dec_units=(64,), latent_dim=10),
     "wide_panel_128": dict(model="vae", n_genes=4500, likelihood="nb", enc_units=(128,), dec_units=(128,), latent_dim=16),
+    # outputs[1:] of the reference's constructors (tests/test_singlecell_models.py:129-141: VAE(outputs=[zinb genes, nbd proteins]);
+    # scvi.py:168-169): further OBSERVED output variables as heads on the decoder output -- weight 1, every cell, metric nllk_o
+    "vae_two_outputs": dict(model="vae", n_genes=180, likelihood="zinb", enc_units=(64,), dec_units=(64,), latent_dim=9, extra_outputs=((12, "nbd"),)),
+    "vae_three_outputs": dict(model="vae", n_genes=140, likelihood="nb", enc_units=(48,), dec_units=(48,), latent_dim=8,
+                              extra_outputs=((14, "zinb"), (38, "zinbd"))),
+    "dca_two_outputs": dict(model="dca", n_genes=120, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=6, extra_outputs=((7, "onehot"),)),
+    "sisua_extra_output": dict(model="sisua", n_genes=150, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=8,
+                               extra_outputs=((10, "nb"),), labels=((12, "nbd"), (5, "onehot")), alpha=10.0),
+    "scale_two_outputs": dict(model="scale", n_genes=130, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=8, n_components=5,
+                              extra_outputs=((9, "nbd"),)),
+    "scvi_two_outputs": dict(model="scvi", n_genes=160, likelihood="zinbd", enc_units=(48,), dec_units=(48,), latent_dim=6, encl_units=(16,),
+                             extra_outputs=((12, "nbd"),)),
+    # scvi.py:55-56,66-86: dispersion / inflation without a Dense head -- one trainable per-gene vector (out1/b, out2/b alone)
+    "scvi_share_dispersion": dict(model="scvi", n_genes=160, likelihood="zinbd", enc_units=(48,), dec_units=(48,), latent_dim=6, encl_units=(16,),
+                                  dispersion="share"),
+    "scvi_share_both": dict(model="scvi", n_genes=130, likelihood="zinbd", enc_units=(40,), dec_units=(40,), latent_dim=5, encl_units=(16,),
+                            dispersion="share", inflation="share"),
+    "scvi_nbd_share_dispersion": dict(model="scvi", n_genes=96, likelihood="nbd", enc_units=(32,), dec_units=(32,), latent_dim=4, encl_units=(8,),
+                                      dispersion="share", batchnorm=False),
 }
 
 
 def _problem(kw, n=300, seed=0):
   spec, cfg = make_pair(**kw)
   x = synth_counts(n, spec.n_genes, sparsity=0.85, seed=seed, max_count=2000 if spec.n_genes < 500 else None)
-  ys = synth_labels(n, spec.labels)
+  ys = synth_labels(n, spec.extra_outputs + spec.labels)   # target arrays in head order: outputs[1:], then the label variables
   _, lm, lv = so.library_size(x)
   lib = np.tile(np.array([[lm, lv]], dtype=np.float32), (n, 1))
   mask = so.label_mask(n, 0.4, n_omics=1 + len(spec.labels), seed=1)
@@ -132,8 +151,10 @@ def test_one_step_matches_oracle(Engine, name, batch):
     assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
   if spec.labels:
     assert np.isclose(m["nllk_y"], res["metrics"]["nllk_y"], rtol=RTOL, atol=1e-5)
+  assert np.isclose(m["nllk_o"], res["metrics"]["nllk_o"], rtol=RTOL, atol=1e-5) and (m["nllk_o"] != 0) == bool(spec.extra_outputs)
   if spec.model == "scvi":
     assert np.isclose(m["kl_l"], res["metrics"]["kl_l"], rtol=RTOL, atol=1e-5)
+    assert ("out1/W" in e.names) == (spec.dispersion == "full") and ("out2/W" in e.names) == (spec.k == 3 and spec.inflation == "full")
   if spec.model == "fvae":
     for key in ("tc", "dtc_loss"):
       assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (key, m[key], res["metrics"][key])
@@ -412,7 +433,7 @@ def test_staged_row_ids_equal_passed_row_ids(Engine):
     assert np.array_equal(got[0][1][k], got[1][1][k]), k
 
 
-@pytest.mark.parametrize("case", ["sisua", "scale_post"])
+@pytest.mark.parametrize("case", ["sisua", "scale_post", "sisua_extra_output", "scvi_two_outputs", "scvi_share_both"])
 def test_eval_and_forward_match_oracle(Engine, case):
   kw = CASES[case]   # ('scale_post': z_mean / z_scale are the mixture posterior's moments; a different draw may pick another component)
   spec, cfg, x, ys, lib, mask = _problem(kw)
@@ -438,7 +459,8 @@ def test_eval_and_forward_match_oracle(Engine, case):
   assert np.allclose(out["z_sample"], res["z"], rtol=1e-3, atol=1e-4)
   for c in range(spec.k):
     assert np.allclose(out["x_params"][c], res["x_params"][c], rtol=1e-3, atol=1e-4)
-  for j in range(len(spec.labels)):
+  assert len(out["y_params"]) == len(spec.extra_outputs + spec.labels)
+  for j in range(len(spec.extra_outputs + spec.labels)):
     assert np.allclose(out["y_params"][j], res["y_params"][j], rtol=1e-3, atol=1e-4)
   # host-batch path (predict on raw arrays) agrees with the resident-row path on the means
   out2 = e.forward(x=x[rows], library=lib[rows])

@@ -298,6 +298,57 @@ def test_full_step_gradients_fd(model, lk, labels, bn):
       assert np.isclose(g.reshape(-1)[idx], fd, rtol=2e-4, atol=1e-7), (name, idx, g.reshape(-1)[idx], fd)
 
 
+EXTRA_CASES = {
+    # outputs[1:] of the reference's constructors (tests/test_singlecell_models.py:129-141; scvi.py:168-169): fully observed heads
+    "vae_two_outputs": ("vae", "zinb", dict(extra_outputs=((4, "nbd"),))),
+    "vae_three_outputs": ("vae", "nb", dict(extra_outputs=((3, "zinb"), (4, "zinbd")))),
+    "sisua_extra_output_and_labels": ("sisua", "zinb", dict(extra_outputs=((3, "nb"),), labels=((4, "nbd"), (3, "onehot")))),
+    "scvi_two_outputs": ("scvi", "zinbd", dict(extra_outputs=((4, "nbd"),))),
+    # scvi.py:55-56,66-86: per-gene dispersion / inflation vectors instead of Dense heads
+    "scvi_share_dispersion": ("scvi", "zinbd", dict(dispersion="share")),
+    "scvi_share_both": ("scvi", "zinbd", dict(dispersion="share", inflation="share")),
+    "scvi_nbd_share_dispersion": ("scvi", "nbd", dict(dispersion="share")),
+}
+
+
+@pytest.mark.parametrize("name", list(EXTRA_CASES))
+def test_extra_outputs_and_scvi_options_gradients_fd(name):
+  """Whole-step central differences for the heads of outputs[1:] (observed: weight 1, no mask -- masked-out cells DO contribute) and
+  for scvi's per-gene dispersion / inflation vectors (tensors out1/b, out2/b without a kernel)."""
+  model, lk, kw = EXTRA_CASES[name]
+  labels = kw.pop("labels", ()) if "labels" in kw else ()
+  kw = dict(kw)
+  spec, params, bn_state, x, y_lab, lib, mask = _toy(model, lk, labels, True, **kw)
+  rng = np.random.default_rng(9)
+  B = x.shape[0]
+  y = [np.eye(P)[rng.integers(0, P, B)] if kind == "onehot" else rng.uniform(0.5, 9.0, size=(B, P)) for P, kind in spec.extra_outputs] + y_lab
+  noise = so.PhiloxNoise(spec.seed, 7, np.arange(B) + 100)
+  names = {n for n, _ in so.manifest(spec)}
+  if spec.model == "scvi":
+    assert ("out1/W" in names) == (spec.dispersion == "full") and "out1/b" in names
+    assert ("out2/W" in names) == (spec.inflation == "full" and spec.k == 3)
+  res = so.forward_backward(spec, params, bn_state, x, noise, y=y, library=lib, mask=mask)
+  assert set(res["grads"]) == names
+  if spec.extra_outputs:   # the observed heads' term is there for EVERY cell, whatever the label mask
+    r0 = so.forward_backward(spec, params, bn_state, x, noise, y=y, library=lib, mask=np.zeros(B, bool), backward=False)
+    assert np.allclose(r0["llk_o"], res["llk_o"]) and np.all(r0["llk_o"] != 0)
+    assert np.isclose(res["loss"], -(res["llk_x"] + res["llk_o"] + spec.alpha * mask * res["llk_y"] - spec.beta * (res["kl"] + res["kl_l"])).mean())
+
+  def loss_of(p):
+    return so.forward_backward(spec, p, bn_state, x, noise, y=y, library=lib, mask=mask, backward=False)["loss"]
+
+  for nm, g in res["grads"].items():
+    flat = params[nm].reshape(-1)
+    for idx in rng.choice(flat.size, size=min(4, flat.size), replace=False):
+      h = 1e-5
+      pp = {k: v.copy() for k, v in params.items()}
+      pm = {k: v.copy() for k, v in params.items()}
+      pp[nm].reshape(-1)[idx] += h
+      pm[nm].reshape(-1)[idx] -= h
+      fd = (loss_of(pp) - loss_of(pm)) / (2 * h)
+      assert np.isclose(g.reshape(-1)[idx], fd, rtol=2e-4, atol=1e-7), (nm, idx, g.reshape(-1)[idx], fd)
+
+
 def test_scale_tied_mixture_gradients_fd():
   """SCALE's tied mixture parameters (scale.py:29-33): one location and / or one scale vector shared by every component, the
   weights fixed uniform.  A tied tensor keeps identical rows and every row receives the derivative with respect to the SHARED

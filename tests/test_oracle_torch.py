@@ -45,7 +45,7 @@ def count_log_prob(x, planes, likelihood, direct):
   distribution of the same name has the same convention; 'nbd'/'zinbd': the scVI formula (there is no distribution
   object with its epsilon terms); zero inflation: log(pi 1[x = 0] + (1 - pi) NB(x)) through logsumexp."""
   if likelihood in ("nb", "zinb"):
-    lp = td.NegativeBinomial(total_count=torch.exp(planes[0]), logits=planes[1]).log_prob(x)
+    lp = td.NegativeBinomial(total_count=torch.exp(planes[0]), logits=planes[1], validate_args=False).log_prob(x)   # (protein levels are real-valued)
   else:
     mu, th = (planes[0], planes[1]) if direct else (torch.nn.functional.softplus(planes[0]), softplus1(planes[1]))
     e = so.NBD_EPS
@@ -105,7 +105,8 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
     kl_l = td.kl_divergence(ql, td.Normal(lib[:, 0], torch.sqrt(lib[:, 1])))
   d = mlp(spec, P, bn, "dec", spec.dec_units, z, noise, so.STREAM_DEC_DROPOUT, spec.dropout_dec, new_bn)
   if spec.model == "scvi":
-    raw = [d @ P[f"out{c}/W"] + P[f"out{c}/b"] for c in range(spec.k)]
+    # dispersion / inflation other than 'full' (scvi.py:66-86): no Dense head, one trainable per-gene vector shared by every cell
+    raw = [(d @ P[f"out{c}/W"] if f"out{c}/W" in P else 0.0) + P[f"out{c}/b"].expand(B, G) for c in range(spec.k)]
     rho = torch.clamp(torch.softmax(raw[0], dim=1), so.SCVI_RHO_MIN, 1 - so.SCVI_RHO_MIN)
     rate = torch.exp(torch.clamp(l, 0.0, spec.clip_library))[:, None] * rho
     planes = [rate, torch.exp(raw[1])] + ([raw[2]] if spec.k == 3 else [])
@@ -113,7 +114,7 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
   else:
     raw = d @ P["out/W"] + P["out/b"]
     llk_x = count_log_prob(x, [raw[:, c * G:(c + 1) * G] for c in range(spec.k)], spec.likelihood, False).sum(1)
-  llk_y = torch.zeros(B)
+  llk_y, llk_o = torch.zeros(B), torch.zeros(B)
   m = torch.zeros(B) if mask is None else torch.as_tensor(np.asarray(mask, np.float64))
   extra_vae, j_disc = 0.0, None
   if spec.model == "fvae":
@@ -135,12 +136,18 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
       yj = torch.as_tensor(np.asarray(y[0], np.float64))
       llk_y = td.OneHotCategorical(logits=logits_v).log_prob(yj)
       j_disc = j_disc - spec.alpha * (m * td.OneHotCategorical(logits=logits_z).log_prob(yj)).mean()
-  for j, (Pj, kind) in enumerate(() if spec.model == "fvae" else spec.labels):
+  # heads on the decoder output: the extra OUTPUT variables first (fully observed: weight 1, no mask), then the label variables
+  heads = [(Pj, kind, True) for Pj, kind in spec.extra_outputs] + ([] if spec.model == "fvae" else [(Pj, kind, False) for Pj, kind in spec.labels])
+  for j, (Pj, kind, observed) in enumerate(heads):
     ry = d @ P[f"lab{j}/W"] + P[f"lab{j}/b"]
     yj = torch.as_tensor(np.asarray(y[j], np.float64))
+    llk_prev, llk_y = llk_y, torch.zeros(B)
     if kind == "nb":
       # protein levels are real-valued (dataset.html:187): the same density formula, support check off
       llk_y = llk_y + td.NegativeBinomial(total_count=torch.exp(ry[:, :Pj]), logits=ry[:, Pj:], validate_args=False).log_prob(yj).sum(1)
+    elif kind in ("nbd", "zinb", "zinbd"):   # the other count posteriors, planes as for the gene output
+      kk = 2 if kind == "nbd" else 3
+      llk_y = llk_y + count_log_prob(yj, [ry[:, c * Pj:(c + 1) * Pj] for c in range(kk)], kind, False).sum(1)
     elif kind.startswith("mixtril"):   # MISA's docstring example (vae.py:58): ONE mixture of C full-covariance Gaussians over the label vector
       C = int(kind[-1])
       pl = ry.reshape(B, C * (2 + Pj), Pj)
@@ -167,7 +174,11 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
       llk_y = llk_y + td.MixtureSameFamily(td.Categorical(logits=pl[:, :C].permute(0, 2, 1)), comp, validate_args=False).log_prob(yj).sum(1)
     else:
       llk_y = llk_y + td.OneHotCategorical(logits=ry).log_prob(yj)
-  loss = -(llk_x + spec.alpha * m * llk_y - spec.beta * (kl + kl_l)).mean() + extra_vae
+    if observed:
+      llk_o, llk_y = llk_o + llk_y, llk_prev
+    else:
+      llk_y = llk_prev + llk_y
+  loss = -(llk_x + llk_o + spec.alpha * m * llk_y - spec.beta * (kl + kl_l)).mean() + extra_vae
   (loss if j_disc is None else loss + j_disc).backward()
   return P, float(loss.detach()), {k: v.grad.numpy() for k, v in P.items()}, new_bn
 
@@ -216,6 +227,22 @@ CASES = {
     "scvi_zinbd": dict(model="scvi", n_genes=52, likelihood="zinbd", enc_units=(16,), dec_units=(16,), latent_dim=4, encl_units=(8,)),
     "scvi_nbd": dict(model="scvi", n_genes=36, likelihood="nbd", enc_units=(12,), dec_units=(12,), latent_dim=3, encl_units=(6,),
                      batchnorm=False),
+    # outputs[1:] (tests/test_singlecell_models.py:129-141: VAE(outputs=[zinb genes, nbd proteins])): fully observed heads, weight 1
+    "vae_two_outputs": dict(model="vae", n_genes=48, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, extra_outputs=((7, "nbd"),)),
+    "vae_three_outputs": dict(model="vae", n_genes=40, likelihood="nb", enc_units=(16,), dec_units=(16,), latent_dim=4,
+                              extra_outputs=((6, "zinb"), (5, "zinbd"))),
+    "sisua_extra_output": dict(model="sisua", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5,
+                               extra_outputs=((6, "nb"),), labels=((5, "nbd"), (4, "onehot")), alpha=10.0),
+    "dca_two_outputs": dict(model="dca", n_genes=36, likelihood="zinb", enc_units=(12,), dec_units=(12,), latent_dim=4, extra_outputs=((5, "onehot"),)),
+    # scvi.py:168-169 (posteriors[1:] on the decoder output) and scvi.py:55-56,66-86 (dispersion / inflation without a head)
+    "scvi_two_outputs": dict(model="scvi", n_genes=40, likelihood="zinbd", enc_units=(16,), dec_units=(16,), latent_dim=4, encl_units=(8,),
+                             extra_outputs=((6, "nbd"),)),
+    "scvi_gene_dispersion": dict(model="scvi", n_genes=44, likelihood="zinbd", enc_units=(16,), dec_units=(16,), latent_dim=4, encl_units=(8,),
+                                 dispersion="share"),
+    "scvi_gene_both": dict(model="scvi", n_genes=36, likelihood="zinbd", enc_units=(12,), dec_units=(12,), latent_dim=3, encl_units=(6,),
+                           dispersion="share", inflation="share"),
+    "scvi_nbd_gene_dispersion": dict(model="scvi", n_genes=36, likelihood="nbd", enc_units=(12,), dec_units=(12,), latent_dim=3, encl_units=(6,),
+                                     dispersion="share", batchnorm=False),
 }
 
 
@@ -224,7 +251,7 @@ def test_torch_autograd_step_equals_the_oracle(name):
   spec = so.Spec(**CASES[name])
   n, B = 90, 40
   x = synth_counts(n, spec.n_genes, sparsity=0.7, seed=2, max_count=300)
-  ys = synth_labels(n, spec.labels)
+  ys = synth_labels(n, spec.extra_outputs + spec.labels)
   _, lm, lv = so.library_size(x)
   lib = np.tile(np.array([[lm, lv]]), (n, 1))
   mask = so.label_mask(n, 0.5, n_omics=1 + len(spec.labels), seed=1)
