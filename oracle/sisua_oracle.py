@@ -1071,6 +1071,8 @@ def adam_update(spec: Spec, params, grads, opt):
   for name in params:
     g = grads[name]
     nrm = float(np.sqrt((g * g).sum()))
+    if spec.model == "scale" and ((name == "prior/loc" and spec.tie_loc) or (name == "prior/scale" and spec.tie_scale)):
+      nrm /= np.sqrt(spec.n_components)   # C identical rows of ONE shared variable (scale.py:29-33): the clip norm is that variable's
     norms[name] = nrm
     if spec.clipnorm > 0 and nrm > spec.clipnorm:
       g = g * (spec.clipnorm / nrm)

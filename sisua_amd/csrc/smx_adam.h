@@ -50,6 +50,7 @@ __device__ inline void adam_chunk_body(const AdamArgs& a, int chunk) {
   if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) sh[threadIdx.x >> 6] = s;
   __syncthreads();
   s = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  if (ch.tensor == a.tied_t0 || ch.tensor == a.tied_t1) s *= a.tied_inv;   // (C identical rows of one shared variable)
   const float norm = sqrtf(s) * a.grad_scale;
   float clip = a.grad_scale;
   if (a.clipnorm > 0.f && norm > a.clipnorm) clip *= a.clipnorm / norm;

@@ -85,6 +85,11 @@ bool dp_active(const smx_model* m) {
 // one all-reduce on the model's own stream +2.6 us.  The overlap only pays when the collective itself is
 // much longer than that, so the default is the single all-reduce; SMX_DP_BUCKETS=2 selects the overlap.
 bool dp_overlap(const smx_model* m) {
+  // Not with the hand-written exchange under SyncBatchNorm: the head bucket's exchange on st_comm would run beside the
+  // SyncBatchNorm-backward exchanges on the model's stream, and both go through ONE staging buffer, ONE done counter and ONE
+  // monotonic flag set (REDUCED(e + 1) satisfies waiters on e; staging overwritten mid-gather -- ADVICE r03).  RCCL serialises per
+  // communicator and keeps the overlap.
+  if (m->p2p && m->p2p->error && m->sync_bn) return false;
   return dp_active(m) && m->dp_two_buckets && !m->capturing && m->st_comm != nullptr && !m->local;
 }
 int local_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {

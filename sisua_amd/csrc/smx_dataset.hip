@@ -57,7 +57,7 @@ int smx_dataset_upload_csr(smx_model* m, const int64_t* indptr, const int32_t* c
   fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1);
   m->X = nullptr; m->library = nullptr; m->mask = nullptr; m->lgx1 = nullptr;
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); m->Y[j] = nullptr; }
-  m->N = n_cells; m->cell_base = cell_id_base; m->x_u16 = false;
+  m->N = n_cells; m->cell_base = cell_id_base; m->x_u16 = false; m->staged_steps = 0;   // (row ids staged against the matrix before are void)
   int rc;
   m->x_csr = true;
   if ((rc = dmalloc(&m->csr_indptr, (size_t)n_cells + 1)) || (rc = dmalloc(&m->csr_cols, (size_t)std::max<int64_t>(nnz, 1))) ||
@@ -87,7 +87,7 @@ static int dataset_upload_impl(smx_model* m, const void* X, bool u16, int64_t n_
   fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1);
   m->X = nullptr; m->library = nullptr; m->mask = nullptr; m->lgx1 = nullptr;
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); m->Y[j] = nullptr; }
-  m->N = n_cells; m->cell_base = cell_id_base;
+  m->N = n_cells; m->cell_base = cell_id_base; m->staged_steps = 0;
   int rc;
   m->x_u16 = u16;
   if (u16) {   // compact store: uint16 counts, same row pitch in ELEMENTS (Gp), half the bytes
@@ -121,7 +121,7 @@ int smx_dataset_generate_lognormal(smx_model* m, uint64_t seed, int32_t rank, in
   fr(m->X); fr(m->library); fr(m->mask); fr(m->lgx1);
   m->X = nullptr; m->library = nullptr; m->mask = nullptr; m->lgx1 = nullptr;
   for (int j = 0; j < SMX_MAX_LABELS; ++j) { fr(m->Y[j]); m->Y[j] = nullptr; }
-  m->N = n_cells; m->cell_base = (int64_t)rank * n_cells; m->x_u16 = storage_u16 != 0;
+  m->N = n_cells; m->cell_base = (int64_t)rank * n_cells; m->x_u16 = storage_u16 != 0; m->staged_steps = 0;
   const size_t bytes = (size_t)n_cells * (size_t)m->Gp * (m->x_u16 ? sizeof(uint16_t) : sizeof(float));
   hipError_t e = hipMalloc((void**)&m->X, bytes);   // (no memset of tens of GB: the generator writes every element of every padded row)
   if (e != hipSuccess) { m->X = nullptr; m->N = 0; set_error(std::string("hipMalloc of the resident matrix failed: ") + hipGetErrorString(e)); return SMX_ERR_NOMEM; }

@@ -248,6 +248,9 @@ struct AdamArgs {
   const StepState* state = nullptr;
   float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, clipnorm = 100.f;
   float grad_scale = 1.f;       // extra factor on the gradient (1: the loss is already scaled by 1 / global batch)
+  // SCALE's tied tensors (scale.py:29-33: ONE shared location / scale vector stored as C identical rows, every row holding the shared
+  // variable's gradient): the clip norm is the shared variable's, i.e. the stored tensor's sum of squares / C
+  int tied_t0 = -1, tied_t1 = -1; float tied_inv = 1.f;
   float* hist_dp = nullptr; const float* tail_metrics = nullptr;   // data parallel: the reduced scalars go to the history here
   // data parallel, world > 1: the moving BatchNorm statistics take the all-reduced batch statistics (mean over the ranks)
   // in extra workgroups of the gradient-norm launch (it was a launch of its own)

@@ -124,6 +124,7 @@ struct P2PState {
   float* scratch[SMX_P2P_MAX] = {};        // ... its small-buffer scratch
   size_t staging_floats = 0, scratch_floats = 0;
   unsigned* done = nullptr; unsigned* error = nullptr;   // local words behind the flags
+  long long timeout_ticks = 3000000000LL;                // bound of a device-side wait, 100 MHz ticks (SMX_P2P_TIMEOUT_S)
 };
 int p2p_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st);
 void p2p_release(smx_model* m);

@@ -33,18 +33,28 @@ struct P2PArgs {
   unsigned* flags[SMX_P2P_MAX];      // every rank's flag block [2][SMX_P2P_MAX] (READY | REDUCED by source rank), own: local
   float* out;                        // where the sum goes (== g[rank] for the in-place form)
   unsigned* done;                    // local: workgroups of launch A that have finished
-  unsigned* error;                   // local: non-zero after a timed-out wait
+  unsigned* error;                   // local: non-zero after a timed-out wait of this rank (1) or a peer's report of one (2); sticky
+  unsigned* peer_error[SMX_P2P_MAX]; // every rank's error word (peers: in their IPC-mapped regions): a failing rank poisons them all
+  long long timeout_ticks;           // bound of every wait on the device's 100 MHz wall clock (SMX_P2P_TIMEOUT_S, default 30 s)
   long count, chunk;                 // floats in all / per rank (chunk a multiple of 4)
   int rank, world; unsigned epoch;
 };
 
-__device__ inline bool wait_flag(const unsigned* f, unsigned epoch, unsigned* error) {
-  const long long t0 = wall_clock64();   // 100 MHz on gfx9: 2 s = 2e8 ticks
+// A wait gives up when its bound passes (error word := 1) or as soon as the rank's error word is set by somebody else -- a peer whose
+// own wait failed poisons every rank's word (2), so one straggler / dead peer fails the step on EVERY rank instead of leaving the others
+// to gather stale staging.  The word is sticky: the host reads it at the next metrics read-back (SMX_ERR_COMM).
+__device__ inline bool wait_flag(const unsigned* f, unsigned epoch, unsigned* error, long long timeout_ticks) {
+  const long long t0 = wall_clock64();   // 100 MHz on gfx9
   while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
     __builtin_amdgcn_s_sleep(8);
-    if (wall_clock64() - t0 > 200000000LL) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
+    if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return false;
+    if (wall_clock64() - t0 > timeout_ticks) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
   }
   return true;
+}
+__device__ inline void poison_peers(const P2PArgs& a) {   // (threads [0, world) of a workgroup)
+  if (threadIdx.x < (unsigned)a.world && (int)threadIdx.x != a.rank)
+    __hip_atomic_store(a.peer_error[threadIdx.x], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int W>   // W = world (compile-time: the per-rank load arrays stay in registers)
@@ -58,8 +68,9 @@ __global__ __launch_bounds__(256) void p2p_reduce_scatter_kernel(P2PArgs a) {
   if (threadIdx.x == 0) ok_s = 1;
   __syncthreads();
   if (threadIdx.x < (unsigned)a.world && (int)threadIdx.x != a.rank)
-    if (!wait_flag(a.flags[a.rank] + threadIdx.x, a.epoch, a.error)) ok_s = 0;
+    if (!wait_flag(a.flags[a.rank] + threadIdx.x, a.epoch, a.error, a.timeout_ticks)) ok_s = 0;
   __syncthreads();
+  if (!ok_s) poison_peers(a);
   if (ok_s) {
     const long base = (long)a.rank * a.chunk;
     const long n4 = std::max<long>(0, std::min(a.chunk, a.count - base)) >> 2;
@@ -93,7 +104,9 @@ __global__ __launch_bounds__(256) void p2p_reduce_scatter_kernel(P2PArgs a) {
   __syncthreads();
   if (ok_s) {
     if (threadIdx.x == 0) *a.done = 0;
-    if (threadIdx.x < (unsigned)a.world && (int)threadIdx.x != a.rank)
+    // (a workgroup whose wait failed set the error word before it counted itself done: S_r is incomplete, REDUCED(e) is NOT raised)
+    const bool failed = __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+    if (!failed && threadIdx.x < (unsigned)a.world && (int)threadIdx.x != a.rank)
       __hip_atomic_store(a.flags[threadIdx.x] + SMX_P2P_MAX + a.rank, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -102,9 +115,9 @@ __global__ __launch_bounds__(256) void p2p_reduce_scatter_kernel(P2PArgs a) {
 __global__ __launch_bounds__(256) void p2p_all_gather_kernel(P2PArgs a) {
   __shared__ int ok_s;
   const int q = blockIdx.y;
-  if (threadIdx.x == 0) ok_s = (q == a.rank) ? 1 : (wait_flag(a.flags[a.rank] + SMX_P2P_MAX + q, a.epoch, a.error) ? 1 : 0);
+  if (threadIdx.x == 0) ok_s = (q == a.rank) ? 1 : (wait_flag(a.flags[a.rank] + SMX_P2P_MAX + q, a.epoch, a.error, a.timeout_ticks) ? 1 : 0);
   __syncthreads();
-  if (!ok_s) return;
+  if (!ok_s) { poison_peers(a); return; }
   const long base = (long)q * a.chunk;
   const long n4 = std::max<long>(0, std::min(a.chunk, a.count - base)) >> 2;
   const float4* src = reinterpret_cast<const float4*>(a.s[q]);
@@ -135,7 +148,9 @@ int p2p_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
     a.g[q] = is_g ? p.grads[q] + off : p.scratch[q];
     a.s[q] = p.staging[q];
     a.flags[q] = p.flags[q];
+    a.peer_error[q] = p.flags[q] + 2 * SMX_P2P_MAX + 1;
   }
+  a.timeout_ticks = p.timeout_ticks;
   a.out = is_g ? buf : p.scratch[p.rank];
   a.done = p.done; a.error = p.error;
   a.count = (long)count;
@@ -251,6 +266,11 @@ int smx_comm_p2p_init(smx_model* m, int rank, int world, const uint8_t* all_hand
   }
   p.done = p.flags[rank] + 2 * SMX_P2P_MAX;
   p.error = p.done + 1;
+  {   // bound of every wait: generous by default (ordinary rank skew -- a slow upload, a validation pass -- must not trip it)
+    const char* ts = getenv("SMX_P2P_TIMEOUT_S");
+    const double sec = ts ? atof(ts) : 30.0;
+    p.timeout_ticks = (long long)(std::min(std::max(sec, 0.05), 3600.0) * 1e8);
+  }
   m->rank = rank; m->world = world;
   SMX_CHECK(smx::ensure_comm_stream(m));
   if (!m->comm) SMX_CHECK(smx::ensure_sync_buf(m));
@@ -258,7 +278,8 @@ int smx_comm_p2p_init(smx_model* m, int rank, int world, const uint8_t* all_hand
   return SMX_OK;
 }
 
-// non-zero after a wait on a peer timed out (the results of that step are then garbage); clears the word
+// non-zero after a wait on a peer timed out (1) or a peer reported that its wait did (2): the results of that step are garbage on
+// every rank.  Reads AND clears the word (smx_train_step* / smx_eval_step with a metrics read-back report it as SMX_ERR_COMM without clearing)
 int smx_comm_p2p_error(smx_model* m, int32_t* error) {
   SMX_REQUIRE(m && error, "null argument");
   *error = 0;

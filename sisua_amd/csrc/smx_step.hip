@@ -1243,6 +1243,10 @@ void fill_adam_args(smx_model* m, AdamArgs& a) {
   // the likelihood / KL / label kernels already scale by 1 / (batch * world), so the SUM all-reduce leaves the
   // global-mean gradient: nothing more to divide by (it used to be divided by world once more here)
   a.grad_scale = 1.f;
+  if (m->scale && (m->flags.tie_loc || m->flags.tie_scale)) {
+    a.tied_t0 = m->flags.tie_loc ? m->t_prLoc : -1; a.tied_t1 = m->flags.tie_scale ? m->t_prScale : -1;
+    a.tied_inv = 1.f / (float)c.n_components;
+  }
 }
 
 int optimizer_pass(smx_model* m) {
@@ -1331,12 +1335,20 @@ int read_metrics(smx_model* m, smx_metrics* out) {
   if (!out) return SMX_OK;
   // into pinned memory (two real DMA copies; into pageable arrays the runtime stages each one synchronously)
   const size_t nt = m->tensors.size();
-  if (!m->metrics_pin) SMX_HIP(hipHostMalloc((void**)&m->metrics_pin, (8 + nt) * sizeof(float), hipHostMallocDefault));
+  if (!m->metrics_pin) SMX_HIP(hipHostMalloc((void**)&m->metrics_pin, (8 + nt + 1) * sizeof(float), hipHostMallocDefault));
   float* h = m->metrics_pin;
   float* norms_p = m->metrics_pin + 8;
+  unsigned* p2p_err = reinterpret_cast<unsigned*>(m->metrics_pin + 8 + nt);
+  *p2p_err = 0u;
   SMX_HIP(hipMemcpyAsync(h, m->grads + m->tail_off_metrics, 8 * sizeof(float), hipMemcpyDeviceToHost, m->st));
   SMX_HIP(hipMemcpyAsync(norms_p, m->tensor_norm, nt * sizeof(float), hipMemcpyDeviceToHost, m->st));
+  if (m->p2p && m->p2p->error) SMX_HIP(hipMemcpyAsync(p2p_err, m->p2p->error, sizeof(unsigned), hipMemcpyDeviceToHost, m->st));
   SMX_HIP(hipStreamSynchronize(m->st));
+  if (*p2p_err) {   // a bounded wait of the peer-to-peer exchange gave up on this rank or on a peer: every rank's step is garbage
+    set_error(*p2p_err == 1u ? "peer-to-peer all-reduce: a wait on a peer's flag timed out (SMX_P2P_TIMEOUT_S)" :
+                               "peer-to-peer all-reduce: a peer reported a timed-out wait");
+    return SMX_ERR_COMM;
+  }
   std::vector<float> norms(norms_p, norms_p + nt);
   out->loss = h[0]; out->nllk_x = h[1]; out->nllk_y = h[2]; out->kl = h[3]; out->kl_l = h[4];
   float mx = 0.f;

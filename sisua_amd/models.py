@@ -356,6 +356,8 @@ class SingleCellModel:
       lib = np.concatenate([lib, valid.library], 0)
       mask = np.concatenate([mask, valid.mask], 0)
     e.upload(X, labs, lib, mask, cell_id_base=lo, storage=storage)   # Philox cell ids are GLOBAL: sharding-independent noise
+    if cp is not None:
+      cp.barrier()   # every rank's shard is resident before the first collective (the exchange's waits are bounded: no upload skew inside them)
     seed_r = train.seed + 7919 * rank
 
     def _prepare(ep):   # pure function of (seed, epoch): prepared on a host thread while the device runs the epoch before

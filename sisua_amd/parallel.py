@@ -43,9 +43,27 @@ def _recv_exact(sock: socket.socket, n: int) -> bytes:
   return bytes(buf)
 
 
+_MAX_PAYLOAD = 256 << 20   # the plane moves unique ids, IPC handles and a few scalars: anything larger is not a peer of this job
+
+
 def _recv(sock: socket.socket) -> Tuple[int, bytes]:
   op, n = struct.unpack("<BQ", _recv_exact(sock, 9))
+  if n > _MAX_PAYLOAD:
+    raise ConnectionError(f"control plane: a payload of {n} bytes was announced (limit {_MAX_PAYLOAD})")
   return op, _recv_exact(sock, n) if n else b""
+
+
+def _is_local(addr: str) -> bool:
+  try:
+    ip = socket.gethostbyname(addr)
+  except OSError:
+    return False
+  if ip.startswith("127."):
+    return True
+  try:
+    return ip in {ai[4][0] for ai in socket.getaddrinfo(socket.gethostname(), None)}
+  except OSError:
+    return False
 
 
 class ControlPlane:
@@ -67,9 +85,21 @@ class ControlPlane:
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     mport = os.environ.get("MASTER_PORT", "0")
     run = os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("SMX_RUN_ID", "none"))
-    token = hashlib.sha256(f"{addr}:{mport}:{run}:{self.world}".encode()).digest()[:16]
+    # the job's token: public values + (fixed port) a launcher-provided SMX_CP_SECRET or (rendezvous file) 16 random bytes rank 0
+    # writes into a file only this user can read -- so another local user can neither join as a rank nor learn the token
+    secret = os.environ.get("SMX_CP_SECRET", "")
+    base = f"{addr}:{mport}:{run}:{self.world}"
+    token = hashlib.sha256(f"{base}:{secret}".encode()).digest()[:16]
     fixed = port if port is not None else (int(os.environ["SMX_CP_PORT"]) if os.environ.get("SMX_CP_PORT") else None)
-    rfile = os.path.join(tempfile.gettempdir(), f"smx_cp_{os.getuid()}_{hashlib.sha256(token).hexdigest()[:16]}.port")
+    if not fixed and not _is_local(addr):
+      raise RuntimeError(f"control plane: MASTER_ADDR={addr} is not this host and SMX_CP_PORT is unset -- the rendezvous file only serves "
+                         "one node; set SMX_CP_PORT (and SMX_CP_SECRET) on every rank for a multi-node job")
+    rdir = os.path.join(tempfile.gettempdir(), f"smx_cp_{os.getuid()}")
+    os.makedirs(rdir, mode=0o700, exist_ok=True)
+    st = os.stat(rdir)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+      raise RuntimeError(f"control plane: {rdir} is not a private directory of this user")
+    rfile = os.path.join(rdir, f"{hashlib.sha256(base.encode()).hexdigest()[:16]}.port")
     deadline = time.time() + timeout
     if self.rank == 0:
       srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
@@ -77,9 +107,12 @@ class ControlPlane:
       srv.bind((addr if fixed else "127.0.0.1", fixed or 0))
       srv.listen(self.world)
       if not fixed:
+        rnd = os.urandom(16).hex()
+        token = hashlib.sha256(f"{base}:{secret}:{rnd}".encode()).digest()[:16]
         tmp = f"{rfile}.{os.getpid()}"
-        with open(tmp, "w") as f:
-          f.write(str(srv.getsockname()[1]))
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "w") as f:
+          f.write(f"{srv.getsockname()[1]} {rnd}")
         os.replace(tmp, rfile)   # atomic: a reader sees the old file or the new one
         self._file = rfile
       got = {}
@@ -111,16 +144,20 @@ class ControlPlane:
         if time.time() > deadline:
           raise TimeoutError(f"control plane: rank {self.rank} could not reach rank 0 within {timeout:.0f} s")
         try:
-          p = fixed or int(open(rfile).read().strip())
+          if fixed:
+            p, tok = fixed, token
+          else:
+            fields = open(rfile).read().split()
+            p, tok = int(fields[0]), hashlib.sha256(f"{base}:{secret}:{fields[1]}".encode()).digest()[:16]
           c = socket.create_connection((addr if fixed else "127.0.0.1", p), timeout=5.0)
-          c.sendall(_MAGIC + token + struct.pack("<I", self.rank))
+          c.sendall(_MAGIC + tok + struct.pack("<I", self.rank))
           if _recv_exact(c, len(_MAGIC)) != _MAGIC:
             raise ConnectionError("bad reply")
           c.settimeout(None)
           c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
           self._root = c
           break
-        except (OSError, ValueError, ConnectionError):
+        except (OSError, ValueError, IndexError, ConnectionError):
           time.sleep(0.05)   # no file yet, a stale file of an earlier job, or rank 0 not listening yet
 
   # every collective: the ranks send (op, payload) to rank 0, which reduces and replies to each

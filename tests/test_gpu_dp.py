@@ -67,20 +67,26 @@ CASES = {
     "scale": dict(model="scale", n_genes=100, likelihood="zinb", enc_units=(32,), dec_units=(32,), latent_dim=7, n_components=4),
     "scale_tril": dict(model="scale", n_genes=100, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=6, n_components=3, covariance="tril"),
     "scale_post": dict(model="scale", n_genes=100, likelihood="zinb", enc_units=(32,), dec_units=(32,), latent_dim=6, n_components=3, latent_mixture=True),
+    # round 4: outputs[1:] as observed heads beside label heads; scvi with per-gene dispersion / inflation vectors and a second output
+    "sisua_extra_output": dict(model="sisua", n_genes=120, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=7,
+                               extra_outputs=((9, "nbd"),), labels=((8, "nb"), (5, "onehot")), alpha=10.0),
+    "scvi_share_two_outputs": dict(model="scvi", n_genes=130, likelihood="zinbd", enc_units=(40,), dec_units=(40,), latent_dim=5, encl_units=(16,),
+                                   dispersion="share", inflation="share", extra_outputs=((7, "zinbd"),)),
 }
 
 
 def _problem(kw, n=400):
   spec, cfg = make_pair(**kw)
   x = synth_counts(n, spec.n_genes, sparsity=0.85, seed=0)
-  ys = synth_labels(n, spec.labels)
+  ys = synth_labels(n, spec.extra_outputs + spec.labels)
   _, lm, lv = so.library_size(x)
   lib = np.tile(np.array([[lm, lv]], dtype=np.float32), (n, 1))
   mask = so.label_mask(n, 0.4, n_omics=1 + len(spec.labels), seed=1)
   return spec, cfg, x, ys, lib, mask
 
 
-@pytest.mark.parametrize("name,world,sync_bn", [("vae_zinb", 2, False), ("vae_zinb", 2, True), ("vae_clip", 2, False),
+@pytest.mark.parametrize("name,world,sync_bn", [("sisua_extra_output", 2, False), ("sisua_extra_output", 3, True), ("scvi_share_two_outputs", 2, False),
+                                                ("scvi_share_two_outputs", 2, True), ("vae_zinb", 2, False), ("vae_zinb", 2, True), ("vae_clip", 2, False),
                                                 ("vae_clip", 3, True), ("sisua", 2, False), ("sisua", 2, True),
                                                 ("scvi_zinbd", 2, False), ("scvi_zinbd", 2, True), ("vae_nobn", 4, False), ("fvae", 2, False),
                                                 ("misa_mix", 2, False), ("scale", 2, True), ("scale_tril", 3, False), ("scale_post", 2, True)])
@@ -113,6 +119,7 @@ def test_world_n_steps_match_oracle(Engine, name, world, sync_bn):
     for r, (e, m) in enumerate(zip(engines, ms)):
       assert m["nan_flag"] == 0 and m["step"] == step + 1
       for key in ("loss", "nllk_x", "kl") + (("nllk_y",) if spec.labels else ()) + (("kl_l",) if spec.model == "scvi" else ()) + \
+          (("nllk_o",) if spec.extra_outputs else ()) + \
           (("tc", "dtc_loss") if spec.model == "fvae" else ()):   # (fvae: z is permuted within each rank's minibatch)
         assert np.isclose(m[key], ref["metrics"][key], rtol=RTOL, atol=1e-5), (r, step, key, m[key], ref["metrics"][key])
       assert np.isclose(m["grad_norm_max"], max(ref["norms"].values()), rtol=1e-3), (r, step)
@@ -389,3 +396,40 @@ def test_rccl_banner_does_not_reach_stdout(tmp_path):
   r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=180)
   assert r.returncode == 0, r.stderr[-2000:]
   assert r.stdout.strip() == '{"ok": 1}', r.stdout
+
+
+def test_bench_line_at_two_ranks_carries_every_scaling_mode(tmp_path):
+  """The driver's launch line for N > 1, rehearsed with 2 ranks sharing the box's one GPU (SMX_SHARE_GPU=1, the hand-written
+  exchange: RCCL refuses two ranks on one device): rank 0 prints ONE JSON line whose `scaling_modes` holds weak, strong +
+  SyncBatchNorm (the reference's global batch and arithmetic) and the C5 share, each with the collective alone, the
+  no-communicator step and their difference, beside DESIGN.md section 5's predictions for N = 8.  (The NUMBERS mean nothing here --
+  the ranks time-slice one device; the fields are what is asserted.)  torch.distributed.run is a fresh child process."""
+  import json
+  import socket
+  s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+  env = dict(os.environ, SMX_SHARE_GPU="1", SMX_ALLREDUCE="p2p-only", PYTHONPATH=ROOT)
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--c5-cells", "4096"]
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+  assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+  lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+  assert len(lines) == 1, r.stdout[-2000:]
+  out = json.loads(lines[0])
+  assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["unit"] == "cells/s" and out["value"] > 0
+  assert out["scaling"] == "weak" and out["config"]["global_batch"] == 256 and out["dp"]["collective"] == "p2p-only"
+  assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out     # (the CPU baseline is an N = 1 item)
+  sm = out["scaling_modes"]
+  assert set(sm) == {"weak", "strong_syncbn", "c5"}
+  expect = {"weak": (128, 256, False), "strong_syncbn": (64, 128, True), "c5": (128, 256, False)}
+  for k, (bpg, gb, sbn) in expect.items():
+    v = sm[k]
+    assert (v["batch_per_gpu"], v["global_batch"], v["sync_bn"]) == (bpg, gb, sbn), (k, v)
+    assert v["collective"] == "p2p-only" and v["allreduce_us"] > 0 and v["allreduce_bytes"] > 0
+    assert v["ms_per_step"] > 0 and v["nocomm_ms_per_step"] > 0 and v["cells_per_s"] > 0 and np.isfinite(v["final_loss"])
+    assert np.isclose(v["dp_overhead_us"], 1e3 * (v["ms_per_step"] - v["nocomm_ms_per_step"]), atol=0.2)
+    assert np.isclose(v["cells_per_s"], gb / (v["ms_per_step"] * 1e-3), rtol=1e-3)
+    p = v["predicted_n8"]
+    assert p["ms_per_step"][0] < p["ms_per_step"][1] and p["x_one_gpu"][0] < p["x_one_gpu"][1] and p["reading"]
+  assert sm["c5"]["cells_resident_per_gpu"] == 2048 and sm["c5"]["allreduce_bytes"] > 9 * sm["weak"]["allreduce_bytes"]

@@ -52,7 +52,11 @@ rng = np.random.default_rng(5)
 res = dict()
 for step in range(3):
   rows = rng.permutation(400)[: 48 * world].astype(np.int32).reshape(world, 48)
-  m = e.train_step(rows[rank])
+  try:
+    m = e.train_step(rows[rank])
+  except Exception as err:            # a failed exchange is REPORTED by the step (SMX_ERR_COMM), not left in an unread word
+    res["raised"] = str(err)
+    break
   res[f"loss{{step}}"] = m["loss"]; res[f"kl{{step}}"] = m["kl"]; res[f"gn{{step}}"] = m["grad_norm_max"]
   if step == 0:
     for k, v in e.get_params(which=1).items():
@@ -101,10 +105,11 @@ def _run(tmp_path, world, kw, sync_bn=0, die=0, timeout=180, extra_env=None):
   return outs
 
 
-@pytest.mark.parametrize("world,sync_bn,buckets", [(2, 0, 1), (3, 0, 1), (2, 1, 1), (2, 0, 2)])
+@pytest.mark.parametrize("world,sync_bn,buckets", [(2, 0, 1), (3, 0, 1), (2, 1, 1), (2, 0, 2), (2, 1, 2)])
 def test_p2p_allreduce_between_processes_matches_oracle(tmp_path, world, sync_bn, buckets):
   """buckets = 2 (SMX_DP_BUCKETS=2): the heads' gradients are exchanged on the communication stream while the rest of the
-  backward pass runs, the remainder afterwards -- two exchanges per step, the same numbers."""
+  backward pass runs, the remainder afterwards -- two exchanges per step, the same numbers.  With SyncBatchNorm the exchange
+  keeps ONE bucket whatever the switch says (its staging / flags are shared with SyncBatchNorm's small collectives: ADVICE r03)."""
   from sisua_amd import build
   build.build(verbose=False)
   kw = KW_SYNC if sync_bn else KW
@@ -139,14 +144,15 @@ def test_p2p_allreduce_between_processes_matches_oracle(tmp_path, world, sync_bn
 
 
 def test_p2p_exchange_gives_up_on_a_dead_peer(tmp_path):
-  """Rank 1 leaves after the handles were exchanged; rank 0's step waits ~2 s for its READY flag, gives up, and the host
-  reads the error word -- the device is not left with a spinning kernel."""
+  """Rank 1 leaves after the handles were exchanged; rank 0's step waits SMX_P2P_TIMEOUT_S (2 s here, 30 s by default) for its READY
+  flag, gives up, and the STEP reports it (SMX_ERR_COMM from the metrics read-back; the error word stays set for smx_comm_p2p_error)
+  -- the device is not left with a spinning kernel and no garbage gradient is applied silently."""
   from sisua_amd import build
   build.build(verbose=False)
-  outs = _run(tmp_path, 2, KW, die=1, timeout=120)
+  outs = _run(tmp_path, 2, KW, die=1, timeout=120, extra_env=dict(SMX_P2P_TIMEOUT_S="2"))
   assert outs[0][0] == 0 and "DONE" in outs[0][1], outs[0][1][-3000:]
   r0 = np.load(tmp_path / "r0.npz")
-  assert int(r0["err"]) != 0
+  assert int(r0["err"]) != 0 and "timed out" in str(r0["raised"])
 
 
 def test_attach_engine_falls_back_to_the_exchange_when_rccl_refuses(tmp_path):

@@ -64,6 +64,9 @@ CASES = {
                        tie_scale=True, tie_mixtures=True),
     "scale_tied_loc": dict(model="scale", n_genes=90, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=6, n_components=4,
                            tie_loc=True),
+    # ... with a clipnorm that binds on the tied tensors: the clip norm of C identical rows is the SHARED variable's (sum of squares / C)
+    "scale_tied_clip": dict(model="scale", n_genes=90, likelihood="nb", enc_units=(32,), dec_units=(32,), latent_dim=6, n_components=4,
+                            tie_loc=True, tie_scale=True, clipnorm=2.0),   # (stored norms 2.3 / 5.4+: loc is clipped only under the stored-tensor convention)
     "scalar": dict(model="scale", n_genes=130, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=8, n_components=5,
                    labels=((10, "nb"), (4, "onehot"))),   # SCALAR = SCALE + SISUA's label heads (scale.py:52-59)
     "fvae": dict(model="fvae", n_genes=150, likelihood="zinb", enc_units=(48,), dec_units=(48,), latent_dim=10, disc_units=100,
