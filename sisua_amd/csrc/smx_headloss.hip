@@ -45,7 +45,12 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
   static_assert(!B3 || SLAB / NW == 16, "the bf16 form needs 8 consecutive k per lane half");
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
   constexpr int KS = SLAB / NW, KH = KS / 2, RPW = 16 / NW;
-  __shared__ float red[NW > 1 ? NW * 1024 : 1];   // ONE plane's NW partial tiles at a time (32 KB at 8 waves: two workgroups per CU)
+  // ONE plane's NW partial tiles at a time (32 KB at 8 waves) | training epilogue: the waves' queues of their non-zero counts
+  // (smx_loss.h: one float2 per element of the tile = 8 KB) -- ONE array (a second __shared__ object can cost waits)
+  constexpr bool QUEUE = EPI == 1 && NW >= 4;
+  constexpr int QOFF = NW > 1 ? NW * 1024 : 0;
+  __shared__ float red[(NW > 1 ? NW * 1024 : 1) + (QUEUE ? 2 * 1024 : 0)];
+  float2* const lq = reinterpret_cast<float2*>(red + QOFF);
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   // blocks b, b + 8, b + 16, ... share an XCD: give them the cell tiles of ONE gene tile
@@ -166,8 +171,9 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
 #pragma unroll
     for (int c = 0; c < RPW; c += CH) {
       typedef float Vec[CH];
+      static_assert(!QUEUE || CH == RPW, "the queue form: one call per tile (a wave's stretch holds its RPW elements per lane)");
       count_elem_vec<LK, 0, CH>(*(const Vec*)(xs + c), *(const Vec*)(v[0] + c), *(const Vec*)(v[1] + c), *(const Vec*)(p2 + c),
-                                *(Vec*)(llk + c), *(Vec*)(d0 + c), *(Vec*)(d1 + c), *(Vec*)(d2 + c));
+                                *(Vec*)(llk + c), *(Vec*)(d0 + c), *(Vec*)(d1 + c), *(Vec*)(d2 + c), QUEUE ? lq : nullptr);
     }
   }
 #pragma unroll

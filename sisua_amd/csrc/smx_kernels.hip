@@ -43,13 +43,19 @@ __device__ inline void vstore(float* p, const float (&v)[VEC]) {
 template <int LK, int DIRECT, int BWD, int VEC, int BLOCK = 256, int U16 = 0>   // U16: counts from the compact uint16 store
 __global__ __launch_bounds__(BLOCK) void count_loss_kernel(LossArgs a) {
   constexpr int K = LK == SMX_LLK_MSE ? 1 : (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
+  constexpr int LKC = LK == SMX_LLK_MSE ? SMX_LLK_NB : LK;
+  // every wave's non-zero counts go through ONE compacted pass of the lgamma / digamma code (smx_loss.h: lgamma_digamma_diff_queue)
+  __shared__ float2 lq[LK == SMX_LLK_MSE ? 1 : BLOCK * VEC];
   const float inv_g = 1.f / (float)a.G;   // SMX_LLK_MSE: -log p = mean over the genes of (x - mean)^2
   const int b = blockIdx.y;
   const int g0 = (blockIdx.x * BLOCK + threadIdx.x) * VEC;
+  const bool in = g0 < a.Gp;   // (lanes beyond the row carry zero counts)
   float acc = 0.f;
-  if (g0 < a.Gp) {
+  float xs[VEC], a0[VEC], a1[VEC], a2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { xs[e] = 0.f; a0[e] = 0.f; a1[e] = 0.f; a2[e] = 0.f; }
+  if (in) {
     const long src = a.rows ? a.rows[b] : b;
-    float xs[VEC], a0[VEC], a1[VEC], a2[VEC];
     const float* pb = a.P + (long)b * a.ldp + g0;
     if (U16) {
       const uint16_t* xh = reinterpret_cast<const uint16_t*>(a.X) + src * a.ldx + g0;
@@ -62,31 +68,41 @@ __global__ __launch_bounds__(BLOCK) void count_loss_kernel(LossArgs a) {
     vload<VEC>(pb, a0);
     if (K >= 2) vload<VEC>(pb + a.plane_stride, a1);
     if (K == 3) vload<VEC>(pb + 2 * a.plane_stride, a2);
-    float r0[VEC], r1[VEC], r2[VEC];
+  }
+  float r0[VEC], r1[VEC], r2[VEC];
+  if (a.likelihood < 0 || LK == SMX_LLK_MSE) {   // (launch-uniform) the diagnostics and the deterministic output: element by element
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       float llk = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
       if (a.likelihood == -1) {  // diagnostic: same traffic, no arithmetic
         d0 = a0[e] + xs[e]; d1 = K >= 2 ? a1[e] : 0.f; d2 = K == 3 ? a2[e] : 0.f; acc += d0;
       } else if (a.likelihood == -2) {  // diagnostic: every count treated as 0 (no lgamma work)
-        count_elem<LK == SMX_LLK_MSE ? SMX_LLK_NB : LK, DIRECT>(0.f, a0[e], K >= 2 ? a1[e] : 0.f, K == 3 ? a2[e] : 0.f, llk, d0, d1, d2);
+        count_elem<LKC, DIRECT>(0.f, a0[e], K >= 2 ? a1[e] : 0.f, K == 3 ? a2[e] : 0.f, llk, d0, d1, d2);
         acc += llk + xs[e];
-      } else if (g0 + e < a.G) {
-        if (LK == SMX_LLK_MSE) {
-          const float df = xs[e] - a0[e];
-          llk = -(df * df) * inv_g; d0 = 2.f * df * inv_g;
-        } else
-        count_elem<LK == SMX_LLK_MSE ? SMX_LLK_NB : LK, DIRECT>(xs[e], a0[e], K >= 2 ? a1[e] : 0.f, K == 3 ? a2[e] : 0.f, llk, d0, d1, d2);
+      } else if (in && g0 + e < a.G) {
+        const float df = xs[e] - a0[e];
+        llk = -(df * df) * inv_g; d0 = 2.f * df * inv_g;
         acc += llk;
       }
       r0[e] = d0 * a.grad_scale; r1[e] = d1 * a.grad_scale; r2[e] = d2 * a.grad_scale;
     }
-    if (BWD) {
-      float* db = a.dP + (long)b * a.ldp + g0;
-      vstore<VEC>(db, r0);
-      if (K >= 2) vstore<VEC>(db + a.plane_stride, r1);
-      if (K == 3) vstore<VEC>(db + 2 * a.plane_stride, r2);
+  } else {
+    float llk[VEC], d0[VEC], d1[VEC], d2[VEC], xq[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) xq[e] = (in && g0 + e < a.G) ? xs[e] : 0.f;
+    count_elem_vec<LKC, DIRECT, VEC>(xq, a0, a1, a2, llk, d0, d1, d2, lq);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const bool ok = in && g0 + e < a.G;
+      acc += ok ? llk[e] : 0.f;
+      r0[e] = ok ? d0[e] * a.grad_scale : 0.f; r1[e] = ok ? d1[e] * a.grad_scale : 0.f; r2[e] = ok ? d2[e] * a.grad_scale : 0.f;
     }
+  }
+  if (BWD && in) {
+    float* db = a.dP + (long)b * a.ldp + g0;
+    vstore<VEC>(db, r0);
+    if (K >= 2) vstore<VEC>(db + a.plane_stride, r1);
+    if (K == 3) vstore<VEC>(db + 2 * a.plane_stride, r2);
   }
   // one partial per wave, no workgroup barrier: the consumer sums [n_chunks * waves] values per cell
   acc = wave_sum(acc);

@@ -114,16 +114,62 @@ __device__ inline void lgamma_digamma_diff_vec(const float (&x)[N], const float 
   }
 }
 
+// ===========================================================================
+// lgamma(x + r) - lgamma(r) and its r-derivative for the NON-ZERO counts of a wave, compacted.
+// 88-93 % of the elements of a single-cell minibatch are x == 0, for which both results are exactly 0 whatever r (the recurrence
+// leaves P = 1: v_log(1) = 0, dP = 0; the Stirling form differences two equal terms) -- yet the straight-line form above runs the
+// 8-step recurrence for every element and the Stirling code for every element of every wave that holds ONE count above 8.  Here the
+// lanes push their non-zero (x, r) pairs into the wave's own stretch of an LDS queue (ballot + mbcnt), the wave drains it 64 entries
+// at a time through the scalar code (which branches per entry) and every lane reads its entries' results back.  No workgroup
+// barrier: a wave's LDS accesses complete in order.  Per element the arithmetic is lgamma_digamma_diff's, operation for operation:
+// bit-identical to the straight-line forms (profiles/r04_likelihood_forms.txt: the same final loss to the last bit over 200 steps at
+// both widths).  What it buys is small, and measured: the whole lgamma / digamma part is 4.7 of the fused head's 35 us at 128 x 20 000
+// (1.7 of the standalone kernel's 15): queue form -1.0 us (C5 width), -0.4 us (C2).  A workgroup-wide queue (one LDS atomic per wave,
+// two barriers, the waves sharing the drain rounds) measured the same as the per-wave form and was not kept.
+//   q : LDS, 64 N float2 per wave of the workgroup (the wave's stretch starts at wave * 64 * N)
+// ===========================================================================
+template <int N>
+__device__ inline void lgamma_digamma_diff_queue(const float (&x)[N], const float (&r_in)[N], float (&lg)[N], float (&dg)[N], float2* q) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  q += wave * 64 * N;
+  int pos[N];
+  int mine = 0;
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const unsigned long long m = __ballot(x[e] != 0.f);
+    pos[e] = mine + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    mine += __popcll(m);
+    lg[e] = 0.f; dg[e] = 0.f;
+    if (x[e] != 0.f) q[pos[e]] = make_float2(x[e], r_in[e]);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();   // (the stretch is this wave's own)
+  for (int k0 = 0; k0 < mine; k0 += 64) {
+    const int k = k0 + lane;
+    if (k < mine) {
+      const float2 v = q[k];
+      const LgDg o = lgamma_digamma_diff(v.x, v.y);
+      q[k] = make_float2(o.lg, o.dg);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int e = 0; e < N; ++e)
+    if (x[e] != 0.f) { const float2 v = q[pos[e]]; lg[e] = v.x; dg[e] = v.y; }
+}
+
+// q != nullptr: lgamma / digamma through the per-wave queue form above
 template <int LK, int DIRECT, int N>
 __device__ inline void count_elem_vec(const float (&x)[N], const float (&p0)[N], const float (&p1)[N], const float (&p2)[N],
-                                      float (&llk)[N], float (&d0)[N], float (&d1)[N], float (&d2)[N]) {
+                                      float (&llk)[N], float (&d0)[N], float (&d1)[N], float (&d2)[N],
+                                      float2* q = nullptr) {
   float ell[N];
   if (LK == SMX_LLK_NB || LK == SMX_LLK_ZINB) {
     float r[N], lg[N], dg[N];
     SpSg s[N];
 #pragma unroll
     for (int e = 0; e < N; ++e) { r[e] = fexp(p0[e]); s[e] = softplus_sigmoid(p1[e]); }
-    lgamma_digamma_diff_vec<N>(x, r, lg, dg);
+    if (q) lgamma_digamma_diff_queue<N>(x, r, lg, dg, q);
+    else lgamma_digamma_diff_vec<N>(x, r, lg, dg);
 #pragma unroll
     for (int e = 0; e < N; ++e) {
       ell[e] = lg[e] + x[e] * (p1[e] - s[e].sp) - r[e] * s[e].sp;
@@ -140,7 +186,8 @@ __device__ inline void count_elem_vec(const float (&x)[N], const float (&p0)[N],
         mu[e] = s0.sp; th[e] = s1.sp; g0[e] = s0.sg; g1[e] = s1.sg;
       }
     }
-    lgamma_digamma_diff_vec<N>(x, th, lg, dg);
+    if (q) lgamma_digamma_diff_queue<N>(x, th, lg, dg, q);
+    else lgamma_digamma_diff_vec<N>(x, th, lg, dg);
 #pragma unroll
     for (int e = 0; e < N; ++e) {
       const float eps = 1e-8f;
