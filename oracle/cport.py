@@ -42,6 +42,18 @@ class CStep:
     self.h = C.c_void_p(self.lib.ost_create(C.byref(c), arr))
     self.shapes = {n: params[n].shape for n in self.names}
 
+  def close(self):
+    if getattr(self, "h", None):
+      self.lib.ost_destroy.argtypes = [C.c_void_p]
+      self.lib.ost_destroy(self.h)
+      self.h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
   @property
   def threads(self):
     return int(self.lib.ost_threads())

@@ -39,6 +39,8 @@ typedef struct {
   /* flat views for the optimiser */
   int n_tensors; float* tp[64]; float* tg[64]; float* tm[64]; float* tv[64]; size_t tn[64];
   int t;
+  /* every buffer of the model (freed by ost_destroy: found by the AddressSanitizer build, tools/asan_build.sh) */
+  float* owned[640]; int n_owned;
   /* activations */
   float *h0, *in_mask, *lat, *z, *sig, *eps, *P, *dP, *dd, *dz, *dlat, *dh, *tmp;
 } ost_t;
@@ -138,23 +140,27 @@ static inline float count_elem(int lik, float x, float p0, float p1, float p2, f
   return (float)(ell - spg);
 }
 
-static float* falloc(size_t n) { float* p = (float*)calloc(n ? n : 1, sizeof(float)); return p; }
-static void reg(ost_t* m, float* p, float* g, size_t n) { int i = m->n_tensors++; m->tp[i] = p; m->tg[i] = g; m->tn[i] = n; m->tm[i] = falloc(n); m->tv[i] = falloc(n); }
+static float* falloc(ost_t* m, size_t n) {
+  float* p = (float*)calloc(n ? n : 1, sizeof(float));
+  if (m->n_owned < (int)(sizeof(m->owned) / sizeof(m->owned[0]))) m->owned[m->n_owned++] = p;
+  return p;
+}
+static void reg(ost_t* m, float* p, float* g, size_t n) { int i = m->n_tensors++; m->tp[i] = p; m->tg[i] = g; m->tn[i] = n; m->tm[i] = falloc(m, n); m->tv[i] = falloc(m, n); }
 
 static void init_mlp(ost_t* m, layer_t* L, int n, const int32_t* units, int n_in, int stream0, float drop, const float* const** pp) {
   for (int i = 0; i < n; ++i) {
     layer_t* l = &L[i];
     l->in = n_in; l->out = units[i]; l->stream = stream0 + i; l->drop = drop;
     const size_t nw = (size_t)n_in * units[i];
-    l->W = falloc(nw); memcpy(l->W, *(*pp)++, nw * sizeof(float)); l->gW = falloc(nw); reg(m, l->W, l->gW, nw);
+    l->W = falloc(m, nw); memcpy(l->W, *(*pp)++, nw * sizeof(float)); l->gW = falloc(m, nw); reg(m, l->W, l->gW, nw);
     if (m->c.batchnorm) {
-      l->gamma = falloc(units[i]); memcpy(l->gamma, *(*pp)++, units[i] * sizeof(float)); l->ggamma = falloc(units[i]); reg(m, l->gamma, l->ggamma, units[i]);
-      l->beta = falloc(units[i]); memcpy(l->beta, *(*pp)++, units[i] * sizeof(float)); l->gbeta = falloc(units[i]); reg(m, l->beta, l->gbeta, units[i]);
-      l->mm = falloc(units[i]); l->mv = falloc(units[i]); for (int j = 0; j < units[i]; ++j) l->mv[j] = 1.f;
+      l->gamma = falloc(m, units[i]); memcpy(l->gamma, *(*pp)++, units[i] * sizeof(float)); l->ggamma = falloc(m, units[i]); reg(m, l->gamma, l->ggamma, units[i]);
+      l->beta = falloc(m, units[i]); memcpy(l->beta, *(*pp)++, units[i] * sizeof(float)); l->gbeta = falloc(m, units[i]); reg(m, l->beta, l->gbeta, units[i]);
+      l->mm = falloc(m, units[i]); l->mv = falloc(m, units[i]); for (int j = 0; j < units[i]; ++j) l->mv[j] = 1.f;
     } else {
-      l->bias = falloc(units[i]); memcpy(l->bias, *(*pp)++, units[i] * sizeof(float)); l->gbias = falloc(units[i]); reg(m, l->bias, l->gbias, units[i]);
+      l->bias = falloc(m, units[i]); memcpy(l->bias, *(*pp)++, units[i] * sizeof(float)); l->gbias = falloc(m, units[i]); reg(m, l->bias, l->gbias, units[i]);
     }
-    l->inv = falloc(units[i]);
+    l->inv = falloc(m, units[i]);
     n_in = units[i];
   }
 }
@@ -165,12 +171,12 @@ void* ost_create(const ost_config* c, const float* const* params) {
   const float* const* pp = params;
   init_mlp(m, m->enc, c->n_enc, c->enc, c->G, 16, c->dropout_enc, &pp);
   const int H = c->enc[c->n_enc - 1], D = c->D;
-  m->Wlat = falloc((size_t)H * 2 * D); memcpy(m->Wlat, *pp++, (size_t)H * 2 * D * sizeof(float)); m->gWlat = falloc((size_t)H * 2 * D); reg(m, m->Wlat, m->gWlat, (size_t)H * 2 * D);
-  m->blat = falloc(2 * D); memcpy(m->blat, *pp++, 2 * D * sizeof(float)); m->gblat = falloc(2 * D); reg(m, m->blat, m->gblat, 2 * D);
+  m->Wlat = falloc(m, (size_t)H * 2 * D); memcpy(m->Wlat, *pp++, (size_t)H * 2 * D * sizeof(float)); m->gWlat = falloc(m, (size_t)H * 2 * D); reg(m, m->Wlat, m->gWlat, (size_t)H * 2 * D);
+  m->blat = falloc(m, 2 * D); memcpy(m->blat, *pp++, 2 * D * sizeof(float)); m->gblat = falloc(m, 2 * D); reg(m, m->blat, m->gblat, 2 * D);
   init_mlp(m, m->dec, c->n_dec, c->dec, D, 48, c->dropout_dec, &pp);
   const int Hd = c->dec[c->n_dec - 1]; const size_t kg = (size_t)m->k * c->G;
-  m->Wout = falloc(Hd * kg); memcpy(m->Wout, *pp++, Hd * kg * sizeof(float)); m->gWout = falloc(Hd * kg); reg(m, m->Wout, m->gWout, Hd * kg);
-  m->bout = falloc(kg); memcpy(m->bout, *pp++, kg * sizeof(float)); m->gbout = falloc(kg); reg(m, m->bout, m->gbout, kg);
+  m->Wout = falloc(m, Hd * kg); memcpy(m->Wout, *pp++, Hd * kg * sizeof(float)); m->gWout = falloc(m, Hd * kg); reg(m, m->Wout, m->gWout, Hd * kg);
+  m->bout = falloc(m, kg); memcpy(m->bout, *pp++, kg * sizeof(float)); m->gbout = falloc(m, kg); reg(m, m->bout, m->gbout, kg);
   return m;
 }
 
@@ -181,9 +187,9 @@ static void ensure(ost_t* m, int B) {
   for (int i = 0; i < m->c.n_enc; ++i) if (m->c.enc[i] > maxw) maxw = m->c.enc[i];
   for (int i = 0; i < m->c.n_dec; ++i) if (m->c.dec[i] > maxw) maxw = m->c.dec[i];
   layer_t* Ls[2] = {m->enc, m->dec}; const int ns[2] = {m->c.n_enc, m->c.n_dec};
-  for (int q = 0; q < 2; ++q) for (int i = 0; i < ns[q]; ++i) { layer_t* l = &Ls[q][i]; const size_t n = (size_t)B * l->out; l->pre = falloc(n); l->xhat = falloc(n); l->act = falloc(n); l->mask = falloc(n); }
-  m->h0 = falloc((size_t)B * G); m->in_mask = falloc((size_t)B * G); m->lat = falloc((size_t)B * 2 * D); m->z = falloc((size_t)B * D); m->sig = falloc((size_t)B * D); m->eps = falloc((size_t)B * D);
-  m->P = falloc((size_t)B * m->k * G); m->dP = falloc((size_t)B * m->k * G); m->dd = falloc((size_t)B * maxw); m->dz = falloc((size_t)B * maxw); m->dlat = falloc((size_t)B * 2 * D); m->dh = falloc((size_t)B * maxw); m->tmp = falloc((size_t)B * maxw);
+  for (int q = 0; q < 2; ++q) for (int i = 0; i < ns[q]; ++i) { layer_t* l = &Ls[q][i]; const size_t n = (size_t)B * l->out; l->pre = falloc(m, n); l->xhat = falloc(m, n); l->act = falloc(m, n); l->mask = falloc(m, n); }
+  m->h0 = falloc(m, (size_t)B * G); m->in_mask = falloc(m, (size_t)B * G); m->lat = falloc(m, (size_t)B * 2 * D); m->z = falloc(m, (size_t)B * D); m->sig = falloc(m, (size_t)B * D); m->eps = falloc(m, (size_t)B * D);
+  m->P = falloc(m, (size_t)B * m->k * G); m->dP = falloc(m, (size_t)B * m->k * G); m->dd = falloc(m, (size_t)B * maxw); m->dz = falloc(m, (size_t)B * maxw); m->dlat = falloc(m, (size_t)B * 2 * D); m->dh = falloc(m, (size_t)B * maxw); m->tmp = falloc(m, (size_t)B * maxw);
 }
 
 static void mlp_fwd(ost_t* m, layer_t* L, int n, const float* in, int B, int step, const int64_t* cells) {
@@ -335,4 +341,9 @@ void ost_set_threads(int n) {
   (void)n;
 #endif
 }
-void ost_destroy(void* h) { free(h); /* process-lifetime buffers: the baseline runs once */ }
+void ost_destroy(void* h) {
+  ost_t* m = (ost_t*)h;
+  if (!m) return;
+  for (int i = 0; i < m->n_owned; ++i) free(m->owned[i]);
+  free(m);
+}

@@ -197,15 +197,17 @@ __global__ __launch_bounds__(256) void bigk_reduce_kernel(const float* __restric
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < n4) {
     const float4* p = reinterpret_cast<const float4*>(part) + e;
-    int zz = t;
-    for (; zz + 48 < n_slices; zz += 64) {   // four of this thread's slices in flight
-      float4 v[4];
+    // ALL of this thread's slices of a batch of 256 in flight at once (~13 loads at 209 slices: ONE memory round trip instead of four;
+    // unconditional loads from a clamped slice -- a predicated 16-byte load is split into four 4-byte ones -- masked at the add; same
+    // order of additions as before: same bits)
+    for (int z0 = t; z0 < n_slices; z0 += 256) {
+      float4 v[16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = p[(long)(zz + 16 * u) * s4];
+      for (int u = 0; u < 16; ++u) v[u] = p[(long)min(z0 + 16 * u, n_slices - 1) * s4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      for (int u = 0; u < 16; ++u)
+        if (z0 + 16 * u < n_slices) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
-    for (; zz < n_slices; zz += 16) { const float4 v = p[(long)zz * s4]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
   }
   sh[t][el] = acc;
   __syncthreads();
