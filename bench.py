@@ -472,6 +472,31 @@ def main():
     entries += roofline_entries(e5, cfg5, b5, kernel_times(e5, o5, b5, 30), "c5-shard")
     e5.close()
 
+  # ---- the scoring path: marginal_log_prob of one batch with the reference's 100 posterior draws (posterior.py:964) ----
+  scoring = None
+  if rank == 0 and world == 1 and args.workload == "8kly" and eng.max_batch >= batch:
+    try:
+      rows_s = order_ev[:batch]
+      for _ in range(3):
+        eng.marginal_llk(row_ids=rows_s, n_samples=100)
+      ts = []
+      for _ in range(20):
+        t_s = time.perf_counter()
+        eng.marginal_llk(row_ids=rows_s, n_samples=100)
+        ts.append(time.perf_counter() - t_s)
+      us_call = 1e6 * float(np.median(ts))
+      # the bound of this path is vector issue, not memory: ~230 vector instructions per likelihood element on
+      # 1024 SIMDs x one wave-instruction per 4 cycles; the 100 draws' planes (396 MB) never exist in memory
+      elems = batch * 100 * cfg.n_genes
+      valu_bound_us = elems * 230.0 / 64.0 / (1024 * 2.4e9 / 4.0) * 1e6
+      scoring = {"what": f"smx_marginal_llk: {batch} cells x 100 posterior draws x {cfg.n_genes} genes, one call (host-synchronous, median of 20)",
+                 "marginal_llk_us": round(us_call, 1), "draws_per_s": round(batch * 100 / (us_call * 1e-6), 0),
+                 "likelihood_elements_per_s": round(elems / (us_call * 1e-6), 0),
+                 "roofline": {"bound": "valu", "model": "230 vector instructions per element / 64 lanes / (1024 SIMDs x 2.4 GHz / 4 cycles per instruction)",
+                              "bound_us": round(valu_bound_us, 1), "frac": round(valu_bound_us / us_call, 4)}}
+    except Exception as err:
+      scoring = {"error": str(err)[:200]}
+
   if rank == 0:
     head = entries[0]
     fused = kt["x8"]["fused"] is not None
@@ -519,6 +544,8 @@ def main():
                      "event_pair_overhead_us": round(null_us, 3), "launches_per_event_pair": LOSS_REPEAT},
         "kernel_us": per_kernel,
     }
+    if scoring is not None:
+      out["scoring"] = scoring
     if dp_info is not None:
       out["dp"] = dp_info
     if scaling_modes is not None:

@@ -276,6 +276,17 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
                 int32_t n_samples, float* z_mean, float* z_scale, float* z_samples, float* l_mean, float* l_scale,
                 float* l_samples, float* x_params, float* const* y_params);
 
+/* The same walk over a host matrix, but what leaves the device is a STATISTIC of the gene output instead of its parameter planes -- what
+ * the reference's callers ask of predict()'s result: `y.mean()`, `.variance()`, `.log_prob(x)` of the output distribution or of its
+ * count distribution without the zero-inflation wrapper (sisua/analysis/posterior.py:187-255: 'reconstructed' / 'imputed').  The planes
+ * are 4 k G bytes per cell and draw (24 KB at 1998 genes, zinb) and a fresh result array of that size is first-touched by the copy;
+ * a mean is a third of it, the mean over the draws 1 / (3 n_samples), a log_prob 4 bytes.  Same passes, same draws as smx_predict.
+ *   stat 0 mean, 1 variance: out [n_samples, n_cells, n_genes];  2 mean averaged over the draws: out [n_cells, n_genes];
+ *   stat 3 log_prob (summed over the genes: Independent(..., 1)): out [n_samples, n_cells], of `target` [n_cells, n_genes] or, target = NULL,
+ *          of host_x itself;  count_only != 0: the count distribution (NB / NBD) of a zero-inflated output. */
+int smx_predict_stat(smx_model* m, const float* host_x, const float* host_library, int64_t n_cells, int32_t batch, int32_t n_samples,
+                     int32_t stat, int32_t count_only, const float* target, float* out);
+
 /* Decoder only (SingleCellModel.decode, single_cell_model.py:141-151; scvi.py:108-171):
  * z [batch,D] (and l [batch] for scvi) -> the same x_params / y_params as smx_forward,
  * eval mode. */

@@ -99,6 +99,7 @@ SIGNATURES = {
     "smx_shuffle_order": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "smx_predict": (C.c_int, [_VP, _FP, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP,
                               C.POINTER(_FP)]),
+    "smx_predict_stat": (C.c_int, [_VP, _FP, _FP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP]),
     "smx_decode": (C.c_int, [_VP, _FP, _FP, C.c_int32, _FP, C.POINTER(_FP)]),
     "smx_dataset_library": (C.c_int, [_VP, _FP]),
     "smx_dataset_corrupt": (C.c_int, [_VP, C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_int64)]),

@@ -1,5 +1,6 @@
 // smx_predict.hip -- evaluation-mode forward passes handed back to the host: smx_forward, smx_forward_samples, smx_predict, smx_decode.
 #include "smx_model.h"
+#include "smx_loss.h"
 
 namespace smx {
 
@@ -87,6 +88,86 @@ __global__ __launch_bounds__(256) void pack_kernel(PackJobs jobs_by_value) {
   }
 }
 
+// ---- statistics of the gene output on the device (smx_predict_stat): what the reference's callers ask of predict()'s result --
+// y.mean() / .variance() / .log_prob(x), posterior.py:187-255 -- computed from the parameter planes of a pass WITHOUT the planes leaving
+// the device (24 KB per cell and draw at C2: predict's D2H traffic).  Formulas = sisua_amd/distributions.py (float32 here).
+struct StatArgs {
+  const float* P; long ldp; long plane_stride;   // planes of `rows` = Sn * B stacked rows (row s * B + b = draw s of cell b)
+  int B, Sn, G, lk, direct, count_only, stat;    // stat: 0 mean, 1 variance (per draw), 2 mean averaged over the draws, 3 log_prob
+  float inv_S; int accumulate;                   // stat 2: this pass adds (sum over its draws) * inv_S to what earlier passes left
+  float* dst; long dst_draw;                     // stat 0 / 1: dst[s * dst_draw + b * G + g]; stat 2: dst[b * G + g]; stat 3: dst[s * dst_draw + b]
+  const float* T; long ldt; const int32_t* trows; int t_u16;   // stat 3: targets [B][ldt] (or the resident rows trows[b])
+};
+__device__ inline void plane_moments(int lk, int direct, int count_only, float p0, float p1, float p2, float& mean, float& var) {
+  float mc, vc;
+  if (lk == SMX_LLK_MSE) { mean = p0; var = 0.f; return; }
+  if (lk == SMX_LLK_NB || lk == SMX_LLK_ZINB) { const float el = expf(p1); mc = expf(p0) * el; vc = mc * (1.f + el); }
+  else {
+    const float mu = direct ? p0 : softplus_sigmoid(p0).sp, th = direct ? p1 : softplus_sigmoid(p1 + SMX_SOFTPLUS_INV_1).sp;
+    mc = mu; vc = mu + mu * mu / th;
+  }
+  if ((lk == SMX_LLK_ZINB || lk == SMX_LLK_ZINBD) && !count_only) {
+    const float pi = 1.f / (1.f + expf(-p2));
+    mean = (1.f - pi) * mc; var = (1.f - pi) * (vc + pi * mc * mc);
+  } else { mean = mc; var = vc; }
+}
+__global__ __launch_bounds__(256) void plane_stat_kernel(StatArgs a) {
+  const int g = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (g >= a.G) return;
+  const bool zi = a.lk == SMX_LLK_ZINB || a.lk == SMX_LLK_ZINBD;
+  float acc = 0.f;
+  for (int s = 0; s < a.Sn; ++s) {   // (draw order: the average over the draws is deterministic)
+    const float* p = a.P + ((long)s * a.B + b) * a.ldp + g;
+    float mean, var;
+    plane_moments(a.lk, a.direct, a.count_only, p[0], a.lk == SMX_LLK_MSE ? 0.f : p[a.plane_stride], zi ? p[2 * a.plane_stride] : 0.f, mean, var);
+    if (a.stat == 2) acc += mean;
+    else a.dst[(long)s * a.dst_draw + (long)b * a.G + g] = a.stat == 0 ? mean : var;
+  }
+  if (a.stat == 2) { float* d = a.dst + (long)b * a.G + g; *d = (a.accumulate ? *d : 0.f) + acc * a.inv_S; }
+}
+template <int LK, int DIRECT>
+__device__ inline float row_llk_elem(float x, float p0, float p1, float p2) {
+  float llk, d0, d1, d2;
+  count_elem<LK, DIRECT>(x, p0, p1, p2, llk, d0, d1, d2);
+  return llk - lgammaf(x + 1.f);
+}
+// stat 3: one workgroup per stacked row: log p(target row | the row's planes), summed over the genes (Independent(..., 1).log_prob)
+__global__ __launch_bounds__(256) void plane_logprob_kernel(StatArgs a) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x, b = row % a.B, s = row / a.B;
+  const float* p = a.P + (long)row * a.ldp;
+  const long trow = a.trows ? a.trows[b] : b;
+  int lk = a.lk;
+  if (a.count_only && lk == SMX_LLK_ZINB) lk = SMX_LLK_NB;
+  if (a.count_only && lk == SMX_LLK_ZINBD) lk = SMX_LLK_NBD;
+  float acc = 0.f;
+  for (int g = threadIdx.x; g < a.G; g += 256) {
+    const float x = a.t_u16 ? (float)reinterpret_cast<const uint16_t*>(a.T)[trow * a.ldt + g] : a.T[trow * a.ldt + g];
+    const float p0 = p[g], p1 = a.lk == SMX_LLK_MSE ? 0.f : p[a.plane_stride + g], p2 = (a.lk == SMX_LLK_ZINB || a.lk == SMX_LLK_ZINBD) ? p[2 * a.plane_stride + g] : 0.f;
+    float v;
+    switch (lk) {
+      case SMX_LLK_NB: v = row_llk_elem<SMX_LLK_NB, 0>(x, p0, p1, p2); break;
+      case SMX_LLK_ZINB: v = row_llk_elem<SMX_LLK_ZINB, 0>(x, p0, p1, p2); break;
+      case SMX_LLK_NBD: v = a.direct ? row_llk_elem<SMX_LLK_NBD, 1>(x, p0, p1, p2) : row_llk_elem<SMX_LLK_NBD, 0>(x, p0, p1, p2); break;
+      case SMX_LLK_ZINBD: v = a.direct ? row_llk_elem<SMX_LLK_ZINBD, 1>(x, p0, p1, p2) : row_llk_elem<SMX_LLK_ZINBD, 0>(x, p0, p1, p2); break;
+      default: { const float df = x - p0; v = -(df * df) / (float)a.G; }   // 'mse': -log_prob == tf.losses.mse
+    }
+    acc += v;
+  }
+  acc = wave_sum(acc);   // the four waves' sums meet in LDS, added in wave order
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.dst[(long)s * a.dst_draw + b] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+static int launch_plane_stat(hipStream_t st, const StatArgs& a) {
+  if (a.stat == 3) hipLaunchKernelGGL(plane_logprob_kernel, dim3((unsigned)(a.Sn * a.B)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(plane_stat_kernel, dim3((unsigned)((a.G + 255) / 256), (unsigned)a.B), dim3(256), 0, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+// what smx_predict_stat asks of the batch loop below in place of the parameter planes
+struct StatReq { int stat = 0, count_only = 0; const float* target = nullptr; float* out = nullptr; };
+
 // Decoder layers over `rows` stacked rows (evaluation mode: moving statistics, no dropout; smx_score.hip).  The last
 // layer's output: last_form 0 row-major f32 in place, 1 k-major f32 in ht [Hp][rows], 2 its three-way bf16 split in ht.
 int stacked_decoder(smx_model* m, const float* z, long rows, float* const* hb, int last_form, float* ht, const float** out, int* out_ld) {
@@ -170,9 +251,9 @@ int smx_forward_samples(smx_model* m, const int32_t* row_ids, const float* host_
   return SMX_OK;
 }
 
-int smx_predict(smx_model* m, const float* host_x, const float* host_library, int64_t n_cells, int32_t batch, int32_t n_samples,
-                float* z_mean, float* z_scale, float* z_samples, float* l_mean, float* l_scale, float* l_samples,
-                float* x_params, float* const* y_params) {
+static int predict_core(smx_model* m, const float* host_x, const float* host_library, int64_t n_cells, int32_t batch, int32_t n_samples,
+                        float* z_mean, float* z_scale, float* z_samples, float* l_mean, float* l_scale, float* l_samples,
+                        float* x_params, float* const* y_params, const StatReq* sr) {
   SMX_REQUIRE(m && host_x && n_cells > 0 && n_samples > 0, "bad arguments");
   SMX_REQUIRE(batch > 0 && batch <= m->Bmax, "batch must be in 1..max_batch");
   const size_t N = (size_t)n_cells, G = (size_t)m->G, D = (size_t)m->D, k = (size_t)m->k, S = (size_t)n_samples;
@@ -189,9 +270,23 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
   if (z_samples) per_cell += S * D;
   if (l_samples) per_cell += S;
   if (x_params) per_cell += S * k * G;
+  // the requested statistic of the gene output, per cell: S G (mean / variance per draw), G (mean over the draws), S (log_prob)
+  const size_t w_stat = !sr ? 0 : sr->stat == 2 ? G : sr->stat == 3 ? S : S * G;
+  per_cell += w_stat;
   for (int j = 0; j < m->n_heads; ++j)
     if (y_params && y_params[j]) { wy[j] = (size_t)m->lab_ky[j] * (size_t)m->cfg.label_dim[j]; per_cell += S * wy[j]; }
   SMX_REQUIRE(per_cell > 0, "no output requested");
+  // the INPUT rows of a chunk travel as ONE contiguous copy too (raw [C][G] -> a device re-pitch to [C][Gp]; library prior; the rows'
+  // likelihood constants from one launch): a host-to-device copy per minibatch from the caller's pageable array is staged
+  // synchronously by the runtime -- ~60 us per batch, at batch 8 (Posterior's default) most of the call
+  const size_t Gp = (size_t)m->Gp;
+  per_cell += G + Gp + 3;
+  if (sr && sr->stat == 3 && sr->target && (size_t)batch * m->Gp > m->pred_target_floats) {   // device copy of a batch of target rows
+    if (m->pred_target) hipFree(m->pred_target);
+    m->pred_target = nullptr; m->pred_target_floats = 0;
+    SMX_CHECK(dmalloc(&m->pred_target, (size_t)m->Bmax * m->Gp));
+    m->pred_target_floats = (size_t)m->Bmax * m->Gp;
+  }
   // 128 MB of staging (SMX_PREDICT_STAGE_FLOATS: tests force several chunks on small problems)
   const size_t cap_floats = getenv("SMX_PREDICT_STAGE_FLOATS") ? (size_t)std::max(1L, atol(getenv("SMX_PREDICT_STAGE_FLOATS"))) : (size_t)32 << 20;
   size_t C = std::max<size_t>((size_t)batch, cap_floats / per_cell / (size_t)batch * (size_t)batch);   // whole batches per chunk
@@ -211,20 +306,59 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
   if (z_samples) { s_zd = st; st += S * C * D; }
   if (l_samples) { s_ld = st; st += S * C; }
   if (x_params) { s_xp = st; st += S * k * C * G; }
+  float* s_st = nullptr;
+  if (w_stat) { s_st = st; st += C * w_stat; }
+  float* in_raw = st; st += C * G;
+  float* in_x = st; st += C * Gp;
+  float* in_lib = st; st += C * 2;
+  float* in_lgx1 = st; st += C;
   for (int j = 0; j < m->n_heads; ++j)
     if (wy[j]) { s_y[j] = st; st += S * C * wy[j]; }
+  // the statistic of the planes of Sn draws (stacked rows) of the batch at b0 into the chunk's staging
+  auto stat_of = [&](const float* P, long ldp_, int B, int Sn, size_t s0, size_t Cn, size_t b0, const Pass& ps) -> int {
+    StatArgs a;
+    a.P = P; a.ldp = ldp_; a.plane_stride = m->Gp; a.B = B; a.Sn = Sn; a.G = m->G; a.lk = m->cfg.likelihood; a.direct = m->scvi ? 1 : 0;
+    a.count_only = sr->count_only; a.stat = sr->stat; a.inv_S = 1.f / (float)S; a.accumulate = s0 > 0 ? 1 : 0;
+    a.T = nullptr; a.ldt = 0; a.trows = nullptr; a.t_u16 = 0;
+    if (sr->stat == 2) { a.dst = s_st + b0 * G; a.dst_draw = 0; }
+    else if (sr->stat == 3) {
+      a.dst = s_st + s0 * Cn + b0; a.dst_draw = (long)Cn;
+      if (sr->target) { a.T = m->pred_target; a.ldt = m->Gp; }
+      else { a.T = ps.Xsrc; a.ldt = m->Gp; a.trows = ps.xrows; a.t_u16 = ps.x_u16; }   // the input rows themselves
+    } else { a.dst = s_st + (s0 * Cn + b0) * G; a.dst_draw = (long)(Cn * G); }
+    return launch_plane_stat(m->st, a);
+  };
   auto out = [&](float* dst, const float* src, size_t count) -> int {   // one contiguous device -> host copy
     SMX_HIP(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, m->st));
     return SMX_OK;
   };
   const bool stack = S > 1 && stacked_scoring_ok(m) && !m->scvi;
+  SMX_REQUIRE(!m->scvi || host_library, "scvi needs host_library with host_x");
+  bool any_y = false;
+  for (int j = 0; j < m->n_heads; ++j) any_y = any_y || s_y[j] != nullptr;
+  const bool need_dec = s_xp || s_st || any_y;   // (latents only: the decoder and the heads are not run at all)
   for (size_t c0 = 0; c0 < N; c0 += C) {
     const size_t Cn = std::min(C, N - c0);   // cells of this chunk
+    {
+      SMX_HIP(hipMemcpyAsync(in_raw, host_x + c0 * G, Cn * G * sizeof(float), hipMemcpyHostToDevice, m->st));
+      if (Gp != G) SMX_HIP(hipMemsetAsync(in_x, 0, Cn * Gp * sizeof(float), m->st));
+      PackJobs J; J.n = 1;
+      PackJob& q = J.j[0];
+      q.dst = in_x; q.dpitch = (long)Gp; q.src = in_raw; q.spitch = (long)G; q.width = (int)G; q.height = (int)Cn; q.n_rep = 1; q.dst_rep = 0; q.src_rep = 0;
+      hipLaunchKernelGGL(pack_kernel, dim3((unsigned)std::min<size_t>(1024, (Cn * G + 255) / 256), 1, 1), dim3(256), 0, m->st, J);
+      SMX_HIP(hipGetLastError());
+      SMX_CHECK(launch_row_stats(m->st, in_x, 0, (long)Gp, (long)Cn, m->G, in_lgx1, nullptr));
+      if (host_library) SMX_HIP(hipMemcpyAsync(in_lib, host_library + c0 * 2, Cn * 2 * sizeof(float), hipMemcpyHostToDevice, m->st));
+    }
     for (size_t b0 = 0; b0 < Cn; b0 += (size_t)batch) {
       const int B = (int)std::min<size_t>((size_t)batch, Cn - b0);
       const size_t g0 = c0 + b0;
-      Pass ps;
-      SMX_CHECK(setup_pass(m, ps, nullptr, host_x + g0 * G, host_library ? host_library + g0 * 2 : nullptr, B, 0, 0));
+      Pass ps;   // (what setup_pass leaves for a host batch, on the chunk's resident copy)
+      ps.B = B; ps.training = 0; ps.sample = 0; ps.global_batch = B;
+      ps.rows = nullptr; ps.Xsrc = in_x + b0 * Gp; ps.lib = in_lib + b0 * 2; ps.lgx1 = in_lgx1 + b0; ps.cell_base = 0;
+      if (sr && sr->stat == 3 && sr->target)
+        SMX_HIP(hipMemcpy2DAsync(m->pred_target, (size_t)m->Gp * sizeof(float), sr->target + g0 * G, G * sizeof(float), G * sizeof(float), (size_t)B,
+                                 hipMemcpyHostToDevice, m->st));
       if (stack) {
         // ---- several draws: the encoder once, then the draws of this batch as rows of one decoder pass (as the scoring
         // paths, smx_score.hip) -- at batch 8 x 10 draws (Posterior's defaults, posterior.py:114-115) the draw-by-draw form
@@ -268,7 +402,7 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
           d.nk = make_key(m, ST_EPS_Z, 0, false); d.rows = ps.rows; d.cell_base = ps.cell_base; d.z = zst; d.lw = lwst;
           SMX_CHECK(launch_score_draws(m->st, d));
           const float* hl = nullptr; int hld = 0;
-          SMX_CHECK(stacked_decoder(m, zst, rows, hb, 0, nullptr, &hl, &hld));
+          if (need_dec) SMX_CHECK(stacked_decoder(m, zst, rows, hb, 0, nullptr, &hl, &hld));
           PackJobs J; J.n = 0;
           int pack_err = SMX_OK;
           auto flush = [&]() {
@@ -286,13 +420,14 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
             q.n_rep = Sn; q.dst_rep = (long)dst_rep; q.src_rep = (long)src_rep;
           };
           addr(s_zd ? s_zd + (s0 * Cn + b0) * D : nullptr, D, Cn * D, zst, (size_t)Dp, (size_t)B * Dp, D);
-          if (s_xp) {
+          if (s_xp || s_st) {
             GemmArgs g;
             g.A = hl; g.lda = hld; g.B = P_(m, m->t_outW[0]); g.ldb = m->tensors[m->t_outW[0]].ld;
             g.C = Pst; g.ldc = (int)ldp; g.M = (int)rows; g.N = (int)ldp; g.K = hld; g.bias = P_(m, m->t_outb[0]); g.split_k = 1;
             SMX_CHECK(launch_gemm(m->st, g));
-            for (size_t c = 0; c < k; ++c)
+            for (size_t c = 0; c < k && s_xp; ++c)
               addr(s_xp + ((s0 * k + c) * Cn + b0) * G, G, k * Cn * G, Pst + c * (size_t)m->Gp, ldp, (size_t)B * ldp, G);
+            if (s_st) SMX_CHECK(stat_of(Pst, (long)ldp, B, Sn, s0, Cn, b0, ps));
           }
           float* ycur = yst;
           for (int j = 0; j < m->n_heads; ++j) {
@@ -315,7 +450,7 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
       for (size_t s = 0; s < S; ++s) {
         ps.sample = (int)s;
         // the encoders run once per batch (eval mode: no noise in them); later draws re-sample the latents and decode
-        SMX_CHECK(forward_pass(m, ps, false, false, s == 0 ? 0 : 2));
+        SMX_CHECK(forward_pass(m, ps, false, false, s == 0 ? ((need_dec || S > 1) ? 0 : 3) : 2));
         PackJobs J; J.n = 0;
         int pack_err = SMX_OK;
         auto flush = [&]() {
@@ -342,6 +477,7 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
         add(s_ld ? s_ld + s * Cn + b0 : nullptr, 1, m->lsmp, 1, 1);
         if (s_xp)
           for (size_t c = 0; c < k; ++c) add(s_xp + ((s * k + c) * Cn + b0) * G, G, m->P + c * (size_t)m->Gp, k * (size_t)m->Gp, G);
+        if (s_st) SMX_CHECK(stat_of(m->P, (long)(k * (size_t)m->Gp), B, 1, s, Cn, b0, ps));
         for (int j = 0; j < m->n_heads; ++j) {
           if (!s_y[j]) continue;
           const size_t P = (size_t)m->cfg.label_dim[j], Pp = (size_t)m->lab_Pp[j], ld = (size_t)m->tensors[m->t_labW[j]].ld;
@@ -356,6 +492,11 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
     if (s_zs) SMX_CHECK(out(z_scale + c0 * D, s_zs, Cn * D));
     if (s_lm) SMX_CHECK(out(l_mean + c0, s_lm, Cn));
     if (s_ls) SMX_CHECK(out(l_scale + c0, s_ls, Cn));
+    if (s_st && sr->stat == 2) SMX_CHECK(out(sr->out + c0 * G, s_st, Cn * G));
+    for (size_t s = 0; s < S && s_st && sr->stat != 2; ++s) {
+      if (sr->stat == 3) SMX_CHECK(out(sr->out + s * N + c0, s_st + s * Cn, Cn));
+      else SMX_CHECK(out(sr->out + (s * N + c0) * G, s_st + s * Cn * G, Cn * G));
+    }
     for (size_t s = 0; s < S; ++s) {
       if (s_zd) SMX_CHECK(out(z_samples + (s * N + c0) * D, s_zd + s * Cn * D, Cn * D));
       if (s_ld) SMX_CHECK(out(l_samples + s * N + c0, s_ld + s * Cn, Cn));
@@ -367,6 +508,21 @@ int smx_predict(smx_model* m, const float* host_x, const float* host_library, in
     SMX_HIP(hipStreamSynchronize(m->st));
   }
   return SMX_OK;
+}
+
+int smx_predict(smx_model* m, const float* host_x, const float* host_library, int64_t n_cells, int32_t batch, int32_t n_samples,
+                float* z_mean, float* z_scale, float* z_samples, float* l_mean, float* l_scale, float* l_samples,
+                float* x_params, float* const* y_params) {
+  return predict_core(m, host_x, host_library, n_cells, batch, n_samples, z_mean, z_scale, z_samples, l_mean, l_scale, l_samples, x_params, y_params, nullptr);
+}
+
+int smx_predict_stat(smx_model* m, const float* host_x, const float* host_library, int64_t n_cells, int32_t batch, int32_t n_samples,
+                     int32_t stat, int32_t count_only, const float* target, float* out) {
+  SMX_REQUIRE(m && out && stat >= 0 && stat <= 3, "bad arguments (stat: 0 mean, 1 variance, 2 mean over the draws, 3 log_prob)");
+  SMX_REQUIRE(!(count_only && m->cfg.likelihood == SMX_LLK_MSE), "the deterministic 'mse' output has no count distribution");
+  StatReq sr;
+  sr.stat = stat; sr.count_only = count_only ? 1 : 0; sr.target = target; sr.out = out;
+  return predict_core(m, host_x, host_library, n_cells, batch, n_samples, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sr);
 }
 
 int smx_decode(smx_model* m, const float* z, const float* l, int32_t batch, float* x_params, float* const* y_params) {

@@ -479,3 +479,90 @@ def count_distribution(likelihood: str, planes, name: str, activated: bool) -> D
   if likelihood in ("zinb", "zinbd"):
     base = ZeroInflated(base, planes[2], name="ZeroInflated")
   return Independent(base, 1, name=name)
+
+
+# ---------------------------------------------------------------------------
+class LazyCountOutput(Distribution):
+  """predict()'s gene output as a handle on the DEVICE side: the parameter planes (4 k G bytes per cell and draw: 24 KB at 1998 genes)
+  never reach the host; `mean()`, `variance()`, `log_prob(x)` run the evaluation passes again inside the library (smx_predict_stat: a
+  forward pass of 128 cells takes ~40 us) and only the statistic asked for leaves the device.  Same surface as the eager result of
+  `count_distribution` -- `.distribution` (the Independent wrapper's inner distribution), `.count_distribution` of a zero-inflated
+  output (sisua/analysis/posterior.py:187-255), `batch_shape` / `event_shape` / `name` -- and `materialize()` returns that eager result
+  (bit-identical planes).  The handle is valid while the model's parameters stay as they were: after further training it raises."""
+
+  reinterpreted_batch_ndims = 1
+
+  def __init__(self, model, x, library, n_samples, batch, name, count_only=False):
+    self._model, self._x, self._lib, self._S, self._B, self.name = model, x, library, int(n_samples), int(batch), name
+    self._count_only = bool(count_only)
+    self._step = model.step
+    self._eager = None
+
+  # ---- structure -----------------------------------------------------------------
+  @property
+  def is_zero_inflated(self):
+    return self._model._cfg.likelihood in ("zinb", "zinbd") and not self._count_only
+
+  @property
+  def batch_shape(self):
+    n = self._x.shape[0]
+    return (self._S, n) if self._S > 1 else (n,)
+
+  @property
+  def event_shape(self):
+    return (self._model._cfg.n_genes,)
+
+  @property
+  def distribution(self):
+    return self
+
+  @property
+  def count_distribution(self):
+    if not self.is_zero_inflated:
+      raise AttributeError("count_distribution: the output is not zero-inflated")
+    return LazyCountOutput(self._model, self._x, self._lib, self._S, self._B, self.name, count_only=True)
+
+  def _params(self):
+    return []
+
+  # ---- statistics (kernels) ---------------------------------------------------------
+  def _engine(self):
+    if self._model.step != self._step:
+      raise RuntimeError("the model was trained after this lazy prediction was made: call predict() again")
+    return self._model._ensure_engine(self._B)
+
+  def _stat(self, stat, target=None, out=None):
+    squeeze = self._S <= 1 and stat != "mean_over_samples"   # (no draw axis in the caller's view)
+    o = out if (out is None or not squeeze) else out.reshape((1,) + tuple(out.shape))
+    r = self._engine().predict_stat(self._x, stat, library=self._lib, n_samples=max(self._S, 1), batch=self._B, count_only=self._count_only,
+                                    target=target, out=o)
+    return (out if out is not None else r[0]) if squeeze else r
+
+  def mean(self, out=None):
+    return self._stat("mean", out=out)
+
+  def variance(self, out=None):
+    return self._stat("variance", out=out)
+
+  def mean_over_samples(self, out=None):
+    """E_s[mean] over the Monte-Carlo draws, [n_cells, n_genes] (what `np.mean(imputed.mean(), axis=0)` computes, posterior.py:985-987)."""
+    return self._stat("mean_over_samples", out=out)
+
+  def log_prob(self, x=None):
+    """log p(x) summed over the genes, [n_samples, n_cells] ([n_cells] without a draw axis); x = None: of the input counts."""
+    return self._stat("log_prob", target=None if x is None else np.asarray(x, np.float32))
+
+  # ---- everything else through the eager result ----------------------------------------
+  def materialize(self):
+    if self._eager is None:
+      pX, _ = self._model.predict(self._x, sample_shape=(self._S,) if self._S > 1 else (), batch_size=self._B, verbose=False, lazy=False)
+      pX = pX[0] if isinstance(pX, tuple) else pX
+      self._eager = pX.distribution.count_distribution if (self._count_only and hasattr(pX.distribution, "count_distribution")) else pX
+      self._engine()   # (raises if the model moved on)
+    return self._eager
+
+  def sample(self, sample_shape=(), seed=None):
+    return self.materialize().sample(sample_shape, seed=seed)
+
+  def __repr__(self):
+    return f"<LazyCountOutput '{self.name}' batch_shape={self.batch_shape} event_shape={self.event_shape} on device>"

@@ -321,9 +321,10 @@ class Engine:
     out["y_params"] = ys
     return out
 
-  def predict(self, x, library=None, n_samples: int = 1, batch: Optional[int] = None):
+  def predict(self, x, library=None, n_samples: int = 1, batch: Optional[int] = None, want_x_params: bool = True):
     """Eval-mode forward of a whole host matrix in one call (smx_predict): arrays over ALL cells, with a leading draw
-    axis for z_sample / l_sample / x_params / y_params -- the layout of forward_samples with n = every cell."""
+    axis for z_sample / l_sample / x_params / y_params -- the layout of forward_samples with n = every cell.
+    want_x_params=False: everything but the gene output's parameter planes (what a lazy result keeps on the device side)."""
     cfg = self.cfg
     xa = _f32(x)
     N, S = xa.shape[0], int(n_samples)
@@ -334,13 +335,36 @@ class Engine:
     out["z_scale"] = np.empty((N, D), np.float32) if cfg.stochastic else None
     if cfg.model == "scvi":
       out.update(l_mean=np.empty((N,), np.float32), l_scale=np.empty((N,), np.float32), l_sample=np.empty((S, N), np.float32))
-    out["x_params"] = np.empty((S, k, N, G), np.float32)
+    out["x_params"] = np.empty((S, k, N, G), np.float32) if want_x_params else None
     ys = [np.empty((S, N, label_planes(llk, P) * P), np.float32) for P, llk in cfg.head_labels]
     yptrs = (C.POINTER(C.c_float) * max(1, len(ys)))(*[_fp(y) for y in ys]) if ys else None
     check(self.lib.smx_predict(self._h, _fp(xa), _fp(la), N, B, S, _fp(out["z_mean"]), _fp(out.get("z_scale")),
                                _fp(out["z_sample"]), _fp(out.get("l_mean")), _fp(out.get("l_scale")), _fp(out.get("l_sample")),
                                _fp(out["x_params"]), yptrs))
     out["y_params"] = ys
+    return out
+
+  STATS = {"mean": 0, "variance": 1, "mean_over_samples": 2, "log_prob": 3}
+
+  def predict_stat(self, x, stat: str, library=None, n_samples: int = 1, batch: Optional[int] = None, count_only: bool = False,
+                   target=None, out=None):
+    """A statistic of the gene output over a whole host matrix (smx_predict_stat): the same passes and draws as predict(), but only the
+    statistic leaves the device.  'mean' / 'variance' [n_samples, N, G]; 'mean_over_samples' [N, G]; 'log_prob' [n_samples, N] of `target`
+    (default: of x itself).  count_only: the count distribution without the zero-inflation wrapper.  `out`: a float32 array of the
+    result's shape to write into (a reused array saves the first-touch page faults of a fresh one)."""
+    cfg = self.cfg
+    xa = _f32(x)
+    N, S, G = xa.shape[0], int(n_samples), cfg.n_genes
+    B = min(int(batch or self.max_batch), self.max_batch)
+    la = None if library is None else _f32(library, (N, 2))
+    code = self.STATS[stat]
+    shape = (N, G) if code == 2 else (S, N) if code == 3 else (S, N, G)
+    if out is None:
+      out = np.empty(shape, np.float32)
+    elif out.dtype != np.float32 or tuple(out.shape) != shape or not out.flags.c_contiguous:
+      raise ValueError(f"out must be a C-contiguous float32 array of shape {shape}")
+    ta = None if target is None else _f32(target, (N, G))
+    check(self.lib.smx_predict_stat(self._h, _fp(xa), _fp(la), N, B, S, code, int(bool(count_only)), _fp(ta), _fp(out)))
     return out
 
   def decode(self, z, l=None):

@@ -504,17 +504,18 @@ class SingleCellModel:
       return [qz, ql]
     return qz
 
-  def _output_dists(self, xp_list, yp_list, stacked=False):
+  def _output_dists(self, xp_list, yp_list, stacked=False, heads_only=False):
     """xp_list: per-MC-sample x_params [k,B,G]; yp_list: per-sample list of label raw outputs.
-    stacked=True: xp_list is one array [S,k,B,G] and yp_list one array [S,B,w] per label head (views, no copies)."""
+    stacked=True: xp_list is one array [S,k,B,G] and yp_list one array [S,B,w] per label head (views, no copies).
+    heads_only: the distributions of the heads alone, as a list (the gene output is handled by the caller)."""
     cfg = self._cfg
     if stacked:
-      planes = [xp_list[:, c] for c in range(cfg.k)]
+      planes = None if heads_only else [xp_list[:, c] for c in range(cfg.k)]
       stack = None
     else:
-      stack = (lambda a: a[0]) if len(xp_list) == 1 else (lambda a: np.stack(a, 0))
-      planes = [stack([xp[c] for xp in xp_list]) for c in range(cfg.k)]
-    outs = [D.count_distribution(cfg.likelihood, planes, self._outputs[0].name or "transcriptomic", activated=cfg.model == "scvi")]
+      stack = (lambda a: a[0]) if len(yp_list if heads_only else xp_list) == 1 else (lambda a: np.stack(a, 0))
+      planes = None if heads_only else [stack([xp[c] for xp in xp_list]) for c in range(cfg.k)]
+    outs = [] if heads_only else [D.count_distribution(cfg.likelihood, planes, self._outputs[0].name or "transcriptomic", activated=cfg.model == "scvi")]
     n_extra = len(cfg.extra_outputs)
     for j, (P, kind) in enumerate(cfg.head_labels):
       raw = yp_list[j] if stacked else stack([yp[j] for yp in yp_list])
@@ -545,6 +546,8 @@ class SingleCellModel:
         outs.append(D.MixtureMultivariateNormalTriL(pl[..., :C, 0], pl[..., C:2 * C, :], L, name=nm))
       else:
         outs.append(D.OneHotCategorical(raw, name=nm))
+    if heads_only:
+      return outs
     return outs[0] if len(outs) == 1 else tuple(outs)
 
   def __call__(self, inputs=None, library=None, mask=None, training=None, sample_shape=(), **kwargs):
@@ -591,8 +594,13 @@ class SingleCellModel:
     out = e.decode(z, l)
     return self._output_dists([out["x_params"]], [out["y_params"]])
 
-  def predict(self, inputs, sample_shape=(), batch_size=32, verbose=True, device="GPU"):
+  def predict(self, inputs, sample_shape=(), batch_size=32, verbose=True, device="GPU", lazy=None):
     r"""Predict on minibatches then return a single distribution by concatenation.
+
+    lazy : the gene output as a device-side handle (`distributions.LazyCountOutput`): its parameter planes -- 24 KB per cell and
+      draw at 1998 genes -- stay off the host, `.mean()` / `.variance()` / `.log_prob(x)` run as kernels and return only what
+      is asked.  Default: on for `SingleCellOMIC` inputs with cells in their own order (what `Posterior` hands in,
+      sisua/analysis/posterior.py:172-182), off for arrays and prepared datasets (eager NumPy-backed distributions).
 
     Return:
       X : `Distribution` or tuple of `Distribution` (multiple outputs)
@@ -601,6 +609,10 @@ class SingleCellModel:
     assert device in ("CPU", "GPU"), f"Only support device CPU or GPU, but given: {device}"
     if device == "CPU":
       raise RuntimeError("sisua_amd has no CPU path; predict runs on the MI355X")
+    if lazy is None:
+      lazy = isinstance(inputs, SingleCellOMIC)
+    if lazy and isinstance(inputs, SingleCellOMIC):
+      inputs = inputs.numpy()   # (cells in their own order: the one-call path)
     ds = _to_data(inputs, batch_size=batch_size) if not isinstance(inputs, BatchDataset) else inputs
     if not isinstance(inputs, (BatchDataset, SingleCellOMIC)):
       ds.drop_remainder = False
@@ -610,7 +622,9 @@ class SingleCellModel:
       # once, straight into the arrays the returned distributions hold -- no per-batch arrays, no concatenation
       n_use = ds.n_obs if not ds.drop_remainder else (ds.n_obs // ds.batch_size) * ds.batch_size
       if n_use > 0:
-        return self._predict_all(ds.arrays[0][:n_use], ds.library[:n_use], sample_shape, ds.batch_size)
+        return self._predict_all(ds.arrays[0][:n_use], ds.library[:n_use], sample_shape, ds.batch_size, lazy=bool(lazy))
+    if lazy:
+      raise ValueError("lazy=True needs the cells in their own order (an array, a SingleCellOMIC, or a dataset with shuffle=0)")
     X, Z = [], []
     for data in ds:
       pX, qZ = self(**data, training=False, sample_shape=sample_shape)
@@ -629,14 +643,22 @@ class SingleCellModel:
       Zc = D.concat_distributions(Z, axis=0)
     return Xc, Zc
 
-  def _predict_all(self, x, library, sample_shape, batch_size):
+  def _predict_all(self, x, library, sample_shape, batch_size, lazy=False):
     n = int(np.prod(sample_shape)) if np.size(sample_shape) else 0
     e = self._ensure_engine(min(int(batch_size), x.shape[0]))
     lib = library if self._cfg.model == "scvi" else None
     if lib is not None and lib.shape[1] != 2:
       lib = library_matrix(x)
-    o = e.predict(x, library=lib, n_samples=max(n, 1), batch=min(int(batch_size), e.max_batch))
-    if n > 1:
+    lazy = lazy and self._cfg.likelihood != "mse"
+    B = min(int(batch_size), e.max_batch)
+    o = e.predict(x, library=lib, n_samples=max(n, 1), batch=B, want_x_params=not lazy)
+    if lazy:
+      # the gene output stays a handle (its planes never leave the device); the small head outputs and the latents are eager as always
+      heads = self._output_dists(None, o["y_params"], stacked=True, heads_only=True) if n > 1 else \
+          self._output_dists(None, [[y[0] for y in o["y_params"]]], heads_only=True)
+      px = D.LazyCountOutput(self, np.ascontiguousarray(x, dtype=np.float32), lib, n, B, self._outputs[0].name or "transcriptomic")
+      pX = (px,) + tuple(heads) if heads else px
+    elif n > 1:
       pX = self._output_dists(o["x_params"], o["y_params"], stacked=True)
     else:
       pX = self._output_dists([o["x_params"][0]], [[y[0] for y in o["y_params"]]])

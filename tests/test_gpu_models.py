@@ -728,3 +728,54 @@ def test_sisua_nbd_labels_are_nbd_heads(api):
   (pX, pY), qZ = m.predict(sco.numpy()[:64], sample_shape=2, verbose=False)
   assert isinstance(pX.distribution.count_distribution, D.NegativeBinomialDisp) and isinstance(pY.distribution, D.NegativeBinomialDisp)
   assert pY.batch_shape == (2, 64) and qZ.sample(1).shape == (1, 64, 8)
+
+
+@pytest.mark.parametrize("name,lk", [("vae", "zinb"), ("vae", "nb"), ("vae", "zinbd"), ("scvi", "zinbd"), ("sisua", "zinb")])
+def test_lazy_predict_keeps_the_planes_on_the_device(api, name, lk):
+  """predict(lazy=True) (the default for SingleCellOMIC inputs): the gene output is a device-side handle whose `.mean()` / `.variance()` /
+  `.log_prob(x)` / `.mean_over_samples()` run as kernels (smx_predict_stat) and return only the statistic -- equal to what the eager,
+  NumPy-backed distributions compute from the planes (float32 on the device against float64 on the host: 2e-5), the latents and the head
+  outputs bit-identical, `materialize()` the eager result itself (what posterior.py:187-255 asks of predict's result)."""
+  from sisua_amd import distributions as D
+  sco = _sco(n=300)
+  kw = dict(outputs=sco.get_rv("transcriptomic", lk), latents=api.RVmeta(8, "diag", True, "Latents"),
+            encoder=api.NetConf([32], batchnorm=True, dropout=0.1), decoder=api.NetConf([32], batchnorm=True, dropout=0.1))
+  if name == "sisua":
+    kw["labels"] = [sco.get_rv("proteomic")]
+  m = api.get_model(name)(**kw)
+  omics = ["transcriptomic"] + (["proteomic"] if name == "sisua" else [])
+  m.fit(sco.create_dataset(omics, labels_percent=0.5, batch_size=64, drop_remainder=True), metadata=sco, epochs=3, learning_rate=2e-3)
+  X = sco.numpy()
+  for S in ((), 3):
+    eX, eZ = m.predict(X, sample_shape=S, batch_size=50, verbose=False)              # arrays: eager by default
+    lX, lZ = m.predict(sco, sample_shape=S, batch_size=50, verbose=False)            # SingleCellOMIC: lazy by default
+    e0, l0 = (eX[0], lX[0]) if isinstance(eX, tuple) else (eX, lX)
+    assert isinstance(l0, D.LazyCountOutput) and not isinstance(e0, D.LazyCountOutput)
+    assert l0.batch_shape == e0.batch_shape and l0.event_shape == e0.event_shape and l0.name == e0.name
+    tol = dict(rtol=2e-5, atol=1e-6)
+    assert np.allclose(l0.mean(), e0.mean(), **tol) and np.allclose(l0.variance(), e0.variance(), rtol=1e-4, atol=1e-5)
+    assert l0.mean().dtype == np.float32 and l0.mean().shape == e0.mean().shape
+    em = e0.mean() if S == () else e0.mean().mean(0)
+    assert np.allclose(l0.mean_over_samples(), em, **tol) and l0.mean_over_samples().shape == (300, 120)
+    # log_prob of the input counts and of another target (here: the counts + 1), summed over the genes
+    assert np.allclose(l0.log_prob(), e0.log_prob(X), rtol=2e-5, atol=1e-3)
+    assert np.allclose(l0.log_prob(X + 1.0), e0.log_prob(X + 1.0), rtol=2e-5, atol=1e-3)
+    if l0.is_zero_inflated:   # 'imputed' of posterior.py:218-225: the count distribution without the zero-inflation wrapper
+      lc, ec = l0.distribution.count_distribution, e0.distribution.count_distribution
+      assert np.allclose(lc.mean(), ec.mean(), **tol) and (lc.mean() >= l0.mean() - 1e-6).all()
+      assert np.allclose(lc.log_prob(X), ec.log_prob(X).sum(-1), rtol=2e-5, atol=1e-3)
+    else:
+      with pytest.raises(AttributeError):
+        l0.count_distribution
+    # a reused result array (no first-touch page faults), and the eager twin on demand: bit-identical planes
+    buf = np.empty(l0.mean().shape, np.float32)
+    assert l0.mean(out=buf) is buf and np.array_equal(buf, l0.mean())
+    assert np.array_equal(l0.materialize().mean(), e0.mean())
+    lz = lZ[0] if isinstance(lZ, (tuple, list)) else lZ
+    ez = eZ[0] if isinstance(eZ, (tuple, list)) else eZ
+    assert np.array_equal(lz.mean(), ez.mean())
+    if isinstance(eX, tuple):
+      assert len(lX) == len(eX) and np.array_equal(lX[1].mean(), eX[1].mean())
+  m.fit(sco.create_dataset(omics, batch_size=64, drop_remainder=True), metadata=sco, epochs=1)
+  with pytest.raises(RuntimeError):   # the handle names the parameters it was made with
+    l0.mean()
