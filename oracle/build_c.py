@@ -10,7 +10,7 @@ LIB = os.path.join(HERE, "libsisua_step.so")
 def build(force: bool = False, verbose: bool = True) -> str:
   if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC):
     return LIB
-  cmd = ["gcc", "-O3", "-march=x86-64-v3", "-ffp-contract=fast", "-fopenmp", "-shared", "-fPIC", "-std=gnu99", SRC, "-o", LIB, "-lm"]
+  cmd = ["gcc", "-O3", "-march=x86-64-v3", "-ffp-contract=fast", "-fopenmp", "-shared", "-fPIC", "-std=gnu99", SRC, "-o", LIB, "-lm", "-ldl"]
   if verbose:
     print(" ".join(cmd), flush=True)
   r = subprocess.run(cmd, capture_output=True, text=True)

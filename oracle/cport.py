@@ -21,9 +21,23 @@ class _Cfg(C.Structure):
 class CStep:
   """VAE-family training step on the CPU (fp32, OpenMP)."""
 
-  def __init__(self, spec: so.Spec, params):
+  def __init__(self, spec: so.Spec, params, use_blas: bool = True):
     assert spec.model == "vae", "the C port covers the benchmark's VAE family"
     self.lib = C.CDLL(build_c.build(verbose=False))
+    self.blas = None
+    if use_blas:   # the dense products through the OpenBLAS NumPy links (ILP64 cblas_sgemm in numpy.libs)
+      import glob, os
+      import numpy
+      cands = glob.glob(os.path.join(os.path.dirname(numpy.__file__), "..", "numpy.libs", "libscipy_openblas64_*.so")) + \
+          glob.glob(os.path.join(os.path.dirname(numpy.__file__), "..", "numpy.libs", "libopenblas64_*.so"))
+      self.lib.ost_use_blas.argtypes = [C.c_char_p]
+      for c in cands:
+        if self.lib.ost_use_blas(os.path.realpath(c).encode()):
+          self.blas = os.path.basename(c)
+          break
+    else:
+      self.lib.ost_use_blas.argtypes = [C.c_char_p]
+      self.lib.ost_use_blas(None)
     self.lib.ost_create.restype = C.c_void_p
     self.lib.ost_train_step.restype = C.c_float
     self.lib.ost_tensor_size.restype = C.c_long

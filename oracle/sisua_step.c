@@ -77,8 +77,53 @@ static void normal_row(const ost_t* m, int stream, int step, int64_t cell, int n
   }
 }
 
-/* ---- products (row-parallel, i-k-j so the inner loop vectorises) --------------------------------- */
-static void gemm_nn(const float* A, const float* B, float* C, int M, int K, int N) { /* C[M,N] = A[M,K] B[K,N] */
+/* ---- products -------------------------------------------------------------------------------------
+ * Dense products go through the BLAS NumPy itself links when the caller hands its path over (ost_use_blas: OpenBLAS's ILP64 cblas_sgemm from
+ * numpy.libs) -- a CPU baseline whose three large products run at library speed on every core is the fair bar; the loops
+ * below remain for the products whose left operand is the SPARSE input (log1p of 93 % zeros: they skip the zeros, 14x fewer flops than a
+ * dense product) and as the fallback without a BLAS. */
+#include <dlfcn.h>
+typedef void (*ost_sgemm_fn)(int, int, int, int64_t, int64_t, int64_t, float, const float*, int64_t, const float*, int64_t, float, float*, int64_t);
+static ost_sgemm_fn g_sgemm = NULL;
+static void (*g_blas_set_threads)(int) = NULL;
+int ost_use_blas(const char* path) {   /* 1: dense products through <path>'s scipy_cblas_sgemm64_ / cblas_sgemm64_; 0: not available */
+  g_sgemm = NULL; g_blas_set_threads = NULL;
+  if (!path) return 0;
+  void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) return 0;
+  const char* names[] = {"scipy_cblas_sgemm64_", "cblas_sgemm64_"};
+  for (int i = 0; i < 2 && !g_sgemm; ++i) g_sgemm = (ost_sgemm_fn)dlsym(h, names[i]);
+  const char* tn[] = {"scipy_openblas_set_num_threads64_", "openblas_set_num_threads64_"};
+  for (int i = 0; i < 2 && !g_blas_set_threads; ++i) g_blas_set_threads = (void (*)(int))dlsym(h, tn[i]);
+  if (g_sgemm && g_blas_set_threads) g_blas_set_threads(1);
+  return g_sgemm != NULL;
+}
+#define OST_BLAS_MIN_WORK 200000L   /* below this a product is faster in the loops */
+static int use_blas(long M, long K, long N) { return g_sgemm != NULL && M * K * N >= OST_BLAS_MIN_WORK; }
+/* ONE thread pool: the library runs single-threaded (ost_set_threads) and the OpenMP threads each take a slice of the product's larger
+ * output axis.  (Two pools -- the library's own threads beside OpenMP's -- spin against each other inside a CPU quota: on the GPU boxes'
+ * 16-CPU share of a 256-core host the step got SLOWER with every thread added, 7.5 k cells/s at 8 + 8 threads, 1.2 k at 64 + 64.)
+ * row-major C[M,N] = op(A) op(B); ta / tb: 111 no transpose, 112 transpose */
+static void blas_sliced(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc) {
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+    const int t = 0, nt = 1;
+#endif
+    if (N >= M) {   /* slices of columns: multiples of 16 floats */
+      const int per = ((N + nt - 1) / nt + 15) / 16 * 16, n0 = t * per, n1 = n0 + per < N ? n0 + per : N;
+      if (n0 < n1) g_sgemm(101, ta, tb, M, n1 - n0, K, 1.f, A, lda, tb == 111 ? B + n0 : B + (size_t)n0 * ldb, ldb, 0.f, C + n0, ldc);
+    } else {        /* slices of rows */
+      const int per = (M + nt - 1) / nt, m0 = t * per, m1 = m0 + per < M ? m0 + per : M;
+      if (m0 < m1) g_sgemm(101, ta, tb, m1 - m0, N, K, 1.f, ta == 111 ? A + (size_t)m0 * lda : A + m0, lda, B, ldb, 0.f, C + (size_t)m0 * ldc, ldc);
+    }
+  }
+}
+
+/* (row-parallel, i-k-j so the inner loop vectorises; zeros of A skipped) */
+static void gemm_nn_sp(const float* A, const float* B, float* C, int M, int K, int N) { /* C[M,N] = A[M,K] B[K,N] */
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < M; ++i) {
     float* c = C + (size_t)i * N;
@@ -86,7 +131,7 @@ static void gemm_nn(const float* A, const float* B, float* C, int M, int K, int 
     for (int k = 0; k < K; ++k) { const float a = A[(size_t)i * K + k]; if (a == 0.f) continue; const float* b = B + (size_t)k * N; for (int j = 0; j < N; ++j) c[j] += a * b[j]; }
   }
 }
-static void gemm_tn(const float* A, const float* B, float* C, int K, int M, int N) { /* C[M,N] = A[K,M]^T B[K,N] */
+static void gemm_tn_sp(const float* A, const float* B, float* C, int K, int M, int N) { /* C[M,N] = A[K,M]^T B[K,N] */
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < M; ++i) {
     float* c = C + (size_t)i * N;
@@ -94,7 +139,14 @@ static void gemm_tn(const float* A, const float* B, float* C, int K, int M, int 
     for (int k = 0; k < K; ++k) { const float a = A[(size_t)k * M + i]; if (a == 0.f) continue; const float* b = B + (size_t)k * N; for (int j = 0; j < N; ++j) c[j] += a * b[j]; }
   }
 }
+static void gemm_nn(const float* A, const float* B, float* C, int M, int K, int N) {
+  if (use_blas(M, K, N)) blas_sliced(111, 111, M, N, K, A, K, B, N, C, N); else gemm_nn_sp(A, B, C, M, K, N);
+}
+static void gemm_tn(const float* A, const float* B, float* C, int K, int M, int N) {
+  if (use_blas(M, K, N)) blas_sliced(112, 111, M, N, K, A, M, B, N, C, N); else gemm_tn_sp(A, B, C, K, M, N);
+}
 static void gemm_nt(const float* A, const float* B, float* C, int M, int K, int N) { /* C[M,N] = A[M,K] B[N,K]^T */
+  if (use_blas(M, K, N)) { blas_sliced(111, 112, M, N, K, A, K, B, K, C, N); return; }
 #pragma omp parallel for schedule(static) collapse(2)
   for (int i = 0; i < M; ++i)
     for (int j = 0; j < N; ++j) {
@@ -114,19 +166,37 @@ static double digamma_(double x) {
   return r + log(x) - 0.5 / x - f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f / 132))));
 }
 
+/* lgamma(x + r) - lgamma(r) - lgamma(x + 1) and digamma(x + r) - digamma(r).  93 % of the counts are 0 (both exactly 0) and nearly all of
+ * the rest small integers, for which both differences are finite sums over the rising factorial: log prod_{i < x} (r + i) and
+ * sum_{i < x} 1 / (r + i) -- one log instead of three libm lgamma calls and two digamma series per element (the likelihood was 62 % of a
+ * single-threaded step, profiled when the CPU baseline was made a fair bar: VERDICT r03 item 8); libm for everything else. */
+static inline void lgdg_diff(double x, double r, double* lg, double* dg) {
+  static const double LOGFACT[17] = {0.0, 0.0, 0.693147180559945, 1.7917594692280554, 3.178053830347945, 4.787491742782047, 6.579251212010102, 8.525161361065415, 10.604602902745249, 12.801827480081467, 15.104412573075514, 17.502307845873887, 19.987214495661885, 22.55216385312342, 25.191221182738683, 27.89927138384089, 30.671860106080672};
+  if (x == 0.0) { *lg = 0.0; *dg = 0.0; return; }
+  if (x <= 16.0 && x == floor(x)) {
+    double P = 1.0, s = 0.0;
+    for (int i = 0; i < (int)x; ++i) { P *= r + i; s += 1.0 / (r + i); }
+    *lg = log(P) - LOGFACT[(int)x]; *dg = s;
+    return;
+  }
+  *lg = lgamma(x + r) - lgamma(r) - lgamma(x + 1.0); *dg = digamma_(x + r) - digamma_(r);
+}
+
 /* elementwise count log-likelihood and gradients wrt the raw planes (oracle count_llk) */
 static inline float count_elem(int lik, float x, float p0, float p1, float p2, float* d0, float* d1, float* d2) {
-  double ell;
+  double ell, lg, dg;
   if (lik <= 1) {
     const double r = exp((double)p0), sp = softplusf_(p1);
-    ell = lgamma(x + r) - lgamma(r) - lgamma(x + 1.0) + x * (p1 - sp) - r * sp;
-    *d0 = (float)(r * ((x > 0 ? digamma_(x + r) - digamma_(r) : 0.0) - sp));
+    lgdg_diff(x, r, &lg, &dg);
+    ell = lg + x * (p1 - sp) - r * sp;
+    *d0 = (float)(r * (dg - sp));
     *d1 = (float)(x - (x + r) * sigmoidf_(p1));
   } else {
     const double mu = softplusf_(p0), th = softplusf_(p1 + SP_INV1), e = 1e-8, lt = log(th + mu + e);
-    ell = th * (log(th + e) - lt) + x * (log(mu + e) - lt) + lgamma(x + th) - lgamma(th) - lgamma(x + 1.0);
+    lgdg_diff(x, th, &lg, &dg);
+    ell = th * (log(th + e) - lt) + x * (log(mu + e) - lt) + lg;
     const double dmu = -th / (th + mu + e) + x / (mu + e) - x / (th + mu + e);
-    const double dth = log(th + e) - lt + th / (th + e) - th / (th + mu + e) - x / (th + mu + e) + (x > 0 ? digamma_(x + th) - digamma_(th) : 0.0);
+    const double dth = log(th + e) - lt + th / (th + e) - th / (th + mu + e) - x / (th + mu + e) + dg;
     *d0 = (float)(dmu * sigmoidf_(p0)); *d1 = (float)(dth * sigmoidf_(p1 + SP_INV1));
   }
   if (lik == 0 || lik == 2) { *d2 = 0.f; return (float)ell; }
@@ -195,7 +265,8 @@ static void ensure(ost_t* m, int B) {
 static void mlp_fwd(ost_t* m, layer_t* L, int n, const float* in, int B, int step, const int64_t* cells) {
   for (int i = 0; i < n; ++i) {
     layer_t* l = &L[i]; const int N = l->out;
-    gemm_nn(in, l->W, l->pre, B, l->in, N);
+    if (L == m->enc && i == 0) gemm_nn_sp(in, l->W, l->pre, B, l->in, N);   /* the sparse counts: the zero-skipping loop */
+    else gemm_nn(in, l->W, l->pre, B, l->in, N);
     if (m->c.batchnorm) {
 #pragma omp parallel for schedule(static)
       for (int j = 0; j < N; ++j) {
@@ -244,7 +315,8 @@ static void mlp_bwd(ost_t* m, layer_t* L, int n, const float* in0, float* dh, fl
         for (int b = 0; b < B; ++b) dpre[(size_t)b * N + j] = dh[(size_t)b * N + j];
       }
     }
-    gemm_tn(in, dpre, l->gW, B, l->in, N);
+    if (L == m->enc && i == 0) gemm_tn_sp(in, dpre, l->gW, B, l->in, N);
+    else gemm_tn(in, dpre, l->gW, B, l->in, N);
     if (i > 0 || din) { float* dst = i > 0 ? dh : din; gemm_nt(dpre, l->W, dst, B, N, l->in); }
   }
 }
@@ -340,6 +412,7 @@ void ost_set_threads(int n) {
 #else
   (void)n;
 #endif
+  if (g_blas_set_threads) g_blas_set_threads(1);   /* (one pool: see blas_sliced) */
 }
 void ost_destroy(void* h) {
   ost_t* m = (ost_t*)h;

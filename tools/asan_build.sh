@@ -9,7 +9,7 @@ OUT="$ROOT/build/asan"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 mkdir -p "$OUT/obj"
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g"
-gcc -O1 $SAN -fopenmp -std=gnu99 "$ROOT/oracle/sisua_step.c" "$ROOT/tools/asan/cstep_driver.c" -o "$OUT/cstep_driver" -lm
+gcc -O1 $SAN -fopenmp -std=gnu99 "$ROOT/oracle/sisua_step.c" "$ROOT/tools/asan/cstep_driver.c" -o "$OUT/cstep_driver" -lm -ldl
 ls "$ROOT"/sisua_amd/csrc/*.hip | xargs -P "${ASAN_JOBS:-6}" -I{} sh -c \
   "$HIPCC --cuda-host-only -O1 -std=c++17 -fPIC $SAN -w -c {} -o $OUT/obj/\$(basename {} .hip).o"
 # host-only objects still name their translation unit's device blob (__hip_fatbin_<hash>, registered by the module constructor): give
