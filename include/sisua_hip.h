@@ -364,6 +364,15 @@ int smx_comm_init_local(smx_model* const* models, int n);
  * generator (the stream that defines the order); out[n_obs] receives the cell indices.  No device work. */
 int smx_shuffle_order(int32_t n_obs, int32_t buffer, const int64_t* picks, int32_t* out);
 
+/* ---- developer knobs -------------------------------------------------------- */
+/* Tile / split-K / share sweeps, A/B of launch forms and test hooks (e.g. "score_rows", "predict_stage_floats", "no_sq_partials",
+ * "adam_wide_share") live in ONE registry instead of an environment variable each: smx_set_tuning sets a knob for the process,
+ * smx_clear_tuning removes one (name = NULL or "": all); the environment variable SMX_TUNING="name=value,name=value" presets them
+ * (the scripts under tools/).  docs/LAB_NOTES.md lists the knobs and their defaults; none of them is needed to USE the library -- the switches a user
+ * may need are the environment variables of INTEGRATION.md section C.  A model's launch-form flags read "no_<flag>" when it is created. */
+int smx_set_tuning(const char* name, double value);
+int smx_clear_tuning(const char* name);
+
 /* ---- code-path switches ---------------------------------------------------- */
 /* The training step has two forms of several stages: the default wide / fused kernels and the separate-launch forms
  * they replaced (which eval, predict and the scoring paths always use).  name: "head_loss" (output product fused with

@@ -122,6 +122,8 @@ SIGNATURES = {
     "smx_k_adam": (C.c_int, [C.c_int32, _IP, _FP, _FP, _FP, _FP, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                              C.c_float, _FP]),
     "smx_set_flag": (C.c_int, [_VP, C.c_char_p, C.c_int]),
+    "smx_set_tuning": (C.c_int, [C.c_char_p, C.c_double]),
+    "smx_clear_tuning": (C.c_int, [C.c_char_p]),
     "smx_timing_enable": (C.c_int, [_VP, C.c_char_p]),
     "smx_timing_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "smx_loss_bytes_per_cell": (C.c_int64, [_VP]),
@@ -170,6 +172,15 @@ def load():
         break
   _lib = lib
   return lib
+
+
+def set_tuning(name: str, value: float = 1.0):
+  """A developer knob of the library (include/sisua_hip.h: smx_set_tuning; docs/LAB_NOTES.md lists them)."""
+  check(load().smx_set_tuning(name.encode(), float(value)))
+
+
+def clear_tuning(name: str = ""):
+  check(load().smx_clear_tuning(name.encode()))
 
 
 def check(rc: int):

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void bigk_reduce_kernel(const float* __restric
 
 // slices: whole 32-deep stages per slice, about one slice per CU (at most `max_slices`)
 int bigk_slices(long K, int max_slices, int* k_chunk) {
-  static const int cap = getenv("SMX_BIGK_SLICES") ? atoi(getenv("SMX_BIGK_SLICES")) : 0;   // (sweeps)
+  static const int cap = (int)tuning("bigk_slices", 0);   // (sweeps)
   if (cap > 0) max_slices = std::min(max_slices, cap);
   long chunk = (K + max_slices - 1) / max_slices;
   chunk = std::max<long>(64, (chunk + 31) / 32 * 32);
@@ -239,7 +239,7 @@ int launch_bigk(hipStream_t st, const BigKArgs& a_in) {
   if (!bigk_supported(a)) { set_error("bigk: unsupported shapes"); return SMX_ERR_INVALID; }
   if (a.n_slices <= 0 || a.k_chunk % 32 || (long)a.n_slices * a.k_chunk < a.K) { set_error("bigk: bad slicing"); return SMX_ERR_INVALID; }
   const dim3 grid((unsigned)a.n_slices, (unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
-  static const int stages_env = getenv("SMX_BIGK_STAGES") ? atoi(getenv("SMX_BIGK_STAGES")) : 0;
+  static const int stages_env = (int)tuning("bigk_stages", 0);
   a.stages = (stages_env >= 2 && stages_env <= BIGK_STAGES) ? stages_env : SMX_BIGK_STAGES_DEFAULT;
   const size_t lds = (size_t)a.stages * ((a.a_u16 ? 128 * 32 * 2 : 128 * 32 * 4) + 128 * 32 * 4);
 #define SMX_BIGK_LAUNCH(U, KM, L)                                                                                         \

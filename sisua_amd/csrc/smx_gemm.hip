@@ -399,7 +399,7 @@ static int launch_cfg(hipStream_t st, GemmArgs g, int* eff_split) {
   if (g.N % BN != 0) { set_error("gemm: N not a multiple of the tile width"); return SMX_ERR_INVALID; }
   dim3 grid((g.M + BM - 1) / BM, g.N / BN, g.split_k), block(256);
   {
-    static const int ws = getenv("SMX_WIDE_STORE") ? atoi(getenv("SMX_WIDE_STORE")) : -1;
+    static const int ws = (int)tuning("wide_store", -1);
     g.wide_store = (WK == 1) && (ws >= 0 ? ws != 0 : (long)g.M * g.N >= 65536);
   }
   if (g.sq_part) {
@@ -429,14 +429,14 @@ static int launch_cfg(hipStream_t st, GemmArgs g, int* eff_split) {
 int suggest_split_k(int M, int N, int K) {
   if (K < 512) return 1;
   const int tiles = ((M + 31) / 32) * (N / 32);
-  static const int cap = getenv("SMX_SPLIT_CAP") ? atoi(getenv("SMX_SPLIT_CAP")) : 16;
-  static const int target = getenv("SMX_SPLIT_TARGET") ? atoi(getenv("SMX_SPLIT_TARGET")) : 256;
+  static const int cap = (int)tuning("split_cap", 16);
+  static const int target = (int)tuning("split_target", 256);
   int s = target / (tiles > 0 ? tiles : 1);
   if (s > cap) s = cap;       // the consumer re-reads every slab
   if (s < 1) s = 1;
   // very deep K (wide gene panels): a slice longer than 8 tiles is a latency-bound loop on a
   // half-empty chip; trade slab traffic for occupancy, up to 64 slices
-  static const int deep = getenv("SMX_SPLIT_DEEP") ? atoi(getenv("SMX_SPLIT_DEEP")) : 1024;
+  static const int deep = (int)tuning("split_deep", 1024);
   while (s < 64 && K / s > deep) s *= 2;
   if (s > 64) s = 64;
   const int chunk = round_up((K + s - 1) / s, 128);  // whole 128-deep tiles per slice
@@ -449,7 +449,7 @@ static int validate_gemm(GemmArgs& g);
 // four times the workgroups, each with a quarter of the dependent K loop.  In isolation K4 wins up to ~256 tiles
 // (tools/gemm_sweep.py); inside the step, with cold operands, 128 and 256 measure the same.
 static int k4_tiles() {
-  static const int v = getenv("SMX_K4_TILES") ? atoi(getenv("SMX_K4_TILES")) : 128;
+  static const int v = (int)tuning("k4_tiles", 128);
   return v;
 }
 
@@ -481,9 +481,9 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
       G.variant[i] = 11;
     }
     {
-      static const int ws = getenv("SMX_WIDE_STORE") ? atoi(getenv("SMX_WIDE_STORE")) : -1;
+      static const int ws = (int)tuning("wide_store", -1);
       // measured: inside the grouped kernel the transpose costs more than the wider stores save (+0.9 us per step)
-      static const bool grp_on = getenv("SMX_WIDE_STORE_GROUP") != nullptr && atoi(getenv("SMX_WIDE_STORE_GROUP")) != 0;
+      static const bool grp_on = tuning_on("wide_store_group");
       g.wide_store = grp_on && (tile == TILE_128x32) && (ws >= 0 ? ws != 0 : (long)g.M * g.N >= 65536);
     }
     if (g.sq_part) {
@@ -501,7 +501,7 @@ int launch_gemm_group(hipStream_t st, const GemmArgs* list, int n, int* eff_spli
   // run faster as separate launches with their own occupancy.
   bool has_epi = false, has_u16 = false;
   for (int i = 0; i < n; ++i) { has_epi |= (G.p[i].epi != 0); has_u16 |= (G.p[i].use_xform && G.p[i].xf.u16); }
-  static const bool split_all = getenv("SMX_SPLIT_GROUPS") != nullptr;
+  static const bool split_all = tuning_on("split_groups");
   // (the grouped kernel carries no uint16-store variant: those products keep their own launches)
   if ((total > 768 && !has_epi) || n == 1 || split_all || has_u16) {   // a lone product also runs leaner as its own kernel
     for (int i = 0; i < n; ++i) {
@@ -582,7 +582,7 @@ int launch_gemm(hipStream_t st, const GemmArgs& g_in, int* eff_split) {
   int tile = g.tile;
   if (tile == TILE_AUTO) {
     const int kper = g.K / g.split_k;
-    static const int xf_tile = getenv("SMX_XF_TILE") ? atoi(getenv("SMX_XF_TILE")) : 0;
+    static const int xf_tile = (int)tuning("xf_tile", 0);
     if (g.use_xform && !g.a_kmajor && xf_tile) tile = xf_tile;
     else if (g.use_xform && !g.a_kmajor) tile = TILE_32x32_K4;  // measured best for the gathered log1p operand (log is one v_log)
     else if (kper >= 128 && (long)((g.M + 127) / 128) * (g.N / 32) < k4_tiles()) tile = TILE_32x32_K4;

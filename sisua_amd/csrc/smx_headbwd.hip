@@ -305,7 +305,6 @@ int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a_in) {
     set_error("out_head_bwd: bad shapes");
     return SMX_ERR_INVALID;
   }
-  { static const int dg = getenv("SMX_HEADBWD_DIAG") ? atoi(getenv("SMX_HEADBWD_DIAG")) : 0; a.diag = dg; }
   a.n_ht = a.Hp / 32; a.n_gt = a.Gp / 32; a.n_ct = (a.B + 31) / 32;
   a.n_w = a.skip_dw ? 0 : a.n_ht * ((a.n_gt + 7) / 8 * 8);
   if (a.n_extra < 0 || a.n_extra > SMX_MAX_LABELS) { set_error("out_head_bwd: bad label riders"); return SMX_ERR_INVALID; }
@@ -508,7 +507,7 @@ int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int b
     P.colsum = g.colsum; P.sq_part = g.sq_part;
     P.n_mt = (g.M + 31) / 32; P.n_nt = g.N / 32;
     P.start = total;
-    P.panel = (bf16x3 && (g.M >= SMX_PANEL_MIN_WIDE || g.panel_hint) && g.N <= 128 && getenv("SMX_NO_PANEL") == nullptr) ? panel_grid(P.n_mt) : 0;
+    P.panel = (bf16x3 && (g.M >= SMX_PANEL_MIN_WIDE || g.panel_hint) && g.N <= 128 && !tuning_on("no_panel")) ? panel_grid(P.n_mt) : 0;
     if (P.panel) {
       any_panel = true;
       total += P.panel;
@@ -546,14 +545,14 @@ __global__ __launch_bounds__(512, ONE ? 4 : 2) void panel_dw_kernel(PanelProblem
 int panel_grid(int units) {
   // the workgroups are resident two per CU (128 registers, 45 KB of LDS) and each walks units first, first + grid, ...: as
   // many rounds as 512 workgroups need, then the grid that fills those rounds evenly (1875 units: 4 rounds of 469)
-  static const int cap = getenv("SMX_PANEL_GRID") ? std::max(atoi(getenv("SMX_PANEL_GRID")), 1) : 512;
+  static const int cap = std::max((int)tuning("panel_grid", 512), 1);
   const int rounds = (units + cap - 1) / cap;
   return (units + rounds - 1) / std::max(rounds, 1);
 }
 
 bool panel_dw_supported(const HeadBwdArgs& a) {
   return !a.sep && a.B > 0 && a.Hp % 32 == 0 && a.Hp <= 128 && a.Gp % 32 == 0 && a.Gp >= SMX_PANEL_MIN_WIDE &&
-         a.n_planes >= 1 && a.n_planes <= 3 && getenv("SMX_NO_PANEL") == nullptr;
+         a.n_planes >= 1 && a.n_planes <= 3 && !tuning_on("no_panel");
 }
 
 int launch_panel_dw(hipStream_t st, const HeadBwdArgs& a) {

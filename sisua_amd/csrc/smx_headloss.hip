@@ -199,11 +199,6 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
 bool head_loss_supported(int B, int Hp, int Gp) { return B > 0 && Hp % 32 == 0 && Gp % 32 == 0; }
 int head_loss_chunks(int Gp) { return Gp / 32; }
 
-static int head_waves() {   // waves per workgroup (SMX_HEAD_WAVES = 4 | 8 | 16)
-  static const int v = getenv("SMX_HEAD_WAVES") ? atoi(getenv("SMX_HEAD_WAVES")) : 8;
-  return (v == 4 || v == 16) ? v : 8;
-}
-
 template <int LK, int NW, int B3 = 0>
 static void launch_hl_w(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
   if (a.product_only) {
@@ -216,7 +211,7 @@ static void launch_hl_w(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
 }
 // bf16 x 3 products: SMX_BF16X3 = 1 always, 0 never (the exact-f32 MFMA forms); default: SMX_BF16X3_MIN_WORK (smx_internal.h)
 bool use_bf16x3(long work) {
-  static const int forced = getenv("SMX_BF16X3") ? atoi(getenv("SMX_BF16X3")) : -1;
+  static const int forced = (int)tuning("bf16x3", -1);
   return forced >= 0 ? forced != 0 : work >= SMX_BF16X3_MIN_WORK;
 }
 template <int LK>
@@ -229,9 +224,7 @@ static void launch_hl(hipStream_t st, const HeadLossArgs& a, dim3 grid) {
     else hipLaunchKernelGGL((out_head_loss_kernel<LK, 0, 2, 2, 64>), grid, dim3(128), 0, st, a);
     return;
   }
-  if (head_waves() == 4) launch_hl_w<LK, 4>(st, a, grid);
-  else if (head_waves() == 16) launch_hl_w<LK, 16>(st, a, grid);
-  else if (a.bf16x3) launch_hl_w<LK, 8, 1>(st, a, grid);
+  if (a.bf16x3) launch_hl_w<LK, 8, 1>(st, a, grid);   // (8 waves: 4 / 16 measured slower at every width, 7.3 / 8.5 / 8.0 us at C2; forms removed in round 4)
   else launch_hl_w<LK, 8>(st, a, grid);
 }
 

@@ -86,6 +86,12 @@ struct GemmArgs {
 };
 // Returns 0 or a negative smx_status.  N, lda, ldb, ldc multiples of 4; N multiple of 32.
 // eff_split (optional) receives the number of slabs actually written.
+// Developer knobs (tile / split-K / share sweeps, A/B of launch forms, test hooks): ONE registry instead of an environment variable per
+// knob.  smx_set_tuning(name, value) sets one; the environment variable SMX_TUNING="name=value,name=value" presets them for a process
+// (the scripts under tools/).  A knob that was never set reads its default.  docs/LAB_NOTES.md lists them; INTEGRATION.md lists the few switches a
+// USER needs (those stay environment variables).
+double tuning(const char* name, double dflt);
+inline bool tuning_on(const char* name) { return tuning(name, 0.0) != 0.0; }
 int launch_gemm(hipStream_t st, const GemmArgs& g, int* eff_split = nullptr);
 // Several independent products in ONE launch (tiles 128x32 / 32x32-K4 only); eff_splits[i] receives
 // the slab count of problem i.

@@ -152,8 +152,8 @@ int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M
     rc = launch_wgrad_group(nullptr, &g, 1, K, 1);
   } else
   rc = launch_gemm(nullptr, g, &eff);
-  if (rc == SMX_OK && getenv("SMX_KGEMM_REPS") && !direct && !wg) {  // diagnostic: average launch time of this shape / tile
-    const int reps = atoi(getenv("SMX_KGEMM_REPS"));
+  if (rc == SMX_OK && tuning("kgemm_reps", 0) > 0 && !direct && !wg) {  // diagnostic: average launch time of this shape / tile
+    const int reps = (int)tuning("kgemm_reps", 0);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 5; ++i) launch_gemm(nullptr, g, nullptr);

@@ -110,21 +110,12 @@ __global__ __launch_bounds__(BLOCK) void count_loss_kernel(LossArgs a) {
     a.llk_part[((long)b * gridDim.x + blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6)] = acc;
 }
 
-static int g_loss_block = 0;
-// (the uint16-store variants exist for 256-thread workgroups only: SMX_LOSS_BLOCK is a float32-store diagnostic)
-static int loss_block() {
-  if (!g_loss_block) {
-    const char* e = getenv("SMX_LOSS_BLOCK");
-    g_loss_block = e ? atoi(e) : 256;
-    if (g_loss_block != 256 && g_loss_block != 512 && g_loss_block != 1024) g_loss_block = 256;
-  }
-  return g_loss_block;
-}
+static int loss_block() { return 256; }
 // Elements per lane: 4-byte accesses win while the launch is latency-bound (one wave of workgroups), 8-byte
 // from ~0.4 M elements (47 % of the HBM peak at 128 x 20 000 against 38 %), 16-byte from ~8 M (64 % at 1024 x
 // 20 000) -- tools/loss_roofline.py.  SMX_LOSS_VEC forces a width.
 static int loss_vec(int B, int Gp) {
-  static const int forced = getenv("SMX_LOSS_VEC") ? atoi(getenv("SMX_LOSS_VEC")) : 0;
+  static const int forced = (int)tuning("loss_vec", 0);
   if (forced == 1 || forced == 2 || forced == 4) return forced;
   const long n = (long)B * Gp;
   return n < 400000 ? 1 : (n < 8000000 ? 2 : 4);
@@ -136,11 +127,9 @@ int loss_chunks_max(int Gp) { return loss_grid_x(Gp, 1) * (loss_block() / 64); }
 
 template <int LK, int DIRECT>
 static void launch_loss_t(hipStream_t st, const LossArgs& a, dim3 grid) {
-  const int v = loss_vec(a.B, a.Gp), blk = loss_block();
+  const int v = loss_vec(a.B, a.Gp);
 #define SMX_LOSS_LAUNCH(B_, V_) do { \
     if (a.x_u16) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 256, 1>), grid, dim3(256), 0, st, a); \
-    else if (blk == 1024) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 1024>), grid, dim3(1024), 0, st, a); \
-    else if (blk == 512) hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 512>), grid, dim3(512), 0, st, a); \
     else hipLaunchKernelGGL((count_loss_kernel<LK, DIRECT, B_, V_, 256>), grid, dim3(256), 0, st, a); } while (0)
   if (a.backward) { if (v == 4) SMX_LOSS_LAUNCH(1, 4); else if (v == 2) SMX_LOSS_LAUNCH(1, 2); else SMX_LOSS_LAUNCH(1, 1); }
   else { if (v == 4) SMX_LOSS_LAUNCH(0, 4); else if (v == 2) SMX_LOSS_LAUNCH(0, 2); else SMX_LOSS_LAUNCH(0, 1); }
@@ -152,9 +141,7 @@ int launch_count_loss(hipStream_t st, const LossArgs& a) {
     set_error("count_loss: bad shapes");
     return SMX_ERR_INVALID;
   }
-  if (a.x_u16 && loss_block() != 256) { set_error("count_loss: SMX_LOSS_BLOCK is a float32-store diagnostic"); return SMX_ERR_INVALID; }
   dim3 grid(loss_grid_x(a.Gp, loss_vec(a.B, a.Gp)), a.B);
-  if (getenv("SMX_LOSS_NOP")) { LossArgs b = a; b.likelihood = -atoi(getenv("SMX_LOSS_NOP")); launch_loss_t<SMX_LLK_ZINB, 0>(st, b, grid); return SMX_OK; }
   switch (a.likelihood) {
     case SMX_LLK_NB: launch_loss_t<SMX_LLK_NB, 0>(st, a, grid); break;
     case SMX_LLK_ZINB: launch_loss_t<SMX_LLK_ZINB, 0>(st, a, grid); break;
@@ -508,7 +495,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_dual_kernel(BnFwdArgs a
   else bn_act_fwd_body<RPT, 0>(b, (int)blockIdx.x - na);
 }
 
-static int bn_diag() { static const int v = getenv("SMX_BN_DIAG") ? atoi(getenv("SMX_BN_DIAG")) : 0; return v; }
 
 bool bn_front_supported(int B, int Dp) {
   const int dq = Dp >> 2;
@@ -541,9 +527,6 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
-  if (bn_diag() & 1) a.drop_p = 0.f;                      // diagnostic: no dropout draw
-  if (bn_diag() & 2) a.n_slabs = 1;                       // diagnostic: one slab only
-  if (bn_diag() & 8) a.n_jobs = 0;                        // diagnostic: no look-ahead noise workgroups
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_fwd: bad shapes"); return SMX_ERR_INVALID; }
   const int grid = a.Hp / BN_COLS + a.n_jobs * SMX_NOISE_BLOCKS_PER_JOB;
   if (a.B <= BN_RL * 2) hipLaunchKernelGGL(bn_act_fwd_kernel<2>, dim3(grid), dim3(BN_THREADS), 0, st, a);
@@ -722,7 +705,6 @@ bool bn_bwd_front_supported(int B, int K) {
 
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
   BnBwdArgs a = a_in;
-  a.diag = bn_diag();
   if (a.front) {
     if (!bn_bwd_front_supported(a.B, a.fK) || !a.fD || !a.fW || (a.fld % 4) || (a.fldw % 4) || a.Hp % BN_COLS) {
       set_error("bn_act_bwd: gradient front not applicable");
@@ -743,7 +725,6 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
-  if (bn_diag() & 4) a.n_slabs = 1;                       // diagnostic: one slab only
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_bwd: bad shapes"); return SMX_ERR_INVALID; }
   const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count + a.sqr_count;
   if (a.B <= BN_RL * 2) hipLaunchKernelGGL(bn_act_bwd_kernel<2>, dim3(grid), dim3(BN_THREADS), 0, st, a);
@@ -998,8 +979,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentArgs a) {
 
 int launch_latent_fwd(hipStream_t st, const LatentArgs& a) {
   const int dq = a.Dp >> 2;
-  static const bool scalar_only = getenv("SMX_LATENT_SCALAR") != nullptr;
-  if (!scalar_only && dq >= 1 && dq <= 64 && (dq & (dq - 1)) == 0 && (a.ld % 4) == 0 && (!a.inj_eps || (a.inj_ld % 4) == 0)) {
+  if (dq >= 1 && dq <= 64 && (dq & (dq - 1)) == 0 && (a.ld % 4) == 0 && (!a.inj_eps || (a.inj_ld % 4) == 0)) {
     hipLaunchKernelGGL(latent_fwd_quad_kernel, dim3((a.B * dq + 63) / 64), dim3(64), 0, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
@@ -1765,8 +1745,7 @@ __global__ __launch_bounds__(256) void scvi_head_bwd_reg_kernel(ScviHeadArgs a) 
 }
 
 static bool scvi_head_reg_ok(const ScviHeadArgs& a) {
-  static const bool off = getenv("SMX_SCVI_HEAD_SWEEP") != nullptr;
-  return !off && (a.ld % 4) == 0 && (a.plane_stride % 4) == 0 && (a.Gp % 4) == 0 && a.Gp <= 4096;
+  return (a.ld % 4) == 0 && (a.plane_stride % 4) == 0 && (a.Gp % 4) == 0 && a.Gp <= 4096;
 }
 
 int launch_scvi_head_fwd(hipStream_t st, const ScviHeadArgs& a) {

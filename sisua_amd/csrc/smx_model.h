@@ -142,16 +142,16 @@ struct smx_model {
   // kernels, 0 = the separate-launch forms they replaced (kept for eval, for shapes the fused kernels do not take, and
   // as A/B references)
   struct Flags {
-    int head_loss = getenv("SMX_NO_HEAD_LOSS") ? 0 : 1;    // output product + likelihood in one kernel
-    int front = getenv("SMX_NO_FRONT") ? 0 : 1;            // latent sample + first decoder product inside BatchNorm-forward
-    int bwd_front = getenv("SMX_NO_BWD_FRONT") ? 0 : 1;    // d h inside BatchNorm-backward, weight gradients grouped at the end
-    int head_bwd = getenv("SMX_NO_HEAD_BWD") ? 0 : 1;      // both backward products of the output head in one wide launch
-    int wgrad = getenv("SMX_NO_WGRAD") ? 0 : 1;            // K = minibatch weight gradients as the wide direct-operand kernel
-    int scvi_fused = getenv("SMX_NO_SCVI_FUSED") ? 0 : 1;  // scvi: library latent + softmax head + likelihood + their backward as one row-local launch
-    int twin = getenv("SMX_NO_TWIN") ? 0 : 1;              // scvi: first layers of both encoders (and pairs of heads) side by side in one launch
-    int act_epilogue = getenv("SMX_NO_ACT_EPILOGUE") ? 0 : 1;  // layers without BatchNorm / dropout: bias + activation (and its derivative) in the products' store paths
-    int label_ride = getenv("SMX_NO_LABEL_RIDE") ? 0 : 1;  // label heads' backward inside the output head's backward launch + the final grouped launch
-    int stacked_scoring = getenv("SMX_NO_STACKED_SCORING") ? 0 : 1;  // marginal_llk: all posterior draws as rows of ONE decoder pass
+    int head_loss = tuning_on("no_head_loss") ? 0 : 1;    // output product + likelihood in one kernel
+    int front = tuning_on("no_front") ? 0 : 1;            // latent sample + first decoder product inside BatchNorm-forward
+    int bwd_front = tuning_on("no_bwd_front") ? 0 : 1;    // d h inside BatchNorm-backward, weight gradients grouped at the end
+    int head_bwd = tuning_on("no_head_bwd") ? 0 : 1;      // both backward products of the output head in one wide launch
+    int wgrad = tuning_on("no_wgrad") ? 0 : 1;            // K = minibatch weight gradients as the wide direct-operand kernel
+    int scvi_fused = tuning_on("no_scvi_fused") ? 0 : 1;  // scvi: library latent + softmax head + likelihood + their backward as one row-local launch
+    int twin = tuning_on("no_twin") ? 0 : 1;              // scvi: first layers of both encoders (and pairs of heads) side by side in one launch
+    int act_epilogue = tuning_on("no_act_epilogue") ? 0 : 1;  // layers without BatchNorm / dropout: bias + activation (and its derivative) in the products' store paths
+    int label_ride = tuning_on("no_label_ride") ? 0 : 1;  // label heads' backward inside the output head's backward launch + the final grouped launch
+    int stacked_scoring = tuning_on("no_stacked_scoring") ? 0 : 1;  // marginal_llk: all posterior draws as rows of ONE decoder pass
     // training products of the output head (fused head, its backward, the encoder's weight gradient) from bf16 MFMAs on
     // three-way split operands: 1 always, 0 never (the exact-f32 MFMA forms), -1 from the width (SMX_BF16X3_MIN_WORK)
     int bf16x3 = -1;

@@ -91,6 +91,37 @@ void unpack(const TensorInfo& t, const std::vector<float>& dev, float* host, flo
 
 }  // namespace smx
 
+// ---- developer knobs (smx_internal.h: tuning) -----------------------------------------------------------------------------
+namespace smx {
+static std::mutex g_tuning_mu;
+static std::map<std::string, double>& tuning_map() {
+  static std::map<std::string, double> mp;
+  static bool parsed = false;
+  if (!parsed) {   // SMX_TUNING="name=value,name=value" (a bare name means 1)
+    parsed = true;
+    if (const char* e = getenv("SMX_TUNING")) {
+      std::string str(e);
+      size_t i = 0;
+      while (i < str.size()) {
+        size_t j = str.find(',', i);
+        if (j == std::string::npos) j = str.size();
+        const std::string item = str.substr(i, j - i);
+        const size_t eq = item.find('=');
+        if (!item.empty()) mp[item.substr(0, eq)] = eq == std::string::npos ? 1.0 : atof(item.c_str() + eq + 1);
+        i = j + 1;
+      }
+    }
+  }
+  return mp;
+}
+double tuning(const char* name, double dflt) {
+  std::lock_guard<std::mutex> lk(g_tuning_mu);
+  auto& mp = tuning_map();
+  auto it = mp.find(name);
+  return it == mp.end() ? dflt : it->second;
+}
+}  // namespace smx
+
 extern "C" {
 
 const char* smx_last_error(void) { return last_error_cstr(); }
@@ -113,6 +144,18 @@ int smx_shuffle_order(int32_t n_obs, int32_t buffer, const int64_t* picks, int32
     if (nxt < n_obs) buf[k] = nxt++;
     else { buf[k] = buf[len - 1]; --len; }
   }
+  return SMX_OK;
+}
+
+int smx_set_tuning(const char* name, double value) {
+  SMX_REQUIRE(name && *name, "null name");
+  std::lock_guard<std::mutex> lk(smx::g_tuning_mu);
+  smx::tuning_map()[name] = value;
+  return SMX_OK;
+}
+int smx_clear_tuning(const char* name) {
+  std::lock_guard<std::mutex> lk(smx::g_tuning_mu);
+  if (name && *name) smx::tuning_map().erase(name); else smx::tuning_map().clear();
   return SMX_OK;
 }
 
@@ -333,9 +376,8 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   }
   // ---- optimiser chunk table ----
   std::vector<OptChunk> chunks;
-  // floats per optimiser workgroup (SMX_OPT_CHUNK = 1024 | 2048 | 4096 | 8192)
-  static const int ch_env = getenv("SMX_OPT_CHUNK") ? atoi(getenv("SMX_OPT_CHUNK")) : 0;
-  const int CH = (ch_env == 1024 || ch_env == 2048 || ch_env == 4096 || ch_env == 8192) ? ch_env : 4096;
+  // floats per optimiser workgroup
+  const int CH = 4096;
   for (size_t t = 0; t < m->tensors.size(); ++t) {
     const TensorInfo& ti = m->tensors[t];
     const int first = (int)chunks.size();

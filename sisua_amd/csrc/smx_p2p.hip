@@ -213,9 +213,9 @@ int smx_comm_p2p_export(smx_model* m, int world, uint8_t handles[128]) {
   // Fine-grained device memory: peers STORE their flags into this region while this rank's waves poll it.  A coarse-grained
   // allocation is only promised to be coherent across agents at kernel boundaries (the owner's L2 may keep serving a polled line);
   // on one device -- where the tests run -- every process shares the L2 and either kind works, so the kind that is right on a
-  // multi-GPU node is the one used everywhere (SMX_P2P_COARSE=1: plain hipMalloc, as rounds 1-3a did).
+  // multi-GPU node is the one used everywhere.
   void* region = nullptr;
-  if (getenv("SMX_P2P_COARSE") != nullptr || hipExtMallocWithFlags(&region, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+  if (hipExtMallocWithFlags(&region, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
     (void)hipGetLastError();
     region = nullptr;
     SMX_HIP(hipMalloc(&region, bytes));

@@ -287,8 +287,8 @@ static int predict_core(smx_model* m, const float* host_x, const float* host_lib
     SMX_CHECK(dmalloc(&m->pred_target, (size_t)m->Bmax * m->Gp));
     m->pred_target_floats = (size_t)m->Bmax * m->Gp;
   }
-  // 128 MB of staging (SMX_PREDICT_STAGE_FLOATS: tests force several chunks on small problems)
-  const size_t cap_floats = getenv("SMX_PREDICT_STAGE_FLOATS") ? (size_t)std::max(1L, atol(getenv("SMX_PREDICT_STAGE_FLOATS"))) : (size_t)32 << 20;
+  // 128 MB of staging (knob predict_stage_floats: tests force several chunks on small problems)
+  const size_t cap_floats = (size_t)std::max(1.0, tuning("predict_stage_floats", (double)((size_t)32 << 20)));
   size_t C = std::max<size_t>((size_t)batch, cap_floats / per_cell / (size_t)batch * (size_t)batch);   // whole batches per chunk
   C = std::min(C, (N + (size_t)batch - 1) / (size_t)batch * (size_t)batch);
   if (C * per_cell > m->pred_floats) {

@@ -440,7 +440,7 @@ int launch_score_head(hipStream_t st, const ScoreHeadArgs& a_in) {
   a.n_gt = a.Gp / 32;
   // (row blocks per L2 group: measured 4 / 8 / 16 / 32 / all within 3 % of each other once the loads are issued up
   // front -- the A operand's re-reads are served by the Infinity Cache at no visible cost; default: one group)
-  static const int rbg = getenv("SMX_SCORE_RB_GROUP") ? std::max(1, atoi(getenv("SMX_SCORE_RB_GROUP"))) : (1 << 30);
+  static const int rbg = std::max(1, (int)tuning("score_rb_group", (double)(1 << 30)));
   a.rb_group = std::min(rbg, a.n_rb);
   a.gt_per_xcd = (a.n_gt + 7) / 8;
   const int n_grp = (a.n_rb + a.rb_group - 1) / a.rb_group;

@@ -61,7 +61,7 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
   for (const MlpLayer& L : m->dec) Hmax = std::max(Hmax, L.out_p);
   // rows per stacked pass: whole draws, up to 16 384 rows (SMX_SCORE_ROWS: the tests force several chunks)
   // (scvi: 4 096 rows -- their raw planes are 100 MB at 2 000 genes)
-  const long cap_rows = getenv("SMX_SCORE_ROWS") ? std::max(1L, atol(getenv("SMX_SCORE_ROWS"))) : (m->scvi ? 4096L : 16384L);
+  const long cap_rows = std::max(1L, (long)tuning("score_rows", m->scvi ? 4096.0 : 16384.0));
   const int Sc = (int)std::min<long>(std::min<long>(n_samples, SMX_SCORE_MAX_DRAWS), std::max<long>(1, cap_rows / B));
   const size_t R = (size_t)Sc * B;
   const size_t raw_ld = (size_t)m->k * m->Gp;
@@ -79,7 +79,7 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
   float* part = ht + 2 * R * Hmax;
   float* lsmp = part + R * n_gt;         // scvi: the library latent of every row ...
   float* raw = lsmp + R;                 // ... and the k raw planes [R][k * Gp]
-  const bool wide_head = m->scvi || getenv("SMX_SCORE_HEAD_WIDE") != nullptr || !score_head_supported(m->dec.back().out_p, m->Gp);   // the training kernel's direct-operand form (A/B)
+  const bool wide_head = m->scvi || tuning_on("score_head_wide") || !score_head_supported(m->dec.back().out_p, m->Gp);   // the training kernel's direct-operand form (A/B)
   const int nslab = m->dec.back().out_p / 32;
   // W as bf16 slab images, one set per plane count in use (3: zero-inflated likelihoods; 2: the others and the
   // count part of a zero-inflated one) -- once per call, W does not change meanwhile

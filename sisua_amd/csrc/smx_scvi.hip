@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
 }
 
 bool scvi_head_train_supported(const ScviTrainArgs& a) {
-  static const bool off = getenv("SMX_NO_SCVI_FUSED") != nullptr;
+  const bool off = false;   // (the launch form is a model flag: smx_set_flag("scvi_fused"))
   return !off && (a.likelihood == SMX_LLK_NBD || a.likelihood == SMX_LLK_ZINBD) && (a.ld % 4) == 0 && (a.plane_stride % 4) == 0 &&
          (a.Gp % 4) == 0 && a.Gp <= 4096 && (a.ldx % 4) == 0 && (a.ldwl % 2) == 0 && a.ldl >= 2 && a.ldl <= 256 && a.Kl > 0;
 }

@@ -81,7 +81,7 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     MlpLayer& L = mlp[i];
     const TensorInfo& tw = m->tensors[L.tW];
     GemmArgs g = make_gemm(L, in, ld, i == 0 && in_is_x, m->slab);
-    static const bool no_ahead = getenv("SMX_NO_NOISE_AHEAD") != nullptr;
+    static const bool no_ahead = tuning_on("no_noise_ahead");
     const bool no_twin = !m->flags.twin;
     const bool sync = sync_bn_on(m, ps.training) && L.bn >= 0;
     // hidden -> hidden layers 32 / 64 / 128 wide: the BatchNorm launch stages the layer's INPUT tile [B][K] in LDS and forms its
@@ -117,7 +117,7 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
       g.bias = P_(m, L.tBias); g.act = 1; g.leak = L.leak; g.C = L.out_buf; g.ldc = L.out_p; g.split_k = 1;
       Timed t(m, (i == 0 && in_is_x) ? label0 : "gemm_mlp_fwd");
       // a deep contraction (the discriminator's 1000-wide layers): the direct-operand bf16 x 3 form (smx_dgemm.hip)
-      if (b3_on(m, ps) && dgemm_supported(g) && getenv("SMX_NO_DGEMM") == nullptr) SMX_CHECK(launch_dgemm(m->st, g));
+      if (b3_on(m, ps) && dgemm_supported(g) && !tuning_on("no_dgemm")) SMX_CHECK(launch_dgemm(m->st, g));
       else SMX_CHECK(launch_gemm(m->st, g));
       in = L.out_buf; ld = L.out_p;
       continue;
@@ -126,7 +126,7 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
     bool bigk = false;
     BigKArgs bk;
     if (i == 0 && in_is_x && !dual && !with_front && m->bigk_part && !g.xf.drop_p && !g.xf.inj_mask && L.out_p <= 128 &&
-        (m->flags.bf16x3 < 0 ? use_bf16x3((long)ps.B * m->Gp * m->k) : m->flags.bf16x3 != 0) && getenv("SMX_NO_BIGK") == nullptr) {
+        (m->flags.bf16x3 < 0 ? use_bf16x3((long)ps.B * m->Gp * m->k) : m->flags.bf16x3 != 0) && !tuning_on("no_bigk")) {
       bk.A = in; bk.lda = ld; bk.a_u16 = ps.x_u16; bk.log1p = m->cfg.log_norm; bk.rows = ps.xrows;
       bk.Bm = P_(m, L.tW); bk.ldb = tw.ld; bk.b_kmajor = 1;
       bk.M = ps.B; bk.N = L.out_p; bk.K = L.in_p; bk.ldc = L.out_p; bk.slab_stride = (long)ps.B * L.out_p;
@@ -232,8 +232,8 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
     return;
   }
   m->adam_early_pending = false;
-  static const bool off = getenv("SMX_NO_ADAM_EARLY") != nullptr;
-  if (off || dp_active(m) || !m->sq_slots || m->chunk_first_head >= m->n_chunks || getenv("SMX_NO_SQ_PARTIALS") != nullptr) return;
+  static const bool off = tuning_on("no_adam_early");
+  if (off || dp_active(m) || !m->sq_slots || m->chunk_first_head >= m->n_chunks || tuning_on("no_sq_partials")) return;
   for (size_t t = (size_t)m->t_outW[0]; t < m->tensors.size(); ++t)   // head tensors are the last ones of the manifest
     if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) return;
   // riders use half of a 512-thread BatchNorm workgroup: fine while the heads' update is a few MB (C2: 22 MB, hidden
@@ -259,9 +259,9 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
     b.sq_total = m->sq_slots + m->sq_total_first;
     // ... and a share of the heads' chunks rides with the NEXT BatchNorm-backward launch as full 512-thread workgroups (the norms are
     // single numbers by then): SMX_ADAM_WIDE_SHARE of them, the optimiser launch keeps the rest
-    static const float share = getenv("SMX_ADAM_WIDE_SHARE") ? (float)atof(getenv("SMX_ADAM_WIDE_SHARE")) : 0.3f;
+    static const float share = (float)tuning("adam_wide_share", 0.3f);
     // ... and SMX_ADAM_WIDE_SHARE_B of them before that with the latent head's backward product (take_adam_riders)
-    static const float share_b = getenv("SMX_ADAM_WIDE_SHARE_B") ? (float)atof(getenv("SMX_ADAM_WIDE_SHARE_B")) : 0.1f;
+    static const float share_b = (float)tuning("adam_wide_share_b", 0.1f);
     const int early_to = m->lab_deferred ? m->chunk_first_label : m->n_chunks;
     const int n = (int)((early_to - m->chunk_first_head) * std::min(std::max(share, 0.f), 1.f));
     const int nb = std::min((int)((early_to - m->chunk_first_head) * std::min(std::max(share_b, 0.f), 1.f)), early_to - m->chunk_first_head - n);
@@ -279,7 +279,7 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
   // 6 for its own work) while the NEXT BatchNorm-backward launch of the step leaves the chip as idle: split them over the two
   // (SMX_ADAM_SPLIT = share of the first, default 0.5; a step with one such launch keeps them all, the final launch takes what
   // nobody carried)
-  static const float split = getenv("SMX_ADAM_SPLIT") ? (float)atof(getenv("SMX_ADAM_SPLIT")) : 0.5f;
+  static const float split = (float)tuning("adam_split", 0.5f);
   const int total = early_to - m->chunk_first_head;
   const int first = std::max(1, std::min(total, (int)(total * std::min(std::max(split, 0.f), 1.f) + 0.5f)));
   b.adam_first = m->chunk_first_head;
@@ -287,13 +287,13 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
   m->adam_early_from = m->chunk_first_head; m->adam_early_to = m->chunk_first_head + first;
   m->adam_rest_from = m->chunk_first_head + first; m->adam_rest_to = early_to;
   // ... of which SMX_ADAM_SPLIT_B of the total go with the latent head's backward product between the two (take_adam_riders)
-  static const float split_b = getenv("SMX_ADAM_SPLIT_B") ? (float)atof(getenv("SMX_ADAM_SPLIT_B")) : 0.f;
+  static const float split_b = (float)tuning("adam_split_b", 0.f);
   m->adam_ride_b = std::min((int)(total * std::min(std::max(split_b, 0.f), 1.f)), m->adam_rest_to - m->adam_rest_from);
 }
 
 // ask the product that writes the gradient of tensor t for sum-of-squares partials
 void want_sq(smx_model* m, GemmArgs& g, int t) {
-  if (!m->sq_slots || getenv("SMX_NO_SQ_PARTIALS") != nullptr) return;   // read per call: tests toggle it
+  if (!m->sq_slots || tuning_on("no_sq_partials")) return;   // read per call: tests toggle it
   g.sq_part = m->sq_slots + m->sq_first[(size_t)t];
   g.sq_count = &m->sq_count[(size_t)t];
 }
@@ -744,12 +744,12 @@ int factor_sweep(smx_model* m, const Pass& ps, int rows, const float* up, bool w
   const MlpLayer& last = m->disc.back();
   // flag bf16x3: the weight gradients (K = the stacked minibatch) through the direct-operand 32 x 32-tile kernel of
   // smx_headbwd.hip, the 1000-deep input gradients through smx_dgemm.hip -- both from bf16 MFMAs on split operands
-  const bool b3 = b3_on(m, ps) && getenv("SMX_NO_DGEMM") == nullptr;
+  const bool b3 = b3_on(m, ps) && !tuning_on("no_dgemm");
   auto wgrad = [&](const GemmArgs& g) -> int {
     if (!(b3 && m->flags.wgrad && wgrad_supported(g, rows))) return launch_gemm(m->st, g);
     // a square 1000 x 1000 gradient: as up to 8 column groups of 128 in the panel form (smx_panel.h role 0: a workgroup takes 32
     // rows with the group's four column tiles -- the A tile is split once per group instead of once per 32 columns)
-    if (g.M >= 512 && g.N % 128 == 0 && g.N / 128 <= SMX_GROUP_MAX && g.N > 128 && getenv("SMX_NO_PANEL") == nullptr) {
+    if (g.M >= 512 && g.N % 128 == 0 && g.N / 128 <= SMX_GROUP_MAX && g.N > 128 && !tuning_on("no_panel")) {
       GemmArgs part[SMX_GROUP_MAX];
       int counts[SMX_GROUP_MAX];
       const int ng = g.N / 128, per = ((g.M + 31) / 32) * 8;
@@ -856,9 +856,9 @@ static int factor_backward_stacked(smx_model* m, const Pass& ps) {
   const int B = ps.B, R2 = 2 * B, R3 = 3 * B;
   const MlpLayer& last = m->disc.back();
   const TensorInfo& two = m->tensors[m->t_discoutW];
-  const bool b3 = b3_on(m, ps) && getenv("SMX_NO_DGEMM") == nullptr;
+  const bool b3 = b3_on(m, ps) && !tuning_on("no_dgemm");
   const float* up = m->u_d;   // [3B][32]
-  static const bool beside_on = getenv("SMX_FVAE_NO_BESIDE") == nullptr;
+  static const bool beside_on = !tuning_on("fvae_no_beside");
   // beside: the layer's input gradient in the same launch (wgrad_dgemm_kernel) where both forms apply, right after it otherwise
   auto input_grad = [&](const GemmArgs& h) -> int {
     if (b3 && dgemm_supported(h)) return launch_dgemm(m->st, h);
@@ -866,7 +866,7 @@ static int factor_backward_stacked(smx_model* m, const Pass& ps) {
   };
   auto wgrad = [&](const GemmArgs& g, const GemmArgs* beside = nullptr) -> int {
     if (!(b3 && m->flags.wgrad && wgrad_supported(g, R2))) return launch_gemm(m->st, g);
-    if (g.M >= 512 && g.N % 128 == 0 && g.N / 128 <= SMX_GROUP_MAX && g.N > 128 && getenv("SMX_NO_PANEL") == nullptr) {
+    if (g.M >= 512 && g.N % 128 == 0 && g.N / 128 <= SMX_GROUP_MAX && g.N > 128 && !tuning_on("no_panel")) {
       GemmArgs part[SMX_GROUP_MAX];
       int counts[SMX_GROUP_MAX];
       const int ng = g.N / 128, per = ((g.M + 31) / 32) * 8;
@@ -926,7 +926,7 @@ static int factor_backward_stacked(smx_model* m, const Pass& ps) {
 }
 
 int factor_backward(smx_model* m, const Pass& ps) {
-  if (m->flags.act_epilogue && getenv("SMX_FVAE_TWO_SWEEPS") == nullptr) return factor_backward_stacked(m, ps);
+  if (m->flags.act_epilogue && !tuning_on("fvae_two_sweeps")) return factor_backward_stacked(m, ps);
   SMX_CHECK(factor_sweep(m, ps, 2 * ps.B, m->u_d, true));                          // discriminator objective -> the discriminator's tensors
   SMX_CHECK(factor_sweep(m, ps, ps.B, m->u_d + (size_t)2 * ps.B * 32, false));     // gamma TC (+ alpha CE) -> d z
   return SMX_OK;
@@ -969,7 +969,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
       hb.sep = 1;
       for (int ch = 0; ch < m->k; ++ch) {
         hb.Wp[ch] = P_(m, m->t_outW[ch]); hb.dWp[ch] = G_(m, m->t_outW[ch]); hb.dbp[ch] = G_(m, m->t_outb[ch]);
-        if (m->sq_slots && getenv("SMX_NO_SQ_PARTIALS") == nullptr) {
+        if (m->sq_slots && !tuning_on("no_sq_partials")) {
           hb.sqp[ch] = m->sq_slots + m->sq_first[(size_t)m->t_outW[ch]]; hb.sq_countp[ch] = &m->sq_count[(size_t)m->t_outW[ch]];
         }
       }
@@ -979,7 +979,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
     hb.n_slices = head_bwd_slices(ldp, ldp <= 8192 ? 16 : 32, &hb.k_chunk);
     hb.slab = m->slab; hb.slab_stride = dd_stride;
     SMX_REQUIRE((size_t)hb.n_slices * (size_t)dd_stride <= m->slab_cap, "split-K slabs exceed the slab buffer");
-    if (!m->scvi && m->sq_slots && getenv("SMX_NO_SQ_PARTIALS") == nullptr) {
+    if (!m->scvi && m->sq_slots && !tuning_on("no_sq_partials")) {
       hb.sq_part = m->sq_slots + m->sq_first[(size_t)m->t_outW[0]]; hb.sq_count = &m->sq_count[(size_t)m->t_outW[0]];
     }
     n_slabs = hb.n_slices;
@@ -1003,7 +1003,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
     // a wide head (the bf16 x 3 regime): d d = dP W^T (K = every gene of every plane) as one workgroup per K slice + a reduce
     // launch (smx_bigk.hip) -- ONE slab for the BatchNorm-backward launch; d W / d b stay with the 32 x 32-tile kernel
     bool dd_bigk = false;
-    if (hb.bf16x3 && !hb.sep && hb.n_extra == 0 && m->bigk_part && dL.out_p <= 128 && getenv("SMX_NO_BIGK") == nullptr) {
+    if (hb.bf16x3 && !hb.sep && hb.n_extra == 0 && m->bigk_part && dL.out_p <= 128 && !tuning_on("no_bigk")) {
       BigKArgs bk;
       bk.A = dparams; bk.lda = ldp; bk.Bm = P_(m, m->t_outW[0]); bk.ldb = tw.ld; bk.b_kmajor = 0;
       bk.M = ps.B; bk.N = dL.out_p; bk.K = (int)ldp; bk.ldc = dL.out_p; bk.slab_stride = dd_stride;
@@ -1232,7 +1232,7 @@ void fill_adam_args(smx_model* m, AdamArgs& a) {
   a.partial = m->partial; a.tensor_norm = m->tensor_norm;
   // norms from the products' partials when every large tensor has them (single GPU: under data parallelism the
   // norm is that of the all-reduced gradient, which only a pass after the collective can give)
-  a.use_sq = (m->sq_slots != nullptr && !dp_active(m) && getenv("SMX_NO_SQ_PARTIALS") == nullptr) ? 1 : 0;
+  a.use_sq = (m->sq_slots != nullptr && !dp_active(m) && !tuning_on("no_sq_partials")) ? 1 : 0;
   for (size_t t = 0; t < m->tensors.size() && a.use_sq; ++t) {
     a.sq_first[t] = m->sq_first[t]; a.sq_count[t] = m->sq_count[t];
     if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) a.use_sq = 0;
@@ -1410,7 +1410,7 @@ int check_rows(smx_model* m, const int32_t* ids, size_t n) {
 int launch_train(smx_model* m, int B, bool use_graph, int s_idx, int n_steps) {
   // With a communicator the RCCL all-reduce is captured too (RCCL supports stream capture);
   // SMX_NO_GRAPH_COMM=1 or a failed capture falls back to eager launches for good.
-  static const bool no_graph_comm = getenv("SMX_NO_GRAPH_COMM") != nullptr;
+  static const bool no_graph_comm = tuning_on("no_graph_comm");
   // (the peer-to-peer exchange carries its epoch as a kernel argument: never captured)
   if (use_graph && !m->local && !m->p2p && !(m->comm && (no_graph_comm || m->graph_comm_failed)) && !m->use_injected && m->timing_label.empty()) {
     auto it = m->graphs.find(B);

@@ -122,11 +122,12 @@ def test_fit_predict(api, name):
   assert np.allclose(Xl0.mean(), Xa0.mean(), rtol=2e-5, atol=1e-6)
   model._engine.set_flag("stacked_scoring", True)
   # ... and when the result leaves the device in several chunks (staging forced small: 16 cells per chunk)
-  os.environ["SMX_PREDICT_STAGE_FLOATS"] = "20000"
+  from sisua_amd import _hip
+  _hip.set_tuning("predict_stage_floats", 20000)
   try:
     Xb, Zb = model.predict(xs, sample_shape=2, batch_size=16, verbose=False)
   finally:
-    del os.environ["SMX_PREDICT_STAGE_FLOATS"]
+    _hip.clear_tuning("predict_stage_floats")
   Xb0 = Xb[0] if isinstance(Xb, tuple) else Xb
   Zb0 = Zb[0] if isinstance(Zb, (tuple, list)) else Zb
   assert np.array_equal(Xb0.mean(), Xa0.mean()) and np.array_equal(Zb0.mean(), Za0.mean())

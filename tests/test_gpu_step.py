@@ -498,7 +498,8 @@ def test_rccl_single_rank_allreduce_is_identity(Engine, monkeypatch, graph, buck
   monkeypatch.setenv("SMX_DP_BUCKETS", buckets)
   # the data-parallel path takes the norms from a pass over the (all-reduced) gradient; give the reference
   # run the same summation order so that the comparison can be exact
-  monkeypatch.setenv("SMX_NO_SQ_PARTIALS", "1")
+  from sisua_amd import _hip
+  _hip.set_tuning("no_sq_partials", 1)   # (cleared after the test: tests/conftest.py)
   spec, cfg, x, ys, lib, mask = _problem(CASES["sisua"])
   outs = []
   for use_comm in (False, True):
@@ -604,18 +605,19 @@ def test_marginal_llk_matches_oracle(Engine, name):
   e.set_flag("stacked_scoring", True)
   assert np.allclose(loop_m, ref_m, rtol=RTOL, atol=1e-3) and np.allclose(loop_l, ref_l, rtol=RTOL, atol=1e-3)
   assert np.allclose(loop_m, got_m, rtol=1e-5, atol=1e-3)
-  os.environ["SMX_SCORE_HEAD_WIDE"] = "1"   # the f32 direct-operand head kernel in its likelihood-only mode
+  from sisua_amd import _hip
+  _hip.set_tuning("score_head_wide", 1)   # the f32 direct-operand head kernel in its likelihood-only mode
   try:
     wide_m, wide_l = e.marginal_llk(row_ids=rows, n_samples=S)
   finally:
-    del os.environ["SMX_SCORE_HEAD_WIDE"]
+    _hip.clear_tuning("score_head_wide")
   assert np.allclose(wide_m, ref_m, rtol=RTOL, atol=1e-3) and np.allclose(wide_m, got_m, rtol=1e-5, atol=1e-3)
   assert np.allclose(wide_l, got_l, rtol=1e-5, atol=1e-3)
-  os.environ["SMX_SCORE_ROWS"] = "250"   # 5 draws of the 50 cells per pass: 5 + 5 + 2
+  _hip.set_tuning("score_rows", 250)   # 5 draws of the 50 cells per pass: 5 + 5 + 2
   try:
     ch_m, ch_l = e.marginal_llk(row_ids=rows, n_samples=S)
   finally:
-    del os.environ["SMX_SCORE_ROWS"]
+    _hip.clear_tuning("score_rows")
   assert np.allclose(ch_m, got_m, rtol=1e-5, atol=1e-3) and np.allclose(ch_l, got_l, rtol=1e-5, atol=1e-3)
   e.close()
 
@@ -669,12 +671,13 @@ def test_score_llk_matches_oracle(Engine, name):
   loop = e.score_llk([x[rows], None], row_ids=rows, n_samples=S)
   e.set_flag("stacked_scoring", True)
   assert np.allclose(loop, ref, rtol=RTOL, atol=1e-3) and np.allclose(loop, got, rtol=1e-5, atol=1e-3)
-  for var, val in (("SMX_SCORE_HEAD_WIDE", "1"), ("SMX_SCORE_ROWS", "100")):
-    os.environ[var] = val
+  from sisua_amd import _hip
+  for var, val in (("score_head_wide", 1), ("score_rows", 100)):
+    _hip.set_tuning(var, val)
     try:
       alt = e.score_llk([x[rows], None], row_ids=rows, n_samples=S)
     finally:
-      del os.environ[var]
+      _hip.clear_tuning(var)
     assert np.allclose(alt, got, rtol=1e-5, atol=1e-3), var
   e.close()
 

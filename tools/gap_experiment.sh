@@ -15,7 +15,7 @@ run() {   # tag, extra bench flags (environment set by the caller)
   rm -rf $O/trace_$tag
 }
 run default
-SMX_BF16X3=0 run no_bf16x3
+SMX_TUNING=bf16x3=0 run no_bf16x3
 run graph --graph
-SMX_NO_ADAM_EARLY=1 run no_adam_early
+SMX_TUNING=no_adam_early run no_adam_early
 cat $O/summary.txt

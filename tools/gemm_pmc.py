@@ -1,6 +1,6 @@
 """One wide product (M=128, N=60000, K=128; the C5-width output head) launched repeatedly: target of PMC passes."""
 import os, sys
-os.environ.setdefault("SMX_KGEMM_REPS", "50")
+os.environ.setdefault("SMX_TUNING", "kgemm_reps=50")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sisua_amd import engine

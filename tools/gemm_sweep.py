@@ -1,6 +1,6 @@
-"""Tile / split-K sweep of the dense products of one C2 step (diagnostic; SMX_KGEMM_REPS prints timings)."""
+"""Tile / split-K sweep of the dense products of one C2 step (diagnostic; knob kgemm_reps prints timings)."""
 import os, sys
-os.environ.setdefault("SMX_KGEMM_REPS", "200")
+os.environ.setdefault("SMX_TUNING", "kgemm_reps=200")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sisua_amd import engine
