@@ -213,6 +213,7 @@ struct smx_model {
   int32_t* rows2[2] = {nullptr, nullptr}; int32_t* order = nullptr; size_t order_cap = 0;
   // pinned staging for the row ids of a train_steps call: hipMemcpyAsync from the caller's pageable array cost ~80 us per call
   int32_t* order_pin = nullptr; size_t order_pin_cap = 0; hipEvent_t ev_order = nullptr; bool order_pin_busy = false;
+  int32_t* pred_ids = nullptr; int pred_ids_batch = 0;   // smx_predict super-batches: noise ids (row % batch)
   float* pred_target = nullptr; size_t pred_target_floats = 0;   // smx_predict_stat(log_prob): a batch of target rows [Bmax][Gp]
   float* metrics_pin = nullptr;   // pinned landing area of read_metrics: 8 ELBO scalars + one gradient norm per tensor
   float* mhist = nullptr; size_t mhist_cap = 0; int32_t mhist_steps = 0;   // ELBO scalars of every step of the last train_steps call

@@ -455,6 +455,7 @@ int smx_model_destroy(smx_model* m) {
   if (m->ev_order) hipEventDestroy(m->ev_order);
   if (m->pred_stage) hipFree(m->pred_stage);
   if (m->pred_target) hipFree(m->pred_target);
+  if (m->pred_ids) hipFree(m->pred_ids);
   if (m->score_buf) hipFree(m->score_buf);
   if (m->score_wimg) hipFree(m->score_wimg);
   if (m->score_aux) hipFree(m->score_aux);

@@ -332,7 +332,23 @@ static int predict_core(smx_model* m, const float* host_x, const float* host_lib
     SMX_HIP(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, m->st));
     return SMX_OK;
   };
-  const bool stack = S > 1 && stacked_scoring_ok(m) && !m->scvi;
+  // the stacked form: with several draws, and for a statistic request at any draw count (smx_predict itself keeps the draw-by-draw
+  // kernels at one draw: bit-identical with smx_forward batch by batch)
+  const bool stack = (S > 1 || sr != nullptr) && stacked_scoring_ok(m) && !m->scvi;
+  // SUPER-BATCHES: in evaluation mode nothing couples the rows of a minibatch (moving statistics, no dropout) but the noise ids -- a
+  // cell's id is its index within ITS minibatch -- so the stacked form takes k minibatches per pass (k batch <= max_batch) and hands the
+  // draw kernel the ids (row % batch): same numbers, 1 / k of the launches (at Posterior's batch 8 a pass is ~12 launches per 8 cells)
+  size_t step = (size_t)batch;
+  if (stack && (size_t)m->Bmax >= 2 * (size_t)batch) {
+    step = (size_t)batch * ((size_t)m->Bmax / (size_t)batch);
+    if (m->pred_ids_batch != batch) {
+      if (!m->pred_ids) SMX_HIP(hipMalloc((void**)&m->pred_ids, (size_t)m->Bmax * sizeof(int32_t)));
+      std::vector<int32_t> ids((size_t)m->Bmax);
+      for (int i = 0; i < m->Bmax; ++i) ids[(size_t)i] = i % batch;
+      SMX_HIP(hipMemcpy(m->pred_ids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      m->pred_ids_batch = batch;
+    }
+  }
   SMX_REQUIRE(!m->scvi || host_library, "scvi needs host_library with host_x");
   bool any_y = false;
   for (int j = 0; j < m->n_heads; ++j) any_y = any_y || s_y[j] != nullptr;
@@ -350,8 +366,8 @@ static int predict_core(smx_model* m, const float* host_x, const float* host_lib
       SMX_CHECK(launch_row_stats(m->st, in_x, 0, (long)Gp, (long)Cn, m->G, in_lgx1, nullptr));
       if (host_library) SMX_HIP(hipMemcpyAsync(in_lib, host_library + c0 * 2, Cn * 2 * sizeof(float), hipMemcpyHostToDevice, m->st));
     }
-    for (size_t b0 = 0; b0 < Cn; b0 += (size_t)batch) {
-      const int B = (int)std::min<size_t>((size_t)batch, Cn - b0);
+    for (size_t b0 = 0; b0 < Cn; b0 += step) {
+      const int B = (int)std::min<size_t>(step, Cn - b0);
       const size_t g0 = c0 + b0;
       Pass ps;   // (what setup_pass leaves for a host batch, on the chunk's resident copy)
       ps.B = B; ps.training = 0; ps.sample = 0; ps.global_batch = B;
@@ -399,7 +415,7 @@ static int predict_core(smx_model* m, const float* host_x, const float* host_lib
           const long rows = (long)Sn * B;
           ScoreDrawArgs d;
           d.lat = m->latbuf; d.ld = 2 * Dp; d.B = B; d.D = m->D; d.Dp = Dp; d.S = Sn; d.s0 = (int)s0;
-          d.nk = make_key(m, ST_EPS_Z, 0, false); d.rows = ps.rows; d.cell_base = ps.cell_base; d.z = zst; d.lw = lwst;
+          d.nk = make_key(m, ST_EPS_Z, 0, false); d.rows = step > (size_t)batch ? m->pred_ids : ps.rows; d.cell_base = ps.cell_base; d.z = zst; d.lw = lwst;
           SMX_CHECK(launch_score_draws(m->st, d));
           const float* hl = nullptr; int hld = 0;
           if (need_dec) SMX_CHECK(stacked_decoder(m, zst, rows, hb, 0, nullptr, &hl, &hld));

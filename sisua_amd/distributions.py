@@ -529,7 +529,7 @@ class LazyCountOutput(Distribution):
   def _engine(self):
     if self._model.step != self._step:
       raise RuntimeError("the model was trained after this lazy prediction was made: call predict() again")
-    return self._model._ensure_engine(self._B)
+    return self._model._ensure_engine(max(self._B, 512 if self._x.shape[0] >= 1024 else 1))
 
   def _stat(self, stat, target=None, out=None):
     squeeze = self._S <= 1 and stat != "mean_over_samples"   # (no draw axis in the caller's view)

@@ -645,7 +645,8 @@ class SingleCellModel:
 
   def _predict_all(self, x, library, sample_shape, batch_size, lazy=False):
     n = int(np.prod(sample_shape)) if np.size(sample_shape) else 0
-    e = self._ensure_engine(min(int(batch_size), x.shape[0]))
+    # (room for super-batches: the library decodes several minibatches per pass when its max_batch allows, same numbers)
+    e = self._ensure_engine(max(min(int(batch_size), x.shape[0]), 512 if x.shape[0] >= 1024 else 1))
     lib = library if self._cfg.model == "scvi" else None
     if lib is not None and lib.shape[1] != 2:
       lib = library_matrix(x)
