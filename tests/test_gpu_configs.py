@@ -236,3 +236,31 @@ def test_misa_heads_at_the_c4_shape(Engine, kind):
   worst = grad_errors(e.get_params(which=1), res["grads"])
   assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
   e.close()
+
+
+@pytest.mark.parametrize("batch", [16, 8])
+def test_c2_shape_at_the_strong_scaling_share_of_eight_ranks(batch):
+  """BASELINE's "batch=128 at 1/2/4/8 GPUs" under strong scaling leaves 16 cells per GPU at N = 8 (bench.py `scaling_modes.strong_syncbn`):
+  one step of the C2 shape at that minibatch (and at 8) against the oracle -- tiles of 32 rows with most rows masked."""
+  from sisua_amd import build
+  build.build(verbose=False)
+  from sisua_amd.engine import Engine
+  from oracle import sisua_oracle as so
+  from tests.util import grad_errors, make_pair, perturbed_params, synth_counts
+  kw = dict(model="vae", n_genes=1998, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=32)
+  spec, cfg = make_pair(**kw)
+  x = synth_counts(200, 1998, sparsity=0.93, seed=4)
+  params = perturbed_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = Engine(cfg, max_batch=batch, init=False)
+  e.set_params(params)
+  e.upload(x, cell_id_base=500)
+  rows = np.random.default_rng(2).choice(200, size=batch, replace=False).astype(np.int32)
+  ref = so.train_step(spec, params, bn, opt, x[rows], so.PhiloxNoise(spec.seed, 0, rows + 500))
+  m = e.train_step(rows)
+  assert m["nan_flag"] == 0
+  for key in ("loss", "nllk_x", "kl"):
+    assert np.isclose(m[key], ref["metrics"][key], rtol=1e-4, atol=1e-5), (key, m[key], ref["metrics"][key])
+  worst = grad_errors(e.get_params(which=1), ref["grads"])
+  assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+  e.close()
