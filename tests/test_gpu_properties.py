@@ -186,15 +186,21 @@ def test_total_count_logits_over_wide_ranges(eng, B, G, lk, seed):
 
 @settings(max_examples=_n(15), deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(G=st.integers(5, 120), H=st.integers(2, 48), D=st.integers(1, 12), B=st.integers(4, 70), P1=st.integers(1, 150), P2=st.integers(2, 90),
-       kinds=st.sampled_from([("nb",), ("onehot",), ("nb", "onehot"), ("onehot", "nb"), ("mixnb2",), ("mixnb3", "nb"), ("onehot", "mixnb4")]),
-       pct=st.floats(0.0, 1.0), seed=st.integers(0, 10**6))
-def test_semi_supervised_step_on_arbitrary_label_widths(eng, G, H, D, B, P1, P2, kinds, pct, seed):
-  """SISUA label heads: label widths beyond one wave (P > 64), any mix of NB / one-hot heads, any labelled
-  fraction (all cells unlabelled and all labelled included).  Batches of 2-3 cells are left out: BatchNorm over two
+       kinds=st.sampled_from([("nb",), ("onehot",), ("nb", "onehot"), ("onehot", "nb"), ("mixnb2",), ("mixnb3", "nb"), ("onehot", "mixnb4"),
+                              ("nbd",), ("zinb", "nbd"), ("zinbd", "onehot")]),
+       n_observed=st.integers(0, 2), pct=st.floats(0.0, 1.0), seed=st.integers(0, 10**6))
+def test_semi_supervised_step_on_arbitrary_label_widths(eng, G, H, D, B, P1, P2, kinds, n_observed, pct, seed):
+  """Heads on the decoder output: widths beyond one wave (P > 64), any mix of count / one-hot / mixture heads, any labelled
+  fraction (all cells unlabelled and all labelled included); the first n_observed of them further OUTPUT variables (outputs[1:]:
+  weight 1, every cell, metric nllk_o), the rest label variables.  Batches of 2-3 cells are left out: BatchNorm over two
   nearly equal values divides fp32 noise by sqrt(eps) (1.5e-4 on a gradient seen once in 600 random examples)."""
   dims = (P1, P2)[: len(kinds)]
-  labels = tuple((int(p), k) for p, k in zip(dims, kinds))
-  spec, cfg = make_pair(model="sisua", n_genes=G, likelihood="zinb", enc_units=(H,), dec_units=(H,), latent_dim=D, labels=labels, seed=seed)
+  heads = tuple((int(p), k) for p, k in zip(dims, kinds))
+  n_observed = min(n_observed, len(heads))
+  extra, labels = heads[:n_observed], heads[n_observed:]
+  spec, cfg = make_pair(model="sisua" if labels else "vae", n_genes=G, likelihood="zinb", enc_units=(H,), dec_units=(H,), latent_dim=D,
+                        extra_outputs=extra, labels=labels, seed=seed)
+  labels = heads   # (the target arrays below: one per head, outputs first)
   rng = np.random.default_rng(seed)
   n = B + 3
   x = (rng.poisson(3.0, size=(n, G)) * (rng.uniform(size=(n, G)) < 0.4)).astype(np.float32)
@@ -212,7 +218,7 @@ def test_semi_supervised_step_on_arbitrary_label_widths(eng, G, H, D, B, P1, P2,
   rows = rng.permutation(n)[:B].astype(np.int32)
   res = _oracle_step_off_kinks(e, spec, params, bnst, opt, x[rows], so.PhiloxNoise(spec.seed, 0, rows), y=[y[rows] for y in ys], mask=mask[rows])
   m = e.train_step(rows)
-  for key in ("loss", "nllk_x", "nllk_y", "kl"):
+  for key in ("loss", "nllk_x", "nllk_y", "nllk_o", "kl"):
     assert np.isclose(m[key], res["metrics"][key], rtol=1e-4, atol=1e-4), (key, m[key], res["metrics"][key])
   worst = grad_errors(e.get_params(which=1), res["grads"], floor_frac=1e-2)
   assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
