@@ -93,7 +93,7 @@ typedef struct {
   int32_t label_observed[SMX_MAX_LABELS];
   /* scvi.py:55-56,66-86,136-160 `dispersion` / `inflation` of the gene output: 0 = 'full' (a Dense head per cell and gene), 1 = 'share'
    * (no head: ONE trainable vector [n_genes] shared by every cell -- tensor out1/b resp. out2/b without out1/W resp. out2/W; theta = exp of
-   * it, gate logits = it).  SMX_MODEL_SCVI only. */
+   * it, gate logits = it), 2 = 'single' (ONE trainable scalar for every cell and gene: out1/b resp. out2/b of one element).  SMX_MODEL_SCVI only. */
   int32_t scvi_dispersion, scvi_inflation;
   int32_t n_components;                /* SMX_MODEL_SCALE: components of the mixture prior (scale.py:27), 1..32 */
   int32_t disc_units, disc_layers;     /* SMX_MODEL_FVAE: hidden width / hidden layers of the discriminator (odin: 1000, 5) */

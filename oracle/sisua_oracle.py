@@ -139,7 +139,8 @@ class Spec:
   # scvi.py:55-56,66-86,136-160: `dispersion` / `inflation` of the gene output.  'full': a Dense head on the decoder output (per cell and
   # gene); otherwise the reference builds NO head and the distribution layer keeps its own variable -- frozen here as [3P-recall]
   # 'share' (alias 'gene'): ONE trainable vector [G] shared by every cell (tensor out1/b resp. out2/b WITHOUT a kernel out{c}/W), zero
-  # initial value, fed like the head's output: theta = exp(r_g) (scvi.py:139-140), gate logits g_g.
+  # initial value, fed like the head's output: theta = exp(r_g) (scvi.py:139-140), gate logits g_g; 'single': ONE trainable scalar for every
+  # cell and gene (tensor out1/b resp. out2/b of shape (1,)).
   dispersion: str = "full"
   inflation: str = "full"
   batchnorm: bool = True
@@ -174,7 +175,7 @@ class Spec:
       assert self.likelihood in ("nbd", "zinbd")  # scvi.py:50-52
     for _, llk in self.labels + self.extra_outputs:
       assert llk in LABEL_LIKELIHOODS, llk
-    assert self.dispersion in ("full", "share") and self.inflation in ("full", "share"), (self.dispersion, self.inflation)
+    assert self.dispersion in ("full", "share", "single") and self.inflation in ("full", "share", "single"), (self.dispersion, self.inflation)
     if self.model != "scvi":
       assert self.dispersion == "full" and self.inflation == "full", "dispersion / inflation are options of scvi (scvi.py:55-56)"
     if self.extra_outputs:
@@ -215,6 +216,10 @@ class Spec:
   def head_plane(self, c: int) -> bool:
     """scvi: whether plane c of the gene output (0 MeanScale, 1 Dispersion, 2 DropoutLogits) is a Dense head (scvi.py:66-86)."""
     return c == 0 or (c == 1 and self.dispersion == "full") or (c == 2 and self.inflation == "full")
+
+  def plane_single(self, c: int) -> bool:
+    """scvi: plane c is ONE scalar for every cell and gene ('single')."""
+    return (c == 1 and self.dispersion == "single") or (c == 2 and self.inflation == "single")
 
 
 def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
@@ -258,7 +263,7 @@ def manifest(spec: Spec) -> List[Tuple[str, Tuple[int, ...]]]:
     for c in range(spec.k):
       if spec.head_plane(c):
         out.append((f"out{c}/W", (hd, G)))
-      out.append((f"out{c}/b", (G,)))   # (no head: the shared per-gene vector itself)
+      out.append((f"out{c}/b", (1,) if spec.plane_single(c) else (G,)))   # (no head: the shared per-gene vector / the one scalar itself)
   else:
     out.append(("out/W", (hd, spec.k * G)))
     out.append(("out/b", (spec.k * G,)))
@@ -913,7 +918,7 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
     dl = dlhat * ((l > 0.0) & (l < spec.clip_library))
     draws = [draw0, dtheta * theta] + ([dplanes[2] * c_x] if k == 3 else [])
     for c in range(k):
-      grads[f"out{c}/b"] = draws[c].sum(0)
+      grads[f"out{c}/b"] = draws[c].sum(keepdims=True).reshape(1) if spec.plane_single(c) else draws[c].sum(0)
       if spec.head_plane(c):
         grads[f"out{c}/W"] = d.T @ draws[c]
         dd += draws[c] @ params[f"out{c}/W"].T

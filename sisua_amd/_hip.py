@@ -20,7 +20,7 @@ SMX_MAX_LABELS = 4
 MODEL_KINDS = {"vae": 0, "dca": 1, "scvi": 2, "sisua": 3, "scale": 4, "fvae": 5, "scale_tril": 6, "scale_post": 7}
 LIKELIHOODS = {"nb": 0, "zinb": 1, "nbd": 2, "zinbd": 3, "mse": 4}
 LABEL_LIKELIHOODS = {"nb": 0, "onehot": 1, "mixnb": 2, "mixgauss": 3, "mixtril": 4, "mixzinb": 5, "nbd": 6, "zinb": 7, "zinbd": 8}
-SCVI_PLANE_OPTIONS = {"full": 0, "share": 1}
+SCVI_PLANE_OPTIONS = {"full": 0, "share": 1, "single": 2}
 ACTIVATIONS = {"relu": 0, "linear": 1}
 
 

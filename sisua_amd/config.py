@@ -104,7 +104,7 @@ class ModelConfig:
   # outputs[1:] of the reference's constructors (tests/test_singlecell_models.py:129-141; scvi.py:168-169): further fully observed
   # output variables -- heads on the decoder output with weight 1 and no label mask.  Heads are ordered extra outputs, then labels.
   extra_outputs: Tuple[Tuple[int, str], ...] = ()
-  # scvi.py:55-56,66-86: 'full' = a Dense head; 'share' = one trainable per-gene vector (out1/b resp. out2/b without a kernel)
+  # scvi.py:55-56,66-86: 'full' = a Dense head; 'share' = one trainable per-gene vector (out1/b resp. out2/b without a kernel); 'single' = one scalar
   dispersion: str = "full"
   inflation: str = "full"
   batchnorm: bool = True
@@ -179,11 +179,15 @@ class ModelConfig:
 
   def head_plane(self, c: int) -> bool:
     """scvi: whether plane c of the gene output (0 MeanScale, 1 Dispersion, 2 DropoutLogits) is a Dense head (scvi.py:66-86)."""
-    if self.dispersion not in ("full", "share") or self.inflation not in ("full", "share"):
-      raise ValueError(f"dispersion / inflation must be 'full' or 'share', given: {self.dispersion} / {self.inflation}")
+    if self.dispersion not in ("full", "share", "single") or self.inflation not in ("full", "share", "single"):
+      raise ValueError(f"dispersion / inflation must be 'full', 'share' or 'single', given: {self.dispersion} / {self.inflation}")
     if self.model != "scvi" and (self.dispersion != "full" or self.inflation != "full"):
       raise ValueError("dispersion / inflation are options of scvi (scvi.py:55-56)")
     return c == 0 or (c == 1 and self.dispersion == "full") or (c == 2 and self.inflation == "full")
+
+  def plane_single(self, c: int) -> bool:
+    """scvi: plane c is ONE trainable scalar for every cell and gene ('single': tensor out{c}/b of shape (1,))."""
+    return (c == 1 and self.dispersion == "single") or (c == 2 and self.inflation == "single")
 
   def to_dict(self):
     return dataclasses.asdict(self)
@@ -227,7 +231,7 @@ def manifest(cfg: ModelConfig) -> List[Tuple[str, Tuple[int, ...]]]:
     out += [("discout/W", (n_in, cfg.disc_outputs)), ("discout/b", (cfg.disc_outputs,))]
   if cfg.model == "scvi":
     for c in range(cfg.k):
-      out += ([(f"out{c}/W", (hd, G))] if cfg.head_plane(c) else []) + [(f"out{c}/b", (G,))]
+      out += ([(f"out{c}/W", (hd, G))] if cfg.head_plane(c) else []) + [(f"out{c}/b", (1,) if cfg.plane_single(c) else (G,))]
   else:
     out += [("out/W", (hd, cfg.k * G)), ("out/b", (cfg.k * G,))]
   for j, (P, llk) in enumerate(cfg.head_labels):

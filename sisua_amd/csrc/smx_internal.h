@@ -373,8 +373,8 @@ bool scvi_head_train_supported(const ScviTrainArgs& a);
 int launch_scvi_head_train(hipStream_t st, const ScviTrainArgs& a);
 // a plane of scvi's gene output without a Dense head (dispersion / inflation = 'share', scvi.py:66-86): its per-gene vector copied into
 // every row of the raw plane / the column sum of the plane's d raw (row order)
-int launch_plane_fill(hipStream_t st, float* dst, long ld, const float* v, int B, int Np);
-int launch_plane_colsum(hipStream_t st, const float* src, long ld, float* dst, int B, int Np);
+int launch_plane_fill(hipStream_t st, float* dst, long ld, const float* v, int B, int Np, int single = 0);   // single: v is ONE scalar
+int launch_plane_colsum(hipStream_t st, const float* src, long ld, float* dst, int B, int Np, int single_G = 0);   // single_G > 0: the sum over the G live genes too -> dst[0]
 
 struct LabelArgs {
   int kind = 0;                  // smx_label_likelihood

@@ -237,6 +237,7 @@ struct smx_model {
   float* llk_y = nullptr;
   float* llk_o = nullptr;   // [B] sum of the observed extra outputs' log-likelihoods (cfg.label_observed)
   int n_observed = 0;       // heads [0, n_observed) are observed output variables, the rest label variables
+  bool out_single[3] = {false, false, false};   // scvi: plane c is ONE trainable scalar ('single')
   bool out_has_W[3] = {true, true, true};   // scvi: plane c of the gene output is a Dense head (false: a shared per-gene vector, cfg.scvi_dispersion / scvi_inflation)
   float* slab = nullptr; size_t slab_cap = 0; int max_feat_p = 0;
   float* bigk_part = nullptr; size_t bigk_floats = 0;   // [SMX_BIGK_MAX_SLICES][Bmax][max_feat_p]: per-slice slabs of smx_bigk.hip (wide panels only)

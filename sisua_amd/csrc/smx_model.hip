@@ -208,7 +208,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   SMX_REQUIRE(n_observed == 0 || (cfg->model != SMX_MODEL_FVAE && cfg->model != SMX_MODEL_SCALE_POST), "extra outputs are not built for FVAE / the mixture-density posterior");
   SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->model == SMX_MODEL_FVAE || cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL || cfg->n_labels == n_observed,
               "label heads need model = SISUA, SCALE (SCALAR) or FVAE (SemiFVAE)");
-  SMX_REQUIRE(cfg->scvi_dispersion >= 0 && cfg->scvi_dispersion <= 1 && cfg->scvi_inflation >= 0 && cfg->scvi_inflation <= 1, "scvi_dispersion / scvi_inflation: 0 ('full') or 1 ('share')");
+  SMX_REQUIRE(cfg->scvi_dispersion >= 0 && cfg->scvi_dispersion <= 2 && cfg->scvi_inflation >= 0 && cfg->scvi_inflation <= 2, "scvi_dispersion / scvi_inflation: 0 ('full'), 1 ('share') or 2 ('single')");
   SMX_REQUIRE(cfg->model == SMX_MODEL_SCVI || (cfg->scvi_dispersion == 0 && cfg->scvi_inflation == 0), "dispersion / inflation are options of scvi");
   if (cfg->model == SMX_MODEL_SCVI) {
     SMX_REQUIRE(cfg->likelihood == SMX_LLK_NBD || cfg->likelihood == SMX_LLK_ZINBD, "scvi supports nbd / zinbd only");
@@ -227,6 +227,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   m->lat_planes = m->mixpost ? 1 + 2 * cfg->n_components : (m->stochastic ? 2 : 1);
   m->fvae = cfg->model == SMX_MODEL_FVAE; m->n_heads = m->fvae ? 0 : cfg->n_labels; m->n_observed = n_observed;
   m->out_has_W[1] = cfg->scvi_dispersion == 0; m->out_has_W[2] = cfg->scvi_inflation == 0;
+  m->out_single[1] = cfg->scvi_dispersion == 2; m->out_single[2] = cfg->scvi_inflation == 2;
   m->Bmax = cfg->max_batch;
   int rc = SMX_OK;
   auto fail = [&](int code) { smx_model_destroy(m); return code; };
@@ -259,7 +260,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   if (m->scvi) {
     for (int ch = 0; ch < m->k; ++ch) {   // (scvi.py:66-86: no Dense head for a 'share'd plane -- its per-gene vector is out{ch}/b alone)
       if (m->out_has_W[ch]) m->t_outW[ch] = add_tensor(m, "out" + std::to_string(ch) + "/W", hd, m->G, 1, false);
-      m->t_outb[ch] = add_tensor(m, "out" + std::to_string(ch) + "/b", 1, m->G, 1, true);
+      m->t_outb[ch] = add_tensor(m, "out" + std::to_string(ch) + "/b", 1, m->out_single[ch] ? 1 : m->G, 1, true);   // ('single': one scalar)
     }
   } else {
     m->t_outW[0] = add_tensor(m, "out/W", hd, m->k * m->G, m->k, false);

@@ -127,7 +127,7 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
     if (m->scvi) {
       for (int ch = 0; ch < m->k; ++ch) {
         if (!m->out_has_W[ch]) {   // (dispersion / inflation = 'share': the per-gene vector in every row)
-          SMX_CHECK(launch_plane_fill(m->st, raw + (size_t)ch * m->Gp, (long)raw_ld, P_(m, m->t_outb[ch]), (int)rows, m->Gp));
+          SMX_CHECK(launch_plane_fill(m->st, raw + (size_t)ch * m->Gp, (long)raw_ld, P_(m, m->t_outb[ch]), (int)rows, m->Gp, m->out_single[ch] ? 1 : 0));
           continue;
         }
         GemmArgs g;

@@ -204,10 +204,10 @@ int launch_scvi_head_train(hipStream_t st, const ScviTrainArgs& a) {
 // The plane's raw value is one trainable per-gene vector v[g] shared by every cell: forward = the vector copied into every row of the
 // raw plane (what the head's product + bias leaves for a 'full' plane, so every consumer downstream is unchanged), backward = the
 // column sum of the plane's d raw in row order (deterministic); no kernel, no d d contribution.
-__global__ __launch_bounds__(256) void plane_fill_kernel(float* dst, long ld, const float* v, int B, int Np) {
+__global__ __launch_bounds__(256) void plane_fill_kernel(float* dst, long ld, const float* v, int B, int Np, int single) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= Np) return;
-  const float x = v[g];
+  const float x = v[single ? 0 : g];   // ('single': one scalar for every gene)
   for (int b = blockIdx.y; b < B; b += gridDim.y) dst[(long)b * ld + g] = x;
 }
 __global__ __launch_bounds__(256) void plane_colsum_kernel(const float* src, long ld, float* dst, int B, int Np) {
@@ -217,13 +217,28 @@ __global__ __launch_bounds__(256) void plane_colsum_kernel(const float* src, lon
   for (int b = 0; b < B; ++b) s += src[(long)b * ld + g];
   dst[g] = s;
 }
-int launch_plane_fill(hipStream_t st, float* dst, long ld, const float* v, int B, int Np) {
-  hipLaunchKernelGGL(plane_fill_kernel, dim3((Np + 255) / 256, std::min(B, 16)), dim3(256), 0, st, dst, ld, v, B, Np);
+// 'single': the one scalar's gradient = the sum of the whole plane's d raw over the G live genes -- one workgroup, fixed order
+// (thread t: genes t, t + 256, ... each summed over the rows; then the threads' sums in LDS order): deterministic
+__global__ __launch_bounds__(256) void plane_sum_kernel(const float* src, long ld, float* dst, int B, int G) {
+  __shared__ float sh[256];
+  float s = 0.f;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    float c = 0.f;
+    for (int b = 0; b < B; ++b) c += src[(long)b * ld + g];
+    s += c;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { float t = 0.f; for (int i = 0; i < 256; ++i) t += sh[i]; dst[0] = t; }
+}
+int launch_plane_fill(hipStream_t st, float* dst, long ld, const float* v, int B, int Np, int single) {
+  hipLaunchKernelGGL(plane_fill_kernel, dim3((Np + 255) / 256, std::min(B, 16)), dim3(256), 0, st, dst, ld, v, B, Np, single);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
-int launch_plane_colsum(hipStream_t st, const float* src, long ld, float* dst, int B, int Np) {
-  hipLaunchKernelGGL(plane_colsum_kernel, dim3((Np + 255) / 256), dim3(256), 0, st, src, ld, dst, B, Np);
+int launch_plane_colsum(hipStream_t st, const float* src, long ld, float* dst, int B, int Np, int single_G) {
+  if (single_G > 0) hipLaunchKernelGGL(plane_sum_kernel, dim3(1), dim3(256), 0, st, src, ld, dst, B, single_G);
+  else hipLaunchKernelGGL(plane_colsum_kernel, dim3((Np + 255) / 256), dim3(256), 0, st, src, ld, dst, B, Np);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }

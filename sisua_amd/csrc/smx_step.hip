@@ -568,7 +568,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     int n_hg = 0;
     for (int ch = 0; ch < m->k; ++ch) {
       if (!m->out_has_W[ch]) {   // dispersion / inflation = 'share' (scvi.py:66-86): the per-gene vector in every row of the raw plane
-        SMX_CHECK(launch_plane_fill(m->st, m->raw + (long)ch * m->Gp, ldp, P_(m, m->t_outb[ch]), ps.B, m->Gp));
+        SMX_CHECK(launch_plane_fill(m->st, m->raw + (long)ch * m->Gp, ldp, P_(m, m->t_outb[ch]), ps.B, m->Gp, m->out_single[ch] ? 1 : 0));
         continue;
       }
       const TensorInfo& tw = m->tensors[m->t_outW[ch]];
@@ -1028,7 +1028,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
     std::vector<int> is_dx;
     for (int ch = 0; ch < n_heads && !hbwd; ++ch) {
       if (m->scvi && !m->out_has_W[ch]) {   // no Dense head: the per-gene vector's gradient is the column sum of the plane's d raw
-        SMX_CHECK(launch_plane_colsum(m->st, dparams + (long)ch * m->Gp, ldp, G_(m, m->t_outb[ch]), ps.B, m->Gp));
+        SMX_CHECK(launch_plane_colsum(m->st, dparams + (long)ch * m->Gp, ldp, G_(m, m->t_outb[ch]), ps.B, m->Gp, m->out_single[ch] ? m->G : 0));
         continue;
       }
       const TensorInfo& tw = m->tensors[m->t_outW[ch]];

@@ -966,13 +966,13 @@ class SCVI(SingleCellModel):
       "scVI only support transcriptomic distribution: 'zinbd' or 'nbd', " + "but given: %s" % str(outs)
     # scvi.py:55-56,66-86: 'full' = a Dense head per plane; otherwise NO head and the distribution layer keeps its own variable --
     # built as 'share' (alias 'gene', scVI's name): one trainable per-gene vector shared by every cell ([3P-recall] odin's
-    # NegativeBinomialDispLayer(dispersion='share')); 'single' (one scalar for every gene) is not built
+    # NegativeBinomialDispLayer(dispersion='share')); 'single': one trainable scalar for every cell and gene
     opts = {}
     for key in ("dispersion", "inflation"):
       v = str(outs[0].kwargs.get(key, "full")).lower()
       v = "share" if v in ("share", "gene") else v
-      if v not in ("full", "share"):
-        raise ValueError(f"scVI {key}='{v}' is not built (supported: 'full', 'share' / 'gene')")
+      if v not in ("full", "share", "single"):
+        raise ValueError(f"scVI {key}='{v}' is not built (supported: 'full', 'share' / 'gene', 'single')")
       opts[key] = v
     self._dispersion, self._inflation = opts["dispersion"], opts["inflation"] if outs[0].posterior == "zinbd" else "full"
     self.dispersion, self.inflation = self._dispersion, self._inflation

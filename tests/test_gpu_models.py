@@ -709,9 +709,15 @@ def test_scvi_extra_outputs_and_gene_dispersion(api, tmp_path):
   assert np.array_equal(pX2.mean(), pX.mean()) and np.array_equal(pY2.mean(), pY.mean())
   sc = m.posterior_llk(X[:16], sample_shape=4)
   assert all(np.isfinite(v) for v in sc.values())
-  for bad in ("single", "nonsense"):
-    with pytest.raises(ValueError):
-      api.SCVI(api.RVmeta(n_genes, "zinbd", kwargs=dict(dispersion=bad)), **kw)
+  with pytest.raises(ValueError):
+    api.SCVI(api.RVmeta(n_genes, "zinbd", kwargs=dict(dispersion="nonsense")), **kw)
+  # 'single': ONE trainable scalar for every cell and gene
+  ms = api.SCVI(api.RVmeta(n_genes, "zinbd", name="rna", kwargs=dict(dispersion="single", inflation="single")), **kw)
+  ms.fit(sco, epochs=6, batch_size=64, learning_rate=2e-3, verbose=False)
+  ps = ms._engine.get_params()
+  assert ps["out1/b"].shape == (1,) and ps["out2/b"].shape == (1,) and abs(float(ps["out1/b"][0])) > 1e-3 and "out1/W" not in ps
+  pXs, _ = ms.predict(X[:40], verbose=False)
+  assert np.allclose(pXs.distribution.count_distribution.disp, np.exp(ps["out1/b"][0]), rtol=1e-5) and np.allclose(pXs.distribution.logits, ps["out2/b"][0], rtol=1e-5, atol=1e-7)
   full = api.SCVI(api.RVmeta(n_genes, "nbd", kwargs=dict(dispersion="gene")), **kw)   # nbd: no gate plane, inflation is moot
   assert (full.dispersion, full.inflation) == ("share", "full")
 

@@ -115,6 +115,8 @@ CASES = {
                                   dispersion="share"),
     "scvi_share_both": dict(model="scvi", n_genes=130, likelihood="zinbd", enc_units=(40,), dec_units=(40,), latent_dim=5, encl_units=(16,),
                             dispersion="share", inflation="share"),
+    "scvi_single": dict(model="scvi", n_genes=130, likelihood="zinbd", enc_units=(40,), dec_units=(40,), latent_dim=5, encl_units=(16,),
+                        dispersion="single", inflation="single"),
     "scvi_nbd_share_dispersion": dict(model="scvi", n_genes=96, likelihood="nbd", enc_units=(32,), dec_units=(32,), latent_dim=4, encl_units=(8,),
                                       dispersion="share", batchnorm=False),
 }
@@ -436,7 +438,7 @@ def test_staged_row_ids_equal_passed_row_ids(Engine):
     assert np.array_equal(got[0][1][k], got[1][1][k]), k
 
 
-@pytest.mark.parametrize("case", ["sisua", "scale_post", "sisua_extra_output", "scvi_two_outputs", "scvi_share_both"])
+@pytest.mark.parametrize("case", ["sisua", "scale_post", "sisua_extra_output", "scvi_two_outputs", "scvi_share_both", "scvi_single"])
 def test_eval_and_forward_match_oracle(Engine, case):
   kw = CASES[case]   # ('scale_post': z_mean / z_scale are the mixture posterior's moments; a different draw may pick another component)
   spec, cfg, x, ys, lib, mask = _problem(kw)

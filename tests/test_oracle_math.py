@@ -308,6 +308,7 @@ EXTRA_CASES = {
     "scvi_share_dispersion": ("scvi", "zinbd", dict(dispersion="share")),
     "scvi_share_both": ("scvi", "zinbd", dict(dispersion="share", inflation="share")),
     "scvi_nbd_share_dispersion": ("scvi", "nbd", dict(dispersion="share")),
+    "scvi_single_dispersion_share_inflation": ("scvi", "zinbd", dict(dispersion="single", inflation="share")),
 }
 
 

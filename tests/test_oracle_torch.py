@@ -241,6 +241,8 @@ CASES = {
                                  dispersion="share"),
     "scvi_gene_both": dict(model="scvi", n_genes=36, likelihood="zinbd", enc_units=(12,), dec_units=(12,), latent_dim=3, encl_units=(6,),
                            dispersion="share", inflation="share"),
+    "scvi_single": dict(model="scvi", n_genes=40, likelihood="zinbd", enc_units=(12,), dec_units=(12,), latent_dim=3, encl_units=(6,),
+                        dispersion="single", inflation="single"),
     "scvi_nbd_gene_dispersion": dict(model="scvi", n_genes=36, likelihood="nbd", enc_units=(12,), dec_units=(12,), latent_dim=3, encl_units=(6,),
                                      dispersion="share", batchnorm=False),
 }
