@@ -1004,15 +1004,16 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
 # Importance-weighted marginal log-likelihood (Posterior.cal_marginal_llk ->
 # scm.marginal_log_prob(**Xs, sample_shape=100), sisua/analysis/posterior.py:941-976)
 # --------------------------------------------------------------------------
-def marginal_log_prob(spec: Spec, params, bn_state, x, cell_ids, n_samples: int, library=None):
+def marginal_log_prob(spec: Spec, params, bn_state, x, cell_ids, n_samples: int, library=None, y=()):
   """log p(x) ~= logsumexp_s[ log p(x|z_s) + log p(z_s) - log q(z_s|x) ] - log S with z_s ~ q(z|x) in eval
   mode (moving BN statistics, no dropout); draw s uses Philox (step 0, sample s).  SCVI adds the library
-  latent's prior/posterior terms.  Returns (mllk[B], mean_s log p(x|z_s)[B])."""
+  latent's prior/posterior terms.  Returns (mllk[B], mean_s log p(x|z_s)[B]).  With further OUTPUT variables (spec.extra_outputs, their
+  targets first in `y`) the estimate is of the JOINT log p(x, y_1, ...): every draw's weight carries all outputs' log-likelihoods."""
   logw, llks = [], []
   for s_ in range(n_samples):
     noise = PhiloxNoise(spec.seed, 0, cell_ids, sample=s_)
-    r = forward_backward(spec, params, bn_state, x, noise, library=library, training=False, backward=False)
-    lw = r["llk_x"].copy()
+    r = forward_backward(spec, params, bn_state, x, noise, y=y, library=library, training=False, backward=False)
+    lw = r["llk_x"] + r["llk_o"]
     if spec.model == "scale":   # log p_GMM(z) - log q(z|x) is minus the Monte-Carlo KL term of this draw
       lw -= r["kl"]
     elif spec.stochastic:

@@ -678,8 +678,7 @@ class SingleCellModel:
     Returns (mllk[B], {output name: mean_s log p(x|z_s) [B]})."""
     arrs = _flatten(inputs)
     if len(self._outputs) > 1:
-      raise NotImplementedError("marginal_log_prob of a model with several output variables (the joint log p(x, y)) is not built; "
-                                "predict() returns every output's distribution")
+      return self._joint_marginal_log_prob(arrs, library, sample_shape, batch_size)
     x = np.ascontiguousarray(arrs[0], dtype=np.float32)
     S = int(np.prod(sample_shape)) if np.size(sample_shape) else 1
     if self._cfg.model == "scvi" and library is None:
@@ -693,6 +692,44 @@ class SingleCellModel:
       mllk.append(a)
       llk.append(b)
     return np.concatenate(mllk), {self._outputs[0].name or "transcriptomic": np.concatenate(llk)}
+
+  def _joint_marginal_log_prob(self, arrs, library, sample_shape, batch_size):
+    r"""Several OUTPUT variables: the importance-weighted estimate of the joint log p(x, y_1, ...), every draw's weight
+    log w_s = sum_o log p(x_o | z_s) + log p(z_s) - log q(z_s | x).  The gene output's log-likelihood of every draw comes from the device
+    (smx_predict_stat: [S, N], the planes never leave it), the heads' raw outputs and the latent draws from the same passes (smx_predict,
+    same Philox draws); the few scalars per draw are combined here.  Returns (mllk [N], {output name: mean_s log p(x_o | z_s) [N]})."""
+    cfg = self._cfg
+    n_out = len(self._outputs)
+    if cfg.model == "scale":
+      raise NotImplementedError("the joint marginal_log_prob of several outputs is built for a standard-normal latent prior (not SCALE's mixture)")
+    if len(arrs) < n_out:
+      raise ValueError(f"marginal_log_prob of this model needs the {n_out} output variables' arrays as inputs=[x, y, ...]")
+    x = np.ascontiguousarray(arrs[0], dtype=np.float32)
+    ys = [np.ascontiguousarray(a, dtype=np.float32) for a in arrs[1:n_out]]
+    S = int(np.prod(sample_shape)) if np.size(sample_shape) else 1
+    if cfg.model == "scvi" and library is None:
+      library = library_matrix(x)
+    e = self._ensure_engine(min(int(batch_size), x.shape[0]))
+    B = min(e.max_batch, int(batch_size))
+    o = e.predict(x, library=library if cfg.model == "scvi" else None, n_samples=S, batch=B, want_x_params=False)
+    llk = {self._outputs[0].name or "transcriptomic": e.predict_stat(x, "log_prob", library=library if cfg.model == "scvi" else None,
+                                                                    n_samples=S, batch=B).astype(np.float64)}
+    heads = self._output_dists(None, o["y_params"], stacked=True, heads_only=True)
+    for j, yj in enumerate(ys):   # (the observed heads come first)
+      llk[self._outputs[1 + j].name or f"output{1 + j}"] = np.asarray(heads[j].log_prob(yj), np.float64)
+    logw = sum(llk.values())
+    if cfg.stochastic:
+      z, mu, sg = o["z_sample"].astype(np.float64), o["z_mean"].astype(np.float64), o["z_scale"].astype(np.float64)
+      eps = (z - mu) / sg
+      logw = logw + (-0.5 * z ** 2 + 0.5 * eps ** 2 + np.log(sg)).sum(-1)
+    if cfg.model == "scvi":
+      l, ml, sl = o["l_sample"].astype(np.float64), o["l_mean"].astype(np.float64), o["l_scale"].astype(np.float64)
+      lib = np.asarray(library, np.float64)
+      mp, sp = lib[:, 0], np.sqrt(lib[:, 1])
+      logw = logw + (-0.5 * ((l - mp) / sp) ** 2 - np.log(sp) + 0.5 * ((l - ml) / sl) ** 2 + np.log(sl))
+    mx = logw.max(0)
+    mllk = mx + np.log(np.exp(logw - mx).sum(0)) - np.log(S)
+    return mllk.astype(np.float32), {k: v.mean(0).astype(np.float32) for k, v in llk.items()}
 
   def posterior_llk(self, corrupted, original=None, library=None, sample_shape=10, batch_size=128):
     r"""The four scores of `Posterior.cal_llk` (analysis/posterior.py:919-938) on the GPU

@@ -666,7 +666,22 @@ def test_variational_model_with_two_outputs(api):
   # a dataset that lacks the second output's targets is refused, and so is the (unbuilt) joint marginal likelihood
   with pytest.raises(ValueError):
     api.VAE(outputs=[api.RVmeta(n_genes, "zinb"), api.RVmeta(n_prots, "nbd")], **kw).fit(sco.create_dataset(batch_size=64), metadata=sco, epochs=1)
-  with pytest.raises(NotImplementedError):
+  # the JOINT marginal likelihood log p(x, y) against the oracle's (same Philox draws: cell ids = index within the minibatch)
+  from oracle import sisua_oracle as so
+  Y = sco.numpy("proteomic")[:128]
+  mllk, llk = vae.marginal_log_prob(inputs=[X[:40], Y[:40]], sample_shape=6, batch_size=64)
+  assert set(llk) == {"transcriptomic", "proteomic"} and mllk.shape == (40,)
+  spec = so.Spec(**vae._make_config().to_dict())
+  e = vae._engine
+  params = {k: v.astype(np.float64) for k, v in e.get_params().items()}
+  names = [p for p, _ in so.bn_manifest(spec)]
+  bn = {}
+  for i, st in e.get_bn().items():
+    bn[f"{names[i]}/moving_mean"], bn[f"{names[i]}/moving_var"] = st["moving_mean"].astype(np.float64), st["moving_var"].astype(np.float64)
+  ref_m, ref_l = so.marginal_log_prob(spec, params, bn, X[:40], np.arange(40), 6, y=[Y[:40]])
+  assert np.allclose(mllk, ref_m, rtol=1e-4, atol=1e-2), np.abs(mllk - ref_m).max()
+  assert np.allclose(llk["transcriptomic"], ref_l, rtol=1e-4, atol=1e-2)
+  with pytest.raises(ValueError):   # the second output's targets are part of the joint
     vae.marginal_log_prob(inputs=X[:8], sample_shape=4)
   with pytest.raises(ValueError):   # a posterior that has no head form is refused at construction, never ignored
     api.VAE(outputs=[api.RVmeta(n_genes, "zinb"), api.RVmeta(n_prots, "poisson")], **kw)
