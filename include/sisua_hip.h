@@ -429,6 +429,11 @@ int smx_k_adam(int32_t n_tensors, const int32_t* sizes, float* params, const flo
  * (transA = 1, transB = 0; 32 x 32 tiles / the gene-tile-owner panel form, N <= 128) -- test entries for those kernels. */
 int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M, int32_t N, int32_t K,
                int32_t split_k, int32_t tile_cfg, float* C);
+/* The kernels' noise function beside hiprand's own generator (BASELINE north_star: "sampling from a hiprand state per wavefront"): for
+ * every counter quadruple (c0, c1, c2, c3) = (column block, cell id, step, stream | sample << 8) `ours` receives the four words the
+ * kernels compute, `hiprand_words` the four words of ONE hiprand4() on a hiprandStatePhilox4_32_10_t set up by
+ * hiprand_init(seed, subsequence = c2 | c3 << 32, offset = 4 * (c0 | c1 << 32)); c1 < 2^30 (the offset is 64 bits). */
+int smx_k_hiprand(uint64_t seed, int32_t n, const uint32_t* counters, uint32_t* ours, uint32_t* hiprand_words);
 /* Philox words / dropout multipliers / normals exactly as the kernels draw them. */
 int smx_k_noise(uint64_t seed, int32_t stream, int32_t step, int32_t sample, const int64_t* cell_ids, int32_t B,
                 int32_t width, float dropout_p, float* dropout_mult, float* normal);

@@ -1,7 +1,40 @@
 // smx_kapi.hip -- kernel-level entry points (parity tests of single kernels): smx_k_count_llk, smx_k_adam, smx_k_gemm, smx_k_noise.
 #include "smx_model.h"
+#include <hiprand/hiprand_kernel.h>
+
+namespace smx {
+// The library's noise function against hiprand's own Philox generator (row N-1, "sampling from a hiprand state per wavefront"): thread i
+// builds a hiprandStatePhilox4_32_10_t with hiprand_init(seed, subsequence = (c2, c3) = (step, stream | sample << 8), offset =
+// 4 * (c0, c1) = 4 * (column block, cell id)) and draws ONE hiprand4 -- and evaluates philox4x32_10(c0, c1, c2, c3, seed) as the kernels do.
+__global__ void hiprand_probe_kernel(uint64_t seed, int n, const uint32_t* c, uint32_t* ours, uint32_t* theirs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t c0 = c[4 * i], c1 = c[4 * i + 1], c2 = c[4 * i + 2], c3 = c[4 * i + 3];
+  const U4 w = philox4x32_10(c0, c1, c2, c3, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32));
+  ours[4 * i] = w.x; ours[4 * i + 1] = w.y; ours[4 * i + 2] = w.z; ours[4 * i + 3] = w.w;
+  hiprandStatePhilox4_32_10_t st;
+  hiprand_init(seed, (unsigned long long)c2 | ((unsigned long long)c3 << 32), 4ull * ((unsigned long long)c0 | ((unsigned long long)c1 << 32)), &st);
+  const uint4 r = hiprand4(&st);
+  theirs[4 * i] = r.x; theirs[4 * i + 1] = r.y; theirs[4 * i + 2] = r.z; theirs[4 * i + 3] = r.w;
+}
+}  // namespace smx
 
 extern "C" {
+
+int smx_k_hiprand(uint64_t seed, int32_t n, const uint32_t* counters, uint32_t* ours, uint32_t* hiprand_words) {
+  SMX_REQUIRE(n > 0 && counters && ours && hiprand_words, "bad arguments");
+  uint32_t *dC = nullptr, *dO = nullptr, *dH = nullptr;
+  int rc;
+  if ((rc = dmalloc(&dC, (size_t)4 * n)) || (rc = dmalloc(&dO, (size_t)4 * n)) || (rc = dmalloc(&dH, (size_t)4 * n))) return rc;
+  SMX_HIP(hipMemcpy(dC, counters, (size_t)16 * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(smx::hiprand_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, seed, (int)n, dC, dO, dH);
+  SMX_HIP(hipGetLastError());
+  SMX_HIP(hipDeviceSynchronize());
+  SMX_HIP(hipMemcpy(ours, dO, (size_t)16 * n, hipMemcpyDeviceToHost));
+  SMX_HIP(hipMemcpy(hiprand_words, dH, (size_t)16 * n, hipMemcpyDeviceToHost));
+  hipFree(dC); hipFree(dO); hipFree(dH);
+  return SMX_OK;
+}
 
 // ---- kernel-level entry points ------------------------------------------------
 int smx_k_count_llk(int likelihood, int direct, const float* x, const float* planes, int32_t B, int32_t G, float* llk,

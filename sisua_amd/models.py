@@ -283,7 +283,15 @@ class SingleCellModel:
       # the current OMIC alone, _single_cell_base.py:557-558, which such a model cannot train on); label variables stay unlabelled
       # (labels_percent = 0, the reference's default) unless the caller prepares the dataset with its own labels_percent
       if isinstance(x, SingleCellOMIC) and need > 0 and len(x.omics) > need:
-        return x.create_dataset(x.omics[:1 + need], batch_size=batch_size)
+        # a variable that names one of the container's OMICs takes that OMIC, the others the remaining OMICs in order
+        rvs = self._outputs[1:] + self._labels
+        taken = [x.omics[0]] + [rv.name for rv in rvs if rv.name in x.omics[1:]]
+        rest = [o for o in x.omics[1:] if o not in taken]
+        omics = [x.omics[0]] + [rv.name if rv.name in x.omics[1:] else rest.pop(0) for rv in rvs]
+        for rv, om in zip(rvs, omics[1:]):
+          if x.get_dim(om) != rv.event_shape:
+            raise ValueError(f"variable '{rv.name}' has {rv.event_shape} dimensions but OMIC '{om}' has {x.get_dim(om)}")
+        return x.create_dataset(omics, batch_size=batch_size)
       return _to_data(x, batch_size=batch_size)
 
     train = to_data(train)

@@ -148,3 +148,28 @@ def test_count_llk_wide_access_forms(eng, B, G, lk):
   ref_e, ref_g = so.count_llk(x.astype(np.float64), list(planes.astype(np.float64)), lk)
   assert np.allclose(llk, ref_e.sum(1), rtol=1e-5, atol=1e-3)
   assert np.allclose(grads, np.stack(ref_g), rtol=1e-4, atol=1e-5)
+
+
+def test_the_noise_function_is_hiprands_philox_generator():
+  """BASELINE north_star: "fused Gaussian reparameterisation sampling from a hiprand state per wavefront".  The kernels evaluate
+  Philox4x32-10 as a pure function of (column block, cell id, step, stream | sample) under the model's seed; this IS a
+  `hiprandStatePhilox4_32_10_t` set up on the fly -- `hiprand_init(seed, subsequence = (step, stream), offset = 4 (column block, cell id))`
+  followed by one `hiprand4()` -- bit for bit, for random counters and the corners, without a state ever being stored or loaded."""
+  import ctypes as C
+  from sisua_amd import _hip, build
+  build.build(verbose=False)
+  lib = _hip.require_gpu(0)
+  rng = np.random.default_rng(7)
+  n = 4096
+  c = rng.integers(0, 2**32, size=(n, 4), dtype=np.uint64).astype(np.uint32)
+  c[:, 1] &= (1 << 30) - 1                                   # cell ids below 2^30 (the offset 4 * (c0 | c1 << 32) is 64 bits)
+  c[:8] = [[0, 0, 0, 0], [1, 0, 0, 0], [0xFFFFFFFF, 0, 0, 0], [0xFFFFFFFF, (1 << 30) - 1, 0, 0], [0, 0, 0xFFFFFFFF, 0xFFFFFFFF],
+           [3, 1000, 7, 64], [0, 1, 2, 64 | (5 << 8)], [499, 3380, 299, 48]]
+  for seed in (8, 0, 2**63 + 12345):
+    ours, theirs = np.empty((n, 4), np.uint32), np.empty((n, 4), np.uint32)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+    _hip.check(lib.smx_k_hiprand(C.c_uint64(seed), n, p(np.ascontiguousarray(c)), p(ours), p(theirs)))
+    assert np.array_equal(ours, theirs), (seed, np.nonzero((ours != theirs).any(1))[0][:5])
+    # ... and it is the function the oracle implements (Random123 known-answer vectors: tests/test_oracle_rng.py)
+    ref = so.philox4x32_10(c[:64, 0], c[:64, 1], c[:64, 2], c[:64, 3], np.uint32(seed & 0xFFFFFFFF), np.uint32(seed >> 32))
+    assert np.array_equal(np.stack(ref, 1).astype(np.uint32), ours[:64])
