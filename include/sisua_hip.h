@@ -429,6 +429,13 @@ int smx_k_adam(int32_t n_tensors, const int32_t* sizes, float* params, const flo
  * (transA = 1, transB = 0; 32 x 32 tiles / the gene-tile-owner panel form, N <= 128) -- test entries for those kernels. */
 int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M, int32_t N, int32_t K,
                int32_t split_k, int32_t tile_cfg, float* C);
+/* The whole output head of a training step at a wide gene panel in ONE launch (smx_headfused.hip; rows a-9, a-10 / a-11 and the head's
+ * part of a-16): P = d W + bias (never stored) -> count log-likelihood of x and dP = grad_scale * d llk / d P (never stored) -> dW = d^T dP,
+ * db = colsum(dP), dd = dP W^T.  Host arrays: x [B][G] counts (u16 != 0: through the uint16 store), d [B][128], W [128][k][G], bias [k][G]
+ * (k = 2 NB / NBD, 3 ZINB / ZINBD); B <= 128, G >= 4096 after padding to 32.  Out: llk [B], dW [128][k][G],
+ * db [k][G], dd [B][128], sumsq = sum of squares of dW (may be NULL); us (may be NULL): average device time of `reps` launches. */
+int smx_k_head_fused(int likelihood, int u16, const float* x, const float* d, const float* W, const float* bias, int32_t B, int32_t G,
+                     float grad_scale, int32_t reps, float* llk, float* dW, float* db, float* dd, float* sumsq, float* us);
 /* The kernels' noise function beside hiprand's own generator (BASELINE north_star: "sampling from a hiprand state per wavefront"): for
  * every counter quadruple (c0, c1, c2, c3) = (column block, cell id, step, stream | sample << 8) `ours` receives the four words the
  * kernels compute, `hiprand_words` the four words of ONE hiprand4() on a hiprandStatePhilox4_32_10_t set up by

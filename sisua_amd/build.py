@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsisua_hip.so")
-SOURCES = ["smx_gemm.hip", "smx_dgemm.hip", "smx_kernels.hip", "smx_data.hip", "smx_headloss.hip", "smx_headbwd.hip", "smx_bigk.hip", "smx_factor.hip", "smx_scvi.hip", "smx_score.hip", "smx_model.hip", "smx_dataset.hip", "smx_comm.hip", "smx_p2p.hip", "smx_step.hip", "smx_predict.hip", "smx_scoring.hip", "smx_kapi.hip"]
+SOURCES = ["smx_gemm.hip", "smx_dgemm.hip", "smx_kernels.hip", "smx_data.hip", "smx_headloss.hip", "smx_headbwd.hip", "smx_headfused.hip", "smx_bigk.hip", "smx_factor.hip", "smx_scvi.hip", "smx_score.hip", "smx_model.hip", "smx_dataset.hip", "smx_comm.hip", "smx_p2p.hip", "smx_step.hip", "smx_predict.hip", "smx_scoring.hip", "smx_kapi.hip"]
 HEADERS = ["smx_device.h", "smx_internal.h", "smx_loss.h", "smx_model.h", "smx_panel.h", "smx_dgemm.h", "smx_adam.h", os.path.join("..", "..", "include", "sisua_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 

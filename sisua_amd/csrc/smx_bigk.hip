@@ -219,6 +219,14 @@ __global__ __launch_bounds__(256) void bigk_reduce_kernel(const float* __restric
   }
 }
 
+// the ordered sum by itself (smx_headfused.hip: the per-workgroup d d slabs of the fused output head)
+int launch_bigk_reduce(hipStream_t st, const float* part, long slab_stride, int n_slices, long n4, float* out) {
+  if (!part || !out || n_slices <= 0 || n4 <= 0 || (slab_stride % 4)) { set_error("bigk_reduce: bad arguments"); return SMX_ERR_INVALID; }
+  hipLaunchKernelGGL(bigk_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, part, slab_stride, n_slices, n4, out);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
 // slices: whole 32-deep stages per slice, about one slice per CU (at most `max_slices`)
 int bigk_slices(long K, int max_slices, int* k_chunk) {
   static const int cap = (int)tuning("bigk_slices", 0);   // (sweeps)

@@ -540,6 +540,31 @@ int bigk_slices(long K, int max_slices, int* k_chunk);
 bool bigk_supported(const BigKArgs& a);
 int launch_bigk(hipStream_t st, const BigKArgs& a);
 
+int launch_bigk_reduce(hipStream_t st, const float* part, long slab_stride, int n_slices, long n4, float* out);
+
+// ---- the whole output head of a training step at a wide panel in one launch (smx_headfused.hip) ----
+#define SMX_HEAD_FUSED_TAB_BYTES (2 * 8 * 12 * 64 * 16)
+#define SMX_HEAD_FUSED_MIN_GENES 4096   // padded genes from which the fused form replaces fused head + bigk (d d) + panel (dW)
+struct HeadFusedArgs {
+  const float* D = nullptr; int ldd = 0;            // decoder output [B][ldd], 128 columns
+  const float* W = nullptr; long ldw = 0;           // [128][k * Gp]
+  const float* bias = nullptr;                      // [k * Gp]
+  const void* X = nullptr; long ldx = 0; const int32_t* rows = nullptr; int x_u16 = 0;   // counts (gathered by row id)
+  float* dW = nullptr; float* db = nullptr;         // gradients, laid out as W / bias
+  float* part = nullptr; long slab_stride = 0;      // [workgroups][B][128]: per-workgroup slabs of d d
+  float* llk_part = nullptr;                        // [B][Gp / 32]
+  float* sq_part = nullptr;                         // 8 sum-of-squares slots of dW per workgroup, or nullptr
+  void* dtab = nullptr;                             // SMX_HEAD_FUSED_TAB_BYTES of scratch: the split views of d (written and read by the launch)
+  int B = 0, G = 0, Gp = 0, likelihood = 0;
+  float grad_scale = 1.f;
+  int n_gt = 0;                                     // set by the launcher
+  long long* dbg = nullptr;                         // development builds (SMX_HF_STAMPS): 128 cycle stamps
+};
+bool head_fused_supported(int B, int Hp, int Gp, int k);
+int head_fused_grid(int Gp);
+// the launch + the ordered sum of its slabs into dd_out [B][128]; *n_sq: sum-of-squares slots written
+int launch_head_fused(hipStream_t st, const HeadFusedArgs& a, float* dd_out, int* n_sq);
+
 // ---- grouped weight gradients with K = the minibatch (smx_headbwd.hip) ---------------------------
 struct WgradProblem {
   const float* A; int lda; int a_mode; int log1p;   // a_mode 0: A [K][M]; 1: rows of the float32 count store gathered by `rows`; 2: uint16 store

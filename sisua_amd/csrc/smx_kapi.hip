@@ -1,4 +1,4 @@
-// smx_kapi.hip -- kernel-level entry points (parity tests of single kernels): smx_k_count_llk, smx_k_adam, smx_k_gemm, smx_k_noise.
+// smx_kapi.hip -- kernel-level entry points (parity tests of single kernels): smx_k_count_llk, smx_k_adam, smx_k_gemm, smx_k_head_fused, smx_k_noise.
 #include "smx_model.h"
 #include <hiprand/hiprand_kernel.h>
 
@@ -212,6 +212,92 @@ int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M
       }
   }
   hipFree(dA); hipFree(dB); hipFree(dC);
+  return rc;
+}
+
+// The fused output head of smx_headfused.hip over host arrays (H = 128 decoder columns, B <= 128 cells, G >= 4096 genes): W [128][k][G]
+// (plane-major columns, as the model's head), bias [k][G], x [B][G] (u16 != 0: the counts travel through the uint16 store).  Out: llk [B], dW [128][k][G], db [k][G], dd [B][128], sumsq (of dW; may be NULL); us (may be
+// NULL): average device time of `reps` launches of the fused kernel + its reduce launch (HIP events).
+int smx_k_head_fused(int likelihood, int u16, const float* x, const float* d, const float* W, const float* bias, int32_t B, int32_t G,
+                     float grad_scale, int32_t reps, float* llk, float* dW, float* db, float* dd, float* sumsq, float* us) {
+  SMX_REQUIRE(x && d && W && bias && llk && dW && db && dd && B > 0 && G > 0, "bad arguments");
+  const int k = llk_planes(likelihood);
+  const int Gp = round_up(G, 32), H = 128;
+  SMX_REQUIRE(head_fused_supported(B, H, Gp, k), "head_fused: unsupported shape (B <= 128, G >= 4096 after padding, 2 or 3 planes)");
+  const int grid = head_fused_grid(Gp), n_gt = Gp / 32;
+  float *dX = nullptr, *dD = nullptr, *dWt = nullptr, *dBias = nullptr, *dGW = nullptr, *dGb = nullptr, *dPart = nullptr, *dLl = nullptr, *dSq = nullptr, *dDd = nullptr;
+  uint16_t* dX16 = nullptr; float* dTab = nullptr;
+  int rc;
+  if ((rc = dmalloc(&dTab, (size_t)SMX_HEAD_FUSED_TAB_BYTES / 4)) || (rc = dmalloc(&dX, (size_t)B * Gp)) || (rc = dmalloc(&dD, (size_t)B * H)) || (rc = dmalloc(&dWt, (size_t)H * k * Gp)) || (rc = dmalloc(&dBias, (size_t)k * Gp)) ||
+      (rc = dmalloc(&dGW, (size_t)H * k * Gp)) || (rc = dmalloc(&dGb, (size_t)k * Gp)) || (rc = dmalloc(&dPart, (size_t)grid * B * H)) ||
+      (rc = dmalloc(&dLl, (size_t)B * n_gt)) || (rc = dmalloc(&dSq, (size_t)grid * 8)) || (rc = dmalloc(&dDd, (size_t)B * H)) || (rc = dmalloc(&dX16, (size_t)B * Gp)))
+    return rc;
+  SMX_HIP(hipMemcpy2D(dX, (size_t)Gp * 4, x, (size_t)G * 4, (size_t)G * 4, (size_t)B, hipMemcpyHostToDevice));
+  if (u16) {
+    std::vector<uint16_t> h16((size_t)B * Gp, 0);
+    for (int b = 0; b < B; ++b)
+      for (int g = 0; g < G; ++g) h16[(size_t)b * Gp + g] = (uint16_t)x[(size_t)b * G + g];
+    SMX_HIP(hipMemcpy(dX16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice));
+  }
+  SMX_HIP(hipMemcpy(dD, d, (size_t)B * H * 4, hipMemcpyHostToDevice));
+  for (int c = 0; c < k; ++c) {
+    SMX_HIP(hipMemcpy2D(dWt + (size_t)c * Gp, (size_t)k * Gp * 4, W + (size_t)c * G, (size_t)k * G * 4, (size_t)G * 4, (size_t)H, hipMemcpyHostToDevice));
+    SMX_HIP(hipMemcpy(dBias + (size_t)c * Gp, bias + (size_t)c * G, (size_t)G * 4, hipMemcpyHostToDevice));
+  }
+  HeadFusedArgs a;
+  a.D = dD; a.ldd = H; a.W = dWt; a.ldw = (long)k * Gp; a.bias = dBias;
+  a.X = u16 ? (const void*)dX16 : (const void*)dX; a.ldx = Gp; a.x_u16 = u16 ? 1 : 0;
+  a.dW = dGW; a.db = dGb; a.part = dPart; a.slab_stride = (long)B * H; a.llk_part = dLl; a.sq_part = dSq; a.dtab = dTab;
+  a.B = B; a.G = G; a.Gp = Gp; a.likelihood = likelihood; a.grad_scale = grad_scale;
+  int n_sq = 0;
+  long long* dDbg = nullptr;
+  if (tuning("hf_dbg", 0) > 0) { if ((rc = dmalloc(&dDbg, (size_t)128))) return rc; a.dbg = dDbg; }
+  rc = launch_head_fused(nullptr, a, dDd, &n_sq);
+  if (rc == SMX_OK && reps > 0 && us) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < reps && rc == SMX_OK; ++i) rc = launch_head_fused(nullptr, a, dDd, &n_sq);
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    *us = 1e3f * ms / (float)reps;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+  if (rc == SMX_OK && hipDeviceSynchronize() != hipSuccess) { set_error("k_head_fused: device synchronize failed"); rc = SMX_ERR_HIP; }
+  if (rc == SMX_OK && dDbg) {
+    long long h[128];
+    hipMemcpy(h, dDbg, sizeof(h), hipMemcpyDeviceToHost);
+    for (int b = 0; b < 2; ++b) {
+      fprintf(stderr, "hf stamps block %d:", b ? 100 : 0);
+      for (int i = 1; i < 40 && h[64 * b + i]; ++i) fprintf(stderr, " %lld", h[64 * b + i] - h[64 * b + i - 1]);
+      fprintf(stderr, "\n");
+    }
+
+    hipFree(dDbg);
+  }
+  if (rc == SMX_OK) {
+    std::vector<float> part((size_t)B * n_gt), sq((size_t)n_sq);
+    SMX_HIP(hipMemcpy(part.data(), dLl, part.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) {
+      double s = 0.0;
+      for (int c = 0; c < n_gt; ++c) s += part[(size_t)b * n_gt + c];
+      for (int g = 0; g < G; ++g) { const float v = x[(size_t)b * G + g]; if (v > 0.f) s -= lgamma((double)v + 1.0); }
+      llk[b] = (float)s;
+    }
+    for (int c = 0; c < k; ++c) {
+      SMX_HIP(hipMemcpy2D(dW + (size_t)c * G, (size_t)k * G * 4, dGW + (size_t)c * Gp, (size_t)k * Gp * 4, (size_t)G * 4, (size_t)H, hipMemcpyDeviceToHost));
+      SMX_HIP(hipMemcpy(db + (size_t)c * G, dGb + (size_t)c * Gp, (size_t)G * 4, hipMemcpyDeviceToHost));
+    }
+    SMX_HIP(hipMemcpy(dd, dDd, (size_t)B * H * 4, hipMemcpyDeviceToHost));
+    if (sumsq) {
+      SMX_HIP(hipMemcpy(sq.data(), dSq, sq.size() * 4, hipMemcpyDeviceToHost));
+      double s = 0.0;
+      for (float v : sq) s += v;
+      *sumsq = (float)s;
+    }
+  }
+  hipFree(dX); hipFree(dD); hipFree(dWt); hipFree(dBias); hipFree(dGW); hipFree(dGb); hipFree(dPart); hipFree(dLl); hipFree(dSq); hipFree(dDd); hipFree(dX16); hipFree(dTab);
   return rc;
 }
 

@@ -128,10 +128,11 @@ __device__ inline void lgamma_digamma_diff_vec(const float (&x)[N], const float 
 // two barriers, the waves sharing the drain rounds) measured the same as the per-wave form and was not kept.
 //   q : LDS, 64 N float2 per wave of the workgroup (the wave's stretch starts at wave * 64 * N)
 // ===========================================================================
-template <int N>
-__device__ inline void lgamma_digamma_diff_queue(const float (&x)[N], const float (&r_in)[N], float (&lg)[N], float (&dg)[N], float2* q) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  q += wave * 64 * N;
+// (Q: anything indexed like a float2 array that is THIS wave's own stretch of 64 N entries -- a pointer, or an accessor over LDS that
+// is laid out otherwise: smx_headfused.hip keeps the queue inside the rows of an operand image it owns)
+template <int N, class Q>
+__device__ inline void lgamma_digamma_diff_queue_at(const float (&x)[N], const float (&r_in)[N], float (&lg)[N], float (&dg)[N], Q q) {
+  const int lane = threadIdx.x & 63;
   int pos[N];
   int mine = 0;
 #pragma unroll
@@ -156,12 +157,20 @@ __device__ inline void lgamma_digamma_diff_queue(const float (&x)[N], const floa
   for (int e = 0; e < N; ++e)
     if (x[e] != 0.f) { const float2 v = q[pos[e]]; lg[e] = v.x; dg[e] = v.y; }
 }
+template <int N>
+__device__ inline void lgamma_digamma_diff_queue(const float (&x)[N], const float (&r_in)[N], float (&lg)[N], float (&dg)[N], float2* q) {
+  lgamma_digamma_diff_queue_at<N>(x, r_in, lg, dg, q + (threadIdx.x >> 6) * 64 * N);
+}
+template <int N, class Q>
+__device__ inline void lgamma_digamma_diff_queue(const float (&x)[N], const float (&r_in)[N], float (&lg)[N], float (&dg)[N], Q q) {
+  lgamma_digamma_diff_queue_at<N>(x, r_in, lg, dg, q);
+}
 
 // q != nullptr: lgamma / digamma through the per-wave queue form above
-template <int LK, int DIRECT, int N>
+template <int LK, int DIRECT, int N, class Q = float2*>
 __device__ inline void count_elem_vec(const float (&x)[N], const float (&p0)[N], const float (&p1)[N], const float (&p2)[N],
                                       float (&llk)[N], float (&d0)[N], float (&d1)[N], float (&d2)[N],
-                                      float2* q = nullptr) {
+                                      Q q = nullptr) {
   float ell[N];
   if (LK == SMX_LLK_NB || LK == SMX_LLK_ZINB) {
     float r[N], lg[N], dg[N];

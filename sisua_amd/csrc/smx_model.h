@@ -143,6 +143,7 @@ struct smx_model {
   // as A/B references)
   struct Flags {
     int head_loss = tuning_on("no_head_loss") ? 0 : 1;    // output product + likelihood in one kernel
+    int head_fused = tuning_on("no_head_fused") ? 0 : 1;  // wide panels: ... and both of the head's backward products in the same launch (smx_headfused.hip)
     int front = tuning_on("no_front") ? 0 : 1;            // latent sample + first decoder product inside BatchNorm-forward
     int bwd_front = tuning_on("no_bwd_front") ? 0 : 1;    // d h inside BatchNorm-backward, weight gradients grouped at the end
     int head_bwd = tuning_on("no_head_bwd") ? 0 : 1;      // both backward products of the output head in one wide launch
@@ -240,6 +241,8 @@ struct smx_model {
   bool out_single[3] = {false, false, false};   // scvi: plane c is ONE trainable scalar ('single')
   bool out_has_W[3] = {true, true, true};   // scvi: plane c of the gene output is a Dense head (false: a shared per-gene vector, cfg.scvi_dispersion / scvi_inflation)
   float* slab = nullptr; size_t slab_cap = 0; int max_feat_p = 0;
+  void* hf_tab = nullptr;             // scratch of the fused output head (smx_headfused.hip: the split views of the decoder output)
+  bool head_fused = false; int head_fused_sq = 0;   // this step's output head ran as ONE launch (loss + dW + db + d d): backward_pass skips its products
   float* bigk_part = nullptr; size_t bigk_floats = 0;   // [SMX_BIGK_MAX_SLICES][Bmax][max_feat_p]: per-slice slabs of smx_bigk.hip (wide panels only)
   // optimiser
   OptChunk* chunks = nullptr; int n_chunks = 0; int chunks_floats = 4096; float* partial = nullptr; float* tensor_norm = nullptr;

@@ -351,6 +351,9 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   if (m->Gp >= 4096) {
     m->bigk_floats = (size_t)SMX_BIGK_MAX_SLICES * B * m->max_feat_p;
     if ((rc = dmalloc(&m->bigk_part, m->bigk_floats))) return fail(rc);
+    float* tab = nullptr;
+    if ((rc = dmalloc(&tab, (size_t)SMX_HEAD_FUSED_TAB_BYTES / 4))) return fail(rc);
+    m->hf_tab = tab;
   }
   if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
       (rc = dmalloc(&m->z, B * m->Dp)) || (rc = dmalloc(&m->noise_eps, B * m->Dp)) || (rc = dmalloc(&m->sig, B * m->Dp)) || (rc = dmalloc(&m->eps, B * m->Dp)) ||
@@ -430,6 +433,7 @@ int smx_model_destroy(smx_model* m) {
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
   for (auto& ev : m->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
   if (m->bigk_part) hipFree(m->bigk_part);
+  if (m->hf_tab) hipFree(m->hf_tab);
   p2p_release(m);
   if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
   m->comm = nullptr;
@@ -575,12 +579,12 @@ int smx_set_flag(smx_model* m, const char* name, int value) {
   SMX_REQUIRE(m && name, "null argument");
   SMX_HIP(hipStreamSynchronize(m->st));
   const std::string n(name);
-  int* f = n == "head_loss" ? &m->flags.head_loss : n == "front" ? &m->flags.front : n == "bwd_front" ? &m->flags.bwd_front
+  int* f = n == "head_loss" ? &m->flags.head_loss : n == "head_fused" ? &m->flags.head_fused : n == "front" ? &m->flags.front : n == "bwd_front" ? &m->flags.bwd_front
          : n == "head_bwd" ? &m->flags.head_bwd : n == "wgrad" ? &m->flags.wgrad : n == "scvi_fused" ? &m->flags.scvi_fused
          : n == "twin" ? &m->flags.twin : n == "label_ride" ? &m->flags.label_ride : n == "act_epilogue" ? &m->flags.act_epilogue
          : n == "stacked_scoring" ? &m->flags.stacked_scoring : n == "bf16x3" ? &m->flags.bf16x3
          : n == "tie_mixtures" ? &m->flags.tie_mixtures : n == "tie_loc" ? &m->flags.tie_loc : n == "tie_scale" ? &m->flags.tie_scale : nullptr;
-  SMX_REQUIRE(f, "unknown flag (head_loss, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue, stacked_scoring, bf16x3; SCALE: tie_mixtures, tie_loc, tie_scale)");
+  SMX_REQUIRE(f, "unknown flag (head_loss, head_fused, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue, stacked_scoring, bf16x3; SCALE: tie_mixtures, tie_loc, tie_scale)");
   *f = (f == &m->flags.bf16x3 && value < 0) ? -1 : (value ? 1 : 0);   // bf16x3: -1 = by the width of the head (the default)
   drop_graphs(m);   // a captured step bakes the launch sequence in
   return SMX_OK;

@@ -479,7 +479,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   const bool encode_only = (mode == 3);   // encoders + latent heads + latent moments / draw 0, no decoder (the stacked-draw paths)
   const smx_config& c = m->cfg;
   const float inv_gb = 1.f / (float)ps.global_batch;
-  m->head_loss = false;
+  m->head_loss = false; m->head_fused = false;
   m->ahead_front_eps = m->ahead_front_drop = false;
   m->scvi_fused = false; m->encl_twinned = false;
   bool front_ok = false; LatentArgs front_la;
@@ -635,6 +635,25 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     hl.B = ps.B; hl.G = m->G; hl.Gp = m->Gp; hl.Hp = dL.out_p; hl.likelihood = c.likelihood; hl.grad_scale = -inv_gb;
     hl.bf16x3 = m->flags.bf16x3 < 0 ? (use_bf16x3((long)ps.B * m->Gp * m->k) ? 1 : 0) : m->flags.bf16x3;
     n_llk_chunks = head_loss_chunks(m->Gp);
+    // a wide panel: the whole head -- product, likelihood, dW / db and the per-workgroup slabs of d d -- in ONE launch + the ordered
+    // sum of the slabs (smx_headfused.hip); backward_pass then finds its head products done
+    m->head_fused = false;
+    if (m->flags.head_fused && hl.bf16x3 && m->hf_tab && m->bigk_part && m->n_heads == 0 && !m->fvae && dL.out_p == 128 && tw.ld == (long)m->k * m->Gp &&
+        head_fused_supported(ps.B, dL.out_p, m->Gp, m->k) && (size_t)head_fused_grid(m->Gp) * (size_t)ps.B * 128 <= m->bigk_floats &&
+        !(!m->capturing && m->timing_label == "out_head_product")) {
+      HeadFusedArgs hf;
+      hf.D = dL.out_buf; hf.ldd = dL.out_p; hf.W = hl.W; hf.ldw = tw.ld; hf.bias = hl.bias;
+      hf.X = ps.Xsrc; hf.ldx = m->Gp; hf.rows = ps.xrows; hf.x_u16 = ps.x_u16;
+      hf.dW = G_(m, m->t_outW[0]); hf.db = G_(m, m->t_outb[0]);
+      hf.part = m->bigk_part; hf.slab_stride = (long)ps.B * dL.out_p; hf.llk_part = m->llk_part;
+      hf.sq_part = (m->sq_slots && !tuning_on("no_sq_partials")) ? m->sq_slots + m->sq_first[(size_t)m->t_outW[0]] : nullptr;
+      hf.dtab = m->hf_tab;
+      hf.B = ps.B; hf.G = m->G; hf.Gp = m->Gp; hf.likelihood = c.likelihood; hf.grad_scale = -inv_gb;
+      const int reps = (!m->capturing && m->timing_label == "out_head") ? m->timing_reps : 1;   // idempotent
+      Timed t(m, "out_head");
+      for (int r = 0; r < reps; ++r) SMX_CHECK(launch_head_fused(m->st, hf, m->slab, &m->head_fused_sq));
+      m->head_fused = true;
+    } else {
     if (!m->capturing && m->timing_label == "out_head_product") {
       // timing mode: the product alone (P stored, no counts, no likelihood) -- what the fused kernel's time is
       // compared with to attribute the rest to the likelihood (bench.py, roofline)
@@ -646,6 +665,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     const int reps = (!m->capturing && m->timing_label == "out_head") ? m->timing_reps : 1;   // idempotent
     Timed t(m, "out_head");
     for (int r = 0; r < reps; ++r) SMX_CHECK(launch_out_head_loss(m->st, hl));
+    }
   } else {
     // timing mode: the (idempotent) kernel is launched SMX_LOSS_TIMING_REPEAT times inside one event pair so
     // the pair's own ~5 us overhead can be separated from the per-launch time (bench.py)
@@ -1000,10 +1020,15 @@ int backward_pass(smx_model* m, const Pass& ps) {
       }
     }
     Timed t(m, "gemm_out_bwd");
+    const bool fused_done = m->head_fused && m->head_loss && !hb.sep && hb.n_extra == 0;   // (forward_pass ran smx_headfused.hip: dW, db, the sum of squares and d d are there)
+    if (fused_done) {
+      n_slabs = 1;
+      if (hb.sq_count) *hb.sq_count = m->head_fused_sq;
+    }
     // a wide head (the bf16 x 3 regime): d d = dP W^T (K = every gene of every plane) as one workgroup per K slice + a reduce
     // launch (smx_bigk.hip) -- ONE slab for the BatchNorm-backward launch; d W / d b stay with the 32 x 32-tile kernel
     bool dd_bigk = false;
-    if (hb.bf16x3 && !hb.sep && hb.n_extra == 0 && m->bigk_part && dL.out_p <= 128 && !tuning_on("no_bigk")) {
+    if (!fused_done && hb.bf16x3 && !hb.sep && hb.n_extra == 0 && m->bigk_part && dL.out_p <= 128 && !tuning_on("no_bigk")) {
       BigKArgs bk;
       bk.A = dparams; bk.lda = ldp; bk.Bm = P_(m, m->t_outW[0]); bk.ldb = tw.ld; bk.b_kmajor = 0;
       bk.M = ps.B; bk.N = dL.out_p; bk.K = (int)ldp; bk.ldc = dL.out_p; bk.slab_stride = dd_stride;
@@ -1018,7 +1043,8 @@ int backward_pass(smx_model* m, const Pass& ps) {
     hb.skip_dd = dd_bigk ? 1 : 0;
     // ... and then d W / d b with one workgroup per (gene tile, plane) that holds every row of H (smx_panel.h): the panel is
     // transformed and split once, not once per 32 rows of H
-    if (dd_bigk && panel_dw_supported(hb)) SMX_CHECK(launch_panel_dw(m->st, hb));
+    if (fused_done) {}
+    else if (dd_bigk && panel_dw_supported(hb)) SMX_CHECK(launch_panel_dw(m->st, hb));
     else if (!(hb.skip_dw && hb.skip_dd)) SMX_CHECK(launch_out_head_bwd(m->st, hb));
   }
   {

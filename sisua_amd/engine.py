@@ -556,6 +556,22 @@ def k_count_llk(likelihood: str, x, planes, direct: bool = False, want_grads: bo
   return llk, grads
 
 
+def k_head_fused(likelihood: str, x, d, W, bias, grad_scale: float = 1.0, u16: bool = False, reps: int = 0):
+  """The fused output head (smx_headfused.hip) over host arrays: x [B][G], d [B][128], W [128][k][G], bias [k][G] ->
+  dict(llk [B], dW, db, dd [B][128], sumsq, us)."""
+  lib = _hip.require_gpu()
+  x, d, W, bias = _f32(x), _f32(d), _f32(W), _f32(bias)
+  B, G = x.shape
+  k = W.shape[1]
+  assert d.shape == (B, 128) and W.shape == (128, k, G) and bias.shape == (k, G)
+  llk = np.empty(B, np.float32)
+  dW, db, dd = np.empty((128, k, G), np.float32), np.empty((k, G), np.float32), np.empty((B, 128), np.float32)
+  sumsq, us = np.zeros(1, np.float32), np.zeros(1, np.float32)
+  check(lib.smx_k_head_fused(_hip.LIKELIHOODS[likelihood], int(u16), _fp(x), _fp(d), _fp(W), _fp(bias), B, G, float(grad_scale), int(reps),
+                             _fp(llk), _fp(dW), _fp(db), _fp(dd), _fp(sumsq), _fp(us)))
+  return dict(llk=llk, dW=dW, db=db, dd=dd, sumsq=float(sumsq[0]), us=float(us[0]))
+
+
 def k_adam(params, grads, m, v, step: int, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, clipnorm=100.0):
   """The optimiser launch by itself over lists of arrays (updated copies are returned): (params, m, v, norms)."""
   lib = _hip.require_gpu()

@@ -173,3 +173,34 @@ def test_the_noise_function_is_hiprands_philox_generator():
     # ... and it is the function the oracle implements (Random123 known-answer vectors: tests/test_oracle_rng.py)
     ref = so.philox4x32_10(c[:64, 0], c[:64, 1], c[:64, 2], c[:64, 3], np.uint32(seed & 0xFFFFFFFF), np.uint32(seed >> 32))
     assert np.array_equal(np.stack(ref, 1).astype(np.uint32), ours[:64])
+
+
+@pytest.mark.parametrize("lk,B,G,u16", [("zinb", 128, 4128, True), ("zinb", 100, 4100, False), ("nb", 128, 4096, False),
+                                         ("nbd", 37, 4130, True), ("zinbd", 128, 8000, False), ("zinb", 1, 4096, True)])
+def test_head_fused_matches_float64(eng, lk, B, G, u16):
+  """smx_headfused.hip: output product + likelihood + dW / db / d d in one launch against the float64 arithmetic of the oracle
+  (P = d W + b; count_llk; dP = scale * d llk / d P; dW = d^T dP; db = colsum dP; dd = dP W^T) -- ragged minibatches, gene
+  counts that are not multiples of 32, both count stores, every likelihood."""
+  rng = np.random.default_rng(B * 7 + G)
+  k = so.n_params_per_gene(lk)
+  x = (rng.poisson(3.0, size=(B, G)) * (rng.uniform(size=(B, G)) < 0.1)).astype(np.float32)
+  x[0, :7] = [9, 40, 181, 1000, 10738, 12, 8]     # counts beyond the rising-factorial path
+  d = np.maximum(rng.normal(size=(B, 128)), 0).astype(np.float32) * (rng.uniform(size=(B, 128)) < 0.9)
+  W = (rng.normal(size=(128, k, G)) * 0.08).astype(np.float32)
+  bias = (rng.normal(size=(k, G)) * 0.3).astype(np.float32)
+  scale = -1.0 / B
+  got = eng.k_head_fused(lk, x, d, W, bias, grad_scale=scale, u16=u16)
+  d64, W64 = d.astype(np.float64), W.astype(np.float64)
+  P = np.einsum("bh,hkg->kbg", d64, W64) + bias.astype(np.float64)[:, None, :]
+  ref_e, ref_g = so.count_llk(x.astype(np.float64), list(P), lk)
+  dP = scale * np.stack(ref_g)                                  # [k][B][G]
+  dW = np.einsum("bh,kbg->hkg", d64, dP)
+  db = dP.sum(1)
+  dd = np.einsum("kbg,hkg->bh", dP, W64)
+  rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+  assert np.allclose(got["llk"], ref_e.sum(1), rtol=2e-5, atol=2e-2), np.abs(got["llk"] - ref_e.sum(1)).max()
+  assert rel(got["dW"], dW) < 2e-5, rel(got["dW"], dW)
+  assert rel(got["db"], db) < 2e-5, rel(got["db"], db)
+  assert rel(got["dd"], dd) < 2e-5, rel(got["dd"], dd)
+  assert np.abs(got["dW"] - dW).max() <= 1e-4 * np.abs(dW).max()
+  assert abs(got["sumsq"] - (dW ** 2).sum()) <= 1e-4 * (dW ** 2).sum()
