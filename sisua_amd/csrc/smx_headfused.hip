@@ -164,6 +164,16 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
   const __amdgpu_buffer_rsrc_t rbias = hf_rsrc(a.bias, a.ldw * 4), rdb = hf_rsrc(a.db, a.ldw * 4);
   const __amdgpu_buffer_rsrc_t rllk = hf_rsrc(a.llk_part, (long)a.B * a.n_gt * 4), rtab = hf_rsrc(a.dtab, SMX_HEAD_FUSED_TAB_BYTES);
 
+  // ---- loads of a tile: this thread's NWL float4 of W (row-major segments of 128 bytes), the lanes' counts ---------------
+  float4 wreg[NWL];
+  auto load_w = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < NWL; ++u)   // u = UPP plane + pass
+      wreg[u] = hf_load4(rW, wgo, (int)((tile * 32 + (long)(RPT * (u % UPP)) * a.ldw + (long)(u / UPP) * a.Gp) * 4));
+  };
+  int tile = blockIdx.x;
+  load_w(tile);   // (requested before the prologue: the first tile's HBM latency runs under the split of d)
+
   // ---- both views of d per share, split once -----------------------------------------------------------------------------
   // dB[v][ks]: B operand of the forward product, d[cell][k], k = 32 ks + (e < 4 ? 4 g + e : 16 + 4 g + e - 4)
   // dA[v][ks]: A operand of dW, d[k = cell'][h = 16 w + j] over the same k order
@@ -240,13 +250,6 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
 #endif
   HF_STAMP();
 
-  // ---- loads of a tile: this thread's NWL float4 of W (row-major segments of 128 bytes), the lanes' counts ---------------
-  float4 wreg[NWL];
-  auto load_w = [&](int tile) {
-#pragma unroll
-    for (int u = 0; u < NWL; ++u)   // u = UPP plane + pass
-      wreg[u] = hf_load4(rW, wgo, (int)((tile * 32 + (long)(RPT * (u % UPP)) * a.ldw + (long)(u / UPP) * a.Gp) * 4));
-  };
   uint2 xraw16[VW][2]; float4 xraw32[VW][2];
   auto load_x = [&](int tile) {
 #pragma unroll
@@ -278,8 +281,9 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
     return r;
   };
 
-  int tile = blockIdx.x;
-  load_w(tile);
+#ifdef HF_PRIO
+  if (wave >= HF_PRIO) __builtin_amdgcn_s_setprio(1);
+#endif
   load_x(tile);
   for (; tile < a.n_gt; tile += gridDim.x) {
     const int n0 = tile * 32;
@@ -380,8 +384,9 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
       lsum += __shfl_xor(lsum, 32, 64);
       if (g == 0 && cell_ok[v]) hf_store1(lsum, rllk, cell[v] * a.n_gt * 4, tile * 4);
 
-      // ---- dP: bias-gradient partials over the share's 16 cells, the [cell][rho] image -----------------------------------
-      Split8 spl[NP];
+      // ---- dP, plane by plane: bias-gradient partials over the share's 16 cells, the [cell][rho] image, d d^T += W dP^T --------
+      // (A = W[h = 16 hs + j][rho = 32 p + (e < 4 ? 4 g + e : 16 + 4 g + e - 4)]: two 8-byte row reads per term; B = the split plane)
+      Split8 cur = row_read(0), nxt = cur;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
 #pragma unroll
@@ -392,26 +397,22 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
 #undef HF_DPP_ADD
           if (j == 0) dbx[w * 32 * NP + 32 * p + 16 * (e >> 2) + 4 * g + (e & 3)] = t;
         }
-        spl[p] = split3x8(dpv[p]);
-        const Split8& sp = spl[p];
+        const Split8 sp = split3x8(dpv[p]);
         {
           const int wo = 1024 * w;   // (the share's rows: a scalar)
           *reinterpret_cast<hf_bf16x4*>(HF_AT(rb[1], 0, p, 0) + wo) = lo4(sp.t0); *reinterpret_cast<hf_bf16x4*>(HF_AT(rb[1], 1, p, 0) + wo) = hi4(sp.t0);
           *reinterpret_cast<hf_bf16x4*>(HF_AT(rb[1], 0, NP + p, 0) + wo) = lo4(sp.t1); *reinterpret_cast<hf_bf16x4*>(HF_AT(rb[1], 1, NP + p, 0) + wo) = hi4(sp.t1);
           *reinterpret_cast<hf_bf16x4*>(HF_AT(rb[1], 0, 2 * NP + p, 0) + wo) = lo4(sp.t2); *reinterpret_cast<hf_bf16x4*>(HF_AT(rb[1], 1, 2 * NP + p, 0) + wo) = hi4(sp.t2);
         }
-      }
-      HF_STAMP();   // dP image written
-      // d d^T += W dP^T.  A = W[h = 16 hs + j][rho = 32 p + (e < 4 ? 4 g + e : 16 + 4 g + e - 4)]: two 8-byte row reads per term
-      {
-        Split8 cur = row_read(0), nxt = cur;
 #pragma unroll
-        for (int n = 0; n < 8 * NP; ++n) {
+        for (int hs = 0; hs < 8; ++hs) {
+          const int n = 8 * p + hs;
           if (n + 1 < 8 * NP) nxt = row_read(n + 1);
-          accDD[v][n % 8] = mfma16_bf16x3(cur, spl[n / 8], accDD[v][n % 8]);
+          accDD[v][hs] = mfma16_bf16x3(cur, sp, accDD[v][hs]);
           cur = nxt;
           __builtin_amdgcn_sched_barrier(0);
         }
+        HF_STAMP();
       }
     }
     HF_STAMP();   // dd done
