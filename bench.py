@@ -437,7 +437,16 @@ def main():
     alone_bytes = e.loss_bytes_per_cell() * batch_
     ent = []
     one, many = kt["x1"], kt["x8"]
-    if many["fused"]:
+    whole = e.head_fused_bytes(batch_)   # > 0: the step's output head is smx_headfused.hip's ONE launch (a wide panel)
+    if many["fused"] and whole:
+      # rows a-9 + a-10 + the head's part of a-16: product, likelihood, dW / db and d d; neither P nor dP exists in memory
+      ach = whole / (many["fused"] * 1e-6) / 1e9
+      ent.append(dict(name=f"head_fused_kernel@{tag}", kernel_regex=r"head_fused_kernel", rows="a-9 + a-10 + a-16 (head): product, likelihood, dW, db, d d in one launch",
+                      cells=batch_, genes=G, bytes_per_launch=whole, avg_launch_us=round(many["fused"], 3), achieved=round(ach, 1),
+                      frac=round(ach / HBM_PEAK_GBS, 4), launches_timed=many["fused_n"], single_launch_minus_empty_pair_us=round(one["fused"], 3),
+                      bound_note="vector + matrix issue, not HBM: ~133 vector instructions per likelihood element and 18 bf16 MFMAs per 16 x 16 x 32 of each of "
+                                 "the three products (DESIGN.md section 4)"))
+    elif many["fused"]:
       ach = fused_bytes / (many["fused"] * 1e-6) / 1e9
       ent.append(dict(name=f"out_head_loss_kernel@{tag}", kernel_regex=r"out_head_loss_kernel<[0-9]+, ?[0-9]+, ?1,", rows="a-9 + a-10 (fused)", cells=batch_, genes=G,
                       bytes_per_launch=fused_bytes, avg_launch_us=round(many["fused"], 3), achieved=round(ach, 1),

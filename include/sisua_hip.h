@@ -410,6 +410,10 @@ int smx_timing_enable(smx_model* m, const char* kernel);
 int smx_timing_read(smx_model* m, double* total_ms, int64_t* launches);
 /* Algorithmic bytes (fwd+bwd loss kernel = (4+8k)G + 16D + 4 per cell). */
 int64_t smx_loss_bytes_per_cell(const smx_model* m);
+/* Algorithmic bytes of ONE launch of the fused output head (smx_headfused.hip: W_out + bias read, dW_out + db written, decoder output,
+ * counts, d d, likelihood partials) when a training step of `batch` cells takes it -- a wide panel (>= 4096 genes), 128 decoder columns,
+ * batch <= 128, no label heads --, else 0: bench.py's roofline entry at the C5 width. */
+int64_t smx_head_fused_bytes(const smx_model* m, int32_t batch);
 
 /* ---- kernel-level entry points (parity tests of single kernels) ------------ */
 /* Fused count log-likelihood forward+backward over host planes [k][B][G]:

@@ -127,6 +127,7 @@ SIGNATURES = {
     "smx_timing_enable": (C.c_int, [_VP, C.c_char_p]),
     "smx_timing_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "smx_loss_bytes_per_cell": (C.c_int64, [_VP]),
+    "smx_head_fused_bytes": (C.c_int64, [_VP, C.c_int32]),
     "smx_k_count_llk": (C.c_int, [C.c_int, C.c_int, _FP, _FP, C.c_int32, C.c_int32, _FP, _FP]),
     "smx_k_head_fused": (C.c_int, [C.c_int, C.c_int, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.c_float, C.c_int32, _FP, _FP, _FP, _FP, _FP,
                                    _FP]),

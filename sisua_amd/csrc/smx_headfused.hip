@@ -499,11 +499,11 @@ static int launch_hf(hipStream_t st, const HeadFusedArgs& a, int grid) {
   return SMX_OK;
 }
 
-// the fused launch + the ordered sum of its d d slabs into `dd_out` [B][128]
-int launch_head_fused(hipStream_t st, const HeadFusedArgs& a_in, float* dd_out, int* n_sq) {
+// the fused launch; *n_slabs workgroups leave a slab of d d each in a.part, *n_sq sum-of-squares slots are written
+int launch_head_fused(hipStream_t st, const HeadFusedArgs& a_in, int* n_slabs, int* n_sq) {
   HeadFusedArgs a = a_in;
   const int k = llk_planes(a.likelihood);
-  if (!head_fused_supported(a.B, 128, a.Gp, k) || !a.D || !a.W || !a.bias || !a.X || !a.dW || !a.db || !a.part || !a.llk_part || !a.dtab || !dd_out ||
+  if (!head_fused_supported(a.B, 128, a.Gp, k) || !a.D || !a.W || !a.bias || !a.X || !a.dW || !a.db || !a.part || !a.llk_part || !a.dtab ||
       (a.ldd % 4) || (a.ldw % 4) || (a.ldx % 8) || a.slab_stride < (long)a.B * 128 || (a.slab_stride % 4)) {
     set_error("head_fused: bad shapes");
     return SMX_ERR_INVALID;
@@ -511,16 +511,23 @@ int launch_head_fused(hipStream_t st, const HeadFusedArgs& a_in, float* dd_out, 
   a.n_gt = a.Gp / 32;
   const int grid = head_fused_grid(a.Gp);
   if (n_sq) *n_sq = grid * (8 / SMX_HF_VW);
-  int rc;
+  if (n_slabs) *n_slabs = grid;
   switch (a.likelihood) {
-    case SMX_LLK_NB: rc = launch_hf<SMX_LLK_NB>(st, a, grid); break;
-    case SMX_LLK_ZINB: rc = launch_hf<SMX_LLK_ZINB>(st, a, grid); break;
-    case SMX_LLK_NBD: rc = launch_hf<SMX_LLK_NBD>(st, a, grid); break;
-    case SMX_LLK_ZINBD: rc = launch_hf<SMX_LLK_ZINBD>(st, a, grid); break;
+    case SMX_LLK_NB: return launch_hf<SMX_LLK_NB>(st, a, grid);
+    case SMX_LLK_ZINB: return launch_hf<SMX_LLK_ZINB>(st, a, grid);
+    case SMX_LLK_NBD: return launch_hf<SMX_LLK_NBD>(st, a, grid);
+    case SMX_LLK_ZINBD: return launch_hf<SMX_LLK_ZINBD>(st, a, grid);
     default: set_error("head_fused: unknown likelihood"); return SMX_ERR_INVALID;
   }
-  if (rc != SMX_OK) return rc;
-  return launch_bigk_reduce(st, a.part, a.slab_stride, grid, ((long)a.B * 128) >> 2, dd_out);
+}
+// ... and the ordered sum of its d d slabs into dd_out [B][128] (smx_bigk.hip's reduce launch)
+int launch_head_fused_reduce(hipStream_t st, const HeadFusedArgs& a, int n_slabs, float* dd_out) {
+  return launch_bigk_reduce(st, a.part, a.slab_stride, n_slabs, ((long)a.B * 128) >> 2, dd_out);
+}
+// algorithmic bytes of one launch: W_out and bias read, dW_out and db written, the decoder output, the counts (as 4-byte values, like
+// the other entries of bench.py's roofline), d d and the likelihood partials
+long head_fused_bytes(int B, int G, int Gp, int k) {
+  return 2L * (4L * 128 * k * Gp + 4L * k * Gp) + 4L * B * 128 + 4L * B * G + 4L * B * 128 + 4L * B * (Gp / 32);
 }
 
 }  // namespace smx

@@ -562,8 +562,10 @@ struct HeadFusedArgs {
 };
 bool head_fused_supported(int B, int Hp, int Gp, int k);
 int head_fused_grid(int Gp);
-// the launch + the ordered sum of its slabs into dd_out [B][128]; *n_sq: sum-of-squares slots written
-int launch_head_fused(hipStream_t st, const HeadFusedArgs& a, float* dd_out, int* n_sq);
+// the launch (*n_slabs workgroups leave a slab of d d each, *n_sq sum-of-squares slots) and the ordered sum of the slabs into dd_out [B][128]
+int launch_head_fused(hipStream_t st, const HeadFusedArgs& a, int* n_slabs, int* n_sq);
+int launch_head_fused_reduce(hipStream_t st, const HeadFusedArgs& a, int n_slabs, float* dd_out);
+long head_fused_bytes(int B, int G, int Gp, int k);
 
 // ---- grouped weight gradients with K = the minibatch (smx_headbwd.hip) ---------------------------
 struct WgradProblem {

@@ -217,7 +217,7 @@ int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M
 
 // The fused output head of smx_headfused.hip over host arrays (H = 128 decoder columns, B <= 128 cells, G >= 4096 genes): W [128][k][G]
 // (plane-major columns, as the model's head), bias [k][G], x [B][G] (u16 != 0: the counts travel through the uint16 store).  Out: llk [B], dW [128][k][G], db [k][G], dd [B][128], sumsq (of dW; may be NULL); us (may be
-// NULL): average device time of `reps` launches of the fused kernel + its reduce launch (HIP events).
+// NULL): average device time of `reps` launches of the fused kernel (HIP events; without the reduce launch).
 int smx_k_head_fused(int likelihood, int u16, const float* x, const float* d, const float* W, const float* bias, int32_t B, int32_t G,
                      float grad_scale, int32_t reps, float* llk, float* dW, float* db, float* dd, float* sumsq, float* us) {
   SMX_REQUIRE(x && d && W && bias && llk && dW && db && dd && B > 0 && G > 0, "bad arguments");
@@ -252,12 +252,14 @@ int smx_k_head_fused(int likelihood, int u16, const float* x, const float* d, co
   int n_sq = 0;
   long long* dDbg = nullptr;
   if (tuning("hf_dbg", 0) > 0) { if ((rc = dmalloc(&dDbg, (size_t)128))) return rc; a.dbg = dDbg; }
-  rc = launch_head_fused(nullptr, a, dDd, &n_sq);
+  int n_slabs = 0;
+  rc = launch_head_fused(nullptr, a, &n_slabs, &n_sq);
+  if (rc == SMX_OK) rc = launch_head_fused_reduce(nullptr, a, n_slabs, dDd);
   if (rc == SMX_OK && reps > 0 && us) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, nullptr);
-    for (int i = 0; i < reps && rc == SMX_OK; ++i) rc = launch_head_fused(nullptr, a, dDd, &n_sq);
+    for (int i = 0; i < reps && rc == SMX_OK; ++i) rc = launch_head_fused(nullptr, a, &n_slabs, &n_sq);
     hipEventRecord(e1, nullptr);
     hipEventSynchronize(e1);
     float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);

@@ -625,4 +625,13 @@ int64_t smx_loss_bytes_per_cell(const smx_model* m) {
   return (int64_t)(4 + 8 * m->k) * m->G + 16 * (int64_t)m->D + 4;
 }
 
+// (the conditions of forward_pass's choice, smx_step.hip)
+int64_t smx_head_fused_bytes(const smx_model* m, int32_t batch) {
+  if (!m || batch <= 0 || m->dec.empty()) return 0;
+  const bool on = m->flags.head_loss && m->flags.head_fused && !m->scvi && m->k >= 2 && m->hf_tab && m->bigk_part && m->n_heads == 0 && !m->fvae &&
+                  m->dec.back().out_p == 128 && head_fused_supported(batch, 128, m->Gp, m->k) &&
+                  (m->flags.bf16x3 < 0 ? use_bf16x3((long)batch * m->Gp * m->k) : m->flags.bf16x3 != 0);
+  return on ? (int64_t)head_fused_bytes(batch, m->G, m->Gp, m->k) : 0;
+}
+
 }  // extern "C"

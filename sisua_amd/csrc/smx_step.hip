@@ -650,8 +650,12 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
       hf.dtab = m->hf_tab;
       hf.B = ps.B; hf.G = m->G; hf.Gp = m->Gp; hf.likelihood = c.likelihood; hf.grad_scale = -inv_gb;
       const int reps = (!m->capturing && m->timing_label == "out_head") ? m->timing_reps : 1;   // idempotent
-      Timed t(m, "out_head");
-      for (int r = 0; r < reps; ++r) SMX_CHECK(launch_head_fused(m->st, hf, m->slab, &m->head_fused_sq));
+      int n_slabs = 0;
+      {
+        Timed t(m, "out_head");
+        for (int r = 0; r < reps; ++r) SMX_CHECK(launch_head_fused(m->st, hf, &n_slabs, &m->head_fused_sq));
+      }
+      SMX_CHECK(launch_head_fused_reduce(m->st, hf, n_slabs, m->slab));
       m->head_fused = true;
     } else {
     if (!m->capturing && m->timing_label == "out_head_product") {

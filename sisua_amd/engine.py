@@ -539,6 +539,10 @@ class Engine:
   def loss_bytes_per_cell(self) -> int:
     return int(self.lib.smx_loss_bytes_per_cell(self._h))
 
+  def head_fused_bytes(self, batch: int) -> int:
+    """Algorithmic bytes of one launch of the fused output head when a training step of `batch` cells takes it, else 0."""
+    return int(self.lib.smx_head_fused_bytes(self._h, int(batch)))
+
   def synchronize(self):
     check(self.lib.smx_synchronize())
 
