@@ -264,3 +264,46 @@ def test_c2_shape_at_the_strong_scaling_share_of_eight_ranks(batch):
   worst = grad_errors(e.get_params(which=1), ref["grads"])
   assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
   e.close()
+
+
+@pytest.mark.parametrize("lk,B,G,storage", [("zinb", 100, 4100, "u16"), ("nb", 128, 4128, "f32"), ("nbd", 77, 4500, "u16"), ("zinbd", 128, 4096, "f32")])
+def test_wide_panel_head_in_one_launch(Engine, lk, B, G, storage):
+  """smx_headfused.hip inside a training step (a panel of >= 4096 genes, 128 decoder columns, at most 128 cells): the output product, the
+  likelihood, dW / db and d d of the head in ONE launch -- every likelihood, a ragged minibatch, gene counts that are no multiple of 32,
+  both count stores.  Three optimiser steps: every gradient of the first against the oracle (rel-L2 <= 1e-4), the ELBO scalars of all
+  three, the Adam moments after them; the separate launches (flag head_fused = 0) meet the same bars, the two forms agree to 2e-5; the third step of
+  either form runs as a captured graph."""
+  from tests.util import adam_state_errors, make_pair, synth_counts
+  spec, cfg = make_pair(model="vae", n_genes=G, likelihood=lk, enc_units=(128,), dec_units=(128,), latent_dim=16)
+  x = synth_counts(512, G, sparsity=0.92, seed=G, max_count=900)
+  results = {}
+  for fused in (True, False):
+    params = so.init_params(spec)
+    bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+    e = Engine(cfg, max_batch=128, init=False)
+    e.set_params(params)
+    e.set_flag("head_fused", fused)
+    e.upload(x, cell_id_base=3, storage=storage)
+    assert (e.head_fused_bytes(B) > 0) == fused
+    rng = np.random.default_rng(7)
+    losses = []
+    for s in range(3):
+      rows = rng.permutation(x.shape[0])[:B].astype(np.int32)
+      res = so.train_step(spec, params, bn, opt, x[rows], so.PhiloxNoise(spec.seed, s, rows + 3))
+      m = e.train_step(rows, graph=(s == 2))
+      assert m["nan_flag"] == 0
+      losses.append(m["loss"])
+      for key in ("loss", "nllk_x", "kl"):
+        assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (fused, s, key, m[key], res["metrics"][key])
+      if s == 0:
+        worst = grad_errors(e.get_params(which=1), res["grads"])
+        assert max(worst.values()) < RTOL, (fused, sorted(worst.items(), key=lambda kv: -kv[1])[:3])
+        assert np.isclose(m["grad_norm_max"], max(np.linalg.norm(g) for g in res["grads"].values()), rtol=1e-4)
+    em, ev, where = adam_state_errors(e, opt)
+    assert em < 4e-4 and ev < 8e-4, (fused, em, ev, where)
+    results[fused] = (losses, e.get_params(which=0))
+    e.close()
+  for a, b in zip(results[True][0], results[False][0]):
+    assert abs(a / b - 1.0) < 2e-5
+  worst = grad_errors(results[True][1], results[False][1])
+  assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
