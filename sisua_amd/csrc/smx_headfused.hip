@@ -244,7 +244,10 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
   const bool gate = __builtin_amdgcn_readfirstlane(hf_hide(1)) != 0;
 #ifdef SMX_HF_STAMPS   // (development: cycle stamps of the phases of workgroups 0 and 100, read back by smx_k_head_fused under the knob hf_dbg)
   int dbg_n = 0;
-#define HF_STAMP() do { if (a.dbg && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) { a.dbg[(blockIdx.x ? 64 : 0) + dbg_n] = clock64(); ++dbg_n; } } while (0)
+#ifndef SMX_HF_STAMP_WAVE
+#define SMX_HF_STAMP_WAVE 0
+#endif
+#define HF_STAMP() do { if (a.dbg && tid == 64 * SMX_HF_STAMP_WAVE && (blockIdx.x == 0 || blockIdx.x == 100)) { a.dbg[(blockIdx.x ? 64 : 0) + dbg_n] = clock64(); ++dbg_n; } } while (0)
 #else
 #define HF_STAMP() do { if (!gate) asm volatile("s_nop 0"); } while (0)
 #endif

@@ -27,6 +27,11 @@ done
 # ---- PMC traffic of the likelihood kernels (separate FETCH_SIZE / WRITE_SIZE passes, calibrated in the same passes) ----
 ./tools/pmc_pass.sh > $O/pmc_summary.txt 2>&1
 cp gpurun_out/pmc/pmc_summary.json $O/ 2>/dev/null; rm -rf gpurun_out/pmc
+./tools/pmc_pass.sh c5-shard > $O/pmc_summary_c5-shard.txt 2>&1
+cp gpurun_out/pmc/pmc_summary.json $O/pmc_summary_c5-shard.json 2>/dev/null; rm -rf gpurun_out/pmc
+# ---- pipe occupancy (SQ counters in separate passes) at the C5 width and of the fused output head by itself ----
+./tools/pipe_pass.sh c5-shard > /dev/null 2>&1; cp gpurun_out/pipe_c5-shard/pipe_util.txt $O/pipe_occupancy_c5-shard.txt 2>/dev/null
+./tools/hf_pipe.sh zinb > /dev/null 2>&1; cp gpurun_out/hfpipe_zinb/pipe_util.txt $O/pipe_occupancy_head_fused.txt 2>/dev/null
 # ---- MFMA utilisation of the product kernels (separate PMC pass + a stats pass) at the benchmark size and at the C5 shard ----
 : > $O/mfma_utilisation.txt
 for w in 8kly c5-shard; do

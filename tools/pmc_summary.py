@@ -11,7 +11,9 @@ out = sys.argv[1]
 # kernel families of the default bench command: the fused training kernel, its product-only timing variant, the
 # standalone likelihood kernel (eval / flag head_loss = 0), the head's backward products
 FAMILIES = {"fused": "out_head_loss_kernel<1, 0, 1", "product_only": "out_head_loss_kernel<1, 0, 0",
-            "standalone": "count_loss_kernel<1, 0, 1", "head_bwd": "out_head_bwd_kernel"}
+            "standalone": "count_loss_kernel<1, 0, 1", "head_bwd": "out_head_bwd_kernel",
+            # the wide-panel forms (bench.py --workload c5-shard): the whole head in one launch, the optimiser, the encoder's wide products
+            "head_fused": "head_fused_kernel", "adam": "adam_update_kernel", "enc_front": "bigk_kernel<", "enc_wgrad": "wgrad_panel_group_kernel"}
 
 
 def counter_rows(d):
