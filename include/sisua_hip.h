@@ -387,6 +387,9 @@ int smx_clear_tuning(const char* name);
  * products' store paths), "stacked_scoring" (smx_marginal_llk, smx_score_llk and smx_predict with several draws: all
  * posterior draws of a batch as rows of ONE decoder pass, in the scoring calls the output head fused with the
  * likelihood; 0 = one decoder pass per draw; SMX_NO_STACKED_SCORING).
+ * "head_fused" (wide panels -- at least 4096 genes, 128 decoder columns, at most 128 cells, no label heads: the output product, the
+ * likelihood AND both backward products of the head as one launch that owns a tile of 32 genes from the raw weights to their
+ * gradients, smx_headfused.hip; 0 = the fused head + the two wide backward kernels).
  * "bf16x3": the training products of the output head (the fused head, both products of its backward, the first layer's
  * weight gradient) from bf16 MFMAs on operands split three ways in registers (f32 accuracy to one rounding of a product;
  * 0.375 of the f32 MFMAs' cycles, on the matrix pipe): 1 always, 0 never (exact f32 MFMAs), -1 (default) from the head's
