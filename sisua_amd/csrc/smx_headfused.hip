@@ -147,8 +147,11 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
   int tb[2][2][2], rb[2][2][2];   // transposed reads / row accesses: [image: W, dP][sub-images 4.. ][column half]
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
-    const int t = 64 * (4 * g + q4) + 32 * (hf ^ (g & 1)) + 8 * (pp ^ (2 * (g >> 1)));
-    const int r = 64 * j + 32 * (hf ^ ((j >> 2) & 1)) + 8 * (g ^ (2 * ((j >> 3) & 1)));
+    // (a row = 64 bytes = 4 slots of 16 bytes; slot s holds columns 4 s .. 4 s + 3 of BOTH halves side by side, so that a lane's two runs of
+    // a row read are ONE 16-byte access; the slot is XOR-ed with f(row >> 2), f = 0, 2, 3, 1: every 16-lane group of ds_read_b128 then
+    // touches 16 different slots; the transposed reads are 2-way on it -- rows r and r + 4 of a half-wave share a bank pair)
+    const int t = 64 * (4 * g + q4) + 16 * (pp ^ ((0x78 >> (2 * g)) & 3)) + 8 * hf;
+    const int r = 64 * j + 16 * (g ^ ((0x78 >> (2 * ((j >> 2) & 3))) & 3));
 #pragma unroll
     for (int im = 0; im < 2; ++im)
 #pragma unroll
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
   const int wt = tid >> 3, wc4 = tid & 7;
   int wwb[2];
 #pragma unroll
-  for (int hi = 0; hi < 2; ++hi) wwb[hi] = hf_hide(64 * wt + 32 * ((wc4 >> 2) ^ ((wt >> 2) & 1)) + 8 * ((wc4 & 3) ^ (2 * ((wt >> 3) & 1))) + hi * 32768);
+  for (int hi = 0; hi < 2; ++hi) wwb[hi] = hf_hide(64 * wt + 16 * ((wc4 & 3) ^ ((0x78 >> (2 * ((wt >> 2) & 3))) & 3)) + 8 * (wc4 >> 2) + hi * 32768);
   const int wgo = (int)((wt * a.ldw + 4 * wc4) * 4);   // this thread's float4 of a W tile (bytes): rows wt, wt + RPT, ... of every plane
   const long wbytes = 128L * a.ldw * 4;
   const __amdgpu_buffer_rsrc_t rW = hf_rsrc(a.W, wbytes), rdW = hf_rsrc(a.dW, wbytes);
@@ -278,9 +281,9 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
   auto row_read = [&](int n) {
     const int p = n / 8, hs = n % 8;
     Split8 r;
-    r.t0 = cat8(*reinterpret_cast<const hf_bf16x4*>(HF_AT(rb[0], 0, p, 1024 * hs)), *reinterpret_cast<const hf_bf16x4*>(HF_AT(rb[0], 1, p, 1024 * hs)));
-    r.t1 = cat8(*reinterpret_cast<const hf_bf16x4*>(HF_AT(rb[0], 0, NP + p, 1024 * hs)), *reinterpret_cast<const hf_bf16x4*>(HF_AT(rb[0], 1, NP + p, 1024 * hs)));
-    r.t2 = cat8(*reinterpret_cast<const hf_bf16x4*>(HF_AT(rb[0], 0, 2 * NP + p, 1024 * hs)), *reinterpret_cast<const hf_bf16x4*>(HF_AT(rb[0], 1, 2 * NP + p, 1024 * hs)));
+    r.t0 = *reinterpret_cast<const smx_bf16x8*>(HF_AT(rb[0], 0, p, 1024 * hs));
+    r.t1 = *reinterpret_cast<const smx_bf16x8*>(HF_AT(rb[0], 0, NP + p, 1024 * hs));
+    r.t2 = *reinterpret_cast<const smx_bf16x8*>(HF_AT(rb[0], 0, 2 * NP + p, 1024 * hs));
     return r;
   };
 
@@ -403,9 +406,9 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
         const Split8 sp = split3x8(dpv[p]);
         {
           const int wo = 1024 * w;   // (the share's rows: a scalar)
-          *reinterpret_cast<hf_bf16x4*>(HF_AT(rb[1], 0, p, 0) + wo) = lo4(sp.t0); *reinterpret_cast<hf_bf16x4*>(HF_AT(rb[1], 1, p, 0) + wo) = hi4(sp.t0);
-          *reinterpret_cast<hf_bf16x4*>(HF_AT(rb[1], 0, NP + p, 0) + wo) = lo4(sp.t1); *reinterpret_cast<hf_bf16x4*>(HF_AT(rb[1], 1, NP + p, 0) + wo) = hi4(sp.t1);
-          *reinterpret_cast<hf_bf16x4*>(HF_AT(rb[1], 0, 2 * NP + p, 0) + wo) = lo4(sp.t2); *reinterpret_cast<hf_bf16x4*>(HF_AT(rb[1], 1, 2 * NP + p, 0) + wo) = hi4(sp.t2);
+          *reinterpret_cast<smx_bf16x8*>(HF_AT(rb[1], 0, p, 0) + wo) = sp.t0;
+          *reinterpret_cast<smx_bf16x8*>(HF_AT(rb[1], 0, NP + p, 0) + wo) = sp.t1;
+          *reinterpret_cast<smx_bf16x8*>(HF_AT(rb[1], 0, 2 * NP + p, 0) + wo) = sp.t2;
         }
 #pragma unroll
         for (int hs = 0; hs < 8; ++hs) {
