@@ -21,8 +21,9 @@
 //  * dW = d^T dP sums over the cell = the LANE index: dP crosses LDS once, written as 8-byte runs of 4 genes into a
 //    [cell][rho] image (three bf16 terms) and read back column-wise by ds_read_b64_tr_b16 (the hardware transpose read).
 //  * W_out's tile is split ONCE per workgroup into a [h][rho] bf16 x 3 image: the forward product reads it transposed
-//    (ds_read_b64_tr_b16), d d reads its rows (ds_read_b64).  Both images: 64-byte rows per (term, plane), the 32-byte half
-//    and the 8-byte slot XOR-ed with row bits so that every read shape is bank-conflict free.
+//    (ds_read_b64_tr_b16), d d reads its rows.  Both images: 64-byte rows per (term, plane) = 4 slots of 16 bytes holding columns
+//    4 s .. 4 s + 3 of both 16-column halves side by side (a lane's two runs of a row read or write are ONE 16-byte access), the slot
+//    XOR-ed with row bits (row reads conflict-free, transposed reads 2-way).
 //  * d's operands never change: both of a wave's views of d (its cells' rows for the forward product, its H rows' columns for
 //    dW) are split once and stay in 96 registers; no LDS image of d (144 KB of LDS are the two images above).
 //  * the k index of every product is permuted consistently in both operands (lane group g, element e <-> k = 4 g + e for
@@ -96,11 +97,6 @@ __device__ inline void hf_store8h(smx_bf16x8 v, __amdgpu_buffer_rsrc_t r, int vo
 }
 __device__ inline void hf_store1(float v, __amdgpu_buffer_rsrc_t r, int vo, int so) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, vo, so, 0);
-}
-
-// byte offset inside one (term, plane) sub-image [128 rows][32 columns] of bf16: column = 16 half + 4 slot + (0..3)
-__device__ inline int hf_off(int row, int half, int slot) {
-  return 64 * row + 32 * (half ^ ((row >> 2) & 1)) + 8 * (slot ^ (2 * ((row >> 3) & 1)));
 }
 
 // the wave's queue of non-zero counts (smx_loss.h) inside rows 16 w .. 16 w + 15 of the dP image's first four sub-images
