@@ -305,5 +305,14 @@ def test_wide_panel_head_in_one_launch(Engine, lk, B, G, storage):
     e.close()
   for a, b in zip(results[True][0], results[False][0]):
     assert abs(a / b - 1.0) < 2e-5
+  # deterministic: a second engine repeats the fused form's losses bit for bit (per-workgroup slabs summed in order, no atomics)
+  e = Engine(cfg, max_batch=128, init=False)
+  e.set_params(so.init_params(spec))
+  e.upload(x, cell_id_base=3, storage=storage)
+  rng = np.random.default_rng(7)
+  for s in range(3):
+    rows = rng.permutation(x.shape[0])[:B].astype(np.int32)
+    assert e.train_step(rows, graph=(s == 2))["loss"] == results[True][0][s]
+  e.close()
   worst = grad_errors(results[True][1], results[False][1])
   assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
