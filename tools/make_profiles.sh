@@ -21,8 +21,8 @@ for w in 8kly c5-shard; do
   cp $(find $O/trace_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
   rm -rf $O/trace_$w
   python3 bench.py --workload $w --steps 300 --warmup 30 --no-cpu-baseline --no-c5-entry > $O/bench_$w.json 2> $O/bench_$w.err
-  { echo "## $w: bench line without the profiler vs the rocprofv3 summary"; python3 tools/check_roofline.py $O/bench_$w.json $O/rocprofv3_kernel_stats_$w.csv $w;
-    echo "## $w: bench line of the profiled run itself vs the same summary"; python3 tools/check_roofline.py $O/bench_under_rocprof_$w.json $O/rocprofv3_kernel_stats_$w.csv $w; } > $O/check_roofline_$w.txt 2>&1
+  { echo "## $w: bench line of the profiled run itself vs the rocprofv3 summary of that run (the check)"; python3 tools/check_roofline.py $O/bench_under_rocprof_$w.json $O/rocprofv3_kernel_stats_$w.csv $w;
+    echo "## $w: bench line of a run without the profiler vs the same summary (informational: the profiler serialises back-to-back dispatches)"; python3 tools/check_roofline.py $O/bench_$w.json $O/rocprofv3_kernel_stats_$w.csv $w --info; } > $O/check_roofline_$w.txt 2>&1
 done
 # ---- PMC traffic of the likelihood kernels (separate FETCH_SIZE / WRITE_SIZE passes, calibrated in the same passes) ----
 ./tools/pmc_pass.sh > $O/pmc_summary.txt 2>&1
