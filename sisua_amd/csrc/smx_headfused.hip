@@ -24,8 +24,9 @@
 //    (ds_read_b64_tr_b16), d d reads its rows.  Both images: 64-byte rows per (term, plane) = 4 slots of 16 bytes holding columns
 //    4 s .. 4 s + 3 of both 16-column halves side by side (a lane's two runs of a row read or write are ONE 16-byte access), the slot
 //    XOR-ed with row bits (row reads conflict-free, transposed reads 2-way).
-//  * d's operands never change: both of a wave's views of d (its cells' rows for the forward product, its H rows' columns for
-//    dW) are split once and stay in 96 registers; no LDS image of d (144 KB of LDS are the two images above).
+//  * d's operands never change: a wave's two views of d (its cells' rows for the forward product, its H rows' columns for dW) are
+//    split once; the first stays in 48 registers, the second is parked in an L2-resident table and fetched per tile (below); no LDS
+//    image of d (144 KB of LDS are the two images above).
 //  * the k index of every product is permuted consistently in both operands (lane group g, element e <-> k = 4 g + e for
 //    e < 4, 16 + 4 g + e - 4 otherwise) so that the transposed reads of a 32-lane half touch 8 consecutive rows.
 //  * 2 workgroup barriers per tile; the next tile's W (global -> registers) and counts are in flight under the current tile.
@@ -111,10 +112,10 @@ struct HfQueue {
 // file takes accumulators), so the two resident views of d (96 registers per share) sit in the half that the likelihood needs.
 //   VW = 2 (256 threads, one wave per SIMD, 512 registers): both views resident; measured 103 us at 128 x 20 000 zinb (117 registers
 //   in scratch, every LDS round trip and every dependent MFMA chain exposed -- nothing else runs on the SIMD).
-//   VW = 1 (512 threads, two waves per SIMD, 256 registers): a view is resident only while its product runs.  Each wave writes its two
-//   split views once to a table in global memory (a.dtab, 192 KB, the same bytes from every workgroup: L2-resident) and reads the
-//   next one back -- 12 coalesced 16-byte loads -- one phase before it is needed; the requests are ordered so that no wait for them
-//   also waits for the next tile's W and counts (vector-memory results return in order).
+//   VW = 1 (512 threads, two waves per SIMD, 256 registers): the view for dW is resident only while that product runs.  Each wave writes
+//   it once to a table in global memory (a.dtab, 96 KB, the same bytes from every workgroup: L2-resident) and reads it back -- 12
+//   coalesced 16-byte loads -- one phase before it is needed, ahead of the next tile's W so that the wait for it does not also wait
+//   for that (vector-memory results return in order).  (Both views that way: +1-2 us -- 123 MB of L2 reads per launch.)
 template <int LK, int U16, int VW>
 __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedArgs a) {
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
   constexpr int UPP = 128 / RPT;           // passes per plane
   constexpr int NWL = NP * UPP;            // float4 of W per thread and tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char* const Wimg = lds;                      // [term][plane][h 128][32]
+  // lds + 0: the W image [term][plane][h 128][32]
   unsigned char* const Pimg = lds + IMG;                // [term][plane][cell 128][32]
   float* const dbx = reinterpret_cast<float*>(lds + 2 * IMG);   // [8 shares][32 NP]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,20 +210,18 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
 #pragma unroll
     for (int hs = 0; hs < 8; ++hs) accDD[v][hs] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // the table of the split views: [view: 0 rows (forward) | 1 columns (dW)][share 8][ks 4][term 3][lane 64] x 16 bytes
+  // the table of the view for dW: [wave 8][ks 4][term 3][lane 64] x 16 bytes
   constexpr bool RELOAD = VW == 1;
-  const int tab_vo = lane * 16, tabB = (0 * 8 + wave) * 12 * 1024, tabA = (1 * 8 + wave) * 12 * 1024;   // (scalar byte offsets of the wave's entries)
+  const int tab_vo = lane * 16, tabA = wave * 12 * 1024;   // (scalar byte offset of the wave's entries)
   if (RELOAD) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      hf_store8h(dB[0][ks].t0, rtab, tab_vo, tabB + (3 * ks + 0) * 1024); hf_store8h(dB[0][ks].t1, rtab, tab_vo, tabB + (3 * ks + 1) * 1024); hf_store8h(dB[0][ks].t2, rtab, tab_vo, tabB + (3 * ks + 2) * 1024);
       hf_store8h(dA[0][ks].t0, rtab, tab_vo, tabA + (3 * ks + 0) * 1024); hf_store8h(dA[0][ks].t1, rtab, tab_vo, tabA + (3 * ks + 1) * 1024); hf_store8h(dA[0][ks].t2, rtab, tab_vo, tabA + (3 * ks + 2) * 1024);
     }
     // the wave's own table entries are written before it reads them back.  The stored registers are operands of the wait: measured on
     // MI355X, a 16-byte buffer store whose data registers are reused by the instructions right behind it (they are dead once stored)
     // wrote garbage -- with the registers held until the stores have completed the table is right (tools/headfused_try.py)
 #define HF_V(x) "v"(x.t0), "v"(x.t1), "v"(x.t2)
-    asm volatile("s_waitcnt vmcnt(0)" :: HF_V(dB[0][0]), HF_V(dB[0][1]), HF_V(dB[0][2]), HF_V(dB[0][3]) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" :: HF_V(dA[0][0]), HF_V(dA[0][1]), HF_V(dA[0][2]), HF_V(dA[0][3]) : "memory");
 #undef HF_V
   }
@@ -378,7 +377,6 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
       }
       if (v == VW - 1 && RELOAD) {
         load_view(tabA, dA[0]);
-        if (next < a.n_gt) load_view(tabB, dB[0]);
       }
       HF_STAMP();   // likelihood done
       // per-cell partial of the tile: the four lane groups hold its 32 genes
@@ -425,7 +423,7 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
     // ---- dW[h = 16 w + 4 g + r][rho] = sum over the cells: A = the share's columns of d, B = dP read transposed ----------
 #pragma unroll
     for (int v = 0; v < VW; ++v) {
-      const int w = VW * wave + v;
+      (void)wave;
       hf_f32x4 accW[NSUB];
 #pragma unroll
       for (int s = 0; s < NSUB; ++s) accW[s] = hf_f32x4{0.f, 0.f, 0.f, 0.f};

@@ -543,7 +543,7 @@ int launch_bigk(hipStream_t st, const BigKArgs& a);
 int launch_bigk_reduce(hipStream_t st, const float* part, long slab_stride, int n_slices, long n4, float* out);
 
 // ---- the whole output head of a training step at a wide panel in one launch (smx_headfused.hip) ----
-#define SMX_HEAD_FUSED_TAB_BYTES (2 * 8 * 12 * 64 * 16)
+#define SMX_HEAD_FUSED_TAB_BYTES (8 * 12 * 64 * 16)
 #define SMX_HEAD_FUSED_MIN_GENES 4096   // padded genes from which the fused form replaces fused head + bigk (d d) + panel (dW)
 struct HeadFusedArgs {
   const float* D = nullptr; int ldd = 0;            // decoder output [B][ldd], 128 columns
@@ -554,7 +554,7 @@ struct HeadFusedArgs {
   float* part = nullptr; long slab_stride = 0;      // [workgroups][B][128]: per-workgroup slabs of d d
   float* llk_part = nullptr;                        // [B][Gp / 32]
   float* sq_part = nullptr;                         // 8 sum-of-squares slots of dW per workgroup, or nullptr
-  void* dtab = nullptr;                             // SMX_HEAD_FUSED_TAB_BYTES of scratch: the split views of d (written and read by the launch)
+  void* dtab = nullptr;                             // SMX_HEAD_FUSED_TAB_BYTES of scratch: the waves' split view of d for dW (written and read by the launch)
   int B = 0, G = 0, Gp = 0, likelihood = 0;
   float grad_scale = 1.f;
   int n_gt = 0;                                     // set by the launcher
