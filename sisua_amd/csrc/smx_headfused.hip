@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
     for (int hs = 0; hs < 8; ++hs) accDD[v][hs] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // the table of the view for dW: [wave 8][ks 4][term 3][lane 64] x 16 bytes
-  constexpr bool RELOAD = VW == 1;
+  constexpr bool RELOAD = VW == 1 && LK != SMX_LLK_NB;   // (two planes, the lighter likelihood: both views fit -- 43.6 -> 41.0 us at 128 x 20 000)
   const int tab_vo = lane * 16, tabA = wave * 12 * 1024;   // (scalar byte offset of the wave's entries)
   if (RELOAD) {
 #pragma unroll
