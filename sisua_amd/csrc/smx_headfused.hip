@@ -282,9 +282,6 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
     return r;
   };
 
-#ifdef HF_PRIO
-  if (wave >= HF_PRIO) __builtin_amdgcn_s_setprio(1);
-#endif
   load_x(tile);
   for (; tile < a.n_gt; tile += gridDim.x) {
     const int n0 = tile * 32;
