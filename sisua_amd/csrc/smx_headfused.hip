@@ -116,6 +116,9 @@ struct HfQueue {
 //   it once to a table in global memory (a.dtab, 96 KB, the same bytes from every workgroup: L2-resident) and reads it back -- 12
 //   coalesced 16-byte loads -- one phase before it is needed, ahead of the next tile's W so that the wait for it does not also wait
 //   for that (vector-memory results return in order).  (Both views that way: +1-2 us -- 123 MB of L2 reads per launch.)
+#ifndef SMX_HF_STAMP_WAVE
+#define SMX_HF_STAMP_WAVE 0
+#endif
 template <int LK, int U16, int VW>
 __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedArgs a) {
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
@@ -173,6 +176,9 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
   };
   int tile = blockIdx.x;
   load_w(tile);   // (requested before the prologue: the first tile's HBM latency runs under the split of d)
+#ifdef SMX_HF_STAMPS
+  if (a.dbg && tid == 64 * SMX_HF_STAMP_WAVE && (blockIdx.x == 0 || blockIdx.x == 100)) a.dbg[(blockIdx.x ? 64 : 0) + 63] = clock64();   // kernel entry
+#endif
 
   // ---- both views of d per share, split once -----------------------------------------------------------------------------
   // dB[v][ks]: B operand of the forward product, d[cell][k], k = 32 ks + (e < 4 ? 4 g + e : 16 + 4 g + e - 4)
@@ -242,9 +248,6 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
   const bool gate = __builtin_amdgcn_readfirstlane(hf_hide(1)) != 0;
 #ifdef SMX_HF_STAMPS   // (development: cycle stamps of the phases of workgroups 0 and 100, read back by smx_k_head_fused under the knob hf_dbg)
   int dbg_n = 0;
-#ifndef SMX_HF_STAMP_WAVE
-#define SMX_HF_STAMP_WAVE 0
-#endif
 #define HF_STAMP() do { if (a.dbg && tid == 64 * SMX_HF_STAMP_WAVE && (blockIdx.x == 0 || blockIdx.x == 100)) { a.dbg[(blockIdx.x ? 64 : 0) + dbg_n] = clock64(); ++dbg_n; } } while (0)
 #else
 #define HF_STAMP() do { if (!gate) asm volatile("s_nop 0"); } while (0)

@@ -271,7 +271,7 @@ int smx_k_head_fused(int likelihood, int u16, const float* x, const float* d, co
     long long h[128];
     hipMemcpy(h, dDbg, sizeof(h), hipMemcpyDeviceToHost);
     for (int b = 0; b < 2; ++b) {
-      fprintf(stderr, "hf stamps block %d:", b ? 100 : 0);
+      fprintf(stderr, "hf stamps block %d: (prologue %lld)", b ? 100 : 0, h[64 * b] - h[64 * b + 63]);
       for (int i = 1; i < 40 && h[64 * b + i]; ++i) fprintf(stderr, " %lld", h[64 * b + i] - h[64 * b + i - 1]);
       fprintf(stderr, "\n");
     }
