@@ -81,15 +81,22 @@ __device__ inline void panel_body(const PanelProblem& P, const int first, const 
     }
   };
   // this lane's 8 cells of one entry of the panel tile of (unit, chunk): issued early, consumed by stage()
+  // the lane's 8 gathered rows, once (one chunk): read inside load_panel they are not hoisted -- the stores of the loop may alias them for all
+  // the compiler knows -- and every unit's panel loads then wait for a round trip of row ids first
+  long rowoff[8];
+  if (MODE && one_chunk) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) rowoff[s] = (long)P.rows[min(8 * cb + s, P.B - 1)] * P.ld_big;
+  }
   auto load_panel = [&](int unit, int kc, float (&bv)[8]) {
     const int wt = unit / P.n_sub, sub = unit - wt * P.n_sub;
     const long col0 = (long)sub * P.sub_stride + wt * 32;
     if (MODE) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const long row = (long)P.rows[min(kc + 8 * cb + s, P.B - 1)];
-        if (MODE == 2) bv[s] = (float)reinterpret_cast<const uint16_t*>(P.big)[row * P.ld_big + col0 + i];
-        else bv[s] = reinterpret_cast<const float*>(P.big)[row * P.ld_big + col0 + i];
+        const long ro = one_chunk ? rowoff[s] : (long)P.rows[min(kc + 8 * cb + s, P.B - 1)] * P.ld_big;
+        if (MODE == 2) bv[s] = (float)reinterpret_cast<const uint16_t*>(P.big)[ro + col0 + i];
+        else bv[s] = reinterpret_cast<const float*>(P.big)[ro + col0 + i];
       }
     } else {
       // (a panel without gather is this step's [cells][wide] buffer: byte offsets below 2^32)
