@@ -487,15 +487,26 @@ template <int LK>
 static int launch_hf(hipStream_t st, const HeadFusedArgs& a, int grid) {
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
   const size_t lds = (size_t)2 * 3 * NP * 8192 + (size_t)8 * 32 * NP * 4;
-  static bool raised[2] = {false, false};
-  if (!raised[a.x_u16 ? 1 : 0]) {
-    if (a.x_u16) SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<LK, 1, SMX_HF_VW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<LK, 0, SMX_HF_VW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    raised[a.x_u16 ? 1 : 0] = true;
-  }
+  { const int rc = head_fused_prepare(); if (rc != SMX_OK) return rc; }
   if (a.x_u16) hipLaunchKernelGGL((head_fused_kernel<LK, 1, SMX_HF_VW>), dim3((unsigned)grid), dim3(512 / SMX_HF_VW), lds, st, a);
   else hipLaunchKernelGGL((head_fused_kernel<LK, 0, SMX_HF_VW>), dim3((unsigned)grid), dim3(512 / SMX_HF_VW), lds, st, a);
   SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
+// every instantiation's dynamic-LDS limit, once per process: at model creation rather than at the first launch, which may sit inside a
+// stream capture
+int head_fused_prepare() {
+  static bool done = false;
+  if (done) return SMX_OK;
+#define SMX_HF_ATTR(LK, NP)                                                                                                                         \
+  SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<LK, 0, SMX_HF_VW>), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              2 * 3 * NP * 8192 + 8 * 32 * NP * 4));                                                                                \
+  SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<LK, 1, SMX_HF_VW>), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              2 * 3 * NP * 8192 + 8 * 32 * NP * 4))
+  SMX_HF_ATTR(SMX_LLK_NB, 2); SMX_HF_ATTR(SMX_LLK_ZINB, 3); SMX_HF_ATTR(SMX_LLK_NBD, 2); SMX_HF_ATTR(SMX_LLK_ZINBD, 3);
+#undef SMX_HF_ATTR
+  done = true;
   return SMX_OK;
 }
 

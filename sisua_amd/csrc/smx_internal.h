@@ -566,6 +566,7 @@ int head_fused_grid(int Gp);
 int launch_head_fused(hipStream_t st, const HeadFusedArgs& a, int* n_slabs, int* n_sq);
 int launch_head_fused_reduce(hipStream_t st, const HeadFusedArgs& a, int n_slabs, float* dd_out);
 long head_fused_bytes(int B, int G, int Gp, int k);
+int head_fused_prepare();   // the kernels' dynamic-LDS limits (model creation; idempotent)
 
 // ---- grouped weight gradients with K = the minibatch (smx_headbwd.hip) ---------------------------
 struct WgradProblem {

@@ -354,6 +354,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     float* tab = nullptr;
     if ((rc = dmalloc(&tab, (size_t)SMX_HEAD_FUSED_TAB_BYTES / 4))) return fail(rc);
     m->hf_tab = tab;
+    if ((rc = head_fused_prepare())) return fail(rc);
   }
   if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
       (rc = dmalloc(&m->z, B * m->Dp)) || (rc = dmalloc(&m->noise_eps, B * m->Dp)) || (rc = dmalloc(&m->sig, B * m->Dp)) || (rc = dmalloc(&m->eps, B * m->Dp)) ||

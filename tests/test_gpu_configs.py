@@ -316,3 +316,21 @@ def test_wide_panel_head_in_one_launch(Engine, lk, B, G, storage):
   e.close()
   worst = grad_errors(results[True][1], results[False][1])
   assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+
+
+def test_wide_panel_first_step_as_a_graph(Engine):
+  """The fused head's launch inside a stream capture on the very FIRST step of a model (its dynamic-LDS limit is set at model creation, not at
+  the first launch): the captured step equals the eager step of a second engine bit for bit."""
+  from tests.util import make_pair, synth_counts
+  spec, cfg = make_pair(model="vae", n_genes=4200, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=16)
+  x = synth_counts(256, 4200, sparsity=0.92, seed=5)
+  rows = np.arange(128, dtype=np.int32)
+  losses = []
+  for graph in (True, False):
+    e = Engine(cfg, max_batch=128, init=False)
+    e.set_params(so.init_params(spec))
+    e.upload(x, storage="u16")
+    assert e.head_fused_bytes(128) > 0
+    losses.append([e.train_step(rows, graph=graph)["loss"] for _ in range(2)])
+    e.close()
+  assert losses[0] == losses[1]
