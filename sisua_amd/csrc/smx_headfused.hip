@@ -18,7 +18,7 @@
 //    then holds, for ONE cell, 8 genes x k planes: the likelihood runs on the accumulators where they are, and its result dP^T
 //    is, register for register, the B operand of d d^T[h][cell] += sum_rho W[h][rho] dP^T[rho][cell] (a product that sums over
 //    the accumulator's ROW index takes it without any lane movement), accumulated in 32 registers for the whole launch.
-//  * dW = d^T dP sums over the cell = the LANE index: dP crosses LDS once, written as 8-byte runs of 4 genes into a
+//  * dW = d^T dP sums over the cell = the LANE index: dP crosses LDS once, written as the lane's two runs of 4 genes (16 bytes per term) into a
 //    [cell][rho] image (three bf16 terms) and read back column-wise by ds_read_b64_tr_b16 (the hardware transpose read).
 //  * W_out's tile is split ONCE per workgroup into a [h][rho] bf16 x 3 image: the forward product reads it transposed
 //    (ds_read_b64_tr_b16), d d reads its rows.  Both images: 64-byte rows per (term, plane) = 4 slots of 16 bytes holding columns
