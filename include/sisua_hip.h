@@ -390,6 +390,9 @@ int smx_clear_tuning(const char* name);
  * "head_fused" (wide panels -- at least 4096 genes, 128 decoder columns, at most 128 cells, no label heads: the output product, the
  * likelihood AND both backward products of the head as one launch that owns a tile of 32 genes from the raw weights to their
  * gradients, smx_headfused.hip; 0 = the fused head + the two wide backward kernels).
+ * "head_sweep" (with "head_fused", one GPU, eager steps: clip + Adam of the heads' tensors -- 3/4 of the parameters at 20 000 genes -- as a
+ * background sweep of a fixed number of workgroups on a second stream, between this step's output head and the next step's; every
+ * smx_train_steps call ends with the sweep joined; 0 = riders of the backward chain + the optimiser launch; same bits either way).
  * "bf16x3": the training products of the output head (the fused head, both products of its backward, the first layer's
  * weight gradient) from bf16 MFMAs on operands split three ways in registers (f32 accuracy to one rounding of a product;
  * 0.375 of the f32 MFMAs' cycles, on the matrix pipe): 1 always, 0 never (exact f32 MFMAs), -1 (default) from the head's

@@ -13,21 +13,12 @@ namespace smx {
 // rounds, so the reduction's barrier and the first loads' latency were a third of its life.  (Nontemporal loads / stores of the
 // moments, to keep the weights in the last-level cache, measured slower: c5-shard 198.0 -> 200.0 us, C2 80.4 -> 81.7.)
 typedef float smx_f32x4 __attribute__((ext_vector_type(4)));
+
+// the chunk's tensor: its gradient norm (written once per tensor, by the tensor's first chunk) and the factor its gradients are scaled by.
+// Every thread of the workgroup calls it (two barriers); the first 256 threads sum in the same order whatever NT is.
 template <int NT = 256>
-__device__ inline void adam_chunk_body(const AdamArgs& a, int chunk) {
+__device__ inline float adam_tensor_clip(const AdamArgs& a, const OptChunk& ch, int chunk) {
   __shared__ float sh[4];
-  const OptChunk ch = a.chunks[chunk];
-  const smx_f32x4* g4 = reinterpret_cast<const smx_f32x4*>(a.grads + ch.offset);
-  smx_f32x4* m4 = reinterpret_cast<smx_f32x4*>(a.m + ch.offset);
-  smx_f32x4* v4 = reinterpret_cast<smx_f32x4*>(a.v + ch.offset);
-  smx_f32x4* p4 = reinterpret_cast<smx_f32x4*>(a.params + ch.offset);
-  const int n4 = ch.count / 4;
-  int i = threadIdx.x;
-  smx_f32x4 g = {0.f, 0.f, 0.f, 0.f}, m = g, v = g, p = g;
-  auto fetch = [&](int j, smx_f32x4& go, smx_f32x4& mo, smx_f32x4& vo, smx_f32x4& po) {
-    go = g4[j]; mo = m4[j]; vo = v4[j]; po = p4[j];
-  };
-  if (i < n4) fetch(i, g, m, v, p);
   float s = 0.f;
   if (NT > 256 && threadIdx.x >= 256) {
   } else if (a.use_sq) {
@@ -55,20 +46,82 @@ __device__ inline void adam_chunk_body(const AdamArgs& a, int chunk) {
   float clip = a.grad_scale;
   if (a.clipnorm > 0.f && norm > a.clipnorm) clip *= a.clipnorm / norm;
   if (threadIdx.x == 0 && chunk == ch.first_chunk) a.tensor_norm[ch.tensor] = norm;
+  return clip;
+}
+
+// one quad of a tensor: the update itself (also the output head's launch, when it applies the step before's update to the tile of W it is
+// about to read: smx_headfused.hip)
+__device__ inline void adam_apply4(float b1, float b2, float eps, float clip, float lr_t, const smx_f32x4& g, smx_f32x4& m, smx_f32x4& v, smx_f32x4& p) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float ge = g[e] * clip;
+    m[e] = b1 * m[e] + (1.f - b1) * ge;
+    v[e] = b2 * v[e] + (1.f - b2) * ge * ge;
+    p[e] -= lr_t * m[e] * frcp(fsqrt(v[e]) + eps);   // v_sqrt + v_rcp (1 ulp each) instead of 22 instructions
+  }
+}
+__device__ inline void adam_apply4(const AdamArgs& a, float clip, float lr_t, const smx_f32x4& g, smx_f32x4& m, smx_f32x4& v, smx_f32x4& p) {
+  adam_apply4(a.b1, a.b2, a.eps, clip, lr_t, g, m, v, p);
+}
+
+template <int NT = 256>
+__device__ inline void adam_chunk_body(const AdamArgs& a, int chunk) {
+  const OptChunk ch = a.chunks[chunk];
+  const smx_f32x4* g4 = reinterpret_cast<const smx_f32x4*>(a.grads + ch.offset);
+  smx_f32x4* m4 = reinterpret_cast<smx_f32x4*>(a.m + ch.offset);
+  smx_f32x4* v4 = reinterpret_cast<smx_f32x4*>(a.v + ch.offset);
+  smx_f32x4* p4 = reinterpret_cast<smx_f32x4*>(a.params + ch.offset);
+  const int n4 = ch.count / 4;
+  int i = threadIdx.x;
+  smx_f32x4 g = {0.f, 0.f, 0.f, 0.f}, m = g, v = g, p = g;
+  auto fetch = [&](int j, smx_f32x4& go, smx_f32x4& mo, smx_f32x4& vo, smx_f32x4& po) {
+    go = g4[j]; mo = m4[j]; vo = v4[j]; po = p4[j];
+  };
+  if (i < n4) fetch(i, g, m, v, p);
+  const float clip = adam_tensor_clip<NT>(a, ch, chunk);
   const float lr_t = a.state->lr_t;
   while (i < n4) {
     const int j = i + NT;
     smx_f32x4 gn = g, mn = m, vn = v, pn = p;
     if (j < n4) fetch(j, gn, mn, vn, pn);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float ge = g[e] * clip;
-      m[e] = a.b1 * m[e] + (1.f - a.b1) * ge;
-      v[e] = a.b2 * v[e] + (1.f - a.b2) * ge * ge;
-      p[e] -= lr_t * m[e] * frcp(fsqrt(v[e]) + a.eps);   // v_sqrt + v_rcp (1 ulp each) instead of 22 instructions
-    }
+    adam_apply4(a, clip, lr_t, g, m, v, p);
     m4[i] = m; v4[i] = v; p4[i] = p;
     g = gn; m = mn; v = vn; p = pn; i = j;
+  }
+}
+
+// the background sweep's workgroup (smx_kernels.hip: adam_sweep_kernel): chunks first + blockIdx.x, + gridDim.x, ... -- the tensor's factor is
+// worked out when the tensor changes (the output head's matrix is ~1900 chunks of one tensor), and a thread keeps two quads of every operand in
+// flight; element by element the same arithmetic as adam_chunk_body: the same bits
+template <int NT>
+__device__ inline void adam_sweep_body(const AdamArgs& a, int first, int count) {
+  int cur_t = -1;
+  float clip = 0.f;
+  const float lr_t = a.state->lr_t;
+  for (int c = (int)blockIdx.x; c < count; c += (int)gridDim.x) {
+    const int chunk = first + c;
+    const OptChunk ch = a.chunks[chunk];
+    if (ch.tensor != cur_t || chunk == ch.first_chunk) { clip = adam_tensor_clip<NT>(a, ch, chunk); cur_t = ch.tensor; }
+    const smx_f32x4* g4 = reinterpret_cast<const smx_f32x4*>(a.grads + ch.offset);
+    smx_f32x4* m4 = reinterpret_cast<smx_f32x4*>(a.m + ch.offset);
+    smx_f32x4* v4 = reinterpret_cast<smx_f32x4*>(a.v + ch.offset);
+    smx_f32x4* p4 = reinterpret_cast<smx_f32x4*>(a.params + ch.offset);
+    const int n4 = ch.count / 4;
+    for (int i = threadIdx.x; i < n4; i += 2 * NT) {
+      const int j = i + NT;
+      const bool two = j < n4;
+      const int jj = two ? j : i;
+      const smx_f32x4 g0 = g4[i], m0 = m4[i], v0 = v4[i], p0 = p4[i];
+      const smx_f32x4 g1 = g4[jj], m1 = m4[jj], v1 = v4[jj], p1 = p4[jj];
+      smx_f32x4 m = m0, v = v0, p = p0;
+      adam_apply4(a, clip, lr_t, g0, m, v, p);
+      m4[i] = m; v4[i] = v; p4[i] = p;
+      if (two) {
+        m = m1; v = v1; p = p1;
+        adam_apply4(a, clip, lr_t, g1, m, v, p);
+        m4[j] = m; v4[j] = v; p4[j] = p;
+      }
+    }
   }
 }
 

@@ -144,6 +144,7 @@ struct smx_model {
   struct Flags {
     int head_loss = tuning_on("no_head_loss") ? 0 : 1;    // output product + likelihood in one kernel
     int head_fused = tuning_on("no_head_fused") ? 0 : 1;  // wide panels: ... and both of the head's backward products in the same launch (smx_headfused.hip)
+    int head_sweep = tuning_on("no_head_sweep") ? 0 : 1;  // wide panels, one GPU, eager steps: the heads' optimiser update as a background sweep on a second stream (smx_step.hip)
     int front = tuning_on("no_front") ? 0 : 1;            // latent sample + first decoder product inside BatchNorm-forward
     int bwd_front = tuning_on("no_bwd_front") ? 0 : 1;    // d h inside BatchNorm-backward, weight gradients grouped at the end
     int head_bwd = tuning_on("no_head_bwd") ? 0 : 1;      // both backward products of the output head in one wide launch
@@ -166,6 +167,19 @@ struct smx_model {
   int adam_early_from = -1;           // >= 0: chunks [adam_early_from, n_chunks) of this step were applied early
   int adam_ride_b = 0;                // wide panels: this many of the waiting chunks go with the latent head's backward product
   int adam_rest_from = 0, adam_rest_to = 0;   // ... and [adam_rest_from, adam_rest_to) wait for the next BatchNorm-backward launch to carry them
+  // wide panels, one GPU, eager steps: the heads' update as a background sweep on a second stream between this step's output head and
+  // the next step's (smx_step.hip: head_sweep_start / head_sweep_join)
+  hipStream_t st_side = nullptr;
+  hipEvent_t ev_hf = nullptr, ev_sweep = nullptr;
+  bool sweep_pending = false;
+  bool ev_hf_fresh = false;            // ev_hf was recorded behind THIS step's output head
+  bool head_fused_bwd_done = false;   // this backward pass found dW / db / d d of the output head done by the forward pass's launch
+  // wide panels, one GPU, eager steps: the output head's update applied by its next reader -- the next step's output-head launch
+  // (smx_step.hip: lazy_*; smx_headfused.hip: LAZY)
+  float* lazy_clip = nullptr;          // [2] the gradient factor of W_out, per step parity
+  bool lazy_defer = false;             // this step's optimiser launch skips W_out and leaves its factor in lazy_clip[par]
+  bool lazy_pending = false;           // W_out / its moments in memory are one update behind
+  int lazy_par = 0;                    // parity (step state, factor) of the pending update
   bool x_u16 = false;   // the resident matrix is stored as uint16 counts (smx_dataset_upload_u16)
   // compact sparse store (smx_dataset_upload_csr): CSR arrays resident, the minibatch's rows expanded per pass into xbatch
   int64_t* csr_indptr = nullptr; int32_t* csr_cols = nullptr; float* csr_vals = nullptr; bool x_csr = false;

@@ -354,6 +354,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     float* tab = nullptr;
     if ((rc = dmalloc(&tab, (size_t)SMX_HEAD_FUSED_TAB_BYTES / 4))) return fail(rc);
     m->hf_tab = tab;
+    if ((rc = dmalloc(&m->lazy_clip, 2))) return fail(rc);
     if ((rc = head_fused_prepare())) return fail(rc);
   }
   if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
@@ -467,6 +468,10 @@ int smx_model_destroy(smx_model* m) {
   if (m->score_aux) hipFree(m->score_aux);
   for (auto& kv : m->injected) fr(kv.second.d);
   if (m->st_comm) { hipStreamSynchronize(m->st_comm); hipStreamDestroy(m->st_comm); }
+  if (m->st_side) { hipStreamSynchronize(m->st_side); hipStreamDestroy(m->st_side); }
+  if (m->lazy_clip) hipFree(m->lazy_clip);
+  if (m->ev_hf) hipEventDestroy(m->ev_hf);
+  if (m->ev_sweep) hipEventDestroy(m->ev_sweep);
   if (m->ev_c1) hipEventDestroy(m->ev_c1);
   if (m->ev_c2) hipEventDestroy(m->ev_c2);
   if (m->ev_c3) hipEventDestroy(m->ev_c3);
@@ -580,12 +585,12 @@ int smx_set_flag(smx_model* m, const char* name, int value) {
   SMX_REQUIRE(m && name, "null argument");
   SMX_HIP(hipStreamSynchronize(m->st));
   const std::string n(name);
-  int* f = n == "head_loss" ? &m->flags.head_loss : n == "head_fused" ? &m->flags.head_fused : n == "front" ? &m->flags.front : n == "bwd_front" ? &m->flags.bwd_front
+  int* f = n == "head_loss" ? &m->flags.head_loss : n == "head_fused" ? &m->flags.head_fused : n == "head_sweep" ? &m->flags.head_sweep : n == "front" ? &m->flags.front : n == "bwd_front" ? &m->flags.bwd_front
          : n == "head_bwd" ? &m->flags.head_bwd : n == "wgrad" ? &m->flags.wgrad : n == "scvi_fused" ? &m->flags.scvi_fused
          : n == "twin" ? &m->flags.twin : n == "label_ride" ? &m->flags.label_ride : n == "act_epilogue" ? &m->flags.act_epilogue
          : n == "stacked_scoring" ? &m->flags.stacked_scoring : n == "bf16x3" ? &m->flags.bf16x3
          : n == "tie_mixtures" ? &m->flags.tie_mixtures : n == "tie_loc" ? &m->flags.tie_loc : n == "tie_scale" ? &m->flags.tie_scale : nullptr;
-  SMX_REQUIRE(f, "unknown flag (head_loss, head_fused, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue, stacked_scoring, bf16x3; SCALE: tie_mixtures, tie_loc, tie_scale)");
+  SMX_REQUIRE(f, "unknown flag (head_loss, head_fused, head_sweep, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue, stacked_scoring, bf16x3; SCALE: tie_mixtures, tie_loc, tie_scale)");
   *f = (f == &m->flags.bf16x3 && value < 0) ? -1 : (value ? 1 : 0);   // bf16x3: -1 = by the width of the head (the default)
   drop_graphs(m);   // a captured step bakes the launch sequence in
   return SMX_OK;

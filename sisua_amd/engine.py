@@ -521,7 +521,7 @@ class Engine:
     check(lib.smx_comm_init_local(arr, len(engines)))
 
   def set_flag(self, name: str, value: bool):
-    """Code-path switch (smx_set_flag).  Training step: head_loss, head_fused, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride,
+    """Code-path switch (smx_set_flag).  Training step: head_loss, head_fused, head_sweep, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride,
     act_epilogue; scoring: stacked_scoring; "bf16x3" (products of the output head from bf16 MFMAs on three-way split operands):
     True / False, or -1 for the default (by the head's width)."""
     v = -1 if (name == "bf16x3" and not isinstance(value, bool) and int(value) < 0) else int(bool(value))

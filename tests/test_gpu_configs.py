@@ -318,6 +318,48 @@ def test_wide_panel_head_in_one_launch(Engine, lk, B, G, storage):
   assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
 
 
+def test_wide_panel_heads_update_as_a_background_sweep(Engine):
+  """Flag head_sweep (smx_step.hip: head_sweep_start / head_sweep_join): with the fused head, clip + Adam of the heads' tensors runs as a fixed
+  number of workgroups on a second stream between this step's output head and the next step's.  Same arithmetic per element, the tensor's norm
+  summed in the same order: losses of every step, parameters and both Adam moments equal the riders + optimiser-launch form BIT FOR BIT -- over
+  two multi-step calls with an evaluation pass and a forward pass (which reads the head) between them, with few workgroups (the next head waits for a slow sweep) and many."""
+  from sisua_amd import _hip
+  from tests.util import make_pair, synth_counts
+  spec, cfg = make_pair(model="vae", n_genes=4500, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=16)
+  x = synth_counts(512, 4500, sparsity=0.9, seed=11, max_count=500)
+  B = 96
+  rng = np.random.default_rng(3)
+  o1 = np.concatenate([rng.permutation(512)[:B] for _ in range(6)]).astype(np.int32)
+  o2 = np.concatenate([rng.permutation(512)[:B] for _ in range(5)]).astype(np.int32)
+  runs = []
+  for sweep, wgs in ((False, None), (True, None), (True, 8), (True, 600)):
+    if wgs:
+      _hip.set_tuning("adam_sweep_wgs", wgs)
+    e = Engine(cfg, max_batch=128, init=False)
+    e.set_params(so.init_params(spec))
+    e.set_flag("head_sweep", sweep)
+    e.upload(x, cell_id_base=7, storage="u16")
+    assert e.head_fused_bytes(B) > 0
+    e.train_steps(o1, 6, B, graph=False)
+    h1 = {k: np.asarray(v).copy() for k, v in e.metrics_history(6).items()}
+    ev = e.eval_step(o2[:B])["loss"]
+    z = e.forward(row_ids=o2[:64])["x_params"]
+    m2 = e.train_steps(o2, 5, B, graph=False, metrics=True)
+    h2 = {k: np.asarray(v).copy() for k, v in e.metrics_history(5).items()}
+    one = e.train_step(o1[:B])["loss"]           # a single-step call, then a captured one
+    two = e.train_step(o1[B:2 * B], graph=True)["loss"]
+    runs.append((h1, ev, z, m2, h2, one, two, e.get_params(0), e.get_params(2), e.get_params(3)))
+    e.close()
+  ref = runs[0]
+  for r in runs[1:]:
+    for k in ref[0]:
+      assert np.array_equal(ref[0][k], r[0][k]) and np.array_equal(ref[4][k], r[4][k]), k
+    assert ref[1] == r[1] and np.array_equal(ref[2], r[2]) and ref[3] == r[3] and ref[5] == r[5] and ref[6] == r[6]
+    for which in (7, 8, 9):
+      for k in ref[which]:
+        assert np.array_equal(ref[which][k], r[which][k]), (which, k)
+
+
 def test_wide_panel_first_step_as_a_graph(Engine):
   """The fused head's launch inside a stream capture on the very FIRST step of a model (its dynamic-LDS limit is set at model creation, not at
   the first launch): the captured step equals the eager step of a second engine bit for bit."""
