@@ -38,7 +38,6 @@
 
 #include "smx_internal.h"
 #include "smx_loss.h"
-#include "smx_adam.h"
 #include "../../include/sisua_hip.h"
 
 namespace smx {
@@ -97,9 +96,6 @@ __device__ inline smx_bf16x8 hf_load8h(__amdgpu_buffer_rsrc_t r, int vo, int so)
 __device__ inline void hf_store8h(smx_bf16x8 v, __amdgpu_buffer_rsrc_t r, int vo, int so) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(hf_u32x4, v), r, vo, so, 0);
 }
-__device__ inline void hf_store4(float4 v, __amdgpu_buffer_rsrc_t r, int vo, int so) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(hf_u32x4, v), r, vo, so, 0);
-}
 __device__ inline void hf_store1(float v, __amdgpu_buffer_rsrc_t r, int vo, int so) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, vo, so, 0);
 }
@@ -123,7 +119,7 @@ struct HfQueue {
 #ifndef SMX_HF_STAMP_WAVE
 #define SMX_HF_STAMP_WAVE 0
 #endif
-template <int LK, int U16, int VW, int LAZY>
+template <int LK, int U16, int VW>
 __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedArgs a) {
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
   constexpr int NSUB = 2 * NP;             // 16-column groups of a tile's rho axis
@@ -168,8 +164,6 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
   const int wgo = (int)((wt * a.ldw + 4 * wc4) * 4);   // this thread's float4 of a W tile (bytes): rows wt, wt + RPT, ... of every plane
   const long wbytes = 128L * a.ldw * 4;
   const __amdgpu_buffer_rsrc_t rW = hf_rsrc(a.W, wbytes), rdW = hf_rsrc(a.dW, wbytes);
-  const __amdgpu_buffer_rsrc_t rM = hf_rsrc(LAZY ? a.lz_m : a.W, wbytes), rV = hf_rsrc(LAZY ? a.lz_v : a.W, wbytes);
-  const float lz_clip = LAZY ? *a.lz_clip : 0.f, lz_lr = LAZY ? a.lz_state->lr_t : 0.f;
   const __amdgpu_buffer_rsrc_t rbias = hf_rsrc(a.bias, a.ldw * 4), rdb = hf_rsrc(a.db, a.ldw * 4);
   const __amdgpu_buffer_rsrc_t rllk = hf_rsrc(a.llk_part, (long)a.B * a.n_gt * 4), rtab = hf_rsrc(a.dtab, SMX_HEAD_FUSED_TAB_BYTES);
 
@@ -303,25 +297,6 @@ __global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_kernel(HeadFusedA
     for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) bq[p][hf] = hf_load4(rbias, 16 * g, (p * a.Gp + n0 + 16 * hf) * 4);
-    if (LAZY) {
-      // ---- the update the step before left to this launch: clip + Adam on this thread's quads of the tile (its gradient is what dW holds
-      // until this tile's own is stored below barrier B), W and the moments stored back, the new W split below --------------------------
-      float4 gq[NWL], mq[NWL], vq[NWL];
-#pragma unroll
-      for (int u = 0; u < NWL; ++u) {
-        const int so = (int)((tile * 32 + (long)(RPT * (u % UPP)) * a.ldw + (long)(u / UPP) * a.Gp) * 4);
-        gq[u] = hf_load4(rdW, wgo, so); mq[u] = hf_load4(rM, wgo, so); vq[u] = hf_load4(rV, wgo, so);
-      }
-#pragma unroll
-      for (int u = 0; u < NWL; ++u) {
-        const int so = (int)((tile * 32 + (long)(RPT * (u % UPP)) * a.ldw + (long)(u / UPP) * a.Gp) * 4);
-        const smx_f32x4 g4 = __builtin_bit_cast(smx_f32x4, gq[u]);
-        smx_f32x4 m4 = __builtin_bit_cast(smx_f32x4, mq[u]), v4 = __builtin_bit_cast(smx_f32x4, vq[u]), p4 = __builtin_bit_cast(smx_f32x4, wreg[u]);
-        adam_apply4(a.lz_b1, a.lz_b2, a.lz_eps, lz_clip, lz_lr, g4, m4, v4, p4);
-        wreg[u] = __builtin_bit_cast(float4, p4);
-        hf_store4(wreg[u], rW, wgo, so); hf_store4(__builtin_bit_cast(float4, m4), rM, wgo, so); hf_store4(__builtin_bit_cast(float4, v4), rV, wgo, so);
-      }
-    }
     // ---- W tile -> bf16 x 3 image (the previous tile's readers are past their last barrier) ---------------------------
 #pragma unroll
     for (int u = 0; u < NWL; ++u) {
@@ -513,12 +488,8 @@ static int launch_hf(hipStream_t st, const HeadFusedArgs& a, int grid) {
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
   const size_t lds = (size_t)2 * 3 * NP * 8192 + (size_t)8 * 32 * NP * 4;
   { const int rc = head_fused_prepare(); if (rc != SMX_OK) return rc; }
-  const bool lazy = a.lz_clip != nullptr;
-  if (lazy && !(a.lz_m && a.lz_v && a.lz_state)) { set_error("head_fused: the deferred update needs the moments and the step state"); return SMX_ERR_INVALID; }
-  if (a.x_u16 && lazy) hipLaunchKernelGGL((head_fused_kernel<LK, 1, SMX_HF_VW, 1>), dim3((unsigned)grid), dim3(512 / SMX_HF_VW), lds, st, a);
-  else if (a.x_u16) hipLaunchKernelGGL((head_fused_kernel<LK, 1, SMX_HF_VW, 0>), dim3((unsigned)grid), dim3(512 / SMX_HF_VW), lds, st, a);
-  else if (lazy) hipLaunchKernelGGL((head_fused_kernel<LK, 0, SMX_HF_VW, 1>), dim3((unsigned)grid), dim3(512 / SMX_HF_VW), lds, st, a);
-  else hipLaunchKernelGGL((head_fused_kernel<LK, 0, SMX_HF_VW, 0>), dim3((unsigned)grid), dim3(512 / SMX_HF_VW), lds, st, a);
+  if (a.x_u16) hipLaunchKernelGGL((head_fused_kernel<LK, 1, SMX_HF_VW>), dim3((unsigned)grid), dim3(512 / SMX_HF_VW), lds, st, a);
+  else hipLaunchKernelGGL((head_fused_kernel<LK, 0, SMX_HF_VW>), dim3((unsigned)grid), dim3(512 / SMX_HF_VW), lds, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
@@ -529,13 +500,9 @@ int head_fused_prepare() {
   static bool done = false;
   if (done) return SMX_OK;
 #define SMX_HF_ATTR(LK, NP)                                                                                                                         \
-  SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<LK, 0, SMX_HF_VW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+  SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<LK, 0, SMX_HF_VW>), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                               2 * 3 * NP * 8192 + 8 * 32 * NP * 4));                                                                                \
-  SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<LK, 1, SMX_HF_VW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                              2 * 3 * NP * 8192 + 8 * 32 * NP * 4));                                                                                \
-  SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<LK, 0, SMX_HF_VW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                              2 * 3 * NP * 8192 + 8 * 32 * NP * 4));                                                                                \
-  SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<LK, 1, SMX_HF_VW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+  SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<LK, 1, SMX_HF_VW>), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                               2 * 3 * NP * 8192 + 8 * 32 * NP * 4))
   SMX_HF_ATTR(SMX_LLK_NB, 2); SMX_HF_ATTR(SMX_LLK_ZINB, 3); SMX_HF_ATTR(SMX_LLK_NBD, 2); SMX_HF_ATTR(SMX_LLK_ZINBD, 3);
 #undef SMX_HF_ATTR

@@ -234,7 +234,7 @@ int launch_metrics(hipStream_t st, const MetricsArgs& a);
 #define SMX_SQR_MAX 16             // reduce riders per BatchNorm-backward launch
 #define SMX_SQR_PER_TENSOR 8       // ... and per tensor
 #define SMX_SQR_MIN_SLOTS 4096     // tensors with fewer sum-of-squares slots are summed by the optimiser's workgroups themselves
-#define SMX_SQ_SMALL_TENSOR 65536   // floats: below this a workgroup re-derives the tensor's norm by itself
+#define SMX_SQ_SMALL_TENSOR 131072  // floats: below this a workgroup re-derives the tensor's norm by itself (the output bias of three planes up to 43 000 genes)
 struct OptChunk { int32_t tensor; int32_t offset; int32_t count; int32_t first_chunk; int32_t n_chunks; int32_t tensor_count; int32_t pad[2]; };
 struct AdamArgs {
   // ELBO scalars ride along as one extra workgroup of the gradient-norm kernel
@@ -261,9 +261,6 @@ struct AdamArgs {
   // data parallel, world > 1: the moving BatchNorm statistics take the all-reduced batch statistics (mean over the ranks)
   // in extra workgroups of the gradient-norm launch (it was a launch of its own)
   float* bn_moving = nullptr; const float* bn_batch = nullptr; int bn_total = 0; float bn_inv_world = 1.f, bn_momentum = 0.99f;
-  // one extra workgroup of the update launch leaves the gradient factor (and the norm) of chunk lazy_chunk's tensor in *lazy_clip_out: that
-  // tensor's chunks are skipped here (the gap) and applied by the tensor's next reader (HeadFusedArgs::lz_clip)
-  float* lazy_clip_out = nullptr; int lazy_chunk = -1;
 };
 int launch_adam(hipStream_t st, const AdamArgs& a);
 int launch_adam_sweep(hipStream_t st, const AdamArgs& a, int first, int count, int wgs);   // chunks [first, first + count) by `wgs` persistent workgroups
@@ -549,10 +546,12 @@ int launch_bigk_reduce(hipStream_t st, const float* part, long slab_stride, int 
 // ---- the whole output head of a training step at a wide panel in one launch (smx_headfused.hip) ----
 #define SMX_HEAD_FUSED_TAB_BYTES (8 * 12 * 64 * 16)
 #define SMX_HEAD_FUSED_MIN_GENES 4096
-// persistent workgroups of the heads' background optimiser sweep (smx_step.hip: head_sweep_start).  Measured at 128 x 20 000 (c5-shard, us per step;
-// 182.3 without): 48 -> 245, 64 -> 176-215 (the next output head waits for the sweep), 96 -> 178-182, 128 -> 175.3-176.3, 160 -> 177.5-181, 192 -> 176.8,
-// 256 -> 182.2, 512 -> 185.7, 1024 -> 191.1 (the small dependent launches beside it slow down by more than it hides)
-#define SMX_HEAD_SWEEP_WGS 128   // padded genes from which the fused form replaces fused head + bigk (d d) + panel (dW)
+// the heads' background optimiser sweep (smx_step.hip: head_sweep_start): from this many 4096-float chunks of head parameters, one persistent
+// workgroup per so many chunks.  Measured at 128 x 20 000 (1880 chunks; c5-shard, us per step; 182.3 without), by workgroups: 48 -> 245,
+// 64 -> 176-215 (the next output head waits for the sweep), 96 -> 178-182, 128 -> 175.3-176.3, 160 -> 177.5-181, 192 -> 176.8, 256 -> 182.2,
+// 512 -> 185.7, 1024 -> 191.1 (the small dependent launches beside it slow down by more than it hides)
+#define SMX_HEAD_SWEEP_MIN_CHUNKS 1536
+#define SMX_HEAD_SWEEP_CHUNKS_PER_WG 15   // padded genes from which the fused form replaces fused head + bigk (d d) + panel (dW)
 struct HeadFusedArgs {
   const float* D = nullptr; int ldd = 0;            // decoder output [B][ldd], 128 columns
   const float* W = nullptr; long ldw = 0;           // [128][k * Gp]
@@ -567,12 +566,6 @@ struct HeadFusedArgs {
   float grad_scale = 1.f;
   int n_gt = 0;                                     // set by the launcher
   long long* dbg = nullptr;                         // development builds (SMX_HF_STAMPS): 128 cycle stamps
-  // the update of W that the step before left to this launch (smx_step.hip: "the output head's update, applied by its next reader"): every
-  // workgroup applies clip + Adam to the tile of W it is about to read -- gradient = what dW still holds, moments lz_m / lz_v laid out as W,
-  // *lz_clip = the factor on the gradient (the optimiser launch of the step before worked it out), lz_state->lr_t that step's step size -- and
-  // stores W and the moments back.  lz_clip == nullptr: W is read as it is
-  const float* lz_clip = nullptr; float* lz_m = nullptr; float* lz_v = nullptr; const StepState* lz_state = nullptr;
-  float lz_b1 = 0.f, lz_b2 = 0.f, lz_eps = 0.f;
 };
 bool head_fused_supported(int B, int Hp, int Gp, int k);
 int head_fused_grid(int Gp);

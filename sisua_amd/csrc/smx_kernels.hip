@@ -2138,14 +2138,8 @@ __device__ inline void sq_reduce_body(const float* sl, int cnt, float* dst) {
 }
 
 __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
-  if ((int)blockIdx.x >= a.n_launch) {
-    if (a.use_sq && a.with_metrics && (int)blockIdx.x == a.n_launch) {  // use_sq form: the ELBO scalars ride along here
-      metrics_body(a.metrics);
-      return;
-    }
-    // the factor of a tensor whose update its next reader applies (smx_step.hip: lazy_*)
-    const float clip = adam_tensor_clip<256>(a, a.chunks[a.lazy_chunk], a.lazy_chunk);
-    if (threadIdx.x == 0) *a.lazy_clip_out = clip;
+  if ((int)blockIdx.x == a.n_launch) {  // use_sq form: the ELBO scalars ride along here
+    metrics_body(a.metrics);
     return;
   }
   adam_chunk_body(a, (int)blockIdx.x >= a.gap_from ? (int)blockIdx.x + a.gap_len : (int)blockIdx.x);
@@ -2185,12 +2179,12 @@ int launch_adam_sweep(hipStream_t st, const AdamArgs& a, int first, int count, i
 // an agent-scope acquire/release round across the 8 XCDs costs far more than a kernel boundary (1.5 us).
 int launch_adam(hipStream_t st, const AdamArgs& a) {
   if (a.use_sq) {   // norms come from the weight-gradient products: no pass over the gradient buffer
-    hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_launch + (a.with_metrics ? 1 : 0) + (a.lazy_clip_out ? 1 : 0)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_launch + (a.with_metrics ? 1 : 0)), dim3(256), 0, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
   hipLaunchKernelGGL(grad_sqsum_kernel, dim3(a.n_chunks + (a.with_metrics ? 1 : 0) + (a.bn_total + 255) / 256), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_launch + (a.lazy_clip_out ? 1 : 0)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_launch), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }

@@ -171,15 +171,9 @@ struct smx_model {
   // the next step's (smx_step.hip: head_sweep_start / head_sweep_join)
   hipStream_t st_side = nullptr;
   hipEvent_t ev_hf = nullptr, ev_sweep = nullptr;
-  bool sweep_pending = false;
+  bool sweep_pending = false;          // the main stream has not been ordered behind the last sweep yet
   bool ev_hf_fresh = false;            // ev_hf was recorded behind THIS step's output head
   bool head_fused_bwd_done = false;   // this backward pass found dW / db / d d of the output head done by the forward pass's launch
-  // wide panels, one GPU, eager steps: the output head's update applied by its next reader -- the next step's output-head launch
-  // (smx_step.hip: lazy_*; smx_headfused.hip: LAZY)
-  float* lazy_clip = nullptr;          // [2] the gradient factor of W_out, per step parity
-  bool lazy_defer = false;             // this step's optimiser launch skips W_out and leaves its factor in lazy_clip[par]
-  bool lazy_pending = false;           // W_out / its moments in memory are one update behind
-  int lazy_par = 0;                    // parity (step state, factor) of the pending update
   bool x_u16 = false;   // the resident matrix is stored as uint16 counts (smx_dataset_upload_u16)
   // compact sparse store (smx_dataset_upload_csr): CSR arrays resident, the minibatch's rows expanded per pass into xbatch
   int64_t* csr_indptr = nullptr; int32_t* csr_cols = nullptr; float* csr_vals = nullptr; bool x_csr = false;

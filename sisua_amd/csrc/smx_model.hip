@@ -354,7 +354,6 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     float* tab = nullptr;
     if ((rc = dmalloc(&tab, (size_t)SMX_HEAD_FUSED_TAB_BYTES / 4))) return fail(rc);
     m->hf_tab = tab;
-    if ((rc = dmalloc(&m->lazy_clip, 2))) return fail(rc);
     if ((rc = head_fused_prepare())) return fail(rc);
   }
   if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
@@ -469,7 +468,6 @@ int smx_model_destroy(smx_model* m) {
   for (auto& kv : m->injected) fr(kv.second.d);
   if (m->st_comm) { hipStreamSynchronize(m->st_comm); hipStreamDestroy(m->st_comm); }
   if (m->st_side) { hipStreamSynchronize(m->st_side); hipStreamDestroy(m->st_side); }
-  if (m->lazy_clip) hipFree(m->lazy_clip);
   if (m->ev_hf) hipEventDestroy(m->ev_hf);
   if (m->ev_sweep) hipEventDestroy(m->ev_sweep);
   if (m->ev_c1) hipEventDestroy(m->ev_c1);

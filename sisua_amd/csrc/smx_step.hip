@@ -299,28 +299,42 @@ void attach_early_adam(smx_model* m, BnBwdArgs& b) {
 // smx_train_steps call wait for the sweep's event, so every other entry point finds the stream order it always had.
 // What it reads stays put meanwhile: the head's gradients and sum-of-squares slots are rewritten by the next output head only, and the
 // step state of parity p by the optimiser launch of the step after next.
-static int head_sweep_wgs(const smx_model* m) { return m->flags.head_sweep ? std::max((int)tuning("adam_sweep_wgs", SMX_HEAD_SWEEP_WGS), 1) : 0; }
+// It pays from ~6 M head parameters: a second queue with work in it costs every launch of the main stream ~1.5 us (the step at 4096 genes:
+// 99.8 -> 117.3 us with the sweep, at 12 000: 139.9 -> 145.3, at 20 000: 181.6 -> 177.7; tools/head_fused_width_ab.py), which the hidden update
+// has to buy back.  Workgroups: one per SMX_HEAD_SWEEP_CHUNKS_PER_WG chunks -- the sweep should last most of the window between two output heads.
+static int head_sweep_wgs(const smx_model* m) {
+  if (!m->flags.head_sweep) return 0;
+  const int chunks = m->n_chunks - m->chunk_first_head;
+  if (chunks < (int)tuning("adam_sweep_min_chunks", SMX_HEAD_SWEEP_MIN_CHUNKS)) return 0;
+  const int forced = (int)tuning("adam_sweep_wgs", 0);
+  return forced > 0 ? forced : std::min(std::max(chunks / SMX_HEAD_SWEEP_CHUNKS_PER_WG, 64), 256);
+}
+// the main stream behind the sweep (its event)
 int head_sweep_join(smx_model* m) {
   if (!m->sweep_pending) return SMX_OK;
   m->sweep_pending = false;
   SMX_HIP(hipStreamWaitEvent(m->st, m->ev_sweep, 0));
   return SMX_OK;
 }
+// decided where the output head is launched (forward_pass), acted on where its gradients are known to be final (backward_pass)
 static bool head_sweep_ok(smx_model* m) {
-  if (head_sweep_wgs(m) <= 0 || dp_active(m) || m->capturing || !m->timing_label.empty() || m->use_injected || m->lab_deferred) return false;
+  if (head_sweep_wgs(m) <= 0 || dp_active(m) || m->capturing || !m->timing_label.empty() || m->use_injected || m->n_heads > 0) return false;
   if (!m->sq_slots || m->chunk_first_head >= m->n_chunks || tuning_on("no_sq_partials") || tuning_on("no_adam_early")) return false;
-  for (size_t t = (size_t)m->t_outW[0]; t < m->tensors.size(); ++t)
+  for (size_t t = (size_t)m->t_outW[0] + 1; t < m->tensors.size(); ++t)   // (W_out's slots come from the output head's launch itself)
     if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) return false;
   return true;
 }
-// after the output head's launch (ev_hf recorded behind it on the main stream)
+static int head_sweep_prepare(smx_model* m) {
+  if (m->st_side) return SMX_OK;
+  int lo = 0, hi = 0;
+  SMX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  SMX_HIP(hipStreamCreateWithPriority(&m->st_side, hipStreamNonBlocking, lo));
+  SMX_HIP(hipEventCreateWithFlags(&m->ev_sweep, hipEventDisableTiming));
+  SMX_HIP(hipEventCreateWithFlags(&m->ev_hf, hipEventDisableTiming));
+  return SMX_OK;
+}
+// behind the output head's launch (ev_hf) on the second stream
 static int head_sweep_start(smx_model* m) {
-  if (!m->st_side) {
-    int lo = 0, hi = 0;
-    SMX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    SMX_HIP(hipStreamCreateWithPriority(&m->st_side, hipStreamNonBlocking, lo));
-    SMX_HIP(hipEventCreateWithFlags(&m->ev_sweep, hipEventDisableTiming));
-  }
   AdamArgs a;
   fill_rider_adam(m, a);
   SMX_HIP(hipStreamWaitEvent(m->st_side, m->ev_hf, 0));
@@ -330,33 +344,6 @@ static int head_sweep_start(smx_model* m) {
   // the optimiser launch skips these chunks; no launch of the backward chain carries any of them
   m->adam_early_from = m->chunk_first_head; m->adam_early_to = m->n_chunks;
   m->adam_early_pending = false; m->adam_rest_from = m->adam_rest_to = 0; m->adam_ride_b = 0;
-  return SMX_OK;
-}
-
-// ---- wide panels, one GPU, eager steps: the output head's update, applied by its next reader ----
-// W_out is 3/4 of the parameters at the C5 width and its clip + Adam update 215 MB of traffic in a launch of its own, while the output head's
-// launch (smx_headfused.hip) is bound by instruction issue and uses a third of the memory bandwidth.  When another step of the same call
-// follows, the optimiser launch skips W_out (its chunks are the launch's gap) and one extra workgroup leaves the tensor's gradient factor in
-// lazy_clip[parity]; the NEXT step's output-head launch applies the update to each tile of W right before it reads it (same arithmetic per
-// element: smx_adam.h adam_apply4 -- same bits).  The gradient it needs is what dW still holds (a tile's new gradient is stored later in the
-// same workgroup), the step size is the step state of the parity before, which nobody rewrites until the optimiser launch after next.
-// Anything else that is about to read W_out with the update pending (an evaluation pass, the separate-launch head, the end of the call after
-// an error) applies it first with the optimiser's own kernel: lazy_flush.
-static int w_out_chunks(smx_model* m) { return (int)((m->tensors[(size_t)m->t_outW[0]].count + (size_t)m->chunks_floats - 1) / (size_t)m->chunks_floats); }
-static bool lazy_ok(smx_model* m) {
-  return tuning_on("head_lazy") && m->lazy_clip && m->seq_prepare_next && !dp_active(m) && !m->capturing && m->timing_label.empty() && !m->use_injected && !m->lab_deferred &&
-         m->chunk_first_head < m->n_chunks;
-}
-int lazy_flush(smx_model* m) {
-  if (!m->lazy_pending) return SMX_OK;
-  m->lazy_pending = false;
-  AdamArgs a;
-  fill_adam_args(m, a);
-  a.state = m->state3 + m->lazy_par;
-  a.master = nullptr; a.with_metrics = 0;
-  a.gap_from = 0; a.gap_len = m->chunk_first_head; a.n_launch = w_out_chunks(m);   // workgroup i takes chunk chunk_first_head + i
-  if (!a.use_sq) { set_error("the pending update of the output head needs the products' sum-of-squares partials"); return SMX_ERR_INVALID; }
-  SMX_CHECK(launch_adam(m->st, a));
   return SMX_OK;
 }
 
@@ -631,7 +618,6 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   // ---- decoder ----
   SMX_CHECK(mlp_forward(m, m->dec, ps, m->z, m->Dp, false, "", -1, front_ok ? &front_la : nullptr));
   SMX_CHECK(head_sweep_join(m));   // (the heads' update of the step before, if it is still under way on the second stream)
-  if (m->lazy_pending && !(with_loss && backward && !m->scvi && use_head_loss(m, ps.B))) SMX_CHECK(lazy_flush(m));   // (not the training head: apply it now)
   const MlpLayer& dL = m->dec.back();
   const long ldp = (long)m->k * m->Gp;
   if (m->scvi) {
@@ -709,19 +695,10 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     // a wide panel: the whole head -- product, likelihood, dW / db and the per-workgroup slabs of d d -- in ONE launch + the ordered
     // sum of the slabs (smx_headfused.hip); backward_pass then finds its head products done
     m->head_fused = false;
-    const bool fused = m->flags.head_fused && hl.bf16x3 && m->hf_tab && m->bigk_part && m->n_heads == 0 && !m->fvae && dL.out_p == 128 && tw.ld == (long)m->k * m->Gp &&
+    if (m->flags.head_fused && hl.bf16x3 && m->hf_tab && m->bigk_part && m->n_heads == 0 && !m->fvae && dL.out_p == 128 && tw.ld == (long)m->k * m->Gp &&
         head_fused_supported(ps.B, dL.out_p, m->Gp, m->k) && (size_t)head_fused_grid(m->Gp) * (size_t)ps.B * 128 <= m->bigk_floats &&
-        !(!m->capturing && m->timing_label == "out_head_product");
-    if (!fused || m->capturing || !m->timing_label.empty()) SMX_CHECK(lazy_flush(m));
-    if (fused) {
+        !(!m->capturing && m->timing_label == "out_head_product")) {
       HeadFusedArgs hf;
-      if (m->lazy_pending) {   // the update of W_out the step before left to this launch
-        const size_t off = m->tensors[(size_t)m->t_outW[0]].offset;
-        hf.lz_clip = m->lazy_clip + m->lazy_par; hf.lz_m = m->adam_m + off; hf.lz_v = m->adam_v + off; hf.lz_state = m->state3 + m->lazy_par;
-        hf.lz_b1 = c.adam_beta1; hf.lz_b2 = c.adam_beta2; hf.lz_eps = c.adam_eps;
-        m->lazy_pending = false;
-        { static int n_dbg = 0; if (n_dbg++ < 2 && getenv("SMX_LAZY_DBG")) fprintf(stderr, "[lazy] head launch applies the pending update (par %d)\n", m->lazy_par); }
-      }
       hf.D = dL.out_buf; hf.ldd = dL.out_p; hf.W = hl.W; hf.ldw = tw.ld; hf.bias = hl.bias;
       hf.X = ps.Xsrc; hf.ldx = m->Gp; hf.rows = ps.xrows; hf.x_u16 = ps.x_u16;
       hf.dW = G_(m, m->t_outW[0]); hf.db = G_(m, m->t_outb[0]);
@@ -735,8 +712,8 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
         Timed t(m, "out_head");
         for (int r = 0; r < reps; ++r) SMX_CHECK(launch_head_fused(m->st, hf, &n_slabs, &m->head_fused_sq));
       }
-      if (head_sweep_wgs(m) > 0 && !m->capturing && m->timing_label.empty() && !dp_active(m)) {
-        if (!m->ev_hf) SMX_HIP(hipEventCreateWithFlags(&m->ev_hf, hipEventDisableTiming));
+      if (hf.sq_part && head_sweep_ok(m)) {   // this step's update of the heads: a sweep on the second stream, started behind this launch
+        SMX_CHECK(head_sweep_prepare(m));
         SMX_HIP(hipEventRecord(m->ev_hf, m->st));
         m->ev_hf_fresh = true;
       }
@@ -1202,13 +1179,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
       }
     }
     m->adam_early_pending = true;   // dW / db of every head are final now
-    m->lazy_defer = false;
-    if (m->head_fused_bwd_done && lazy_ok(m)) {
-      // W_out's chunks are the optimiser launch's gap; nothing of the heads rides with the backward chain (the bias chunks stay with that launch)
-      m->lazy_defer = true;
-      m->adam_early_pending = false; m->adam_rest_from = m->adam_rest_to = 0; m->adam_ride_b = 0;
-      m->adam_early_from = m->chunk_first_head; m->adam_early_to = m->chunk_first_head + w_out_chunks(m);
-    } else if (m->head_fused_bwd_done && m->ev_hf_fresh && head_sweep_ok(m)) SMX_CHECK(head_sweep_start(m));
+    if (m->head_fused_bwd_done && m->ev_hf_fresh) SMX_CHECK(head_sweep_start(m));
     m->ev_hf_fresh = false;
     m->head_fused_bwd_done = false;
     if (dp_overlap(m)) {  // head gradients are final: reduce them while the rest of backward runs
@@ -1414,7 +1385,6 @@ int optimizer_pass(smx_model* m) {
     a.gap_from = m->n_chunks; a.gap_len = 0; a.n_launch = m->n_chunks;
   }
   m->adam_early_from = -1;
-  if (m->lazy_defer) { a.lazy_chunk = m->chunk_first_head; a.lazy_clip_out = m->lazy_clip + m->par; }
   if (m->have_pending_metrics) { a.metrics = m->pending_metrics; a.with_metrics = 1; m->have_pending_metrics = false; }
   a.master = master_state(m); a.lr = c.lr; a.batch = m->seq_batch;
   if (dp_active(m)) { a.hist_dp = m->mhist; a.tail_metrics = m->grads + m->tail_off_metrics; }
@@ -1422,7 +1392,6 @@ int optimizer_pass(smx_model* m) {
   if (a.prepare_next) { a.next_state = m->state3 + (m->par ^ 1); a.next_rows = m->rows2[m->par ^ 1]; a.order = m->order; }
   Timed t(m, "adam");
   SMX_CHECK(launch_adam(m->st, a));
-  if (m->lazy_defer) { m->lazy_pending = true; m->lazy_par = m->par; m->lazy_defer = false; }
   return SMX_OK;
 }
 
@@ -1625,7 +1594,6 @@ int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t
   int rc = SMX_OK;
   for (int s = 0; s < n_steps && rc == SMX_OK; ++s) rc = launch_train(m, batch, use_graph != 0, s, n_steps);
   { const int rj = smx::head_sweep_join(m); if (rc == SMX_OK) rc = rj; }   // every other entry point sees one stream
-  { const int rj = smx::lazy_flush(m); if (rc == SMX_OK) rc = rj; }        // (only after an error: the last step of a call defers nothing)
   if (rc != SMX_OK) return rc;
   if (m->use_injected) { m->use_injected = false; }
   // a non-finite loss / gradient norm is REPORTED (out->nan_flag), not an error of the call: terminate_on_nan

@@ -322,7 +322,7 @@ def test_wide_panel_heads_update_as_a_background_sweep(Engine):
   """Flag head_sweep (smx_step.hip: head_sweep_start / head_sweep_join): with the fused head, clip + Adam of the heads' tensors runs as a fixed
   number of workgroups on a second stream between this step's output head and the next step's.  Same arithmetic per element, the tensor's norm
   summed in the same order: losses of every step, parameters and both Adam moments equal the riders + optimiser-launch form BIT FOR BIT -- over
-  two multi-step calls with an evaluation pass and a forward pass (which reads the head) between them, with few workgroups (the next head waits for a slow sweep) and many."""
+  two multi-step calls with an evaluation pass and a forward pass (which reads the head) between them, with few workgroups (the next head waits for a slow sweep) and many.  (The 20 000-gene width, where the sweep is the default: test_c5_*.)"""
   from sisua_amd import _hip
   from tests.util import make_pair, synth_counts
   spec, cfg = make_pair(model="vae", n_genes=4500, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=16)
@@ -332,6 +332,7 @@ def test_wide_panel_heads_update_as_a_background_sweep(Engine):
   o1 = np.concatenate([rng.permutation(512)[:B] for _ in range(6)]).astype(np.int32)
   o2 = np.concatenate([rng.permutation(512)[:B] for _ in range(5)]).astype(np.int32)
   runs = []
+  _hip.set_tuning("adam_sweep_min_chunks", 0)   # (by default the sweep is taken from ~6 M head parameters: 20 000 genes x 3 planes)
   for sweep, wgs in ((False, None), (True, None), (True, 8), (True, 600)):
     if wgs:
       _hip.set_tuning("adam_sweep_wgs", wgs)
