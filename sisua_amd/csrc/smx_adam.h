@@ -24,8 +24,18 @@ __device__ inline float adam_tensor_clip(const AdamArgs& a, const OptChunk& ch, 
   } else if (a.use_sq) {
     const int cnt = a.sq_count[ch.tensor];
     if (cnt > 0) {   // partial sums written by the weight-gradient product's workgroups
+      // (a thread's slots eight at a time in flight -- unconditional loads from a clamped index, masked at the add, added in the same order
+      // as one by one: same bits.  As a rider of a 5-10 us launch a workgroup's LIFE is what counts, and 7 dependent round trips for the
+      // 1672 slots of the one-launch output head were most of it)
       const float* sl = a.sq_slots + a.sq_first[ch.tensor];
-      for (int k = threadIdx.x; k < cnt; k += 256) s += sl[k];
+      for (int k0 = threadIdx.x; k0 < cnt; k0 += 8 * 256) {
+        float q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = sl[min(k0 + 256 * u, cnt - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + 256 * u < cnt) s += q[u];
+      }
     } else {         // small tensor (bias, BatchNorm scale / shift): sweep its whole gradient
       const float4* t4 = reinterpret_cast<const float4*>(a.grads + a.chunks[ch.first_chunk].offset);
       for (int k = threadIdx.x; k < ch.tensor_count / 4; k += 256) {
