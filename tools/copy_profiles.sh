@@ -14,6 +14,7 @@ cp $S/bench_c5_full.json $P/${T}_bench_c5_full_residency.json
 cat $S/check_roofline_8kly.txt $S/check_roofline_c5-shard.txt > $P/${T}_check_roofline.txt
 cp $S/kernel_stats_summary_8kly.txt $P/${T}_kernel_stats_summary.txt
 cp $S/kernel_stats_summary_c5-shard.txt $P/${T}_kernel_stats_summary_c5-shard.txt
+cp $S/sweep_timeline_c5-shard.txt $P/${T}_c5shard_sweep_timeline.txt 2>/dev/null
 cp $S/rocprofv3_kernel_stats_8kly.csv $P/${T}_rocprofv3_kernel_stats.csv
 cp $S/rocprofv3_kernel_stats_c5-shard.csv $P/${T}_rocprofv3_kernel_stats_c5shard.csv
 cp $S/pmc_summary.json $P/${T}_pmc_likelihood_kernels.json

@@ -19,6 +19,8 @@ for w in 8kly c5-shard; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$w -- python3 bench.py --workload $w --steps 300 --warmup 30 --no-cpu-baseline --no-c5-entry > $O/bench_under_rocprof_$w.json 2> $O/rocprof_$w.err
   python3 tools/prof_summary.py $O/trace_$w > $O/kernel_stats_summary_$w.txt 2>&1
   cp $(find $O/trace_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
+  # (the timed steps of a wide panel run the heads' optimiser update as a background sweep on a second queue: their timeline, queue by queue)
+  [ $w = c5-shard ] && python3 tools/sweep_timeline.py $O/trace_$w > $O/sweep_timeline_$w.txt 2>&1
   rm -rf $O/trace_$w
   python3 bench.py --workload $w --steps 300 --warmup 30 --no-cpu-baseline --no-c5-entry > $O/bench_$w.json 2> $O/bench_$w.err
   { echo "## $w: bench line of the profiled run itself vs the rocprofv3 summary of that run (the check)"; python3 tools/check_roofline.py $O/bench_under_rocprof_$w.json $O/rocprofv3_kernel_stats_$w.csv $w;

@@ -23,7 +23,7 @@ if len(starts) > 12:
   cand = [i for i in range(len(starts) - 1) if starts[i + 1] - starts[i] == modal]
   pick = cand[len(cand) // 2]
   a, b = starts[pick] + 1, starts[pick + 1] + 1
-  print(f"# one step: {b - a} kernels")
+  print(f"# one step: {b - a} kernels" + (" (the modal step of the trace; with a background optimiser sweep in the trace -- adam_sweep_kernel -- the timed steps' own timeline is tools/sweep_timeline.py's)" if any("adam_sweep" in n for n in names) else ""))
   prev = None
   t0 = int(rows[a]["Start_Timestamp"])
   for r in rows[a:b]:
