@@ -1,17 +1,13 @@
 // smx_adam.h -- the optimiser's workgroup body (per-tensor clipnorm + Adam over one chunk of the flat buffer),
-// shared by the optimiser launch (smx_kernels.hip) and by the launches that carry chunks as riders: the BatchNorm-backward kernels
-// (smx_kernels.hip) and the latent head's backward product (smx_gemm.hip).
+// shared by the optimiser launch (smx_kernels.hip), by the launches that carry chunks as riders -- the BatchNorm-backward kernels
+// (smx_kernels.hip) and the latent head's backward product (smx_gemm.hip) -- and by the heads' background sweep on the second stream
+// (adam_sweep_body; smx_step.hip: head_sweep_*).
 #pragma once
 #include "smx_device.h"
 #include "smx_internal.h"
 
 namespace smx {
 
-// clip + Adam for one chunk of the flat buffer; NT = 256 threads, or 512 as a rider of a 512-thread launch (the tensor's norm is
-// summed by the first 256 threads in the same order either way: both forms give the same bits).  A thread's first operands are
-// requested BEFORE the norm is reduced and each later round's before the current round's arithmetic: a workgroup lives for 2-4
-// rounds, so the reduction's barrier and the first loads' latency were a third of its life.  (Nontemporal loads / stores of the
-// moments, to keep the weights in the last-level cache, measured slower: c5-shard 198.0 -> 200.0 us, C2 80.4 -> 81.7.)
 typedef float smx_f32x4 __attribute__((ext_vector_type(4)));
 
 // the chunk's tensor: its gradient norm (written once per tensor, by the tensor's first chunk) and the factor its gradients are scaled by.
@@ -74,6 +70,11 @@ __device__ inline void adam_apply4(const AdamArgs& a, float clip, float lr_t, co
   adam_apply4(a.b1, a.b2, a.eps, clip, lr_t, g, m, v, p);
 }
 
+// clip + Adam for one chunk of the flat buffer; NT = 256 threads, or 512 as a rider of a 512-thread launch (the tensor's norm is
+// summed by the first 256 threads in the same order either way: both forms give the same bits).  A thread's first operands are
+// requested BEFORE the norm is reduced and each later round's before the current round's arithmetic: a workgroup lives for 2-4
+// rounds, so the reduction's barrier and the first loads' latency were a third of its life.  (Nontemporal loads / stores of the
+// moments, to keep the weights in the last-level cache, measured slower: c5-shard 198.0 -> 200.0 us, C2 80.4 -> 81.7.)
 template <int NT = 256>
 __device__ inline void adam_chunk_body(const AdamArgs& a, int chunk) {
   const OptChunk ch = a.chunks[chunk];
