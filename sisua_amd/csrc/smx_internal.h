@@ -546,6 +546,7 @@ int launch_bigk_reduce(hipStream_t st, const float* part, long slab_stride, int 
 // ---- the whole output head of a training step at a wide panel in one launch (smx_headfused.hip) ----
 #define SMX_HEAD_FUSED_TAB_BYTES (8 * 12 * 64 * 16)
 #define SMX_HEAD_FUSED_MIN_GENES 4096
+#define SMX_HEAD_FUSED_MAX_CELLS 256   // (one launch per 128 cells)
 // the heads' background optimiser sweep (smx_step.hip: head_sweep_start): from this many 4096-float chunks of head parameters, one persistent
 // workgroup per so many chunks.  Measured at 128 x 20 000 (1880 chunks; c5-shard, us per step; 182.3 without), by workgroups: 48 -> 245,
 // 64 -> 176-215 (the next output head waits for the sweep), 96 -> 178-182, 128 -> 175.3-176.3, 160 -> 177.5-181, 192 -> 176.8, 256 -> 182.2,
@@ -559,16 +560,17 @@ struct HeadFusedArgs {
   const void* X = nullptr; long ldx = 0; const int32_t* rows = nullptr; int x_u16 = 0;   // counts (gathered by row id)
   float* dW = nullptr; float* db = nullptr;         // gradients, laid out as W / bias
   float* part = nullptr; long slab_stride = 0;      // [workgroups][B][128]: per-workgroup slabs of d d
-  float* llk_part = nullptr;                        // [B][Gp / 32]
+  float* llk_part = nullptr;                        // [B][head_fused_chunks(Gp)]
   float* sq_part = nullptr;                         // 8 sum-of-squares slots of dW per workgroup, or nullptr
   void* dtab = nullptr;                             // SMX_HEAD_FUSED_TAB_BYTES of scratch: the waves' split view of d for dW (written and read by the launch)
   int B = 0, G = 0, Gp = 0, likelihood = 0;
   float grad_scale = 1.f;
-  int n_gt = 0;                                     // set by the launcher
+  int n_gt = 0, per_wg = 0, n_chunks = 0;           // set by the launcher: units (gene tiles), units per workgroup, likelihood partials per cell
   long long* dbg = nullptr;                         // development builds (SMX_HF_STAMPS): 128 cycle stamps
 };
 bool head_fused_supported(int B, int Hp, int Gp, int k);
 int head_fused_grid(int Gp);
+int head_fused_chunks(int Gp);   // likelihood partials per cell of a launch (<= 256)
 // the launch (*n_slabs workgroups leave a slab of d d each, *n_sq sum-of-squares slots) and the ordered sum of the slabs into dd_out [B][128]
 int launch_head_fused(hipStream_t st, const HeadFusedArgs& a, int* n_slabs, int* n_sq);
 int launch_head_fused_reduce(hipStream_t st, const HeadFusedArgs& a, int n_slabs, float* dd_out);

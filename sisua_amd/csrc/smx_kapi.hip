@@ -223,8 +223,8 @@ int smx_k_head_fused(int likelihood, int u16, const float* x, const float* d, co
   SMX_REQUIRE(x && d && W && bias && llk && dW && db && dd && B > 0 && G > 0, "bad arguments");
   const int k = llk_planes(likelihood);
   const int Gp = round_up(G, 32), H = 128;
-  SMX_REQUIRE(head_fused_supported(B, H, Gp, k), "head_fused: unsupported shape (B <= 128, G >= 4096 after padding, 2 or 3 planes)");
-  const int grid = head_fused_grid(Gp), n_gt = Gp / 32;
+  SMX_REQUIRE(head_fused_supported(B, H, Gp, k), "head_fused: unsupported shape (B <= 256, G >= 4096 after padding, 2 or 3 planes)");
+  const int grid = head_fused_grid(Gp), n_gt = head_fused_chunks(Gp);
   float *dX = nullptr, *dD = nullptr, *dWt = nullptr, *dBias = nullptr, *dGW = nullptr, *dGb = nullptr, *dPart = nullptr, *dLl = nullptr, *dSq = nullptr, *dDd = nullptr;
   uint16_t* dX16 = nullptr; float* dTab = nullptr;
   int rc;
@@ -272,7 +272,7 @@ int smx_k_head_fused(int likelihood, int u16, const float* x, const float* d, co
     hipMemcpy(h, dDbg, sizeof(h), hipMemcpyDeviceToHost);
     for (int b = 0; b < 2; ++b) {
       fprintf(stderr, "hf stamps block %d: (prologue %lld)", b ? 100 : 0, h[64 * b] - h[64 * b + 63]);
-      for (int i = 1; i < 40 && h[64 * b + i]; ++i) fprintf(stderr, " %lld", h[64 * b + i] - h[64 * b + i - 1]);
+      for (int i = 1; i < 62 && h[64 * b + i]; ++i) fprintf(stderr, " %lld", h[64 * b + i] - h[64 * b + i - 1]);
       fprintf(stderr, "\n");
     }
 

@@ -351,6 +351,7 @@ int setup_pass(smx_model* m, Pass& ps, const int32_t* row_ids, const float* host
                int32_t batch, int training, int sample);
 // smx_predict.hip
 bool stacked_scoring_ok(const smx_model* m);
+bool head_fused_ok(const smx_model* m, int B);   // a training step of B cells takes the one-launch output head (smx_step.hip)
 int stacked_decoder(smx_model* m, const float* z, long rows, float* const* hb, int last_form, float* ht, const float** out, int* out_ld);
 
 }  // namespace smx

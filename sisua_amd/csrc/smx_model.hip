@@ -359,7 +359,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   if ((rc = dmalloc(&m->slab, m->slab_cap)) || (rc = dmalloc(&m->latbuf, B * lat_ld)) || (rc = dmalloc(&m->dlat, B * lat_ld)) ||
       (rc = dmalloc(&m->z, B * m->Dp)) || (rc = dmalloc(&m->noise_eps, B * m->Dp)) || (rc = dmalloc(&m->sig, B * m->Dp)) || (rc = dmalloc(&m->eps, B * m->Dp)) ||
       (rc = dmalloc(&m->kl, B)) || (rc = dmalloc(&m->P, B * ldp)) || (rc = dmalloc(&m->dP, B * ldp)) ||
-      (rc = dmalloc(&m->llk_part, B * (size_t)std::max(loss_chunks_max(m->Gp), head_loss_chunks(m->Gp)))) || (rc = dmalloc(&m->llk_y, B)) || (rc = dmalloc(&m->llk_o, B)) ||
+      (rc = dmalloc(&m->llk_part, B * (size_t)std::max(std::max(loss_chunks_max(m->Gp), head_loss_chunks(m->Gp)), 256))) || (rc = dmalloc(&m->llk_y, B)) || (rc = dmalloc(&m->llk_o, B)) ||
       (rc = dmalloc(&m->rows2[0], B)) || (rc = dmalloc(&m->rows2[1], B)) || (rc = dmalloc(&m->state3, (size_t)3)) ||
       (rc = dmalloc(&m->hostX, B * m->Gp)) || (rc = dmalloc(&m->hostLib, B * 2)) || (rc = dmalloc(&m->hostLgx1, B)))
     return fail(rc);
@@ -629,13 +629,10 @@ int64_t smx_loss_bytes_per_cell(const smx_model* m) {
   return (int64_t)(4 + 8 * m->k) * m->G + 16 * (int64_t)m->D + 4;
 }
 
-// (the conditions of forward_pass's choice, smx_step.hip)
+// (forward_pass's own predicate, smx_step.hip: head_fused_ok)
 int64_t smx_head_fused_bytes(const smx_model* m, int32_t batch) {
   if (!m || batch <= 0 || m->dec.empty()) return 0;
-  const bool on = m->flags.head_loss && m->flags.head_fused && !m->scvi && m->k >= 2 && m->hf_tab && m->bigk_part && m->n_heads == 0 && !m->fvae &&
-                  m->dec.back().out_p == 128 && head_fused_supported(batch, 128, m->Gp, m->k) &&
-                  (m->flags.bf16x3 < 0 ? use_bf16x3((long)batch * m->Gp * m->k) : m->flags.bf16x3 != 0);
-  return on ? (int64_t)head_fused_bytes(batch, m->G, m->Gp, m->k) : 0;
+  return head_fused_ok(m, batch) ? (int64_t)head_fused_bytes(batch, m->G, m->Gp, m->k) : 0;
 }
 
 }  // extern "C"

@@ -501,6 +501,20 @@ bool use_head_loss(const smx_model* m, int B) {
   return head_loss_supported(B, m->dec.back().out_p, m->Gp);
 }
 
+// Whether a training step of B cells takes the ONE-launch output head (smx_headfused.hip): the one predicate behind forward_pass's
+// choice and smx_head_fused_bytes (two copies of it had drifted apart).  flags.head_bwd is part of it: the fused launch
+// never stores dP, so the separate-launch backward forms (head_bwd = 0) cannot follow it.  Label heads do not stand in the way since
+// round 5: their products run as the grouped launch of the backward pass (they cannot ride with a head launch that is not there).
+bool head_fused_ok(const smx_model* m, int B) {
+  if (!use_head_loss(m, B) || !m->flags.head_fused || !m->flags.head_bwd || !m->hf_tab || !m->bigk_part || m->fvae) return false;
+  if (m->k > 3 || !m->out_has_W[1] || (m->k == 3 && !m->out_has_W[2])) return false;
+  const MlpLayer& dL = m->dec.back();
+  const TensorInfo& tw = m->tensors[m->t_outW[0]];
+  const bool b3 = m->flags.bf16x3 < 0 ? use_bf16x3((long)B * m->Gp * m->k) : m->flags.bf16x3 != 0;
+  return b3 && dL.out_p == 128 && tw.ld == (long)m->k * m->Gp && head_fused_supported(B, dL.out_p, m->Gp, m->k) && head_bwd_supported(B, dL.out_p, m->Gp) &&
+         (size_t)head_fused_grid(m->Gp) * (size_t)B * 128 <= m->bigk_floats;
+}
+
 // arguments of the row-local scvi head launch of a training step; returns whether that launch applies
 // (out == nullptr: only the test)
 static bool scvi_train_args(smx_model* m, const Pass& ps, ScviTrainArgs* out) {
@@ -695,9 +709,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     // a wide panel: the whole head -- product, likelihood, dW / db and the per-workgroup slabs of d d -- in ONE launch + the ordered
     // sum of the slabs (smx_headfused.hip); backward_pass then finds its head products done
     m->head_fused = false;
-    if (m->flags.head_fused && hl.bf16x3 && m->hf_tab && m->bigk_part && m->n_heads == 0 && !m->fvae && dL.out_p == 128 && tw.ld == (long)m->k * m->Gp &&
-        head_fused_supported(ps.B, dL.out_p, m->Gp, m->k) && (size_t)head_fused_grid(m->Gp) * (size_t)ps.B * 128 <= m->bigk_floats &&
-        !(!m->capturing && m->timing_label == "out_head_product")) {
+    if (head_fused_ok(m, ps.B) && !(!m->capturing && m->timing_label == "out_head_product")) {
       HeadFusedArgs hf;
       hf.D = dL.out_buf; hf.ldd = dL.out_p; hf.W = hl.W; hf.ldw = tw.ld; hf.bias = hl.bias;
       hf.X = ps.Xsrc; hf.ldx = m->Gp; hf.rows = ps.xrows; hf.x_u16 = ps.x_u16;
@@ -718,6 +730,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
         m->ev_hf_fresh = true;
       }
       SMX_CHECK(launch_head_fused_reduce(m->st, hf, n_slabs, m->slab));
+      n_llk_chunks = head_fused_chunks(m->Gp);
       m->head_fused = true;
     } else {
     if (!m->capturing && m->timing_label == "out_head_product") {
@@ -1071,7 +1084,7 @@ int backward_pass(smx_model* m, const Pass& ps) {
     n_slabs = hb.n_slices;
     // label heads (SISUA / MISA): d d += d Y W_lab^T as extra slabs of this launch, the head's weight gradient with the
     // grouped launch at the end of the backward pass -- instead of a grouped launch of their own here (8.6 us at C4)
-    if (m->n_heads > 0 && m->flags.label_ride && !m->fvae && !m->scvi) {
+    if (m->n_heads > 0 && m->flags.label_ride && !m->fvae && !m->scvi && !(m->head_fused && m->head_loss)) {
       bool ok = true;
       for (int j = 0; j < m->n_heads; ++j) ok = ok && (m->tensors[m->t_labW[j]].ld % 32) == 0;
       ok = ok && (size_t)(hb.n_slices + m->n_heads) * (size_t)dd_stride <= m->slab_cap;

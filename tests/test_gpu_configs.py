@@ -268,7 +268,7 @@ def test_c2_shape_at_the_strong_scaling_share_of_eight_ranks(batch):
 
 @pytest.mark.parametrize("lk,B,G,storage", [("zinb", 100, 4100, "u16"), ("nb", 128, 4128, "f32"), ("nbd", 77, 4500, "u16"), ("zinbd", 128, 4096, "f32")])
 def test_wide_panel_head_in_one_launch(Engine, lk, B, G, storage):
-  """smx_headfused.hip inside a training step (a panel of >= 4096 genes, 128 decoder columns, at most 128 cells): the output product, the
+  """smx_headfused.hip inside a training step (a panel of >= 4096 genes, 128 decoder columns): the output product, the
   likelihood, dW / db and d d of the head in ONE launch -- every likelihood, a ragged minibatch, gene counts that are no multiple of 32,
   both count stores.  Three optimiser steps: every gradient of the first against the oracle (rel-L2 <= 1e-4), the ELBO scalars of all
   three, the Adam moments after them; the separate launches (flag head_fused = 0) meet the same bars, the two forms agree to 2e-5; the third step of
@@ -316,6 +316,57 @@ def test_wide_panel_head_in_one_launch(Engine, lk, B, G, storage):
   e.close()
   worst = grad_errors(results[True][1], results[False][1])
   assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+
+
+@pytest.mark.parametrize("case", ["sisua_labels", "sisua_extra_output", "batch_256", "sisua_batch_200", "head_bwd_off"])
+def test_wide_panel_head_with_labels_and_two_cell_passes(Engine, case):
+  """What round 5 let into the one-launch head (smx_step.hip: head_fused_ok): SISUA models -- label heads and an
+  extra observed output beside the gene panel (their launches run beside it; their d d no longer rides with a head-backward launch that
+  is not there) -- and minibatches of up to 256 cells (one launch per 128 cells, the second adding its dW / db).  One step: the ELBO terms
+  and EVERY gradient against the oracle, the Adam moments; two more steps' losses.  `head_bwd_off`: with the separate-launch
+  backward forms asked for (flag head_bwd = 0) the fused launch -- which never stores dP -- must not be taken, and the gradients are right."""
+  from tests.util import adam_state_errors, make_pair, synth_counts, synth_labels
+  kw = dict(model="vae", n_genes=4128, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=16)
+  B = 100
+  if case == "sisua_labels":
+    kw.update(model="sisua", n_genes=4100, labels=((12, "nb"), (7, "onehot")), alpha=10.0)
+  elif case == "sisua_extra_output":
+    kw.update(model="sisua", n_genes=4500, likelihood="nb", extra_outputs=((10, "nb"),), labels=((12, "nbd"), (5, "onehot")), alpha=10.0)
+  elif case == "batch_256":
+    B = 256
+  elif case == "sisua_batch_200":
+    kw.update(model="sisua", n_genes=4100, likelihood="nbd", labels=((38, "nb"),))
+    B = 200
+  spec, cfg = make_pair(**kw)
+  n = 600
+  x = synth_counts(n, spec.n_genes, sparsity=0.92, seed=spec.n_genes, max_count=900)
+  ys = synth_labels(n, spec.extra_outputs + spec.labels)
+  _, lm, lv = so.library_size(x)
+  lib = np.tile(np.array([[lm, lv]], dtype=np.float32), (n, 1))
+  mask = so.label_mask(n, 0.4, n_omics=1 + len(spec.labels), seed=1)
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  e = Engine(cfg, max_batch=max(128, B), init=False)
+  e.set_params(params)
+  if case == "head_bwd_off":
+    e.set_flag("head_bwd", False)
+  e.upload(x, ys, lib, mask, cell_id_base=11, storage="u16")
+  assert (e.head_fused_bytes(B) > 0) == (case != "head_bwd_off")
+  rng = np.random.default_rng(5)
+  for s in range(3):
+    rows = rng.permutation(n)[:B].astype(np.int32)
+    res = so.train_step(spec, params, bn, opt, x[rows], so.PhiloxNoise(spec.seed, s, rows + 11), y=[y[rows] for y in ys], library=lib[rows], mask=mask[rows])
+    m = e.train_step(rows)
+    assert m["nan_flag"] == 0
+    for key in ("loss", "nllk_x", "kl") + (("nllk_y",) if spec.labels else ()) + (("nllk_o",) if spec.extra_outputs else ()):
+      assert np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-5), (s, key, m[key], res["metrics"][key])
+    if s == 0:
+      worst = grad_errors(e.get_params(which=1), res["grads"])
+      assert max(worst.values()) < RTOL, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+      assert np.isclose(m["grad_norm_max"], max(np.linalg.norm(g) for g in res["grads"].values()), rtol=1e-4)
+  em, ev, where = adam_state_errors(e, opt)
+  assert em < 4e-4 and ev < 8e-4, (em, ev, where)
+  e.close()
 
 
 def test_wide_panel_heads_update_as_a_background_sweep(Engine):
