@@ -327,6 +327,11 @@ int smx_comm_unique_id(uint8_t id[128]);
 int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]);
 int smx_comm_world(const smx_model* m);
 int smx_comm_rank(const smx_model* m);
+/* How an (eager) training step exchanges its gradients right now: 0 no collective (world 1), 1 ONE all-reduce of the flat buffer between
+ * the backward pass and the optimiser (north star), 2 the two-bucket chain -- the heads' gradients (3/4 of the bytes) all-reduced, normed and
+ * applied on a communication stream beside the rest of the step, the front bucket all-reduced on the model's stream (taken from 3 MB of
+ * head gradients; SMX_DP_BUCKETS=1|2 overrides), 3 the hand-written exchange's two-bucket form (both buckets on the communication stream). */
+int smx_comm_form(const smx_model* m);
 /* The same all-reduce as a hand-written two-shot exchange over peer-mapped buffers instead of RCCL (reduce-scatter
  * + all-gather of the flat buffer through HIP-IPC-mapped peer memory over xGMI; sums in rank order -- bitwise the same on every
  * rank): smx_comm_p2p_export allocates this rank's communication region and returns its two 64-byte IPC handles (the flat

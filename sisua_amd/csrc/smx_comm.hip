@@ -44,6 +44,7 @@ int load_rccl() {
   g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
   g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_rccl.CommSplit = (decltype(g_rccl.CommSplit))dlsym(h, "ncclCommSplit");
   g_rccl.GetVersion = (decltype(g_rccl.GetVersion))dlsym(h, "ncclGetVersion");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
@@ -81,9 +82,13 @@ bool dp_active(const smx_model* m) {
   // dp_force: exercise RCCL on a 1-rank communicator (tests); local: the loopback communicator of the tests
   return (m->comm && (m->world > 1 || m->dp_force)) || (m->local && m->world > 1) || (m->p2p && m->p2p->error && (m->world > 1 || m->dp_force));
 }
-// Measured on a 1-rank communicator: the cross-stream events of the two-bucket form cost +42 us per step,
-// one all-reduce on the model's own stream +2.6 us.  The overlap only pays when the collective itself is
-// much longer than that, so the default is the single all-reduce; SMX_DP_BUCKETS=2 selects the overlap.
+// Two buckets: the heads' gradients (3/4 of the bytes, final long before the rest) on the communication stream, the rest on the
+// model's stream.  Taken from SMX_DP_BUCKETS_MIN_BYTES of head gradients (3 MB: BASELINE configs[1] sits right at it) unless
+// SMX_DP_BUCKETS says 1 or 2.  Round 4's form -- BOTH buckets on the communication stream, the optimiser behind an event of that stream --
+// cost +32-35 us on ONE rank (profiles/r04_dp_overhead_one_rank.txt): two cross-queue hops (main -> comm -> main) on the critical path of
+// every step.  Since round 5 the two-bucket step is a CHAIN (smx_step.hip: dp_chain_start): head bucket all-reduce -> its norms -> the
+// heads' clip + Adam, all on the communication stream and joined in front of the NEXT step's output head; the main stream all-reduces the
+// front bucket itself and never waits for the other queue inside a step.
 bool dp_overlap(const smx_model* m) {
   // Not with the hand-written exchange under SyncBatchNorm: the head bucket's exchange on st_comm would run beside the
   // SyncBatchNorm-backward exchanges on the model's stream, and both go through ONE staging buffer, ONE done counter and ONE
@@ -92,10 +97,20 @@ bool dp_overlap(const smx_model* m) {
   if (m->p2p && m->p2p->error && m->sync_bn) return false;
   return dp_active(m) && m->dp_two_buckets && !m->capturing && m->st_comm != nullptr && !m->local;
 }
+// the chained form: RCCL (the heads' bucket on its own communicator when ncclCommSplit gave one) or the tests' loopback communicator; the
+// hand-written exchange keeps round 4's form (one staging buffer, one flag set: its two buckets cannot be in flight together)
+bool dp_chain_ok(const smx_model* m) {
+  if (!dp_active(m) || !m->dp_two_buckets || m->capturing || !m->st_comm || (m->p2p && m->p2p->error)) return false;
+  return m->bucket1_count > 0 && m->chunk_first_head < m->n_chunks;
+}
 int local_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
   LocalGroup& g = *m->local;
   const int me = m->rank;
-  SMX_REQUIRE(count <= m->local_scratch_cap, "loopback all-reduce: scratch too small");
+  // (a bucket of the flat gradients takes the same stretch of the scratch: the heads' bucket on the communication stream and a collective
+  // of the main stream may be under way together)
+  const size_t soff = (buf >= m->grads && buf < m->grads + m->grads_count) ? (size_t)(buf - m->grads) : 0;
+  SMX_REQUIRE(soff + count <= m->local_scratch_cap, "loopback all-reduce: scratch too small");
+  float* const scratch = m->local_scratch + soff;
   { std::lock_guard<std::mutex> lk(g.mu); g.src[me] = buf; }
   SMX_HIP(hipEventRecord(g.ready[me], st));
   if (!g.barrier()) { set_error("loopback communicator: a member did not arrive (timeout)"); return SMX_ERR_COMM; }
@@ -106,25 +121,25 @@ int local_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
     if (r != me) SMX_HIP(hipStreamWaitEvent(st, g.ready[r], 0));
   }
   const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, 2048);
-  hipLaunchKernelGGL(local_sum_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, m->local_scratch, count);
+  hipLaunchKernelGGL(local_sum_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, scratch, count);
   SMX_HIP(hipEventRecord(g.done[me], st));
   if (!g.barrier()) { set_error("loopback communicator: a member did not arrive (timeout)"); return SMX_ERR_COMM; }
   for (int r = 0; r < g.world; ++r)
     if (r != me) SMX_HIP(hipStreamWaitEvent(st, g.done[r], 0));   // nobody still reads this rank's buffer
-  SMX_HIP(hipMemcpyAsync(buf, m->local_scratch, count * sizeof(float), hipMemcpyDeviceToDevice, st));
+  SMX_HIP(hipMemcpyAsync(buf, scratch, count * sizeof(float), hipMemcpyDeviceToDevice, st));
   return SMX_OK;
 }
-int dp_allreduce_buf(smx_model* m, float* buf, size_t count, hipStream_t st) {
+int dp_allreduce_buf(smx_model* m, float* buf, size_t count, hipStream_t st, bool second) {
   if (m->local) return local_allreduce(m, buf, count, st);
   if (m->p2p && m->p2p->error) return p2p_allreduce(m, buf, count, st);
-  ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclFloat32, ncclSum, m->comm, st);
+  ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclFloat32, ncclSum, (second && m->comm2) ? m->comm2 : m->comm, st);
   if (r != ncclSuccess) {
     set_error(std::string("ncclAllReduce failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
     return SMX_ERR_COMM;
   }
   return SMX_OK;
 }
-int dp_allreduce(smx_model* m, size_t off, size_t count, hipStream_t st) { return dp_allreduce_buf(m, m->grads + off, count, st); }
+int dp_allreduce(smx_model* m, size_t off, size_t count, hipStream_t st, bool second) { return dp_allreduce_buf(m, m->grads + off, count, st, second); }
 
 }  // namespace smx
 
@@ -144,6 +159,8 @@ static int comm_detach(smx_model* m) {   // leave whatever communicator the mode
   if (m->st) SMX_HIP(hipStreamSynchronize(m->st));
   if (m->st_comm) SMX_HIP(hipStreamSynchronize(m->st_comm));
   p2p_release(m);
+  if (m->comm2 && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm2);
+  m->comm2 = nullptr;
   if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
   m->comm = nullptr;
   m->local.reset();
@@ -154,11 +171,12 @@ static int comm_detach(smx_model* m) {   // leave whatever communicator the mode
 
 }  // extern "C"
 namespace smx {
-// the communication stream of the two-bucket form (SMX_DP_BUCKETS=2: the heads' gradients, 3/4 of the bytes and final after the
-// head's backward launch, are reduced while the rest of the backward pass runs) and the switches read when a communicator is attached
+// the communication stream of the two-bucket form (the heads' gradients, 3/4 of the bytes and final long before the rest, are reduced
+// -- and applied -- beside the rest of the step) and the switches read when a communicator is attached
 int ensure_comm_stream(smx_model* m) {
   m->dp_force = getenv("SMX_FORCE_ALLREDUCE") != nullptr;
-  m->dp_two_buckets = getenv("SMX_DP_BUCKETS") != nullptr && atoi(getenv("SMX_DP_BUCKETS")) == 2;
+  const char* nb = getenv("SMX_DP_BUCKETS");
+  m->dp_two_buckets = nb ? atoi(nb) == 2 : m->bucket1_count * sizeof(float) >= SMX_DP_BUCKETS_MIN_BYTES;
   if (!m->st_comm) {
     if (hipStreamCreateWithFlags(&m->st_comm, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_c1, hipEventDisableTiming) != hipSuccess ||
@@ -200,6 +218,13 @@ int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]) {
   m->comm = comm;
   m->rank = rank; m->world = world;
   SMX_CHECK(ensure_comm_stream(m));
+  // the heads' bucket on a communicator of its own (same ranks, same order): RCCL serialises the operations of ONE communicator in issue
+  // order whatever their streams, which would put the front bucket's all-reduce behind the heads' 30 MB.  Without ncclCommSplit (or when it
+  // fails) both buckets share `comm`: still correct, the overlap is then what the backward pass covers.
+  if (m->dp_two_buckets && g_rccl.CommSplit && !getenv("SMX_DP_ONE_COMM")) {
+    ncclComm_t c2 = nullptr;
+    if (g_rccl.CommSplit(comm, 0, rank, &c2, nullptr) == ncclSuccess && c2) m->comm2 = c2;
+  }
   SMX_CHECK(ensure_sync_buf(m));
   drop_graphs(m);
   return SMX_OK;
@@ -233,6 +258,7 @@ int smx_comm_init_local(smx_model* const* models, int n) {
       m->local_scratch_cap = need;
     }
     SMX_CHECK(ensure_sync_buf(m));
+    SMX_CHECK(ensure_comm_stream(m));   // (the chained two-bucket form runs on the loopback too: smx_step.hip, dp_chain_start)
   }
   return SMX_OK;
 }
@@ -277,6 +303,10 @@ int smx_comm_time_allreduce(smx_model* m, int iters, float* us_per_call, int64_t
 }
 
 int smx_comm_rank(const smx_model* m) { return m ? m->rank : 0; }
+int smx_comm_form(const smx_model* m) {
+  if (!m || !smx::dp_active(m)) return 0;
+  return smx::dp_chain_ok(m) ? 2 : smx::dp_overlap(m) ? 3 : 1;
+}
 int smx_comm_world(const smx_model* m) { return m ? m->world : 0; }
 
 }  // extern "C"

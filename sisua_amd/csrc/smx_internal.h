@@ -247,6 +247,7 @@ struct AdamArgs {
   int n_launch = 0;             // workgroups of the optimiser launch: every chunk but [gap_from, gap_from + gap_len) (those rode along earlier)
   int gap_from = 0, gap_len = 0;
   float* partial = nullptr;     // [n_chunks] sum of squares per chunk
+  int sq_chunks = -1;           // chunks the norm pass of launch_adam covers (-1: all; the chained data-parallel form: the front chunks -- the heads' went on the communication stream)
   // norms without the separate pass (use_sq): per tensor either the slots the weight-gradient products wrote
   // (sq_count > 0) or, for small tensors, a sweep of the tensor's gradient by every workgroup that needs it
   int use_sq = 0; const float* sq_slots = nullptr; int sq_first[SMX_MAX_TENSORS]; int sq_count[SMX_MAX_TENSORS];
@@ -264,6 +265,7 @@ struct AdamArgs {
 };
 int launch_adam(hipStream_t st, const AdamArgs& a);
 int launch_adam_sweep(hipStream_t st, const AdamArgs& a, int first, int count, int wgs);   // chunks [first, first + count) by `wgs` persistent workgroups
+int launch_grad_sqsum_range(hipStream_t st, const AdamArgs& a, int first, int count);   // a.partial[chunk] = the chunk's sum of squares, chunks [first, first + count)
 
 struct BnBwdArgs {
   const float* dout = nullptr; int n_slabs = 1; long slab_stride = 0; int ld = 0;  // d loss / d out slabs
@@ -545,6 +547,7 @@ int launch_bigk_reduce(hipStream_t st, const float* part, long slab_stride, int 
 
 // ---- the whole output head of a training step at a wide panel in one launch (smx_headfused.hip) ----
 #define SMX_HEAD_FUSED_TAB_BYTES (8 * 12 * 64 * 16)
+#define SMX_DP_BUCKETS_MIN_BYTES 3000000   // data parallel: two buckets from this many bytes of head gradients
 #define SMX_HEAD_FUSED_MIN_GENES 4096
 #define SMX_HEAD_FUSED_MAX_CELLS 256   // (one launch per 128 cells)
 // the heads' background optimiser sweep (smx_step.hip: head_sweep_start): from this many 4096-float chunks of head parameters, one persistent

@@ -2104,7 +2104,7 @@ int launch_metrics(hipStream_t st, const MetricsArgs& a) {
 // optimiser: per-tensor clipnorm + Adam over the flat buffer
 // ===========================================================================
 __global__ __launch_bounds__(256) void grad_sqsum_kernel(AdamArgs a) {
-  const int extra = (int)blockIdx.x - a.n_chunks;
+  const int extra = (int)blockIdx.x - (a.sq_chunks >= 0 ? a.sq_chunks : a.n_chunks);
   if (extra >= 0) {   // extra workgroups: the ELBO scalars of this step, then the moving BatchNorm statistics (data parallel)
     if (a.with_metrics && extra == 0) { metrics_body(a.metrics); return; }
     const int i = (extra - (a.with_metrics ? 1 : 0)) * 256 + (int)threadIdx.x;
@@ -2166,9 +2166,31 @@ template <int NT>
 __global__ __launch_bounds__(NT) void adam_sweep_kernel(AdamArgs a, int first, int count) {
   adam_sweep_body<NT>(a, first, count);
 }
+// the chunks' sums of squares for a RANGE of chunks (data parallel, chained form: the heads' chunks on the communication stream behind
+// their bucket's all-reduce; the optimiser launch's own pass then covers the front chunks only)
+__global__ __launch_bounds__(256) void grad_sqsum_range_kernel(AdamArgs a, int first) {
+  __shared__ float sh[4];
+  const int chunk = first + (int)blockIdx.x;
+  const OptChunk ch = a.chunks[chunk];
+  float s = 0.f;
+  const float4* g4 = reinterpret_cast<const float4*>(a.grads + ch.offset);
+  for (int i = threadIdx.x; i < ch.count / 4; i += 256) {
+    const float4 g = g4[i];
+    s += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) a.partial[chunk] = s;
+}
+int launch_grad_sqsum_range(hipStream_t st, const AdamArgs& a, int first, int count) {
+  if (count <= 0) return SMX_OK;
+  hipLaunchKernelGGL(grad_sqsum_range_kernel, dim3((unsigned)count), dim3(256), 0, st, a, first);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
 int launch_adam_sweep(hipStream_t st, const AdamArgs& a, int first, int count, int wgs) {
   if (count <= 0) return SMX_OK;
-  if (!a.use_sq || wgs <= 0) { set_error("adam sweep: needs the products' sum-of-squares partials"); return SMX_ERR_INVALID; }
+  // (norms from the products' sum-of-squares partials, or -- use_sq = 0 -- from a.partial, filled by launch_grad_sqsum_range before)
+  if (wgs <= 0) { set_error("adam sweep: no workgroups"); return SMX_ERR_INVALID; }
   hipLaunchKernelGGL(adam_sweep_kernel<256>, dim3((unsigned)std::min(wgs, count)), dim3(256), 0, st, a, first, count);   // (512-thread workgroups: 181-184 us per c5-shard step against 175-176)
   SMX_HIP(hipGetLastError());
   return SMX_OK;
@@ -2183,7 +2205,7 @@ int launch_adam(hipStream_t st, const AdamArgs& a) {
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
-  hipLaunchKernelGGL(grad_sqsum_kernel, dim3(a.n_chunks + (a.with_metrics ? 1 : 0) + (a.bn_total + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(grad_sqsum_kernel, dim3((a.sq_chunks >= 0 ? a.sq_chunks : a.n_chunks) + (a.with_metrics ? 1 : 0) + (a.bn_total + 255) / 256), dim3(256), 0, st, a);
   hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_launch), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;

@@ -79,6 +79,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;   // (optional: a second communicator for the heads' bucket)
   ncclResult_t (*GetVersion)(int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -258,6 +259,7 @@ struct smx_model {
   std::map<int, Injected> injected; bool use_injected = false;
   // comm
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
+  ncclComm_t comm2 = nullptr;   // the heads' bucket's own communicator (ncclCommSplit of `comm`): its exchange runs BESIDE the collectives of the main stream
   std::shared_ptr<LocalGroup> local; float* local_scratch = nullptr; size_t local_scratch_cap = 0;   // loopback communicator (tests)
   std::shared_ptr<P2PState> p2p;   // hand-written two-shot all-reduce over IPC-mapped peer buffers (smx_p2p.hip); takes precedence over RCCL
   // SyncBatchNorm (opt-in, smx_comm_set_sync_bn): per BN launch one small all-reduce of per-rank column statistics
@@ -266,6 +268,7 @@ struct smx_model {
   hipStream_t st_comm = nullptr; hipEvent_t ev_c1 = nullptr, ev_c2 = nullptr, ev_c3 = nullptr;
   size_t bucket1_off = 0, bucket1_count = 0;   // gradients of the output / label heads: ready first, reduced early
   bool bucket1_in_flight = false;
+  bool chain_started = false;    // this step's head bucket went: all-reduce -> norms -> clip + Adam sweep on the communication stream (smx_step.hip: dp_chain_start)
   // graphs
   std::map<int, hipGraphExec_t> graphs;
   bool capturing = false;
@@ -336,8 +339,9 @@ void drop_graphs(smx_model* m);
 // smx_comm.hip
 bool dp_active(const smx_model* m);
 bool dp_overlap(const smx_model* m);
-int dp_allreduce_buf(smx_model* m, float* buf, size_t count, hipStream_t st);
-int dp_allreduce(smx_model* m, size_t off, size_t count, hipStream_t st);
+int dp_allreduce_buf(smx_model* m, float* buf, size_t count, hipStream_t st, bool second = false);   // second: the heads' bucket (its own communicator / scratch)
+int dp_allreduce(smx_model* m, size_t off, size_t count, hipStream_t st, bool second = false);
+bool dp_chain_ok(const smx_model* m);
 // smx_step.hip
 // mode: 0 full forward; 1 decoder only (z given in m->z); 2 resample (encoder outputs m->latbuf / m->latlbuf kept,
 // only the latent draw and everything after it run again); 3 encoders + latent moments only

@@ -347,6 +347,37 @@ static int head_sweep_start(smx_model* m) {
   return SMX_OK;
 }
 
+// Data parallel, two buckets (smx_comm.hip: dp_chain_ok): the heads' part of the step as ONE chain on the communication stream, started
+// where the heads' gradients are final (`after`: an event of the model's stream recorded there) --
+//   all-reduce of the head bucket (its own communicator)  ->  the chunks' sums of squares of the REDUCED gradient  ->  clip + Adam of the
+//   heads' chunks (the sweep above, norms from those sums)
+// -- and joined where the background sweep is joined: in front of the next step's output head and at the end of every smx_train_steps
+// call.  The model's stream all-reduces the front bucket [encoder / latent / decoder | BatchNorm statistics | ELBO scalars] itself and
+// updates the front chunks; it never waits for the communication stream inside a step (round 4's two-bucket form did, twice: +32-35 us on
+// one rank).  Same arithmetic as the one-bucket step element by element (sum over ranks in RCCL's order, norm of the reduced gradient,
+// clip, Adam); the per-tensor norm is summed per chunk, then over the tensor's chunks, as the optimiser launch does.
+int dp_chain_start(smx_model* m) {
+  if (m->chain_started) return SMX_OK;
+  SMX_CHECK(head_sweep_prepare(m));
+  SMX_HIP(hipEventRecord(m->ev_hf, m->st));
+  SMX_HIP(hipStreamWaitEvent(m->st_comm, m->ev_hf, 0));
+  SMX_CHECK(dp_allreduce(m, m->bucket1_off, m->bucket1_count, m->st_comm, true));
+  AdamArgs a;
+  fill_adam_args(m, a);
+  a.use_sq = 0; a.master = nullptr; a.with_metrics = 0;
+  const int first = m->chunk_first_head, count = m->n_chunks - m->chunk_first_head;
+  SMX_CHECK(launch_grad_sqsum_range(m->st_comm, a, first, count));
+  const int forced = (int)tuning("adam_sweep_wgs", 0);
+  SMX_CHECK(launch_adam_sweep(m->st_comm, a, first, count, forced > 0 ? forced : std::min(std::max(count / SMX_HEAD_SWEEP_CHUNKS_PER_WG, 64), 256)));
+  SMX_HIP(hipEventRecord(m->ev_sweep, m->st_comm));
+  m->sweep_pending = true;
+  m->chain_started = true;
+  // the optimiser launch skips these chunks; no launch of the backward chain carries any of them
+  m->adam_early_from = m->chunk_first_head; m->adam_early_to = m->n_chunks;
+  m->adam_rest_from = m->adam_rest_to = 0; m->adam_ride_b = 0;
+  return SMX_OK;
+}
+
 // ask the product that writes the gradient of tensor t for sum-of-squares partials
 void want_sq(smx_model* m, GemmArgs& g, int t) {
   if (!m->sq_slots || tuning_on("no_sq_partials")) return;   // read per call: tests toggle it
@@ -729,6 +760,9 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
         SMX_HIP(hipEventRecord(m->ev_hf, m->st));
         m->ev_hf_fresh = true;
       }
+      // data parallel, two buckets: without label heads every gradient of the head bucket is final HERE -- its chain (all-reduce, norms,
+      // clip + Adam) runs beside the whole backward pass, the optimiser launch and the next step's encoder and decoder
+      if (m->n_heads == 0 && dp_chain_ok(m)) SMX_CHECK(dp_chain_start(m));
       SMX_CHECK(launch_head_fused_reduce(m->st, hf, n_slabs, m->slab));
       n_llk_chunks = head_fused_chunks(m->Gp);
       m->head_fused = true;
@@ -1035,7 +1069,8 @@ int backward_pass(smx_model* m, const Pass& ps) {
   const smx_config& c = m->cfg;
   std::fill(m->sq_count.begin(), m->sq_count.end(), 0);   // the products of this step report what they wrote
   std::fill(m->sq_reduced.begin(), m->sq_reduced.end(), 0);
-  m->adam_early_pending = false; m->adam_early_from = -1; m->adam_rest_from = m->adam_rest_to = 0; m->adam_ride_b = 0;
+  m->adam_early_pending = false; m->adam_rest_from = m->adam_rest_to = 0; m->adam_ride_b = 0;
+  if (!m->chain_started) m->adam_early_from = -1;   // (forward_pass may have sent the heads' chunks down the data-parallel chain already)
   const float inv_gb = 1.f / (float)ps.global_batch;
   if (m->fvae) SMX_CHECK(factor_backward(m, ps));   // first: it uses the slab buffer the head's backward fills next
   const MlpLayer& dL = m->dec.back();
@@ -1195,7 +1230,9 @@ int backward_pass(smx_model* m, const Pass& ps) {
     if (m->head_fused_bwd_done && m->ev_hf_fresh) SMX_CHECK(head_sweep_start(m));
     m->ev_hf_fresh = false;
     m->head_fused_bwd_done = false;
-    if (dp_overlap(m)) {  // head gradients are final: reduce them while the rest of backward runs
+    if (dp_chain_ok(m)) {   // head gradients are final (label heads whose weight gradient rides with the last launch of the pass: optimizer_pass)
+      if (!m->lab_deferred) SMX_CHECK(dp_chain_start(m));
+    } else if (dp_overlap(m)) {  // (the hand-written exchange) head gradients are final: reduce them while the rest of backward runs
       SMX_HIP(hipEventRecord(m->ev_c1, m->st));
       SMX_HIP(hipStreamWaitEvent(m->st_comm, m->ev_c1, 0));
       SMX_CHECK(dp_allreduce(m, m->bucket1_off, m->bucket1_count, m->st_comm));
@@ -1364,7 +1401,12 @@ int optimizer_pass(smx_model* m) {
     SMX_CHECK(launch_metrics(m->st, m->pending_metrics));
     m->have_pending_metrics = false;
   }
-  if (dp_active(m)) {
+  const bool chain = dp_chain_ok(m);
+  if (chain) {
+    Timed t(m, "allreduce");
+    SMX_CHECK(dp_chain_start(m));   // (a no-op when the forward or the backward pass started it)
+    SMX_CHECK(dp_allreduce(m, 0, m->bucket1_off, m->st));   // front bucket [encoder / latent / decoder | BatchNorm statistics | ELBO scalars]
+  } else if (dp_active(m)) {
     Timed t(m, "allreduce");
     if (m->bucket1_in_flight) {
       // front bucket [encoder/latent/decoder grads | BN stats | metrics] behind the head bucket on the
@@ -1381,6 +1423,8 @@ int optimizer_pass(smx_model* m) {
   }
   AdamArgs a;
   fill_adam_args(m, a);
+  if (chain) a.sq_chunks = m->chunk_first_head;   // (the heads' chunks have their norm pass on the communication stream)
+  m->chain_started = false;
   if (dp_active(m) && m->bn_total && m->world > 1) {
     if (!a.use_sq) {   // (the usual case under data parallelism: the gradient-norm launch takes the update along)
       a.bn_moving = m->bn_moving; a.bn_batch = m->grads + m->tail_off_bn; a.bn_total = (int)m->bn_total;
@@ -1432,6 +1476,7 @@ int train_sequence(smx_model* m, int B, bool with_begin, bool begin_from_master,
   if (with_begin)
     SMX_CHECK(launch_step_begin(m->st, master_state(m), cur_state(m), m->order, cur_rows(m), B, begin_from_master ? 1 : 0,
                                 cursor, m->cfg.lr, m->cfg.adam_beta1, m->cfg.adam_beta2));
+  m->chain_started = false;
   { Timed null_pair(m, "null"); }  // an event pair around nothing: the timing method's own overhead
   SMX_CHECK(csr_stage(m, ps));     // sparse store: this minibatch's rows as a dense tile (no-op otherwise)
   SMX_CHECK(forward_pass(m, ps, true, true));

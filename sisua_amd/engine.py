@@ -500,6 +500,12 @@ class Engine:
   def rank(self) -> int:
     return self.lib.smx_comm_rank(self._h)
 
+  @property
+  def comm_form(self) -> int:
+    """How a training step exchanges its gradients: 0 no collective, 1 one all-reduce, 2 the two-bucket chain (the heads' bucket reduced,
+    normed and applied on the communication stream), 3 the hand-written exchange's two-bucket form (include/sisua_hip.h: smx_comm_form)."""
+    return self.lib.smx_comm_form(self._h)
+
   def set_sync_bn(self, on: bool = True):
     """SyncBatchNorm under data parallelism (global-batch statistics; one small extra all-reduce per BatchNorm pass)."""
     check(self.lib.smx_comm_set_sync_bn(self._h, int(bool(on))))

@@ -150,6 +150,65 @@ def test_world_n_steps_match_oracle(Engine, name, world, sync_bn):
     e.close()
 
 
+@pytest.mark.parametrize("name,world,sync_bn", [("vae_zinb", 2, False), ("vae_zinb", 3, True), ("sisua", 2, False), ("sisua_extra_output", 3, False),
+                                                ("misa_mix", 2, True), ("scale", 2, False)])
+def test_two_bucket_chain_matches_oracle(Engine, monkeypatch, name, world, sync_bn):
+  """The two-bucket step of round 5 (smx_step.hip: dp_chain_start; forced here with SMX_DP_BUCKETS=2, by default taken from 3 MB of head
+  gradients): the heads' bucket is all-reduced, normed and APPLIED on the communication stream -- started where the heads' gradients are
+  final (with label heads whose weight gradient rides with the last launch of the backward pass: in front of the optimiser), joined in front of
+  the next step's output head --, the front bucket on the model's stream.  Four steps through ONE multi-step call and one single-step call
+  (the chain of step n is still under way when step n + 1 starts): losses of every step, the reduced gradients of the last one, parameters,
+  Adam moments and moving statistics equal the oracle's data-parallel contract; every rank ends bit-identical; and the one-bucket form of
+  the same run gives the same losses to rounding."""
+  spec, cfg, x, ys, lib, mask = _problem(CASES[name])
+  B, steps, base = 48, 4, 1000
+  rng = np.random.default_rng(5)
+  rows = [rng.permutation(x.shape[0])[: B * world].astype(np.int32).reshape(world, B) for _ in range(steps + 1)]
+  hist = {}
+  for buckets in ("2", "1"):
+    monkeypatch.setenv("SMX_DP_BUCKETS", buckets)
+    params = perturbed_params(spec)
+    bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+    engines = []
+    for r in range(world):
+      e = Engine(cfg, max_batch=64, init=False)
+      e.set_params(params)
+      e.upload(x, ys, lib, mask, cell_id_base=base)
+      engines.append(e)
+    Engine.comm_init_local(engines)
+    for e in engines:
+      e.set_sync_bn(sync_bn)
+      assert e.comm_form == int(buckets)
+    refs = [so.dp_train_step(spec, params, bn, opt, x, list(rows[s]), s, cell_base=base, y=ys, library=lib, mask=mask, sync_bn=sync_bn) for s in range(steps)]
+    orders = [np.concatenate([rows[s][r] for s in range(steps)]) for r in range(world)]
+    ms = run_ranks([lambda r=r: engines[r].train_steps(orders[r], steps, B, graph=False, metrics=True) for r in range(world)])
+    hs = [e.metrics_history(steps) for e in engines]
+    for r in range(world):
+      for s in range(steps):
+        assert np.isclose(hs[r]["loss"][s], refs[s]["metrics"]["loss"], rtol=RTOL, atol=1e-5), (buckets, r, s)
+      assert np.isclose(ms[r]["grad_norm_max"], max(refs[-1]["norms"].values()), rtol=1e-3), (buckets, r)
+    em, ev, where = adam_state_errors(engines[0], opt)
+    assert em < 2e-3 and ev < 4e-3, (buckets, em, ev, where)
+    # one more step as a call of its own: every gradient of it
+    p_before = {k: v.copy() for k, v in params.items()}
+    ref = so.dp_train_step(spec, params, bn, opt, x, list(rows[steps]), steps, cell_base=base, y=ys, library=lib, mask=mask, sync_bn=sync_bn)
+    ms = run_ranks([lambda r=r: engines[r].train_step(rows[steps][r]) for r in range(world)])
+    for r, m in enumerate(ms):
+      assert m["step"] == steps + 1 and np.isclose(m["loss"], ref["metrics"]["loss"], rtol=RTOL, atol=1e-5), (buckets, r)
+    finals = [e.get_params() for e in engines]
+    for k in finals[0]:
+      for r in range(1, world):
+        assert np.array_equal(finals[0][k], finals[r][k]), (buckets, k, r)
+    names = [p for p, _ in so.bn_manifest(spec)]
+    for i, st in engines[-1].get_bn().items():
+      assert np.allclose(st["moving_mean"], bn[f"{names[i]}/moving_mean"], rtol=1e-4, atol=1e-6)
+      assert np.allclose(st["moving_var"], bn[f"{names[i]}/moving_var"], rtol=1e-4, atol=1e-6)
+    hist[buckets] = np.asarray(hs[0]["loss"])
+    for e in engines:
+      e.close()
+  assert np.allclose(hist["2"], hist["1"], rtol=2e-6)
+
+
 def test_sync_bn_equals_single_process_on_the_global_batch(Engine):
   """SURVEY 8e caveat (i): with SyncBatchNorm two replicas of 32 cells ARE one process on the 64 cells."""
   spec, cfg, x, ys, lib, mask = _problem(CASES["vae_zinb"])
@@ -366,6 +425,7 @@ def test_world8_c5_split_matches_oracle(Engine, sync_bn):
   Engine.comm_init_local(engines)
   for e in engines:
     e.set_sync_bn(sync_bn)
+    assert e.comm_form == 2   # (30 MB of head gradients: the two-bucket chain, started behind the one-launch output head)
   rng = np.random.default_rng(5)
   local = [rng.permutation(per)[:B].astype(np.int32) for r in range(world)]
   glob = [local[r] + r * per for r in range(world)]
