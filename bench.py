@@ -192,7 +192,7 @@ def cpu_baseline(cfg, xt, batch, budget_s=12.0, threads=None, extra=None):
               sample=f"{timed} steps of batch {batch} of the same workload; NumPy float64 oracle (oracle/sisua_oracle.py), {threads} BLAS threads (host has {ncpu} cores)")
 
 
-def measure_mode(cp, rank, world, local_rank, cfg, batch, steps, warmup, upload, n_cells, sync_bn=False, use_graph=False):
+def measure_mode(cp, rank, world, local_rank, cfg, batch, steps, warmup, upload, n_cells, sync_bn=False):
   """One data-parallel mode, measured in-run on every rank: (a) the per-GPU step WITHOUT a communicator (what one GPU does with this
   rank's batch), (b) the same step with the job's collective, K steps between barrier + synchronize brackets, max over ranks,
   (c) the collective alone.  Returns the dict that goes into `scaling_modes` (rank 0's copy is printed) and the engine is closed."""
@@ -206,7 +206,7 @@ def measure_mode(cp, rank, world, local_rank, cfg, batch, steps, warmup, upload,
     for _ in range(50):
       eng.eval_step(order[:batch])
     if warmup:
-      eng.train_steps(order[: warmup * batch], warmup, batch, graph=use_graph)
+      eng.train_steps(order[: warmup * batch], warmup, batch)
     eng.stage_steps(order[warmup * batch:], steps, batch)
     eng.synchronize()
     cp.barrier()
@@ -216,7 +216,7 @@ def measure_mode(cp, rank, world, local_rank, cfg, batch, steps, warmup, upload,
       except Exception as err:
         print(f"bench: device-side line-up skipped: {err}", file=sys.stderr)
     t0 = time.perf_counter()
-    eng.train_steps(None, steps, batch, graph=use_graph)
+    eng.train_steps(None, steps, batch)
     eng.synchronize()
     t1 = time.perf_counter()
     cp.barrier()
@@ -239,9 +239,10 @@ def measure_mode(cp, rank, world, local_rank, cfg, batch, steps, warmup, upload,
   hist = eng.metrics_history(steps)
   if not np.isfinite(hist["loss"]).all():
     sys.exit("bench: non-finite loss in the timed steps")
+  form = {0: "none", 1: "one all-reduce", 2: "two-bucket chain", 3: "two buckets on the communication stream"}.get(eng.comm_form, "?")
   eng.close()
   return {"cells_per_s": round(steps * batch * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4),
-          "batch_per_gpu": batch, "global_batch": batch * world, "sync_bn": bool(sync_bn), "collective": collective,
+          "batch_per_gpu": batch, "global_batch": batch * world, "sync_bn": bool(sync_bn), "collective": collective, "exchange": form,
           "allreduce_us": round(us, 1) if us >= 0 else None, "allreduce_bytes": nbytes,
           "nocomm_ms_per_step": round(1e3 * dt0 / steps, 4), "dp_overhead_us": round(1e6 * (dt - dt0) / steps, 1),
           "final_loss": round(float(hist["loss"][-1]), 4)}
@@ -269,7 +270,6 @@ def main():
   ap.add_argument("--steps", type=int, default=300)
   ap.add_argument("--warmup", type=int, default=30)
   ap.add_argument("--workload", default="8kly")
-  ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (eager launches measured faster)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--c5-cells", type=int, default=0, help="--workload c5: total cells over all ranks (default 1 000 000)")
   ap.add_argument("--no-c5-entry", action="store_true", help="skip the roofline entries at the C5-shard width (128 cells x 20 000 genes)")
@@ -327,7 +327,7 @@ def main():
   if world > 1 and args.sync_bn:
     eng.set_sync_bn(True)
 
-  use_graph = args.graph
+  # (eager launches: a captured hipGraph of the step replays at 88.7 us against 79.6 us, profiles/r05_graph_vs_eager.txt -- `--graph` went in round 5)
   order = make_order(xt.shape[0], batch, args.warmup + args.steps)
   # loads the code object and brings the device clocks up (evaluation passes: parameters and optimiser state untouched, so
   # the W warm-up + K timed TRAINING steps below are exactly the run they would be without them; a fresh box otherwise
@@ -335,7 +335,7 @@ def main():
   for _ in range(200):
     eng.eval_step(order[:batch])
   if args.warmup:
-    eng.train_steps(order[: args.warmup * batch], args.warmup, batch, graph=use_graph)
+    eng.train_steps(order[: args.warmup * batch], args.warmup, batch)
   # the timed steps' row ids are resident before the clock starts, like the matrix they index (inputs in HBM: an input pipeline
   # prefetches the next epoch's schedule while the current one runs)
   eng.stage_steps(order[args.warmup * batch:], args.steps, batch)
@@ -349,7 +349,7 @@ def main():
     except Exception as err:   # (the line-up is a refinement of the barrier above, not a condition of the run)
       print(f"bench: device-side line-up skipped: {err}", file=sys.stderr)
   t0 = time.perf_counter()
-  eng.train_steps(None, args.steps, batch, graph=use_graph)   # K steps queued by ONE library call, no host sync between them
+  eng.train_steps(None, args.steps, batch)   # K steps queued by ONE library call, no host sync between them
   eng.synchronize()
   t1 = time.perf_counter()   # this rank's K steps are done (every step ends in a collective: so are everybody's)
   cp.barrier()
@@ -367,7 +367,8 @@ def main():
     us = cp.max(us)
     if cp.max(float(eng.comm_p2p_error() if collective in ("p2p", "p2p-only") else 0)) > 0:
       sys.exit("bench: the peer-to-peer exchange reported a timed-out wait; the timed steps are void")
-    dp_info = {"collective": collective, "allreduce_us": round(us, 1) if us >= 0 else None, "allreduce_bytes": nbytes}
+    dp_info = {"collective": collective, "allreduce_us": round(us, 1) if us >= 0 else None, "allreduce_bytes": nbytes,
+               "exchange": {0: "none", 1: "one all-reduce", 2: "two-bucket chain", 3: "two buckets on the communication stream"}.get(eng.comm_form, "?")}
   # N > 1: the line is self-sufficient -- weak, strong + SyncBatchNorm (the reference's arithmetic) and the C5 share, measured in this run
   scaling_modes = None
   if world > 1 and not args.no_scaling_modes and args.workload == "8kly":
@@ -389,6 +390,19 @@ def main():
   m = {k: float(v[-1]) for k, v in hist.items()}
   if not np.isfinite(hist["loss"]).all():
     sys.exit("bench: non-finite loss in the timed steps")
+  # a longer run beside the contract's K steps (the driver's 20 steps are a 1.6 ms window): 300 more steps of the SAME engine,
+  # ids staged, one library call, the same brackets -- reported as value_300 / ms_per_step_300, never as `value`
+  n300 = 300
+  order300 = make_order(xt.shape[0], batch, n300)
+  eng.stage_steps(order300, n300, batch)
+  eng.synchronize()
+  cp.barrier()
+  t0 = time.perf_counter()
+  eng.train_steps(None, n300, batch, graph=False)
+  eng.synchronize()
+  t1 = time.perf_counter()
+  cp.barrier()
+  dt300 = cp.max(t1 - t0)
 
   # ---- roofline: every figure is ONE kernel's algorithmic bytes over that kernel's OWN duration -----------------
   # HIP events on the model's stream; the kernel is launched LOSS_REPEAT times back to back inside one event pair and the
@@ -549,11 +563,12 @@ def main():
         "unit": "cells/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "value_300": round(n300 * batch * world / dt300, 1), "ms_per_step_300": round(1e3 * dt300 / n300, 4),
         "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}-shaped synthetic counts {xt.shape[0]}x{xt.shape[1]} "
                                f"({resident_as}), {cfg.model} {cfg.likelihood} hidden={list(cfg.enc_units)} latent={cfg.latent_dim}, "
-                               f"batch {batch}/GPU, hipGraph={'on' if use_graph else 'off'}",
+                               f"batch {batch}/GPU, eager launches",
                    "global_batch": batch * world, "parallelism": f"dp{world}" + ("+syncbn" if (world > 1 and args.sync_bn) else "")},
         "final_loss": round(m["loss"], 4),
         "roofline": {"bound": "hbm", "kernel": head["name"], "rows": head["rows"],

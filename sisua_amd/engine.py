@@ -235,7 +235,7 @@ class Engine:
     check(fn(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size, C.byref(m) if metrics else None))
     return m.as_dict() if metrics else None
 
-  def train_steps(self, order, n_steps: int, batch: int, graph: bool = True, metrics: bool = False):
+  def train_steps(self, order, n_steps: int, batch: int, graph: bool = False, metrics: bool = False):
     """order = None: the row ids made resident by stage_steps(order, n_steps, batch) (no host-to-device copy in this call)."""
     if order is None:
       ptr = None

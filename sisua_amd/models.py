@@ -303,7 +303,7 @@ class SingleCellModel:
            valid_freq=500, valid_interval=0, epochs=500, max_iter=-1, sample_shape=(), logging_interval=2,
            earlystop_threshold=0.001, earlystop_progress_length=0, earlystop_patience=20, earlystop_min_epoch=-1,
            terminate_on_nan=True, checkpoint=None, allow_rollback=False, allow_none_gradients=False,
-           track_gradient_norms=False, log_tag=None, verbose=False, use_graph=False, distributed="auto",
+           track_gradient_norms=False, log_tag=None, verbose=False, distributed="auto",
            dp_batch="global", sync_bn=False, storage="f32", epochs_are_total=False, **ignored):
     r"""The training loop (odin Trainer under single_cell_model.py:213-236).
 
@@ -426,7 +426,7 @@ class SingleCellModel:
         first_ep, last_ep = it // spe, (it + n - 1) // spe
         for ep in [k for k in cache if k < first_ep]:
           del cache[ep]
-        m = e.train_steps(order, n, bs, graph=bool(use_graph) and bs == B, metrics=True)
+        m = e.train_steps(order, n, bs, metrics=True)   # (eager launches: a captured hipGraph of the step replays 11 % slower)
         nxt = min(it_end - (it + n), valid_freq if valid_freq and valid_freq > 0 else max_chunk, max_chunk)
         prefetch(last_ep, last_ep + 2 + max(nxt, 0) // max(spe, 1))   # what the next call will walk
         h = e.metrics_history(n)

@@ -66,3 +66,15 @@ def test_rccl_banner_is_kept_off_stdout():
   assert r.stdout.splitlines()[0] == '{"before": 1}' and sorted(r.stdout.splitlines()[1:]) == ["after", "after-c"]
   kept = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, SMX_KEEP_RCCL_BANNER="1"))
   assert "RCCL version : x" in kept.stdout
+
+
+def test_the_line_carries_a_longer_run_and_the_graph_flag_is_gone():
+  """`value` / `ms_per_step` stay the contract's K steps; `value_300` / `ms_per_step_300` (300 further staged steps of
+  the same engine) stand beside them.  The hipGraph replay of the step measured 88.7 us against 79.6 us of eager launches
+  (profiles/r05_graph_vs_eager.txt): `--graph` left the command line (DESIGN.md section 6 says why; the capture entry points stay in the
+  C-ABI for callers that embed the step in a graph of their own)."""
+  src = open(os.path.join(ROOT, "bench.py")).read()
+  assert '"value_300"' in src and '"ms_per_step_300"' in src
+  r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+  assert r.returncode == 0 and "--graph" not in r.stdout and "--steps" in r.stdout
+

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Where do the ~5.6 us dispatch gaps of the round-3 timelines come from?  One step's kernel rows (every column) under
-# rocprofv3 for: the default build, bf16x3 off, graph replay; plus the unprofiled step time of each.
+# rocprofv3 for: the default build, bf16x3 off; plus the unprofiled step time of each.
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -16,6 +16,5 @@ run() {   # tag, extra bench flags (environment set by the caller)
 }
 run default
 SMX_TUNING=bf16x3=0 run no_bf16x3
-run graph --graph
 SMX_TUNING=no_adam_early run no_adam_early
 cat $O/summary.txt
