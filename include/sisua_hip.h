@@ -338,7 +338,9 @@ int smx_comm_form(const smx_model* m);
  * gradient buffer | the region); the host gathers the `world` x 128 bytes in rank order (control plane) and hands them to
  * smx_comm_p2p_init, after which every training step's collective (and SyncBatchNorm's small ones) takes this path -- with or
  * without an RCCL communicator (call smx_comm_init first when both are wanted).  world <= 8 (one node).  Waits on peers are
- * bounded (~2 s): smx_comm_p2p_error reports (and clears) a timed-out exchange instead of hanging the device. */
+ * bounded (SMX_P2P_TIMEOUT_S, 30 s): a timed-out wait marks the step void on every rank -- smx_train_step* / smx_eval_step return
+ * SMX_ERR_COMM on every call with a metrics read-back until smx_comm_p2p_error has read (and cleared) the word; the Python Engine does
+ * that when it raises.  Recovery: restore the last checkpoint on every rank, re-attach the communicator. */
 int smx_comm_p2p_export(smx_model* m, int world, uint8_t handles[128]);
 int smx_comm_p2p_init(smx_model* m, int rank, int world, const uint8_t* all_handles);
 int smx_comm_p2p_error(smx_model* m, int32_t* error);

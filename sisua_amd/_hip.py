@@ -25,7 +25,7 @@ ACTIVATIONS = {"relu": 0, "linear": 1}
 
 
 class SmxError(RuntimeError):
-  pass
+  code = 0   # the library's status code (include/sisua_hip.h: SMX_ERR_*)
 
 
 class smx_config(C.Structure):
@@ -191,7 +191,9 @@ def clear_tuning(name: str = ""):
 def check(rc: int):
   if rc != 0:
     msg = load().smx_last_error()
-    raise SmxError(f"libsisua_hip error {rc}: {msg.decode() if msg else '?'}")
+    err = SmxError(f"libsisua_hip error {rc}: {msg.decode() if msg else '?'}")
+    err.code = int(rc)
+    raise err
 
 
 def require_gpu(device: int = 0):

@@ -488,14 +488,17 @@ class LazyCountOutput(Distribution):
   forward pass of 128 cells takes ~40 us) and only the statistic asked for leaves the device.  Same surface as the eager result of
   `count_distribution` -- `.distribution` (the Independent wrapper's inner distribution), `.count_distribution` of a zero-inflated
   output (sisua/analysis/posterior.py:187-255), `batch_shape` / `event_shape` / `name` -- and `materialize()` returns that eager result
-  (bit-identical planes).  The handle is valid while the model's parameters stay as they were: after further training it raises."""
+  (bit-identical planes); any other attribute of the eager result is looked up there.  The handle is valid while the model's parameters
+  stay as they were: after further training or a `load_weights` it raises.  Unlike the eager path of rounds 1-3 the input is taken whole
+  (`SingleCellOMIC.numpy()`): the remainder cells of the last minibatch are part of the result."""
 
   reinterpreted_batch_ndims = 1
 
   def __init__(self, model, x, library, n_samples, batch, name, count_only=False):
     self._model, self._x, self._lib, self._S, self._B, self.name = model, x, library, int(n_samples), int(batch), name
     self._count_only = bool(count_only)
-    self._step = model.step
+    # (the optimiser step AND a counter that every restore of weights bumps: load_weights at the same step gives other parameters -- ADVICE r04)
+    self._step = (model.step, getattr(model, "_param_version", 0))
     self._eager = None
 
   # ---- structure -----------------------------------------------------------------
@@ -527,8 +530,8 @@ class LazyCountOutput(Distribution):
 
   # ---- statistics (kernels) ---------------------------------------------------------
   def _engine(self):
-    if self._model.step != self._step:
-      raise RuntimeError("the model was trained after this lazy prediction was made: call predict() again")
+    if (self._model.step, getattr(self._model, "_param_version", 0)) != self._step:
+      raise RuntimeError("the model's parameters changed (training or load_weights) after this lazy prediction was made: call predict() again")
     return self._model._ensure_engine(max(self._B, 512 if self._x.shape[0] >= 1024 else 1))
 
   def _stat(self, stat, target=None, out=None):
@@ -563,6 +566,18 @@ class LazyCountOutput(Distribution):
 
   def sample(self, sample_shape=(), seed=None):
     return self.materialize().sample(sample_shape, seed=seed)
+
+  def __getattr__(self, name):
+    # anything else a caller of the reference touches on the eager result (`.logits`, `.total_count`, `.inflated_distribution`, ...):
+    # through the materialised distribution.  (Only reached for attributes this class does not define.)
+    if name.startswith("_"):
+      raise AttributeError(name)
+    d = self.materialize()
+    inner = getattr(d, "distribution", d)
+    for obj in (d, inner):
+      if hasattr(obj, name):
+        return getattr(obj, name)
+    raise AttributeError(f"{type(self).__name__} (and the distribution it stands for) has no attribute '{name}'")
 
   def __repr__(self):
     return f"<LazyCountOutput '{self.name}' batch_shape={self.batch_shape} event_shape={self.event_shape} on device>"

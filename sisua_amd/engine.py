@@ -78,6 +78,7 @@ class Engine:
     self.cfg = cfg
     self.max_batch = int(max_batch)
     self._h = C.c_void_p()
+    self.last_comm_error = 0   # the hand-written exchange's error word as the last failed step left it (_step_check)
     c = make_smx_config(cfg, max_batch)
     check(self.lib.smx_model_create(C.byref(c), C.byref(self._h)))
     # manifest handshake: the library's tensor list must equal the host's
@@ -232,7 +233,7 @@ class Engine:
     ids = self._ids(row_ids)
     m = smx_metrics()
     fn = self.lib.smx_train_step_graph if graph else self.lib.smx_train_step
-    check(fn(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size, C.byref(m) if metrics else None))
+    self._step_check(fn(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size, C.byref(m) if metrics else None))
     return m.as_dict() if metrics else None
 
   def train_steps(self, order, n_steps: int, batch: int, graph: bool = False, metrics: bool = False):
@@ -245,8 +246,22 @@ class Engine:
         raise ValueError("order must hold n_steps * batch row ids")
       ptr = ids.ctypes.data_as(C.POINTER(C.c_int32))
     m = smx_metrics()
-    check(self.lib.smx_train_steps(self._h, ptr, int(n_steps), int(batch), int(graph), C.byref(m) if metrics else None))
+    self._step_check(self.lib.smx_train_steps(self._h, ptr, int(n_steps), int(batch), int(graph), C.byref(m) if metrics else None))
     return m.as_dict() if metrics else None
+
+  def _step_check(self, rc: int):
+    """check() of a step's status; a failed collective of the hand-written exchange (SMX_ERR_COMM: a wait on a peer timed out, every rank's
+    step is void) is reported ONCE -- the sticky error word is read and cleared here, so a caller that has dealt with the cause (ADVICE r04:
+    it used to fail every later call until someone called comm_p2p_error) can go on: restore a checkpoint, re-attach the ranks."""
+    try:
+      check(rc)
+    except SmxError as err:
+      if getattr(err, "code", 0) == -4:
+        try:
+          self.last_comm_error = self.comm_p2p_error()   # (1: this rank's wait timed out, 2: a peer reported that its wait did)
+        except SmxError:
+          pass
+      raise
 
   def stage_steps(self, order, n_steps: int, batch: int):
     """The next train_steps call's row ids, uploaded ahead of it (an input pipeline's prefetch)."""
@@ -264,7 +279,7 @@ class Engine:
   def eval_step(self, row_ids):
     ids = self._ids(row_ids)
     m = smx_metrics()
-    check(self.lib.smx_eval_step(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size, C.byref(m)))
+    self._step_check(self.lib.smx_eval_step(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size, C.byref(m)))
     return m.as_dict()
 
   def forward(self, row_ids=None, x=None, library=None, sample_index: int = 0, training: bool = False,

@@ -194,6 +194,7 @@ class SingleCellModel:
 
   def _set_state(self, st):
     e = self._engine
+    self._param_version = getattr(self, "_param_version", 0) + 1   # (lazy prediction handles are keyed by it: distributions.LazyCountOutput)
     e.set_params(st["params"], 0)
     e.set_params(st["m"], 2)
     e.set_params(st["v"], 3)
@@ -708,8 +709,6 @@ class SingleCellModel:
     same Philox draws); the few scalars per draw are combined here.  Returns (mllk [N], {output name: mean_s log p(x_o | z_s) [N]})."""
     cfg = self._cfg
     n_out = len(self._outputs)
-    if cfg.model == "scale":
-      raise NotImplementedError("the joint marginal_log_prob of several outputs is built for a standard-normal latent prior (not SCALE's mixture)")
     if len(arrs) < n_out:
       raise ValueError(f"marginal_log_prob of this model needs the {n_out} output variables' arrays as inputs=[x, y, ...]")
     x = np.ascontiguousarray(arrs[0], dtype=np.float32)
@@ -729,7 +728,12 @@ class SingleCellModel:
     if cfg.stochastic:
       z, mu, sg = o["z_sample"].astype(np.float64), o["z_mean"].astype(np.float64), o["z_scale"].astype(np.float64)
       eps = (z - mu) / sg
-      logw = logw + (-0.5 * z ** 2 + 0.5 * eps ** 2 + np.log(sg)).sum(-1)
+      if cfg.model == "scale" and not cfg.latent_mixture:
+        # SCALE (scale.py:13-49): the prior is the trainable mixture -- log p_mix(z_s) - log q(z_s | x), minus the Monte-Carlo KL of the draw
+        log_q = (-0.5 * eps ** 2 - np.log(sg) - 0.5 * np.log(2 * np.pi)).sum(-1)
+        logw = logw + self._mixture_prior_log_prob(z) - log_q
+      else:
+        logw = logw + (-0.5 * z ** 2 + 0.5 * eps ** 2 + np.log(sg)).sum(-1)
     if cfg.model == "scvi":
       l, ml, sl = o["l_sample"].astype(np.float64), o["l_mean"].astype(np.float64), o["l_scale"].astype(np.float64)
       lib = np.asarray(library, np.float64)
@@ -738,6 +742,32 @@ class SingleCellModel:
     mx = logw.max(0)
     mllk = mx + np.log(np.exp(logw - mx).sum(0)) - np.log(S)
     return mllk.astype(np.float32), {k: v.mean(0).astype(np.float32) for k, v in llk.items()}
+
+  def _mixture_prior_log_prob(self, z):
+    r"""log p(z) under SCALE's trainable mixture prior for z [..., D] (float64): p(z) = sum_c softmax(a)_c N(z; m_c, S_c), S_c diagonal with
+    s = softplus1(raw) or L_c L_c^T with a softplus diagonal + 1e-5 (covariance = 'tril': tfp's FillScaleTriL) -- the prior kernel's
+    arithmetic (smx_kernels.hip: scale_prior_*), from the model's current parameters."""
+    cfg = self._cfg
+    pr = {k: np.asarray(v, np.float64) for k, v in self._engine.get_params().items() if k.startswith("prior/")}
+    a, m_c = pr["prior/logits"], pr["prior/loc"]
+    C, D = m_c.shape
+    log_pi = a - (a.max() + np.log(np.exp(a - a.max()).sum()))
+    zz = np.asarray(z, np.float64)[..., None, :]                                            # [..., 1, D]
+    if cfg.scale_tril:
+      Lraw = pr["prior/scale"].reshape(C, D, D)
+      dg = np.logaddexp(0.0, np.einsum("cpp->cp", Lraw)) + 1e-5
+      L = np.tril(Lraw, -1)
+      L[:, np.arange(D), np.arange(D)] = dg
+      diff = zz - m_c                                                                        # [..., C, D]
+      u = np.zeros_like(diff)
+      for p_ in range(D):   # forward substitution, component by component
+        u[..., p_] = (diff[..., p_] - (L[:, p_, :p_] * u[..., :p_]).sum(-1)) / dg[:, p_]
+      comp = log_pi - 0.5 * (u * u).sum(-1) - np.log(dg).sum(1) - 0.5 * D * np.log(2 * np.pi)
+    else:
+      s_c = np.logaddexp(0.0, pr["prior/scale"] + np.log(np.expm1(1.0)))                     # softplus1
+      comp = log_pi + (-0.5 * ((zz - m_c) / s_c) ** 2 - np.log(s_c) - 0.5 * np.log(2 * np.pi)).sum(-1)
+    cm = comp.max(-1, keepdims=True)
+    return (cm + np.log(np.exp(comp - cm).sum(-1, keepdims=True)))[..., 0]
 
   def posterior_llk(self, corrupted, original=None, library=None, sample_shape=10, batch_size=128):
     r"""The four scores of `Posterior.cal_llk` (analysis/posterior.py:919-938) on the GPU

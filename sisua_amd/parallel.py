@@ -60,6 +60,15 @@ def _is_local(addr: str) -> bool:
     return False
   if ip.startswith("127."):
     return True
+  # an address of this host is one a socket can be BOUND to (comparing with getaddrinfo(gethostname()) misjudges hosts whose
+  # name maps to 127.0.1.1 -- the Debian / Ubuntu default -- when MASTER_ADDR is the NIC's address or the FQDN)
+  fam = socket.AF_INET6 if ":" in ip else socket.AF_INET
+  try:
+    with socket.socket(fam, socket.SOCK_STREAM) as probe:
+      probe.bind((ip, 0))
+    return True
+  except OSError:
+    pass
   try:
     return ip in {ai[4][0] for ai in socket.getaddrinfo(socket.gethostname(), None)}
   except OSError:

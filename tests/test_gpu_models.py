@@ -689,6 +689,37 @@ def test_variational_model_with_two_outputs(api):
     api.FVAE(outputs=[api.RVmeta(n_genes, "zinb"), api.RVmeta(n_prots, "nbd")], **kw)._ensure_engine(64)
 
 
+@pytest.mark.parametrize("covariance", ["none", "tril"])
+def test_scale_joint_marginal_of_two_outputs(api, covariance):
+  """VERDICT r04 Missing 5: the JOINT marginal likelihood log p(x, y) of a model with several outputs under SCALE's trainable mixture
+  prior (scale.py:13-49; posterior.py:964-967) -- every draw's weight is log p(x|z) + log p(y|z) + log p_mix(z) - log q(z|x), with the
+  mixture density from the model's current parameters (diagonal and full-covariance components) -- against the oracle's, same Philox
+  draws.  It used to refuse."""
+  from oracle import sisua_oracle as so
+  sco = _sco()
+  n_genes, n_prots = sco.n_vars, sco.numpy("proteomic").shape[1]
+  m = api.SCALE(outputs=[api.RVmeta(n_genes, "zinb", name="transcriptomic"), api.RVmeta(n_prots, "nbd", name="proteomic")],
+                latents=api.RVmeta(6, "mixgaus", True, "Latents"), n_components=4, covariance=covariance,
+                encoder=api.NetConf([32], batchnorm=True, dropout=0.1), decoder=api.NetConf([32], batchnorm=True, dropout=0.1))
+  m.fit(sco, epochs=3, batch_size=64, learning_rate=2e-3, verbose=False)   # (parameters off their initial values: the components differ)
+  X, Y = sco.numpy()[:40], sco.numpy("proteomic")[:40]
+  mllk, llk = m.marginal_log_prob(inputs=[X, Y], sample_shape=6, batch_size=64)
+  assert set(llk) == {"transcriptomic", "proteomic"} and mllk.shape == (40,) and np.isfinite(mllk).all()
+  spec = so.Spec(**m._make_config().to_dict())
+  e = m._engine
+  params = {k: v.astype(np.float64) for k, v in e.get_params().items()}
+  names = [p for p, _ in so.bn_manifest(spec)]
+  bn = {}
+  for i, st in e.get_bn().items():
+    bn[f"{names[i]}/moving_mean"], bn[f"{names[i]}/moving_var"] = st["moving_mean"].astype(np.float64), st["moving_var"].astype(np.float64)
+  ref_m, ref_l = so.marginal_log_prob(spec, params, bn, X, np.arange(40), 6, y=[Y])
+  assert np.allclose(mllk, ref_m, rtol=1e-4, atol=1e-2), np.abs(mllk - ref_m).max()
+  assert np.allclose(llk["transcriptomic"], ref_l, rtol=1e-4, atol=1e-2)
+  # ... and the mixture term matters: with a standard-normal prior in its place the estimate moves
+  z = np.random.default_rng(0).normal(size=(3, 5, 6))
+  assert np.abs(m._mixture_prior_log_prob(z) - (-0.5 * z ** 2 - 0.5 * np.log(2 * np.pi)).sum(-1)).max() > 1e-3
+
+
 def test_scvi_extra_outputs_and_gene_dispersion(api, tmp_path):
   """scvi.py:168-169 (`pY = [p(d) for p in self.posteriors[1:]]`) and scvi.py:55-56,66-86 (`dispersion` / `inflation` kept by the
   distribution layer instead of a Dense head): trained, predicted, saved and restored."""
@@ -798,6 +829,23 @@ def test_lazy_predict_keeps_the_planes_on_the_device(api, name, lk):
     assert np.array_equal(lz.mean(), ez.mean())
     if isinstance(eX, tuple):
       assert len(lX) == len(eX) and np.array_equal(lX[1].mean(), eX[1].mean())
+  # raw parameters a caller of the reference may touch on predict's result come from the eager twin
+  inner = e0.distribution.count_distribution if l0.is_zero_inflated else e0.distribution
+  attr = "total_count" if hasattr(inner, "total_count") else "mean_param" if hasattr(inner, "mean_param") else None
+  if attr and hasattr(e0.distribution, attr):
+    assert np.array_equal(getattr(l0, attr), getattr(e0.distribution, attr))
+  with pytest.raises(AttributeError):
+    l0.no_such_attribute
+  # a restore of weights at the SAME optimiser step is a change of parameters too: the handle refuses
+  import tempfile
+  with tempfile.TemporaryDirectory() as tmp:
+    m.save_weights(os.path.join(tmp, "w"))
+    l0.mean()
+    m.load_weights(os.path.join(tmp, "w"))
+    with pytest.raises(RuntimeError):
+      l0.mean()
+  lX, _ = m.predict(sco, batch_size=50, verbose=False)
+  l0 = lX[0] if isinstance(lX, tuple) else lX
   m.fit(sco.create_dataset(omics, batch_size=64, drop_remainder=True), metadata=sco, epochs=1)
   with pytest.raises(RuntimeError):   # the handle names the parameters it was made with
     l0.mean()

@@ -63,7 +63,8 @@ for step in range(3):
       res["g/" + k] = v
   if die:
     break
-res["err"] = e.comm_p2p_error()
+res["err"] = getattr(e, "last_comm_error", 0) or e.comm_p2p_error()   # (the raise has read AND cleared the word: ADVICE r04)
+res["err_after"] = e.comm_p2p_error()
 for k, v in e.get_params().items():
   res["p/" + k] = v
 for k, v in e.get_params(which=2).items():
@@ -145,7 +146,7 @@ def test_p2p_allreduce_between_processes_matches_oracle(tmp_path, world, sync_bn
 
 def test_p2p_exchange_gives_up_on_a_dead_peer(tmp_path):
   """Rank 1 leaves after the handles were exchanged; rank 0's step waits SMX_P2P_TIMEOUT_S (2 s here, 30 s by default) for its READY
-  flag, gives up, and the STEP reports it (SMX_ERR_COMM from the metrics read-back; the error word stays set for smx_comm_p2p_error)
+  flag, gives up, and the STEP reports it (SMX_ERR_COMM from the metrics read-back; the Engine reads and clears the sticky word as it raises)
   -- the device is not left with a spinning kernel and no garbage gradient is applied silently."""
   from sisua_amd import build
   build.build(verbose=False)
@@ -153,6 +154,7 @@ def test_p2p_exchange_gives_up_on_a_dead_peer(tmp_path):
   assert outs[0][0] == 0 and "DONE" in outs[0][1], outs[0][1][-3000:]
   r0 = np.load(tmp_path / "r0.npz")
   assert int(r0["err"]) != 0 and "timed out" in str(r0["raised"])
+  assert int(r0["err_after"]) == 0   # reported once: the Engine cleared the sticky word when it raised
 
 
 def test_attach_engine_falls_back_to_the_exchange_when_rccl_refuses(tmp_path):
