@@ -237,6 +237,21 @@ __device__ inline uint32_t lds_addr(const void* p) {   // byte address within th
 }
 
 // ---------------------------------------------------------------------------
+// development: cycle stamps of a kernel's phases (builds with -DSMX_STAMPS only: tools/c2_stamps.sh).  Thread 0 of workgroup
+// SMX_STAMP_WG writes clock64() into the translation unit's own table [slot][16]; smx_dbg_stamps_<unit>() copies it out.
+// ---------------------------------------------------------------------------
+#ifdef SMX_STAMPS
+#ifndef SMX_STAMP_WG
+#define SMX_STAMP_WG 0
+#endif
+#define SMX_STAMP_TABLE static __device__ long long smx_tu_stamps[16 * 16];
+#define SMX_STAMP(slot, id) do { if ((int)blockIdx.x == SMX_STAMP_WG && threadIdx.x == 0) smx_tu_stamps[(slot) * 16 + (id)] = clock64(); } while (0)
+#else
+#define SMX_STAMP_TABLE
+#define SMX_STAMP(slot, id) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------------------
 // wave / block reductions (wave = 64)
 // ---------------------------------------------------------------------------
 // (four DPP steps inside the rows of 16, then two ds_bpermute across the four rows -- instead of six ds_bpermute)

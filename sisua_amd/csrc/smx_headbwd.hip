@@ -25,6 +25,8 @@
 #include "../../include/sisua_hip.h"
 
 namespace smx {
+SMX_STAMP_TABLE
+
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
     float csum[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) csum[p] = 0.f;
+    SMX_STAMP(4, 0);   // entry (role 0: a dW tile)
     for (int kc = 0; kc < a.B; kc += 128) {
       const int k0 = kc + 16 * q + 8 * hh;
       if (kc + 16 * q >= a.B) break;   // wave-uniform
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
         }
       }
     }
+    SMX_STAMP(4, 1);   // the products over the minibatch (loads in flight included)
     float sq = 0.f;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -137,6 +141,7 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
         } else a.db[(long)q * a.Gp + g0 + lane] = t;
       }
     }
+    SMX_STAMP(4, 2);   // the planes' partial tiles summed, dW / db / sum of squares stored
     return;
   }
 
@@ -571,3 +576,9 @@ int launch_panel_dw(hipStream_t st, const HeadBwdArgs& a) {
 }
 
 }  // namespace smx
+
+#ifdef SMX_STAMPS
+extern "C" int smx_dbg_stamps_headbwd(long long* out) {   // development builds only (tools/c2_stamps.sh): this unit's stamp table [16][16]
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(smx::smx_tu_stamps), sizeof(long long) * 256) == hipSuccess ? 0 : -1;
+}
+#endif

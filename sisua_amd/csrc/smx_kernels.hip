@@ -17,6 +17,8 @@
 #include "../../include/sisua_hip.h"
 
 namespace smx {
+SMX_STAMP_TABLE
+
 
 // grid (n_chunks, B); thread = VEC consecutive genes of one cell (VEC*4-byte accesses).
 template <int VEC> struct VecT;
@@ -189,13 +191,49 @@ __device__ inline float bn_col_reduce(float v, float* sh /*[BN_WAVES][BN_COLS]*/
   return t;
 }
 
-// sum of the split-K slabs for BN_RPT rows of one column, loads issued together
+// sum of the split-K slabs for BN_RPT rows of one column, loads issued together.
+// Up to SLAB_FLIGHT slabs' values of a thread (RPT rows each) are requested in ONE batch -- unconditional loads from a clamped slab index,
+// left out at the add -- so that a column's sum costs one memory round trip, not one per batch of 8 plus one per remaining slab (the
+// decoder's 12 slabs at BASELINE configs[1]: 5 dependent round trips, 4.6 of the launch's 9 us; tools/c2_stamps.sh).  The adds keep
+// their order (slab 0, 1, ...): the same bits.
+constexpr int SLAB_FLIGHT = 16;
+template <int NR>
+struct SlabBatch { float t[SLAB_FLIGHT][NR]; };
+template <int NR>
+__device__ inline void slab_issue(const float* base, int s0, int n_slabs, long slab_stride, int ld, int col, int r0, int rl, int B, SlabBatch<NR>& sb) {
+#pragma unroll
+  for (int q = 0; q < SLAB_FLIGHT; ++q) {
+    const int s = min(s0 + q, n_slabs - 1);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int r = min(r0 + rl + BN_RL * i, B - 1);
+      sb.t[q][i] = base[(long)s * slab_stride + (long)r * ld + col];
+    }
+  }
+}
+template <int NR>
+__device__ inline void slab_accumulate(const SlabBatch<NR>& sb, int s0, int n_slabs, int r0, int rl, int B, float (&acc)[NR]) {
+#pragma unroll
+  for (int q = 0; q < SLAB_FLIGHT; ++q)
+    if (s0 + q < n_slabs) {   // (block-uniform)
+#pragma unroll
+      for (int i = 0; i < NR; ++i) acc[i] += (r0 + rl + BN_RL * i < B) ? sb.t[q][i] : 0.f;
+    }
+}
 template <int BN_RPT>
 __device__ inline void slab_sum(const float* base, int n_slabs, long slab_stride, int ld, int col, int r0, int rl,
                                 int B, float (&acc)[BN_RPT]) {
 #pragma unroll
   for (int i = 0; i < BN_RPT; ++i) acc[i] = 0.f;
-  constexpr int SU = BN_RPT <= 2 ? 8 : (BN_RPT <= 4 ? 4 : 2);   // slabs per batch of loads: 16 values in flight per lane
+  if (BN_RPT <= 2) {   // (32 values in flight per lane)
+    for (int s = 0; s < n_slabs; s += SLAB_FLIGHT) {
+      SlabBatch<BN_RPT> sb;
+      slab_issue<BN_RPT>(base, s, n_slabs, slab_stride, ld, col, r0, rl, B, sb);
+      slab_accumulate<BN_RPT>(sb, s, n_slabs, r0, rl, B, acc);
+    }
+    return;
+  }
+  constexpr int SU = BN_RPT <= 4 ? 4 : 2;   // slabs per batch of loads: 16 values in flight per lane
   int s = 0;
   for (; s + SU <= n_slabs; s += SU) {
     float t[SU][BN_RPT];
@@ -319,10 +357,12 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
   }
   __shared__ float sh[BN_WAVES * BN_COLS];
   extern __shared__ float zs[];   // FRONT: [B][Dp + 1]
+  SMX_STAMP(FRONT ? 1 : 0, 0);   // entry
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = bid * BN_COLS + c;
   const bool live = col < a.H;  // padded columns produce zeros
   const float bias = (!a.batchnorm && a.bias && live) ? a.bias[col] : 0.f;
+  const float gamma_pre = (a.batchnorm && live) ? a.gamma[col] : 0.f, beta_pre = (a.batchnorm && live) ? a.beta[col] : 0.f;   // (requested ahead of pass 1)
   constexpr int CH = BN_RL * BN_RPT;
   float vreg[BN_RPT];
   // FRONT = 1: input tile up to 64 wide; FRONT = 2: exactly 128 wide (hidden -> hidden layers of 128-unit networks: the
@@ -365,12 +405,14 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
       if (t < a.lat.Dp * BN_COLS) ws[t] = wl[u];
     }
     __syncthreads();
+    SMX_STAMP(1, 1);   // latent tile (sample + KL) and the W tile are in LDS
     if constexpr (FRONT == 1) {
 #pragma unroll
       for (int k = 0; k < 64; ++k) wcol[k] = (k < a.lat.Dp) ? ws[k * BN_COLS + c] : 0.f;
     } else {
       wcol_lds = ws + c;
     }
+    SMX_STAMP(1, 2);   // the thread's column of W in registers
   }
 
   // dropout multipliers drawn ahead by an earlier launch (or injected): loaded now, used after the reductions
@@ -419,12 +461,14 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
     }
   }
   float mean = 0.f, inv = 1.f, gamma = 1.f, beta = 0.f;
+  SMX_STAMP(FRONT ? 1 : 0, 3);   // pass 1: slab sum / dot products
   if (a.batchnorm) {
-    gamma = live ? a.gamma[col] : 0.f;
-    beta = live ? a.beta[col] : 0.f;
+    gamma = gamma_pre;
+    beta = beta_pre;
     float var;
     if (a.training) {
       s1 = bn_col_reduce(s1, sh);
+      SMX_STAMP(FRONT ? 1 : 0, 4);   // column sums
       mean = s1 / (float)a.B;
       float s2 = 0.f;
       if (SMALL) {
@@ -438,6 +482,7 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
         }
       }
       s2 = bn_col_reduce(s2, sh);
+      SMX_STAMP(FRONT ? 1 : 0, 5);   // column variances
       var = s2 / (float)a.B;
       if (rl == 0) {
         if (a.batch_mean) { a.batch_mean[col] = mean; a.batch_var[col] = var; }
@@ -483,6 +528,7 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
   } else {
     for (int r = rl; r < a.B; r += BN_RL) finish(r, a.xhat[(long)r * a.Hp + col], 0.f);
   }
+  SMX_STAMP(FRONT ? 1 : 0, 6);   // normalise, ReLU, dropout, stores issued
 }
 
 template <int RPT, int FRONT = 0>
@@ -576,12 +622,26 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
     }
   }
   __shared__ float sh[BN_WAVES * BN_COLS];
+  SMX_STAMP(FRONT ? 3 : 2, 0);   // entry
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = bid * BN_COLS + c;
   const bool live = col < a.H;
   constexpr int CH = BN_RL * BN_RPT;
   float dyreg[BN_RPT], xhreg[BN_RPT];
   float s1 = 0.f, s2 = 0.f;
+  // (register-resident forms) what the activation mask and the BatchNorm formula need of the forward pass, requested FIRST: these loads
+  // used to follow the dot products / slab sums -- a memory round trip of their own behind them (tools/c2_stamps.sh)
+  float outpre[BN_RPT], xhpre[BN_RPT];
+  float gamma_pre = 0.f, inv_pre = 0.f;
+  if (SMALL) {
+#pragma unroll
+    for (int i = 0; i < BN_RPT; ++i) {
+      const long o = (long)min(rl + BN_RL * i, a.B - 1) * a.Hp + col;
+      outpre[i] = a.out[o];
+      xhpre[i] = a.batchnorm ? a.xhat[o] : 0.f;
+    }
+    if (a.batchnorm) { gamma_pre = live ? a.gamma[col] : 0.f; inv_pre = a.inv_std[col]; }
+  }
   constexpr int FK = FRONT == 2 ? 128 : 64;   // FRONT = 2: K = 128 exactly (see bn_act_fwd_body)
   float wrow[FRONT ? FK : 1];
   if (FRONT) {
@@ -613,11 +673,13 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
       if ((int)threadIdx.x < BN_COLS * kq) *reinterpret_cast<float4*>(&ws[(threadIdx.x / kq) * ldw_s + (threadIdx.x % kq) * 4]) = wl;
     }
     __syncthreads();
+    SMX_STAMP(3, 1);   // the gradient tile and the rows of W are in LDS
 #pragma unroll
     for (int v = 0; v < FK / 4; ++v) {
       const float4 t = (4 * v < a.fK) ? *reinterpret_cast<const float4*>(&ws[c * ldw_s + 4 * v]) : make_float4(0.f, 0.f, 0.f, 0.f);
       wrow[4 * v] = t.x; wrow[4 * v + 1] = t.y; wrow[4 * v + 2] = t.z; wrow[4 * v + 3] = t.w;
     }
+    SMX_STAMP(3, 2);   // the thread's row of W in registers
   }
   for (int r0 = 0; r0 < a.B; r0 += CH) {
     float acc[BN_RPT];
@@ -649,9 +711,10 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
       float dy = 0.f, xh = 0.f;
       if (r < a.B) {
         const long o = (long)r * a.Hp + col;
-        dy = (live && a.out[o] > 0.f) ? acc[i] * a.drop_scale : 0.f;
-        if (a.leak != 0.f && live && !(a.out[o] > 0.f)) dy = acc[i] * a.leak;
-        if (a.batchnorm) xh = a.xhat[o];
+        const float ov = SMALL ? outpre[i] : a.out[o];
+        dy = (live && ov > 0.f) ? acc[i] * a.drop_scale : 0.f;
+        if (a.leak != 0.f && live && !(ov > 0.f)) dy = acc[i] * a.leak;
+        if (a.batchnorm) xh = SMALL ? xhpre[i] : a.xhat[o];
         if (!SMALL) a.dpre[o] = dy;
         s1 += dy;
         s2 += dy * xh;
@@ -659,7 +722,9 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
       if (SMALL) { dyreg[i] = dy; xhreg[i] = xh; }
     }
   }
+  SMX_STAMP(FRONT ? 3 : 2, 3);   // slab sum / dot products, activation mask, the loads of out and xhat
   s1 = bn_col_reduce(s1, sh);
+  SMX_STAMP(FRONT ? 3 : 2, 4);
   if (!a.batchnorm) {
     if (rl == 0 && a.dbias && live) a.dbias[col] = s1;
     if (SMALL) {
@@ -670,8 +735,9 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
     return;
   }
   s2 = bn_col_reduce(s2, sh);
-  const float gamma = live ? a.gamma[col] : 0.f;
-  const float inv = a.inv_std[col];
+  SMX_STAMP(FRONT ? 3 : 2, 5);
+  const float gamma = SMALL ? gamma_pre : (live ? a.gamma[col] : 0.f);
+  const float inv = SMALL ? inv_pre : a.inv_std[col];
   if (rl == 0) { a.dgamma[col] = live ? s2 : 0.f; a.dbeta[col] = live ? s1 : 0.f; }
   const float invB = 1.f / (float)a.B;
   auto finish = [&](int r, float dy, float xh) {
@@ -687,6 +753,7 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
   } else {
     for (int r = rl; r < a.B; r += BN_RL) finish(r, a.dpre[(long)r * a.Hp + col], a.xhat[(long)r * a.Hp + col]);
   }
+  SMX_STAMP(FRONT ? 3 : 2, 6);   // stores issued
 }
 
 template <int RPT, int FRONT = 0>
@@ -2235,3 +2302,9 @@ int launch_noise_probe(hipStream_t st, NoiseKey nk, const int64_t* cell_ids, int
 }
 
 }  // namespace smx
+
+#ifdef SMX_STAMPS
+extern "C" int smx_dbg_stamps_kernels(long long* out) {   // development builds only (tools/c2_stamps.sh): this unit's stamp table [16][16]
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(smx::smx_tu_stamps), sizeof(long long) * 256) == hipSuccess ? 0 : -1;
+}
+#endif
