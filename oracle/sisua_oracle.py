@@ -178,8 +178,6 @@ class Spec:
     assert self.dispersion in ("full", "share", "single") and self.inflation in ("full", "share", "single"), (self.dispersion, self.inflation)
     if self.model != "scvi":
       assert self.dispersion == "full" and self.inflation == "full", "dispersion / inflation are options of scvi (scvi.py:55-56)"
-    if self.extra_outputs:
-      assert self.model != "fvae" and not self.latent_mixture, "extra outputs are not built for fvae / the mixture-density posterior"
     if self.model == "fvae":
       assert len(self.labels) <= 1 and all(llk == "onehot" for _, llk in self.labels), "SemiFVAE: one 'onehot' label variable"
       assert self.disc_layers >= 1 and self.disc_units >= 1 and 0.0 <= self.disc_leak < 1.0
@@ -870,7 +868,8 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
   mvec = np.zeros(B) if mask is None else np.asarray(mask, dtype=np.float64).reshape(B)
   fac = None
   if spec.model == "fvae":
-    fac = _factor_forward(spec, params, z, noise.uniform(STREAM_PERMUTE, D), y[0] if spec.labels else None, mvec)
+    # (SemiFVAE's label variable sits behind the observed outputs in the target order: fvae.py:9-18 passes `outputs` through unchanged)
+    fac = _factor_forward(spec, params, z, noise.uniform(STREAM_PERMUTE, D), y[len(spec.extra_outputs)] if spec.labels else None, mvec)
     llk_y = -fac["sup"]      # (already masked; the mask is idempotent below)
     out.update(disc_logits=fac["logits"])
   for j, (P, kind, observed) in enumerate(spec.heads):

@@ -212,8 +212,6 @@ def manifest(cfg: ModelConfig) -> List[Tuple[str, Tuple[int, ...]]]:
   G, D = cfg.n_genes, cfg.latent_dim
   h = mlp("enc", G, cfg.enc_units)
   _ = cfg.scale_tril, cfg.head_plane(0)   # (validates the SCALE / scvi options)
-  if cfg.extra_outputs and (cfg.model == "fvae" or cfg.latent_mixture):
-    raise ValueError("extra outputs are not built for FVAE / the mixture-density posterior")
   nl = (1 + 2 * cfg.n_components) * D if cfg.latent_mixture else (2 * D if cfg.stochastic else D)
   out += [("lat/W", (h, nl)), ("lat/b", (nl,))]
   if cfg.model == "scale" and not cfg.latent_mixture:

@@ -190,13 +190,10 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   if (cfg->model == SMX_MODEL_FVAE) {
     SMX_REQUIRE(cfg->disc_layers >= 1 && cfg->disc_layers <= SMX_MAX_LAYERS && cfg->disc_units >= 1, "fvae: discriminator needs 1..8 hidden layers");
     SMX_REQUIRE(cfg->disc_leak >= 0.f && cfg->disc_leak < 1.f, "fvae: leaky-ReLU slope in [0, 1)");
-    SMX_REQUIRE(cfg->n_labels <= 1, "fvae: at most one (one-hot) label variable");
-    if (cfg->n_labels == 1)
-      SMX_REQUIRE(cfg->label_llk[0] == SMX_LABEL_ONEHOT && cfg->label_dim[0] >= 2 && cfg->label_dim[0] <= 32, "fvae: the label variable is one-hot with 2..32 classes");
   }
   if (cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL) SMX_REQUIRE(cfg->n_components >= 2 && cfg->n_components <= 32, "scale: 2..32 mixture components");
   if (cfg->model == SMX_MODEL_SCALE_TRIL) SMX_REQUIRE(cfg->latent_dim <= 32, "scale with full-covariance components: at most 32 latent dimensions");
-  if (cfg->model == SMX_MODEL_SCALE_POST) SMX_REQUIRE(cfg->n_components >= 2 && cfg->n_components <= 8 && cfg->n_components <= cfg->latent_dim && cfg->latent_dim <= 64 && cfg->n_labels == 0, "scale with a mixture-density posterior: 2 .. min(latent_dim, 8) components, at most 64 latent dimensions, no label heads");
+  if (cfg->model == SMX_MODEL_SCALE_POST) SMX_REQUIRE(cfg->n_components >= 2 && cfg->n_components <= 8 && cfg->n_components <= cfg->latent_dim && cfg->latent_dim <= 64, "scale with a mixture-density posterior: 2 .. min(latent_dim, 8) components, at most 64 latent dimensions");
   SMX_REQUIRE(cfg->likelihood >= SMX_LLK_NB && cfg->likelihood <= SMX_LLK_MSE, "unknown likelihood");
   SMX_REQUIRE(cfg->n_labels >= 0 && cfg->n_labels <= SMX_MAX_LABELS, "too many label heads");
   // (SCALE with label heads = SCALAR, sisua/models/scale.py:52-59: the mixture prior of SCALE under SISUA's semi-supervised heads)
@@ -204,8 +201,14 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   for (int j = 0; j < cfg->n_labels; ++j) {
     if (cfg->label_observed[j]) { SMX_REQUIRE(j == n_observed, "observed output heads come before the label heads"); ++n_observed; }
   }
-  // (outputs[1:], tests/test_singlecell_models.py:129-141 / scvi.py:168-169: observed heads on any model's decoder output)
-  SMX_REQUIRE(n_observed == 0 || (cfg->model != SMX_MODEL_FVAE && cfg->model != SMX_MODEL_SCALE_POST), "extra outputs are not built for FVAE / the mixture-density posterior");
+  // (outputs[1:], tests/test_singlecell_models.py:129-141 / scvi.py:168-169: observed heads on any model's decoder output -- FactorVAE
+  // (fvae.py:9-18 passes `outputs` through unchanged) and the mixture-density posterior included since round 5)
+  if (cfg->model == SMX_MODEL_FVAE) {   // SemiFVAE's label variable (behind the observed outputs) is classified by the discriminator: no head
+    SMX_REQUIRE(cfg->n_labels - n_observed <= 1, "fvae: at most one (one-hot) label variable");
+    if (cfg->n_labels > n_observed)
+      SMX_REQUIRE(cfg->label_llk[n_observed] == SMX_LABEL_ONEHOT && cfg->label_dim[n_observed] >= 2 && cfg->label_dim[n_observed] <= 32, "fvae: the label variable is one-hot with 2..32 classes");
+  }
+  if (cfg->model == SMX_MODEL_SCALE_POST) SMX_REQUIRE(cfg->n_labels == n_observed, "scale with a mixture-density posterior: no label heads (observed outputs only)");
   SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->model == SMX_MODEL_FVAE || cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL || cfg->n_labels == n_observed,
               "label heads need model = SISUA, SCALE (SCALAR) or FVAE (SemiFVAE)");
   SMX_REQUIRE(cfg->scvi_dispersion >= 0 && cfg->scvi_dispersion <= 2 && cfg->scvi_inflation >= 0 && cfg->scvi_inflation <= 2, "scvi_dispersion / scvi_inflation: 0 ('full'), 1 ('share') or 2 ('single')");
@@ -225,7 +228,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   m->stochastic = cfg->model != SMX_MODEL_DCA; m->scvi = cfg->model == SMX_MODEL_SCVI; m->scale = cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL; m->scale_tril = cfg->model == SMX_MODEL_SCALE_TRIL;
   m->mixpost = cfg->model == SMX_MODEL_SCALE_POST;
   m->lat_planes = m->mixpost ? 1 + 2 * cfg->n_components : (m->stochastic ? 2 : 1);
-  m->fvae = cfg->model == SMX_MODEL_FVAE; m->n_heads = m->fvae ? 0 : cfg->n_labels; m->n_observed = n_observed;
+  m->fvae = cfg->model == SMX_MODEL_FVAE; m->n_heads = m->fvae ? n_observed : cfg->n_labels; m->n_observed = n_observed;
   m->out_has_W[1] = cfg->scvi_dispersion == 0; m->out_has_W[2] = cfg->scvi_inflation == 0;
   m->out_single[1] = cfg->scvi_dispersion == 2; m->out_single[2] = cfg->scvi_inflation == 2;
   m->Bmax = cfg->max_batch;
@@ -252,10 +255,11 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     int32_t du[SMX_MAX_LAYERS];
     for (int i = 0; i < cfg->disc_layers; ++i) du[i] = cfg->disc_units;
     const int hu = build_mlp(m, m->disc, "disc", m->D, cfg->disc_layers, du, 0, 0.f, false, cfg->disc_leak);
-    const int n_out = cfg->n_labels ? cfg->label_dim[0] : 1;
+    const bool semi = cfg->n_labels > n_observed;   // (the label variable sits behind the observed outputs in the target order)
+    const int n_out = semi ? cfg->label_dim[n_observed] : 1;
     m->t_discoutW = add_tensor(m, "discout/W", hu, n_out, 1, false);
     m->t_discoutb = add_tensor(m, "discout/b", 1, n_out, 1, true);
-    if (cfg->n_labels) m->lab_Pp[0] = round_up(cfg->label_dim[0], 32);
+    if (semi) m->lab_Pp[n_observed] = round_up(cfg->label_dim[n_observed], 32);
   }
   if (m->scvi) {
     for (int ch = 0; ch < m->k; ++ch) {   // (scvi.py:66-86: no Dense head for a 'share'd plane -- its per-gene vector is out{ch}/b alone)

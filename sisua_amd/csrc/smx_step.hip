@@ -862,9 +862,11 @@ int factor_forward(smx_model* m, const Pass& ps, bool backward) {
   h.logits = m->slab; h.n_slabs = eff; h.slab_stride = g.slab_stride; h.ld = tw.ld;
   h.bias = P_(m, m->t_discoutb); h.n_out = tw.cols; h.B = B;
   h.gamma = c.gamma; h.alpha = c.alpha; h.inv_gb = 1.f / (float)ps.global_batch; h.backward = backward ? 1 : 0;
-  if (c.n_labels && m->Y[0] && ps.Xsrc == m->X) { h.Y = m->Y[0]; h.ldy = m->lab_Pp[0]; h.rows = ps.rows; h.mask = m->mask; }
+  const int jd = m->n_observed;   // SemiFVAE's label variable: behind the observed outputs in the target order
+  const bool semi = c.n_labels > jd;
+  if (semi && m->Y[jd] && ps.Xsrc == m->X) { h.Y = m->Y[jd]; h.ldy = m->lab_Pp[jd]; h.rows = ps.rows; h.mask = m->mask; }
   h.u_tc = m->u_d + (size_t)2 * B * 32; h.u_d = m->u_d;   // (one buffer: rows [0, 2B) the discriminator's objective, [2B, 3B) the TC term)
-  h.tc_cell = m->tc_cell; h.dl_cell = m->dl_cell; h.llk_y = c.n_labels ? m->llk_y : nullptr;
+  h.tc_cell = m->tc_cell; h.dl_cell = m->dl_cell; h.llk_y = semi ? m->llk_y : nullptr;
   Timed t(m, "disc_head");
   SMX_CHECK(launch_disc_head(m->st, h));
   return SMX_OK;

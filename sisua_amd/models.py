@@ -157,8 +157,6 @@ class SingleCellModel:
     enc = self._encoder[0]
     labels = [_head_kind(rv, "label") for rv in self._labels]
     extras = [_head_kind(rv, "output") for rv in self._outputs[1:]]   # outputs[1:]: fully observed heads (weight 1, no label mask)
-    if extras and (self._kind == "fvae" or getattr(self, "_latent_mixture", False)):
-      raise ValueError(f"{type(self).__name__} is built for ONE output variable (outputs[1:] are not built for FVAE / the mixture-density posterior)")
     if len(extras) + len(labels) > 4:
       raise ValueError("at most 4 heads (outputs[1:] + label variables) are built")
     encl = self._encoder[1].units if len(self._encoder) > 1 else (64,)

@@ -133,7 +133,7 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
     j_disc = 0.5 * (torch.nn.functional.softplus(-torch.logsumexp(logits_z, 1)).mean()
                     + torch.nn.functional.softplus(torch.logsumexp(logits_p, 1)).mean())
     if spec.labels:
-      yj = torch.as_tensor(np.asarray(y[0], np.float64))
+      yj = torch.as_tensor(np.asarray(y[len(spec.extra_outputs)], np.float64))   # (behind the observed outputs in the target order)
       llk_y = td.OneHotCategorical(logits=logits_v).log_prob(yj)
       j_disc = j_disc - spec.alpha * (m * td.OneHotCategorical(logits=logits_z).log_prob(yj)).mean()
   # heads on the decoder output: the extra OUTPUT variables first (fully observed: weight 1, no mask), then the label variables
@@ -233,6 +233,13 @@ CASES = {
                               extra_outputs=((6, "zinb"), (5, "zinbd"))),
     "sisua_extra_output": dict(model="sisua", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5,
                                extra_outputs=((6, "nb"),), labels=((5, "nbd"), (4, "onehot")), alpha=10.0),
+    # round 5: outputs[1:] on FactorVAE / SemiFVAE (its label variable behind the observed outputs) and on the mixture-density posterior
+    "fvae_two_outputs": dict(model="fvae", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, disc_units=24, disc_layers=3,
+                             extra_outputs=((6, "nbd"),)),
+    "semifvae_two_outputs": dict(model="fvae", n_genes=40, likelihood="nb", enc_units=(16,), dec_units=(16,), latent_dim=4, disc_units=20, disc_layers=2,
+                                 extra_outputs=((5, "zinb"),), labels=((4, "onehot"),), alpha=5.0),
+    "scale_post_two_outputs": dict(model="scale", n_genes=40, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, n_components=3, latent_mixture=True,
+                                   extra_outputs=((6, "nb"),)),
     "dca_two_outputs": dict(model="dca", n_genes=36, likelihood="zinb", enc_units=(12,), dec_units=(12,), latent_dim=4, extra_outputs=((5, "onehot"),)),
     # scvi.py:168-169 (posteriors[1:] on the decoder output) and scvi.py:55-56,66-86 (dispersion / inflation without a head)
     "scvi_two_outputs": dict(model="scvi", n_genes=40, likelihood="zinbd", enc_units=(16,), dec_units=(16,), latent_dim=4, encl_units=(8,),
