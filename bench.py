@@ -248,19 +248,23 @@ def measure_mode(cp, rank, world, local_rank, cfg, batch, steps, warmup, upload,
           "final_loss": round(float(hist["loss"][-1]), 4)}
 
 
-# DESIGN.md section 5 "What N = 8 will print": the per-step budget table turned into figures (one MI355X node, RCCL over xGMI).  These
-# are PREDICTIONS written before any multi-GPU run existed (no node was available to the builder in rounds 1-4); the driver's scaling
-# record is what replaces them.
+# DESIGN.md section 5 "What N = 8 is expected to print": the per-step budget table turned into figures (one MI355X node, RCCL over xGMI).
+# These are PREDICTIONS written before any multi-GPU run existed (no node was available to the builder in rounds 1-5); the driver's scaling
+# record is what replaces them.  Round 5: the step exchanges two buckets as a chain (head bucket all-reduced, normed and applied on the
+# communication stream beside the rest of the step; front bucket on the model's stream), so what is left on the critical path is the front
+# bucket's all-reduce and the second queue's cost (profiles/r05_dp_overhead_one_rank.txt).
 PREDICTED_N8 = {
-    "weak": {"ms_per_step": [0.125, 0.165], "cells_per_s": [6.2e6, 8.2e6], "x_one_gpu": [3.9, 5.2],
-             "reading": "82 us of step + 4.4 us for the data-parallel form + a blocking 4.2 MB all-reduce (>= 13.7 us of link time at peak, "
-                        "40-80 us expected from RCCL's ring at this size): the >= 6.5x target (<= 102 us) is NOT expected without overlap"},
-    "strong_syncbn": {"ms_per_step": [0.17, 0.25], "cells_per_s": [0.5e6, 0.75e6], "x_one_gpu": [0.32, 0.48],
-                      "reading": "16 cells per GPU: the step stays a chain of 11 launch-bound launches (~75 us), + the 4.2 MB all-reduce + 4 small "
+    "weak": {"ms_per_step": [0.116, 0.136], "cells_per_s": [7.5e6, 8.8e6], "x_one_gpu": [4.5, 5.3],
+             "reading": "76 us of step + ~20 us for the chained data-parallel form (measured on one rank: 99.5 against 79.9 us) + a blocking all-reduce of the "
+                        "1.1 MB front bucket (latency-bound: 20-40 us expected from RCCL); the 3.1 MB head bucket has ~75 us of window (40-60 us expected): "
+                        "the >= 6.5x target (<= 93 us per step) is still NOT expected at 128 cells per GPU"},
+    "strong_syncbn": {"ms_per_step": [0.16, 0.24], "cells_per_s": [0.53e6, 0.8e6], "x_one_gpu": [0.32, 0.48],
+                      "reading": "16 cells per GPU: the step stays a chain of 11 launch-bound launches (~72 us), + the front bucket's all-reduce + 4 small "
                                  "SyncBatchNorm collectives of ~10-20 us each: strong scaling at batch 128 is a slowdown, as DESIGN section 5 says"},
-    "c5": {"ms_per_step": [0.40, 0.75], "cells_per_s": [1.4e6, 2.6e6], "x_one_gpu": [2.1, 4.0],
-           "reading": "~165-195 us of step + a blocking 41 MB all-reduce: 134 us of link time at peak two-shot, 0.3-0.5 ms expected from "
-                      "RCCL's ring; only the two-bucket overlap (SMX_DP_BUCKETS=2) can hide most of it"},
+    "c5": {"ms_per_step": [0.25, 0.37], "cells_per_s": [2.8e6, 4.1e6], "x_one_gpu": [3.6, 5.3],
+           "reading": "~165 us of step (172.5 us with the chain on one rank) + a blocking all-reduce of the 10.4 MB front bucket (34 us of link time at peak "
+                      "two-shot, 80-120 us expected from RCCL's ring); the 30.7 MB head bucket runs beside the backward pass, the optimiser and the next "
+                      "step's encoder / decoder (~120 us of window: 100 us of link time at peak, 120-200 us expected from the ring -- up to ~80 us of it exposed)"},
 }
 
 
