@@ -481,7 +481,7 @@ def test_bench_line_at_two_ranks_carries_every_scaling_mode(tmp_path):
   assert out["scaling"] == "weak" and out["config"]["global_batch"] == 256 and out["dp"]["collective"] == "p2p-only"
   assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out     # (the CPU baseline is an N = 1 item)
   # the longer run beside the contract's K steps: 300 more steps of the same engine, never `value`
-  assert out["value_300"] > 0 and np.isclose(out["value_300"], 300 * 256 / (out["ms_per_step_300"] * 1e-3), rtol=1e-3)
+  assert out["value_300"] > 0 and np.isclose(out["value_300"], 256 / (out["ms_per_step_300"] * 1e-3), rtol=1e-3)
   sm = out["scaling_modes"]
   assert set(sm) == {"weak", "strong_syncbn", "c5"}
   expect = {"weak": (128, 256, False), "strong_syncbn": (64, 128, True), "c5": (128, 256, False)}
