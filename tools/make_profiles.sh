@@ -9,8 +9,11 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-r03}
 O=$R/gpurun_out/$TAG
-rm -rf $O; mkdir -p $O   # (gpurun merges into an existing gpurun_out/: remove stale trace dirs locally before copying)
+PART=${2:-all}   # a gpurun call is limited to 20 minutes: `make_profiles.sh r05 1`, then `make_profiles.sh r05 2` (outputs merge under gpurun_out/<tag>/)
+[ "$PART" != 2 ] && rm -rf $O
+mkdir -p $O   # (gpurun merges into an existing gpurun_out/: remove stale trace dirs locally before copying)
 cd $R
+if [ "$PART" != 2 ]; then
 # ---- the headline: default flags as the driver runs them, then a long run ----
 python3 bench.py --steps 20 --warmup 5 > $O/bench_driver_settings.json 2> $O/bench_driver_settings.err
 python3 bench.py --steps 300 --warmup 30 > $O/bench.json 2> $O/bench.err
@@ -31,6 +34,8 @@ done
 cp gpurun_out/pmc/pmc_summary.json $O/ 2>/dev/null; rm -rf gpurun_out/pmc
 ./tools/pmc_pass.sh c5-shard > $O/pmc_summary_c5-shard.txt 2>&1
 cp gpurun_out/pmc/pmc_summary.json $O/pmc_summary_c5-shard.json 2>/dev/null; rm -rf gpurun_out/pmc
+fi
+if [ "$PART" != 1 ]; then
 # ---- pipe occupancy (SQ counters in separate passes) at the C5 width and of the fused output head by itself ----
 ./tools/pipe_pass.sh c5-shard > /dev/null 2>&1; cp gpurun_out/pipe_c5-shard/pipe_util.txt $O/pipe_occupancy_c5-shard.txt 2>/dev/null
 ./tools/hf_pipe.sh zinb > /dev/null 2>&1; cp gpurun_out/hfpipe_zinb/pipe_util.txt $O/pipe_occupancy_head_fused.txt 2>/dev/null
@@ -62,4 +67,5 @@ python3 bench.py --workload c5 --steps 300 --warmup 30 > $O/bench_c5_full.json 2
 for s in f32 u16 csr; do python3 bench.py --storage $s --steps 300 --warmup 30 --no-cpu-baseline --no-c5-entry 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$s', d['ms_per_step'], d['final_loss'])"; done > $O/storage_formats.txt
 # ---- data-parallel overheads on one rank: RCCL vs the peer-to-peer exchange, one collective vs two buckets ----
 { python3 tools/dp_overhead.py 8kly; python3 tools/dp_overhead.py c5-shard; } > $O/dp_overhead.txt 2>&1
+fi
 ls -la $O
