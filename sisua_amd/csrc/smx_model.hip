@@ -440,6 +440,8 @@ int smx_model_destroy(smx_model* m) {
   if (m->bigk_part) hipFree(m->bigk_part);
   if (m->hf_tab) hipFree(m->hf_tab);
   p2p_release(m);
+  if (m->comm2 && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm2);   // (the heads' bucket's communicator: a split of `comm`, destroyed first)
+  m->comm2 = nullptr;
   if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
   m->comm = nullptr;
   m->local.reset();
