@@ -4,34 +4,33 @@
 //   P = d W_out + b  ->  NB / ZINB / NBD / ZINBD log-likelihood of x, d llk / d P (scaled) = dP
 //   dW_out = d^T dP,  db_out = colsum(dP),  sum of squares of dW_out (clipnorm),  d d = dP W_out^T (per-workgroup slabs)
 //
-// Neither P nor dP exists in memory.  Before: out_head_loss_kernel (P in registers, dP stored: 31 MB) -> bigk_kernel +
+// Neither P nor dP exists in memory.  Before (round 3): out_head_loss_kernel (P in registers, dP stored: 31 MB) -> bigk_kernel +
 // bigk_reduce_kernel (d d: dP and W_out read again) -> panel_dw_kernel (dW: dP read a third time): 35 + 20 + 5 + 18 us at
-// 128 x 20 000 with three launch boundaries between them.  Here a workgroup OWNS a tile of 32 genes (all k planes, all <= 128
-// cells) from the raw weights to their gradients and walks its tiles; per tile W_out is read once and dW_out written once.
+// 128 x 20 000 with three launch boundaries between them.  Here a workgroup OWNS gene tiles (all k planes, all <= 128 cells) from
+// the raw weights to their gradients and walks them; W_out is read once and dW_out written once.
 //
 // Shape of the work (the flash-attention-backward decomposition, cdna_hip_programming.md "Attention backward": the gene plays
 // the key, the cell the query):
 //  * 8 waves (2 per SIMD, 256 registers each); wave w owns the cells 16 w .. 16 w + 15 in the forward product and in d d, and
 //    the rows 16 w .. 16 w + 15 of H in dW.  All products are v_mfma_f32_16x16x32_bf16 on three-way split operands (six of
 //    the nine cross products: f32 accuracy, smx_device.h).
-//  * forward with the CELL ON THE LANE: P^T[rho][cell] = sum_h W[h][rho] d[cell][h] (rho = 32 plane + gene of the tile).  A lane
-//    then holds, for ONE cell, 8 genes x k planes: the likelihood runs on the accumulators where they are, and its result dP^T
-//    is, register for register, the B operand of d d^T[h][cell] += sum_rho W[h][rho] dP^T[rho][cell] (a product that sums over
-//    the accumulator's ROW index takes it without any lane movement), accumulated in 32 registers for the whole launch.
-//  * dW = d^T dP sums over the cell = the LANE index: dP crosses LDS once, written as the lane's two runs of 4 genes (16 bytes per term) into a
-//    [cell][rho] image (three bf16 terms) and read back column-wise by ds_read_b64_tr_b16 (the hardware transpose read).
-//  * W_out's tile is split ONCE per workgroup into a [h][rho] bf16 x 3 image: the forward product reads it transposed
-//    (ds_read_b64_tr_b16), d d reads its rows.  Both images: 64-byte rows per (term, plane) = 4 slots of 16 bytes holding columns
-//    4 s .. 4 s + 3 of both 16-column halves side by side (a lane's two runs of a row read or write are ONE 16-byte access), the slot
-//    XOR-ed with row bits (row reads conflict-free, transposed reads 2-way).
+//  * forward with the CELL ON THE LANE: P^T[rho][cell] = sum_h W[h][rho] d[cell][h] (rho = plane, gene of the unit).  A lane
+//    then holds, for ONE cell, 4 genes x k planes: the likelihood runs on the accumulators where they are, and its result dP^T
+//    is (after one v_permlane32_swap: below) the B operand of d d^T[h][cell] += sum_rho W[h][rho] dP^T[rho][cell] (a product that
+//    sums over the accumulator's ROW index), accumulated in 32 registers for the whole launch.
+//  * dW = d^T dP sums over the cell = the LANE index: dP crosses LDS once as a [cell][gene] image of three bf16 terms per plane and is
+//    read back column-wise by ds_read_b64_tr_b16 (the hardware transpose read).
+//  * W_out's tile is split ONCE per workgroup into a [h][gene] bf16 x 3 image per plane: the forward product reads it transposed
+//    (ds_read_b64_tr_b16), d d reads its rows.
 //  * d's operands never change: a wave's two views of d (its cells' rows for the forward product, its H rows' columns for dW) are
-//    split once; the first stays in 48 registers, the second is parked in an L2-resident table and fetched per tile (below); no LDS
-//    image of d (144 KB of LDS are the two images above).
+//    split once and stay in 48 + 48 registers (zinbd: the second is parked in an L2-resident table and fetched per unit); no LDS
+//    image of d (144 KB of LDS are the images above, two slots of each).
 //  * the k index of every product is permuted consistently in both operands (lane group g, element e <-> k = 4 g + e for
 //    e < 4, 16 + 4 g + e - 4 otherwise) so that the transposed reads of a 32-lane half touch 8 consecutive rows.
-//  * 2 workgroup barriers per tile; the next tile's W (global -> registers) and counts are in flight under the current tile.
 //  * the per-wave queue of the non-zero counts (smx_loss.h) lives in the wave's own rows of the dP image.
 // Deterministic: no atomics; per-workgroup d d slabs are summed by bigk_reduce_kernel in workgroup order.
+// Round 4's kernel walked whole tiles of 32 genes with two barriers per tile (one phase kind between them); round 5's (below) walks
+// units of 16 genes through two slots of each image with one barrier per unit -- profiles/r05_head_fused_experiments.txt has the A/B.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -100,378 +99,9 @@ __device__ inline void hf_store1(float v, __amdgpu_buffer_rsrc_t r, int vo, int 
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, vo, so, 0);
 }
 
-// the wave's queue of non-zero counts (smx_loss.h) inside rows 16 w .. 16 w + 15 of the dP image's first four sub-images
-struct HfQueue {
-  unsigned char* base;
-  __device__ float2& operator[](int k) const { return *reinterpret_cast<float2*>(base + (k >> 7) * 8192 + (k & 127) * 8); }
-  __device__ explicit operator bool() const { return true; }
-};
-
-// VW: the eight 16-cell / 16-row shares of a workgroup are carried by 8 / VW hardware waves.
-// What decides it is the register file: hipcc gives the MFMAs' A / B operands vector registers only (the accumulator half of the
-// file takes accumulators), so the two resident views of d (96 registers per share) sit in the half that the likelihood needs.
-//   VW = 2 (256 threads, one wave per SIMD, 512 registers): both views resident; measured 103 us at 128 x 20 000 zinb (117 registers
-//   in scratch, every LDS round trip and every dependent MFMA chain exposed -- nothing else runs on the SIMD).
-//   VW = 1 (512 threads, two waves per SIMD, 256 registers): the view for dW is resident only while that product runs.  Each wave writes
-//   it once to a table in global memory (a.dtab, 96 KB, the same bytes from every workgroup: L2-resident) and reads it back -- 12
-//   coalesced 16-byte loads -- one phase before it is needed, ahead of the next tile's W so that the wait for it does not also wait
-//   for that (vector-memory results return in order).  (Both views that way: +1-2 us -- 123 MB of L2 reads per launch.)
 #ifndef SMX_HF_STAMP_WAVE
 #define SMX_HF_STAMP_WAVE 0
 #endif
-template <int LK, int U16, int VW>
-__global__ __launch_bounds__(512 / VW, 2 / VW) void head_fused_v1_kernel(HeadFusedArgs a) {
-  constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
-  constexpr int NSUB = 2 * NP;             // 16-column groups of a tile's rho axis
-  constexpr int IMG = 3 * NP * 8192;       // bytes of one image (three terms x NP planes x [128][32] bf16)
-  constexpr int T = 512 / VW;              // threads
-  constexpr int RPT = T / 8;               // W rows one pass of the workgroup's float4 loads covers (8 threads per 128-byte row segment)
-  constexpr int UPP = 128 / RPT;           // passes per plane
-  constexpr int NWL = NP * UPP;            // float4 of W per thread and tile
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  // lds + 0: the W image [term][plane][h 128][32]
-  unsigned char* const Pimg = lds + IMG;                // [term][plane][cell 128][32]
-  float* const dbx = reinterpret_cast<float*>(lds + 2 * IMG);   // [8 shares][32 NP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 15, g = lane >> 4;               // column of a 16 x 16 tile | lane group (k octet / row quad)
-  const int q4 = j >> 2, pp = j & 3;                    // transposed read: this lane addresses row q4, slot pp of its group's block
-  // Lane parts of every LDS address, formed once; everything else of an address is a compile-time constant (an immediate
-  // of the ds instruction).  The swizzle's row bits are lane bits in every access shape:
-  //   transposed reads: row = 32 ks + 16 rd + 4 g + q4 -> bits 2, 3 of the row are bits 0, 1 of g
-  //   row reads of d d / the dP writes: row = 16 hs + j (16 w + j) -> bits 2, 3 of j
-  //   the W image's writes: row = RPT u + (tid >> 3) -> bits 2, 3 of tid >> 3
-  // ... and every base is made OPAQUE to the optimiser (hf_hide): knowing that a base's bits below 1024 are the only ones set it turns
-  // base + 8192 n into base | 8192 n, no longer folds the constant into the instruction's offset field, and keeps one register per
-  // distinct address instead (~100 of them, spilled around the tile loop).  The offset field holds 16 bits: two bases per image half
-  // (sub-images 0..3 and 4..8).
-  int tb[2][2][2], rb[2][2][2];   // transposed reads / row accesses: [image: W, dP][sub-images 4.. ][column half]
-#pragma unroll
-  for (int hf = 0; hf < 2; ++hf) {
-    // (a row = 64 bytes = 4 slots of 16 bytes; slot s holds columns 4 s .. 4 s + 3 of BOTH halves side by side, so that a lane's two runs of
-    // a row read are ONE 16-byte access; the slot is XOR-ed with f(row >> 2), f = 0, 2, 3, 1: every 16-lane group of ds_read_b128 then
-    // touches 16 different slots; the transposed reads are 2-way on it -- rows r and r + 4 of a half-wave share a bank pair)
-    const int t = 64 * (4 * g + q4) + 16 * (pp ^ ((0x78 >> (2 * g)) & 3)) + 8 * hf;
-    const int r = 64 * j + 16 * (g ^ ((0x78 >> (2 * ((j >> 2) & 3))) & 3));
-#pragma unroll
-    for (int im = 0; im < 2; ++im)
-#pragma unroll
-      for (int hi = 0; hi < 2; ++hi) { tb[im][hi][hf] = hf_hide(t + im * IMG + hi * 32768); rb[im][hi][hf] = hf_hide(r + im * IMG + hi * 32768); }
-  }
-  const int wt = tid >> 3, wc4 = tid & 7;
-  int wwb[2];
-#pragma unroll
-  for (int hi = 0; hi < 2; ++hi) wwb[hi] = hf_hide(64 * wt + 16 * ((wc4 & 3) ^ ((0x78 >> (2 * ((wt >> 2) & 3))) & 3)) + 8 * (wc4 >> 2) + hi * 32768);
-  const int wgo = (int)((wt * a.ldw + 4 * wc4) * 4);   // this thread's float4 of a W tile (bytes): rows wt, wt + RPT, ... of every plane
-  const long wbytes = 128L * a.ldw * 4;
-  const __amdgpu_buffer_rsrc_t rW = hf_rsrc(a.W, wbytes), rdW = hf_rsrc(a.dW, wbytes);
-  const __amdgpu_buffer_rsrc_t rbias = hf_rsrc(a.bias, a.ldw * 4), rdb = hf_rsrc(a.db, a.ldw * 4);
-  const __amdgpu_buffer_rsrc_t rllk = hf_rsrc(a.llk_part, (long)a.B * a.n_gt * 4), rtab = hf_rsrc(a.dtab, SMX_HEAD_FUSED_TAB_BYTES);
-
-  // ---- loads of a tile: this thread's NWL float4 of W (row-major segments of 128 bytes), the lanes' counts ---------------
-  float4 wreg[NWL];
-  auto load_w = [&](int tile) {
-#pragma unroll
-    for (int u = 0; u < NWL; ++u)   // u = UPP plane + pass
-      wreg[u] = hf_load4(rW, wgo, (int)((tile * 32 + (long)(RPT * (u % UPP)) * a.ldw + (long)(u / UPP) * a.Gp) * 4));
-  };
-  int tile = blockIdx.x;
-  load_w(tile);   // (requested before the prologue: the first tile's HBM latency runs under the split of d)
-#ifdef SMX_HF_STAMPS
-  if (a.dbg && tid == 64 * SMX_HF_STAMP_WAVE && (blockIdx.x == 0 || blockIdx.x == 100)) a.dbg[(blockIdx.x ? 64 : 0) + 63] = clock64();   // kernel entry
-#endif
-
-  // ---- both views of d per share, split once -----------------------------------------------------------------------------
-  // dB[v][ks]: B operand of the forward product, d[cell][k], k = 32 ks + (e < 4 ? 4 g + e : 16 + 4 g + e - 4)
-  // dA[v][ks]: A operand of dW, d[k = cell'][h = 16 w + j] over the same k order
-  Split8 dB[VW][4], dA[VW][4];
-  hf_f32x4 accDD[VW][8];
-  int cell[VW], dw_vo[VW]; bool cell_ok[VW]; long src[VW];
-#pragma unroll
-  for (int v = 0; v < VW; ++v) {
-    const int w = VW * wave + v;
-    cell[v] = 16 * w + j;                               // forward / d d: the lane's cell
-    dw_vo[v] = (int)(((16 * w + 4 * g) * a.ldw + j) * 4);   // dW: row 16 w + 4 g (+ r), column j (+ the tile's) in bytes
-    const int cellc = min(cell[v], a.B - 1);
-    cell_ok[v] = cell[v] < a.B;
-    src[v] = a.rows ? (long)a.rows[cellc] : (long)cellc;
-    const float* dp = a.D + (long)cellc * a.ldd;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const float4 lo = *reinterpret_cast<const float4*>(dp + 32 * ks + 4 * g);
-      const float4 hi = *reinterpret_cast<const float4*>(dp + 32 * ks + 16 + 4 * g);
-      const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      dB[v][ks] = split3x8(x);
-    }
-    const float* da = a.D + 16 * w + j;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      float x[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = 32 * ks + (e < 4 ? 4 * g + e : 16 + 4 * g + e - 4);
-        x[e] = da[(long)min(c, a.B - 1) * a.ldd];       // (a cell beyond the minibatch meets dP = 0)
-      }
-      dA[v][ks] = split3x8(x);
-    }
-#pragma unroll
-    for (int hs = 0; hs < 8; ++hs) accDD[v][hs] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  // the table of the view for dW: [wave 8][ks 4][term 3][lane 64] x 16 bytes
-  constexpr bool RELOAD = VW == 1 && LK != SMX_LLK_NB;   // (two planes, the lighter likelihood: both views fit -- 43.6 -> 41.0 us at 128 x 20 000)
-  const int tab_vo = lane * 16, tabA = wave * 12 * 1024;   // (scalar byte offset of the wave's entries)
-  if (RELOAD) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      hf_store8h(dA[0][ks].t0, rtab, tab_vo, tabA + (3 * ks + 0) * 1024); hf_store8h(dA[0][ks].t1, rtab, tab_vo, tabA + (3 * ks + 1) * 1024); hf_store8h(dA[0][ks].t2, rtab, tab_vo, tabA + (3 * ks + 2) * 1024);
-    }
-    // the wave's own table entries are written before it reads them back.  The stored registers are operands of the wait: measured on
-    // MI355X, a 16-byte buffer store whose data registers are reused by the instructions right behind it (they are dead once stored)
-    // wrote garbage -- with the registers held until the stores have completed the table is right (tools/headfused_try.py)
-#define HF_V(x) "v"(x.t0), "v"(x.t1), "v"(x.t2)
-    asm volatile("s_waitcnt vmcnt(0)" :: HF_V(dA[0][0]), HF_V(dA[0][1]), HF_V(dA[0][2]), HF_V(dA[0][3]) : "memory");
-#undef HF_V
-  }
-  // (the lane offset goes through hf_hide at every call: a load from a loop-invariant address is otherwise hoisted out of the tile loop --
-  // the view would be resident again, and requested right behind its own stores)
-  auto load_view = [&](int tab, Split8 (&dst)[4]) {
-    const int vo = hf_hide(tab_vo);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      dst[ks].t0 = hf_load8h(rtab, vo, tab + (3 * ks + 0) * 1024); dst[ks].t1 = hf_load8h(rtab, vo, tab + (3 * ks + 1) * 1024); dst[ks].t2 = hf_load8h(rtab, vo, tab + (3 * ks + 2) * 1024);
-    }
-  };
-  float ssq = 0.f;
-  // `gate` is always true, and opaque: HF_STAMP() at the seam of two phases is a (never taken) branch on it, which makes every phase a
-  // basic block of its own.  Without real block boundaries there the compiler merges the phases of a tile into one scheduling region --
-  // across sched_barrier(0) too -- to the point of ~70 registers in scratch, whose reloads (a memory round trip each, with two waves
-  // per SIMD to hide it) were half of a tile's time.
-  const bool gate = __builtin_amdgcn_readfirstlane(hf_hide(1)) != 0;
-#ifdef SMX_HF_STAMPS   // (development: cycle stamps of the phases of workgroups 0 and 100, read back by smx_k_head_fused under the knob hf_dbg)
-  int dbg_n = 0;
-#define HF_STAMP() do { if (a.dbg && tid == 64 * SMX_HF_STAMP_WAVE && (blockIdx.x == 0 || blockIdx.x == 100)) { a.dbg[(blockIdx.x ? 64 : 0) + dbg_n] = clock64(); ++dbg_n; } } while (0)
-#else
-#define HF_STAMP() do { if (!gate) asm volatile("s_nop 0"); } while (0)
-#endif
-  HF_STAMP();
-
-  uint2 xraw16[VW][2]; float4 xraw32[VW][2];
-  auto load_x = [&](int tile) {
-#pragma unroll
-    for (int v = 0; v < VW; ++v)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const long o = src[v] * a.ldx + (long)tile * 32 + 16 * hf + 4 * g;
-        if (U16) xraw16[v][hf] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.X) + o);
-        else xraw32[v][hf] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.X) + o);
-      }
-  };
-
-  // operand group n = NSUB ks + s of a transposed sweep over image im: rows (k) 32 ks + 16 rd + 4 g + q4, columns of group s
-  auto tr_read = [&](int im, int n) {
-    const int ks = n / NSUB, sb = n % NSUB, p = sb >> 1, hf = sb & 1;
-    Split8 r;
-    r.t0 = cat8(as_bf(__builtin_amdgcn_ds_read_tr16_b64_v4i16(HF_LDS3(HF_AT(tb[im], hf, p, 2048 * ks)))), as_bf(__builtin_amdgcn_ds_read_tr16_b64_v4i16(HF_LDS3(HF_AT(tb[im], hf, p, 2048 * ks + 1024)))));
-    r.t1 = cat8(as_bf(__builtin_amdgcn_ds_read_tr16_b64_v4i16(HF_LDS3(HF_AT(tb[im], hf, NP + p, 2048 * ks)))), as_bf(__builtin_amdgcn_ds_read_tr16_b64_v4i16(HF_LDS3(HF_AT(tb[im], hf, NP + p, 2048 * ks + 1024)))));
-    r.t2 = cat8(as_bf(__builtin_amdgcn_ds_read_tr16_b64_v4i16(HF_LDS3(HF_AT(tb[im], hf, 2 * NP + p, 2048 * ks)))), as_bf(__builtin_amdgcn_ds_read_tr16_b64_v4i16(HF_LDS3(HF_AT(tb[im], hf, 2 * NP + p, 2048 * ks + 1024)))));
-    return r;
-  };
-  // operand group n = 8 p + hs of d d: rows 16 hs + j of the W image, the lane group's two 8-byte runs of plane p
-  auto row_read = [&](int n) {
-    const int p = n / 8, hs = n % 8;
-    Split8 r;
-    r.t0 = *reinterpret_cast<const smx_bf16x8*>(HF_AT(rb[0], 0, p, 1024 * hs));
-    r.t1 = *reinterpret_cast<const smx_bf16x8*>(HF_AT(rb[0], 0, NP + p, 1024 * hs));
-    r.t2 = *reinterpret_cast<const smx_bf16x8*>(HF_AT(rb[0], 0, 2 * NP + p, 1024 * hs));
-    return r;
-  };
-
-  load_x(tile);
-  for (; tile < a.n_gt; tile += gridDim.x) {
-    const int n0 = tile * 32;
-    HF_STAMP();   // top
-    // biases of the lane's 8 genes: the accumulators of the forward product start from them.  (Requested here, after the wait for
-    // W's registers and ahead of the next tile's counts: vector-memory results return in order, so a wait for the biases also waits
-    // for everything requested before them.)
-    float4 bq[NP][2];
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) bq[p][hf] = hf_load4(rbias, 16 * g, (p * a.Gp + n0 + 16 * hf) * 4);
-    // ---- W tile -> bf16 x 3 image (the previous tile's readers are past their last barrier) ---------------------------
-#pragma unroll
-    for (int u = 0; u < NWL; ++u) {
-      const float x[4] = {wreg[u].x, wreg[u].y, wreg[u].z, wreg[u].w};
-      const Split4 s = split3x4(x);
-      const int pl = u / UPP, more = 64 * RPT * (u % UPP);
-      *reinterpret_cast<hf_bf16x4*>(lds + wwb[(pl) >= 4] + (pl - 4 * (pl >= 4)) * 8192 + more) = s.t0;
-      *reinterpret_cast<hf_bf16x4*>(lds + wwb[(NP + pl) >= 4] + (NP + pl - 4 * ((NP + pl) >= 4)) * 8192 + more) = s.t1;
-      *reinterpret_cast<hf_bf16x4*>(lds + wwb[(2 * NP + pl) >= 4] + (2 * NP + pl - 4 * ((2 * NP + pl) >= 4)) * 8192 + more) = s.t2;
-    }
-    // this tile's counts out of their raw registers
-    float xs[VW][8];
-#pragma unroll
-    for (int v = 0; v < VW; ++v)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        if (U16) {
-          xs[v][4 * hf] = (float)(xraw16[v][hf].x & 0xFFFFu); xs[v][4 * hf + 1] = (float)(xraw16[v][hf].x >> 16);
-          xs[v][4 * hf + 2] = (float)(xraw16[v][hf].y & 0xFFFFu); xs[v][4 * hf + 3] = (float)(xraw16[v][hf].y >> 16);
-        } else {
-          xs[v][4 * hf] = xraw32[v][hf].x; xs[v][4 * hf + 1] = xraw32[v][hf].y; xs[v][4 * hf + 2] = xraw32[v][hf].z; xs[v][4 * hf + 3] = xraw32[v][hf].w;
-        }
-      }
-    HF_STAMP();   // W written
-    __syncthreads();   // (A) the W image is complete; every wave has left the previous tile's dW (the dP image, dbx are free)
-    HF_STAMP();   // barrier A passed
-    const int next = tile + gridDim.x;
-
-#pragma unroll
-    for (int v = 0; v < VW; ++v) {
-      const int w = VW * wave + v;
-      // ---- forward: P^T[rho][cell], A = W^T read transposed from the image, B = the share's rows of d -----------------
-      hf_f32x4 accP[NSUB];
-#pragma unroll
-      for (int s = 0; s < NSUB; ++s) accP[s] = hf_f32x4{bq[s >> 1][s & 1].x, bq[s >> 1][s & 1].y, bq[s >> 1][s & 1].z, bq[s >> 1][s & 1].w};
-      if (v == 0 && next < a.n_gt) load_x(next);
-      // (one wave per SIMD: nothing hides an LDS round trip but this wave's own MFMAs -- the operands of step n + 1 are requested
-      // before the products of step n are issued)
-      {
-        Split8 cur = tr_read(0, 0), nxt = cur;
-#pragma unroll
-        for (int n = 0; n < 4 * NSUB; ++n) {
-          if (n + 1 < 4 * NSUB) nxt = tr_read(0, n + 1);
-          accP[n % NSUB] = mfma16_bf16x3(cur, dB[v][n / NSUB], accP[n % NSUB]);
-          cur = nxt;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-
-      HF_STAMP();   // fwd done
-      // ---- likelihood on the accumulators: element e = 4 half + r is gene n0 + 16 half + 4 g + r of the lane's cell ---
-      float lsum = 0.f;
-      float dpv[NP][8];
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {   // (four elements at a time)
-        float x4[4], v0[4], v1[4], v2[4], llk[4], d0[4], d1[4], d2[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          x4[r] = xs[v][4 * hf + r];
-          v0[r] = accP[hf][r];
-          v1[r] = accP[2 + hf][r];
-          v2[r] = NP == 3 ? accP[2 * (NP - 1) + hf][r] : 0.f;
-        }
-        if (!gate) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { llk[r] = v0[r] * x4[r]; d0[r] = v0[r]; d1[r] = v1[r]; d2[r] = v2[r]; }
-        } else
-        count_elem_vec<LK, 0, 4>(x4, v0, v1, v2, llk, d0, d1, d2, HfQueue{Pimg + 1024 * w});
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = cell_ok[v] && (n0 + 16 * hf + 4 * g + r) < a.G;
-          lsum += ok ? llk[r] : 0.f;
-          dpv[0][4 * hf + r] = ok ? d0[r] * a.grad_scale : 0.f;
-          dpv[1][4 * hf + r] = ok ? d1[r] * a.grad_scale : 0.f;
-          if (NP == 3) dpv[NP - 1][4 * hf + r] = ok ? d2[r] * a.grad_scale : 0.f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (v == VW - 1 && RELOAD) {
-        load_view(tabA, dA[0]);
-      }
-      HF_STAMP();   // likelihood done
-      // per-cell partial of the tile: the four lane groups hold its 32 genes
-      lsum += __shfl_xor(lsum, 16, 64);
-      lsum += __shfl_xor(lsum, 32, 64);
-      if (g == 0 && cell_ok[v]) hf_store1(lsum, rllk, cell[v] * a.n_gt * 4, tile * 4);
-
-      // ---- dP, plane by plane: bias-gradient partials over the share's 16 cells, the [cell][rho] image, d d^T += W dP^T --------
-      // (A = W[h = 16 hs + j][rho = 32 p + (e < 4 ? 4 g + e : 16 + 4 g + e - 4)]: two 8-byte row reads per term; B = the split plane)
-      Split8 cur = row_read(0), nxt = cur;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float t = dpv[p][e];
-#define HF_DPP_ADD(ctrl) t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), ctrl, 0xF, 0xF, false))
-          HF_DPP_ADD(0xB1); HF_DPP_ADD(0x4E); HF_DPP_ADD(0x141); HF_DPP_ADD(0x140);   // sum over the 16 lanes of the row
-#undef HF_DPP_ADD
-          if (j == 0) dbx[w * 32 * NP + 32 * p + 16 * (e >> 2) + 4 * g + (e & 3)] = t;
-        }
-        const Split8 sp = split3x8(dpv[p]);
-        {
-          const int wo = 1024 * w;   // (the share's rows: a scalar)
-          *reinterpret_cast<smx_bf16x8*>(HF_AT(rb[1], 0, p, 0) + wo) = sp.t0;
-          *reinterpret_cast<smx_bf16x8*>(HF_AT(rb[1], 0, NP + p, 0) + wo) = sp.t1;
-          *reinterpret_cast<smx_bf16x8*>(HF_AT(rb[1], 0, 2 * NP + p, 0) + wo) = sp.t2;
-        }
-#pragma unroll
-        for (int hs = 0; hs < 8; ++hs) {
-          const int n = 8 * p + hs;
-          if (n + 1 < 8 * NP) nxt = row_read(n + 1);
-          accDD[v][hs] = mfma16_bf16x3(cur, sp, accDD[v][hs]);
-          cur = nxt;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        HF_STAMP();
-      }
-    }
-    HF_STAMP();   // dd done
-    if (next < a.n_gt) load_w(next);   // (as late as dW still covers it: its 24 registers are not free before)
-    __syncthreads();   // (B) the dP image and the bias partials are complete; every wave is done with the W image
-    HF_STAMP();   // barrier B passed
-
-    // ---- dW[h = 16 w + 4 g + r][rho] = sum over the cells: A = the share's columns of d, B = dP read transposed ----------
-#pragma unroll
-    for (int v = 0; v < VW; ++v) {
-      (void)wave;
-      hf_f32x4 accW[NSUB];
-#pragma unroll
-      for (int s = 0; s < NSUB; ++s) accW[s] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
-      {
-        Split8 cur = tr_read(1, 0), nxt = cur;
-#pragma unroll
-        for (int n = 0; n < 4 * NSUB; ++n) {
-          if (n + 1 < 4 * NSUB) nxt = tr_read(1, n + 1);
-          accW[n % NSUB] = mfma16_bf16x3(dA[v][n / NSUB], cur, accW[n % NSUB]);
-          cur = nxt;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < NSUB; ++s) {
-        const int p = s >> 1, hf = s & 1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = accW[s][r];
-          hf_store1(x, rdW, dw_vo[v], (int)((r * a.ldw + (long)p * a.Gp + n0 + 16 * hf) * 4));
-          ssq += x * x;
-        }
-      }
-    }
-    HF_STAMP();   // dW + stores done
-    if (tid < 32 * NP) {   // bias gradient: the eight shares' partials in order
-      float t = dbx[tid];
-#pragma unroll
-      for (int ww = 1; ww < 8; ++ww) t += dbx[ww * 32 * NP + tid];
-      hf_store1(t, rdb, (tid & 31) * 4, ((tid >> 5) * a.Gp + n0) * 4);
-    }
-  }
-
-  HF_STAMP();
-  // ---- this workgroup's slab of d d: accumulator register r of tile hs is h = 16 hs + 4 g + r of the lane's cell -----------
-#pragma unroll
-  for (int v = 0; v < VW; ++v)
-    if (cell_ok[v]) {
-      float* op = a.part + (long)blockIdx.x * a.slab_stride + (long)cell[v] * 128 + 4 * g;
-#pragma unroll
-      for (int hs = 0; hs < 8; ++hs) *reinterpret_cast<float4*>(op + 16 * hs) = make_float4(accDD[v][hs][0], accDD[v][hs][1], accDD[v][hs][2], accDD[v][hs][3]);
-    }
-  if (a.sq_part) {
-    ssq = wave_sum(ssq);
-    if (lane == 0) a.sq_part[(long)blockIdx.x * (8 / VW) + wave] = ssq;
-  }
-}
-
 // x = t0 + t1 + t2 (bf16 each; split3x8's arithmetic, bit for bit) with the conversions two values at a time: one v_cvt_pk_bf16_f32 per
 // pair and term IS the packed operand register; its two halves go back to f32 with a shift and a mask (5.5 vector instructions per value
 // where the element-wise spelling above compiles to 8.5)
@@ -525,8 +155,8 @@ struct Hf2Queue {
 // =====================================================================================================================================
 // Round 5: the same head at HALF-tile granularity (16 genes), software-pipelined so that the matrix and the vector phases overlap.
 //
-// The kernel above keeps its two waves per SIMD in the same phase: two workgroup barriers per tile, ONE phase kind between them (matrix:
-// forward product, d d, dW; vector: W split, likelihood, dP split) -- the pipes follow each other (profiles/r04_pipe_occupancy_head_fused.txt:
+// Round 4's kernel kept its two waves per SIMD in the same phase: two workgroup barriers per tile, ONE phase kind between them (matrix:
+// forward product, d d, dW; vector: W split, likelihood, dP split) -- the pipes followed each other (profiles/r04_pipe_occupancy_head_fused.txt:
 // any-instruction 47-52 %).  Here a workgroup walks units of 16 genes through TWO W-image slots and TWO dP-image slots (the same 144 KB):
 //   interval i:   F / L / D of unit i   (reads W slot i & 1, writes dP slot i & 1 -- the wave's own rows)
 //                 dW of unit i - 1      (reads dP slot (i - 1) & 1 -- complete since the barrier)
@@ -550,7 +180,7 @@ struct Hf2Queue {
 template <int LK, int U16, int ACC>
 __global__ __launch_bounds__(512, 2) void head_fused_kernel(HeadFusedArgs a) {
   // both views of d resident (48 + 48 registers), except zinbd (104 bytes of scratch that way): its view for dW is parked in the L2-resident
-  // table and fetched per unit, as in the kernel above
+  // table (a.dtab, 96 KB, the same bytes from every workgroup) and fetched per unit
   constexpr int RES = LK != SMX_LLK_ZINBD;
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
   constexpr int SUBI = 4096;               // bytes of one (term, plane) sub-image: [128 rows][16 genes] bf16
@@ -588,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void head_fused_kernel(HeadFusedArgs a) {
   if (a.dbg && tid == 64 * SMX_HF_STAMP_WAVE && (blockIdx.x == 0 || blockIdx.x == 100)) a.dbg[(blockIdx.x ? 64 : 0) + 63] = clock64();
 #endif
 
-  // ---- both views of d, split once (as above) ------------------------------------------------------------------------------
+  // ---- both views of d, split once ------------------------------------------------------------------------------
   Split8 dB[4], dA[4];
   hf_f32x4 accDD[8];
   const int w = wave;
@@ -627,7 +257,10 @@ __global__ __launch_bounds__(512, 2) void head_fused_kernel(HeadFusedArgs a) {
       hf_store8h(dA[ks].t0, rtab, tab_vo, tabA + (3 * ks + 0) * 1024); hf_store8h(dA[ks].t1, rtab, tab_vo, tabA + (3 * ks + 1) * 1024); hf_store8h(dA[ks].t2, rtab, tab_vo, tabA + (3 * ks + 2) * 1024);
     }
 #define HF_V(x) "v"(x.t0), "v"(x.t1), "v"(x.t2)
-    asm volatile("s_waitcnt vmcnt(0)" :: HF_V(dA[0]), HF_V(dA[1]), HF_V(dA[2]), HF_V(dA[3]) : "memory");   // (the store hazard of the kernel above)
+    // the wave's own table entries are written before it reads them back.  The stored registers are operands of the wait: measured on
+    // MI355X (round 4), a 16-byte buffer store whose data registers are reused by the instructions right behind it (they are dead once
+    // stored) wrote garbage -- with the registers held until the stores have completed the table is right
+    asm volatile("s_waitcnt vmcnt(0)" :: HF_V(dA[0]), HF_V(dA[1]), HF_V(dA[2]), HF_V(dA[3]) : "memory");
 #undef HF_V
   }
   auto load_view = [&]() {
@@ -879,9 +512,8 @@ __global__ __launch_bounds__(512, 2) void head_fused_kernel(HeadFusedArgs a) {
 bool head_fused_supported(int B, int Hp, int Gp, int k) {
   return B > 0 && B <= SMX_HEAD_FUSED_MAX_CELLS && Hp == 128 && Gp % 32 == 0 && Gp >= SMX_HEAD_FUSED_MIN_GENES && (k == 2 || k == 3) && !tuning_on("no_head_fused");
 }
-static bool hf_v1() { static const bool on = tuning_on("hf_v1"); return on; }   // (development: round 4's whole-tile kernel, for A/B runs; <= 128 cells)
-// workgroups: one per CU at most, every one with the same number of units (+- 1); a unit = 16 genes (round 4's kernel: 32)
-static int hf_units(int Gp) { return hf_v1() ? Gp / 32 : Gp / 16; }
+// workgroups: one per CU at most, every one with the same number of units (+- 1); a unit = 16 genes
+static int hf_units(int Gp) { return Gp / 16; }
 static int hf_rounds(int Gp) {
   static const int cap = std::max((int)tuning("head_fused_grid", 256), 1);
   return (hf_units(Gp) + cap - 1) / cap;
@@ -891,24 +523,17 @@ int head_fused_grid(int Gp) {
   return (hf_units(Gp) + rounds - 1) / std::max(rounds, 1);
 }
 // likelihood partials per cell the launch leaves in llk_part
-int head_fused_chunks(int Gp) { return hf_v1() ? Gp / 32 : head_fused_grid(Gp); }
+int head_fused_chunks(int Gp) { return head_fused_grid(Gp); }
 
-#define SMX_HF_VW 1   // (round 4's kernel: one share per hardware wave, two waves per SIMD)
 template <int LK>
 static int launch_hf(hipStream_t st, const HeadFusedArgs& a, int grid, int acc) {
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
   { const int rc = head_fused_prepare(); if (rc != SMX_OK) return rc; }
-  if (hf_v1()) {
-    const size_t lds = (size_t)2 * 3 * NP * 8192 + (size_t)8 * 32 * NP * 4;
-    if (a.x_u16) hipLaunchKernelGGL((head_fused_v1_kernel<LK, 1, SMX_HF_VW>), dim3((unsigned)grid), dim3(512 / SMX_HF_VW), lds, st, a);
-    else hipLaunchKernelGGL((head_fused_v1_kernel<LK, 0, SMX_HF_VW>), dim3((unsigned)grid), dim3(512 / SMX_HF_VW), lds, st, a);
-  } else {
-    const size_t lds = (size_t)4 * 3 * NP * 4096 + (size_t)2 * 8 * 16 * NP * 4;
+  const size_t lds = (size_t)4 * 3 * NP * 4096 + (size_t)2 * 8 * 16 * NP * 4;
 #define SMX_HF_GO(U, A) hipLaunchKernelGGL((head_fused_kernel<LK, U, A>), dim3((unsigned)grid), dim3(512), lds, st, a)
-    if (a.x_u16) { if (acc) SMX_HF_GO(1, 1); else SMX_HF_GO(1, 0); }
-    else { if (acc) SMX_HF_GO(0, 1); else SMX_HF_GO(0, 0); }
+  if (a.x_u16) { if (acc) SMX_HF_GO(1, 1); else SMX_HF_GO(1, 0); }
+  else { if (acc) SMX_HF_GO(0, 1); else SMX_HF_GO(0, 0); }
 #undef SMX_HF_GO
-  }
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
@@ -918,15 +543,12 @@ static int launch_hf(hipStream_t st, const HeadFusedArgs& a, int grid, int acc) 
 int head_fused_prepare() {
   static bool done = false;
   if (done) return SMX_OK;
-#define SMX_HF_ATTR1(K, NP) SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * NP * 8192 + 8 * 32 * NP * 4))
 #define SMX_HF_ATTR2(K, NP) SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * NP * 4096 + 2 * 8 * 16 * NP * 4))
 #define SMX_HF_ATTR(LK, NP)                                                                        \
-  SMX_HF_ATTR1((head_fused_v1_kernel<LK, 0, SMX_HF_VW>), NP); SMX_HF_ATTR1((head_fused_v1_kernel<LK, 1, SMX_HF_VW>), NP); \
   SMX_HF_ATTR2((head_fused_kernel<LK, 0, 0>), NP); SMX_HF_ATTR2((head_fused_kernel<LK, 0, 1>), NP);                       \
   SMX_HF_ATTR2((head_fused_kernel<LK, 1, 0>), NP); SMX_HF_ATTR2((head_fused_kernel<LK, 1, 1>), NP)
   SMX_HF_ATTR(SMX_LLK_NB, 2); SMX_HF_ATTR(SMX_LLK_ZINB, 3); SMX_HF_ATTR(SMX_LLK_NBD, 2); SMX_HF_ATTR(SMX_LLK_ZINBD, 3);
 #undef SMX_HF_ATTR
-#undef SMX_HF_ATTR1
 #undef SMX_HF_ATTR2
   done = true;
   return SMX_OK;
@@ -940,12 +562,12 @@ int launch_head_fused(hipStream_t st, const HeadFusedArgs& a_in, int* n_slabs, i
   const int k = llk_planes(a_in.likelihood);
   if (!head_fused_supported(a_in.B, 128, a_in.Gp, k) || !a_in.D || !a_in.W || !a_in.bias || !a_in.X || !a_in.dW || !a_in.db || !a_in.part || !a_in.llk_part ||
       !a_in.dtab || (a_in.ldd % 4) || (a_in.ldw % 4) || (a_in.ldx % 8) || a_in.slab_stride < (long)a_in.B * 128 || (a_in.slab_stride % 4) ||
-      (hf_v1() && a_in.B > 128)) {
+      false) {
     set_error("head_fused: bad shapes");
     return SMX_ERR_INVALID;
   }
   const int grid = head_fused_grid(a_in.Gp);
-  if (n_sq) *n_sq = grid * (8 / SMX_HF_VW);
+  if (n_sq) *n_sq = grid * 8;
   if (n_slabs) *n_slabs = grid;
   for (int c0 = 0; c0 < a_in.B; c0 += 128) {
     HeadFusedArgs a = a_in;

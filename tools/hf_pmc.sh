@@ -1,23 +1,22 @@
 #!/bin/bash
 # development: SQ counters of the one-launch output head by itself (tools/headfused_try.py at 128 x 20 000 zinb), one --pmc pass per pair,
-# for the half-tile kernel and for round 4's (knob hf_v1).  Prints per-launch means of every counter.
+# Prints per-launch means of every counter (round 4's kernel beside it: profiles/r05_head_fused_experiments.txt).
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/hf_pmc
 rm -rf $O; mkdir -p $O
-for V in v2 v1; do
+for V in v2; do
   i=0
   for C in "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" "SQ_IFETCH SQ_WAIT_ANY"; do
     i=$((i + 1))
-    if [ $V = v1 ]; then export SMX_TUNING=hf_v1; else unset SMX_TUNING; fi
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/$V$i -- python3 $R/tools/headfused_try.py --time-only ${1:-zinb} --reps 10 > /dev/null 2> $O/$V$i.err
   done
 done
 python3 - $O <<'PY' | tee $O/summary.txt
 import csv, glob, sys, collections
 o = sys.argv[1]
-for v in ("v2", "v1"):
+for v in ("v2",):
   acc = collections.defaultdict(list)
   for p in glob.glob(f"{o}/{v}*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(p)):

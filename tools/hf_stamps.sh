@@ -3,7 +3,6 @@
 # one wave (argument 2: 0..7) of workgroups 0 and 100.  Half-tile kernel (round 5), per interval:
 #   [forward | likelihood | dP image | d d] -> dW + stores of the unit before -> W split of the unit after -> barrier
 # Overwrites sisua_amd/libsisua_hip.so: run it on the GPU box's scratch copy (gpurun), rebuild afterwards when run in place.
-# (SMX_TUNING=hf_v1: round 4's whole-tile kernel and its own stamps)
 set -e
 cd "$(dirname "$0")/.."
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSMX_HF_STAMPS -DSMX_HF_STAMP_WAVE=${2:-0} ${HF_DEFS:-} -c sisua_amd/csrc/smx_headfused.hip -o /tmp/hf_stamps.o
