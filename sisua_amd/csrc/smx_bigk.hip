@@ -174,6 +174,24 @@ __global__ __launch_bounds__(512) void bigk_kernel(BigKArgs a) {
   }
   // ---- this slice's slab: register r of a tile is row (r & 3) + 8 (r >> 2) + 4 hh, column i ----
   float* out = a.part + (long)z * a.slab_stride;
+  if (a.colmajor) {
+    // column-major slab [N][128]: a lane's four consecutive rows of a column are one 16-byte store (M <= 128: one row block; rows beyond M zero)
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      const int col = n0 + 64 * ch + 32 * c2 + i;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = 32 * rt + 8 * q + 4 * hh;
+        float4 v;
+        v.x = row + 0 < a.M ? acc[c2][4 * q + 0] : 0.f;
+        v.y = row + 1 < a.M ? acc[c2][4 * q + 1] : 0.f;
+        v.z = row + 2 < a.M ? acc[c2][4 * q + 2] : 0.f;
+        v.w = row + 3 < a.M ? acc[c2][4 * q + 3] : 0.f;
+        if (col < a.N) *reinterpret_cast<float4*>(out + (long)col * 128 + row) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int c2 = 0; c2 < 2; ++c2) {
     const int col = n0 + 64 * ch + 32 * c2 + i;
@@ -245,6 +263,7 @@ bool bigk_supported(const BigKArgs& a) {
 int launch_bigk(hipStream_t st, const BigKArgs& a_in) {
   BigKArgs a = a_in;
   if (!bigk_supported(a)) { set_error("bigk: unsupported shapes"); return SMX_ERR_INVALID; }
+  if (a.colmajor && (a.M > 128 || a.N > 128 || a.slab_stride < (long)a.N * 128)) { set_error("bigk: column-major slabs take one 128 x 128 output"); return SMX_ERR_INVALID; }
   if (a.n_slices <= 0 || a.k_chunk % 32 || (long)a.n_slices * a.k_chunk < a.K) { set_error("bigk: bad slicing"); return SMX_ERR_INVALID; }
   const dim3 grid((unsigned)a.n_slices, (unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
   static const int stages_env = (int)tuning("bigk_stages", 0);
@@ -266,6 +285,7 @@ int launch_bigk(hipStream_t st, const BigKArgs& a_in) {
   else { set_error("bigk: operand form not built"); return SMX_ERR_INVALID; }
 #undef SMX_BIGK_LAUNCH
   SMX_HIP(hipGetLastError());
+  if (a.colmajor) return SMX_OK;   // (the consumer sums the slabs)
   const long n4 = ((long)a.M * a.ldc) >> 2;
   hipLaunchKernelGGL(bigk_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, a.part, a.slab_stride, a.n_slices, n4, a.out);
   SMX_HIP(hipGetLastError());

@@ -497,9 +497,17 @@ __global__ __launch_bounds__(512, 2) void head_fused_kernel(HeadFusedArgs a) {
   lsum += __shfl_xor(lsum, 32, 64);
   if (cell_ok) {
     if (g == 0) a.llk_part[(long)cell * a.n_chunks + blockIdx.x] = lsum;
-    float* op = a.part + (long)blockIdx.x * a.slab_stride + (long)cell * 128 + 4 * g;
+    if (a.part_colmajor) {   // [column][128 cells]: the BatchNorm-backward launch sums the slabs itself (bn_wide_bwd_kernel)
+      float* op = a.part + (long)blockIdx.x * a.slab_stride + (long)(4 * g) * 128 + cell;
 #pragma unroll
-    for (int hs = 0; hs < 8; ++hs) *reinterpret_cast<float4*>(op + 16 * hs) = make_float4(accDD[hs][0], accDD[hs][1], accDD[hs][2], accDD[hs][3]);
+      for (int hs = 0; hs < 8; ++hs)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) op[(16 * hs + e) * 128] = accDD[hs][e];
+    } else {
+      float* op = a.part + (long)blockIdx.x * a.slab_stride + (long)cell * 128 + 4 * g;
+#pragma unroll
+      for (int hs = 0; hs < 8; ++hs) *reinterpret_cast<float4*>(op + 16 * hs) = make_float4(accDD[hs][0], accDD[hs][1], accDD[hs][2], accDD[hs][3]);
+    }
   }
   if (a.sq_part) {
     ssq = wave_sum(ssq);
@@ -566,6 +574,7 @@ int launch_head_fused(hipStream_t st, const HeadFusedArgs& a_in, int* n_slabs, i
     set_error("head_fused: bad shapes");
     return SMX_ERR_INVALID;
   }
+  if (a_in.part_colmajor && (a_in.B > 128 || a_in.slab_stride < 128L * 128)) { set_error("head_fused: column-major slabs take at most 128 cells"); return SMX_ERR_INVALID; }
   const int grid = head_fused_grid(a_in.Gp);
   if (n_sq) *n_sq = grid * 8;
   if (n_slabs) *n_slabs = grid;

@@ -199,7 +199,11 @@ struct BnFwdArgs {
   // (K = Dp <= 64: 64 fmas per output row and thread), so the latent kernel and the product kernel disappear
   int front = 0; LatentArgs lat; const float* W = nullptr; int ldw = 0;
   float leak = 0.f;   // activation max(y, 0) + leak min(y, 0): 0 = ReLU; the FactorVAE discriminator's leaky ReLU uses 0.2
+  // wide != 0: `pre` holds HUNDREDS of slabs (one per workgroup of a wide-panel product: smx_bigk.hip), each COLUMN-major [Hp][128 rows]; the
+  // launch sums them itself, one workgroup per column, in the order of bigk_reduce_kernel (bn_wide_fwd_kernel: no reduce launch)
+  int wide = 0;
 };
+bool bn_wide_supported(int B, int Hp, int n_slabs);
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a);
 bool bn_front_supported(int B, int Dp);
 
@@ -291,6 +295,7 @@ struct BnBwdArgs {
   int front = 0; const float* fD = nullptr; int fld = 0; const float* fW = nullptr; int fldw = 0; int fK = 0;
   int diag = 0;   // SMX_BN_DIAG bits 16 / 32 / 64: skip the front's dot products / tile load / W row load (timing only)
   float leak = 0.f;   // slope of the activation for out <= 0 (layers without dropout only)
+  int wide = 0;       // as BnFwdArgs::wide: `dout` = column-major slabs [n_slabs][Hp][128], summed here (bn_wide_bwd_kernel)
 };
 bool bn_bwd_front_supported(int B, int K);
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a);
@@ -534,6 +539,9 @@ struct BigKArgs {
   int M = 0, N = 0, K = 0;
   int n_slices = 0, k_chunk = 0;                   // from bigk_slices
   int stages = 0;                                  // set by the launcher: 32-deep stages in flight + 1 (SMX_BIGK_STAGES)
+  // colmajor: the slabs are stored [slice][N columns][128 rows] (M <= 128; rows beyond M zero) and NOT summed by this launch:
+  // the consumer is a BatchNorm launch that sums them itself (BnFwdArgs::wide)
+  int colmajor = 0;
 };
 // measured at 128 x 20 000 (tools/bigk_stages_ab.sh, same box): 4 / 3 / 2 stage buffers -> c5-shard 205.4 / 203.8 / 202.9 us per step, bit-identical
 // results: the operands of these launches come from the last-level cache, one stage ahead covers their latency, and 64 KB of LDS
@@ -563,6 +571,7 @@ struct HeadFusedArgs {
   const void* X = nullptr; long ldx = 0; const int32_t* rows = nullptr; int x_u16 = 0;   // counts (gathered by row id)
   float* dW = nullptr; float* db = nullptr;         // gradients, laid out as W / bias
   float* part = nullptr; long slab_stride = 0;      // [workgroups][B][128]: per-workgroup slabs of d d
+  int part_colmajor = 0;                            // the slabs as [workgroups][128 columns][128 cells] (B <= 128): summed by bn_wide_bwd_kernel
   float* llk_part = nullptr;                        // [B][head_fused_chunks(Gp)]
   float* sq_part = nullptr;                         // 8 sum-of-squares slots of dW per workgroup, or nullptr
   void* dtab = nullptr;                             // SMX_HEAD_FUSED_TAB_BYTES of scratch: the waves' split view of d for dW (written and read by the launch)

@@ -542,6 +542,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_dual_kernel(BnFwdArgs a
 }
 
 
+__global__ void bn_wide_fwd_kernel(BnFwdArgs a);   // (below: the forms that sum a wide panel's column-major slabs themselves)
+__global__ void bn_wide_bwd_kernel(BnBwdArgs a);
+
 bool bn_front_supported(int B, int Dp) {
   const int dq = Dp >> 2;
   return B > 0 && B <= BN_RL * 4 && Dp >= 4 && (Dp <= 64 || Dp == 128) && (Dp % 4) == 0 && (dq & (dq - 1)) == 0 && ((size_t)B * (Dp + 1) + (size_t)Dp * 8) * sizeof(float) <= 96 * 1024;
@@ -574,6 +577,12 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
     return SMX_OK;
   }
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_fwd: bad shapes"); return SMX_ERR_INVALID; }
+  if (a.wide) {
+    if (a.B > 128 || a.Hp > 128 || !a.pre || !a.xhat || a.slab_stride < (long)a.Hp * 128 || (a.slab_stride % 4)) { set_error("bn_act_fwd: wide slabs take at most 128 x 128"); return SMX_ERR_INVALID; }
+    hipLaunchKernelGGL(bn_wide_fwd_kernel, dim3(a.Hp + a.n_jobs * SMX_NOISE_BLOCKS_PER_JOB), dim3(BN_THREADS), 0, st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   const int grid = a.Hp / BN_COLS + a.n_jobs * SMX_NOISE_BLOCKS_PER_JOB;
   if (a.B <= BN_RL * 2) hipLaunchKernelGGL(bn_act_fwd_kernel<2>, dim3(grid), dim3(BN_THREADS), 0, st, a);
   else if (a.B <= BN_RL * 4) hipLaunchKernelGGL(bn_act_fwd_kernel<4>, dim3(grid), dim3(BN_THREADS), 0, st, a);
@@ -793,6 +802,12 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
     return SMX_OK;
   }
   if (a.Hp % BN_COLS || a.B <= 0) { set_error("bn_act_bwd: bad shapes"); return SMX_ERR_INVALID; }
+  if (a.wide) {
+    if (a.B > 128 || a.Hp > 128 || !a.dout || a.slab_stride < (long)a.Hp * 128 || (a.slab_stride % 4)) { set_error("bn_act_bwd: wide slabs take at most 128 x 128"); return SMX_ERR_INVALID; }
+    hipLaunchKernelGGL(bn_wide_bwd_kernel, dim3(a.Hp + (a.with_metrics ? 1 : 0) + a.adam_count + a.sqr_count), dim3(BN_THREADS), 0, st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count + a.sqr_count;
   if (a.B <= BN_RL * 2) hipLaunchKernelGGL(bn_act_bwd_kernel<2>, dim3(grid), dim3(BN_THREADS), 0, st, a);
   else if (a.B <= BN_RL * 4) hipLaunchKernelGGL(bn_act_bwd_kernel<4>, dim3(grid), dim3(BN_THREADS), 0, st, a);
@@ -826,6 +841,187 @@ int launch_bn_act_bwd_dual(hipStream_t st, const BnBwdArgs& a_in, const BnBwdArg
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
+
+// ===========================================================================
+// BatchNorm launches that sum the HUNDREDS of slabs of a wide-panel product themselves (BASELINE.json configs[4]: the encoder front's
+// 209 K slices, the fused output head's 250 workgroups, each with a [128][128] partial sum).  Until round 5 a reduce launch
+// (bigk_reduce_kernel) stood between the product and the 16-workgroup BatchNorm launch: two latency-bound launches (5-6 us + 6-7 us) for
+// 14-16 MB of slabs and 64 KB of result.  Here the producers leave their slabs COLUMN-major ([slab][column][128 rows]: a column of a slab
+// is 512 contiguous bytes) and ONE workgroup per column sums its column over the slabs -- 16-byte loads, every slab of a thread in flight
+// at once -- and finishes the BatchNorm pass on the 128 sums.  The additions keep the order of the launches they replace (thread sg of 16
+// sums the slabs sg, sg + 16, ...; the 16 partial sums in sg order; the column statistics as the balanced tree over rows (r, r + 64) of
+// bn_col_reduce): bit for bit the same results (tests/test_gpu_configs.py).  Minibatches of at most 128 cells.
+// ===========================================================================
+__device__ inline void wide_slab_column(const float* part, long slab_stride, int n_slabs, int col, float* sh /*[16][128]*/) {
+  const int rq = threadIdx.x & 31, sg = threadIdx.x >> 5;   // rows 4 rq .. + 3; slabs sg, sg + 16, ...
+  const float4* p = reinterpret_cast<const float4*>(part) + (long)col * 32 + rq;
+  const long s4 = slab_stride >> 2;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z0 = sg; z0 < n_slabs; z0 += 256) {
+    float4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(long)min(z0 + 16 * u, n_slabs - 1) * s4];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (z0 + 16 * u < n_slabs) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  *reinterpret_cast<float4*>(sh + sg * 128 + 4 * rq) = acc;
+}
+// the column's value of row r (threads 0 .. 127 after the barrier)
+__device__ inline float wide_row_value(const float* sh, int r) {
+  float v = sh[r];
+#pragma unroll
+  for (int u = 1; u < 16; ++u) v += sh[u * 128 + r];
+  return v;
+}
+// sum over the 64 pairs (r, r + 64) held by the lanes of wave 0: the balanced tree of bn_col_reduce
+__device__ inline float wide_tree64(float p) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) p += __shfl_xor(p, off, 64);
+  return p;
+}
+
+// (Which multiply-adds the compiler fuses in bn_act_fwd_body / bn_act_bwd_body<2, 0> was read off their ISA; the kernels below spell the
+// same operations out with contraction switched off, so that the two forms stay equal bit for bit.)
+__global__ __launch_bounds__(BN_THREADS) void bn_wide_fwd_kernel(BnFwdArgs a) {
+#pragma clang fp contract(off)
+  const int bid = (int)blockIdx.x;
+  if (bid >= a.Hp) { noise_fill(a, bid - a.Hp); return; }
+  __shared__ __attribute__((aligned(16))) float sh[16 * 128];
+  __shared__ float vs[128], st[2];
+  const int col = bid, r = (int)threadIdx.x;
+  const bool live = col < a.H, rowt = r < 128, on = rowt && r < a.B;
+  const float bias = (!a.batchnorm && a.bias && live) ? a.bias[col] : 0.f;
+  const float gamma = (a.batchnorm && live) ? a.gamma[col] : 0.f, beta = (a.batchnorm && live) ? a.beta[col] : 0.f;
+  const bool drop = a.training && a.drop_p > 0.f;
+  float mpre = 0.f;
+  if (drop && a.inj_mask && on) mpre = a.inj_mask[(long)r * a.inj_ld + col];
+  wide_slab_column(a.pre, a.slab_stride, a.n_slabs, col, sh);
+  __syncthreads();
+  float v = 0.f;
+  if (rowt) { v = wide_row_value(sh, r) + bias; vs[r] = v; }
+  float mean = 0.f, inv = 1.f;
+  if (a.batchnorm) {
+    float var;
+    if (a.training) {
+      __syncthreads();
+      if (r < 64) {   // wave 0: rows r and r + 64, summed and squared in the form of bn_act_fwd_body (the same contractions: the same bits)
+        const float v0 = vs[r], v1 = vs[r + 64];
+        float s1 = 0.f;
+        if (r < a.B) s1 += v0;
+        if (r + 64 < a.B) s1 += v1;
+        s1 = wide_tree64(s1);
+        const float mu = s1 / (float)a.B;
+        float s2 = 0.f;
+        if (r < a.B) { const float d = v0 - mu; s2 = d * d; }
+        if (r + 64 < a.B) { const float d = v1 - mu; s2 = __builtin_fmaf(d, d, s2); }
+        s2 = wide_tree64(s2);
+        if (r == 0) { st[0] = mu; st[1] = s2 / (float)a.B; }
+      }
+      __syncthreads();
+      mean = st[0];
+      var = st[1];
+      if (r == 0) {
+        if (a.batch_mean) { a.batch_mean[col] = mean; a.batch_var[col] = var; }
+        if (a.update_moving && live) {
+          a.moving_mean[col] = a.moving_mean[col] * a.momentum + mean * (1.f - a.momentum);
+          a.moving_var[col] = a.moving_var[col] * a.momentum + var * (1.f - a.momentum);
+        }
+      }
+    } else {
+      mean = live ? a.moving_mean[col] : 0.f;
+      var = live ? a.moving_var[col] : 1.f;
+    }
+    inv = rsqrtf(var + a.eps);
+    if (r == 0 && a.inv_std) a.inv_std[col] = inv;
+  }
+  if (!on) return;
+  const float scale = drop ? 1.f / (1.f - a.drop_p) : 1.f;
+  const long o = (long)r * a.Hp + col;
+  float y = v;
+  if (a.batchnorm) {
+    v = (v - mean) * inv;
+    y = __builtin_fmaf(gamma, v, beta);
+  }
+  a.xhat[o] = v;
+  float h = fmaxf(y, 0.f);
+  if (a.leak != 0.f) h += a.leak * fminf(y, 0.f);
+  if (drop) {
+    float mult = mpre;
+    if (!a.inj_mask) {
+      const uint32_t cell = a.cell_base + (uint32_t)(a.rows ? a.rows[r] : r);
+      const U4 w = philox_block(a.nk, cell, (uint32_t)(col >> 2));
+      mult = dropout_mult1(w, col & 3, a.drop_p, scale);
+    }
+    h *= mult;
+  }
+  a.out[o] = live ? h : 0.f;
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_wide_bwd_kernel(BnBwdArgs a) {
+#pragma clang fp contract(off)
+  const int bid = (int)blockIdx.x;
+  {
+    const int extra = bid - a.Hp;
+    if (extra >= 0) {   // the riders of bn_act_bwd_body
+      const int e = extra - (a.with_metrics ? 1 : 0);
+      if (e >= 0 && e < a.adam_count) { adam_chunk_body<BN_THREADS>(a.adam, a.adam_first + e); return; }
+      if (threadIdx.x >= 256) return;
+      if (e < 0) metrics_body(a.metrics);
+      else {
+        const int i = e - a.adam_count;
+        sq_reduce_body(a.adam.sq_slots + a.sqr_first[i], a.sqr_n[i], a.sq_total + a.sqr_dst[i]);
+      }
+      return;
+    }
+  }
+  __shared__ __attribute__((aligned(16))) float sh[16 * 128];
+  __shared__ float vs[128], xs[128], st[2];
+  const int col = bid, r = (int)threadIdx.x;
+  const bool live = col < a.H, rowt = r < 128, on = rowt && r < a.B;
+  // what the activation mask and the BatchNorm formula need of the forward pass, requested ahead of the slabs
+  float ov = 0.f, xh = 0.f, gamma = 0.f, inv = 0.f;
+  if (on) {
+    const long o = (long)r * a.Hp + col;
+    ov = a.out[o];
+    if (a.batchnorm) xh = a.xhat[o];
+  }
+  if (a.batchnorm) { gamma = live ? a.gamma[col] : 0.f; inv = a.inv_std[col]; }
+  wide_slab_column(a.dout, a.slab_stride, a.n_slabs, col, sh);
+  __syncthreads();
+  float dy = 0.f;
+  if (on) {
+    const float acc = wide_row_value(sh, r);
+    dy = (live && ov > 0.f) ? acc * a.drop_scale : 0.f;
+    if (a.leak != 0.f && live && !(ov > 0.f)) dy = acc * a.leak;
+  }
+  if (rowt) { vs[r] = dy; xs[r] = xh; }
+  __syncthreads();
+  if (r < 64) {   // wave 0: rows r and r + 64 in the form of bn_act_bwd_body
+    float s1 = 0.f, s2 = 0.f;
+    if (r < a.B) { const float d0 = vs[r]; s1 += d0; s2 += d0 * xs[r]; }
+    if (r + 64 < a.B) { const float d1 = vs[r + 64]; s1 += d1; s2 += d1 * xs[r + 64]; }
+    s1 = wide_tree64(s1);
+    if (a.batchnorm) s2 = wide_tree64(s2);
+    if (r == 0) { st[0] = s1; st[1] = s2; }
+  }
+  __syncthreads();
+  const float s1 = st[0], s2 = st[1];
+  if (!a.batchnorm) {
+    if (r == 0 && a.dbias && live) a.dbias[col] = s1;
+    if (on) a.dpre[(long)r * a.Hp + col] = dy;
+    return;
+  }
+  if (r == 0) { a.dgamma[col] = live ? s2 : 0.f; a.dbeta[col] = live ? s1 : 0.f; }
+  if (!on) return;
+  const float invB = 1.f / (float)a.B;
+  float d;
+  if (a.training) d = (gamma * inv) * __builtin_fmaf(-__builtin_fmaf(xh, s2, s1), invB, dy);
+  else d = dy * gamma * inv;
+  a.dpre[(long)r * a.Hp + col] = d;
+}
+
+bool bn_wide_supported(int B, int Hp, int n_slabs) { return B > 0 && B <= 128 && Hp > 0 && Hp <= 128 && n_slabs > 0 && !tuning_on("no_bn_wide"); }
 
 // ===========================================================================
 // SyncBatchNorm (opt-in under data parallelism, SURVEY.md 8e caveat i): statistics over the GLOBAL minibatch.

@@ -251,6 +251,7 @@ struct smx_model {
   bool out_has_W[3] = {true, true, true};   // scvi: plane c of the gene output is a Dense head (false: a shared per-gene vector, cfg.scvi_dispersion / scvi_inflation)
   float* slab = nullptr; size_t slab_cap = 0; int max_feat_p = 0;
   void* hf_tab = nullptr;             // scratch of the fused output head (smx_headfused.hip: the split views of the decoder output)
+  int wide_dd_slabs = 0;   // > 0: this step's d d waits as that many column-major slabs in bigk_part for the decoder's BatchNorm-backward launch (bn_wide_bwd_kernel)
   bool head_fused = false; int head_fused_sq = 0;   // this step's output head ran as ONE launch (loss + dW + db + d d): backward_pass skips its products
   float* bigk_part = nullptr; size_t bigk_floats = 0;   // [SMX_BIGK_MAX_SLICES][Bmax][max_feat_p]: per-slice slabs of smx_bigk.hip (wide panels only)
   // optimiser

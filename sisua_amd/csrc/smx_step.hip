@@ -133,6 +133,10 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
       bk.part = m->bigk_part; bk.out = m->slab;
       bk.n_slices = bigk_slices(bk.K, SMX_BIGK_MAX_SLICES, &bk.k_chunk);
       bigk = bk.log1p && bigk_supported(bk) && (size_t)bk.n_slices * (size_t)bk.slab_stride <= m->bigk_floats;
+      // ... and no reduce launch: column-major slabs, summed by the BatchNorm launch (bn_wide_fwd_kernel)
+      if (bigk && !sync && bn_wide_supported(ps.B, L.out_p, bk.n_slices) && (size_t)bk.n_slices * 128 * 128 <= m->bigk_floats) {
+        bk.colmajor = 1; bk.slab_stride = 128L * 128;
+      }
     }
     if (bigk) {
       Timed t(m, label0);
@@ -146,6 +150,7 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
       SMX_CHECK(launch_gemm(m->st, g, &eff));
     }
     BnFwdArgs b = make_bn(L, m->slab, eff, g.slab_stride);
+    if (bigk && bk.colmajor) { b.pre = bk.part; b.n_slabs = bk.n_slices; b.slab_stride = bk.slab_stride; b.wide = 1; }
     if (!no_ahead && !sync && i == 0 && in_is_x && &mlp == &m->enc && ps.training && front_shapes_ok(m, ps) &&
         !with_front && b.n_jobs == 0) {
       // the decoder's front launch (latent sample + first decoder layer) computes the whole latent tile in EVERY one of
@@ -408,6 +413,9 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     if (L.bn >= 0) { b.gamma = P_(m, L.tGamma); b.dgamma = G_(m, L.tGamma); b.dbeta = G_(m, L.tBeta); }
     else b.dbias = G_(m, L.tBias);
     if (front) { b.front = 1; b.fD = front->fD; b.fld = front->fld; b.fW = front->fW; b.fldw = front->fldw; b.fK = front->fK; }
+    if (&mlp == &m->dec && &L == &mlp.back() && m->wide_dd_slabs > 0 && !front) {   // the one-launch head's slabs, column-major
+      b.dout = m->bigk_part; b.n_slabs = m->wide_dd_slabs; b.slab_stride = 128L * 128; b.wide = 1;
+    }
     return b;
   };
   if (twin_done) *twin_done = false;
@@ -580,7 +588,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   const bool encode_only = (mode == 3);   // encoders + latent heads + latent moments / draw 0, no decoder (the stacked-draw paths)
   const smx_config& c = m->cfg;
   const float inv_gb = 1.f / (float)ps.global_batch;
-  m->head_loss = false; m->head_fused = false; m->ev_hf_fresh = false;
+  m->head_loss = false; m->head_fused = false; m->ev_hf_fresh = false; m->wide_dd_slabs = 0;
   m->ahead_front_eps = m->ahead_front_drop = false;
   m->scvi_fused = false; m->encl_twinned = false;
   bool front_ok = false; LatentArgs front_la;
@@ -740,12 +748,17 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
     // a wide panel: the whole head -- product, likelihood, dW / db and the per-workgroup slabs of d d -- in ONE launch + the ordered
     // sum of the slabs (smx_headfused.hip); backward_pass then finds its head products done
     m->head_fused = false;
+    m->wide_dd_slabs = 0;
     if (head_fused_ok(m, ps.B) && !(!m->capturing && m->timing_label == "out_head_product")) {
       HeadFusedArgs hf;
       hf.D = dL.out_buf; hf.ldd = dL.out_p; hf.W = hl.W; hf.ldw = tw.ld; hf.bias = hl.bias;
       hf.X = ps.Xsrc; hf.ldx = m->Gp; hf.rows = ps.xrows; hf.x_u16 = ps.x_u16;
       hf.dW = G_(m, m->t_outW[0]); hf.db = G_(m, m->t_outb[0]);
       hf.part = m->bigk_part; hf.slab_stride = (long)ps.B * dL.out_p; hf.llk_part = m->llk_part;
+      // without label heads (their d d arrives as further slabs) the decoder's BatchNorm-backward launch sums the workgroups' slabs itself
+      const bool wide_dd = m->n_heads == 0 && !(sync_bn_on(m, ps.training) && dL.bn >= 0) && bn_wide_supported(ps.B, dL.out_p, head_fused_grid(m->Gp)) &&
+                           (size_t)head_fused_grid(m->Gp) * 128 * 128 <= m->bigk_floats;
+      if (wide_dd) { hf.part_colmajor = 1; hf.slab_stride = 128L * 128; }
       hf.sq_part = (m->sq_slots && !tuning_on("no_sq_partials")) ? m->sq_slots + m->sq_first[(size_t)m->t_outW[0]] : nullptr;
       hf.dtab = m->hf_tab;
       hf.B = ps.B; hf.G = m->G; hf.Gp = m->Gp; hf.likelihood = c.likelihood; hf.grad_scale = -inv_gb;
@@ -763,7 +776,8 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
       // data parallel, two buckets: without label heads every gradient of the head bucket is final HERE -- its chain (all-reduce, norms,
       // clip + Adam) runs beside the whole backward pass, the optimiser launch and the next step's encoder and decoder
       if (m->n_heads == 0 && dp_chain_ok(m)) SMX_CHECK(dp_chain_start(m));
-      SMX_CHECK(launch_head_fused_reduce(m->st, hf, n_slabs, m->slab));
+      m->wide_dd_slabs = wide_dd ? n_slabs : 0;
+      if (!wide_dd) SMX_CHECK(launch_head_fused_reduce(m->st, hf, n_slabs, m->slab));
       n_llk_chunks = head_fused_chunks(m->Gp);
       m->head_fused = true;
     } else {

@@ -412,6 +412,46 @@ def test_wide_panel_heads_update_as_a_background_sweep(Engine):
         assert np.array_equal(ref[which][k], r[which][k]), (which, k)
 
 
+@pytest.mark.parametrize("lk,B,G,storage", [("zinb", 100, 4100, "u16"), ("nb", 128, 4128, "f32"), ("zinbd", 77, 4500, "u16")])
+def test_wide_panel_batchnorm_sums_the_slabs_itself(Engine, lk, B, G, storage):
+  """Wide panels, at most 128 cells (smx_kernels.hip: bn_wide_fwd_kernel / bn_wide_bwd_kernel): the encoder front's K slices and the one-launch
+  head's workgroups leave their [128][128] partial sums as COLUMN-major slabs and the BatchNorm launch behind them -- one workgroup per
+  column -- sums them itself: no reduce launch in either pass.  The additions keep the order of the reduce launch + 8-column BatchNorm launch
+  they replace (knob no_bn_wide): losses of every step, an evaluation pass, parameters, both Adam moments and the BatchNorm moving statistics
+  are equal BIT FOR BIT -- ragged minibatches, every count store, a captured step included."""
+  from sisua_amd import _hip
+  from tests.util import make_pair, synth_counts
+  spec, cfg = make_pair(model="vae", n_genes=G, likelihood=lk, enc_units=(128,), dec_units=(128,), latent_dim=16)
+  x = synth_counts(512, G, sparsity=0.92, seed=G + 1, max_count=700)
+  rng = np.random.default_rng(11)
+  order = np.concatenate([rng.permutation(512)[:B] for _ in range(4)]).astype(np.int32)
+  runs = []
+  try:
+    for off in (1, 0):
+      _hip.set_tuning("no_bn_wide", off)
+      e = Engine(cfg, max_batch=128, init=False)
+      e.set_params(so.init_params(spec))
+      e.upload(x, cell_id_base=9, storage=storage)
+      assert e.head_fused_bytes(B) > 0
+      e.train_steps(order, 4, B, graph=False)
+      h = {k: np.asarray(v).copy() for k, v in e.metrics_history(4).items()}
+      ev = e.eval_step(order[:B])["loss"]
+      one = e.train_step(order[:B])["loss"]
+      two = e.train_step(order[B:2 * B], graph=True)["loss"]
+      bn = {f"{i}/{k}": v for i, d in e.get_bn().items() for k, v in d.items()}
+      runs.append((h, ev, one, two, e.get_params(0), e.get_params(2), e.get_params(3), bn))
+      e.close()
+  finally:
+    _hip.set_tuning("no_bn_wide", 0)
+  a, b = runs
+  for k in a[0]:
+    assert np.array_equal(a[0][k], b[0][k]), k
+  assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
+  for which in (4, 5, 6, 7):
+    for k in a[which]:
+      assert np.array_equal(a[which][k], b[which][k]), (which, k)
+
+
 def test_wide_panel_first_step_as_a_graph(Engine):
   """The fused head's launch inside a stream capture on the very FIRST step of a model (its dynamic-LDS limit is set at model creation, not at
   the first launch): the captured step equals the eager step of a second engine bit for bit."""
