@@ -299,6 +299,16 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
       const float4 v = *reinterpret_cast<const float4*>(&tile[rr * 36 + c4]);
       if (row < g.M) *reinterpret_cast<float4*>(&C[(long)row * g.ldc + n0 + wn * 32 + c4]) = v;
     }
+  } else if (RPW == 4 && g.c_colmajor) {
+    // column-major slab [N][128]: wave wk finishes rows 8 wk + 4 lh .. + 3 of column li -- one 16-byte store
+    float* C = g.C + (long)bz * g.slab_stride;
+    const int col = n0 + wn * 32 + li, row = m0 + wm * 32 + 8 * wk + 4 * lh;
+    float4 v;
+    v.x = row + 0 < g.M ? out[0] : 0.f;
+    v.y = row + 1 < g.M ? out[1] : 0.f;
+    v.z = row + 2 < g.M ? out[2] : 0.f;
+    v.w = row + 3 < g.M ? out[3] : 0.f;
+    *reinterpret_cast<float4*>(&C[(long)col * 128 + row]) = v;
   } else {
     float* C = g.C + (long)bz * g.slab_stride;
     const int col = n0 + wn * 32 + li;
@@ -589,6 +599,10 @@ int launch_gemm(hipStream_t st, const GemmArgs& g_in, int* eff_split) {
     else if (g.M > 64 || g.N % 64) tile = TILE_128x32;
     else if (g.M > 32) tile = TILE_64x64;
     else tile = (g.N % 128 == 0) ? TILE_32x128 : TILE_64x64;
+  }
+  if (g.c_colmajor && (tile != TILE_32x32_K4 || g.M > 128 || g.bias || g.act || g.sq_part || g.colsum || g.slab_stride < (long)g.N * 128)) {
+    set_error("gemm: column-major slabs take the 32 x 32 K4 tile, at most 128 rows and no epilogue");
+    return SMX_ERR_INVALID;
   }
   switch (tile) {
     case TILE_128x32: return launch_cfg<4, 1, 1>(st, g, eff_split);

@@ -284,7 +284,8 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
 #pragma unroll
     for (int w = 1; w < 8; ++w) t += red[(w * 16 + r) * 64 + lane];
     const int row = m0 + rowof[j];
-    if (row < a.B) slab[(long)row * a.ldd + h0 + i] = t;
+    if (a.dd_colmajor) { if (row < 128) slab[(long)(h0 + i) * 128 + row] = row < a.B ? t : 0.f; }
+    else if (row < a.B) slab[(long)row * a.ldd + h0 + i] = t;
   }
 }
 
@@ -310,6 +311,7 @@ int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a_in) {
     set_error("out_head_bwd: bad shapes");
     return SMX_ERR_INVALID;
   }
+  if (a.dd_colmajor && (a.B > 128 || a.n_extra != 0 || a.skip_dd || a.slab_stride < (long)a.Hp * 128)) { set_error("out_head_bwd: column-major d d slabs take at most 128 cells and no label slabs"); return SMX_ERR_INVALID; }
   a.n_ht = a.Hp / 32; a.n_gt = a.Gp / 32; a.n_ct = (a.B + 31) / 32;
   a.n_w = a.skip_dw ? 0 : a.n_ht * ((a.n_gt + 7) / 8 * 8);
   if (a.n_extra < 0 || a.n_extra > SMX_MAX_LABELS) { set_error("out_head_bwd: bad label riders"); return SMX_ERR_INVALID; }

@@ -72,6 +72,7 @@ struct GemmArgs {
   // the launcher fills sq_gx and *sq_count (= slots written)
   float* sq_part = nullptr; int sq_gx = 0; int* sq_count = nullptr;
   int wide_store = 0;   // set by the launcher: 16-byte stores through an LDS transpose (large outputs)
+  int c_colmajor = 0;   // split-K slabs stored [slice][N][128 rows] (32 x 32-K4 tile, M <= 128; rows beyond M zero): summed by a BatchNorm launch (BnFwdArgs::wide)
   int epi = 0;                     // 0: store C; 2: latent-head backward (EpiLatentBwd), split_k == 1
   EpiLatentBwd lb;
   // activation in the store path (layers without BatchNorm and dropout; split_k == 1): act = 1: C = act(acc + bias) with
@@ -509,6 +510,7 @@ struct HeadBwdArgs {
   const float* W = nullptr; int ldw = 0;           // [Hp][k * Gp]
   float* dW = nullptr; float* db = nullptr;        // gradients, laid out as W / bias
   float* slab = nullptr; long slab_stride = 0;     // dd slabs [n_slices][B][Hp]
+  int dd_colmajor = 0;                             // ... stored [n_slices][Hp][128 cells] instead (B <= 128, no label slabs): BnBwdArgs::wide
   int B = 0, Hp = 0, Gp = 0, n_planes = 0;
   int n_slices = 0, k_chunk = 0;                   // from head_bwd_slices
   float* sq_part = nullptr; int* sq_count = nullptr;

@@ -171,7 +171,7 @@ struct smx_model {
   // wide panels, one GPU, eager steps: the heads' update as a background sweep on a second stream between this step's output head and
   // the next step's (smx_step.hip: head_sweep_start / head_sweep_join)
   hipStream_t st_side = nullptr;
-  hipEvent_t ev_hf = nullptr, ev_sweep = nullptr;
+  hipEvent_t ev_hf = nullptr, ev_sweep = nullptr; int ev_mode = -1;   // (ev_mode: created with 1 / without 0 the system-scope fence: head_sweep_prepare)
   bool sweep_pending = false;          // the main stream has not been ordered behind the last sweep yet
   bool ev_hf_fresh = false;            // ev_hf was recorded behind THIS step's output head
   bool head_fused_bwd_done = false;   // this backward pass found dW / db / d d of the output head done by the forward pass's launch
@@ -251,6 +251,8 @@ struct smx_model {
   bool out_has_W[3] = {true, true, true};   // scvi: plane c of the gene output is a Dense head (false: a shared per-gene vector, cfg.scvi_dispersion / scvi_inflation)
   float* slab = nullptr; size_t slab_cap = 0; int max_feat_p = 0;
   void* hf_tab = nullptr;             // scratch of the fused output head (smx_headfused.hip: the split views of the decoder output)
+  long wide_dd_stride = 0;
+  const float* wide_dd_src = nullptr;   // where those slabs are (bigk_part or the slab buffer)
   int wide_dd_slabs = 0;   // > 0: this step's d d waits as that many column-major slabs in bigk_part for the decoder's BatchNorm-backward launch (bn_wide_bwd_kernel)
   bool head_fused = false; int head_fused_sq = 0;   // this step's output head ran as ONE launch (loss + dW + db + d d): backward_pass skips its products
   float* bigk_part = nullptr; size_t bigk_floats = 0;   // [SMX_BIGK_MAX_SLICES][Bmax][max_feat_p]: per-slice slabs of smx_bigk.hip (wide panels only)

@@ -146,11 +146,19 @@ int mlp_forward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const 
       Timed t(m, label0);
       SMX_CHECK(launch_gemm_dual(m->st, g, g2, &eff));
     } else if (!with_front) {
+      // the gathered first layer at up to 128 cells: its (at most 16) split-K slabs column-major, summed by a BatchNorm launch of one
+      // workgroup per column -- every load 16 bytes of a contiguous 512-byte column instead of 4 bytes of a 32-byte row piece, the additions
+      // in the same order (slab 0, 1, ...): the same bits (bn_wide_fwd_kernel)
+      if (i == 0 && in_is_x && !sync && g.use_xform && g.tile == TILE_AUTO && g.split_k <= 16 && bn_wide_supported(ps.B, L.out_p, g.split_k) &&
+          (size_t)g.split_k * 128 * (size_t)L.out_p <= m->slab_cap && !tuning_on("xf_tile")) {
+        g.c_colmajor = 1; g.slab_stride = 128L * L.out_p;
+      }
       Timed t(m, (i == 0 && in_is_x) ? label0 : "gemm_mlp_fwd");
       SMX_CHECK(launch_gemm(m->st, g, &eff));
     }
     BnFwdArgs b = make_bn(L, m->slab, eff, g.slab_stride);
     if (bigk && bk.colmajor) { b.pre = bk.part; b.n_slabs = bk.n_slices; b.slab_stride = bk.slab_stride; b.wide = 1; }
+    else if (!bigk && !dual && !with_front && g.c_colmajor) b.wide = 1;
     if (!no_ahead && !sync && i == 0 && in_is_x && &mlp == &m->enc && ps.training && front_shapes_ok(m, ps) &&
         !with_front && b.n_jobs == 0) {
       // the decoder's front launch (latent sample + first decoder layer) computes the whole latent tile in EVERY one of
@@ -330,12 +338,22 @@ static bool head_sweep_ok(smx_model* m) {
   return true;
 }
 static int head_sweep_prepare(smx_model* m) {
-  if (m->st_side) return SMX_OK;
-  int lo = 0, hi = 0;
-  SMX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  SMX_HIP(hipStreamCreateWithPriority(&m->st_side, hipStreamNonBlocking, lo));
-  SMX_HIP(hipEventCreateWithFlags(&m->ev_sweep, hipEventDisableTiming));
-  SMX_HIP(hipEventCreateWithFlags(&m->ev_hf, hipEventDisableTiming));
+  // one GPU: both ends of these events are queues of THIS device -- the kernels' own agent-scope release / acquire orders their memory, and the
+  // system-scope fence an event record carries by default costs ~1.5 us at either end of the output head (c5-shard 156 -> 153 us, same bits;
+  // knob event_system_fence).  With a communicator attached (peers read what the chain's collective sends) the default stays.
+  const int mode = (dp_active(m) || tuning_on("event_system_fence")) ? 1 : 0;
+  if (m->st_side && m->ev_mode == mode) return SMX_OK;
+  if (!m->st_side) {
+    int lo = 0, hi = 0;
+    SMX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    SMX_HIP(hipStreamCreateWithPriority(&m->st_side, hipStreamNonBlocking, lo));
+  }
+  if (m->ev_sweep) { hipEventDestroy(m->ev_sweep); m->ev_sweep = nullptr; }
+  if (m->ev_hf) { hipEventDestroy(m->ev_hf); m->ev_hf = nullptr; }
+  const unsigned fl = hipEventDisableTiming | (mode ? 0u : (unsigned)hipEventDisableSystemFence);
+  SMX_HIP(hipEventCreateWithFlags(&m->ev_sweep, fl));
+  SMX_HIP(hipEventCreateWithFlags(&m->ev_hf, fl));
+  m->ev_mode = mode;
   return SMX_OK;
 }
 // behind the output head's launch (ev_hf) on the second stream
@@ -414,7 +432,7 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     else b.dbias = G_(m, L.tBias);
     if (front) { b.front = 1; b.fD = front->fD; b.fld = front->fld; b.fW = front->fW; b.fldw = front->fldw; b.fK = front->fK; }
     if (&mlp == &m->dec && &L == &mlp.back() && m->wide_dd_slabs > 0 && !front) {   // the one-launch head's slabs, column-major
-      b.dout = m->bigk_part; b.n_slabs = m->wide_dd_slabs; b.slab_stride = 128L * 128; b.wide = 1;
+      b.dout = m->wide_dd_src; b.n_slabs = m->wide_dd_slabs; b.slab_stride = m->wide_dd_stride; b.wide = 1;
     }
     return b;
   };
@@ -776,7 +794,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
       // data parallel, two buckets: without label heads every gradient of the head bucket is final HERE -- its chain (all-reduce, norms,
       // clip + Adam) runs beside the whole backward pass, the optimiser launch and the next step's encoder and decoder
       if (m->n_heads == 0 && dp_chain_ok(m)) SMX_CHECK(dp_chain_start(m));
-      m->wide_dd_slabs = wide_dd ? n_slabs : 0;
+      m->wide_dd_slabs = wide_dd ? n_slabs : 0; m->wide_dd_src = m->bigk_part; m->wide_dd_stride = hf.slab_stride;
       if (!wide_dd) SMX_CHECK(launch_head_fused_reduce(m->st, hf, n_slabs, m->slab));
       n_llk_chunks = head_fused_chunks(m->Gp);
       m->head_fused = true;
@@ -1149,6 +1167,10 @@ int backward_pass(smx_model* m, const Pass& ps) {
         m->lab_deferred = true;
       }
     }
+    // at most 128 cells, no label slabs: d d's slabs column-major, summed by the decoder's BatchNorm-backward launch as one workgroup per
+    // column (bn_wide_bwd_kernel; <= 16 slabs: the additions in the order of the 8-column launch, the same bits)
+    const bool dd_wide = !(m->head_fused && m->head_loss) && m->n_heads == 0 && hb.n_extra == 0 && !hb.sep && hb.n_slices <= 16 && !(sync_bn_on(m, ps.training) && dL.bn >= 0) &&
+                         bn_wide_supported(ps.B, dL.out_p, hb.n_slices) && (size_t)hb.n_slices * 128 * (size_t)dL.out_p <= m->slab_cap;
     Timed t(m, "gemm_out_bwd");
     const bool fused_done = m->head_fused && m->head_loss && !hb.sep && hb.n_extra == 0;   // (forward_pass ran smx_headfused.hip: dW, db, the sum of squares and d d are there)
     if (fused_done) {
@@ -1166,12 +1188,20 @@ int backward_pass(smx_model* m, const Pass& ps) {
       bk.part = m->bigk_part; bk.out = m->slab;
       bk.n_slices = bigk_slices(bk.K, SMX_BIGK_MAX_SLICES, &bk.k_chunk);
       if (bigk_supported(bk) && (size_t)bk.n_slices * (size_t)bk.slab_stride <= m->bigk_floats) {
+        if (m->n_heads == 0 && !(sync_bn_on(m, ps.training) && dL.bn >= 0) && bn_wide_supported(ps.B, dL.out_p, bk.n_slices) && (size_t)bk.n_slices * 128 * 128 <= m->bigk_floats) {
+          bk.colmajor = 1; bk.slab_stride = 128L * 128;   // (no reduce launch: as behind the one-launch head)
+          m->wide_dd_slabs = bk.n_slices; m->wide_dd_src = m->bigk_part; m->wide_dd_stride = bk.slab_stride;
+        }
         SMX_CHECK(launch_bigk(m->st, bk));
         dd_bigk = true;
         n_slabs = 1;
       }
     }
     hb.skip_dd = dd_bigk ? 1 : 0;
+    if (dd_wide && !fused_done && !dd_bigk) {
+      hb.dd_colmajor = 1; hb.slab_stride = 128L * dL.out_p;
+      m->wide_dd_slabs = hb.n_slices; m->wide_dd_src = m->slab; m->wide_dd_stride = hb.slab_stride;
+    }
     // ... and then d W / d b with one workgroup per (gene tile, plane) that holds every row of H (smx_panel.h): the panel is
     // transformed and split once, not once per 32 rows of H
     if (fused_done) {}

@@ -412,16 +412,19 @@ def test_wide_panel_heads_update_as_a_background_sweep(Engine):
         assert np.array_equal(ref[which][k], r[which][k]), (which, k)
 
 
-@pytest.mark.parametrize("lk,B,G,storage", [("zinb", 100, 4100, "u16"), ("nb", 128, 4128, "f32"), ("zinbd", 77, 4500, "u16")])
-def test_wide_panel_batchnorm_sums_the_slabs_itself(Engine, lk, B, G, storage):
+@pytest.mark.parametrize("lk,B,G,storage,units,bnorm", [("zinb", 100, 4100, "u16", 128, True), ("nb", 128, 4128, "f32", 128, True), ("zinbd", 77, 4500, "u16", 128, True),
+                                                       ("nb", 90, 4128, "u16", 96, False), ("zinb", 128, 1998, "f32", 128, True), ("nb", 50, 700, "u16", 64, True),
+                                                       ("zinb", 100, 1200, "f32", 96, False)])
+def test_batchnorm_launch_sums_column_major_slabs_itself(Engine, lk, B, G, storage, units, bnorm):
   """Wide panels, at most 128 cells (smx_kernels.hip: bn_wide_fwd_kernel / bn_wide_bwd_kernel): the encoder front's K slices and the one-launch
   head's workgroups leave their [128][128] partial sums as COLUMN-major slabs and the BatchNorm launch behind them -- one workgroup per
   column -- sums them itself: no reduce launch in either pass.  The additions keep the order of the reduce launch + 8-column BatchNorm launch
   they replace (knob no_bn_wide): losses of every step, an evaluation pass, parameters, both Adam moments and the BatchNorm moving statistics
-  are equal BIT FOR BIT -- ragged minibatches, every count store, a captured step included."""
+  are equal BIT FOR BIT -- ragged minibatches, every count store, a captured step included.  The same pair of launches behind the 32 x 32-tile
+  products of narrower panels (BASELINE configs[1]: 16 slabs of the encoder product, 12 of d d), with and without BatchNorm, 64 / 96 / 128 units."""
   from sisua_amd import _hip
   from tests.util import make_pair, synth_counts
-  spec, cfg = make_pair(model="vae", n_genes=G, likelihood=lk, enc_units=(128,), dec_units=(128,), latent_dim=16)
+  spec, cfg = make_pair(model="vae", n_genes=G, likelihood=lk, enc_units=(units,), dec_units=(units,), latent_dim=16, batchnorm=bnorm)
   x = synth_counts(512, G, sparsity=0.92, seed=G + 1, max_count=700)
   rng = np.random.default_rng(11)
   order = np.concatenate([rng.permutation(512)[:B] for _ in range(4)]).astype(np.int32)
@@ -432,7 +435,7 @@ def test_wide_panel_batchnorm_sums_the_slabs_itself(Engine, lk, B, G, storage):
       e = Engine(cfg, max_batch=128, init=False)
       e.set_params(so.init_params(spec))
       e.upload(x, cell_id_base=9, storage=storage)
-      assert e.head_fused_bytes(B) > 0
+      assert (e.head_fused_bytes(B) > 0) == (G >= 4096 and units == 128)
       e.train_steps(order, 4, B, graph=False)
       h = {k: np.asarray(v).copy() for k, v in e.metrics_history(4).items()}
       ev = e.eval_step(order[:B])["loss"]
