@@ -237,6 +237,54 @@ __device__ inline uint32_t lds_addr(const void* p) {   // byte address within th
 }
 
 // ---------------------------------------------------------------------------
+// Kernel arguments: the argument structs of the step's launches are hundreds of bytes (4 - 12 cache lines of the kernarg segment, written by the
+// host a few microseconds before the launch: cold in the scalar cache AND in L2), and the compiler loads their fields where it needs them --
+// s_load -> s_waitcnt -> branch -> s_load -> s_waitcnt ..., up to ten DEPENDENT misses at the head of a launch (the decoder's BatchNorm-forward
+// launch issued its first global load 4840 cycles = 2.3 us after entry: tools/c2_stamps.sh).  kernarg_warm<BYTES>() at the top of a kernel
+// requests every 64-byte line of the first BYTES of the segment in ONE batch (a scalar load each into a scratch register, one wait): the later
+// field loads hit the scalar cache.  One asm statement, so that no compiler-scheduled instruction reuses the scratch register while a load is
+// still on its way to it.
+// ---------------------------------------------------------------------------
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+  // (at most the first 16 lines = 1 KB)
+  const uint64_t p = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  uint32_t d;
+#define SMX_KW(o) "s_load_dword %0, %1, " #o "\n\t"
+  if constexpr (BYTES <= 256)
+    asm volatile(SMX_KW(0x0) SMX_KW(0x40) SMX_KW(0x80) SMX_KW(0xc0) "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(p) : "memory");
+  else if constexpr (BYTES <= 512)
+    asm volatile(SMX_KW(0x0) SMX_KW(0x40) SMX_KW(0x80) SMX_KW(0xc0) SMX_KW(0x100) SMX_KW(0x140) SMX_KW(0x180) SMX_KW(0x1c0) "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(d) : "s"(p) : "memory");
+  else if constexpr (BYTES <= 768)
+    asm volatile(SMX_KW(0x0) SMX_KW(0x40) SMX_KW(0x80) SMX_KW(0xc0) SMX_KW(0x100) SMX_KW(0x140) SMX_KW(0x180) SMX_KW(0x1c0) SMX_KW(0x200) SMX_KW(0x240)
+                 SMX_KW(0x280) SMX_KW(0x2c0) "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(p) : "memory");
+  else
+    asm volatile(SMX_KW(0x0) SMX_KW(0x40) SMX_KW(0x80) SMX_KW(0xc0) SMX_KW(0x100) SMX_KW(0x140) SMX_KW(0x180) SMX_KW(0x1c0) SMX_KW(0x200) SMX_KW(0x240)
+                 SMX_KW(0x280) SMX_KW(0x2c0) SMX_KW(0x300) SMX_KW(0x340) SMX_KW(0x380) SMX_KW(0x3c0) "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(p) : "memory");
+#undef SMX_KW
+  (void)d;
+}
+
+// preload(field, ...): have these kernel-argument fields in scalar registers HERE.  The compiler loads a field of a by-value argument
+// struct where it is first needed, which inside predicated code means s_load -> s_waitcnt -> use once per field and branch: a chain of
+// DEPENDENT scalar-cache round trips (~200 cycles each even when they hit; 17 of them ahead of the first global load of the decoder's
+// BatchNorm-forward launch).  An empty asm that takes the values as scalar inputs makes the loads one batch with one wait.
+template <class T>
+__device__ __forceinline__ auto sbits(const T& v) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "preload: 4- or 8-byte fields");
+  if constexpr (sizeof(T) == 4) return __builtin_bit_cast(uint32_t, v);
+  else return __builtin_bit_cast(uint64_t, v);
+}
+// (one asm statement per call -- all of a call's fields are one batch of loads; 8, 16 or 24 fields: an asm statement takes at most 30 operands)
+template <class T0, class T1, class T2, class T3, class T4, class T5, class T6, class T7>
+__device__ __forceinline__ void preload(const T0& v0, const T1& v1, const T2& v2, const T3& v3, const T4& v4, const T5& v5, const T6& v6, const T7& v7) { asm volatile("" ::"s"(sbits(v0)), "s"(sbits(v1)), "s"(sbits(v2)), "s"(sbits(v3)), "s"(sbits(v4)), "s"(sbits(v5)), "s"(sbits(v6)), "s"(sbits(v7))); }
+template <class T0, class T1, class T2, class T3, class T4, class T5, class T6, class T7, class T8, class T9, class T10, class T11, class T12, class T13, class T14, class T15>
+__device__ __forceinline__ void preload(const T0& v0, const T1& v1, const T2& v2, const T3& v3, const T4& v4, const T5& v5, const T6& v6, const T7& v7, const T8& v8, const T9& v9, const T10& v10, const T11& v11, const T12& v12, const T13& v13, const T14& v14, const T15& v15) { asm volatile("" ::"s"(sbits(v0)), "s"(sbits(v1)), "s"(sbits(v2)), "s"(sbits(v3)), "s"(sbits(v4)), "s"(sbits(v5)), "s"(sbits(v6)), "s"(sbits(v7)), "s"(sbits(v8)), "s"(sbits(v9)), "s"(sbits(v10)), "s"(sbits(v11)), "s"(sbits(v12)), "s"(sbits(v13)), "s"(sbits(v14)), "s"(sbits(v15))); }
+template <class T0, class T1, class T2, class T3, class T4, class T5, class T6, class T7, class T8, class T9, class T10, class T11, class T12, class T13, class T14, class T15, class T16, class T17, class T18, class T19, class T20, class T21, class T22, class T23>
+__device__ __forceinline__ void preload(const T0& v0, const T1& v1, const T2& v2, const T3& v3, const T4& v4, const T5& v5, const T6& v6, const T7& v7, const T8& v8, const T9& v9, const T10& v10, const T11& v11, const T12& v12, const T13& v13, const T14& v14, const T15& v15, const T16& v16, const T17& v17, const T18& v18, const T19& v19, const T20& v20, const T21& v21, const T22& v22, const T23& v23) { asm volatile("" ::"s"(sbits(v0)), "s"(sbits(v1)), "s"(sbits(v2)), "s"(sbits(v3)), "s"(sbits(v4)), "s"(sbits(v5)), "s"(sbits(v6)), "s"(sbits(v7)), "s"(sbits(v8)), "s"(sbits(v9)), "s"(sbits(v10)), "s"(sbits(v11)), "s"(sbits(v12)), "s"(sbits(v13)), "s"(sbits(v14)), "s"(sbits(v15)), "s"(sbits(v16)), "s"(sbits(v17)), "s"(sbits(v18)), "s"(sbits(v19)), "s"(sbits(v20)), "s"(sbits(v21)), "s"(sbits(v22)), "s"(sbits(v23))); }
+
+// ---------------------------------------------------------------------------
 // development: cycle stamps of a kernel's phases (builds with -DSMX_STAMPS only: tools/c2_stamps.sh).  Thread 0 of workgroup
 // SMX_STAMP_WG writes clock64() into the translation unit's own table [slot][16]; smx_dbg_stamps_<unit>() copies it out.
 // ---------------------------------------------------------------------------

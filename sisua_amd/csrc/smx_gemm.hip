@@ -89,31 +89,34 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
   const int k_end = min(g.K, k_begin + g.k_chunk);
 
   float4 ra[NA], rb[NB];
+  uint2 ra_h[NA];   // (XF == 2: the uint16 counts as loaded)
+  int a_src[NA];    // gathered source row of the A piece (XF)
 
+  // The A pieces of a tile are requested in two batches -- every row id, then every piece from a clamped address -- and transformed
+  // (uint16 -> float, log1p, dropout) only when they go to LDS.  As a lane-predicated block per piece (row id -> piece -> log1p inside
+  // `if (m < M && k < k_end)`) the gathered first layer's four pieces were EIGHT dependent memory round trips one after the other
+  // (BASELINE configs[1]: the encoder product's whole launch, 6.3 us).
   auto load_tiles = [&](int k0) {
+    int a_m[NA], a_k[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int f = tid + 256 * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (A_KM) {
         const int kr = f / (BM / 4), mq = f % (BM / 4);
-        const int k = k0 + kr, m = m0 + mq * 4;
-        if (k < k_end && m < g.M) {
-          const int src = (XF && g.xf.rows) ? g.xf.rows[k] : k;
-          v = load_a4<XF>(g, (long)src * g.lda + m);
-          v = xform4<XF>(v, g.xf, k, src, m);
-        }
+        a_k[j] = min(k0 + kr, k_end - 1); a_m[j] = min(m0 + mq * 4, g.M - 4);
       } else {
         const int mr = f / (BK / 4), kq = f % (BK / 4);
-        const int m = m0 + mr, k = k0 + kq * 4;
-        if (m < g.M && k < k_end) {
-          const int src = (XF && g.xf.rows) ? g.xf.rows[m] : m;
-          v = load_a4<XF>(g, (long)src * g.lda + k);
-          v = xform4<XF>(v, g.xf, m, src, k);
-          // K is ragged only when it is the batch axis (A_KM); here K is a padded feature axis.
-        }
+        a_m[j] = min(m0 + mr, g.M - 1); a_k[j] = min(k0 + kq * 4, k_end - 4);
       }
-      ra[j] = v;
+      const int id = A_KM ? a_k[j] : a_m[j];
+      a_src[j] = id;
+      if (XF && g.xf.rows) a_src[j] = g.xf.rows[id];
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const long off = (long)a_src[j] * g.lda + (A_KM ? a_m[j] : a_k[j]);
+      if (XF == 2) ra_h[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(g.A) + off);
+      else ra[j] = *reinterpret_cast<const float4*>(g.A + off);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -132,19 +135,27 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
     }
   };
 
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int k0) {   // k0: the tile the registers hold
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int f = tid + 256 * j;
+      float4 v = ra[j];
+      if (XF == 2) v = make_float4((float)(ra_h[j].x & 0xFFFFu), (float)(ra_h[j].x >> 16), (float)(ra_h[j].y & 0xFFFFu), (float)(ra_h[j].y >> 16));
       if (A_KM) {
         const int kr = f / (BM / 4), mq = f % (BM / 4);
-        *reinterpret_cast<float4*>(&As[kr * LDAS + mq * 4]) = ra[j];
+        const int k = k0 + kr, m = m0 + mq * 4;
+        if (k < k_end && m < g.M) v = xform4<XF>(v, g.xf, k, a_src[j], m);
+        else v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&As[kr * LDAS + mq * 4]) = v;
       } else {
         const int mr = f / (BK / 4), kq = f % (BK / 4);
-        As[(kq * 4 + 0) * LDAS + mr] = ra[j].x;
-        As[(kq * 4 + 1) * LDAS + mr] = ra[j].y;
-        As[(kq * 4 + 2) * LDAS + mr] = ra[j].z;
-        As[(kq * 4 + 3) * LDAS + mr] = ra[j].w;
+        const int m = m0 + mr, k = k0 + kq * 4;
+        if (m < g.M && k < k_end) v = xform4<XF>(v, g.xf, m, a_src[j], k);
+        else v = make_float4(0.f, 0.f, 0.f, 0.f);
+        As[(kq * 4 + 0) * LDAS + mr] = v.x;
+        As[(kq * 4 + 1) * LDAS + mr] = v.y;
+        As[(kq * 4 + 2) * LDAS + mr] = v.z;
+        As[(kq * 4 + 3) * LDAS + mr] = v.w;
       }
     }
 #pragma unroll
@@ -171,7 +182,7 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
 
   if (k_begin < k_end) load_tiles(k_begin);
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-    store_tiles();
+    store_tiles(k0);
     __syncthreads();
     if (k0 + BK < k_end) load_tiles(k0 + BK);
     const float* as = As + (wk * 32 + lh) * LDAS + wm * 32 + li;

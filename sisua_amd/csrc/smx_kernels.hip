@@ -282,36 +282,48 @@ __device__ inline void noise_fill(const BnFwdArgs& a, int job_block) {
 template <int MAXIT>
 __device__ inline void latent_tile_to_lds(const LatentArgs& a, float* zs, bool store) {
   const int dq = a.Dp >> 2, ldz = a.Dp + 1;
+  const int dsh = __builtin_ctz((unsigned)dq), dmask = dq - 1;   // dq is a power of two (bn_front_supported): shifts, not the ~35-instruction integer division per index
   const int total = a.B * dq;
   // every load of every iteration first (left as a loop the compiler waits for each iteration's loads in turn:
   // MAXIT serial round trips to data the previous launch has just written)
   float4 m4[MAXIT], s4[MAXIT], n4[MAXIT];
   uint32_t cell[MAXIT];
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int total_r = (total + 63) & ~63;
+  // Unconditional loads from a clamped index under block-uniform branches only: a lane-predicated load sits in a block of its own, and the
+  // row id's `cell_base + rows[b]` inside such a block made the compiler wait for EVERY outstanding load of the iteration before the next
+  // iteration's loads were issued -- two serial memory round trips ahead of the first dot product (tools/c2_stamps.sh).  The row id is only
+  // read when the normals are drawn here (not when an earlier launch drew them: inj_eps).
+  const bool need_cell = a.stochastic && !a.inj_eps;
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
-    const int idx = threadIdx.x + it * BN_THREADS;
-    const bool ok = idx < total;
-    const int b = ok ? idx / dq : 0, d0 = (idx % dq) * 4;
-    // (assign-then-overwrite, not `ok ? *p : z4`: that conditional is an lvalue, so z4 gets an address -- in scratch)
-    m4[it] = z4; s4[it] = z4; n4[it] = z4;
-    if (ok) m4[it] = *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + d0);
-    if (ok && a.stochastic) s4[it] = *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + a.Dp + d0);
-    if (ok && a.stochastic && a.inj_eps) n4[it] = *reinterpret_cast<const float4*>(a.inj_eps + (long)b * a.inj_ld + d0);
-    cell[it] = a.cell_base + (uint32_t)((ok && a.rows) ? a.rows[b] : b);
+    m4[it] = z4; s4[it] = z4; n4[it] = z4; cell[it] = 0;
+    if (it * BN_THREADS >= total_r) continue;   // block-uniform
+    const int idx = min((int)threadIdx.x + it * BN_THREADS, total - 1);
+    const int b = idx >> dsh, d0 = (idx & dmask) * 4;
+    m4[it] = *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + d0);
+    if (a.stochastic) s4[it] = *reinterpret_cast<const float4*>(a.lat + (long)b * a.ld + a.Dp + d0);
+    if (a.stochastic && a.inj_eps) n4[it] = *reinterpret_cast<const float4*>(a.inj_eps + (long)b * a.inj_ld + d0);
+    cell[it] = (uint32_t)b;
+    if (need_cell && a.rows) cell[it] = (uint32_t)a.rows[b];
   }
+  SMX_STAMP(1, 7);   // the tile's loads issued
+#ifdef SMX_STAMPS
+  if (m4[0].x == 12345.678f && s4[0].x == 1.f) zs[0] = n4[0].x;   // (the first iteration's operands have arrived)
+  SMX_STAMP(1, 8);
+#endif
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int idx = threadIdx.x + it * BN_THREADS;
     if (it * BN_THREADS >= ((total + 63) & ~63)) break;   // block-uniform
-    const int b = idx / dq, d0 = (idx % dq) * 4;
+    const int b = idx >> dsh, d0 = (idx & dmask) * 4;
     float kl = 0.f;
     if (idx < total) {
       float4 zq = z4, sq = make_float4(1.f, 1.f, 1.f, 1.f), eq = z4;
       const float4 mq = m4[it];
       if (a.stochastic) {
         float4 nq = n4[it];
-        if (!a.inj_eps) nq = normal4(philox_block(a.nk, cell[it], (uint32_t)(d0 >> 2)));
+        if (!a.inj_eps) nq = normal4(philox_block(a.nk, a.cell_base + cell[it], (uint32_t)(d0 >> 2)));
         const float4 sr = s4[it];
         auto one = [&](int e, float mu, float s_raw, float nn, float& z, float& s, float& en) {
           if (d0 + e < a.D) {
@@ -342,9 +354,10 @@ __device__ inline void latent_tile_to_lds(const LatentArgs& a, float* zs, bool s
     }
     if (store && a.kl && idx < ((total + 63) & ~63)) {   // the dq lanes of a cell are adjacent (dq a power of two <= 16)
       for (int off = 1; off < dq; off <<= 1) kl += __shfl_xor(kl, off, 64);
-      if (idx < total && (idx % dq) == 0) a.kl[b] = kl;
+      if (idx < total && (idx & dmask) == 0) a.kl[b] = kl;
     }
   }
+  SMX_STAMP(1, 9);   // sample + KL computed, LDS / global stores issued
 }
 
 template <int RPT, int FRONT>
@@ -358,6 +371,9 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
   __shared__ float sh[BN_WAVES * BN_COLS];
   extern __shared__ float zs[];   // FRONT: [B][Dp + 1]
   SMX_STAMP(FRONT ? 1 : 0, 0);   // entry
+  if (FRONT) preload(a.lat.lat, a.lat.ld, a.lat.Dp, a.lat.D, a.lat.B, a.lat.stochastic, a.lat.inj_eps, a.lat.inj_ld, a.lat.rows, a.lat.z, a.lat.sig, a.lat.eps,
+                     a.lat.kl, a.W, a.ldw, a.B, a.H, a.Hp, a.gamma, a.beta, a.inj_mask, a.inj_ld, a.batchnorm, a.training);
+  else preload(a.pre, a.n_slabs, a.slab_stride, a.ld, a.B, a.H, a.Hp, a.gamma, a.beta, a.bias, a.inj_mask, a.inj_ld, a.xhat, a.out, a.batchnorm, a.training);
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = bid * BN_COLS + c;
   const bool live = col < a.H;  // padded columns produce zeros
@@ -382,17 +398,18 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
     if constexpr (FRONT == 2) {   // a plain input tile (hidden layers): every load first, then LDS
       constexpr int MAXIT = BN_RPT * 4;
       const int kq = a.lat.Dp >> 2, ldz = a.lat.Dp + 1, total = a.B * kq;
+      const int ksh = __builtin_ctz((unsigned)kq), kmask = kq - 1;   // (Dp = 128)
       float4 t4[MAXIT];
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it) {
         const int idx = threadIdx.x + it * BN_THREADS;
-        t4[it] = idx < total ? *reinterpret_cast<const float4*>(a.lat.lat + (long)(idx / kq) * a.lat.ld + (idx % kq) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        t4[it] = idx < total ? *reinterpret_cast<const float4*>(a.lat.lat + (long)(idx >> ksh) * a.lat.ld + (idx & kmask) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it) {
         const int idx = threadIdx.x + it * BN_THREADS;
         if (idx < total) {
-          const int o = (idx / kq) * ldz + (idx % kq) * 4;
+          const int o = (idx >> ksh) * ldz + (idx & kmask) * 4;
           zs[o] = t4[it].x; zs[o + 1] = t4[it].y; zs[o + 2] = t4[it].z; zs[o + 3] = t4[it].w;
         }
       }
@@ -532,7 +549,7 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
 }
 
 template <int RPT, int FRONT = 0>
-__global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) { bn_act_fwd_body<RPT, FRONT>(a, (int)blockIdx.x); }
+__global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) { kernarg_warm<sizeof(BnFwdArgs)>(); bn_act_fwd_body<RPT, FRONT>(a, (int)blockIdx.x); }
 // two independent layers over the same minibatch in ONE launch (scvi: first layers of the encoder and of the library
 // encoder): blocks [0, na) belong to a (its column blocks, then its noise jobs), the rest to b
 template <int RPT>
@@ -632,6 +649,8 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
   }
   __shared__ float sh[BN_WAVES * BN_COLS];
   SMX_STAMP(FRONT ? 3 : 2, 0);   // entry
+  if (FRONT) preload(a.fD, a.fld, a.fW, a.fldw, a.fK, a.diag, a.out, a.xhat, a.inv_std, a.gamma, a.B, a.H, a.Hp, a.batchnorm, a.training, a.drop_scale);
+  else preload(a.dout, a.n_slabs, a.slab_stride, a.ld, a.out, a.xhat, a.inv_std, a.gamma, a.B, a.H, a.Hp, a.batchnorm, a.training, a.drop_scale, a.dpre, a.leak);
   const int c = threadIdx.x % BN_COLS, rl = threadIdx.x / BN_COLS;
   const int col = bid * BN_COLS + c;
   const bool live = col < a.H;
@@ -655,31 +674,32 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
   float wrow[FRONT ? FK : 1];
   if (FRONT) {
     const int ldd = a.fK + 1, kq = a.fK >> 2;
+    const int ksh = __builtin_ctz((unsigned)kq), kmask = kq - 1;   // fK is 32, 64 or 128 (bn_bwd_front_supported)
     // this workgroup's 8 rows of W_lat: ONE coalesced pass into LDS (every thread loading its own row from global
     // memory is 8 different cache lines per quarter-wave: 5 us), then each thread copies its row to registers
     float* ws = ds + ((a.B * ldd + 3) & ~3);     // [BN_COLS][fK + 4], 16-byte aligned
     const int ldw_s = a.fK + 4;
     float4 wl = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool wl_on = (int)threadIdx.x < BN_COLS * kq && !(a.diag & 64);   // (8 rows x fK / 4 <= 256 float4: one per thread)
-    if (wl_on) wl = *reinterpret_cast<const float4*>(a.fW + (long)(bid * BN_COLS + threadIdx.x / kq) * a.fldw + (threadIdx.x % kq) * 4);
+    if (wl_on) wl = *reinterpret_cast<const float4*>(a.fW + (long)(bid * BN_COLS + ((int)threadIdx.x >> ksh)) * a.fldw + ((int)threadIdx.x & kmask) * 4);
     {   // all loads of the tile in flight at once (B fK / 4 float4 over 512 threads), then LDS
       constexpr int MAXIT = BN_RPT * (FK / 32);
       float4 tl[MAXIT];
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it) {
         const int idx = threadIdx.x + it * BN_THREADS;
-        tl[it] = (idx < a.B * kq && !(a.diag & 32)) ? *reinterpret_cast<const float4*>(a.fD + (long)(idx / kq) * a.fld + (idx % kq) * 4)
+        tl[it] = (idx < a.B * kq && !(a.diag & 32)) ? *reinterpret_cast<const float4*>(a.fD + (long)(idx >> ksh) * a.fld + (idx & kmask) * 4)
                                   : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it) {
         const int idx = threadIdx.x + it * BN_THREADS;
         if (idx < a.B * kq) {
-          const int o = (idx / kq) * ldd + (idx % kq) * 4;
+          const int o = (idx >> ksh) * ldd + (idx & kmask) * 4;
           ds[o] = tl[it].x; ds[o + 1] = tl[it].y; ds[o + 2] = tl[it].z; ds[o + 3] = tl[it].w;
         }
       }
-      if ((int)threadIdx.x < BN_COLS * kq) *reinterpret_cast<float4*>(&ws[(threadIdx.x / kq) * ldw_s + (threadIdx.x % kq) * 4]) = wl;
+      if ((int)threadIdx.x < BN_COLS * kq) *reinterpret_cast<float4*>(&ws[((int)threadIdx.x >> ksh) * ldw_s + ((int)threadIdx.x & kmask) * 4]) = wl;
     }
     __syncthreads();
     SMX_STAMP(3, 1);   // the gradient tile and the rows of W are in LDS
@@ -766,7 +786,7 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
 }
 
 template <int RPT, int FRONT = 0>
-__global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) { bn_act_bwd_body<RPT, FRONT>(a, (int)blockIdx.x); }
+__global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) { kernarg_warm<sizeof(BnBwdArgs)>(); bn_act_bwd_body<RPT, FRONT>(a, (int)blockIdx.x); }
 // two independent layers in ONE launch, both with the gradient front (scvi: last layers of the encoder and of the
 // library encoder): blocks [0, na) belong to a (column blocks, then its riders), the rest to b (no riders)
 template <int RPT>
@@ -885,6 +905,7 @@ __device__ inline float wide_tree64(float p) {
 // same operations out with contraction switched off, so that the two forms stay equal bit for bit.)
 __global__ __launch_bounds__(BN_THREADS) void bn_wide_fwd_kernel(BnFwdArgs a) {
 #pragma clang fp contract(off)
+  kernarg_warm<sizeof(BnFwdArgs)>();
   const int bid = (int)blockIdx.x;
   if (bid >= a.Hp) { noise_fill(a, bid - a.Hp); return; }
   __shared__ __attribute__((aligned(16))) float sh[16 * 128];
@@ -960,6 +981,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_wide_fwd_kernel(BnFwdArgs a) {
 
 __global__ __launch_bounds__(BN_THREADS) void bn_wide_bwd_kernel(BnBwdArgs a) {
 #pragma clang fp contract(off)
+  kernarg_warm<sizeof(BnBwdArgs)>();
   const int bid = (int)blockIdx.x;
   {
     const int extra = bid - a.Hp;
@@ -2401,6 +2423,7 @@ __device__ inline void sq_reduce_body(const float* sl, int cnt, float* dst) {
 }
 
 __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
+  kernarg_warm<sizeof(AdamArgs)>();
   if ((int)blockIdx.x == a.n_launch) {  // use_sq form: the ELBO scalars ride along here
     metrics_body(a.metrics);
     return;
