@@ -80,6 +80,8 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
   float* As = smem;
   float* Bs = smem + BK * LDAS;
 
+  preload(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, g.k_chunk, g.slab_stride, g.bias, g.colsum, g.sq_part, g.act, g.c_colmajor);   // (one batch: smx_device.h)
+  if (XF) preload(g.xf.rows, g.xf.log1p, g.xf.inj_mask, g.xf.drop_p, g.xf.cell_base, g.xf.drop_scale, g.xf.inj_ld, g.wide_store);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wk = wave / (WM * WN), wm = (wave / WN) % WM, wn = wave % WN;

@@ -38,6 +38,8 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
   // ONE plane's eight partial tiles at a time (32 KB); the bf16 form's role 1 turns its operands through wave-private tiles
   // first (2 x 8 x 32 x 36 floats = 72 KB, the partial tiles then go over them): two workgroups per CU either way
   __shared__ __attribute__((aligned(16))) float red[B3 ? 2 * 8 * 32 * 36 : 8 * 1024];
+  preload(a.D, a.ldd, a.dP, a.ldp, a.W, a.ldw, a.dW, a.db, a.slab, a.slab_stride, a.B, a.Hp, a.Gp, a.n_slices, a.k_chunk, a.sq_part,
+          a.n_w, a.n_ht, a.n_gt, a.n_ct, a.n_extra, a.diag, a.dd_colmajor, a.skip_dd);   // (the argument fields in one batch: smx_device.h)
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = lane & 31, hh = lane >> 5;
   // accumulator register r of a 32 x 32 tile is row (r & 3) + 8 (r >> 2) + 4 hh, column i; wave q finishes r = 2q, 2q + 1
@@ -347,6 +349,7 @@ namespace smx {
 
 // one 32 x 32 tile of problem P: `red` 8 partial tiles (32 KB), `sqs` 8 floats
 __device__ inline void wgrad_tile_body(const WgradGroup& Gr, const WgradProblem& P, float* red, float* sqs) {
+  preload(P.A, P.lda, P.a_mode, P.log1p, P.rows, P.Bm, P.ldb, P.C, P.ldc, P.M, P.n_mt, P.n_nt, P.start, P.colsum, P.sq_part, Gr.B);   // (one batch: smx_device.h)
   const int local = blockIdx.x - P.start;
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = lane & 31, hh = lane >> 5;
@@ -434,14 +437,22 @@ __device__ inline void wgrad_tile_body(const WgradGroup& Gr, const WgradProblem&
 }
 
 
+// the problem of this workgroup: every start in one scalar load (a `while (blockIdx.x >= p[pi + 1].start)` walk is a scalar load, a wait and a
+// branch per problem: up to seven dependent scalar-cache round trips at the head of every workgroup)
+__device__ __forceinline__ int wgrad_problem_of(const WgradGroup& Gr) {
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < SMX_GROUP_MAX; ++k) pi += ((int)blockIdx.x >= Gr.starts[k]) ? 1 : 0;
+  return pi;
+}
+
 __global__ __launch_bounds__(512) void wgrad_group_kernel(WgradGroup G) {
   __shared__ float red[8 * 1024];
   __shared__ float sqs[8];
   // the descriptor through the kernarg segment pointer: indexing the by-value struct with a run-time problem id would
   // make the compiler copy all of it to scratch (see gemm_group_kernel)
   const WgradGroup& Gr = *(const WgradGroup*)__builtin_amdgcn_kernarg_segment_ptr();
-  int pi = 0;
-  while (pi + 1 < Gr.n && (int)blockIdx.x >= Gr.p[pi + 1].start) ++pi;
+  const int pi = wgrad_problem_of(Gr);
   wgrad_tile_body(Gr, Gr.p[pi], red, sqs);
 }
 
@@ -453,8 +464,7 @@ __global__ __launch_bounds__(512, ONE ? 4 : 2) void wgrad_panel_group_kernel(Wgr
   __shared__ __attribute__((aligned(16))) float red[SMX_PANEL_SMEM_FLOATS];
   __shared__ float sqs[8];
   const WgradGroup& Gr = *(const WgradGroup*)__builtin_amdgcn_kernarg_segment_ptr();
-  int pi = 0;
-  while (pi + 1 < Gr.n && (int)blockIdx.x >= Gr.p[pi + 1].start) ++pi;
+  const int pi = wgrad_problem_of(Gr);
   const WgradProblem& P = Gr.p[pi];
   if (!P.panel) { wgrad_tile_body(Gr, P, red, sqs); return; }   // (block-uniform)
   PanelProblem pp;
@@ -476,8 +486,7 @@ __global__ __launch_bounds__(512, ONE ? 4 : 2) void wgrad_dgemm_kernel(WgradGrou
   __shared__ float sqs[8];
   if ((int)blockIdx.x >= n_w) { dgemm_body<1>(g, (int)blockIdx.x - n_w, red); return; }   // (block-uniform)
   const WgradGroup& Gr = *(const WgradGroup*)__builtin_amdgcn_kernarg_segment_ptr();
-  int pi = 0;
-  while (pi + 1 < Gr.n && (int)blockIdx.x >= Gr.p[pi + 1].start) ++pi;
+  const int pi = wgrad_problem_of(Gr);
   const WgradProblem& P = Gr.p[pi];
   if (!P.panel) { wgrad_tile_body(Gr, P, red, sqs); return; }
   PanelProblem pp;
@@ -502,12 +511,14 @@ int launch_wgrad_group(hipStream_t st, const GemmArgs* list, int n, int B, int b
   WgradGroup G;
   memset(&G, 0, sizeof(G));
   G.n = n; G.B = B; G.b3 = bf16x3;
+  for (int k = 0; k < SMX_GROUP_MAX; ++k) G.starts[k] = 0x7FFFFFFF;
   int total = 0;
   bool any_panel = false;
   for (int k = 0; k < n; ++k) {
     const GemmArgs& g = list[k];
     if (!wgrad_supported(g, B)) { set_error("wgrad group: unsupported problem"); return SMX_ERR_INVALID; }
     WgradProblem& P = G.p[k];
+    G.starts[k] = total;
     P.A = g.A; P.lda = g.lda; P.a_mode = g.use_xform ? (g.xf.u16 ? 2 : 1) : 0; P.log1p = g.use_xform ? g.xf.log1p : 0;
     P.rows = g.use_xform ? g.xf.rows : nullptr;
     P.Bm = g.B; P.ldb = g.ldb; P.C = g.C; P.ldc = g.ldc; P.M = g.M; P.N = g.N;

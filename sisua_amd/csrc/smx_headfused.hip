@@ -517,8 +517,12 @@ __global__ __launch_bounds__(512, 2) void head_fused_kernel(HeadFusedArgs a) {
 #undef HF2_SLOT
 }
 
+int head_fused_min_genes() {
+  static const int v = std::max(512, (int)tuning("head_fused_min_genes", SMX_HEAD_FUSED_MIN_GENES));
+  return v;
+}
 bool head_fused_supported(int B, int Hp, int Gp, int k) {
-  return B > 0 && B <= SMX_HEAD_FUSED_MAX_CELLS && Hp == 128 && Gp % 32 == 0 && Gp >= SMX_HEAD_FUSED_MIN_GENES && (k == 2 || k == 3) && !tuning_on("no_head_fused");
+  return B > 0 && B <= SMX_HEAD_FUSED_MAX_CELLS && Hp == 128 && Gp % 32 == 0 && Gp >= head_fused_min_genes() && (k == 2 || k == 3) && !tuning_on("no_head_fused");
 }
 // workgroups: one per CU at most, every one with the same number of units (+- 1); a unit = 16 genes
 static int hf_units(int Gp) { return Gp / 16; }

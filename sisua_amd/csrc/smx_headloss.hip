@@ -51,6 +51,8 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
   constexpr int QOFF = NW > 1 ? NW * 1024 : 0;
   __shared__ float red[(NW > 1 ? NW * 1024 : 1) + (QUEUE ? 2 * 1024 : 0)];
   float2* const lq = reinterpret_cast<float2*>(red + QOFF);
+  preload(a.H, a.ldh, a.W, a.ldw, a.bias, a.X, a.ldx, a.rows, a.dP, a.ldp, a.plane_stride, a.llk_part, a.B, a.G, a.Gp, a.Hp,
+          a.grad_scale, a.n_ct, a.n_gt, a.x_u16, a.row_mod, a.product_only, a.llk_only, a.likelihood);   // (the argument fields in one batch: smx_device.h)
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   // blocks b, b + 8, b + 16, ... share an XCD: give them the cell tiles of ONE gene tile

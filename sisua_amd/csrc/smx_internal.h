@@ -559,6 +559,7 @@ int launch_bigk_reduce(hipStream_t st, const float* part, long slab_stride, int 
 #define SMX_HEAD_FUSED_TAB_BYTES (8 * 12 * 64 * 16)
 #define SMX_DP_BUCKETS_MIN_BYTES 3000000   // data parallel: two buckets from this many bytes of head gradients
 #define SMX_HEAD_FUSED_MIN_GENES 4096
+int head_fused_min_genes();   // (knob head_fused_min_genes; smx_headfused.hip)
 #define SMX_HEAD_FUSED_MAX_CELLS 256   // (one launch per 128 cells)
 // the heads' background optimiser sweep (smx_step.hip: head_sweep_start): from this many 4096-float chunks of head parameters, one persistent
 // workgroup per so many chunks.  Measured at 128 x 20 000 (1880 chunks; c5-shard, us per step; 182.3 without), by workgroups: 48 -> 245,
@@ -601,7 +602,7 @@ struct WgradProblem {
   int start, n_mt, n_nt;
   int panel;   // > 0: a wide M (a gene panel) with N <= 128 in the panel form (smx_panel.h, role 0): this many workgroups walk its 32-row tiles
 };
-struct WgradGroup { int n; int B; int b3; WgradProblem p[SMX_GROUP_MAX]; };   // b3: bf16 x 3 MFMAs (smx_device.h)
+struct WgradGroup { int n; int B; int b3; int pad; int starts[SMX_GROUP_MAX]; WgradProblem p[SMX_GROUP_MAX]; };   // starts[k] = p[k].start (INT_MAX beyond n): ONE scalar load finds a workgroup's problem;   // b3: bf16 x 3 MFMAs (smx_device.h)
 bool wgrad_supported(const GemmArgs& g, int B);
 
 // ---- minibatch-contracted weight gradients of a wide panel: one workgroup per 32 entries of the wide axis (smx_panel.h) ----

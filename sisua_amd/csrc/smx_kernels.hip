@@ -910,6 +910,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_wide_fwd_kernel(BnFwdArgs a) {
   if (bid >= a.Hp) { noise_fill(a, bid - a.Hp); return; }
   __shared__ __attribute__((aligned(16))) float sh[16 * 128];
   __shared__ float vs[128], st[2];
+  preload(a.pre, a.n_slabs, a.slab_stride, a.B, a.H, a.Hp, a.gamma, a.beta, a.bias, a.inj_mask, a.inj_ld, a.xhat, a.out, a.batchnorm, a.training, a.drop_p,
+          a.batch_mean, a.batch_var, a.moving_mean, a.moving_var, a.inv_std, a.update_moving, a.rows, a.leak);   // (one batch: smx_device.h)
   const int col = bid, r = (int)threadIdx.x;
   const bool live = col < a.H, rowt = r < 128, on = rowt && r < a.B;
   const float bias = (!a.batchnorm && a.bias && live) ? a.bias[col] : 0.f;
@@ -999,6 +1001,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_wide_bwd_kernel(BnBwdArgs a) {
   }
   __shared__ __attribute__((aligned(16))) float sh[16 * 128];
   __shared__ float vs[128], xs[128], st[2];
+  preload(a.dout, a.n_slabs, a.slab_stride, a.out, a.xhat, a.inv_std, a.gamma, a.B, a.H, a.Hp, a.batchnorm, a.training, a.drop_scale, a.dpre, a.dgamma, a.dbeta);
   const int col = bid, r = (int)threadIdx.x;
   const bool live = col < a.H, rowt = r < 128, on = rowt && r < a.B;
   // what the activation mask and the BatchNorm formula need of the forward pass, requested ahead of the slabs

@@ -352,7 +352,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   const size_t lat_ld = (size_t)m->lat_planes * (size_t)m->Dp;
   const size_t ldp = (size_t)m->k * m->Gp;
   // wide panels: scratch for the per-slice slabs of the products that contract over the gene axis (smx_bigk.hip)
-  if (m->Gp >= 4096) {
+  if (m->Gp >= std::min(4096, head_fused_min_genes())) {
     m->bigk_floats = (size_t)SMX_BIGK_MAX_SLICES * B * m->max_feat_p;
     if ((rc = dmalloc(&m->bigk_part, m->bigk_floats))) return fail(rc);
     float* tab = nullptr;
