@@ -495,3 +495,23 @@ def test_bench_line_at_two_ranks_carries_every_scaling_mode(tmp_path):
     p = v["predicted_n8"]
     assert p["ms_per_step"][0] < p["ms_per_step"][1] and p["x_one_gpu"][0] < p["x_one_gpu"][1] and p["reading"]
   assert sm["c5"]["cells_resident_per_gpu"] == 2048 and sm["c5"]["allreduce_bytes"] > 9 * sm["weak"]["allreduce_bytes"]
+
+
+def test_bench_line_survives_scaling_modes_that_do_not_finish(tmp_path):
+  """The scaling modes run LAST behind a watchdog on rank 0 (bench.py): with a budget they cannot meet (SMX_BENCH_MODES_BUDGET_S) the
+  contract's line -- value, ms_per_step, roofline, dp -- is still printed, once, with the modes marked as unfinished."""
+  import json
+  import socket
+  s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+  env = dict(os.environ, SMX_SHARE_GPU="1", SMX_ALLREDUCE="p2p-only", PYTHONPATH=ROOT, SMX_BENCH_MODES_BUDGET_S="0.05")
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--c5-cells", "4096"]
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+  lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+  assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+  out = json.loads(lines[0])
+  assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["frac"] > 0 and out["dp"]["collective"] == "p2p-only"
+  assert "error" in out["scaling_modes"]
+
