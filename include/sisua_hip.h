@@ -332,6 +332,14 @@ int smx_comm_rank(const smx_model* m);
  * applied on a communication stream beside the rest of the step, the front bucket all-reduced on the model's stream (taken from 3 MB of
  * head gradients; SMX_DP_BUCKETS=1|2 overrides), 3 the hand-written exchange's two-bucket form (both buckets on the communication stream). */
 int smx_comm_form(const smx_model* m);
+/* Flag "opt_shard" (smx_set_flag; off by default; data parallel, the chained form -- it is taken whenever the flag is set): the output and
+ * label heads' optimiser state is SHARDED over the ranks -- reduce-scatter of their gradient bucket, per-tensor clipnorm + Adam on this rank's
+ * 1 / world slice, all-gather of the updated parameters (the same wire bytes as the all-reduce; 1 / world of the optimiser's memory traffic).
+ * Parameters stay replicated and bit-identical on every rank; the Adam MOMENTS of the heads outside a rank's slice go stale.  smx_opt_gather
+ * (a collective: every rank calls it, between training calls) all-gathers both moments, after which smx_get_tensor(which = 2 | 3) of a head
+ * tensor -- refused while stale -- returns the job's moments on every rank (checkpoints).  RCCL or the loopback communicator; with the
+ * hand-written exchange the flag is ignored (the all-reduce form runs). */
+int smx_opt_gather(smx_model* m);
 /* The same all-reduce as a hand-written two-shot exchange over peer-mapped buffers instead of RCCL (reduce-scatter
  * + all-gather of the flat buffer through HIP-IPC-mapped peer memory over xGMI; sums in rank order -- bitwise the same on every
  * rank): smx_comm_p2p_export allocates this rank's communication region and returns its two 64-byte IPC handles (the flat

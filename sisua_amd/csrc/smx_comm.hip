@@ -45,6 +45,8 @@ int load_rccl() {
   g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
   g_rccl.CommSplit = (decltype(g_rccl.CommSplit))dlsym(h, "ncclCommSplit");
+  g_rccl.ReduceScatter = (decltype(g_rccl.ReduceScatter))dlsym(h, "ncclReduceScatter");
+  g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
   g_rccl.GetVersion = (decltype(g_rccl.GetVersion))dlsym(h, "ncclGetVersion");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
@@ -100,7 +102,7 @@ bool dp_overlap(const smx_model* m) {
 // the chained form: RCCL (the heads' bucket on its own communicator when ncclCommSplit gave one) or the tests' loopback communicator; the
 // hand-written exchange keeps round 4's form (one staging buffer, one flag set: its two buckets cannot be in flight together)
 bool dp_chain_ok(const smx_model* m) {
-  if (!dp_active(m) || !m->dp_two_buckets || m->capturing || !m->st_comm || (m->p2p && m->p2p->error)) return false;
+  if (!dp_active(m) || !(m->dp_two_buckets || m->flags.opt_shard) || m->capturing || !m->st_comm || (m->p2p && m->p2p->error)) return false;
   return m->bucket1_count > 0 && m->chunk_first_head < m->n_chunks;
 }
 int local_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
@@ -108,7 +110,8 @@ int local_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
   const int me = m->rank;
   // (a bucket of the flat gradients takes the same stretch of the scratch: the heads' bucket on the communication stream and a collective
   // of the main stream may be under way together)
-  const size_t soff = (buf >= m->grads && buf < m->grads + m->grads_count) ? (size_t)(buf - m->grads) : 0;
+  size_t soff = (buf >= m->grads && buf < m->grads + m->grads_count) ? (size_t)(buf - m->grads) : 0;
+  if (buf >= m->shard_partial && buf < m->shard_partial + m->n_chunks) soff = m->grads_count + (size_t)(buf - m->shard_partial);   // (flag opt_shard: the chunks' partial sums, on the communication stream)
   SMX_REQUIRE(soff + count <= m->local_scratch_cap, "loopback all-reduce: scratch too small");
   float* const scratch = m->local_scratch + soff;
   { std::lock_guard<std::mutex> lk(g.mu); g.src[me] = buf; }
@@ -140,6 +143,50 @@ int dp_allreduce_buf(smx_model* m, float* buf, size_t count, hipStream_t st, boo
   return SMX_OK;
 }
 int dp_allreduce(smx_model* m, size_t off, size_t count, hipStream_t st, bool second) { return dp_allreduce_buf(m, m->grads + off, count, st, second); }
+
+// ---- flag opt_shard: the head bucket as world slices of `slice` floats each (in place: rank r's slice is buf + r * slice) -------------------
+// loopback: every rank sums ITS slice over the ranks' buffers in rank order (the all-reduce's order: the same sums) into its own buffer --
+// the other ranks read only their own slices of it --, and gathers by copying the owners' slices
+static int local_slices(smx_model* m, float* buf, size_t slice, hipStream_t st, bool gather) {
+  LocalGroup& g = *m->local;
+  const int me = m->rank;
+  { std::lock_guard<std::mutex> lk(g.mu); g.src[me] = buf; }
+  SMX_HIP(hipEventRecord(g.ready[me], st));
+  if (!g.barrier()) { set_error("loopback communicator: a member did not arrive (timeout)"); return SMX_ERR_COMM; }
+  for (int r = 0; r < g.world; ++r)
+    if (r != me) SMX_HIP(hipStreamWaitEvent(st, g.ready[r], 0));
+  if (gather) {
+    for (int r = 0; r < g.world; ++r)
+      if (r != me) SMX_HIP(hipMemcpyAsync(buf + (size_t)r * slice, g.src[r] + (size_t)r * slice, slice * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else {
+    LocalSrc src;
+    src.n = g.world;
+    for (int r = 0; r < g.world; ++r) src.p[r] = g.src[r] + (size_t)me * slice;
+    const unsigned blocks = (unsigned)std::min<size_t>((slice + 255) / 256, 2048);
+    hipLaunchKernelGGL(local_sum_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, buf + (size_t)me * slice, slice);   // (in place: element i of this rank's slice is read and written by one thread)
+  }
+  SMX_HIP(hipEventRecord(g.done[me], st));
+  if (!g.barrier()) { set_error("loopback communicator: a member did not arrive (timeout)"); return SMX_ERR_COMM; }
+  for (int r = 0; r < g.world; ++r)
+    if (r != me) SMX_HIP(hipStreamWaitEvent(st, g.done[r], 0));   // nobody still reads this rank's buffer
+  return SMX_OK;
+}
+bool dp_shard_available(const smx_model* m) {
+  if (m->local) return true;
+  return m->comm && g_rccl.ReduceScatter && g_rccl.AllGather && !(m->p2p && m->p2p->error);
+}
+int dp_reduce_scatter(smx_model* m, float* buf, size_t slice, hipStream_t st, bool second) {
+  if (m->local) return local_slices(m, buf, slice, st, false);
+  ncclResult_t r = g_rccl.ReduceScatter(buf, buf + (size_t)m->rank * slice, slice, ncclFloat32, ncclSum, (second && m->comm2) ? m->comm2 : m->comm, st);
+  if (r != ncclSuccess) { set_error(std::string("ncclReduceScatter failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); return SMX_ERR_COMM; }
+  return SMX_OK;
+}
+int dp_all_gather(smx_model* m, float* buf, size_t slice, hipStream_t st, bool second) {
+  if (m->local) return local_slices(m, buf, slice, st, true);
+  ncclResult_t r = g_rccl.AllGather(buf + (size_t)m->rank * slice, buf, slice, ncclFloat32, (second && m->comm2) ? m->comm2 : m->comm, st);
+  if (r != ncclSuccess) { set_error(std::string("ncclAllGather failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); return SMX_ERR_COMM; }
+  return SMX_OK;
+}
 
 }  // namespace smx
 
@@ -250,7 +297,7 @@ int smx_comm_init_local(smx_model* const* models, int n) {
     m->rank = r; m->world = n; m->local = g;
     int wmax = 0;
     for (int w : m->bn_wp) wmax = std::max(wmax, w);
-    const size_t need = std::max(m->grads_count, (size_t)n * 2 * (size_t)wmax);
+    const size_t need = std::max(m->grads_count + (size_t)m->n_chunks, (size_t)n * 2 * (size_t)wmax);
     if (need > m->local_scratch_cap) {
       if (m->local_scratch) hipFree(m->local_scratch);
       m->local_scratch = nullptr; m->local_scratch_cap = 0;
@@ -303,6 +350,19 @@ int smx_comm_time_allreduce(smx_model* m, int iters, float* us_per_call, int64_t
 }
 
 int smx_comm_rank(const smx_model* m) { return m ? m->rank : 0; }
+int smx_opt_gather(smx_model* m) {
+  SMX_REQUIRE(m, "null model");
+  SMX_HIP(hipStreamSynchronize(m->st));
+  if (m->st_comm) SMX_HIP(hipStreamSynchronize(m->st_comm));
+  if (!m->opt_stale) return SMX_OK;
+  SMX_REQUIRE(smx::dp_active(m) && smx::dp_shard_available(m), "opt_gather: the communicator the sharded steps ran on is gone");
+  const size_t slice = (((size_t)m->bucket1_count + m->world - 1) / m->world + 63) / 64 * 64;
+  SMX_CHECK(smx::dp_all_gather(m, m->adam_m + m->bucket1_off, slice, m->st));
+  SMX_CHECK(smx::dp_all_gather(m, m->adam_v + m->bucket1_off, slice, m->st));
+  SMX_HIP(hipStreamSynchronize(m->st));
+  m->opt_stale = false;
+  return SMX_OK;
+}
 int smx_comm_form(const smx_model* m) {
   if (!m || !smx::dp_active(m)) return 0;
   return smx::dp_chain_ok(m) ? 2 : smx::dp_overlap(m) ? 3 : 1;

@@ -257,6 +257,8 @@ struct AdamArgs {
   // (sq_count > 0) or, for small tensors, a sweep of the tensor's gradient by every workgroup that needs it
   int use_sq = 0; const float* sq_slots = nullptr; int sq_first[SMX_MAX_TENSORS]; int sq_count[SMX_MAX_TENSORS];
   float* tensor_norm = nullptr; // [n_tensors] written by the update kernel (pre-clip norms)
+  // flag opt_shard: this rank's slice [shard_lo, shard_hi) of the flat buffer (floats, multiples of 64); the sharded kernels touch nothing outside it
+  long shard_lo = 0, shard_hi = 0;
   const StepState* state = nullptr;
   float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, clipnorm = 100.f;
   float grad_scale = 1.f;       // extra factor on the gradient (1: the loss is already scaled by 1 / global batch)
@@ -553,10 +555,14 @@ int bigk_slices(long K, int max_slices, int* k_chunk);
 bool bigk_supported(const BigKArgs& a);
 int launch_bigk(hipStream_t st, const BigKArgs& a);
 
+int launch_grad_sqsum_shard(hipStream_t st, const AdamArgs& a, int first, int count);   // partial[chunk] = sum of squares of the chunk's part inside the slice
+int launch_head_norms(hipStream_t st, const AdamArgs& a, int first, int count);        // tensor_norm of every tensor of the chunk range from partial[]
+int launch_adam_shard(hipStream_t st, const AdamArgs& a, int first, int count, int wgs);   // clip + Adam of the chunk range's elements inside the slice
 int launch_bigk_reduce(hipStream_t st, const float* part, long slab_stride, int n_slices, long n4, float* out);
 
 // ---- the whole output head of a training step at a wide panel in one launch (smx_headfused.hip) ----
 #define SMX_HEAD_FUSED_TAB_BYTES (8 * 12 * 64 * 16)
+#define SMX_SHARD_SLACK 4096          // floats behind the flat buffers: world x round_up(bucket / world, 64) <= bucket + 64 world (world <= 64)
 #define SMX_DP_BUCKETS_MIN_BYTES 3000000   // data parallel: two buckets from this many bytes of head gradients
 #define SMX_HEAD_FUSED_MIN_GENES 4096
 int head_fused_min_genes();   // (knob head_fused_min_genes; smx_headfused.hip)

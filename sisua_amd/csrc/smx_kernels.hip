@@ -2485,6 +2485,90 @@ int launch_adam_sweep(hipStream_t st, const AdamArgs& a, int first, int count, i
   return SMX_OK;
 }
 
+// ---- flag opt_shard (data parallel, chained form): the heads' optimiser state sharded over the ranks --------------------------------------
+// This rank owns the floats [shard_lo, shard_hi) of the head bucket -- a slice cut at a 64-float boundary, through chunks where it falls.
+// (1) per chunk, the sum of squares of the chunk's part inside the slice (0 for a chunk outside it): summed over the ranks these are the
+//     chunks' sums of squares of the whole reduced gradient;  (2) the tensors' norms from them, on every rank, for the metrics;
+// (3) clip + Adam of the elements inside the slice, the tensor's norm from the summed partials (adam_tensor_clip's use_sq = 0 path).
+__device__ inline void shard_range(const AdamArgs& a, const OptChunk& ch, int& i_lo, int& i_hi) {
+  const long n4 = ch.count / 4;
+  const long lo = (a.shard_lo - (long)ch.offset) / 4, hi = (a.shard_hi - (long)ch.offset + 3) / 4;   // (offsets and bounds are multiples of 4)
+  i_lo = (int)(lo < 0 ? 0 : (lo > n4 ? n4 : lo));
+  i_hi = (int)(hi < 0 ? 0 : (hi > n4 ? n4 : hi));
+}
+__global__ __launch_bounds__(256) void grad_sqsum_shard_kernel(AdamArgs a, int first) {
+  __shared__ float sh[4];
+  const int chunk = first + (int)blockIdx.x;
+  const OptChunk ch = a.chunks[chunk];
+  int i_lo, i_hi;
+  shard_range(a, ch, i_lo, i_hi);
+  float s = 0.f;
+  const float4* g4 = reinterpret_cast<const float4*>(a.grads + ch.offset);
+  for (int i = i_lo + (int)threadIdx.x; i < i_hi; i += 256) {
+    const float4 g = g4[i];
+    s += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) a.partial[chunk] = s;
+}
+// one workgroup per tensor of the chunk range [first, first + count): the b-th tensor is found by walking the chunk table
+__global__ __launch_bounds__(256) void head_norms_kernel(AdamArgs a, int first, int count) {
+  __shared__ float sh[4];
+  int c = first;
+  for (int b = 0; b < (int)blockIdx.x && c < first + count; ++b) c += a.chunks[c].n_chunks;
+  if (c >= first + count) return;
+  const OptChunk ch = a.chunks[c];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < ch.n_chunks; k += 256) s += a.partial[ch.first_chunk + k];
+  s = block_sum(s, sh);
+  if (ch.tensor == a.tied_t0 || ch.tensor == a.tied_t1) s *= a.tied_inv;
+  if (threadIdx.x == 0) a.tensor_norm[ch.tensor] = sqrtf(s) * a.grad_scale;
+}
+__global__ __launch_bounds__(256) void adam_shard_kernel(AdamArgs a, int first, int count) {
+  int cur_t = -1;
+  float clip = 0.f;
+  const float lr_t = a.state->lr_t;
+  for (int c = (int)blockIdx.x; c < count; c += (int)gridDim.x) {
+    const int chunk = first + c;
+    const OptChunk ch = a.chunks[chunk];
+    int i_lo, i_hi;
+    shard_range(a, ch, i_lo, i_hi);
+    if (i_lo >= i_hi) continue;   // (block-uniform) a chunk of another rank's slice
+    if (ch.tensor != cur_t) {     // the factor of this chunk's tensor, from the summed partials (the launcher insists on use_sq = 0; every thread takes part: two barriers)
+      clip = adam_tensor_clip<256>(a, ch, -1);   // (chunk -1: tensor_norm is head_norms_kernel's to write)
+      cur_t = ch.tensor;
+    }
+    const smx_f32x4* g4 = reinterpret_cast<const smx_f32x4*>(a.grads + ch.offset);
+    smx_f32x4* m4 = reinterpret_cast<smx_f32x4*>(a.m + ch.offset);
+    smx_f32x4* v4 = reinterpret_cast<smx_f32x4*>(a.v + ch.offset);
+    smx_f32x4* p4 = reinterpret_cast<smx_f32x4*>(a.params + ch.offset);
+    for (int i = i_lo + (int)threadIdx.x; i < i_hi; i += 256) {
+      smx_f32x4 m = m4[i], v = v4[i], p = p4[i];
+      adam_apply4(a, clip, lr_t, g4[i], m, v, p);
+      m4[i] = m; v4[i] = v; p4[i] = p;
+    }
+  }
+}
+int launch_grad_sqsum_shard(hipStream_t st, const AdamArgs& a, int first, int count) {
+  if (count <= 0) return SMX_OK;
+  hipLaunchKernelGGL(grad_sqsum_shard_kernel, dim3((unsigned)count), dim3(256), 0, st, a, first);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+int launch_head_norms(hipStream_t st, const AdamArgs& a, int first, int count) {
+  if (count <= 0) return SMX_OK;
+  hipLaunchKernelGGL(head_norms_kernel, dim3((unsigned)std::min(count, SMX_MAX_TENSORS)), dim3(256), 0, st, a, first, count);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+int launch_adam_shard(hipStream_t st, const AdamArgs& a, int first, int count, int wgs) {
+  if (count <= 0) return SMX_OK;
+  if (wgs <= 0 || a.use_sq || a.shard_hi <= a.shard_lo || (a.shard_lo % 4) || (a.shard_hi % 4)) { set_error("adam shard: bad arguments"); return SMX_ERR_INVALID; }
+  hipLaunchKernelGGL(adam_shard_kernel, dim3((unsigned)std::min(wgs, count)), dim3(256), 0, st, a, first, count);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
 // Two launches.  A single-launch form (per-tensor arrival counters, the chunk's gradient kept in registers
 // while the workgroup waits for its tensor's other chunks) was measured at 39 us against 16 us for this pair:
 // an agent-scope acquire/release round across the 8 XCDs costs far more than a kernel boundary (1.5 us).

@@ -78,6 +78,8 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;   // (optional: flag opt_shard)
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;   // (optional: a second communicator for the heads' bucket)
   ncclResult_t (*GetVersion)(int*) = nullptr;
@@ -158,6 +160,9 @@ struct smx_model {
     // training products of the output head (fused head, its backward, the encoder's weight gradient) from bf16 MFMAs on
     // three-way split operands: 1 always, 0 never (the exact-f32 MFMA forms), -1 from the width (SMX_BF16X3_MIN_WORK)
     int bf16x3 = -1;
+    // data parallel, chained two-bucket form: the heads' optimiser state SHARDED over the ranks (smx_step.hip: dp_chain_start) -- reduce-scatter of
+    // the head bucket, clip + Adam on this rank's 1 / world slice, all-gather of the updated parameters.  Off by default (the north star: one all-reduce).
+    int opt_shard = 0;
   int tie_mixtures = 0, tie_loc = 0, tie_scale = 0;   // SCALE (scale.py:29-33): the prior's mixture weights fixed / one location / one scale for every component
   } flags;
   int chunk_first_head = 0;           // first optimiser chunk of the output / label heads (they are last in the table)
@@ -251,6 +256,8 @@ struct smx_model {
   bool out_has_W[3] = {true, true, true};   // scvi: plane c of the gene output is a Dense head (false: a shared per-gene vector, cfg.scvi_dispersion / scvi_inflation)
   float* slab = nullptr; size_t slab_cap = 0; int max_feat_p = 0;
   void* hf_tab = nullptr;             // scratch of the fused output head (smx_headfused.hip: the split views of the decoder output)
+  float* shard_partial = nullptr;   // [n_chunks] per-chunk sums of squares of this rank's slice (flag opt_shard), summed over the ranks
+  bool opt_stale = false;            // the heads' Adam moments outside this rank's slice are stale (flag opt_shard): smx_opt_gather brings them in
   long wide_dd_stride = 0;
   const float* wide_dd_src = nullptr;   // where those slabs are (bigk_part or the slab buffer)
   int wide_dd_slabs = 0;   // > 0: this step's d d waits as that many column-major slabs in bigk_part for the decoder's BatchNorm-backward launch (bn_wide_bwd_kernel)
@@ -341,6 +348,9 @@ void unpack(const TensorInfo& t, const std::vector<float>& dev, float* host, flo
 void drop_graphs(smx_model* m);
 // smx_comm.hip
 bool dp_active(const smx_model* m);
+bool dp_shard_available(const smx_model* m);   // flag opt_shard can be honoured: the loopback communicator, or RCCL with ncclReduceScatter / ncclAllGather
+int dp_reduce_scatter(smx_model* m, float* buf, size_t slice, hipStream_t st, bool second = false);   // in place: rank r's sum lands in buf + r * slice
+int dp_all_gather(smx_model* m, float* buf, size_t slice, hipStream_t st, bool second = false);       // in place: rank r contributes buf + r * slice
 bool dp_overlap(const smx_model* m);
 int dp_allreduce_buf(smx_model* m, float* buf, size_t count, hipStream_t st, bool second = false);   // second: the heads' bucket (its own communicator / scratch)
 int dp_allreduce(smx_model* m, size_t off, size_t count, hipStream_t st, bool second = false);

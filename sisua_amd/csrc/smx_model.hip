@@ -306,10 +306,11 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     m->flat_count = cur;
     m->grads_count = cur;
   }
-  if ((rc = dmalloc(&m->params, m->flat_count))) return fail(rc);
-  if ((rc = dmalloc(&m->grads, m->grads_count))) return fail(rc);
-  if ((rc = dmalloc(&m->adam_m, m->flat_count))) return fail(rc);
-  if ((rc = dmalloc(&m->adam_v, m->flat_count))) return fail(rc);
+  // (SMX_SHARD_SLACK floats behind the head bucket: flag opt_shard cuts the bucket into world slices of equal, 64-float-aligned length)
+  if ((rc = dmalloc(&m->params, m->flat_count + SMX_SHARD_SLACK))) return fail(rc);
+  if ((rc = dmalloc(&m->grads, m->grads_count + SMX_SHARD_SLACK))) return fail(rc);
+  if ((rc = dmalloc(&m->adam_m, m->flat_count + SMX_SHARD_SLACK))) return fail(rc);
+  if ((rc = dmalloc(&m->adam_v, m->flat_count + SMX_SHARD_SLACK))) return fail(rc);
   if ((rc = dmalloc(&m->bn_moving, m->bn_total))) return fail(rc);
   {  // moving variance starts at 1 (Keras)
     std::vector<float> init(m->bn_total, 0.f);
@@ -422,7 +423,7 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     m->sq_reduced.assign(m->tensors.size(), 0);
     if ((rc = dmalloc(&m->sq_slots, total + m->tensors.size() * SMX_SQR_PER_TENSOR))) return fail(rc);
   }
-  if ((rc = dmalloc(&m->chunks, chunks.size())) || (rc = dmalloc(&m->partial, chunks.size())) ||
+  if ((rc = dmalloc(&m->chunks, chunks.size())) || (rc = dmalloc(&m->partial, chunks.size())) || (rc = dmalloc(&m->shard_partial, chunks.size())) ||
       (rc = dmalloc(&m->tensor_norm, m->tensors.size())))
     return fail(rc);
   if (hipMemcpy(m->chunks, chunks.data(), chunks.size() * sizeof(OptChunk), hipMemcpyHostToDevice) != hipSuccess) {
@@ -460,7 +461,7 @@ int smx_model_destroy(smx_model* m) {
   fr(m->noise_eps); fr(m->latbuf); fr(m->dlat); fr(m->z); fr(m->sig); fr(m->eps); fr(m->kl);
   fr(m->latlbuf); fr(m->dlatl); fr(m->lsmp); fr(m->lsig); fr(m->leps); fr(m->kl_l); fr(m->dl);
   fr(m->P); fr(m->dP); fr(m->raw); fr(m->draw); fr(m->rho); fr(m->llk_part); fr(m->llk_y); fr(m->llk_o); fr(m->slab);
-  fr(m->chunks); fr(m->partial); fr(m->tensor_norm); fr(m->sq_slots);
+  fr(m->chunks); fr(m->partial); fr(m->shard_partial); fr(m->tensor_norm); fr(m->sq_slots);
   if (m->pinned) hipHostFree(m->pinned);
   if (m->order_pin) hipHostFree(m->order_pin);
   if (m->metrics_pin) hipHostFree(m->metrics_pin);
@@ -505,6 +506,8 @@ int smx_get_tensor(smx_model* m, int which, int index, float* host) {
   float* base = which_buf(m, which);
   SMX_REQUIRE(base, "which must be 0..3");
   const TensorInfo& t = m->tensors[index];
+  SMX_REQUIRE(!(m->opt_stale && (which == 2 || which == 3) && t.offset >= m->bucket1_off),
+              "the heads' Adam moments are sharded over the ranks (flag opt_shard): call smx_opt_gather on every rank first");
   std::vector<float> dev(t.count);
   SMX_HIP(hipStreamSynchronize(m->st));
   SMX_HIP(hipMemcpy(dev.data(), base + t.offset, t.count * sizeof(float), hipMemcpyDeviceToHost));
@@ -592,9 +595,9 @@ int smx_set_flag(smx_model* m, const char* name, int value) {
   int* f = n == "head_loss" ? &m->flags.head_loss : n == "head_fused" ? &m->flags.head_fused : n == "head_sweep" ? &m->flags.head_sweep : n == "front" ? &m->flags.front : n == "bwd_front" ? &m->flags.bwd_front
          : n == "head_bwd" ? &m->flags.head_bwd : n == "wgrad" ? &m->flags.wgrad : n == "scvi_fused" ? &m->flags.scvi_fused
          : n == "twin" ? &m->flags.twin : n == "label_ride" ? &m->flags.label_ride : n == "act_epilogue" ? &m->flags.act_epilogue
-         : n == "stacked_scoring" ? &m->flags.stacked_scoring : n == "bf16x3" ? &m->flags.bf16x3
+         : n == "stacked_scoring" ? &m->flags.stacked_scoring : n == "bf16x3" ? &m->flags.bf16x3 : n == "opt_shard" ? &m->flags.opt_shard
          : n == "tie_mixtures" ? &m->flags.tie_mixtures : n == "tie_loc" ? &m->flags.tie_loc : n == "tie_scale" ? &m->flags.tie_scale : nullptr;
-  SMX_REQUIRE(f, "unknown flag (head_loss, head_fused, head_sweep, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue, stacked_scoring, bf16x3; SCALE: tie_mixtures, tie_loc, tie_scale)");
+  SMX_REQUIRE(f, "unknown flag (head_loss, head_fused, head_sweep, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride, act_epilogue, stacked_scoring, bf16x3, opt_shard; SCALE: tie_mixtures, tie_loc, tie_scale)");
   *f = (f == &m->flags.bf16x3 && value < 0) ? -1 : (value ? 1 : 0);   // bf16x3: -1 = by the width of the head (the default)
   drop_graphs(m);   // a captured step bakes the launch sequence in
   return SMX_OK;

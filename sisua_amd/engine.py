@@ -521,6 +521,11 @@ class Engine:
     normed and applied on the communication stream), 3 the hand-written exchange's two-bucket form (include/sisua_hip.h: smx_comm_form)."""
     return self.lib.smx_comm_form(self._h)
 
+  def opt_gather(self):
+    """Flag opt_shard: all-gather the heads' Adam moments (a collective: every rank calls it, between training calls); afterwards
+    get_params(2 | 3) returns the job's moments on every rank (include/sisua_hip.h: smx_opt_gather)."""
+    check(self.lib.smx_opt_gather(self._h))
+
   def set_sync_bn(self, on: bool = True):
     """SyncBatchNorm under data parallelism (global-batch statistics; one small extra all-reduce per BatchNorm pass)."""
     check(self.lib.smx_comm_set_sync_bn(self._h, int(bool(on))))

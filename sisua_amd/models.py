@@ -456,7 +456,7 @@ class SingleCellModel:
           improved = vl < best * (1.0 - float(earlystop_threshold)) if np.isfinite(best) else True
           if vl < best:
             best = vl
-            self._checkpoint(checkpoint, rank, cp)
+            self._checkpoint(checkpoint, rank, cp, e)
           bad = 0 if improved else bad + 1
           if earlystop_patience and bad >= int(earlystop_patience) and epoch >= int(earlystop_min_epoch):
             stop = True
@@ -470,13 +470,15 @@ class SingleCellModel:
     if valid is not None and not hist_v.get("val_loss"):
       hist_v.setdefault("val_loss", []).append(self._validate(e, valid, n_tr, cp))
     if valid is None:
-      self._checkpoint(checkpoint, rank, cp)
+      self._checkpoint(checkpoint, rank, cp, e)
     if cp is not None:
       cp.barrier()
     return self
 
   @staticmethod
-  def _checkpoint(checkpoint, rank, cp):
+  def _checkpoint(checkpoint, rank, cp, engine=None):
+    if checkpoint is not None and engine is not None and cp is not None and cp.world > 1:
+      engine.opt_gather()   # (flag opt_shard: the heads' Adam moments live sliced over the ranks between checkpoints; a collective, every rank is here)
     if checkpoint is not None and rank == 0:   # replicas are identical: one writer
       checkpoint()
     if cp is not None:

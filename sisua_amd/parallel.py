@@ -362,4 +362,6 @@ def attach_engine(engine, cp):
   if mode != "rccl":
     handles = cp.allgather_bytes(engine.comm_p2p_export(cp.world))
     engine.comm_p2p_init(cp.rank, cp.world, b"".join(handles))
+  if os.environ.get("SMX_OPT_SHARD", "0") not in ("", "0"):   # opt-in: the heads' optimiser state sharded over the ranks (RCCL only; smx_opt_gather)
+    engine.set_flag("opt_shard", True)
   return mode   # the collective the steps take: 'rccl', or the exchange ('p2p' beside an RCCL communicator, 'p2p-only' without one)

@@ -209,6 +209,69 @@ def test_two_bucket_chain_matches_oracle(Engine, monkeypatch, name, world, sync_
   assert np.allclose(hist["2"], hist["1"], rtol=2e-6)
 
 
+@pytest.mark.parametrize("name,world,sync_bn", [("vae_zinb", 2, False), ("vae_zinb", 3, True), ("sisua", 2, False), ("sisua_extra_output", 3, False),
+                                                ("vae_zinb", 8, False), ("scale", 2, False)])
+def test_sharded_optimiser_state_matches_oracle(Engine, name, world, sync_bn):
+  """Flag opt_shard (smx_step.hip: dp_chain_start): the heads' bucket is reduce-SCATTERED, every rank clips and applies
+  Adam to its 1 / world slice only (slices cut at 64-float boundaries, through optimiser chunks and tensors where they fall; the per-tensor
+  norm from the ranks' partial sums of squares), and the updated parameters are all-gathered.  Four steps through one multi-step call + a
+  single-step call: losses of every step, the largest gradient norm, the parameters and -- after smx_opt_gather -- both Adam moments equal
+  the oracle's data-parallel contract; every rank ends bit-identical, moments included; reading a head's moments before the gather is
+  refused; the unsharded chain of the same run gives the same losses to rounding."""
+  from sisua_amd._hip import SmxError
+  spec, cfg, x, ys, lib, mask = _problem(CASES[name])
+  B, steps, base = 24 if world == 8 else 48, 4, 1000
+  rng = np.random.default_rng(5)
+  rows = [rng.permutation(x.shape[0])[: B * world].astype(np.int32).reshape(world, B) for _ in range(steps + 1)]
+  hist = {}
+  for shard in (True, False):
+    params = perturbed_params(spec)
+    bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+    engines = []
+    for r in range(world):
+      e = Engine(cfg, max_batch=64, init=False)
+      e.set_params(params)
+      e.upload(x, ys, lib, mask, cell_id_base=base)
+      engines.append(e)
+    Engine.comm_init_local(engines)
+    for e in engines:
+      e.set_sync_bn(sync_bn)
+      e.set_flag("opt_shard", shard)
+      if shard:
+        assert e.comm_form == 2   # (the flag takes the chained form whatever the bucket's size)
+    refs = [so.dp_train_step(spec, params, bn, opt, x, list(rows[s]), s, cell_base=base, y=ys, library=lib, mask=mask, sync_bn=sync_bn) for s in range(steps)]
+    orders = [np.concatenate([rows[s][r] for s in range(steps)]) for r in range(world)]
+    ms = run_ranks([lambda r=r: engines[r].train_steps(orders[r], steps, B, graph=False, metrics=True) for r in range(world)])
+    hs = [e.metrics_history(steps) for e in engines]
+    for r in range(world):
+      for s in range(steps):
+        assert np.isclose(hs[r]["loss"][s], refs[s]["metrics"]["loss"], rtol=RTOL, atol=1e-5), (shard, r, s)
+      assert np.isclose(ms[r]["grad_norm_max"], max(refs[-1]["norms"].values()), rtol=1e-3), (shard, r)
+    if shard:
+      with pytest.raises(SmxError, match="opt_gather"):
+        engines[0].get_params(which=2)
+      run_ranks([lambda r=r: engines[r].opt_gather() for r in range(world)])
+    em, ev, where = adam_state_errors(engines[world - 1], opt)
+    assert em < 2e-3 and ev < 4e-3, (shard, em, ev, where)
+    ref = so.dp_train_step(spec, params, bn, opt, x, list(rows[steps]), steps, cell_base=base, y=ys, library=lib, mask=mask, sync_bn=sync_bn)
+    ms = run_ranks([lambda r=r: engines[r].train_step(rows[steps][r]) for r in range(world)])
+    for r, m in enumerate(ms):
+      assert m["step"] == steps + 1 and np.isclose(m["loss"], ref["metrics"]["loss"], rtol=RTOL, atol=1e-5), (shard, r)
+    if shard:
+      run_ranks([lambda r=r: engines[r].opt_gather() for r in range(world)])
+    finals = [(e.get_params(), e.get_params(which=2), e.get_params(which=3)) for e in engines]
+    worst = grad_errors(finals[0][0], params)
+    assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    for which in range(3):
+      for k in finals[0][which]:
+        for r in range(1, world):
+          assert np.array_equal(finals[0][which][k], finals[r][which][k]), (shard, which, k, r)
+    hist[shard] = np.asarray(hs[0]["loss"])
+    for e in engines:
+      e.close()
+  assert np.allclose(hist[True], hist[False], rtol=2e-6)
+
+
 def test_sync_bn_equals_single_process_on_the_global_batch(Engine):
   """SURVEY 8e caveat (i): with SyncBatchNorm two replicas of 32 cells ARE one process on the 64 cells."""
   spec, cfg, x, ys, lib, mask = _problem(CASES["vae_zinb"])

@@ -499,13 +499,16 @@ def test_error_paths(Engine):
   e.close()
 
 
-@pytest.mark.parametrize("graph,buckets", [(False, "1"), (False, "2"), (True, "1")])
+@pytest.mark.parametrize("graph,buckets", [(False, "1"), (False, "2"), (True, "1"), (False, "shard")])
 def test_rccl_single_rank_allreduce_is_identity(Engine, monkeypatch, graph, buckets):
   """The data-parallel code path exercised on the one GPU of the test box (1-rank RCCL communicator,
   SMX_FORCE_ALLREDUCE): eager = two buckets on the communication stream overlapped with backward,
-  graph = one captured all-reduce.  A 1-rank all-reduce must not change any result."""
+  graph = one captured all-reduce.  A 1-rank all-reduce must not change any result.  `shard`: flag opt_shard -- ncclReduceScatter, the sharded
+  clip + Adam over the (one) slice, ncclAllGather, smx_opt_gather -- through RCCL itself."""
+  from sisua_amd._hip import SmxError
+  shard = buckets == "shard"
   monkeypatch.setenv("SMX_FORCE_ALLREDUCE", "1")
-  monkeypatch.setenv("SMX_DP_BUCKETS", buckets)
+  monkeypatch.setenv("SMX_DP_BUCKETS", "2" if shard else buckets)
   # the data-parallel path takes the norms from a pass over the (all-reduced) gradient; give the reference
   # run the same summation order so that the comparison can be exact
   from sisua_amd import _hip
@@ -518,9 +521,15 @@ def test_rccl_single_rank_allreduce_is_identity(Engine, monkeypatch, graph, buck
     if use_comm:
       e.comm_init(0, 1, Engine.comm_unique_id())
       assert e.world == 1
+      if shard:
+        e.set_flag("opt_shard", True)
     order = np.arange(64 * 6, dtype=np.int32) % x.shape[0]
     m = e.train_steps(order, 6, 64, graph=graph, metrics=True)
-    outs.append((m, e.get_params(), e.get_bn()))
+    if use_comm and shard:
+      with pytest.raises(SmxError, match="opt_gather"):
+        e.get_params(which=2)
+      e.opt_gather()
+    outs.append((m, e.get_params(), e.get_bn(), e.get_params(which=2), e.get_params(which=3)))
     if use_comm:   # the measurement hook of bench.py (N > 1): the collective alone; it must leave the model's state as it is
       us, nbytes = e.comm_time_allreduce(20)
       assert 0.0 < us < 1e4 and nbytes >= 4 * sum(v.size for v in outs[-1][1].values())
@@ -533,8 +542,9 @@ def test_rccl_single_rank_allreduce_is_identity(Engine, monkeypatch, graph, buck
     e.close()
   for key in ("loss", "nllk_x", "nllk_y", "kl"):
     assert outs[0][0][key] == outs[1][0][key], key
-  for k in outs[0][1]:
-    assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+  for which in (1, 3, 4):
+    for k in outs[0][which]:
+      assert np.array_equal(outs[0][which][k], outs[1][which][k]), (which, k)
   for i in outs[0][2]:
     assert np.array_equal(outs[0][2][i]["moving_mean"], outs[1][2][i]["moving_mean"])
 
