@@ -335,7 +335,8 @@ int smx_comm_form(const smx_model* m);
 /* Flag "opt_shard" (smx_set_flag; off by default; data parallel, the chained form -- it is taken whenever the flag is set): the output and
  * label heads' optimiser state is SHARDED over the ranks -- reduce-scatter of their gradient bucket, per-tensor clipnorm + Adam on this rank's
  * 1 / world slice, all-gather of the updated parameters (the same wire bytes as the all-reduce; 1 / world of the optimiser's memory traffic).
- * Parameters stay replicated and bit-identical on every rank; the Adam MOMENTS of the heads outside a rank's slice go stale.  smx_opt_gather
+ * Parameters stay replicated and bit-identical on every rank; a rank's gradient buffer (smx_get_tensor, which = 1) holds the heads' REDUCED
+ * gradient inside its slice only, and the Adam MOMENTS of the heads outside a rank's slice go stale.  smx_opt_gather
  * (a collective: every rank calls it, between training calls) all-gathers both moments, after which smx_get_tensor(which = 2 | 3) of a head
  * tensor -- refused while stale -- returns the job's moments on every rank (checkpoints).  RCCL or the loopback communicator; with the
  * hand-written exchange the flag is ignored (the all-reduce form runs). */
