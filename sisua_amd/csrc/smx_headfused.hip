@@ -35,6 +35,7 @@
 
 #include <algorithm>
 
+#include <hip/hip_ext.h>
 #include "smx_internal.h"
 #include "smx_loss.h"
 #include "../../include/sisua_hip.h"
@@ -538,11 +539,17 @@ int head_fused_grid(int Gp) {
 int head_fused_chunks(int Gp) { return head_fused_grid(Gp); }
 
 template <int LK>
-static int launch_hf(hipStream_t st, const HeadFusedArgs& a, int grid, int acc) {
+static int launch_hf(hipStream_t st, const HeadFusedArgs& a, int grid, int acc, hipEvent_t stop) {
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
   { const int rc = head_fused_prepare(); if (rc != SMX_OK) return rc; }
   const size_t lds = (size_t)4 * 3 * NP * 4096 + (size_t)2 * 8 * 16 * NP * 4;
-#define SMX_HF_GO(U, A) hipLaunchKernelGGL((head_fused_kernel<LK, U, A>), dim3((unsigned)grid), dim3(512), lds, st, a)
+  // stop: an event that is recorded when THIS launch completes -- as the completion signal of the launch's own packet (hipExtLaunchKernelGGL),
+  // not as a marker packet behind it (hipEventRecord), which the next launch of the stream would have to wait for
+#define SMX_HF_GO(U, A)                                                                                                                   \
+  do {                                                                                                                                    \
+    if (stop) hipExtLaunchKernelGGL((head_fused_kernel<LK, U, A>), dim3((unsigned)grid), dim3(512), (uint32_t)lds, st, nullptr, stop, 0u, a); \
+    else hipLaunchKernelGGL((head_fused_kernel<LK, U, A>), dim3((unsigned)grid), dim3(512), lds, st, a);                                  \
+  } while (0)
   if (a.x_u16) { if (acc) SMX_HF_GO(1, 1); else SMX_HF_GO(1, 0); }
   else { if (acc) SMX_HF_GO(0, 1); else SMX_HF_GO(0, 0); }
 #undef SMX_HF_GO
@@ -570,7 +577,7 @@ int head_fused_prepare() {
 // launches after the first ADD their dW / db (W_out's tiles are read once per launch, the weight gradient is read and written once more).
 // *n_slabs workgroups leave a slab of d d each in a.part ([workgroup][B][128]: a launch fills its cells' rows), *n_sq sum-of-squares slots
 // are written (by the last launch: the finished gradient's), llk_part holds head_fused_chunks(Gp) partials per cell.
-int launch_head_fused(hipStream_t st, const HeadFusedArgs& a_in, int* n_slabs, int* n_sq) {
+int launch_head_fused(hipStream_t st, const HeadFusedArgs& a_in, int* n_slabs, int* n_sq, hipEvent_t stop) {
   const int k = llk_planes(a_in.likelihood);
   if (!head_fused_supported(a_in.B, 128, a_in.Gp, k) || !a_in.D || !a_in.W || !a_in.bias || !a_in.X || !a_in.dW || !a_in.db || !a_in.part || !a_in.llk_part ||
       !a_in.dtab || (a_in.ldd % 4) || (a_in.ldw % 4) || (a_in.ldx % 8) || a_in.slab_stride < (long)a_in.B * 128 || (a_in.slab_stride % 4) ||
@@ -594,12 +601,13 @@ int launch_head_fused(hipStream_t st, const HeadFusedArgs& a_in, int* n_slabs, i
     a.part = a_in.part + (long)c0 * 128;
     a.llk_part = a_in.llk_part + (long)c0 * a.n_chunks;
     if (c0 + 128 < a_in.B) a.sq_part = nullptr;   // (only the finished gradient's sum of squares)
+    const hipEvent_t ev = (c0 + 128 < a_in.B) ? nullptr : stop;   // (the last launch's completion)
     int rc;
     switch (a.likelihood) {
-      case SMX_LLK_NB: rc = launch_hf<SMX_LLK_NB>(st, a, grid, c0 > 0); break;
-      case SMX_LLK_ZINB: rc = launch_hf<SMX_LLK_ZINB>(st, a, grid, c0 > 0); break;
-      case SMX_LLK_NBD: rc = launch_hf<SMX_LLK_NBD>(st, a, grid, c0 > 0); break;
-      case SMX_LLK_ZINBD: rc = launch_hf<SMX_LLK_ZINBD>(st, a, grid, c0 > 0); break;
+      case SMX_LLK_NB: rc = launch_hf<SMX_LLK_NB>(st, a, grid, c0 > 0, ev); break;
+      case SMX_LLK_ZINB: rc = launch_hf<SMX_LLK_ZINB>(st, a, grid, c0 > 0, ev); break;
+      case SMX_LLK_NBD: rc = launch_hf<SMX_LLK_NBD>(st, a, grid, c0 > 0, ev); break;
+      case SMX_LLK_ZINBD: rc = launch_hf<SMX_LLK_ZINBD>(st, a, grid, c0 > 0, ev); break;
       default: set_error("head_fused: unknown likelihood"); return SMX_ERR_INVALID;
     }
     if (rc != SMX_OK) return rc;

@@ -593,7 +593,7 @@ bool head_fused_supported(int B, int Hp, int Gp, int k);
 int head_fused_grid(int Gp);
 int head_fused_chunks(int Gp);   // likelihood partials per cell of a launch (<= 256)
 // the launch (*n_slabs workgroups leave a slab of d d each, *n_sq sum-of-squares slots) and the ordered sum of the slabs into dd_out [B][128]
-int launch_head_fused(hipStream_t st, const HeadFusedArgs& a, int* n_slabs, int* n_sq);
+int launch_head_fused(hipStream_t st, const HeadFusedArgs& a, int* n_slabs, int* n_sq, hipEvent_t stop = nullptr);   // stop: recorded by the (last) launch's own packet
 int launch_head_fused_reduce(hipStream_t st, const HeadFusedArgs& a, int n_slabs, float* dd_out);
 long head_fused_bytes(int B, int G, int Gp, int k);
 int head_fused_prepare();   // the kernels' dynamic-LDS limits (model creation; idempotent)

@@ -806,13 +806,17 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
       hf.B = ps.B; hf.G = m->G; hf.Gp = m->Gp; hf.likelihood = c.likelihood; hf.grad_scale = -inv_gb;
       const int reps = (!m->capturing && m->timing_label == "out_head") ? m->timing_reps : 1;   // idempotent
       int n_slabs = 0;
+      // this step's update of the heads: a sweep on the second stream, started behind this launch -- its event is the launch's own completion
+      // signal (no marker packet for the stream's next launch to wait behind; knob no_hf_ext_event: hipEventRecord)
+      const bool sweep_ev = hf.sq_part && head_sweep_ok(m);
+      const bool ext_ev = sweep_ev && reps == 1 && !tuning_on("no_hf_ext_event");
+      if (sweep_ev) SMX_CHECK(head_sweep_prepare(m));
       {
         Timed t(m, "out_head");
-        for (int r = 0; r < reps; ++r) SMX_CHECK(launch_head_fused(m->st, hf, &n_slabs, &m->head_fused_sq));
+        for (int r = 0; r < reps; ++r) SMX_CHECK(launch_head_fused(m->st, hf, &n_slabs, &m->head_fused_sq, ext_ev ? m->ev_hf : nullptr));
       }
-      if (hf.sq_part && head_sweep_ok(m)) {   // this step's update of the heads: a sweep on the second stream, started behind this launch
-        SMX_CHECK(head_sweep_prepare(m));
-        SMX_HIP(hipEventRecord(m->ev_hf, m->st));
+      if (sweep_ev) {
+        if (!ext_ev) SMX_HIP(hipEventRecord(m->ev_hf, m->st));
         m->ev_hf_fresh = true;
       }
       // data parallel, two buckets: without label heads every gradient of the head bucket is final HERE -- its chain (all-reduce, norms,
