@@ -13,7 +13,9 @@ out = sys.argv[1]
 FAMILIES = {"fused": "out_head_loss_kernel<1, 0, 1", "product_only": "out_head_loss_kernel<1, 0, 0",
             "standalone": "count_loss_kernel<1, 0, 1", "head_bwd": "out_head_bwd_kernel",
             # the wide-panel forms (bench.py --workload c5-shard): the whole head in one launch, the optimiser, the encoder's wide products
-            "head_fused": "head_fused_kernel", "adam": "adam_update_kernel", "enc_front": "bigk_kernel<", "enc_wgrad": "wgrad_panel_group_kernel"}
+            "head_fused": "head_fused_kernel", "adam": "adam_update_kernel", "enc_front": "bigk_kernel<", "enc_wgrad": "wgrad_panel_group_kernel",
+            # the BatchNorm launches that sum the wide products' column-major slabs themselves (round 5: no reduce launch)
+            "bn_wide_fwd": "bn_wide_fwd_kernel", "bn_wide_bwd": "bn_wide_bwd_kernel"}
 
 
 def counter_rows(d):
