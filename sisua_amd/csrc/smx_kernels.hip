@@ -276,12 +276,12 @@ __device__ inline void noise_fill(const BnFwdArgs& a, int job_block) {
 
 // RPT > 0: B <= BN_RL * RPT, every value of the column stays in registers (RPT rows per thread);
 // RPT == 0: any B, the normalised values make a round trip through xhat
-// the latent tile of the whole minibatch into LDS (row stride Dp + 1), one thread per 4 latent dims of a cell; the
+// the latent tile of the whole minibatch into LDS (row stride Dp + 4), one thread per 4 latent dims of a cell; the
 // first workgroup also leaves z / sigma / eps / KL in memory for the backward pass (same arithmetic, same Philox
 // blocks as latent_fwd_quad_kernel)
 template <int MAXIT>
 __device__ inline void latent_tile_to_lds(const LatentArgs& a, float* zs, bool store) {
-  const int dq = a.Dp >> 2, ldz = a.Dp + 1;
+  const int dq = a.Dp >> 2, ldz = a.Dp + 4;   // (rows 16-byte aligned: the dot products read the tile four k at a time)
   const int dsh = __builtin_ctz((unsigned)dq), dmask = dq - 1;   // dq is a power of two (bn_front_supported): shifts, not the ~35-instruction integer division per index
   const int total = a.B * dq;
   // every load of every iteration first (left as a loop the compiler waits for each iteration's loads in turn:
@@ -341,8 +341,7 @@ __device__ inline void latent_tile_to_lds(const LatentArgs& a, float* zs, bool s
         auto one = [&](int e, float mu, float& z) { if (d0 + e < a.D) z = a.relu ? fmaxf(mu, 0.f) : mu; };
         one(0, mq.x, zq.x); one(1, mq.y, zq.y); one(2, mq.z, zq.z); one(3, mq.w, zq.w);
       }
-      float* zrow = zs + b * ldz + d0;
-      zrow[0] = zq.x; zrow[1] = zq.y; zrow[2] = zq.z; zrow[3] = zq.w;
+      *reinterpret_cast<float4*>(zs + b * ldz + d0) = zq;
       if (store) {
         const long o = (long)b * a.Dp + d0;
         *reinterpret_cast<float4*>(a.z + o) = zq;
@@ -369,7 +368,7 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
     return;
   }
   __shared__ float sh[BN_WAVES * BN_COLS];
-  extern __shared__ float zs[];   // FRONT: [B][Dp + 1]
+  extern __shared__ __attribute__((aligned(16))) float zs[];   // FRONT: [B][Dp + 4] | this workgroup's columns of W [8][Dp + 4]
   SMX_STAMP(FRONT ? 1 : 0, 0);   // entry
   if (FRONT) preload(a.lat.lat, a.lat.ld, a.lat.Dp, a.lat.D, a.lat.B, a.lat.stochastic, a.lat.inj_eps, a.lat.inj_ld, a.lat.rows, a.lat.z, a.lat.sig, a.lat.eps,
                      a.lat.kl, a.W, a.ldw, a.B, a.H, a.Hp, a.gamma, a.beta, a.inj_mask, a.inj_ld, a.batchnorm, a.training);
@@ -379,6 +378,10 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
   const bool live = col < a.H;  // padded columns produce zeros
   const float bias = (!a.batchnorm && a.bias && live) ? a.bias[col] : 0.f;
   const float gamma_pre = (a.batchnorm && live) ? a.gamma[col] : 0.f, beta_pre = (a.batchnorm && live) ? a.beta[col] : 0.f;   // (requested ahead of pass 1)
+  // ... and the moving statistics the column's first thread updates at the end: read there, they were a memory round trip of their own between
+  // the last reduction and the thread's exit -- the workgroup's life
+  float mm_pre = 0.f, mv_pre = 0.f;
+  if (a.batchnorm && a.training && a.update_moving && live && rl == 0) { mm_pre = a.moving_mean[col]; mv_pre = a.moving_var[col]; }
   constexpr int CH = BN_RL * BN_RPT;
   float vreg[BN_RPT];
   // FRONT = 1: input tile up to 64 wide; FRONT = 2: exactly 128 wide (hidden -> hidden layers of 128-unit networks: the
@@ -387,8 +390,10 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
   float wcol[FRONT == 1 ? 64 : 1];   // FRONT = 2 reads its column of W from LDS inside the dot products (128 registers spilled)
   const float* wcol_lds = nullptr;
   if (FRONT) {
-    // this workgroup's [Dp][8] tile of W: one coalesced pass into LDS (its latency hides under the latent tile)
-    float* ws = zs + a.B * (a.lat.Dp + 1);       // [Dp][BN_COLS]
+    // this workgroup's [Dp][8] tile of W: one coalesced pass, left in LDS TRANSPOSED ([8 columns][Dp + 4]: a thread's column is a run of
+    // 16-byte reads; as [Dp][8] it was Dp 4-byte reads, and the input tile's rows -- stride Dp + 1 -- one 4-byte read per multiply-add)
+    const int lds_ld = a.lat.Dp + 4;
+    float* ws = zs + a.B * lds_ld;
     float wl[FRONT == 2 ? 2 : 1];
 #pragma unroll
     for (int u = 0; u < (FRONT == 2 ? 2 : 1); ++u) {
@@ -397,7 +402,7 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
     }
     if constexpr (FRONT == 2) {   // a plain input tile (hidden layers): every load first, then LDS
       constexpr int MAXIT = BN_RPT * 4;
-      const int kq = a.lat.Dp >> 2, ldz = a.lat.Dp + 1, total = a.B * kq;
+      const int kq = a.lat.Dp >> 2, ldz = lds_ld, total = a.B * kq;
       const int ksh = __builtin_ctz((unsigned)kq), kmask = kq - 1;   // (Dp = 128)
       float4 t4[MAXIT];
 #pragma unroll
@@ -409,8 +414,7 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
       for (int it = 0; it < MAXIT; ++it) {
         const int idx = threadIdx.x + it * BN_THREADS;
         if (idx < total) {
-          const int o = (idx >> ksh) * ldz + (idx & kmask) * 4;
-          zs[o] = t4[it].x; zs[o + 1] = t4[it].y; zs[o + 2] = t4[it].z; zs[o + 3] = t4[it].w;
+          *reinterpret_cast<float4*>(zs + (idx >> ksh) * ldz + (idx & kmask) * 4) = t4[it];
         }
       }
     } else {
@@ -419,15 +423,18 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
 #pragma unroll
     for (int u = 0; u < (FRONT == 2 ? 2 : 1); ++u) {
       const int t = (int)threadIdx.x + u * BN_THREADS;
-      if (t < a.lat.Dp * BN_COLS) ws[t] = wl[u];
+      if (t < a.lat.Dp * BN_COLS) ws[(t % BN_COLS) * lds_ld + t / BN_COLS] = wl[u];
     }
     __syncthreads();
     SMX_STAMP(1, 1);   // latent tile (sample + KL) and the W tile are in LDS
     if constexpr (FRONT == 1) {
 #pragma unroll
-      for (int k = 0; k < 64; ++k) wcol[k] = (k < a.lat.Dp) ? ws[k * BN_COLS + c] : 0.f;
+      for (int v = 0; v < 16; ++v) {
+        const float4 w4 = (4 * v < a.lat.Dp) ? *reinterpret_cast<const float4*>(ws + c * lds_ld + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wcol[4 * v] = w4.x; wcol[4 * v + 1] = w4.y; wcol[4 * v + 2] = w4.z; wcol[4 * v + 3] = w4.w;
+      }
     } else {
-      wcol_lds = ws + c;
+      wcol_lds = ws + c * lds_ld;
     }
     SMX_STAMP(1, 2);   // the thread's column of W in registers
   }
@@ -447,20 +454,30 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
   for (int r0 = 0; r0 < a.B; r0 += CH) {
     float acc[BN_RPT];
     if (FRONT) {
-      const int ldz = a.lat.Dp + 1;
+      const int ldz = a.lat.Dp + 4;
 #pragma unroll
       for (int i = 0; i < BN_RPT; ++i) {
         const int r = min(r0 + rl + BN_RL * i, a.B - 1);
+        const float4* z4 = reinterpret_cast<const float4*>(zs + r * ldz);
         float t = 0.f;
         if (FRONT == 2) {
-#pragma unroll 16
-          for (int k = 0; k < FK; ++k) t = fmaf(zs[r * ldz + k], wcol_lds[k * BN_COLS], t);
+#pragma unroll 4
+          for (int v = 0; v < FK / 4; ++v) {
+            const float4 z = z4[v], w = *reinterpret_cast<const float4*>(wcol_lds + 4 * v);
+            t = fmaf(z.x, w.x, t); t = fmaf(z.y, w.y, t); t = fmaf(z.z, w.z, t); t = fmaf(z.w, w.w, t);
+          }
         } else if (a.lat.Dp <= 32) {
 #pragma unroll
-          for (int k = 0; k < 32; ++k) t = fmaf(zs[r * ldz + k], wcol[k], t);
+          for (int v = 0; v < 8; ++v) {
+            const float4 z = z4[v];
+            t = fmaf(z.x, wcol[4 * v], t); t = fmaf(z.y, wcol[4 * v + 1], t); t = fmaf(z.z, wcol[4 * v + 2], t); t = fmaf(z.w, wcol[4 * v + 3], t);
+          }
         } else {
 #pragma unroll
-          for (int k = 0; k < 64; ++k) t = fmaf(zs[r * ldz + k], wcol[k], t);
+          for (int v = 0; v < 16; ++v) {
+            const float4 z = z4[v];
+            t = fmaf(z.x, wcol[4 * v], t); t = fmaf(z.y, wcol[4 * v + 1], t); t = fmaf(z.z, wcol[4 * v + 2], t); t = fmaf(z.w, wcol[4 * v + 3], t);
+          }
         }
         acc[i] = t;
       }
@@ -504,8 +521,8 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
       if (rl == 0) {
         if (a.batch_mean) { a.batch_mean[col] = mean; a.batch_var[col] = var; }
         if (a.update_moving && live) {
-          a.moving_mean[col] = a.moving_mean[col] * a.momentum + mean * (1.f - a.momentum);
-          a.moving_var[col] = a.moving_var[col] * a.momentum + var * (1.f - a.momentum);
+          a.moving_mean[col] = mm_pre * a.momentum + mean * (1.f - a.momentum);
+          a.moving_var[col] = mv_pre * a.momentum + var * (1.f - a.momentum);
         }
       }
     } else {
@@ -564,7 +581,7 @@ __global__ void bn_wide_bwd_kernel(BnBwdArgs a);
 
 bool bn_front_supported(int B, int Dp) {
   const int dq = Dp >> 2;
-  return B > 0 && B <= BN_RL * 4 && Dp >= 4 && (Dp <= 64 || Dp == 128) && (Dp % 4) == 0 && (dq & (dq - 1)) == 0 && ((size_t)B * (Dp + 1) + (size_t)Dp * 8) * sizeof(float) <= 96 * 1024;
+  return B > 0 && B <= BN_RL * 4 && Dp >= 4 && (Dp <= 64 || Dp == 128) && (Dp % 4) == 0 && (dq & (dq - 1)) == 0 && ((size_t)B * (Dp + 4) + (size_t)8 * (Dp + 4)) * sizeof(float) <= 96 * 1024;
 }
 
 int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
@@ -576,7 +593,7 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
       return SMX_ERR_INVALID;
     }
     if (a.Hp % BN_COLS) { set_error("bn_act_fwd: bad shapes"); return SMX_ERR_INVALID; }
-    const size_t lds = ((size_t)a.B * (a.lat.Dp + 1) + (size_t)a.lat.Dp * BN_COLS) * sizeof(float);
+    const size_t lds = ((size_t)a.B * (a.lat.Dp + 4) + (size_t)BN_COLS * (a.lat.Dp + 4)) * sizeof(float);
     static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_fwd_kernel<4, 1>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     if (lds > 64 * 1024 && !big_ok) { set_error("bn_act_fwd: cannot reserve the dynamic LDS of the latent front"); return SMX_ERR_HIP; }
@@ -632,7 +649,7 @@ template <int RPT, int FRONT>
 __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
   constexpr bool SMALL = RPT > 0;
   constexpr int BN_RPT = SMALL ? RPT : BN_RPT_DEFAULT;
-  extern __shared__ float ds[];   // FRONT: d lat tile [B][fK + 1]
+  extern __shared__ __attribute__((aligned(16))) float ds[];   // FRONT: d lat tile [B][fK + 4] | this workgroup's rows of W [8][fK + 4]
   {
     const int nb = a.Hp / BN_COLS, extra = bid - nb;
     if (extra >= 0) {
@@ -673,11 +690,11 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
   constexpr int FK = FRONT == 2 ? 128 : 64;   // FRONT = 2: K = 128 exactly (see bn_act_fwd_body)
   float wrow[FRONT ? FK : 1];
   if (FRONT) {
-    const int ldd = a.fK + 1, kq = a.fK >> 2;
+    const int ldd = a.fK + 4, kq = a.fK >> 2;   // (rows 16-byte aligned: the dot products read the tile four k at a time)
     const int ksh = __builtin_ctz((unsigned)kq), kmask = kq - 1;   // fK is 32, 64 or 128 (bn_bwd_front_supported)
     // this workgroup's 8 rows of W_lat: ONE coalesced pass into LDS (every thread loading its own row from global
     // memory is 8 different cache lines per quarter-wave: 5 us), then each thread copies its row to registers
-    float* ws = ds + ((a.B * ldd + 3) & ~3);     // [BN_COLS][fK + 4], 16-byte aligned
+    float* ws = ds + a.B * ldd;                  // [BN_COLS][fK + 4]
     const int ldw_s = a.fK + 4;
     float4 wl = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool wl_on = (int)threadIdx.x < BN_COLS * kq && !(a.diag & 64);   // (8 rows x fK / 4 <= 256 float4: one per thread)
@@ -695,8 +712,7 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
       for (int it = 0; it < MAXIT; ++it) {
         const int idx = threadIdx.x + it * BN_THREADS;
         if (idx < a.B * kq) {
-          const int o = (idx >> ksh) * ldd + (idx & kmask) * 4;
-          ds[o] = tl[it].x; ds[o + 1] = tl[it].y; ds[o + 2] = tl[it].z; ds[o + 3] = tl[it].w;
+          *reinterpret_cast<float4*>(ds + (idx >> ksh) * ldd + (idx & kmask) * 4) = tl[it];
         }
       }
       if ((int)threadIdx.x < BN_COLS * kq) *reinterpret_cast<float4*>(&ws[((int)threadIdx.x >> ksh) * ldw_s + ((int)threadIdx.x & kmask) * 4]) = wl;
@@ -713,23 +729,23 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
   for (int r0 = 0; r0 < a.B; r0 += CH) {
     float acc[BN_RPT];
     if (FRONT) {
-      const int ldd = a.fK + 1;
+      const int ldd = a.fK + 4;
 #pragma unroll
       for (int i = 0; i < BN_RPT; ++i) {
         const int r = min(r0 + rl + BN_RL * i, a.B - 1);
+        const float4* d4 = reinterpret_cast<const float4*>(ds + r * ldd);
         float t = 0.f;
-        if (a.diag & 16) {
-          t = ds[r * ldd] + wrow[0] + wrow[63];
-        } else if (FRONT == 2) {
+        auto dots = [&](auto nv) {
 #pragma unroll
-          for (int k = 0; k < FK; ++k) t = fmaf(ds[r * ldd + k], wrow[k], t);
-        } else if (a.fK <= 32) {
-#pragma unroll
-          for (int k = 0; k < 32; ++k) t = fmaf(ds[r * ldd + k], wrow[k], t);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 64; ++k) t = fmaf(ds[r * ldd + k], wrow[k], t);
-        }
+          for (int v = 0; v < decltype(nv)::value; ++v) {
+            const float4 d = d4[v];
+            t = fmaf(d.x, wrow[4 * v], t); t = fmaf(d.y, wrow[4 * v + 1], t); t = fmaf(d.z, wrow[4 * v + 2], t); t = fmaf(d.w, wrow[4 * v + 3], t);
+          }
+        };
+        if (a.diag & 16) t = ds[r * ldd] + wrow[0] + wrow[63];
+        else if (FRONT == 2) dots(std::integral_constant<int, FK / 4>());
+        else if (a.fK <= 32) dots(std::integral_constant<int, 8>());
+        else dots(std::integral_constant<int, 16>());
         acc[i] = t;
       }
     } else
@@ -796,7 +812,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_dual_kernel(BnBwdArgs a
 }
 
 bool bn_bwd_front_supported(int B, int K) {
-  return B > 0 && B <= BN_RL * 4 && (K == 32 || K == 64 || (K == 128 && B <= BN_RL * 2)) && ((size_t)B * (K + 1) + 8 * (K + 4)) * sizeof(float) <= 96 * 1024;
+  return B > 0 && B <= BN_RL * 4 && (K == 32 || K == 64 || (K == 128 && B <= BN_RL * 2)) && ((size_t)B * (K + 4) + 8 * (K + 4)) * sizeof(float) <= 96 * 1024;
 }
 
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
@@ -807,7 +823,7 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
       return SMX_ERR_INVALID;
     }
     const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count + a.sqr_count;
-    const size_t lds = ((size_t)a.B * (a.fK + 1) + 4 + (size_t)BN_COLS * (a.fK + 4)) * sizeof(float);
+    const size_t lds = ((size_t)a.B * (a.fK + 4) + (size_t)BN_COLS * (a.fK + 4)) * sizeof(float);
     static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_bwd_kernel<4, 1>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     if (lds > 64 * 1024 && !big_ok) { set_error("bn_act_bwd: cannot reserve the dynamic LDS of the gradient front"); return SMX_ERR_HIP; }
@@ -851,7 +867,7 @@ int launch_bn_act_bwd_dual(hipStream_t st, const BnBwdArgs& a_in, const BnBwdArg
   }
   const int na = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count + a.sqr_count;
   const int grid = na + b.Hp / BN_COLS;
-  auto need = [](const BnBwdArgs& x) { return ((size_t)x.B * (x.fK + 1) + 4 + (size_t)BN_COLS * (x.fK + 4)) * sizeof(float); };
+  auto need = [](const BnBwdArgs& x) { return ((size_t)x.B * (x.fK + 4) + (size_t)BN_COLS * (x.fK + 4)) * sizeof(float); };
   const size_t lds = need(a) > need(b) ? need(a) : need(b);
   static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_bwd_dual_kernel<4>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
@@ -919,6 +935,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_wide_fwd_kernel(BnFwdArgs a) {
   const bool drop = a.training && a.drop_p > 0.f;
   float mpre = 0.f;
   if (drop && a.inj_mask && on) mpre = a.inj_mask[(long)r * a.inj_ld + col];
+  float mm_pre = 0.f, mv_pre = 0.f;   // (the moving statistics thread 0 updates at the end, requested now)
+  if (a.batchnorm && a.training && a.update_moving && live && r == 0) { mm_pre = a.moving_mean[col]; mv_pre = a.moving_var[col]; }
   wide_slab_column(a.pre, a.slab_stride, a.n_slabs, col, sh);
   __syncthreads();
   float v = 0.f;
@@ -947,8 +965,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_wide_fwd_kernel(BnFwdArgs a) {
       if (r == 0) {
         if (a.batch_mean) { a.batch_mean[col] = mean; a.batch_var[col] = var; }
         if (a.update_moving && live) {
-          a.moving_mean[col] = a.moving_mean[col] * a.momentum + mean * (1.f - a.momentum);
-          a.moving_var[col] = a.moving_var[col] * a.momentum + var * (1.f - a.momentum);
+          a.moving_mean[col] = mm_pre * a.momentum + mean * (1.f - a.momentum);
+          a.moving_var[col] = mv_pre * a.momentum + var * (1.f - a.momentum);
         }
       }
     } else {
