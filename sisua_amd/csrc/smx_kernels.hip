@@ -330,7 +330,7 @@ __device__ inline void latent_tile_to_lds(const LatentArgs& a, float* zs, bool s
             const float sg = softplusf(s_raw + SMX_SOFTPLUS_INV_1);
             s = sg; en = nn;
             z = mu + sg * nn;
-            kl += 0.5f * (sg * sg + mu * mu - 1.f - 2.f * flog(sg));
+            if (store) kl += 0.5f * (sg * sg + mu * mu - 1.f - 2.f * flog(sg));   // (block-uniform: the KL term belongs to the workgroup that stores)
           }
         };
         one(0, mq.x, sr.x, nq.x, zq.x, sq.x, eq.x);
@@ -363,12 +363,15 @@ template <int RPT, int FRONT>
 __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
   constexpr bool SMALL = RPT > 0;
   constexpr int BN_RPT = SMALL ? RPT : BN_RPT_DEFAULT;
+  extern __shared__ __attribute__((aligned(16))) float zs[];   // FRONT: [B][Dp + 4] | this workgroup's columns of W [8][Dp + 4]
   if (bid >= a.Hp / BN_COLS) {
-    noise_fill(a, bid - a.Hp / BN_COLS);
+    // FRONT = 1: ONE extra workgroup leaves z / sigma / eps / KL in memory for the backward pass and does nothing else -- as a duty of column
+    // block 0 the stores and the KL arithmetic made that workgroup the launch's longest
+    if constexpr (FRONT == 1) latent_tile_to_lds<BN_RPT * 2>(a.lat, zs, true);
+    else noise_fill(a, bid - a.Hp / BN_COLS);
     return;
   }
   __shared__ float sh[BN_WAVES * BN_COLS];
-  extern __shared__ __attribute__((aligned(16))) float zs[];   // FRONT: [B][Dp + 4] | this workgroup's columns of W [8][Dp + 4]
   SMX_STAMP(FRONT ? 1 : 0, 0);   // entry
   if (FRONT) preload(a.lat.lat, a.lat.ld, a.lat.Dp, a.lat.D, a.lat.B, a.lat.stochastic, a.lat.inj_eps, a.lat.inj_ld, a.lat.rows, a.lat.z, a.lat.sig, a.lat.eps,
                      a.lat.kl, a.W, a.ldw, a.B, a.H, a.Hp, a.gamma, a.beta, a.inj_mask, a.inj_ld, a.batchnorm, a.training);
@@ -418,7 +421,7 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
         }
       }
     } else {
-      latent_tile_to_lds<BN_RPT * 2>(a.lat, zs, bid == 0 && a.lat.z != nullptr);   // B Dp / 4 quads over 512 threads: <= 2 RPT iterations
+      latent_tile_to_lds<BN_RPT * 2>(a.lat, zs, false);   // B Dp / 4 quads over 512 threads: <= 2 RPT iterations (the extra workgroup stores)
     }
 #pragma unroll
     for (int u = 0; u < (FRONT == 2 ? 2 : 1); ++u) {
@@ -605,8 +608,8 @@ int launch_bn_act_fwd(hipStream_t st, const BnFwdArgs& a_in) {
         return SMX_ERR_INVALID;
       }
       hipLaunchKernelGGL((bn_act_fwd_kernel<2, 2>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
-    } else if (a.B <= BN_RL * 2) hipLaunchKernelGGL((bn_act_fwd_kernel<2, 1>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
-    else hipLaunchKernelGGL((bn_act_fwd_kernel<4, 1>), dim3(a.Hp / BN_COLS), dim3(BN_THREADS), lds, st, a);
+    } else if (a.B <= BN_RL * 2) hipLaunchKernelGGL((bn_act_fwd_kernel<2, 1>), dim3(a.Hp / BN_COLS + (a.lat.z ? 1 : 0)), dim3(BN_THREADS), lds, st, a);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<4, 1>), dim3(a.Hp / BN_COLS + (a.lat.z ? 1 : 0)), dim3(BN_THREADS), lds, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
