@@ -305,6 +305,20 @@ __device__ __forceinline__ void preload(const T0& v0, const T1& v1, const T2& v2
 // (four DPP steps inside the rows of 16, then two ds_bpermute across the four rows -- instead of six ds_bpermute)
 // a lane's value to every lane (v_readlane: the lane index is uniform); __shfl would go through the LDS crossbar (ds_bpermute)
 __device__ inline float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+// v + (v of lane ^ 16) and v + (v of lane ^ 32) without the LDS crossbar: gfx950's v_permlane16_swap / v_permlane32_swap exchange rows /
+// halves between two registers holding the same value, after which their sum is what `v + __shfl_xor(v, 16 | 32)` gives (the same two
+// addends in every lane: the same bits; tools/dev/permlane_sum.hip).  Inline asm with the hazard's wait states spelled out: given the SAME
+// value for both operands the builtins (ROCm 7.2) return the first register twice.
+__device__ inline float xor16_add(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ inline float xor32_add(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
 __device__ inline float wave_sum(float v) {
 #define SMX_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false))
   SMX_DPP_ADD(0xB1);    // quad_perm [1, 0, 3, 2]
@@ -312,12 +326,10 @@ __device__ inline float wave_sum(float v) {
   SMX_DPP_ADD(0x141);   // row_half_mirror
   SMX_DPP_ADD(0x140);   // row_mirror
 #undef SMX_DPP_ADD
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  return xor32_add(xor16_add(v));   // (were two ds_bpermute round trips)
 }
 // Sum over the 32 lanes of each half of a wave (lanes 0..31 and 32..63 separately), every lane gets its half's sum.
-// Four DPP steps inside the rows of 16 (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: ~8 cycles each) and ONE
-// ds_bpermute across the two rows of a half, instead of five ds_bpermute round trips through the LDS pipe.
+// Four DPP steps inside the rows of 16 (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: ~8 cycles each) and one row exchange.
 __device__ inline float half_wave_sum(float v) {
 #define SMX_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false))
   SMX_DPP_ADD(0xB1);    // quad_perm [1, 0, 3, 2]
@@ -325,7 +337,7 @@ __device__ inline float half_wave_sum(float v) {
   SMX_DPP_ADD(0x141);   // row_half_mirror
   SMX_DPP_ADD(0x140);   // row_mirror
 #undef SMX_DPP_ADD
-  return v + __shfl_xor(v, 16, 64);
+  return xor16_add(v);
 }
 __device__ inline float wave_max(float v) {
 #define SMX_DPP_MAX(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xF, 0xF, false)))

@@ -179,8 +179,9 @@ constexpr int BN_WAVES = BN_THREADS / 64;
 // then the 4 waves meet in LDS; fixed order -> deterministic
 __device__ inline float bn_col_reduce(float v, float* sh /*[BN_WAVES][BN_COLS]*/) {
   const int c = threadIdx.x % BN_COLS, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int off = BN_COLS; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+  static_assert(BN_COLS == 8, "bn_col_reduce: the lanes of a column are 8 apart");
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));   // row_ror:8 = lane ^ 8 (were three ds_bpermute round trips)
+  v = xor32_add(xor16_add(v));
   __syncthreads();
   if ((threadIdx.x & 63) < BN_COLS) sh[w * BN_COLS + c] = v;
   __syncthreads();
@@ -914,11 +915,7 @@ __device__ inline float wide_row_value(const float* sh, int r) {
   return v;
 }
 // sum over the 64 pairs (r, r + 64) held by the lanes of wave 0: the balanced tree of bn_col_reduce
-__device__ inline float wide_tree64(float p) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) p += __shfl_xor(p, off, 64);
-  return p;
-}
+__device__ inline float wide_tree64(float p) { return wave_sum(p); }   // (lane ^ 1, 2, 4, 8 by DPP, 16 and 32 by row / half exchanges: that tree)
 
 // (Which multiply-adds the compiler fuses in bn_act_fwd_body / bn_act_bwd_body<2, 0> was read off their ISA; the kernels below spell the
 // same operations out with contraction switched off, so that the two forms stay equal bit for bit.)
@@ -940,7 +937,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_wide_fwd_kernel(BnFwdArgs a) {
   if (drop && a.inj_mask && on) mpre = a.inj_mask[(long)r * a.inj_ld + col];
   float mm_pre = 0.f, mv_pre = 0.f;   // (the moving statistics thread 0 updates at the end, requested now)
   if (a.batchnorm && a.training && a.update_moving && live && r == 0) { mm_pre = a.moving_mean[col]; mv_pre = a.moving_var[col]; }
+  SMX_STAMP(0, 0);
   wide_slab_column(a.pre, a.slab_stride, a.n_slabs, col, sh);
+  SMX_STAMP(0, 3);   // the thread's slabs summed, partial sums in LDS
   __syncthreads();
   float v = 0.f;
   if (rowt) { v = wide_row_value(sh, r) + bias; vs[r] = v; }
@@ -979,6 +978,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_wide_fwd_kernel(BnFwdArgs a) {
     inv = rsqrtf(var + a.eps);
     if (r == 0 && a.inv_std) a.inv_std[col] = inv;
   }
+  SMX_STAMP(0, 5);   // column statistics
   if (!on) return;
   const float scale = drop ? 1.f / (1.f - a.drop_p) : 1.f;
   const long o = (long)r * a.Hp + col;
@@ -1000,6 +1000,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_wide_fwd_kernel(BnFwdArgs a) {
     h *= mult;
   }
   a.out[o] = live ? h : 0.f;
+  SMX_STAMP(0, 6);   // stores issued
 }
 
 __global__ __launch_bounds__(BN_THREADS) void bn_wide_bwd_kernel(BnBwdArgs a) {
@@ -1033,7 +1034,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_wide_bwd_kernel(BnBwdArgs a) {
     if (a.batchnorm) xh = a.xhat[o];
   }
   if (a.batchnorm) { gamma = live ? a.gamma[col] : 0.f; inv = a.inv_std[col]; }
+  SMX_STAMP(2, 0);
   wide_slab_column(a.dout, a.slab_stride, a.n_slabs, col, sh);
+  SMX_STAMP(2, 3);
   __syncthreads();
   float dy = 0.f;
   if (on) {
@@ -1053,6 +1056,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_wide_bwd_kernel(BnBwdArgs a) {
   }
   __syncthreads();
   const float s1 = st[0], s2 = st[1];
+  SMX_STAMP(2, 5);
   if (!a.batchnorm) {
     if (r == 0 && a.dbias && live) a.dbias[col] = s1;
     if (on) a.dpre[(long)r * a.Hp + col] = dy;
@@ -1065,6 +1069,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_wide_bwd_kernel(BnBwdArgs a) {
   if (a.training) d = (gamma * inv) * __builtin_fmaf(-__builtin_fmaf(xh, s2, s1), invB, dy);
   else d = dy * gamma * inv;
   a.dpre[(long)r * a.Hp + col] = d;
+  SMX_STAMP(2, 6);
 }
 
 bool bn_wide_supported(int B, int Hp, int n_slabs) { return B > 0 && B <= 128 && Hp > 0 && Hp <= 128 && n_slabs > 0 && !tuning_on("no_bn_wide"); }

@@ -14,9 +14,9 @@ order = bench.make_order(xt.shape[0], batch, 60)
 for _ in range(100): e.eval_step(order[:batch])
 e.train_steps(order, 60, batch, graph=False); e.synchronize()
 lib = _hip.load()
-NAMES = {("kernels", 0): ("bn_act_fwd_kernel<2,0> (encoder: slab sum, BatchNorm, ReLU, dropout)", ["entry", "", "", "slab sum", "column sums", "column variances", "normalise + stores issued"]),
+NAMES = {("kernels", 0): ("bn_wide_fwd_kernel (encoder: column-major slabs summed, BatchNorm, ReLU, dropout; stamps of column 0's workgroup, from its first load)", ["entry", "", "", "slabs summed, partials in LDS", "", "column statistics", "normalise + stores issued"]),
          ("kernels", 1): ("bn_act_fwd_kernel<2,1> (latent sample + KL, first decoder product, BatchNorm)", ["entry", "latent + W tile in LDS (barrier)", "column of W -> registers", "dot products", "column sums", "column variances", "normalise + stores issued", "(from entry) the tile's loads issued", "(...) its first operands arrived", "(...) sample + KL computed, stores issued"]),
-         ("kernels", 2): ("bn_act_bwd_kernel<2,0> (decoder: slab sum of d d, BatchNorm backward)", ["entry", "", "", "slab sum + mask + loads of out / xhat", "sum dy", "sum dy xhat", "finish + stores issued"]),
+         ("kernels", 2): ("bn_wide_bwd_kernel (decoder: column-major slabs of d d summed, BatchNorm backward)", ["entry", "", "", "slabs summed, partials in LDS", "", "sum dy, sum dy xhat", "finish + stores issued"]),
          ("kernels", 3): ("bn_act_bwd_kernel<2,1> (d h product, encoder BatchNorm backward)", ["entry", "gradient tile + W rows in LDS (barrier)", "row of W -> registers", "dot products + mask + loads of out / xhat", "sum dy", "sum dy xhat", "finish + stores issued"]),
          ("headbwd", 4): ("out_head_bwd_kernel (workgroup 0: a dW tile)", ["entry", "products over the minibatch", "partial tiles summed, dW / db / sum of squares stored"])}
 for unit in ("kernels", "headbwd"):
