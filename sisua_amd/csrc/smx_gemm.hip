@@ -176,6 +176,27 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
     }
   };
 
+  // EPI = 2: what the latent-backward epilogue reads beside the product -- requested NOW, ahead of the tile loads (behind the product and the
+  // partial tiles' exchange they were one more memory round trip at the end of a four-workgroup launch)
+  constexpr int RPW_E = 16 / WK;
+  float e_mu[RPW_E], e_sr[RPW_E], e_sg[RPW_E], e_ep[RPW_E], e_dk[RPW_E], e_za[RPW_E];
+  if (EPI == 2) {
+    const EpiLatentBwd& e = g.lb;
+    const int d = n0 + wn * 32 + li;
+    const bool live = d < e.D;
+#pragma unroll
+    for (int j = 0; j < RPW_E; ++j) {
+      const int r = wk * RPW_E + j;
+      const int b = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const bool ok = live && b < g.M;
+      e_dk[j] = (ok && e.dklz) ? e.dklz[(long)b * e.Dp + d] : 0.f;
+      e_za[j] = (ok && e.dz_add) ? e.dz_add[(long)b * e.Dp + d] : 0.f;
+      e_mu[j] = ok ? e.lat[(long)b * e.ld + d] : 0.f;
+      e_sr[j] = (ok && e.stochastic) ? e.lat[(long)b * e.ld + e.Dp + d] : 0.f;
+      e_sg[j] = (ok && e.stochastic) ? e.sig[(long)b * e.Dp + d] : 1.f;
+      e_ep[j] = (ok && e.stochastic) ? e.eps[(long)b * e.Dp + d] : 0.f;
+    }
+  }
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -244,20 +265,9 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
     const EpiLatentBwd& e = g.lb;
     const int d = n0 + wn * 32 + li;
     const bool live = d < e.D;
-    // all loads first (independent, in flight together), then the arithmetic, then the stores
-    float mu[RPW], sr[RPW], sg[RPW], ep[RPW], dk[RPW], za[RPW];
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-      const int r = r_base + j;
-      const int b = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const bool ok = live && b < g.M;
-      dk[j] = (ok && e.dklz) ? e.dklz[(long)b * e.Dp + d] : 0.f;
-      za[j] = (ok && e.dz_add) ? e.dz_add[(long)b * e.Dp + d] : 0.f;
-      mu[j] = ok ? e.lat[(long)b * e.ld + d] : 0.f;
-      sr[j] = (ok && e.stochastic) ? e.lat[(long)b * e.ld + e.Dp + d] : 0.f;
-      sg[j] = (ok && e.stochastic) ? e.sig[(long)b * e.Dp + d] : 1.f;
-      ep[j] = (ok && e.stochastic) ? e.eps[(long)b * e.Dp + d] : 0.f;
-    }
+    // (the operands were requested at entry)
+    const float (&mu)[RPW_E] = e_mu; const float (&sr)[RPW_E] = e_sr; const float (&sg)[RPW_E] = e_sg;
+    const float (&ep)[RPW_E] = e_ep; const float (&dk)[RPW_E] = e_dk; const float (&za)[RPW_E] = e_za;
     float o0[RPW], o1[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {

@@ -2453,12 +2453,17 @@ __device__ inline void sq_reduce_body(const float* sl, int cnt, float* dst) {
 
 __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
   kernarg_warm<sizeof(AdamArgs)>();
-  if ((int)blockIdx.x == a.n_launch) {  // use_sq form: the ELBO scalars ride along here
+  if ((int)blockIdx.x == a.n_launch && a.use_sq && a.with_metrics) {  // use_sq form: the ELBO scalars ride along here
     metrics_body(a.metrics);
     return;
   }
-  adam_chunk_body(a, (int)blockIdx.x >= a.gap_from ? (int)blockIdx.x + a.gap_len : (int)blockIdx.x);
-  if (blockIdx.x == 0 && a.master) {  // close the step; nobody reads next_state / next_rows during this step
+  if ((int)blockIdx.x < a.n_launch) {
+    adam_chunk_body(a, (int)blockIdx.x >= a.gap_from ? (int)blockIdx.x + a.gap_len : (int)blockIdx.x);
+    return;
+  }
+  // the LAST workgroup closes the step (nobody reads next_state / next_rows during this step).  As a duty of workgroup 0 behind its chunk --
+  // state -> row ids -> stores: two more dependent round trips and a powf -- it was the launch's critical path.
+  if (a.master) {
     const uint32_t step = a.state->step, cur = a.state->cursor;
     if (a.hist_dp && threadIdx.x < 8) a.hist_dp[(long)cur * 8 + threadIdx.x] = a.tail_metrics[threadIdx.x];
     if (a.prepare_next)
@@ -2600,12 +2605,12 @@ int launch_adam_shard(hipStream_t st, const AdamArgs& a, int first, int count, i
 // an agent-scope acquire/release round across the 8 XCDs costs far more than a kernel boundary (1.5 us).
 int launch_adam(hipStream_t st, const AdamArgs& a) {
   if (a.use_sq) {   // norms come from the weight-gradient products: no pass over the gradient buffer
-    hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_launch + (a.with_metrics ? 1 : 0)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_launch + (a.with_metrics ? 1 : 0) + (a.master ? 1 : 0)), dim3(256), 0, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
   hipLaunchKernelGGL(grad_sqsum_kernel, dim3((a.sq_chunks >= 0 ? a.sq_chunks : a.n_chunks) + (a.with_metrics ? 1 : 0) + (a.bn_total + 255) / 256), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_launch), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(adam_update_kernel, dim3(a.n_launch + (a.master ? 1 : 0)), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
