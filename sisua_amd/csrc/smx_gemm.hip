@@ -182,19 +182,22 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
   float e_mu[RPW_E], e_sr[RPW_E], e_sg[RPW_E], e_ep[RPW_E], e_dk[RPW_E], e_za[RPW_E];
   if (EPI == 2) {
     const EpiLatentBwd& e = g.lb;
-    const int d = n0 + wn * 32 + li;
-    const bool live = d < e.D;
+    // (unconditional loads from clamped indices under launch-uniform branches: a lane-predicated load per register was a block with a wait
+    // of its own -- four round trips in a row; what a lane beyond the tile reads is never used)
+    const int d = min(n0 + wn * 32 + li, e.Dp - 1);
 #pragma unroll
     for (int j = 0; j < RPW_E; ++j) {
       const int r = wk * RPW_E + j;
-      const int b = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const bool ok = live && b < g.M;
-      e_dk[j] = (ok && e.dklz) ? e.dklz[(long)b * e.Dp + d] : 0.f;
-      e_za[j] = (ok && e.dz_add) ? e.dz_add[(long)b * e.Dp + d] : 0.f;
-      e_mu[j] = ok ? e.lat[(long)b * e.ld + d] : 0.f;
-      e_sr[j] = (ok && e.stochastic) ? e.lat[(long)b * e.ld + e.Dp + d] : 0.f;
-      e_sg[j] = (ok && e.stochastic) ? e.sig[(long)b * e.Dp + d] : 1.f;
-      e_ep[j] = (ok && e.stochastic) ? e.eps[(long)b * e.Dp + d] : 0.f;
+      const int b = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+      e_dk[j] = 0.f; e_za[j] = 0.f; e_sr[j] = 0.f; e_sg[j] = 1.f; e_ep[j] = 0.f;
+      if (e.dklz) e_dk[j] = e.dklz[(long)b * e.Dp + d];
+      if (e.dz_add) e_za[j] = e.dz_add[(long)b * e.Dp + d];
+      e_mu[j] = e.lat[(long)b * e.ld + d];
+      if (e.stochastic) {
+        e_sr[j] = e.lat[(long)b * e.ld + e.Dp + d];
+        e_sg[j] = e.sig[(long)b * e.Dp + d];
+        e_ep[j] = e.eps[(long)b * e.Dp + d];
+      }
     }
   }
   f32x16 acc;
