@@ -2366,21 +2366,64 @@ int launch_step_begin(hipStream_t st, StepState* master, StepState* dst, const i
 }
 
 __device__ inline void metrics_body(const MetricsArgs& a) {
-  __shared__ float sh[4];
+  // ONE workgroup riding with another launch: its life is that launch's.  Every load is part of a batch (a thread's 32 likelihood partials at
+  // a time; the per-cell terms and the history cursor beside them), the seven sums meet in LDS behind ONE pair of barriers -- as a sweep of
+  // eight loads per round, a remainder loop of dependent loads and a block_sum per term it was ~15 memory round trips and 14 barriers in a
+  // row.  The additions keep their order: the same bits.
+  __shared__ float sh[7][4];
   float sx = 0.f, sy = 0.f, sk = 0.f, sl = 0.f, st = 0.f, sd = 0.f, so = 0.f;
-  // only the batch total of the count log-likelihood is needed: a flat, coalesced sweep of [B][n_chunks]
+  const int tid = (int)threadIdx.x;
+  const uint32_t cursor = a.hist ? a.state->cursor : 0u;
+  // the per-cell terms of this thread's first cell (minibatches of up to 256 cells: every cell), requested ahead of the sweep
+  float c_lg = 0.f, c_y = 0.f, c_o = 0.f, c_k = 0.f, c_l = 0.f, c_t = 0.f, c_d0 = 0.f, c_d1 = 0.f;
+  {
+    const int b = min(tid, a.B - 1);
+    if (a.lgx1) c_lg = a.lgx1[a.rows ? a.rows[b] : b];
+    if (a.llk_y) c_y = a.llk_y[b];
+    if (a.llk_o) c_o = a.llk_o[b];
+    if (a.kl) c_k = a.kl[b];
+    if (a.kl_l) c_l = a.kl_l[b];
+    if (a.tc) { c_t = a.tc[b]; c_d0 = a.dl[b]; c_d1 = a.dl[a.B + b]; }
+  }
+  // only the batch total of the count log-likelihood is needed: a flat, coalesced sweep of [B][n_chunks]; part[u] takes the elements
+  // tid + 256 u + 2048 k of the full rounds (k ascending), part[0] then the remainder one by one -- as the loop this replaces
   const int total = a.B * a.n_chunks;
   {
-    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // independent loads in flight, fixed order
-    int i = threadIdx.x;
-    for (; i + 7 * 256 < total; i += 8 * 256) {
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int nfull = (total > tid + 7 * 256) ? (total - 1 - tid - 7 * 256) / 2048 + 1 : 0;   // rounds with all eight elements in range
+    for (int k0 = 0; k0 < nfull; k0 += 4) {
+      float v[4][8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) part[u] += a.llk_part[i + u * 256];
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[kk][u] = a.llk_part[min(tid + (k0 + kk) * 2048 + u * 256, total - 1)];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        if (k0 + kk < nfull) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) part[u] += v[kk][u];
+        }
     }
-    for (; i < total; i += 256) part[0] += a.llk_part[i];
+    {
+      const int i0 = tid + nfull * 2048;   // fewer than eight elements are left for this thread
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = a.llk_part[min(max(i0 + r * 256, 0), total - 1)];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (i0 + r * 256 < total) part[0] += v[r];
+    }
     sx = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
   }
-  for (int b = threadIdx.x; b < a.B; b += 256) {
+  if (tid < a.B) {
+    if (a.lgx1) sx -= c_lg;
+    if (a.llk_y) sy += c_y;
+    if (a.llk_o) so += c_o;
+    if (a.kl) sk += c_k;
+    if (a.kl_l) sl += c_l;
+    if (a.tc) { st += c_t; sd += c_d0 + c_d1; }
+  }
+  for (int b = tid + 256; b < a.B; b += 256) {
     if (a.lgx1) sx -= a.lgx1[a.rows ? a.rows[b] : b];
     if (a.llk_y) sy += a.llk_y[b];
     if (a.llk_o) so += a.llk_o[b];
@@ -2388,21 +2431,32 @@ __device__ inline void metrics_body(const MetricsArgs& a) {
     if (a.kl_l) sl += a.kl_l[b];
     if (a.tc) { st += a.tc[b]; sd += a.dl[b] + a.dl[a.B + b]; }
   }
-  sx = block_sum(sx, sh); sy = block_sum(sy, sh); sk = block_sum(sk, sh); sl = block_sum(sl, sh);
-  if (a.tc) { st = block_sum(st, sh); sd = block_sum(sd, sh); }
-  if (a.llk_o) so = block_sum(so, sh);
-  if (threadIdx.x == 0) {
+  // seven block sums (wave_sum, then the four waves as (0 + 1) + (2 + 3): block_sum's order) behind one pair of barriers
+  sx = wave_sum(sx); sy = wave_sum(sy); sk = wave_sum(sk); sl = wave_sum(sl); st = wave_sum(st); sd = wave_sum(sd); so = wave_sum(so);
+  __syncthreads();
+  if ((tid & 63) == 0) {
+    const int w = tid >> 6;
+    sh[0][w] = sx; sh[1][w] = sy; sh[2][w] = sk; sh[3][w] = sl; sh[4][w] = st; sh[5][w] = sd; sh[6][w] = so;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    auto tot = [&](int k) { return (sh[k][0] + sh[k][1]) + (sh[k][2] + sh[k][3]); };
+    sx = tot(0); sy = tot(1); sk = tot(2); sl = tot(3);
+    st = a.tc ? tot(4) : st; sd = a.tc ? tot(5) : sd; so = a.llk_o ? tot(6) : so;
     const float s = a.inv_global_batch;
-    a.out[0] = (a.gamma * st - (sx + so + a.alpha * sy - a.beta * (sk + sl))) * s;
-    a.out[1] = -sx * s;
-    a.out[2] = -sy * s;
-    a.out[3] = sk * s;
-    a.out[4] = sl * s;
-    a.out[5] = st * s; a.out[6] = a.tc ? (sd - a.alpha * sy) * s : 0.f; a.out[7] = -so * s;
-    if (a.hist) {
-      float* h = a.hist + (long)a.state->cursor * 8;
+    float o[8];
+    o[0] = (a.gamma * st - (sx + so + a.alpha * sy - a.beta * (sk + sl))) * s;
+    o[1] = -sx * s;
+    o[2] = -sy * s;
+    o[3] = sk * s;
+    o[4] = sl * s;
+    o[5] = st * s; o[6] = a.tc ? (sd - a.alpha * sy) * s : 0.f; o[7] = -so * s;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) h[i] = a.out[i];
+    for (int i = 0; i < 8; ++i) a.out[i] = o[i];
+    if (a.hist) {
+      float* h = a.hist + (long)cursor * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) h[i] = o[i];
     }
   }
 }
