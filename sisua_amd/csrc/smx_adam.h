@@ -88,9 +88,9 @@ __device__ inline void adam_chunk_body(const AdamArgs& a, int chunk) {
   auto fetch = [&](int j, smx_f32x4& go, smx_f32x4& mo, smx_f32x4& vo, smx_f32x4& po) {
     go = g4[j]; mo = m4[j]; vo = v4[j]; po = p4[j];
   };
+  const float lr_t = a.state->lr_t;   // (ahead of the norm's barriers: behind them it was a round trip of its own)
   if (i < n4) fetch(i, g, m, v, p);
   const float clip = adam_tensor_clip<NT>(a, ch, chunk);
-  const float lr_t = a.state->lr_t;
   while (i < n4) {
     const int j = i + NT;
     smx_f32x4 gn = g, mn = m, vn = v, pn = p;
