@@ -237,35 +237,13 @@ __device__ inline uint32_t lds_addr(const void* p) {   // byte address within th
 }
 
 // ---------------------------------------------------------------------------
-// Kernel arguments: the argument structs of the step's launches are hundreds of bytes (4 - 12 cache lines of the kernarg segment, written by the
-// host a few microseconds before the launch: cold in the scalar cache AND in L2), and the compiler loads their fields where it needs them --
-// s_load -> s_waitcnt -> branch -> s_load -> s_waitcnt ..., up to ten DEPENDENT misses at the head of a launch (the decoder's BatchNorm-forward
-// launch issued its first global load 4840 cycles = 2.3 us after entry: tools/c2_stamps.sh).  kernarg_warm<BYTES>() at the top of a kernel
-// requests every 64-byte line of the first BYTES of the segment in ONE batch (a scalar load each into a scratch register, one wait): the later
-// field loads hit the scalar cache.  One asm statement, so that no compiler-scheduled instruction reuses the scratch register while a load is
-// still on its way to it.
+// Kernel arguments: the argument structs of the step's launches are hundreds of bytes (4 - 20 cache lines of the kernarg segment), and the
+// compiler loads their fields where it needs them.
+// (A kernarg_warm<BYTES>() that requested every 64-byte line of the segment in one batch of scalar loads at kernel entry was measured -- no
+// gain: the WAITS between the lazily placed field loads are the cost, not their misses -- and removed: rounded up to whole groups of lines it read
+// past the end of a 600-byte segment, which is past the end of the runtime's kernarg pool when that launch's arguments are the pool's last:
+// a memory access fault once per few thousand launches, in whichever workload's launch sequence happened to land there.)
 // ---------------------------------------------------------------------------
-template <int BYTES>
-__device__ __forceinline__ void kernarg_warm() {
-  // (at most the first 16 lines = 1 KB)
-  const uint64_t p = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-  uint32_t d;
-#define SMX_KW(o) "s_load_dword %0, %1, " #o "\n\t"
-  if constexpr (BYTES <= 256)
-    asm volatile(SMX_KW(0x0) SMX_KW(0x40) SMX_KW(0x80) SMX_KW(0xc0) "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(p) : "memory");
-  else if constexpr (BYTES <= 512)
-    asm volatile(SMX_KW(0x0) SMX_KW(0x40) SMX_KW(0x80) SMX_KW(0xc0) SMX_KW(0x100) SMX_KW(0x140) SMX_KW(0x180) SMX_KW(0x1c0) "s_waitcnt lgkmcnt(0)"
-                 : "=&s"(d) : "s"(p) : "memory");
-  else if constexpr (BYTES <= 768)
-    asm volatile(SMX_KW(0x0) SMX_KW(0x40) SMX_KW(0x80) SMX_KW(0xc0) SMX_KW(0x100) SMX_KW(0x140) SMX_KW(0x180) SMX_KW(0x1c0) SMX_KW(0x200) SMX_KW(0x240)
-                 SMX_KW(0x280) SMX_KW(0x2c0) "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(p) : "memory");
-  else
-    asm volatile(SMX_KW(0x0) SMX_KW(0x40) SMX_KW(0x80) SMX_KW(0xc0) SMX_KW(0x100) SMX_KW(0x140) SMX_KW(0x180) SMX_KW(0x1c0) SMX_KW(0x200) SMX_KW(0x240)
-                 SMX_KW(0x280) SMX_KW(0x2c0) SMX_KW(0x300) SMX_KW(0x340) SMX_KW(0x380) SMX_KW(0x3c0) "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(p) : "memory");
-#undef SMX_KW
-  (void)d;
-}
-
 // preload(field, ...): have these kernel-argument fields in scalar registers HERE.  The compiler loads a field of a by-value argument
 // struct where it is first needed, which inside predicated code means s_load -> s_waitcnt -> use once per field and branch: a chain of
 // DEPENDENT scalar-cache round trips (~200 cycles each even when they hit; 17 of them ahead of the first global load of the decoder's

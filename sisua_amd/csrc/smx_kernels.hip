@@ -570,7 +570,7 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
 }
 
 template <int RPT, int FRONT = 0>
-__global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) { kernarg_warm<sizeof(BnFwdArgs)>(); bn_act_fwd_body<RPT, FRONT>(a, (int)blockIdx.x); }
+__global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(BnFwdArgs a) { bn_act_fwd_body<RPT, FRONT>(a, (int)blockIdx.x); }
 // two independent layers over the same minibatch in ONE launch (scvi: first layers of the encoder and of the library
 // encoder): blocks [0, na) belong to a (its column blocks, then its noise jobs), the rest to b
 template <int RPT>
@@ -806,7 +806,7 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
 }
 
 template <int RPT, int FRONT = 0>
-__global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) { kernarg_warm<sizeof(BnBwdArgs)>(); bn_act_bwd_body<RPT, FRONT>(a, (int)blockIdx.x); }
+__global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_kernel(BnBwdArgs a) { bn_act_bwd_body<RPT, FRONT>(a, (int)blockIdx.x); }
 // two independent layers in ONE launch, both with the gradient front (scvi: last layers of the encoder and of the
 // library encoder): blocks [0, na) belong to a (column blocks, then its riders), the rest to b (no riders)
 template <int RPT>
@@ -921,7 +921,6 @@ __device__ inline float wide_tree64(float p) { return wave_sum(p); }   // (lane 
 // same operations out with contraction switched off, so that the two forms stay equal bit for bit.)
 __global__ __launch_bounds__(BN_THREADS) void bn_wide_fwd_kernel(BnFwdArgs a) {
 #pragma clang fp contract(off)
-  kernarg_warm<sizeof(BnFwdArgs)>();
   const int bid = (int)blockIdx.x;
   if (bid >= a.Hp) { noise_fill(a, bid - a.Hp); return; }
   __shared__ __attribute__((aligned(16))) float sh[16 * 128];
@@ -1005,7 +1004,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_wide_fwd_kernel(BnFwdArgs a) {
 
 __global__ __launch_bounds__(BN_THREADS) void bn_wide_bwd_kernel(BnBwdArgs a) {
 #pragma clang fp contract(off)
-  kernarg_warm<sizeof(BnBwdArgs)>();
   const int bid = (int)blockIdx.x;
   {
     const int extra = bid - a.Hp;
@@ -2506,7 +2504,6 @@ __device__ inline void sq_reduce_body(const float* sl, int cnt, float* dst) {
 }
 
 __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
-  kernarg_warm<sizeof(AdamArgs)>();
   if ((int)blockIdx.x == a.n_launch && a.use_sq && a.with_metrics) {  // use_sq form: the ELBO scalars ride along here
     metrics_body(a.metrics);
     return;

@@ -42,6 +42,7 @@ __device__ inline __amdgpu_buffer_rsrc_t panel_rsrc(const void* p, long bytes) {
 // ONE: the minibatch is at most 128 cells (one chunk; a launch-time choice, so that neither form carries the other's registers)
 template <int ROLE, int MODE, int ONE>
 __device__ inline void panel_body(const PanelProblem& P, const int first, const int stride, float* smem) {
+  preload(P.big, P.ld_big, P.big_mode, P.log1p, P.rows, P.sub_stride, P.n_sub, P.S, P.ldS, P.n_st, P.out, P.ld_out, P.big_colsum, P.s_colsum, P.sq_part, P.n_wt);   // (one batch of scalar loads: smx_device.h)
   smx_bf16x8* img = reinterpret_cast<smx_bf16x8*>(smem);   // [3 terms][16 cell blocks][32 entries]
   float* ex = smem + 6144;                                  // [2 senders][4 narrow tiles][8 registers][64 lanes]
   float* cs = smem + 10240;                                 // [16 cell blocks][32 entries]
@@ -89,7 +90,7 @@ __device__ inline void panel_body(const PanelProblem& P, const int first, const 
     for (int s = 0; s < 8; ++s) rowoff[s] = (long)P.rows[min(8 * cb + s, P.B - 1)] * P.ld_big;
   }
   auto load_panel = [&](int unit, int kc, float (&bv)[8]) {
-    const int wt = unit / P.n_sub, sub = unit - wt * P.n_sub;
+    const int wt = P.n_sub == 1 ? unit : unit / P.n_sub, sub = unit - wt * P.n_sub;   // (one plane: no integer division per unit)
     const long col0 = (long)sub * P.sub_stride + wt * 32;
     if (MODE) {
 #pragma unroll
@@ -112,7 +113,7 @@ __device__ inline void panel_body(const PanelProblem& P, const int first, const 
   load_panel(first, 0, bv);
   if (one_chunk) load_narrow(0, want_ss);
   for (int unit = first; unit < n_units; unit += stride) {
-    const int wt = unit / P.n_sub, sub = unit - wt * P.n_sub;
+    const int wt = P.n_sub == 1 ? unit : unit / P.n_sub, sub = unit - wt * P.n_sub;   // (one plane: no integer division per unit)
     const int w0 = wt * 32;
     const long boff = (long)sub * P.sub_stride + w0 + i;
     smx_f32x16 acc;
