@@ -471,3 +471,24 @@ def test_wide_panel_first_step_as_a_graph(Engine):
     losses.append([e.train_step(rows, graph=graph)["loss"] for _ in range(2)])
     e.close()
   assert losses[0] == losses[1]
+
+
+@pytest.mark.parametrize("workload", ["cortex-base", "8kly-2layer", "8kly-scvi", "eccly-sisua"])
+def test_every_bench_workload_steps_through_thousands_of_launches(Engine, workload):
+  """Every workload bench.py knows (the reference's default cortex run, the two-layer network, BASELINE configs[2] / [3]) for 400 optimiser
+  steps + 100 evaluation passes = several thousand launches: finite losses, a loss that went down.  (Round 5: a kernel that read 100 bytes past
+  its argument struct was harmless until a launch's arguments were the last of the runtime's kernarg pool -- once per few thousand launches, in
+  whichever workload's launch sequence landed there: `--workload cortex-base` and none of the tests.)"""
+  import bench
+  cfg, xt, batch, extra = bench.build_workload(0, 1, workload)
+  extra.pop("cell_id_base", None)
+  e = Engine(cfg, max_batch=batch)
+  e.upload(xt, **extra)
+  order = bench.make_order(xt.shape[0], batch, 400)
+  for _ in range(100):
+    e.eval_step(order[:batch])
+  e.train_steps(order, 400, batch, graph=False)
+  h = np.asarray(e.metrics_history(400)["loss"])
+  assert np.isfinite(h).all() and h[-20:].mean() < h[:20].mean()
+  e.close()
+
