@@ -254,17 +254,17 @@ def measure_mode(cp, rank, world, local_rank, cfg, batch, steps, warmup, upload,
 # communication stream beside the rest of the step; front bucket on the model's stream), so what is left on the critical path is the front
 # bucket's all-reduce and the second queue's cost (profiles/r05_dp_overhead_one_rank.txt).
 PREDICTED_N8 = {
-    "weak": {"ms_per_step": [0.116, 0.136], "cells_per_s": [7.5e6, 8.8e6], "x_one_gpu": [4.5, 5.3],
-             "reading": "76 us of step + ~20 us for the chained data-parallel form (measured on one rank: 99.5 against 79.9 us) + a blocking all-reduce of the "
-                        "1.1 MB front bucket (latency-bound: 20-40 us expected from RCCL); the 3.1 MB head bucket has ~75 us of window (40-60 us expected): "
-                        "the >= 6.5x target (<= 93 us per step) is still NOT expected at 128 cells per GPU"},
-    "strong_syncbn": {"ms_per_step": [0.16, 0.24], "cells_per_s": [0.53e6, 0.8e6], "x_one_gpu": [0.32, 0.48],
-                      "reading": "16 cells per GPU: the step stays a chain of 11 launch-bound launches (~72 us), + the front bucket's all-reduce + 4 small "
+    "weak": {"ms_per_step": [0.102, 0.122], "cells_per_s": [8.4e6, 10.0e6], "x_one_gpu": [4.2, 5.1],
+             "reading": "65 us of step + ~17 us for the chained data-parallel form (measured on one rank: 82.8 against 65.8 us) + a blocking all-reduce of the "
+                        "1.1 MB front bucket (latency-bound: 20-40 us expected from RCCL); the 3.1 MB head bucket has ~60 us of window (40-60 us expected): "
+                        "the >= 6.5x target (<= 79 us per step) is still NOT expected at 128 cells per GPU"},
+    "strong_syncbn": {"ms_per_step": [0.15, 0.23], "cells_per_s": [0.56e6, 0.85e6], "x_one_gpu": [0.28, 0.43],
+                      "reading": "16 cells per GPU: the step stays a chain of 11 launch-bound launches (~62 us), + the front bucket's all-reduce + 4 small "
                                  "SyncBatchNorm collectives of ~10-20 us each: strong scaling at batch 128 is a slowdown, as DESIGN section 5 says"},
-    "c5": {"ms_per_step": [0.25, 0.37], "cells_per_s": [2.8e6, 4.1e6], "x_one_gpu": [3.6, 5.3],
-           "reading": "~165 us of step (172.5 us with the chain on one rank) + a blocking all-reduce of the 10.4 MB front bucket (34 us of link time at peak "
+    "c5": {"ms_per_step": [0.234, 0.354], "cells_per_s": [2.9e6, 4.4e6], "x_one_gpu": [3.3, 5.0],
+           "reading": "~144 us of step (153.7 us with the chain on one rank) + a blocking all-reduce of the 10.4 MB front bucket (34 us of link time at peak "
                       "two-shot, 80-120 us expected from RCCL's ring); the 30.7 MB head bucket runs beside the backward pass, the optimiser and the next "
-                      "step's encoder / decoder (~120 us of window: 100 us of link time at peak, 120-200 us expected from the ring -- up to ~80 us of it exposed)"},
+                      "step's encoder / decoder (~100 us of window: 100 us of link time at peak, 120-200 us expected from the ring -- up to ~80 us of it exposed)"},
 }
 
 
