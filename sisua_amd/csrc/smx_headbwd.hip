@@ -37,7 +37,7 @@ template <int NP, int SEP = 0, int B3 = 0>
 __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
   // ONE plane's eight partial tiles at a time (32 KB); the bf16 form's role 1 turns its operands through wave-private tiles
   // first (2 x 8 x 32 x 36 floats = 72 KB, the partial tiles then go over them): two workgroups per CU either way
-  __shared__ __attribute__((aligned(16))) float red[B3 ? 2 * 8 * 32 * 36 : 8 * 1024];
+  __shared__ __attribute__((aligned(16))) float red[B3 ? 2 * 8 * 32 * 36 : 2 * 8 * 1024];   // (>= two planes' eight partial tiles)
   preload(a.D, a.ldd, a.dP, a.ldp, a.W, a.ldw, a.dW, a.db, a.slab, a.slab_stride, a.B, a.Hp, a.Gp, a.n_slices, a.k_chunk, a.sq_part,
           a.n_w, a.n_ht, a.n_gt, a.n_ct, a.n_extra, a.diag, a.dd_colmajor, a.skip_dd);   // (the argument fields in one batch: smx_device.h)
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -101,19 +101,20 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
     }
     SMX_STAMP(4, 1);   // the products over the minibatch (loads in flight included)
     float sq = 0.f;
+    // planes 0 and 1 go through LDS TOGETHER (two slots of eight partial tiles), the third plane behind them: three barriers for three planes
+    // (one for two) instead of five (three); the partial tiles of a plane are added in the same order as one plane at a time
+    auto park = [&](int p, float* slot) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
+      for (int r = 0; r < 16; ++r) slot[(q * 16 + r) * 64 + lane] = acc[p][r];
+    };
+    auto finish = [&](int p, const float* slot) {
       if (SEP) sq = 0.f;
-      if (p) __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[(q * 16 + r) * 64 + lane] = acc[p][r];
-      __syncthreads();
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int r = 2 * q + j;
-        float t = red[(0 * 16 + r) * 64 + lane];
+        float t = slot[(0 * 16 + r) * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) t += red[(w * 16 + r) * 64 + lane];
+        for (int w = 1; w < 8; ++w) t += slot[(w * 16 + r) * 64 + lane];
         const int h = h0 + rowof[j];
         if (SEP) a.dWp[p][(long)h * a.ldw + g0 + i] = t;
         else a.dW[(long)h * a.ldw + (long)p * a.Gp + g0 + i] = t;   // rows >= H and columns >= G are zero by construction
@@ -123,6 +124,15 @@ __global__ __launch_bounds__(512) void out_head_bwd_kernel(HeadBwdArgs a) {
         const float sw = wave_sum(sq);
         if (lane == 0) a.sqp[p][((long)ht * a.n_gt + gt) * 8 + q] = sw;
       }
+    };
+    park(0, red); park(1, red + 8 * 1024);
+    __syncthreads();
+    finish(0, red); finish(1, red + 8 * 1024);
+    if constexpr (NP == 3) {
+      __syncthreads();
+      park(2, red);
+      __syncthreads();
+      finish(2, red);
     }
     if (!SEP && a.sq_part) {
       sq = wave_sum(sq);
