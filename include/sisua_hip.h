@@ -338,7 +338,8 @@ int smx_comm_form(const smx_model* m);
  * Parameters stay replicated and bit-identical on every rank; a rank's gradient buffer (smx_get_tensor, which = 1) holds the heads' REDUCED
  * gradient inside its slice only, and the Adam MOMENTS of the heads outside a rank's slice go stale.  smx_opt_gather
  * (a collective: every rank calls it, between training calls) all-gathers both moments, after which smx_get_tensor(which = 2 | 3) of a head
- * tensor -- refused while stale -- returns the job's moments on every rank (checkpoints).  RCCL or the loopback communicator; with the
+ * tensor -- refused while stale -- returns the job's moments on every rank (checkpoints); smx_train_steps calls it itself in front of steps that will
+ * not take the sharded chain (a captured graph, the flag switched off since).  RCCL or the loopback communicator; with the
  * hand-written exchange the flag is ignored (the all-reduce form runs). */
 int smx_opt_gather(smx_model* m);
 /* The same all-reduce as a hand-written two-shot exchange over peer-mapped buffers instead of RCCL (reduce-scatter

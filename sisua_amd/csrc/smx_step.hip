@@ -1723,6 +1723,10 @@ int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t
     SMX_REQUIRE(m->staged_steps == n_steps && m->staged_batch == batch, "order = NULL: no ids staged for this n_steps x batch (smx_train_stage)");
   }
   m->staged_steps = 0;   // (staged ids serve one call)
+  // flag opt_shard: the heads' Adam moments outside this rank's slice are stale.  Steps that will NOT take the sharded chain (a captured graph,
+  // the flag switched off since) update every element from its moments: gather them first (a collective -- every rank takes the same branch:
+  // the flag, the communicator and use_graph are the job's, not a rank's)
+  if (m->opt_stale && (use_graph || !(m->flags.opt_shard && smx::dp_chain_ok(m) && smx::dp_shard_available(m)))) SMX_CHECK(smx_opt_gather(m));
   int rc = SMX_OK;
   for (int s = 0; s < n_steps && rc == SMX_OK; ++s) rc = launch_train(m, batch, use_graph != 0, s, n_steps);
   { const int rj = smx::head_sweep_join(m); if (rc == SMX_OK) rc = rj; }   // every other entry point sees one stream

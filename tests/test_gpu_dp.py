@@ -222,7 +222,7 @@ def test_sharded_optimiser_state_matches_oracle(Engine, name, world, sync_bn):
   spec, cfg, x, ys, lib, mask = _problem(CASES[name])
   B, steps, base = 24 if world == 8 else 48, 4, 1000
   rng = np.random.default_rng(5)
-  rows = [rng.permutation(x.shape[0])[: B * world].astype(np.int32).reshape(world, B) for _ in range(steps + 1)]
+  rows = [rng.permutation(x.shape[0])[: B * world].astype(np.int32).reshape(world, B) for _ in range(steps + 2)]
   hist = {}
   for shard in (True, False):
     params = perturbed_params(spec)
@@ -257,9 +257,16 @@ def test_sharded_optimiser_state_matches_oracle(Engine, name, world, sync_bn):
     ms = run_ranks([lambda r=r: engines[r].train_step(rows[steps][r]) for r in range(world)])
     for r, m in enumerate(ms):
       assert m["step"] == steps + 1 and np.isclose(m["loss"], ref["metrics"]["loss"], rtol=RTOL, atol=1e-5), (shard, r)
-    if shard:
-      run_ranks([lambda r=r: engines[r].opt_gather() for r in range(world)])
+    # one more step with the flag switched OFF and no gather by the caller: the library brings the stale moments in before an unsharded step
+    for e in engines:
+      e.set_flag("opt_shard", False)
+    ref = so.dp_train_step(spec, params, bn, opt, x, list(rows[steps + 1]), steps + 1, cell_base=base, y=ys, library=lib, mask=mask, sync_bn=sync_bn)
+    ms = run_ranks([lambda r=r: engines[r].train_step(rows[steps + 1][r]) for r in range(world)])
+    for r, m in enumerate(ms):
+      assert m["step"] == steps + 2 and np.isclose(m["loss"], ref["metrics"]["loss"], rtol=RTOL, atol=1e-5), (shard, r)
     finals = [(e.get_params(), e.get_params(which=2), e.get_params(which=3)) for e in engines]
+    em, ev, where = adam_state_errors(engines[0], opt)
+    assert em < 2e-3 and ev < 4e-3, (shard, em, ev, where)
     worst = grad_errors(finals[0][0], params)
     assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
     for which in range(3):
