@@ -354,6 +354,11 @@ __global__ __launch_bounds__(256) void score_head_kernel(ScoreHeadArgs a) {
   }
 
   // ---- likelihood of the wave's 32 x 32 tile: register r of plane p is row (r & 3) + 8 (r >> 2) + 4 h, column i ----
+  // lgamma(x + r) - lgamma(r) through the per-wave queue of the NON-ZERO counts (smx_loss.h: 88-93 % of the counts are zero, for which the
+  // straight-line form still runs its 8-step recurrence -- a third of this kernel's vector instructions); the queue takes the place of the W
+  // image, which every wave has finished with behind this barrier (knob no_score_queue: the straight-line form)
+  __syncthreads();
+  float2* const lq = a.no_queue ? nullptr : reinterpret_cast<float2*>(bl);
   float bias[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) bias[p] = a.bias[(long)p * a.Gp + col];
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(256) void score_head_kernel(ScoreHeadArgs a) {
       p2[j] = NP == 3 ? acc[NP - 1][c + j] + bias[NP - 1] : 0.f;
     }
     typedef float Vec[8];
-    count_elem_vec<LK, 0, 8>(*(const Vec*)(xs + c), p0, p1, p2, *(Vec*)(L + c), d0, d1, d2);
+    count_elem_vec<LK, 0, 8>(*(const Vec*)(xs + c), p0, p1, p2, *(Vec*)(L + c), d0, d1, d2, lq);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) L[r] = live ? L[r] : 0.f;
@@ -410,13 +415,16 @@ bool score_head_supported(int Hp, int Gp) { return Hp > 0 && Hp % 32 == 0 && Hp 
 template <int LK, int NSLAB>
 static int launch_score_head_t(hipStream_t st, const ScoreHeadArgs& a, dim3 grid) {
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
-  constexpr size_t lds = (size_t)NSLAB * 3 * NP * 128 * 16;
+  constexpr size_t lds0 = (size_t)NSLAB * 3 * NP * 128 * 16;
+  constexpr size_t lds = lds0 > 4 * 64 * 8 * sizeof(float2) ? lds0 : 4 * 64 * 8 * sizeof(float2);   // (the W image, then the four waves' non-zero queues)
   static bool raised = false;   // (above 64 KB of dynamic LDS a kernel needs the attribute once)
   if (!raised && lds > 64 * 1024) {
     SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_head_kernel<LK, NSLAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     raised = true;
   }
-  hipLaunchKernelGGL((score_head_kernel<LK, NSLAB>), grid, dim3(256), lds, st, a);
+  ScoreHeadArgs b = a;
+  b.no_queue = tuning_on("no_score_queue") ? 1 : 0;
+  hipLaunchKernelGGL((score_head_kernel<LK, NSLAB>), grid, dim3(256), lds, st, b);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
