@@ -524,6 +524,7 @@ int smx_set_tensor(smx_model* m, int which, int index, const float* host) {
   pack(t, host, dev);
   SMX_HIP(hipStreamSynchronize(m->st));
   SMX_HIP(hipMemcpy(base + t.offset, dev.data(), t.count * sizeof(float), hipMemcpyHostToDevice));
+  if (which == 0) ++m->params_epoch;
   return SMX_OK;
 }
 

@@ -1728,6 +1728,7 @@ int smx_train_steps(smx_model* m, const int32_t* order, int32_t n_steps, int32_t
   // the flag, the communicator and use_graph are the job's, not a rank's)
   if (m->opt_stale && (use_graph || !(m->flags.opt_shard && smx::dp_chain_ok(m) && smx::dp_shard_available(m)))) SMX_CHECK(smx_opt_gather(m));
   int rc = SMX_OK;
+  ++m->params_epoch;   // (the parameters are about to change)
   for (int s = 0; s < n_steps && rc == SMX_OK; ++s) rc = launch_train(m, batch, use_graph != 0, s, n_steps);
   { const int rj = smx::head_sweep_join(m); if (rc == SMX_OK) rc = rj; }   // every other entry point sees one stream
   if (rc != SMX_OK) return rc;

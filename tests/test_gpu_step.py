@@ -597,6 +597,37 @@ def test_hip_matches_committed_trajectory_fixture(Engine):
   e.close()
 
 
+
+def test_scoring_head_images_follow_the_parameters(Engine):
+  """The scoring head's bf16 x 3 images of W_out are kept while the parameters stand (a scoring sweep over a dataset splits W once) and rebuilt
+  when they move: after optimiser steps, and after set_params, marginal_llk equals -- bit for bit -- what the same engine gives with the images
+  rebuilt on every call (knob no_wimg_cache)."""
+  from sisua_amd import _hip
+  spec, cfg, x, ys, lib, mask = _problem(dict(CASES["vae_zinb"], labels=()))
+  e = Engine(cfg, max_batch=64)
+  e.upload(x, ys, lib, mask)
+  rows = np.arange(10, 58, dtype=np.int32)
+
+  def both():
+    a = e.marginal_llk(row_ids=rows, n_samples=8)
+    b = e.marginal_llk(row_ids=rows, n_samples=8)   # (a second call: served from the kept images)
+    _hip.set_tuning("no_wimg_cache", 1)
+    try:
+      c = e.marginal_llk(row_ids=rows, n_samples=8)
+    finally:
+      _hip.set_tuning("no_wimg_cache", 0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    return a[0]
+  m0 = both()
+  e.train_steps(np.arange(64 * 3, dtype=np.int32) % x.shape[0], 3, 64)
+  m1 = both()
+  assert not np.array_equal(m0, m1)
+  e.set_params(perturbed_params(spec))
+  m2 = both()
+  assert not np.array_equal(m1, m2)
+  e.close()
+
+
 @pytest.mark.parametrize("name", ["vae_zinb", "scvi_zinbd", "dca_zinb", "scale", "scale_tril", "scale_post"])
 def test_marginal_llk_matches_oracle(Engine, name):
   """importance-weighted log p(x) (posterior.py:941-976) on the GPU vs the oracle."""
