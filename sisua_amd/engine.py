@@ -548,7 +548,7 @@ class Engine:
 
   def set_flag(self, name: str, value: bool):
     """Code-path switch (smx_set_flag).  Training step: head_loss, head_fused, head_sweep, front, bwd_front, head_bwd, wgrad, scvi_fused, twin, label_ride,
-    act_epilogue; scoring: stacked_scoring; "bf16x3" (products of the output head from bf16 MFMAs on three-way split operands):
+    act_epilogue; data parallel: opt_shard (the heads' optimiser state sharded over the ranks; opt_gather()); scoring: stacked_scoring; "bf16x3" (products of the output head from bf16 MFMAs on three-way split operands):
     True / False, or -1 for the default (by the head's width)."""
     v = -1 if (name == "bf16x3" and not isinstance(value, bool) and int(value) < 0) else int(bool(value))
     check(self.lib.smx_set_flag(self._h, name.encode(), v))
