@@ -43,8 +43,15 @@ __global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
   const long src = a.rows ? a.rows[b] : b;
   const long xsrc = a.x_identity ? b : src;
   const float* raw = a.raw + (long)b * a.ld;
-  // ---- every load of the row first: raw planes and the cell's counts ------------------------------------------------
+  // ---- every load of the row first: raw planes and the cell's counts; what thread 0 needs for the library latent beside them (the prior's
+  // moments, the head's biases, injected noise: read where they were used -- behind the wave's dot products -- each was a round trip of its own on
+  // the path every wave then waits for at the row maximum's barrier) -----------------------------------------------------------------
+  const float bl0 = a.bl[0], bl1 = a.bl[1];
+  const float mp_in = a.library[src * 2], vp_in = a.library[src * 2 + 1];
+  float eps_in = 0.f;
+  if (a.inj_eps) eps_in = a.inj_eps[(long)b * a.inj_ld];
   float4 r0[NV], r1[NV], r2[NV], xv[NV];
+  ushort4 xh[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int g = (threadIdx.x + 256 * j) * 4;
@@ -52,29 +59,33 @@ __global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
     r0[j] = ok ? *reinterpret_cast<const float4*>(raw + g) : zero4();
     r1[j] = ok ? *reinterpret_cast<const float4*>(raw + a.plane_stride + g) : zero4();
     r2[j] = (ok && K3) ? *reinterpret_cast<const float4*>(raw + 2 * a.plane_stride + g) : zero4();
-    if (U16) {
-      const ushort4 h = ok ? *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(a.X) + xsrc * a.ldx + g) : make_ushort4(0, 0, 0, 0);
-      xv[j] = make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
-    } else {
-      xv[j] = ok ? *reinterpret_cast<const float4*>(a.X + xsrc * a.ldx + g) : zero4();
-    }
+    if (U16) xh[j] = ok ? *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(a.X) + xsrc * a.ldx + g) : make_ushort4(0, 0, 0, 0);
+    else xv[j] = ok ? *reinterpret_cast<const float4*>(a.X + xsrc * a.ldx + g) : zero4();
   }
   // ---- library latent of this cell (wave 0; its loads overlap the row's) ----------------------------------------------
   float mu_l = 0.f, sraw_l = 0.f, sig_l = 1.f, eps_l = 0.f, mp = 0.f, vp = 1.f;
   if (threadIdx.x < 64) {
     float p0 = 0.f, p1 = 0.f;
-    for (int k = threadIdx.x; k < a.Kl; k += 64) {
-      const float h = a.hl[(long)b * a.ldh + k];
-      const float2 w = *reinterpret_cast<const float2*>(a.Wl + (long)k * a.ldwl);
-      p0 = fmaf(h, w.x, p0); p1 = fmaf(h, w.y, p1);
+    // (a lane's elements k = lane, lane + 64, ... four at a time in flight; the multiply-adds keep their order)
+    for (int k0 = threadIdx.x; k0 < a.Kl; k0 += 256) {
+      float hv[4]; float2 wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = min(k0 + 64 * u, a.Kl - 1);
+        hv[u] = a.hl[(long)b * a.ldh + k];
+        wv[u] = *reinterpret_cast<const float2*>(a.Wl + (long)k * a.ldwl);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k0 + 64 * u < a.Kl) { p0 = fmaf(hv[u], wv[u].x, p0); p1 = fmaf(hv[u], wv[u].y, p1); }
     }
     p0 = wave_sum(p0); p1 = wave_sum(p1);
     if (threadIdx.x == 0) {
-      mu_l = p0 + a.bl[0]; sraw_l = p1 + a.bl[1];
+      mu_l = p0 + bl0; sraw_l = p1 + bl1;
       sig_l = softplusf(sraw_l + SMX_SOFTPLUS_INV_1);
-      if (a.inj_eps) eps_l = a.inj_eps[(long)b * a.inj_ld];
+      if (a.inj_eps) eps_l = eps_in;
       else eps_l = normal4(philox_block(a.nk, a.cell_base + (uint32_t)src, 0u)).x;
-      mp = a.library[src * 2]; vp = a.library[src * 2 + 1];
+      mp = mp_in; vp = vp_in;
       const float sp = sqrtf(vp);
       const float l = mu_l + sig_l * eps_l;
       a.l[b] = l; a.sig[b] = sig_l; a.eps[b] = eps_l;
@@ -82,6 +93,10 @@ __global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
       a.latl[(long)b * a.ldl] = mu_l; a.latl[(long)b * a.ldl + 1] = sraw_l;
       shl[0] = l;
     }
+  }
+  if (U16) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) xv[j] = make_float4((float)xh[j].x, (float)xh[j].y, (float)xh[j].z, (float)xh[j].w);
   }
   // ---- softmax over the genes (row max, row sum) ----------------------------------------------------------------------
   float mx = -3.0e38f;
