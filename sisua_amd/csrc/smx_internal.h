@@ -573,7 +573,9 @@ int head_fused_min_genes();   // (knob head_fused_min_genes; smx_headfused.hip)
 // 64 -> 176-215 (the next output head waits for the sweep), 96 -> 178-182, 128 -> 175.3-176.3, 160 -> 177.5-181, 192 -> 176.8, 256 -> 182.2,
 // 512 -> 185.7, 1024 -> 191.1 (the small dependent launches beside it slow down by more than it hides)
 #define SMX_HEAD_SWEEP_MIN_CHUNKS 1536
-#define SMX_HEAD_SWEEP_CHUNKS_PER_WG 15   // padded genes from which the fused form replaces fused head + bigk (d d) + panel (dW)
+// (end of round 5, the window between two output heads ~25 us shorter: 126 -> 144.8 us, 104 -> 143.1, 96 -> 144.2, 88 -> 142.8-146.4, 80 -> 147.5, 72 -> 152-154:
+// one workgroup per 18 chunks = 105)
+#define SMX_HEAD_SWEEP_CHUNKS_PER_WG 18
 struct HeadFusedArgs {
   const float* D = nullptr; int ldd = 0;            // decoder output [B][ldd], 128 columns
   const float* W = nullptr; long ldw = 0;           // [128][k * Gp]
