@@ -287,6 +287,9 @@ __device__ inline float lane_bcast(float v, int l) { return __builtin_bit_cast(f
 // halves between two registers holding the same value, after which their sum is what `v + __shfl_xor(v, 16 | 32)` gives (the same two
 // addends in every lane: the same bits; tools/dev/permlane_sum.hip).  Inline asm with the hazard's wait states spelled out: given the SAME
 // value for both operands the builtins (ROCm 7.2) return the first register twice.
+// Callers: the rows that trade places must be active together.  Every early `return` ahead of a wave_sum / half_wave_sum in csrc/ is
+// wave-uniform (one wave per cell or row, or a block-uniform test), except the factor kernels' `r >= 2 * B`, where whole half-waves
+// leave and half_wave_sum's row swap stays inside the half that remains.
 __device__ inline float xor16_add(float v) {
   unsigned a = __builtin_bit_cast(unsigned, v), b = a;
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
