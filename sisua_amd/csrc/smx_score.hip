@@ -283,68 +283,10 @@ int launch_score_split_w(hipStream_t st, const ScoreSplitWArgs& a) {
   return SMX_OK;
 }
 
-template <int LK, int NSLAB>
-__global__ __launch_bounds__(256) void score_head_kernel(ScoreHeadArgs a) {
-  constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
-  constexpr int UNITS = 3 * NP * 128;             // 16-byte units of one slab image
-  constexpr int ALL = NSLAB * UNITS;              // ... of the gene tile's whole K (72 KB at Hp = 128 with 3 planes)
-  extern __shared__ uint4 bl[];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = lane & 31, h = lane >> 5;
-  // blocks 8 apart share an XCD: they take the row blocks of ONE gene tile (its W images stay in that L2), in groups
-  // of row blocks over which ALL of the XCD's gene tiles pass before the next group (A stays in the L2 meanwhile)
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int per_grp = a.rb_group * a.gt_per_xcd;
-  const int grp = idx / per_grp, rem = idx % per_grp;
-  const int rb = grp * a.rb_group + rem % a.rb_group, gt = (rem / a.rb_group) * 8 + xcd;
-  if (gt >= a.n_gt || rb >= a.n_rb) return;
-  const int m0 = rb * 128 + 32 * w, n0 = gt * 32, col = n0 + i;
-  const int arow = min(m0 + i, a.R - 1);   // rows beyond the pass compute garbage that is never stored
-  const uint4* wimg = reinterpret_cast<const uint4*>(a.Wimg) + (long)gt * ALL;
-  const long aterm = (long)a.R * a.Hp;   // bf16 elements between the terms of A
-
-  // ---- every load of the tile is requested up front (K <= 128: the whole W image of the gene tile fits in LDS and the
-  // wave's A operand in registers).  A memory round trip under this load takes ~3 us, longer than the MFMAs of a slab:
-  // a slab-by-slab pipeline waited for it once per slab; this way a workgroup waits once and the CU's other workgroup
-  // computes meanwhile ----
-  // W image: global -> LDS directly (no staging registers; one wave-instruction moves 1 KB to wave-uniform base + 16 lane)
-  constexpr int UPT = (ALL + 255) / 256;
-#pragma unroll
-  for (int u = 0; u < UPT; ++u) {
-    const int q0 = u * 256 + w * 64;   // first unit of this wave's piece (ALL is a multiple of 64)
-    if (q0 < ALL)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wimg + q0 + lane),
-                                       (__attribute__((address_space(3))) void*)(bl + q0), 16, 0, 0);
-  }
-  uint4 av[NSLAB][3][2];
-  {
-    const __bf16* ap = a.A3 + (long)arow * a.Hp + 8 * h;
-#pragma unroll
-    for (int t = 0; t < NSLAB; ++t)
-#pragma unroll
-      for (int T = 0; T < 3; ++T)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) av[t][T][n] = *reinterpret_cast<const uint4*>(ap + T * aterm + 32 * t + 16 * n);
-  }
-  // the counts of the wave's 16 rows x this column
-  float xs[16];
-  {
-    const int base = m0 % a.row_mod;
-    int src[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int cell = base + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (cell >= a.row_mod) cell -= a.row_mod;
-      if (cell >= a.row_mod) cell %= a.row_mod;   // (fewer than 32 cells per draw)
-      src[r] = a.rows ? a.rows[cell] : cell;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      xs[r] = a.x_u16 ? (float)reinterpret_cast<const uint16_t*>(a.X)[(long)src[r] * a.ldx + col] : a.X[(long)src[r] * a.ldx + col];
-  }
-  __syncthreads();   // (waits for this wave's loads -- the image pieces included -- then for the other waves')
-
-  f32x16 acc[NP];
+// The products of one wave's 32 x 32 tile from the W image in LDS and the wave's A operand in registers (smallest terms first).
+template <int NP, int NSLAB>
+__device__ inline void score_products(const uint4* bl, const uint4 (&av)[NSLAB][3][2], f32x16 (&acc)[NP], int i, int h) {
+  constexpr int UNITS = 3 * NP * 128;
 #pragma unroll
   for (int p = 0; p < NP; ++p)
 #pragma unroll
@@ -372,17 +314,14 @@ __global__ __launch_bounds__(256) void score_head_kernel(ScoreHeadArgs a) {
         acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[p], 0, 0, 0);
       }
   }
-
-  // ---- likelihood of the wave's 32 x 32 tile: register r of plane p is row (r & 3) + 8 (r >> 2) + 4 h, column i ----
-  // lgamma(x + r) - lgamma(r) through the per-wave queue of the NON-ZERO counts (smx_loss.h: 88-93 % of the counts are zero, for which the
-  // straight-line form still runs its 8-step recurrence -- a third of this kernel's vector instructions); the queue takes the place of the W
-  // image, which every wave has finished with behind this barrier (knob no_score_queue: the straight-line form)
-  __syncthreads();
-  float2* const lq = a.no_queue ? nullptr : reinterpret_cast<float2*>(bl);
-  float bias[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) bias[p] = a.bias[(long)p * a.Gp + col];
-  const bool live = col < a.G;
+}
+// The likelihood of the wave's 32 x 32 tile and its per-row sums over the 32 columns: register r of plane p is row (r & 3) + 8 (r >> 2) + 4 h, column i.
+// lgamma(x + r) - lgamma(r) through the per-wave queue of the NON-ZERO counts (smx_loss.h: 88-93 % of the counts are zero, for which the
+// straight-line form still runs its 8-step recurrence -- a third of the vector instructions; lq == nullptr: the straight-line form)
+// (mid: called between the two halves of the tile, when the first half's accumulators are dead)
+template <int LK, int NP, class Mid>
+__device__ inline void score_tile_llk(const ScoreHeadArgs& a, const f32x16 (&acc)[NP], const float (&xs)[16], const float (&bias)[NP], bool live,
+                                      float2* lq, int i, int h, int m0, int gt, Mid mid) {
   float L[16];
 #pragma unroll
   for (int c = 0; c < 16; c += 8) {
@@ -395,6 +334,7 @@ __global__ __launch_bounds__(256) void score_head_kernel(ScoreHeadArgs a) {
     }
     typedef float Vec[8];
     count_elem_vec<LK, 0, 8>(*(const Vec*)(xs + c), p0, p1, p2, *(Vec*)(L + c), d0, d1, d2, lq);
+    if (c == 0) mid();
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) L[r] = live ? L[r] : 0.f;
@@ -429,32 +369,222 @@ __global__ __launch_bounds__(256) void score_head_kernel(ScoreHeadArgs a) {
     if ((i & 1) == 0 && row < a.R) a.llk_part[(long)row * a.n_gt + gt] = tot;
   }
 }
+// the counts of a wave's 16 rows (of its 32: the lane half's) x its column, in two steps: the cells' dataset rows (to be requested BEFORE the tile's other
+// loads: the counts' addresses wait for them, and a wait for the youngest request is a wait for everything in front of it), then the counts.  The storage
+// format's branch is outside the loops: inside them it put a branch and a wait between every two requests (sixteen round trips in a row for u16 counts).
+__device__ inline void score_count_rows(const ScoreHeadArgs& a, int m0, int h, int (&src)[16]) {
+  const int base = m0 % a.row_mod;
+  int cell[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    cell[r] = base + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (cell[r] >= a.row_mod) cell[r] -= a.row_mod;
+    if (cell[r] >= a.row_mod) cell[r] %= a.row_mod;   // (fewer than 32 cells per draw)
+  }
+  // (no branch on `rows`: behind a join the compiler's wait for these requests becomes a wait for every request in flight -- the image and the A operand,
+  // issued after them, included -- and the counts' requests, which need these, would leave one round trip late.  Without the table: a load of word 0 of the counts, unused)
+  const bool tab = a.rows != nullptr;
+  const int32_t* rp = tab ? a.rows : reinterpret_cast<const int32_t*>(a.X);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) src[r] = rp[tab ? cell[r] : 0];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) src[r] = tab ? src[r] : cell[r];
+}
+__device__ inline void score_count_values(const ScoreHeadArgs& a, const int (&src)[16], int col, float (&xs)[16]) {
+  if (a.x_u16) {
+    const uint16_t* X = reinterpret_cast<const uint16_t*>(a.X);
+    uint16_t raw[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) raw[r] = X[(long)src[r] * a.ldx + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xs[r] = (float)raw[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xs[r] = a.X[(long)src[r] * a.ldx + col];
+  }
+}
+
+template <int LK, int NSLAB>
+__global__ __launch_bounds__(256) void score_head_kernel(ScoreHeadArgs a) {
+  constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
+  constexpr int UNITS = 3 * NP * 128;             // 16-byte units of one slab image
+  constexpr int ALL = NSLAB * UNITS;              // ... of the gene tile's whole K (72 KB at Hp = 128 with 3 planes)
+  extern __shared__ uint4 bl[];
+  const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3;
+  const int i = lane & 31, h = lane >> 5;
+  // blocks 8 apart share an XCD: they take the row blocks of ONE gene tile (its W images stay in that L2), in groups
+  // of row blocks over which ALL of the XCD's gene tiles pass before the next group (A stays in the L2 meanwhile)
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int per_grp = a.rb_group * a.gt_per_xcd;
+  const int grp = idx / per_grp, rem = idx % per_grp;
+  const int rb = grp * a.rb_group + rem % a.rb_group, gt = (rem / a.rb_group) * 8 + xcd;
+  if (gt >= a.n_gt || rb >= a.n_rb) return;
+  const int m0 = rb * 128 + 32 * w, n0 = gt * 32, col = n0 + i;
+  const int arow = min(m0 + i, a.R - 1);   // rows beyond the pass compute garbage that is never stored
+  const uint4* wimg = reinterpret_cast<const uint4*>(a.Wimg) + (long)gt * ALL;
+  const long aterm = (long)a.R * a.Hp;   // bf16 elements between the terms of A
+
+  // ---- every load of the tile is requested up front (K <= 128: the whole W image of the gene tile fits in LDS and the
+  // wave's A operand in registers).  A memory round trip under this load takes ~3 us, longer than the MFMAs of a slab:
+  // a slab-by-slab pipeline waited for it once per slab; this way a workgroup waits once and the CU's other workgroup
+  // computes meanwhile ----
+  int src[16];
+  score_count_rows(a, m0, h, src);
+  // W image: global -> LDS directly (no staging registers; one wave-instruction moves 1 KB to wave-uniform base + 16 lane)
+  // (no branch around a last partial round -- a piece beyond the image re-reads its last unit into the slack the launcher allocates behind it: behind a
+  // join the compiler's waits count nothing and become waits for everything)
+  constexpr int UPT = (ALL + 255) / 256;
+#pragma unroll
+  for (int u = 0; u < UPT; ++u) {
+    const int q0 = u * 256 + w * 64;   // first unit of this wave's piece (ALL is a multiple of 64)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wimg + min(q0 + lane, ALL - 1)),
+                                     (__attribute__((address_space(3))) void*)(bl + q0), 16, 0, 0);
+  }
+  uint4 av[NSLAB][3][2];
+  {
+    const __bf16* ap = a.A3 + (long)arow * a.Hp + 8 * h;
+#pragma unroll
+    for (int t = 0; t < NSLAB; ++t)
+#pragma unroll
+      for (int T = 0; T < 3; ++T)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) av[t][T][n] = *reinterpret_cast<const uint4*>(ap + T * aterm + 32 * t + 16 * n);
+  }
+  __builtin_amdgcn_sched_barrier(0);   // (the counts' addresses, which wait for the rows, behind the requests above)
+  float xs[16];
+  score_count_values(a, src, col, xs);
+  __syncthreads();   // (waits for this wave's loads -- the image pieces included -- then for the other waves')
+
+  f32x16 acc[NP];
+  score_products<NP, NSLAB>(bl, av, acc, i, h);
+
+  // the queue takes the place of the W image, which every wave has finished with behind this barrier (knob no_score_queue: the straight-line form)
+  __syncthreads();
+  float2* const lq = a.no_queue ? nullptr : reinterpret_cast<float2*>(bl);
+  float bias[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) bias[p] = a.bias[(long)p * a.Gp + col];
+  score_tile_llk<LK, NP>(a, acc, xs, bias, col < a.G, lq, i, h, m0, gt, [] {});
+}
+
+// The same tiles as a WALK: a workgroup of eight waves keeps its gene tile's W image in LDS and walks a range of 256-row blocks under it.  The wave's A
+// operand of the NEXT block is requested as soon as the products of this one have issued (the registers are free from then on) and lands
+// during the likelihood, so no wave waits for memory inside the walk; there is no workgroup barrier inside it either (the queue is each wave's own
+// and sits behind the image), so the two waves of a SIMD drift apart and one's products run beside the other's likelihood.  score_head_kernel
+// reloads 168 KB per 128 x 32 tile (1.06 GB per launch of 128 cells x 100 draws x 1998 genes) and its workgroup pairs keep step with each other:
+// load, products and likelihood of both follow one another (32 k cycles per pair of tiles against 23 k of issue).
+template <int LK, int NSLAB>
+__global__ __launch_bounds__(512) void score_walk_kernel(ScoreHeadArgs a) {
+  constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
+  constexpr int UNITS = 3 * NP * 128;
+  constexpr int ALL = NSLAB * UNITS;
+  extern __shared__ uint4 bl[];   // the image, then the eight waves' queues
+  const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 7;
+  const int i = lane & 31, h = lane >> 5;
+  // blocks 8 apart share an XCD: it takes a contiguous stretch of the (row range, gene tile) pairs in row-range-major order, so that the A rows
+  // its workgroups walk are the same few MB of its L2
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int pair = xcd * a.wg_per_xcd + idx;
+  if (idx >= a.wg_per_xcd || pair >= a.n_gt * a.n_split) return;
+  const int split = pair / a.n_gt, gt = pair - split * a.n_gt;
+  const int rb0 = (int)((long)split * a.n_rb / a.n_split), rb1 = (int)((long)(split + 1) * a.n_rb / a.n_split);   // (n_rb: blocks of 256 rows here)
+  const int col = gt * 32 + i;
+  const uint4* wimg = reinterpret_cast<const uint4*>(a.Wimg) + (long)gt * ALL;
+  const long aterm = (long)a.R * a.Hp;
+  int src[16];
+  score_count_rows(a, rb0 * 256 + 32 * w, h, src);
+  constexpr int UPT = (ALL + 511) / 512, ALLP = UPT * 512;   // (the image's slack, as in score_head_kernel)
+#pragma unroll
+  for (int u = 0; u < UPT; ++u) {
+    const int q0 = u * 512 + w * 64;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wimg + min(q0 + lane, ALL - 1)),
+                                     (__attribute__((address_space(3))) void*)(bl + q0), 16, 0, 0);
+  }
+  uint4 av[NSLAB][3][2];
+  // (with four slabs the last one's registers are requested at the top of the block instead, behind three slabs' MFMAs (~1.5 us): all four held through the
+  // likelihood spilled, and so did requesting them between its halves -- an accumulator tuple stays allocated until its last element is read)
+  constexpr int NEARLY = NSLAB == 4 ? 3 : NSLAB;
+  auto load_a = [&](int rb, int t_lo, int t_hi) {
+    const int arow = min(rb * 256 + 32 * w + i, a.R - 1);   // rows beyond the pass compute garbage that is never stored
+    const __bf16* ap = a.A3 + (long)arow * a.Hp + 8 * h;
+#pragma unroll
+    for (int t = t_lo; t < t_hi; ++t)
+#pragma unroll
+      for (int T = 0; T < 3; ++T)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) av[t][T][n] = *reinterpret_cast<const uint4*>(ap + T * aterm + 32 * t + 16 * n);
+  };
+  load_a(rb0, 0, NEARLY);
+  __builtin_amdgcn_sched_barrier(0);   // (the counts' addresses, which wait for the rows, behind the requests above)
+  float xs[16];
+  int base = (rb0 * 256 + 32 * w) % a.row_mod;
+  score_count_values(a, src, col, xs);
+  float bias[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) bias[p] = a.bias[(long)p * a.Gp + col];
+  const bool live = col < a.G;
+  float2* const lq = a.no_queue ? nullptr : reinterpret_cast<float2*>(bl + ALLP);
+  __syncthreads();   // (the image: this wave's pieces, then the other waves')
+  if (w >= 4)   // the second wave of every SIMD starts its products when the first starts its likelihood
+    for (int k = 0; k < a.dephase; ++k) __builtin_amdgcn_s_sleep(8);
+  for (int rb = rb0; rb < rb1; ++rb) {
+    const int m0 = rb * 256 + 32 * w;
+    if (m0 >= a.R) break;   // (wave-uniform: the last block's waves beyond the pass)
+    f32x16 acc[NP];
+    if (NEARLY < NSLAB) {
+      load_a(rb, NEARLY, NSLAB);
+      __builtin_amdgcn_sched_barrier(0);   // (the requests stay here: the scheduler would sink them to their first use)
+    }
+    score_products<NP, NSLAB>(bl, av, acc, i, h);
+    if (rb + 1 < rb1) load_a(rb + 1, 0, NEARLY);
+    __builtin_amdgcn_sched_barrier(0);
+    score_tile_llk<LK, NP>(a, acc, xs, bias, live, lq, i, h, m0, gt, [] {});
+    // (the counts repeat from block to block when 256 is a multiple of the cells per draw: the usual case)
+    const int base_n = (m0 + 256) % a.row_mod;
+    if (rb + 1 < rb1 && base_n != base) {
+      score_count_rows(a, m0 + 256, h, src);
+      score_count_values(a, src, col, xs);
+      base = base_n;
+    }
+  }
+}
 
 bool score_head_supported(int Hp, int Gp) { return Hp > 0 && Hp % 32 == 0 && Hp <= 128 && Gp % 32 == 0; }
 
 template <int LK, int NSLAB>
-static int launch_score_head_t(hipStream_t st, const ScoreHeadArgs& a, dim3 grid) {
+static int launch_score_head_t(hipStream_t st, const ScoreHeadArgs& a, dim3 grid, bool walk) {
   constexpr int NP = (LK == SMX_LLK_ZINB || LK == SMX_LLK_ZINBD) ? 3 : 2;
-  constexpr size_t lds0 = (size_t)NSLAB * 3 * NP * 128 * 16;
+  constexpr size_t units = (size_t)NSLAB * 3 * NP * 128;
+  constexpr size_t lds0 = (units + 255) / 256 * 256 * 16;   // (whole rounds of the workgroup's pieces: the kernels' slack)
   constexpr size_t lds = lds0 > 4 * 64 * 8 * sizeof(float2) ? lds0 : 4 * 64 * 8 * sizeof(float2);   // (the W image, then the four waves' non-zero queues)
-  static bool raised = false;   // (above 64 KB of dynamic LDS a kernel needs the attribute once)
+  constexpr size_t lds_walk = (units + 511) / 512 * 512 * 16 + 8 * 64 * 8 * sizeof(float2);          // (the W image and, behind it, the eight waves' queues)
+  static bool raised = false, raised_walk = false;   // (above 64 KB of dynamic LDS a kernel needs the attribute once)
+  ScoreHeadArgs b = a;
+  b.no_queue = tuning_on("no_score_queue") ? 1 : 0;
+  if (walk) {
+    if (!raised_walk && lds_walk > 64 * 1024) {
+      SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_walk_kernel<LK, NSLAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk));
+      raised_walk = true;
+    }
+    hipLaunchKernelGGL((score_walk_kernel<LK, NSLAB>), grid, dim3(512), lds_walk, st, b);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+  }
   if (!raised && lds > 64 * 1024) {
     SMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_head_kernel<LK, NSLAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     raised = true;
   }
-  ScoreHeadArgs b = a;
-  b.no_queue = tuning_on("no_score_queue") ? 1 : 0;
   hipLaunchKernelGGL((score_head_kernel<LK, NSLAB>), grid, dim3(256), lds, st, b);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
 template <int LK>
-static int launch_score_head_lk(hipStream_t st, const ScoreHeadArgs& a, dim3 grid) {
+static int launch_score_head_lk(hipStream_t st, const ScoreHeadArgs& a, dim3 grid, bool walk) {
   switch (a.Hp / 32) {
-    case 1: return launch_score_head_t<LK, 1>(st, a, grid);
-    case 2: return launch_score_head_t<LK, 2>(st, a, grid);
-    case 3: return launch_score_head_t<LK, 3>(st, a, grid);
-    default: return launch_score_head_t<LK, 4>(st, a, grid);
+    case 1: return launch_score_head_t<LK, 1>(st, a, grid, walk);
+    case 2: return launch_score_head_t<LK, 2>(st, a, grid, walk);
+    case 3: return launch_score_head_t<LK, 3>(st, a, grid, walk);
+    default: return launch_score_head_t<LK, 4>(st, a, grid, walk);
   }
 }
 
@@ -464,20 +594,45 @@ int launch_score_head(hipStream_t st, const ScoreHeadArgs& a_in) {
     set_error("score_head: bad shapes");
     return SMX_ERR_INVALID;
   }
-  a.n_rb = (a.R + 127) / 128;
   a.n_gt = a.Gp / 32;
-  // (row blocks per L2 group: measured 4 / 8 / 16 / 32 / all within 3 % of each other once the loads are issued up
-  // front -- the A operand's re-reads are served by the Infinity Cache at no visible cost; default: one group)
-  static const int rbg = std::max(1, (int)tuning("score_rb_group", (double)(1 << 30)));
-  a.rb_group = std::min(rbg, a.n_rb);
-  a.gt_per_xcd = (a.n_gt + 7) / 8;
-  const int n_grp = (a.n_rb + a.rb_group - 1) / a.rb_group;
-  const dim3 grid((unsigned)(8 * n_grp * a.rb_group * a.gt_per_xcd));
+  // The walk (score_walk_kernel) from three 256-row blocks per workgroup up: every gene tile's rows in n_split ranges, chosen so that the
+  // workgroups fill the 256 CUs (one workgroup per CU: 72 KB of image + 32 KB of queues) in whole rounds as nearly as they can.
+  const int walk_knob = (int)tuning("score_walk", -1.0);   // 0: never; n > 0: n ranges
+  const int dephase = (int)tuning("score_walk_dephase", 0.0);
+  const int n_rb256 = (a.R + 255) / 256;
+  int n_split = 0;
+  if (walk_knob != 0 && n_rb256 >= 3) {
+    double best = -1.0;
+    for (int s = 1; s <= 8 && 3 * s <= n_rb256; ++s) {
+      const long wgs = (long)a.n_gt * s;
+      const double fill = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+      if (fill > best + 0.02) { best = fill; n_split = s; }
+    }
+    if (walk_knob > 0) n_split = std::min(walk_knob, n_rb256);
+  }
+  dim3 grid;
+  if (n_split > 0) {
+    a.n_rb = n_rb256;
+    a.n_split = n_split;
+    a.wg_per_xcd = (a.n_gt * n_split + 7) / 8;
+    a.dephase = dephase;
+    grid = dim3((unsigned)(8 * a.wg_per_xcd));
+  } else {
+    a.n_rb = (a.R + 127) / 128;
+    // (row blocks per L2 group: measured 4 / 8 / 16 / 32 / all within 3 % of each other once the loads are issued up
+    // front -- the A operand's re-reads are served by the Infinity Cache at no visible cost; default: one group)
+    static const int rbg = std::max(1, (int)tuning("score_rb_group", (double)(1 << 30)));
+    a.rb_group = std::min(rbg, a.n_rb);
+    a.gt_per_xcd = (a.n_gt + 7) / 8;
+    const int n_grp = (a.n_rb + a.rb_group - 1) / a.rb_group;
+    grid = dim3((unsigned)(8 * n_grp * a.rb_group * a.gt_per_xcd));
+  }
+  const bool walk = n_split > 0;
   switch (a.likelihood) {
-    case SMX_LLK_NB: return launch_score_head_lk<SMX_LLK_NB>(st, a, grid);
-    case SMX_LLK_ZINB: return launch_score_head_lk<SMX_LLK_ZINB>(st, a, grid);
-    case SMX_LLK_NBD: return launch_score_head_lk<SMX_LLK_NBD>(st, a, grid);
-    case SMX_LLK_ZINBD: return launch_score_head_lk<SMX_LLK_ZINBD>(st, a, grid);
+    case SMX_LLK_NB: return launch_score_head_lk<SMX_LLK_NB>(st, a, grid, walk);
+    case SMX_LLK_ZINB: return launch_score_head_lk<SMX_LLK_ZINB>(st, a, grid, walk);
+    case SMX_LLK_NBD: return launch_score_head_lk<SMX_LLK_NBD>(st, a, grid, walk);
+    case SMX_LLK_ZINBD: return launch_score_head_lk<SMX_LLK_ZINBD>(st, a, grid, walk);
     default: set_error("score_head: unknown likelihood"); return SMX_ERR_INVALID;
   }
 }
