@@ -484,7 +484,7 @@ struct ScoreHeadArgs {
   int R = 0, row_mod = 0, G = 0, Gp = 0, Hp = 0, likelihood = 0;
   int n_rb = 0, n_gt = 0, rb_group = 0, gt_per_xcd = 0;   // set by the launcher
   int no_queue = 0;                               // set by the launcher (knob no_score_queue): lgamma differences straight-line instead of through the non-zero queue
-  int n_split = 0, wg_per_xcd = 0, dephase = 0;   // set by the launcher for score_walk_kernel: row ranges per gene tile, workgroups per XCD, the second waves' head start
+  int n_split = 0, wg_per_xcd = 0;                // set by the launcher for score_walk_kernel: row ranges per gene tile, workgroups per XCD
 };
 bool score_head_supported(int Hp, int Gp);
 int launch_score_head(hipStream_t st, const ScoreHeadArgs& a);

@@ -318,10 +318,9 @@ __device__ inline void score_products(const uint4* bl, const uint4 (&av)[NSLAB][
 // The likelihood of the wave's 32 x 32 tile and its per-row sums over the 32 columns: register r of plane p is row (r & 3) + 8 (r >> 2) + 4 h, column i.
 // lgamma(x + r) - lgamma(r) through the per-wave queue of the NON-ZERO counts (smx_loss.h: 88-93 % of the counts are zero, for which the
 // straight-line form still runs its 8-step recurrence -- a third of the vector instructions; lq == nullptr: the straight-line form)
-// (mid: called between the two halves of the tile, when the first half's accumulators are dead)
-template <int LK, int NP, class Mid>
+template <int LK, int NP>
 __device__ inline void score_tile_llk(const ScoreHeadArgs& a, const f32x16 (&acc)[NP], const float (&xs)[16], const float (&bias)[NP], bool live,
-                                      float2* lq, int i, int h, int m0, int gt, Mid mid) {
+                                      float2* lq, int i, int h, int m0, int gt) {
   float L[16];
 #pragma unroll
   for (int c = 0; c < 16; c += 8) {
@@ -334,7 +333,6 @@ __device__ inline void score_tile_llk(const ScoreHeadArgs& a, const f32x16 (&acc
     }
     typedef float Vec[8];
     count_elem_vec<LK, 0, 8>(*(const Vec*)(xs + c), p0, p1, p2, *(Vec*)(L + c), d0, d1, d2, lq);
-    if (c == 0) mid();
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) L[r] = live ? L[r] : 0.f;
@@ -464,7 +462,7 @@ __global__ __launch_bounds__(256) void score_head_kernel(ScoreHeadArgs a) {
   float bias[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) bias[p] = a.bias[(long)p * a.Gp + col];
-  score_tile_llk<LK, NP>(a, acc, xs, bias, col < a.G, lq, i, h, m0, gt, [] {});
+  score_tile_llk<LK, NP>(a, acc, xs, bias, col < a.G, lq, i, h, m0, gt);
 }
 
 // The same tiles as a WALK: a workgroup of eight waves keeps its gene tile's W image in LDS and walks a range of 256-row blocks under it.  The wave's A
@@ -525,8 +523,8 @@ __global__ __launch_bounds__(512) void score_walk_kernel(ScoreHeadArgs a) {
   const bool live = col < a.G;
   float2* const lq = a.no_queue ? nullptr : reinterpret_cast<float2*>(bl + ALLP);
   __syncthreads();   // (the image: this wave's pieces, then the other waves')
-  if (w >= 4)   // the second wave of every SIMD starts its products when the first starts its likelihood
-    for (int k = 0; k < a.dephase; ++k) __builtin_amdgcn_s_sleep(8);
+  // (measured and not kept: a head start of one matrix phase for the second wave of every SIMD, 223 against 226 us per call; a word per SIMD that a wave
+  // takes for its products so that its partner is in its likelihood meanwhile, 216-225 against 218-226: neither beyond the spread between two runs)
   for (int rb = rb0; rb < rb1; ++rb) {
     const int m0 = rb * 256 + 32 * w;
     if (m0 >= a.R) break;   // (wave-uniform: the last block's waves beyond the pass)
@@ -538,7 +536,7 @@ __global__ __launch_bounds__(512) void score_walk_kernel(ScoreHeadArgs a) {
     score_products<NP, NSLAB>(bl, av, acc, i, h);
     if (rb + 1 < rb1) load_a(rb + 1, 0, NEARLY);
     __builtin_amdgcn_sched_barrier(0);
-    score_tile_llk<LK, NP>(a, acc, xs, bias, live, lq, i, h, m0, gt, [] {});
+    score_tile_llk<LK, NP>(a, acc, xs, bias, live, lq, i, h, m0, gt);
     // (the counts repeat from block to block when 256 is a multiple of the cells per draw: the usual case)
     const int base_n = (m0 + 256) % a.row_mod;
     if (rb + 1 < rb1 && base_n != base) {
@@ -598,7 +596,6 @@ int launch_score_head(hipStream_t st, const ScoreHeadArgs& a_in) {
   // The walk (score_walk_kernel) from three 256-row blocks per workgroup up: every gene tile's rows in n_split ranges, chosen so that the
   // workgroups fill the 256 CUs (one workgroup per CU: 72 KB of image + 32 KB of queues) in whole rounds as nearly as they can.
   const int walk_knob = (int)tuning("score_walk", -1.0);   // 0: never; n > 0: n ranges
-  const int dephase = (int)tuning("score_walk_dephase", 0.0);
   const int n_rb256 = (a.R + 255) / 256;
   int n_split = 0;
   if (walk_knob != 0 && n_rb256 >= 3) {
@@ -615,7 +612,6 @@ int launch_score_head(hipStream_t st, const ScoreHeadArgs& a_in) {
     a.n_rb = n_rb256;
     a.n_split = n_split;
     a.wg_per_xcd = (a.n_gt * n_split + 7) / 8;
-    a.dephase = dephase;
     grid = dim3((unsigned)(8 * a.wg_per_xcd));
   } else {
     a.n_rb = (a.R + 127) / 128;

@@ -673,6 +673,36 @@ def test_marginal_llk_matches_oracle(Engine, name):
   e.close()
 
 
+@pytest.mark.parametrize("name,storage,n_rows,S", [("vae_zinb", "f32", 50, 40), ("vae_zinb", "u16", 37, 100), ("vae_nbd", "f32", 64, 24),
+                                                   ("vae_zinbd", "csr", 128, 30), ("vae_zinb", "f32", 31, 70)])
+def test_scoring_head_walk_equals_tile_per_workgroup(Engine, name, storage, n_rows, S):
+  """The scoring head's two forms -- score_head_kernel (one 128 x 32 tile per workgroup: what short passes still use) and score_walk_kernel (a workgroup
+  walks 256-row blocks under its gene tile's resident W image; from three blocks per workgroup up) -- give the same bits: the same products in the same
+  order, the same likelihood code.  Cells per draw that divide 256 and that do not (the counts then change from block to block), every count store, the row
+  ranges forced to 1 / 2 / 3 per gene tile, marginal_log_prob and the posterior-predictive scores."""
+  from sisua_amd import _hip
+  spec, cfg, x, ys, lib, mask = _problem(dict(CASES[name], labels=()))
+  e = Engine(cfg, max_batch=128)
+  e.upload(x, ys, lib, mask, storage=storage)
+  rows = np.arange(5, 5 + n_rows, dtype=np.int32)
+
+  def both():
+    return e.marginal_llk(row_ids=rows, n_samples=S), e.score_llk([None, x[rows][:, ::-1].copy()], row_ids=rows, n_samples=S)
+  walk = both()
+  forms = {}
+  for ranges in (0, 1, 2, 3):
+    _hip.set_tuning("score_walk", ranges)
+    try:
+      forms[ranges] = both()
+    finally:
+      _hip.clear_tuning("score_walk")
+  assert np.isfinite(walk[0][0]).all() and np.isfinite(walk[1]).all()
+  for ranges, got in forms.items():
+    assert np.array_equal(got[0][0], walk[0][0]) and np.array_equal(got[0][1], walk[0][1]), ranges
+    assert np.array_equal(got[1], walk[1]), ranges
+  e.close()
+
+
 def test_marginal_llk_stacked_two_layer_decoder_and_compact_store(Engine):
   """Stacked scoring through a two-layer decoder, the uint16 and the sparse store, 100 draws (posterior.py:964)."""
   spec, cfg, x, ys, lib, mask = _problem(dict(CASES["vae_zinb"], labels=(), dec_units=(40, 56)))

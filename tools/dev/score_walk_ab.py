@@ -34,9 +34,11 @@ def run(label, knobs):
   return out
 
 variants = [("tile per workgroup (score_walk=0)", {"score_walk": 0}), ("walk", {})]
-for d in os.environ.get("DEPHASE", "4 9 14").split():
+for d in os.environ.get("DEPHASE", "9").split():
   variants.append((f"walk, dephase {d}", {"score_walk_dephase": float(d)}))
-for s in os.environ.get("SPLITS", "2 3 8").split():
+variants.append(("walk, token", {"score_walk_token": 1}))
+variants.append(("walk, token, dephase 9", {"score_walk_token": 1, "score_walk_dephase": 9}))
+for s in os.environ.get("SPLITS", "").split():
   variants.append((f"walk, {s} ranges", {"score_walk": float(s)}))
 ref = None
 for label, knobs in variants + variants[:2]:

@@ -10,6 +10,6 @@ e = Engine(cfg, max_batch=batch)
 e.upload(xt)
 e.train_steps(bench.make_order(xt.shape[0], batch, 20), 20, batch)
 rows = np.arange(batch, dtype=np.int32)
-for _ in range(2):
+for _ in range(int(os.environ.get("CALLS", "2"))):
   e.marginal_llk(row_ids=rows, n_samples=int(os.environ.get("DRAWS", "1000")))
 e.close()

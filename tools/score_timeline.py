@@ -5,7 +5,7 @@ import csv, glob, sys
 d = sys.argv[1]
 trace = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
-sh = [i for i, r in enumerate(rows) if "score_head_kernel" in r["Kernel_Name"]]
+sh = [i for i, r in enumerate(rows) if ("score_head_kernel" in r["Kernel_Name"] or "score_walk_kernel" in r["Kernel_Name"])]
 a, b = sh[len(sh) // 2], sh[len(sh) // 2 + 1]
 t0 = int(rows[a + 1]["Start_Timestamp"]); prev = int(rows[a]["End_Timestamp"])
 print(f"(previous score_head ended {(t0 - prev) / 1e3:.1f} us before the next call's first launch)")
