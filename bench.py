@@ -509,19 +509,19 @@ def main():
         ts.append(time.perf_counter() - t_s)
       us_call = 1e6 * float(np.median(ts))
       # the bound of this path is vector issue, not memory (the 100 draws' planes, 396 MB, never exist in memory).  MEASURED instruction counts of
-      # the head kernel (PMC, profiles/r05_scoring_pmc.txt): 1720 vector instructions + 144 bf16 MFMAs per wave and 32 x 32 x 3-plane tile = 108
-      # vector instructions per likelihood element since the lgamma differences go through the non-zero queue (round 4's model said 230: the
-      # straight-line likelihood of that round).  Bound = vector issue alone, one wave-instruction per 4 cycles on 1024 SIMDs at 2.4 GHz, the
-      # MFMAs (54 us by themselves) taken as hidden beside it; the call also holds eleven small launches and the host's return (~85 us).
+      # the head kernel (PMC, profiles/r05_scoring_pmc.txt): the walk (score_walk_kernel) issues 1356 vector instructions + 144 bf16 MFMAs per wave and
+      # 32 x 32 x 3-plane tile = 85 vector instructions per likelihood element (the tile-per-workgroup form 108, round 4's straight-line likelihood 230).
+      # Bound = vector issue alone, one wave-instruction per 4 cycles on 1024 SIMDs at 2.4 GHz, the MFMAs (54 us by themselves) taken as hidden
+      # beside it; the call also holds ten small launches and the host's return (~90 us).
       elems = batch * 100 * cfg.n_genes
-      valu_bound_us = elems * 108.0 / 64.0 / (1024 * 2.4e9 / 4.0) * 1e6
+      valu_bound_us = elems * 85.0 / 64.0 / (1024 * 2.4e9 / 4.0) * 1e6
       scoring = {"what": f"smx_marginal_llk: {batch} cells x 100 posterior draws x {cfg.n_genes} genes, one call (host-synchronous, median of 20)",
                  "marginal_llk_us": round(us_call, 1), "draws_per_s": round(batch * 100 / (us_call * 1e-6), 0),
                  "likelihood_elements_per_s": round(elems / (us_call * 1e-6), 0),
-                 "roofline": {"bound": "valu", "model": "108 vector instructions per element (measured: SQ_INSTS_VALU) / 64 lanes / (1024 SIMDs x 2.4 GHz / 4 cycles per instruction); "
+                 "roofline": {"bound": "valu", "model": "85 vector instructions per element (measured: SQ_INSTS_VALU of score_walk_kernel) / 64 lanes / (1024 SIMDs x 2.4 GHz / 4 cycles per instruction); "
                                                         "rounds 3-4 quoted the same formula with 230 instructions per element (frac_230 keeps that yardstick)",
                               "bound_us": round(valu_bound_us, 1), "frac": round(valu_bound_us / us_call, 4),
-                              "frac_230": round(valu_bound_us * 230.0 / 108.0 / us_call, 4)}}
+                              "frac_230": round(valu_bound_us * 230.0 / 85.0 / us_call, 4)}}
     except Exception as err:
       scoring = {"error": str(err)[:200]}
 
