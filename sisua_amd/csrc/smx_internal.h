@@ -468,6 +468,17 @@ struct ScoreBnArgs {
   float* out_t = nullptr; long ldt = 0;   // non-null: write the result transposed, out_t [Hp][ldt] (gamma may then be null: plain transpose)
   __bf16* out3 = nullptr;                 // non-null: write the result as its three-way bf16 split [3][R][Hp] (gamma may be null)
 };
+// a one-layer decoder with BatchNorm over the stacked rows in one launch (draws + product + BatchNorm + activation + split): score_decoder1_kernel
+struct ScoreDec1Args {
+  ScoreDrawArgs d;                                 // (z is not written; no mixture prior, no library latent)
+  const float* W = nullptr; int ldw = 0;           // [Dp][Hp]
+  int H = 0, Hp = 0;
+  const float* gamma = nullptr; const float* beta = nullptr; const float* moving_mean = nullptr; const float* moving_var = nullptr;
+  float eps = 1e-3f, leak = 0.f;
+  __bf16* out3 = nullptr;                          // [3][S * B][Hp]
+};
+bool score_decoder1_supported(int Dp, int Hp);
+int launch_score_decoder1(hipStream_t st, const ScoreDec1Args& a);
 struct ScoreSplitWArgs {
   const float* W = nullptr; int ldw = 0, Gp = 0;   // [Hp][k * Gp]
   int n_gt = 0, nslab = 0, NP = 0;                 // gene tiles of 32, slabs of 32 k, parameter planes

@@ -254,6 +254,140 @@ __global__ __launch_bounds__(256) void score_bn_act_split_kernel(ScoreBnArgs a) 
   }
 }
 
+// A ONE-layer decoder with BatchNorm in one launch: the draws, the product with the layer's [Dp][Hp] weights, evaluation-mode BatchNorm + activation and the
+// three-way bf16 split of 32 stacked rows per workgroup -- score_draws_kernel + the product + score_bn_act_split_kernel (8.5 + 5.7 + 8.2 us of launches at 128 cells x
+// 100 draws; z and the f32 activations never exist in memory, and the host, which paces the call's short launches, queues two fewer).  The draws are
+// score_draws_kernel's, bit for bit (two rows per wave when Dp <= 32: half_wave_sum is wave_sum's tree over a half whose other half adds zeros); the product is
+// plain f32 multiply-adds in ascending k (32 per output).
+template <bool PAIR>   // two rows per pass, one per half of the wave (Dp <= 32), or one (Dp <= 64)
+__global__ __launch_bounds__(256) void score_decoder1_kernel(ScoreDec1Args a) {
+  __shared__ __attribute__((aligned(16))) float zs[32][68];
+  extern __shared__ __attribute__((aligned(16))) float ws[];   // [Dp][Hp]
+  const ScoreDrawArgs& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long R = (long)d.S * d.B, r0 = (long)blockIdx.x * 32;
+  // ---- every request first: the rows' cells, their (mu, s_raw), the layer's weights, the thread's four columns' BatchNorm constants (pass by pass behind
+  // one another -- the stores of lw between them kept the compiler from hoisting -- the rows' two dependent round trips came eight times over: 18.6 us) ----
+  constexpr int NPASS = PAIR ? 4 : 8;
+  const int half = lane >> 5, dd = PAIR ? (lane & 31) : lane;
+  const bool d_ok = dd < d.D;
+  int bs[NPASS], ss[NPASS]; uint32_t cells[NPASS]; bool row_ok[NPASS];
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const long r = r0 + 8 * wv + (PAIR ? 2 * p + half : p);
+    row_ok[p] = r < R;
+    const long rc = row_ok[p] ? r : R - 1;
+    ss[p] = (int)(rc / d.B); bs[p] = (int)(rc - (long)ss[p] * d.B);
+  }
+  if (d.rows) {
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) cells[p] = (uint32_t)d.rows[bs[p]];
+  } else {
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) cells[p] = (uint32_t)bs[p];
+  }
+  float mus[NPASS], srs[NPASS];
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const float* lp = d.lat + (long)bs[p] * d.ld + (d_ok ? dd : 0);
+    mus[p] = lp[0]; srs[p] = lp[d.Dp];
+  }
+  const int q = a.Hp >> 2;
+  for (int it = tid; it < d.Dp * q; it += 256) {
+    const int k = it / q, c = (it - k * q) * 4;
+    *reinterpret_cast<float4*>(ws + k * a.Hp + c) = *reinterpret_cast<const float4*>(a.W + (long)k * a.ldw + c);
+  }
+  const int cq = tid & 31, rg = tid >> 5, c0 = 4 * cq;
+  const bool col_ok = cq < q;
+  float g4[4], b4[4], m4[4], i4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = col_ok ? c0 + j : 0;
+    g4[j] = a.gamma[c]; b4[j] = a.beta[c]; m4[j] = a.moving_mean[c]; i4[j] = a.moving_var[c];
+  }
+  // ---- the draws of the block's 32 rows: wave wv takes rows 8 wv .. 8 wv + 7 ----
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int rl = 8 * wv + (PAIR ? 2 * p + half : p);
+    NoiseKey nk = d.nk;
+    nk.stream = (d.nk.stream & 0xFFu) | (((uint32_t)(d.s0 + ss[p]) & 0xFFFFFFu) << 8);
+    float lw = 0.f, z = 0.f;
+    if (d_ok) {
+      const float sig = softplusf(srs[p] + SMX_SOFTPLUS_INV_1);
+      const float4 n = normal4(philox_block(nk, d.cell_base + cells[p], (uint32_t)(dd >> 2)));
+      const float eps = (dd & 3) == 0 ? n.x : (dd & 3) == 1 ? n.y : (dd & 3) == 2 ? n.z : n.w;
+      z = mus[p] + sig * eps;
+      lw = -0.5f * z * z + 0.5f * eps * eps + logf(sig);
+    }
+    if (dd < d.Dp) zs[rl][dd] = z;
+    lw = PAIR ? half_wave_sum(lw) : wave_sum(lw);
+    if (dd == 0 && row_ok[p]) d.lw[r0 + rl] = lw;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) i4[j] = rsqrtf(i4[j] + a.eps);
+  __syncthreads();
+  if (!col_ok) return;
+  // ---- product: thread (row group rg, column quad cq): rows rg, rg + 8, rg + 16, rg + 24 ----
+  float acc[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
+  for (int k0 = 0; k0 < d.Dp; k0 += 4) {
+    float4 w4[4], z4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w4[e] = *reinterpret_cast<const float4*>(ws + (k0 + e) * a.Hp + c0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z4[k] = *reinterpret_cast<const float4*>(&zs[rg + 8 * k][k0]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float zz[4] = {z4[k].x, z4[k].y, z4[k].z, z4[k].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[k][0] = __builtin_fmaf(zz[e], w4[e].x, acc[k][0]);
+        acc[k][1] = __builtin_fmaf(zz[e], w4[e].y, acc[k][1]);
+        acc[k][2] = __builtin_fmaf(zz[e], w4[e].z, acc[k][2]);
+        acc[k][3] = __builtin_fmaf(zz[e], w4[e].w, acc[k][3]);
+      }
+    }
+  }
+  // ---- BatchNorm (moving statistics), activation, split, stores ----
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long r = r0 + rg + 8 * k;
+    if (r >= R) continue;
+    __bf16 t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float y = g4[j] * ((acc[k][j] - m4[j]) * i4[j]) + b4[j];
+      float hval = fmaxf(y, 0.f);
+      if (a.leak != 0.f) hval += a.leak * fminf(y, 0.f);
+      if (c0 + j >= a.H) hval = 0.f;
+      split3(hval, t[0][j], t[1][j], t[2][j]);
+    }
+#pragma unroll
+    for (int T = 0; T < 3; ++T) *reinterpret_cast<uint2*>(a.out3 + (long)T * R * a.Hp + r * a.Hp + c0) = *reinterpret_cast<const uint2*>(t[T]);
+  }
+}
+
+bool score_decoder1_supported(int Dp, int Hp) { return Dp > 0 && Dp % 4 == 0 && Dp <= 64 && Hp > 0 && Hp % 32 == 0 && Hp <= 128; }
+
+int launch_score_decoder1(hipStream_t st, const ScoreDec1Args& a) {
+  const ScoreDrawArgs& d = a.d;
+  if (!score_decoder1_supported(d.Dp, a.Hp) || d.S <= 0 || d.B <= 0 || !d.lat || !d.lw || d.pr_logits || d.latl || !a.W || !a.gamma || !a.beta || !a.moving_mean ||
+      !a.moving_var || !a.out3 || a.ldw < a.Hp) {
+    set_error("score_decoder1: bad arguments");
+    return SMX_ERR_INVALID;
+  }
+  const long R = (long)d.S * d.B;
+  const dim3 grid((unsigned)((R + 31) / 32));
+  const size_t lds = (size_t)d.Dp * a.Hp * sizeof(float);
+  if (d.Dp <= 32) hipLaunchKernelGGL(score_decoder1_kernel<true>, grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(score_decoder1_kernel<false>, grid, dim3(256), lds, st, a);
+  SMX_HIP(hipGetLastError());
+  return SMX_OK;
+}
+
 // W [Hp][k * Gp] -> images [gene tile][slab][term][plane][k block n][lane half h][column][8 k] of bf16: the 16 bytes at
 // (term, plane, n, h, column i) are what lane (i, h) feeds to v_mfma_f32_32x32x16_bf16 for k = 32 slab + 16 n + 8 h ..+7
 __global__ __launch_bounds__(256) void score_split_w_kernel(ScoreSplitWArgs a) {
@@ -593,19 +727,22 @@ int launch_score_head(hipStream_t st, const ScoreHeadArgs& a_in) {
     return SMX_ERR_INVALID;
   }
   a.n_gt = a.Gp / 32;
-  // The walk (score_walk_kernel) from three 256-row blocks per workgroup up: every gene tile's rows in n_split ranges, chosen so that the
-  // workgroups fill the 256 CUs (one workgroup per CU: 72 KB of image + 32 KB of queues) in whole rounds as nearly as they can.
+  // Which form: the walk (score_walk_kernel; every gene tile's rows in n_split ranges, one workgroup of eight waves each, one workgroup per CU: 72 KB of
+  // image + 32 KB of queues) when its rounds of workgroups x blocks per workgroup come to less than the tile form's rounds of 512 resident tiles.  Fitted to
+  // tools/dev/score_form_sweep.py at three planes x four slabs (both forms scale alike with those): ~11 us per 256-row block + ~7 us per workgroup against
+  // ~15 us per round of 128-row tiles -- at 128 cells the walk pays from ~15 draws (126.6 against 141.6 us per call at 25, 223 against 281 at 100); below, it
+  // has too few workgroups (forced at 10 draws: 108-135 against 105).
   const int walk_knob = (int)tuning("score_walk", -1.0);   // 0: never; n > 0: n ranges
   const int n_rb256 = (a.R + 255) / 256;
   int n_split = 0;
-  if (walk_knob != 0 && n_rb256 >= 3) {
-    double best = -1.0;
-    for (int s = 1; s <= 8 && 3 * s <= n_rb256; ++s) {
-      const long wgs = (long)a.n_gt * s;
-      const double fill = (double)wgs / (double)(((wgs + 255) / 256) * 256);
-      if (fill > best + 0.02) { best = fill; n_split = s; }
+  if (walk_knob > 0) n_split = std::min(walk_knob, n_rb256);
+  else if (walk_knob < 0) {
+    double best = 15.0 * std::max(0.3, (double)((a.R + 127) / 128) * a.n_gt / 512.0);
+    for (int s = 1; s <= 8 && s <= n_rb256; ++s) {
+      const long rounds = ((long)a.n_gt * s + 255) / 256;
+      const double cost = (double)rounds * (7.0 + 10.9 * ((double)a.R / 256.0) / s);
+      if (cost < best - 0.5) { best = cost; n_split = s; }
     }
-    if (walk_knob > 0) n_split = std::min(walk_knob, n_rb256);
   }
   dim3 grid;
   if (n_split > 0) {

@@ -110,6 +110,9 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
     }
     m->wimg_epoch = m->params_epoch; m->wimg_key = key;
   }
+  // (knob no_score_dec1: the three launches)
+  const bool dec1 = !wide_head && !m->scvi && !m->scale && m->dec.size() == 1 && m->dec[0].bn >= 0 && m->dec[0].in_p == m->Dp &&
+                    score_decoder1_supported(m->Dp, m->dec[0].out_p) && !tuning_on("no_score_dec1");
   // the encoders and the latent heads
   SMX_CHECK(forward_pass(m, ps, false, false, 3));
   for (int s0 = 0; s0 < n_samples; s0 += Sc) {
@@ -124,10 +127,19 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
     if (m->scvi) {
       d.latl = m->latlbuf; d.ld_l = 32; d.library = ps.lib; d.lib_rows = ps.rows; d.nk_l = make_key(m, ST_EPS_L, 0, false); d.l = lsmp;
     }
-    SMX_CHECK(launch_score_draws(m->st, d));
     const float* in = nullptr;
     int ld = 0;
-    SMX_CHECK(stacked_decoder(m, z, rows, hb, m->scvi ? 0 : (wide_head ? 1 : 2), ht, &in, &ld));
+    if (dec1) {   // draws, product, BatchNorm, activation and split of a one-layer decoder in one launch (z is not stored)
+      const MlpLayer& L = m->dec[0];
+      ScoreDec1Args f;
+      f.d = d; f.W = P_(m, L.tW); f.ldw = m->tensors[L.tW].ld; f.H = L.out; f.Hp = L.out_p;
+      f.gamma = P_(m, L.tGamma); f.beta = P_(m, L.tBeta); f.moving_mean = m->bn_moving + m->bn_off[L.bn]; f.moving_var = f.moving_mean + L.out_p;
+      f.eps = m->cfg.bn_eps; f.leak = L.leak; f.out3 = reinterpret_cast<__bf16*>(ht);
+      SMX_CHECK(launch_score_decoder1(m->st, f));
+    } else {
+      SMX_CHECK(launch_score_draws(m->st, d));
+      SMX_CHECK(stacked_decoder(m, z, rows, hb, m->scvi ? 0 : (wide_head ? 1 : 2), ht, &in, &ld));
+    }
     if (m->scvi) {
       for (int ch = 0; ch < m->k; ++ch) {
         if (!m->out_has_W[ch]) {   // (dispersion / inflation = 'share': the per-gene vector in every row)

@@ -703,6 +703,32 @@ def test_scoring_head_walk_equals_tile_per_workgroup(Engine, name, storage, n_ro
   e.close()
 
 
+@pytest.mark.parametrize("latent_dim,dec", [(10, 40), (32, 128), (40, 64), (64, 96)])
+def test_scoring_decoder_in_one_launch(Engine, latent_dim, dec):
+  """A one-layer decoder with BatchNorm over the stacked draws in ONE launch (score_decoder1_kernel: the draws, the product, evaluation-mode BatchNorm,
+  the activation and the bf16 x 3 split) against the three launches it replaces (knob no_score_dec1) and against the oracle: the draws are the same bits
+  (one or two rows per wave by the latent width), the product the same ascending sum."""
+  from sisua_amd import _hip
+  spec, cfg, x, ys, lib, mask = _problem(dict(CASES["vae_zinb"], labels=(), latent_dim=latent_dim, dec_units=(dec,)))
+  params = perturbed_params(spec)
+  bn = so.init_bn_state(spec)
+  e = Engine(cfg, max_batch=64, init=False)
+  e.set_params(params)
+  e.upload(x, ys, lib, mask)
+  rows = np.arange(7, 60, dtype=np.int32)
+  S = 9
+  ref_m, ref_l = so.marginal_log_prob(spec, params, bn, x[rows], rows, S, library=lib[rows])
+  one = e.marginal_llk(row_ids=rows, n_samples=S)
+  _hip.set_tuning("no_score_dec1", 1)
+  try:
+    three = e.marginal_llk(row_ids=rows, n_samples=S)
+  finally:
+    _hip.clear_tuning("no_score_dec1")
+  assert np.allclose(one[0], ref_m, rtol=RTOL, atol=1e-3) and np.allclose(one[1], ref_l, rtol=RTOL, atol=1e-3)
+  assert np.allclose(one[0], three[0], rtol=1e-6, atol=1e-4) and np.allclose(one[1], three[1], rtol=1e-6, atol=1e-4)
+  e.close()
+
+
 def test_marginal_llk_stacked_two_layer_decoder_and_compact_store(Engine):
   """Stacked scoring through a two-layer decoder, the uint16 and the sparse store, 100 draws (posterior.py:964)."""
   spec, cfg, x, ys, lib, mask = _problem(dict(CASES["vae_zinb"], labels=(), dec_units=(40, 56)))

@@ -34,10 +34,9 @@ def run(label, knobs):
   return out
 
 variants = [("tile per workgroup (score_walk=0)", {"score_walk": 0}), ("walk", {})]
-for d in os.environ.get("DEPHASE", "9").split():
+for d in os.environ.get("DEPHASE", "").split():
   variants.append((f"walk, dephase {d}", {"score_walk_dephase": float(d)}))
-variants.append(("walk, token", {"score_walk_token": 1}))
-variants.append(("walk, token, dephase 9", {"score_walk_token": 1, "score_walk_dephase": 9}))
+variants.append(("walk, decoder in three launches", {"no_score_dec1": 1}))
 for s in os.environ.get("SPLITS", "").split():
   variants.append((f"walk, {s} ranges", {"score_walk": float(s)}))
 ref = None
@@ -45,6 +44,9 @@ for label, knobs in variants + variants[:2]:
   out = run(label, knobs)
   if ref is None:
     ref = out
+  elif "three launches" in label:   # (the product's summation order differs: close, not equal)
+    print("   max |difference| of log p(x):", float(np.abs(out[0] - ref[0]).max()), "of", float(np.abs(ref[0]).mean()))
+    assert np.allclose(out[0], ref[0], rtol=1e-5, atol=1e-3)
   else:
     assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1]), label
 print("every form: the same bits")
