@@ -7,7 +7,7 @@ import bench
 from sisua_amd import _hip
 from sisua_amd.engine import Engine
 
-cfg, xt, batch, _ = bench.build_workload(0, 1, "8kly")
+cfg, xt, batch, _ = bench.build_workload(0, 1, os.environ.get("WORKLOAD", "8kly"))
 e = Engine(cfg, max_batch=batch)
 e.upload(xt)
 e.train_steps(bench.make_order(xt.shape[0], batch, 20), 20, batch)
