@@ -231,6 +231,7 @@ struct smx_model {
   int32_t* pred_ids = nullptr; int pred_ids_batch = 0;   // smx_predict super-batches: noise ids (row % batch)
   float* pred_target = nullptr; size_t pred_target_floats = 0;   // smx_predict_stat(log_prob): a batch of target rows [Bmax][Gp]
   float* metrics_pin = nullptr;   // pinned landing area of read_metrics: 8 ELBO scalars + one gradient norm per tensor
+  float* score_pin = nullptr; size_t score_pin_floats = 0;   // pinned landing area of the scoring entry points' results (smx_scoring.hip: score_landing)
   float* mhist = nullptr; size_t mhist_cap = 0; int32_t mhist_steps = 0;   // ELBO scalars of every step of the last train_steps call
   int32_t staged_steps = 0, staged_batch = 0;   // row ids made resident by smx_train_stage for the next smx_train_steps(order = NULL)
   StepState* state3 = nullptr;  // [0],[1]: per-step state by parity, [2]: master counter

@@ -465,6 +465,7 @@ int smx_model_destroy(smx_model* m) {
   if (m->pinned) hipHostFree(m->pinned);
   if (m->order_pin) hipHostFree(m->order_pin);
   if (m->metrics_pin) hipHostFree(m->metrics_pin);
+  if (m->score_pin) hipHostFree(m->score_pin);
   if (m->ev_order) hipEventDestroy(m->ev_order);
   if (m->pred_stage) hipFree(m->pred_stage);
   if (m->pred_target) hipFree(m->pred_target);

@@ -203,6 +203,19 @@ static int score_aux(smx_model* m, size_t floats, float** out) {
   return SMX_OK;
 }
 
+// the results' landing area on the host, pinned and kept across calls: into a pageable array the runtime's copy waits for the stream, stages, and the
+// hipStreamSynchronize behind it is a second trip through the runtime for nothing
+static int score_landing(smx_model* m, size_t floats, float** out) {
+  if (floats > m->score_pin_floats) {
+    if (m->score_pin) { SMX_HIP(hipStreamSynchronize(m->st)); hipHostFree(m->score_pin); }
+    m->score_pin = nullptr; m->score_pin_floats = 0;
+    SMX_HIP(hipHostMalloc((void**)&m->score_pin, floats * sizeof(float), hipHostMallocDefault));
+    m->score_pin_floats = floats;
+  }
+  *out = m->score_pin;
+  return SMX_OK;
+}
+
 }  // namespace smx
 
 extern "C" {
@@ -240,8 +253,9 @@ int smx_marginal_llk(smx_model* m, const int32_t* row_ids, const float* host_x, 
     hipLaunchKernelGGL(iw_accum_kernel, dim3((batch + 3) / 4), dim3(256), 0, m->st, a);
   }
   if (rc == SMX_OK) {
-    std::vector<float> h((size_t)3 * batch);
-    hipError_t e = hipMemcpyAsync(h.data(), run, h.size() * sizeof(float), hipMemcpyDeviceToHost, m->st);
+    float* h = nullptr;
+    SMX_CHECK(score_landing(m, (size_t)3 * batch, &h));
+    hipError_t e = hipMemcpyAsync(h, run, (size_t)3 * batch * sizeof(float), hipMemcpyDeviceToHost, m->st);
     if (e == hipSuccess) e = hipStreamSynchronize(m->st);
     if (e != hipSuccess) { set_error(std::string("marginal_llk readback failed: ") + hipGetErrorString(e)); rc = SMX_ERR_HIP; }
     else
@@ -329,14 +343,15 @@ int smx_score_llk(smx_model* m, const int32_t* row_ids, const float* host_x, con
     }
   }
   if (rc == SMX_OK) {
-    std::vector<float> h((size_t)n_targets * 2 * 2 * batch);
-    e = hipMemcpyAsync(h.data(), run, h.size() * sizeof(float), hipMemcpyDeviceToHost, m->st);
+    float* h = nullptr;
+    SMX_CHECK(score_landing(m, (size_t)n_targets * 2 * 2 * batch, &h));
+    e = hipMemcpyAsync(h, run, (size_t)n_targets * 2 * 2 * batch * sizeof(float), hipMemcpyDeviceToHost, m->st);
     if (e == hipSuccess) e = hipStreamSynchronize(m->st);
     if (e != hipSuccess) { set_error(std::string("score_llk readback failed: ") + hipGetErrorString(e)); rc = SMX_ERR_HIP; }
     else
       for (int t = 0; t < n_targets; ++t)
         for (int j = 0; j < 2; ++j) {
-          const float* r = h.data() + ((size_t)t * 2 + (j < n_dist ? j : 0)) * 2 * batch;
+          const float* r = h + ((size_t)t * 2 + (j < n_dist ? j : 0)) * 2 * batch;
           for (int b = 0; b < batch; ++b)
             out[((size_t)t * 2 + j) * batch + b] = r[b] + logf(r[batch + b]) - logf((float)n_samples);
         }
