@@ -500,10 +500,10 @@ def main():
   if rank == 0 and world == 1 and args.workload == "8kly" and eng.max_batch >= batch:
     try:
       rows_s = order_ev[:batch]
-      for _ in range(3):
+      for _ in range(30):   # (the clocks come back up over the first ~20 calls behind the idle stretch of the engines' set-up: 223 us at the median of calls 4-23, 203 later)
         eng.marginal_llk(row_ids=rows_s, n_samples=100)
       ts = []
-      for _ in range(20):
+      for _ in range(50):
         t_s = time.perf_counter()
         eng.marginal_llk(row_ids=rows_s, n_samples=100)
         ts.append(time.perf_counter() - t_s)
@@ -515,7 +515,7 @@ def main():
       # beside it; the call also holds ten small launches and the host's return (~90 us).
       elems = batch * 100 * cfg.n_genes
       valu_bound_us = elems * 85.0 / 64.0 / (1024 * 2.4e9 / 4.0) * 1e6
-      scoring = {"what": f"smx_marginal_llk: {batch} cells x 100 posterior draws x {cfg.n_genes} genes, one call (host-synchronous, median of 20)",
+      scoring = {"what": f"smx_marginal_llk: {batch} cells x 100 posterior draws x {cfg.n_genes} genes, one call (host-synchronous, median of 50)",
                  "marginal_llk_us": round(us_call, 1), "draws_per_s": round(batch * 100 / (us_call * 1e-6), 0),
                  "likelihood_elements_per_s": round(elems / (us_call * 1e-6), 0),
                  "roofline": {"bound": "valu", "model": "85 vector instructions per element (measured: SQ_INSTS_VALU of score_walk_kernel) / 64 lanes / (1024 SIMDs x 2.4 GHz / 4 cycles per instruction); "
