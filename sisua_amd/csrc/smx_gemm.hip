@@ -182,22 +182,41 @@ __device__ inline void gemm_body(const GemmArgs& g, const int bx, const int by, 
   float e_mu[RPW_E], e_sr[RPW_E], e_sg[RPW_E], e_ep[RPW_E], e_dk[RPW_E], e_za[RPW_E];
   if (EPI == 2) {
     const EpiLatentBwd& e = g.lb;
-    // (unconditional loads from clamped indices under launch-uniform branches: a lane-predicated load per register was a block with a wait
-    // of its own -- four round trips in a row; what a lane beyond the tile reads is never used)
+    // (unconditional loads from clamped indices: a lane-predicated load per register was a block with a wait of its own -- four round trips in a row; what a
+    // lane beyond the tile reads is never used.  And NO branch on the launch-uniform switches either: an absent operand is read from `lat` instead (valid
+    // at every index used here) and replaced by its constant afterwards -- inside `if (e.stochastic) { loads }` the compiler folded the first USE of the
+    // loaded value (s_raw + log(e - 1)) into the branch, against a constant in the other arm, and with it a wait per register: four round trips in a row again)
     const int d = min(n0 + wn * 32 + li, e.Dp - 1);
+    const bool has_dk = e.dklz != nullptr, has_za = e.dz_add != nullptr, sto = e.stochastic != 0;
+    const float* p_dk = has_dk ? e.dklz : e.lat;
+    const float* p_za = has_za ? e.dz_add : e.lat;
+    const float* p_sr = sto ? e.lat + e.Dp : e.lat;
+    const long ld_sr = sto ? (long)e.ld : (long)e.Dp;   // (a deterministic latent's rows may be Dp wide)
+    const float* p_sg = sto ? e.sig : e.lat;
+    const float* p_ep = sto ? e.eps : e.lat;
+    long bo[RPW_E];
 #pragma unroll
     for (int j = 0; j < RPW_E; ++j) {
       const int r = wk * RPW_E + j;
-      const int b = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
-      e_dk[j] = 0.f; e_za[j] = 0.f; e_sr[j] = 0.f; e_sg[j] = 1.f; e_ep[j] = 0.f;
-      if (e.dklz) e_dk[j] = e.dklz[(long)b * e.Dp + d];
-      if (e.dz_add) e_za[j] = e.dz_add[(long)b * e.Dp + d];
-      e_mu[j] = e.lat[(long)b * e.ld + d];
-      if (e.stochastic) {
-        e_sr[j] = e.lat[(long)b * e.ld + e.Dp + d];
-        e_sg[j] = e.sig[(long)b * e.Dp + d];
-        e_ep[j] = e.eps[(long)b * e.Dp + d];
-      }
+      bo[j] = (long)min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < RPW_E; ++j) {
+      e_dk[j] = p_dk[bo[j] * e.Dp + d];
+      e_za[j] = p_za[bo[j] * e.Dp + d];
+      e_mu[j] = e.lat[bo[j] * e.ld + d];
+      e_sr[j] = p_sr[bo[j] * ld_sr + d];
+      e_sg[j] = p_sg[bo[j] * e.Dp + d];
+      e_ep[j] = p_ep[bo[j] * e.Dp + d];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < RPW_E; ++j) {
+      e_dk[j] = has_dk ? e_dk[j] : 0.f;
+      e_za[j] = has_za ? e_za[j] : 0.f;
+      e_sr[j] = sto ? e_sr[j] : 0.f;
+      e_sg[j] = sto ? e_sg[j] : 1.f;
+      e_ep[j] = sto ? e_ep[j] : 0.f;
     }
   }
   f32x16 acc;

@@ -89,8 +89,8 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
   float av[KH], bv[NP][KH];
   // ALL operand loads of a slab are issued before its first MFMA (left alone the compiler waits for each W load
   // right before the MFMA that uses it: ~30 serial L2 / HBM round trips, 9.8 us for the product alone)
-  auto load_slab = [&](int kc) {
-    const int k0 = kc + KS * q + KH * h;          // first k of this lane half in this slab
+  auto load_slab = [&](int kc, bool mine) {
+    const int k0 = mine ? kc + KS * q + KH * h : KH * h;   // first k of this lane half in this slab (a wave without a slice: any valid rows, unused)
     if (EPI == 2) {   // k-major H (smx_score.hip): lanes i = 32 consecutive rows of one k, as for W
       const float* ap = a.H + (long)k0 * a.ldh + arow;
 #pragma unroll
@@ -122,7 +122,9 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
     }
   };
   const bool active = KS * q < a.Hp;              // wave-uniform: this wave has a K slice in the first slab
-  if (active) load_slab(0);
+  // (no branch around the requests: behind its join the compiler's wait for the row ids -- which the counts' addresses need -- had to fit the path
+  // WITHOUT the slab's 26 requests and became a wait for all of them: the counts left one round trip late)
+  load_slab(0, active);
   __builtin_amdgcn_sched_barrier(0);
   float xs[RPW];
 #pragma unroll
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(64 * NW) void out_head_loss_kernel(HeadLossArgs a) 
   __builtin_amdgcn_sched_barrier(0);
   if (active) mfma_slab();
   for (int kc = SLAB; kc + KS * q < a.Hp; kc += SLAB) {
-    load_slab(kc);
+    load_slab(kc, true);
     __builtin_amdgcn_sched_barrier(0);
     mfma_slab();
   }
