@@ -17,6 +17,8 @@ for K in [int(v) for v in os.environ.get("KS", "1 5 20 100").split()]:
   ts = []
   for rep in range(int(os.environ.get("REPS", "15"))):
     e.stage_steps(order[: K * batch], K, batch)
+    for _ in range(int(os.environ.get("EVAL_BEFORE", "0"))):   # (evaluation passes right in front of the bracket: the device's clocks are up when the clock starts)
+      e.eval_step(order[:batch])
     e.synchronize()
     t0 = time.perf_counter()
     e.train_steps(None, K, batch)
