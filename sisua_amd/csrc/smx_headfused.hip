@@ -227,7 +227,11 @@ __global__ __launch_bounds__(512, 2) void head_fused_kernel(HeadFusedArgs a) {
   const int dw_vo = (int)(((16 * w + 4 * g) * a.ldw + j) * 4);
   const int cellc = min(cell, a.B - 1);
   const bool cell_ok = cell < a.B;
-  const long src = a.rows ? (long)a.rows[cellc] : (long)cellc;
+  // (the cell's dataset row: requested here, used by load_xb behind the split of d.  No branch on `rows`: inside one the compiler put the first use of the
+  // loaded word -- its sign extension -- together with a wait for it, one memory round trip at the head of every workgroup before any of d's 40 requests)
+  const bool tab = a.rows != nullptr;
+  const int32_t* const rp = tab ? a.rows : reinterpret_cast<const int32_t*>(a.D);
+  const int src_w = rp[tab ? cellc : 0];
   {
     const float* dp = a.D + (long)cellc * a.ldd;
 #pragma unroll
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void head_fused_kernel(HeadFusedArgs a) {
   uint2 xraw16; float4 xraw32 = zero4(); float4 bq[NP];
   xraw16.x = 0; xraw16.y = 0;
   auto load_xb = [&](int u) {
-    const long o = src * a.ldx + (long)u * 16 + 4 * g;
+    const long o = (long)(tab ? src_w : cellc) * a.ldx + (long)u * 16 + 4 * g;
     if (U16) xraw16 = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.X) + o);
     else xraw32 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.X) + o);
 #pragma unroll
