@@ -358,7 +358,7 @@ int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a_in) {
 namespace smx {
 
 // one 32 x 32 tile of problem P: `red` 8 partial tiles (32 KB), `sqs` 8 floats
-__device__ inline void wgrad_tile_body(const WgradGroup& Gr, const WgradProblem& P, float* red, float* sqs) {
+__device__ __forceinline__ void wgrad_tile_body(const WgradGroup& Gr, const WgradProblem& P, float* red, float* sqs) {
   preload(P.A, P.lda, P.a_mode, P.log1p, P.rows, P.Bm, P.ldb, P.C, P.ldc, P.M, P.n_mt, P.n_nt, P.start, P.colsum, P.sq_part, Gr.B);   // (one batch: smx_device.h)
   const int local = blockIdx.x - P.start;
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -383,12 +383,23 @@ __device__ inline void wgrad_tile_body(const WgradGroup& Gr, const WgradProblem&
       arow[s] = (P.a_mode && P.rows) ? (long)P.rows[cell] : (long)cell;
     }
     float av[8], bv[8];
+    // (the store's format outside the request loop: `a_mode == 2 ? u16 : f32` per element put a wait and the conversion behind every uint16 request --
+    // eight round trips in a row for the compact store; the f32 arm is the loop as it was)
+    if (P.a_mode == 2) {
+      uint16_t raw[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int cell = min(k0 + s, B - 1);
-      bv[s] = P.Bm[(long)cell * P.ldb + n0 + i];
-      if (P.a_mode == 2) av[s] = (float)reinterpret_cast<const uint16_t*>(P.A)[arow[s] * P.lda + m0 + i];
-      else av[s] = P.A[arow[s] * P.lda + m0 + i];
+      for (int s = 0; s < 8; ++s) {
+        bv[s] = P.Bm[(long)min(k0 + s, B - 1) * P.ldb + n0 + i];
+        raw[s] = reinterpret_cast<const uint16_t*>(P.A)[arow[s] * P.lda + m0 + i];
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) av[s] = (float)raw[s];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        bv[s] = P.Bm[(long)min(k0 + s, B - 1) * P.ldb + n0 + i];
+        av[s] = P.A[arow[s] * P.lda + m0 + i];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (Gr.b3) {   // (launch-uniform) the product from bf16 MFMAs on three-way split operands: the lane's 8 cells are one operand
