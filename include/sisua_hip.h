@@ -463,6 +463,12 @@ int smx_k_gemm(int transA, int transB, const float* A, const float* B, int32_t M
  * db [k][G], dd [B][128], sumsq = sum of squares of dW (may be NULL); us (may be NULL): average device time of `reps` launches. */
 int smx_k_head_fused(int likelihood, int u16, const float* x, const float* d, const float* W, const float* bias, int32_t B, int32_t G,
                      float grad_scale, int32_t reps, float* llk, float* dW, float* db, float* dd, float* sumsq, float* us);
+/* The same launch `launches` (>= 2) times on the same inputs, every launch after the first compared on the device, bit for bit, with what
+ * the first left (dW, db, the d d slabs, the likelihood partials): *n_differ = launches that differed, *first_word (may be NULL) = index of
+ * the first differing word within [dW | db | slabs | partials] or -1.  Regression test of two hardware behaviours that made this kernel's
+ * results timing-dependent (tools/isa_lint.py rules R1, R2). */
+int smx_k_head_fused_stress(int likelihood, int u16, const float* x, const float* d, const float* W, const float* bias, int32_t B, int32_t G,
+                            float grad_scale, int32_t launches, int32_t* n_differ, int64_t* first_word);
 /* The kernels' noise function beside hiprand's own generator (BASELINE north_star: "sampling from a hiprand state per wavefront"): for
  * every counter quadruple (c0, c1, c2, c3) = (column block, cell id, step, stream | sample << 8) `ours` receives the four words the
  * kernels compute, `hiprand_words` the four words of ONE hiprand4() on a hiprandStatePhilox4_32_10_t set up by

@@ -133,6 +133,8 @@ SIGNATURES = {
     "smx_k_count_llk": (C.c_int, [C.c_int, C.c_int, _FP, _FP, C.c_int32, C.c_int32, _FP, _FP]),
     "smx_k_head_fused": (C.c_int, [C.c_int, C.c_int, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.c_float, C.c_int32, _FP, _FP, _FP, _FP, _FP,
                                    _FP]),
+    "smx_k_head_fused_stress": (C.c_int, [C.c_int, C.c_int, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int64)]),
     "smx_k_gemm": (C.c_int, [C.c_int, C.c_int, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
     "smx_k_hiprand": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "smx_k_noise": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.c_int32,

@@ -262,10 +262,20 @@ __global__ __launch_bounds__(512, 2) void head_fused_kernel(HeadFusedArgs a) {
       hf_store8h(dA[ks].t0, rtab, tab_vo, tabA + (3 * ks + 0) * 1024); hf_store8h(dA[ks].t1, rtab, tab_vo, tabA + (3 * ks + 1) * 1024); hf_store8h(dA[ks].t2, rtab, tab_vo, tabA + (3 * ks + 2) * 1024);
     }
 #define HF_V(x) "v"(x.t0), "v"(x.t1), "v"(x.t2)
-    // the wave's own table entries are written before it reads them back.  The stored registers are operands of the wait: measured on
-    // MI355X (round 4), a 16-byte buffer store whose data registers are reused by the instructions right behind it (they are dead once
-    // stored) wrote garbage -- with the registers held until the stores have completed the table is right
+    // the wave's own table entries are written before it reads them back.  The stored registers are operands of the wait, so that nothing
+    // overwrites them before the stores have completed.  ISA fact (gfx950, measured: tools/dev/store_hazard.hip, profiles/r06_hazards.txt):
+    // `buffer_store_dwordx4 v[a:a+3], voff, srsrc, sN offen` followed DIRECTLY by a vector instruction that writes v[a] stores the NEW value
+    // in 0.15 % of the lanes; one wait state cures it.  The same store with an IMMEDIATE soffset needs two, which the compiler inserts
+    // (the ">64-bit VMEM store -> VALU write of its data" hazard); with a REGISTER soffset -- these stores: soffset = the wave's table
+    // base -- LLVM's GCNHazardRecognizer::createsVALUHazard assumes none are needed and emitted `buffer_store_dwordx4 v[14:17] ...;
+    // v_pk_add_f32 v[14:15], ...` (the split of the next k step) back to back.  Round 4 saw the table's garbage and held the registers
+    // without knowing why; tools/isa_lint.py rule R2 now rejects that pair in any kernel of the library at build time
+    // (-DSMX_HF_NOHOLD rebuilds the failing form: the lint stops the build).
+#ifdef SMX_HF_NOHOLD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(0)" :: HF_V(dA[0]), HF_V(dA[1]), HF_V(dA[2]), HF_V(dA[3]) : "memory");
+#endif
 #undef HF_V
   }
   auto load_view = [&]() {
@@ -384,9 +394,17 @@ __global__ __launch_bounds__(512, 2) void head_fused_kernel(HeadFusedArgs a) {
     } else {
       xs[0] = xraw32.x; xs[1] = xraw32.y; xs[2] = xraw32.z; xs[3] = xraw32.w;
     }
-#ifndef SMX_HF_NOPIN
-    asm volatile("" : "+v"(xs[0]), "+v"(xs[1]), "+v"(xs[2]), "+v"(xs[3]));   // (the counts are unpacked HERE, ahead of the forward product)
-#endif
+    // (Round 5 pinned this unpacking ahead of the forward product with an empty asm because, sunk behind it, the nbd / u16 instantiation
+    // lost the term x / (mu + eps) of dP for the last gene of a unit in waves 4-7, "timing-dependent, cause not established".  The cause
+    // (round 6; tools/dev/hf_hazard.hip ran hand-edited ISA variants of the kernel, tools/dev/pk_opsel_hazard.hip / pk_opsel_forms.hip
+    // reproduce it in 60 lines; numbers in profiles/r06_hazards.txt): with the unpacking sunk, the SLP vectoriser paired
+    // rcp(mu + eps) * x and inv * x of element 3 into `v_pk_mul_f32 v[154:155], v[206:207], v[166:167] op_sel:[0,1]` -- and on gfx950 a
+    // packed-f32 instruction whose op_sel takes src1's HIGH dword for the LOW result (src0's bit clear) reads that operand as 0 in lanes
+    // 48-63 whenever the SIMD's OTHER wave issues a bf16 MFMA in the same cycles (v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16; not the
+    // f32 MFMA, not op_sel_hi, not the high result).  Lanes 48-63 of element 3 are gene 15 of the unit; waves 4-7 trail their SIMD partners
+    // 0-3 behind each barrier and meet the partners' dW products in their likelihood.  No wait state in the issuing wave can help, and the
+    // pin only moved the vectoriser's choice.  The library is built with -fno-slp-vectorize (sisua_amd/build.py; also 1-2 us per step
+    // faster) and tools/isa_lint.py rule R1 rejects the instruction form in every kernel at build time: the pin is gone.)
     {
       const int base = wbase + tbl;
       Split8 cur = tr_read(base, 0, 0), nx1 = tr_read(base, 1 % NP, 1 / NP), nx2 = nx1;

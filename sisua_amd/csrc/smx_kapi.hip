@@ -17,6 +17,12 @@ __global__ void hiprand_probe_kernel(uint64_t seed, int n, const uint32_t* c, ui
   const uint4 r = hiprand4(&st);
   theirs[4 * i] = r.x; theirs[4 * i + 1] = r.y; theirs[4 * i + 2] = r.z; theirs[4 * i + 3] = r.w;
 }
+// words of a and b that differ, added to *n (the stress entry point below)
+__global__ void count_diff_kernel(const uint32_t* a, const uint32_t* b, long n, unsigned* out) {
+  unsigned mine = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) mine += a[i] != b[i];
+  if (mine) atomicAdd(out, mine);
+}
 }  // namespace smx
 
 extern "C" {
@@ -300,6 +306,71 @@ int smx_k_head_fused(int likelihood, int u16, const float* x, const float* d, co
     }
   }
   hipFree(dX); hipFree(dD); hipFree(dWt); hipFree(dBias); hipFree(dGW); hipFree(dGb); hipFree(dPart); hipFree(dLl); hipFree(dSq); hipFree(dDd); hipFree(dX16); hipFree(dTab);
+  return rc;
+}
+
+// The fused head launched `launches` times on the same inputs; every launch after the first is compared on the device, bit for bit, with
+// what the first one left (dW, db, the d d slabs, the likelihood partials).  *n_differ = launches that differed anywhere, *first_word = index
+// of the first differing word of the first differing launch within [dW | db | slabs | partials] (-1 if none).  Two timing-dependent wrong
+// results of this kernel were hardware behaviour that no single launch shows reliably (tools/isa_lint.py); this is their regression test.
+int smx_k_head_fused_stress(int likelihood, int u16, const float* x, const float* d, const float* W, const float* bias, int32_t B, int32_t G,
+                            float grad_scale, int32_t launches, int32_t* n_differ, int64_t* first_word) {
+  SMX_REQUIRE(x && d && W && bias && n_differ && B > 0 && B <= 128 && G > 0 && launches >= 2, "bad arguments");
+  const int k = llk_planes(likelihood);
+  const int Gp = round_up(G, 32), H = 128;
+  SMX_REQUIRE(head_fused_supported(B, H, Gp, k), "head_fused: unsupported shape");
+  const int grid = head_fused_grid(Gp), n_gt = head_fused_chunks(Gp);
+  const size_t nW = (size_t)H * k * Gp, nb = (size_t)k * Gp, nP = (size_t)grid * B * H, nL = (size_t)B * n_gt, nOut = nW + nb + nP + nL;
+  float *dX = nullptr, *dD = nullptr, *dWt = nullptr, *dBias = nullptr, *dOut = nullptr, *dRef = nullptr, *dSq = nullptr, *dTab = nullptr;
+  uint16_t* dX16 = nullptr; unsigned* dN = nullptr;
+  int rc;
+  if ((rc = dmalloc(&dTab, (size_t)SMX_HEAD_FUSED_TAB_BYTES / 4)) || (rc = dmalloc(&dX, (size_t)B * Gp)) || (rc = dmalloc(&dD, (size_t)B * H)) || (rc = dmalloc(&dWt, nW)) ||
+      (rc = dmalloc(&dBias, nb)) || (rc = dmalloc(&dOut, nOut)) || (rc = dmalloc(&dRef, nOut)) || (rc = dmalloc(&dSq, (size_t)grid * 8)) || (rc = dmalloc(&dX16, (size_t)B * Gp)) ||
+      (rc = dmalloc(&dN, (size_t)1)))
+    return rc;
+  SMX_HIP(hipMemset(dX, 0, (size_t)B * Gp * 4)); SMX_HIP(hipMemset(dWt, 0, nW * 4)); SMX_HIP(hipMemset(dBias, 0, nb * 4));
+  SMX_HIP(hipMemcpy2D(dX, (size_t)Gp * 4, x, (size_t)G * 4, (size_t)G * 4, (size_t)B, hipMemcpyHostToDevice));
+  if (u16) {
+    std::vector<uint16_t> h16((size_t)B * Gp, 0);
+    for (int b = 0; b < B; ++b)
+      for (int g = 0; g < G; ++g) h16[(size_t)b * Gp + g] = (uint16_t)x[(size_t)b * G + g];
+    SMX_HIP(hipMemcpy(dX16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice));
+  }
+  SMX_HIP(hipMemcpy(dD, d, (size_t)B * H * 4, hipMemcpyHostToDevice));
+  for (int c = 0; c < k; ++c) {
+    SMX_HIP(hipMemcpy2D(dWt + (size_t)c * Gp, (size_t)k * Gp * 4, W + (size_t)c * G, (size_t)k * G * 4, (size_t)G * 4, (size_t)H, hipMemcpyHostToDevice));
+    SMX_HIP(hipMemcpy(dBias + (size_t)c * Gp, bias + (size_t)c * G, (size_t)G * 4, hipMemcpyHostToDevice));
+  }
+  HeadFusedArgs a;
+  a.D = dD; a.ldd = H; a.W = dWt; a.ldw = (long)k * Gp; a.bias = dBias;
+  a.X = u16 ? (const void*)dX16 : (const void*)dX; a.ldx = Gp; a.x_u16 = u16 ? 1 : 0;
+  a.dW = dOut; a.db = dOut + nW; a.part = dOut + nW + nb; a.slab_stride = (long)B * H; a.llk_part = dOut + nW + nb + nP; a.sq_part = dSq; a.dtab = dTab;
+  a.B = B; a.G = G; a.Gp = Gp; a.likelihood = likelihood; a.grad_scale = grad_scale;
+  int n_sq = 0, n_slabs = 0, differ = 0;
+  long long first = -1;
+  std::vector<uint32_t> ho, hr;
+  for (int it = 0; it < launches && rc == SMX_OK; ++it) {
+    SMX_HIP(hipMemsetAsync(dOut, 0xFF, nOut * 4, nullptr));
+    rc = launch_head_fused(nullptr, a, &n_slabs, &n_sq);
+    if (rc != SMX_OK) break;
+    if (it == 0) { SMX_HIP(hipMemcpyAsync(dRef, dOut, nOut * 4, hipMemcpyDeviceToDevice, nullptr)); continue; }
+    SMX_HIP(hipMemsetAsync(dN, 0, 4, nullptr));
+    hipLaunchKernelGGL(smx::count_diff_kernel, dim3(1024), dim3(256), 0, nullptr, reinterpret_cast<const uint32_t*>(dOut), reinterpret_cast<const uint32_t*>(dRef), (long)nOut, dN);
+    unsigned n = 0;
+    SMX_HIP(hipMemcpy(&n, dN, 4, hipMemcpyDeviceToHost));
+    if (n) {
+      ++differ;
+      if (first < 0) {
+        ho.resize(nOut); hr.resize(nOut);
+        SMX_HIP(hipMemcpy(ho.data(), dOut, nOut * 4, hipMemcpyDeviceToHost)); SMX_HIP(hipMemcpy(hr.data(), dRef, nOut * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < nOut; ++i) if (ho[i] != hr[i]) { first = (long long)i; break; }
+      }
+    }
+  }
+  if (rc == SMX_OK && hipDeviceSynchronize() != hipSuccess) { set_error("k_head_fused_stress: device synchronize failed"); rc = SMX_ERR_HIP; }
+  *n_differ = differ;
+  if (first_word) *first_word = first;
+  hipFree(dX); hipFree(dD); hipFree(dWt); hipFree(dBias); hipFree(dOut); hipFree(dRef); hipFree(dSq); hipFree(dX16); hipFree(dTab); hipFree(dN);
   return rc;
 }
 

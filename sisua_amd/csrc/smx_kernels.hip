@@ -512,11 +512,11 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
       if (SMALL) {
 #pragma unroll
         for (int i = 0; i < BN_RPT; ++i)
-          if (rl + BN_RL * i < a.B) { const float d = vreg[i] - mean; s2 += d * d; }
+          if (rl + BN_RL * i < a.B) { const float d = vreg[i] - mean; s2 = __builtin_fmaf(d, d, s2); }
       } else {
         for (int r = rl; r < a.B; r += BN_RL) {
           const float d = a.xhat[(long)r * a.Hp + col] - mean;
-          s2 += d * d;
+          s2 = __builtin_fmaf(d, d, s2);
         }
       }
       s2 = bn_col_reduce(s2, sh);
@@ -525,6 +525,9 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
       if (rl == 0) {
         if (a.batch_mean) { a.batch_mean[col] = mean; a.batch_var[col] = var; }
         if (a.update_moving && live) {
+          // (two products and a sum each, NOT fused: the arithmetic of every build so far -- round 5's compiler paired the two updates
+          // into packed multiplies and a packed add; spelled out since the library is built without that pairing, sisua_amd/build.py)
+#pragma clang fp contract(off)
           a.moving_mean[col] = mm_pre * a.momentum + mean * (1.f - a.momentum);
           a.moving_var[col] = mv_pre * a.momentum + var * (1.f - a.momentum);
         }
@@ -538,11 +541,12 @@ __device__ inline void bn_act_fwd_body(const BnFwdArgs& a, const int bid) {
   }
   const float scale = drop ? 1.f / (1.f - a.drop_p) : 1.f;
   auto finish = [&](int r, float v, float mahead) {
+#pragma clang fp contract(off)
     const long o = (long)r * a.Hp + col;
     float y = v;
     if (a.batchnorm) {
       v = (v - mean) * inv;
-      y = gamma * v + beta;
+      y = __builtin_fmaf(gamma, v, beta);
     }
     if (a.batchnorm || SMALL) a.xhat[o] = v;
     float h = fmaxf(y, 0.f);
@@ -766,7 +770,10 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
         if (a.batchnorm) xh = SMALL ? xhpre[i] : a.xhat[o];
         if (!SMALL) a.dpre[o] = dy;
         s1 += dy;
-        s2 += dy * xh;
+        { // (product, then sum: not fused -- see the moving statistics of bn_act_fwd_body)
+#pragma clang fp contract(off)
+          s2 += dy * xh;
+        }
       }
       if (SMALL) { dyreg[i] = dy; xhreg[i] = xh; }
     }
@@ -791,7 +798,7 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
   const float invB = 1.f / (float)a.B;
   auto finish = [&](int r, float dy, float xh) {
     float d;
-    if (a.training) d = gamma * inv * (dy - invB * (s1 + xh * s2));
+    if (a.training) d = (gamma * inv) * __builtin_fmaf(-__builtin_fmaf(xh, s2, s1), invB, dy);
     else d = dy * gamma * inv;
     a.dpre[(long)r * a.Hp + col] = d;
   };

@@ -602,6 +602,20 @@ def k_head_fused(likelihood: str, x, d, W, bias, grad_scale: float = 1.0, u16: b
   return dict(llk=llk, dW=dW, db=db, dd=dd, sumsq=float(sumsq[0]), us=float(us[0]))
 
 
+def k_head_fused_stress(likelihood: str, x, d, W, bias, launches: int, grad_scale: float = 1.0, u16: bool = False):
+  """`launches` launches of the fused output head on the same inputs, each compared bit for bit on the device with the first:
+  (launches that differed, index of the first differing output word or -1)."""
+  lib = _hip.require_gpu()
+  x, d, W, bias = _f32(x), _f32(d), _f32(W), _f32(bias)
+  B, G = x.shape
+  k = W.shape[1]
+  assert d.shape == (B, 128) and W.shape == (128, k, G) and bias.shape == (k, G)
+  n, first = C.c_int32(0), C.c_int64(-1)
+  check(lib.smx_k_head_fused_stress(_hip.LIKELIHOODS[likelihood], int(u16), _fp(x), _fp(d), _fp(W), _fp(bias), B, G, float(grad_scale), int(launches),
+                                    C.byref(n), C.byref(first)))
+  return int(n.value), int(first.value)
+
+
 def k_adam(params, grads, m, v, step: int, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, clipnorm=100.0):
   """The optimiser launch by itself over lists of arrays (updated copies are returned): (params, m, v, norms)."""
   lib = _hip.require_gpu()
