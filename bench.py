@@ -197,7 +197,7 @@ def measure_mode(cp, rank, world, local_rank, cfg, batch, steps, warmup, upload,
   rank's batch), (b) the same step with the job's collective, K steps between barrier + synchronize brackets, max over ranks,
   (c) the collective alone.  Returns the dict that goes into `scaling_modes` (rank 0's copy is printed) and the engine is closed."""
   from sisua_amd.engine import Engine
-  from sisua_amd.parallel import attach_engine
+  from sisua_amd.parallel import attach_engine, calibrate_forms
   eng = Engine(cfg, max_batch=batch, device=local_rank)
   upload(eng)
   order = make_order(n_cells, batch, warmup + steps)
@@ -226,6 +226,7 @@ def measure_mode(cp, rank, world, local_rank, cfg, batch, steps, warmup, upload,
   collective = attach_engine(eng, cp)
   if sync_bn:
     eng.set_sync_bn(True)
+  calib = calibrate_forms(eng, cp, collective, make_order(n_cells, batch, 35), batch)   # the exchange form: measured, the same on every rank
   dt = timed_steps()                        # (b) the data-parallel step
   us, nbytes = -1.0, None
   try:
@@ -239,10 +240,11 @@ def measure_mode(cp, rank, world, local_rank, cfg, batch, steps, warmup, upload,
   hist = eng.metrics_history(steps)
   if not np.isfinite(hist["loss"]).all():
     sys.exit("bench: non-finite loss in the timed steps")
-  form = {0: "none", 1: "one all-reduce", 2: "two-bucket chain", 3: "two buckets on the communication stream"}.get(eng.comm_form, "?")
+  form = Engine.FORM_NAMES.get(eng.comm_form, "?")
   eng.close()
   return {"cells_per_s": round(steps * batch * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4),
           "batch_per_gpu": batch, "global_batch": batch * world, "sync_bn": bool(sync_bn), "collective": collective, "exchange": form,
+          "exchange_forms_us_per_step": {Engine.FORM_NAMES[k]: v for k, v in calib["us_per_step"].items()},
           "allreduce_us": round(us, 1) if us >= 0 else None, "allreduce_bytes": nbytes,
           "nocomm_ms_per_step": round(1e3 * dt0 / steps, 4), "dp_overhead_us": round(1e6 * (dt - dt0) / steps, 1),
           "final_loss": round(float(hist["loss"][-1]), 4)}
@@ -372,7 +374,7 @@ def main():
     if cp.max(float(eng.comm_p2p_error() if collective in ("p2p", "p2p-only") else 0)) > 0:
       sys.exit("bench: the peer-to-peer exchange reported a timed-out wait; the timed steps are void")
     dp_info = {"collective": collective, "allreduce_us": round(us, 1) if us >= 0 else None, "allreduce_bytes": nbytes,
-               "exchange": {0: "none", 1: "one all-reduce", 2: "two-bucket chain", 3: "two buckets on the communication stream"}.get(eng.comm_form, "?")}
+               "exchange": Engine.FORM_NAMES.get(eng.comm_form, "?")}
   # the ELBO scalars of every timed step stayed on the device (smx_metrics_history): read after the clock has stopped
   hist = eng.metrics_history(args.steps)
   m = {k: float(v[-1]) for k, v in hist.items()}
@@ -579,33 +581,88 @@ def main():
       out["dp"] = dp_info
   else:
     out = None
-  # N > 1: the line is self-sufficient -- weak, strong + SyncBatchNorm (the reference's arithmetic) and the C5 share, measured in this run
-  # They come LAST, behind a watchdog on rank 0: no multi-GPU node has ever run this code, and a mode that hangs or
-  # raises on one rank must not take the contract's line -- complete by now -- with it.  SMX_BENCH_MODES_BUDGET_S (default 300) after they
-  # start, rank 0 prints the line without them and leaves.
+  # N > 1, the late phases: the line above is COMPLETE by now (its K steps ran with ONE all-reduce of the flat buffer, the north star's form and
+  # the only one a multi-GPU node has ever run).  What follows has never run on N > 1 GPUs: (1) the exchange form
+  # chosen by measurement -- parallel.calibrate_forms times one all-reduce / the two-bucket chain / the hand-written exchange on this job's own
+  # step, max over ranks; if another form wins, the contract's W + K steps are run again with it and THAT is `value` --, (2) the scaling
+  # modes.  A watchdog on EVERY rank (SMX_BENCH_MODES_BUDGET_S, default 300 s from here): if a phase hangs or a rank dies, rank 0 prints the
+  # line as far as it got and every rank leaves (a watchdog on rank 0 alone left the others in their collectives for good).
   scaling_modes = None
+  late = {"phase": "exchange-form calibration"}
+  if world > 1:
+    import threading
+    def _give_up():
+      if rank == 0:
+        line = dict(out)
+        line.setdefault("dp", {})["late_phases"] = f"not finished within the budget (stopped in: {late['phase']}); everything above is complete"
+        if not args.no_scaling_modes and args.workload == "8kly":
+          line["scaling_modes"] = {"error": "not finished within the budget; the line above them is complete", "finished": sorted(k for k in (scaling_modes or {}) if k[:1] != "_")}
+        print(json.dumps(line), flush=True)
+      else:
+        time.sleep(3.0)   # (rank 0 prints first)
+      os._exit(0)
+    watchdog = threading.Timer(float(os.environ.get("SMX_BENCH_MODES_BUDGET_S", "300")), _give_up)
+    watchdog.daemon = True
+    watchdog.start()
+    from sisua_amd.parallel import calibrate_forms
+    first_form = eng.comm_form
+    calib = calibrate_forms(eng, cp, collective, make_order(xt.shape[0], batch, 35), batch)
+    dp_line = {"first_form": Engine.FORM_NAMES.get(first_form, "?"), "first_form_ms_per_step": round(1e3 * dt / args.steps, 4),
+               "forms_us_per_step": {Engine.FORM_NAMES[k]: v for k, v in calib["us_per_step"].items()},
+               "selected": Engine.FORM_NAMES.get(calib["selected"], "?"),
+               "how": f"parallel.calibrate_forms: {calib['steps']} steps per form from the same state, max over ranks; SMX_DP_FORM / SMX_DP_CALIBRATE=0 override"}
+    if calib["selected"] != first_form:
+      late["phase"] = "the contract's steps with the selected form"
+      if args.warmup:
+        eng.train_steps(order[: args.warmup * batch], args.warmup, batch)
+      eng.stage_steps(order[args.warmup * batch:], args.steps, batch)
+      eng.synchronize()
+      cp.barrier()
+      try:
+        eng.comm_time_allreduce(1)
+      except Exception as err:
+        print(f"bench: device-side line-up skipped: {err}", file=sys.stderr)
+      t0 = time.perf_counter()
+      eng.train_steps(None, args.steps, batch)
+      eng.synchronize()
+      t1 = time.perf_counter()
+      cp.barrier()
+      dt_sel = cp.max(t1 - t0)
+      h2 = eng.metrics_history(args.steps)
+      dp_line["selected_ms_per_step"] = round(1e3 * dt_sel / args.steps, 4)
+      if np.isfinite(h2["loss"]).all() and dt_sel < dt and rank == 0:
+        out.update(value=round(args.steps * batch * world / dt_sel, 1), ms_per_step=round(1e3 * dt_sel / args.steps, 4), final_loss=round(float(h2["loss"][-1]), 4))
+        dp_line["value_is"] = "the selected form's K steps"
+      elif rank == 0:
+        dp_line["value_is"] = "the first form's K steps (the selected form was not faster over the contract's K)"
+    else:
+      dp_line["value_is"] = "the first form's K steps (it is the selected form)"
+    if rank == 0:
+      out["dp"].update(dp_line)
+      out["dp"]["exchange"] = Engine.FORM_NAMES.get(eng.comm_form, "?")
+    if args.no_scaling_modes or args.workload != "8kly":
+      watchdog.cancel()
   if world > 1 and not args.no_scaling_modes and args.workload == "8kly":
     scaling_modes = {}
-    watchdog = None
-    if rank == 0:
-      import threading
-      def _give_up():
-        out["scaling_modes"] = {"error": "not finished within the budget; the line above them is complete", "finished": sorted(scaling_modes.keys())}
-        print(json.dumps(out), flush=True)
-        os._exit(0)
-      watchdog = threading.Timer(float(os.environ.get("SMX_BENCH_MODES_BUDGET_S", "300")), _give_up)
-      watchdog.daemon = True
-      watchdog.start()
+    late["phase"] = "scaling modes"
     k_steps, k_warm = max(args.steps, 20), max(args.warmup, 5)
     cfg8, x8, b8, ex8 = build_workload(rank, world, "8kly")
     base8 = ex8.pop("cell_id_base", 0)
     up8 = lambda e: e.upload(x8, cell_id_base=base8, storage=args.storage, **ex8)
-    def run_mode(name, **more):   # (a mode that fails is reported as such; the ranks that did not fail meet rank 0's watchdog)
+    def run_mode(name, **more):   # (a mode that fails on ANY rank ends the modes on every rank: its peers may still be inside its collectives)
       def go(*a, **kw):
+        late["phase"] = f"scaling mode {name}"
+        if scaling_modes.get("_stopped"):
+          return
+        failed = 0.0
         try:
           scaling_modes[name] = dict(measure_mode(*a, **kw), **more)
         except (Exception, SystemExit) as err:
           scaling_modes[name] = {"error": str(err)[:300]}
+          failed = 1.0
+        if cp.max(failed) > 0:   # (ranks that did not fail arrive here too -- or meet the watchdog)
+          scaling_modes.setdefault(name, {})["stopped_here"] = "a rank failed in this mode; the later modes were not started"
+          scaling_modes["_stopped"] = True
       return go
     run_mode("weak")(cp, rank, world, local_rank, cfg8, b8, k_steps, k_warm, up8, x8.shape[0])
     if b8 % world == 0:
@@ -614,10 +671,10 @@ def main():
     n5 = (args.c5_cells or 1_000_000) // world
     up5 = lambda e: e.generate_lognormal(n5, seed=8, rank=rank, storage="u16")
     run_mode("c5", cells_resident_per_gpu=n5, storage="u16, generated on the device from (seed, rank)")(cp, rank, world, local_rank, cfg5, b5, k_steps, k_warm, up5, n5)
-    if watchdog is not None:
-      watchdog.cancel()
+    watchdog.cancel()
   if rank == 0:
     if scaling_modes is not None:
+      scaling_modes.pop("_stopped", None)
       for k_, v_ in scaling_modes.items():
         v_["predicted_n8"] = PREDICTED_N8.get(k_)
       out["scaling_modes"] = scaling_modes

@@ -328,10 +328,16 @@ int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]);
 int smx_comm_world(const smx_model* m);
 int smx_comm_rank(const smx_model* m);
 /* How an (eager) training step exchanges its gradients right now: 0 no collective (world 1), 1 ONE all-reduce of the flat buffer between
- * the backward pass and the optimiser (north star), 2 the two-bucket chain -- the heads' gradients (3/4 of the bytes) all-reduced, normed and
- * applied on a communication stream beside the rest of the step, the front bucket all-reduced on the model's stream (taken from 3 MB of
- * head gradients; SMX_DP_BUCKETS=1|2 overrides), 3 the hand-written exchange's two-bucket form (both buckets on the communication stream). */
+ * the backward pass and the optimiser (north star; RCCL or the tests' loopback), 2 the two-bucket chain -- the heads' gradients (3/4 of the
+ * bytes) all-reduced, normed and applied on a communication stream beside the rest of the step, the front bucket all-reduced on the model's
+ * stream --, 3 the hand-written exchange over IPC-mapped peer buffers, one bucket, ONE launch per all-reduce on the model's stream, 4 the
+ * hand-written exchange's two-bucket form of round 4 (both buckets on the communication stream; only under the library's own rule). */
 int smx_comm_form(const smx_model* m);
+/* Ask for a form: 1, 2 or 3 as above (3 needs smx_comm_p2p_init, 1 / 2 a communicator), or 0 = the library's own rule (the hand-written
+ * exchange whenever it is attached; two buckets from 3 MB of head gradients, SMX_DP_BUCKETS=1|2 overrides).  A COLLECTIVE call when it
+ * asks for 2 (the heads' communicator is split off on first use): every rank, same order.  sisua_amd/parallel.py measures the available
+ * forms on the job's own steps and sets the fastest on every rank (calibrate_forms); nothing asked = nothing measured. */
+int smx_comm_set_form(smx_model* m, int form);
 /* Flag "opt_shard" (smx_set_flag; off by default; data parallel, the chained form -- it is taken whenever the flag is set): the output and
  * label heads' optimiser state is SHARDED over the ranks -- reduce-scatter of their gradient bucket, per-tensor clipnorm + Adam on this rank's
  * 1 / world slice, all-gather of the updated parameters (the same wire bytes as the all-reduce; 1 / world of the optimiser's memory traffic).

@@ -117,6 +117,7 @@ SIGNATURES = {
     "smx_comm_world": (C.c_int, [_VP]),
     "smx_comm_rank": (C.c_int, [_VP]),
     "smx_comm_form": (C.c_int, [_VP]),
+    "smx_comm_set_form": (C.c_int, [_VP, C.c_int]),
     "smx_opt_gather": (C.c_int, [_VP]),
     "smx_comm_library": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, _IP]),
     "smx_comm_set_sync_bn": (C.c_int, [_VP, C.c_int]),

@@ -79,6 +79,12 @@ __global__ void local_sum_kernel(LocalSrc s, float* dst, size_t count) {
   }
 }
 
+// The hand-written exchange (smx_p2p.hip) takes the step's collectives when it is attached and either asked for (form 3) or the only one
+// there is; under the library's own rule (form 0) it keeps the precedence over RCCL it has had since round 3 (SMX_ALLREDUCE=p2p).
+bool p2p_selected(const smx_model* m) {
+  if (!(m->p2p && m->p2p->error)) return false;
+  return m->dp_form == 0 || m->dp_form == 3 || !m->comm;
+}
 // data-parallel overlap: two buckets on a communication stream (eager launches only)
 bool dp_active(const smx_model* m) {
   // dp_force: exercise RCCL on a 1-rank communicator (tests); local: the loopback communicator of the tests
@@ -96,13 +102,13 @@ bool dp_overlap(const smx_model* m) {
   // SyncBatchNorm-backward exchanges on the model's stream, and both go through ONE staging buffer, ONE done counter and ONE
   // monotonic flag set (REDUCED(e + 1) satisfies waiters on e; staging overwritten mid-gather -- ADVICE r03).  RCCL serialises per
   // communicator and keeps the overlap.
-  if (m->p2p && m->p2p->error && m->sync_bn) return false;
+  if (p2p_selected(m) && m->sync_bn) return false;
   return dp_active(m) && m->dp_two_buckets && !m->capturing && m->st_comm != nullptr && !m->local;
 }
 // the chained form: RCCL (the heads' bucket on its own communicator when ncclCommSplit gave one) or the tests' loopback communicator; the
 // hand-written exchange keeps round 4's form (one staging buffer, one flag set: its two buckets cannot be in flight together)
 bool dp_chain_ok(const smx_model* m) {
-  if (!dp_active(m) || !(m->dp_two_buckets || m->flags.opt_shard) || m->capturing || !m->st_comm || (m->p2p && m->p2p->error)) return false;
+  if (!dp_active(m) || !(m->dp_two_buckets || m->flags.opt_shard) || m->capturing || !m->st_comm || p2p_selected(m)) return false;
   return m->bucket1_count > 0 && m->chunk_first_head < m->n_chunks;
 }
 int local_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
@@ -134,7 +140,7 @@ int local_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
 }
 int dp_allreduce_buf(smx_model* m, float* buf, size_t count, hipStream_t st, bool second) {
   if (m->local) return local_allreduce(m, buf, count, st);
-  if (m->p2p && m->p2p->error) return p2p_allreduce(m, buf, count, st);
+  if (p2p_selected(m)) return p2p_allreduce(m, buf, count, st);
   ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclFloat32, ncclSum, (second && m->comm2) ? m->comm2 : m->comm, st);
   if (r != ncclSuccess) {
     set_error(std::string("ncclAllReduce failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
@@ -173,7 +179,7 @@ static int local_slices(smx_model* m, float* buf, size_t slice, hipStream_t st, 
 }
 bool dp_shard_available(const smx_model* m) {
   if (m->local) return true;
-  return m->comm && g_rccl.ReduceScatter && g_rccl.AllGather && !(m->p2p && m->p2p->error);
+  return m->comm && g_rccl.ReduceScatter && g_rccl.AllGather && !p2p_selected(m);
 }
 int dp_reduce_scatter(smx_model* m, float* buf, size_t slice, hipStream_t st, bool second) {
   if (m->local) return local_slices(m, buf, slice, st, false);
@@ -212,6 +218,7 @@ static int comm_detach(smx_model* m) {   // leave whatever communicator the mode
   m->comm = nullptr;
   m->local.reset();
   m->rank = 0; m->world = 1;
+  m->dp_form = 0;
   drop_graphs(m);
   return SMX_OK;
 }
@@ -220,10 +227,19 @@ static int comm_detach(smx_model* m) {   // leave whatever communicator the mode
 namespace smx {
 // the communication stream of the two-bucket form (the heads' gradients, 3/4 of the bytes and final long before the rest, are reduced
 // -- and applied -- beside the rest of the step) and the switches read when a communicator is attached
+// Which exchange the steps take.  Asked for (smx_comm_set_form 1 / 2 / 3: what sisua_amd/parallel.py's calibration measured fastest on
+// every rank, or SMX_DP_FORM) -- or, with nothing asked (form 0), the rule of rounds 4-5: SMX_DP_BUCKETS if set, else two buckets from
+// SMX_DP_BUCKETS_MIN_BYTES of head gradients.  That constant is a guess that BASELINE configs[1] sits right on: it only
+// decides when nobody measured.
+void apply_dp_form(smx_model* m) {
+  const char* nb = getenv("SMX_DP_BUCKETS");
+  if (m->dp_form == 1 || m->dp_form == 3) m->dp_two_buckets = false;
+  else if (m->dp_form == 2) m->dp_two_buckets = true;
+  else m->dp_two_buckets = nb ? atoi(nb) == 2 : m->bucket1_count * sizeof(float) >= SMX_DP_BUCKETS_MIN_BYTES;
+}
 int ensure_comm_stream(smx_model* m) {
   m->dp_force = getenv("SMX_FORCE_ALLREDUCE") != nullptr;
-  const char* nb = getenv("SMX_DP_BUCKETS");
-  m->dp_two_buckets = nb ? atoi(nb) == 2 : m->bucket1_count * sizeof(float) >= SMX_DP_BUCKETS_MIN_BYTES;
+  apply_dp_form(m);
   if (!m->st_comm) {
     if (hipStreamCreateWithFlags(&m->st_comm, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_c1, hipEventDisableTiming) != hipSuccess ||
@@ -234,6 +250,12 @@ int ensure_comm_stream(smx_model* m) {
     }
   }
   return SMX_OK;
+}
+// the heads' bucket's own communicator (a COLLECTIVE call: every rank, in the same order)
+void ensure_comm2(smx_model* m) {
+  if (!m->comm || m->comm2 || !m->dp_two_buckets || !g_rccl.CommSplit || getenv("SMX_DP_ONE_COMM")) return;
+  ncclComm_t c2 = nullptr;
+  if (g_rccl.CommSplit(m->comm, 0, m->rank, &c2, nullptr) == ncclSuccess && c2) m->comm2 = c2;
 }
 int ensure_sync_buf(smx_model* m) {
   int wmax = 0;
@@ -268,10 +290,7 @@ int smx_comm_init(smx_model* m, int rank, int world, const uint8_t id[128]) {
   // the heads' bucket on a communicator of its own (same ranks, same order): RCCL serialises the operations of ONE communicator in issue
   // order whatever their streams, which would put the front bucket's all-reduce behind the heads' 30 MB.  Without ncclCommSplit (or when it
   // fails) both buckets share `comm`: still correct, the overlap is then what the backward pass covers.
-  if (m->dp_two_buckets && g_rccl.CommSplit && !getenv("SMX_DP_ONE_COMM")) {
-    ncclComm_t c2 = nullptr;
-    if (g_rccl.CommSplit(comm, 0, rank, &c2, nullptr) == ncclSuccess && c2) m->comm2 = c2;
-  }
+  ensure_comm2(m);
   SMX_CHECK(ensure_sync_buf(m));
   drop_graphs(m);
   return SMX_OK;
@@ -365,7 +384,22 @@ int smx_opt_gather(smx_model* m) {
 }
 int smx_comm_form(const smx_model* m) {
   if (!m || !smx::dp_active(m)) return 0;
-  return smx::dp_chain_ok(m) ? 2 : smx::dp_overlap(m) ? 3 : 1;
+  if (smx::dp_chain_ok(m)) return 2;
+  if (smx::p2p_selected(m)) return smx::dp_overlap(m) ? 4 : 3;
+  return 1;
+}
+int smx_comm_set_form(smx_model* m, int form) {
+  SMX_REQUIRE(m && form >= 0 && form <= 3, "comm_set_form: 0 (the library's rule), 1 (one all-reduce), 2 (two-bucket chain) or 3 (hand-written exchange)");
+  SMX_REQUIRE(form != 3 || (m->p2p && m->p2p->error), "comm_set_form: the hand-written exchange is not attached (smx_comm_p2p_export / _init)");
+  SMX_REQUIRE(form == 0 || form == 3 || m->comm || m->local, "comm_set_form: no RCCL / loopback communicator attached");
+  if (m->st) SMX_HIP(hipStreamSynchronize(m->st));
+  if (m->st_comm) SMX_HIP(hipStreamSynchronize(m->st_comm));
+  if (m->opt_stale) SMX_CHECK(smx_opt_gather(m));   // (sharded moments are whole again before the form that shards them can go)
+  m->dp_form = form;
+  smx::apply_dp_form(m);
+  smx::ensure_comm2(m);
+  drop_graphs(m);
+  return SMX_OK;
 }
 int smx_comm_world(const smx_model* m) { return m ? m->world : 0; }
 

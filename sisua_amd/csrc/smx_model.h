@@ -130,6 +130,7 @@ struct P2PState {
   long long timeout_ticks = 3000000000LL;                // bound of a device-side wait, 100 MHz ticks (SMX_P2P_TIMEOUT_S)
 };
 int p2p_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st);
+bool p2p_selected(const smx_model* m);   // the hand-written exchange is attached AND the form in force takes it (smx_comm.hip)
 void p2p_release(smx_model* m);
 int ensure_sync_buf(smx_model* m);
 int ensure_comm_stream(smx_model* m);
@@ -278,6 +279,9 @@ struct smx_model {
   // SyncBatchNorm (opt-in, smx_comm_set_sync_bn): per BN launch one small all-reduce of per-rank column statistics
   bool sync_bn = false; float* sync_buf = nullptr; size_t sync_cap = 0;
   bool dp_force = false, dp_two_buckets = false;   // SMX_FORCE_ALLREDUCE / SMX_DP_BUCKETS=2, read when the communicator is attached
+  // the exchange form asked for (smx_comm_set_form): 0 = the library's rule (bytes of head gradients, the hand-written exchange whenever it is
+  // attached), 1 = ONE all-reduce of the flat buffer on the model's stream, 2 = the two-bucket chain, 3 = the hand-written exchange (one bucket)
+  int dp_form = 0;
   hipStream_t st_comm = nullptr; hipEvent_t ev_c1 = nullptr, ev_c2 = nullptr, ev_c3 = nullptr;
   size_t bucket1_off = 0, bucket1_count = 0;   // gradients of the output / label heads: ready first, reduced early
   bool bucket1_in_flight = false;

@@ -6,14 +6,14 @@
 // communication region R_r = [flags | staging S_r | scratch X_r] -- and maps its peers' (xGMI: a peer pointer is a load /
 // store target like local memory).  An all-reduce of G over `world` ranks, chunk c = the c-th 1 / world of the buffer:
 //
-//   launch A  signal READY(e) to every peer; wait for every peer's READY(e)        -- all backward passes have written G
-//             S_r = sum over q (rank order) of G_q[chunk r]                        -- reduce-scatter: reads 1/world of every peer
+//   phase A   signal READY(e) to every peer; wait for every peer's READY(e)        -- all backward passes have written G
+//             S_r = G_r[chunk r] = sum over q (rank order) of G_q[chunk r]         -- reduce-scatter: reads 1/world of every peer
 //             the last workgroup to finish signals REDUCED(e) to every peer
-//   launch B  for every q: wait for REDUCED(e) of q; G_r[chunk q] = S_q            -- all-gather: reads every peer's staging
+//   phase B   for every q: wait for REDUCED(e) of q; G_r[chunk q] = S_q            -- all-gather: reads every peer's staging
 //
-// Two launches, two flag rounds, each byte crosses a link twice (in, as 1/world pieces from 7 peers at once: the bandwidth of
-// all links together).  No exit round: S_r is rewritten only in launch A(e + 1), behind READY(e + 1) of every peer -- which a
-// peer raises after its own launch B(e) has completed on its stream; G_r is read by peers only between READY(e) and
+// ONE launch (round 6: the phases were two launches before), two flag rounds, each byte crosses a link twice (in, as 1/world pieces from 7 peers at once: the bandwidth of
+// all links together).  No exit round: S_r is rewritten only in phase A(e + 1), behind READY(e + 1) of every peer -- which a
+// peer raises after its own launch of epoch e has completed on its stream; G_r is read by peers only between READY(e) and
 // REDUCED(e).  Summation in rank order on every rank: bitwise the same result everywhere, run to run.
 // Flags are monotonic epochs written with system-scope release stores and polled with system-scope acquire loads; every wait
 // is BOUNDED (a peer that died must not hang the device: after ~2 s the wait gives up and raises an error word the host
@@ -57,8 +57,14 @@ __device__ inline void poison_peers(const P2PArgs& a) {   // (threads [0, world)
     __hip_atomic_store(a.peer_error[threadIdx.x], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ONE launch per all-reduce (round 6; rounds 3-5 ran the two phases as two launches: +22 us per C2 step on one rank before a byte crossed a
+// link).  The protocol is the header's, flag for flag -- only the kernel boundary between the reduce-scatter and the all-gather is gone:
+// a workgroup that has finished its part of S_r goes on to fetch the peers' reduced chunks, each behind that peer's REDUCED(e).  Nothing is
+// read or written earlier or by anybody else than before: G_r[chunk q] is overwritten only after REDUCED(e) of q, which q raises when ALL
+// its reads of chunk q are done; this rank's own chunk is written in place by the thread that read it (no peer reads G_r[chunk r]).
+// Every rank's launch must be resident while its peers' are (as before: <= 128 workgroups); the waits stay bounded.
 template <int W>   // W = world (compile-time: the per-rank load arrays stay in registers)
-__global__ __launch_bounds__(256) void p2p_reduce_scatter_kernel(P2PArgs a) {
+__global__ __launch_bounds__(256) void p2p_exchange_kernel(P2PArgs a) {
   __shared__ int ok_s;
   if (threadIdx.x < (unsigned)a.world) {
     const int q = threadIdx.x;
@@ -71,12 +77,12 @@ __global__ __launch_bounds__(256) void p2p_reduce_scatter_kernel(P2PArgs a) {
     if (!wait_flag(a.flags[a.rank] + threadIdx.x, a.epoch, a.error, a.timeout_ticks)) ok_s = 0;
   __syncthreads();
   if (!ok_s) poison_peers(a);
-  if (ok_s) {
+  const long stride = (long)gridDim.x * 256;
+  if (ok_s && W > 1) {   // (a world of one: the sum over one rank is the buffer itself)
     const long base = (long)a.rank * a.chunk;
     const long n4 = std::max<long>(0, std::min(a.chunk, a.count - base)) >> 2;
     // four positions x every rank in flight per thread (a link's latency x bandwidth is ~150 KB: one 16-byte load per thread of
     // a small grid would leave the links idle most of the time); the sum itself in rank order
-    const long stride = (long)gridDim.x * 256;
     for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
       float4 v[W][4];
 #pragma unroll
@@ -93,42 +99,43 @@ __global__ __launch_bounds__(256) void p2p_reduce_scatter_kernel(P2PArgs a) {
         float4 acc = v[0][u];
 #pragma unroll
         for (int q = 1; q < W; ++q) { acc.x += v[q][u].x; acc.y += v[q][u].y; acc.z += v[q][u].z; acc.w += v[q][u].w; }
-        reinterpret_cast<float4*>(a.s[a.rank])[i] = acc;
+        reinterpret_cast<float4*>(a.s[a.rank])[i] = acc;          // for the peers
+        reinterpret_cast<float4*>(a.out + base)[i] = acc;         // this rank's own copy of its chunk
       }
     }
   }
   // REDUCED(e) once every workgroup's part of S is visible system-wide
   __threadfence_system();
   __syncthreads();
-  if (threadIdx.x == 0) ok_s = (atomicAdd(a.done, 1u) == gridDim.x - 1) ? 1 : 0;
+  __shared__ int last_s;
+  if (threadIdx.x == 0) last_s = (atomicAdd(a.done, 1u) == gridDim.x - 1) ? 1 : 0;
   __syncthreads();
-  if (ok_s) {
+  if (last_s) {
     if (threadIdx.x == 0) *a.done = 0;
     // (a workgroup whose wait failed set the error word before it counted itself done: S_r is incomplete, REDUCED(e) is NOT raised)
     const bool failed = __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
     if (!failed && threadIdx.x < (unsigned)a.world && (int)threadIdx.x != a.rank)
       __hip_atomic_store(a.flags[threadIdx.x] + SMX_P2P_MAX + a.rank, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-}
-
-// grid = world x blocks_per_rank: blockIdx.y = the source rank whose reduced chunk this workgroup fetches
-__global__ __launch_bounds__(256) void p2p_all_gather_kernel(P2PArgs a) {
-  __shared__ int ok_s;
-  const int q = blockIdx.y;
-  if (threadIdx.x == 0) ok_s = (q == a.rank) ? 1 : (wait_flag(a.flags[a.rank] + SMX_P2P_MAX + q, a.epoch, a.error, a.timeout_ticks) ? 1 : 0);
-  __syncthreads();
-  if (!ok_s) { poison_peers(a); return; }
-  const long base = (long)q * a.chunk;
-  const long n4 = std::max<long>(0, std::min(a.chunk, a.count - base)) >> 2;
-  const float4* src = reinterpret_cast<const float4*>(a.s[q]);
-  float4* dst = reinterpret_cast<float4*>(a.out + base);
-  const long stride = (long)gridDim.x * 256;
-  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {   // four loads in flight per thread
-    float4 v[4];
+  if (!ok_s) return;
+  // all-gather: the peers' reduced chunks, nearest rank first (rank + 1, rank + 2, ...: the ranks do not all start on the same source)
+  for (int j = 1; j < W; ++j) {
+    const int q = (a.rank + j) % W;
+    __syncthreads();
+    if (threadIdx.x == 0) ok_s = wait_flag(a.flags[a.rank] + SMX_P2P_MAX + q, a.epoch, a.error, a.timeout_ticks) ? 1 : 0;
+    __syncthreads();
+    if (!ok_s) { poison_peers(a); return; }
+    const long base = (long)q * a.chunk;
+    const long n4 = std::max<long>(0, std::min(a.chunk, a.count - base)) >> 2;
+    const float4* src = reinterpret_cast<const float4*>(a.s[q]);
+    float4* dst = reinterpret_cast<float4*>(a.out + base);
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {   // four loads in flight per thread
+      float4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const long i = i0 + u * stride; v[u] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+      for (int u = 0; u < 4; ++u) { const long i = i0 + u * stride; v[u] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const long i = i0 + u * stride; if (i < n4) dst[i] = v[u]; }
+      for (int u = 0; u < 4; ++u) { const long i = i0 + u * stride; if (i < n4) dst[i] = v[u]; }
+    }
   }
 }
 
@@ -161,16 +168,15 @@ int p2p_allreduce(smx_model* m, float* buf, size_t count, hipStream_t st) {
   // a fraction of the chip: the exchange is link-bound, and every rank's launches must be resident together (the flag rounds)
   const unsigned nb = (unsigned)std::max<long>(1, std::min<long>(128, (a.chunk / 4 + 1023) / 1024));
   switch (p.world) {
-    case 1: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<1>, dim3(nb), dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<2>, dim3(nb), dim3(256), 0, st, a); break;
-    case 3: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<3>, dim3(nb), dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<4>, dim3(nb), dim3(256), 0, st, a); break;
-    case 5: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<5>, dim3(nb), dim3(256), 0, st, a); break;
-    case 6: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<6>, dim3(nb), dim3(256), 0, st, a); break;
-    case 7: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<7>, dim3(nb), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL(p2p_reduce_scatter_kernel<8>, dim3(nb), dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL(p2p_exchange_kernel<1>, dim3(1), dim3(256), 0, st, a); break;   // (flags only: one workgroup)
+    case 2: hipLaunchKernelGGL(p2p_exchange_kernel<2>, dim3(nb), dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(p2p_exchange_kernel<3>, dim3(nb), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(p2p_exchange_kernel<4>, dim3(nb), dim3(256), 0, st, a); break;
+    case 5: hipLaunchKernelGGL(p2p_exchange_kernel<5>, dim3(nb), dim3(256), 0, st, a); break;
+    case 6: hipLaunchKernelGGL(p2p_exchange_kernel<6>, dim3(nb), dim3(256), 0, st, a); break;
+    case 7: hipLaunchKernelGGL(p2p_exchange_kernel<7>, dim3(nb), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(p2p_exchange_kernel<8>, dim3(nb), dim3(256), 0, st, a); break;
   }
-  hipLaunchKernelGGL(p2p_all_gather_kernel, dim3(std::max(1u, std::min(nb, 128u / (unsigned)p.world)), (unsigned)p.world), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   if (!is_g) SMX_HIP(hipMemcpyAsync(buf, p.scratch[p.rank], count * sizeof(float), hipMemcpyDeviceToDevice, st));
   return SMX_OK;

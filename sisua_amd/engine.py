@@ -145,6 +145,18 @@ class Engine:
       check(self.lib.smx_set_bn(self._h, int(i), 0, _fp(_f32(st["moving_mean"]))))
       check(self.lib.smx_set_bn(self._h, int(i), 1, _fp(_f32(st["moving_var"]))))
 
+  def snapshot(self) -> dict:
+    """Everything a training step changes -- parameters, both Adam moments, the BatchNorm moving statistics, the step counter -- as host
+    arrays (what models.py keeps in a checkpoint; parallel.calibrate_forms restores it after its trial steps)."""
+    return dict(params=self.get_params(0), m=self.get_params(2), v=self.get_params(3), bn=self.get_bn(), step=self.step)
+
+  def restore(self, st: dict):
+    self.set_params(st["params"], 0)
+    self.set_params(st["m"], 2)
+    self.set_params(st["v"], 3)
+    self.set_bn(st["bn"])
+    self.step = int(st["step"])
+
   @property
   def step(self) -> int:
     s = C.c_int32()
@@ -518,8 +530,15 @@ class Engine:
   @property
   def comm_form(self) -> int:
     """How a training step exchanges its gradients: 0 no collective, 1 one all-reduce, 2 the two-bucket chain (the heads' bucket reduced,
-    normed and applied on the communication stream), 3 the hand-written exchange's two-bucket form (include/sisua_hip.h: smx_comm_form)."""
+    normed and applied on the communication stream), 3 the hand-written exchange (one launch per all-reduce), 4 its two-bucket form of
+    round 4 (include/sisua_hip.h: smx_comm_form)."""
     return self.lib.smx_comm_form(self._h)
+
+  FORM_NAMES = {0: "none", 1: "one all-reduce", 2: "two-bucket chain", 3: "hand-written exchange", 4: "hand-written exchange, two buckets"}
+
+  def comm_set_form(self, form: int):
+    """Ask for an exchange form (smx_comm_set_form: 1 / 2 / 3, or 0 = the library's rule).  A collective call for form 2: every rank."""
+    check(self.lib.smx_comm_set_form(self._h, int(form)))
 
   def opt_gather(self):
     """Flag opt_shard: all-gather the heads' Adam moments (a collective: every rank calls it, between training calls); afterwards

@@ -201,10 +201,11 @@ class SingleCellModel:
 
   # ---- reference attribute surface ---------------------------------------------------
   def set_metadata(self, sco: SingleCellOMIC):
-    assert isinstance(sco, SingleCellOMIC), f"sco must be instance of SingleCellOMIC but given: {type(sco)}"
+    """Remember which dataset the model was fitted on and the variable names of each of its OMICs (single_cell_model.py:103-109)."""
+    if not isinstance(sco, SingleCellOMIC):
+      raise AssertionError(f"sco must be instance of SingleCellOMIC but given: {type(sco)}")
+    self.metadata.update({omic: sco.get_var_names(omic) for omic in sco.omics})
     self.dataset = sco.name
-    for om in sco.omics:
-      self.metadata[om] = sco.get_var_names(om)
     return self
 
   @property
@@ -264,13 +265,11 @@ class SingleCellModel:
     r"""Train on the GPU.  Keyword arguments are the `train:` block of configs/base.yaml:45-62
     (optimizer, learning_rate, clipnorm, valid_freq, epochs, max_iter, earlystop_*,
     terminate_on_nan, checkpoint, log_tag, ...) plus `batch_size`."""
-    if isinstance(train, SingleCellOMIC):
-      self.set_metadata(train)
-    elif isinstance(valid, SingleCellOMIC):
-      self.set_metadata(valid)
-    elif isinstance(metadata, SingleCellOMIC):
-      self.set_metadata(metadata)
-    if self.dataset is None or len(self.metadata) == 0:
+    # the first container among (train, valid, metadata) describes the dataset; prepared batches carry no names (single_cell_model.py:213-231)
+    described_by = next((c for c in (train, valid, metadata) if isinstance(c, SingleCellOMIC)), None)
+    if described_by is not None:
+      self.set_metadata(described_by)
+    if not self.metadata or self.dataset is None:
       raise RuntimeError("First time call `fit`, set the 'metadata' argument to a "
                          "SingleCellOMIC dataset to keep the dataset name and OMICs' "
                          "variables description.")
@@ -347,7 +346,8 @@ class SingleCellModel:
       cp = cp or ControlPlane(rank, world)
     e = self._ensure_engine(max(B, valid.batch_size if valid is not None else 1))
     if world > 1 and e.world != world:
-      attach_engine(e, cp)
+      self._dp_mode = attach_engine(e, cp)
+      self._dp_calibrated = False
     if world > 1:
       e.set_sync_bn(bool(sync_bn))
     n_tr = hi - lo
@@ -369,6 +369,15 @@ class SingleCellModel:
 
     def _prepare(ep):   # pure function of (seed, epoch): prepared on a host thread while the device runs the epoch before
       return _data.iter_batches(_data.epoch_order(n_tr, ep, train.shuffle, seed_r), B, drop_rem)
+
+    if world > 1 and getattr(self, "_dp_mode", "loopback") != "loopback" and not getattr(self, "_dp_calibrated", True):
+      # the exchange form of this job's steps, measured once per communicator on the job's own step and set identically on every rank
+      # (parallel.calibrate_forms: trial steps from the current state, which is restored; SMX_DP_CALIBRATE=0 / SMX_DP_FORM switch it off)
+      from sisua_amd.parallel import calibrate_forms
+      ids = np.concatenate([np.asarray(b, np.int32) for b in _prepare(0) if len(b) == B] or [np.zeros(0, np.int32)])
+      if ids.size >= B:
+        self.dp_report = calibrate_forms(e, cp, self._dp_mode, np.resize(ids, 35 * B), B)
+      self._dp_calibrated = True
 
     spe = n_tr // B if drop_rem else -(-n_tr // B)
     hist_t, hist_v = self.train_history, self.valid_history
@@ -472,6 +481,10 @@ class SingleCellModel:
     if valid is None:
       self._checkpoint(checkpoint, rank, cp, e)
     if cp is not None:
+      if cp.world > 1:
+        #  flag opt_shard: the heads' Adam moments are whole again on every rank when fit returns -- a later save_weights /
+        # _get_state reads them without being a collective (every rank is here; a no-op when nothing is stale)
+        e.opt_gather()
       cp.barrier()
     return self
 
@@ -709,6 +722,12 @@ class SingleCellModel:
     same Philox draws); the few scalars per draw are combined here.  Returns (mllk [N], {output name: mean_s log p(x_o | z_s) [N]})."""
     cfg = self._cfg
     n_out = len(self._outputs)
+    if cfg.latent_mixture:
+      # (ADVICE r05) a draw's weight needs log q_mix(z_s | x) of the mixture-density posterior: predict() reports the mixture's mean and
+      # scale, from which a single Gaussian's density is NOT that -- refused rather than estimated with the wrong weights.  The
+      # one-output call computes the per-draw term on the device (smx_marginal_llk).
+      raise NotImplementedError("marginal_log_prob of several outputs under SCALE's mixture-density posterior (mixture='posterior') is not "
+                                "built: the joint estimate needs the per-draw log q_mix(z | x) from the device")
     if len(arrs) < n_out:
       raise ValueError(f"marginal_log_prob of this model needs the {n_out} output variables' arrays as inputs=[x, y, ...]")
     x = np.ascontiguousarray(arrs[0], dtype=np.float32)
@@ -901,20 +920,27 @@ class MISA(SISUA):
   dimensions; 'mixtril' (the docstring example of vae.py:58): ONE mixture of 2..4 full-covariance Gaussians over the whole label
   vector (at most 64 label dimensions)."""
   _kind = "sisua"
+  _DISCRETE = frozenset(("nb", "nbd", "zinb", "zinbd", "onehot", "categorical", "bernoulli", "poisson"))
+
+  @classmethod
+  def _as_mixture(cls, rv, n_components, zero_inflated):
+    """One label variable as MISA trains it (vae.py:76-95): a discrete posterior becomes 'mixnb' (zero-inflated on request), any other
+    non-mixture posterior 'mixgaussian' -- each conversion with the reference's warning (its wording, typo included: callers match on it) --
+    and every variable learns how many components it has."""
+    kind = rv.posterior
+    is_mixture = kind.startswith(("mix", "mdn"))
+    counts_like = kind in cls._DISCRETE or kind.startswith(("mixnb", "mixzinb"))
+    if not is_mixture:
+      warnings.warn(f"MISA only support labels is a mixture distribution , given: {kind}")
+      rv.posterior = "mixnb" if counts_like else "mixgaussian"
+    if counts_like:
+      rv.kwargs.setdefault("zero_inflated", zero_inflated)
+    rv.kwargs.setdefault("n_components", n_components)
+    return rv
 
   def __init__(self, outputs, labels, n_components=2, zero_inflated=False, **kwargs):
-    labs = [l.copy() for l in _flatten(labels)]
     n_components, zero_inflated = int(n_components), bool(zero_inflated)
-    for rv in labs:
-      if rv.posterior in ("nb", "nbd", "zinb", "zinbd", "onehot", "categorical", "bernoulli", "poisson") or rv.posterior[:5] == "mixnb" or rv.posterior[:7] == "mixzinb":
-        if rv.posterior[:3] != "mix":
-          warnings.warn(f"MISA only support labels is a mixture distribution , given: {rv.posterior}")
-          rv.posterior = "mixnb"
-        rv.kwargs.setdefault("zero_inflated", zero_inflated)
-      elif rv.posterior[:3] not in ("mix", "mdn"):
-        warnings.warn(f"MISA only support labels is a mixture distribution , given: {rv.posterior}")
-        rv.posterior = "mixgaussian"
-      rv.kwargs.setdefault("n_components", n_components)
+    labs = [self._as_mixture(l.copy(), n_components, zero_inflated) for l in _flatten(labels)]
     super().__init__(outputs=outputs, labels=labs, **kwargs)
     self.init_args = dict(outputs=outputs, labels=labels, n_components=n_components, zero_inflated=zero_inflated, **kwargs)
 
@@ -1076,23 +1102,30 @@ class DeepCountAutoencoder(SingleCellModel):
 
 
 # ---- registry (sisua/models/__init__.py:11-38) -------------------------------------------------------
+def _registry() -> Dict[str, type]:
+  """{lower-case class name: class} of every model family of this module, base class included (found through the class tree: a
+  subclass a user defines elsewhere is a model too)."""
+  found, todo = {}, [SingleCellModel]
+  while todo:
+    cls = todo.pop()
+    found.setdefault(cls.__name__.lower(), cls)
+    todo.extend(cls.__subclasses__())
+  return found
+
+
 def get_all_models() -> list:
-  all_models = []
-  for key, val in globals().items():
-    if isinstance(val, type) and issubclass(val, SingleCellModel):
-      all_models.append(val)
-  return sorted(all_models, key=lambda cls: cls.id)
+  """Every model class, ordered by its short id (`vae`, `scvi`, `sisua`, ...; models/__init__.py:11-16)."""
+  return sorted(_registry().values(), key=lambda cls: cls.id)
 
 
 def get_model(model):
-  if isinstance(model, type):
-    model = model.__name__
-  model = str(model).lower()
-  for key, val in globals().items():
-    if isinstance(val, type) and issubclass(val, SingleCellModel):
-      if model == key.lower() or model == val.id:
-        return val
-  raise RuntimeError(f"Cannot find SingleCellModel with type '{model}'")
+  """A model class by class object, class name or short id, case-insensitive (models/__init__.py:19-27)."""
+  wanted = (model.__name__ if isinstance(model, type) else str(model)).lower()
+  classes = _registry()
+  hit = classes.get(wanted) or next((cls for cls in classes.values() if cls.id == wanted), None)
+  if hit is None:
+    raise RuntimeError(f"Cannot find SingleCellModel with type '{wanted}'")
+  return hit
 
 
 def load_model(filepath: str) -> SingleCellModel:

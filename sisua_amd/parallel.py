@@ -322,17 +322,22 @@ def stdout_to_stderr():
 
 
 def attach_engine(engine, cp):
-  """Join the engine to the communicator of the job: RCCL (unique id from rank 0 over the control plane), or the
-  library's loopback communicator for an in-process LocalControlPlane."""
+  """Join the engine to the communicator of the job: RCCL (unique id from rank 0 over the control plane) and, beside it where HIP IPC allows,
+  the library's hand-written exchange -- or the library's loopback communicator for an in-process LocalControlPlane.  Which of the attached
+  collectives the steps take is the exchange FORM (Engine.comm_form): SMX_DP_FORM=1|2|3 if set, else ONE all-reduce of the flat buffer (the
+  north star's wording, and the only form a multi-GPU node has ever run) until `calibrate_forms` below has measured the alternatives on the
+  job's own steps."""
   if cp.world <= 1:
     return "none"
   if isinstance(cp, LocalControlPlane):
     cp.attach(engine)
     return "loopback"
   from sisua_amd.engine import Engine
-  mode = os.environ.get("SMX_ALLREDUCE", "rccl").lower()   # 'rccl' (default) | 'p2p' (hand-written two-shot exchange over IPC-mapped
-  if mode not in ("rccl", "p2p", "p2p-only"):               # peer buffers, beside RCCL) | 'p2p-only' (no RCCL communicator at all)
-    raise ValueError("SMX_ALLREDUCE must be 'rccl', 'p2p' or 'p2p-only'")
+  # 'auto' (default): RCCL, with the hand-written two-shot exchange over IPC-mapped peer buffers attached beside it when every rank can map
+  # its peers | 'rccl': RCCL alone | 'p2p': both, the exchange taking the steps (the library's own rule) | 'p2p-only': no RCCL communicator
+  mode = os.environ.get("SMX_ALLREDUCE", "auto").lower()
+  if mode not in ("auto", "rccl", "p2p", "p2p-only"):
+    raise ValueError("SMX_ALLREDUCE must be 'auto', 'rccl', 'p2p' or 'p2p-only'")
   if mode != "p2p-only":
     def unique_id():
       try:
@@ -360,8 +365,101 @@ def attach_engine(engine, cp):
         warnings.warn(f"RCCL communicator unavailable ({err}); falling back to SMX_ALLREDUCE=p2p-only")
       mode = "p2p-only"
   if mode != "rccl":
-    handles = cp.allgather_bytes(engine.comm_p2p_export(cp.world))
-    engine.comm_p2p_init(cp.rank, cp.world, b"".join(handles))
+    # (every rank takes part in both gathers whatever happens to it: a rank whose export or mapping fails says so instead of leaving)
+    try:
+      mine, perr = engine.comm_p2p_export(cp.world), None
+    except Exception as e:
+      mine, perr = b"", e
+    handles = cp.allgather_bytes(mine)
+    if perr is None and all(len(h) == 128 for h in handles):
+      try:
+        engine.comm_p2p_init(cp.rank, cp.world, b"".join(handles))
+      except Exception as e:
+        perr = e
+    elif perr is None:
+      perr = RuntimeError("a peer could not export its buffers")
+    bad = [b == b"1" for b in cp.allgather_bytes(b"1" if perr is not None else b"0")]
+    if any(bad):
+      if mode != "auto":   # asked for by name: its absence is an error
+        raise perr if perr is not None else RuntimeError("hand-written exchange: ranks " + str([i for i, f in enumerate(bad) if f]) + " could not map their peers")
+      mode = "rccl"        # (ranks that did map their peers keep the mapping and never use it: no form below selects it)
   if os.environ.get("SMX_OPT_SHARD", "0") not in ("", "0"):   # opt-in: the heads' optimiser state sharded over the ranks (RCCL only; smx_opt_gather)
     engine.set_flag("opt_shard", True)
-  return mode   # the collective the steps take: 'rccl', or the exchange ('p2p' beside an RCCL communicator, 'p2p-only' without one)
+  forced = os.environ.get("SMX_DP_FORM", "").strip()
+  if forced:
+    if forced not in ("1", "2", "3") or (forced == "3" and mode == "rccl") or (forced != "3" and mode == "p2p-only"):
+      raise ValueError(f"SMX_DP_FORM={forced} is not available with SMX_ALLREDUCE={mode}")
+    engine.comm_set_form(int(forced))
+  elif mode in ("auto", "rccl"):
+    engine.comm_set_form(1)
+  # ('p2p' / 'p2p-only': the library's own rule, as in rounds 3-5: the exchange takes the steps)
+  return mode   # what is attached: 'rccl', 'auto' (RCCL + the exchange), 'p2p' (both, the exchange first) or 'p2p-only'
+
+
+def dp_forms_available(engine, mode: str):
+  """The exchange forms `calibrate_forms` may try for what attach_engine attached (Engine.comm_form's numbering)."""
+  return {"loopback": [1, 2], "rccl": [1, 2], "auto": [1, 2, 3], "p2p": [1, 2, 3], "p2p-only": [3]}.get(mode, [])
+
+
+def calibrate_forms(engine, cp, mode, order, batch, steps: int = 30, warmup: int = 5, forms=None):
+  """Measure every available exchange form on the job's OWN training step and keep the fastest (the form used to be
+  picked by a guessed byte count that BASELINE configs[1] sits right on).  Collective: every rank calls it with the same arguments, between
+  training calls, data uploaded.  Per form: `warmup` + `steps` steps over `order` (row ids of this rank's shard, >= (warmup + steps) * batch
+  of them) from the SAME parameter / optimiser / BatchNorm state, bracketed like bench.py's timed region, MAX over ranks; a form that
+  raises on any rank, or whose bounded waits time out, is dropped on every rank.  The state the call found is restored at the end, so
+  calibration leaves no trace in the training run.  Within 2 % the one all-reduce wins (the north star's form), then the lower number.
+  Returns {"selected": form, "us_per_step": {form: us or None}, "steps": steps}.  SMX_DP_CALIBRATE=0 or SMX_DP_FORM turn it off
+  (`selected` is then whatever is in force)."""
+  forms = list(forms if forms is not None else dp_forms_available(engine, mode))
+  report = {"selected": int(engine.comm_form), "us_per_step": {}, "steps": int(steps)}
+  if cp.world <= 1 and not os.environ.get("SMX_FORCE_ALLREDUCE"):
+    return report
+  if os.environ.get("SMX_DP_CALIBRATE", "1") in ("0", "") or os.environ.get("SMX_DP_FORM", "").strip() or not forms:
+    return report
+  need = (warmup + steps) * batch
+  order = np.ascontiguousarray(np.asarray(order, np.int32)[:need])
+  if order.size < need:
+    raise ValueError(f"calibrate_forms needs {need} row ids, got {order.size}")
+  fake = {}   # test hook: SMX_DP_FAKE_SLOW="2:500,3:80" adds that many us per step to a form's measurement
+  for item in filter(None, os.environ.get("SMX_DP_FAKE_SLOW", "").split(",")):
+    k, v = item.split(":")
+    fake[int(k)] = float(v)
+  state = engine.snapshot()
+  agreed = lambda ok: cp.max(0.0 if ok else 1.0) == 0.0   # noqa: E731  (True on every rank or on none)
+  try:
+    for f in forms:
+      ok = True
+      try:
+        engine.comm_set_form(f)
+      except Exception:
+        ok = False
+      if not agreed(ok and engine.comm_form == f):
+        report["us_per_step"][f] = None
+        continue
+      us = None
+      try:
+        engine.restore(state)
+        if warmup:
+          engine.train_steps(order[: warmup * batch], warmup, batch)
+        engine.stage_steps(order[warmup * batch:], steps, batch)
+        engine.synchronize()
+        cp.barrier()
+        engine.comm_time_allreduce(1)   # device-side line-up of the ranks
+        t0 = time.perf_counter()
+        engine.train_steps(None, steps, batch)
+        engine.synchronize()
+        us = 1e6 * (time.perf_counter() - t0) / steps + fake.get(f, 0.0)
+        if f == 3 and engine.comm_p2p_error():
+          us = None
+      except Exception:
+        us = None
+      worst = cp.max(us if us is not None else float("inf"))
+      report["us_per_step"][f] = None if not np.isfinite(worst) else round(worst, 2)
+  finally:
+    timed = {f: u for f, u in report["us_per_step"].items() if u is not None}
+    best = min(timed.values()) if timed else None
+    pick = report["selected"] if best is None else (1 if 1 in timed and timed[1] <= 1.02 * best else min(f for f, u in timed.items() if u == best))
+    engine.comm_set_form(pick)
+    engine.restore(state)
+  report["selected"] = int(pick)
+  return report

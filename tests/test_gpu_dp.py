@@ -350,6 +350,74 @@ def test_comm_library_is_resolved_beside_the_hip_runtime(Engine):
   assert info["rccl_version"] > 20000
 
 
+def test_every_exchange_form_on_one_rank_and_the_measured_choice(Engine, monkeypatch):
+  """the step's exchange form is chosen by measurement (parallel.calibrate_forms), not by the 3 MB constant.  One
+  rank with SMX_FORCE_ALLREDUCE (the whole data-parallel path runs, the collective moves nothing), RCCL and the hand-written exchange
+  both attached, at a wide panel (the chain's head bucket exists): (a) forms 1 / 2 / 3 each report themselves and train the SAME numbers
+  as no communicator at all (a world of one: bit for bit); (b) calibrate_forms measures all three, leaves parameters, moments, BatchNorm
+  statistics and the step counter exactly as it found them, and sets what it measured fastest; (c) with two forms faked slow
+  (SMX_DP_FAKE_SLOW) it takes the third, whichever that is."""
+  from sisua_amd import parallel
+  from tests.util import make_pair, synth_counts
+  monkeypatch.setenv("SMX_FORCE_ALLREDUCE", "1")
+  for k in ("SMX_DP_FORM", "SMX_DP_CALIBRATE", "SMX_DP_BUCKETS", "SMX_DP_FAKE_SLOW"):
+    monkeypatch.delenv(k, raising=False)
+  spec, cfg = make_pair(model="vae", n_genes=4160, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=16)
+  x = synth_counts(512, 4160, sparsity=0.92, seed=3)
+  rng = np.random.default_rng(2)
+  order = np.concatenate([rng.permutation(512)[:128] for _ in range(40)]).astype(np.int32)
+
+  class Solo:
+    rank, world = 0, 1
+    def barrier(self): pass
+    def max(self, v): return float(v)
+
+  def run(form):
+    e = Engine(cfg, max_batch=128, init=False)
+    e.set_params(so.init_params(spec))
+    e.upload(x, storage="u16")
+    if form:
+      e.comm_init(0, 1, Engine.comm_unique_id())
+      e.comm_p2p_init(0, 1, e.comm_p2p_export(1))
+      e.comm_set_form(form)
+      assert e.comm_form == form
+    e.train_steps(order[:6 * 128], 6, 128, graph=False)
+    h = e.metrics_history(6)["loss"].copy()
+    if form == 3:
+      assert e.comm_p2p_error() == 0
+    return e, h, e.get_params(0)
+
+  e0, h0, p0 = run(0)
+  e0.close()
+  for form in (1, 2, 3):
+    e, h, p = run(form)
+    assert np.array_equal(h, h0), (form, h, h0)
+    for k in p0:
+      assert np.array_equal(p[k], p0[k]), (form, k)
+    if form < 3:
+      e.close()
+  # e: forms 1-3 attached, six steps in
+  before = e.snapshot()
+  rep = parallel.calibrate_forms(e, Solo(), "auto", order, 128, steps=12, warmup=2)
+  assert set(rep["us_per_step"]) == {1, 2, 3} and all(v and v > 0 for v in rep["us_per_step"].values()), rep
+  assert e.comm_form == rep["selected"]
+  after = e.snapshot()
+  assert after["step"] == before["step"]
+  for part in ("params", "m", "v"):
+    for k in before[part]:
+      assert np.array_equal(before[part][k], after[part][k]), (part, k)
+  for i in before["bn"]:
+    for k in before["bn"][i]:
+      assert np.array_equal(before["bn"][i][k], after["bn"][i][k])
+  for slow, expect in (("1:9000,2:9000", 3), ("1:9000,3:9000", 2), ("2:9000,3:9000", 1)):
+    monkeypatch.setenv("SMX_DP_FAKE_SLOW", slow)
+    rep = parallel.calibrate_forms(e, Solo(), "auto", order, 128, steps=4, warmup=1)
+    assert rep["selected"] == expect and e.comm_form == expect, (slow, rep)
+  monkeypatch.setenv("SMX_DP_CALIBRATE", "0")
+  assert parallel.calibrate_forms(e, Solo(), "auto", order, 128)["us_per_step"] == {}
+  e.close()
+
+
 _BAD_COMM = r"""
 import os, sys, time
 sys.path.insert(0, {root!r})
@@ -557,6 +625,9 @@ def test_bench_line_at_two_ranks_carries_every_scaling_mode(tmp_path):
   out = json.loads(lines[0])
   assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["unit"] == "cells/s" and out["value"] > 0
   assert out["scaling"] == "weak" and out["config"]["global_batch"] == 256 and out["dp"]["collective"] == "p2p-only"
+  # the exchange form is a measured choice (here the hand-written exchange is the only form two ranks on ONE device have)
+  dp = out["dp"]
+  assert dp["selected"] == dp["exchange"] == "hand-written exchange" and dp["forms_us_per_step"]["hand-written exchange"] > 0 and dp["value_is"]
   assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out     # (the CPU baseline is an N = 1 item)
   # the longer run beside the contract's K steps: 300 more steps of the same engine, never `value`
   assert out["value_300"] > 0 and np.isclose(out["value_300"], 256 / (out["ms_per_step_300"] * 1e-3), rtol=1e-3)
@@ -567,6 +638,7 @@ def test_bench_line_at_two_ranks_carries_every_scaling_mode(tmp_path):
     v = sm[k]
     assert (v["batch_per_gpu"], v["global_batch"], v["sync_bn"]) == (bpg, gb, sbn), (k, v)
     assert v["collective"] == "p2p-only" and v["allreduce_us"] > 0 and v["allreduce_bytes"] > 0
+    assert v["exchange"] == "hand-written exchange" and v["exchange_forms_us_per_step"]["hand-written exchange"] > 0
     assert v["ms_per_step"] > 0 and v["nocomm_ms_per_step"] > 0 and v["cells_per_s"] > 0 and np.isfinite(v["final_loss"])
     assert np.isclose(v["dp_overhead_us"], 1e3 * (v["ms_per_step"] - v["nocomm_ms_per_step"]), atol=0.2)
     assert np.isclose(v["cells_per_s"], gb / (v["ms_per_step"] * 1e-3), rtol=1e-3)

@@ -724,6 +724,25 @@ def test_scale_joint_marginal_of_two_outputs(api, covariance):
   assert np.abs(m._mixture_prior_log_prob(z) - (-0.5 * z ** 2 - 0.5 * np.log(2 * np.pi)).sum(-1)).max() > 1e-3
 
 
+def test_joint_marginal_under_the_mixture_density_posterior_refuses(api):
+  """SCALE(mixture='posterior') with several outputs has no per-draw log q_mix(z | x) on the host side of marginal_log_prob; the
+  single-Gaussian density of the mixture's mean / scale is not it.  The call refuses instead of returning wrongly weighted estimates; the
+  one-output call (the device's per-draw term) stays available."""
+  sco = _sco()
+  n_genes, n_prots = sco.n_vars, sco.numpy("proteomic").shape[1]
+  kw = dict(latents=api.RVmeta(6, "mixgaus", True, "Latents"), n_components=3, mixture="posterior",
+            encoder=api.NetConf([32], batchnorm=True, dropout=0.1), decoder=api.NetConf([32], batchnorm=True, dropout=0.1))
+  m = api.SCALE(outputs=[api.RVmeta(n_genes, "zinb", name="transcriptomic"), api.RVmeta(n_prots, "nbd", name="proteomic")], **kw)
+  m.fit(sco, epochs=1, batch_size=64, verbose=False)
+  X, Y = sco.numpy()[:16], sco.numpy("proteomic")[:16]
+  with pytest.raises(NotImplementedError, match="mixture-density posterior"):
+    m.marginal_log_prob(inputs=[X, Y], sample_shape=4, batch_size=64)
+  one = api.SCALE(outputs=api.RVmeta(n_genes, "zinb", name="transcriptomic"), **kw)
+  one.fit(sco, epochs=1, batch_size=64, verbose=False)
+  mllk, _ = one.marginal_log_prob(inputs=X, sample_shape=4, batch_size=64)
+  assert mllk.shape == (16,) and np.isfinite(mllk).all()
+
+
 def test_scvi_extra_outputs_and_gene_dispersion(api, tmp_path):
   """scvi.py:168-169 (`pY = [p(d) for p in self.posteriors[1:]]`) and scvi.py:55-56,66-86 (`dispersion` / `inflation` kept by the
   distribution layer instead of a Dense head): trained, predicted, saved and restored."""

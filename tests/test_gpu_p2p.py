@@ -50,6 +50,11 @@ if die and rank == 1:
   os._exit(0)                       # a peer that never takes part in the exchange
 rng = np.random.default_rng(5)
 res = dict()
+if os.environ.get("SMX_TEST_CALIBRATE"):   # parallel.calibrate_forms between real processes: trial steps, then the state it found
+  from sisua_amd.parallel import calibrate_forms
+  rep = calibrate_forms(e, cp, "p2p-only", rng.permutation(400)[:(2 + 5) * 48].astype(np.int32), 48, steps=5, warmup=2)
+  res["calib_selected"], res["calib_us"] = rep["selected"], rep["us_per_step"].get(3) or -1.0
+  rng = np.random.default_rng(5)
 for step in range(3):
   rows = rng.permutation(400)[: 48 * world].astype(np.int32).reshape(world, 48)
   try:
@@ -106,7 +111,7 @@ def _run(tmp_path, world, kw, sync_bn=0, die=0, timeout=180, extra_env=None):
   return outs
 
 
-@pytest.mark.parametrize("world,sync_bn,buckets", [(2, 0, 1), (3, 0, 1), (2, 1, 1), (2, 0, 2), (2, 1, 2)])
+@pytest.mark.parametrize("world,sync_bn,buckets", [(2, 0, 1), (3, 0, 1), (2, 1, 1), (2, 0, 2), (2, 1, 2), (2, 0, "calibrate")])
 def test_p2p_allreduce_between_processes_matches_oracle(tmp_path, world, sync_bn, buckets):
   """buckets = 2 (SMX_DP_BUCKETS=2): the heads' gradients are exchanged on the communication stream while the rest of the
   backward pass runs, the remainder afterwards -- two exchanges per step, the same numbers.  With SyncBatchNorm the exchange
@@ -114,10 +119,16 @@ def test_p2p_allreduce_between_processes_matches_oracle(tmp_path, world, sync_bn
   from sisua_amd import build
   build.build(verbose=False)
   kw = KW_SYNC if sync_bn else KW
-  outs = _run(tmp_path, world, kw, sync_bn=sync_bn, extra_env={"SMX_DP_BUCKETS": str(buckets)})
+  # "calibrate": parallel.calibrate_forms first (the exchange is the only form two processes on ONE device have: its trial steps run, the
+  # ranks agree on the figure, and the three steps checked below start from the state it found)
+  extra = {"SMX_TEST_CALIBRATE": "1"} if buckets == "calibrate" else {"SMX_DP_BUCKETS": str(buckets)}
+  outs = _run(tmp_path, world, kw, sync_bn=sync_bn, extra_env=extra)
   for rc, out in outs:
     assert rc == 0 and "DONE" in out, out[-3000:]
   got = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+  if buckets == "calibrate":
+    assert all(int(g["calib_selected"]) == 3 and float(g["calib_us"]) > 0 for g in got)
+    assert float(got[0]["calib_us"]) == float(got[1]["calib_us"])   # the MAX over the ranks, the same figure on both
   spec, _ = make_pair(**kw)
   x = synth_counts(400, spec.n_genes, sparsity=0.85, seed=0)
   params = perturbed_params(spec)
@@ -178,3 +189,51 @@ def test_attach_engine_falls_back_to_the_exchange_when_rccl_refuses(tmp_path):
   # and the switch that forbids the fallback keeps the old behaviour: the job stops with RCCL's error
   outs = _run(fb, 2, KW, extra_env=dict(SMX_TEST_ATTACH="1", SMX_NO_COMM_FALLBACK="1"))
   assert all(rc != 0 for rc, _ in outs)
+
+
+_FIT_CHILD = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import sisua_amd.models as api
+from sisua_amd.data import SingleCellOMIC
+from tests.util import synth_counts
+rank, out = int(os.environ["RANK"]), sys.argv[1]
+sco = SingleCellOMIC(synth_counts(640, 120, sparsity=0.8, seed=3), name="toy")
+m = api.VAE(outputs=api.RVmeta(120, "zinb", name="transcriptomic"), latents=api.RVmeta(8, "diag", True, "Latents"),
+            encoder=api.NetConf([32], batchnorm=True, dropout=0.1), decoder=api.NetConf([32], batchnorm=True, dropout=0.1))
+m.fit(sco, epochs=3, batch_size=32, verbose=False, distributed="auto")
+rep = m.dp_report
+np.savez(out, selected=rep["selected"], us=rep["us_per_step"].get(3) or -1.0, loss=np.asarray(m.train_history["loss"], np.float64),
+         **{{"p/" + k: v for k, v in m._engine.get_params().items()}})
+print("DONE", flush=True)
+"""
+
+
+def test_fit_between_processes_measures_its_exchange_form(tmp_path):
+  """SingleCellModel.fit(distributed='auto') in two fresh processes sharing the box's GPU (RCCL refuses the duplicate device on both: the
+  job goes on over the hand-written exchange): the first fit on a communicator measures the exchange form on its own step
+  (parallel.calibrate_forms, `model.dp_report`), training then runs as if it had not -- the replicas end bit-identical, the loss falls."""
+  from sisua_amd import build
+  build.build(verbose=False)
+  script = tmp_path / "fit_child.py"
+  script.write_text(_FIT_CHILD.format(root=ROOT))
+  port = _free_port()
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="1", SMX_CP_PORT=str(port), WORLD_SIZE="2", LOCAL_RANK="0", SMX_RUN_ID=f"fit{port}")
+  for k in ("SMX_ALLREDUCE", "SMX_DP_FORM", "SMX_DP_CALIBRATE"):
+    env.pop(k, None)
+  ps = [subprocess.Popen([sys.executable, str(script), str(tmp_path / f"f{r}.npz")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         env=dict(env, RANK=str(r)), text=True) for r in range(2)]
+  for p in ps:
+    try:
+      out, _ = p.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+      for q in ps:
+        q.kill()
+      pytest.fail("a rank of the two-process fit hangs")
+    assert p.returncode == 0 and "DONE" in out, out[-3000:]
+  a, b = np.load(tmp_path / "f0.npz"), np.load(tmp_path / "f1.npz")
+  assert int(a["selected"]) == int(b["selected"]) == 3 and float(a["us"]) == float(b["us"]) > 0
+  for k in [k for k in a.files if k.startswith("p/")]:
+    assert np.array_equal(a[k], b[k]), k
+  assert np.isfinite(a["loss"]).all() and a["loss"][-1] < a["loss"][0]

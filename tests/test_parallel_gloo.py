@@ -172,10 +172,16 @@ class _FakeEngine:
   def comm_p2p_init(self, rank, world, handles):
     self.calls.append(f"p2p_init:{len(handles)}")
 
+  def comm_set_form(self, form):
+    self.calls.append(f"set_form:{form}")
 
-def _attach_worker(rank, world, port, out_dir, failing):
+
+def _attach_worker(rank, world, port, out_dir, failing, mode_env=None):
   os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), SMX_RUN_ID=f"a{port}")
-  os.environ.pop("SMX_ALLREDUCE", None)
+  for k in ("SMX_ALLREDUCE", "SMX_DP_FORM", "SMX_OPT_SHARD"):
+    os.environ.pop(k, None)
+  if mode_env:
+    os.environ["SMX_ALLREDUCE"] = mode_env
   import warnings
   from sisua_amd import engine as eng_mod
   from sisua_amd.parallel import ControlPlane, attach_engine
@@ -194,24 +200,124 @@ def _attach_worker(rank, world, port, out_dir, failing):
   open(os.path.join(out_dir, f"res{rank}"), "w").write(res)
 
 
-@pytest.mark.parametrize("failing,expect", [((), "rccl"), ((0, 1), "p2p-only"), ((1,), "raised")])
+@pytest.mark.parametrize("failing,expect", [((), "auto"), ((), "rccl"), ((0, 1), "p2p-only"), ((1,), "raised")])
 def test_attach_engine_agrees_on_the_collective(tmp_path, failing, expect):
   """parallel.attach_engine over the TCP control plane with two ranks and a stand-in engine (no GPU): RCCL comes up on every rank ->
-  'rccl'; on NO rank -> every rank takes the peer-to-peer exchange (handles of both ranks gathered), rank 0 warns; on SOME ranks only ->
-  every rank stops (a half-built communicator cannot be repaired), nobody hangs."""
+  'auto' (the hand-written exchange attached beside it, ONE all-reduce in force until calibrate_forms has measured) or, with
+  SMX_ALLREDUCE=rccl, RCCL alone; on NO rank -> every rank takes the peer-to-peer exchange (handles of both ranks gathered), rank 0 warns;
+  on SOME ranks only -> every rank stops (a half-built communicator cannot be repaired), nobody hangs."""
   import multiprocessing as pymp
   ctx = pymp.get_context("spawn")
   port = _free_port()
-  ps = [ctx.Process(target=_attach_worker, args=(r, 2, port, str(tmp_path), tuple(failing))) for r in range(2)]
+  ps = [ctx.Process(target=_attach_worker, args=(r, 2, port, str(tmp_path), tuple(failing), "rccl" if expect == "rccl" else None)) for r in range(2)]
   for p in ps:
     p.start()
   for p in ps:
     p.join(120)
   assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
   res = [(tmp_path / f"res{r}").read_text() for r in range(2)]
-  if expect == "rccl":
-    assert res == ["rccl|comm_init|0", "rccl|comm_init|0"]
+  if expect == "auto":
+    assert res == ["auto|comm_init,p2p_export,p2p_init:256,set_form:1|0"] * 2
+  elif expect == "rccl":
+    assert res == ["rccl|comm_init,set_form:1|0"] * 2
   elif expect == "p2p-only":
     assert res == ["p2p-only|comm_init,p2p_export,p2p_init:256|1", "p2p-only|comm_init,p2p_export,p2p_init:256|0"]
   else:
     assert all(r.startswith("raised:") for r in res), res
+
+
+# ---- parallel.calibrate_forms: the exchange form chosen by measurement, identically on every rank (VERDICT r05 item 2) ----------------
+class _FakeCalibEngine:
+  """What calibrate_forms touches of an Engine: `cost` seconds per step and form on THIS rank."""
+  def __init__(self, cost, refuse=(), world=2):
+    self.cost, self.refuse, self.form, self.world = cost, set(refuse), 1, world
+    self.state, self.log = {"params": 0}, []
+
+  comm_form = property(lambda self: self.form)
+
+  def comm_set_form(self, f):
+    if f in self.refuse:
+      raise RuntimeError("form not available on this rank")
+    self.form = f
+    self.log.append(("form", f))
+
+  def snapshot(self):
+    return dict(self.state)
+
+  def restore(self, st):
+    self.state = dict(st)
+    self.log.append(("restore", st["params"]))
+
+  def train_steps(self, order, n, batch, **kw):
+    import time
+    self.state["params"] += n          # training moves the state ...
+    time.sleep(self.cost[self.form] * n)
+
+  def stage_steps(self, order, n, batch):
+    pass
+
+  def synchronize(self):
+    pass
+
+  def comm_time_allreduce(self, n):
+    return 0.0, 0
+
+  def comm_p2p_error(self):
+    return 0
+
+
+def _calib_worker(rank, world, port, out_dir):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+  for k in ("SMX_DP_FORM", "SMX_DP_CALIBRATE", "SMX_DP_FAKE_SLOW"):
+    os.environ.pop(k, None)
+  import json
+  from sisua_amd.parallel import ControlPlane, calibrate_forms
+  cp = ControlPlane(rank, world)
+  order = np.arange(4096, dtype=np.int32)
+  out = {}
+  # (1) form 3 is the fastest on rank 0 but the slowest on rank 1: the MAX over ranks decides, the same on both
+  e = _FakeCalibEngine({1: 2e-3, 2: 1.5e-3, 3: 0.2e-3 if rank == 0 else 4e-3})
+  out["max_over_ranks"] = calibrate_forms(e, cp, "auto", order, 8, steps=6, warmup=1)
+  out["state_restored"] = e.state["params"] == 0 and e.form == out["max_over_ranks"]["selected"]
+  # (2) a form that one rank cannot set is dropped on EVERY rank
+  e = _FakeCalibEngine({1: 2e-3, 2: 0.2e-3, 3: 1e-3}, refuse=(2,) if rank == 1 else ())
+  out["refused_on_one_rank"] = calibrate_forms(e, cp, "auto", order, 8, steps=6, warmup=1)
+  # (3) within 2 % of the best the one all-reduce wins
+  e = _FakeCalibEngine({1: 1.0e-3, 2: 0.995e-3, 3: 3e-3})
+  os.environ["SMX_DP_FAKE_SLOW"] = "1:0,2:0"
+  out["tie"] = calibrate_forms(e, cp, "rccl", order, 8, steps=12, warmup=0)["us_per_step"]
+  # (4) the test hook that fakes a slow form
+  os.environ["SMX_DP_FAKE_SLOW"] = "1:5000,2:5000"
+  e = _FakeCalibEngine({1: 1e-3, 2: 1e-3, 3: 1e-3})
+  out["faked"] = calibrate_forms(e, cp, "auto", order, 8, steps=4, warmup=0)
+  os.environ.pop("SMX_DP_FAKE_SLOW")
+  # (5) switched off: nothing is measured, the form in force stays
+  os.environ["SMX_DP_CALIBRATE"] = "0"
+  e = _FakeCalibEngine({1: 1e-3, 2: 1e-4, 3: 1e-4})
+  out["off"] = calibrate_forms(e, cp, "auto", order, 8)
+  out["off_log"] = len(e.log)
+  with open(os.path.join(out_dir, f"calib{rank}.json"), "w") as f:
+    json.dump(out, f)
+  cp.close()
+
+
+def test_exchange_form_is_chosen_by_measurement_identically_on_every_rank(tmp_path):
+  import json
+  import multiprocessing as mp
+  world, port = 2, _free_port()
+  ctx = mp.get_context("spawn")
+  ps = [ctx.Process(target=_calib_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+  for p in ps:
+    p.start()
+  for p in ps:
+    p.join(120)
+    assert p.exitcode == 0
+  a, b = [json.load(open(tmp_path / f"calib{r}.json")) for r in range(world)]
+  assert a == b                                                        # every rank made the same choices from the same numbers
+  r = a["max_over_ranks"]
+  assert r["selected"] == 2 and set(r["us_per_step"]) == {"1", "2", "3"} and r["us_per_step"]["3"] > r["us_per_step"]["1"] > r["us_per_step"]["2"]
+  assert a["state_restored"]
+  r = a["refused_on_one_rank"]
+  assert r["us_per_step"]["2"] is None and r["selected"] == 3
+  assert a["faked"]["selected"] == 3
+  assert a["off"]["us_per_step"] == {} and a["off_log"] == 0
