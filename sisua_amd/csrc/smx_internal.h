@@ -296,11 +296,17 @@ struct BnBwdArgs {
   // (K = width of the latent head <= 64; d lat [B][fK] staged in LDS, this thread's row of W_lat in registers)
   // instead of being read from a slab another launch wrote
   int front = 0; const float* fD = nullptr; int fld = 0; const float* fW = nullptr; int fldw = 0; int fK = 0;
+  // fold_dz (round 6; with front, fK = 64 = 2 Dp, at most 128 cells, a first decoder layer of 128 units): the launch computes fD ITSELF --
+  // d z = zD zW^T (zD [B][128]: d pre-activation of the first decoder layer, zW [Dp = 32][128]: its weights) as bf16 x 3 MFMAs and the
+  // latent head's backward (zlb: what gemm_latent_bwd_kernel's epilogue did) on it, in every workgroup; workgroup 0 also stores d lat for
+  // the weight-gradient launch.  One launch of the chain less (smx_step.hip: backward_pass).
+  int fold_dz = 0; const float* zD = nullptr; int zld = 0; const float* zW = nullptr; int zldw = 0; EpiLatentBwd zlb;
   int diag = 0;   // SMX_BN_DIAG bits 16 / 32 / 64: skip the front's dot products / tile load / W row load (timing only)
   float leak = 0.f;   // slope of the activation for out <= 0 (layers without dropout only)
   int wide = 0;       // as BnFwdArgs::wide: `dout` = column-major slabs [n_slabs][Hp][128], summed here (bn_wide_bwd_kernel)
 };
 bool bn_bwd_front_supported(int B, int K);
+bool bn_bwd_fold_supported(int B, int fK, int Dp);   // BnBwdArgs::fold_dz
 int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a);
 // two layers over the same minibatch in ONE launch (scvi: encoder + library encoder)
 bool bn_dual_supported(int B);

@@ -653,6 +653,96 @@ int launch_bn_act_fwd_dual(hipStream_t st, const BnFwdArgs& a, const BnFwdArgs& 
 __device__ inline void metrics_body(const MetricsArgs& a);
 __device__ inline void sq_reduce_body(const float* sl, int cnt, float* dst);
 
+// ---- fold_dz: d lat [B][64 + 4] into `tile` (LDS), computed by the workgroup itself (BnBwdArgs::fold_dz) ------------------------------------
+// 8 waves; wave w owns the cells 16 w .. 16 w + 15.  d z [128 x 32] = zD [128 x 128] zW^T as v_mfma_f32_16x16x32_bf16 on three-way split
+// operands (six of the nine cross products: f32 accuracy, smx_device.h): A = the wave's rows of zD straight from global memory in the
+// operand's layout (lane: row lane & 15, eight consecutive k from 8 (lane >> 4)), B = zW's bf16 x 3 image in LDS (split once per
+// workgroup: 32 x 128 values over 512 threads).  The latent head's backward runs on the accumulators in place; its
+// operand loads (mu, s_raw, sigma, eps) were requested at entry.  `wimg`: 3 x 32 rows of 136 bf16.
+typedef float bnf_f32x4 __attribute__((ext_vector_type(4)));
+__device__ inline bnf_f32x4 bnf_mfma16x3(const Split8& a, const Split8& b, bnf_f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.t2, b.t0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.t0, b.t2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.t1, b.t1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.t1, b.t0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.t0, b.t1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.t0, b.t0, acc, 0, 0, 0);
+  return acc;
+}
+#define SMX_FOLD_WROW 136   /* bf16 per row of the W image: 128 + 8 (rows 272 bytes apart: 16-byte reads of 16 rows spread over the banks) */
+#define SMX_FOLD_WIMG_BYTES (3 * 32 * SMX_FOLD_WROW * 2)
+__device__ inline void fold_dz_tile(const BnBwdArgs& a, const int bid, float* tile, const int ldd, unsigned char* wimg) {
+  const EpiLatentBwd& e = a.zlb;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, kg = lane >> 4;
+  // (1) what the latent backward reads at the accumulators' positions -- cell 16 w + 4 kg + r, latent dim 16 nb + li -- requested first (64-byte runs per
+  // 16 lanes; the same unconditional loads from clamped rows as gemm_body's EPI = 2)
+  float e_mu[2][4], e_sr[2][4], e_sg[2][4], e_ep[2][4];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long b = min(16 * w + 4 * kg + r, a.B - 1);
+      const int d = 16 * nb + li;
+      e_mu[nb][r] = e.lat[b * e.ld + d];
+      e_sr[nb][r] = e.lat[b * e.ld + e.Dp + d];
+      e_sg[nb][r] = e.sig[b * e.Dp + d];
+      e_ep[nb][r] = e.eps[b * e.Dp + d];
+    }
+  // (2) zW -> bf16 x 3 image: thread -> row d = tid >> 4, k = 8 (tid & 15) .. + 7
+  {
+    const int d = tid >> 4, k0 = (tid & 15) * 8;
+    const float4 lo = *reinterpret_cast<const float4*>(a.zW + (long)d * a.zldw + k0), hi = *reinterpret_cast<const float4*>(a.zW + (long)d * a.zldw + k0 + 4);
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const Split8 sp = split3x8(x);
+    smx_bf16x8* row = reinterpret_cast<smx_bf16x8*>(wimg + ((long)d * SMX_FOLD_WROW + k0) * 2);
+    row[0] = sp.t0;
+    row[(32 * SMX_FOLD_WROW * 2) / 16] = sp.t1;
+    row[(2 * 32 * SMX_FOLD_WROW * 2) / 16] = sp.t2;
+  }
+  // (3) the wave's rows of zD in the A operand's layout
+  Split8 A[4];
+  {
+    const float* zr = a.zD + (long)min(16 * w + li, a.B - 1) * a.zld + 8 * kg;
+    float4 v[8];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { v[2 * ks] = *reinterpret_cast<const float4*>(zr + 32 * ks); v[2 * ks + 1] = *reinterpret_cast<const float4*>(zr + 32 * ks + 4); }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float x[8] = {v[2 * ks].x, v[2 * ks].y, v[2 * ks].z, v[2 * ks].w, v[2 * ks + 1].x, v[2 * ks + 1].y, v[2 * ks + 1].z, v[2 * ks + 1].w};
+      A[ks] = split3x8(x);
+    }
+  }
+  __syncthreads();
+  // (4) d z: two 16 x 16 tiles per wave (latent dims 0-15, 16-31), K = 128 in four steps
+  bnf_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const smx_bf16x8* row = reinterpret_cast<const smx_bf16x8*>(wimg + ((long)(16 * nb + li) * SMX_FOLD_WROW + 32 * ks + 8 * kg) * 2);
+      Split8 Bq;
+      Bq.t0 = row[0]; Bq.t1 = row[(32 * SMX_FOLD_WROW * 2) / 16]; Bq.t2 = row[(2 * 32 * SMX_FOLD_WROW * 2) / 16];
+      acc[nb] = bnf_mfma16x3(A[ks], Bq, acc[nb]);
+    }
+  // (5) the latent head's backward on the accumulators where they are (gemm_body's EPI = 2, the plain stochastic form): d mu | d s_raw into the tile
+  // (rows of 16 w .. 16 w + 15: this wave's own) and, from workgroup 0, once to memory for the weight-gradient launch
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = 16 * w + 4 * kg + r, d = 16 * nb + li;
+      const bool live = d < e.D;
+      const float dz = acc[nb][r];
+      const float o0 = live ? dz + e.kl_scale * e_mu[nb][r] : 0.f;
+      const float o1 = live ? (dz * e_ep[nb][r] + e.kl_scale * (e_sg[nb][r] - frcp(e_sg[nb][r]))) * sigmoidf(e_sr[nb][r] + SMX_SOFTPLUS_INV_1) : 0.f;
+      if (b < a.B) {
+        tile[b * ldd + d] = o0;
+        tile[b * ldd + e.Dp + d] = o1;
+        if (bid == 0) { e.dlat[(long)b * e.ld + d] = o0; e.dlat[(long)b * e.ld + e.Dp + d] = o1; }
+      }
+    }
+}
+
 template <int RPT, int FRONT>
 __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
   constexpr bool SMALL = RPT > 0;
@@ -707,6 +797,10 @@ __device__ inline void bn_act_bwd_body(const BnBwdArgs& a, const int bid) {
     float4 wl = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool wl_on = (int)threadIdx.x < BN_COLS * kq && !(a.diag & 64);   // (8 rows x fK / 4 <= 256 float4: one per thread)
     if (wl_on) wl = *reinterpret_cast<const float4*>(a.fW + (long)(bid * BN_COLS + ((int)threadIdx.x >> ksh)) * a.fldw + ((int)threadIdx.x & kmask) * 4);
+    if (FRONT == 1 && a.fold_dz) {   // (block-uniform) the tile is computed here: d z product + latent backward (fold_dz_tile)
+      fold_dz_tile(a, bid, ds, ldd, reinterpret_cast<unsigned char*>(ws + BN_COLS * ldw_s));
+      if ((int)threadIdx.x < BN_COLS * kq) *reinterpret_cast<float4*>(&ws[((int)threadIdx.x >> ksh) * ldw_s + ((int)threadIdx.x & kmask) * 4]) = wl;
+    } else
     {   // all loads of the tile in flight at once (B fK / 4 float4 over 512 threads), then LDS
       constexpr int MAXIT = BN_RPT * (FK / 32);
       float4 tl[MAXIT];
@@ -822,6 +916,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_bwd_dual_kernel(BnBwdArgs a
   else bn_act_bwd_body<RPT, 1>(b, (int)blockIdx.x - na);
 }
 
+// fold_dz: the latent tile is [B][64] = mu | s_raw halves of 32; the d z tile [B][36] and the rows it overwrites live in the tile's own space
+bool bn_bwd_fold_supported(int B, int fK, int Dp) { return B > 0 && B <= 128 && fK == 64 && Dp == 32 && !tuning_on("no_fold_dz"); }
 bool bn_bwd_front_supported(int B, int K) {
   return B > 0 && B <= BN_RL * 4 && (K == 32 || K == 64 || (K == 128 && B <= BN_RL * 2)) && ((size_t)B * (K + 4) + 8 * (K + 4)) * sizeof(float) <= 96 * 1024;
 }
@@ -834,7 +930,19 @@ int launch_bn_act_bwd(hipStream_t st, const BnBwdArgs& a_in) {
       return SMX_ERR_INVALID;
     }
     const int grid = a.Hp / BN_COLS + (a.with_metrics ? 1 : 0) + a.adam_count + a.sqr_count;
-    const size_t lds = ((size_t)a.B * (a.fK + 4) + (size_t)BN_COLS * (a.fK + 4)) * sizeof(float);
+    size_t lds = ((size_t)a.B * (a.fK + 4) + (size_t)BN_COLS * (a.fK + 4)) * sizeof(float);
+    if (a.fold_dz) {
+      const EpiLatentBwd& e = a.zlb;
+      if (!bn_bwd_fold_supported(a.B, a.fK, e.Dp) || !a.zD || !a.zW || (a.zld % 4) || (a.zldw % 4) || a.zldw < 128 || a.zld < 128 || !e.lat || !e.sig || !e.eps || !e.dlat ||
+          !e.stochastic || e.dklz || e.dz_add || (e.ld % 4) || e.ld < 2 * e.Dp || a.B > BN_RL * 2) {
+        set_error("bn_act_bwd: fold_dz not applicable");
+        return SMX_ERR_INVALID;
+      }
+      lds += SMX_FOLD_WIMG_BYTES;
+      static const bool fold_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_bwd_kernel<2, 1>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+      if (lds > 64 * 1024 && !fold_ok) { set_error("bn_act_bwd: cannot reserve the dynamic LDS of fold_dz"); return SMX_ERR_HIP; }
+    }
     static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_act_bwd_kernel<4, 1>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     if (lds > 64 * 1024 && !big_ok) { set_error("bn_act_bwd: cannot reserve the dynamic LDS of the gradient front"); return SMX_ERR_HIP; }

@@ -285,6 +285,7 @@ struct smx_model {
   hipStream_t st_comm = nullptr; hipEvent_t ev_c1 = nullptr, ev_c2 = nullptr, ev_c3 = nullptr;
   size_t bucket1_off = 0, bucket1_count = 0;   // gradients of the output / label heads: ready first, reduced early
   bool bucket1_in_flight = false;
+  bool fold_dz_now = false;      // this backward pass: the d z product + latent backward run inside the encoder's BatchNorm-backward launch (smx_step.hip)
   bool chain_started = false;    // this step's head bucket went: all-reduce -> norms -> clip + Adam sweep on the communication stream (smx_step.hip: dp_chain_start)
   // graphs
   std::map<int, hipGraphExec_t> graphs;

@@ -454,7 +454,10 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
     b.dpre = L.dpre;
     if (L.bn >= 0) { b.gamma = P_(m, L.tGamma); b.dgamma = G_(m, L.tGamma); b.dbeta = G_(m, L.tBeta); }
     else b.dbias = G_(m, L.tBias);
-    if (front) { b.front = 1; b.fD = front->fD; b.fld = front->fld; b.fW = front->fW; b.fldw = front->fldw; b.fK = front->fK; }
+    if (front) {
+      b.front = 1; b.fD = front->fD; b.fld = front->fld; b.fW = front->fW; b.fldw = front->fldw; b.fK = front->fK;
+      b.fold_dz = front->fold_dz; b.zD = front->zD; b.zld = front->zld; b.zW = front->zW; b.zldw = front->zldw; b.zlb = front->zlb;
+    }
     if (&mlp == &m->dec && &L == &mlp.back() && m->wide_dd_slabs > 0 && !front) {   // the one-launch head's slabs, column-major
       b.dout = m->wide_dd_src; b.n_slabs = m->wide_dd_slabs; b.slab_stride = m->wide_dd_stride; b.wide = 1;
     }
@@ -556,7 +559,11 @@ int mlp_backward(smx_model* m, std::vector<MlpLayer>& mlp, const Pass& ps, const
       dpre_done = true;
     }
     int effs[2] = {1, 1};
-    if (defer && i == 0 && lat_epi) {   // d z (+ latent-head backward) alone; d W joins the final grouped launch
+    if (defer && i == 0 && lat_epi && m->fold_dz_now) {
+      // fold_dz: no launch here -- the encoder's last BatchNorm-backward launch computes d z and the latent head's backward itself
+      // (BnBwdArgs::fold_dz, smx_kernels.hip: fold_dz_tile); d W joins the final grouped launch as before
+      defer->push_back(g);
+    } else if (defer && i == 0 && lat_epi) {   // d z (+ latent-head backward) alone; d W joins the final grouped launch
       defer->push_back(g);
       AdamArgs riders;
       if (m->adam_ride_b > 0) take_adam_riders(m, h, riders);
@@ -1336,6 +1343,15 @@ int backward_pass(smx_model* m, const Pass& ps) {
   // launch computes d h = d lat W_lat^T itself.  SMX_NO_BWD_FRONT=1: the separate launches of before.
   const MlpLayer& eL = m->enc.back();
   const bool bfront = m->flags.bwd_front && !sync_bn_on(m, ps.training) && bn_bwd_front_supported(ps.B, lat_ld) && eL.out_p % 8 == 0;
+  // fold_dz (round 6): the d z product and the latent head's backward inside the encoder's last BatchNorm-backward launch -- the plain
+  // reparameterised latent of VAE / SISUA at D <= 32, a first decoder layer of 128 units, at most 128 cells, below the wide-panel width,
+  // no second MLP sharing the launch (scvi)
+  // (a property of the MODEL, not of the step: at a wide panel the optimiser's chunks may ride with the d z launch -- how many is scheduling
+  // state --, so wide panels keep that launch whatever rides with it this step; the fold's rounding never depends on what else is going on)
+  const bool wide_panel = m->Gp >= std::min(4096, head_fused_min_genes());
+  m->fold_dz_now = bfront && !m->mixpost && !m->scvi && !m->scale && !m->fvae && m->stochastic && !wide_panel && !m->dec.empty() &&
+                   m->dec[0].out_p == 128 && m->dec[0].in_p == m->Dp && (m->tensors[m->dec[0].tW].ld % 4) == 0 && m->tensors[m->dec[0].tW].ld >= 128 &&
+                   bn_bwd_fold_supported(ps.B, lat_ld, m->Dp);
   std::vector<GemmArgs> tail;
   if (m->mixpost) {
     // mixture-density posterior: d z leaves the decoder as slabs, a launch of its own turns it into d lat (every component's
@@ -1365,6 +1381,10 @@ int backward_pass(smx_model* m, const Pass& ps) {
     if (bfront) {
       tail.push_back(g);
       gf.fD = m->dlat; gf.fld = lat_ld; gf.fW = P_(m, m->t_latW); gf.fldw = tw.ld; gf.fK = lat_ld;
+      if (m->fold_dz_now) {
+        const MlpLayer& d0 = m->dec[0];
+        gf.fold_dz = 1; gf.zD = d0.dpre; gf.zld = d0.out_p; gf.zW = P_(m, d0.tW); gf.zldw = (int)m->tensors[d0.tW].ld; gf.zlb = le;
+      }
     } else {   // independent: one grouped launch
       GemmArgs& h = pair[1];
       h.A = m->dlat; h.lda = lat_ld; h.B = P_(m, m->t_latW); h.ldb = tw.ld; h.b_nmajor = 1;

@@ -412,6 +412,45 @@ def test_wide_panel_heads_update_as_a_background_sweep(Engine):
         assert np.array_equal(ref[which][k], r[which][k]), (which, k)
 
 
+@pytest.mark.parametrize("lk,B,G,units,latent", [("zinb", 128, 1998, 128, 32), ("nb", 77, 700, 128, 20), ("zinb", 128, 4160, 128, 32), ("zinbd", 1, 300, 128, 8)])
+def test_dz_product_and_latent_backward_inside_the_batchnorm_backward_launch(Engine, lk, B, G, units, latent):
+  """Round 6 (launches off the C2 chain): at a latent of at most 32 dimensions, a first decoder layer of 128 units and
+  at most 128 cells the encoder's last BatchNorm-backward launch computes d z = d pre_dec W_dec^T (bf16 x 3 MFMAs) and the latent head's
+  backward itself, in every workgroup (smx_kernels.hip: fold_dz_tile) -- gemm_latent_bwd_kernel's launch is gone.  Against the separate
+  launches (knob no_fold_dz): the same step to rounding -- every gradient, the losses of four steps, parameters and moments --, ragged
+  minibatches and a latent narrower than its padding included.  (Against the oracle: every step test of the suite runs the fold.)"""
+  from sisua_amd import _hip
+  from tests.util import make_pair, synth_counts
+  spec, cfg = make_pair(model="vae", n_genes=G, likelihood=lk, enc_units=(units,), dec_units=(128,), latent_dim=latent)
+  x = synth_counts(512, G, sparsity=0.9, seed=G + 7, max_count=300)
+  rng = np.random.default_rng(5)
+  order = np.concatenate([rng.permutation(512)[:B] for _ in range(4)]).astype(np.int32)
+  runs = []
+  try:
+    for off in (1, 0):
+      _hip.set_tuning("no_fold_dz", off)
+      e = Engine(cfg, max_batch=128, init=False)
+      e.set_params(so.init_params(spec))
+      e.upload(x, cell_id_base=3)
+      m1 = e.train_step(order[:B])
+      g1 = e.get_params(1)
+      e.train_steps(order[B:], 3, B, graph=False)
+      h = e.metrics_history(3)["loss"].copy()
+      runs.append((m1["loss"], g1, h, e.get_params(0), e.get_params(2)))
+      e.close()
+  finally:
+    _hip.set_tuning("no_fold_dz", 0)
+  a, b = runs
+  assert a[0] == b[0]                                        # (the forward pass is the same launches)
+  rel = lambda u, v: np.linalg.norm(u - v) / max(np.linalg.norm(v), 1e-30)
+  for k in a[1]:
+    assert rel(b[1][k], a[1][k]) < 2e-6, (k, rel(b[1][k], a[1][k]))
+  assert np.allclose(a[2], b[2], rtol=2e-6)
+  for which in (3, 4):
+    for k in a[which]:
+      assert rel(b[which][k], a[which][k]) < 5e-6, (which, k)
+
+
 @pytest.mark.parametrize("lk,B,G,storage,units,bnorm", [("zinb", 100, 4100, "u16", 128, True), ("nb", 128, 4128, "f32", 128, True), ("zinbd", 77, 4500, "u16", 128, True),
                                                        ("nb", 90, 4128, "u16", 96, False), ("zinb", 128, 1998, "f32", 128, True), ("nb", 50, 700, "u16", 64, True),
                                                        ("zinb", 100, 1200, "f32", 96, False)])
