@@ -408,18 +408,29 @@ class SingleCellModel:
           pending[ep] = pool.submit(_prepare, ep)
 
     acc = {}
+    first_call = True
     try:
       prefetch(ep0, ep0 + 2)
       while it < it_end and not stop:
         until_valid = valid_freq - (it % valid_freq) if valid_freq and valid_freq > 0 else it_end - it
         want = max(1, min(it_end - it, until_valid, max_chunk))
+        if first_call and want > 2 * spe:
+          # the call's FIRST chunk is two epochs: the device starts after two epochs' schedule instead of after the ~20 a valid_freq of 500 spans
+          # (4-6 ms of a 50-epoch fit), and the host thread prepares the rest while it runs; later chunks are as long as before
+          want = 2 * spe - (it % spe)
+        first_call = False
         # gather `want` steps of equal batch size, walking over epoch boundaries
         parts, n, bs, j = [], 0, None, it
         while n < want:
           ep, pos = divmod(j, spe)
+          if n > 0 and ep not in cache and ep in pending and not pending[ep].done():
+            break   # (the host thread is still preparing that epoch: launch what is gathered instead of waiting for it)
           b = batches_of(ep)
           take = 0
-          while pos + take < spe and n + take < want and (bs is None or len(b[pos + take]) == bs):
+          if drop_rem:   # every batch has B cells: the run's length is arithmetic
+            bs = B
+            take = min(spe - pos, want - n)
+          while not drop_rem and pos + take < spe and n + take < want and (bs is None or len(b[pos + take]) == bs):
             if bs is None:
               bs = len(b[pos])   # a ragged last batch (drop_remainder=False, the reference's default for fit(SingleCellOMIC)) is a step of its own
             take += 1
@@ -438,17 +449,24 @@ class SingleCellModel:
         nxt = min(it_end - (it + n), valid_freq if valid_freq and valid_freq > 0 else max_chunk, max_chunk)
         prefetch(last_ep, last_ep + 2 + max(nxt, 0) // max(spe, 1))   # what the next call will walk
         h = e.metrics_history(n)
-        # per-epoch means: cut the per-step scalars at the epoch boundaries
+        # per-epoch means: cut the per-step scalars at the epoch boundaries (every key at once: one reduction per epoch, not one per key and epoch)
+        keys = list(h)
+        H = np.stack([np.asarray(h[k], np.float32) for k in keys])   # [key][step]
         s0 = 0
         while s0 < n:
           ep_here = (it + s0) // spe
           s1 = min(n, (ep_here + 1) * spe - it)
-          for k, v in h.items():
-            acc.setdefault(k, []).append(v[s0:s1])
-          if it + s1 == (ep_here + 1) * spe:   # the epoch is complete: one value per epoch, the mean over its steps
-            for k, seg in acc.items():
-              hist_t.setdefault(k, []).append(float(np.mean(np.concatenate(seg))))
-            acc = {}
+          done = it + s1 == (ep_here + 1) * spe   # the epoch is complete: one value per epoch, the mean over its steps
+          if done and not acc:
+            for k, mean in zip(keys, H[:, s0:s1].mean(axis=1)):
+              hist_t.setdefault(k, []).append(float(mean))
+          else:
+            for i_k, k in enumerate(keys):
+              acc.setdefault(k, []).append(H[i_k, s0:s1])
+            if done:
+              for k, seg in acc.items():
+                hist_t.setdefault(k, []).append(float(np.mean(np.concatenate(seg))))
+              acc = {}
           s0 = s1
         it += n
         epoch = (it - 1) // spe
