@@ -270,14 +270,15 @@ def measure_mode(cp, rank, world, local_rank, cfg, batch, steps, warmup, upload,
 
 # DESIGN.md section 5 "What N = 8 is expected to print": the per-step budget table turned into figures (one MI355X node, RCCL over xGMI).
 # These are PREDICTIONS written before any multi-GPU run existed (no node was available to the builder in rounds 1-5); the driver's scaling
-# record is what replaces them.  Round 5: the step exchanges two buckets as a chain (head bucket all-reduced, normed and applied on the
+# record is what replaces them.  Round 6: which exchange form a step takes is measured in the run (dp.forms_us_per_step).  Round 5: the step exchanges two buckets as a chain (head bucket all-reduced, normed and applied on the
 # communication stream beside the rest of the step; front bucket on the model's stream), so what is left on the critical path is the front
 # bucket's all-reduce and the second queue's cost (profiles/r05_dp_overhead_one_rank.txt).
 PREDICTED_N8 = {
-    "weak": {"ms_per_step": [0.102, 0.122], "cells_per_s": [8.4e6, 10.0e6], "x_one_gpu": [4.2, 5.1],
-             "reading": "65 us of step + ~17 us for the chained data-parallel form (measured on one rank: 82.8 against 65.8 us) + a blocking all-reduce of the "
-                        "1.1 MB front bucket (latency-bound: 20-40 us expected from RCCL); the 3.1 MB head bucket has ~60 us of window (40-60 us expected): "
-                        "the >= 6.5x target (<= 79 us per step) is still NOT expected at 128 cells per GPU"},
+    "weak": {"ms_per_step": [0.084, 0.126], "cells_per_s": [8.1e6, 12.2e6], "x_one_gpu": [4.0, 6.0],
+             "reading": "63 us of step + the exchange form the run measures fastest (round 6: parallel.calibrate_forms) -- one all-reduce: + 3 us of machinery + a "
+                        "blocking all-reduce of 4.2 MB (latency-bound: 30-60 us expected from RCCL); two-bucket chain: + 16 us (one rank, measured) + the 1.1 MB front "
+                        "bucket (20-40 us); hand-written exchange, one launch: + 5.5 us (one rank, measured) + 2 x 3.7 MB over seven links at once (15-30 us expected): "
+                        "the >= 6.5x target (<= 78 us per step) is still NOT expected at 128 cells per GPU"},
     "strong_syncbn": {"ms_per_step": [0.15, 0.23], "cells_per_s": [0.56e6, 0.85e6], "x_one_gpu": [0.28, 0.43],
                       "reading": "16 cells per GPU: the step stays a chain of 11 launch-bound launches (~62 us), + the front bucket's all-reduce + 4 small "
                                  "SyncBatchNorm collectives of ~10-20 us each: strong scaling at batch 128 is a slowdown, as DESIGN section 5 says"},
