@@ -92,6 +92,7 @@ struct GemmArgs {
 // (the scripts under tools/).  A knob that was never set reads its default.  docs/LAB_NOTES.md lists them; INTEGRATION.md lists the few switches a
 // USER needs (those stay environment variables).
 double tuning(const char* name, double dflt);
+unsigned long long tuning_epoch();   // moves on with every smx_set_tuning / smx_clear_tuning
 inline bool tuning_on(const char* name) { return tuning(name, 0.0) != 0.0; }
 int launch_gemm(hipStream_t st, const GemmArgs& g, int* eff_split = nullptr);
 // Several independent products in ONE launch (tiles 128x32 / 32x32-K4 only); eff_splits[i] receives

@@ -261,7 +261,7 @@ struct smx_model {
   float* shard_partial = nullptr;   // [n_chunks] per-chunk sums of squares of this rank's slice (flag opt_shard), summed over the ranks
   bool opt_stale = false;            // the heads' Adam moments outside this rank's slice are stale (flag opt_shard): smx_opt_gather brings them in
   // parameters written (an optimiser step, smx_set_tensor(which = 0)) -> params_epoch moves on; the scoring head's bf16 images of W_out are kept while it stands
-  unsigned long long params_epoch = 1, wimg_epoch = 0; int wimg_key = 0;
+  unsigned long long params_epoch = 1, wimg_epoch = 0, wimg_tuning = 0; int wimg_key = 0;
   long wide_dd_stride = 0;
   const float* wide_dd_src = nullptr;   // where those slabs are (bigk_part or the slab buffer)
   int wide_dd_slabs = 0;   // > 0: this step's d d waits as that many column-major slabs in bigk_part for the decoder's BatchNorm-backward launch (bn_wide_bwd_kernel)

@@ -1,3 +1,4 @@
+#include <atomic>
 // smx_model.hip -- model state: construction / destruction, tensors, BatchNorm statistics, noise injection, flags, timing.
 #include "smx_model.h"
 
@@ -114,6 +115,9 @@ static std::map<std::string, double>& tuning_map() {
   }
   return mp;
 }
+// moves on whenever a knob is set or cleared: anything cached under the knobs in force (the scoring head's W images: ADVICE r05) is keyed by it
+std::atomic<unsigned long long> g_tuning_epoch{1};
+unsigned long long tuning_epoch() { return g_tuning_epoch.load(); }
 double tuning(const char* name, double dflt) {
   std::lock_guard<std::mutex> lk(g_tuning_mu);
   auto& mp = tuning_map();
@@ -151,11 +155,13 @@ int smx_set_tuning(const char* name, double value) {
   SMX_REQUIRE(name && *name, "null name");
   std::lock_guard<std::mutex> lk(smx::g_tuning_mu);
   smx::tuning_map()[name] = value;
+  ++smx::g_tuning_epoch;
   return SMX_OK;
 }
 int smx_clear_tuning(const char* name) {
   std::lock_guard<std::mutex> lk(smx::g_tuning_mu);
   if (name && *name) smx::tuning_map().erase(name); else smx::tuning_map().clear();
+  ++smx::g_tuning_epoch;
   return SMX_OK;
 }
 

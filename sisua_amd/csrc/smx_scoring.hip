@@ -98,7 +98,8 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
     __bf16* at = reinterpret_cast<__bf16*>(m->score_wimg);
     // (the images stand while the parameters do: a scoring sweep over a dataset splits W once, not once per batch)
     const int key = n_gt * 64 + nslab * 4 + (use_np[2] ? 1 : 0) + (use_np[3] ? 2 : 0);
-    const bool fresh = m->wimg_epoch == m->params_epoch && m->wimg_key == key && !tuning_on("no_wimg_cache");
+    // (... and while the knobs do: ADVICE r05 -- the key used to ignore the head's form knobs)
+    const bool fresh = m->wimg_epoch == m->params_epoch && m->wimg_key == key && m->wimg_tuning == tuning_epoch() && !tuning_on("no_wimg_cache");
     for (int np = 2; np <= 3; ++np) {
       if (!use_np[np]) continue;
       ScoreSplitWArgs sw;
@@ -108,7 +109,7 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
       wimg[np] = at;
       at += per_plane * np;
     }
-    m->wimg_epoch = m->params_epoch; m->wimg_key = key;
+    m->wimg_epoch = m->params_epoch; m->wimg_key = key; m->wimg_tuning = tuning_epoch();
   }
   // (knob no_score_dec1: the three launches)
   const bool dec1 = !wide_head && !m->scvi && !m->scale && m->dec.size() == 1 && m->dec[0].bn >= 0 && m->dec[0].in_p == m->Dp &&
