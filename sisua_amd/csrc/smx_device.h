@@ -195,16 +195,30 @@ __device__ inline LgDg lgamma_digamma_diff(float x, float r) {
 typedef __bf16 smx_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float smx_f32x16 __attribute__((ext_vector_type(16)));
 struct Split8 { smx_bf16x8 t0, t1, t2; };
+// x = t0 + t1 + t2 (bf16 each): t0 = bf16(x), r1 = x - t0 (exact), t1 = bf16(r1), t2 = bf16(r1 - t1).  The conversions run TWO values at a time:
+// one v_cvt_pk_bf16_f32 per pair and term IS the packed operand register, and its two halves go back to f32 with a shift and a mask -- 5.5 vector
+// instructions per value where the element-by-element spelling (a cast, a widening, a subtraction per term and value, then the packing) compiled
+// to 8.5.  Round 6: the head's backward launch at C2 turned out to be bound by exactly this arithmetic (its two roles, 4.0 and 4.9 us alone, ADD
+// to 8.6 although their workgroups are resident together: ~6.6 k of ~8.5 k cycles per SIMD are operand splits); the fused head had the
+// pair-wise form since round 5 (hf_split_pair).  The same roundings in the same order: the same bits.
+typedef float smx_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 smx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int smx_u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline void split3_pair(float x0, float x1, unsigned& t0, unsigned& t1, unsigned& t2) {
+  const unsigned a = __builtin_bit_cast(unsigned, __builtin_convertvector(smx_f32x2{x0, x1}, smx_bf16x2));
+  const float r0 = x0 - __uint_as_float(a << 16), r1 = x1 - __uint_as_float(a & 0xFFFF0000u);      // exact
+  const unsigned b = __builtin_bit_cast(unsigned, __builtin_convertvector(smx_f32x2{r0, r1}, smx_bf16x2));
+  const float s0 = r0 - __uint_as_float(b << 16), s1 = r1 - __uint_as_float(b & 0xFFFF0000u);
+  t0 = a; t1 = b; t2 = __builtin_bit_cast(unsigned, __builtin_convertvector(smx_f32x2{s0, s1}, smx_bf16x2));
+}
 __device__ inline Split8 split3x8(const float (&x)[8]) {
-  Split8 o;
+  unsigned a[4], b[4], c[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const __bf16 a = (__bf16)x[k];
-    const float r1 = x[k] - (float)a;   // exact
-    const __bf16 b = (__bf16)r1;
-    const __bf16 c = (__bf16)(r1 - (float)b);
-    o.t0[k] = a; o.t1[k] = b; o.t2[k] = c;
-  }
+  for (int k = 0; k < 4; ++k) split3_pair(x[2 * k], x[2 * k + 1], a[k], b[k], c[k]);
+  Split8 o;
+  o.t0 = __builtin_bit_cast(smx_bf16x8, smx_u32x4{a[0], a[1], a[2], a[3]});
+  o.t1 = __builtin_bit_cast(smx_bf16x8, smx_u32x4{b[0], b[1], b[2], b[3]});
+  o.t2 = __builtin_bit_cast(smx_bf16x8, smx_u32x4{c[0], c[1], c[2], c[3]});
   return o;
 }
 // acc += A B over 16 k: lane (i, h) gives rows / columns i, k = 8 h .. 8 h + 7 of the step (smallest terms first)

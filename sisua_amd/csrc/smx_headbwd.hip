@@ -326,6 +326,7 @@ int launch_out_head_bwd(hipStream_t st, const HeadBwdArgs& a_in) {
   if (a.dd_colmajor && (a.B > 128 || a.n_extra != 0 || a.skip_dd || a.slab_stride < (long)a.Hp * 128)) { set_error("out_head_bwd: column-major d d slabs take at most 128 cells and no label slabs"); return SMX_ERR_INVALID; }
   a.n_ht = a.Hp / 32; a.n_gt = a.Gp / 32; a.n_ct = (a.B + 31) / 32;
   a.n_w = a.skip_dw ? 0 : a.n_ht * ((a.n_gt + 7) / 8 * 8);
+  { static const int dg = (int)tuning("head_bwd_diag", 0); if (dg) a.diag = dg; }   // (timing only: 1 = role 0 returns at once, 2 = role 1 does)
   if (a.n_extra < 0 || a.n_extra > SMX_MAX_LABELS) { set_error("out_head_bwd: bad label riders"); return SMX_ERR_INVALID; }
   for (int e = 0; e < a.n_extra; ++e)
     if (!a.xA[e] || !a.xW[e] || a.xK[e] <= 0 || (a.xK[e] % 32) || (a.xlda[e] % 4) || (a.xldw[e] % 4)) { set_error("out_head_bwd: bad label riders"); return SMX_ERR_INVALID; }

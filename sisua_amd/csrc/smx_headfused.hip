@@ -105,7 +105,7 @@ __device__ inline void hf_store1(float v, __amdgpu_buffer_rsrc_t r, int vo, int 
 #endif
 // x = t0 + t1 + t2 (bf16 each; split3x8's arithmetic, bit for bit) with the conversions two values at a time: one v_cvt_pk_bf16_f32 per
 // pair and term IS the packed operand register; its two halves go back to f32 with a shift and a mask (5.5 vector instructions per value
-// where the element-wise spelling above compiles to 8.5)
+// where the element-wise spelling above compiles to 8.5).  Since round 6 smx_device.h's split3x8 is this form too (the whole library).
 typedef float hf_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 hf_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ inline void hf_split_pair(float x0, float x1, unsigned& t0, unsigned& t1, unsigned& t2) {
