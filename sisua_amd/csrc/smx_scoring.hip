@@ -115,7 +115,7 @@ static int stacked_scores(smx_model* m, const Pass& ps, int n_samples, const Sco
   const bool dec1 = !wide_head && !m->scvi && !m->scale && m->dec.size() == 1 && m->dec[0].bn >= 0 && m->dec[0].in_p == m->Dp &&
                     score_decoder1_supported(m->Dp, m->dec[0].out_p) && !tuning_on("no_score_dec1");
   // the encoders and the latent heads
-  SMX_CHECK(forward_pass(m, ps, false, false, 3));
+  SMX_CHECK(forward_pass(m, ps, false, false, (m->scale || m->mixpost) ? 3 : 4));   // (4: without the latent moments' launch -- the draws below read `latbuf`)
   for (int s0 = 0; s0 < n_samples; s0 += Sc) {
     const int S = std::min(Sc, n_samples - s0);
     const long rows = (long)S * B;

@@ -634,7 +634,8 @@ static bool scvi_train_args(smx_model* m, const Pass& ps, ScviTrainArgs* out) {
 int factor_forward(smx_model* m, const Pass& ps, bool backward);
 int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, int mode) {
   const bool decode_only = (mode == 1), resample = (mode == 2);
-  const bool encode_only = (mode == 3);   // encoders + latent heads + latent moments / draw 0, no decoder (the stacked-draw paths)
+  const bool encode_only = (mode == 3 || mode == 4);   // encoders + latent heads + latent moments / draw 0, no decoder (the stacked-draw paths)
+  const bool no_moments = (mode == 4);                  // ... and not even the moments / draw 0: the caller reads the latent head's raw output only
   const smx_config& c = m->cfg;
   const float inv_gb = 1.f / (float)ps.global_batch;
   m->head_loss = false; m->head_fused = false; m->ev_hf_fresh = false; m->wide_dd_slabs = 0;
@@ -680,6 +681,8 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
   front_la = la;
   if (front_ok || m->mixpost) {
     // (launched below with the decoder / drawn above)
+  } else if (no_moments && !m->scale) {
+    // (the stacked scoring pass draws from the head's raw output itself: sigma, z and the KL of draw 0 would be a launch nobody reads)
   } else {
     Timed t(m, "latent_fwd");
     SMX_CHECK(launch_latent_fwd(m->st, la));
