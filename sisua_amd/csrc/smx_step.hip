@@ -360,10 +360,13 @@ static int head_sweep_prepare(smx_model* m) {
 static int head_sweep_start(smx_model* m) {
   AdamArgs a;
   fill_rider_adam(m, a);
-  SMX_HIP(hipStreamWaitEvent(m->st_side, m->ev_hf, 0));
-  SMX_CHECK(launch_adam_sweep(m->st_side, a, m->chunk_first_head, m->n_chunks - m->chunk_first_head, head_sweep_wgs(m)));
-  SMX_HIP(hipEventRecord(m->ev_sweep, m->st_side));
-  m->sweep_pending = true;
+  static const bool skip = tuning_on("skip_head_adam");   // timing only (WRONG results): the heads are never updated -- what their update costs the step
+  if (!skip) {
+    SMX_HIP(hipStreamWaitEvent(m->st_side, m->ev_hf, 0));
+    SMX_CHECK(launch_adam_sweep(m->st_side, a, m->chunk_first_head, m->n_chunks - m->chunk_first_head, head_sweep_wgs(m)));
+    SMX_HIP(hipEventRecord(m->ev_sweep, m->st_side));
+    m->sweep_pending = true;
+  }
   // the optimiser launch skips these chunks; no launch of the backward chain carries any of them
   m->adam_early_from = m->chunk_first_head; m->adam_early_to = m->n_chunks;
   m->adam_early_pending = false; m->adam_rest_from = m->adam_rest_to = 0; m->adam_ride_b = 0;
