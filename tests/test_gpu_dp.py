@@ -350,6 +350,33 @@ def test_comm_library_is_resolved_beside_the_hip_runtime(Engine):
   assert info["rccl_version"] > 20000
 
 
+def test_exchange_form_requests_are_checked(Engine, monkeypatch):
+  """smx_comm_set_form refuses what is not attached: a form without a communicator, the hand-written exchange without its peer mapping, a
+  form number that does not exist -- and leaves the model as it was."""
+  from sisua_amd import SmxError
+  from tests.util import make_pair
+  monkeypatch.setenv("SMX_FORCE_ALLREDUCE", "1")
+  _, cfg = make_pair(model="vae", n_genes=40, likelihood="nb", enc_units=(16,), dec_units=(16,), latent_dim=4)
+  e = Engine(cfg, max_batch=16)
+  assert e.comm_form == 0
+  for form in (1, 2, 3, 7, -1):
+    with pytest.raises(SmxError):
+      e.comm_set_form(form)
+  e.comm_set_form(0)
+  e.comm_init(0, 1, Engine.comm_unique_id())
+  e.comm_set_form(1)
+  assert e.comm_form == 1
+  with pytest.raises(SmxError):
+    e.comm_set_form(3)          # (no peer mapping)
+  assert e.comm_form == 1
+  e.comm_p2p_init(0, 1, e.comm_p2p_export(1))
+  e.comm_set_form(3)
+  assert e.comm_form == 3
+  e.comm_set_form(1)
+  assert e.comm_form == 1
+  e.close()
+
+
 def test_every_exchange_form_on_one_rank_and_the_measured_choice(Engine, monkeypatch):
   """the step's exchange form is chosen by measurement (parallel.calibrate_forms), not by the 3 MB constant.  One
   rank with SMX_FORCE_ALLREDUCE (the whole data-parallel path runs, the collective moves nothing), RCCL and the hand-written exchange
