@@ -55,15 +55,17 @@ __device__ inline float adam_tensor_clip(const AdamArgs& a, const OptChunk& ch, 
   return clip;
 }
 
-// one quad of a tensor: the update itself (also the output head's launch, when it applies the step before's update to the tile of W it is
-// about to read: smx_headfused.hip)
+// one quad of a tensor: the update itself.  Every contraction is SPELLED: the launches that carry this body (optimiser, riders, sweep, the sharded
+// chain) must give the same bits, and which multiply-adds the compiler fuses depends on the code around them (round 6: inlined into the output
+// head's launch -- tools/dev/head_lazy_update.patch -- the unspelled form differed from the sweep's in the last bit of some elements).
 __device__ inline void adam_apply4(float b1, float b2, float eps, float clip, float lr_t, const smx_f32x4& g, smx_f32x4& m, smx_f32x4& v, smx_f32x4& p) {
+#pragma clang fp contract(off)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const float ge = g[e] * clip;
-    m[e] = b1 * m[e] + (1.f - b1) * ge;
-    v[e] = b2 * v[e] + (1.f - b2) * ge * ge;
-    p[e] -= lr_t * m[e] * frcp(fsqrt(v[e]) + eps);   // v_sqrt + v_rcp (1 ulp each) instead of 22 instructions
+    m[e] = __builtin_fmaf(b1, m[e], (1.f - b1) * ge);
+    v[e] = __builtin_fmaf(b2, v[e], ((1.f - b2) * ge) * ge);
+    p[e] = __builtin_fmaf(-(lr_t * m[e]), frcp(fsqrt(v[e]) + eps), p[e]);   // v_sqrt + v_rcp (1 ulp each) instead of 22 instructions
   }
 }
 __device__ inline void adam_apply4(const AdamArgs& a, float clip, float lr_t, const smx_f32x4& g, smx_f32x4& m, smx_f32x4& v, smx_f32x4& p) {

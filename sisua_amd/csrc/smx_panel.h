@@ -87,7 +87,10 @@ __device__ inline void panel_body(const PanelProblem& P, const int first, const 
   long rowoff[8];
   if (MODE && one_chunk) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) rowoff[s] = (long)P.rows[min(8 * cb + s, P.B - 1)] * P.ld_big;
+    for (int s = 0; s < 8; ++s) {   // (no row ids: the sparse store's dense tile of this minibatch -- cell c is row c)
+      const int c = min(8 * cb + s, P.B - 1);
+      rowoff[s] = (long)(P.rows ? P.rows[c] : c) * P.ld_big;
+    }
   }
   auto load_panel = [&](int unit, int kc, float (&bv)[8]) {
     const int wt = P.n_sub == 1 ? unit : unit / P.n_sub, sub = unit - wt * P.n_sub;   // (one plane: no integer division per unit)
@@ -95,7 +98,8 @@ __device__ inline void panel_body(const PanelProblem& P, const int first, const 
     if (MODE) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const long ro = one_chunk ? rowoff[s] : (long)P.rows[min(kc + 8 * cb + s, P.B - 1)] * P.ld_big;
+        const int c = min(kc + 8 * cb + s, P.B - 1);
+        const long ro = one_chunk ? rowoff[s] : (long)(P.rows ? P.rows[c] : c) * P.ld_big;
         if (MODE == 2) bv[s] = (float)reinterpret_cast<const uint16_t*>(P.big)[ro + col0 + i];
         else bv[s] = reinterpret_cast<const float*>(P.big)[ro + col0 + i];
       }

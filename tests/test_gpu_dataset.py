@@ -194,6 +194,40 @@ def test_csr_store_is_bit_identical_to_f32(Engine, model, likelihood, graph):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("G,B", [(4500, 128), (4200, 77)])
+def test_csr_store_at_a_wide_gene_panel(Engine, G, B):
+  """... and at a gene panel wide enough for the panel kernels (the encoder's weight gradient as smx_panel.h's role 0, the one-launch output
+  head, the wide BatchNorm launches).  Round 6 found the encoder's weight-gradient launch reading row ids the sparse store's dense tile does
+  not have (a GPU memory fault at address 0 on the first training step): a null row-id pointer now means `cell c is row c` there as in every
+  other kernel.  Same bits as the float32 store: the losses of multi-step and single-step calls, every parameter, evaluation, scoring."""
+  x = synth_counts(400, G, sparsity=0.9, seed=G, max_count=900)
+  spec, cfg = make_pair(model="vae", n_genes=G, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=16)
+  order = (np.arange(B * 6) * 7 % len(x)).astype(np.int32)
+  outs = []
+  for storage in ("f32", "csr"):
+    e = Engine(cfg, max_batch=128, init=False)
+    e.set_params(so.init_params(spec))
+    e.upload(x, cell_id_base=11, storage=storage)
+    assert e.head_fused_bytes(B) > 0
+    e.train_steps(order[: 4 * B], 4, B, graph=False)
+    h = {k: np.asarray(v).copy() for k, v in e.metrics_history(4).items()}
+    one = e.train_step(order[4 * B: 5 * B])["loss"]
+    cap = e.train_step(order[5 * B: 6 * B], graph=True)["loss"]
+    rows = np.arange(40, dtype=np.int32)
+    ev = e.eval_step(rows)["loss"]
+    mllk, _ = e.marginal_llk(row_ids=rows, n_samples=3)
+    outs.append((h, (one, cap, ev), mllk, e.get_params()))
+    e.close()
+  a, b = outs
+  for k in a[0]:
+    assert np.array_equal(a[0][k], b[0][k]), k
+  assert a[1] == b[1] and np.array_equal(a[2], b[2])
+  for k in a[3]:
+    assert np.array_equal(a[3][k], b[3][k]), k
+  assert np.isfinite(a[0]["loss"]).all()
+
+
+@pytest.mark.gpu
 def test_csr_store_takes_sparse_inputs_and_rejects_bad_ones(Engine):
   import scipy.sparse as sp
   x = synth_counts(60, 64, sparsity=0.85, seed=1)
