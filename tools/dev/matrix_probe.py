@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Cross-product probe of configurations the parity tests do not enumerate one by one: model family x likelihood x gene-panel width x
+hidden widths x minibatch raggedness x dropout / BatchNorm, each (a) against the oracle -- ELBO terms of three steps, every gradient of the
+first, both Adam moments -- and (b) across the three resident stores (float32 / uint16 / CSR), which must agree BIT FOR BIT on a multi-step
+call, an evaluation, a forward pass and a scoring call.  Round 6 wrote it after a parity case of an unrelated experiment met a GPU memory
+fault that no test reached (the CSR store at a wide panel: docs/LAB_NOTES.md).
+
+Every configuration runs in a CHILD process (a fault names its configuration; the parent stops at the first abnormal exit -- a GPU fault is
+not to be repeated).  Run on the GPU box:
+    python tools/dev/matrix_probe.py [--only SUBSTRING] [--limit N] > gpurun_out/matrix_probe.txt
+The oracle is test infrastructure: this tool is a checker like tests/, not part of the product path."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+RTOL = 2e-3
+
+
+def configurations():
+  """A spread, not the full product: every model family at every width class, the other axes rotated through."""
+  lks = {"vae": ["zinb", "nb", "zinbd", "nbd"], "dca": ["zinb", "nb"], "scvi": ["zinbd", "nbd"], "sisua": ["zinb", "nbd", "nb"],
+         "scale": ["zinb", "nb"], "fvae": ["zinb", "nbd"]}
+  widths = [257, 1998, 4100, 4500]
+  hiddens = [((128,), (128,)), ((64, 32), (32, 64)), ((128, 128), (128,)), ((32,), (96,))]
+  batches = [128, 77, 1, 100]
+  latents = [16, 32, 10, 7]
+  out = []
+  k = 0
+  for model in ("vae", "dca", "scvi", "sisua", "scale", "fvae"):
+    for wi, G in enumerate(widths):
+      for rep in range(2):
+        lk = lks[model][(wi + rep + k) % len(lks[model])]
+        enc, dec = hiddens[(wi + 2 * rep + k) % len(hiddens)]
+        c = dict(model=model, n_genes=G, likelihood=lk, enc_units=enc, dec_units=dec, latent_dim=latents[(2 * wi + rep + k) % 4],
+                 B=batches[(wi + 3 * rep + 2 * k) % 4], batchnorm=bool((wi + rep + k) % 3), dropout=(0.1 if (rep + k) % 2 else 0.0))
+        if model == "sisua":
+          c["labels"] = [[12, "nb"], [7, "onehot"]] if rep else [[9, "nbd"]]
+          if rep and wi % 2:
+            c["extra_outputs"] = [[10, "nb"]]
+        if model == "scale":
+          c["n_components"] = 3 + rep
+          if rep and wi % 2 == 0:
+            c["labels"] = [[6, "onehot"]]
+        if model == "fvae":
+          c["labels"] = [[5, "onehot"]] if rep else []
+        if model == "scvi":
+          c["encl_units"] = (32,) if rep else (64,)
+          c["dispersion"] = ["full", "share", "single"][(wi + rep) % 3]
+        out.append(c)
+    k += 1
+  return out
+
+
+def name_of(c):
+  return "%s-%s-G%d-e%s-d%s-z%d-B%d-%s-%s%s" % (c["model"], c["likelihood"], c["n_genes"], "x".join(map(str, c["enc_units"])), "x".join(map(str, c["dec_units"])),
+                                                 c["latent_dim"], c["B"], "bn" if c["batchnorm"] else "nobn", "do" if c["dropout"] else "nodo",
+                                                 "".join("-%s%s" % (k, json.dumps(c[k]).replace(" ", "")) for k in ("labels", "extra_outputs", "n_components", "dispersion") if c.get(k)))
+
+
+def run_one(c):
+  import numpy as np
+  from oracle import sisua_oracle as so
+  from sisua_amd.engine import Engine
+  from tests.util import adam_state_errors, grad_errors, make_pair, synth_counts, synth_labels
+  kw = {k: v for k, v in c.items() if k not in ("B", "dropout")}
+  for k in ("enc_units", "dec_units", "encl_units"):
+    if k in kw:
+      kw[k] = tuple(kw[k])
+  for k in ("labels", "extra_outputs"):
+    if k in kw:
+      kw[k] = tuple((int(p), str(l)) for p, l in kw[k])
+  kw.update(dropout_enc=c["dropout"], dropout_dec=c["dropout"])
+  B = c["B"]
+  spec, cfg = make_pair(**kw)
+  n = 400
+  x = synth_counts(n, spec.n_genes, sparsity=0.9, seed=spec.n_genes + B, max_count=700)
+  heads = tuple(spec.extra_outputs) + tuple(spec.labels)
+  ys = synth_labels(n, heads) if heads else []
+  _, lm, lv = so.library_size(x)
+  lib = np.tile(np.array([[lm, lv]], dtype=np.float32), (n, 1)) if spec.model == "scvi" else None
+  mask = so.label_mask(n, 0.4, n_omics=1 + len(spec.labels), seed=1) if spec.labels else None
+  params = so.init_params(spec)
+  bn, opt = so.init_bn_state(spec), so.init_opt_state(params)
+  problems = []
+  # ---- (a) against the oracle, float32 store ----
+  e = Engine(cfg, max_batch=max(128, B), init=False)
+  e.set_params(params)
+  e.upload(x, ys, lib, mask, cell_id_base=11, storage="f32")
+  rng = np.random.default_rng(5)
+  for s in range(3):
+    rows = rng.permutation(n)[:B].astype(np.int32)
+    res = so.train_step(spec, params, bn, opt, x[rows], so.PhiloxNoise(spec.seed, s, rows + 11), y=[y[rows] for y in ys],
+                        library=None if lib is None else lib[rows], mask=None if mask is None else mask[rows])
+    m = e.train_step(rows)
+    if m["nan_flag"]:
+      problems.append("nan at step %d" % s)
+    for key in ("loss", "nllk_x", "kl"):
+      if key in res["metrics"] and not np.isclose(m[key], res["metrics"][key], rtol=RTOL, atol=1e-4):
+        problems.append("step %d %s: %.6g against the oracle's %.6g" % (s, key, m[key], res["metrics"][key]))
+    if s == 0:
+      worst = grad_errors(e.get_params(which=1), res["grads"])
+      k = max(worst, key=worst.get)
+      if worst[k] > RTOL:
+        problems.append("gradient %s off by %.2e" % (k, worst[k]))
+  # (three steps: from the second on the trajectories carry Adam's amplification of rounding-level gradients -- a first step moves every
+  # parameter by lr whatever its gradient's size --, so the moments are held to a looser bound than the first step's gradients)
+  em, ev, where = adam_state_errors(e, opt)
+  if em > 2e-3 or ev > 4e-3:
+    problems.append("moments off by %.2e / %.2e at %s" % (em, ev, where))
+  e.close()
+  # ---- (b) the stores against each other, bit for bit ----
+  order = (np.arange(B * 4) * 7 % n).astype(np.int32)
+  rows = np.arange(min(40, n), dtype=np.int32)
+  outs = {}
+  for storage in ("f32", "u16", "csr"):
+    e = Engine(cfg, max_batch=max(128, B), init=False)
+    e.set_params(so.init_params(spec))
+    e.upload(x, ys, lib, mask, cell_id_base=11, storage=storage)
+    if storage == "csr" and c["dropout"] and getattr(spec, "input_dropout", 0.0) > 0:
+      e.close()
+      continue
+    e.train_steps(order[: 3 * B], 3, B, graph=False)
+    h = {k: np.asarray(v).copy() for k, v in e.metrics_history(3).items()}
+    one = e.train_step(order[3 * B: 4 * B])["loss"]
+    ev_ = e.eval_step(rows)["loss"]
+    fw = e.forward(row_ids=rows)["x_params"]
+    sc = None
+    if spec.stochastic:
+      sc, _ = e.marginal_llk(row_ids=rows, n_samples=3)
+    outs[storage] = (h, one, ev_, fw, sc, e.get_params())
+    e.close()
+  ref = outs["f32"]
+  for storage, o in outs.items():
+    if storage == "f32":
+      continue
+    for k in ref[0]:
+      if not np.array_equal(ref[0][k], o[0][k]):
+        problems.append("%s store: history %s differs from the float32 store's" % (storage, k))
+        break
+    if ref[1] != o[1] or ref[2] != o[2]:
+      problems.append("%s store: single step / evaluation differ" % storage)
+    if not np.array_equal(ref[3], o[3]):
+      problems.append("%s store: forward pass differs" % storage)
+    if ref[4] is not None and not np.array_equal(ref[4], o[4]):
+      problems.append("%s store: marginal likelihood differs" % storage)
+    bad = [k for k in ref[5] if not np.array_equal(ref[5][k], o[5][k])]
+    if bad:
+      problems.append("%s store: parameters differ (%s ...)" % (storage, bad[0]))
+  return problems
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--one", default=None, help="(child) one configuration as JSON")
+  ap.add_argument("--only", default="", help="substring of the configurations' names")
+  ap.add_argument("--limit", type=int, default=0)
+  ap.add_argument("--list", action="store_true")
+  args = ap.parse_args()
+  if args.one:
+    problems = run_one(json.loads(args.one))
+    print(json.dumps(problems))
+    return 0
+  cs = [c for c in configurations() if args.only in name_of(c)]
+  if args.limit:
+    cs = cs[: args.limit]
+  if args.list:
+    for c in cs:
+      print(name_of(c))
+    return 0
+  bad = 0
+  for c in cs:
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", json.dumps(c)], capture_output=True, text=True, timeout=600)
+    last = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ""
+    if p.returncode != 0:
+      print("ABNORMAL rc=%d  %s\n%s" % (p.returncode, name_of(c), (p.stderr or "")[-1500:]), flush=True)
+      if p.returncode < 0 or "fault" in (p.stderr or "").lower():
+        print("stopping: a crash is not to be repeated", flush=True)
+        return 3
+      bad += 1
+      continue
+    problems = json.loads(last)
+    bad += 1 if problems else 0
+    print("%s  %5.1fs  %s%s" % ("ok  " if not problems else "FAIL", time.time() - t0, name_of(c), "".join("\n      " + q for q in problems)), flush=True)
+  print("matrix_probe: %d configuration(s), %d with problems" % (len(cs), bad), flush=True)
+  return 1 if bad else 0
+
+
+if __name__ == "__main__":
+  sys.exit(main())
