@@ -2,7 +2,7 @@
 """Cross-product probe of configurations the parity tests do not enumerate one by one: model family x likelihood x gene-panel width x
 hidden widths x minibatch raggedness x dropout / BatchNorm, each (a) against the oracle -- ELBO terms of three steps, every gradient of the
 first, both Adam moments -- and (b) across the three resident stores (float32 / uint16 / CSR), which must agree BIT FOR BIT on a multi-step
-call, an evaluation, a forward pass and a scoring call.  Round 6 wrote it after a parity case of an unrelated experiment met a GPU memory
+call, an evaluation, a forward pass, several draws of one, the marginal likelihood and the posterior-predictive score.  Round 6 wrote it after a parity case of an unrelated experiment met a GPU memory
 fault that no test reached (the CSR store at a wide panel: docs/LAB_NOTES.md).
 
 Every configuration runs in a CHILD process (a fault names its configuration; the parent stops at the first abnormal exit -- a GPU fault is
@@ -154,7 +154,11 @@ def run_one(c):
     sc = None
     if spec.stochastic:
       sc, _ = e.marginal_llk(row_ids=rows, n_samples=3)
-    outs[storage] = (h, one, ev_, fw, sc, e.get_params())
+    fs = e.forward_samples(2, row_ids=rows)
+    fs = (fs["z_sample"], fs["x_params"])
+    # (scoring under the output distribution: the input cells as one target, a second matrix as another -- resident counts through every store's reader)
+    sl = e.score_llk([None, x[rows[::-1]]], row_ids=rows, n_samples=2) if spec.stochastic and not heads else None
+    outs[storage] = (h, one, ev_, fw, sc, e.get_params(), fs, sl)
     e.close()
   ref = outs["f32"]
   for storage, o in outs.items():
@@ -170,6 +174,10 @@ def run_one(c):
       problems.append("%s store: forward pass differs" % storage)
     if ref[4] is not None and not np.array_equal(ref[4], o[4]):
       problems.append("%s store: marginal likelihood differs" % storage)
+    if not (np.array_equal(ref[6][0], o[6][0]) and np.array_equal(ref[6][1], o[6][1])):
+      problems.append("%s store: forward_samples differs" % storage)
+    if ref[7] is not None and not np.array_equal(ref[7], o[7]):
+      problems.append("%s store: score_llk differs" % storage)
     bad = [k for k in ref[5] if not np.array_equal(ref[5][k], o[5][k])]
     if bad:
       problems.append("%s store: parameters differ (%s ...)" % (storage, bad[0]))
