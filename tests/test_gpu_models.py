@@ -149,6 +149,47 @@ def test_fit_predict(api, name):
   assert all(np.isfinite(v) for v in sc.values())
 
 
+@pytest.mark.parametrize("name,genes", [("vae", 120), ("sisua", 4200), ("scvi", 4100), ("dca", 300)])
+def test_fit_on_each_resident_store_is_the_same_fit(api, name, genes):
+  """`fit(..., storage=)`: the compact stores of SURVEY 8 f-2 -- uint16 counts, CSR -- hold the same cells as the reference's dense float32
+  matrix, so a fit on any of them IS the same fit: per-epoch training history, validation losses, parameters and the predictions of the
+  fitted model, bit for bit -- at a narrow panel and at panels wide enough for the one-launch output head and the panel kernels (where round
+  6 found the CSR store faulting on its first step), validation cells resident behind the training cells, a ragged last batch."""
+  from sisua_amd.data import SingleCellOMIC
+  n = 500
+  sco = SingleCellOMIC(synth_counts(n, genes, sparsity=0.9, seed=genes, max_count=900), name="toy")
+  sco.add_omic("proteomic", synth_labels(n, ((9, "nb"),))[0])
+  train, test = sco.split(0.8)
+  cls = api.get_model(name)
+  omics = ["transcriptomic"] + (["proteomic"] if name == "sisua" else [])
+  runs = []
+  for storage in ("f32", "u16", "csr"):
+    kw = dict(outputs=sco.get_rv("transcriptomic", "zinbd" if name == "scvi" else "zinb"), encoder=api.NetConf([128], batchnorm=True, dropout=0.1),
+              decoder=api.NetConf([128], batchnorm=True, dropout=0.1))
+    if name != "dca":
+      kw["latents"] = api.RVmeta(10, "diag", True, "Latents")
+    if name == "sisua":
+      kw["labels"] = [sco.get_rv("proteomic")]
+    model = cls(**kw)
+    ds = train.create_dataset(omics, labels_percent=0.5, batch_size=96, drop_remainder=False)
+    vs = test.create_dataset(omics, labels_percent=1.0, batch_size=50, drop_remainder=False)
+    model.fit(ds, valid=vs, metadata=sco, epochs=3, valid_freq=4, storage=storage)
+    X, Z = model.predict(test.numpy()[:40], batch_size=16, verbose=False)
+    X0 = X[0] if isinstance(X, tuple) else X
+    Z0 = Z[0] if isinstance(Z, (tuple, list)) else Z
+    runs.append(({k: np.asarray(v) for k, v in model.train_history.items()}, np.asarray(model.valid_history["val_loss"]), model._engine.get_params(),
+                 X0.mean(), Z0.mean()))
+  ref = runs[0]
+  assert len(ref[0]["loss"]) == 3 and len(ref[1]) >= 2 and np.isfinite(ref[0]["loss"]).all()
+  for r in runs[1:]:
+    for k in ref[0]:
+      assert np.array_equal(ref[0][k], r[0][k]), k
+    assert np.array_equal(ref[1], r[1])
+    for k in ref[2]:
+      assert np.array_equal(ref[2][k], r[2][k]), k
+    assert np.array_equal(ref[3], r[3]) and np.array_equal(ref[4], r[4])
+
+
 def test_save_load_roundtrip(api, tmp_path):
   sco = _sco(with_labels=False)
   train, test = sco.split(0.8)
