@@ -44,8 +44,9 @@ typedef enum {
  * is SCALAR (scale.py:52-59: SCALE + SISUA's semi-supervised heads). */
 /* SMX_MODEL_FVAE: fvae.py:9-18 (FVAE / SemiFVAE; Kim & Mnih 2018): VAE + a discriminator on z whose logit estimates the
  * total correlation; the VAE's tensors follow -ELBO + gamma TC, the discriminator's tensors its own classification loss
- * (z against z with every dimension permuted over the minibatch), both in the same step.  n_labels = 1 with
- * SMX_LABEL_ONEHOT makes it the semi-supervised form (one logit per class, TC logit = their logsumexp). */
+ * (z against z with every dimension permuted over the minibatch), both in the same step.  Label variables (behind the
+ * observed outputs; SMX_LABEL_ONEHOT, 32 classes in all) make it the semi-supervised form: one logit per class of every
+ * variable, TC logit = the logsumexp of all of them, each variable's masked cross-entropy under the softmax of its own. */
 typedef enum { SMX_MODEL_VAE = 0, SMX_MODEL_DCA = 1, SMX_MODEL_SCVI = 2, SMX_MODEL_SISUA = 3, SMX_MODEL_SCALE = 4,
                SMX_MODEL_FVAE = 5,
                SMX_MODEL_SCALE_TRIL = 6 /* SCALE with covariance = 'tril' / 'full' (scale.py:28,35): a lower-triangular scale factor per

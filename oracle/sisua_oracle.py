@@ -101,8 +101,9 @@ class Spec:
   (single_cell_model.py:74-97, scvi.py:33-48, vae.py:40-44, dca.py:16-28)."""
   model: str = "vae"                  # 'vae' | 'dca' | 'scvi' | 'sisua' (MISA = sisua with 'mixnbC' label heads) | 'scale' | 'fvae'
   # fvae (fvae.py:9-18; Kim & Mnih 2018): total-correlation discriminator on z -- disc_layers hidden layers of disc_units
-  # leaky-ReLU(disc_leak) units, no BatchNorm / dropout; gamma weighs the TC term.  One 'onehot' label variable makes it
-  # the semi-supervised form (SemiFVAE): the discriminator has one logit per class, its TC logit is their logsumexp.
+  # leaky-ReLU(disc_leak) units, no BatchNorm / dropout; gamma weighs the TC term.  'onehot' label variables make it the
+  # semi-supervised form (SemiFVAE): the discriminator has one logit per class of every variable (32 at most in all), its
+  # TC logit is the logsumexp of ALL of them, each variable's cross-entropy is taken over its own classes.
   disc_units: int = 1000
   disc_layers: int = 5
   gamma: float = 6.0
@@ -179,7 +180,8 @@ class Spec:
     if self.model != "scvi":
       assert self.dispersion == "full" and self.inflation == "full", "dispersion / inflation are options of scvi (scvi.py:55-56)"
     if self.model == "fvae":
-      assert len(self.labels) <= 1 and all(llk == "onehot" for _, llk in self.labels), "SemiFVAE: one 'onehot' label variable"
+      assert all(llk == "onehot" and P >= 2 for P, llk in self.labels) and sum(P for P, _ in self.labels) <= 32, \
+          "SemiFVAE: 'onehot' label variables of 32 classes in all"
       assert self.disc_layers >= 1 and self.disc_units >= 1 and 0.0 <= self.disc_leak < 1.0
     elif self.model not in ("sisua", "scale"):   # ('scale' with label heads = SCALAR, sisua/models/scale.py:52-59)
       assert len(self.labels) == 0
@@ -202,8 +204,8 @@ class Spec:
 
   @property
   def disc_outputs(self) -> int:
-    """Logits of the fvae discriminator: 1 (FVAE) or the number of classes (SemiFVAE)."""
-    return self.labels[0][0] if self.labels else 1
+    """Logits of the fvae discriminator: 1 (FVAE) or the classes of all label variables, one variable behind the other (SemiFVAE)."""
+    return sum(P for P, _ in self.labels) if self.labels else 1
 
   @property
   def heads(self):
@@ -657,7 +659,14 @@ def _mlp_bwd(spec, params, prefix, units, caches, dh, grads, training):
 # Factorising", Algorithm 2).  Frozen reading [3P-recall]:
 # * discriminator D: z -> disc_layers x Dense(disc_units) + leaky_relu(0.2) -> Dense(n_out); n_out = 1 logit d(z) (the
 #   two-logit softmax form of the paper with d = l0 - l1), or one logit per class with d = logsumexp (SemiFVAE,
-#   ss_strategy 'logsumexp');
+#   ss_strategy 'logsumexp').  SEVERAL label variables (round 6; `labels` is a list in the reference's constructor,
+#   fvae.py:15-18): one output layer per variable on the last hidden layer = one logit layer whose columns are the
+#   variables' classes one behind the other; d = logsumexp over the CONCATENATED logits (the recalled `_tc_logits`:
+#   concat along the last axis, then the strategy's reduction); the supervised term is the SUM over the variables of
+#   the masked cross-entropy, each under the softmax of its own logits (the recalled `supervised_loss`: a loop over
+#   (distribution, labels) pairs adding -log_prob); one per-cell label mask for all of them, as everywhere
+#   (data/_single_cell_base.py:580-591).  Label variables that are not categorical are not built: which number of a
+#   count posterior the recalled `_tc_logits` would read as a "logit" is nothing this restatement can freeze.
 # * VAE objective   J_vae = -ELBO + gamma mean_b d(z_b) [+ alpha mean_b mask_b CE(y_b, logits_b)], gradient with
 #   respect to the VAE's tensors only (the discriminator is a fixed function in it);
 # * discriminator objective  J_d = 1/2 [mean softplus(-d(z)) + mean softplus(d(z_perm))] [+ the same supervised term],
@@ -706,10 +715,15 @@ def _factor_forward(spec: Spec, params, z, u, y=None, mvec=None):
   dloss = 0.5 * (softplus(-d[:B]) + softplus(d[B:]))
   sup = np.zeros(B)
   dsup = np.zeros_like(logits)
-  if spec.labels:
-    yy = np.asarray(y, dtype=np.float64)
-    sup = -mvec * (yy * (logits[:B] - d[:B, None])).sum(1)        # masked cross-entropy against the one-hot label
-    dsup[:B] = mvec[:, None] * (sm[:B] * yy.sum(1, keepdims=True) - yy)
+  c0 = 0
+  for (P, _), yj in zip(spec.labels, y if spec.labels else ()):   # every label variable: masked cross-entropy under the softmax of ITS logits
+    yy = np.asarray(yj, dtype=np.float64)
+    lg = logits[:B, c0:c0 + P]
+    gm = lg.max(1, keepdims=True)
+    lse = gm + np.log(np.exp(lg - gm).sum(1, keepdims=True))
+    sup = sup - mvec * (yy * (lg - lse)).sum(1)
+    dsup[:B, c0:c0 + P] = mvec[:, None] * (np.exp(lg - lse) * yy.sum(1, keepdims=True) - yy)
+    c0 += P
   return dict(h_last=h, caches=caches, logits=logits, d=d, sm=sm, tc=tc, dloss=dloss, sup=sup, dsup=dsup)
 
 
@@ -868,8 +882,8 @@ def forward_backward(spec: Spec, params, bn_state, x, noise, y: Sequence[np.ndar
   mvec = np.zeros(B) if mask is None else np.asarray(mask, dtype=np.float64).reshape(B)
   fac = None
   if spec.model == "fvae":
-    # (SemiFVAE's label variable sits behind the observed outputs in the target order: fvae.py:9-18 passes `outputs` through unchanged)
-    fac = _factor_forward(spec, params, z, noise.uniform(STREAM_PERMUTE, D), y[len(spec.extra_outputs)] if spec.labels else None, mvec)
+    # (SemiFVAE's label variables sit behind the observed outputs in the target order: fvae.py:9-18 passes `outputs` through unchanged)
+    fac = _factor_forward(spec, params, z, noise.uniform(STREAM_PERMUTE, D), list(y[len(spec.extra_outputs):]) if spec.labels else None, mvec)
     llk_y = -fac["sup"]      # (already masked; the mask is idempotent below)
     out.update(disc_logits=fac["logits"])
   for j, (P, kind, observed) in enumerate(spec.heads):

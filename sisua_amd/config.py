@@ -164,7 +164,7 @@ class ModelConfig:
 
   @property
   def disc_outputs(self) -> int:
-    return self.labels[0][0] if self.labels else 1
+    return sum(P for P, _ in self.labels) if self.labels else 1   # (SemiFVAE: the classes of every label variable, one variable behind the other)
 
   @property
   def head_labels(self):

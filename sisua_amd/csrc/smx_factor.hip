@@ -7,7 +7,7 @@
 //                         so it depends on (seed, step, cell ids) only and the oracle draws the same one;
 //   disc_head_kernel      logits -> d = logsumexp (one logit: d itself), the total-correlation estimate d(z), the
 //                         discriminator's loss 1/2 [softplus(-d(z)) + softplus(d(z_perm))], SemiFVAE's masked
-//                         cross-entropy, and the two upstream gradients (VAE objective on the rows of z, discriminator
+//                         cross-entropy (summed over its label variables, each over its own logits), and the two upstream gradients (VAE objective on the rows of z, discriminator
 //                         objective on all 2B rows).
 // Both are HBM-trivial ([B][D] and [2B][<= 32] floats); they exist to keep the step on the device.
 #include "smx_internal.h"
@@ -82,14 +82,26 @@ __global__ __launch_bounds__(256) void disc_head_kernel(DiscHeadArgs a) {
     if (real) a.tc_cell[r] = d;
     a.dl_cell[r] = 0.5f * softplusf(real ? -d : d);
   }
-  float mk = 0.f, ysum = 0.f, yj = 0.f;
-  const bool sup = real && a.Y;
+  // the supervised term: every label variable's masked cross-entropy under the softmax of ITS logits (one variable: that softmax is the
+  // one of the TC logit, d its log-sum-exp -- the same arithmetic as before there were several)
+  float mk = 0.f, ysum = 0.f, yj = 0.f, gl = d;   // (gl: the log-sum-exp of this lane's variable)
+  const bool sup = real && a.n_groups > 0;
   if (sup) {
     const long row = a.rows ? a.rows[r] : r;
     mk = (a.mask && a.mask[row]) ? 1.f : 0.f;
-    yj = live ? a.Y[row * a.ldy + j] : 0.f;
-    ysum = half_wave_sum(yj);
-    const float ce = -half_wave_sum(live ? yj * (l - d) : 0.f);
+    float ce = 0.f;
+    for (int g = 0; g < a.n_groups; ++g) {   // (launch-uniform; every reduction by the whole half-wave)
+      const bool mine = j >= a.gstart[g] && j < a.gstart[g + 1];
+      const float yv = mine ? a.Y[g][row * a.ldy[g] + (j - a.gstart[g])] : 0.f;
+      float lse = d;
+      if (a.n_groups > 1) {
+        const float gm = half_wave_max(mine ? l : -3.0e38f);
+        lse = gm + logf(half_wave_sum(mine ? expf(l - gm) : 0.f));
+      }
+      const float ys = half_wave_sum(yv);
+      ce -= half_wave_sum(mine ? yv * (l - lse) : 0.f);
+      if (mine) { yj = yv; ysum = ys; gl = lse; }
+    }
     if (j == 0) a.llk_y[r] = -mk * ce;
   } else if (real && a.llk_y && j == 0) a.llk_y[r] = 0.f;
   if (!a.backward) return;
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256) void disc_head_kernel(DiscHeadArgs a) {
   float ut = 0.f, ud = 0.f;
   if (live) {
     const float sm = expf(l - d);                                        // softmax = d logsumexp / d logit (1 for one logit)
-    const float su = sup ? a.alpha * a.inv_gb * mk * (sm * ysum - yj) : 0.f;
+    const float su = sup ? a.alpha * a.inv_gb * mk * ((a.n_groups > 1 ? expf(l - gl) : sm) * ysum - yj) : 0.f;
     ut = a.gamma * a.inv_gb * sm + su;
     ud = gd * sm + su;
   }
@@ -107,7 +119,12 @@ __global__ __launch_bounds__(256) void disc_head_kernel(DiscHeadArgs a) {
 }
 
 int launch_disc_head(hipStream_t st, const DiscHeadArgs& a) {
-  if (a.B <= 0 || a.n_out < 1 || a.n_out > 32 || a.ld < a.n_out) { set_error("disc_head: bad shapes"); return SMX_ERR_INVALID; }
+  if (a.B <= 0 || a.n_out < 1 || a.n_out > 32 || a.ld < a.n_out || a.n_groups < 0 || a.n_groups > SMX_DISC_MAX_GROUPS) { set_error("disc_head: bad shapes"); return SMX_ERR_INVALID; }
+  for (int g = 0; g < a.n_groups; ++g)
+    if (!a.Y[g] || a.gstart[g + 1] <= a.gstart[g] || a.gstart[0] != 0 || a.gstart[a.n_groups] != a.n_out || a.ldy[g] < a.gstart[g + 1] - a.gstart[g] || !a.llk_y) {
+      set_error("disc_head: the label variables' logit ranges must tile the logit layer");
+      return SMX_ERR_INVALID;
+    }
   hipLaunchKernelGGL(disc_head_kernel, dim3((2 * a.B + 7) / 8), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;

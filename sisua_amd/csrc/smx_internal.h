@@ -665,12 +665,15 @@ struct PermuteArgs {
 };
 int launch_permute_dims(hipStream_t st, const PermuteArgs& a);
 
+#define SMX_DISC_MAX_GROUPS 8   // label variables of SemiFVAE (their classes: 32 in all, the logit layer's width)
 struct DiscHeadArgs {
   const float* logits = nullptr; int n_slabs = 1; long slab_stride = 0; int ld = 0;   // [S][2B][ld] split-K slabs of h W_out
   const float* bias = nullptr; int n_out = 1; int B = 0;
   float gamma = 0.f, alpha = 0.f, inv_gb = 0.f;
   int backward = 1;
-  const float* Y = nullptr; int ldy = 0; const int32_t* rows = nullptr; const uint8_t* mask = nullptr;   // SemiFVAE: resident one-hot labels
+  // SemiFVAE: the resident one-hot label variables; variable g owns the logits gstart[g] .. gstart[g + 1] - 1 (n_groups = 0: unsupervised)
+  int n_groups = 0; int gstart[SMX_DISC_MAX_GROUPS + 1] = {0}; const float* Y[SMX_DISC_MAX_GROUPS] = {nullptr}; int ldy[SMX_DISC_MAX_GROUPS] = {0};
+  const int32_t* rows = nullptr; const uint8_t* mask = nullptr;
   float* u_tc = nullptr;     // [B][32]  d J_vae / d logits (rows of z)
   float* u_d = nullptr;      // [2B][32] d J_d / d logits
   float* tc_cell = nullptr;  // [B]  d(z_b)

@@ -209,10 +209,14 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
   }
   // (outputs[1:], tests/test_singlecell_models.py:129-141 / scvi.py:168-169: observed heads on any model's decoder output -- FactorVAE
   // (fvae.py:9-18 passes `outputs` through unchanged) and the mixture-density posterior included since round 5)
-  if (cfg->model == SMX_MODEL_FVAE) {   // SemiFVAE's label variable (behind the observed outputs) is classified by the discriminator: no head
-    SMX_REQUIRE(cfg->n_labels - n_observed <= 1, "fvae: at most one (one-hot) label variable");
-    if (cfg->n_labels > n_observed)
-      SMX_REQUIRE(cfg->label_llk[n_observed] == SMX_LABEL_ONEHOT && cfg->label_dim[n_observed] >= 2 && cfg->label_dim[n_observed] <= 32, "fvae: the label variable is one-hot with 2..32 classes");
+  if (cfg->model == SMX_MODEL_FVAE) {   // SemiFVAE's label variables (behind the observed outputs) are classified by the discriminator: no heads
+    SMX_REQUIRE(cfg->n_labels - n_observed <= SMX_DISC_MAX_GROUPS, "fvae: at most 8 label variables");
+    int classes = 0;
+    for (int j = n_observed; j < cfg->n_labels; ++j) {
+      SMX_REQUIRE(cfg->label_llk[j] == SMX_LABEL_ONEHOT && cfg->label_dim[j] >= 2, "fvae: label variables are one-hot with at least 2 classes");
+      classes += cfg->label_dim[j];
+    }
+    SMX_REQUIRE(classes <= 32, "fvae: the label variables have at most 32 classes in all (the discriminator's logit layer)");
   }
   if (cfg->model == SMX_MODEL_SCALE_POST) SMX_REQUIRE(cfg->n_labels == n_observed, "scale with a mixture-density posterior: no label heads (observed outputs only)");
   SMX_REQUIRE(cfg->model == SMX_MODEL_SISUA || cfg->model == SMX_MODEL_FVAE || cfg->model == SMX_MODEL_SCALE || cfg->model == SMX_MODEL_SCALE_TRIL || cfg->n_labels == n_observed,
@@ -261,11 +265,10 @@ int smx_model_create(const smx_config* cfg, smx_model** out) {
     int32_t du[SMX_MAX_LAYERS];
     for (int i = 0; i < cfg->disc_layers; ++i) du[i] = cfg->disc_units;
     const int hu = build_mlp(m, m->disc, "disc", m->D, cfg->disc_layers, du, 0, 0.f, false, cfg->disc_leak);
-    const bool semi = cfg->n_labels > n_observed;   // (the label variable sits behind the observed outputs in the target order)
-    const int n_out = semi ? cfg->label_dim[n_observed] : 1;
+    int n_out = cfg->n_labels > n_observed ? 0 : 1;   // (the label variables sit behind the observed outputs in the target order)
+    for (int j = n_observed; j < cfg->n_labels; ++j) { n_out += cfg->label_dim[j]; m->lab_Pp[j] = round_up(cfg->label_dim[j], 32); }
     m->t_discoutW = add_tensor(m, "discout/W", hu, n_out, 1, false);
     m->t_discoutb = add_tensor(m, "discout/b", 1, n_out, 1, true);
-    if (semi) m->lab_Pp[n_observed] = round_up(cfg->label_dim[n_observed], 32);
   }
   if (m->scvi) {
     for (int ch = 0; ch < m->k; ++ch) {   // (scvi.py:66-86: no Dense head for a 'share'd plane -- its per-gene vector is out{ch}/b alone)

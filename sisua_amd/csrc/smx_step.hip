@@ -937,7 +937,14 @@ int factor_forward(smx_model* m, const Pass& ps, bool backward) {
   h.gamma = c.gamma; h.alpha = c.alpha; h.inv_gb = 1.f / (float)ps.global_batch; h.backward = backward ? 1 : 0;
   const int jd = m->n_observed;   // SemiFVAE's label variable: behind the observed outputs in the target order
   const bool semi = c.n_labels > jd;
-  if (semi && m->Y[jd] && ps.Xsrc == m->X) { h.Y = m->Y[jd]; h.ldy = m->lab_Pp[jd]; h.rows = ps.rows; h.mask = m->mask; }
+  if (semi && m->Y[jd] && ps.Xsrc == m->X) {   // (resident cells: their labels are; a pass over host data has none)
+    for (int j = jd; j < c.n_labels; ++j) {
+      h.Y[h.n_groups] = m->Y[j]; h.ldy[h.n_groups] = m->lab_Pp[j];
+      h.gstart[h.n_groups + 1] = h.gstart[h.n_groups] + c.label_dim[j];
+      ++h.n_groups;
+    }
+    h.rows = ps.rows; h.mask = m->mask;
+  }
   h.u_tc = m->u_d + (size_t)2 * B * 32; h.u_d = m->u_d;   // (one buffer: rows [0, 2B) the discriminator's objective, [2B, 3B) the TC term)
   h.tc_cell = m->tc_cell; h.dl_cell = m->dl_cell; h.llk_y = semi ? m->llk_y : nullptr;
   Timed t(m, "disc_head");

@@ -1053,13 +1053,16 @@ class FVAE(SingleCellModel):
 
 class SemiFVAE(FVAE):
   r"""Semi-supervised FactorVAE (sisua/models/fvae.py:15-18 -> odin `SemifactorVAE`): the discriminator has one logit
-  per class of ONE one-hot label variable, its total-correlation logit is their logsumexp, and the masked
-  cross-entropy of the labelled cells (x `alpha`) joins both objectives."""
+  per class of every one-hot label variable (`labels`: one `RVmeta` or a list; 32 classes in all), its total-correlation
+  logit is the logsumexp of all of them, and the labelled cells' masked cross-entropy (x `alpha`) -- summed over the
+  variables, each under the softmax of its own logits -- joins both objectives.  [3P-recall: the reading of odin's
+  `_tc_logits` / `supervised_loss` is frozen in oracle/sisua_oracle.py; label variables that are not categorical have
+  no logits to take and are refused.]"""
 
   def __init__(self, outputs, labels, **kwargs):
     labs = _flatten(labels)
-    if len(labs) != 1 or labs[0].posterior not in ("onehot", "categorical") or not 2 <= labs[0].event_shape <= 32:
-      raise ValueError("SemiFVAE is built for one 'onehot' label variable with 2..32 classes")
+    if not 1 <= len(labs) <= 8 or any(l.posterior not in ("onehot", "categorical") or l.event_shape < 2 for l in labs) or sum(l.event_shape for l in labs) > 32:
+      raise ValueError("SemiFVAE is built for 1..8 'onehot' label variables with at most 32 classes in all")
     super().__init__(outputs=outputs, labels=labels, **kwargs)
     self.init_args = dict(self.init_args, labels=labels)
 

@@ -671,6 +671,27 @@ def test_fvae_fit_predict(api, tmp_path):
   assert hs["nllk_y"][-1] < hs["nllk_y"][0] and np.isfinite(hs["loss"]).all(), hs["nllk_y"]   # the classifier learns the labelled cells
   with pytest.raises(ValueError):
     api.SemiFVAE(outputs=sco2.get_rv("transcriptomic"), labels=[sco.get_rv("transcriptomic")])
+  # several label variables (round 6): `labels` is a list in the reference's constructor (fvae.py:15-18) -- one logit per class of every
+  # variable; both classifiers learn their labelled cells
+  cls2 = (x[:, 80:].sum(1) > np.median(x[:, 80:].sum(1))).astype(int)
+  sco2.add_omic("condition", np.eye(2, dtype=np.float32)[cls2])
+  tr3, te3 = sco2.split(0.8)
+  s2 = api.SemiFVAE(outputs=sco2.get_rv("transcriptomic"), labels=[sco2.get_rv("celltype", "onehot"), sco2.get_rv("condition", "onehot")], alpha=5.0, **kw)
+  cfg2 = s2._make_config()
+  assert cfg2.disc_outputs == 6 and cfg2.labels == ((4, "onehot"), (2, "onehot")) and cfg2.head_labels == ()
+  s2.fit(tr3.create_dataset(["transcriptomic", "celltype", "condition"], labels_percent=0.5, batch_size=64, drop_remainder=True), metadata=sco2,
+         epochs=10, learning_rate=2e-3)
+  h2 = s2.train_history
+  assert h2["nllk_y"][-1] < h2["nllk_y"][0] and np.isfinite(h2["loss"]).all() and h2["nllk_y"][0] > hs["nllk_y"][0], (h2["nllk_y"], hs["nllk_y"])   # (two cross-entropies)
+  assert s2._engine.get_params()["discout/W"].shape == (64, 6)
+  X2, Z2 = s2.predict(te3.numpy(), batch_size=64, verbose=False)
+  assert Z2.mean().shape == (te3.n_obs, 8) and np.isfinite(X2.mean()).all()
+  p2 = os.path.join(tmp_path, "semifvae2")
+  s2.save_weights(p2)
+  s3 = api.load_model(p2)
+  assert type(s3) is api.SemiFVAE and np.array_equal(s3._engine.get_params()["discout/W"], s2._engine.get_params()["discout/W"])
+  with pytest.raises(ValueError):   # 33 classes in all
+    api.SemiFVAE(outputs=sco2.get_rv("transcriptomic"), labels=[api.RVmeta(20, "onehot", name="a"), api.RVmeta(13, "onehot", name="b")])
 
 
 def test_variational_model_with_two_outputs(api):

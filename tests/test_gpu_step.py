@@ -77,6 +77,12 @@ CASES = {
     # mixture-density posterior (VERDICT r04 Missing 5: these refused)
     "fvae_two_outputs": dict(model="fvae", n_genes=130, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=8, disc_units=64,
                              disc_layers=2, extra_outputs=((9, "nbd"),)),
+    # round 6 (VERDICT r05 Missing 3): SemiFVAE with SEVERAL label variables -- one logit per class of every variable, the TC logit their
+    # joint logsumexp, each variable's masked cross-entropy under the softmax of its own logits (smx_factor.hip: disc_head_kernel)
+    "semifvae_three_labels": dict(model="fvae", n_genes=120, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=7, disc_units=70,
+                                  disc_layers=2, labels=((6, "onehot"), (2, "onehot"), (9, "onehot")), gamma=3.0, alpha=4.0),
+    "semifvae_two_labels_two_outputs": dict(model="fvae", n_genes=110, likelihood="nb", enc_units=(40,), dec_units=(40,), latent_dim=7, disc_units=70,
+                                            disc_layers=2, extra_outputs=((8, "nbd"),), labels=((16, "onehot"), (16, "onehot")), gamma=2.0, alpha=5.0),
     "semifvae_two_outputs": dict(model="fvae", n_genes=110, likelihood="nb", enc_units=(40,), dec_units=(40,), latent_dim=7, disc_units=70,
                                  disc_layers=2, extra_outputs=((8, "zinb"), (5, "nb")), labels=((6, "onehot"),), gamma=3.0, alpha=5.0),
     "scale_post_two_outputs": dict(model="scale", n_genes=120, likelihood="zinb", enc_units=(40,), dec_units=(40,), latent_dim=8, n_components=4,
@@ -229,7 +235,7 @@ def test_separate_launch_forms_match_oracle(Engine, name, flags):
   e.close(); e0.close()
 
 
-@pytest.mark.parametrize("name", ["fvae", "semifvae"])
+@pytest.mark.parametrize("name", ["fvae", "semifvae", "semifvae_three_labels", "semifvae_two_labels_two_outputs"])
 def test_activation_epilogue_forms_match_oracle(Engine, name):
   """Layers without BatchNorm and dropout (the FactorVAE discriminator): bias + activation in the products' store paths
   and the activation's derivative in the d-input products, or the separate bias / activation launches (flag

@@ -267,7 +267,8 @@ CASES = [("vae", "zinb", (), True), ("vae", "nb", (), False), ("vae", "zinbd", (
          ("sisua", "nb", ((4, "mixzinb2"),), True),                 # MISA(zero_inflated=True)
          ("scale", "zinb", (), True), ("scale", "nb", (), False),    # SCALE: mixture prior, Monte-Carlo KL
          ("scale_post", "zinb", (), True), ("scale_post", "nb", (), False),   # SCALE read literally: mixture-density posterior
-         ("fvae", "zinb", (), True), ("fvae", "nb", ((3, "onehot"),), False)]   # FVAE / SemiFVAE: two objectives
+         ("fvae", "zinb", (), True), ("fvae", "nb", ((3, "onehot"),), False),   # FVAE / SemiFVAE: two objectives
+         ("fvae", "zinb", ((3, "onehot"), (4, "onehot"), (2, "onehot")), True)]     # SemiFVAE, several label variables (round 6)
 
 
 # round 5 (VERDICT r04 Missing 5): outputs[1:] on FactorVAE (fvae.py:9-18 passes `outputs` through unchanged), on SemiFVAE (the label

@@ -132,10 +132,12 @@ def torch_step(spec, params, bn, x, noise, y=(), library=None, mask=None):
     extra_vae = spec.gamma * torch.logsumexp(logits_v, 1).mean()
     j_disc = 0.5 * (torch.nn.functional.softplus(-torch.logsumexp(logits_z, 1)).mean()
                     + torch.nn.functional.softplus(torch.logsumexp(logits_p, 1)).mean())
-    if spec.labels:
-      yj = torch.as_tensor(np.asarray(y[len(spec.extra_outputs)], np.float64))   # (behind the observed outputs in the target order)
-      llk_y = td.OneHotCategorical(logits=logits_v).log_prob(yj)
-      j_disc = j_disc - spec.alpha * (m * td.OneHotCategorical(logits=logits_z).log_prob(yj)).mean()
+    c0 = 0
+    for jl, (Pj, _) in enumerate(spec.labels):   # every label variable: a categorical over ITS columns of the logit layer (the TC logit above: over all of them)
+      yj = torch.as_tensor(np.asarray(y[len(spec.extra_outputs) + jl], np.float64))   # (behind the observed outputs in the target order)
+      llk_y = llk_y + td.OneHotCategorical(logits=logits_v[:, c0:c0 + Pj]).log_prob(yj)
+      j_disc = j_disc - spec.alpha * (m * td.OneHotCategorical(logits=logits_z[:, c0:c0 + Pj]).log_prob(yj)).mean()
+      c0 += Pj
   # heads on the decoder output: the extra OUTPUT variables first (fully observed: weight 1, no mask), then the label variables
   heads = [(Pj, kind, True) for Pj, kind in spec.extra_outputs] + ([] if spec.model == "fvae" else [(Pj, kind, False) for Pj, kind in spec.labels])
   for j, (Pj, kind, observed) in enumerate(heads):
@@ -224,6 +226,11 @@ CASES = {
     "fvae": dict(model="fvae", n_genes=44, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=5, disc_units=24, disc_layers=3),
     "semifvae": dict(model="fvae", n_genes=40, likelihood="nb", enc_units=(16,), dec_units=(16,), latent_dim=4, disc_units=20, disc_layers=2,
                      labels=((5, "onehot"),), gamma=3.0, alpha=4.0),
+    # round 6: SemiFVAE with several label variables (one logit per class of every variable; TC logit over all, cross-entropy per variable)
+    "semifvae_three_labels": dict(model="fvae", n_genes=40, likelihood="zinb", enc_units=(16,), dec_units=(16,), latent_dim=4, disc_units=20, disc_layers=2,
+                                  labels=((5, "onehot"), (2, "onehot"), (7, "onehot")), gamma=3.0, alpha=4.0),
+    "semifvae_two_labels_two_outputs": dict(model="fvae", n_genes=36, likelihood="nb", enc_units=(16,), dec_units=(16,), latent_dim=4, disc_units=20, disc_layers=2,
+                                            extra_outputs=((5, "nbd"),), labels=((3, "onehot"), (4, "onehot")), alpha=6.0),
     "scvi_zinbd": dict(model="scvi", n_genes=52, likelihood="zinbd", enc_units=(16,), dec_units=(16,), latent_dim=4, encl_units=(8,)),
     "scvi_nbd": dict(model="scvi", n_genes=36, likelihood="nbd", enc_units=(12,), dec_units=(12,), latent_dim=3, encl_units=(6,),
                      batchnorm=False),

@@ -69,9 +69,12 @@ int main() {
   { smx_config b = c; b.n_labels = SMX_MAX_LABELS + 1; refused("n_labels", b); }
   { smx_config b = c; b.n_labels = 1; b.label_dim[0] = 5; b.label_llk[0] = SMX_LABEL_NB; refused("label heads on a VAE", b); }
   { smx_config b = c; b.n_labels = 2; b.label_dim[0] = 5; b.label_dim[1] = 4; b.label_observed[1] = 1; refused("observed head behind a label head", b); }
-  // (an extra output on FVAE is built since round 5; what stays refused: a SECOND label variable behind it, a label head on the mixture-density posterior)
+  // (an extra output on FVAE is built since round 5, several one-hot label variables behind it since round 6; what stays refused: more than 32
+  // classes in all, a label head on the mixture-density posterior)
   { smx_config b = c; b.model = SMX_MODEL_FVAE; b.disc_layers = 2; b.disc_units = 8; b.n_labels = 3; b.label_dim[0] = 5; b.label_llk[0] = SMX_LABEL_NBD; b.label_observed[0] = 1;
-    b.label_dim[1] = 3; b.label_llk[1] = SMX_LABEL_ONEHOT; b.label_dim[2] = 4; b.label_llk[2] = SMX_LABEL_ONEHOT; refused("two label variables on FVAE", b); }
+    b.label_dim[1] = 20; b.label_llk[1] = SMX_LABEL_ONEHOT; b.label_dim[2] = 13; b.label_llk[2] = SMX_LABEL_ONEHOT; refused("33 classes of label variables on FVAE", b); }
+  { smx_config b = c; b.model = SMX_MODEL_FVAE; b.disc_layers = 2; b.disc_units = 8; b.n_labels = 2; b.label_dim[0] = 3; b.label_llk[0] = SMX_LABEL_ONEHOT;
+    b.label_dim[1] = 1; b.label_llk[1] = SMX_LABEL_ONEHOT; refused("a one-class label variable on FVAE", b); }
   { smx_config b = c; b.model = SMX_MODEL_SCALE_POST; b.n_components = 3; b.n_labels = 1; b.label_dim[0] = 5; b.label_llk[0] = SMX_LABEL_NB; refused("label head on the mixture-density posterior", b); }
   { smx_config b = c; b.model = SMX_MODEL_FVAE; b.disc_layers = 0; refused("fvae discriminator depth", b); }
   { smx_config b = c; b.model = SMX_MODEL_FVAE; b.disc_leak = 1.5f; refused("fvae leak", b); }
