@@ -596,8 +596,18 @@ bool use_head_loss(const smx_model* m, int B) {
 // choice and smx_head_fused_bytes (two copies of it had drifted apart).  flags.head_bwd is part of it: the fused launch
 // never stores dP, so the separate-launch backward forms (head_bwd = 0) cannot follow it.  Label heads do not stand in the way since
 // round 5: their products run as the grouped launch of the backward pass (they cannot ride with a head launch that is not there).
+// ... the launch's d d as column-major slabs that the decoder's BatchNorm-backward launch sums itself (no reduce launch, nothing in m->slab): at most 128
+// cells, no label slabs beside them, no SyncBatchNorm on that layer
+static bool head_fused_wide_dd(const smx_model* m, int B, bool training) {
+  const MlpLayer& dL = m->dec.back();
+  return m->n_heads == 0 && !(sync_bn_on(m, training) && dL.bn >= 0) && bn_wide_supported(B, dL.out_p, head_fused_grid(m->Gp)) &&
+         (size_t)head_fused_grid(m->Gp) * 128 * 128 <= m->bigk_floats;
+}
 bool head_fused_ok(const smx_model* m, int B) {
-  if (!use_head_loss(m, B) || !m->flags.head_fused || !m->flags.head_bwd || !m->hf_tab || !m->bigk_part || m->fvae) return false;
+  if (!use_head_loss(m, B) || !m->flags.head_fused || !m->flags.head_bwd || !m->hf_tab || !m->bigk_part) return false;
+  // FactorVAE (round 6): the discriminator's passes use m->slab between the head's launch and the decoder's backward -- fine where the head's d d
+  // does not live there (the column-major slab form); with an observed output beside the genes (its d d arrives as a further slab) the separate launches stay
+  if (m->fvae && !head_fused_wide_dd(m, B, true)) return false;
   if (m->k > 3 || !m->out_has_W[1] || (m->k == 3 && !m->out_has_W[2])) return false;
   const MlpLayer& dL = m->dec.back();
   const TensorInfo& tw = m->tensors[m->t_outW[0]];
@@ -811,8 +821,7 @@ int forward_pass(smx_model* m, const Pass& ps, bool with_loss, bool backward, in
       hf.dW = G_(m, m->t_outW[0]); hf.db = G_(m, m->t_outb[0]);
       hf.part = m->bigk_part; hf.slab_stride = (long)ps.B * dL.out_p; hf.llk_part = m->llk_part;
       // without label heads (their d d arrives as further slabs) the decoder's BatchNorm-backward launch sums the workgroups' slabs itself
-      const bool wide_dd = m->n_heads == 0 && !(sync_bn_on(m, ps.training) && dL.bn >= 0) && bn_wide_supported(ps.B, dL.out_p, head_fused_grid(m->Gp)) &&
-                           (size_t)head_fused_grid(m->Gp) * 128 * 128 <= m->bigk_floats;
+      const bool wide_dd = head_fused_wide_dd(m, ps.B, ps.training != 0);
       if (wide_dd) { hf.part_colmajor = 1; hf.slab_stride = 128L * 128; }
       hf.sq_part = (m->sq_slots && !tuning_on("no_sq_partials")) ? m->sq_slots + m->sq_first[(size_t)m->t_outW[0]] : nullptr;
       hf.dtab = m->hf_tab;
