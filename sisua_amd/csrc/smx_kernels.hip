@@ -2172,13 +2172,14 @@ __global__ __launch_bounds__(256) void scvi_head_bwd_reg_kernel(ScviHeadArgs a) 
 }
 
 static bool scvi_head_reg_ok(const ScviHeadArgs& a) {
-  return (a.ld % 4) == 0 && (a.plane_stride % 4) == 0 && (a.Gp % 4) == 0 && a.Gp <= 4096;
+  return (a.ld % 4) == 0 && (a.plane_stride % 4) == 0 && (a.Gp % 4) == 0 && a.Gp <= 8192;
 }
 
 int launch_scvi_head_fwd(hipStream_t st, const ScviHeadArgs& a) {
   if (scvi_head_reg_ok(a)) {
     if (a.Gp <= 2048) hipLaunchKernelGGL(scvi_head_fwd_reg_kernel<2>, dim3(a.B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(scvi_head_fwd_reg_kernel<4>, dim3(a.B), dim3(256), 0, st, a);
+    else if (a.Gp <= 4096) hipLaunchKernelGGL(scvi_head_fwd_reg_kernel<4>, dim3(a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(scvi_head_fwd_reg_kernel<8>, dim3(a.B), dim3(256), 0, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
@@ -2224,7 +2225,8 @@ __global__ __launch_bounds__(256) void scvi_head_bwd_kernel(ScviHeadArgs a) {
 int launch_scvi_head_bwd(hipStream_t st, const ScviHeadArgs& a) {
   if (scvi_head_reg_ok(a)) {
     if (a.Gp <= 2048) hipLaunchKernelGGL(scvi_head_bwd_reg_kernel<2>, dim3(a.B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(scvi_head_bwd_reg_kernel<4>, dim3(a.B), dim3(256), 0, st, a);
+    else if (a.Gp <= 4096) hipLaunchKernelGGL(scvi_head_bwd_reg_kernel<4>, dim3(a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(scvi_head_bwd_reg_kernel<8>, dim3(a.B), dim3(256), 0, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }

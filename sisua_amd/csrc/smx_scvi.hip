@@ -19,25 +19,33 @@
 
 namespace smx {
 
+template <int NT = 256>
 __device__ inline float scvi_block_sum(float v, float* sh) {
   v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
-  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  const float lo = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  return NT > 256 ? lo + ((sh[4] + sh[5]) + (sh[6] + sh[7])) : lo;
 }
+template <int NT = 256>
 __device__ inline float scvi_block_max(float v, float* sh) {
   v = wave_max(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
-  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  const float lo = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  return NT > 256 ? fmaxf(lo, fmaxf(fmaxf(sh[4], sh[5]), fmaxf(sh[6], sh[7]))) : lo;
 }
 
-template <int NV, int LK, int U16>
-__global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
+// NT threads hold 4 NT NV genes of the row: 256 threads up to 8192 genes (NV = 8: one wave per SIMD, its 512 registers), 512 threads up to
+// 20 480 (NV = 10; round 6 -- before it, panels beyond 4096 genes took the separate launches, whose one-workgroup-per-cell sweeps with 4-byte
+// accesses made the scVI step at 20 000 genes three times the VAE's).  What is held across the barriers is kept small for that: d raw of the
+// dispersion and gate planes leave as soon as they are known, the softmax terms become rho in place.
+template <int NV, int LK, int U16, int NT = 256>
+__global__ __launch_bounds__(NT) void scvi_head_train_kernel(ScviTrainArgs a) {
   constexpr int K3 = (LK == SMX_LLK_ZINBD) ? 1 : 0;
-  __shared__ float sh[4];
+  __shared__ float sh[NT / 64];
   __shared__ float shl[2];
   const int b = blockIdx.x;
   const long src = a.rows ? a.rows[b] : b;
@@ -54,7 +62,7 @@ __global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
   ushort4 xh[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    const int g = (threadIdx.x + 256 * j) * 4;
+    const int g = (threadIdx.x + NT * j) * 4;
     const bool ok = g < a.Gp;
     r0[j] = ok ? *reinterpret_cast<const float4*>(raw + g) : zero4();
     r1[j] = ok ? *reinterpret_cast<const float4*>(raw + a.plane_stride + g) : zero4();
@@ -102,17 +110,17 @@ __global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
   float mx = -3.0e38f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    const int g = (threadIdx.x + 256 * j) * 4;
+    const int g = (threadIdx.x + NT * j) * 4;
     const float v[4] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) if (g + e < a.G) mx = fmaxf(mx, v[e]);
   }
-  mx = scvi_block_max(mx, sh);   // (its barriers also publish shl[0])
+  mx = scvi_block_max<NT>(mx, sh);   // (its barriers also publish shl[0])
   float ex[NV][4];
   float sum = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    const int g = (threadIdx.x + 256 * j) * 4;
+    const int g = (threadIdx.x + NT * j) * 4;
     const float v[4] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -120,16 +128,18 @@ __global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
       sum += ex[j][e];
     }
   }
-  sum = scvi_block_sum(sum, sh);
+  sum = scvi_block_sum<NT>(sum, sh);
   const float inv = 1.f / sum;
   const float lraw = shl[0];
   const float el = expf(fminf(fmaxf(lraw, 0.f), a.clip_library));
   // ---- parameters, likelihood and its gradient; the two row sums of the backward pass ---------------------------------
-  float d0s[NV][4], d1s[NV][4], d2s[NV][4], rho[NV][4];
+  float d0s[NV][4];
+  float (&rho)[NV][4] = ex;   // (in place)
+  float* dr = a.draw + (long)b * a.ld;
   float llk_sum = 0.f, s = 0.f, dlh = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    const int g = (threadIdx.x + 256 * j) * 4;
+    const int g = (threadIdx.x + NT * j) * 4;
     const float t[4] = {r1[j].x, r1[j].y, r1[j].z, r1[j].w};
     const float gt[4] = {r2[j].x, r2[j].y, r2[j].z, r2[j].w};
     const float xs[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
@@ -143,13 +153,14 @@ __global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
       gate[e] = live ? gt[e] : 0.f;
     }
     count_elem_vec<LK, 1, 4>(xs, rate, th, gate, llk, d0, d1, d2);
+    float o1[4], o2[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const bool live = g + e < a.G;
       const float dd = live ? d0[e] * a.grad_scale : 0.f;   // d loss / d rate
       d0s[j][e] = dd;
-      d1s[j][e] = live ? d1[e] * a.grad_scale * th[e] : 0.f;   // d loss / d raw_1 (theta = exp(raw_1))
-      d2s[j][e] = live ? d2[e] * a.grad_scale : 0.f;
+      o1[e] = live ? d1[e] * a.grad_scale * th[e] : 0.f;   // d loss / d raw_1 (theta = exp(raw_1))
+      o2[e] = live ? d2[e] * a.grad_scale : 0.f;
       if (live) {
         llk_sum += llk[e];
         const float inside = (rho[j][e] > 1e-7f && rho[j][e] < 1.f - 1e-7f) ? 1.f : 0.f;
@@ -157,15 +168,18 @@ __global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
         dlh += dd * rate[e];
       }
     }
+    if (g < a.Gp) {   // (these two planes' gradients are final: out now, not held across the row sums' barriers)
+      *reinterpret_cast<float4*>(dr + a.plane_stride + g) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+      if (K3) *reinterpret_cast<float4*>(dr + 2 * a.plane_stride + g) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+    }
   }
-  llk_sum = scvi_block_sum(llk_sum, sh);
-  s = scvi_block_sum(s, sh);
-  dlh = scvi_block_sum(dlh, sh);
+  llk_sum = scvi_block_sum<NT>(llk_sum, sh);
+  s = scvi_block_sum<NT>(s, sh);
+  dlh = scvi_block_sum<NT>(dlh, sh);
   // ---- gradient wrt the raw head outputs ------------------------------------------------------------------------------
-  float* dr = a.draw + (long)b * a.ld;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    const int g = (threadIdx.x + 256 * j) * 4;
+    const int g = (threadIdx.x + NT * j) * 4;
     if (g >= a.Gp) continue;
     float o0[4];
 #pragma unroll
@@ -175,8 +189,6 @@ __global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
       o0[e] = live ? rho[j][e] * (d0s[j][e] * el * inside - s) : 0.f;
     }
     *reinterpret_cast<float4*>(dr + g) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-    *reinterpret_cast<float4*>(dr + a.plane_stride + g) = make_float4(d1s[j][0], d1s[j][1], d1s[j][2], d1s[j][3]);
-    if (K3) *reinterpret_cast<float4*>(dr + 2 * a.plane_stride + g) = make_float4(d2s[j][0], d2s[j][1], d2s[j][2], d2s[j][3]);
   }
   // ---- the cell's scalars: likelihood partial, d l and the library latent's backward ----------------------------------
   if (threadIdx.x == 0) {
@@ -193,13 +205,13 @@ __global__ __launch_bounds__(256) void scvi_head_train_kernel(ScviTrainArgs a) {
 bool scvi_head_train_supported(const ScviTrainArgs& a) {
   const bool off = false;   // (the launch form is a model flag: smx_set_flag("scvi_fused"))
   return !off && (a.likelihood == SMX_LLK_NBD || a.likelihood == SMX_LLK_ZINBD) && (a.ld % 4) == 0 && (a.plane_stride % 4) == 0 &&
-         (a.Gp % 4) == 0 && a.Gp <= 4096 && (a.ldx % 4) == 0 && (a.ldwl % 2) == 0 && a.ldl >= 2 && a.ldl <= 256 && a.Kl > 0;
+         (a.Gp % 4) == 0 && a.Gp <= 20480 && (a.ldx % 4) == 0 && (a.ldwl % 2) == 0 && a.ldl >= 2 && a.ldl <= 256 && a.Kl > 0;
 }
 
-template <int NV, int LK>
+template <int NV, int LK, int NT = 256>
 static void launch_sht(hipStream_t st, const ScviTrainArgs& a) {
-  if (a.x_u16) hipLaunchKernelGGL((scvi_head_train_kernel<NV, LK, 1>), dim3(a.B), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((scvi_head_train_kernel<NV, LK, 0>), dim3(a.B), dim3(256), 0, st, a);
+  if (a.x_u16) hipLaunchKernelGGL((scvi_head_train_kernel<NV, LK, 1, NT>), dim3(a.B), dim3(NT), 0, st, a);
+  else hipLaunchKernelGGL((scvi_head_train_kernel<NV, LK, 0, NT>), dim3(a.B), dim3(NT), 0, st, a);
 }
 
 int launch_scvi_head_train(hipStream_t st, const ScviTrainArgs& a) {
@@ -210,7 +222,10 @@ int launch_scvi_head_train(hipStream_t st, const ScviTrainArgs& a) {
   }
   const bool zi = a.likelihood == SMX_LLK_ZINBD;
   if (a.Gp <= 2048) { if (zi) launch_sht<2, SMX_LLK_ZINBD>(st, a); else launch_sht<2, SMX_LLK_NBD>(st, a); }
-  else { if (zi) launch_sht<4, SMX_LLK_ZINBD>(st, a); else launch_sht<4, SMX_LLK_NBD>(st, a); }
+  else if (a.Gp <= 4096) { if (zi) launch_sht<4, SMX_LLK_ZINBD>(st, a); else launch_sht<4, SMX_LLK_NBD>(st, a); }
+  else if (a.Gp <= 8192) { if (zi) launch_sht<8, SMX_LLK_ZINBD>(st, a); else launch_sht<8, SMX_LLK_NBD>(st, a); }   // (one wave per SIMD: 512 registers hold 8192 genes of a row)
+  else if (a.Gp <= 16384) { if (zi) launch_sht<8, SMX_LLK_ZINBD, 512>(st, a); else launch_sht<8, SMX_LLK_NBD, 512>(st, a); }
+  else { if (zi) launch_sht<10, SMX_LLK_ZINBD, 512>(st, a); else launch_sht<10, SMX_LLK_NBD, 512>(st, a); }
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
