@@ -330,10 +330,14 @@ int head_sweep_join(smx_model* m) {
   return SMX_OK;
 }
 // decided where the output head is launched (forward_pass), acted on where its gradients are known to be final (backward_pass)
+// (With label heads -- SISUA, SCALAR, observed outputs: round 6 -- the sweep covers the OUTPUT head's chunks only: the label heads' gradients come from the
+// grouped launch of the backward pass, which the second stream does not wait for; their chunks stay with the optimiser launch.)
+static int head_sweep_end(const smx_model* m) { return m->n_heads > 0 ? m->chunk_first_label : m->n_chunks; }
 static bool head_sweep_ok(smx_model* m) {
-  if (head_sweep_wgs(m) <= 0 || dp_active(m) || m->capturing || !m->timing_label.empty() || m->use_injected || m->n_heads > 0) return false;
-  if (!m->sq_slots || m->chunk_first_head >= m->n_chunks || tuning_on("no_sq_partials") || tuning_on("no_adam_early")) return false;
-  for (size_t t = (size_t)m->t_outW[0] + 1; t < m->tensors.size(); ++t)   // (W_out's slots come from the output head's launch itself)
+  if (head_sweep_wgs(m) <= 0 || dp_active(m) || m->capturing || !m->timing_label.empty() || m->use_injected) return false;
+  if (!m->sq_slots || m->chunk_first_head >= head_sweep_end(m) || tuning_on("no_sq_partials") || tuning_on("no_adam_early")) return false;
+  const size_t t_end = m->n_heads > 0 ? (size_t)m->t_labW[0] : m->tensors.size();
+  for (size_t t = (size_t)m->t_outW[0] + 1; t < t_end; ++t)   // (W_out's slots come from the output head's launch itself)
     if (m->sq_count[t] == 0 && m->tensors[t].count > SMX_SQ_SMALL_TENSOR) return false;
   return true;
 }
@@ -363,12 +367,12 @@ static int head_sweep_start(smx_model* m) {
   static const bool skip = tuning_on("skip_head_adam");   // timing only (WRONG results): the heads are never updated -- what their update costs the step
   if (!skip) {
     SMX_HIP(hipStreamWaitEvent(m->st_side, m->ev_hf, 0));
-    SMX_CHECK(launch_adam_sweep(m->st_side, a, m->chunk_first_head, m->n_chunks - m->chunk_first_head, head_sweep_wgs(m)));
+    SMX_CHECK(launch_adam_sweep(m->st_side, a, m->chunk_first_head, head_sweep_end(m) - m->chunk_first_head, head_sweep_wgs(m)));
     SMX_HIP(hipEventRecord(m->ev_sweep, m->st_side));
     m->sweep_pending = true;
   }
   // the optimiser launch skips these chunks; no launch of the backward chain carries any of them
-  m->adam_early_from = m->chunk_first_head; m->adam_early_to = m->n_chunks;
+  m->adam_early_from = m->chunk_first_head; m->adam_early_to = head_sweep_end(m);
   m->adam_early_pending = false; m->adam_rest_from = m->adam_rest_to = 0; m->adam_ride_b = 0;
   return SMX_OK;
 }

@@ -491,6 +491,54 @@ def test_wide_panel_heads_update_as_a_background_sweep(Engine):
         assert np.array_equal(ref[which][k], r[which][k]), (which, k)
 
 
+@pytest.mark.parametrize("case", ["sisua_labels", "scalar_labels", "vae_extra_output"])
+def test_background_sweep_with_label_heads_covers_the_output_head_only(Engine, case):
+  """Round 6: with label heads (SISUA, SCALAR) or an observed output beside the genes the heads' background sweep (test above) used to be off --
+  their gradients come from the grouped launch of the backward pass, which the second stream does not wait for -- and the C5-width step paid
+  the riders + optimiser-launch form (180 us against 142 for the plain VAE).  The sweep now covers the OUTPUT head's chunks and leaves the
+  label heads' to the optimiser launch.  Against the form without the sweep, bit for bit: losses of every step of two multi-step calls with
+  an evaluation between them, a single step, every parameter and both Adam moments."""
+  from sisua_amd import _hip
+  from tests.util import make_pair, synth_counts, synth_labels
+  kw = dict(model="sisua", n_genes=4500, likelihood="zinb", enc_units=(128,), dec_units=(128,), latent_dim=16, labels=((12, "nb"), (5, "onehot")), alpha=10.0)
+  if case == "scalar_labels":
+    kw.update(model="scale", n_components=4, labels=((9, "nbd"),))
+  elif case == "vae_extra_output":
+    kw.update(model="vae", labels=(), extra_outputs=((10, "nb"),))
+  spec, cfg = make_pair(**kw)
+  n, B = 512, 96
+  x = synth_counts(n, spec.n_genes, sparsity=0.9, seed=11, max_count=500)
+  ys = synth_labels(n, spec.extra_outputs + spec.labels)
+  mask = so.label_mask(n, 0.4, n_omics=1 + len(spec.labels), seed=1) if spec.labels else None
+  rng = np.random.default_rng(3)
+  o1 = np.concatenate([rng.permutation(n)[:B] for _ in range(6)]).astype(np.int32)
+  o2 = np.concatenate([rng.permutation(n)[:B] for _ in range(4)]).astype(np.int32)
+  _hip.set_tuning("adam_sweep_min_chunks", 0)   # (by default the sweep is taken from ~6 M head parameters: 20 000 genes x 3 planes)
+  runs = []
+  for sweep in (False, True):
+    e = Engine(cfg, max_batch=128, init=False)
+    e.set_params(so.init_params(spec))
+    e.set_flag("head_sweep", sweep)
+    e.upload(x, ys, None, mask, cell_id_base=7, storage="u16")
+    assert e.head_fused_bytes(B) > 0
+    e.train_steps(o1, 6, B, graph=False)
+    h1 = {k: np.asarray(v).copy() for k, v in e.metrics_history(6).items()}
+    ev = e.eval_step(o2[:B])["loss"]
+    e.train_steps(o2, 4, B, graph=False)
+    h2 = {k: np.asarray(v).copy() for k, v in e.metrics_history(4).items()}
+    one = e.train_step(o1[:B])["loss"]
+    runs.append((h1, h2, (ev, one), e.get_params(0), e.get_params(2), e.get_params(3)))
+    e.close()
+  ref, r = runs
+  for k in ref[0]:
+    assert np.array_equal(ref[0][k], r[0][k]) and np.array_equal(ref[1][k], r[1][k]), k
+  assert ref[2] == r[2]
+  for which in (3, 4, 5):
+    for k in ref[which]:
+      assert np.array_equal(ref[which][k], r[which][k]), (which, k)
+  assert np.isfinite(ref[0]["loss"]).all() and (("nllk_y" in ref[0] and np.abs(ref[0]["nllk_y"]).max() > 0) or case == "vae_extra_output")
+
+
 @pytest.mark.parametrize("lk,B,G,units,latent", [("zinb", 128, 1998, 128, 32), ("nb", 77, 700, 128, 20), ("zinb", 128, 4160, 128, 32), ("zinbd", 1, 300, 128, 8)])
 def test_dz_product_and_latent_backward_inside_the_batchnorm_backward_launch(Engine, lk, B, G, units, latent):
   """Round 6 (launches off the C2 chain): at a latent of at most 32 dimensions, a first decoder layer of 128 units and
