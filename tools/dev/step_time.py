@@ -22,10 +22,11 @@ def main():
   args = ap.parse_args()
   import bench
   from sisua_amd.engine import Engine
-  cfg, x, b, _ = bench.build_workload(0, 1, args.workload)
+  cfg, x, b, extra = bench.build_workload(0, 1, args.workload)
+  extra.pop("cell_id_base", None)
   steps = args.steps or (100 if args.workload.startswith("c5") else 300)
   e = Engine(cfg, max_batch=b, device=0)
-  e.upload(x, storage=args.storage or ("u16" if args.workload.startswith("c5") else "f32"))
+  e.upload(x, storage=args.storage or ("u16" if args.workload.startswith("c5") else "f32"), **extra)
   o = bench.make_order(x.shape[0], b, steps + args.warmup)
   for _ in range(50):
     e.eval_step(o[:b])
