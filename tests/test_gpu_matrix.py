@@ -25,9 +25,9 @@ def Engine():
 
 def test_the_probes_list_covers_every_family_at_every_width():
   seen = {(c["model"], c["n_genes"]) for c in CASES}
-  assert len(CASES) == 35 and len(seen) >= 24
+  assert len(CASES) == 36 and len(seen) >= 24
   assert {c["model"] for c in CASES} == {"vae", "dca", "scvi", "sisua", "scale", "fvae"}
-  assert len({matrix_probe.name_of(c) for c in matrix_probe.configurations()}) == 69 and max(c["B"] for c in CASES) == 300
+  assert len({matrix_probe.name_of(c) for c in matrix_probe.configurations()}) == 72 and max(c["B"] for c in CASES) == 300
 
 
 @pytest.mark.gpu

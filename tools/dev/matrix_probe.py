@@ -77,7 +77,8 @@ def configurations():
   odd = [("vae", "zinb", 4097, (256,), (256,), 64, 128), ("vae", "nb", 1999, (512, 256), (256, 512), 100, 96), ("scvi", "zinbd", 4129, (200,), (200,), 1, 64),
          ("sisua", "zinb", 2049, (1000,), (1000,), 20, 128), ("dca", "nb", 8193, (256, 64), (64, 256), 32, 50), ("scale", "zinb", 513, (160,), (320,), 12, 128),
          ("fvae", "zinb", 4223, (256,), (128,), 3, 64), ("vae", "zinbd", 31, (8,), (8,), 2, 5), ("vae", "nbd", 12289, (128,), (128,), 16, 128),
-         ("sisua", "nbd", 4095, (384,), (96, 96, 96), 48, 130), ("fvae", "nb", 700, (64,), (64,), 9, 90)]
+         ("sisua", "nbd", 4095, (384,), (96, 96, 96), 48, 130), ("fvae", "nb", 700, (64,), (64,), 9, 90),
+         ("vae", "zinb", 33001, (128,), (128,), 10, 128), ("scvi", "zinbd", 25003, (128,), (128,), 10, 64), ("sisua", "nb", 40000, (128,), (128,), 10, 100)]   # (beyond every kernel's "wide" case)
   for j, (model, lk, G, enc, dec, D, B) in enumerate(odd):
     c = dict(model=model, n_genes=G, likelihood=lk, enc_units=enc, dec_units=dec, latent_dim=D, B=B, batchnorm=bool(j % 3 != 2), dropout=(0.1 if j % 2 else 0.0))
     if model == "sisua":
