@@ -1335,6 +1335,15 @@ int backward_pass(smx_model* m, const Pass& ps) {
     }
     m->adam_early_pending = true;   // dW / db of every head are final now
     if (m->head_fused_bwd_done && m->ev_hf_fresh) SMX_CHECK(head_sweep_start(m));
+    else if (!m->head_fused_bwd_done && !m->scvi && m->sq_count[(size_t)m->t_outW[0]] > 0 && !tuning_on("no_sweep_unfused") && head_sweep_ok(m)) {
+      // (round 6) ... and behind the SEPARATE head products of a wide panel too (decoder layers other than 128 units: 128 x 20 000 with 256 units
+      // 350 -> 330 us per step): the same sweep, started behind an event of this stream recorded here.  (scVI's three head tensors: 276.4 against
+      // 277.4 us with it -- its riders stay.)  The tensor's norm is then summed from the products' slots directly instead of from the reduce
+      // riders' partial sums: where the clip bites, the last bits of the update differ between the two forms.
+      SMX_CHECK(head_sweep_prepare(m));
+      SMX_HIP(hipEventRecord(m->ev_hf, m->st));
+      SMX_CHECK(head_sweep_start(m));
+    }
     m->ev_hf_fresh = false;
     m->head_fused_bwd_done = false;
     if (dp_chain_ok(m)) {   // head gradients are final (label heads whose weight gradient rides with the last launch of the pass: optimizer_pass)

@@ -491,6 +491,45 @@ def test_wide_panel_heads_update_as_a_background_sweep(Engine):
         assert np.array_equal(ref[which][k], r[which][k]), (which, k)
 
 
+def test_background_sweep_behind_the_separate_head_products(Engine):
+  """Round 6: a decoder whose last layer is not 128 units wide keeps the separate head launches at a wide gene panel -- and now gets the heads'
+  background sweep behind them as well (an event recorded where their gradients are final; 128 x 20 000 with 256 units: 350 -> 330 us per step).
+  Against the riders + optimiser-launch form (knob no_sweep_unfused): the same trajectory to rounding -- the tensor norms are summed in another
+  order, which shows where the clip bites (clipnorm 0.05 here: it always does) -- over two multi-step calls, an evaluation and a single step."""
+  from sisua_amd import _hip
+  from tests.util import make_pair, synth_counts
+  spec, cfg = make_pair(model="vae", n_genes=4500, likelihood="zinb", enc_units=(256,), dec_units=(256,), latent_dim=16, clipnorm=0.05)
+  n, B = 512, 100
+  x = synth_counts(n, spec.n_genes, sparsity=0.9, seed=11, max_count=500)
+  rng = np.random.default_rng(3)
+  o1 = np.concatenate([rng.permutation(n)[:B] for _ in range(6)]).astype(np.int32)
+  o2 = np.concatenate([rng.permutation(n)[:B] for _ in range(4)]).astype(np.int32)
+  runs = []
+  for sweep in (False, True):
+    _hip.clear_tuning("")
+    _hip.set_tuning("adam_sweep_min_chunks", 0)   # (by default the sweep is taken from ~6 M head parameters)
+    if not sweep:
+      _hip.set_tuning("no_sweep_unfused", 1)
+    e = Engine(cfg, max_batch=128, init=False)
+    e.set_params(so.init_params(spec))
+    e.upload(x, cell_id_base=7, storage="u16")
+    assert e.head_fused_bytes(B) == 0
+    e.train_steps(o1, 6, B, graph=False)
+    h1 = np.asarray(e.metrics_history(6)["loss"]).copy()
+    ev = e.eval_step(o2[:B])["loss"]
+    e.train_steps(o2, 4, B, graph=False)
+    h2 = np.asarray(e.metrics_history(4)["loss"]).copy()
+    one = e.train_step(o1[:B])["loss"]
+    runs.append((h1, h2, np.array([ev, one]), e.get_params(0), e.get_params(2)))
+    e.close()
+  ref, r = runs
+  for i in (0, 1, 2):
+    assert np.allclose(ref[i], r[i], rtol=2e-6), (i, ref[i], r[i])
+  for which in (3, 4):
+    worst = grad_errors(r[which], ref[which])
+    assert max(worst.values()) < 2e-5, (which, sorted(worst.items(), key=lambda kv: -kv[1])[:3])
+
+
 @pytest.mark.parametrize("case", ["sisua_labels", "scalar_labels", "vae_extra_output"])
 def test_background_sweep_with_label_heads_covers_the_output_head_only(Engine, case):
   """Round 6: with label heads (SISUA, SCALAR) or an observed output beside the genes the heads' background sweep (test above) used to be off --
