@@ -2171,6 +2171,119 @@ __global__ __launch_bounds__(256) void scvi_head_bwd_reg_kernel(ScviHeadArgs a) 
   }
 }
 
+// Panels beyond the register forms (more than 8192 genes outside a training step's row-local launch, more than 20 480 inside one): the three
+// sweeps of the generic kernels with 1024 threads and 16-byte accesses (round 6: the generic forms walk a row with 256 threads and 4-byte loads --
+// 87 + 104 us per step at 20 000 genes).  Same arithmetic per element; the row sums are taken in another order.
+__device__ inline float block_sum16(float v, float* sh) {   // 16 waves
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) t += sh[w];
+  return t;
+}
+__device__ inline float block_max16(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = sh[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) t = fmaxf(t, sh[w]);
+  return t;
+}
+__global__ __launch_bounds__(1024) void scvi_head_fwd_vec_kernel(ScviHeadArgs a) {
+  __shared__ float sh[16];
+  const int b = blockIdx.x;
+  const float* raw = a.raw + (long)b * a.ld;
+  float* pl = a.planes + (long)b * a.ld;
+  float mx = -3.0e38f;
+  for (int g = threadIdx.x * 4; g < a.Gp; g += 4096) {
+    const float4 v = *reinterpret_cast<const float4*>(raw + g);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (g + e < a.G) mx = fmaxf(mx, x[e]);
+  }
+  mx = block_max16(mx, sh);
+  float sum = 0.f;
+  for (int g = threadIdx.x * 4; g < a.Gp; g += 4096) {
+    const float4 v = *reinterpret_cast<const float4*>(raw + g);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (g + e < a.G) sum += fexp(x[e] - mx);
+  }
+  sum = block_sum16(sum, sh);
+  const float inv = 1.f / sum;
+  const float el = expf(fminf(fmaxf(a.l[b], 0.f), a.clip_library));
+  for (int g = threadIdx.x * 4; g < a.Gp; g += 4096) {
+    const float4 v0 = *reinterpret_cast<const float4*>(raw + g), v1 = *reinterpret_cast<const float4*>(raw + a.plane_stride + g);
+    const float4 v2 = a.k == 3 ? *reinterpret_cast<const float4*>(raw + 2 * a.plane_stride + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float x0[4] = {v0.x, v0.y, v0.z, v0.w}, x1[4] = {v1.x, v1.y, v1.z, v1.w}, x2[4] = {v2.x, v2.y, v2.z, v2.w};
+    float rho[4], rate[4], th[4], gate[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool live = g + e < a.G;
+      rho[e] = live ? fexp(x0[e] - mx) * inv : 0.f;
+      rate[e] = live ? el * fminf(fmaxf(rho[e], 1e-7f), 1.f - 1e-7f) : 0.f;
+      th[e] = live ? fexp(x1[e]) : 0.f;
+      gate[e] = live ? x2[e] : 0.f;
+    }
+    *reinterpret_cast<float4*>(a.rho_raw + (long)b * a.Gp + g) = make_float4(rho[0], rho[1], rho[2], rho[3]);
+    *reinterpret_cast<float4*>(pl + g) = make_float4(rate[0], rate[1], rate[2], rate[3]);
+    *reinterpret_cast<float4*>(pl + a.plane_stride + g) = make_float4(th[0], th[1], th[2], th[3]);
+    if (a.k == 3) *reinterpret_cast<float4*>(pl + 2 * a.plane_stride + g) = make_float4(gate[0], gate[1], gate[2], gate[3]);
+  }
+}
+__global__ __launch_bounds__(1024) void scvi_head_bwd_vec_kernel(ScviHeadArgs a) {
+  __shared__ float sh[16];
+  const int b = blockIdx.x;
+  const float* pl = a.planes + (long)b * a.ld;
+  const float* dp = a.dplanes + (long)b * a.ld;
+  float* dr = a.draw + (long)b * a.ld;
+  const float* rho = a.rho_raw + (long)b * a.Gp;
+  const float lraw = a.l[b];
+  const float el = expf(fminf(fmaxf(lraw, 0.f), a.clip_library));
+  float s = 0.f, dlh = 0.f;
+  for (int g = threadIdx.x * 4; g < a.Gp; g += 4096) {
+    const float4 r4 = *reinterpret_cast<const float4*>(rho + g), d4 = *reinterpret_cast<const float4*>(dp + g), p4 = *reinterpret_cast<const float4*>(pl + g);
+    const float r[4] = {r4.x, r4.y, r4.z, r4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (g + e < a.G) {
+        const float inside = (r[e] > 1e-7f && r[e] < 1.f - 1e-7f) ? 1.f : 0.f;
+        s += dd[e] * el * inside * r[e];
+        dlh += dd[e] * pp[e];
+      }
+  }
+  s = block_sum16(s, sh);
+  dlh = block_sum16(dlh, sh);
+  if (threadIdx.x == 0) a.dl[b] = (lraw > 0.f && lraw < a.clip_library) ? dlh : 0.f;
+  for (int g = threadIdx.x * 4; g < a.Gp; g += 4096) {
+    const float4 r4 = *reinterpret_cast<const float4*>(rho + g), d4 = *reinterpret_cast<const float4*>(dp + g);
+    const float4 d14 = *reinterpret_cast<const float4*>(dp + a.plane_stride + g), p14 = *reinterpret_cast<const float4*>(pl + a.plane_stride + g);
+    const float4 d24 = a.k == 3 ? *reinterpret_cast<const float4*>(dp + 2 * a.plane_stride + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float r[4] = {r4.x, r4.y, r4.z, r4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w}, d1[4] = {d14.x, d14.y, d14.z, d14.w}, p1[4] = {p14.x, p14.y, p14.z, p14.w},
+                d2[4] = {d24.x, d24.y, d24.z, d24.w};
+    float o0[4], o1[4], o2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool live = g + e < a.G;
+      const float inside = (r[e] > 1e-7f && r[e] < 1.f - 1e-7f) ? 1.f : 0.f;
+      o0[e] = live ? r[e] * (dd[e] * el * inside - s) : 0.f;
+      o1[e] = live ? d1[e] * p1[e] : 0.f;
+      o2[e] = live ? d2[e] : 0.f;
+    }
+    *reinterpret_cast<float4*>(dr + g) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+    *reinterpret_cast<float4*>(dr + a.plane_stride + g) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    if (a.k == 3) *reinterpret_cast<float4*>(dr + 2 * a.plane_stride + g) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+  }
+}
+static bool scvi_head_vec_ok(const ScviHeadArgs& a) {
+  return (a.ld % 4) == 0 && (a.plane_stride % 4) == 0 && (a.Gp % 4) == 0 && !tuning_on("no_scvi_head_vec");
+}
+
 static bool scvi_head_reg_ok(const ScviHeadArgs& a) {
   return (a.ld % 4) == 0 && (a.plane_stride % 4) == 0 && (a.Gp % 4) == 0 && a.Gp <= 8192;
 }
@@ -2183,7 +2296,8 @@ int launch_scvi_head_fwd(hipStream_t st, const ScviHeadArgs& a) {
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
-  hipLaunchKernelGGL(scvi_head_fwd_kernel, dim3(a.B), dim3(256), 0, st, a);
+  if (scvi_head_vec_ok(a)) hipLaunchKernelGGL(scvi_head_fwd_vec_kernel, dim3(a.B), dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL(scvi_head_fwd_kernel, dim3(a.B), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
@@ -2230,7 +2344,8 @@ int launch_scvi_head_bwd(hipStream_t st, const ScviHeadArgs& a) {
     SMX_HIP(hipGetLastError());
     return SMX_OK;
   }
-  hipLaunchKernelGGL(scvi_head_bwd_kernel, dim3(a.B), dim3(256), 0, st, a);
+  if (scvi_head_vec_ok(a)) hipLaunchKernelGGL(scvi_head_bwd_vec_kernel, dim3(a.B), dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL(scvi_head_bwd_kernel, dim3(a.B), dim3(256), 0, st, a);
   SMX_HIP(hipGetLastError());
   return SMX_OK;
 }
